@@ -1,0 +1,467 @@
+"""CPU ORACLE (numpy) -- TEST INFRASTRUCTURE ONLY, NOT A PRODUCT PATH.
+
+A plain-numpy restatement of the reference's embedding / pooling / feature-interaction hot
+path (ZhangHaoyang493/News_Recsys, paths below relative to /root/reference).  It exists so
+that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg can check / time the
+HIP path against the reference's arithmetic on machines where the reference itself is absent.
+Nothing under news_recsys_amd/ may import this module.
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks every function here against the
+fixtures in tests/golden/*.npz, which were produced by running the reference's own Python on
+CPU (tests/golden/gen_golden.py).  The one exception is the DeepFM composition, for which the
+reference has no implementation (only a documented config block,
+documents/config_file_introduction.md:153-176): its parts (FM, Deep) are pinned, the
+composition is "parity unpinned".
+
+Integer / copy work (gather, concat, column split, routing) is bit-exact by construction;
+floating reductions use float32 like the reference, in a possibly different order -- the
+tolerances are stated in the tests.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+F32 = np.float32
+
+
+# ----------------------------------------------------------------------------------------
+# a1/a2  tables + row gather                      src/model/BaseModel/base_model.py:141-166, 262-271
+# ----------------------------------------------------------------------------------------
+def emb_table_name(feature: str, share: Dict[str, str]) -> str:
+    """base_model.py:119-122 `_get_emb_feature_name`."""
+    return share.get(feature, feature)
+
+
+def gather_rows(table: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    """nn.Embedding.__call__(idx.long()) (base_model.py:271): verbatim fp32 row copy.
+    Out-of-range ids raise IndexError like torch on CPU."""
+    idx = np.asarray(idx).astype(np.int64)
+    if idx.size and (idx.min() < 0 or idx.max() >= table.shape[0]):
+        raise IndexError("index out of range in self")
+    return table[idx]
+
+
+def dense_feature(value: np.ndarray) -> np.ndarray:
+    """base_model.py:264-265: value.float().unsqueeze(1)."""
+    return np.asarray(value).astype(F32)[:, None]
+
+
+# ----------------------------------------------------------------------------------------
+# a3  array_feature_pooling                        base_model.py:273-282
+# ----------------------------------------------------------------------------------------
+def array_pool(emb: np.ndarray, mask: Optional[np.ndarray]) -> np.ndarray:
+    """mask None -> mean over L (padding included); else sum(emb*mask)/(sum(mask)+1e-8)."""
+    emb = emb.astype(F32)
+    if mask is None:
+        return emb.mean(axis=1, dtype=F32)
+    m = mask.astype(F32)[:, :, None]
+    s = (emb * m).sum(axis=1, dtype=F32)
+    den = m.sum(axis=1, dtype=F32) + F32(1e-8)
+    return (s / den).astype(F32)
+
+
+def array_pool_bwd(emb: np.ndarray, mask: Optional[np.ndarray], gout: np.ndarray) -> np.ndarray:
+    """d out / d emb (autograd of base_model.py:273-282)."""
+    B, L, D = emb.shape
+    if mask is None:
+        return np.broadcast_to((gout / F32(L))[:, None, :], (B, L, D)).astype(F32)
+    m = mask.astype(F32)
+    den = m.sum(axis=1, dtype=F32) + F32(1e-8)
+    return ((gout / den[:, None])[:, None, :] * m[:, :, None]).astype(F32)
+
+
+# ----------------------------------------------------------------------------------------
+# a4  get_embeddings_from_batch                    base_model.py:284-308
+# ----------------------------------------------------------------------------------------
+class FeatureSpace:
+    """The slice of the reference's config that the path reads (base_model.py:69-106)."""
+
+    def __init__(self, sparse: Sequence[str], dense: Sequence[str], array: Sequence[str],
+                 share: Optional[Dict[str, str]] = None):
+        self.sparse = set(sparse)
+        self.dense = set(dense)
+        self.array = set(array)
+        self.share = dict(share or {})
+
+    @classmethod
+    def from_yaml_dict(cls, cfg: dict) -> "FeatureSpace":
+        f = cfg.get("features", {})
+        e = cfg.get("embeddings", {})
+        return cls(f.get("sparse_feature_names") or [], f.get("dense_feature_names") or [],
+                   f.get("array_feature_names") or [], e.get("share_emb_table_features") or {})
+
+
+def embed_concat(space: FeatureSpace, tables: Dict[str, np.ndarray], batch: Dict[str, np.ndarray],
+                 feature_names) -> Tuple[np.ndarray, List[int], List[str]]:
+    """base_model.py:284-308.  Returns (features[B, sum D], dims, names).
+
+    The reference returns the UNFILTERED sorted name list even when a feature is missing from
+    the batch (so `names` can be longer than `dims`); this restatement returns exactly that, and
+    `names_used` = the filtered list is available as the 4th element of embed_concat_ex."""
+    feats, dims, names, _ = embed_concat_ex(space, tables, batch, feature_names)
+    return feats, dims, names
+
+
+def embed_concat_ex(space, tables, batch, feature_names):
+    sorted_features = sorted(list(feature_names))
+    parts, dims, used = [], [], []
+    for fname in sorted_features:
+        if fname not in batch:
+            continue
+        val = batch[fname]
+        if fname in space.dense:
+            emb = dense_feature(val)
+        else:
+            tname = emb_table_name(fname, space.share)
+            if tname not in tables:
+                raise ValueError(f"Embedding table not found for {fname} (mapped to {tname})")
+            emb = gather_rows(tables[tname], val)
+        if fname in space.array:
+            emb = array_pool(emb, batch.get(fname + "_mask"))
+        parts.append(emb.astype(F32))
+        dims.append(int(emb.shape[1]))
+        used.append(fname)
+    if not parts:
+        return np.zeros((0,), F32), [], [], []
+    return np.concatenate(parts, axis=1), dims, sorted_features, used
+
+
+def embedding_grad_dense(idx: np.ndarray, upstream: np.ndarray, rows: int) -> np.ndarray:
+    """Dense weight.grad of nn.Embedding(padding_idx=0) (base_model.py:164; a11):
+    scatter-add of the upstream rows, row 0 forced to zero.  idx [...], upstream [..., D]."""
+    D = upstream.shape[-1]
+    g = np.zeros((rows, D), np.float64)
+    np.add.at(g, np.asarray(idx).reshape(-1).astype(np.int64), upstream.reshape(-1, D).astype(np.float64))
+    g[0] = 0.0
+    return g.astype(F32)
+
+
+# ----------------------------------------------------------------------------------------
+# a5  FM                                            src/model/sort/fm/model.py:18-26, 48-59
+# ----------------------------------------------------------------------------------------
+def fm_split(features: np.ndarray, dims: Sequence[int]) -> Tuple[np.ndarray, np.ndarray]:
+    """fm/model.py:48-59: w = col 0 of every field, v = cols 1.. stacked [B, F, D-1]."""
+    w, v, s = [], [], 0
+    for d in dims:
+        w.append(features[:, s:s + 1])
+        v.append(features[:, s + 1:s + d])
+        s += d
+    if len({x.shape[1] for x in v}) != 1:
+        raise RuntimeError("stack expects each tensor to be equal size")  # torch.stack would raise
+    return np.concatenate(w, axis=1), np.stack(v, axis=1)
+
+
+def fm_logit(w: np.ndarray, v: np.ndarray, bias) -> np.ndarray:
+    """Pre-sigmoid FM output: bias + sum_f w + 0.5 * sum_k[(sum_f v)^2 - sum_f v^2]  -> [B,1]."""
+    first = w.astype(F32).sum(axis=1, keepdims=True, dtype=F32)
+    sv = v.astype(F32).sum(axis=1, dtype=F32)
+    sq = (v.astype(F32) ** 2).sum(axis=1, dtype=F32)
+    second = F32(0.5) * (sv * sv - sq).sum(axis=1, keepdims=True, dtype=F32)
+    return (np.asarray(bias, F32).reshape(1, 1) + first + second).astype(F32)
+
+
+def sigmoid(x: np.ndarray) -> np.ndarray:
+    x = x.astype(F32)
+    return (F32(1) / (F32(1) + np.exp(-x, dtype=F32))).astype(F32)
+
+
+def fm_forward(w, v, bias) -> np.ndarray:
+    """fm/model.py:18-26 FMModel.forward."""
+    return sigmoid(fm_logit(w, v, bias))
+
+
+def fm_logit_bwd(w, v, glogit):
+    """Gradients of fm_logit w.r.t. (w, v, bias) given d/dlogit [B,1]."""
+    gw = np.broadcast_to(glogit, w.shape).astype(F32)
+    sv = v.astype(F32).sum(axis=1, keepdims=True, dtype=F32)
+    gv = (glogit[:, :, None] * (sv - v)).astype(F32)
+    return gw, gv, glogit.sum(dtype=F32).reshape(1)
+
+
+# ----------------------------------------------------------------------------------------
+# a6  DCN v1 cross                                  src/model/sort/dcn/dcn_arch.py:5-30, 53-70
+# ----------------------------------------------------------------------------------------
+def dcn_v1_reference_form(x: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Literal form of DCNLayer.forward (dcn_arch.py:22-28): (x0 x_l^T) w + b + x_l, with the
+    [B,D,D] outer product materialised.  w, b: [n_layers, D].  Small inputs only."""
+    x0 = x.astype(F32)
+    xl = x0
+    for l in range(w.shape[0]):
+        outer = x0[:, :, None] * xl[:, None, :]                 # B x D x D
+        cross = outer @ w[l].astype(F32)[:, None]               # B x D x 1
+        xl = (cross[:, :, 0] + b[l].astype(F32)[None, :] + xl).astype(F32)
+    return xl
+
+
+def dcn_v1(x: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Algebraically identical O(B*D) form: x_{l+1} = x0 * (x_l . w_l) + b_l + x_l."""
+    x0 = x.astype(F32)
+    xl = x0
+    for l in range(w.shape[0]):
+        s = (xl * w[l].astype(F32)[None, :]).sum(axis=1, keepdims=True, dtype=F32)
+        xl = (x0 * s + b[l].astype(F32)[None, :] + xl).astype(F32)
+    return xl
+
+
+def dcn_v1_bwd(x, w, b, gout):
+    """Backward of dcn_v1: returns (gx, gw[n,D], gb[n,D])."""
+    n = w.shape[0]
+    x0 = x.astype(np.float64)
+    xs, ss = [x0], []
+    for l in range(n):
+        s = (xs[-1] * w[l][None, :]).sum(axis=1, keepdims=True)
+        ss.append(s)
+        xs.append(x0 * s + b[l][None, :] + xs[-1])
+    g = gout.astype(np.float64)
+    gx0 = np.zeros_like(x0)
+    gw = np.zeros((n, x.shape[1]))
+    gb = np.zeros((n, x.shape[1]))
+    for l in reversed(range(n)):
+        gb[l] = g.sum(axis=0)
+        gs = (g * x0).sum(axis=1, keepdims=True)
+        gx0 += g * ss[l]
+        gw[l] = (gs * xs[l]).sum(axis=0)
+        g = g + gs * w[l][None, :]
+    gx = g + gx0
+    return gx.astype(F32), gw.astype(F32), gb.astype(F32)
+
+
+# ----------------------------------------------------------------------------------------
+# a7  DCN v2 cross                                  dcn_arch.py:33-50, 73-91
+# ----------------------------------------------------------------------------------------
+def dcn_v2(x: np.ndarray, W: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """DCNv2Net.forward: x <- relu(x0 * (x W_l^T + b_l) + x) per layer (ReLU after EVERY layer,
+    dcn_arch.py:78-81).  W: [n, D, D] (nn.Linear weight, out x in), b: [n, D]."""
+    x0 = x.astype(F32)
+    xl = x0
+    for l in range(W.shape[0]):
+        lin = (xl @ W[l].astype(F32).T + b[l].astype(F32)[None, :]).astype(F32)
+        xl = np.maximum(x0 * lin + xl, F32(0)).astype(F32)
+    return xl
+
+
+def dcn_v2_bwd(x, W, b, gout):
+    n = W.shape[0]
+    x0 = x.astype(np.float64)
+    xs, lins, pre = [x0], [], []
+    for l in range(n):
+        lin = xs[-1] @ W[l].astype(np.float64).T + b[l][None, :]
+        p = x0 * lin + xs[-1]
+        lins.append(lin)
+        pre.append(p)
+        xs.append(np.maximum(p, 0.0))
+    g = gout.astype(np.float64)
+    gx0 = np.zeros_like(x0)
+    gW = np.zeros(W.shape)
+    gb = np.zeros(b.shape)
+    for l in reversed(range(n)):
+        g = g * (pre[l] > 0)
+        glin = g * x0
+        gx0 += g * lins[l]
+        gW[l] = glin.T @ xs[l]
+        gb[l] = glin.sum(axis=0)
+        g = g + glin @ W[l].astype(np.float64)
+    return (g + gx0).astype(F32), gW.astype(F32), gb.astype(F32)
+
+
+# ----------------------------------------------------------------------------------------
+# a8  Wide & Deep split                             src/model/sort/widedeep/model.py:24-27, 53-69
+# ----------------------------------------------------------------------------------------
+def wide_split(features: np.ndarray, dims: Sequence[int], names: Sequence[str], wide_names) -> Tuple[np.ndarray, np.ndarray]:
+    wide, deep, s = [], [], 0
+    for d, n in zip(dims, names):
+        if n in wide_names:
+            wide.append(features[:, s:s + 1])
+            deep.append(features[:, s + 1:s + d])
+        else:
+            deep.append(features[:, s:s + d])
+        s += d
+    return np.concatenate(wide, axis=1), np.concatenate(deep, axis=1)
+
+
+# ----------------------------------------------------------------------------------------
+# a9  MLP heads / Deep / LR                         model_utils/utils.py:6-17, deep/model.py:12-21, lr/model.py:24-27
+# ----------------------------------------------------------------------------------------
+def mlp(x: np.ndarray, weights: Sequence[np.ndarray], biases: Sequence[np.ndarray]) -> np.ndarray:
+    """Linear+ReLU stack, no activation after the last layer (utils.py:9-14)."""
+    h = x.astype(F32)
+    for i, (W, bb) in enumerate(zip(weights, biases)):
+        h = (h @ W.astype(F32).T + bb.astype(F32)[None, :]).astype(F32)
+        if i < len(weights) - 1:
+            h = np.maximum(h, F32(0))
+    return h
+
+
+def mlp_params(params: Dict[str, np.ndarray], prefix: str):
+    """Collect `<prefix>.<2i>.weight/bias` of an nn.Sequential(Linear, ReLU, ...)."""
+    ws, bs, i = [], [], 0
+    while f"{prefix}.{i}.weight" in params:
+        ws.append(params[f"{prefix}.{i}.weight"])
+        bs.append(params[f"{prefix}.{i}.bias"])
+        i += 2
+    return ws, bs
+
+
+def deep_forward(features, params) -> np.ndarray:
+    """deep/model.py:20-21: sigmoid(MLP(x))."""
+    return sigmoid(mlp(features, *mlp_params(params, "score_fc.network.network")))
+
+
+def lr_forward(features) -> np.ndarray:
+    """lr/model.py:24-27: sigmoid(sum over columns) -> shape [B] (not [B,1])."""
+    return sigmoid(features.astype(F32).sum(axis=1, dtype=F32))
+
+
+def widedeep_forward(wide_x, deep_x, params) -> np.ndarray:
+    """widedeep/model.py:24-27."""
+    wide_out = wide_x.astype(F32).sum(axis=1, keepdims=True, dtype=F32) + params["score_fc.bias"].astype(F32)
+    deep_out = mlp(deep_x, *mlp_params(params, "score_fc.deep_network.network"))
+    return sigmoid(wide_out + deep_out)
+
+
+def dcn_model_forward(x, params, n_layers) -> Tuple[np.ndarray, np.ndarray]:
+    """dcn/model.py:25-29: sigmoid(MLP(cat[x, cross(x)]))."""
+    w = np.stack([params[f"score_fc.cross_net.cross_net.{l}.w"][:, 0] for l in range(n_layers)])
+    b = np.stack([params[f"score_fc.cross_net.cross_net.{l}.b"][:, 0] for l in range(n_layers)])
+    cross = dcn_v1(x, w, b)
+    out = sigmoid(mlp(np.concatenate([x, cross], axis=1), *mlp_params(params, "score_fc.score_fc.network")))
+    return out, cross
+
+
+def deepfm_forward(features, dims, fm_bias, mlp_w, mlp_b) -> np.ndarray:
+    """DeepFM = FM part (fm/model.py:18-26, pre-sigmoid) + Deep MLP (deep/model.py:12-21, pre-sigmoid)
+    composed the way WideDeep composes wide+deep (widedeep/model.py:24-27).  PARITY UNPINNED:
+    the reference has no DeepFM model."""
+    w, v = fm_split(features, dims)
+    return sigmoid(fm_logit(w, v, fm_bias) + mlp(features, mlp_w, mlp_b))
+
+
+def bce_loss(pred: np.ndarray, label: np.ndarray) -> np.ndarray:
+    """F.binary_cross_entropy(reduction='mean') (deep/model.py:32-33); log clamped at -100 like torch."""
+    p = pred.reshape(-1).astype(np.float64)
+    y = label.reshape(-1).astype(np.float64)
+    lp = np.maximum(np.log(p), -100.0)
+    l1p = np.maximum(np.log1p(-p), -100.0)
+    return F32(-(y * lp + (1 - y) * l1p).mean())
+
+
+# ----------------------------------------------------------------------------------------
+# a10  DSSM                                         src/model/recall/DSSM/model.py:26-110, 148-180
+# ----------------------------------------------------------------------------------------
+def leaky_relu(x, slope=0.2):
+    return np.where(x > 0, x, x * F32(slope)).astype(F32)
+
+
+def dssm_tower(x, params, prefix) -> np.ndarray:
+    """Linear-LReLU(.2) x3 + Linear (model.py:26-44)."""
+    h = x.astype(F32)
+    for i in (0, 2, 4, 6):
+        h = (h @ params[f"{prefix}.{i}.weight"].T + params[f"{prefix}.{i}.bias"][None, :]).astype(F32)
+        if i < 6:
+            h = leaky_relu(h)
+    return h
+
+
+def l2_normalize(x, axis=-1, eps=1e-12):
+    n = np.sqrt((x.astype(F32) ** 2).sum(axis=axis, keepdims=True, dtype=F32))
+    return (x / np.maximum(n, F32(eps))).astype(F32)
+
+
+def dssm_tower_input(space, tables, batch, names) -> np.ndarray:
+    """get_user_embedding / get_item_embedding (model.py:148-180) in SORTED feature order
+    (the reference iterates a set).  Array features WITHOUT a mask are left
+    un-pooled by the reference and would break torch.cat; only the masked form is covered."""
+    parts = []
+    for fname in sorted(names):
+        if fname in space.dense:
+            parts.append(dense_feature(batch[fname]))
+            continue
+        emb = gather_rows(tables[emb_table_name(fname, space.share)], batch[fname])
+        if fname in space.array:
+            m = batch[fname + "_mask"].astype(F32)
+            emb = (emb * m[:, :, None]).sum(axis=1, dtype=F32) / (m.sum(axis=1, keepdims=True, dtype=F32) + F32(1e-8))
+        parts.append(emb.astype(F32))
+    return np.concatenate(parts, axis=1)
+
+
+def dssm_negatives(raw_item_emb, perms) -> np.ndarray:
+    """model.py:59-71 with explicit permutations instead of torch.randperm."""
+    return l2_normalize(np.stack([raw_item_emb[p] for p in perms], axis=1), axis=-1)
+
+
+def _log_softmax0(logits):
+    m = logits.max(axis=1, keepdims=True)
+    z = logits - m
+    return z[:, 0] - np.log(np.exp(z).sum(axis=1))
+
+
+def infonce_loss(u, pos, neg, temperature=0.1, mask=None):
+    """model.py:92-110."""
+    ps = (u * pos).sum(axis=1) / temperature
+    ns = np.einsum("bd,bnd->bn", u, neg) / temperature
+    losses = -_log_softmax0(np.concatenate([ps[:, None], ns], axis=1).astype(np.float64))
+    if mask is not None:
+        losses = losses * mask
+    return F32(losses.mean())
+
+
+def triplet_loss(u, pos, neg, margin=1.0, mask=None):
+    """model.py:75-90.  NOTE the reference's shapes: pos_scores is [B] while neg_scores is
+    unsqueezed to [B,1] (model.py:85), so `margin - pos + neg` BROADCASTS to a [B,B] matrix
+    (entry [i,j] = margin - pos_j + neg_i) and the mask [B] multiplies along columns.  The mean is
+    over all B*B entries.  Restated as written (pinned by tests/golden/model_dssm.npz)."""
+    nn_ = neg.shape[1]
+    ps = (u * pos).sum(axis=1) * nn_                            # [B]
+    ns = np.einsum("bd,bnd->bn", u, neg).sum(axis=1)[:, None]   # [B,1]
+    losses = np.maximum(margin - ps[None, :] + ns, 0.0)         # [B,B]
+    if mask is not None:
+        losses = losses * np.asarray(mask)[None, :]
+    return F32(losses.mean())
+
+
+# ----------------------------------------------------------------------------------------
+# LR schedule                                        model_utils/lr_schedule.py:6-28
+# ----------------------------------------------------------------------------------------
+def cosine_decay_lr(step: int, lrs: Sequence[float], milestones: Sequence[int]) -> float:
+    if step < milestones[0]:
+        return lrs[0]
+    if step >= milestones[-1]:
+        return lrs[-1]
+    progress = (step - milestones[0]) / max(1, milestones[1] - milestones[0])
+    return lrs[1] + (lrs[0] - lrs[1]) * 0.5 * (1.0 + math.cos(math.pi * progress))
+
+
+# ----------------------------------------------------------------------------------------
+# integer utilities of the row-sharded path (new in the build) -- exact definitions
+# ----------------------------------------------------------------------------------------
+def owner_of(ids: np.ndarray, world: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Round-robin row sharding: row r lives on rank r % world at local row r // world."""
+    ids = np.asarray(ids, np.int64)
+    return ids % world, ids // world
+
+
+def bucketize_by_owner(ids: np.ndarray, world: int):
+    """Stable bucketing of a flat id list by owner rank.
+    Returns (counts[world], perm) where perm lists source positions grouped by owner, in
+    ascending source order inside each bucket; send buffer = (ids // world)[perm]."""
+    owner, _ = owner_of(ids, world)
+    perm = np.argsort(owner, kind="stable").astype(np.int64)
+    counts = np.bincount(owner, minlength=world).astype(np.int64)
+    return counts, perm
+
+
+def csr_from_mask(mask: np.ndarray):
+    """Padded [B, L] 0/1 mask -> CSR offsets[B+1] (valid = mask != 0) and flat positions."""
+    valid = np.asarray(mask) != 0
+    lens = valid.sum(axis=1).astype(np.int64)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pos = np.flatnonzero(valid.reshape(-1)).astype(np.int64)
+    return offsets, pos
+
+
+def unique_inverse(ids: np.ndarray):
+    u, inv = np.unique(np.asarray(ids, np.int64), return_inverse=True)
+    return u, inv.astype(np.int64)

@@ -1,0 +1,283 @@
+"""Pin the CPU oracle (oracle/ref_np.py) against golden vectors captured from the reference's
+own Python (tests/golden/gen_golden.py).  CPU-only; runs everywhere.
+
+Tolerances: gather / concat / column split are bit-exact (verbatim copies).  fp32 reductions
+(pooling, FM, DCN, MLP heads) use rtol/atol as stated per test: the oracle sums in a different
+order than ATen."""
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+from oracle import ref_np as R
+from tests.conftest import CONFIGS, GOLDEN
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def params_of(g):
+    return {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+
+
+def batch_of(g):
+    return {k[len("batch/"):]: v for k, v in g.items() if k.startswith("batch/")}
+
+
+def tables_of(p):
+    pre = "embedding_tables."
+    return {k[len(pre):-len(".weight")]: v for k, v in p.items() if k.startswith(pre)}
+
+
+def space_of(cfg_name):
+    cfg = yaml.safe_load(open(os.path.join(CONFIGS, cfg_name)))
+    names = set(cfg["features"]["user_feature_names"]) | set(cfg["features"]["item_feature_names"])
+    return R.FeatureSpace.from_yaml_dict(cfg), names, cfg
+
+
+@pytest.mark.parametrize("gname,cfg", [("model_deep", "cf_deep_small.yaml"), ("model_fm", "cf_fm_small.yaml"),
+                                       ("model_dcn", "cf_dcn_small.yaml"), ("model_widedeep", "cf_widedeep_small.yaml"),
+                                       ("model_lr", "cf_lr_small.yaml")])
+def test_embed_concat_bit_exact(gname, cfg):
+    g = load(gname)
+    space, names, _ = space_of(cfg)
+    feats, dims, fnames = R.embed_concat(space, tables_of(params_of(g)), batch_of(g), names)
+    assert feats.dtype == np.float32
+    assert np.array_equal(feats, g["out/features"])          # pure gather + concat: bit-exact
+    assert dims == list(g["out/dims"])
+    assert fnames == list(g["out/names"])
+
+
+def test_embed_concat_arrays_dense_shared():
+    g = load("model_deep_array")
+    space, names, _ = space_of("cf_array_small.yaml")
+    p, b = params_of(g), batch_of(g)
+    feats, dims, _ = R.embed_concat(space, tables_of(p), b, names)
+    assert dims == list(g["out/dims"])
+    # pooled columns: fp32 sum order differs from ATen -> tolerance
+    np.testing.assert_allclose(feats, g["out/features"], rtol=1e-6, atol=1e-6)
+    # single-valued columns stay bit-exact: names sorted = category,item_id,user_click_cats,user_history,user_id
+    assert np.array_equal(feats[:, :8 + 32], g["out/features"][:, :8 + 32])
+    # all-masked bag -> exact zeros
+    hist_cols = slice(8 + 32 + 12, 8 + 32 + 12 + 32)
+    assert np.all(feats[1, hist_cols] == 0.0)
+
+    # case 2: dense feature, non-binary mask weights, missing mask (plain mean)
+    b2 = dict(b)
+    b2["ctr"] = g["case2/batch/ctr"]
+    b2["user_history_mask"] = g["case2/batch/user_history_mask"]
+    del b2["user_click_cats_mask"]
+    f2, d2, _ = R.embed_concat(space, tables_of(p), b2, set(g["case2/names_in"].tolist()))
+    assert d2 == list(g["case2/dims"])
+    np.testing.assert_allclose(f2, g["case2/features"], rtol=1e-6, atol=1e-6)
+
+    # case 3: feature missing from the batch is skipped; reference returns unfiltered names
+    b3 = {k: v for k, v in b.items() if k != "category"}
+    f3, d3, n3 = R.embed_concat(space, tables_of(p), b3, {"user_id", "category", "item_id"})
+    assert np.array_equal(f3, g["case3/features"])
+    assert d3 == list(g["case3/dims"]) and n3 == list(g["case3/names_returned"])
+
+
+def test_gather_oob_raises():
+    t = np.zeros((5, 4), np.float32)
+    with pytest.raises(IndexError):
+        R.gather_rows(t, np.array([1, 5]))
+    with pytest.raises(IndexError):
+        R.gather_rows(t, np.array([-1]))
+
+
+def test_missing_table_raises():
+    space = R.FeatureSpace(["a"], [], [])
+    with pytest.raises(ValueError):
+        R.embed_concat(space, {}, {"a": np.array([1])}, {"a"})
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+@pytest.mark.parametrize("mtag", ["none", "bin", "w"])
+def test_array_pool(tag, mtag):
+    g = load("ops")
+    emb = g[f"pool/{tag}/emb"]
+    mask = {"none": None, "bin": g[f"pool/{tag}/mask"], "w": g[f"pool/{tag}/wmask"]}[mtag]
+    out = R.array_pool(emb, mask)
+    np.testing.assert_allclose(out, g[f"pool/{tag}/{mtag}/out"], rtol=1e-6, atol=1e-6)
+    gemb = R.array_pool_bwd(emb, mask, g[f"pool/{tag}/up"])
+    np.testing.assert_allclose(gemb, g[f"pool/{tag}/{mtag}/gemb"], rtol=1e-6, atol=1e-7)
+    if mtag != "none":
+        assert np.all(out[0] == 0.0)  # all-masked bag -> exact zero
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_fm(tag):
+    g = load("ops")
+    w, v, bias = g[f"fm/{tag}/w"], g[f"fm/{tag}/v"], g[f"fm/{tag}/bias"]
+    out = R.fm_forward(w, v, bias)
+    # sum-square identity in a different summation order: rtol 1e-5, atol 1e-5
+    np.testing.assert_allclose(out, g[f"fm/{tag}/out"], rtol=1e-5, atol=1e-5)
+    # backward through the sigmoid
+    s = out
+    gl = g[f"fm/{tag}/up"] * s * (1 - s)
+    gw, gv, gb = R.fm_logit_bwd(w, v, gl)
+    np.testing.assert_allclose(gw, g[f"fm/{tag}/gw"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gv, g[f"fm/{tag}/gv"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gb, g[f"fm/{tag}/gbias"], rtol=1e-4, atol=1e-5)
+
+
+def test_fm_model_split_bit_exact():
+    g = load("model_fm")
+    w, v = R.fm_split(g["out/features"], list(g["out/dims"]))
+    assert np.array_equal(w, g["out/fm_w"]) and np.array_equal(v, g["out/fm_v"])
+    out = R.fm_forward(w, v, params_of(g)["score_fc.bias"])
+    np.testing.assert_allclose(out, g["out/forward"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(R.bce_loss(out, g["batch/label"][:, 0]), g["out/loss"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_dcn_v1(tag):
+    g = load("ops")
+    x, w, b = g[f"dcn1/{tag}/x"], g[f"dcn1/{tag}/w"], g[f"dcn1/{tag}/b"]
+    ref = g[f"dcn1/{tag}/out"]
+    scale = np.abs(ref).max()
+    # outer-product form vs algebraic form differ by fp32 re-association (SURVEY hard part 4):
+    # rtol 1e-5, atol 1e-6 * max|out|
+    np.testing.assert_allclose(R.dcn_v1_reference_form(x, w, b), ref, rtol=1e-5, atol=2e-6 * scale)
+    np.testing.assert_allclose(R.dcn_v1(x, w, b), ref, rtol=1e-5, atol=2e-6 * scale)
+    gx, gw, gb = R.dcn_v1_bwd(x, w, b, g[f"dcn1/{tag}/up"])
+    for got, key in ((gx, "gx"), (gw, "gw"), (gb, "gb")):
+        want = g[f"dcn1/{tag}/{key}"]
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(want).max()))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_dcn_v2(tag):
+    g = load("ops")
+    x, W, b = g[f"dcn2/{tag}/x"], g[f"dcn2/{tag}/W"], g[f"dcn2/{tag}/b"]
+    ref = g[f"dcn2/{tag}/out"]
+    np.testing.assert_allclose(R.dcn_v2(x, W, b), ref, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(ref).max()))
+    gx, gW, gb = R.dcn_v2_bwd(x, W, b, g[f"dcn2/{tag}/up"])
+    for got, key in ((gx, "gx"), (gW, "gW"), (gb, "gb")):
+        want = g[f"dcn2/{tag}/{key}"]
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5 * max(1.0, np.abs(want).max()))
+
+
+def test_deep_model():
+    g = load("model_deep")
+    out = R.deep_forward(g["out/features"], params_of(g))
+    np.testing.assert_allclose(out, g["out/forward"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(R.bce_loss(out, g["batch/label"][:, 0]), g["out/loss"], rtol=1e-5)
+
+
+def test_lr_model_shape_and_value():
+    g = load("model_lr")
+    out = R.lr_forward(g["out/features"])
+    assert out.shape == g["out/forward"].shape and out.ndim == 1   # LR returns [B], not [B,1]
+    np.testing.assert_allclose(out, g["out/forward"], rtol=1e-6, atol=1e-6)
+
+
+def test_widedeep_model():
+    g = load("model_widedeep")
+    _, _, cfg = space_of("cf_widedeep_small.yaml")
+    wide = set(cfg["wide_and_deep_cfg"]["wide_feature_names"])
+    wx, dx = R.wide_split(g["out/features"], list(g["out/dims"]), list(g["out/names"]), wide)
+    assert np.array_equal(wx, g["out/wide_x"]) and np.array_equal(dx, g["out/deep_x"])  # copies: bit-exact
+    out = R.widedeep_forward(wx, dx, params_of(g))
+    np.testing.assert_allclose(out, g["out/forward"], rtol=1e-5, atol=1e-6)
+
+
+def test_dcn_model():
+    g = load("model_dcn")
+    out, cross = R.dcn_model_forward(g["out/features"], params_of(g), 3)
+    scale = np.abs(g["out/cross"]).max()
+    np.testing.assert_allclose(cross, g["out/cross"], rtol=1e-5, atol=2e-6 * scale)
+    np.testing.assert_allclose(out, g["out/forward"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("gname,cfg", [("model_deep", "cf_deep_small.yaml"), ("model_deep_array", "cf_array_small.yaml")])
+def test_embedding_dense_grad(gname, cfg):
+    """a11: dense weight.grad = scatter-add of the upstream grad of the concat, row 0 zero.
+    The upstream grad of `features` is recovered from the first MLP layer's grads (dL/dx = dL/dz W)
+    only for checking structure; here we check the scatter itself on the golden table grads by
+    re-deriving upstream with finite algebra: grad_table = sum over lookups of upstream rows."""
+    g = load(gname)
+    space, names, _ = space_of(cfg)
+    p, b = params_of(g), batch_of(g)
+    # recompute dL/dfeatures through the oracle's MLP backward (float64)
+    ws, bs = R.mlp_params(p, "score_fc.network.network")
+    x = g["out/features"].astype(np.float64)
+    acts = [x]
+    for i, (W, bb) in enumerate(zip(ws, bs)):
+        h = acts[-1] @ W.T.astype(np.float64) + bb
+        acts.append(np.maximum(h, 0) if i < len(ws) - 1 else h)
+    pred = 1 / (1 + np.exp(-acts[-1]))
+    y = b["label"][:, :1].astype(np.float64)
+    gz = (pred - y) / y.shape[0]
+    for i in reversed(range(len(ws))):
+        if i < len(ws) - 1:
+            gz = gz * (acts[i + 1] > 0)
+        gz = gz @ ws[i].astype(np.float64)
+    gfeat = gz  # [B, sum D]
+    _, dims, _, used = R.embed_concat_ex(space, tables_of(p), b, names)
+    col = 0
+    acc = {}
+    for fname, d in zip(used, dims):
+        up = gfeat[:, col:col + d]
+        col += d
+        tname = R.emb_table_name(fname, space.share)
+        rows = p[f"embedding_tables.{tname}.weight"].shape[0]
+        if fname in space.array:
+            emb = R.gather_rows(tables_of(p)[tname], b[fname])
+            up_rows = R.array_pool_bwd(emb, b.get(fname + "_mask"), up.astype(np.float32))
+            gt = R.embedding_grad_dense(b[fname], up_rows, rows)
+        else:
+            gt = R.embedding_grad_dense(b[fname], up.astype(np.float32), rows)
+        acc[tname] = acc.get(tname, 0) + gt
+    for tname, gt in acc.items():
+        want = g[f"grad/embedding_tables.{tname}.weight"]
+        assert np.all(gt[0] == 0) and np.all(want[0] == 0)      # padding row never trains
+        np.testing.assert_allclose(gt, want, rtol=1e-4, atol=1e-7)
+
+
+def test_dssm():
+    g = load("model_dssm")
+    cfg = yaml.safe_load(open(os.path.join(CONFIGS, "cf_dssm_small.yaml")))
+    space = R.FeatureSpace.from_yaml_dict(cfg)
+    p, b = params_of(g), batch_of(g)
+    uvec = R.dssm_tower_input(space, tables_of(p), b, cfg["features"]["user_feature_names"])
+    ivec = R.dssm_tower_input(space, tables_of(p), b, cfg["features"]["item_feature_names"])
+    np.testing.assert_allclose(uvec, g["out/user_vector"], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(ivec, g["out/item_vector"])     # item tower has no pooled feature
+    raw_i = R.dssm_tower(ivec, p, "item_fc")
+    uemb = R.l2_normalize(R.dssm_tower(uvec, p, "user_fc"))
+    iemb = R.l2_normalize(raw_i)
+    np.testing.assert_allclose(uemb, g["out/user_emb"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(iemb, g["out/item_emb"], rtol=1e-4, atol=1e-5)
+    neg = R.dssm_negatives(raw_i, g["out/perms"])
+    np.testing.assert_allclose(neg, g["out/neg_item_emb"], rtol=1e-4, atol=1e-5)
+    msk = b["label"][:, 1]
+    np.testing.assert_allclose(R.infonce_loss(uemb, iemb, neg, 0.1, msk), g["out/infonce"], rtol=1e-4)
+    np.testing.assert_allclose(R.triplet_loss(uemb, iemb, neg, 1.0, msk), g["out/triplet"], rtol=1e-4)
+
+
+def test_lr_schedule():
+    g = load("lr_schedule")
+    got = [R.cosine_decay_lr(s, list(g["lr"]), list(g["milestones"])) for s in range(len(g["lrs"]))]
+    np.testing.assert_allclose(got, g["lrs"], rtol=1e-12)
+
+
+def test_integer_utils():
+    rng = np.random.default_rng(0)
+    ids = rng.integers(0, 1000, 257)
+    for world in (1, 2, 3, 8):
+        counts, perm = R.bucketize_by_owner(ids, world)
+        assert counts.sum() == ids.size and sorted(perm.tolist()) == list(range(ids.size))
+        owner = ids % world
+        assert np.all(np.diff(owner[perm]) >= 0)
+        for r in range(world):
+            seg = perm[counts[:r].sum():counts[:r + 1].sum()]
+            assert np.all(np.diff(seg) > 0)             # stable
+    mask = (rng.random((6, 5)) < 0.5).astype(np.float32)
+    off, pos = R.csr_from_mask(mask)
+    assert off[-1] == mask.sum() and np.all(mask.reshape(-1)[pos] == 1)
+    u, inv = R.unique_inverse(ids)
+    assert np.array_equal(u[inv], ids)
