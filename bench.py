@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""bench.py -- impressions/sec of the embedding hot path at batch 65536 (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic MIND-shaped impressions already
+resident in HBM: fused multi-table gather (+pool) -> concat (+ the model's interaction epilogue).
+Default workload = BASELINE.json configs[1] ("c2": DeepFM-shaped, 26 sparse x 1M rows x 16, B=65536,
+uniform ids): gather -> [B,416] concat + fused FM logit.  A fresh id batch (from a pool of 8) is used
+every step so no step re-reads the previous step's rows from cache.
+
+N > 1: tables are row-sharded (row r on rank r % N) and every rank owns B=65536 impressions (weak
+scaling); ids are routed with RCCL all-to-all, rows returned with a second all-to-all
+(news_recsys_amd/sharding.py).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 measured achievable
+BATCH = 65536
+
+
+# ------------------------------------------------------------------------------------ workloads
+def workload_spec(name: str):
+    """(features, description).  feature = dict(name, rows, dim, bag_len)."""
+    if name == "c2":      # DeepFM: 26 sparse x 1M rows, D=16
+        feats = [dict(name=f"C{i:02d}", rows=1_000_000, dim=16, bag=0) for i in range(26)]
+        return feats, "c2: DeepFM 26 sparse x 1M rows, D=16, B=65536, uniform ids; gather->concat[B,416] + fused FM logit"
+    if name == "c3":      # DCN: 5 feats D=64, news table 100M rows
+        rows = dict(item_id=100_000_000, user_id=1_000_000, category=18, subcategory=270, user_click_category=18)
+        feats = [dict(name=k, rows=v, dim=64, bag=0) for k, v in sorted(rows.items())]
+        return feats, "c3: DCN 5 feats D=64 (item_id 100M rows), B=65536; gather->concat[B,320] + fused 2-layer cross"
+    if name == "c4":      # DSSM: user_id 10M, item_id 200k, history L=50 shares item table, D=16
+        feats = [dict(name="item_id", rows=200_000, dim=16, bag=0),
+                 dict(name="user_history", rows=200_000, dim=16, bag=50, share="item_id"),
+                 dict(name="user_id", rows=10_000_000, dim=16, bag=0)]
+        return feats, "c4: DSSM user_id 10M + history L=50 (mean-pool, shares 200k news table) + item_id, D=16, B=65536"
+    if name == "c5":      # WideDeep: 40 feats 1k..500M rows D=32 (one GPU holds the <=16M-row tables only)
+        rows = [int(round(1e3 * (5e5) ** (i / 39))) for i in range(40)]
+        feats = [dict(name=f"W{i:02d}", rows=r, dim=32, bag=0) for i, r in enumerate(rows)]
+        return feats, "c5: WideDeep 40 feats 1k..500M rows D=32"
+    raise SystemExit(f"unknown workload {name}")
+
+
+def algorithmic_bytes_per_impression(feats, fm: bool, cross_dim: int = 0) -> int:
+    """int64 ids 8 B, fp32 rows, each looked-up row counted once, output written once.
+    single-valued: 8 + 4D (row read) + 4D (write); bag (L padded, all valid): L*(8+4) + L*4D + 4D."""
+    total = 0
+    for f in feats:
+        D, L = f["dim"], f["bag"]
+        total += (8 + 4 * D + 4 * D) if L == 0 else (L * 12 + L * 4 * D + 4 * D)
+    if fm:
+        total += 4
+    total += 4 * cross_dim          # fused cross output written next to x
+    return total
+
+
+# ------------------------------------------------------------------------------------ single-GPU runner
+class SingleGpuPath:
+    def __init__(self, wl: str, device, seed: int, n_pool: int = 8):
+        from news_recsys_amd import ops
+        from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN, NRX_SPARSE
+        self.ops = ops
+        self.wl = wl
+        feats, self.desc = workload_spec(wl)
+        if wl == "c5":
+            feats = [f for f in feats if f["rows"] <= 16_000_000]
+            self.desc += f" -- single GPU run keeps the {len(feats)} tables <= 16M rows"
+        self.feats = feats
+        gen = torch.Generator(device=device).manual_seed(seed)
+        self.tables, tindex = [], {}
+        for f in feats:
+            tname = f.get("share", f["name"])
+            if tname in tindex:
+                continue
+            t = torch.empty((f["rows"], f["dim"]), dtype=torch.float32, device=device)
+            t.normal_(generator=gen)
+            t[0].zero_()
+            tindex[tname] = len(self.tables)
+            self.tables.append(t)
+        slots, col = [], 0
+        self.fm = wl == "c2"
+        for f in feats:
+            kind = NRX_BAG_MASKED_MEAN if f["bag"] else NRX_SPARSE
+            slots.append(ops.Slot(f["name"], kind, tindex[f.get("share", f["name"])], f["dim"], f["bag"], col,
+                                  fm_field=int(self.fm)))
+            col += f["dim"]
+        self.width = col
+        self.plan = ops.EmbedPlan(slots, out_width=col, use_fm=self.fm)
+        self.cross = None
+        if wl == "c3":
+            self.cross_w = torch.randn(2, col, device=device, generator=gen) / col ** 0.5
+            self.cross_b = torch.zeros(2, col, device=device)
+            self.cross = True
+        self.pool = []
+        for _ in range(n_pool):
+            ins, ws = [], []
+            for f in feats:
+                if f["bag"]:
+                    ids = torch.randint(1, f["rows"], (BATCH, f["bag"]), device=device, generator=gen)
+                    ins.append(ids)
+                    ws.append(torch.ones((BATCH, f["bag"]), dtype=torch.float32, device=device))
+                else:
+                    ins.append(torch.randint(1, f["rows"], (BATCH,), device=device, generator=gen))
+                    ws.append(None)
+            self.pool.append((ins, ws))
+        self.bytes_per_impr = algorithmic_bytes_per_impression(feats, self.fm, col if self.cross else 0)
+
+    @torch.no_grad()
+    def step(self, i: int):
+        ins, ws = self.pool[i % len(self.pool)]
+        if self.cross:
+            buf, _, _ = self.ops.embed_apply(self.plan, self.tables, ins, ws, out_ld=2 * self.width)
+            return self.ops.dcn_v1_cat_(buf, self.cross_w, self.cross_b)
+        return self.ops.embed_apply(self.plan, self.tables, ins, ws)
+
+
+# ------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(path: SingleGpuPath, budget_s: float = 12.0):
+    """Times the CPU oracle (oracle/ref_np.py = numpy restatement of the reference path, 'port') on a
+    bounded sample of the same workload: same tables (copied to host), same id batches."""
+    from oracle import ref_np as R
+    space = R.FeatureSpace([f["name"] for f in path.feats if not f["bag"]], [],
+                           [f["name"] for f in path.feats if f["bag"]],
+                           {f["name"]: f["share"] for f in path.feats if "share" in f})
+    tnames = []
+    for f in path.feats:
+        t = f.get("share", f["name"])
+        if t not in tnames:
+            tnames.append(t)
+    tables = {n: t.cpu().numpy() for n, t in zip(tnames, path.tables)}
+    ins, ws = path.pool[0]
+    Bs = BATCH if path.wl != "c4" else 8192
+    batch = {}
+    for f, x, w in zip(path.feats, ins, ws):
+        batch[f["name"]] = x[:Bs].cpu().numpy()
+        if w is not None:
+            batch[f["name"] + "_mask"] = w[:Bs].cpu().numpy()
+    names = {f["name"] for f in path.feats}
+    dims = [f["dim"] for f in sorted(path.feats, key=lambda f: f["name"])]
+
+    def one():
+        feats, _, _ = R.embed_concat(space, tables, batch, names)
+        if path.fm:
+            w, v = R.fm_split(feats, dims)
+            R.fm_logit(w, v, 0.0)
+        if path.cross:
+            R.dcn_v1(feats, path.cross_w.cpu().numpy(), path.cross_b.cpu().numpy())
+
+    one()
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        one()
+        reps += 1
+        if time.perf_counter() - t0 > budget_s or reps >= 200:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": Bs / dt, "unit": "impressions/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} passes of {Bs} impressions of the same workload (oracle/ref_np.py, numpy, 1 thread); "
+                      f"{dt * 1e3:.1f} ms/pass; host has {os.cpu_count()} logical cores"}
+
+
+# ------------------------------------------------------------------------------------ main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-mode", default="row", choices=["row", "auto"],
+                    help="N>1: 'row' shards every table row-wise (north star); 'auto' replicates tables <= 64 MiB")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    from news_recsys_amd import ops
+    ops.set_index_check("off")            # ids are generated in range; the flag read-back would sync every step
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    seed = 20260116 + {"c2": 2, "c3": 3, "c4": 4, "c5": 5}[args.workload] + rank
+    if world == 1:
+        path = SingleGpuPath(args.workload, device, seed)
+        step = path.step
+        bytes_per_impr = path.bytes_per_impr
+        desc = path.desc
+        parallelism = "single-gpu"
+    else:
+        from news_recsys_amd.sharding import ShardedBenchPath
+        path = ShardedBenchPath(args.workload, device, seed, rank, world, BATCH, args.shard_mode)
+        step = path.step
+        bytes_per_impr = path.bytes_per_impr
+        desc = path.desc
+        parallelism = f"row-sharded tables x{world} (mode={args.shard_mode}), batch-parallel {BATCH}/GPU, RCCL all-to-all"
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    # per-launch durations of the dominant kernel path with HIP events on the launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        step(args.warmup + i)
+        ev[i][1].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    launch_ms = np.array([a.elapsed_time(b) for a, b in ev])
+
+    if rank == 0:
+        total_impr = BATCH * world * args.steps
+        ms_per_step = dt * 1e3 / args.steps
+        kern_ms = float(np.mean(launch_ms))
+        achieved = bytes_per_impr * BATCH / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "impressions/sec at batch 65536 (embedding hot path forward)",
+            "value": total_impr / dt,
+            "unit": "impressions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": desc, "batch_per_gpu": BATCH, "parallelism": parallelism,
+                       "algorithmic_bytes_per_impression": bytes_per_impr, "id_pool": 8},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel_ms_mean": kern_ms, "kernel_ms_p10": float(np.percentile(launch_ms, 10)),
+                         "kernel_ms_p90": float(np.percentile(launch_ms, 90)),
+                         "note": "achieved = algorithmic bytes per launch / mean HIP-event duration of the hot-path "
+                                 "launch(es) of one step on the launch stream; PMC traffic: see profiles/"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(path)
+        try:
+            info = ops.device_info(local_rank)
+            out["config"]["device"] = {"compute_units": info["compute_units"], "clock_khz": info["clock_khz"],
+                                       "hbm_gib": round(info["global_mem_bytes"] / 2 ** 30, 1)}
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

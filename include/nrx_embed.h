@@ -1,0 +1,167 @@
+/*
+ * nrx_embed.h -- C-ABI of libnrx_hip.so: the MI355X (gfx950) embedding / pooling /
+ * feature-interaction hot path behind News_Recsys' BaseModel surface.
+ *
+ * The reference (ZhangHaoyang493/News_Recsys) has NO native / FFI layer: its "operator API"
+ * for this path is the Python surface of BaseModel and its subclasses.  Each entry point below
+ * therefore names the reference Python function(s) whose arithmetic it replaces (paths relative
+ * to the reference root).  The Python host side (news_recsys_amd/_lib.py, ops.py) binds these
+ * with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only; no torch / ATen types.
+ *   - every data pointer is a CALLER-OWNED DEVICE pointer (tensor.data_ptr()); descriptor
+ *     arrays (`nrx_feature_t*`, `float* const*` lists) are HOST arrays read during the call.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     calls only enqueue work: they never synchronise, allocate or free device memory.
+ *   - return value: NRX_OK (0) or a negative NRX_ERR_* code; nrx_last_error() gives text.
+ *   - tables are fp32 row-major [rows, dim]; ids are int64 or int32 (the reference casts
+ *     with .long(), base_model.py:271); id 0 is the padding row (feature_extractor_base.py:162).
+ *   - out-of-range ids never fault: the lookup is treated as row 0, and `status` (device
+ *     int32[4], caller-zeroed: {count, feature, sample, id_lo}) records the offence so the
+ *     host wrapper can raise IndexError like torch does on CPU.
+ *   - re-entrant: no global mutable state except the thread-local last-error string.
+ */
+#ifndef NRX_EMBED_H
+#define NRX_EMBED_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define NRX_API __attribute__((visibility("default")))
+#else
+#define NRX_API
+#endif
+
+#define NRX_ABI_VERSION 1
+#define NRX_MAX_FEATURES 64   /* per launch; the host splits wider feature sets */
+#define NRX_MAX_DCN_LAYERS 8
+
+#define NRX_OK 0
+#define NRX_ERR_BAD_ARG (-1)
+#define NRX_ERR_LAUNCH (-2)
+#define NRX_ERR_UNSUPPORTED (-3)
+
+/* How one input feature becomes columns of the concat (base_model.py:284-308). */
+enum nrx_feature_kind {
+    NRX_SPARSE = 0,          /* ids [B]      -> table row                      (base_model.py:267-271) */
+    NRX_DENSE = 1,           /* value [B]    -> one column, value.float()      (base_model.py:264-265) */
+    NRX_BAG_MASKED_MEAN = 2, /* ids [B,L] + weight [B,L] -> sum(w*e)/(sum(w)+1e-8)  (base_model.py:278-282) */
+    NRX_BAG_MEAN = 3,        /* ids [B,L], no mask -> mean over L incl. padding      (base_model.py:275-276) */
+    NRX_BAG_SUM = 4          /* ids [B,L] (+ optional weight) -> sum(w*e); owner-side partial pooling */
+};
+
+typedef struct nrx_feature {
+    const float* table;  /* device [rows, dim]; NULL for NRX_DENSE. In *_bwd calls: float* grad table */
+    const void* index;   /* device ids [B] / [B, bag_len]; for NRX_DENSE the values (f32 or f64)   */
+    const float* weight; /* device [B, bag_len] mask / weights, or NULL                           */
+    int64_t rows;        /* table rows (ids must lie in [0, rows))                                 */
+    int32_t dim;         /* embedding dim (1 for NRX_DENSE)                                        */
+    int32_t bag_len;     /* L for bag kinds, 0 otherwise                                           */
+    int32_t kind;        /* enum nrx_feature_kind                                                  */
+    int32_t index_bits;  /* 32 or 64: width of ids (or of the dense value type)                    */
+    int32_t out_col;     /* first column of this feature in `out`                                  */
+    int32_t wide_col;    /* -1, or: column 0 goes to wide_out[:, wide_col] and columns 1..dim-1 to
+                            out[:, out_col .. out_col+dim-2]          (widedeep/model.py:58-66)   */
+    int32_t fm_field;    /* 1: field of the FM epilogue (col 0 = w, cols 1.. = v; fm/model.py:48-59) */
+    int32_t reserved;
+} nrx_feature_t;
+
+/* ---- library ---------------------------------------------------------------------------- */
+NRX_API int nrx_abi_version(void);
+NRX_API const char* nrx_last_error(void);
+/* device facts used by the bench harness:
+ * {CUs, wavefront size, core clock kHz, global memory bytes, memory clock kHz, memory bus bits} */
+NRX_API int nrx_device_info(int device, int64_t info[6]);
+
+/* ---- fused multi-table gather (+pool) -> concat, optional wide split and FM epilogue --------
+ * Replaces BaseModel.get_embeddings_from_batch (base_model.py:284-308) = per-feature
+ * get_feature_embedding (262-271) + array_feature_pooling (273-282) + torch.cat, and, when
+ * requested, WideDeep.get_inp_embedding's column routing (widedeep/model.py:53-69) and
+ * FM.get_inp_embedding + the pre-sigmoid part of FMModel.forward (fm/model.py:18-26,48-59):
+ *   fm_out[b] = sum_f w_f + 0.5 * sum_k[(sum_f v_fk)^2 - sum_f v_fk^2]      (no bias, no sigmoid)
+ * out      : [B, out_ld] fp32 (may be NULL only if every feature routes nowhere else -- i.e. never)
+ * wide_out : [B, wide_ld] or NULL;  fm_out : [B] or NULL;  status: device int32[4] or NULL.      */
+NRX_API int nrx_embed_fwd(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
+                  float* out, int64_t out_ld, float* wide_out, int64_t wide_ld,
+                  float* fm_out, int32_t* status, void* stream);
+
+/* Backward of nrx_embed_fwd's gather/pool/concat/wide-split: scatter-adds into DENSE grad tables
+ * (feats[i].table is the float* grad table [rows, dim], pre-zeroed by the caller), i.e. what
+ * autograd produces for nn.Embedding(sparse=False) (base_model.py:164); the padding row 0
+ * receives no gradient.  g_out [B, out_ld] (or NULL), g_wide [B, wide_ld] (or NULL).
+ * The FM epilogue's gradient is folded into g_out by the caller with nrx_fm_bwd (it only
+ * needs the forward concat).  NRX_DENSE features are inputs and receive no gradient.          */
+NRX_API int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
+                  const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                  void* stream);
+
+/* ---- standalone pooling on materialised embeddings -------------------------------------------
+ * BaseModel.array_feature_pooling(emb[B,L,D], mask[B,L] | None) (base_model.py:273-282).       */
+NRX_API int nrx_bag_pool_fwd(const float* emb, const float* mask, int64_t batch, int32_t bag_len,
+                     int32_t dim, float* out, void* stream);
+NRX_API int nrx_bag_pool_bwd(const float* g_out, const float* mask, int64_t batch, int32_t bag_len,
+                     int32_t dim, float* g_emb, void* stream);
+
+/* ---- standalone FM on a concat [B, n_fields*dim] (all fields share dim) ---------------------
+ * FM.get_inp_embedding + FMModel.forward without bias/sigmoid (fm/model.py:18-26,48-59).       */
+NRX_API int nrx_fm_fwd(const float* feat, int64_t ld, int32_t n_fields, int32_t dim, int64_t batch,
+               float* fm_out, void* stream);
+NRX_API int nrx_fm_bwd(const float* feat, int64_t ld, int32_t n_fields, int32_t dim, int64_t batch,
+               const float* g_fm, float* g_feat, int64_t g_ld, int32_t accumulate, void* stream);
+
+/* ---- DCN v1 cross network: x_{l+1} = x0 * (x_l . w_l) + b_l + x_l ------------------------------
+ * DCNLayer.forward / DCNNet.forward (dcn/dcn_arch.py:14-30, 63-70) in the algebraic O(B*D)
+ * form (the reference materialises a [B,D,D] outer product).  w, b: device [n_layers, dim].
+ * All layers run in one launch with the row held in registers.  out may alias a different
+ * column block of the same buffer as x (e.g. out = x + dim with ld = 2*dim gives cat[x, cross],
+ * dcn/model.py:29).                                                                            */
+NRX_API int nrx_dcn_v1_fwd(const float* x, int64_t x_ld, int64_t batch, int32_t dim, int32_t n_layers,
+                   const float* w, const float* b, float* out, int64_t out_ld, void* stream);
+/* g_w, g_b: device [n_layers, dim], pre-zeroed, accumulated with atomics. */
+NRX_API int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, int64_t batch, int32_t dim, int32_t n_layers,
+                   const float* w, const float* b, const float* g_out, int64_t g_out_ld,
+                   float* g_x, int64_t g_x_ld, float* g_w, float* g_b, void* stream);
+
+/* ---- DCN v2 cross layer on the matrix cores: out = act(x0 * (x_l W^T + bias) + x_l) -----------
+ * DCNv2Layer.forward + the ReLU DCNv2Net puts after every layer (dcn_arch.py:33-50, 73-91).
+ * W: device [dim, dim] (nn.Linear weight: out x in), bias [dim].  fp32 in / fp32 accumulate on
+ * v_mfma_f32_32x32x2_f32 (exact f32 fma chain).  relu: 1 = apply ReLU (reference), 0 = none.    */
+NRX_API int nrx_dcn_v2_layer_fwd(const float* x0, const float* xl, int64_t ld, int64_t batch, int32_t dim,
+                         const float* W, const float* bias, int32_t relu, float* out,
+                         int64_t out_ld, void* stream);
+/* (The v2 backward is two plain GEMMs + elementwise work; the host composes it from library
+ * GEMMs -- rocBLAS via torch.matmul -- see news_recsys_amd/ops.py.)                             */
+
+/* ---- integer utilities of the row-sharded path (bit-exact vs the CPU definitions) -------------
+ * Row r of a table lives on rank r % world at local row r / world.                              */
+/* Stable bucketing of a flat id list by owner rank (three deterministic passes: per-wavefront
+ * histograms, scan, ballot-ranked placement; no order-dependent atomics).  Outputs (device int64):
+ *   counts[world]  ids per owner;
+ *   local_rows[n]  the send buffer: (id / world) grouped by owner, source order kept inside a bucket;
+ *   slot[n]        slot[i] = position of source element i in that send buffer (the un-permute map).
+ * workspace: device int64[nrx_bucketize_workspace(n, world)], contents undefined on entry.        */
+NRX_API int64_t nrx_bucketize_workspace(int64_t n, int32_t world);
+NRX_API int nrx_bucketize_by_owner(const void* ids, int32_t index_bits, int64_t n, int32_t world,
+                           int64_t* counts, int64_t* local_rows, int64_t* slot,
+                           int64_t* workspace, void* stream);
+/* Owner-side gather of a flat id list that is segmented by table: segment s covers
+ * local_rows[seg_start[s] .. seg_start[s+1]) and reads tables[seg_table[s]]; every table is `dim`
+ * wide.  tables / table_rows: HOST arrays (n_tables device pointers / row counts); seg_start
+ * (n_seg+1, int64) and seg_table (n_seg, int32): DEVICE arrays; n_rows = seg_start[n_seg].
+ * out_rows: device [n_rows, dim].  Out-of-range rows read row 0 and are recorded in `status`.     */
+NRX_API int nrx_gather_rows_segmented(const float* const* tables, const int64_t* table_rows, int32_t n_tables,
+                              const int64_t* seg_start, const int32_t* seg_table, int32_t n_seg,
+                              int64_t n_rows, int32_t dim, const int64_t* local_rows,
+                              float* out_rows, int32_t* status, void* stream);
+/* lens[b] = #(mask[b,:] != 0); used to build CSR offsets from the reference's padded masks. */
+NRX_API int nrx_mask_lengths(const float* mask, int64_t batch, int32_t bag_len, int64_t* lens, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NRX_EMBED_H */

@@ -1,0 +1,102 @@
+"""ctypes binding of libnrx_hip.so (the C-ABI declared in include/nrx_embed.h).
+
+There is deliberately NO CPU fallback here: if the shared library is missing or a tensor is
+not on a ROCm device the call raises.  Build the library with `python -c "import
+__graft_entry__ as g; g.build()"` or `make -C news_recsys_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnrx_hip.so")
+
+NRX_MAX_FEATURES = 64
+NRX_MAX_DCN_LAYERS = 8
+NRX_OK = 0
+
+# enum nrx_feature_kind
+NRX_SPARSE, NRX_DENSE, NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM = 0, 1, 2, 3, 4
+
+
+class NrxFeature(C.Structure):
+    """struct nrx_feature (include/nrx_embed.h)."""
+    _fields_ = [
+        ("table", C.c_void_p),
+        ("index", C.c_void_p),
+        ("weight", C.c_void_p),
+        ("rows", C.c_int64),
+        ("dim", C.c_int32),
+        ("bag_len", C.c_int32),
+        ("kind", C.c_int32),
+        ("index_bits", C.c_int32),
+        ("out_col", C.c_int32),
+        ("wide_col", C.c_int32),
+        ("fm_field", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class NrxError(RuntimeError):
+    pass
+
+
+_i32, _i64, _p = C.c_int32, C.c_int64, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/nrx_embed.h one to one
+SIGNATURES = {
+    "nrx_abi_version": (C.c_int, []),
+    "nrx_last_error": (C.c_char_p, []),
+    "nrx_device_info": (C.c_int, [C.c_int, C.POINTER(_i64)]),
+    "nrx_embed_fwd": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p]),
+    "nrx_embed_bwd": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, _p]),
+    "nrx_bag_pool_fwd": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
+    "nrx_bag_pool_bwd": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
+    "nrx_fm_fwd": (C.c_int, [_p, _i64, _i32, _i32, _i64, _p, _p]),
+    "nrx_fm_bwd": (C.c_int, [_p, _i64, _i32, _i32, _i64, _p, _p, _i64, _i32, _p]),
+    "nrx_dcn_v1_fwd": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p]),
+    "nrx_dcn_v1_bwd": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _i64, _p, _p, _p]),
+    "nrx_dcn_v2_layer_fwd": (C.c_int, [_p, _p, _i64, _i64, _i32, _p, _p, _i32, _p, _i64, _p]),
+    "nrx_bucketize_workspace": (_i64, [_i64, _i32]),
+    "nrx_bucketize_by_owner": (C.c_int, [_p, _i32, _i64, _i32, _p, _p, _p, _p, _p]),
+    "nrx_gather_rows_segmented": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, _p, _p, _i32, _i64, _i32, _p, _p, _p, _p]),
+    "nrx_mask_lengths": (C.c_int, [_p, _i64, _i32, _p, _p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load(path: Optional[str] = None) -> C.CDLL:
+    """Load the shared library (once).  Loading needs no GPU; calling compute entry points does."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise NrxError(
+            f"{p} not found: the HIP extension is not built. Run `make -C news_recsys_amd/csrc` "
+            "(or __graft_entry__.build()). There is no CPU fallback for the product path.")
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.nrx_abi_version() != 1:
+        raise NrxError(f"ABI version mismatch: library reports {lib.nrx_abi_version()}, binding expects 1")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != NRX_OK:
+        msg = load().nrx_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise NrxError(f"{what} failed (code {rc}): {msg}")
+
+
+def is_available() -> bool:
+    return os.path.exists(LIB_PATH)

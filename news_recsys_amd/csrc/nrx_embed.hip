@@ -1,0 +1,650 @@
+// Fused multi-table embedding gather (+ bag pooling) -> concat, with optional Wide&Deep column
+// routing and FM epilogue, and its dense-grad backward.  gfx950 / wave64.
+//
+// Replaces, per launch, the reference's Python loop over features
+//   BaseModel.get_embeddings_from_batch   src/model/BaseModel/base_model.py:284-308
+//     get_feature_embedding               :262-271   (one ATen gather per feature)
+//     array_feature_pooling               :273-282   (mul, sum, sum, add, div over [B,L,D])
+//     torch.cat                           :308
+//   WideDeep.get_inp_embedding            src/model/sort/widedeep/model.py:53-69
+//   FM.get_inp_embedding + FMModel.forward (pre-sigmoid) src/model/sort/fm/model.py:18-26,48-59
+//
+// Work decomposition ("row-group" mapping): a sample is owned by Q = 2^QLOG2 adjacent lanes, lane q
+// holding columns [4q, 4q+4) of whichever feature is being processed; a 256-thread block owns
+// TB = 256/Q consecutive samples and walks the features.  Consequences:
+//   * a D-float row is fetched by D/4 adjacent lanes with one 16 B load each (coalesced 64..256 B
+//     segments of HBM), and lands in its final place in the [B, sum D] concat -- no torch.cat pass;
+//   * single-valued ids are read coalesced over the block's samples (8 B x TB contiguous per feature);
+//   * bag ids/weights ([B, L] padded, reference layout) are staged per block through LDS as packed
+//     {int32 id, f32 weight} pairs, read back as broadcast ds_read_b64;
+//   * the FM sums over fields stay in registers across the feature walk; the final reduction over
+//     the Q lanes of a sample is a wavefront shuffle (Q <= 64 lanes never straddle a wave).
+// The uniform kernel is the same mapping specialised for "all features single-valued, same D = 4Q":
+// ids and rows of U features are requested back-to-back so that U independent random row reads per
+// lane are in flight (the path is latency x bandwidth bound: 64 B rows from tables >> L2/MALL).
+#include "nrx_common.h"
+
+namespace {
+
+struct EmbedArgs {
+    FeatDev f[NRX_MAX_FEATURES];
+    int64_t batch;
+    float* out;          // fwd: concat out (may be null); bwd: g_out (read only)
+    int64_t out_ld;
+    float* wide;         // fwd: wide_out; bwd: g_wide (read only)
+    int64_t wide_ld;
+    float* fm_out;
+    int32_t* status;
+    int32_t n;
+    int32_t lds_chunk;   // bag entries staged per pass
+};
+static_assert(sizeof(EmbedArgs) <= 3584, "kernarg budget");
+
+struct BagPair {
+    int32_t id;
+    float w;
+};
+
+__device__ __forceinline__ float4 load_row4(const float* table, int64_t id, int D, int k0, bool vec) {
+    const float* p = table + id * (int64_t)D + k0;
+    float4 v;
+    if (vec) {
+        v = *reinterpret_cast<const float4*>(p);
+    } else {
+        v.x = p[0];
+        v.y = (k0 + 1 < D) ? p[1] : 0.f;
+        v.z = (k0 + 2 < D) ? p[2] : 0.f;
+        v.w = (k0 + 3 < D) ? p[3] : 0.f;
+    }
+    return v;
+}
+
+// FM bookkeeping for one field chunk held by this lane (columns k0..k0+3 of the field):
+// column 0 is the first-order weight, columns 1.. are the factor vector.
+__device__ __forceinline__ void fm_accumulate(float4 v, int k0, int D, float& first, float4& s, float4& sq) {
+    if (k0 == 0) {
+        first += v.x;
+        v.x = 0.f;
+    }
+    if (k0 + 1 >= D) v.y = 0.f;
+    if (k0 + 2 >= D) v.z = 0.f;
+    if (k0 + 3 >= D) v.w = 0.f;
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+}
+
+template <int Q>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = Q / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// --------------------------------------------------------------------------------------------
+// Generic forward: any mix of sparse / dense / bag features, any dims, wide routing, FM.
+// --------------------------------------------------------------------------------------------
+template <int QLOG2>
+__global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_generic(const EmbedArgs a) {
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    BagPair* s_bag = reinterpret_cast<BagPair*>(smem);
+
+    const int tid = threadIdx.x;
+    const int q = tid & (Q - 1);
+    const int sb = tid >> QLOG2;
+    const int64_t b0 = (int64_t)blockIdx.x * TB;
+    const int64_t b = b0 + sb;
+    const bool live = b < a.batch;
+    const int nb = (int)((a.batch - b0) < (int64_t)TB ? (a.batch - b0) : (int64_t)TB);
+    const bool out_vec = a.out != nullptr && ((a.out_ld & 3) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0);
+
+    float fm_first = 0.f;
+    float4 fm_s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 fm_q = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int fi = 0; fi < a.n; ++fi) {
+        const FeatDev& f = a.f[fi];
+        const int D = f.dim;
+        const bool vec_load = ((D & 3) == 0) && ((reinterpret_cast<uintptr_t>(f.table) & 15u) == 0);
+        for (int kc = 0; kc < D; kc += 4 * Q) {
+            const int k0 = kc + q * 4;
+            const bool active = live && k0 < D;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f.kind == NRX_SPARSE) {
+                if (active) {
+                    int64_t id = nrx_load_id(f.index, b, f.idx64);
+                    if ((uint64_t)id >= (uint64_t)f.rows) {
+                        if (q == 0) nrx_report_oob(a.status, fi, b, id);
+                        id = 0;
+                    }
+                    v = load_row4(f.table, id, D, k0, vec_load);
+                }
+            } else if (f.kind == NRX_DENSE) {
+                if (active && k0 == 0)
+                    v.x = f.idx64 ? (float)reinterpret_cast<const double*>(f.index)[b]
+                                  : reinterpret_cast<const float*>(f.index)[b];
+            } else {
+                // ---- bag: stage {id, weight} of the block's samples through LDS, chunk by chunk
+                const int L = f.bag_len;
+                const int lc = a.lds_chunk;
+                const int stride = lc | 1;   // odd pair-stride: conflict-free broadcast ds_read_b64
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                float den = 0.f;
+                for (int l0 = 0; l0 < L; l0 += lc) {
+                    const int cur = (L - l0) < lc ? (L - l0) : lc;
+                    __syncthreads();
+                    for (int e = tid; e < nb * cur; e += NRX_BLOCK) {
+                        const int s = e / cur;
+                        const int l = e - s * cur;
+                        const int64_t gi = (b0 + s) * (int64_t)L + l0 + l;
+                        int64_t id = nrx_load_id(f.index, gi, f.idx64);
+                        const float w = f.weight ? f.weight[gi] : 1.0f;
+                        if ((uint64_t)id >= (uint64_t)f.rows) {
+                            nrx_report_oob(a.status, fi, b0 + s, id);
+                            id = 0;
+                        }
+                        BagPair p;
+                        p.id = (int32_t)id;
+                        p.w = w;
+                        s_bag[s * stride + l] = p;
+                    }
+                    __syncthreads();
+                    if (active) {
+                        const BagPair* row = s_bag + sb * stride;
+                        constexpr int U = 8;
+                        int l = 0;
+                        for (; l + U <= cur; l += U) {
+                            BagPair p[U];
+                            float4 r[U];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) p[u] = row[l + u];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                                if (p[u].w != 0.f) r[u] = load_row4(f.table, p[u].id, D, k0, vec_load);
+                            }
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+#pragma clang fp contract(off)
+                                den += p[u].w;
+                                acc.x += r[u].x * p[u].w;
+                                acc.y += r[u].y * p[u].w;
+                                acc.z += r[u].z * p[u].w;
+                                acc.w += r[u].w * p[u].w;
+                            }
+                        }
+                        for (; l < cur; ++l) {
+#pragma clang fp contract(off)
+                            const BagPair p = row[l];
+                            den += p.w;
+                            if (p.w != 0.f) {
+                                const float4 r = load_row4(f.table, p.id, D, k0, vec_load);
+                                acc.x += r.x * p.w;
+                                acc.y += r.y * p.w;
+                                acc.z += r.z * p.w;
+                                acc.w += r.w * p.w;
+                            }
+                        }
+                    }
+                }
+                if (f.kind == NRX_BAG_MASKED_MEAN) {
+                    const float d = den + 1e-8f;
+                    v = make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d);
+                } else if (f.kind == NRX_BAG_MEAN) {
+                    const float d = (float)L;
+                    v = make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d);
+                } else {
+                    v = acc;
+                }
+            }
+
+            if (active) {
+                if (f.wide_col >= 0) {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = k0 + j;
+                        if (k < D) {
+                            if (k == 0) {
+                                if (a.wide) a.wide[b * a.wide_ld + f.wide_col] = vv[j];
+                            } else if (a.out) {
+                                a.out[b * a.out_ld + f.out_col + k - 1] = vv[j];
+                            }
+                        }
+                    }
+                } else if (a.out) {
+                    float* p = a.out + b * a.out_ld + f.out_col + k0;
+                    if (out_vec && ((f.out_col & 3) == 0) && (k0 + 4 <= D)) {
+                        *reinterpret_cast<float4*>(p) = v;
+                    } else {
+                        p[0] = v.x;
+                        if (k0 + 1 < D) p[1] = v.y;
+                        if (k0 + 2 < D) p[2] = v.z;
+                        if (k0 + 3 < D) p[3] = v.w;
+                    }
+                }
+                if (f.fm) fm_accumulate(v, k0, D, fm_first, fm_s, fm_q);
+            }
+        }
+    }
+
+    if (a.fm_out != nullptr) {
+        // 0.5 * sum_k [(sum_f v)^2 - sum_f v^2] over this lane's 4 columns, then over the Q lanes
+        float part = 0.5f * ((fm_s.x * fm_s.x - fm_q.x) + (fm_s.y * fm_s.y - fm_q.y) +
+                             (fm_s.z * fm_s.z - fm_q.z) + (fm_s.w * fm_s.w - fm_q.w)) + fm_first;
+        part = group_sum<Q>(part);
+        if (live && q == 0) a.fm_out[b] = part;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Uniform forward: every feature single-valued with the same D = 4*Q, 16 B aligned everywhere.
+// --------------------------------------------------------------------------------------------
+struct UniformArgs {
+    const float* table[NRX_MAX_FEATURES];
+    const void* index[NRX_MAX_FEATURES];
+    int64_t rows[NRX_MAX_FEATURES];
+    int32_t col4[NRX_MAX_FEATURES];   // out column / 4
+    int64_t batch;
+    float4* out;                      // may be null (FM-only inference)
+    int64_t ld4;                      // out_ld / 4
+    float* fm_out;
+    int32_t* status;
+    int32_t n;
+};
+static_assert(sizeof(UniformArgs) <= 3584, "kernarg budget");
+
+// One straight-line group of CNT features: CNT id loads, then CNT independent row loads, then CNT
+// stores -- no control flow, so all CNT random row reads of a lane are in flight together.
+// Out-of-range ids are clamped branch-free and reported once per lane after the feature walk.
+template <int Q, int CNT, bool IDX64, bool FM, bool STORE>
+__device__ __forceinline__ void uniform_group(const NRX_CONST UniformArgs* a, int f0, int64_t b, int q, int& bad_feat, int64_t& bad_id,
+                                              float& fm_first, float4& fm_s, float4& fm_q) {
+    int64_t id[CNT];
+    float4 v[CNT];
+#pragma unroll
+    for (int u = 0; u < CNT; ++u)
+        id[u] = IDX64 ? nrx_gconst<int64_t>(a->index[f0 + u])[b]
+                      : (int64_t)nrx_gconst<int32_t>(a->index[f0 + u])[b];
+#pragma unroll
+    for (int u = 0; u < CNT; ++u) {
+        const bool bad = (uint64_t)id[u] >= (uint64_t)a->rows[f0 + u];
+        bad_feat = bad ? f0 + u : bad_feat;
+        bad_id = bad ? id[u] : bad_id;
+        id[u] = bad ? 0 : id[u];
+        v[u] = nrx_ldg4(a->table[f0 + u], id[u] * Q + q);
+    }
+#pragma unroll
+    for (int u = 0; u < CNT; ++u) {
+        if (STORE) nrx_stg4(a->out, b * a->ld4 + a->col4[f0 + u] + q, v[u]);
+        if (FM) fm_accumulate(v[u], q * 4, 4 * Q, fm_first, fm_s, fm_q);
+    }
+}
+
+template <int Q, int U, int R, bool IDX64, bool FM, bool STORE>
+struct UniformTail {
+    static __device__ __forceinline__ void run(const NRX_CONST UniformArgs* a, int f0, int rem, int64_t b, int q, int& bad_feat,
+                                               int64_t& bad_id, float& fm_first, float4& fm_s, float4& fm_q) {
+        if (rem == R) uniform_group<Q, R, IDX64, FM, STORE>(a, f0, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
+        else UniformTail<Q, U, R + 1, IDX64, FM, STORE>::run(a, f0, rem, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
+    }
+};
+template <int Q, int U, bool IDX64, bool FM, bool STORE>
+struct UniformTail<Q, U, U, IDX64, FM, STORE> {
+    static __device__ __forceinline__ void run(const NRX_CONST UniformArgs*, int, int, int64_t, int, int&, int64_t&, float&, float4&, float4&) {}
+};
+
+template <int QLOG2, int U, bool IDX64, bool FM, bool STORE>
+__global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_uniform(const UniformArgs args_in_kernarg_segment) {
+    const NRX_CONST UniformArgs* a = nrx_kernarg<UniformArgs>();   // == &args_in_kernarg_segment
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    const int tid = threadIdx.x;
+    const int q = tid & (Q - 1);
+    const int64_t b = (int64_t)blockIdx.x * TB + (tid >> QLOG2);
+    if (b >= a->batch) return;   // the Q lanes of a sample leave together: the FM shuffle stays inside the group
+
+    float fm_first = 0.f;
+    float4 fm_s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 fm_q = make_float4(0.f, 0.f, 0.f, 0.f);
+    int bad_feat = -1;
+    int64_t bad_id = 0;
+
+    int f0 = 0;
+    const int n = a->n;
+    for (; f0 + U <= n; f0 += U)
+        uniform_group<Q, U, IDX64, FM, STORE>(a, f0, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
+    const int rem = n - f0;
+    if (rem > 0) UniformTail<Q, U, 1, IDX64, FM, STORE>::run(a, f0, rem, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
+
+    if (bad_feat >= 0 && q == 0) nrx_report_oob(a->status, bad_feat, b, bad_id);
+    if (FM) {
+        float part = 0.5f * ((fm_s.x * fm_s.x - fm_q.x) + (fm_s.y * fm_s.y - fm_q.y) +
+                             (fm_s.z * fm_s.z - fm_q.z) + (fm_s.w * fm_s.w - fm_q.w)) + fm_first;
+        part = group_sum<Q>(part);
+        if (q == 0) nrx_gmut<float>(a->fm_out)[b] = part;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Backward: dense-grad scatter-add (what autograd gives nn.Embedding(sparse=False)).
+// f.table is the grad table; a.out = g_out, a.wide = g_wide (both read only here).
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_add_row4(float* gtable, int64_t id, int D, int k0, float4 g) {
+    float* p = gtable + id * (int64_t)D + k0;
+    unsafeAtomicAdd(p, g.x);
+    if (k0 + 1 < D) unsafeAtomicAdd(p + 1, g.y);
+    if (k0 + 2 < D) unsafeAtomicAdd(p + 2, g.z);
+    if (k0 + 3 < D) unsafeAtomicAdd(p + 3, g.w);
+}
+
+template <int QLOG2>
+__global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a) {
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    BagPair* s_bag = reinterpret_cast<BagPair*>(smem);
+
+    const int tid = threadIdx.x;
+    const int q = tid & (Q - 1);
+    const int sb = tid >> QLOG2;
+    const int64_t b0 = (int64_t)blockIdx.x * TB;
+    const int64_t b = b0 + sb;
+    const bool live = b < a.batch;
+    const int nb = (int)((a.batch - b0) < (int64_t)TB ? (a.batch - b0) : (int64_t)TB);
+
+    for (int fi = 0; fi < a.n; ++fi) {
+        const FeatDev& f = a.f[fi];
+        if (f.kind == NRX_DENSE) continue;
+        const int D = f.dim;
+        float* gtable = const_cast<float*>(f.table);
+        for (int kc = 0; kc < D; kc += 4 * Q) {
+            const int k0 = kc + q * 4;
+            const bool active = live && k0 < D;
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (active) {
+                float gg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + j;
+                    if (k < D) {
+                        if (f.wide_col >= 0) {
+                            if (k == 0) gg[j] = a.wide ? a.wide[b * a.wide_ld + f.wide_col] : 0.f;
+                            else gg[j] = a.out ? a.out[b * a.out_ld + f.out_col + k - 1] : 0.f;
+                        } else {
+                            gg[j] = a.out ? a.out[b * a.out_ld + f.out_col + k] : 0.f;
+                        }
+                    }
+                }
+                g = make_float4(gg[0], gg[1], gg[2], gg[3]);
+            }
+            if (f.kind == NRX_SPARSE) {
+                if (active) {
+                    const int64_t id = nrx_load_id(f.index, b, f.idx64);
+                    if (id > 0 && id < f.rows) atomic_add_row4(gtable, id, D, k0, g);
+                }
+                continue;
+            }
+            // ---- bags
+            const int L = f.bag_len;
+            float den = 1.0f;
+            if (f.kind == NRX_BAG_MASKED_MEAN) {
+                den = 0.f;
+                if (active)
+                    for (int l = 0; l < L; ++l) den += f.weight[b * (int64_t)L + l];
+                den += 1e-8f;
+            } else if (f.kind == NRX_BAG_MEAN) {
+                den = (float)L;
+            }
+            const float4 gs = make_float4(g.x / den, g.y / den, g.z / den, g.w / den);
+            const int lc = a.lds_chunk;
+            const int stride = lc | 1;
+            for (int l0 = 0; l0 < L; l0 += lc) {
+                const int cur = (L - l0) < lc ? (L - l0) : lc;
+                __syncthreads();
+                for (int e = tid; e < nb * cur; e += NRX_BLOCK) {
+                    const int s = e / cur;
+                    const int l = e - s * cur;
+                    const int64_t gi = (b0 + s) * (int64_t)L + l0 + l;
+                    int64_t id = nrx_load_id(f.index, gi, f.idx64);
+                    const float w = f.weight ? f.weight[gi] : 1.0f;
+                    if ((uint64_t)id >= (uint64_t)f.rows) id = 0;
+                    BagPair p;
+                    p.id = (int32_t)id;
+                    p.w = w;
+                    s_bag[s * stride + l] = p;
+                }
+                __syncthreads();
+                if (active) {
+                    const BagPair* row = s_bag + sb * stride;
+                    for (int l = 0; l < cur; ++l) {
+                        const BagPair p = row[l];
+                        if (p.id != 0 && p.w != 0.f)
+                            atomic_add_row4(gtable, p.id, D, k0,
+                                            make_float4(gs.x * p.w, gs.y * p.w, gs.z * p.w, gs.w * p.w));
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------- host side
+int ceil_log2(int x) {
+    int l = 0;
+    while ((1 << l) < x) ++l;
+    return l;
+}
+
+int pack_features(const nrx_feature_t* feats, int32_t n, EmbedArgs& a, int& max_dim, int& max_bag, const char* who) {
+    max_dim = 1;
+    max_bag = 0;
+    for (int i = 0; i < n; ++i) {
+        const nrx_feature_t& s = feats[i];
+        NRX_REQUIRE(s.kind >= NRX_SPARSE && s.kind <= NRX_BAG_SUM, "%s: feature %d: bad kind %d", who, i, s.kind);
+        NRX_REQUIRE(s.index != nullptr, "%s: feature %d: null index pointer", who, i);
+        NRX_REQUIRE(s.index_bits == 32 || s.index_bits == 64, "%s: feature %d: index_bits must be 32 or 64", who, i);
+        NRX_REQUIRE(s.dim >= 1 && s.dim <= 32767, "%s: feature %d: dim %d out of range", who, i, s.dim);
+        if (s.kind == NRX_DENSE) {
+            NRX_REQUIRE(s.dim == 1, "%s: feature %d: dense features have dim 1", who, i);
+        } else {
+            NRX_REQUIRE(s.table != nullptr, "%s: feature %d: null table pointer", who, i);
+            NRX_REQUIRE(s.rows >= 1 && s.rows <= 0x7fffffffLL, "%s: feature %d: rows %lld out of range", who, i, (long long)s.rows);
+        }
+        if (s.kind >= NRX_BAG_MASKED_MEAN) {
+            NRX_REQUIRE(s.bag_len >= 1 && s.bag_len <= 32767, "%s: feature %d: bag_len %d out of range", who, i, s.bag_len);
+            NRX_REQUIRE(s.kind != NRX_BAG_MASKED_MEAN || s.weight != nullptr, "%s: feature %d: masked mean needs weights", who, i);
+        }
+        NRX_REQUIRE(s.out_col >= 0, "%s: feature %d: negative out_col", who, i);
+        FeatDev& d = a.f[i];
+        d.table = s.table;
+        d.index = s.index;
+        d.weight = (s.kind == NRX_BAG_MEAN) ? nullptr : s.weight;
+        d.rows = s.rows;
+        d.out_col = s.out_col;
+        d.wide_col = s.wide_col;
+        d.dim = (int16_t)s.dim;
+        d.bag_len = (int16_t)s.bag_len;
+        d.kind = (uint8_t)s.kind;
+        d.idx64 = s.index_bits == 64;
+        d.fm = s.fm_field != 0;
+        d.pad = 0;
+        if (s.dim > max_dim) max_dim = s.dim;
+        if (s.kind >= NRX_BAG_MASKED_MEAN && s.bag_len > max_bag) max_bag = s.bag_len;
+    }
+    return NRX_OK;
+}
+
+#define NRX_QSWITCH(qlog2, ...)               \
+    switch (qlog2) {                           \
+        case 0: { constexpr int QL = 0; __VA_ARGS__; } break; \
+        case 1: { constexpr int QL = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int QL = 2; __VA_ARGS__; } break; \
+        case 3: { constexpr int QL = 3; __VA_ARGS__; } break; \
+        case 4: { constexpr int QL = 4; __VA_ARGS__; } break; \
+        case 5: { constexpr int QL = 5; __VA_ARGS__; } break; \
+        default: { constexpr int QL = 6; __VA_ARGS__; } break; \
+    }
+
+// pick Q (lanes per sample) and the LDS bag chunk for the generic kernels
+void plan_generic(int max_dim, int max_bag, int& qlog2, int& lds_chunk, size_t& smem) {
+    qlog2 = ceil_log2((max_dim + 3) / 4);
+    if (qlog2 > 6) qlog2 = 6;
+    const int tb = NRX_BLOCK >> qlog2;
+    lds_chunk = 0;
+    smem = 0;
+    if (max_bag > 0) {
+        // keep the staging tile <= 32 KiB so >= 4 blocks stay resident per CU
+        int cap = (32 * 1024) / (tb * (int)sizeof(BagPair));
+        if (cap < 8) cap = 8;
+        lds_chunk = max_bag < cap ? max_bag : cap;
+        smem = (size_t)tb * (lds_chunk | 1) * sizeof(BagPair);
+    }
+}
+
+// U = features in flight per lane, chosen per call to divide the feature count well.
+template <int QLOG2, int U>
+void launch_uniform_u(const UniformArgs& ua, int64_t batch, bool i64, bool fm, bool store, hipStream_t st) {
+    constexpr int TB = NRX_BLOCK >> QLOG2;
+    const dim3 grid((unsigned)((batch + TB - 1) / TB)), block(NRX_BLOCK);
+    if (i64) {
+        if (fm && store) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, true, true, true>), grid, block, 0, st, ua);
+        else if (fm) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, true, true, false>), grid, block, 0, st, ua);
+        else hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, true, false, true>), grid, block, 0, st, ua);
+    } else {
+        if (fm && store) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, false, true, true>), grid, block, 0, st, ua);
+        else if (fm) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, false, true, false>), grid, block, 0, st, ua);
+        else hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, false, false, true>), grid, block, 0, st, ua);
+    }
+}
+
+template <int QLOG2>
+void launch_uniform(const UniformArgs& ua, int64_t batch, bool i64, bool fm, bool store, hipStream_t st) {
+    // group sizes on offer: 13 and 8 (narrow rows), 8 and 5 (wide rows); pick the one that wastes
+    // the fewest tail iterations, ties to the larger group.
+    const int n = ua.n;
+    if (QLOG2 <= 3) {
+        const int w13 = (13 - n % 13) % 13, w8 = (8 - n % 8) % 8;
+        if (n >= 13 && w13 <= w8) launch_uniform_u<QLOG2, 13>(ua, batch, i64, fm, store, st);
+        else launch_uniform_u<QLOG2, 8>(ua, batch, i64, fm, store, st);
+    } else {
+        const int w8 = (8 - n % 8) % 8, w5 = (5 - n % 5) % 5;
+        if (n >= 8 && w8 <= w5) launch_uniform_u<QLOG2, 8>(ua, batch, i64, fm, store, st);
+        else launch_uniform_u<QLOG2, 5>(ua, batch, i64, fm, store, st);
+    }
+}
+
+}  // namespace
+
+extern "C" int nrx_embed_fwd(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
+                             float* out, int64_t out_ld, float* wide_out, int64_t wide_ld,
+                             float* fm_out, int32_t* status, void* stream) {
+    NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
+                "nrx_embed_fwd: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
+    NRX_REQUIRE(batch >= 0, "nrx_embed_fwd: negative batch");
+    NRX_REQUIRE(out != nullptr || fm_out != nullptr || wide_out != nullptr, "nrx_embed_fwd: no output requested");
+    if (batch == 0) return NRX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+    // ---- uniform fast path?
+    bool uniform = true;
+    const int D0 = feats[0].dim;
+    int n_fm = 0;
+    for (int i = 0; i < n_feats; ++i) {
+        const nrx_feature_t& s = feats[i];
+        uniform &= s.kind == NRX_SPARSE && s.dim == D0 && s.wide_col < 0 && s.index_bits == feats[0].index_bits &&
+                   s.table != nullptr && nrx_aligned16(s.table) && (s.out_col & 3) == 0 && s.rows >= 1;
+        n_fm += s.fm_field != 0;
+    }
+    const int Q0 = D0 / 4;
+    uniform &= (D0 & 3) == 0 && Q0 >= 4 && Q0 <= 64 && (Q0 & (Q0 - 1)) == 0;   // D in {16,32,64,128,256}
+    uniform &= (out == nullptr) || (nrx_aligned16(out) && (out_ld & 3) == 0);
+    uniform &= (n_fm == 0 || n_fm == n_feats) && wide_out == nullptr;
+    uniform &= (out != nullptr) || (fm_out != nullptr && n_fm > 0);
+    if (uniform) {
+        UniformArgs ua;
+        for (int i = 0; i < n_feats; ++i) {
+            NRX_REQUIRE(feats[i].index != nullptr, "nrx_embed_fwd: feature %d: null index pointer", i);
+            NRX_REQUIRE(feats[i].rows <= 0x7fffffffLL, "nrx_embed_fwd: feature %d: rows out of range", i);
+            ua.table[i] = feats[i].table;
+            ua.index[i] = feats[i].index;
+            ua.rows[i] = feats[i].rows;
+            ua.col4[i] = feats[i].out_col / 4;
+        }
+        ua.batch = batch;
+        ua.out = reinterpret_cast<float4*>(out);
+        ua.ld4 = out_ld / 4;
+        ua.fm_out = fm_out;
+        ua.status = status;
+        ua.n = n_feats;
+        const bool fm = fm_out != nullptr && n_fm > 0;
+        const bool i64 = feats[0].index_bits == 64;
+        const bool store = out != nullptr;
+        switch (Q0) {
+            case 4: launch_uniform<2>(ua, batch, i64, fm, store, st); break;
+            case 8: launch_uniform<3>(ua, batch, i64, fm, store, st); break;
+            case 16: launch_uniform<4>(ua, batch, i64, fm, store, st); break;
+            case 32: launch_uniform<5>(ua, batch, i64, fm, store, st); break;
+            default: launch_uniform<6>(ua, batch, i64, fm, store, st); break;
+        }
+        NRX_LAUNCH_CHECK("nrx_embed_fwd(uniform)");
+        return NRX_OK;
+    }
+
+    // ---- generic path
+    EmbedArgs a;
+    int max_dim, max_bag;
+    int rc = pack_features(feats, n_feats, a, max_dim, max_bag, "nrx_embed_fwd");
+    if (rc != NRX_OK) return rc;
+    a.batch = batch;
+    a.out = out;
+    a.out_ld = out_ld;
+    a.wide = wide_out;
+    a.wide_ld = wide_ld;
+    a.fm_out = (n_fm > 0) ? fm_out : nullptr;
+    a.status = status;
+    a.n = n_feats;
+    NRX_REQUIRE(n_fm == 0 || fm_out != nullptr, "nrx_embed_fwd: fm_field set but fm_out is null");
+    NRX_REQUIRE(n_fm == 0 || max_dim <= 256, "nrx_embed_fwd: fused FM epilogue supports dim <= 256");
+    int qlog2;
+    size_t smem;
+    plan_generic(max_dim, max_bag, qlog2, a.lds_chunk, smem);
+    const int tb = NRX_BLOCK >> qlog2;
+    const unsigned grid = (unsigned)((batch + tb - 1) / tb);
+    NRX_QSWITCH(qlog2, { hipLaunchKernelGGL((embed_fwd_generic<QL>), dim3(grid), dim3(NRX_BLOCK), smem, st, a); });
+    NRX_LAUNCH_CHECK("nrx_embed_fwd(generic)");
+    return NRX_OK;
+}
+
+extern "C" int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
+                             const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                             void* stream) {
+    NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
+                "nrx_embed_bwd: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
+    NRX_REQUIRE(batch >= 0, "nrx_embed_bwd: negative batch");
+    NRX_REQUIRE(g_out != nullptr || g_wide != nullptr, "nrx_embed_bwd: no upstream gradient");
+    if (batch == 0) return NRX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    EmbedArgs a;
+    int max_dim, max_bag;
+    int rc = pack_features(feats, n_feats, a, max_dim, max_bag, "nrx_embed_bwd");
+    if (rc != NRX_OK) return rc;
+    a.batch = batch;
+    a.out = const_cast<float*>(g_out);
+    a.out_ld = out_ld;
+    a.wide = const_cast<float*>(g_wide);
+    a.wide_ld = wide_ld;
+    a.fm_out = nullptr;
+    a.status = nullptr;
+    a.n = n_feats;
+    int qlog2;
+    size_t smem;
+    plan_generic(max_dim, max_bag, qlog2, a.lds_chunk, smem);
+    const int tb = NRX_BLOCK >> qlog2;
+    const unsigned grid = (unsigned)((batch + tb - 1) / tb);
+    NRX_QSWITCH(qlog2, { hipLaunchKernelGGL((embed_bwd_generic<QL>), dim3(grid), dim3(NRX_BLOCK), smem, st, a); });
+    NRX_LAUNCH_CHECK("nrx_embed_bwd");
+    return NRX_OK;
+}

@@ -1,0 +1,436 @@
+// Standalone pooling / FM / DCN-v1 kernels (forward + backward) on materialised tensors.  gfx950.
+//
+//   nrx_bag_pool_*  BaseModel.array_feature_pooling        src/model/BaseModel/base_model.py:273-282
+//   nrx_fm_*        FM.get_inp_embedding + FMModel.forward  src/model/sort/fm/model.py:18-26,48-59
+//   nrx_dcn_v1_*    DCNLayer / DCNNet                       src/model/sort/dcn/dcn_arch.py:14-30,63-70
+//
+// All three are < 1 flop/byte: HBM-bound streaming kernels.  FM and DCN keep a sample's row in
+// registers (FM: Q lanes per sample like the gather kernel; DCN: one wavefront per row, all cross
+// layers fused, the per-layer dot product reduced with wave shuffles, w/b staged once per block in LDS).
+#include "nrx_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------ bag pooling
+__global__ __launch_bounds__(NRX_BLOCK) void bag_pool_fwd_kernel(const float* __restrict__ emb, const float* __restrict__ mask,
+                                                                 int64_t batch, int L, int D, float* __restrict__ out) {
+    const int64_t total = batch * (int64_t)D;
+    for (int64_t i = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * NRX_BLOCK) {
+        const int64_t b = i / D;
+        const int d = (int)(i - b * D);
+        const float* e = emb + (b * L) * (int64_t)D + d;
+        float acc = 0.f, den = 0.f;
+        if (mask != nullptr) {
+            const float* m = mask + b * (int64_t)L;
+            for (int l = 0; l < L; ++l) {
+#pragma clang fp contract(off)
+                const float w = m[l];
+                den += w;
+                acc += e[(int64_t)l * D] * w;
+            }
+            out[i] = acc / (den + 1e-8f);
+        } else {
+            for (int l = 0; l < L; ++l) acc += e[(int64_t)l * D];
+            out[i] = acc / (float)L;
+        }
+    }
+}
+
+// one block per sample: den once, then the [L, D] slab
+__global__ __launch_bounds__(NRX_BLOCK) void bag_pool_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ mask,
+                                                                 int64_t batch, int L, int D, float* __restrict__ g_emb) {
+    __shared__ float s_den;
+    for (int64_t b = blockIdx.x; b < batch; b += gridDim.x) {
+        if (mask != nullptr) {
+            if (threadIdx.x < NRX_WAVE) {
+                float part = 0.f;
+                for (int l = threadIdx.x; l < L; l += NRX_WAVE) part += mask[b * (int64_t)L + l];
+                part = nrx_wave_sum(part);
+                if (threadIdx.x == 0) s_den = part + 1e-8f;
+            }
+            __syncthreads();
+        }
+        const float den = mask ? s_den : (float)L;
+        const int n = L * D;
+        for (int e = threadIdx.x; e < n; e += NRX_BLOCK) {
+            const int l = e / D;
+            const int d = e - l * D;
+            const float g = g_out[b * (int64_t)D + d] / den;
+            g_emb[b * (int64_t)n + e] = mask ? g * mask[b * (int64_t)L + l] : g;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------ FM
+__device__ __forceinline__ float4 ld4(const float* p, int k0, int D, bool vec) {
+    float4 v;
+    if (vec) {
+        v = *reinterpret_cast<const float4*>(p);
+    } else {
+        v.x = p[0];
+        v.y = (k0 + 1 < D) ? p[1] : 0.f;
+        v.z = (k0 + 2 < D) ? p[2] : 0.f;
+        v.w = (k0 + 3 < D) ? p[3] : 0.f;
+    }
+    return v;
+}
+
+template <int QLOG2>
+__global__ __launch_bounds__(NRX_BLOCK) void fm_fwd_kernel(const float* __restrict__ feat, int64_t ld, int F, int D,
+                                                           int64_t batch, float* __restrict__ fm_out, bool vec) {
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    const int q = threadIdx.x & (Q - 1);
+    const int64_t b = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
+    const bool live = b < batch;
+    float total = 0.f;
+    for (int kc = 0; kc < D; kc += 4 * Q) {     // one pass when D <= 4Q (the normal case)
+        const int k0 = kc + q * 4;
+        float first = 0.f;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sq = s;
+        if (live && k0 < D) {
+            const float* row = feat + b * ld + k0;
+            for (int f = 0; f < F; ++f) {
+                float4 v = ld4(row + (int64_t)f * D, k0, D, vec);
+                if (k0 == 0) { first += v.x; v.x = 0.f; }
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+            }
+        }
+        total += 0.5f * ((s.x * s.x - sq.x) + (s.y * s.y - sq.y) + (s.z * s.z - sq.z) + (s.w * s.w - sq.w)) + first;
+    }
+#pragma unroll
+    for (int off = Q / 2; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+    if (live && q == 0) fm_out[b] = total;
+}
+
+template <int QLOG2>
+__global__ __launch_bounds__(NRX_BLOCK) void fm_bwd_kernel(const float* __restrict__ feat, int64_t ld, int F, int D, int64_t batch,
+                                                           const float* __restrict__ g_fm, float* __restrict__ g_feat, int64_t g_ld,
+                                                           bool accumulate, bool vec) {
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    const int q = threadIdx.x & (Q - 1);
+    const int64_t b = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
+    if (b >= batch) return;
+    const float gl = g_fm[b];
+    for (int kc = 0; kc < D; kc += 4 * Q) {
+        const int k0 = kc + q * 4;
+        if (k0 >= D) continue;
+        const float* row = feat + b * ld + k0;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int f = 0; f < F; ++f) {
+            const float4 v = ld4(row + (int64_t)f * D, k0, D, vec);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        for (int f = 0; f < F; ++f) {
+            const float4 v = ld4(row + (int64_t)f * D, k0, D, vec);
+            float g[4] = {gl * (s.x - v.x), gl * (s.y - v.y), gl * (s.z - v.z), gl * (s.w - v.w)};
+            if (k0 == 0) g[0] = gl;     // d/dw = 1
+            float* gp = g_feat + b * g_ld + (int64_t)f * D + k0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j < D) gp[j] = accumulate ? gp[j] + g[j] : g[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ DCN v1
+// One wavefront per row; lane holds R chunks of V contiguous floats: element (r, lane, j) is
+// column (r*64 + lane)*V + j.  V = 4 when D % 4 == 0 and everything is 16 B aligned, else 1.
+template <int R, int V>
+struct RowRegs {
+    float v[R][V];
+};
+
+template <int R, int V>
+__device__ __forceinline__ void row_load(RowRegs<R, V>& x, const float* p, int D, int lane) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int c = (r * 64 + lane) * V;
+        if (V == 4) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < D) t = *reinterpret_cast<const float4*>(p + c);
+            x.v[r][0] = t.x; x.v[r][1 % V] = t.y; x.v[r][2 % V] = t.z; x.v[r][3 % V] = t.w;
+        } else {
+            x.v[r][0] = (c < D) ? p[c] : 0.f;
+        }
+    }
+}
+
+template <int R, int V>
+__device__ __forceinline__ void row_store(const RowRegs<R, V>& x, float* p, int D, int lane) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int c = (r * 64 + lane) * V;
+        if (c < D) {
+            if (V == 4) *reinterpret_cast<float4*>(p + c) = make_float4(x.v[r][0], x.v[r][1 % V], x.v[r][2 % V], x.v[r][3 % V]);
+            else p[c] = x.v[r][0];
+        }
+    }
+}
+
+template <int R, int V>
+__device__ __forceinline__ float row_dot(const RowRegs<R, V>& a, const RowRegs<R, V>& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < V; ++j) s += a.v[r][j] * b.v[r][j];
+    return nrx_wave_sum(s);
+}
+
+template <int R, int V>
+__global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_fwd_kernel(const float* __restrict__ x, int64_t x_ld, int64_t batch, int D, int NL,
+                                                               const float* __restrict__ w, const float* __restrict__ bvec,
+                                                               float* __restrict__ out, int64_t out_ld) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_w = reinterpret_cast<float*>(smem);          // [NL][Dp]
+    const int Dp = (D + 3) & ~3;
+    float* s_b = s_w + NL * Dp;
+    for (int i = threadIdx.x; i < NL * Dp; i += NRX_BLOCK) {
+        const int l = i / Dp, c = i - l * Dp;
+        s_w[i] = (c < D) ? w[l * (int64_t)D + c] : 0.f;
+        s_b[i] = (c < D) ? bvec[l * (int64_t)D + c] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (NRX_BLOCK / 64);
+    for (int64_t row = wave; row < batch; row += nwaves) {
+        RowRegs<R, V> x0, xl;
+        row_load<R, V>(x0, x + row * x_ld, D, lane);
+        xl = x0;
+        for (int l = 0; l < NL; ++l) {
+            RowRegs<R, V> wl, bl;
+            row_load<R, V>(wl, s_w + l * Dp, Dp, lane);
+            row_load<R, V>(bl, s_b + l * Dp, Dp, lane);
+            const float s = row_dot<R, V>(xl, wl);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int j = 0; j < V; ++j) xl.v[r][j] = x0.v[r][j] * s + bl.v[r][j] + xl.v[r][j];
+        }
+        row_store<R, V>(xl, out + row * out_ld, D, lane);
+    }
+}
+
+// Backward.  For layer l (top down): g = dL/dx_{l+1};  gs = g . x0;
+//   gb_l += g;  gw_l += gs * x_l;  gx0 += g * s_l;  g <- g + gs * w_l.      Finally gx = g + gx0.
+// x_l and s_l are recomputed from x0 (l forward steps) instead of being stored: the kernel is
+// HBM-bound and the extra FMAs are free; gw/gb accumulate in LDS per block, then one global atomic
+// per element per block.
+template <int R, int V>
+__global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_bwd_kernel(const float* __restrict__ x, int64_t x_ld, int64_t batch, int D, int NL,
+                                                               const float* __restrict__ w, const float* __restrict__ bvec,
+                                                               const float* __restrict__ g_out, int64_t g_out_ld,
+                                                               float* __restrict__ g_x, int64_t g_x_ld,
+                                                               float* __restrict__ g_w, float* __restrict__ g_b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Dp = (D + 3) & ~3;
+    float* s_w = reinterpret_cast<float*>(smem);   // [NL][Dp]
+    float* s_b = s_w + NL * Dp;
+    float* s_gw = s_b + NL * Dp;
+    float* s_gb = s_gw + NL * Dp;
+    for (int i = threadIdx.x; i < NL * Dp; i += NRX_BLOCK) {
+        const int l = i / Dp, c = i - l * Dp;
+        s_w[i] = (c < D) ? w[l * (int64_t)D + c] : 0.f;
+        s_b[i] = (c < D) ? bvec[l * (int64_t)D + c] : 0.f;
+        s_gw[i] = 0.f;
+        s_gb[i] = 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (NRX_BLOCK / 64);
+    for (int64_t row = wave; row < batch; row += nwaves) {
+        RowRegs<R, V> x0, g, gx0;
+        row_load<R, V>(x0, x + row * x_ld, D, lane);
+        row_load<R, V>(g, g_out + row * g_out_ld, D, lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < V; ++j) gx0.v[r][j] = 0.f;
+        for (int l = NL - 1; l >= 0; --l) {
+            // recompute x_l, s_l
+            RowRegs<R, V> xl = x0, wl, bl;
+            float s = 0.f;
+            for (int t = 0; t <= l; ++t) {
+                row_load<R, V>(wl, s_w + t * Dp, Dp, lane);
+                s = row_dot<R, V>(xl, wl);
+                if (t < l) {
+                    row_load<R, V>(bl, s_b + t * Dp, Dp, lane);
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int j = 0; j < V; ++j) xl.v[r][j] = x0.v[r][j] * s + bl.v[r][j] + xl.v[r][j];
+                }
+            }
+            const float gs = row_dot<R, V>(g, x0);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const int c = (r * 64 + lane) * V + j;
+                    if (c < D) {
+                        atomicAdd(&s_gb[l * Dp + c], g.v[r][j]);
+                        atomicAdd(&s_gw[l * Dp + c], gs * xl.v[r][j]);
+                    }
+                    gx0.v[r][j] += g.v[r][j] * s;
+                    g.v[r][j] += gs * wl.v[r][j];
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < V; ++j) g.v[r][j] += gx0.v[r][j];
+        row_store<R, V>(g, g_x + row * g_x_ld, D, lane);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NL * Dp; i += NRX_BLOCK) {
+        const int l = i / Dp, c = i - l * Dp;
+        if (c < D) {
+            unsafeAtomicAdd(&g_w[l * (int64_t)D + c], s_gw[i]);
+            unsafeAtomicAdd(&g_b[l * (int64_t)D + c], s_gb[i]);
+        }
+    }
+}
+
+int ceil_log2i(int x) {
+    int l = 0;
+    while ((1 << l) < x) ++l;
+    return l;
+}
+
+unsigned stream_grid(int64_t items, int per_block) {
+    int64_t g = (items + per_block - 1) / per_block;
+    const int64_t cap = 256 * 8;   // 8 blocks per CU, grid-stride the rest
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+#define NRX_QSWITCH(qlog2, ...)               \
+    switch (qlog2) {                           \
+        case 0: { constexpr int QL = 0; __VA_ARGS__; } break; \
+        case 1: { constexpr int QL = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int QL = 2; __VA_ARGS__; } break; \
+        case 3: { constexpr int QL = 3; __VA_ARGS__; } break; \
+        case 4: { constexpr int QL = 4; __VA_ARGS__; } break; \
+        case 5: { constexpr int QL = 5; __VA_ARGS__; } break; \
+        default: { constexpr int QL = 6; __VA_ARGS__; } break; \
+    }
+
+// R (chunks per lane) for the DCN row kernels
+#define NRX_RSWITCH(R_, V_, ...)                                   \
+    if (V_ == 4) {                                                  \
+        constexpr int VV = 4;                                       \
+        if (R_ <= 1) { constexpr int RR = 1; __VA_ARGS__; }                \
+        else if (R_ <= 2) { constexpr int RR = 2; __VA_ARGS__; }           \
+        else if (R_ <= 4) { constexpr int RR = 4; __VA_ARGS__; }           \
+        else { constexpr int RR = 8; __VA_ARGS__; }                        \
+    } else {                                                        \
+        constexpr int VV = 1;                                       \
+        if (R_ <= 1) { constexpr int RR = 1; __VA_ARGS__; }                \
+        else if (R_ <= 2) { constexpr int RR = 2; __VA_ARGS__; }           \
+        else if (R_ <= 4) { constexpr int RR = 4; __VA_ARGS__; }           \
+        else if (R_ <= 8) { constexpr int RR = 8; __VA_ARGS__; }           \
+        else if (R_ <= 16) { constexpr int RR = 16; __VA_ARGS__; }         \
+        else { constexpr int RR = 32; __VA_ARGS__; }                       \
+    }
+
+}  // namespace
+
+extern "C" int nrx_bag_pool_fwd(const float* emb, const float* mask, int64_t batch, int32_t bag_len,
+                                int32_t dim, float* out, void* stream) {
+    NRX_REQUIRE(emb && out && batch >= 0 && bag_len >= 1 && dim >= 1, "nrx_bag_pool_fwd: bad argument");
+    if (batch == 0) return NRX_OK;
+    hipLaunchKernelGGL(bag_pool_fwd_kernel, dim3(stream_grid(batch * dim, NRX_BLOCK)), dim3(NRX_BLOCK), 0,
+                       reinterpret_cast<hipStream_t>(stream), emb, mask, batch, bag_len, dim, out);
+    NRX_LAUNCH_CHECK("nrx_bag_pool_fwd");
+    return NRX_OK;
+}
+
+extern "C" int nrx_bag_pool_bwd(const float* g_out, const float* mask, int64_t batch, int32_t bag_len,
+                                int32_t dim, float* g_emb, void* stream) {
+    NRX_REQUIRE(g_out && g_emb && batch >= 0 && bag_len >= 1 && dim >= 1, "nrx_bag_pool_bwd: bad argument");
+    if (batch == 0) return NRX_OK;
+    hipLaunchKernelGGL(bag_pool_bwd_kernel, dim3(stream_grid(batch, 1)), dim3(NRX_BLOCK), 0,
+                       reinterpret_cast<hipStream_t>(stream), g_out, mask, batch, bag_len, dim, g_emb);
+    NRX_LAUNCH_CHECK("nrx_bag_pool_bwd");
+    return NRX_OK;
+}
+
+extern "C" int nrx_fm_fwd(const float* feat, int64_t ld, int32_t n_fields, int32_t dim, int64_t batch,
+                          float* fm_out, void* stream) {
+    NRX_REQUIRE(feat && fm_out && n_fields >= 1 && dim >= 1 && batch >= 0 && ld >= (int64_t)n_fields * dim,
+                "nrx_fm_fwd: bad argument");
+    if (batch == 0) return NRX_OK;
+    int ql = ceil_log2i((dim + 3) / 4);
+    if (ql > 6) ql = 6;
+    const bool vec = (dim & 3) == 0 && (ld & 3) == 0 && nrx_aligned16(feat);
+    const int tb = NRX_BLOCK >> ql;
+    const unsigned grid = (unsigned)((batch + tb - 1) / tb);
+    NRX_QSWITCH(ql, { hipLaunchKernelGGL((fm_fwd_kernel<QL>), dim3(grid), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
+                                         feat, ld, n_fields, dim, batch, fm_out, vec); });
+    NRX_LAUNCH_CHECK("nrx_fm_fwd");
+    return NRX_OK;
+}
+
+extern "C" int nrx_fm_bwd(const float* feat, int64_t ld, int32_t n_fields, int32_t dim, int64_t batch,
+                          const float* g_fm, float* g_feat, int64_t g_ld, int32_t accumulate, void* stream) {
+    NRX_REQUIRE(feat && g_fm && g_feat && n_fields >= 1 && dim >= 1 && batch >= 0, "nrx_fm_bwd: bad argument");
+    if (batch == 0) return NRX_OK;
+    int ql = ceil_log2i((dim + 3) / 4);
+    if (ql > 6) ql = 6;
+    const bool vec = (dim & 3) == 0 && (ld & 3) == 0 && nrx_aligned16(feat);
+    const int tb = NRX_BLOCK >> ql;
+    const unsigned grid = (unsigned)((batch + tb - 1) / tb);
+    NRX_QSWITCH(ql, { hipLaunchKernelGGL((fm_bwd_kernel<QL>), dim3(grid), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
+                                         feat, ld, n_fields, dim, batch, g_fm, g_feat, g_ld, accumulate != 0, vec); });
+    NRX_LAUNCH_CHECK("nrx_fm_bwd");
+    return NRX_OK;
+}
+
+extern "C" int nrx_dcn_v1_fwd(const float* x, int64_t x_ld, int64_t batch, int32_t dim, int32_t n_layers,
+                              const float* w, const float* b, float* out, int64_t out_ld, void* stream) {
+    NRX_REQUIRE(x && w && b && out && batch >= 0 && dim >= 1, "nrx_dcn_v1_fwd: bad argument");
+    NRX_REQUIRE(n_layers >= 0 && n_layers <= NRX_MAX_DCN_LAYERS, "nrx_dcn_v1_fwd: n_layers must be in [0, %d]", NRX_MAX_DCN_LAYERS);
+    NRX_REQUIRE(dim <= 2048, "nrx_dcn_v1_fwd: dim %d > 2048 unsupported", dim);
+    if (batch == 0) return NRX_OK;
+    const bool vec = (dim & 3) == 0 && (x_ld & 3) == 0 && (out_ld & 3) == 0 && nrx_aligned16(x) && nrx_aligned16(out);
+    const int V = vec ? 4 : 1;
+    const int R = (dim + 64 * V - 1) / (64 * V);
+    const size_t smem = (size_t)2 * n_layers * ((dim + 3) & ~3) * sizeof(float);
+    NRX_REQUIRE(smem <= 64 * 1024, "nrx_dcn_v1_fwd: n_layers*dim too large for the LDS stage");
+    const unsigned grid = stream_grid(batch, NRX_BLOCK / 64);
+    NRX_RSWITCH(R, V, { hipLaunchKernelGGL((dcn_v1_fwd_kernel<RR, VV>), dim3(grid), dim3(NRX_BLOCK), smem, reinterpret_cast<hipStream_t>(stream),
+                                           x, x_ld, batch, dim, n_layers, w, b, out, out_ld); });
+    NRX_LAUNCH_CHECK("nrx_dcn_v1_fwd");
+    return NRX_OK;
+}
+
+extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, int64_t batch, int32_t dim, int32_t n_layers,
+                              const float* w, const float* b, const float* g_out, int64_t g_out_ld,
+                              float* g_x, int64_t g_x_ld, float* g_w, float* g_b, void* stream) {
+    NRX_REQUIRE(x && w && b && g_out && g_x && g_w && g_b && batch >= 0 && dim >= 1, "nrx_dcn_v1_bwd: bad argument");
+    NRX_REQUIRE(n_layers >= 0 && n_layers <= NRX_MAX_DCN_LAYERS, "nrx_dcn_v1_bwd: n_layers must be in [0, %d]", NRX_MAX_DCN_LAYERS);
+    NRX_REQUIRE(dim <= 2048, "nrx_dcn_v1_bwd: dim %d > 2048 unsupported", dim);
+    if (batch == 0) return NRX_OK;
+    const bool vec = (dim & 3) == 0 && (x_ld & 3) == 0 && (g_out_ld & 3) == 0 && (g_x_ld & 3) == 0 &&
+                     nrx_aligned16(x) && nrx_aligned16(g_out) && nrx_aligned16(g_x);
+    const int V = vec ? 4 : 1;
+    const int R = (dim + 64 * V - 1) / (64 * V);
+    const size_t smem = (size_t)4 * n_layers * ((dim + 3) & ~3) * sizeof(float);
+    NRX_REQUIRE(smem <= 128 * 1024, "nrx_dcn_v1_bwd: n_layers*dim too large for the LDS stage");
+    const unsigned grid = stream_grid(batch, NRX_BLOCK / 64);
+    NRX_RSWITCH(R, V, {
+        auto kern = dcn_v1_bwd_kernel<RR, VV>;
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NRX_BLOCK), smem, reinterpret_cast<hipStream_t>(stream),
+                           x, x_ld, batch, dim, n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b);
+    });
+    NRX_LAUNCH_CHECK("nrx_dcn_v1_bwd");
+    return NRX_OK;
+}

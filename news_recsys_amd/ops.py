@@ -1,0 +1,523 @@
+"""torch-facing operators of the path: thin autograd wrappers over the C-ABI (include/nrx_embed.h).
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); every operator runs a
+hand-written HIP kernel from libnrx_hip.so and raises if the library is missing or a tensor is not
+on a ROCm device -- there is no eager/CPU fallback.
+
+Operator                          replaces (reference file:line)
+  embed_apply / EmbedPlan          BaseModel.get_embeddings_from_batch  BaseModel/base_model.py:284-308
+                                   (+ wide split widedeep/model.py:53-69, FM fm/model.py:18-26,48-59)
+  bag_pool                         BaseModel.array_feature_pooling      base_model.py:273-282
+  fm_interaction                   FM.get_inp_embedding + FMModel.forward (pre-sigmoid)  fm/model.py
+  dcn_v1 / dcn_v1_cat_             DCNLayer / DCNNet (+ torch.cat of dcn/model.py:29)  dcn/dcn_arch.py:14-30,63-70
+  dcn_v2                           DCNv2Layer / DCNv2Net                dcn/dcn_arch.py:33-50,73-91
+  bucketize_by_owner, gather_rows_segmented, mask_lengths   (new: row-sharded tables)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_MAX_FEATURES, NRX_SPARSE,
+                   NrxFeature, check)
+
+# ------------------------------------------------------------------------------- helpers
+_INDEX_CHECK = "sync"      # "sync": raise IndexError in the offending call (reference behaviour on CPU)
+                           # "lazy": checked at the next call / flush_index_checks(); "off": never read back
+_pending_status: List[Tuple[torch.Tensor, "torch.cuda.Event", Sequence[str]]] = []
+
+
+def set_index_check(mode: str) -> None:
+    global _INDEX_CHECK
+    if mode not in ("sync", "lazy", "off"):
+        raise ValueError("index check mode must be 'sync', 'lazy' or 'off'")
+    _INDEX_CHECK = mode
+
+
+def _raise_if_oob(status: torch.Tensor, names: Sequence[str]) -> None:
+    st = status.tolist()
+    if st[0] != 0:
+        fname = names[st[1]] if 0 <= st[1] < len(names) else f"#{st[1]}"
+        raise IndexError(f"index out of range in self: {st[0]} lookup(s); first: feature '{fname}', "
+                         f"sample {st[2]}, id {st[3]}")
+
+
+def flush_index_checks() -> None:
+    """Raise IndexError for any out-of-range id seen by earlier 'lazy' calls."""
+    while _pending_status:
+        status, ev, names = _pending_status.pop(0)
+        ev.synchronize()
+        _raise_if_oob(status, names)
+
+
+def _stream_ptr(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.NrxError(f"{what}: expected a ROCm device tensor, got device '{t.device}'. The HIP path has no CPU "
+                            "fallback (move the module and the batch to cuda).")
+    return t
+
+
+def _f32c(t: torch.Tensor, what: str) -> torch.Tensor:
+    _dev(t, what)
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------- embed plan
+@dataclass
+class Slot:
+    """One feature of a launch (host mirror of struct nrx_feature)."""
+    name: str
+    kind: int
+    table: int          # index into the plan's table list; -1 for NRX_DENSE
+    dim: int
+    bag_len: int = 0
+    out_col: int = 0
+    wide_col: int = -1
+    fm_field: int = 0
+
+
+@dataclass
+class EmbedPlan:
+    slots: List[Slot]
+    out_width: int                 # columns written in `out`
+    wide_width: int = 0
+    use_fm: bool = False
+    names: List[str] = field(default_factory=list)
+
+    def __post_init__(self):
+        self.names = [s.name for s in self.slots]
+
+
+def _fill_features(plan: EmbedPlan, lo: int, hi: int, tables: Sequence[torch.Tensor], inputs, weights,
+                   table_ptrs: Optional[Sequence[int]] = None, fm: bool = True):
+    n = hi - lo
+    arr = (NrxFeature * n)()
+    for i, s in enumerate(plan.slots[lo:hi]):
+        f = arr[i]
+        idx = inputs[lo + i]
+        f.index = idx.data_ptr()
+        f.kind = s.kind
+        f.dim = s.dim
+        f.bag_len = s.bag_len
+        f.out_col = s.out_col
+        f.wide_col = s.wide_col
+        f.fm_field = s.fm_field if fm else 0
+        f.index_bits = idx.element_size() * 8
+        if s.kind == NRX_DENSE:
+            f.table, f.rows = None, 0
+        else:
+            t = tables[s.table]
+            f.table = table_ptrs[s.table] if table_ptrs is not None else t.data_ptr()
+            f.rows = t.shape[0]
+        w = weights[lo + i]
+        f.weight = None if w is None else w.data_ptr()
+    return arr
+
+
+def _prep_inputs(plan: EmbedPlan, tables, inputs, weights):
+    if len(inputs) != len(plan.slots) or len(weights) != len(plan.slots):
+        raise ValueError("inputs / weights must have one entry per slot")
+    B = None
+    ins, ws = [], []
+    for s, x, w in zip(plan.slots, inputs, weights):
+        _dev(x, f"feature '{s.name}'")
+        if s.kind == NRX_DENSE:
+            if x.dtype not in (torch.float32, torch.float64):
+                x = x.float()
+        elif x.dtype not in (torch.int64, torch.int32):
+            x = x.long()                      # reference: feature_value.long()  (base_model.py:271)
+        x = x if x.is_contiguous() else x.contiguous()
+        if s.kind >= NRX_BAG_MASKED_MEAN:
+            if x.dim() != 2 or x.shape[1] != s.bag_len:
+                raise ValueError(f"feature '{s.name}': expected ids of shape [B, {s.bag_len}], got {tuple(x.shape)}")
+        elif x.dim() != 1:
+            raise ValueError(f"feature '{s.name}': expected a 1-D [B] tensor, got {tuple(x.shape)}")
+        if B is None:
+            B = x.shape[0]
+        elif x.shape[0] != B:
+            raise ValueError(f"feature '{s.name}': batch {x.shape[0]} != {B}")
+        if w is not None:
+            w = _f32c(w, f"mask of '{s.name}'")
+            if tuple(w.shape) != tuple(x.shape):
+                raise ValueError(f"mask of '{s.name}': shape {tuple(w.shape)} != ids {tuple(x.shape)}")
+        if s.kind == NRX_BAG_MASKED_MEAN and w is None:
+            raise ValueError(f"feature '{s.name}': masked mean needs a mask")
+        ins.append(x)
+        ws.append(w)
+    for t in tables:
+        _f32c(t, "embedding table")
+        if not t.is_contiguous():
+            raise ValueError("embedding tables must be contiguous [rows, dim] fp32")
+    return B, ins, ws
+
+
+class _EmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan: EmbedPlan, inputs, weights, out_ld, need_out, *tables):
+        lib = _lib.load()
+        B, ins, ws = _prep_inputs(plan, tables, inputs, weights)
+        dev = tables[0].device if tables else ins[0].device
+        ld = int(out_ld) if out_ld else plan.out_width
+        if ld < plan.out_width:
+            raise ValueError("out_ld smaller than the plan's out_width")
+        out = torch.empty((B, ld), dtype=torch.float32, device=dev) if need_out else None
+        wide = torch.empty((B, plan.wide_width), dtype=torch.float32, device=dev) if plan.wide_width else None
+        fm = torch.empty((B,), dtype=torch.float32, device=dev) if plan.use_fm else None
+        status = torch.zeros(4, dtype=torch.int32, device=dev) if _INDEX_CHECK != "off" else None
+        stream = _stream_ptr(ins[0])
+        n = len(plan.slots)
+        single = n <= NRX_MAX_FEATURES
+        if B > 0:
+            for lo in range(0, n, NRX_MAX_FEATURES):
+                hi = min(n, lo + NRX_MAX_FEATURES)
+                arr = _fill_features(plan, lo, hi, tables, ins, ws, fm=single)
+                check(lib.nrx_embed_fwd(arr, hi - lo, B, _ptr(out), ld, _ptr(wide), plan.wide_width,
+                                        _ptr(fm) if single else None, _ptr(status), stream), "nrx_embed_fwd")
+            if plan.use_fm and not single:
+                # > 64 FM fields: the cross-field sums cannot be split over launches; run FM on the concat
+                d0 = plan.slots[0].dim
+                check(lib.nrx_fm_fwd(out.data_ptr(), ld, n, d0, B, fm.data_ptr(), stream), "nrx_fm_fwd")
+        if status is not None:
+            if _INDEX_CHECK == "sync":
+                _raise_if_oob(status, plan.names)
+            else:
+                ev = torch.cuda.Event()
+                ev.record()
+                _pending_status.append((status, ev, plan.names))
+                while _pending_status and _pending_status[0][1].query():
+                    st, _, nm = _pending_status.pop(0)
+                    _raise_if_oob(st, nm)
+        ctx.plan, ctx.B, ctx.ld = plan, B, ld
+        ctx.ins, ctx.ws = ins, ws
+        ctx.table_meta = [(t.shape, t.device) for t in tables]
+        ctx.fm_feat = out if (plan.use_fm and need_out) else None
+        ctx.set_materialize_grads(False)
+        return out, wide, fm
+
+    @staticmethod
+    def backward(ctx, g_out, g_wide, g_fm):
+        lib = _lib.load()
+        plan, B, ld = ctx.plan, ctx.B, ctx.ld
+        n_tables = len(ctx.table_meta)
+        if g_out is None and g_wide is None and g_fm is None:
+            return (None,) * (5 + n_tables)
+        dev = ctx.table_meta[0][1]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if g_out is not None:
+            g_out = _f32c(g_out, "grad of the concat")
+        if g_fm is not None:
+            if ctx.fm_feat is None:
+                raise RuntimeError("FM backward needs the forward concat: call with need_out=True when training")
+            g_fm = _f32c(g_fm, "grad of fm_out")
+            d0 = plan.slots[0].dim
+            if g_out is None:
+                g_out = torch.empty((B, ld), dtype=torch.float32, device=dev)
+                acc = 0
+            else:
+                g_out = g_out.clone()
+                acc = 1
+            check(lib.nrx_fm_bwd(ctx.fm_feat.data_ptr(), ld, len(plan.slots), d0, B, g_fm.data_ptr(),
+                                 g_out.data_ptr(), ld, acc, stream), "nrx_fm_bwd")
+        if g_wide is not None:
+            g_wide = _f32c(g_wide, "grad of wide_x")
+        grads = [torch.zeros(shape, dtype=torch.float32, device=d) for shape, d in ctx.table_meta]
+        if B > 0 and (g_out is not None or g_wide is not None):
+            gptrs = [g.data_ptr() for g in grads]
+            n = len(plan.slots)
+            for lo in range(0, n, NRX_MAX_FEATURES):
+                hi = min(n, lo + NRX_MAX_FEATURES)
+                arr = _fill_features(plan, lo, hi, grads, ctx.ins, ctx.ws, table_ptrs=gptrs)
+                check(lib.nrx_embed_bwd(arr, hi - lo, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, stream),
+                      "nrx_embed_bwd")
+        return (None, None, None, None, None, *grads)
+
+
+def embed_apply(plan: EmbedPlan, tables: Sequence[torch.Tensor], inputs: Sequence[torch.Tensor],
+                weights: Sequence[Optional[torch.Tensor]], out_ld: Optional[int] = None, need_out: bool = True):
+    """Run the fused gather(+pool)->concat.  Returns (out[B, out_ld or out_width] | None,
+    wide[B, wide_width] | None, fm[B] | None).  Differentiable w.r.t. `tables` (dense grads)."""
+    if not need_out and not (plan.use_fm or plan.wide_width):
+        raise ValueError("need_out=False only makes sense with an FM or wide output")
+    return _EmbedFn.apply(plan, list(inputs), list(weights), out_ld, need_out, *tables)
+
+
+# ------------------------------------------------------------------------------- pooling
+class _BagPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, mask):
+        lib = _lib.load()
+        emb = _f32c(emb, "embedding")
+        if emb.dim() != 3:
+            raise ValueError("embedding must be [B, L, D]")
+        B, L, D = emb.shape
+        if mask is not None:
+            mask = _f32c(mask.float() if mask.dtype != torch.float32 else mask, "mask")
+            if tuple(mask.shape) != (B, L):
+                raise ValueError("mask must be [B, L]")
+        out = torch.empty((B, D), dtype=torch.float32, device=emb.device)
+        check(lib.nrx_bag_pool_fwd(emb.data_ptr(), _ptr(mask), B, L, D, out.data_ptr(), _stream_ptr(emb)), "nrx_bag_pool_fwd")
+        ctx.mask, ctx.shape = mask, (B, L, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        B, L, D = ctx.shape
+        g = _f32c(g, "grad")
+        gemb = torch.empty((B, L, D), dtype=torch.float32, device=g.device)
+        check(lib.nrx_bag_pool_bwd(g.data_ptr(), _ptr(ctx.mask), B, L, D, gemb.data_ptr(), _stream_ptr(g)), "nrx_bag_pool_bwd")
+        return gemb, None
+
+
+def bag_pool(embedding: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """array_feature_pooling (base_model.py:273-282) on a materialised [B, L, D] tensor."""
+    return _BagPoolFn.apply(embedding, mask)
+
+
+# ------------------------------------------------------------------------------- FM
+class _FmFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, n_fields, dim):
+        lib = _lib.load()
+        feat = _f32c(feat, "features")
+        B, W = feat.shape
+        if W != n_fields * dim:
+            raise RuntimeError(f"FM expects {n_fields} fields of equal dim {dim}; got width {W} "
+                               "(the reference's torch.stack would fail on unequal field dims)")
+        out = torch.empty((B,), dtype=torch.float32, device=feat.device)
+        check(lib.nrx_fm_fwd(feat.data_ptr(), W, n_fields, dim, B, out.data_ptr(), _stream_ptr(feat)), "nrx_fm_fwd")
+        ctx.save_for_backward(feat)
+        ctx.nf, ctx.dim = n_fields, dim
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (feat,) = ctx.saved_tensors
+        g = _f32c(g, "grad")
+        B, W = feat.shape
+        gfeat = torch.empty_like(feat)
+        check(lib.nrx_fm_bwd(feat.data_ptr(), W, ctx.nf, ctx.dim, B, g.data_ptr(), gfeat.data_ptr(), W, 0,
+                             _stream_ptr(feat)), "nrx_fm_bwd")
+        return gfeat, None, None
+
+
+def fm_interaction(features: torch.Tensor, n_fields: int, dim: int) -> torch.Tensor:
+    """[B, n_fields*dim] -> [B]: sum_f w_f + 0.5*sum_k[(sum_f v)^2 - sum_f v^2] (no bias, no sigmoid)."""
+    return _FmFn.apply(features, n_fields, dim)
+
+
+# ------------------------------------------------------------------------------- DCN v1
+def _dcn_params(w: torch.Tensor, b: torch.Tensor):
+    w = _f32c(w, "cross w")
+    b = _f32c(b, "cross b")
+    if w.dim() != 2 or w.shape != b.shape:
+        raise ValueError("cross w/b must both be [n_layers, dim]")
+    return w, b
+
+
+class _DcnV1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        w, b = _dcn_params(w, b)
+        B, D = x.shape
+        if w.shape[1] != D:
+            raise ValueError(f"cross weights are for dim {w.shape[1]}, input has dim {D}")
+        out = torch.empty_like(x)
+        check(lib.nrx_dcn_v1_fwd(x.data_ptr(), D, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), out.data_ptr(), D,
+                                 _stream_ptr(x)), "nrx_dcn_v1_fwd")
+        ctx.save_for_backward(x, w, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, w, b = ctx.saved_tensors
+        g = _f32c(g, "grad")
+        B, D = x.shape
+        gx = torch.empty_like(x)
+        gw = torch.zeros_like(w)
+        gb = torch.zeros_like(b)
+        check(lib.nrx_dcn_v1_bwd(x.data_ptr(), D, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), g.data_ptr(), D,
+                                 gx.data_ptr(), D, gw.data_ptr(), gb.data_ptr(), _stream_ptr(x)), "nrx_dcn_v1_bwd")
+        return gx, gw, gb
+
+
+def dcn_v1(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """DCNNet.forward (dcn_arch.py:63-70): all cross layers fused; w, b are [n_layers, dim]."""
+    return _DcnV1Fn.apply(x, w, b)
+
+
+class _DcnV1CatFn(torch.autograd.Function):
+    """In place: buf[:, :D] holds x (written by embed_apply with out_ld = 2D); fills buf[:, D:] with
+    cross(x), giving torch.cat([x, cross], dim=1) of dcn/model.py:29 without the extra pass."""
+
+    @staticmethod
+    def forward(ctx, buf, w, b):
+        lib = _lib.load()
+        _dev(buf, "buf")
+        w, b = _dcn_params(w, b)
+        B, W2 = buf.shape
+        D = W2 // 2
+        if not buf.is_contiguous() or W2 != 2 * D or w.shape[1] != D:
+            raise ValueError("buf must be contiguous [B, 2*dim]")
+        check(lib.nrx_dcn_v1_fwd(buf.data_ptr(), W2, B, D, w.shape[0], w.data_ptr(), b.data_ptr(),
+                                 buf.data_ptr() + 4 * D, W2, _stream_ptr(buf)), "nrx_dcn_v1_fwd")
+        ctx.mark_dirty(buf)
+        ctx.save_for_backward(buf, w, b)
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        buf, w, b = ctx.saved_tensors
+        g = _f32c(g, "grad")
+        B, W2 = buf.shape
+        D = W2 // 2
+        gbuf = torch.zeros_like(buf)          # right half of the input buffer was never read
+        gw = torch.zeros_like(w)
+        gb = torch.zeros_like(b)
+        check(lib.nrx_dcn_v1_bwd(buf.data_ptr(), W2, B, D, w.shape[0], w.data_ptr(), b.data_ptr(),
+                                 g.data_ptr() + 4 * D, W2, gbuf.data_ptr(), W2, gw.data_ptr(), gb.data_ptr(),
+                                 _stream_ptr(buf)), "nrx_dcn_v1_bwd")
+        gbuf[:, :D] += g[:, :D]
+        return gbuf, gw, gb
+
+
+def dcn_v1_cat_(buf: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return _DcnV1CatFn.apply(buf, w, b)
+
+
+# ------------------------------------------------------------------------------- DCN v2 (MFMA)
+class _DcnV2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, relu):
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        W = _f32c(W, "W")
+        b = _f32c(b, "b")
+        B, D = x.shape
+        n = W.shape[0]
+        if tuple(W.shape) != (n, D, D) or tuple(b.shape) != (n, D):
+            raise ValueError("W must be [n_layers, dim, dim] and b [n_layers, dim]")
+        xs = [x]
+        stream = _stream_ptr(x)
+        for l in range(n):
+            out = torch.empty_like(x)
+            check(lib.nrx_dcn_v2_layer_fwd(x.data_ptr(), xs[-1].data_ptr(), D, B, D, W[l].data_ptr(), b[l].data_ptr(),
+                                           1 if relu else 0, out.data_ptr(), D, stream), "nrx_dcn_v2_layer_fwd")
+            xs.append(out)
+        ctx.save_for_backward(W, b, *xs)
+        ctx.relu = relu
+        return xs[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        # Two plain GEMMs per layer (library GEMMs via torch.matmul = rocBLAS/hipBLASLt) + elementwise.
+        W, b, *xs = ctx.saved_tensors
+        x0 = xs[0]
+        n = W.shape[0]
+        g = g.contiguous()
+        gx0 = torch.zeros_like(x0)
+        gW = torch.empty_like(W)
+        gb = torch.empty_like(b)
+        for l in reversed(range(n)):
+            if ctx.relu:
+                g = g * (xs[l + 1] > 0)
+            lin = torch.addmm(b[l], xs[l], W[l].t())
+            glin = g * x0
+            gx0 += g * lin
+            gW[l] = glin.t() @ xs[l]
+            gb[l] = glin.sum(dim=0)
+            g = g + glin @ W[l]
+        return g + gx0, gW, gb, None
+
+
+def dcn_v2(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, relu: bool = True) -> torch.Tensor:
+    """DCNv2Net.forward (dcn_arch.py:83-91): x <- relu(x0 * (x W_l^T + b_l) + x) per layer, on MFMA."""
+    return _DcnV2Fn.apply(x, W, b, relu)
+
+
+# ------------------------------------------------------------------------------- integer utilities
+def bucketize_by_owner(ids: torch.Tensor, world: int):
+    """Stable bucketing of a flat id tensor by owner rank (id % world).
+    Returns (counts[world] int64, local_rows[n] int64 (= id // world in send order), slot[n] int64)."""
+    lib = _lib.load()
+    _dev(ids, "ids")
+    ids = ids.contiguous().view(-1)
+    if ids.dtype not in (torch.int64, torch.int32):
+        ids = ids.long()
+    n = ids.numel()
+    dev = ids.device
+    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    local_rows = torch.empty(n, dtype=torch.int64, device=dev)
+    slot = torch.empty(n, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(1, lib.nrx_bucketize_workspace(n, world)), dtype=torch.int64, device=dev)
+    check(lib.nrx_bucketize_by_owner(ids.data_ptr(), ids.element_size() * 8, n, world, counts.data_ptr(),
+                                     local_rows.data_ptr(), slot.data_ptr(), ws.data_ptr(), _stream_ptr(ids)),
+          "nrx_bucketize_by_owner")
+    return counts, local_rows, slot
+
+
+def gather_rows_segmented(tables: Sequence[torch.Tensor], seg_start: torch.Tensor, seg_table: torch.Tensor,
+                          local_rows: torch.Tensor, n_rows: int, check_index: bool = True) -> torch.Tensor:
+    """Owner-side gather: rows of tables[seg_table[s]] for local_rows[seg_start[s]:seg_start[s+1]]."""
+    lib = _lib.load()
+    dim = tables[0].shape[1]
+    for t in tables:
+        _f32c(t, "table")
+        if t.shape[1] != dim or not t.is_contiguous():
+            raise ValueError("segmented gather needs contiguous tables of one common dim")
+    dev = tables[0].device
+    out = torch.empty((n_rows, dim), dtype=torch.float32, device=dev)
+    if n_rows == 0:
+        return out
+    seg_start = _dev(seg_start, "seg_start").to(torch.int64).contiguous()
+    seg_table = _dev(seg_table, "seg_table").to(torch.int32).contiguous()
+    local_rows = _dev(local_rows, "local_rows").to(torch.int64).contiguous()
+    n_seg = seg_table.numel()
+    tp = (C.c_void_p * len(tables))(*[t.data_ptr() for t in tables])
+    tr = (C.c_int64 * len(tables))(*[t.shape[0] for t in tables])
+    status = torch.zeros(4, dtype=torch.int32, device=dev) if check_index else None
+    check(lib.nrx_gather_rows_segmented(tp, tr, len(tables), seg_start.data_ptr(), seg_table.data_ptr(), n_seg,
+                                        n_rows, dim, local_rows.data_ptr(), out.data_ptr(), _ptr(status),
+                                        _stream_ptr(out)), "nrx_gather_rows_segmented")
+    if status is not None:
+        st = status.tolist()
+        if st[0] != 0:
+            raise IndexError(f"index out of range in self: {st[0]} routed lookup(s); first: table #{st[1]}, "
+                             f"position {st[2]}, local row {st[3]}")
+    return out
+
+
+def mask_lengths(mask: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    mask = _f32c(mask, "mask")
+    B, L = mask.shape
+    lens = torch.empty(B, dtype=torch.int64, device=mask.device)
+    check(lib.nrx_mask_lengths(mask.data_ptr(), B, L, lens.data_ptr(), _stream_ptr(mask)), "nrx_mask_lengths")
+    return lens
+
+
+def device_info(device: int = 0):
+    lib = _lib.load()
+    info = (C.c_int64 * 6)()
+    check(lib.nrx_device_info(device, info), "nrx_device_info")
+    return {"compute_units": info[0], "wavefront": info[1], "clock_khz": info[2], "global_mem_bytes": info[3],
+            "mem_clock_khz": info[4], "mem_bus_bits": info[5]}

@@ -1,0 +1,530 @@
+"""GPU parity tests: the HIP path (through the C-ABI, via news_recsys_amd.ops) against
+ (1) golden vectors captured from the reference's own Python (tests/golden/*.npz),
+ (2) the CPU oracle (oracle/ref_np.py) on seeded random inputs at sizes the oracle finishes in seconds,
+ (3) size-independent properties at BASELINE.json's full sizes (identity tables, linearity).
+
+Bars: bit-exact for gather / concat / column routing / integer utilities; for fp32 reductions the
+tolerance is written next to each assert (the oracle and the kernels sum in different orders)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from news_recsys_amd import _lib, ops
+from news_recsys_amd._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_SPARSE)
+from oracle import ref_np as R
+from tests.conftest import CONFIGS, GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def params_of(g):
+    return {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+
+
+def batch_of(g):
+    return {k[len("batch/"):]: v for k, v in g.items() if k.startswith("batch/")}
+
+
+def tables_of(p):
+    pre = "embedding_tables."
+    return {k[len(pre):-len(".weight")]: v for k, v in p.items() if k.startswith(pre)}
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def build_plan(space, np_tables, batch, names, wide_names=(), fm=False):
+    """Test-side plan builder (the product one lives in BaseModel): sorted feature order, skip
+    features missing from the batch, exactly like base_model.py:284-308."""
+    tnames = sorted(np_tables)
+    slots, inputs, weights = [], [], []
+    col, wcol = 0, 0
+    for fname in sorted(names):
+        if fname not in batch:
+            continue
+        if fname in space.dense:
+            slots.append(ops.Slot(fname, NRX_DENSE, -1, 1, 0, col))
+            inputs.append(dev(batch[fname]))
+            weights.append(None)
+            col += 1
+            continue
+        tname = R.emb_table_name(fname, space.share)
+        t = np_tables[tname]
+        D = t.shape[1]
+        ti = tnames.index(tname)
+        if fname in space.array:
+            m = batch.get(fname + "_mask")
+            kind = NRX_BAG_MASKED_MEAN if m is not None else NRX_BAG_MEAN
+            slots.append(ops.Slot(fname, kind, ti, D, batch[fname].shape[1], col, fm_field=int(fm)))
+            weights.append(None if m is None else dev(m.astype(np.float32)))
+        else:
+            wide = fname in wide_names
+            slots.append(ops.Slot(fname, NRX_SPARSE, ti, D, 0, col, wide_col=wcol if wide else -1, fm_field=int(fm)))
+            weights.append(None)
+            if wide:
+                wcol += 1
+                col -= 1
+        inputs.append(dev(batch[fname]))
+        col += D
+    plan = ops.EmbedPlan(slots, out_width=col, wide_width=wcol, use_fm=fm)
+    tables = [dev(np_tables[n]).requires_grad_(True) for n in tnames]
+    return plan, tables, inputs, weights, tnames
+
+
+def space_of(cfg_name):
+    cfg = yaml.safe_load(open(os.path.join(CONFIGS, cfg_name)))
+    names = set(cfg["features"]["user_feature_names"]) | set(cfg["features"]["item_feature_names"])
+    return R.FeatureSpace.from_yaml_dict(cfg), names, cfg
+
+
+# ----------------------------------------------------------------------------- goldens
+@pytest.mark.parametrize("gname,cfg", [("model_deep", "cf_deep_small.yaml"), ("model_fm", "cf_fm_small.yaml"),
+                                       ("model_dcn", "cf_dcn_small.yaml"), ("model_widedeep", "cf_widedeep_small.yaml"),
+                                       ("model_lr", "cf_lr_small.yaml")])
+def test_golden_embed_concat_bit_exact(gname, cfg):
+    g = load(gname)
+    space, names, _ = space_of(cfg)
+    plan, tables, inputs, weights, _ = build_plan(space, tables_of(params_of(g)), batch_of(g), names)
+    out, _, _ = ops.embed_apply(plan, tables, inputs, weights)
+    assert np.array_equal(out.cpu().numpy(), g["out/features"])      # gather + concat: bit-exact
+
+
+def test_golden_arrays_dense_shared():
+    g = load("model_deep_array")
+    space, names, _ = space_of("cf_array_small.yaml")
+    p, b = params_of(g), batch_of(g)
+    plan, tables, inputs, weights, _ = build_plan(space, tables_of(p), b, names)
+    out = ops.embed_apply(plan, tables, inputs, weights)[0].cpu().numpy()
+    np.testing.assert_allclose(out, g["out/features"], rtol=1e-6, atol=1e-6)   # pooled: fp32 sum order
+    assert np.array_equal(out[:, :40], g["out/features"][:, :40])            # single-valued cols exact
+    assert np.all(out[1, 52:84] == 0.0)                                      # all-masked bag -> exact 0
+    b2 = dict(b)
+    b2["ctr"] = g["case2/batch/ctr"]
+    b2["user_history_mask"] = g["case2/batch/user_history_mask"]
+    del b2["user_click_cats_mask"]
+    plan, tables, inputs, weights, _ = build_plan(space, tables_of(p), b2, set(g["case2/names_in"].tolist()))
+    out2 = ops.embed_apply(plan, tables, inputs, weights)[0].cpu().numpy()
+    np.testing.assert_allclose(out2, g["case2/features"], rtol=1e-6, atol=1e-6)
+    b3 = {k: v for k, v in b.items() if k != "category"}
+    plan, tables, inputs, weights, _ = build_plan(space, tables_of(p), b3, {"user_id", "category", "item_id"})
+    assert np.array_equal(ops.embed_apply(plan, tables, inputs, weights)[0].cpu().numpy(), g["case3/features"])
+
+
+def test_golden_fm_fused_and_standalone():
+    g = load("model_fm")
+    space, names, _ = space_of("cf_fm_small.yaml")
+    plan, tables, inputs, weights, _ = build_plan(space, tables_of(params_of(g)), batch_of(g), names, fm=True)
+    out, _, fm = ops.embed_apply(plan, tables, inputs, weights)
+    bias = dev(params_of(g)["score_fc.bias"])
+    pred = torch.sigmoid(fm[:, None] + bias)
+    # sum-square identity in a different order than ATen: rtol 1e-5, atol 1e-5
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g["out/forward"], rtol=1e-5, atol=1e-5)
+    fm2 = ops.fm_interaction(out.detach(), len(plan.slots), 16)
+    np.testing.assert_allclose(fm2.cpu().numpy(), fm.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+    # training parity: loss + table grads through fused FM
+    labels = dev(g["batch/label"][:, 0])
+    loss = torch.nn.functional.binary_cross_entropy(pred.view(-1), labels)
+    np.testing.assert_allclose(loss.item(), g["out/loss"], rtol=1e-5)
+    loss.backward()
+    tn = sorted(tables_of(params_of(g)))
+    for t, name in zip(tables, tn):
+        want = g[f"grad/embedding_tables.{name}.weight"]
+        np.testing.assert_allclose(t.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-6)
+        assert np.all(t.grad[0].cpu().numpy() == 0)
+
+
+def test_golden_widedeep_split_bit_exact():
+    g = load("model_widedeep")
+    space, names, cfg = space_of("cf_widedeep_small.yaml")
+    wide = set(cfg["wide_and_deep_cfg"]["wide_feature_names"])
+    plan, tables, inputs, weights, _ = build_plan(space, tables_of(params_of(g)), batch_of(g), names, wide_names=wide)
+    deep_x, wide_x, _ = ops.embed_apply(plan, tables, inputs, weights)
+    assert np.array_equal(wide_x.cpu().numpy(), g["out/wide_x"])
+    assert np.array_equal(deep_x.cpu().numpy(), g["out/deep_x"])
+
+
+@pytest.mark.parametrize("gname,cfg", [("model_deep", "cf_deep_small.yaml"), ("model_deep_array", "cf_array_small.yaml")])
+def test_golden_deep_model_grads(gname, cfg):
+    """Whole Deep model: HIP embed path + torch MLP head (rocBLAS) vs the reference's loss and grads."""
+    g = load(gname)
+    space, names, _ = space_of(cfg)
+    p, b = params_of(g), batch_of(g)
+    plan, tables, inputs, weights, tn = build_plan(space, tables_of(p), b, names)
+    x = ops.embed_apply(plan, tables, inputs, weights)[0]
+    ws, bs = R.mlp_params(p, "score_fc.network.network")
+    h = x
+    for i, (W, bb) in enumerate(zip(ws, bs)):
+        h = torch.nn.functional.linear(h, dev(W), dev(bb))
+        if i < len(ws) - 1:
+            h = torch.relu(h)
+    pred = torch.sigmoid(h)
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g["out/forward"], rtol=1e-4, atol=1e-5)
+    loss = torch.nn.functional.binary_cross_entropy(pred.view(-1), dev(b["label"][:, 0]))
+    np.testing.assert_allclose(loss.item(), g["out/loss"], rtol=1e-4)
+    loss.backward()
+    for t, name in zip(tables, tn):
+        want = g[f"grad/embedding_tables.{name}.weight"]
+        # dense grad via float atomics: order differs from autograd's index_add -> rtol 1e-4
+        np.testing.assert_allclose(t.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-6)
+        assert np.all(t.grad[0].cpu().numpy() == 0)            # padding row never trains
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+@pytest.mark.parametrize("mtag", ["none", "bin", "w"])
+def test_golden_bag_pool(tag, mtag):
+    g = load("ops")
+    emb = dev(g[f"pool/{tag}/emb"]).requires_grad_(True)
+    mask = {"none": None, "bin": g[f"pool/{tag}/mask"], "w": g[f"pool/{tag}/wmask"]}[mtag]
+    out = ops.bag_pool(emb, None if mask is None else dev(mask))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"pool/{tag}/{mtag}/out"], rtol=1e-6, atol=1e-6)
+    (out * dev(g[f"pool/{tag}/up"])).sum().backward()
+    np.testing.assert_allclose(emb.grad.cpu().numpy(), g[f"pool/{tag}/{mtag}/gemb"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_golden_fm_op(tag):
+    g = load("ops")
+    w, v = g[f"fm/{tag}/w"], g[f"fm/{tag}/v"]
+    B, Fn, K = v.shape
+    feat = np.concatenate([w[:, :, None], v], axis=2).reshape(B, Fn * (K + 1))   # field = [w | v]
+    x = dev(feat).requires_grad_(True)
+    pred = torch.sigmoid(ops.fm_interaction(x, Fn, K + 1)[:, None] + dev(g[f"fm/{tag}/bias"]))
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g[f"fm/{tag}/out"], rtol=1e-5, atol=1e-5)
+    (pred * dev(g[f"fm/{tag}/up"])).sum().backward()
+    gx = x.grad.cpu().numpy().reshape(B, Fn, K + 1)
+    np.testing.assert_allclose(gx[:, :, 0], g[f"fm/{tag}/gw"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gx[:, :, 1:], g[f"fm/{tag}/gv"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_golden_dcn_v1(tag):
+    g = load("ops")
+    x = dev(g[f"dcn1/{tag}/x"]).requires_grad_(True)
+    w = dev(g[f"dcn1/{tag}/w"]).requires_grad_(True)
+    b = dev(g[f"dcn1/{tag}/b"]).requires_grad_(True)
+    out = ops.dcn_v1(x, w, b)
+    ref = g[f"dcn1/{tag}/out"]
+    # algebraic form vs the reference's outer-product form (SURVEY hard part 4): rtol 1e-5, atol 2e-6*max|out|
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-5, atol=2e-6 * np.abs(ref).max())
+    (out * dev(g[f"dcn1/{tag}/up"])).sum().backward()
+    for got, key in ((x.grad, "gx"), (w.grad, "gw"), (b.grad, "gb")):
+        want = g[f"dcn1/{tag}/{key}"]
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(want).max()))
+
+
+def test_dcn_v1_cat_inplace_matches_separate():
+    g = load("ops")
+    x = g["dcn1/a/x"]
+    B, D = x.shape
+    buf = torch.empty(B, 2 * D, device=DEV)
+    buf[:, :D] = dev(x)
+    w, b = dev(g["dcn1/a/w"]), dev(g["dcn1/a/b"])
+    out = ops.dcn_v1_cat_(buf, w, b)
+    sep = ops.dcn_v1(dev(x), w, b)
+    assert torch.equal(out[:, D:], sep) and torch.equal(out[:, :D], dev(x))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_golden_dcn_v2_mfma(tag):
+    g = load("ops")
+    x = dev(g[f"dcn2/{tag}/x"]).requires_grad_(True)
+    W = dev(g[f"dcn2/{tag}/W"]).requires_grad_(True)
+    b = dev(g[f"dcn2/{tag}/b"]).requires_grad_(True)
+    out = ops.dcn_v2(x, W, b)
+    ref = g[f"dcn2/{tag}/out"]
+    # fp32 GEMM, accumulation order differs from the CPU BLAS: rtol 1e-4
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(ref).max()))
+    (out * dev(g[f"dcn2/{tag}/up"])).sum().backward()
+    for got, key in ((x.grad, "gx"), (W.grad, "gW"), (b.grad, "gb")):
+        want = g[f"dcn2/{tag}/{key}"]
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-3, atol=5e-5 * max(1.0, np.abs(want).max()))
+
+
+# ----------------------------------------------------------------------------- oracle, seeded random
+def _rand_case(rng, B, specs, idx_dtype=np.int64):
+    """specs: list of (kind, rows, D, L).  Returns numpy tables / batch + FeatureSpace."""
+    sparse, dense, array = [], [], []
+    tables, batch = {}, {}
+    for i, (kind, rows, D, L) in enumerate(specs):
+        name = f"f{i:02d}"
+        if kind == NRX_DENSE:
+            dense.append(name)
+            batch[name] = rng.random(B)
+            continue
+        t = rng.standard_normal((rows, D)).astype(np.float32)
+        t[0] = 0
+        tables[name] = t
+        if kind == NRX_SPARSE:
+            sparse.append(name)
+            ids = rng.integers(0, rows, B)
+            ids[: min(B, 3)] = [rows - 1, 0, rows - 1][: min(B, 3)]
+            batch[name] = ids.astype(idx_dtype)
+        else:
+            array.append(name)
+            ids = rng.integers(1, rows, (B, L))
+            lens = rng.integers(0, L + 1, B)
+            if B > 1:
+                lens[0], lens[1] = L, 0
+            m = (np.arange(L)[None] < lens[:, None]).astype(np.float32)
+            batch[name] = (ids * m.astype(np.int64)).astype(idx_dtype)
+            if kind == NRX_BAG_MASKED_MEAN:
+                batch[name + "_mask"] = m
+    return R.FeatureSpace(sparse, dense, array), tables, batch
+
+
+UNIFORM_CASES = [(1, 5, 16), (63, 26, 16), (64, 26, 16), (1000, 26, 16), (257, 13, 16), (300, 40, 32), (129, 5, 64),
+                 (77, 8, 128), (33, 3, 256), (500, 27, 16), (100, 1, 32), (90, 14, 64), (4096, 9, 16)]
+
+
+@pytest.mark.parametrize("B,F,D", UNIFORM_CASES)
+@pytest.mark.parametrize("idx_dtype", [np.int64, np.int32])
+def test_uniform_gather_concat_bit_exact_vs_oracle(B, F, D, idx_dtype):
+    rng = np.random.default_rng(B * 1000 + F * 10 + D)
+    space, tables, batch = _rand_case(rng, B, [(NRX_SPARSE, 50 + 7 * i, D, 0) for i in range(F)], idx_dtype)
+    want, _, _ = R.embed_concat(space, tables, batch, set(tables))
+    plan, tt, inputs, weights, _ = build_plan(space, tables, batch, set(tables))
+    out = ops.embed_apply(plan, tt, inputs, weights)[0]
+    assert np.array_equal(out.cpu().numpy(), want)
+    # FM epilogue on the same inputs (fused, uniform kernel)
+    plan, tt, inputs, weights, _ = build_plan(space, tables, batch, set(tables), fm=True)
+    out, _, fm = ops.embed_apply(plan, tt, inputs, weights)
+    assert np.array_equal(out.cpu().numpy(), want)
+    w, v = R.fm_split(want, [D] * F)
+    ref = R.fm_logit(w.astype(np.float64), v.astype(np.float64), 0.0)[:, 0]
+    # fp32 accumulation over F*D terms against a float64 oracle value: rtol 1e-5, atol 1e-5*scale
+    scale = max(1.0, np.abs(ref).max())
+    np.testing.assert_allclose(fm.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * scale)
+    # FM-only inference (no concat written)
+    fm_only = ops.embed_apply(plan, tt, inputs, weights, need_out=False)[2]
+    assert torch.equal(fm_only, fm)
+
+
+GENERIC_CASES = {
+    "mixed_dims": [(NRX_SPARSE, 97, 32, 0), (NRX_SPARSE, 61, 32, 0), (NRX_SPARSE, 18, 16, 0), (NRX_SPARSE, 27, 16, 0)],
+    "odd_dims": [(NRX_SPARSE, 40, 17, 0), (NRX_SPARSE, 30, 1, 0), (NRX_SPARSE, 50, 5, 0), (NRX_SPARSE, 9, 33, 0)],
+    "lr_dim1": [(NRX_SPARSE, 40, 1, 0)] * 5,
+    "bags": [(NRX_SPARSE, 100, 16, 0), (NRX_BAG_MASKED_MEAN, 200, 16, 50), (NRX_BAG_MEAN, 30, 16, 7)],
+    "bag_long_odd": [(NRX_BAG_MASKED_MEAN, 64, 12, 333), (NRX_DENSE, 0, 1, 0), (NRX_SPARSE, 11, 8, 0)],
+    "wide_row": [(NRX_SPARSE, 20, 300, 0), (NRX_BAG_MASKED_MEAN, 20, 260, 9)],
+    "dense_only_plus_one": [(NRX_DENSE, 0, 1, 0), (NRX_DENSE, 0, 1, 0), (NRX_SPARSE, 5, 4, 0)],
+}
+
+
+@pytest.mark.parametrize("case", sorted(GENERIC_CASES))
+@pytest.mark.parametrize("B", [1, 37, 256, 1031])
+def test_generic_embed_vs_oracle(case, B):
+    rng = np.random.default_rng(sum(map(ord, case)) + B)
+    space, tables, batch = _rand_case(rng, B, GENERIC_CASES[case])
+    names = set(tables) | space.dense
+    want, dims, _, used = R.embed_concat_ex(space, tables, batch, names)
+    plan, tt, inputs, weights, _ = build_plan(space, tables, batch, names)
+    out = ops.embed_apply(plan, tt, inputs, weights)[0].cpu().numpy()
+    col = 0
+    for fname, d in zip(used, dims):
+        blk, ref = out[:, col:col + d], want[:, col:col + d]
+        if fname in space.array:
+            np.testing.assert_allclose(blk, ref, rtol=1e-6, atol=1e-6)     # pooled: fp32 sum order
+        elif fname in space.dense:
+            assert np.array_equal(blk, ref)
+        else:
+            assert np.array_equal(blk, ref)                                # copies: bit-exact
+        col += d
+
+
+def test_bag_sum_kind_and_weights():
+    rng = np.random.default_rng(5)
+    B, L, D, rows = 70, 13, 16, 40
+    t = rng.standard_normal((rows, D)).astype(np.float32)
+    ids = rng.integers(0, rows, (B, L))
+    w = rng.random((B, L)).astype(np.float32)
+    w[rng.random((B, L)) < 0.3] = 0
+    for weights in (None, w):
+        plan = ops.EmbedPlan([ops.Slot("h", NRX_BAG_SUM, 0, D, L, 0)], out_width=D)
+        out = ops.embed_apply(plan, [dev(t)], [dev(ids)], [None if weights is None else dev(weights)])[0]
+        ref = (t[ids] * (1.0 if weights is None else weights[:, :, None])).sum(axis=1)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_oob_index_raises_indexerror_like_torch_cpu():
+    t = torch.randn(10, 16, device=DEV)
+    plan = ops.EmbedPlan([ops.Slot("a", NRX_SPARSE, 0, 16)], out_width=16)
+    for bad in (10, -1, 2 ** 40):
+        with pytest.raises(IndexError):
+            ops.embed_apply(plan, [t], [torch.tensor([1, bad, 3], device=DEV)], [None])
+    plan = ops.EmbedPlan([ops.Slot("a", NRX_SPARSE, 0, 16), ops.Slot("h", NRX_BAG_MEAN, 0, 16, 4, 16)], out_width=32)
+    with pytest.raises(IndexError):     # generic kernel, bag position
+        ops.embed_apply(plan, [t], [torch.tensor([1, 2], device=DEV), torch.tensor([[1, 2, 3, 4], [1, 99, 3, 4]], device=DEV)],
+                        [None, None])
+
+
+def test_empty_batch():
+    t = torch.randn(10, 16, device=DEV)
+    plan = ops.EmbedPlan([ops.Slot("a", NRX_SPARSE, 0, 16)], out_width=16)
+    out = ops.embed_apply(plan, [t], [torch.zeros(0, dtype=torch.long, device=DEV)], [None])[0]
+    assert out.shape == (0, 16)
+
+
+def test_more_than_64_features_split_over_launches():
+    rng = np.random.default_rng(9)
+    space, tables, batch = _rand_case(rng, 150, [(NRX_SPARSE, 30 + i, 16, 0) for i in range(70)])
+    want, _, _ = R.embed_concat(space, tables, batch, set(tables))
+    plan, tt, inputs, weights, _ = build_plan(space, tables, batch, set(tables), fm=True)
+    out, _, fm = ops.embed_apply(plan, tt, inputs, weights)
+    assert np.array_equal(out.cpu().numpy(), want)
+    w, v = R.fm_split(want, [16] * 70)
+    ref = R.fm_logit(w.astype(np.float64), v.astype(np.float64), 0.0)[:, 0]
+    np.testing.assert_allclose(fm.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("case", ["mixed_dims", "odd_dims", "bags", "bag_long_odd"])
+def test_embed_backward_dense_grads_vs_oracle(case):
+    rng = np.random.default_rng(77)
+    B = 300
+    space, tables, batch = _rand_case(rng, B, GENERIC_CASES[case])
+    names = set(tables) | space.dense
+    plan, tt, inputs, weights, tn = build_plan(space, tables, batch, names)
+    out = ops.embed_apply(plan, tt, inputs, weights)[0]
+    up = rng.standard_normal(out.shape).astype(np.float32)
+    (out * dev(up)).sum().backward()
+    _, dims, _, used = R.embed_concat_ex(space, tables, batch, names)
+    col = 0
+    want = {n: np.zeros_like(tables[n]) for n in tables}
+    for fname, d in zip(used, dims):
+        u = up[:, col:col + d]
+        col += d
+        if fname in space.dense:
+            continue
+        if fname in space.array:
+            rows_up = R.array_pool_bwd(tables[fname][batch[fname]], batch.get(fname + "_mask"), u)
+            want[fname] += R.embedding_grad_dense(batch[fname], rows_up, tables[fname].shape[0])
+        else:
+            want[fname] += R.embedding_grad_dense(batch[fname], u, tables[fname].shape[0])
+    for t, name in zip(tt, tn):
+        # float atomics accumulate in arbitrary order: rtol 1e-4, atol 1e-5
+        np.testing.assert_allclose(t.grad.cpu().numpy(), want[name], rtol=1e-4, atol=1e-5)
+        assert np.all(t.grad[0].cpu().numpy() == 0)
+
+
+@pytest.mark.parametrize("B,D,NL", [(1, 4, 1), (100, 320, 2), (257, 112, 3), (65, 37, 3), (31, 1000, 8), (50, 2048, 1), (9, 6, 0)])
+def test_dcn_v1_vs_oracle(B, D, NL):
+    rng = np.random.default_rng(B + D)
+    x = rng.standard_normal((B, D)).astype(np.float32)
+    w = (rng.standard_normal((NL, D)) / np.sqrt(D)).astype(np.float32)
+    b = (rng.standard_normal((NL, D)) * 0.1).astype(np.float32)
+    xt, wt, bt = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    out = ops.dcn_v1(xt, wt, bt)
+    ref = R.dcn_v1(x, w, b)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-5, atol=2e-6 * max(1.0, np.abs(ref).max()))
+    up = rng.standard_normal((B, D)).astype(np.float32)
+    (out * dev(up)).sum().backward()
+    gx, gw, gb = R.dcn_v1_bwd(x, w, b, up)
+    for got, want in ((xt.grad, gx), (wt.grad, gw), (bt.grad, gb)):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(want).max()))
+
+
+@pytest.mark.parametrize("B,D,NL", [(1, 4, 1), (200, 320, 2), (130, 112, 3), (65, 37, 2), (1000, 64, 1), (127, 129, 1)])
+def test_dcn_v2_vs_oracle(B, D, NL):
+    rng = np.random.default_rng(B * 3 + D)
+    x = rng.standard_normal((B, D)).astype(np.float32)
+    W = (rng.standard_normal((NL, D, D)) / np.sqrt(D)).astype(np.float32)
+    # asymmetric W (transpose-detecting, guide rule 16): scale the upper triangle
+    W = W * (1.0 + np.triu(np.ones((D, D), np.float32)))[None]
+    b = (rng.standard_normal((NL, D)) * 0.1).astype(np.float32)
+    out = ops.dcn_v2(dev(x), dev(W), dev(b))
+    ref = R.dcn_v2(x, W, b)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(ref).max()))
+    out_nr = ops.dcn_v2(dev(x), dev(W[:1]), dev(b[:1]), relu=False)
+    lin = x.astype(np.float64) @ W[0].astype(np.float64).T + b[0]
+    np.testing.assert_allclose(out_nr.cpu().numpy(), x * lin + x, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(lin).max()))
+
+
+# ----------------------------------------------------------------------------- integer utilities (bit-exact)
+@pytest.mark.parametrize("n,world", [(0, 2), (1, 1), (63, 2), (2048, 8), (2049, 8), (100000, 8), (77777, 3), (5000, 64)])
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32])
+def test_bucketize_by_owner_bit_exact(n, world, dtype):
+    rng = np.random.default_rng(n + world)
+    ids = rng.integers(0, 1 << 20, n)
+    counts, local_rows, slot = ops.bucketize_by_owner(torch.from_numpy(ids).to(DEV).to(dtype), world)
+    c_ref, perm = R.bucketize_by_owner(ids, world)
+    assert np.array_equal(counts.cpu().numpy(), c_ref)
+    assert np.array_equal(local_rows.cpu().numpy(), (ids // world)[perm])     # stable send buffer
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    assert np.array_equal(slot.cpu().numpy(), inv)
+
+
+def test_gather_rows_segmented_bit_exact():
+    rng = np.random.default_rng(3)
+    D = 16
+    tabs = [rng.standard_normal((r, D)).astype(np.float32) for r in (50, 7, 300)]
+    seg_table = np.array([0, 2, 1, 0, 2], np.int32)
+    seg_len = np.array([100, 0, 33, 1, 257])
+    seg_start = np.concatenate([[0], np.cumsum(seg_len)])
+    rows = np.concatenate([rng.integers(0, tabs[t].shape[0], l) for t, l in zip(seg_table, seg_len)])
+    out = ops.gather_rows_segmented([dev(t) for t in tabs], dev(seg_start), dev(seg_table), dev(rows), int(seg_start[-1]))
+    want = np.concatenate([tabs[t][rows[s:e]] for t, s, e in zip(seg_table, seg_start[:-1], seg_start[1:])])
+    assert np.array_equal(out.cpu().numpy(), want)
+    bad = rows.copy()
+    bad[120] = 7            # table 1 has 7 rows -> out of range
+    with pytest.raises(IndexError):
+        ops.gather_rows_segmented([dev(t) for t in tabs], dev(seg_start), dev(seg_table), dev(bad), int(seg_start[-1]))
+
+
+def test_mask_lengths():
+    rng = np.random.default_rng(4)
+    m = (rng.random((1000, 50)) < 0.4).astype(np.float32)
+    off, _ = R.csr_from_mask(m)
+    assert np.array_equal(ops.mask_lengths(dev(m)).cpu().numpy(), np.diff(off))
+
+
+# ----------------------------------------------------------------------------- full-size properties
+def test_full_size_c2_identity_tables_and_linearity():
+    """BASELINE config 2 shape (26 x 1M rows x 16, B=65536): tables whose row r holds the value r in
+    every column make the expected output computable from the ids alone (bit-exact, no oracle pass)."""
+    F, rows, D, B = 26, 1_000_000, 16, 65536
+    gen = torch.Generator(device=DEV).manual_seed(20260116)
+    base = torch.arange(rows, device=DEV, dtype=torch.float32)[:, None].expand(rows, D).contiguous()
+    tables = [base + f for f in range(F)]
+    for t in tables:
+        t[0] = 0
+    ids = [torch.randint(1, rows, (B,), device=DEV, generator=gen) for _ in range(F)]
+    slots = [ops.Slot(f"C{f:02d}", NRX_SPARSE, f, D, 0, f * D, fm_field=1) for f in range(F)]
+    plan = ops.EmbedPlan(slots, out_width=F * D, use_fm=True)
+    out, _, fm = ops.embed_apply(plan, tables, ids, [None] * F)
+    want = torch.stack([ids[f].float() + f for f in range(F)], dim=1)[:, :, None].expand(B, F, D).reshape(B, F * D)
+    assert torch.equal(out, want)
+    # checksum of checksums: every row of the table is reachable and summed once per lookup
+    assert out.double().sum().item() == want.double().sum().item()
+    # FM on constant-per-field rows: closed form in float64
+    vals = torch.stack([ids[f].double() + f for f in range(F)], dim=1)          # [B, F]
+    ref = vals.sum(1) + 0.5 * (D - 1) * (vals.sum(1) ** 2 - (vals ** 2).sum(1))
+    rel = ((fm.double() - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
+    assert rel < 1e-5        # fp32 accumulation of ~1e13-sized terms
+
+
+def test_full_size_c4_history_pooling_property():
+    """Config 4 shape (history L=50, D=16, B=65536, 200k-row news table): mean-pooling rows that all
+    equal the row id gives mean(ids over valid positions); all-masked bags give exact zeros."""
+    rows, D, B, L = 200_000, 16, 65536, 50
+    gen = torch.Generator(device=DEV).manual_seed(20260120)
+    table = torch.arange(rows, device=DEV, dtype=torch.float32)[:, None].expand(rows, D).contiguous()
+    table[0] = 0
+    lens = torch.randint(0, L + 1, (B,), device=DEV, generator=gen)
+    mask = (torch.arange(L, device=DEV)[None] < lens[:, None]).float()
+    ids = torch.randint(1, rows, (B, L), device=DEV, generator=gen) * mask.long()
+    plan = ops.EmbedPlan([ops.Slot("user_history", NRX_BAG_MASKED_MEAN, 0, D, L, 0)], out_width=D)
+    out = ops.embed_apply(plan, [table], [ids], [mask])[0]
+    ref = (ids.double() * mask.double()).sum(1) / (mask.double().sum(1) + 1e-8)
+    assert torch.all(out[lens == 0] == 0)
+    rel = ((out.double() - ref[:, None]).abs() / ref[:, None].clamp_min(1.0)).max().item()
+    assert rel < 1e-6        # stated fp32 pooling tolerance
+    assert torch.equal(out[:, 0], out[:, D - 1])
