@@ -10,6 +10,12 @@ import ctypes as C
 import os
 from typing import Optional
 
+# torch must be imported BEFORE libnrx_hip.so is dlopen'ed: PyTorch-ROCm bundles its own
+# libamdhip64.so, and the process must end up with exactly one HIP runtime (torch's), which our
+# library then shares (same SONAME).  Loading ours first would pull in /opt/rocm's copy and leave
+# torch and the kernels on two different runtimes ("no ROCm-capable device is detected").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnrx_hip.so")
 

@@ -74,6 +74,12 @@ __device__ __forceinline__ float4 nrx_ldg4(const void* base, int64_t i) {
     const nrx_f32x4 t = ((const NRX_GLOBAL nrx_f32x4*)(base))[i];
     return make_float4(t.x, t.y, t.z, t.w);
 }
+// Non-temporal variant for rows of tables far larger than L2 + Infinity Cache: measured +8 % on
+// 64 B rows (26 x 1M x 16) -- the streamed rows stop displacing the output lines and id blocks.
+__device__ __forceinline__ float4 nrx_ldg4_nt(const void* base, int64_t i) {
+    const nrx_f32x4 t = __builtin_nontemporal_load(((const NRX_GLOBAL nrx_f32x4*)(base)) + i);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
 __device__ __forceinline__ void nrx_stg4(void* base, int64_t i, float4 v) {
     nrx_f32x4 t;
     t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;

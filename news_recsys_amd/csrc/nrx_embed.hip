@@ -259,7 +259,7 @@ static_assert(sizeof(UniformArgs) <= 3584, "kernarg budget");
 // One straight-line group of CNT features: CNT id loads, then CNT independent row loads, then CNT
 // stores -- no control flow, so all CNT random row reads of a lane are in flight together.
 // Out-of-range ids are clamped branch-free and reported once per lane after the feature walk.
-template <int Q, int CNT, bool IDX64, bool FM, bool STORE>
+template <int Q, int CNT, bool IDX64, bool FM, bool STORE, bool NT>
 __device__ __forceinline__ void uniform_group(const NRX_CONST UniformArgs* a, int f0, int64_t b, int q, int& bad_feat, int64_t& bad_id,
                                               float& fm_first, float4& fm_s, float4& fm_q) {
     int64_t id[CNT];
@@ -274,7 +274,7 @@ __device__ __forceinline__ void uniform_group(const NRX_CONST UniformArgs* a, in
         bad_feat = bad ? f0 + u : bad_feat;
         bad_id = bad ? id[u] : bad_id;
         id[u] = bad ? 0 : id[u];
-        v[u] = nrx_ldg4(a->table[f0 + u], id[u] * Q + q);
+        v[u] = NT ? nrx_ldg4_nt(a->table[f0 + u], id[u] * Q + q) : nrx_ldg4(a->table[f0 + u], id[u] * Q + q);
     }
 #pragma unroll
     for (int u = 0; u < CNT; ++u) {
@@ -283,20 +283,20 @@ __device__ __forceinline__ void uniform_group(const NRX_CONST UniformArgs* a, in
     }
 }
 
-template <int Q, int U, int R, bool IDX64, bool FM, bool STORE>
+template <int Q, int U, int R, bool IDX64, bool FM, bool STORE, bool NT>
 struct UniformTail {
     static __device__ __forceinline__ void run(const NRX_CONST UniformArgs* a, int f0, int rem, int64_t b, int q, int& bad_feat,
                                                int64_t& bad_id, float& fm_first, float4& fm_s, float4& fm_q) {
-        if (rem == R) uniform_group<Q, R, IDX64, FM, STORE>(a, f0, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
-        else UniformTail<Q, U, R + 1, IDX64, FM, STORE>::run(a, f0, rem, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
+        if (rem == R) uniform_group<Q, R, IDX64, FM, STORE, NT>(a, f0, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
+        else UniformTail<Q, U, R + 1, IDX64, FM, STORE, NT>::run(a, f0, rem, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
     }
 };
-template <int Q, int U, bool IDX64, bool FM, bool STORE>
-struct UniformTail<Q, U, U, IDX64, FM, STORE> {
+template <int Q, int U, bool IDX64, bool FM, bool STORE, bool NT>
+struct UniformTail<Q, U, U, IDX64, FM, STORE, NT> {
     static __device__ __forceinline__ void run(const NRX_CONST UniformArgs*, int, int, int64_t, int, int&, int64_t&, float&, float4&, float4&) {}
 };
 
-template <int QLOG2, int U, bool IDX64, bool FM, bool STORE>
+template <int QLOG2, int U, bool IDX64, bool FM, bool STORE, bool NT>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_uniform(const UniformArgs args_in_kernarg_segment) {
     const NRX_CONST UniformArgs* a = nrx_kernarg<UniformArgs>();   // == &args_in_kernarg_segment
     constexpr int Q = 1 << QLOG2;
@@ -315,9 +315,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_uniform(const UniformArgs
     int f0 = 0;
     const int n = a->n;
     for (; f0 + U <= n; f0 += U)
-        uniform_group<Q, U, IDX64, FM, STORE>(a, f0, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
+        uniform_group<Q, U, IDX64, FM, STORE, NT>(a, f0, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
     const int rem = n - f0;
-    if (rem > 0) UniformTail<Q, U, 1, IDX64, FM, STORE>::run(a, f0, rem, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
+    if (rem > 0) UniformTail<Q, U, 1, IDX64, FM, STORE, NT>::run(a, f0, rem, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
 
     if (bad_feat >= 0 && q == 0) nrx_report_oob(a->status, bad_feat, b, bad_id);
     if (FM) {
@@ -505,18 +505,18 @@ void plan_generic(int max_dim, int max_bag, int& qlog2, int& lds_chunk, size_t& 
 }
 
 // U = features in flight per lane, chosen per call to divide the feature count well.
-template <int QLOG2, int U>
+template <int QLOG2, int U, bool NT>
 void launch_uniform_u(const UniformArgs& ua, int64_t batch, bool i64, bool fm, bool store, hipStream_t st) {
     constexpr int TB = NRX_BLOCK >> QLOG2;
     const dim3 grid((unsigned)((batch + TB - 1) / TB)), block(NRX_BLOCK);
     if (i64) {
-        if (fm && store) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, true, true, true>), grid, block, 0, st, ua);
-        else if (fm) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, true, true, false>), grid, block, 0, st, ua);
-        else hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, true, false, true>), grid, block, 0, st, ua);
+        if (fm && store) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, true, true, true, NT>), grid, block, 0, st, ua);
+        else if (fm) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, true, true, false, NT>), grid, block, 0, st, ua);
+        else hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, true, false, true, NT>), grid, block, 0, st, ua);
     } else {
-        if (fm && store) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, false, true, true>), grid, block, 0, st, ua);
-        else if (fm) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, false, true, false>), grid, block, 0, st, ua);
-        else hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, false, false, true>), grid, block, 0, st, ua);
+        if (fm && store) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, false, true, true, NT>), grid, block, 0, st, ua);
+        else if (fm) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, false, true, false, NT>), grid, block, 0, st, ua);
+        else hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, false, false, true, NT>), grid, block, 0, st, ua);
     }
 }
 
@@ -525,15 +525,20 @@ void launch_uniform(const UniformArgs& ua, int64_t batch, bool i64, bool fm, boo
     // group sizes on offer: 13 and 8 (narrow rows), 8 and 5 (wide rows); pick the one that wastes
     // the fewest tail iterations, ties to the larger group.
     const int n = ua.n;
+    // non-temporal row loads once the launch's tables exceed the 256 MiB Infinity Cache
+    int64_t table_bytes = 0;
+    for (int i = 0; i < n; ++i) table_bytes += ua.rows[i] * (int64_t)(16 << QLOG2);
+    const bool nt = table_bytes > (256ll << 20);
+#define NRX_LU(U_) (nt ? launch_uniform_u<QLOG2, U_, true>(ua, batch, i64, fm, store, st) \
+                       : launch_uniform_u<QLOG2, U_, false>(ua, batch, i64, fm, store, st))
     if (QLOG2 <= 3) {
         const int w13 = (13 - n % 13) % 13, w8 = (8 - n % 8) % 8;
-        if (n >= 13 && w13 <= w8) launch_uniform_u<QLOG2, 13>(ua, batch, i64, fm, store, st);
-        else launch_uniform_u<QLOG2, 8>(ua, batch, i64, fm, store, st);
+        if (n >= 13 && w13 <= w8) NRX_LU(13); else NRX_LU(8);
     } else {
         const int w8 = (8 - n % 8) % 8, w5 = (5 - n % 5) % 5;
-        if (n >= 8 && w8 <= w5) launch_uniform_u<QLOG2, 8>(ua, batch, i64, fm, store, st);
-        else launch_uniform_u<QLOG2, 5>(ua, batch, i64, fm, store, st);
+        if (n >= 8 && w8 <= w5) NRX_LU(8); else NRX_LU(5);
     }
+#undef NRX_LU
 }
 
 }  // namespace

@@ -395,8 +395,9 @@ extern "C" int nrx_fm_bwd(const float* feat, int64_t ld, int32_t n_fields, int32
 
 extern "C" int nrx_dcn_v1_fwd(const float* x, int64_t x_ld, int64_t batch, int32_t dim, int32_t n_layers,
                               const float* w, const float* b, float* out, int64_t out_ld, void* stream) {
-    NRX_REQUIRE(x && w && b && out && batch >= 0 && dim >= 1, "nrx_dcn_v1_fwd: bad argument");
+    NRX_REQUIRE(x && out && batch >= 0 && dim >= 1, "nrx_dcn_v1_fwd: bad argument");
     NRX_REQUIRE(n_layers >= 0 && n_layers <= NRX_MAX_DCN_LAYERS, "nrx_dcn_v1_fwd: n_layers must be in [0, %d]", NRX_MAX_DCN_LAYERS);
+    NRX_REQUIRE(n_layers == 0 || (w && b), "nrx_dcn_v1_fwd: null cross weights");
     NRX_REQUIRE(dim <= 2048, "nrx_dcn_v1_fwd: dim %d > 2048 unsupported", dim);
     if (batch == 0) return NRX_OK;
     const bool vec = (dim & 3) == 0 && (x_ld & 3) == 0 && (out_ld & 3) == 0 && nrx_aligned16(x) && nrx_aligned16(out);
@@ -414,8 +415,9 @@ extern "C" int nrx_dcn_v1_fwd(const float* x, int64_t x_ld, int64_t batch, int32
 extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, int64_t batch, int32_t dim, int32_t n_layers,
                               const float* w, const float* b, const float* g_out, int64_t g_out_ld,
                               float* g_x, int64_t g_x_ld, float* g_w, float* g_b, void* stream) {
-    NRX_REQUIRE(x && w && b && g_out && g_x && g_w && g_b && batch >= 0 && dim >= 1, "nrx_dcn_v1_bwd: bad argument");
+    NRX_REQUIRE(x && g_out && g_x && batch >= 0 && dim >= 1, "nrx_dcn_v1_bwd: bad argument");
     NRX_REQUIRE(n_layers >= 0 && n_layers <= NRX_MAX_DCN_LAYERS, "nrx_dcn_v1_bwd: n_layers must be in [0, %d]", NRX_MAX_DCN_LAYERS);
+    NRX_REQUIRE(n_layers == 0 || (w && b && g_w && g_b), "nrx_dcn_v1_bwd: null cross weights");
     NRX_REQUIRE(dim <= 2048, "nrx_dcn_v1_bwd: dim %d > 2048 unsupported", dim);
     if (batch == 0) return NRX_OK;
     const bool vec = (dim & 3) == 0 && (x_ld & 3) == 0 && (g_out_ld & 3) == 0 && (g_x_ld & 3) == 0 &&

@@ -95,7 +95,7 @@ def test_golden_embed_concat_bit_exact(gname, cfg):
     space, names, _ = space_of(cfg)
     plan, tables, inputs, weights, _ = build_plan(space, tables_of(params_of(g)), batch_of(g), names)
     out, _, _ = ops.embed_apply(plan, tables, inputs, weights)
-    assert np.array_equal(out.cpu().numpy(), g["out/features"])      # gather + concat: bit-exact
+    assert np.array_equal(out.detach().cpu().numpy(), g["out/features"])      # gather + concat: bit-exact
 
 
 def test_golden_arrays_dense_shared():
@@ -103,7 +103,7 @@ def test_golden_arrays_dense_shared():
     space, names, _ = space_of("cf_array_small.yaml")
     p, b = params_of(g), batch_of(g)
     plan, tables, inputs, weights, _ = build_plan(space, tables_of(p), b, names)
-    out = ops.embed_apply(plan, tables, inputs, weights)[0].cpu().numpy()
+    out = ops.embed_apply(plan, tables, inputs, weights)[0].detach().cpu().numpy()
     np.testing.assert_allclose(out, g["out/features"], rtol=1e-6, atol=1e-6)   # pooled: fp32 sum order
     assert np.array_equal(out[:, :40], g["out/features"][:, :40])            # single-valued cols exact
     assert np.all(out[1, 52:84] == 0.0)                                      # all-masked bag -> exact 0
@@ -112,11 +112,11 @@ def test_golden_arrays_dense_shared():
     b2["user_history_mask"] = g["case2/batch/user_history_mask"]
     del b2["user_click_cats_mask"]
     plan, tables, inputs, weights, _ = build_plan(space, tables_of(p), b2, set(g["case2/names_in"].tolist()))
-    out2 = ops.embed_apply(plan, tables, inputs, weights)[0].cpu().numpy()
+    out2 = ops.embed_apply(plan, tables, inputs, weights)[0].detach().cpu().numpy()
     np.testing.assert_allclose(out2, g["case2/features"], rtol=1e-6, atol=1e-6)
     b3 = {k: v for k, v in b.items() if k != "category"}
     plan, tables, inputs, weights, _ = build_plan(space, tables_of(p), b3, {"user_id", "category", "item_id"})
-    assert np.array_equal(ops.embed_apply(plan, tables, inputs, weights)[0].cpu().numpy(), g["case3/features"])
+    assert np.array_equal(ops.embed_apply(plan, tables, inputs, weights)[0].detach().cpu().numpy(), g["case3/features"])
 
 
 def test_golden_fm_fused_and_standalone():
@@ -129,7 +129,7 @@ def test_golden_fm_fused_and_standalone():
     # sum-square identity in a different order than ATen: rtol 1e-5, atol 1e-5
     np.testing.assert_allclose(pred.detach().cpu().numpy(), g["out/forward"], rtol=1e-5, atol=1e-5)
     fm2 = ops.fm_interaction(out.detach(), len(plan.slots), 16)
-    np.testing.assert_allclose(fm2.cpu().numpy(), fm.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(fm2.detach().cpu().numpy(), fm.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
     # training parity: loss + table grads through fused FM
     labels = dev(g["batch/label"][:, 0])
     loss = torch.nn.functional.binary_cross_entropy(pred.view(-1), labels)
@@ -138,8 +138,8 @@ def test_golden_fm_fused_and_standalone():
     tn = sorted(tables_of(params_of(g)))
     for t, name in zip(tables, tn):
         want = g[f"grad/embedding_tables.{name}.weight"]
-        np.testing.assert_allclose(t.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-6)
-        assert np.all(t.grad[0].cpu().numpy() == 0)
+        np.testing.assert_allclose(t.grad.detach().cpu().numpy(), want, rtol=1e-4, atol=1e-6)
+        assert np.all(t.grad[0].detach().cpu().numpy() == 0)
 
 
 def test_golden_widedeep_split_bit_exact():
@@ -148,8 +148,8 @@ def test_golden_widedeep_split_bit_exact():
     wide = set(cfg["wide_and_deep_cfg"]["wide_feature_names"])
     plan, tables, inputs, weights, _ = build_plan(space, tables_of(params_of(g)), batch_of(g), names, wide_names=wide)
     deep_x, wide_x, _ = ops.embed_apply(plan, tables, inputs, weights)
-    assert np.array_equal(wide_x.cpu().numpy(), g["out/wide_x"])
-    assert np.array_equal(deep_x.cpu().numpy(), g["out/deep_x"])
+    assert np.array_equal(wide_x.detach().cpu().numpy(), g["out/wide_x"])
+    assert np.array_equal(deep_x.detach().cpu().numpy(), g["out/deep_x"])
 
 
 @pytest.mark.parametrize("gname,cfg", [("model_deep", "cf_deep_small.yaml"), ("model_deep_array", "cf_array_small.yaml")])
@@ -174,8 +174,8 @@ def test_golden_deep_model_grads(gname, cfg):
     for t, name in zip(tables, tn):
         want = g[f"grad/embedding_tables.{name}.weight"]
         # dense grad via float atomics: order differs from autograd's index_add -> rtol 1e-4
-        np.testing.assert_allclose(t.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-6)
-        assert np.all(t.grad[0].cpu().numpy() == 0)            # padding row never trains
+        np.testing.assert_allclose(t.grad.detach().cpu().numpy(), want, rtol=1e-4, atol=1e-6)
+        assert np.all(t.grad[0].detach().cpu().numpy() == 0)            # padding row never trains
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
@@ -187,7 +187,7 @@ def test_golden_bag_pool(tag, mtag):
     out = ops.bag_pool(emb, None if mask is None else dev(mask))
     np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"pool/{tag}/{mtag}/out"], rtol=1e-6, atol=1e-6)
     (out * dev(g[f"pool/{tag}/up"])).sum().backward()
-    np.testing.assert_allclose(emb.grad.cpu().numpy(), g[f"pool/{tag}/{mtag}/gemb"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(emb.grad.detach().cpu().numpy(), g[f"pool/{tag}/{mtag}/gemb"], rtol=1e-6, atol=1e-7)
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
@@ -200,7 +200,7 @@ def test_golden_fm_op(tag):
     pred = torch.sigmoid(ops.fm_interaction(x, Fn, K + 1)[:, None] + dev(g[f"fm/{tag}/bias"]))
     np.testing.assert_allclose(pred.detach().cpu().numpy(), g[f"fm/{tag}/out"], rtol=1e-5, atol=1e-5)
     (pred * dev(g[f"fm/{tag}/up"])).sum().backward()
-    gx = x.grad.cpu().numpy().reshape(B, Fn, K + 1)
+    gx = x.grad.detach().cpu().numpy().reshape(B, Fn, K + 1)
     np.testing.assert_allclose(gx[:, :, 0], g[f"fm/{tag}/gw"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(gx[:, :, 1:], g[f"fm/{tag}/gv"], rtol=1e-4, atol=1e-5)
 
@@ -218,7 +218,7 @@ def test_golden_dcn_v1(tag):
     (out * dev(g[f"dcn1/{tag}/up"])).sum().backward()
     for got, key in ((x.grad, "gx"), (w.grad, "gw"), (b.grad, "gb")):
         want = g[f"dcn1/{tag}/{key}"]
-        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(want).max()))
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(want).max()))
 
 
 def test_dcn_v1_cat_inplace_matches_separate():
@@ -246,7 +246,7 @@ def test_golden_dcn_v2_mfma(tag):
     (out * dev(g[f"dcn2/{tag}/up"])).sum().backward()
     for got, key in ((x.grad, "gx"), (W.grad, "gW"), (b.grad, "gb")):
         want = g[f"dcn2/{tag}/{key}"]
-        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-3, atol=5e-5 * max(1.0, np.abs(want).max()))
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=1e-3, atol=5e-5 * max(1.0, np.abs(want).max()))
 
 
 # ----------------------------------------------------------------------------- oracle, seeded random
@@ -293,16 +293,16 @@ def test_uniform_gather_concat_bit_exact_vs_oracle(B, F, D, idx_dtype):
     want, _, _ = R.embed_concat(space, tables, batch, set(tables))
     plan, tt, inputs, weights, _ = build_plan(space, tables, batch, set(tables))
     out = ops.embed_apply(plan, tt, inputs, weights)[0]
-    assert np.array_equal(out.cpu().numpy(), want)
+    assert np.array_equal(out.detach().cpu().numpy(), want)
     # FM epilogue on the same inputs (fused, uniform kernel)
     plan, tt, inputs, weights, _ = build_plan(space, tables, batch, set(tables), fm=True)
     out, _, fm = ops.embed_apply(plan, tt, inputs, weights)
-    assert np.array_equal(out.cpu().numpy(), want)
+    assert np.array_equal(out.detach().cpu().numpy(), want)
     w, v = R.fm_split(want, [D] * F)
     ref = R.fm_logit(w.astype(np.float64), v.astype(np.float64), 0.0)[:, 0]
     # fp32 accumulation over F*D terms against a float64 oracle value: rtol 1e-5, atol 1e-5*scale
     scale = max(1.0, np.abs(ref).max())
-    np.testing.assert_allclose(fm.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * scale)
+    np.testing.assert_allclose(fm.detach().cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * scale)
     # FM-only inference (no concat written)
     fm_only = ops.embed_apply(plan, tt, inputs, weights, need_out=False)[2]
     assert torch.equal(fm_only, fm)
@@ -327,7 +327,7 @@ def test_generic_embed_vs_oracle(case, B):
     names = set(tables) | space.dense
     want, dims, _, used = R.embed_concat_ex(space, tables, batch, names)
     plan, tt, inputs, weights, _ = build_plan(space, tables, batch, names)
-    out = ops.embed_apply(plan, tt, inputs, weights)[0].cpu().numpy()
+    out = ops.embed_apply(plan, tt, inputs, weights)[0].detach().cpu().numpy()
     col = 0
     for fname, d in zip(used, dims):
         blk, ref = out[:, col:col + d], want[:, col:col + d]
@@ -351,7 +351,7 @@ def test_bag_sum_kind_and_weights():
         plan = ops.EmbedPlan([ops.Slot("h", NRX_BAG_SUM, 0, D, L, 0)], out_width=D)
         out = ops.embed_apply(plan, [dev(t)], [dev(ids)], [None if weights is None else dev(weights)])[0]
         ref = (t[ids] * (1.0 if weights is None else weights[:, :, None])).sum(axis=1)
-        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
 
 
 def test_oob_index_raises_indexerror_like_torch_cpu():
@@ -379,10 +379,10 @@ def test_more_than_64_features_split_over_launches():
     want, _, _ = R.embed_concat(space, tables, batch, set(tables))
     plan, tt, inputs, weights, _ = build_plan(space, tables, batch, set(tables), fm=True)
     out, _, fm = ops.embed_apply(plan, tt, inputs, weights)
-    assert np.array_equal(out.cpu().numpy(), want)
+    assert np.array_equal(out.detach().cpu().numpy(), want)
     w, v = R.fm_split(want, [16] * 70)
     ref = R.fm_logit(w.astype(np.float64), v.astype(np.float64), 0.0)[:, 0]
-    np.testing.assert_allclose(fm.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+    np.testing.assert_allclose(fm.detach().cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
 
 
 @pytest.mark.parametrize("case", ["mixed_dims", "odd_dims", "bags", "bag_long_odd"])
@@ -410,8 +410,8 @@ def test_embed_backward_dense_grads_vs_oracle(case):
             want[fname] += R.embedding_grad_dense(batch[fname], u, tables[fname].shape[0])
     for t, name in zip(tt, tn):
         # float atomics accumulate in arbitrary order: rtol 1e-4, atol 1e-5
-        np.testing.assert_allclose(t.grad.cpu().numpy(), want[name], rtol=1e-4, atol=1e-5)
-        assert np.all(t.grad[0].cpu().numpy() == 0)
+        np.testing.assert_allclose(t.grad.detach().cpu().numpy(), want[name], rtol=1e-4, atol=1e-5)
+        assert np.all(t.grad[0].detach().cpu().numpy() == 0)
 
 
 @pytest.mark.parametrize("B,D,NL", [(1, 4, 1), (100, 320, 2), (257, 112, 3), (65, 37, 3), (31, 1000, 8), (50, 2048, 1), (9, 6, 0)])
@@ -428,7 +428,7 @@ def test_dcn_v1_vs_oracle(B, D, NL):
     (out * dev(up)).sum().backward()
     gx, gw, gb = R.dcn_v1_bwd(x, w, b, up)
     for got, want in ((xt.grad, gx), (wt.grad, gw), (bt.grad, gb)):
-        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(want).max()))
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(want).max()))
 
 
 @pytest.mark.parametrize("B,D,NL", [(1, 4, 1), (200, 320, 2), (130, 112, 3), (65, 37, 2), (1000, 64, 1), (127, 129, 1)])
@@ -441,10 +441,10 @@ def test_dcn_v2_vs_oracle(B, D, NL):
     b = (rng.standard_normal((NL, D)) * 0.1).astype(np.float32)
     out = ops.dcn_v2(dev(x), dev(W), dev(b))
     ref = R.dcn_v2(x, W, b)
-    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(ref).max()))
     out_nr = ops.dcn_v2(dev(x), dev(W[:1]), dev(b[:1]), relu=False)
     lin = x.astype(np.float64) @ W[0].astype(np.float64).T + b[0]
-    np.testing.assert_allclose(out_nr.cpu().numpy(), x * lin + x, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(lin).max()))
+    np.testing.assert_allclose(out_nr.detach().cpu().numpy(), x * lin + x, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(lin).max()))
 
 
 # ----------------------------------------------------------------------------- integer utilities (bit-exact)
@@ -455,11 +455,11 @@ def test_bucketize_by_owner_bit_exact(n, world, dtype):
     ids = rng.integers(0, 1 << 20, n)
     counts, local_rows, slot = ops.bucketize_by_owner(torch.from_numpy(ids).to(DEV).to(dtype), world)
     c_ref, perm = R.bucketize_by_owner(ids, world)
-    assert np.array_equal(counts.cpu().numpy(), c_ref)
-    assert np.array_equal(local_rows.cpu().numpy(), (ids // world)[perm])     # stable send buffer
+    assert np.array_equal(counts.detach().cpu().numpy(), c_ref)
+    assert np.array_equal(local_rows.detach().cpu().numpy(), (ids // world)[perm])     # stable send buffer
     inv = np.empty(n, np.int64)
     inv[perm] = np.arange(n)
-    assert np.array_equal(slot.cpu().numpy(), inv)
+    assert np.array_equal(slot.detach().cpu().numpy(), inv)
 
 
 def test_gather_rows_segmented_bit_exact():
@@ -472,7 +472,7 @@ def test_gather_rows_segmented_bit_exact():
     rows = np.concatenate([rng.integers(0, tabs[t].shape[0], l) for t, l in zip(seg_table, seg_len)])
     out = ops.gather_rows_segmented([dev(t) for t in tabs], dev(seg_start), dev(seg_table), dev(rows), int(seg_start[-1]))
     want = np.concatenate([tabs[t][rows[s:e]] for t, s, e in zip(seg_table, seg_start[:-1], seg_start[1:])])
-    assert np.array_equal(out.cpu().numpy(), want)
+    assert np.array_equal(out.detach().cpu().numpy(), want)
     bad = rows.copy()
     bad[120] = 7            # table 1 has 7 rows -> out of range
     with pytest.raises(IndexError):
@@ -483,7 +483,7 @@ def test_mask_lengths():
     rng = np.random.default_rng(4)
     m = (rng.random((1000, 50)) < 0.4).astype(np.float32)
     off, _ = R.csr_from_mask(m)
-    assert np.array_equal(ops.mask_lengths(dev(m)).cpu().numpy(), np.diff(off))
+    assert np.array_equal(ops.mask_lengths(dev(m)).detach().cpu().numpy(), np.diff(off))
 
 
 # ----------------------------------------------------------------------------- full-size properties
