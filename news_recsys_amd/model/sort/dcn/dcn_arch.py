@@ -1,0 +1,77 @@
+"""Cross networks.  Reference: src/model/sort/dcn/dcn_arch.py (DCNLayer :5-30, DCNv2Layer :33-50,
+DCNNet :53-70, DCNv2Net :73-91).  Parameter shapes / module nesting follow the reference so its
+checkpoints load unchanged; the arithmetic runs in the HIP kernels:
+
+  v1  x_{l+1} = (x0 x_l^T) w + b + x_l  is evaluated as  x0 * (x_l . w) + b + x_l  (no [B,D,D]
+      temporary), all layers in one launch with the row in registers;
+  v2  x_{l+1} = relu(x0 * (W x_l + b) + x_l) on the fp32 matrix cores, epilogue fused."""
+import torch
+import torch.nn as nn
+
+from .... import ops
+
+
+class DCNLayer(nn.Module):
+    def __init__(self, dim=32):
+        super().__init__()
+        self.w = nn.Parameter(torch.empty(dim, 1))
+        self.b = nn.Parameter(torch.zeros(dim, 1))
+        nn.init.xavier_uniform_(self.w)
+
+    def forward(self, x_l, x_0):
+        """Per-layer API of the reference (dcn_arch.py:14-30).  The kernel fuses whole stacks, so a lone
+        layer is only expressible when it is the first one (x_l is x_0); deeper layers go through
+        DCNNet.forward, which runs the stack in one launch."""
+        if x_l is not x_0:
+            raise NotImplementedError("call DCNNet.forward: the HIP path fuses all cross layers in one launch")
+        return ops.dcn_v1(x_0, self.w[:, 0].unsqueeze(0), self.b[:, 0].unsqueeze(0))
+
+
+class DCNv2Layer(nn.Module):
+    def __init__(self, dim=32):
+        super().__init__()
+        self.linear = nn.Linear(dim, dim, bias=True)
+
+    def forward(self, x_l, x_0):
+        """x_0 * (W x_l + b) + x_l on the matrix cores (dcn_arch.py:39-50); no ReLU (DCNv2Net adds it)."""
+        return ops.dcn_v2_layer(x_0, x_l, self.linear.weight, self.linear.bias, relu=False)
+
+
+class DCNNet(nn.Module):
+    def __init__(self, input_dim, num_layers=3):
+        super().__init__()
+        self.cross_net = nn.ModuleList([DCNLayer(input_dim) for _ in range(num_layers)])
+
+    def stacked(self):
+        w = torch.stack([l.w[:, 0] for l in self.cross_net]) if len(self.cross_net) else None
+        b = torch.stack([l.b[:, 0] for l in self.cross_net]) if len(self.cross_net) else None
+        return w, b
+
+    def forward(self, x):
+        if len(self.cross_net) == 0:
+            return x
+        w, b = self.stacked()
+        return ops.dcn_v1(x, w, b)
+
+    def forward_cat_(self, buf):
+        """buf [B, 2D] with x in the left half: fills the right half with cross(x) in place."""
+        w, b = self.stacked()
+        return ops.dcn_v1_cat_(buf, w, b)
+
+
+class DCNv2Net(nn.Module):
+    def __init__(self, input_dim, num_layers=3):
+        super().__init__()
+        layers = []
+        for _ in range(num_layers):
+            layers.append(DCNv2Layer(input_dim))
+            layers.append(nn.ReLU())
+        self.cross_net = nn.ModuleList(layers)
+
+    def forward(self, x):
+        lins = [l.linear for l in self.cross_net if isinstance(l, DCNv2Layer)]
+        if not lins:
+            return x
+        W = torch.stack([l.weight for l in lins])
+        b = torch.stack([l.bias for l in lins])
+        return ops.dcn_v2(x, W, b, relu=True)

@@ -1,0 +1,60 @@
+"""DCN ranker: sigmoid(MLP(cat[x, cross(x)])).  Reference: src/model/sort/dcn/model.py
+(DCNModel :15-29, DCN :31-76).  The reference hard-codes 3 v1 cross layers (:36); optional config
+keys `dcn_cfg.cross_num_layers` and `dcn_cfg.version` (1 = reference behaviour, 2 = DCNv2Net, which
+the reference defines but never instantiates) are accepted, defaulting to the reference.
+
+forward(batch) writes the concat straight into the left half of a [B, 2D] buffer and the cross
+output into its right half, so the reference's torch.cat([x, cross]) costs no extra pass."""
+import torch
+
+from ...BaseModel.base_model import BaseModel
+from ...model_utils.utils import MLP
+from .dcn_arch import DCNNet, DCNv2Net, DCNLayer, DCNv2Layer  # noqa: F401  (re-exported like the reference)
+
+
+class DCNModel(torch.nn.Module):
+    def __init__(self, input_dim, cross_num_layers=3, deep_hidden_dims=(32, 32, 1), version=1):
+        super().__init__()
+        self.input_dim = input_dim
+        self.version = version
+        net = DCNNet if version == 1 else DCNv2Net
+        self.cross_net = net(input_dim=input_dim, num_layers=cross_num_layers)
+        self.score_fc = MLP(dims=[input_dim * 2] + list(deep_hidden_dims))
+
+    def forward(self, x):
+        cross_f = self.cross_net(x)
+        return torch.sigmoid(self.score_fc(torch.cat([x, cross_f], dim=1)))
+
+    def forward_buf_(self, buf):
+        """buf [B, 2D], left half = x.  v1 only."""
+        return torch.sigmoid(self.score_fc(self.cross_net.forward_cat_(buf)))
+
+
+class DCN(BaseModel):
+    def __init__(self, config_path):
+        super().__init__(config_path)
+        cfg = self.config.get("dcn_cfg", {}) or {}
+        self.score_fc = DCNModel(input_dim=self.user_input_dim + self.item_input_dim,
+                                 cross_num_layers=int(cfg.get("cross_num_layers", 3)),
+                                 deep_hidden_dims=[128, 128, 128, 64, 1], version=int(cfg.get("version", 1)))
+
+    def get_inp_embedding(self, batch):
+        features, _, _ = self.get_embeddings_from_batch(batch, self.user_feature_names | self.item_feature_names)
+        return features
+
+    def forward(self, x):
+        m = self.score_fc
+        if m.version == 1 and len(m.cross_net.cross_net) > 0:
+            buf, _, _, _, _ = self._embed(x, self.user_feature_names | self.item_feature_names, out_ld=2 * m.input_dim)
+            return m.forward_buf_(buf)
+        return m(self.get_inp_embedding(x))
+
+    def training_step(self, batch, batch_idx):
+        return self._ranking_training_step(batch)
+
+    def configure_optimizers(self):
+        return self._ranking_optimizers()
+
+    @torch.no_grad()
+    def inference(self, batch):
+        return self.forward(batch)

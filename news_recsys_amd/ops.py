@@ -449,6 +449,37 @@ class _DcnV2Fn(torch.autograd.Function):
         return g + gx0, gW, gb, None
 
 
+class _DcnV2LayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, xl, W, b, relu):
+        lib = _lib.load()
+        x0, xl, W, b = _f32c(x0, "x0"), _f32c(xl, "xl"), _f32c(W, "W"), _f32c(b, "b")
+        B, D = xl.shape
+        if x0.shape != xl.shape or tuple(W.shape) != (D, D) or tuple(b.shape) != (D,):
+            raise ValueError("x0/xl must be [B, dim], W [dim, dim], b [dim]")
+        out = torch.empty_like(xl)
+        check(lib.nrx_dcn_v2_layer_fwd(x0.data_ptr(), xl.data_ptr(), D, B, D, W.data_ptr(), b.data_ptr(),
+                                       1 if relu else 0, out.data_ptr(), D, _stream_ptr(xl)), "nrx_dcn_v2_layer_fwd")
+        ctx.save_for_backward(x0, xl, W, b, out)
+        ctx.relu = relu
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, xl, W, b, out = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.relu:
+            g = g * (out > 0)
+        lin = torch.addmm(b, xl, W.t())
+        glin = g * x0
+        return g * lin, g + glin @ W, glin.t() @ xl, glin.sum(dim=0), None
+
+
+def dcn_v2_layer(x0: torch.Tensor, xl: torch.Tensor, W: torch.Tensor, b: torch.Tensor, relu: bool = False) -> torch.Tensor:
+    """One DCNv2Layer (dcn_arch.py:39-50): act(x0 * (xl W^T + b) + xl) on MFMA."""
+    return _DcnV2LayerFn.apply(x0, xl, W, b, relu)
+
+
 def dcn_v2(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, relu: bool = True) -> torch.Tensor:
     """DCNv2Net.forward (dcn_arch.py:83-91): x <- relu(x0 * (x W_l^T + b_l) + x) per layer, on MFMA."""
     return _DcnV2Fn.apply(x, W, b, relu)
