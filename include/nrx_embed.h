@@ -68,8 +68,12 @@ typedef struct nrx_feature {
     int32_t wide_col;    /* -1, or: column 0 goes to wide_out[:, wide_col] and columns 1..dim-1 to
                             out[:, out_col .. out_col+dim-2]          (widedeep/model.py:58-66)   */
     int32_t fm_field;    /* 1: field of the FM epilogue (col 0 = w, cols 1.. = v; fm/model.py:48-59) */
-    int32_t reserved;
+    int32_t flags;       /* NRX_FEAT_* bits                                                        */
 } nrx_feature_t;
+
+/* nrx_feature.flags: row 0 of `table` is an ordinary row (the "table" is a buffer of routed rows
+ * addressed by slot, sharding step 4): the backward must not treat index 0 as the padding row. */
+#define NRX_FEAT_ROW0_IS_DATA 1
 
 /* ---- library ---------------------------------------------------------------------------- */
 NRX_API int nrx_abi_version(void);
@@ -158,6 +162,13 @@ NRX_API int nrx_gather_rows_segmented(const float* const* tables, const int64_t*
                               const int64_t* seg_start, const int32_t* seg_table, int32_t n_seg,
                               int64_t n_rows, int32_t dim, const int64_t* local_rows,
                               float* out_rows, int32_t* status, void* stream);
+/* Backward of nrx_gather_rows_segmented on the owner: grad_tables[seg_table[s]][local_rows[p]] +=
+ * g_rows[p] for p in segment s (fp32 atomics).  skip_row0 != 0: local row 0 is the global padding
+ * row (true on rank 0 only) and receives no gradient (nn.Embedding(padding_idx=0), base_model.py:164). */
+NRX_API int nrx_scatter_add_rows_segmented(float* const* grad_tables, const int64_t* table_rows, int32_t n_tables,
+                                   const int64_t* seg_start, const int32_t* seg_table, int32_t n_seg,
+                                   int64_t n_rows, int32_t dim, const int64_t* local_rows,
+                                   const float* g_rows, int32_t skip_row0, void* stream);
 /* lens[b] = #(mask[b,:] != 0); used to build CSR offsets from the reference's padded masks. */
 NRX_API int nrx_mask_lengths(const float* mask, int64_t batch, int32_t bag_len, int64_t* lens, void* stream);
 

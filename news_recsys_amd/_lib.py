@@ -25,6 +25,7 @@ NRX_OK = 0
 
 # enum nrx_feature_kind
 NRX_SPARSE, NRX_DENSE, NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM = 0, 1, 2, 3, 4
+NRX_FEAT_ROW0_IS_DATA = 1
 
 
 class NrxFeature(C.Structure):
@@ -41,7 +42,7 @@ class NrxFeature(C.Structure):
         ("out_col", C.c_int32),
         ("wide_col", C.c_int32),
         ("fm_field", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 
@@ -68,6 +69,7 @@ SIGNATURES = {
     "nrx_bucketize_workspace": (_i64, [_i64, _i32]),
     "nrx_bucketize_by_owner": (C.c_int, [_p, _i32, _i64, _i32, _p, _p, _p, _p, _p]),
     "nrx_gather_rows_segmented": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, _p, _p, _i32, _i64, _i32, _p, _p, _p, _p]),
+    "nrx_scatter_add_rows_segmented": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, _p, _p, _i32, _i64, _i32, _p, _p, _i32, _p]),
     "nrx_mask_lengths": (C.c_int, [_p, _i64, _i32, _p, _p]),
 }
 

@@ -44,7 +44,7 @@ struct FeatDev {
     uint8_t kind;
     uint8_t idx64;
     uint8_t fm;
-    uint8_t pad;
+    uint8_t row0_is_data;   // NRX_FEAT_ROW0_IS_DATA
 };
 static_assert(sizeof(FeatDev) == 48, "FeatDev must stay 48 bytes");
 

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
             if (f.kind == NRX_SPARSE) {
                 if (active) {
                     const int64_t id = nrx_load_id(f.index, b, f.idx64);
-                    if (id > 0 && id < f.rows) atomic_add_row4(gtable, id, D, k0, g);
+                    if (id >= (f.row0_is_data ? 0 : 1) && id < f.rows) atomic_add_row4(gtable, id, D, k0, g);
                 }
                 continue;
             }
@@ -410,10 +410,10 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
                     const int64_t gi = (b0 + s) * (int64_t)L + l0 + l;
                     int64_t id = nrx_load_id(f.index, gi, f.idx64);
                     const float w = f.weight ? f.weight[gi] : 1.0f;
-                    if ((uint64_t)id >= (uint64_t)f.rows) id = 0;
+                    const bool oob = (uint64_t)id >= (uint64_t)f.rows;
                     BagPair p;
-                    p.id = (int32_t)id;
-                    p.w = w;
+                    p.id = oob ? 0 : (int32_t)id;
+                    p.w = oob ? 0.f : w;
                     s_bag[s * stride + l] = p;
                 }
                 __syncthreads();
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
                     const BagPair* row = s_bag + sb * stride;
                     for (int l = 0; l < cur; ++l) {
                         const BagPair p = row[l];
-                        if (p.id != 0 && p.w != 0.f)
+                        if ((p.id != 0 || f.row0_is_data) && p.w != 0.f)
                             atomic_add_row4(gtable, p.id, D, k0,
                                             make_float4(gs.x * p.w, gs.y * p.w, gs.z * p.w, gs.w * p.w));
                     }
@@ -470,7 +470,7 @@ int pack_features(const nrx_feature_t* feats, int32_t n, EmbedArgs& a, int& max_
         d.kind = (uint8_t)s.kind;
         d.idx64 = s.index_bits == 64;
         d.fm = s.fm_field != 0;
-        d.pad = 0;
+        d.row0_is_data = (s.flags & NRX_FEAT_ROW0_IS_DATA) != 0;
         if (s.dim > max_dim) max_dim = s.dim;
         if (s.kind >= NRX_BAG_MASKED_MEAN && s.bag_len > max_bag) max_bag = s.bag_len;
     }

@@ -148,6 +148,44 @@ __global__ __launch_bounds__(NRX_BLOCK) void gather_segmented_kernel(const SegAr
     }
 }
 
+struct SegGradArgs {
+    float* table[NRX_MAX_FEATURES];
+    int64_t rows[NRX_MAX_FEATURES];
+};
+
+template <int QLOG2>
+__global__ __launch_bounds__(NRX_BLOCK) void scatter_segmented_kernel(const SegGradArgs a, const int64_t* __restrict__ seg_start,
+                                                                      const int32_t* __restrict__ seg_table, int n_seg, int D,
+                                                                      const int64_t* __restrict__ local_rows,
+                                                                      const float* __restrict__ g_rows, bool skip_row0) {
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int64_t* s_start = reinterpret_cast<int64_t*>(smem);
+    for (int i = threadIdx.x; i <= n_seg; i += NRX_BLOCK) s_start[i] = seg_start[i];
+    __syncthreads();
+    const int64_t total = s_start[n_seg];
+    const int q = threadIdx.x & (Q - 1);
+    const int64_t p = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
+    if (p >= total) return;
+    int lo = 0, hi = n_seg;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_start[mid] <= p) lo = mid; else hi = mid;
+    }
+    const int t = seg_table[lo];
+    const int64_t row = local_rows[p];
+    if ((uint64_t)row >= (uint64_t)a.rows[t] || (skip_row0 && row == 0)) return;
+    for (int k0 = q * 4; k0 < D; k0 += 4 * Q) {
+        const float* src = g_rows + p * (int64_t)D + k0;
+        float* dst = a.table[t] + row * (int64_t)D + k0;
+        unsafeAtomicAdd(dst, src[0]);
+        if (k0 + 1 < D) unsafeAtomicAdd(dst + 1, src[1]);
+        if (k0 + 2 < D) unsafeAtomicAdd(dst + 2, src[2]);
+        if (k0 + 3 < D) unsafeAtomicAdd(dst + 3, src[3]);
+    }
+}
+
 __global__ __launch_bounds__(NRX_BLOCK) void mask_lengths_kernel(const float* __restrict__ mask, int64_t batch, int L, int64_t* __restrict__ lens) {
     for (int64_t b = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x; b < batch; b += (int64_t)gridDim.x * NRX_BLOCK) {
         int64_t c = 0;
@@ -222,6 +260,38 @@ extern "C" int nrx_gather_rows_segmented(const float* const* tables, const int64
 #undef NRX_CASE
     }
     NRX_LAUNCH_CHECK("nrx_gather_rows_segmented");
+    return NRX_OK;
+}
+
+extern "C" int nrx_scatter_add_rows_segmented(float* const* grad_tables, const int64_t* table_rows, int32_t n_tables,
+                                              const int64_t* seg_start, const int32_t* seg_table, int32_t n_seg,
+                                              int64_t n_rows, int32_t dim, const int64_t* local_rows,
+                                              const float* g_rows, int32_t skip_row0, void* stream) {
+    NRX_REQUIRE(grad_tables && table_rows && n_tables >= 1 && n_tables <= NRX_MAX_FEATURES,
+                "nrx_scatter_add_rows_segmented: n_tables must be in [1, %d]", NRX_MAX_FEATURES);
+    NRX_REQUIRE(seg_start && seg_table && n_seg >= 1 && n_seg <= 4096, "nrx_scatter_add_rows_segmented: n_seg must be in [1, 4096]");
+    NRX_REQUIRE(dim >= 1 && n_rows >= 0, "nrx_scatter_add_rows_segmented: bad argument");
+    if (n_rows == 0) return NRX_OK;
+    NRX_REQUIRE(local_rows && g_rows, "nrx_scatter_add_rows_segmented: null buffer");
+    SegGradArgs a;
+    for (int i = 0; i < n_tables; ++i) {
+        NRX_REQUIRE(grad_tables[i] != nullptr, "nrx_scatter_add_rows_segmented: table %d is null", i);
+        a.table[i] = grad_tables[i];
+        a.rows[i] = table_rows[i];
+    }
+    int ql = ceil_log2u((dim + 3) / 4);
+    if (ql > 6) ql = 6;
+    const int tb = NRX_BLOCK >> ql;
+    const unsigned grid = (unsigned)((n_rows + tb - 1) / tb);
+    const size_t smem = (size_t)(n_seg + 1) * sizeof(int64_t);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (ql) {
+#define NRX_CASE(QL_) case QL_: hipLaunchKernelGGL((scatter_segmented_kernel<QL_>), dim3(grid), dim3(NRX_BLOCK), smem, st, a, seg_start, seg_table, n_seg, dim, local_rows, g_rows, skip_row0 != 0); break;
+        NRX_CASE(0) NRX_CASE(1) NRX_CASE(2) NRX_CASE(3) NRX_CASE(4) NRX_CASE(5)
+        default: hipLaunchKernelGGL((scatter_segmented_kernel<6>), dim3(grid), dim3(NRX_BLOCK), smem, st, a, seg_start, seg_table, n_seg, dim, local_rows, g_rows, skip_row0 != 0); break;
+#undef NRX_CASE
+    }
+    NRX_LAUNCH_CHECK("nrx_scatter_add_rows_segmented");
     return NRX_OK;
 }
 

@@ -88,6 +88,7 @@ class Slot:
     out_col: int = 0
     wide_col: int = -1
     fm_field: int = 0
+    flags: int = 0      # NRX_FEAT_* bits
 
 
 @dataclass
@@ -116,6 +117,7 @@ def _fill_features(plan: EmbedPlan, lo: int, hi: int, tables: Sequence[torch.Ten
         f.out_col = s.out_col
         f.wide_col = s.wide_col
         f.fm_field = s.fm_field if fm else 0
+        f.flags = s.flags
         f.index_bits = idx.element_size() * 8
         if s.kind == NRX_DENSE:
             f.table, f.rows = None, 0
@@ -253,6 +255,56 @@ def embed_apply(plan: EmbedPlan, tables: Sequence[torch.Tensor], inputs: Sequenc
     if not need_out and not (plan.use_fm or plan.wide_width):
         raise ValueError("need_out=False only makes sense with an FM or wide output")
     return _EmbedFn.apply(plan, list(inputs), list(weights), out_ld, need_out, *tables)
+
+
+class PreparedEmbed:
+    """A bound, re-launchable forward call (inference / benchmarking): validation, output allocation
+    and the C descriptor arrays are done once; `run()` only enqueues the launch(es) on the current
+    stream.  The ids / masks are read from the SAME tensors every run (refill them in place, or keep
+    one PreparedEmbed per input buffer).  No autograd."""
+
+    def __init__(self, plan: EmbedPlan, tables: Sequence[torch.Tensor], inputs, weights,
+                 out_ld: Optional[int] = None, need_out: bool = True, check_index: bool = False,
+                 out: Optional[torch.Tensor] = None, fm: Optional[torch.Tensor] = None):
+        self.lib = _lib.load()
+        self.plan = plan
+        self.tables = [t.detach() for t in tables]
+        self.B, self.ins, self.ws = _prep_inputs(plan, self.tables, list(inputs), list(weights))
+        dev = self.ins[0].device
+        self.ld = int(out_ld) if out_ld else plan.out_width
+        B = self.B
+        if out is not None and (tuple(out.shape) != (B, self.ld) or out.dtype != torch.float32 or not out.is_contiguous()):
+            raise ValueError("out must be a contiguous float32 [B, out_ld] tensor")
+        self.out = out if out is not None else (torch.empty((B, self.ld), dtype=torch.float32, device=dev) if need_out else None)
+        self.wide = torch.empty((B, plan.wide_width), dtype=torch.float32, device=dev) if plan.wide_width else None
+        self.fm = fm if fm is not None else (torch.empty((B,), dtype=torch.float32, device=dev) if plan.use_fm else None)
+        self.status = torch.zeros(4, dtype=torch.int32, device=dev) if check_index else None
+        n = len(plan.slots)
+        self.single = n <= NRX_MAX_FEATURES
+        self.calls = []
+        for lo in range(0, n, NRX_MAX_FEATURES):
+            hi = min(n, lo + NRX_MAX_FEATURES)
+            self.calls.append((_fill_features(plan, lo, hi, self.tables, self.ins, self.ws, fm=self.single), hi - lo))
+        self._args = (_ptr(self.out), self.ld, _ptr(self.wide), plan.wide_width,
+                      _ptr(self.fm) if self.single else None, _ptr(self.status))
+        self.device = dev
+
+    def run(self):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        fwd = self.lib.nrx_embed_fwd
+        a = self._args
+        for arr, n in self.calls:
+            rc = fwd(arr, n, self.B, a[0], a[1], a[2], a[3], a[4], a[5], stream)
+            if rc:
+                check(rc, "nrx_embed_fwd")
+        if self.plan.use_fm and not self.single:
+            check(self.lib.nrx_fm_fwd(self.out.data_ptr(), self.ld, len(self.plan.slots), self.plan.slots[0].dim,
+                                      self.B, self.fm.data_ptr(), stream), "nrx_fm_fwd")
+        return self.out, self.wide, self.fm
+
+    def check(self):
+        if self.status is not None:
+            _raise_if_oob(self.status, self.plan.names)
 
 
 # ------------------------------------------------------------------------------- pooling
@@ -507,8 +559,10 @@ def bucketize_by_owner(ids: torch.Tensor, world: int):
 
 
 def gather_rows_segmented(tables: Sequence[torch.Tensor], seg_start: torch.Tensor, seg_table: torch.Tensor,
-                          local_rows: torch.Tensor, n_rows: int, check_index: bool = True) -> torch.Tensor:
-    """Owner-side gather: rows of tables[seg_table[s]] for local_rows[seg_start[s]:seg_start[s+1]]."""
+                          local_rows: torch.Tensor, n_rows: int, check_index: bool = True, defer_check: bool = False):
+    """Owner-side gather: rows of tables[seg_table[s]] for local_rows[seg_start[s]:seg_start[s+1]].
+    defer_check=True returns (rows, status) without reading the status back (the sharded exchange
+    checks it collectively after the return all-to-all); status is None when index checks are off."""
     lib = _lib.load()
     dim = tables[0].shape[1]
     for t in tables:
@@ -517,7 +571,11 @@ def gather_rows_segmented(tables: Sequence[torch.Tensor], seg_start: torch.Tenso
             raise ValueError("segmented gather needs contiguous tables of one common dim")
     dev = tables[0].device
     out = torch.empty((n_rows, dim), dtype=torch.float32, device=dev)
+    if defer_check:
+        check_index = _INDEX_CHECK != "off"
     if n_rows == 0:
+        if defer_check:
+            return out, (torch.zeros(4, dtype=torch.int32, device=dev) if check_index else None)
         return out
     seg_start = _dev(seg_start, "seg_start").to(torch.int64).contiguous()
     seg_table = _dev(seg_table, "seg_table").to(torch.int32).contiguous()
@@ -529,12 +587,36 @@ def gather_rows_segmented(tables: Sequence[torch.Tensor], seg_start: torch.Tenso
     check(lib.nrx_gather_rows_segmented(tp, tr, len(tables), seg_start.data_ptr(), seg_table.data_ptr(), n_seg,
                                         n_rows, dim, local_rows.data_ptr(), out.data_ptr(), _ptr(status),
                                         _stream_ptr(out)), "nrx_gather_rows_segmented")
+    if defer_check:
+        return out, status
     if status is not None:
         st = status.tolist()
         if st[0] != 0:
             raise IndexError(f"index out of range in self: {st[0]} routed lookup(s); first: table #{st[1]}, "
                              f"position {st[2]}, local row {st[3]}")
     return out
+
+
+def scatter_add_rows_segmented(grad_tables: Sequence[torch.Tensor], seg_start: torch.Tensor, seg_table: torch.Tensor,
+                               local_rows: torch.Tensor, g_rows: torch.Tensor, skip_row0: bool) -> None:
+    """Owner-side backward of gather_rows_segmented: grad_tables[seg_table[s]][local_rows[p]] += g_rows[p]."""
+    lib = _lib.load()
+    n_rows, dim = g_rows.shape
+    if n_rows == 0:
+        return
+    g_rows = _f32c(g_rows, "g_rows")
+    for t in grad_tables:
+        _f32c(t, "grad table")
+        if t.shape[1] != dim or not t.is_contiguous():
+            raise ValueError("segmented scatter needs contiguous grad tables of one common dim")
+    seg_start = _dev(seg_start, "seg_start").to(torch.int64).contiguous()
+    seg_table = _dev(seg_table, "seg_table").to(torch.int32).contiguous()
+    local_rows = _dev(local_rows, "local_rows").to(torch.int64).contiguous()
+    tp = (C.c_void_p * len(grad_tables))(*[t.data_ptr() for t in grad_tables])
+    tr = (C.c_int64 * len(grad_tables))(*[t.shape[0] for t in grad_tables])
+    check(lib.nrx_scatter_add_rows_segmented(tp, tr, len(grad_tables), seg_start.data_ptr(), seg_table.data_ptr(),
+                                             seg_table.numel(), n_rows, dim, local_rows.data_ptr(), g_rows.data_ptr(),
+                                             1 if skip_row0 else 0, _stream_ptr(g_rows)), "nrx_scatter_add_rows_segmented")
 
 
 def mask_lengths(mask: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,365 @@
+"""Row-sharded embedding tables over the GPUs of one node (new in this build; the reference is
+single-device -- every trainer is `devices=1`, e.g. src/model/sort/deep/train.py:38-44).
+
+Partitioning: data-parallel batch (every rank owns B impressions, dense params are
+replicated), tables row-wise round-robin: global row r lives on rank r % G at local row r // G.
+The padding row 0 is rank 0's local row 0.
+
+One forward, per group of features that share an embedding dim (one exchange each):
+  1. flat id list of the group (feature-major; bag features contribute B*L ids)
+  2. stable bucketing by owner (HIP, deterministic)  -> send buffer of local rows + slot[] un-permute map
+  3. per-(owner, feature) counts  -> all_to_all_single  (tells each owner how its inbox is segmented)
+  4. local rows                   -> all_to_all_single  (RCCL over xGMI; variable splits)
+  5. owner-side segmented gather from the local shards (HIP)
+  6. rows back                    -> all_to_all_single
+  7. ONE fused launch over the returned rows addressed by slot[]: bag pooling + concat
+     (+ wide split / FM epilogue) -- the same kernel as the single-GPU path, with the returned-row
+     buffer as its "table".
+Backward mirrors it: slot-scatter of the upstream grad (a permutation, so collision-free), one
+all_to_all_single back to the owners, segmented scatter-add into the local dense grads (row 0 of
+rank 0 -- the global padding row -- excluded).  Dense parameters are all-reduced by
+`allreduce_dense_grads`.
+
+The local kernels come from a backend object.  The product backend is `HipBackend` (the C-ABI);
+tests inject a CPU checker backend so that the routing + collectives can run under gloo without a
+GPU -- no CPU implementation ships in this package.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_FEAT_ROW0_IS_DATA, NRX_SPARSE)
+
+
+# --------------------------------------------------------------------------------- partition helpers
+def local_row_count(rows: int, rank: int, world: int) -> int:
+    """Number of global rows r in [0, rows) with r % world == rank."""
+    return (rows - rank + world - 1) // world if rows > rank else 0
+
+
+def shard_table(full: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Rows rank, rank+world, ... of a full [rows, D] table (scatter-on-load)."""
+    return full[rank::world].contiguous()
+
+
+def unshard_tables(shards: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Inverse of shard_table over all ranks (gather-on-save): shards[r] holds rows r::world."""
+    world = len(shards)
+    rows = sum(s.shape[0] for s in shards)
+    full = shards[0].new_empty((rows, shards[0].shape[1]))
+    for r, s in enumerate(shards):
+        full[r::world] = s
+    return full
+
+
+# --------------------------------------------------------------------------------- local backend
+class HipBackend:
+    """The product backend: every local step is a HIP kernel behind the C-ABI."""
+
+    def bucketize(self, ids: torch.Tensor, world: int):
+        return ops.bucketize_by_owner(ids, world)
+
+    def gather_segmented(self, tables, seg_start, seg_table, local_rows, n_rows):
+        """Returns (rows, status | None).  status is the device int32[4] out-of-range record; it is NOT
+        checked here: raising on one rank before the return all-to-all would strand its peers."""
+        return ops.gather_rows_segmented(tables, seg_start, seg_table, local_rows, n_rows, defer_check=True)
+
+    def scatter_add_segmented(self, grad_tables, seg_start, seg_table, local_rows, g_rows, skip_row0):
+        ops.scatter_add_rows_segmented(grad_tables, seg_start, seg_table, local_rows, g_rows, skip_row0)
+
+    def embed(self, plan, tables, inputs, weights, out_ld=None, need_out=True):
+        return ops.embed_apply(plan, tables, inputs, weights, out_ld=out_ld, need_out=need_out)
+
+
+# --------------------------------------------------------------------------------- feature description
+@dataclass
+class ShardedFeature:
+    name: str
+    kind: int            # NRX_SPARSE / NRX_DENSE / NRX_BAG_*
+    table: str           # table name ('' for dense)
+    dim: int
+    bag_len: int = 0
+    wide: bool = False
+    fm: bool = False
+
+
+@dataclass
+class _Route:
+    """What one exchange leaves behind for the backward."""
+    feats: List[int]                # indices into the feature list, in group order
+    table_names: List[str]
+    dim: int
+    n_send: int
+    send_counts: List[int]          # ids sent to each rank
+    recv_counts: List[int]          # ids received from each rank
+    seg_start: torch.Tensor         # [world*F + 1] segment starts of the inbox (src-major, feature-minor)
+    seg_table: torch.Tensor         # [world*F] table index of each segment
+    recv_rows: torch.Tensor         # [n_recv] local rows asked of this rank
+    slot: torch.Tensor              # [n_send] position of each source id in the send buffer
+    feat_off: List[int]             # start of each feature inside the flat source list
+
+
+class RowShardedEmbedding:
+    """Exchange engine for one process.  `tables` maps table name -> LOCAL shard tensor
+    [local_row_count(rows), dim] (a leaf requiring grad when training)."""
+
+    def __init__(self, rank: int, world: int, group=None, backend=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.backend = backend if backend is not None else HipBackend()
+
+    # ---- collectives (RCCL when the tensors are on GPUs: backend "nccl" is RCCL on ROCm)
+    def _a2a(self, out: torch.Tensor, inp: torch.Tensor, out_split=None, in_split=None) -> torch.Tensor:
+        if self.world == 1:
+            out.copy_(inp)
+        else:
+            dist.all_to_all_single(out, inp, out_split, in_split, group=self.group)
+        return out
+
+    def _exchange(self, feats: Sequence[ShardedFeature], idxs: List[int], inputs, tables: Dict[str, torch.Tensor]):
+        """Steps 1-6 for one dim-group.  Returns (returned rows [n_send, D], _Route)."""
+        W = self.world
+        dev = inputs[idxs[0]].device
+        flat, feat_off, off = [], [], 0
+        for i in idxs:
+            x = inputs[i].reshape(-1)
+            x = x if x.dtype == torch.int64 else x.long()
+            flat.append(x)
+            feat_off.append(off)
+            off += x.numel()
+        ids = torch.cat(flat) if len(flat) > 1 else flat[0].contiguous()
+        n_send = ids.numel()
+        F_ = len(idxs)
+        table_names: List[str] = []
+        for i in idxs:
+            if feats[i].table not in table_names:
+                table_names.append(feats[i].table)
+        D = feats[idxs[0]].dim
+
+        counts, send_rows, slot = self.backend.bucketize(ids, W)                       # step 2
+        # step 3: per-(owner, feature) counts.  feature id of every source position:
+        lens = torch.tensor([flat[k].numel() for k in range(F_)], device=dev)
+        fid = torch.repeat_interleave(torch.arange(F_, device=dev), lens)
+        owner = torch.where(ids < 0, torch.zeros_like(ids), torch.remainder(ids, W))   # same rule as the HIP bucketing
+        counts2d = torch.bincount(owner * F_ + fid, minlength=W * F_).view(W, F_)
+        recv2d = torch.empty_like(counts2d)
+        self._a2a(recv2d.view(-1), counts2d.contiguous().view(-1))                    # equal splits: F_ each
+        host = torch.stack([counts2d.sum(1), recv2d.sum(1)]).cpu()                     # the one host sync per group
+        send_counts, recv_counts = host[0].tolist(), host[1].tolist()
+        n_recv = int(sum(recv_counts))
+
+        recv_rows = torch.empty(n_recv, dtype=torch.int64, device=dev)                 # step 4
+        self._a2a(recv_rows, send_rows, recv_counts, send_counts)
+
+        seg_len = recv2d.reshape(-1)                                                   # src-major, feature-minor
+        seg_start = torch.zeros(W * F_ + 1, dtype=torch.int64, device=dev)
+        seg_start[1:] = torch.cumsum(seg_len, 0)
+        tix = torch.tensor([table_names.index(feats[i].table) for i in idxs], dtype=torch.int32, device=dev)
+        seg_table = tix.repeat(W)
+        local_tables = [tables[t] for t in table_names]
+        rows_out, status = self.backend.gather_segmented(local_tables, seg_start, seg_table, recv_rows, n_recv)   # step 5
+
+        ret = torch.empty((n_send, D), dtype=torch.float32, device=dev)                # step 6
+        self._a2a(ret.view(-1), rows_out.view(-1), [c * D for c in send_counts], [c * D for c in recv_counts])
+        if status is not None:
+            # every rank learns about an out-of-range id on ANY owner and raises together (reference:
+            # IndexError from nn.Embedding on CPU), instead of one rank leaving the collective sequence
+            bad = status[:1].to(torch.int64)
+            if W > 1:
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+            if int(bad.item()) != 0:
+                raise IndexError("index out of range in self: a routed lookup exceeded its table on some rank "
+                                 f"(this rank's record: {status.tolist()})")
+        route = _Route(list(idxs), table_names, D, n_send, send_counts, recv_counts, seg_start, seg_table,
+                       recv_rows, slot, feat_off)
+        return ret, route
+
+    def _final_plan(self, feats: Sequence[ShardedFeature], groups: List[List[int]]):
+        """Step 7 plan: tables = one returned-row buffer per dim-group; indices = slot[] segments."""
+        slots, col, wcol = [], 0, 0
+        gidx = {}
+        for g, idxs in enumerate(groups):
+            for i in idxs:
+                gidx[i] = g
+        for i, f in enumerate(feats):
+            if f.kind == NRX_DENSE:
+                slots.append(ops.Slot(f.name, NRX_DENSE, -1, 1, 0, col))
+                col += 1
+                continue
+            slots.append(ops.Slot(f.name, f.kind, gidx[i], f.dim, f.bag_len, col, wide_col=wcol if f.wide else -1,
+                                  fm_field=int(f.fm), flags=NRX_FEAT_ROW0_IS_DATA))
+            if f.wide:
+                wcol += 1
+                col += f.dim - 1
+            else:
+                col += f.dim
+        use_fm = any(f.fm for f in feats)
+        return ops.EmbedPlan(slots, out_width=col, wide_width=wcol, use_fm=use_fm)
+
+    def forward(self, feats: Sequence[ShardedFeature], inputs: Sequence[torch.Tensor],
+                weights: Sequence[Optional[torch.Tensor]], tables: Dict[str, torch.Tensor],
+                out_ld: Optional[int] = None, need_out: bool = True):
+        """Returns (out, wide, fm) like ops.embed_apply; differentiable w.r.t. the local shards."""
+        names = sorted(tables)
+        return _ShardedEmbedFn.apply(self, list(feats), list(inputs), list(weights), names, out_ld, need_out,
+                                     *[tables[n] for n in names])
+
+
+class _ShardedEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng: RowShardedEmbedding, feats, inputs, weights, names, out_ld, need_out, *shards):
+        tables = dict(zip(names, shards))
+        by_dim: Dict[int, List[int]] = {}
+        for i, f in enumerate(feats):
+            if f.kind != NRX_DENSE:
+                by_dim.setdefault(f.dim, []).append(i)
+        groups = [by_dim[d] for d in sorted(by_dim)]
+        rets, routes = [], []
+        for idxs in groups:
+            ret, route = eng._exchange(feats, idxs, inputs, tables)
+            rets.append(ret)
+            routes.append(route)
+        plan = eng._final_plan(feats, groups)
+        final_inputs = []
+        for i, f in enumerate(feats):
+            if f.kind == NRX_DENSE:
+                final_inputs.append(inputs[i])
+                continue
+            g = next(k for k, idxs in enumerate(groups) if i in idxs)
+            r = routes[g]
+            k = r.feats.index(i)
+            n = inputs[i].numel()
+            final_inputs.append(r.slot[r.feat_off[k]: r.feat_off[k] + n].view(inputs[i].shape))
+        train = any(ctx.needs_input_grad[7:])
+        with torch.set_grad_enabled(train):
+            leaves = [r.detach().requires_grad_(train) for r in rets]
+            out, wide, fm = eng.backend.embed(plan, leaves, final_inputs, list(weights), out_ld=out_ld, need_out=need_out)
+        ctx.eng, ctx.routes, ctx.leaves = eng, routes, leaves
+        ctx.outs = (out, wide, fm)
+        ctx.names, ctx.shard_meta = names, [(s.shape, s.device) for s in shards]
+        ctx.set_materialize_grads(False)
+        det = tuple(None if t is None else t.detach() for t in (out, wide, fm))
+        return det
+
+    @staticmethod
+    def backward(ctx, g_out, g_wide, g_fm):
+        eng: RowShardedEmbedding = ctx.eng
+        outs, grads_in = [], []
+        for t, g in zip(ctx.outs, (g_out, g_wide, g_fm)):
+            if t is not None and g is not None:
+                outs.append(t)
+                grads_in.append(g)
+        n_lead = 7
+        if not outs:
+            return (None,) * (n_lead + len(ctx.names))
+        g_rets = torch.autograd.grad(outs, ctx.leaves, grads_in, allow_unused=True)     # slot-scatter (HIP bwd kernel)
+        shard_grads = {n: torch.zeros(shape, dtype=torch.float32, device=dev) for n, (shape, dev) in zip(ctx.names, ctx.shard_meta)}
+        for route, leaf, g_ret in zip(ctx.routes, ctx.leaves, g_rets):
+            if g_ret is None:
+                g_ret = torch.zeros_like(leaf)
+            D = route.dim
+            n_recv = int(sum(route.recv_counts))
+            g_recv = torch.empty((n_recv, D), dtype=torch.float32, device=leaf.device)
+            eng._a2a(g_recv.view(-1), g_ret.contiguous().view(-1), [c * D for c in route.recv_counts],
+                     [c * D for c in route.send_counts])
+            eng.backend.scatter_add_segmented([shard_grads[t] for t in route.table_names], route.seg_start,
+                                              route.seg_table, route.recv_rows, g_recv, skip_row0=(eng.rank == 0))
+        return (None,) * n_lead + tuple(shard_grads[n] for n in ctx.names)
+
+
+# --------------------------------------------------------------------------------- dense params
+def allreduce_dense_grads(params, world: int, group=None) -> None:
+    """Data-parallel dense parameters (MLP / cross / FM bias): one flat bucketed all-reduce, averaged.
+    They are tiny here (<= ~0.3 MB), so a single latency-bound collective is the right shape."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if world == 1 or not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, group=group)
+    flat.div_(world)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+# --------------------------------------------------------------------------------- model integration
+def shard_model_(model, rank: int, world: int, group=None, backend=None):
+    """Convert a BaseModel in place to row-sharded tables: every `embedding_tables[name].weight` becomes
+    the local shard (rows rank::world) and `_embed` is routed through the exchange engine.  The
+    state_dict keys are unchanged; values are the local shards (use shard_table / unshard_tables to
+    convert checkpoints: scatter-on-load / gather-on-save)."""
+    import torch.nn as nn
+    eng = RowShardedEmbedding(rank, world, group, backend)
+    for name, emb in model.embedding_tables.items():
+        local = shard_table(emb.weight.data, rank, world)
+        new = nn.Embedding(max(1, local.shape[0]), local.shape[1])
+        new.weight = nn.Parameter(local if local.shape[0] else local.new_zeros((1, local.shape[1])))
+        new.global_rows = emb.num_embeddings
+        model.embedding_tables[name] = new
+    model._shard_engine = eng
+
+    def _embed_sharded(batch, feature_names, fm=False, wide_names=(), out_ld=None, need_out=True):
+        plan, table_names, dims, present = model._plan(batch, feature_names, fm, wide_names)
+        if not present:
+            return None, None, None, [], []
+        feats = []
+        for s in plan.slots:
+            tname = '' if s.kind == NRX_DENSE else table_names[s.table]
+            feats.append(ShardedFeature(s.name, s.kind, tname, s.dim, s.bag_len, s.wide_col >= 0, bool(s.fm_field)))
+        inputs = [batch[s.name] for s in plan.slots]
+        weights = [batch.get(f"{s.name}_mask") if s.kind == NRX_BAG_MASKED_MEAN else None for s in plan.slots]
+        tables = {t: model.embedding_tables[t].weight for t in table_names}
+        out, wide, fmv = eng.forward(feats, inputs, weights, tables, out_ld=out_ld, need_out=need_out)
+        return out, wide, fmv, list(dims), list(present)
+
+    model._embed = _embed_sharded
+    return model
+
+
+# --------------------------------------------------------------------------------- bench path (N > 1)
+class ShardedBenchPath:
+    """bench.py's N>1 workload: the same synthetic configuration as the single-GPU path, tables
+    row-sharded over `world` ranks, B impressions per rank (weak scaling)."""
+
+    def __init__(self, wl: str, device, seed: int, rank: int, world: int, batch: int, mode: str = "row", n_pool: int = 8):
+        import bench
+        feats, self.desc = bench.workload_spec(wl)
+        self.rank, self.world, self.batch = rank, world, batch
+        self.eng = RowShardedEmbedding(rank, world)
+        gen = torch.Generator(device=device).manual_seed(seed)
+        self.tables: Dict[str, torch.Tensor] = {}
+        self.feats: List[ShardedFeature] = []
+        self.fm = wl == "c2"
+        for f in sorted(feats, key=lambda f: f["name"]):
+            tname = f.get("share", f["name"])
+            if tname not in self.tables:
+                t = torch.empty((local_row_count(f["rows"], rank, world), f["dim"]), dtype=torch.float32, device=device)
+                t.normal_(generator=gen)
+                if rank == 0:
+                    t[0].zero_()
+                self.tables[tname] = t
+            kind = NRX_BAG_MASKED_MEAN if f["bag"] else NRX_SPARSE
+            self.feats.append(ShardedFeature(f["name"], kind, tname, f["dim"], f["bag"], False, self.fm))
+        self.rows = {f["name"]: f["rows"] for f in feats}
+        self.pool = []
+        for _ in range(n_pool):
+            ins, ws = [], []
+            for f in self.feats:
+                shape = (batch, f.bag_len) if f.bag_len else (batch,)
+                ins.append(torch.randint(1, self.rows[f.name], shape, device=device, generator=gen))
+                ws.append(torch.ones(shape, dtype=torch.float32, device=device) if f.bag_len else None)
+            self.pool.append((ins, ws))
+        self.bytes_per_impr = bench.algorithmic_bytes_per_impression(
+            [dict(dim=f.dim, bag=f.bag_len) for f in self.feats], self.fm, 0)
+        self.desc += f" -- tables row-sharded over {world} GPUs (mode={mode})"
+
+    @torch.no_grad()
+    def step(self, i: int):
+        ins, ws = self.pool[i % len(self.pool)]
+        return self.eng.forward(self.feats, ins, ws, self.tables)

@@ -1,0 +1,83 @@
+"""Test-only CPU backend for news_recsys_amd.sharding.RowShardedEmbedding.
+
+It stands in for the HIP kernels (bucketing, owner-side gather / scatter-add, the final fused embed)
+with numpy / torch-CPU restatements built on the oracle, so that the routing logic and the
+all-to-all sequence can be exercised with gloo on machines without a GPU.  Lives under tests/ on
+purpose: the product package has no CPU path."""
+import numpy as np
+import torch
+
+from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_SPARSE
+from oracle import ref_np as R
+
+
+class CheckerBackend:
+    def bucketize(self, ids, world):
+        a = ids.cpu().numpy()
+        counts, perm = R.bucketize_by_owner(np.where(a < 0, 0, a), world)
+        inv = np.empty(a.size, np.int64)
+        inv[perm] = np.arange(a.size)
+        return torch.from_numpy(counts), torch.from_numpy((a // world)[perm]), torch.from_numpy(inv)
+
+    def gather_segmented(self, tables, seg_start, seg_table, local_rows, n_rows):
+        D = tables[0].shape[1]
+        out = torch.empty((n_rows, D), dtype=torch.float32)
+        ss, st = seg_start.tolist(), seg_table.tolist()
+        for s, t in enumerate(st):
+            lo, hi = ss[s], ss[s + 1]
+            if hi > lo:
+                out[lo:hi] = torch.from_numpy(R.gather_rows(tables[t].detach().numpy(), local_rows[lo:hi].numpy()))
+        return out, None
+
+    def scatter_add_segmented(self, grad_tables, seg_start, seg_table, local_rows, g_rows, skip_row0):
+        ss, st = seg_start.tolist(), seg_table.tolist()
+        for s, t in enumerate(st):
+            lo, hi = ss[s], ss[s + 1]
+            if hi > lo:
+                g = grad_tables[t].numpy()
+                rows = local_rows[lo:hi].numpy()
+                vals = g_rows[lo:hi].numpy()
+                if skip_row0:
+                    keep = rows != 0
+                    rows, vals = rows[keep], vals[keep]
+                np.add.at(g, rows, vals)
+
+    def embed(self, plan, tables, inputs, weights, out_ld=None, need_out=True):
+        """torch-CPU restatement of the fused launch (differentiable w.r.t. `tables`)."""
+        B = inputs[0].shape[0]
+        ld = out_ld or plan.out_width
+        out = torch.zeros((B, ld), dtype=torch.float32)
+        wide = torch.zeros((B, plan.wide_width), dtype=torch.float32) if plan.wide_width else None
+        pieces, fields = [], []
+        for s, x, w in zip(plan.slots, inputs, weights):
+            if s.kind == NRX_DENSE:
+                v = x.float().unsqueeze(1)
+            else:
+                e = tables[s.table][x.long()]
+                if s.kind == NRX_SPARSE:
+                    v = e
+                elif s.kind == NRX_BAG_MEAN:
+                    v = e.mean(dim=1)
+                elif s.kind == NRX_BAG_MASKED_MEAN:
+                    v = (e * w.unsqueeze(-1)).sum(1) / (w.sum(1, keepdim=True) + 1e-8)
+                else:
+                    v = (e * (w.unsqueeze(-1) if w is not None else 1.0)).sum(1)
+            if s.fm_field:
+                fields.append(v)
+            pieces.append((s, v))
+        cols = []
+        for s, v in pieces:
+            if s.wide_col >= 0:
+                cols.append((s.out_col, v[:, 1:]))
+            else:
+                cols.append((s.out_col, v))
+        out = torch.cat([v for _, v in sorted(cols, key=lambda t: t[0])] +
+                        ([torch.zeros((B, ld - plan.out_width))] if ld > plan.out_width else []), dim=1)
+        if wide is not None:
+            wide = torch.cat([v[:, :1] for s, v in sorted(pieces, key=lambda t: t[0].wide_col) if s.wide_col >= 0], dim=1)
+        fm = None
+        if plan.use_fm:
+            f3 = torch.stack(fields, dim=1)
+            wv, vv = f3[:, :, 0], f3[:, :, 1:]
+            fm = wv.sum(1) + 0.5 * ((vv.sum(1) ** 2) - (vv ** 2).sum(1)).sum(1)
+        return (out if need_out else None), wide, fm

@@ -1,0 +1,113 @@
+"""GPU tests of the row-sharded engine with the product (HIP) backend in a single process (world=1:
+the routing, owner-side segmented gather / scatter-add and the slot-addressed final launch all run;
+the all-to-alls degenerate to copies).  Multi-rank behaviour is covered by tests/test_sharding_gloo.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from news_recsys_amd import ops, sharding
+from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_DENSE, NRX_SPARSE
+from news_recsys_amd.model.sort.deep.model import Deep
+from news_recsys_amd.model.sort.fm.model import FM
+from news_recsys_amd.sharding import RowShardedEmbedding, ShardedFeature
+from tests.conftest import CONFIGS, GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _case(B=777, fm=False):
+    g = torch.Generator(device=DEV).manual_seed(5)
+    rows = {"a": 1000, "b": 77, "c": 5000}
+    dims = {"a": 16, "b": 16, "c": 32}
+    tables = {n: torch.randn(rows[n], dims[n], device=DEV, generator=g) for n in rows}
+    for t in tables.values():
+        t[0] = 0
+    feats = [ShardedFeature("f_a", NRX_SPARSE, "a", 16, fm=fm), ShardedFeature("f_b", NRX_SPARSE, "b", 16, fm=fm),
+             ShardedFeature("f_hist", NRX_BAG_MASKED_MEAN, "a", 16, 9, fm=fm)]
+    if not fm:
+        feats += [ShardedFeature("f_c", NRX_SPARSE, "c", 32), ShardedFeature("f_cm", NRX_BAG_MEAN, "c", 32, 4),
+                  ShardedFeature("f_d", NRX_DENSE, "", 1)]
+    inputs, weights = [], []
+    for f in feats:
+        if f.kind == NRX_DENSE:
+            inputs.append(torch.rand(B, device=DEV, generator=g))
+            weights.append(None)
+            continue
+        shape = (B, f.bag_len) if f.bag_len else (B,)
+        ids = torch.randint(0, rows[f.table], shape, device=DEV, generator=g)
+        if f.kind == NRX_BAG_MASKED_MEAN:
+            lens = torch.randint(0, f.bag_len + 1, (B,), device=DEV, generator=g)
+            m = (torch.arange(f.bag_len, device=DEV)[None] < lens[:, None]).float()
+            ids = ids * m.long()
+            weights.append(m)
+        else:
+            weights.append(None)
+        inputs.append(ids)
+    return tables, feats, inputs, weights
+
+
+def _direct(tables, feats, inputs, weights, fm):
+    names = sorted(tables)
+    slots, col = [], 0
+    for f in feats:
+        if f.kind == NRX_DENSE:
+            slots.append(ops.Slot(f.name, NRX_DENSE, -1, 1, 0, col))
+            col += 1
+        else:
+            slots.append(ops.Slot(f.name, f.kind, names.index(f.table), f.dim, f.bag_len, col, fm_field=int(fm)))
+            col += f.dim
+    plan = ops.EmbedPlan(slots, out_width=col, use_fm=fm)
+    leaves = [tables[n].clone().requires_grad_(True) for n in names]
+    return ops.embed_apply(plan, leaves, inputs, weights), leaves, names
+
+
+@pytest.mark.parametrize("fm", [False, True])
+def test_world1_engine_equals_direct_path(fm):
+    tables, feats, inputs, weights = _case(fm=fm)
+    (out_d, _, fm_d), leaves_d, names = _direct(tables, feats, inputs, weights, fm)
+    shards = {n: tables[n].clone().requires_grad_(True) for n in names}
+    eng = RowShardedEmbedding(0, 1)
+    out_s, _, fm_s = eng.forward(feats, inputs, weights, shards)
+    # single-valued columns are routed copies: bit-exact; pooled columns see the same rows in the same order
+    assert torch.equal(out_s, out_d)
+    up = torch.randn_like(out_d)
+    loss_d = (out_d * up).sum() + (fm_d.sum() if fm else 0)
+    loss_s = (out_s * up).sum() + (fm_s.sum() if fm else 0)
+    if fm:
+        np.testing.assert_allclose(fm_s.detach().cpu().numpy(), fm_d.detach().cpu().numpy(), rtol=1e-6, atol=1e-5)
+    loss_d.backward()
+    loss_s.backward()
+    for n, leaf in zip(names, leaves_d):
+        np.testing.assert_allclose(shards[n].grad.cpu().numpy(), leaf.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
+        assert torch.all(shards[n].grad[0] == 0)          # global padding row (rank 0, local row 0)
+
+
+def test_oob_raises_on_the_routed_path():
+    tables, feats, inputs, weights = _case(B=50)
+    inputs[1] = inputs[1].clone()
+    inputs[1][7] = 77           # table b has 77 rows
+    eng = RowShardedEmbedding(0, 1)
+    with pytest.raises(IndexError):
+        eng.forward(feats, inputs, weights, {n: t for n, t in tables.items()})
+
+
+@pytest.mark.parametrize("cls,cfg,gname", [(Deep, "cf_array_small.yaml", "model_deep_array"), (FM, "cf_fm_small.yaml", "model_fm")])
+def test_shard_model_world1_matches_reference_golden(cls, cfg, gname):
+    g = dict(np.load(os.path.join(GOLDEN, gname + ".npz"), allow_pickle=False))
+    m = cls(os.path.join(CONFIGS, cfg))
+    m.load_state_dict({k[6:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}, strict=True)
+    m = m.to(DEV)
+    keys_before = sorted(m.state_dict())
+    sharding.shard_model_(m, 0, 1)
+    assert sorted(m.state_dict()) == keys_before                      # checkpoint keys unchanged
+    batch = {k[6:]: torch.from_numpy(v).to(DEV) for k, v in g.items() if k.startswith("batch/")}
+    out = m(batch)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out/forward"], rtol=1e-4, atol=1e-6)
+    loss = m.bceLoss(out, batch["label"][:, 0])
+    loss.backward()
+    for name, emb in m.embedding_tables.items():
+        want = g[f"grad/embedding_tables.{name}.weight"]
+        np.testing.assert_allclose(emb.weight.grad.cpu().numpy(), want, rtol=2e-3, atol=2e-6 + 1e-4 * np.abs(want).max())
