@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded engine even at N=1 (testing)")
     ap.add_argument("--shard-mode", default="row", choices=["row", "auto"],
                     help="N>1: 'row' shards every table row-wise (north star); 'auto' replicates tables <= 64 MiB")
     args = ap.parse_args()
@@ -219,7 +220,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     seed = 20260116 + {"c2": 2, "c3": 3, "c4": 4, "c5": 5}[args.workload] + rank
-    if world == 1:
+    if world == 1 and not args.force_sharded:
         path = SingleGpuPath(args.workload, device, seed)
         step = path.step
         bytes_per_impr = path.bytes_per_impr
@@ -258,6 +259,8 @@ def main():
         dt = t.item()
     kern_ms = e0.elapsed_time(e1) / args.steps
 
+    if hasattr(path, "overflowed") and path.overflowed():
+        raise SystemExit("fixed-capacity exchange overflowed: rerun with a larger slack (ids too skewed)")
     if rank == 0:
         total_impr = BATCH * world * args.steps
         ms_per_step = dt * 1e3 / args.steps
@@ -291,7 +294,7 @@ def main():
                                  "the timed region on the launch stream / steps); traffic = DRAM bytes per launch from "
                                  "the committed rocprofv3 PMC passes (profiles/traffic.json), null if not profiled"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.force_sharded:
             out["cpu_baseline"] = cpu_baseline(path)
         try:
             info = ops.device_info(local_rank)

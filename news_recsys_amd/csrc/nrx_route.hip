@@ -1,0 +1,424 @@
+// Fixed-capacity, host-sync-free routing for row-sharded tables (row r on rank r % world at local
+// row r / world).  New in this build (the reference is single-device); definitions of the results are
+// in oracle/ref_np.py (route_ids / gather_inbox).  Everything is deterministic: order comes from
+// ballot ranks and prefix sums; the only atomics are integer counters whose final value is
+// order-independent.
+//
+//   route_hist   per 2048-id chunk (one wavefront): ids of each owner           -> hist[chunk][o]
+//                and per-(owner, feature) totals                                 -> counts2d
+//   route_scan   one block: exclusive scan of hist over chunks per owner, block counts -> overflow
+//   route_place  per chunk: stable rank of each id inside its owner block -> send_rows, slot
+//   inbox_*      owner side: walk the [world, cap] inbox; a slot's feature (hence table) comes from
+//                the prefix sums of the device-resident recv2d row, staged in LDS per block.
+#include "nrx_common.h"
+
+namespace {
+
+constexpr int CHUNK = 512;      // ids per wavefront: 8 per lane, all loaded before any is ranked
+constexpr int PER_LANE = CHUNK / 64;
+
+struct RouteArgs {
+    const void* ids[NRX_MAX_FEATURES];
+    int64_t off[NRX_MAX_FEATURES + 1];    // flat start of each feature
+    int32_t n_feats;
+    int32_t world;
+    int32_t idx64;
+    int32_t pad;
+    int64_t n_total;
+    int64_t cap;
+    int64_t* hist;       // [world][nchunks]  (owner-major: the scan reads it coalesced)
+    int64_t nchunks;
+    int64_t* counts2d;   // [world][n_feats]
+    int64_t* block_cnt;  // [world]  (workspace)
+    int64_t* send_rows;
+    int64_t* slot;
+    int64_t* overflow;
+};
+static_assert(sizeof(RouteArgs) <= 3584, "kernarg budget");
+
+__device__ __forceinline__ int feat_of(const NRX_CONST RouteArgs* a, int64_t p) {
+    int lo = 0, hi = a->n_feats;         // last f with off[f] <= p
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a->off[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int64_t route_load(const NRX_CONST RouteArgs* a, int f, int64_t p) {
+    const int64_t i = p - a->off[f];
+    return a->idx64 ? nrx_gconst<int64_t>(a->ids[f])[i] : (int64_t)nrx_gconst<int32_t>(a->ids[f])[i];
+}
+
+__device__ __forceinline__ int owner_rank(int64_t id, int world) { return id < 0 ? 0 : (int)(id % world); }
+
+// Loads the chunk's ids (PER_LANE per lane, group g covers positions begin + g*64 + lane) and their
+// features/owners into registers: all global loads are issued before the first ballot.
+struct ChunkRegs {
+    int64_t id[PER_LANE];
+    int o[PER_LANE];
+    int f[PER_LANE];
+};
+
+__device__ __forceinline__ void load_chunk(const NRX_CONST RouteArgs* a, int64_t begin, int64_t end, int lane, ChunkRegs& c) {
+    const int world = a->world;
+    const int f_first = feat_of(a, begin);
+    const bool one_feature = (end - 1) < a->off[f_first + 1];        // wave-uniform: the usual case
+#pragma unroll
+    for (int g = 0; g < PER_LANE; ++g) {
+        const int64_t p = begin + g * 64 + lane;
+        c.o[g] = -1;
+        c.f[g] = f_first;
+        c.id[g] = 0;
+        if (p < end) {
+            if (!one_feature) c.f[g] = feat_of(a, p);
+            c.id[g] = route_load(a, c.f[g], p);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < PER_LANE; ++g) {
+        const int64_t p = begin + g * 64 + lane;
+        if (p < end) c.o[g] = owner_rank(c.id[g], world);
+    }
+}
+
+__global__ __launch_bounds__(NRX_BLOCK) void route_hist(const RouteArgs args_in_kernarg) {
+    const NRX_CONST RouteArgs* a = nrx_kernarg<RouteArgs>();
+    const int lane = threadIdx.x & 63;
+    const int64_t chunk = (int64_t)blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t begin = chunk * CHUNK;
+    if (begin >= a->n_total) return;
+    const int64_t end = (begin + CHUNK < a->n_total) ? begin + CHUNK : a->n_total;
+    const int world = a->world, F = a->n_feats;
+    ChunkRegs c;
+    load_chunk(a, begin, end, lane, c);
+    const int f_first = feat_of(a, begin);
+    const bool one_feature = (end - 1) < a->off[f_first + 1];
+    int64_t cnt = 0;        // lane o: ids of owner o in this chunk
+#pragma unroll
+    for (int g = 0; g < PER_LANE; ++g) {
+        for (int t = 0; t < world; ++t) {
+            const unsigned long long m = __ballot(c.o[g] == t);
+            if (lane == t) cnt += __popcll(m);
+        }
+        if (!one_feature && c.o[g] >= 0)       // chunk straddles features: count per lane
+            atomicAdd((unsigned long long*)&a->counts2d[c.o[g] * F + c.f[g]], 1ull);
+    }
+    if (lane < world) {
+        if (one_feature && cnt) atomicAdd((unsigned long long*)&a->counts2d[lane * F + f_first], (unsigned long long)cnt);
+        a->hist[lane * a->nchunks + chunk] = cnt;
+    }
+}
+
+// One wavefront per owner: exclusive scan of hist[o][0..nchunks) in place, 4 chunks per lane per
+// step (256 chunks per step, coalesced), block totals -> block_cnt, their max -> overflow.
+__global__ __launch_bounds__(NRX_BLOCK) void route_scan(int64_t* __restrict__ hist, int64_t nchunks, int world, int64_t cap,
+                                                        int64_t* __restrict__ block_cnt, int64_t* __restrict__ overflow) {
+    __shared__ int64_t s_tot[64];
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    for (int o = wid; o < world; o += NRX_BLOCK / 64) {
+        int64_t* h = hist + (int64_t)o * nchunks;
+        int64_t running = 0;
+        for (int64_t c0 = 0; c0 < nchunks; c0 += 256) {
+            const int64_t c = c0 + lane * 4;
+            int64_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (c + k < nchunks) ? h[c + k] : 0;
+            const int64_t mine = v[0] + v[1] + v[2] + v[3];
+            int64_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int64_t t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            int64_t base = running + incl - mine;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (c + k < nchunks) h[c + k] = base;
+                base += v[k];
+            }
+            running += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) s_tot[o] = running;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t worst = 0;
+        for (int o = 0; o < world; ++o) {
+            block_cnt[o] = s_tot[o];
+            if (s_tot[o] > worst) worst = s_tot[o];
+        }
+        overflow[0] = worst;
+    }
+}
+
+__global__ __launch_bounds__(NRX_BLOCK) void route_place(const RouteArgs args_in_kernarg) {
+    const NRX_CONST RouteArgs* a = nrx_kernarg<RouteArgs>();
+    const int lane = threadIdx.x & 63;
+    const int64_t chunk = (int64_t)blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t begin = chunk * CHUNK;
+    if (begin >= a->n_total) return;
+    const int64_t end = (begin + CHUNK < a->n_total) ? begin + CHUNK : a->n_total;
+    const int world = a->world;
+    const int64_t cap = a->cap;
+    ChunkRegs c;
+    load_chunk(a, begin, end, lane, c);
+    int64_t run = (lane < world) ? a->hist[lane * a->nchunks + chunk] : 0;    // lane o: rank of the next id of owner o
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int g = 0; g < PER_LANE; ++g) {
+        const int64_t p = begin + g * 64 + lane;
+        int64_t k = 0;
+        for (int t = 0; t < world; ++t) {
+            const unsigned long long m = __ballot(c.o[g] == t);
+            const int64_t base = __shfl(run, t, 64);
+            if (c.o[g] == t) k = base + __popcll(m & lt);
+            if (lane == t) run += __popcll(m);
+        }
+        if (p < end) {
+            if (k < cap) {
+                a->slot[p] = c.o[g] * cap + k;
+                a->send_rows[c.o[g] * cap + k] = c.id[g] < 0 ? c.id[g] : c.id[g] / world;
+            } else {
+                a->slot[p] = -1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- owner side
+struct InboxArgs {
+    float* table[NRX_MAX_FEATURES];        // weight tables (gather) or grad tables (scatter)
+    int64_t rows[NRX_MAX_FEATURES];
+    int32_t feat_table[NRX_MAX_FEATURES];
+    int32_t n_feats;
+    int32_t world;
+    int64_t cap;
+    const int64_t* recv2d;
+    const int64_t* inbox;
+    float* buf;                            // out_rows (gather) / g_rows (scatter, read only)
+    int32_t* status;
+    int32_t dim;
+    int32_t skip_row0;
+};
+static_assert(sizeof(InboxArgs) <= 3584, "kernarg budget");
+
+constexpr int INBOX_R = 4;   // slots per thread: 4 independent row reads in flight
+
+template <int QLOG2, bool SCATTER>
+__global__ __launch_bounds__(NRX_BLOCK) void inbox_kernel(const InboxArgs args_in_kernarg) {
+    const NRX_CONST InboxArgs* a = nrx_kernarg<InboxArgs>();
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int64_t* s_pre = reinterpret_cast<int64_t*>(smem);       // [F + 1] prefix of this block's source rank
+    const int F = a->n_feats;
+    const int64_t cap = a->cap;
+    // blocks are laid out per source rank: blockIdx.y = s, blockIdx.x tiles its cap slots
+    const int s = blockIdx.y;
+    if (threadIdx.x == 0) {
+        int64_t acc = 0;
+        for (int f = 0; f < F; ++f) {
+            s_pre[f] = acc;
+            acc += a->recv2d[s * F + f];
+        }
+        s_pre[F] = acc;
+    }
+    __syncthreads();
+    const int64_t total = s_pre[F] < cap ? s_pre[F] : cap;
+    const int q = threadIdx.x & (Q - 1);
+    const int64_t j0 = (int64_t)blockIdx.x * (TB * INBOX_R) + (threadIdx.x >> QLOG2);
+    if (j0 >= total) return;
+    const int D = a->dim;
+    const bool vec = (D & 3) == 0;
+    int64_t row[INBOX_R];
+    int tab[INBOX_R];
+    bool ok[INBOX_R];
+#pragma unroll
+    for (int r = 0; r < INBOX_R; ++r) {
+        const int64_t j = j0 + r * TB;
+        ok[r] = j < total;
+        row[r] = ok[r] ? nrx_gconst<int64_t>(a->inbox)[s * cap + j] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < INBOX_R; ++r) {
+        const int64_t j = j0 + r * TB;
+        int lo = 0, hi = F;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_pre[mid] <= j) lo = mid; else hi = mid;
+        }
+        tab[r] = a->feat_table[lo];
+        if (ok[r] && (uint64_t)row[r] >= (uint64_t)a->rows[tab[r]]) {
+            if (!SCATTER && q == 0) nrx_report_oob(a->status, tab[r], s * cap + j, row[r]);
+            if (SCATTER) ok[r] = false;
+            row[r] = 0;
+        }
+        if (SCATTER && a->skip_row0 && row[r] == 0) ok[r] = false;
+    }
+    for (int k0 = q * 4; k0 < D; k0 += 4 * Q) {
+        if (SCATTER) {
+#pragma unroll
+            for (int r = 0; r < INBOX_R; ++r) {
+                if (!ok[r]) continue;
+                const int64_t p = s * cap + j0 + r * TB;
+                const NRX_GLOBAL float* src = nrx_gconst<float>(a->buf) + p * (int64_t)D + k0;
+                float* dst = a->table[tab[r]] + row[r] * (int64_t)D + k0;
+                unsafeAtomicAdd(dst, src[0]);
+                if (k0 + 1 < D) unsafeAtomicAdd(dst + 1, src[1]);
+                if (k0 + 2 < D) unsafeAtomicAdd(dst + 2, src[2]);
+                if (k0 + 3 < D) unsafeAtomicAdd(dst + 3, src[3]);
+            }
+        } else if (vec) {
+            float4 v[INBOX_R];
+#pragma unroll
+            for (int r = 0; r < INBOX_R; ++r)
+                v[r] = ok[r] ? nrx_ldg4_nt(a->table[tab[r]] + row[r] * (int64_t)D + k0, 0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < INBOX_R; ++r)
+                if (ok[r]) nrx_stg4(a->buf, ((s * cap + j0 + r * TB) * (int64_t)D + k0) >> 2, v[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < INBOX_R; ++r) {
+                if (!ok[r]) continue;
+                const float* src = a->table[tab[r]] + row[r] * (int64_t)D + k0;
+                NRX_GLOBAL float* dst = nrx_gmut<float>(a->buf) + (s * cap + j0 + r * TB) * (int64_t)D + k0;
+                dst[0] = src[0];
+                if (k0 + 1 < D) dst[1] = src[1];
+                if (k0 + 2 < D) dst[2] = src[2];
+                if (k0 + 3 < D) dst[3] = src[3];
+            }
+        }
+    }
+}
+
+int log2_ceil(int x) {
+    int l = 0;
+    while ((1 << l) < x) ++l;
+    return l;
+}
+
+template <bool SCATTER>
+int launch_inbox(InboxArgs& a, hipStream_t st, const char* who) {
+    int ql = log2_ceil((a.dim + 3) / 4);
+    if (ql > 6) ql = 6;
+    const int tb = NRX_BLOCK >> ql;
+    const int per_block = tb * INBOX_R;
+    dim3 grid((unsigned)((a.cap + per_block - 1) / per_block), (unsigned)a.world);
+    const size_t smem = (size_t)(a.n_feats + 1) * sizeof(int64_t);
+    switch (ql) {
+#define NRX_CASE(QL_) case QL_: hipLaunchKernelGGL((inbox_kernel<QL_, SCATTER>), grid, dim3(NRX_BLOCK), smem, st, a); break;
+        NRX_CASE(0) NRX_CASE(1) NRX_CASE(2) NRX_CASE(3) NRX_CASE(4) NRX_CASE(5)
+        default: hipLaunchKernelGGL((inbox_kernel<6, SCATTER>), grid, dim3(NRX_BLOCK), smem, st, a); break;
+#undef NRX_CASE
+    }
+    NRX_LAUNCH_CHECK(who);
+    return NRX_OK;
+}
+
+int fill_inbox_args(InboxArgs& a, float* const* tables, const int64_t* table_rows, int32_t n_tables,
+                    const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap, const int64_t* recv2d,
+                    const int64_t* inbox_rows, int32_t dim, const char* who) {
+    NRX_REQUIRE(tables && table_rows && n_tables >= 1 && n_tables <= NRX_MAX_FEATURES, "%s: n_tables must be in [1, %d]", who, NRX_MAX_FEATURES);
+    NRX_REQUIRE(feat_table && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES, "%s: n_feats must be in [1, %d]", who, NRX_MAX_FEATURES);
+    NRX_REQUIRE(world >= 1 && world <= 64 && cap >= 1 && dim >= 1, "%s: bad world/cap/dim", who);
+    NRX_REQUIRE(recv2d && inbox_rows, "%s: null buffer", who);
+    for (int i = 0; i < n_tables; ++i) {
+        NRX_REQUIRE(tables[i] != nullptr, "%s: table %d is null", who, i);
+        NRX_REQUIRE((dim & 3) != 0 || nrx_aligned16(tables[i]), "%s: table %d must be 16-byte aligned", who, i);
+        a.table[i] = tables[i];
+        a.rows[i] = table_rows[i];
+    }
+    for (int f = 0; f < n_feats; ++f) {
+        NRX_REQUIRE(feat_table[f] >= 0 && feat_table[f] < n_tables, "%s: feat_table[%d] out of range", who, f);
+        a.feat_table[f] = feat_table[f];
+    }
+    a.n_feats = n_feats;
+    a.world = world;
+    a.cap = cap;
+    a.recv2d = recv2d;
+    a.inbox = inbox_rows;
+    a.dim = dim;
+    return NRX_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t nrx_route_workspace(int64_t n_total, int32_t world) {
+    if (n_total < 0 || world < 1) return -1;
+    return ((n_total + CHUNK - 1) / CHUNK) * world + world;
+}
+
+extern "C" int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_t n_feats, int32_t index_bits,
+                             int32_t world, int64_t cap, int64_t* send_rows, int64_t* slot, int64_t* counts2d,
+                             int64_t* overflow, int64_t* workspace, void* stream) {
+    NRX_REQUIRE(ids && lens && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES, "nrx_route_ids: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
+    NRX_REQUIRE(index_bits == 32 || index_bits == 64, "nrx_route_ids: index_bits must be 32 or 64");
+    NRX_REQUIRE(world >= 1 && world <= 64 && cap >= 1, "nrx_route_ids: bad world / cap");
+    NRX_REQUIRE(send_rows && slot && counts2d && overflow && workspace, "nrx_route_ids: null buffer");
+    RouteArgs a;
+    int64_t off = 0;
+    for (int f = 0; f < n_feats; ++f) {
+        NRX_REQUIRE(lens[f] >= 0 && (lens[f] == 0 || ids[f] != nullptr), "nrx_route_ids: feature %d: bad ids/len", f);
+        a.ids[f] = ids[f];
+        a.off[f] = off;
+        off += lens[f];
+    }
+    a.off[n_feats] = off;
+    a.n_feats = n_feats;
+    a.world = world;
+    a.idx64 = index_bits == 64;
+    a.pad = 0;
+    a.n_total = off;
+    a.cap = cap;
+    const int64_t nchunks = (off + CHUNK - 1) / CHUNK;
+    a.hist = workspace;
+    a.nchunks = nchunks;
+    a.block_cnt = workspace + nchunks * world;
+    a.counts2d = counts2d;
+    a.send_rows = send_rows;
+    a.slot = slot;
+    a.overflow = overflow;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(counts2d, 0, sizeof(int64_t) * (size_t)world * n_feats, st) != hipSuccess) {
+        nrx_set_error("nrx_route_ids: memset failed");
+        return NRX_ERR_LAUNCH;
+    }
+    const unsigned grid = (unsigned)((nchunks + 3) / 4);
+    if (nchunks > 0) hipLaunchKernelGGL(route_hist, dim3(grid), dim3(NRX_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(route_scan, dim3(1), dim3(NRX_BLOCK), 0, st, a.hist, nchunks, world, cap, a.block_cnt, overflow);
+    if (nchunks > 0) hipLaunchKernelGGL(route_place, dim3(grid), dim3(NRX_BLOCK), 0, st, a);
+    NRX_LAUNCH_CHECK("nrx_route_ids");
+    return NRX_OK;
+}
+
+extern "C" int nrx_gather_inbox(const float* const* tables, const int64_t* table_rows, int32_t n_tables,
+                                const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,
+                                const int64_t* recv2d, const int64_t* inbox_rows, int32_t dim,
+                                float* out_rows, int32_t* status, void* stream) {
+    InboxArgs a;
+    int rc = fill_inbox_args(a, const_cast<float* const*>(tables), table_rows, n_tables, feat_table, n_feats, world, cap,
+                             recv2d, inbox_rows, dim, "nrx_gather_inbox");
+    if (rc != NRX_OK) return rc;
+    NRX_REQUIRE(out_rows != nullptr && ((dim & 3) != 0 || nrx_aligned16(out_rows)), "nrx_gather_inbox: bad out_rows");
+    a.buf = out_rows;
+    a.status = status;
+    a.skip_row0 = 0;
+    return launch_inbox<false>(a, reinterpret_cast<hipStream_t>(stream), "nrx_gather_inbox");
+}
+
+extern "C" int nrx_scatter_add_inbox(float* const* grad_tables, const int64_t* table_rows, int32_t n_tables,
+                                     const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,
+                                     const int64_t* recv2d, const int64_t* inbox_rows, int32_t dim,
+                                     const float* g_rows, int32_t skip_row0, void* stream) {
+    InboxArgs a;
+    int rc = fill_inbox_args(a, grad_tables, table_rows, n_tables, feat_table, n_feats, world, cap, recv2d, inbox_rows, dim,
+                             "nrx_scatter_add_inbox");
+    if (rc != NRX_OK) return rc;
+    NRX_REQUIRE(g_rows != nullptr, "nrx_scatter_add_inbox: null g_rows");
+    a.buf = const_cast<float*>(g_rows);
+    a.status = nullptr;
+    a.skip_row0 = skip_row0;
+    return launch_inbox<true>(a, reinterpret_cast<hipStream_t>(stream), "nrx_scatter_add_inbox");
+}

@@ -619,6 +619,71 @@ def scatter_add_rows_segmented(grad_tables: Sequence[torch.Tensor], seg_start: t
                                              1 if skip_row0 else 0, _stream_ptr(g_rows)), "nrx_scatter_add_rows_segmented")
 
 
+def route_ids(id_tensors: Sequence[torch.Tensor], world: int, cap: int):
+    """Fixed-capacity routing of the ids of one exchange (no host synchronisation).
+    Returns (send_rows [world*cap] int64, slot [N] int64, counts2d [world, F] int64, overflow [1] int64)."""
+    lib = _lib.load()
+    n = len(id_tensors)
+    if not 1 <= n <= NRX_MAX_FEATURES:
+        raise ValueError(f"route_ids takes 1..{NRX_MAX_FEATURES} id tensors per exchange")
+    dt = id_tensors[0].dtype
+    if dt not in (torch.int64, torch.int32):
+        raise TypeError("ids must be int64 or int32")
+    xs = []
+    for x in id_tensors:
+        _dev(x, "ids")
+        if x.dtype != dt:
+            raise TypeError("all id tensors of one exchange must share a dtype")
+        xs.append(x if x.is_contiguous() else x.contiguous())
+    dev = xs[0].device
+    total = sum(x.numel() for x in xs)
+    send_rows = torch.empty(world * cap, dtype=torch.int64, device=dev)
+    slot = torch.empty(total, dtype=torch.int64, device=dev)
+    counts2d = torch.empty((world, n), dtype=torch.int64, device=dev)
+    overflow = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(1, lib.nrx_route_workspace(total, world)), dtype=torch.int64, device=dev)
+    ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    lens = (C.c_int64 * n)(*[x.numel() for x in xs])
+    check(lib.nrx_route_ids(ptrs, lens, n, xs[0].element_size() * 8, world, cap, send_rows.data_ptr(), slot.data_ptr(),
+                            counts2d.data_ptr(), overflow.data_ptr(), ws.data_ptr(), _stream_ptr(xs[0])), "nrx_route_ids")
+    return send_rows, slot, counts2d, overflow
+
+
+def _inbox_common(tables, feat_table):
+    dim = tables[0].shape[1]
+    for t in tables:
+        _f32c(t, "table")
+        if t.shape[1] != dim or not t.is_contiguous():
+            raise ValueError("inbox gather/scatter needs contiguous tables of one common dim")
+    tp = (C.c_void_p * len(tables))(*[t.data_ptr() for t in tables])
+    tr = (C.c_int64 * len(tables))(*[t.shape[0] for t in tables])
+    ft = (C.c_int32 * len(feat_table))(*feat_table)
+    return dim, tp, tr, ft
+
+
+def gather_inbox(tables: Sequence[torch.Tensor], feat_table: Sequence[int], world: int, cap: int,
+                 recv2d: torch.Tensor, inbox_rows: torch.Tensor, status: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Owner side of the fixed-capacity exchange: rows for the valid prefix of every source block.
+    Returns [world*cap, dim] (slots past a block's count are left uninitialised)."""
+    lib = _lib.load()
+    dim, tp, tr, ft = _inbox_common(tables, feat_table)
+    out = torch.empty((world * cap, dim), dtype=torch.float32, device=tables[0].device)
+    check(lib.nrx_gather_inbox(tp, tr, len(tables), ft, len(feat_table), world, cap, recv2d.data_ptr(),
+                               inbox_rows.data_ptr(), dim, out.data_ptr(), _ptr(status), _stream_ptr(out)),
+          "nrx_gather_inbox")
+    return out
+
+
+def scatter_add_inbox(grad_tables: Sequence[torch.Tensor], feat_table: Sequence[int], world: int, cap: int,
+                      recv2d: torch.Tensor, inbox_rows: torch.Tensor, g_rows: torch.Tensor, skip_row0: bool) -> None:
+    lib = _lib.load()
+    dim, tp, tr, ft = _inbox_common(grad_tables, feat_table)
+    g_rows = _f32c(g_rows, "g_rows")
+    check(lib.nrx_scatter_add_inbox(tp, tr, len(grad_tables), ft, len(feat_table), world, cap, recv2d.data_ptr(),
+                                    inbox_rows.data_ptr(), dim, g_rows.data_ptr(), 1 if skip_row0 else 0,
+                                    _stream_ptr(g_rows)), "nrx_scatter_add_inbox")
+
+
 def mask_lengths(mask: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     mask = _f32c(mask, "mask")

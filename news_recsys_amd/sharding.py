@@ -20,6 +20,12 @@ all_to_all_single back to the owners, segmented scatter-add into the local dense
 rank 0 -- the global padding row -- excluded).  Dense parameters are all-reduced by
 `allreduce_dense_grads`.
 
+Two exchange modes.  "capacity" (default) is host-sync free: every (source, owner) pair gets a fixed
+block of `cap = ceil(N/G * (1 + slack))` slots, so all three all-to-alls use EQUAL splits, the owner
+learns its inbox segmentation from a device-resident counts matrix, and nothing is read back to the
+host inside a step (`nrx_route_ids` / `nrx_gather_inbox`).  If a block overflows (heavily skewed
+ids) the step is redone in "exact" mode: variable splits sized from counts read back to the host.
+
 The local kernels come from a backend object.  The product backend is `HipBackend` (the C-ABI);
 tests inject a CPU checker backend so that the routing + collectives can run under gloo without a
 GPU -- no CPU implementation ships in this package.
@@ -75,6 +81,20 @@ class HipBackend:
     def embed(self, plan, tables, inputs, weights, out_ld=None, need_out=True):
         return ops.embed_apply(plan, tables, inputs, weights, out_ld=out_ld, need_out=need_out)
 
+    # fixed-capacity (sync-free) exchange
+    def route(self, id_tensors, world, cap):
+        return ops.route_ids(id_tensors, world, cap)
+
+    def gather_inbox(self, tables, feat_table, world, cap, recv2d, inbox, want_status):
+        status = torch.zeros(4, dtype=torch.int32, device=inbox.device) if want_status else None
+        return ops.gather_inbox(tables, feat_table, world, cap, recv2d, inbox, status), status
+
+    def scatter_add_inbox(self, grad_tables, feat_table, world, cap, recv2d, inbox, g_rows, skip_row0):
+        ops.scatter_add_inbox(grad_tables, feat_table, world, cap, recv2d, inbox, g_rows, skip_row0)
+
+    def index_checks_on(self) -> bool:
+        return ops._INDEX_CHECK != "off"
+
 
 # --------------------------------------------------------------------------------- feature description
 @dataclass
@@ -102,15 +122,41 @@ class _Route:
     recv_rows: torch.Tensor         # [n_recv] local rows asked of this rank
     slot: torch.Tensor              # [n_send] position of each source id in the send buffer
     feat_off: List[int]             # start of each feature inside the flat source list
+    cap: int = 0                    # > 0: fixed-capacity route (recv2d / feat_table used instead of seg_*)
+    recv2d: Optional[torch.Tensor] = None
+    feat_table: Optional[List[int]] = None
 
 
 class RowShardedEmbedding:
     """Exchange engine for one process.  `tables` maps table name -> LOCAL shard tensor
     [local_row_count(rows), dim] (a leaf requiring grad when training)."""
 
-    def __init__(self, rank: int, world: int, group=None, backend=None):
+    def __init__(self, rank: int, world: int, group=None, backend=None, mode: str = "capacity",
+                 slack: float = 0.05, overflow_policy: str = "check"):
+        """mode: "capacity" (sync-free, default) or "exact".  overflow_policy (capacity mode):
+        "check" = agree on overflow across ranks after each forward (one small all-reduce + host read)
+        and transparently redo the step in exact mode; "defer" = never read back inside the step --
+        the caller polls `overflowed()` (bench / inference pipelines)."""
+        if mode not in ("capacity", "exact"):
+            raise ValueError("mode must be 'capacity' or 'exact'")
         self.rank, self.world, self.group = rank, world, group
         self.backend = backend if backend is not None else HipBackend()
+        self.mode, self.slack, self.overflow_policy = mode, slack, overflow_policy
+        self._overflow_marks: List[Tuple[torch.Tensor, int]] = []
+
+    def capacity_for(self, n_total: int) -> int:
+        if self.world == 1:
+            return max(64, n_total)
+        cap = int(n_total / self.world * (1.0 + self.slack)) + 256
+        return (cap + 63) // 64 * 64
+
+    def overflowed(self) -> bool:
+        """True if any fixed-capacity exchange since the last call exceeded its block capacity."""
+        bad = False
+        for t, cap in self._overflow_marks:
+            bad |= int(t.item()) > cap
+        self._overflow_marks.clear()
+        return bad
 
     # ---- collectives (RCCL when the tensors are on GPUs: backend "nccl" is RCCL on ROCm)
     def _a2a(self, out: torch.Tensor, inp: torch.Tensor, out_split=None, in_split=None) -> torch.Tensor:
@@ -178,6 +224,41 @@ class RowShardedEmbedding:
                        recv_rows, slot, feat_off)
         return ret, route
 
+    def _exchange_capacity(self, feats: Sequence[ShardedFeature], idxs: List[int], inputs, tables: Dict[str, torch.Tensor]):
+        """Sync-free steps 1-6 for one group (<= 64 features of one dim).  Returns (rows, _Route, overflow)."""
+        W = self.world
+        ids = []
+        dt = torch.int32 if all(inputs[i].dtype == torch.int32 for i in idxs) else torch.int64
+        feat_off, off = [], 0
+        for i in idxs:
+            x = inputs[i]
+            ids.append(x if x.dtype == dt else x.to(dt))
+            feat_off.append(off)
+            off += x.numel()
+        n_send = off
+        cap = self.capacity_for(n_send)
+        table_names: List[str] = []
+        for i in idxs:
+            if feats[i].table not in table_names:
+                table_names.append(feats[i].table)
+        feat_table = [table_names.index(feats[i].table) for i in idxs]
+        D = feats[idxs[0]].dim
+        dev = inputs[idxs[0]].device
+
+        send_rows, slot, counts2d, overflow = self.backend.route(ids, W, cap)            # steps 1-3
+        recv2d = torch.empty_like(counts2d)
+        self._a2a(recv2d.view(-1), counts2d.view(-1))                                   # equal splits
+        inbox = torch.empty(W * cap, dtype=torch.int64, device=dev)
+        self._a2a(inbox, send_rows)                                                     # step 4, equal splits
+        want_status = self.backend.index_checks_on() and self.overflow_policy == "check"
+        rows_out, status = self.backend.gather_inbox([tables[t] for t in table_names], feat_table, W, cap,
+                                                     recv2d, inbox, want_status)        # step 5
+        ret = torch.empty((W * cap, D), dtype=torch.float32, device=dev)
+        self._a2a(ret.view(-1), rows_out.view(-1))                                      # step 6, equal splits
+        route = _Route(list(idxs), table_names, D, n_send, [], [], None, None, inbox, slot, feat_off,
+                       cap=cap, recv2d=recv2d, feat_table=feat_table)
+        return ret, route, overflow, status
+
     def _final_plan(self, feats: Sequence[ShardedFeature], groups: List[List[int]]):
         """Step 7 plan: tables = one returned-row buffer per dim-group; indices = slot[] segments."""
         slots, col, wcol = [], 0, 0
@@ -217,12 +298,39 @@ class _ShardedEmbedFn(torch.autograd.Function):
         for i, f in enumerate(feats):
             if f.kind != NRX_DENSE:
                 by_dim.setdefault(f.dim, []).append(i)
-        groups = [by_dim[d] for d in sorted(by_dim)]
-        rets, routes = [], []
-        for idxs in groups:
-            ret, route = eng._exchange(feats, idxs, inputs, tables)
-            rets.append(ret)
-            routes.append(route)
+        groups: List[List[int]] = []
+        for d in sorted(by_dim):                       # one exchange per (dim, <= 64 features)
+            idxs = by_dim[d]
+            groups += [idxs[k:k + 64] for k in range(0, len(idxs), 64)]
+
+        def run(mode):
+            rets, routes, flags = [], [], []
+            for idxs in groups:
+                if mode == "capacity":
+                    ret, route, overflow, status = eng._exchange_capacity(feats, idxs, inputs, tables)
+                    flags.append((overflow, route.cap, status))
+                else:
+                    ret, route = eng._exchange(feats, idxs, inputs, tables)
+                rets.append(ret)
+                routes.append(route)
+            return rets, routes, flags
+
+        rets, routes, flags = run(eng.mode)
+        if eng.mode == "capacity":
+            if eng.overflow_policy == "check":
+                # one tiny all-reduce so that every rank takes the same branch, then one host read
+                worst = torch.stack([torch.stack([o[0] - cap, (st[0].to(torch.int64) if st is not None else o[0] * 0)])
+                                     for o, cap, st in flags]).max(dim=0).values
+                if eng.world > 1:
+                    dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=eng.group)
+                over, bad = worst.tolist()
+                if bad > 0:
+                    raise IndexError("index out of range in self: a routed lookup exceeded its table on some rank")
+                if over > 0:
+                    rets, routes, flags = run("exact")
+            else:
+                eng._overflow_marks += [(o, cap) for o, cap, _ in flags]
+
         plan = eng._final_plan(feats, groups)
         final_inputs = []
         for i, f in enumerate(feats):
@@ -262,13 +370,107 @@ class _ShardedEmbedFn(torch.autograd.Function):
             if g_ret is None:
                 g_ret = torch.zeros_like(leaf)
             D = route.dim
-            n_recv = int(sum(route.recv_counts))
-            g_recv = torch.empty((n_recv, D), dtype=torch.float32, device=leaf.device)
-            eng._a2a(g_recv.view(-1), g_ret.contiguous().view(-1), [c * D for c in route.recv_counts],
-                     [c * D for c in route.send_counts])
-            eng.backend.scatter_add_segmented([shard_grads[t] for t in route.table_names], route.seg_start,
-                                              route.seg_table, route.recv_rows, g_recv, skip_row0=(eng.rank == 0))
+            gts = [shard_grads[t] for t in route.table_names]
+            if route.cap:
+                g_recv = torch.empty_like(g_ret)
+                eng._a2a(g_recv.view(-1), g_ret.contiguous().view(-1))                    # equal splits
+                eng.backend.scatter_add_inbox(gts, route.feat_table, eng.world, route.cap, route.recv2d,
+                                              route.recv_rows, g_recv, skip_row0=(eng.rank == 0))
+            else:
+                n_recv = int(sum(route.recv_counts))
+                g_recv = torch.empty((n_recv, D), dtype=torch.float32, device=leaf.device)
+                eng._a2a(g_recv.view(-1), g_ret.contiguous().view(-1), [c * D for c in route.recv_counts],
+                         [c * D for c in route.send_counts])
+                eng.backend.scatter_add_segmented(gts, route.seg_start, route.seg_table, route.recv_rows, g_recv,
+                                                  skip_row0=(eng.rank == 0))
         return (None,) * n_lead + tuple(shard_grads[n] for n in ctx.names)
+
+
+# --------------------------------------------------------------------------------- bound forward
+class PreparedShardedForward:
+    """A bound, re-launchable sync-free sharded forward (inference / benchmarking; HIP backend only):
+    all exchange buffers, C descriptor arrays and the final fused launch are built once; `run()` only
+    enqueues 3 routing kernels + 3 equal-split all-to-alls + the owner gather per exchange group, then
+    the final launch.  ids / masks are re-read from the SAME tensors on every run.  `overflowed()`
+    reports (with one host read) whether any block exceeded its capacity since the last call."""
+
+    def __init__(self, eng: RowShardedEmbedding, feats: Sequence[ShardedFeature], inputs, weights,
+                 tables: Dict[str, torch.Tensor], out_ld: Optional[int] = None,
+                 out: Optional[torch.Tensor] = None, fm: Optional[torch.Tensor] = None):
+        import ctypes as C
+        from . import _lib
+        self.lib = _lib.load()
+        self.eng = eng
+        W = eng.world
+        by_dim: Dict[int, List[int]] = {}
+        for i, f in enumerate(feats):
+            if f.kind != NRX_DENSE:
+                by_dim.setdefault(f.dim, []).append(i)
+        groups: List[List[int]] = []
+        for d in sorted(by_dim):
+            idxs = by_dim[d]
+            groups += [idxs[k:k + 64] for k in range(0, len(idxs), 64)]
+        self.groups = []
+        self.keep = [inputs, weights, tables]
+        slot_of: Dict[int, torch.Tensor] = {}
+        rets = []
+        for idxs in groups:
+            dev = inputs[idxs[0]].device
+            dt = torch.int32 if all(inputs[i].dtype == torch.int32 for i in idxs) else torch.int64
+            ids = [inputs[i] if inputs[i].dtype == dt else inputs[i].to(dt) for i in idxs]
+            ids = [x if x.is_contiguous() else x.contiguous() for x in ids]
+            n = len(ids)
+            total = sum(x.numel() for x in ids)
+            cap = eng.capacity_for(total)
+            D = feats[idxs[0]].dim
+            table_names: List[str] = []
+            for i in idxs:
+                if feats[i].table not in table_names:
+                    table_names.append(feats[i].table)
+            loc = [tables[t] for t in table_names]
+            g = dict(
+                n=n, cap=cap, D=D, bits=ids[0].element_size() * 8, ids=ids,
+                ptrs=(C.c_void_p * n)(*[x.data_ptr() for x in ids]), lens=(C.c_int64 * n)(*[x.numel() for x in ids]),
+                send=torch.empty(W * cap, dtype=torch.int64, device=dev), slot=torch.empty(total, dtype=torch.int64, device=dev),
+                counts2d=torch.empty((W, n), dtype=torch.int64, device=dev), recv2d=torch.empty((W, n), dtype=torch.int64, device=dev),
+                overflow=torch.zeros(1, dtype=torch.int64, device=dev),
+                ws=torch.empty(max(1, self.lib.nrx_route_workspace(total, W)), dtype=torch.int64, device=dev),
+                inbox=torch.empty(W * cap, dtype=torch.int64, device=dev),
+                rows_out=torch.empty((W * cap, D), dtype=torch.float32, device=dev),
+                ret=torch.empty((W * cap, D), dtype=torch.float32, device=dev),
+                tp=(C.c_void_p * len(loc))(*[t.data_ptr() for t in loc]), tr=(C.c_int64 * len(loc))(*[t.shape[0] for t in loc]),
+                nt=len(loc), ft=(C.c_int32 * n)(*[table_names.index(feats[i].table) for i in idxs]), dev=dev)
+            off = 0
+            for i, x in zip(idxs, ids):
+                slot_of[i] = g["slot"][off: off + x.numel()].view(inputs[i].shape)
+                off += x.numel()
+            self.groups.append(g)
+            rets.append(g["ret"])
+        plan = eng._final_plan(feats, groups)
+        final_inputs = [inputs[i] if f.kind == NRX_DENSE else slot_of[i] for i, f in enumerate(feats)]
+        self.final = ops.PreparedEmbed(plan, rets, final_inputs, list(weights), out_ld=out_ld, out=out, fm=fm)
+
+    def run(self):
+        eng, lib = self.eng, self.lib
+        W = eng.world
+        for g in self.groups:
+            stream = torch.cuda.current_stream(g["dev"]).cuda_stream
+            rc = lib.nrx_route_ids(g["ptrs"], g["lens"], g["n"], g["bits"], W, g["cap"], g["send"].data_ptr(),
+                                   g["slot"].data_ptr(), g["counts2d"].data_ptr(), g["overflow"].data_ptr(),
+                                   g["ws"].data_ptr(), stream)
+            if rc:
+                ops.check(rc, "nrx_route_ids")
+            eng._a2a(g["recv2d"].view(-1), g["counts2d"].view(-1))
+            eng._a2a(g["inbox"], g["send"])
+            rc = lib.nrx_gather_inbox(g["tp"], g["tr"], g["nt"], g["ft"], g["n"], W, g["cap"], g["recv2d"].data_ptr(),
+                                      g["inbox"].data_ptr(), g["D"], g["rows_out"].data_ptr(), None, stream)
+            if rc:
+                ops.check(rc, "nrx_gather_inbox")
+            eng._a2a(g["ret"].view(-1), g["rows_out"].view(-1))
+        return self.final.run()
+
+    def overflowed(self) -> bool:
+        return any(int(g["overflow"].item()) > g["cap"] for g in self.groups)
 
 
 # --------------------------------------------------------------------------------- dense params
@@ -331,7 +533,7 @@ class ShardedBenchPath:
         import bench
         feats, self.desc = bench.workload_spec(wl)
         self.rank, self.world, self.batch = rank, world, batch
-        self.eng = RowShardedEmbedding(rank, world)
+        self.eng = RowShardedEmbedding(rank, world, overflow_policy="defer")
         gen = torch.Generator(device=device).manual_seed(seed)
         self.tables: Dict[str, torch.Tensor] = {}
         self.feats: List[ShardedFeature] = []
@@ -359,7 +561,15 @@ class ShardedBenchPath:
             [dict(dim=f.dim, bag=f.bag_len) for f in self.feats], self.fm, 0)
         self.desc += f" -- tables row-sharded over {world} GPUs (mode={mode})"
 
+        width = sum(f.dim for f in self.feats)
+        out = torch.empty((batch, width), dtype=torch.float32, device=device)       # recycled (see bench.py)
+        fmb = torch.empty((batch,), dtype=torch.float32, device=device) if self.fm else None
+        self.calls = [PreparedShardedForward(self.eng, self.feats, ins, ws, self.tables, out=out, fm=fmb)
+                      for ins, ws in self.pool]
+
     @torch.no_grad()
     def step(self, i: int):
-        ins, ws = self.pool[i % len(self.pool)]
-        return self.eng.forward(self.feats, ins, ws, self.tables)
+        return self.calls[i % len(self.calls)].run()
+
+    def overflowed(self) -> bool:
+        return any(c.overflowed() for c in self.calls)

@@ -465,3 +465,41 @@ def csr_from_mask(mask: np.ndarray):
 def unique_inverse(ids: np.ndarray):
     u, inv = np.unique(np.asarray(ids, np.int64), return_inverse=True)
     return u, inv.astype(np.int64)
+
+
+def route_ids(id_arrays, world: int, cap: int):
+    """Fixed-capacity routing (definition of nrx_route_ids).  id_arrays: list of integer arrays, one per
+    feature, flattened feature-major.  Returns (send_rows [world*cap] with unused slots = -1,
+    slot [N] (-1 where a block overflowed), counts2d [world, F], max block count)."""
+    flat = [np.asarray(a, np.int64).reshape(-1) for a in id_arrays]
+    ids = np.concatenate(flat) if flat else np.zeros(0, np.int64)
+    fid = np.concatenate([np.full(a.size, f, np.int64) for f, a in enumerate(flat)]) if flat else ids
+    owner = np.where(ids < 0, 0, ids % world)
+    F = len(flat)
+    counts2d = np.bincount(owner * F + fid, minlength=world * F).reshape(world, F).astype(np.int64)
+    send = np.full(world * cap, -1, np.int64)
+    slot = np.full(ids.size, -1, np.int64)
+    for o in range(world):
+        pos = np.flatnonzero(owner == o)                 # ascending source order = stable
+        k = np.arange(pos.size)
+        ok = k < cap
+        slot[pos[ok]] = o * cap + k[ok]
+        loc = np.where(ids[pos] < 0, ids[pos], ids[pos] // world)
+        send[o * cap + k[ok]] = loc[ok]
+    return send, slot, counts2d, int(counts2d.sum(axis=1).max()) if world else 0
+
+
+def gather_inbox(tables, feat_table, world: int, cap: int, recv2d, inbox_rows, dim: int):
+    """Owner side (definition of nrx_gather_inbox): block s of the inbox holds sum_f recv2d[s, f] valid
+    local rows, feature-major; slot p reads tables[feat_table[f]][inbox_rows[p]].  Unwritten slots = 0."""
+    out = np.zeros((world * cap, dim), F32)
+    for s_ in range(world):
+        j = 0
+        for f, n in enumerate(np.asarray(recv2d).reshape(world, -1)[s_]):
+            n = int(n)
+            take = max(0, min(n, cap - j))
+            if take:
+                rows = inbox_rows[s_ * cap + j: s_ * cap + j + take]
+                out[s_ * cap + j: s_ * cap + j + take] = gather_rows(tables[feat_table[f]], rows)
+            j += n
+    return out

@@ -42,6 +42,41 @@ class CheckerBackend:
                     rows, vals = rows[keep], vals[keep]
                 np.add.at(g, rows, vals)
 
+    # ---- fixed-capacity exchange (definitions: oracle/ref_np.py route_ids / gather_inbox)
+    def index_checks_on(self):
+        return True
+
+    def route(self, id_tensors, world, cap):
+        send, slot, counts2d, worst = R.route_ids([t.cpu().numpy() for t in id_tensors], world, cap)
+        return (torch.from_numpy(send), torch.from_numpy(slot), torch.from_numpy(counts2d),
+                torch.tensor([worst], dtype=torch.int64))
+
+    def gather_inbox(self, tables, feat_table, world, cap, recv2d, inbox, want_status):
+        status = torch.zeros(4, dtype=torch.int32)
+        tabs = [t.detach().numpy() for t in tables]
+        try:
+            out = R.gather_inbox(tabs, feat_table, world, cap, recv2d.numpy(), inbox.numpy(), tabs[0].shape[1])
+        except IndexError:
+            status[0] = 1
+            out = np.zeros((world * cap, tabs[0].shape[1]), np.float32)
+        return torch.from_numpy(out), (status if want_status else None)
+
+    def scatter_add_inbox(self, grad_tables, feat_table, world, cap, recv2d, inbox, g_rows, skip_row0):
+        r2 = recv2d.numpy().reshape(world, -1)
+        for s in range(world):
+            j = 0
+            for f, n in enumerate(r2[s]):
+                n = int(n)
+                take = max(0, min(n, cap - j))
+                if take:
+                    rows = inbox[s * cap + j: s * cap + j + take].numpy()
+                    vals = g_rows[s * cap + j: s * cap + j + take].numpy()
+                    if skip_row0:
+                        keep = rows != 0
+                        rows, vals = rows[keep], vals[keep]
+                    np.add.at(grad_tables[feat_table[f]].numpy(), rows, vals)
+                j += n
+
     def embed(self, plan, tables, inputs, weights, out_ld=None, need_out=True):
         """torch-CPU restatement of the fused launch (differentiable w.r.t. `tables`)."""
         B = inputs[0].shape[0]

@@ -528,3 +528,74 @@ def test_full_size_c4_history_pooling_property():
     rel = ((out.double() - ref[:, None]).abs() / ref[:, None].clamp_min(1.0)).max().item()
     assert rel < 1e-6        # stated fp32 pooling tolerance
     assert torch.equal(out[:, 0], out[:, D - 1])
+
+
+def test_prepared_embed_matches_embed_apply_and_reruns():
+    rng = np.random.default_rng(21)
+    space, tables, batch = _rand_case(rng, 500, [(NRX_SPARSE, 90 + i, 16, 0) for i in range(26)])
+    plan, tt, inputs, weights, _ = build_plan(space, tables, batch, set(tables), fm=True)
+    ref_out, _, ref_fm = ops.embed_apply(plan, tt, inputs, weights)
+    call = ops.PreparedEmbed(plan, tt, inputs, weights, check_index=True)
+    for _ in range(3):
+        out, _, fm = call.run()
+    call.check()
+    assert torch.equal(out, ref_out.detach()) and torch.equal(fm, ref_fm.detach())
+    inputs[3].fill_(10 ** 6)                 # ids are re-read from the same tensors on every run
+    call.run()
+    with pytest.raises(IndexError):
+        call.check()
+
+
+@pytest.mark.parametrize("world,lens,cap", [(1, [100], 100), (2, [63, 1, 300], 256), (8, [4096, 4096, 5000, 17], 2048),
+                                            (3, [0, 777, 0, 2050], 1024), (8, [65536] * 5, 44000), (4, [5000], 64)])
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32])
+def test_route_ids_bit_exact_vs_oracle(world, lens, cap, dtype):
+    """Fixed-capacity routing incl. feature boundaries inside a 64-id group, empty features and an
+    overflowing block (last case)."""
+    rng = np.random.default_rng(sum(lens) + world)
+    arrays = [rng.integers(0, 1 << 20, n) for n in lens]
+    send, slot, counts2d, overflow = ops.route_ids([torch.from_numpy(a).to(DEV).to(dtype) for a in arrays], world, cap)
+    r_send, r_slot, r_counts, r_worst = R.route_ids(arrays, world, cap)
+    assert np.array_equal(counts2d.cpu().numpy(), r_counts)
+    assert int(overflow.item()) == r_worst
+    assert np.array_equal(slot.cpu().numpy(), r_slot)
+    valid = r_send >= 0
+    assert np.array_equal(send.cpu().numpy()[valid], r_send[valid])      # unused slots are unspecified
+
+
+def test_inbox_gather_and_scatter_vs_oracle():
+    rng = np.random.default_rng(8)
+    world, cap, D = 3, 512, 16
+    tabs = [rng.standard_normal((r, D)).astype(np.float32) for r in (40, 300)]
+    feat_table = [0, 1, 0]
+    recv2d = rng.integers(0, 170, (world, 3))
+    recv2d[1] = [0, 0, 0]
+    inbox = np.full(world * cap, 10 ** 9, np.int64)                      # garbage past the valid prefixes
+    for s in range(world):
+        j = 0
+        for f in range(3):
+            n = recv2d[s, f]
+            inbox[s * cap + j: s * cap + j + n] = rng.integers(0, tabs[feat_table[f]].shape[0], n)
+            j += n
+    status = torch.zeros(4, dtype=torch.int32, device=DEV)
+    out = ops.gather_inbox([dev(t) for t in tabs], feat_table, world, cap, dev(recv2d), dev(inbox), status)
+    want = R.gather_inbox(tabs, feat_table, world, cap, recv2d, inbox, D)
+    got = out.cpu().numpy()
+    for s in range(world):
+        n = recv2d[s].sum()
+        assert np.array_equal(got[s * cap: s * cap + n], want[s * cap: s * cap + n])
+    assert status[0].item() == 0
+    g_rows = rng.standard_normal((world * cap, D)).astype(np.float32)
+    grads = [torch.zeros_like(dev(t)) for t in tabs]
+    ops.scatter_add_inbox(grads, feat_table, world, cap, dev(recv2d), dev(inbox), dev(g_rows), True)
+    ref = [np.zeros_like(t) for t in tabs]
+    for s in range(world):
+        j = 0
+        for f in range(3):
+            n = recv2d[s, f]
+            rows = inbox[s * cap + j: s * cap + j + n]
+            np.add.at(ref[feat_table[f]], rows, g_rows[s * cap + j: s * cap + j + n])
+            j += n
+    for g, r in zip(grads, ref):
+        r[0] = 0                                                          # skip_row0
+        np.testing.assert_allclose(g.cpu().numpy(), r, rtol=1e-5, atol=1e-5)

@@ -74,14 +74,16 @@ def oracle_forward_and_grads(world):
     return outs, grads
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="capacity", slack=0.5):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         tabs = full_tables()
         shards = {n: sharding.shard_table(torch.from_numpy(t), rank, world).requires_grad_(True) for n, t in tabs.items()}
-        eng = RowShardedEmbedding(rank, world, backend=CheckerBackend())
+        eng = RowShardedEmbedding(rank, world, backend=CheckerBackend(), mode=mode, slack=slack)
+        if slack < 0:          # force tiny blocks: every exchange overflows and must fall back to exact
+            eng.capacity_for = lambda n: 8
         b = batch_for(rank)
         inputs = [torch.from_numpy(np.asarray(b[f.name])) for f in FEATS]
         weights = [torch.from_numpy(b["user_history_mask"]) if f.kind == NRX_BAG_MASKED_MEAN else None for f in FEATS]
@@ -102,12 +104,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_row_sharded_forward_backward_over_gloo(world):
+@pytest.mark.parametrize("world,mode,slack", [(2, "capacity", 0.5), (3, "capacity", 0.5), (2, "exact", 0.0),
+                                              (2, "capacity", -1.0)])
+def test_row_sharded_forward_backward_over_gloo(world, mode, slack):
+    """capacity = sync-free fixed blocks; exact = variable splits; slack -1 = capacity forced to
+    overflow, which must be detected on every rank and redone exactly."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, slack)) for r in range(world)]
     for p in procs:
         p.start()
     results = {}

@@ -65,11 +65,12 @@ def _direct(tables, feats, inputs, weights, fm):
 
 
 @pytest.mark.parametrize("fm", [False, True])
-def test_world1_engine_equals_direct_path(fm):
+@pytest.mark.parametrize("mode", ["capacity", "exact"])
+def test_world1_engine_equals_direct_path(fm, mode):
     tables, feats, inputs, weights = _case(fm=fm)
     (out_d, _, fm_d), leaves_d, names = _direct(tables, feats, inputs, weights, fm)
     shards = {n: tables[n].clone().requires_grad_(True) for n in names}
-    eng = RowShardedEmbedding(0, 1)
+    eng = RowShardedEmbedding(0, 1, mode=mode)
     out_s, _, fm_s = eng.forward(feats, inputs, weights, shards)
     # single-valued columns are routed copies: bit-exact; pooled columns see the same rows in the same order
     assert torch.equal(out_s, out_d)
@@ -89,9 +90,10 @@ def test_oob_raises_on_the_routed_path():
     tables, feats, inputs, weights = _case(B=50)
     inputs[1] = inputs[1].clone()
     inputs[1][7] = 77           # table b has 77 rows
-    eng = RowShardedEmbedding(0, 1)
-    with pytest.raises(IndexError):
-        eng.forward(feats, inputs, weights, {n: t for n, t in tables.items()})
+    for mode in ("capacity", "exact"):
+        eng = RowShardedEmbedding(0, 1, mode=mode)
+        with pytest.raises(IndexError):
+            eng.forward(feats, inputs, weights, {n: t for n, t in tables.items()})
 
 
 @pytest.mark.parametrize("cls,cfg,gname", [(Deep, "cf_array_small.yaml", "model_deep_array"), (FM, "cf_fm_small.yaml", "model_fm")])
@@ -111,3 +113,14 @@ def test_shard_model_world1_matches_reference_golden(cls, cfg, gname):
     for name, emb in m.embedding_tables.items():
         want = g[f"grad/embedding_tables.{name}.weight"]
         np.testing.assert_allclose(emb.weight.grad.cpu().numpy(), want, rtol=2e-3, atol=2e-6 + 1e-4 * np.abs(want).max())
+
+
+def test_prepared_sharded_forward_matches_engine():
+    tables, feats, inputs, weights = _case(B=900)
+    eng = RowShardedEmbedding(0, 1, overflow_policy="defer")
+    ref_out, _, _ = eng.forward(feats, inputs, weights, tables)
+    call = sharding.PreparedShardedForward(eng, feats, inputs, weights, tables)
+    for _ in range(2):
+        out, _, _ = call.run()
+    assert torch.equal(out, ref_out)
+    assert not call.overflowed() and not eng.overflowed()
