@@ -145,12 +145,10 @@ class SingleGpuPath:
 
 # ------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(path: SingleGpuPath, budget_s: float = 12.0):
-    """Times the CPU oracle (oracle/ref_np.py = numpy restatement of the reference path, 'port') on a
-    bounded sample of the same workload: same tables (copied to host), same id batches."""
-    from oracle import ref_np as R
-    space = R.FeatureSpace([f["name"] for f in path.feats if not f["bag"]], [],
-                           [f["name"] for f in path.feats if f["bag"]],
-                           {f["name"]: f["share"] for f in path.feats if "share" in f})
+    """Times the CPU oracle's C/OpenMP restatement of the reference path (oracle/nrx_oracle.c, checked
+    against the same goldens as oracle/ref_np.py; 'port') on ALL host cores, on a bounded sample of the
+    same workload: same tables (copied to host), same id batches, gather(+pool)->concat (+FM / cross)."""
+    from oracle import ref_c
     tnames = []
     for f in path.feats:
         t = f.get("share", f["name"])
@@ -158,22 +156,23 @@ def cpu_baseline(path: SingleGpuPath, budget_s: float = 12.0):
             tnames.append(t)
     tables = {n: t.cpu().numpy() for n, t in zip(tnames, path.tables)}
     ins, ws = path.pool[0]
-    Bs = BATCH if path.wl != "c4" else 8192
-    batch = {}
-    for f, x, w in zip(path.feats, ins, ws):
-        batch[f["name"]] = x[:Bs].cpu().numpy()
-        if w is not None:
-            batch[f["name"] + "_mask"] = w[:Bs].cpu().numpy()
-    names = {f["name"] for f in path.feats}
-    dims = [f["dim"] for f in sorted(path.feats, key=lambda f: f["name"])]
+    Bs = BATCH
+    feats = []
+    for f, x, w in sorted(zip(path.feats, ins, ws), key=lambda t: t[0]["name"]):
+        kind = ref_c.BAG_MASKED_MEAN if f["bag"] else ref_c.SPARSE
+        feats.append(dict(kind=kind, table=tables[f.get("share", f["name"])], index=x[:Bs].cpu().numpy(),
+                          weight=None if w is None else w[:Bs].cpu().numpy()))
+    call = ref_c.EmbedCall(feats, Bs)
+    cores = ref_c.threads()
+    cw = path.cross_w.cpu().numpy() if path.cross else None
+    cb = path.cross_b.cpu().numpy() if path.cross else None
 
     def one():
-        feats, _, _ = R.embed_concat(space, tables, batch, names)
+        out = call.run()
         if path.fm:
-            w, v = R.fm_split(feats, dims)
-            R.fm_logit(w, v, 0.0)
+            ref_c.fm_logit(out, len(call.dims), call.dims[0])
         if path.cross:
-            R.dcn_v1(feats, path.cross_w.cpu().numpy(), path.cross_b.cpu().numpy())
+            ref_c.dcn_v1(out, cw, cb)
 
     one()
     t0 = time.perf_counter()
@@ -181,12 +180,12 @@ def cpu_baseline(path: SingleGpuPath, budget_s: float = 12.0):
     while True:
         one()
         reps += 1
-        if time.perf_counter() - t0 > budget_s or reps >= 200:
+        if time.perf_counter() - t0 > budget_s or reps >= 2000:
             break
     dt = (time.perf_counter() - t0) / reps
-    return {"value": Bs / dt, "unit": "impressions/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} passes of {Bs} impressions of the same workload (oracle/ref_np.py, numpy, 1 thread); "
-                      f"{dt * 1e3:.1f} ms/pass; host has {os.cpu_count()} logical cores"}
+    return {"value": Bs / dt, "unit": "impressions/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} passes of {Bs} impressions of the same workload (oracle/nrx_oracle.c, OpenMP, "
+                      f"{cores} threads); {dt * 1e3:.2f} ms/pass; host has {os.cpu_count()} logical cores"}
 
 
 # ------------------------------------------------------------------------------------ main

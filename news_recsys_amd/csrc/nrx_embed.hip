@@ -259,15 +259,23 @@ static_assert(sizeof(UniformArgs) <= 3584, "kernarg budget");
 // One straight-line group of CNT features: CNT id loads, then CNT independent row loads, then CNT
 // stores -- no control flow, so all CNT random row reads of a lane are in flight together.
 // Out-of-range ids are clamped branch-free and reported once per lane after the feature walk.
-template <int Q, int CNT, bool IDX64, bool FM, bool STORE, bool NT>
-__device__ __forceinline__ void uniform_group(const NRX_CONST UniformArgs* a, int f0, int64_t b, int q, int& bad_feat, int64_t& bad_id,
-                                              float& fm_first, float4& fm_s, float4& fm_q) {
-    int64_t id[CNT];
-    float4 v[CNT];
+template <int CNT, bool IDX64>
+__device__ __forceinline__ void uniform_load_ids(const NRX_CONST UniformArgs* a, int f0, int64_t b, int64_t (&id)[CNT]) {
 #pragma unroll
     for (int u = 0; u < CNT; ++u)
         id[u] = IDX64 ? nrx_gconst<int64_t>(a->index[f0 + u])[b]
                       : (int64_t)nrx_gconst<int32_t>(a->index[f0 + u])[b];
+}
+
+// One straight-line group of CNT features: the ids are already in registers; CNT independent row
+// loads are issued, then (software pipeline) the NEXT group's ids are requested before this group's
+// stores, so their latency hides behind the row loads instead of queueing behind the stores.
+// Out-of-range ids are clamped branch-free and reported once per lane after the feature walk.
+template <int Q, int CNT, int NEXT, bool IDX64, bool FM, bool STORE, bool NT>
+__device__ __forceinline__ void uniform_group(const NRX_CONST UniformArgs* a, int f0, int64_t b, int q,
+                                              int64_t (&id)[CNT], int64_t (&id_next)[NEXT == 0 ? 1 : NEXT],
+                                              int& bad_feat, int64_t& bad_id, float& fm_first, float4& fm_s, float4& fm_q) {
+    float4 v[CNT];
 #pragma unroll
     for (int u = 0; u < CNT; ++u) {
         const bool bad = (uint64_t)id[u] >= (uint64_t)a->rows[f0 + u];
@@ -276,6 +284,7 @@ __device__ __forceinline__ void uniform_group(const NRX_CONST UniformArgs* a, in
         id[u] = bad ? 0 : id[u];
         v[u] = NT ? nrx_ldg4_nt(a->table[f0 + u], id[u] * Q + q) : nrx_ldg4(a->table[f0 + u], id[u] * Q + q);
     }
+    if (NEXT > 0) uniform_load_ids<(NEXT == 0 ? 1 : NEXT), IDX64>(a, f0 + CNT, b, id_next);
 #pragma unroll
     for (int u = 0; u < CNT; ++u) {
         if (STORE) nrx_stg4(a->out, b * a->ld4 + a->col4[f0 + u] + q, v[u]);
@@ -287,8 +296,13 @@ template <int Q, int U, int R, bool IDX64, bool FM, bool STORE, bool NT>
 struct UniformTail {
     static __device__ __forceinline__ void run(const NRX_CONST UniformArgs* a, int f0, int rem, int64_t b, int q, int& bad_feat,
                                                int64_t& bad_id, float& fm_first, float4& fm_s, float4& fm_q) {
-        if (rem == R) uniform_group<Q, R, IDX64, FM, STORE, NT>(a, f0, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
-        else UniformTail<Q, U, R + 1, IDX64, FM, STORE, NT>::run(a, f0, rem, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
+        if (rem == R) {
+            int64_t id[R], none[1];
+            uniform_load_ids<R, IDX64>(a, f0, b, id);
+            uniform_group<Q, R, 0, IDX64, FM, STORE, NT>(a, f0, b, q, id, none, bad_feat, bad_id, fm_first, fm_s, fm_q);
+        } else {
+            UniformTail<Q, U, R + 1, IDX64, FM, STORE, NT>::run(a, f0, rem, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
+        }
     }
 };
 template <int Q, int U, bool IDX64, bool FM, bool STORE, bool NT>
@@ -314,8 +328,17 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_uniform(const UniformArgs
 
     int f0 = 0;
     const int n = a->n;
-    for (; f0 + U <= n; f0 += U)
-        uniform_group<Q, U, IDX64, FM, STORE, NT>(a, f0, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
+    if (n >= U) {
+        int64_t id[U], id_next[U], none[1];
+        uniform_load_ids<U, IDX64>(a, 0, b, id);
+        for (; f0 + 2 * U <= n; f0 += U) {       // a full group follows: prefetch its ids
+            uniform_group<Q, U, U, IDX64, FM, STORE, NT>(a, f0, b, q, id, id_next, bad_feat, bad_id, fm_first, fm_s, fm_q);
+#pragma unroll
+            for (int u = 0; u < U; ++u) id[u] = id_next[u];
+        }
+        uniform_group<Q, U, 0, IDX64, FM, STORE, NT>(a, f0, b, q, id, none, bad_feat, bad_id, fm_first, fm_s, fm_q);
+        f0 += U;
+    }
     const int rem = n - f0;
     if (rem > 0) UniformTail<Q, U, 1, IDX64, FM, STORE, NT>::run(a, f0, rem, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
 

@@ -1,0 +1,102 @@
+/* CPU ORACLE (plain C + OpenMP) -- TEST INFRASTRUCTURE ONLY, NOT A PRODUCT PATH.
+ *
+ * Restatement of the reference's hot path for the timed CPU baseline of bench.py and for parity
+ * checks at sizes where the numpy oracle is slow.  Same functions as oracle/ref_np.py (which is
+ * pinned against golden vectors captured from the reference); tests/test_oracle_golden.py checks this
+ * file against the same goldens.  Reference (paths relative to /root/reference):
+ *   get_embeddings_from_batch / get_feature_embedding / array_feature_pooling
+ *                                   src/model/BaseModel/base_model.py:262-308
+ *   FMModel.forward (pre-sigmoid)   src/model/sort/fm/model.py:18-26, 48-59
+ *   DCNLayer / DCNNet               src/model/sort/dcn/dcn_arch.py:14-30, 63-70  (algebraic form)
+ * Parallelisation: over samples (what ATen's CPU kernels do for the reference's gather / cat).
+ */
+#include <stdint.h>
+#include <string.h>
+#include <omp.h>
+
+enum { O_SPARSE = 0, O_DENSE = 1, O_BAG_MASKED_MEAN = 2, O_BAG_MEAN = 3 };
+
+typedef struct {
+    const float* table;   /* [rows, dim] */
+    const int64_t* index; /* [B] or [B, bag_len]; O_DENSE: const double* values */
+    const float* weight;  /* [B, bag_len] or NULL */
+    int64_t rows;
+    int32_t dim, bag_len, kind, out_col;
+} oracle_feature_t;
+
+int oracle_threads(void) { return omp_get_max_threads(); }
+void oracle_set_threads(int n) { omp_set_num_threads(n); }
+
+/* returns the number of out-of-range ids (reference: IndexError), 0 on success */
+int64_t oracle_embed_concat(const oracle_feature_t* f, int32_t n, int64_t B, float* out, int64_t ld) {
+    int64_t bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (int64_t b = 0; b < B; ++b) {
+        float* o = out + b * ld;
+        for (int32_t i = 0; i < n; ++i) {
+            const oracle_feature_t* s = &f[i];
+            float* dst = o + s->out_col;
+            const int D = s->dim;
+            if (s->kind == O_DENSE) {
+                dst[0] = (float)((const double*)s->index)[b];
+            } else if (s->kind == O_SPARSE) {
+                int64_t id = s->index[b];
+                if (id < 0 || id >= s->rows) { ++bad; id = 0; }
+                memcpy(dst, s->table + id * D, sizeof(float) * D);
+            } else {
+                const int L = s->bag_len;
+                float den = 0.f;
+                for (int k = 0; k < D; ++k) dst[k] = 0.f;
+                for (int l = 0; l < L; ++l) {
+                    int64_t id = s->index[b * L + l];
+                    const float w = s->weight ? s->weight[b * L + l] : 1.0f;
+                    if (id < 0 || id >= s->rows) { ++bad; id = 0; }
+                    const float* row = s->table + id * D;
+                    den += w;
+                    for (int k = 0; k < D; ++k) dst[k] += row[k] * w;
+                }
+                const float d = (s->kind == O_BAG_MASKED_MEAN) ? den + 1e-8f : (float)L;
+                for (int k = 0; k < D; ++k) dst[k] /= d;
+            }
+        }
+    }
+    return bad;
+}
+
+/* feat [B, ld] holding n_fields fields of `dim` columns: col 0 = w, cols 1.. = v */
+void oracle_fm_logit(const float* feat, int64_t ld, int32_t n_fields, int32_t dim, int64_t B, float* logit) {
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; ++b) {
+        const float* x = feat + b * ld;
+        float first = 0.f, second = 0.f;
+        for (int f = 0; f < n_fields; ++f) first += x[f * dim];
+        for (int k = 1; k < dim; ++k) {
+            float s = 0.f, sq = 0.f;
+            for (int f = 0; f < n_fields; ++f) {
+                const float v = x[f * dim + k];
+                s += v;
+                sq += v * v;
+            }
+            second += s * s - sq;
+        }
+        logit[b] = first + 0.5f * second;
+    }
+}
+
+/* x_{l+1} = x0 * (x_l . w_l) + b_l + x_l ; w, b: [n_layers, dim]; out may not alias x */
+void oracle_dcn_v1(const float* x, int64_t x_ld, int64_t B, int32_t dim, int32_t n_layers,
+                   const float* w, const float* bias, float* out, int64_t out_ld) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < B; ++r) {
+        const float* x0 = x + r * x_ld;
+        float* xl = out + r * out_ld;
+        memcpy(xl, x0, sizeof(float) * dim);
+        for (int l = 0; l < n_layers; ++l) {
+            const float* wl = w + (int64_t)l * dim;
+            const float* bl = bias + (int64_t)l * dim;
+            float s = 0.f;
+            for (int k = 0; k < dim; ++k) s += xl[k] * wl[k];
+            for (int k = 0; k < dim; ++k) xl[k] = x0[k] * s + bl[k] + xl[k];
+        }
+    }
+}

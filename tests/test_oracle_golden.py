@@ -281,3 +281,55 @@ def test_integer_utils():
     assert off[-1] == mask.sum() and np.all(mask.reshape(-1)[pos] == 1)
     u, inv = R.unique_inverse(ids)
     assert np.array_equal(u[inv], ids)
+
+
+# ---------------------------------------------------------------- the C/OpenMP restatement (oracle/nrx_oracle.c)
+def _c_feats(space, tables, batch, names):
+    from oracle import ref_c
+    feats = []
+    for n in sorted(names):
+        if n not in batch:
+            continue
+        if n in space.dense:
+            feats.append(dict(kind=ref_c.DENSE, index=batch[n]))
+        elif n in space.array:
+            m = batch.get(n + "_mask")
+            feats.append(dict(kind=ref_c.BAG_MASKED_MEAN if m is not None else ref_c.BAG_MEAN,
+                              table=tables[R.emb_table_name(n, space.share)], index=batch[n], weight=m))
+        else:
+            feats.append(dict(kind=ref_c.SPARSE, table=tables[R.emb_table_name(n, space.share)], index=batch[n]))
+    return feats
+
+
+@pytest.mark.parametrize("gname,cfg", [("model_deep", "cf_deep_small.yaml"), ("model_fm", "cf_fm_small.yaml"),
+                                       ("model_deep_array", "cf_array_small.yaml")])
+def test_c_oracle_matches_goldens(gname, cfg):
+    from oracle import ref_c
+    g = load(gname)
+    space, names, _ = space_of(cfg)
+    call = ref_c.EmbedCall(_c_feats(space, tables_of(params_of(g)), batch_of(g), names), g["out/features"].shape[0])
+    out = call.run()
+    if space.array:
+        np.testing.assert_allclose(out, g["out/features"], rtol=1e-6, atol=1e-6)
+    else:
+        assert np.array_equal(out, g["out/features"])
+    if gname == "model_fm":
+        logit = ref_c.fm_logit(out, len(call.dims), call.dims[0])
+        pred = R.sigmoid(logit[:, None] + params_of(g)["score_fc.bias"])
+        np.testing.assert_allclose(pred, g["out/forward"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_c_oracle_dcn_v1(tag):
+    from oracle import ref_c
+    g = load("ops")
+    ref = g[f"dcn1/{tag}/out"]
+    np.testing.assert_allclose(ref_c.dcn_v1(g[f"dcn1/{tag}/x"], g[f"dcn1/{tag}/w"], g[f"dcn1/{tag}/b"]), ref,
+                               rtol=1e-5, atol=2e-6 * np.abs(ref).max())
+
+
+def test_c_oracle_oob_raises():
+    from oracle import ref_c
+    t = np.zeros((5, 4), np.float32)
+    with pytest.raises(IndexError):
+        ref_c.EmbedCall([dict(kind=ref_c.SPARSE, table=t, index=np.array([1, 5]))], 2).run()
