@@ -221,7 +221,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_fwd_kernel(const float* __re
 // x_l and s_l are recomputed from x0 (l forward steps) instead of being stored: the kernel is
 // HBM-bound and the extra FMAs are free; gw/gb accumulate in LDS per block, then one global atomic
 // per element per block.
-template <int R, int V>
+// NLR > 0: gw/gb of the wave's rows accumulate in registers (NLR = n_layers, compile time) and are
+// flushed to LDS once per wave; NLR == 0: generic path, per-row LDS atomics (any n_layers).
+template <int R, int V, int NLR>
 __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_bwd_kernel(const float* __restrict__ x, int64_t x_ld, int64_t batch, int D, int NL,
                                                                const float* __restrict__ w, const float* __restrict__ bvec,
                                                                const float* __restrict__ g_out, int64_t g_out_ld,
@@ -244,6 +246,15 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_bwd_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (NRX_BLOCK / 64);
+    constexpr int NA = NLR > 0 ? NLR : 1;
+    float acc_w[NA][R][V], acc_b[NA][R][V];
+#pragma unroll
+    for (int l = 0; l < NA; ++l)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < V; ++j) { acc_w[l][r][j] = 0.f; acc_b[l][r][j] = 0.f; }
+
     for (int64_t row = wave; row < batch; row += nwaves) {
         RowRegs<R, V> x0, g, gx0;
         row_load<R, V>(x0, x + row * x_ld, D, lane);
@@ -252,40 +263,62 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_bwd_kernel(const float* __re
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int j = 0; j < V; ++j) gx0.v[r][j] = 0.f;
-        for (int l = NL - 1; l >= 0; --l) {
-            // recompute x_l, s_l
-            RowRegs<R, V> xl = x0, wl, bl;
-            float s = 0.f;
-            for (int t = 0; t <= l; ++t) {
-                row_load<R, V>(wl, s_w + t * Dp, Dp, lane);
-                s = row_dot<R, V>(xl, wl);
-                if (t < l) {
-                    row_load<R, V>(bl, s_b + t * Dp, Dp, lane);
 #pragma unroll
-                    for (int r = 0; r < R; ++r)
+        for (int li = 0; li < (NLR > 0 ? NLR : 1); ++li) {
+            // generic path walks the runtime layer count with the same body
+            for (int l = (NLR > 0 ? NLR - 1 - li : NL - 1); l >= (NLR > 0 ? NLR - 1 - li : 0); --l) {
+                RowRegs<R, V> xl = x0, wl, bl;
+                float s = 0.f;
+                for (int t = 0; t <= l; ++t) {          // recompute x_l, s_l from x0
+                    row_load<R, V>(wl, s_w + t * Dp, Dp, lane);
+                    s = row_dot<R, V>(xl, wl);
+                    if (t < l) {
+                        row_load<R, V>(bl, s_b + t * Dp, Dp, lane);
 #pragma unroll
-                        for (int j = 0; j < V; ++j) xl.v[r][j] = x0.v[r][j] * s + bl.v[r][j] + xl.v[r][j];
-                }
-            }
-            const float gs = row_dot<R, V>(g, x0);
+                        for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    const int c = (r * 64 + lane) * V + j;
-                    if (c < D) {
-                        atomicAdd(&s_gb[l * Dp + c], g.v[r][j]);
-                        atomicAdd(&s_gw[l * Dp + c], gs * xl.v[r][j]);
+                            for (int j = 0; j < V; ++j) xl.v[r][j] = x0.v[r][j] * s + bl.v[r][j] + xl.v[r][j];
                     }
-                    gx0.v[r][j] += g.v[r][j] * s;
-                    g.v[r][j] += gs * wl.v[r][j];
                 }
+                const float gs = row_dot<R, V>(g, x0);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        if (NLR > 0) {
+                            acc_b[NLR > 0 ? NLR - 1 - li : 0][r][j] += g.v[r][j];
+                            acc_w[NLR > 0 ? NLR - 1 - li : 0][r][j] += gs * xl.v[r][j];
+                        } else {
+                            const int c = (r * 64 + lane) * V + j;
+                            if (c < D) {
+                                atomicAdd(&s_gb[l * Dp + c], g.v[r][j]);
+                                atomicAdd(&s_gw[l * Dp + c], gs * xl.v[r][j]);
+                            }
+                        }
+                        gx0.v[r][j] += g.v[r][j] * s;
+                        g.v[r][j] += gs * wl.v[r][j];
+                    }
+            }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int j = 0; j < V; ++j) g.v[r][j] += gx0.v[r][j];
         row_store<R, V>(g, g_x + row * g_x_ld, D, lane);
+    }
+    if (NLR > 0) {
+#pragma unroll
+        for (int l = 0; l < NA; ++l)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const int c = (r * 64 + lane) * V + j;
+                    if (c < D) {
+                        atomicAdd(&s_gb[l * Dp + c], acc_b[l][r][j]);
+                        atomicAdd(&s_gw[l * Dp + c], acc_w[l][r][j]);
+                    }
+                }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < NL * Dp; i += NRX_BLOCK) {
@@ -427,12 +460,24 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, int64_t batch, int32
     const size_t smem = (size_t)4 * n_layers * ((dim + 3) & ~3) * sizeof(float);
     NRX_REQUIRE(smem <= 128 * 1024, "nrx_dcn_v1_bwd: n_layers*dim too large for the LDS stage");
     const unsigned grid = stream_grid(batch, NRX_BLOCK / 64);
-    NRX_RSWITCH(R, V, {
-        auto kern = dcn_v1_bwd_kernel<RR, VV>;
-        if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NRX_BLOCK), smem, reinterpret_cast<hipStream_t>(stream),
-                           x, x_ld, batch, dim, n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b);
-    });
+    // register accumulation of gw/gb when the accumulators fit (n_layers <= 4 and <= 2 chunks per lane)
+    const int nlr = (n_layers >= 1 && n_layers <= 4 && R <= 2) ? n_layers : 0;
+#define NRX_DCN_BWD(NLR_)                                                                                           \
+    NRX_RSWITCH(R, V, {                                                                                             \
+        auto kern = dcn_v1_bwd_kernel<RR, VV, NLR_>;                                                                \
+        if (smem > 64 * 1024)                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NRX_BLOCK), smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, \
+                           batch, dim, n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b);                     \
+    })
+    switch (nlr) {
+        case 1: NRX_DCN_BWD(1); break;
+        case 2: NRX_DCN_BWD(2); break;
+        case 3: NRX_DCN_BWD(3); break;
+        case 4: NRX_DCN_BWD(4); break;
+        default: NRX_DCN_BWD(0); break;
+    }
+#undef NRX_DCN_BWD
     NRX_LAUNCH_CHECK("nrx_dcn_v1_bwd");
     return NRX_OK;
 }

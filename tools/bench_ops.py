@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Per-operator timings at BASELINE shapes (B=65536): DCN v1/v2 forward+backward, embed backward, FM,
+bag pooling.  Prints us, algorithmic GB/s (HBM-bound ops) or TFLOP/s (DCN-v2, MFMA-bound)."""
+import os, sys, json
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from news_recsys_amd import ops
+from news_recsys_amd._lib import NRX_SPARSE, NRX_BAG_MASKED_MEAN
+ops.set_index_check("off")
+dev = torch.device("cuda:0")
+B = 65536
+only = set(sys.argv[1:])
+
+def timeit(fn, steps=30, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(steps): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / steps * 1e3
+
+def want(name): return not only or name in only
+
+if want("dcn_v2"):
+    for D in (320, 112, 256, 512):
+        x = torch.randn(B, D, device=dev); W = torch.randn(1, D, D, device=dev) / D ** 0.5; b = torch.zeros(1, D, device=dev)
+        with torch.no_grad():
+            us = timeit(lambda: ops.dcn_v2(x, W, b))
+            us_ref = timeit(lambda: torch.relu(x * torch.addmm(b[0], x, W[0].t()) + x))
+        fl = 2.0 * B * D * D + 3.0 * B * D
+        print(f"dcn_v2 fwd  D={D:4d}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s ({fl / us / 1e6 / 157.3 * 100:5.1f}% of 157.3 fp32-matrix peak)   [rocBLAS+eltwise: {us_ref:8.1f} us]", flush=True)
+if want("dcn_v1"):
+    for D, NL in ((320, 2), (320, 3), (112, 3)):
+        x = torch.randn(B, D, device=dev); w = torch.randn(NL, D, device=dev) / D ** 0.5; b = torch.zeros(NL, D, device=dev)
+        with torch.no_grad():
+            us = timeit(lambda: ops.dcn_v1(x, w, b))
+        print(f"dcn_v1 fwd  D={D} L={NL}: {us:8.1f} us  {2 * B * D * 4 / us / 1e3:7.1f} GB/s algorithmic (read x + write out)", flush=True)
+        xg = x.clone().requires_grad_(True); wg = w.clone().requires_grad_(True); bg = b.clone().requires_grad_(True)
+        out = ops.dcn_v1(xg, wg, bg); up = torch.randn_like(out)
+        us = timeit(lambda: torch.autograd.grad(out, (xg, wg, bg), up, retain_graph=True))
+        print(f"dcn_v1 bwd  D={D} L={NL}: {us:8.1f} us  {3 * B * D * 4 / us / 1e3:7.1f} GB/s algorithmic (read x,g + write gx)", flush=True)
+if want("embed_bwd"):
+    F, D, rows = 26, 16, 1_000_000
+    gen = torch.Generator(device=dev).manual_seed(1)
+    tables = [torch.randn(rows, D, device=dev).requires_grad_(True) for _ in range(F)]
+    plan = ops.EmbedPlan([ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, i * D, fm_field=1) for i in range(F)], out_width=F * D, use_fm=True)
+    ids = [torch.randint(1, rows, (B,), device=dev, generator=gen) for _ in range(F)]
+    out, _, fm = ops.embed_apply(plan, tables, ids, [None] * F)
+    up = torch.randn_like(out); upf = torch.randn_like(fm)
+    us = timeit(lambda: torch.autograd.grad((out, fm), tables, (up, upf), retain_graph=True), steps=10)
+    print(f"embed bwd (C2, dense grads incl. 1.66 GB zero-fill + FM bwd): {us:8.1f} us", flush=True)
+    from news_recsys_amd import _lib
+    lib = _lib.load()
+    grads = [torch.zeros_like(t) for t in tables]
+    arr = ops._fill_features(plan, 0, F, grads, ids, [None] * F, table_ptrs=[g.data_ptr() for g in grads])
+    st = torch.cuda.current_stream().cuda_stream
+    us = timeit(lambda: lib.nrx_embed_bwd(arr, F, B, up.data_ptr(), F * D, None, 0, st))
+    print(f"embed bwd scatter kernel alone (atomics into 26 x 1M x 16): {us:8.1f} us  {B * F * (8 + 64 + 2 * 64) / us / 1e3:7.1f} GB/s algorithmic (ids + g read + row RMW)", flush=True)
+if want("fm"):
+    x = torch.randn(B, 416, device=dev)
+    with torch.no_grad():
+        us = timeit(lambda: ops.fm_interaction(x, 26, 16))
+    print(f"fm standalone fwd [B,416]: {us:8.1f} us  {B * 416 * 4 / us / 1e3:7.1f} GB/s", flush=True)
+if want("pool"):
+    emb = torch.randn(B, 50, 16, device=dev); m = (torch.rand(B, 50, device=dev) < 0.6).float()
+    with torch.no_grad():
+        us = timeit(lambda: ops.bag_pool(emb, m))
+    print(f"bag_pool standalone [B,50,16]: {us:8.1f} us  {B * 50 * 17 * 4 / us / 1e3:7.1f} GB/s", flush=True)
