@@ -1,0 +1,90 @@
+"""Property tests (hypothesis) of the integer routing definitions in oracle/ref_np.py -- the
+specification the HIP routing kernels are held to bit-exactly -- and, on a GPU, of the kernels
+themselves against those definitions on hypothesis-generated shapes."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import ref_np as R
+
+lens_st = st.lists(st.integers(min_value=0, max_value=700), min_size=1, max_size=9)
+
+
+@settings(max_examples=60, deadline=None)
+@given(lens=lens_st, world=st.integers(1, 9), slack=st.floats(0.0, 1.0), seed=st.integers(0, 2 ** 16))
+def test_route_ids_definition_properties(lens, world, slack, seed):
+    rng = np.random.default_rng(seed)
+    arrays = [rng.integers(0, 5000, n) for n in lens]
+    total = sum(lens)
+    cap = max(1, int(total / world * (1 + slack)) + 1)
+    send, slot, counts2d, worst = R.route_ids(arrays, world, cap)
+    ids = np.concatenate(arrays) if total else np.zeros(0, np.int64)
+    assert counts2d.shape == (world, len(lens)) and counts2d.sum() == total
+    assert worst == (counts2d.sum(axis=1).max() if total else 0)
+    placed = slot >= 0
+    assert len(set(slot[placed].tolist())) == placed.sum()               # slots are unique
+    assert np.array_equal(send[slot[placed]], ids[placed] // world)       # send buffer holds the local row
+    assert np.all(slot[placed] // cap == ids[placed] % world)             # ... in the owner's block
+    if worst <= cap:
+        assert placed.all()
+    for o in range(world):                                                # stable: source order kept per owner
+        pos = np.flatnonzero((ids % world == o) & placed)
+        assert np.all(np.diff(slot[pos]) > 0)
+    # the owner can rebuild (feature, local row) of every slot from counts2d alone
+    for o in range(world):
+        j = 0
+        for f, n in enumerate(counts2d[o]):
+            src = np.flatnonzero((np.concatenate([np.full(a.size, k) for k, a in enumerate(arrays)]) == f) & (ids % world == o)) if total else []
+            for k, p in enumerate(src):
+                if j + k < cap:
+                    assert slot[p] == o * cap + j + k
+            j += int(n)
+
+
+@settings(max_examples=40, deadline=None)
+@given(n=st.integers(0, 3000), world=st.integers(1, 9), seed=st.integers(0, 2 ** 16))
+def test_bucketize_definition_properties(n, world, seed):
+    ids = np.random.default_rng(seed).integers(0, 10 ** 6, n)
+    counts, perm = R.bucketize_by_owner(ids, world)
+    assert counts.sum() == n and sorted(perm.tolist()) == list(range(n))
+    owner = ids % world
+    assert np.all(np.diff(owner[perm]) >= 0)
+    start = 0
+    for o in range(world):
+        seg = perm[start:start + counts[o]]
+        assert np.all(owner[seg] == o) and np.all(np.diff(seg) > 0)
+        start += counts[o]
+
+
+@pytest.mark.gpu
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(lens=st.lists(st.integers(min_value=0, max_value=3000), min_size=1, max_size=12), world=st.integers(1, 8),
+       slack=st.floats(-0.5, 0.5), seed=st.integers(0, 2 ** 16), i32=st.booleans())
+def test_hip_route_ids_matches_definition(lens, world, slack, seed, i32):
+    import torch
+    from news_recsys_amd import ops
+    rng = np.random.default_rng(seed)
+    arrays = [rng.integers(0, 1 << 20, n) for n in lens]
+    total = sum(lens)
+    cap = max(1, int(total / world * (1 + slack)) + 1)
+    dt = torch.int32 if i32 else torch.int64
+    send, slot, counts2d, overflow = ops.route_ids([torch.from_numpy(a).cuda().to(dt) for a in arrays], world, cap)
+    r_send, r_slot, r_counts, r_worst = R.route_ids(arrays, world, cap)
+    assert np.array_equal(counts2d.cpu().numpy(), r_counts)
+    assert int(overflow.item()) == r_worst
+    assert np.array_equal(slot.cpu().numpy(), r_slot)
+    valid = r_send >= 0
+    assert np.array_equal(send.cpu().numpy()[valid], r_send[valid])
+
+
+@pytest.mark.gpu
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(n=st.integers(0, 20000), world=st.integers(1, 16), seed=st.integers(0, 2 ** 16))
+def test_hip_bucketize_matches_definition(n, world, seed):
+    import torch
+    from news_recsys_amd import ops
+    ids = np.random.default_rng(seed).integers(0, 1 << 30, n)
+    counts, local_rows, slot = ops.bucketize_by_owner(torch.from_numpy(ids).cuda(), world)
+    c_ref, perm = R.bucketize_by_owner(ids, world)
+    assert np.array_equal(counts.cpu().numpy(), c_ref)
+    assert np.array_equal(local_rows.cpu().numpy(), (ids // world)[perm])
