@@ -356,7 +356,7 @@ extern "C" int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_
     NRX_REQUIRE(ids && lens && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES, "nrx_route_ids: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(index_bits == 32 || index_bits == 64, "nrx_route_ids: index_bits must be 32 or 64");
     NRX_REQUIRE(world >= 1 && world <= 64 && cap >= 1, "nrx_route_ids: bad world / cap");
-    NRX_REQUIRE(send_rows && slot && counts2d && overflow && workspace, "nrx_route_ids: null buffer");
+    NRX_REQUIRE(send_rows && counts2d && overflow && workspace, "nrx_route_ids: null buffer");
     RouteArgs a;
     int64_t off = 0;
     for (int f = 0; f < n_feats; ++f) {
@@ -366,6 +366,7 @@ extern "C" int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_
         off += lens[f];
     }
     a.off[n_feats] = off;
+    NRX_REQUIRE(slot != nullptr || off == 0, "nrx_route_ids: null slot buffer");   // an exchange may carry zero ids
     a.n_feats = n_feats;
     a.world = world;
     a.idx64 = index_bits == 64;
