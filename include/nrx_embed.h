@@ -200,6 +200,13 @@ NRX_API int nrx_scatter_add_inbox(float* const* grad_tables, const int64_t* tabl
                           const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,
                           const int64_t* recv2d, const int64_t* inbox_rows, int32_t dim,
                           const float* g_rows, int32_t skip_row0, void* stream);
+/* Expands a CSR batch of an array feature (values[offsets[b] .. offsets[b+1]), offsets relative to the
+ * batch, device int64[batch+1]) into the reference's padded form: ids [batch, bag_len] (0-padded,
+ * same integer width as `values`) and mask float32 [batch, bag_len] (1 = real, 0 = padding) --
+ * what DataReader builds per sample on the host (src/dataset/DataReader/data_reader.py:96-109;
+ * longer arrays are truncated to bag_len like :104-106).                                          */
+NRX_API int nrx_csr_to_padded(const void* values, int32_t value_bits, const int64_t* offsets, int64_t batch,
+                      int32_t bag_len, void* ids_out, float* mask_out, void* stream);
 /* lens[b] = #(mask[b,:] != 0); used to build CSR offsets from the reference's padded masks. */
 NRX_API int nrx_mask_lengths(const float* mask, int64_t batch, int32_t bag_len, int64_t* lens, void* stream);
 

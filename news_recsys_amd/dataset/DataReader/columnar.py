@@ -1,0 +1,221 @@
+"""Columnar binary form of a feature file + a batch loader that feeds the GPU path.
+
+`convert_features_txt` parses a reference-format text file ONCE (same grammar as DataReader /
+data_reader.py:54-115) into one flat array per column under a directory:
+
+    meta.json                       names, dtypes, max lengths, sample count, label width
+    sparse/<name>.npy               int32 (or int64 when an id needs it)   [N]
+    dense/<name>.npy                float64                               [N]
+    array/<name>.values.npy         int32/int64, truncated to max_len      [sum len]   (CSR)
+    array/<name>.offsets.npy        int64                                  [N + 1]
+    label.npy                       float32                                [N, n_labels]
+
+`ColumnarLoader` memory-maps them and yields the batch dict the models consume (the collated form of
+DataReader items: sparse int[B], dense float64[B], array int[B, L] + `<name>_mask` float32[B, L],
+`label` float32[B, n_labels]) already on the device: host batches are assembled into pinned buffers,
+copied with an async H2D on a side stream (double-buffered), and array features travel as compact
+CSR and are expanded to padded ids + mask on the GPU by `nrx_csr_to_padded` (less PCIe traffic than
+the padded form: only the valid ids cross the link).  Narrow (int32) ids are kept narrow end to end
+-- the kernels accept them (`index_bits = 32`), like the reference accepts any integer dtype through
+`.long()` (base_model.py:271)."""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Iterator, List, Optional
+
+import numpy as np
+import torch
+
+from ...config import load_config
+from .data_reader import parse_feature_line
+
+FORMAT_VERSION = 1
+
+
+def convert_features_txt(config_path: str, txt_path: str, out_dir: str, index_dtype: str = "auto") -> Dict:
+    cfg = load_config(config_path)
+    sparse = list(cfg.features.sparse_feature_names or [])
+    dense = list(cfg.features.dense_feature_names or [])
+    array = list(cfg.features.array_feature_names or [])
+    max_len = dict(cfg.features.array_max_length or {})
+    s_set, d_set, a_set = set(sparse), set(dense), set(array)
+    cols_s = {n: [] for n in sparse}
+    cols_d = {n: [] for n in dense}
+    vals_a = {n: [] for n in array}
+    offs_a = {n: [0] for n in array}
+    labels: List[List[float]] = []
+    n = 0
+    with open(txt_path, "r", encoding="utf-8") as f:
+        for line in f:
+            line = line.strip()
+            if not line:
+                continue
+            raw = parse_feature_line(line, n, s_set, d_set, a_set, max_len)
+            for k in sparse:
+                if k not in raw:
+                    raise ValueError(f"Line {n}: sparse feature '{k}' missing (columnar files need every column)")
+                cols_s[k].append(raw[k])
+            for k in dense:
+                if k not in raw:
+                    raise ValueError(f"Line {n}: dense feature '{k}' missing (columnar files need every column)")
+                cols_d[k].append(raw[k])
+            for k in array:
+                if k not in raw:
+                    raise ValueError(f"Line {n}: array feature '{k}' missing (columnar files need every column)")
+                ids = raw[k][: max_len[k]]
+                vals_a[k].extend(ids)
+                offs_a[k].append(len(vals_a[k]))
+            labels.append(raw["label"])
+            n += 1
+    if n and len({len(l) for l in labels}) != 1:
+        raise ValueError("all lines must carry the same number of labels")
+
+    def idt(values) -> str:
+        if index_dtype in ("int32", "int64"):
+            return index_dtype
+        mx = max(values) if len(values) else 0
+        mn = min(values) if len(values) else 0
+        return "int32" if (mx < 2 ** 31 and mn >= -2 ** 31) else "int64"
+
+    for sub in ("sparse", "dense", "array"):
+        os.makedirs(os.path.join(out_dir, sub), exist_ok=True)
+    meta = {"version": FORMAT_VERSION, "n": n, "sparse": {}, "dense": dense, "array": {},
+            "n_labels": len(labels[0]) if n else 0}
+    for k in sparse:
+        dt = idt(cols_s[k])
+        np.save(os.path.join(out_dir, "sparse", k + ".npy"), np.asarray(cols_s[k], dtype=dt))
+        meta["sparse"][k] = dt
+    for k in dense:
+        np.save(os.path.join(out_dir, "dense", k + ".npy"), np.asarray(cols_d[k], dtype=np.float64))
+    for k in array:
+        dt = idt(vals_a[k])
+        np.save(os.path.join(out_dir, "array", k + ".values.npy"), np.asarray(vals_a[k], dtype=dt))
+        np.save(os.path.join(out_dir, "array", k + ".offsets.npy"), np.asarray(offs_a[k], dtype=np.int64))
+        meta["array"][k] = {"dtype": dt, "max_len": int(max_len[k])}
+    np.save(os.path.join(out_dir, "label.npy"), np.asarray(labels, dtype=np.float32).reshape(n, -1))
+    with open(os.path.join(out_dir, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    return meta
+
+
+class ColumnarDataset:
+    """Memory-mapped view of a converted directory."""
+
+    def __init__(self, col_dir: str):
+        with open(os.path.join(col_dir, "meta.json")) as f:
+            self.meta = json.load(f)
+        if self.meta.get("version") != FORMAT_VERSION:
+            raise ValueError(f"unsupported columnar format version {self.meta.get('version')}")
+        mm = lambda *p: np.load(os.path.join(col_dir, *p), mmap_mode="r")
+        self.sparse = {k: mm("sparse", k + ".npy") for k in self.meta["sparse"]}
+        self.dense = {k: mm("dense", k + ".npy") for k in self.meta["dense"]}
+        self.values = {k: mm("array", k + ".values.npy") for k in self.meta["array"]}
+        self.offsets = {k: mm("array", k + ".offsets.npy") for k in self.meta["array"]}
+        self.max_len = {k: v["max_len"] for k, v in self.meta["array"].items()}
+        self.label = mm("label.npy")
+        self.n = int(self.meta["n"])
+
+    def __len__(self) -> int:
+        return self.n
+
+
+class ColumnarLoader:
+    """Iterates device batches.  `shuffle` draws a fresh permutation per epoch (numpy Generator seeded
+    with seed + epoch); contiguous epochs (shuffle=False) slice the mmaps without a gather."""
+
+    def __init__(self, dataset: ColumnarDataset, batch_size: int, device, shuffle: bool = False,
+                 drop_last: bool = False, seed: int = 0, expand_on_device: bool = True):
+        self.ds, self.B, self.device = dataset, int(batch_size), torch.device(device)
+        self.shuffle, self.drop_last, self.seed, self.epoch = shuffle, drop_last, seed, 0
+        self.expand_on_device = expand_on_device and self.device.type == "cuda"
+        self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+
+    def __len__(self) -> int:
+        return self.ds.n // self.B if self.drop_last else (self.ds.n + self.B - 1) // self.B
+
+    # ---- host side: one batch as numpy views/gathers (arrays stay CSR)
+    def _host_batch(self, sel):
+        ds = self.ds
+        take = (lambda a: a[sel]) if isinstance(sel, slice) else (lambda a: a[sel])
+        # np.array(...) copies out of the read-only mmap into a fresh writable buffer (pinned next)
+        hb = {"sparse": {k: np.array(take(a)) for k, a in ds.sparse.items()},
+              "dense": {k: np.array(take(a)) for k, a in ds.dense.items()},
+              "label": np.array(take(ds.label)), "array": {}}
+        for k in ds.values:
+            off = ds.offsets[k]
+            if isinstance(sel, slice):
+                lo, hi = sel.start, sel.stop
+                o = np.asarray(off[lo:hi + 1])
+                vals = np.array(ds.values[k][o[0]:o[-1]])
+                rel = (o - o[0]).astype(np.int64)
+            else:
+                starts, ends = np.asarray(off[sel]), np.asarray(off[sel + 1])
+                lens = ends - starts
+                rel = np.zeros(len(sel) + 1, np.int64)
+                np.cumsum(lens, out=rel[1:])
+                idx = np.repeat(starts - rel[:-1], lens) + np.arange(rel[-1])
+                vals = np.array(ds.values[k][idx])
+            hb["array"][k] = (vals, rel)
+        return hb
+
+    def _to_device(self, hb) -> Dict[str, torch.Tensor]:
+        from ... import ops
+        dev = self.device
+        pin = (lambda a: torch.from_numpy(a).pin_memory()) if dev.type == "cuda" else torch.from_numpy
+        out: Dict[str, torch.Tensor] = {}
+        for k, a in hb["sparse"].items():
+            out[k] = pin(a).to(dev, non_blocking=True)
+        for k, a in hb["dense"].items():
+            out[k] = pin(a).to(dev, non_blocking=True)
+        out["label"] = pin(hb["label"]).to(dev, non_blocking=True)
+        for k, (vals, rel) in hb["array"].items():
+            L = self.ds.max_len[k]
+            if self.expand_on_device:
+                v = pin(vals).to(dev, non_blocking=True) if vals.size else torch.zeros(0, dtype=torch.from_numpy(vals).dtype, device=dev)
+                o = pin(rel).to(dev, non_blocking=True)
+                out[k], out[f"{k}_mask"] = ops.csr_to_padded(v, o, L)
+            else:
+                Bn = len(rel) - 1
+                ids = np.zeros((Bn, L), vals.dtype)
+                mask = np.zeros((Bn, L), np.float32)
+                lens = np.diff(rel)
+                col = np.arange(rel[-1]) - np.repeat(rel[:-1], lens)
+                row = np.repeat(np.arange(Bn), lens)
+                ids[row, col] = vals
+                mask[row, col] = 1.0
+                out[k] = pin(ids).to(dev, non_blocking=True)
+                out[f"{k}_mask"] = pin(mask).to(dev, non_blocking=True)
+        return out
+
+    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        n, B = self.ds.n, self.B
+        nb = len(self)
+        if self.shuffle:
+            perm = np.random.default_rng(self.seed + self.epoch).permutation(n)
+        self.epoch += 1
+        sels = []
+        for i in range(nb):
+            lo, hi = i * B, min(n, (i + 1) * B)
+            sels.append(np.sort(perm[lo:hi]) if self.shuffle else slice(lo, hi))
+
+        def stage(sel):
+            hb = self._host_batch(sel)
+            if self._side is None:
+                return self._to_device(hb), None
+            with torch.cuda.stream(self._side):
+                batch = self._to_device(hb)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            return batch, ev
+
+        nxt = stage(sels[0]) if nb else None
+        for i in range(nb):
+            cur = nxt
+            nxt = stage(sels[i + 1]) if i + 1 < nb else None      # next batch's H2D overlaps this batch's compute
+            batch, ev = cur
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                for t in batch.values():
+                    t.record_stream(torch.cuda.current_stream(self.device))
+            yield batch

@@ -684,6 +684,24 @@ def scatter_add_inbox(grad_tables: Sequence[torch.Tensor], feat_table: Sequence[
                                     _stream_ptr(g_rows)), "nrx_scatter_add_inbox")
 
 
+def csr_to_padded(values: torch.Tensor, offsets: torch.Tensor, bag_len: int):
+    """CSR batch of an array feature -> (ids [B, bag_len] 0-padded, mask float32 [B, bag_len]) on the device:
+    the padded form DataReader builds per sample on the host (data_reader.py:96-109)."""
+    lib = _lib.load()
+    _dev(values, "values")
+    _dev(offsets, "offsets")
+    if values.dtype not in (torch.int64, torch.int32):
+        raise TypeError("values must be int64 or int32")
+    offsets = offsets.to(torch.int64).contiguous()
+    values = values.contiguous()
+    B = offsets.numel() - 1
+    ids = torch.empty((B, bag_len), dtype=values.dtype, device=values.device)
+    mask = torch.empty((B, bag_len), dtype=torch.float32, device=values.device)
+    check(lib.nrx_csr_to_padded(_ptr(values) if values.numel() else None, values.element_size() * 8, offsets.data_ptr(), B,
+                                bag_len, ids.data_ptr(), mask.data_ptr(), _stream_ptr(offsets)), "nrx_csr_to_padded")
+    return ids, mask
+
+
 def mask_lengths(mask: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     mask = _f32c(mask, "mask")

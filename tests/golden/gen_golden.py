@@ -382,6 +382,35 @@ def gen_lr_schedule():
                          "lr": np.array([1e-3, 5e-6])})
 
 
+def gen_datareader():
+    """Input pipeline goldens: a small synthetic feature file (data generated here, committed under
+    tests/golden/data/) parsed by the REFERENCE DataReader (src/dataset/DataReader/data_reader.py) and
+    collated by torch's default_collate exactly as MINDDataModule's DataLoader does (pl_dataloader.py:77-96)."""
+    from torch.utils.data import DataLoader
+    from src.dataset.DataReader.data_reader import DataReader
+    rng = np.random.default_rng(2026)
+    os.makedirs(os.path.join(HERE, "data"), exist_ok=True)
+    path = os.path.join(HERE, "data", "features_small.txt")
+    lines = []
+    for i in range(23):
+        n_hist = [0, 9, 7, 1][i] if i < 4 else int(rng.integers(0, 10))       # empty, over-long (truncated to 7), exact, one
+        hist = ",".join(str(int(x)) for x in rng.integers(1, 41, n_hist))
+        cats = ",".join(str(int(x)) for x in rng.integers(1, 18, int(rng.integers(0, 6))))
+        feats = [f"user_id:{int(rng.integers(1, 53))}", f"item_id:{int(rng.integers(1, 41))}",
+                 f"category:{int(rng.integers(1, 18))}", f"ctr:{rng.random():.6f}", f"user_history:{hist}",
+                 f"user_click_cats:{cats}", f"ignored_feature:{i}"]
+        rng.shuffle(feats)                                                      # order inside a line is free
+        lines.append(" ".join(feats) + "\t" + f"{int(rng.integers(0, 2))} {int(rng.integers(0, 2))}")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n\n")                                     # trailing blank line is skipped
+    ds = DataReader(os.path.join(CFG, "cf_array_small.yaml"), path)
+    d = {"n": np.array(len(ds))}
+    for bi, batch in enumerate(DataLoader(ds, batch_size=7, shuffle=False)):
+        for k, v in batch.items():
+            d[f"b{bi}/{k}"] = np_(v)
+    save("datareader", d)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
@@ -392,3 +421,4 @@ if __name__ == "__main__":
     gen_ops()
     gen_dssm()
     gen_lr_schedule()
+    gen_datareader()

@@ -1,0 +1,154 @@
+"""Input pipeline against goldens produced by the REFERENCE DataReader + torch
+default_collate (tests/golden/gen_golden.py:gen_datareader): the text reader mirror and the columnar
+loader must both reproduce the reference's batches exactly (ids, masks, float64 dense values, labels)."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import DataLoader
+
+from news_recsys_amd.dataset.DataReader.columnar import ColumnarDataset, ColumnarLoader, convert_features_txt
+from news_recsys_amd.dataset.DataReader.data_reader import DataReader
+from news_recsys_amd.dataset.DataReader.pl_dataloader import MINDDataModule
+from tests.conftest import CONFIGS, GOLDEN
+
+CFG = os.path.join(CONFIGS, "cf_array_small.yaml")
+TXT = os.path.join(GOLDEN, "data", "features_small.txt")
+
+
+def golden_batches():
+    g = dict(np.load(os.path.join(GOLDEN, "datareader.npz")))
+    n = int(g.pop("n"))
+    nb = 1 + max(int(k.split("/")[0][1:]) for k in g)
+    return n, [{k.split("/", 1)[1]: v for k, v in g.items() if k.startswith(f"b{i}/")} for i in range(nb)]
+
+
+def assert_batch_equal(got, want):
+    assert sorted(got) == sorted(want)
+    for k, v in want.items():
+        t = got[k].cpu().numpy()
+        assert t.shape == v.shape, k
+        if v.dtype.kind == "f":
+            assert t.dtype == v.dtype, k                        # dense float64, masks/labels float32
+            assert np.array_equal(t, v), k
+        else:
+            assert np.array_equal(t.astype(np.int64), v), k      # ids may travel as int32
+
+
+def test_text_reader_matches_reference():
+    n, want = golden_batches()
+    ds = DataReader(CFG, TXT)
+    assert len(ds) == n == 23
+    got = list(DataLoader(ds, batch_size=7, shuffle=False))
+    assert len(got) == len(want) == 4
+    for gb, wb in zip(got, want):
+        assert_batch_equal(gb, wb)
+        assert gb["user_id"].dtype == torch.int64 and gb["ctr"].dtype == torch.float64
+    item = ds[1]                                                  # over-long history is truncated to 7
+    assert item["user_history"].tolist() == [37, 12, 26, 25, 31, 5, 21] and item["user_history_mask"].sum() == 7
+    assert "ignored_feature" not in item
+
+
+def test_text_reader_errors_match_reference(tmp_path):
+    with pytest.raises(ValueError, match="Data file path"):
+        DataReader(CFG, None)
+    with pytest.raises(FileNotFoundError):
+        DataReader(CFG, str(tmp_path / "nope.txt"))
+    bad = tmp_path / "bad.txt"
+    bad.write_text("user_id:1 item_id:2 0\n")                    # no tab
+    with pytest.raises(ValueError, match="missing tab"):
+        DataReader(CFG, str(bad))[0]
+    bad.write_text("user_id:1 item_id\t0\n")                     # no colon
+    with pytest.raises(ValueError, match="does not contain"):
+        DataReader(CFG, str(bad))[0]
+
+
+@pytest.fixture(scope="module")
+def col_dir(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("col"))
+    meta = convert_features_txt(CFG, TXT, d)
+    assert meta["n"] == 23 and meta["n_labels"] == 2 and meta["sparse"]["user_id"] == "int32"
+    assert meta["array"]["user_history"] == {"dtype": "int32", "max_len": 7}
+    return d
+
+
+def test_columnar_cpu_loader_matches_reference(col_dir):
+    n, want = golden_batches()
+    ds = ColumnarDataset(col_dir)
+    assert len(ds) == n
+    loader = ColumnarLoader(ds, 7, "cpu", shuffle=False)
+    got = list(loader)
+    assert len(got) == len(loader) == 4
+    for gb, wb in zip(got, want):
+        assert_batch_equal(gb, wb)
+
+
+def test_columnar_shuffle_is_a_permutation(col_dir):
+    ds = ColumnarDataset(col_dir)
+    loader = ColumnarLoader(ds, 5, "cpu", shuffle=True, seed=3)
+    seen = torch.cat([b["ctr"] for b in loader])
+    ref = torch.from_numpy(np.asarray(ds.dense["ctr"]))
+    assert seen.numel() == 23 and torch.equal(seen.sort().values, ref.sort().values)
+    again = torch.cat([b["ctr"] for b in loader])                 # next epoch: a different order
+    assert not torch.equal(seen, again)
+    assert len(list(ColumnarLoader(ds, 5, "cpu", drop_last=True))) == 4
+
+
+def test_datamodule_mirror(tmp_path):
+    import yaml
+    cfg = yaml.safe_load(open(CFG))
+    cfg["paths"]["out_basedir"] = str(tmp_path)
+    cfg["dataset"] = {"batch_size": 7, "num_workers": 0, "pin_memory": False}
+    os.makedirs(tmp_path / "extractored_feature")
+    for name in ("train_features.txt", "dev_features.txt"):
+        shutil.copy(TXT, tmp_path / "extractored_feature" / name)
+    cpath = tmp_path / "cfg.yaml"
+    cpath.write_text(yaml.safe_dump(cfg))
+    dm = MINDDataModule(str(cpath))
+    dm.setup("fit")
+    _, want = golden_batches()
+    for gb, wb in zip(dm.val_dataloader(), want):
+        assert_batch_equal(gb, wb)
+    for gb, wb in zip(dm.val_loader_columnar("cpu"), want):
+        assert_batch_equal(gb, wb)
+    assert len(dm.train_dataloader()) == 4
+    os.remove(tmp_path / "extractored_feature" / "dev_features.txt")
+    with pytest.raises(FileNotFoundError):
+        MINDDataModule(str(cpath)).setup("fit")
+
+
+@pytest.mark.gpu
+def test_columnar_device_loader_matches_reference_and_feeds_the_model(col_dir):
+    """Device batches (async H2D, CSR expanded on the GPU by nrx_csr_to_padded) == reference batches,
+    and they drive the Deep model built from the same YAML."""
+    from news_recsys_amd.model.sort.deep.model import Deep
+    _, want = golden_batches()
+    ds = ColumnarDataset(col_dir)
+    got = list(ColumnarLoader(ds, 7, "cuda:0", shuffle=False))
+    for gb, wb in zip(got, want):
+        assert all(t.is_cuda for t in gb.values())
+        assert_batch_equal(gb, wb)
+    m = Deep(CFG).to("cuda:0")
+    out = m(got[0])
+    assert out.shape == (7, 1) and torch.isfinite(out).all()
+
+
+@pytest.mark.gpu
+def test_csr_to_padded_kernel_vs_numpy():
+    from news_recsys_amd import ops
+    rng = np.random.default_rng(0)
+    for dt in (np.int32, np.int64):
+        B, L = 1000, 50
+        lens = rng.integers(0, L + 1, B)
+        lens[:3] = [0, L, 1]
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        vals = rng.integers(1, 10 ** 6, off[-1]).astype(dt)
+        ids, mask = ops.csr_to_padded(torch.from_numpy(vals).cuda(), torch.from_numpy(off).cuda(), L)
+        ref = np.zeros((B, L), dt)
+        rm = np.zeros((B, L), np.float32)
+        for b in range(B):
+            ref[b, :lens[b]] = vals[off[b]:off[b + 1]]
+            rm[b, :lens[b]] = 1
+        assert np.array_equal(ids.cpu().numpy(), ref) and np.array_equal(mask.cpu().numpy(), rm)
