@@ -130,6 +130,22 @@ class ColumnarLoader:
         self.shuffle, self.drop_last, self.seed, self.epoch = shuffle, drop_last, seed, 0
         self.expand_on_device = expand_on_device and self.device.type == "cuda"
         self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        # ring of grow-only pinned staging buffers: batch-dependent sizes (CSR value counts under
+        # shuffle) would otherwise miss torch's pinned-memory cache and pay a hipHostMalloc per batch
+        self._ring = [dict() for _ in range(3)]
+        self._ring_ev = [None, None, None]
+        self._ring_i = 0
+
+    def _stage_pinned(self, slot: dict, key: str, a: np.ndarray) -> torch.Tensor:
+        n = a.size
+        buf = slot.get(key)
+        if buf is None or buf.numel() < n or buf.dtype != torch.from_numpy(a[:0]).dtype:
+            cap = max(1024, 1 << (max(n, 1) - 1).bit_length())
+            buf = torch.empty(cap, dtype=torch.from_numpy(a[:0]).dtype).pin_memory()
+            slot[key] = buf
+        view = buf[:n]
+        view.numpy()[...] = a.reshape(-1)
+        return view.view(a.shape)
 
     def __len__(self) -> int:
         return self.ds.n // self.B if self.drop_last else (self.ds.n + self.B - 1) // self.B
@@ -162,7 +178,19 @@ class ColumnarLoader:
     def _to_device(self, hb) -> Dict[str, torch.Tensor]:
         from ... import ops
         dev = self.device
-        pin = (lambda a: torch.from_numpy(a).pin_memory()) if dev.type == "cuda" else torch.from_numpy
+        if dev.type == "cuda":
+            i = self._ring_i
+            self._ring_i = (i + 1) % len(self._ring)
+            if self._ring_ev[i] is not None:
+                self._ring_ev[i].synchronize()          # the H2D copies that last used this slot are done
+            slot = self._ring[i]
+            keyed = [0]
+
+            def pin(a):
+                keyed[0] += 1
+                return self._stage_pinned(slot, f"k{keyed[0]}", a)
+        else:
+            pin = torch.from_numpy
         out: Dict[str, torch.Tensor] = {}
         for k, a in hb["sparse"].items():
             out[k] = pin(a).to(dev, non_blocking=True)
@@ -186,6 +214,10 @@ class ColumnarLoader:
                 mask[row, col] = 1.0
                 out[k] = pin(ids).to(dev, non_blocking=True)
                 out[f"{k}_mask"] = pin(mask).to(dev, non_blocking=True)
+        if dev.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            self._ring_ev[i] = ev
         return out
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
