@@ -238,6 +238,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(step_fn):
+        for i in range(args.warmup):
+            step_fn(i)
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        e0.record()
+        for i in range(args.steps):
+            step_fn(args.warmup + i)
+        e1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt, e0.elapsed_time(e1) / args.steps
+
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -260,6 +279,17 @@ def main():
 
     if hasattr(path, "overflowed") and path.overflowed():
         raise SystemExit("fixed-capacity exchange overflowed: rerun with a larger slack (ids too skewed)")
+    planner = None
+    if world > 1 and args.shard_mode == "row":
+        # secondary measurement (never the headline): the planner layout -- tables <= 256 MiB replicated,
+        # larger ones row-sharded (SURVEY hard part 1a) -- same workload, same K steps
+        del path
+        torch.cuda.empty_cache()
+        from news_recsys_amd.sharding import ShardedBenchPath
+        p2 = ShardedBenchPath(args.workload, device, seed, rank, world, BATCH, "auto")
+        dt2, k2 = timed(p2.step)
+        planner = {"value": BATCH * world * args.steps / dt2, "unit": "impressions/s", "ms_per_step": dt2 * 1e3 / args.steps,
+                   "layout": p2.desc, "note": "secondary: planner-sharded layout; the headline value is all-row-sharded"}
     if rank == 0:
         total_impr = BATCH * world * args.steps
         ms_per_step = dt * 1e3 / args.steps
@@ -293,6 +323,8 @@ def main():
                                  "the timed region on the launch stream / steps); traffic = DRAM bytes per launch from "
                                  "the committed rocprofv3 PMC passes (profiles/traffic.json), null if not profiled"},
         }
+        if planner is not None:
+            out["planner_sharded"] = planner
         if world == 1 and not args.no_cpu_baseline and not args.force_sharded:
             out["cpu_baseline"] = cpu_baseline(path)
         try:

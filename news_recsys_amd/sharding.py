@@ -106,6 +106,7 @@ class ShardedFeature:
     bag_len: int = 0
     wide: bool = False
     fm: bool = False
+    replicated: bool = False   # planner: this feature's table is held in full on every rank (no exchange)
 
 
 @dataclass
@@ -259,20 +260,34 @@ class RowShardedEmbedding:
                        cap=cap, recv2d=recv2d, feat_table=feat_table)
         return ret, route, overflow, status
 
+    @staticmethod
+    def replicated_tables(feats: Sequence[ShardedFeature]) -> List[str]:
+        names: List[str] = []
+        for f in feats:
+            if f.kind != NRX_DENSE and f.replicated and f.table not in names:
+                names.append(f.table)
+        return names
+
     def _final_plan(self, feats: Sequence[ShardedFeature], groups: List[List[int]]):
-        """Step 7 plan: tables = one returned-row buffer per dim-group; indices = slot[] segments."""
+        """Step 7 plan: tables = one returned-row buffer per exchange group, then the replicated tables;
+        indices = slot[] segments (routed features) or the original ids (replicated features)."""
         slots, col, wcol = [], 0, 0
         gidx = {}
         for g, idxs in enumerate(groups):
             for i in idxs:
                 gidx[i] = g
+        rep = self.replicated_tables(feats)
         for i, f in enumerate(feats):
             if f.kind == NRX_DENSE:
                 slots.append(ops.Slot(f.name, NRX_DENSE, -1, 1, 0, col))
                 col += 1
                 continue
-            slots.append(ops.Slot(f.name, f.kind, gidx[i], f.dim, f.bag_len, col, wide_col=wcol if f.wide else -1,
-                                  fm_field=int(f.fm), flags=NRX_FEAT_ROW0_IS_DATA))
+            if f.replicated:
+                tix, flags = len(groups) + rep.index(f.table), 0
+            else:
+                tix, flags = gidx[i], NRX_FEAT_ROW0_IS_DATA
+            slots.append(ops.Slot(f.name, f.kind, tix, f.dim, f.bag_len, col, wide_col=wcol if f.wide else -1,
+                                  fm_field=int(f.fm), flags=flags))
             if f.wide:
                 wcol += 1
                 col += f.dim - 1
@@ -296,7 +311,7 @@ class _ShardedEmbedFn(torch.autograd.Function):
         tables = dict(zip(names, shards))
         by_dim: Dict[int, List[int]] = {}
         for i, f in enumerate(feats):
-            if f.kind != NRX_DENSE:
+            if f.kind != NRX_DENSE and not f.replicated:
                 by_dim.setdefault(f.dim, []).append(i)
         groups: List[List[int]] = []
         for d in sorted(by_dim):                       # one exchange per (dim, <= 64 features)
@@ -332,9 +347,10 @@ class _ShardedEmbedFn(torch.autograd.Function):
                 eng._overflow_marks += [(o, cap) for o, cap, _ in flags]
 
         plan = eng._final_plan(feats, groups)
+        rep_names = eng.replicated_tables(feats)
         final_inputs = []
         for i, f in enumerate(feats):
-            if f.kind == NRX_DENSE:
+            if f.kind == NRX_DENSE or f.replicated:
                 final_inputs.append(inputs[i])
                 continue
             g = next(k for k, idxs in enumerate(groups) if i in idxs)
@@ -345,8 +361,9 @@ class _ShardedEmbedFn(torch.autograd.Function):
         train = any(ctx.needs_input_grad[7:])
         with torch.set_grad_enabled(train):
             leaves = [r.detach().requires_grad_(train) for r in rets]
+            leaves += [tables[n].detach().requires_grad_(train) for n in rep_names]   # replicated: local full tables
             out, wide, fm = eng.backend.embed(plan, leaves, final_inputs, list(weights), out_ld=out_ld, need_out=need_out)
-        ctx.eng, ctx.routes, ctx.leaves = eng, routes, leaves
+        ctx.eng, ctx.routes, ctx.leaves, ctx.rep_names = eng, routes, leaves, rep_names
         ctx.outs = (out, wide, fm)
         ctx.names, ctx.shard_meta = names, [(s.shape, s.device) for s in shards]
         ctx.set_materialize_grads(False)
@@ -366,6 +383,10 @@ class _ShardedEmbedFn(torch.autograd.Function):
             return (None,) * (n_lead + len(ctx.names))
         g_rets = torch.autograd.grad(outs, ctx.leaves, grads_in, allow_unused=True)     # slot-scatter (HIP bwd kernel)
         shard_grads = {n: torch.zeros(shape, dtype=torch.float32, device=dev) for n, (shape, dev) in zip(ctx.names, ctx.shard_meta)}
+        # replicated tables: the local dense grad (the caller all-reduces it like any data-parallel parameter)
+        for n, g_rep in zip(ctx.rep_names, g_rets[len(ctx.routes):]):
+            if g_rep is not None:
+                shard_grads[n] = g_rep
         for route, leaf, g_ret in zip(ctx.routes, ctx.leaves, g_rets):
             if g_ret is None:
                 g_ret = torch.zeros_like(leaf)
@@ -404,7 +425,7 @@ class PreparedShardedForward:
         W = eng.world
         by_dim: Dict[int, List[int]] = {}
         for i, f in enumerate(feats):
-            if f.kind != NRX_DENSE:
+            if f.kind != NRX_DENSE and not f.replicated:
                 by_dim.setdefault(f.dim, []).append(i)
         groups: List[List[int]] = []
         for d in sorted(by_dim):
@@ -447,7 +468,8 @@ class PreparedShardedForward:
             self.groups.append(g)
             rets.append(g["ret"])
         plan = eng._final_plan(feats, groups)
-        final_inputs = [inputs[i] if f.kind == NRX_DENSE else slot_of[i] for i, f in enumerate(feats)]
+        final_inputs = [inputs[i] if (f.kind == NRX_DENSE or f.replicated) else slot_of[i] for i, f in enumerate(feats)]
+        rets += [tables[n] for n in eng.replicated_tables(feats)]
         self.final = ops.PreparedEmbed(plan, rets, final_inputs, list(weights), out_ld=out_ld, out=out, fm=fm)
 
     def run(self):
@@ -529,7 +551,11 @@ class ShardedBenchPath:
     """bench.py's N>1 workload: the same synthetic configuration as the single-GPU path, tables
     row-sharded over `world` ranks, B impressions per rank (weak scaling)."""
 
-    def __init__(self, wl: str, device, seed: int, rank: int, world: int, batch: int, mode: str = "row", n_pool: int = 8):
+    def __init__(self, wl: str, device, seed: int, rank: int, world: int, batch: int, mode: str = "row", n_pool: int = 8,
+                 replicate_below_bytes: int = 256 << 20):
+        """mode "row": every table row-sharded (the north-star layout).  mode "auto": planner -- tables
+        of at most `replicate_below_bytes` are held in full on every rank (no exchange for them), larger
+        ones are row-sharded."""
         import bench
         feats, self.desc = bench.workload_spec(wl)
         self.rank, self.world, self.batch = rank, world, batch
@@ -538,16 +564,26 @@ class ShardedBenchPath:
         self.tables: Dict[str, torch.Tensor] = {}
         self.feats: List[ShardedFeature] = []
         self.fm = wl == "c2"
+        self.n_replicated = self.n_sharded = 0
+        rep_of: Dict[str, bool] = {}
         for f in sorted(feats, key=lambda f: f["name"]):
             tname = f.get("share", f["name"])
             if tname not in self.tables:
-                t = torch.empty((local_row_count(f["rows"], rank, world), f["dim"]), dtype=torch.float32, device=device)
-                t.normal_(generator=gen)
-                if rank == 0:
+                rep = mode == "auto" and f["rows"] * f["dim"] * 4 <= replicate_below_bytes
+                rep_of[tname] = rep
+                nrows = f["rows"] if rep else local_row_count(f["rows"], rank, world)
+                t = torch.empty((nrows, f["dim"]), dtype=torch.float32, device=device)
+                if rep:      # identical replica on every rank
+                    t.normal_(generator=torch.Generator(device=device).manual_seed(seed - rank + len(self.tables)))
+                else:
+                    t.normal_(generator=gen)
+                if rank == 0 or rep:
                     t[0].zero_()
                 self.tables[tname] = t
+                self.n_replicated += rep
+                self.n_sharded += not rep
             kind = NRX_BAG_MASKED_MEAN if f["bag"] else NRX_SPARSE
-            self.feats.append(ShardedFeature(f["name"], kind, tname, f["dim"], f["bag"], False, self.fm))
+            self.feats.append(ShardedFeature(f["name"], kind, tname, f["dim"], f["bag"], False, self.fm, rep_of[tname]))
         self.rows = {f["name"]: f["rows"] for f in feats}
         self.pool = []
         for _ in range(n_pool):
@@ -559,7 +595,8 @@ class ShardedBenchPath:
             self.pool.append((ins, ws))
         self.bytes_per_impr = bench.algorithmic_bytes_per_impression(
             [dict(dim=f.dim, bag=f.bag_len) for f in self.feats], self.fm, 0)
-        self.desc += f" -- tables row-sharded over {world} GPUs (mode={mode})"
+        self.desc += (f" -- {self.n_sharded} tables row-sharded over {world} GPUs, {self.n_replicated} replicated "
+                      f"(mode={mode})")
 
         width = sum(f.dim for f in self.feats)
         out = torch.empty((batch, width), dtype=torch.float32, device=device)       # recycled (see bench.py)

@@ -89,6 +89,8 @@ class CheckerBackend:
                 v = x.float().unsqueeze(1)
             else:
                 e = tables[s.table][x.long()]
+                if not (s.flags & 1):       # ordinary table: index 0 is the padding row and gets no gradient
+                    e = torch.where((x != 0).unsqueeze(-1), e, e.detach())
                 if s.kind == NRX_SPARSE:
                     v = e
                 elif s.kind == NRX_BAG_MEAN:

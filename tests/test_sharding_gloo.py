@@ -74,20 +74,22 @@ def oracle_forward_and_grads(world):
     return outs, grads
 
 
-def _worker(rank, world, port, q, mode="capacity", slack=0.5):
+def _worker(rank, world, port, q, mode="capacity", slack=0.5, replicate=()):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         tabs = full_tables()
-        shards = {n: sharding.shard_table(torch.from_numpy(t), rank, world).requires_grad_(True) for n, t in tabs.items()}
+        shards = {n: (torch.from_numpy(t).clone() if n in replicate else sharding.shard_table(torch.from_numpy(t), rank, world)
+                      ).requires_grad_(True) for n, t in tabs.items()}
+        feats = [ShardedFeature(f.name, f.kind, f.table, f.dim, f.bag_len, f.wide, f.fm, f.table in replicate) for f in FEATS]
         eng = RowShardedEmbedding(rank, world, backend=CheckerBackend(), mode=mode, slack=slack)
         if slack < 0:          # force tiny blocks: every exchange overflows and must fall back to exact
             eng.capacity_for = lambda n: 8
         b = batch_for(rank)
         inputs = [torch.from_numpy(np.asarray(b[f.name])) for f in FEATS]
         weights = [torch.from_numpy(b["user_history_mask"]) if f.kind == NRX_BAG_MASKED_MEAN else None for f in FEATS]
-        out, wide, fm = eng.forward(FEATS, inputs, weights, shards)
+        out, wide, fm = eng.forward(feats, inputs, weights, shards)
         (out * torch.from_numpy(b["_up"])).sum().backward()
         # a dense-parameter all-reduce on the side
         p = torch.nn.Parameter(torch.zeros(3))
@@ -104,15 +106,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,mode,slack", [(2, "capacity", 0.5), (3, "capacity", 0.5), (2, "exact", 0.0),
-                                              (2, "capacity", -1.0)])
-def test_row_sharded_forward_backward_over_gloo(world, mode, slack):
+@pytest.mark.parametrize("world,mode,slack,replicate", [(2, "capacity", 0.5, ()), (3, "capacity", 0.5, ()), (2, "exact", 0.0, ()),
+                                                        (2, "capacity", -1.0, ()), (2, "capacity", 0.5, ("category",)),
+                                                        (2, "exact", 0.0, ("category", "user_id"))])
+def test_row_sharded_forward_backward_over_gloo(world, mode, slack, replicate):
     """capacity = sync-free fixed blocks; exact = variable splits; slack -1 = capacity forced to
     overflow, which must be detected on every rank and redone exactly."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, slack)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, slack, replicate)) for r in range(world)]
     for p in procs:
         p.start()
     results = {}
@@ -130,8 +133,15 @@ def test_row_sharded_forward_backward_over_gloo(world, mode, slack):
             assert np.array_equal(out[:, lo:hi], want_outs[r][:, lo:hi])               # routed copies: bit-exact
         np.testing.assert_allclose(out[:, 25:49], want_outs[r][:, 25:49], rtol=1e-6, atol=1e-6)   # pooled
         for n, g in grads.items():
+            if n in replicate:
+                continue            # replicated: local data-parallel grads, summed below
             want = want_grads[n][r::world]
             np.testing.assert_allclose(g, want, rtol=1e-5, atol=1e-6, err_msg=f"rank {r} table {n}")
+    for n in replicate:          # planner-replicated tables: the ranks' local grads sum to the full grad
+        total = sum(results[r][1][n] for r in range(world))
+        np.testing.assert_allclose(total, want_grads[n], rtol=1e-5, atol=1e-6, err_msg=f"replicated table {n}")
+    for r in range(world):
+        out, grads, pg = results[r]
         assert np.all(results[0][1]["item_id"][0] == 0)                                # global padding row: no grad
         np.testing.assert_allclose(pg, np.full(3, sum(range(1, world + 1)) / world))
 

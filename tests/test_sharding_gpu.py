@@ -124,3 +124,22 @@ def test_prepared_sharded_forward_matches_engine():
         out, _, _ = call.run()
     assert torch.equal(out, ref_out)
     assert not call.overflowed() and not eng.overflowed()
+
+
+def test_planner_replicated_tables_match_direct_path():
+    """Planner layout at world=1 with the HIP backend: replicated features read their full table with the
+    original ids, routed features go through the exchange; output and grads equal the direct path."""
+    tables, feats, inputs, weights = _case(B=500)
+    (out_d, _, _), leaves_d, names = _direct(tables, feats, inputs, weights, False)
+    feats_p = [ShardedFeature(f.name, f.kind, f.table, f.dim, f.bag_len, f.wide, f.fm, f.table == "a") for f in feats]
+    shards = {n: tables[n].clone().requires_grad_(True) for n in names}
+    eng = RowShardedEmbedding(0, 1)
+    out_s, _, _ = eng.forward(feats_p, inputs, weights, shards)
+    assert torch.equal(out_s, out_d)
+    up = torch.randn_like(out_d)
+    (out_d * up).sum().backward()
+    (out_s * up).sum().backward()
+    for n, leaf in zip(names, leaves_d):
+        np.testing.assert_allclose(shards[n].grad.cpu().numpy(), leaf.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    call = sharding.PreparedShardedForward(RowShardedEmbedding(0, 1, overflow_policy="defer"), feats_p, inputs, weights, tables)
+    assert torch.equal(call.run()[0], out_d.detach())
