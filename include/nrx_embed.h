@@ -104,6 +104,20 @@ NRX_API int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_t b
                   const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
                   void* stream);
 
+/* Deterministic row-sparse backward for ONE table (alternative to nrx_embed_bwd's dense atomics).
+ * The caller has sorted the table's lookups by row id (stable): `order[e]` is the flat lookup index of
+ * the e-th sorted entry, flat lookups being feature-major over the n_feats features that read the
+ * table (feats[i]: kind, index (unused), weight, bag_len, out_col, wide_col as in the forward; a
+ * sparse feature contributes B lookups, a bag feature B*bag_len), and unique row u owns the sorted
+ * entries seg_start[u] .. seg_start[u+1).  For every unique row the kernel sums, in sorted order,
+ *   g_out[b, cols of the feature] * (1 | w/(sum w + 1e-8) | 1/L | w)
+ * into values[u, :dim] -- no atomics, bit-reproducible.  Rows that must not train (id 0) are simply
+ * not passed in.  order / seg_start: device int64; values: device [n_unique, dim].              */
+NRX_API int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                         const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                         const int64_t* order, const int64_t* seg_start, int64_t n_unique,
+                         float* values, void* stream);
+
 /* ---- standalone pooling on materialised embeddings -------------------------------------------
  * BaseModel.array_feature_pooling(emb[B,L,D], mask[B,L] | None) (base_model.py:273-282).       */
 NRX_API int nrx_bag_pool_fwd(const float* emb, const float* mask, int64_t batch, int32_t bag_len,

@@ -454,6 +454,87 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// Deterministic row-sparse backward of one table: segmented reduction over id-sorted lookups.
+// One Q-lane group per unique row; entries of a row are summed in sorted (stable) order.
+// --------------------------------------------------------------------------------------------
+struct SortedBwdArgs {
+    FeatDev f[NRX_MAX_FEATURES];      // the features reading this table (index pointer unused)
+    int64_t off[NRX_MAX_FEATURES + 1];  // flat lookup offset of each feature
+    int64_t batch;
+    const float* g_out;
+    int64_t out_ld;
+    const float* g_wide;
+    int64_t wide_ld;
+    const int64_t* order;
+    const int64_t* seg_start;
+    int64_t n_unique;
+    float* values;
+    int32_t n;
+    int32_t dim;
+};
+static_assert(sizeof(SortedBwdArgs) <= 3840, "kernarg budget");
+
+template <int QLOG2>
+__global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_kernel(const SortedBwdArgs args_in_kernarg) {
+    const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    const int q = threadIdx.x & (Q - 1);
+    const int64_t u = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
+    if (u >= a->n_unique) return;
+    const int D = a->dim;
+    const int64_t lo = nrx_gconst<int64_t>(a->seg_start)[u], hi = nrx_gconst<int64_t>(a->seg_start)[u + 1];
+    for (int k0 = q * 4; k0 < D; k0 += 4 * Q) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t e = lo; e < hi; ++e) {
+            const int64_t p = nrx_gconst<int64_t>(a->order)[e];
+            int fi = 0;
+            {   // feature of flat lookup p (<= 64 entries)
+                int l0 = 0, h0 = a->n;
+                while (h0 - l0 > 1) {
+                    const int mid = (l0 + h0) >> 1;
+                    if (a->off[mid] <= p) l0 = mid; else h0 = mid;
+                }
+                fi = l0;
+            }
+            const int64_t r = p - a->off[fi];
+            const int kind = a->f[fi].kind;
+            const int L = kind >= NRX_BAG_MASKED_MEAN ? a->f[fi].bag_len : 1;
+            const int64_t b = r / L;
+            float scale = 1.0f;
+            if (kind == NRX_BAG_MASKED_MEAN) {
+                const NRX_GLOBAL float* w = nrx_gconst<float>(a->f[fi].weight) + b * L;
+                float den = 0.f;
+                for (int l = 0; l < L; ++l) den += w[l];
+                scale = w[r - b * L] / (den + 1e-8f);
+            } else if (kind == NRX_BAG_MEAN) {
+                scale = 1.0f / (float)L;
+            } else if (kind == NRX_BAG_SUM && a->f[fi].weight != nullptr) {
+                scale = nrx_gconst<float>(a->f[fi].weight)[r];
+            }
+            const int wide_col = a->f[fi].wide_col, out_col = a->f[fi].out_col;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j;
+                if (k < D) {
+                    float g;
+                    if (wide_col >= 0)
+                        g = (k == 0) ? (a->g_wide ? nrx_gconst<float>(a->g_wide)[b * a->wide_ld + wide_col] : 0.f)
+                                     : (a->g_out ? nrx_gconst<float>(a->g_out)[b * a->out_ld + out_col + k - 1] : 0.f);
+                    else
+                        g = a->g_out ? nrx_gconst<float>(a->g_out)[b * a->out_ld + out_col + k] : 0.f;
+                    acc[j] += g * scale;
+                }
+            }
+        }
+        NRX_GLOBAL float* dst = nrx_gmut<float>(a->values) + u * (int64_t)D + k0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < D) dst[j] = acc[j];
+    }
+}
+
 // ----------------------------------------------------------------------------------- host side
 int ceil_log2(int x) {
     int l = 0;
@@ -674,5 +755,61 @@ extern "C" int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_
     const unsigned grid = (unsigned)((batch + tb - 1) / tb);
     NRX_QSWITCH(qlog2, { hipLaunchKernelGGL((embed_bwd_generic<QL>), dim3(grid), dim3(NRX_BLOCK), smem, st, a); });
     NRX_LAUNCH_CHECK("nrx_embed_bwd");
+    return NRX_OK;
+}
+
+extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                                    const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                                    const int64_t* order, const int64_t* seg_start, int64_t n_unique,
+                                    float* values, void* stream) {
+    NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
+                "nrx_embed_bwd_sorted: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
+    NRX_REQUIRE(batch >= 0 && dim >= 1 && n_unique >= 0, "nrx_embed_bwd_sorted: bad argument");
+    NRX_REQUIRE(g_out != nullptr || g_wide != nullptr, "nrx_embed_bwd_sorted: no upstream gradient");
+    if (n_unique == 0 || batch == 0) return NRX_OK;
+    NRX_REQUIRE(order && seg_start && values, "nrx_embed_bwd_sorted: null buffer");
+    SortedBwdArgs a;
+    int64_t off = 0;
+    for (int i = 0; i < n_feats; ++i) {
+        const nrx_feature_t& s = feats[i];
+        NRX_REQUIRE(s.kind == NRX_SPARSE || (s.kind >= NRX_BAG_MASKED_MEAN && s.kind <= NRX_BAG_SUM),
+                    "nrx_embed_bwd_sorted: feature %d: kind %d has no table gradient", i, s.kind);
+        NRX_REQUIRE(s.dim == dim, "nrx_embed_bwd_sorted: feature %d: dim %d != table dim %d", i, s.dim, dim);
+        NRX_REQUIRE(s.kind != NRX_BAG_MASKED_MEAN || s.weight != nullptr, "nrx_embed_bwd_sorted: feature %d: masked mean needs weights", i);
+        FeatDev& d = a.f[i];
+        d.table = nullptr;
+        d.index = nullptr;
+        d.weight = (s.kind == NRX_BAG_MEAN) ? nullptr : s.weight;
+        d.rows = 0;
+        d.out_col = s.out_col;
+        d.wide_col = s.wide_col;
+        d.dim = (int16_t)s.dim;
+        d.bag_len = (int16_t)s.bag_len;
+        d.kind = (uint8_t)s.kind;
+        d.idx64 = 1;
+        d.fm = 0;
+        d.row0_is_data = 0;
+        a.off[i] = off;
+        off += batch * (s.kind == NRX_SPARSE ? 1 : s.bag_len);
+    }
+    a.off[n_feats] = off;
+    a.batch = batch;
+    a.g_out = g_out;
+    a.out_ld = out_ld;
+    a.g_wide = g_wide;
+    a.wide_ld = wide_ld;
+    a.order = order;
+    a.seg_start = seg_start;
+    a.n_unique = n_unique;
+    a.values = values;
+    a.n = n_feats;
+    a.dim = dim;
+    int ql = ceil_log2((dim + 3) / 4);
+    if (ql > 6) ql = 6;
+    const int tb = NRX_BLOCK >> ql;
+    const unsigned grid = (unsigned)((n_unique + tb - 1) / tb);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    NRX_QSWITCH(ql, { hipLaunchKernelGGL((embed_bwd_sorted_kernel<QL>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); });
+    NRX_LAUNCH_CHECK("nrx_embed_bwd_sorted");
     return NRX_OK;
 }

@@ -74,6 +74,9 @@ class BaseModel(LightningModule):
         self.embedding_size: Dict[str, int] = dict(e.get("embedding_size") or {})
         self.embedding_table_size: Dict[str, int] = dict(e.get("embedding_table_size") or {})
         self.share_emb_table_features: Dict[str, str] = dict(e.get("share_emb_table_features") or {})
+        # new optional key (default = reference behaviour: dense weight.grad): deterministic row-sparse
+        # table gradients, for tables too large to zero-fill / dense-update every step
+        self.sparse_grad: bool = bool(e.get("sparse_grad", False))
 
         self.dataset_cfg = self.config.get("dataset", {}) or {}
         self.train_hparams = self.config.get("train_hparams", {}) or {}
@@ -204,7 +207,8 @@ class BaseModel(LightningModule):
         tables = [self.embedding_tables[t].weight for t in table_names]
         inputs = [batch[s.name] for s in plan.slots]
         weights = [batch.get(f"{s.name}_mask") if s.kind == NRX_BAG_MASKED_MEAN else None for s in plan.slots]
-        out, wide, fmv = ops.embed_apply(plan, tables, inputs, weights, out_ld=out_ld, need_out=need_out)
+        out, wide, fmv = ops.embed_apply(plan, tables, inputs, weights, out_ld=out_ld, need_out=need_out,
+                                         sparse_grad=self.sparse_grad)
         return out, wide, fmv, list(dims), list(present)
 
     def get_embeddings_from_batch(self, batch: Dict[str, torch.Tensor], feature_names) -> Tuple[torch.Tensor, List[int], List[str]]:
@@ -253,6 +257,14 @@ class BaseModel(LightningModule):
         """configure_optimizers of every sort model (e.g. sort/deep/model.py:54-65)."""
         from ..model_utils.lr_schedule import CosinDecayLR
         hp = self.train_hparams
-        optimizer = torch.optim.AdamW(self.parameters(), lr=hp.lr, betas=(0.9, 0.999))
+        if self.sparse_grad:
+            # AdamW cannot take sparse grads: tables go to SparseAdam (lazy moments, no weight decay --
+            # a documented deviation from the reference's dense AdamW), everything else stays AdamW
+            from ..model_utils.optim import SparseDenseAdam
+            table_params = [e.weight for e in self.embedding_tables.values()]
+            ids = {id(p) for p in table_params}
+            optimizer = SparseDenseAdam(table_params, [p for p in self.parameters() if id(p) not in ids], lr=hp.lr)
+        else:
+            optimizer = torch.optim.AdamW(self.parameters(), lr=hp.lr, betas=(0.9, 0.999))
         sched = CosinDecayLR(optimizer, lrs=[hp.lr, hp.min_lr], milestones=list(hp.lr_milestones))
         return {"optimizer": optimizer, "lr_scheduler": {"scheduler": sched, "interval": "step", "frequency": 1}}

@@ -124,7 +124,7 @@ def _fill_features(plan: EmbedPlan, lo: int, hi: int, tables: Sequence[torch.Ten
         else:
             t = tables[s.table]
             f.table = table_ptrs[s.table] if table_ptrs is not None else t.data_ptr()
-            f.rows = t.shape[0]
+            f.rows = t.shape[0] if t is not None else 0
         w = weights[lo + i]
         f.weight = None if w is None else w.data_ptr()
     return arr
@@ -169,8 +169,9 @@ def _prep_inputs(plan: EmbedPlan, tables, inputs, weights):
 
 class _EmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan: EmbedPlan, inputs, weights, out_ld, need_out, *tables):
+    def forward(ctx, plan: EmbedPlan, inputs, weights, out_ld, need_out, sparse_grad, *tables):
         lib = _lib.load()
+        ctx.sparse_grad = bool(sparse_grad)
         B, ins, ws = _prep_inputs(plan, tables, inputs, weights)
         dev = tables[0].device if tables else ins[0].device
         ld = int(out_ld) if out_ld else plan.out_width
@@ -216,7 +217,7 @@ class _EmbedFn(torch.autograd.Function):
         plan, B, ld = ctx.plan, ctx.B, ctx.ld
         n_tables = len(ctx.table_meta)
         if g_out is None and g_wide is None and g_fm is None:
-            return (None,) * (5 + n_tables)
+            return (None,) * (6 + n_tables)
         dev = ctx.table_meta[0][1]
         stream = torch.cuda.current_stream(dev).cuda_stream
         if g_out is not None:
@@ -236,6 +237,8 @@ class _EmbedFn(torch.autograd.Function):
                                  g_out.data_ptr(), ld, acc, stream), "nrx_fm_bwd")
         if g_wide is not None:
             g_wide = _f32c(g_wide, "grad of wide_x")
+        if ctx.sparse_grad:
+            return (None, None, None, None, None, None, *_sorted_sparse_grads(ctx, lib, g_out, g_wide, stream))
         grads = [torch.zeros(shape, dtype=torch.float32, device=d) for shape, d in ctx.table_meta]
         if B > 0 and (g_out is not None or g_wide is not None):
             gptrs = [g.data_ptr() for g in grads]
@@ -245,16 +248,53 @@ class _EmbedFn(torch.autograd.Function):
                 arr = _fill_features(plan, lo, hi, grads, ctx.ins, ctx.ws, table_ptrs=gptrs)
                 check(lib.nrx_embed_bwd(arr, hi - lo, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, stream),
                       "nrx_embed_bwd")
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
+
+
+def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream):
+    """Row-sparse, deterministic table grads: per table, sort its lookups by row id (torch.sort = rocPRIM
+    radix sort; plumbing), then ONE segmented-reduction launch (nrx_embed_bwd_sorted) sums the upstream
+    rows of every unique id in sorted order.  No dense zero-fill, no atomics, bit-reproducible; the
+    padding row 0 gets an explicit zero.  Returns torch.sparse_coo tensors (what nn.Embedding(sparse=True)
+    produces), usable with SGD / SparseAdam / Adagrad."""
+    plan, B, ld = ctx.plan, ctx.B, ctx.ld
+    out = []
+    for ti, (shape, dev) in enumerate(ctx.table_meta):
+        fs = [i for i, s in enumerate(plan.slots) if s.kind != NRX_DENSE and s.table == ti]
+        D = shape[1]
+        if not fs or B == 0:
+            out.append(torch.sparse_coo_tensor(torch.zeros((1, 0), dtype=torch.int64, device=dev),
+                                               torch.zeros((0, D), dtype=torch.float32, device=dev), size=shape))
+            continue
+        keys = torch.cat([ctx.ins[i].reshape(-1).long() for i in fs]) if len(fs) > 1 else ctx.ins[fs[0]].reshape(-1).long()
+        skeys, order = torch.sort(keys, stable=True)
+        uniq, counts = torch.unique_consecutive(skeys, return_counts=True)
+        seg = torch.zeros(uniq.numel() + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts, 0, out=seg[1:])
+        nu = uniq.numel()
+        values = torch.empty((nu, D), dtype=torch.float32, device=dev)
+        sub = EmbedPlan([plan.slots[i] for i in fs], out_width=plan.out_width, wide_width=plan.wide_width)
+        arr = _fill_features(sub, 0, len(fs), [None] * (ti + 1), [ctx.ins[i] for i in fs], [ctx.ws[i] for i in fs],
+                             table_ptrs=[0] * (ti + 1), fm=False)
+        check(lib.nrx_embed_bwd_sorted(arr, len(fs), B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width,
+                                       order.data_ptr(), seg.data_ptr(), nu, values.data_ptr(), stream),
+              "nrx_embed_bwd_sorted")
+        values[0].mul_((uniq[0] != 0).to(values.dtype))          # padding row never trains (base_model.py:164)
+        g = torch.sparse_coo_tensor(uniq.unsqueeze(0), values, size=shape)
+        out.append(g._coalesced_(True))
+    return out
 
 
 def embed_apply(plan: EmbedPlan, tables: Sequence[torch.Tensor], inputs: Sequence[torch.Tensor],
-                weights: Sequence[Optional[torch.Tensor]], out_ld: Optional[int] = None, need_out: bool = True):
+                weights: Sequence[Optional[torch.Tensor]], out_ld: Optional[int] = None, need_out: bool = True,
+                sparse_grad: bool = False):
     """Run the fused gather(+pool)->concat.  Returns (out[B, out_ld or out_width] | None,
-    wide[B, wide_width] | None, fm[B] | None).  Differentiable w.r.t. `tables` (dense grads)."""
+    wide[B, wide_width] | None, fm[B] | None).  Differentiable w.r.t. `tables`: dense grads by default
+    (what the reference's nn.Embedding(sparse=False) produces), or -- sparse_grad=True -- deterministic
+    row-sparse COO grads (sorted segmented reduction; no full-table zero-fill)."""
     if not need_out and not (plan.use_fm or plan.wide_width):
         raise ValueError("need_out=False only makes sense with an FM or wide output")
-    return _EmbedFn.apply(plan, list(inputs), list(weights), out_ld, need_out, *tables)
+    return _EmbedFn.apply(plan, list(inputs), list(weights), out_ld, need_out, sparse_grad, *tables)
 
 
 class PreparedEmbed:

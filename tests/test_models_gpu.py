@@ -167,3 +167,35 @@ def test_training_steps_reduce_loss():
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0]
+
+
+def test_sparse_grad_mode_trains_with_split_optimizer(tmp_path):
+    """`embeddings.sparse_grad: true`: table grads are COO, the reference's loss is reproduced, grads
+    densify to the reference's, and a few steps of the SparseAdam+AdamW pair reduce the loss."""
+    import yaml
+    g = gold("model_deep_array")
+    cfg = yaml.safe_load(open(os.path.join(CONFIGS, "cf_array_small.yaml")))
+    cfg["embeddings"]["sparse_grad"] = True
+    cpath = tmp_path / "cfg.yaml"
+    cpath.write_text(yaml.safe_dump(cfg))
+    m = Deep(str(cpath))
+    m.load_state_dict({k[len("param/"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param/")}, strict=True)
+    m = m.to(DEV)
+    batch = batch_of(g)
+    out = m(batch)
+    loss = m.bceLoss(out, batch["label"][:, 0])
+    np.testing.assert_allclose(loss.item(), g["out/loss"], rtol=1e-5)
+    loss.backward()
+    for name, emb in m.embedding_tables.items():
+        assert emb.weight.grad.is_sparse
+        want = g[f"grad/embedding_tables.{name}.weight"]
+        np.testing.assert_allclose(emb.weight.grad.to_dense().cpu().numpy(), want, rtol=2e-3, atol=2e-6 + 1e-4 * np.abs(want).max())
+    opt = m.configure_optimizers()["optimizer"]
+    losses = []
+    for step in range(8):
+        opt.zero_grad()
+        l = m.training_step(batch, step)
+        l.backward()
+        opt.step()
+        losses.append(l.item())
+    assert losses[-1] < losses[0]

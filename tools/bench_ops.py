@@ -57,6 +57,19 @@ if want("embed_bwd"):
     st = torch.cuda.current_stream().cuda_stream
     us = timeit(lambda: lib.nrx_embed_bwd(arr, F, B, up.data_ptr(), F * D, None, 0, st))
     print(f"embed bwd scatter kernel alone (atomics into 26 x 1M x 16): {us:8.1f} us  {B * F * (8 + 64 + 2 * 64) / us / 1e3:7.1f} GB/s algorithmic (ids + g read + row RMW)", flush=True)
+if want("train_step"):
+    F, D, rows = 26, 16, 1_000_000
+    gen = torch.Generator(device=dev).manual_seed(1)
+    tables = [torch.randn(rows, D, device=dev).requires_grad_(True) for _ in range(F)]
+    plan = ops.EmbedPlan([ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, i * D, fm_field=1) for i in range(F)], out_width=F * D, use_fm=True)
+    ids = [torch.randint(1, rows, (B,), device=dev, generator=gen) for _ in range(F)]
+    for sg in (False, True):
+        def step():
+            out, _, fm = ops.embed_apply(plan, tables, ids, [None] * F, sparse_grad=sg)
+            (out.sum() * 1e-6 + fm.sum()).backward()
+            for t in tables: t.grad = None
+        us = timeit(step, steps=10)
+        print(f"C2 embed+FM forward+backward, sparse_grad={sg}: {us:9.1f} us  -> {B / us:7.2f} M impressions/s", flush=True)
 if want("fm"):
     x = torch.randn(B, 416, device=dev)
     with torch.no_grad():
