@@ -111,12 +111,20 @@ NRX_API int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_t b
  * sparse feature contributes B lookups, a bag feature B*bag_len), and unique row u owns the sorted
  * entries seg_start[u] .. seg_start[u+1).  For every unique row the kernel sums, in sorted order,
  *   g_out[b, cols of the feature] * (1 | w/(sum w + 1e-8) | 1/L | w)
- * into values[u, :dim] -- no atomics, bit-reproducible.  Rows that must not train (id 0) are simply
- * not passed in.  order / seg_start: device int64; values: device [n_unique, dim].              */
+ * into values[u, :dim] -- no atomics, bit-reproducible.  uniq_keys (optional, device int64
+ * [n_unique]): the sort key of each unique entry; entries whose low 40 bits (the row id) are 0 -- the
+ * padding row, which never trains -- get zeros.  order / seg_start: device int64; values [n_unique, dim]. */
 NRX_API int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
                          const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
-                         const int64_t* order, const int64_t* seg_start, int64_t n_unique,
-                         float* values, void* stream);
+                         const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
+                         int64_t n_unique, float* values, void* stream);
+
+/* Composite sort keys for nrx_embed_bwd_sorted over SEVERAL tables at once: for the flat,
+ * feature-major lookup list of n_feats features (ids[f]: lens[f] elements; HOST pointer arrays),
+ * keys[p] = (table_of[f] << 40) | id, so that one stable sort groups the lookups by (table, row).
+ * Negative ids map to row 0 of their table (the padding row, which never trains).               */
+NRX_API int nrx_make_table_keys(const void* const* ids, const int64_t* lens, const int32_t* table_of,
+                        int32_t n_feats, int32_t index_bits, int64_t* keys, void* stream);
 
 /* ---- standalone pooling on materialised embeddings -------------------------------------------
  * BaseModel.array_feature_pooling(emb[B,L,D], mask[B,L] | None) (base_model.py:273-282).       */

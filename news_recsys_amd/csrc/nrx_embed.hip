@@ -468,6 +468,7 @@ struct SortedBwdArgs {
     int64_t wide_ld;
     const int64_t* order;
     const int64_t* seg_start;
+    const int64_t* uniq_keys;   // optional: (table << 40 | row) of each unique entry; row 0 -> zero grad
     int64_t n_unique;
     float* values;
     int32_t n;
@@ -484,7 +485,10 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_kernel(const Sorte
     const int64_t u = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
     if (u >= a->n_unique) return;
     const int D = a->dim;
-    const int64_t lo = nrx_gconst<int64_t>(a->seg_start)[u], hi = nrx_gconst<int64_t>(a->seg_start)[u + 1];
+    const int64_t lo = nrx_gconst<int64_t>(a->seg_start)[u];
+    int64_t hi = nrx_gconst<int64_t>(a->seg_start)[u + 1];
+    // padding row (id 0) never trains (nn.Embedding(padding_idx=0)): its segment is skipped, zeros are written
+    if (a->uniq_keys != nullptr && (nrx_gconst<int64_t>(a->uniq_keys)[u] & ((1ll << 40) - 1)) == 0) hi = lo;
     for (int k0 = q * 4; k0 < D; k0 += 4 * Q) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int64_t e = lo; e < hi; ++e) {
@@ -760,8 +764,8 @@ extern "C" int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_
 
 extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
                                     const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
-                                    const int64_t* order, const int64_t* seg_start, int64_t n_unique,
-                                    float* values, void* stream) {
+                                    const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
+                                    int64_t n_unique, float* values, void* stream) {
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_bwd_sorted: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0 && dim >= 1 && n_unique >= 0, "nrx_embed_bwd_sorted: bad argument");
@@ -800,6 +804,7 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     a.wide_ld = wide_ld;
     a.order = order;
     a.seg_start = seg_start;
+    a.uniq_keys = uniq_keys;
     a.n_unique = n_unique;
     a.values = values;
     a.n = n_feats;

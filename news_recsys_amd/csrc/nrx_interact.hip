@@ -111,27 +111,54 @@ __global__ __launch_bounds__(NRX_BLOCK) void fm_bwd_kernel(const float* __restri
                                                            bool accumulate, bool vec) {
     constexpr int Q = 1 << QLOG2;
     constexpr int TB = NRX_BLOCK / Q;
+    constexpr int U = 8;               // field rows in flight per lane
     const int q = threadIdx.x & (Q - 1);
     const int64_t b = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
     if (b >= batch) return;
     const float gl = g_fm[b];
+    const bool gvec = vec && (g_ld & 3) == 0 && ((reinterpret_cast<uintptr_t>(g_feat) & 15u) == 0);
     for (int kc = 0; kc < D; kc += 4 * Q) {
         const int k0 = kc + q * 4;
         if (k0 >= D) continue;
         const float* row = feat + b * ld + k0;
+        float* grow = g_feat + b * g_ld + k0;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int f = 0; f < F; ++f) {
+        int f = 0;
+        for (; f + U <= F; f += U) {          // pass 1: S = sum over fields (U independent loads in flight)
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = ld4(row + (int64_t)(f + u) * D, k0, D, vec);
+#pragma unroll
+            for (int u = 0; u < U; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; f < F; ++f) {
             const float4 v = ld4(row + (int64_t)f * D, k0, D, vec);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        for (int f = 0; f < F; ++f) {
-            const float4 v = ld4(row + (int64_t)f * D, k0, D, vec);
-            float g[4] = {gl * (s.x - v.x), gl * (s.y - v.y), gl * (s.z - v.z), gl * (s.w - v.w)};
-            if (k0 == 0) g[0] = gl;     // d/dw = 1
-            float* gp = g_feat + b * g_ld + (int64_t)f * D + k0;
+        for (f = 0; f < F; f += U) {          // pass 2: d/dv_f = gl * (S - v_f); the rows are L1/L2-hot
+            float4 v[U], old[U];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k0 + j < D) gp[j] = accumulate ? gp[j] + g[j] : g[j];
+            for (int u = 0; u < U; ++u) {
+                if (f + u < F) {
+                    v[u] = ld4(row + (int64_t)(f + u) * D, k0, D, vec);
+                    old[u] = (accumulate && gvec) ? *reinterpret_cast<const float4*>(grow + (int64_t)(f + u) * D) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (f + u < F) {
+                    float g[4] = {gl * (s.x - v[u].x), gl * (s.y - v[u].y), gl * (s.z - v[u].z), gl * (s.w - v[u].w)};
+                    if (k0 == 0) g[0] = gl;     // d/dw = 1
+                    float* gp = grow + (int64_t)(f + u) * D;
+                    if (gvec && k0 + 4 <= D) {
+                        *reinterpret_cast<float4*>(gp) = make_float4(old[u].x + g[0], old[u].y + g[1], old[u].z + g[2], old[u].w + g[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (k0 + j < D) gp[j] = accumulate ? gp[j] + g[j] : g[j];
+                    }
+                }
+            }
         }
     }
 }

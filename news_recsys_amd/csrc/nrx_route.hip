@@ -187,6 +187,32 @@ __global__ __launch_bounds__(NRX_BLOCK) void route_place(const RouteArgs args_in
     }
 }
 
+// composite (table, row) keys for the sorted backward
+struct KeyArgs {
+    const void* ids[NRX_MAX_FEATURES];
+    int64_t off[NRX_MAX_FEATURES + 1];
+    int32_t table_of[NRX_MAX_FEATURES];
+    int32_t n_feats;
+    int32_t idx64;
+    int64_t n_total;
+    int64_t* keys;
+};
+
+__global__ __launch_bounds__(NRX_BLOCK) void make_keys_kernel(const KeyArgs args_in_kernarg) {
+    const NRX_CONST KeyArgs* a = nrx_kernarg<KeyArgs>();
+    for (int64_t p = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x; p < a->n_total; p += (int64_t)gridDim.x * NRX_BLOCK) {
+        int lo = 0, hi = a->n_feats;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a->off[mid] <= p) lo = mid; else hi = mid;
+        }
+        const int64_t i = p - a->off[lo];
+        int64_t id = a->idx64 ? nrx_gconst<int64_t>(a->ids[lo])[i] : (int64_t)nrx_gconst<int32_t>(a->ids[lo])[i];
+        if (id < 0) id = 0;
+        a->keys[p] = ((int64_t)a->table_of[lo] << 40) | (id & ((1ll << 40) - 1));
+    }
+}
+
 // ------------------------------------------------------------------------------- owner side
 struct InboxArgs {
     float* table[NRX_MAX_FEATURES];        // weight tables (gather) or grad tables (scatter)
@@ -422,4 +448,33 @@ extern "C" int nrx_scatter_add_inbox(float* const* grad_tables, const int64_t* t
     a.status = nullptr;
     a.skip_row0 = skip_row0;
     return launch_inbox<true>(a, reinterpret_cast<hipStream_t>(stream), "nrx_scatter_add_inbox");
+}
+
+extern "C" int nrx_make_table_keys(const void* const* ids, const int64_t* lens, const int32_t* table_of,
+                                   int32_t n_feats, int32_t index_bits, int64_t* keys, void* stream) {
+    NRX_REQUIRE(ids && lens && table_of && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
+                "nrx_make_table_keys: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
+    NRX_REQUIRE(index_bits == 32 || index_bits == 64, "nrx_make_table_keys: index_bits must be 32 or 64");
+    KeyArgs a;
+    int64_t off = 0;
+    for (int f = 0; f < n_feats; ++f) {
+        NRX_REQUIRE(lens[f] >= 0 && (lens[f] == 0 || ids[f] != nullptr), "nrx_make_table_keys: feature %d: bad ids/len", f);
+        NRX_REQUIRE(table_of[f] >= 0 && table_of[f] < (1 << 20), "nrx_make_table_keys: feature %d: bad table index", f);
+        a.ids[f] = ids[f];
+        a.off[f] = off;
+        a.table_of[f] = table_of[f];
+        off += lens[f];
+    }
+    a.off[n_feats] = off;
+    a.n_feats = n_feats;
+    a.idx64 = index_bits == 64;
+    a.n_total = off;
+    a.keys = keys;
+    if (off == 0) return NRX_OK;
+    NRX_REQUIRE(keys != nullptr, "nrx_make_table_keys: null keys buffer");
+    int64_t g = (off + NRX_BLOCK - 1) / NRX_BLOCK;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(make_keys_kernel, dim3((unsigned)g), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), a);
+    NRX_LAUNCH_CHECK("nrx_make_table_keys");
+    return NRX_OK;
 }

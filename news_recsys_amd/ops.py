@@ -252,37 +252,64 @@ class _EmbedFn(torch.autograd.Function):
 
 
 def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream):
-    """Row-sparse, deterministic table grads: per table, sort its lookups by row id (torch.sort = rocPRIM
-    radix sort; plumbing), then ONE segmented-reduction launch (nrx_embed_bwd_sorted) sums the upstream
-    rows of every unique id in sorted order.  No dense zero-fill, no atomics, bit-reproducible; the
-    padding row 0 gets an explicit zero.  Returns torch.sparse_coo tensors (what nn.Embedding(sparse=True)
-    produces), usable with SGD / SparseAdam / Adagrad."""
+    """Row-sparse, deterministic table grads.  Per group of tables sharing an embedding dim: composite
+    (table << 40 | row) keys for all lookups (nrx_make_table_keys), ONE stable sort (torch.sort = rocPRIM
+    radix sort; plumbing), ONE segmented-reduction launch (nrx_embed_bwd_sorted) summing the upstream rows
+    of every unique (table, row) in sorted order, one host read for the per-table split.  No dense
+    zero-fill, no atomics, bit-reproducible; padding rows get explicit zeros.  Returns torch.sparse_coo
+    tensors (what nn.Embedding(sparse=True) produces), usable with SGD / SparseAdam / Adagrad."""
     plan, B, ld = ctx.plan, ctx.B, ctx.ld
-    out = []
-    for ti, (shape, dev) in enumerate(ctx.table_meta):
-        fs = [i for i, s in enumerate(plan.slots) if s.kind != NRX_DENSE and s.table == ti]
-        D = shape[1]
-        if not fs or B == 0:
-            out.append(torch.sparse_coo_tensor(torch.zeros((1, 0), dtype=torch.int64, device=dev),
-                                               torch.zeros((0, D), dtype=torch.float32, device=dev), size=shape))
-            continue
-        keys = torch.cat([ctx.ins[i].reshape(-1).long() for i in fs]) if len(fs) > 1 else ctx.ins[fs[0]].reshape(-1).long()
-        skeys, order = torch.sort(keys, stable=True)
-        uniq, counts = torch.unique_consecutive(skeys, return_counts=True)
-        seg = torch.zeros(uniq.numel() + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(counts, 0, out=seg[1:])
-        nu = uniq.numel()
-        values = torch.empty((nu, D), dtype=torch.float32, device=dev)
-        sub = EmbedPlan([plan.slots[i] for i in fs], out_width=plan.out_width, wide_width=plan.wide_width)
-        arr = _fill_features(sub, 0, len(fs), [None] * (ti + 1), [ctx.ins[i] for i in fs], [ctx.ws[i] for i in fs],
-                             table_ptrs=[0] * (ti + 1), fm=False)
-        check(lib.nrx_embed_bwd_sorted(arr, len(fs), B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width,
-                                       order.data_ptr(), seg.data_ptr(), nu, values.data_ptr(), stream),
-              "nrx_embed_bwd_sorted")
-        values[0].mul_((uniq[0] != 0).to(values.dtype))          # padding row never trains (base_model.py:164)
-        g = torch.sparse_coo_tensor(uniq.unsqueeze(0), values, size=shape)
-        out.append(g._coalesced_(True))
-    return out
+    n_tables = len(ctx.table_meta)
+    grads = [None] * n_tables
+    by_dim = {}
+    for i, s in enumerate(plan.slots):
+        if s.kind != NRX_DENSE:
+            by_dim.setdefault(s.dim, []).append(i)
+    MASK = (1 << 40) - 1
+    for D, fs_all in by_dim.items():
+        for c0 in range(0, len(fs_all), NRX_MAX_FEATURES):
+            fs = fs_all[c0:c0 + NRX_MAX_FEATURES]
+            dev = ctx.table_meta[plan.slots[fs[0]].table][1]
+            ids = [ctx.ins[i] for i in fs]
+            dt = ids[0].dtype
+            if any(x.dtype != dt for x in ids):
+                ids = [x.long() for x in ids]
+            n = len(fs)
+            total = sum(x.numel() for x in ids)
+            if total == 0:
+                continue
+            keys = torch.empty(total, dtype=torch.int64, device=dev)
+            ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in ids])
+            lens = (C.c_int64 * n)(*[x.numel() for x in ids])
+            tof = (C.c_int32 * n)(*[plan.slots[i].table for i in fs])
+            check(lib.nrx_make_table_keys(ptrs, lens, tof, n, ids[0].element_size() * 8, keys.data_ptr(), stream),
+                  "nrx_make_table_keys")
+            skeys, order = torch.sort(keys, stable=True)
+            uniq, counts = torch.unique_consecutive(skeys, return_counts=True)
+            nu = uniq.numel()
+            seg = torch.zeros(nu + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(counts, 0, out=seg[1:])
+            values = torch.empty((nu, D), dtype=torch.float32, device=dev)
+            sub = EmbedPlan([plan.slots[i] for i in fs], out_width=plan.out_width, wide_width=plan.wide_width)
+            arr = _fill_features(sub, 0, n, [None] * n_tables, ids, [ctx.ws[i] for i in fs], table_ptrs=[0] * n_tables, fm=False)
+            check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width,
+                                           order.data_ptr(), seg.data_ptr(), uniq.data_ptr(), nu, values.data_ptr(), stream),
+                  "nrx_embed_bwd_sorted")                         # padding rows (id 0) come back as zeros
+            rows = uniq & MASK
+            tids = sorted({plan.slots[i].table for i in fs})
+            bounds = torch.searchsorted(uniq, torch.tensor([t << 40 for t in tids] + [(tids[-1] + 1) << 40],
+                                                            dtype=torch.int64, device=dev)).tolist()   # the one host read
+            for k, t in enumerate(tids):
+                lo, hi = bounds[k], bounds[k + 1]
+                g = torch.sparse_coo_tensor(rows[lo:hi].unsqueeze(0), values[lo:hi], size=ctx.table_meta[t][0])
+                g = g._coalesced_(True)
+                grads[t] = g if grads[t] is None else (grads[t] + g).coalesce()
+    for t in range(n_tables):
+        if grads[t] is None:
+            shape, dev = ctx.table_meta[t]
+            grads[t] = torch.sparse_coo_tensor(torch.zeros((1, 0), dtype=torch.int64, device=dev),
+                                               torch.zeros((0, shape[1]), dtype=torch.float32, device=dev), size=shape)
+    return grads
 
 
 def embed_apply(plan: EmbedPlan, tables: Sequence[torch.Tensor], inputs: Sequence[torch.Tensor],
