@@ -43,7 +43,7 @@ def workload_spec(name: str):
     if name == "c3":      # DCN: 5 feats D=64, news table 100M rows
         rows = dict(item_id=100_000_000, user_id=1_000_000, category=18, subcategory=270, user_click_category=18)
         feats = [dict(name=k, rows=v, dim=64, bag=0) for k, v in sorted(rows.items())]
-        return feats, "c3: DCN 5 feats D=64 (item_id 100M rows), B=65536; gather->concat[B,320] + fused 2-layer cross"
+        return feats, "c3: DCN 5 feats D=64 (item_id 100M rows), B=65536; gather->concat into [B,640] + 2-layer cross written next to x (2 launches)"
     if name == "c4":      # DSSM: user_id 10M, item_id 200k, history L=50 shares item table, D=16
         feats = [dict(name="item_id", rows=200_000, dim=16, bag=0),
                  dict(name="user_history", rows=200_000, dim=16, bag=50, share="item_id"),
@@ -127,15 +127,22 @@ class SingleGpuPath:
         out = torch.empty((BATCH, ld), dtype=torch.float32, device=device)
         fmb = torch.empty((BATCH,), dtype=torch.float32, device=device) if self.fm else None
         self.calls = [ops.PreparedEmbed(self.plan, self.tables, ins, ws, out_ld=ld, out=out, fm=fmb) for ins, ws in self.pool]
+        self.fused = None
+        if self.cross and os.environ.get("NRX_BENCH_FUSED_CROSS") == "1":
+            # one-launch gather -> cat[x, cross(x)] (ops.PreparedEmbedDcn): bit-identical, but measured
+            # 72 us vs 62 us for the two launches below on MI355X (round 1) -- opt-in until it wins
+            self.fused = [ops.PreparedEmbedDcn(self.plan, self.tables, ins, self.cross_w, self.cross_b, out=out) for ins, _ in self.pool]
         self.device = device
         from news_recsys_amd import _lib
         self.lib = _lib.load()
 
     @torch.no_grad()
     def step(self, i: int):
+        if self.fused is not None:
+            return self.fused[i % len(self.fused)].run()
         call = self.calls[i % len(self.calls)]
         res = call.run()
-        if self.cross:       # cat[x, cross(x)]: cross written next to x in the same [B, 2D] buffer
+        if self.cross:       # (two-launch form) cat[x, cross(x)]: cross written next to x in the same [B, 2D] buffer
             buf, D = call.out, self.width
             rc = self.lib.nrx_dcn_v1_fwd(buf.data_ptr(), 2 * D, BATCH, D, self.cross_w.shape[0], self.cross_w.data_ptr(),
                                          self.cross_b.data_ptr(), buf.data_ptr() + 4 * D, 2 * D,

@@ -153,6 +153,16 @@ NRX_API int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, int64_t batch, int32_t 
                    const float* w, const float* b, const float* g_out, int64_t g_out_ld,
                    float* g_x, int64_t g_x_ld, float* g_w, float* g_b, void* stream);
 
+/* Fused gather -> concat -> DCN-v1 cross for the DCN ranker (dcn/model.py:25-29 on top of
+ * base_model.py:284-308): out[:, 0:width] = concat of the looked-up rows (x), out[:, width:2*width] =
+ * cross(x); the rows stay in registers through all cross layers, x is never re-read.  Restrictions
+ * (else NRX_ERR_UNSUPPORTED; use nrx_embed_fwd + nrx_dcn_v1_fwd): every feature NRX_SPARSE with
+ * dim % 4 == 0, out_col % 4 == 0, width % 4 == 0, width <= 2048, 16-byte aligned tables / out,
+ * out_ld % 4 == 0 and out_ld >= 2*width.  Bit-identical to the two-launch path.                */
+NRX_API int nrx_embed_dcn_v1_fwd(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t width,
+                         float* out, int64_t out_ld, int32_t n_layers, const float* w, const float* b,
+                         int32_t* status, void* stream);
+
 /* ---- DCN v2 cross layer on the matrix cores: out = act(x0 * (x_l W^T + bias) + x_l) -----------
  * DCNv2Layer.forward + the ReLU DCNv2Net puts after every layer (dcn_arch.py:33-50, 73-91).
  * W: device [dim, dim] (nn.Linear weight: out x in), bias [dim].  fp32 in / fp32 accumulate on

@@ -357,6 +357,113 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_bwd_kernel(const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------ fused gather + DCN v1
+// One wavefront per sample (S samples in flight per wave); the concat row is laid out over the lanes
+// exactly like RowRegs (chunk c = r*64 + lane holds columns 4c..4c+3), so the cross arithmetic and
+// its reduction order are those of dcn_v1_fwd_kernel: bit-identical results.  Which feature / row
+// offset a (lane, r) chunk belongs to is the same for every sample and is resolved once per lane.
+struct EmbedDcnArgs {
+    const float* table[NRX_MAX_FEATURES];
+    const void* index[NRX_MAX_FEATURES];
+    int64_t rows[NRX_MAX_FEATURES];
+    int32_t col[NRX_MAX_FEATURES + 1];   // out_col of each feature (sorted ascending), col[n] = width
+    int64_t batch;
+    float* out;
+    int64_t out_ld;
+    const float* w;
+    const float* b;
+    int32_t* status;
+    int32_t n;
+    int32_t width;
+    int32_t n_layers;
+    int32_t idx64;
+};
+static_assert(sizeof(EmbedDcnArgs) <= 3840, "kernarg budget");
+
+template <int R, int S>
+__global__ __launch_bounds__(NRX_BLOCK) void embed_dcn_v1_kernel(const EmbedDcnArgs args_in_kernarg) {
+    const NRX_CONST EmbedDcnArgs* a = nrx_kernarg<EmbedDcnArgs>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int W = a->width, NL = a->n_layers;
+    float* s_w = reinterpret_cast<float*>(smem);          // [NL][W]
+    float* s_b = s_w + NL * W;
+    for (int i = threadIdx.x; i < NL * W; i += NRX_BLOCK) {
+        s_w[i] = a->w[i];
+        s_b[i] = a->b[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    // per-lane chunk -> (feature, float4 offset inside the row), resolved once
+    const float* tab[R];
+    const void* idxp[R];
+    int64_t nrows[R];
+    int koff[R], feat[R];
+    bool on[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int c4 = (r * 64 + lane) * 4;
+        on[r] = c4 < W;
+        int lo = 0, hi = a->n;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a->col[mid] <= c4) lo = mid; else hi = mid;
+        }
+        on[r] = on[r] && c4 < a->col[lo + 1];          // (holes between features stay zero)
+        feat[r] = lo;
+        tab[r] = a->table[lo];
+        idxp[r] = a->index[lo];
+        nrows[r] = a->rows[lo];
+        koff[r] = c4 - a->col[lo];
+    }
+    const int64_t wave = (int64_t)blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (NRX_BLOCK / 64);
+    for (int64_t b0 = wave * S; b0 < a->batch; b0 += nwaves * S) {
+        RowRegs<R, 4> x0[S];
+        int64_t id[S][R];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                id[s][r] = 0;
+                if (on[r] && b0 + s < a->batch)
+                    id[s][r] = a->idx64 ? nrx_gconst<int64_t>(idxp[r])[b0 + s] : (int64_t)nrx_gconst<int32_t>(idxp[r])[b0 + s];
+            }
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (on[r] && b0 + s < a->batch) {
+                    int64_t i = id[s][r];
+                    if ((uint64_t)i >= (uint64_t)nrows[r]) {
+                        if (koff[r] == 0) nrx_report_oob(a->status, feat[r], b0 + s, i);
+                        i = 0;
+                    }
+                    v = nrx_ldg4(tab[r] + i * (int64_t)(a->col[feat[r] + 1] - a->col[feat[r]]) + koff[r], 0);
+                }
+                x0[s].v[r][0] = v.x; x0[s].v[r][1] = v.y; x0[s].v[r][2] = v.z; x0[s].v[r][3] = v.w;
+            }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (b0 + s >= a->batch) break;
+            RowRegs<R, 4> xl = x0[s];
+            for (int l = 0; l < NL; ++l) {
+                RowRegs<R, 4> wl, bl;
+                row_load<R, 4>(wl, s_w + l * W, W, lane);
+                row_load<R, 4>(bl, s_b + l * W, W, lane);
+                const float dot = row_dot<R, 4>(xl, wl);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xl.v[r][j] = x0[s].v[r][j] * dot + bl.v[r][j] + xl.v[r][j];
+            }
+            float* o = a->out + (b0 + s) * a->out_ld;
+            row_store<R, 4>(x0[s], o, W, lane);
+            row_store<R, 4>(xl, o + W, W, lane);
+        }
+    }
+}
+
 int ceil_log2i(int x) {
     int l = 0;
     while ((1 << l) < x) ++l;
@@ -506,5 +613,57 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, int64_t batch, int32
     }
 #undef NRX_DCN_BWD
     NRX_LAUNCH_CHECK("nrx_dcn_v1_bwd");
+    return NRX_OK;
+}
+
+extern "C" int nrx_embed_dcn_v1_fwd(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t width,
+                                    float* out, int64_t out_ld, int32_t n_layers, const float* w, const float* b,
+                                    int32_t* status, void* stream) {
+    NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
+                "nrx_embed_dcn_v1_fwd: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
+    NRX_REQUIRE(batch >= 0 && out != nullptr && width >= 4, "nrx_embed_dcn_v1_fwd: bad argument");
+    NRX_REQUIRE(n_layers >= 1 && n_layers <= NRX_MAX_DCN_LAYERS && w && b, "nrx_embed_dcn_v1_fwd: n_layers must be in [1, %d]", NRX_MAX_DCN_LAYERS);
+#define NRX_UNSUP(cond, ...) do { if (!(cond)) { nrx_set_error(__VA_ARGS__); return NRX_ERR_UNSUPPORTED; } } while (0)
+    NRX_UNSUP((width & 3) == 0 && width <= 2048, "nrx_embed_dcn_v1_fwd: width must be a multiple of 4 and <= 2048");
+    NRX_UNSUP((out_ld & 3) == 0 && out_ld >= 2 * (int64_t)width && nrx_aligned16(out), "nrx_embed_dcn_v1_fwd: out must be 16-byte aligned with out_ld %% 4 == 0 and >= 2*width");
+    EmbedDcnArgs a;
+    int prev_end = 0;
+    for (int i = 0; i < n_feats; ++i) {
+        const nrx_feature_t& s = feats[i];
+        NRX_UNSUP(s.kind == NRX_SPARSE && s.wide_col < 0, "nrx_embed_dcn_v1_fwd: feature %d: only plain single-valued features are fused", i);
+        NRX_UNSUP((s.dim & 3) == 0 && (s.out_col & 3) == 0 && nrx_aligned16(s.table), "nrx_embed_dcn_v1_fwd: feature %d: dim/out_col %% 4 and 16-byte aligned table required", i);
+        NRX_REQUIRE(s.table && s.index && s.rows >= 1 && s.rows <= 0x7fffffffLL, "nrx_embed_dcn_v1_fwd: feature %d: bad table/index/rows", i);
+        NRX_REQUIRE(s.index_bits == feats[0].index_bits && (s.index_bits == 32 || s.index_bits == 64), "nrx_embed_dcn_v1_fwd: mixed index widths");
+        NRX_REQUIRE(s.out_col >= prev_end && s.out_col + s.dim <= width, "nrx_embed_dcn_v1_fwd: features must be ordered by out_col, non-overlapping, inside width");
+        NRX_UNSUP(s.out_col == prev_end, "nrx_embed_dcn_v1_fwd: the concat must be gap-free");
+        prev_end = s.out_col + s.dim;
+        a.table[i] = s.table;
+        a.index[i] = s.index;
+        a.rows[i] = s.rows;
+        a.col[i] = s.out_col;
+    }
+    NRX_UNSUP(prev_end == width, "nrx_embed_dcn_v1_fwd: features must fill the whole width");
+#undef NRX_UNSUP
+    a.col[n_feats] = width;
+    if (batch == 0) return NRX_OK;
+    a.batch = batch;
+    a.out = out;
+    a.out_ld = out_ld;
+    a.w = w;
+    a.b = b;
+    a.status = status;
+    a.n = n_feats;
+    a.width = width;
+    a.n_layers = n_layers;
+    a.idx64 = feats[0].index_bits == 64;
+    const size_t smem = (size_t)2 * n_layers * width * sizeof(float);
+    NRX_REQUIRE(smem <= 64 * 1024, "nrx_embed_dcn_v1_fwd: n_layers*width too large for the LDS stage");
+    const int R = (width + 255) / 256;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const unsigned grid = stream_grid((batch + 7) / 8, NRX_BLOCK / 64);
+#define NRX_ED(R_, S_) hipLaunchKernelGGL((embed_dcn_v1_kernel<R_, S_>), dim3(grid), dim3(NRX_BLOCK), smem, st, a)
+    if (R <= 1) NRX_ED(1, 8); else if (R <= 2) NRX_ED(2, 8); else if (R <= 4) NRX_ED(4, 4); else NRX_ED(8, 2);
+#undef NRX_ED
+    NRX_LAUNCH_CHECK("nrx_embed_dcn_v1_fwd");
     return NRX_OK;
 }

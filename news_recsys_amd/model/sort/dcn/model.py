@@ -34,6 +34,7 @@ class DCN(BaseModel):
     def __init__(self, config_path):
         super().__init__(config_path)
         cfg = self.config.get("dcn_cfg", {}) or {}
+        self.fuse_gather_cross = bool(cfg.get("fuse_gather_cross", False))
         self.score_fc = DCNModel(input_dim=self.user_input_dim + self.item_input_dim,
                                  cross_num_layers=int(cfg.get("cross_num_layers", 3)),
                                  deep_hidden_dims=[128, 128, 128, 64, 1], version=int(cfg.get("version", 1)))
@@ -44,8 +45,22 @@ class DCN(BaseModel):
 
     def forward(self, x):
         m = self.score_fc
+        names = self.user_feature_names | self.item_feature_names
         if m.version == 1 and len(m.cross_net.cross_net) > 0:
-            buf, _, _, _, _ = self._embed(x, self.user_feature_names | self.item_feature_names, out_ld=2 * m.input_dim)
+            if self.fuse_gather_cross and not torch.is_grad_enabled() and getattr(self, "_shard_engine", None) is None:
+                # inference, opt-in (`dcn_cfg.fuse_gather_cross: true`): gather -> cat[x, cross(x)] in ONE launch.
+                # Bit-identical to the two launches below; on MI355X it currently measures 72 us vs 62 us at the
+                # C3 shape, so the default stays the two-launch path.
+                from .... import ops
+                plan, table_names, _, present = self._plan(x, names, False, ())
+                try:
+                    w, b = m.cross_net.stacked()
+                    buf = ops.embed_dcn_v1(plan, [self.embedding_tables[t].weight for t in table_names],
+                                           [x[s.name] for s in plan.slots], w, b)
+                    return torch.sigmoid(m.score_fc(buf))
+                except ops.FusedUnsupported:
+                    pass
+            buf, _, _, _, _ = self._embed(x, names, out_ld=2 * m.input_dim)
             return m.forward_buf_(buf)
         return m(self.get_inp_embedding(x))
 

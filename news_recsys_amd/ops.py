@@ -523,6 +523,57 @@ def dcn_v1_cat_(buf: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Te
     return _DcnV1CatFn.apply(buf, w, b)
 
 
+class FusedUnsupported(Exception):
+    """The fused gather+cross kernel does not cover this feature mix; use the two-launch path."""
+
+
+class PreparedEmbedDcn:
+    """Bound forward of gather -> concat -> DCN-v1 cross in ONE launch (inference / benchmarking):
+    out[:, :W] = x, out[:, W:] = cross(x).  Raises FusedUnsupported when the plan is not eligible
+    (bags, dense features, dims not multiples of 4, ...)."""
+
+    def __init__(self, plan: EmbedPlan, tables, inputs, w: torch.Tensor, b: torch.Tensor,
+                 out: Optional[torch.Tensor] = None, check_index: bool = False):
+        self.lib = _lib.load()
+        if any(s.kind != NRX_SPARSE or s.wide_col >= 0 for s in plan.slots) or plan.use_fm or len(plan.slots) > NRX_MAX_FEATURES:
+            raise FusedUnsupported("only plain single-valued features are fused")
+        self.tables = [t.detach() for t in tables]
+        self.B, self.ins, _ = _prep_inputs(plan, self.tables, list(inputs), [None] * len(plan.slots))
+        self.w, self.b = _dcn_params(w.detach(), b.detach())
+        W = plan.out_width
+        if self.w.shape[1] != W:
+            raise ValueError(f"cross weights are for dim {self.w.shape[1]}, the concat has {W}")
+        dev = self.ins[0].device
+        self.out = out if out is not None else torch.empty((self.B, 2 * W), dtype=torch.float32, device=dev)
+        self.status = torch.zeros(4, dtype=torch.int32, device=dev) if check_index else None
+        self.arr = _fill_features(plan, 0, len(plan.slots), self.tables, self.ins, [None] * len(plan.slots), fm=False)
+        self.plan, self.W, self.device = plan, W, dev
+        self.run()          # eligibility is decided by the library: surface NRX_ERR_UNSUPPORTED now
+
+    def run(self):
+        rc = self.lib.nrx_embed_dcn_v1_fwd(self.arr, len(self.plan.slots), self.B, self.W, self.out.data_ptr(),
+                                           self.out.shape[1], self.w.shape[0], self.w.data_ptr(), self.b.data_ptr(),
+                                           _ptr(self.status), torch.cuda.current_stream(self.device).cuda_stream)
+        if rc == -3:
+            raise FusedUnsupported(self.lib.nrx_last_error().decode())
+        if rc:
+            check(rc, "nrx_embed_dcn_v1_fwd")
+        return self.out
+
+    def check(self):
+        if self.status is not None:
+            _raise_if_oob(self.status, self.plan.names)
+
+
+@torch.no_grad()
+def embed_dcn_v1(plan: EmbedPlan, tables, inputs, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """One-shot fused gather -> cat[x, cross(x)] (no autograd; training uses embed_apply + dcn_v1_cat_)."""
+    call = PreparedEmbedDcn(plan, tables, inputs, w, b, check_index=_INDEX_CHECK != "off")
+    if _INDEX_CHECK == "sync":
+        call.check()
+    return call.out
+
+
 # ------------------------------------------------------------------------------- DCN v2 (MFMA)
 class _DcnV2Fn(torch.autograd.Function):
     @staticmethod

@@ -640,3 +640,41 @@ def test_sorted_sparse_backward_matches_dense_and_is_deterministic(case):
         np.testing.assert_allclose(dense, want[name], rtol=1e-5, atol=1e-6)
         assert np.all(dense[0] == 0)
         assert g.values().shape[0] <= B * 400 and g.indices().min().item() >= 0
+
+
+@pytest.mark.parametrize("B,dims,NL", [(1, [16], 1), (300, [64] * 5, 2), (257, [32, 32, 16, 16, 16], 3), (100, [256] * 8, 1),
+                                       (77, [128, 4, 4, 64], 8), (65, [16] * 26, 2)])
+def test_fused_gather_cross_is_bit_identical_to_two_launches(B, dims, NL):
+    rng = np.random.default_rng(B + len(dims))
+    tables = [rng.standard_normal((40 + 3 * i, d)).astype(np.float32) for i, d in enumerate(dims)]
+    ids = [rng.integers(0, t.shape[0], B) for t in tables]
+    W = sum(dims)
+    cols = np.concatenate([[0], np.cumsum(dims)])
+    plan = ops.EmbedPlan([ops.Slot(f"f{i}", NRX_SPARSE, i, d, 0, int(cols[i])) for i, d in enumerate(dims)], out_width=W)
+    tt = [dev(t) for t in tables]
+    ii = [dev(x) for x in ids]
+    w = dev((rng.standard_normal((NL, W)) / np.sqrt(W)).astype(np.float32))
+    b = dev((rng.standard_normal((NL, W)) * 0.1).astype(np.float32))
+    fused = ops.embed_dcn_v1(plan, tt, ii, w, b)
+    buf = ops.embed_apply(plan, tt, ii, [None] * len(dims), out_ld=2 * W)[0]
+    two = ops.dcn_v1_cat_(buf, w, b)
+    assert torch.equal(fused, two)                                         # same layout, same reduction order
+    x = np.concatenate([t[i] for t, i in zip(tables, ids)], axis=1)
+    assert np.array_equal(fused[:, :W].cpu().numpy(), x)                   # gather + concat: bit-exact vs numpy
+    ref = R.dcn_v1(x, w.cpu().numpy(), b.cpu().numpy())
+    np.testing.assert_allclose(fused[:, W:].cpu().numpy(), ref, rtol=1e-5, atol=2e-6 * max(1.0, np.abs(ref).max()))
+    with pytest.raises(IndexError):
+        bad = [t.clone() for t in ii]
+        bad[0][0] = 10 ** 6
+        ops.embed_dcn_v1(plan, tt, bad, w, b)
+
+
+def test_fused_gather_cross_rejects_what_it_does_not_cover():
+    t = torch.randn(10, 6, device=DEV)                                        # dim 6: not a multiple of 4
+    plan = ops.EmbedPlan([ops.Slot("a", NRX_SPARSE, 0, 6)], out_width=6)
+    with pytest.raises(ops.FusedUnsupported):
+        ops.embed_dcn_v1(plan, [t], [torch.tensor([1, 2], device=DEV)], torch.zeros(1, 6, device=DEV), torch.zeros(1, 6, device=DEV))
+    t16 = torch.randn(10, 16, device=DEV)
+    plan = ops.EmbedPlan([ops.Slot("h", NRX_BAG_MEAN, 0, 16, 3)], out_width=16)
+    with pytest.raises(ops.FusedUnsupported):
+        ops.embed_dcn_v1(plan, [t16], [torch.zeros(2, 3, dtype=torch.long, device=DEV)], torch.zeros(1, 16, device=DEV), torch.zeros(1, 16, device=DEV))
