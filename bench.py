@@ -70,8 +70,21 @@ def algorithmic_bytes_per_impression(feats, fm: bool, cross_dim: int = 0) -> int
 
 
 # ------------------------------------------------------------------------------------ single-GPU runner
+def draw_ids(rows: int, shape, device, gen, dist: str) -> torch.Tensor:
+    """Synthetic ids in [1, rows): 'uniform' (headline: cache-hostile) or 'zipf' = Zipf(1.05) popularity
+    ranks clipped to the table (MIND-like: a few hot news ids), by inverse-CDF sampling on the device."""
+    if dist == "uniform":
+        return torch.randint(1, rows, shape, device=device, generator=gen)
+    u = torch.rand(shape, device=device, generator=gen, dtype=torch.float64)
+    a = 1.05
+    n = float(rows - 1)
+    # continuous power-law on [1, n]: F^-1(u) = (1 + u (n^(1-a) - 1))^(1/(1-a))
+    r = (1.0 + u * (n ** (1.0 - a) - 1.0)) ** (1.0 / (1.0 - a))
+    return r.long().clamp_(1, rows - 1)
+
+
 class SingleGpuPath:
-    def __init__(self, wl: str, device, seed: int, n_pool: int = 8):
+    def __init__(self, wl: str, device, seed: int, n_pool: int = 8, id_dist: str = "uniform"):
         from news_recsys_amd import ops
         from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN, NRX_SPARSE
         self.ops = ops
@@ -111,11 +124,10 @@ class SingleGpuPath:
             ins, ws = [], []
             for f in feats:
                 if f["bag"]:
-                    ids = torch.randint(1, f["rows"], (BATCH, f["bag"]), device=device, generator=gen)
-                    ins.append(ids)
+                    ins.append(draw_ids(f["rows"], (BATCH, f["bag"]), device, gen, id_dist))
                     ws.append(torch.ones((BATCH, f["bag"]), dtype=torch.float32, device=device))
                 else:
-                    ins.append(torch.randint(1, f["rows"], (BATCH,), device=device, generator=gen))
+                    ins.append(draw_ids(f["rows"], (BATCH,), device, gen, id_dist))
                     ws.append(None)
             self.pool.append((ins, ws))
         self.bytes_per_impr = algorithmic_bytes_per_impression(feats, self.fm, col if self.cross else 0)
@@ -204,6 +216,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ids", default="uniform", choices=["uniform", "zipf"],
+                    help="id distribution: uniform (headline, cache-hostile) or Zipf(1.05) popularity (MIND-like); N=1 only")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded engine even at N=1 (testing)")
     ap.add_argument("--shard-mode", default="auto", choices=["row", "auto"],
                     help="N>1 headline layout: 'auto' = planner (tables <= 256 MiB replicated, larger ones row-sharded "
@@ -230,7 +244,9 @@ def main():
 
     seed = 20260116 + {"c2": 2, "c3": 3, "c4": 4, "c5": 5}[args.workload] + rank
     if world == 1 and not args.force_sharded:
-        path = SingleGpuPath(args.workload, device, seed)
+        path = SingleGpuPath(args.workload, device, seed, id_dist=args.ids)
+        if args.ids != "uniform":
+            path.desc = path.desc.replace("uniform ids", "ids") + f" -- ids ~ {args.ids}(1.05)"
         step = path.step
         bytes_per_impr = path.bytes_per_impr
         desc = path.desc

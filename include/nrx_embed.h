@@ -239,6 +239,14 @@ NRX_API int nrx_scatter_add_inbox(float* const* grad_tables, const int64_t* tabl
  * longer arrays are truncated to bag_len like :104-106).                                          */
 NRX_API int nrx_csr_to_padded(const void* values, int32_t value_bits, const int64_t* offsets, int64_t batch,
                       int32_t bag_len, void* ids_out, float* mask_out, void* stream);
+/* Per-user ranking metrics of the reference's validation loop (base_model.py:333-435) on the device.
+ * Inputs are the validation samples sorted by (user, score descending, arrival order) -- i.e. every
+ * user's samples are contiguous, seg_start[u] .. seg_start[u+1), and inside a segment they are in the
+ * order of Python's stable sorted(items, key=score, reverse=True).  scores fp32, labels fp32 (1 = positive).
+ * Outputs, fp64 [n_users] each: auc (NaN when the user has a single class -- the reference skips those),
+ * ndcg@k, hr@k, mrr@k (0 for users without positives, as the reference records them).            */
+NRX_API int nrx_user_rank_metrics(const float* scores, const float* labels, const int64_t* seg_start, int64_t n_users,
+                          int32_t k, double* auc, double* ndcg, double* hr, double* mrr, void* stream);
 /* lens[b] = #(mask[b,:] != 0); used to build CSR offsets from the reference's padded masks. */
 NRX_API int nrx_mask_lengths(const float* mask, int64_t batch, int32_t bag_len, int64_t* lens, void* stream);
 

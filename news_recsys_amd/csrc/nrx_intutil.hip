@@ -209,6 +209,51 @@ __global__ __launch_bounds__(NRX_BLOCK) void csr_to_padded_kernel(const T* __res
     }
 }
 
+// One thread per user segment (segments are short: tens to hundreds of impressions per user in MIND).
+__global__ __launch_bounds__(NRX_BLOCK) void user_rank_metrics_kernel(const float* __restrict__ scores, const float* __restrict__ labels,
+                                                                      const int64_t* __restrict__ seg_start, int64_t n_users, int k,
+                                                                      double* __restrict__ auc, double* __restrict__ ndcg,
+                                                                      double* __restrict__ hr, double* __restrict__ mrr) {
+    for (int64_t u = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x; u < n_users; u += (int64_t)gridDim.x * NRX_BLOCK) {
+        const int64_t lo = seg_start[u], hi = seg_start[u + 1];
+        double P = 0.0;
+        for (int64_t i = lo; i < hi; ++i) P += labels[i] == 1.0f ? 1.0 : 0.0;
+        const double N = (double)(hi - lo) - P;
+        // AUC with ties at 1/2 (sklearn.roc_auc_score): groups of equal score, descending
+        double num = 0.0, neg_above = 0.0;
+        for (int64_t i = lo; i < hi;) {
+            int64_t j = i;
+            double p = 0.0;
+            while (j < hi && scores[j] == scores[i]) {
+                p += labels[j] == 1.0f ? 1.0 : 0.0;
+                ++j;
+            }
+            const double q = (double)(j - i) - p;
+            num += p * (N - neg_above - q + 0.5 * q);
+            neg_above += q;
+            i = j;
+        }
+        auc[u] = (P > 0.0 && N > 0.0) ? num / (P * N) : __longlong_as_double(0x7ff8000000000000LL);
+        // top-k metrics (base_model.py:381-433)
+        double dcg = 0.0, first = 0.0, hit = 0.0;
+        const int64_t top = (hi - lo) < k ? (hi - lo) : k;
+        for (int64_t r = 1; r <= top; ++r) {
+            if (labels[lo + r - 1] == 1.0f) {
+                dcg += 1.0 / log2((double)(r + 1));
+                if (first == 0.0) first = 1.0 / (double)r;
+                hit = 1.0;
+            }
+        }
+        double idcg = 0.0;
+        const int64_t ideal = P < (double)k ? (int64_t)P : k;
+        for (int64_t r = 1; r <= ideal; ++r) idcg += 1.0 / log2((double)(r + 1));
+        const bool any_pos = P > 0.0;
+        hr[u] = any_pos ? hit : 0.0;
+        ndcg[u] = (any_pos && idcg > 0.0) ? dcg / idcg : 0.0;
+        mrr[u] = any_pos ? first : 0.0;
+    }
+}
+
 int ceil_log2u(int x) {
     int l = 0;
     while ((1 << l) < x) ++l;
@@ -326,6 +371,19 @@ extern "C" int nrx_csr_to_padded(const void* values, int32_t value_bits, const i
         hipLaunchKernelGGL(csr_to_padded_kernel<int32_t>, dim3((unsigned)g), dim3(NRX_BLOCK), 0, st, (const int32_t*)values, offsets,
                            batch, bag_len, (int32_t*)ids_out, mask_out);
     NRX_LAUNCH_CHECK("nrx_csr_to_padded");
+    return NRX_OK;
+}
+
+extern "C" int nrx_user_rank_metrics(const float* scores, const float* labels, const int64_t* seg_start, int64_t n_users,
+                                     int32_t k, double* auc, double* ndcg, double* hr, double* mrr, void* stream) {
+    NRX_REQUIRE(n_users >= 0 && k >= 1, "nrx_user_rank_metrics: bad argument");
+    if (n_users == 0) return NRX_OK;
+    NRX_REQUIRE(scores && labels && seg_start && auc && ndcg && hr && mrr, "nrx_user_rank_metrics: null buffer");
+    int64_t g = (n_users + NRX_BLOCK - 1) / NRX_BLOCK;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(user_rank_metrics_kernel, dim3((unsigned)g), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
+                       scores, labels, seg_start, n_users, k, auc, ndcg, hr, mrr);
+    NRX_LAUNCH_CHECK("nrx_user_rank_metrics");
     return NRX_OK;
 }
 

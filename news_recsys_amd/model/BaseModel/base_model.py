@@ -17,7 +17,8 @@ Documented deviations from the reference (SURVEY facts 4, 5 and hard part 5):
   * `dense_feature_dim` exists (default 1); the reference reads it but never sets it (:94 vs :129);
   * the third return value of `get_embeddings_from_batch` lists only the features actually present in
     the batch, so it always lines up with `dims` (the reference returns the unfiltered list, :308).
-The training half (validation metrics, log files; base_model.py:181-256, 320-528) is outside the path.
+The validation half (base_model.py:320-528) is rebuilt on the device (news_recsys_amd/metrics.py); the remaining
+trainer glue (train.log / model_info.log, :215-256) is outside the path.
 """
 from __future__ import annotations
 
@@ -126,6 +127,7 @@ class BaseModel(LightningModule):
         self.best_metrics = {"AUC": 0.0, "LogLoss": float("inf"), "GAUC": 0.0, "HR@10": 0.0, "NDCG@10": 0.0,
                              "MRR@10": 0.0, "Step": -1}
         self.user_scores_dict = {}
+        self._val_uid, self._val_score, self._val_label = [], [], []
 
     # ------------------------------------------------------------------ lookups (base_model.py:262-308)
     def _table_weight(self, feature_name: str) -> torch.Tensor:
@@ -217,6 +219,53 @@ class BaseModel(LightningModule):
         if out is None:
             return torch.tensor([]).to(self.device), [], []
         return out, dims, names
+
+    # ------------------------------------------------------------------ validation (:181-218, :320-528)
+    def setup(self, stage: str = None):
+        """Log / checkpoint dirs, `val_log.log`, and the warm-user set (base_model.py:181-211).  Tolerant where
+        the reference is not: a missing `preprocess/train_user_ids.json` means "no cold users" instead of a crash."""
+        logger_dir = getattr(getattr(self, "logger", None), "log_dir", None)
+        self.log_dir = logger_dir or (self.out_basedir if self.out_basedir else "./logs")
+        self.ckpt_dir = os.path.join(self.log_dir, "ckpts")
+        os.makedirs(self.ckpt_dir, exist_ok=True)
+        val_log_path = os.path.join(self.log_dir, "val_log.log")
+        if not os.path.exists(val_log_path):
+            open(val_log_path, "w").close()
+        self.user_in_train_path = os.path.join(self.out_basedir, "preprocess", "train_user_ids.json")
+        self.user_in_train_set = set()
+        if os.path.exists(self.user_in_train_path):
+            with open(self.user_in_train_path, "r") as f:
+                self.user_in_train_set = set(json.load(f))
+
+    def validation_step(self, batch, batch_idx):
+        """Keeps the step's (user, score, label) on the device -- the reference copies them to the host and
+        appends Python tuples per sample (:320-330)."""
+        scores = self.inference(batch).reshape(-1)
+        n = scores.numel()
+        self._val_uid.append(batch["user_id"].reshape(-1)[:n])
+        self._val_score.append(scores.detach().float())
+        self._val_label.append(batch["label"].reshape(-1)[:n].float())     # the reference zips view(-1): first n labels
+
+    def on_validation_epoch_end(self):
+        """GAUC / NDCG@10 / HR@10 / MRR@10 / AUC / LogLoss with the warm-cold split, computed on the device
+        (news_recsys_amd/metrics.py); prints and appends the reference's text block to val_log.log.  Unlike the
+        reference (whose `user_scores_dict` is never cleared and so accumulates across epochs, :179), the
+        epoch's samples are dropped afterwards."""
+        from ...metrics import format_val_log, ranking_metrics
+        if not self._val_score:
+            return None
+        uid, sc, lb = torch.cat(self._val_uid), torch.cat(self._val_score), torch.cat(self._val_label)
+        self._val_uid, self._val_score, self._val_label = [], [], []
+        warm = getattr(self, "user_in_train_set", None)
+        warm_ids = [int(u) for u in warm if str(u).lstrip("-").isdigit()] if warm else None
+        results = ranking_metrics(uid, sc, lb, warm_ids, k=10)
+        msg = format_val_log(results, getattr(self, "current_epoch", 0), k=10)
+        print(msg)
+        if hasattr(self, "log_dir"):
+            with open(os.path.join(self.log_dir, "val_log.log"), "a") as f:
+                f.write(msg)
+        self.last_val_results = results
+        return results
 
     # ------------------------------------------------------------------ abstract interface (:313-318)
     def forward(self, x):

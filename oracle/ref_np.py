@@ -503,3 +503,84 @@ def gather_inbox(tables, feat_table, world: int, cap: int, recv2d, inbox_rows, d
                 out[s_ * cap + j: s_ * cap + j + take] = gather_rows(tables[feat_table[f]], rows)
             j += n
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# validation metrics                               src/model/BaseModel/base_model.py:320-528
+# ----------------------------------------------------------------------------------------
+def auc_ties(scores: np.ndarray, labels: np.ndarray) -> float:
+    """roc_auc_score for binary labels (what sklearn computes: trapezoid = Mann-Whitney with ties at 0.5)."""
+    s = np.asarray(scores, np.float64)
+    y = np.asarray(labels, np.float64)
+    P, N = float((y == 1).sum()), float((y != 1).sum())
+    order = np.argsort(-s, kind="stable")
+    s, y = s[order], y[order]
+    num, neg_above, i = 0.0, 0.0, 0
+    while i < s.size:
+        j = i
+        while j < s.size and s[j] == s[i]:
+            j += 1
+        p = float((y[i:j] == 1).sum())
+        q = float(j - i) - p
+        num += p * (N - neg_above - q + 0.5 * q)
+        neg_above += q
+        i = j
+    return num / (P * N)
+
+
+def validation_metrics(user_ids, scores, labels, warm_users, k: int = 10):
+    """Restatement of BaseModel.on_validation_epoch_end (base_model.py:333-492) over flat arrays in the
+    order validation_step appended them (:320-330).  Returns the same nested dict as its `results`."""
+    groups = {}
+    for u, s, y in zip(user_ids, scores, labels):
+        groups.setdefault(int(u), []).append((float(s), float(y)))
+    warm = set(int(u) for u in warm_users) if warm_users is not None else None
+    lists = {g: {"auc": [], "ndcg": [], "hr": [], "mrr": [], "p": [], "y": []} for g in ("Overall", "Warm_Start", "Cold_Start")}
+    for uid, items in groups.items():
+        is_cold = bool(warm) and uid not in warm          # :355-359 (an empty / missing set means nobody is cold)
+        tgt = lists["Cold_Start" if is_cold else "Warm_Start"]
+        preds = [x[0] for x in items]
+        labs = [x[1] for x in items]
+        for dst in (lists["Overall"], tgt):
+            dst["p"].extend(preds)
+            dst["y"].extend(labs)
+        if len(set(labs)) > 1:
+            a = auc_ties(np.array(preds), np.array(labs))
+            lists["Overall"]["auc"].append(a)
+            tgt["auc"].append(a)
+        top = sorted(items, key=lambda x: x[0], reverse=True)[:k]      # stable: ties keep arrival order
+        npos = sum(1 for x in items if x[1] == 1)
+        if npos == 0:
+            vals = (0.0, 0.0, 0.0)
+        else:
+            hr = 1.0 if any(x[1] == 1 for x in top) else 0.0
+            dcg = sum(1.0 / np.log2(r + 1) for r, (_, y) in enumerate(top, start=1) if y == 1)
+            idcg = sum(1.0 / np.log2(r + 1) for r in range(1, min(npos, k) + 1))
+            mrr = next((1.0 / r for r, (_, y) in enumerate(top, start=1) if y == 1), 0.0)
+            vals = (hr, dcg / idcg if idcg > 0 else 0.0, mrr)
+        for dst in (lists["Overall"], tgt):
+            dst["hr"].append(vals[0])
+            dst["ndcg"].append(vals[1])
+            dst["mrr"].append(vals[2])
+
+    def auc_logloss(p, y):
+        if not p:
+            return 0.0, 0.0
+        p, y = np.array(p, np.float32), np.array(y, np.float32)
+        auc = auc_ties(p, y) if len(set(y.tolist())) > 1 else 0.0
+        # As written in the reference (:445-449): the scores are float32, so the clip's upper bound
+        # 1 - 1e-15 rounds to exactly 1.0 and a score of 1.0 gives log(0): LogLoss = inf / nan.
+        with np.errstate(divide="ignore", invalid="ignore"):
+            pc = np.clip(p, 1e-15, 1 - 1e-15)
+            ll = -np.mean(y * np.log(pc) + (1 - y) * np.log(1 - pc))
+        return auc, float(ll)
+
+    mean = lambda l: float(np.mean(l)) if l else 0.0
+    res = {}
+    for g, d in lists.items():
+        auc, ll = auc_logloss(d["p"], d["y"])
+        res[g] = {"AUC": auc, "LogLoss": ll, "GAUC": mean(d["auc"]), f"NDCG@{k}": mean(d["ndcg"]),
+                  f"HR@{k}": mean(d["hr"]), f"MRR@{k}": mean(d["mrr"])}
+        if g != "Overall":
+            res[g]["User_Count"] = len(d["hr"])
+    return res

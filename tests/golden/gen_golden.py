@@ -411,6 +411,37 @@ def gen_datareader():
     save("datareader", d)
 
 
+def gen_validation():
+    """Validation-metric goldens: synthetic (uid, score, label) streams pushed through the REFERENCE's
+    BaseModel.on_validation_epoch_end (base_model.py:333-528) exactly as validation_step fills
+    user_scores_dict (:320-330); the printed val_log text is captured (the function returns nothing)."""
+    import contextlib, io
+    from types import SimpleNamespace
+    from src.model.BaseModel.base_model import BaseModel
+    d = {}
+    for case, (n_users, n, tie, seed, warm_frac) in {"a": (40, 600, False, 1, 0.6), "b": (300, 5000, True, 2, 0.5),
+                                                     "c": (5, 40, True, 3, 1.0), "d": (60, 900, False, 4, 0.0)}.items():
+        rng = np.random.default_rng(seed)
+        uid = rng.integers(1, n_users + 1, n)
+        score = rng.random(n).astype(np.float32)
+        if tie:
+            score = np.round(score, 1).astype(np.float32)            # heavy ties
+        label = (rng.random(n) < 0.15 + 0.5 * score).astype(np.float32)
+        label[uid == 1] = 0.0                                         # a user without positives
+        label[uid == 2] = 1.0                                         # a user with a single class (no AUC)
+        warm = sorted(rng.choice(np.arange(1, n_users + 1), int(n_users * warm_frac), replace=False).tolist())
+        stub = SimpleNamespace(user_scores_dict={}, user_in_train_set=set(warm), current_epoch=3)
+        for u, s_, y in zip(uid, score, label):                       # validation_step's loop (:326-329)
+            stub.user_scores_dict.setdefault(u, []).append((s_, y))
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+            BaseModel.on_validation_epoch_end(stub)
+        d[f"{case}/uid"], d[f"{case}/score"], d[f"{case}/label"] = uid, score, label
+        d[f"{case}/warm"] = np.array(warm, dtype=np.int64)
+        d[f"{case}/log"] = np.array(buf.getvalue())
+    save("validation", d)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
@@ -422,3 +453,4 @@ if __name__ == "__main__":
     gen_dssm()
     gen_lr_schedule()
     gen_datareader()
+    gen_validation()
