@@ -104,23 +104,36 @@ class EmbedPlan:
 
 
 def _fill_features(plan: EmbedPlan, lo: int, hi: int, tables: Sequence[torch.Tensor], inputs, weights,
-                   table_ptrs: Optional[Sequence[int]] = None, fm: bool = True):
+                   table_ptrs: Optional[Sequence[int]] = None, fm: bool = True, cache_key: Optional[str] = None):
+    """C descriptor array for slots [lo, hi).  With `cache_key` the array lives on the plan: the static
+    fields (kind, dim, bag_len, columns, flags) are written once and a call only refreshes the pointers
+    (the library copies the descriptors into the kernel arguments during the call, so reuse is safe)."""
     n = hi - lo
-    arr = (NrxFeature * n)()
-    for i, s in enumerate(plan.slots[lo:hi]):
+    cache = plan.__dict__.setdefault("_arr_cache", {}) if cache_key is not None else None
+    key = (cache_key, lo, hi, fm)
+    arr = cache.get(key) if cache is not None else None
+    fresh = arr is None
+    if fresh:
+        arr = (NrxFeature * n)()
+        if cache is not None:
+            cache[key] = arr
+    for i in range(n):
+        s = plan.slots[lo + i]
         f = arr[i]
         idx = inputs[lo + i]
+        if fresh:
+            f.kind = s.kind
+            f.dim = s.dim
+            f.bag_len = s.bag_len
+            f.out_col = s.out_col
+            f.wide_col = s.wide_col
+            f.fm_field = s.fm_field if fm else 0
+            f.flags = s.flags
         f.index = idx.data_ptr()
-        f.kind = s.kind
-        f.dim = s.dim
-        f.bag_len = s.bag_len
-        f.out_col = s.out_col
-        f.wide_col = s.wide_col
-        f.fm_field = s.fm_field if fm else 0
-        f.flags = s.flags
         f.index_bits = idx.element_size() * 8
         if s.kind == NRX_DENSE:
-            f.table, f.rows = None, 0
+            if fresh:
+                f.table, f.rows = None, 0
         else:
             t = tables[s.table]
             f.table = table_ptrs[s.table] if table_ptrs is not None else t.data_ptr()
@@ -135,34 +148,39 @@ def _prep_inputs(plan: EmbedPlan, tables, inputs, weights):
         raise ValueError("inputs / weights must have one entry per slot")
     B = None
     ins, ws = [], []
+    i64, i32, f32, f64 = torch.int64, torch.int32, torch.float32, torch.float64
     for s, x, w in zip(plan.slots, inputs, weights):
-        _dev(x, f"feature '{s.name}'")
+        if not x.is_cuda:
+            _dev(x, f"feature '{s.name}'")
+        dt = x.dtype
         if s.kind == NRX_DENSE:
-            if x.dtype not in (torch.float32, torch.float64):
+            if dt is not f32 and dt is not f64:
                 x = x.float()
-        elif x.dtype not in (torch.int64, torch.int32):
+        elif dt is not i64 and dt is not i32:
             x = x.long()                      # reference: feature_value.long()  (base_model.py:271)
-        x = x if x.is_contiguous() else x.contiguous()
+        if not x.is_contiguous():
+            x = x.contiguous()
+        shp = x.shape
         if s.kind >= NRX_BAG_MASKED_MEAN:
-            if x.dim() != 2 or x.shape[1] != s.bag_len:
-                raise ValueError(f"feature '{s.name}': expected ids of shape [B, {s.bag_len}], got {tuple(x.shape)}")
-        elif x.dim() != 1:
-            raise ValueError(f"feature '{s.name}': expected a 1-D [B] tensor, got {tuple(x.shape)}")
+            if len(shp) != 2 or shp[1] != s.bag_len:
+                raise ValueError(f"feature '{s.name}': expected ids of shape [B, {s.bag_len}], got {tuple(shp)}")
+        elif len(shp) != 1:
+            raise ValueError(f"feature '{s.name}': expected a 1-D [B] tensor, got {tuple(shp)}")
         if B is None:
-            B = x.shape[0]
-        elif x.shape[0] != B:
-            raise ValueError(f"feature '{s.name}': batch {x.shape[0]} != {B}")
+            B = shp[0]
+        elif shp[0] != B:
+            raise ValueError(f"feature '{s.name}': batch {shp[0]} != {B}")
         if w is not None:
             w = _f32c(w, f"mask of '{s.name}'")
-            if tuple(w.shape) != tuple(x.shape):
-                raise ValueError(f"mask of '{s.name}': shape {tuple(w.shape)} != ids {tuple(x.shape)}")
-        if s.kind == NRX_BAG_MASKED_MEAN and w is None:
+            if w.shape != shp:
+                raise ValueError(f"mask of '{s.name}': shape {tuple(w.shape)} != ids {tuple(shp)}")
+        elif s.kind == NRX_BAG_MASKED_MEAN:
             raise ValueError(f"feature '{s.name}': masked mean needs a mask")
         ins.append(x)
         ws.append(w)
     for t in tables:
-        _f32c(t, "embedding table")
-        if not t.is_contiguous():
+        if not (t.is_cuda and t.dtype is f32 and t.is_contiguous()):
+            _f32c(t, "embedding table")
             raise ValueError("embedding tables must be contiguous [rows, dim] fp32")
     return B, ins, ws
 
@@ -187,7 +205,7 @@ class _EmbedFn(torch.autograd.Function):
         if B > 0:
             for lo in range(0, n, NRX_MAX_FEATURES):
                 hi = min(n, lo + NRX_MAX_FEATURES)
-                arr = _fill_features(plan, lo, hi, tables, ins, ws, fm=single)
+                arr = _fill_features(plan, lo, hi, tables, ins, ws, fm=single, cache_key="fwd")
                 check(lib.nrx_embed_fwd(arr, hi - lo, B, _ptr(out), ld, _ptr(wide), plan.wide_width,
                                         _ptr(fm) if single else None, _ptr(status), stream), "nrx_embed_fwd")
             if plan.use_fm and not single:
@@ -245,7 +263,7 @@ class _EmbedFn(torch.autograd.Function):
             n = len(plan.slots)
             for lo in range(0, n, NRX_MAX_FEATURES):
                 hi = min(n, lo + NRX_MAX_FEATURES)
-                arr = _fill_features(plan, lo, hi, grads, ctx.ins, ctx.ws, table_ptrs=gptrs)
+                arr = _fill_features(plan, lo, hi, grads, ctx.ins, ctx.ws, table_ptrs=gptrs, cache_key="bwd")
                 check(lib.nrx_embed_bwd(arr, hi - lo, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, stream),
                       "nrx_embed_bwd")
         return (None, None, None, None, None, None, *grads)
