@@ -52,7 +52,7 @@ __device__ __forceinline__ float4 clamped_load4(const float* base, int64_t row, 
 }
 
 template <bool RELU, bool VEC>
-__global__ __launch_bounds__(256) void dcn_v2_layer_kernel(const float* __restrict__ x0, const float* __restrict__ xl, int64_t ld,
+__global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __restrict__ x0, const float* __restrict__ xl, int64_t ld,
                                                            int64_t M, int N, const float* __restrict__ W, const float* __restrict__ bias,
                                                            float* __restrict__ out, int64_t out_ld, unsigned nx) {
     __shared__ float As[BK * LDA];
