@@ -247,6 +247,19 @@ NRX_API int nrx_csr_to_padded(const void* values, int32_t value_bits, const int6
  * ndcg@k, hr@k, mrr@k (0 for users without positives, as the reference records them).            */
 NRX_API int nrx_user_rank_metrics(const float* scores, const float* labels, const int64_t* seg_start, int64_t n_users,
                           int32_t k, double* auc, double* ndcg, double* hr, double* mrr, void* stream);
+/* Exact inner-product top-k retrieval (replaces faiss.IndexFlatIP.search as wrapped by
+ * src/model/model_utils/TopKSearcher.py:50-84 and used by DSSM.hit_rate, recall/DSSM/model.py:182-228).
+ * items [n_items, dim], queries [n_queries, dim] fp32 row-major (dim % 4 == 0, dim <= 128, k <= 32).
+ * Optional per-query exclusion lists in CSR form (excl_offsets [n_queries+1], excl_items sorted ascending
+ * inside each list; both device int64): excluded items never enter the result -- the reference instead
+ * over-fetches k + len(history) and filters on the host.  Output: out_idx / out_score [n_queries, k], scores
+ * descending, ties broken toward the lower item index; unused slots (fewer than k candidates) = -1 / -FLT_MAX
+ * (what faiss's heap leaves there).  score = fp32 fma chain over dim, ascending.
+ * workspace: device bytes >= nrx_topk_workspace(n_items, n_queries, k).                          */
+NRX_API int64_t nrx_topk_workspace(int64_t n_items, int64_t n_queries, int32_t k);
+NRX_API int nrx_topk_ip(const float* items, int64_t n_items, int32_t dim, const float* queries, int64_t n_queries,
+                int32_t k, const int64_t* excl_offsets, const int64_t* excl_items,
+                int64_t* out_idx, float* out_score, void* workspace, void* stream);
 /* lens[b] = #(mask[b,:] != 0); used to build CSR offsets from the reference's padded masks. */
 NRX_API int nrx_mask_lengths(const float* mask, int64_t batch, int32_t bag_len, int64_t* lens, void* stream);
 

@@ -80,6 +80,8 @@ SIGNATURES = {
     "nrx_csr_to_padded": (C.c_int, [_p, _i32, _p, _i64, _i32, _p, _p, _p]),
     "nrx_user_rank_metrics": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "nrx_mask_lengths": (C.c_int, [_p, _i64, _i32, _p, _p]),
+    "nrx_topk_workspace": (_i64, [_i64, _i64, _i32]),
+    "nrx_topk_ip": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -6,11 +6,21 @@ fused HIP launch per tower; towers / normalize / losses are plain torch.
 
 Deviations, all documented in SURVEY: features are concatenated in SORTED order (the reference iterates
 a Python set: order depends on PYTHONHASHSEED); `forward(x, perms=None)` accepts explicit negative-
-sampling permutations so results are reproducible (the reference draws torch.randperm, :63)."""
+sampling permutations so results are reproducible (the reference draws torch.randperm, :63).
+
+Recall evaluation (`on_train_epoch_end` :230-254, `hit_rate` :182-228): the reference builds a faiss
+IndexFlatIP on the host and searches one user at a time (it raises unless batch_size == 1), over-fetching
+k + len(history) and filtering in Python.  Here the item matrix stays in HBM and a whole validation batch
+is one `nrx_topk_ip` call with the history passed as per-query exclusion lists; any batch size works.
+The reference's `self.user_history` / `self.emb_idx_2_val_dict` are never defined anywhere in its tree
+(stale file); here `user_history` is an attribute {user id value -> iterable of item id values} in the
+id space of the batch columns `user_id_feature` / `item_id_feature` (hparams; default 'user_id' /
+'movie_id' as in the reference)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .... import ops
 from ...BaseModel.base_model import BaseModel
 
 
@@ -28,6 +38,12 @@ class DSSM(BaseModel):
         self.item_fc = _tower(self.item_input_dim)
         self.movies_dataloader = dataloaders.get("movies_dataloader", None)
         self.val_dataloader_ = dataloaders.get("val_dataloader", None)
+        self.user_id_feature = self.hparams_.get("user_id_feature", "user_id")
+        self.item_id_feature = self.hparams_.get("item_id_feature", "movie_id")
+        self.user_history = {}
+        self.all_item_embeddings = None       # [N, 16] fp32, device resident (reference: numpy + faiss index)
+        self.idx_item_emb_dic = {}            # index position -> item id value (model.py:233,247)
+        self.last_hit_rate = None
 
     def get_user_embedding(self, batch):
         out, _, _ = self.get_embeddings_from_batch(batch, self.user_feature_names)
@@ -100,3 +116,58 @@ class DSSM(BaseModel):
     def inference(self, batch):
         return (F.normalize(self.user_fc(self.get_user_embedding(batch)), p=2, dim=1),
                 F.normalize(self.item_fc(self.get_item_embedding(batch)), p=2, dim=1))
+
+    # ---- recall evaluation -------------------------------------------------------------------------
+    def _to_device(self, batch):
+        return {k: (v.to(self.device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+
+    @torch.no_grad()
+    def build_item_index(self, movies_dataloader=None):
+        """model.py:232-252: run every item through the item tower, L2-normalise, keep the matrix (on the
+        device) and the position -> item id map."""
+        loader = movies_dataloader if movies_dataloader is not None else self.movies_dataloader
+        embs, ids = [], []
+        for batch in loader:
+            batch = self._to_device(batch)
+            embs.append(F.normalize(self.item_fc(self.get_item_embedding(batch)), p=2, dim=1))
+            ids.append(batch[self.item_id_feature].reshape(-1).to(torch.int64))
+        self.all_item_embeddings = torch.cat(embs, dim=0).contiguous()
+        self.item_index_ids = torch.cat(ids, dim=0)
+        self.idx_item_emb_dic = dict(enumerate(self.item_index_ids.tolist()))
+        self._item_pos = {v: i for i, v in self.idx_item_emb_dic.items()}
+        return self.all_item_embeddings
+
+    @torch.no_grad()
+    def hit_rate(self, k=10, val_dataloader=None):
+        """model.py:182-228 for any batch size: a hit = the batch's target item id is among the k best
+        items by inner product once the user's history is removed."""
+        from ...model_utils.TopKSearcher import exclusion_csr
+        if self.all_item_embeddings is None:
+            raise ValueError("item index not built: call build_item_index() / on_train_epoch_end() first")
+        loader = val_dataloader if val_dataloader is not None else self.val_dataloader_
+        hits = torch.zeros((), dtype=torch.int64, device=self.all_item_embeddings.device)
+        all_nums = 0
+        for batch in loader:
+            batch = self._to_device(batch)
+            user_emb = F.normalize(self.user_fc(self.get_user_embedding(batch)), p=2, dim=1)
+            uids = batch[self.user_id_feature].reshape(-1).tolist()
+            lists = [[self._item_pos[i] for i in self.user_history.get(u, self.user_history.get(str(u), ())) if i in self._item_pos]
+                     for u in uids]
+            excl = exclusion_csr(lists, user_emb.device) if any(lists) else None
+            idx, _ = ops.topk_ip(self.all_item_embeddings, user_emb.contiguous(), k, exclude=excl)
+            found = self.item_index_ids[idx.clamp_min(0)].masked_fill(idx < 0, -1)
+            target = batch[self.item_id_feature].reshape(-1, 1).to(torch.int64)
+            hits += (found == target).any(dim=1).sum()
+            all_nums += len(uids)
+        hit_rate = (int(hits.item()) / all_nums) if all_nums > 0 else 0
+        self.last_hit_rate = hit_rate
+        self.log(f"Hit_Rate_{k}", hit_rate)
+        print(f"Hit Rate@{k}: {hit_rate}")
+        return hit_rate
+
+    @torch.no_grad()
+    def on_train_epoch_end(self):
+        if self.movies_dataloader is None or self.val_dataloader_ is None:
+            return
+        self.build_item_index()
+        self.hit_rate(k=10)

@@ -847,6 +847,38 @@ def mask_lengths(mask: torch.Tensor) -> torch.Tensor:
     return lens
 
 
+def topk_ip(items: torch.Tensor, queries: torch.Tensor, k: int, exclude=None):
+    """Exact inner-product top-k (faiss.IndexFlatIP.search semantics; TopKSearcher.py:50-84).
+    items [N, d], queries [Q, d] fp32 on the GPU.  `exclude` = (offsets [Q+1], item_idx) device int64
+    CSR of per-query item positions to skip (each list ascending).  Returns (idx [Q, k] int64, score
+    [Q, k] fp32): scores descending, ties toward the lower index, empty slots -1 / -FLT_MAX."""
+    lib = _lib.load()
+    items = _f32c(items, "items")
+    queries = _f32c(queries, "queries")
+    if items.dim() != 2 or queries.dim() != 2 or items.shape[1] != queries.shape[1]:
+        raise ValueError(f"topk_ip: items {tuple(items.shape)} vs queries {tuple(queries.shape)}")
+    N, d = items.shape
+    Q = queries.shape[0]
+    out_idx = torch.empty((Q, k), dtype=torch.int64, device=queries.device)
+    out_score = torch.empty((Q, k), dtype=torch.float32, device=queries.device)
+    nbytes = lib.nrx_topk_workspace(N, Q, k)
+    if nbytes < 0:
+        raise ValueError("topk_ip: bad sizes")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=queries.device)
+    eo = ei = None
+    if exclude is not None:
+        eo, ei = exclude
+        eo = eo.to(device=queries.device, dtype=torch.int64).contiguous()
+        ei = ei.to(device=queries.device, dtype=torch.int64).contiguous()
+        if eo.numel() != Q + 1:
+            raise ValueError("topk_ip: exclude offsets must have n_queries + 1 entries")
+    check(lib.nrx_topk_ip(items.data_ptr(), N, d, queries.data_ptr(), Q, k,
+                          eo.data_ptr() if eo is not None else None,
+                          ei.data_ptr() if ei is not None and ei.numel() else (ws.data_ptr() if eo is not None else None),
+                          out_idx.data_ptr(), out_score.data_ptr(), ws.data_ptr(), _stream_ptr(queries)), "nrx_topk_ip")
+    return out_idx, out_score
+
+
 def device_info(device: int = 0):
     lib = _lib.load()
     info = (C.c_int64 * 6)()

@@ -10,6 +10,8 @@
  *   DCNLayer / DCNNet               src/model/sort/dcn/dcn_arch.py:14-30, 63-70  (algebraic form)
  * Parallelisation: over samples (what ATen's CPU kernels do for the reference's gather / cat).
  */
+#include <float.h>
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 #include <omp.h>
@@ -97,6 +99,38 @@ void oracle_dcn_v1(const float* x, int64_t x_ld, int64_t B, int32_t dim, int32_t
             float s = 0.f;
             for (int k = 0; k < dim; ++k) s += xl[k] * wl[k];
             for (int k = 0; k < dim; ++k) xl[k] = x0[k] * s + bl[k] + xl[k];
+        }
+    }
+}
+
+/* Exact inner-product top-k: what faiss.IndexFlatIP.search returns as used by
+ * src/model/model_utils/TopKSearcher.py:50-84 and DSSM.hit_rate (recall/DSSM/model.py:182-228).  faiss
+ * (faiss-cpu, unpinned in the reference's requirements; absent from this image) documents IndexFlatIP as
+ * exhaustive search by inner product with results sorted by decreasing score, label -1 / score -FLT_MAX
+ * where fewer than k vectors exist; its tie order and fp32 summation order are unspecified.  This
+ * restatement fixes both: score = fp32 fma chain over the dimension in ascending order, ties toward the
+ * lower index.  excl (optional CSR, lists ascending): items a query must not return -- the reference's
+ * "search k + len(history), drop history, keep k" (model.py:209-221) yields the same list.          */
+void oracle_topk_ip(const float* items, int64_t n_items, int32_t dim, const float* queries, int64_t n_queries,
+                    int32_t k, const int64_t* excl_off, const int64_t* excl_items, int64_t* out_idx, float* out_score) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t q = 0; q < n_queries; ++q) {
+        int64_t* oi = out_idx + q * k;
+        float* os = out_score + q * k;
+        for (int j = 0; j < k; ++j) { oi[j] = -1; os[j] = -FLT_MAX; }
+        const int64_t e0 = excl_off ? excl_off[q] : 0, e1 = excl_off ? excl_off[q + 1] : 0;
+        int64_t ep = e0;
+        const float* qv = queries + q * dim;
+        for (int64_t i = 0; i < n_items; ++i) {
+            while (ep < e1 && excl_items[ep] < i) ++ep;
+            if (ep < e1 && excl_items[ep] == i) continue;
+            const float* v = items + i * dim;
+            float a = 0.f;
+            for (int d = 0; d < dim; ++d) a = fmaf(qv[d], v[d], a);
+            if (!(a > os[k - 1])) continue;
+            int j = k - 1;
+            while (j > 0 && a > os[j - 1]) { os[j] = os[j - 1]; oi[j] = oi[j - 1]; --j; }
+            os[j] = a; oi[j] = i;
         }
     }
 }

@@ -30,6 +30,8 @@ def load():
         _lib.oracle_dcn_v1.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int64]
         _lib.oracle_threads.restype = C.c_int
+        _lib.oracle_topk_ip.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -97,3 +99,23 @@ def dcn_v1(x, w, b):
     load().oracle_dcn_v1(x.ctypes.data, x.shape[1], x.shape[0], x.shape[1], w.shape[0], w.ctypes.data, b.ctypes.data,
                          out.ctypes.data, x.shape[1])
     return out
+
+
+def topk_ip(items, queries, k, exclude=None):
+    """oracle_topk_ip: (idx [Q,k] int64, score [Q,k] f32); exclude = (offsets [Q+1], item_idx) int64 CSR."""
+    lib = load()
+    items = np.ascontiguousarray(items, np.float32)
+    queries = np.ascontiguousarray(queries, np.float32)
+    Q, d = queries.shape
+    idx = np.empty((Q, k), np.int64)
+    score = np.empty((Q, k), np.float32)
+    eo = ei = None
+    if exclude is not None:
+        eo = np.ascontiguousarray(exclude[0], np.int64)
+        ei = np.ascontiguousarray(exclude[1], np.int64)
+        if ei.size == 0:
+            ei = np.zeros(1, np.int64)
+    lib.oracle_topk_ip(items.ctypes.data, items.shape[0], d, queries.ctypes.data, Q, k,
+                       eo.ctypes.data if eo is not None else None, ei.ctypes.data if ei is not None else None,
+                       idx.ctypes.data, score.ctypes.data)
+    return idx, score

@@ -584,3 +584,57 @@ def validation_metrics(user_ids, scores, labels, warm_users, k: int = 10):
         if g != "Overall":
             res[g]["User_Count"] = len(d["hr"])
     return res
+
+
+# ---------------------------------------------------------------------------------------------------
+# Recall evaluation: exact inner-product top-k + hit rate
+# ---------------------------------------------------------------------------------------------------
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def topk_ip(items: np.ndarray, queries: np.ndarray, k: int, exclude=None):
+    """faiss.IndexFlatIP(d).add(items); .search(queries, k) as TopKSearcher.search wraps it
+    (src/model/model_utils/TopKSearcher.py:50-84): exhaustive inner products, the k largest per query in
+    decreasing order, (-1, -FLT_MAX) where fewer than k items qualify.  faiss is absent from the
+    reference tree and this image (parity with faiss itself is UNPINNED; anchored on the call sites):
+    its tie order / summation order are unspecified, this restatement takes ties toward the lower index
+    and accumulates in float64 (the C oracle and the HIP kernel use an fp32 fma chain; they agree with this
+    to ~1e-6 and exactly on the order wherever scores are separated by more than that).
+    exclude: optional list (per query) of item positions that must not be returned = the reference's
+    over-fetch-and-filter of the user's history (recall/DSSM/model.py:209-221)."""
+    items = np.asarray(items, np.float32)
+    queries = np.asarray(queries, np.float32)
+    Q = queries.shape[0]
+    idx = np.full((Q, k), -1, np.int64)
+    score = np.full((Q, k), -FLT_MAX, np.float32)
+    if items.shape[0] == 0:
+        return idx, score
+    s = queries.astype(np.float64) @ items.astype(np.float64).T
+    for q in range(Q):
+        row = s[q].copy()
+        keep = np.ones(items.shape[0], bool)
+        if exclude is not None and len(exclude[q]):
+            keep[np.asarray(exclude[q], np.int64)] = False
+        cand = np.nonzero(keep)[0]
+        order = cand[np.argsort(-row[cand], kind="stable")][:k]
+        idx[q, :len(order)] = order
+        score[q, :len(order)] = row[order].astype(np.float32)
+    return idx, score
+
+
+def hit_rate_reference_loop(items: np.ndarray, queries: np.ndarray, targets: np.ndarray, histories, k: int) -> float:
+    """DSSM.hit_rate as written (recall/DSSM/model.py:182-228), one query at a time: search k + len(history),
+    drop the history, keep the first k, count the target.  `histories[q]` = item positions the user already
+    interacted with; `targets[q]` = position of the held-out item."""
+    hits = 0
+    for q in range(queries.shape[0]):
+        h = set(int(x) for x in histories[q])
+        I, _ = topk_ip(items, queries[q:q + 1], min(k + len(h), items.shape[0]))
+        filtered = []
+        for it in I[0]:
+            if it >= 0 and int(it) not in h:
+                filtered.append(int(it))
+            if len(filtered) >= k:
+                break
+        hits += int(int(targets[q]) in filtered)
+    return hits / queries.shape[0] if queries.shape[0] else 0

@@ -1,0 +1,208 @@
+"""Exact inner-product top-k retrieval + DSSM hit rate.
+Reference: src/model/model_utils/TopKSearcher.py:50-84, src/model/recall/DSSM/model.py:182-254.
+
+faiss is not in this image, so parity with faiss itself is unpinned; the oracle restates IndexFlatIP's
+documented contract (exhaustive IP search, scores descending, -1 / -FLT_MAX padding) and the reference's
+over-fetch-and-filter loop.  Bars: HIP vs the C oracle (same fp32 fma chain) BIT-EXACT for scores and
+indices; C oracle vs the float64 numpy restatement: scores to 1e-5, indices equal wherever the neighbouring
+scores are separated by more than 1e-5."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_c, ref_np as R
+from tests.conftest import CONFIGS
+
+DEV = "cuda:0"
+FLT_MAX = np.finfo(np.float32).max
+
+
+def _case(seed, N, Q, d, max_excl=0, dup=False):
+    rng = np.random.default_rng(seed)
+    items = rng.standard_normal((N, d)).astype(np.float32)
+    if dup and N >= 8:                      # exact ties: duplicated item rows
+        items[N // 2:N // 2 + 4] = items[:4]
+    q = rng.standard_normal((Q, d)).astype(np.float32)
+    lists = [np.sort(rng.choice(N, size=int(rng.integers(0, min(max_excl, N) + 1)), replace=False)).astype(np.int64)
+             if max_excl and N else np.zeros(0, np.int64) for _ in range(Q)]
+    off = np.zeros(Q + 1, np.int64)
+    off[1:] = np.cumsum([len(l) for l in lists])
+    flat = np.concatenate(lists) if lists else np.zeros(0, np.int64)
+    return items, q, lists, (off, flat)
+
+
+# ------------------------------------------------------------------ CPU: the two oracles agree
+@pytest.mark.parametrize("N,Q,d,k,me", [(300, 17, 16, 10, 0), (300, 17, 16, 10, 25), (7, 5, 8, 10, 3), (64, 9, 32, 1, 0)])
+def test_c_oracle_matches_numpy_restatement(N, Q, d, k, me):
+    items, q, lists, csr = _case(N + k, N, Q, d, me)
+    i_np, s_np = R.topk_ip(items, q, k, lists if me else None)
+    i_c, s_c = ref_c.topk_ip(items, q, k, csr if me else None)
+    live = i_np >= 0
+    assert np.array_equal(live, i_c >= 0)
+    np.testing.assert_allclose(s_c[live], s_np[live], rtol=0, atol=1e-5)
+    assert np.all(s_c[~live] == -FLT_MAX) and np.all(i_c[~live] == -1)
+    gap_ok = np.ones_like(live)
+    gap_ok[:, 1:] &= np.abs(np.diff(s_np.astype(np.float64), axis=1)) > 1e-5
+    gap_ok[:, :-1] &= np.abs(np.diff(s_np.astype(np.float64), axis=1)) > 1e-5
+    assert np.array_equal(i_c[live & gap_ok], i_np[live & gap_ok])
+
+
+def test_ties_go_to_the_lower_index_and_exclusions_never_return():
+    items, q, lists, csr = _case(5, 40, 6, 16, 10, dup=True)
+    i_c, s_c = ref_c.topk_ip(items, q, 40, csr)
+    for r in range(6):
+        got = i_c[r][i_c[r] >= 0]
+        assert len(got) == 40 - len(lists[r]) and not set(got.tolist()) & set(lists[r].tolist())
+        sc = s_c[r][: len(got)]
+        assert np.all(np.diff(sc) <= 0)
+        for a, b in zip(range(len(got) - 1), range(1, len(got))):
+            if sc[a] == sc[b]:
+                assert got[a] < got[b]
+
+
+def test_batched_exclusion_equals_the_reference_overfetch_loop():
+    """recall/DSSM/model.py:209-221 (search k + len(history), drop history, keep k, test the target) ==
+    one batched top-k with the history excluded."""
+    items, q, lists, csr = _case(11, 200, 23, 16, 30)
+    rng = np.random.default_rng(3)
+    i_top, _ = ref_c.topk_ip(items, q, 10, csr)
+    targets = np.where(rng.random(23) < 0.5, i_top[:, rng.integers(0, 10)], rng.integers(0, 200, 23))
+    loop = R.hit_rate_reference_loop(items, q, targets, lists, 10)
+    batched = float(np.mean((i_top == targets[:, None]).any(axis=1)))
+    assert loop == pytest.approx(batched) and 0.0 < loop < 1.0
+
+
+# ------------------------------------------------------------------ GPU parity
+gpu = pytest.mark.gpu
+
+
+def _run_hip(items, q, k, csr=None):
+    from news_recsys_amd import ops
+    ex = None if csr is None else (torch.from_numpy(csr[0]).to(DEV), torch.from_numpy(csr[1]).to(DEV))
+    idx, score = ops.topk_ip(torch.from_numpy(items).to(DEV), torch.from_numpy(q).to(DEV), k, exclude=ex)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy(), score.cpu().numpy()
+
+
+@gpu
+@pytest.mark.parametrize("d", [4, 8, 12, 16, 32, 64, 128])
+@pytest.mark.parametrize("k", [1, 10, 16, 32])
+def test_hip_topk_bit_exact_vs_c_oracle(d, k):
+    items, q, lists, csr = _case(d * 100 + k, 5000, 300, d, 0, dup=True)
+    i_h, s_h = _run_hip(items, q, k)
+    i_c, s_c = ref_c.topk_ip(items, q, k)
+    assert np.array_equal(s_h.view(np.uint32), s_c.view(np.uint32))
+    assert np.array_equal(i_h, i_c)
+
+
+@gpu
+@pytest.mark.parametrize("N,Q,k,me", [(0, 5, 10, 0), (3, 7, 10, 0), (3, 7, 10, 3), (1000, 1, 10, 50), (4096, 257, 10, 200),
+                                       (4097, 256, 5, 0), (70001, 513, 10, 300), (50, 0, 10, 0)])
+def test_hip_topk_edges_and_exclusions(N, Q, k, me):
+    items, q, lists, csr = _case(N + Q + k, N, Q, 16, me, dup=True)
+    i_h, s_h = _run_hip(items, q, k, csr if me else None)
+    i_c, s_c = ref_c.topk_ip(items, q, k, csr if me else None)
+    assert i_h.shape == (Q, k)
+    assert np.array_equal(s_h.view(np.uint32), s_c.view(np.uint32))
+    assert np.array_equal(i_h, i_c)
+
+
+@gpu
+def test_hip_topk_full_size_properties():
+    """200k items x 16384 queries (too big for the oracle in test time): size-independent properties --
+    scores descending, returned score == recomputed inner product, k-th score >= every non-returned score on a
+    sample of queries, and the first 64 queries bit-exact vs the oracle."""
+    from news_recsys_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(0)
+    items = torch.nn.functional.normalize(torch.randn(200_000, 16, generator=g), dim=1).to(DEV)
+    q = torch.nn.functional.normalize(torch.randn(16_384, 16, generator=g), dim=1).to(DEV)
+    idx, score = ops.topk_ip(items, q, 10)
+    assert bool((score[:, :-1] >= score[:, 1:]).all()) and bool((idx >= 0).all())
+    re = (items[idx] * q[:, None, :]).sum(-1)
+    torch.testing.assert_close(re, score, rtol=0, atol=2e-6)
+    sub = slice(0, 512)
+    full = q[sub] @ items.T
+    kth = score[sub, -1:]
+    assert int((full > kth + 2e-6).sum(dim=1).max().item()) <= 9
+    i_c, s_c = ref_c.topk_ip(items.cpu().numpy(), q[:64].cpu().numpy(), 10)
+    assert np.array_equal(idx[:64].cpu().numpy(), i_c)
+    assert np.array_equal(score[:64].cpu().numpy().view(np.uint32), s_c.view(np.uint32))
+
+
+@gpu
+def test_hip_topk_rejects_unsupported():
+    from news_recsys_amd import ops
+    it = torch.zeros(10, 16, device=DEV)
+    with pytest.raises(Exception):
+        ops.topk_ip(it, torch.zeros(2, 16, device=DEV), 33)
+    with pytest.raises(Exception):
+        ops.topk_ip(torch.zeros(10, 6, device=DEV), torch.zeros(2, 6, device=DEV), 5)
+    with pytest.raises(ValueError):
+        ops.topk_ip(it, torch.zeros(2, 8, device=DEV), 5)
+
+
+@gpu
+def test_topk_searcher_surface():
+    """TopKSearcher.py: update_embedding(nn.Embedding, normalize) + search(list of [d] tensors) -> python lists."""
+    from news_recsys_amd.model.model_utils.TopKSearcher import TopKSearcher
+    torch.manual_seed(0)
+    emb = torch.nn.Embedding(500, 16)
+    s = TopKSearcher(k=7)
+    with pytest.raises(ValueError):
+        s.search([torch.zeros(16)])
+    s.update_embedding(emb, normalize=True, verbose=False)
+    assert s.dimension == 16 and s.search([], normalize=True) == ([], [])
+    qs = [torch.randn(16) for _ in range(5)]
+    I, D = s.search(qs, normalize=True)
+    assert isinstance(I, list) and isinstance(I[0], list) and len(I) == 5 and len(I[0]) == 7 and isinstance(D[0][0], float)
+    w = emb.weight.detach().numpy()
+    w = w / np.linalg.norm(w, axis=1, keepdims=True)
+    qn = torch.stack(qs).numpy()
+    qn = qn / np.linalg.norm(qn, axis=1, keepdims=True)
+    i_np, s_np = R.topk_ip(w, qn, 7)
+    assert I == i_np.tolist()
+    np.testing.assert_allclose(np.array(D), s_np, atol=1e-5)
+
+
+@gpu
+def test_dssm_hit_rate_matches_reference_loop():
+    """DSSM.on_train_epoch_end + hit_rate (model.py:182-254) with batched retrieval == the reference's
+    per-user loop restated in the oracle, on the item / user embeddings the model itself produced."""
+    from news_recsys_amd.model.recall.DSSM.model import DSSM
+    torch.manual_seed(1)
+    hp = {"negative_sample_rate": 2, "lr": 1e-3, "min_lr": 1e-5, "lr_milestones": [4, 20], "item_id_feature": "item_id"}
+    n_items, n_users = 44, 60
+    rng = np.random.default_rng(0)
+    item_ids = np.arange(1, n_items + 1)
+    movies = [{"item_id": torch.from_numpy(item_ids[i:i + 16]), "category": torch.from_numpy(rng.integers(1, 18, len(item_ids[i:i + 16])))}
+              for i in range(0, n_items, 16)]
+    val = []
+    hist_of = {}
+    for b in range(0, n_users, 20):
+        uid = np.arange(b + 1, b + 21)
+        hist = rng.integers(1, n_items + 1, (20, 9))
+        mask = (rng.random((20, 9)) < 0.6).astype(np.float32)
+        hist = hist * mask.astype(np.int64)
+        for u, h, mk in zip(uid, hist, mask):
+            hist_of[int(u)] = [int(x) for x, m_ in zip(h, mk) if m_ > 0]
+        val.append({"user_id": torch.from_numpy(uid), "user_history": torch.from_numpy(hist), "user_history_mask": torch.from_numpy(mask),
+                    "item_id": torch.from_numpy(rng.integers(1, n_items + 1, 20))})
+    m = DSSM(os.path.join(CONFIGS, "cf_dssm_small.yaml"), {"movies_dataloader": movies, "val_dataloader": val}, hp).to(DEV)
+    m.user_history = hist_of
+    m.on_train_epoch_end()
+    assert m.all_item_embeddings.shape == (n_items, 16) and m.idx_item_emb_dic[0] == 1
+    got = m.last_hit_rate
+    items = m.all_item_embeddings.cpu().numpy()
+    users, targets, hists = [], [], []
+    for batch in val:
+        db = {k: v.to(DEV) for k, v in batch.items()}
+        users.append(m.inference({**db, "category": torch.ones(20, dtype=torch.int64, device=DEV)})[0].cpu().numpy())
+        targets += [int(t) - 1 for t in batch["item_id"]]                     # item id v sits at index v-1
+        hists += [[h - 1 for h in set(hist_of[int(u)])] for u in batch["user_id"]]
+    ref = R.hit_rate_reference_loop(items, np.concatenate(users), np.array(targets), hists, 10)
+    assert got == pytest.approx(ref) and 0.0 < got < 1.0
+    # batch size 1 (the only size the reference accepts) gives the same number
+    val1 = [{k: v[i:i + 1] for k, v in b.items()} for b in val for i in range(20)]
+    assert m.hit_rate(10, val1) == pytest.approx(ref)

@@ -97,3 +97,25 @@ if want("metrics"):
     n2 = 200_000
     t0 = time.perf_counter(); ref = R.validation_metrics(uid[:n2].cpu().numpy(), sc[:n2].cpu().numpy(), lb[:n2].cpu().numpy(), warm); dt2 = time.perf_counter() - t0
     print(f"reference-style Python loop (oracle port, 1 thread): {n2} samples: {dt2 * 1e3:8.1f} ms  ({n2 / dt2 / 1e6:6.3f} M samples/s)", flush=True)
+
+if want("topk"):
+    import time, numpy as np
+    from oracle import ref_c
+    N, Q, d, k = 200_000, 65_536, 16, 10
+    gen = torch.Generator(device=dev).manual_seed(9)
+    items = torch.nn.functional.normalize(torch.randn(N, d, device=dev, generator=gen), dim=1)
+    q = torch.nn.functional.normalize(torch.randn(Q, d, device=dev, generator=gen), dim=1)
+    with torch.no_grad():
+        us = timeit(lambda: ops.topk_ip(items, q, k), steps=5, warm=1)
+        us_t = timeit(lambda: torch.topk(q @ items.T, k, dim=1), steps=2, warm=1)
+    fl = 2.0 * N * Q * d
+    print(f"topk_ip {Q} queries x {N} items x {d}, k={k}: {us / 1e3:8.2f} ms  {fl / us / 1e6:6.1f} TFLOP/s "
+          f"({fl / us / 1e6 / 157.3 * 100:4.1f}% of fp32 peak)  {Q / us:6.2f} M queries/s  [torch matmul+topk {us_t / 1e3:8.2f} ms]", flush=True)
+    off = torch.arange(Q + 1, device=dev, dtype=torch.int64) * 50
+    ex = torch.sort(torch.randint(0, N, (Q, 50), device=dev, generator=gen), dim=1).values.reshape(-1)
+    with torch.no_grad():
+        us_e = timeit(lambda: ops.topk_ip(items, q, k, exclude=(off, ex)), steps=5, warm=1)
+    print(f"  with 50 excluded items per query: {us_e / 1e3:8.2f} ms", flush=True)
+    nq = 2048
+    t0 = time.perf_counter(); ref_c.topk_ip(items.cpu().numpy(), q[:nq].cpu().numpy(), k); dt = time.perf_counter() - t0
+    print(f"  C oracle (OpenMP, {ref_c.threads()} threads): {nq} queries {dt * 1e3:8.1f} ms  ({nq / dt / 1e6:6.3f} M queries/s)", flush=True)
