@@ -2,39 +2,32 @@
 // Reference: src/model/model_utils/TopKSearcher.py:50-84, src/model/recall/DSSM/model.py:182-254.
 //
 // Shape: Q queries x N items x d (d = 16 for the reference's towers): 2*Q*N*d flop against N*d*4 bytes
-// of items that every query re-reads -> compute-bound.  On gfx950 the fp32 MFMA rate equals the fp32
-// VALU rate (157 TF), so the contraction runs on the VALU, where the per-lane k-selection lives anyway:
-// one thread owns one query (its d floats in registers), a block shares LDS tiles of items (every lane
-// reads the same item row: broadcast ds_read_b128, conflict-free), 4 items in flight per lane for ILP,
-// and each lane keeps its running top-k sorted in registers (insertion only when a score beats the
-// current k-th, which becomes rare after the first few tiles).  Items are split over blockIdx.y so small
-// query counts still fill the chip; a second kernel merges the per-split lists.
+// of items that every query re-reads -> compute-bound.  On gfx950 the fp32 MFMA rate equals the packed
+// fp32 VALU rate (157 TF), so the contraction runs on the VALU, where the per-lane k-selection lives
+// anyway: one thread owns one query (its d floats in registers), item rows are wave-uniform and arrive
+// through the scalar cache, v_pk_fma_f32 accumulates even / odd dimensions, and each lane keeps its
+// running top-k sorted in registers (insertion only when a score beats the current k-th, which becomes
+// rare after the first few hundred items).  Items are split over blockIdx.y so small query counts still
+// fill the chip; a second kernel merges the per-split lists.
+// Score definition (the oracle restates it): s = fl(e + o), e / o = fp32 fma chains over the even / odd
+// dimensions in ascending order.
 #include "nrx_common.h"
 #include <float.h>
+#include <limits.h>
+#include <stdlib.h>
 #include <math.h>
 
 namespace {
 
 constexpr int KMAX = 32;
-constexpr int TILE_BYTES = 32 * 1024;
+constexpr int QCAP = 8;          // per-lane candidate queue depth (LDS)
 
-// score = sequential fp32 fma chain over the dimension (k ascending): the oracle restates exactly this
-__device__ __forceinline__ float dot4(const float4 q, const float4 v, float a) {
-    a = fmaf(q.x, v.x, a);
-    a = fmaf(q.y, v.y, a);
-    a = fmaf(q.z, v.z, a);
-    return fmaf(q.w, v.w, a);
-}
-
-__device__ __forceinline__ bool excluded(const int64_t* lst, int64_t n, int64_t item) {
-    int64_t lo = 0, hi = n;
+__device__ __forceinline__ int64_t lower_bound(const int64_t* lst, int64_t lo, int64_t hi, int64_t v) {
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        const int64_t v = lst[mid];
-        if (v == item) return true;
-        if (v < item) lo = mid + 1; else hi = mid;
+        if (lst[mid] < v) lo = mid + 1; else hi = mid;
     }
-    return false;
+    return lo;
 }
 
 // insert (score, idx) into a descending list of length K kept in registers (static indexing only)
@@ -55,66 +48,101 @@ __device__ __forceinline__ void topk_insert(float (&s)[K], I (&ix)[K], float sco
     }
 }
 
-template <int K, int D4>
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// One thread = one query; the item row is the same for every lane of the wave, so it is fetched with
+// SCALAR loads (constant address space -> s_load_dwordx8/x16 through the scalar cache) and consumed
+// straight from SGPRs by packed fp32 FMAs: v_pk_fma_f32 does the even and the odd dimension of one
+// (query, item) pair per lane per issue.  UNROLL items are in flight for ILP.  No LDS, no barriers.
+template <int K, int D2, int UNROLL>
 __global__ __launch_bounds__(NRX_BLOCK) void topk_partial_kernel(const float* __restrict__ items, int64_t n_items, const float* __restrict__ queries,
                                                                  int64_t n_queries, int k, const int64_t* __restrict__ excl_off,
                                                                  const int64_t* __restrict__ excl_items, int64_t items_per_split,
-                                                                 int tile_items, float* __restrict__ p_score, int* __restrict__ p_idx) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* s_items = reinterpret_cast<float4*>(smem);          // [tile_items][D4]
+                                                                 float* __restrict__ p_score, int* __restrict__ p_idx) {
     const int64_t qi = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x;
     const bool live = qi < n_queries;
-    float4 q[D4];
+    const int64_t qc = live ? qi : n_queries - 1;
+    f32x2 q[D2];
 #pragma unroll
-    for (int j = 0; j < D4; ++j) q[j] = live ? reinterpret_cast<const float4*>(queries + qi * (int64_t)(4 * D4))[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < D2; ++j) q[j] = reinterpret_cast<const f32x2*>(queries + qc * (int64_t)(2 * D2))[j];
     float bs[K];
     int bi[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) { bs[j] = -FLT_MAX; bi[j] = -1; }
-    const int64_t e0 = (live && excl_off) ? excl_off[qi] : 0;
-    const int64_t en = (live && excl_off) ? excl_off[qi + 1] - e0 : 0;
     const int64_t begin = (int64_t)blockIdx.y * items_per_split;
     const int64_t end = begin + items_per_split < n_items ? begin + items_per_split : n_items;
-    for (int64_t t0 = begin; t0 < end; t0 += tile_items) {
-        const int cur = (int)((end - t0) < tile_items ? (end - t0) : tile_items);
-        __syncthreads();
-        for (int e = threadIdx.x; e < cur * D4; e += NRX_BLOCK)
-            s_items[e] = reinterpret_cast<const float4*>(items + t0 * (int64_t)(4 * D4))[e];
-        __syncthreads();
-        if (!live) continue;
-        int i = 0;
-        for (; i + 4 <= cur; i += 4) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-            for (int j = 0; j < D4; ++j) {
-                const float4 v0 = s_items[(i + 0) * D4 + j], v1 = s_items[(i + 1) * D4 + j];
-                const float4 v2 = s_items[(i + 2) * D4 + j], v3 = s_items[(i + 3) * D4 + j];
-                a0 = dot4(q[j], v0, a0);
-                a1 = dot4(q[j], v1, a1);
-                a2 = dot4(q[j], v2, a2);
-                a3 = dot4(q[j], v3, a3);
+    // exclusion list (ascending) walked in step with the ascending item scan: next_ex = first excluded
+    // position >= the last candidate looked at; advanced lazily, only when a candidate is examined
+    int64_t ep = excl_off ? excl_off[qc] : 0;
+    const int64_t e1 = excl_off ? excl_off[qc + 1] : 0;
+    ep = lower_bound(excl_items, ep, e1, begin);
+    int next_ex = ep < e1 ? (int)excl_items[ep] : INT_MAX;
+    auto is_excluded = [&](int it) {
+        while (next_ex < it) { ++ep; next_ex = ep < e1 ? (int)excl_items[ep] : INT_MAX; }
+        return next_ex == it;
+    };
+    const f32x2 NRX_CONST* itc = (const f32x2 NRX_CONST*)(items);
+    // Candidates that beat the (possibly stale) k-th score are appended to a small per-lane queue in LDS
+    // and merged into the sorted register list only when some lane's queue could overflow: a wave takes
+    // the ~100-instruction insertion path once per ~QCAP hits of its busiest lane instead of on every
+    // hit of ANY of its 64 lanes.  Appending in item order + strict '>' insertion keeps the result
+    // identical to immediate insertion (ties toward the lower index).
+    __shared__ float q_s[QCAP][NRX_BLOCK];
+    __shared__ int q_i[QCAP][NRX_BLOCK];
+    int cnt = 0;
+    float kth = -FLT_MAX;
+    auto flush = [&]() {
+#pragma unroll 1
+        for (int c = 0; c < QCAP; ++c) {
+            if (c < cnt) {
+                const float cs = q_s[c][threadIdx.x];
+                if (cs > bs[K - 1]) topk_insert<K, int>(bs, bi, cs, q_i[c][threadIdx.x]);
             }
-            const float kth = bs[K - 1];
-            if (a0 > kth || a1 > kth || a2 > kth || a3 > kth) {
-                const float sc[4] = {a0, a1, a2, a3};
+        }
+        cnt = 0;
+        kth = bs[K - 1];
+    };
+    int64_t i = begin;
+    for (; i + UNROLL <= end; i += UNROLL) {
+        const f32x2 NRX_CONST* row = itc + i * D2;
+        f32x2 acc[UNROLL];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int64_t it = t0 + i + u;
-                    if (sc[u] > bs[K - 1] && !(en && excluded(excl_items + e0, en, it))) topk_insert<K, int>(bs, bi, sc[u], (int)it);
+        for (int u = 0; u < UNROLL; ++u) acc[u] = (f32x2){0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < D2; ++j)
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) acc[u] = __builtin_elementwise_fma(q[j], row[u * D2 + j], acc[u]);
+        float sc[UNROLL];
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) { sc[u] = acc[u].x + acc[u].y; any |= sc[u] > kth; }
+        if (__builtin_amdgcn_ballot_w64(any) != 0) {      // wave-uniform branch
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t it = i + u;
+                if (sc[u] > kth && !is_excluded((int)it)) {
+                    q_s[cnt][threadIdx.x] = sc[u];
+                    q_i[cnt][threadIdx.x] = (int)it;
+                    ++cnt;
                 }
             }
-        }
-        for (; i < cur; ++i) {
-            float a0 = 0.f;
-#pragma unroll
-            for (int j = 0; j < D4; ++j) {
-                const float4 v0 = s_items[i * D4 + j];
-                a0 = dot4(q[j], v0, a0);
-            }
-            const int64_t it = t0 + i;
-            if (a0 > bs[K - 1] && !(en && excluded(excl_items + e0, en, it))) topk_insert<K, int>(bs, bi, a0, (int)it);
+            if (__builtin_amdgcn_ballot_w64(cnt > QCAP - UNROLL) != 0) flush();
         }
     }
+    for (; i < end; ++i) {
+        const f32x2 NRX_CONST* row = itc + i * D2;
+        f32x2 acc = (f32x2){0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < D2; ++j) acc = __builtin_elementwise_fma(q[j], row[j], acc);
+        const float a0 = acc.x + acc.y;
+        if (a0 > kth && !is_excluded((int)i)) {
+            q_s[cnt][threadIdx.x] = a0;
+            q_i[cnt][threadIdx.x] = (int)i;
+            ++cnt;
+        }
+        if (__builtin_amdgcn_ballot_w64(cnt > QCAP - UNROLL) != 0) flush();
+    }
+    flush();
     if (live) {
         float* ps = p_score + (qi * gridDim.y + blockIdx.y) * (int64_t)K;
         int* pi = p_idx + (qi * gridDim.y + blockIdx.y) * (int64_t)K;
@@ -150,7 +178,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void topk_merge_kernel(const float* __re
 
 int choose_splits(int64_t n_items, int64_t n_queries) {
     const int64_t qblocks = n_queries > 0 ? (n_queries + NRX_BLOCK - 1) / NRX_BLOCK : 1;
-    int64_t s = (1024 + qblocks - 1) / qblocks;            // aim at >= 1024 blocks (4 per CU)
+    const char* env = getenv("NRX_TOPK_BLOCKS");
+    const int64_t target = env ? atoll(env) : 2048;
+    int64_t s = (target + qblocks - 1) / qblocks;            // aim at >= 2048 blocks (8 per CU)
     const int64_t max_s = (n_items + 4095) / 4096;          // keep >= 4096 items per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -181,21 +211,19 @@ extern "C" int nrx_topk_ip(const float* items, int64_t n_items, int32_t dim, con
     const int K = k <= 8 ? 8 : (k <= 16 ? 16 : KMAX);
     const int S = choose_splits(n_items, n_queries);
     const int64_t per_split = ((n_items + S - 1) / S + 3) & ~3ll;
-    const int D4 = dim / 4;
-    const int tile_items = (TILE_BYTES / (dim * 4)) & ~3;
+    const int D2 = dim / 2;
     char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     int* p_idx = reinterpret_cast<int*>(ws);
     float* p_score = reinterpret_cast<float*>(ws + (size_t)S * n_queries * K * sizeof(int));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((unsigned)((n_queries + NRX_BLOCK - 1) / NRX_BLOCK), (unsigned)S);
-    const size_t smem = (size_t)tile_items * dim * 4;
-#define NRX_TK(K_, D4_) hipLaunchKernelGGL((topk_partial_kernel<K_, D4_>), grid, dim3(NRX_BLOCK), smem, st, items, n_items, queries, \
-                                           n_queries, k, excl_offsets, excl_items, per_split, tile_items, p_score, p_idx)
-#define NRX_TK_D(K_)                                                                                     \
-    switch (D4) {                                                                                        \
-        case 1: NRX_TK(K_, 1); break; case 2: NRX_TK(K_, 2); break; case 3: NRX_TK(K_, 3); break;        \
-        case 4: NRX_TK(K_, 4); break; case 8: NRX_TK(K_, 8); break; case 16: NRX_TK(K_, 16); break;      \
-        case 32: NRX_TK(K_, 32); break;                                                                  \
+#define NRX_TK(K_, D2_, U_) hipLaunchKernelGGL((topk_partial_kernel<K_, D2_, U_>), grid, dim3(NRX_BLOCK), 0, st, items, n_items, queries, \
+                                               n_queries, k, excl_offsets, excl_items, per_split, p_score, p_idx)
+#define NRX_TK_D(K_)                                                                                            \
+    switch (D2) {                                                                                               \
+        case 2: NRX_TK(K_, 2, 4); break; case 4: NRX_TK(K_, 4, 4); break; case 6: NRX_TK(K_, 6, 4); break;      \
+        case 8: NRX_TK(K_, 8, 4); break; case 16: NRX_TK(K_, 16, 2); break; case 32: NRX_TK(K_, 32, 1); break;  \
+        case 64: NRX_TK(K_, 64, 1); break;                                                                      \
         default: nrx_set_error("nrx_topk_ip: dim %d not instantiated (4,8,12,16,32,64,128)", dim); return NRX_ERR_UNSUPPORTED; \
     }
     if (K == 8) { NRX_TK_D(8) } else if (K == 16) { NRX_TK_D(16) } else { NRX_TK_D(32) }

@@ -108,8 +108,8 @@ void oracle_dcn_v1(const float* x, int64_t x_ld, int64_t B, int32_t dim, int32_t
  * (faiss-cpu, unpinned in the reference's requirements; absent from this image) documents IndexFlatIP as
  * exhaustive search by inner product with results sorted by decreasing score, label -1 / score -FLT_MAX
  * where fewer than k vectors exist; its tie order and fp32 summation order are unspecified.  This
- * restatement fixes both: score = fp32 fma chain over the dimension in ascending order, ties toward the
- * lower index.  excl (optional CSR, lists ascending): items a query must not return -- the reference's
+ * restatement fixes both: score = fl(e + o) with e / o the fp32 fma chains over the even / odd dimensions
+ * (ascending), ties toward the lower index.  excl (optional CSR, lists ascending): items a query must not return -- the reference's
  * "search k + len(history), drop history, keep k" (model.py:209-221) yields the same list.          */
 void oracle_topk_ip(const float* items, int64_t n_items, int32_t dim, const float* queries, int64_t n_queries,
                     int32_t k, const int64_t* excl_off, const int64_t* excl_items, int64_t* out_idx, float* out_score) {
@@ -125,8 +125,10 @@ void oracle_topk_ip(const float* items, int64_t n_items, int32_t dim, const floa
             while (ep < e1 && excl_items[ep] < i) ++ep;
             if (ep < e1 && excl_items[ep] == i) continue;
             const float* v = items + i * dim;
-            float a = 0.f;
-            for (int d = 0; d < dim; ++d) a = fmaf(qv[d], v[d], a);
+            float ev = 0.f, od = 0.f;       /* the kernel's packed-fma order: even / odd chains, then one add */
+            for (int d = 0; d + 1 < dim; d += 2) { ev = fmaf(qv[d], v[d], ev); od = fmaf(qv[d + 1], v[d + 1], od); }
+            if (dim & 1) ev = fmaf(qv[dim - 1], v[dim - 1], ev);
+            const float a = ev + od;
             if (!(a > os[k - 1])) continue;
             int j = k - 1;
             while (j > 0 && a > os[j - 1]) { os[j] = os[j - 1]; oi[j] = oi[j - 1]; --j; }

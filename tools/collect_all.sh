@@ -16,6 +16,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $F/dcn2/stats -- python3
 python3 tools/summarize_profile.py $F/dcn2 > $F/dcn2_summary.txt 2>&1
 python3 tools/bench_ops.py > $F/bench_ops.log 2>&1
 python3 tools/bench_loader.py 300000 > $F/bench_loader.log 2>&1
+python3 tools/bench_host_overhead.py > $F/host_overhead.log 2>&1
+for z in c2 c4; do python3 bench.py --workload $z --ids zipf --steps 100 --warmup 10 --no-cpu-baseline > $F/bench_${z}_zipf.log 2>&1; done
 python3 tools/probe_bag.py > $F/probe_bag.log 2>&1
 python3 tools/probe_outbuf.py > $F/probe_outbuf.log 2>&1
 python3 bench.py --force-sharded --shard-mode row --steps 100 --warmup 10 --no-cpu-baseline > $F/bench_c2_sharded_world1.log 2>&1
