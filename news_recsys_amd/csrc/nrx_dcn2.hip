@@ -14,6 +14,7 @@
 // The Hadamard / bias / residual / ReLU epilogue is fused on the accumulator registers
 // (C layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)).
 #include "nrx_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -39,18 +40,6 @@ __device__ __forceinline__ float4 guarded_load4(const float* base, int64_t row, 
     return v;
 }
 
-// Branch-free 16-byte load for the aligned fast path (ld % 4 == 0, K % 4 == 0): out-of-range rows /
-// k are clamped to a valid address and the result is zeroed with selects, so the six prefetch loads of
-// a slab are issued back-to-back with no exec-mask control flow.
-__device__ __forceinline__ float4 clamped_load4(const float* base, int64_t row, int64_t nrows, int64_t ld, int k, int K) {
-    const bool ok = row < nrows && k < K;
-    const int64_t r = row < nrows ? row : nrows - 1;
-    const int kc = k < K ? k : 0;
-    float4 v = nrx_ldg4(base + r * ld + kc, 0);
-    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-    return v;
-}
-
 template <bool RELU, bool VEC>
 __global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __restrict__ x0, const float* __restrict__ xl, int64_t ld,
                                                            int64_t M, int N, const float* __restrict__ W, const float* __restrict__ bias,
@@ -60,7 +49,7 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __res
     const int K = N;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = tid >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform by construction; tell the compiler
     const int wm = wid >> 1, wn = wid & 1;
     const int l31 = lane & 31, hi = lane >> 5;
     // XCD-aware tile order (guide T1, bijective form): hardware places block b on XCD b % 8; remap so
@@ -83,12 +72,57 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __res
 
     // Register-prefetch pipeline: the global loads of slab k+1 are in flight while slab k's 32 MFMAs
     // per wave (2048 cycles) run out of LDS; one LDS buffer, two barriers per slab.
+    // VALU instructions do not overlap the fp32 MFMA on gfx950 (profiles/r01_mfma_f32_valu_overlap_probe.txt:
+    // each one costs its 4 cycles of matrix time), so the aligned path keeps them out of the k loop: the
+    // tile base is a wave-uniform pointer advanced on the scalar unit, each thread adds a fixed 32-bit byte
+    // offset (global_load saddr + voffset form), rows past M / N are clamped instead of zeroed (their
+    // outputs are never stored) and only a partial last slab pays for zero selects.
     constexpr int AP = BM / 32;       // float4 loads of the A slab per thread
     float4 a[AP], w[2];
+    uint32_t oa[AP], ow[2];
+    const char* const xtile = reinterpret_cast<const char*>(xl + m0 * ld);
+    const char* const wtile = reinterpret_cast<const char*>(W + (int64_t)n0 * K);
 #pragma unroll
-    for (int p = 0; p < AP; ++p) a[p] = VEC ? clamped_load4(xl, m0 + srow + 32 * p, M, ld, skq, K) : guarded_load4(xl, m0 + srow + 32 * p, M, ld, skq, K, false);
+    for (int p = 0; p < AP; ++p) {
+        const int64_t r = m0 + srow + 32 * p < M ? srow + 32 * p : M - 1 - m0;
+        oa[p] = (uint32_t)((r * ld + skq) * 4);
+    }
 #pragma unroll
-    for (int p = 0; p < 2; ++p) w[p] = VEC ? clamped_load4(W, n0 + srow + 32 * p, N, K, skq, K) : guarded_load4(W, n0 + srow + 32 * p, N, K, skq, K, false);
+    for (int p = 0; p < 2; ++p) {
+        const int r = n0 + srow + 32 * p < N ? srow + 32 * p : N - 1 - n0;
+        ow[p] = (uint32_t)((r * K + skq) * 4);
+    }
+    auto load_slab = [&](int k0) {
+        if (VEC) {
+            const char* xk = xtile + (size_t)k0 * 4;
+            const char* wk = wtile + (size_t)k0 * 4;
+            if (k0 + BK <= K) {
+#pragma unroll
+                for (int p = 0; p < AP; ++p) a[p] = *reinterpret_cast<const float4*>(xk + oa[p]);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) w[p] = *reinterpret_cast<const float4*>(wk + ow[p]);
+            } else {                    // partial last slab: K % 4 == 0, so a float4 is all-in or all-out;
+                const bool ok = k0 + skq < K;                  // out-of-range lanes re-read slab 0 and zero it
+                const size_t back = ok ? 0 : (size_t)k0 * 4;
+#pragma unroll
+                for (int p = 0; p < AP; ++p) {
+                    const float4 t = *reinterpret_cast<const float4*>(xk + oa[p] - back);
+                    a[p] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const float4 t = *reinterpret_cast<const float4*>(wk + ow[p] - back);
+                    w[p] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < AP; ++p) a[p] = guarded_load4(xl, m0 + srow + 32 * p, M, ld, k0 + skq, K, false);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) w[p] = guarded_load4(W, n0 + srow + 32 * p, N, K, k0 + skq, K, false);
+        }
+    };
+    load_slab(0);
 
     for (int k0 = 0; k0 < K; k0 += BK) {
 #pragma unroll
@@ -108,12 +142,7 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __res
             Ws[(skq + 3) * LDW + n] = w[p].w;
         }
         __syncthreads();
-        if (k0 + BK < K) {           // next slab: loads stay in flight across the MFMA block below
-#pragma unroll
-            for (int p = 0; p < AP; ++p) a[p] = VEC ? clamped_load4(xl, m0 + srow + 32 * p, M, ld, k0 + BK + skq, K) : guarded_load4(xl, m0 + srow + 32 * p, M, ld, k0 + BK + skq, K, false);
-#pragma unroll
-            for (int p = 0; p < 2; ++p) w[p] = VEC ? clamped_load4(W, n0 + srow + 32 * p, N, K, k0 + BK + skq, K) : guarded_load4(W, n0 + srow + 32 * p, N, K, k0 + BK + skq, K, false);
-        }
+        if (k0 + BK < K) load_slab(k0 + BK);      // next slab: loads stay in flight across the MFMA block below
         // fragments of half a slab (8 k-pairs: 8 B + 32 A dwords) are read ahead of a dense block of
         // 32 MFMAs, so the LDS latency is paid twice per slab instead of once per MFMA group
 #pragma unroll
@@ -134,22 +163,51 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __res
         __syncthreads();             // slab fully consumed before the next LDS write
     }
 
+    // Epilogue, also written for few VALU instructions: the address of register r's element is a wave-uniform
+    // row pointer (tile base + constant * ld, scalar unit) plus one fixed per-lane byte offset, so a full
+    // tile costs add-bias, fma, max per element; only a tile that crosses M takes the guarded path.
     const int col = n0 + wn * 32 + l31;
     const bool same_x = (x0 == xl);
     if (col < N) {
         const float bc = bias[col];
+        const int64_t r0 = m0 + wm * (32 * TM);                       // wave-uniform first row
+        const uint32_t lo = (uint32_t)(((int64_t)(4 * hi) * ld + col) * 4);         // per-lane byte offset (inputs)
+        const uint32_t lo_o = (uint32_t)(((int64_t)(4 * hi) * out_ld + col) * 4);   // per-lane byte offset (output)
+        if (r0 + 32 * TM <= M) {
+            // 16 independent loads in flight per batch, then the arithmetic and the stores (no branch inside)
+            auto tile_out = [&](auto same) {
 #pragma unroll
-        for (int t = 0; t < TM; ++t) {
+                for (int t = 0; t < TM; ++t) {
+                    float xv[16], x0v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * (32 * TM) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (row < M) {
-                    const float lin = acc[t][r] + bc;
-                    const float xv = xl[row * ld + col];
-                    const float x0v = same_x ? xv : x0[row * ld + col];     // layer 0: x0 is x_l, one load
-                    float v = x0v * lin + xv;
-                    if (RELU) v = v > 0.f ? v : 0.f;
-                    out[row * out_ld + col] = v;
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2);      // + 4 * hi, folded into lo
+                        xv[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xl + row * ld) + lo);
+                        x0v[r] = decltype(same)::value ? xv[r] : *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x0 + row * ld) + lo);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2);
+                        float v = fmaf(x0v[r], acc[t][r] + bc, xv[r]);
+                        if (RELU) v = fmaxf(v, 0.f);
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(out + row * out_ld) + lo_o) = v;
+                    }
+                }
+            };
+            if (same_x) tile_out(std::true_type{}); else tile_out(std::false_type{});
+        } else {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (row < M) {
+                        const float xv = xl[row * ld + col];
+                        const float x0v = same_x ? xv : x0[row * ld + col];     // layer 0: x0 is x_l, one load
+                        float v = fmaf(x0v, acc[t][r] + bc, xv);
+                        if (RELU) v = fmaxf(v, 0.f);
+                        out[row * out_ld + col] = v;
+                    }
                 }
             }
         }

@@ -2,25 +2,35 @@
 // Reference: src/model/model_utils/TopKSearcher.py:50-84, src/model/recall/DSSM/model.py:182-254.
 //
 // Shape: Q queries x N items x d (d = 16 for the reference's towers): 2*Q*N*d flop against N*d*4 bytes
-// of items that every query re-reads -> compute-bound.  On gfx950 the fp32 MFMA rate equals the packed
-// fp32 VALU rate (157 TF), so the contraction runs on the VALU, where the per-lane k-selection lives
-// anyway: one thread owns one query (its d floats in registers), item rows are wave-uniform and arrive
-// through the scalar cache, v_pk_fma_f32 accumulates even / odd dimensions, and each lane keeps its
-// running top-k sorted in registers (insertion only when a score beats the current k-th, which becomes
-// rare after the first few hundred items).  Items are split over blockIdx.y so small query counts still
-// fill the chip; a second kernel merges the per-split lists.
-// Score definition (the oracle restates it): s = fl(e + o), e / o = fp32 fma chains over the even / odd
-// dimensions in ascending order.
+// of items that every query re-reads -> compute-bound, GEMM-shaped -> the matrix cores.
+// One wavefront owns 32 queries.  v_mfma_f32_32x32x2_f32 with A = a 32-item tile, B = the wave's 32
+// queries (kept in registers for the whole scan) leaves, in every lane, 16 scores of ONE query
+// (C layout: column = lane & 31 = query, rows = items), so the k-selection is lane-local: each lane keeps a
+// sorted top-k of the item rows it sees (the two lanes of a query and the item splits over blockIdx.y are
+// merged by a second kernel).  Candidates that beat the lane's (possibly stale) k-th score go to a small
+// per-lane LDS queue; the ~100-instruction sorted insertion runs only when some lane's queue could overflow.
+// The user's history is a per-query ascending exclusion list walked in step with the ascending item scan.
+// VALU work (compare / queue) of one wave overlaps the MFMAs of the others.
+//
+// Score definition (measured: tools/mfma_f32_probe.hip -> profiles/r01_mfma_f32_semantics.txt, the MFMA is
+// the fused chain fma(a1,b1, fma(a0,b0,c)) bit for bit): with P = dim rounded up to a multiple of 8 (zero
+// padded) and H = P/2,   s = 0;  for j in 0..H-1:  s = fma(it[j], q[j], s);  s = fma(it[H+j], q[H+j], s).
+// Ties: lower item index first (total order (score desc, index asc), so the result does not depend on
+// how items are split over lanes and blocks).  The oracle restates exactly this.
 #include "nrx_common.h"
 #include <float.h>
 #include <limits.h>
-#include <stdlib.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
 constexpr int KMAX = 32;
-constexpr int QCAP = 8;          // per-lane candidate queue depth (LDS)
+constexpr int FLUSH_AT = 6;       // merge the queues once some lane holds more than this many candidates
+constexpr int QCAP = FLUSH_AT + 16;   // one tile can add 16 per lane before the next check
+constexpr int WAVES = NRX_BLOCK / 64;
 
 __device__ __forceinline__ int64_t lower_bound(const int64_t* lst, int64_t lo, int64_t hi, int64_t v) {
     while (lo < hi) {
@@ -30,15 +40,14 @@ __device__ __forceinline__ int64_t lower_bound(const int64_t* lst, int64_t lo, i
     return lo;
 }
 
-// insert (score, idx) into a descending list of length K kept in registers (static indexing only)
+// insert into a list sorted by (score desc, index asc), kept in registers (static indexing only)
 template <int K, typename I>
 __device__ __forceinline__ void topk_insert(float (&s)[K], I (&ix)[K], float score, I idx) {
-    // ties: an equal score that arrives later (higher index) goes AFTER the existing one
     float cs = score;
     I ci = idx;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        const bool take = cs > s[j];
+        const bool take = cs > s[j] || (cs == s[j] && ci < ix[j]);
         const float ts = s[j];
         const I ti = ix[j];
         s[j] = take ? cs : ts;
@@ -48,31 +57,41 @@ __device__ __forceinline__ void topk_insert(float (&s)[K], I (&ix)[K], float sco
     }
 }
 
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-
-// One thread = one query; the item row is the same for every lane of the wave, so it is fetched with
-// SCALAR loads (constant address space -> s_load_dwordx8/x16 through the scalar cache) and consumed
-// straight from SGPRs by packed fp32 FMAs: v_pk_fma_f32 does the even and the odd dimension of one
-// (query, item) pair per lane per issue.  UNROLL items are in flight for ILP.  No LDS, no barriers.
-template <int K, int D2, int UNROLL>
-__global__ __launch_bounds__(NRX_BLOCK) void topk_partial_kernel(const float* __restrict__ items, int64_t n_items, const float* __restrict__ queries,
-                                                                 int64_t n_queries, int k, const int64_t* __restrict__ excl_off,
-                                                                 const int64_t* __restrict__ excl_items, int64_t items_per_split,
-                                                                 float* __restrict__ p_score, int* __restrict__ p_idx) {
-    const int64_t qi = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x;
+// H4 = float4 loads per lane per item row (= padded_dim / 8).
+// Measured on gfx950 (tools/mfma_peak_probe.hip -> profiles/r01_mfma_f32_valu_overlap_probe.txt): the fp32 MFMA
+// reaches 155 TF even as one dependent chain, but VALU instructions do NOT overlap with it -- from the same
+// wave or from others, every VALU instruction costs its 4 cycles of matrix time.  So the loop is written
+// for the fewest VALU instructions per MFMA: a v_max3 tree (8 per 8 MFMAs) decides whether a tile has any
+// candidate, its inner nodes are reused to find which registers do, the queue address doubles as the
+// counter, and the two A-fragment register sets ping-pong without copies.
+template <int K, int H4, bool PAD, int MINB>
+__global__ __launch_bounds__(NRX_BLOCK, MINB) void topk_mfma_kernel(const float* __restrict__ items, int64_t n_items, int dim,
+                                                              const float* __restrict__ queries, int64_t n_queries,
+                                                              const int64_t* __restrict__ excl_off, const int64_t* __restrict__ excl_items,
+                                                              int64_t items_per_split, float* __restrict__ p_score, int* __restrict__ p_idx, float kth0) {
+    constexpr int H = 4 * H4;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int64_t qi = ((int64_t)blockIdx.x * WAVES + wid) * 32 + l31;
     const bool live = qi < n_queries;
     const int64_t qc = live ? qi : n_queries - 1;
-    f32x2 q[D2];
+    const int e_base = hi * H;                      // first element of this lane's half of the (padded) row
+
+    float qf[H];
 #pragma unroll
-    for (int j = 0; j < D2; ++j) q[j] = reinterpret_cast<const f32x2*>(queries + qc * (int64_t)(2 * D2))[j];
+    for (int v = 0; v < H4; ++v) {
+        const bool ok = live && e_base + 4 * v < dim;
+        const float4 t = nrx_ldg4(queries + qc * dim + (ok ? e_base + 4 * v : 0), 0);
+        qf[4 * v + 0] = ok ? t.x : 0.f; qf[4 * v + 1] = ok ? t.y : 0.f;
+        qf[4 * v + 2] = ok ? t.z : 0.f; qf[4 * v + 3] = ok ? t.w : 0.f;
+    }
     float bs[K];
     int bi[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) { bs[j] = -FLT_MAX; bi[j] = -1; }
-    const int64_t begin = (int64_t)blockIdx.y * items_per_split;
-    const int64_t end = begin + items_per_split < n_items ? begin + items_per_split : n_items;
-    // exclusion list (ascending) walked in step with the ascending item scan: next_ex = first excluded
-    // position >= the last candidate looked at; advanced lazily, only when a candidate is examined
+
+    const int begin = (int)((int64_t)blockIdx.y * items_per_split);
+    const int end = (int)(begin + items_per_split < n_items ? begin + items_per_split : n_items);
     int64_t ep = excl_off ? excl_off[qc] : 0;
     const int64_t e1 = excl_off ? excl_off[qc + 1] : 0;
     ep = lower_bound(excl_items, ep, e1, begin);
@@ -81,106 +100,154 @@ __global__ __launch_bounds__(NRX_BLOCK) void topk_partial_kernel(const float* __
         while (next_ex < it) { ++ep; next_ex = ep < e1 ? (int)excl_items[ep] : INT_MAX; }
         return next_ex == it;
     };
-    const f32x2 NRX_CONST* itc = (const f32x2 NRX_CONST*)(items);
-    // Candidates that beat the (possibly stale) k-th score are appended to a small per-lane queue in LDS
-    // and merged into the sorted register list only when some lane's queue could overflow: a wave takes
-    // the ~100-instruction insertion path once per ~QCAP hits of its busiest lane instead of on every
-    // hit of ANY of its 64 lanes.  Appending in item order + strict '>' insertion keeps the result
-    // identical to immediate insertion (ties toward the lower index).
+
+    // per-lane candidate queue in LDS: slot c of this lane lives at q_s[c][tid]; `qpos` (a byte address
+    // relative to q_s) is the next free slot, so it is also the count
     __shared__ float q_s[QCAP][NRX_BLOCK];
     __shared__ int q_i[QCAP][NRX_BLOCK];
-    int cnt = 0;
-    float kth = -FLT_MAX;
+    constexpr int SLOT = NRX_BLOCK * 4;
+    const int qbase = threadIdx.x * 4;
+    int qpos = qbase;
+    const int qflush = qbase + FLUSH_AT * SLOT;
+    char* const q_s_b = reinterpret_cast<char*>(&q_s[0][0]);
+    char* const q_i_b = reinterpret_cast<char*>(&q_i[0][0]);
+    float kth = kth0;
+    // queue entries are in ascending item order, so the exclusion walk happens here, once per candidate;
+    // inside one lane a later entry has the higher index, so strict '>' keeps ties in index order
     auto flush = [&]() {
 #pragma unroll 1
-        for (int c = 0; c < QCAP; ++c) {
-            if (c < cnt) {
-                const float cs = q_s[c][threadIdx.x];
-                if (cs > bs[K - 1]) topk_insert<K, int>(bs, bi, cs, q_i[c][threadIdx.x]);
-            }
-        }
-        cnt = 0;
-        kth = bs[K - 1];
-    };
-    int64_t i = begin;
-    for (; i + UNROLL <= end; i += UNROLL) {
-        const f32x2 NRX_CONST* row = itc + i * D2;
-        f32x2 acc[UNROLL];
+        for (int c = qbase; __builtin_amdgcn_ballot_w64(c < qpos) != 0; c += SLOT) {
+            if (c < qpos) {
+                const float cs = *reinterpret_cast<const float*>(q_s_b + c);
+                const int it = *reinterpret_cast<const int*>(q_i_b + c);
+                if (cs > bs[K - 1] && it < end && !is_excluded(it)) {
+                    float ns = cs;
+                    int ni = it;
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) acc[u] = (f32x2){0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < D2; ++j)
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) acc[u] = __builtin_elementwise_fma(q[j], row[u * D2 + j], acc[u]);
-        float sc[UNROLL];
-        bool any = false;
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) { sc[u] = acc[u].x + acc[u].y; any |= sc[u] > kth; }
-        if (__builtin_amdgcn_ballot_w64(any) != 0) {      // wave-uniform branch
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int64_t it = i + u;
-                if (sc[u] > kth && !is_excluded((int)it)) {
-                    q_s[cnt][threadIdx.x] = sc[u];
-                    q_i[cnt][threadIdx.x] = (int)it;
-                    ++cnt;
+                    for (int j = 0; j < K; ++j) {
+                        const bool take = ns > bs[j];
+                        const float ts = bs[j];
+                        const int ti = bi[j];
+                        bs[j] = take ? ns : ts;
+                        bi[j] = take ? ni : ti;
+                        ns = take ? ts : ns;
+                        ni = take ? ti : ni;
+                    }
                 }
             }
-            if (__builtin_amdgcn_ballot_w64(cnt > QCAP - UNROLL) != 0) flush();
         }
-    }
-    for (; i < end; ++i) {
-        const f32x2 NRX_CONST* row = itc + i * D2;
-        f32x2 acc = (f32x2){0.f, 0.f};
+        qpos = qbase;
+        kth = bs[K - 1];
+    };
+
+    // A fragment of one tile: lane (l31, hi) holds elements [hi*H, hi*H + H) of item row (i0 + l31).
+    // Rows past the end are clamped to the last row (their scores are dropped at flush by `it < end`);
+    // only a padded dimension (dim % 8 != 0) needs zero selects.
+    const float* const ibase = items + e_base;
+    const int last_row = (int)n_items - 1;
+    auto load_tile = [&](float (&a)[H], int i0) {
+        const int r = min(i0 + l31, last_row);
+        const float* rp = ibase + (int64_t)r * dim;
 #pragma unroll
-        for (int j = 0; j < D2; ++j) acc = __builtin_elementwise_fma(q[j], row[j], acc);
-        const float a0 = acc.x + acc.y;
-        if (a0 > kth && !is_excluded((int)i)) {
-            q_s[cnt][threadIdx.x] = a0;
-            q_i[cnt][threadIdx.x] = (int)i;
-            ++cnt;
+        for (int v = 0; v < H4; ++v) {
+            const bool ok = !PAD || e_base + 4 * v < dim;
+            const float4 t = nrx_ldg4(rp + (ok ? 4 * v : -e_base), 0);
+            a[4 * v + 0] = ok ? t.x : 0.f; a[4 * v + 1] = ok ? t.y : 0.f;
+            a[4 * v + 2] = ok ? t.z : 0.f; a[4 * v + 3] = ok ? t.w : 0.f;
         }
-        if (__builtin_amdgcn_ballot_w64(cnt > QCAP - UNROLL) != 0) flush();
+    };
+
+    auto push = [&](float sc, int it) {
+        if (sc > kth) {
+            *reinterpret_cast<float*>(q_s_b + qpos) = sc;
+            *reinterpret_cast<int*>(q_i_b + qpos) = it;
+            qpos += SLOT;
+        }
+    };
+
+    auto step = [&](const float (&a)[H], int i0) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < H; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], qf[s], acc, 0, 0, 0);
+        // v_max3 tree; the first-level nodes are reused below
+        const float n0 = fmaxf(fmaxf(acc[0], acc[1]), acc[2]), n1 = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
+        const float n2 = fmaxf(fmaxf(acc[6], acc[7]), acc[8]), n3 = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
+        const float n4 = fmaxf(fmaxf(acc[12], acc[13]), acc[14]);
+        const float m = fmaxf(fmaxf(fmaxf(n0, n1), n2), fmaxf(fmaxf(n3, n4), acc[15]));
+        if (__builtin_amdgcn_ballot_w64(m > kth) != 0) {           // wave-uniform
+            const int ib = i0 + 4 * hi;                            // item of register r: ib + (r & 3) + 8 * (r >> 2)
+#define NRX_ROW(r_) (ib + ((r_) & 3) + 8 * ((r_) >> 2))
+            if (n0 > kth) { push(acc[0], NRX_ROW(0)); push(acc[1], NRX_ROW(1)); push(acc[2], NRX_ROW(2)); }
+            if (n1 > kth) { push(acc[3], NRX_ROW(3)); push(acc[4], NRX_ROW(4)); push(acc[5], NRX_ROW(5)); }
+            if (n2 > kth) { push(acc[6], NRX_ROW(6)); push(acc[7], NRX_ROW(7)); push(acc[8], NRX_ROW(8)); }
+            if (n3 > kth) { push(acc[9], NRX_ROW(9)); push(acc[10], NRX_ROW(10)); push(acc[11], NRX_ROW(11)); }
+            if (n4 > kth) { push(acc[12], NRX_ROW(12)); push(acc[13], NRX_ROW(13)); push(acc[14], NRX_ROW(14)); }
+            push(acc[15], NRX_ROW(15));
+#undef NRX_ROW
+            if (__builtin_amdgcn_ballot_w64(qpos > qflush) != 0) flush();
+        }
+    };
+
+    // two A-fragment register sets ping-pong: the loads of tile t+1 are in flight during tile t's MFMAs.
+    // (Software-pipelining the selection of tile t-1 under tile t's chain was tried: slower, 4.6 vs 4.2 ms.)
+    if (begin < end) {
+        float fa[H], fb[H];
+        load_tile(fa, begin);
+        for (int i0 = begin; i0 < end; i0 += 64) {
+            load_tile(fb, i0 + 32);
+            step(fa, i0);
+            load_tile(fa, i0 + 64);
+            if (i0 + 32 < end) step(fb, i0 + 32);
+        }
     }
     flush();
     if (live) {
-        float* ps = p_score + (qi * gridDim.y + blockIdx.y) * (int64_t)K;
-        int* pi = p_idx + (qi * gridDim.y + blockIdx.y) * (int64_t)K;
+        const int64_t slot = (qi * gridDim.y + blockIdx.y) * 2 + hi;
+        float* ps = p_score + slot * K;
+        int* pi = p_idx + slot * K;
 #pragma unroll
         for (int j = 0; j < K; ++j) { ps[j] = bs[j]; pi[j] = bi[j]; }
     }
 }
 
-// merge the per-split lists of one query (each sorted descending; splits cover ascending item ranges)
+// merge the partial lists of one query (each sorted by (score desc, index asc))
 template <int K>
 __global__ __launch_bounds__(NRX_BLOCK) void topk_merge_kernel(const float* __restrict__ p_score, const int* __restrict__ p_idx,
-                                                               int64_t n_queries, int n_split, int k,
+                                                               int64_t n_queries, int n_lists, int k,
                                                                int64_t* __restrict__ out_idx, float* __restrict__ out_score) {
     const int64_t qi = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x;
     if (qi >= n_queries) return;
     float bs[K];
-    int64_t bi[K];
+    int bi[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) { bs[j] = -FLT_MAX; bi[j] = -1; }
-    for (int s = 0; s < n_split; ++s) {
-        const float* ps = p_score + (qi * n_split + s) * (int64_t)K;
-        const int* pi = p_idx + (qi * n_split + s) * (int64_t)K;
+    for (int s = 0; s < n_lists; ++s) {
+        const float* ps = p_score + (qi * n_lists + s) * (int64_t)K;
+        const int* pi = p_idx + (qi * n_lists + s) * (int64_t)K;
         for (int j = 0; j < K; ++j) {
-            if (pi[j] < 0 || !(ps[j] > bs[K - 1])) break;      // lists are sorted: nothing further can enter
-            topk_insert<K, int64_t>(bs, bi, ps[j], (int64_t)pi[j]);
+            const float cs = ps[j];
+            const int ci = pi[j];
+            if (ci < 0 || !(cs > bs[K - 1] || (cs == bs[K - 1] && ci < bi[K - 1]))) break;   // sorted: nothing further can enter
+            topk_insert<K, int>(bs, bi, cs, ci);
         }
     }
     for (int j = 0; j < k; ++j) {
-        out_idx[qi * k + j] = j < K ? bi[j] : -1;
-        out_score[qi * k + j] = j < K ? bs[j] : -FLT_MAX;
+        out_idx[qi * k + j] = (int64_t)bi[j];
+        out_score[qi * k + j] = bs[j];
     }
 }
 
+// list length instantiated for a requested k (10 is what the reference's hit_rate asks for)
+int pick_k(int k) { return k <= 4 ? 4 : (k <= 10 ? 10 : (k <= 16 ? 16 : KMAX)); }
+
 int choose_splits(int64_t n_items, int64_t n_queries) {
-    const int64_t qblocks = n_queries > 0 ? (n_queries + NRX_BLOCK - 1) / NRX_BLOCK : 1;
+    const int64_t qblocks = n_queries > 0 ? (n_queries + 32 * WAVES - 1) / (32 * WAVES) : 1;
     const char* env = getenv("NRX_TOPK_BLOCKS");
-    const int64_t target = env ? atoll(env) : 2048;
-    int64_t s = (target + qblocks - 1) / qblocks;            // aim at >= 2048 blocks (8 per CU)
+    const int64_t target = env ? atoll(env) : 512;
+    int64_t s = (target + qblocks - 1) / qblocks;             // aim at >= 512 blocks (2 waves per SIMD: MFMA-bound,
+                                                              // and every extra split repeats the top-k warm-up)
     const int64_t max_s = (n_items + 4095) / 4096;          // keep >= 4096 items per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -192,8 +259,8 @@ int choose_splits(int64_t n_items, int64_t n_queries) {
 
 extern "C" int64_t nrx_topk_workspace(int64_t n_items, int64_t n_queries, int32_t k) {
     if (n_items < 0 || n_queries < 0 || k < 1) return -1;
-    const int K = k <= 8 ? 8 : (k <= 16 ? 16 : KMAX);
-    return (int64_t)choose_splits(n_items, n_queries) * n_queries * K * (int64_t)(sizeof(float) + sizeof(int)) + 256;
+    const int K = pick_k(k);
+    return 2 * (int64_t)choose_splits(n_items, n_queries) * n_queries * K * (int64_t)(sizeof(float) + sizeof(int)) + 256;
 }
 
 extern "C" int nrx_topk_ip(const float* items, int64_t n_items, int32_t dim, const float* queries, int64_t n_queries,
@@ -207,30 +274,35 @@ extern "C" int nrx_topk_ip(const float* items, int64_t n_items, int32_t dim, con
     if (n_queries == 0) return NRX_OK;
     NRX_REQUIRE(queries && out_idx && out_score && workspace && (n_items == 0 || items), "nrx_topk_ip: null buffer");
     NRX_REQUIRE(nrx_aligned16(items) && nrx_aligned16(queries), "nrx_topk_ip: items / queries must be 16-byte aligned");
-    NRX_REQUIRE((excl_offsets == nullptr) == (excl_items == nullptr) || excl_offsets != nullptr, "nrx_topk_ip: exclusion lists need offsets");
-    const int K = k <= 8 ? 8 : (k <= 16 ? 16 : KMAX);
+    NRX_REQUIRE(excl_offsets == nullptr || excl_items != nullptr, "nrx_topk_ip: exclusion offsets without items");
+    const int K = pick_k(k);
     const int S = choose_splits(n_items, n_queries);
-    const int64_t per_split = ((n_items + S - 1) / S + 3) & ~3ll;
-    const int D2 = dim / 2;
+    const int64_t per_split = ((n_items + S - 1) / S + 63) & ~63ll;
+    const bool pad = (dim & 7) != 0;
+    const int H4 = dim <= 8 ? 1 : (dim <= 16 ? 2 : (dim <= 32 ? 4 : (dim <= 64 ? 8 : 16)));
     char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     int* p_idx = reinterpret_cast<int*>(ws);
-    float* p_score = reinterpret_cast<float*>(ws + (size_t)S * n_queries * K * sizeof(int));
+    float* p_score = reinterpret_cast<float*>(ws + (size_t)2 * S * n_queries * K * sizeof(int));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid((unsigned)((n_queries + NRX_BLOCK - 1) / NRX_BLOCK), (unsigned)S);
-#define NRX_TK(K_, D2_, U_) hipLaunchKernelGGL((topk_partial_kernel<K_, D2_, U_>), grid, dim3(NRX_BLOCK), 0, st, items, n_items, queries, \
-                                               n_queries, k, excl_offsets, excl_items, per_split, p_score, p_idx)
-#define NRX_TK_D(K_)                                                                                            \
-    switch (D2) {                                                                                               \
-        case 2: NRX_TK(K_, 2, 4); break; case 4: NRX_TK(K_, 4, 4); break; case 6: NRX_TK(K_, 6, 4); break;      \
-        case 8: NRX_TK(K_, 8, 4); break; case 16: NRX_TK(K_, 16, 2); break; case 32: NRX_TK(K_, 32, 1); break;  \
-        case 64: NRX_TK(K_, 64, 1); break;                                                                      \
-        default: nrx_set_error("nrx_topk_ip: dim %d not instantiated (4,8,12,16,32,64,128)", dim); return NRX_ERR_UNSUPPORTED; \
+    dim3 grid((unsigned)((n_queries + 32 * WAVES - 1) / (32 * WAVES)), (unsigned)S);
+    const float kth0 = getenv("NRX_TOPK_NOSEL") ? FLT_MAX : -FLT_MAX;      // dev knob: MFMA-only timing
+#define NRX_TK2(K_, H4_, PAD_) hipLaunchKernelGGL((topk_mfma_kernel<K_, H4_, PAD_, 2>), grid, dim3(NRX_BLOCK), 0, st, items, n_items, (int)dim, \
+                                                  queries, n_queries, excl_offsets, excl_items, per_split, p_score, p_idx, kth0)
+#define NRX_TK(K_, H4_) if (pad) NRX_TK2(K_, H4_, true); else NRX_TK2(K_, H4_, false)
+#define NRX_TK_D(K_)                                                                \
+    switch (H4) {                                                                   \
+        case 1: NRX_TK(K_, 1); break; case 2: NRX_TK(K_, 2); break;                 \
+        case 4: NRX_TK(K_, 4); break; case 8: NRX_TK(K_, 8); break;                 \
+        default: NRX_TK(K_, 16); break;                                             \
     }
-    if (K == 8) { NRX_TK_D(8) } else if (K == 16) { NRX_TK_D(16) } else { NRX_TK_D(32) }
     const unsigned mg = (unsigned)((n_queries + NRX_BLOCK - 1) / NRX_BLOCK);
-    if (K == 8) hipLaunchKernelGGL(topk_merge_kernel<8>, dim3(mg), dim3(NRX_BLOCK), 0, st, p_score, p_idx, n_queries, S, k, out_idx, out_score);
-    else if (K == 16) hipLaunchKernelGGL(topk_merge_kernel<16>, dim3(mg), dim3(NRX_BLOCK), 0, st, p_score, p_idx, n_queries, S, k, out_idx, out_score);
-    else hipLaunchKernelGGL(topk_merge_kernel<32>, dim3(mg), dim3(NRX_BLOCK), 0, st, p_score, p_idx, n_queries, S, k, out_idx, out_score);
+#define NRX_MERGE(K_) hipLaunchKernelGGL(topk_merge_kernel<K_>, dim3(mg), dim3(NRX_BLOCK), 0, st, p_score, p_idx, n_queries, 2 * S, k, out_idx, out_score)
+    switch (K) {
+        case 4: NRX_TK_D(4) NRX_MERGE(4); break;
+        case 10: NRX_TK_D(10) NRX_MERGE(10); break;
+        case 16: NRX_TK_D(16) NRX_MERGE(16); break;
+        default: NRX_TK_D(32) NRX_MERGE(32); break;
+    }
     NRX_LAUNCH_CHECK("nrx_topk_ip");
     return NRX_OK;
 }

@@ -108,8 +108,8 @@ void oracle_dcn_v1(const float* x, int64_t x_ld, int64_t B, int32_t dim, int32_t
  * (faiss-cpu, unpinned in the reference's requirements; absent from this image) documents IndexFlatIP as
  * exhaustive search by inner product with results sorted by decreasing score, label -1 / score -FLT_MAX
  * where fewer than k vectors exist; its tie order and fp32 summation order are unspecified.  This
- * restatement fixes both: score = fl(e + o) with e / o the fp32 fma chains over the even / odd dimensions
- * (ascending), ties toward the lower index.  excl (optional CSR, lists ascending): items a query must not return -- the reference's
+ * restatement fixes both: score = the fp32 fma chain in the kernel's matrix-core order (below), ties toward
+ * the lower index.  excl (optional CSR, lists ascending): items a query must not return -- the reference's
  * "search k + len(history), drop history, keep k" (model.py:209-221) yields the same list.          */
 void oracle_topk_ip(const float* items, int64_t n_items, int32_t dim, const float* queries, int64_t n_queries,
                     int32_t k, const int64_t* excl_off, const int64_t* excl_items, int64_t* out_idx, float* out_score) {
@@ -125,14 +125,39 @@ void oracle_topk_ip(const float* items, int64_t n_items, int32_t dim, const floa
             while (ep < e1 && excl_items[ep] < i) ++ep;
             if (ep < e1 && excl_items[ep] == i) continue;
             const float* v = items + i * dim;
-            float ev = 0.f, od = 0.f;       /* the kernel's packed-fma order: even / odd chains, then one add */
-            for (int d = 0; d + 1 < dim; d += 2) { ev = fmaf(qv[d], v[d], ev); od = fmaf(qv[d + 1], v[d + 1], od); }
-            if (dim & 1) ev = fmaf(qv[dim - 1], v[dim - 1], ev);
-            const float a = ev + od;
+            /* the kernel's matrix-core order: P = dim padded to a multiple of 8, H = P/2; per step j the
+             * MFMA fuses element j then element H+j (pads are zeros) */
+            const int H = ((dim + 7) / 8) * 4;
+            float a = 0.f;
+            for (int j = 0; j < H; ++j) {
+                a = fmaf(j < dim ? v[j] : 0.f, j < dim ? qv[j] : 0.f, a);
+                a = fmaf(H + j < dim ? v[H + j] : 0.f, H + j < dim ? qv[H + j] : 0.f, a);
+            }
             if (!(a > os[k - 1])) continue;
             int j = k - 1;
             while (j > 0 && a > os[j - 1]) { os[j] = os[j - 1]; oi[j] = oi[j - 1]; --j; }
             os[j] = a; oi[j] = i;
+        }
+    }
+}
+
+/* One DCN-v2 cross layer, out = act(x0 * (x_l W^T + b) + x_l)  (DCNv2Layer.forward + ReLU,
+ * src/model/sort/dcn/dcn_arch.py:39-50,78-81) in the exact fp32 order of the matrix-core kernel: the dot
+ * product is one fused-multiply-add chain over k ascending (v_mfma_f32_32x32x2_f32 is bit-for-bit
+ * fma(a1,b1, fma(a0,b0,c)): profiles/r01_mfma_f32_semantics.txt), then fma(x0, lin + b, x_l).  The numpy
+ * restatement (ref_np.dcn_v2, BLAS order) stays the tolerance reference; this one pins the kernel bitwise. */
+void oracle_dcn_v2_layer(const float* x0, const float* xl, int64_t ld, int64_t B, int32_t D, const float* W,
+                         const float* bias, int32_t relu, float* out, int64_t out_ld) {
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; ++b) {
+        const float* xr = xl + b * ld;
+        for (int n = 0; n < D; ++n) {
+            const float* wr = W + (int64_t)n * D;
+            float acc = 0.f;
+            for (int k = 0; k < D; ++k) acc = fmaf(xr[k], wr[k], acc);
+            float v = fmaf(x0[b * ld + n], acc + bias[n], xr[n]);
+            if (relu && !(v > 0.f)) v = 0.f;
+            out[b * out_ld + n] = v;
         }
     }
 }

@@ -30,6 +30,8 @@ def load():
         _lib.oracle_dcn_v1.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int64]
         _lib.oracle_threads.restype = C.c_int
+        _lib.oracle_dcn_v2_layer.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                             C.c_int32, C.c_void_p, C.c_int64]
         _lib.oracle_topk_ip.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p]
     return _lib
@@ -119,3 +121,19 @@ def topk_ip(items, queries, k, exclude=None):
                        eo.ctypes.data if eo is not None else None, ei.ctypes.data if ei is not None else None,
                        idx.ctypes.data, score.ctypes.data)
     return idx, score
+
+
+def dcn_v2(x, W, b, relu=True):
+    """All layers of DCNv2Net through oracle_dcn_v2_layer (the kernel's exact fp32 order).  x [B, D], W [n, D, D], b [n, D]."""
+    lib = load()
+    x0 = np.ascontiguousarray(x, np.float32)
+    W = np.ascontiguousarray(W, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    B, D = x0.shape
+    xl = x0
+    for l in range(W.shape[0]):
+        out = np.empty_like(x0)
+        lib.oracle_dcn_v2_layer(x0.ctypes.data, xl.ctypes.data, D, B, D, W[l].ctypes.data, b[l].ctypes.data, int(relu),
+                                out.ctypes.data, D)
+        xl = out
+    return xl

@@ -598,7 +598,7 @@ def topk_ip(items: np.ndarray, queries: np.ndarray, k: int, exclude=None):
     decreasing order, (-1, -FLT_MAX) where fewer than k items qualify.  faiss is absent from the
     reference tree and this image (parity with faiss itself is UNPINNED; anchored on the call sites):
     its tie order / summation order are unspecified, this restatement takes ties toward the lower index
-    and accumulates in float64 (the C oracle and the HIP kernel use an fp32 fma chain; they agree with this
+    and accumulates in float64 (the C oracle and the HIP kernel use the same fp32 fma chain; they agree with this
     to ~1e-6 and exactly on the order wherever scores are separated by more than that).
     exclude: optional list (per query) of item positions that must not be returned = the reference's
     over-fetch-and-filter of the user's history (recall/DSSM/model.py:209-221)."""

@@ -445,6 +445,11 @@ def test_dcn_v2_vs_oracle(B, D, NL):
     out_nr = ops.dcn_v2(dev(x), dev(W[:1]), dev(b[:1]), relu=False)
     lin = x.astype(np.float64) @ W[0].astype(np.float64).T + b[0]
     np.testing.assert_allclose(out_nr.detach().cpu().numpy(), x * lin + x, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(lin).max()))
+    # the matrix-core kernel is a pinned fp32 order (k-ascending fma chain, then fma(x0, lin + b, x_l)):
+    # value-for-value equal to the C oracle that restates that order, for every layer count and odd D
+    from oracle import ref_c
+    assert np.array_equal(out.detach().cpu().numpy(), ref_c.dcn_v2(x, W, b))
+    assert np.array_equal(out_nr.detach().cpu().numpy(), ref_c.dcn_v2(x, W[:1], b[:1], relu=False))
 
 
 # ----------------------------------------------------------------------------- integer utilities (bit-exact)
