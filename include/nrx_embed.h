@@ -113,11 +113,29 @@ NRX_API int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_t b
  *   g_out[b, cols of the feature] * (1 | w/(sum w + 1e-8) | 1/L | w)
  * into values[u, :dim] -- no atomics, bit-reproducible.  uniq_keys (optional, device int64
  * [n_unique]): the sort key of each unique entry; entries whose low 40 bits (the row id) are 0 -- the
- * padding row, which never trains -- get zeros.  order / seg_start: device int64; values [n_unique, dim]. */
+ * padding row, which never trains -- get zeros.  order / seg_start: device int64; values [n_unique, dim].
+ * n_unique_dev (optional, device int64[1]): the actual number of unique entries when the host does not
+ * know it yet (nrx_sparse_plan's counts[0]); n_unique is then an upper bound that sizes the launch. */
 NRX_API int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
                          const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
                          const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
-                         int64_t n_unique, float* values, void* stream);
+                         int64_t n_unique, const int64_t* n_unique_dev, float* values, void* stream);
+
+/* Whole planning step of the row-sparse backward in one call (replaces nrx_make_table_keys + an external
+ * 64-bit sort + unique + scan): for the flat, feature-major lookup list of n_feats features (ids[f]: lens[f]
+ * ids of width index_bits reading table table_of[f] with rows[f] rows; HOST arrays of device pointers /
+ * sizes) it leaves on the device
+ *   order     [n]      flat lookup index of the e-th entry in (table, row)-sorted, stable order
+ *   uniq_keys [<= n]   (table << 40) | row of every distinct (table, row), ascending
+ *   seg_start [<= n+1] unique entry u owns sorted entries seg_start[u] .. seg_start[u+1)
+ *   counts    [n_tables + 2]   counts[0] = n_unique; table t owns unique entries counts[1+t] .. counts[2+t)
+ * -- exactly the inputs of nrx_embed_bwd_sorted.  Ids < 0 or >= rows[f] fall on row 0 (the padding row, which
+ * never trains).  Keys are sorted on table_bits + row_bits bits only (32-bit keys when they fit).  All
+ * outputs device int64; workspace >= nrx_sparse_plan_workspace(n) device bytes; n < 2^32 - 1.          */
+NRX_API int64_t nrx_sparse_plan_workspace(int64_t n_lookups);
+NRX_API int nrx_sparse_plan(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
+                    int32_t n_feats, int32_t index_bits, int32_t n_tables, int64_t* order, int64_t* uniq_keys,
+                    int64_t* seg_start, int64_t* counts, void* workspace, void* stream);
 
 /* Composite sort keys for nrx_embed_bwd_sorted over SEVERAL tables at once: for the flat,
  * feature-major lookup list of n_feats features (ids[f]: lens[f] elements; HOST pointer arrays),

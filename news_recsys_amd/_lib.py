@@ -59,7 +59,7 @@ SIGNATURES = {
     "nrx_device_info": (C.c_int, [C.c_int, C.POINTER(_i64)]),
     "nrx_embed_fwd": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p]),
     "nrx_embed_bwd": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, _p]),
-    "nrx_embed_bwd_sorted": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _i32, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _p]),
+    "nrx_embed_bwd_sorted": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _i32, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _p, _p]),
     "nrx_make_table_keys": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), C.POINTER(_i32), _i32, _i32, _p, _p]),
     "nrx_bag_pool_fwd": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     "nrx_bag_pool_bwd": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
@@ -80,6 +80,8 @@ SIGNATURES = {
     "nrx_csr_to_padded": (C.c_int, [_p, _i32, _p, _i64, _i32, _p, _p, _p]),
     "nrx_user_rank_metrics": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "nrx_mask_lengths": (C.c_int, [_p, _i64, _i32, _p, _p]),
+    "nrx_sparse_plan_workspace": (_i64, [_i64]),
+    "nrx_sparse_plan": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     "nrx_topk_workspace": (_i64, [_i64, _i64, _i32]),
     "nrx_topk_ip": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
 }

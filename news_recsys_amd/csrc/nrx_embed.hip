@@ -470,6 +470,7 @@ struct SortedBwdArgs {
     const int64_t* seg_start;
     const int64_t* uniq_keys;   // optional: (table << 40 | row) of each unique entry; row 0 -> zero grad
     int64_t n_unique;
+    const int64_t* n_unique_dev;   // optional: actual count on the device (n_unique is then an upper bound)
     float* values;
     int32_t n;
     int32_t dim;
@@ -484,6 +485,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_kernel(const Sorte
     const int q = threadIdx.x & (Q - 1);
     const int64_t u = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
     if (u >= a->n_unique) return;
+    if (a->n_unique_dev != nullptr && u >= nrx_gconst<int64_t>(a->n_unique_dev)[0]) return;
     const int D = a->dim;
     const int64_t lo = nrx_gconst<int64_t>(a->seg_start)[u];
     int64_t hi = nrx_gconst<int64_t>(a->seg_start)[u + 1];
@@ -765,7 +767,7 @@ extern "C" int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_
 extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
                                     const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
                                     const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
-                                    int64_t n_unique, float* values, void* stream) {
+                                    int64_t n_unique, const int64_t* n_unique_dev, float* values, void* stream) {
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_bwd_sorted: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0 && dim >= 1 && n_unique >= 0, "nrx_embed_bwd_sorted: bad argument");
@@ -806,6 +808,7 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     a.seg_start = seg_start;
     a.uniq_keys = uniq_keys;
     a.n_unique = n_unique;
+    a.n_unique_dev = n_unique_dev;
     a.values = values;
     a.n = n_feats;
     a.dim = dim;

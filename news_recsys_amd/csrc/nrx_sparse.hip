@@ -1,0 +1,201 @@
+// Planning step of the deterministic row-sparse embedding backward: group all lookups of a launch by
+// (table, row).  Reference behaviour being replaced: autograd of nn.Embedding over every lookup feature
+// (src/model/BaseModel/base_model.py:262-308), here producing nn.Embedding(sparse=True)-style COO grads.
+//
+// keys = (table << row_bits) | row are built COMPACT -- only table_bits + row_bits significant bits, 32-bit
+// when they fit (C2: 5 + 20 bits) -- and sorted with rocPRIM's radix sort limited to those bits (4 digit
+// passes instead of the 8 that a generic 64-bit sort pays), payload = the 32-bit flat lookup index; the sort
+// is stable, so the lookups of one row stay in (feature, sample) order and the segmented reduction that
+// follows (nrx_embed_bwd_sorted) is bit-reproducible.  Head flags + one scan give the unique (table,row)
+// list, the segment starts, the number of unique rows and the per-table split, all left on the device:
+// the host reads n_tables + 2 integers once.  rocPRIM (radix sort, scan) is the vendor primitive library;
+// key construction / head detection / finalisation are the kernels below.
+#include "nrx_common.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace {
+
+struct PlanArgs {
+    const void* ids[NRX_MAX_FEATURES];
+    int64_t off[NRX_MAX_FEATURES + 1];
+    int64_t rows[NRX_MAX_FEATURES];
+    int32_t table_of[NRX_MAX_FEATURES];
+    int32_t n_feats;
+    int32_t idx64;
+    int32_t row_bits;
+    int64_t n_total;
+};
+static_assert(sizeof(PlanArgs) <= 3584, "kernarg budget");
+
+template <typename KeyT>
+__global__ __launch_bounds__(NRX_BLOCK) void plan_keys_kernel(const PlanArgs args_in_kernarg, KeyT* __restrict__ keys, uint32_t* __restrict__ payload) {
+    const NRX_CONST PlanArgs* a = nrx_kernarg<PlanArgs>();
+    for (int64_t p = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x; p < a->n_total; p += (int64_t)gridDim.x * NRX_BLOCK) {
+        int lo = 0, hi = a->n_feats;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a->off[mid] <= p) lo = mid; else hi = mid;
+        }
+        const int64_t i = p - a->off[lo];
+        int64_t id = a->idx64 ? nrx_gconst<int64_t>(a->ids[lo])[i] : (int64_t)nrx_gconst<int32_t>(a->ids[lo])[i];
+        if (id < 0 || id >= a->rows[lo]) id = 0;           // out-of-range ids were reported by the forward; the
+        keys[p] = ((KeyT)a->table_of[lo] << a->row_bits) | (KeyT)id;     // padding row never trains
+        payload[p] = (uint32_t)p;
+    }
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(NRX_BLOCK) void plan_heads_kernel(const KeyT* __restrict__ skeys, int64_t n, uint32_t* __restrict__ flags) {
+    const int64_t e = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x;
+    if (e < n) flags[e] = (e == 0 || skeys[e] != skeys[e - 1]) ? 1u : 0u;
+}
+
+// uidx = exclusive scan of the head flags.  Writes order (int64 view of the payload), and for every head the
+// unique key in the (table << 40 | row) form nrx_embed_bwd_sorted expects plus its segment start; the last
+// entry also writes n_unique and the closing segment start.
+template <typename KeyT>
+__global__ __launch_bounds__(NRX_BLOCK) void plan_finalize_kernel(const KeyT* __restrict__ skeys, const uint32_t* __restrict__ spayload,
+                                                                  const uint32_t* __restrict__ flags, const uint32_t* __restrict__ uidx,
+                                                                  int64_t n, int row_bits, int64_t* __restrict__ order,
+                                                                  int64_t* __restrict__ uniq_keys, int64_t* __restrict__ seg_start,
+                                                                  int64_t* __restrict__ counts) {
+    const int64_t e = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x;
+    if (e >= n) return;
+    order[e] = (int64_t)spayload[e];
+    if (flags[e]) {
+        const uint64_t k = (uint64_t)skeys[e];
+        const uint64_t row = k & ((1ull << row_bits) - 1);
+        uniq_keys[uidx[e]] = (int64_t)(((k >> row_bits) << 40) | row);
+        seg_start[uidx[e]] = e;
+    }
+    if (e == n - 1) {
+        const int64_t nu = (int64_t)uidx[e] + (int64_t)flags[e];
+        counts[0] = nu;
+        seg_start[nu] = n;
+    }
+}
+
+// counts[1 + t] = first unique index whose table id is >= t, t = 0..n_tables (so table t owns
+// [counts[1+t], counts[2+t]) )
+__global__ void plan_bounds_kernel(const int64_t* __restrict__ uniq_keys, int32_t n_tables, int64_t* __restrict__ counts) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tables) return;
+    const int64_t nu = counts[0];
+    const int64_t target = (int64_t)t << 40;
+    int64_t lo = 0, hi = nu;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (uniq_keys[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    counts[1 + t] = lo;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <typename KeyT>
+size_t sort_temp_bytes(int64_t n, int bits) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const KeyT*)nullptr, (KeyT*)nullptr, (const uint32_t*)nullptr,
+                                    (uint32_t*)nullptr, (size_t)n, 0u, (unsigned)bits, (hipStream_t) nullptr);
+    return bytes;
+}
+
+size_t scan_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::exclusive_scan(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n,
+                                  rocprim::plus<uint32_t>(), (hipStream_t) nullptr);
+    return bytes;
+}
+
+int bits_for(int64_t v) {      // bits needed to represent values 0 .. v-1 (at least 1)
+    int b = 1;
+    while (((int64_t)1 << b) < v) ++b;
+    return b;
+}
+
+}  // namespace
+
+extern "C" int64_t nrx_sparse_plan_workspace(int64_t n_lookups) {
+    if (n_lookups < 0 || n_lookups >= 0xffffffffLL) return -1;
+    const size_t n = (size_t)(n_lookups > 0 ? n_lookups : 1);
+    size_t t1 = sort_temp_bytes<uint64_t>(n, 64), t2 = scan_temp_bytes(n);
+    return (int64_t)(2 * align256(n * 8) + 2 * align256(n * 4) + 2 * align256(n * 4) + align256(t1 > t2 ? t1 : t2) + 256);
+}
+
+extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
+                               int32_t n_feats, int32_t index_bits, int32_t n_tables, int64_t* order, int64_t* uniq_keys,
+                               int64_t* seg_start, int64_t* counts, void* workspace, void* stream) {
+    NRX_REQUIRE(n_feats >= 0 && n_feats <= NRX_MAX_FEATURES && (index_bits == 32 || index_bits == 64) && n_tables >= 1 && n_tables < (1 << 20),
+                "nrx_sparse_plan: bad argument");
+    NRX_REQUIRE(counts != nullptr, "nrx_sparse_plan: null counts");
+    PlanArgs a;
+    int64_t off = 0, max_rows = 1;
+    for (int f = 0; f < n_feats; ++f) {
+        NRX_REQUIRE(lens[f] >= 0 && (lens[f] == 0 || ids[f] != nullptr) && table_of[f] >= 0 && table_of[f] < n_tables && rows[f] >= 1,
+                    "nrx_sparse_plan: bad feature entry");
+        a.ids[f] = ids[f];
+        a.off[f] = off;
+        a.rows[f] = rows[f];
+        a.table_of[f] = table_of[f];
+        off += lens[f];
+        if (rows[f] > max_rows) max_rows = rows[f];
+    }
+    a.off[n_feats] = off;
+    a.n_feats = n_feats;
+    a.idx64 = index_bits == 64;
+    a.n_total = off;
+    const int row_bits = bits_for(max_rows), table_bits = bits_for(n_tables);
+    NRX_REQUIRE(row_bits <= 40 && row_bits + table_bits <= 62, "nrx_sparse_plan: table too large for the composite key");
+    NRX_REQUIRE(off < 0xffffffffLL, "nrx_sparse_plan: too many lookups for one plan");
+    a.row_bits = row_bits;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t n = off;
+    if (n == 0) {
+        // counts = {0, 0, ..., 0}; seg_start[0] = 0
+        hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)(n_tables + 2), st);
+        if (seg_start) hipMemsetAsync(seg_start, 0, sizeof(int64_t), st);
+        return NRX_OK;
+    }
+    NRX_REQUIRE(order && uniq_keys && seg_start && workspace, "nrx_sparse_plan: null buffer");
+    char* w = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    char* keys_in = w;                 w += align256((size_t)n * 8);
+    char* keys_out = w;                w += align256((size_t)n * 8);
+    uint32_t* pay_in = (uint32_t*)w;   w += align256((size_t)n * 4);
+    uint32_t* pay_out = (uint32_t*)w;  w += align256((size_t)n * 4);
+    uint32_t* flags = (uint32_t*)w;    w += align256((size_t)n * 4);
+    uint32_t* uidx = (uint32_t*)w;     w += align256((size_t)n * 4);
+    void* temp = w;
+    const int bits = row_bits + table_bits;
+    int64_t g = (n + NRX_BLOCK - 1) / NRX_BLOCK;
+    const unsigned gfull = (unsigned)g;
+    if (g > 4096) g = 4096;
+    hipError_t err = hipSuccess;
+    size_t tb = 0;
+#define NRX_PLAN(KeyT)                                                                                                    \
+    {                                                                                                                     \
+        hipLaunchKernelGGL(plan_keys_kernel<KeyT>, dim3((unsigned)g), dim3(NRX_BLOCK), 0, st, a, (KeyT*)keys_in, pay_in);  \
+        tb = sort_temp_bytes<KeyT>(n, bits);                                                                              \
+        err = rocprim::radix_sort_pairs(temp, tb, (const KeyT*)keys_in, (KeyT*)keys_out, (const uint32_t*)pay_in, pay_out, \
+                                        (size_t)n, 0u, (unsigned)bits, st);                                               \
+        if (err == hipSuccess) {                                                                                          \
+            hipLaunchKernelGGL(plan_heads_kernel<KeyT>, dim3(gfull), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out, n, flags); \
+            tb = scan_temp_bytes(n);                                                                                      \
+            err = rocprim::exclusive_scan(temp, tb, (const uint32_t*)flags, uidx, 0u, (size_t)n, rocprim::plus<uint32_t>(), st); \
+        }                                                                                                                 \
+        if (err == hipSuccess)                                                                                            \
+            hipLaunchKernelGGL(plan_finalize_kernel<KeyT>, dim3(gfull), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out,     \
+                               (const uint32_t*)pay_out, (const uint32_t*)flags, (const uint32_t*)uidx, n, row_bits, order, \
+                               uniq_keys, seg_start, counts);                                                             \
+    }
+    if (bits <= 32) NRX_PLAN(uint32_t) else NRX_PLAN(uint64_t)
+#undef NRX_PLAN
+    if (err != hipSuccess) {
+        nrx_set_error("nrx_sparse_plan: rocPRIM call failed: %s", hipGetErrorString(err));
+        return NRX_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(plan_bounds_kernel, dim3((unsigned)((n_tables + 1 + 63) / 64)), dim3(64), 0, st, (const int64_t*)uniq_keys, n_tables, counts);
+    NRX_LAUNCH_CHECK("nrx_sparse_plan");
+    return NRX_OK;
+}

@@ -269,13 +269,43 @@ class _EmbedFn(torch.autograd.Function):
         return (None, None, None, None, None, None, *grads)
 
 
+SPARSE_BWD_SYNC_FREE = False   # True: size the reduction for the worst case and read the count on the device
+
+
+def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int):
+    """nrx_sparse_plan: group the flat, feature-major lookups `ids` (one device tensor per feature, all int32 or
+    all int64) by (table, row).  Returns device int64 tensors (order [n], uniq_keys [n], seg_start [n+1],
+    counts [n_tables+2]); only the first counts[0] entries of uniq_keys / counts[0]+1 of seg_start are
+    meaningful.  No host synchronisation."""
+    lib = _lib.load()
+    n = len(ids)
+    dev = ids[0].device
+    total = sum(x.numel() for x in ids)
+    order = torch.empty(total, dtype=torch.int64, device=dev)
+    uniq = torch.empty(total, dtype=torch.int64, device=dev)
+    seg = torch.empty(total + 1, dtype=torch.int64, device=dev)
+    counts = torch.empty(n_tables + 2, dtype=torch.int64, device=dev)
+    nbytes = lib.nrx_sparse_plan_workspace(total)
+    if nbytes < 0:
+        raise ValueError("sparse_plan: too many lookups for one plan")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in ids])
+    lens = (C.c_int64 * n)(*[x.numel() for x in ids])
+    tof = (C.c_int32 * n)(*[int(t) for t in table_of])
+    rws = (C.c_int64 * n)(*[int(r) for r in rows])
+    check(lib.nrx_sparse_plan(ptrs, lens, tof, rws, n, ids[0].element_size() * 8, n_tables, order.data_ptr(), uniq.data_ptr(),
+                              seg.data_ptr(), counts.data_ptr(), ws.data_ptr(), _stream_ptr(ids[0])), "nrx_sparse_plan")
+    return order, uniq, seg, counts
+
+
 def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream):
-    """Row-sparse, deterministic table grads.  Per group of tables sharing an embedding dim: composite
-    (table << 40 | row) keys for all lookups (nrx_make_table_keys), ONE stable sort (torch.sort = rocPRIM
-    radix sort; plumbing), ONE segmented-reduction launch (nrx_embed_bwd_sorted) summing the upstream rows
-    of every unique (table, row) in sorted order, one host read for the per-table split.  No dense
-    zero-fill, no atomics, bit-reproducible; padding rows get explicit zeros.  Returns torch.sparse_coo
-    tensors (what nn.Embedding(sparse=True) produces), usable with SGD / SparseAdam / Adagrad."""
+    """Row-sparse, deterministic table grads.  Per group of tables sharing an embedding dim: ONE planning
+    call (nrx_sparse_plan: compact (table, row) keys, rocPRIM radix sort on just the significant bits, head
+    flags + scan -> unique rows, segment starts, per-table split, all on the device), one host read of
+    n_tables + 2 integers, ONE segmented-reduction launch (nrx_embed_bwd_sorted) summing the upstream rows
+    of every unique (table, row) in sorted order.  No dense zero-fill, no atomics, bit-reproducible;
+    padding rows get explicit zeros.  Returns torch.sparse_coo tensors (what nn.Embedding(sparse=True)
+    produces), usable with SGD / SparseAdam / Adagrad."""
     plan, B, ld = ctx.plan, ctx.B, ctx.ld
     n_tables = len(ctx.table_meta)
     grads = [None] * n_tables
@@ -296,31 +326,31 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream):
             total = sum(x.numel() for x in ids)
             if total == 0:
                 continue
-            keys = torch.empty(total, dtype=torch.int64, device=dev)
-            ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in ids])
-            lens = (C.c_int64 * n)(*[x.numel() for x in ids])
-            tof = (C.c_int32 * n)(*[plan.slots[i].table for i in fs])
-            check(lib.nrx_make_table_keys(ptrs, lens, tof, n, ids[0].element_size() * 8, keys.data_ptr(), stream),
-                  "nrx_make_table_keys")
-            skeys, order = torch.sort(keys, stable=True)
-            uniq, counts = torch.unique_consecutive(skeys, return_counts=True)
-            nu = uniq.numel()
-            seg = torch.zeros(nu + 1, dtype=torch.int64, device=dev)
-            torch.cumsum(counts, 0, out=seg[1:])
-            values = torch.empty((nu, D), dtype=torch.float32, device=dev)
+            tabs = [plan.slots[i].table for i in fs]
+            order, uniq, seg, counts = sparse_plan(ids, tabs, [ctx.table_meta[t][0][0] for t in tabs], n_tables)
+            # The one host read (n_tables + 2 integers).  Reading it BEFORE the reduction lets the host build the
+            # per-table COO tensors while that kernel runs (1.00 ms per C2 step vs 1.11 ms with the sync-free
+            # n_unique_dev form of the call, which leaves the host work exposed after the GPU is done).
             sub = EmbedPlan([plan.slots[i] for i in fs], out_width=plan.out_width, wide_width=plan.wide_width)
             arr = _fill_features(sub, 0, n, [None] * n_tables, ids, [ctx.ws[i] for i in fs], table_ptrs=[0] * n_tables, fm=False)
-            check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width,
-                                           order.data_ptr(), seg.data_ptr(), uniq.data_ptr(), nu, values.data_ptr(), stream),
-                  "nrx_embed_bwd_sorted")                         # padding rows (id 0) come back as zeros
-            rows = uniq & MASK
-            tids = sorted({plan.slots[i].table for i in fs})
-            bounds = torch.searchsorted(uniq, torch.tensor([t << 40 for t in tids] + [(tids[-1] + 1) << 40],
-                                                            dtype=torch.int64, device=dev)).tolist()   # the one host read
-            for k, t in enumerate(tids):
-                lo, hi = bounds[k], bounds[k + 1]
-                g = torch.sparse_coo_tensor(rows[lo:hi].unsqueeze(0), values[lo:hi], size=ctx.table_meta[t][0])
-                g = g._coalesced_(True)
+            if SPARSE_BWD_SYNC_FREE:
+                values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
+                check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
+                                               seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), values.data_ptr(), stream),
+                      "nrx_embed_bwd_sorted")
+                cl = counts.tolist()
+                nu = cl[0]
+            else:
+                cl = counts.tolist()
+                nu = cl[0]
+                values = torch.empty((nu, D), dtype=torch.float32, device=dev)
+                check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
+                                               seg.data_ptr(), uniq.data_ptr(), nu, None, values.data_ptr(), stream),
+                      "nrx_embed_bwd_sorted")                     # padding rows (id 0) come back as zeros
+            rows = (uniq[:nu] & MASK).unsqueeze(0)
+            for t in sorted(set(tabs)):
+                lo, hi = cl[1 + t], cl[2 + t]
+                g = torch.sparse_coo_tensor(rows[:, lo:hi], values[lo:hi], size=ctx.table_meta[t][0], is_coalesced=True)
                 grads[t] = g if grads[t] is None else (grads[t] + g).coalesce()
     for t in range(n_tables):
         if grads[t] is None:

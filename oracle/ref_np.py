@@ -638,3 +638,25 @@ def hit_rate_reference_loop(items: np.ndarray, queries: np.ndarray, targets: np.
                 break
         hits += int(int(targets[q]) in filtered)
     return hits / queries.shape[0] if queries.shape[0] else 0
+
+
+def sparse_plan(id_arrays, table_of, rows, n_tables: int):
+    """Definition of nrx_sparse_plan (planning step of the row-sparse backward; groups the lookups that
+    autograd of nn.Embedding, base_model.py:262-308, would scatter-add): flat feature-major lookup p of feature
+    f gets key (table_of[f], row) with out-of-range ids on row 0; `order` = stable argsort of the keys;
+    uniq_keys = distinct (table << 40 | row) ascending; seg_start = first sorted position of each; counts =
+    [n_unique, first unique index with table >= t for t in 0..n_tables]."""
+    keys = []
+    for ids, t, r in zip(id_arrays, table_of, rows):
+        ids = np.asarray(ids, np.int64).reshape(-1)
+        ids = np.where((ids < 0) | (ids >= r), 0, ids)
+        keys.append((np.int64(t) << np.int64(40)) | ids)
+    keys = np.concatenate(keys) if keys else np.zeros(0, np.int64)
+    order = np.argsort(keys, kind="stable").astype(np.int64)
+    sk = keys[order]
+    head = np.ones(len(sk), bool)
+    head[1:] = sk[1:] != sk[:-1]
+    uniq = sk[head]
+    seg = np.concatenate([np.nonzero(head)[0], [len(sk)]]).astype(np.int64)
+    counts = np.array([len(uniq)] + [int(np.searchsorted(uniq, np.int64(t) << np.int64(40))) for t in range(n_tables + 1)], np.int64)
+    return order, uniq, seg, counts

@@ -88,3 +88,40 @@ def test_hip_bucketize_matches_definition(n, world, seed):
     c_ref, perm = R.bucketize_by_owner(ids, world)
     assert np.array_equal(counts.cpu().numpy(), c_ref)
     assert np.array_equal(local_rows.cpu().numpy(), (ids // world)[perm])
+
+
+# ----------------------------------------------------------------------------- sparse-backward planning
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    dict(n=[0], rows=[5], tab=[0], nt=1), dict(n=[1], rows=[1], tab=[0], nt=1),
+    dict(n=[300, 300, 77], rows=[50, 50, 9], tab=[0, 1, 1], nt=3),
+    dict(n=[5000] * 26, rows=[1000] * 26, tab=list(range(26)), nt=26),
+    dict(n=[4096, 8192], rows=[1 << 20, 1 << 27], tab=[3, 1], nt=5),            # 3 + 27 bits: 32-bit keys
+    dict(n=[4096, 100], rows=[(1 << 31) + 5, 7], tab=[0, 9], nt=10),            # 36 bits: 64-bit keys
+])
+@pytest.mark.parametrize("dtype", ["int64", "int32"])
+def test_sparse_plan_bit_exact(case, dtype):
+    """nrx_sparse_plan == its definition (oracle.ref_np.sparse_plan): stable order, unique keys, segment
+    starts, per-table bounds -- including out-of-range / negative ids (row 0) and tables with no lookups."""
+    import torch
+    from news_recsys_amd import ops
+    from oracle import ref_np as R
+    rng = np.random.default_rng(sum(case["n"]) + case["nt"])
+    ids = []
+    for n, r in zip(case["n"], case["rows"]):
+        hi = min(r, (1 << 31) - 1) if dtype == "int32" else r
+        x = rng.integers(0, max(hi, 1), n).astype(dtype)
+        if n > 10:
+            x[3] = -1
+            if hi == r and r < (1 << 31) - 10:
+                x[5] = r + 3                                       # past the table: falls on row 0
+            x[7:10] = x[6]                                         # duplicates
+        ids.append(x)
+    order, uniq, seg, counts = ops.sparse_plan([torch.from_numpy(x).to("cuda:0") for x in ids], case["tab"], case["rows"], case["nt"])
+    o_r, u_r, s_r, c_r = R.sparse_plan(ids, case["tab"], case["rows"], case["nt"])
+    c = counts.cpu().numpy()
+    assert np.array_equal(c, c_r)
+    nu = int(c[0])
+    assert np.array_equal(order.cpu().numpy(), o_r)
+    assert np.array_equal(uniq.cpu().numpy()[:nu], u_r)
+    assert np.array_equal(seg.cpu().numpy()[:nu + 1], s_r)
