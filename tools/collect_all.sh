@@ -14,6 +14,14 @@ for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $F/dcn2/stats -- python3 tools/run_dcn2.py > /dev/null 2>&1
 python3 tools/summarize_profile.py $F/dcn2 > $F/dcn2_summary.txt 2>&1
+i=0
+for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1)); rocprofv3 --pmc $C --kernel-trace --output-format csv -d $F/topk/pmc$i -- python3 tools/run_topk.py > /dev/null 2>&1
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $F/topk/stats -- python3 tools/run_topk.py > /dev/null 2>&1
+python3 tools/summarize_profile.py $F/topk > $F/topk_summary.txt 2>&1
+./tools/bin/mfma_f32_probe > $F/mfma_f32_semantics.txt 2>&1
+./tools/bin/mfma_peak_probe > $F/mfma_f32_valu_overlap_probe.txt 2>&1
 python3 tools/bench_ops.py > $F/bench_ops.log 2>&1
 python3 tools/bench_loader.py 300000 > $F/bench_loader.log 2>&1
 python3 tools/bench_host_overhead.py > $F/host_overhead.log 2>&1
