@@ -38,7 +38,8 @@ BATCH = 65536
 def workload_spec(name: str):
     """(features, description).  feature = dict(name, rows, dim, bag_len)."""
     if name == "c2":      # DeepFM: 26 sparse x 1M rows, D=16
-        feats = [dict(name=f"C{i:02d}", rows=1_000_000, dim=16, bag=0) for i in range(26)]
+        rows = int(os.environ.get("NRX_BENCH_C2_ROWS", 1_000_000))      # dev knob (cache-resident tables); headline = 1M
+        feats = [dict(name=f"C{i:02d}", rows=rows, dim=16, bag=0) for i in range(26)]
         return feats, "c2: DeepFM 26 sparse x 1M rows, D=16, B=65536, uniform ids; gather->concat[B,416] + fused FM logit"
     if name == "c3":      # DCN: 5 feats D=64, news table 100M rows
         rows = dict(item_id=100_000_000, user_id=1_000_000, category=18, subcategory=270, user_click_category=18)
