@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include "nrx_embed.h"
 typedef float f4 __attribute__((ext_vector_type(4)));
 static uint64_t mix64(uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); }
@@ -124,6 +125,11 @@ int main() {
     const int B = 65536, F = 26;
     float *out, *tab; int* ids;
     hipMalloc(&out, (size_t)B * F * 64);
+    if (const char* m = getenv("TABLE_ALLOC")) {
+        const unsigned flag = !strcmp(m, "uncached") ? hipDeviceMallocUncached : (!strcmp(m, "finegrained") ? hipDeviceMallocFinegrained : hipDeviceMallocDefault);
+        hipError_t e = hipExtMallocWithFlags((void**)&tab, (size_t)F * 1048576 * 64, flag);
+        printf("table allocation: %s (flag %u) -> %s\n", m, flag, hipGetErrorString(e));
+    } else
     hipMalloc(&tab, (size_t)F * 1048576 * 64);
     hipMalloc(&ids, (size_t)B * F * 4);
     int* h = (int*)malloc((size_t)B * F * 4);
@@ -161,13 +167,25 @@ int main() {
             RUN16(2, true, false, i64fb, "  + table pointers via LDS");
             RUN16(2, true, true, i64fb, "  + FM epilogue");
             BigArgs ba; ba.n = F; ba.B = B; ba.out = out; ba.fm = fmo;
-            for (int f = 0; f < F; ++f) { ba.table[f] = tab + (int64_t)f * R * 16; ba.index[f] = i64fb + (int64_t)f * B; ba.rows[f] = R; }
+            static float* sep[64]; static int64_t* sepi[64];
+            const bool split = getenv("TABLE_SPLIT") != nullptr;
+            for (int f = 0; f < F; ++f) {
+                ba.table[f] = tab + (int64_t)f * R * 16; ba.index[f] = i64fb + (int64_t)f * B; ba.rows[f] = R;
+                if (split) {            // one allocation per table / id array, like 26 torch tensors
+                    if (sep[f]) { hipFree(sep[f]); hipFree(sepi[f]); }
+                    hipMalloc(&sep[f], (size_t)R * 64); hipMalloc(&sepi[f], (size_t)B * 8);
+                    hipMemcpy(sep[f], ba.table[f], (size_t)R * 64, hipMemcpyDeviceToDevice);
+                    hipMemcpy(sepi[f], ba.index[f], (size_t)B * 8, hipMemcpyDeviceToDevice);
+                    ba.table[f] = sep[f]; ba.index[f] = sepi[f];
+                }
+            }
+            if (split) printf("(one hipMalloc per table and per id array)\n");
             run("  + pointers/sizes in a by-value argument block", [&]() { hipLaunchKernelGGL((k16_args<false>), dim3((unsigned)(((int64_t)B * 16 + 255) / 256)), dim3(256), 0, 0, ba); }, bytes);
             {
                 nrx_feature_t fe[64];
                 int32_t* status; hipMalloc(&status, 16); hipMemset(status, 0, 16);
                 for (int f = 0; f < F; ++f) {
-                    fe[f].table = tab + (int64_t)f * R * 16; fe[f].index = i64fb + (int64_t)f * B; fe[f].weight = nullptr; fe[f].rows = R;
+                    fe[f].table = ba.table[f]; fe[f].index = ba.index[f]; fe[f].weight = nullptr; fe[f].rows = R;
                     fe[f].dim = 16; fe[f].bag_len = 0; fe[f].kind = NRX_SPARSE; fe[f].index_bits = 64; fe[f].out_col = 16 * f; fe[f].wide_col = -1;
                     fe[f].fm_field = 1; fe[f].flags = 0;
                 }
