@@ -267,7 +267,8 @@ NRX_API int nrx_user_rank_metrics(const float* scores, const float* labels, cons
                           int32_t k, double* auc, double* ndcg, double* hr, double* mrr, void* stream);
 /* Exact inner-product top-k retrieval (replaces faiss.IndexFlatIP.search as wrapped by
  * src/model/model_utils/TopKSearcher.py:50-84 and used by DSSM.hit_rate, recall/DSSM/model.py:182-228).
- * items [n_items, dim], queries [n_queries, dim] fp32 row-major (dim % 4 == 0, dim <= 128, k <= 32).
+ * items [n_items, dim], queries [n_queries, dim] fp32 row-major (dim % 4 == 0, dim <= 128, k <= 32 per call;
+ * a caller that wants more runs ceil(k/32) calls, each excluding what the earlier ones returned).
  * Optional per-query exclusion lists in CSR form (excl_offsets [n_queries+1], excl_items sorted ascending
  * inside each list; both device int64): excluded items never enter the result -- the reference instead
  * over-fetches k + len(history) and filters on the host.  Output: out_idx / out_score [n_queries, k], scores

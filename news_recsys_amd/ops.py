@@ -877,16 +877,11 @@ def mask_lengths(mask: torch.Tensor) -> torch.Tensor:
     return lens
 
 
-def topk_ip(items: torch.Tensor, queries: torch.Tensor, k: int, exclude=None):
-    """Exact inner-product top-k (faiss.IndexFlatIP.search semantics; TopKSearcher.py:50-84).
-    items [N, d], queries [Q, d] fp32 on the GPU.  `exclude` = (offsets [Q+1], item_idx) device int64
-    CSR of per-query item positions to skip (each list ascending).  Returns (idx [Q, k] int64, score
-    [Q, k] fp32): scores descending, ties toward the lower index, empty slots -1 / -FLT_MAX."""
+TOPK_KMAX = 32          # list length one launch keeps in registers (nrx_topk.hip)
+
+
+def _topk_ip_once(items, queries, k, exclude):
     lib = _lib.load()
-    items = _f32c(items, "items")
-    queries = _f32c(queries, "queries")
-    if items.dim() != 2 or queries.dim() != 2 or items.shape[1] != queries.shape[1]:
-        raise ValueError(f"topk_ip: items {tuple(items.shape)} vs queries {tuple(queries.shape)}")
     N, d = items.shape
     Q = queries.shape[0]
     out_idx = torch.empty((Q, k), dtype=torch.int64, device=queries.device)
@@ -907,6 +902,54 @@ def topk_ip(items: torch.Tensor, queries: torch.Tensor, k: int, exclude=None):
                           ei.data_ptr() if ei is not None and ei.numel() else (ws.data_ptr() if eo is not None else None),
                           out_idx.data_ptr(), out_score.data_ptr(), ws.data_ptr(), _stream_ptr(queries)), "nrx_topk_ip")
     return out_idx, out_score
+
+
+def topk_ip(items: torch.Tensor, queries: torch.Tensor, k: int, exclude=None):
+    """Exact inner-product top-k (faiss.IndexFlatIP.search semantics; TopKSearcher.py:50-84).
+    items [N, d], queries [Q, d] fp32 on the GPU.  `exclude` = (offsets [Q+1], item_idx) device int64
+    CSR of per-query item positions to skip (each list ascending).  Returns (idx [Q, k] int64, score
+    [Q, k] fp32): scores descending, ties toward the lower index, empty slots -1 / -FLT_MAX.
+    k > 32 runs ceil(k / 32) passes, each excluding what the earlier ones returned (same result as one
+    pass: the order (score desc, index asc) is total)."""
+    items = _f32c(items, "items")
+    queries = _f32c(queries, "queries")
+    if items.dim() != 2 or queries.dim() != 2 or items.shape[1] != queries.shape[1]:
+        raise ValueError(f"topk_ip: items {tuple(items.shape)} vs queries {tuple(queries.shape)}")
+    if k < 1:
+        raise ValueError("topk_ip: k must be >= 1")
+    if k <= TOPK_KMAX or queries.shape[0] == 0:
+        return _topk_ip_once(items, queries, k, exclude)
+    Q = queries.shape[0]
+    dev = queries.device
+    BIG = torch.iinfo(torch.int64).max
+    if exclude is not None:                                  # CSR -> padded [Q, L] with BIG as filler
+        eo = exclude[0].to(device=dev, dtype=torch.int64)
+        ei = exclude[1].to(device=dev, dtype=torch.int64)
+        lens = eo[1:] - eo[:-1]
+        L = int(lens.max().item()) if Q else 0
+        acc = torch.full((Q, L), BIG, dtype=torch.int64, device=dev)
+        if ei.numel():
+            row = torch.repeat_interleave(torch.arange(Q, device=dev), lens)
+            col = torch.arange(ei.numel(), device=dev) - torch.repeat_interleave(eo[:-1], lens)
+            acc[row, col] = ei
+    else:
+        acc = torch.empty((Q, 0), dtype=torch.int64, device=dev)
+    idxs, scs = [], []
+    done = 0
+    excl = exclude
+    while done < k:
+        kk = min(TOPK_KMAX, k - done)
+        idx, sc = _topk_ip_once(items, queries, kk, excl)
+        idxs.append(idx)
+        scs.append(sc)
+        done += kk
+        if done < k:
+            acc = torch.sort(torch.cat([acc, torch.where(idx >= 0, idx, torch.full_like(idx, BIG))], dim=1), dim=1).values
+            valid = acc != BIG
+            offs = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(valid.sum(dim=1), 0, out=offs[1:])
+            excl = (offs, acc[valid])
+    return torch.cat(idxs, dim=1), torch.cat(scs, dim=1)
 
 
 def device_info(device: int = 0):

@@ -132,11 +132,23 @@ def test_hip_topk_full_size_properties():
 
 
 @gpu
+@pytest.mark.parametrize("k,me", [(33, 0), (100, 0), (70, 40), (500, 5)])
+def test_hip_topk_large_k_multipass(k, me):
+    """k > 32: ceil(k/32) launches, each excluding the earlier results -- identical to the one-pass oracle,
+    including the -1 / -FLT_MAX padding once the items run out (N = 300 < 500)."""
+    items, q, lists, csr = _case(k + me, 300, 41, 16, me, dup=True)
+    i_h, s_h = _run_hip(items, q, k, csr if me else None)
+    i_c, s_c = ref_c.topk_ip(items, q, k, csr if me else None)
+    assert np.array_equal(i_h, i_c)
+    assert np.array_equal(s_h.view(np.uint32), s_c.view(np.uint32))
+
+
+@gpu
 def test_hip_topk_rejects_unsupported():
     from news_recsys_amd import ops
     it = torch.zeros(10, 16, device=DEV)
-    with pytest.raises(Exception):
-        ops.topk_ip(it, torch.zeros(2, 16, device=DEV), 33)
+    with pytest.raises(ValueError):
+        ops.topk_ip(it, torch.zeros(2, 16, device=DEV), 0)
     with pytest.raises(Exception):
         ops.topk_ip(torch.zeros(10, 6, device=DEV), torch.zeros(2, 6, device=DEV), 5)
     with pytest.raises(ValueError):
