@@ -254,8 +254,9 @@ NRX_API int nrx_scatter_add_inbox(float* const* grad_tables, const int64_t* tabl
  * batch, device int64[batch+1]) into the reference's padded form: ids [batch, bag_len] (0-padded,
  * same integer width as `values`) and mask float32 [batch, bag_len] (1 = real, 0 = padding) --
  * what DataReader builds per sample on the host (src/dataset/DataReader/data_reader.py:96-109;
- * longer arrays are truncated to bag_len like :104-106).                                          */
-NRX_API int nrx_csr_to_padded(const void* values, int32_t value_bits, const int64_t* offsets, int64_t batch,
+ * longer arrays are truncated to bag_len like :104-106).  rows (optional, device int64[batch]): batch row b
+ * is row rows[b] of a larger CSR (a dataset kept resident in HBM; offsets then index the whole dataset). */
+NRX_API int nrx_csr_to_padded(const void* values, int32_t value_bits, const int64_t* offsets, const int64_t* rows, int64_t batch,
                       int32_t bag_len, void* ids_out, float* mask_out, void* stream);
 /* Per-user ranking metrics of the reference's validation loop (base_model.py:333-435) on the device.
  * Inputs are the validation samples sorted by (user, score descending, arrival order) -- i.e. every

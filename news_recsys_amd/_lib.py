@@ -77,7 +77,7 @@ SIGNATURES = {
     "nrx_route_ids": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p]),
     "nrx_gather_inbox": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, C.POINTER(_i32), _i32, _i32, _i64, _p, _p, _i32, _p, _p, _p]),
     "nrx_scatter_add_inbox": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, C.POINTER(_i32), _i32, _i32, _i64, _p, _p, _i32, _p, _i32, _p]),
-    "nrx_csr_to_padded": (C.c_int, [_p, _i32, _p, _i64, _i32, _p, _p, _p]),
+    "nrx_csr_to_padded": (C.c_int, [_p, _i32, _p, _p, _i64, _i32, _p, _p, _p]),
     "nrx_user_rank_metrics": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "nrx_mask_lengths": (C.c_int, [_p, _i64, _i32, _p, _p]),
     "nrx_sparse_plan_workspace": (_i64, [_i64]),

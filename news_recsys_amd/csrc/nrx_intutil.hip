@@ -196,13 +196,15 @@ __global__ __launch_bounds__(NRX_BLOCK) void mask_lengths_kernel(const float* __
 
 template <typename T>
 __global__ __launch_bounds__(NRX_BLOCK) void csr_to_padded_kernel(const T* __restrict__ values, const int64_t* __restrict__ offsets,
-                                                                  int64_t batch, int L, T* __restrict__ ids, float* __restrict__ mask) {
+                                                                  const int64_t* __restrict__ rows, int64_t batch, int L,
+                                                                  T* __restrict__ ids, float* __restrict__ mask) {
     const int64_t total = batch * (int64_t)L;
     for (int64_t i = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * NRX_BLOCK) {
         const int64_t b = i / L;
         const int l = (int)(i - b * L);
-        const int64_t lo = offsets[b];
-        const int64_t n = offsets[b + 1] - lo;
+        const int64_t src = rows ? rows[b] : b;         // device-resident dataset: batch row b = dataset row rows[b]
+        const int64_t lo = offsets[src];
+        const int64_t n = offsets[src + 1] - lo;
         const bool real = l < n;
         ids[i] = real ? values[lo + l] : (T)0;
         mask[i] = real ? 1.0f : 0.0f;
@@ -355,7 +357,7 @@ extern "C" int nrx_scatter_add_rows_segmented(float* const* grad_tables, const i
     return NRX_OK;
 }
 
-extern "C" int nrx_csr_to_padded(const void* values, int32_t value_bits, const int64_t* offsets, int64_t batch,
+extern "C" int nrx_csr_to_padded(const void* values, int32_t value_bits, const int64_t* offsets, const int64_t* rows, int64_t batch,
                                  int32_t bag_len, void* ids_out, float* mask_out, void* stream) {
     NRX_REQUIRE(value_bits == 32 || value_bits == 64, "nrx_csr_to_padded: value_bits must be 32 or 64");
     NRX_REQUIRE(batch >= 0 && bag_len >= 1, "nrx_csr_to_padded: bad argument");
@@ -366,10 +368,10 @@ extern "C" int nrx_csr_to_padded(const void* values, int32_t value_bits, const i
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (value_bits == 64)
         hipLaunchKernelGGL(csr_to_padded_kernel<int64_t>, dim3((unsigned)g), dim3(NRX_BLOCK), 0, st, (const int64_t*)values, offsets,
-                           batch, bag_len, (int64_t*)ids_out, mask_out);
+                           rows, batch, bag_len, (int64_t*)ids_out, mask_out);
     else
         hipLaunchKernelGGL(csr_to_padded_kernel<int32_t>, dim3((unsigned)g), dim3(NRX_BLOCK), 0, st, (const int32_t*)values, offsets,
-                           batch, bag_len, (int32_t*)ids_out, mask_out);
+                           rows, batch, bag_len, (int32_t*)ids_out, mask_out);
     NRX_LAUNCH_CHECK("nrx_csr_to_padded");
     return NRX_OK;
 }

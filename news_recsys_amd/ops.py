@@ -850,9 +850,10 @@ def scatter_add_inbox(grad_tables: Sequence[torch.Tensor], feat_table: Sequence[
                                     _stream_ptr(g_rows)), "nrx_scatter_add_inbox")
 
 
-def csr_to_padded(values: torch.Tensor, offsets: torch.Tensor, bag_len: int):
+def csr_to_padded(values: torch.Tensor, offsets: torch.Tensor, bag_len: int, rows: Optional[torch.Tensor] = None):
     """CSR batch of an array feature -> (ids [B, bag_len] 0-padded, mask float32 [B, bag_len]) on the device:
-    the padded form DataReader builds per sample on the host (data_reader.py:96-109)."""
+    the padded form DataReader builds per sample on the host (data_reader.py:96-109).  With `rows` (device
+    int64 [B]) the CSR is a whole dataset resident in HBM and batch row b is its row rows[b]."""
     lib = _lib.load()
     _dev(values, "values")
     _dev(offsets, "offsets")
@@ -860,10 +861,14 @@ def csr_to_padded(values: torch.Tensor, offsets: torch.Tensor, bag_len: int):
         raise TypeError("values must be int64 or int32")
     offsets = offsets.to(torch.int64).contiguous()
     values = values.contiguous()
-    B = offsets.numel() - 1
+    if rows is not None:
+        rows = _dev(rows, "rows").to(torch.int64).contiguous()
+        B = rows.numel()
+    else:
+        B = offsets.numel() - 1
     ids = torch.empty((B, bag_len), dtype=values.dtype, device=values.device)
     mask = torch.empty((B, bag_len), dtype=torch.float32, device=values.device)
-    check(lib.nrx_csr_to_padded(_ptr(values) if values.numel() else None, values.element_size() * 8, offsets.data_ptr(), B,
+    check(lib.nrx_csr_to_padded(_ptr(values) if values.numel() else None, values.element_size() * 8, offsets.data_ptr(), _ptr(rows), B,
                                 bag_len, ids.data_ptr(), mask.data_ptr(), _stream_ptr(offsets)), "nrx_csr_to_padded")
     return ids, mask
 

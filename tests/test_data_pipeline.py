@@ -136,6 +136,42 @@ def test_columnar_device_loader_matches_reference_and_feeds_the_model(col_dir):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_resident_loader_yields_the_same_batches(col_dir, shuffle):
+    """resident=True (dataset kept in HBM, batches gathered on the device) == the streaming loader, bit for
+    bit, sequential and shuffled (same permutation, same in-batch order), over two epochs."""
+    ds = ColumnarDataset(col_dir)
+    a = ColumnarLoader(ds, 5, "cuda:0", shuffle=shuffle, seed=3)
+    b = ColumnarLoader(ds, 5, "cuda:0", shuffle=shuffle, seed=3, resident=True)
+    for _ in range(2):
+        la, lb = list(a), list(b)
+        assert len(la) == len(lb) == len(a)
+        for x, y in zip(la, lb):
+            assert set(x) == set(y)
+            for k in x:
+                assert x[k].dtype == y[k].dtype and torch.equal(x[k], y[k]), k
+    assert b.resident_bytes() > 0
+    with pytest.raises(ValueError):
+        ColumnarLoader(ds, 5, "cpu", resident=True)
+
+
+@pytest.mark.gpu
+def test_csr_to_padded_row_selection():
+    from news_recsys_amd import ops
+    rng = np.random.default_rng(1)
+    N, L = 500, 9
+    lens = rng.integers(0, 14, N)                       # some longer than L: truncated
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    vals = rng.integers(1, 10 ** 6, off[-1]).astype(np.int32)
+    rows = rng.integers(0, N, 77).astype(np.int64)
+    ids, mask = ops.csr_to_padded(torch.from_numpy(vals).cuda(), torch.from_numpy(off).cuda(), L, rows=torch.from_numpy(rows).cuda())
+    for i, r in enumerate(rows):
+        n = min(lens[r], L)
+        assert np.array_equal(ids[i, :n].cpu().numpy(), vals[off[r]:off[r] + n]) and not ids[i, n:].any()
+        assert mask[i].sum().item() == n
+
+
+@pytest.mark.gpu
 def test_csr_to_padded_kernel_vs_numpy():
     from news_recsys_amd import ops
     rng = np.random.default_rng(0)

@@ -50,3 +50,15 @@ for dev, tag in (("cpu", "(b) columnar loader -> CPU batches (host gather) "),) 
         if dev != "cpu": torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f"{tag} shuffle={int(shuffle)}: {n / dt:12.0f} samples/s", flush=True)
+
+if torch.cuda.is_available():
+    for shuffle in (False, True):
+        loader = ColumnarLoader(cds, B, "cuda:0", shuffle=shuffle, resident=True)
+        for _ in loader: pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); n = 0
+        for ep in range(10):
+            for b in loader: n += b["user_id"].shape[0]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"(d) device-resident dataset ({loader.resident_bytes() / 1e6:.0f} MB in HBM), device-side batch gather shuffle={int(shuffle)}: {n / dt:12.0f} samples/s", flush=True)
