@@ -72,8 +72,10 @@ class MINDDataModule(_Base):
             convert_features_txt(self.config_path, txt_path, col_dir)
         return ColumnarDataset(col_dir)
 
-    def train_loader_columnar(self, device, seed: int = 0) -> ColumnarLoader:
-        return ColumnarLoader(self._columnar(self.train_file_path), self.batch_size, device, shuffle=True, seed=seed)
+    def train_loader_columnar(self, device, seed: int = 0, resident: bool = False) -> ColumnarLoader:
+        """resident=True keeps the whole split in GPU memory and gathers batches on the device."""
+        return ColumnarLoader(self._columnar(self.train_file_path), self.batch_size, device, shuffle=True, seed=seed,
+                              resident=resident)
 
-    def val_loader_columnar(self, device) -> ColumnarLoader:
-        return ColumnarLoader(self._columnar(self.val_file_path), self.batch_size, device, shuffle=False)
+    def val_loader_columnar(self, device, resident: bool = False) -> ColumnarLoader:
+        return ColumnarLoader(self._columnar(self.val_file_path), self.batch_size, device, shuffle=False, resident=resident)
