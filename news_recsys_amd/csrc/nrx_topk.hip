@@ -244,9 +244,7 @@ int pick_k(int k) { return k <= 4 ? 4 : (k <= 10 ? 10 : (k <= 16 ? 16 : KMAX)); 
 
 int choose_splits(int64_t n_items, int64_t n_queries) {
     const int64_t qblocks = n_queries > 0 ? (n_queries + 32 * WAVES - 1) / (32 * WAVES) : 1;
-    const char* env = getenv("NRX_TOPK_BLOCKS");
-    const int64_t target = env ? atoll(env) : 512;
-    int64_t s = (target + qblocks - 1) / qblocks;             // aim at >= 512 blocks (2 waves per SIMD: MFMA-bound,
+    int64_t s = (512 + qblocks - 1) / qblocks;             // aim at >= 512 blocks (2 waves per SIMD: MFMA-bound,
                                                               // and every extra split repeats the top-k warm-up)
     const int64_t max_s = (n_items + 4095) / 4096;          // keep >= 4096 items per split
     if (s > max_s) s = max_s;
@@ -285,7 +283,7 @@ extern "C" int nrx_topk_ip(const float* items, int64_t n_items, int32_t dim, con
     float* p_score = reinterpret_cast<float*>(ws + (size_t)2 * S * n_queries * K * sizeof(int));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((unsigned)((n_queries + 32 * WAVES - 1) / (32 * WAVES)), (unsigned)S);
-    const float kth0 = getenv("NRX_TOPK_NOSEL") ? FLT_MAX : -FLT_MAX;      // dev knob: MFMA-only timing
+    const float kth0 = -FLT_MAX;      // initial threshold (FLT_MAX here disables selection: how the MFMA-only time in DESIGN.md was taken)
 #define NRX_TK2(K_, H4_, PAD_) hipLaunchKernelGGL((topk_mfma_kernel<K_, H4_, PAD_, 2>), grid, dim3(NRX_BLOCK), 0, st, items, n_items, (int)dim, \
                                                   queries, n_queries, excl_offsets, excl_items, per_split, p_score, p_idx, kth0)
 #define NRX_TK(K_, H4_) if (pad) NRX_TK2(K_, H4_, true); else NRX_TK2(K_, H4_, false)
