@@ -1,0 +1,72 @@
+"""A whole training step on the fused path captured in a HIP graph (news_recsys_amd.graph.GraphedStep) gives the
+losses of the eager loop and -- up to float-atomic reordering in the dense-gradient scatter -- its parameters."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.conftest import CONFIGS
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _batch(m, B, gen):
+    b = {}
+    for n in m.sparse_feature_names:
+        rows = m.embedding_tables[m._get_emb_feature_name(n)].weight.shape[0]
+        b[n] = torch.randint(1, rows, (B,), device=DEV, generator=gen)
+    for n in m.array_feature_names:
+        rows = m.embedding_tables[m._get_emb_feature_name(n)].weight.shape[0]
+        b[n] = torch.randint(1, rows, (B, 9), device=DEV, generator=gen)
+        b[n + "_mask"] = (torch.rand(B, 9, device=DEV, generator=gen) < 0.6).float()
+    b["label"] = (torch.rand(B, 2, device=DEV, generator=gen) < 0.3).float()
+    return b
+
+
+def test_graphed_training_step_matches_eager():
+    from news_recsys_amd import ops
+    from news_recsys_amd.graph import GraphedStep
+    from news_recsys_amd.model.sort.deep.model import Deep
+    cfg = os.path.join(CONFIGS, "cf_array_small.yaml")
+    torch.manual_seed(3)
+    m_e = Deep(cfg).to(DEV)
+    m_g = Deep(cfg).to(DEV)
+    m_g.load_state_dict(m_e.state_dict())
+    opt_e = torch.optim.Adam(m_e.parameters(), lr=1e-3, capturable=True)
+    opt_g = torch.optim.Adam(m_g.parameters(), lr=1e-3, capturable=True)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    batches = [_batch(m_e, 256, gen) for _ in range(5)]
+
+    def make_step(m, opt):
+        def step(b):
+            opt.zero_grad(set_to_none=False)
+            loss = F.binary_cross_entropy(m(b).view(-1), b["label"][:, 0])
+            loss.backward()
+            opt.step()
+            return loss
+        return step
+
+    snapshot = {k: v.clone() for k, v in m_g.state_dict().items()}
+    mode_before = ops._INDEX_CHECK
+    gs = GraphedStep(make_step(m_g, opt_g), batches[0], warmup=2)
+    assert ops._INDEX_CHECK == mode_before                      # the capture restores the caller's check mode
+    m_g.load_state_dict(snapshot)                               # undo the warm-up / capture updates
+    for st in opt_g.state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                v.zero_()
+    step_e = make_step(m_e, opt_e)
+    ops.set_index_check("off")
+    try:
+        for b in batches:
+            le = step_e(b).item()
+            lg = gs(b).item()
+            assert abs(le - lg) <= 1e-6 * max(1.0, abs(le))
+    finally:
+        ops.set_index_check(mode_before)
+    for p, q in zip(m_e.parameters(), m_g.parameters()):
+        torch.testing.assert_close(p, q, rtol=0, atol=5e-6)
+    with pytest.raises(ValueError):
+        gs(_batch(m_e, 128, gen))                               # a different batch shape cannot be replayed
