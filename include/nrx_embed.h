@@ -137,6 +137,19 @@ NRX_API int nrx_sparse_plan(const void* const* ids, const int64_t* lens, const i
                     int32_t n_feats, int32_t index_bits, int32_t n_tables, int64_t* order, int64_t* uniq_keys,
                     int64_t* seg_start, int64_t* counts, void* workspace, void* stream);
 
+/* Fused row-sparse Adam(W) over the unique rows of nrx_sparse_plan / nrx_embed_bwd_sorted: for every unique entry u
+ * (key = (table << 40) | row, gradient grads[u, :dim]) of up to NRX_MAX_FEATURES tables sharing `dim`,
+ *   m += (g - m)(1 - beta1);  v += (g*g - v)(1 - beta2);  w -= w * lr_times_weight_decay;
+ *   w -= step_size * m / (sqrt(v) + eps)        with step_size = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+ * -- torch.optim.SparseAdam's update (plus optional decoupled decay of the touched rows); rows that were not
+ * looked up do not move, row 0 (padding) never moves.  This replaces, for the embedding tables, the reference's
+ * dense AdamW over every row (src/model/sort/deep/model.py:54-65) -- a documented deviation, see DESIGN.md.
+ * n_unique_dev (optional, device int64[1]): actual count; n_unique is then an upper bound sizing the launch. */
+NRX_API int nrx_sparse_adam_step(float* const* tables, float* const* exp_avg, float* const* exp_avg_sq, int32_t n_tables,
+                         int32_t dim, const int64_t* uniq_keys, const float* grads, int64_t n_unique,
+                         const int64_t* n_unique_dev, float step_size, float beta1, float beta2, float eps,
+                         float lr_times_weight_decay, void* stream);
+
 /* Composite sort keys for nrx_embed_bwd_sorted over SEVERAL tables at once: for the flat,
  * feature-major lookup list of n_feats features (ids[f]: lens[f] elements; HOST pointer arrays),
  * keys[p] = (table_of[f] << 40) | id, so that one stable sort groups the lookups by (table, row).

@@ -199,3 +199,106 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
     NRX_LAUNCH_CHECK("nrx_sparse_plan");
     return NRX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Fused row-sparse Adam(W) on the unique rows the sorted backward produced.
+// Replaces, for the embedding tables only, the reference's dense AdamW over every row of every table
+// (configure_optimizers, src/model/sort/deep/model.py:54-65).  Semantics = torch.optim.SparseAdam (moments and
+// weights of a row move only in steps that looked the row up; bias correction from the global step) plus an
+// optional decoupled weight decay applied to the touched rows; the padding row (row 0) never moves.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct SparseAdamArgs {
+    float* table[NRX_MAX_FEATURES];
+    float* m[NRX_MAX_FEATURES];
+    float* v[NRX_MAX_FEATURES];
+    const int64_t* keys;        // (table << 40) | row, one per unique row
+    const float* grads;         // [n, dim]
+    const int64_t* n_dev;       // optional: actual count on the device
+    int64_t max_n;
+    int32_t n_tables;
+    int32_t dim;
+    float step_size, one_minus_b1, one_minus_b2, eps, decay;
+};
+static_assert(sizeof(SparseAdamArgs) <= 3584, "kernarg budget");
+
+template <int QLOG2>
+__global__ __launch_bounds__(NRX_BLOCK) void sparse_adam_kernel(const SparseAdamArgs args_in_kernarg) {
+    const NRX_CONST SparseAdamArgs* a = nrx_kernarg<SparseAdamArgs>();
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    const int q = threadIdx.x & (Q - 1);
+    const int64_t u = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
+    if (u >= a->max_n) return;
+    if (a->n_dev != nullptr && u >= nrx_gconst<int64_t>(a->n_dev)[0]) return;
+    const int64_t key = nrx_gconst<int64_t>(a->keys)[u];
+    const int64_t t = key >> 40, row = key & ((1ll << 40) - 1);
+    if (row == 0 || t < 0 || t >= a->n_tables) return;          // padding row / filler keys of a merged list
+    const int D = a->dim;
+    float* p = a->table[t] + row * D;
+    float* pm = a->m[t] + row * D;
+    float* pv = a->v[t] + row * D;
+    const float* g = a->grads + u * (int64_t)D;
+    for (int k = q * 4; k < D; k += 4 * Q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (k + j < D) {
+                const float gj = g[k + j];
+                const float m_old = pm[k + j], v_old = pv[k + j];
+                const float m_new = m_old + (gj - m_old) * a->one_minus_b1;          // torch's update order
+                const float v_new = v_old + (gj * gj - v_old) * a->one_minus_b2;
+                pm[k + j] = m_new;
+                pv[k + j] = v_new;
+                float w = p[k + j];
+                w -= w * a->decay;
+                p[k + j] = w - a->step_size * (m_new / (sqrtf(v_new) + a->eps));
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int nrx_sparse_adam_step(float* const* tables, float* const* exp_avg, float* const* exp_avg_sq, int32_t n_tables,
+                                    int32_t dim, const int64_t* uniq_keys, const float* grads, int64_t n_unique,
+                                    const int64_t* n_unique_dev, float step_size, float beta1, float beta2, float eps,
+                                    float lr_times_weight_decay, void* stream) {
+    NRX_REQUIRE(n_tables >= 1 && n_tables <= NRX_MAX_FEATURES && dim >= 1 && n_unique >= 0, "nrx_sparse_adam_step: bad argument");
+    if (n_unique == 0) return NRX_OK;
+    NRX_REQUIRE(tables && exp_avg && exp_avg_sq && uniq_keys && grads, "nrx_sparse_adam_step: null buffer");
+    SparseAdamArgs a;
+    for (int t = 0; t < n_tables; ++t) {
+        NRX_REQUIRE(tables[t] && exp_avg[t] && exp_avg_sq[t], "nrx_sparse_adam_step: table %d: null pointer", t);
+        a.table[t] = tables[t];
+        a.m[t] = exp_avg[t];
+        a.v[t] = exp_avg_sq[t];
+    }
+    a.keys = uniq_keys;
+    a.grads = grads;
+    a.n_dev = n_unique_dev;
+    a.max_n = n_unique;
+    a.n_tables = n_tables;
+    a.dim = dim;
+    a.step_size = step_size;
+    a.one_minus_b1 = 1.0f - beta1;
+    a.one_minus_b2 = 1.0f - beta2;
+    a.eps = eps;
+    a.decay = lr_times_weight_decay;
+    int ql = 0;
+    while ((4 << ql) < dim && ql < 6) ++ql;
+    const int tb = NRX_BLOCK >> ql;
+    const unsigned grid = (unsigned)((n_unique + tb - 1) / tb);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (ql) {
+        case 0: hipLaunchKernelGGL(sparse_adam_kernel<0>, dim3(grid), dim3(NRX_BLOCK), 0, st, a); break;
+        case 1: hipLaunchKernelGGL(sparse_adam_kernel<1>, dim3(grid), dim3(NRX_BLOCK), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(sparse_adam_kernel<2>, dim3(grid), dim3(NRX_BLOCK), 0, st, a); break;
+        case 3: hipLaunchKernelGGL(sparse_adam_kernel<3>, dim3(grid), dim3(NRX_BLOCK), 0, st, a); break;
+        case 4: hipLaunchKernelGGL(sparse_adam_kernel<4>, dim3(grid), dim3(NRX_BLOCK), 0, st, a); break;
+        case 5: hipLaunchKernelGGL(sparse_adam_kernel<5>, dim3(grid), dim3(NRX_BLOCK), 0, st, a); break;
+        default: hipLaunchKernelGGL(sparse_adam_kernel<6>, dim3(grid), dim3(NRX_BLOCK), 0, st, a); break;
+    }
+    NRX_LAUNCH_CHECK("nrx_sparse_adam_step");
+    return NRX_OK;
+}

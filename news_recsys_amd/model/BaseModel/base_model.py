@@ -77,7 +77,11 @@ class BaseModel(LightningModule):
         self.share_emb_table_features: Dict[str, str] = dict(e.get("share_emb_table_features") or {})
         # new optional key (default = reference behaviour: dense weight.grad): deterministic row-sparse
         # table gradients, for tables too large to zero-fill / dense-update every step
-        self.sparse_grad: bool = bool(e.get("sparse_grad", False))
+        # "fused": the same reduction stays on the device and optim.FusedSparseAdam updates the touched rows in
+        # one launch (no COO tensors, no host read per step)
+        sg = e.get("sparse_grad", False)
+        self.sparse_grad = "fused" if str(sg).lower() == "fused" else bool(sg)
+        self._sparse_sink = None
 
         self.dataset_cfg = self.config.get("dataset", {}) or {}
         self.train_hparams = self.config.get("train_hparams", {}) or {}
@@ -209,8 +213,12 @@ class BaseModel(LightningModule):
         tables = [self.embedding_tables[t].weight for t in table_names]
         inputs = [batch[s.name] for s in plan.slots]
         weights = [batch.get(f"{s.name}_mask") if s.kind == NRX_BAG_MASKED_MEAN else None for s in plan.slots]
-        out, wide, fmv = ops.embed_apply(plan, tables, inputs, weights, out_ld=out_ld, need_out=need_out,
-                                         sparse_grad=self.sparse_grad)
+        sg = self.sparse_grad
+        if sg == "fused":
+            if self._sparse_sink is None:
+                self._sparse_sink = ops.SparseGradSink()
+            sg = self._sparse_sink if torch.is_grad_enabled() else False
+        out, wide, fmv = ops.embed_apply(plan, tables, inputs, weights, out_ld=out_ld, need_out=need_out, sparse_grad=sg)
         return out, wide, fmv, list(dims), list(present)
 
     def get_embeddings_from_batch(self, batch: Dict[str, torch.Tensor], feature_names) -> Tuple[torch.Tensor, List[int], List[str]]:
@@ -312,7 +320,12 @@ class BaseModel(LightningModule):
             from ..model_utils.optim import SparseDenseAdam
             table_params = [e.weight for e in self.embedding_tables.values()]
             ids = {id(p) for p in table_params}
-            optimizer = SparseDenseAdam(table_params, [p for p in self.parameters() if id(p) not in ids], lr=hp.lr)
+            sink = None
+            if self.sparse_grad == "fused":
+                if self._sparse_sink is None:
+                    self._sparse_sink = ops.SparseGradSink()
+                sink = self._sparse_sink
+            optimizer = SparseDenseAdam(table_params, [p for p in self.parameters() if id(p) not in ids], lr=hp.lr, fused_sink=sink)
         else:
             optimizer = torch.optim.AdamW(self.parameters(), lr=hp.lr, betas=(0.9, 0.999))
         sched = CosinDecayLR(optimizer, lrs=[hp.lr, hp.min_lr], milestones=list(hp.lr_milestones))

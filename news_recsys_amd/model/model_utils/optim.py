@@ -5,23 +5,118 @@ The reference trains everything with one dense `AdamW(self.parameters())` (sort/
 row-sparse table grads the tables are updated by `torch.optim.SparseAdam` (moments touched only for the
 looked-up rows; no weight decay) and the dense parameters keep AdamW.  This wrapper presents both as
 one `Optimizer` so `configure_optimizers()` keeps its reference shape (one optimizer + one scheduler)."""
+import ctypes as C
+import math
+
 import torch
+
+from ... import _lib, ops
+
+
+class FusedSparseAdam:
+    """Adam(W) for the embedding tables, fused with the row-sparse backward.  The backward
+    leaves (unique (table,row) keys, summed row gradients, counts) on the device in an ops.SparseGradSink; step()
+    updates exactly those rows of weights and moments with one `nrx_sparse_adam_step` launch per group -- no
+    COO tensors, no host synchronisation, no traffic proportional to the table size.  Update rule =
+    torch.optim.SparseAdam (tested against it) + optional decoupled weight decay on the touched rows.
+    A table that received gradients from several backward groups in one step (DSSM's towers share the news
+    table) gets them merged first, so the step is still ONE Adam update per row.  Tables are identified by tensor
+    identity; their moments are created (zeros) the first time a table shows up in the sink."""
+
+    def __init__(self, sink: "ops.SparseGradSink", lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.sink, self.lr, self.betas, self.eps, self.weight_decay = sink, lr, betas, eps, weight_decay
+        self.t = 0
+        self.tables = []         # every table seen so far; position = the table's index in the optimizer's key space
+        self._index = {}         # id(tensor) -> position
+        self.moments = []        # (exp_avg, exp_avg_sq) per table
+
+    def _register(self, t: torch.Tensor) -> int:
+        i = self._index.get(id(t))
+        if i is None:
+            i = len(self.tables)
+            self._index[id(t)] = i
+            self.tables.append(t)
+            self.moments.append((torch.zeros_like(t), torch.zeros_like(t)))
+        return i
+
+    def _global_keys(self, e):
+        """Re-express an entry's keys (table index = position in that launch's table list) in the optimizer's own
+        table numbering; filler past the device-side count becomes INT64_MAX (ignored by the kernel)."""
+        BIG = torch.iinfo(torch.int64).max
+        MASK = (1 << 40) - 1
+        dev = e["uniq"].device
+        gmap = torch.tensor([self._register(t) for t in e["tables"]], dtype=torch.int64, device=dev)
+        k = e["uniq"]
+        valid = torch.arange(e["cap"], device=dev) < e["counts"][0]
+        local = torch.where(valid, k >> 40, torch.zeros_like(k))
+        return torch.where(valid, (gmap[local] << 40) | (k & MASK), torch.full_like(k, BIG))
+
+    @staticmethod
+    def _merge(keys, vals):
+        """(keys, values) lists with possibly repeated (table,row) keys -> one entry per key.  Device-only torch
+        ops; INT64_MAX filler sorts last and stays filler."""
+        BIG = torch.iinfo(torch.int64).max
+        skeys, order = torch.sort(keys, stable=True)
+        head = torch.ones_like(skeys, dtype=torch.bool)
+        head[1:] = skeys[1:] != skeys[:-1]
+        seg = torch.cumsum(head, 0) - 1
+        merged_vals = torch.zeros_like(vals).index_add_(0, seg, vals[order])
+        merged_keys = torch.full_like(skeys, BIG)
+        merged_keys[seg] = skeys
+        return merged_keys, merged_vals
+
+    @torch.no_grad()
+    def step(self):
+        if not self.sink.pending:
+            return
+        lib = _lib.load()
+        self.t += 1
+        b1, b2 = self.betas
+        step_size = self.lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
+        by_dim = {}
+        for e in self.sink.pending:
+            by_dim.setdefault(e["dim"], []).append((self._global_keys(e), e["values"]))
+        n = len(self.tables)
+        if n > _lib.NRX_MAX_FEATURES:
+            raise NotImplementedError("FusedSparseAdam: more than 64 distinct tables")
+        tp = (C.c_void_p * n)(*[t.data_ptr() for t in self.tables])
+        mp = (C.c_void_p * n)(*[m.data_ptr() for m, _ in self.moments])
+        vp = (C.c_void_p * n)(*[v.data_ptr() for _, v in self.moments])
+        for dim, lst in by_dim.items():
+            if len(lst) == 1:
+                keys, vals = lst[0]
+            else:       # one table fed by several backward groups (DSSM's towers share the news table): ONE update per row
+                keys, vals = self._merge(torch.cat([k for k, _ in lst]), torch.cat([v for _, v in lst]))
+            dev = keys.device
+            ops.check(lib.nrx_sparse_adam_step(tp, mp, vp, n, dim, keys.data_ptr(), vals.data_ptr(), keys.numel(), None,
+                                               step_size, b1, b2, self.eps, self.lr * self.weight_decay,
+                                               torch.cuda.current_stream(dev).cuda_stream), "nrx_sparse_adam_step")
+        self.sink.clear()
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.sink.clear()
 
 
 class SparseDenseAdam(torch.optim.Optimizer):
-    def __init__(self, sparse_params, dense_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, sparse_params, dense_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, fused_sink=None):
+        """fused_sink: an ops.SparseGradSink -> the tables are updated by FusedSparseAdam from the sink instead of
+        torch.optim.SparseAdam from COO .grad tensors."""
         sparse_params, dense_params = list(sparse_params), list(dense_params)
         groups = [{"params": sparse_params, "sparse": True}]
         if dense_params:
             groups.append({"params": dense_params, "sparse": False})
         super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._sparse = torch.optim.SparseAdam(sparse_params, lr=lr, betas=betas, eps=eps)
+        self._sparse = (FusedSparseAdam(fused_sink, lr=lr, betas=betas, eps=eps) if fused_sink is not None
+                        else torch.optim.SparseAdam(sparse_params, lr=lr, betas=betas, eps=eps))
         self._dense = torch.optim.AdamW(dense_params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay) if dense_params else None
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         for g in self.param_groups:           # a scheduler edits self.param_groups: forward the lr
+            if g["sparse"] and isinstance(self._sparse, FusedSparseAdam):
+                self._sparse.lr = g["lr"]
+                continue
             for inner in ((self._sparse,) if g["sparse"] else ((self._dense,) if self._dense else ())):
                 for ig in inner.param_groups:
                     ig["lr"] = g["lr"]

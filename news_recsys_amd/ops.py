@@ -189,7 +189,9 @@ class _EmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan: EmbedPlan, inputs, weights, out_ld, need_out, sparse_grad, *tables):
         lib = _lib.load()
+        ctx.sink = sparse_grad if isinstance(sparse_grad, SparseGradSink) else None
         ctx.sparse_grad = bool(sparse_grad)
+        ctx.tables = list(tables) if ctx.sink is not None else None
         B, ins, ws = _prep_inputs(plan, tables, inputs, weights)
         dev = tables[0].device if tables else ins[0].device
         ld = int(out_ld) if out_ld else plan.out_width
@@ -255,6 +257,9 @@ class _EmbedFn(torch.autograd.Function):
                                  g_out.data_ptr(), ld, acc, stream), "nrx_fm_bwd")
         if g_wide is not None:
             g_wide = _f32c(g_wide, "grad of wide_x")
+        if ctx.sink is not None:
+            _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream)      # results go to the sink, not to .grad
+            return (None,) * (6 + n_tables)
         if ctx.sparse_grad:
             return (None, None, None, None, None, None, *_sorted_sparse_grads(ctx, lib, g_out, g_wide, stream))
         grads = [torch.zeros(shape, dtype=torch.float32, device=d) for shape, d in ctx.table_meta]
@@ -267,6 +272,19 @@ class _EmbedFn(torch.autograd.Function):
                 check(lib.nrx_embed_bwd(arr, hi - lo, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, stream),
                       "nrx_embed_bwd")
         return (None, None, None, None, None, None, *grads)
+
+
+class SparseGradSink:
+    """Where the row-sparse backward leaves its result when the optimizer is fused (optim.FusedSparseAdam):
+    per launch group the device-resident (unique keys, row gradients, counts) of nrx_sparse_plan /
+    nrx_embed_bwd_sorted plus the table tensors the keys index -- no COO tensors, no host synchronisation.
+    Pass the sink as `sparse_grad=` to embed_apply; the optimizer drains it in step()."""
+
+    def __init__(self):
+        self.pending = []       # dicts: tables (list of tensors, index = table id in the keys), dim, uniq, values, counts, cap
+
+    def clear(self):
+        self.pending.clear()
 
 
 SPARSE_BWD_SYNC_FREE = False   # True: size the reduction for the worst case and read the count on the device
@@ -333,6 +351,13 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream):
             # n_unique_dev form of the call, which leaves the host work exposed after the GPU is done).
             sub = EmbedPlan([plan.slots[i] for i in fs], out_width=plan.out_width, wide_width=plan.wide_width)
             arr = _fill_features(sub, 0, n, [None] * n_tables, ids, [ctx.ws[i] for i in fs], table_ptrs=[0] * n_tables, fm=False)
+            if ctx.sink is not None:
+                values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
+                check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
+                                               seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), values.data_ptr(), stream),
+                      "nrx_embed_bwd_sorted")
+                ctx.sink.pending.append(dict(tables=ctx.tables, dim=D, uniq=uniq, values=values, counts=counts, cap=total))
+                continue
             if SPARSE_BWD_SYNC_FREE:
                 values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
                 check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
@@ -362,11 +387,12 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream):
 
 def embed_apply(plan: EmbedPlan, tables: Sequence[torch.Tensor], inputs: Sequence[torch.Tensor],
                 weights: Sequence[Optional[torch.Tensor]], out_ld: Optional[int] = None, need_out: bool = True,
-                sparse_grad: bool = False):
+                sparse_grad=False):
     """Run the fused gather(+pool)->concat.  Returns (out[B, out_ld or out_width] | None,
     wide[B, wide_width] | None, fm[B] | None).  Differentiable w.r.t. `tables`: dense grads by default
     (what the reference's nn.Embedding(sparse=False) produces), or -- sparse_grad=True -- deterministic
-    row-sparse COO grads (sorted segmented reduction; no full-table zero-fill)."""
+    row-sparse COO grads (sorted segmented reduction; no full-table zero-fill), or -- sparse_grad=a
+    SparseGradSink -- the same reduction left on the device for optim.FusedSparseAdam (tables get no .grad)."""
     if not need_out and not (plan.use_fm or plan.wide_width):
         raise ValueError("need_out=False only makes sense with an FM or wide output")
     return _EmbedFn.apply(plan, list(inputs), list(weights), out_ld, need_out, sparse_grad, *tables)

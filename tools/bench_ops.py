@@ -164,3 +164,31 @@ if want("eager"):
         us_e = timeit(eager_c4, steps=20)
         us_f = timeit(prep4.run, steps=50)
     print(f"C4 tower input (id + masked-mean history L=50 + id),  PyTorch-ROCm eager: {us_e:8.1f} us   fused HIP launch: {us_f:7.1f} us   x{us_e / us_f:5.1f}", flush=True)
+
+if want("train_opt"):
+    # C2 tables: forward + backward + OPTIMIZER step, three ways.  (a) the reference's semantics: dense table grads +
+    # dense AdamW over every row; (b) row-sparse COO grads + torch.optim.SparseAdam; (c) the fused path: sorted
+    # reduction left on the device + nrx_sparse_adam_step (no COO tensors, no host read).
+    from news_recsys_amd.model.model_utils.optim import FusedSparseAdam
+    F, D, rows = 26, 16, 1_000_000
+    gen = torch.Generator(device=dev).manual_seed(1)
+    plan = ops.EmbedPlan([ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, i * D, fm_field=1) for i in range(F)], out_width=F * D, use_fm=True)
+    ids = [torch.randint(1, rows, (B,), device=dev, generator=gen) for _ in range(F)]
+    up = torch.randn(B, F * D, device=dev, generator=gen) * 1e-3
+    for mode in ("dense+AdamW", "coo+SparseAdam", "fused"):
+        tables = [torch.randn(rows, D, device=dev).requires_grad_(True) for _ in range(F)]
+        if mode == "dense+AdamW":
+            opt = torch.optim.AdamW(tables, lr=1e-3); sg = False
+        elif mode == "coo+SparseAdam":
+            opt = torch.optim.SparseAdam(tables, lr=1e-3); sg = True
+        else:
+            sg = ops.SparseGradSink(); opt = FusedSparseAdam(sg, lr=1e-3)
+        def step():
+            out, _, fm = ops.embed_apply(plan, tables, ids, [None] * F, sparse_grad=sg)
+            ((out * up).sum() + fm.sum()).backward()
+            opt.step()
+            if mode != "fused": opt.zero_grad(set_to_none=True)
+        us = timeit(step, steps=10)
+        print(f"C2 embed+FM fwd+bwd+optimizer, {mode:15s}: {us:9.1f} us  -> {B / us:7.2f} M impressions/s", flush=True)
+        del tables, opt
+        torch.cuda.empty_cache()
