@@ -223,36 +223,81 @@ struct SparseAdamArgs {
 };
 static_assert(sizeof(SparseAdamArgs) <= 3584, "kernarg budget");
 
-template <int QLOG2>
+__device__ __forceinline__ float adam_elem(float g, float& m, float& v, float w, const NRX_CONST SparseAdamArgs* a) {
+    m = m + (g - m) * a->one_minus_b1;          // torch's update order
+    v = v + (g * g - v) * a->one_minus_b2;
+    w -= w * a->decay;
+    return w - a->step_size * (m / (sqrtf(v) + a->eps));
+}
+
+// VEC: dim % 4 == 0 and 16-byte aligned rows -> one float4 per lane per array; R rows are in flight per lane
+// group (key loads, then 4R independent row loads) -- the update is a random 3-array read-modify-write, HBM-bound.
+template <int QLOG2, bool VEC>
 __global__ __launch_bounds__(NRX_BLOCK) void sparse_adam_kernel(const SparseAdamArgs args_in_kernarg) {
     const NRX_CONST SparseAdamArgs* a = nrx_kernarg<SparseAdamArgs>();
     constexpr int Q = 1 << QLOG2;
     constexpr int TB = NRX_BLOCK / Q;
+    constexpr int R = 4;
     const int q = threadIdx.x & (Q - 1);
-    const int64_t u = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
-    if (u >= a->max_n) return;
-    if (a->n_dev != nullptr && u >= nrx_gconst<int64_t>(a->n_dev)[0]) return;
-    const int64_t key = nrx_gconst<int64_t>(a->keys)[u];
-    const int64_t t = key >> 40, row = key & ((1ll << 40) - 1);
-    if (row == 0 || t < 0 || t >= a->n_tables) return;          // padding row / filler keys of a merged list
     const int D = a->dim;
-    float* p = a->table[t] + row * D;
-    float* pm = a->m[t] + row * D;
-    float* pv = a->v[t] + row * D;
-    const float* g = a->grads + u * (int64_t)D;
-    for (int k = q * 4; k < D; k += 4 * Q) {
+    int64_t n = a->max_n;
+    if (a->n_dev != nullptr) {
+        const int64_t nd = nrx_gconst<int64_t>(a->n_dev)[0];
+        n = nd < n ? nd : n;
+    }
+    const int64_t u0 = ((int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2)) * R;
+    if (u0 >= n) return;
+    int64_t key[R];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (k + j < D) {
-                const float gj = g[k + j];
-                const float m_old = pm[k + j], v_old = pv[k + j];
-                const float m_new = m_old + (gj - m_old) * a->one_minus_b1;          // torch's update order
-                const float v_new = v_old + (gj * gj - v_old) * a->one_minus_b2;
-                pm[k + j] = m_new;
-                pv[k + j] = v_new;
-                float w = p[k + j];
-                w -= w * a->decay;
-                p[k + j] = w - a->step_size * (m_new / (sqrtf(v_new) + a->eps));
+    for (int r = 0; r < R; ++r) key[r] = u0 + r < n ? nrx_gconst<int64_t>(a->keys)[u0 + r] : -1;
+    float* p[R];
+    float* pm[R];
+    float* pv[R];
+    bool on[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t t = key[r] >> 40, row = key[r] & ((1ll << 40) - 1);
+        on[r] = key[r] >= 0 && row != 0 && t < a->n_tables;        // padding row / filler keys of a merged list
+        const int64_t tc = on[r] ? t : 0, rc = on[r] ? row : 0;
+        p[r] = a->table[tc] + rc * D;
+        pm[r] = a->m[tc] + rc * D;
+        pv[r] = a->v[tc] + rc * D;
+    }
+    if (VEC) {
+        for (int k = q * 4; k < D; k += 4 * Q) {
+            float4 g[R], w[R], m[R], v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                g[r] = nrx_ldg4(a->grads + (u0 + (on[r] ? r : 0)) * (int64_t)D + k, 0);
+                w[r] = nrx_ldg4(p[r] + k, 0);
+                m[r] = nrx_ldg4(pm[r] + k, 0);
+                v[r] = nrx_ldg4(pv[r] + k, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (on[r]) {
+                    float4 o;
+                    o.x = adam_elem(g[r].x, m[r].x, v[r].x, w[r].x, a);
+                    o.y = adam_elem(g[r].y, m[r].y, v[r].y, w[r].y, a);
+                    o.z = adam_elem(g[r].z, m[r].z, v[r].z, w[r].z, a);
+                    o.w = adam_elem(g[r].w, m[r].w, v[r].w, w[r].w, a);
+                    nrx_stg4(pm[r] + k, 0, m[r]);
+                    nrx_stg4(pv[r] + k, 0, v[r]);
+                    nrx_stg4(p[r] + k, 0, o);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (!on[r]) continue;
+            const float* g = a->grads + (u0 + r) * (int64_t)D;
+            for (int k = q; k < D; k += Q) {
+                float m = pm[r][k], v = pv[r][k];
+                const float o = adam_elem(g[k], m, v, p[r][k], a);
+                pm[r][k] = m;
+                pv[r][k] = v;
+                p[r][k] = o;
             }
         }
     }
@@ -287,18 +332,19 @@ extern "C" int nrx_sparse_adam_step(float* const* tables, float* const* exp_avg,
     a.decay = lr_times_weight_decay;
     int ql = 0;
     while ((4 << ql) < dim && ql < 6) ++ql;
+    bool vec = (dim & 3) == 0 && nrx_aligned16(grads);
+    for (int t = 0; t < n_tables && vec; ++t) vec = nrx_aligned16(tables[t]) && nrx_aligned16(exp_avg[t]) && nrx_aligned16(exp_avg_sq[t]);
     const int tb = NRX_BLOCK >> ql;
-    const unsigned grid = (unsigned)((n_unique + tb - 1) / tb);
+    const int64_t groups = (n_unique + 3) / 4;                   // 4 rows per lane group
+    const unsigned grid = (unsigned)((groups + tb - 1) / tb);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define NRX_SA(QL_) if (vec) hipLaunchKernelGGL((sparse_adam_kernel<QL_, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+                    else hipLaunchKernelGGL((sparse_adam_kernel<QL_, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a)
     switch (ql) {
-        case 0: hipLaunchKernelGGL(sparse_adam_kernel<0>, dim3(grid), dim3(NRX_BLOCK), 0, st, a); break;
-        case 1: hipLaunchKernelGGL(sparse_adam_kernel<1>, dim3(grid), dim3(NRX_BLOCK), 0, st, a); break;
-        case 2: hipLaunchKernelGGL(sparse_adam_kernel<2>, dim3(grid), dim3(NRX_BLOCK), 0, st, a); break;
-        case 3: hipLaunchKernelGGL(sparse_adam_kernel<3>, dim3(grid), dim3(NRX_BLOCK), 0, st, a); break;
-        case 4: hipLaunchKernelGGL(sparse_adam_kernel<4>, dim3(grid), dim3(NRX_BLOCK), 0, st, a); break;
-        case 5: hipLaunchKernelGGL(sparse_adam_kernel<5>, dim3(grid), dim3(NRX_BLOCK), 0, st, a); break;
-        default: hipLaunchKernelGGL(sparse_adam_kernel<6>, dim3(grid), dim3(NRX_BLOCK), 0, st, a); break;
+        case 0: NRX_SA(0); break; case 1: NRX_SA(1); break; case 2: NRX_SA(2); break; case 3: NRX_SA(3); break;
+        case 4: NRX_SA(4); break; case 5: NRX_SA(5); break; default: NRX_SA(6); break;
     }
+#undef NRX_SA
     NRX_LAUNCH_CHECK("nrx_sparse_adam_step");
     return NRX_OK;
 }
