@@ -144,11 +144,13 @@ NRX_API int nrx_sparse_plan(const void* const* ids, const int64_t* lens, const i
  * -- torch.optim.SparseAdam's update (plus optional decoupled decay of the touched rows); rows that were not
  * looked up do not move, row 0 (padding) never moves.  This replaces, for the embedding tables, the reference's
  * dense AdamW over every row (src/model/sort/deep/model.py:54-65) -- a documented deviation, see DESIGN.md.
- * n_unique_dev (optional, device int64[1]): actual count; n_unique is then an upper bound sizing the launch. */
+ * n_unique_dev (optional, device int64[1]): actual count; n_unique is then an upper bound sizing the launch.
+ * step_size_dev (optional, device float[1]): overrides step_size with a value read on the device, so a training
+ * loop captured in a hipGraph can advance the bias correction between replays. */
 NRX_API int nrx_sparse_adam_step(float* const* tables, float* const* exp_avg, float* const* exp_avg_sq, int32_t n_tables,
                          int32_t dim, const int64_t* uniq_keys, const float* grads, int64_t n_unique,
-                         const int64_t* n_unique_dev, float step_size, float beta1, float beta2, float eps,
-                         float lr_times_weight_decay, void* stream);
+                         const int64_t* n_unique_dev, float step_size, const float* step_size_dev, float beta1,
+                         float beta2, float eps, float lr_times_weight_decay, void* stream);
 
 /* Composite sort keys for nrx_embed_bwd_sorted over SEVERAL tables at once: for the flat,
  * feature-major lookup list of n_feats features (ids[f]: lens[f] elements; HOST pointer arrays),

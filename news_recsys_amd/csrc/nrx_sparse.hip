@@ -220,14 +220,15 @@ struct SparseAdamArgs {
     int32_t n_tables;
     int32_t dim;
     float step_size, one_minus_b1, one_minus_b2, eps, decay;
+    const float* step_size_dev;   // optional: step size read on the device (graph-captured training loops)
 };
 static_assert(sizeof(SparseAdamArgs) <= 3584, "kernarg budget");
 
-__device__ __forceinline__ float adam_elem(float g, float& m, float& v, float w, const NRX_CONST SparseAdamArgs* a) {
+__device__ __forceinline__ float adam_elem(float g, float& m, float& v, float w, float step_size, const NRX_CONST SparseAdamArgs* a) {
     m = m + (g - m) * a->one_minus_b1;          // torch's update order
     v = v + (g * g - v) * a->one_minus_b2;
     w -= w * a->decay;
-    return w - a->step_size * (m / (sqrtf(v) + a->eps));
+    return w - step_size * (m / (sqrtf(v) + a->eps));
 }
 
 // VEC: dim % 4 == 0 and 16-byte aligned rows -> one float4 per lane per array; R rows are in flight per lane
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void sparse_adam_kernel(const SparseAdam
     constexpr int R = 4;
     const int q = threadIdx.x & (Q - 1);
     const int D = a->dim;
+    const float ss = a->step_size_dev != nullptr ? nrx_gconst<float>(a->step_size_dev)[0] : a->step_size;
     int64_t n = a->max_n;
     if (a->n_dev != nullptr) {
         const int64_t nd = nrx_gconst<int64_t>(a->n_dev)[0];
@@ -277,10 +279,10 @@ __global__ __launch_bounds__(NRX_BLOCK) void sparse_adam_kernel(const SparseAdam
             for (int r = 0; r < R; ++r) {
                 if (on[r]) {
                     float4 o;
-                    o.x = adam_elem(g[r].x, m[r].x, v[r].x, w[r].x, a);
-                    o.y = adam_elem(g[r].y, m[r].y, v[r].y, w[r].y, a);
-                    o.z = adam_elem(g[r].z, m[r].z, v[r].z, w[r].z, a);
-                    o.w = adam_elem(g[r].w, m[r].w, v[r].w, w[r].w, a);
+                    o.x = adam_elem(g[r].x, m[r].x, v[r].x, w[r].x, ss, a);
+                    o.y = adam_elem(g[r].y, m[r].y, v[r].y, w[r].y, ss, a);
+                    o.z = adam_elem(g[r].z, m[r].z, v[r].z, w[r].z, ss, a);
+                    o.w = adam_elem(g[r].w, m[r].w, v[r].w, w[r].w, ss, a);
                     nrx_stg4(pm[r] + k, 0, m[r]);
                     nrx_stg4(pv[r] + k, 0, v[r]);
                     nrx_stg4(p[r] + k, 0, o);
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void sparse_adam_kernel(const SparseAdam
             const float* g = a->grads + (u0 + r) * (int64_t)D;
             for (int k = q; k < D; k += Q) {
                 float m = pm[r][k], v = pv[r][k];
-                const float o = adam_elem(g[k], m, v, p[r][k], a);
+                const float o = adam_elem(g[k], m, v, p[r][k], ss, a);
                 pm[r][k] = m;
                 pv[r][k] = v;
                 p[r][k] = o;
@@ -307,8 +309,8 @@ __global__ __launch_bounds__(NRX_BLOCK) void sparse_adam_kernel(const SparseAdam
 
 extern "C" int nrx_sparse_adam_step(float* const* tables, float* const* exp_avg, float* const* exp_avg_sq, int32_t n_tables,
                                     int32_t dim, const int64_t* uniq_keys, const float* grads, int64_t n_unique,
-                                    const int64_t* n_unique_dev, float step_size, float beta1, float beta2, float eps,
-                                    float lr_times_weight_decay, void* stream) {
+                                    const int64_t* n_unique_dev, float step_size, const float* step_size_dev, float beta1,
+                                    float beta2, float eps, float lr_times_weight_decay, void* stream) {
     NRX_REQUIRE(n_tables >= 1 && n_tables <= NRX_MAX_FEATURES && dim >= 1 && n_unique >= 0, "nrx_sparse_adam_step: bad argument");
     if (n_unique == 0) return NRX_OK;
     NRX_REQUIRE(tables && exp_avg && exp_avg_sq && uniq_keys && grads, "nrx_sparse_adam_step: null buffer");
@@ -326,6 +328,7 @@ extern "C" int nrx_sparse_adam_step(float* const* tables, float* const* exp_avg,
     a.n_tables = n_tables;
     a.dim = dim;
     a.step_size = step_size;
+    a.step_size_dev = step_size_dev;
     a.one_minus_b1 = 1.0f - beta1;
     a.one_minus_b2 = 1.0f - beta2;
     a.eps = eps;

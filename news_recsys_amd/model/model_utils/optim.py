@@ -23,12 +23,18 @@ class FusedSparseAdam:
     table) gets them merged first, so the step is still ONE Adam update per row.  Tables are identified by tensor
     identity; their moments are created (zeros) the first time a table shows up in the sink."""
 
-    def __init__(self, sink: "ops.SparseGradSink", lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, sink: "ops.SparseGradSink", lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
+        """capturable=True keeps the step counter and the bias-corrected step size on the device (like
+        torch.optim.Adam(capturable=True)) so step() can be captured in a HIP graph (graph.GraphedStep); lr is
+        then fixed at capture time."""
         self.sink, self.lr, self.betas, self.eps, self.weight_decay = sink, lr, betas, eps, weight_decay
+        self.capturable = bool(capturable)
+        self._t_dev = None
         self.t = 0
         self.tables = []         # every table seen so far; position = the table's index in the optimizer's key space
         self._index = {}         # id(tensor) -> position
         self.moments = []        # (exp_avg, exp_avg_sq) per table
+        self._gmaps = {}         # table-list identity -> device map (launch-local table index -> position)
 
     def _register(self, t: torch.Tensor) -> int:
         i = self._index.get(id(t))
@@ -45,7 +51,11 @@ class FusedSparseAdam:
         BIG = torch.iinfo(torch.int64).max
         MASK = (1 << 40) - 1
         dev = e["uniq"].device
-        gmap = torch.tensor([self._register(t) for t in e["tables"]], dtype=torch.int64, device=dev)
+        ck = tuple(id(t) for t in e["tables"])
+        gmap = self._gmaps.get(ck)
+        if gmap is None:        # built once per table list (a host-to-device copy: must not happen inside a graph capture)
+            gmap = torch.tensor([self._register(t) for t in e["tables"]], dtype=torch.int64, device=dev)
+            self._gmaps[ck] = gmap
         k = e["uniq"]
         valid = torch.arange(e["cap"], device=dev) < e["counts"][0]
         local = torch.where(valid, k >> 40, torch.zeros_like(k))
@@ -73,6 +83,13 @@ class FusedSparseAdam:
         self.t += 1
         b1, b2 = self.betas
         step_size = self.lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
+        ss_dev = None
+        if self.capturable:
+            dev = self.sink.pending[0]["uniq"].device
+            if self._t_dev is None:
+                self._t_dev = torch.zeros((), dtype=torch.float64, device=dev)
+            self._t_dev += 1
+            ss_dev = (self.lr * torch.sqrt(1.0 - b2 ** self._t_dev) / (1.0 - b1 ** self._t_dev)).to(torch.float32).reshape(1)
         by_dim = {}
         for e in self.sink.pending:
             by_dim.setdefault(e["dim"], []).append((self._global_keys(e), e["values"]))
@@ -89,7 +106,8 @@ class FusedSparseAdam:
                 keys, vals = self._merge(torch.cat([k for k, _ in lst]), torch.cat([v for _, v in lst]))
             dev = keys.device
             ops.check(lib.nrx_sparse_adam_step(tp, mp, vp, n, dim, keys.data_ptr(), vals.data_ptr(), keys.numel(), None,
-                                               step_size, b1, b2, self.eps, self.lr * self.weight_decay,
+                                               step_size, ss_dev.data_ptr() if ss_dev is not None else None, b1, b2, self.eps,
+                                               self.lr * self.weight_decay,
                                                torch.cuda.current_stream(dev).cuda_stream), "nrx_sparse_adam_step")
         self.sink.clear()
 
@@ -98,7 +116,8 @@ class FusedSparseAdam:
 
 
 class SparseDenseAdam(torch.optim.Optimizer):
-    def __init__(self, sparse_params, dense_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, fused_sink=None):
+    def __init__(self, sparse_params, dense_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, fused_sink=None,
+                 capturable=False):
         """fused_sink: an ops.SparseGradSink -> the tables are updated by FusedSparseAdam from the sink instead of
         torch.optim.SparseAdam from COO .grad tensors."""
         sparse_params, dense_params = list(sparse_params), list(dense_params)
@@ -106,9 +125,10 @@ class SparseDenseAdam(torch.optim.Optimizer):
         if dense_params:
             groups.append({"params": dense_params, "sparse": False})
         super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._sparse = (FusedSparseAdam(fused_sink, lr=lr, betas=betas, eps=eps) if fused_sink is not None
+        self._sparse = (FusedSparseAdam(fused_sink, lr=lr, betas=betas, eps=eps, capturable=capturable) if fused_sink is not None
                         else torch.optim.SparseAdam(sparse_params, lr=lr, betas=betas, eps=eps))
-        self._dense = torch.optim.AdamW(dense_params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay) if dense_params else None
+        self._dense = (torch.optim.AdamW(dense_params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable)
+                       if dense_params else None)
 
     @torch.no_grad()
     def step(self, closure=None):

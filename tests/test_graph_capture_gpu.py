@@ -70,3 +70,57 @@ def test_graphed_training_step_matches_eager():
         torch.testing.assert_close(p, q, rtol=0, atol=5e-6)
     with pytest.raises(ValueError):
         gs(_batch(m_e, 128, gen))                               # a different batch shape cannot be replayed
+
+
+def test_graphed_fused_sparse_training_step_matches_eager():
+    """The fused row-sparse path (sorted backward left on the device + nrx_sparse_adam_step with a device-side step
+    size) is capturable too: replaying the graph == running the same step eagerly."""
+    import yaml
+    from news_recsys_amd import ops
+    from news_recsys_amd.graph import GraphedStep
+    from news_recsys_amd.model.model_utils.optim import SparseDenseAdam
+    from news_recsys_amd.model.sort.deep.model import Deep
+    cfg = os.path.join(CONFIGS, "cf_array_small.yaml")
+    torch.manual_seed(5)
+
+    def build():
+        m = Deep(cfg).to(DEV)
+        m.sparse_grad = "fused"
+        m._sparse_sink = ops.SparseGradSink()
+        tabs = [e.weight for e in m.embedding_tables.values()]
+        ids = {id(p) for p in tabs}
+        opt = SparseDenseAdam(tabs, [p for p in m.parameters() if id(p) not in ids], lr=1e-2, fused_sink=m._sparse_sink, capturable=True)
+        return m, opt
+
+    m_e, opt_e = build()
+    m_g, opt_g = build()
+    m_g.load_state_dict(m_e.state_dict())
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    batches = [_batch(m_e, 256, gen) for _ in range(5)]
+
+    def make_step(m, opt):
+        def step(b):
+            opt.zero_grad(set_to_none=False)
+            loss = F.binary_cross_entropy(m(b).view(-1), b["label"][:, 0])
+            loss.backward()
+            opt.step()
+            return loss
+        return step
+
+    mode_before = ops._INDEX_CHECK
+    ops.set_index_check("off")
+    try:
+        # identical histories: GraphedStep runs its 2 warm-up steps eagerly on m_g (the capture itself only records),
+        # so m_e takes the same 2 eager steps first
+        gs = GraphedStep(make_step(m_g, opt_g), batches[0], warmup=2)
+        step_e = make_step(m_e, opt_e)
+        for _ in range(2):
+            step_e(batches[0])
+        for b in batches:
+            le = step_e(b).item()
+            lg = gs(b).item()
+            assert abs(le - lg) <= 2e-5 * max(1.0, abs(le)), (le, lg)
+    finally:
+        ops.set_index_check(mode_before)
+    for p, q in zip(m_e.parameters(), m_g.parameters()):
+        torch.testing.assert_close(p, q, rtol=1e-4, atol=2e-5)
