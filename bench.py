@@ -310,6 +310,19 @@ def main():
         dt = t.item()
     kern_ms = e0.elapsed_time(e1) / args.steps
 
+    # per-step spread (outside the timed region, rank 0 / N=1 only): each step bracketed by its own pair of events
+    spread = None
+    if world == 1:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+        for i, (a, b) in enumerate(evs):
+            a.record()
+            step(args.warmup + args.steps + i)
+            b.record()
+        torch.cuda.synchronize()
+        us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+        spread = {"p10": us[6], "p50": us[32], "p90": us[57], "n": 64,
+                  "note": "single steps between their own HIP events (includes one launch gap each); not part of the timed region"}
+
     if hasattr(path, "overflowed") and path.overflowed():
         raise SystemExit("fixed-capacity exchange overflowed: rerun with a larger slack (ids too skewed)")
     planner = None
@@ -353,6 +366,7 @@ def main():
             "config": {"workload": desc, "batch_per_gpu": BATCH, "parallelism": parallelism,
                        "algorithmic_bytes_per_impression": bytes_per_impr, "id_pool": 8,
                        "output_buffer": "recycled each step (as the caching allocator does)"},
+            "step_us": spread,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "kernel_ms_mean": kern_ms, "algorithmic_bytes_per_launch": bytes_per_impr * BATCH,
