@@ -102,8 +102,22 @@ __device__ __forceinline__ int64_t nrx_load_id(const void* p, int64_t i, bool is
     return is64 ? reinterpret_cast<const int64_t*>(p)[i] : (int64_t)reinterpret_cast<const int32_t*>(p)[i];
 }
 
+// Sum over the 64 lanes, result in every lane.  Data-parallel-primitive moves inside each row of 16 lanes (no
+// LDS round trips: __shfl_xor compiles to ds_bpermute_b32, ~100 cycles of latency per step, six steps per
+// reduction -- the DCN-v1 backward does five reductions per sample and was bound by them), then the four row
+// sums are read as scalars.  Fixed summation tree: ((xor 1, xor 2), half-row mirror, row mirror), (r0+r1)+(r2+r3).
+template <int CTRL>
+__device__ __forceinline__ float nrx_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float nrx_wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += nrx_dpp<0xB1>(v);      // quad_perm [1,0,3,2]: lane ^ 1
+    v += nrx_dpp<0x4E>(v);      // quad_perm [2,3,0,1]: lane ^ 2
+    v += nrx_dpp<0x141>(v);     // row_half_mirror: the other quad of each 8
+    v += nrx_dpp<0x140>(v);     // row_mirror: the other half of each 16
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
 }

@@ -250,8 +250,12 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_fwd_kernel(const float* __re
 // per element per block.
 // NLR > 0: gw/gb of the wave's rows accumulate in registers (NLR = n_layers, compile time) and are
 // flushed to LDS once per wave; NLR == 0: generic path, per-row LDS atomics (any n_layers).
-template <int R, int V, int NLR>
-__global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_bwd_kernel(const float* __restrict__ x, int64_t x_ld, int64_t batch, int D, int NL,
+// 1024-thread blocks, at most one per CU: the per-block flush of gw / gb is NL*D global atomics on the SAME addresses
+// from every block, and device-scope atomics on one address serialise -- with 2048 blocks of 256 threads that
+// tail was ~60 of the kernel's 99 us; 256 blocks cut the atomics eightfold while 16 waves per block keep 4 per SIMD.
+// (3+ layers need more than the 128 VGPRs a 1024-thread block allows: 512-thread blocks, two per CU.)
+template <int R, int V, int NLR, int DCN_BWD_BLOCK>
+__global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* __restrict__ x, int64_t x_ld, int64_t batch, int D, int NL,
                                                                const float* __restrict__ w, const float* __restrict__ bvec,
                                                                const float* __restrict__ g_out, int64_t g_out_ld,
                                                                float* __restrict__ g_x, int64_t g_x_ld,
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_bwd_kernel(const float* __re
     float* s_b = s_w + NL * Dp;
     float* s_gw = s_b + NL * Dp;
     float* s_gb = s_gw + NL * Dp;
-    for (int i = threadIdx.x; i < NL * Dp; i += NRX_BLOCK) {
+    for (int i = threadIdx.x; i < NL * Dp; i += DCN_BWD_BLOCK) {
         const int l = i / Dp, c = i - l * Dp;
         s_w[i] = (c < D) ? w[l * (int64_t)D + c] : 0.f;
         s_b[i] = (c < D) ? bvec[l * (int64_t)D + c] : 0.f;
@@ -271,8 +275,8 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_bwd_kernel(const float* __re
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * (NRX_BLOCK / 64);
+    const int64_t wave = (int64_t)blockIdx.x * (DCN_BWD_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (DCN_BWD_BLOCK / 64);
     constexpr int NA = NLR > 0 ? NLR : 1;
     float acc_w[NA][R][V], acc_b[NA][R][V];
 #pragma unroll
@@ -282,10 +286,19 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_bwd_kernel(const float* __re
 #pragma unroll
             for (int j = 0; j < V; ++j) { acc_w[l][r][j] = 0.f; acc_b[l][r][j] = 0.f; }
 
+    // software pipeline: the next row's x0 / g loads are issued before this row's five reductions and the
+    // store, so the memory system is never idle behind the arithmetic of a wave
+    RowRegs<R, V> x0n, gn;
+    if (wave < batch) {
+        row_load<R, V>(x0n, x + wave * x_ld, D, lane);
+        row_load<R, V>(gn, g_out + wave * g_out_ld, D, lane);
+    }
     for (int64_t row = wave; row < batch; row += nwaves) {
-        RowRegs<R, V> x0, g, gx0;
-        row_load<R, V>(x0, x + row * x_ld, D, lane);
-        row_load<R, V>(g, g_out + row * g_out_ld, D, lane);
+        RowRegs<R, V> x0 = x0n, g = gn, gx0;
+        if (row + nwaves < batch) {
+            row_load<R, V>(x0n, x + (row + nwaves) * x_ld, D, lane);
+            row_load<R, V>(gn, g_out + (row + nwaves) * g_out_ld, D, lane);
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -348,7 +361,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_bwd_kernel(const float* __re
                 }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < NL * Dp; i += NRX_BLOCK) {
+    for (int i = threadIdx.x; i < NL * Dp; i += DCN_BWD_BLOCK) {
         const int l = i / Dp, c = i - l * Dp;
         if (c < D) {
             unsafeAtomicAdd(&g_w[l * (int64_t)D + c], s_gw[i]);
@@ -593,15 +606,17 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, int64_t batch, int32
     const int R = (dim + 64 * V - 1) / (64 * V);
     const size_t smem = (size_t)4 * n_layers * ((dim + 3) & ~3) * sizeof(float);
     NRX_REQUIRE(smem <= 128 * 1024, "nrx_dcn_v1_bwd: n_layers*dim too large for the LDS stage");
-    const unsigned grid = stream_grid(batch, NRX_BLOCK / 64);
     // register accumulation of gw/gb when the accumulators fit (n_layers <= 4 and <= 2 chunks per lane)
     const int nlr = (n_layers >= 1 && n_layers <= 4 && R <= 2) ? n_layers : 0;
 #define NRX_DCN_BWD(NLR_)                                                                                           \
     NRX_RSWITCH(R, V, {                                                                                             \
-        auto kern = dcn_v1_bwd_kernel<RR, VV, NLR_>;                                                                \
+        constexpr int DCN_BWD_BLOCK = (NLR_ >= 1 && NLR_ <= 2) ? 1024 : 512;                                        \
+        unsigned grid = (unsigned)((batch + DCN_BWD_BLOCK / 64 - 1) / (DCN_BWD_BLOCK / 64));                         \
+        if (grid > 256u * (1024 / DCN_BWD_BLOCK)) grid = 256u * (1024 / DCN_BWD_BLOCK);                              \
+        auto kern = dcn_v1_bwd_kernel<RR, VV, NLR_, DCN_BWD_BLOCK>;                                                 \
         if (smem > 64 * 1024)                                                                                       \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NRX_BLOCK), smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(DCN_BWD_BLOCK), smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, \
                            batch, dim, n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b);                     \
     })
     switch (nlr) {
