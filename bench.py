@@ -141,10 +141,11 @@ class SingleGpuPath:
         fmb = torch.empty((BATCH,), dtype=torch.float32, device=device) if self.fm else None
         self.calls = [ops.PreparedEmbed(self.plan, self.tables, ins, ws, out_ld=ld, out=out, fm=fmb) for ins, ws in self.pool]
         self.fused = None
-        if self.cross and os.environ.get("NRX_BENCH_FUSED_CROSS") == "1":
-            # one-launch gather -> cat[x, cross(x)] (ops.PreparedEmbedDcn): bit-identical, but measured
-            # 72 us vs 62 us for the two launches below on MI355X (round 1) -- opt-in until it wins
+        if self.cross and ops.fused_cross_is_fast(self.plan) and os.environ.get("NRX_BENCH_FUSED_CROSS", "1") != "0":
+            # one-launch gather -> cat[x, cross(x)] (ops.PreparedEmbedDcn, grouped kernel): 47.9 us vs 60.0 us for the two
+            # launches below on MI355X; NRX_BENCH_FUSED_CROSS=0 measures the two-launch form
             self.fused = [ops.PreparedEmbedDcn(self.plan, self.tables, ins, self.cross_w, self.cross_b, out=out) for ins, _ in self.pool]
+            self.desc = self.desc.replace("(2 launches)", "(1 fused launch)")
         self.device = device
         from news_recsys_amd import _lib
         self.lib = _lib.load()

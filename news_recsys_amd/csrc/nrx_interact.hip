@@ -477,6 +477,81 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_dcn_v1_kernel(const EmbedDcnA
     }
 }
 
+// Grouped variant for uniform 128 / 256-byte rows (D = 32, 64) and N <= 8 features: the Q = D/4 lanes that own a
+// row chunk walk ALL N features of one sample, so the whole concat row of a sample sits in the registers of one
+// 8- or 16-lane group (4 or 8 samples per wave instruction, exactly the access pattern of embed_fwd_uniform, the
+// fastest gather here).  N row loads in flight, then per cross layer a 4N-term partial dot per lane, a DPP
+// reduction inside the group (no LDS), the update, and 2N stores (x and cross).  w / b come from LDS.
+template <int Q>
+__device__ __forceinline__ float group_sum_dpp(float v) {
+    v += nrx_dpp<0xB1>(v);                       // lane ^ 1
+    v += nrx_dpp<0x4E>(v);                       // lane ^ 2
+    if (Q >= 8) v += nrx_dpp<0x141>(v);          // other quad of each 8
+    if (Q >= 16) v += nrx_dpp<0x140>(v);         // other half of each 16
+    return v;
+}
+
+template <int QLOG2, int N, bool IDX64, bool NT>
+__global__ __launch_bounds__(NRX_BLOCK) void embed_dcn_v1_group_kernel(const EmbedDcnArgs args_in_kernarg) {
+    const NRX_CONST EmbedDcnArgs* a = nrx_kernarg<EmbedDcnArgs>();
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int W = a->width, NL = a->n_layers;
+    float4* s_w = reinterpret_cast<float4*>(smem);          // [NL][W/4]
+    float4* s_b = s_w + NL * (W / 4);
+    for (int i = threadIdx.x; i < NL * (W / 4); i += NRX_BLOCK) {
+        s_w[i] = reinterpret_cast<const float4*>(a->w)[i];
+        s_b[i] = reinterpret_cast<const float4*>(a->b)[i];
+    }
+    __syncthreads();
+    const int q = threadIdx.x & (Q - 1);
+    const int64_t b = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
+    if (b >= a->batch) return;                      // the Q lanes of a sample leave together
+    int64_t id[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u)
+        id[u] = IDX64 ? nrx_gconst<int64_t>(a->index[u])[b] : (int64_t)nrx_gconst<int32_t>(a->index[u])[b];
+    float4 x0[N];
+    int bad_feat = -1;
+    int64_t bad_id = 0;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const bool bad = (uint64_t)id[u] >= (uint64_t)a->rows[u];
+        bad_feat = bad ? u : bad_feat;
+        bad_id = bad ? id[u] : bad_id;
+        x0[u] = NT ? nrx_ldg4_nt(a->table[u], (bad ? 0 : id[u]) * Q + q) : nrx_ldg4(a->table[u], (bad ? 0 : id[u]) * Q + q);
+    }
+    if (bad_feat >= 0 && q == 0) nrx_report_oob(a->status, bad_feat, b, bad_id);
+    float4 xl[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) xl[u] = x0[u];
+    for (int l = 0; l < NL; ++l) {
+        const float4* wl = s_w + l * (W / 4) + q;
+        const float4* bl = s_b + l * (W / 4) + q;
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            const float4 wv = wl[u * Q];
+            part += xl[u].x * wv.x + xl[u].y * wv.y + xl[u].z * wv.z + xl[u].w * wv.w;
+        }
+        const float dot = group_sum_dpp<Q>(part);
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            const float4 bv = bl[u * Q];
+            xl[u].x = x0[u].x * dot + bv.x + xl[u].x;
+            xl[u].y = x0[u].y * dot + bv.y + xl[u].y;
+            xl[u].z = x0[u].z * dot + bv.z + xl[u].z;
+            xl[u].w = x0[u].w * dot + bv.w + xl[u].w;
+        }
+    }
+    float4* o = reinterpret_cast<float4*>(a->out + b * a->out_ld);
+#pragma unroll
+    for (int u = 0; u < N; ++u) o[u * Q + q] = x0[u];
+#pragma unroll
+    for (int u = 0; u < N; ++u) o[W / 4 + u * Q + q] = xl[u];
+}
+
 int ceil_log2i(int x) {
     int l = 0;
     while ((1 << l) < x) ++l;
@@ -673,8 +748,32 @@ extern "C" int nrx_embed_dcn_v1_fwd(const nrx_feature_t* feats, int32_t n_feats,
     a.idx64 = feats[0].index_bits == 64;
     const size_t smem = (size_t)2 * n_layers * width * sizeof(float);
     NRX_REQUIRE(smem <= 64 * 1024, "nrx_embed_dcn_v1_fwd: n_layers*width too large for the LDS stage");
-    const int R = (width + 255) / 256;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    {   // grouped variant: every feature the same 128- or 256-byte row, at most 8 of them
+        const int D0 = feats[0].dim;
+        bool uni = (D0 == 32 || D0 == 64) && n_feats >= 2 && n_feats <= 8 && nrx_aligned16(w) && nrx_aligned16(b);
+        for (int i = 0; i < n_feats && uni; ++i) uni = feats[i].dim == D0;
+        if (uni) {
+            const int tb = NRX_BLOCK / (D0 / 4);
+            const dim3 ggrid((unsigned)((batch + tb - 1) / tb));
+            int64_t table_bytes = 0;
+            for (int i = 0; i < n_feats; ++i) table_bytes += feats[i].rows * (int64_t)D0 * 4;
+            const bool nt = table_bytes > (256ll << 20);     // non-temporal row loads once the tables exceed the Infinity Cache
+#define NRX_EG3(QL_, N_, I_) do { if (nt) hipLaunchKernelGGL((embed_dcn_v1_group_kernel<QL_, N_, I_, true>), ggrid, dim3(NRX_BLOCK), smem, st, a); \
+                                  else hipLaunchKernelGGL((embed_dcn_v1_group_kernel<QL_, N_, I_, false>), ggrid, dim3(NRX_BLOCK), smem, st, a); } while (0)
+#define NRX_EG2(QL_, N_) do { if (a.idx64) NRX_EG3(QL_, N_, true); else NRX_EG3(QL_, N_, false); } while (0)
+#define NRX_EG(QL_) switch (n_feats) { case 2: NRX_EG2(QL_, 2); break; case 3: NRX_EG2(QL_, 3); break; case 4: NRX_EG2(QL_, 4); break; \
+                                       case 5: NRX_EG2(QL_, 5); break; case 6: NRX_EG2(QL_, 6); break; case 7: NRX_EG2(QL_, 7); break; \
+                                       default: NRX_EG2(QL_, 8); break; }
+            if (D0 == 32) NRX_EG(3) else NRX_EG(4)
+#undef NRX_EG
+#undef NRX_EG2
+#undef NRX_EG3
+            NRX_LAUNCH_CHECK("nrx_embed_dcn_v1_fwd(grouped)");
+            return NRX_OK;
+        }
+    }
+    const int R = (width + 255) / 256;
     const unsigned grid = stream_grid((batch + 7) / 8, NRX_BLOCK / 64);
 #define NRX_ED(R_, S_) hipLaunchKernelGGL((embed_dcn_v1_kernel<R_, S_>), dim3(grid), dim3(NRX_BLOCK), smem, st, a)
     if (R <= 1) NRX_ED(1, 8); else if (R <= 2) NRX_ED(2, 8); else if (R <= 4) NRX_ED(4, 4); else NRX_ED(8, 2);

@@ -34,7 +34,11 @@ class DCN(BaseModel):
     def __init__(self, config_path):
         super().__init__(config_path)
         cfg = self.config.get("dcn_cfg", {}) or {}
-        self.fuse_gather_cross = bool(cfg.get("fuse_gather_cross", False))
+        # "auto" (default): one fused launch (gather -> cat[x, cross(x)]) whenever the grouped kernel applies
+        # (ops.fused_cross_is_fast: uniform 32/64-wide rows, 2..8 plain features); true: whenever the library accepts
+        # the feature mix; false: always gather + cross as two launches
+        fz = cfg.get("fuse_gather_cross", "auto")
+        self.fuse_gather_cross = "auto" if str(fz).lower() == "auto" else bool(fz)
         self.score_fc = DCNModel(input_dim=self.user_input_dim + self.item_input_dim,
                                  cross_num_layers=int(cfg.get("cross_num_layers", 3)),
                                  deep_hidden_dims=[128, 128, 128, 64, 1], version=int(cfg.get("version", 1)))
@@ -47,19 +51,24 @@ class DCN(BaseModel):
         m = self.score_fc
         names = self.user_feature_names | self.item_feature_names
         if m.version == 1 and len(m.cross_net.cross_net) > 0:
-            if self.fuse_gather_cross and not torch.is_grad_enabled() and getattr(self, "_shard_engine", None) is None:
-                # inference, opt-in (`dcn_cfg.fuse_gather_cross: true`): gather -> cat[x, cross(x)] in ONE launch.
-                # Bit-identical to the two launches below; on MI355X it currently measures 72 us vs 62 us at the
-                # C3 shape, so the default stays the two-launch path.
+            if self.fuse_gather_cross and getattr(self, "_shard_engine", None) is None:
+                # gather -> cat[x, cross(x)] in ONE launch (training too: backward = cross backward on the saved buffer,
+                # then the embedding backward).  C3 shape: 47.9 us vs 60.0 us for the two launches below.
                 from .... import ops
                 plan, table_names, _, present = self._plan(x, names, False, ())
-                try:
-                    w, b = m.cross_net.stacked()
-                    buf = ops.embed_dcn_v1(plan, [self.embedding_tables[t].weight for t in table_names],
-                                           [x[s.name] for s in plan.slots], w, b)
-                    return torch.sigmoid(m.score_fc(buf))
-                except ops.FusedUnsupported:
-                    pass
+                if present and (self.fuse_gather_cross is True or ops.fused_cross_is_fast(plan)):
+                    try:
+                        w, b = m.cross_net.stacked()
+                        sg = self.sparse_grad
+                        if sg == "fused":
+                            if self._sparse_sink is None:
+                                self._sparse_sink = ops.SparseGradSink()
+                            sg = self._sparse_sink if torch.is_grad_enabled() else False
+                        buf = ops.embed_dcn_v1(plan, [self.embedding_tables[t].weight for t in table_names],
+                                               [x[s.name] for s in plan.slots], w, b, sparse_grad=sg)
+                        return torch.sigmoid(m.score_fc(buf))
+                    except ops.FusedUnsupported:
+                        pass
             buf, _, _, _, _ = self._embed(x, names, out_ld=2 * m.input_dim)
             return m.forward_buf_(buf)
         return m(self.get_inp_embedding(x))

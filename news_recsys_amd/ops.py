@@ -639,9 +639,68 @@ class PreparedEmbedDcn:
             _raise_if_oob(self.status, self.plan.names)
 
 
-@torch.no_grad()
-def embed_dcn_v1(plan: EmbedPlan, tables, inputs, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """One-shot fused gather -> cat[x, cross(x)] (no autograd; training uses embed_apply + dcn_v1_cat_)."""
+def fused_cross_is_fast(plan: EmbedPlan) -> bool:
+    """True when nrx_embed_dcn_v1_fwd runs its grouped kernel (mirrors the rule in csrc/nrx_interact.hip): plain
+    single-valued features, all with the same 32- or 64-wide rows, 2..8 of them, gap-free concat.  Measured at the
+    C3 shape: 47.9 us for the one launch vs 60.0 us for gather + cross; other eligible mixes run the
+    one-wave-per-sample kernel, which is slower than two launches."""
+    sl = plan.slots
+    if not (2 <= len(sl) <= 8) or plan.use_fm or plan.wide_width:
+        return False
+    d0 = sl[0].dim
+    col = 0
+    for s_ in sl:
+        if s_.kind != NRX_SPARSE or s_.wide_col >= 0 or s_.dim != d0 or s_.out_col != col:
+            return False
+        col += s_.dim
+    return d0 in (32, 64) and col == plan.out_width
+
+
+class _EmbedDcnFn(torch.autograd.Function):
+    """Fused gather -> cat[x, cross(x)] with autograd: backward = nrx_dcn_v1_bwd on the saved buffer's x half, then the
+    embedding backward (dense, COO or sink -- the same three modes as embed_apply)."""
+
+    @staticmethod
+    def forward(ctx, plan: EmbedPlan, inputs, sparse_grad, w, b, *tables):
+        call = PreparedEmbedDcn(plan, tables, inputs, w, b, check_index=_INDEX_CHECK != "off")
+        if _INDEX_CHECK == "sync":
+            call.check()
+        elif _INDEX_CHECK == "lazy":
+            flush_index_checks()
+            call.check()
+        ctx.plan, ctx.B, ctx.ld = plan, call.B, plan.out_width
+        ctx.ins, ctx.ws = call.ins, [None] * len(plan.slots)
+        ctx.table_meta = [(t.shape, t.device) for t in tables]
+        ctx.fm_feat = None
+        ctx.sink = sparse_grad if isinstance(sparse_grad, SparseGradSink) else None
+        ctx.sparse_grad = bool(sparse_grad)
+        ctx.tables = list(tables) if ctx.sink is not None else None
+        ctx.save_for_backward(call.out, call.w, call.b)
+        ctx.w_shape, ctx.b_shape = tuple(w.shape), tuple(b.shape)
+        return call.out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        buf, w, b = ctx.saved_tensors
+        g = _f32c(g, "grad")
+        B, W2 = buf.shape
+        D = W2 // 2
+        gx = torch.empty((B, D), dtype=torch.float32, device=buf.device)
+        gw = torch.zeros_like(w)
+        gb = torch.zeros_like(b)
+        check(lib.nrx_dcn_v1_bwd(buf.data_ptr(), W2, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), g.data_ptr() + 4 * D, W2,
+                                 gx.data_ptr(), D, gw.data_ptr(), gb.data_ptr(), _stream_ptr(buf)), "nrx_dcn_v1_bwd")
+        gx += g[:, :D]
+        table_grads = _EmbedFn.backward(ctx, gx, None, None)[6:]
+        return (None, None, None, gw.view(ctx.w_shape), gb.view(ctx.b_shape), *table_grads)
+
+
+def embed_dcn_v1(plan: EmbedPlan, tables, inputs, w: torch.Tensor, b: torch.Tensor, sparse_grad=False) -> torch.Tensor:
+    """Fused gather -> cat[x, cross(x)] in one launch.  Differentiable w.r.t. tables, w and b when gradients are
+    enabled (sparse_grad as in embed_apply); raises FusedUnsupported for feature mixes the kernel does not cover."""
+    if torch.is_grad_enabled() and (w.requires_grad or b.requires_grad or any(t.requires_grad for t in tables)):
+        return _EmbedDcnFn.apply(plan, list(inputs), sparse_grad, w, b, *tables)
     call = PreparedEmbedDcn(plan, tables, inputs, w, b, check_index=_INDEX_CHECK != "off")
     if _INDEX_CHECK == "sync":
         call.check()

@@ -652,8 +652,13 @@ def test_sorted_sparse_backward_matches_dense_and_is_deterministic(case):
 
 
 @pytest.mark.parametrize("B,dims,NL", [(1, [16], 1), (300, [64] * 5, 2), (257, [32, 32, 16, 16, 16], 3), (100, [256] * 8, 1),
-                                       (77, [128, 4, 4, 64], 8), (65, [16] * 26, 2)])
-def test_fused_gather_cross_is_bit_identical_to_two_launches(B, dims, NL):
+                                       (77, [128, 4, 4, 64], 8), (65, [16] * 26, 2), (1000, [32] * 8, 3), (129, [64] * 2, 1),
+                                       (513, [32] * 3, 4)])
+def test_fused_gather_cross_matches_two_launches(B, dims, NL):
+    """One launch vs gather + cross: the gathered half is bit-exact always; the cross half is bit-identical when
+    the one-wave-per-sample kernel runs (same lane layout and reduction tree as dcn_v1_fwd_kernel) and equal to fp32
+    rounding when the grouped kernel runs (uniform 32/64-wide rows, <= 8 features: its dot product is reduced
+    inside an 8/16-lane group, a different summation tree)."""
     rng = np.random.default_rng(B + len(dims))
     tables = [rng.standard_normal((40 + 3 * i, d)).astype(np.float32) for i, d in enumerate(dims)]
     ids = [rng.integers(0, t.shape[0], B) for t in tables]
@@ -667,7 +672,12 @@ def test_fused_gather_cross_is_bit_identical_to_two_launches(B, dims, NL):
     fused = ops.embed_dcn_v1(plan, tt, ii, w, b)
     buf = ops.embed_apply(plan, tt, ii, [None] * len(dims), out_ld=2 * W)[0]
     two = ops.dcn_v1_cat_(buf, w, b)
-    assert torch.equal(fused, two)                                         # same layout, same reduction order
+    grouped = len(set(dims)) == 1 and dims[0] in (32, 64) and 2 <= len(dims) <= 8
+    if grouped:
+        assert torch.equal(fused[:, :W], two[:, :W])
+        torch.testing.assert_close(fused[:, W:], two[:, W:], rtol=2e-5, atol=2e-6 * max(1.0, two.abs().max().item()))
+    else:
+        assert torch.equal(fused, two)                                     # same layout, same reduction order
     x = np.concatenate([t[i] for t, i in zip(tables, ids)], axis=1)
     assert np.array_equal(fused[:, :W].cpu().numpy(), x)                   # gather + concat: bit-exact vs numpy
     ref = R.dcn_v1(x, w.cpu().numpy(), b.cpu().numpy())
