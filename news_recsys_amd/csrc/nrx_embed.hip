@@ -73,10 +73,16 @@ __device__ __forceinline__ void fm_accumulate(float4 v, int k0, int D, float& fi
     sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
 }
 
+// sum over the Q lanes of a sample, result in all of them: DPP moves inside a 16-lane row (no LDS round trip);
+// wider groups finish with cross-row shuffles
 template <int Q>
 __device__ __forceinline__ float group_sum(float v) {
+    if (Q >= 2) v += nrx_dpp<0xB1>(v);           // lane ^ 1
+    if (Q >= 4) v += nrx_dpp<0x4E>(v);           // lane ^ 2
+    if (Q >= 8) v += nrx_dpp<0x141>(v);          // other quad of each 8
+    if (Q >= 16) v += nrx_dpp<0x140>(v);         // other half of each 16
 #pragma unroll
-    for (int off = Q / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    for (int off = 16; off < Q; off <<= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
