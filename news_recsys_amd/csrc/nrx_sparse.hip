@@ -154,8 +154,12 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
     const int64_t n = off;
     if (n == 0) {
         // counts = {0, 0, ..., 0}; seg_start[0] = 0
-        hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)(n_tables + 2), st);
-        if (seg_start) hipMemsetAsync(seg_start, 0, sizeof(int64_t), st);
+        hipError_t e = hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)(n_tables + 2), st);
+        if (e == hipSuccess && seg_start) e = hipMemsetAsync(seg_start, 0, sizeof(int64_t), st);
+        if (e != hipSuccess) {
+            nrx_set_error("nrx_sparse_plan: hipMemsetAsync failed: %s", hipGetErrorString(e));
+            return NRX_ERR_LAUNCH;
+        }
         return NRX_OK;
     }
     NRX_REQUIRE(order && uniq_keys && seg_start && workspace, "nrx_sparse_plan: null buffer");

@@ -22,7 +22,7 @@ from __future__ import annotations
 
 import json
 import os
-from typing import Dict, Iterator, List, Optional
+from typing import Dict, Iterator, List
 
 import numpy as np
 import torch

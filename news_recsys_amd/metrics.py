@@ -13,7 +13,6 @@ and the global AUC (ties at 1/2, like sklearn) / LogLoss are a handful of fp64 t
 the same text."""
 from __future__ import annotations
 
-import ctypes as C
 from typing import Dict, Iterable, Optional
 
 import torch

@@ -11,7 +11,6 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ... import ops
 
