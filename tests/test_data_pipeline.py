@@ -89,7 +89,7 @@ def test_columnar_shuffle_is_a_permutation(col_dir):
     ds = ColumnarDataset(col_dir)
     loader = ColumnarLoader(ds, 5, "cpu", shuffle=True, seed=3)
     seen = torch.cat([b["ctr"] for b in loader])
-    ref = torch.from_numpy(np.asarray(ds.dense["ctr"]))
+    ref = torch.from_numpy(np.array(ds.dense["ctr"]))
     assert seen.numel() == 23 and torch.equal(seen.sort().values, ref.sort().values)
     again = torch.cat([b["ctr"] for b in loader])                 # next epoch: a different order
     assert not torch.equal(seen, again)
