@@ -289,7 +289,7 @@ NRX_API int nrx_user_rank_metrics(const float* scores, const float* labels, cons
  * inside each list; both device int64): excluded items never enter the result -- the reference instead
  * over-fetches k + len(history) and filters on the host.  Output: out_idx / out_score [n_queries, k], scores
  * descending, ties broken toward the lower item index; unused slots (fewer than k candidates) = -1 / -FLT_MAX
- * (what faiss's heap leaves there).  score = fp32 fma chain, element order j, H+j (H = padded dim / 2).
+ * (what faiss's heap leaves there).  score = fp32 fma chain, element order j, H+j (H = half of dim padded to 8, 16, 32, 64 or 128).
  * workspace: device bytes >= nrx_topk_workspace(n_items, n_queries, k).                          */
 NRX_API int64_t nrx_topk_workspace(int64_t n_items, int64_t n_queries, int32_t k);
 NRX_API int nrx_topk_ip(const float* items, int64_t n_items, int32_t dim, const float* queries, int64_t n_queries,

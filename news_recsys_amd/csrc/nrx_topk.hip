@@ -13,7 +13,7 @@
 // VALU work (compare / queue) of one wave overlaps the MFMAs of the others.
 //
 // Score definition (measured: tools/mfma_f32_probe.hip -> profiles/r01_mfma_f32_semantics.txt, the MFMA is
-// the fused chain fma(a1,b1, fma(a0,b0,c)) bit for bit): with P = dim rounded up to a multiple of 8 (zero
+// the fused chain fma(a1,b1, fma(a0,b0,c)) bit for bit): with P = dim rounded up to 8, 16, 32, 64 or 128 (zero
 // padded) and H = P/2,   s = 0;  for j in 0..H-1:  s = fma(it[j], q[j], s);  s = fma(it[H+j], q[H+j], s).
 // Ties: lower item index first (total order (score desc, index asc), so the result does not depend on
 // how items are split over lanes and blocks).  The oracle restates exactly this.

@@ -125,9 +125,10 @@ void oracle_topk_ip(const float* items, int64_t n_items, int32_t dim, const floa
             while (ep < e1 && excl_items[ep] < i) ++ep;
             if (ep < e1 && excl_items[ep] == i) continue;
             const float* v = items + i * dim;
-            /* the kernel's matrix-core order: P = dim padded to a multiple of 8, H = P/2; per step j the
+            /* the kernel's matrix-core order: P = dim padded to 8, 16, 32, 64 or 128, H = P/2; per step j the
              * MFMA fuses element j then element H+j (pads are zeros) */
-            const int H = ((dim + 7) / 8) * 4;
+            int H = 4;                       /* half of the padded width: 4, 8, 16, 32 or 64 (power of two >= dim/2) */
+            while (2 * H < dim) H *= 2;
             float a = 0.f;
             for (int j = 0; j < H; ++j) {
                 a = fmaf(j < dim ? v[j] : 0.f, j < dim ? qv[j] : 0.f, a);

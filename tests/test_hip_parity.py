@@ -697,3 +697,22 @@ def test_fused_gather_cross_rejects_what_it_does_not_cover():
     plan = ops.EmbedPlan([ops.Slot("h", NRX_BAG_MEAN, 0, 16, 3)], out_width=16)
     with pytest.raises(ops.FusedUnsupported):
         ops.embed_dcn_v1(plan, [t16], [torch.zeros(2, 3, dtype=torch.long, device=DEV)], torch.zeros(1, 16, device=DEV), torch.zeros(1, 16, device=DEV))
+
+
+def test_dcn_v2_property_random_shapes_value_exact():
+    """Hypothesis sweep over batch / width (odd, tiny, non-multiples of the 128x64 tile and of the 32-deep slab): the
+    matrix-core layer equals the C oracle's fp32 fma chain value for value."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from oracle import ref_c
+
+    @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(B=st.integers(1, 400), D=st.integers(1, 200), NL=st.integers(1, 2), relu=st.booleans(), seed=st.integers(0, 10 ** 6))
+    def run(B, D, NL, relu, seed):
+        rng = np.random.default_rng(seed)
+        x = rng.standard_normal((B, D)).astype(np.float32)
+        W = (rng.standard_normal((NL, D, D)) / np.sqrt(D)).astype(np.float32)
+        b = (rng.standard_normal((NL, D)) * 0.1).astype(np.float32)
+        out = ops.dcn_v2(dev(x), dev(W), dev(b), relu=relu)
+        assert np.array_equal(out.detach().cpu().numpy(), ref_c.dcn_v2(x, W, b, relu=relu))
+
+    run()

@@ -218,3 +218,23 @@ def test_dssm_hit_rate_matches_reference_loop():
     # batch size 1 (the only size the reference accepts) gives the same number
     val1 = [{k: v[i:i + 1] for k, v in b.items()} for b in val for i in range(20)]
     assert m.hit_rate(10, val1) == pytest.approx(ref)
+
+
+@gpu
+def test_hip_topk_property_random_shapes():
+    """Hypothesis sweep: random N, Q, dim, k, exclusion sizes and duplicated items -- HIP == C oracle bit for bit."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(N=st.integers(0, 3000), Q=st.integers(1, 200), d4=st.integers(1, 16), k=st.integers(1, 32),
+           me=st.integers(0, 40), seed=st.integers(0, 10 ** 6))
+    def run(N, Q, d4, k, me, seed):
+        d = 4 * d4
+        items, q, lists, csr = _case(seed, N, Q, d, me if N else 0, dup=True)
+        use = me > 0 and N > 0
+        i_h, s_h = _run_hip(items, q, k, csr if use else None)
+        i_c, s_c = ref_c.topk_ip(items, q, k, csr if use else None)
+        assert np.array_equal(i_h, i_c)
+        assert np.array_equal(s_h.view(np.uint32), s_c.view(np.uint32))
+
+    run()
