@@ -24,6 +24,9 @@
 // lane are in flight (the path is latency x bandwidth bound: 64 B rows from tables >> L2/MALL).
 #include "nrx_common.h"
 
+bool nrx_launch_uniform_wide(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, float* out, int64_t out_ld,
+                             float* wide_out, int64_t wide_ld, int32_t* status, hipStream_t st);   // nrx_embed_wide.hip
+
 namespace {
 
 struct EmbedArgs {
@@ -711,6 +714,12 @@ extern "C" int nrx_embed_fwd(const nrx_feature_t* feats, int32_t n_feats, int64_
             default: launch_uniform<6>(ua, batch, i64, fm, store, st); break;
         }
         NRX_LAUNCH_CHECK("nrx_embed_fwd(uniform)");
+        return NRX_OK;
+    }
+
+    // ---- uniform features with the Wide&Deep column split (nrx_embed_wide.hip)
+    if (fm_out == nullptr && nrx_launch_uniform_wide(feats, n_feats, batch, out, out_ld, wide_out, wide_ld, status, st)) {
+        NRX_LAUNCH_CHECK("nrx_embed_fwd(uniform+wide)");
         return NRX_OK;
     }
 

@@ -1,0 +1,150 @@
+// Fused gather -> concat WITH the Wide&Deep column split, fast path for uniform single-valued features.
+// Reference: WideDeep.get_inp_embedding (src/model/sort/widedeep/model.py:53-69): for a feature in
+// `wide_feature_names` column 0 of its embedding row goes to the wide tensor and columns 1..D-1 to the deep concat,
+// every other feature goes to the deep concat whole.  The deep row therefore has blocks of D and D-1 floats and
+// nothing after the first wide feature is 16-byte aligned any more; the generic kernel falls back to one feature at
+// a time and scalar stores there (C5's table set: 210 us against 82 us for the same gather without the split).
+// Global memory only needs dword alignment for multi-dword accesses, so this kernel keeps the uniform kernel's
+// structure -- U independent aligned 16-byte row loads per lane in flight, then the stores -- and writes each
+// lane's 4 floats with dword-aligned 12-byte + 4-byte stores at the (shifted) deep position; the 4-byte store of a
+// wide feature's lane 0 is redirected to the wide tensor.  Branch-free inside a group (see nrx_embed.hip on why).
+#include "nrx_common.h"
+
+struct UniformWideArgs {
+    const float* table[NRX_MAX_FEATURES];
+    const void* index[NRX_MAX_FEATURES];
+    int64_t rows[NRX_MAX_FEATURES];
+    int32_t col[NRX_MAX_FEATURES];        // first deep column of the feature (float units)
+    int32_t wide_col[NRX_MAX_FEATURES];   // column in the wide tensor, -1 = not a wide feature
+    int64_t batch;
+    float* out;                           // deep concat [batch, ld]
+    int64_t ld;
+    float* wide;                          // [batch, wide_ld]
+    int64_t wide_ld;
+    int32_t* status;
+    int32_t n;
+};
+static_assert(sizeof(UniformWideArgs) <= 3584, "kernarg budget");
+
+namespace {
+
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int Q, int CNT, bool IDX64, bool NT>
+__device__ __forceinline__ void wide_group(const NRX_CONST UniformWideArgs* a, int f0, int64_t b, int q, int& bad_feat, int64_t& bad_id) {
+    int64_t id[CNT];
+    float4 v[CNT];
+#pragma unroll
+    for (int u = 0; u < CNT; ++u)
+        id[u] = IDX64 ? nrx_gconst<int64_t>(a->index[f0 + u])[b] : (int64_t)nrx_gconst<int32_t>(a->index[f0 + u])[b];
+#pragma unroll
+    for (int u = 0; u < CNT; ++u) {
+        const bool bad = (uint64_t)id[u] >= (uint64_t)a->rows[f0 + u];
+        bad_feat = bad ? f0 + u : bad_feat;
+        bad_id = bad ? id[u] : bad_id;
+        id[u] = bad ? 0 : id[u];
+        v[u] = NT ? nrx_ldg4_nt(a->table[f0 + u], id[u] * Q + q) : nrx_ldg4(a->table[f0 + u], id[u] * Q + q);
+    }
+    float* const orow = a->out + b * a->ld;
+#pragma unroll
+    for (int u = 0; u < CNT; ++u) {
+        const int wc = a->wide_col[f0 + u];                     // wave-uniform
+        const int shift = wc >= 0 ? 1 : 0;
+        float* p = orow + a->col[f0 + u] + 4 * q - shift;       // where this lane's element 0 would land in the deep row
+        if (wc >= 0) {                                           // wave-uniform: 4-byte + 12-byte stores, lane 0's first
+            float* p0 = q == 0 ? a->wide + b * a->wide_ld + wc : p;          // float goes to the wide tensor
+            *p0 = v[u].x;
+            f32x3u t;
+            t.x = v[u].y; t.y = v[u].z; t.z = v[u].w;
+            *reinterpret_cast<f32x3u*>(p + 1) = t;
+        } else {                                                 // whole row to the deep concat: one (dword-aligned) 16-byte store
+            f32x4u t;
+            t.x = v[u].x; t.y = v[u].y; t.z = v[u].z; t.w = v[u].w;
+            *reinterpret_cast<f32x4u*>(p) = t;
+        }
+    }
+}
+
+template <int Q, int U, int R, bool IDX64, bool NT>
+struct WideTail {
+    static __device__ __forceinline__ void run(const NRX_CONST UniformWideArgs* a, int f0, int rem, int64_t b, int q, int& bad_feat, int64_t& bad_id) {
+        if (rem == R) wide_group<Q, R, IDX64, NT>(a, f0, b, q, bad_feat, bad_id);
+        else WideTail<Q, U, R + 1, IDX64, NT>::run(a, f0, rem, b, q, bad_feat, bad_id);
+    }
+};
+template <int Q, int U, bool IDX64, bool NT>
+struct WideTail<Q, U, U, IDX64, NT> {
+    static __device__ __forceinline__ void run(const NRX_CONST UniformWideArgs*, int, int, int64_t, int, int&, int64_t&) {}
+};
+
+template <int QLOG2, int U, bool IDX64, bool NT>
+__global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_uniform_wide(const UniformWideArgs args_in_kernarg_segment) {
+    const NRX_CONST UniformWideArgs* a = nrx_kernarg<UniformWideArgs>();
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    const int q = threadIdx.x & (Q - 1);
+    const int64_t b = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
+    if (b >= a->batch) return;
+    int bad_feat = -1;
+    int64_t bad_id = 0;
+    const int n = a->n;
+    int f0 = 0;
+    for (; f0 + U <= n; f0 += U) wide_group<Q, U, IDX64, NT>(a, f0, b, q, bad_feat, bad_id);
+    if (f0 < n) WideTail<Q, U, 1, IDX64, NT>::run(a, f0, n - f0, b, q, bad_feat, bad_id);
+    if (bad_feat >= 0 && q == 0) nrx_report_oob(a->status, bad_feat, b, bad_id);
+}
+
+template <int QLOG2, int U>
+void launch_wide(const UniformWideArgs& ua, int64_t batch, bool i64, bool nt, hipStream_t st) {
+    constexpr int TB = NRX_BLOCK >> QLOG2;
+    const dim3 grid((unsigned)((batch + TB - 1) / TB)), block(NRX_BLOCK);
+    if (i64) { if (nt) hipLaunchKernelGGL((embed_fwd_uniform_wide<QLOG2, U, true, true>), grid, block, 0, st, ua);
+               else hipLaunchKernelGGL((embed_fwd_uniform_wide<QLOG2, U, true, false>), grid, block, 0, st, ua); }
+    else     { if (nt) hipLaunchKernelGGL((embed_fwd_uniform_wide<QLOG2, U, false, true>), grid, block, 0, st, ua);
+               else hipLaunchKernelGGL((embed_fwd_uniform_wide<QLOG2, U, false, false>), grid, block, 0, st, ua); }
+}
+
+}  // namespace
+
+// Returns false when the feature set is not eligible (caller falls back to the generic kernel).
+bool nrx_launch_uniform_wide(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, float* out, int64_t out_ld,
+                             float* wide_out, int64_t wide_ld, int32_t* status, hipStream_t st) {
+    if (out == nullptr || wide_out == nullptr || n_feats < 1) return false;
+    const int D0 = feats[0].dim;
+    if (D0 != 16 && D0 != 32 && D0 != 64) return false;
+    UniformWideArgs ua;
+    int64_t table_bytes = 0;
+    bool any_wide = false;
+    for (int i = 0; i < n_feats; ++i) {
+        const nrx_feature_t& s = feats[i];
+        if (s.kind != NRX_SPARSE || s.dim != D0 || s.fm_field != 0 || s.index_bits != feats[0].index_bits || s.table == nullptr ||
+            s.index == nullptr || !nrx_aligned16(s.table) || s.rows < 1 || s.rows > 0x7fffffffLL || s.out_col < 0)
+            return false;
+        ua.table[i] = s.table;
+        ua.index[i] = s.index;
+        ua.rows[i] = s.rows;
+        ua.col[i] = s.out_col;
+        ua.wide_col[i] = s.wide_col;
+        any_wide |= s.wide_col >= 0;
+        table_bytes += s.rows * (int64_t)D0 * 4;
+    }
+    if (!any_wide) return false;
+    ua.batch = batch;
+    ua.out = out;
+    ua.ld = out_ld;
+    ua.wide = wide_out;
+    ua.wide_ld = wide_ld;
+    ua.status = status;
+    ua.n = n_feats;
+    const bool i64 = feats[0].index_bits == 64;
+    const bool nt = table_bytes > (256ll << 20);
+    const int w13 = (13 - n_feats % 13) % 13, w8 = (8 - n_feats % 8) % 8;
+    const bool u13 = D0 <= 32 && n_feats >= 13 && w13 <= w8;
+    switch (D0) {
+        case 16: if (u13) launch_wide<2, 13>(ua, batch, i64, nt, st); else launch_wide<2, 8>(ua, batch, i64, nt, st); break;
+        case 32: if (u13) launch_wide<3, 13>(ua, batch, i64, nt, st); else launch_wide<3, 8>(ua, batch, i64, nt, st); break;
+        default: launch_wide<4, 8>(ua, batch, i64, nt, st); break;
+    }
+    return true;
+}

@@ -716,3 +716,41 @@ def test_dcn_v2_property_random_shapes_value_exact():
         assert np.array_equal(out.detach().cpu().numpy(), ref_c.dcn_v2(x, W, b, relu=relu))
 
     run()
+
+
+@pytest.mark.parametrize("B,F,D,wide_every", [(1, 3, 16, 1), (300, 27, 32, 3), (257, 14, 16, 2), (1000, 40, 32, 4), (129, 9, 64, 1),
+                                              (65, 13, 32, 13), (4096, 26, 16, 5)])
+@pytest.mark.parametrize("idx_dtype", [np.int64, np.int32])
+def test_uniform_wide_split_bit_exact_vs_oracle(B, F, D, wide_every, idx_dtype):
+    """Wide&Deep split on uniform features (embed_fwd_uniform_wide): every `wide_every`-th feature sends column 0 to
+    the wide tensor and columns 1.. to the deep concat, so the deep row loses 16-byte alignment -- copies stay
+    bit-exact vs the oracle (widedeep/model.py:53-69), the dense backward equals the oracle's too, out-of-range ids
+    are reported."""
+    rng = np.random.default_rng(B + 31 * F + D + wide_every)
+    space, tables, batch = _rand_case(rng, B, [(NRX_SPARSE, 40 + 5 * i, D, 0) for i in range(F)], idx_dtype)
+    names = sorted(tables)
+    wide = set(names[::wide_every])
+    feats, dims, used = R.embed_concat(space, tables, batch, set(tables))
+    want_wide, want_deep = R.wide_split(feats, dims, used, wide)
+    plan, tt, inputs, weights, _ = build_plan(space, tables, batch, set(tables), wide_names=wide)
+    deep, wd, _ = ops.embed_apply(plan, tt, inputs, weights)
+    assert np.array_equal(deep.detach().cpu().numpy(), want_deep)
+    assert np.array_equal(wd.detach().cpu().numpy(), want_wide)
+    # backward through both outputs == scatter-add of the re-joined upstream rows
+    up_d = rng.standard_normal(want_deep.shape).astype(np.float32)
+    up_w = rng.standard_normal(want_wide.shape).astype(np.float32)
+    ((deep * dev(up_d)).sum() + (wd * dev(up_w)).sum()).backward()
+    col, wc = 0, 0
+    for n, t in zip(names, tt):
+        if n in wide:
+            g_rows = np.concatenate([up_w[:, wc:wc + 1], up_d[:, col:col + D - 1]], axis=1)
+            col, wc = col + D - 1, wc + 1
+        else:
+            g_rows = up_d[:, col:col + D]
+            col += D
+        want = R.embedding_grad_dense(batch[n], g_rows, tables[n].shape[0])
+        np.testing.assert_allclose(t.grad.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    with pytest.raises(IndexError):
+        bad = [x.clone() for x in inputs]
+        bad[-1][0] = 10 ** 6
+        ops.embed_apply(plan, [t.detach() for t in tt], bad, weights)

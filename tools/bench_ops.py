@@ -192,3 +192,29 @@ if want("train_opt"):
         print(f"C2 embed+FM fwd+bwd+optimizer, {mode:15s}: {us:9.1f} us  -> {B / us:7.2f} M impressions/s", flush=True)
         del tables, opt
         torch.cuda.empty_cache()
+
+if want("widedeep"):
+    # C5's single-GPU table set (27 tables <= 16M rows, D=32) gathered (a) as a plain concat (uniform kernel, what
+    # `bench.py --workload c5` times) and (b) with the Wide&Deep split of widedeep/model.py:53-69: the 10 smallest tables
+    # send column 0 to wide[B,10] and columns 1..31 to the deep concat (embed_fwd_uniform_wide: dword-aligned vector stores;
+    # the generic kernel took 210 us here)
+    rows_all = [int(round(1e3 * (5e5) ** (i / 39))) for i in range(40)]
+    rows = [r for r in rows_all if r <= 16_000_000]
+    D = 32
+    gen = torch.Generator(device=dev).manual_seed(5)
+    tables = [torch.randn(r, D, device=dev) for r in rows]
+    ids = [torch.randint(1, r, (B,), device=dev, generator=gen) for r in rows]
+    F_ = len(rows)
+    plain = ops.EmbedPlan([ops.Slot(f"w{i}", NRX_SPARSE, i, D, 0, i * D) for i in range(F_)], out_width=F_ * D)
+    slots, col = [], 0
+    for i in range(F_):
+        wide = i < 10                                      # rows ascend with i: the 10 smallest tables
+        slots.append(ops.Slot(f"w{i}", NRX_SPARSE, i, D, 0, col, wide_col=i if wide else -1))
+        col += D - 1 if wide else D
+    split = ops.EmbedPlan(slots, out_width=col, wide_width=10)
+    alg = F_ * (8 + 4 * D + 4 * D) * B
+    for name, plan in (("plain concat (uniform kernel)", plain), ("wide split, 10 wide features (uniform+wide kernel)", split)):
+        prep = ops.PreparedEmbed(plan, tables, ids, [None] * F_)
+        with torch.no_grad():
+            us = timeit(prep.run, steps=50)
+        print(f"C5 single-GPU tables, {name:48s}: {us:7.1f} us   {alg / us / 1e3:7.1f} GB/s algorithmic  ({alg / us / 1e3 / 8000:.3f} of peak)", flush=True)
