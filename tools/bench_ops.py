@@ -218,3 +218,21 @@ if want("widedeep"):
         with torch.no_grad():
             us = timeit(prep.run, steps=50)
         print(f"C5 single-GPU tables, {name:48s}: {us:7.1f} us   {alg / us / 1e3:7.1f} GB/s algorithmic  ({alg / us / 1e3 / 8000:.3f} of peak)", flush=True)
+
+if want("c1shape"):
+    # the reference's own deep config shape (train_cf_deep.yaml: user_id/item_id D=32, three D=16 features) at B=65536:
+    # mixed dims -> generic kernel
+    dims = [16, 32, 16, 16, 32]
+    rows = [18, 65239, 270, 18, 94058]
+    gen = torch.Generator(device=dev).manual_seed(6)
+    tables = [torch.randn(r, d, device=dev) for r, d in zip(rows, dims)]
+    ids = [torch.randint(1, r, (B,), device=dev, generator=gen) for r in rows]
+    col, slots = 0, []
+    for i, d in enumerate(dims):
+        slots.append(ops.Slot(f"f{i}", NRX_SPARSE, i, d, 0, col)); col += d
+    plan = ops.EmbedPlan(slots, out_width=col)
+    prep = ops.PreparedEmbed(plan, tables, ids, [None] * 5)
+    with torch.no_grad():
+        us = timeit(prep.run, steps=100)
+    alg = B * sum(8 + 8 * d for d in dims)
+    print(f"C1-shaped gather (5 feats, dims 16/32 mixed, cache-resident tables), B=65536: {us:7.1f} us   {alg / us / 1e3:7.1f} GB/s algorithmic", flush=True)
