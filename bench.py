@@ -243,7 +243,7 @@ def main():
     ops.set_index_check("off")            # ids are generated in range; the flag read-back would sync every step
 
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("NRX_BENCH_FORCE_DIST") == "1":       # env: exercise the RCCL plumbing on one GPU (testing)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
