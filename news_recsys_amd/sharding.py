@@ -133,7 +133,7 @@ class RowShardedEmbedding:
     [local_row_count(rows), dim] (a leaf requiring grad when training)."""
 
     def __init__(self, rank: int, world: int, group=None, backend=None, mode: str = "capacity",
-                 slack: float = 0.05, overflow_policy: str = "check"):
+                 slack: float = 0.05, overflow_policy: str = "check", host_staged: bool = False):
         """mode: "capacity" (sync-free, default) or "exact".  overflow_policy (capacity mode):
         "check" = agree on overflow across ranks after each forward (one small all-reduce + host read)
         and transparently redo the step in exact mode; "defer" = never read back inside the step --
@@ -141,6 +141,10 @@ class RowShardedEmbedding:
         if mode not in ("capacity", "exact"):
             raise ValueError("mode must be 'capacity' or 'exact'")
         self.rank, self.world, self.group = rank, world, group
+        # host_staged: collectives bounce device buffers through host memory (a gloo group works then).  A TEST transport:
+        # it lets several ranks share one GPU, so the HIP routing / owner kernels can be run with world > 1 on a
+        # single-GPU box (RCCL refuses two ranks on one device); the product transport is RCCL on device buffers.
+        self.host_staged = bool(host_staged)
         self.backend = backend if backend is not None else HipBackend()
         self.mode, self.slack, self.overflow_policy = mode, slack, overflow_policy
         self._overflow_marks: List[Tuple[torch.Tensor, int]] = []
@@ -163,9 +167,23 @@ class RowShardedEmbedding:
     def _a2a(self, out: torch.Tensor, inp: torch.Tensor, out_split=None, in_split=None) -> torch.Tensor:
         if self.world == 1:
             out.copy_(inp)
+        elif self.host_staged and out.is_cuda:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), out_split, in_split, group=self.group)
+            out.copy_(o)
         else:
             dist.all_to_all_single(out, inp, out_split, in_split, group=self.group)
         return out
+
+    def _all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world > 1:
+            if self.host_staged and t.is_cuda:
+                c = t.cpu()
+                dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.group)
+                t.copy_(c)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
 
     def _exchange(self, feats: Sequence[ShardedFeature], idxs: List[int], inputs, tables: Dict[str, torch.Tensor]):
         """Steps 1-6 for one dim-group.  Returns (returned rows [n_send, D], _Route)."""
@@ -216,8 +234,7 @@ class RowShardedEmbedding:
             # every rank learns about an out-of-range id on ANY owner and raises together (reference:
             # IndexError from nn.Embedding on CPU), instead of one rank leaving the collective sequence
             bad = status[:1].to(torch.int64)
-            if W > 1:
-                dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+            self._all_reduce_max(bad)
             if int(bad.item()) != 0:
                 raise IndexError("index out of range in self: a routed lookup exceeded its table on some rank "
                                  f"(this rank's record: {status.tolist()})")
@@ -336,8 +353,7 @@ class _ShardedEmbedFn(torch.autograd.Function):
                 # one tiny all-reduce so that every rank takes the same branch, then one host read
                 worst = torch.stack([torch.stack([o[0] - cap, (st[0].to(torch.int64) if st is not None else o[0] * 0)])
                                      for o, cap, st in flags]).max(dim=0).values
-                if eng.world > 1:
-                    dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=eng.group)
+                eng._all_reduce_max(worst)
                 over, bad = worst.tolist()
                 if bad > 0:
                     raise IndexError("index out of range in self: a routed lookup exceeded its table on some rank")

@@ -1,0 +1,103 @@
+"""world_size 2 and 3 with the PRODUCT (HIP) backend: all ranks share cuda:0 and exchange through gloo with
+host-staged buffers (RowShardedEmbedding(host_staged=True), a test transport -- RCCL refuses two ranks on one device).
+Everything else is the code an 8-GPU node runs: nrx_route_ids placing ids for W > 1 owners, the equal-split block
+exchange, nrx_gather_inbox / nrx_scatter_add_inbox on each owner's shard, the slot-addressed final fused launch, the
+overflow / out-of-range agreement.  Truth = the single-process oracle of tests/test_sharding_gloo.py."""
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from news_recsys_amd import sharding
+from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN
+from news_recsys_amd.sharding import RowShardedEmbedding, ShardedFeature
+from tests.test_sharding_gloo import FEATS, _free_port, batch_for, full_tables, oracle_forward_and_grads
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _worker(rank, world, port, q, mode, slack, replicate, prepared):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tabs = full_tables()
+        shards = {n: (torch.from_numpy(t).clone() if n in replicate else sharding.shard_table(torch.from_numpy(t), rank, world)
+                      ).to(DEV).requires_grad_(True) for n, t in tabs.items()}
+        feats = [ShardedFeature(f.name, f.kind, f.table, f.dim, f.bag_len, f.wide, f.fm, f.table in replicate) for f in FEATS]
+        eng = RowShardedEmbedding(rank, world, mode=mode, slack=slack, host_staged=True,
+                                  overflow_policy="defer" if prepared else "check")
+        if slack < 0:
+            eng.capacity_for = lambda n: 64
+        b = batch_for(rank)
+        inputs = [torch.from_numpy(np.asarray(b[f.name])).to(DEV) for f in FEATS]
+        inputs = [x.float() if x.dtype == torch.float64 else x for x in inputs]
+        weights = [torch.from_numpy(b["user_history_mask"]).to(DEV) if f.kind == NRX_BAG_MASKED_MEAN else None for f in FEATS]
+        if prepared:        # the sync-free bound forward bench.py uses at N > 1
+            call = sharding.PreparedShardedForward(eng, feats, inputs, weights, {n: s.detach() for n, s in shards.items()})
+            call.run()
+            call.run()                                   # re-launchable: same buffers, same result
+            out = call.final.out
+            torch.cuda.synchronize()
+            q.put((rank, out.detach().cpu().numpy(), None, bool(call.overflowed())))
+            return
+        out, wide, fm = eng.forward(feats, inputs, weights, shards)
+        (out * torch.from_numpy(b["_up"]).to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        q.put((rank, out.detach().cpu().numpy(), {n: s.grad.cpu().numpy() for n, s in shards.items()}, False))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, mode, slack, replicate, prepared):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, slack, replicate, prepared)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(world):
+        rank, out, grads, over = q.get(timeout=300)
+        results[rank] = (out, grads, over)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return results
+
+
+def _check_outputs(results, world):
+    want_outs, want_grads = oracle_forward_and_grads(world)
+    for r in range(world):
+        out = results[r][0]
+        for lo, hi in ((0, 8), (9, 25), (49, 65)):
+            assert np.array_equal(out[:, lo:hi], want_outs[r][:, lo:hi])               # routed copies: bit-exact
+        np.testing.assert_allclose(out[:, 8:9], want_outs[r][:, 8:9], rtol=1e-6)         # dense feature (float32 here)
+        np.testing.assert_allclose(out[:, 25:49], want_outs[r][:, 25:49], rtol=1e-6, atol=1e-6)   # pooled
+    return want_grads
+
+
+@pytest.mark.parametrize("world,mode,slack,replicate", [(2, "capacity", 0.5, ()), (3, "capacity", 0.5, ()), (2, "exact", 0.0, ()),
+                                                        (2, "capacity", -1.0, ()), (2, "capacity", 0.5, ("category",))])
+def test_hip_backend_forward_backward_with_several_ranks(world, mode, slack, replicate):
+    results = _run(world, mode, slack, replicate, prepared=False)
+    want_grads = _check_outputs(results, world)
+    for r in range(world):
+        for n, g in results[r][1].items():
+            if n in replicate:
+                continue
+            np.testing.assert_allclose(g, want_grads[n][r::world], rtol=1e-5, atol=1e-6, err_msg=f"rank {r} table {n}")
+    for n in replicate:
+        total = sum(results[r][1][n] for r in range(world))
+        np.testing.assert_allclose(total, want_grads[n], rtol=1e-5, atol=1e-6)
+    assert np.all(results[0][1]["item_id"][0] == 0)
+
+
+@pytest.mark.parametrize("world,replicate", [(2, ()), (3, ("category",))])
+def test_hip_backend_prepared_sync_free_forward_with_several_ranks(world, replicate):
+    results = _run(world, "capacity", 0.5, replicate, prepared=True)
+    _check_outputs(results, world)
+    assert not any(results[r][2] for r in range(world))
