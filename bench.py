@@ -237,6 +237,11 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # NRX_BENCH_HOST_STAGED=1 (testing): all ranks share GPU 0 and exchange over gloo through host-staged buffers, so the
+    # N > 1 control flow and the sharded data path can be run on a one-GPU box; the numbers it prints are not a measurement
+    staged = os.environ.get("NRX_BENCH_HOST_STAGED") == "1"
+    if staged:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from news_recsys_amd import ops
@@ -246,7 +251,10 @@ def main():
     if world > 1 or os.environ.get("NRX_BENCH_FORCE_DIST") == "1":       # env: exercise the RCCL plumbing on one GPU (testing)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if staged:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     seed = 20260116 + {"c2": 2, "c3": 3, "c4": 4, "c5": 5}[args.workload] + rank
     if world == 1 and not args.force_sharded:
@@ -259,7 +267,7 @@ def main():
         parallelism = "single-gpu"
     else:
         from news_recsys_amd.sharding import ShardedBenchPath
-        path = ShardedBenchPath(args.workload, device, seed, rank, world, BATCH, args.shard_mode)
+        path = ShardedBenchPath(args.workload, device, seed, rank, world, BATCH, args.shard_mode, host_staged=staged)
         step = path.step
         bytes_per_impr = path.bytes_per_impr
         desc = path.desc
@@ -333,7 +341,7 @@ def main():
         del path
         torch.cuda.empty_cache()
         from news_recsys_amd.sharding import ShardedBenchPath
-        p2 = ShardedBenchPath(args.workload, device, seed, rank, world, BATCH, other)
+        p2 = ShardedBenchPath(args.workload, device, seed, rank, world, BATCH, other, host_staged=staged)
         dt2, k2 = timed(p2.step)
         if p2.overflowed():
             raise SystemExit("fixed-capacity exchange overflowed in the secondary measurement")

@@ -568,14 +568,14 @@ class ShardedBenchPath:
     row-sharded over `world` ranks, B impressions per rank (weak scaling)."""
 
     def __init__(self, wl: str, device, seed: int, rank: int, world: int, batch: int, mode: str = "row", n_pool: int = 8,
-                 replicate_below_bytes: int = 256 << 20):
+                 replicate_below_bytes: int = 256 << 20, host_staged: bool = False):
         """mode "row": every table row-sharded (the north-star layout).  mode "auto": planner -- tables
         of at most `replicate_below_bytes` are held in full on every rank (no exchange for them), larger
         ones are row-sharded."""
         import bench
         feats, self.desc = bench.workload_spec(wl)
         self.rank, self.world, self.batch = rank, world, batch
-        self.eng = RowShardedEmbedding(rank, world, overflow_policy="defer")
+        self.eng = RowShardedEmbedding(rank, world, overflow_policy="defer", host_staged=host_staged)
         gen = torch.Generator(device=device).manual_seed(seed)
         self.tables: Dict[str, torch.Tensor] = {}
         self.feats: List[ShardedFeature] = []
