@@ -480,6 +480,7 @@ struct SortedBwdArgs {
     const int64_t* uniq_keys;   // optional: (table << 40 | row) of each unique entry; row 0 -> zero grad
     int64_t n_unique;
     const int64_t* n_unique_dev;   // optional: actual count on the device (n_unique is then an upper bound)
+    int64_t uniform_len;           // > 0: every feature has this many flat lookups (feature = p / uniform_len)
     float* values;
     int32_t n;
     int32_t dim;
@@ -505,7 +506,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_kernel(const Sorte
         for (int64_t e = lo; e < hi; ++e) {
             const int64_t p = nrx_gconst<int64_t>(a->order)[e];
             int fi = 0;
-            {   // feature of flat lookup p (<= 64 entries)
+            if (a->uniform_len > 0) {
+                fi = (int)(p / a->uniform_len);      // every feature contributes the same number of lookups: no search
+            } else {   // feature of flat lookup p (<= 64 entries): a chain of dependent loads from the argument block
                 int l0 = 0, h0 = a->n;
                 while (h0 - l0 > 1) {
                     const int mid = (l0 + h0) >> 1;
@@ -814,6 +817,9 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
         off += batch * (s.kind == NRX_SPARSE ? 1 : s.bag_len);
     }
     a.off[n_feats] = off;
+    a.uniform_len = a.off[1] - a.off[0];
+    for (int i = 0; i < n_feats && a.uniform_len > 0; ++i)
+        if (a.off[i + 1] - a.off[i] != a.uniform_len) a.uniform_len = 0;
     a.batch = batch;
     a.g_out = g_out;
     a.out_ld = out_ld;
