@@ -170,8 +170,10 @@ NRX_API int nrx_bag_pool_bwd(const float* g_out, const float* mask, int64_t batc
  * FM.get_inp_embedding + FMModel.forward without bias/sigmoid (fm/model.py:18-26,48-59).       */
 NRX_API int nrx_fm_fwd(const float* feat, int64_t ld, int32_t n_fields, int32_t dim, int64_t batch,
                float* fm_out, void* stream);
+/* g_feat[b, :] = (g_in ? g_in[b, :] : 0) + g_fm[b] * d fm / d feat[b, :].  g_in may be g_feat (in place) or another
+ * buffer (e.g. the upstream gradient of the concat, left untouched: no copy needed) or NULL.                 */
 NRX_API int nrx_fm_bwd(const float* feat, int64_t ld, int32_t n_fields, int32_t dim, int64_t batch,
-               const float* g_fm, float* g_feat, int64_t g_ld, int32_t accumulate, void* stream);
+               const float* g_fm, const float* g_in, int64_t g_in_ld, float* g_feat, int64_t g_ld, void* stream);
 
 /* ---- DCN v1 cross network: x_{l+1} = x0 * (x_l . w_l) + b_l + x_l ------------------------------
  * DCNLayer.forward / DCNNet.forward (dcn/dcn_arch.py:14-30, 63-70) in the algebraic O(B*D)

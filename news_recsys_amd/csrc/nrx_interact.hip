@@ -107,8 +107,8 @@ __global__ __launch_bounds__(NRX_BLOCK) void fm_fwd_kernel(const float* __restri
 
 template <int QLOG2>
 __global__ __launch_bounds__(NRX_BLOCK) void fm_bwd_kernel(const float* __restrict__ feat, int64_t ld, int F, int D, int64_t batch,
-                                                           const float* __restrict__ g_fm, float* __restrict__ g_feat, int64_t g_ld,
-                                                           bool accumulate, bool vec) {
+                                                           const float* __restrict__ g_fm, const float* g_in, int64_t g_in_ld,
+                                                           float* g_feat, int64_t g_ld, bool vec) {
     constexpr int Q = 1 << QLOG2;
     constexpr int TB = NRX_BLOCK / Q;
     constexpr int U = 8;               // field rows in flight per lane
@@ -116,11 +116,13 @@ __global__ __launch_bounds__(NRX_BLOCK) void fm_bwd_kernel(const float* __restri
     const int64_t b = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
     if (b >= batch) return;
     const float gl = g_fm[b];
-    const bool gvec = vec && (g_ld & 3) == 0 && ((reinterpret_cast<uintptr_t>(g_feat) & 15u) == 0);
+    const bool gvec = vec && (g_ld & 3) == 0 && ((reinterpret_cast<uintptr_t>(g_feat) & 15u) == 0) &&
+                      (g_in == nullptr || ((g_in_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(g_in) & 15u) == 0));
     for (int kc = 0; kc < D; kc += 4 * Q) {
         const int k0 = kc + q * 4;
         if (k0 >= D) continue;
         const float* row = feat + b * ld + k0;
+        const float* irow = g_in ? g_in + b * g_in_ld + k0 : nullptr;
         float* grow = g_feat + b * g_ld + k0;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         int f = 0;
@@ -135,30 +137,34 @@ __global__ __launch_bounds__(NRX_BLOCK) void fm_bwd_kernel(const float* __restri
             const float4 v = ld4(row + (int64_t)f * D, k0, D, vec);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        for (f = 0; f < F; f += U) {          // pass 2: d/dv_f = gl * (S - v_f); the rows are L1/L2-hot
-            float4 v[U], old[U];
+        // pass 2: d/dv_f = gl * (S - v_f) (+ upstream); the feature rows are L1/L2-hot.  Full groups are straight-line
+        // (2U loads in flight, then U stores); the aligned fast path only -- the tail and odd shapes go field by field
+        f = 0;
+        if (gvec && k0 + 4 <= D) {
+            for (; f + U <= F; f += U) {
+                float4 v[U], up[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (f + u < F) {
+                for (int u = 0; u < U; ++u) {
                     v[u] = ld4(row + (int64_t)(f + u) * D, k0, D, vec);
-                    old[u] = (accumulate && gvec) ? *reinterpret_cast<const float4*>(grow + (int64_t)(f + u) * D) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    up[u] = irow ? *reinterpret_cast<const float4*>(irow + (int64_t)(f + u) * D) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float4 g = make_float4(gl * (s.x - v[u].x), gl * (s.y - v[u].y), gl * (s.z - v[u].z), gl * (s.w - v[u].w));
+                    if (k0 == 0) g.x = gl;      // d/dw = 1
+                    *reinterpret_cast<float4*>(grow + (int64_t)(f + u) * D) = make_float4(up[u].x + g.x, up[u].y + g.y, up[u].z + g.z, up[u].w + g.w);
                 }
             }
+        }
+        for (; f < F; ++f) {
+            const float4 v = ld4(row + (int64_t)f * D, k0, D, vec);
+            float g[4] = {gl * (s.x - v.x), gl * (s.y - v.y), gl * (s.z - v.z), gl * (s.w - v.w)};
+            if (k0 == 0) g[0] = gl;
+            float* gp = grow + (int64_t)f * D;
+            const float* ip = irow ? irow + (int64_t)f * D : nullptr;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (f + u < F) {
-                    float g[4] = {gl * (s.x - v[u].x), gl * (s.y - v[u].y), gl * (s.z - v[u].z), gl * (s.w - v[u].w)};
-                    if (k0 == 0) g[0] = gl;     // d/dw = 1
-                    float* gp = grow + (int64_t)(f + u) * D;
-                    if (gvec && k0 + 4 <= D) {
-                        *reinterpret_cast<float4*>(gp) = make_float4(old[u].x + g[0], old[u].y + g[1], old[u].z + g[2], old[u].w + g[3]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (k0 + j < D) gp[j] = accumulate ? gp[j] + g[j] : g[j];
-                    }
-                }
-            }
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j < D) gp[j] = (ip ? ip[j] : 0.f) + g[j];
         }
     }
 }
@@ -634,7 +640,7 @@ extern "C" int nrx_fm_fwd(const float* feat, int64_t ld, int32_t n_fields, int32
 }
 
 extern "C" int nrx_fm_bwd(const float* feat, int64_t ld, int32_t n_fields, int32_t dim, int64_t batch,
-                          const float* g_fm, float* g_feat, int64_t g_ld, int32_t accumulate, void* stream) {
+                          const float* g_fm, const float* g_in, int64_t g_in_ld, float* g_feat, int64_t g_ld, void* stream) {
     NRX_REQUIRE(feat && g_fm && g_feat && n_fields >= 1 && dim >= 1 && batch >= 0, "nrx_fm_bwd: bad argument");
     if (batch == 0) return NRX_OK;
     int ql = ceil_log2i((dim + 3) / 4);
@@ -643,7 +649,7 @@ extern "C" int nrx_fm_bwd(const float* feat, int64_t ld, int32_t n_fields, int32
     const int tb = NRX_BLOCK >> ql;
     const unsigned grid = (unsigned)((batch + tb - 1) / tb);
     NRX_QSWITCH(ql, { hipLaunchKernelGGL((fm_bwd_kernel<QL>), dim3(grid), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
-                                         feat, ld, n_fields, dim, batch, g_fm, g_feat, g_ld, accumulate != 0, vec); });
+                                         feat, ld, n_fields, dim, batch, g_fm, g_in, g_in_ld, g_feat, g_ld, vec); });
     NRX_LAUNCH_CHECK("nrx_fm_bwd");
     return NRX_OK;
 }
