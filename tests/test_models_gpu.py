@@ -241,3 +241,26 @@ def test_dcn_fused_gather_cross_training_matches_two_launches(tmp_path, sparse_g
         torch.testing.assert_close(gp, gq, rtol=2e-4, atol=2e-6, msg=lambda m, n=n: f"{n}: {m}")
     with torch.no_grad():
         torch.testing.assert_close(m_f(batch), m_t(batch), rtol=1e-5, atol=1e-6)
+
+
+def test_training_steps_leave_no_uncollected_tensors():
+    """A model with the fused FM epilogue saves the forward concat for backward; that must not form a reference cycle
+    (ctx -> output -> grad_fn -> ctx): with the garbage collector OFF, allocated device memory stays flat over steps."""
+    import gc
+    g = gold("model_fm")
+    m = DeepFM(os.path.join(CONFIGS, "cf_fm_small.yaml")).to(DEV)
+    batch = batch_of(g)
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+    gc.collect()
+    gc.disable()
+    try:
+        seen = []
+        for i in range(12):
+            opt.zero_grad()
+            F.binary_cross_entropy(m(batch).view(-1), batch["label"][:, 0]).backward()
+            opt.step()
+            torch.cuda.synchronize()
+            seen.append(torch.cuda.memory_allocated())
+        assert len(set(seen[3:])) == 1, seen
+    finally:
+        gc.enable()
