@@ -6,7 +6,7 @@ MI355X host) for well under 0.4 ms of GPU work.  The fused HIP launches only enq
 stream and allocate through torch's caching allocator, so the complete step -- fused gather forward, MLP,
 loss, backward including the HIP scatter, optimizer -- can be captured once in a `torch.cuda.CUDAGraph` (a
 hipGraph) and replayed: 367 us per step at B = 1024, same losses, parameters equal to eager within float-atomic
-reordering (tools/try_graph_capture.py, tests/test_graph_capture_gpu.py).
+reordering (tools/bench_train_step.py, tests/test_graph_capture_gpu.py).
 
 Constraints while capturing (checked / arranged by `GraphedStep`): the out-of-range-id check must not read
 back (`ops.set_index_check("off")` for the duration of the capture and of every replay's semantics: ids are

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Dev: can a whole training step (fused HIP embedding fwd -> MLP -> BCE -> backward incl. the HIP scatter ->
+"""Whole-training-step timing at small batches: (a) the reference's module code restated in plain PyTorch-ROCm eager
+(one nn.Embedding per table, masked-mean pooling, torch.cat, the same MLP, Adam), (b) this package's Deep eagerly,
+(c) the same step captured in a HIP graph.  Also answers: can a whole training step (fused HIP embedding fwd -> MLP -> BCE -> backward incl. the HIP scatter ->
 Adam) be captured in a HIP graph (torch.cuda.CUDAGraph) and replayed?  Compares eager vs replay results and
 step time in the host-bound small-batch regime."""
 import os, sys, time
@@ -93,4 +95,33 @@ def timeit(fn, n=200):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
-print(f"B={B}: eager step {timeit(lambda: step(m_e, opt_e, batches[0])):8.1f} us   graph replay {timeit(g.replay):8.1f} us")
+
+
+class TorchDeep(torch.nn.Module):
+    """base_model.py:262-308 + deep/model.py:36-43 in stock torch ops (what the reference runs on any GPU)."""
+    def __init__(self, m):
+        super().__init__()
+        self.tables = torch.nn.ModuleDict({n: torch.nn.Embedding(e.weight.shape[0], e.weight.shape[1], padding_idx=0)
+                                           for n, e in m.embedding_tables.items()})
+        self.names = sorted(m.user_feature_names | m.item_feature_names)
+        self.share = dict(m.share_emb_table_features)
+        self.arrays = set(m.array_feature_names)
+        import copy
+        self.score_fc = copy.deepcopy(m.score_fc)
+    def forward(self, b):
+        outs = []
+        for n in self.names:
+            e = self.tables[self.share.get(n, n)](b[n].long())
+            if n in self.arrays:
+                mk = b[n + "_mask"]
+                e = (e * mk.unsqueeze(-1)).sum(dim=1) / (mk.sum(dim=1, keepdim=True) + 1e-8)
+            outs.append(e)
+        return torch.sigmoid(self.score_fc(torch.cat(outs, dim=1)))
+
+m_t = TorchDeep(m_e).to(dev)
+opt_t = torch.optim.Adam(m_t.parameters(), lr=1e-3)
+t_ref = timeit(lambda: step(m_t, opt_t, batches[0]))
+t_e = timeit(lambda: step(m_e, opt_e, batches[0]))
+t_g = timeit(g.replay)
+print(f"B={B}: stock-torch eager {t_ref:8.1f} us   this package eager {t_e:8.1f} us   HIP-graph replay {t_g:8.1f} us   "
+      f"(x{t_ref / t_g:.1f} vs stock torch)")
