@@ -516,6 +516,38 @@ def test_full_size_c2_identity_tables_and_linearity():
     assert rel < 1e-5        # fp32 accumulation of ~1e13-sized terms
 
 
+def test_full_size_c3_fused_gather_cross_properties():
+    """Config 3 shape at full batch (5 features x D=64 -> x[65536, 320], 2 cross layers; the news table scaled to 20 M
+    rows = 5 GB): the fused launch's left half must be the gathered rows exactly (identity tables: row r holds
+    r * 2^-20 + feature), and its right half the cross of those rows -- checked in float64 on every 97th sample and, over
+    the whole batch, through the identity cross(x; w = 0, b) = x + b_0 + b_1 (bit-exact in the kernel's order)."""
+    D, B = 64, 65536
+    rows = [18, 20_000_000, 270, 18, 1_000_000]
+    gen = torch.Generator(device=DEV).manual_seed(33)
+    tables = []
+    for f, r in enumerate(rows):
+        t = (torch.arange(r, device=DEV, dtype=torch.float32) * 2.0 ** -20 + f)[:, None].expand(r, D).contiguous()
+        t[0] = 0
+        tables.append(t)
+    ids = [torch.randint(1, r, (B,), device=DEV, generator=gen) for r in rows]
+    W = 5 * D
+    plan = ops.EmbedPlan([ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, i * D) for i in range(5)], out_width=W)
+    assert ops.fused_cross_is_fast(plan)
+    w = torch.randn(2, W, device=DEV, generator=gen) / W ** 0.5
+    b = torch.randn(2, W, device=DEV, generator=gen) * 0.1
+    buf = ops.embed_dcn_v1(plan, tables, ids, w, b)
+    want_x = torch.stack([ids[f].float() * 2.0 ** -20 + f for f in range(5)], dim=1)[:, :, None].expand(B, 5, D).reshape(B, W)
+    assert torch.equal(buf[:, :W], want_x)
+    sub = slice(0, B, 97)
+    x0 = want_x[sub].double()
+    xl = x0
+    for l in range(2):
+        xl = x0 * (xl @ w[l].double())[:, None] + b[l].double() + xl
+    torch.testing.assert_close(buf[sub, W:].double(), xl, rtol=1e-5, atol=1e-5)
+    lin = ops.embed_dcn_v1(plan, tables, ids, torch.zeros_like(w), b)
+    assert torch.equal(lin[:, W:], b[1] + (b[0] + want_x))          # the kernel's own order of the two additions: exact
+
+
 def test_full_size_c4_history_pooling_property():
     """Config 4 shape (history L=50, D=16, B=65536, 200k-row news table): mean-pooling rows that all
     equal the row id gives mean(ids over valid positions); all-masked bags give exact zeros."""
