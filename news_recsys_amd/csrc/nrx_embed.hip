@@ -19,10 +19,10 @@
 //     {int32 id, f32 weight} pairs, read back as broadcast ds_read_b64;
 //   * the FM sums over fields stay in registers across the feature walk; the final reduction over
 //     the Q lanes of a sample is a wavefront shuffle (Q <= 64 lanes never straddle a wave).
-// The uniform kernel is the same mapping specialised for "all features single-valued, same D = 4Q":
-// ids and rows of U features are requested back-to-back so that U independent random row reads per
-// lane are in flight (the path is latency x bandwidth bound: 64 B rows from tables >> L2/MALL).
+// The uniform kernel (nrx_embed_ring.h) is the same mapping specialised for "all features single-valued, same D = 4Q":
+// ids staged once per block in LDS, then a ring of R row loads per lane kept in flight across the feature walk.
 #include "nrx_common.h"
+#include "nrx_embed_ring.h"   // UniformArgs, fm_accumulate, group_sum, embed_fwd_ring
 
 bool nrx_launch_uniform_wide(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, float* out, int64_t out_ld,
                              float* wide_out, int64_t wide_ld, int32_t* status, hipStream_t st);   // nrx_embed_wide.hip
@@ -59,33 +59,6 @@ __device__ __forceinline__ float4 load_row4(const float* table, int64_t id, int 
         v.z = (k0 + 2 < D) ? p[2] : 0.f;
         v.w = (k0 + 3 < D) ? p[3] : 0.f;
     }
-    return v;
-}
-
-// FM bookkeeping for one field chunk held by this lane (columns k0..k0+3 of the field):
-// column 0 is the first-order weight, columns 1.. are the factor vector.
-__device__ __forceinline__ void fm_accumulate(float4 v, int k0, int D, float& first, float4& s, float4& sq) {
-    if (k0 == 0) {
-        first += v.x;
-        v.x = 0.f;
-    }
-    if (k0 + 1 >= D) v.y = 0.f;
-    if (k0 + 2 >= D) v.z = 0.f;
-    if (k0 + 3 >= D) v.w = 0.f;
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
-}
-
-// sum over the Q lanes of a sample, result in all of them: DPP moves inside a 16-lane row (no LDS round trip);
-// wider groups finish with cross-row shuffles
-template <int Q>
-__device__ __forceinline__ float group_sum(float v) {
-    if (Q >= 2) v += nrx_dpp<0xB1>(v);           // lane ^ 1
-    if (Q >= 4) v += nrx_dpp<0x4E>(v);           // lane ^ 2
-    if (Q >= 8) v += nrx_dpp<0x141>(v);          // other quad of each 8
-    if (Q >= 16) v += nrx_dpp<0x140>(v);         // other half of each 16
-#pragma unroll
-    for (int off = 16; off < Q; off <<= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
@@ -245,118 +218,6 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_generic(const EmbedArgs a
                              (fm_s.z * fm_s.z - fm_q.z) + (fm_s.w * fm_s.w - fm_q.w)) + fm_first;
         part = group_sum<Q>(part);
         if (live && q == 0) a.fm_out[b] = part;
-    }
-}
-
-// --------------------------------------------------------------------------------------------
-// Uniform forward: every feature single-valued with the same D = 4*Q, 16 B aligned everywhere.
-// --------------------------------------------------------------------------------------------
-struct UniformArgs {
-    const float* table[NRX_MAX_FEATURES];
-    const void* index[NRX_MAX_FEATURES];
-    int64_t rows[NRX_MAX_FEATURES];
-    int32_t col4[NRX_MAX_FEATURES];   // out column / 4
-    int64_t batch;
-    float4* out;                      // may be null (FM-only inference)
-    int64_t ld4;                      // out_ld / 4
-    float* fm_out;
-    int32_t* status;
-    int32_t n;
-};
-static_assert(sizeof(UniformArgs) <= 3584, "kernarg budget");
-
-// One straight-line group of CNT features: CNT id loads, then CNT independent row loads, then CNT
-// stores -- no control flow, so all CNT random row reads of a lane are in flight together.
-// Out-of-range ids are clamped branch-free and reported once per lane after the feature walk.
-template <int CNT, bool IDX64>
-__device__ __forceinline__ void uniform_load_ids(const NRX_CONST UniformArgs* a, int f0, int64_t b, int64_t (&id)[CNT]) {
-#pragma unroll
-    for (int u = 0; u < CNT; ++u)
-        id[u] = IDX64 ? nrx_gconst<int64_t>(a->index[f0 + u])[b]
-                      : (int64_t)nrx_gconst<int32_t>(a->index[f0 + u])[b];
-}
-
-// One straight-line group of CNT features: the ids are already in registers; CNT independent row
-// loads are issued, then (software pipeline) the NEXT group's ids are requested before this group's
-// stores, so their latency hides behind the row loads instead of queueing behind the stores.
-// Out-of-range ids are clamped branch-free and reported once per lane after the feature walk.
-template <int Q, int CNT, int NEXT, bool IDX64, bool FM, bool STORE, bool NT>
-__device__ __forceinline__ void uniform_group(const NRX_CONST UniformArgs* a, int f0, int64_t b, int q,
-                                              int64_t (&id)[CNT], int64_t (&id_next)[NEXT == 0 ? 1 : NEXT],
-                                              int& bad_feat, int64_t& bad_id, float& fm_first, float4& fm_s, float4& fm_q) {
-    float4 v[CNT];
-#pragma unroll
-    for (int u = 0; u < CNT; ++u) {
-        const bool bad = (uint64_t)id[u] >= (uint64_t)a->rows[f0 + u];
-        bad_feat = bad ? f0 + u : bad_feat;
-        bad_id = bad ? id[u] : bad_id;
-        id[u] = bad ? 0 : id[u];
-        v[u] = NT ? nrx_ldg4_nt(a->table[f0 + u], id[u] * Q + q) : nrx_ldg4(a->table[f0 + u], id[u] * Q + q);
-    }
-    if (NEXT > 0) uniform_load_ids<(NEXT == 0 ? 1 : NEXT), IDX64>(a, f0 + CNT, b, id_next);
-#pragma unroll
-    for (int u = 0; u < CNT; ++u) {
-        if (STORE) nrx_stg4(a->out, b * a->ld4 + a->col4[f0 + u] + q, v[u]);
-        if (FM) fm_accumulate(v[u], q * 4, 4 * Q, fm_first, fm_s, fm_q);
-    }
-}
-
-template <int Q, int U, int R, bool IDX64, bool FM, bool STORE, bool NT>
-struct UniformTail {
-    static __device__ __forceinline__ void run(const NRX_CONST UniformArgs* a, int f0, int rem, int64_t b, int q, int& bad_feat,
-                                               int64_t& bad_id, float& fm_first, float4& fm_s, float4& fm_q) {
-        if (rem == R) {
-            int64_t id[R], none[1];
-            uniform_load_ids<R, IDX64>(a, f0, b, id);
-            uniform_group<Q, R, 0, IDX64, FM, STORE, NT>(a, f0, b, q, id, none, bad_feat, bad_id, fm_first, fm_s, fm_q);
-        } else {
-            UniformTail<Q, U, R + 1, IDX64, FM, STORE, NT>::run(a, f0, rem, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
-        }
-    }
-};
-template <int Q, int U, bool IDX64, bool FM, bool STORE, bool NT>
-struct UniformTail<Q, U, U, IDX64, FM, STORE, NT> {
-    static __device__ __forceinline__ void run(const NRX_CONST UniformArgs*, int, int, int64_t, int, int&, int64_t&, float&, float4&, float4&) {}
-};
-
-template <int QLOG2, int U, bool IDX64, bool FM, bool STORE, bool NT>
-__global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_uniform(const UniformArgs args_in_kernarg_segment) {
-    const NRX_CONST UniformArgs* a = nrx_kernarg<UniformArgs>();   // == &args_in_kernarg_segment
-    constexpr int Q = 1 << QLOG2;
-    constexpr int TB = NRX_BLOCK / Q;
-    const int tid = threadIdx.x;
-    const int q = tid & (Q - 1);
-    const int64_t b = (int64_t)blockIdx.x * TB + (tid >> QLOG2);
-    if (b >= a->batch) return;   // the Q lanes of a sample leave together: the FM shuffle stays inside the group
-
-    float fm_first = 0.f;
-    float4 fm_s = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 fm_q = make_float4(0.f, 0.f, 0.f, 0.f);
-    int bad_feat = -1;
-    int64_t bad_id = 0;
-
-    int f0 = 0;
-    const int n = a->n;
-    if (n >= U) {
-        int64_t id[U], id_next[U], none[1];
-        uniform_load_ids<U, IDX64>(a, 0, b, id);
-        for (; f0 + 2 * U <= n; f0 += U) {       // a full group follows: prefetch its ids
-            uniform_group<Q, U, U, IDX64, FM, STORE, NT>(a, f0, b, q, id, id_next, bad_feat, bad_id, fm_first, fm_s, fm_q);
-#pragma unroll
-            for (int u = 0; u < U; ++u) id[u] = id_next[u];
-        }
-        uniform_group<Q, U, 0, IDX64, FM, STORE, NT>(a, f0, b, q, id, none, bad_feat, bad_id, fm_first, fm_s, fm_q);
-        f0 += U;
-    }
-    const int rem = n - f0;
-    if (rem > 0) UniformTail<Q, U, 1, IDX64, FM, STORE, NT>::run(a, f0, rem, b, q, bad_feat, bad_id, fm_first, fm_s, fm_q);
-
-    if (bad_feat >= 0 && q == 0) nrx_report_oob(a->status, bad_feat, b, bad_id);
-    if (FM) {
-        float part = 0.5f * ((fm_s.x * fm_s.x - fm_q.x) + (fm_s.y * fm_s.y - fm_q.y) +
-                             (fm_s.z * fm_s.z - fm_q.z) + (fm_s.w * fm_s.w - fm_q.w)) + fm_first;
-        part = group_sum<Q>(part);
-        if (q == 0) nrx_gmut<float>(a->fm_out)[b] = part;
     }
 }
 
@@ -626,41 +487,32 @@ void plan_generic(int max_dim, int max_bag, int& qlog2, int& lds_chunk, size_t& 
     }
 }
 
-// U = features in flight per lane, chosen per call to divide the feature count well.
-template <int QLOG2, int U, bool NT>
-void launch_uniform_u(const UniformArgs& ua, int64_t batch, bool i64, bool fm, bool store, hipStream_t st) {
+// Uniform features (all single-valued, one D = 4Q): the ring kernel of nrx_embed_ring.h.  R = rows in flight per lane.
+template <int QLOG2, int R, bool NT>
+void launch_ring_r(const UniformArgs& ua, int64_t batch, bool fm, bool store, hipStream_t st) {
     constexpr int TB = NRX_BLOCK >> QLOG2;
     const dim3 grid((unsigned)((batch + TB - 1) / TB)), block(NRX_BLOCK);
-    if (i64) {
-        if (fm && store) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, true, true, true, NT>), grid, block, 0, st, ua);
-        else if (fm) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, true, true, false, NT>), grid, block, 0, st, ua);
-        else hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, true, false, true, NT>), grid, block, 0, st, ua);
-    } else {
-        if (fm && store) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, false, true, true, NT>), grid, block, 0, st, ua);
-        else if (fm) hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, false, true, false, NT>), grid, block, 0, st, ua);
-        else hipLaunchKernelGGL((embed_fwd_uniform<QLOG2, U, false, false, true, NT>), grid, block, 0, st, ua);
-    }
+    const size_t lds = (size_t)ua.n * TB * sizeof(int32_t);
+    if (fm && store) hipLaunchKernelGGL((embed_fwd_ring<QLOG2, R, true, true, NT>), grid, block, lds, st, ua);
+    else if (fm) hipLaunchKernelGGL((embed_fwd_ring<QLOG2, R, true, false, NT>), grid, block, lds, st, ua);
+    else hipLaunchKernelGGL((embed_fwd_ring<QLOG2, R, false, true, NT>), grid, block, lds, st, ua);
 }
 
 template <int QLOG2>
-void launch_uniform(const UniformArgs& ua, int64_t batch, bool i64, bool fm, bool store, hipStream_t st) {
-    // group sizes on offer: 13 and 8 (narrow rows), 8 and 5 (wide rows); pick the one that wastes
-    // the fewest tail iterations, ties to the larger group.
+void launch_uniform(const UniformArgs& ua, int64_t batch, bool fm, bool store, hipStream_t st) {
     const int n = ua.n;
-    // non-temporal row loads once the launch's tables exceed the 256 MiB Infinity Cache
+    // non-temporal row loads once the launch's tables exceed the 256 MiB Infinity Cache (cache-resident tables lose
+    // 15-30 % with them, DRAM-resident ones gain 5-8 %)
     int64_t table_bytes = 0;
     for (int i = 0; i < n; ++i) table_bytes += ua.rows[i] * (int64_t)(16 << QLOG2);
     const bool nt = table_bytes > (256ll << 20);
-#define NRX_LU(U_) (nt ? launch_uniform_u<QLOG2, U_, true>(ua, batch, i64, fm, store, st) \
-                       : launch_uniform_u<QLOG2, U_, false>(ua, batch, i64, fm, store, st))
-    if (QLOG2 <= 3) {
-        const int w13 = (13 - n % 13) % 13, w8 = (8 - n % 8) % 8;
-        if (n >= 13 && w13 <= w8) NRX_LU(13); else NRX_LU(8);
-    } else {
-        const int w8 = (8 - n % 8) % 8, w5 = (5 - n % 5) % 5;
-        if (n >= 8 && w8 <= w5) NRX_LU(8); else NRX_LU(5);
-    }
-#undef NRX_LU
+#define NRX_LR(R_) (nt ? launch_ring_r<QLOG2, R_, true>(ua, batch, fm, store, st) : launch_ring_r<QLOG2, R_, false>(ua, batch, fm, store, st))
+    // ring depth: 8 rows in flight per lane, except 64-byte rows streamed from DRAM (C2), where 4 measured 2-3 % faster
+    // with a recycled output buffer (57.7 vs 59.1 us; profiles/r02_c2_ring_sweep.md)
+    if (n >= 8 && !(QLOG2 == 2 && nt)) NRX_LR(8);
+    else if (n >= 4) NRX_LR(4);
+    else NRX_LR(1);
+#undef NRX_LR
 }
 
 }  // namespace
@@ -706,15 +558,15 @@ extern "C" int nrx_embed_fwd(const nrx_feature_t* feats, int32_t n_feats, int64_
         ua.fm_out = fm_out;
         ua.status = status;
         ua.n = n_feats;
+        ua.idx64 = feats[0].index_bits == 64;
         const bool fm = fm_out != nullptr && n_fm > 0;
-        const bool i64 = feats[0].index_bits == 64;
         const bool store = out != nullptr;
         switch (Q0) {
-            case 4: launch_uniform<2>(ua, batch, i64, fm, store, st); break;
-            case 8: launch_uniform<3>(ua, batch, i64, fm, store, st); break;
-            case 16: launch_uniform<4>(ua, batch, i64, fm, store, st); break;
-            case 32: launch_uniform<5>(ua, batch, i64, fm, store, st); break;
-            default: launch_uniform<6>(ua, batch, i64, fm, store, st); break;
+            case 4: launch_uniform<2>(ua, batch, fm, store, st); break;
+            case 8: launch_uniform<3>(ua, batch, fm, store, st); break;
+            case 16: launch_uniform<4>(ua, batch, fm, store, st); break;
+            case 32: launch_uniform<5>(ua, batch, fm, store, st); break;
+            default: launch_uniform<6>(ua, batch, fm, store, st); break;
         }
         NRX_LAUNCH_CHECK("nrx_embed_fwd(uniform)");
         return NRX_OK;
