@@ -9,6 +9,13 @@ writes small .npz fixtures next to this file.  No reference source is copied: th
 hold tensors only (weights, index batches, outputs, gradients).
 
     python tests/golden/gen_golden.py          # rewrites tests/golden/*.npz
+    python tests/golden/gen_golden.py --check  # regenerates into a temp dir and compares with the committed fixtures
+
+Reproducibility: the reference iterates Python sets of feature names (base_model.py:85-90), so the order in which its
+modules register parameters -- and with it which random numbers land in which table -- follows the process's string-hash
+seed.  The script therefore pins PYTHONHASHSEED=0 by re-executing itself before anything is imported (no GPU is involved),
+and randomises parameters in sorted-name order; two runs give bit-identical arrays (checked by --check and by
+tests/test_golden_reproducible.py).
 
 Reference entry points exercised (paths relative to /root/reference):
   src/model/BaseModel/base_model.py:262-308   get_feature_embedding / array_feature_pooling /
@@ -24,6 +31,12 @@ Reference entry points exercised (paths relative to /root/reference):
 """
 import os
 import sys
+
+if os.environ.get("PYTHONHASHSEED") != "0":          # before torch / the reference are imported: pin the set order
+    os.environ["PYTHONHASHSEED"] = "0"
+    os.execv(sys.executable, [sys.executable] + sys.argv)
+
+import tempfile
 import types
 
 import numpy as np
@@ -33,6 +46,7 @@ import torch.nn.functional as F
 import yaml
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE                      # --check writes to a temp dir instead
 CFG = os.path.join(HERE, "configs")
 REF = "/root/reference"
 
@@ -108,7 +122,7 @@ def np_(t):
 
 
 def save(name, d):
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **d)
     print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB, {len(d)} arrays)")
 
@@ -116,7 +130,7 @@ def save(name, d):
 def randomize_tables(model, g):
     """Explicit table weights (the reference's init order is hash-seed dependent)."""
     with torch.no_grad():
-        for name, p in model.named_parameters():
+        for name, p in sorted(model.named_parameters(), key=lambda kv: kv[0]):     # sorted: independent of registration order
             p.copy_(torch.randn(p.shape, generator=g) * (0.5 if "embedding" in name else 0.2))
         for emb in model.embedding_tables.values():
             emb.weight[0].zero_()  # padding_idx row, as nn.Embedding(padding_idx=0) initialises it
@@ -389,8 +403,8 @@ def gen_datareader():
     from torch.utils.data import DataLoader
     from src.dataset.DataReader.data_reader import DataReader
     rng = np.random.default_rng(2026)
-    os.makedirs(os.path.join(HERE, "data"), exist_ok=True)
-    path = os.path.join(HERE, "data", "features_small.txt")
+    os.makedirs(os.path.join(OUT, "data"), exist_ok=True)
+    path = os.path.join(OUT, "data", "features_small.txt")
     lines = []
     for i in range(23):
         n_hist = [0, 9, 7, 1][i] if i < 4 else int(rng.integers(0, 10))       # empty, over-long (truncated to 7), exact, one
@@ -442,10 +456,7 @@ def gen_validation():
     save("validation", d)
 
 
-if __name__ == "__main__":
-    if not os.path.isdir(REF):
-        sys.exit("needs /root/reference (build container only)")
-    install_stubs()
+def generate_all():
     torch.manual_seed(0)
     torch.set_num_threads(1)
     gen_models()
@@ -454,3 +465,46 @@ if __name__ == "__main__":
     gen_lr_schedule()
     gen_datareader()
     gen_validation()
+
+
+def compare_dirs(ref_dir, new_dir):
+    """Array-for-array, bit-for-bit comparison of every fixture (npz containers carry zip timestamps, so the
+    arrays are compared, not the container bytes).  Returns a list of differences."""
+    bad = []
+    names = sorted(f for f in os.listdir(new_dir) if f.endswith(".npz"))
+    for f in names:
+        if not os.path.exists(os.path.join(ref_dir, f)):
+            bad.append(f"{f}: not committed")
+            continue
+        a, b = np.load(os.path.join(ref_dir, f)), np.load(os.path.join(new_dir, f))
+        if sorted(a.files) != sorted(b.files):
+            bad.append(f"{f}: key sets differ")
+            continue
+        for k in a.files:
+            x, y = a[k], b[k]
+            if x.dtype != y.dtype or x.shape != y.shape or x.tobytes() != y.tobytes():
+                bad.append(f"{f}:{k}")
+    for f in sorted(os.listdir(ref_dir)):
+        if f.endswith(".npz") and f not in names:
+            bad.append(f"{f}: committed but not regenerated")
+    a = open(os.path.join(ref_dir, "data", "features_small.txt"), "rb").read()
+    b = open(os.path.join(new_dir, "data", "features_small.txt"), "rb").read()
+    if a != b:
+        bad.append("data/features_small.txt")
+    return bad
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("needs /root/reference (build container only)")
+    install_stubs()
+    if "--check" in sys.argv[1:]:
+        with tempfile.TemporaryDirectory() as tmp:
+            OUT = tmp
+            generate_all()
+            bad = compare_dirs(HERE, tmp)
+        if bad:
+            sys.exit("golden fixtures differ from a regeneration:\n  " + "\n  ".join(bad))
+        print("OK: a regeneration reproduces every committed fixture bit for bit")
+    else:
+        generate_all()
