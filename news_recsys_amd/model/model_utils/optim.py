@@ -23,12 +23,15 @@ class FusedSparseAdam:
     table) gets them merged first, so the step is still ONE Adam update per row.  Tables are identified by tensor
     identity; their moments are created (zeros) the first time a table shows up in the sink."""
 
-    def __init__(self, sink: "ops.SparseGradSink", lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
+    def __init__(self, sink: "ops.SparseGradSink", lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False,
+                 params=None):
         """capturable=True keeps the step counter and the bias-corrected step size on the device (like
         torch.optim.Adam(capturable=True)) so step() can be captured in a HIP graph (graph.GraphedStep); lr is
-        then fixed at capture time."""
+        then fixed at capture time.  params (optional): the table tensors in a stable order -- state_dict() then
+        keys the moments by position in that list, so a checkpoint restores into a freshly built model."""
         self.sink, self.lr, self.betas, self.eps, self.weight_decay = sink, lr, betas, eps, weight_decay
         self.capturable = bool(capturable)
+        self.params = list(params) if params is not None else None
         self._t_dev = None
         self.t = 0
         self.tables = []         # every table seen so far; position = the table's index in the optimizer's key space
@@ -114,6 +117,38 @@ class FusedSparseAdam:
     def zero_grad(self, set_to_none: bool = True):
         self.sink.clear()
 
+    # ---- checkpointing: step count + both moments of every table that has been updated so far
+    def _stable_index(self, t):
+        if self.params is not None:
+            for i, p in enumerate(self.params):
+                if p is t:
+                    return i
+        return None
+
+    def state_dict(self):
+        tables = {}
+        for pos, t in enumerate(self.tables):
+            key = self._stable_index(t)
+            m, v = self.moments[pos]
+            tables[key if key is not None else f"unlisted:{pos}"] = {"exp_avg": m, "exp_avg_sq": v}
+        return {"t": self.t, "t_dev": None if self._t_dev is None else float(self._t_dev.item()), "tables": tables}
+
+    def load_state_dict(self, sd):
+        self.t = int(sd["t"])
+        self._t_dev = None
+        if sd.get("t_dev") is not None and self.capturable and self.params:
+            self._t_dev = torch.tensor(sd["t_dev"], dtype=torch.float64, device=self.params[0].device)
+        for key, mv in sd["tables"].items():
+            if isinstance(key, str):
+                raise ValueError("FusedSparseAdam.load_state_dict: the checkpoint holds moments of a table that was not in "
+                                 "`params` when it was saved; construct the optimizer with params=<the table list>")
+            if self.params is None or not 0 <= key < len(self.params):
+                raise ValueError("FusedSparseAdam.load_state_dict needs params=<the same table list as at save time>")
+            pos = self._register(self.params[key])
+            m, v = self.moments[pos]
+            m.copy_(mv["exp_avg"])
+            v.copy_(mv["exp_avg_sq"])
+
 
 class SparseDenseAdam(torch.optim.Optimizer):
     def __init__(self, sparse_params, dense_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, fused_sink=None,
@@ -125,14 +160,18 @@ class SparseDenseAdam(torch.optim.Optimizer):
         if dense_params:
             groups.append({"params": dense_params, "sparse": False})
         super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._sparse = (FusedSparseAdam(fused_sink, lr=lr, betas=betas, eps=eps, capturable=capturable) if fused_sink is not None
+        self._sparse = (FusedSparseAdam(fused_sink, lr=lr, betas=betas, eps=eps, capturable=capturable, params=sparse_params)
+                        if fused_sink is not None
                         else torch.optim.SparseAdam(sparse_params, lr=lr, betas=betas, eps=eps))
         self._dense = (torch.optim.AdamW(dense_params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable)
                        if dense_params else None)
 
     @torch.no_grad()
     def step(self, closure=None):
-        loss = closure() if closure is not None else None
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():         # the closure runs forward + backward
+                loss = closure()
         for g in self.param_groups:           # a scheduler edits self.param_groups: forward the lr
             if g["sparse"] and isinstance(self._sparse, FusedSparseAdam):
                 self._sparse.lr = g["lr"]
@@ -149,3 +188,19 @@ class SparseDenseAdam(torch.optim.Optimizer):
         self._sparse.zero_grad(set_to_none)
         if self._dense is not None:
             self._dense.zero_grad(set_to_none)
+
+    # ---- checkpointing (Lightning saves optimizer.state_dict()): all Adam state lives in the inner optimizers
+    def state_dict(self):
+        return {"sparse_dense_adam": 1,
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
+                "sparse": self._sparse.state_dict(),
+                "dense": self._dense.state_dict() if self._dense is not None else None}
+
+    def load_state_dict(self, sd):
+        if "sparse_dense_adam" not in sd:
+            raise ValueError("not a SparseDenseAdam state dict")
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
+            g.update(saved)
+        self._sparse.load_state_dict(sd["sparse"])
+        if self._dense is not None and sd.get("dense") is not None:
+            self._dense.load_state_dict(sd["dense"])

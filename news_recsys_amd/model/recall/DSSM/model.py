@@ -12,10 +12,13 @@ Recall evaluation (`on_train_epoch_end` :230-254, `hit_rate` :182-228): the refe
 IndexFlatIP on the host and searches one user at a time (it raises unless batch_size == 1), over-fetching
 k + len(history) and filtering in Python.  Here the item matrix stays in HBM and a whole validation batch
 is one `nrx_topk_ip` call with the history passed as per-query exclusion lists; any batch size works.
-The reference's `self.user_history` / `self.emb_idx_2_val_dict` are never defined anywhere in its tree
-(stale file); here `user_history` is an attribute {user id value -> iterable of item id values} in the
-id space of the batch columns `user_id_feature` / `item_id_feature` (hparams; default 'user_id' /
-'movie_id' as in the reference)."""
+`user_history` is what BaseModel loads from `paths.user_history_path` (base_model.py:55-58; JSON, so user keys are
+strings and a user's entry is a dict keyed by item id, model.py:206) -- or any {user id -> iterable of item ids}
+assigned by hand.  The reference translates batch ids to the history's id space through `emb_idx_2_val_dict`
+(model.py:205,215), which its tree never defines; here it is an optional attribute
+{feature name: {str(embedding index): true id}}: when set, ids are mapped through it exactly as the reference
+does, otherwise the history is taken to be in the id space of the batch columns `user_id_feature` /
+`item_id_feature` (hparams; default 'user_id' / 'movie_id' as in the reference).  Keys may be ints or strings."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -40,7 +43,9 @@ class DSSM(BaseModel):
         self.val_dataloader_ = dataloaders.get("val_dataloader", None)
         self.user_id_feature = self.hparams_.get("user_id_feature", "user_id")
         self.item_id_feature = self.hparams_.get("item_id_feature", "movie_id")
-        self.user_history = {}
+        if not hasattr(self, "user_history"):      # BaseModel.__init__ has loaded paths.user_history_path if configured
+            self.user_history = {}
+        self.emb_idx_2_val_dict = None        # optional {feature: {str(emb idx): true id}} (reference model.py:205,215)
         self.all_item_embeddings = None       # [N, 16] fp32, device resident (reference: numpy + faiss index)
         self.idx_item_emb_dic = {}            # index position -> item id value (model.py:233,247)
         self.last_hit_rate = None
@@ -135,7 +140,46 @@ class DSSM(BaseModel):
         self.item_index_ids = torch.cat(ids, dim=0)
         self.idx_item_emb_dic = dict(enumerate(self.item_index_ids.tolist()))
         self._item_pos = {v: i for i, v in self.idx_item_emb_dic.items()}
+        self._item_pos_true = None
         return self.all_item_embeddings
+
+    @staticmethod
+    def _lookup(d, key, default=None):
+        """dict lookup tolerant of JSON's string keys: tries key, str(key), int(key)."""
+        if key in d:
+            return d[key]
+        sk = str(key)
+        if sk in d:
+            return d[sk]
+        try:
+            ik = int(key)
+        except (TypeError, ValueError):
+            return default
+        return d.get(ik, default)
+
+    def _history_positions(self, uid):
+        """Index positions (rows of all_item_embeddings) of the items user `uid` has interacted with
+        (reference model.py:205-206,213-217: those items are removed from the ranking before the top k is taken)."""
+        m = self.emb_idx_2_val_dict
+        if m is not None:
+            uid = self._lookup(m.get(self.user_id_feature, {}), uid, uid)
+        hist = self._lookup(self.user_history, uid, ())
+        if not hist:
+            return []
+        if m is not None:          # history holds TRUE item ids: compare after mapping every indexed item id
+            true_pos = getattr(self, "_item_pos_true", None)
+            if true_pos is None:
+                im = m.get(self.item_id_feature, {})
+                true_pos = self._item_pos_true = {}
+                for item_id, pos in self._item_pos.items():
+                    true_pos.setdefault(str(self._lookup(im, item_id, item_id)), []).append(pos)
+            return sorted(p for h in hist for p in true_pos.get(str(h), ()))
+        out = []
+        for h in hist:             # a dict (the reference's JSON) iterates its keys
+            p = self._lookup(self._item_pos, h)
+            if p is not None:
+                out.append(p)
+        return out
 
     @torch.no_grad()
     def hit_rate(self, k=10, val_dataloader=None):
@@ -151,8 +195,7 @@ class DSSM(BaseModel):
             batch = self._to_device(batch)
             user_emb = F.normalize(self.user_fc(self.get_user_embedding(batch)), p=2, dim=1)
             uids = batch[self.user_id_feature].reshape(-1).tolist()
-            lists = [[self._item_pos[i] for i in self.user_history.get(u, self.user_history.get(str(u), ())) if i in self._item_pos]
-                     for u in uids]
+            lists = [self._history_positions(u) for u in uids]
             excl = exclusion_csr(lists, user_emb.device) if any(lists) else None
             idx, _ = ops.topk_ip(self.all_item_embeddings, user_emb.contiguous(), k, exclude=excl)
             found = self.item_index_ids[idx.clamp_min(0)].masked_fill(idx < 0, -1)

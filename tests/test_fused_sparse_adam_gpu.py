@@ -126,3 +126,43 @@ def test_model_trains_with_fused_sparse_grad(tmp_path):
     assert losses[-1] < losses[0] - 0.05
     with torch.no_grad():
         assert torch.isfinite(m(b)).all()
+
+
+def test_sparse_dense_adam_fused_checkpoint_resume():
+    """optimizer.state_dict() must carry FusedSparseAdam's moments and step count -- a run restored from it
+    continues bit-identically (the sorted backward and the fused step are deterministic), a run restarted without it
+    does not."""
+    import copy
+    from news_recsys_amd import ops
+    from news_recsys_amd.model.model_utils.optim import SparseDenseAdam
+    plan, tables, batch = _setup(9, shared=True)
+    lin = torch.nn.Linear(56, 1).to(DEV)
+    batches = [batch() for _ in range(5)]
+
+    def build(tabs, lin_):
+        sink = ops.SparseGradSink()
+        ps = [t.clone().requires_grad_(True) for t in tabs]
+        return ps, sink, SparseDenseAdam(ps, list(lin_.parameters()), lr=0.05, fused_sink=sink)
+
+    def run(ps, sink, opt, lin_, bs):
+        for ins, ws, up in bs:
+            opt.zero_grad()
+            (lin_(ops.embed_apply(plan, ps, ins, ws, sparse_grad=sink)[0]) * up[:, :1]).sum().backward()
+            opt.step()
+
+    pa, sa, oa = build(tables, lin)
+    run(pa, sa, oa, lin, batches[:3])
+    sd = oa.state_dict()
+    assert sd["sparse"]["t"] == 3 and len(sd["sparse"]["tables"]) == 3 and sd["dense"]["state"]
+    sd = copy.deepcopy(sd)
+    lin_b, lin_c = copy.deepcopy(lin), copy.deepcopy(lin)
+    pb, sb, ob = build([p.detach() for p in pa], lin_b)          # restored
+    ob.load_state_dict(sd)
+    pc, sc, oc = build([p.detach() for p in pa], lin_c)          # weights only: Adam restarts
+    run(pa, sa, oa, lin, batches[3:])
+    run(pb, sb, ob, lin_b, batches[3:])
+    run(pc, sc, oc, lin_c, batches[3:])
+    for a, b, c in zip(pa, pb, pc):
+        assert torch.equal(a.detach(), b.detach())
+        assert not torch.equal(a.detach(), c.detach())
+    assert torch.equal(lin.weight, lin_b.weight)

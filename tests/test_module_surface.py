@@ -186,3 +186,28 @@ def test_config_loader_attr_access():
     assert c.wide_and_deep_cfg.wide_feature_names == ["category", "subcategory", "user_click_category"]
     assert c.get("paths", {}).get("out_basedir") == "tests/tmp" and c.get("missing", 7) == 7
     assert isinstance(config.to_container(c), dict)
+
+
+def test_dssm_keeps_configured_user_history_and_maps_ids(tmp_path):
+    """DSSM.__init__ must not discard the history BaseModel loaded from paths.user_history_path
+    (reference base_model.py:55-58), and hit_rate's filter must find JSON's string keys (model.py:205-217)."""
+    import json
+    import yaml
+    from news_recsys_amd.model.recall.DSSM.model import DSSM
+    hist = {"3": {"5": 1, "7": 1, "99": 1}, "4": {}}
+    hp = tmp_path / "user_history.json"
+    hp.write_text(json.dumps(hist))
+    cfg = yaml.safe_load(open(os.path.join(CONFIGS, "cf_dssm_small.yaml")))
+    cfg.setdefault("paths", {})["user_history_path"] = str(hp)
+    cfg_path = tmp_path / "cf.yaml"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    m = DSSM(str(cfg_path), {}, {"negative_sample_rate": 1, "item_id_feature": "item_id"})
+    assert m.user_history == hist
+    m._item_pos = {1: 0, 5: 1, 7: 2}                    # what build_item_index leaves: item id -> index position
+    m._item_pos_true = None
+    assert m._history_positions(3) == [1, 2]            # int user id from the batch, string keys in the JSON; 99 not indexed
+    assert m._history_positions(4) == [] and m._history_positions(12345) == []
+    # the reference's id translation (emb_idx_2_val_dict, model.py:205,215), when the caller provides it
+    m.emb_idx_2_val_dict = {"user_id": {"3": "u3"}, "item_id": {"1": "A", "5": "B", "7": "C"}}
+    m.user_history = {"u3": {"C": 1, "A": 1}}
+    assert m._history_positions(3) == [0, 2]

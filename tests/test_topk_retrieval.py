@@ -218,6 +218,23 @@ def test_dssm_hit_rate_matches_reference_loop():
     # batch size 1 (the only size the reference accepts) gives the same number
     val1 = [{k: v[i:i + 1] for k, v in b.items()} for b in val for i in range(20)]
     assert m.hit_rate(10, val1) == pytest.approx(ref)
+    # the history as the reference gets it: JSON at paths.user_history_path (string user keys, per-user dicts keyed by
+    # item id; base_model.py:55-58, model.py:206) -- loaded by BaseModel.__init__ and NOT discarded by DSSM.__init__
+    import json, tempfile, yaml
+    with tempfile.TemporaryDirectory() as tmp:
+        hp_path = os.path.join(tmp, "user_history.json")
+        json.dump({str(u): {str(i): 1 for i in h} for u, h in hist_of.items()}, open(hp_path, "w"))
+        cfg = yaml.safe_load(open(os.path.join(CONFIGS, "cf_dssm_small.yaml")))
+        cfg.setdefault("paths", {})["user_history_path"] = hp_path
+        cfg_path = os.path.join(tmp, "cf.yaml")
+        yaml.safe_dump(cfg, open(cfg_path, "w"))
+        m2 = DSSM(cfg_path, {"movies_dataloader": movies, "val_dataloader": val}, hp).to(DEV)
+    assert set(m2.user_history) == {str(u) for u in hist_of}
+    m2.load_state_dict(m.state_dict())
+    m2.on_train_epoch_end()
+    assert m2.last_hit_rate == pytest.approx(ref)
+    m2.user_history = {}                       # without the history the seen items come back and the rate changes
+    assert m2.hit_rate(10) != pytest.approx(ref)
 
 
 @gpu
