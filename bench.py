@@ -158,7 +158,7 @@ class SingleGpuPath:
         res = call.run()
         if self.cross:       # (two-launch form) cat[x, cross(x)]: cross written next to x in the same [B, 2D] buffer
             buf, D = call.out, self.width
-            rc = self.lib.nrx_dcn_v1_fwd(buf.data_ptr(), 2 * D, BATCH, D, self.cross_w.shape[0], self.cross_w.data_ptr(),
+            rc = self.lib.nrx_dcn_v1_fwd(buf.data_ptr(), 2 * D, None, 0, BATCH, D, self.cross_w.shape[0], self.cross_w.data_ptr(),
                                          self.cross_b.data_ptr(), buf.data_ptr() + 4 * D, 2 * D,
                                          torch.cuda.current_stream(self.device).cuda_stream)
             assert rc == 0

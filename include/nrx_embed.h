@@ -37,7 +37,7 @@ extern "C" {
 #define NRX_API
 #endif
 
-#define NRX_ABI_VERSION 1
+#define NRX_ABI_VERSION 2
 #define NRX_MAX_FEATURES 64   /* per launch; the host splits wider feature sets */
 #define NRX_MAX_DCN_LAYERS 8
 
@@ -178,15 +178,19 @@ NRX_API int nrx_fm_bwd(const float* feat, int64_t ld, int32_t n_fields, int32_t 
 /* ---- DCN v1 cross network: x_{l+1} = x0 * (x_l . w_l) + b_l + x_l ------------------------------
  * DCNLayer.forward / DCNNet.forward (dcn/dcn_arch.py:14-30, 63-70) in the algebraic O(B*D)
  * form (the reference materialises a [B,D,D] outer product).  w, b: device [n_layers, dim].
- * All layers run in one launch with the row held in registers.  out may alias a different
- * column block of the same buffer as x (e.g. out = x + dim with ld = 2*dim gives cat[x, cross],
- * dcn/model.py:29).                                                                            */
-NRX_API int nrx_dcn_v1_fwd(const float* x, int64_t x_ld, int64_t batch, int32_t dim, int32_t n_layers,
-                   const float* w, const float* b, float* out, int64_t out_ld, void* stream);
-/* g_w, g_b: device [n_layers, dim], pre-zeroed, accumulated with atomics. */
-NRX_API int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, int64_t batch, int32_t dim, int32_t n_layers,
-                   const float* w, const float* b, const float* g_out, int64_t g_out_ld,
-                   float* g_x, int64_t g_x_ld, float* g_w, float* g_b, void* stream);
+ * All layers run in one launch with the row held in registers.  x is the input of the FIRST of the n_layers
+ * layers; x0 is the layer-0 input of the whole cross network (DCNLayer.forward(x_l, x_0) takes both,
+ * dcn_arch.py:14): NULL (or x itself) when the stack starts at layer 0 -- DCNNet.forward's case.
+ * out may alias a different column block of the same buffer as x (e.g. out = x + dim with ld = 2*dim
+ * gives cat[x, cross], dcn/model.py:29).                                                          */
+NRX_API int nrx_dcn_v1_fwd(const float* x, int64_t x_ld, const float* x0, int64_t x0_ld, int64_t batch, int32_t dim,
+                   int32_t n_layers, const float* w, const float* b, float* out, int64_t out_ld, void* stream);
+/* g_w, g_b: device [n_layers, dim], pre-zeroed, accumulated with atomics.  With x0 == NULL, g_x0 must be NULL
+ * and g_x receives the whole input gradient; with a separate x0, g_x = dL/dx (the stack's first input) and
+ * g_x0 = dL/dx0. */
+NRX_API int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int64_t x0_ld, int64_t batch, int32_t dim,
+                   int32_t n_layers, const float* w, const float* b, const float* g_out, int64_t g_out_ld,
+                   float* g_x, int64_t g_x_ld, float* g_x0, int64_t g_x0_ld, float* g_w, float* g_b, void* stream);
 
 /* Fused gather -> concat -> DCN-v1 cross for the DCN ranker (dcn/model.py:25-29 on top of
  * base_model.py:284-308): out[:, 0:width] = concat of the looked-up rows (x), out[:, width:2*width] =

@@ -19,6 +19,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnrx_hip.so")
 
+NRX_ABI_VERSION = 2
 NRX_MAX_FEATURES = 64
 NRX_MAX_DCN_LAYERS = 8
 NRX_OK = 0
@@ -65,8 +66,8 @@ SIGNATURES = {
     "nrx_bag_pool_bwd": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     "nrx_fm_fwd": (C.c_int, [_p, _i64, _i32, _i32, _i64, _p, _p]),
     "nrx_fm_bwd": (C.c_int, [_p, _i64, _i32, _i32, _i64, _p, _p, _i64, _p, _i64, _p]),
-    "nrx_dcn_v1_fwd": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p]),
-    "nrx_dcn_v1_bwd": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _i64, _p, _p, _p]),
+    "nrx_dcn_v1_fwd": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p]),
+    "nrx_dcn_v1_bwd": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p]),
     "nrx_embed_dcn_v1_fwd": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _i32, _p, _i64, _i32, _p, _p, _p, _p]),
     "nrx_dcn_v2_layer_fwd": (C.c_int, [_p, _p, _i64, _i64, _i32, _p, _p, _i32, _p, _i64, _p]),
     "nrx_bucketize_workspace": (_i64, [_i64, _i32]),
@@ -106,8 +107,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
         fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.nrx_abi_version() != 1:
-        raise NrxError(f"ABI version mismatch: library reports {lib.nrx_abi_version()}, binding expects 1")
+    if lib.nrx_abi_version() != NRX_ABI_VERSION:
+        raise NrxError(f"ABI version mismatch: library reports {lib.nrx_abi_version()}, binding expects {NRX_ABI_VERSION}")
     if path is None:
         _lib = lib
     return lib

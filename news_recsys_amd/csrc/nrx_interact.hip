@@ -214,8 +214,10 @@ __device__ __forceinline__ float row_dot(const RowRegs<R, V>& a, const RowRegs<R
     return nrx_wave_sum(s);
 }
 
+// x0p: the layer-0 input when the stack starts from a later x_l (DCNLayer.forward(x_l, x_0), dcn_arch.py:14-30); null = x.
 template <int R, int V>
-__global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_fwd_kernel(const float* __restrict__ x, int64_t x_ld, int64_t batch, int D, int NL,
+__global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_fwd_kernel(const float* __restrict__ x, int64_t x_ld, const float* __restrict__ x0p,
+                                                               int64_t x0_ld, int64_t batch, int D, int NL,
                                                                const float* __restrict__ w, const float* __restrict__ bvec,
                                                                float* __restrict__ out, int64_t out_ld) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -233,8 +235,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_fwd_kernel(const float* __re
     const int64_t nwaves = (int64_t)gridDim.x * (NRX_BLOCK / 64);
     for (int64_t row = wave; row < batch; row += nwaves) {
         RowRegs<R, V> x0, xl;
-        row_load<R, V>(x0, x + row * x_ld, D, lane);
-        xl = x0;
+        row_load<R, V>(xl, x + row * x_ld, D, lane);
+        if (x0p != nullptr) row_load<R, V>(x0, x0p + row * x0_ld, D, lane);
+        else x0 = xl;
         for (int l = 0; l < NL; ++l) {
             RowRegs<R, V> wl, bl;
             row_load<R, V>(wl, s_w + l * Dp, Dp, lane);
@@ -260,12 +263,15 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_fwd_kernel(const float* __re
 // from every block, and device-scope atomics on one address serialise -- with 2048 blocks of 256 threads that
 // tail was ~60 of the kernel's 99 us; 256 blocks cut the atomics eightfold while 16 waves per block keep 4 per SIMD.
 // (3+ layers need more than the 128 VGPRs a 1024-thread block allows: 512-thread blocks, two per CU.)
-template <int R, int V, int NLR, int DCN_BWD_BLOCK>
+// SEP: the stack starts from x (= x_l) with a separate layer-0 input x0p; its gradient goes to g_x0 (x's to g_x).
+template <int R, int V, int NLR, int DCN_BWD_BLOCK, bool SEP = false>
 __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* __restrict__ x, int64_t x_ld, int64_t batch, int D, int NL,
                                                                const float* __restrict__ w, const float* __restrict__ bvec,
                                                                const float* __restrict__ g_out, int64_t g_out_ld,
                                                                float* __restrict__ g_x, int64_t g_x_ld,
-                                                               float* __restrict__ g_w, float* __restrict__ g_b) {
+                                                               float* __restrict__ g_w, float* __restrict__ g_b,
+                                                               const float* __restrict__ x0p, int64_t x0_ld,
+                                                               float* __restrict__ g_x0, int64_t g_x0_ld) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Dp = (D + 3) & ~3;
     float* s_w = reinterpret_cast<float*>(smem);   // [NL][Dp]
@@ -296,13 +302,14 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
     // store, so the memory system is never idle behind the arithmetic of a wave
     RowRegs<R, V> x0n, gn;
     if (wave < batch) {
-        row_load<R, V>(x0n, x + wave * x_ld, D, lane);
+        row_load<R, V>(x0n, (SEP ? x0p + wave * x0_ld : x + wave * x_ld), D, lane);
         row_load<R, V>(gn, g_out + wave * g_out_ld, D, lane);
     }
     for (int64_t row = wave; row < batch; row += nwaves) {
-        RowRegs<R, V> x0 = x0n, g = gn, gx0;
+        RowRegs<R, V> x0 = x0n, g = gn, gx0, xs;
+        if (SEP) row_load<R, V>(xs, x + row * x_ld, D, lane);      // the stack's first input x_l (not prefetched)
         if (row + nwaves < batch) {
-            row_load<R, V>(x0n, x + (row + nwaves) * x_ld, D, lane);
+            row_load<R, V>(x0n, (SEP ? x0p + (row + nwaves) * x0_ld : x + (row + nwaves) * x_ld), D, lane);
             row_load<R, V>(gn, g_out + (row + nwaves) * g_out_ld, D, lane);
         }
 #pragma unroll
@@ -313,9 +320,9 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
         for (int li = 0; li < (NLR > 0 ? NLR : 1); ++li) {
             // generic path walks the runtime layer count with the same body
             for (int l = (NLR > 0 ? NLR - 1 - li : NL - 1); l >= (NLR > 0 ? NLR - 1 - li : 0); --l) {
-                RowRegs<R, V> xl = x0, wl, bl;
+                RowRegs<R, V> xl = SEP ? xs : x0, wl, bl;
                 float s = 0.f;
-                for (int t = 0; t <= l; ++t) {          // recompute x_l, s_l from x0
+                for (int t = 0; t <= l; ++t) {          // recompute x_l, s_l from the stack's input
                     row_load<R, V>(wl, s_w + t * Dp, Dp, lane);
                     s = row_dot<R, V>(xl, wl);
                     if (t < l) {
@@ -346,10 +353,14 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
                     }
             }
         }
+        if (SEP) {
+            row_store<R, V>(gx0, g_x0 + row * g_x0_ld, D, lane);
+        } else {
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+            for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int j = 0; j < V; ++j) g.v[r][j] += gx0.v[r][j];
+                for (int j = 0; j < V; ++j) g.v[r][j] += gx0.v[r][j];
+        }
         row_store<R, V>(g, g_x + row * g_x_ld, D, lane);
     }
     if (NLR > 0) {
@@ -654,35 +665,40 @@ extern "C" int nrx_fm_bwd(const float* feat, int64_t ld, int32_t n_fields, int32
     return NRX_OK;
 }
 
-extern "C" int nrx_dcn_v1_fwd(const float* x, int64_t x_ld, int64_t batch, int32_t dim, int32_t n_layers,
-                              const float* w, const float* b, float* out, int64_t out_ld, void* stream) {
+extern "C" int nrx_dcn_v1_fwd(const float* x, int64_t x_ld, const float* x0, int64_t x0_ld, int64_t batch, int32_t dim,
+                              int32_t n_layers, const float* w, const float* b, float* out, int64_t out_ld, void* stream) {
     NRX_REQUIRE(x && out && batch >= 0 && dim >= 1, "nrx_dcn_v1_fwd: bad argument");
+    if (x0 == x && x0_ld == x_ld) x0 = nullptr;
     NRX_REQUIRE(n_layers >= 0 && n_layers <= NRX_MAX_DCN_LAYERS, "nrx_dcn_v1_fwd: n_layers must be in [0, %d]", NRX_MAX_DCN_LAYERS);
     NRX_REQUIRE(n_layers == 0 || (w && b), "nrx_dcn_v1_fwd: null cross weights");
     NRX_REQUIRE(dim <= 2048, "nrx_dcn_v1_fwd: dim %d > 2048 unsupported", dim);
     if (batch == 0) return NRX_OK;
-    const bool vec = (dim & 3) == 0 && (x_ld & 3) == 0 && (out_ld & 3) == 0 && nrx_aligned16(x) && nrx_aligned16(out);
+    const bool vec = (dim & 3) == 0 && (x_ld & 3) == 0 && (out_ld & 3) == 0 && nrx_aligned16(x) && nrx_aligned16(out) &&
+                     (x0 == nullptr || ((x0_ld & 3) == 0 && nrx_aligned16(x0)));
     const int V = vec ? 4 : 1;
     const int R = (dim + 64 * V - 1) / (64 * V);
     const size_t smem = (size_t)2 * n_layers * ((dim + 3) & ~3) * sizeof(float);
     NRX_REQUIRE(smem <= 64 * 1024, "nrx_dcn_v1_fwd: n_layers*dim too large for the LDS stage");
     const unsigned grid = stream_grid(batch, NRX_BLOCK / 64);
     NRX_RSWITCH(R, V, { hipLaunchKernelGGL((dcn_v1_fwd_kernel<RR, VV>), dim3(grid), dim3(NRX_BLOCK), smem, reinterpret_cast<hipStream_t>(stream),
-                                           x, x_ld, batch, dim, n_layers, w, b, out, out_ld); });
+                                           x, x_ld, x0, x0_ld, batch, dim, n_layers, w, b, out, out_ld); });
     NRX_LAUNCH_CHECK("nrx_dcn_v1_fwd");
     return NRX_OK;
 }
 
-extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, int64_t batch, int32_t dim, int32_t n_layers,
-                              const float* w, const float* b, const float* g_out, int64_t g_out_ld,
-                              float* g_x, int64_t g_x_ld, float* g_w, float* g_b, void* stream) {
+extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int64_t x0_ld, int64_t batch, int32_t dim,
+                              int32_t n_layers, const float* w, const float* b, const float* g_out, int64_t g_out_ld,
+                              float* g_x, int64_t g_x_ld, float* g_x0, int64_t g_x0_ld, float* g_w, float* g_b, void* stream) {
     NRX_REQUIRE(x && g_out && g_x && batch >= 0 && dim >= 1, "nrx_dcn_v1_bwd: bad argument");
+    if (x0 == x && x0_ld == x_ld && g_x0 == nullptr) x0 = nullptr;
+    NRX_REQUIRE((x0 == nullptr) == (g_x0 == nullptr), "nrx_dcn_v1_bwd: x0 and g_x0 go together (both null: x0 is x, one gradient)");
     NRX_REQUIRE(n_layers >= 0 && n_layers <= NRX_MAX_DCN_LAYERS, "nrx_dcn_v1_bwd: n_layers must be in [0, %d]", NRX_MAX_DCN_LAYERS);
     NRX_REQUIRE(n_layers == 0 || (w && b && g_w && g_b), "nrx_dcn_v1_bwd: null cross weights");
     NRX_REQUIRE(dim <= 2048, "nrx_dcn_v1_bwd: dim %d > 2048 unsupported", dim);
     if (batch == 0) return NRX_OK;
     const bool vec = (dim & 3) == 0 && (x_ld & 3) == 0 && (g_out_ld & 3) == 0 && (g_x_ld & 3) == 0 &&
-                     nrx_aligned16(x) && nrx_aligned16(g_out) && nrx_aligned16(g_x);
+                     nrx_aligned16(x) && nrx_aligned16(g_out) && nrx_aligned16(g_x) &&
+                     (x0 == nullptr || ((x0_ld & 3) == 0 && (g_x0_ld & 3) == 0 && nrx_aligned16(x0) && nrx_aligned16(g_x0)));
     const int V = vec ? 4 : 1;
     const int R = (dim + 64 * V - 1) / (64 * V);
     const size_t smem = (size_t)4 * n_layers * ((dim + 3) & ~3) * sizeof(float);
@@ -698,8 +714,22 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, int64_t batch, int32
         if (smem > 64 * 1024)                                                                                       \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(DCN_BWD_BLOCK), smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, \
-                           batch, dim, n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b);                     \
+                           batch, dim, n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b,                      \
+                           (const float*)nullptr, (int64_t)0, (float*)nullptr, (int64_t)0);                         \
     })
+    if (x0 != nullptr) {      // separate layer-0 input: the generic (any n_layers) body with the SEP loads / stores
+        NRX_RSWITCH(R, V, {
+            unsigned grid = (unsigned)((batch + 512 / 64 - 1) / (512 / 64));
+            if (grid > 512u) grid = 512u;
+            auto kern = dcn_v1_bwd_kernel<RR, VV, 0, 512, true>;
+            if (smem > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, batch, dim,
+                               n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b, x0, x0_ld, g_x0, g_x0_ld);
+        });
+        NRX_LAUNCH_CHECK("nrx_dcn_v1_bwd(x0)");
+        return NRX_OK;
+    }
     switch (nlr) {
         case 1: NRX_DCN_BWD(1); break;
         case 2: NRX_DCN_BWD(2); break;

@@ -19,12 +19,10 @@ class DCNLayer(nn.Module):
         nn.init.xavier_uniform_(self.w)
 
     def forward(self, x_l, x_0):
-        """Per-layer API of the reference (dcn_arch.py:14-30).  The kernel fuses whole stacks, so a lone
-        layer is only expressible when it is the first one (x_l is x_0); deeper layers go through
-        DCNNet.forward, which runs the stack in one launch."""
-        if x_l is not x_0:
-            raise NotImplementedError("call DCNNet.forward: the HIP path fuses all cross layers in one launch")
-        return ops.dcn_v1(x_0, self.w[:, 0].unsqueeze(0), self.b[:, 0].unsqueeze(0))
+        """Per-layer API of the reference (dcn_arch.py:14-30): x_0 * (x_l . w) + b + x_l for ANY layer -- x_l need not
+        be x_0 (nrx_dcn_v1_fwd / _bwd take the layer-0 input separately).  DCNNet.forward still runs the whole stack
+        in one launch; chaining layers through this method is the same arithmetic, one launch per layer."""
+        return ops.dcn_v1(x_l, self.w[:, 0].unsqueeze(0), self.b[:, 0].unsqueeze(0), x0=x_0)
 
 
 class DCNv2Layer(nn.Module):

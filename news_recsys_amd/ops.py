@@ -527,36 +527,47 @@ def _dcn_params(w: torch.Tensor, b: torch.Tensor):
 
 class _DcnV1Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, x0):
         lib = _lib.load()
         x = _f32c(x, "x")
         w, b = _dcn_params(w, b)
         B, D = x.shape
         if w.shape[1] != D:
             raise ValueError(f"cross weights are for dim {w.shape[1]}, input has dim {D}")
+        if x0 is not None:
+            x0 = _f32c(x0, "x0")
+            if x0.shape != x.shape:
+                raise ValueError(f"x0 {tuple(x0.shape)} and x_l {tuple(x.shape)} must have the same shape")
         out = torch.empty_like(x)
-        check(lib.nrx_dcn_v1_fwd(x.data_ptr(), D, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), out.data_ptr(), D,
+        check(lib.nrx_dcn_v1_fwd(x.data_ptr(), D, _ptr(x0), D, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), out.data_ptr(), D,
                                  _stream_ptr(x)), "nrx_dcn_v1_fwd")
-        ctx.save_for_backward(x, w, b)
+        ctx.sep = x0 is not None
+        ctx.save_for_backward(x, w, b, *((x0,) if ctx.sep else ()))
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        x, w, b = ctx.saved_tensors
+        x, w, b, *rest = ctx.saved_tensors
+        x0 = rest[0] if ctx.sep else None
         g = _f32c(g, "grad")
         B, D = x.shape
         gx = torch.empty_like(x)
+        gx0 = torch.empty_like(x) if ctx.sep else None
         gw = torch.zeros_like(w)
         gb = torch.zeros_like(b)
-        check(lib.nrx_dcn_v1_bwd(x.data_ptr(), D, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), g.data_ptr(), D,
-                                 gx.data_ptr(), D, gw.data_ptr(), gb.data_ptr(), _stream_ptr(x)), "nrx_dcn_v1_bwd")
-        return gx, gw, gb
+        check(lib.nrx_dcn_v1_bwd(x.data_ptr(), D, _ptr(x0), D, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), g.data_ptr(), D,
+                                 gx.data_ptr(), D, _ptr(gx0), D, gw.data_ptr(), gb.data_ptr(), _stream_ptr(x)), "nrx_dcn_v1_bwd")
+        return gx, gw, gb, gx0
 
 
-def dcn_v1(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """DCNNet.forward (dcn_arch.py:63-70): all cross layers fused; w, b are [n_layers, dim]."""
-    return _DcnV1Fn.apply(x, w, b)
+def dcn_v1(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, x0: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """DCNNet.forward (dcn_arch.py:63-70): all cross layers fused; w, b are [n_layers, dim].  With `x0` the stack
+    starts from a later layer's input x (= x_l) and x0 is the cross network's layer-0 input -- the per-layer call
+    DCNLayer.forward(x_l, x_0) (dcn_arch.py:14-30) is n_layers = 1 of this."""
+    if x0 is x:
+        x0 = None
+    return _DcnV1Fn.apply(x, w, b, x0)
 
 
 class _DcnV1CatFn(torch.autograd.Function):
@@ -572,7 +583,7 @@ class _DcnV1CatFn(torch.autograd.Function):
         D = W2 // 2
         if not buf.is_contiguous() or W2 != 2 * D or w.shape[1] != D:
             raise ValueError("buf must be contiguous [B, 2*dim]")
-        check(lib.nrx_dcn_v1_fwd(buf.data_ptr(), W2, B, D, w.shape[0], w.data_ptr(), b.data_ptr(),
+        check(lib.nrx_dcn_v1_fwd(buf.data_ptr(), W2, None, 0, B, D, w.shape[0], w.data_ptr(), b.data_ptr(),
                                  buf.data_ptr() + 4 * D, W2, _stream_ptr(buf)), "nrx_dcn_v1_fwd")
         ctx.mark_dirty(buf)
         ctx.save_for_backward(buf, w, b)
@@ -588,8 +599,8 @@ class _DcnV1CatFn(torch.autograd.Function):
         gbuf = torch.zeros_like(buf)          # right half of the input buffer was never read
         gw = torch.zeros_like(w)
         gb = torch.zeros_like(b)
-        check(lib.nrx_dcn_v1_bwd(buf.data_ptr(), W2, B, D, w.shape[0], w.data_ptr(), b.data_ptr(),
-                                 g.data_ptr() + 4 * D, W2, gbuf.data_ptr(), W2, gw.data_ptr(), gb.data_ptr(),
+        check(lib.nrx_dcn_v1_bwd(buf.data_ptr(), W2, None, 0, B, D, w.shape[0], w.data_ptr(), b.data_ptr(),
+                                 g.data_ptr() + 4 * D, W2, gbuf.data_ptr(), W2, None, 0, gw.data_ptr(), gb.data_ptr(),
                                  _stream_ptr(buf)), "nrx_dcn_v1_bwd")
         gbuf[:, :D] += g[:, :D]
         return gbuf, gw, gb
@@ -691,8 +702,8 @@ class _EmbedDcnFn(torch.autograd.Function):
         gx = torch.empty((B, D), dtype=torch.float32, device=buf.device)
         gw = torch.zeros_like(w)
         gb = torch.zeros_like(b)
-        check(lib.nrx_dcn_v1_bwd(buf.data_ptr(), W2, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), g.data_ptr() + 4 * D, W2,
-                                 gx.data_ptr(), D, gw.data_ptr(), gb.data_ptr(), _stream_ptr(buf)), "nrx_dcn_v1_bwd")
+        check(lib.nrx_dcn_v1_bwd(buf.data_ptr(), W2, None, 0, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), g.data_ptr() + 4 * D, W2,
+                                 gx.data_ptr(), D, None, 0, gw.data_ptr(), gb.data_ptr(), _stream_ptr(buf)), "nrx_dcn_v1_bwd")
         gx += g[:, :D]
         table_grads = _EmbedFn.backward(ctx, gx, None, None)[6:]
         return (None, None, None, gw.view(ctx.w_shape), gb.view(ctx.b_shape), *table_grads)
