@@ -92,8 +92,15 @@ class SingleGpuPath:
         self.wl = wl
         feats, self.desc = workload_spec(wl)
         if wl == "c5":
-            feats = [f for f in feats if f["rows"] <= 16_000_000]
-            self.desc += f" -- single GPU run keeps the {len(feats)} tables <= 16M rows"
+            # all 40 tables (224 GB of fp32 rows) fit one 288 GB MI355X; a smaller device keeps the tables it can hold
+            need = sum(f["rows"] * f["dim"] * 4 for f in feats) + (6 << 30)
+            free = torch.cuda.mem_get_info(device)[0]
+            if os.environ.get("NRX_BENCH_C5_SMALL") == "1" or free < need:
+                feats = [f for f in feats if f["rows"] <= 16_000_000]
+                self.desc += f" -- this run keeps the {len(feats)} tables <= 16M rows ({free >> 30} GiB free, {need >> 30} GiB needed for all 40)"
+            else:
+                self.desc += " -- all 40 tables resident on one GPU (224 GB)"
+            feats = sorted(feats, key=lambda f: -f["rows"])       # allocate the big tables first
         self.feats = feats
         gen = torch.Generator(device=device).manual_seed(seed)
         self.tables, tindex = [], {}
@@ -102,7 +109,8 @@ class SingleGpuPath:
             if tname in tindex:
                 continue
             t = torch.empty((f["rows"], f["dim"]), dtype=torch.float32, device=device)
-            t.normal_(generator=gen)
+            for r0 in range(0, f["rows"], 1 << 26):               # in slabs: no multi-GB temporaries from the generator
+                t[r0:r0 + (1 << 26)].normal_(generator=gen)
             t[0].zero_()
             tindex[tname] = len(self.tables)
             self.tables.append(t)
@@ -132,23 +140,62 @@ class SingleGpuPath:
                     ws.append(None)
             self.pool.append((ins, ws))
         self.bytes_per_impr = algorithmic_bytes_per_impression(feats, self.fm, col if self.cross else 0)
+        self.bytes_note = ("SURVEY 8d: per lookup 8 B id + 4D row read + 4D concat write"
+                           + (", + 4 B FM logit per impression" if self.fm else "")
+                           + (f"; + {4 * col} B per impression for the fused cross output written next to x (SURVEY 8d's 2600 B "
+                              "counts the gather alone: the cross adds arithmetic but also this write)" if self.cross else ""))
         # one bound call per id buffer: descriptors are built once, a step only enqueues the launch(es)
         # The output buffer is recycled every step, as torch's caching allocator does for any real
         # loop (the module path allocates `out` with torch.empty per call and gets the same block back).
         # Measured on MI355X for c2: recycled 62.4 us, 8 distinct output buffers 72.9 us.
         ld = 2 * col if self.cross else col
+        self.ld = ld
         out = torch.empty((BATCH, ld), dtype=torch.float32, device=device)
         fmb = torch.empty((BATCH,), dtype=torch.float32, device=device) if self.fm else None
-        self.calls = [ops.PreparedEmbed(self.plan, self.tables, ins, ws, out_ld=ld, out=out, fm=fmb) for ins, ws in self.pool]
+        # index checking stays ON in the timed path: the kernel records an out-of-range id in a device status word (no
+        # cost when ids are in range); it is read once after the timed region (check_indices) -- the reference raises
+        # IndexError per call, here the raise is deferred, not dropped
+        self.calls = [ops.PreparedEmbed(self.plan, self.tables, ins, ws, out_ld=ld, out=out, fm=fmb, check_index=True)
+                      for ins, ws in self.pool]
         self.fused = None
         if self.cross and ops.fused_cross_is_fast(self.plan) and os.environ.get("NRX_BENCH_FUSED_CROSS", "1") != "0":
             # one-launch gather -> cat[x, cross(x)] (ops.PreparedEmbedDcn, grouped kernel): 47.9 us vs 60.0 us for the two
             # launches below on MI355X; NRX_BENCH_FUSED_CROSS=0 measures the two-launch form
-            self.fused = [ops.PreparedEmbedDcn(self.plan, self.tables, ins, self.cross_w, self.cross_b, out=out) for ins, _ in self.pool]
+            self.fused = [ops.PreparedEmbedDcn(self.plan, self.tables, ins, self.cross_w, self.cross_b, out=out, check_index=True)
+                          for ins, _ in self.pool]
             self.desc = self.desc.replace("(2 launches)", "(1 fused launch)")
         self.device = device
         from news_recsys_amd import _lib
         self.lib = _lib.load()
+
+    def check_indices(self):
+        for c in (self.fused if self.fused is not None else self.calls):
+            c.check()
+
+    def distinct_output_calls(self):
+        """The same bound launches, each writing its own output buffer (8 x [B, ld]): what a pipeline that keeps every
+        step's activations alive sees; the recycled single buffer (headline) stays in the 256 MiB Infinity Cache."""
+        ops = self.ops
+        outs = [torch.empty((BATCH, self.ld), dtype=torch.float32, device=self.device) for _ in self.pool]
+        if self.fused is not None:
+            return [ops.PreparedEmbedDcn(self.plan, self.tables, ins, self.cross_w, self.cross_b, out=o) for (ins, _), o in zip(self.pool, outs)]
+        fmb = torch.empty((BATCH,), dtype=torch.float32, device=self.device) if self.fm else None
+        return [ops.PreparedEmbed(self.plan, self.tables, ins, ws, out_ld=self.ld, out=o, fm=fmb) for (ins, ws), o in zip(self.pool, outs)]
+
+    def train_pass(self):
+        """Forward (training form) + row-sparse backward of the gather path, bound once: (forward calls, backward calls).
+        Upstream gradients are fixed random buffers (g_out [B, width], g_fm [B] for the FM workload)."""
+        ops, dev = self.ops, self.device
+        gen = torch.Generator(device=dev).manual_seed(7)
+        g_out = torch.randn((BATCH, self.ld), device=dev, generator=gen)
+        g_fm = torch.randn((BATCH,), device=dev, generator=gen) if self.fm else None
+        out = torch.empty((BATCH, self.ld), dtype=torch.float32, device=dev)
+        fmb = torch.empty((BATCH,), dtype=torch.float32, device=dev) if self.fm else None
+        sums = torch.empty((BATCH, self.feats[0]["dim"]), dtype=torch.float32, device=dev) if self.fm else None
+        fwd = [ops.PreparedEmbed(self.plan, self.tables, ins, ws, out_ld=self.ld, out=out, fm=fmb, fm_sums=sums)
+               for ins, ws in self.pool[:2]]                    # two id batches alternate (the backward owns ~0.3 GB of buffers each)
+        bwd = [ops.PreparedSparseBackward(f, g_out, g_fm) for f in fwd]
+        return fwd, bwd
 
     @torch.no_grad()
     def step(self, i: int):
@@ -210,6 +257,74 @@ def cpu_baseline(path: SingleGpuPath, budget_s: float = 12.0):
                       f"{cores} threads); {dt * 1e3:.2f} ms/pass; host has {os.cpu_count()} logical cores"}
 
 
+def cpu_baseline_torch(path: SingleGpuPath, budget_s: float = 10.0):
+    """The reference's own module code restated in stock PyTorch on the host cores: one
+    F.embedding per feature (get_feature_embedding, base_model.py:262-271), masked-mean pooling (:273-282), torch.cat
+    (:308), then the model's interaction -- FM from sums (fm/model.py:18-26) or the DCN cross.  For DCN the reference
+    materialises a [B, D, D] outer product per layer (dcn_arch.py:25): timed at B = 8192 and labelled (26.8 GB at
+    B = 65536); the rest runs at the full batch.  torch.set_num_threads(all cores)."""
+    import torch.nn.functional as F
+    cores = os.cpu_count() or 1
+    B = 8192 if path.cross else BATCH
+    tnames = []
+    for f in path.feats:
+        t = f.get("share", f["name"])
+        if t not in tnames:
+            tnames.append(t)
+    tables = {n: t.cpu() for n, t in zip(tnames, path.tables)}
+    ins, ws = path.pool[0]
+    ins = [x[:B].cpu() for x in ins]
+    ws = [None if w is None else w[:B].cpu() for w in ws]
+    cw = path.cross_w.cpu() if path.cross else None
+    cb = path.cross_b.cpu() if path.cross else None
+    D0 = path.feats[0]["dim"]
+
+    @torch.no_grad()
+    def one():
+        cols = []
+        for f, x, w in zip(path.feats, ins, ws):
+            e = F.embedding(x.long(), tables[f.get("share", f["name"])], padding_idx=0)
+            if f["bag"]:
+                e = (e * w.unsqueeze(-1)).sum(dim=1) / (w.sum(dim=1, keepdim=True) + 1e-8)
+            cols.append(e)
+        x = torch.cat(cols, dim=1)
+        if path.fm:
+            fv = x.view(B, len(cols), D0)
+            v = fv[:, :, 1:]
+            return fv[:, :, 0].sum(1) + 0.5 * (v.sum(1).pow(2) - v.pow(2).sum(1)).sum(1)
+        if path.cross:
+            x0, xl = x.unsqueeze(-1), x.unsqueeze(-1)
+            for l in range(cw.shape[0]):
+                xl = torch.matmul(torch.matmul(x0, xl.transpose(1, 2)), cw[l].unsqueeze(-1)) + cb[l].unsqueeze(-1) + xl
+            return torch.cat([x, xl.squeeze(-1)], dim=1)
+        return x
+
+    # torch's intra-op pool does not scale to hundreds of threads on these small ops (256 threads measured 100x slower
+    # than 32 on the MI355X host): time a few pool sizes within the budget and report the best one, with its size
+    best, best_threads, reps = 1e30, 1, 0
+    t0 = time.perf_counter()
+    for nt in sorted({min(cores, n) for n in (32, 64, 16, cores)}, key=lambda n: (n == cores, n)):
+        if time.perf_counter() - t0 > budget_s:
+            break
+        torch.set_num_threads(nt)
+        one()
+        t_nt = time.perf_counter()
+        while True:
+            t1 = time.perf_counter()
+            one()
+            dt1 = time.perf_counter() - t1
+            reps += 1
+            if dt1 < best:
+                best, best_threads = dt1, nt
+            if time.perf_counter() - t_nt > budget_s / 4 or reps >= 400:
+                break
+    return {"value": B / best, "unit": "impressions/s", "cores": best_threads, "kind": "torch-restatement",
+            "sample": f"best of {reps} passes of {B} impressions, stock PyTorch CPU eager restatement of the reference module code "
+                      f"(F.embedding per feature + cat + interaction), best intra-op pool = {best_threads} threads of {cores} "
+                      f"logical cores; {best * 1e3:.1f} ms/pass"
+                      + ("; DCN in the reference's [B,D,D] outer-product form, hence B = 8192" if path.cross else "")}
+
+
 # ------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -218,6 +333,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the secondary legs (distinct output buffers, fwd+bwd)")
     ap.add_argument("--ids", default="uniform", choices=["uniform", "zipf"],
                     help="id distribution: uniform (headline, cache-hostile) or Zipf(1.05) popularity (MIND-like); N=1 only")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded engine even at N=1 (testing)")
@@ -332,6 +448,48 @@ def main():
         spread = {"p10": us[6], "p50": us[32], "p90": us[57], "n": 64,
                   "note": "single steps between their own HIP events (includes one launch gap each); not part of the timed region"}
 
+    if hasattr(path, "check_indices"):
+        path.check_indices()              # deferred IndexError of the timed launches (the reference raises per call)
+
+    # secondary legs at N = 1, outside the headline timed region
+    distinct = fwd_bwd = None
+    if world == 1 and not args.force_sharded and not args.headline_only:
+        def time_calls(fn, n):
+            for i in range(min(10, args.warmup)):
+                fn(i)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for i in range(n):
+                fn(i)
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / n
+
+        steps2 = min(args.steps, 100)
+        if path.tables and sum(t.numel() for t in path.tables) * 4 < (200 << 30):     # room for 8 more output buffers
+            dcalls = path.distinct_output_calls()
+            ms = time_calls(lambda i: dcalls[i % len(dcalls)].run(), steps2)
+            ach = bytes_per_impr * BATCH / (ms * 1e-3) / 1e9
+            distinct = {"kernel_ms_mean": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBPS, "unit": "GB/s",
+                        "note": "same launches, 8 distinct output buffers instead of one recycled buffer (the recycled buffer "
+                                "stays in the 256 MiB Infinity Cache)"}
+            del dcalls
+        if not path.cross:
+            fwd, bwd = path.train_pass()
+            f_ms = time_calls(lambda i: fwd[i % len(fwd)].run(), steps2)
+            def both(i):
+                fwd[i % len(fwd)].run()
+                bwd[i % len(bwd)].run()
+            fb_ms = time_calls(both, steps2)
+            fwd_bwd = {"ms_per_step": fb_ms, "value": BATCH / (fb_ms * 1e-3), "unit": "impressions/s",
+                       "forward_ms": f_ms, "backward_ms": fb_ms - f_ms,
+                       "mode": "forward (training form: + FM field sums) + deterministic row-sparse backward: nrx_sparse_plan "
+                               "(bit-limited radix sort, unique rows, segments) + nrx_embed_bwd_sorted with the FM gradient folded in; "
+                               "upstream gradients g_out [B, width]" + (" and g_fm [B]" if path.fm else "") + " given; result = unique "
+                               "(table,row) keys + summed row gradients on the device (what optim.FusedSparseAdam consumes)"}
+            del fwd, bwd
+
     if hasattr(path, "overflowed") and path.overflowed():
         raise SystemExit("fixed-capacity exchange overflowed: rerun with a larger slack (ids too skewed)")
     planner = None
@@ -373,8 +531,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": desc, "batch_per_gpu": BATCH, "parallelism": parallelism,
-                       "algorithmic_bytes_per_impression": bytes_per_impr, "id_pool": 8,
-                       "output_buffer": "recycled each step (as the caching allocator does)"},
+                       "algorithmic_bytes_per_impression": bytes_per_impr,
+                       "algorithmic_bytes_definition": getattr(path, "bytes_note", "SURVEY 8d"), "id_pool": 8,
+                       "output_buffer": "recycled each step (as the caching allocator does); `distinct_output_buffers` has the other mode",
+                       "index_check": "on (device status word, read once after the timed region)"},
             "step_us": spread,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes/launch",
@@ -385,8 +545,17 @@ def main():
         }
         if planner is not None:
             out["other_layout"] = planner
+        if distinct is not None:
+            out["distinct_output_buffers"] = distinct
+        if fwd_bwd is not None:
+            out["fwd_bwd"] = fwd_bwd
         if world == 1 and not args.no_cpu_baseline and not args.force_sharded:
-            out["cpu_baseline"] = cpu_baseline(path)
+            big = sum(t.numel() for t in path.tables) * 4 > (64 << 30)      # host copies of > 64 GB of tables: skip
+            if not big:
+                out["cpu_baseline"] = cpu_baseline(path)
+                out["cpu_baseline_torch"] = cpu_baseline_torch(path)
+            else:
+                out["cpu_baseline"] = None
         try:
             info = ops.device_info(local_rank)
             out["config"]["device"] = {"compute_units": info["compute_units"], "clock_khz": info["clock_khz"],

@@ -94,15 +94,35 @@ NRX_API int nrx_embed_fwd(const nrx_feature_t* feats, int32_t n_feats, int64_t b
                   float* out, int64_t out_ld, float* wide_out, int64_t wide_ld,
                   float* fm_out, int32_t* status, void* stream);
 
+/* Training form of nrx_embed_fwd: additionally leaves the FM epilogue's per-sample field sums in
+ * fm_sums [B, sums_ld] (column k >= 1: sum_f v_fk, column 0: sum_f w_f; sums_ld >= the FM field dim) -- 4 B x dim per
+ * sample, what the backward needs to form d fm / d field without a pass of its own (nrx_fm_grad_t below).
+ * fm_sums == NULL: identical to nrx_embed_fwd.                                                     */
+NRX_API int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
+                        float* out, int64_t out_ld, float* wide_out, int64_t wide_ld,
+                        float* fm_out, float* fm_sums, int64_t sums_ld, int32_t* status, void* stream);
+
+/* Gradient of the FM epilogue, folded into the embedding backward (autograd of FMModel.forward, fm/model.py:18-26):
+ * for a lookup of an FM field (fm_field = 1) the upstream row becomes
+ *   g_out[b, col + k] + g_fm[b] * (k == 0 ? 1 : fm_sums[b, k] - feat[b, col + k])
+ * where feat is the forward concat (the field's value v_fk).  All device pointers; NULL struct or NULL g_fm: no FM term. */
+typedef struct nrx_fm_grad {
+    const float* g_fm;     /* [B]            dL / d fm_out                                   */
+    const float* fm_sums;  /* [B, sums_ld]   from nrx_embed_fwd_train                        */
+    int64_t sums_ld;
+    const float* feat;     /* [B, feat_ld]   the forward's `out`                             */
+    int64_t feat_ld;
+} nrx_fm_grad_t;
+
 /* Backward of nrx_embed_fwd's gather/pool/concat/wide-split: scatter-adds into DENSE grad tables
  * (feats[i].table is the float* grad table [rows, dim], pre-zeroed by the caller), i.e. what
  * autograd produces for nn.Embedding(sparse=False) (base_model.py:164); the padding row 0
  * receives no gradient.  g_out [B, out_ld] (or NULL), g_wide [B, wide_ld] (or NULL).
- * The FM epilogue's gradient is folded into g_out by the caller with nrx_fm_bwd (it only
- * needs the forward concat).  NRX_DENSE features are inputs and receive no gradient.          */
+ * The FM epilogue's gradient rides along through `fm` (nrx_fm_grad_t; NULL = none): no separate FM backward pass
+ * and no [B, sum D] temporary.  NRX_DENSE features are inputs and receive no gradient.          */
 NRX_API int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
                   const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
-                  void* stream);
+                  const nrx_fm_grad_t* fm, void* stream);
 
 /* Deterministic row-sparse backward for ONE table (alternative to nrx_embed_bwd's dense atomics).
  * The caller has sorted the table's lookups by row id (stable): `order[e]` is the flat lookup index of
@@ -115,11 +135,13 @@ NRX_API int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_t b
  * [n_unique]): the sort key of each unique entry; entries whose low 40 bits (the row id) are 0 -- the
  * padding row, which never trains -- get zeros.  order / seg_start: device int64; values [n_unique, dim].
  * n_unique_dev (optional, device int64[1]): the actual number of unique entries when the host does not
- * know it yet (nrx_sparse_plan's counts[0]); n_unique is then an upper bound that sizes the launch. */
+ * know it yet (nrx_sparse_plan's counts[0]); n_unique is then an upper bound that sizes the launch.
+ * fm (optional): the FM epilogue's gradient, as in nrx_embed_bwd. */
 NRX_API int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
                          const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
                          const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
-                         int64_t n_unique, const int64_t* n_unique_dev, float* values, void* stream);
+                         int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
+                         void* stream);
 
 /* Whole planning step of the row-sparse backward in one call (replaces nrx_make_table_keys + an external
  * 64-bit sort + unique + scan): for the flat, feature-major lookup list of n_feats features (ids[f]: lens[f]

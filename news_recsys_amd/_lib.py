@@ -47,6 +47,11 @@ class NrxFeature(C.Structure):
     ]
 
 
+class NrxFmGrad(C.Structure):
+    """struct nrx_fm_grad (include/nrx_embed.h)."""
+    _fields_ = [("g_fm", C.c_void_p), ("fm_sums", C.c_void_p), ("sums_ld", C.c_int64), ("feat", C.c_void_p), ("feat_ld", C.c_int64)]
+
+
 class NrxError(RuntimeError):
     pass
 
@@ -59,8 +64,10 @@ SIGNATURES = {
     "nrx_last_error": (C.c_char_p, []),
     "nrx_device_info": (C.c_int, [C.c_int, C.POINTER(_i64)]),
     "nrx_embed_fwd": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p]),
-    "nrx_embed_bwd": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, _p]),
-    "nrx_embed_bwd_sorted": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _i32, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _p, _p]),
+    "nrx_embed_fwd_train": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p]),
+    "nrx_embed_bwd": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, C.POINTER(NrxFmGrad), _p]),
+    "nrx_embed_bwd_sorted": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _i32, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p,
+                                       C.POINTER(NrxFmGrad), _p, _p]),
     "nrx_make_table_keys": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), C.POINTER(_i32), _i32, _i32, _p, _p]),
     "nrx_bag_pool_fwd": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     "nrx_bag_pool_bwd": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),

@@ -37,6 +37,11 @@ struct EmbedArgs {
     float* wide;         // fwd: wide_out; bwd: g_wide (read only)
     int64_t wide_ld;
     float* fm_out;
+    float* fm_sums;      // fwd (optional): [batch, sums_ld] field sums of the FM epilogue; bwd: the same tensor (read only)
+    int64_t sums_ld;
+    const float* g_fm;   // bwd (optional): dL/d fm_out [batch]
+    const float* feat;   // bwd (with g_fm): the forward concat [batch, feat_ld]
+    int64_t feat_ld;
     int32_t* status;
     int32_t n;
     int32_t lds_chunk;   // bag entries staged per pass
@@ -216,6 +221,13 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_generic(const EmbedArgs a
         // 0.5 * sum_k [(sum_f v)^2 - sum_f v^2] over this lane's 4 columns, then over the Q lanes
         float part = 0.5f * ((fm_s.x * fm_s.x - fm_q.x) + (fm_s.y * fm_s.y - fm_q.y) +
                              (fm_s.z * fm_s.z - fm_q.z) + (fm_s.w * fm_s.w - fm_q.w)) + fm_first;
+        if (a.fm_sums != nullptr && live) {     // field sums for the FM backward (one chunk: dims <= 4Q here)
+            float* sp = a.fm_sums + b * a.sums_ld + 4 * q;
+            const float sv[4] = {q == 0 ? fm_first : fm_s.x, fm_s.y, fm_s.z, fm_s.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * q + j < a.sums_ld) sp[j] = sv[j];
+        }
         part = group_sum<Q>(part);
         if (live && q == 0) a.fm_out[b] = part;
     }
@@ -268,6 +280,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
                             else gg[j] = a.out ? a.out[b * a.out_ld + f.out_col + k - 1] : 0.f;
                         } else {
                             gg[j] = a.out ? a.out[b * a.out_ld + f.out_col + k] : 0.f;
+                            if (f.fm && a.g_fm != nullptr)      // d fm / d field: column 0 -> 1, column k -> S_k - v_k
+                                gg[j] += (k == 0) ? a.g_fm[b]
+                                                  : a.g_fm[b] * (a.fm_sums[b * a.sums_ld + k] - a.feat[b * a.feat_ld + f.out_col + k]);
                         }
                     }
                 }
@@ -342,12 +357,29 @@ struct SortedBwdArgs {
     int64_t n_unique;
     const int64_t* n_unique_dev;   // optional: actual count on the device (n_unique is then an upper bound)
     int64_t uniform_len;           // > 0: every feature has this many flat lookups (feature = p / uniform_len)
+    const float* g_fm;             // optional FM gradient inputs (see nrx_fm_grad_t)
+    const float* fm_sums;
+    int64_t sums_ld;
+    const float* feat;
+    int64_t feat_ld;
     float* values;
     int32_t n;
     int32_t dim;
 };
 static_assert(sizeof(SortedBwdArgs) <= 3840, "kernarg budget");
 
+// feature of flat lookup p (<= 64 features): direct when every feature contributes the same number of lookups
+__device__ __forceinline__ int sorted_feat_of(const NRX_CONST SortedBwdArgs* a, int64_t p) {
+    if (a->uniform_len > 0) return (int)(p / a->uniform_len);
+    int l0 = 0, h0 = a->n;            // a chain of dependent loads from the argument block
+    while (h0 - l0 > 1) {
+        const int mid = (l0 + h0) >> 1;
+        if (a->off[mid] <= p) l0 = mid; else h0 = mid;
+    }
+    return l0;
+}
+
+// General form: any feature kinds (bags, wide routing), any dim.  One Q-lane group per unique row.
 template <int QLOG2>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_kernel(const SortedBwdArgs args_in_kernarg) {
     const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
@@ -362,21 +394,75 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_kernel(const Sorte
     int64_t hi = nrx_gconst<int64_t>(a->seg_start)[u + 1];
     // padding row (id 0) never trains (nn.Embedding(padding_idx=0)): its segment is skipped, zeros are written
     if (a->uniq_keys != nullptr && (nrx_gconst<int64_t>(a->uniq_keys)[u] & ((1ll << 40) - 1)) == 0) hi = lo;
-    for (int k0 = q * 4; k0 < D; k0 += 4 * Q) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int MAXC = 4;            // up to 4 column chunks per lane (D <= 16 Q), else the slow loop below
+    float acc[MAXC][4];
+    const int nchunk = (D + 4 * Q - 1) / (4 * Q);
+    if (nchunk <= MAXC) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c][j] = 0.f;
         for (int64_t e = lo; e < hi; ++e) {
             const int64_t p = nrx_gconst<int64_t>(a->order)[e];
-            int fi = 0;
-            if (a->uniform_len > 0) {
-                fi = (int)(p / a->uniform_len);      // every feature contributes the same number of lookups: no search
-            } else {   // feature of flat lookup p (<= 64 entries): a chain of dependent loads from the argument block
-                int l0 = 0, h0 = a->n;
-                while (h0 - l0 > 1) {
-                    const int mid = (l0 + h0) >> 1;
-                    if (a->off[mid] <= p) l0 = mid; else h0 = mid;
-                }
-                fi = l0;
+            const int fi = sorted_feat_of(a, p);
+            const int64_t r = p - a->off[fi];
+            const int kind = a->f[fi].kind;
+            const int L = kind >= NRX_BAG_MASKED_MEAN ? a->f[fi].bag_len : 1;
+            const int64_t b = r / L;
+            float scale = 1.0f;
+            if (kind == NRX_BAG_MASKED_MEAN) {      // the Q lanes share the row of L weights, then a group reduction
+                const NRX_GLOBAL float* w = nrx_gconst<float>(a->f[fi].weight) + b * L;
+                float den = 0.f;
+                for (int l = q; l < L; l += Q) den += w[l];
+                den = group_sum<Q>(den);
+                scale = w[r - b * L] / (den + 1e-8f);
+            } else if (kind == NRX_BAG_MEAN) {
+                scale = 1.0f / (float)L;
+            } else if (kind == NRX_BAG_SUM && a->f[fi].weight != nullptr) {
+                scale = nrx_gconst<float>(a->f[fi].weight)[r];
             }
+            const int wide_col = a->f[fi].wide_col, out_col = a->f[fi].out_col;
+            const bool fm = a->g_fm != nullptr && a->f[fi].fm;
+            const float gf = fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int k0 = (c * Q + q) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + j;
+                    if (c < nchunk && k < D) {
+                        float g;
+                        if (wide_col >= 0) {
+                            g = (k == 0) ? (a->g_wide ? nrx_gconst<float>(a->g_wide)[b * a->wide_ld + wide_col] : 0.f)
+                                         : (a->g_out ? nrx_gconst<float>(a->g_out)[b * a->out_ld + out_col + k - 1] : 0.f);
+                        } else {
+                            g = a->g_out ? nrx_gconst<float>(a->g_out)[b * a->out_ld + out_col + k] : 0.f;
+                            if (fm)
+                                g += (k == 0) ? gf
+                                              : gf * (nrx_gconst<float>(a->fm_sums)[b * a->sums_ld + k] -
+                                                      nrx_gconst<float>(a->feat)[b * a->feat_ld + out_col + k]);
+                        }
+                        acc[c][j] += g * scale;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int k0 = (c * Q + q) * 4;
+            NRX_GLOBAL float* dst = nrx_gmut<float>(a->values) + u * (int64_t)D + k0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c < nchunk && k0 + j < D) dst[j] = acc[c][j];
+        }
+        return;
+    }
+    // very wide rows (D > 16 Q = 1024 at Q = 64): column chunk outermost, the entries are re-walked per chunk
+    for (int k0 = q * 4; k0 < D; k0 += 4 * Q) {
+        float ac[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t e = lo; e < hi; ++e) {
+            const int64_t p = nrx_gconst<int64_t>(a->order)[e];
+            const int fi = sorted_feat_of(a, p);
             const int64_t r = p - a->off[fi];
             const int kind = a->f[fi].kind;
             const int L = kind >= NRX_BAG_MASKED_MEAN ? a->f[fi].bag_len : 1;
@@ -403,15 +489,99 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_kernel(const Sorte
                                      : (a->g_out ? nrx_gconst<float>(a->g_out)[b * a->out_ld + out_col + k - 1] : 0.f);
                     else
                         g = a->g_out ? nrx_gconst<float>(a->g_out)[b * a->out_ld + out_col + k] : 0.f;
-                    acc[j] += g * scale;
+                    ac[j] += g * scale;
                 }
             }
         }
         NRX_GLOBAL float* dst = nrx_gmut<float>(a->values) + u * (int64_t)D + k0;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (k0 + j < D) dst[j] = acc[j];
+            if (k0 + j < D) dst[j] = ac[j];
     }
+}
+
+// Fast form for the common launch: every feature single-valued without wide routing, D = 4 Q, everything 16-byte
+// aligned.  A Q-lane group owns R consecutive unique rows: their segment bounds, then their first entries' lookup
+// indices, then all their upstream rows (g_out, and for FM fields the forward value and the field sums) are fetched as
+// R independent requests per lane -- the reduction is a chain of three dependent random reads per row, so what bounds it
+// is how many chains a lane keeps in flight.  Segments longer than one entry (duplicate ids) continue in a loop that
+// adds the remaining entries in sorted order: the summation order is the sorted order, as in the general form.
+template <int QLOG2, int R, bool FM>
+__global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const SortedBwdArgs args_in_kernarg) {
+    const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    const int q = threadIdx.x & (Q - 1);
+    const int64_t u0 = ((int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2)) * R;
+    int64_t n = a->n_unique;
+    if (a->n_unique_dev != nullptr) {
+        const int64_t nd = nrx_gconst<int64_t>(a->n_unique_dev)[0];
+        n = nd < n ? nd : n;
+    }
+    if (u0 >= n) return;
+    const NRX_GLOBAL int64_t* seg = nrx_gconst<int64_t>(a->seg_start);
+    int64_t lo[R], hi[R], key[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t u = u0 + r < n ? u0 + r : n - 1;
+        lo[r] = seg[u];
+        hi[r] = seg[u + 1];
+        key[r] = a->uniq_keys != nullptr ? nrx_gconst<int64_t>(a->uniq_keys)[u] : 1;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if ((key[r] & ((1ll << 40) - 1)) == 0 || u0 + r >= n) hi[r] = lo[r];      // padding row: zeros
+    float4 acc[R];
+    int64_t e[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        e[r] = lo[r];
+    }
+    bool more = true;
+    while (more) {                      // one entry of each of the R rows per pass; most rows have exactly one
+        int64_t p[R];
+        bool on[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            on[r] = e[r] < hi[r];
+            p[r] = nrx_gconst<int64_t>(a->order)[on[r] ? e[r] : lo[0]];
+        }
+        float4 g[R], v[R], s[R];
+        float gf[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int fi = sorted_feat_of(a, p[r]);
+            const int64_t b = p[r] - a->off[fi];
+            const int64_t c4 = (b * a->out_ld + a->f[fi].out_col) / 4 + q;
+            g[r] = a->g_out ? nrx_ldg4(a->g_out, c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FM) {
+                const bool fm = a->f[fi].fm;
+                gf[r] = fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
+                v[r] = nrx_ldg4(a->feat, (b * a->feat_ld + a->f[fi].out_col) / 4 + q);
+                s[r] = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
+            }
+        }
+        more = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float4 t = g[r];
+            if (FM) {                     // d fm / d field: column 0 -> 1, column k -> S_k - v_k
+                t.x += q == 0 ? gf[r] : gf[r] * (s[r].x - v[r].x);
+                t.y += gf[r] * (s[r].y - v[r].y);
+                t.z += gf[r] * (s[r].z - v[r].z);
+                t.w += gf[r] * (s[r].w - v[r].w);
+            }
+            if (on[r]) {
+                acc[r].x += t.x; acc[r].y += t.y; acc[r].z += t.z; acc[r].w += t.w;
+                e[r] += 1;
+            }
+            more |= e[r] < hi[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (u0 + r < n) nrx_stg4(a->values, (u0 + r) * (int64_t)Q + q, acc[r]);
 }
 
 // ----------------------------------------------------------------------------------- host side
@@ -520,6 +690,12 @@ void launch_uniform(const UniformArgs& ua, int64_t batch, bool fm, bool store, h
 extern "C" int nrx_embed_fwd(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
                              float* out, int64_t out_ld, float* wide_out, int64_t wide_ld,
                              float* fm_out, int32_t* status, void* stream) {
+    return nrx_embed_fwd_train(feats, n_feats, batch, out, out_ld, wide_out, wide_ld, fm_out, nullptr, 0, status, stream);
+}
+
+extern "C" int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
+                                   float* out, int64_t out_ld, float* wide_out, int64_t wide_ld,
+                                   float* fm_out, float* fm_sums, int64_t sums_ld, int32_t* status, void* stream) {
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_fwd: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0, "nrx_embed_fwd: negative batch");
@@ -556,6 +732,8 @@ extern "C" int nrx_embed_fwd(const nrx_feature_t* feats, int32_t n_feats, int64_
         ua.out = reinterpret_cast<float4*>(out);
         ua.ld4 = out_ld / 4;
         ua.fm_out = fm_out;
+        ua.fm_sums = (fm_out != nullptr && n_fm > 0) ? fm_sums : nullptr;
+        ua.sums_ld = sums_ld;
         ua.status = status;
         ua.n = n_feats;
         ua.idx64 = feats[0].index_bits == 64;
@@ -589,6 +767,11 @@ extern "C" int nrx_embed_fwd(const nrx_feature_t* feats, int32_t n_feats, int64_
     a.wide = wide_out;
     a.wide_ld = wide_ld;
     a.fm_out = (n_fm > 0) ? fm_out : nullptr;
+    a.fm_sums = (n_fm > 0) ? fm_sums : nullptr;
+    a.sums_ld = sums_ld;
+    a.g_fm = nullptr;
+    a.feat = nullptr;
+    a.feat_ld = 0;
     a.status = status;
     a.n = n_feats;
     NRX_REQUIRE(n_fm == 0 || fm_out != nullptr, "nrx_embed_fwd: fm_field set but fm_out is null");
@@ -603,19 +786,39 @@ extern "C" int nrx_embed_fwd(const nrx_feature_t* feats, int32_t n_feats, int64_
     return NRX_OK;
 }
 
+// FM gradient folded into the embedding backward (see nrx_fm_grad_t): validated once for both backward forms
+static int check_fm_grad(const nrx_fm_grad_t* fm, const nrx_feature_t* feats, int32_t n_feats, const char* who) {
+    if (fm == nullptr || fm->g_fm == nullptr) return NRX_OK;
+    NRX_REQUIRE(fm->fm_sums != nullptr && fm->feat != nullptr, "%s: FM gradient needs fm_sums and the forward concat", who);
+    for (int i = 0; i < n_feats; ++i)
+        if (feats[i].fm_field) {
+            NRX_REQUIRE(feats[i].wide_col < 0, "%s: feature %d: an FM field cannot also be a wide feature", who, i);
+            NRX_REQUIRE(feats[i].dim <= fm->sums_ld, "%s: feature %d: dim %d > sums_ld", who, i, feats[i].dim);
+        }
+    return NRX_OK;
+}
+
 extern "C" int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
                              const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
-                             void* stream) {
+                             const nrx_fm_grad_t* fm, void* stream) {
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_bwd: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0, "nrx_embed_bwd: negative batch");
-    NRX_REQUIRE(g_out != nullptr || g_wide != nullptr, "nrx_embed_bwd: no upstream gradient");
+    const bool has_fm = fm != nullptr && fm->g_fm != nullptr;
+    NRX_REQUIRE(g_out != nullptr || g_wide != nullptr || has_fm, "nrx_embed_bwd: no upstream gradient");
     if (batch == 0) return NRX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     EmbedArgs a;
     int max_dim, max_bag;
     int rc = pack_features(feats, n_feats, a, max_dim, max_bag, "nrx_embed_bwd");
     if (rc != NRX_OK) return rc;
+    rc = check_fm_grad(fm, feats, n_feats, "nrx_embed_bwd");
+    if (rc != NRX_OK) return rc;
+    a.g_fm = has_fm ? fm->g_fm : nullptr;
+    a.fm_sums = has_fm ? const_cast<float*>(fm->fm_sums) : nullptr;
+    a.sums_ld = has_fm ? fm->sums_ld : 0;
+    a.feat = has_fm ? fm->feat : nullptr;
+    a.feat_ld = has_fm ? fm->feat_ld : 0;
     a.batch = batch;
     a.out = const_cast<float*>(g_out);
     a.out_ld = out_ld;
@@ -637,14 +840,25 @@ extern "C" int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_
 extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
                                     const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
                                     const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
-                                    int64_t n_unique, const int64_t* n_unique_dev, float* values, void* stream) {
+                                    int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
+                                    void* stream) {
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_bwd_sorted: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0 && dim >= 1 && n_unique >= 0, "nrx_embed_bwd_sorted: bad argument");
-    NRX_REQUIRE(g_out != nullptr || g_wide != nullptr, "nrx_embed_bwd_sorted: no upstream gradient");
+    const bool has_fm = fm != nullptr && fm->g_fm != nullptr;
+    NRX_REQUIRE(g_out != nullptr || g_wide != nullptr || has_fm, "nrx_embed_bwd_sorted: no upstream gradient");
     if (n_unique == 0 || batch == 0) return NRX_OK;
     NRX_REQUIRE(order && seg_start && values, "nrx_embed_bwd_sorted: null buffer");
+    {
+        int rc = check_fm_grad(fm, feats, n_feats, "nrx_embed_bwd_sorted");
+        if (rc != NRX_OK) return rc;
+    }
     SortedBwdArgs a;
+    a.g_fm = has_fm ? fm->g_fm : nullptr;
+    a.fm_sums = has_fm ? fm->fm_sums : nullptr;
+    a.sums_ld = has_fm ? fm->sums_ld : 0;
+    a.feat = has_fm ? fm->feat : nullptr;
+    a.feat_ld = has_fm ? fm->feat_ld : 0;
     int64_t off = 0;
     for (int i = 0; i < n_feats; ++i) {
         const nrx_feature_t& s = feats[i];
@@ -663,7 +877,7 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
         d.bag_len = (int16_t)s.bag_len;
         d.kind = (uint8_t)s.kind;
         d.idx64 = 1;
-        d.fm = 0;
+        d.fm = has_fm && s.fm_field != 0;
         d.row0_is_data = 0;
         a.off[i] = off;
         off += batch * (s.kind == NRX_SPARSE ? 1 : s.bag_len);
@@ -688,8 +902,28 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     int ql = ceil_log2((dim + 3) / 4);
     if (ql > 6) ql = 6;
     const int tb = NRX_BLOCK >> ql;
-    const unsigned grid = (unsigned)((n_unique + tb - 1) / tb);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // fast form: plain single-valued features, D = 4 Q exactly, float4-addressable everywhere
+    bool fast = dim == (4 << ql) && ql >= 2 && ql <= 4 && (g_out == nullptr || (nrx_aligned16(g_out) && (out_ld & 3) == 0)) && nrx_aligned16(values) &&
+                (!has_fm || (g_out != nullptr && nrx_aligned16(fm->feat) && (fm->feat_ld & 3) == 0 && nrx_aligned16(fm->fm_sums) &&
+                             (fm->sums_ld & 3) == 0 && fm->sums_ld >= dim));
+    for (int i = 0; i < n_feats && fast; ++i)
+        fast = feats[i].kind == NRX_SPARSE && feats[i].wide_col < 0 && (feats[i].out_col & 3) == 0;
+    if (fast) {
+        constexpr int R = 4;
+        const int64_t groups = (n_unique + R - 1) / R;
+        const unsigned grid = (unsigned)((groups + tb - 1) / tb);
+#define NRX_SF(QL_)                                                                                                        \
+    {                                                                                                                      \
+        if (has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a);      \
+    }
+        if (ql == 2) NRX_SF(2) else if (ql == 3) NRX_SF(3) else NRX_SF(4)
+#undef NRX_SF
+        NRX_LAUNCH_CHECK("nrx_embed_bwd_sorted(fast)");
+        return NRX_OK;
+    }
+    const unsigned grid = (unsigned)((n_unique + tb - 1) / tb);
     NRX_QSWITCH(ql, { hipLaunchKernelGGL((embed_bwd_sorted_kernel<QL>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); });
     NRX_LAUNCH_CHECK("nrx_embed_bwd_sorted");
     return NRX_OK;

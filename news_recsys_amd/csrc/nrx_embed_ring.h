@@ -30,6 +30,8 @@ struct UniformArgs {
     float4* out;                      // may be null (FM-only inference)
     int64_t ld4;                      // out_ld / 4
     float* fm_out;
+    float* fm_sums;                   // optional [batch, sums_ld]: per-sample field sums of the FM epilogue (training)
+    int64_t sums_ld;
     int32_t* status;
     int32_t n;
     int32_t idx64;                    // ids are int64 (else int32)
@@ -191,7 +193,12 @@ __global__ __launch_bounds__(NRX_BLOCK, MINW) void embed_fwd_ring(const UniformA
     if (FM) {
         float part = 0.5f * ((fm_s.x * fm_s.x - fm_q.x) + (fm_s.y * fm_s.y - fm_q.y) +
                              (fm_s.z * fm_s.z - fm_q.z) + (fm_s.w * fm_s.w - fm_q.w)) + fm_first;
+        if (a->fm_sums != nullptr) {   // S[b, :] = sum over fields (column 0: the first-order sum); the FM backward needs it
+            nrx_f32x4 t;
+            t.x = q == 0 ? fm_first : fm_s.x; t.y = fm_s.y; t.z = fm_s.z; t.w = fm_s.w;
+            *(NRX_GLOBAL nrx_f32x4*)(nrx_gmut<float>(a->fm_sums) + b * a->sums_ld + 4 * q) = t;
+        }
         part = group_sum<Q>(part);
-        if (q == 0) nrx_gmut<float>(a->fm_out)[b] = part;
+        if (q == 0 && a->fm_out != nullptr) nrx_gmut<float>(a->fm_out)[b] = part;
     }
 }

@@ -6,14 +6,13 @@
 // when they fit (C2: 5 + 20 bits) -- and sorted with rocPRIM's radix sort limited to those bits (4 digit
 // passes instead of the 8 that a generic 64-bit sort pays), payload = the 32-bit flat lookup index; the sort
 // is stable, so the lookups of one row stay in (feature, sample) order and the segmented reduction that
-// follows (nrx_embed_bwd_sorted) is bit-reproducible.  Head flags + one scan give the unique (table,row)
-// list, the segment starts, the number of unique rows and the per-table split, all left on the device:
-// the host reads n_tables + 2 integers once.  rocPRIM (radix sort, scan) is the vendor primitive library;
-// key construction / head detection / finalisation are the kernels below.
+// follows (nrx_embed_bwd_sorted) is bit-reproducible.  Two more launches (head count per tile, then rank + emit) give
+// the unique (table,row) list, the segment starts, the number of unique rows and the per-table split, all left on
+// the device: the host reads n_tables + 2 integers once (or nothing, in the fused-optimizer mode).  rocPRIM's radix
+// sort is the vendor primitive; key construction / head ranking / emission are the kernels below.
 #include "nrx_common.h"
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 namespace {
 
@@ -46,50 +45,107 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_keys_kernel(const PlanArgs arg
     }
 }
 
+// Unique rows, segment starts and per-table bounds from the sorted keys in TWO launches (was: head flags, rocPRIM scan
+// (+ its init kernel), finalize, bounds -- five launches of a few microseconds of work each):
+//   plan_count_kernel   block c counts the segment heads among its PLAN_TILE sorted entries      -> block_heads[c]
+//   plan_emit_kernel    block c sums block_heads[0..c) itself (a few KB, L2-resident), ranks its heads with one block
+//                       scan and writes order / uniq_keys / seg_start; a head whose table differs from its
+//                       predecessor's also writes that table's first-unique bound (counts[1 + t] for every table id in
+//                       between, so tables without lookups get empty ranges); the last entry closes counts / seg_start.
+constexpr int PLAN_TILE = 1024;        // entries per block = 4 per thread
+
 template <typename KeyT>
-__global__ __launch_bounds__(NRX_BLOCK) void plan_heads_kernel(const KeyT* __restrict__ skeys, int64_t n, uint32_t* __restrict__ flags) {
-    const int64_t e = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x;
-    if (e < n) flags[e] = (e == 0 || skeys[e] != skeys[e - 1]) ? 1u : 0u;
+__device__ __forceinline__ bool plan_is_head(const KeyT* __restrict__ skeys, int64_t e) {
+    return e == 0 || skeys[e] != skeys[e - 1];
 }
 
-// uidx = exclusive scan of the head flags.  Writes order (int64 view of the payload), and for every head the
-// unique key in the (table << 40 | row) form nrx_embed_bwd_sorted expects plus its segment start; the last
-// entry also writes n_unique and the closing segment start.
 template <typename KeyT>
-__global__ __launch_bounds__(NRX_BLOCK) void plan_finalize_kernel(const KeyT* __restrict__ skeys, const uint32_t* __restrict__ spayload,
-                                                                  const uint32_t* __restrict__ flags, const uint32_t* __restrict__ uidx,
-                                                                  int64_t n, int row_bits, int64_t* __restrict__ order,
-                                                                  int64_t* __restrict__ uniq_keys, int64_t* __restrict__ seg_start,
-                                                                  int64_t* __restrict__ counts) {
-    const int64_t e = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x;
-    if (e >= n) return;
-    order[e] = (int64_t)spayload[e];
-    if (flags[e]) {
-        const uint64_t k = (uint64_t)skeys[e];
-        const uint64_t row = k & ((1ull << row_bits) - 1);
-        uniq_keys[uidx[e]] = (int64_t)(((k >> row_bits) << 40) | row);
-        seg_start[uidx[e]] = e;
+__global__ __launch_bounds__(NRX_BLOCK) void plan_count_kernel(const KeyT* __restrict__ skeys, int64_t n, uint32_t* __restrict__ block_heads) {
+    __shared__ uint32_t s_cnt[NRX_BLOCK / 64];
+    const int64_t e0 = (int64_t)blockIdx.x * PLAN_TILE + threadIdx.x;
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < PLAN_TILE / NRX_BLOCK; ++j) {
+        const int64_t e = e0 + j * NRX_BLOCK;
+        c += (uint32_t)__popcll(__ballot(e < n && plan_is_head(skeys, e)));      // wave-uniform count
     }
-    if (e == n - 1) {
-        const int64_t nu = (int64_t)uidx[e] + (int64_t)flags[e];
-        counts[0] = nu;
-        seg_start[nu] = n;
-    }
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_heads[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
-// counts[1 + t] = first unique index whose table id is >= t, t = 0..n_tables (so table t owns
-// [counts[1+t], counts[2+t]) )
-__global__ void plan_bounds_kernel(const int64_t* __restrict__ uniq_keys, int32_t n_tables, int64_t* __restrict__ counts) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > n_tables) return;
-    const int64_t nu = counts[0];
-    const int64_t target = (int64_t)t << 40;
-    int64_t lo = 0, hi = nu;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (uniq_keys[mid] < target) lo = mid + 1; else hi = mid;
+// entry e of the tile is handled by thread (e % 256) in round (e / 256): coalesced key / payload / order accesses; the
+// rank of a head = heads of earlier blocks + heads of earlier (round, wave) cells + heads of lower lanes in its cell
+template <typename KeyT>
+__global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const KeyT* __restrict__ skeys, const uint32_t* __restrict__ spayload,
+                                                              const uint32_t* __restrict__ block_heads, int64_t n, int row_bits,
+                                                              int32_t n_tables, int64_t* __restrict__ order,
+                                                              int64_t* __restrict__ uniq_keys, int64_t* __restrict__ seg_start,
+                                                              int64_t* __restrict__ counts) {
+    constexpr int ROUNDS = PLAN_TILE / NRX_BLOCK, WAVES = NRX_BLOCK / 64;
+    __shared__ uint32_t s_cell[ROUNDS * WAVES + 1];
+    __shared__ uint32_t s_part[WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t e0 = (int64_t)blockIdx.x * PLAN_TILE + tid;
+    KeyT key[ROUNDS], prev[ROUNDS];
+    uint32_t pay[ROUNDS];
+#pragma unroll
+    for (int j = 0; j < ROUNDS; ++j) {            // all of the tile's loads are issued before anything waits
+        const int64_t e = e0 + j * NRX_BLOCK;
+        const int64_t ec = e < n ? e : n - 1;
+        key[j] = skeys[ec];
+        prev[j] = skeys[ec > 0 ? ec - 1 : 0];
+        pay[j] = spayload[ec];
     }
-    counts[1 + t] = lo;
+    uint32_t acc = 0;
+    for (uint32_t i = tid; i < blockIdx.x; i += NRX_BLOCK) acc += block_heads[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) s_part[wid] = acc;
+    bool head[ROUNDS];
+    unsigned long long mask[ROUNDS];
+#pragma unroll
+    for (int j = 0; j < ROUNDS; ++j) {
+        const int64_t e = e0 + j * NRX_BLOCK;
+        head[j] = e < n && (e == 0 || key[j] != prev[j]);
+        mask[j] = __ballot(head[j]);
+        if (lane == 0) s_cell[j * WAVES + wid] = (uint32_t)__popcll(mask[j]);
+    }
+    __syncthreads();
+    if (tid == 0) {                                // exclusive scan of the 16 cells, seeded with the earlier blocks' heads
+        uint32_t run = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        for (int c = 0; c < ROUNDS * WAVES; ++c) {
+            const uint32_t v = s_cell[c];
+            s_cell[c] = run;
+            run += v;
+        }
+        s_cell[ROUNDS * WAVES] = run;
+    }
+    __syncthreads();
+    const uint64_t rmask = (1ull << row_bits) - 1;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int j = 0; j < ROUNDS; ++j) {
+        const int64_t e = e0 + j * NRX_BLOCK;
+        if (e >= n) continue;
+        order[e] = (int64_t)pay[j];
+        const uint32_t u = s_cell[j * WAVES + wid] + (uint32_t)__popcll(mask[j] & lt);
+        if (head[j]) {
+            const uint64_t k = (uint64_t)key[j];
+            const int64_t t = (int64_t)(k >> row_bits);
+            uniq_keys[u] = (t << 40) | (int64_t)(k & rmask);
+            seg_start[u] = e;
+            const int64_t tprev = e == 0 ? -1 : (int64_t)((uint64_t)prev[j] >> row_bits);
+            for (int64_t tt = tprev + 1; tt <= t; ++tt) counts[1 + tt] = u;     // first unique entry of tables tprev+1 .. t
+        }
+        if (e == n - 1) {
+            const uint32_t nu = u + (head[j] ? 1u : 0u);
+            counts[0] = nu;
+            seg_start[nu] = n;
+            const int64_t tl = (int64_t)((uint64_t)key[j] >> row_bits);
+            for (int64_t tt = tl + 1; tt <= n_tables; ++tt) counts[1 + tt] = nu;
+        }
+    }
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -99,13 +155,6 @@ size_t sort_temp_bytes(int64_t n, int bits) {
     size_t bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (const KeyT*)nullptr, (KeyT*)nullptr, (const uint32_t*)nullptr,
                                     (uint32_t*)nullptr, (size_t)n, 0u, (unsigned)bits, (hipStream_t) nullptr);
-    return bytes;
-}
-
-size_t scan_temp_bytes(int64_t n) {
-    size_t bytes = 0;
-    (void)rocprim::exclusive_scan(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n,
-                                  rocprim::plus<uint32_t>(), (hipStream_t) nullptr);
     return bytes;
 }
 
@@ -120,8 +169,8 @@ int bits_for(int64_t v) {      // bits needed to represent values 0 .. v-1 (at l
 extern "C" int64_t nrx_sparse_plan_workspace(int64_t n_lookups) {
     if (n_lookups < 0 || n_lookups >= 0xffffffffLL) return -1;
     const size_t n = (size_t)(n_lookups > 0 ? n_lookups : 1);
-    size_t t1 = sort_temp_bytes<uint64_t>(n, 64), t2 = scan_temp_bytes(n);
-    return (int64_t)(2 * align256(n * 8) + 2 * align256(n * 4) + 2 * align256(n * 4) + align256(t1 > t2 ? t1 : t2) + 256);
+    const size_t t1 = sort_temp_bytes<uint64_t>(n, 64);
+    return (int64_t)(2 * align256(n * 8) + 2 * align256(n * 4) + 2 * align256(n * 4) + align256(t1) + 256);
 }
 
 extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
@@ -169,11 +218,11 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
     uint32_t* pay_in = (uint32_t*)w;   w += align256((size_t)n * 4);
     uint32_t* pay_out = (uint32_t*)w;  w += align256((size_t)n * 4);
     uint32_t* flags = (uint32_t*)w;    w += align256((size_t)n * 4);
-    uint32_t* uidx = (uint32_t*)w;     w += align256((size_t)n * 4);
+    w += align256((size_t)n * 4);
     void* temp = w;
     const int bits = row_bits + table_bits;
     int64_t g = (n + NRX_BLOCK - 1) / NRX_BLOCK;
-    const unsigned gfull = (unsigned)g;
+    const unsigned gtile = (unsigned)((n + PLAN_TILE - 1) / PLAN_TILE);
     if (g > 4096) g = 4096;
     hipError_t err = hipSuccess;
     size_t tb = 0;
@@ -184,14 +233,11 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
         err = rocprim::radix_sort_pairs(temp, tb, (const KeyT*)keys_in, (KeyT*)keys_out, (const uint32_t*)pay_in, pay_out, \
                                         (size_t)n, 0u, (unsigned)bits, st);                                               \
         if (err == hipSuccess) {                                                                                          \
-            hipLaunchKernelGGL(plan_heads_kernel<KeyT>, dim3(gfull), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out, n, flags); \
-            tb = scan_temp_bytes(n);                                                                                      \
-            err = rocprim::exclusive_scan(temp, tb, (const uint32_t*)flags, uidx, 0u, (size_t)n, rocprim::plus<uint32_t>(), st); \
+            hipLaunchKernelGGL(plan_count_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out, n, flags); \
+            hipLaunchKernelGGL(plan_emit_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out,          \
+                               (const uint32_t*)pay_out, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys,  \
+                               seg_start, counts);                                                                        \
         }                                                                                                                 \
-        if (err == hipSuccess)                                                                                            \
-            hipLaunchKernelGGL(plan_finalize_kernel<KeyT>, dim3(gfull), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out,     \
-                               (const uint32_t*)pay_out, (const uint32_t*)flags, (const uint32_t*)uidx, n, row_bits, order, \
-                               uniq_keys, seg_start, counts);                                                             \
     }
     if (bits <= 32) NRX_PLAN(uint32_t) else NRX_PLAN(uint64_t)
 #undef NRX_PLAN
@@ -199,7 +245,6 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
         nrx_set_error("nrx_sparse_plan: rocPRIM call failed: %s", hipGetErrorString(err));
         return NRX_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(plan_bounds_kernel, dim3((unsigned)((n_tables + 1 + 63) / 64)), dim3(64), 0, st, (const int64_t*)uniq_keys, n_tables, counts);
     NRX_LAUNCH_CHECK("nrx_sparse_plan");
     return NRX_OK;
 }

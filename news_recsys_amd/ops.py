@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_MAX_FEATURES, NRX_SPARSE,
-                   NrxFeature, check)
+                   NrxFeature, NrxFmGrad, check)
 
 # ------------------------------------------------------------------------------- helpers
 _INDEX_CHECK = "sync"      # "sync": raise IndexError in the offending call (reference behaviour on CPU)
@@ -204,12 +204,18 @@ class _EmbedFn(torch.autograd.Function):
         stream = _stream_ptr(ins[0])
         n = len(plan.slots)
         single = n <= NRX_MAX_FEATURES
+        # training with the FM epilogue: the forward also leaves the per-sample field sums, so that the backward can form
+        # d fm / d field on the fly (nrx_fm_grad_t) -- no separate FM backward pass, no [B, sum D] temporary
+        fm_dim = max((s.dim for s in plan.slots if s.fm_field), default=0)
+        sums = (torch.empty((B, fm_dim), dtype=torch.float32, device=dev)
+                if plan.use_fm and single and need_out and fm_dim and any(t.requires_grad for t in tables) else None)
         if B > 0:
             for lo in range(0, n, NRX_MAX_FEATURES):
                 hi = min(n, lo + NRX_MAX_FEATURES)
                 arr = _fill_features(plan, lo, hi, tables, ins, ws, fm=single, cache_key="fwd")
-                check(lib.nrx_embed_fwd(arr, hi - lo, B, _ptr(out), ld, _ptr(wide), plan.wide_width,
-                                        _ptr(fm) if single else None, _ptr(status), stream), "nrx_embed_fwd")
+                check(lib.nrx_embed_fwd_train(arr, hi - lo, B, _ptr(out), ld, _ptr(wide), plan.wide_width,
+                                              _ptr(fm) if single else None, _ptr(sums), fm_dim, _ptr(status), stream),
+                      "nrx_embed_fwd_train")
             if plan.use_fm and not single:
                 # > 64 FM fields: the cross-field sums cannot be split over launches; run FM on the concat
                 d0 = plan.slots[0].dim
@@ -231,6 +237,7 @@ class _EmbedFn(torch.autograd.Function):
         # a plain attribute would make a reference cycle (ctx -> out -> grad_fn -> ctx) that only the garbage collector
         # frees: 100+ MB per step kept alive, and a ~35 ms collection every few dozen steps
         ctx.has_fm_feat = bool(plan.use_fm and need_out)
+        ctx.fm_sums = sums
         if ctx.has_fm_feat:
             ctx.save_for_backward(out)
         ctx.set_materialize_grads(False)
@@ -247,31 +254,36 @@ class _EmbedFn(torch.autograd.Function):
         stream = torch.cuda.current_stream(dev).cuda_stream
         if g_out is not None:
             g_out = _f32c(g_out, "grad of the concat")
+        fmg = None
         if g_fm is not None:
             fm_feat = ctx.saved_tensors[0] if getattr(ctx, "has_fm_feat", False) else None
             if fm_feat is None:
                 raise RuntimeError("FM backward needs the forward concat: call with need_out=True when training")
             g_fm = _f32c(g_fm, "grad of fm_out")
-            d0 = plan.slots[0].dim
-            g_in = g_out                       # upstream gradient of the concat: read, never written (no clone)
-            g_out = torch.empty((B, ld), dtype=torch.float32, device=dev)
-            check(lib.nrx_fm_bwd(fm_feat.data_ptr(), ld, len(plan.slots), d0, B, g_fm.data_ptr(), _ptr(g_in), ld,
-                                 g_out.data_ptr(), ld, stream), "nrx_fm_bwd")
+            sums = getattr(ctx, "fm_sums", None)
+            if sums is not None:               # folded into the embedding backward (nrx_fm_grad_t)
+                fmg = NrxFmGrad(g_fm.data_ptr(), sums.data_ptr(), sums.shape[1], fm_feat.data_ptr(), ld)
+            else:                              # > 64 FM fields: the sums span launches; FM backward on the concat
+                d0 = plan.slots[0].dim
+                g_in = g_out                   # upstream gradient of the concat: read, never written (no clone)
+                g_out = torch.empty((B, ld), dtype=torch.float32, device=dev)
+                check(lib.nrx_fm_bwd(fm_feat.data_ptr(), ld, len(plan.slots), d0, B, g_fm.data_ptr(), _ptr(g_in), ld,
+                                     g_out.data_ptr(), ld, stream), "nrx_fm_bwd")
         if g_wide is not None:
             g_wide = _f32c(g_wide, "grad of wide_x")
         if ctx.sink is not None:
-            _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream)      # results go to the sink, not to .grad
+            _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg)      # results go to the sink, not to .grad
             return (None,) * (6 + n_tables)
         if ctx.sparse_grad:
-            return (None, None, None, None, None, None, *_sorted_sparse_grads(ctx, lib, g_out, g_wide, stream))
+            return (None, None, None, None, None, None, *_sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg))
         grads = [torch.zeros(shape, dtype=torch.float32, device=d) for shape, d in ctx.table_meta]
-        if B > 0 and (g_out is not None or g_wide is not None):
+        if B > 0 and (g_out is not None or g_wide is not None or fmg is not None):
             gptrs = [g.data_ptr() for g in grads]
             n = len(plan.slots)
             for lo in range(0, n, NRX_MAX_FEATURES):
                 hi = min(n, lo + NRX_MAX_FEATURES)
                 arr = _fill_features(plan, lo, hi, grads, ctx.ins, ctx.ws, table_ptrs=gptrs, cache_key="bwd")
-                check(lib.nrx_embed_bwd(arr, hi - lo, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, stream),
+                check(lib.nrx_embed_bwd(arr, hi - lo, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, fmg, stream),
                       "nrx_embed_bwd")
         return (None, None, None, None, None, None, *grads)
 
@@ -318,7 +330,7 @@ def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequ
     return order, uniq, seg, counts
 
 
-def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream):
+def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
     """Row-sparse, deterministic table grads.  Per group of tables sharing an embedding dim: ONE planning
     call (nrx_sparse_plan: compact (table, row) keys, rocPRIM radix sort on just the significant bits, head
     flags + scan -> unique rows, segment starts, per-table split, all on the device), one host read of
@@ -352,18 +364,19 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream):
             # per-table COO tensors while that kernel runs (1.00 ms per C2 step vs 1.11 ms with the sync-free
             # n_unique_dev form of the call, which leaves the host work exposed after the GPU is done).
             sub = EmbedPlan([plan.slots[i] for i in fs], out_width=plan.out_width, wide_width=plan.wide_width)
-            arr = _fill_features(sub, 0, n, [None] * n_tables, ids, [ctx.ws[i] for i in fs], table_ptrs=[0] * n_tables, fm=False)
+            arr = _fill_features(sub, 0, n, [None] * n_tables, ids, [ctx.ws[i] for i in fs], table_ptrs=[0] * n_tables,
+                                 fm=fmg is not None)
             if ctx.sink is not None:
                 values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
                 check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
-                                               seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), values.data_ptr(), stream),
+                                               seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), fmg, values.data_ptr(), stream),
                       "nrx_embed_bwd_sorted")
                 ctx.sink.pending.append(dict(tables=ctx.tables, dim=D, uniq=uniq, values=values, counts=counts, cap=total))
                 continue
             if SPARSE_BWD_SYNC_FREE:
                 values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
                 check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
-                                               seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), values.data_ptr(), stream),
+                                               seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), fmg, values.data_ptr(), stream),
                       "nrx_embed_bwd_sorted")
                 cl = counts.tolist()
                 nu = cl[0]
@@ -372,7 +385,7 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream):
                 nu = cl[0]
                 values = torch.empty((nu, D), dtype=torch.float32, device=dev)
                 check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
-                                               seg.data_ptr(), uniq.data_ptr(), nu, None, values.data_ptr(), stream),
+                                               seg.data_ptr(), uniq.data_ptr(), nu, None, fmg, values.data_ptr(), stream),
                       "nrx_embed_bwd_sorted")                     # padding rows (id 0) come back as zeros
             rows = (uniq[:nu] & MASK).unsqueeze(0)
             for t in sorted(set(tabs)):
@@ -408,7 +421,9 @@ class PreparedEmbed:
 
     def __init__(self, plan: EmbedPlan, tables: Sequence[torch.Tensor], inputs, weights,
                  out_ld: Optional[int] = None, need_out: bool = True, check_index: bool = False,
-                 out: Optional[torch.Tensor] = None, fm: Optional[torch.Tensor] = None):
+                 out: Optional[torch.Tensor] = None, fm: Optional[torch.Tensor] = None, fm_sums: Optional[torch.Tensor] = None):
+        """fm_sums (optional, [B, >= FM field dim] float32): training form -- the launch also leaves the FM field sums
+        there (nrx_embed_fwd_train) for a later PreparedSparseBackward."""
         self.lib = _lib.load()
         self.plan = plan
         self.tables = [t.detach() for t in tables]
@@ -428,18 +443,23 @@ class PreparedEmbed:
         for lo in range(0, n, NRX_MAX_FEATURES):
             hi = min(n, lo + NRX_MAX_FEATURES)
             self.calls.append((_fill_features(plan, lo, hi, self.tables, self.ins, self.ws, fm=self.single), hi - lo))
+        if fm_sums is not None and (not self.single or not plan.use_fm or fm_sums.dtype != torch.float32 or fm_sums.dim() != 2
+                                    or fm_sums.shape[0] != B or not fm_sums.is_contiguous()):
+            raise ValueError("fm_sums must be a contiguous float32 [B, dim] tensor, for an FM plan of <= 64 features")
+        self.fm_sums = fm_sums
         self._args = (_ptr(self.out), self.ld, _ptr(self.wide), plan.wide_width,
-                      _ptr(self.fm) if self.single else None, _ptr(self.status))
+                      _ptr(self.fm) if self.single else None, _ptr(fm_sums), fm_sums.shape[1] if fm_sums is not None else 0,
+                      _ptr(self.status))
         self.device = dev
 
     def run(self):
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        fwd = self.lib.nrx_embed_fwd
+        fwd = self.lib.nrx_embed_fwd_train
         a = self._args
         for arr, n in self.calls:
-            rc = fwd(arr, n, self.B, a[0], a[1], a[2], a[3], a[4], a[5], stream)
+            rc = fwd(arr, n, self.B, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], stream)
             if rc:
-                check(rc, "nrx_embed_fwd")
+                check(rc, "nrx_embed_fwd_train")
         if self.plan.use_fm and not self.single:
             check(self.lib.nrx_fm_fwd(self.out.data_ptr(), self.ld, len(self.plan.slots), self.plan.slots[0].dim,
                                       self.B, self.fm.data_ptr(), stream), "nrx_fm_fwd")
@@ -448,6 +468,69 @@ class PreparedEmbed:
     def check(self):
         if self.status is not None:
             _raise_if_oob(self.status, self.plan.names)
+
+
+class PreparedSparseBackward:
+    """A bound, re-launchable row-sparse backward of a PreparedEmbed launch (benchmarking / hand-written training
+    loops): planning (nrx_sparse_plan) + the deterministic segmented reduction (nrx_embed_bwd_sorted, FM gradient
+    folded in) with every buffer allocated once; `run()` only enqueues.  Results stay on the device: per embedding dim
+    a dict(dim, uniq, values, counts, cap) exactly like an ops.SparseGradSink entry.  No autograd, no host reads."""
+
+    def __init__(self, fwd: PreparedEmbed, g_out: Optional[torch.Tensor], g_fm: Optional[torch.Tensor] = None,
+                 g_wide: Optional[torch.Tensor] = None):
+        self.lib, self.fwd, plan = fwd.lib, fwd, fwd.plan
+        if not fwd.single:
+            raise ValueError("PreparedSparseBackward covers plans of <= 64 features")
+        self.g_out = None if g_out is None else _f32c(g_out, "g_out")
+        self.g_wide = None if g_wide is None else _f32c(g_wide, "g_wide")
+        self.fmg = None
+        if g_fm is not None:
+            if fwd.fm_sums is None or fwd.out is None:
+                raise ValueError("an FM gradient needs the forward's fm_sums and concat (PreparedEmbed(..., fm_sums=...))")
+            self.g_fm = _f32c(g_fm, "g_fm")
+            self.fmg = NrxFmGrad(self.g_fm.data_ptr(), fwd.fm_sums.data_ptr(), fwd.fm_sums.shape[1], fwd.out.data_ptr(), fwd.ld)
+        n_tables = len(fwd.tables)
+        by_dim = {}
+        for i, s in enumerate(plan.slots):
+            if s.kind != NRX_DENSE:
+                by_dim.setdefault(s.dim, []).append(i)
+        self.groups = []
+        dev = fwd.device
+        for D, fs in by_dim.items():
+            ids = [fwd.ins[i] for i in fs]
+            if any(x.dtype != ids[0].dtype for x in ids):
+                raise TypeError("PreparedSparseBackward: the ids of one embedding dim must share a dtype")
+            n = len(fs)
+            total = sum(x.numel() for x in ids)
+            tabs = [plan.slots[i].table for i in fs]
+            sub = EmbedPlan([plan.slots[i] for i in fs], out_width=plan.out_width, wide_width=plan.wide_width)
+            g = dict(dim=D, n=n, total=total, cap=total,
+                     order=torch.empty(total, dtype=torch.int64, device=dev), uniq=torch.empty(total, dtype=torch.int64, device=dev),
+                     seg=torch.empty(total + 1, dtype=torch.int64, device=dev),
+                     counts=torch.empty(n_tables + 2, dtype=torch.int64, device=dev),
+                     ws=torch.empty(max(1, self.lib.nrx_sparse_plan_workspace(total)), dtype=torch.uint8, device=dev),
+                     values=torch.empty((total, D), dtype=torch.float32, device=dev),
+                     ptrs=(C.c_void_p * n)(*[x.data_ptr() for x in ids]), lens=(C.c_int64 * n)(*[x.numel() for x in ids]),
+                     tof=(C.c_int32 * n)(*tabs), rws=(C.c_int64 * n)(*[fwd.tables[t].shape[0] for t in tabs]),
+                     bits=ids[0].element_size() * 8, n_tables=n_tables,
+                     arr=_fill_features(sub, 0, n, [None] * n_tables, ids, [fwd.ws[i] for i in fs], table_ptrs=[0] * n_tables,
+                                        fm=self.fmg is not None))
+            self.groups.append(g)
+
+    def run(self):
+        lib, f = self.lib, self.fwd
+        stream = torch.cuda.current_stream(f.device).cuda_stream
+        for g in self.groups:
+            rc = lib.nrx_sparse_plan(g["ptrs"], g["lens"], g["tof"], g["rws"], g["n"], g["bits"], g["n_tables"], g["order"].data_ptr(),
+                                     g["uniq"].data_ptr(), g["seg"].data_ptr(), g["counts"].data_ptr(), g["ws"].data_ptr(), stream)
+            if rc:
+                check(rc, "nrx_sparse_plan")
+            rc = lib.nrx_embed_bwd_sorted(g["arr"], g["n"], f.B, g["dim"], _ptr(self.g_out), f.ld, _ptr(self.g_wide), f.plan.wide_width,
+                                          g["order"].data_ptr(), g["seg"].data_ptr(), g["uniq"].data_ptr(), g["total"],
+                                          g["counts"].data_ptr(), self.fmg, g["values"].data_ptr(), stream)
+            if rc:
+                check(rc, "nrx_embed_bwd_sorted")
+        return self.groups
 
 
 # ------------------------------------------------------------------------------- pooling

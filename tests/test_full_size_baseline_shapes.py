@@ -1,0 +1,151 @@
+"""Full-size property tests on the REAL BASELINE.json table shapes: identity-valued tables whose
+every element is a closed form of (row, column), so the gathered output can be checked bit for bit at any size without a
+CPU copy of the table.
+
+  C3  DCN: item_id table 100 000 000 x 64 fp32 (25.6 GB; element offsets far beyond 2^31), B = 65 536
+  C4  DSSM: user_id table 10 000 000 x 16 + history L = 50 over the 200 000-row news table, B = 65 536
+  C5  Wide&Deep: ALL 40 tables (1 k .. 500 M rows x 32, 224 GB) resident on one 288 GB GPU, wide split on the 10
+      smallest, B = 65 536 -- skipped when the device cannot hold them
+
+Reference arithmetic: BaseModel.get_feature_embedding / get_embeddings_from_batch (src/model/BaseModel/base_model.py:
+262-271, 284-308), WideDeep.get_inp_embedding (src/model/sort/widedeep/model.py:53-69), DSSM tower inputs
+(src/model/recall/DSSM/model.py:148-180).  Gather / concat / wide split: bit-exact; pooled history: rtol 1e-6."""
+import pytest
+import torch
+
+from news_recsys_amd import ops
+from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN, NRX_SPARSE
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+B = 65536
+SLAB = 1 << 24
+
+
+def pattern(rows_idx: torch.Tensor, D: int, salt: int) -> torch.Tensor:
+    """Closed-form table content: even columns (r & 8191) + k + salt, odd columns (r >> 13) + k -- exact in fp32
+    (all values < 2^24) and (even, odd) together identify r.  rows_idx int64 [n] -> float32 [n, D]."""
+    k = torch.arange(D, device=rows_idx.device)
+    lo = (rows_idx & 8191)[:, None] + k[None] + salt
+    hi = (rows_idx >> 13)[:, None] + k[None]
+    return torch.where((k % 2 == 0)[None], lo, hi).to(torch.float32)
+
+
+def make_table(rows: int, D: int, salt: int) -> torch.Tensor:
+    t = torch.empty((rows, D), dtype=torch.float32, device=DEV)
+    for r0 in range(0, rows, SLAB):                        # in slabs: the int64 temporaries stay ~1 GB
+        r1 = min(rows, r0 + SLAB)
+        t[r0:r1] = pattern(torch.arange(r0, r1, device=DEV), D, salt)
+    t[0].zero_()                                           # padding row (nn.Embedding(padding_idx=0))
+    return t
+
+
+def expect(ids: torch.Tensor, D: int, salt: int) -> torch.Tensor:
+    e = pattern(ids.reshape(-1).long(), D, salt)
+    e[ids.reshape(-1) == 0] = 0
+    return e
+
+
+def need_free(bytes_):
+    free = torch.cuda.mem_get_info(torch.device(DEV))[0]
+    if free < bytes_:
+        pytest.skip(f"needs {bytes_ >> 30} GiB of free HBM, device has {free >> 30} GiB")
+
+
+def draw(gen, rows, shape=(B,)):
+    ids = torch.randint(1, rows, shape, device=DEV, generator=gen)
+    flat = ids.view(-1)
+    flat[0], flat[1], flat[2] = rows - 1, 0, rows - 1      # last row (max offset), padding, duplicate
+    return ids
+
+
+def test_c3_real_100m_row_table_gather_and_fused_cross():
+    need_free(40 << 30)
+    gen = torch.Generator(device=DEV).manual_seed(20260301)
+    rows = dict(category=18, item_id=100_000_000, subcategory=270, user_click_category=18, user_id=1_000_000)
+    names = sorted(rows)
+    D = 64
+    tables = [make_table(rows[n], D, 3 * i) for i, n in enumerate(names)]
+    assert tables[1].numel() > 2 ** 31                                     # element offsets do not fit 32 bits
+    ids = [draw(gen, rows[n]) for n in names]
+    ids[1][3] = 33_554_432                                                 # first row whose element offset is exactly 2^31
+    ids[1][4] = 99_999_999
+    plan = ops.EmbedPlan([ops.Slot(n, NRX_SPARSE, i, D, 0, i * D) for i, n in enumerate(names)], out_width=5 * D)
+    want = torch.cat([expect(x, D, 3 * i) for i, x in enumerate(ids)], dim=1)
+    for dt in (torch.int64, torch.int32):
+        out = ops.embed_apply(plan, tables, [x.to(dt) for x in ids], [None] * 5)[0]
+        assert torch.equal(out, want)
+    # the C3 bench path: one fused launch gather -> cat[x, cross(x)]; x half bit-exact, cross half vs fp64 on a sample
+    W = 5 * D
+    w = torch.randn(2, W, device=DEV, generator=gen) / W ** 0.5 * 1e-3
+    b = torch.randn(2, W, device=DEV, generator=gen)
+    buf = ops.embed_dcn_v1(plan, tables, ids, w, b)
+    assert torch.equal(buf[:, :W], want)
+    sub = slice(0, B, 61)
+    x0 = want[sub].double()
+    xl = x0
+    for l in range(2):
+        xl = x0 * (xl @ w[l].double())[:, None] + b[l].double() + xl
+    torch.testing.assert_close(buf[sub, W:].double(), xl, rtol=1e-5, atol=1e-5 * xl.abs().max().item())
+
+
+def test_c4_real_10m_user_table_and_history_pooling():
+    need_free(4 << 30)
+    gen = torch.Generator(device=DEV).manual_seed(20260302)
+    D, L = 16, 50
+    users, news = make_table(10_000_000, D, 0), make_table(200_000, D, 5)
+    uid = draw(gen, 10_000_000)
+    iid = draw(gen, 200_000)
+    lens = torch.randint(0, L + 1, (B,), device=DEV, generator=gen)
+    lens[0], lens[1] = L, 0
+    mask = (torch.arange(L, device=DEV)[None] < lens[:, None]).float()
+    hist = torch.randint(1, 200_000, (B, L), device=DEV, generator=gen) * mask.long()
+    # user tower input: sorted names -> [user_history (pooled, news table), user_id]; item tower: [item_id]
+    plan_u = ops.EmbedPlan([ops.Slot("user_history", NRX_BAG_MASKED_MEAN, 1, D, L, 0), ops.Slot("user_id", NRX_SPARSE, 0, D, 0, D)],
+                           out_width=2 * D)
+    out = ops.embed_apply(plan_u, [users, news], [hist, uid], [mask, None])[0]
+    assert torch.equal(out[:, D:], expect(uid, D, 0))                                     # gather: bit-exact
+    rows = expect(hist, D, 5).view(B, L, D).double()
+    ref = (rows * mask.double()[..., None]).sum(1) / (mask.double().sum(1, keepdim=True) + 1e-8)
+    assert torch.all(out[lens == 0, :D] == 0)                                             # all-masked bag: exact zeros
+    rel = ((out[:, :D].double() - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
+    assert rel < 1e-6                                                                      # stated pooling tolerance
+    plan_i = ops.EmbedPlan([ops.Slot("item_id", NRX_SPARSE, 0, D, 0, 0)], out_width=D)
+    assert torch.equal(ops.embed_apply(plan_i, [news], [iid], [None])[0], expect(iid, D, 5))
+
+
+def test_c5_all_40_tables_on_one_gpu_with_wide_split():
+    sizes = [int(round(1e3 * (5e5) ** (i / 39))) for i in range(40)]                      # 1 k .. 500 M rows
+    D = 32
+    need_free(sum(sizes) * D * 4 + (10 << 30))
+    gen = torch.Generator(device=DEV).manual_seed(20260303)
+    order = sorted(range(40), key=lambda i: -sizes[i])                                    # allocate the big ones first
+    tables = [None] * 40
+    for i in order:
+        tables[i] = make_table(sizes[i], D, i)
+    assert sum(t.numel() for t in tables) * 4 > 220e9
+    ids = [draw(gen, sizes[i]) for i in range(40)]
+    ids[39][5] = 499_999_999
+    # wide features = the 10 smallest tables: column 0 -> wide tensor, columns 1.. -> deep concat (widedeep/model.py:53-69)
+    slots, col = [], 0
+    for i in range(40):
+        wide = i < 10
+        slots.append(ops.Slot(f"W{i:02d}", NRX_SPARSE, i, D, 0, col, wide_col=i if wide else -1))
+        col += D - 1 if wide else D
+    plan = ops.EmbedPlan(slots, out_width=col, wide_width=10)
+    deep, wide, _ = ops.embed_apply(plan, tables, ids, [None] * 40)
+    assert tuple(deep.shape) == (B, 40 * D - 10) and tuple(wide.shape) == (B, 10)
+    c = 0
+    for i in range(40):
+        e = expect(ids[i], D, i)
+        if i < 10:
+            assert torch.equal(wide[:, i], e[:, 0]) and torch.equal(deep[:, c:c + D - 1], e[:, 1:])
+            c += D - 1
+        else:
+            assert torch.equal(deep[:, c:c + D], e)
+            c += D
+    # plain concat (no split): the uniform ring kernel over all 40 tables
+    plan2 = ops.EmbedPlan([ops.Slot(f"W{i:02d}", NRX_SPARSE, i, D, 0, i * D) for i in range(40)], out_width=40 * D)
+    out = ops.embed_apply(plan2, tables, ids, [None] * 40)[0]
+    for i in (0, 9, 10, 38, 39):
+        assert torch.equal(out[:, i * D:(i + 1) * D], expect(ids[i], D, i))

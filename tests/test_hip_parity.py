@@ -638,6 +638,81 @@ def test_prepared_embed_matches_embed_apply_and_reruns():
         call.check()
 
 
+@pytest.mark.parametrize("mix", ["uniform16", "with_bag"])
+def test_fm_gradient_folded_into_embed_backward_all_three_modes(mix):
+    """The FM epilogue's gradient rides in the embedding backward (nrx_fm_grad_t: field sums from nrx_embed_fwd_train,
+    values from the forward concat) instead of a separate nrx_fm_bwd pass.  Dense, COO and the bound
+    PreparedSparseBackward must all equal torch autograd on the reference formula (fm/model.py:18-26) in fp64."""
+    rng = np.random.default_rng(33)
+    B = 700
+    feats = [(NRX_SPARSE, 40 + 3 * i, 16, 0) for i in range(9)]
+    if mix == "with_bag":
+        feats[4] = (NRX_BAG_MASKED_MEAN, 61, 16, 7)          # a pooled field inside the FM (generic kernel)
+    space, tables, batch = _rand_case(rng, B, feats)
+    plan, tt, inputs, weights, _ = build_plan(space, tables, batch, set(tables), fm=True)
+    up = torch.randn(B, plan.out_width, device=DEV)
+    upf = torch.randn(B, device=DEV)
+
+    # reference: gather/pool in torch fp64, FM by the reference's formula
+    t64 = [t.detach().double().requires_grad_(True) for t in tt]
+    cols = []
+    for s_, x, w in zip(plan.slots, inputs, weights):
+        e = t64[s_.table][x.long()]
+        if s_.kind == NRX_BAG_MASKED_MEAN:
+            e = (e * w.double()[..., None]).sum(1) / (w.double().sum(1, keepdim=True) + 1e-8)
+        cols.append(e)
+    feat = torch.cat(cols, 1)
+    fv = torch.stack(cols, 1)
+    first = fv[:, :, 0].sum(1)
+    v = fv[:, :, 1:]
+    fmr = first + 0.5 * ((v.sum(1) ** 2) - (v ** 2).sum(1)).sum(1)
+    ((feat * up.double()).sum() + (fmr * upf.double()).sum()).backward()
+    want = [t.grad.clone() for t in t64]
+    for w_ in want:
+        w_[0].zero_()                                          # padding row never trains
+
+    def check(grads, tag):
+        for g_, w_ in zip(grads, want):
+            gd = g_.to_dense() if g_.is_sparse else g_
+            torch.testing.assert_close(gd.double(), w_, rtol=2e-4, atol=2e-4, msg=lambda m: f"{tag}: {m}")
+
+    for mode in (False, True):
+        ts = [t.detach().clone().requires_grad_(True) for t in tt]
+        out, _, fm = ops.embed_apply(plan, ts, inputs, weights, sparse_grad=mode)
+        torch.testing.assert_close(fm.double(), fmr.detach(), rtol=1e-5, atol=1e-4)
+        ((out * up).sum() + (fm * upf).sum()).backward()
+        check([t.grad for t in ts], f"sparse_grad={mode}")
+    # only the FM output is used downstream (g_out is None)
+    ts = [t.detach().clone().requires_grad_(True) for t in tt]
+    _, _, fm = ops.embed_apply(plan, ts, inputs, weights)
+    (fm * upf).sum().backward()
+    t64b = [t.grad for t in ts]
+    ts2 = [t.detach().clone().requires_grad_(True) for t in tt]
+    out2, _, fm2 = ops.embed_apply(plan, ts2, inputs, weights)
+    ((out2 * 0).sum() + (fm2 * upf).sum()).backward()
+    for a_, b_ in zip(t64b, ts2):
+        torch.testing.assert_close(a_, b_.grad, rtol=1e-4, atol=1e-5)       # float-atomic order differs between runs
+
+    # bound form: PreparedEmbed(fm_sums=...) + PreparedSparseBackward, scattered into dense for the comparison
+    D = 16
+    sums = torch.empty(B, D, device=DEV)
+    fwd = ops.PreparedEmbed(plan, tt, inputs, weights, fm_sums=sums)
+    out, _, fm = fwd.run()
+    fv32 = torch.stack([c.float() for c in cols], 1).detach()
+    torch.testing.assert_close(sums[:, 1:], fv32[:, :, 1:].sum(1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(sums[:, 0], fv32[:, :, 0].sum(1), rtol=1e-5, atol=1e-5)
+    bwd = ops.PreparedSparseBackward(fwd, up, upf)
+    for _ in range(2):
+        groups = bwd.run()
+    dense = [torch.zeros_like(t) for t in tt]
+    for g_ in groups:
+        nu = int(g_["counts"][0])
+        keys = g_["uniq"][:nu]
+        for k_, v_ in zip(keys.tolist(), g_["values"][:nu]):
+            dense[k_ >> 40][k_ & ((1 << 40) - 1)] += v_
+    check(dense, "PreparedSparseBackward")
+
+
 @pytest.mark.parametrize("world,lens,cap", [(1, [100], 100), (2, [63, 1, 300], 256), (8, [4096, 4096, 5000, 17], 2048),
                                             (3, [0, 777, 0, 2050], 1024), (8, [65536] * 5, 44000), (4, [5000], 64)])
 @pytest.mark.parametrize("dtype", [torch.int64, torch.int32])

@@ -55,7 +55,7 @@ if want("embed_bwd"):
     grads = [torch.zeros_like(t) for t in tables]
     arr = ops._fill_features(plan, 0, F, grads, ids, [None] * F, table_ptrs=[g.data_ptr() for g in grads])
     st = torch.cuda.current_stream().cuda_stream
-    us = timeit(lambda: lib.nrx_embed_bwd(arr, F, B, up.data_ptr(), F * D, None, 0, st))
+    us = timeit(lambda: lib.nrx_embed_bwd(arr, F, B, up.data_ptr(), F * D, None, 0, None, st))
     print(f"embed bwd scatter kernel alone (atomics into 26 x 1M x 16): {us:8.1f} us  {B * F * (8 + 64 + 2 * 64) / us / 1e3:7.1f} GB/s algorithmic (ids + g read + row RMW)", flush=True)
 if want("train_step"):
     F, D, rows = 26, 16, 1_000_000

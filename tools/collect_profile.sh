@@ -7,7 +7,7 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-B="python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline $*"
+B="python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --headline-only $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > $OUT/stats.log 2>&1
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" \
