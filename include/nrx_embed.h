@@ -267,18 +267,19 @@ NRX_API int nrx_scatter_add_rows_segmented(float* const* grad_tables, const int6
  * int64 or all int32; ids / lens are HOST arrays, n_feats <= NRX_MAX_FEATURES); flat position p
  * enumerates them feature-major.  Every (source, owner) pair gets a send block of `cap` slots, so
  * the all-to-alls use equal splits and nobody needs the counts on the host:
- *   send_rows[o*cap + k]      local row (id / world) of the k-th id owned by o, in source order
+ *   send_rows[o*cap + k]      int32 local row (id / world) of the k-th id owned by o, in source order
  *                             (slots past the block's count are left untouched: the owner learns the
- *                             count from counts2d and never reads them);
- *   slot[p]                   o*cap + k: where source position p's row will sit in the returned-row
- *                             buffer [world*cap, dim]; -1 if block o overflowed (k >= cap);
+ *                             count from counts2d and never reads them); ids outside [0, 2^31) go to rank 0
+ *                             as -1 / INT32_MAX and are reported there as out of range;
+ *   slot[p]                   int32 o*cap + k: where source position p's row will sit in the returned-row
+ *                             buffer [world*cap, dim]; -1 if block o overflowed (k >= cap);   world*cap < 2^31
  *   counts2d[o*n_feats + f]   ids of feature f owned by o (the owner's inbox segmentation);
  *   overflow[0]               max over owners of (block count), written always: > cap means the
  *                             capacity was exceeded and the caller must redo the step exactly.
  * workspace: device int64[nrx_route_workspace(n_total, world)].  Deterministic.               */
 NRX_API int64_t nrx_route_workspace(int64_t n_total, int32_t world);
 NRX_API int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_t n_feats, int32_t index_bits,
-                  int32_t world, int64_t cap, int64_t* send_rows, int64_t* slot, int64_t* counts2d,
+                  int32_t world, int64_t cap, int32_t* send_rows, int32_t* slot, int64_t* counts2d,
                   int64_t* overflow, int64_t* workspace, void* stream);
 /* Owner side of the fixed-capacity exchange.  inbox_rows [world*cap]: block s came from rank s, its
  * valid prefix has sum_f recv2d[s*n_feats+f] entries, feature-major.  feat_table (HOST, n_feats):
@@ -286,12 +287,12 @@ NRX_API int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_t n
  * are not written).  recv2d is a DEVICE array: nothing is read back to the host.               */
 NRX_API int nrx_gather_inbox(const float* const* tables, const int64_t* table_rows, int32_t n_tables,
                      const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,
-                     const int64_t* recv2d, const int64_t* inbox_rows, int32_t dim,
+                     const int64_t* recv2d, const int32_t* inbox_rows, int32_t dim,
                      float* out_rows, int32_t* status, void* stream);
 /* Backward of nrx_gather_inbox: grad_tables[..][row] += g_rows[p] over the valid prefixes.        */
 NRX_API int nrx_scatter_add_inbox(float* const* grad_tables, const int64_t* table_rows, int32_t n_tables,
                           const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,
-                          const int64_t* recv2d, const int64_t* inbox_rows, int32_t dim,
+                          const int64_t* recv2d, const int32_t* inbox_rows, int32_t dim,
                           const float* g_rows, int32_t skip_row0, void* stream);
 /* Expands a CSR batch of an array feature (values[offsets[b] .. offsets[b+1]), offsets relative to the
  * batch, device int64[batch+1]) into the reference's padded form: ids [batch, bag_len] (0-padded,

@@ -4,135 +4,129 @@
 // ballot ranks and prefix sums; the only atomics are integer counters whose final value is
 // order-independent.
 //
-//   route_hist   per 2048-id chunk (one wavefront): ids of each owner           -> hist[chunk][o]
-//                and per-(owner, feature) totals                                 -> counts2d
-//   route_scan   one block: exclusive scan of hist over chunks per owner, block counts -> overflow
-//   route_place  per chunk: stable rank of each id inside its owner block -> send_rows, slot
+//   route_hist   per 2048-id chunk of one feature (one block): ids of each owner   -> hist[o][chunk]
+//                and per-(owner, feature) totals                                   -> counts2d
+//   route_scan   one block: exclusive scan of hist over chunks per owner, largest block -> overflow
+//   route_place  per chunk: stable rank of each id inside its owner block -> send_rows (int32 local rows), slot (int32)
+//   route_single world == 1: one narrowing pass
 //   inbox_*      owner side: walk the [world, cap] inbox; a slot's feature (hence table) comes from
 //                the prefix sums of the device-resident recv2d row, staged in LDS per block.
 #include "nrx_common.h"
 
 namespace {
 
-constexpr int CHUNK = 512;      // ids per wavefront: 8 per lane, all loaded before any is ranked
-constexpr int PER_LANE = CHUNK / 64;
+// ------------------------------------------------------------------------------- source side
+// A 256-thread block owns one CHUNK of 2048 ids of ONE feature (chunks are enumerated feature-major, so the chunk
+// order IS the source order): the feature -- hence the id array -- is block-uniform, ids are read coalesced
+// (position p = chunk start + j * 256 + thread), and the stable rank of an id inside its owner block is
+//     (ids of that owner in earlier chunks)  +  (in earlier (round j, wavefront) cells of this chunk)  +  (in lower lanes)
+// = scanned histogram + LDS cell prefix + ballot rank.  On the wire a row is an int32 local row (tables have < 2^31 rows).
+constexpr int CHUNK = 2048;
+constexpr int ROUNDS = CHUNK / NRX_BLOCK;     // 8 ids per thread
+constexpr int RWAVES = NRX_BLOCK / 64;
 
 struct RouteArgs {
     const void* ids[NRX_MAX_FEATURES];
-    int64_t off[NRX_MAX_FEATURES + 1];    // flat start of each feature
+    int64_t len[NRX_MAX_FEATURES];
+    int64_t off[NRX_MAX_FEATURES + 1];        // flat start of each feature
+    int32_t chunk0[NRX_MAX_FEATURES + 1];     // first chunk of each feature
     int32_t n_feats;
     int32_t world;
     int32_t idx64;
-    int32_t pad;
-    int64_t n_total;
+    int32_t nchunks;
     int64_t cap;
-    int64_t* hist;       // [world][nchunks]  (owner-major: the scan reads it coalesced)
-    int64_t nchunks;
+    int32_t* hist;       // [world][nchunks]  (owner-major: the scan reads it coalesced)
     int64_t* counts2d;   // [world][n_feats]
-    int64_t* block_cnt;  // [world]  (workspace)
-    int64_t* send_rows;
-    int64_t* slot;
+    int32_t* send_rows;
+    int32_t* slot;
     int64_t* overflow;
 };
 static_assert(sizeof(RouteArgs) <= 3584, "kernarg budget");
 
-__device__ __forceinline__ int feat_of(const NRX_CONST RouteArgs* a, int64_t p) {
-    int lo = 0, hi = a->n_feats;         // last f with off[f] <= p
+__device__ __forceinline__ int chunk_feature(const NRX_CONST RouteArgs* a, int chunk) {
+    int lo = 0, hi = a->n_feats;               // last f with chunk0[f] <= chunk (features without ids own no chunk)
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (a->off[mid] <= p) lo = mid; else hi = mid;
+        if (a->chunk0[mid] <= chunk) lo = mid; else hi = mid;
     }
     return lo;
 }
 
-__device__ __forceinline__ int64_t route_load(const NRX_CONST RouteArgs* a, int f, int64_t p) {
-    const int64_t i = p - a->off[f];
-    return a->idx64 ? nrx_gconst<int64_t>(a->ids[f])[i] : (int64_t)nrx_gconst<int32_t>(a->ids[f])[i];
+// owner and wire form of an id: ids outside [0, 2^31) cannot be rows of any table -- they go to rank 0 as -1 / INT32_MAX
+// and are reported there as out of range (the reference raises IndexError for them too)
+__device__ __forceinline__ void route_split(int64_t id, int world, int& owner, int32_t& local) {
+    if (id < 0) { owner = 0; local = -1; return; }
+    if (id > 0x7fffffffLL) { owner = 0; local = 0x7fffffff; return; }
+    const uint32_t u = (uint32_t)id;
+    const uint32_t l = u / (uint32_t)world;
+    owner = (int)(u - l * (uint32_t)world);
+    local = (int32_t)l;
 }
 
-__device__ __forceinline__ int owner_rank(int64_t id, int world) { return id < 0 ? 0 : (int)(id % world); }
-
-// Loads the chunk's ids (PER_LANE per lane, group g covers positions begin + g*64 + lane) and their
-// features/owners into registers: all global loads are issued before the first ballot.
-struct ChunkRegs {
-    int64_t id[PER_LANE];
-    int o[PER_LANE];
-    int f[PER_LANE];
+struct ChunkIds {
+    int owner[ROUNDS];
+    int32_t local[ROUNDS];
 };
 
-__device__ __forceinline__ void load_chunk(const NRX_CONST RouteArgs* a, int64_t begin, int64_t end, int lane, ChunkRegs& c) {
-    const int world = a->world;
-    const int f_first = feat_of(a, begin);
-    const bool one_feature = (end - 1) < a->off[f_first + 1];        // wave-uniform: the usual case
+__device__ __forceinline__ void load_chunk(const NRX_CONST RouteArgs* a, int f, int64_t i0, int64_t len, int tid, ChunkIds& c) {
+    int64_t id[ROUNDS];
+    const void* p = a->ids[f];
 #pragma unroll
-    for (int g = 0; g < PER_LANE; ++g) {
-        const int64_t p = begin + g * 64 + lane;
-        c.o[g] = -1;
-        c.f[g] = f_first;
-        c.id[g] = 0;
-        if (p < end) {
-            if (!one_feature) c.f[g] = feat_of(a, p);
-            c.id[g] = route_load(a, c.f[g], p);
-        }
+    for (int j = 0; j < ROUNDS; ++j) {
+        const int64_t i = i0 + j * NRX_BLOCK + tid;
+        id[j] = 0;
+        if (i < len) id[j] = a->idx64 ? nrx_gconst<int64_t>(p)[i] : (int64_t)nrx_gconst<int32_t>(p)[i];
     }
 #pragma unroll
-    for (int g = 0; g < PER_LANE; ++g) {
-        const int64_t p = begin + g * 64 + lane;
-        if (p < end) c.o[g] = owner_rank(c.id[g], world);
+    for (int j = 0; j < ROUNDS; ++j) {
+        route_split(id[j], a->world, c.owner[j], c.local[j]);
+        if (i0 + j * NRX_BLOCK + tid >= len) c.owner[j] = -1;
     }
 }
 
 __global__ __launch_bounds__(NRX_BLOCK) void route_hist(const RouteArgs args_in_kernarg) {
     const NRX_CONST RouteArgs* a = nrx_kernarg<RouteArgs>();
-    const int lane = threadIdx.x & 63;
-    const int64_t chunk = (int64_t)blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6);
-    const int64_t begin = chunk * CHUNK;
-    if (begin >= a->n_total) return;
-    const int64_t end = (begin + CHUNK < a->n_total) ? begin + CHUNK : a->n_total;
-    const int world = a->world, F = a->n_feats;
-    ChunkRegs c;
-    load_chunk(a, begin, end, lane, c);
-    const int f_first = feat_of(a, begin);
-    const bool one_feature = (end - 1) < a->off[f_first + 1];
-    int64_t cnt = 0;        // lane o: ids of owner o in this chunk
+    __shared__ int s_cnt[64];
+    const int tid = threadIdx.x, chunk = blockIdx.x;
+    const int f = chunk_feature(a, chunk);
+    const int64_t i0 = (int64_t)(chunk - a->chunk0[f]) * CHUNK;
+    if (tid < 64) s_cnt[tid] = 0;
+    __syncthreads();
+    ChunkIds c;
+    load_chunk(a, f, i0, a->len[f], tid, c);
 #pragma unroll
-    for (int g = 0; g < PER_LANE; ++g) {
-        for (int t = 0; t < world; ++t) {
-            const unsigned long long m = __ballot(c.o[g] == t);
-            if (lane == t) cnt += __popcll(m);
-        }
-        if (!one_feature && c.o[g] >= 0)       // chunk straddles features: count per lane
-            atomicAdd((unsigned long long*)&a->counts2d[c.o[g] * F + c.f[g]], 1ull);
-    }
-    if (lane < world) {
-        if (one_feature && cnt) atomicAdd((unsigned long long*)&a->counts2d[lane * F + f_first], (unsigned long long)cnt);
-        a->hist[lane * a->nchunks + chunk] = cnt;
+    for (int j = 0; j < ROUNDS; ++j)
+        if (c.owner[j] >= 0) atomicAdd(&s_cnt[c.owner[j]], 1);       // integer counts: the final value is order-independent
+    __syncthreads();
+    if (tid < a->world) {
+        const int n = s_cnt[tid];
+        a->hist[(int64_t)tid * a->nchunks + chunk] = n;
+        if (n) atomicAdd((unsigned long long*)&a->counts2d[tid * a->n_feats + f], (unsigned long long)n);
     }
 }
 
-// One wavefront per owner: exclusive scan of hist[o][0..nchunks) in place, 4 chunks per lane per
-// step (256 chunks per step, coalesced), block totals -> block_cnt, their max -> overflow.
-__global__ __launch_bounds__(NRX_BLOCK) void route_scan(int64_t* __restrict__ hist, int64_t nchunks, int world, int64_t cap,
-                                                        int64_t* __restrict__ block_cnt, int64_t* __restrict__ overflow) {
-    __shared__ int64_t s_tot[64];
+// One wavefront per owner: exclusive scan of hist[o][0..nchunks) in place (256 chunks per step, coalesced); the largest
+// owner total -> overflow.
+__global__ __launch_bounds__(NRX_BLOCK) void route_scan(int32_t* __restrict__ hist, int nchunks, int world, int64_t* __restrict__ overflow) {
+    __shared__ int s_tot[64];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
     for (int o = wid; o < world; o += NRX_BLOCK / 64) {
-        int64_t* h = hist + (int64_t)o * nchunks;
-        int64_t running = 0;
-        for (int64_t c0 = 0; c0 < nchunks; c0 += 256) {
-            const int64_t c = c0 + lane * 4;
-            int64_t v[4];
+        int32_t* h = hist + (int64_t)o * nchunks;
+        int running = 0;
+        for (int c0 = 0; c0 < nchunks; c0 += 256) {
+            const int c = c0 + lane * 4;
+            int v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = (c + k < nchunks) ? h[c + k] : 0;
-            const int64_t mine = v[0] + v[1] + v[2] + v[3];
-            int64_t incl = mine;
+            const int mine = v[0] + v[1] + v[2] + v[3];
+            int incl = mine;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
-                const int64_t t = __shfl_up(incl, off, 64);
+                const int t = __shfl_up(incl, off, 64);
                 if (lane >= off) incl += t;
             }
-            int64_t base = running + incl - mine;
+            int base = running + incl - mine;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (c + k < nchunks) h[c + k] = base;
@@ -144,45 +138,83 @@ __global__ __launch_bounds__(NRX_BLOCK) void route_scan(int64_t* __restrict__ hi
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int64_t worst = 0;
-        for (int o = 0; o < world; ++o) {
-            block_cnt[o] = s_tot[o];
+        int worst = 0;
+        for (int o = 0; o < world; ++o)
             if (s_tot[o] > worst) worst = s_tot[o];
-        }
         overflow[0] = worst;
     }
 }
 
 __global__ __launch_bounds__(NRX_BLOCK) void route_place(const RouteArgs args_in_kernarg) {
     const NRX_CONST RouteArgs* a = nrx_kernarg<RouteArgs>();
-    const int lane = threadIdx.x & 63;
-    const int64_t chunk = (int64_t)blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6);
-    const int64_t begin = chunk * CHUNK;
-    if (begin >= a->n_total) return;
-    const int64_t end = (begin + CHUNK < a->n_total) ? begin + CHUNK : a->n_total;
+    __shared__ int s_cell[ROUNDS * RWAVES][64];          // ids of owner o in cell (round j, wavefront w), then their prefix
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, chunk = blockIdx.x;
     const int world = a->world;
-    const int64_t cap = a->cap;
-    ChunkRegs c;
-    load_chunk(a, begin, end, lane, c);
-    int64_t run = (lane < world) ? a->hist[lane * a->nchunks + chunk] : 0;    // lane o: rank of the next id of owner o
+    const int f = chunk_feature(a, chunk);
+    const int64_t i0 = (int64_t)(chunk - a->chunk0[f]) * CHUNK;
+    const int64_t len = a->len[f];
+    ChunkIds c;
+    load_chunk(a, f, i0, len, tid, c);
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int rank[ROUNDS];
 #pragma unroll
-    for (int g = 0; g < PER_LANE; ++g) {
-        const int64_t p = begin + g * 64 + lane;
-        int64_t k = 0;
+    for (int j = 0; j < ROUNDS; ++j) {
+        rank[j] = 0;
         for (int t = 0; t < world; ++t) {
-            const unsigned long long m = __ballot(c.o[g] == t);
-            const int64_t base = __shfl(run, t, 64);
-            if (c.o[g] == t) k = base + __popcll(m & lt);
-            if (lane == t) run += __popcll(m);
+            const unsigned long long m = __ballot(c.owner[j] == t);
+            if (c.owner[j] == t) rank[j] = __popcll(m & lt);
+            if (lane == t) s_cell[j * RWAVES + wid][t] = __popcll(m);
         }
-        if (p < end) {
-            if (k < cap) {
-                a->slot[p] = c.o[g] * cap + k;
-                a->send_rows[c.o[g] * cap + k] = c.id[g] < 0 ? c.id[g] : c.id[g] / world;
-            } else {
-                a->slot[p] = -1;
-            }
+    }
+    __syncthreads();
+    if (tid < world) {                                   // lane o: exclusive prefix of owner o's cells, seeded with earlier chunks
+        int run = a->hist[(int64_t)tid * a->nchunks + chunk];
+        for (int cidx = 0; cidx < ROUNDS * RWAVES; ++cidx) {
+            const int v = s_cell[cidx][tid];
+            s_cell[cidx][tid] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    const int64_t cap = a->cap;
+    const int64_t p0 = a->off[f] + i0;
+#pragma unroll
+    for (int j = 0; j < ROUNDS; ++j) {
+        if (c.owner[j] < 0) continue;
+        const int64_t p = p0 + j * NRX_BLOCK + tid;
+        const int64_t k = s_cell[j * RWAVES + wid][c.owner[j]] + rank[j];
+        if (k < cap) {
+            a->slot[p] = (int32_t)(c.owner[j] * cap + k);
+            a->send_rows[c.owner[j] * cap + k] = c.local[j];
+        } else {
+            a->slot[p] = -1;
+        }
+    }
+}
+
+// world == 1: every id stays here, in source order -- one pass, nothing to rank
+__global__ __launch_bounds__(NRX_BLOCK) void route_single(const RouteArgs args_in_kernarg) {
+    const NRX_CONST RouteArgs* a = nrx_kernarg<RouteArgs>();
+    const int tid = threadIdx.x, chunk = blockIdx.x;
+    if (chunk == 0) {
+        if (tid < a->n_feats) a->counts2d[tid] = a->len[tid];
+        if (tid == 0) a->overflow[0] = a->off[a->n_feats];
+    }
+    if (chunk >= a->nchunks) return;
+    const int f = chunk_feature(a, chunk);
+    const int64_t i0 = (int64_t)(chunk - a->chunk0[f]) * CHUNK;
+    ChunkIds c;
+    load_chunk(a, f, i0, a->len[f], tid, c);
+    const int64_t p0 = a->off[f] + i0;
+#pragma unroll
+    for (int j = 0; j < ROUNDS; ++j) {
+        if (c.owner[j] < 0) continue;
+        const int64_t p = p0 + j * NRX_BLOCK + tid;
+        if (p < a->cap) {
+            a->slot[p] = (int32_t)p;
+            a->send_rows[p] = c.local[j];
+        } else {
+            a->slot[p] = -1;
         }
     }
 }
@@ -222,7 +254,7 @@ struct InboxArgs {
     int32_t world;
     int64_t cap;
     const int64_t* recv2d;
-    const int64_t* inbox;
+    const int32_t* inbox;
     float* buf;                            // out_rows (gather) / g_rows (scatter, read only)
     int32_t* status;
     int32_t dim;
@@ -230,7 +262,7 @@ struct InboxArgs {
 };
 static_assert(sizeof(InboxArgs) <= 3584, "kernarg budget");
 
-constexpr int INBOX_R = 4;   // slots per thread: 4 independent row reads in flight
+constexpr int INBOX_R = 8;   // slots per thread: 8 independent row reads in flight
 
 template <int QLOG2, bool SCATTER>
 __global__ __launch_bounds__(NRX_BLOCK) void inbox_kernel(const InboxArgs args_in_kernarg) {
@@ -265,7 +297,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void inbox_kernel(const InboxArgs args_i
     for (int r = 0; r < INBOX_R; ++r) {
         const int64_t j = j0 + r * TB;
         ok[r] = j < total;
-        row[r] = ok[r] ? nrx_gconst<int64_t>(a->inbox)[s * cap + j] : 0;
+        row[r] = ok[r] ? (int64_t)nrx_gconst<int32_t>(a->inbox)[s * cap + j] : 0;
     }
 #pragma unroll
     for (int r = 0; r < INBOX_R; ++r) {
@@ -345,7 +377,7 @@ int launch_inbox(InboxArgs& a, hipStream_t st, const char* who) {
 
 int fill_inbox_args(InboxArgs& a, float* const* tables, const int64_t* table_rows, int32_t n_tables,
                     const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap, const int64_t* recv2d,
-                    const int64_t* inbox_rows, int32_t dim, const char* who) {
+                    const int32_t* inbox_rows, int32_t dim, const char* who) {
     NRX_REQUIRE(tables && table_rows && n_tables >= 1 && n_tables <= NRX_MAX_FEATURES, "%s: n_tables must be in [1, %d]", who, NRX_MAX_FEATURES);
     NRX_REQUIRE(feat_table && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES, "%s: n_feats must be in [1, %d]", who, NRX_MAX_FEATURES);
     NRX_REQUIRE(world >= 1 && world <= 64 && cap >= 1 && dim >= 1, "%s: bad world/cap/dim", who);
@@ -373,56 +405,64 @@ int fill_inbox_args(InboxArgs& a, float* const* tables, const int64_t* table_row
 
 extern "C" int64_t nrx_route_workspace(int64_t n_total, int32_t world) {
     if (n_total < 0 || world < 1) return -1;
-    return ((n_total + CHUNK - 1) / CHUNK) * world + world;
+    // int32 histogram [world][chunks]; every feature may end in a partial chunk.  Size in int64 units.
+    const int64_t nchunks = (n_total + CHUNK - 1) / CHUNK + NRX_MAX_FEATURES;
+    return (nchunks * world + 1) / 2 + 1;
 }
 
 extern "C" int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_t n_feats, int32_t index_bits,
-                             int32_t world, int64_t cap, int64_t* send_rows, int64_t* slot, int64_t* counts2d,
+                             int32_t world, int64_t cap, int32_t* send_rows, int32_t* slot, int64_t* counts2d,
                              int64_t* overflow, int64_t* workspace, void* stream) {
     NRX_REQUIRE(ids && lens && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES, "nrx_route_ids: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(index_bits == 32 || index_bits == 64, "nrx_route_ids: index_bits must be 32 or 64");
-    NRX_REQUIRE(world >= 1 && world <= 64 && cap >= 1, "nrx_route_ids: bad world / cap");
+    NRX_REQUIRE(world >= 1 && world <= 64 && cap >= 1 && cap * world <= 0x7fffffffLL, "nrx_route_ids: bad world / cap");
     NRX_REQUIRE(send_rows && counts2d && overflow && workspace, "nrx_route_ids: null buffer");
     RouteArgs a;
-    int64_t off = 0;
+    int64_t off = 0, chunks = 0;
     for (int f = 0; f < n_feats; ++f) {
         NRX_REQUIRE(lens[f] >= 0 && (lens[f] == 0 || ids[f] != nullptr), "nrx_route_ids: feature %d: bad ids/len", f);
         a.ids[f] = ids[f];
+        a.len[f] = lens[f];
         a.off[f] = off;
+        a.chunk0[f] = (int32_t)chunks;
         off += lens[f];
+        chunks += (lens[f] + CHUNK - 1) / CHUNK;
     }
     a.off[n_feats] = off;
+    a.chunk0[n_feats] = (int32_t)chunks;
+    NRX_REQUIRE(off <= 0x7fffffffLL, "nrx_route_ids: too many ids for one exchange");
     NRX_REQUIRE(slot != nullptr || off == 0, "nrx_route_ids: null slot buffer");   // an exchange may carry zero ids
     a.n_feats = n_feats;
     a.world = world;
     a.idx64 = index_bits == 64;
-    a.pad = 0;
-    a.n_total = off;
+    a.nchunks = (int32_t)chunks;
     a.cap = cap;
-    const int64_t nchunks = (off + CHUNK - 1) / CHUNK;
-    a.hist = workspace;
-    a.nchunks = nchunks;
-    a.block_cnt = workspace + nchunks * world;
+    a.hist = reinterpret_cast<int32_t*>(workspace);
     a.counts2d = counts2d;
     a.send_rows = send_rows;
     a.slot = slot;
     a.overflow = overflow;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (world == 1) {       // nothing to bucket: one narrowing pass; block 0 also writes the counts (= the lengths)
+        const unsigned g = chunks > 0 ? (unsigned)chunks : 1u;
+        hipLaunchKernelGGL(route_single, dim3(g), dim3(NRX_BLOCK), 0, st, a);
+        NRX_LAUNCH_CHECK("nrx_route_ids(world 1)");
+        return NRX_OK;
+    }
     if (hipMemsetAsync(counts2d, 0, sizeof(int64_t) * (size_t)world * n_feats, st) != hipSuccess) {
         nrx_set_error("nrx_route_ids: memset failed");
         return NRX_ERR_LAUNCH;
     }
-    const unsigned grid = (unsigned)((nchunks + 3) / 4);
-    if (nchunks > 0) hipLaunchKernelGGL(route_hist, dim3(grid), dim3(NRX_BLOCK), 0, st, a);
-    hipLaunchKernelGGL(route_scan, dim3(1), dim3(NRX_BLOCK), 0, st, a.hist, nchunks, world, cap, a.block_cnt, overflow);
-    if (nchunks > 0) hipLaunchKernelGGL(route_place, dim3(grid), dim3(NRX_BLOCK), 0, st, a);
+    if (chunks > 0) hipLaunchKernelGGL(route_hist, dim3((unsigned)chunks), dim3(NRX_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(route_scan, dim3(1), dim3(NRX_BLOCK), 0, st, a.hist, (int)chunks, world, overflow);
+    if (chunks > 0) hipLaunchKernelGGL(route_place, dim3((unsigned)chunks), dim3(NRX_BLOCK), 0, st, a);
     NRX_LAUNCH_CHECK("nrx_route_ids");
     return NRX_OK;
 }
 
 extern "C" int nrx_gather_inbox(const float* const* tables, const int64_t* table_rows, int32_t n_tables,
                                 const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,
-                                const int64_t* recv2d, const int64_t* inbox_rows, int32_t dim,
+                                const int64_t* recv2d, const int32_t* inbox_rows, int32_t dim,
                                 float* out_rows, int32_t* status, void* stream) {
     InboxArgs a;
     int rc = fill_inbox_args(a, const_cast<float* const*>(tables), table_rows, n_tables, feat_table, n_feats, world, cap,
@@ -437,7 +477,7 @@ extern "C" int nrx_gather_inbox(const float* const* tables, const int64_t* table
 
 extern "C" int nrx_scatter_add_inbox(float* const* grad_tables, const int64_t* table_rows, int32_t n_tables,
                                      const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,
-                                     const int64_t* recv2d, const int64_t* inbox_rows, int32_t dim,
+                                     const int64_t* recv2d, const int32_t* inbox_rows, int32_t dim,
                                      const float* g_rows, int32_t skip_row0, void* stream) {
     InboxArgs a;
     int rc = fill_inbox_args(a, grad_tables, table_rows, n_tables, feat_table, n_feats, world, cap, recv2d, inbox_rows, dim,

@@ -968,7 +968,7 @@ def scatter_add_rows_segmented(grad_tables: Sequence[torch.Tensor], seg_start: t
 
 def route_ids(id_tensors: Sequence[torch.Tensor], world: int, cap: int):
     """Fixed-capacity routing of the ids of one exchange (no host synchronisation).
-    Returns (send_rows [world*cap] int64, slot [N] int64, counts2d [world, F] int64, overflow [1] int64)."""
+    Returns (send_rows [world*cap] int32, slot [N] int32, counts2d [world, F] int64, overflow [1] int64)."""
     lib = _lib.load()
     n = len(id_tensors)
     if not 1 <= n <= NRX_MAX_FEATURES:
@@ -984,8 +984,8 @@ def route_ids(id_tensors: Sequence[torch.Tensor], world: int, cap: int):
         xs.append(x if x.is_contiguous() else x.contiguous())
     dev = xs[0].device
     total = sum(x.numel() for x in xs)
-    send_rows = torch.empty(world * cap, dtype=torch.int64, device=dev)
-    slot = torch.empty(total, dtype=torch.int64, device=dev)
+    send_rows = torch.empty(world * cap, dtype=torch.int32, device=dev)
+    slot = torch.empty(total, dtype=torch.int32, device=dev)
     counts2d = torch.empty((world, n), dtype=torch.int64, device=dev)
     overflow = torch.empty(1, dtype=torch.int64, device=dev)
     ws = torch.empty(max(1, lib.nrx_route_workspace(total, world)), dtype=torch.int64, device=dev)
@@ -1014,6 +1014,8 @@ def gather_inbox(tables: Sequence[torch.Tensor], feat_table: Sequence[int], worl
     Returns [world*cap, dim] (slots past a block's count are left uninitialised)."""
     lib = _lib.load()
     dim, tp, tr, ft = _inbox_common(tables, feat_table)
+    if inbox_rows.dtype != torch.int32:
+        inbox_rows = inbox_rows.to(torch.int32)        # the wire format is int32 local rows
     out = torch.empty((world * cap, dim), dtype=torch.float32, device=tables[0].device)
     check(lib.nrx_gather_inbox(tp, tr, len(tables), ft, len(feat_table), world, cap, recv2d.data_ptr(),
                                inbox_rows.data_ptr(), dim, out.data_ptr(), _ptr(status), _stream_ptr(out)),
@@ -1025,6 +1027,8 @@ def scatter_add_inbox(grad_tables: Sequence[torch.Tensor], feat_table: Sequence[
                       recv2d: torch.Tensor, inbox_rows: torch.Tensor, g_rows: torch.Tensor, skip_row0: bool) -> None:
     lib = _lib.load()
     dim, tp, tr, ft = _inbox_common(grad_tables, feat_table)
+    if inbox_rows.dtype != torch.int32:
+        inbox_rows = inbox_rows.to(torch.int32)
     g_rows = _f32c(g_rows, "g_rows")
     check(lib.nrx_scatter_add_inbox(tp, tr, len(grad_tables), ft, len(feat_table), world, cap, recv2d.data_ptr(),
                                     inbox_rows.data_ptr(), dim, g_rows.data_ptr(), 1 if skip_row0 else 0,

@@ -266,8 +266,8 @@ class RowShardedEmbedding:
         send_rows, slot, counts2d, overflow = self.backend.route(ids, W, cap)            # steps 1-3
         recv2d = torch.empty_like(counts2d)
         self._a2a(recv2d.view(-1), counts2d.view(-1))                                   # equal splits
-        inbox = torch.empty(W * cap, dtype=torch.int64, device=dev)
-        self._a2a(inbox, send_rows)                                                     # step 4, equal splits
+        inbox = torch.empty(W * cap, dtype=send_rows.dtype, device=dev)
+        self._a2a(inbox, send_rows)                                                     # step 4, equal splits (int32 local rows)
         want_status = self.backend.index_checks_on() and self.overflow_policy == "check"
         rows_out, status = self.backend.gather_inbox([tables[t] for t in table_names], feat_table, W, cap,
                                                      recv2d, inbox, want_status)        # step 5
@@ -468,15 +468,17 @@ class PreparedShardedForward:
             g = dict(
                 n=n, cap=cap, D=D, bits=ids[0].element_size() * 8, ids=ids,
                 ptrs=(C.c_void_p * n)(*[x.data_ptr() for x in ids]), lens=(C.c_int64 * n)(*[x.numel() for x in ids]),
-                send=torch.empty(W * cap, dtype=torch.int64, device=dev), slot=torch.empty(total, dtype=torch.int64, device=dev),
+                send=torch.empty(W * cap, dtype=torch.int32, device=dev), slot=torch.empty(total, dtype=torch.int32, device=dev),
                 counts2d=torch.empty((W, n), dtype=torch.int64, device=dev), recv2d=torch.empty((W, n), dtype=torch.int64, device=dev),
                 overflow=torch.zeros(1, dtype=torch.int64, device=dev),
                 ws=torch.empty(max(1, self.lib.nrx_route_workspace(total, W)), dtype=torch.int64, device=dev),
-                inbox=torch.empty(W * cap, dtype=torch.int64, device=dev),
+                inbox=torch.empty(W * cap, dtype=torch.int32, device=dev),
                 rows_out=torch.empty((W * cap, D), dtype=torch.float32, device=dev),
                 ret=torch.empty((W * cap, D), dtype=torch.float32, device=dev),
                 tp=(C.c_void_p * len(loc))(*[t.data_ptr() for t in loc]), tr=(C.c_int64 * len(loc))(*[t.shape[0] for t in loc]),
                 nt=len(loc), ft=(C.c_int32 * n)(*[table_names.index(feats[i].table) for i in idxs]), dev=dev)
+            if W == 1:        # a one-rank group exchanges with itself: the "received" buffers ARE the sent ones (no copies)
+                g["inbox"], g["recv2d"], g["ret"] = g["send"], g["counts2d"], g["rows_out"]
             off = 0
             for i, x in zip(idxs, ids):
                 slot_of[i] = g["slot"][off: off + x.numel()].view(inputs[i].shape)
@@ -498,13 +500,15 @@ class PreparedShardedForward:
                                    g["ws"].data_ptr(), stream)
             if rc:
                 ops.check(rc, "nrx_route_ids")
-            eng._a2a(g["recv2d"].view(-1), g["counts2d"].view(-1))
-            eng._a2a(g["inbox"], g["send"])
+            if W > 1:
+                eng._a2a(g["recv2d"].view(-1), g["counts2d"].view(-1))
+                eng._a2a(g["inbox"], g["send"])
             rc = lib.nrx_gather_inbox(g["tp"], g["tr"], g["nt"], g["ft"], g["n"], W, g["cap"], g["recv2d"].data_ptr(),
                                       g["inbox"].data_ptr(), g["D"], g["rows_out"].data_ptr(), None, stream)
             if rc:
                 ops.check(rc, "nrx_gather_inbox")
-            eng._a2a(g["ret"].view(-1), g["rows_out"].view(-1))
+            if W > 1:
+                eng._a2a(g["ret"].view(-1), g["rows_out"].view(-1))
         return self.final.run()
 
     def overflowed(self) -> bool:

@@ -469,12 +469,14 @@ def unique_inverse(ids: np.ndarray):
 
 def route_ids(id_arrays, world: int, cap: int):
     """Fixed-capacity routing (definition of nrx_route_ids).  id_arrays: list of integer arrays, one per
-    feature, flattened feature-major.  Returns (send_rows [world*cap] with unused slots = -1,
+    feature, flattened feature-major.  On the wire a row is an int32 local row.  Returns (send_rows [world*cap] with unused slots = -1,
     slot [N] (-1 where a block overflowed), counts2d [world, F], max block count)."""
     flat = [np.asarray(a, np.int64).reshape(-1) for a in id_arrays]
     ids = np.concatenate(flat) if flat else np.zeros(0, np.int64)
     fid = np.concatenate([np.full(a.size, f, np.int64) for f, a in enumerate(flat)]) if flat else ids
-    owner = np.where(ids < 0, 0, ids % world)
+    I32MAX = (1 << 31) - 1
+    bad = (ids < 0) | (ids > I32MAX)                 # cannot be rows of any table: go to rank 0 as -1 / INT32_MAX
+    owner = np.where(bad, 0, ids % world)
     F = len(flat)
     counts2d = np.bincount(owner * F + fid, minlength=world * F).reshape(world, F).astype(np.int64)
     send = np.full(world * cap, -1, np.int64)
@@ -484,7 +486,7 @@ def route_ids(id_arrays, world: int, cap: int):
         k = np.arange(pos.size)
         ok = k < cap
         slot[pos[ok]] = o * cap + k[ok]
-        loc = np.where(ids[pos] < 0, ids[pos], ids[pos] // world)
+        loc = np.where(ids[pos] < 0, -1, np.where(ids[pos] > I32MAX, I32MAX, ids[pos] // world))
         send[o * cap + k[ok]] = loc[ok]
     return send, slot, counts2d, int(counts2d.sum(axis=1).max()) if world else 0
 
