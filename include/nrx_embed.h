@@ -294,6 +294,35 @@ NRX_API int nrx_scatter_add_inbox(float* const* grad_tables, const int64_t* tabl
                           const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,
                           const int64_t* recv2d, const int32_t* inbox_rows, int32_t dim,
                           const float* g_rows, int32_t skip_row0, void* stream);
+/* ---- owner-side partial pooling of row-sharded bag features -------------------
+ * A bag feature whose table is row-sharded does not fetch its L rows per sample across the fabric: every owner pools
+ * the rows it holds and returns ONE partial vector per (sample, owner); the source adds the `world` partials.
+ *   nrx_bag_norm_weights   per-lookup weight with the pooling's normalisation folded in:
+ *                          masked mean  w / (sum_l w + 1e-8)   (array_feature_pooling, base_model.py:278-282)
+ *                          mean         1 / L                  (:275-276);     sum: w (or 1)
+ *   nrx_route_bags         like nrx_route_ids for n_feats bag features ([batch, bag_len] ids each): lookups with weight
+ *                          != 0 are placed, in source order, in their owner's send block as a triple
+ *                            send_rows[d] local row, send_tag[d] = f * batch + sample, send_w[d] weight
+ *                          (no slot map: nothing comes back per lookup); counts2d / overflow as in nrx_route_ids
+ *   nrx_pool_inbox_fwd     owner: partial[s][tag][:] = sum over source s's entries with that tag of w * table row,
+ *                          in source order (deterministic, no atomics); every element of partial
+ *                          [world, n_feats*batch, dim] is written; workspace: nrx_pool_inbox_workspace(...) device bytes
+ *   nrx_pool_inbox_bwd     owner: grad_table[row] += w * g_partial[s][tag][:] per entry (fp32 atomics; skip_row0 as in
+ *                          nrx_scatter_add_inbox)
+ * The source finishes with an NRX_BAG_SUM of bag_len = world over the returned slabs (rows o*n_feats*batch + tag).  */
+NRX_API int nrx_bag_norm_weights(const float* mask, int64_t batch, int32_t bag_len, int32_t kind, float* out_w, void* stream);
+NRX_API int nrx_route_bags(const void* const* ids, const float* const* weights, const int32_t* bag_lens, int32_t n_feats,
+                   int32_t index_bits, int64_t batch, int32_t world, int64_t cap, int32_t* send_rows, int32_t* send_tag,
+                   float* send_w, int64_t* counts2d, int64_t* overflow, int64_t* workspace, void* stream);
+NRX_API int64_t nrx_pool_inbox_workspace(int32_t n_feats, int64_t batch, int32_t world);
+NRX_API int nrx_pool_inbox_fwd(const float* const* tables, const int64_t* table_rows, int32_t n_tables, const int32_t* feat_table,
+                       int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
+                       const int32_t* inbox_rows, const int32_t* inbox_tag, const float* inbox_w, int32_t dim,
+                       float* partial, void* workspace, int32_t* status, void* stream);
+NRX_API int nrx_pool_inbox_bwd(float* const* grad_tables, const int64_t* table_rows, int32_t n_tables, const int32_t* feat_table,
+                       int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
+                       const int32_t* inbox_rows, const int32_t* inbox_tag, const float* inbox_w, int32_t dim,
+                       const float* g_partial, int32_t skip_row0, void* stream);
 /* Expands a CSR batch of an array feature (values[offsets[b] .. offsets[b+1]), offsets relative to the
  * batch, device int64[batch+1]) into the reference's padded form: ids [batch, bag_len] (0-padded,
  * same integer width as `values`) and mask float32 [batch, bag_len] (1 = real, 0 = padding) --

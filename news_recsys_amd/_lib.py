@@ -83,6 +83,13 @@ SIGNATURES = {
     "nrx_scatter_add_rows_segmented": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, _p, _p, _i32, _i64, _i32, _p, _p, _i32, _p]),
     "nrx_route_workspace": (_i64, [_i64, _i32]),
     "nrx_route_ids": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p]),
+    "nrx_bag_norm_weights": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
+    "nrx_route_bags": (C.c_int, [C.POINTER(_p), C.POINTER(_p), C.POINTER(_i32), _i32, _i32, _i64, _i32, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "nrx_pool_inbox_workspace": (_i64, [_i32, _i64, _i32]),
+    "nrx_pool_inbox_fwd": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, C.POINTER(_i32), _i32, _i64, _i32, _i64, _p, _p, _p, _p, _i32,
+                                     _p, _p, _p, _p]),
+    "nrx_pool_inbox_bwd": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, C.POINTER(_i32), _i32, _i64, _i32, _i64, _p, _p, _p, _p, _i32,
+                                     _p, _i32, _p]),
     "nrx_gather_inbox": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, C.POINTER(_i32), _i32, _i32, _i64, _p, _p, _i32, _p, _p, _p]),
     "nrx_scatter_add_inbox": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, C.POINTER(_i32), _i32, _i32, _i64, _p, _p, _i32, _p, _i32, _p]),
     "nrx_csr_to_padded": (C.c_int, [_p, _i32, _p, _p, _i64, _i32, _p, _p, _p]),

@@ -40,8 +40,16 @@ struct RouteArgs {
     int32_t* send_rows;
     int32_t* slot;
     int64_t* overflow;
+    // pooled-bag channel (nrx_route_bags): lookups carry the sample they pool into and their normalised weight;
+    // zero-weight lookups are not sent at all.  tag = tag0[f] + i / bag_len[f]  (i = position inside feature f)
+    const float* weight[NRX_MAX_FEATURES];
+    int32_t bag_len[NRX_MAX_FEATURES];
+    int32_t tag0[NRX_MAX_FEATURES];
+    int32_t* send_tag;
+    float* send_w;
+    int32_t bags;
 };
-static_assert(sizeof(RouteArgs) <= 3584, "kernarg budget");
+static_assert(sizeof(RouteArgs) <= 3840, "kernarg budget");
 
 __device__ __forceinline__ int chunk_feature(const NRX_CONST RouteArgs* a, int chunk) {
     int lo = 0, hi = a->n_feats;               // last f with chunk0[f] <= chunk (features without ids own no chunk)
@@ -66,6 +74,7 @@ __device__ __forceinline__ void route_split(int64_t id, int world, int& owner, i
 struct ChunkIds {
     int owner[ROUNDS];
     int32_t local[ROUNDS];
+    float w[ROUNDS];
 };
 
 __device__ __forceinline__ void load_chunk(const NRX_CONST RouteArgs* a, int f, int64_t i0, int64_t len, int tid, ChunkIds& c) {
@@ -77,10 +86,18 @@ __device__ __forceinline__ void load_chunk(const NRX_CONST RouteArgs* a, int f, 
         id[j] = 0;
         if (i < len) id[j] = a->idx64 ? nrx_gconst<int64_t>(p)[i] : (int64_t)nrx_gconst<int32_t>(p)[i];
     }
+    const bool bags = a->bags != 0;
+    const float* wp = bags ? a->weight[f] : nullptr;
+#pragma unroll
+    for (int j = 0; j < ROUNDS; ++j) {
+        const int64_t i = i0 + j * NRX_BLOCK + tid;
+        c.w[j] = 1.0f;
+        if (wp != nullptr && i < len) c.w[j] = nrx_gconst<float>(wp)[i];
+    }
 #pragma unroll
     for (int j = 0; j < ROUNDS; ++j) {
         route_split(id[j], a->world, c.owner[j], c.local[j]);
-        if (i0 + j * NRX_BLOCK + tid >= len) c.owner[j] = -1;
+        if (i0 + j * NRX_BLOCK + tid >= len || (bags && c.w[j] == 0.f)) c.owner[j] = -1;
     }
 }
 
@@ -94,9 +111,15 @@ __global__ __launch_bounds__(NRX_BLOCK) void route_hist(const RouteArgs args_in_
     __syncthreads();
     ChunkIds c;
     load_chunk(a, f, i0, a->len[f], tid, c);
+    const int lane = tid & 63;
+    int cnt = 0;                                                      // lane o: ids of owner o seen by this wavefront
 #pragma unroll
     for (int j = 0; j < ROUNDS; ++j)
-        if (c.owner[j] >= 0) atomicAdd(&s_cnt[c.owner[j]], 1);       // integer counts: the final value is order-independent
+        for (int t = 0; t < a->world; ++t) {
+            const unsigned long long m = __ballot(c.owner[j] == t);
+            if (lane == t) cnt += __popcll(m);
+        }
+    if (lane < a->world && cnt) atomicAdd(&s_cnt[lane], cnt);         // integer counts: the final value is order-independent
     __syncthreads();
     if (tid < a->world) {
         const int n = s_cnt[tid];
@@ -183,7 +206,14 @@ __global__ __launch_bounds__(NRX_BLOCK) void route_place(const RouteArgs args_in
         if (c.owner[j] < 0) continue;
         const int64_t p = p0 + j * NRX_BLOCK + tid;
         const int64_t k = s_cell[j * RWAVES + wid][c.owner[j]] + rank[j];
-        if (k < cap) {
+        if (a->bags) {
+            if (k < cap) {
+                const int64_t d = c.owner[j] * cap + k;
+                a->send_rows[d] = c.local[j];
+                a->send_tag[d] = a->tag0[f] + (int32_t)((i0 + j * NRX_BLOCK + tid) / a->bag_len[f]);
+                a->send_w[d] = c.w[j];
+            }
+        } else if (k < cap) {
             a->slot[p] = (int32_t)(c.owner[j] * cap + k);
             a->send_rows[c.owner[j] * cap + k] = c.local[j];
         } else {
@@ -351,6 +381,160 @@ __global__ __launch_bounds__(NRX_BLOCK) void inbox_kernel(const InboxArgs args_i
     }
 }
 
+// ------------------------------------------------------------------------------- owner-side partial pooling
+// Pooled-bag channel: block s of the inbox holds {local row, tag, weight} triples in SOURCE order, so
+// all lookups of one (feature, sample) -- one tag -- that this rank owns are CONTIGUOUS: a run.  Pass 1 (one thread per
+// entry) records where every run starts and ends; pass 2 puts one Q-lane group on every (source, tag), which walks its run
+// with 8 rows in flight -- the fused bag kernel's shape, every lane busy whatever the run lengths -- and writes
+//     partial[s][tag][:] = sum_k w_k * table[row_k][:]           (summed in source order: deterministic, no atomics)
+// (zeros for a (feature, sample) without a lookup on this rank).  The source then adds the `world` partials of a sample in rank order (a BAG_SUM over the returned
+// slabs) -- the normalisation is already inside w (nrx_bag_norm_weights), so
+//     sum_o sum_{k in o} (w_k / den) * row_k   ==   array_feature_pooling's  (sum_k w_k row_k) / den      (base_model.py:278-282)
+// up to fp32 summation order (stated tolerance rtol 1e-6).
+struct PoolArgs {
+    float* table[NRX_MAX_FEATURES];        // weight tables (fwd) or grad tables (bwd)
+    int64_t rows[NRX_MAX_FEATURES];
+    int32_t feat_table[NRX_MAX_FEATURES];
+    int32_t n_feats;
+    int32_t world;
+    int64_t cap;
+    int64_t batch;                         // tags of feature f are f*batch .. (f+1)*batch - 1
+    const int64_t* recv2d;                 // [world][n_feats] valid entries per (source, feature)
+    const int32_t* inbox_rows;
+    const int32_t* inbox_tag;
+    const float* inbox_w;
+    float* partial;                        // fwd: out [world][n_feats*batch][dim]; bwd: g_partial (read only)
+    int32_t* status;
+    int32_t dim;
+    int32_t skip_row0;
+};
+static_assert(sizeof(PoolArgs) <= 3584, "kernarg budget");
+
+__device__ __forceinline__ int64_t pool_block_total(const NRX_CONST PoolArgs* a, int s) {
+    int64_t t = 0;
+    for (int f = 0; f < a->n_feats; ++f) t += nrx_gconst<int64_t>(a->recv2d)[s * a->n_feats + f];
+    return t < a->cap ? t : a->cap;
+}
+
+// pass 1: where does the run of every (source, tag) start and end?  One thread per inbox entry; run[.][0] = first entry,
+// run[.][1] = one past the last (the array is zeroed first: tags without a lookup on this rank keep the empty run 0..0).
+__global__ __launch_bounds__(NRX_BLOCK) void pool_mark_kernel(const PoolArgs args_in_kernarg, int32_t* __restrict__ run) {
+    const NRX_CONST PoolArgs* a = nrx_kernarg<PoolArgs>();
+    const int s = blockIdx.y;
+    const int64_t total = pool_block_total(a, s);
+    const int64_t j = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x;
+    if (j >= total) return;
+    const NRX_GLOBAL int32_t* tags = nrx_gconst<int32_t>(a->inbox_tag) + (int64_t)s * a->cap;
+    const int32_t tag = tags[j];
+    const int64_t ntag = (int64_t)a->n_feats * a->batch;
+    if ((uint32_t)tag >= (uint64_t)ntag) return;
+    int32_t* r = run + ((int64_t)s * ntag + tag) * 2;
+    if (j == 0 || tags[j - 1] != tag) r[0] = (int32_t)j;
+    if (j == total - 1 || tags[j + 1] != tag) r[1] = (int32_t)(j + 1);
+}
+
+// pass 2: one Q-lane group per (source, tag) walks its run with AHEAD rows in flight -- the shape of the fused bag kernel
+template <int QLOG2>
+__global__ __launch_bounds__(NRX_BLOCK) void pool_inbox_fwd_kernel(const PoolArgs args_in_kernarg, const int32_t* __restrict__ run) {
+    const NRX_CONST PoolArgs* a = nrx_kernarg<PoolArgs>();
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    constexpr int AHEAD = 8;
+    const int s = blockIdx.y;
+    const int q = threadIdx.x & (Q - 1);
+    const int64_t ntag = (int64_t)a->n_feats * a->batch;
+    const int64_t tag = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
+    if (tag >= ntag) return;
+    const int32_t lo = run[((int64_t)s * ntag + tag) * 2], hi = run[((int64_t)s * ntag + tag) * 2 + 1];
+    const int64_t base = (int64_t)s * a->cap;
+    const int D = a->dim;
+    const int f = (int)(tag / a->batch);
+    const int tix = a->feat_table[f];
+    const float* table = a->table[tix];
+    const int64_t nrows = a->rows[tix];
+    const bool vec = (D & 3) == 0;
+    for (int k0 = q * 4; k0 < D; k0 += 4 * Q) {              // one pass when D <= 4Q (the launch picks Q for that)
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e0 = lo; e0 < hi; e0 += AHEAD) {
+            int32_t row[AHEAD];
+            float w[AHEAD];
+#pragma unroll
+            for (int u = 0; u < AHEAD; ++u) {
+                const int e = e0 + u < hi ? e0 + u : lo;
+                row[u] = nrx_gconst<int32_t>(a->inbox_rows)[base + e];
+                w[u] = e0 + u < hi ? nrx_gconst<float>(a->inbox_w)[base + e] : 0.f;
+            }
+            float4 v[AHEAD];
+#pragma unroll
+            for (int u = 0; u < AHEAD; ++u) {
+                if ((uint32_t)row[u] >= (uint64_t)nrows) {
+                    if (q == 0 && k0 == 0 && w[u] != 0.f) nrx_report_oob(a->status, tix, base + e0 + u, row[u]);
+                    row[u] = 0;
+                    w[u] = 0.f;
+                }
+                const float* p = table + (int64_t)row[u] * D + k0;
+                if (vec) v[u] = nrx_ldg4(p, 0);
+                else { v[u] = make_float4(p[0], k0 + 1 < D ? p[1] : 0.f, k0 + 2 < D ? p[2] : 0.f, k0 + 3 < D ? p[3] : 0.f); }
+            }
+#pragma unroll
+            for (int u = 0; u < AHEAD; ++u) {
+#pragma clang fp contract(off)
+                acc.x += v[u].x * w[u]; acc.y += v[u].y * w[u]; acc.z += v[u].z * w[u]; acc.w += v[u].w * w[u];
+            }
+        }
+        float* dst = a->partial + ((int64_t)s * ntag + tag) * D + k0;
+        dst[0] = acc.x;
+        if (k0 + 1 < D) dst[1] = acc.y;
+        if (k0 + 2 < D) dst[2] = acc.z;
+        if (k0 + 3 < D) dst[3] = acc.w;
+    }
+}
+
+// backward: grad_table[row] += w * g_partial[s][tag][:] for every entry (fp32 atomics; the global padding row is skipped)
+template <int QLOG2>
+__global__ __launch_bounds__(NRX_BLOCK) void pool_inbox_bwd_kernel(const PoolArgs args_in_kernarg) {
+    const NRX_CONST PoolArgs* a = nrx_kernarg<PoolArgs>();
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    const int s = blockIdx.y;
+    const int64_t total = pool_block_total(a, s);
+    const int q = threadIdx.x & (Q - 1);
+    const int64_t j = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
+    if (j >= total) return;
+    const int64_t base = (int64_t)s * a->cap;
+    const int32_t tag = nrx_gconst<int32_t>(a->inbox_tag)[base + j];
+    const int32_t row = nrx_gconst<int32_t>(a->inbox_rows)[base + j];
+    const float w = nrx_gconst<float>(a->inbox_w)[base + j];
+    const int D = a->dim;
+    const int f = (int)(tag / a->batch);
+    const int tix = a->feat_table[f < a->n_feats ? f : 0];
+    if ((uint32_t)row >= (uint64_t)a->rows[tix]) return;      // reported by the forward
+    if (a->skip_row0 && row == 0) return;
+    const float* g = a->partial + ((int64_t)s * a->n_feats * a->batch + tag) * D;
+    float* dst = a->table[tix] + (int64_t)row * D;
+    for (int k = q; k < D; k += Q) unsafeAtomicAdd(dst + k, nrx_gconst<float>(g)[k] * w);
+}
+
+// normalised bag weights: masked mean w/(sum w + 1e-8) (base_model.py:278-282), plain mean 1/L (:275-276), sum w | 1
+__global__ __launch_bounds__(NRX_BLOCK) void bag_norm_weights_kernel(const float* __restrict__ mask, int64_t batch, int L, int kind,
+                                                                     float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6);      // one wavefront per sample
+    if (b >= batch) return;
+    float den = 1.0f;
+    if (kind == NRX_BAG_MASKED_MEAN) {
+        float part = 0.f;
+        for (int l = lane; l < L; l += 64) part += mask[b * L + l];
+        den = nrx_wave_sum(part) + 1e-8f;
+    } else if (kind == NRX_BAG_MEAN) {
+        den = (float)L;
+    }
+    for (int l = lane; l < L; l += 64) {
+        const float m = (kind == NRX_BAG_MEAN || mask == nullptr) ? 1.0f : mask[b * L + l];
+        out[b * L + l] = m / den;
+    }
+}
+
 int log2_ceil(int x) {
     int l = 0;
     while ((1 << l) < x) ++l;
@@ -442,6 +626,9 @@ extern "C" int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_
     a.send_rows = send_rows;
     a.slot = slot;
     a.overflow = overflow;
+    a.send_tag = nullptr;
+    a.send_w = nullptr;
+    a.bags = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (world == 1) {       // nothing to bucket: one narrowing pass; block 0 also writes the counts (= the lengths)
         const unsigned g = chunks > 0 ? (unsigned)chunks : 1u;
@@ -488,6 +675,170 @@ extern "C" int nrx_scatter_add_inbox(float* const* grad_tables, const int64_t* t
     a.status = nullptr;
     a.skip_row0 = skip_row0;
     return launch_inbox<true>(a, reinterpret_cast<hipStream_t>(stream), "nrx_scatter_add_inbox");
+}
+
+extern "C" int nrx_bag_norm_weights(const float* mask, int64_t batch, int32_t bag_len, int32_t kind, float* out_w, void* stream) {
+    NRX_REQUIRE(out_w && batch >= 0 && bag_len >= 1, "nrx_bag_norm_weights: bad argument");
+    NRX_REQUIRE(kind == NRX_BAG_MASKED_MEAN || kind == NRX_BAG_MEAN || kind == NRX_BAG_SUM, "nrx_bag_norm_weights: bad kind");
+    NRX_REQUIRE(kind != NRX_BAG_MASKED_MEAN || mask != nullptr, "nrx_bag_norm_weights: masked mean needs a mask");
+    if (batch == 0) return NRX_OK;
+    const unsigned grid = (unsigned)((batch + NRX_BLOCK / 64 - 1) / (NRX_BLOCK / 64));
+    hipLaunchKernelGGL(bag_norm_weights_kernel, dim3(grid), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), mask, batch,
+                       bag_len, kind, out_w);
+    NRX_LAUNCH_CHECK("nrx_bag_norm_weights");
+    return NRX_OK;
+}
+
+extern "C" int nrx_route_bags(const void* const* ids, const float* const* weights, const int32_t* bag_lens, int32_t n_feats,
+                              int32_t index_bits, int64_t batch, int32_t world, int64_t cap, int32_t* send_rows,
+                              int32_t* send_tag, float* send_w, int64_t* counts2d, int64_t* overflow, int64_t* workspace,
+                              void* stream) {
+    NRX_REQUIRE(ids && bag_lens && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES, "nrx_route_bags: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
+    NRX_REQUIRE(index_bits == 32 || index_bits == 64, "nrx_route_bags: index_bits must be 32 or 64");
+    NRX_REQUIRE(world >= 1 && world <= 64 && cap >= 1 && cap * world <= 0x7fffffffLL && batch >= 0, "nrx_route_bags: bad world / cap / batch");
+    NRX_REQUIRE((int64_t)n_feats * batch <= 0x7fffffffLL, "nrx_route_bags: n_feats * batch must fit 31 bits");
+    NRX_REQUIRE(send_rows && send_tag && send_w && counts2d && overflow && workspace, "nrx_route_bags: null buffer");
+    RouteArgs a;
+    int64_t off = 0, chunks = 0;
+    for (int f = 0; f < n_feats; ++f) {
+        NRX_REQUIRE(bag_lens[f] >= 1 && (batch == 0 || ids[f] != nullptr), "nrx_route_bags: feature %d: bad ids / bag_len", f);
+        const int64_t len = batch * bag_lens[f];
+        a.ids[f] = ids[f];
+        a.len[f] = len;
+        a.off[f] = off;
+        a.chunk0[f] = (int32_t)chunks;
+        a.weight[f] = weights ? weights[f] : nullptr;
+        a.bag_len[f] = bag_lens[f];
+        a.tag0[f] = (int32_t)(f * batch);
+        off += len;
+        chunks += (len + CHUNK - 1) / CHUNK;
+    }
+    a.off[n_feats] = off;
+    a.chunk0[n_feats] = (int32_t)chunks;
+    NRX_REQUIRE(off <= 0x7fffffffLL, "nrx_route_bags: too many ids for one exchange");
+    a.n_feats = n_feats;
+    a.world = world;
+    a.idx64 = index_bits == 64;
+    a.nchunks = (int32_t)chunks;
+    a.cap = cap;
+    a.hist = reinterpret_cast<int32_t*>(workspace);
+    a.counts2d = counts2d;
+    a.send_rows = send_rows;
+    a.slot = nullptr;
+    a.overflow = overflow;
+    a.send_tag = send_tag;
+    a.send_w = send_w;
+    a.bags = 1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(counts2d, 0, sizeof(int64_t) * (size_t)world * n_feats, st) != hipSuccess) {
+        nrx_set_error("nrx_route_bags: memset failed");
+        return NRX_ERR_LAUNCH;
+    }
+    if (chunks > 0) hipLaunchKernelGGL(route_hist, dim3((unsigned)chunks), dim3(NRX_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(route_scan, dim3(1), dim3(NRX_BLOCK), 0, st, a.hist, (int)chunks, world, overflow);
+    if (chunks > 0) hipLaunchKernelGGL(route_place, dim3((unsigned)chunks), dim3(NRX_BLOCK), 0, st, a);
+    NRX_LAUNCH_CHECK("nrx_route_bags");
+    return NRX_OK;
+}
+
+namespace {
+int fill_pool_args(PoolArgs& a, float* const* tables, const int64_t* table_rows, int32_t n_tables, const int32_t* feat_table,
+                   int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d, const int32_t* inbox_rows,
+                   const int32_t* inbox_tag, const float* inbox_w, int32_t dim, const char* who) {
+    NRX_REQUIRE(tables && table_rows && n_tables >= 1 && n_tables <= NRX_MAX_FEATURES, "%s: n_tables must be in [1, %d]", who, NRX_MAX_FEATURES);
+    NRX_REQUIRE(feat_table && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES, "%s: n_feats must be in [1, %d]", who, NRX_MAX_FEATURES);
+    NRX_REQUIRE(world >= 1 && world <= 64 && cap >= 1 && dim >= 1 && dim <= 1024 && batch >= 1, "%s: bad world/cap/dim/batch", who);
+    NRX_REQUIRE(recv2d && inbox_rows && inbox_tag && inbox_w, "%s: null buffer", who);
+    for (int i = 0; i < n_tables; ++i) {
+        NRX_REQUIRE(tables[i] != nullptr, "%s: table %d is null", who, i);
+        NRX_REQUIRE((dim & 3) != 0 || nrx_aligned16(tables[i]), "%s: table %d must be 16-byte aligned", who, i);
+        a.table[i] = tables[i];
+        a.rows[i] = table_rows[i];
+    }
+    for (int f = 0; f < n_feats; ++f) {
+        NRX_REQUIRE(feat_table[f] >= 0 && feat_table[f] < n_tables, "%s: feat_table[%d] out of range", who, f);
+        a.feat_table[f] = feat_table[f];
+    }
+    a.n_feats = n_feats;
+    a.world = world;
+    a.cap = cap;
+    a.batch = batch;
+    a.recv2d = recv2d;
+    a.inbox_rows = inbox_rows;
+    a.inbox_tag = inbox_tag;
+    a.inbox_w = inbox_w;
+    a.dim = dim;
+    return NRX_OK;
+}
+
+int pool_ql(int dim) {
+    int ql = log2_ceil((dim + 3) / 4);
+    return ql > 6 ? 6 : ql;
+}
+}  // namespace
+
+extern "C" int64_t nrx_pool_inbox_workspace(int32_t n_feats, int64_t batch, int32_t world) {
+    if (n_feats < 1 || batch < 0 || world < 1) return -1;
+    return (int64_t)world * n_feats * batch * 2 * (int64_t)sizeof(int32_t);      // bytes: run start / end per (source, tag)
+}
+
+extern "C" int nrx_pool_inbox_fwd(const float* const* tables, const int64_t* table_rows, int32_t n_tables, const int32_t* feat_table,
+                                  int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
+                                  const int32_t* inbox_rows, const int32_t* inbox_tag, const float* inbox_w, int32_t dim,
+                                  float* partial, void* workspace, int32_t* status, void* stream) {
+    PoolArgs a;
+    int rc = fill_pool_args(a, const_cast<float* const*>(tables), table_rows, n_tables, feat_table, n_feats, batch, world, cap, recv2d,
+                            inbox_rows, inbox_tag, inbox_w, dim, "nrx_pool_inbox_fwd");
+    if (rc != NRX_OK) return rc;
+    NRX_REQUIRE(partial != nullptr && workspace != nullptr, "nrx_pool_inbox_fwd: null partial / workspace");
+    a.partial = partial;
+    a.status = status;
+    a.skip_row0 = 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int32_t* run = reinterpret_cast<int32_t*>(workspace);
+    const int64_t ntag = (int64_t)n_feats * batch;
+    if (hipMemsetAsync(run, 0, (size_t)world * ntag * 2 * sizeof(int32_t), st) != hipSuccess) {
+        nrx_set_error("nrx_pool_inbox_fwd: memset failed");
+        return NRX_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(pool_mark_kernel, dim3((unsigned)((cap + NRX_BLOCK - 1) / NRX_BLOCK), (unsigned)world), dim3(NRX_BLOCK), 0, st, a, run);
+    const int ql = pool_ql(dim);
+    const int tb = NRX_BLOCK >> ql;
+    const dim3 grid((unsigned)((ntag + tb - 1) / tb), (unsigned)world);
+    switch (ql) {
+#define NRX_CASE(QL_) case QL_: hipLaunchKernelGGL((pool_inbox_fwd_kernel<QL_>), grid, dim3(NRX_BLOCK), 0, st, a, (const int32_t*)run); break;
+        NRX_CASE(0) NRX_CASE(1) NRX_CASE(2) NRX_CASE(3) NRX_CASE(4) NRX_CASE(5)
+        default: hipLaunchKernelGGL((pool_inbox_fwd_kernel<6>), grid, dim3(NRX_BLOCK), 0, st, a, (const int32_t*)run); break;
+#undef NRX_CASE
+    }
+    NRX_LAUNCH_CHECK("nrx_pool_inbox_fwd");
+    return NRX_OK;
+}
+
+extern "C" int nrx_pool_inbox_bwd(float* const* grad_tables, const int64_t* table_rows, int32_t n_tables, const int32_t* feat_table,
+                                  int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
+                                  const int32_t* inbox_rows, const int32_t* inbox_tag, const float* inbox_w, int32_t dim,
+                                  const float* g_partial, int32_t skip_row0, void* stream) {
+    PoolArgs a;
+    int rc = fill_pool_args(a, grad_tables, table_rows, n_tables, feat_table, n_feats, batch, world, cap, recv2d, inbox_rows, inbox_tag,
+                            inbox_w, dim, "nrx_pool_inbox_bwd");
+    if (rc != NRX_OK) return rc;
+    NRX_REQUIRE(g_partial != nullptr, "nrx_pool_inbox_bwd: null g_partial");
+    a.partial = const_cast<float*>(g_partial);
+    a.status = nullptr;
+    a.skip_row0 = skip_row0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int ql = pool_ql(dim);
+    const int tb = NRX_BLOCK >> ql;
+    const dim3 grid((unsigned)((cap + tb - 1) / tb), (unsigned)world);
+    switch (ql) {
+#define NRX_CASE(QL_) case QL_: hipLaunchKernelGGL((pool_inbox_bwd_kernel<QL_>), grid, dim3(NRX_BLOCK), 0, st, a); break;
+        NRX_CASE(0) NRX_CASE(1) NRX_CASE(2) NRX_CASE(3) NRX_CASE(4) NRX_CASE(5)
+        default: hipLaunchKernelGGL((pool_inbox_bwd_kernel<6>), grid, dim3(NRX_BLOCK), 0, st, a); break;
+#undef NRX_CASE
+    }
+    NRX_LAUNCH_CHECK("nrx_pool_inbox_bwd");
+    return NRX_OK;
 }
 
 extern "C" int nrx_make_table_keys(const void* const* ids, const int64_t* lens, const int32_t* table_of,

@@ -1035,6 +1035,71 @@ def scatter_add_inbox(grad_tables: Sequence[torch.Tensor], feat_table: Sequence[
                                     _stream_ptr(g_rows)), "nrx_scatter_add_inbox")
 
 
+def bag_norm_weights(mask: Optional[torch.Tensor], batch: int, bag_len: int, kind: int, device=None) -> torch.Tensor:
+    """Per-lookup pooling weights with the normalisation folded in (see nrx_bag_norm_weights): [batch, bag_len] float32."""
+    lib = _lib.load()
+    if mask is not None:
+        mask = _f32c(mask, "mask")
+        device = mask.device
+    out = torch.empty((batch, bag_len), dtype=torch.float32, device=device)
+    check(lib.nrx_bag_norm_weights(_ptr(mask), batch, bag_len, kind, out.data_ptr(), torch.cuda.current_stream(out.device).cuda_stream),
+          "nrx_bag_norm_weights")
+    return out
+
+
+def route_bags(id_tensors: Sequence[torch.Tensor], weights: Sequence[Optional[torch.Tensor]], world: int, cap: int):
+    """Pooled-bag routing (nrx_route_bags).  id_tensors: [B, L_f] each, one dtype; weights: normalised [B, L_f] or None.
+    Returns (send_rows int32 [world*cap], send_tag int32, send_w float32, counts2d int64 [world, F], overflow int64 [1])."""
+    lib = _lib.load()
+    n = len(id_tensors)
+    dt = id_tensors[0].dtype
+    if dt not in (torch.int64, torch.int32) or any(x.dtype != dt for x in id_tensors):
+        raise TypeError("route_bags: ids must share one integer dtype (int64 or int32)")
+    xs = [_dev(x, "ids") if x.is_contiguous() else x.contiguous() for x in id_tensors]
+    B = xs[0].shape[0]
+    ws = [None if w is None else _f32c(w, "weights") for w in weights]
+    dev = xs[0].device
+    total = sum(x.numel() for x in xs)
+    send_rows = torch.empty(world * cap, dtype=torch.int32, device=dev)
+    send_tag = torch.empty(world * cap, dtype=torch.int32, device=dev)
+    send_w = torch.empty(world * cap, dtype=torch.float32, device=dev)
+    counts2d = torch.empty((world, n), dtype=torch.int64, device=dev)
+    overflow = torch.empty(1, dtype=torch.int64, device=dev)
+    wsb = torch.empty(max(1, lib.nrx_route_workspace(total, world)), dtype=torch.int64, device=dev)
+    ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    wptrs = (C.c_void_p * n)(*[(_ptr(w) or 0) for w in ws])
+    bl = (C.c_int32 * n)(*[x.shape[1] for x in xs])
+    check(lib.nrx_route_bags(ptrs, wptrs, bl, n, xs[0].element_size() * 8, B, world, cap, send_rows.data_ptr(), send_tag.data_ptr(),
+                             send_w.data_ptr(), counts2d.data_ptr(), overflow.data_ptr(), wsb.data_ptr(), _stream_ptr(xs[0])),
+          "nrx_route_bags")
+    return send_rows, send_tag, send_w, counts2d, overflow
+
+
+def pool_inbox(tables: Sequence[torch.Tensor], feat_table: Sequence[int], batch: int, world: int, cap: int, recv2d, inbox_rows,
+               inbox_tag, inbox_w, status: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Owner-side partial pooling (nrx_pool_inbox_fwd): returns partial [world, n_feats*batch, dim] (zeros where this rank
+    holds nothing of a (feature, sample))."""
+    lib = _lib.load()
+    dim, tp, tr, ft = _inbox_common(tables, feat_table)
+    nf = len(feat_table)
+    partial = torch.empty((world, nf * batch, dim), dtype=torch.float32, device=tables[0].device)
+    ws = torch.empty(max(1, lib.nrx_pool_inbox_workspace(nf, batch, world)), dtype=torch.uint8, device=tables[0].device)
+    check(lib.nrx_pool_inbox_fwd(tp, tr, len(tables), ft, nf, batch, world, cap, recv2d.data_ptr(), inbox_rows.data_ptr(),
+                                 inbox_tag.data_ptr(), inbox_w.data_ptr(), dim, partial.data_ptr(), ws.data_ptr(), _ptr(status),
+                                 _stream_ptr(partial)), "nrx_pool_inbox_fwd")
+    return partial
+
+
+def pool_inbox_bwd(grad_tables: Sequence[torch.Tensor], feat_table: Sequence[int], batch: int, world: int, cap: int, recv2d,
+                   inbox_rows, inbox_tag, inbox_w, g_partial: torch.Tensor, skip_row0: bool) -> None:
+    lib = _lib.load()
+    dim, tp, tr, ft = _inbox_common(grad_tables, feat_table)
+    g_partial = _f32c(g_partial, "g_partial")
+    check(lib.nrx_pool_inbox_bwd(tp, tr, len(grad_tables), ft, len(feat_table), batch, world, cap, recv2d.data_ptr(),
+                                 inbox_rows.data_ptr(), inbox_tag.data_ptr(), inbox_w.data_ptr(), dim, g_partial.data_ptr(),
+                                 1 if skip_row0 else 0, _stream_ptr(g_partial)), "nrx_pool_inbox_bwd")
+
+
 def csr_to_padded(values: torch.Tensor, offsets: torch.Tensor, bag_len: int, rows: Optional[torch.Tensor] = None):
     """CSR batch of an array feature -> (ids [B, bag_len] 0-padded, mask float32 [B, bag_len]) on the device:
     the padded form DataReader builds per sample on the host (data_reader.py:96-109).  With `rows` (device

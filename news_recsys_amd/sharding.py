@@ -92,6 +92,20 @@ class HipBackend:
     def scatter_add_inbox(self, grad_tables, feat_table, world, cap, recv2d, inbox, g_rows, skip_row0):
         ops.scatter_add_inbox(grad_tables, feat_table, world, cap, recv2d, inbox, g_rows, skip_row0)
 
+    # pooled-bag channel (owner-side partial pooling)
+    def bag_norm_weights(self, mask, batch, bag_len, kind, device):
+        return ops.bag_norm_weights(mask, batch, bag_len, kind, device)
+
+    def route_bags(self, id_tensors, weights, world, cap):
+        return ops.route_bags(id_tensors, weights, world, cap)
+
+    def pool_inbox(self, tables, feat_table, batch, world, cap, recv2d, inbox_rows, inbox_tag, inbox_w, want_status):
+        status = torch.zeros(4, dtype=torch.int32, device=inbox_rows.device) if want_status else None
+        return ops.pool_inbox(tables, feat_table, batch, world, cap, recv2d, inbox_rows, inbox_tag, inbox_w, status), status
+
+    def pool_inbox_bwd(self, grad_tables, feat_table, batch, world, cap, recv2d, inbox_rows, inbox_tag, inbox_w, g_partial, skip_row0):
+        ops.pool_inbox_bwd(grad_tables, feat_table, batch, world, cap, recv2d, inbox_rows, inbox_tag, inbox_w, g_partial, skip_row0)
+
     def index_checks_on(self) -> bool:
         return ops._INDEX_CHECK != "off"
 
@@ -126,6 +140,10 @@ class _Route:
     cap: int = 0                    # > 0: fixed-capacity route (recv2d / feat_table used instead of seg_*)
     recv2d: Optional[torch.Tensor] = None
     feat_table: Optional[List[int]] = None
+    pooled: bool = False            # pooled-bag channel: the owner returned partial sums, not rows
+    inbox_tag: Optional[torch.Tensor] = None
+    inbox_w: Optional[torch.Tensor] = None
+    batch: int = 0
 
 
 class RowShardedEmbedding:
@@ -133,7 +151,7 @@ class RowShardedEmbedding:
     [local_row_count(rows), dim] (a leaf requiring grad when training)."""
 
     def __init__(self, rank: int, world: int, group=None, backend=None, mode: str = "capacity",
-                 slack: float = 0.05, overflow_policy: str = "check", host_staged: bool = False):
+                 slack: float = 0.05, overflow_policy: str = "check", host_staged: bool = False, pool_bags: bool = True):
         """mode: "capacity" (sync-free, default) or "exact".  overflow_policy (capacity mode):
         "check" = agree on overflow across ranks after each forward (one small all-reduce + host read)
         and transparently redo the step in exact mode; "defer" = never read back inside the step --
@@ -147,7 +165,28 @@ class RowShardedEmbedding:
         self.host_staged = bool(host_staged)
         self.backend = backend if backend is not None else HipBackend()
         self.mode, self.slack, self.overflow_policy = mode, slack, overflow_policy
+        # pool_bags: row-sharded bag features are pooled AT THE OWNER (one partial vector per (sample, owner) comes back
+        # instead of L rows per sample -- SURVEY 8e step 2).  Off: bags travel as rows like single-valued features.
+        self.pool_bags = bool(pool_bags) and mode == "capacity"
         self._overflow_marks: List[Tuple[torch.Tensor, int]] = []
+
+    def plan_groups(self, feats: Sequence["ShardedFeature"]):
+        """Exchange groups: features that share an embedding dim travel together (<= 64 per exchange); row-sharded bag
+        features form their own groups when they are pooled at the owner.  Returns (groups, indices of the pooled ones)."""
+        by_key: Dict[tuple, List[int]] = {}
+        for i, f in enumerate(feats):
+            if f.kind != NRX_DENSE and not f.replicated:
+                pooled = self.pool_bags and f.kind in (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM) and not f.wide
+                by_key.setdefault((f.dim, pooled), []).append(i)
+        groups: List[List[int]] = []
+        pooled_set = set()
+        for key in sorted(by_key):
+            idxs = by_key[key]
+            for k in range(0, len(idxs), 64):
+                if key[1]:
+                    pooled_set.add(len(groups))
+                groups.append(idxs[k:k + 64])
+        return groups, pooled_set
 
     def capacity_for(self, n_total: int) -> int:
         if self.world == 1:
@@ -277,6 +316,55 @@ class RowShardedEmbedding:
                        cap=cap, recv2d=recv2d, feat_table=feat_table)
         return ret, route, overflow, status
 
+    _POOL_KIND = {NRX_BAG_MASKED_MEAN: NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN: NRX_BAG_MEAN, NRX_BAG_SUM: NRX_BAG_SUM}
+
+    def _exchange_pooled(self, feats: Sequence[ShardedFeature], idxs: List[int], inputs, weights, tables: Dict[str, torch.Tensor]):
+        """Pooled-bag channel for one group (<= 64 bag features of one dim): normalised weights -> nrx_route_bags ->
+        equal-split all-to-alls of {local rows, tags, weights} -> owner-side pooling -> all-to-all of the dense partials.
+        Returns (partials [world, nf*B, D] as received from every owner, _Route, overflow, status)."""
+        W = self.world
+        dev = inputs[idxs[0]].device
+        B = inputs[idxs[0]].shape[0]
+        dt = torch.int32 if all(inputs[i].dtype == torch.int32 for i in idxs) else torch.int64
+        ids = [inputs[i] if inputs[i].dtype == dt else inputs[i].to(dt) for i in idxs]
+        wn = [self.backend.bag_norm_weights(weights[i] if feats[i].kind != NRX_BAG_MEAN else None, B, feats[i].bag_len,
+                                            feats[i].kind, dev) for i in idxs]
+        n_send = sum(x.numel() for x in ids)
+        cap = self.capacity_for(n_send)
+        table_names: List[str] = []
+        for i in idxs:
+            if feats[i].table not in table_names:
+                table_names.append(feats[i].table)
+        feat_table = [table_names.index(feats[i].table) for i in idxs]
+        D = feats[idxs[0]].dim
+        nf = len(idxs)
+        send_rows, send_tag, send_w, counts2d, overflow = self.backend.route_bags(ids, wn, W, cap)
+        recv2d = torch.empty_like(counts2d)
+        self._a2a(recv2d.view(-1), counts2d.view(-1))
+        inbox_rows, inbox_tag, inbox_w = torch.empty_like(send_rows), torch.empty_like(send_tag), torch.empty_like(send_w)
+        self._a2a(inbox_rows, send_rows)
+        self._a2a(inbox_tag, send_tag)
+        self._a2a(inbox_w, send_w)
+        want_status = self.backend.index_checks_on() and self.overflow_policy == "check"
+        partial, status = self.backend.pool_inbox([tables[t] for t in table_names], feat_table, B, W, cap, recv2d, inbox_rows,
+                                                  inbox_tag, inbox_w, want_status)
+        ret = torch.empty_like(partial)                                                # [W, nf*B, D]: slab o came from owner o
+        self._a2a(ret.view(-1), partial.view(-1))
+        route = _Route(list(idxs), table_names, D, n_send, [], [], None, None, inbox_rows, None, [], cap=cap, recv2d=recv2d,
+                       feat_table=feat_table, pooled=True, inbox_tag=inbox_tag, inbox_w=inbox_w, batch=B)
+        return ret, route, overflow, status
+
+    def _pooled_ids(self, B: int, nf: int, k: int, device) -> torch.Tensor:
+        """ids [B, world] of feature k of a pooled group inside the returned slabs viewed as [world*nf*B, D] rows."""
+        key = (B, nf, k, str(device))
+        cache = self.__dict__.setdefault("_pooled_id_cache", {})
+        t = cache.get(key)
+        if t is None:
+            o = torch.arange(self.world, device=device, dtype=torch.int32)[None, :] * (nf * B)
+            t = (o + (k * B + torch.arange(B, device=device, dtype=torch.int32))[:, None]).contiguous()
+            cache[key] = t
+        return t
+
     @staticmethod
     def replicated_tables(feats: Sequence[ShardedFeature]) -> List[str]:
         names: List[str] = []
@@ -285,7 +373,7 @@ class RowShardedEmbedding:
                 names.append(f.table)
         return names
 
-    def _final_plan(self, feats: Sequence[ShardedFeature], groups: List[List[int]]):
+    def _final_plan(self, feats: Sequence[ShardedFeature], groups: List[List[int]], pooled_groups: Sequence[int] = ()):
         """Step 7 plan: tables = one returned-row buffer per exchange group, then the replicated tables;
         indices = slot[] segments (routed features) or the original ids (replicated features)."""
         slots, col, wcol = [], 0, 0
@@ -299,11 +387,14 @@ class RowShardedEmbedding:
                 slots.append(ops.Slot(f.name, NRX_DENSE, -1, 1, 0, col))
                 col += 1
                 continue
+            kind, blen = f.kind, f.bag_len
             if f.replicated:
                 tix, flags = len(groups) + rep.index(f.table), 0
             else:
                 tix, flags = gidx[i], NRX_FEAT_ROW0_IS_DATA
-            slots.append(ops.Slot(f.name, f.kind, tix, f.dim, f.bag_len, col, wide_col=wcol if f.wide else -1,
+                if gidx[i] in pooled_groups:      # the owners pooled: add the `world` partials, rank order
+                    kind, blen = NRX_BAG_SUM, self.world
+            slots.append(ops.Slot(f.name, kind, tix, f.dim, blen, col, wide_col=wcol if f.wide else -1,
                                   fm_field=int(f.fm), flags=flags))
             if f.wide:
                 wcol += 1
@@ -326,19 +417,16 @@ class _ShardedEmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng: RowShardedEmbedding, feats, inputs, weights, names, out_ld, need_out, *shards):
         tables = dict(zip(names, shards))
-        by_dim: Dict[int, List[int]] = {}
-        for i, f in enumerate(feats):
-            if f.kind != NRX_DENSE and not f.replicated:
-                by_dim.setdefault(f.dim, []).append(i)
-        groups: List[List[int]] = []
-        for d in sorted(by_dim):                       # one exchange per (dim, <= 64 features)
-            idxs = by_dim[d]
-            groups += [idxs[k:k + 64] for k in range(0, len(idxs), 64)]
+        groups, pooled_set = eng.plan_groups(feats)
 
         def run(mode):
             rets, routes, flags = [], [], []
-            for idxs in groups:
-                if mode == "capacity":
+            for g, idxs in enumerate(groups):
+                if mode == "capacity" and g in pooled_set:
+                    ret, route, overflow, status = eng._exchange_pooled(feats, idxs, inputs, weights, tables)
+                    flags.append((overflow, route.cap, status))
+                    ret = ret.view(-1, route.dim)                       # [world*nf*B, D] pseudo-table of partial sums
+                elif mode == "capacity":
                     ret, route, overflow, status = eng._exchange_capacity(feats, idxs, inputs, tables)
                     flags.append((overflow, route.cap, status))
                 else:
@@ -358,13 +446,15 @@ class _ShardedEmbedFn(torch.autograd.Function):
                 if bad > 0:
                     raise IndexError("index out of range in self: a routed lookup exceeded its table on some rank")
                 if over > 0:
+                    pooled_set = set()                                   # exact mode returns rows for every feature
                     rets, routes, flags = run("exact")
             else:
                 eng._overflow_marks += [(o, cap) for o, cap, _ in flags]
 
-        plan = eng._final_plan(feats, groups)
+        plan = eng._final_plan(feats, groups, pooled_set)
         rep_names = eng.replicated_tables(feats)
         final_inputs = []
+        final_weights = list(weights)
         for i, f in enumerate(feats):
             if f.kind == NRX_DENSE or f.replicated:
                 final_inputs.append(inputs[i])
@@ -372,13 +462,17 @@ class _ShardedEmbedFn(torch.autograd.Function):
             g = next(k for k, idxs in enumerate(groups) if i in idxs)
             r = routes[g]
             k = r.feats.index(i)
+            if r.pooled:
+                final_inputs.append(eng._pooled_ids(r.batch, len(r.feats), k, inputs[i].device))
+                final_weights[i] = None
+                continue
             n = inputs[i].numel()
             final_inputs.append(r.slot[r.feat_off[k]: r.feat_off[k] + n].view(inputs[i].shape))
         train = any(ctx.needs_input_grad[7:])
         with torch.set_grad_enabled(train):
             leaves = [r.detach().requires_grad_(train) for r in rets]
             leaves += [tables[n].detach().requires_grad_(train) for n in rep_names]   # replicated: local full tables
-            out, wide, fm = eng.backend.embed(plan, leaves, final_inputs, list(weights), out_ld=out_ld, need_out=need_out)
+            out, wide, fm = eng.backend.embed(plan, leaves, final_inputs, final_weights, out_ld=out_ld, need_out=need_out)
         ctx.eng, ctx.routes, ctx.leaves, ctx.rep_names = eng, routes, leaves, rep_names
         ctx.outs = (out, wide, fm)
         ctx.names, ctx.shard_meta = names, [(s.shape, s.device) for s in shards]
@@ -408,7 +502,12 @@ class _ShardedEmbedFn(torch.autograd.Function):
                 g_ret = torch.zeros_like(leaf)
             D = route.dim
             gts = [shard_grads[t] for t in route.table_names]
-            if route.cap:
+            if route.pooled:
+                g_part = torch.empty_like(g_ret)
+                eng._a2a(g_part.view(-1), g_ret.contiguous().view(-1))                   # slab s goes back to owner... from source s
+                eng.backend.pool_inbox_bwd(gts, route.feat_table, route.batch, eng.world, route.cap, route.recv2d, route.recv_rows,
+                                           route.inbox_tag, route.inbox_w, g_part.view(eng.world, -1, D), skip_row0=(eng.rank == 0))
+            elif route.cap:
                 g_recv = torch.empty_like(g_ret)
                 eng._a2a(g_recv.view(-1), g_ret.contiguous().view(-1))                    # equal splits
                 eng.backend.scatter_add_inbox(gts, route.feat_table, eng.world, route.cap, route.recv2d,
@@ -439,20 +538,22 @@ class PreparedShardedForward:
         self.lib = _lib.load()
         self.eng = eng
         W = eng.world
-        by_dim: Dict[int, List[int]] = {}
-        for i, f in enumerate(feats):
-            if f.kind != NRX_DENSE and not f.replicated:
-                by_dim.setdefault(f.dim, []).append(i)
-        groups: List[List[int]] = []
-        for d in sorted(by_dim):
-            idxs = by_dim[d]
-            groups += [idxs[k:k + 64] for k in range(0, len(idxs), 64)]
+        groups, pooled_set = eng.plan_groups(feats)
         self.groups = []
         self.keep = [inputs, weights, tables]
         slot_of: Dict[int, torch.Tensor] = {}
+        final_weights = list(weights)
         rets = []
-        for idxs in groups:
+        for gi, idxs in enumerate(groups):
             dev = inputs[idxs[0]].device
+            if gi in pooled_set:
+                g = self._bind_pooled(eng, feats, idxs, inputs, weights, tables, C)
+                for k, i in enumerate(idxs):
+                    slot_of[i] = eng._pooled_ids(g["B"], g["n"], k, dev)
+                    final_weights[i] = None
+                self.groups.append(g)
+                rets.append(g["ret"].view(-1, g["D"]))
+                continue
             dt = torch.int32 if all(inputs[i].dtype == torch.int32 for i in idxs) else torch.int64
             ids = [inputs[i] if inputs[i].dtype == dt else inputs[i].to(dt) for i in idxs]
             ids = [x if x.is_contiguous() else x.contiguous() for x in ids]
@@ -485,16 +586,84 @@ class PreparedShardedForward:
                 off += x.numel()
             self.groups.append(g)
             rets.append(g["ret"])
-        plan = eng._final_plan(feats, groups)
+        plan = eng._final_plan(feats, groups, pooled_set)
         final_inputs = [inputs[i] if (f.kind == NRX_DENSE or f.replicated) else slot_of[i] for i, f in enumerate(feats)]
         rets += [tables[n] for n in eng.replicated_tables(feats)]
-        self.final = ops.PreparedEmbed(plan, rets, final_inputs, list(weights), out_ld=out_ld, out=out, fm=fm)
+        self.final = ops.PreparedEmbed(plan, rets, final_inputs, final_weights, out_ld=out_ld, out=out, fm=fm)
+
+    def _bind_pooled(self, eng, feats, idxs, inputs, weights, tables, C):
+        """Buffers and descriptor arrays of one pooled-bag group (owner-side partial pooling)."""
+        W = eng.world
+        dev = inputs[idxs[0]].device
+        dt = torch.int32 if all(inputs[i].dtype == torch.int32 for i in idxs) else torch.int64
+        if any(inputs[i].dtype != dt for i in idxs):
+            raise TypeError("PreparedShardedForward: the ids of one exchange group must share a dtype")
+        ids = [inputs[i] if inputs[i].is_contiguous() else inputs[i].contiguous() for i in idxs]
+        n = len(ids)
+        B = ids[0].shape[0]
+        total = sum(x.numel() for x in ids)
+        cap = eng.capacity_for(total)
+        D = feats[idxs[0]].dim
+        table_names: List[str] = []
+        for i in idxs:
+            if feats[i].table not in table_names:
+                table_names.append(feats[i].table)
+        loc = [tables[t] for t in table_names]
+        masks = [weights[i] if feats[i].kind != NRX_BAG_MEAN else None for i in idxs]
+        wn = [torch.empty((B, feats[i].bag_len), dtype=torch.float32, device=dev) for i in idxs]
+        g = dict(pooled=True, n=n, B=B, cap=cap, D=D, bits=ids[0].element_size() * 8, ids=ids, masks=masks, wn=wn,
+                 kinds=[feats[i].kind for i in idxs], lens=[feats[i].bag_len for i in idxs],
+                 ptrs=(C.c_void_p * n)(*[x.data_ptr() for x in ids]), wptrs=(C.c_void_p * n)(*[w.data_ptr() for w in wn]),
+                 bl=(C.c_int32 * n)(*[feats[i].bag_len for i in idxs]),
+                 send=torch.empty(W * cap, dtype=torch.int32, device=dev), send_tag=torch.empty(W * cap, dtype=torch.int32, device=dev),
+                 send_w=torch.empty(W * cap, dtype=torch.float32, device=dev),
+                 counts2d=torch.empty((W, n), dtype=torch.int64, device=dev), recv2d=torch.empty((W, n), dtype=torch.int64, device=dev),
+                 overflow=torch.zeros(1, dtype=torch.int64, device=dev),
+                 ws=torch.empty(max(1, self.lib.nrx_route_workspace(total, W)), dtype=torch.int64, device=dev),
+                 inbox=torch.empty(W * cap, dtype=torch.int32, device=dev), inbox_tag=torch.empty(W * cap, dtype=torch.int32, device=dev),
+                 inbox_w=torch.empty(W * cap, dtype=torch.float32, device=dev),
+                 partial=torch.empty((W, n * B, D), dtype=torch.float32, device=dev),
+                 pws=torch.empty(max(1, self.lib.nrx_pool_inbox_workspace(n, B, W)), dtype=torch.uint8, device=dev),
+                 ret=torch.empty((W, n * B, D), dtype=torch.float32, device=dev),
+                 tp=(C.c_void_p * len(loc))(*[t.data_ptr() for t in loc]), tr=(C.c_int64 * len(loc))(*[t.shape[0] for t in loc]),
+                 nt=len(loc), ft=(C.c_int32 * n)(*[table_names.index(feats[i].table) for i in idxs]), dev=dev)
+        if W == 1:
+            g["inbox"], g["inbox_tag"], g["inbox_w"], g["recv2d"], g["ret"] = g["send"], g["send_tag"], g["send_w"], g["counts2d"], g["partial"]
+        return g
+
+    def _run_pooled(self, g, stream):
+        eng, lib = self.eng, self.lib
+        W = eng.world
+        for m, w, kind, L in zip(g["masks"], g["wn"], g["kinds"], g["lens"]):
+            rc = lib.nrx_bag_norm_weights(None if m is None else m.data_ptr(), g["B"], L, kind, w.data_ptr(), stream)
+            if rc:
+                ops.check(rc, "nrx_bag_norm_weights")
+        rc = lib.nrx_route_bags(g["ptrs"], g["wptrs"], g["bl"], g["n"], g["bits"], g["B"], W, g["cap"], g["send"].data_ptr(),
+                                g["send_tag"].data_ptr(), g["send_w"].data_ptr(), g["counts2d"].data_ptr(), g["overflow"].data_ptr(),
+                                g["ws"].data_ptr(), stream)
+        if rc:
+            ops.check(rc, "nrx_route_bags")
+        if W > 1:
+            eng._a2a(g["recv2d"].view(-1), g["counts2d"].view(-1))
+            eng._a2a(g["inbox"], g["send"])
+            eng._a2a(g["inbox_tag"], g["send_tag"])
+            eng._a2a(g["inbox_w"], g["send_w"])
+        rc = lib.nrx_pool_inbox_fwd(g["tp"], g["tr"], g["nt"], g["ft"], g["n"], g["B"], W, g["cap"], g["recv2d"].data_ptr(),
+                                    g["inbox"].data_ptr(), g["inbox_tag"].data_ptr(), g["inbox_w"].data_ptr(), g["D"],
+                                    g["partial"].data_ptr(), g["pws"].data_ptr(), None, stream)
+        if rc:
+            ops.check(rc, "nrx_pool_inbox_fwd")
+        if W > 1:
+            eng._a2a(g["ret"].view(-1), g["partial"].view(-1))
 
     def run(self):
         eng, lib = self.eng, self.lib
         W = eng.world
         for g in self.groups:
             stream = torch.cuda.current_stream(g["dev"]).cuda_stream
+            if g.get("pooled"):
+                self._run_pooled(g, stream)
+                continue
             rc = lib.nrx_route_ids(g["ptrs"], g["lens"], g["n"], g["bits"], W, g["cap"], g["send"].data_ptr(),
                                    g["slot"].data_ptr(), g["counts2d"].data_ptr(), g["overflow"].data_ptr(),
                                    g["ws"].data_ptr(), stream)

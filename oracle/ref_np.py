@@ -507,6 +507,71 @@ def gather_inbox(tables, feat_table, world: int, cap: int, recv2d, inbox_rows, d
     return out
 
 
+def bag_norm_weights(mask, batch: int, bag_len: int, kind: str):
+    """Definition of nrx_bag_norm_weights: pooling weights with the normalisation folded in.
+    kind 'masked_mean': w / (sum_l w + 1e-8) (array_feature_pooling, base_model.py:278-282); 'mean': 1 / L (:275-276);
+    'sum': w (or 1)."""
+    if kind == "mean":
+        return np.full((batch, bag_len), 1.0, F32) / F32(bag_len)
+    m = np.ones((batch, bag_len), F32) if mask is None else np.asarray(mask, F32)
+    if kind == "sum":
+        return m
+    den = m.sum(axis=1, dtype=F32, keepdims=True) + F32(1e-8)
+    return (m / den).astype(F32)
+
+
+def route_bags(id_arrays, weights, world: int, cap: int):
+    """Definition of nrx_route_bags (pooled-bag channel): id_arrays[f] is [B, L_f]; lookups with weight != 0 go, in
+    source order (feature-major, then sample, then position), to their owner's block as (local row, tag = f*B + sample,
+    weight).  Returns (send_rows, send_tag, send_w [world*cap] (unused slots -1 / -1 / 0), counts2d [world, F], max block)."""
+    F = len(id_arrays)
+    B = id_arrays[0].shape[0] if F else 0
+    send = np.full(world * cap, -1, np.int64)
+    tag = np.full(world * cap, -1, np.int64)
+    sw = np.zeros(world * cap, F32)
+    counts2d = np.zeros((world, F), np.int64)
+    fill = np.zeros(world, np.int64)
+    I32MAX = (1 << 31) - 1
+    for f, ids in enumerate(id_arrays):
+        ids = np.asarray(ids, np.int64)
+        L = ids.shape[1]
+        w = np.ones((B, L), F32) if weights[f] is None else np.asarray(weights[f], F32)
+        flat, wf = ids.reshape(-1), w.reshape(-1)
+        keep = wf != 0
+        bad = (flat < 0) | (flat > I32MAX)
+        owner = np.where(bad, 0, flat % world)
+        loc = np.where(flat < 0, -1, np.where(flat > I32MAX, I32MAX, flat // world))
+        smp = np.arange(flat.size) // L
+        for o in range(world):
+            pos = np.flatnonzero(keep & (owner == o))
+            counts2d[o, f] = pos.size
+            k = fill[o] + np.arange(pos.size)
+            ok = k < cap
+            send[o * cap + k[ok]] = loc[pos[ok]]
+            tag[o * cap + k[ok]] = f * B + smp[pos[ok]]
+            sw[o * cap + k[ok]] = wf[pos[ok]]
+            fill[o] += pos.size
+    return send, tag, sw, counts2d, int(fill.max()) if world else 0
+
+
+def pool_inbox(tables, feat_table, batch: int, world: int, cap: int, recv2d, inbox_rows, inbox_tag, inbox_w, dim: int):
+    """Definition of nrx_pool_inbox_fwd: partial[s, tag] = sum over block s's valid entries with that tag of
+    w * tables[feat_table[tag // batch]][row], accumulated in entry order (fp32, product then add)."""
+    nf = len(feat_table)
+    out = np.zeros((world, nf * batch, dim), F32)
+    r2 = np.asarray(recv2d).reshape(world, -1)
+    for s_ in range(world):
+        total = min(int(r2[s_].sum()), cap)
+        for j in range(total):
+            t = int(inbox_tag[s_ * cap + j])
+            row = int(inbox_rows[s_ * cap + j])
+            tab = tables[feat_table[t // batch]]
+            if row < 0 or row >= tab.shape[0]:
+                raise IndexError("routed bag lookup out of range")
+            out[s_, t] = out[s_, t] + tab[row] * F32(inbox_w[s_ * cap + j])
+    return out
+
+
 # ----------------------------------------------------------------------------------------
 # validation metrics                               src/model/BaseModel/base_model.py:320-528
 # ----------------------------------------------------------------------------------------

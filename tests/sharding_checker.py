@@ -77,6 +77,40 @@ class CheckerBackend:
                     np.add.at(grad_tables[feat_table[f]].numpy(), rows, vals)
                 j += n
 
+    # ---- pooled-bag channel (definitions: oracle/ref_np.py bag_norm_weights / route_bags / pool_inbox)
+    _KIND = {NRX_BAG_MASKED_MEAN: "masked_mean", NRX_BAG_MEAN: "mean", NRX_BAG_SUM: "sum"}
+
+    def bag_norm_weights(self, mask, batch, bag_len, kind, device):
+        return torch.from_numpy(R.bag_norm_weights(None if mask is None else mask.numpy(), batch, bag_len, self._KIND[kind]))
+
+    def route_bags(self, id_tensors, weights, world, cap):
+        send, tag, sw, counts2d, worst = R.route_bags([t.numpy() for t in id_tensors], [None if w is None else w.numpy() for w in weights],
+                                                      world, cap)
+        return (torch.from_numpy(send.astype(np.int32)), torch.from_numpy(tag.astype(np.int32)), torch.from_numpy(sw),
+                torch.from_numpy(counts2d), torch.tensor([worst], dtype=torch.int64))
+
+    def pool_inbox(self, tables, feat_table, batch, world, cap, recv2d, inbox_rows, inbox_tag, inbox_w, want_status):
+        status = torch.zeros(4, dtype=torch.int32)
+        tabs = [t.detach().numpy() for t in tables]
+        try:
+            out = R.pool_inbox(tabs, feat_table, batch, world, cap, recv2d.numpy(), inbox_rows.numpy(), inbox_tag.numpy(),
+                               inbox_w.numpy(), tabs[0].shape[1])
+        except IndexError:
+            status[0] = 1
+            out = np.zeros((world, len(feat_table) * batch, tabs[0].shape[1]), np.float32)
+        return torch.from_numpy(out), (status if want_status else None)
+
+    def pool_inbox_bwd(self, grad_tables, feat_table, batch, world, cap, recv2d, inbox_rows, inbox_tag, inbox_w, g_partial, skip_row0):
+        r2 = recv2d.numpy().reshape(world, -1)
+        gp = g_partial.numpy()
+        for s in range(world):
+            total = min(int(r2[s].sum()), cap)
+            for j in range(total):
+                row, tag, w = int(inbox_rows[s * cap + j]), int(inbox_tag[s * cap + j]), float(inbox_w[s * cap + j])
+                if skip_row0 and row == 0:
+                    continue
+                grad_tables[feat_table[tag // batch]].numpy()[row] += np.float32(w) * gp[s, tag]
+
     def embed(self, plan, tables, inputs, weights, out_ld=None, need_out=True):
         """torch-CPU restatement of the fused launch (differentiable w.r.t. `tables`)."""
         B = inputs[0].shape[0]

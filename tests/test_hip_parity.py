@@ -730,6 +730,80 @@ def test_route_ids_bit_exact_vs_oracle(world, lens, cap, dtype):
     assert np.array_equal(send.cpu().numpy()[valid], r_send[valid])      # unused slots are unspecified
 
 
+@pytest.mark.parametrize("world,B,Ls,cap,dtype", [(1, 50, [7], 400, torch.int64), (2, 300, [9, 4], 2048, torch.int64),
+                                                  (3, 1000, [50], 20000, torch.int32), (8, 513, [5, 5, 12], 2048, torch.int64),
+                                                  (4, 200, [6], 64, torch.int64)])
+def test_pooled_bag_channel_vs_oracle(world, B, Ls, cap, dtype):
+    """Owner-side partial pooling: nrx_bag_norm_weights, nrx_route_bags (bit-exact vs the definition,
+    incl. dropped zero-weight lookups, feature boundaries inside a chunk and an overflowing block = last case) and
+    nrx_pool_inbox_fwd / _bwd on every owner's shard; the partials summed over owners reproduce
+    array_feature_pooling (base_model.py:273-282) to the stated 1e-6."""
+    rng = np.random.default_rng(world * 1000 + B)
+    D, rows = 16, 211
+    kinds = [("masked_mean", NRX_BAG_MASKED_MEAN), ("mean", NRX_BAG_MEAN), ("sum", NRX_BAG_SUM)]
+    table = rng.standard_normal((rows, D)).astype(np.float32)
+    table[0] = 0
+    ids, masks, wn_ref, kk = [], [], [], []
+    for f, L in enumerate(Ls):
+        name, kind = kinds[f % 3]
+        lens = rng.integers(0, L + 1, B)
+        lens[0] = 0
+        m = (np.arange(L)[None] < lens[:, None]).astype(np.float32)
+        x = rng.integers(1, rows, (B, L)) * (m.astype(np.int64) if name != "mean" else 1)
+        ids.append(x)
+        masks.append(None if name == "mean" else m)
+        wn_ref.append(R.bag_norm_weights(masks[-1], B, L, name))
+        kk.append(kind)
+    wn = [ops.bag_norm_weights(None if m is None else dev(m), B, L, k, DEV) for m, L, k in zip(masks, Ls, kk)]
+    for a_, b_ in zip(wn, wn_ref):
+        np.testing.assert_allclose(a_.cpu().numpy(), b_, rtol=1e-6, atol=0)
+    send, tag, sw, c2, over = ops.route_bags([dev(x).to(dtype) for x in ids], wn, world, cap)
+    r_send, r_tag, r_sw, r_c2, r_worst = R.route_bags(ids, [w.cpu().numpy() for w in wn], world, cap)
+    assert np.array_equal(c2.cpu().numpy(), r_c2) and int(over.item()) == r_worst
+    valid = r_send >= 0
+    assert np.array_equal(send.cpu().numpy()[valid], r_send[valid]) and np.array_equal(tag.cpu().numpy()[valid], r_tag[valid])
+    assert np.array_equal(sw.cpu().numpy()[valid], r_sw[valid])
+    if r_worst > cap:
+        return                                           # overflow detected: the engine redoes the step exactly
+    # every owner pools its block (this process plays all owners of ONE source): inbox block 0 = the block sent to o
+    nf = len(Ls)
+    total = np.zeros((nf * B, D), np.float64)
+    gtab = torch.zeros((rows, D), device=DEV)
+    up = rng.standard_normal((nf * B, D)).astype(np.float32)
+    for o in range(world):
+        shard = table[o::world]
+        recv = np.zeros((world, nf), np.int64)
+        recv[0] = r_c2[o]
+        ib = torch.full((world * cap,), 10 ** 9, dtype=torch.int32, device=DEV)
+        it = torch.full((world * cap,), -5, dtype=torch.int32, device=DEV)
+        iw = torch.zeros(world * cap, device=DEV)
+        ib[:cap], it[:cap], iw[:cap] = send[o * cap:(o + 1) * cap], tag[o * cap:(o + 1) * cap], sw[o * cap:(o + 1) * cap]
+        status = torch.zeros(4, dtype=torch.int32, device=DEV)
+        part = ops.pool_inbox([dev(shard)], [0] * nf, B, world, cap, dev(recv), ib, it, iw, status)
+        want = R.pool_inbox([shard], [0] * nf, B, world, cap, recv, ib.cpu().numpy(), it.cpu().numpy(), iw.cpu().numpy(), D)
+        np.testing.assert_allclose(part.cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+        assert status[0].item() == 0 and torch.all(part[1:] == 0)
+        total += part[0].cpu().numpy()
+        gshard = torch.zeros_like(dev(shard))
+        gp = torch.zeros((world, nf * B, D), device=DEV)
+        gp[0] = dev(up)
+        ops.pool_inbox_bwd([gshard], [0] * nf, B, world, cap, dev(recv), ib, it, iw, gp, skip_row0=(o == 0))
+        gtab[o::world] += gshard
+    for f, (L, (name, _)) in enumerate(zip(Ls, [kinds[f % 3] for f in range(nf)])):
+        ref = R.array_pool(table[ids[f]], masks[f]) if name != "sum" else (table[ids[f]] * masks[f][..., None]).sum(1)
+        np.testing.assert_allclose(total[f * B:(f + 1) * B], ref, rtol=1e-6, atol=1e-6)
+    # backward: d/dtable of sum(up * pooled) in fp64
+    t64 = torch.from_numpy(table).double().requires_grad_(True)
+    loss = 0
+    for f, L in enumerate(Ls):
+        w = torch.from_numpy(wn_ref[f]).double()
+        loss = loss + ((t64[torch.from_numpy(ids[f])] * w[..., None]).sum(1) * torch.from_numpy(up[f * B:(f + 1) * B]).double()).sum()
+    loss.backward()
+    g_ref = t64.grad.clone()
+    g_ref[0] = 0
+    torch.testing.assert_close(gtab.cpu().double(), g_ref, rtol=1e-4, atol=1e-4)
+
+
 def test_inbox_gather_and_scatter_vs_oracle():
     rng = np.random.default_rng(8)
     world, cap, D = 3, 512, 16
