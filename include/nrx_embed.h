@@ -281,6 +281,22 @@ NRX_API int64_t nrx_route_workspace(int64_t n_total, int32_t world);
 NRX_API int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_t n_feats, int32_t index_bits,
                   int32_t world, int64_t cap, int32_t* send_rows, int32_t* slot, int64_t* counts2d,
                   int64_t* overflow, int64_t* workspace, void* stream);
+/* De-duplicated form of nrx_route_ids (per-destination dedup, SURVEY 7 hard part 1b): every DISTINCT (owner, table, local
+ * row) of the exchange is sent once.  table_of[f] (HOST, n_feats): table index of feature f; table_local_rows[t] (HOST,
+ * n_tables): rows of the largest local shard of table t (ids that cannot be rows are sent as that value and reported by the
+ * owner).  Layout as nrx_route_ids with TABLES in the place of features: inside owner o's block the unique rows are ordered
+ * by table then row, counts2d is [world, n_tables] (the owner gathers with feat_table = identity), slot[p] -- for every
+ * lookup, duplicates included -- is the position of its unique entry, overflow[0] the largest block's unique count.
+ * workspace: nrx_route_dedup_workspace(n_total, world) device bytes.  Deterministic (stable bit-limited radix sort).    */
+NRX_API int64_t nrx_route_dedup_workspace(int64_t n_total, int32_t world);
+NRX_API int nrx_route_ids_dedup(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* table_local_rows,
+                        int32_t n_feats, int32_t n_tables, int32_t index_bits, int32_t world, int64_t cap,
+                        int32_t* send_rows, int32_t* slot, int64_t* counts2d, int64_t* overflow, void* workspace, void* stream);
+/* np.unique(ids, return_inverse=True) on the device: unique_out [<= n] ascending distinct values, inverse_out [n] with
+ * unique_out[inverse_out[i]] == ids[i], n_unique (device int64[1]).  workspace: nrx_unique_inverse_workspace(n) bytes.   */
+NRX_API int64_t nrx_unique_inverse_workspace(int64_t n);
+NRX_API int nrx_unique_inverse(const void* ids, int32_t index_bits, int64_t n, int64_t* unique_out, int64_t* inverse_out,
+                       int64_t* n_unique, void* workspace, void* stream);
 /* Owner side of the fixed-capacity exchange.  inbox_rows [world*cap]: block s came from rank s, its
  * valid prefix has sum_f recv2d[s*n_feats+f] entries, feature-major.  feat_table (HOST, n_feats):
  * table index of each feature.  Gathers into out_rows [world*cap, dim] (slots past a block's count

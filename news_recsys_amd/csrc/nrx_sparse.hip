@@ -250,6 +250,298 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Per-destination de-duplicated routing (SURVEY 7 hard part 1b / 8e step 1): the ids of one exchange are grouped by
+// (owner, table, local row) with the same bit-limited stable sort as the backward planner; every DISTINCT
+// (owner, table, row) is sent once, and slot[] maps every lookup -- duplicates included -- to its unique entry's position
+// in the returned-row buffer.  Same block layout as nrx_route_ids with tables in the place of features: inside owner o's
+// block the unique rows are ordered by table, then by row, so the owner segments its inbox with counts2d[o][table].
+// Pays off on skewed (click-log) ids: a hot row crosses the fabric once per step instead of once per lookup.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct DedupArgs {
+    const void* ids[NRX_MAX_FEATURES];
+    int64_t off[NRX_MAX_FEATURES + 1];
+    int64_t local_rows[NRX_MAX_FEATURES];   // rows of the LARGEST local shard of the feature's table (= the out-of-range marker)
+    int32_t table_of[NRX_MAX_FEATURES];
+    int32_t n_feats;
+    int32_t idx64;
+    int32_t world;
+    int32_t row_bits;
+    int32_t table_bits;
+    int64_t n_total;
+};
+static_assert(sizeof(DedupArgs) <= 3584, "kernarg budget");
+
+template <typename KeyT>
+__global__ __launch_bounds__(NRX_BLOCK) void dedup_keys_kernel(const DedupArgs args_in_kernarg, KeyT* __restrict__ keys, uint32_t* __restrict__ payload) {
+    const NRX_CONST DedupArgs* a = nrx_kernarg<DedupArgs>();
+    for (int64_t p = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x; p < a->n_total; p += (int64_t)gridDim.x * NRX_BLOCK) {
+        int lo = 0, hi = a->n_feats;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a->off[mid] <= p) lo = mid; else hi = mid;
+        }
+        const int64_t i = p - a->off[lo];
+        const int64_t id = a->idx64 ? nrx_gconst<int64_t>(a->ids[lo])[i] : (int64_t)nrx_gconst<int32_t>(a->ids[lo])[i];
+        uint64_t owner = 0, local = (uint64_t)a->local_rows[lo];           // ids that cannot be rows: rank 0, first row past the shard
+        if (id >= 0 && id <= 0x7fffffffLL) {
+            const uint32_t u = (uint32_t)id, l = u / (uint32_t)a->world;
+            owner = u - l * (uint32_t)a->world;
+            local = l < (uint64_t)a->local_rows[lo] ? l : (uint64_t)a->local_rows[lo];
+        }
+        keys[p] = (KeyT)((owner << (a->table_bits + a->row_bits)) | ((uint64_t)a->table_of[lo] << a->row_bits) | local);
+        payload[p] = (uint32_t)p;
+    }
+}
+
+// global unique rank of every sorted entry (same tile scheme as plan_emit_kernel) + first unique entry of every owner
+template <typename KeyT>
+__global__ __launch_bounds__(NRX_BLOCK) void dedup_rank_kernel(const KeyT* __restrict__ skeys, const uint32_t* __restrict__ block_heads, int64_t n,
+                                                               int owner_shift, int world, uint32_t* __restrict__ urank,
+                                                               uint32_t* __restrict__ owner_base /* [world + 1] */) {
+    constexpr int ROUNDS = PLAN_TILE / NRX_BLOCK, WAVES = NRX_BLOCK / 64;
+    __shared__ uint32_t s_cell[ROUNDS * WAVES + 1];
+    __shared__ uint32_t s_part[WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t e0 = (int64_t)blockIdx.x * PLAN_TILE + tid;
+    KeyT key[ROUNDS], prev[ROUNDS];
+#pragma unroll
+    for (int j = 0; j < ROUNDS; ++j) {
+        const int64_t e = e0 + j * NRX_BLOCK;
+        const int64_t ec = e < n ? e : n - 1;
+        key[j] = skeys[ec];
+        prev[j] = skeys[ec > 0 ? ec - 1 : 0];
+    }
+    uint32_t acc = 0;
+    for (uint32_t i = tid; i < blockIdx.x; i += NRX_BLOCK) acc += block_heads[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) s_part[wid] = acc;
+    bool head[ROUNDS];
+    unsigned long long mask[ROUNDS];
+#pragma unroll
+    for (int j = 0; j < ROUNDS; ++j) {
+        const int64_t e = e0 + j * NRX_BLOCK;
+        head[j] = e < n && (e == 0 || key[j] != prev[j]);
+        mask[j] = __ballot(head[j]);
+        if (lane == 0) s_cell[j * WAVES + wid] = (uint32_t)__popcll(mask[j]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        for (int c = 0; c < ROUNDS * WAVES; ++c) {
+            const uint32_t v = s_cell[c];
+            s_cell[c] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int j = 0; j < ROUNDS; ++j) {
+        const int64_t e = e0 + j * NRX_BLOCK;
+        if (e >= n) continue;
+        // rank of the entry's unique key = heads before it (+ itself if it is a head) - 1
+        const uint32_t before = s_cell[j * WAVES + wid] + (uint32_t)__popcll(mask[j] & lt);
+        const uint32_t u = head[j] ? before : before - 1;
+        urank[e] = u;
+        if (head[j]) {
+            const int64_t o = (int64_t)((uint64_t)key[j] >> owner_shift);
+            const int64_t oprev = e == 0 ? -1 : (int64_t)((uint64_t)prev[j] >> owner_shift);
+            for (int64_t t = oprev + 1; t <= o; ++t) owner_base[t] = u;
+        }
+        if (e == n - 1) {
+            const int64_t ol = (int64_t)((uint64_t)key[j] >> owner_shift);
+            for (int64_t t = ol + 1; t <= world; ++t) owner_base[t] = u + 1;
+        }
+    }
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(NRX_BLOCK) void dedup_place_kernel(const KeyT* __restrict__ skeys, const uint32_t* __restrict__ spayload,
+                                                                const uint32_t* __restrict__ urank, const uint32_t* __restrict__ owner_base,
+                                                                int64_t n, int row_bits, int table_bits, int world, int n_tables,
+                                                                int64_t cap, int32_t* __restrict__ send_rows, int32_t* __restrict__ slot,
+                                                                int64_t* __restrict__ counts2d, int64_t* __restrict__ overflow) {
+    const int64_t e = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x;
+    if (e == 0) {
+        int64_t worst = 0;
+        for (int o = 0; o < world; ++o) {
+            const int64_t c = (int64_t)owner_base[o + 1] - (int64_t)owner_base[o];
+            worst = c > worst ? c : worst;
+        }
+        overflow[0] = worst;
+    }
+    if (e >= n) return;
+    const uint64_t key = (uint64_t)skeys[e];
+    const int o = (int)(key >> (table_bits + row_bits));
+    const int t = (int)((key >> row_bits) & ((1ull << table_bits) - 1));
+    const int64_t k = (int64_t)urank[e] - (int64_t)owner_base[o];
+    const bool head = e == 0 || skeys[e - 1] != skeys[e];
+    slot[spayload[e]] = k < cap ? (int32_t)(o * cap + k) : -1;
+    if (head) {
+        if (k < cap) send_rows[o * cap + k] = (int32_t)(key & ((1ull << row_bits) - 1));
+        atomicAdd((unsigned long long*)&counts2d[(int64_t)o * n_tables + t], 1ull);      // integer count: order-independent
+    }
+}
+
+// np.unique(return_inverse=True) on the device, for the ABI's integer utility: sorted distinct values and, for
+// every input element, the index of its value among them
+__global__ __launch_bounds__(NRX_BLOCK) void uinv_keys_kernel(const void* __restrict__ ids, int idx64, int64_t n, uint64_t* __restrict__ keys,
+                                                              uint32_t* __restrict__ payload) {
+    const int64_t p = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x;
+    if (p >= n) return;
+    const int64_t id = idx64 ? reinterpret_cast<const int64_t*>(ids)[p] : (int64_t)reinterpret_cast<const int32_t*>(ids)[p];
+    keys[p] = (uint64_t)id ^ 0x8000000000000000ull;          // order-preserving map of signed to unsigned
+    payload[p] = (uint32_t)p;
+}
+
+__global__ __launch_bounds__(NRX_BLOCK) void uinv_emit_kernel(const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ spayload,
+                                                              const uint32_t* __restrict__ urank, int64_t n, int64_t* __restrict__ unique_out,
+                                                              int64_t* __restrict__ inverse_out, int64_t* __restrict__ n_unique) {
+    const int64_t e = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t u = urank[e];
+    inverse_out[spayload[e]] = (int64_t)u;
+    if (e == 0 || skeys[e - 1] != skeys[e]) unique_out[u] = (int64_t)(skeys[e] ^ 0x8000000000000000ull);
+    if (e == n - 1) n_unique[0] = (int64_t)u + 1;
+}
+
+}  // namespace
+
+extern "C" int64_t nrx_route_dedup_workspace(int64_t n_total, int32_t world) {
+    if (n_total < 0 || n_total >= 0xffffffffLL || world < 1) return -1;
+    const size_t n = (size_t)(n_total > 0 ? n_total : 1);
+    const size_t t1 = sort_temp_bytes<uint64_t>(n, 64);
+    return (int64_t)(2 * align256(n * 8) + 2 * align256(n * 4) + 2 * align256(n * 4) + align256((size_t)(world + 2) * 4) + align256(t1) + 256);
+}
+
+extern "C" int nrx_route_ids_dedup(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* table_local_rows,
+                                   int32_t n_feats, int32_t n_tables, int32_t index_bits, int32_t world, int64_t cap,
+                                   int32_t* send_rows, int32_t* slot, int64_t* counts2d, int64_t* overflow, void* workspace,
+                                   void* stream) {
+    NRX_REQUIRE(ids && lens && table_of && table_local_rows && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES && n_tables >= 1 &&
+                    n_tables <= NRX_MAX_FEATURES, "nrx_route_ids_dedup: bad feature / table count");
+    NRX_REQUIRE(index_bits == 32 || index_bits == 64, "nrx_route_ids_dedup: index_bits must be 32 or 64");
+    NRX_REQUIRE(world >= 1 && world <= 64 && cap >= 1 && cap * world <= 0x7fffffffLL, "nrx_route_ids_dedup: bad world / cap");
+    NRX_REQUIRE(send_rows && counts2d && overflow && workspace, "nrx_route_ids_dedup: null buffer");
+    DedupArgs a;
+    int64_t off = 0, max_rows = 1;
+    for (int f = 0; f < n_feats; ++f) {
+        NRX_REQUIRE(lens[f] >= 0 && (lens[f] == 0 || ids[f] != nullptr) && table_of[f] >= 0 && table_of[f] < n_tables,
+                    "nrx_route_ids_dedup: feature %d: bad entry", f);
+        const int64_t lr = table_local_rows[table_of[f]];
+        NRX_REQUIRE(lr >= 0 && lr <= 0x7fffffffLL, "nrx_route_ids_dedup: table %d: bad local row count", table_of[f]);
+        a.ids[f] = ids[f];
+        a.off[f] = off;
+        a.local_rows[f] = lr;
+        a.table_of[f] = table_of[f];
+        off += lens[f];
+        if (lr + 1 > max_rows) max_rows = lr + 1;
+    }
+    a.off[n_feats] = off;
+    NRX_REQUIRE(off < 0x7fffffffLL, "nrx_route_ids_dedup: too many ids for one exchange");
+    NRX_REQUIRE(slot != nullptr || off == 0, "nrx_route_ids_dedup: null slot buffer");
+    a.n_feats = n_feats;
+    a.idx64 = index_bits == 64;
+    a.world = world;
+    a.row_bits = bits_for(max_rows);
+    a.table_bits = bits_for(n_tables);
+    a.n_total = off;
+    const int owner_bits = bits_for(world);
+    const int bits = owner_bits + a.table_bits + a.row_bits;
+    NRX_REQUIRE(bits <= 62, "nrx_route_ids_dedup: composite key too wide");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t n = off;
+    hipError_t err = hipMemsetAsync(counts2d, 0, sizeof(int64_t) * (size_t)world * n_tables, st);
+    if (err == hipSuccess && n == 0) err = hipMemsetAsync(overflow, 0, sizeof(int64_t), st);
+    if (err != hipSuccess) {
+        nrx_set_error("nrx_route_ids_dedup: memset failed: %s", hipGetErrorString(err));
+        return NRX_ERR_LAUNCH;
+    }
+    if (n == 0) return NRX_OK;
+    char* w = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    char* keys_in = w;                 w += align256((size_t)n * 8);
+    char* keys_out = w;                w += align256((size_t)n * 8);
+    uint32_t* pay_in = (uint32_t*)w;   w += align256((size_t)n * 4);
+    uint32_t* pay_out = (uint32_t*)w;  w += align256((size_t)n * 4);
+    uint32_t* heads = (uint32_t*)w;    w += align256((size_t)n * 4);
+    uint32_t* urank = (uint32_t*)w;    w += align256((size_t)n * 4);
+    uint32_t* obase = (uint32_t*)w;    w += align256((size_t)(world + 2) * 4);
+    void* temp = w;
+    int64_t g = (n + NRX_BLOCK - 1) / NRX_BLOCK;
+    const unsigned gfull = (unsigned)g, gtile = (unsigned)((n + PLAN_TILE - 1) / PLAN_TILE);
+    if (g > 4096) g = 4096;
+    size_t tb = 0;
+#define NRX_DD(KeyT)                                                                                                       \
+    {                                                                                                                      \
+        hipLaunchKernelGGL(dedup_keys_kernel<KeyT>, dim3((unsigned)g), dim3(NRX_BLOCK), 0, st, a, (KeyT*)keys_in, pay_in);  \
+        tb = sort_temp_bytes<KeyT>(n, bits);                                                                               \
+        err = rocprim::radix_sort_pairs(temp, tb, (const KeyT*)keys_in, (KeyT*)keys_out, (const uint32_t*)pay_in, pay_out,  \
+                                        (size_t)n, 0u, (unsigned)bits, st);                                                \
+        if (err == hipSuccess) {                                                                                           \
+            hipLaunchKernelGGL(plan_count_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out, n, heads); \
+            hipLaunchKernelGGL(dedup_rank_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out,          \
+                               (const uint32_t*)heads, n, a.table_bits + a.row_bits, world, urank, obase);                  \
+            hipLaunchKernelGGL(dedup_place_kernel<KeyT>, dim3(gfull), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out,         \
+                               (const uint32_t*)pay_out, (const uint32_t*)urank, (const uint32_t*)obase, n, a.row_bits,     \
+                               a.table_bits, world, n_tables, cap, send_rows, slot, counts2d, overflow);                    \
+        }                                                                                                                  \
+    }
+    if (bits <= 32) NRX_DD(uint32_t) else NRX_DD(uint64_t)
+#undef NRX_DD
+    if (err != hipSuccess) {
+        nrx_set_error("nrx_route_ids_dedup: rocPRIM call failed: %s", hipGetErrorString(err));
+        return NRX_ERR_LAUNCH;
+    }
+    NRX_LAUNCH_CHECK("nrx_route_ids_dedup");
+    return NRX_OK;
+}
+
+extern "C" int64_t nrx_unique_inverse_workspace(int64_t n) { return nrx_route_dedup_workspace(n, 1); }
+
+extern "C" int nrx_unique_inverse(const void* ids, int32_t index_bits, int64_t n, int64_t* unique_out, int64_t* inverse_out,
+                                  int64_t* n_unique, void* workspace, void* stream) {
+    NRX_REQUIRE((index_bits == 32 || index_bits == 64) && n >= 0 && n < 0x7fffffffLL, "nrx_unique_inverse: bad argument");
+    NRX_REQUIRE(n_unique != nullptr, "nrx_unique_inverse: null n_unique");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (n == 0) {
+        if (hipMemsetAsync(n_unique, 0, sizeof(int64_t), st) != hipSuccess) {
+            nrx_set_error("nrx_unique_inverse: memset failed");
+            return NRX_ERR_LAUNCH;
+        }
+        return NRX_OK;
+    }
+    NRX_REQUIRE(ids && unique_out && inverse_out && workspace, "nrx_unique_inverse: null buffer");
+    char* w = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    uint64_t* keys_in = (uint64_t*)w;  w += align256((size_t)n * 8);
+    uint64_t* keys_out = (uint64_t*)w; w += align256((size_t)n * 8);
+    uint32_t* pay_in = (uint32_t*)w;   w += align256((size_t)n * 4);
+    uint32_t* pay_out = (uint32_t*)w;  w += align256((size_t)n * 4);
+    uint32_t* heads = (uint32_t*)w;    w += align256((size_t)n * 4);
+    uint32_t* urank = (uint32_t*)w;    w += align256((size_t)n * 4);
+    uint32_t* obase = (uint32_t*)w;    w += align256((size_t)3 * 4);
+    void* temp = w;
+    const unsigned gfull = (unsigned)((n + NRX_BLOCK - 1) / NRX_BLOCK), gtile = (unsigned)((n + PLAN_TILE - 1) / PLAN_TILE);
+    hipLaunchKernelGGL(uinv_keys_kernel, dim3(gfull), dim3(NRX_BLOCK), 0, st, ids, (int)(index_bits == 64), n, keys_in, pay_in);
+    size_t tb = sort_temp_bytes<uint64_t>(n, 64);
+    hipError_t err = rocprim::radix_sort_pairs(temp, tb, (const uint64_t*)keys_in, keys_out, (const uint32_t*)pay_in, pay_out, (size_t)n,
+                                               0u, 64u, st);
+    if (err != hipSuccess) {
+        nrx_set_error("nrx_unique_inverse: rocPRIM call failed: %s", hipGetErrorString(err));
+        return NRX_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(plan_count_kernel<uint64_t>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const uint64_t*)keys_out, n, heads);
+    hipLaunchKernelGGL(dedup_rank_kernel<uint64_t>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const uint64_t*)keys_out, (const uint32_t*)heads, n,
+                       64 - 1, 1, urank, obase);      // owner_shift 63: one "owner" (bit 63 may be set: two bases are reserved)
+    hipLaunchKernelGGL(uinv_emit_kernel, dim3(gfull), dim3(NRX_BLOCK), 0, st, (const uint64_t*)keys_out, (const uint32_t*)pay_out,
+                       (const uint32_t*)urank, n, unique_out, inverse_out, n_unique);
+    NRX_LAUNCH_CHECK("nrx_unique_inverse");
+    return NRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Fused row-sparse Adam(W) on the unique rows the sorted backward produced.
 // Replaces, for the embedding tables only, the reference's dense AdamW over every row of every table
 // (configure_optimizers, src/model/sort/deep/model.py:54-65).  Semantics = torch.optim.SparseAdam (moments and

@@ -996,6 +996,51 @@ def route_ids(id_tensors: Sequence[torch.Tensor], world: int, cap: int):
     return send_rows, slot, counts2d, overflow
 
 
+def route_ids_dedup(id_tensors: Sequence[torch.Tensor], table_of: Sequence[int], table_local_rows: Sequence[int], world: int, cap: int):
+    """De-duplicated fixed-capacity routing (nrx_route_ids_dedup): every distinct (owner, table, row) is sent once.
+    Returns (send_rows int32 [world*cap], slot int32 [N], counts2d int64 [world, n_tables], overflow int64 [1])."""
+    lib = _lib.load()
+    n, nt = len(id_tensors), len(table_local_rows)
+    dt = id_tensors[0].dtype
+    if dt not in (torch.int64, torch.int32) or any(x.dtype != dt for x in id_tensors):
+        raise TypeError("route_ids_dedup: ids must share one integer dtype (int64 or int32)")
+    xs = [_dev(x, "ids") if x.is_contiguous() else x.contiguous() for x in id_tensors]
+    dev = xs[0].device
+    total = sum(x.numel() for x in xs)
+    send_rows = torch.empty(world * cap, dtype=torch.int32, device=dev)
+    slot = torch.empty(total, dtype=torch.int32, device=dev)
+    counts2d = torch.empty((world, nt), dtype=torch.int64, device=dev)
+    overflow = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(1, lib.nrx_route_dedup_workspace(total, world)), dtype=torch.uint8, device=dev)
+    ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    lens = (C.c_int64 * n)(*[x.numel() for x in xs])
+    tof = (C.c_int32 * n)(*[int(t) for t in table_of])
+    tlr = (C.c_int64 * nt)(*[int(r) for r in table_local_rows])
+    check(lib.nrx_route_ids_dedup(ptrs, lens, tof, tlr, n, nt, xs[0].element_size() * 8, world, cap, send_rows.data_ptr(),
+                                  slot.data_ptr(), counts2d.data_ptr(), overflow.data_ptr(), ws.data_ptr(), _stream_ptr(xs[0])),
+          "nrx_route_ids_dedup")
+    return send_rows, slot, counts2d, overflow
+
+
+def unique_inverse(ids: torch.Tensor):
+    """np.unique(ids, return_inverse=True) on the device (nrx_unique_inverse).  Returns (unique [n_unique] int64 ascending,
+    inverse [ids.shape] int64).  One host read (the count) to size the result."""
+    lib = _lib.load()
+    _dev(ids, "ids")
+    if ids.dtype not in (torch.int64, torch.int32):
+        ids = ids.long()
+    flat = ids.contiguous().view(-1)
+    n = flat.numel()
+    dev = flat.device
+    uniq = torch.empty(n, dtype=torch.int64, device=dev)
+    inv = torch.empty(n, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(1, lib.nrx_unique_inverse_workspace(n)), dtype=torch.uint8, device=dev)
+    check(lib.nrx_unique_inverse(_ptr(flat) if n else None, flat.element_size() * 8, n, uniq.data_ptr(), inv.data_ptr(), cnt.data_ptr(),
+                                 ws.data_ptr(), _stream_ptr(flat)), "nrx_unique_inverse")
+    return uniq[:int(cnt.item())], inv.view(ids.shape)
+
+
 def _inbox_common(tables, feat_table):
     dim = tables[0].shape[1]
     for t in tables:

@@ -85,6 +85,9 @@ class HipBackend:
     def route(self, id_tensors, world, cap):
         return ops.route_ids(id_tensors, world, cap)
 
+    def route_dedup(self, id_tensors, table_of, table_local_rows, world, cap):
+        return ops.route_ids_dedup(id_tensors, table_of, table_local_rows, world, cap)
+
     def gather_inbox(self, tables, feat_table, world, cap, recv2d, inbox, want_status):
         status = torch.zeros(4, dtype=torch.int32, device=inbox.device) if want_status else None
         return ops.gather_inbox(tables, feat_table, world, cap, recv2d, inbox, status), status
@@ -151,7 +154,8 @@ class RowShardedEmbedding:
     [local_row_count(rows), dim] (a leaf requiring grad when training)."""
 
     def __init__(self, rank: int, world: int, group=None, backend=None, mode: str = "capacity",
-                 slack: float = 0.05, overflow_policy: str = "check", host_staged: bool = False, pool_bags: bool = True):
+                 slack: float = 0.05, overflow_policy: str = "check", host_staged: bool = False, pool_bags: bool = True,
+                 dedup: bool = False):
         """mode: "capacity" (sync-free, default) or "exact".  overflow_policy (capacity mode):
         "check" = agree on overflow across ranks after each forward (one small all-reduce + host read)
         and transparently redo the step in exact mode; "defer" = never read back inside the step --
@@ -168,6 +172,9 @@ class RowShardedEmbedding:
         # pool_bags: row-sharded bag features are pooled AT THE OWNER (one partial vector per (sample, owner) comes back
         # instead of L rows per sample -- SURVEY 8e step 2).  Off: bags travel as rows like single-valued features.
         self.pool_bags = bool(pool_bags) and mode == "capacity"
+        # dedup: every distinct (owner, table, row) of an exchange travels once (nrx_route_ids_dedup; a sort per step: pays
+        # on skewed click-log ids, costs on uniform ones -- off by default)
+        self.dedup = bool(dedup) and mode == "capacity"
         self._overflow_marks: List[Tuple[torch.Tensor, int]] = []
 
     def plan_groups(self, feats: Sequence["ShardedFeature"]):
@@ -302,7 +309,12 @@ class RowShardedEmbedding:
         D = feats[idxs[0]].dim
         dev = inputs[idxs[0]].device
 
-        send_rows, slot, counts2d, overflow = self.backend.route(ids, W, cap)            # steps 1-3
+        if self.dedup:            # segments of an owner's block = tables (unique rows, ordered by table then row)
+            lrows = [tables[t].shape[0] + 1 for t in table_names]
+            send_rows, slot, counts2d, overflow = self.backend.route_dedup(ids, feat_table, lrows, W, cap)
+            feat_table = list(range(len(table_names)))
+        else:
+            send_rows, slot, counts2d, overflow = self.backend.route(ids, W, cap)        # steps 1-3
         recv2d = torch.empty_like(counts2d)
         self._a2a(recv2d.view(-1), counts2d.view(-1))                                   # equal splits
         inbox = torch.empty(W * cap, dtype=send_rows.dtype, device=dev)

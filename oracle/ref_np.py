@@ -507,6 +507,37 @@ def gather_inbox(tables, feat_table, world: int, cap: int, recv2d, inbox_rows, d
     return out
 
 
+def route_ids_dedup(id_arrays, table_of, table_local_rows, world: int, cap: int):
+    """Definition of nrx_route_ids_dedup: every distinct (owner, table, local row) is sent once; inside owner o's block
+    the unique rows are ordered by (table, row).  Ids that cannot be rows go to rank 0 as `table_local_rows[t]` (one past
+    the largest shard).  Returns (send_rows [world*cap] unused = -1, slot [N] (-1 on overflow), counts2d [world, n_tables],
+    largest block's unique count)."""
+    flat = [np.asarray(a, np.int64).reshape(-1) for a in id_arrays]
+    ids = np.concatenate(flat) if flat else np.zeros(0, np.int64)
+    tab = np.concatenate([np.full(a.size, table_of[f], np.int64) for f, a in enumerate(flat)]) if flat else ids
+    lr = np.asarray(table_local_rows, np.int64)[tab] if ids.size else ids
+    I32MAX = (1 << 31) - 1
+    bad = (ids < 0) | (ids > I32MAX)
+    owner = np.where(bad, 0, ids % world)
+    local = np.where(bad, lr, np.minimum(ids // world, lr))
+    nt = len(table_local_rows)
+    send = np.full(world * cap, -1, np.int64)
+    slot = np.full(ids.size, -1, np.int64)
+    counts2d = np.zeros((world, nt), np.int64)
+    worst = 0
+    for o in range(world):
+        pos = np.flatnonzero(owner == o)
+        keys = tab[pos] * (1 << 32) + local[pos]
+        uniq, inv = np.unique(keys, return_inverse=True)
+        worst = max(worst, uniq.size)
+        ok = inv < cap
+        slot[pos[ok]] = o * cap + inv[ok]
+        k = np.arange(uniq.size)
+        send[o * cap + k[k < cap]] = (uniq & ((1 << 32) - 1))[k < cap]
+        counts2d[o] = np.bincount(uniq >> 32, minlength=nt)
+    return send, slot, counts2d, worst
+
+
 def bag_norm_weights(mask, batch: int, bag_len: int, kind: str):
     """Definition of nrx_bag_norm_weights: pooling weights with the normalisation folded in.
     kind 'masked_mean': w / (sum_l w + 1e-8) (array_feature_pooling, base_model.py:278-282); 'mean': 1 / L (:275-276);

@@ -51,6 +51,10 @@ class CheckerBackend:
         return (torch.from_numpy(send), torch.from_numpy(slot), torch.from_numpy(counts2d),
                 torch.tensor([worst], dtype=torch.int64))
 
+    def route_dedup(self, id_tensors, table_of, table_local_rows, world, cap):
+        send, slot, counts2d, worst = R.route_ids_dedup([t.cpu().numpy() for t in id_tensors], table_of, table_local_rows, world, cap)
+        return (torch.from_numpy(send), torch.from_numpy(slot), torch.from_numpy(counts2d), torch.tensor([worst], dtype=torch.int64))
+
     def gather_inbox(self, tables, feat_table, world, cap, recv2d, inbox, want_status):
         status = torch.zeros(4, dtype=torch.int32)
         tabs = [t.detach().numpy() for t in tables]

@@ -730,6 +730,49 @@ def test_route_ids_bit_exact_vs_oracle(world, lens, cap, dtype):
     assert np.array_equal(send.cpu().numpy()[valid], r_send[valid])      # unused slots are unspecified
 
 
+@pytest.mark.parametrize("world,lens,tables,cap,hi", [(1, [100], [0], 100, 50), (2, [63, 1, 300], [0, 1, 0], 256, 40),
+                                                      (8, [4096, 4096, 5000, 17], [0, 1, 2, 1], 2048, 3000),
+                                                      (3, [0, 777, 0, 2050], [1, 0, 0, 1], 1024, 1 << 20), (4, [5000], [0], 64, 100000)])
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32])
+def test_route_ids_dedup_bit_exact_vs_oracle(world, lens, tables, cap, hi, dtype):
+    """Per-destination de-duplication (nrx_route_ids_dedup): unique (owner, table, row) lists, the slot of every lookup
+    (duplicates share one), per-(owner, table) counts and the overflow word, all equal to the definition; small id
+    ranges = heavy duplication, the last case overflows its blocks."""
+    rng = np.random.default_rng(sum(lens) + world)
+    arrays = [rng.integers(0, hi, n) for n in lens]
+    nt = max(tables) + 1
+    lrows = [(hi + world - 1) // world + 1] * nt
+    send, slot, c2, over = ops.route_ids_dedup([torch.from_numpy(a).to(DEV).to(dtype) for a in arrays], tables, lrows, world, cap)
+    r_send, r_slot, r_c2, r_worst = R.route_ids_dedup(arrays, tables, lrows, world, cap)
+    assert np.array_equal(c2.cpu().numpy(), r_c2) and int(over.item()) == r_worst
+    assert np.array_equal(slot.cpu().numpy(), r_slot)
+    valid = r_send >= 0
+    assert np.array_equal(send.cpu().numpy()[valid], r_send[valid])
+    # un-permute: the row a lookup gets back is the row it asked for
+    if r_worst <= cap and sum(lens):
+        ids = np.concatenate(arrays)
+        sl = slot.cpu().numpy()
+        got_local = send.cpu().numpy()[sl]
+        assert np.array_equal(got_local, ids // world) and np.array_equal(sl // cap, ids % world)
+
+
+def test_unique_inverse_matches_numpy():
+    """nrx_unique_inverse == np.unique(return_inverse=True): int64 incl. negatives and extremes, int32, empty, all-equal."""
+    rng = np.random.default_rng(5)
+    cases = [rng.integers(-50, 50, 10000), rng.integers(-2 ** 62, 2 ** 62, 5000), np.array([7] * 3000), np.zeros(0, np.int64),
+             np.array([np.iinfo(np.int64).min, np.iinfo(np.int64).max, 0, -1, np.iinfo(np.int64).max]), rng.integers(0, 1 << 20, 200003)]
+    for a in cases:
+        for dt in (torch.int64, torch.int32):
+            if dt == torch.int32 and a.size and (a.min() < -2 ** 31 or a.max() >= 2 ** 31):
+                continue
+            u, inv = ops.unique_inverse(torch.from_numpy(a).to(DEV).to(dt))
+            ru, rinv = np.unique(a, return_inverse=True)
+            assert np.array_equal(u.cpu().numpy(), ru) and np.array_equal(inv.cpu().numpy(), rinv.reshape(a.shape))
+    x = torch.randint(0, 100, (37, 5), device=DEV)
+    u, inv = ops.unique_inverse(x)
+    assert torch.equal(u[inv], x)
+
+
 @pytest.mark.parametrize("world,B,Ls,cap,dtype", [(1, 50, [7], 400, torch.int64), (2, 300, [9, 4], 2048, torch.int64),
                                                   (3, 1000, [50], 20000, torch.int32), (8, 513, [5, 5, 12], 2048, torch.int64),
                                                   (4, 200, [6], 64, torch.int64)])

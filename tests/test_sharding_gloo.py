@@ -74,7 +74,7 @@ def oracle_forward_and_grads(world):
     return outs, grads
 
 
-def _worker(rank, world, port, q, mode="capacity", slack=0.5, replicate=(), pool_bags=True):
+def _worker(rank, world, port, q, mode="capacity", slack=0.5, replicate=(), pool_bags=True, dedup=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -83,7 +83,7 @@ def _worker(rank, world, port, q, mode="capacity", slack=0.5, replicate=(), pool
         shards = {n: (torch.from_numpy(t).clone() if n in replicate else sharding.shard_table(torch.from_numpy(t), rank, world)
                       ).requires_grad_(True) for n, t in tabs.items()}
         feats = [ShardedFeature(f.name, f.kind, f.table, f.dim, f.bag_len, f.wide, f.fm, f.table in replicate) for f in FEATS]
-        eng = RowShardedEmbedding(rank, world, backend=CheckerBackend(), mode=mode, slack=slack, pool_bags=pool_bags)
+        eng = RowShardedEmbedding(rank, world, backend=CheckerBackend(), mode=mode, slack=slack, pool_bags=pool_bags, dedup=dedup)
         if slack < 0:          # force tiny blocks: every exchange overflows and must fall back to exact
             eng.capacity_for = lambda n: 8
         b = batch_for(rank)
@@ -106,19 +106,21 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,mode,slack,replicate,pool_bags",
-                         [(2, "capacity", 0.5, (), True), (3, "capacity", 0.5, (), True), (2, "capacity", 0.5, (), False),
-                          (2, "exact", 0.0, (), True), (2, "capacity", -1.0, (), True), (2, "capacity", 0.5, ("category",), True),
-                          (2, "exact", 0.0, ("category", "user_id"), True)])
-def test_row_sharded_forward_backward_over_gloo(world, mode, slack, replicate, pool_bags):
+@pytest.mark.parametrize("world,mode,slack,replicate,pool_bags,dedup",
+                         [(2, "capacity", 0.5, (), True, False), (3, "capacity", 0.5, (), True, False), (2, "capacity", 0.5, (), False, False),
+                          (2, "exact", 0.0, (), True, False), (2, "capacity", -1.0, (), True, False),
+                          (2, "capacity", 0.5, ("category",), True, False), (2, "exact", 0.0, ("category", "user_id"), True, False),
+                          (3, "capacity", 0.5, (), True, True), (2, "capacity", 0.5, (), False, True), (2, "capacity", -1.0, (), False, True)])
+def test_row_sharded_forward_backward_over_gloo(world, mode, slack, replicate, pool_bags, dedup):
     """capacity = sync-free fixed blocks; exact = variable splits; slack -1 = capacity forced to
     overflow, which must be detected on every rank and redone exactly.  pool_bags: the row-sharded bag features
     (user_click_cats: plain mean, user_history: masked mean) are pooled AT THE OWNER and come back as one partial
-    vector per (sample, owner) -- stated tolerance for pooled columns rtol 1e-6."""
+    vector per (sample, owner) -- stated tolerance for pooled columns rtol 1e-6.  dedup: per-destination de-duplication
+    (every distinct (owner, table, row) travels once; duplicates share a slot) -- routed copies stay bit-exact."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, slack, replicate, pool_bags)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, slack, replicate, pool_bags, dedup)) for r in range(world)]
     for p in procs:
         p.start()
     results = {}

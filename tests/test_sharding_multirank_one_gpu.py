@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _worker(rank, world, port, q, mode, slack, replicate, prepared):
+def _worker(rank, world, port, q, mode, slack, replicate, prepared, dedup=False, pool_bags=True):
     import os
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -29,7 +29,7 @@ def _worker(rank, world, port, q, mode, slack, replicate, prepared):
                       ).to(DEV).requires_grad_(True) for n, t in tabs.items()}
         feats = [ShardedFeature(f.name, f.kind, f.table, f.dim, f.bag_len, f.wide, f.fm, f.table in replicate) for f in FEATS]
         eng = RowShardedEmbedding(rank, world, mode=mode, slack=slack, host_staged=True,
-                                  overflow_policy="defer" if prepared else "check")
+                                  overflow_policy="defer" if prepared else "check", dedup=dedup, pool_bags=pool_bags)
         if slack < 0:
             eng.capacity_for = lambda n: 64
         b = batch_for(rank)
@@ -52,11 +52,11 @@ def _worker(rank, world, port, q, mode, slack, replicate, prepared):
         dist.destroy_process_group()
 
 
-def _run(world, mode, slack, replicate, prepared):
+def _run(world, mode, slack, replicate, prepared, dedup=False, pool_bags=True):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, slack, replicate, prepared)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, slack, replicate, prepared, dedup, pool_bags)) for r in range(world)]
     for p in procs:
         p.start()
     results = {}
@@ -80,10 +80,14 @@ def _check_outputs(results, world):
     return want_grads
 
 
-@pytest.mark.parametrize("world,mode,slack,replicate", [(2, "capacity", 0.5, ()), (3, "capacity", 0.5, ()), (2, "exact", 0.0, ()),
-                                                        (2, "capacity", -1.0, ()), (2, "capacity", 0.5, ("category",))])
-def test_hip_backend_forward_backward_with_several_ranks(world, mode, slack, replicate):
-    results = _run(world, mode, slack, replicate, prepared=False)
+@pytest.mark.parametrize("world,mode,slack,replicate,dedup,pool_bags",
+                         [(2, "capacity", 0.5, (), False, True), (3, "capacity", 0.5, (), False, True), (2, "exact", 0.0, (), False, True),
+                          (2, "capacity", -1.0, (), False, True), (2, "capacity", 0.5, ("category",), False, True),
+                          (2, "capacity", 0.5, (), False, False),        # bags travel as rows (pool at the source)
+                          (3, "capacity", 0.5, (), True, True),          # per-destination dedup + owner-side pooling
+                          (2, "capacity", 0.5, (), True, False)])        # dedup of bag lookups too
+def test_hip_backend_forward_backward_with_several_ranks(world, mode, slack, replicate, dedup, pool_bags):
+    results = _run(world, mode, slack, replicate, prepared=False, dedup=dedup, pool_bags=pool_bags)
     want_grads = _check_outputs(results, world)
     for r in range(world):
         for n, g in results[r][1].items():
