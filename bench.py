@@ -11,10 +11,13 @@ Default workload = BASELINE.json configs[1] ("c2": DeepFM-shaped, 26 sparse x 1M
 uniform ids): gather -> [B,416] concat + fused FM logit.  A fresh id batch (from a pool of 8) is used
 every step so no step re-reads the previous step's rows from cache.
 
-N > 1: every rank owns B=65536 impressions (weak scaling).  Table layout = planner (default): tables of
-at most 256 MiB are replicated, larger ones are row-sharded (row r on rank r % N) with RCCL all-to-all id
-routing + row return (news_recsys_amd/sharding.py); `--shard-mode row` shards every table.  The layout
-that is not the headline is measured too with --measure-other-layout and reported under "other_layout".  Rank 0 prints ONE JSON line.
+N > 1: every rank owns B=65536 impressions (weak scaling; `value`).  Two table layouts, BOTH timed by default:
+"row" = every table row-sharded (row r on rank r % N) with RCCL all-to-all id routing + row return / owner-side
+pooling (news_recsys_amd/sharding.py) -- the headline for c4 / c5; "auto" = planner: tables of at most 256 MiB are
+replicated, larger ones row-sharded -- the headline for c2 / c3 (their tables are small or few).  The other layout
+goes under "other_layout"; "strong_scaling" re-times the headline layout with the global batch fixed at 65536; "a2a"
+times the row-return all-to-all alone (GB/s per rank and per xGMI link).  A watchdog prints the headline line if a
+secondary leg stalls.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -337,15 +340,16 @@ def main():
     ap.add_argument("--ids", default="uniform", choices=["uniform", "zipf"],
                     help="id distribution: uniform (headline, cache-hostile) or Zipf(1.05) popularity (MIND-like); N=1 only")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded engine even at N=1 (testing)")
-    ap.add_argument("--shard-mode", default="auto", choices=["row", "auto"],
-                    help="N>1 headline layout: 'auto' = planner (tables <= 256 MiB replicated, larger ones row-sharded "
-                         "with RCCL all-to-all); 'row' = every table row-sharded.  The other layout is measured too and "
-                         "reported as a secondary field.")
-    ap.add_argument("--measure-other-layout", action="store_true",
-                    help="N>1: after the headline run, also time the other table layout (secondary field `other_layout`). Off by "
-                         "default: the all-row-sharded exchange could not be exercised on real multi-GPU hardware while this "
-                         "was written, and a fault there must not cost the headline line.")
+    ap.add_argument("--shard-mode", default="default", choices=["default", "row", "auto"],
+                    help="N>1 headline layout: 'row' = every table row-sharded; 'auto' = planner (tables <= 256 MiB replicated, "
+                         "larger ones row-sharded); 'default' = row for c4 / c5, auto for c2 / c3.  The other layout is timed "
+                         "too (field `other_layout`).")
+    ap.add_argument("--secondary-timeout", type=float, default=240.0,
+                    help="N>1: seconds the secondary legs (other layout, strong scaling, a2a probe) may take before the "
+                         "headline line is printed without them")
     args = ap.parse_args()
+    if args.shard_mode == "default":
+        args.shard_mode = "row" if args.workload in ("c4", "c5") else "auto"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -492,22 +496,10 @@ def main():
 
     if hasattr(path, "overflowed") and path.overflowed():
         raise SystemExit("fixed-capacity exchange overflowed: rerun with a larger slack (ids too skewed)")
-    planner = None
-    if world > 1 and args.measure_other_layout:
-        # secondary measurement (never the headline `value`): the OTHER table layout, same workload, same K steps
-        other = "row" if args.shard_mode == "auto" else "auto"
-        del path
-        torch.cuda.empty_cache()
-        from news_recsys_amd.sharding import ShardedBenchPath
-        p2 = ShardedBenchPath(args.workload, device, seed, rank, world, BATCH, other, host_staged=staged)
-        dt2, k2 = timed(p2.step)
-        if p2.overflowed():
-            raise SystemExit("fixed-capacity exchange overflowed in the secondary measurement")
-        planner = {"layout_mode": other, "value": BATCH * world * args.steps / dt2, "unit": "impressions/s",
-                   "ms_per_step": dt2 * 1e3 / args.steps, "layout": p2.desc,
-                   "note": "secondary measurement of the other table layout; xGMI is point-to-point (one ~153 GB/s link per "
-                           "GPU pair), so the all-row-sharded row return is per-link bound, worst at N=2"}
-    if rank == 0:
+    planner = strong = a2a = None
+    secondary_note = None
+    emitted = {"done": False}
+    def _build_line():
         total_impr = BATCH * world * args.steps
         ms_per_step = dt * 1e3 / args.steps
         achieved = bytes_per_impr * BATCH / (kern_ms * 1e-3) / 1e9
@@ -543,8 +535,6 @@ def main():
                                  "the timed region on the launch stream / steps); traffic = DRAM bytes per launch from "
                                  "the committed rocprofv3 PMC passes (profiles/traffic.json), null if not profiled"},
         }
-        if planner is not None:
-            out["other_layout"] = planner
         if distinct is not None:
             out["distinct_output_buffers"] = distinct
         if fwd_bwd is not None:
@@ -562,11 +552,82 @@ def main():
                                        "hbm_gib": round(info["global_mem_bytes"] / 2 ** 30, 1)}
         except Exception:
             pass
+        return out
+    base_line = _build_line() if rank == 0 else None      # everything of the headline, before any secondary leg runs
+
+    def _print_line(note):
+        out = base_line
+        if planner is not None:
+            out["other_layout"] = planner
+        if strong is not None:
+            out["strong_scaling"] = strong
+        if a2a is not None:
+            out["a2a"] = a2a
+        if note or secondary_note:
+            out["secondary_note"] = note or secondary_note
         line = json.dumps(out)
         print(line, flush=True)
         if os.environ.get("NRX_BENCH_OUT"):
             with open(os.environ["NRX_BENCH_OUT"], "a") as f:
                 f.write(line + "\n")
+
+
+    def emit(note=None):
+        if emitted["done"]:
+            return
+        emitted["done"] = True
+        if rank == 0:
+            _print_line(note)
+
+    if world > 1 and not args.headline_only:
+        # secondary legs (never the headline `value`).  None of the multi-rank collectives below could be exercised on real
+        # xGMI while this was written: a watchdog prints the headline line and leaves if they stall
+        import threading
+
+        def on_timeout():
+            emit(f"secondary legs did not finish within {args.secondary_timeout:.0f} s: headline only")
+            os._exit(0)
+
+        dog = threading.Timer(args.secondary_timeout, on_timeout)
+        dog.daemon = True
+        dog.start()
+        from news_recsys_amd.sharding import ShardedBenchPath
+        try:
+            probe = path.a2a_probe(min(args.steps, 50)) if hasattr(path, "a2a_probe") else None
+            if probe is not None:
+                t = torch.tensor([probe["ms"]], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms = t.item()
+                remote = probe["bytes"] * (world - 1) / world
+                a2a = {"bytes_per_rank_per_step": probe["bytes"], "ms": ms, "GBps_per_rank": remote / (ms * 1e-3) / 1e9,
+                       "GBps_per_link": remote / (world - 1) / (ms * 1e-3) / 1e9,
+                       "note": "the return all-to-all(s) of the row-sharded exchange alone (equal splits, max over ranks); "
+                               "per link = remote bytes / (N-1) point-to-point xGMI links"}
+            del path
+            torch.cuda.empty_cache()
+            bs = BATCH // world
+            p3 = ShardedBenchPath(args.workload, device, seed, rank, world, bs, args.shard_mode, host_staged=staged)
+            dt3, _ = timed(p3.step)
+            if not p3.overflowed():
+                strong = {"value": bs * world * args.steps / dt3, "unit": "impressions/s", "ms_per_step": dt3 * 1e3 / args.steps,
+                          "global_batch": bs * world, "batch_per_gpu": bs, "layout_mode": args.shard_mode,
+                          "note": "strong scaling: the global batch stays 65536, every rank takes 65536 / N of it"}
+            del p3
+            torch.cuda.empty_cache()
+            other = "row" if args.shard_mode == "auto" else "auto"
+            p2 = ShardedBenchPath(args.workload, device, seed, rank, world, BATCH, other, host_staged=staged)
+            dt2, _ = timed(p2.step)
+            if not p2.overflowed():
+                planner = {"layout_mode": other, "value": BATCH * world * args.steps / dt2, "unit": "impressions/s",
+                           "ms_per_step": dt2 * 1e3 / args.steps, "layout": p2.desc,
+                           "note": "the other table layout, same workload and steps; xGMI is point-to-point (one ~153 GB/s link "
+                                   "per GPU pair), so an all-row-sharded row return is per-link bound, worst at N=2"}
+            del p2
+        except Exception as e:          # noqa: BLE001 -- a failed secondary leg must not cost the headline
+            secondary_note = f"a secondary leg failed: {type(e).__name__}: {e}"
+        dog.cancel()
+
+    emit()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -811,3 +811,24 @@ class ShardedBenchPath:
 
     def overflowed(self) -> bool:
         return any(c.overflowed() for c in self.calls)
+
+    def a2a_probe(self, steps: int):
+        """Times the RETURN all-to-all(s) of one bound forward alone (rows / partial sums coming back from the owners):
+        {"bytes": bytes received per rank per step, "ms": mean per step}, or None when nothing is row-sharded."""
+        groups = self.calls[0].groups
+        if not groups or self.world == 1:
+            return None
+        pairs = [(g["ret"], g["partial"] if g.get("pooled") else g["rows_out"]) for g in groups]
+        nbytes = sum(r.numel() * r.element_size() for r, _ in pairs)
+        for _ in range(3):
+            for r, src in pairs:
+                self.eng._a2a(r.view(-1), src.view(-1))
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(steps):
+            for r, src in pairs:
+                self.eng._a2a(r.view(-1), src.view(-1))
+        b.record()
+        torch.cuda.synchronize()
+        return {"bytes": nbytes, "ms": a.elapsed_time(b) / steps}
