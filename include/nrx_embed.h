@@ -227,12 +227,22 @@ NRX_API int nrx_embed_dcn_v1_fwd(const nrx_feature_t* feats, int32_t n_feats, in
 /* ---- DCN v2 cross layer on the matrix cores: out = act(x0 * (x_l W^T + bias) + x_l) -----------
  * DCNv2Layer.forward + the ReLU DCNv2Net puts after every layer (dcn_arch.py:33-50, 73-91).
  * W: device [dim, dim] (nn.Linear weight: out x in), bias [dim].  fp32 in / fp32 accumulate on
- * v_mfma_f32_32x32x2_f32 (exact f32 fma chain).  relu: 1 = apply ReLU (reference), 0 = none.    */
+ * v_mfma_f32_32x32x2_f32 (exact f32 fma chain).  relu: 1 = apply ReLU (reference), 0 = none.
+ * lin_out (optional, [batch, ld]): x_l W^T + bias before the Hadamard -- what the backward needs (training).      */
 NRX_API int nrx_dcn_v2_layer_fwd(const float* x0, const float* xl, int64_t ld, int64_t batch, int32_t dim,
                          const float* W, const float* bias, int32_t relu, float* out,
-                         int64_t out_ld, void* stream);
-/* (The v2 backward is two plain GEMMs + elementwise work; the host composes it from library
- * GEMMs -- rocBLAS via torch.matmul -- see news_recsys_amd/ops.py.)                             */
+                         int64_t out_ld, float* lin_out, void* stream);
+/* Backward of one DCN-v2 layer on the matrix cores (autograd of dcn_arch.py:39-50 + the ReLU of :80):
+ *   gm = g_out * (out > 0) [relu] ;  glin = gm * x0 ;  g_x0 (+)= gm * lin ;  g_b = sum_rows glin ;
+ *   g_xl = gm + glin W   (MFMA dgrad) ;  g_W = glin^T x_l   (MFMA wgrad, split over the batch, fp32 atomics).
+ * lin: the forward's lin_out; out: the forward's output (ReLU mask; may be NULL when relu == 0).  g_x0 is overwritten,
+ * or accumulated into when accumulate_x0 != 0 (x0 feeds every layer).  g_W [dim, dim] and g_b [dim] are overwritten.
+ * workspace: nrx_dcn_v2_layer_bwd_workspace(batch, dim) device bytes.                                           */
+NRX_API int64_t nrx_dcn_v2_layer_bwd_workspace(int64_t batch, int32_t dim);
+NRX_API int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld, const float* lin, const float* out, int32_t relu,
+                         int64_t batch, int32_t dim, const float* W, const float* g_out, int64_t g_ld,
+                         float* g_xl, int64_t gxl_ld, float* g_x0, int64_t gx0_ld, int32_t accumulate_x0,
+                         float* g_W, float* g_b, void* workspace, void* stream);
 
 /* ---- integer utilities of the row-sharded path (bit-exact vs the CPU definitions) -------------
  * Row r of a table lives on rank r % world at local row r / world.                              */

@@ -43,7 +43,8 @@ __device__ __forceinline__ float4 guarded_load4(const float* base, int64_t row, 
 template <bool RELU, bool VEC>
 __global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __restrict__ x0, const float* __restrict__ xl, int64_t ld,
                                                            int64_t M, int N, const float* __restrict__ W, const float* __restrict__ bias,
-                                                           float* __restrict__ out, int64_t out_ld, unsigned nx) {
+                                                           float* __restrict__ out, int64_t out_ld, unsigned nx,
+                                                           float* __restrict__ lin_out) {
     __shared__ float As[BK * LDA];
     __shared__ float Ws[BK * LDW];
     const int K = N;
@@ -188,7 +189,10 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __res
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2);
-                        float v = fmaf(x0v[r], acc[t][r] + bc, xv[r]);
+                        const float lin = acc[t][r] + bc;
+                        if (lin_out != nullptr)      // training: the backward needs x_l W^T + b (wave-uniform branch)
+                            *reinterpret_cast<float*>(reinterpret_cast<char*>(lin_out + row * ld) + lo) = lin;
+                        float v = fmaf(x0v[r], lin, xv[r]);
                         if (RELU) v = fmaxf(v, 0.f);
                         *reinterpret_cast<float*>(reinterpret_cast<char*>(out + row * out_ld) + lo_o) = v;
                     }
@@ -204,7 +208,9 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __res
                     if (row < M) {
                         const float xv = xl[row * ld + col];
                         const float x0v = same_x ? xv : x0[row * ld + col];     // layer 0: x0 is x_l, one load
-                        float v = fmaf(x0v, acc[t][r] + bc, xv);
+                        const float lin = acc[t][r] + bc;
+                        if (lin_out != nullptr) lin_out[row * ld + col] = lin;
+                        float v = fmaf(x0v, lin, xv);
                         if (RELU) v = fmaxf(v, 0.f);
                         out[row * out_ld + col] = v;
                     }
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __res
 
 extern "C" int nrx_dcn_v2_layer_fwd(const float* x0, const float* xl, int64_t ld, int64_t batch, int32_t dim,
                                     const float* W, const float* bias, int32_t relu, float* out,
-                                    int64_t out_ld, void* stream) {
+                                    int64_t out_ld, float* lin_out, void* stream) {
     NRX_REQUIRE(x0 && xl && W && bias && out && batch >= 0 && dim >= 1 && ld >= dim && out_ld >= dim,
                 "nrx_dcn_v2_layer_fwd: bad argument");
     NRX_REQUIRE(out != xl && out != x0, "nrx_dcn_v2_layer_fwd: out must not alias the inputs");
@@ -229,7 +235,7 @@ extern "C" int nrx_dcn_v2_layer_fwd(const float* x0, const float* xl, int64_t ld
     NRX_REQUIRE(nblocks <= 0x7fffffffLL, "nrx_dcn_v2_layer_fwd: batch too large for one launch");
     dim3 grid((unsigned)nblocks);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define NRX_DCN2(R_, V_) hipLaunchKernelGGL((dcn_v2_layer_kernel<R_, V_>), grid, dim3(256), 0, st, x0, xl, ld, batch, dim, W, bias, out, out_ld, nx)
+#define NRX_DCN2(R_, V_) hipLaunchKernelGGL((dcn_v2_layer_kernel<R_, V_>), grid, dim3(256), 0, st, x0, xl, ld, batch, dim, W, bias, out, out_ld, nx, lin_out)
     if (relu) { if (vec) NRX_DCN2(true, true); else NRX_DCN2(true, false); }
     else      { if (vec) NRX_DCN2(false, true); else NRX_DCN2(false, false); }
 #undef NRX_DCN2

@@ -1,0 +1,352 @@
+// Backward of the DCN-v2 cross layer on the CDNA4 matrix cores (fp32 in / fp32 accumulate).
+// Reference arithmetic: autograd of DCNv2Layer.forward + the ReLU DCNv2Net puts after it
+// (src/model/sort/dcn/dcn_arch.py:33-50, 73-91):   out = act(x0 * lin + xl),  lin = xl W^T + b.
+// Given g = dL/dout (gm = g where out > 0 with ReLU, else g):
+//     glin = gm * x0                 g_x0 += gm * lin                 g_b = sum_rows glin
+//     g_xl = gm + glin W             (dgrad:  [B, D] x [D, D])
+//     g_W  = glin^T xl               (wgrad:  [D, B] x [B, D], the batch is the contraction)
+// Three launches per layer:
+//   dcn_v2_bwd_prep_kernel   elementwise: gm, glin, g_x0 accumulation, column sums of glin (HBM-bound)
+//   dcn2_gemm_kernel<DGRAD>  g_xl = gm + glin W: the forward kernel's tiling (128 x 64 block tile, 4 waves x two 32x32
+//                            accumulators sharing a B fragment, K in slabs of 32 through LDS, register prefetch); the B
+//                            operand W is read K-major (its rows are the contraction index), so its slab lands in LDS
+//                            without a transpose
+//   dcn2_gemm_kernel<WGRAD>  g_W += glin^T xl: both operands K-major (a batch row is contiguous over the output index),
+//                            split over the batch: every block owns one 128 x 64 tile of g_W and a slice of the batch and
+//                            adds its partial tile with fp32 atomics (g_W pre-zeroed; D*D outputs x ~40 slices)
+// The forward saves lin when asked (nrx_dcn_v2_layer_fwd's lin_out): one extra [B, D] write instead of a third GEMM here.
+#include "nrx_common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int TM = 2;
+constexpr int BM = 2 * TM * 32, BN = 64, BK = 32;      // 128 x 64 block tile, K slabs of 32
+constexpr int LDA = BM + 1, LDW = BN + 1;
+
+enum { DGRAD = 0, WGRAD = 1 };
+
+// ---- elementwise preparation ------------------------------------------------------------------------------------
+// glin = gm * x0 (the GEMMs' operand), g_x0 (+)= gm * lin, g_b = column sums of glin; gm itself is not materialised (the
+// dgrad epilogue rebuilds it from g and out).  TPR = 2^TPRLOG2 threads cover one row (4 columns each), a block covers
+// 256 / TPR rows per pass and U passes are in flight (HBM-bound streaming: 4 reads + 2 writes of [B, D]); a thread keeps
+// its 4 column sums in registers across all its rows, then one atomic per column per block.
+template <int TPRLOG2, bool VEC>
+__global__ __launch_bounds__(NRX_BLOCK) void dcn_v2_bwd_prep_kernel(const float* __restrict__ g, int64_t g_ld, const float* __restrict__ out,
+                                                                  const float* __restrict__ x0, const float* __restrict__ lin,
+                                                                  int64_t ld, int64_t M, int D, int relu,
+                                                                  float* __restrict__ glin, int64_t w_ld, float* __restrict__ g_x0,
+                                                                  int64_t gx0_ld, int accumulate_x0, float* __restrict__ g_b) {
+    constexpr int TPR = 1 << TPRLOG2, RPB = NRX_BLOCK / TPR, U = 4;
+    const int c = (threadIdx.x & (TPR - 1)) * 4;
+    const int rsub = threadIdx.x >> TPRLOG2;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    {                                                   // D <= 4 TPR (the launch picks TPR; dims up to 1024)
+        const int cc = c;
+        const bool full = VEC && cc + 4 <= D;
+        if (cc < D)
+        for (int64_t r0 = (int64_t)blockIdx.x * RPB * U + rsub; r0 < M; r0 += (int64_t)gridDim.x * RPB * U) {
+            float4 gv[U], xv[U], lv[U], ov[U], ax[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = r0 + (int64_t)u * RPB;
+                const int64_t rc = r < M ? r : M - 1;
+                if (full) {
+                    gv[u] = *reinterpret_cast<const float4*>(g + rc * g_ld + cc);
+                    xv[u] = *reinterpret_cast<const float4*>(x0 + rc * ld + cc);
+                    lv[u] = *reinterpret_cast<const float4*>(lin + rc * ld + cc);
+                    ov[u] = relu ? *reinterpret_cast<const float4*>(out + rc * ld + cc) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    ax[u] = accumulate_x0 ? *reinterpret_cast<const float4*>(g_x0 + rc * gx0_ld + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    float t[5][4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool in = cc + j < D;
+                        t[0][j] = in ? g[rc * g_ld + cc + j] : 0.f;
+                        t[1][j] = in ? x0[rc * ld + cc + j] : 0.f;
+                        t[2][j] = in ? lin[rc * ld + cc + j] : 0.f;
+                        t[3][j] = (in && relu) ? out[rc * ld + cc + j] : 1.f;
+                        t[4][j] = (in && accumulate_x0) ? g_x0[rc * gx0_ld + cc + j] : 0.f;
+                    }
+                    gv[u] = make_float4(t[0][0], t[0][1], t[0][2], t[0][3]); xv[u] = make_float4(t[1][0], t[1][1], t[1][2], t[1][3]);
+                    lv[u] = make_float4(t[2][0], t[2][1], t[2][2], t[2][3]); ov[u] = make_float4(t[3][0], t[3][1], t[3][2], t[3][3]);
+                    ax[u] = make_float4(t[4][0], t[4][1], t[4][2], t[4][3]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = r0 + (int64_t)u * RPB;
+                if (r >= M) continue;
+                float4 m_;
+                m_.x = (relu && !(ov[u].x > 0.f)) ? 0.f : gv[u].x; m_.y = (relu && !(ov[u].y > 0.f)) ? 0.f : gv[u].y;
+                m_.z = (relu && !(ov[u].z > 0.f)) ? 0.f : gv[u].z; m_.w = (relu && !(ov[u].w > 0.f)) ? 0.f : gv[u].w;
+                const float4 gl = make_float4(m_.x * xv[u].x, m_.y * xv[u].y, m_.z * xv[u].z, m_.w * xv[u].w);
+                const float4 gx = make_float4(fmaf(m_.x, lv[u].x, ax[u].x), fmaf(m_.y, lv[u].y, ax[u].y), fmaf(m_.z, lv[u].z, ax[u].z),
+                                              fmaf(m_.w, lv[u].w, ax[u].w));
+                bs[0] += gl.x; bs[1] += gl.y; bs[2] += gl.z; bs[3] += gl.w;
+                if (full) {
+                    *reinterpret_cast<float4*>(glin + r * w_ld + cc) = gl;
+                    *reinterpret_cast<float4*>(g_x0 + r * gx0_ld + cc) = gx;
+                } else {
+                    const float gla[4] = {gl.x, gl.y, gl.z, gl.w}, gxa[4] = {gx.x, gx.y, gx.z, gx.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (cc + j < D) { glin[r * w_ld + cc + j] = gla[j]; g_x0[r * gx0_ld + cc + j] = gxa[j]; }
+                }
+            }
+        }
+    }
+    // column sums: the RPB row-lanes of a column meet in LDS, then ONE device atomic per column per block (same-address
+    // device atomics serialise: one per thread made this kernel 8x slower)
+    __shared__ float s_b[NRX_BLOCK * 4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s_b[(rsub * TPR + (threadIdx.x & (TPR - 1))) * 4 + j] = bs[j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < TPR * 4; i += NRX_BLOCK) {
+        float t = 0.f;
+        for (int r = 0; r < RPB; ++r) t += s_b[r * TPR * 4 + i];
+        if (i < D) unsafeAtomicAdd(g_b + i, t);
+    }
+}
+
+// ---- the GEMM ----------------------------------------------------------------------------------------------------
+// C[m, n] = sum_k A(m, k) B(k, n) over k in [kbeg, kend).
+//   DGRAD: A(m, k) = glin[m * lda + k]   (M-major rows, transposed into LDS like the forward's x slab)
+//          B(k, n) = W[k * ldb + n]      (K-major: copied straight)           epilogue: out[m, n] = gm[m, n] + C
+//   WGRAD: A(m, k) = glin[k * lda + m]   (K-major)     B(k, n) = xl[k * ldb + n]  (K-major)   epilogue: atomicAdd(out[m, n], C)
+// M, N, K are the GEMM's own dims (DGRAD: batch, D, D;  WGRAD: D, D, batch).  Rows / columns past M / N are clamped on
+// load (their products land in accumulator rows / columns that are never stored); a partial last K slab is zero-filled.
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                         int64_t M, int N, int64_t K, int64_t kslice, const float* __restrict__ addend,
+                                                         int64_t add_ld, const float* __restrict__ mask, int64_t mask_ld,
+                                                         float* __restrict__ out, int64_t out_ld, unsigned nx, unsigned ntiles) {
+    __shared__ float As[BK * LDA];
+    __shared__ float Ws[BK * LDW];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    // tile id (XCD-aware bijective remap as in the forward: the nx column tiles of one row panel share an L2) and K slice
+    const unsigned tile_lin = blockIdx.x % ntiles, ks = blockIdx.x / ntiles;
+    const unsigned xcd = tile_lin & 7u, qd = ntiles >> 3, rm = ntiles & 7u;
+    const unsigned logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (tile_lin >> 3);
+    const int64_t m0 = (int64_t)(logical / nx) * BM;
+    const int n0 = (int)(logical % nx) * BN;
+    const int64_t kbeg = (int64_t)ks * kslice;
+    const int64_t kend = kbeg + kslice < K ? kbeg + kslice : K;
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    constexpr int AP = BM / 32;           // float4 per thread of the A slab (4), B slab: 2
+    float4 a[AP], w[2];
+    auto zero4 = [] { return make_float4(0.f, 0.f, 0.f, 0.f); };
+    auto ld4 = [&](const float* p, bool full) -> float4 {        // p valid for >= 1 element
+        if (VEC) return *reinterpret_cast<const float4*>(p);
+        (void)full;
+        return make_float4(p[0], 0.f, 0.f, 0.f);
+    };
+    auto load_slab = [&](int64_t k0) {
+        if (MODE == DGRAD) {
+            // A M-major: thread (row = tid >> 3 (+32p), kq = (tid & 7) * 4): float4 along k
+            const int srow = tid >> 3, skq = (tid & 7) * 4;
+#pragma unroll
+            for (int p = 0; p < AP; ++p) {
+                int64_t r = m0 + srow + 32 * p;
+                r = r < M ? r : M - 1;
+                const int64_t k = k0 + skq;
+                if (VEC) a[p] = k + 4 <= kend ? *reinterpret_cast<const float4*>(A + r * lda + k) : zero4();
+                else {
+                    a[p].x = k < kend ? A[r * lda + k] : 0.f; a[p].y = k + 1 < kend ? A[r * lda + k + 1] : 0.f;
+                    a[p].z = k + 2 < kend ? A[r * lda + k + 2] : 0.f; a[p].w = k + 3 < kend ? A[r * lda + k + 3] : 0.f;
+                }
+            }
+        } else {
+            // A K-major: thread (k = tid >> 3 (0..31), m4 = (tid & 7) + 8p): float4 along m
+            const int kk = tid >> 3;
+            const int64_t k = k0 + kk;
+#pragma unroll
+            for (int p = 0; p < AP; ++p) {
+                const int64_t m = m0 + 4 * ((tid & 7) + 8 * p);
+                if (k < kend) {
+                    if (VEC && m + 4 <= M) a[p] = *reinterpret_cast<const float4*>(A + k * lda + m);
+                    else {
+                        a[p].x = m < M ? A[k * lda + m] : 0.f; a[p].y = m + 1 < M ? A[k * lda + m + 1] : 0.f;
+                        a[p].z = m + 2 < M ? A[k * lda + m + 2] : 0.f; a[p].w = m + 3 < M ? A[k * lda + m + 3] : 0.f;
+                    }
+                } else a[p] = zero4();
+            }
+        }
+        {   // B K-major in both modes: thread (k = tid >> 3, n4 = (tid & 7) + 8p), p < 2
+            const int kk = tid >> 3;
+            const int64_t k = k0 + kk;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int n = n0 + 4 * ((tid & 7) + 8 * p);
+                if (k < kend) {
+                    if (VEC && n + 4 <= N) w[p] = *reinterpret_cast<const float4*>(B + k * ldb + n);
+                    else {
+                        w[p].x = n < N ? B[k * ldb + n] : 0.f; w[p].y = n + 1 < N ? B[k * ldb + n + 1] : 0.f;
+                        w[p].z = n + 2 < N ? B[k * ldb + n + 2] : 0.f; w[p].w = n + 3 < N ? B[k * ldb + n + 3] : 0.f;
+                    }
+                } else w[p] = zero4();
+            }
+        }
+    };
+    (void)ld4;
+    if (kbeg < kend) load_slab(kbeg);
+
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+        if (MODE == DGRAD) {
+            const int srow = tid >> 3, skq = (tid & 7) * 4;
+#pragma unroll
+            for (int p = 0; p < AP; ++p) {
+                const int m = srow + 32 * p;
+                As[(skq + 0) * LDA + m] = a[p].x;
+                As[(skq + 1) * LDA + m] = a[p].y;
+                As[(skq + 2) * LDA + m] = a[p].z;
+                As[(skq + 3) * LDA + m] = a[p].w;
+            }
+        } else {
+            const int kk = tid >> 3;
+#pragma unroll
+            for (int p = 0; p < AP; ++p) {
+                const int m = 4 * ((tid & 7) + 8 * p);
+                As[kk * LDA + m + 0] = a[p].x;
+                As[kk * LDA + m + 1] = a[p].y;
+                As[kk * LDA + m + 2] = a[p].z;
+                As[kk * LDA + m + 3] = a[p].w;
+            }
+        }
+        {
+            const int kk = tid >> 3;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int n = 4 * ((tid & 7) + 8 * p);
+                Ws[kk * LDW + n + 0] = w[p].x;
+                Ws[kk * LDW + n + 1] = w[p].y;
+                Ws[kk * LDW + n + 2] = w[p].z;
+                Ws[kk * LDW + n + 3] = w[p].w;
+            }
+        }
+        __syncthreads();
+        if (k0 + BK < kend) load_slab(k0 + BK);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float fb[BK / 4], fa[TM][BK / 4];
+#pragma unroll
+            for (int i = 0; i < BK / 4; ++i) {
+                const int kr = 2 * (h * (BK / 4) + i) + hi;
+                fb[i] = Ws[kr * LDW + wn * 32 + l31];
+#pragma unroll
+                for (int t = 0; t < TM; ++t) fa[t][i] = As[kr * LDA + wm * (32 * TM) + 32 * t + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < BK / 4; ++i)
+#pragma unroll
+                for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][i], fb[i], acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const int col = n0 + wn * 32 + l31;
+    if (col >= N) return;
+    const int64_t r0 = m0 + wm * (32 * TM);
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (row < M) {
+                if (MODE == DGRAD) {        // g_xl = gm + glin W, gm = g (x) [forward output > 0] rebuilt here
+                    float gmv = addend[row * add_ld + col];
+                    if (mask != nullptr && !(mask[row * mask_ld + col] > 0.f)) gmv = 0.f;
+                    out[row * out_ld + col] = gmv + acc[t][r];
+                } else {
+                    unsafeAtomicAdd(out + row * out_ld + col, acc[t][r]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t nrx_dcn_v2_layer_bwd_workspace(int64_t batch, int32_t dim) {
+    if (batch < 0 || dim < 1) return -1;
+    const int64_t ld = (dim + 3) & ~3;
+    return batch * ld * (int64_t)sizeof(float) + 256;          // glin [batch, ld]
+}
+
+extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld, const float* lin, const float* out, int32_t relu,
+                                    int64_t batch, int32_t dim, const float* W, const float* g_out, int64_t g_ld,
+                                    float* g_xl, int64_t gxl_ld, float* g_x0, int64_t gx0_ld, int32_t accumulate_x0,
+                                    float* g_W, float* g_b, void* workspace, void* stream) {
+    NRX_REQUIRE(x0 && xl && lin && W && g_out && g_xl && g_x0 && g_W && g_b && workspace && batch >= 0 && dim >= 1 && ld >= dim,
+                "nrx_dcn_v2_layer_bwd: bad argument");
+    NRX_REQUIRE(!relu || out != nullptr, "nrx_dcn_v2_layer_bwd: the ReLU mask needs the layer's forward output");
+    NRX_REQUIRE(g_ld >= dim && gxl_ld >= dim && gx0_ld >= dim, "nrx_dcn_v2_layer_bwd: bad leading dimension");
+    NRX_REQUIRE(g_xl != g_out, "nrx_dcn_v2_layer_bwd: g_xl must not alias g_out");
+    NRX_REQUIRE(dim <= 1024, "nrx_dcn_v2_layer_bwd: dim %d > 1024 unsupported", dim);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(g_W, 0, sizeof(float) * (size_t)dim * dim, st);
+    if (e == hipSuccess) e = hipMemsetAsync(g_b, 0, sizeof(float) * (size_t)dim, st);
+    if (e != hipSuccess) {
+        nrx_set_error("nrx_dcn_v2_layer_bwd: memset failed: %s", hipGetErrorString(e));
+        return NRX_ERR_LAUNCH;
+    }
+    if (batch == 0) return NRX_OK;
+    const int64_t wld = (dim + 3) & ~3;
+    float* glin = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const bool vec = (dim & 3) == 0 && (ld & 3) == 0 && (g_ld & 3) == 0 && (gx0_ld & 3) == 0 && (gxl_ld & 3) == 0 && nrx_aligned16(x0) &&
+                     nrx_aligned16(xl) && nrx_aligned16(lin) && nrx_aligned16(g_out) && nrx_aligned16(g_x0) && nrx_aligned16(g_xl) &&
+                     nrx_aligned16(W) && (out == nullptr || nrx_aligned16(out));
+    {
+        int tl = 2;                                   // threads per row = 2^tl >= dim / 4 (<= 256)
+        while ((4 << tl) < dim && tl < 8) ++tl;
+        const int rpb = NRX_BLOCK >> tl;
+        int64_t grid = (batch + rpb * 4 - 1) / (rpb * 4);
+        if (grid > 512) grid = 512;
+#define NRX_PREP(TL_)                                                                                                              \
+    case TL_:                                                                                                                      \
+        if (vec) hipLaunchKernelGGL((dcn_v2_bwd_prep_kernel<TL_, true>), dim3((unsigned)grid), dim3(NRX_BLOCK), 0, st, g_out, g_ld, out,  \
+                                    x0, lin, ld, batch, dim, relu, glin, wld, g_x0, gx0_ld, accumulate_x0, g_b);                  \
+        else hipLaunchKernelGGL((dcn_v2_bwd_prep_kernel<TL_, false>), dim3((unsigned)grid), dim3(NRX_BLOCK), 0, st, g_out, g_ld, out,    \
+                                x0, lin, ld, batch, dim, relu, glin, wld, g_x0, gx0_ld, accumulate_x0, g_b);                      \
+        break;
+        switch (tl) { NRX_PREP(2) NRX_PREP(3) NRX_PREP(4) NRX_PREP(5) NRX_PREP(6) NRX_PREP(7) default: NRX_PREP(8) }
+#undef NRX_PREP
+    }
+    const float* mask = relu ? out : nullptr;
+    {   // dgrad: g_xl = gm + glin W        (M = batch, N = K = dim; B operand = W rows, K-major)
+        const unsigned nx = (unsigned)((dim + BN - 1) / BN);
+        const int64_t nt = (int64_t)nx * ((batch + BM - 1) / BM);
+        NRX_REQUIRE(nt <= 0x7fffffffLL, "nrx_dcn_v2_layer_bwd: batch too large for one launch");
+        if (vec) hipLaunchKernelGGL((dcn2_gemm_kernel<DGRAD, true>), dim3((unsigned)nt), dim3(256), 0, st, glin, wld, W, (int64_t)dim, batch,
+                                    dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, ld, g_xl, gxl_ld, nx, (unsigned)nt);
+        else hipLaunchKernelGGL((dcn2_gemm_kernel<DGRAD, false>), dim3((unsigned)nt), dim3(256), 0, st, glin, wld, W, (int64_t)dim, batch,
+                                dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, ld, g_xl, gxl_ld, nx, (unsigned)nt);
+    }
+    {   // wgrad: g_W[i, j] += sum_b glin[b, i] xl[b, j]   (M = N = dim, K = batch, split over the batch)
+        const unsigned nx = (unsigned)((dim + BN - 1) / BN);
+        const unsigned nt = nx * (unsigned)((dim + BM - 1) / BM);
+        int64_t splits = (1024 + nt - 1) / nt;                          // ~1024 blocks on 256 CUs
+        int64_t kslice = ((batch + splits - 1) / splits + BK - 1) / BK * BK;
+        if (kslice < BK) kslice = BK;
+        splits = (batch + kslice - 1) / kslice;
+        if (vec) hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, true>), dim3((unsigned)(nt * splits)), dim3(256), 0, st, glin, wld, xl, ld,
+                                    (int64_t)dim, dim, batch, kslice, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0,
+                                    g_W, (int64_t)dim, nx, nt);
+        else hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, false>), dim3((unsigned)(nt * splits)), dim3(256), 0, st, glin, wld, xl, ld,
+                                (int64_t)dim, dim, batch, kslice, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0,
+                                g_W, (int64_t)dim, nx, nt);
+    }
+    NRX_LAUNCH_CHECK("nrx_dcn_v2_layer_bwd");
+    return NRX_OK;
+}

@@ -804,6 +804,21 @@ def embed_dcn_v1(plan: EmbedPlan, tables, inputs, w: torch.Tensor, b: torch.Tens
 
 
 # ------------------------------------------------------------------------------- DCN v2 (MFMA)
+def _dcn_v2_layer_backward(lib, x0, xl, lin, out, relu, W, g, g_x0, accumulate):
+    """One layer of the hand-written backward (nrx_dcn_v2_layer_bwd: elementwise prep + MFMA dgrad + MFMA wgrad).
+    Returns (g_xl, g_W, g_b); g_x0 is written / accumulated in place."""
+    B, D = xl.shape
+    g = _f32c(g, "grad")
+    g_xl = torch.empty_like(xl)
+    gW = torch.empty((D, D), dtype=torch.float32, device=xl.device)
+    gb = torch.empty((D,), dtype=torch.float32, device=xl.device)
+    ws = torch.empty(max(1, lib.nrx_dcn_v2_layer_bwd_workspace(B, D)), dtype=torch.uint8, device=xl.device)
+    check(lib.nrx_dcn_v2_layer_bwd(x0.data_ptr(), xl.data_ptr(), D, lin.data_ptr(), _ptr(out), 1 if relu else 0, B, D, W.data_ptr(),
+                                   g.data_ptr(), D, g_xl.data_ptr(), D, g_x0.data_ptr(), D, 1 if accumulate else 0, gW.data_ptr(),
+                                   gb.data_ptr(), ws.data_ptr(), _stream_ptr(xl)), "nrx_dcn_v2_layer_bwd")
+    return g_xl, gW, gb
+
+
 class _DcnV2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, relu):
@@ -815,36 +830,35 @@ class _DcnV2Fn(torch.autograd.Function):
         n = W.shape[0]
         if tuple(W.shape) != (n, D, D) or tuple(b.shape) != (n, D):
             raise ValueError("W must be [n_layers, dim, dim] and b [n_layers, dim]")
-        xs = [x]
+        train = any(ctx.needs_input_grad[:3])       # (grad mode is off inside forward: ask the node, not torch.is_grad_enabled)
+        xs, lins = [x], []
         stream = _stream_ptr(x)
         for l in range(n):
             out = torch.empty_like(x)
+            lin = torch.empty_like(x) if train else None      # x_l W^T + b, saved for the backward (one extra write, no GEMM later)
             check(lib.nrx_dcn_v2_layer_fwd(x.data_ptr(), xs[-1].data_ptr(), D, B, D, W[l].data_ptr(), b[l].data_ptr(),
-                                           1 if relu else 0, out.data_ptr(), D, stream), "nrx_dcn_v2_layer_fwd")
+                                           1 if relu else 0, out.data_ptr(), D, _ptr(lin), stream), "nrx_dcn_v2_layer_fwd")
             xs.append(out)
-        ctx.save_for_backward(W, b, *xs)
-        ctx.relu = relu
+            lins.append(lin)
+        ctx.save_for_backward(W, *xs, *[t for t in lins if t is not None])
+        ctx.relu, ctx.n, ctx.train = relu, n, train
         return xs[-1]
 
     @staticmethod
     def backward(ctx, g):
-        # Two plain GEMMs per layer (library GEMMs via torch.matmul = rocBLAS/hipBLASLt) + elementwise.
-        W, b, *xs = ctx.saved_tensors
+        lib = _lib.load()
+        n = ctx.n
+        W, *rest = ctx.saved_tensors
+        xs, lins = rest[:n + 1], rest[n + 1:]
+        if len(lins) != n:
+            raise RuntimeError("dcn_v2 backward: the forward ran without gradients enabled")
         x0 = xs[0]
-        n = W.shape[0]
-        g = g.contiguous()
-        gx0 = torch.zeros_like(x0)
+        gx0 = torch.empty_like(x0)
         gW = torch.empty_like(W)
-        gb = torch.empty_like(b)
+        gb = torch.empty((n, W.shape[1]), dtype=torch.float32, device=W.device)
+        g = g.contiguous()
         for l in reversed(range(n)):
-            if ctx.relu:
-                g = g * (xs[l + 1] > 0)
-            lin = torch.addmm(b[l], xs[l], W[l].t())
-            glin = g * x0
-            gx0 += g * lin
-            gW[l] = glin.t() @ xs[l]
-            gb[l] = glin.sum(dim=0)
-            g = g + glin @ W[l]
+            g, gW[l], gb[l] = _dcn_v2_layer_backward(lib, x0, xs[l], lins[l], xs[l + 1], ctx.relu, W[l], g, gx0, accumulate=l != n - 1)
         return g + gx0, gW, gb, None
 
 
@@ -857,21 +871,23 @@ class _DcnV2LayerFn(torch.autograd.Function):
         if x0.shape != xl.shape or tuple(W.shape) != (D, D) or tuple(b.shape) != (D,):
             raise ValueError("x0/xl must be [B, dim], W [dim, dim], b [dim]")
         out = torch.empty_like(xl)
+        train = any(ctx.needs_input_grad[:4])
+        lin = torch.empty_like(xl) if train else None
         check(lib.nrx_dcn_v2_layer_fwd(x0.data_ptr(), xl.data_ptr(), D, B, D, W.data_ptr(), b.data_ptr(),
-                                       1 if relu else 0, out.data_ptr(), D, _stream_ptr(xl)), "nrx_dcn_v2_layer_fwd")
-        ctx.save_for_backward(x0, xl, W, b, out)
+                                       1 if relu else 0, out.data_ptr(), D, _ptr(lin), _stream_ptr(xl)), "nrx_dcn_v2_layer_fwd")
+        ctx.save_for_backward(x0, xl, W, out, *((lin,) if train else ()))
         ctx.relu = relu
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x0, xl, W, b, out = ctx.saved_tensors
-        g = g.contiguous()
-        if ctx.relu:
-            g = g * (out > 0)
-        lin = torch.addmm(b, xl, W.t())
-        glin = g * x0
-        return g * lin, g + glin @ W, glin.t() @ xl, glin.sum(dim=0), None
+        lib = _lib.load()
+        x0, xl, W, out, *rest = ctx.saved_tensors
+        if not rest:
+            raise RuntimeError("dcn_v2_layer backward: the forward ran without gradients enabled")
+        gx0 = torch.empty_like(x0)
+        g_xl, gW, gb = _dcn_v2_layer_backward(lib, x0, xl, rest[0], out, ctx.relu, W, g, gx0, accumulate=False)
+        return gx0, g_xl, gW, gb, None
 
 
 def dcn_v2_layer(x0: torch.Tensor, xl: torch.Tensor, W: torch.Tensor, b: torch.Tensor, relu: bool = False) -> torch.Tensor:

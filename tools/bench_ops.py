@@ -30,6 +30,20 @@ if want("dcn_v2"):
             us_ref = timeit(lambda: torch.relu(x * torch.addmm(b[0], x, W[0].t()) + x))
         fl = 2.0 * B * D * D + 3.0 * B * D
         print(f"dcn_v2 fwd  D={D:4d}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s ({fl / us / 1e6 / 157.3 * 100:5.1f}% of 157.3 fp32-matrix peak)   [rocBLAS+eltwise: {us_ref:8.1f} us]", flush=True)
+        # backward of one layer: hand-written (prep + MFMA dgrad + MFMA wgrad) vs the torch composition it replaced (3 library
+        # GEMMs incl. the lin recompute + elementwise)
+        xg = x.clone().requires_grad_(True); Wg = W.clone().requires_grad_(True); bg = b.clone().requires_grad_(True)
+        out = ops.dcn_v2(xg, Wg, bg); up = torch.randn_like(out)
+        us_b = timeit(lambda: torch.autograd.grad(out, (xg, Wg, bg), up, retain_graph=True), steps=20)
+        def torch_bwd():
+            g = up * (out > 0)
+            lin = torch.addmm(bg[0], xg, Wg[0].t())
+            glin = g * xg
+            return g * lin + g + glin @ Wg[0], glin.t() @ xg, glin.sum(0)
+        with torch.no_grad():
+            us_t = timeit(torch_bwd, steps=20)
+        flb = 4.0 * B * D * D
+        print(f"dcn_v2 bwd  D={D:4d}: {us_b:8.1f} us  {flb / us_b / 1e6:7.1f} TFLOP/s of its two GEMMs ({flb / us_b / 1e6 / 157.3 * 100:5.1f}% of peak)   [torch composition: {us_t:8.1f} us]", flush=True)
 if want("dcn_v1"):
     for D, NL in ((320, 2), (320, 3), (112, 3)):
         x = torch.randn(B, D, device=dev); w = torch.randn(NL, D, device=dev) / D ** 0.5; b = torch.zeros(NL, D, device=dev)
