@@ -54,6 +54,9 @@ class BaseModel(LightningModule):
         self.save_hyperparameters(to_container(self.config))
         self.feature_id_mapper = None
         self._plan_cache: Dict[tuple, Tuple[ops.EmbedPlan, List[str], List[int], List[str]]] = {}
+        self._embed_cache: Dict[tuple, tuple] = {}
+        self._first_table: Dict[tuple, str] = {}
+        self._none_lists: Dict[int, list] = {}
 
     # ------------------------------------------------------------------ config (base_model.py:69-139)
     def _load_config(self, config_path: str) -> None:
@@ -82,6 +85,14 @@ class BaseModel(LightningModule):
         sg = e.get("sparse_grad", False)
         self.sparse_grad = "fused" if str(sg).lower() == "fused" else bool(sg)
         self._sparse_sink = None
+        # new optional key: how an out-of-range id surfaces on the fused batch path (get_embeddings_from_batch / forward).
+        # "deferred" (default): no device synchronisation -- the kernel records the offence in a host-mapped status word
+        # and the NEXT call (or ops.flush_index_checks(), called at the end of every validation epoch) raises IndexError;
+        # "sync": IndexError in the offending call, as torch does on CPU (one device sync per call); "off": never checked.
+        # get_feature_embedding (the per-feature reference API) always raises in the offending call.
+        self.index_check = str(e.get("index_check", "deferred")).lower()
+        if self.index_check not in ("deferred", "sync", "lazy", "off"):
+            raise ValueError("embeddings.index_check must be 'deferred', 'sync', 'lazy' or 'off'")
 
         self.dataset_cfg = self.config.get("dataset", {}) or {}
         self.train_hparams = self.config.get("train_hparams", {}) or {}
@@ -148,7 +159,7 @@ class BaseModel(LightningModule):
         D = weight.shape[1]
         flat = feature_value.reshape(-1)
         plan = ops.EmbedPlan([ops.Slot(feature_name, NRX_SPARSE, 0, D, 0, 0)], out_width=D)
-        out = ops.embed_apply(plan, [weight], [flat], [None])[0]
+        out = ops.embed_apply(plan, [weight], [flat], [None], index_check="sync")[0]
         return out.view(*feature_value.shape, D)
 
     def array_feature_pooling(self, embedding: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -206,20 +217,49 @@ class BaseModel(LightningModule):
 
     def _embed(self, batch: Dict[str, torch.Tensor], feature_names, fm: bool = False, wide_names: Sequence[str] = (),
                out_ld: Optional[int] = None, need_out: bool = True):
-        """One fused launch.  Returns (out | None, wide | None, fm | None, dims, names)."""
-        plan, table_names, dims, present = self._plan(batch, feature_names, fm, wide_names)
-        if not present:
-            return None, None, None, [], []
-        tables = [self.embedding_tables[t].weight for t in table_names]
-        inputs = [batch[s.name] for s in plan.slots]
-        weights = [batch.get(f"{s.name}_mask") if s.kind == NRX_BAG_MASKED_MEAN else None for s in plan.slots]
+        """One fused launch.  Returns (out | None, wide | None, fm | None, dims, names).
+        Host cost: the plan, the table list and the input key lists are cached per (feature set, batch keys) -- a call is
+        two dict lookups + one list comprehension over the batch before ops.embed_apply (profiles/r02_host_overhead.txt)."""
+        ck = (frozenset(feature_names), tuple(batch), bool(fm), tuple(wide_names))
+        ent = self._embed_cache.get(ck)
+        if ent is not None:
+            plan, tables, in_names, mask_names, bag_lens, dims, present = ent
+            for n, L in bag_lens:                       # array features: the padded length is part of the plan
+                if batch[n].shape[1] != L:
+                    ent = None
+                    break
+            if ent is not None and tables and tables[0] is not self.embedding_tables[self._first_table[ck]].weight:
+                ent = None                              # the tables were replaced (e.g. shard_model_): rebuild
+        if ent is None:
+            plan, table_names, dims, present = self._plan(batch, feature_names, fm, wide_names)
+            if not present:
+                return None, None, None, [], []
+            tables = [self.embedding_tables[t].weight for t in table_names]
+            in_names = [s.name for s in plan.slots]
+            mask_names = [f"{s.name}_mask" if s.kind == NRX_BAG_MASKED_MEAN else None for s in plan.slots]
+            bag_lens = [(s.name, s.bag_len) for s in plan.slots if s.kind in (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN)]
+            any_mask = any(m is not None for m in mask_names)
+            ent = (plan, tables, in_names, mask_names if any_mask else None, bag_lens, list(dims), list(present))
+            if table_names:
+                self._first_table[ck] = table_names[0]
+            self._embed_cache[ck] = ent
+            mask_names = ent[3]
+        inputs = [batch[n] for n in in_names]
+        weights = self._no_weights(len(in_names)) if mask_names is None else [None if m is None else batch.get(m) for m in mask_names]
         sg = self.sparse_grad
         if sg == "fused":
             if self._sparse_sink is None:
                 self._sparse_sink = ops.SparseGradSink()
             sg = self._sparse_sink if torch.is_grad_enabled() else False
-        out, wide, fmv = ops.embed_apply(plan, tables, inputs, weights, out_ld=out_ld, need_out=need_out, sparse_grad=sg)
+        out, wide, fmv = ops.embed_apply(plan, tables, inputs, weights, out_ld=out_ld, need_out=need_out, sparse_grad=sg,
+                                         index_check=self.index_check)
         return out, wide, fmv, list(dims), list(present)
+
+    def _no_weights(self, n: int):
+        w = self._none_lists.get(n)
+        if w is None:
+            w = self._none_lists[n] = [None] * n
+        return w
 
     def get_embeddings_from_batch(self, batch: Dict[str, torch.Tensor], feature_names) -> Tuple[torch.Tensor, List[int], List[str]]:
         """(features [B, sum D], dims, names) for `sorted(feature_names)` present in the batch."""
@@ -266,6 +306,7 @@ class BaseModel(LightningModule):
         self._val_uid, self._val_score, self._val_label = [], [], []
         warm = getattr(self, "user_in_train_set", None)
         warm_ids = [int(u) for u in warm if str(u).lstrip("-").isdigit()] if warm else None
+        ops.flush_index_checks()           # an out-of-range id of the epoch's deferred checks surfaces here at the latest
         results = ranking_metrics(uid, sc, lb, warm_ids, k=10)
         msg = format_val_log(results, getattr(self, "current_epoch", 0), k=10)
         print(msg)

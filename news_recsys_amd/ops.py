@@ -26,16 +26,42 @@ from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NR
                    NrxFeature, NrxFmGrad, check)
 
 # ------------------------------------------------------------------------------- helpers
-_INDEX_CHECK = "sync"      # "sync": raise IndexError in the offending call (reference behaviour on CPU)
-                           # "lazy": checked at the next call / flush_index_checks(); "off": never read back
+_INDEX_CHECK = "sync"      # "sync": raise IndexError in the offending call (reference behaviour on CPU; one device sync per call)
+                           # "deferred": no sync, no copies -- the kernels record an offence in a host-mapped status word that
+                           #             the NEXT call (and flush_index_checks()) reads as plain host memory
+                           # "lazy": device status + event per call, checked once the event has passed; "off": never read back
 _pending_status: List[Tuple[torch.Tensor, "torch.cuda.Event", Sequence[str]]] = []
+_host_status: Optional[torch.Tensor] = None       # pinned int32[4] the GPU writes through its mapped address
+_host_status_names: Sequence[str] = ()
 
 
 def set_index_check(mode: str) -> None:
     global _INDEX_CHECK
-    if mode not in ("sync", "lazy", "off"):
-        raise ValueError("index check mode must be 'sync', 'lazy' or 'off'")
+    if mode not in ("sync", "deferred", "lazy", "off"):
+        raise ValueError("index check mode must be 'sync', 'deferred', 'lazy' or 'off'")
     _INDEX_CHECK = mode
+
+
+def _deferred_status(names: Sequence[str]) -> torch.Tensor:
+    """The process-wide host-mapped status word of the 'deferred' mode.  An offence recorded by an EARLIER launch raises
+    here (IndexError, one call late instead of never); the word is only ever written by a kernel that met a bad id, so
+    the check is a read of four host integers."""
+    global _host_status, _host_status_names
+    if _host_status is None:
+        _host_status = torch.zeros(4, dtype=torch.int32).pin_memory()
+    elif _host_status[0] != 0:
+        _raise_deferred()
+    _host_status_names = names
+    return _host_status
+
+
+def _raise_deferred() -> None:
+    st = _host_status.tolist()
+    _host_status.zero_()
+    names = _host_status_names
+    fname = names[st[1]] if 0 <= st[1] < len(names) else f"#{st[1]}"
+    raise IndexError(f"index out of range in self (reported by an earlier launch): {st[0]} lookup(s); first: feature "
+                     f"'{fname}', sample {st[2]}, id {st[3]}")
 
 
 def _raise_if_oob(status: torch.Tensor, names: Sequence[str]) -> None:
@@ -47,7 +73,11 @@ def _raise_if_oob(status: torch.Tensor, names: Sequence[str]) -> None:
 
 
 def flush_index_checks() -> None:
-    """Raise IndexError for any out-of-range id seen by earlier 'lazy' calls."""
+    """Raise IndexError for any out-of-range id seen by earlier 'lazy' / 'deferred' calls (synchronises the device)."""
+    if _host_status is not None:
+        torch.cuda.synchronize()
+        if _host_status[0] != 0:
+            _raise_deferred()
     while _pending_status:
         status, ev, names = _pending_status.pop(0)
         ev.synchronize()
@@ -187,8 +217,9 @@ def _prep_inputs(plan: EmbedPlan, tables, inputs, weights):
 
 class _EmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan: EmbedPlan, inputs, weights, out_ld, need_out, sparse_grad, *tables):
+    def forward(ctx, plan: EmbedPlan, inputs, weights, out_ld, need_out, sparse_grad, index_check, *tables):
         lib = _lib.load()
+        mode = index_check or _INDEX_CHECK
         ctx.sink = sparse_grad if isinstance(sparse_grad, SparseGradSink) else None
         ctx.sparse_grad = bool(sparse_grad)
         ctx.tables = list(tables) if ctx.sink is not None else None
@@ -200,7 +231,10 @@ class _EmbedFn(torch.autograd.Function):
         out = torch.empty((B, ld), dtype=torch.float32, device=dev) if need_out else None
         wide = torch.empty((B, plan.wide_width), dtype=torch.float32, device=dev) if plan.wide_width else None
         fm = torch.empty((B,), dtype=torch.float32, device=dev) if plan.use_fm else None
-        status = torch.zeros(4, dtype=torch.int32, device=dev) if _INDEX_CHECK != "off" else None
+        if mode == "deferred":
+            status = _deferred_status(plan.names)
+        else:
+            status = torch.zeros(4, dtype=torch.int32, device=dev) if mode != "off" else None
         stream = _stream_ptr(ins[0])
         n = len(plan.slots)
         single = n <= NRX_MAX_FEATURES
@@ -220,8 +254,8 @@ class _EmbedFn(torch.autograd.Function):
                 # > 64 FM fields: the cross-field sums cannot be split over launches; run FM on the concat
                 d0 = plan.slots[0].dim
                 check(lib.nrx_fm_fwd(out.data_ptr(), ld, n, d0, B, fm.data_ptr(), stream), "nrx_fm_fwd")
-        if status is not None:
-            if _INDEX_CHECK == "sync":
+        if status is not None and mode != "deferred":
+            if mode == "sync":
                 _raise_if_oob(status, plan.names)
             else:
                 ev = torch.cuda.Event()
@@ -249,7 +283,7 @@ class _EmbedFn(torch.autograd.Function):
         plan, B, ld = ctx.plan, ctx.B, ctx.ld
         n_tables = len(ctx.table_meta)
         if g_out is None and g_wide is None and g_fm is None:
-            return (None,) * (6 + n_tables)
+            return (None,) * (7 + n_tables)
         dev = ctx.table_meta[0][1]
         stream = torch.cuda.current_stream(dev).cuda_stream
         if g_out is not None:
@@ -273,9 +307,9 @@ class _EmbedFn(torch.autograd.Function):
             g_wide = _f32c(g_wide, "grad of wide_x")
         if ctx.sink is not None:
             _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg)      # results go to the sink, not to .grad
-            return (None,) * (6 + n_tables)
+            return (None,) * (7 + n_tables)
         if ctx.sparse_grad:
-            return (None, None, None, None, None, None, *_sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg))
+            return (None, None, None, None, None, None, None, *_sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg))
         grads = [torch.zeros(shape, dtype=torch.float32, device=d) for shape, d in ctx.table_meta]
         if B > 0 and (g_out is not None or g_wide is not None or fmg is not None):
             gptrs = [g.data_ptr() for g in grads]
@@ -285,7 +319,7 @@ class _EmbedFn(torch.autograd.Function):
                 arr = _fill_features(plan, lo, hi, grads, ctx.ins, ctx.ws, table_ptrs=gptrs, cache_key="bwd")
                 check(lib.nrx_embed_bwd(arr, hi - lo, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, fmg, stream),
                       "nrx_embed_bwd")
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 class SparseGradSink:
@@ -400,17 +434,140 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
     return grads
 
 
+_FEATURE_DTYPE = None
+
+
+def _feature_np_dtype():
+    """numpy view of struct nrx_feature (64 bytes): lets a call refresh the pointer columns of a cached descriptor array
+    with one vectorised assignment instead of 26 ctypes field stores."""
+    global _FEATURE_DTYPE
+    if _FEATURE_DTYPE is None:
+        import numpy as np
+        _FEATURE_DTYPE = np.dtype([("table", "<u8"), ("index", "<u8"), ("weight", "<u8"), ("rows", "<i8"), ("dim", "<i4"),
+                                   ("bag_len", "<i4"), ("kind", "<i4"), ("index_bits", "<i4"), ("out_col", "<i4"), ("wide_col", "<i4"),
+                                   ("fm_field", "<i4"), ("flags", "<i4")])
+        assert _FEATURE_DTYPE.itemsize == C.sizeof(NrxFeature)
+    return _FEATURE_DTYPE
+
+
+class _FastForward:
+    """Inference / no-grad form of embed_apply for plans of <= 64 features: the descriptor array lives on the plan with
+    its static fields filled once; a call validates the inputs in ONE pass, refreshes the pointer columns through a numpy
+    view and enqueues the launch.  ~3x less host time than the autograd path (profiles/r02_host_overhead.txt)."""
+
+    def __init__(self, plan: EmbedPlan):
+        import numpy as np
+        self.lib = _lib.load()
+        self.plan = plan
+        n = len(plan.slots)
+        self.n = n
+        self.arr = (NrxFeature * n)()
+        self.view = np.frombuffer(self.arr, dtype=_feature_np_dtype())
+        for i, s_ in enumerate(plan.slots):
+            f = self.arr[i]
+            f.kind, f.dim, f.bag_len, f.out_col, f.wide_col, f.fm_field, f.flags = s_.kind, s_.dim, s_.bag_len, s_.out_col, s_.wide_col, s_.fm_field, s_.flags
+        self.table_of = [s_.table for s_ in plan.slots]
+        self.kinds = [s_.kind for s_ in plan.slots]
+        self.simple = all(k == NRX_SPARSE for k in self.kinds)            # ids only: no masks, no dense values
+        self.bag = [(i, s_.bag_len, s_.kind) for i, s_ in enumerate(plan.slots) if s_.kind >= NRX_BAG_MASKED_MEAN]
+        self._tables_id = None
+        self._tkey = None
+        self.fm_dim = max((s_.dim for s_ in plan.slots if s_.fm_field), default=0)
+        self.fwd = self.lib.nrx_embed_fwd_train
+
+    def _bind_tables(self, tables):
+        i64 = torch.float32
+        for t in tables:
+            if not (t.is_cuda and t.dtype is i64 and t.is_contiguous()):
+                _f32c(t, "embedding table")
+                raise ValueError("embedding tables must be contiguous [rows, dim] fp32")
+        ptrs = [t.data_ptr() for t in tables]
+        rows = [t.shape[0] for t in tables]
+        self.view["table"] = [ptrs[k] if k >= 0 else 0 for k in self.table_of]
+        self.view["rows"] = [rows[k] if k >= 0 else 0 for k in self.table_of]
+        self._tables_id = tables
+        self._tkey = (len(tables), ptrs[0], ptrs[-1]) if tables else None
+        self.device = tables[0].device if tables else None
+
+    def __call__(self, tables, inputs, weights, out_ld, need_out, mode):
+        plan = self.plan
+        if tables is not self._tables_id or (tables and self._tkey != (len(tables), tables[0].data_ptr(), tables[-1].data_ptr())):
+            self._bind_tables(tables)
+        if self.simple:
+            x0 = inputs[0]
+            dt, B = x0.dtype, x0.shape[0]
+            ptrs = []
+            for x in inputs:                                     # the one validating pass
+                if x.dtype is not dt or not x.is_cuda or x.dim() != 1 or x.shape[0] != B or not x.is_contiguous():
+                    return None                                  # odd input: let the general path convert / complain
+                ptrs.append(x.data_ptr())
+            if dt is torch.int64:
+                bits = 64
+            elif dt is torch.int32:
+                bits = 32
+            else:
+                return None
+            self.view["index"] = ptrs
+            if bits != getattr(self, "_bits", None):
+                self.view["index_bits"] = bits
+                self._bits = bits
+            dev = x0.device
+        else:
+            B, ins, ws = _prep_inputs(plan, tables, inputs, weights)
+            self.view["index"] = [x.data_ptr() for x in ins]
+            self.view["index_bits"] = [x.element_size() * 8 for x in ins]
+            self.view["weight"] = [0 if w is None or k == NRX_BAG_MEAN else w.data_ptr() for w, k in zip(ws, self.kinds)]
+            self._bits = None
+            self._keep = (ins, ws)
+            dev = ins[0].device
+        ld = int(out_ld) if out_ld else plan.out_width
+        if ld < plan.out_width:
+            raise ValueError("out_ld smaller than the plan's out_width")
+        out = torch.empty((B, ld), dtype=torch.float32, device=dev) if need_out else None
+        wide = torch.empty((B, plan.wide_width), dtype=torch.float32, device=dev) if plan.wide_width else None
+        fm = torch.empty((B,), dtype=torch.float32, device=dev) if plan.use_fm else None
+        if mode == "deferred":
+            status = _deferred_status(plan.names)
+        else:
+            status = torch.zeros(4, dtype=torch.int32, device=dev) if mode != "off" else None
+        if B > 0:
+            rc = self.fwd(self.arr, self.n, B, _ptr(out), ld, _ptr(wide), plan.wide_width, _ptr(fm), None, 0, _ptr(status),
+                          torch.cuda.current_stream(dev).cuda_stream)
+            if rc:
+                check(rc, "nrx_embed_fwd")
+        if status is not None and mode != "deferred":
+            if mode == "sync":
+                _raise_if_oob(status, plan.names)
+            else:
+                ev = torch.cuda.Event()
+                ev.record()
+                _pending_status.append((status, ev, plan.names))
+                while _pending_status and _pending_status[0][1].query():
+                    st, _, nm = _pending_status.pop(0)
+                    _raise_if_oob(st, nm)
+        return out, wide, fm
+
+
 def embed_apply(plan: EmbedPlan, tables: Sequence[torch.Tensor], inputs: Sequence[torch.Tensor],
                 weights: Sequence[Optional[torch.Tensor]], out_ld: Optional[int] = None, need_out: bool = True,
-                sparse_grad=False):
-    """Run the fused gather(+pool)->concat.  Returns (out[B, out_ld or out_width] | None,
+                sparse_grad=False, index_check: Optional[str] = None):
+    """Run the fused gather(+pool)->concat.  index_check: None = the module-wide mode (set_index_check; default 'sync' =
+    IndexError in the offending call, like torch on CPU), or 'deferred' / 'sync' / 'off' for this call.  Returns (out[B, out_ld or out_width] | None,
     wide[B, wide_width] | None, fm[B] | None).  Differentiable w.r.t. `tables`: dense grads by default
     (what the reference's nn.Embedding(sparse=False) produces), or -- sparse_grad=True -- deterministic
     row-sparse COO grads (sorted segmented reduction; no full-table zero-fill), or -- sparse_grad=a
     SparseGradSink -- the same reduction left on the device for optim.FusedSparseAdam (tables get no .grad)."""
     if not need_out and not (plan.use_fm or plan.wide_width):
         raise ValueError("need_out=False only makes sense with an FM or wide output")
-    return _EmbedFn.apply(plan, list(inputs), list(weights), out_ld, need_out, sparse_grad, *tables)
+    if len(plan.slots) <= NRX_MAX_FEATURES and len(inputs) == len(plan.slots) and \
+            (not torch.is_grad_enabled() or not any(t.requires_grad for t in tables)):
+        fast = plan.__dict__.get("_fast")
+        if fast is None:
+            fast = plan.__dict__["_fast"] = _FastForward(plan)
+        res = fast(tables, inputs, weights, out_ld, need_out, index_check or _INDEX_CHECK)
+        if res is not None:
+            return res
+    return _EmbedFn.apply(plan, list(inputs), list(weights), out_ld, need_out, sparse_grad, index_check, *tables)
 
 
 class PreparedEmbed:
@@ -703,7 +860,7 @@ class PreparedEmbedDcn:
     (bags, dense features, dims not multiples of 4, ...)."""
 
     def __init__(self, plan: EmbedPlan, tables, inputs, w: torch.Tensor, b: torch.Tensor,
-                 out: Optional[torch.Tensor] = None, check_index: bool = False):
+                 out: Optional[torch.Tensor] = None, check_index: bool = False, status: Optional[torch.Tensor] = None):
         self.lib = _lib.load()
         if any(s.kind != NRX_SPARSE or s.wide_col >= 0 for s in plan.slots) or plan.use_fm or len(plan.slots) > NRX_MAX_FEATURES:
             raise FusedUnsupported("only plain single-valued features are fused")
@@ -715,7 +872,7 @@ class PreparedEmbedDcn:
             raise ValueError(f"cross weights are for dim {self.w.shape[1]}, the concat has {W}")
         dev = self.ins[0].device
         self.out = out if out is not None else torch.empty((self.B, 2 * W), dtype=torch.float32, device=dev)
-        self.status = torch.zeros(4, dtype=torch.int32, device=dev) if check_index else None
+        self.status = status if status is not None else (torch.zeros(4, dtype=torch.int32, device=dev) if check_index else None)
         self.arr = _fill_features(plan, 0, len(plan.slots), self.tables, self.ins, [None] * len(plan.slots), fm=False)
         self.plan, self.W, self.device = plan, W, dev
         self.run()          # eligibility is decided by the library: surface NRX_ERR_UNSUPPORTED now
@@ -758,12 +915,15 @@ class _EmbedDcnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, plan: EmbedPlan, inputs, sparse_grad, w, b, *tables):
-        call = PreparedEmbedDcn(plan, tables, inputs, w, b, check_index=_INDEX_CHECK != "off")
-        if _INDEX_CHECK == "sync":
-            call.check()
-        elif _INDEX_CHECK == "lazy":
-            flush_index_checks()
-            call.check()
+        if _INDEX_CHECK == "deferred":
+            call = PreparedEmbedDcn(plan, tables, inputs, w, b, status=_deferred_status(plan.names))
+        else:
+            call = PreparedEmbedDcn(plan, tables, inputs, w, b, check_index=_INDEX_CHECK != "off")
+            if _INDEX_CHECK == "sync":
+                call.check()
+            elif _INDEX_CHECK == "lazy":
+                flush_index_checks()
+                call.check()
         ctx.plan, ctx.B, ctx.ld = plan, call.B, plan.out_width
         ctx.ins, ctx.ws = call.ins, [None] * len(plan.slots)
         ctx.table_meta = [(t.shape, t.device) for t in tables]
@@ -788,7 +948,7 @@ class _EmbedDcnFn(torch.autograd.Function):
         check(lib.nrx_dcn_v1_bwd(buf.data_ptr(), W2, None, 0, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), g.data_ptr() + 4 * D, W2,
                                  gx.data_ptr(), D, None, 0, gw.data_ptr(), gb.data_ptr(), _stream_ptr(buf)), "nrx_dcn_v1_bwd")
         gx += g[:, :D]
-        table_grads = _EmbedFn.backward(ctx, gx, None, None)[6:]
+        table_grads = _EmbedFn.backward(ctx, gx, None, None)[7:]
         return (None, None, None, gw.view(ctx.w_shape), gb.view(ctx.b_shape), *table_grads)
 
 
@@ -797,6 +957,8 @@ def embed_dcn_v1(plan: EmbedPlan, tables, inputs, w: torch.Tensor, b: torch.Tens
     enabled (sparse_grad as in embed_apply); raises FusedUnsupported for feature mixes the kernel does not cover."""
     if torch.is_grad_enabled() and (w.requires_grad or b.requires_grad or any(t.requires_grad for t in tables)):
         return _EmbedDcnFn.apply(plan, list(inputs), sparse_grad, w, b, *tables)
+    if _INDEX_CHECK == "deferred":
+        return PreparedEmbedDcn(plan, tables, inputs, w, b, status=_deferred_status(plan.names)).out
     call = PreparedEmbedDcn(plan, tables, inputs, w, b, check_index=_INDEX_CHECK != "off")
     if _INDEX_CHECK == "sync":
         call.check()

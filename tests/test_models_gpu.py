@@ -111,6 +111,23 @@ def test_per_feature_api_matches_fused():
     np.testing.assert_allclose(pooled.detach().cpu().numpy(), fused.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
     with pytest.raises(IndexError):                                                  # OOB like torch on CPU
         m.get_feature_embedding("category", torch.tensor([1, 18], device=DEV))
+    # the fused batch path checks without synchronising (embeddings.index_check: deferred, the default): the offence is
+    # recorded by the kernel in host-mapped memory and raised by the next call or by ops.flush_index_checks()
+    from news_recsys_amd import ops
+    assert m.index_check == "deferred"
+    bad = dict(batch)
+    bad["category"] = torch.full_like(batch["category"], 10 ** 6)
+    m.get_embeddings_from_batch(bad, {"category", "user_history"})
+    with pytest.raises(IndexError):
+        ops.flush_index_checks()
+    m.get_embeddings_from_batch(bad, {"category", "user_history"})
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        m.get_embeddings_from_batch(batch, {"category", "user_history"})           # the NEXT call raises
+    m.index_check = "sync"
+    with pytest.raises(IndexError):
+        m.get_embeddings_from_batch(bad, {"category", "user_history"})             # reference behaviour on request
+    ops.flush_index_checks()
 
 
 def test_dssm_towers_and_losses_match_reference():
