@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __res
         // 32 MFMAs, so the LDS latency is paid twice per slab instead of once per MFMA group
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            if (h == 1 && k0 + BK / 2 >= K) break;      // the last slab's upper half is all padding (K % 32 <= 16): skip its MFMAs
             float fb[BK / 4], fa[TM][BK / 4];
 #pragma unroll
             for (int i = 0; i < BK / 4; ++i) {

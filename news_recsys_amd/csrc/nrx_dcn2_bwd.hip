@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
         if (k0 + BK < kend) load_slab(k0 + BK);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            if (h == 1 && k0 + BK / 2 >= kend) break;   // upper half of the last slab all padding: skip its MFMAs
             float fb[BK / 4], fa[TM][BK / 4];
 #pragma unroll
             for (int i = 0; i < BK / 4; ++i) {
