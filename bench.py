@@ -494,8 +494,22 @@ def main():
                                "(table,row) keys + summed row gradients on the device (what optim.FusedSparseAdam consumes)"}
             del fwd, bwd
 
-    if hasattr(path, "overflowed") and path.overflowed():
-        raise SystemExit("fixed-capacity exchange overflowed: rerun with a larger slack (ids too skewed)")
+    if hasattr(path, "overflowed"):
+        # every rank must take the same branch: agree on the flag first (a lone SystemExit would strand the peers in the
+        # next collective until the RCCL timeout)
+        over = torch.tensor([1 if path.overflowed() else 0], dtype=torch.int32, device=device)
+        if dist is not None:
+            if staged:
+                oc = over.cpu()
+                dist.all_reduce(oc, op=dist.ReduceOp.MAX)
+                over = oc
+            else:
+                dist.all_reduce(over, op=dist.ReduceOp.MAX)
+        if int(over.item()):
+            if dist is not None:
+                dist.barrier()
+                dist.destroy_process_group()
+            raise SystemExit("fixed-capacity exchange overflowed on some rank: rerun with a larger slack (ids too skewed)")
     planner = strong = a2a = None
     secondary_note = None
     emitted = {"done": False}

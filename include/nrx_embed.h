@@ -284,8 +284,9 @@ NRX_API int nrx_scatter_add_rows_segmented(float* const* grad_tables, const int6
  *   slot[p]                   int32 o*cap + k: where source position p's row will sit in the returned-row
  *                             buffer [world*cap, dim]; -1 if block o overflowed (k >= cap);   world*cap < 2^31
  *   counts2d[o*n_feats + f]   ids of feature f owned by o (the owner's inbox segmentation);
- *   overflow[0]               max over owners of (block count), written always: > cap means the
- *                             capacity was exceeded and the caller must redo the step exactly.
+ *   overflow[0]               RUNNING MAXIMUM, since the caller last zeroed it, of the largest block count of a call:
+ *                             > cap means a capacity was exceeded and the caller must redo that step exactly (a bound
+ *                             launch that is replayed many times is checked once, not after every replay).
  * workspace: device int64[nrx_route_workspace(n_total, world)].  Deterministic.               */
 NRX_API int64_t nrx_route_workspace(int64_t n_total, int32_t world);
 NRX_API int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_t n_feats, int32_t index_bits,

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void route_scan(int32_t* __restrict__ hi
         int worst = 0;
         for (int o = 0; o < world; ++o)
             if (s_tot[o] > worst) worst = s_tot[o];
-        overflow[0] = worst;
+        if ((int64_t)worst > overflow[0]) overflow[0] = worst;     // running maximum since the caller zeroed the word
     }
 }
 
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void route_single(const RouteArgs args_i
     const int tid = threadIdx.x, chunk = blockIdx.x;
     if (chunk == 0) {
         if (tid < a->n_feats) a->counts2d[tid] = a->len[tid];
-        if (tid == 0) a->overflow[0] = a->off[a->n_feats];
+        if (tid == 0 && a->off[a->n_feats] > a->overflow[0]) a->overflow[0] = a->off[a->n_feats];
     }
     if (chunk >= a->nchunks) return;
     const int f = chunk_feature(a, chunk);

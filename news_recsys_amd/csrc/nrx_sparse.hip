@@ -371,7 +371,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void dedup_place_kernel(const KeyT* __re
             const int64_t c = (int64_t)owner_base[o + 1] - (int64_t)owner_base[o];
             worst = c > worst ? c : worst;
         }
-        overflow[0] = worst;
+        if (worst > overflow[0]) overflow[0] = worst;          // running maximum since the caller zeroed the word
     }
     if (e >= n) return;
     const uint64_t key = (uint64_t)skeys[e];
@@ -455,7 +455,7 @@ extern "C" int nrx_route_ids_dedup(const void* const* ids, const int64_t* lens, 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t n = off;
     hipError_t err = hipMemsetAsync(counts2d, 0, sizeof(int64_t) * (size_t)world * n_tables, st);
-    if (err == hipSuccess && n == 0) err = hipMemsetAsync(overflow, 0, sizeof(int64_t), st);
+    (void)overflow;
     if (err != hipSuccess) {
         nrx_set_error("nrx_route_ids_dedup: memset failed: %s", hipGetErrorString(err));
         return NRX_ERR_LAUNCH;

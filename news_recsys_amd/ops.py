@@ -228,7 +228,11 @@ class _EmbedFn(torch.autograd.Function):
         ld = int(out_ld) if out_ld else plan.out_width
         if ld < plan.out_width:
             raise ValueError("out_ld smaller than the plan's out_width")
-        out = torch.empty((B, ld), dtype=torch.float32, device=dev) if need_out else None
+        n_slots = len(plan.slots)
+        # > 64 FM fields: the cross-field sums span launches, so the FM runs on the concat -- it is needed even when the
+        # caller did not ask for it (returned as None all the same)
+        scratch_out = plan.use_fm and n_slots > NRX_MAX_FEATURES and not need_out
+        out = torch.empty((B, ld), dtype=torch.float32, device=dev) if (need_out or scratch_out) else None
         wide = torch.empty((B, plan.wide_width), dtype=torch.float32, device=dev) if plan.wide_width else None
         fm = torch.empty((B,), dtype=torch.float32, device=dev) if plan.use_fm else None
         if mode == "deferred":
@@ -275,7 +279,7 @@ class _EmbedFn(torch.autograd.Function):
         if ctx.has_fm_feat:
             ctx.save_for_backward(out)
         ctx.set_materialize_grads(False)
-        return out, wide, fm
+        return (None if scratch_out else out), wide, fm
 
     @staticmethod
     def backward(ctx, g_out, g_wide, g_fm):
@@ -590,7 +594,8 @@ class PreparedEmbed:
         B = self.B
         if out is not None and (tuple(out.shape) != (B, self.ld) or out.dtype != torch.float32 or not out.is_contiguous()):
             raise ValueError("out must be a contiguous float32 [B, out_ld] tensor")
-        self.out = out if out is not None else (torch.empty((B, self.ld), dtype=torch.float32, device=dev) if need_out else None)
+        need_scratch = plan.use_fm and len(plan.slots) > NRX_MAX_FEATURES          # FM over > 64 fields runs on the concat
+        self.out = out if out is not None else (torch.empty((B, self.ld), dtype=torch.float32, device=dev) if (need_out or need_scratch) else None)
         self.wide = torch.empty((B, plan.wide_width), dtype=torch.float32, device=dev) if plan.wide_width else None
         self.fm = fm if fm is not None else (torch.empty((B,), dtype=torch.float32, device=dev) if plan.use_fm else None)
         self.status = torch.zeros(4, dtype=torch.int32, device=dev) if check_index else None
@@ -1165,7 +1170,7 @@ def route_ids(id_tensors: Sequence[torch.Tensor], world: int, cap: int):
     send_rows = torch.empty(world * cap, dtype=torch.int32, device=dev)
     slot = torch.empty(total, dtype=torch.int32, device=dev)
     counts2d = torch.empty((world, n), dtype=torch.int64, device=dev)
-    overflow = torch.empty(1, dtype=torch.int64, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int64, device=dev)
     ws = torch.empty(max(1, lib.nrx_route_workspace(total, world)), dtype=torch.int64, device=dev)
     ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
     lens = (C.c_int64 * n)(*[x.numel() for x in xs])
@@ -1188,7 +1193,7 @@ def route_ids_dedup(id_tensors: Sequence[torch.Tensor], table_of: Sequence[int],
     send_rows = torch.empty(world * cap, dtype=torch.int32, device=dev)
     slot = torch.empty(total, dtype=torch.int32, device=dev)
     counts2d = torch.empty((world, nt), dtype=torch.int64, device=dev)
-    overflow = torch.empty(1, dtype=torch.int64, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int64, device=dev)
     ws = torch.empty(max(1, lib.nrx_route_dedup_workspace(total, world)), dtype=torch.uint8, device=dev)
     ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
     lens = (C.c_int64 * n)(*[x.numel() for x in xs])
@@ -1287,7 +1292,7 @@ def route_bags(id_tensors: Sequence[torch.Tensor], weights: Sequence[Optional[to
     send_tag = torch.empty(world * cap, dtype=torch.int32, device=dev)
     send_w = torch.empty(world * cap, dtype=torch.float32, device=dev)
     counts2d = torch.empty((world, n), dtype=torch.int64, device=dev)
-    overflow = torch.empty(1, dtype=torch.int64, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int64, device=dev)
     wsb = torch.empty(max(1, lib.nrx_route_workspace(total, world)), dtype=torch.int64, device=dev)
     ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
     wptrs = (C.c_void_p * n)(*[(_ptr(w) or 0) for w in ws])

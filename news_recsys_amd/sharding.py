@@ -155,7 +155,7 @@ class RowShardedEmbedding:
 
     def __init__(self, rank: int, world: int, group=None, backend=None, mode: str = "capacity",
                  slack: float = 0.05, overflow_policy: str = "check", host_staged: bool = False, pool_bags: bool = True,
-                 dedup: bool = False):
+                 dedup: bool = False, grad_average: bool = True):
         """mode: "capacity" (sync-free, default) or "exact".  overflow_policy (capacity mode):
         "check" = agree on overflow across ranks after each forward (one small all-reduce + host read)
         and transparently redo the step in exact mode; "defer" = never read back inside the step --
@@ -175,6 +175,11 @@ class RowShardedEmbedding:
         # dedup: every distinct (owner, table, row) of an exchange travels once (nrx_route_ids_dedup; a sort per step: pays
         # on skewed click-log ids, costs on uniform ones -- off by default)
         self.dedup = bool(dedup) and mode == "capacity"
+        # grad_average: every rank's loss is a mean over ITS batch; a row-sharded table receives the SUM of all ranks'
+        # gradient rows.  True (default) scales them by 1 / world so that tables see the gradient of the global-batch mean
+        # -- the same convention as allreduce_dense_grads for the replicated dense parameters (and what a single-GPU run
+        # over the concatenated batch computes).  False: the plain sum.
+        self.grad_average = bool(grad_average)
         self._overflow_marks: List[Tuple[torch.Tensor, int]] = []
 
     def plan_groups(self, feats: Sequence["ShardedFeature"]):
@@ -503,12 +508,16 @@ class _ShardedEmbedFn(torch.autograd.Function):
         n_lead = 7
         if not outs:
             return (None,) * (n_lead + len(ctx.names))
+        if eng.grad_average and eng.world > 1:
+            grads_in = [g / eng.world for g in grads_in]
         g_rets = torch.autograd.grad(outs, ctx.leaves, grads_in, allow_unused=True)     # slot-scatter (HIP bwd kernel)
         shard_grads = {n: torch.zeros(shape, dtype=torch.float32, device=dev) for n, (shape, dev) in zip(ctx.names, ctx.shard_meta)}
-        # replicated tables: the local dense grad (the caller all-reduces it like any data-parallel parameter)
+        # replicated tables: the LOCAL dense grad of a data-parallel parameter -- the caller all-reduces it together with the
+        # other dense parameters (allreduce_dense_grads(data_parallel_params(model), world) averages, which undoes the
+        # 1 / world applied above only once: the local grad is kept unscaled here)
         for n, g_rep in zip(ctx.rep_names, g_rets[len(ctx.routes):]):
             if g_rep is not None:
-                shard_grads[n] = g_rep
+                shard_grads[n] = g_rep * eng.world if (eng.grad_average and eng.world > 1) else g_rep
         for route, leaf, g_ret in zip(ctx.routes, ctx.leaves, g_rets):
             if g_ret is None:
                 g_ret = torch.zeros_like(leaf)
@@ -566,9 +575,12 @@ class PreparedShardedForward:
                 self.groups.append(g)
                 rets.append(g["ret"].view(-1, g["D"]))
                 continue
-            dt = torch.int32 if all(inputs[i].dtype == torch.int32 for i in idxs) else torch.int64
-            ids = [inputs[i] if inputs[i].dtype == dt else inputs[i].to(dt) for i in idxs]
-            ids = [x if x.is_contiguous() else x.contiguous() for x in ids]
+            dt = inputs[idxs[0]].dtype
+            if dt not in (torch.int32, torch.int64) or any(inputs[i].dtype != dt or not inputs[i].is_contiguous() for i in idxs):
+                # a converted copy would be a snapshot: the bound call promises to re-read the caller's tensors every run
+                raise TypeError("PreparedShardedForward: the ids of one exchange group must be contiguous and share one dtype "
+                                "(int32 or int64)")
+            ids = [inputs[i] for i in idxs]
             n = len(ids)
             total = sum(x.numel() for x in ids)
             cap = eng.capacity_for(total)
@@ -693,7 +705,12 @@ class PreparedShardedForward:
         return self.final.run()
 
     def overflowed(self) -> bool:
-        return any(int(g["overflow"].item()) > g["cap"] for g in self.groups)
+        """True if any run since the last call exceeded a block capacity (the kernels keep a running maximum)."""
+        bad = False
+        for g in self.groups:
+            bad |= int(g["overflow"].item()) > g["cap"]
+            g["overflow"].zero_()
+        return bad
 
 
 # --------------------------------------------------------------------------------- dense params
@@ -714,12 +731,24 @@ def allreduce_dense_grads(params, world: int, group=None) -> None:
 
 
 # --------------------------------------------------------------------------------- model integration
+def data_parallel_params(model):
+    """Parameters that are REPLICATED on every rank of a shard_model_'ed model and therefore need the gradient
+    all-reduce: everything except the row-sharded tables (dense heads, cross / FM parameters, planner-replicated
+    tables).  Use: allreduce_dense_grads(data_parallel_params(model), world)."""
+    sharded = {id(e.weight) for n, e in model.embedding_tables.items() if n not in getattr(model, "_replicated_tables", ())}
+    return [p for p in model.parameters() if id(p) not in sharded]
+
+
 def shard_model_(model, rank: int, world: int, group=None, backend=None):
     """Convert a BaseModel in place to row-sharded tables: every `embedding_tables[name].weight` becomes
     the local shard (rows rank::world) and `_embed` is routed through the exchange engine.  The
     state_dict keys are unchanged; values are the local shards (use shard_table / unshard_tables to
     convert checkpoints: scatter-on-load / gather-on-save)."""
     import torch.nn as nn
+    if getattr(model, "sparse_grad", False):
+        # the routed backward delivers dense shard gradients; the row-sparse optimizers expect COO grads / the fused sink
+        raise NotImplementedError("shard_model_: embeddings.sparse_grad is not supported together with row-sharded tables")
+    model._replicated_tables = ()
     eng = RowShardedEmbedding(rank, world, group, backend)
     for name, emb in model.embedding_tables.items():
         local = shard_table(emb.weight.data, rank, world)

@@ -83,7 +83,8 @@ def _worker(rank, world, port, q, mode="capacity", slack=0.5, replicate=(), pool
         shards = {n: (torch.from_numpy(t).clone() if n in replicate else sharding.shard_table(torch.from_numpy(t), rank, world)
                       ).requires_grad_(True) for n, t in tabs.items()}
         feats = [ShardedFeature(f.name, f.kind, f.table, f.dim, f.bag_len, f.wide, f.fm, f.table in replicate) for f in FEATS]
-        eng = RowShardedEmbedding(rank, world, backend=CheckerBackend(), mode=mode, slack=slack, pool_bags=pool_bags, dedup=dedup)
+        eng = RowShardedEmbedding(rank, world, backend=CheckerBackend(), mode=mode, slack=slack, pool_bags=pool_bags, dedup=dedup,
+                                  grad_average=(mode == "exact"))
         if slack < 0:          # force tiny blocks: every exchange overflows and must fall back to exact
             eng.capacity_for = lambda n: 8
         b = batch_for(rank)
@@ -137,10 +138,13 @@ def test_row_sharded_forward_backward_over_gloo(world, mode, slack, replicate, p
         for lo, hi in ((0, 8), (8, 9), (9, 25), (49, 65)):
             assert np.array_equal(out[:, lo:hi], want_outs[r][:, lo:hi])               # routed copies: bit-exact
         np.testing.assert_allclose(out[:, 25:49], want_outs[r][:, 25:49], rtol=1e-6, atol=1e-6)   # pooled
+        # grad_average (on for the exact-mode cases): routed table grads are the gradient of the GLOBAL-batch mean, i.e.
+        # the summed grads / world; the replicated tables' local grads stay unscaled (their all-reduce averages)
+        scale = world if mode == "exact" else 1
         for n, g in grads.items():
             if n in replicate:
                 continue            # replicated: local data-parallel grads, summed below
-            want = want_grads[n][r::world]
+            want = want_grads[n][r::world] / scale
             np.testing.assert_allclose(g, want, rtol=1e-5, atol=1e-6, err_msg=f"rank {r} table {n}")
     for n in replicate:          # planner-replicated tables: the ranks' local grads sum to the full grad
         total = sum(results[r][1][n] for r in range(world))

@@ -29,7 +29,8 @@ def _worker(rank, world, port, q, mode, slack, replicate, prepared, dedup=False,
                       ).to(DEV).requires_grad_(True) for n, t in tabs.items()}
         feats = [ShardedFeature(f.name, f.kind, f.table, f.dim, f.bag_len, f.wide, f.fm, f.table in replicate) for f in FEATS]
         eng = RowShardedEmbedding(rank, world, mode=mode, slack=slack, host_staged=True,
-                                  overflow_policy="defer" if prepared else "check", dedup=dedup, pool_bags=pool_bags)
+                                  overflow_policy="defer" if prepared else "check", dedup=dedup, pool_bags=pool_bags,
+                                  grad_average=False)
         if slack < 0:
             eng.capacity_for = lambda n: 64
         b = batch_for(rank)

@@ -1,0 +1,1 @@
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4
