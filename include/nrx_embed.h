@@ -136,12 +136,17 @@ NRX_API int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_t b
  * padding row, which never trains -- get zeros.  order / seg_start: device int64; values [n_unique, dim].
  * n_unique_dev (optional, device int64[1]): the actual number of unique entries when the host does not
  * know it yet (nrx_sparse_plan's counts[0]); n_unique is then an upper bound that sizes the launch.
- * fm (optional): the FM epilogue's gradient, as in nrx_embed_bwd. */
+ * fm (optional): the FM epilogue's gradient, as in nrx_embed_bwd.
+ * workspace (optional, device bytes >= nrx_embed_bwd_sorted_workspace(n_lookups, dim)): rows looked up more than 16 times
+ * in the batch (hot ids of a skewed click log, tiny tables) are then reduced by whole wavefronts in chunks of 256 lookups
+ * instead of serially by one lane group -- same fixed summation order from run to run.  NULL: every row is walked by its
+ * lane group (fine for near-unique ids). */
+NRX_API int64_t nrx_embed_bwd_sorted_workspace(int64_t n_lookups, int32_t dim);
 NRX_API int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
                          const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
                          const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
                          int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
-                         void* stream);
+                         void* workspace, void* stream);
 
 /* Whole planning step of the row-sparse backward in one call (replaces nrx_make_table_keys + an external
  * 64-bit sort + unique + scan): for the flat, feature-major lookup list of n_feats features (ids[f]: lens[f]

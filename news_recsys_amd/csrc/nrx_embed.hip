@@ -362,6 +362,9 @@ struct SortedBwdArgs {
     int64_t sums_ld;
     const float* feat;
     int64_t feat_ld;
+    int32_t* long_ws;              // optional workspace of the long-segment path (see sorted_long_kernel); null = none
+    int64_t long_items_cap;        // capacity of the item list
+    int64_t long_slots_cap;        // capacity of the partial-sum slots
     float* values;
     int32_t n;
     int32_t dim;
@@ -500,6 +503,48 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_kernel(const Sorte
     }
 }
 
+// ---- work lists of the long-segment path (workspace layout: 4 counters | items | multi-chunk rows | partial sums)
+constexpr int SORTED_LONG_T = 16;            // segments longer than this leave the lane-group kernel
+constexpr int SORTED_LONG_CHUNK = 256;       // entries per work item (small: items are the unit of load balance)
+struct LongItem { int32_t u; int32_t dest; int64_t e_begin; int64_t e_end; };      // dest < 0: straight to values[u]
+struct LongMulti { int32_t u; int32_t slot0; int32_t nchunks; int32_t pad; };
+
+__device__ __forceinline__ LongItem* sorted_long_items(const NRX_CONST SortedBwdArgs* a) {
+    return reinterpret_cast<LongItem*>(a->long_ws + 4);
+}
+__device__ __forceinline__ LongMulti* sorted_long_multi(const NRX_CONST SortedBwdArgs* a) {
+    return reinterpret_cast<LongMulti*>(reinterpret_cast<char*>(a->long_ws + 4) + a->long_items_cap * sizeof(LongItem));
+}
+__device__ __forceinline__ float* sorted_long_partials(const NRX_CONST SortedBwdArgs* a) {
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(sorted_long_multi(a)) + a->long_slots_cap * sizeof(LongMulti));
+}
+
+// one lane: put unique row u (sorted entries [lo, hi)) on the work lists.  Slot / list positions come from integer atomics:
+// WHICH slot a row gets varies from run to run, the sums do not (every item sums fixed entries in a fixed order).
+__device__ __forceinline__ void sorted_long_append(const NRX_CONST SortedBwdArgs* a, int32_t u, int64_t lo, int64_t hi) {
+    const int nchunks = (int)((hi - lo + SORTED_LONG_CHUNK - 1) / SORTED_LONG_CHUNK);
+    int slot0 = -1;
+    if (nchunks > 1) {
+        slot0 = atomicAdd(&a->long_ws[2], nchunks);
+        const int m = atomicAdd(&a->long_ws[1], 1);
+        if (m < a->long_slots_cap) {
+            LongMulti w;
+            w.u = u; w.slot0 = slot0; w.nchunks = nchunks; w.pad = 0;
+            sorted_long_multi(a)[m] = w;
+        }
+    }
+    const int base = atomicAdd(&a->long_ws[0], nchunks);
+    for (int c = 0; c < nchunks; ++c) {
+        if (base + c >= a->long_items_cap) break;
+        LongItem w;
+        w.u = u;
+        w.dest = nchunks > 1 ? slot0 + c : -1;
+        w.e_begin = lo + (int64_t)c * SORTED_LONG_CHUNK;
+        w.e_end = w.e_begin + SORTED_LONG_CHUNK < hi ? w.e_begin + SORTED_LONG_CHUNK : hi;
+        sorted_long_items(a)[base + c] = w;
+    }
+}
+
 // Fast form for the common launch: every feature single-valued without wide routing, D = 4 Q, everything 16-byte
 // aligned.  A Q-lane group owns R consecutive unique rows: their segment bounds, then their first entries' lookup
 // indices, then all their upstream rows (g_out, and for FM fields the forward value and the field sums) are fetched as
@@ -531,6 +576,17 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if ((key[r] & ((1ll << 40) - 1)) == 0 || u0 + r >= n) hi[r] = lo[r];      // padding row: zeros
+    // rows looked up many times (hot ids of a skewed distribution, tiny tables) would serialise this lane group for
+    // their whole segment: they go to a work list and are reduced by whole wavefronts (sorted_long_kernel)
+    bool lng[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        lng[r] = a->long_ws != nullptr && hi[r] - lo[r] > SORTED_LONG_T;
+        if (lng[r]) {
+            if (q == 0) sorted_long_append(a, (int32_t)(u0 + r), lo[r], hi[r]);
+            hi[r] = lo[r];
+        }
+    }
     float4 acc[R];
     int64_t e[R];
 #pragma unroll
@@ -581,7 +637,91 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (u0 + r < n) nrx_stg4(a->values, (u0 + r) * (int64_t)Q + q, acc[r]);
+        if (u0 + r < n && !lng[r]) nrx_stg4(a->values, (u0 + r) * (int64_t)Q + q, acc[r]);
+}
+
+// Long segments.  An item = up to SORTED_LONG_CHUNK consecutive sorted entries of ONE unique row; a wavefront reduces an
+// item: its 64 / Q lane groups stride over the entries (two in flight each), then a fixed xor-shuffle tree adds the
+// groups -- the same entries always meet in the same order, so the result is reproducible.  A row of one item is written
+// straight to values; a row of several items leaves one partial per item, which sorted_combine_kernel adds in item order.
+template <int QLOG2, bool FM>
+__global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdArgs args_in_kernarg) {
+    const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
+    constexpr int Q = 1 << QLOG2, G = 64 / Q;
+    const int lane = threadIdx.x & 63, q = lane & (Q - 1), g = lane >> QLOG2;
+    const int nitems = a->long_ws[0] < a->long_items_cap ? a->long_ws[0] : (int)a->long_items_cap;
+    const LongItem* items = sorted_long_items(a);
+    float* partial = sorted_long_partials(a);
+    const int nwaves = gridDim.x * (NRX_BLOCK / 64);
+    for (int it = blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6); it < nitems; it += nwaves) {
+        const LongItem w = items[it];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int UL = 4;                                   // entries in flight per lane group
+        for (int64_t e0 = w.e_begin + g; e0 < w.e_end; e0 += UL * G) {
+            int64_t p[UL];
+            bool on[UL];
+#pragma unroll
+            for (int k = 0; k < UL; ++k) {
+                on[k] = e0 + k * G < w.e_end;
+                p[k] = nrx_gconst<int64_t>(a->order)[on[k] ? e0 + k * G : w.e_begin];
+            }
+            float4 gr[UL], v[UL], s_[UL];
+            float gf[UL];
+#pragma unroll
+            for (int k = 0; k < UL; ++k) {
+                const int fi = sorted_feat_of(a, p[k]);
+                const int64_t b = p[k] - a->off[fi];
+                gr[k] = a->g_out ? nrx_ldg4(a->g_out, (b * a->out_ld + a->f[fi].out_col) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (FM) {
+                    gf[k] = a->f[fi].fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
+                    v[k] = nrx_ldg4(a->feat, (b * a->feat_ld + a->f[fi].out_col) / 4 + q);
+                    s_[k] = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < UL; ++k) {
+                float4 t = gr[k];
+                if (FM) {
+                    t.x += q == 0 ? gf[k] : gf[k] * (s_[k].x - v[k].x);
+                    t.y += gf[k] * (s_[k].y - v[k].y);
+                    t.z += gf[k] * (s_[k].z - v[k].z);
+                    t.w += gf[k] * (s_[k].w - v[k].w);
+                }
+                if (on[k]) { acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+            }
+        }
+#pragma unroll
+        for (int off = Q; off < 64; off <<= 1) {             // add the G lane groups: fixed tree
+            acc.x += __shfl_xor(acc.x, off, 64);
+            acc.y += __shfl_xor(acc.y, off, 64);
+            acc.z += __shfl_xor(acc.z, off, 64);
+            acc.w += __shfl_xor(acc.w, off, 64);
+        }
+        if (g == 0) {
+            if (w.dest < 0) nrx_stg4(a->values, (int64_t)w.u * Q + q, acc);
+            else if (w.dest < a->long_slots_cap) nrx_stg4(partial, (int64_t)w.dest * Q + q, acc);
+        }
+    }
+}
+
+template <int QLOG2>
+__global__ __launch_bounds__(NRX_BLOCK) void sorted_combine_kernel(const SortedBwdArgs args_in_kernarg) {
+    const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
+    constexpr int Q = 1 << QLOG2, TB = NRX_BLOCK / Q;
+    const int q = threadIdx.x & (Q - 1);
+    const int nmulti = a->long_ws[1];
+    const LongMulti* multi = sorted_long_multi(a);
+    const float* partial = sorted_long_partials(a);
+    for (int m = blockIdx.x * TB + (threadIdx.x >> QLOG2); m < nmulti; m += gridDim.x * TB) {
+        const LongMulti w = multi[m];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < w.nchunks; ++c) {
+            if (w.slot0 + c >= a->long_slots_cap) break;
+            const float4 t = nrx_ldg4(partial, (int64_t)(w.slot0 + c) * Q + q);
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        nrx_stg4(a->values, (int64_t)w.u * Q + q, acc);
+    }
 }
 
 // ----------------------------------------------------------------------------------- host side
@@ -837,11 +977,17 @@ extern "C" int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_
     return NRX_OK;
 }
 
+extern "C" int64_t nrx_embed_bwd_sorted_workspace(int64_t n_lookups, int32_t dim) {
+    if (n_lookups < 0 || dim < 1) return -1;
+    const int64_t items = n_lookups / SORTED_LONG_T + 8, slots = 2 * n_lookups / SORTED_LONG_CHUNK + 8;
+    return 32 + items * (int64_t)sizeof(LongItem) + slots * (int64_t)sizeof(LongMulti) + slots * (int64_t)dim * 4 + 64;
+}
+
 extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
                                     const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
                                     const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
                                     int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
-                                    void* stream) {
+                                    void* workspace, void* stream) {
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_bwd_sorted: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0 && dim >= 1 && n_unique >= 0, "nrx_embed_bwd_sorted: bad argument");
@@ -859,6 +1005,8 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     a.sums_ld = has_fm ? fm->sums_ld : 0;
     a.feat = has_fm ? fm->feat : nullptr;
     a.feat_ld = has_fm ? fm->feat_ld : 0;
+    a.long_ws = nullptr;
+    a.long_items_cap = a.long_slots_cap = 0;
     int64_t off = 0;
     for (int i = 0; i < n_feats; ++i) {
         const nrx_feature_t& s = feats[i];
@@ -913,6 +1061,15 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
         constexpr int R = 4;
         const int64_t groups = (n_unique + R - 1) / R;
         const unsigned grid = (unsigned)((groups + tb - 1) / tb);
+        if (workspace != nullptr) {        // long segments (hot rows) go through the wavefront-per-item path
+            a.long_ws = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15);
+            a.long_items_cap = off / SORTED_LONG_T + 8;
+            a.long_slots_cap = 2 * off / SORTED_LONG_CHUNK + 8;
+            if (hipMemsetAsync(a.long_ws, 0, 16, st) != hipSuccess) {
+                nrx_set_error("nrx_embed_bwd_sorted: memset failed");
+                return NRX_ERR_LAUNCH;
+            }
+        }
 #define NRX_SF(QL_)                                                                                                        \
     {                                                                                                                      \
         if (has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
@@ -920,6 +1077,16 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     }
         if (ql == 2) NRX_SF(2) else if (ql == 3) NRX_SF(3) else NRX_SF(4)
 #undef NRX_SF
+        if (workspace != nullptr) {
+#define NRX_SL(QL_)                                                                                                        \
+    {                                                                                                                      \
+        if (has_fm) hipLaunchKernelGGL((sorted_long_kernel<QL_, true>), dim3(2048), dim3(NRX_BLOCK), 0, st, a);             \
+        else hipLaunchKernelGGL((sorted_long_kernel<QL_, false>), dim3(2048), dim3(NRX_BLOCK), 0, st, a);                   \
+        hipLaunchKernelGGL((sorted_combine_kernel<QL_>), dim3(64), dim3(NRX_BLOCK), 0, st, a);                              \
+    }
+            if (ql == 2) NRX_SL(2) else if (ql == 3) NRX_SL(3) else NRX_SL(4)
+#undef NRX_SL
+        }
         NRX_LAUNCH_CHECK("nrx_embed_bwd_sorted(fast)");
         return NRX_OK;
     }

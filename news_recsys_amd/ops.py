@@ -404,17 +404,18 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
             sub = EmbedPlan([plan.slots[i] for i in fs], out_width=plan.out_width, wide_width=plan.wide_width)
             arr = _fill_features(sub, 0, n, [None] * n_tables, ids, [ctx.ws[i] for i in fs], table_ptrs=[0] * n_tables,
                                  fm=fmg is not None)
+            lws = torch.empty(lib.nrx_embed_bwd_sorted_workspace(total, D), dtype=torch.uint8, device=dev)   # hot-row work lists
             if ctx.sink is not None:
                 values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
                 check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
-                                               seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), fmg, values.data_ptr(), stream),
+                                               seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), fmg, values.data_ptr(), lws.data_ptr(), stream),
                       "nrx_embed_bwd_sorted")
                 ctx.sink.pending.append(dict(tables=ctx.tables, dim=D, uniq=uniq, values=values, counts=counts, cap=total))
                 continue
             if SPARSE_BWD_SYNC_FREE:
                 values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
                 check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
-                                               seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), fmg, values.data_ptr(), stream),
+                                               seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), fmg, values.data_ptr(), lws.data_ptr(), stream),
                       "nrx_embed_bwd_sorted")
                 cl = counts.tolist()
                 nu = cl[0]
@@ -423,7 +424,7 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
                 nu = cl[0]
                 values = torch.empty((nu, D), dtype=torch.float32, device=dev)
                 check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
-                                               seg.data_ptr(), uniq.data_ptr(), nu, None, fmg, values.data_ptr(), stream),
+                                               seg.data_ptr(), uniq.data_ptr(), nu, None, fmg, values.data_ptr(), lws.data_ptr(), stream),
                       "nrx_embed_bwd_sorted")                     # padding rows (id 0) come back as zeros
             rows = (uniq[:nu] & MASK).unsqueeze(0)
             for t in sorted(set(tabs)):
@@ -672,6 +673,7 @@ class PreparedSparseBackward:
                      counts=torch.empty(n_tables + 2, dtype=torch.int64, device=dev),
                      ws=torch.empty(max(1, self.lib.nrx_sparse_plan_workspace(total)), dtype=torch.uint8, device=dev),
                      values=torch.empty((total, D), dtype=torch.float32, device=dev),
+                     lws=torch.empty(self.lib.nrx_embed_bwd_sorted_workspace(total, D), dtype=torch.uint8, device=dev),
                      ptrs=(C.c_void_p * n)(*[x.data_ptr() for x in ids]), lens=(C.c_int64 * n)(*[x.numel() for x in ids]),
                      tof=(C.c_int32 * n)(*tabs), rws=(C.c_int64 * n)(*[fwd.tables[t].shape[0] for t in tabs]),
                      bits=ids[0].element_size() * 8, n_tables=n_tables,
@@ -689,7 +691,7 @@ class PreparedSparseBackward:
                 check(rc, "nrx_sparse_plan")
             rc = lib.nrx_embed_bwd_sorted(g["arr"], g["n"], f.B, g["dim"], _ptr(self.g_out), f.ld, _ptr(self.g_wide), f.plan.wide_width,
                                           g["order"].data_ptr(), g["seg"].data_ptr(), g["uniq"].data_ptr(), g["total"],
-                                          g["counts"].data_ptr(), self.fmg, g["values"].data_ptr(), stream)
+                                          g["counts"].data_ptr(), self.fmg, g["values"].data_ptr(), g["lws"].data_ptr(), stream)
             if rc:
                 check(rc, "nrx_embed_bwd_sorted")
         return self.groups

@@ -638,6 +638,39 @@ def test_prepared_embed_matches_embed_apply_and_reruns():
         call.check()
 
 
+@pytest.mark.parametrize("fm", [False, True])
+def test_sorted_backward_hot_rows_long_segment_path(fm):
+    """Skewed ids: rows looked up hundreds or thousands of times in one batch (a 40-row table, one id repeated 5000
+    times) take the wavefront-per-chunk path of nrx_embed_bwd_sorted (work lists, partial sums, combine) -- same result as
+    the dense scatter within float tolerance, identical bits from run to run."""
+    rng = np.random.default_rng(77)
+    B, D = 20000, 16
+    rows = [40, 3000, 500000]
+    tabs = [torch.randn(r, D, device=DEV) for r in rows]
+    ids = [torch.from_numpy(rng.integers(0, r, B)).to(DEV) for r in rows]
+    ids[2][:5000] = 4242                                        # one hot row: 20 chunks of 256 entries
+    ids[1][100:130] = 7                                         # a 30-entry segment (single work item)
+    slots = [ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, i * D, fm_field=int(fm)) for i in range(3)]
+    plan = ops.EmbedPlan(slots, out_width=3 * D, use_fm=fm)
+    up = torch.randn(B, 3 * D, device=DEV)
+    upf = torch.randn(B, device=DEV)
+
+    def run(mode):
+        ts = [t.clone().requires_grad_(True) for t in tabs]
+        out, _, f_ = ops.embed_apply(plan, ts, ids, [None] * 3, sparse_grad=mode)
+        loss = (out * up).sum() + ((f_ * upf).sum() if fm else 0)
+        loss.backward()
+        return [t.grad.to_dense() if t.grad.is_sparse else t.grad for t in ts]
+
+    dense = run(False)
+    s1, s2 = run(True), run(True)
+    for a, b, c in zip(dense, s1, s2):
+        assert torch.equal(b, c)                                # bit-reproducible
+        scale = a.abs().max().item()
+        torch.testing.assert_close(b, a, rtol=2e-4, atol=2e-5 * max(1.0, scale))
+        assert torch.all(b[0] == 0)                             # padding row
+
+
 @pytest.mark.parametrize("mix", ["uniform16", "with_bag"])
 def test_fm_gradient_folded_into_embed_backward_all_three_modes(mix):
     """The FM epilogue's gradient rides in the embedding backward (nrx_fm_grad_t: field sums from nrx_embed_fwd_train,

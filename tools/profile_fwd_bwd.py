@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev: run only the bound training pass (forward training form + row-sparse backward) of a bench workload, for
-rocprofv3 --kernel-trace --stats.   usage: profile_fwd_bwd.py [c2|c4|c5] [steps]"""
+rocprofv3 --kernel-trace --stats.   usage: profile_fwd_bwd.py [c2|c4|c5] [steps] [uniform|zipf]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 if wl == "c5":
     os.environ.setdefault("NRX_BENCH_C5_SMALL", "1")
 dev = torch.device("cuda:0")
-path = bench.SingleGpuPath(wl, dev, 1)
+dist = sys.argv[3] if len(sys.argv) > 3 else "uniform"
+path = bench.SingleGpuPath(wl, dev, 1, id_dist=dist)
 fwd, bwd = path.train_pass()
 for i in range(steps):
     fwd[i % 2].run()
@@ -23,4 +24,4 @@ for i in range(steps):
     bwd[i % 2].run()
 b.record()
 torch.cuda.synchronize()
-print(f"{wl}: fwd+bwd {a.elapsed_time(b) / steps * 1e3:.1f} us per step")
+print(f"{wl} ({dist} ids): fwd+bwd {a.elapsed_time(b) / steps * 1e3:.1f} us per step")
