@@ -74,6 +74,15 @@ typedef struct nrx_feature {
 /* nrx_feature.flags: row 0 of `table` is an ordinary row (the "table" is a buffer of routed rows
  * addressed by slot, sharding step 4): the backward must not treat index 0 as the padding row. */
 #define NRX_FEAT_ROW0_IS_DATA 1
+/* nrx_feature.flags, bag kinds only: the bag arrives in CSR form instead of the reference's padded [B, L] + mask
+ * (data_reader.py:96-109 builds the padded form per sample on the host): `index` = the concatenated ids of all bags
+ * (int32 / int64 per index_bits), `weight` is reinterpreted as `const int64_t* offsets` (device, [B + 1], ascending),
+ * sample b's bag = index[offsets[b] .. offsets[b + 1]) truncated to its first bag_len entries -- DataReader's
+ * truncation.  Every entry counts with weight 1, i.e. the result is bit-identical to the padded form with DataReader's
+ * mask (NRX_BAG_MASKED_MEAN: sum / (n + 1e-8); NRX_BAG_MEAN: the bag_len - n missing positions read row 0 like padding
+ * ids do; NRX_BAG_SUM: sum) while a sample costs 4-8 B per REAL entry instead of 12 B x bag_len.  Accepted by
+ * nrx_embed_fwd / nrx_embed_fwd_train / nrx_embed_bwd; the sorted backward wants the padded form (nrx_csr_to_padded). */
+#define NRX_FEAT_BAG_CSR 2
 
 /* ---- library ---------------------------------------------------------------------------- */
 NRX_API int nrx_abi_version(void);

@@ -27,6 +27,7 @@ NRX_OK = 0
 # enum nrx_feature_kind
 NRX_SPARSE, NRX_DENSE, NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM = 0, 1, 2, 3, 4
 NRX_FEAT_ROW0_IS_DATA = 1
+NRX_FEAT_BAG_CSR = 2
 
 
 class NrxFeature(C.Structure):

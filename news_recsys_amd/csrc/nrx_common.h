@@ -11,6 +11,8 @@
 #define NRX_BLOCK 256
 
 void nrx_set_error(const char* fmt, ...);
+// zero-fill by a kernel launch (capture-safe replacement of hipMemsetAsync; see nrx_lib.hip); p and bytes dword-aligned
+int nrx_zero_async(void* p, size_t bytes, hipStream_t st);
 
 #define NRX_REQUIRE(cond, ...)                \
     do {                                      \
@@ -44,7 +46,7 @@ struct FeatDev {
     uint8_t kind;
     uint8_t idx64;
     uint8_t fm;
-    uint8_t row0_is_data;   // NRX_FEAT_ROW0_IS_DATA
+    uint8_t flags;          // NRX_FEAT_* bits (ROW0_IS_DATA, BAG_CSR)
 };
 static_assert(sizeof(FeatDev) == 48, "FeatDev must stay 48 bytes");
 

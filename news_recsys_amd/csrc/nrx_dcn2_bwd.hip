@@ -296,12 +296,8 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
     NRX_REQUIRE(g_xl != g_out, "nrx_dcn_v2_layer_bwd: g_xl must not alias g_out");
     NRX_REQUIRE(dim <= 1024, "nrx_dcn_v2_layer_bwd: dim %d > 1024 unsupported", dim);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(g_W, 0, sizeof(float) * (size_t)dim * dim, st);
-    if (e == hipSuccess) e = hipMemsetAsync(g_b, 0, sizeof(float) * (size_t)dim, st);
-    if (e != hipSuccess) {
-        nrx_set_error("nrx_dcn_v2_layer_bwd: memset failed: %s", hipGetErrorString(e));
+    if (nrx_zero_async(g_W, sizeof(float) * (size_t)dim * dim, st) != NRX_OK || nrx_zero_async(g_b, sizeof(float) * (size_t)dim, st) != NRX_OK)
         return NRX_ERR_LAUNCH;
-    }
     if (batch == 0) return NRX_OK;
     const int64_t wld = (dim + 3) & ~3;
     float* glin = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);

@@ -22,6 +22,7 @@
 // The uniform kernel (nrx_embed_ring.h) is the same mapping specialised for "all features single-valued, same D = 4Q":
 // ids staged once per block in LDS, then a ring of R row loads per lane kept in flight across the feature walk.
 #include "nrx_common.h"
+#include <type_traits>
 #include "nrx_embed_ring.h"   // UniformArgs, fm_accumulate, group_sum, embed_fwd_ring
 
 bool nrx_launch_uniform_wide(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, float* out, int64_t out_ld,
@@ -65,6 +66,27 @@ __device__ __forceinline__ float4 load_row4(const float* table, int64_t id, int 
         v.w = (k0 + 3 < D) ? p[3] : 0.f;
     }
     return v;
+}
+
+// Entry `pos` of sample b's bag as the raw (id, weight) the pooling uses.  Padded form: ids [B, L] + optional weights.
+// CSR form (NRX_FEAT_BAG_CSR): f.weight holds int64 offsets [B + 1]; real entries weigh 1, the positions past the bag's
+// end are what DataReader pads with -- id 0, mask 0 (weight 1 for NRX_BAG_MEAN, whose padded form has no mask).
+__device__ __forceinline__ void bag_entry(const FeatDev& f, int64_t b, int pos, int L, int64_t& id, float& w) {
+    if (f.flags & NRX_FEAT_BAG_CSR) {
+        const int64_t* offs = reinterpret_cast<const int64_t*>(f.weight);
+        const int64_t o0 = offs[b];
+        if ((int64_t)pos < offs[b + 1] - o0) {
+            id = nrx_load_id(f.index, o0 + pos, f.idx64);
+            w = 1.0f;
+        } else {
+            id = 0;
+            w = f.kind == NRX_BAG_MEAN ? 1.0f : 0.f;
+        }
+    } else {
+        const int64_t gi = b * (int64_t)L + pos;
+        id = nrx_load_id(f.index, gi, f.idx64);
+        w = f.weight ? f.weight[gi] : 1.0f;
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -125,9 +147,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_generic(const EmbedArgs a
                     for (int e = tid; e < nb * cur; e += NRX_BLOCK) {
                         const int s = e / cur;
                         const int l = e - s * cur;
-                        const int64_t gi = (b0 + s) * (int64_t)L + l0 + l;
-                        int64_t id = nrx_load_id(f.index, gi, f.idx64);
-                        const float w = f.weight ? f.weight[gi] : 1.0f;
+                        int64_t id;
+                        float w;
+                        bag_entry(f, b0 + s, l0 + l, L, id, w);
                         if ((uint64_t)id >= (uint64_t)f.rows) {
                             nrx_report_oob(a.status, fi, b0 + s, id);
                             id = 0;
@@ -291,7 +313,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
             if (f.kind == NRX_SPARSE) {
                 if (active) {
                     const int64_t id = nrx_load_id(f.index, b, f.idx64);
-                    if (id >= (f.row0_is_data ? 0 : 1) && id < f.rows) atomic_add_row4(gtable, id, D, k0, g);
+                    if (id >= ((f.flags & NRX_FEAT_ROW0_IS_DATA) ? 0 : 1) && id < f.rows) atomic_add_row4(gtable, id, D, k0, g);
                 }
                 continue;
             }
@@ -300,8 +322,15 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
             float den = 1.0f;
             if (f.kind == NRX_BAG_MASKED_MEAN) {
                 den = 0.f;
-                if (active)
-                    for (int l = 0; l < L; ++l) den += f.weight[b * (int64_t)L + l];
+                if (active) {
+                    if (f.flags & NRX_FEAT_BAG_CSR) {
+                        const int64_t* offs = reinterpret_cast<const int64_t*>(f.weight);
+                        const int64_t n = offs[b + 1] - offs[b];
+                        den = (float)(n < (int64_t)L ? n : (int64_t)L);      // the forward's sum of n ones
+                    } else {
+                        for (int l = 0; l < L; ++l) den += f.weight[b * (int64_t)L + l];
+                    }
+                }
                 den += 1e-8f;
             } else if (f.kind == NRX_BAG_MEAN) {
                 den = (float)L;
@@ -315,9 +344,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
                 for (int e = tid; e < nb * cur; e += NRX_BLOCK) {
                     const int s = e / cur;
                     const int l = e - s * cur;
-                    const int64_t gi = (b0 + s) * (int64_t)L + l0 + l;
-                    int64_t id = nrx_load_id(f.index, gi, f.idx64);
-                    const float w = f.weight ? f.weight[gi] : 1.0f;
+                    int64_t id;
+                    float w;
+                    bag_entry(f, b0 + s, l0 + l, L, id, w);
                     const bool oob = (uint64_t)id >= (uint64_t)f.rows;
                     BagPair p;
                     p.id = oob ? 0 : (int32_t)id;
@@ -329,7 +358,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
                     const BagPair* row = s_bag + sb * stride;
                     for (int l = 0; l < cur; ++l) {
                         const BagPair p = row[l];
-                        if ((p.id != 0 || f.row0_is_data) && p.w != 0.f)
+                        if ((p.id != 0 || (f.flags & NRX_FEAT_ROW0_IS_DATA)) && p.w != 0.f)
                             atomic_add_row4(gtable, p.id, D, k0,
                                             make_float4(gs.x * p.w, gs.y * p.w, gs.z * p.w, gs.w * p.w));
                     }
@@ -357,6 +386,7 @@ struct SortedBwdArgs {
     int64_t n_unique;
     const int64_t* n_unique_dev;   // optional: actual count on the device (n_unique is then an upper bound)
     int64_t uniform_len;           // > 0: every feature has this many flat lookups (feature = p / uniform_len)
+    uint64_t uniform_magic;        // floor(2^64 / uniform_len) + 1: p / uniform_len == mulhi64(p, magic) for p < 2^32
     const float* g_fm;             // optional FM gradient inputs (see nrx_fm_grad_t)
     const float* fm_sums;
     int64_t sums_ld;
@@ -365,6 +395,7 @@ struct SortedBwdArgs {
     int32_t* long_ws;              // optional workspace of the long-segment path (see sorted_long_kernel); null = none
     int64_t long_items_cap;        // capacity of the item list
     int64_t long_slots_cap;        // capacity of the partial-sum slots
+    const float* scale;            // fast form with bag features: per flat lookup, the factor of its upstream row (bag_scale_kernel)
     float* values;
     int32_t n;
     int32_t dim;
@@ -373,7 +404,12 @@ static_assert(sizeof(SortedBwdArgs) <= 3840, "kernarg budget");
 
 // feature of flat lookup p (<= 64 features): direct when every feature contributes the same number of lookups
 __device__ __forceinline__ int sorted_feat_of(const NRX_CONST SortedBwdArgs* a, int64_t p) {
-    if (a->uniform_len > 0) return (int)(p / a->uniform_len);
+    if (a->uniform_len > 0) return (int)__umul64hi((uint64_t)p, a->uniform_magic);    // exact for p < 2^32 (host-checked)
+    if (a->n <= 4) {                  // few features (a shared table: history + item id): compare against scalars, no loads
+        const int64_t big = 0x7fffffffffffffffLL;
+        const int64_t o1 = a->off[1], o2 = a->n > 2 ? a->off[2] : big, o3 = a->n > 3 ? a->off[3] : big;
+        return (int)(p >= o1) + (int)(p >= o2) + (int)(p >= o3);
+    }
     int l0 = 0, h0 = a->n;            // a chain of dependent loads from the argument block
     while (h0 - l0 > 1) {
         const int mid = (l0 + h0) >> 1;
@@ -551,7 +587,9 @@ __device__ __forceinline__ void sorted_long_append(const NRX_CONST SortedBwdArgs
 // R independent requests per lane -- the reduction is a chain of three dependent random reads per row, so what bounds it
 // is how many chains a lane keeps in flight.  Segments longer than one entry (duplicate ids) continue in a loop that
 // adds the remaining entries in sorted order: the summation order is the sorted order, as in the general form.
-template <int QLOG2, int R, bool FM>
+// BAG: some features are bags -- a lookup's sample is (flat index) / L and its upstream row is scaled by the per-lookup
+// factor bag_scale_kernel left in a->scale (mask / (sum mask + 1e-8), 1 / L, or the weight).
+template <int QLOG2, int R, bool FM, bool BAG>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const SortedBwdArgs args_in_kernarg) {
     const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
     constexpr int Q = 1 << QLOG2;
@@ -594,21 +632,34 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
         acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
         e[r] = lo[r];
     }
-    bool more = true;
-    while (more) {                      // one entry of each of the R rows per pass; most rows have exactly one
+    // One pass takes the next sorted entry of each of the R rows: R independent chains (lookup index -> upstream row) per
+    // lane, added in sorted order.  The lookup indices of the NEXT pass are requested before this pass's rows, so a pass
+    // costs one memory round trip, not two.
+    int64_t pn[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) pn[r] = nrx_gconst<int64_t>(a->order)[e[r] < hi[r] ? e[r] : lo[0]];
+    auto pass = [&]() -> bool {
         int64_t p[R];
         bool on[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             on[r] = e[r] < hi[r];
-            p[r] = nrx_gconst<int64_t>(a->order)[on[r] ? e[r] : lo[0]];
+            p[r] = pn[r];
         }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (e[r] + 1 < hi[r]) pn[r] = nrx_gconst<int64_t>(a->order)[e[r] + 1];      // rows with one entry (most) request nothing
         float4 g[R], v[R], s[R];
-        float gf[R];
+        float gf[R], sc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int fi = sorted_feat_of(a, p[r]);
-            const int64_t b = p[r] - a->off[fi];
+            int64_t b = p[r] - a->off[fi];
+            sc[r] = 1.0f;
+            if (BAG && a->f[fi].kind >= NRX_BAG_MASKED_MEAN) {
+                sc[r] = nrx_gconst<float>(a->scale)[p[r]];
+                if (a->f[fi].bag_len > 1) b = (int64_t)__umul64hi((uint64_t)b, (uint64_t)a->f[fi].rows);   // b / bag_len (b < 2^32)
+            }
             const int64_t c4 = (b * a->out_ld + a->f[fi].out_col) / 4 + q;
             g[r] = a->g_out ? nrx_ldg4(a->g_out, c4) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (FM) {
@@ -618,7 +669,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
                 s[r] = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
             }
         }
-        more = false;
+        bool more = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float4 t = g[r];
@@ -629,12 +680,22 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
                 t.w += gf[r] * (s[r].w - v[r].w);
             }
             if (on[r]) {
-                acc[r].x += t.x; acc[r].y += t.y; acc[r].z += t.z; acc[r].w += t.w;
-                e[r] += 1;
+                if (BAG) {
+#pragma clang fp contract(off)
+                    acc[r].x += t.x * sc[r]; acc[r].y += t.y * sc[r]; acc[r].z += t.z * sc[r]; acc[r].w += t.w * sc[r];
+                } else {
+                    acc[r].x += t.x; acc[r].y += t.y; acc[r].z += t.z; acc[r].w += t.w;
+                }
             }
+            e[r] += 1;
             more |= e[r] < hi[r];
         }
-    }
+        return more;
+    };
+    // (tried: UPN = 2 / 4 entries per row for the passes after the first -- more chains in flight per lane, but the extra
+    // registers cost a wave of occupancy and every workload got slower: C2 166 -> 225 us, C5 177 -> 266 us)
+    bool more = true;
+    while (more) more = pass();
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (u0 + r < n && !lng[r]) nrx_stg4(a->values, (u0 + r) * (int64_t)Q + q, acc[r]);
@@ -644,7 +705,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
 // item: its 64 / Q lane groups stride over the entries (two in flight each), then a fixed xor-shuffle tree adds the
 // groups -- the same entries always meet in the same order, so the result is reproducible.  A row of one item is written
 // straight to values; a row of several items leaves one partial per item, which sorted_combine_kernel adds in item order.
-template <int QLOG2, bool FM>
+template <int QLOG2, bool FM, bool BAG>
 __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdArgs args_in_kernarg) {
     const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
     constexpr int Q = 1 << QLOG2, G = 64 / Q;
@@ -666,11 +727,16 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
                 p[k] = nrx_gconst<int64_t>(a->order)[on[k] ? e0 + k * G : w.e_begin];
             }
             float4 gr[UL], v[UL], s_[UL];
-            float gf[UL];
+            float gf[UL], sc[UL];
 #pragma unroll
             for (int k = 0; k < UL; ++k) {
                 const int fi = sorted_feat_of(a, p[k]);
-                const int64_t b = p[k] - a->off[fi];
+                int64_t b = p[k] - a->off[fi];
+                sc[k] = 1.0f;
+                if (BAG && a->f[fi].kind >= NRX_BAG_MASKED_MEAN) {
+                    sc[k] = nrx_gconst<float>(a->scale)[p[k]];
+                    if (a->f[fi].bag_len > 1) b = (int64_t)__umul64hi((uint64_t)b, (uint64_t)a->f[fi].rows);
+                }
                 gr[k] = a->g_out ? nrx_ldg4(a->g_out, (b * a->out_ld + a->f[fi].out_col) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (FM) {
                     gf[k] = a->f[fi].fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
@@ -687,7 +753,14 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
                     t.z += gf[k] * (s_[k].z - v[k].z);
                     t.w += gf[k] * (s_[k].w - v[k].w);
                 }
-                if (on[k]) { acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+                if (on[k]) {
+                    if (BAG) {
+#pragma clang fp contract(off)
+                        acc.x += t.x * sc[k]; acc.y += t.y * sc[k]; acc.z += t.z * sc[k]; acc.w += t.w * sc[k];
+                    } else {
+                        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                    }
+                }
             }
         }
 #pragma unroll
@@ -704,23 +777,55 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
     }
 }
 
+// A row of several items: a wavefront adds its partials -- the 64 / Q lane groups stride over them in item order, then the
+// same fixed xor-shuffle tree as above (a single lane group walking the ~400 partials of a 100 k-entry hot row took
+// 177 us on Zipf ids).
 template <int QLOG2>
 __global__ __launch_bounds__(NRX_BLOCK) void sorted_combine_kernel(const SortedBwdArgs args_in_kernarg) {
     const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
-    constexpr int Q = 1 << QLOG2, TB = NRX_BLOCK / Q;
-    const int q = threadIdx.x & (Q - 1);
-    const int nmulti = a->long_ws[1];
+    constexpr int Q = 1 << QLOG2, G = 64 / Q;
+    const int lane = threadIdx.x & 63, q = lane & (Q - 1), g = lane >> QLOG2;
+    const int nmulti = a->long_ws[1] < a->long_slots_cap ? a->long_ws[1] : (int)a->long_slots_cap;
     const LongMulti* multi = sorted_long_multi(a);
     const float* partial = sorted_long_partials(a);
-    for (int m = blockIdx.x * TB + (threadIdx.x >> QLOG2); m < nmulti; m += gridDim.x * TB) {
+    const int nwaves = gridDim.x * (NRX_BLOCK / 64);
+    for (int m = blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6); m < nmulti; m += nwaves) {
         const LongMulti w = multi[m];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c = 0; c < w.nchunks; ++c) {
+        for (int c = g; c < w.nchunks; c += G) {
             if (w.slot0 + c >= a->long_slots_cap) break;
             const float4 t = nrx_ldg4(partial, (int64_t)(w.slot0 + c) * Q + q);
             acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
         }
-        nrx_stg4(a->values, (int64_t)w.u * Q + q, acc);
+#pragma unroll
+        for (int off = Q; off < 64; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off, 64);
+            acc.y += __shfl_xor(acc.y, off, 64);
+            acc.z += __shfl_xor(acc.z, off, 64);
+            acc.w += __shfl_xor(acc.w, off, 64);
+        }
+        if (g == 0) nrx_stg4(a->values, (int64_t)w.u * Q + q, acc);
+    }
+}
+
+// Per-lookup factor of a bag feature's upstream row (what the general kernel recomputes per lookup from the whole row of
+// weights): w / (sum_l w + 1e-8) (masked mean, base_model.py:278-282), 1 / L (mean) or w (sum).  16 lanes per sample.
+__global__ __launch_bounds__(NRX_BLOCK) void bag_scale_kernel(const float* __restrict__ w, int kind, int64_t batch, int L,
+                                                            float* __restrict__ scale) {
+    const int q = threadIdx.x & 15;
+    const int64_t b = ((int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x) >> 4;
+    if (b >= batch) return;                                   // whole 16-lane groups leave together
+    float den = 0.f;
+    if (kind == NRX_BAG_MASKED_MEAN) {
+        for (int l = q; l < L; l += 16) den += w[b * L + l];
+        den = group_sum<16>(den) + 1e-8f;
+    }
+    for (int l = q; l < L; l += 16) {
+        float v;
+        if (kind == NRX_BAG_MASKED_MEAN) v = w[b * L + l] / den;
+        else if (kind == NRX_BAG_MEAN) v = 1.0f / (float)L;
+        else v = w != nullptr ? w[b * L + l] : 1.0f;
+        scale[b * L + l] = v;
     }
 }
 
@@ -749,12 +854,15 @@ int pack_features(const nrx_feature_t* feats, int32_t n, EmbedArgs& a, int& max_
         if (s.kind >= NRX_BAG_MASKED_MEAN) {
             NRX_REQUIRE(s.bag_len >= 1 && s.bag_len <= 32767, "%s: feature %d: bag_len %d out of range", who, i, s.bag_len);
             NRX_REQUIRE(s.kind != NRX_BAG_MASKED_MEAN || s.weight != nullptr, "%s: feature %d: masked mean needs weights", who, i);
+            NRX_REQUIRE(!(s.flags & NRX_FEAT_BAG_CSR) || s.weight != nullptr, "%s: feature %d: CSR bag without offsets", who, i);
+        } else {
+            NRX_REQUIRE(!(s.flags & NRX_FEAT_BAG_CSR), "%s: feature %d: NRX_FEAT_BAG_CSR on a non-bag feature", who, i);
         }
         NRX_REQUIRE(s.out_col >= 0, "%s: feature %d: negative out_col", who, i);
         FeatDev& d = a.f[i];
         d.table = s.table;
         d.index = s.index;
-        d.weight = (s.kind == NRX_BAG_MEAN) ? nullptr : s.weight;
+        d.weight = (s.kind == NRX_BAG_MEAN && !(s.flags & NRX_FEAT_BAG_CSR)) ? nullptr : s.weight;
         d.rows = s.rows;
         d.out_col = s.out_col;
         d.wide_col = s.wide_col;
@@ -763,7 +871,7 @@ int pack_features(const nrx_feature_t* feats, int32_t n, EmbedArgs& a, int& max_
         d.kind = (uint8_t)s.kind;
         d.idx64 = s.index_bits == 64;
         d.fm = s.fm_field != 0;
-        d.row0_is_data = (s.flags & NRX_FEAT_ROW0_IS_DATA) != 0;
+        d.flags = (uint8_t)(s.flags & (NRX_FEAT_ROW0_IS_DATA | NRX_FEAT_BAG_CSR));
         if (s.dim > max_dim) max_dim = s.dim;
         if (s.kind >= NRX_BAG_MASKED_MEAN && s.bag_len > max_bag) max_bag = s.bag_len;
     }
@@ -843,6 +951,9 @@ extern "C" int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, 
     if (batch == 0) return NRX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
+    for (int i = 0; i < n_feats; ++i)
+        NRX_REQUIRE(!(feats[i].flags & NRX_FEAT_BAG_CSR) || feats[i].kind >= NRX_BAG_MASKED_MEAN,
+                    "nrx_embed_fwd: feature %d: NRX_FEAT_BAG_CSR on a non-bag feature", i);
     // ---- uniform fast path?
     bool uniform = true;
     const int D0 = feats[0].dim;
@@ -980,7 +1091,8 @@ extern "C" int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_
 extern "C" int64_t nrx_embed_bwd_sorted_workspace(int64_t n_lookups, int32_t dim) {
     if (n_lookups < 0 || dim < 1) return -1;
     const int64_t items = n_lookups / SORTED_LONG_T + 8, slots = 2 * n_lookups / SORTED_LONG_CHUNK + 8;
-    return 32 + items * (int64_t)sizeof(LongItem) + slots * (int64_t)sizeof(LongMulti) + slots * (int64_t)dim * 4 + 64;
+    return 32 + items * (int64_t)sizeof(LongItem) + slots * (int64_t)sizeof(LongMulti) + slots * (int64_t)dim * 4 + 64 +
+           n_lookups * 4 + 64;                                   // + the per-lookup scale of bag features
 }
 
 extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
@@ -1007,6 +1119,7 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     a.feat_ld = has_fm ? fm->feat_ld : 0;
     a.long_ws = nullptr;
     a.long_items_cap = a.long_slots_cap = 0;
+    a.scale = nullptr;
     int64_t off = 0;
     for (int i = 0; i < n_feats; ++i) {
         const nrx_feature_t& s = feats[i];
@@ -1014,11 +1127,17 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
                     "nrx_embed_bwd_sorted: feature %d: kind %d has no table gradient", i, s.kind);
         NRX_REQUIRE(s.dim == dim, "nrx_embed_bwd_sorted: feature %d: dim %d != table dim %d", i, s.dim, dim);
         NRX_REQUIRE(s.kind != NRX_BAG_MASKED_MEAN || s.weight != nullptr, "nrx_embed_bwd_sorted: feature %d: masked mean needs weights", i);
+        if (s.flags & NRX_FEAT_BAG_CSR) {
+            nrx_set_error("nrx_embed_bwd_sorted: feature %d: CSR bags are not planned; expand with nrx_csr_to_padded", i);
+            return NRX_ERR_UNSUPPORTED;
+        }
         FeatDev& d = a.f[i];
         d.table = nullptr;
         d.index = nullptr;
         d.weight = (s.kind == NRX_BAG_MEAN) ? nullptr : s.weight;
-        d.rows = 0;
+        // fast form: `rows` carries the 2^64 reciprocal of bag_len (sample = lookup / bag_len as one multiply-high, exact for
+        // lookups < 2^32; (2^64 - 1) / d + 1 is floor(2^64 / d) + 1, or 2^64 / d itself for a power of two -- both exact)
+        d.rows = s.bag_len > 1 ? (int64_t)(~0ull / (uint64_t)s.bag_len + 1) : 0;
         d.out_col = s.out_col;
         d.wide_col = s.wide_col;
         d.dim = (int16_t)s.dim;
@@ -1026,7 +1145,7 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
         d.kind = (uint8_t)s.kind;
         d.idx64 = 1;
         d.fm = has_fm && s.fm_field != 0;
-        d.row0_is_data = 0;
+        d.flags = 0;
         a.off[i] = off;
         off += batch * (s.kind == NRX_SPARSE ? 1 : s.bag_len);
     }
@@ -1034,6 +1153,8 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     a.uniform_len = a.off[1] - a.off[0];
     for (int i = 0; i < n_feats && a.uniform_len > 0; ++i)
         if (a.off[i + 1] - a.off[i] != a.uniform_len) a.uniform_len = 0;
+    if (a.uniform_len < 2 || off >= 0xffffffffLL) a.uniform_len = 0;      // the reciprocal form needs a divisor >= 2 and lookups < 2^32
+    a.uniform_magic = a.uniform_len > 0 ? ~0ull / (uint64_t)a.uniform_len + 1 : 0;
     a.batch = batch;
     a.g_out = g_out;
     a.out_ld = out_ld;
@@ -1055,8 +1176,14 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     bool fast = dim == (4 << ql) && ql >= 2 && ql <= 4 && (g_out == nullptr || (nrx_aligned16(g_out) && (out_ld & 3) == 0)) && nrx_aligned16(values) &&
                 (!has_fm || (g_out != nullptr && nrx_aligned16(fm->feat) && (fm->feat_ld & 3) == 0 && nrx_aligned16(fm->fm_sums) &&
                              (fm->sums_ld & 3) == 0 && fm->sums_ld >= dim));
-    for (int i = 0; i < n_feats && fast; ++i)
-        fast = feats[i].kind == NRX_SPARSE && feats[i].wide_col < 0 && (feats[i].out_col & 3) == 0;
+    bool has_bag = false;
+    for (int i = 0; i < n_feats && fast; ++i) {
+        fast = feats[i].wide_col < 0 && (feats[i].out_col & 3) == 0;
+        has_bag |= feats[i].kind != NRX_SPARSE;
+    }
+    // bag features ride the fast form through a per-lookup scale array that lives in the workspace; FM fields are
+    // single-valued by construction (fm/model.py:48-59 stacks [B, D] tensors)
+    if (has_bag) fast = fast && workspace != nullptr && !has_fm && off < 0xffffffffLL;
     if (fast) {
         constexpr int R = 4;
         const int64_t groups = (n_unique + R - 1) / R;
@@ -1065,24 +1192,37 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
             a.long_ws = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15);
             a.long_items_cap = off / SORTED_LONG_T + 8;
             a.long_slots_cap = 2 * off / SORTED_LONG_CHUNK + 8;
-            if (hipMemsetAsync(a.long_ws, 0, 16, st) != hipSuccess) {
-                nrx_set_error("nrx_embed_bwd_sorted: memset failed");
-                return NRX_ERR_LAUNCH;
+            // the four work-list counters are cleared by a kernel (nrx_zero_async), not hipMemsetAsync: inside a captured HIP graph
+            // the 16-byte memset node did not take effect on replay (counters kept growing, the list was read past what was written)
+            if (nrx_zero_async(a.long_ws, 16, st) != NRX_OK) return NRX_ERR_LAUNCH;
+        }
+        if (has_bag) {
+            char* end = reinterpret_cast<char*>(a.long_ws + 4) + a.long_items_cap * sizeof(LongItem) +
+                        a.long_slots_cap * sizeof(LongMulti) + a.long_slots_cap * (size_t)dim * 4;
+            float* scale = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(end) + 15) & ~(uintptr_t)15);
+            a.scale = scale;
+            for (int i = 0; i < n_feats; ++i) {
+                if (feats[i].kind == NRX_SPARSE || batch == 0) continue;
+                const int64_t groups16 = batch;                                          // 16 lanes per sample
+                hipLaunchKernelGGL(bag_scale_kernel, dim3((unsigned)((groups16 * 16 + NRX_BLOCK - 1) / NRX_BLOCK)), dim3(NRX_BLOCK), 0, st,
+                                   a.f[i].weight, (int)feats[i].kind, batch, (int)feats[i].bag_len, scale + a.off[i]);
             }
         }
 #define NRX_SF(QL_)                                                                                                        \
     {                                                                                                                      \
-        if (has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a);      \
+        if (has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else if (has_bag) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a);      \
     }
         if (ql == 2) NRX_SF(2) else if (ql == 3) NRX_SF(3) else NRX_SF(4)
 #undef NRX_SF
         if (workspace != nullptr) {
 #define NRX_SL(QL_)                                                                                                        \
     {                                                                                                                      \
-        if (has_fm) hipLaunchKernelGGL((sorted_long_kernel<QL_, true>), dim3(2048), dim3(NRX_BLOCK), 0, st, a);             \
-        else hipLaunchKernelGGL((sorted_long_kernel<QL_, false>), dim3(2048), dim3(NRX_BLOCK), 0, st, a);                   \
-        hipLaunchKernelGGL((sorted_combine_kernel<QL_>), dim3(64), dim3(NRX_BLOCK), 0, st, a);                              \
+        if (has_fm) hipLaunchKernelGGL((sorted_long_kernel<QL_, true, false>), dim3(2048), dim3(NRX_BLOCK), 0, st, a);      \
+        else if (has_bag) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); \
+        else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, false>), dim3(2048), dim3(NRX_BLOCK), 0, st, a);            \
+        hipLaunchKernelGGL((sorted_combine_kernel<QL_>), dim3(256), dim3(NRX_BLOCK), 0, st, a);                              \
     }
             if (ql == 2) NRX_SL(2) else if (ql == 3) NRX_SL(3) else NRX_SL(4)
 #undef NRX_SL

@@ -636,10 +636,7 @@ extern "C" int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_
         NRX_LAUNCH_CHECK("nrx_route_ids(world 1)");
         return NRX_OK;
     }
-    if (hipMemsetAsync(counts2d, 0, sizeof(int64_t) * (size_t)world * n_feats, st) != hipSuccess) {
-        nrx_set_error("nrx_route_ids: memset failed");
-        return NRX_ERR_LAUNCH;
-    }
+    if (nrx_zero_async(counts2d, sizeof(int64_t) * (size_t)world * n_feats, st) != NRX_OK) return NRX_ERR_LAUNCH;
     if (chunks > 0) hipLaunchKernelGGL(route_hist, dim3((unsigned)chunks), dim3(NRX_BLOCK), 0, st, a);
     hipLaunchKernelGGL(route_scan, dim3(1), dim3(NRX_BLOCK), 0, st, a.hist, (int)chunks, world, overflow);
     if (chunks > 0) hipLaunchKernelGGL(route_place, dim3((unsigned)chunks), dim3(NRX_BLOCK), 0, st, a);
@@ -730,10 +727,7 @@ extern "C" int nrx_route_bags(const void* const* ids, const float* const* weight
     a.send_w = send_w;
     a.bags = 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(counts2d, 0, sizeof(int64_t) * (size_t)world * n_feats, st) != hipSuccess) {
-        nrx_set_error("nrx_route_bags: memset failed");
-        return NRX_ERR_LAUNCH;
-    }
+    if (nrx_zero_async(counts2d, sizeof(int64_t) * (size_t)world * n_feats, st) != NRX_OK) return NRX_ERR_LAUNCH;
     if (chunks > 0) hipLaunchKernelGGL(route_hist, dim3((unsigned)chunks), dim3(NRX_BLOCK), 0, st, a);
     hipLaunchKernelGGL(route_scan, dim3(1), dim3(NRX_BLOCK), 0, st, a.hist, (int)chunks, world, overflow);
     if (chunks > 0) hipLaunchKernelGGL(route_place, dim3((unsigned)chunks), dim3(NRX_BLOCK), 0, st, a);
@@ -797,10 +791,7 @@ extern "C" int nrx_pool_inbox_fwd(const float* const* tables, const int64_t* tab
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int32_t* run = reinterpret_cast<int32_t*>(workspace);
     const int64_t ntag = (int64_t)n_feats * batch;
-    if (hipMemsetAsync(run, 0, (size_t)world * ntag * 2 * sizeof(int32_t), st) != hipSuccess) {
-        nrx_set_error("nrx_pool_inbox_fwd: memset failed");
-        return NRX_ERR_LAUNCH;
-    }
+    if (nrx_zero_async(run, (size_t)world * ntag * 2 * sizeof(int32_t), st) != NRX_OK) return NRX_ERR_LAUNCH;
     hipLaunchKernelGGL(pool_mark_kernel, dim3((unsigned)((cap + NRX_BLOCK - 1) / NRX_BLOCK), (unsigned)world), dim3(NRX_BLOCK), 0, st, a, run);
     const int ql = pool_ql(dim);
     const int tb = NRX_BLOCK >> ql;

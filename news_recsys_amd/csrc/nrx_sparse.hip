@@ -203,12 +203,9 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
     const int64_t n = off;
     if (n == 0) {
         // counts = {0, 0, ..., 0}; seg_start[0] = 0
-        hipError_t e = hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)(n_tables + 2), st);
-        if (e == hipSuccess && seg_start) e = hipMemsetAsync(seg_start, 0, sizeof(int64_t), st);
-        if (e != hipSuccess) {
-            nrx_set_error("nrx_sparse_plan: hipMemsetAsync failed: %s", hipGetErrorString(e));
-            return NRX_ERR_LAUNCH;
-        }
+        int e = nrx_zero_async(counts, sizeof(int64_t) * (size_t)(n_tables + 2), st);
+        if (e == NRX_OK && seg_start) e = nrx_zero_async(seg_start, sizeof(int64_t), st);
+        if (e != NRX_OK) return NRX_ERR_LAUNCH;
         return NRX_OK;
     }
     NRX_REQUIRE(order && uniq_keys && seg_start && workspace, "nrx_sparse_plan: null buffer");
@@ -454,7 +451,7 @@ extern "C" int nrx_route_ids_dedup(const void* const* ids, const int64_t* lens, 
     NRX_REQUIRE(bits <= 62, "nrx_route_ids_dedup: composite key too wide");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t n = off;
-    hipError_t err = hipMemsetAsync(counts2d, 0, sizeof(int64_t) * (size_t)world * n_tables, st);
+    hipError_t err = nrx_zero_async(counts2d, sizeof(int64_t) * (size_t)world * n_tables, st) == NRX_OK ? hipSuccess : hipErrorLaunchFailure;
     (void)overflow;
     if (err != hipSuccess) {
         nrx_set_error("nrx_route_ids_dedup: memset failed: %s", hipGetErrorString(err));
@@ -507,10 +504,7 @@ extern "C" int nrx_unique_inverse(const void* ids, int32_t index_bits, int64_t n
     NRX_REQUIRE(n_unique != nullptr, "nrx_unique_inverse: null n_unique");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (n == 0) {
-        if (hipMemsetAsync(n_unique, 0, sizeof(int64_t), st) != hipSuccess) {
-            nrx_set_error("nrx_unique_inverse: memset failed");
-            return NRX_ERR_LAUNCH;
-        }
+        if (nrx_zero_async(n_unique, sizeof(int64_t), st) != NRX_OK) return NRX_ERR_LAUNCH;
         return NRX_OK;
     }
     NRX_REQUIRE(ids && unique_out && inverse_out && workspace, "nrx_unique_inverse: null buffer");

@@ -125,8 +125,12 @@ class ColumnarLoader:
     with seed + epoch); contiguous epochs (shuffle=False) slice the mmaps without a gather."""
 
     def __init__(self, dataset: ColumnarDataset, batch_size: int, device, shuffle: bool = False,
-                 drop_last: bool = False, seed: int = 0, expand_on_device: bool = True, resident: bool = False):
-        """resident=True: every column is uploaded ONCE and stays in HBM (MIND's training split is a few GB of
+                 drop_last: bool = False, seed: int = 0, expand_on_device: bool = True, resident: bool = False,
+                 csr_bags: bool = False):
+        """csr_bags=True (streaming mode, cuda): array features are delivered as they are stored -- `name` = the
+        concatenated ids [nnz] and `name_offsets` = int64 [B + 1] -- instead of DataReader's padded ids + mask; the
+        models' fused launch reads that form directly (NRX_FEAT_BAG_CSR: same pooled values, bit for bit).
+        resident=True: every column is uploaded ONCE and stays in HBM (MIND's training split is a few GB of
         integer columns; one MI355X has 288 GB); a batch is then a device-side row gather -- no host work, no
         PCIe traffic per batch, and a shuffled epoch costs the same as a sequential one.  Same batches, bit
         for bit, as the streaming mode."""
@@ -137,6 +141,9 @@ class ColumnarLoader:
             raise ValueError("resident=True keeps the dataset in GPU memory: it needs a cuda device")
         self._res = None
         self.expand_on_device = expand_on_device and self.device.type == "cuda"
+        self.csr_bags = bool(csr_bags)
+        if self.csr_bags and (self.resident or self.device.type != "cuda"):
+            raise ValueError("csr_bags=True is a streaming-mode option for cuda devices")
         self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         # ring of grow-only pinned staging buffers: batch-dependent sizes (CSR value counts under
         # shuffle) would otherwise miss torch's pinned-memory cache and pay a hipHostMalloc per batch
@@ -207,10 +214,13 @@ class ColumnarLoader:
         out["label"] = pin(hb["label"]).to(dev, non_blocking=True)
         for k, (vals, rel) in hb["array"].items():
             L = self.ds.max_len[k]
-            if self.expand_on_device:
+            if self.expand_on_device or self.csr_bags:
                 v = pin(vals).to(dev, non_blocking=True) if vals.size else torch.zeros(0, dtype=torch.from_numpy(vals).dtype, device=dev)
                 o = pin(rel).to(dev, non_blocking=True)
-                out[k], out[f"{k}_mask"] = ops.csr_to_padded(v, o, L)
+                if self.csr_bags:
+                    out[k], out[f"{k}_offsets"] = v, o
+                else:
+                    out[k], out[f"{k}_mask"] = ops.csr_to_padded(v, o, L)
             else:
                 Bn = len(rel) - 1
                 ids = np.zeros((Bn, L), vals.dtype)

@@ -31,7 +31,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ..._lib import NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_DENSE, NRX_SPARSE
+from ..._lib import NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_DENSE, NRX_FEAT_BAG_CSR, NRX_SPARSE
 from ...config import load_config, to_container
 from ...lightning_shim import LightningModule
 
@@ -172,6 +172,14 @@ class BaseModel(LightningModule):
             if n in self.dense_feature_names:
                 key_items.append((n, NRX_DENSE, 0))
             elif n in self.array_feature_names:
+                if batch.get(f"{n}_offsets") is not None:
+                    # CSR batch (ColumnarLoader(csr_bags=True)): ids [nnz] + offsets [B + 1] instead of DataReader's padded
+                    # ids + mask; same result, the padded length comes from the config (negative L marks the form here)
+                    L = self.array_max_length.get(n)
+                    if L is None:
+                        raise ValueError(f"Max length for array feature '{n}' missing in config.")
+                    key_items.append((n, NRX_BAG_MASKED_MEAN, -int(L)))
+                    continue
                 has_mask = f"{n}_mask" in batch and batch[f"{n}_mask"] is not None
                 key_items.append((n, NRX_BAG_MASKED_MEAN if has_mask else NRX_BAG_MEAN, int(batch[n].shape[1])))
             else:
@@ -200,8 +208,8 @@ class BaseModel(LightningModule):
             wide = n in wide_names
             if wide and kind != NRX_SPARSE:
                 raise ValueError(f"wide feature '{n}' must be a single-valued sparse feature")
-            slots.append(ops.Slot(n, kind, table_names.index(tname), D, L, col, wide_col=wcol if wide else -1,
-                                  fm_field=int(fm)))
+            slots.append(ops.Slot(n, kind, table_names.index(tname), D, abs(L), col, wide_col=wcol if wide else -1,
+                                  fm_field=int(fm), flags=NRX_FEAT_BAG_CSR if L < 0 else 0))
             dims.append(D)
             if wide:
                 wcol += 1
@@ -225,7 +233,7 @@ class BaseModel(LightningModule):
         if ent is not None:
             plan, tables, in_names, mask_names, bag_lens, dims, present = ent
             for n, L in bag_lens:                       # array features: the padded length is part of the plan
-                if batch[n].shape[1] != L:
+                if batch[n].dim() != 2 or batch[n].shape[1] != L:
                     ent = None
                     break
             if ent is not None and tables and tables[0] is not self.embedding_tables[self._first_table[ck]].weight:
@@ -236,8 +244,10 @@ class BaseModel(LightningModule):
                 return None, None, None, [], []
             tables = [self.embedding_tables[t].weight for t in table_names]
             in_names = [s.name for s in plan.slots]
-            mask_names = [f"{s.name}_mask" if s.kind == NRX_BAG_MASKED_MEAN else None for s in plan.slots]
-            bag_lens = [(s.name, s.bag_len) for s in plan.slots if s.kind in (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN)]
+            mask_names = [(f"{s.name}_offsets" if s.flags & NRX_FEAT_BAG_CSR else f"{s.name}_mask") if s.kind == NRX_BAG_MASKED_MEAN
+                          else None for s in plan.slots]
+            bag_lens = [(s.name, s.bag_len) for s in plan.slots
+                        if s.kind in (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN) and not s.flags & NRX_FEAT_BAG_CSR]
             any_mask = any(m is not None for m in mask_names)
             ent = (plan, tables, in_names, mask_names if any_mask else None, bag_lens, list(dims), list(present))
             if table_names:

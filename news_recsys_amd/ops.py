@@ -22,7 +22,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_MAX_FEATURES, NRX_SPARSE,
+from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_FEAT_BAG_CSR, NRX_MAX_FEATURES, NRX_SPARSE,
                    NrxFeature, NrxFmGrad, check)
 
 # ------------------------------------------------------------------------------- helpers
@@ -183,6 +183,26 @@ def _prep_inputs(plan: EmbedPlan, tables, inputs, weights):
         if not x.is_cuda:
             _dev(x, f"feature '{s.name}'")
         dt = x.dtype
+        if s.flags & NRX_FEAT_BAG_CSR:
+            # CSR bag: x = the concatenated ids of all bags [nnz], w = int64 offsets [B + 1] (no mask: every entry counts)
+            if s.kind < NRX_BAG_MASKED_MEAN:
+                raise ValueError(f"feature '{s.name}': NRX_FEAT_BAG_CSR on a non-bag feature")
+            if w is None or w.dim() != 1 or w.numel() < 1 or w.dtype is not i64 or not w.is_cuda:
+                raise ValueError(f"feature '{s.name}': a CSR bag needs device int64 offsets [B + 1] in place of the mask")
+            if x.dim() != 1:
+                raise ValueError(f"feature '{s.name}': CSR bag ids must be a 1-D [nnz] tensor, got {tuple(x.shape)}")
+            if dt is not i64 and dt is not i32:
+                x = x.long()
+            if x.numel() == 0:
+                x = torch.zeros(1, dtype=x.dtype, device=x.device)      # never read (every bag is empty); keeps the pointer valid
+            nb = w.numel() - 1
+            if B is None:
+                B = nb
+            elif nb != B:
+                raise ValueError(f"feature '{s.name}': batch {nb} != {B}")
+            ins.append(x.contiguous())
+            ws.append(w.contiguous())
+            continue
         if s.kind == NRX_DENSE:
             if dt is not f32 and dt is not f64:
                 x = x.float()
@@ -215,6 +235,23 @@ def _prep_inputs(plan: EmbedPlan, tables, inputs, weights):
     return B, ins, ws
 
 
+def _csr_plan_to_padded(plan: EmbedPlan, inputs, weights):
+    """The same launch with every CSR bag expanded to the reference's padded ids + mask (nrx_csr_to_padded): what the
+    row-sparse backward's planner takes.  The derived plan is cached on the plan."""
+    import dataclasses
+    padded = plan.__dict__.get("_padded_plan")
+    if padded is None:
+        padded = EmbedPlan([dataclasses.replace(s, flags=s.flags & ~NRX_FEAT_BAG_CSR) for s in plan.slots],
+                           out_width=plan.out_width, wide_width=plan.wide_width, use_fm=plan.use_fm)
+        plan.__dict__["_padded_plan"] = padded
+    inputs, weights = list(inputs), list(weights)
+    for i, s in enumerate(plan.slots):
+        if s.flags & NRX_FEAT_BAG_CSR:
+            ids, mask = csr_to_padded(inputs[i], weights[i], s.bag_len)
+            inputs[i], weights[i] = ids, (None if s.kind == NRX_BAG_MEAN else mask)
+    return padded, inputs, weights
+
+
 class _EmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan: EmbedPlan, inputs, weights, out_ld, need_out, sparse_grad, index_check, *tables):
@@ -223,6 +260,8 @@ class _EmbedFn(torch.autograd.Function):
         ctx.sink = sparse_grad if isinstance(sparse_grad, SparseGradSink) else None
         ctx.sparse_grad = bool(sparse_grad)
         ctx.tables = list(tables) if ctx.sink is not None else None
+        if sparse_grad and any(s.flags & NRX_FEAT_BAG_CSR for s in plan.slots):
+            plan, inputs, weights = _csr_plan_to_padded(plan, inputs, weights)      # the planner sorts padded [B, L] lookups
         B, ins, ws = _prep_inputs(plan, tables, inputs, weights)
         dev = tables[0].device if tables else ins[0].device
         ld = int(out_ld) if out_ld else plan.out_width
@@ -521,7 +560,7 @@ class _FastForward:
             B, ins, ws = _prep_inputs(plan, tables, inputs, weights)
             self.view["index"] = [x.data_ptr() for x in ins]
             self.view["index_bits"] = [x.element_size() * 8 for x in ins]
-            self.view["weight"] = [0 if w is None or k == NRX_BAG_MEAN else w.data_ptr() for w, k in zip(ws, self.kinds)]
+            self.view["weight"] = [0 if w is None else w.data_ptr() for w in ws]      # (ignored by the library for padded NRX_BAG_MEAN)
             self._bits = None
             self._keep = (ins, ws)
             dev = ins[0].device

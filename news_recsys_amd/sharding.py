@@ -39,7 +39,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_FEAT_ROW0_IS_DATA, NRX_SPARSE)
+from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_FEAT_BAG_CSR, NRX_FEAT_ROW0_IS_DATA, NRX_SPARSE)
 
 
 # --------------------------------------------------------------------------------- partition helpers
@@ -768,6 +768,9 @@ def shard_model_(model, rank: int, world: int, group=None, backend=None):
             feats.append(ShardedFeature(s.name, s.kind, tname, s.dim, s.bag_len, s.wide_col >= 0, bool(s.fm_field)))
         inputs = [batch[s.name] for s in plan.slots]
         weights = [batch.get(f"{s.name}_mask") if s.kind == NRX_BAG_MASKED_MEAN else None for s in plan.slots]
+        for i, s in enumerate(plan.slots):          # CSR bags (name + "_offsets"): the exchange routes the padded form
+            if s.flags & NRX_FEAT_BAG_CSR:
+                inputs[i], weights[i] = ops.csr_to_padded(inputs[i], batch[f"{s.name}_offsets"], s.bag_len)
         tables = {t: model.embedding_tables[t].weight for t in table_names}
         out, wide, fmv = eng.forward(feats, inputs, weights, tables, out_ld=out_ld, need_out=need_out)
         return out, wide, fmv, list(dims), list(present)

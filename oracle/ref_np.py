@@ -462,6 +462,21 @@ def csr_from_mask(mask: np.ndarray):
     return offsets, pos
 
 
+def csr_bag_to_padded(values: np.ndarray, offsets: np.ndarray, bag_len: int):
+    """CSR bags -> the padded ids [B, L] + mask [B, L] that DataReader.__getitem__ builds per sample
+    (src/dataset/DataReader/data_reader.py:96-109: short bags are 0-padded with mask 0, long ones cut to the first L).
+    The definition of what a NRX_FEAT_BAG_CSR feature pools."""
+    values, offsets = np.asarray(values), np.asarray(offsets, np.int64)
+    B = len(offsets) - 1
+    ids = np.zeros((B, bag_len), values.dtype if values.size else np.int64)
+    mask = np.zeros((B, bag_len), np.float32)
+    for b in range(B):
+        n = min(int(offsets[b + 1] - offsets[b]), bag_len)
+        ids[b, :n] = values[offsets[b]:offsets[b] + n]
+        mask[b, :n] = 1.0
+    return ids, mask
+
+
 def unique_inverse(ids: np.ndarray):
     u, inv = np.unique(np.asarray(ids, np.int64), return_inverse=True)
     return u, inv.astype(np.int64)

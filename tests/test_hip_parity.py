@@ -486,7 +486,10 @@ def test_dcn_v1_vs_oracle(B, D, NL):
         np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(want).max() if want.size else 0.0))
 
 
-@pytest.mark.parametrize("B,D,NL", [(1, 4, 1), (200, 320, 2), (130, 112, 3), (65, 37, 2), (1000, 64, 1), (127, 129, 1)])
+@pytest.mark.parametrize("B,D,NL", [(1, 4, 1), (200, 320, 2), (130, 112, 3), (65, 37, 2), (1000, 64, 1), (127, 129, 1),
+                                    # 64 < D <= 128, D % 4 == 0: the narrow kernel (W in registers, persistent 64-row tiles) at every
+                                    # group count, partial last tiles, and batches larger than one pass of the persistent grid
+                                    (63, 68, 2), (64, 80, 1), (1, 96, 1), (257, 100, 2), (40000, 112, 1), (131, 128, 2), (70000, 124, 1)])
 def test_dcn_v2_vs_oracle(B, D, NL):
     rng = np.random.default_rng(B * 3 + D)
     x = rng.standard_normal((B, D)).astype(np.float32)

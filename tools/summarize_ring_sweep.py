@@ -7,7 +7,7 @@ d = sys.argv[1]
 
 
 def short(name):
-    m = re.search(r"embed_fwd_(ring|uniform)<([^>]*)>", name)
+    m = re.search(r"embed_fwd_(ring|uniform)<([^>]*)>", name.replace("(", ">(", 1) if "<" in name and ">" not in name else name)
     if not m:
         return None
     a = [x.strip() for x in m.group(2).split(",")]
@@ -43,6 +43,25 @@ for f in sorted(glob.glob(f"{d}/pmc*/*/*_counter_collection.csv")):
             rows.setdefault(k, {})[c] = sum(v) / len(v)
 
 
+# compiler resource usage (hipcc -Rpass-analysis=kernel-resource-usage, captured at build time in tools/c2_ring_sweep.resources.txt):
+# the kernel-trace CSV's VGPR_Count is the arch-VGPR half of the unified file on gfx950, not the allocation
+import os
+res = {}
+rp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c2_ring_sweep.resources.txt")
+if os.path.exists(rp):
+    for line in open(rp):
+        parts = [x.strip() for x in line.split("|")]
+        k = short(parts[0] + "(")
+        if k:
+            res[k] = {p.rsplit(" ", 1)[0]: p.rsplit(" ", 1)[1] for p in parts[1:]}
+for k, r in rows.items():
+    if k in res:
+        r["vgpr"] = int(res[k]["VGPRs"])
+        r["occ"] = res[k]["waves/SIMD"]
+        r["sgpr"] = res[k]["SGPRs"]
+        r["spill"] = res[k]["VGPR spills"]
+
+
 def occ(v):
     if not v:
         return ""
@@ -53,13 +72,13 @@ def occ(v):
 print(f"# C2 uniform-gather sweep ({d}): 26 tables x 1M x 16 fp32, B = 65536, uniform int64 ids, recycled output buffer")
 print("# rocprofv3 per kernel: --kernel-trace --stats (avg us) and separate --pmc passes (mean per dispatch, warm-up fifth dropped)")
 print("# quad-cycle counters (SQ_*) are summed over all waves; DRAM MB = *_DRAM_32B x 32 B\n")
-cols = ["variant", "VGPR", "waves/SIMD", "rocprof avg us", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "TCP_PENDING_STALL",
+cols = ["variant", "VGPR", "SGPR", "spills", "waves/SIMD", "rocprof avg us", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "TCP_PENDING_STALL",
         "VMEM_RD", "VMEM_WR", "VALU", "DRAM rd MB", "DRAM wr MB", "EA rd req", "EA wr 64B req"]
 print("| " + " | ".join(cols) + " |")
 print("|" + "---|" * len(cols))
 g = lambda r, k, s=1.0, f="{:.0f}": (f.format(r[k] * s) if k in r else "")
 for k, r in rows.items():
-    print("| " + " | ".join([k, str(r.get("vgpr", "")), str(occ(r.get("vgpr", 0))), g(r, "avg_us", 1, "{:.2f}"),
+    print("| " + " | ".join([k, str(r.get("vgpr", "")), str(r.get("sgpr", "")), str(r.get("spill", "")), str(r.get("occ", occ(r.get("vgpr", 0)))), g(r, "avg_us", 1, "{:.2f}"),
                              g(r, "SQ_WAVE_CYCLES", 1e-6, "{:.1f}M"), g(r, "SQ_WAIT_ANY", 1e-6, "{:.1f}M"), g(r, "SQ_WAIT_INST_ANY", 1e-6, "{:.1f}M"),
                              g(r, "TCP_PENDING_STALL_CYCLES_sum", 1e-6, "{:.1f}M"), g(r, "SQ_INSTS_VMEM_RD"), g(r, "SQ_INSTS_VMEM_WR"), g(r, "SQ_INSTS_VALU"),
                              g(r, "TCC_EA0_RDREQ_DRAM_32B_sum", 32e-6, "{:.1f}"), g(r, "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", 32e-6, "{:.1f}"),
