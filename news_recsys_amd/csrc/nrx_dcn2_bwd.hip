@@ -147,64 +147,102 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
     constexpr int AP = BM / 32;           // float4 per thread of the A slab (4), B slab: 2
     float4 a[AP], w[2];
     auto zero4 = [] { return make_float4(0.f, 0.f, 0.f, 0.f); };
-    auto ld4 = [&](const float* p, bool full) -> float4 {        // p valid for >= 1 element
-        if (VEC) return *reinterpret_cast<const float4*>(p);
-        (void)full;
-        return make_float4(p[0], 0.f, 0.f, 0.f);
-    };
+    // Aligned (VEC) path, written for few VALU instructions per slab like the forward kernel (VALU time is not hidden under
+    // the fp32 MFMA): wave-uniform tile bases advanced on the scalar unit + fixed 32-bit per-thread byte offsets; rows /
+    // columns past the edge are CLAMPED (their products land in accumulator rows / columns that are never stored), and only
+    // a partial last K slab pays for zero selects.  M-major operand: thread (row = tid / 8 (+32 p), 4 floats at k = 4 (tid % 8));
+    // K-major operand: thread (k = tid / 8, 4 floats at column 4 (tid % 8 + 8 p)).
+    const int srow = tid >> 3, skq = (tid & 7) * 4;
+    const int kk = tid >> 3, c4 = tid & 7;
+    uint32_t oa[AP], ow[2];
+    const char* abase;
+    const char* bbase = reinterpret_cast<const char*>(B + n0);
+    if (MODE == DGRAD) {
+        abase = reinterpret_cast<const char*>(A + m0 * lda);
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            const int64_t r = m0 + srow + 32 * p < M ? srow + 32 * p : M - 1 - m0;
+            oa[p] = (uint32_t)((r * lda + skq) * 4);
+        }
+    } else {
+        abase = reinterpret_cast<const char*>(A + m0);
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            int64_t m = 4 * (c4 + 8 * p);
+            if (m0 + m + 4 > M) m = M - 4 - m0 > 0 ? M - 4 - m0 : 0;
+            oa[p] = (uint32_t)(((int64_t)kk * lda + m) * 4);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        int n = 4 * (c4 + 8 * p);
+        if (n0 + n + 4 > N) n = N - 4 - n0 > 0 ? N - 4 - n0 : 0;
+        ow[p] = (uint32_t)(((int64_t)kk * ldb + n) * 4);
+    }
     auto load_slab = [&](int64_t k0) {
+        if (VEC) {
+            // K-major operands advance by whole rows of the source, the M-major one by 32 floats
+            const char* ak = abase + (MODE == DGRAD ? (size_t)k0 * 4 : (size_t)k0 * (size_t)lda * 4);
+            const char* bk = bbase + (size_t)k0 * (size_t)ldb * 4;
+            if (k0 + BK <= kend) {
+#pragma unroll
+                for (int p = 0; p < AP; ++p) a[p] = *reinterpret_cast<const float4*>(ak + oa[p]);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) w[p] = *reinterpret_cast<const float4*>(bk + ow[p]);
+            } else {                    // partial last slab: out-of-range k re-reads slab kbeg's address and is zeroed
+                const bool oka = MODE == DGRAD ? k0 + skq + 4 <= kend : k0 + kk < kend;
+                const bool okb = k0 + kk < kend;
+                const size_t backa = oka ? 0 : (MODE == DGRAD ? (size_t)(k0 - kbeg) * 4 : (size_t)(k0 - kbeg) * (size_t)lda * 4);
+                const size_t backb = okb ? 0 : (size_t)(k0 - kbeg) * (size_t)ldb * 4;
+#pragma unroll
+                for (int p = 0; p < AP; ++p) {
+                    const float4 t = *reinterpret_cast<const float4*>(ak + oa[p] - backa);
+                    a[p] = oka ? t : zero4();
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const float4 t = *reinterpret_cast<const float4*>(bk + ow[p] - backb);
+                    w[p] = okb ? t : zero4();
+                }
+            }
+            return;
+        }
         if (MODE == DGRAD) {
-            // A M-major: thread (row = tid >> 3 (+32p), kq = (tid & 7) * 4): float4 along k
-            const int srow = tid >> 3, skq = (tid & 7) * 4;
 #pragma unroll
             for (int p = 0; p < AP; ++p) {
                 int64_t r = m0 + srow + 32 * p;
                 r = r < M ? r : M - 1;
                 const int64_t k = k0 + skq;
-                if (VEC) a[p] = k + 4 <= kend ? *reinterpret_cast<const float4*>(A + r * lda + k) : zero4();
-                else {
-                    a[p].x = k < kend ? A[r * lda + k] : 0.f; a[p].y = k + 1 < kend ? A[r * lda + k + 1] : 0.f;
-                    a[p].z = k + 2 < kend ? A[r * lda + k + 2] : 0.f; a[p].w = k + 3 < kend ? A[r * lda + k + 3] : 0.f;
-                }
+                a[p].x = k < kend ? A[r * lda + k] : 0.f; a[p].y = k + 1 < kend ? A[r * lda + k + 1] : 0.f;
+                a[p].z = k + 2 < kend ? A[r * lda + k + 2] : 0.f; a[p].w = k + 3 < kend ? A[r * lda + k + 3] : 0.f;
             }
         } else {
-            // A K-major: thread (k = tid >> 3 (0..31), m4 = (tid & 7) + 8p): float4 along m
-            const int kk = tid >> 3;
             const int64_t k = k0 + kk;
 #pragma unroll
             for (int p = 0; p < AP; ++p) {
-                const int64_t m = m0 + 4 * ((tid & 7) + 8 * p);
+                const int64_t m = m0 + 4 * (c4 + 8 * p);
                 if (k < kend) {
-                    if (VEC && m + 4 <= M) a[p] = *reinterpret_cast<const float4*>(A + k * lda + m);
-                    else {
-                        a[p].x = m < M ? A[k * lda + m] : 0.f; a[p].y = m + 1 < M ? A[k * lda + m + 1] : 0.f;
-                        a[p].z = m + 2 < M ? A[k * lda + m + 2] : 0.f; a[p].w = m + 3 < M ? A[k * lda + m + 3] : 0.f;
-                    }
+                    a[p].x = m < M ? A[k * lda + m] : 0.f; a[p].y = m + 1 < M ? A[k * lda + m + 1] : 0.f;
+                    a[p].z = m + 2 < M ? A[k * lda + m + 2] : 0.f; a[p].w = m + 3 < M ? A[k * lda + m + 3] : 0.f;
                 } else a[p] = zero4();
             }
         }
-        {   // B K-major in both modes: thread (k = tid >> 3, n4 = (tid & 7) + 8p), p < 2
-            const int kk = tid >> 3;
+        {
             const int64_t k = k0 + kk;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const int n = n0 + 4 * ((tid & 7) + 8 * p);
+                const int n = n0 + 4 * (c4 + 8 * p);
                 if (k < kend) {
-                    if (VEC && n + 4 <= N) w[p] = *reinterpret_cast<const float4*>(B + k * ldb + n);
-                    else {
-                        w[p].x = n < N ? B[k * ldb + n] : 0.f; w[p].y = n + 1 < N ? B[k * ldb + n + 1] : 0.f;
-                        w[p].z = n + 2 < N ? B[k * ldb + n + 2] : 0.f; w[p].w = n + 3 < N ? B[k * ldb + n + 3] : 0.f;
-                    }
+                    w[p].x = n < N ? B[k * ldb + n] : 0.f; w[p].y = n + 1 < N ? B[k * ldb + n + 1] : 0.f;
+                    w[p].z = n + 2 < N ? B[k * ldb + n + 2] : 0.f; w[p].w = n + 3 < N ? B[k * ldb + n + 3] : 0.f;
                 } else w[p] = zero4();
             }
         }
     };
-    (void)ld4;
     if (kbeg < kend) load_slab(kbeg);
 
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         if (MODE == DGRAD) {
-            const int srow = tid >> 3, skq = (tid & 7) * 4;
 #pragma unroll
             for (int p = 0; p < AP; ++p) {
                 const int m = srow + 32 * p;
@@ -214,7 +252,6 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
                 As[(skq + 3) * LDA + m] = a[p].w;
             }
         } else {
-            const int kk = tid >> 3;
 #pragma unroll
             for (int p = 0; p < AP; ++p) {
                 const int m = 4 * ((tid & 7) + 8 * p);
@@ -225,7 +262,6 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
             }
         }
         {
-            const int kk = tid >> 3;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int n = 4 * ((tid & 7) + 8 * p);

@@ -3,12 +3,13 @@
 // next to the library's current nrx_embed_fwd, checking every variant bit-for-bit against it.
 //   make -C news_recsys_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Inews_recsys_amd/csrc \
 //       tools/c2_ring_sweep.hip -Lnews_recsys_amd/lib -lnrx_hip -Wl,-rpath,'$ORIGIN/../../news_recsys_amd/lib' -o tools/bin/c2_ring_sweep
-// usage: c2_ring_sweep [F=26] [rows=1000000] [D=16] [distinct_out=0]
+// usage: c2_ring_sweep [F=26] [rows=1000000] [D=16] [distinct_out=0] [zipf=0]   (zipf=1: Zipf(1.05) ids as bench.py --ids zipf)
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <vector>
 #include <algorithm>
 #include "nrx_embed_ring.h"
@@ -33,10 +34,12 @@ int main(int argc, char** argv) {
     const int64_t rows = argc > 2 ? atoll(argv[2]) : 1000000;
     const int D = argc > 3 ? atoi(argv[3]) : 16;
     const int distinct = argc > 4 ? atoi(argv[4]) : 0;
+    const int zipf = argc > 5 ? atoi(argv[5]) : 0;
     const int64_t B = 65536;
     const int POOL = 8, STEPS = 60, REPS = 3;
     const int Q = D / 4;
-    printf("# F=%d rows=%lld D=%d B=%lld pool=%d steps=%d distinct_out=%d\n", F, (long long)rows, D, (long long)B, POOL, STEPS, distinct);
+    printf("# F=%d rows=%lld D=%d B=%lld pool=%d steps=%d distinct_out=%d ids=%s\n", F, (long long)rows, D, (long long)B, POOL, STEPS, distinct,
+           zipf ? "zipf(1.05)" : "uniform");
 
     std::vector<float*> tables(F);
     for (int f = 0; f < F; ++f) {
@@ -49,7 +52,17 @@ int main(int argc, char** argv) {
     uint64_t s = 1234567;
     for (int pl = 0; pl < POOL; ++pl)
         for (int f = 0; f < F; ++f) {
-            for (int64_t i = 0; i < B; ++i) { s = mix64(s); h[i] = 1 + (int64_t)(s % (uint64_t)(rows - 1)); }
+            for (int64_t i = 0; i < B; ++i) {
+                s = mix64(s);
+                if (zipf) {      // continuous power law on [1, n], inverse CDF (bench.py draw_ids)
+                    const double u = (double)(s >> 11) * (1.0 / 9007199254740992.0), a = 1.05, n = (double)(rows - 1);
+                    const double r = pow(1.0 + u * (pow(n, 1.0 - a) - 1.0), 1.0 / (1.0 - a));
+                    int64_t v = (int64_t)r;
+                    h[i] = v < 1 ? 1 : (v > rows - 1 ? rows - 1 : v);
+                } else {
+                    h[i] = 1 + (int64_t)(s % (uint64_t)(rows - 1));
+                }
+            }
             CK(hipMalloc(&ids[pl][f], B * 8));
             CK(hipMemcpy(ids[pl][f], h.data(), B * 8, hipMemcpyHostToDevice));
         }
@@ -80,7 +93,7 @@ int main(int argc, char** argv) {
     auto ua_for = [&](int pl, float* out, float* fmo) {
         UniformArgs ua;
         for (int f = 0; f < F; ++f) { ua.table[f] = tables[f]; ua.index[f] = ids[pl][f]; ua.rows[f] = rows; ua.col4[f] = f * Q; }
-        ua.batch = B; ua.out = (float4*)out; ua.ld4 = (int64_t)F * Q; ua.fm_out = fmo; ua.status = status; ua.n = F; ua.idx64 = 1;
+        ua.batch = B; ua.out = (float4*)out; ua.ld4 = (int64_t)F * Q; ua.fm_out = fmo; ua.fm_sums = nullptr; ua.sums_ld = 0; ua.status = status; ua.n = F; ua.idx64 = 1;
         return ua;
     };
 
@@ -108,7 +121,11 @@ int main(int argc, char** argv) {
             }
             if (has_fm) {
                 CK(hipMemcpy(h_fm.data(), fm, B * 4, hipMemcpyDeviceToHost));
-                ok &= memcmp(h_fm.data(), h_fm_ref.data(), B * 4) == 0;
+                // the concat must be bit-exact; the FM logit is a float reduction whose contraction (fma or mul + add) the
+                // compiler chooses per instantiation: compared within 1e-5 of the largest logit
+                float scale = 1.f;
+                for (int64_t i = 0; i < B; ++i) scale = fabsf(h_fm_ref[i]) > scale ? fabsf(h_fm_ref[i]) : scale;
+                for (int64_t i = 0; i < B && ok; ++i) ok &= fabsf(h_fm[i] - h_fm_ref[i]) <= 1e-5f * scale;
             }
             if (!ok) { printf("%-44s MISMATCH vs library result\n", name); fflush(stdout); return; }
         }
@@ -160,6 +177,7 @@ int main(int argc, char** argv) {
     RING(2, 13, true, true, true, 2);
     RING(2, 20, true, true, true, 2);
     RING(2, 8, true, true, false, 4);
+    RING(2, 4, true, true, false, 4);
     RING(2, 8, false, true, true, 4);      // no FM epilogue
     RING(2, 8, true, false, true, 4);      // gather only (FM logit only)
     // wider rows
