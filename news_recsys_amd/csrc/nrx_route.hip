@@ -381,6 +381,103 @@ __global__ __launch_bounds__(NRX_BLOCK) void inbox_kernel(const InboxArgs args_i
     }
 }
 
+// Ring form of the owner-side GATHER for float4-addressable rows of up to 256 floats (the common case; the kernel above keeps
+// the scatter-add, odd widths and wider rows).  Same idea as embed_fwd_ring: the R-load burst + R-store burst of the kernel
+// above makes every block phase between reading and writing; here a lane group walks NS = R * NC consecutive-stride slots
+// with R row reads in flight -- `store slot i; issue the load of slot i + R` -- so reads and writes interleave at row
+// granularity, and a persistent grid (a few blocks per CU, each looping over (source, chunk) work items) replaces thousands
+// of short blocks whose prologue (per-source feature prefix + binary searches) was paid once per 8 rows per lane.
+// C2 at world = 1 (1.7 M rows of 64 B): 85 -> see profiles; results identical (a gather: bit-exact).
+constexpr int INBOX_NC = 4;   // chunks of INBOX_R slots per lane group and work item
+
+template <int QLOG2>
+__global__ __launch_bounds__(NRX_BLOCK) void inbox_gather_ring_kernel(const InboxArgs args_in_kernarg, int chunks_per_source) {
+    const NRX_CONST InboxArgs* a = nrx_kernarg<InboxArgs>();
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    constexpr int R = INBOX_R, NS = INBOX_R * INBOX_NC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int64_t* s_pre = reinterpret_cast<int64_t*>(smem);       // [F + 1] prefix of the current source rank
+    __shared__ const float* s_ptr[NS * TB];                  // the work item's row addresses (null past the source's count)
+    const int F = a->n_feats;
+    const int64_t cap = a->cap;
+    const int q = threadIdx.x & (Q - 1), g = threadIdx.x >> QLOG2;
+    const int D4 = a->dim >> 2;                              // float4 per row; lanes with q >= D4 idle
+    const int nwork = a->world * chunks_per_source;
+    int s_cur = -1;
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const int s = work / chunks_per_source;
+        const int chunk = work - s * chunks_per_source;
+        if (s != s_cur) {                                    // block-uniform: (re)build the feature prefix of source s
+            __syncthreads();
+            if (threadIdx.x < 64) {                          // one wavefront: F <= 64 counts, inclusive scan by shuffles
+                const int f = threadIdx.x;
+                int64_t c = f < F ? a->recv2d[s * F + f] : 0;
+                int64_t incl = c;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int64_t t = __shfl_up(incl, off, 64);
+                    if (f >= off) incl += t;
+                }
+                if (f < F) s_pre[f] = incl - c;
+                if (f == F - 1) s_pre[F] = incl;
+            }
+            __syncthreads();
+            s_cur = s;
+        }
+        const int64_t total = s_pre[F] < cap ? s_pre[F] : cap;
+        const int64_t base = (int64_t)chunk * (TB * NS);
+        if (base >= total) continue;                         // block-uniform: nothing of this chunk is in use
+        const int64_t j0 = base + g;
+        // the chunk's slots are resolved ONCE, by the whole block in full-width coalesced loads: local row -> bounds check ->
+        // owning table (prefix search) -> row address, parked in LDS; the walk below then needs one ds_read per row load
+        // (resolving inside the walk put a ~6-step dependent chain in front of every load: 113 us instead of 85)
+        __syncthreads();                                     // (the previous work item's readers are done)
+        const NRX_GLOBAL int32_t* inb = nrx_gconst<int32_t>(a->inbox) + s * cap + base;
+#pragma unroll
+        for (int i = 0; i < NS * TB / NRX_BLOCK; ++i) {
+            const int pos = i * NRX_BLOCK + threadIdx.x;
+            const int64_t j = base + pos;
+            const float* ptr = nullptr;
+            if (j < total) {
+                int lo = 0, hi = F;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_pre[mid] <= j) lo = mid; else hi = mid;
+                }
+                const int tab = a->feat_table[lo];
+                int64_t row = inb[pos];
+                if ((uint64_t)row >= (uint64_t)a->rows[tab]) {
+                    nrx_report_oob(a->status, tab, s * cap + j, row);
+                    row = 0;
+                }
+                ptr = a->table[tab] + row * (int64_t)a->dim;
+            }
+            s_ptr[pos] = ptr;
+        }
+        __syncthreads();
+        auto fetch = [&](int i) -> float4 {
+            const float* ptr = s_ptr[i * TB + g];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ptr != nullptr && q < D4) v = nrx_ldg4_nt(ptr, q);
+            return v;
+        };
+        float4 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = fetch(r);
+#pragma unroll 1
+        for (int c = 0; c < INBOX_NC; ++c) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = c * R + r;
+                const int64_t j = j0 + (int64_t)i * TB;
+                if (j < total && q < D4) nrx_stg4(a->buf, (s * cap + j) * D4 + q, v[r]);
+                if (c + 1 < INBOX_NC) v[r] = fetch(i + R);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- owner-side partial pooling
 // Pooled-bag channel: block s of the inbox holds {local row, tag, weight} triples in SOURCE order, so
 // all lookups of one (feature, sample) -- one tag -- that this rank owns are CONTIGUOUS: a run.  Pass 1 (one thread per
@@ -549,6 +646,28 @@ int launch_inbox(InboxArgs& a, hipStream_t st, const char* who) {
     const int per_block = tb * INBOX_R;
     dim3 grid((unsigned)((a.cap + per_block - 1) / per_block), (unsigned)a.world);
     const size_t smem = (size_t)(a.n_feats + 1) * sizeof(int64_t);
+    if (!SCATTER && (a.dim & 3) == 0 && a.dim <= 256 && ql >= 2) {          // ring form (see inbox_gather_ring_kernel)
+        for (int t = 0; t < a.n_feats; ++t)
+            if (!nrx_aligned16(a.table[a.feat_table[t]])) goto classic;
+        {
+            const int per_item = tb * INBOX_R * INBOX_NC;
+            const int64_t cps = (a.cap + per_item - 1) / per_item;
+            NRX_REQUIRE(cps * a.world <= 0x7fffffffLL, "%s: too many rows for one launch", who);
+            int64_t g = cps * a.world;
+            if (g < 512) goto classic;            // a small exchange (C4's id features: 64 items) fills the chip better with the short blocks
+            const int64_t persistent = 256 * 6;                              // ~6 resident blocks per CU walk the work items
+            if (g > persistent) g = persistent;
+            switch (ql) {
+#define NRX_RCASE(QL_) case QL_: hipLaunchKernelGGL((inbox_gather_ring_kernel<QL_>), dim3((unsigned)g), dim3(NRX_BLOCK), smem, st, a, (int)cps); break;
+                NRX_RCASE(2) NRX_RCASE(3) NRX_RCASE(4) NRX_RCASE(5)
+                default: hipLaunchKernelGGL((inbox_gather_ring_kernel<6>), dim3((unsigned)g), dim3(NRX_BLOCK), smem, st, a, (int)cps); break;
+#undef NRX_RCASE
+            }
+            NRX_LAUNCH_CHECK(who);
+            return NRX_OK;
+        }
+    }
+classic:
     switch (ql) {
 #define NRX_CASE(QL_) case QL_: hipLaunchKernelGGL((inbox_kernel<QL_, SCATTER>), grid, dim3(NRX_BLOCK), smem, st, a); break;
         NRX_CASE(0) NRX_CASE(1) NRX_CASE(2) NRX_CASE(3) NRX_CASE(4) NRX_CASE(5)

@@ -553,7 +553,7 @@ class PreparedShardedForward:
 
     def __init__(self, eng: RowShardedEmbedding, feats: Sequence[ShardedFeature], inputs, weights,
                  tables: Dict[str, torch.Tensor], out_ld: Optional[int] = None,
-                 out: Optional[torch.Tensor] = None, fm: Optional[torch.Tensor] = None):
+                 out: Optional[torch.Tensor] = None, fm: Optional[torch.Tensor] = None, overlap_local: bool = True):
         import ctypes as C
         from . import _lib
         self.lib = _lib.load()
@@ -613,7 +613,38 @@ class PreparedShardedForward:
         plan = eng._final_plan(feats, groups, pooled_set)
         final_inputs = [inputs[i] if (f.kind == NRX_DENSE or f.replicated) else slot_of[i] for i, f in enumerate(feats)]
         rets += [tables[n] for n in eng.replicated_tables(feats)]
-        self.final = ops.PreparedEmbed(plan, rets, final_inputs, final_weights, out_ld=out_ld, out=out, fm=fm)
+        # Features that need no exchange (dense values, planner-replicated tables) do not wait for one: they get their own
+        # launch on a side stream, concurrent with routing / all-to-alls / owner gather, and the routed features get a second
+        # launch after the exchange -- both write their own columns of the same concat.  Not possible when one epilogue
+        # spans all features (FM) or when both halves carry wide columns.
+        local = [i for i, f in enumerate(feats) if f.kind == NRX_DENSE or f.replicated]
+        routed = [i for i in range(len(feats)) if i not in set(local)]
+        wide_l = any(feats[i].wide for i in local)
+        wide_r = any(feats[i].wide for i in routed)
+        self.local = None
+        # worth two launches + two cross-stream waits only when the exchange is long: always with real peers (collective
+        # latencies), at world 1 only for a large exchange (measured at world 1: C5 17 routed tables 275 -> 225 us, but C4 /
+        # C3 with one or two routed id features 75 -> 88 / 57 -> 62 us: the step is then bound by the host's launch rate)
+        n_routed = sum(inputs[i].numel() for i in routed)
+        if overlap_local and local and routed and not plan.use_fm and not (wide_l and wide_r) and \
+                len(feats) <= ops.NRX_MAX_FEATURES and (W > 1 or n_routed >= (1 << 20)):
+            ld = int(out_ld) if out_ld else plan.out_width
+            B = inputs[0].shape[0]
+            dev0 = inputs[0].device
+            if out is None:
+                out = torch.empty((B, ld), dtype=torch.float32, device=dev0)
+
+            def sub(idx):
+                sp = ops.EmbedPlan([plan.slots[i] for i in idx], out_width=plan.out_width,
+                                   wide_width=plan.wide_width if any(feats[i].wide for i in idx) else 0)
+                return ops.PreparedEmbed(sp, rets, [final_inputs[i] for i in idx], [final_weights[i] for i in idx],
+                                         out_ld=ld, out=out)
+            self.local = sub(local)
+            self.final = sub(routed)
+            self._side = torch.cuda.Stream(device=dev0)
+            self._wide_from_local = wide_l
+        else:
+            self.final = ops.PreparedEmbed(plan, rets, final_inputs, final_weights, out_ld=out_ld, out=out, fm=fm)
 
     def _bind_pooled(self, eng, feats, idxs, inputs, weights, tables, C):
         """Buffers and descriptor arrays of one pooled-bag group (owner-side partial pooling)."""
@@ -683,6 +714,11 @@ class PreparedShardedForward:
     def run(self):
         eng, lib = self.eng, self.lib
         W = eng.world
+        if self.local is not None:          # the exchange-free features start now, on the side stream
+            cur = torch.cuda.current_stream(self._side.device)
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                lres = self.local.run()
         for g in self.groups:
             stream = torch.cuda.current_stream(g["dev"]).cuda_stream
             if g.get("pooled"):
@@ -702,7 +738,11 @@ class PreparedShardedForward:
                 ops.check(rc, "nrx_gather_inbox")
             if W > 1:
                 eng._a2a(g["ret"].view(-1), g["rows_out"].view(-1))
-        return self.final.run()
+        if self.local is None:
+            return self.final.run()
+        res = self.final.run()
+        torch.cuda.current_stream(self._side.device).wait_stream(self._side)      # both halves of the concat are in place
+        return res[0], (lres[1] if self._wide_from_local else res[1]), None
 
     def overflowed(self) -> bool:
         """True if any run since the last call exceeded a block capacity (the kernels keep a running maximum)."""
@@ -834,7 +874,9 @@ class ShardedBenchPath:
         width = sum(f.dim for f in self.feats)
         out = torch.empty((batch, width), dtype=torch.float32, device=device)       # recycled (see bench.py)
         fmb = torch.empty((batch,), dtype=torch.float32, device=device) if self.fm else None
-        self.calls = [PreparedShardedForward(self.eng, self.feats, ins, ws, self.tables, out=out, fm=fmb)
+        import os
+        overlap = os.environ.get("NRX_SHARD_NO_OVERLAP") is None            # measurement knob: time the serial form
+        self.calls = [PreparedShardedForward(self.eng, self.feats, ins, ws, self.tables, out=out, fm=fmb, overlap_local=overlap)
                       for ins, ws in self.pool]
 
     @torch.no_grad()
