@@ -121,16 +121,20 @@ __global__ __launch_bounds__(NRX_BLOCK) void route_hist(const RouteArgs args_in_
         }
     if (lane < a->world && cnt) atomicAdd(&s_cnt[lane], cnt);         // integer counts: the final value is order-independent
     __syncthreads();
-    if (tid < a->world) {
-        const int n = s_cnt[tid];
-        a->hist[(int64_t)tid * a->nchunks + chunk] = n;
-        if (n) atomicAdd((unsigned long long*)&a->counts2d[tid * a->n_feats + f], (unsigned long long)n);
-    }
+    // (the per-(owner, feature) totals come out of route_scan: one device atomic per block on the same few addresses
+    // serialised -- 1 600 blocks took 32 us for 26 MB of ids)
+    if (tid < a->world) a->hist[(int64_t)tid * a->nchunks + chunk] = s_cnt[tid];
 }
 
 // One wavefront per owner: exclusive scan of hist[o][0..nchunks) in place (256 chunks per step, coalesced); the largest
 // owner total -> overflow.
-__global__ __launch_bounds__(NRX_BLOCK) void route_scan(int32_t* __restrict__ hist, int nchunks, int world, int64_t* __restrict__ overflow) {
+// Chunks are feature-uniform, so the ids owner o receives of feature f are a difference of the scanned histogram at the
+// feature's chunk range: counts2d[o][f] = excl[chunk0[f + 1]] - excl[chunk0[f]].
+__global__ __launch_bounds__(NRX_BLOCK) void route_scan(const RouteArgs args_in_kernarg) {
+    const NRX_CONST RouteArgs* a = nrx_kernarg<RouteArgs>();
+    int32_t* __restrict__ hist = a->hist;
+    const int nchunks = a->nchunks, world = a->world;
+    int64_t* __restrict__ overflow = a->overflow;
     __shared__ int s_tot[64];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
@@ -158,6 +162,13 @@ __global__ __launch_bounds__(NRX_BLOCK) void route_scan(int32_t* __restrict__ hi
             running += __shfl(incl, 63, 64);
         }
         if (lane == 0) s_tot[o] = running;
+        __threadfence();                                   // this wavefront's scanned values, read back below by other lanes
+        for (int f = lane; f < a->n_feats; f += 64) {
+            const int c0 = a->chunk0[f], c1 = a->chunk0[f + 1];
+            const int lo = c0 < nchunks ? h[c0] : running;
+            const int hi = c1 < nchunks ? h[c1] : running;
+            a->counts2d[o * a->n_feats + f] = (int64_t)(hi - lo);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -615,18 +626,30 @@ __global__ __launch_bounds__(NRX_BLOCK) void pool_inbox_bwd_kernel(const PoolArg
 // normalised bag weights: masked mean w/(sum w + 1e-8) (base_model.py:278-282), plain mean 1/L (:275-276), sum w | 1
 __global__ __launch_bounds__(NRX_BLOCK) void bag_norm_weights_kernel(const float* __restrict__ mask, int64_t batch, int L, int kind,
                                                                      float* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6);      // one wavefront per sample
-    if (b >= batch) return;
+    // bags of up to 64 entries: 16 lanes per sample, four samples per wavefront (a wavefront per 50-entry bag left most lanes
+    // idle: 14.8 us at the C4 shape); longer bags: one wavefront per sample.  Sum order per sample is fixed either way.
+    const bool narrow = L <= 64;
+    const int gl = narrow ? 16 : 64;                                                    // lanes per sample
+    const int q = threadIdx.x & (gl - 1);
+    const int64_t b = ((int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x) / gl;
+    if (b >= batch) return;                                                              // whole lane groups leave together
     float den = 1.0f;
     if (kind == NRX_BAG_MASKED_MEAN) {
         float part = 0.f;
-        for (int l = lane; l < L; l += 64) part += mask[b * L + l];
-        den = nrx_wave_sum(part) + 1e-8f;
+        for (int l = q; l < L; l += gl) part += mask[b * L + l];
+        if (narrow) {                                                                    // sum over the 16-lane row (DPP)
+            part += nrx_dpp<0xB1>(part);
+            part += nrx_dpp<0x4E>(part);
+            part += nrx_dpp<0x141>(part);
+            part += nrx_dpp<0x140>(part);
+        } else {
+            part = nrx_wave_sum(part);
+        }
+        den = part + 1e-8f;
     } else if (kind == NRX_BAG_MEAN) {
         den = (float)L;
     }
-    for (int l = lane; l < L; l += 64) {
+    for (int l = q; l < L; l += gl) {
         const float m = (kind == NRX_BAG_MEAN || mask == nullptr) ? 1.0f : mask[b * L + l];
         out[b * L + l] = m / den;
     }
@@ -755,9 +778,8 @@ extern "C" int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_
         NRX_LAUNCH_CHECK("nrx_route_ids(world 1)");
         return NRX_OK;
     }
-    if (nrx_zero_async(counts2d, sizeof(int64_t) * (size_t)world * n_feats, st) != NRX_OK) return NRX_ERR_LAUNCH;
     if (chunks > 0) hipLaunchKernelGGL(route_hist, dim3((unsigned)chunks), dim3(NRX_BLOCK), 0, st, a);
-    hipLaunchKernelGGL(route_scan, dim3(1), dim3(NRX_BLOCK), 0, st, a.hist, (int)chunks, world, overflow);
+    hipLaunchKernelGGL(route_scan, dim3(1), dim3(NRX_BLOCK), 0, st, a);
     if (chunks > 0) hipLaunchKernelGGL(route_place, dim3((unsigned)chunks), dim3(NRX_BLOCK), 0, st, a);
     NRX_LAUNCH_CHECK("nrx_route_ids");
     return NRX_OK;
@@ -798,7 +820,8 @@ extern "C" int nrx_bag_norm_weights(const float* mask, int64_t batch, int32_t ba
     NRX_REQUIRE(kind == NRX_BAG_MASKED_MEAN || kind == NRX_BAG_MEAN || kind == NRX_BAG_SUM, "nrx_bag_norm_weights: bad kind");
     NRX_REQUIRE(kind != NRX_BAG_MASKED_MEAN || mask != nullptr, "nrx_bag_norm_weights: masked mean needs a mask");
     if (batch == 0) return NRX_OK;
-    const unsigned grid = (unsigned)((batch + NRX_BLOCK / 64 - 1) / (NRX_BLOCK / 64));
+    const int per_block = NRX_BLOCK / (bag_len <= 64 ? 16 : 64);
+    const unsigned grid = (unsigned)((batch + per_block - 1) / per_block);
     hipLaunchKernelGGL(bag_norm_weights_kernel, dim3(grid), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), mask, batch,
                        bag_len, kind, out_w);
     NRX_LAUNCH_CHECK("nrx_bag_norm_weights");
@@ -846,9 +869,8 @@ extern "C" int nrx_route_bags(const void* const* ids, const float* const* weight
     a.send_w = send_w;
     a.bags = 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (nrx_zero_async(counts2d, sizeof(int64_t) * (size_t)world * n_feats, st) != NRX_OK) return NRX_ERR_LAUNCH;
     if (chunks > 0) hipLaunchKernelGGL(route_hist, dim3((unsigned)chunks), dim3(NRX_BLOCK), 0, st, a);
-    hipLaunchKernelGGL(route_scan, dim3(1), dim3(NRX_BLOCK), 0, st, a.hist, (int)chunks, world, overflow);
+    hipLaunchKernelGGL(route_scan, dim3(1), dim3(NRX_BLOCK), 0, st, a);
     if (chunks > 0) hipLaunchKernelGGL(route_place, dim3((unsigned)chunks), dim3(NRX_BLOCK), 0, st, a);
     NRX_LAUNCH_CHECK("nrx_route_bags");
     return NRX_OK;
