@@ -555,21 +555,8 @@ __device__ __forceinline__ float* sorted_long_partials(const NRX_CONST SortedBwd
     return reinterpret_cast<float*>(reinterpret_cast<char*>(sorted_long_multi(a)) + a->long_slots_cap * sizeof(LongMulti));
 }
 
-// one lane: put unique row u (sorted entries [lo, hi)) on the work lists.  Slot / list positions come from integer atomics:
-// WHICH slot a row gets varies from run to run, the sums do not (every item sums fixed entries in a fixed order).
-__device__ __forceinline__ void sorted_long_append(const NRX_CONST SortedBwdArgs* a, int32_t u, int64_t lo, int64_t hi) {
-    const int nchunks = (int)((hi - lo + SORTED_LONG_CHUNK - 1) / SORTED_LONG_CHUNK);
-    int slot0 = -1;
-    if (nchunks > 1) {
-        slot0 = atomicAdd(&a->long_ws[2], nchunks);
-        const int m = atomicAdd(&a->long_ws[1], 1);
-        if (m < a->long_slots_cap) {
-            LongMulti w;
-            w.u = u; w.slot0 = slot0; w.nchunks = nchunks; w.pad = 0;
-            sorted_long_multi(a)[m] = w;
-        }
-    }
-    const int base = atomicAdd(&a->long_ws[0], nchunks);
+__device__ __forceinline__ void sorted_long_write_items(const NRX_CONST SortedBwdArgs* a, int32_t u, int64_t lo, int64_t hi, int nchunks,
+                                                        int slot0, int base) {
     for (int c = 0; c < nchunks; ++c) {
         if (base + c >= a->long_items_cap) break;
         LongItem w;
@@ -601,7 +588,8 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
         const int64_t nd = nrx_gconst<int64_t>(a->n_unique_dev)[0];
         n = nd < n ? nd : n;
     }
-    if (u0 >= n) return;
+    if (__ballot(u0 < n) == 0ull) return;      // whole wavefronts past the last row leave; inside the last live wavefront the
+                                               // lane groups past it stay (the work-list append below is a wavefront scan)
     const NRX_GLOBAL int64_t* seg = nrx_gconst<int64_t>(a->seg_start);
     int64_t lo[R], hi[R], key[R];
 #pragma unroll
@@ -616,15 +604,50 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
         if ((key[r] & ((1ll << 40) - 1)) == 0 || u0 + r >= n) hi[r] = lo[r];      // padding row: zeros
     // rows looked up many times (hot ids of a skewed distribution, tiny tables) would serialise this lane group for
     // their whole segment: they go to a work list and are reduced by whole wavefronts (sorted_long_kernel)
+    // The list positions of a whole wavefront come from ONE atomic: the lanes' item counts are scanned, the last lane adds
+    // the total to the item counter and every lane places its rows' items after the lanes below it.  (One atomic per row:
+    // every second row of the C4 news table is long -- 100 k round trips to the same counter.)  Rows of several chunks
+    // (rare: > 256 entries) still take their partial-sum slots individually.
     bool lng[R];
+    int need = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         lng[r] = a->long_ws != nullptr && hi[r] - lo[r] > SORTED_LONG_T;
-        if (lng[r]) {
-            if (q == 0) sorted_long_append(a, (int32_t)(u0 + r), lo[r], hi[r]);
-            hi[r] = lo[r];
+        if (lng[r] && q == 0) need += (int)((hi[r] - lo[r] + SORTED_LONG_CHUNK - 1) / SORTED_LONG_CHUNK);
+    }
+    if (__ballot(need != 0) != 0ull) {                       // wave-uniform
+        const int lane = threadIdx.x & 63;
+        int incl = need;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        int base = 0;
+        if (lane == 63) base = atomicAdd(&a->long_ws[0], incl);
+        base = __shfl(base, 63, 64) + incl - need;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (lng[r] && q == 0) {
+                const int nchunks = (int)((hi[r] - lo[r] + SORTED_LONG_CHUNK - 1) / SORTED_LONG_CHUNK);
+                int slot0 = -1;
+                if (nchunks > 1) {
+                    slot0 = atomicAdd(&a->long_ws[2], nchunks);
+                    const int m = atomicAdd(&a->long_ws[1], 1);
+                    if (m < a->long_slots_cap) {
+                        LongMulti w;
+                        w.u = (int32_t)(u0 + r); w.slot0 = slot0; w.nchunks = nchunks; w.pad = 0;
+                        sorted_long_multi(a)[m] = w;
+                    }
+                }
+                sorted_long_write_items(a, (int32_t)(u0 + r), lo[r], hi[r], nchunks, slot0, base);
+                base += nchunks;
+            }
         }
     }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (lng[r]) hi[r] = lo[r];
     float4 acc[R];
     int64_t e[R];
 #pragma unroll

