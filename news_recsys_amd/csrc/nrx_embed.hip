@@ -71,11 +71,13 @@ __device__ __forceinline__ float4 load_row4(const float* table, int64_t id, int 
 // Entry `pos` of sample b's bag as the raw (id, weight) the pooling uses.  Padded form: ids [B, L] + optional weights.
 // CSR form (NRX_FEAT_BAG_CSR): f.weight holds int64 offsets [B + 1]; real entries weigh 1, the positions past the bag's
 // end are what DataReader pads with -- id 0, mask 0 (weight 1 for NRX_BAG_MEAN, whose padded form has no mask).
-__device__ __forceinline__ void bag_entry(const FeatDev& f, int64_t b, int pos, int L, int64_t& id, float& w) {
+// s_off (CSR only): the offsets of the block's samples, staged in LDS by the caller (s_off[s] = offsets[b0 + s], s <= nb) --
+// read from memory per entry they put a second dependent load in front of every id load (CSR 54 us vs padded 51 us at
+// the C4 shape; with the LDS copy the CSR form is the faster one).
+__device__ __forceinline__ void bag_entry(const FeatDev& f, int64_t b, int s, const int64_t* s_off, int pos, int L, int64_t& id, float& w) {
     if (f.flags & NRX_FEAT_BAG_CSR) {
-        const int64_t* offs = reinterpret_cast<const int64_t*>(f.weight);
-        const int64_t o0 = offs[b];
-        if ((int64_t)pos < offs[b + 1] - o0) {
+        const int64_t o0 = s_off[s];
+        if ((int64_t)pos < s_off[s + 1] - o0) {
             id = nrx_load_id(f.index, o0 + pos, f.idx64);
             w = 1.0f;
         } else {
@@ -141,6 +143,11 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_generic(const EmbedArgs a
                 const int stride = lc | 1;   // odd pair-stride: conflict-free broadcast ds_read_b64
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 float den = 0.f;
+                int64_t* s_off = reinterpret_cast<int64_t*>(s_bag + TB * stride);
+                if (f.flags & NRX_FEAT_BAG_CSR) {
+                    __syncthreads();            // (the previous feature's readers are done with the LDS area)
+                    if (tid <= nb) s_off[tid] = reinterpret_cast<const int64_t*>(f.weight)[b0 + tid];
+                }
                 for (int l0 = 0; l0 < L; l0 += lc) {
                     const int cur = (L - l0) < lc ? (L - l0) : lc;
                     __syncthreads();
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_generic(const EmbedArgs a
                         const int l = e - s * cur;
                         int64_t id;
                         float w;
-                        bag_entry(f, b0 + s, l0 + l, L, id, w);
+                        bag_entry(f, b0 + s, s, s_off, l0 + l, L, id, w);
                         if ((uint64_t)id >= (uint64_t)f.rows) {
                             nrx_report_oob(a.status, fi, b0 + s, id);
                             id = 0;
@@ -338,6 +345,11 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
             const float4 gs = make_float4(g.x / den, g.y / den, g.z / den, g.w / den);
             const int lc = a.lds_chunk;
             const int stride = lc | 1;
+            int64_t* s_off = reinterpret_cast<int64_t*>(s_bag + TB * stride);
+            if (f.flags & NRX_FEAT_BAG_CSR) {
+                __syncthreads();
+                if (tid <= nb) s_off[tid] = reinterpret_cast<const int64_t*>(f.weight)[b0 + tid];
+            }
             for (int l0 = 0; l0 < L; l0 += lc) {
                 const int cur = (L - l0) < lc ? (L - l0) : lc;
                 __syncthreads();
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
                     const int l = e - s * cur;
                     int64_t id;
                     float w;
-                    bag_entry(f, b0 + s, l0 + l, L, id, w);
+                    bag_entry(f, b0 + s, s, s_off, l0 + l, L, id, w);
                     const bool oob = (uint64_t)id >= (uint64_t)f.rows;
                     BagPair p;
                     p.id = oob ? 0 : (int32_t)id;
@@ -399,6 +411,7 @@ struct SortedBwdArgs {
     float* values;
     int32_t n;
     int32_t dim;
+    int32_t long_t;
 };
 static_assert(sizeof(SortedBwdArgs) <= 3840, "kernarg budget");
 
@@ -540,7 +553,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_kernel(const Sorte
 }
 
 // ---- work lists of the long-segment path (workspace layout: 4 counters | items | multi-chunk rows | partial sums)
-constexpr int SORTED_LONG_T = 16;            // segments longer than this leave the lane-group kernel
+constexpr int SORTED_LONG_T = 16;            // segments longer than this leave the lane-group kernel (32 for bag launches)
 constexpr int SORTED_LONG_CHUNK = 256;       // entries per work item (small: items are the unit of load balance)
 struct LongItem { int32_t u; int32_t dest; int64_t e_begin; int64_t e_end; };      // dest < 0: straight to values[u]
 struct LongMulti { int32_t u; int32_t slot0; int32_t nchunks; int32_t pad; };
@@ -612,7 +625,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
     int need = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        lng[r] = a->long_ws != nullptr && hi[r] - lo[r] > SORTED_LONG_T;
+        lng[r] = a->long_ws != nullptr && hi[r] - lo[r] > a->long_t;
         if (lng[r] && q == 0) need += (int)((hi[r] - lo[r] + SORTED_LONG_CHUNK - 1) / SORTED_LONG_CHUNK);
     }
     if (__ballot(need != 0) != 0ull) {                       // wave-uniform
@@ -924,7 +937,7 @@ void plan_generic(int max_dim, int max_bag, int& qlog2, int& lds_chunk, size_t& 
         int cap = (32 * 1024) / (tb * (int)sizeof(BagPair));
         if (cap < 8) cap = 8;
         lds_chunk = max_bag < cap ? max_bag : cap;
-        smem = (size_t)tb * (lds_chunk | 1) * sizeof(BagPair);
+        smem = (size_t)tb * (lds_chunk | 1) * sizeof(BagPair) + (size_t)(tb + 1) * sizeof(int64_t);     // + the CSR offsets of the block's samples
     }
 }
 
@@ -1143,6 +1156,7 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     a.long_ws = nullptr;
     a.long_items_cap = a.long_slots_cap = 0;
     a.scale = nullptr;
+    a.long_t = SORTED_LONG_T;
     int64_t off = 0;
     for (int i = 0; i < n_feats; ++i) {
         const nrx_feature_t& s = feats[i];
@@ -1207,6 +1221,9 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     // bag features ride the fast form through a per-lookup scale array that lives in the workspace; FM fields are
     // single-valued by construction (fm/model.py:48-59 stacks [B, D] tensors)
     if (has_bag) fast = fast && workspace != nullptr && !has_fm && off < 0xffffffffLL;
+    // threshold sweep (T = 16 / 24 / 32 / 48 / 64, fwd+bwd us): C4 521 / 505 / 493 / 492 / 492, C4 Zipf 581 / 575 / 564 / 598 / 674,
+    // C2 Zipf 501 / 545 / 588 / 678 / 758, C5 478 / 491 / 527 / 578 / 618: bag launches (a few rows, each looked up ~L times) take 32
+    if (has_bag) a.long_t = 2 * SORTED_LONG_T;
     if (fast) {
         constexpr int R = 4;
         const int64_t groups = (n_unique + R - 1) / R;

@@ -250,3 +250,30 @@ if want("c1shape"):
         us = timeit(prep.run, steps=100)
     alg = B * sum(8 + 8 * d for d in dims)
     print(f"C1-shaped gather (5 feats, dims 16/32 mixed, cache-resident tables), B=65536: {us:7.1f} us   {alg / us / 1e3:7.1f} GB/s algorithmic", flush=True)
+
+if want("bag_csr"):
+    # the DSSM user tower input (user_id + history pooled over the 200 k news table, D = 16, L = 50) with the history in the
+    # reference's padded ids + mask form vs the CSR form (NRX_FEAT_BAG_CSR: ids [nnz] + offsets [B + 1]); lengths uniform in
+    # [0, 50] (MIND-like: most users have short histories) and full length.  Same pooled values, bit for bit.
+    from news_recsys_amd._lib import NRX_FEAT_BAG_CSR
+    D, L = 16, 50
+    gen = torch.Generator(device=dev).manual_seed(8)
+    t_user = torch.randn(10_000_000, D, device=dev); t_item = torch.randn(200_000, D, device=dev)
+    uid = torch.randint(1, 10_000_000, (B,), device=dev, generator=gen)
+    for name, lens in (("lengths uniform in [0, 50]", torch.randint(0, L + 1, (B,), device=dev, generator=gen)),
+                       ("every history full (50)", torch.full((B,), L, device=dev, dtype=torch.int64))):
+        mask = (torch.arange(L, device=dev)[None] < lens[:, None]).float()
+        hist = torch.randint(1, 200_000, (B, L), device=dev, generator=gen) * mask.long()
+        offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), lens.cumsum(0)])
+        values = hist[mask.bool()].contiguous()
+        pp = ops.EmbedPlan([ops.Slot("user_history", NRX_BAG_MASKED_MEAN, 0, D, L, 0), ops.Slot("user_id", NRX_SPARSE, 1, D, 0, D)], out_width=2 * D)
+        pc = ops.EmbedPlan([ops.Slot("user_history", NRX_BAG_MASKED_MEAN, 0, D, L, 0, flags=NRX_FEAT_BAG_CSR), ops.Slot("user_id", NRX_SPARSE, 1, D, 0, D)],
+                           out_width=2 * D)
+        a = ops.PreparedEmbed(pp, [t_item, t_user], [hist, uid], [mask, None])
+        c64 = ops.PreparedEmbed(pc, [t_item, t_user], [values, uid], [offsets, None])
+        c32 = ops.PreparedEmbed(pc, [t_item, t_user], [values.int(), uid.int()], [offsets, None])
+        with torch.no_grad():
+            a.run(); c64.run(); c32.run(); torch.cuda.synchronize()
+            assert torch.equal(a.out, c64.out) and torch.equal(a.out, c32.out)
+            us = [timeit(x.run, steps=100) for x in (a, c64, c32)]
+        print(f"user tower input, {name}: padded int64 ids + mask {us[0]:6.1f} us   CSR int64 {us[1]:6.1f} us   CSR int32 {us[2]:6.1f} us", flush=True)
