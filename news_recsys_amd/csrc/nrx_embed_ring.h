@@ -89,8 +89,8 @@ __device__ __forceinline__ void consume(const NRX_CONST UniformArgs* a, int f, f
 // Wavefront `wave` of the block stages the ids of features wave, wave + 4, ... (wave-uniform feature => table sizes
 // and id pointers come from scalar loads); lanes < TB each fetch one id; the loads of a pass are in flight together
 // (branch-free up to the rare out-of-range report; a pass past the last feature re-reads it and drops the result).
-template <int TB, bool IDX64>
-__device__ __forceinline__ void stage_ids(const NRX_CONST UniformArgs* a, int32_t* s_ids, int n, int64_t b0, int nb, int lane, int wave) {
+template <int TB, bool IDX64, typename A = UniformArgs>       // A: any argument block with index[] / rows[] / status
+__device__ __forceinline__ void stage_ids(const NRX_CONST A* a, int32_t* s_ids, int n, int64_t b0, int nb, int lane, int wave) {
     const int s = lane < nb ? lane : nb - 1;          // TB <= 64 = wavefront size
     constexpr int PASS = 4;
     for (int k0 = 0; k0 * 4 < n; k0 += PASS) {

@@ -9,6 +9,7 @@
 // lane's 4 floats with dword-aligned 12-byte + 4-byte stores at the (shifted) deep position; the 4-byte store of a
 // wide feature's lane 0 is redirected to the wide tensor.  Branch-free inside a group (see nrx_embed.hip on why).
 #include "nrx_common.h"
+#include "nrx_embed_ring.h"   // nrx_ring::stage_ids / load_row (the ring form below)
 
 struct UniformWideArgs {
     const float* table[NRX_MAX_FEATURES];
@@ -23,6 +24,7 @@ struct UniformWideArgs {
     int64_t wide_ld;
     int32_t* status;
     int32_t n;
+    int32_t idx64;
 };
 static_assert(sizeof(UniformWideArgs) <= 3584, "kernarg budget");
 
@@ -95,6 +97,98 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_uniform_wide(const Unifor
     if (bad_feat >= 0 && q == 0) nrx_report_oob(a->status, bad_feat, b, bad_id);
 }
 
+// Ring form (as embed_fwd_ring, nrx_embed_ring.h): ids staged once per block in LDS (bounds-checked, 32-bit), R row loads in
+// flight per lane, `store feature f; load feature f + R`.  Requires n >= R.  C5 with the split on the 10 smallest tables:
+// burst form 159 us -> see profiles.
+template <int Q>
+__device__ __forceinline__ void wide_store(const NRX_CONST UniformWideArgs* a, int f, float4 v, int q, float* orow, float* wrow) {
+    const int wc = a->wide_col[f];                              // wave-uniform
+    float* p = orow + a->col[f] + 4 * q - (wc >= 0 ? 1 : 0);
+    if (wc >= 0) {
+        float* p0 = q == 0 ? wrow + wc : p;
+        *p0 = v.x;
+        f32x3u t;
+        t.x = v.y; t.y = v.z; t.z = v.w;
+        *reinterpret_cast<f32x3u*>(p + 1) = t;
+    } else {
+        f32x4u t;
+        t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+        *reinterpret_cast<f32x4u*>(p) = t;
+    }
+}
+
+template <int QLOG2, int R, bool NT>
+__global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_ring_wide(const UniformWideArgs args_in_kernarg_segment) {
+    using namespace nrx_ring;
+    const NRX_CONST UniformWideArgs* a = nrx_kernarg<UniformWideArgs>();
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    extern __shared__ __attribute__((aligned(16))) int32_t s_ids[];   // [n][TB]
+    const int tid = threadIdx.x;
+    const int n = a->n;
+    const int64_t b0 = (int64_t)blockIdx.x * TB;
+    const int nb = (int)((a->batch - b0) < (int64_t)TB ? (a->batch - b0) : (int64_t)TB);
+    {
+        const int lane = tid & (NRX_WAVE - 1);
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        if (a->idx64) stage_ids<TB, true>(a, s_ids, n, b0, nb, lane, wave);
+        else stage_ids<TB, false>(a, s_ids, n, b0, nb, lane, wave);
+    }
+    __syncthreads();
+    const int q = tid & (Q - 1);
+    const int sb = tid >> QLOG2;
+    const int64_t b = b0 + sb;
+    if (b >= a->batch) return;
+    const int32_t* s_my = s_ids + sb;
+    float* const orow = a->out + b * a->ld;
+    float* const wrow = a->wide + b * a->wide_ld;
+    float4 v[R];
+    {
+        int32_t idn[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) idn[u] = s_my[u * TB];
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = load_row<QLOG2, NT>(a->table[u], idn[u], q);
+    }
+    int f0 = 0;
+    for (; f0 + 2 * R <= n; f0 += R) {
+        int32_t idn[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) idn[u] = s_my[(f0 + R + u) * TB];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            wide_store<Q>(a, f0 + u, v[u], q, orow, wrow);
+            v[u] = load_row<QLOG2, NT>(a->table[f0 + R + u], idn[u], q);
+        }
+    }
+    {
+        int32_t idn[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int f = f0 + R + u;
+            idn[u] = s_my[(f < n ? f : n - 1) * TB];
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            wide_store<Q>(a, f0 + u, v[u], q, orow, wrow);
+            if (f0 + R + u < n) v[u] = load_row<QLOG2, NT>(a->table[f0 + R + u], idn[u], q);
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+            if (f0 + R + u < n) wide_store<Q>(a, f0 + R + u, v[u], q, orow, wrow);
+    }
+}
+
+template <int QLOG2>
+void launch_ring_wide(const UniformWideArgs& ua, int64_t batch, bool nt, hipStream_t st) {
+    constexpr int TB = NRX_BLOCK >> QLOG2;
+    constexpr int R = 8;
+    const dim3 grid((unsigned)((batch + TB - 1) / TB)), block(NRX_BLOCK);
+    const size_t smem = (size_t)ua.n * TB * 4;
+    if (nt) hipLaunchKernelGGL((embed_fwd_ring_wide<QLOG2, R, true>), grid, block, smem, st, ua);
+    else hipLaunchKernelGGL((embed_fwd_ring_wide<QLOG2, R, false>), grid, block, smem, st, ua);
+}
+
 template <int QLOG2, int U>
 void launch_wide(const UniformWideArgs& ua, int64_t batch, bool i64, bool nt, hipStream_t st) {
     constexpr int TB = NRX_BLOCK >> QLOG2;
@@ -139,6 +233,15 @@ bool nrx_launch_uniform_wide(const nrx_feature_t* feats, int32_t n_feats, int64_
     ua.n = n_feats;
     const bool i64 = feats[0].index_bits == 64;
     const bool nt = table_bytes > (256ll << 20);
+    ua.idx64 = i64;
+    if (n_feats >= 8 && n_feats * (NRX_BLOCK / (D0 / 4)) * 4 <= 48 * 1024) {      // ring form: >= R features, ids fit a modest LDS tile
+        switch (D0) {
+            case 16: launch_ring_wide<2>(ua, batch, nt, st); break;
+            case 32: launch_ring_wide<3>(ua, batch, nt, st); break;
+            default: launch_ring_wide<4>(ua, batch, nt, st); break;
+        }
+        return true;
+    }
     const int w13 = (13 - n_feats % 13) % 13, w8 = (8 - n_feats % 8) % 8;
     const bool u13 = D0 <= 32 && n_feats >= 13 && w13 <= w8;
     switch (D0) {
