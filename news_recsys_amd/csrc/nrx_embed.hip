@@ -587,9 +587,34 @@ __device__ __forceinline__ void sorted_long_write_items(const NRX_CONST SortedBw
 // R independent requests per lane -- the reduction is a chain of three dependent random reads per row, so what bounds it
 // is how many chains a lane keeps in flight.  Segments longer than one entry (duplicate ids) continue in a loop that
 // adds the remaining entries in sorted order: the summation order is the sorted order, as in the general form.
+// UNAL: the launch has Wide&Deep column routing (widedeep/model.py:53-69) -- after the first wide feature nothing in g_out is
+// 16-byte aligned (deep blocks of D - 1 floats), and column 0 of a wide feature's gradient comes from g_wide.  Global memory
+// only needs dword alignment for multi-dword accesses: the lane's 4 floats are one dword-aligned 16-byte load at the shifted
+// position; lane 0 of a wide feature takes 3 floats from g_out and its first one from g_wide.
+typedef float nrx_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float nrx_f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+template <bool UNAL>
+__device__ __forceinline__ float4 sorted_upstream(const NRX_CONST SortedBwdArgs* a, int fi, int64_t b, int q) {
+    if (!UNAL) return a->g_out ? nrx_ldg4(a->g_out, (b * a->out_ld + a->f[fi].out_col) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int wc = a->f[fi].wide_col;                          // the lanes of a group share the feature
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    // one load shape for every lane (a second path for "lane 0 of a wide feature" would run serially in every wavefront that
+    // mixes wide and plain rows): 16 bytes at the shifted position; lane 0 of a wide feature thereby reads one float of the
+    // previous feature's block, which the select below replaces by the wide gradient -- except at the very first element of
+    // g_out (sample 0, column 0), where the load starts one float later and is shifted back in registers
+    int64_t eo = b * a->out_ld + a->f[fi].out_col + 4 * q - (wc >= 0 ? 1 : 0);
+    const bool edge = eo < 0;
+    if (a->g_out) {
+        const nrx_f32x4u t = *reinterpret_cast<const nrx_f32x4u*>(a->g_out + (edge ? 0 : eo));
+        g = edge ? make_float4(0.f, t.x, t.y, t.z) : make_float4(t.x, t.y, t.z, t.w);
+    }
+    if (wc >= 0 && q == 0) g.x = a->g_wide ? nrx_gconst<float>(a->g_wide)[b * a->wide_ld + wc] : 0.f;
+    return g;
+}
+
 // BAG: some features are bags -- a lookup's sample is (flat index) / L and its upstream row is scaled by the per-lookup
 // factor bag_scale_kernel left in a->scale (mask / (sum mask + 1e-8), 1 / L, or the weight).
-template <int QLOG2, int R, bool FM, bool BAG>
+template <int QLOG2, int R, bool FM, bool BAG, bool UNAL>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const SortedBwdArgs args_in_kernarg) {
     const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
     constexpr int Q = 1 << QLOG2;
@@ -696,8 +721,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
                 sc[r] = nrx_gconst<float>(a->scale)[p[r]];
                 if (a->f[fi].bag_len > 1) b = (int64_t)__umul64hi((uint64_t)b, (uint64_t)a->f[fi].rows);   // b / bag_len (b < 2^32)
             }
-            const int64_t c4 = (b * a->out_ld + a->f[fi].out_col) / 4 + q;
-            g[r] = a->g_out ? nrx_ldg4(a->g_out, c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            g[r] = sorted_upstream<UNAL>(a, fi, b, q);
             if (FM) {
                 const bool fm = a->f[fi].fm;
                 gf[r] = fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
@@ -741,7 +765,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
 // item: its 64 / Q lane groups stride over the entries (two in flight each), then a fixed xor-shuffle tree adds the
 // groups -- the same entries always meet in the same order, so the result is reproducible.  A row of one item is written
 // straight to values; a row of several items leaves one partial per item, which sorted_combine_kernel adds in item order.
-template <int QLOG2, bool FM, bool BAG>
+template <int QLOG2, bool FM, bool BAG, bool UNAL>
 __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdArgs args_in_kernarg) {
     const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
     constexpr int Q = 1 << QLOG2, G = 64 / Q;
@@ -773,7 +797,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
                     sc[k] = nrx_gconst<float>(a->scale)[p[k]];
                     if (a->f[fi].bag_len > 1) b = (int64_t)__umul64hi((uint64_t)b, (uint64_t)a->f[fi].rows);
                 }
-                gr[k] = a->g_out ? nrx_ldg4(a->g_out, (b * a->out_ld + a->f[fi].out_col) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                gr[k] = sorted_upstream<UNAL>(a, fi, b, q);
                 if (FM) {
                     gf[k] = a->f[fi].fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
                     v[k] = nrx_ldg4(a->feat, (b * a->feat_ld + a->f[fi].out_col) / 4 + q);
@@ -1210,14 +1234,17 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     const int tb = NRX_BLOCK >> ql;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // fast form: plain single-valued features, D = 4 Q exactly, float4-addressable everywhere
-    bool fast = dim == (4 << ql) && ql >= 2 && ql <= 4 && (g_out == nullptr || (nrx_aligned16(g_out) && (out_ld & 3) == 0)) && nrx_aligned16(values) &&
+    bool fast = dim == (4 << ql) && ql >= 2 && ql <= 4 && nrx_aligned16(values) &&
                 (!has_fm || (g_out != nullptr && nrx_aligned16(fm->feat) && (fm->feat_ld & 3) == 0 && nrx_aligned16(fm->fm_sums) &&
                              (fm->sums_ld & 3) == 0 && fm->sums_ld >= dim));
     bool has_bag = false;
+    bool unal = !(g_out == nullptr || (nrx_aligned16(g_out) && (out_ld & 3) == 0));      // wide routing / shifted columns / odd strides
     for (int i = 0; i < n_feats && fast; ++i) {
-        fast = feats[i].wide_col < 0 && (feats[i].out_col & 3) == 0;
+        unal |= feats[i].wide_col >= 0 || (feats[i].out_col & 3) != 0;
+        if (feats[i].wide_col >= 0) fast = feats[i].kind == NRX_SPARSE;                 // (the split is defined for single-valued features)
         has_bag |= feats[i].kind != NRX_SPARSE;
     }
+    if (unal) fast = fast && !has_fm && (reinterpret_cast<uintptr_t>(g_out) & 3u) == 0;
     // bag features ride the fast form through a per-lookup scale array that lives in the workspace; FM fields are
     // single-valued by construction (fm/model.py:48-59 stacks [B, D] tensors)
     if (has_bag) fast = fast && workspace != nullptr && !has_fm && off < 0xffffffffLL;
@@ -1250,18 +1277,20 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
         }
 #define NRX_SF(QL_)                                                                                                        \
     {                                                                                                                      \
-        if (has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else if (has_bag) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a);      \
+        if (has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else if (unal) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, true, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else if (has_bag) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, true, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a);      \
     }
         if (ql == 2) NRX_SF(2) else if (ql == 3) NRX_SF(3) else NRX_SF(4)
 #undef NRX_SF
         if (workspace != nullptr) {
 #define NRX_SL(QL_)                                                                                                        \
     {                                                                                                                      \
-        if (has_fm) hipLaunchKernelGGL((sorted_long_kernel<QL_, true, false>), dim3(2048), dim3(NRX_BLOCK), 0, st, a);      \
-        else if (has_bag) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); \
-        else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, false>), dim3(2048), dim3(NRX_BLOCK), 0, st, a);            \
+        if (has_fm) hipLaunchKernelGGL((sorted_long_kernel<QL_, true, false, false>), dim3(2048), dim3(NRX_BLOCK), 0, st, a);      \
+        else if (unal) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, true>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); \
+        else if (has_bag) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, false>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); \
+        else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, false, false>), dim3(2048), dim3(NRX_BLOCK), 0, st, a);            \
         hipLaunchKernelGGL((sorted_combine_kernel<QL_>), dim3(256), dim3(NRX_BLOCK), 0, st, a);                              \
     }
             if (ql == 2) NRX_SL(2) else if (ql == 3) NRX_SL(3) else NRX_SL(4)

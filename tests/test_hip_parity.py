@@ -1065,6 +1065,18 @@ def test_uniform_wide_split_bit_exact_vs_oracle(B, F, D, wide_every, idx_dtype):
             col += D
         want = R.embedding_grad_dense(batch[n], g_rows, tables[n].shape[0])
         np.testing.assert_allclose(t.grad.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    # the deterministic row-sparse backward takes the same routing (dword-aligned 16-byte reads of the shifted deep columns,
+    # column 0 from the wide gradient): densified it equals the dense result, and two runs are bit-identical
+    dense = [t.grad.clone() for t in tt]
+    runs = []
+    for _ in range(2):
+        t2 = [t.detach().clone().requires_grad_() for t in tt]
+        deep2, wd2, _ = ops.embed_apply(plan, t2, inputs, weights, sparse_grad=True)
+        ((deep2 * dev(up_d)).sum() + (wd2 * dev(up_w)).sum()).backward()
+        runs.append([t.grad.coalesce() for t in t2])
+    for g0, g1, gd in zip(runs[0], runs[1], dense):
+        assert torch.equal(g0.indices(), g1.indices()) and torch.equal(g0.values(), g1.values())
+        torch.testing.assert_close(g0.to_dense(), gd, rtol=1e-5, atol=1e-5)
     with pytest.raises(IndexError):
         bad = [x.clone() for x in inputs]
         bad[-1][0] = 10 ** 6
