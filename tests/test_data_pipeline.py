@@ -85,6 +85,27 @@ def test_columnar_cpu_loader_matches_reference(col_dir):
         assert_batch_equal(gb, wb)
 
 
+def test_oracle_csr_bag_definition_matches_reference_padding(col_dir):
+    """oracle.ref_np.csr_bag_to_padded -- the definition of what a CSR bag feature (NRX_FEAT_BAG_CSR) pools -- applied to the
+    stored CSR columns reproduces the padded ids + masks of the REFERENCE DataReader (golden batches), truncation included."""
+    from oracle import ref_np as R
+    n, want = golden_batches()
+    ds = ColumnarDataset(col_dir)
+    lo = 0
+    for wb in want:
+        nb = len(wb["label"])
+        for k, L in ds.max_len.items():
+            off = np.asarray(ds.offsets[k][lo:lo + nb + 1], np.int64)
+            vals = np.asarray(ds.values[k][off[0]:off[-1]])
+            ids, mask = R.csr_bag_to_padded(vals, off - off[0], L)
+            assert np.array_equal(ids.astype(np.int64), wb[k]) and np.array_equal(mask, wb[f"{k}_mask"])
+        lo += nb
+    assert lo == n
+    # longer than L: cut to the first L entries; empty: all padding
+    ids, mask = R.csr_bag_to_padded(np.arange(1, 10), np.array([0, 6, 6, 9]), 4)
+    assert ids.tolist() == [[1, 2, 3, 4], [0, 0, 0, 0], [7, 8, 9, 0]] and mask.tolist() == [[1, 1, 1, 1], [0, 0, 0, 0], [1, 1, 1, 0]]
+
+
 def test_columnar_shuffle_is_a_permutation(col_dir):
     ds = ColumnarDataset(col_dir)
     loader = ColumnarLoader(ds, 5, "cpu", shuffle=True, seed=3)
