@@ -250,7 +250,8 @@ NRX_API int nrx_dcn_v2_layer_fwd(const float* x0, const float* xl, int64_t ld, i
  *   gm = g_out * (out > 0) [relu] ;  glin = gm * x0 ;  g_x0 (+)= gm * lin ;  g_b = sum_rows glin ;
  *   g_xl = gm + glin W   (MFMA dgrad) ;  g_W = glin^T x_l   (MFMA wgrad, split over the batch, fp32 atomics).
  * lin: the forward's lin_out; out: the forward's output (ReLU mask; may be NULL when relu == 0).  g_x0 is overwritten,
- * or accumulated into when accumulate_x0 != 0 (x0 feeds every layer).  g_W [dim, dim] and g_b [dim] are overwritten.
+ * or accumulated into when bit 0 of accumulate_x0 is set (x0 feeds every layer); bit 1 additionally adds the resulting g_x0
+ * into g_xl in the dgrad epilogue -- the stack's FIRST layer, whose x_l is x0, so that g_xl is dL/dx of the whole stack.  g_W [dim, dim] and g_b [dim] are overwritten.
  * workspace: nrx_dcn_v2_layer_bwd_workspace(batch, dim) device bytes.                                           */
 NRX_API int64_t nrx_dcn_v2_layer_bwd_workspace(int64_t batch, int32_t dim);
 NRX_API int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld, const float* lin, const float* out, int32_t relu,

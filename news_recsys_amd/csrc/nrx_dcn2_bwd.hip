@@ -121,7 +121,8 @@ template <int MODE, bool VEC>
 __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                          int64_t M, int N, int64_t K, int64_t kslice, const float* __restrict__ addend,
                                                          int64_t add_ld, const float* __restrict__ mask, int64_t mask_ld,
-                                                         float* __restrict__ out, int64_t out_ld, unsigned nx, unsigned ntiles) {
+                                                         float* __restrict__ out, int64_t out_ld, unsigned nx, unsigned ntiles,
+                                                         const float* __restrict__ add2, int64_t add2_ld) {
     __shared__ float As[BK * LDA];
     __shared__ float Ws[BK * LDW];
     const int tid = threadIdx.x;
@@ -304,7 +305,9 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
                 if (MODE == DGRAD) {        // g_xl = gm + glin W, gm = g (x) [forward output > 0] rebuilt here
                     float gmv = addend[row * add_ld + col];
                     if (mask != nullptr && !(mask[row * mask_ld + col] > 0.f)) gmv = 0.f;
-                    out[row * out_ld + col] = gmv + acc[t][r];
+                    float v = gmv + acc[t][r];
+                    if (add2 != nullptr) v += add2[row * add2_ld + col];      // layer 0 (x0 is x_l): dL/dx = g_xl + g_x0 in one pass
+                    out[row * out_ld + col] = v;
                 } else {
                     unsafeAtomicAdd(out + row * out_ld + col, acc[t][r]);
                 }
@@ -332,6 +335,8 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
     NRX_REQUIRE(g_xl != g_out, "nrx_dcn_v2_layer_bwd: g_xl must not alias g_out");
     NRX_REQUIRE(dim <= 1024, "nrx_dcn_v2_layer_bwd: dim %d > 1024 unsupported", dim);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int acc_x0 = accumulate_x0 & 1;                          // bit 0: add to g_x0 instead of overwriting it
+    const float* fold = (accumulate_x0 & 2) ? g_x0 : nullptr;      // bit 1: fold the (written or accumulated) g_x0 into g_xl (the stack's first layer)
     if (nrx_zero_async(g_W, sizeof(float) * (size_t)dim * dim, st) != NRX_OK || nrx_zero_async(g_b, sizeof(float) * (size_t)dim, st) != NRX_OK)
         return NRX_ERR_LAUNCH;
     if (batch == 0) return NRX_OK;
@@ -349,9 +354,9 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
 #define NRX_PREP(TL_)                                                                                                              \
     case TL_:                                                                                                                      \
         if (vec) hipLaunchKernelGGL((dcn_v2_bwd_prep_kernel<TL_, true>), dim3((unsigned)grid), dim3(NRX_BLOCK), 0, st, g_out, g_ld, out,  \
-                                    x0, lin, ld, batch, dim, relu, glin, wld, g_x0, gx0_ld, accumulate_x0, g_b);                  \
+                                    x0, lin, ld, batch, dim, relu, glin, wld, g_x0, gx0_ld, acc_x0, g_b);                  \
         else hipLaunchKernelGGL((dcn_v2_bwd_prep_kernel<TL_, false>), dim3((unsigned)grid), dim3(NRX_BLOCK), 0, st, g_out, g_ld, out,    \
-                                x0, lin, ld, batch, dim, relu, glin, wld, g_x0, gx0_ld, accumulate_x0, g_b);                      \
+                                x0, lin, ld, batch, dim, relu, glin, wld, g_x0, gx0_ld, acc_x0, g_b);                      \
         break;
         switch (tl) { NRX_PREP(2) NRX_PREP(3) NRX_PREP(4) NRX_PREP(5) NRX_PREP(6) NRX_PREP(7) default: NRX_PREP(8) }
 #undef NRX_PREP
@@ -362,9 +367,9 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
         const int64_t nt = (int64_t)nx * ((batch + BM - 1) / BM);
         NRX_REQUIRE(nt <= 0x7fffffffLL, "nrx_dcn_v2_layer_bwd: batch too large for one launch");
         if (vec) hipLaunchKernelGGL((dcn2_gemm_kernel<DGRAD, true>), dim3((unsigned)nt), dim3(256), 0, st, glin, wld, W, (int64_t)dim, batch,
-                                    dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, ld, g_xl, gxl_ld, nx, (unsigned)nt);
+                                    dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, ld, g_xl, gxl_ld, nx, (unsigned)nt, fold, gx0_ld);
         else hipLaunchKernelGGL((dcn2_gemm_kernel<DGRAD, false>), dim3((unsigned)nt), dim3(256), 0, st, glin, wld, W, (int64_t)dim, batch,
-                                dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, ld, g_xl, gxl_ld, nx, (unsigned)nt);
+                                dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, ld, g_xl, gxl_ld, nx, (unsigned)nt, fold, gx0_ld);
     }
     {   // wgrad: g_W[i, j] += sum_b glin[b, i] xl[b, j]   (M = N = dim, K = batch, split over the batch)
         const unsigned nx = (unsigned)((dim + BN - 1) / BN);
@@ -375,10 +380,10 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
         splits = (batch + kslice - 1) / kslice;
         if (vec) hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, true>), dim3((unsigned)(nt * splits)), dim3(256), 0, st, glin, wld, xl, ld,
                                     (int64_t)dim, dim, batch, kslice, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0,
-                                    g_W, (int64_t)dim, nx, nt);
+                                    g_W, (int64_t)dim, nx, nt, (const float*)nullptr, (int64_t)0);
         else hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, false>), dim3((unsigned)(nt * splits)), dim3(256), 0, st, glin, wld, xl, ld,
                                 (int64_t)dim, dim, batch, kslice, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0,
-                                g_W, (int64_t)dim, nx, nt);
+                                g_W, (int64_t)dim, nx, nt, (const float*)nullptr, (int64_t)0);
     }
     NRX_LAUNCH_CHECK("nrx_dcn_v2_layer_bwd");
     return NRX_OK;
