@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
         }
     };
     if (kbeg < kend) load_slab(kbeg);
+    const bool wave_live = m0 + wm * (32 * TM) < M && n0 + wn * 32 < N;      // wave-uniform
 
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         if (MODE == DGRAD) {
@@ -274,6 +275,10 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
         }
         __syncthreads();
         if (k0 + BK < kend) load_slab(k0 + BK);
+        if (!wave_live) {                              // this wave's 64 x 32 sub-tile lies wholly past M or N (D = 320: the third
+            __syncthreads();                           // 128-row tile of g_W has rows 320..383) -- it only helps staging
+            continue;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h == 1 && k0 + BK / 2 >= kend) break;   // upper half of the last slab all padding: skip its MFMAs
