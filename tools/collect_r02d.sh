@@ -15,7 +15,7 @@ PY
 }
 python -m pytest tests -x -q -m gpu > $F/pytest_gpu.log 2>&1; tail -2 $F/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-/usr/bin/time -v python3 bench.py > $F/bench_default.log 2> $F/bench_default.time; grep -E "Elapsed|Maximum resident" $F/bench_default.time; tail -1 $F/bench_default.log | cut -c1-300
+SECONDS=0; python3 bench.py > $F/bench_default.log 2>&1; echo "default bench.py run: ${SECONDS} s"; tail -1 $F/bench_default.log | cut -c1-300
 {
 for D in 320 112; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $F/dcn2_$D -- python3 tools/profile_dcn2_bwd.py $D > $F/dcn2_$D.log 2>&1
