@@ -508,13 +508,15 @@ def main():
             fwd, bwd = path.train_pass()
             f_ms = time_calls(lambda i: fwd[i % len(fwd)].run(), steps2)
             def both(i):
+                bwd[i % len(bwd)].plan_ahead()      # the backward's planning depends only on the ids: side stream, under the forward
                 fwd[i % len(fwd)].run()
                 bwd[i % len(bwd)].run()
             fb_ms = time_calls(both, steps2)
             fwd_bwd = {"ms_per_step": fb_ms, "value": BATCH / (fb_ms * 1e-3), "unit": "impressions/s",
                        "forward_ms": f_ms, "backward_ms": fb_ms - f_ms,
                        "mode": "forward (training form: + FM field sums) + deterministic row-sparse backward: nrx_sparse_plan "
-                               "(bit-limited radix sort, unique rows, segments) + nrx_embed_bwd_sorted with the FM gradient folded in; "
+                               "(bit-limited radix sort, unique rows, segments; enqueued on a side stream next to the forward launch -- it "
+                               "depends only on the ids) + nrx_embed_bwd_sorted with the FM gradient folded in; "
                                "upstream gradients g_out [B, width]" + (" and g_fm [B]" if path.fm else "") + " given; result = unique "
                                "(table,row) keys + summed row gradients on the device (what optim.FusedSparseAdam consumes)"}
             del fwd, bwd

@@ -315,6 +315,18 @@ class _EmbedFn(torch.autograd.Function):
         # frees: 100+ MB per step kept alive, and a ~35 ms collection every few dozen steps
         ctx.has_fm_feat = bool(plan.use_fm and need_out)
         ctx.fm_sums = sums
+        ctx.plans = None
+        if ctx.sparse_grad and PLAN_AHEAD and B > 0 and any(t.requires_grad for t in tables) and \
+                not torch.cuda.is_current_stream_capturing():
+            ctx.plans = {}
+            for D_, fs_ in _sparse_groups(plan):
+                ids_ = [ins[i] for i in fs_]
+                if any(x.dtype != ids_[0].dtype for x in ids_):
+                    ids_ = [x.long() for x in ids_]
+                if sum(x.numel() for x in ids_) == 0:
+                    continue
+                tabs_ = [plan.slots[i].table for i in fs_]
+                ctx.plans[(D_, fs_[0])] = (ids_,) + sparse_plan_ahead(ids_, tabs_, [tables[t].shape[0] for t in tabs_], len(tables))
         if ctx.has_fm_feat:
             ctx.save_for_backward(out)
         ctx.set_materialize_grads(False)
@@ -381,6 +393,34 @@ class SparseGradSink:
 SPARSE_BWD_SYNC_FREE = False   # True: size the reduction for the worst case and read the count on the device
 
 
+_plan_streams = {}
+PLAN_AHEAD = True      # row-sparse training: plan the backward (sort, unique rows, segments) at FORWARD time on a side stream
+
+
+def _plan_stream(dev) -> "torch.cuda.Stream":
+    s = _plan_streams.get(dev)
+    if s is None:
+        s = _plan_streams[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
+def sparse_plan_ahead(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int):
+    """sparse_plan on a side stream: the planning of the backward depends only on the ids, so it can run while the forward,
+    the dense part of the model and its backward occupy the main stream.  Returns ((order, uniq, seg, counts), event);
+    the consumer makes its stream wait for `event` before reading the plan."""
+    dev = ids[0].device
+    cur = torch.cuda.current_stream(dev)
+    side = _plan_stream(dev)
+    side.wait_stream(cur)                      # the ids are ready where the caller's stream is now
+    with torch.cuda.stream(side):
+        res = sparse_plan(ids, table_of, rows, n_tables)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    for t in res:
+        t.record_stream(cur)                   # allocated under the side stream, consumed (and freed) under the caller's
+    return res, ev
+
+
 def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int):
     """nrx_sparse_plan: group the flat, feature-major lookups `ids` (one device tensor per feature, all int32 or
     all int64) by (table, row).  Returns device int64 tensors (order [n], uniq_keys [n], seg_start [n+1],
@@ -407,6 +447,20 @@ def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequ
     return order, uniq, seg, counts
 
 
+def _sparse_groups(plan: EmbedPlan):
+    """(dim, slot indices) of every backward launch of the row-sparse mode: table features grouped by embedding dim, in
+    chunks of NRX_MAX_FEATURES."""
+    by_dim = {}
+    for i, s in enumerate(plan.slots):
+        if s.kind != NRX_DENSE:
+            by_dim.setdefault(s.dim, []).append(i)
+    out = []
+    for D, fs_all in by_dim.items():
+        for c0 in range(0, len(fs_all), NRX_MAX_FEATURES):
+            out.append((D, fs_all[c0:c0 + NRX_MAX_FEATURES]))
+    return out
+
+
 def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
     """Row-sparse, deterministic table grads.  Per group of tables sharing an embedding dim: ONE planning
     call (nrx_sparse_plan: compact (table, row) keys, rocPRIM radix sort on just the significant bits, head
@@ -418,58 +472,59 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
     plan, B, ld = ctx.plan, ctx.B, ctx.ld
     n_tables = len(ctx.table_meta)
     grads = [None] * n_tables
-    by_dim = {}
-    for i, s in enumerate(plan.slots):
-        if s.kind != NRX_DENSE:
-            by_dim.setdefault(s.dim, []).append(i)
     MASK = (1 << 40) - 1
-    for D, fs_all in by_dim.items():
-        for c0 in range(0, len(fs_all), NRX_MAX_FEATURES):
-            fs = fs_all[c0:c0 + NRX_MAX_FEATURES]
-            dev = ctx.table_meta[plan.slots[fs[0]].table][1]
+    ahead = getattr(ctx, "plans", None) or {}
+    for D, fs in _sparse_groups(plan):
+        dev = ctx.table_meta[plan.slots[fs[0]].table][1]
+        tabs = [plan.slots[i].table for i in fs]
+        n = len(fs)
+        pre = ahead.get((D, fs[0]))
+        if pre is not None:                 # planned at forward time on the side stream (sparse_plan_ahead)
+            ids, (order, uniq, seg, counts), ev = pre
+            torch.cuda.current_stream(dev).wait_event(ev)
+            total = sum(x.numel() for x in ids)
+        else:
             ids = [ctx.ins[i] for i in fs]
             dt = ids[0].dtype
             if any(x.dtype != dt for x in ids):
                 ids = [x.long() for x in ids]
-            n = len(fs)
             total = sum(x.numel() for x in ids)
             if total == 0:
                 continue
-            tabs = [plan.slots[i].table for i in fs]
             order, uniq, seg, counts = sparse_plan(ids, tabs, [ctx.table_meta[t][0][0] for t in tabs], n_tables)
-            # The one host read (n_tables + 2 integers).  Reading it BEFORE the reduction lets the host build the
-            # per-table COO tensors while that kernel runs (1.00 ms per C2 step vs 1.11 ms with the sync-free
-            # n_unique_dev form of the call, which leaves the host work exposed after the GPU is done).
-            sub = EmbedPlan([plan.slots[i] for i in fs], out_width=plan.out_width, wide_width=plan.wide_width)
-            arr = _fill_features(sub, 0, n, [None] * n_tables, ids, [ctx.ws[i] for i in fs], table_ptrs=[0] * n_tables,
-                                 fm=fmg is not None)
-            lws = torch.empty(lib.nrx_embed_bwd_sorted_workspace(total, D), dtype=torch.uint8, device=dev)   # hot-row work lists
-            if ctx.sink is not None:
-                values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
-                check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
-                                               seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), fmg, values.data_ptr(), lws.data_ptr(), stream),
-                      "nrx_embed_bwd_sorted")
-                ctx.sink.pending.append(dict(tables=ctx.tables, dim=D, uniq=uniq, values=values, counts=counts, cap=total))
-                continue
-            if SPARSE_BWD_SYNC_FREE:
-                values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
-                check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
-                                               seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), fmg, values.data_ptr(), lws.data_ptr(), stream),
-                      "nrx_embed_bwd_sorted")
-                cl = counts.tolist()
-                nu = cl[0]
-            else:
-                cl = counts.tolist()
-                nu = cl[0]
-                values = torch.empty((nu, D), dtype=torch.float32, device=dev)
-                check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
-                                               seg.data_ptr(), uniq.data_ptr(), nu, None, fmg, values.data_ptr(), lws.data_ptr(), stream),
-                      "nrx_embed_bwd_sorted")                     # padding rows (id 0) come back as zeros
-            rows = (uniq[:nu] & MASK).unsqueeze(0)
-            for t in sorted(set(tabs)):
-                lo, hi = cl[1 + t], cl[2 + t]
-                g = torch.sparse_coo_tensor(rows[:, lo:hi], values[lo:hi], size=ctx.table_meta[t][0], is_coalesced=True)
-                grads[t] = g if grads[t] is None else (grads[t] + g).coalesce()
+        # The one host read (n_tables + 2 integers).  Reading it BEFORE the reduction lets the host build the
+        # per-table COO tensors while that kernel runs (1.00 ms per C2 step vs 1.11 ms with the sync-free
+        # n_unique_dev form of the call, which leaves the host work exposed after the GPU is done).
+        sub = EmbedPlan([plan.slots[i] for i in fs], out_width=plan.out_width, wide_width=plan.wide_width)
+        arr = _fill_features(sub, 0, n, [None] * n_tables, ids, [ctx.ws[i] for i in fs], table_ptrs=[0] * n_tables,
+                             fm=fmg is not None)
+        lws = torch.empty(lib.nrx_embed_bwd_sorted_workspace(total, D), dtype=torch.uint8, device=dev)   # hot-row work lists
+        if ctx.sink is not None:
+            values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
+            check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
+                                           seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), fmg, values.data_ptr(), lws.data_ptr(), stream),
+                  "nrx_embed_bwd_sorted")
+            ctx.sink.pending.append(dict(tables=ctx.tables, dim=D, uniq=uniq, values=values, counts=counts, cap=total))
+            continue
+        if SPARSE_BWD_SYNC_FREE:
+            values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
+            check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
+                                           seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), fmg, values.data_ptr(), lws.data_ptr(), stream),
+                  "nrx_embed_bwd_sorted")
+            cl = counts.tolist()
+            nu = cl[0]
+        else:
+            cl = counts.tolist()
+            nu = cl[0]
+            values = torch.empty((nu, D), dtype=torch.float32, device=dev)
+            check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
+                                           seg.data_ptr(), uniq.data_ptr(), nu, None, fmg, values.data_ptr(), lws.data_ptr(), stream),
+                  "nrx_embed_bwd_sorted")                     # padding rows (id 0) come back as zeros
+        rows = (uniq[:nu] & MASK).unsqueeze(0)
+        for t in sorted(set(tabs)):
+            lo, hi = cl[1 + t], cl[2 + t]
+            g = torch.sparse_coo_tensor(rows[:, lo:hi], values[lo:hi], size=ctx.table_meta[t][0], is_coalesced=True)
+            grads[t] = g if grads[t] is None else (grads[t] + g).coalesce()
     for t in range(n_tables):
         if grads[t] is None:
             shape, dev = ctx.table_meta[t]
@@ -720,14 +775,37 @@ class PreparedSparseBackward:
                                         fm=self.fmg is not None))
             self.groups.append(g)
 
-    def run(self):
-        lib, f = self.lib, self.fwd
-        stream = torch.cuda.current_stream(f.device).cuda_stream
+    def _plan(self, stream):
+        lib = self.lib
         for g in self.groups:
             rc = lib.nrx_sparse_plan(g["ptrs"], g["lens"], g["tof"], g["rws"], g["n"], g["bits"], g["n_tables"], g["order"].data_ptr(),
                                      g["uniq"].data_ptr(), g["seg"].data_ptr(), g["counts"].data_ptr(), g["ws"].data_ptr(), stream)
             if rc:
                 check(rc, "nrx_sparse_plan")
+
+    def plan_ahead(self):
+        """Enqueue the planning (sort, unique rows, segments: it depends only on the ids) on a side stream NOW -- call it
+        next to the forward launch; the following run() then waits for it instead of planning inline.  In a training step
+        the dense model's forward and backward sit between the two calls and the planning is hidden behind them."""
+        dev = self.fwd.device
+        cur, side = torch.cuda.current_stream(dev), _plan_stream(dev)
+        side.wait_stream(cur)              # ids ready; and the previous run()'s reduction is done with the plan buffers
+        with torch.cuda.stream(side):
+            self._plan(side.cuda_stream)
+            self._plan_ev = torch.cuda.Event()
+            self._plan_ev.record(side)
+
+    def run(self):
+        lib, f = self.lib, self.fwd
+        cur = torch.cuda.current_stream(f.device)
+        stream = cur.cuda_stream
+        ev = getattr(self, "_plan_ev", None)
+        if ev is not None:
+            cur.wait_event(ev)
+            self._plan_ev = None
+        else:
+            self._plan(stream)
+        for g in self.groups:
             rc = lib.nrx_embed_bwd_sorted(g["arr"], g["n"], f.B, g["dim"], _ptr(self.g_out), f.ld, _ptr(self.g_wide), f.plan.wide_width,
                                           g["order"].data_ptr(), g["seg"].data_ptr(), g["uniq"].data_ptr(), g["total"],
                                           g["counts"].data_ptr(), self.fmg, g["values"].data_ptr(), g["lws"].data_ptr(), stream)
