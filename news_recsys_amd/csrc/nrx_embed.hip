@@ -408,6 +408,8 @@ struct SortedBwdArgs {
     int64_t long_items_cap;        // capacity of the item list
     int64_t long_slots_cap;        // capacity of the partial-sum slots
     const float* scale;            // fast form with bag features: per flat lookup, the factor of its upstream row (bag_scale_kernel)
+    const float* bag_inv;          // ... and its compact form when every weight is 0 or 1 (long_ws[3] == 0): per (feature, sample)
+    const uint32_t* bag_bits;      //     the factor of a weight-1 lookup, and one bit per lookup (weight != 0); both stay in L2
     float* values;
     int32_t n;
     int32_t dim;
@@ -593,16 +595,51 @@ __device__ __forceinline__ void sorted_long_write_items(const NRX_CONST SortedBw
 // position; lane 0 of a wide feature takes 3 floats from g_out and its first one from g_wide.
 typedef float nrx_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float nrx_f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+
+// What the reduction needs to know about the feature of a lookup.  The feature index differs from lane group to lane group,
+// so reading the argument block by it is a VECTOR load per field -- five per lookup, each a full pass of the CU's address
+// unit for a handful of bytes; the C4 launch (history + item id on the news table) issued 3 M load instructions for 3.3 M
+// lookups and was bound by exactly that.  Launches of <= 4 features read all candidates with scalar loads and select.
+struct FeatLite {
+    int64_t off;        // flat lookup offset of the feature
+    uint64_t magic;     // 2^64 reciprocal of bag_len (bags)
+    int32_t out_col, wide_col;
+    int32_t bag_len;
+    int32_t kind;
+    bool fm;
+};
+__device__ __forceinline__ FeatLite sorted_feat(const NRX_CONST SortedBwdArgs* a, int fi) {
+    FeatLite f;
+    if (a->n <= 4) {
+        f.off = a->off[0]; f.magic = (uint64_t)a->f[0].rows; f.out_col = a->f[0].out_col; f.wide_col = a->f[0].wide_col;
+        f.bag_len = a->f[0].bag_len; f.kind = a->f[0].kind; f.fm = a->f[0].fm != 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {           // constant indices: scalar loads (entries past n are inside the block and unused)
+            const bool hit = fi == i;
+            f.off = hit ? a->off[i] : f.off;
+            f.magic = hit ? (uint64_t)a->f[i].rows : f.magic;
+            f.out_col = hit ? a->f[i].out_col : f.out_col;
+            f.wide_col = hit ? a->f[i].wide_col : f.wide_col;
+            f.bag_len = hit ? (int32_t)a->f[i].bag_len : f.bag_len;
+            f.kind = hit ? (int32_t)a->f[i].kind : f.kind;
+            f.fm = hit ? a->f[i].fm != 0 : f.fm;
+        }
+        return f;
+    }
+    f.off = a->off[fi]; f.magic = (uint64_t)a->f[fi].rows; f.out_col = a->f[fi].out_col; f.wide_col = a->f[fi].wide_col;
+    f.bag_len = a->f[fi].bag_len; f.kind = a->f[fi].kind; f.fm = a->f[fi].fm != 0;
+    return f;
+}
 template <bool UNAL>
-__device__ __forceinline__ float4 sorted_upstream(const NRX_CONST SortedBwdArgs* a, int fi, int64_t b, int q) {
-    if (!UNAL) return a->g_out ? nrx_ldg4(a->g_out, (b * a->out_ld + a->f[fi].out_col) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int wc = a->f[fi].wide_col;                          // the lanes of a group share the feature
+__device__ __forceinline__ float4 sorted_upstream(const NRX_CONST SortedBwdArgs* a, const FeatLite& f, int64_t b, int q) {
+    if (!UNAL) return a->g_out ? nrx_ldg4(a->g_out, (b * a->out_ld + f.out_col) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int wc = f.wide_col;                                 // the lanes of a group share the feature
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     // one load shape for every lane (a second path for "lane 0 of a wide feature" would run serially in every wavefront that
     // mixes wide and plain rows): 16 bytes at the shifted position; lane 0 of a wide feature thereby reads one float of the
     // previous feature's block, which the select below replaces by the wide gradient -- except at the very first element of
     // g_out (sample 0, column 0), where the load starts one float later and is shifted back in registers
-    int64_t eo = b * a->out_ld + a->f[fi].out_col + 4 * q - (wc >= 0 ? 1 : 0);
+    int64_t eo = b * a->out_ld + f.out_col + 4 * q - (wc >= 0 ? 1 : 0);
     const bool edge = eo < 0;
     if (a->g_out) {
         const nrx_f32x4u t = *reinterpret_cast<const nrx_f32x4u*>(a->g_out + (edge ? 0 : eo));
@@ -614,9 +651,10 @@ __device__ __forceinline__ float4 sorted_upstream(const NRX_CONST SortedBwdArgs*
 
 // BAG: some features are bags -- a lookup's sample is (flat index) / L and its upstream row is scaled by the per-lookup
 // factor bag_scale_kernel left in a->scale (mask / (sum mask + 1e-8), 1 / L, or the weight).
-template <int QLOG2, int R, bool FM, bool BAG, bool UNAL>
+template <int QLOG2, int R, bool FM, bool BAG, bool UNAL, int UP = 1>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const SortedBwdArgs args_in_kernarg) {
     const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
+    const bool bag_binary = BAG && a->bag_bits != nullptr && a->long_ws[3] == 0;      // every bag weight is 0 or 1 (bag_scale_kernel)
     constexpr int Q = 1 << QLOG2;
     constexpr int TB = NRX_BLOCK / Q;
     const int q = threadIdx.x & (Q - 1);
@@ -696,64 +734,82 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
     // One pass takes the next sorted entry of each of the R rows: R independent chains (lookup index -> upstream row) per
     // lane, added in sorted order.  The lookup indices of the NEXT pass are requested before this pass's rows, so a pass
     // costs one memory round trip, not two.
-    int64_t pn[R];
+    // UP sorted entries of each of the R rows per pass (UP = 1: uniform-id launches, where most rows have one entry; UP = 4: bag
+    // launches, where a row of the pooled table is looked up ~L times and a one-entry pass made the walk latency-bound:
+    // all rows of the launch are in flight at once, so the only parallelism left is INSIDE a row).  The lookup indices of the
+    // next pass are requested before this pass's rows: one memory round trip per pass, not two.
+    int64_t pn[R][UP];
 #pragma unroll
-    for (int r = 0; r < R; ++r) pn[r] = nrx_gconst<int64_t>(a->order)[e[r] < hi[r] ? e[r] : lo[0]];
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < UP; ++j) pn[r][j] = nrx_gconst<int64_t>(a->order)[e[r] + j < hi[r] ? e[r] + j : lo[0]];
     auto pass = [&]() -> bool {
-        int64_t p[R];
-        bool on[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            on[r] = e[r] < hi[r];
-            p[r] = pn[r];
-        }
+        int64_t p[R][UP];
+        bool on[R][UP];
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (e[r] + 1 < hi[r]) pn[r] = nrx_gconst<int64_t>(a->order)[e[r] + 1];      // rows with one entry (most) request nothing
-        float4 g[R], v[R], s[R];
-        float gf[R], sc[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int fi = sorted_feat_of(a, p[r]);
-            int64_t b = p[r] - a->off[fi];
-            sc[r] = 1.0f;
-            if (BAG && a->f[fi].kind >= NRX_BAG_MASKED_MEAN) {
-                sc[r] = nrx_gconst<float>(a->scale)[p[r]];
-                if (a->f[fi].bag_len > 1) b = (int64_t)__umul64hi((uint64_t)b, (uint64_t)a->f[fi].rows);   // b / bag_len (b < 2^32)
+            for (int j = 0; j < UP; ++j) {
+                on[r][j] = e[r] + j < hi[r];
+                p[r][j] = pn[r][j];
             }
-            g[r] = sorted_upstream<UNAL>(a, fi, b, q);
-            if (FM) {
-                const bool fm = a->f[fi].fm;
-                gf[r] = fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
-                v[r] = nrx_ldg4(a->feat, (b * a->feat_ld + a->f[fi].out_col) / 4 + q);
-                s[r] = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < UP; ++j)
+                if (e[r] + UP + j < hi[r]) pn[r][j] = nrx_gconst<int64_t>(a->order)[e[r] + UP + j];      // (one-entry rows request nothing)
+        float4 g[R][UP], v[R][UP], s[R][UP];
+        float gf[R][UP], sc[R][UP];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < UP; ++j) {
+                const FeatLite f = sorted_feat(a, sorted_feat_of(a, p[r][j]));
+                int64_t b = p[r][j] - f.off;
+                sc[r][j] = 1.0f;
+                if (BAG && f.kind >= NRX_BAG_MASKED_MEAN) {
+                    if (f.bag_len > 1) b = (int64_t)__umul64hi((uint64_t)b, f.magic);   // b / bag_len (b < 2^32)
+                    if (bag_binary) {
+                        const uint32_t wb = nrx_gconst<uint32_t>(a->bag_bits)[p[r][j] >> 5];
+                        const float one = nrx_gconst<float>(a->bag_inv)[f.off + b];
+                        sc[r][j] = (wb >> (p[r][j] & 31)) & 1u ? one : 0.f;
+                    } else {
+                        sc[r][j] = nrx_gconst<float>(a->scale)[p[r][j]];
+                    }
+                }
+                g[r][j] = sorted_upstream<UNAL>(a, f, b, q);
+                if (FM) {
+                    gf[r][j] = f.fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
+                    v[r][j] = nrx_ldg4(a->feat, (b * a->feat_ld + f.out_col) / 4 + q);
+                    s[r][j] = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
+                }
             }
-        }
         bool more = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float4 t = g[r];
-            if (FM) {                     // d fm / d field: column 0 -> 1, column k -> S_k - v_k
-                t.x += q == 0 ? gf[r] : gf[r] * (s[r].x - v[r].x);
-                t.y += gf[r] * (s[r].y - v[r].y);
-                t.z += gf[r] * (s[r].z - v[r].z);
-                t.w += gf[r] * (s[r].w - v[r].w);
-            }
-            if (on[r]) {
-                if (BAG) {
+#pragma unroll
+            for (int j = 0; j < UP; ++j) {
+                float4 t = g[r][j];
+                if (FM) {                     // d fm / d field: column 0 -> 1, column k -> S_k - v_k
+                    t.x += q == 0 ? gf[r][j] : gf[r][j] * (s[r][j].x - v[r][j].x);
+                    t.y += gf[r][j] * (s[r][j].y - v[r][j].y);
+                    t.z += gf[r][j] * (s[r][j].z - v[r][j].z);
+                    t.w += gf[r][j] * (s[r][j].w - v[r][j].w);
+                }
+                if (on[r][j]) {               // added in sorted order: j ascending inside the pass
+                    if (BAG) {
 #pragma clang fp contract(off)
-                    acc[r].x += t.x * sc[r]; acc[r].y += t.y * sc[r]; acc[r].z += t.z * sc[r]; acc[r].w += t.w * sc[r];
-                } else {
-                    acc[r].x += t.x; acc[r].y += t.y; acc[r].z += t.z; acc[r].w += t.w;
+                        acc[r].x += t.x * sc[r][j]; acc[r].y += t.y * sc[r][j]; acc[r].z += t.z * sc[r][j]; acc[r].w += t.w * sc[r][j];
+                    } else {
+                        acc[r].x += t.x; acc[r].y += t.y; acc[r].z += t.z; acc[r].w += t.w;
+                    }
                 }
             }
-            e[r] += 1;
+            e[r] += UP;
             more |= e[r] < hi[r];
         }
         return more;
     };
-    // (tried: UPN = 2 / 4 entries per row for the passes after the first -- more chains in flight per lane, but the extra
-    // registers cost a wave of occupancy and every workload got slower: C2 166 -> 225 us, C5 177 -> 266 us)
     bool more = true;
     while (more) more = pass();
 #pragma unroll
@@ -768,6 +824,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
 template <int QLOG2, bool FM, bool BAG, bool UNAL>
 __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdArgs args_in_kernarg) {
     const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
+    const bool bag_binary = BAG && a->bag_bits != nullptr && a->long_ws[3] == 0;      // every bag weight is 0 or 1 (bag_scale_kernel)
     constexpr int Q = 1 << QLOG2, G = 64 / Q;
     const int lane = threadIdx.x & 63, q = lane & (Q - 1), g = lane >> QLOG2;
     const int nitems = a->long_ws[0] < a->long_items_cap ? a->long_ws[0] : (int)a->long_items_cap;
@@ -790,17 +847,23 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
             float gf[UL], sc[UL];
 #pragma unroll
             for (int k = 0; k < UL; ++k) {
-                const int fi = sorted_feat_of(a, p[k]);
-                int64_t b = p[k] - a->off[fi];
+                const FeatLite f = sorted_feat(a, sorted_feat_of(a, p[k]));
+                int64_t b = p[k] - f.off;
                 sc[k] = 1.0f;
-                if (BAG && a->f[fi].kind >= NRX_BAG_MASKED_MEAN) {
-                    sc[k] = nrx_gconst<float>(a->scale)[p[k]];
-                    if (a->f[fi].bag_len > 1) b = (int64_t)__umul64hi((uint64_t)b, (uint64_t)a->f[fi].rows);
+                if (BAG && f.kind >= NRX_BAG_MASKED_MEAN) {
+                    if (f.bag_len > 1) b = (int64_t)__umul64hi((uint64_t)b, f.magic);
+                    if (bag_binary) {
+                        const uint32_t wb = nrx_gconst<uint32_t>(a->bag_bits)[p[k] >> 5];
+                        const float one = nrx_gconst<float>(a->bag_inv)[f.off + b];
+                        sc[k] = (wb >> (p[k] & 31)) & 1u ? one : 0.f;
+                    } else {
+                        sc[k] = nrx_gconst<float>(a->scale)[p[k]];
+                    }
                 }
-                gr[k] = sorted_upstream<UNAL>(a, fi, b, q);
+                gr[k] = sorted_upstream<UNAL>(a, f, b, q);
                 if (FM) {
-                    gf[k] = a->f[fi].fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
-                    v[k] = nrx_ldg4(a->feat, (b * a->feat_ld + a->f[fi].out_col) / 4 + q);
+                    gf[k] = f.fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
+                    v[k] = nrx_ldg4(a->feat, (b * a->feat_ld + f.out_col) / 4 + q);
                     s_[k] = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
                 }
             }
@@ -871,7 +934,12 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_combine_kernel(const SortedB
 // Per-lookup factor of a bag feature's upstream row (what the general kernel recomputes per lookup from the whole row of
 // weights): w / (sum_l w + 1e-8) (masked mean, base_model.py:278-282), 1 / L (mean) or w (sum).  16 lanes per sample.
 __global__ __launch_bounds__(NRX_BLOCK) void bag_scale_kernel(const float* __restrict__ w, int kind, int64_t batch, int L,
-                                                            float* __restrict__ scale) {
+                                                            float* __restrict__ scale, float* __restrict__ inv, uint32_t* __restrict__ bits,
+                                                            int64_t base, int32_t* __restrict__ nonbinary) {
+    // also leaves the compact form: inv[b] = factor of a weight-1 lookup of sample b, bits = one bit per lookup (weight != 0;
+    // `bits` pre-zeroed, indexed by the flat lookup base + b L + l), and raises *nonbinary when some weight is neither 0 nor 1.
+    // DataReader's masks are 0/1 (data_reader.py:96-109), and then the reduction reads 0.7 MB of L2-resident words instead of
+    // one random 4-byte scale (= a 128-byte line) per lookup.
     const int q = threadIdx.x & 15;
     const int64_t b = ((int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x) >> 4;
     if (b >= batch) return;                                   // whole 16-lane groups leave together
@@ -880,13 +948,31 @@ __global__ __launch_bounds__(NRX_BLOCK) void bag_scale_kernel(const float* __res
         for (int l = q; l < L; l += 16) den += w[b * L + l];
         den = group_sum<16>(den) + 1e-8f;
     }
-    for (int l = q; l < L; l += 16) {
-        float v;
-        if (kind == NRX_BAG_MASKED_MEAN) v = w[b * L + l] / den;
-        else if (kind == NRX_BAG_MEAN) v = 1.0f / (float)L;
-        else v = w != nullptr ? w[b * L + l] : 1.0f;
-        scale[b * L + l] = v;
+    const float one = kind == NRX_BAG_MASKED_MEAN ? 1.0f / den : (kind == NRX_BAG_MEAN ? 1.0f / (float)L : 1.0f);
+    if (q == 0) inv[b] = one;
+    const int gsh = (threadIdx.x & 63) & ~15;                 // this group's first lane inside the wavefront
+    bool odd = false;
+    for (int l0 = 0; l0 < L; l0 += 16) {
+        const int l = l0 + q;
+        const bool in = l < L;
+        const float wv = (in && w != nullptr && kind != NRX_BAG_MEAN) ? w[b * L + l] : 1.0f;
+        if (in) {
+            float v;
+            if (kind == NRX_BAG_MASKED_MEAN) v = wv / den;
+            else if (kind == NRX_BAG_MEAN) v = 1.0f / (float)L;
+            else v = wv;
+            scale[b * L + l] = v;
+        }
+        odd |= in && wv != 0.0f && wv != 1.0f;
+        const uint32_t m = (uint32_t)((__ballot(in && wv != 0.0f) >> gsh) & 0xffffull);     // the group's 16 lookups
+        if (q == 0 && m != 0u) {
+            const int64_t p0 = base + b * L + l0;
+            const int sh = (int)(p0 & 31);
+            atomicOr(&bits[p0 >> 5], m << sh);
+            if (sh > 16) atomicOr(&bits[(p0 >> 5) + 1], m >> (32 - sh));
+        }
     }
+    if (__ballot(odd) != 0ull && (threadIdx.x & 63) == 0) atomicOr(nonbinary, 1);
 }
 
 // ----------------------------------------------------------------------------------- host side
@@ -1152,7 +1238,7 @@ extern "C" int64_t nrx_embed_bwd_sorted_workspace(int64_t n_lookups, int32_t dim
     if (n_lookups < 0 || dim < 1) return -1;
     const int64_t items = n_lookups / SORTED_LONG_T + 8, slots = 2 * n_lookups / SORTED_LONG_CHUNK + 8;
     return 32 + items * (int64_t)sizeof(LongItem) + slots * (int64_t)sizeof(LongMulti) + slots * (int64_t)dim * 4 + 64 +
-           n_lookups * 4 + 64;                                   // + the per-lookup scale of bag features
+           2 * (n_lookups * 4 + 64) + n_lookups / 8 + 128;       // + bag features: per-lookup scale, per-sample factor, weight bits
 }
 
 extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
@@ -1180,6 +1266,8 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     a.long_ws = nullptr;
     a.long_items_cap = a.long_slots_cap = 0;
     a.scale = nullptr;
+    a.bag_inv = nullptr;
+    a.bag_bits = nullptr;
     a.long_t = SORTED_LONG_T;
     int64_t off = 0;
     for (int i = 0; i < n_feats; ++i) {
@@ -1253,7 +1341,9 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     if (has_bag) a.long_t = 2 * SORTED_LONG_T;
     if (fast) {
         constexpr int R = 4;
-        const int64_t groups = (n_unique + R - 1) / R;
+        constexpr int RB = 2;                   // bag launches: 2 rows x 4 entries per pass (see the kernel)
+        const bool bag_shape = has_bag && !unal && !has_fm;
+        const int64_t groups = (n_unique + (bag_shape ? RB : R) - 1) / (bag_shape ? RB : R);
         const unsigned grid = (unsigned)((groups + tb - 1) / tb);
         if (workspace != nullptr) {        // long segments (hot rows) go through the wavefront-per-item path
             a.long_ws = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15);
@@ -1267,19 +1357,25 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
             char* end = reinterpret_cast<char*>(a.long_ws + 4) + a.long_items_cap * sizeof(LongItem) +
                         a.long_slots_cap * sizeof(LongMulti) + a.long_slots_cap * (size_t)dim * 4;
             float* scale = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(end) + 15) & ~(uintptr_t)15);
+            float* inv = scale + ((off + 15) & ~(int64_t)15);
+            uint32_t* bits = reinterpret_cast<uint32_t*>(inv + ((off + 15) & ~(int64_t)15));
             a.scale = scale;
+            a.bag_inv = inv;
+            a.bag_bits = bits;
+            if (nrx_zero_async(bits, (size_t)(off / 32 + 2) * 4, st) != NRX_OK) return NRX_ERR_LAUNCH;
             for (int i = 0; i < n_feats; ++i) {
                 if (feats[i].kind == NRX_SPARSE || batch == 0) continue;
                 const int64_t groups16 = batch;                                          // 16 lanes per sample
                 hipLaunchKernelGGL(bag_scale_kernel, dim3((unsigned)((groups16 * 16 + NRX_BLOCK - 1) / NRX_BLOCK)), dim3(NRX_BLOCK), 0, st,
-                                   a.f[i].weight, (int)feats[i].kind, batch, (int)feats[i].bag_len, scale + a.off[i]);
+                                   a.f[i].weight, (int)feats[i].kind, batch, (int)feats[i].bag_len, scale + a.off[i], inv + a.off[i], bits,
+                                   a.off[i], a.long_ws + 3);
             }
         }
 #define NRX_SF(QL_)                                                                                                        \
     {                                                                                                                      \
         if (has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
         else if (unal) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, true, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else if (has_bag) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, true, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else if (has_bag) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, false, 4>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
         else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a);      \
     }
         if (ql == 2) NRX_SF(2) else if (ql == 3) NRX_SF(3) else NRX_SF(4)
