@@ -414,6 +414,9 @@ struct SortedBwdArgs {
     int32_t n;
     int32_t dim;
     int32_t long_t;
+    int32_t regular;               // 1: every feature single-valued, no wide routing, uniform_len > 0, out_col = col0 + i * col_stride,
+    int32_t col0, col_stride;      //    one FM flag for all -- the per-feature fields are then arithmetic on the feature index
+    int32_t all_fm;
 };
 static_assert(sizeof(SortedBwdArgs) <= 3840, "kernarg budget");
 
@@ -610,6 +613,11 @@ struct FeatLite {
 };
 __device__ __forceinline__ FeatLite sorted_feat(const NRX_CONST SortedBwdArgs* a, int fi) {
     FeatLite f;
+    if (a->regular) {                  // (the C2 / C5 shape: 26 / 40 single-valued features laid out back to back)
+        f.off = (int64_t)fi * a->uniform_len; f.magic = 0; f.out_col = a->col0 + fi * a->col_stride; f.wide_col = -1;
+        f.bag_len = 0; f.kind = NRX_SPARSE; f.fm = a->all_fm != 0;
+        return f;
+    }
     if (a->n <= 4) {
         f.off = a->off[0]; f.magic = (uint64_t)a->f[0].rows; f.out_col = a->f[0].out_col; f.wide_col = a->f[0].wide_col;
         f.bag_len = a->f[0].bag_len; f.kind = a->f[0].kind; f.fm = a->f[0].fm != 0;
@@ -1304,6 +1312,13 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
         if (a.off[i + 1] - a.off[i] != a.uniform_len) a.uniform_len = 0;
     if (a.uniform_len < 2 || off >= 0xffffffffLL) a.uniform_len = 0;      // the reciprocal form needs a divisor >= 2 and lookups < 2^32
     a.uniform_magic = a.uniform_len > 0 ? ~0ull / (uint64_t)a.uniform_len + 1 : 0;
+    a.col0 = feats[0].out_col;
+    a.col_stride = n_feats > 1 ? feats[1].out_col - feats[0].out_col : dim;
+    a.all_fm = a.f[0].fm;
+    a.regular = a.uniform_len > 0 && n_feats > 4;
+    for (int i = 0; i < n_feats && a.regular; ++i)
+        a.regular = feats[i].kind == NRX_SPARSE && feats[i].wide_col < 0 && feats[i].out_col == a.col0 + i * a.col_stride &&
+                    a.f[i].fm == a.f[0].fm;
     a.batch = batch;
     a.g_out = g_out;
     a.out_ld = out_ld;
