@@ -3,15 +3,17 @@
 // (src/model/BaseModel/base_model.py:262-308), here producing nn.Embedding(sparse=True)-style COO grads.
 //
 // keys = (table << row_bits) | row are built COMPACT -- only table_bits + row_bits significant bits, 32-bit
-// when they fit (C2: 5 + 20 bits) -- and sorted with rocPRIM's radix sort limited to those bits (4 digit
-// passes instead of the 8 that a generic 64-bit sort pays), payload = the 32-bit flat lookup index; the sort
-// is stable, so the lookups of one row stay in (feature, sample) order and the segmented reduction that
-// follows (nrx_embed_bwd_sorted) is bit-reproducible.  Two more launches (head count per tile, then rank + emit) give
+// when they fit (C2: 5 + 20 bits) -- with payload = the 32-bit flat lookup index, and sorted STABLY, so the lookups of one
+// row stay in (feature, sample) order and the segmented reduction that follows (nrx_embed_bwd_sorted) is bit-reproducible.
+// The sort is the table-segmented LSD radix sort below (the table of a lookup is known from its feature, so the pairs are
+// laid out table-major by the key kernel and only the row bits are sorted, inside each table's segment: C2 plan 96 us vs
+// 171 us with the general sort); rocPRIM's radix sort limited to the significant bits is the fallback for more than 64
+// tables and under NRX_PLAN_SORT=rocprim.  Two more launches (head count per tile, then rank + emit) give
 // the unique (table,row) list, the segment starts, the number of unique rows and the per-table split, all left on
-// the device: the host reads n_tables + 2 integers once (or nothing, in the fused-optimizer mode).  rocPRIM's radix
-// sort is the vendor primitive; key construction / head ranking / emission are the kernels below.
+// the device: the host reads n_tables + 2 integers once (or nothing, in the fused-optimizer mode).
 #include "nrx_common.h"
 #include <cstring>
+#include <cstdlib>
 #include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
@@ -148,6 +150,378 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const KeyT* __rest
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Table-segmented LSD radix sort of the compact keys (the default planner sort; rocPRIM's onesweep stays as the fallback for
+// shapes outside its limits and under NRX_PLAN_SORT=rocprim).
+// The general-purpose sort has to order all table_bits + row_bits bits (C2: 25 bits = four 8-bit onesweep passes, each with its
+// own memset + look-back chain: 155 us for 1.7 M pairs).  But the TABLE of a lookup is known from its feature, and the number
+// of lookups per table is known on the host: the key kernel writes the pairs table-major to begin with (table t's lookups,
+// in (feature, sample) order, at seg_off[t]), so only the ROW bits are left to sort, inside each table's segment, with
+// digits as wide as a block ranks comfortably in LDS (up to 10 bits; every segment splits ITS row bits evenly over the
+// passes): two passes for C2 (20 row bits = 2 x 10), three for a 10 M-row table.  One pass =
+//   seg_hist_kernel      one block per 4096-entry tile (tiles never straddle a segment): LDS histogram of the digit
+//                        (pass 0: fused into the key kernel)                                      -> hist[tile][bin]
+//   seg_scan_chunks      (only when a segment has more than 32 tiles) per (32-tile chunk, bin): running sum over the
+//                        chunk's tiles in place, chunk totals -> ctot[chunk][bin]
+//   seg_scan_bins        one block per segment: per bin the running sum over the segment's tiles (or chunks), then the
+//                        exclusive scan over the bins + the segment's base                         -> bin_base[seg][bin]
+//   seg_scatter_kernel   re-reads the tile; each wavefront ranks its 1024 contiguous entries round by round (equal-digit
+//                        peers by ballots, running per-wave bin counts in LDS); a cross-wave prefix + a block scan over
+//                        the bins give the stable rank inside the tile; the pairs are first permuted INSIDE LDS and
+//                        then written out in tile order, so that the entries of one bin leave as one contiguous run.
+// Every step is order-preserving, so equal rows stay in (feature, sample) order: the result is the same permutation the
+// stable rocPRIM sort produces (tests compare both against the oracle's plan).
+// ---------------------------------------------------------------------------------------------------
+constexpr int SEG_TILE = 4096;                      // entries per block
+constexpr int SEG_THREADS = 512;                    // threads of the tile kernels: 8 wavefronts x 512 contiguous entries (the
+                                                    // kernels are latency-bound at these sizes: short serial chains, more of them)
+constexpr int SEG_PER_THREAD = SEG_TILE / SEG_THREADS;
+constexpr int SEG_MAX_DB = 10;                      // widest digit
+constexpr int SEG_CHUNK = 32;                       // tiles per scan chunk
+
+struct SegArgs {
+    const void* ids[NRX_MAX_FEATURES];
+    int64_t qoff[NRX_MAX_FEATURES + 1];      // table-major start of the q-th feature slot (slots ordered by table, then feature)
+    int64_t poff[NRX_MAX_FEATURES];          // feature-major start (the payload) of the slot's feature
+    int64_t rows[NRX_MAX_FEATURES];          // per slot
+    int64_t seg_off[NRX_MAX_FEATURES + 1];   // per table: first entry
+    int32_t seg_tile[NRX_MAX_FEATURES + 1];  // per table: first tile
+    int32_t seg_chunk[NRX_MAX_FEATURES + 1]; // per table: first chunk
+    uint8_t table[NRX_MAX_FEATURES];         // per slot
+    uint8_t seg_db[NRX_MAX_FEATURES];        // per table: digit width
+    int32_t n_slots, n_seg, idx64, row_bits, nb;     // nb = 1 << (widest digit) = row stride of hist / ctot / bin_base
+};
+static_assert(sizeof(SegArgs) <= 3584, "kernarg budget");
+
+// Segment of a tile: the LAST segment whose first tile is <= tile.  Written as a count over the whole (<= 64-entry) array
+// with a uniform index, so that the loads are a handful of independent scalar loads -- a binary search would be six
+// DEPENDENT round trips to the argument block before the block can load anything.
+__device__ __forceinline__ int seg_of_tile(const NRX_CONST SegArgs* a, int tile) {
+    int seg = 0;
+    const int n = a->n_seg;
+#pragma unroll
+    for (int i = 1; i < NRX_MAX_FEATURES; ++i) seg += (i < n && a->seg_tile[i] <= tile) ? 1 : 0;
+    return seg;
+}
+
+// keys + payload in table-major order, and the histogram of digit 0
+template <typename KeyT>
+__global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs args_in_kernarg, KeyT* __restrict__ keys, uint32_t* __restrict__ payload,
+                                                               uint32_t* __restrict__ hist) {
+    extern __shared__ uint32_t s_hist[];
+    const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
+    const int tile = blockIdx.x, seg = seg_of_tile(a, tile);
+    const int nbins = 1 << a->seg_db[seg];
+    for (int b = threadIdx.x; b < nbins; b += SEG_THREADS) s_hist[b] = 0;
+    const int64_t q0 = a->seg_off[seg] + (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE, qend = a->seg_off[seg + 1];
+    const uint32_t dmask = (uint32_t)nbins - 1u;
+    // first feature slot of the tile (wave-uniform, counted like seg_of_tile); a tile rarely holds a second one: then
+    // every per-slot field is a scalar, otherwise the entries past the boundary walk on from there with per-lane indices
+    int lo = 0;
+    {
+        const int ns = a->n_slots;
+#pragma unroll
+        for (int i = 1; i < NRX_MAX_FEATURES; ++i) lo += (i < ns && a->qoff[i] <= q0) ? 1 : 0;
+    }
+    const int64_t lo_end = a->qoff[lo + 1];
+    const bool one_slot = lo_end >= qend || lo_end >= q0 + SEG_TILE;
+    int sl[SEG_PER_THREAD];
+    int64_t id[SEG_PER_THREAD];
+    if (one_slot) {
+        const int64_t i0 = q0 - a->qoff[lo];
+        const void* idp = a->ids[lo];
+#pragma unroll
+        for (int j = 0; j < SEG_PER_THREAD; ++j) {          // all id loads issued before anything waits
+            const int64_t q = q0 + j * SEG_THREADS + threadIdx.x;
+            sl[j] = lo;
+            id[j] = 0;
+            if (q < qend) {
+                const int64_t i = i0 + j * SEG_THREADS + threadIdx.x;
+                id[j] = a->idx64 ? nrx_gconst<int64_t>(idp)[i] : (int64_t)nrx_gconst<int32_t>(idp)[i];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SEG_PER_THREAD; ++j) {
+            const int64_t q = q0 + j * SEG_THREADS + threadIdx.x;
+            int s = lo;
+            if (q >= lo_end && q < qend) {
+                do ++s; while (a->qoff[s + 1] <= q);
+            }
+            sl[j] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < SEG_PER_THREAD; ++j) {
+            const int64_t q = q0 + j * SEG_THREADS + threadIdx.x;
+            id[j] = 0;
+            if (q < qend) {
+                const int64_t i = q - a->qoff[sl[j]];
+                id[j] = a->idx64 ? nrx_gconst<int64_t>(a->ids[sl[j]])[i] : (int64_t)nrx_gconst<int32_t>(a->ids[sl[j]])[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (one_slot) {
+        const int64_t rows = a->rows[lo], pbase = a->poff[lo] + (q0 - a->qoff[lo]);
+        const KeyT tkey = (KeyT)a->table[lo] << a->row_bits;
+#pragma unroll
+        for (int j = 0; j < SEG_PER_THREAD; ++j) {
+            const int64_t q = q0 + j * SEG_THREADS + threadIdx.x;
+            if (q < qend) {
+                int64_t v = id[j];
+                if (v < 0 || v >= rows) v = 0;            // out-of-range ids were reported by the forward; the padding row never trains
+                keys[q] = tkey | (KeyT)v;
+                payload[q] = (uint32_t)(pbase + j * SEG_THREADS + threadIdx.x);
+                atomicAdd(&s_hist[(uint32_t)v & dmask], 1u);
+            }
+        }
+    } else {
+#pragma unroll
+    for (int j = 0; j < SEG_PER_THREAD; ++j) {
+        const int64_t q = q0 + j * SEG_THREADS + threadIdx.x;
+        if (q < qend) {
+            const int s = sl[j];
+            int64_t v = id[j];
+            if (v < 0 || v >= a->rows[s]) v = 0;
+            keys[q] = ((KeyT)a->table[s] << a->row_bits) | (KeyT)v;
+            payload[q] = (uint32_t)(a->poff[s] + (q - a->qoff[s]));
+            atomicAdd(&s_hist[(uint32_t)v & dmask], 1u);
+        }
+    }
+    }
+    __syncthreads();
+    uint32_t* h = hist + (size_t)tile * a->nb;
+    for (int b = threadIdx.x; b < nbins; b += SEG_THREADS) h[b] = s_hist[b];
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(SEG_THREADS) void seg_hist_kernel(const SegArgs args_in_kernarg, const KeyT* __restrict__ keys, int pass,
+                                                             uint32_t* __restrict__ hist) {
+    extern __shared__ uint32_t s_hist[];
+    const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
+    const int tile = blockIdx.x, seg = seg_of_tile(a, tile);
+    const int db = a->seg_db[seg], nbins = 1 << db, shift = pass * db;
+    for (int b = threadIdx.x; b < nbins; b += SEG_THREADS) s_hist[b] = 0;
+    const int64_t q0 = a->seg_off[seg] + (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE, qend = a->seg_off[seg + 1];
+    const uint32_t dmask = (uint32_t)nbins - 1u;
+    KeyT k[SEG_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < SEG_PER_THREAD; ++j) {
+        const int64_t q = q0 + j * SEG_THREADS + threadIdx.x;
+        k[j] = keys[q < qend ? q : qend - 1];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SEG_PER_THREAD; ++j)
+        if (q0 + j * SEG_THREADS + threadIdx.x < qend) atomicAdd(&s_hist[(uint32_t)(k[j] >> shift) & dmask], 1u);
+    __syncthreads();
+    uint32_t* h = hist + (size_t)tile * a->nb;
+    for (int b = threadIdx.x; b < nbins; b += SEG_THREADS) h[b] = s_hist[b];
+}
+
+// segments of more than SEG_CHUNK tiles: hist[tile][bin] -> exclusive prefix over the earlier tiles of the tile's chunk
+// (in place); ctot[chunk][bin] = the chunk's total.  grid (nb / 256, chunks)
+__global__ __launch_bounds__(NRX_BLOCK) void seg_scan_chunks(const SegArgs args_in_kernarg, uint32_t* __restrict__ hist, uint32_t* __restrict__ ctot) {
+    const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
+    const int chunk = blockIdx.y;
+    int seg = 0;
+    {
+        const int n = a->n_seg;
+#pragma unroll
+        for (int i = 1; i < NRX_MAX_FEATURES; ++i) seg += (i < n && a->seg_chunk[i] <= chunk) ? 1 : 0;
+    }
+    const int nb = a->nb;
+    const int bin = blockIdx.x * NRX_BLOCK + threadIdx.x;
+    if (bin >= (1 << a->seg_db[seg])) return;
+    const int t0 = a->seg_tile[seg] + (chunk - a->seg_chunk[seg]) * SEG_CHUNK;
+    const int t1 = t0 + SEG_CHUNK < a->seg_tile[seg + 1] ? t0 + SEG_CHUNK : a->seg_tile[seg + 1];
+    uint32_t* h = hist + (size_t)t0 * nb + bin;
+    uint32_t run = 0;
+    int t = t0;
+    for (; t + 4 <= t1; t += 4, h += (size_t)4 * nb) {       // four independent loads in flight
+        const uint32_t v0 = h[0], v1 = h[nb], v2 = h[2 * (size_t)nb], v3 = h[3 * (size_t)nb];
+        h[0] = run; h[nb] = run + v0; h[2 * (size_t)nb] = run + v0 + v1; h[3 * (size_t)nb] = run + v0 + v1 + v2;
+        run += v0 + v1 + v2 + v3;
+    }
+    for (; t < t1; ++t, h += nb) { const uint32_t v = h[0]; h[0] = run; run += v; }
+    ctot[(size_t)chunk * nb + bin] = run;
+}
+
+// One block per segment.  Per bin: running sum over the segment's tiles (a one-chunk segment: hist in place) or over its
+// chunks (ctot in place); then the exclusive scan over the bins + the segment's first entry -> bin_base[seg][bin].
+__global__ __launch_bounds__(NRX_BLOCK) void seg_scan_bins(const SegArgs args_in_kernarg, uint32_t* __restrict__ hist, uint32_t* __restrict__ ctot,
+                                                            uint32_t* __restrict__ bin_base) {
+    __shared__ uint32_t s_part[NRX_BLOCK / 64];
+    const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
+    const int seg = blockIdx.x, nb = a->nb, nbins = 1 << a->seg_db[seg];
+    constexpr int PER = (1 << SEG_MAX_DB) / NRX_BLOCK;            // bins per thread: bin = i * 256 + tid (coalesced rows)
+    const int nchunks = a->seg_chunk[seg + 1] - a->seg_chunk[seg];
+    uint32_t v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int bin = i * NRX_BLOCK + threadIdx.x;
+        uint32_t run = 0;
+        if (bin < nbins) {
+            const bool direct = nchunks <= 1;
+            uint32_t* h = direct ? hist + (size_t)a->seg_tile[seg] * nb + bin : ctot + (size_t)a->seg_chunk[seg] * nb + bin;
+            const int cnt = direct ? a->seg_tile[seg + 1] - a->seg_tile[seg] : nchunks;
+            int t = 0;
+            for (; t + 8 <= cnt; t += 8, h += (size_t)8 * nb) {      // eight independent loads in flight
+                uint32_t x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = h[(size_t)u * nb];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { h[(size_t)u * nb] = run; run += x[u]; }
+            }
+            for (; t < cnt; ++t, h += nb) { const uint32_t x = h[0]; h[0] = run; run += x; }
+        }
+        v[i] = run;
+    }
+    // exclusive scan over the bins in bin order: bin = i * 256 + tid -> scan each i-row across the block, carry between rows
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t carry = (uint32_t)a->seg_off[seg];
+    uint32_t* o = bin_base + (size_t)seg * nb;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        if (i * NRX_BLOCK >= nbins) break;
+        uint32_t inc = v[i];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t x = __shfl_up(inc, off, 64); if (lane >= off) inc += x; }
+        __syncthreads();
+        if (lane == 63) s_part[wid] = inc;
+        __syncthreads();
+        uint32_t base = carry;
+        for (int w = 0; w < wid; ++w) base += s_part[w];
+        const int bin = i * NRX_BLOCK + threadIdx.x;
+        if (bin < nbins) o[bin] = base + inc - v[i];
+        carry += s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    }
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs args_in_kernarg, const KeyT* __restrict__ keys_in,
+                                                                const uint32_t* __restrict__ pay_in, int pass,
+                                                                const uint32_t* __restrict__ hist, const uint32_t* __restrict__ ctot,
+                                                                const uint32_t* __restrict__ bin_base,
+                                                                KeyT* __restrict__ keys_out, uint32_t* __restrict__ pay_out) {
+    constexpr int WAVES = SEG_THREADS / 64, ROUNDS = SEG_TILE / SEG_THREADS;      // 8 waves x 8 rounds of 64 entries
+    extern __shared__ uint32_t s_mem[];
+    const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tile = blockIdx.x, seg = seg_of_tile(a, tile);
+    const int db = a->seg_db[seg], nbins = 1 << db, shift = pass * db, nb = a->nb;
+    uint32_t* s_wh = s_mem;                               // [WAVES][nbins]: running bin counts of each wave's 1024-entry chunk
+    uint32_t* s_bin = s_wh + WAVES * nbins;               // [nbins]: the bin's first position inside the tile
+    uint32_t* s_gb = s_bin + nbins;                       // [nbins]: global position of the bin's first entry of this tile - s_bin
+    uint32_t* s_pay = s_gb + nbins;                       // [SEG_TILE]
+    KeyT* s_key = reinterpret_cast<KeyT*>(s_pay + SEG_TILE);      // [SEG_TILE]
+    __shared__ uint32_t s_part[WAVES];
+    for (int b = tid; b < WAVES * nbins; b += SEG_THREADS) s_wh[b] = 0;
+    const int64_t q0 = a->seg_off[seg] + (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE, qend = a->seg_off[seg + 1];
+    const int count = (int)(qend - q0 < SEG_TILE ? qend - q0 : SEG_TILE);
+    const int64_t qw = q0 + (int64_t)wid * (64 * ROUNDS) + lane;         // wave w owns entries [w * 512, (w + 1) * 512) of the tile
+    const uint32_t dmask = (uint32_t)nbins - 1u;
+    KeyT key[ROUNDS];
+    uint32_t pay[ROUNDS], loc[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {            // all loads issued before anything waits
+        const int64_t q = qw + r * 64;
+        const int64_t qc = q < qend ? q : qend - 1;
+        key[r] = keys_in[qc];
+        pay[r] = pay_in[qc];
+    }
+    // the tile's global bases per bin: in flight during the ranking
+    constexpr int PER = (1 << SEG_MAX_DB) / SEG_THREADS;
+    const int chunk = a->seg_chunk[seg] + (tile - a->seg_tile[seg]) / SEG_CHUNK;
+    const bool chunked = a->seg_chunk[seg + 1] - a->seg_chunk[seg] > 1;
+    uint32_t gbase[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int b = i * SEG_THREADS + tid;
+        gbase[i] = 0;
+        if (b < nbins) {
+            gbase[i] = bin_base[(size_t)seg * nb + b] + hist[(size_t)tile * nb + b];
+            if (chunked) gbase[i] += ctot[(size_t)chunk * nb + b];
+        }
+    }
+    __syncthreads();
+    uint32_t* wh = s_wh + wid * nbins;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const bool valid = qw + r * 64 < qend;
+        const uint32_t d = (uint32_t)(key[r] >> shift) & dmask;
+        unsigned long long peers = __ballot(valid);
+        for (int b = 0; b < db; ++b) {             // lanes of this round with the same digit
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t before = (uint32_t)__popcll(peers & lt);
+        uint32_t base = 0;
+        if (valid) {
+            base = wh[d];                                         // every peer reads the count before the leader bumps it
+            if (before == 0) wh[d] = base + (uint32_t)__popcll(peers);
+        }
+        loc[r] = base + before;
+    }
+    __syncthreads();
+    // per bin: exclusive prefix over the waves (in place) and the tile total; then the block scan of the totals
+    uint32_t tot[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int b = i * SEG_THREADS + tid;
+        uint32_t run = 0;
+        if (b < nbins) {
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) { const uint32_t v = s_wh[w * nbins + b]; s_wh[w * nbins + b] = run; run += v; }
+        }
+        tot[i] = run;
+    }
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        if (i * SEG_THREADS >= nbins) break;
+        uint32_t inc = tot[i];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t x = __shfl_up(inc, off, 64); if (lane >= off) inc += x; }
+        __syncthreads();
+        if (lane == 63) s_part[wid] = inc;
+        __syncthreads();
+        uint32_t base = carry;
+        for (int w = 0; w < wid; ++w) base += s_part[w];
+        const int b = i * SEG_THREADS + tid;
+        if (b < nbins) {
+            const uint32_t start = base + inc - tot[i];
+            s_bin[b] = start;
+            s_gb[b] = gbase[i] - start;
+        }
+        for (int w = 0; w < WAVES; ++w) carry += s_part[w];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (qw + r * 64 < qend) {
+            const uint32_t d = (uint32_t)(key[r] >> shift) & dmask;
+            const uint32_t lp = s_bin[d] + wh[d] + loc[r];
+            s_key[lp] = key[r];
+            s_pay[lp] = pay[r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SEG_PER_THREAD; ++j) {         // tile order = bin order: the entries of one bin leave as one run
+        const int i = j * SEG_THREADS + tid;
+        if (i < count) {
+            const KeyT k = s_key[i];
+            const uint32_t pos = s_gb[(uint32_t)(k >> shift) & dmask] + (uint32_t)i;
+            keys_out[pos] = k;
+            pay_out[pos] = s_pay[i];
+        }
+    }
+}
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 template <typename KeyT>
@@ -156,6 +530,12 @@ size_t sort_temp_bytes(int64_t n, int bits) {
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (const KeyT*)nullptr, (KeyT*)nullptr, (const uint32_t*)nullptr,
                                     (uint32_t*)nullptr, (size_t)n, 0u, (unsigned)bits, (hipStream_t) nullptr);
     return bytes;
+}
+
+// scratch of the table-segmented sort: per-tile histograms + per-segment totals and bases, at the widest digit
+inline size_t seg_scratch_bytes(size_t n) {
+    const size_t tiles = n / SEG_TILE + NRX_MAX_FEATURES + 1;          // hist rows; ctot has at most as many rows as there are tiles / 32 + segments
+    return align256((tiles + tiles / SEG_CHUNK + 2 * (size_t)NRX_MAX_FEATURES + 1) * ((size_t)1 << SEG_MAX_DB) * sizeof(uint32_t));
 }
 
 int bits_for(int64_t v) {      // bits needed to represent values 0 .. v-1 (at least 1)
@@ -170,7 +550,7 @@ extern "C" int64_t nrx_sparse_plan_workspace(int64_t n_lookups) {
     if (n_lookups < 0 || n_lookups >= 0xffffffffLL) return -1;
     const size_t n = (size_t)(n_lookups > 0 ? n_lookups : 1);
     const size_t t1 = sort_temp_bytes<uint64_t>(n, 64);
-    return (int64_t)(2 * align256(n * 8) + 2 * align256(n * 4) + 2 * align256(n * 4) + align256(t1) + 256);
+    return (int64_t)(2 * align256(n * 8) + 2 * align256(n * 4) + 2 * align256(n * 4) + align256(t1) + seg_scratch_bytes(n) + 256);
 }
 
 extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
@@ -223,6 +603,86 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
     if (g > 4096) g = 4096;
     hipError_t err = hipSuccess;
     size_t tb = 0;
+    // ---- default: table-segmented LSD sort (see the kernels' header); NRX_PLAN_SORT=rocprim forces the library sort
+    const char* sort_env = getenv("NRX_PLAN_SORT");              // read per call: tests switch it between calls
+    const bool force_rocprim = sort_env && !strcmp(sort_env, "rocprim");
+    if (!force_rocprim && n_tables <= NRX_MAX_FEATURES) {
+        SegArgs sa;
+        int digit_cap = SEG_MAX_DB;                                   // NRX_PLAN_DIGIT_BITS narrows the digits (measurement knob)
+        if (const char* e = getenv("NRX_PLAN_DIGIT_BITS")) { const int v = atoi(e); if (v >= 4 && v <= SEG_MAX_DB) digit_cap = v; }
+        const int passes = (row_bits + digit_cap - 1) / digit_cap;
+        int slot = 0, tile = 0, chunk = 0, max_db = 1;
+        bool chunked = false;
+        int64_t q = 0;
+        for (int t = 0; t < n_tables; ++t) {
+            sa.seg_off[t] = q;
+            sa.seg_tile[t] = tile;
+            sa.seg_chunk[t] = chunk;
+            int64_t seg_rows = 1;
+            for (int f = 0; f < n_feats; ++f) {
+                if (table_of[f] != t || lens[f] == 0) continue;
+                sa.ids[slot] = ids[f];
+                sa.qoff[slot] = q;
+                sa.poff[slot] = a.off[f];
+                sa.rows[slot] = rows[f];
+                sa.table[slot] = (uint8_t)t;
+                if (rows[f] > seg_rows) seg_rows = rows[f];
+                q += lens[f];
+                ++slot;
+            }
+            const int db = (bits_for(seg_rows) + passes - 1) / passes;      // the segment's row bits, split evenly over the passes
+            sa.seg_db[t] = (uint8_t)db;
+            if (db > max_db) max_db = db;
+            const int tiles = (int)((q - sa.seg_off[t] + SEG_TILE - 1) / SEG_TILE);
+            tile += tiles;
+            chunk += (tiles + SEG_CHUNK - 1) / SEG_CHUNK;
+            chunked |= tiles > SEG_CHUNK;
+        }
+        sa.seg_off[n_tables] = q;
+        sa.seg_tile[n_tables] = tile;
+        sa.seg_chunk[n_tables] = chunk;
+        sa.qoff[slot] = q;
+        sa.n_slots = slot;
+        sa.n_seg = n_tables;
+        sa.idx64 = a.idx64;
+        sa.row_bits = row_bits;
+        sa.nb = 1 << max_db;
+        const int nb = sa.nb;
+        uint32_t* hist = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(temp) + align256(sort_temp_bytes<uint64_t>(n, 64)));
+        uint32_t* ctot = hist + (size_t)tile * nb;
+        uint32_t* bin_base = ctot + (size_t)chunk * nb;
+        const size_t lds_hist = (size_t)nb * 4;
+        const dim3 gchunks((unsigned)((nb + NRX_BLOCK - 1) / NRX_BLOCK), (unsigned)chunk);
+#define NRX_SEGSORT(KeyT)                                                                                                 \
+    {                                                                                                                     \
+        const size_t lds_scatter = (size_t)nb * 4 * (SEG_THREADS / 64 + 2) + (size_t)SEG_TILE * (4 + sizeof(KeyT));         \
+        static const bool lds_ok = [] {                                                                                   \
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (4 << SEG_MAX_DB) * (SEG_THREADS / 64 + 2) + SEG_TILE * (4 + (int)sizeof(KeyT))) == hipSuccess; \
+        }();                                                                                                              \
+        (void)lds_ok;                                                                                                     \
+        KeyT* src = (KeyT*)keys_in; KeyT* dst = (KeyT*)keys_out;                                                          \
+        uint32_t* psrc = pay_in; uint32_t* pdst = pay_out;                                                                \
+        hipLaunchKernelGGL(seg_keys_kernel<KeyT>, dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, src, psrc, hist); \
+        for (int pass = 0; pass < passes; ++pass) {                                                                       \
+            if (pass > 0) hipLaunchKernelGGL(seg_hist_kernel<KeyT>, dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, (const KeyT*)src, pass, hist); \
+            if (chunked) hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot);            \
+            hipLaunchKernelGGL(seg_scan_bins, dim3((unsigned)n_tables), dim3(NRX_BLOCK), 0, st, sa, hist, ctot, bin_base); \
+            hipLaunchKernelGGL(seg_scatter_kernel<KeyT>, dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
+                               (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst); \
+            KeyT* tk = src; src = dst; dst = tk;                                                                          \
+            uint32_t* tp = psrc; psrc = pdst; pdst = tp;                                                                  \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(plan_count_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)src, n, flags);      \
+        hipLaunchKernelGGL(plan_emit_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)src,                  \
+                           (const uint32_t*)psrc, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys,         \
+                           seg_start, counts);                                                                            \
+    }
+        if (bits <= 32) NRX_SEGSORT(uint32_t) else NRX_SEGSORT(uint64_t)
+#undef NRX_SEGSORT
+        NRX_LAUNCH_CHECK("nrx_sparse_plan(segmented sort)");
+        return NRX_OK;
+    }
 #define NRX_PLAN(KeyT)                                                                                                    \
     {                                                                                                                     \
         hipLaunchKernelGGL(plan_keys_kernel<KeyT>, dim3((unsigned)g), dim3(NRX_BLOCK), 0, st, a, (KeyT*)keys_in, pay_in);  \

@@ -98,19 +98,32 @@ def test_hip_bucketize_matches_definition(n, world, seed):
     dict(n=[5000] * 26, rows=[1000] * 26, tab=list(range(26)), nt=26),
     dict(n=[4096, 8192], rows=[1 << 20, 1 << 27], tab=[3, 1], nt=5),            # 3 + 27 bits: 32-bit keys
     dict(n=[4096, 100], rows=[(1 << 31) + 5, 7], tab=[0, 9], nt=10),            # 36 bits: 64-bit keys
+    dict(n=[70000, 30000, 5000], rows=[1 << 24, 1 << 24, 300], tab=[0, 2, 0], nt=3),     # many tiles per table, 2 x 12-bit digits,
+                                                                                # a table shared by non-adjacent features
+    dict(n=[50000, 50000], rows=[1 << 20, 200000], tab=[1, 0], nt=2, zipf=1.05),          # skewed ids: long runs of one row
+    dict(n=[9000, 4097], rows=[1 << 38, 11], tab=[1, 0], nt=2),                 # 38 row bits: four digit passes, 64-bit keys
+    dict(n=[9000, 4097], rows=[1 << 21, 11], tab=[69, 0], nt=70),               # more tables than segments: library sort
 ])
 @pytest.mark.parametrize("dtype", ["int64", "int32"])
-def test_sparse_plan_bit_exact(case, dtype):
+@pytest.mark.parametrize("sort", ["segmented", "rocprim"])
+def test_sparse_plan_bit_exact(case, dtype, sort, monkeypatch):
     """nrx_sparse_plan == its definition (oracle.ref_np.sparse_plan): stable order, unique keys, segment
     starts, per-table bounds -- including out-of-range / negative ids (row 0) and tables with no lookups."""
     import torch
     from news_recsys_amd import ops
     from oracle import ref_np as R
+    if sort == "rocprim":
+        monkeypatch.setenv("NRX_PLAN_SORT", "rocprim")             # read by the library on every call
+    else:
+        monkeypatch.delenv("NRX_PLAN_SORT", raising=False)
     rng = np.random.default_rng(sum(case["n"]) + case["nt"])
     ids = []
     for n, r in zip(case["n"], case["rows"]):
         hi = min(r, (1 << 31) - 1) if dtype == "int32" else r
-        x = rng.integers(0, max(hi, 1), n).astype(dtype)
+        if case.get("zipf"):
+            x = np.minimum(rng.zipf(case["zipf"], n) - 1, max(hi, 1) - 1).astype(dtype)
+        else:
+            x = rng.integers(0, max(hi, 1), n).astype(dtype)
         if n > 10:
             x[3] = -1
             if hi == r and r < (1 << 31) - 10:
