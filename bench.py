@@ -515,7 +515,7 @@ def main():
             fwd_bwd = {"ms_per_step": fb_ms, "value": BATCH / (fb_ms * 1e-3), "unit": "impressions/s",
                        "forward_ms": f_ms, "backward_ms": fb_ms - f_ms,
                        "mode": "forward (training form: + FM field sums) + deterministic row-sparse backward: nrx_sparse_plan "
-                               "(bit-limited radix sort, unique rows, segments; enqueued on a side stream next to the forward launch -- it "
+                               "(table-segmented stable radix sort of the row bits, unique rows, segments; enqueued on a side stream next to the forward launch -- it "
                                "depends only on the ids) + nrx_embed_bwd_sorted with the FM gradient folded in; "
                                "upstream gradients g_out [B, width]" + (" and g_fm [B]" if path.fm else "") + " given; result = unique "
                                "(table,row) keys + summed row gradients on the device (what optim.FusedSparseAdam consumes)"}

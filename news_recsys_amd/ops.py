@@ -463,7 +463,7 @@ def _sparse_groups(plan: EmbedPlan):
 
 def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
     """Row-sparse, deterministic table grads.  Per group of tables sharing an embedding dim: ONE planning
-    call (nrx_sparse_plan: compact (table, row) keys, rocPRIM radix sort on just the significant bits, head
+    call (nrx_sparse_plan: compact (table, row) keys, table-segmented stable radix sort of the row bits, head
     flags + scan -> unique rows, segment starts, per-table split, all on the device), one host read of
     n_tables + 2 integers, ONE segmented-reduction launch (nrx_embed_bwd_sorted) summing the upstream rows
     of every unique (table, row) in sorted order.  No dense zero-fill, no atomics, bit-reproducible;
