@@ -11,9 +11,18 @@ dev = torch.device("cuda:0")
 B = 65536
 only = set(sys.argv[1:])
 
-def timeit(fn, steps=30, warm=3):
+def timeit(fn, steps=30, warm=3, settle_ms=60.0):
+    """Mean launch time AFTER the clocks have settled: the op is repeated for >= settle_ms first.  Coming out of idle the
+    chip ramps its core clock over tens of milliseconds; a 3 + 30-launch burst of a matrix-core kernel measures that ramp
+    (DCN-v2 forward D=320: 145-155 us in the first 5 ms, 122 us settled -- profiles/r02_dcn_v2_phase_probe.txt); kernels
+    bound by HBM read the same either way."""
+    import time as _t
     for _ in range(warm): fn()
     torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    while (_t.perf_counter() - t0) * 1e3 < settle_ms:
+        for _ in range(4): fn()
+        torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(steps): fn()
