@@ -54,7 +54,16 @@ __global__ __launch_bounds__(256, PROBE_OCC) void dcn_v2_layer_kernel(const floa
     const int64_t m0 = (int64_t)(logical / nx) * BM;
     const int n0 = (int)(logical % nx) * BN;
 
-    if (PRIO) {
+    if (PRIO >= 10) {
+        // stagger: a first-round block sleeps (its wave slot) x (PRIO - 10) x ~1.1 us before it starts (s_sleep 40 = 2560 cycles)
+        if (blockIdx.x < 1280u) {
+            __shared__ unsigned s_slot2;
+            if (tid == 0) s_slot2 = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u;
+            __syncthreads();
+            const unsigned n = __builtin_amdgcn_readfirstlane(s_slot2) * (unsigned)(PRIO - 10);
+            for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(40);
+        }
+    } else if (PRIO) {
         // distinct issue priority per co-resident block: PRIO 1 = this wave's slot on its SIMD, PRIO 2 = wave 0's slot for the whole block
         unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u;     // HW_REG_HW_ID.wave_id
         if (PRIO == 2) {
@@ -287,6 +296,9 @@ int main(int argc, char** argv) {
         hipDeviceSynchronize();
         run<true, 0>("product form (x0 != x_l, inference)", x0, x, W, b, out, B, D, iters);
         run<true, 0>("product form, x0 == x_l", x, x, W, b, out, B, D, iters);
+        run<true, 0, 12>("product, first-round blocks staggered 2.2 us per wave slot", x0, x, W, b, out, B, D, iters);
+        run<true, 0, 15>("product, first-round blocks staggered 5.5 us per wave slot", x0, x, W, b, out, B, D, iters);
+        run<true, 0, 20>("product, first-round blocks staggered 11 us per wave slot", x0, x, W, b, out, B, D, iters);
         run<true, 0, 1>("product + per-slot issue priority (wave's own slot)", x0, x, W, b, out, B, D, iters);
         run<true, 0, 2>("product + per-slot issue priority (block-uniform)", x0, x, W, b, out, B, D, iters);
         run<false, 1, 2>("LDS + MFMA loop only + priority (block-uniform)", x0, x, W, b, out, B, D, iters);
