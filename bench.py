@@ -476,8 +476,16 @@ def main():
     distinct = fwd_bwd = wide_split = None
     if world == 1 and not args.force_sharded and not args.headline_only:
         def time_calls(fn, n):
-            for i in range(min(10, args.warmup)):
+            # warm-up by TIME (>= 50 ms of the same launches): the legs that contain latency-bound launches (the backward's
+            # planning) depend on the core clock, which takes tens of milliseconds to come up after an idle gap
+            # (profiles/r02_dcn_v2_phase_probe.txt section 0); the HBM-bound headline reads the same either way
+            t_w = time.perf_counter()
+            i = 0
+            while i < min(10, args.warmup) or (time.perf_counter() - t_w < 0.05 and args.warmup > 0):
                 fn(i)
+                i += 1
+                if i % 8 == 0:
+                    torch.cuda.synchronize()
             torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
