@@ -138,3 +138,41 @@ def test_sparse_plan_bit_exact(case, dtype, sort, monkeypatch):
     assert np.array_equal(order.cpu().numpy(), o_r)
     assert np.array_equal(uniq.cpu().numpy()[:nu], u_r)
     assert np.array_equal(seg.cpu().numpy()[:nu + 1], s_r)
+
+
+@pytest.mark.gpu
+@settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(lens=st.lists(st.integers(min_value=0, max_value=9000), min_size=1, max_size=7),
+       row_bits=st.lists(st.integers(min_value=1, max_value=26), min_size=7, max_size=7),
+       tabs=st.lists(st.integers(min_value=0, max_value=4), min_size=7, max_size=7),
+       skew=st.booleans(), seed=st.integers(0, 2 ** 16))
+def test_sparse_plan_segmented_sort_matches_definition(lens, row_bits, tabs, skew, seed):
+    """The table-segmented planner sort on hypothesis-generated shapes: any mix of segment lengths (empty segments, tiles that
+    hold several features, tables shared by non-adjacent features), digit plans from 1 to 26 row bits, uniform and heavily
+    repeated ids -- same plan as the definition, bit for bit."""
+    import torch
+    from news_recsys_amd import ops
+    rng = np.random.default_rng(seed)
+    n = len(lens)
+    tab = tabs[:n]
+    nt = max(tab) + 1
+    rows_of_table = [1 << row_bits[t] for t in range(nt)]
+    rows = [rows_of_table[t] - (seed % 3 if rows_of_table[t] > 4 else 0) for t in tab]       # not only powers of two
+    rows = [max(rows[i], 1) for i in range(n)]
+    for t in range(nt):                                     # features of one table agree on its row count
+        r = min(rows[i] for i in range(n) if tab[i] == t) if any(tab[i] == t for i in range(n)) else 1
+        rows = [r if tab[i] == t else rows[i] for i in range(n)]
+    ids = []
+    for ln, r in zip(lens, rows):
+        x = rng.integers(0, r, ln)
+        if skew and ln:
+            x = np.where(rng.random(ln) < 0.6, x[0], x)     # 60 % of the lookups hit one row
+        ids.append(x.astype(np.int64))
+    order, uniq, seg, counts = ops.sparse_plan([torch.from_numpy(x).to("cuda:0") for x in ids], tab, rows, nt)
+    o_r, u_r, s_r, c_r = R.sparse_plan(ids, tab, rows, nt)
+    c = counts.cpu().numpy()
+    assert np.array_equal(c, c_r)
+    nu = int(c[0])
+    assert np.array_equal(order.cpu().numpy(), o_r)
+    assert np.array_equal(uniq.cpu().numpy()[:nu], u_r)
+    assert np.array_equal(seg.cpu().numpy()[:nu + 1], s_r)
