@@ -399,7 +399,10 @@ __global__ __launch_bounds__(NRX_BLOCK) void seg_scan_bins(const SegArgs args_in
     }
 }
 
-template <typename KeyT>
+// DIRECT (every segment has at most SEG_CHUNK tiles): no scan launches at all -- the block sums the histogram rows of its
+// own segment itself (<= 32 L2-resident rows: the earlier tiles' counts and the segment totals per bin) and scans the totals
+// together with its local ones; hist is read-only in this mode.
+template <typename KeyT, bool DIRECT>
 __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs args_in_kernarg, const KeyT* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ pay_in, int pass,
                                                                 const uint32_t* __restrict__ hist, const uint32_t* __restrict__ ctot,
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
     uint32_t* s_gb = s_bin + nbins;                       // [nbins]: global position of the bin's first entry of this tile - s_bin
     uint32_t* s_pay = s_gb + nbins;                       // [SEG_TILE]
     KeyT* s_key = reinterpret_cast<KeyT*>(s_pay + SEG_TILE);      // [SEG_TILE]
-    __shared__ uint32_t s_part[WAVES];
+    __shared__ uint32_t s_part[WAVES], s_gpart[WAVES];
     for (int b = tid; b < WAVES * nbins; b += SEG_THREADS) s_wh[b] = 0;
     const int64_t q0 = a->seg_off[seg] + (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE, qend = a->seg_off[seg + 1];
     const int count = (int)(qend - q0 < SEG_TILE ? qend - q0 : SEG_TILE);
@@ -435,14 +438,36 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
     constexpr int PER = (1 << SEG_MAX_DB) / SEG_THREADS;
     const int chunk = a->seg_chunk[seg] + (tile - a->seg_tile[seg]) / SEG_CHUNK;
     const bool chunked = a->seg_chunk[seg + 1] - a->seg_chunk[seg] > 1;
-    uint32_t gbase[PER];
+    uint32_t gbase[PER], gtot[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int b = i * SEG_THREADS + tid;
         gbase[i] = 0;
+        gtot[i] = 0;
         if (b < nbins) {
-            gbase[i] = bin_base[(size_t)seg * nb + b] + hist[(size_t)tile * nb + b];
-            if (chunked) gbase[i] += ctot[(size_t)chunk * nb + b];
+            if (DIRECT) {
+                const int t0 = a->seg_tile[seg], t1 = a->seg_tile[seg + 1];
+                const uint32_t* h = hist + (size_t)t0 * nb + b;
+                uint32_t before = 0, all = 0;
+                int t = t0;
+                for (; t + 8 <= t1; t += 8, h += (size_t)8 * nb) {         // eight independent loads in flight
+                    uint32_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = h[(size_t)u * nb];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { all += v[u]; before += t + u < tile ? v[u] : 0u; }
+                }
+                for (; t < t1; ++t, h += nb) {
+                    const uint32_t v = h[0];
+                    all += v;
+                    before += t < tile ? v : 0u;
+                }
+                gbase[i] = before;
+                gtot[i] = all;
+            } else {
+                gbase[i] = bin_base[(size_t)seg * nb + b] + hist[(size_t)tile * nb + b];
+                if (chunked) gbase[i] += ctot[(size_t)chunk * nb + b];
+            }
         }
     }
     __syncthreads();
@@ -479,25 +504,29 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
         }
         tot[i] = run;
     }
-    uint32_t carry = 0;
+    uint32_t carry = 0, gcarry = DIRECT ? (uint32_t)a->seg_off[seg] : 0u;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         if (i * SEG_THREADS >= nbins) break;
-        uint32_t inc = tot[i];
+        uint32_t inc = tot[i], ginc = gtot[i];            // the tile's counts and (DIRECT) the segment's totals, scanned together
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t x = __shfl_up(inc, off, 64); if (lane >= off) inc += x; }
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t x = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += x;
+            if (DIRECT) { const uint32_t y = __shfl_up(ginc, off, 64); if (lane >= off) ginc += y; }
+        }
         __syncthreads();
-        if (lane == 63) s_part[wid] = inc;
+        if (lane == 63) { s_part[wid] = inc; if (DIRECT) s_gpart[wid] = ginc; }
         __syncthreads();
-        uint32_t base = carry;
-        for (int w = 0; w < wid; ++w) base += s_part[w];
+        uint32_t base = carry, gb = gcarry;
+        for (int w = 0; w < wid; ++w) { base += s_part[w]; if (DIRECT) gb += s_gpart[w]; }
         const int b = i * SEG_THREADS + tid;
         if (b < nbins) {
             const uint32_t start = base + inc - tot[i];
             s_bin[b] = start;
-            s_gb[b] = gbase[i] - start;
+            s_gb[b] = (DIRECT ? gb + ginc - gtot[i] + gbase[i] : gbase[i]) - start;
         }
-        for (int w = 0; w < WAVES; ++w) carry += s_part[w];
+        for (int w = 0; w < WAVES; ++w) { carry += s_part[w]; if (DIRECT) gcarry += s_gpart[w]; }
     }
     __syncthreads();
 #pragma unroll
@@ -657,8 +686,9 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
     {                                                                                                                     \
         const size_t lds_scatter = (size_t)nb * 4 * (SEG_THREADS / 64 + 2) + (size_t)SEG_TILE * (4 + sizeof(KeyT));         \
         static const bool lds_ok = [] {                                                                                   \
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (4 << SEG_MAX_DB) * (SEG_THREADS / 64 + 2) + SEG_TILE * (4 + (int)sizeof(KeyT))) == hipSuccess; \
+            const int bytes = (4 << SEG_MAX_DB) * (SEG_THREADS / 64 + 2) + SEG_TILE * (4 + (int)sizeof(KeyT));            \
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess && \
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; \
         }();                                                                                                              \
         (void)lds_ok;                                                                                                     \
         KeyT* src = (KeyT*)keys_in; KeyT* dst = (KeyT*)keys_out;                                                          \
@@ -666,10 +696,15 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
         hipLaunchKernelGGL(seg_keys_kernel<KeyT>, dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, src, psrc, hist); \
         for (int pass = 0; pass < passes; ++pass) {                                                                       \
             if (pass > 0) hipLaunchKernelGGL(seg_hist_kernel<KeyT>, dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, (const KeyT*)src, pass, hist); \
-            if (chunked) hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot);            \
-            hipLaunchKernelGGL(seg_scan_bins, dim3((unsigned)n_tables), dim3(NRX_BLOCK), 0, st, sa, hist, ctot, bin_base); \
-            hipLaunchKernelGGL(seg_scatter_kernel<KeyT>, dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
-                               (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst); \
+            if (chunked) {                                                                                               \
+                hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot);                      \
+                hipLaunchKernelGGL(seg_scan_bins, dim3((unsigned)n_tables), dim3(NRX_BLOCK), 0, st, sa, hist, ctot, bin_base); \
+                hipLaunchKernelGGL((seg_scatter_kernel<KeyT, false>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
+                                   (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst); \
+            } else {                                                                                                      \
+                hipLaunchKernelGGL((seg_scatter_kernel<KeyT, true>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
+                                   (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst); \
+            }                                                                                                             \
             KeyT* tk = src; src = dst; dst = tk;                                                                          \
             uint32_t* tp = psrc; psrc = pdst; pdst = tp;                                                                  \
         }                                                                                                                 \
