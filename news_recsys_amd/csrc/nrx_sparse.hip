@@ -56,12 +56,19 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_keys_kernel(const PlanArgs arg
 //                       between, so tables without lookups get empty ranges); the last entry closes counts / seg_start.
 constexpr int PLAN_TILE = 1024;        // entries per block = 4 per thread
 
-template <typename KeyT>
-__device__ __forceinline__ bool plan_is_head(const KeyT* __restrict__ skeys, int64_t e) {
-    return e == 0 || skeys[e] != skeys[e - 1];
+// PAIR (32-bit keys from the segmented sort): the sorted list is ONE array of {key, payload} pairs
+template <typename KeyT, bool PAIR>
+__device__ __forceinline__ KeyT plan_key_at(const KeyT* __restrict__ skeys, int64_t e) {
+    if (PAIR) return (KeyT)reinterpret_cast<const uint2*>(skeys)[e].x;
+    return skeys[e];
 }
 
-template <typename KeyT>
+template <typename KeyT, bool PAIR = false>
+__device__ __forceinline__ bool plan_is_head(const KeyT* __restrict__ skeys, int64_t e) {
+    return e == 0 || plan_key_at<KeyT, PAIR>(skeys, e) != plan_key_at<KeyT, PAIR>(skeys, e - 1);
+}
+
+template <typename KeyT, bool PAIR = false>
 __global__ __launch_bounds__(NRX_BLOCK) void plan_count_kernel(const KeyT* __restrict__ skeys, int64_t n, uint32_t* __restrict__ block_heads) {
     __shared__ uint32_t s_cnt[NRX_BLOCK / 64];
     const int64_t e0 = (int64_t)blockIdx.x * PLAN_TILE + threadIdx.x;
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_count_kernel(const KeyT* __res
 #pragma unroll
     for (int j = 0; j < PLAN_TILE / NRX_BLOCK; ++j) {
         const int64_t e = e0 + j * NRX_BLOCK;
-        c += (uint32_t)__popcll(__ballot(e < n && plan_is_head(skeys, e)));      // wave-uniform count
+        c += (uint32_t)__popcll(__ballot(e < n && plan_is_head<KeyT, PAIR>(skeys, e)));      // wave-uniform count
     }
     if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_count_kernel(const KeyT* __res
 
 // entry e of the tile is handled by thread (e % 256) in round (e / 256): coalesced key / payload / order accesses; the
 // rank of a head = heads of earlier blocks + heads of earlier (round, wave) cells + heads of lower lanes in its cell
-template <typename KeyT>
+template <typename KeyT, bool PAIR = false>
 __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const KeyT* __restrict__ skeys, const uint32_t* __restrict__ spayload,
                                                               const uint32_t* __restrict__ block_heads, int64_t n, int row_bits,
                                                               int32_t n_tables, int64_t* __restrict__ order,
@@ -95,9 +102,15 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const KeyT* __rest
     for (int j = 0; j < ROUNDS; ++j) {            // all of the tile's loads are issued before anything waits
         const int64_t e = e0 + j * NRX_BLOCK;
         const int64_t ec = e < n ? e : n - 1;
-        key[j] = skeys[ec];
-        prev[j] = skeys[ec > 0 ? ec - 1 : 0];
-        pay[j] = spayload[ec];
+        if (PAIR) {
+            const uint2 kp = reinterpret_cast<const uint2*>(skeys)[ec];
+            key[j] = (KeyT)kp.x;
+            pay[j] = kp.y;
+        } else {
+            key[j] = skeys[ec];
+            pay[j] = spayload[ec];
+        }
+        prev[j] = plan_key_at<KeyT, PAIR>(skeys, ec > 0 ? ec - 1 : 0);
     }
     uint32_t acc = 0;
     for (uint32_t i = tid; i < blockIdx.x; i += NRX_BLOCK) acc += block_heads[i];
@@ -206,7 +219,9 @@ __device__ __forceinline__ int seg_of_tile(const NRX_CONST SegArgs* a, int tile)
 }
 
 // keys + payload in table-major order, and the histogram of digit 0
-template <typename KeyT>
+// PAIR (32-bit keys): {key, payload} travel as one 8-byte element through every pass and into plan_count / plan_emit -- the scatter's
+// runs are short (4 entries per bin and tile at 10-bit digits), so one 32-byte piece per run instead of two 16-byte ones.
+template <typename KeyT, bool PAIR>
 __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs args_in_kernarg, KeyT* __restrict__ keys, uint32_t* __restrict__ payload,
                                                                uint32_t* __restrict__ hist) {
     extern __shared__ uint32_t s_hist[];
@@ -271,8 +286,11 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
             if (q < qend) {
                 int64_t v = id[j];
                 if (v < 0 || v >= rows) v = 0;            // out-of-range ids were reported by the forward; the padding row never trains
-                keys[q] = tkey | (KeyT)v;
-                payload[q] = (uint32_t)(pbase + j * SEG_THREADS + threadIdx.x);
+                if (PAIR) reinterpret_cast<uint2*>(keys)[q] = make_uint2((uint32_t)(tkey | (KeyT)v), (uint32_t)(pbase + j * SEG_THREADS + threadIdx.x));
+                else {
+                    keys[q] = tkey | (KeyT)v;
+                    payload[q] = (uint32_t)(pbase + j * SEG_THREADS + threadIdx.x);
+                }
                 atomicAdd(&s_hist[(uint32_t)v & dmask], 1u);
             }
         }
@@ -284,8 +302,11 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
             const int s = sl[j];
             int64_t v = id[j];
             if (v < 0 || v >= a->rows[s]) v = 0;
-            keys[q] = ((KeyT)a->table[s] << a->row_bits) | (KeyT)v;
-            payload[q] = (uint32_t)(a->poff[s] + (q - a->qoff[s]));
+            if (PAIR) reinterpret_cast<uint2*>(keys)[q] = make_uint2((uint32_t)(((KeyT)a->table[s] << a->row_bits) | (KeyT)v), (uint32_t)(a->poff[s] + (q - a->qoff[s])));
+            else {
+                keys[q] = ((KeyT)a->table[s] << a->row_bits) | (KeyT)v;
+                payload[q] = (uint32_t)(a->poff[s] + (q - a->qoff[s]));
+            }
             atomicAdd(&s_hist[(uint32_t)v & dmask], 1u);
         }
     }
@@ -295,7 +316,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
     for (int b = threadIdx.x; b < nbins; b += SEG_THREADS) h[b] = s_hist[b];
 }
 
-template <typename KeyT>
+template <typename KeyT, bool PAIR>
 __global__ __launch_bounds__(SEG_THREADS) void seg_hist_kernel(const SegArgs args_in_kernarg, const KeyT* __restrict__ keys, int pass,
                                                              uint32_t* __restrict__ hist) {
     extern __shared__ uint32_t s_hist[];
@@ -309,7 +330,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_hist_kernel(const SegArgs arg
 #pragma unroll
     for (int j = 0; j < SEG_PER_THREAD; ++j) {
         const int64_t q = q0 + j * SEG_THREADS + threadIdx.x;
-        k[j] = keys[q < qend ? q : qend - 1];
+        k[j] = plan_key_at<KeyT, PAIR>(keys, q < qend ? q : qend - 1);
     }
     __syncthreads();
 #pragma unroll
@@ -402,7 +423,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void seg_scan_bins(const SegArgs args_in
 // DIRECT (every segment has at most SEG_CHUNK tiles): no scan launches at all -- the block sums the histogram rows of its
 // own segment itself (<= 32 L2-resident rows: the earlier tiles' counts and the segment totals per bin) and scans the totals
 // together with its local ones; hist is read-only in this mode.
-template <typename KeyT, bool DIRECT>
+template <typename KeyT, bool DIRECT, bool PAIR>
 __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs args_in_kernarg, const KeyT* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ pay_in, int pass,
                                                                 const uint32_t* __restrict__ hist, const uint32_t* __restrict__ ctot,
@@ -431,8 +452,14 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
     for (int r = 0; r < ROUNDS; ++r) {            // all loads issued before anything waits
         const int64_t q = qw + r * 64;
         const int64_t qc = q < qend ? q : qend - 1;
-        key[r] = keys_in[qc];
-        pay[r] = pay_in[qc];
+        if (PAIR) {
+            const uint2 kp = reinterpret_cast<const uint2*>(keys_in)[qc];
+            key[r] = (KeyT)kp.x;
+            pay[r] = kp.y;
+        } else {
+            key[r] = keys_in[qc];
+            pay[r] = pay_in[qc];
+        }
     }
     // the tile's global bases per bin: in flight during the ranking
     constexpr int PER = (1 << SEG_MAX_DB) / SEG_THREADS;
@@ -534,8 +561,11 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
         if (qw + r * 64 < qend) {
             const uint32_t d = (uint32_t)(key[r] >> shift) & dmask;
             const uint32_t lp = s_bin[d] + wh[d] + loc[r];
-            s_key[lp] = key[r];
-            s_pay[lp] = pay[r];
+            if (PAIR) reinterpret_cast<uint2*>(s_pay)[lp] = make_uint2((uint32_t)key[r], pay[r]);      // s_pay .. s_key are one 8-byte-per-entry area
+            else {
+                s_key[lp] = key[r];
+                s_pay[lp] = pay[r];
+            }
         }
     }
     __syncthreads();
@@ -543,10 +573,16 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
     for (int j = 0; j < SEG_PER_THREAD; ++j) {         // tile order = bin order: the entries of one bin leave as one run
         const int i = j * SEG_THREADS + tid;
         if (i < count) {
-            const KeyT k = s_key[i];
-            const uint32_t pos = s_gb[(uint32_t)(k >> shift) & dmask] + (uint32_t)i;
-            keys_out[pos] = k;
-            pay_out[pos] = s_pay[i];
+            if (PAIR) {
+                const uint2 kp = reinterpret_cast<const uint2*>(s_pay)[i];
+                const uint32_t pos = s_gb[(kp.x >> shift) & dmask] + (uint32_t)i;
+                reinterpret_cast<uint2*>(keys_out)[pos] = kp;
+            } else {
+                const KeyT k = s_key[i];
+                const uint32_t pos = s_gb[(uint32_t)(k >> shift) & dmask] + (uint32_t)i;
+                keys_out[pos] = k;
+                pay_out[pos] = s_pay[i];
+            }
         }
     }
 }
@@ -684,32 +720,33 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
         const dim3 gchunks((unsigned)((nb + NRX_BLOCK - 1) / NRX_BLOCK), (unsigned)chunk);
 #define NRX_SEGSORT(KeyT)                                                                                                 \
     {                                                                                                                     \
+        constexpr bool PAIR_ = sizeof(KeyT) == 4;                                                                         \
         const size_t lds_scatter = (size_t)nb * 4 * (SEG_THREADS / 64 + 2) + (size_t)SEG_TILE * (4 + sizeof(KeyT));         \
         static const bool lds_ok = [] {                                                                                   \
             const int bytes = (4 << SEG_MAX_DB) * (SEG_THREADS / 64 + 2) + SEG_TILE * (4 + (int)sizeof(KeyT));            \
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess && \
-                   hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; \
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, false, PAIR_>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess && \
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, true, PAIR_>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; \
         }();                                                                                                              \
         (void)lds_ok;                                                                                                     \
         KeyT* src = (KeyT*)keys_in; KeyT* dst = (KeyT*)keys_out;                                                          \
         uint32_t* psrc = pay_in; uint32_t* pdst = pay_out;                                                                \
-        hipLaunchKernelGGL(seg_keys_kernel<KeyT>, dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, src, psrc, hist); \
+        hipLaunchKernelGGL((seg_keys_kernel<KeyT, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, src, psrc, hist); \
         for (int pass = 0; pass < passes; ++pass) {                                                                       \
-            if (pass > 0) hipLaunchKernelGGL(seg_hist_kernel<KeyT>, dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, (const KeyT*)src, pass, hist); \
+            if (pass > 0) hipLaunchKernelGGL((seg_hist_kernel<KeyT, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, (const KeyT*)src, pass, hist); \
             if (chunked) {                                                                                               \
                 hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot);                      \
                 hipLaunchKernelGGL(seg_scan_bins, dim3((unsigned)n_tables), dim3(NRX_BLOCK), 0, st, sa, hist, ctot, bin_base); \
-                hipLaunchKernelGGL((seg_scatter_kernel<KeyT, false>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
+                hipLaunchKernelGGL((seg_scatter_kernel<KeyT, false, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
                                    (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst); \
             } else {                                                                                                      \
-                hipLaunchKernelGGL((seg_scatter_kernel<KeyT, true>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
+                hipLaunchKernelGGL((seg_scatter_kernel<KeyT, true, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
                                    (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst); \
             }                                                                                                             \
             KeyT* tk = src; src = dst; dst = tk;                                                                          \
             uint32_t* tp = psrc; psrc = pdst; pdst = tp;                                                                  \
         }                                                                                                                 \
-        hipLaunchKernelGGL(plan_count_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)src, n, flags);      \
-        hipLaunchKernelGGL(plan_emit_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)src,                  \
+        hipLaunchKernelGGL((plan_count_kernel<KeyT, PAIR_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)src, n, flags);      \
+        hipLaunchKernelGGL((plan_emit_kernel<KeyT, PAIR_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)src,                  \
                            (const uint32_t*)psrc, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys,         \
                            seg_start, counts);                                                                            \
     }
