@@ -192,6 +192,7 @@ constexpr int SEG_THREADS = 512;                    // threads of the tile kerne
 constexpr int SEG_PER_THREAD = SEG_TILE / SEG_THREADS;
 constexpr int SEG_MAX_DB = 10;                      // widest digit
 constexpr int SEG_CHUNK = 32;                       // tiles per scan chunk
+constexpr int SEG_DIRECT_CHUNKS = 128;              // longest segment (in chunks) whose chunk totals every scatter block sums itself
 
 struct SegArgs {
     const void* ids[NRX_MAX_FEATURES];
@@ -369,8 +370,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void seg_scan_chunks(const SegArgs args_
     ctot[(size_t)chunk * nb + bin] = run;
 }
 
-// One block per segment.  Per bin: running sum over the segment's tiles (a one-chunk segment: hist in place) or over its
-// chunks (ctot in place); then the exclusive scan over the bins + the segment's first entry -> bin_base[seg][bin].
+// One block per segment (launched after seg_scan_chunks, for segments too long for the scatter blocks to sum their chunk totals
+// themselves).  Per bin: running sum over the segment's chunks (ctot in place); then the exclusive scan over the bins + the
+// segment's first entry -> bin_base[seg][bin].
 __global__ __launch_bounds__(NRX_BLOCK) void seg_scan_bins(const SegArgs args_in_kernarg, uint32_t* __restrict__ hist, uint32_t* __restrict__ ctot,
                                                             uint32_t* __restrict__ bin_base) {
     __shared__ uint32_t s_part[NRX_BLOCK / 64];
@@ -384,9 +386,11 @@ __global__ __launch_bounds__(NRX_BLOCK) void seg_scan_bins(const SegArgs args_in
         const int bin = i * NRX_BLOCK + threadIdx.x;
         uint32_t run = 0;
         if (bin < nbins) {
-            const bool direct = nchunks <= 1;
-            uint32_t* h = direct ? hist + (size_t)a->seg_tile[seg] * nb + bin : ctot + (size_t)a->seg_chunk[seg] * nb + bin;
-            const int cnt = direct ? a->seg_tile[seg + 1] - a->seg_tile[seg] : nchunks;
+            // always over the chunk totals: seg_scan_chunks has already turned EVERY segment's histogram rows into in-chunk
+            // prefixes, one-chunk segments included (summing those rows again here corrupted the short segments of a launch
+            // that also held a long one -- caught by the 83-tile parity case)
+            uint32_t* h = ctot + (size_t)a->seg_chunk[seg] * nb + bin;
+            const int cnt = nchunks;
             int t = 0;
             for (; t + 8 <= cnt; t += 8, h += (size_t)8 * nb) {      // eight independent loads in flight
                 uint32_t x[8];
@@ -420,10 +424,11 @@ __global__ __launch_bounds__(NRX_BLOCK) void seg_scan_bins(const SegArgs args_in
     }
 }
 
-// DIRECT (every segment has at most SEG_CHUNK tiles): no scan launches at all -- the block sums the histogram rows of its
+// DIRECT 1 (every segment has at most SEG_CHUNK tiles): no scan launches at all -- the block sums the histogram rows of its
 // own segment itself (<= 32 L2-resident rows: the earlier tiles' counts and the segment totals per bin) and scans the totals
-// together with its local ones; hist is read-only in this mode.
-template <typename KeyT, bool DIRECT, bool PAIR>
+// together with its local ones; hist is read-only in this mode.  DIRECT 2 (longer segments, at most SEG_DIRECT_CHUNKS chunks
+// each): seg_scan_chunks runs, the block sums the segment's chunk totals the same way -- seg_scan_bins is not launched.
+template <typename KeyT, int DIRECT, bool PAIR>
 __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs args_in_kernarg, const KeyT* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ pay_in, int pass,
                                                                 const uint32_t* __restrict__ hist, const uint32_t* __restrict__ ctot,
@@ -473,9 +478,12 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
         gtot[i] = 0;
         if (b < nbins) {
             if (DIRECT) {
-                const int t0 = a->seg_tile[seg], t1 = a->seg_tile[seg + 1];
-                const uint32_t* h = hist + (size_t)t0 * nb + b;
-                uint32_t before = 0, all = 0;
+                // DIRECT 1: the rows are the segment's tile histograms; DIRECT 2 (seg_scan_chunks has run): the rows are its chunk
+                // totals, and the tile's own histogram row already holds the counts of the earlier tiles of its chunk
+                const int t0 = DIRECT == 1 ? a->seg_tile[seg] : a->seg_chunk[seg], t1 = DIRECT == 1 ? a->seg_tile[seg + 1] : a->seg_chunk[seg + 1];
+                const int tile = DIRECT == 1 ? (int)blockIdx.x : chunk;
+                const uint32_t* h = (DIRECT == 1 ? hist : ctot) + (size_t)t0 * nb + b;
+                uint32_t before = DIRECT == 1 ? 0u : hist[(size_t)blockIdx.x * nb + b], all = 0;
                 int t = t0;
                 for (; t + 8 <= t1; t += 8, h += (size_t)8 * nb) {         // eight independent loads in flight
                     uint32_t v[8];
@@ -673,11 +681,13 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
     const bool force_rocprim = sort_env && !strcmp(sort_env, "rocprim");
     if (!force_rocprim && n_tables <= NRX_MAX_FEATURES) {
         SegArgs sa;
+        const bool force_bins = sort_env && !strcmp(sort_env, "segmented-bins");      // tests: the seg_scan_bins path of very long segments
         int digit_cap = SEG_MAX_DB;                                   // NRX_PLAN_DIGIT_BITS narrows the digits (measurement knob)
         if (const char* e = getenv("NRX_PLAN_DIGIT_BITS")) { const int v = atoi(e); if (v >= 4 && v <= SEG_MAX_DB) digit_cap = v; }
         const int passes = (row_bits + digit_cap - 1) / digit_cap;
         int slot = 0, tile = 0, chunk = 0, max_db = 1;
         bool chunked = false;
+        int max_chunks = 0;
         int64_t q = 0;
         for (int t = 0; t < n_tables; ++t) {
             sa.seg_off[t] = q;
@@ -702,6 +712,7 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
             tile += tiles;
             chunk += (tiles + SEG_CHUNK - 1) / SEG_CHUNK;
             chunked |= tiles > SEG_CHUNK;
+            if ((tiles + SEG_CHUNK - 1) / SEG_CHUNK > max_chunks) max_chunks = (tiles + SEG_CHUNK - 1) / SEG_CHUNK;
         }
         sa.seg_off[n_tables] = q;
         sa.seg_tile[n_tables] = tile;
@@ -724,8 +735,9 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
         const size_t lds_scatter = (size_t)nb * 4 * (SEG_THREADS / 64 + 2) + (size_t)SEG_TILE * (4 + sizeof(KeyT));         \
         static const bool lds_ok = [] {                                                                                   \
             const int bytes = (4 << SEG_MAX_DB) * (SEG_THREADS / 64 + 2) + SEG_TILE * (4 + (int)sizeof(KeyT));            \
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, false, PAIR_>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess && \
-                   hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, true, PAIR_>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; \
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, 0, PAIR_>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess && \
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, 1, PAIR_>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess && \
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, 2, PAIR_>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; \
         }();                                                                                                              \
         (void)lds_ok;                                                                                                     \
         KeyT* src = (KeyT*)keys_in; KeyT* dst = (KeyT*)keys_out;                                                          \
@@ -733,13 +745,17 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
         hipLaunchKernelGGL((seg_keys_kernel<KeyT, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, src, psrc, hist); \
         for (int pass = 0; pass < passes; ++pass) {                                                                       \
             if (pass > 0) hipLaunchKernelGGL((seg_hist_kernel<KeyT, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, (const KeyT*)src, pass, hist); \
-            if (chunked) {                                                                                               \
+            if (chunked && (max_chunks > SEG_DIRECT_CHUNKS || force_bins)) {                                              \
                 hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot);                      \
                 hipLaunchKernelGGL(seg_scan_bins, dim3((unsigned)n_tables), dim3(NRX_BLOCK), 0, st, sa, hist, ctot, bin_base); \
-                hipLaunchKernelGGL((seg_scatter_kernel<KeyT, false, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
+                hipLaunchKernelGGL((seg_scatter_kernel<KeyT, 0, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
+                                   (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst); \
+            } else if (chunked) {                                                                                         \
+                hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot);                      \
+                hipLaunchKernelGGL((seg_scatter_kernel<KeyT, 2, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
                                    (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst); \
             } else {                                                                                                      \
-                hipLaunchKernelGGL((seg_scatter_kernel<KeyT, true, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
+                hipLaunchKernelGGL((seg_scatter_kernel<KeyT, 1, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
                                    (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst); \
             }                                                                                                             \
             KeyT* tk = src; src = dst; dst = tk;                                                                          \

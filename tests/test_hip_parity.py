@@ -369,6 +369,8 @@ GENERIC_CASES = {
     "lr_dim1": [(NRX_SPARSE, 40, 1, 0)] * 5,
     "bags": [(NRX_SPARSE, 100, 16, 0), (NRX_BAG_MASKED_MEAN, 200, 16, 50), (NRX_BAG_MEAN, 30, 16, 7)],
     "bag_long_odd": [(NRX_BAG_MASKED_MEAN, 64, 12, 333), (NRX_DENSE, 0, 1, 0), (NRX_SPARSE, 11, 8, 0)],
+    # DSSM-tower shape: at B = 4096 the history table gets 204 800 lookups (50 planner tiles: chunked scans) next to one-tile tables
+    "tower_large": [(NRX_SPARSE, 50000, 16, 0), (NRX_BAG_MASKED_MEAN, 20000, 16, 50), (NRX_SPARSE, 3000, 16, 0)],
     "wide_row": [(NRX_SPARSE, 20, 300, 0), (NRX_BAG_MASKED_MEAN, 20, 260, 9)],
     "dense_only_plus_one": [(NRX_DENSE, 0, 1, 0), (NRX_DENSE, 0, 1, 0), (NRX_SPARSE, 5, 4, 0)],
 }
@@ -921,13 +923,13 @@ def test_inbox_gather_and_scatter_vs_oracle():
         np.testing.assert_allclose(g.cpu().numpy(), r, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("case", ["mixed_dims", "odd_dims", "bags", "bag_long_odd"])
+@pytest.mark.parametrize("case", ["mixed_dims", "odd_dims", "bags", "bag_long_odd", "tower_large"])
 def test_sorted_sparse_backward_matches_dense_and_is_deterministic(case):
     """sparse_grad=True: sorted segmented reduction -> COO grads.  Densified they equal the oracle's dense
     grads (tighter than the atomic path: a fixed summation order), two runs are bit-identical, and the
     padding row carries an explicit zero."""
     rng = np.random.default_rng(78)
-    B = 300
+    B = 4096 if case == "tower_large" else 300
     space, tables, batch = _rand_case(rng, B, GENERIC_CASES[case])
     names = set(tables) | space.dense
     up = None

@@ -101,20 +101,21 @@ def test_hip_bucketize_matches_definition(n, world, seed):
     dict(n=[70000, 30000, 5000], rows=[1 << 24, 1 << 24, 300], tab=[0, 2, 0], nt=3),     # many tiles per table, 2 x 12-bit digits,
                                                                                 # a table shared by non-adjacent features
     dict(n=[50000, 50000], rows=[1 << 20, 200000], tab=[1, 0], nt=2, zipf=1.05),          # skewed ids: long runs of one row
+    dict(n=[200000, 4097, 140000], rows=[1 << 19, 11, 1 << 19], tab=[1, 0, 1], nt=2),    # a segment of 83 tiles: chunked scans
     dict(n=[9000, 4097], rows=[1 << 38, 11], tab=[1, 0], nt=2),                 # 38 row bits: four digit passes, 64-bit keys
     dict(n=[9000, 4097], rows=[1 << 21, 11], tab=[69, 0], nt=70),               # more tables than segments: library sort
 ])
 @pytest.mark.parametrize("dtype", ["int64", "int32"])
-@pytest.mark.parametrize("sort", ["segmented", "rocprim"])
+@pytest.mark.parametrize("sort", ["segmented", "segmented-bins", "rocprim"])
 def test_sparse_plan_bit_exact(case, dtype, sort, monkeypatch):
     """nrx_sparse_plan == its definition (oracle.ref_np.sparse_plan): stable order, unique keys, segment
     starts, per-table bounds -- including out-of-range / negative ids (row 0) and tables with no lookups."""
     import torch
     from news_recsys_amd import ops
     from oracle import ref_np as R
-    if sort == "rocprim":
-        monkeypatch.setenv("NRX_PLAN_SORT", "rocprim")             # read by the library on every call
-    else:
+    if sort != "segmented":
+        monkeypatch.setenv("NRX_PLAN_SORT", sort)                  # read by the library on every call ("segmented-bins": long segments
+    else:                                                          # through seg_scan_bins, the path beyond 128 chunks per segment)
         monkeypatch.delenv("NRX_PLAN_SORT", raising=False)
     rng = np.random.default_rng(sum(case["n"]) + case["nt"])
     ids = []
