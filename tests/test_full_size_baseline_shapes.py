@@ -149,3 +149,36 @@ def test_c5_all_40_tables_on_one_gpu_with_wide_split():
     out = ops.embed_apply(plan2, tables, ids, [None] * 40)[0]
     for i in (0, 9, 10, 38, 39):
         assert torch.equal(out[:, i * D:(i + 1) * D], expect(ids[i], D, i))
+
+
+@pytest.mark.parametrize("shape", ["c2", "c4", "c5"])
+@pytest.mark.parametrize("skew", [False, True])
+def test_backward_plan_at_baseline_shapes_matches_definition(shape, skew):
+    """nrx_sparse_plan (the row-sparse backward's planning step: table-segmented stable sort of the lookups, unique rows,
+    segment starts, per-table bounds) at the REAL lookup counts of the BASELINE shapes, B = 65 536, against its numpy
+    definition (oracle.ref_np.sparse_plan) bit for bit.  C2: 26 one-chunk segments; C4: an 800-tile segment (history, which
+    shares the news table with item_id) next to a 16-tile one; C5: 40 tables of 1 k .. 500 M rows -> 64-bit keys, three
+    digit passes.  Reference: autograd of nn.Embedding over every lookup feature (src/model/BaseModel/base_model.py:262-308)."""
+    import numpy as np
+    from oracle import ref_np as R
+    rng = np.random.default_rng({"c2": 2, "c4": 4, "c5": 5}[shape] + (100 if skew else 0))
+    if shape == "c2":
+        lens, rows, tab = [B] * 26, [1_000_000] * 26, list(range(26))
+    elif shape == "c4":
+        lens, rows, tab = [B, B * 50, B], [10_000_000, 200_000, 200_000], [0, 1, 1]
+    else:
+        rows = [int(round(1e3 * (5e5) ** (i / 39))) for i in range(40)]
+        lens, tab = [B] * 40, list(range(40))
+    ids = []
+    for n, r in zip(lens, rows):
+        x = np.minimum(rng.zipf(1.05, n) - 1, r - 1) if skew else rng.integers(0, r, n)
+        ids.append(x.astype(np.int64))
+    nt = max(tab) + 1
+    order, uniq, seg, counts = ops.sparse_plan([torch.from_numpy(x).to(DEV) for x in ids], tab, rows, nt)
+    o_r, u_r, s_r, c_r = R.sparse_plan(ids, tab, rows, nt)
+    c = counts.cpu().numpy()
+    assert np.array_equal(c, c_r)
+    nu = int(c[0])
+    assert np.array_equal(order.cpu().numpy(), o_r)
+    assert np.array_equal(uniq.cpu().numpy()[:nu], u_r)
+    assert np.array_equal(seg.cpu().numpy()[:nu + 1], s_r)
