@@ -182,3 +182,66 @@ def test_backward_plan_at_baseline_shapes_matches_definition(shape, skew):
     assert np.array_equal(order.cpu().numpy(), o_r)
     assert np.array_equal(uniq.cpu().numpy()[:nu], u_r)
     assert np.array_equal(seg.cpu().numpy()[:nu + 1], s_r)
+
+
+@pytest.mark.parametrize("skew", [False, True])
+def test_c4_row_sparse_backward_equals_dense_backward_at_full_size(skew):
+    """The deterministic row-sparse backward (planning + sorted segmented reduction: what `embeddings.sparse_grad` and the
+    bench's fwd_bwd leg run) against the dense-gradient backward (atomic scatter, a different kernel and no planning at
+    all) on the REAL C4 shape: user_id over the 10 M-row table, history L = 50 + item_id sharing the 200 k-row news table,
+    B = 65 536 -- 3.4 M lookups, an 800-tile segment next to a 16-tile one.  Densified, the two gradients agree to the
+    atomics' summation-order noise; two sparse runs are bit-identical.  (Autograd of nn.Embedding + array_feature_pooling:
+    src/model/BaseModel/base_model.py:262-282.)"""
+    need_free(6 << 30)
+    gen = torch.Generator(device=DEV).manual_seed(20261002 + int(skew))
+    D, L = 16, 50
+    users = torch.randn((10_000_000, D), device=DEV, generator=gen)
+    news = torch.randn((200_000, D), device=DEV, generator=gen)
+
+    def ids_of(rows, shape):
+        if not skew:
+            return torch.randint(1, rows, shape, device=DEV, generator=gen)
+        u = torch.rand(shape, device=DEV, generator=gen)              # popularity-skewed: rank ~ rows ** u
+        return (torch.pow(float(rows), u).long() - 1).clamp_(1, rows - 1)
+
+    uid, iid = ids_of(10_000_000, (B,)), ids_of(200_000, (B,))
+    lens = torch.randint(0, L + 1, (B,), device=DEV, generator=gen)
+    lens[0], lens[1] = L, 0
+    mask = (torch.arange(L, device=DEV)[None] < lens[:, None]).float()
+    hist = ids_of(200_000, (B, L)) * mask.long()
+    plan = ops.EmbedPlan([ops.Slot("user_id", NRX_SPARSE, 0, D, 0, 0), ops.Slot("user_history", NRX_BAG_MASKED_MEAN, 1, D, L, D),
+                          ops.Slot("item_id", NRX_SPARSE, 1, D, 0, 2 * D)], out_width=3 * D)
+    up = torch.randn((B, 3 * D), device=DEV, generator=gen)
+    grads = {}
+    for mode in ("dense", "sparse", "sparse2"):
+        tabs = [users.clone().requires_grad_(True), news.clone().requires_grad_(True)]
+        out = ops.embed_apply(plan, tabs, [uid, hist, iid], [None, mask, None], sparse_grad=mode != "dense")[0]
+        (out * up).sum().backward()
+        grads[mode] = [t.grad for t in tabs]
+        del out, tabs
+    for a, b in zip(grads["sparse"], grads["sparse2"]):
+        a, b = a.coalesce(), b.coalesce()
+        assert torch.equal(a.indices(), b.indices()) and torch.equal(a.values(), b.values())           # bit-reproducible
+    # float64 restatement of the definition (index_add of every lookup's contribution) + the L1 mass per row: fp32 sums of n
+    # terms in ANY order stay within n * eps * sum|x|; hot rows of the skewed draw collect ~1e5 terms, so the bound is per row
+    w = mask.double() / (mask.double().sum(1, keepdim=True) + 1e-8)
+    upd = up.double()
+    contrib = [(0, uid, upd[:, :D]), (1, hist.reshape(-1), (w[..., None] * upd[:, None, D:2 * D]).reshape(-1, D)), (1, iid, upd[:, 2 * D:])]
+    for t, (d, sp) in enumerate(zip(grads["dense"], grads["sparse"])):
+        ref = torch.zeros(d.shape, dtype=torch.float64, device=DEV)
+        mass = torch.zeros(d.shape, dtype=torch.float64, device=DEV)
+        for tt, ids, c in contrib:
+            if tt == t:
+                ref.index_add_(0, ids, c)
+                mass.index_add_(0, ids, c.abs())
+        ref[0] = 0                                                                                   # padding row never trains
+        sp = sp.coalesce()
+        rows = sp.indices()[0]
+        assert torch.all(rows[1:] > rows[:-1])                                                       # every row once, ascending
+        touched = torch.zeros(d.shape[0], dtype=torch.bool, device=DEV)
+        touched[rows] = True
+        assert torch.all(d[~touched] == 0) and torch.all(ref[~touched] == 0)                         # same support
+        tol = 2e-6 * mass[rows] + 1e-6
+        assert torch.all((sp.values().double() - ref[rows]).abs() <= tol)                            # sorted reduction
+        assert torch.all((d[rows].double() - ref[rows]).abs() <= 4 * tol)                            # atomic scatter (order noise)
+        del ref, mass
