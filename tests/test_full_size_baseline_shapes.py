@@ -245,3 +245,39 @@ def test_c4_row_sparse_backward_equals_dense_backward_at_full_size(skew):
         assert torch.all((sp.values().double() - ref[rows]).abs() <= tol)                            # sorted reduction
         assert torch.all((d[rows].double() - ref[rows]).abs() <= 4 * tol)                            # atomic scatter (order noise)
         del ref, mass
+
+
+def test_c2_row_sparse_backward_with_fm_gradient_at_full_size():
+    """C2 (DeepFM: 26 tables x 1 M rows x 16, B = 65 536, FM logit fused into the gather): the row-sparse backward with the FM
+    gradient folded into the reduction, against float64 autograd of the reference arithmetic restated in torch
+    (embedding rows -> concat; column 0 of every field is its first-order weight, columns 1.. its factors:
+    fm = sum_f w + 0.5 * sum_k[(sum_f v)^2 - sum_f v^2], src/model/sort/fm/model.py:18-26, 48-59) -- every touched row of every table."""
+    need_free(24 << 30)
+    gen = torch.Generator(device=DEV).manual_seed(20261003)
+    F, D, rows = 26, 16, 1_000_000
+    tables = [torch.randn((rows, D), device=DEV, generator=gen) * 0.1 for _ in range(F)]
+    for t in tables:
+        t[0].zero_()
+    ids = [torch.randint(1, rows, (B,), device=DEV, generator=gen) for _ in range(F)]
+    up = torch.randn((B, F * D), device=DEV, generator=gen)
+    upf = torch.randn((B,), device=DEV, generator=gen)
+    plan = ops.EmbedPlan([ops.Slot(f"f{i:02d}", NRX_SPARSE, i, D, 0, i * D, fm_field=1) for i in range(F)], out_width=F * D, use_fm=True)
+    tabs = [t.clone().requires_grad_(True) for t in tables]
+    out, _, fm = ops.embed_apply(plan, tabs, ids, [None] * F, sparse_grad=True)
+    ((out * up).sum() + (fm * upf).sum()).backward()
+    # float64 autograd of the definition
+    rows64 = [t[i].double().requires_grad_(True) for t, i in zip(tables, ids)]          # [B, D] per field
+    v = torch.stack(rows64, 1)                                                             # [B, F, D]
+    fm64 = v[:, :, 0].sum(1) + 0.5 * (v[:, :, 1:].sum(1).pow(2) - v[:, :, 1:].pow(2).sum(1)).sum(1)
+    loss = (torch.cat(rows64, 1) * up.double()).sum() + (fm64 * upf.double()).sum()
+    g64 = torch.autograd.grad(loss, rows64)
+    assert torch.allclose(fm.double(), fm64, rtol=2e-5, atol=2e-5)
+    for f in range(F):
+        sp = tabs[f].grad.coalesce()
+        r = sp.indices()[0]
+        ref = torch.zeros((rows, D), dtype=torch.float64, device=DEV).index_add_(0, ids[f], g64[f])
+        touched = torch.zeros(rows, dtype=torch.bool, device=DEV)
+        touched[r] = True
+        assert torch.all(ref[~touched] == 0)
+        assert torch.allclose(sp.values().double(), ref[r], rtol=1e-5, atol=2e-5), f"table {f}"
+        del ref
