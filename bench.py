@@ -520,6 +520,15 @@ def main():
                 fwd[i % len(fwd)].run()
                 bwd[i % len(bwd)].run()
             fb_ms = time_calls(both, steps2)
+            # the leg is not only timed: every group's plan must list each (table, row) once, ascending, with segments that tile
+            # the lookups exactly (a mis-sorted plan would still run at full speed)
+            for g in bwd[0].run():
+                nu = int(g["counts"][0].item())
+                uq, sg = g["uniq"][:nu], g["seg"][:nu + 1]
+                if not (nu > 0 and bool(torch.all(uq[1:] > uq[:-1])) and int(sg[0].item()) == 0 and int(sg[-1].item()) == g["total"]
+                        and bool(torch.all(sg[1:] > sg[:-1])) and bool(torch.isfinite(g["values"][:nu]).all())):
+                    raise SystemExit("fwd_bwd leg: the row-sparse backward's plan is inconsistent (unique rows not ascending / segments "
+                                     "do not tile the lookups)")
             fwd_bwd = {"ms_per_step": fb_ms, "value": BATCH / (fb_ms * 1e-3), "unit": "impressions/s",
                        "forward_ms": f_ms, "backward_ms": fb_ms - f_ms,
                        "mode": "forward (training form: + FM field sums) + deterministic row-sparse backward: nrx_sparse_plan "
