@@ -182,7 +182,9 @@ NRX_API int nrx_sparse_plan(const void* const* ids, const int64_t* lens, const i
  * dense AdamW over every row (src/model/sort/deep/model.py:54-65) -- a documented deviation, see DESIGN.md.
  * n_unique_dev (optional, device int64[1]): actual count; n_unique is then an upper bound sizing the launch.
  * step_size_dev (optional, device float[1]): overrides step_size with a value read on the device, so a training
- * loop captured in a hipGraph can advance the bias correction between replays. */
+ * loop captured in a hipGraph can advance the bias correction between replays.
+ * Moment layout: exp_avg[t] / exp_avg_sq[t] are [rows, dim] arrays; a table with exp_avg_sq[t] == exp_avg[t] + dim is taken
+ * as ONE [rows, 2, dim] array (a row's two moments adjacent: one 128-byte line per row at dim 16). */
 NRX_API int nrx_sparse_adam_step(float* const* tables, float* const* exp_avg, float* const* exp_avg_sq, int32_t n_tables,
                          int32_t dim, const int64_t* uniq_keys, const float* grads, int64_t n_unique,
                          const int64_t* n_unique_dev, float step_size, const float* step_size_dev, float beta1,

@@ -1102,6 +1102,7 @@ struct SparseAdamArgs {
     int64_t max_n;
     int32_t n_tables;
     int32_t dim;
+    int32_t mom_ld[NRX_MAX_FEATURES];   // per table: floats between consecutive rows of a moment array: dim, or 2 * dim when the row's two moments are adjacent
     float step_size, one_minus_b1, one_minus_b2, eps, decay;
     const float* step_size_dev;   // optional: step size read on the device (graph-captured training loops)
 };
@@ -1145,8 +1146,8 @@ __global__ __launch_bounds__(NRX_BLOCK) void sparse_adam_kernel(const SparseAdam
         on[r] = key[r] >= 0 && row != 0 && t < a->n_tables;        // padding row / filler keys of a merged list
         const int64_t tc = on[r] ? t : 0, rc = on[r] ? row : 0;
         p[r] = a->table[tc] + rc * D;
-        pm[r] = a->m[tc] + rc * D;
-        pv[r] = a->v[tc] + rc * D;
+        pm[r] = a->m[tc] + rc * a->mom_ld[tc];
+        pv[r] = a->v[tc] + rc * a->mom_ld[tc];
     }
     if (VEC) {
         for (int k = q * 4; k < D; k += 4 * Q) {
@@ -1198,11 +1199,16 @@ extern "C" int nrx_sparse_adam_step(float* const* tables, float* const* exp_avg,
     if (n_unique == 0) return NRX_OK;
     NRX_REQUIRE(tables && exp_avg && exp_avg_sq && uniq_keys && grads, "nrx_sparse_adam_step: null buffer");
     SparseAdamArgs a;
+    // Interleaved moments: exp_avg_sq[t] == exp_avg[t] + dim means the two moments of a row of table t sit side by side
+    // ([rows, 2, dim]: for dim = 16 ONE 128-byte line per row instead of two half-used ones -- the update is a random
+    // read-modify-write and every 64-byte access costs a 128-byte fetch).  Separate arrays can never satisfy this by accident.
+    // (The caller may list tables of other widths too -- the keys of this call never name them; their entry is unused.)
     for (int t = 0; t < n_tables; ++t) {
         NRX_REQUIRE(tables[t] && exp_avg[t] && exp_avg_sq[t], "nrx_sparse_adam_step: table %d: null pointer", t);
         a.table[t] = tables[t];
         a.m[t] = exp_avg[t];
         a.v[t] = exp_avg_sq[t];
+        a.mom_ld[t] = exp_avg_sq[t] == exp_avg[t] + dim ? 2 * dim : dim;
     }
     a.keys = uniq_keys;
     a.grads = grads;

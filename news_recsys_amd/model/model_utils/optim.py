@@ -45,7 +45,10 @@ class FusedSparseAdam:
             i = len(self.tables)
             self._index[id(t)] = i
             self.tables.append(t)
-            self.moments.append((torch.zeros_like(t), torch.zeros_like(t)))
+            # both moments of a row side by side ([rows, 2, D]; exp_avg / exp_avg_sq are its two views): the update is a random
+            # read-modify-write of (w, m, v) and every 64-byte access costs a 128-byte fetch -- adjacent, m and v share one
+            mv = torch.zeros((t.shape[0], 2, t.shape[1]), dtype=t.dtype, device=t.device)
+            self.moments.append((mv[:, 0], mv[:, 1]))
         return i
 
     def _global_keys(self, e):
