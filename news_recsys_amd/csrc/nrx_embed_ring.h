@@ -26,6 +26,7 @@ struct UniformArgs {
     const void* index[NRX_MAX_FEATURES];
     int64_t rows[NRX_MAX_FEATURES];
     int32_t col4[NRX_MAX_FEATURES];   // out column / 4
+    uint8_t feat_id[NRX_MAX_FEATURES]; // the feature's index in the caller's list (what an out-of-range report names)
     int64_t batch;
     float4* out;                      // may be null (FM-only inference)
     int64_t ld4;                      // out_ld / 4
@@ -108,7 +109,7 @@ __device__ __forceinline__ void stage_ids(const NRX_CONST A* a, int32_t* s_ids, 
             const int fc = f < n ? f : n - 1;
             int64_t id = idv[u];
             if ((uint64_t)id >= (uint64_t)a->rows[fc]) {
-                if (f < n && lane < nb) nrx_report_oob(a->status, f, b0 + lane, id);
+                if (f < n && lane < nb) nrx_report_oob(a->status, a->feat_id[f], b0 + lane, id);
                 id = 0;
             }
             if (f < n && lane < TB) s_ids[f * TB + lane] = (int32_t)id;

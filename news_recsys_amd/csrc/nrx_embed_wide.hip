@@ -17,6 +17,7 @@ struct UniformWideArgs {
     int64_t rows[NRX_MAX_FEATURES];
     int32_t col[NRX_MAX_FEATURES];        // first deep column of the feature (float units)
     int32_t wide_col[NRX_MAX_FEATURES];   // column in the wide tensor, -1 = not a wide feature
+    uint8_t feat_id[NRX_MAX_FEATURES];    // the feature's index in the caller's list (out-of-range reports; stage_ids of nrx_embed_ring.h reads it)
     int64_t batch;
     float* out;                           // deep concat [batch, ld]
     int64_t ld;
@@ -220,6 +221,7 @@ bool nrx_launch_uniform_wide(const nrx_feature_t* feats, int32_t n_feats, int64_
         ua.rows[i] = s.rows;
         ua.col[i] = s.out_col;
         ua.wide_col[i] = s.wide_col;
+        ua.feat_id[i] = (uint8_t)i;
         any_wide |= s.wide_col >= 0;
         table_bytes += s.rows * (int64_t)D0 * 4;
     }

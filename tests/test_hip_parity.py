@@ -366,6 +366,14 @@ def test_uniform_gather_concat_bit_exact_vs_oracle(B, F, D, idx_dtype):
 GENERIC_CASES = {
     "mixed_dims": [(NRX_SPARSE, 97, 32, 0), (NRX_SPARSE, 61, 32, 0), (NRX_SPARSE, 18, 16, 0), (NRX_SPARSE, 27, 16, 0)],
     "odd_dims": [(NRX_SPARSE, 40, 17, 0), (NRX_SPARSE, 30, 1, 0), (NRX_SPARSE, 50, 5, 0), (NRX_SPARSE, 9, 33, 0)],
+    # >= 6 single-valued features of several 4Q widths: one uniform launch per width into the same concat (not the generic kernel)
+    "many_mixed_dims": [(NRX_SPARSE, 300 + 7 * i, (16, 32, 64, 16, 128)[i % 5], 0) for i in range(13)],
+    # a ranker's feature set: eight + two single-valued features of widths 16 / 32 (uniform launches) next to a dense value, a history
+    # bag and an odd width (generic kernel) -- one concat
+    # (the unaligned ones last: a feature whose first column is not a multiple of 4 cannot take the 16-byte stores)
+    "deep_like_hybrid": [(NRX_SPARSE, 90 + i, 16, 0) for i in range(4)] + [(NRX_BAG_MASKED_MEAN, 70, 16, 20)] +
+                        [(NRX_SPARSE, 50 + i, 16, 0) for i in range(4)] + [(NRX_SPARSE, 33, 32, 0), (NRX_SPARSE, 44, 32, 0),
+                                                                            (NRX_SPARSE, 21, 5, 0), (NRX_DENSE, 0, 1, 0)],
     "lr_dim1": [(NRX_SPARSE, 40, 1, 0)] * 5,
     "bags": [(NRX_SPARSE, 100, 16, 0), (NRX_BAG_MASKED_MEAN, 200, 16, 50), (NRX_BAG_MEAN, 30, 16, 7)],
     "bag_long_odd": [(NRX_BAG_MASKED_MEAN, 64, 12, 333), (NRX_DENSE, 0, 1, 0), (NRX_SPARSE, 11, 8, 0)],
@@ -395,6 +403,27 @@ def test_generic_embed_vs_oracle(case, B):
         else:
             assert np.array_equal(blk, ref)                                # copies: bit-exact
         col += d
+
+
+def test_out_of_range_report_names_the_callers_feature_in_split_launches():
+    """A feature set served by several launches (uniform launches per width + the generic kernel for the rest): the IndexError
+    still names the feature by its position in the caller's list, whichever launch met the bad id."""
+    rng = np.random.default_rng(11)
+    B = 64
+    space, tables, batch = _rand_case(rng, B, GENERIC_CASES["deep_like_hybrid"])
+    names = set(tables) | space.dense
+    plan, tt, inputs, weights, _ = build_plan(space, tables, batch, names)
+    order = [s.name for s in plan.slots]
+    for victim in (order.index("f07"), order.index("f10"), order.index("f04"), order.index("f11")):    # width 16, width 32, the bag, the odd width
+        bad = [x.clone() for x in inputs]
+        flat = bad[victim].view(-1)
+        flat[3] = 10 ** 6
+        w = list(weights)
+        if w[victim] is not None:
+            w[victim] = w[victim].clone()
+            w[victim].view(-1)[3] = 1.0
+        with pytest.raises(IndexError, match=plan.slots[victim].name):
+            ops.embed_apply(plan, tt, bad, w, index_check="sync")
 
 
 def test_bag_sum_kind_and_weights():
