@@ -184,9 +184,15 @@ __global__ __launch_bounds__(256, PROBE_OCC) void dcn_v2_layer_kernel(const floa
 #pragma unroll
             for (int i = 0; i < BK / 4; ++i) {
                 const int kr = 2 * (h * (BK / 4) + i) + hi;
+#ifdef PROBE_VOLATILE_LDS
+                fb[i] = ((const volatile __attribute__((address_space(3))) float*)Ws)[kr * LDW + wn * 32 + l31];
+#pragma unroll
+                for (int t = 0; t < TM; ++t) fa[t][i] = ((const volatile __attribute__((address_space(3))) float*)As)[kr * LDA + wm * (32 * TM) + 32 * t + l31];
+#else
                 fb[i] = Ws[kr * LDW + wn * 32 + l31];
 #pragma unroll
                 for (int t = 0; t < TM; ++t) fa[t][i] = As[kr * LDA + wm * (32 * TM) + 32 * t + l31];
+#endif
             }
 #pragma unroll
             for (int i = 0; i < BK / 4; ++i)
