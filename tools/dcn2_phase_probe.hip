@@ -45,6 +45,11 @@ __global__ __launch_bounds__(256, PROBE_OCC) void dcn_v2_layer_kernel(const floa
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform by construction; tell the compiler
     const int wm = wid >> 1, wn = wid & 1;
     const int l31 = lane & 31, hi = lane >> 5;
+#ifdef PROBE_ASM_KLOOP
+    static_assert(TM == 2 && LDA == 129 && LDW == 65, "the asm K loop's offsets are written for the 128x64 tile");
+    const uint32_t lds_bw = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) float*)Ws + hi * LDW + wn * 32 + l31);
+    const uint32_t lds_ba = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) float*)As + hi * LDA + wm * (32 * TM) + l31);
+#endif
     // XCD-aware tile order (guide T1, bijective form): hardware places block b on XCD b % 8; remap so
     // that the nx column tiles of one 128-row panel of x_l are consecutive on ONE XCD and share its L2
     // (without it the panel was fetched from DRAM once per XCD: 516 MB read vs ~250 MB, measured).
@@ -177,6 +182,36 @@ __global__ __launch_bounds__(256, PROBE_OCC) void dcn_v2_layer_kernel(const floa
         if (MAINLOAD && k0 + BK < K) load_slab(k0 + BK);      // next slab: loads stay in flight across the MFMA block below
         // fragments of half a slab (8 k-pairs: 8 B + 32 A dwords) are read ahead of a dense block of
         // 32 MFMAs, so the LDS latency is paid twice per slab instead of once per MFMA group
+#ifdef PROBE_ASM_KLOOP
+        // hand-scheduled half slab: 12 fragment reads (ds_read_b32 with immediate offsets: no address VALU) in flight, then every
+        // MFMA pair waits only for its own three fragments while the reads of the pair four steps ahead are issued behind it
+        // (lgkmcnt is a 4-bit counter: never more than 12 LDS reads outstanding)
+#define NRX_RDW(D_, H_, I_) "ds_read_b32 %[" #D_ "], %[bw] offset:(16*" #H_ "+2*" #I_ ")*260\n"
+#define NRX_RDA(D_, H_, I_, T_) "ds_read_b32 %[" #D_ "], %[ba] offset:(16*" #H_ "+2*" #I_ ")*516+128*" #T_ "\n"
+#define NRX_RD3(H_, I_) NRX_RDW(b##I_, H_, I_) NRX_RDA(a0##I_, H_, I_, 0) NRX_RDA(a1##I_, H_, I_, 1)
+#define NRX_MM(I_) "v_mfma_f32_32x32x2_f32 %[c0], %[a0" #I_ "], %[b" #I_ "], %[c0]\n" "v_mfma_f32_32x32x2_f32 %[c1], %[a1" #I_ "], %[b" #I_ "], %[c1]\n"
+#define NRX_HALF(H_)                                                                                                        \
+        {                                                                                                                    \
+            float b0, b1, b2, b3, b4, b5, b6, b7, a00, a01, a02, a03, a04, a05, a06, a07, a10, a11, a12, a13, a14, a15, a16, a17;   \
+            asm volatile(NRX_RD3(H_, 0) NRX_RD3(H_, 1) NRX_RD3(H_, 2) NRX_RD3(H_, 3)                                         \
+                         "s_waitcnt lgkmcnt(9)\n" NRX_MM(0) NRX_RD3(H_, 4)                                                   \
+                         "s_waitcnt lgkmcnt(9)\n" NRX_MM(1) NRX_RD3(H_, 5)                                                   \
+                         "s_waitcnt lgkmcnt(9)\n" NRX_MM(2) NRX_RD3(H_, 6)                                                   \
+                         "s_waitcnt lgkmcnt(9)\n" NRX_MM(3) NRX_RD3(H_, 7)                                                   \
+                         "s_waitcnt lgkmcnt(9)\n" NRX_MM(4)                                                                  \
+                         "s_waitcnt lgkmcnt(6)\n" NRX_MM(5)                                                                  \
+                         "s_waitcnt lgkmcnt(3)\n" NRX_MM(6)                                                                  \
+                         "s_waitcnt lgkmcnt(0)\n" NRX_MM(7)                                                                  \
+                         : [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [b4] "=&v"(b4), [b5] "=&v"(b5), [b6] "=&v"(b6), [b7] "=&v"(b7), \
+                           [a00] "=&v"(a00), [a01] "=&v"(a01), [a02] "=&v"(a02), [a03] "=&v"(a03), [a04] "=&v"(a04), [a05] "=&v"(a05), [a06] "=&v"(a06), [a07] "=&v"(a07), \
+                           [a10] "=&v"(a10), [a11] "=&v"(a11), [a12] "=&v"(a12), [a13] "=&v"(a13), [a14] "=&v"(a14), [a15] "=&v"(a15), [a16] "=&v"(a16), [a17] "=&v"(a17), \
+                           [c0] "+v"(acc[0]), [c1] "+v"(acc[1])                                                              \
+                         : [bw] "v"(lds_bw), [ba] "v"(lds_ba)                                                                \
+                         : "memory");                                                                                        \
+        }
+        NRX_HALF(0)
+        if (k0 + BK / 2 < K) NRX_HALF(1)
+#else
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h == 1 && k0 + BK / 2 >= K) break;      // the last slab's upper half is all padding (K % 32 <= 16): skip its MFMAs
@@ -199,6 +234,7 @@ __global__ __launch_bounds__(256, PROBE_OCC) void dcn_v2_layer_kernel(const floa
 #pragma unroll
                 for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][i], fb[i], acc[t], 0, 0, 0);
         }
+#endif
         __syncthreads();             // slab fully consumed before the next LDS write
     }
 
@@ -280,7 +316,14 @@ static void run(const char* name, const float* x0, const float* x, const float* 
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / iters, tf = (2.0 * D * D + 3.0 * D) * B / us * 1e-6;
-    printf("D=%d %-52s %8.1f us  %6.1f TF  %5.1f %% of 157.3\n", D, name, us, tf, tf / 157.3 * 100);
+    unsigned long long hsh = 0;
+    if (EPI == 0 && MAINLOAD) {             // FNV-1a over the output bits: equal across builds of this probe <=> same values
+        std::vector<unsigned> h((size_t)B * D);
+        hipMemcpy(h.data(), out, (size_t)B * D * 4, hipMemcpyDeviceToHost);
+        hsh = 1469598103934665603ull;
+        for (unsigned v : h) { hsh ^= v; hsh *= 1099511628211ull; }
+    }
+    printf("D=%d %-52s %8.1f us  %6.1f TF  %5.1f %% of 157.3   out hash %016llx\n", D, name, us, tf, tf / 157.3 * 100, hsh);
 }
 __global__ void fill(float* p, size_t n, unsigned seed) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
