@@ -22,6 +22,7 @@
 // The uniform kernel (nrx_embed_ring.h) is the same mapping specialised for "all features single-valued, same D = 4Q":
 // ids staged once per block in LDS, then a ring of R row loads per lane kept in flight across the feature walk.
 #include "nrx_common.h"
+#include <cstdlib>
 #include <type_traits>
 #include "nrx_embed_ring.h"   // UniformArgs, fm_accumulate, group_sum, embed_fwd_ring
 
@@ -1110,7 +1111,7 @@ extern "C" int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, 
         NRX_REQUIRE(!(feats[i].flags & NRX_FEAT_BAG_CSR) || feats[i].kind >= NRX_BAG_MASKED_MEAN,
                     "nrx_embed_fwd: feature %d: NRX_FEAT_BAG_CSR on a non-bag feature", i);
     // ---- uniform fast path?  One launch when every feature is single-valued with the same width D = 4Q.  Otherwise, with no FM
-    // epilogue and no wide split in play, the features that DO qualify (at least six of them) are served by one uniform launch
+    // epilogue and no wide split in play, and enough lookups to amortise the launches, the features that DO qualify are served by one uniform launch
     // per width, each writing its own columns of the same concat, and only the rest -- bags, dense values, odd widths -- goes
     // through the generic kernel, which walks its features one at a time (a 24-feature mix of widths 16 / 32 / 64: 186 us
     // generic, 95 us as three uniform launches).
@@ -1137,7 +1138,13 @@ extern "C" int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, 
     }
     const bool single = n_el == n_feats && n_dims == 1 && wide_out == nullptr && (n_fm == 0 || n_fm == n_feats) &&
                         ((out != nullptr) || (fm_out != nullptr && n_fm > 0));
-    const bool per_width = !single && n_el >= 6 && n_fm == 0 && fm_out == nullptr && wide_out == nullptr && out != nullptr;
+    // split only when there is work to amortise the extra launches: at the reference's own feature set (5 features, widths 16 / 32)
+    // one generic launch costs 6.5 us at B <= 16 384 against 9.5 us for two uniform ones, and 15.0 against 12.0 us at B = 65 536
+    // (tools/probe_c1_split.py).  NRX_SPLIT_MIN_LOOKUPS overrides the threshold (tests force the split on small batches).
+    int64_t min_lookups = 262144;
+    if (const char* e = getenv("NRX_SPLIT_MIN_LOOKUPS")) min_lookups = atoll(e);
+    const bool per_width = !single && n_el >= 2 && batch * (int64_t)n_el >= min_lookups && n_fm == 0 && fm_out == nullptr &&
+                           wide_out == nullptr && out != nullptr;
     nrx_feature_t rest[NRX_MAX_FEATURES];
     uint8_t rest_id[NRX_MAX_FEATURES];
     for (int i = 0; i < NRX_MAX_FEATURES; ++i) rest_id[i] = (uint8_t)i;

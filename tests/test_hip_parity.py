@@ -366,7 +366,7 @@ def test_uniform_gather_concat_bit_exact_vs_oracle(B, F, D, idx_dtype):
 GENERIC_CASES = {
     "mixed_dims": [(NRX_SPARSE, 97, 32, 0), (NRX_SPARSE, 61, 32, 0), (NRX_SPARSE, 18, 16, 0), (NRX_SPARSE, 27, 16, 0)],
     "odd_dims": [(NRX_SPARSE, 40, 17, 0), (NRX_SPARSE, 30, 1, 0), (NRX_SPARSE, 50, 5, 0), (NRX_SPARSE, 9, 33, 0)],
-    # >= 6 single-valued features of several 4Q widths: one uniform launch per width into the same concat (not the generic kernel)
+    # single-valued features of several 4Q widths: one uniform launch per width into the same concat (not the generic kernel)
     "many_mixed_dims": [(NRX_SPARSE, 300 + 7 * i, (16, 32, 64, 16, 128)[i % 5], 0) for i in range(13)],
     # a ranker's feature set: eight + two single-valued features of widths 16 / 32 (uniform launches) next to a dense value, a history
     # bag and an odd width (generic kernel) -- one concat
@@ -386,7 +386,9 @@ GENERIC_CASES = {
 
 @pytest.mark.parametrize("case", sorted(GENERIC_CASES))
 @pytest.mark.parametrize("B", [1, 37, 256, 1031])
-def test_generic_embed_vs_oracle(case, B):
+def test_generic_embed_vs_oracle(case, B, monkeypatch):
+    if case in ("many_mixed_dims", "deep_like_hybrid"):
+        monkeypatch.setenv("NRX_SPLIT_MIN_LOOKUPS", "0")      # small batches: force the per-width split these cases are about
     rng = np.random.default_rng(sum(map(ord, case)) + B)
     space, tables, batch = _rand_case(rng, B, GENERIC_CASES[case])
     names = set(tables) | space.dense
@@ -405,9 +407,10 @@ def test_generic_embed_vs_oracle(case, B):
         col += d
 
 
-def test_out_of_range_report_names_the_callers_feature_in_split_launches():
+def test_out_of_range_report_names_the_callers_feature_in_split_launches(monkeypatch):
     """A feature set served by several launches (uniform launches per width + the generic kernel for the rest): the IndexError
     still names the feature by its position in the caller's list, whichever launch met the bad id."""
+    monkeypatch.setenv("NRX_SPLIT_MIN_LOOKUPS", "0")
     rng = np.random.default_rng(11)
     B = 64
     space, tables, batch = _rand_case(rng, B, GENERIC_CASES["deep_like_hybrid"])
