@@ -440,13 +440,14 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tile = blockIdx.x, seg = seg_of_tile(a, tile);
     const int db = a->seg_db[seg], nbins = 1 << db, shift = pass * db, nb = a->nb;
-    uint32_t* s_wh = s_mem;                               // [WAVES][nbins]: running bin counts of each wave's 1024-entry chunk
-    uint32_t* s_bin = s_wh + WAVES * nbins;               // [nbins]: the bin's first position inside the tile
+    uint16_t* s_wh = reinterpret_cast<uint16_t*>(s_mem);  // [WAVES][nbins]: running bin counts of each wave's 512-entry chunk (16-bit: a tile
+                                                          // holds 4096 entries; halves this area -- a third / fourth resident block per CU)
+    uint32_t* s_bin = s_mem + WAVES * nbins / 2;          // [nbins]: the bin's first position inside the tile
     uint32_t* s_gb = s_bin + nbins;                       // [nbins]: global position of the bin's first entry of this tile - s_bin
     uint32_t* s_pay = s_gb + nbins;                       // [SEG_TILE]
     KeyT* s_key = reinterpret_cast<KeyT*>(s_pay + SEG_TILE);      // [SEG_TILE]
     __shared__ uint32_t s_part[WAVES], s_gpart[WAVES];
-    for (int b = tid; b < WAVES * nbins; b += SEG_THREADS) s_wh[b] = 0;
+    for (int b = tid; b < WAVES * nbins / 2; b += SEG_THREADS) s_mem[b] = 0;
     const int64_t q0 = a->seg_off[seg] + (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE, qend = a->seg_off[seg + 1];
     const int count = (int)(qend - q0 < SEG_TILE ? qend - q0 : SEG_TILE);
     const int64_t qw = q0 + (int64_t)wid * (64 * ROUNDS) + lane;         // wave w owns entries [w * 512, (w + 1) * 512) of the tile
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
         }
     }
     __syncthreads();
-    uint32_t* wh = s_wh + wid * nbins;
+    uint16_t* wh = s_wh + wid * nbins;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
         uint32_t base = 0;
         if (valid) {
             base = wh[d];                                         // every peer reads the count before the leader bumps it
-            if (before == 0) wh[d] = base + (uint32_t)__popcll(peers);
+            if (before == 0) wh[d] = (uint16_t)(base + (uint32_t)__popcll(peers));
         }
         loc[r] = base + before;
     }
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
         uint32_t run = 0;
         if (b < nbins) {
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) { const uint32_t v = s_wh[w * nbins + b]; s_wh[w * nbins + b] = run; run += v; }
+            for (int w = 0; w < WAVES; ++w) { const uint32_t v = s_wh[w * nbins + b]; s_wh[w * nbins + b] = (uint16_t)run; run += v; }
         }
         tot[i] = run;
     }
@@ -732,9 +733,9 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
 #define NRX_SEGSORT(KeyT)                                                                                                 \
     {                                                                                                                     \
         constexpr bool PAIR_ = sizeof(KeyT) == 4;                                                                         \
-        const size_t lds_scatter = (size_t)nb * 4 * (SEG_THREADS / 64 + 2) + (size_t)SEG_TILE * (4 + sizeof(KeyT));         \
+        const size_t lds_scatter = (size_t)nb * (2 * (SEG_THREADS / 64) + 8) + (size_t)SEG_TILE * (4 + sizeof(KeyT));         \
         static const bool lds_ok = [] {                                                                                   \
-            const int bytes = (4 << SEG_MAX_DB) * (SEG_THREADS / 64 + 2) + SEG_TILE * (4 + (int)sizeof(KeyT));            \
+            const int bytes = (1 << SEG_MAX_DB) * (2 * (SEG_THREADS / 64) + 8) + SEG_TILE * (4 + (int)sizeof(KeyT));            \
             return hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, 0, PAIR_>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess && \
                    hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, 1, PAIR_>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess && \
                    hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, 2, PAIR_>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; \
