@@ -208,18 +208,20 @@ struct SegArgs {
 };
 static_assert(sizeof(SegArgs) <= 3584, "kernarg budget");
 
-// Segment of a tile: the LAST segment whose first tile is <= tile.  Written as a count over the whole (<= 64-entry) array
-// with a uniform index, so that the loads are a handful of independent scalar loads -- a binary search would be six
-// DEPENDENT round trips to the argument block before the block can load anything.
+// Segment of a tile: the LAST segment whose first tile is <= tile = the number of entries 1 .. n-1 of the (<= 64-entry) array that are
+// <= tile.  One lane per entry: ONE vector load from the argument block, one compare, a ballot and a popcount per wavefront -- a binary
+// search is six DEPENDENT round trips to the argument block before the block can load anything, and an unrolled scalar count of all
+// 64 entries cost the kernels around it 128 VGPRs.
+template <typename T>
+__device__ __forceinline__ int seg_count_le(const NRX_CONST T* arr, int n, T x) {
+    const int lane = threadIdx.x & 63;
+    const bool hit = lane >= 1 && lane < n && arr[lane < n ? lane : 0] <= x;
+    return (int)__popcll(__ballot(hit));
+}
 __device__ __forceinline__ int seg_of_tile(const NRX_CONST SegArgs* a, int tile) {
-    int seg = 0;
-    const int n = a->n_seg;
-#pragma unroll
-    for (int i = 1; i < NRX_MAX_FEATURES; ++i) seg += (i < n && a->seg_tile[i] <= tile) ? 1 : 0;
-    return seg;
+    return __builtin_amdgcn_readfirstlane(seg_count_le<int32_t>(a->seg_tile, a->n_seg, tile));
 }
 
-// keys + payload in table-major order, and the histogram of digit 0
 // PAIR (32-bit keys): {key, payload} travel as one 8-byte element through every pass and into plan_count / plan_emit -- the scatter's
 // runs are short (4 entries per bin and tile at 10-bit digits), so one 32-byte piece per run instead of two 16-byte ones.
 template <typename KeyT, bool PAIR>
@@ -234,12 +236,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
     const uint32_t dmask = (uint32_t)nbins - 1u;
     // first feature slot of the tile (wave-uniform, counted like seg_of_tile); a tile rarely holds a second one: then
     // every per-slot field is a scalar, otherwise the entries past the boundary walk on from there with per-lane indices
-    int lo = 0;
-    {
-        const int ns = a->n_slots;
-#pragma unroll
-        for (int i = 1; i < NRX_MAX_FEATURES; ++i) lo += (i < ns && a->qoff[i] <= q0) ? 1 : 0;
-    }
+    const int lo = __builtin_amdgcn_readfirstlane(seg_count_le<int64_t>(a->qoff, a->n_slots, q0));
     const int64_t lo_end = a->qoff[lo + 1];
     const bool one_slot = lo_end >= qend || lo_end >= q0 + SEG_TILE;
     int sl[SEG_PER_THREAD];
@@ -347,12 +344,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_hist_kernel(const SegArgs arg
 __global__ __launch_bounds__(NRX_BLOCK) void seg_scan_chunks(const SegArgs args_in_kernarg, uint32_t* __restrict__ hist, uint32_t* __restrict__ ctot) {
     const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
     const int chunk = blockIdx.y;
-    int seg = 0;
-    {
-        const int n = a->n_seg;
-#pragma unroll
-        for (int i = 1; i < NRX_MAX_FEATURES; ++i) seg += (i < n && a->seg_chunk[i] <= chunk) ? 1 : 0;
-    }
+    const int seg = __builtin_amdgcn_readfirstlane(seg_count_le<int32_t>(a->seg_chunk, a->n_seg, chunk));
     const int nb = a->nb;
     const int bin = blockIdx.x * NRX_BLOCK + threadIdx.x;
     if (bin >= (1 << a->seg_db[seg])) return;
