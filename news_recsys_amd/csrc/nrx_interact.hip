@@ -204,18 +204,33 @@ __device__ __forceinline__ void row_store(const RowRegs<R, V>& x, float* p, int 
     }
 }
 
-template <int R, int V>
-__device__ __forceinline__ float row_dot(const RowRegs<R, V>& a, const RowRegs<R, V>& b) {
+// G = lanes per row: 64 (one row per wavefront) or 32 (narrow rows, D <= 32 V: TWO rows per wavefront, lanes 0..31 / 32..63; lane
+// here is the lane inside the row's half).  The half-wave sum uses the same DPP steps inside rows of 16 and adds the two row sums
+// of its half -- for a row that fits 32 lanes this is bit for bit what the full-wave tree gives ((r0 + r1) + (0 + 0)).
+__device__ __forceinline__ float nrx_half_wave_sum(float v, bool upper) {
+    v += nrx_dpp<0xB1>(v);
+    v += nrx_dpp<0x4E>(v);
+    v += nrx_dpp<0x141>(v);
+    v += nrx_dpp<0x140>(v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return upper ? r2 + r3 : r0 + r1;
+}
+
+template <int R, int V, int G = 64>
+__device__ __forceinline__ float row_dot(const RowRegs<R, V>& a, const RowRegs<R, V>& b, bool upper = false) {
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int j = 0; j < V; ++j) s += a.v[r][j] * b.v[r][j];
-    return nrx_wave_sum(s);
+    return G == 64 ? nrx_wave_sum(s) : nrx_half_wave_sum(s, upper);
 }
 
 // x0p: the layer-0 input when the stack starts from a later x_l (DCNLayer.forward(x_l, x_0), dcn_arch.py:14-30); null = x.
-template <int R, int V>
+template <int R, int V, int G = 64>
 __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_fwd_kernel(const float* __restrict__ x, int64_t x_ld, const float* __restrict__ x0p,
                                                                int64_t x0_ld, int64_t batch, int D, int NL,
                                                                const float* __restrict__ w, const float* __restrict__ bvec,
@@ -230,10 +245,15 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_fwd_kernel(const float* __re
         s_b[i] = (c < D) ? bvec[l * (int64_t)D + c] : 0.f;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
+    constexpr int RPW = 64 / G;                            // rows per wavefront
+    const int lane = threadIdx.x & (G - 1);
+    const bool upper = G == 32 && (threadIdx.x & 32) != 0;
     const int64_t wave = (int64_t)blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (NRX_BLOCK / 64);
-    for (int64_t row = wave; row < batch; row += nwaves) {
+    for (int64_t r0 = wave * RPW; r0 < batch; r0 += nwaves * RPW) {
+        const int64_t rr = r0 + (upper ? 1 : 0);
+        const bool live = rr < batch;                      // an odd batch leaves the last wavefront's upper half without a row
+        const int64_t row = live ? rr : batch - 1;
         RowRegs<R, V> x0, xl;
         row_load<R, V>(xl, x + row * x_ld, D, lane);
         if (x0p != nullptr) row_load<R, V>(x0, x0p + row * x0_ld, D, lane);
@@ -242,13 +262,13 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_fwd_kernel(const float* __re
             RowRegs<R, V> wl, bl;
             row_load<R, V>(wl, s_w + l * Dp, Dp, lane);
             row_load<R, V>(bl, s_b + l * Dp, Dp, lane);
-            const float s = row_dot<R, V>(xl, wl);
+            const float s = row_dot<R, V, G>(xl, wl, upper);
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int j = 0; j < V; ++j) xl.v[r][j] = x0.v[r][j] * s + bl.v[r][j] + xl.v[r][j];
         }
-        row_store<R, V>(xl, out + row * out_ld, D, lane);
+        if (live) row_store<R, V>(xl, out + row * out_ld, D, lane);
     }
 }
 
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_fwd_kernel(const float* __re
 // tail was ~60 of the kernel's 99 us; 256 blocks cut the atomics eightfold while 16 waves per block keep 4 per SIMD.
 // (3+ layers need more than the 128 VGPRs a 1024-thread block allows: 512-thread blocks, two per CU.)
 // SEP: the stack starts from x (= x_l) with a separate layer-0 input x0p; its gradient goes to g_x0 (x's to g_x).
-template <int R, int V, int NLR, int DCN_BWD_BLOCK, bool SEP = false>
+template <int R, int V, int NLR, int DCN_BWD_BLOCK, bool SEP = false, int G = 64>
 __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* __restrict__ x, int64_t x_ld, int64_t batch, int D, int NL,
                                                                const float* __restrict__ w, const float* __restrict__ bvec,
                                                                const float* __restrict__ g_out, int64_t g_out_ld,
@@ -286,9 +306,12 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
         s_gb[i] = 0.f;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * (DCN_BWD_BLOCK / 64) + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * (DCN_BWD_BLOCK / 64);
+    static_assert(G == 64 || (G == 32 && R == 1), "two rows per wavefront only for rows that fit 32 lanes");
+    constexpr int RPW = 64 / G;                            // rows per wavefront (G = 32: lanes 0..31 / 32..63 hold one row each)
+    const int lane = threadIdx.x & (G - 1);
+    const bool upper = G == 32 && (threadIdx.x & 32) != 0;
+    const int64_t wave = ((int64_t)blockIdx.x * (DCN_BWD_BLOCK / 64) + (threadIdx.x >> 6)) * RPW;      // first row of this wavefront
+    const int64_t nwaves = (int64_t)gridDim.x * (DCN_BWD_BLOCK / 64) * RPW;                            // row stride of the walk
     constexpr int NA = NLR > 0 ? NLR : 1;
     float acc_w[NA][R][V], acc_b[NA][R][V];
 #pragma unroll
@@ -300,17 +323,31 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
 
     // software pipeline: the next row's x0 / g loads are issued before this row's five reductions and the
     // store, so the memory system is never idle behind the arithmetic of a wave
+    // (G = 32: an odd batch leaves the last wavefront's upper half without a row -- it re-reads the last row with a zero
+    // upstream gradient, so nothing it computes contributes, and skips its stores)
+    auto row_of = [&](int64_t r0) { const int64_t rr = r0 + (upper ? 1 : 0); return rr < batch ? rr : batch - 1; };
+    auto load_g = [&](RowRegs<R, V>& gr, int64_t r0) {
+        row_load<R, V>(gr, g_out + row_of(r0) * g_out_ld, D, lane);
+        if (G == 32 && r0 + (upper ? 1 : 0) >= batch) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int j = 0; j < V; ++j) gr.v[r][j] = 0.f;
+        }
+    };
     RowRegs<R, V> x0n, gn;
     if (wave < batch) {
-        row_load<R, V>(x0n, (SEP ? x0p + wave * x0_ld : x + wave * x_ld), D, lane);
-        row_load<R, V>(gn, g_out + wave * g_out_ld, D, lane);
+        row_load<R, V>(x0n, (SEP ? x0p + row_of(wave) * x0_ld : x + row_of(wave) * x_ld), D, lane);
+        load_g(gn, wave);
     }
-    for (int64_t row = wave; row < batch; row += nwaves) {
+    for (int64_t rw = wave; rw < batch; rw += nwaves) {
+        const int64_t row = row_of(rw);
+        const bool live = rw + (upper ? 1 : 0) < batch;
         RowRegs<R, V> x0 = x0n, g = gn, gx0, xs;
         if (SEP) row_load<R, V>(xs, x + row * x_ld, D, lane);      // the stack's first input x_l (not prefetched)
-        if (row + nwaves < batch) {
-            row_load<R, V>(x0n, (SEP ? x0p + (row + nwaves) * x0_ld : x + (row + nwaves) * x_ld), D, lane);
-            row_load<R, V>(gn, g_out + (row + nwaves) * g_out_ld, D, lane);
+        if (rw + nwaves < batch) {
+            row_load<R, V>(x0n, (SEP ? x0p + row_of(rw + nwaves) * x0_ld : x + row_of(rw + nwaves) * x_ld), D, lane);
+            load_g(gn, rw + nwaves);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -324,7 +361,7 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
                 float s = 0.f;
                 for (int t = 0; t <= l; ++t) {          // recompute x_l, s_l from the stack's input
                     row_load<R, V>(wl, s_w + t * Dp, Dp, lane);
-                    s = row_dot<R, V>(xl, wl);
+                    s = row_dot<R, V, G>(xl, wl, upper);
                     if (t < l) {
                         row_load<R, V>(bl, s_b + t * Dp, Dp, lane);
 #pragma unroll
@@ -333,7 +370,7 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
                             for (int j = 0; j < V; ++j) xl.v[r][j] = x0.v[r][j] * s + bl.v[r][j] + xl.v[r][j];
                     }
                 }
-                const float gs = row_dot<R, V>(g, x0);
+                const float gs = row_dot<R, V, G>(g, x0, upper);
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -342,7 +379,7 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
                             acc_b[NLR > 0 ? NLR - 1 - li : 0][r][j] += g.v[r][j];
                             acc_w[NLR > 0 ? NLR - 1 - li : 0][r][j] += gs * xl.v[r][j];
                         } else {
-                            const int c = (r * 64 + lane) * V + j;
+                            const int c = (r * G + lane) * V + j;
                             if (c < D) {
                                 atomicAdd(&s_gb[l * Dp + c], g.v[r][j]);
                                 atomicAdd(&s_gw[l * Dp + c], gs * xl.v[r][j]);
@@ -354,36 +391,55 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
             }
         }
         if (SEP) {
-            row_store<R, V>(gx0, g_x0 + row * g_x0_ld, D, lane);
+            if (live) row_store<R, V>(gx0, g_x0 + row * g_x0_ld, D, lane);
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int j = 0; j < V; ++j) g.v[r][j] += gx0.v[r][j];
         }
-        row_store<R, V>(g, g_x + row * g_x_ld, D, lane);
+        if (live) row_store<R, V>(g, g_x + row * g_x_ld, D, lane);
     }
     if (NLR > 0) {
+        // Block-level sum of the per-wavefront accumulators, layer by layer: every wavefront (every half, with two rows per
+        // wavefront) writes its partial row to its own LDS slab, then the block adds the slabs in a fixed order.  (The first
+        // version did this with ds_add_f32 from all 16 wavefronts onto the same addresses: 26 us per launch, whatever the batch --
+        // a timestamped run at B = 16 showed 1 us of staging, 1.3 us of rows and 26 us of LDS atomics.)
+        constexpr int SLABS = (DCN_BWD_BLOCK / 64) * RPW;
+        float* s_slab = s_gb + NL * Dp;                      // [SLABS][2][Dp]
+        const int slab = (threadIdx.x >> 6) * RPW + (upper ? 1 : 0);
 #pragma unroll
-        for (int l = 0; l < NA; ++l)
+        for (int l = 0; l < NA; ++l) {
+            __syncthreads();                                 // the previous layer's slabs have been consumed
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
-                    const int c = (r * 64 + lane) * V + j;
-                    if (c < D) {
-                        atomicAdd(&s_gb[l * Dp + c], acc_b[l][r][j]);
-                        atomicAdd(&s_gw[l * Dp + c], acc_w[l][r][j]);
+                    const int c = (r * G + lane) * V + j;
+                    if (c < Dp) {
+                        s_slab[(slab * 2 + 0) * Dp + c] = acc_w[l][r][j];
+                        s_slab[(slab * 2 + 1) * Dp + c] = acc_b[l][r][j];
                     }
                 }
+            __syncthreads();
+            for (int i = threadIdx.x; i < 2 * Dp; i += DCN_BWD_BLOCK) {
+                const int which = i >= Dp, c = i - which * Dp;
+                float sum = 0.f;
+#pragma unroll 8
+                for (int sidx = 0; sidx < SLABS; ++sidx) sum += s_slab[(sidx * 2 + which) * Dp + c];
+                (which ? s_gb : s_gw)[l * Dp + c] = sum;
+            }
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < NL * Dp; i += DCN_BWD_BLOCK) {
         const int l = i / Dp, c = i - l * Dp;
+#ifndef NRX_PROBE_NOFLUSH
         if (c < D) {
             unsafeAtomicAdd(&g_w[l * (int64_t)D + c], s_gw[i]);
             unsafeAtomicAdd(&g_b[l * (int64_t)D + c], s_gb[i]);
         }
+#endif
     }
 }
 
@@ -679,6 +735,13 @@ extern "C" int nrx_dcn_v1_fwd(const float* x, int64_t x_ld, const float* x0, int
     const int R = (dim + 64 * V - 1) / (64 * V);
     const size_t smem = (size_t)2 * n_layers * ((dim + 3) & ~3) * sizeof(float);
     NRX_REQUIRE(smem <= 64 * 1024, "nrx_dcn_v1_fwd: n_layers*dim too large for the LDS stage");
+    if (vec && dim <= 128) {          // rows of <= 32 float4 chunks (the reference's own DCN width is 112): two rows per wavefront
+        const unsigned grid2 = stream_grid((batch + 1) / 2, NRX_BLOCK / 64);
+        hipLaunchKernelGGL((dcn_v1_fwd_kernel<1, 4, 32>), dim3(grid2), dim3(NRX_BLOCK), smem, reinterpret_cast<hipStream_t>(stream),
+                           x, x_ld, x0, x0_ld, batch, dim, n_layers, w, b, out, out_ld);
+        NRX_LAUNCH_CHECK("nrx_dcn_v1_fwd(half-wave rows)");
+        return NRX_OK;
+    }
     const unsigned grid = stream_grid(batch, NRX_BLOCK / 64);
     NRX_RSWITCH(R, V, { hipLaunchKernelGGL((dcn_v1_fwd_kernel<RR, VV>), dim3(grid), dim3(NRX_BLOCK), smem, reinterpret_cast<hipStream_t>(stream),
                                            x, x_ld, x0, x0_ld, batch, dim, n_layers, w, b, out, out_ld); });
@@ -701,10 +764,12 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
                      (x0 == nullptr || ((x0_ld & 3) == 0 && (g_x0_ld & 3) == 0 && nrx_aligned16(x0) && nrx_aligned16(g_x0)));
     const int V = vec ? 4 : 1;
     const int R = (dim + 64 * V - 1) / (64 * V);
-    const size_t smem = (size_t)4 * n_layers * ((dim + 3) & ~3) * sizeof(float);
-    NRX_REQUIRE(smem <= 128 * 1024, "nrx_dcn_v1_bwd: n_layers*dim too large for the LDS stage");
     // register accumulation of gw/gb when the accumulators fit (n_layers <= 4 and <= 2 chunks per lane)
     const int nlr = (n_layers >= 1 && n_layers <= 4 && R <= 2) ? n_layers : 0;
+    // w, b, gw, gb [n_layers][Dp] (+ with register accumulation the per-wavefront slabs of the block-level gw / gb sum:
+    // [<= 16 slabs][2][Dp])
+    const size_t smem = ((size_t)4 * n_layers + (nlr > 0 ? 32 : 0)) * ((dim + 3) & ~3) * sizeof(float);
+    NRX_REQUIRE(smem <= 128 * 1024, "nrx_dcn_v1_bwd: n_layers*dim too large for the LDS stage");
 #define NRX_DCN_BWD(NLR_)                                                                                           \
     NRX_RSWITCH(R, V, {                                                                                             \
         constexpr int DCN_BWD_BLOCK = (NLR_ >= 1 && NLR_ <= 2) ? 1024 : 512;                                        \
@@ -717,6 +782,31 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
                            batch, dim, n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b,                      \
                            (const float*)nullptr, (int64_t)0, (float*)nullptr, (int64_t)0);                         \
     })
+    if (vec && dim <= 128) {          // two rows per wavefront (see nrx_dcn_v1_fwd)
+        const int64_t pairs = (batch + 1) / 2;
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define NRX_DCN_BWD_H(NLR_, BLK_, SEP_)                                                                             \
+        {                                                                                                           \
+            unsigned grid = (unsigned)((pairs + BLK_ / 64 - 1) / (BLK_ / 64));                                      \
+            if (grid > 256u * (1024 / BLK_)) grid = 256u * (1024 / BLK_);                                           \
+            auto kern = dcn_v1_bwd_kernel<1, 4, NLR_, BLK_, SEP_, 32>;                                              \
+            if (smem > 64 * 1024)                                                                                   \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(BLK_), smem, st, x, x_ld, batch, dim, n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, \
+                               g_w, g_b, x0, x0_ld, g_x0, g_x0_ld);                                                 \
+        }
+        if (x0 != nullptr) NRX_DCN_BWD_H(0, 512, true)
+        else switch (nlr) {
+            case 1: NRX_DCN_BWD_H(1, 1024, false) break;
+            case 2: NRX_DCN_BWD_H(2, 1024, false) break;
+            case 3: NRX_DCN_BWD_H(3, 512, false) break;
+            case 4: NRX_DCN_BWD_H(4, 512, false) break;
+            default: NRX_DCN_BWD_H(0, 512, false) break;
+        }
+#undef NRX_DCN_BWD_H
+        NRX_LAUNCH_CHECK("nrx_dcn_v1_bwd(half-wave rows)");
+        return NRX_OK;
+    }
     if (x0 != nullptr) {      // separate layer-0 input: the generic (any n_layers) body with the SEP loads / stores
         NRX_RSWITCH(R, V, {
             unsigned grid = (unsigned)((batch + 512 / 64 - 1) / (512 / 64));
