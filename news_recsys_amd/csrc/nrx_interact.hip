@@ -767,8 +767,9 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
     // register accumulation of gw/gb when the accumulators fit (n_layers <= 4 and <= 2 chunks per lane)
     const int nlr = (n_layers >= 1 && n_layers <= 4 && R <= 2) ? n_layers : 0;
     // w, b, gw, gb [n_layers][Dp] (+ with register accumulation the per-wavefront slabs of the block-level gw / gb sum:
-    // [<= 16 slabs][2][Dp])
-    const size_t smem = ((size_t)4 * n_layers + (nlr > 0 ? 32 : 0)) * ((dim + 3) & ~3) * sizeof(float);
+    // [slabs][2][Dp], one slab per wavefront of a block of up to 1024 threads -- two per wavefront in the two-rows-per-wavefront form)
+    const int slabs = (vec && dim <= 128) ? 32 : 16;
+    const size_t smem = ((size_t)4 * n_layers + (nlr > 0 ? 2 * slabs : 0)) * ((dim + 3) & ~3) * sizeof(float);
     NRX_REQUIRE(smem <= 128 * 1024, "nrx_dcn_v1_bwd: n_layers*dim too large for the LDS stage");
 #define NRX_DCN_BWD(NLR_)                                                                                           \
     NRX_RSWITCH(R, V, {                                                                                             \
@@ -795,7 +796,8 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
             hipLaunchKernelGGL(kern, dim3(grid), dim3(BLK_), smem, st, x, x_ld, batch, dim, n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, \
                                g_w, g_b, x0, x0_ld, g_x0, g_x0_ld);                                                 \
         }
-        if (x0 != nullptr) NRX_DCN_BWD_H(0, 512, true)
+        if (x0 != nullptr && n_layers == 1) NRX_DCN_BWD_H(1, 1024, true)      // DCNLayer.forward(x_l, x_0): one layer, register accumulation
+        else if (x0 != nullptr) NRX_DCN_BWD_H(0, 512, true)
         else switch (nlr) {
             case 1: NRX_DCN_BWD_H(1, 1024, false) break;
             case 2: NRX_DCN_BWD_H(2, 1024, false) break;
@@ -805,6 +807,19 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
         }
 #undef NRX_DCN_BWD_H
         NRX_LAUNCH_CHECK("nrx_dcn_v1_bwd(half-wave rows)");
+        return NRX_OK;
+    }
+    if (x0 != nullptr && n_layers == 1 && R <= 2) {      // DCNLayer.forward(x_l, x_0), one layer: the register-accumulation body
+        NRX_RSWITCH(R, V, {
+            unsigned grid = (unsigned)((batch + 1024 / 64 - 1) / (1024 / 64));
+            if (grid > 256u) grid = 256u;
+            auto kern = dcn_v1_bwd_kernel<(RR <= 2 ? RR : 2), VV, 1, 1024, true>;
+            if (smem > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, batch, dim,
+                               n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b, x0, x0_ld, g_x0, g_x0_ld);
+        });
+        NRX_LAUNCH_CHECK("nrx_dcn_v1_bwd(x0, one layer)");
         return NRX_OK;
     }
     if (x0 != nullptr) {      // separate layer-0 input: the generic (any n_layers) body with the SEP loads / stores
