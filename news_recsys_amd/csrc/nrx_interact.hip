@@ -284,7 +284,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v1_fwd_kernel(const float* __re
 // tail was ~60 of the kernel's 99 us; 256 blocks cut the atomics eightfold while 16 waves per block keep 4 per SIMD.
 // (3+ layers need more than the 128 VGPRs a 1024-thread block allows: 512-thread blocks, two per CU.)
 // SEP: the stack starts from x (= x_l) with a separate layer-0 input x0p; its gradient goes to g_x0 (x's to g_x).
-template <int R, int V, int NLR, int DCN_BWD_BLOCK, bool SEP = false, int G = 64>
+template <int R, int V, int NLR, int DCN_BWD_BLOCK, bool SEP = false, int G = 64, bool ATOMIC = false>
 __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* __restrict__ x, int64_t x_ld, int64_t batch, int D, int NL,
                                                                const float* __restrict__ w, const float* __restrict__ bvec,
                                                                const float* __restrict__ g_out, int64_t g_out_ld,
@@ -305,6 +305,9 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
         s_gw[i] = 0.f;
         s_gb[i] = 0.f;
     }
+    float* const s_gslab = s_gb + NL * Dp;                 // NLR == 0: [slabs][NL][2][Dp], one slab per wavefront (half)
+    if (NLR == 0 && !ATOMIC)
+        for (int i = threadIdx.x; i < (DCN_BWD_BLOCK / 64) * (64 / G) * NL * 2 * Dp; i += DCN_BWD_BLOCK) s_gslab[i] = 0.f;
     __syncthreads();
     static_assert(G == 64 || (G == 32 && R == 1), "two rows per wavefront only for rows that fit 32 lanes");
     constexpr int RPW = 64 / G;                            // rows per wavefront (G = 32: lanes 0..31 / 32..63 hold one row each)
@@ -312,6 +315,7 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
     const bool upper = G == 32 && (threadIdx.x & 32) != 0;
     const int64_t wave = ((int64_t)blockIdx.x * (DCN_BWD_BLOCK / 64) + (threadIdx.x >> 6)) * RPW;      // first row of this wavefront
     const int64_t nwaves = (int64_t)gridDim.x * (DCN_BWD_BLOCK / 64) * RPW;                            // row stride of the walk
+    const int gslab = (threadIdx.x >> 6) * RPW + (upper ? 1 : 0);
     constexpr int NA = NLR > 0 ? NLR : 1;
     float acc_w[NA][R][V], acc_b[NA][R][V];
 #pragma unroll
@@ -379,10 +383,20 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
                             acc_b[NLR > 0 ? NLR - 1 - li : 0][r][j] += g.v[r][j];
                             acc_w[NLR > 0 ? NLR - 1 - li : 0][r][j] += gs * xl.v[r][j];
                         } else {
+                            // generic depth / width: the wavefront (half) owns an LDS slab [NL][2][Dp] and adds into it with plain
+                            // loads and stores -- the same lane always touches the same words, nobody else does (this was a pair of
+                            // ds_add_f32 per element per row onto addresses shared by the whole block: D=320 L=5 1 090 us)
+                            // (ATOMIC: the last resort when NL x D is too large for the slabs)
                             const int c = (r * G + lane) * V + j;
                             if (c < D) {
-                                atomicAdd(&s_gb[l * Dp + c], g.v[r][j]);
-                                atomicAdd(&s_gw[l * Dp + c], gs * xl.v[r][j]);
+                                if (ATOMIC) {
+                                    atomicAdd(&s_gb[l * Dp + c], g.v[r][j]);
+                                    atomicAdd(&s_gw[l * Dp + c], gs * xl.v[r][j]);
+                                } else {
+                                    float* my = s_gslab + ((size_t)gslab * NL + l) * 2 * Dp;
+                                    my[c] += gs * xl.v[r][j];
+                                    my[Dp + c] += g.v[r][j];
+                                }
                             }
                         }
                         gx0.v[r][j] += g.v[r][j] * s;
@@ -429,6 +443,15 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
                 for (int sidx = 0; sidx < SLABS; ++sidx) sum += s_slab[(sidx * 2 + which) * Dp + c];
                 (which ? s_gb : s_gw)[l * Dp + c] = sum;
             }
+        }
+    } else if (!ATOMIC) {
+        __syncthreads();
+        constexpr int GSLABS = (DCN_BWD_BLOCK / 64) * RPW;
+        for (int i = threadIdx.x; i < NL * 2 * Dp; i += DCN_BWD_BLOCK) {
+            const int l = i / (2 * Dp), rem = i - l * 2 * Dp, which = rem >= Dp, c = rem - which * Dp;
+            float sum = 0.f;
+            for (int sidx = 0; sidx < GSLABS; ++sidx) sum += s_gslab[((size_t)sidx * NL + l) * 2 * Dp + rem];
+            (which ? s_gb : s_gw)[l * Dp + c] = sum;
         }
     }
     __syncthreads();
@@ -769,8 +792,13 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
     // w, b, gw, gb [n_layers][Dp] (+ with register accumulation the per-wavefront slabs of the block-level gw / gb sum:
     // [slabs][2][Dp], one slab per wavefront of a block of up to 1024 threads -- two per wavefront in the two-rows-per-wavefront form)
     const int slabs = (vec && dim <= 128) ? 32 : 16;
-    const size_t smem = ((size_t)4 * n_layers + (nlr > 0 ? 2 * slabs : 0)) * ((dim + 3) & ~3) * sizeof(float);
+    const size_t Dp = (size_t)((dim + 3) & ~3);
+    size_t smem = ((size_t)4 * n_layers + (nlr > 0 ? 2 * slabs : 0)) * Dp * sizeof(float);
     NRX_REQUIRE(smem <= 128 * 1024, "nrx_dcn_v1_bwd: n_layers*dim too large for the LDS stage");
+    // generic depth / width (no register accumulation): 256-thread blocks whose 4 wavefronts (8 halves) each own an LDS slab
+    // [n_layers][2][Dp]; when even that does not fit, the per-row LDS-atomic body at 512 threads
+    const size_t gen_smem = ((size_t)4 * n_layers + (size_t)(vec && dim <= 128 ? 8 : 4) * n_layers * 2) * Dp * sizeof(float);
+    const bool gen_slabs = gen_smem <= 128 * 1024;
 #define NRX_DCN_BWD(NLR_)                                                                                           \
     NRX_RSWITCH(R, V, {                                                                                             \
         constexpr int DCN_BWD_BLOCK = (NLR_ >= 1 && NLR_ <= 2) ? 1024 : 512;                                        \
@@ -789,7 +817,7 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
 #define NRX_DCN_BWD_H(NLR_, BLK_, SEP_)                                                                             \
         {                                                                                                           \
             unsigned grid = (unsigned)((pairs + BLK_ / 64 - 1) / (BLK_ / 64));                                      \
-            if (grid > 256u * (1024 / BLK_)) grid = 256u * (1024 / BLK_);                                           \
+            if (grid > 256u * (BLK_ >= 512 ? 1024 / BLK_ : 2)) grid = 256u * (BLK_ >= 512 ? 1024 / BLK_ : 2);                  \
             auto kern = dcn_v1_bwd_kernel<1, 4, NLR_, BLK_, SEP_, 32>;                                              \
             if (smem > 64 * 1024)                                                                                   \
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
@@ -797,13 +825,13 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
                                g_w, g_b, x0, x0_ld, g_x0, g_x0_ld);                                                 \
         }
         if (x0 != nullptr && n_layers == 1) NRX_DCN_BWD_H(1, 1024, true)      // DCNLayer.forward(x_l, x_0): one layer, register accumulation
-        else if (x0 != nullptr) NRX_DCN_BWD_H(0, 512, true)
+        else if (x0 != nullptr) { smem = gen_smem; NRX_DCN_BWD_H(0, 256, true) }
         else switch (nlr) {
             case 1: NRX_DCN_BWD_H(1, 1024, false) break;
             case 2: NRX_DCN_BWD_H(2, 1024, false) break;
             case 3: NRX_DCN_BWD_H(3, 512, false) break;
             case 4: NRX_DCN_BWD_H(4, 512, false) break;
-            default: NRX_DCN_BWD_H(0, 512, false) break;
+            default: { smem = gen_smem; NRX_DCN_BWD_H(0, 256, false) } break;
         }
 #undef NRX_DCN_BWD_H
         NRX_LAUNCH_CHECK("nrx_dcn_v1_bwd(half-wave rows)");
@@ -822,16 +850,28 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
         NRX_LAUNCH_CHECK("nrx_dcn_v1_bwd(x0, one layer)");
         return NRX_OK;
     }
-    if (x0 != nullptr) {      // separate layer-0 input: the generic (any n_layers) body with the SEP loads / stores
-        NRX_RSWITCH(R, V, {
-            unsigned grid = (unsigned)((batch + 512 / 64 - 1) / (512 / 64));
-            if (grid > 512u) grid = 512u;
-            auto kern = dcn_v1_bwd_kernel<RR, VV, 0, 512, true>;
-            if (smem > 64 * 1024)
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, batch, dim,
-                               n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b, x0, x0_ld, g_x0, g_x0_ld);
-        });
+#define NRX_DCN_BWD_GEN(SEP_)                                                                                       \
+    NRX_RSWITCH(R, V, {                                                                                             \
+        if (gen_slabs) {                                                                                            \
+            unsigned grid = (unsigned)((batch + 256 / 64 - 1) / (256 / 64));                                        \
+            if (grid > 512u) grid = 512u;                                                                           \
+            auto kern = dcn_v1_bwd_kernel<RR, VV, 0, 256, SEP_, 64, false>;                                         \
+            if (gen_smem > 64 * 1024)                                                                               \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gen_smem); \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), gen_smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, batch, dim, \
+                               n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b, x0, x0_ld, g_x0, g_x0_ld);   \
+        } else {                                                                                                    \
+            unsigned grid = (unsigned)((batch + 512 / 64 - 1) / (512 / 64));                                        \
+            if (grid > 512u) grid = 512u;                                                                           \
+            auto kern = dcn_v1_bwd_kernel<RR, VV, 0, 512, SEP_, 64, true>;                                          \
+            if (smem > 64 * 1024)                                                                                   \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, batch, dim, \
+                               n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b, x0, x0_ld, g_x0, g_x0_ld);   \
+        }                                                                                                           \
+    })
+    if (x0 != nullptr) {      // separate layer-0 input, more than one layer (or a wide row): the generic body
+        NRX_DCN_BWD_GEN(true);
         NRX_LAUNCH_CHECK("nrx_dcn_v1_bwd(x0)");
         return NRX_OK;
     }
@@ -840,9 +880,10 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
         case 2: NRX_DCN_BWD(2); break;
         case 3: NRX_DCN_BWD(3); break;
         case 4: NRX_DCN_BWD(4); break;
-        default: NRX_DCN_BWD(0); break;
+        default: NRX_DCN_BWD_GEN(false); break;
     }
 #undef NRX_DCN_BWD
+#undef NRX_DCN_BWD_GEN
     NRX_LAUNCH_CHECK("nrx_dcn_v1_bwd");
     return NRX_OK;
 }

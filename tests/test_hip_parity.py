@@ -503,7 +503,8 @@ def test_embed_backward_dense_grads_vs_oracle(case):
         assert np.all(t.grad[0].detach().cpu().numpy() == 0)
 
 
-@pytest.mark.parametrize("B,D,NL", [(1, 4, 1), (100, 320, 2), (257, 112, 3), (65, 37, 3), (31, 1000, 8), (50, 2048, 1), (9, 6, 0)])
+@pytest.mark.parametrize("B,D,NL", [(1, 4, 1), (100, 320, 2), (257, 112, 3), (65, 37, 3), (31, 1000, 8), (50, 2048, 1), (9, 6, 0),
+                                    (41, 96, 6), (70, 320, 5), (33, 640, 2)])      # deeper / wider than the register-accumulation forms
 def test_dcn_v1_vs_oracle(B, D, NL):
     rng = np.random.default_rng(B + D)
     x = rng.standard_normal((B, D)).astype(np.float32)
