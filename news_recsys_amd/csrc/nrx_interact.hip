@@ -37,28 +37,42 @@ __global__ __launch_bounds__(NRX_BLOCK) void bag_pool_fwd_kernel(const float* __
 }
 
 // one block per sample: den once, then the [L, D] slab
+// One wavefront per sample (the first version used a 256-thread block per sample with two barriers, scalar stores and a division
+// per element: 94.7 us for [65536, 50, 16], 2.35 TB/s; this form: float4 stores of g / den * mask over the sample's L x D floats).
+template <bool VEC>
 __global__ __launch_bounds__(NRX_BLOCK) void bag_pool_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ mask,
                                                                  int64_t batch, int L, int D, float* __restrict__ g_emb) {
-    __shared__ float s_den;
-    for (int64_t b = blockIdx.x; b < batch; b += gridDim.x) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (NRX_BLOCK / 64);
+    const int n = L * D;
+    for (int64_t b = wave; b < batch; b += nwaves) {
+        float den = (float)L;
         if (mask != nullptr) {
-            if (threadIdx.x < NRX_WAVE) {
-                float part = 0.f;
-                for (int l = threadIdx.x; l < L; l += NRX_WAVE) part += mask[b * (int64_t)L + l];
-                part = nrx_wave_sum(part);
-                if (threadIdx.x == 0) s_den = part + 1e-8f;
+            float part = 0.f;
+            for (int l = lane; l < L; l += NRX_WAVE) part += mask[b * (int64_t)L + l];
+            den = nrx_wave_sum(part) + 1e-8f;
+        }
+        const float* gb = g_out + b * (int64_t)D;
+        const float* mb = mask ? mask + b * (int64_t)L : nullptr;
+        float* ob = g_emb + b * (int64_t)n;
+        if (VEC) {
+            const unsigned q = (unsigned)D >> 2;            // float4 chunks per bag position
+            for (unsigned e4 = lane; e4 < (unsigned)n >> 2; e4 += NRX_WAVE) {
+                const unsigned l = e4 / q, d = (e4 - l * q) * 4;
+                const float4 g = *reinterpret_cast<const float4*>(gb + d);
+                const float m = mb ? mb[l] : 1.0f;
+                float4 o = make_float4(g.x / den, g.y / den, g.z / den, g.w / den);
+                if (mb) o = make_float4(o.x * m, o.y * m, o.z * m, o.w * m);
+                *reinterpret_cast<float4*>(ob + (size_t)e4 * 4) = o;
             }
-            __syncthreads();
+        } else {
+            for (int e = lane; e < n; e += NRX_WAVE) {
+                const int l = e / D, d = e - l * D;
+                const float g = gb[d] / den;
+                ob[e] = mb ? g * mb[l] : g;
+            }
         }
-        const float den = mask ? s_den : (float)L;
-        const int n = L * D;
-        for (int e = threadIdx.x; e < n; e += NRX_BLOCK) {
-            const int l = e / D;
-            const int d = e - l * D;
-            const float g = g_out[b * (int64_t)D + d] / den;
-            g_emb[b * (int64_t)n + e] = mask ? g * mask[b * (int64_t)L + l] : g;
-        }
-        __syncthreads();
     }
 }
 
@@ -707,8 +721,11 @@ extern "C" int nrx_bag_pool_bwd(const float* g_out, const float* mask, int64_t b
                                 int32_t dim, float* g_emb, void* stream) {
     NRX_REQUIRE(g_out && g_emb && batch >= 0 && bag_len >= 1 && dim >= 1, "nrx_bag_pool_bwd: bad argument");
     if (batch == 0) return NRX_OK;
-    hipLaunchKernelGGL(bag_pool_bwd_kernel, dim3(stream_grid(batch, 1)), dim3(NRX_BLOCK), 0,
-                       reinterpret_cast<hipStream_t>(stream), g_out, mask, batch, bag_len, dim, g_emb);
+    const bool vec = (dim & 3) == 0 && nrx_aligned16(g_out) && nrx_aligned16(g_emb);
+    if (vec) hipLaunchKernelGGL(bag_pool_bwd_kernel<true>, dim3(stream_grid(batch, NRX_BLOCK / 64)), dim3(NRX_BLOCK), 0,
+                                reinterpret_cast<hipStream_t>(stream), g_out, mask, batch, bag_len, dim, g_emb);
+    else hipLaunchKernelGGL(bag_pool_bwd_kernel<false>, dim3(stream_grid(batch, NRX_BLOCK / 64)), dim3(NRX_BLOCK), 0,
+                            reinterpret_cast<hipStream_t>(stream), g_out, mask, batch, bag_len, dim, g_emb);
     NRX_LAUNCH_CHECK("nrx_bag_pool_bwd");
     return NRX_OK;
 }
