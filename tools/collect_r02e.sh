@@ -40,4 +40,5 @@ for D in 320 512 112; do
 done
 } > $F/dcn_v2_fwd_settled_kernel_stats.txt 2>&1
 python3 tools/bench_ops.py > $F/bench_ops.log 2>&1
+{ python3 tools/probe_dcn1_bwd.py 16 4096 65536; SEP=1 python3 tools/probe_dcn1_bwd.py 65536; python3 tools/probe_small_bwd.py; for w in c2 c4 c5; do python3 tools/profile_plan.py $w 300 uniform; NRX_PLAN_SORT=rocprim python3 tools/profile_plan.py $w 300 uniform; done; } 2>&1 | grep "us" > $F/direct_kernel_timings.txt
 grep -v "amdgpu.ids\|Warning" $F/bench_ops.log | tail -40
