@@ -371,6 +371,40 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int j = 0; j < V; ++j) gx0.v[r][j] = 0.f;
+        if constexpr (NLR > 0) {
+            // forward once, keeping every layer's input x_l and scalar s_l in registers (the same arithmetic, in the same order, as
+            // the forward kernel), then top-down: NLR + NLR row reductions per row -- recomputing x_l for every layer took
+            // NLR (NLR + 1) / 2 + NLR of them (3 layers: 6 instead of 9)
+            RowRegs<R, V> xls[NLR], wl, bl;
+            float ss[NLR];
+            xls[0] = SEP ? xs : x0;
+#pragma unroll
+            for (int t = 0; t < NLR; ++t) {
+                row_load<R, V>(wl, s_w + t * Dp, Dp, lane);
+                ss[t] = row_dot<R, V, G>(xls[t], wl, upper);
+                if (t + 1 < NLR) {
+                    row_load<R, V>(bl, s_b + t * Dp, Dp, lane);
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int j = 0; j < V; ++j) xls[t + 1 < NLR ? t + 1 : t].v[r][j] = x0.v[r][j] * ss[t] + bl.v[r][j] + xls[t].v[r][j];
+                }
+            }
+#pragma unroll
+            for (int l = NLR - 1; l >= 0; --l) {
+                row_load<R, V>(wl, s_w + l * Dp, Dp, lane);
+                const float gs = row_dot<R, V, G>(g, x0, upper);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        acc_b[l][r][j] += g.v[r][j];
+                        acc_w[l][r][j] += gs * xls[l].v[r][j];
+                        gx0.v[r][j] += g.v[r][j] * ss[l];
+                        g.v[r][j] += gs * wl.v[r][j];
+                    }
+            }
+        } else {
 #pragma unroll
         for (int li = 0; li < (NLR > 0 ? NLR : 1); ++li) {
             // generic path walks the runtime layer count with the same body
@@ -417,6 +451,7 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
                         g.v[r][j] += gs * wl.v[r][j];
                     }
             }
+        }
         }
         if (SEP) {
             if (live) row_store<R, V>(gx0, g_x0 + row * g_x0_ld, D, lane);
