@@ -856,7 +856,7 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
         constexpr int DCN_BWD_BLOCK = (NLR_ >= 1 && NLR_ <= 2) ? 1024 : 512;                                        \
         unsigned grid = (unsigned)((batch + DCN_BWD_BLOCK / 64 - 1) / (DCN_BWD_BLOCK / 64));                         \
         if (grid > 256u * (1024 / DCN_BWD_BLOCK)) grid = 256u * (1024 / DCN_BWD_BLOCK);                              \
-        auto kern = dcn_v1_bwd_kernel<RR, VV, NLR_, DCN_BWD_BLOCK>;                                                 \
+        auto kern = dcn_v1_bwd_kernel<(RR <= 2 ? RR : 2), VV, NLR_, DCN_BWD_BLOCK>;      /* nlr > 0 only with R <= 2 */     \
         if (smem > 64 * 1024)                                                                                       \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(DCN_BWD_BLOCK), smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, \
