@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Whole training step of a ranker at the C2 scale: the package's `Deep` model (train_cf_deep.yaml schema) over 26 features x 1 M rows x 16
+with the reference's MLP head [416, 128, 128, 128, 64, 1], BCE loss, backward, optimizer, at B = 65 536 --
+  (a) `embeddings.sparse_grad: fused`: fused gather forward, deterministic row-sparse backward, fused row-sparse Adam on the tables,
+      AdamW on the MLP;
+  (b) the reference's own arrangement: dense table gradients + AdamW over every row (src/model/sort/deep/model.py:54-65);
+  (c) the module code restated in stock PyTorch-ROCm: one nn.Embedding(sparse=True) per feature + torch.cat + the same MLP,
+      torch.optim.SparseAdam on the tables / AdamW on the MLP (the closest stock equivalent of (a)).
+Prints ms per step and impressions/s.  usage: bench_full_step_c2.py [batch]"""
+import os, sys, tempfile, time
+import torch, torch.nn as nn, torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from news_recsys_amd import ops
+from news_recsys_amd.model.sort.deep.model import Deep
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+NF, ROWS, D = 26, 1_000_000, 16
+dev = "cuda:0"
+ops.set_index_check("deferred")
+names = [f"c{i:02d}" for i in range(NF)]
+user, item = names[:13], names[13:]
+ind = lambda xs: "".join(f"    - {x}\n" for x in xs)
+yaml_text = f"""name: deep
+paths:
+  out_basedir: "{tempfile.gettempdir()}"
+  user_history_path: ""
+features:
+  sparse_feature_names:
+{ind(names)}  dense_feature_names: []
+  array_feature_names: []
+  item_feature_names:
+{ind(item)}  user_feature_names:
+{ind(user)}  array_max_length: {{}}
+embeddings:
+  sparse_grad: SPARSE_GRAD
+  embedding_size:
+{''.join(f'    {n}: {D}' + chr(10) for n in names)}  embedding_table_size:
+{''.join(f'    {n}: {ROWS}' + chr(10) for n in names)}  share_emb_table_features: {{}}
+dataset:
+  batch_size: {B}
+  num_workers: 0
+  pin_memory: false
+train_hparams:
+  val_freq: 1
+  max_epoch: 1
+  lr: 1.0e-3
+  min_lr: 5.0e-6
+  lr_milestones: [4, 20]
+  max_step: 1000
+  device: "gpu"
+  gpus: [0]
+"""
+
+def make_model(mode):
+    path = os.path.join(tempfile.gettempdir(), f"nrx_c2_{mode}.yaml")
+    open(path, "w").write(yaml_text.replace("SPARSE_GRAD", mode))
+    torch.manual_seed(0)
+    m = Deep(path).to(dev)
+    m.setup("fit") if hasattr(m, "setup") else None
+    return m, m.configure_optimizers()["optimizer"]
+
+gen = torch.Generator(device=dev).manual_seed(1)
+batches = []
+for _ in range(4):
+    b = {n: torch.randint(1, ROWS, (B,), device=dev, generator=gen) for n in names}
+    b["label"] = (torch.rand(B, 1, device=dev, generator=gen) < 0.3).float()
+    batches.append(b)
+
+def timeit(step, n=30, warm=8):
+    for i in range(warm): step(batches[i % 4])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n): step(batches[i % 4])
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+def run_package(mode, label):
+    m, opt = make_model(mode)
+    def step(b):
+        opt.zero_grad(set_to_none=True)
+        out = m(b)
+        loss = F.binary_cross_entropy(out.view(-1), b["label"][:, 0])
+        loss.backward()
+        opt.step()
+    ms = timeit(step)
+    print(f"{label:78s} {ms:8.2f} ms/step  {B / ms / 1e3:7.2f} M impressions/s", flush=True)
+    del m, opt
+    torch.cuda.empty_cache()
+
+run_package("fused", "(a) this package, sparse_grad: fused (row-sparse backward + fused row-sparse Adam)")
+run_package("false", "(b) this package, the reference's arrangement (dense table grads + AdamW over all rows)")
+
+class Stock(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.tabs = nn.ModuleList([nn.Embedding(ROWS, D, padding_idx=0, sparse=True) for _ in range(NF)])
+        dims = [NF * D, 128, 128, 128, 64, 1]
+        layers = []
+        for i in range(len(dims) - 1):
+            layers.append(nn.Linear(dims[i], dims[i + 1]))
+            if i < len(dims) - 2: layers.append(nn.ReLU())
+        self.mlp = nn.Sequential(*layers)
+    def forward(self, b):
+        x = torch.cat([t(b[n]) for t, n in zip(self.tabs, names)], dim=1)
+        return torch.sigmoid(self.mlp(x))
+
+torch.manual_seed(0)
+sm = Stock().to(dev)
+o1 = torch.optim.SparseAdam([t.weight for t in sm.tabs], lr=1e-3)
+o2 = torch.optim.AdamW(sm.mlp.parameters(), lr=1e-3)
+def stock_step(b):
+    o1.zero_grad(set_to_none=True); o2.zero_grad(set_to_none=True)
+    loss = F.binary_cross_entropy(sm(b).view(-1), b["label"][:, 0])
+    loss.backward()
+    o1.step(); o2.step()
+ms = timeit(stock_step, n=10, warm=3)
+print(f"{'(c) stock PyTorch-ROCm: nn.Embedding(sparse=True) x 26 + cat + MLP, SparseAdam + AdamW':78s} {ms:8.2f} ms/step  {B / ms / 1e3:7.2f} M impressions/s", flush=True)
