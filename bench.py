@@ -516,7 +516,9 @@ def main():
             fwd, bwd = path.train_pass()
             f_ms = time_calls(lambda i: fwd[i % len(fwd)].run(), steps2)
             def both(i):
-                bwd[i % len(bwd)].plan_ahead()      # the backward's planning depends only on the ids: side stream, under the forward
+                # planning inline, after the forward: with nothing between forward and backward to hide it behind, running the
+                # planner on a side stream NEXT to the forward (PreparedSparseBackward.plan_ahead, what a training step with a
+                # dense model in between does) only makes the two contend: C2 283 vs 267 us, C4 384 vs 364 (tools/profile_fwd_bwd.py)
                 fwd[i % len(fwd)].run()
                 bwd[i % len(bwd)].run()
             fb_ms = time_calls(both, steps2)
@@ -532,8 +534,8 @@ def main():
             fwd_bwd = {"ms_per_step": fb_ms, "value": BATCH / (fb_ms * 1e-3), "unit": "impressions/s",
                        "forward_ms": f_ms, "backward_ms": fb_ms - f_ms,
                        "mode": "forward (training form: + FM field sums) + deterministic row-sparse backward: nrx_sparse_plan "
-                               "(table-segmented stable radix sort of the row bits, unique rows, segments; enqueued on a side stream next to the forward launch -- it "
-                               "depends only on the ids) + nrx_embed_bwd_sorted with the FM gradient folded in; "
+                               "(table-segmented stable radix sort of the row bits, unique rows, segments; inline here -- in a training step it is "
+                               "enqueued on a side stream at forward time and hidden behind the dense model) + nrx_embed_bwd_sorted with the FM gradient folded in; "
                                "upstream gradients g_out [B, width]" + (" and g_fm [B]" if path.fm else "") + " given; result = unique "
                                "(table,row) keys + summed row gradients on the device (what optim.FusedSparseAdam consumes)"}
             del fwd, bwd

@@ -14,14 +14,14 @@ dist = sys.argv[3] if len(sys.argv) > 3 else "uniform"
 path = bench.SingleGpuPath(wl, dev, 1, id_dist=dist)
 fwd, bwd = path.train_pass()
 for i in range(steps):
-    bwd[i % 2].plan_ahead()
+    if not os.environ.get("NO_PLAN_AHEAD"): bwd[i % 2].plan_ahead()
     fwd[i % 2].run()
     bwd[i % 2].run()
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
 for i in range(steps):
-    bwd[i % 2].plan_ahead()
+    if not os.environ.get("NO_PLAN_AHEAD"): bwd[i % 2].plan_ahead()      # NO_PLAN_AHEAD=1: the planning runs inline, after the forward
     fwd[i % 2].run()
     bwd[i % 2].run()
 b.record()
