@@ -421,3 +421,27 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
     NRX_LAUNCH_CHECK("nrx_dcn_v2_layer_bwd");
     return NRX_OK;
 }
+
+extern "C" int nrx_linear_wgrad(const float* g, int64_t g_ld, const float* a, int64_t a_ld, int64_t batch, int32_t out_features,
+                                int32_t in_features, float* g_W, void* stream) {
+    NRX_REQUIRE(g && a && g_W && batch >= 0 && out_features >= 1 && in_features >= 1 && g_ld >= out_features && a_ld >= in_features,
+                "nrx_linear_wgrad: bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (nrx_zero_async(g_W, sizeof(float) * (size_t)out_features * in_features, st) != NRX_OK) return NRX_ERR_LAUNCH;
+    if (batch == 0) return NRX_OK;
+    const bool vec = (g_ld & 3) == 0 && (a_ld & 3) == 0 && (out_features & 3) == 0 && (in_features & 3) == 0 && nrx_aligned16(g) && nrx_aligned16(a);
+    const unsigned nx = (unsigned)((in_features + BN - 1) / BN);
+    const unsigned nt = nx * (unsigned)((out_features + BM - 1) / BM);
+    int64_t splits = (1024 + nt - 1) / nt;                              // ~1024 blocks on 256 CUs
+    int64_t kslice = ((batch + splits - 1) / splits + BK - 1) / BK * BK;
+    if (kslice < BK) kslice = BK;
+    splits = (batch + kslice - 1) / kslice;
+    if (vec) hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, true>), dim3((unsigned)(nt * splits)), dim3(256), 0, st, g, g_ld, a, a_ld,
+                                (int64_t)out_features, in_features, batch, kslice, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0,
+                                g_W, (int64_t)in_features, nx, nt, (const float*)nullptr, (int64_t)0);
+    else hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, false>), dim3((unsigned)(nt * splits)), dim3(256), 0, st, g, g_ld, a, a_ld,
+                            (int64_t)out_features, in_features, batch, kslice, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0,
+                            g_W, (int64_t)in_features, nx, nt, (const float*)nullptr, (int64_t)0);
+    NRX_LAUNCH_CHECK("nrx_linear_wgrad");
+    return NRX_OK;
+}

@@ -1190,6 +1190,45 @@ def dcn_v2(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, relu: bool = True)
 
 
 # ------------------------------------------------------------------------------- integer utilities
+class _LinearFn(torch.autograd.Function):
+    """y = a W^T + b with the weight gradient on nrx_linear_wgrad (the batch is the contraction there: at B = 65 536 the vendor
+    GEMM takes 0.2-0.3 ms per MLP layer, the split-over-the-batch MFMA kernel of the DCN-v2 backward a fraction of that).  The
+    forward and the input gradient stay on the vendor GEMM.  Reference layer: src/model/model_utils/utils.py:6-17."""
+
+    @staticmethod
+    def forward(ctx, a, W, b):
+        ctx.save_for_backward(a, W)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(a, W, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, W = ctx.saved_tensors
+        lib = _lib.load()
+        g2 = _f32c(g.reshape(-1, g.shape[-1]), "grad")
+        a2 = a.reshape(-1, a.shape[-1])
+        if a2.stride(-1) != 1:
+            a2 = a2.contiguous()
+        ga = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = (g2 @ W).reshape(a.shape)
+        if ctx.needs_input_grad[1]:
+            gW = torch.empty_like(W, memory_format=torch.contiguous_format)
+            check(lib.nrx_linear_wgrad(g2.data_ptr(), g2.stride(0), a2.data_ptr(), a2.stride(0), g2.shape[0], W.shape[0], W.shape[1],
+                                       gW.data_ptr(), _stream_ptr(g2)), "nrx_linear_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return ga, gW, gb
+
+
+def linear(a: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """torch.nn.functional.linear whose weight gradient runs on this package's split-over-the-batch MFMA kernel (fp32, CUDA only)."""
+    _dev(a, "linear input")
+    if a.dtype != torch.float32 or W.dtype != torch.float32:
+        raise TypeError("ops.linear computes in fp32")
+    return _LinearFn.apply(a, W, b)
+
+
 def bucketize_by_owner(ids: torch.Tensor, world: int):
     """Stable bucketing of a flat id tensor by owner rank (id % world).
     Returns (counts[world] int64, local_rows[n] int64 (= id // world in send order), slot[n] int64)."""

@@ -2,7 +2,7 @@
 """Whole training step of a ranker at the C2 scale: the package's `Deep` model (train_cf_deep.yaml schema) over 26 features x 1 M rows x 16
 with the reference's MLP head [416, 128, 128, 128, 64, 1], BCE loss, backward, optimizer, at B = 65 536 --
   (a) `embeddings.sparse_grad: fused`: fused gather forward, deterministic row-sparse backward, fused row-sparse Adam on the tables,
-      AdamW on the MLP;
+      AdamW on the MLP; (a') the same with the MLP layers' weight gradients on nrx_linear_wgrad (opt-in);
   (b) the reference's own arrangement: dense table gradients + AdamW over every row (src/model/sort/deep/model.py:54-65);
   (c) the module code restated in stock PyTorch-ROCm: one nn.Embedding(sparse=True) per feature + torch.cat + the same MLP,
       torch.optim.SparseAdam on the tables / AdamW on the MLP (the closest stock equivalent of (a)).
@@ -88,6 +88,10 @@ def run_package(mode, label):
     torch.cuda.empty_cache()
 
 run_package("fused", "(a) this package, sparse_grad: fused (row-sparse backward + fused row-sparse Adam)")
+from news_recsys_amd.model.model_utils import utils as _mlp_utils
+_mlp_utils.MLP_WGRAD = True
+run_package("fused", "(a') as (a) with the MLP weight gradients on nrx_linear_wgrad (NRX_MLP_WGRAD=1)")
+_mlp_utils.MLP_WGRAD = False
 run_package("false", "(b) this package, the reference's arrangement (dense table grads + AdamW over all rows)")
 
 class Stock(nn.Module):
