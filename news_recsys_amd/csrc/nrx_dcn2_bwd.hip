@@ -28,29 +28,36 @@ constexpr int LDA = BM + 1, LDW = BN + 1;
 enum { DGRAD = 0, WGRAD = 1 };
 
 // ---- elementwise preparation ------------------------------------------------------------------------------------
-// glin = gm * x0 (the GEMMs' operand), g_x0 (+)= gm * lin, g_b = column sums of glin; gm itself is not materialised (the
-// dgrad epilogue rebuilds it from g and out).  TPR = 2^TPRLOG2 threads cover one row (4 columns each), a block covers
-// 256 / TPR rows per pass and U passes are in flight (HBM-bound streaming: 4 reads + 2 writes of [B, D]); a thread keeps
-// its 4 column sums in registers across all its rows, then one atomic per column per block.
+// glin = gm * x0 (the GEMMs' operand), g_x0 (+)= gm * lin, g_b = column sums of glin; gm itself is not materialised: the
+// ReLU mask [out > 0] leaves this kernel as BITS, transposed for the dgrad epilogue -- maskT[row / 32][col] holds the 32 rows
+// of one column, so a lane of the GEMM (one column, 16 rows of a 32-row MFMA tile) reads ONE dword per tile instead of 16
+// values of `out` (re-reading `out` there cost 30 us of the 165 us launch at D = 320).  TPR = 2^TPRLOG2 threads cover one
+// row (4 columns each); a thread owns its 4 columns over one GROUP of 32 consecutive rows (8 passes of U = 4 rows in flight,
+// HBM-bound streaming: 4-5 reads + 2 writes of [B, D]) and collects the group's mask bits and its column sums in registers;
+// a block covers 256 / TPR groups per sweep; then one atomic per column per block.
 template <int TPRLOG2, bool VEC>
 __global__ __launch_bounds__(NRX_BLOCK) void dcn_v2_bwd_prep_kernel(const float* __restrict__ g, int64_t g_ld, const float* __restrict__ out,
                                                                   const float* __restrict__ x0, const float* __restrict__ lin,
                                                                   int64_t ld, int64_t M, int D, int relu,
                                                                   float* __restrict__ glin, int64_t w_ld, float* __restrict__ g_x0,
-                                                                  int64_t gx0_ld, int accumulate_x0, float* __restrict__ g_b) {
+                                                                  int64_t gx0_ld, int accumulate_x0, float* __restrict__ g_b,
+                                                                  uint32_t* __restrict__ maskT) {
     constexpr int TPR = 1 << TPRLOG2, RPB = NRX_BLOCK / TPR, U = 4;
-    const int c = (threadIdx.x & (TPR - 1)) * 4;
+    const int cc = (threadIdx.x & (TPR - 1)) * 4;          // D <= 4 TPR (the launch picks TPR; dims up to 1024)
     const int rsub = threadIdx.x >> TPRLOG2;
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    {                                                   // D <= 4 TPR (the launch picks TPR; dims up to 1024)
-        const int cc = c;
-        const bool full = VEC && cc + 4 <= D;
-        if (cc < D)
-        for (int64_t r0 = (int64_t)blockIdx.x * RPB * U + rsub; r0 < M; r0 += (int64_t)gridDim.x * RPB * U) {
+    const bool full = VEC && cc + 4 <= D;
+    const int64_t ngroups = (M + 31) >> 5;
+    if (cc < D)
+    for (int64_t gi = (int64_t)blockIdx.x * RPB + rsub; gi < ngroups; gi += (int64_t)gridDim.x * RPB) {
+        uint32_t bits[4] = {0u, 0u, 0u, 0u};
+        for (int it = 0; it < 32 / U; ++it) {
+            const int64_t r0 = gi * 32 + it * U;
+            if (r0 >= M) break;
             float4 gv[U], xv[U], lv[U], ov[U], ax[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t r = r0 + (int64_t)u * RPB;
+                const int64_t r = r0 + u;
                 const int64_t rc = r < M ? r : M - 1;
                 if (full) {
                     gv[u] = *reinterpret_cast<const float4*>(g + rc * g_ld + cc);
@@ -76,11 +83,13 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v2_bwd_prep_kernel(const float*
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t r = r0 + (int64_t)u * RPB;
+                const int64_t r = r0 + u;
                 if (r >= M) continue;
+                const bool k0 = !relu || ov[u].x > 0.f, k1 = !relu || ov[u].y > 0.f, k2 = !relu || ov[u].z > 0.f, k3 = !relu || ov[u].w > 0.f;
+                const int sh = it * U + u;
+                bits[0] |= (uint32_t)k0 << sh; bits[1] |= (uint32_t)k1 << sh; bits[2] |= (uint32_t)k2 << sh; bits[3] |= (uint32_t)k3 << sh;
                 float4 m_;
-                m_.x = (relu && !(ov[u].x > 0.f)) ? 0.f : gv[u].x; m_.y = (relu && !(ov[u].y > 0.f)) ? 0.f : gv[u].y;
-                m_.z = (relu && !(ov[u].z > 0.f)) ? 0.f : gv[u].z; m_.w = (relu && !(ov[u].w > 0.f)) ? 0.f : gv[u].w;
+                m_.x = k0 ? gv[u].x : 0.f; m_.y = k1 ? gv[u].y : 0.f; m_.z = k2 ? gv[u].z : 0.f; m_.w = k3 ? gv[u].w : 0.f;
                 const float4 gl = make_float4(m_.x * xv[u].x, m_.y * xv[u].y, m_.z * xv[u].z, m_.w * xv[u].w);
                 const float4 gx = make_float4(fmaf(m_.x, lv[u].x, ax[u].x), fmaf(m_.y, lv[u].y, ax[u].y), fmaf(m_.z, lv[u].z, ax[u].z),
                                               fmaf(m_.w, lv[u].w, ax[u].w));
@@ -96,6 +105,8 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v2_bwd_prep_kernel(const float*
                 }
             }
         }
+        if (relu)                                       // w_ld is a multiple of 4 and cc < D <= w_ld: the 16-byte store stays in the row
+            *reinterpret_cast<uint4*>(maskT + gi * w_ld + cc) = make_uint4(bits[0], bits[1], bits[2], bits[3]);
     }
     // column sums: the RPB row-lanes of a column meet in LDS, then ONE device atomic per column per block (same-address
     // device atomics serialise: one per thread made this kernel 8x slower)
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v2_bwd_prep_kernel(const float*
 template <int MODE, bool VEC>
 __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                          int64_t M, int N, int64_t K, int64_t kslice, const float* __restrict__ addend,
-                                                         int64_t add_ld, const float* __restrict__ mask, int64_t mask_ld,
+                                                         int64_t add_ld, const uint32_t* __restrict__ maskT, int64_t mask_ld,
                                                          float* __restrict__ out, int64_t out_ld, unsigned nx, unsigned ntiles,
                                                          const float* __restrict__ add2, int64_t add2_ld) {
     __shared__ float As[BK * LDA];
@@ -306,23 +317,23 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
         // 32-row sub-tile batched ahead of the arithmetic (as the forward's epilogue; per-element 64-bit address arithmetic and
         // load -> use chains made this epilogue the difference between 186 us here and 155 us for the forward)
         const uint32_t lo_a = (uint32_t)(((int64_t)(4 * hi) * add_ld + col) * 4);
-        const uint32_t lo_m = (uint32_t)(((int64_t)(4 * hi) * mask_ld + col) * 4);
         const uint32_t lo_2 = (uint32_t)(((int64_t)(4 * hi) * add2_ld + col) * 4);
         const uint32_t lo_o = (uint32_t)(((int64_t)(4 * hi) * out_ld + col) * 4);
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-            float gv[16], mv[16], av[16];
+            float gv[16], av[16];
+            // the ReLU mask of this lane's column over the tile's 32 rows: bit (r & 3) + 8 (r >> 2) + 4 hi is row r's
+            const uint32_t mw = (maskT != nullptr ? maskT[((r0 + t * 32) >> 5) * mask_ld + col] : 0xffffffffu) >> (4 * hi);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2);          // + 4 * hi, folded into the lane offsets
                 gv[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(addend + row * add_ld) + lo_a);
-                mv[r] = mask != nullptr ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask + row * mask_ld) + lo_m) : 1.0f;
                 av[r] = add2 != nullptr ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(add2 + row * add2_ld) + lo_2) : 0.0f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2);
-                float v = (mv[r] > 0.f ? gv[r] : 0.f) + acc[t][r];
+                float v = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u ? gv[r] : 0.f) + acc[t][r];
                 if (add2 != nullptr) v += av[r];
                 *reinterpret_cast<float*>(reinterpret_cast<char*>(out + row * out_ld) + lo_o) = v;
             }
@@ -337,7 +348,7 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
             if (row < M) {
                 if (MODE == DGRAD) {        // g_xl = gm + glin W, gm = g (x) [forward output > 0] rebuilt here
                     float gmv = addend[row * add_ld + col];
-                    if (mask != nullptr && !(mask[row * mask_ld + col] > 0.f)) gmv = 0.f;
+                    if (maskT != nullptr && !((maskT[(row >> 5) * mask_ld + col] >> (row & 31)) & 1u)) gmv = 0.f;
                     float v = gmv + acc[t][r];
                     if (add2 != nullptr) v += add2[row * add2_ld + col];      // layer 0 (x0 is x_l): dL/dx = g_xl + g_x0 in one pass
                     out[row * out_ld + col] = v;
@@ -354,7 +365,7 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
 extern "C" int64_t nrx_dcn_v2_layer_bwd_workspace(int64_t batch, int32_t dim) {
     if (batch < 0 || dim < 1) return -1;
     const int64_t ld = (dim + 3) & ~3;
-    return batch * ld * (int64_t)sizeof(float) + 256;          // glin [batch, ld]
+    return (batch + (batch + 31) / 32) * ld * (int64_t)sizeof(float) + 512;          // glin [batch, ld] + the ReLU mask bits [ceil(batch / 32), ld]
 }
 
 extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld, const float* lin, const float* out, int32_t relu,
@@ -375,47 +386,49 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
     if (batch == 0) return NRX_OK;
     const int64_t wld = (dim + 3) & ~3;
     float* glin = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    uint32_t* maskT = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(glin + batch * wld) + 255) & ~(uintptr_t)255);
     const bool vec = (dim & 3) == 0 && (ld & 3) == 0 && (g_ld & 3) == 0 && (gx0_ld & 3) == 0 && (gxl_ld & 3) == 0 && nrx_aligned16(x0) &&
                      nrx_aligned16(xl) && nrx_aligned16(lin) && nrx_aligned16(g_out) && nrx_aligned16(g_x0) && nrx_aligned16(g_xl) &&
                      nrx_aligned16(W) && (out == nullptr || nrx_aligned16(out));
     {
         int tl = 2;                                   // threads per row = 2^tl >= dim / 4 (<= 256)
         while ((4 << tl) < dim && tl < 8) ++tl;
-        const int rpb = NRX_BLOCK >> tl;
-        int64_t grid = (batch + rpb * 4 - 1) / (rpb * 4);
+        const int rpb = NRX_BLOCK >> tl;                 // 32-row groups per block and sweep
+        int64_t grid = ((batch + 31) / 32 + rpb - 1) / rpb;
         if (grid > 512) grid = 512;
 #define NRX_PREP(TL_)                                                                                                              \
     case TL_:                                                                                                                      \
         if (vec) hipLaunchKernelGGL((dcn_v2_bwd_prep_kernel<TL_, true>), dim3((unsigned)grid), dim3(NRX_BLOCK), 0, st, g_out, g_ld, out,  \
-                                    x0, lin, ld, batch, dim, relu, glin, wld, g_x0, gx0_ld, acc_x0, g_b);                  \
+                                    x0, lin, ld, batch, dim, relu, glin, wld, g_x0, gx0_ld, acc_x0, g_b, maskT);           \
         else hipLaunchKernelGGL((dcn_v2_bwd_prep_kernel<TL_, false>), dim3((unsigned)grid), dim3(NRX_BLOCK), 0, st, g_out, g_ld, out,    \
-                                x0, lin, ld, batch, dim, relu, glin, wld, g_x0, gx0_ld, acc_x0, g_b);                      \
+                                x0, lin, ld, batch, dim, relu, glin, wld, g_x0, gx0_ld, acc_x0, g_b, maskT);               \
         break;
         switch (tl) { NRX_PREP(2) NRX_PREP(3) NRX_PREP(4) NRX_PREP(5) NRX_PREP(6) NRX_PREP(7) default: NRX_PREP(8) }
 #undef NRX_PREP
     }
-    const float* mask = relu ? out : nullptr;
+    const uint32_t* mask = relu ? maskT : nullptr;
     {   // dgrad: g_xl = gm + glin W        (M = batch, N = K = dim; B operand = W rows, K-major)
         const unsigned nx = (unsigned)((dim + BN - 1) / BN);
         const int64_t nt = (int64_t)nx * ((batch + BM - 1) / BM);
         NRX_REQUIRE(nt <= 0x7fffffffLL, "nrx_dcn_v2_layer_bwd: batch too large for one launch");
         if (vec) hipLaunchKernelGGL((dcn2_gemm_kernel<DGRAD, true>), dim3((unsigned)nt), dim3(256), 0, st, glin, wld, W, (int64_t)dim, batch,
-                                    dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, ld, g_xl, gxl_ld, nx, (unsigned)nt, fold, gx0_ld);
+                                    dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, wld, g_xl, gxl_ld, nx, (unsigned)nt, fold, gx0_ld);
         else hipLaunchKernelGGL((dcn2_gemm_kernel<DGRAD, false>), dim3((unsigned)nt), dim3(256), 0, st, glin, wld, W, (int64_t)dim, batch,
-                                dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, ld, g_xl, gxl_ld, nx, (unsigned)nt, fold, gx0_ld);
+                                dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, wld, g_xl, gxl_ld, nx, (unsigned)nt, fold, gx0_ld);
     }
     {   // wgrad: g_W[i, j] += sum_b glin[b, i] xl[b, j]   (M = N = dim, K = batch, split over the batch)
         const unsigned nx = (unsigned)((dim + BN - 1) / BN);
         const unsigned nt = nx * (unsigned)((dim + BM - 1) / BM);
-        int64_t splits = (1024 + nt - 1) / nt;                          // ~1024 blocks on 256 CUs
+        int64_t splits = (1024 + nt - 1) / nt;                          // ~1024 blocks on 256 CUs,
         int64_t kslice = ((batch + splits - 1) / splits + BK - 1) / BK * BK;
-        if (kslice < BK) kslice = BK;
+        if (kslice < 8 * BK) kslice = 8 * BK;                           // of at least 8 slabs each (few tiles: the atomics of a shorter slice
+                                                                        // cost more than the blocks it adds -- D = 112: 46.8 -> 36 us)
         splits = (batch + kslice - 1) / kslice;
         if (vec) hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, true>), dim3((unsigned)(nt * splits)), dim3(256), 0, st, glin, wld, xl, ld,
-                                    (int64_t)dim, dim, batch, kslice, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0,
+                                    (int64_t)dim, dim, batch, kslice, (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0,
                                     g_W, (int64_t)dim, nx, nt, (const float*)nullptr, (int64_t)0);
         else hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, false>), dim3((unsigned)(nt * splits)), dim3(256), 0, st, glin, wld, xl, ld,
-                                (int64_t)dim, dim, batch, kslice, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0,
+                                (int64_t)dim, dim, batch, kslice, (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0,
                                 g_W, (int64_t)dim, nx, nt, (const float*)nullptr, (int64_t)0);
     }
     NRX_LAUNCH_CHECK("nrx_dcn_v2_layer_bwd");
@@ -432,15 +445,15 @@ extern "C" int nrx_linear_wgrad(const float* g, int64_t g_ld, const float* a, in
     const bool vec = (g_ld & 3) == 0 && (a_ld & 3) == 0 && (out_features & 3) == 0 && (in_features & 3) == 0 && nrx_aligned16(g) && nrx_aligned16(a);
     const unsigned nx = (unsigned)((in_features + BN - 1) / BN);
     const unsigned nt = nx * (unsigned)((out_features + BM - 1) / BM);
-    int64_t splits = (1024 + nt - 1) / nt;                              // ~1024 blocks on 256 CUs
+    int64_t splits = (1024 + nt - 1) / nt;                              // ~1024 blocks on 256 CUs, at least 8 slabs each
     int64_t kslice = ((batch + splits - 1) / splits + BK - 1) / BK * BK;
-    if (kslice < BK) kslice = BK;
+    if (kslice < 8 * BK) kslice = 8 * BK;
     splits = (batch + kslice - 1) / kslice;
     if (vec) hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, true>), dim3((unsigned)(nt * splits)), dim3(256), 0, st, g, g_ld, a, a_ld,
-                                (int64_t)out_features, in_features, batch, kslice, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0,
+                                (int64_t)out_features, in_features, batch, kslice, (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0,
                                 g_W, (int64_t)in_features, nx, nt, (const float*)nullptr, (int64_t)0);
     else hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, false>), dim3((unsigned)(nt * splits)), dim3(256), 0, st, g, g_ld, a, a_ld,
-                            (int64_t)out_features, in_features, batch, kslice, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0,
+                            (int64_t)out_features, in_features, batch, kslice, (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0,
                             g_W, (int64_t)in_features, nx, nt, (const float*)nullptr, (int64_t)0);
     NRX_LAUNCH_CHECK("nrx_linear_wgrad");
     return NRX_OK;

@@ -1090,14 +1090,17 @@ def embed_dcn_v1(plan: EmbedPlan, tables, inputs, w: torch.Tensor, b: torch.Tens
 
 
 # ------------------------------------------------------------------------------- DCN v2 (MFMA)
-def _dcn_v2_layer_backward(lib, x0, xl, lin, out, relu, W, g, g_x0, accumulate):
+def _dcn_v2_layer_backward(lib, x0, xl, lin, out, relu, W, g, g_x0, accumulate, gW=None, gb=None):
     """One layer of the hand-written backward (nrx_dcn_v2_layer_bwd: elementwise prep + MFMA dgrad + MFMA wgrad).
-    Returns (g_xl, g_W, g_b); g_x0 is written (accumulate bit 0 clear) or accumulated (set) in place, and folded into g_xl when bit 1 is set."""
+    Returns (g_xl, g_W, g_b); g_x0 is written (accumulate bit 0 clear) or accumulated (set) in place, and folded into g_xl when bit 1 is set.
+    `gW` / `gb`: contiguous destinations (a layer's slice of the stack's gradient tensors) written in place of fresh tensors."""
     B, D = xl.shape
     g = _f32c(g, "grad")
     g_xl = torch.empty_like(xl)
-    gW = torch.empty((D, D), dtype=torch.float32, device=xl.device)
-    gb = torch.empty((D,), dtype=torch.float32, device=xl.device)
+    if gW is None:
+        gW = torch.empty((D, D), dtype=torch.float32, device=xl.device)
+    if gb is None:
+        gb = torch.empty((D,), dtype=torch.float32, device=xl.device)
     ws = torch.empty(max(1, lib.nrx_dcn_v2_layer_bwd_workspace(B, D)), dtype=torch.uint8, device=xl.device)
     check(lib.nrx_dcn_v2_layer_bwd(x0.data_ptr(), xl.data_ptr(), D, lin.data_ptr(), _ptr(out), 1 if relu else 0, B, D, W.data_ptr(),
                                    g.data_ptr(), D, g_xl.data_ptr(), D, g_x0.data_ptr(), D, int(accumulate), gW.data_ptr(),
@@ -1147,7 +1150,7 @@ class _DcnV2Fn(torch.autograd.Function):
             # accumulate bit 0: layers before the last add to g_x0 (the last one writes it); bit 1: layer 0 folds the total into
             # its g_xl (x_0 IS the stack's input there): no separate `g + gx0` pass over [B, D]
             acc = (0 if l == n - 1 else 1) | (2 if l == 0 else 0)
-            g, gW[l], gb[l] = _dcn_v2_layer_backward(lib, x0, xs[l], lins[l], xs[l + 1], ctx.relu, W[l], g, gx0, accumulate=acc)
+            g, _, _ = _dcn_v2_layer_backward(lib, x0, xs[l], lins[l], xs[l + 1], ctx.relu, W[l], g, gx0, accumulate=acc, gW=gW[l], gb=gb[l])
         return g, gW, gb, None
 
 

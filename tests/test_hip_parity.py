@@ -545,6 +545,78 @@ def test_dcn_v2_vs_oracle(B, D, NL):
     assert np.array_equal(out_nr.detach().cpu().numpy(), ref_c.dcn_v2(x, W[:1], b[:1], relu=False))
 
 
+def _dcn_v2_bwd_f64(x, W, b, up, relu, masks):
+    """fp64 autograd of DCNv2Net written out (dcn_arch.py:33-50, 73-91), with the ReLU decisions taken from the fp32 forward
+    (`masks[l]` = layer l's fp32 output > 0): a pre-activation within rounding of zero must not flip the comparison."""
+    n = W.shape[0]
+    x0 = x.astype(np.float64)
+    xs, lins = [x0], []
+    for l in range(n):
+        lin = xs[-1] @ W[l].astype(np.float64).T + b[l][None, :]
+        p = x0 * lin + xs[-1]
+        lins.append(lin)
+        xs.append(np.where(masks[l], p, 0.0) if relu else p)
+    g = up.astype(np.float64)
+    gx0 = np.zeros_like(x0)
+    gW, gb = np.zeros(W.shape), np.zeros(b.shape)
+    for l in reversed(range(n)):
+        if relu:
+            g = g * masks[l]
+        glin = g * x0
+        gx0 += g * lins[l]
+        gW[l] = glin.T @ xs[l]
+        gb[l] = glin.sum(axis=0)
+        g = g + glin @ W[l].astype(np.float64)
+    return g + gx0, gW, gb
+
+
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("B,D,NL", [(1, 4, 1), (200, 320, 2), (130, 112, 3), (65, 37, 2), (1000, 64, 1), (127, 129, 1), (33, 16, 3),
+                                    # whole 128-row tiles (the batched epilogue), a partial last tile, a last 32-row mask group that is
+                                    # not full, more row groups than one sweep of the elementwise kernel, odd D with whole tiles
+                                    (4133, 112, 2), (2048, 320, 2), (20011, 64, 1), (300, 1000, 1), (515, 37, 2), (40000, 16, 1)])
+def test_dcn_v2_bwd_vs_fp64(B, D, NL, relu):
+    from oracle import ref_c
+    rng = np.random.default_rng(B * 7 + D + NL)
+    x = rng.standard_normal((B, D)).astype(np.float32)
+    W = (rng.standard_normal((NL, D, D)) / np.sqrt(D)).astype(np.float32)
+    W = W * (1.0 + np.triu(np.ones((D, D), np.float32)))[None]          # asymmetric: a transposed operand cannot pass
+    b = (rng.standard_normal((NL, D)) * 0.1).astype(np.float32)
+    up = rng.standard_normal((B, D)).astype(np.float32)
+    xt, Wt, bt = dev(x).requires_grad_(True), dev(W).requires_grad_(True), dev(b).requires_grad_(True)
+    out = ops.dcn_v2(xt, Wt, bt, relu=relu)
+    out.backward(dev(up))
+    masks = [ref_c.dcn_v2(x, W[:l + 1], b[:l + 1], relu=relu) > 0 for l in range(NL)]      # value-exact with the device forward
+    assert np.array_equal(out.detach().cpu().numpy() > 0, masks[-1])
+    gx, gW, gb = _dcn_v2_bwd_f64(x, W, b, up, relu, masks)
+    # fp32 matrix-core sums over D (g_x) and over the batch (g_W, g_b; atomics-ordered): tolerance grows with the sum length
+    for got, want, length in ((xt.grad, gx, D * NL), (Wt.grad, gW, B), (bt.grad, gb, B)):
+        tol = 3e-6 * max(1.0, length ** 0.5)
+        err = np.abs(got.detach().cpu().numpy().astype(np.float64) - want).max()
+        assert err <= tol * max(1.0, np.abs(want).max()), (err, np.abs(want).max())
+
+
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("B,D", [(700, 112), (1, 8), (259, 320)])
+def test_dcn_v2_layer_bwd_separate_x0(B, D, relu):
+    """DCNv2Layer.forward(x_l, x_0) with x_0 != x_l (dcn_arch.py:39-50): all four gradients against fp64."""
+    rng = np.random.default_rng(B + D)
+    x0, xl, up = (rng.standard_normal((B, D)).astype(np.float32) for _ in range(3))
+    W = (rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32)
+    b = (rng.standard_normal(D) * 0.1).astype(np.float32)
+    t = [dev(a).requires_grad_(True) for a in (x0, xl, W, b)]
+    out = ops.dcn_v2_layer(t[0], t[1], t[2], t[3], relu=relu)
+    out.backward(dev(up))
+    m = out.detach().cpu().numpy() > 0 if relu else np.ones((B, D), bool)
+    g = up.astype(np.float64) * m
+    lin = xl.astype(np.float64) @ W.astype(np.float64).T + b
+    glin = g * x0
+    want = (g * lin, g + glin @ W.astype(np.float64), glin.T @ xl.astype(np.float64), glin.sum(0))
+    for got, w in zip(t, want):
+        err = np.abs(got.grad.detach().cpu().numpy().astype(np.float64) - w).max()
+        assert err <= 3e-6 * max(1.0, B ** 0.5, D ** 0.5) * max(1.0, np.abs(w).max()), err
+
+
 # ----------------------------------------------------------------------------- integer utilities (bit-exact)
 @pytest.mark.parametrize("n,world", [(0, 2), (1, 1), (63, 2), (2048, 8), (2049, 8), (100000, 8), (77777, 3), (5000, 64)])
 @pytest.mark.parametrize("dtype", [torch.int64, torch.int32])

@@ -242,6 +242,15 @@ def test_dcn_fused_gather_cross_training_matches_two_launches(tmp_path, sparse_g
         for l in m_f.score_fc.cross_net.cross_net:
             l.b.normal_(0, 0.1)
     m_t.load_state_dict(m_f.state_dict())
+    # The two paths' forwards agree to rounding, not bit for bit, and the vendor GEMMs of the MLP head are not run-to-run
+    # identical: a hidden unit whose pre-activation sits within that noise of zero takes a different ReLU branch in the two
+    # models and moves one row of a weight gradient by far more than any tolerance (seen about once in 200 runs,
+    # tools/stress_dcn_fused.py).  What is compared here is the gather + cross path: give the head a smooth activation.
+    for m in (m_f, m_t):
+        net = m.score_fc.score_fc.network
+        for i, layer in enumerate(net):
+            if isinstance(layer, torch.nn.ReLU):
+                net[i] = torch.nn.Tanh()
     from news_recsys_amd import ops
     g = torch.Generator(device=DEV).manual_seed(4)
     batch = {n: torch.randint(1, m_f.embedding_tables[n].weight.shape[0], (200,), device=DEV, generator=g) for n in m_f.sparse_feature_names}
