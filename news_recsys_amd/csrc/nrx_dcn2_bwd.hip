@@ -16,6 +16,7 @@
 //                            adds its partial tile with fp32 atomics (g_W pre-zeroed; D*D outputs x ~40 slices)
 // The forward saves lin when asked (nrx_dcn_v2_layer_fwd's lin_out): one extra [B, D] write instead of a third GEMM here.
 #include "nrx_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -23,7 +24,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int TM = 2;
 constexpr int BM = 2 * TM * 32, BN = 64, BK = 32;      // 128 x 64 block tile, K slabs of 32
-constexpr int LDA = BM + 1, LDW = BN + 1;
+constexpr int LDW = BN + 1;
 
 enum { DGRAD = 0, WGRAD = 1 };
 
@@ -128,12 +129,13 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v2_bwd_prep_kernel(const float*
 //   WGRAD: A(m, k) = glin[k * lda + m]   (K-major)     B(k, n) = xl[k * ldb + n]  (K-major)   epilogue: atomicAdd(out[m, n], C)
 // M, N, K are the GEMM's own dims (DGRAD: batch, D, D;  WGRAD: D, D, batch).  Rows / columns past M / N are clamped on
 // load (their products land in accumulator rows / columns that are never stored); a partial last K slab is zero-filled.
-template <int MODE, bool VEC>
+template <int MODE, bool VEC, int TMv = 2>
 __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                          int64_t M, int N, int64_t K, int64_t kslice, const float* __restrict__ addend,
                                                          int64_t add_ld, const uint32_t* __restrict__ maskT, int64_t mask_ld,
                                                          float* __restrict__ out, int64_t out_ld, unsigned nx, unsigned ntiles,
                                                          const float* __restrict__ add2, int64_t add2_ld) {
+    constexpr int TM = TMv, BM = 2 * TM * 32, LDA = BM + 1;      // TMv = 1: 64 x 64 block tiles (wgrad of narrow layers: twice the tiles)
     __shared__ float As[BK * LDA];
     __shared__ float Ws[BK * LDW];
     const int tid = threadIdx.x;
@@ -360,6 +362,35 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
     }
 }
 
+// out[M, N] += A^T B over the batch (A [batch, M], B [batch, N], both K-major), split into batch slices; out pre-zeroed.
+// Tile and slice choice (tools/dcn2_dgrad_probe.hip, B = 65 536): up to M = 384 the 64 x 64 block tile wins (M = 320 is 5 whole
+// tiles instead of 2.5; narrow layers get twice the tiles to spread over the CUs: D = 112 38 -> 30 us, D = 320 135 -> 123 us), above
+// it the 128 x 64 tile (less LDS traffic per MFMA: D = 512 280 vs 298 us).  ~1 536 (64 x 64) / ~1 024 (128 x 64) blocks, but never
+// slices shorter than 512 / 256 batch rows (256 for a single tile): with few tiles the atomics of a short slice cost more than the
+// blocks it adds.  NRX_WGRAD_TILE / NRX_WGRAD_BLOCKS / NRX_WGRAD_MIN_ROWS override the choice (tools/run_wgrad_sweep.sh).
+void launch_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int64_t batch, float* out, bool vec, hipStream_t st) {
+    static const int env_tile = getenv("NRX_WGRAD_TILE") ? atoi(getenv("NRX_WGRAD_TILE")) : 0;            // tuning: 64 | 128
+    static const int env_blocks = getenv("NRX_WGRAD_BLOCKS") ? atoi(getenv("NRX_WGRAD_BLOCKS")) : 0;      // tuning: target block count
+    static const int env_rows = getenv("NRX_WGRAD_MIN_ROWS") ? atoi(getenv("NRX_WGRAD_MIN_ROWS")) : 0;    // tuning: shortest batch slice
+    const bool small = env_tile ? env_tile == 64 : M <= 384;
+    const int bm = small ? 64 : BM;
+    const unsigned nx = (unsigned)((N + BN - 1) / BN);
+    const unsigned nt = nx * (unsigned)((M + bm - 1) / bm);
+    int64_t splits = ((env_blocks ? env_blocks : small ? 1536 : 1024) + nt - 1) / nt;
+    int64_t kslice = ((batch + splits - 1) / splits + BK - 1) / BK * BK;
+    const int64_t kmin = env_rows ? (env_rows + BK - 1) / BK * BK : (small && nt > 1 ? 16 : 8) * BK;
+    if (kslice < kmin) kslice = kmin;
+    splits = (batch + kslice - 1) / kslice;
+    const dim3 grid((unsigned)(nt * splits));
+#define NRX_WGRAD(VEC_, TM_)                                                                                                          \
+    hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, VEC_, TM_>), grid, dim3(256), 0, st, A, lda, B, ldb, (int64_t)M, N, batch, kslice,     \
+                       (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, out, (int64_t)N, nx, nt,              \
+                       (const float*)nullptr, (int64_t)0)
+    if (small) { if (vec) NRX_WGRAD(true, 1); else NRX_WGRAD(false, 1); }
+    else       { if (vec) NRX_WGRAD(true, 2); else NRX_WGRAD(false, 2); }
+#undef NRX_WGRAD
+}
+
 }  // namespace
 
 extern "C" int64_t nrx_dcn_v2_layer_bwd_workspace(int64_t batch, int32_t dim) {
@@ -416,21 +447,8 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
         else hipLaunchKernelGGL((dcn2_gemm_kernel<DGRAD, false>), dim3((unsigned)nt), dim3(256), 0, st, glin, wld, W, (int64_t)dim, batch,
                                 dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, wld, g_xl, gxl_ld, nx, (unsigned)nt, fold, gx0_ld);
     }
-    {   // wgrad: g_W[i, j] += sum_b glin[b, i] xl[b, j]   (M = N = dim, K = batch, split over the batch)
-        const unsigned nx = (unsigned)((dim + BN - 1) / BN);
-        const unsigned nt = nx * (unsigned)((dim + BM - 1) / BM);
-        int64_t splits = (1024 + nt - 1) / nt;                          // ~1024 blocks on 256 CUs,
-        int64_t kslice = ((batch + splits - 1) / splits + BK - 1) / BK * BK;
-        if (kslice < 8 * BK) kslice = 8 * BK;                           // of at least 8 slabs each (few tiles: the atomics of a shorter slice
-                                                                        // cost more than the blocks it adds -- D = 112: 46.8 -> 36 us)
-        splits = (batch + kslice - 1) / kslice;
-        if (vec) hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, true>), dim3((unsigned)(nt * splits)), dim3(256), 0, st, glin, wld, xl, ld,
-                                    (int64_t)dim, dim, batch, kslice, (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0,
-                                    g_W, (int64_t)dim, nx, nt, (const float*)nullptr, (int64_t)0);
-        else hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, false>), dim3((unsigned)(nt * splits)), dim3(256), 0, st, glin, wld, xl, ld,
-                                (int64_t)dim, dim, batch, kslice, (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0,
-                                g_W, (int64_t)dim, nx, nt, (const float*)nullptr, (int64_t)0);
-    }
+    // wgrad: g_W[i, j] += sum_b glin[b, i] xl[b, j]   (M = N = dim, K = batch, split over the batch)
+    launch_wgrad(glin, wld, xl, ld, dim, dim, batch, g_W, vec, st);
     NRX_LAUNCH_CHECK("nrx_dcn_v2_layer_bwd");
     return NRX_OK;
 }
@@ -443,18 +461,7 @@ extern "C" int nrx_linear_wgrad(const float* g, int64_t g_ld, const float* a, in
     if (nrx_zero_async(g_W, sizeof(float) * (size_t)out_features * in_features, st) != NRX_OK) return NRX_ERR_LAUNCH;
     if (batch == 0) return NRX_OK;
     const bool vec = (g_ld & 3) == 0 && (a_ld & 3) == 0 && (out_features & 3) == 0 && (in_features & 3) == 0 && nrx_aligned16(g) && nrx_aligned16(a);
-    const unsigned nx = (unsigned)((in_features + BN - 1) / BN);
-    const unsigned nt = nx * (unsigned)((out_features + BM - 1) / BM);
-    int64_t splits = (1024 + nt - 1) / nt;                              // ~1024 blocks on 256 CUs, at least 8 slabs each
-    int64_t kslice = ((batch + splits - 1) / splits + BK - 1) / BK * BK;
-    if (kslice < 8 * BK) kslice = 8 * BK;
-    splits = (batch + kslice - 1) / kslice;
-    if (vec) hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, true>), dim3((unsigned)(nt * splits)), dim3(256), 0, st, g, g_ld, a, a_ld,
-                                (int64_t)out_features, in_features, batch, kslice, (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0,
-                                g_W, (int64_t)in_features, nx, nt, (const float*)nullptr, (int64_t)0);
-    else hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, false>), dim3((unsigned)(nt * splits)), dim3(256), 0, st, g, g_ld, a, a_ld,
-                            (int64_t)out_features, in_features, batch, kslice, (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0,
-                            g_W, (int64_t)in_features, nx, nt, (const float*)nullptr, (int64_t)0);
+    launch_wgrad(g, g_ld, a, a_ld, out_features, in_features, batch, g_W, vec, st);
     NRX_LAUNCH_CHECK("nrx_linear_wgrad");
     return NRX_OK;
 }

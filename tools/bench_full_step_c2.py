@@ -66,12 +66,16 @@ for _ in range(4):
     b["label"] = (torch.rand(B, 1, device=dev, generator=gen) < 0.3).float()
     batches.append(b)
 
+ISSUE = {}
+
 def timeit(step, n=30, warm=8):
     for i in range(warm): step(batches[i % 4])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n): step(batches[i % 4])
+    t1 = time.perf_counter()                      # all steps enqueued: host time per step (== the step time when the host is the bound)
     torch.cuda.synchronize()
+    ISSUE["ms"] = (t1 - t0) / n * 1e3
     return (time.perf_counter() - t0) / n * 1e3
 
 def run_package(mode, label):
@@ -83,10 +87,38 @@ def run_package(mode, label):
         loss.backward()
         opt.step()
     ms = timeit(step)
-    print(f"{label:78s} {ms:8.2f} ms/step  {B / ms / 1e3:7.2f} M impressions/s", flush=True)
+    print(f"{label:78s} {ms:8.2f} ms/step  {B / ms / 1e3:7.2f} M impressions/s   (host enqueue {ISSUE['ms']:.2f} ms/step)", flush=True)
+    if os.environ.get("HOST_BREAKDOWN") == "1":       # host time of each part of the step (nothing synchronises inside)
+        acc = [0.0] * 5
+        for i in range(30):
+            b = batches[i % 4]
+            t = [time.perf_counter()]
+            opt.zero_grad(set_to_none=True); t.append(time.perf_counter())
+            out = m(b); t.append(time.perf_counter())
+            loss = F.binary_cross_entropy(out.view(-1), b["label"][:, 0]); t.append(time.perf_counter())
+            loss.backward(); t.append(time.perf_counter())
+            opt.step(); t.append(time.perf_counter())
+            for j in range(5): acc[j] += (t[j + 1] - t[j]) / 30 * 1e3
+        torch.cuda.synchronize()
+        print("      host ms/step: zero_grad %.3f  forward %.3f  loss %.3f  backward %.3f  optimizer %.3f" % tuple(acc), flush=True)
     del m, opt
     torch.cuda.empty_cache()
 
+if os.environ.get("ONLY_A") == "1":               # tools/host_profile_step_c2.py: cProfile of the host side of (a)
+    import cProfile, pstats, torch.nn.functional as F_
+    m, opt = make_model("fused")
+    def step(b):
+        opt.zero_grad(set_to_none=True)
+        loss = F_.binary_cross_entropy(m(b).view(-1), b["label"][:, 0])
+        loss.backward()
+        opt.step()
+    for i in range(10): step(batches[i % 4])
+    torch.cuda.synchronize()
+    pr = cProfile.Profile(); pr.enable()
+    for i in range(50): step(batches[i % 4])
+    pr.disable(); torch.cuda.synchronize()
+    st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(45)
+    sys.exit(0)
 run_package("fused", "(a) this package, sparse_grad: fused (row-sparse backward + fused row-sparse Adam)")
 from news_recsys_amd.model.model_utils import utils as _mlp_utils
 _mlp_utils.MLP_WGRAD = True

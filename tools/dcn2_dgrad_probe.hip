@@ -42,7 +42,19 @@ int main(int argc, char** argv) {
     t = timeit([&] { dgrad(mbits, gx0); }, warm, iters);     printf("D=%d dgrad g+bits+fold            %7.1f us  %5.1f TF\n", D, t, gf / t * 1e3);
     t = timeit([&] { dgrad(mbits, nullptr); }, warm, iters); printf("D=%d dgrad g+bits                 %7.1f us  %5.1f TF\n", D, t, gf / t * 1e3);
     t = timeit([&] { dgrad(nullptr, nullptr); }, warm, iters); printf("D=%d dgrad g                      %7.1f us  %5.1f TF\n", D, t, gf / t * 1e3);
-    for (int target : {256, 512, 768, 1024, 1536, 2048, 4096}) {        // the product launch aims at ~1024 blocks
+    for (int target : {512, 1024, 1536, 2048}) {        // 64 x 64 tiles
+        const unsigned wnt = nx * (unsigned)((D + 63) / 64);
+        int64_t splits = (target + wnt - 1) / wnt;
+        int64_t kslice = ((B + splits - 1) / splits + BK - 1) / BK * BK;
+        if (kslice < (getenv("KMIN") ? atoi(getenv("KMIN")) : 8) * BK) kslice = (getenv("KMIN") ? atoi(getenv("KMIN")) : 8) * BK;
+        splits = (B + kslice - 1) / kslice;
+        t = timeit([&] {
+            hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, true, 1>), dim3((unsigned)(wnt * splits)), dim3(256), 0, 0, glin, (int64_t)D, xl, (int64_t)D, (int64_t)D, D, B,
+                               kslice, (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, gW, (int64_t)D, nx, wnt, (const float*)nullptr, (int64_t)0);
+        }, warm, iters);
+        printf("D=%d wgrad 64x64 (%u tiles x %lld slices of %lld rows)   %7.1f us  %5.1f TF\n", D, wnt, (long long)splits, (long long)kslice, t, gf / t * 1e3);
+    }
+    for (int target : {512, 1024}) {        // the product launch aims at ~1024 blocks
         const unsigned wnt = nx * (unsigned)((D + BM - 1) / BM);
         int64_t splits = (target + wnt - 1) / wnt;
         int64_t kslice = ((B + splits - 1) / splits + BK - 1) / BK * BK;
