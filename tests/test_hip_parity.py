@@ -617,6 +617,54 @@ def test_dcn_v2_layer_bwd_separate_x0(B, D, relu):
         assert err <= 3e-6 * max(1.0, B ** 0.5, D ** 0.5) * max(1.0, np.abs(w).max()), err
 
 
+@pytest.mark.parametrize("acc", [0, 1, 3])
+@pytest.mark.parametrize("B,D", [(300, 112), (129, 37), (1000, 320)])
+def test_dcn_v2_layer_bwd_capi_padded_leading_dims(B, D, acc):
+    """nrx_dcn_v2_layer_bwd called directly with every operand inside a wider allocation (ld > dim) and all accumulate_x0
+    modes: same results as the contiguous call (g_xl, g_x0 value for value -- their sums run in a fixed order)."""
+    from news_recsys_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device=DEV).manual_seed(B + D + acc)
+    rnd = lambda *shape: torch.randn(*shape, device=DEV, generator=gen)
+    x0, xl, g = rnd(B, D), rnd(B, D), rnd(B, D)
+    W, b = rnd(D, D) / D ** 0.5, rnd(D) * 0.1
+    gx0_init = rnd(B, D)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(pad):
+        def wide(t, extra):                           # t's values in the first D columns of a [B, D + extra] allocation
+            w = torch.full((B, D + extra), float("nan"), device=DEV)
+            w[:, :D] = t
+            return w
+        X0, XL = wide(x0, pad), wide(xl, pad)
+        OUT, LIN = wide(torch.zeros(B, D, device=DEV), pad), wide(torch.zeros(B, D, device=DEV), pad)
+        ld = D + pad
+        assert lib.nrx_dcn_v2_layer_fwd(X0.data_ptr(), XL.data_ptr(), ld, B, D, W.data_ptr(), b.data_ptr(), 1, OUT.data_ptr(), ld,
+                                        LIN.data_ptr(), st) == 0
+        G, GXL, GX0 = wide(g, 2 * pad), wide(torch.zeros(B, D, device=DEV), 3 * pad), wide(gx0_init, pad)
+        gW, gb = torch.empty(D, D, device=DEV), torch.empty(D, device=DEV)
+        ws = torch.empty(lib.nrx_dcn_v2_layer_bwd_workspace(B, D), dtype=torch.uint8, device=DEV)
+        assert lib.nrx_dcn_v2_layer_bwd(X0.data_ptr(), XL.data_ptr(), ld, LIN.data_ptr(), OUT.data_ptr(), 1, B, D, W.data_ptr(), G.data_ptr(),
+                                        D + 2 * pad, GXL.data_ptr(), D + 3 * pad, GX0.data_ptr(), D + pad, acc, gW.data_ptr(), gb.data_ptr(),
+                                        ws.data_ptr(), st) == 0, lib.nrx_last_error()
+        if pad:                                       # nothing outside the first D columns was touched
+            assert torch.isnan(GXL[:, D:]).all() and torch.isnan(GX0[:, D:]).all()
+        return GXL[:, :D].clone(), GX0[:, :D].clone(), gW, gb, OUT[:, :D].clone()
+
+    ref, got = run(0), run(4)
+    assert torch.equal(ref[4], got[4]) and torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+    torch.testing.assert_close(got[2], ref[2], rtol=1e-4, atol=1e-4)          # atomics-ordered sums over the batch
+    torch.testing.assert_close(got[3], ref[3], rtol=1e-4, atol=1e-4)
+    # and against the definition (fp64)
+    m = (ref[4] > 0).double()
+    gm = g.double() * m
+    lin = xl.double() @ W.double().t() + b.double()
+    gx0 = gm * lin + (gx0_init.double() if acc & 1 else 0)
+    gxl = gm + (gm * x0.double()) @ W.double() + (gx0 if acc & 2 else 0)
+    assert (got[1].double() - gx0).abs().max().item() <= 1e-4 * max(1.0, gx0.abs().max().item())
+    assert (got[0].double() - gxl).abs().max().item() <= 1e-4 * max(1.0, gxl.abs().max().item())
+
+
 # ----------------------------------------------------------------------------- integer utilities (bit-exact)
 @pytest.mark.parametrize("n,world", [(0, 2), (1, 1), (63, 2), (2048, 8), (2049, 8), (100000, 8), (77777, 3), (5000, 64)])
 @pytest.mark.parametrize("dtype", [torch.int64, torch.int32])
