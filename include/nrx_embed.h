@@ -264,10 +264,11 @@ NRX_API int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld, c
 /* Weight gradient of a dense layer fed by the path's concat (the MLP heads of the rankers, src/model/model_utils/utils.py:6-17:
  * y = a W^T + b  =>  g_W[o, i] = sum_b g[b, o] a[b, i]): the batch is the contraction, which the vendor GEMMs serve badly at
  * B = 65 536 (0.2-0.3 ms per layer); this is the split-over-the-batch matrix-core kernel of nrx_dcn_v2_layer_bwd's wgrad with
- * M = out_features, N = in_features.  g_W [out_features, in_features] (contiguous) is overwritten; fp32 atomics across the batch
- * slices (summation order not fixed).                                                                              */
+ * M = out_features, N = in_features.  g_W [out_features, in_features] (contiguous) is overwritten; g_b [out_features] (optional, may be
+ * NULL) receives the bias gradient sum_b g[b, o], taken from the same pass over g; fp32 atomics across the batch slices (summation
+ * order not fixed).                                                                                                 */
 NRX_API int nrx_linear_wgrad(const float* g, int64_t g_ld, const float* a, int64_t a_ld, int64_t batch, int32_t out_features,
-                     int32_t in_features, float* g_W, void* stream);
+                     int32_t in_features, float* g_W, float* g_b, void* stream);
 
 /* ---- integer utilities of the row-sharded path (bit-exact vs the CPU definitions) -------------
  * Row r of a table lives on rank r % world at local row r / world.                              */

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
                                                          int64_t M, int N, int64_t K, int64_t kslice, const float* __restrict__ addend,
                                                          int64_t add_ld, const uint32_t* __restrict__ maskT, int64_t mask_ld,
                                                          float* __restrict__ out, int64_t out_ld, unsigned nx, unsigned ntiles,
-                                                         const float* __restrict__ add2, int64_t add2_ld) {
+                                                         const float* __restrict__ add2, int64_t add2_ld, float* __restrict__ colsum) {
     constexpr int TM = TMv, BM = 2 * TM * 32, LDA = BM + 1;      // TMv = 1: 64 x 64 block tiles (wgrad of narrow layers: twice the tiles)
     __shared__ float As[BK * LDA];
     __shared__ float Ws[BK * LDW];
@@ -253,6 +253,12 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
             }
         }
     };
+    // WGRAD, optional: column sums of A over this block's batch slice (a dense layer's bias gradient), taken from the staging
+    // registers by the blocks of the first column tile; block-uniform
+    const bool do_cs = MODE == WGRAD && colsum != nullptr && n0 == 0;
+    float4 cs[AP];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) cs[p] = zero4();
     if (kbeg < kend) load_slab(kbeg);
     const bool wave_live = m0 + wm * (32 * TM) < M && n0 + wn * 32 < N;      // wave-uniform
 
@@ -274,6 +280,7 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
                 As[kk * LDA + m + 1] = a[p].y;
                 As[kk * LDA + m + 2] = a[p].z;
                 As[kk * LDA + m + 3] = a[p].w;
+                if (do_cs) { cs[p].x += a[p].x; cs[p].y += a[p].y; cs[p].z += a[p].z; cs[p].w += a[p].w; }
             }
         }
         {
@@ -311,6 +318,24 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
         __syncthreads();
     }
 
+    if (do_cs) {                         // (the K loop ended on a barrier: the A slab area is free)
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            const int m = 4 * ((tid & 7) + 8 * p);
+            const bool own = !VEC || m0 + m + 4 <= M;          // aligned path: columns past M were CLAMPED loads (copies of other columns)
+            As[kk * LDA + m + 0] = own ? cs[p].x : 0.f;
+            As[kk * LDA + m + 1] = own ? cs[p].y : 0.f;
+            As[kk * LDA + m + 2] = own ? cs[p].z : 0.f;
+            As[kk * LDA + m + 3] = own ? cs[p].w : 0.f;
+        }
+        __syncthreads();
+        if (tid < BM && m0 + tid < M) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < BK; ++k) t += As[k * LDA + tid];
+            unsafeAtomicAdd(colsum + m0 + tid, t);
+        }
+    }
     const int col = n0 + wn * 32 + l31;
     if (col >= N) return;
     const int64_t r0 = m0 + wm * (32 * TM);
@@ -368,7 +393,7 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
 // it the 128 x 64 tile (less LDS traffic per MFMA: D = 512 280 vs 298 us).  ~1 536 (64 x 64) / ~1 024 (128 x 64) blocks, but never
 // slices shorter than 512 / 256 batch rows (256 for a single tile): with few tiles the atomics of a short slice cost more than the
 // blocks it adds.  NRX_WGRAD_TILE / NRX_WGRAD_BLOCKS / NRX_WGRAD_MIN_ROWS override the choice (tools/run_wgrad_sweep.sh).
-void launch_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int64_t batch, float* out, bool vec, hipStream_t st) {
+void launch_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int64_t batch, float* out, float* colsum, bool vec, hipStream_t st) {
     static const int env_tile = getenv("NRX_WGRAD_TILE") ? atoi(getenv("NRX_WGRAD_TILE")) : 0;            // tuning: 64 | 128
     static const int env_blocks = getenv("NRX_WGRAD_BLOCKS") ? atoi(getenv("NRX_WGRAD_BLOCKS")) : 0;      // tuning: target block count
     static const int env_rows = getenv("NRX_WGRAD_MIN_ROWS") ? atoi(getenv("NRX_WGRAD_MIN_ROWS")) : 0;    // tuning: shortest batch slice
@@ -385,7 +410,7 @@ void launch_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, int 
 #define NRX_WGRAD(VEC_, TM_)                                                                                                          \
     hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, VEC_, TM_>), grid, dim3(256), 0, st, A, lda, B, ldb, (int64_t)M, N, batch, kslice,     \
                        (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, out, (int64_t)N, nx, nt,              \
-                       (const float*)nullptr, (int64_t)0)
+                       (const float*)nullptr, (int64_t)0, colsum)
     if (small) { if (vec) NRX_WGRAD(true, 1); else NRX_WGRAD(false, 1); }
     else       { if (vec) NRX_WGRAD(true, 2); else NRX_WGRAD(false, 2); }
 #undef NRX_WGRAD
@@ -443,25 +468,26 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
         const int64_t nt = (int64_t)nx * ((batch + BM - 1) / BM);
         NRX_REQUIRE(nt <= 0x7fffffffLL, "nrx_dcn_v2_layer_bwd: batch too large for one launch");
         if (vec) hipLaunchKernelGGL((dcn2_gemm_kernel<DGRAD, true>), dim3((unsigned)nt), dim3(256), 0, st, glin, wld, W, (int64_t)dim, batch,
-                                    dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, wld, g_xl, gxl_ld, nx, (unsigned)nt, fold, gx0_ld);
+                                    dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, wld, g_xl, gxl_ld, nx, (unsigned)nt, fold, gx0_ld, (float*)nullptr);
         else hipLaunchKernelGGL((dcn2_gemm_kernel<DGRAD, false>), dim3((unsigned)nt), dim3(256), 0, st, glin, wld, W, (int64_t)dim, batch,
-                                dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, wld, g_xl, gxl_ld, nx, (unsigned)nt, fold, gx0_ld);
+                                dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, wld, g_xl, gxl_ld, nx, (unsigned)nt, fold, gx0_ld, (float*)nullptr);
     }
     // wgrad: g_W[i, j] += sum_b glin[b, i] xl[b, j]   (M = N = dim, K = batch, split over the batch)
-    launch_wgrad(glin, wld, xl, ld, dim, dim, batch, g_W, vec, st);
+    launch_wgrad(glin, wld, xl, ld, dim, dim, batch, g_W, nullptr, vec, st);
     NRX_LAUNCH_CHECK("nrx_dcn_v2_layer_bwd");
     return NRX_OK;
 }
 
 extern "C" int nrx_linear_wgrad(const float* g, int64_t g_ld, const float* a, int64_t a_ld, int64_t batch, int32_t out_features,
-                                int32_t in_features, float* g_W, void* stream) {
+                                int32_t in_features, float* g_W, float* g_b, void* stream) {
     NRX_REQUIRE(g && a && g_W && batch >= 0 && out_features >= 1 && in_features >= 1 && g_ld >= out_features && a_ld >= in_features,
                 "nrx_linear_wgrad: bad argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (nrx_zero_async(g_W, sizeof(float) * (size_t)out_features * in_features, st) != NRX_OK) return NRX_ERR_LAUNCH;
+    if (g_b != nullptr && nrx_zero_async(g_b, sizeof(float) * (size_t)out_features, st) != NRX_OK) return NRX_ERR_LAUNCH;
     if (batch == 0) return NRX_OK;
     const bool vec = (g_ld & 3) == 0 && (a_ld & 3) == 0 && (out_features & 3) == 0 && (in_features & 3) == 0 && nrx_aligned16(g) && nrx_aligned16(a);
-    launch_wgrad(g, g_ld, a, a_ld, out_features, in_features, batch, g_W, vec, st);
+    launch_wgrad(g, g_ld, a, a_ld, out_features, in_features, batch, g_W, g_b, vec, st);
     NRX_LAUNCH_CHECK("nrx_linear_wgrad");
     return NRX_OK;
 }

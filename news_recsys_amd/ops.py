@@ -1215,11 +1215,14 @@ class _LinearFn(torch.autograd.Function):
         ga = gW = gb = None
         if ctx.needs_input_grad[0]:
             ga = (g2 @ W).reshape(a.shape)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             gW = torch.empty_like(W, memory_format=torch.contiguous_format)
+            if want_b:                        # the bias gradient comes out of the same pass over g
+                gb = torch.empty((W.shape[0],), dtype=torch.float32, device=W.device)
             check(lib.nrx_linear_wgrad(g2.data_ptr(), g2.stride(0), a2.data_ptr(), a2.stride(0), g2.shape[0], W.shape[0], W.shape[1],
-                                       gW.data_ptr(), _stream_ptr(g2)), "nrx_linear_wgrad")
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+                                       gW.data_ptr(), _ptr(gb), _stream_ptr(g2)), "nrx_linear_wgrad")
+        elif want_b:
             gb = g2.sum(0)
         return ga, gW, gb
 

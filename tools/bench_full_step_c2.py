@@ -68,7 +68,7 @@ for _ in range(4):
 
 ISSUE = {}
 
-def timeit(step, n=30, warm=8):
+def timeit(step, n=30, warm=40):          # the caching allocator keeps growing for ~40 steps (a device allocation costs milliseconds of host time)
     for i in range(warm): step(batches[i % 4])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -86,8 +86,11 @@ def run_package(mode, label):
         loss = F.binary_cross_entropy(out.view(-1), b["label"][:, 0])
         loss.backward()
         opt.step()
+    n0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     ms = timeit(step)
     print(f"{label:78s} {ms:8.2f} ms/step  {B / ms / 1e3:7.2f} M impressions/s   (host enqueue {ISSUE['ms']:.2f} ms/step)", flush=True)
+    if os.environ.get("HOST_BREAKDOWN") == "1":
+        print(f"      device allocations during the 70 steps: {torch.cuda.memory_stats().get('num_device_alloc', 0) - n0}", flush=True)
     if os.environ.get("HOST_BREAKDOWN") == "1":       # host time of each part of the step (nothing synchronises inside)
         acc = [0.0] * 5
         for i in range(30):
@@ -119,12 +122,48 @@ if os.environ.get("ONLY_A") == "1":               # tools/host_profile_step_c2.p
     pr.disable(); torch.cuda.synchronize()
     st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(45)
     sys.exit(0)
-run_package("fused", "(a) this package, sparse_grad: fused (row-sparse backward + fused row-sparse Adam)")
+LEGS = set(os.environ.get("LEGS", "a,a1,a1g,ag,b,c").split(","))          # which lines to produce (rocprofv3 runs pick one)
+if "a" in LEGS:
+    run_package("fused", "(a) this package, sparse_grad: fused (row-sparse backward + fused row-sparse Adam)")
 from news_recsys_amd.model.model_utils import utils as _mlp_utils
 _mlp_utils.MLP_WGRAD = True
-run_package("fused", "(a') as (a) with the MLP weight gradients on nrx_linear_wgrad (NRX_MLP_WGRAD=1)")
+if "a1" in LEGS:
+    run_package("fused", "(a') as (a) with the MLP weight gradients on nrx_linear_wgrad (NRX_MLP_WGRAD=1)")
+def run_graphed(label):
+    """(a) / (a') replayed from a HIP graph (news_recsys_amd.graph.GraphedStep): the host enqueues one graph launch per step."""
+    from news_recsys_amd.graph import GraphedStep
+    from news_recsys_amd.model.model_utils.optim import SparseDenseAdam
+    m, _ = make_model("fused")
+    tabs = [e.weight for e in m.embedding_tables.values()]
+    ids = {id(p) for p in tabs}
+    opt = SparseDenseAdam(tabs, [p for p in m.parameters() if id(p) not in ids], lr=1e-3, fused_sink=m._sparse_sink, capturable=True)
+    def step(b):
+        opt.zero_grad(set_to_none=False)
+        loss = F.binary_cross_entropy(m(b).view(-1), b["label"][:, 0])
+        loss.backward()
+        opt.step()
+        return loss
+    prev = ops._INDEX_CHECK
+    ops.set_index_check("off")
+    try:
+        gs = GraphedStep(step, batches[0], warmup=3)
+        ms = timeit(lambda b: gs(b))
+    finally:
+        ops.set_index_check(prev)
+    print(f"{label:78s} {ms:8.2f} ms/step  {B / ms / 1e3:7.2f} M impressions/s   (host enqueue {ISSUE['ms']:.2f} ms/step)", flush=True)
+    del gs, m, opt
+    torch.cuda.empty_cache()
+
+if "a1g" in LEGS:
+    run_graphed("(a'g) (a') replayed from a HIP graph (GraphedStep; ids not range-checked inside a replay)")
 _mlp_utils.MLP_WGRAD = False
-run_package("false", "(b) this package, the reference's arrangement (dense table grads + AdamW over all rows)")
+if "ag" in LEGS:
+    run_graphed("(ag) (a) replayed from a HIP graph")
+if "b" in LEGS:
+    run_package("false", "(b) this package, the reference's arrangement (dense table grads + AdamW over all rows)")
+
+if "c" not in LEGS:
+    sys.exit(0)
 
 class Stock(nn.Module):
     def __init__(self):

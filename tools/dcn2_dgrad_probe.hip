@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     const unsigned nt = nx * (unsigned)((B + BM - 1) / BM);
     auto dgrad = [&](const uint32_t* mask, const float* fold) {
         hipLaunchKernelGGL((dcn2_gemm_kernel<DGRAD, true>), dim3(nt), dim3(256), 0, 0, glin, (int64_t)D, W, (int64_t)D, B, D, (int64_t)D, (int64_t)D,
-                           g, (int64_t)D, mask, (int64_t)D, gxl, (int64_t)D, nx, nt, fold, (int64_t)D);
+                           g, (int64_t)D, mask, (int64_t)D, gxl, (int64_t)D, nx, nt, fold, (int64_t)D, (float*)nullptr);
     };
     const double gf = 2.0 * B * D * D * 1e-9;
     float t;
@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
         splits = (B + kslice - 1) / kslice;
         t = timeit([&] {
             hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, true, 1>), dim3((unsigned)(wnt * splits)), dim3(256), 0, 0, glin, (int64_t)D, xl, (int64_t)D, (int64_t)D, D, B,
-                               kslice, (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, gW, (int64_t)D, nx, wnt, (const float*)nullptr, (int64_t)0);
+                               kslice, (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, gW, (int64_t)D, nx, wnt, (const float*)nullptr, (int64_t)0, (float*)nullptr);
         }, warm, iters);
         printf("D=%d wgrad 64x64 (%u tiles x %lld slices of %lld rows)   %7.1f us  %5.1f TF\n", D, wnt, (long long)splits, (long long)kslice, t, gf / t * 1e3);
     }
@@ -61,7 +61,7 @@ int main(int argc, char** argv) {
         splits = (B + kslice - 1) / kslice;
         t = timeit([&] {
             hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, true>), dim3((unsigned)(wnt * splits)), dim3(256), 0, 0, glin, (int64_t)D, xl, (int64_t)D, (int64_t)D, D, B,
-                               kslice, (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, gW, (int64_t)D, nx, wnt, (const float*)nullptr, (int64_t)0);
+                               kslice, (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, gW, (int64_t)D, nx, wnt, (const float*)nullptr, (int64_t)0, (float*)nullptr);
         }, warm, iters);
         printf("D=%d wgrad (%u tiles x %lld slices of %lld rows)   %7.1f us  %5.1f TF\n", D, wnt, (long long)splits, (long long)kslice, t, gf / t * 1e3);
     }

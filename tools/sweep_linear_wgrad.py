@@ -12,9 +12,9 @@ st = torch.cuda.current_stream().cuda_stream
 tag = " ".join(f"{k}={os.environ[k]}" for k in ("NRX_WGRAD_TILE", "NRX_WGRAD_BLOCKS", "NRX_WGRAD_MIN_ROWS") if k in os.environ) or "default"
 res = []
 for o, i in shapes:
-    g = torch.randn(B, o, device="cuda"); a = torch.randn(B, i, device="cuda"); gW = torch.empty(o, i, device="cuda")
+    g = torch.randn(B, o, device="cuda"); a = torch.randn(B, i, device="cuda"); gW = torch.empty(o, i, device="cuda"); gb = torch.empty(o, device="cuda")
     def run():
-        rc = lib.nrx_linear_wgrad(g.data_ptr(), o, a.data_ptr(), i, B, o, i, gW.data_ptr(), st)
+        rc = lib.nrx_linear_wgrad(g.data_ptr(), o, a.data_ptr(), i, B, o, i, gW.data_ptr(), gb.data_ptr(), st)
         assert rc == 0
     def ref():
         return g.t() @ a
