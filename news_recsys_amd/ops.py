@@ -1194,7 +1194,7 @@ def dcn_v2(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, relu: bool = True)
 
 # ------------------------------------------------------------------------------- integer utilities
 class _LinearFn(torch.autograd.Function):
-    """y = a W^T + b with the weight gradient on nrx_linear_wgrad (the batch is the contraction there: at B = 65 536 the vendor
+    """y = a W^T + b with the weight and bias gradients on nrx_linear_wgrad (the batch is the contraction there: at B = 65 536 the vendor
     GEMM takes 0.2-0.3 ms per MLP layer, the split-over-the-batch MFMA kernel of the DCN-v2 backward a fraction of that).  The
     forward and the input gradient stay on the vendor GEMM.  Reference layer: src/model/model_utils/utils.py:6-17."""
 
