@@ -75,18 +75,20 @@ def test_c3_real_100m_row_table_gather_and_fused_cross():
     for dt in (torch.int64, torch.int32):
         out = ops.embed_apply(plan, tables, [x.to(dt) for x in ids], [None] * 5)[0]
         assert torch.equal(out, want)
-    # the C3 bench path: one fused launch gather -> cat[x, cross(x)]; x half bit-exact, cross half vs fp64 on a sample
+    # the C3 bench path: one fused launch gather -> cat[x, cross(x)]; x half bit-exact, cross half vs fp64 and vs the two-launch form on every row
     W = 5 * D
     w = torch.randn(2, W, device=DEV, generator=gen) / W ** 0.5 * 1e-3
     b = torch.randn(2, W, device=DEV, generator=gen)
     buf = ops.embed_dcn_v1(plan, tables, ids, w, b)
     assert torch.equal(buf[:, :W], want)
-    sub = slice(0, B, 61)
-    x0 = want[sub].double()
+    x0 = want.double()                                                     # every row of the batch, in fp64
     xl = x0
     for l in range(2):
         xl = x0 * (xl @ w[l].double())[:, None] + b[l].double() + xl
-    torch.testing.assert_close(buf[sub, W:].double(), xl, rtol=1e-5, atol=1e-5 * xl.abs().max().item())
+    torch.testing.assert_close(buf[:, W:].double(), xl, rtol=1e-5, atol=1e-5 * xl.abs().max().item())
+    del x0, xl
+    two = ops.dcn_v1(want, w, b)                                           # the two-launch form of the same cross, every row
+    torch.testing.assert_close(buf[:, W:], two, rtol=1e-6, atol=1e-6 * two.abs().max().item())
 
 
 def test_c4_real_10m_user_table_and_history_pooling():
