@@ -65,5 +65,33 @@ int main(int argc, char** argv) {
         }, warm, iters);
         printf("D=%d wgrad (%u tiles x %lld slices of %lld rows)   %7.1f us  %5.1f TF\n", D, wnt, (long long)splits, (long long)kslice, t, gf / t * 1e3);
     }
+    {   // dgrad and wgrad of one layer: back to back on one stream vs side by side on two (both read glin; each alone sits at the sum of its
+        // matrix and memory bounds -- do the phases of two different kernels overlap?)
+        const unsigned wnt = nx * (unsigned)((D + 63) / 64);
+        int64_t splits = (1536 + wnt - 1) / wnt;
+        int64_t kslice = ((B + splits - 1) / splits + BK - 1) / BK * BK;
+        if (kslice < 16 * BK) kslice = 16 * BK;
+        splits = (B + kslice - 1) / kslice;
+        hipStream_t s1, s2; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+        hipEvent_t ef, ej; hipEventCreateWithFlags(&ef, hipEventDisableTiming); hipEventCreateWithFlags(&ej, hipEventDisableTiming);
+        auto pair = [&](bool two) {
+            hipStream_t sw = two ? s2 : s1;
+            if (two) { hipEventRecord(ef, s1); hipStreamWaitEvent(s2, ef, 0); }
+            hipLaunchKernelGGL((dcn2_gemm_kernel<DGRAD, true>), dim3(nt), dim3(256), 0, s1, glin, (int64_t)D, W, (int64_t)D, B, D, (int64_t)D, (int64_t)D,
+                               g, (int64_t)D, mbits, (int64_t)D, gxl, (int64_t)D, nx, nt, (const float*)nullptr, (int64_t)D, (float*)nullptr);
+            hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, true, 1>), dim3((unsigned)(wnt * splits)), dim3(256), 0, sw, glin, (int64_t)D, xl, (int64_t)D, (int64_t)D, D, B,
+                               kslice, (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, gW, (int64_t)D, nx, wnt, (const float*)nullptr, (int64_t)0, (float*)nullptr);
+            if (two) { hipEventRecord(ej, s2); hipStreamWaitEvent(s1, ej, 0); }
+        };
+        for (int two = 0; two < 2; ++two) {
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            for (int i = 0; i < warm; ++i) pair(two);
+            hipEventRecord(e0, s1);
+            for (int i = 0; i < iters; ++i) pair(two);
+            hipEventRecord(e1, s1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("D=%d dgrad + wgrad %s: %7.1f us per pair\n", D, two ? "on two streams (fork / join by events)" : "back to back on one stream", ms * 1e3f / iters);
+        }
+    }
     return 0;
 }
