@@ -66,8 +66,14 @@ def test_graphed_training_step_matches_eager():
             assert abs(le - lg) <= 1e-5 * max(1.0, abs(le))      # float atomics in the dense scatter: order differs run to run
     finally:
         ops.set_index_check(mode_before)
+    # Adam's first steps move a weight by ~lr * sign(gradient): where a gradient is within float-atomic reordering of zero, the
+    # two runs may step in different directions (seen: 3 of 16 384 weights of one layer 6e-5 apart, about once in 35 runs).
+    # A replay that was NOT the eager step (stale inputs, a skipped or doubled update) moves every weight, by up to lr per step.
+    lr, n_steps = 1e-3, len(batches)
     for p, q in zip(m_e.parameters(), m_g.parameters()):
-        torch.testing.assert_close(p, q, rtol=0, atol=5e-5)      # Adam turns an atomic-order ulp in a tiny gradient into ~lr-sized steps
+        d = (p - q).abs()
+        assert d.max().item() <= 2 * lr * n_steps
+        assert (d > 5e-5).float().mean().item() <= 2e-3, (d > 5e-5).sum().item()
     with pytest.raises(ValueError):
         gs(_batch(m_e, 128, gen))                               # a different batch shape cannot be replayed
 
