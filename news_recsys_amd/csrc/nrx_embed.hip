@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_generic(const EmbedArgs a
                 int64_t* s_off = reinterpret_cast<int64_t*>(s_bag + TB * stride);
                 if (f.flags & NRX_FEAT_BAG_CSR) {
                     __syncthreads();            // (the previous feature's readers are done with the LDS area)
-                    if (tid <= nb) s_off[tid] = reinterpret_cast<const int64_t*>(f.weight)[b0 + tid];
+                    for (int i = tid; i <= nb; i += NRX_BLOCK) s_off[i] = reinterpret_cast<const int64_t*>(f.weight)[b0 + i];   // nb + 1 entries: nb can equal NRX_BLOCK
                 }
                 for (int l0 = 0; l0 < L; l0 += lc) {
                     const int cur = (L - l0) < lc ? (L - l0) : lc;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
             int64_t* s_off = reinterpret_cast<int64_t*>(s_bag + TB * stride);
             if (f.flags & NRX_FEAT_BAG_CSR) {
                 __syncthreads();
-                if (tid <= nb) s_off[tid] = reinterpret_cast<const int64_t*>(f.weight)[b0 + tid];
+                for (int i = tid; i <= nb; i += NRX_BLOCK) s_off[i] = reinterpret_cast<const int64_t*>(f.weight)[b0 + i];   // nb + 1 entries: nb can equal NRX_BLOCK
             }
             for (int l0 = 0; l0 < L; l0 += lc) {
                 const int cur = (L - l0) < lc ? (L - l0) : lc;

@@ -304,6 +304,14 @@ class BaseModel(LightningModule):
         self._val_score.append(scores.detach().float())
         self._val_label.append(batch["label"].reshape(-1)[:n].float())     # the reference zips view(-1): first n labels
 
+    def on_train_epoch_end(self):
+        """Lightning hook (the reference defines none on BaseModel): an out-of-range id met by the LAST training batches'
+        deferred index checks must not stay unreported until some later call -- it raises here (IndexError)."""
+        ops.flush_index_checks()
+
+    def on_fit_end(self):
+        ops.flush_index_checks()
+
     def on_validation_epoch_end(self):
         """GAUC / NDCG@10 / HR@10 / MRR@10 / AUC / LogLoss with the warm-cold split, computed on the device
         (news_recsys_amd/metrics.py); prints and appends the reference's text block to val_log.log.  Unlike the

@@ -210,6 +210,7 @@ class DSSM(BaseModel):
 
     @torch.no_grad()
     def on_train_epoch_end(self):
+        super().on_train_epoch_end()          # deferred index checks of the epoch's last batches
         if self.movies_dataloader is None or self.val_dataloader_ is None:
             return
         self.build_item_index()

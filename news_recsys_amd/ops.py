@@ -32,7 +32,7 @@ _INDEX_CHECK = "sync"      # "sync": raise IndexError in the offending call (ref
                            # "lazy": device status + event per call, checked once the event has passed; "off": never read back
 _pending_status: List[Tuple[torch.Tensor, "torch.cuda.Event", Sequence[str]]] = []
 _host_status: Optional[torch.Tensor] = None       # pinned int32[4] the GPU writes through its mapped address
-_host_status_names: Sequence[str] = ()
+_host_status_names: List[Sequence[str]] = []       # feature-name lists of the launches since the status word was last clear
 
 
 def set_index_check(mode: str) -> None:
@@ -45,23 +45,41 @@ def set_index_check(mode: str) -> None:
 def _deferred_status(names: Sequence[str]) -> torch.Tensor:
     """The process-wide host-mapped status word of the 'deferred' mode.  An offence recorded by an EARLIER launch raises
     here (IndexError, one call late instead of never); the word is only ever written by a kernel that met a bad id, so
-    the check is a read of four host integers."""
-    global _host_status, _host_status_names
+    the check is a read of four host integers.  Several plans may launch between two checks (DSSM's towers, the wide and
+    deep halves): every launch's name list is remembered until the word has been seen clear again, and the report names
+    the feature only as far as those lists agree."""
+    global _host_status
     if _host_status is None:
         _host_status = torch.zeros(4, dtype=torch.int32).pin_memory()
     elif _host_status[0] != 0:
         _raise_deferred()
-    _host_status_names = names
+    if not any(n is names for n in _host_status_names):
+        if len(_host_status_names) >= 16:      # launches still in flight are at most a few calls back
+            del _host_status_names[0]
+        _host_status_names.append(names)
     return _host_status
 
 
 def _raise_deferred() -> None:
+    # the kernel publishes the count (atomicAdd) BEFORE the first offender's feature / sample / id words: a non-zero
+    # count can be visible with a stale payload.  This is the error path -- wait for the device, then read
+    torch.cuda.synchronize()
     st = _host_status.tolist()
     _host_status.zero_()
-    names = _host_status_names
-    fname = names[st[1]] if 0 <= st[1] < len(names) else f"#{st[1]}"
+    cands = []
+    for names in _host_status_names:
+        n = names[st[1]] if 0 <= st[1] < len(names) else None
+        if n is not None and n not in cands:
+            cands.append(n)
+    del _host_status_names[:]
+    if len(cands) == 1:
+        fname = f"'{cands[0]}'"
+    elif cands:
+        fname = f"#{st[1]} of its launch (one of: {', '.join(repr(c) for c in cands)})"
+    else:
+        fname = f"#{st[1]}"
     raise IndexError(f"index out of range in self (reported by an earlier launch): {st[0]} lookup(s); first: feature "
-                     f"'{fname}', sample {st[2]}, id {st[3]}")
+                     f"{fname}, sample {st[2]}, id {st[3]}")
 
 
 def _raise_if_oob(status: torch.Tensor, names: Sequence[str]) -> None:
@@ -412,6 +430,11 @@ def sparse_plan_ahead(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows
     cur = torch.cuda.current_stream(dev)
     side = _plan_stream(dev)
     side.wait_stream(cur)                      # the ids are ready where the caller's stream is now
+    for x in ids:
+        # the planner READS the ids on the side stream: tell the caching allocator, or an id tensor that dies early (a
+        # .long() / .contiguous() temporary, a csr_to_padded output, a forward whose loss is dropped without a backward)
+        # could have its block handed out again on the caller's stream while the sort is still reading it
+        x.record_stream(side)
     with torch.cuda.stream(side):
         res = sparse_plan(ids, table_of, rows, n_tables)
         ev = torch.cuda.Event()

@@ -33,8 +33,8 @@ import os
 import sys
 
 if os.environ.get("PYTHONHASHSEED") != "0":          # before torch / the reference are imported: pin the set order
-    os.environ["PYTHONHASHSEED"] = "0"
-    os.execv(sys.executable, [sys.executable] + sys.argv)
+    import subprocess                                # (a child process, not an exec: no exec anywhere in this tree)
+    sys.exit(subprocess.run([sys.executable] + sys.argv, env={**os.environ, "PYTHONHASHSEED": "0"}).returncode)
 
 import tempfile
 import types

@@ -45,7 +45,9 @@ def plans(kind, D, L, extra_sparse=True):
 
 @pytest.mark.parametrize("kind", [NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM])
 @pytest.mark.parametrize("B,L,D,dtype", [(1, 5, 16, np.int64), (257, 50, 16, np.int32), (1000, 7, 64, np.int64), (300, 130, 8, np.int64),
-                                         (65, 33, 6, np.int32)])
+                                         (65, 33, 6, np.int32),
+                                         # dims <= 4 put 256 samples in a block: the offsets staging needs 257 entries
+                                         (513, 5, 1, np.int64), (700, 9, 4, np.int32), (256, 3, 1, np.int64), (257, 6, 2, np.int64)])
 def test_csr_bag_forward_equals_padded_and_oracle(kind, B, L, D, dtype):
     rng = np.random.default_rng(B * 131 + L + D + kind)
     rows = 200
@@ -112,9 +114,10 @@ def test_csr_bag_argument_errors():
 
 @pytest.mark.parametrize("sparse_grad", [False, True])
 @pytest.mark.parametrize("kind", [NRX_BAG_MASKED_MEAN, NRX_BAG_SUM])
-def test_csr_bag_backward_matches_padded(kind, sparse_grad):
-    rng = np.random.default_rng(77 + kind)
-    B, L, D, rows = 400, 20, 16, 120
+@pytest.mark.parametrize("B,D", [(400, 16), (600, 1), (513, 4)])        # D <= 4: 256 samples per block (257 staged offsets)
+def test_csr_bag_backward_matches_padded(kind, sparse_grad, B, D):
+    rng = np.random.default_rng(77 + kind + B)
+    L, rows = 20, 120
     t0 = rng.standard_normal((rows, D)).astype(np.float32)
     u0 = rng.standard_normal((50, D)).astype(np.float32)
     values, offsets = rand_csr(rng, B, L, rows, np.int64)

@@ -130,6 +130,29 @@ def test_per_feature_api_matches_fused():
     ops.flush_index_checks()
 
 
+def test_deferred_index_check_names_the_right_plan_and_flushes_at_epoch_end():
+    """Two different plans launch between two checks (as DSSM's towers do): the report must not name a feature of the
+    wrong plan, and an offence in the LAST training batch surfaces at on_train_epoch_end."""
+    from news_recsys_amd import ops
+    g = gold("model_deep_array")
+    m = load_model(Deep, "cf_array_small.yaml", g)
+    batch = batch_of(g)
+    ops.flush_index_checks()
+    bad = dict(batch)
+    bad["category"] = torch.full_like(batch["category"], 10 ** 6)
+    m.get_embeddings_from_batch(bad, {"category", "user_history"})                  # plan A: offender = 'category'
+    with pytest.raises(IndexError) as ei:
+        # plan B's call raises if plan A's kernel has already finished (the unsynchronised check at its start sees the
+        # word); if it is still in flight plan B launches too and the epoch-end hook raises
+        m.get_embeddings_from_batch(batch, {"item_id", "user_id"})
+        m.on_train_epoch_end()
+    msg = str(ei.value)
+    assert "category" in msg and "sample 0" in msg and "id 1000000" in msg
+    assert "'item_id'" not in msg.split("one of")[0]                                # never plainly blamed on plan B's feature
+    m.on_fit_end()                                                                   # clear again: nothing raised
+    m.get_embeddings_from_batch(batch, {"category", "user_history"})
+
+
 def test_dssm_towers_and_losses_match_reference():
     g = gold("model_dssm")
     hp = {"negative_sample_rate": 3, "lr": 1e-3, "min_lr": 1e-5, "lr_milestones": [4, 20]}

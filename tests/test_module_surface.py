@@ -211,3 +211,27 @@ def test_dssm_keeps_configured_user_history_and_maps_ids(tmp_path):
     m.emb_idx_2_val_dict = {"user_id": {"3": "u3"}, "item_id": {"1": "A", "5": "B", "7": "C"}}
     m.user_history = {"u3": {"C": 1, "A": 1}}
     assert m._history_positions(3) == [0, 2]
+
+
+def test_deferred_index_report_with_several_plans_in_flight(monkeypatch):
+    """Host half of the 'deferred' index check (ops._deferred_status / _raise_deferred): with two plans launched between two
+    checks, the offender's feature index is resolved against BOTH name lists -- named plainly only when they agree."""
+    import torch
+    from news_recsys_amd import ops
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(ops, "_host_status", torch.zeros(4, dtype=torch.int32))
+    monkeypatch.setattr(ops, "_host_status_names", [])
+    a, b = ["category", "user_history"], ["item_id", "user_id"]
+    st = ops._deferred_status(a)
+    assert ops._deferred_status(b) is st and ops._host_status_names == [a, b]
+    st.copy_(torch.tensor([3, 0, 7, 99], dtype=torch.int32))              # what a kernel of EITHER plan would have written
+    with pytest.raises(IndexError) as ei:
+        ops._deferred_status(a)
+    msg = str(ei.value)
+    assert "one of: 'category', 'item_id'" in msg and "sample 7" in msg and "id 99" in msg and "3 lookup" in msg
+    assert int(st[0]) == 0 and ops._host_status_names == []               # cleared: the next launch starts a new window
+    ops._deferred_status(a)
+    st.copy_(torch.tensor([1, 1, 2, 5], dtype=torch.int32))
+    with pytest.raises(IndexError) as ei:
+        ops._deferred_status(a)
+    assert "feature 'user_history'" in str(ei.value)                      # one plan in the window: named plainly
