@@ -173,6 +173,32 @@ NRX_API int nrx_sparse_plan(const void* const* ids, const int64_t* lens, const i
                     int32_t n_feats, int32_t index_bits, int32_t n_tables, int64_t* order, int64_t* uniq_keys,
                     int64_t* seg_start, int64_t* counts, void* workspace, void* stream);
 
+/* nrx_sparse_plan plus the PLACEMENT of the rows that need no reduction (autograd of nn.Embedding,
+ * src/model/BaseModel/base_model.py:262-308, gives a row looked up once exactly that lookup's upstream row).
+ * A unique (table, row) that is looked up exactly once in the launch, is not the padding row, and whose lookup belongs to a
+ * feature f with bit f of place_feats set (pass the single-valued features: a bag lookup is scaled, not copied), is "placed":
+ *   dest   [n]        int32: dest[p] = the unique index u of lookup p's row if that row is placed, else -1 (written for the
+ *                            lookups of the features in place_feats only; the other words are left untouched)
+ *   walk   [<= n]     int32: the unique indices that are NOT placed (several lookups, a non-placeable lookup, row 0), ascending
+ *   n_walk [1]        int64: how many
+ * nrx_embed_bwd_placed streams the upstream rows sample-major and stores the placed ones (coalesced reads, one 4-D-byte
+ * write per row; the walk of every sorted entry re-fetches upstream rows at random: 128-byte fabric requests for 64-byte rows)
+ * and reduces only the `walk` rows in sorted order.  Everything else as nrx_sparse_plan (same workspace size). */
+NRX_API int nrx_sparse_plan_place(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
+                          int32_t n_feats, int32_t index_bits, int32_t n_tables, uint64_t place_feats, int64_t* order,
+                          int64_t* uniq_keys, int64_t* seg_start, int64_t* counts, int32_t* dest, int32_t* walk,
+                          int64_t* n_walk, void* workspace, void* stream);
+
+/* nrx_embed_bwd_sorted driven by a placement plan (nrx_sparse_plan_place): same arguments and the same values[] -- bit for
+ * bit -- plus dest / walk / n_walk.  place_feats must be the mask the plan was made with; it may only name NRX_SPARSE
+ * features.  Launch shapes outside the fast form (odd dims, unaligned FM inputs) ignore the placement and walk every row. */
+NRX_API int nrx_embed_bwd_placed(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                         const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                         const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
+                         int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
+                         uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
+                         void* workspace, void* stream);
+
 /* Fused row-sparse Adam(W) over the unique rows of nrx_sparse_plan / nrx_embed_bwd_sorted: for every unique entry u
  * (key = (table << 40) | row, gradient grads[u, :dim]) of up to NRX_MAX_FEATURES tables sharing `dim`,
  *   m += (g - m)(1 - beta1);  v += (g*g - v)(1 - beta2);  w -= w * lr_times_weight_decay;

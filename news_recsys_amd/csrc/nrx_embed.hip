@@ -416,6 +416,8 @@ struct SortedBwdArgs {
     int32_t n;
     int32_t dim;
     int32_t long_t;
+    const int32_t* walk;           // placement mode (nrx_embed_bwd_placed): the unique rows this launch reduces, and how many;
+    const int64_t* n_walk_dev;     //   null = every unique row
     int32_t regular;               // 1: every feature single-valued, no wide routing, uniform_len > 0, out_col = col0 + i * col_stride,
     int32_t col0, col_stride;      //    one FM flag for all -- the per-feature fields are then arithmetic on the feature index
     int32_t all_fm;
@@ -640,23 +642,202 @@ __device__ __forceinline__ FeatLite sorted_feat(const NRX_CONST SortedBwdArgs* a
     f.bag_len = a->f[fi].bag_len; f.kind = a->f[fi].kind; f.fm = a->f[fi].fm != 0;
     return f;
 }
+// d fm / d field folded into an upstream row chunk (columns 4q .. 4q+3 of the field): column 0 -> g_fm, column k -> g_fm (S_k - v_k).
+// One definition (explicit fused multiply-adds) for the walk, the work-list and the placement kernels: their results must agree
+// bit for bit.
+__device__ __forceinline__ void fm_fold4(float4& t, float gf, const float4& s, const float4& v, int q) {
+    t.x = q == 0 ? t.x + gf : __builtin_fmaf(gf, s.x - v.x, t.x);
+    t.y = __builtin_fmaf(gf, s.y - v.y, t.y);
+    t.z = __builtin_fmaf(gf, s.z - v.z, t.z);
+    t.w = __builtin_fmaf(gf, s.w - v.w, t.w);
+}
+
+// Columns 4q .. 4q+3 of a feature's upstream row.  UNAL: see above (shifted deep blocks, column 0 from the wide gradient).
 template <bool UNAL>
-__device__ __forceinline__ float4 sorted_upstream(const NRX_CONST SortedBwdArgs* a, const FeatLite& f, int64_t b, int q) {
-    if (!UNAL) return a->g_out ? nrx_ldg4(a->g_out, (b * a->out_ld + f.out_col) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int wc = f.wide_col;                                 // the lanes of a group share the feature
+__device__ __forceinline__ float4 upstream_chunk(const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld, int out_col,
+                                                 int wide_col, int64_t b, int q) {
+    if (!UNAL) return g_out ? nrx_ldg4(g_out, (b * out_ld + out_col) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int wc = wide_col;                                   // the lanes of a group share the feature
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     // one load shape for every lane (a second path for "lane 0 of a wide feature" would run serially in every wavefront that
     // mixes wide and plain rows): 16 bytes at the shifted position; lane 0 of a wide feature thereby reads one float of the
     // previous feature's block, which the select below replaces by the wide gradient -- except at the very first element of
     // g_out (sample 0, column 0), where the load starts one float later and is shifted back in registers
-    int64_t eo = b * a->out_ld + f.out_col + 4 * q - (wc >= 0 ? 1 : 0);
+    int64_t eo = b * out_ld + out_col + 4 * q - (wc >= 0 ? 1 : 0);
     const bool edge = eo < 0;
-    if (a->g_out) {
-        const nrx_f32x4u t = *reinterpret_cast<const nrx_f32x4u*>(a->g_out + (edge ? 0 : eo));
+    if (g_out) {
+        const nrx_f32x4u t = *reinterpret_cast<const nrx_f32x4u*>(g_out + (edge ? 0 : eo));
         g = edge ? make_float4(0.f, t.x, t.y, t.z) : make_float4(t.x, t.y, t.z, t.w);
     }
-    if (wc >= 0 && q == 0) g.x = a->g_wide ? nrx_gconst<float>(a->g_wide)[b * a->wide_ld + wc] : 0.f;
+    if (wc >= 0 && q == 0) g.x = g_wide ? nrx_gconst<float>(g_wide)[b * wide_ld + wc] : 0.f;
     return g;
+}
+template <bool UNAL>
+__device__ __forceinline__ float4 sorted_upstream(const NRX_CONST SortedBwdArgs* a, const FeatLite& f, int64_t b, int q) {
+    return upstream_chunk<UNAL>(a->g_out, a->out_ld, a->g_wide, a->wide_ld, f.out_col, f.wide_col, b, q);
+}
+
+// ---- Placement pass (nrx_embed_bwd_placed).  A unique row looked up ONCE in the launch needs no reduction: its gradient is
+// that lookup's upstream row.  The plan (nrx_sparse_plan_place) says where it goes: dest[flat lookup] = unique index, or -1.
+// This kernel is the forward ring kernel run backwards: a sample is owned by Q lanes, the block's dest words go through LDS
+// once (coalesced), the upstream rows -- g_out, and for FM fields the forward concat and the field sums -- are read where
+// they lie, sample-major and fully coalesced, and each placed row leaves as one 4-D-byte store.  The sorted walk reads the
+// same rows through the sort permutation instead: one 128-byte fabric request per 64-byte row and array (C2: 678 MB of
+// requests for 230 MB of operands -- profiles/r03_bwd_c2_counters_before.txt).
+struct PlaceArgs {
+    int64_t off[NRX_MAX_FEATURES];       // flat lookup offset of the i-th PLACEABLE (single-valued) feature
+    int32_t out_col[NRX_MAX_FEATURES];
+    int32_t wide_col[NRX_MAX_FEATURES];
+    uint8_t fm[NRX_MAX_FEATURES];
+    int64_t batch;
+    const float* g_out;
+    int64_t out_ld;
+    const float* g_wide;
+    int64_t wide_ld;
+    const float* g_fm;
+    const float* fm_sums;
+    int64_t sums_ld;
+    const float* feat;
+    int64_t feat_ld;
+    const int32_t* dest;
+    float* values;
+    int32_t* long_ws;                    // the walk's four work-list counters: cleared here (the walk is the next launch)
+    int32_t n;
+    int32_t nt;                          // non-temporal upstream loads (default; NRX_PLACE_NT=0 turns them off): the rows are read once
+};
+static_assert(sizeof(PlaceArgs) <= 3584, "kernarg budget");
+
+template <int QLOG2, int U, bool FM, bool UNAL>
+__global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceArgs args_in_kernarg) {
+    const NRX_CONST PlaceArgs* a = nrx_kernarg<PlaceArgs>();
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;                 // samples per block (<= 64)
+    constexpr int FPW = 64 / TB;                      // features staged per wavefront instruction
+    extern __shared__ __attribute__((aligned(16))) int32_t s_dest[];      // [n][TB]
+    const int tid = threadIdx.x;
+    const int n = a->n;
+    const int64_t b0 = (int64_t)blockIdx.x * TB;
+    const int nb = (int)((a->batch - b0) < (int64_t)TB ? (a->batch - b0) : (int64_t)TB);
+    if (blockIdx.x == 0 && tid < 4 && a->long_ws != nullptr) a->long_ws[tid] = 0;
+    {   // ---- stage the block's dest words: a wavefront instruction covers FPW features x TB samples (TB consecutive words each)
+        const int lane = tid & 63, wave = tid >> 6;
+        const int s = lane & (TB - 1), fl = lane / TB;
+        constexpr int PASS = 4;
+        for (int k0 = 0; k0 * 4 * FPW < n; k0 += PASS) {
+            int32_t d[PASS];
+#pragma unroll
+            for (int u = 0; u < PASS; ++u) {
+                const int f = ((k0 + u) * 4 + wave) * FPW + fl;
+                const int fc = f < n ? f : n - 1;
+                d[u] = nrx_gconst<int32_t>(a->dest)[a->off[fc] + b0 + (s < nb ? s : nb - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < PASS; ++u) {
+                const int f = ((k0 + u) * 4 + wave) * FPW + fl;
+                if (f < n) s_dest[f * TB + s] = s < nb ? d[u] : -1;
+            }
+        }
+    }
+    __syncthreads();
+    const int q = tid & (Q - 1);
+    const int sb = tid >> QLOG2;
+    const int64_t b = b0 + sb;
+    if (b >= a->batch) return;
+    float gf = 0.f;
+    float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FM) {
+        gf = nrx_gconst<float>(a->g_fm)[b];
+        S = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
+    }
+    // Measured on C2 (26 x D=16, FM; profiles/r03_place_variants.txt): the pass alone 78 us = loads only 38 us + stores only 28 us and
+    // then some -- sequential reads and random 64-byte row writes do not overlap well; non-temporal loads -7 us (C5 set: -16 us),
+    // 4 instead of 8 fetches in flight -2 us, 13 in flight +36 us (3 waves per SIMD).
+    const bool nt = a->nt != 0;
+    auto fetch = [&](int f, int32_t d, float4& g, float4& v) {          // f wave-uniform: column numbers come from scalar loads
+        if (d >= 0) {
+            if (!UNAL && nt) {
+                g = nrx_ldg4_nt(a->g_out, (b * a->out_ld + a->out_col[f]) / 4 + q);
+                if (FM) v = nrx_ldg4_nt(a->feat, (b * a->feat_ld + a->out_col[f]) / 4 + q);
+                return;
+            }
+            g = upstream_chunk<UNAL>(a->g_out, a->out_ld, a->g_wide, a->wide_ld, a->out_col[f], a->wide_col[f], b, q);
+            if (FM) v = nrx_ldg4(a->feat, (b * a->feat_ld + a->out_col[f]) / 4 + q);
+        }
+    };
+    auto place = [&](int f, int32_t d, const float4& g, const float4& v) {
+        if (d >= 0) {
+            float4 t = g;
+            if (FM) fm_fold4(t, a->fm[f] ? gf : 0.f, S, v, q);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);         // 0 + t, as the walk forms it (a -0 becomes +0 there too)
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            nrx_stg4(a->values, (int64_t)d * Q + q, acc);
+        }
+    };
+    if (n >= U) {
+        // ring, as in the forward (embed_fwd_ring): `place feature f; fetch feature f + U` -- U row fetches in flight per lane from
+        // the first feature to the last, loads and stores interleaved at row granularity
+        const int32_t* s_my = s_dest + sb;
+        int32_t d[U];
+        float4 g[U], v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = s_my[u * TB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) fetch(u, d[u], g[u], v[u]);
+        int f0 = 0;
+        for (; f0 + 2 * U <= n; f0 += U) {
+            int32_t dn[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dn[u] = s_my[(f0 + U + u) * TB];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                place(f0 + u, d[u], g[u], v[u]);
+                d[u] = dn[u];
+                fetch(f0 + U + u, d[u], g[u], v[u]);
+            }
+        }
+        // f0 + U <= n < f0 + 2U: drain; the n - f0 - U fetches still to be issued sit behind wave-uniform branches
+        int32_t dn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int f = f0 + U + u;
+            dn[u] = f < n ? s_my[f * TB] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            place(f0 + u, d[u], g[u], v[u]);
+            d[u] = dn[u];
+            if (f0 + U + u < n) fetch(f0 + U + u, d[u], g[u], v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (f0 + U + u < n) place(f0 + U + u, d[u], g[u], v[u]);
+        return;
+    }
+    for (int f0 = 0; f0 < n; f0 += U) {
+        int32_t d[U];
+        float4 g[U], v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = f0 + u < n ? s_dest[(f0 + u) * TB + sb] : -1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int f = f0 + u < n ? f0 + u : n - 1;            // wave-uniform: column numbers come from scalar loads
+            if (d[u] >= 0) {
+                g[u] = upstream_chunk<UNAL>(a->g_out, a->out_ld, a->g_wide, a->wide_ld, a->out_col[f], a->wide_col[f], b, q);
+                if (FM) v[u] = nrx_ldg4(a->feat, (b * a->feat_ld + a->out_col[f]) / 4 + q);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int f = f0 + u < n ? f0 + u : n - 1;
+            if (d[u] >= 0) {
+                float4 t = g[u];
+                if (FM) fm_fold4(t, a->fm[f] ? gf : 0.f, S, v[u], q);
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);     // 0 + t, as the walk forms it (a -0 becomes +0 there too)
+                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                nrx_stg4(a->values, (int64_t)d[u] * Q + q, acc);
+            }
+        }
+    }
 }
 
 // BAG: some features are bags -- a lookup's sample is (flat index) / L and its upstream row is scaled by the per-lookup
@@ -669,18 +850,28 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
     constexpr int TB = NRX_BLOCK / Q;
     const int q = threadIdx.x & (Q - 1);
     const int64_t u0 = ((int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2)) * R;
+    // n = rows of this launch: all unique rows, or (placement mode) the `walk` list -- then u0 + r indexes the list
     int64_t n = a->n_unique;
-    if (a->n_unique_dev != nullptr) {
-        const int64_t nd = nrx_gconst<int64_t>(a->n_unique_dev)[0];
-        n = nd < n ? nd : n;
+    const bool listed = a->walk != nullptr;
+    {
+        const int64_t* ndp = listed ? a->n_walk_dev : a->n_unique_dev;
+        if (ndp != nullptr) {
+            const int64_t nd = nrx_gconst<int64_t>(ndp)[0];
+            n = nd < n ? nd : n;
+        }
     }
     if (__ballot(u0 < n) == 0ull) return;      // whole wavefronts past the last row leave; inside the last live wavefront the
                                                // lane groups past it stay (the work-list append below is a wavefront scan)
     const NRX_GLOBAL int64_t* seg = nrx_gconst<int64_t>(a->seg_start);
-    int64_t lo[R], hi[R], key[R];
+    int64_t lo[R], hi[R], key[R], urow[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int64_t u = u0 + r < n ? u0 + r : n - 1;
+        const int64_t li = u0 + r < n ? u0 + r : n - 1;
+        urow[r] = listed ? (int64_t)nrx_gconst<int32_t>(a->walk)[li] : li;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t u = urow[r];
         lo[r] = seg[u];
         hi[r] = seg[u + 1];
         key[r] = a->uniq_keys != nullptr ? nrx_gconst<int64_t>(a->uniq_keys)[u] : 1;
@@ -722,11 +913,11 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
                     const int m = atomicAdd(&a->long_ws[1], 1);
                     if (m < a->long_slots_cap) {
                         LongMulti w;
-                        w.u = (int32_t)(u0 + r); w.slot0 = slot0; w.nchunks = nchunks; w.pad = 0;
+                        w.u = (int32_t)urow[r]; w.slot0 = slot0; w.nchunks = nchunks; w.pad = 0;
                         sorted_long_multi(a)[m] = w;
                     }
                 }
-                sorted_long_write_items(a, (int32_t)(u0 + r), lo[r], hi[r], nchunks, slot0, base);
+                sorted_long_write_items(a, (int32_t)urow[r], lo[r], hi[r], nchunks, slot0, base);
                 base += nchunks;
             }
         }
@@ -800,12 +991,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
 #pragma unroll
             for (int j = 0; j < UP; ++j) {
                 float4 t = g[r][j];
-                if (FM) {                     // d fm / d field: column 0 -> 1, column k -> S_k - v_k
-                    t.x += q == 0 ? gf[r][j] : gf[r][j] * (s[r][j].x - v[r][j].x);
-                    t.y += gf[r][j] * (s[r][j].y - v[r][j].y);
-                    t.z += gf[r][j] * (s[r][j].z - v[r][j].z);
-                    t.w += gf[r][j] * (s[r][j].w - v[r][j].w);
-                }
+                if (FM) fm_fold4(t, gf[r][j], s[r][j], v[r][j], q);      // d fm / d field: column 0 -> 1, column k -> S_k - v_k
                 if (on[r][j]) {               // added in sorted order: j ascending inside the pass
                     if (BAG) {
 #pragma clang fp contract(off)
@@ -824,7 +1010,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
     while (more) more = pass();
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (u0 + r < n && !lng[r]) nrx_stg4(a->values, (u0 + r) * (int64_t)Q + q, acc[r]);
+        if (u0 + r < n && !lng[r]) nrx_stg4(a->values, urow[r] * (int64_t)Q + q, acc[r]);
 }
 
 // Long segments.  An item = up to SORTED_LONG_CHUNK consecutive sorted entries of ONE unique row; a wavefront reduces an
@@ -880,12 +1066,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
 #pragma unroll
             for (int k = 0; k < UL; ++k) {
                 float4 t = gr[k];
-                if (FM) {
-                    t.x += q == 0 ? gf[k] : gf[k] * (s_[k].x - v[k].x);
-                    t.y += gf[k] * (s_[k].y - v[k].y);
-                    t.z += gf[k] * (s_[k].z - v[k].z);
-                    t.w += gf[k] * (s_[k].w - v[k].w);
-                }
+                if (FM) fm_fold4(t, gf[k], s_[k], v[k], q);
                 if (on[k]) {
                     if (BAG) {
 #pragma clang fp contract(off)
@@ -1287,11 +1468,12 @@ extern "C" int64_t nrx_embed_bwd_sorted_workspace(int64_t n_lookups, int32_t dim
            2 * (n_lookups * 4 + 64) + n_lookups / 8 + 128;       // + bag features: per-lookup scale, per-sample factor, weight bits
 }
 
-extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
-                                    const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
-                                    const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
-                                    int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
-                                    void* workspace, void* stream) {
+static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                                 const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                                 const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
+                                 int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
+                                 uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
+                                 void* workspace, void* stream) {
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_bwd_sorted: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0 && dim >= 1 && n_unique >= 0, "nrx_embed_bwd_sorted: bad argument");
@@ -1314,6 +1496,8 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     a.scale = nullptr;
     a.bag_inv = nullptr;
     a.bag_bits = nullptr;
+    a.walk = nullptr;
+    a.n_walk_dev = nullptr;
     a.long_t = SORTED_LONG_T;
     int64_t off = 0;
     for (int i = 0; i < n_feats; ++i) {
@@ -1392,11 +1576,36 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     // threshold sweep (T = 16 / 24 / 32 / 48 / 64, fwd+bwd us): C4 521 / 505 / 493 / 492 / 492, C4 Zipf 581 / 575 / 564 / 598 / 674,
     // C2 Zipf 501 / 545 / 588 / 678 / 758, C5 478 / 491 / 527 / 578 / 618: bag launches (a few rows, each looked up ~L times) take 32
     if (has_bag) a.long_t = 2 * SORTED_LONG_T;
+    // placement mode: single-lookup rows are stored by the placement pass, the walk reduces the listed rows only
+    const bool placed = fast && dest != nullptr;
     if (fast) {
         constexpr int R = 4;
         constexpr int RB = 2;                   // bag launches: 2 rows x 4 entries per pass (see the kernel)
         const bool bag_shape = has_bag && !unal && !has_fm;
-        const int64_t groups = (n_unique + (bag_shape ? RB : R) - 1) / (bag_shape ? RB : R);
+        const bool wide_pass = bag_shape || placed;       // placement mode: every walked row has >= 2 entries -> 2 rows x 4 entries too
+        int64_t n_rows = n_unique;                        // rows of the walk launch (upper bound when the count lives on the device)
+        int n_place = 0;
+        PlaceArgs pa;
+        if (placed) {
+            int64_t placeable = 0;
+            for (int i = 0; i < n_feats; ++i) {
+                if (!((place_feats >> i) & 1ull)) continue;
+                NRX_REQUIRE(feats[i].kind == NRX_SPARSE, "nrx_embed_bwd_placed: feature %d is not single-valued: it cannot be placed", i);
+                pa.off[n_place] = a.off[i];
+                pa.out_col[n_place] = feats[i].out_col;
+                pa.wide_col[n_place] = feats[i].wide_col;
+                pa.fm[n_place] = a.f[i].fm;
+                placeable += batch;
+                ++n_place;
+            }
+            // walked rows: >= 2 lookups each, or one lookup of a feature outside the mask, or a table's padding row
+            const int64_t bound = placeable / 2 + (off - placeable) + n_feats + 1;
+            if (bound < n_rows) n_rows = bound;
+            a.walk = walk;
+            a.n_walk_dev = n_walk;
+            a.n_unique = n_rows;
+        }
+        const int64_t groups = (n_rows + (wide_pass ? RB : R) - 1) / (wide_pass ? RB : R);
         const unsigned grid = (unsigned)((groups + tb - 1) / tb);
         if (workspace != nullptr) {        // long segments (hot rows) go through the wavefront-per-item path
             a.long_ws = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15);
@@ -1404,7 +1613,32 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
             a.long_slots_cap = 2 * off / SORTED_LONG_CHUNK + 8;
             // the four work-list counters are cleared by a kernel (nrx_zero_async), not hipMemsetAsync: inside a captured HIP graph
             // the 16-byte memset node did not take effect on replay (counters kept growing, the list was read past what was written)
-            if (nrx_zero_async(a.long_ws, 16, st) != NRX_OK) return NRX_ERR_LAUNCH;
+            // (placement mode: the placement pass clears them -- one launch less)
+            if (!(placed && n_place > 0) && nrx_zero_async(a.long_ws, 16, st) != NRX_OK) return NRX_ERR_LAUNCH;
+        }
+        if (placed && n_place > 0) {
+            pa.batch = batch;
+            pa.g_out = g_out; pa.out_ld = out_ld; pa.g_wide = g_wide; pa.wide_ld = wide_ld;
+            pa.g_fm = a.g_fm; pa.fm_sums = a.fm_sums; pa.sums_ld = a.sums_ld; pa.feat = a.feat; pa.feat_ld = a.feat_ld;
+            pa.dest = dest;
+            pa.values = values;
+            pa.long_ws = a.long_ws;
+            pa.n = n_place;
+            { const char* e = getenv("NRX_PLACE_NT"); pa.nt = e ? atoi(e) : 1; }
+            const int uvar = getenv("NRX_PLACE_U") ? atoi(getenv("NRX_PLACE_U")) : 4;       // fetches in flight per lane (4 | 8)
+            const unsigned pgrid = (unsigned)((batch + tb - 1) / tb);
+            const size_t plds = (size_t)n_place * tb * 4;
+            constexpr int U = 8;
+#define NRX_PL(QL_)                                                                                                        \
+    {                                                                                                                      \
+        if (has_fm && uvar == 4) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, true, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
+        else if (has_fm) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, true, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
+        else if (unal) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa); \
+        else if (uvar == 4) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, false, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);        \
+        else hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, false, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);        \
+    }
+            if (ql == 2) NRX_PL(2) else if (ql == 3) NRX_PL(3) else NRX_PL(4)
+#undef NRX_PL
         }
         if (has_bag) {
             char* end = reinterpret_cast<char*>(a.long_ws + 4) + a.long_items_cap * sizeof(LongItem) +
@@ -1426,7 +1660,10 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
         }
 #define NRX_SF(QL_)                                                                                                        \
     {                                                                                                                      \
-        if (has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        if (placed && has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else if (placed && unal) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, true, 4>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else if (placed && !has_bag) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else if (has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
         else if (unal) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, true, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
         else if (has_bag) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, false, 4>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
         else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a);      \
@@ -1452,4 +1689,24 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     NRX_QSWITCH(ql, { hipLaunchKernelGGL((embed_bwd_sorted_kernel<QL>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); });
     NRX_LAUNCH_CHECK("nrx_embed_bwd_sorted");
     return NRX_OK;
+}
+
+extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                                    const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                                    const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
+                                    int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
+                                    void* workspace, void* stream) {
+    return embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, g_wide, wide_ld, order, seg_start, uniq_keys, n_unique,
+                                 n_unique_dev, fm, values, 0, nullptr, nullptr, nullptr, workspace, stream);
+}
+
+extern "C" int nrx_embed_bwd_placed(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                                    const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                                    const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
+                                    int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
+                                    uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
+                                    void* workspace, void* stream) {
+    NRX_REQUIRE(dest != nullptr && walk != nullptr && n_walk != nullptr, "nrx_embed_bwd_placed: null placement buffer");
+    return embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, g_wide, wide_ld, order, seg_start, uniq_keys, n_unique,
+                                 n_unique_dev, fm, values, place_feats, dest, walk, n_walk, workspace, stream);
 }

@@ -68,35 +68,90 @@ __device__ __forceinline__ bool plan_is_head(const KeyT* __restrict__ skeys, int
     return e == 0 || plan_key_at<KeyT, PAIR>(skeys, e) != plan_key_at<KeyT, PAIR>(skeys, e - 1);
 }
 
-template <typename KeyT, bool PAIR = false>
-__global__ __launch_bounds__(NRX_BLOCK) void plan_count_kernel(const KeyT* __restrict__ skeys, int64_t n, uint32_t* __restrict__ block_heads) {
-    __shared__ uint32_t s_cnt[NRX_BLOCK / 64];
+// Placement (nrx_sparse_plan_place): a unique row that is looked up exactly ONCE in the launch, by a single-valued feature,
+// needs no reduction -- its gradient row is the lookup's upstream row.  The plan then also says, per lookup p, where that row
+// goes (dest[p] = its unique index, or -1) and lists the remaining unique rows (several lookups, a bag feature's lookup, or the
+// padding row) as `walk`: the backward streams the upstream rows sample-major and places them (embed_bwd_place_kernel) and
+// walks only the listed rows.  PlaceInfo: which features' lookups may be placed, by flat offset.
+struct PlaceInfo {
+    int64_t off[NRX_MAX_FEATURES + 1];
+    uint64_t feats;                 // bit f: lookups of feature f may be placed
+    int32_t n;
+    int32_t all;                    // every feature may be placed: no feature lookup needed
+};
+__device__ __forceinline__ bool plan_placeable(const NRX_CONST PlaceInfo* pi, uint32_t p) {
+    if (pi->all) return true;
+    int f = 0;
+    for (int i = 1; i < pi->n; ++i) f += (int64_t)p >= pi->off[i] ? 1 : 0;      // uniform loop, scalar loads
+    return (pi->feats >> f) & 1ull;
+}
+// entry e (key k, payload p) is PLACED iff it is a whole segment by itself, not the padding row, and of a placeable feature
+template <typename KeyT>
+__device__ __forceinline__ bool plan_is_placed(bool head, bool next_head, KeyT key, uint64_t rmask, const NRX_CONST PlaceInfo* pi, uint32_t p) {
+    return head && next_head && ((uint64_t)key & rmask) != 0 && plan_placeable(pi, p);
+}
+
+template <typename KeyT, bool PAIR = false, bool PLACE = false>
+__global__ __launch_bounds__(NRX_BLOCK) void plan_count_kernel(const PlaceInfo place_in_kernarg /* first: read through nrx_kernarg */,
+                                                               const KeyT* __restrict__ skeys, int64_t n, uint32_t* __restrict__ block_heads,
+                                                               const uint32_t* __restrict__ spayload, int row_bits) {
+    __shared__ uint32_t s_cnt[2 * (NRX_BLOCK / 64)];
     const int64_t e0 = (int64_t)blockIdx.x * PLAN_TILE + threadIdx.x;
-    uint32_t c = 0;
+    uint32_t c = 0, cw = 0;
+    const uint64_t rmask = (1ull << row_bits) - 1;
 #pragma unroll
     for (int j = 0; j < PLAN_TILE / NRX_BLOCK; ++j) {
         const int64_t e = e0 + j * NRX_BLOCK;
-        c += (uint32_t)__popcll(__ballot(e < n && plan_is_head<KeyT, PAIR>(skeys, e)));      // wave-uniform count
+        const bool head = e < n && plan_is_head<KeyT, PAIR>(skeys, e);
+        c += (uint32_t)__popcll(__ballot(head));      // wave-uniform count
+        if (PLACE) {
+            const NRX_CONST PlaceInfo* pi = nrx_kernarg<PlaceInfo>();
+            bool walked = false;
+            if (head) {
+                const bool next_head = e + 1 >= n || plan_key_at<KeyT, PAIR>(skeys, e + 1) != plan_key_at<KeyT, PAIR>(skeys, e);
+                const uint32_t pay = PAIR ? reinterpret_cast<const uint2*>(skeys)[e].y : spayload[e];
+                walked = !plan_is_placed<KeyT>(true, next_head, plan_key_at<KeyT, PAIR>(skeys, e), rmask, pi, pay);
+            }
+            cw += (uint32_t)__popcll(__ballot(walked));
+        }
     }
-    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+    if ((threadIdx.x & 63) == 0) {
+        s_cnt[threadIdx.x >> 6] = c;
+        s_cnt[NRX_BLOCK / 64 + (threadIdx.x >> 6)] = cw;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) block_heads[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (threadIdx.x == 0) {
+        block_heads[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (PLACE) block_heads[gridDim.x + blockIdx.x] = s_cnt[4] + s_cnt[5] + s_cnt[6] + s_cnt[7];
+    }
 }
 
 // entry e of the tile is handled by thread (e % 256) in round (e / 256): coalesced key / payload / order accesses; the
 // rank of a head = heads of earlier blocks + heads of earlier (round, wave) cells + heads of lower lanes in its cell
-template <typename KeyT, bool PAIR = false>
-__global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const KeyT* __restrict__ skeys, const uint32_t* __restrict__ spayload,
+template <typename KeyT, bool PAIR = false, bool PLACE = false>
+__global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo place_in_kernarg /* first: read through nrx_kernarg */,
+                                                              const KeyT* __restrict__ skeys, const uint32_t* __restrict__ spayload,
                                                               const uint32_t* __restrict__ block_heads, int64_t n, int row_bits,
                                                               int32_t n_tables, int64_t* __restrict__ order,
                                                               int64_t* __restrict__ uniq_keys, int64_t* __restrict__ seg_start,
-                                                              int64_t* __restrict__ counts) {
+                                                              int64_t* __restrict__ counts, int32_t* __restrict__ dest,
+                                                              int32_t* __restrict__ walk, int64_t* __restrict__ n_walk) {
     constexpr int ROUNDS = PLAN_TILE / NRX_BLOCK, WAVES = NRX_BLOCK / 64;
     __shared__ uint32_t s_cell[ROUNDS * WAVES + 1];
-    __shared__ uint32_t s_part[WAVES];
+    __shared__ uint32_t s_wcell[ROUNDS * WAVES + 1];
+    __shared__ uint32_t s_part[2 * WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int64_t e0 = (int64_t)blockIdx.x * PLAN_TILE + tid;
-    KeyT key[ROUNDS], prev[ROUNDS];
+    // PLACE: the dest words of a tile (one table's lookups) all fall into that feature's stretch of dest -- B x 4 bytes.  Blocks
+    // land on XCD (block % 8), each with its own L2: in launch order the eight XCDs would each hold PARTIAL lines of every
+    // stretch and write them back piecemeal.  Giving XCD x the x-th eighth of the tiles (a bijection of the grid) keeps a
+    // stretch inside one L2 until its lines are complete.
+    unsigned tile = blockIdx.x;
+    if (PLACE) {
+        const unsigned x = blockIdx.x & 7u, i = blockIdx.x >> 3, qt = gridDim.x >> 3, rt = gridDim.x & 7u;
+        tile = x * qt + (x < rt ? x : rt) + i;
+    }
+    const int64_t e0 = (int64_t)tile * PLAN_TILE + tid;
+    KeyT key[ROUNDS], prev[ROUNDS], next[ROUNDS];
     uint32_t pay[ROUNDS];
 #pragma unroll
     for (int j = 0; j < ROUNDS; ++j) {            // all of the tile's loads are issued before anything waits
@@ -111,20 +166,39 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const KeyT* __rest
             pay[j] = spayload[ec];
         }
         prev[j] = plan_key_at<KeyT, PAIR>(skeys, ec > 0 ? ec - 1 : 0);
+        if (PLACE) next[j] = plan_key_at<KeyT, PAIR>(skeys, ec + 1 < n ? ec + 1 : ec);
     }
-    uint32_t acc = 0;
-    for (uint32_t i = tid; i < blockIdx.x; i += NRX_BLOCK) acc += block_heads[i];
+    uint32_t acc = 0, wacc = 0;
+    for (uint32_t i = tid; i < tile; i += NRX_BLOCK) {
+        acc += block_heads[i];
+        if (PLACE) wacc += block_heads[gridDim.x + i];
+    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (lane == 0) s_part[wid] = acc;
-    bool head[ROUNDS];
-    unsigned long long mask[ROUNDS];
+    for (int off = 32; off > 0; off >>= 1) {
+        acc += __shfl_xor(acc, off, 64);
+        if (PLACE) wacc += __shfl_xor(wacc, off, 64);
+    }
+    if (lane == 0) {
+        s_part[wid] = acc;
+        s_part[WAVES + wid] = wacc;
+    }
+    const uint64_t rmask = (1ull << row_bits) - 1;
+    bool head[ROUNDS], walked[ROUNDS], placed[ROUNDS], able[ROUNDS];
+    unsigned long long mask[ROUNDS], wmask[ROUNDS];
 #pragma unroll
     for (int j = 0; j < ROUNDS; ++j) {
         const int64_t e = e0 + j * NRX_BLOCK;
         head[j] = e < n && (e == 0 || key[j] != prev[j]);
         mask[j] = __ballot(head[j]);
         if (lane == 0) s_cell[j * WAVES + wid] = (uint32_t)__popcll(mask[j]);
+        if (PLACE) {
+            const bool next_head = e + 1 >= n || next[j] != key[j];
+            able[j] = plan_placeable(nrx_kernarg<PlaceInfo>(), pay[j]);
+            placed[j] = head[j] && next_head && ((uint64_t)key[j] & rmask) != 0 && able[j];
+            walked[j] = head[j] && !placed[j];
+            wmask[j] = __ballot(walked[j]);
+            if (lane == 0) s_wcell[j * WAVES + wid] = (uint32_t)__popcll(wmask[j]);
+        }
     }
     __syncthreads();
     if (tid == 0) {                                // exclusive scan of the 16 cells, seeded with the earlier blocks' heads
@@ -136,8 +210,16 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const KeyT* __rest
         }
         s_cell[ROUNDS * WAVES] = run;
     }
+    if (PLACE && tid == 64) {
+        uint32_t run = s_part[WAVES] + s_part[WAVES + 1] + s_part[WAVES + 2] + s_part[WAVES + 3];
+        for (int c = 0; c < ROUNDS * WAVES; ++c) {
+            const uint32_t v = s_wcell[c];
+            s_wcell[c] = run;
+            run += v;
+        }
+        s_wcell[ROUNDS * WAVES] = run;
+    }
     __syncthreads();
-    const uint64_t rmask = (1ull << row_bits) - 1;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
     for (int j = 0; j < ROUNDS; ++j) {
@@ -145,6 +227,13 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const KeyT* __rest
         if (e >= n) continue;
         order[e] = (int64_t)pay[j];
         const uint32_t u = s_cell[j * WAVES + wid] + (uint32_t)__popcll(mask[j] & lt);
+        if (PLACE) {
+            if (able[j]) dest[pay[j]] = placed[j] ? (int32_t)u : -1;      // every placeable lookup gets an answer: no fill pass
+                                                                          // (the words of other features' lookups are never read)
+            const uint32_t wr = s_wcell[j * WAVES + wid] + (uint32_t)__popcll(wmask[j] & lt);
+            if (walked[j]) walk[wr] = (int32_t)u;
+            if (e == n - 1) n_walk[0] = (int64_t)(wr + (walked[j] ? 1u : 0u));
+        }
         if (head[j]) {
             const uint64_t k = (uint64_t)key[j];
             const int64_t t = (int64_t)(k >> row_bits);
@@ -619,9 +708,10 @@ extern "C" int64_t nrx_sparse_plan_workspace(int64_t n_lookups) {
     return (int64_t)(2 * align256(n * 8) + 2 * align256(n * 4) + 2 * align256(n * 4) + align256(t1) + seg_scratch_bytes(n) + 256);
 }
 
-extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
-                               int32_t n_feats, int32_t index_bits, int32_t n_tables, int64_t* order, int64_t* uniq_keys,
-                               int64_t* seg_start, int64_t* counts, void* workspace, void* stream) {
+static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
+                            int32_t n_feats, int32_t index_bits, int32_t n_tables, int64_t* order, int64_t* uniq_keys,
+                            int64_t* seg_start, int64_t* counts, uint64_t place_feats, int32_t* dest, int32_t* walk, int64_t* n_walk,
+                            void* workspace, void* stream) {
     NRX_REQUIRE(n_feats >= 0 && n_feats <= NRX_MAX_FEATURES && (index_bits == 32 || index_bits == 64) && n_tables >= 1 && n_tables < (1 << 20),
                 "nrx_sparse_plan: bad argument");
     NRX_REQUIRE(counts != nullptr, "nrx_sparse_plan: null counts");
@@ -641,6 +731,15 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
     a.n_feats = n_feats;
     a.idx64 = index_bits == 64;
     a.n_total = off;
+    PlaceInfo pinfo;
+    memset(&pinfo, 0, sizeof(pinfo));
+    if (dest != nullptr) {
+        for (int f = 0; f <= n_feats; ++f) pinfo.off[f] = a.off[f];
+        pinfo.n = n_feats;
+        const uint64_t every = n_feats >= 64 ? ~0ull : ((1ull << n_feats) - 1);
+        pinfo.feats = place_feats & every;
+        pinfo.all = pinfo.feats == every;
+    }
     const int row_bits = bits_for(max_rows), table_bits = bits_for(n_tables);
     NRX_REQUIRE(row_bits <= 40 && row_bits + table_bits <= 62, "nrx_sparse_plan: table too large for the composite key");
     NRX_REQUIRE(off < 0xffffffffLL, "nrx_sparse_plan: too many lookups for one plan");
@@ -651,6 +750,7 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
         // counts = {0, 0, ..., 0}; seg_start[0] = 0
         int e = nrx_zero_async(counts, sizeof(int64_t) * (size_t)(n_tables + 2), st);
         if (e == NRX_OK && seg_start) e = nrx_zero_async(seg_start, sizeof(int64_t), st);
+        if (e == NRX_OK && n_walk) e = nrx_zero_async(n_walk, sizeof(int64_t), st);
         if (e != NRX_OK) return NRX_ERR_LAUNCH;
         return NRX_OK;
     }
@@ -754,10 +854,17 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
             KeyT* tk = src; src = dst; dst = tk;                                                                          \
             uint32_t* tp = psrc; psrc = pdst; pdst = tp;                                                                  \
         }                                                                                                                 \
-        hipLaunchKernelGGL((plan_count_kernel<KeyT, PAIR_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)src, n, flags);      \
-        hipLaunchKernelGGL((plan_emit_kernel<KeyT, PAIR_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)src,                  \
-                           (const uint32_t*)psrc, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys,         \
-                           seg_start, counts);                                                                            \
+        if (dest != nullptr) {                                                                                            \
+            hipLaunchKernelGGL((plan_count_kernel<KeyT, PAIR_, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src, n, flags, (const uint32_t*)psrc, row_bits); \
+            hipLaunchKernelGGL((plan_emit_kernel<KeyT, PAIR_, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src,     \
+                               (const uint32_t*)psrc, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys,     \
+                               seg_start, counts, dest, walk, n_walk);                                                    \
+        } else {                                                                                                          \
+            hipLaunchKernelGGL((plan_count_kernel<KeyT, PAIR_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src, n, flags, (const uint32_t*)psrc, row_bits); \
+            hipLaunchKernelGGL((plan_emit_kernel<KeyT, PAIR_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src,           \
+                               (const uint32_t*)psrc, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys,     \
+                               seg_start, counts, (int32_t*)nullptr, (int32_t*)nullptr, (int64_t*)nullptr);               \
+        }                                                                                                                 \
     }
         if (bits <= 32) NRX_SEGSORT(uint32_t) else NRX_SEGSORT(uint64_t)
 #undef NRX_SEGSORT
@@ -771,10 +878,17 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
         err = rocprim::radix_sort_pairs(temp, tb, (const KeyT*)keys_in, (KeyT*)keys_out, (const uint32_t*)pay_in, pay_out, \
                                         (size_t)n, 0u, (unsigned)bits, st);                                               \
         if (err == hipSuccess) {                                                                                          \
-            hipLaunchKernelGGL(plan_count_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out, n, flags); \
-            hipLaunchKernelGGL(plan_emit_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out,          \
-                               (const uint32_t*)pay_out, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys,  \
-                               seg_start, counts);                                                                        \
+            if (dest != nullptr) {                                                                                        \
+                hipLaunchKernelGGL((plan_count_kernel<KeyT, false, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out, n, flags, (const uint32_t*)pay_out, row_bits); \
+                hipLaunchKernelGGL((plan_emit_kernel<KeyT, false, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out, \
+                                   (const uint32_t*)pay_out, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys, \
+                                   seg_start, counts, dest, walk, n_walk);                                                \
+            } else {                                                                                                      \
+                hipLaunchKernelGGL(plan_count_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out, n, flags, (const uint32_t*)pay_out, row_bits); \
+                hipLaunchKernelGGL(plan_emit_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out,      \
+                                   (const uint32_t*)pay_out, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys, \
+                                   seg_start, counts, (int32_t*)nullptr, (int32_t*)nullptr, (int64_t*)nullptr);           \
+            }                                                                                                             \
         }                                                                                                                 \
     }
     if (bits <= 32) NRX_PLAN(uint32_t) else NRX_PLAN(uint64_t)
@@ -785,6 +899,22 @@ extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, cons
     }
     NRX_LAUNCH_CHECK("nrx_sparse_plan");
     return NRX_OK;
+}
+
+extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
+                               int32_t n_feats, int32_t index_bits, int32_t n_tables, int64_t* order, int64_t* uniq_keys,
+                               int64_t* seg_start, int64_t* counts, void* workspace, void* stream) {
+    return sparse_plan_impl(ids, lens, table_of, rows, n_feats, index_bits, n_tables, order, uniq_keys, seg_start, counts, 0, nullptr,
+                            nullptr, nullptr, workspace, stream);
+}
+
+extern "C" int nrx_sparse_plan_place(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
+                                     int32_t n_feats, int32_t index_bits, int32_t n_tables, uint64_t place_feats, int64_t* order,
+                                     int64_t* uniq_keys, int64_t* seg_start, int64_t* counts, int32_t* dest, int32_t* walk,
+                                     int64_t* n_walk, void* workspace, void* stream) {
+    NRX_REQUIRE(dest != nullptr && walk != nullptr && n_walk != nullptr, "nrx_sparse_plan_place: null placement buffer");
+    return sparse_plan_impl(ids, lens, table_of, rows, n_feats, index_bits, n_tables, order, uniq_keys, seg_start, counts, place_feats,
+                            dest, walk, n_walk, workspace, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1019,7 +1149,7 @@ extern "C" int nrx_route_ids_dedup(const void* const* ids, const int64_t* lens, 
         err = rocprim::radix_sort_pairs(temp, tb, (const KeyT*)keys_in, (KeyT*)keys_out, (const uint32_t*)pay_in, pay_out,  \
                                         (size_t)n, 0u, (unsigned)bits, st);                                                \
         if (err == hipSuccess) {                                                                                           \
-            hipLaunchKernelGGL(plan_count_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out, n, heads); \
+            hipLaunchKernelGGL(plan_count_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, PlaceInfo(), (const KeyT*)keys_out, n, heads, (const uint32_t*)nullptr, 0); \
             hipLaunchKernelGGL(dedup_rank_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out,          \
                                (const uint32_t*)heads, n, a.table_bits + a.row_bits, world, urank, obase);                  \
             hipLaunchKernelGGL(dedup_place_kernel<KeyT>, dim3(gfull), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out,         \
@@ -1067,7 +1197,7 @@ extern "C" int nrx_unique_inverse(const void* ids, int32_t index_bits, int64_t n
         nrx_set_error("nrx_unique_inverse: rocPRIM call failed: %s", hipGetErrorString(err));
         return NRX_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(plan_count_kernel<uint64_t>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const uint64_t*)keys_out, n, heads);
+    hipLaunchKernelGGL(plan_count_kernel<uint64_t>, dim3(gtile), dim3(NRX_BLOCK), 0, st, PlaceInfo(), (const uint64_t*)keys_out, n, heads, (const uint32_t*)nullptr, 0);
     hipLaunchKernelGGL(dedup_rank_kernel<uint64_t>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const uint64_t*)keys_out, (const uint32_t*)heads, n,
                        64 - 1, 1, urank, obase);      // owner_shift 63: one "owner" (bit 63 may be set: two bases are reserved)
     hipLaunchKernelGGL(uinv_emit_kernel, dim3(gfull), dim3(NRX_BLOCK), 0, st, (const uint64_t*)keys_out, (const uint32_t*)pay_out,

@@ -16,6 +16,7 @@ Operator                          replaces (reference file:line)
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -344,7 +345,8 @@ class _EmbedFn(torch.autograd.Function):
                 if sum(x.numel() for x in ids_) == 0:
                     continue
                 tabs_ = [plan.slots[i].table for i in fs_]
-                ctx.plans[(D_, fs_[0])] = (ids_,) + sparse_plan_ahead(ids_, tabs_, [tables[t].shape[0] for t in tabs_], len(tables))
+                ctx.plans[(D_, fs_[0])] = (ids_,) + sparse_plan_ahead(ids_, tabs_, [tables[t].shape[0] for t in tabs_], len(tables),
+                                                                      place_mask([plan.slots[i].kind for i in fs_]) if SPARSE_PLACE else None)
         if ctx.has_fm_feat:
             ctx.save_for_backward(out)
         ctx.set_materialize_grads(False)
@@ -422,7 +424,8 @@ def _plan_stream(dev) -> "torch.cuda.Stream":
     return s
 
 
-def sparse_plan_ahead(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int):
+def sparse_plan_ahead(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int,
+                      place_feats: Optional[int] = None):
     """sparse_plan on a side stream: the planning of the backward depends only on the ids, so it can run while the forward,
     the dense part of the model and its backward occupy the main stream.  Returns ((order, uniq, seg, counts), event);
     the consumer makes its stream wait for `event` before reading the plan."""
@@ -436,7 +439,7 @@ def sparse_plan_ahead(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows
         # could have its block handed out again on the caller's stream while the sort is still reading it
         x.record_stream(side)
     with torch.cuda.stream(side):
-        res = sparse_plan(ids, table_of, rows, n_tables)
+        res = sparse_plan(ids, table_of, rows, n_tables, place_feats)
         ev = torch.cuda.Event()
         ev.record(side)
     for t in res:
@@ -444,11 +447,27 @@ def sparse_plan_ahead(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows
     return res, ev
 
 
-def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int):
+SPARSE_PLACE = os.environ.get("NRX_SPARSE_PLACE", "1") != "0"      # row-sparse backward: place single-lookup rows (A/B knob)
+
+
+def place_mask(kinds: Sequence[int]) -> int:
+    """Bit f set for every single-valued feature: the lookups nrx_sparse_plan_place may place (a bag lookup is scaled)."""
+    m = 0
+    for i, k in enumerate(kinds):
+        if k == NRX_SPARSE:
+            m |= 1 << i
+    return m
+
+
+def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int,
+                place_feats: Optional[int] = None):
     """nrx_sparse_plan: group the flat, feature-major lookups `ids` (one device tensor per feature, all int32 or
     all int64) by (table, row).  Returns device int64 tensors (order [n], uniq_keys [n], seg_start [n+1],
     counts [n_tables+2]); only the first counts[0] entries of uniq_keys / counts[0]+1 of seg_start are
-    meaningful.  No host synchronisation."""
+    meaningful.  No host synchronisation.
+    place_feats (bit mask over the features, see place_mask): nrx_sparse_plan_place -- three more device tensors, dest
+    int32 [n] (unique index of a lookup whose row is looked up once, else -1), walk int32 [n] (the other unique rows)
+    and n_walk int64 [1]: what nrx_embed_bwd_placed consumes."""
     lib = _lib.load()
     n = len(ids)
     dev = ids[0].device
@@ -465,9 +484,31 @@ def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequ
     lens = (C.c_int64 * n)(*[x.numel() for x in ids])
     tof = (C.c_int32 * n)(*[int(t) for t in table_of])
     rws = (C.c_int64 * n)(*[int(r) for r in rows])
+    if place_feats is not None:
+        dest = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        walk = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        n_walk = torch.empty(1, dtype=torch.int64, device=dev)
+        check(lib.nrx_sparse_plan_place(ptrs, lens, tof, rws, n, ids[0].element_size() * 8, n_tables, int(place_feats), order.data_ptr(),
+                                        uniq.data_ptr(), seg.data_ptr(), counts.data_ptr(), dest.data_ptr(), walk.data_ptr(),
+                                        n_walk.data_ptr(), ws.data_ptr(), _stream_ptr(ids[0])), "nrx_sparse_plan_place")
+        return order, uniq, seg, counts, dest, walk, n_walk
     check(lib.nrx_sparse_plan(ptrs, lens, tof, rws, n, ids[0].element_size() * 8, n_tables, order.data_ptr(), uniq.data_ptr(),
                               seg.data_ptr(), counts.data_ptr(), ws.data_ptr(), _stream_ptr(ids[0])), "nrx_sparse_plan")
     return order, uniq, seg, counts
+
+
+def _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, wide_ld, n_unique, n_unique_dev, fmg, values, lws, stream):
+    """nrx_embed_bwd_sorted, or nrx_embed_bwd_placed when the plan `pl` carries a placement (7 tensors)."""
+    order, uniq, seg = pl[0], pl[1], pl[2]
+    if len(pl) == 7:
+        check(lib.nrx_embed_bwd_placed(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), wide_ld, order.data_ptr(), seg.data_ptr(),
+                                       uniq.data_ptr(), n_unique, _ptr(n_unique_dev), fmg, values.data_ptr(), int(pmask),
+                                       pl[4].data_ptr(), pl[5].data_ptr(), pl[6].data_ptr(), lws.data_ptr(), stream),
+              "nrx_embed_bwd_placed")
+    else:
+        check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), wide_ld, order.data_ptr(), seg.data_ptr(),
+                                       uniq.data_ptr(), n_unique, _ptr(n_unique_dev), fmg, values.data_ptr(), lws.data_ptr(), stream),
+              "nrx_embed_bwd_sorted")
 
 
 def _sparse_groups(plan: EmbedPlan):
@@ -502,8 +543,9 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
         tabs = [plan.slots[i].table for i in fs]
         n = len(fs)
         pre = ahead.get((D, fs[0]))
+        pmask = place_mask([plan.slots[i].kind for i in fs]) if SPARSE_PLACE else None
         if pre is not None:                 # planned at forward time on the side stream (sparse_plan_ahead)
-            ids, (order, uniq, seg, counts), ev = pre
+            ids, pl, ev = pre
             torch.cuda.current_stream(dev).wait_event(ev)
             total = sum(x.numel() for x in ids)
         else:
@@ -514,7 +556,8 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
             total = sum(x.numel() for x in ids)
             if total == 0:
                 continue
-            order, uniq, seg, counts = sparse_plan(ids, tabs, [ctx.table_meta[t][0][0] for t in tabs], n_tables)
+            pl = sparse_plan(ids, tabs, [ctx.table_meta[t][0][0] for t in tabs], n_tables, pmask)
+        uniq, counts = pl[1], pl[3]
         # The one host read (n_tables + 2 integers).  Reading it BEFORE the reduction lets the host build the
         # per-table COO tensors while that kernel runs (1.00 ms per C2 step vs 1.11 ms with the sync-free
         # n_unique_dev form of the call, which leaves the host work exposed after the GPU is done).
@@ -524,25 +567,20 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
         lws = torch.empty(lib.nrx_embed_bwd_sorted_workspace(total, D), dtype=torch.uint8, device=dev)   # hot-row work lists
         if ctx.sink is not None:
             values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
-            check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
-                                           seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), fmg, values.data_ptr(), lws.data_ptr(), stream),
-                  "nrx_embed_bwd_sorted")
+            _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, total, counts, fmg, values, lws, stream)
             ctx.sink.pending.append(dict(tables=ctx.tables, dim=D, uniq=uniq, values=values, counts=counts, cap=total))
             continue
         if SPARSE_BWD_SYNC_FREE:
             values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
-            check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
-                                           seg.data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), fmg, values.data_ptr(), lws.data_ptr(), stream),
-                  "nrx_embed_bwd_sorted")
+            _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, total, counts, fmg, values, lws, stream)
             cl = counts.tolist()
             nu = cl[0]
         else:
             cl = counts.tolist()
             nu = cl[0]
             values = torch.empty((nu, D), dtype=torch.float32, device=dev)
-            check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, order.data_ptr(),
-                                           seg.data_ptr(), uniq.data_ptr(), nu, None, fmg, values.data_ptr(), lws.data_ptr(), stream),
-                  "nrx_embed_bwd_sorted")                     # padding rows (id 0) come back as zeros
+            _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, nu, None, fmg, values, lws, stream)
+                                                              # padding rows (id 0) come back as zeros
         rows = (uniq[:nu] & MASK).unsqueeze(0)
         for t in sorted(set(tabs)):
             lo, hi = cl[1 + t], cl[2 + t]
@@ -790,6 +828,10 @@ class PreparedSparseBackward:
                      counts=torch.empty(n_tables + 2, dtype=torch.int64, device=dev),
                      ws=torch.empty(max(1, self.lib.nrx_sparse_plan_workspace(total)), dtype=torch.uint8, device=dev),
                      values=torch.empty((total, D), dtype=torch.float32, device=dev),
+                     pmask=place_mask([plan.slots[i].kind for i in fs]) if SPARSE_PLACE else None,
+                     dest=torch.empty(max(total, 1), dtype=torch.int32, device=dev),
+                     walk=torch.empty(max(total, 1), dtype=torch.int32, device=dev),
+                     n_walk=torch.empty(1, dtype=torch.int64, device=dev),
                      lws=torch.empty(self.lib.nrx_embed_bwd_sorted_workspace(total, D), dtype=torch.uint8, device=dev),
                      ptrs=(C.c_void_p * n)(*[x.data_ptr() for x in ids]), lens=(C.c_int64 * n)(*[x.numel() for x in ids]),
                      tof=(C.c_int32 * n)(*tabs), rws=(C.c_int64 * n)(*[fwd.tables[t].shape[0] for t in tabs]),
@@ -801,8 +843,13 @@ class PreparedSparseBackward:
     def _plan(self, stream):
         lib = self.lib
         for g in self.groups:
-            rc = lib.nrx_sparse_plan(g["ptrs"], g["lens"], g["tof"], g["rws"], g["n"], g["bits"], g["n_tables"], g["order"].data_ptr(),
-                                     g["uniq"].data_ptr(), g["seg"].data_ptr(), g["counts"].data_ptr(), g["ws"].data_ptr(), stream)
+            if g["pmask"] is not None:
+                rc = lib.nrx_sparse_plan_place(g["ptrs"], g["lens"], g["tof"], g["rws"], g["n"], g["bits"], g["n_tables"], g["pmask"],
+                                               g["order"].data_ptr(), g["uniq"].data_ptr(), g["seg"].data_ptr(), g["counts"].data_ptr(),
+                                               g["dest"].data_ptr(), g["walk"].data_ptr(), g["n_walk"].data_ptr(), g["ws"].data_ptr(), stream)
+            else:
+                rc = lib.nrx_sparse_plan(g["ptrs"], g["lens"], g["tof"], g["rws"], g["n"], g["bits"], g["n_tables"], g["order"].data_ptr(),
+                                         g["uniq"].data_ptr(), g["seg"].data_ptr(), g["counts"].data_ptr(), g["ws"].data_ptr(), stream)
             if rc:
                 check(rc, "nrx_sparse_plan")
 
@@ -829,9 +876,15 @@ class PreparedSparseBackward:
         else:
             self._plan(stream)
         for g in self.groups:
-            rc = lib.nrx_embed_bwd_sorted(g["arr"], g["n"], f.B, g["dim"], _ptr(self.g_out), f.ld, _ptr(self.g_wide), f.plan.wide_width,
-                                          g["order"].data_ptr(), g["seg"].data_ptr(), g["uniq"].data_ptr(), g["total"],
-                                          g["counts"].data_ptr(), self.fmg, g["values"].data_ptr(), g["lws"].data_ptr(), stream)
+            if g["pmask"] is not None:
+                rc = lib.nrx_embed_bwd_placed(g["arr"], g["n"], f.B, g["dim"], _ptr(self.g_out), f.ld, _ptr(self.g_wide), f.plan.wide_width,
+                                              g["order"].data_ptr(), g["seg"].data_ptr(), g["uniq"].data_ptr(), g["total"],
+                                              g["counts"].data_ptr(), self.fmg, g["values"].data_ptr(), g["pmask"], g["dest"].data_ptr(),
+                                              g["walk"].data_ptr(), g["n_walk"].data_ptr(), g["lws"].data_ptr(), stream)
+            else:
+                rc = lib.nrx_embed_bwd_sorted(g["arr"], g["n"], f.B, g["dim"], _ptr(self.g_out), f.ld, _ptr(self.g_wide), f.plan.wide_width,
+                                              g["order"].data_ptr(), g["seg"].data_ptr(), g["uniq"].data_ptr(), g["total"],
+                                              g["counts"].data_ptr(), self.fmg, g["values"].data_ptr(), g["lws"].data_ptr(), stream)
             if rc:
                 check(rc, "nrx_embed_bwd_sorted")
         return self.groups

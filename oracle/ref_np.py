@@ -773,3 +773,27 @@ def sparse_plan(id_arrays, table_of, rows, n_tables: int):
     seg = np.concatenate([np.nonzero(head)[0], [len(sk)]]).astype(np.int64)
     counts = np.array([len(uniq)] + [int(np.searchsorted(uniq, np.int64(t) << np.int64(40))) for t in range(n_tables + 1)], np.int64)
     return order, uniq, seg, counts
+
+
+def sparse_plan_place(id_arrays, table_of, rows, n_tables: int, place_feats=None):
+    """Definition of nrx_sparse_plan_place: sparse_plan plus the PLACEMENT of the rows that need no reduction.  A unique
+    (table, row) looked up exactly once in the launch, not the padding row, by a feature listed in `place_feats` (default:
+    all), is `placed`: dest[p] = its unique index for that lookup p; every other lookup has dest -1.  walk = the
+    unique indices that are not placed (several lookups, a non-placeable feature's lookup, or row 0), ascending.
+    The backward of nn.Embedding (base_model.py:262-308) for a placed row is the lookup's upstream row itself."""
+    order, uniq, seg, counts = sparse_plan(id_arrays, table_of, rows, n_tables)
+    lens = [int(np.asarray(x).size) for x in id_arrays]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    n = int(off[-1])
+    ok = np.ones(len(lens), bool) if place_feats is None else np.array([f in set(place_feats) for f in range(len(lens))], bool)
+    feat_of = np.searchsorted(off, np.arange(n), side="right") - 1 if n else np.zeros(0, np.int64)
+    dest = np.full(n, -1, np.int32)
+    seg_len = seg[1:] - seg[:-1]
+    row = uniq & ((np.int64(1) << np.int64(40)) - 1)
+    first = order[seg[:-1]] if n else np.zeros(0, np.int64)
+    placed = (seg_len == 1) & (row != 0)
+    if n:
+        placed &= ok[feat_of[first]]
+    dest[first[placed]] = np.nonzero(placed)[0].astype(np.int32)
+    walk = np.nonzero(~placed)[0].astype(np.int32)
+    return order, uniq, seg, counts, dest, walk

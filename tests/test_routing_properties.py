@@ -139,6 +139,19 @@ def test_sparse_plan_bit_exact(case, dtype, sort, monkeypatch):
     assert np.array_equal(order.cpu().numpy(), o_r)
     assert np.array_equal(uniq.cpu().numpy()[:nu], u_r)
     assert np.array_equal(seg.cpu().numpy()[:nu + 1], s_r)
+    # the placement form (nrx_sparse_plan_place): same plan + dest / walk, for "every feature placeable" and for a partial mask
+    nf = len(ids)
+    for feats in (list(range(nf)), [f for f in range(nf) if f % 2 == 0]):
+        mask = sum(1 << f for f in feats)
+        o2, u2, s2, c2, dest, walk, n_walk = ops.sparse_plan([torch.from_numpy(x).to("cuda:0") for x in ids], case["tab"], case["rows"],
+                                                             case["nt"], place_feats=mask)
+        _, _, _, _, d_r, w_r = R.sparse_plan_place(ids, case["tab"], case["rows"], case["nt"], feats)
+        assert np.array_equal(c2.cpu().numpy(), c_r) and np.array_equal(o2.cpu().numpy(), o_r)
+        assert np.array_equal(u2.cpu().numpy()[:nu], u_r) and np.array_equal(s2.cpu().numpy()[:nu + 1], s_r)
+        assert int(n_walk.item()) == len(w_r)
+        assert np.array_equal(walk.cpu().numpy()[:len(w_r)], w_r)
+        able = np.isin(np.repeat(np.arange(nf), [len(x) for x in ids]), feats)          # dest is written for placeable lookups only
+        assert np.array_equal(dest.cpu().numpy()[:len(d_r)][able], d_r[able]) and np.all(d_r[~able] == -1)
 
 
 @pytest.mark.gpu
@@ -169,11 +182,33 @@ def test_sparse_plan_segmented_sort_matches_definition(lens, row_bits, tabs, ske
         if skew and ln:
             x = np.where(rng.random(ln) < 0.6, x[0], x)     # 60 % of the lookups hit one row
         ids.append(x.astype(np.int64))
-    order, uniq, seg, counts = ops.sparse_plan([torch.from_numpy(x).to("cuda:0") for x in ids], tab, rows, nt)
-    o_r, u_r, s_r, c_r = R.sparse_plan(ids, tab, rows, nt)
+    feats = [f for f in range(n) if (seed >> f) & 1] if seed % 4 else list(range(n))
+    order, uniq, seg, counts, dest, walk, n_walk = ops.sparse_plan([torch.from_numpy(x).to("cuda:0") for x in ids], tab, rows, nt,
+                                                                   place_feats=sum(1 << f for f in feats))
+    o_r, u_r, s_r, c_r, d_r, w_r = R.sparse_plan_place(ids, tab, rows, nt, feats)
     c = counts.cpu().numpy()
     assert np.array_equal(c, c_r)
     nu = int(c[0])
     assert np.array_equal(order.cpu().numpy(), o_r)
     assert np.array_equal(uniq.cpu().numpy()[:nu], u_r)
     assert np.array_equal(seg.cpu().numpy()[:nu + 1], s_r)
+    assert int(n_walk.item()) == len(w_r) and np.array_equal(walk.cpu().numpy()[:len(w_r)], w_r)
+    able = np.isin(np.repeat(np.arange(n), [len(x) for x in ids]), feats)              # dest is written for placeable lookups only
+    assert np.array_equal(dest.cpu().numpy()[:len(d_r)][able], d_r[able]) and np.all(d_r[~able] == -1)
+
+
+def test_oracle_sparse_plan_place_definition():
+    """The placement definition itself, on a case small enough to read: dest names the unique index of a row looked up once
+    (not row 0, placeable feature), walk lists every other unique row."""
+    #           feature 0 (table 0)   feature 1 (table 1, not placeable)   feature 2 (table 0)
+    ids = [np.array([5, 7, 0, 9]), np.array([3, 3, 4]), np.array([7, 2, 11])]
+    order, uniq, seg, counts, dest, walk = R.sparse_plan_place(ids, [0, 1, 0], [16, 8, 16], 2, place_feats=[0, 2])
+    rows = uniq & ((1 << 40) - 1)
+    tabs = uniq >> 40
+    assert list(zip(tabs.tolist(), rows.tolist())) == [(0, 0), (0, 2), (0, 5), (0, 7), (0, 9), (0, 11), (1, 3), (1, 4)]
+    #            p:  0  1   2   3 | 4   5   6 | 7   8  9
+    assert dest.tolist() == [2, -1, -1, 4, -1, -1, -1, -1, 1, 5]          # row 7 twice, row 0 = padding, table 1 not placeable
+    assert walk.tolist() == [0, 3, 6, 7]
+    # every unique row is either placed exactly once or walked
+    placed = sorted(d for d in dest.tolist() if d >= 0)
+    assert sorted(placed + walk.tolist()) == list(range(len(uniq)))
