@@ -190,14 +190,21 @@ NRX_API int nrx_sparse_plan_place(const void* const* ids, const int64_t* lens, c
                           int64_t* n_walk, void* workspace, void* stream);
 
 /* nrx_embed_bwd_sorted driven by a placement plan (nrx_sparse_plan_place): same arguments and the same values[] -- bit for
- * bit -- plus dest / walk / n_walk.  place_feats must be the mask the plan was made with; it may only name NRX_SPARSE
- * features.  Launch shapes outside the fast form (odd dims, unaligned FM inputs) ignore the placement and walk every row. */
+ * bit -- plus dest / walk / n_walk (all three NULL: no placement, every row is walked).  place_feats must be the mask the plan
+ * was made with; it may only name NRX_SPARSE features.  Launch shapes outside the fast form (odd dims, unaligned FM inputs)
+ * ignore the placement and walk every row.
+ * workspace_bytes: the size of `workspace` (0 = unknown: taken to be nrx_embed_bwd_sorted_workspace's).  With at least
+ * nrx_embed_bwd_workspace_for(feats, ...) bytes the bag features with 0/1 weights (masked mean over DataReader's masks, mean) are
+ * reduced from PRE-SCALED upstream rows kept in the workspace -- one row request per lookup instead of a row, a factor and a
+ * weight bit -- and feats[i].index (the ids, optional here) lets the launch skip the weight bits when every zero weight sits on a
+ * padding id. */
+NRX_API int64_t nrx_embed_bwd_workspace_for(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim);
 NRX_API int nrx_embed_bwd_placed(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
                          const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
                          const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
                          int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
                          uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
-                         void* workspace, void* stream);
+                         void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Fused row-sparse Adam(W) over the unique rows of nrx_sparse_plan / nrx_embed_bwd_sorted: for every unique entry u
  * (key = (table << 40) | row, gradient grads[u, :dim]) of up to NRX_MAX_FEATURES tables sharing `dim`,

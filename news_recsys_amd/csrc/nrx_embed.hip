@@ -416,6 +416,7 @@ struct SortedBwdArgs {
     int32_t n;
     int32_t dim;
     int32_t long_t;
+    const float* gs_all;           // bag launches with 0/1 weights: ONE staging array of every feature's (pre-scaled) upstream rows
     const int32_t* walk;           // placement mode (nrx_embed_bwd_placed): the unique rows this launch reduces, and how many;
     const int64_t* n_walk_dev;     //   null = every unique row
     int32_t regular;               // 1: every feature single-valued, no wide routing, uniform_len > 0, out_col = col0 + i * col_stride,
@@ -614,17 +615,18 @@ struct FeatLite {
     int32_t bag_len;
     int32_t kind;
     bool fm;
+    const float* gs;    // bag feature with 0/1 weights: its upstream rows ALREADY scaled, [B, dim] (bag_scale_kernel), or null
 };
 __device__ __forceinline__ FeatLite sorted_feat(const NRX_CONST SortedBwdArgs* a, int fi) {
     FeatLite f;
     if (a->regular) {                  // (the C2 / C5 shape: 26 / 40 single-valued features laid out back to back)
         f.off = (int64_t)fi * a->uniform_len; f.magic = 0; f.out_col = a->col0 + fi * a->col_stride; f.wide_col = -1;
-        f.bag_len = 0; f.kind = NRX_SPARSE; f.fm = a->all_fm != 0;
+        f.bag_len = 0; f.kind = NRX_SPARSE; f.fm = a->all_fm != 0; f.gs = nullptr;
         return f;
     }
     if (a->n <= 4) {
         f.off = a->off[0]; f.magic = (uint64_t)a->f[0].rows; f.out_col = a->f[0].out_col; f.wide_col = a->f[0].wide_col;
-        f.bag_len = a->f[0].bag_len; f.kind = a->f[0].kind; f.fm = a->f[0].fm != 0;
+        f.bag_len = a->f[0].bag_len; f.kind = a->f[0].kind; f.fm = a->f[0].fm != 0; f.gs = a->f[0].table;
 #pragma unroll
         for (int i = 1; i < 4; ++i) {           // constant indices: scalar loads (entries past n are inside the block and unused)
             const bool hit = fi == i;
@@ -635,11 +637,12 @@ __device__ __forceinline__ FeatLite sorted_feat(const NRX_CONST SortedBwdArgs* a
             f.bag_len = hit ? (int32_t)a->f[i].bag_len : f.bag_len;
             f.kind = hit ? (int32_t)a->f[i].kind : f.kind;
             f.fm = hit ? a->f[i].fm != 0 : f.fm;
+            f.gs = hit ? a->f[i].table : f.gs;
         }
         return f;
     }
     f.off = a->off[fi]; f.magic = (uint64_t)a->f[fi].rows; f.out_col = a->f[fi].out_col; f.wide_col = a->f[fi].wide_col;
-    f.bag_len = a->f[fi].bag_len; f.kind = a->f[fi].kind; f.fm = a->f[fi].fm != 0;
+    f.bag_len = a->f[fi].bag_len; f.kind = a->f[fi].kind; f.fm = a->f[fi].fm != 0; f.gs = a->f[fi].table;
     return f;
 }
 // d fm / d field folded into an upstream row chunk (columns 4q .. 4q+3 of the field): column 0 -> g_fm, column k -> g_fm (S_k - v_k).
@@ -840,12 +843,42 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceA
     }
 }
 
+// Upstream row chunk + factor of ONE sorted entry (flat lookup p of feature f) for launches with bag features.  Three forms, all
+// giving the same product bit for bit:  general weights: g_out row x scale[p];  0/1 weights: g_out row x (bit ? inv[sample] : 0);
+// 0/1 weights with the rows pre-scaled by bag_scale_kernel (f.gs): gs row x (bit ? 1 : 0) -- one L2-resident row request per
+// lookup instead of a row, a factor and a bit word (the C4 walk issued 13 M L1->L2 requests for 3.4 M lookups and ran at their
+// rate: profiles/r03_bwd_c4_counters_before.txt).  The bit word is skipped as well when no live lookup has weight 0 (DataReader's
+// masks are zero exactly at the padding ids, whose row is never walked).
+template <bool UNAL>
+__device__ __forceinline__ void sorted_bag_entry(const NRX_CONST SortedBwdArgs* a, const FeatLite& f, int64_t p, int q, int Q,
+                                                 bool bag_binary, bool need_bits, int64_t& b, float4& g, float& sc) {
+    b = p - f.off;
+    sc = 1.0f;
+    if (f.kind >= NRX_BAG_MASKED_MEAN) {
+        if (f.bag_len > 1) b = (int64_t)__umul64hi((uint64_t)b, f.magic);   // b / bag_len (b < 2^32)
+        if (bag_binary) {
+            bool bit = true;
+            if (need_bits || f.gs == nullptr) bit = (nrx_gconst<uint32_t>(a->bag_bits)[p >> 5] >> (p & 31)) & 1u;
+            if (!UNAL && f.gs != nullptr) {
+                sc = bit ? 1.0f : 0.f;
+                g = nrx_ldg4(f.gs, b * Q + q);
+                return;
+            }
+            sc = bit ? nrx_gconst<float>(a->bag_inv)[f.off + b] : 0.f;
+        } else {
+            sc = nrx_gconst<float>(a->scale)[p];
+        }
+    }
+    g = sorted_upstream<UNAL>(a, f, b, q);
+}
+
 // BAG: some features are bags -- a lookup's sample is (flat index) / L and its upstream row is scaled by the per-lookup
 // factor bag_scale_kernel left in a->scale (mask / (sum mask + 1e-8), 1 / L, or the weight).
 template <int QLOG2, int R, bool FM, bool BAG, bool UNAL, int UP = 1>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const SortedBwdArgs args_in_kernarg) {
     const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
-    const bool bag_binary = BAG && a->bag_bits != nullptr && a->long_ws[3] == 0;      // every bag weight is 0 or 1 (bag_scale_kernel)
+    const bool bag_binary = BAG && a->bag_bits != nullptr && (a->long_ws[3] & 1) == 0;      // every bag weight is 0 or 1 (bag_scale_kernel)
+    const bool need_bits = BAG && a->bag_bits != nullptr && (a->long_ws[3] & 2) != 0;       // some live lookup has weight 0
     constexpr int Q = 1 << QLOG2;
     constexpr int TB = NRX_BLOCK / Q;
     const int q = threadIdx.x & (Q - 1);
@@ -939,11 +972,21 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
     // launches, where a row of the pooled table is looked up ~L times and a one-entry pass made the walk latency-bound:
     // all rows of the launch are in flight at once, so the only parallelism left is INSIDE a row).  The lookup indices of the
     // next pass are requested before this pass's rows: one memory round trip per pass, not two.
-    int64_t pn[R][UP];
+    // The UP consecutive order words of a row are ONE request per lane group: lane q fetches word (q mod UP), the group shares them
+    // through the cross-lane unit (every lane loading all UP words made UP requests of 8 bytes each).
+    constexpr bool WIDE = UP > 1 && UP <= Q;
+    const int gbase = (threadIdx.x & 63) & ~(Q - 1);
+    int64_t pn[R][WIDE ? 1 : UP];
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+    for (int r = 0; r < R; ++r) {
+        if (WIDE) {
+            const int64_t ei = e[r] + (q & (UP - 1));
+            pn[r][0] = nrx_gconst<int64_t>(a->order)[ei < hi[r] ? ei : lo[0]];
+        } else {
 #pragma unroll
-        for (int j = 0; j < UP; ++j) pn[r][j] = nrx_gconst<int64_t>(a->order)[e[r] + j < hi[r] ? e[r] + j : lo[0]];
+            for (int j = 0; j < (WIDE ? 1 : UP); ++j) pn[r][j] = nrx_gconst<int64_t>(a->order)[e[r] + j < hi[r] ? e[r] + j : lo[0]];
+        }
+    }
     auto pass = [&]() -> bool {
         int64_t p[R][UP];
         bool on[R][UP];
@@ -952,13 +995,19 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
 #pragma unroll
             for (int j = 0; j < UP; ++j) {
                 on[r][j] = e[r] + j < hi[r];
-                p[r][j] = pn[r][j];
+                p[r][j] = WIDE ? __shfl(pn[r][0], gbase + j, 64) : pn[r][WIDE ? 0 : j];
             }
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+        for (int r = 0; r < R; ++r) {
+            if (WIDE) {
+                const int64_t ei = e[r] + UP + (q & (UP - 1));
+                if (ei < hi[r]) pn[r][0] = nrx_gconst<int64_t>(a->order)[ei];
+            } else {
 #pragma unroll
-            for (int j = 0; j < UP; ++j)
-                if (e[r] + UP + j < hi[r]) pn[r][j] = nrx_gconst<int64_t>(a->order)[e[r] + UP + j];      // (one-entry rows request nothing)
+                for (int j = 0; j < (WIDE ? 1 : UP); ++j)
+                    if (e[r] + UP + j < hi[r]) pn[r][j] = nrx_gconst<int64_t>(a->order)[e[r] + UP + j];      // (one-entry rows request nothing)
+            }
+        }
         float4 g[R][UP], v[R][UP], s[R][UP];
         float gf[R][UP], sc[R][UP];
 #pragma unroll
@@ -966,19 +1015,14 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
 #pragma unroll
             for (int j = 0; j < UP; ++j) {
                 const FeatLite f = sorted_feat(a, sorted_feat_of(a, p[r][j]));
-                int64_t b = p[r][j] - f.off;
-                sc[r][j] = 1.0f;
-                if (BAG && f.kind >= NRX_BAG_MASKED_MEAN) {
-                    if (f.bag_len > 1) b = (int64_t)__umul64hi((uint64_t)b, f.magic);   // b / bag_len (b < 2^32)
-                    if (bag_binary) {
-                        const uint32_t wb = nrx_gconst<uint32_t>(a->bag_bits)[p[r][j] >> 5];
-                        const float one = nrx_gconst<float>(a->bag_inv)[f.off + b];
-                        sc[r][j] = (wb >> (p[r][j] & 31)) & 1u ? one : 0.f;
-                    } else {
-                        sc[r][j] = nrx_gconst<float>(a->scale)[p[r][j]];
-                    }
+                int64_t b;
+                if (BAG) {
+                    sorted_bag_entry<UNAL>(a, f, p[r][j], q, Q, bag_binary, need_bits, b, g[r][j], sc[r][j]);
+                } else {
+                    b = p[r][j] - f.off;
+                    sc[r][j] = 1.0f;
+                    g[r][j] = sorted_upstream<UNAL>(a, f, b, q);
                 }
-                g[r][j] = sorted_upstream<UNAL>(a, f, b, q);
                 if (FM) {
                     gf[r][j] = f.fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
                     v[r][j] = nrx_ldg4(a->feat, (b * a->feat_ld + f.out_col) / 4 + q);
@@ -1006,8 +1050,62 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
         }
         return more;
     };
+    // Staged form (a->gs_all: every feature's upstream rows, already scaled, in one array): the lane that fetched an order word
+    // also DECODES it -- feature, sample, row of the staging array, weight bit -- and the group exchanges finished 32-bit row
+    // numbers.  In the general pass every lane decodes all R x UP entries of its group (the same work in each of the Q lanes):
+    // ~100 vector instructions per entry; the C4 walk was bound by them once its memory requests had been cut.
+    auto pass_staged = [&]() -> bool {
+        int32_t mine[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t ei = e[r] + (q & (UP - 1));
+            const int64_t pw = pn[r][0];
+            int32_t id = -1;
+            if (ei < hi[r]) {
+                const FeatLite f = sorted_feat(a, sorted_feat_of(a, pw));
+                uint64_t b = (uint64_t)(pw - f.off);
+                if (f.bag_len > 1) b = __umul64hi(b, f.magic);
+                id = (int32_t)((f.gs - a->gs_all) >> (QLOG2 + 2)) + (int32_t)b;
+                if (need_bits && f.kind >= NRX_BAG_MASKED_MEAN &&
+                    ((nrx_gconst<uint32_t>(a->bag_bits)[pw >> 5] >> (pw & 31)) & 1u) == 0) id = -1;
+            }
+            mine[r] = id;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t ei = e[r] + UP + (q & (UP - 1));
+            if (ei < hi[r]) pn[r][0] = nrx_gconst<int64_t>(a->order)[ei];
+        }
+        int32_t id[R][UP];
+        float4 g[R][UP];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < UP; ++j) id[r][j] = __shfl(mine[r], gbase + j, 64);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < UP; ++j)
+                if (id[r][j] >= 0) g[r][j] = nrx_ldg4(a->gs_all, (int64_t)id[r][j] * Q + q);
+        bool more = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int j = 0; j < UP; ++j)
+                if (id[r][j] >= 0) {          // added in sorted order: j ascending inside the pass
+                    acc[r].x += g[r][j].x; acc[r].y += g[r][j].y; acc[r].z += g[r][j].z; acc[r].w += g[r][j].w;
+                }
+            e[r] += UP;
+            more |= e[r] < hi[r];
+        }
+        return more;
+    };
     bool more = true;
-    while (more) more = pass();
+    if (BAG && WIDE && bag_binary && a->gs_all != nullptr) {
+        while (more) more = pass_staged();
+    } else {
+        while (more) more = pass();
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (u0 + r < n && !lng[r]) nrx_stg4(a->values, urow[r] * (int64_t)Q + q, acc[r]);
@@ -1020,7 +1118,8 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
 template <int QLOG2, bool FM, bool BAG, bool UNAL>
 __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdArgs args_in_kernarg) {
     const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
-    const bool bag_binary = BAG && a->bag_bits != nullptr && a->long_ws[3] == 0;      // every bag weight is 0 or 1 (bag_scale_kernel)
+    const bool bag_binary = BAG && a->bag_bits != nullptr && (a->long_ws[3] & 1) == 0;      // every bag weight is 0 or 1 (bag_scale_kernel)
+    const bool need_bits = BAG && a->bag_bits != nullptr && (a->long_ws[3] & 2) != 0;
     constexpr int Q = 1 << QLOG2, G = 64 / Q;
     const int lane = threadIdx.x & 63, q = lane & (Q - 1), g = lane >> QLOG2;
     const int nitems = a->long_ws[0] < a->long_items_cap ? a->long_ws[0] : (int)a->long_items_cap;
@@ -1044,19 +1143,14 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
 #pragma unroll
             for (int k = 0; k < UL; ++k) {
                 const FeatLite f = sorted_feat(a, sorted_feat_of(a, p[k]));
-                int64_t b = p[k] - f.off;
-                sc[k] = 1.0f;
-                if (BAG && f.kind >= NRX_BAG_MASKED_MEAN) {
-                    if (f.bag_len > 1) b = (int64_t)__umul64hi((uint64_t)b, f.magic);
-                    if (bag_binary) {
-                        const uint32_t wb = nrx_gconst<uint32_t>(a->bag_bits)[p[k] >> 5];
-                        const float one = nrx_gconst<float>(a->bag_inv)[f.off + b];
-                        sc[k] = (wb >> (p[k] & 31)) & 1u ? one : 0.f;
-                    } else {
-                        sc[k] = nrx_gconst<float>(a->scale)[p[k]];
-                    }
+                int64_t b;
+                if (BAG) {
+                    sorted_bag_entry<UNAL>(a, f, p[k], q, Q, bag_binary, need_bits, b, gr[k], sc[k]);
+                } else {
+                    b = p[k] - f.off;
+                    sc[k] = 1.0f;
+                    gr[k] = sorted_upstream<UNAL>(a, f, b, q);
                 }
-                gr[k] = sorted_upstream<UNAL>(a, f, b, q);
                 if (FM) {
                     gf[k] = f.fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
                     v[k] = nrx_ldg4(a->feat, (b * a->feat_ld + f.out_col) / 4 + q);
@@ -1126,7 +1220,12 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_combine_kernel(const SortedB
 // weights): w / (sum_l w + 1e-8) (masked mean, base_model.py:278-282), 1 / L (mean) or w (sum).  16 lanes per sample.
 __global__ __launch_bounds__(NRX_BLOCK) void bag_scale_kernel(const float* __restrict__ w, int kind, int64_t batch, int L,
                                                             float* __restrict__ scale, float* __restrict__ inv, uint32_t* __restrict__ bits,
-                                                            int64_t base, int32_t* __restrict__ nonbinary) {
+                                                            int64_t base, int32_t* __restrict__ nonbinary, const void* __restrict__ ids,
+                                                            int idx64, const float* __restrict__ g_out, int64_t out_ld, int out_col, int D,
+                                                            float* __restrict__ gs) {
+    // flags in *nonbinary: bit 0 = some weight is neither 0 nor 1; bit 1 = some LIVE lookup (id != 0; any lookup when ids is null)
+    // has weight 0 -- only then does the reduction need the bit words next to the pre-scaled rows.
+    // gs (optional, [batch, D]): the sample's upstream row times `one`, for the reduction's one-request-per-lookup form.
     // also leaves the compact form: inv[b] = factor of a weight-1 lookup of sample b, bits = one bit per lookup (weight != 0;
     // `bits` pre-zeroed, indexed by the flat lookup base + b L + l), and raises *nonbinary when some weight is neither 0 nor 1.
     // DataReader's masks are 0/1 (data_reader.py:96-109), and then the reduction reads 0.7 MB of L2-resident words instead of
@@ -1141,8 +1240,14 @@ __global__ __launch_bounds__(NRX_BLOCK) void bag_scale_kernel(const float* __res
     }
     const float one = kind == NRX_BAG_MASKED_MEAN ? 1.0f / den : (kind == NRX_BAG_MEAN ? 1.0f / (float)L : 1.0f);
     if (q == 0) inv[b] = one;
+    if (gs != nullptr) {
+        for (int k = q; k < D / 4; k += 16) {
+            const float4 t = nrx_ldg4(g_out, (b * out_ld + out_col) / 4 + k);
+            nrx_stg4(gs, b * (D / 4) + k, make_float4(t.x * one, t.y * one, t.z * one, t.w * one));
+        }
+    }
     const int gsh = (threadIdx.x & 63) & ~15;                 // this group's first lane inside the wavefront
-    bool odd = false;
+    bool odd = false, zero_live = false;
     for (int l0 = 0; l0 < L; l0 += 16) {
         const int l = l0 + q;
         const bool in = l < L;
@@ -1155,6 +1260,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void bag_scale_kernel(const float* __res
             scale[b * L + l] = v;
         }
         odd |= in && wv != 0.0f && wv != 1.0f;
+        if (in && wv == 0.0f) zero_live |= ids == nullptr || nrx_load_id(ids, b * L + l, idx64 != 0) != 0;
         const uint32_t m = (uint32_t)((__ballot(in && wv != 0.0f) >> gsh) & 0xffffull);     // the group's 16 lookups
         if (q == 0 && m != 0u) {
             const int64_t p0 = base + b * L + l0;
@@ -1164,6 +1270,24 @@ __global__ __launch_bounds__(NRX_BLOCK) void bag_scale_kernel(const float* __res
         }
     }
     if (__ballot(odd) != 0ull && (threadIdx.x & 63) == 0) atomicOr(nonbinary, 1);
+    if (__ballot(zero_live) != 0ull && (threadIdx.x & 63) == 0) atomicOr(nonbinary, 2);
+}
+
+// Staging array of a bag launch (SortedBwdArgs::gs_all): the rows of its SINGLE-VALUED features are plain copies of their g_out
+// columns (block y of the grid = the y-th such feature).
+struct StageArgs {
+    int32_t out_col[NRX_MAX_FEATURES];
+    int32_t block[NRX_MAX_FEATURES];       // the feature's block number in the staging array (its index in the launch)
+};
+__global__ __launch_bounds__(NRX_BLOCK) void stage_rows_kernel(const StageArgs args_in_kernarg, const float* __restrict__ g_out, int64_t out_ld,
+                                                             int64_t batch, int d4, float* __restrict__ gs) {
+    const NRX_CONST StageArgs* a = nrx_kernarg<StageArgs>();
+    const int y = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x;      // float4 index inside the feature's block
+    if (i >= batch * d4) return;
+    const int64_t b = i / d4;
+    const int k = (int)(i - b * d4);
+    nrx_stg4(gs, ((int64_t)a->block[y] * batch + b) * d4 + k, nrx_ldg4(g_out, (b * out_ld + a->out_col[y]) / 4 + k));
 }
 
 // ----------------------------------------------------------------------------------- host side
@@ -1473,7 +1597,7 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
                                  const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
                                  int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
                                  uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
-                                 void* workspace, void* stream) {
+                                 void* workspace, int64_t ws_bytes /* 0: the size nrx_embed_bwd_sorted_workspace promises */, void* stream) {
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_bwd_sorted: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0 && dim >= 1 && n_unique >= 0, "nrx_embed_bwd_sorted: bad argument");
@@ -1498,6 +1622,7 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
     a.bag_bits = nullptr;
     a.walk = nullptr;
     a.n_walk_dev = nullptr;
+    a.gs_all = nullptr;
     a.long_t = SORTED_LONG_T;
     int64_t off = 0;
     for (int i = 0; i < n_feats; ++i) {
@@ -1650,13 +1775,42 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             a.bag_inv = inv;
             a.bag_bits = bits;
             if (nrx_zero_async(bits, (size_t)(off / 32 + 2) * 4, st) != NRX_OK) return NRX_ERR_LAUNCH;
+            // pre-scaled upstream rows of the 0/1-weight bag features ([batch, dim] each) live behind the bit words -- when the
+            // caller's workspace is known to hold them (nrx_embed_bwd_workspace_for) and the launch reads g_out aligned
+            float* gs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(bits + off / 32 + 2) + 255) & ~(uintptr_t)255);
+            // (every feature gets a block of the staging array: a single-valued feature's rows are copied, as "bags of one with
+            // weight 1" -- then one array serves every lookup of the launch and a row is named by a 32-bit number: pass_staged)
+            bool all_01 = true;                  // kinds whose factor is per SAMPLE when the weights are 0/1
+            for (int i = 0; i < n_feats; ++i) all_01 &= feats[i].kind != NRX_BAG_SUM;
+            const int64_t gs_end = (reinterpret_cast<char*>(gs) - reinterpret_cast<char*>(workspace)) + (int64_t)n_feats * batch * dim * 4;
+            const char* gs_env = getenv("NRX_BAG_PRESCALE");             // "0": the per-lookup factor form (tests compare the two)
+            const bool use_gs = bag_shape && g_out != nullptr && ws_bytes >= gs_end && !(gs_env && gs_env[0] == '0') &&
+                                (int64_t)n_feats * batch < 0x7fffffffLL;
+            if (use_gs && all_01) a.gs_all = gs;
+            StageArgs sg;
+            int n_sg = 0;
             for (int i = 0; i < n_feats; ++i) {
-                if (feats[i].kind == NRX_SPARSE || batch == 0) continue;
+                if (batch == 0) continue;
+                float* gsi = (use_gs && feats[i].kind != NRX_BAG_SUM) ? gs + (int64_t)i * batch * dim : nullptr;
+                if (feats[i].kind == NRX_SPARSE) {
+                    if (a.gs_all != nullptr) {
+                        a.f[i].table = gsi;
+                        sg.out_col[n_sg] = feats[i].out_col;
+                        sg.block[n_sg] = i;
+                        ++n_sg;
+                    }
+                    continue;
+                }
+                a.f[i].table = gsi;
                 const int64_t groups16 = batch;                                          // 16 lanes per sample
                 hipLaunchKernelGGL(bag_scale_kernel, dim3((unsigned)((groups16 * 16 + NRX_BLOCK - 1) / NRX_BLOCK)), dim3(NRX_BLOCK), 0, st,
                                    a.f[i].weight, (int)feats[i].kind, batch, (int)feats[i].bag_len, scale + a.off[i], inv + a.off[i], bits,
-                                   a.off[i], a.long_ws + 3);
+                                   a.off[i], a.long_ws + 3, feats[i].index, (int)(feats[i].index_bits == 64), g_out, out_ld,
+                                   (int)feats[i].out_col, (int)dim, gsi);
             }
+            if (n_sg > 0)
+                hipLaunchKernelGGL(stage_rows_kernel, dim3((unsigned)((batch * (dim / 4) + NRX_BLOCK - 1) / NRX_BLOCK), (unsigned)n_sg),
+                                   dim3(NRX_BLOCK), 0, st, sg, g_out, out_ld, batch, (int)(dim / 4), gs);
         }
 #define NRX_SF(QL_)                                                                                                        \
     {                                                                                                                      \
@@ -1697,7 +1851,18 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
                                     int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
                                     void* workspace, void* stream) {
     return embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, g_wide, wide_ld, order, seg_start, uniq_keys, n_unique,
-                                 n_unique_dev, fm, values, 0, nullptr, nullptr, nullptr, workspace, stream);
+                                 n_unique_dev, fm, values, 0, nullptr, nullptr, nullptr, workspace, 0, stream);
+}
+
+// workspace size that also holds the pre-scaled upstream rows of the launch's 0/1-weight bag features
+extern "C" int64_t nrx_embed_bwd_workspace_for(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim) {
+    if (feats == nullptr || n_feats < 0 || batch < 0 || dim < 1) return -1;
+    int64_t n_lookups = 0, n_gs = 0;
+    for (int i = 0; i < n_feats; ++i) {
+        n_lookups += batch * (feats[i].kind == NRX_SPARSE ? 1 : feats[i].bag_len);
+        n_gs |= feats[i].kind == NRX_BAG_MASKED_MEAN || feats[i].kind == NRX_BAG_MEAN;
+    }
+    return nrx_embed_bwd_sorted_workspace(n_lookups, dim) + 512 + (n_gs ? (int64_t)n_feats * batch * (int64_t)dim * 4 : 0);
 }
 
 extern "C" int nrx_embed_bwd_placed(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
@@ -1705,8 +1870,11 @@ extern "C" int nrx_embed_bwd_placed(const nrx_feature_t* feats, int32_t n_feats,
                                     const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
                                     int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
                                     uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
-                                    void* workspace, void* stream) {
-    NRX_REQUIRE(dest != nullptr && walk != nullptr && n_walk != nullptr, "nrx_embed_bwd_placed: null placement buffer");
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+    NRX_REQUIRE((dest != nullptr) == (walk != nullptr) && (dest != nullptr) == (n_walk != nullptr),
+                "nrx_embed_bwd_placed: dest, walk and n_walk come together (all null: no placement)");
+    NRX_REQUIRE(workspace == nullptr || workspace_bytes == 0 || workspace_bytes >= nrx_embed_bwd_sorted_workspace(0, dim),
+                "nrx_embed_bwd_placed: workspace_bytes too small");
     return embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, g_wide, wide_ld, order, seg_start, uniq_keys, n_unique,
-                                 n_unique_dev, fm, values, place_feats, dest, walk, n_walk, workspace, stream);
+                                 n_unique_dev, fm, values, place_feats, dest, walk, n_walk, workspace, workspace_bytes, stream);
 }

@@ -500,15 +500,12 @@ def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequ
 def _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, wide_ld, n_unique, n_unique_dev, fmg, values, lws, stream):
     """nrx_embed_bwd_sorted, or nrx_embed_bwd_placed when the plan `pl` carries a placement (7 tensors)."""
     order, uniq, seg = pl[0], pl[1], pl[2]
-    if len(pl) == 7:
-        check(lib.nrx_embed_bwd_placed(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), wide_ld, order.data_ptr(), seg.data_ptr(),
-                                       uniq.data_ptr(), n_unique, _ptr(n_unique_dev), fmg, values.data_ptr(), int(pmask),
-                                       pl[4].data_ptr(), pl[5].data_ptr(), pl[6].data_ptr(), lws.data_ptr(), stream),
-              "nrx_embed_bwd_placed")
-    else:
-        check(lib.nrx_embed_bwd_sorted(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), wide_ld, order.data_ptr(), seg.data_ptr(),
-                                       uniq.data_ptr(), n_unique, _ptr(n_unique_dev), fmg, values.data_ptr(), lws.data_ptr(), stream),
-              "nrx_embed_bwd_sorted")
+    placed = len(pl) == 7
+    check(lib.nrx_embed_bwd_placed(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), wide_ld, order.data_ptr(), seg.data_ptr(),
+                                   uniq.data_ptr(), n_unique, _ptr(n_unique_dev), fmg, values.data_ptr(), int(pmask) if placed else 0,
+                                   pl[4].data_ptr() if placed else None, pl[5].data_ptr() if placed else None,
+                                   pl[6].data_ptr() if placed else None, lws.data_ptr(), lws.numel(), stream),
+          "nrx_embed_bwd_placed")
 
 
 def _sparse_groups(plan: EmbedPlan):
@@ -564,7 +561,7 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
         sub = EmbedPlan([plan.slots[i] for i in fs], out_width=plan.out_width, wide_width=plan.wide_width)
         arr = _fill_features(sub, 0, n, [None] * n_tables, ids, [ctx.ws[i] for i in fs], table_ptrs=[0] * n_tables,
                              fm=fmg is not None)
-        lws = torch.empty(lib.nrx_embed_bwd_sorted_workspace(total, D), dtype=torch.uint8, device=dev)   # hot-row work lists
+        lws = torch.empty(lib.nrx_embed_bwd_workspace_for(arr, n, B, D), dtype=torch.uint8, device=dev)   # hot-row work lists, bag scales
         if ctx.sink is not None:
             values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
             _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, total, counts, fmg, values, lws, stream)
@@ -822,6 +819,8 @@ class PreparedSparseBackward:
             total = sum(x.numel() for x in ids)
             tabs = [plan.slots[i].table for i in fs]
             sub = EmbedPlan([plan.slots[i] for i in fs], out_width=plan.out_width, wide_width=plan.wide_width)
+            arr = _fill_features(sub, 0, n, [None] * n_tables, ids, [fwd.ws[i] for i in fs], table_ptrs=[0] * n_tables,
+                                 fm=self.fmg is not None)
             g = dict(dim=D, n=n, total=total, cap=total,
                      order=torch.empty(total, dtype=torch.int64, device=dev), uniq=torch.empty(total, dtype=torch.int64, device=dev),
                      seg=torch.empty(total + 1, dtype=torch.int64, device=dev),
@@ -832,12 +831,11 @@ class PreparedSparseBackward:
                      dest=torch.empty(max(total, 1), dtype=torch.int32, device=dev),
                      walk=torch.empty(max(total, 1), dtype=torch.int32, device=dev),
                      n_walk=torch.empty(1, dtype=torch.int64, device=dev),
-                     lws=torch.empty(self.lib.nrx_embed_bwd_sorted_workspace(total, D), dtype=torch.uint8, device=dev),
+                     lws=torch.empty(self.lib.nrx_embed_bwd_workspace_for(arr, n, fwd.B, D), dtype=torch.uint8, device=dev),
                      ptrs=(C.c_void_p * n)(*[x.data_ptr() for x in ids]), lens=(C.c_int64 * n)(*[x.numel() for x in ids]),
                      tof=(C.c_int32 * n)(*tabs), rws=(C.c_int64 * n)(*[fwd.tables[t].shape[0] for t in tabs]),
                      bits=ids[0].element_size() * 8, n_tables=n_tables,
-                     arr=_fill_features(sub, 0, n, [None] * n_tables, ids, [fwd.ws[i] for i in fs], table_ptrs=[0] * n_tables,
-                                        fm=self.fmg is not None))
+                     arr=arr)
             self.groups.append(g)
 
     def _plan(self, stream):
@@ -876,17 +874,14 @@ class PreparedSparseBackward:
         else:
             self._plan(stream)
         for g in self.groups:
-            if g["pmask"] is not None:
-                rc = lib.nrx_embed_bwd_placed(g["arr"], g["n"], f.B, g["dim"], _ptr(self.g_out), f.ld, _ptr(self.g_wide), f.plan.wide_width,
-                                              g["order"].data_ptr(), g["seg"].data_ptr(), g["uniq"].data_ptr(), g["total"],
-                                              g["counts"].data_ptr(), self.fmg, g["values"].data_ptr(), g["pmask"], g["dest"].data_ptr(),
-                                              g["walk"].data_ptr(), g["n_walk"].data_ptr(), g["lws"].data_ptr(), stream)
-            else:
-                rc = lib.nrx_embed_bwd_sorted(g["arr"], g["n"], f.B, g["dim"], _ptr(self.g_out), f.ld, _ptr(self.g_wide), f.plan.wide_width,
-                                              g["order"].data_ptr(), g["seg"].data_ptr(), g["uniq"].data_ptr(), g["total"],
-                                              g["counts"].data_ptr(), self.fmg, g["values"].data_ptr(), g["lws"].data_ptr(), stream)
+            pm = g["pmask"] is not None
+            rc = lib.nrx_embed_bwd_placed(g["arr"], g["n"], f.B, g["dim"], _ptr(self.g_out), f.ld, _ptr(self.g_wide), f.plan.wide_width,
+                                          g["order"].data_ptr(), g["seg"].data_ptr(), g["uniq"].data_ptr(), g["total"],
+                                          g["counts"].data_ptr(), self.fmg, g["values"].data_ptr(), g["pmask"] if pm else 0,
+                                          g["dest"].data_ptr() if pm else None, g["walk"].data_ptr() if pm else None,
+                                          g["n_walk"].data_ptr() if pm else None, g["lws"].data_ptr(), g["lws"].numel(), stream)
             if rc:
-                check(rc, "nrx_embed_bwd_sorted")
+                check(rc, "nrx_embed_bwd_placed")
         return self.groups
 
 

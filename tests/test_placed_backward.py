@@ -104,6 +104,44 @@ def test_placed_backward_with_bag_features_equals_sorted_walk(kind, dist, monkey
     a = _grads(plan, tables, inputs, weights, g_out, None, None, True, monkeypatch)
     b = _grads(plan, tables, inputs, weights, g_out, None, None, False, monkeypatch)
     _same(a, b)
+    # ... and the pre-scaled-row form of the 0/1-weight bags (one row request per lookup) against the per-lookup factor form
+    monkeypatch.setenv("NRX_BAG_PRESCALE", "0")
+    c = _grads(plan, tables, inputs, weights, g_out, None, None, True, monkeypatch)
+    d = _grads(plan, tables, inputs, weights, g_out, None, None, False, monkeypatch)
+    monkeypatch.delenv("NRX_BAG_PRESCALE")
+    _same(a, c)
+    _same(a, d)
+
+
+@pytest.mark.parametrize("live_zero", [False, True])
+@pytest.mark.parametrize("D", [16, 32, 64])
+def test_bag_backward_prescaled_rows_with_and_without_weight_bits(live_zero, D, monkeypatch):
+    """Masked-mean history: when every zero weight sits on a padding id (DataReader's masks) the reduction reads no weight bits;
+    a zero weight on a REAL id (live_zero) must still contribute nothing.  Both against the per-lookup factor form, bit for bit,
+    and against a float64 restatement of the pooling backward (base_model.py:273-282)."""
+    rng = np.random.default_rng(3 + D + int(live_zero))
+    L, B, news = 12, 1800, 700
+    plan = ops.EmbedPlan([ops.Slot("user_history", NRX_BAG_MASKED_MEAN, 0, D, L, 0)], out_width=D)
+    table = torch.from_numpy(rng.standard_normal((news, D)).astype(np.float32)).to(DEV)
+    lens = rng.integers(0, L + 1, B)
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.float32)
+    hist = np.where(mask > 0, rng.integers(1, news, (B, L)), 0)
+    if live_zero:
+        kill = (rng.random((B, L)) < 0.2) & (mask > 0)
+        mask = np.where(kill, 0.0, mask).astype(np.float32)              # ids stay: zero weight on live rows
+    inputs, weights = [torch.from_numpy(hist).to(DEV)], [torch.from_numpy(mask).to(DEV)]
+    g_out = torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32)).to(DEV)
+    a = _grads(plan, [table], inputs, weights, g_out, None, None, True, monkeypatch)
+    monkeypatch.setenv("NRX_BAG_PRESCALE", "0")
+    b = _grads(plan, [table], inputs, weights, g_out, None, None, True, monkeypatch)
+    monkeypatch.delenv("NRX_BAG_PRESCALE")
+    _same(a, b)
+    den = mask.sum(1, keepdims=True).astype(np.float64) + 1e-8
+    contrib = (mask.astype(np.float64) / den)[:, :, None] * g_out.cpu().numpy().astype(np.float64)[:, None, :]
+    ref = np.zeros((news, D))
+    np.add.at(ref, hist.reshape(-1), contrib.reshape(-1, D))
+    ref[0] = 0
+    np.testing.assert_allclose(a[0].to_dense().cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
 
 
 def test_placed_backward_c2_shape_full_batch(monkeypatch):
