@@ -234,6 +234,38 @@ def algorithmic_bytes_per_impression(feats, fm: bool, cross_dim: int = 0) -> int
     return total
 
 
+def granule_bytes_per_impression(feats, fm: bool, cross_dim: int = 0) -> int:
+    """The same lookups priced at the memory system's granules: a random row read costs whole 128-byte lines (every fabric read
+    request of these kernels is 128 bytes: TCC_EA0_RDREQ_128B == RDREQ in profiles/), writes go out in 64-byte requests, ids and
+    masks stream.  For 64-byte rows (D = 16) this is what the counters measure (C2: 341 MB per launch vs 232 MB algorithmic)."""
+    total = 0
+    for f in feats:
+        D, L = f["dim"], f["bag"]
+        row_rd = -(-4 * D // 128) * 128
+        row_wr = -(-4 * D // 64) * 64
+        total += (8 + row_rd + row_wr) if L == 0 else (L * 12 + L * row_rd + row_wr)
+    if fm:
+        total += 4
+    total += 4 * cross_dim
+    return total
+
+
+def backward_bytes_per_impression(feats, fm: bool) -> int:
+    """Algorithmic bytes of the row-sparse backward, same conventions as SURVEY 8d (ids 8 B, fp32 rows, every lookup counted once):
+    per lookup the planner reads the id (8) and the reduction reads the upstream row (4D; a bag lookup reads its sample's row and
+    its 4-byte weight) and -- FM fields -- the forward value (4D); per unique row one gradient row (4D) and one key (8) are
+    written, counted per lookup (uniform ids: ~97 % of the lookups are distinct rows); per sample the FM field sums (4D) and
+    g_fm (4) are read.  Sorting traffic is NOT counted: it is overhead of the method, not of the problem."""
+    total = 0
+    for f in feats:
+        D, L = f["dim"], f["bag"]
+        n = max(L, 1)
+        total += n * (8 + 4 * D + (4 if L else 0) + (4 * D if fm else 0) + 4 * D + 8)
+    if fm:
+        total += 4 * feats[0]["dim"] + 4
+    return total
+
+
 # ------------------------------------------------------------------------------------ single-GPU runner
 def draw_ids(rows: int, shape, device, gen, dist: str) -> torch.Tensor:
     """Synthetic ids in [1, rows): 'uniform' (headline: cache-hostile) or 'zipf' = Zipf(1.05) popularity
@@ -304,6 +336,8 @@ class SingleGpuPath:
                     ws.append(None)
             self.pool.append((ins, ws))
         self.bytes_per_impr = algorithmic_bytes_per_impression(feats, self.fm, col if self.cross else 0)
+        self.granule_bytes_per_impr = granule_bytes_per_impression(feats, self.fm, col if self.cross else 0)
+        self.bwd_bytes_per_impr = backward_bytes_per_impression(feats, self.fm)
         self.bytes_note = ("SURVEY 8d: per lookup 8 B id + 4D row read + 4D concat write"
                            + (", + 4 B FM logit per impression" if self.fm else "")
                            + (f"; + {4 * col} B per impression for the fused cross output written next to x (SURVEY 8d's 2600 B "
@@ -617,6 +651,35 @@ def main():
     if hasattr(path, "check_indices"):
         path.check_indices()              # deferred IndexError of the timed launches (the reference raises per call)
 
+    def _traffic(key):
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                return json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:       # noqa: BLE001
+            return None
+
+    # what a plain copy sustains on THIS box, same run: 1 GiB read + 1 GiB written per launch, 16 bytes per lane
+    stream_copy = None
+    if world == 1 and not args.force_sharded and hasattr(path, "lib"):
+        try:
+            nbytes = 1 << 30
+            src = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+            dst = torch.empty_like(src)
+            st = torch.cuda.current_stream(device).cuda_stream
+            for _ in range(3):
+                path.lib.nrx_stream_copy(dst.data_ptr(), src.data_ptr(), nbytes, st)
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record()
+            for _ in range(10):
+                path.lib.nrx_stream_copy(dst.data_ptr(), src.data_ptr(), nbytes, st)
+            b_.record()
+            torch.cuda.synchronize()
+            stream_copy = 2 * nbytes * 10 / (a_.elapsed_time(b_) * 1e-3) / 1e9
+            del src, dst
+            torch.cuda.empty_cache()
+        except Exception:       # noqa: BLE001
+            stream_copy = None
+
     # secondary legs at N = 1, outside the headline timed region
     distinct = fwd_bwd = wide_split = None
     if world == 1 and not args.force_sharded and not args.headline_only:
@@ -676,8 +739,18 @@ def main():
                         and bool(torch.all(sg[1:] > sg[:-1])) and bool(torch.isfinite(g["values"][:nu]).all())):
                     raise SystemExit("fwd_bwd leg: the row-sparse backward's plan is inconsistent (unique rows not ascending / segments "
                                      "do not tile the lookups)")
+            fb_bytes = (bytes_per_impr + (4 * path.feats[0]["dim"] if path.fm else 0) + path.bwd_bytes_per_impr) * BATCH
+            fb_ach = fb_bytes / (fb_ms * 1e-3) / 1e9
             fwd_bwd = {"ms_per_step": fb_ms, "value": BATCH / (fb_ms * 1e-3), "unit": "impressions/s",
                        "forward_ms": f_ms, "backward_ms": fb_ms - f_ms,
+                       "roofline": {"bound": "hbm", "achieved": fb_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": fb_ach / HBM_PEAK_GBPS,
+                                    "algorithmic_bytes_per_step": fb_bytes,
+                                    "algorithmic_bytes_definition": "forward (training form: + 4D field sums written per sample for FM) + backward: per lookup 8 B id (planner) "
+                                                                    "+ 4D upstream row read (+ 4 B weight for a bag lookup) (+ 4D forward value read for FM fields) + 4D gradient "
+                                                                    "row written + 8 B key written; per sample 4D field sums + 4 B g_fm read (FM).  The sort's own traffic is not counted",
+                                    "traffic": _traffic(args.workload + "_fwd_bwd"), "traffic_unit": "bytes/step",
+                                    "note": "achieved = algorithmic bytes per step / mean step time (HIP events over the timed steps: forward + planning + "
+                                            "reduction, ~10 launches); traffic = fabric bytes per step summed over those launches from the committed PMC passes"},
                        "mode": "forward (training form: + FM field sums) + deterministic row-sparse backward: nrx_sparse_plan "
                                "(table-segmented stable radix sort of the row bits, unique rows, segments; inline here -- in a training step it is "
                                "enqueued on a side stream at forward time and hidden behind the dense model) + nrx_embed_bwd_sorted with the FM gradient folded in; "
@@ -708,12 +781,8 @@ def main():
         total_impr = BATCH * world * args.steps
         ms_per_step = dt * 1e3 / args.steps
         achieved = bytes_per_impr * BATCH / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                traffic = json.load(f).get(args.workload if world == 1 else "", {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+        traffic = _traffic(args.workload) if (world == 1 and args.ids == "uniform") else None
+        granule = getattr(path, "granule_bytes_per_impr", None)
         out = {
             "metric": "impressions/sec at batch 65536 (embedding hot path forward)",
             "value": total_impr / dt,
@@ -736,6 +805,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "kernel_ms_mean": kern_ms, "algorithmic_bytes_per_launch": bytes_per_impr * BATCH,
+                         "granule_bytes_per_launch": None if granule is None else granule * BATCH,
+                         "stream_copy_GBps": stream_copy,
+                         "traffic_GBps": None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9,
+                         "traffic_frac_of_stream_copy": None if (traffic is None or not stream_copy) else traffic / (kern_ms * 1e-3) / 1e9 / stream_copy,
+                         "ceiling_note": "granule_bytes_per_launch = the same lookups at the memory system's granules (random row reads in whole 128-byte "
+                                         "lines, writes in 64-byte requests); stream_copy_GBps = a plain 1 GiB copy (read + written bytes / time) measured in "
+                                         "this run on this box.  frac can not exceed (algorithmic / granule bytes) x (stream copy / peak); "
+                                         "traffic_frac_of_stream_copy says how close the launch's REAL traffic rate is to the box's copy rate",
                          "note": "achieved = algorithmic bytes per launch / mean launch duration (HIP events around "
                                  "the timed region on the launch stream / steps); traffic = DRAM bytes per launch from "
                                  "the committed rocprofv3 PMC passes (profiles/traffic.json), null if not profiled"},

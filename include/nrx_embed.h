@@ -90,6 +90,9 @@ NRX_API const char* nrx_last_error(void);
 /* device facts used by the bench harness:
  * {CUs, wavefront size, core clock kHz, global memory bytes, memory clock kHz, memory bus bits} */
 NRX_API int nrx_device_info(int device, int64_t info[6]);
+/* measurement utility of the bench harness: dst[0..bytes) = src[0..bytes), 16 bytes per lane, non-temporal -- the plain-copy rate
+ * of the box the roofline fractions are read against.  16-byte aligned device pointers, bytes % 16 == 0. */
+NRX_API int nrx_stream_copy(void* dst, const void* src, int64_t bytes, void* stream);
 
 /* ---- fused multi-table gather (+pool) -> concat, optional wide split and FM epilogue --------
  * Replaces BaseModel.get_embeddings_from_batch (base_model.py:284-308) = per-feature

@@ -64,6 +64,7 @@ SIGNATURES = {
     "nrx_abi_version": (C.c_int, []),
     "nrx_last_error": (C.c_char_p, []),
     "nrx_device_info": (C.c_int, [C.c_int, C.POINTER(_i64)]),
+    "nrx_stream_copy": (C.c_int, [_p, _p, _i64, _p]),
     "nrx_embed_fwd": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p]),
     "nrx_embed_fwd_train": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p]),
     "nrx_embed_bwd": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, C.POINTER(NrxFmGrad), _p]),

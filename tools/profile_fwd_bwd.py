@@ -7,8 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-if wl == "c5":
-    os.environ.setdefault("NRX_BENCH_C5_SMALL", "1")
+# c5: all 40 tables (224 GB) when the device holds them, like bench.py (NRX_BENCH_C5_SMALL=1 keeps the 27 tables of <= 16M rows)
 dev = torch.device("cuda:0")
 dist = sys.argv[3] if len(sys.argv) > 3 else "uniform"
 path = bench.SingleGpuPath(wl, dev, 1, id_dist=dist)

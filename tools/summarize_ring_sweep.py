@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses a tools/collect_ring_sweep.sh directory into the per-variant table committed as profiles/r02_c2_ring_sweep.md:
+"""Condenses a directory of tools/collect.sh runs of tools/c2_ring_sweep.hip (one per variant) into the per-variant table committed as profiles/r02_c2_ring_sweep.md:
 VGPRs / occupancy (from the kernel trace), harness time, rocprof mean time, SQ wait counters, TCP stall, DRAM bytes."""
 import collections, csv, glob, re, sys
 
