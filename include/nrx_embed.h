@@ -279,7 +279,10 @@ NRX_API int nrx_embed_dcn_v1_fwd(const nrx_feature_t* feats, int32_t n_feats, in
 /* ---- DCN v2 cross layer on the matrix cores: out = act(x0 * (x_l W^T + bias) + x_l) -----------
  * DCNv2Layer.forward + the ReLU DCNv2Net puts after every layer (dcn_arch.py:33-50, 73-91).
  * W: device [dim, dim] (nn.Linear weight: out x in), bias [dim].  fp32 in / fp32 accumulate on
- * v_mfma_f32_32x32x2_f32 (exact f32 fma chain).  relu: 1 = apply ReLU (reference), 0 = none.
+ * v_mfma_f32_32x32x2_f32 (exact f32 fma chain).  relu: FLAGS -- bit 0: apply ReLU (reference) / none; bit 1 (opt-in,
+ * dcn_cfg.math = bf16x3): split-bf16 matrix math -- every operand as two bfloat16 parts, x W^T ~= xh wh + xh wl + xl wh on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (16 significant operand bits; |err| ~5e-6 max|x W^T| at dim 320, stated in
+ * tests/test_dcn2_bf16x3.py); aligned shapes only, others take the fp32 form.
  * lin_out (optional, [batch, ld]): x_l W^T + bias before the Hadamard -- what the backward needs (training).      */
 NRX_API int nrx_dcn_v2_layer_fwd(const float* x0, const float* xl, int64_t ld, int64_t batch, int32_t dim,
                          const float* W, const float* bias, int32_t relu, float* out,

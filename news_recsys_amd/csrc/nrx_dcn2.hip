@@ -15,6 +15,8 @@
 // (C layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)).
 #include "nrx_common.h"
 #include <type_traits>
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -221,6 +223,164 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __res
     }
 }
 
+// ---- split-bf16 form (opt-in: dcn_cfg.math = bf16x3; flags bit 1 of nrx_dcn_v2_layer_fwd) --------------------------------------
+// fp32 MFMA runs at the fp32 VECTOR rate (1/16 of the bf16 matrix rate): at D = 320 the layer is 85 us of matrix time next to
+// ~50 us of memory time.  Each operand is split ONCE, in the load stage, into two bfloat16 parts, x = xh + xl (xh = bf16(x),
+// xl = bf16(x - xh)): 16 significant bits instead of 24.  x W^T ~= xl wh + xh wl + xh wh on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation (one accumulator: a second one for the small terms bought no measurable accuracy and cost a resident block per
+// CU); xl wl (2^-18 relative) is dropped.  Three
+// bf16 MFMAs of 16 k per 32 cycles instead of eight fp32 MFMAs of 2 k per 64: 5.3x less matrix time, the layer becomes
+// memory-bound.  Result: NOT the fp32 fma chain of the default kernel (which stays value-exact against the C oracle); error
+// vs float64 measured in tests/test_dcn2_bf16x3.py (max |err| ~5e-6 of max |x W^T| at D = 320, ~10x the fp32 kernel's).
+// LDS: operands as bf16, [row][k] with 80-byte rows (32 k + 16 bytes of padding): a lane's fragment (8 consecutive k of one row)
+// is one ds_read_b128, conflict-free across the 16 lanes an LDS cycle serves.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+constexpr int LDH = 40;      // halfs per LDS row
+
+// x = hi + lo in bfloat16 (round-to-nearest-even both times), two elements per v_cvt_pk_bf16_f32: 10 vector instructions per
+// float4.  (Written element by element through __bf16 casts the compiler spent ~50: the first version of this kernel issued 25
+// vector instructions per MFMA and was bound by them -- profiles/r03_dcn_v2_bf16x3.txt.)
+typedef __bf16 nrx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float nrx_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const nrx_f32x2 v = {a, b};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, nrx_bf16x2));
+    const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+    const nrx_f32x2 r = {a - ha, b - hb};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, nrx_bf16x2));
+}
+__device__ __forceinline__ void split_bf16x4(const float4& v, uint2& hi, uint2& lo) {
+    split_bf16x2(v.x, v.y, hi.x, lo.x);
+    split_bf16x2(v.z, v.w, hi.y, lo.y);
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256, 5) void dcn_v2_layer_bf16x3_kernel(const float* __restrict__ x0, const float* __restrict__ xl, int64_t ld,
+                                                                  int64_t M, int N, const float* __restrict__ W, const float* __restrict__ bias,
+                                                                  float* __restrict__ out, int64_t out_ld, unsigned nx,
+                                                                  float* __restrict__ lin_out) {
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[BM * LDH], Al[BM * LDH], Wh[BN * LDH], Wl[BN * LDH];
+    const int K = N;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const unsigned nb = gridDim.x, bid = blockIdx.x;          // XCD-aware tile order, as in the fp32 kernel
+    const unsigned xcd = bid & 7u, qd = nb >> 3, rm = nb & 7u;
+    const unsigned logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int64_t m0 = (int64_t)(logical / nx) * BM;
+    const int n0 = (int)(logical % nx) * BN;
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int srow = tid >> 3;        // 0..31
+    const int skq = (tid & 7) * 4;    // k offset inside the BK slab
+    constexpr int AP = BM / 32;
+    float4 a[AP], w[2];
+    uint32_t oa[AP], ow[2];
+    const char* const xtile = reinterpret_cast<const char*>(xl + m0 * ld);
+    const char* const wtile = reinterpret_cast<const char*>(W + (int64_t)n0 * K);
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+        const int64_t r = m0 + srow + 32 * p < M ? srow + 32 * p : M - 1 - m0;
+        oa[p] = (uint32_t)((r * ld + skq) * 4);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = n0 + srow + 32 * p < N ? srow + 32 * p : N - 1 - n0;
+        ow[p] = (uint32_t)((r * K + skq) * 4);
+    }
+    auto load_slab = [&](int k0) {
+        const char* xk = xtile + (size_t)k0 * 4;
+        const char* wk = wtile + (size_t)k0 * 4;
+        const bool ok = k0 + skq < K;                  // K % 4 == 0: a float4 is all-in or all-out; lanes past K re-read slab 0 and zero it
+        const size_t back = ok ? 0 : (size_t)k0 * 4;
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            const float4 t = *reinterpret_cast<const float4*>(xk + oa[p] - back);
+            a[p] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float4 t = *reinterpret_cast<const float4*>(wk + ow[p] - back);
+            w[p] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+        }
+    };
+    load_slab(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            uint2 h, l;
+            split_bf16x4(a[p], h, l);
+            *reinterpret_cast<uint2*>(&Ah[(srow + 32 * p) * LDH + skq]) = h;
+            *reinterpret_cast<uint2*>(&Al[(srow + 32 * p) * LDH + skq]) = l;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            uint2 h, l;
+            split_bf16x4(w[p], h, l);
+            *reinterpret_cast<uint2*>(&Wh[(srow + 32 * p) * LDH + skq]) = h;
+            *reinterpret_cast<uint2*>(&Wl[(srow + 32 * p) * LDH + skq]) = l;
+        }
+        __syncthreads();
+        if (k0 + BK < K) load_slab(k0 + BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 1 && k0 + 16 >= K) break;         // the last slab's upper half is all padding
+            const int ko = ks * 16 + 8 * hi;
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Wh[(wn * 32 + l31) * LDH + ko]);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Wl[(wn * 32 + l31) * LDH + ko]);
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const int row = wm * (32 * TM) + 32 * t + l31;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ah[row * LDH + ko]);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Al[row * LDH + ko]);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);       // the two small terms, then the leading one
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue: the fp32 kernel's (same C layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
+    const int col = n0 + wn * 32 + l31;
+    const bool same_x = (x0 == xl);
+    if (col < N) {
+        const float bc = bias[col];
+        const int64_t r0 = m0 + wm * (32 * TM);
+        const uint32_t lo = (uint32_t)(((int64_t)(4 * hi) * ld + col) * 4);
+        const uint32_t lo_o = (uint32_t)(((int64_t)(4 * hi) * out_ld + col) * 4);
+        const bool full = r0 + 32 * TM <= M;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            float xv[16], x0v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2);
+                if (!full && row + 4 * hi >= M) row = M - 1 - 4 * hi;          // clamp: the value is never stored
+                xv[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xl + row * ld) + lo);
+                x0v[r] = same_x ? xv[r] : *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x0 + row * ld) + lo);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2);
+                if (!full && row + 4 * hi >= M) continue;
+                const float lin = acc[t][r] + bc;
+                if (lin_out != nullptr)
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(lin_out + row * ld) + lo) = lin;
+                float v = fmaf(x0v[r], lin, xv[r]);
+                if (RELU) v = fmaxf(v, 0.f);
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(out + row * out_ld) + lo_o) = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int nrx_dcn_v2_layer_fwd(const float* x0, const float* xl, int64_t ld, int64_t batch, int32_t dim,
@@ -230,6 +390,8 @@ extern "C" int nrx_dcn_v2_layer_fwd(const float* x0, const float* xl, int64_t ld
                 "nrx_dcn_v2_layer_fwd: bad argument");
     NRX_REQUIRE(out != xl && out != x0, "nrx_dcn_v2_layer_fwd: out must not alias the inputs");
     if (batch == 0) return NRX_OK;
+    const bool split = (relu & 2) != 0;       // flags: bit 0 = ReLU, bit 1 = split-bf16 math (see dcn_v2_layer_bf16x3_kernel)
+    relu &= 1;
     const bool vec = (ld & 3) == 0 && (dim & 3) == 0 && nrx_aligned16(xl) && nrx_aligned16(W);
     const unsigned nx = (unsigned)((dim + BN - 1) / BN);
     const int64_t nblocks = (int64_t)nx * ((batch + BM - 1) / BM);
@@ -237,6 +399,10 @@ extern "C" int nrx_dcn_v2_layer_fwd(const float* x0, const float* xl, int64_t ld
     dim3 grid((unsigned)nblocks);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define NRX_DCN2(R_, V_) hipLaunchKernelGGL((dcn_v2_layer_kernel<R_, V_>), grid, dim3(256), 0, st, x0, xl, ld, batch, dim, W, bias, out, out_ld, nx, lin_out)
+    if (split && vec && batch >= 8) {        // (unaligned shapes and tiny batches take the fp32 kernel: more exact, never wrong)
+        if (relu) hipLaunchKernelGGL((dcn_v2_layer_bf16x3_kernel<true>), grid, dim3(256), 0, st, x0, xl, ld, batch, dim, W, bias, out, out_ld, nx, lin_out);
+        else hipLaunchKernelGGL((dcn_v2_layer_bf16x3_kernel<false>), grid, dim3(256), 0, st, x0, xl, ld, batch, dim, W, bias, out, out_ld, nx, lin_out);
+    } else
     if (relu) { if (vec) NRX_DCN2(true, true); else NRX_DCN2(true, false); }
     else      { if (vec) NRX_DCN2(false, true); else NRX_DCN2(false, false); }
 #undef NRX_DCN2

@@ -122,6 +122,64 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v2_bwd_prep_kernel(const float*
     }
 }
 
+// Epilogue of a block tile, shared by the fp32 and the split-bf16 GEMM kernels (same accumulator layout: col = lane & 31,
+// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).
+template <int MODE, int TM>
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM], int64_t m0, int n0, int wm, int wn, int l31, int hi, int64_t M, int N,
+                                              const float* __restrict__ addend, int64_t add_ld, const uint32_t* __restrict__ maskT,
+                                              int64_t mask_ld, float* __restrict__ out, int64_t out_ld, const float* __restrict__ add2,
+                                              int64_t add2_ld) {
+    const int col = n0 + wn * 32 + l31;
+    if (col >= N) return;
+    const int64_t r0 = m0 + wm * (32 * TM);
+    if (MODE == DGRAD && r0 + 32 * TM <= M) {
+        // full tile: a wave-uniform row pointer (scalar unit) + one fixed per-lane byte offset per array, the loads of a
+        // 32-row sub-tile batched ahead of the arithmetic (as the forward's epilogue; per-element 64-bit address arithmetic and
+        // load -> use chains made this epilogue the difference between 186 us here and 155 us for the forward)
+        const uint32_t lo_a = (uint32_t)(((int64_t)(4 * hi) * add_ld + col) * 4);
+        const uint32_t lo_2 = (uint32_t)(((int64_t)(4 * hi) * add2_ld + col) * 4);
+        const uint32_t lo_o = (uint32_t)(((int64_t)(4 * hi) * out_ld + col) * 4);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            float gv[16], av[16];
+            // the ReLU mask of this lane's column over the tile's 32 rows: bit (r & 3) + 8 (r >> 2) + 4 hi is row r's
+            const uint32_t mw = (maskT != nullptr ? maskT[((r0 + t * 32) >> 5) * mask_ld + col] : 0xffffffffu) >> (4 * hi);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2);          // + 4 * hi, folded into the lane offsets
+                gv[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(addend + row * add_ld) + lo_a);
+                av[r] = add2 != nullptr ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(add2 + row * add2_ld) + lo_2) : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2);
+                float v = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u ? gv[r] : 0.f) + acc[t][r];
+                if (add2 != nullptr) v += av[r];
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(out + row * out_ld) + lo_o) = v;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (row < M) {
+                if (MODE == DGRAD) {        // g_xl = gm + glin W, gm = g (x) [forward output > 0] rebuilt here
+                    float gmv = addend[row * add_ld + col];
+                    if (maskT != nullptr && !((maskT[(row >> 5) * mask_ld + col] >> (row & 31)) & 1u)) gmv = 0.f;
+                    float v = gmv + acc[t][r];
+                    if (add2 != nullptr) v += add2[row * add2_ld + col];      // layer 0 (x0 is x_l): dL/dx = g_xl + g_x0 in one pass
+                    out[row * out_ld + col] = v;
+                } else {
+                    unsafeAtomicAdd(out + row * out_ld + col, acc[t][r]);
+                }
+            }
+        }
+    }
+}
+
 // ---- the GEMM ----------------------------------------------------------------------------------------------------
 // C[m, n] = sum_k A(m, k) B(k, n) over k in [kbeg, kend).
 //   DGRAD: A(m, k) = glin[m * lda + k]   (M-major rows, transposed into LDS like the forward's x slab)
@@ -336,55 +394,152 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
             unsafeAtomicAdd(colsum + m0 + tid, t);
         }
     }
-    const int col = n0 + wn * 32 + l31;
-    if (col >= N) return;
-    const int64_t r0 = m0 + wm * (32 * TM);
-    if (MODE == DGRAD && r0 + 32 * TM <= M) {
-        // full tile: a wave-uniform row pointer (scalar unit) + one fixed per-lane byte offset per array, the loads of a
-        // 32-row sub-tile batched ahead of the arithmetic (as the forward's epilogue; per-element 64-bit address arithmetic and
-        // load -> use chains made this epilogue the difference between 186 us here and 155 us for the forward)
-        const uint32_t lo_a = (uint32_t)(((int64_t)(4 * hi) * add_ld + col) * 4);
-        const uint32_t lo_2 = (uint32_t)(((int64_t)(4 * hi) * add2_ld + col) * 4);
-        const uint32_t lo_o = (uint32_t)(((int64_t)(4 * hi) * out_ld + col) * 4);
+    gemm_epilogue<MODE, TM>(acc, m0, n0, wm, wn, l31, hi, M, N, addend, add_ld, maskT, mask_ld, out, out_ld, add2, add2_ld);
+}
+
+// ---- the GEMM in split-bf16 math (flags bit 1; see dcn_v2_layer_bf16x3_kernel in nrx_dcn2.hip) ----------------------------------
+// Same tiles, same epilogue; operands as bf16 hi / lo parts, [row][k] in LDS with 80-byte rows, three v_mfma_f32_32x32x16_bf16 per
+// fragment pair.  A bf16 fragment is 8 CONSECUTIVE k of one row.  The M-major operand (dgrad's glin) has them contiguous in memory
+// (float4 loads, as the forward's x).  A K-major operand (W in dgrad; glin and x_l in wgrad: a memory row is one k) does not: there a
+// lane owns ONE output row / column and fetches its 8 k as 8 dword loads -- 64 lanes = 64 consecutive floats of each memory row,
+// still coalesced -- splits them and writes its fragment with one ds_write_b128 per part (a transposing LDS write of 2-byte
+// elements would be 8 conflicting ds_write_b16 per float4).
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+typedef __bf16 nrx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float nrx_f32x2 __attribute__((ext_vector_type(2)));
+constexpr int LDH = 40;      // halfs per LDS row (32 k + 16 bytes of padding: conflict-free ds_read_b128 / ds_write_b128)
+
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const nrx_f32x2 v = {a, b};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, nrx_bf16x2));
+    const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+    const nrx_f32x2 r = {a - ha, b - hb};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, nrx_bf16x2));
+}
+
+// the K-major operand's staging: `pairs` (row, k-octet) fragments per thread; fragment i of thread tid: row = (tid + 256 i) % ROWS,
+// octet = (tid + 256 i) / ROWS.  src(k, row) = base[k * ld + row0 + row]; rows past `nrows` are clamped, k past kend zeroed.
+template <int ROWS>
+struct KMajorStage {
+    static constexpr int PAIRS = ROWS * 4 / 256;          // 32 k = 4 octets per row
+    float v[PAIRS][8];
+    __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, int64_t kend, int tid) {
 #pragma unroll
-        for (int t = 0; t < TM; ++t) {
-            float gv[16], av[16];
-            // the ReLU mask of this lane's column over the tile's 32 rows: bit (r & 3) + 8 (r >> 2) + 4 hi is row r's
-            const uint32_t mw = (maskT != nullptr ? maskT[((r0 + t * 32) >> 5) * mask_ld + col] : 0xffffffffu) >> (4 * hi);
+        for (int i = 0; i < PAIRS; ++i) {
+            const int f = tid + 256 * i, row = f % ROWS, oct = f / ROWS;
+            int64_t r = row0 + row;
+            r = r < nrows ? r : nrows - 1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2);          // + 4 * hi, folded into the lane offsets
-                gv[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(addend + row * add_ld) + lo_a);
-                av[r] = add2 != nullptr ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(add2 + row * add2_ld) + lo_2) : 0.0f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2);
-                float v = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u ? gv[r] : 0.f) + acc[t][r];
-                if (add2 != nullptr) v += av[r];
-                *reinterpret_cast<float*>(reinterpret_cast<char*>(out + row * out_ld) + lo_o) = v;
+            for (int j = 0; j < 8; ++j) {
+                const int64_t k = k0 + 8 * oct + j;
+                const float t = base[(k < kend ? k : kend - 1) * ld + r];
+                v[i][j] = k < kend ? t : 0.f;
             }
         }
-        return;
     }
+    __device__ __forceinline__ void store(unsigned short* __restrict__ sh, unsigned short* __restrict__ sl, int tid) const {
 #pragma unroll
-    for (int t = 0; t < TM; ++t) {
+        for (int i = 0; i < PAIRS; ++i) {
+            const int f = tid + 256 * i, row = f % ROWS, oct = f / ROWS;
+            uint4 h, l;
+            split2(v[i][0], v[i][1], h.x, l.x);
+            split2(v[i][2], v[i][3], h.y, l.y);
+            split2(v[i][4], v[i][5], h.z, l.z);
+            split2(v[i][6], v[i][7], h.w, l.w);
+            *reinterpret_cast<uint4*>(&sh[row * LDH + 8 * oct]) = h;
+            *reinterpret_cast<uint4*>(&sl[row * LDH + 8 * oct]) = l;
+        }
+    }
+};
+
+template <int MODE, int TMv = 2>
+__global__ __launch_bounds__(256, 4) void dcn2_gemm_split_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                               int64_t M, int N, int64_t K, int64_t kslice, const float* __restrict__ addend,
+                                                               int64_t add_ld, const uint32_t* __restrict__ maskT, int64_t mask_ld,
+                                                               float* __restrict__ out, int64_t out_ld, unsigned nx, unsigned ntiles,
+                                                               const float* __restrict__ add2, int64_t add2_ld) {
+    constexpr int TM = TMv, BM = 2 * TM * 32;
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[BM * LDH], Al[BM * LDH], Wh[BN * LDH], Wl[BN * LDH];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const unsigned tile_lin = blockIdx.x % ntiles, ks = blockIdx.x / ntiles;
+    const unsigned xcd = tile_lin & 7u, qd = ntiles >> 3, rm = ntiles & 7u;
+    const unsigned logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (tile_lin >> 3);
+    const int64_t m0 = (int64_t)(logical / nx) * BM;
+    const int n0 = (int)(logical % nx) * BN;
+    const int64_t kbeg = (int64_t)ks * kslice;
+    const int64_t kend = kbeg + kslice < K ? kbeg + kslice : K;
+
+    f32x16 acc[TM];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (row < M) {
-                if (MODE == DGRAD) {        // g_xl = gm + glin W, gm = g (x) [forward output > 0] rebuilt here
-                    float gmv = addend[row * add_ld + col];
-                    if (maskT != nullptr && !((maskT[(row >> 5) * mask_ld + col] >> (row & 31)) & 1u)) gmv = 0.f;
-                    float v = gmv + acc[t][r];
-                    if (add2 != nullptr) v += add2[row * add2_ld + col];      // layer 0 (x0 is x_l): dL/dx = g_xl + g_x0 in one pass
-                    out[row * out_ld + col] = v;
-                } else {
-                    unsafeAtomicAdd(out + row * out_ld + col, acc[t][r]);
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    // staging registers: DGRAD A is M-major (float4 along k, as the forward's x); everything else K-major
+    constexpr int AP = BM / 32;
+    float4 a4[MODE == DGRAD ? AP : 1];
+    KMajorStage<BM> ak;
+    KMajorStage<BN> bk;
+    const int srow = tid >> 3, skq = (tid & 7) * 4;
+    auto load_slab = [&](int64_t k0) {
+        if (MODE == DGRAD) {
+#pragma unroll
+            for (int p = 0; p < AP; ++p) {
+                int64_t r = m0 + srow + 32 * p;
+                r = r < M ? r : M - 1;
+                const int64_t k = k0 + skq;                      // K % 4 == 0 (aligned shapes only): a float4 is all-in or all-out
+                const float4 t = *reinterpret_cast<const float4*>(A + r * lda + (k + 4 <= kend ? k : kbeg));
+                a4[p] = k + 4 <= kend ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            ak.load(A, lda, m0, M, k0, kend, tid);
+        }
+        bk.load(B, ldb, n0, N, k0, kend, tid);
+    };
+    if (kbeg < kend) load_slab(kbeg);
+    const bool wave_live = m0 + wm * (32 * TM) < M && n0 + wn * 32 < N;
+
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+        if (MODE == DGRAD) {
+#pragma unroll
+            for (int p = 0; p < AP; ++p) {
+                uint2 h, l;
+                split2(a4[p].x, a4[p].y, h.x, l.x);
+                split2(a4[p].z, a4[p].w, h.y, l.y);
+                *reinterpret_cast<uint2*>(&Ah[(srow + 32 * p) * LDH + skq]) = h;
+                *reinterpret_cast<uint2*>(&Al[(srow + 32 * p) * LDH + skq]) = l;
+            }
+        } else {
+            ak.store(Ah, Al, tid);
+        }
+        bk.store(Wh, Wl, tid);
+        __syncthreads();
+        if (k0 + BK < kend) load_slab(k0 + BK);
+        if (wave_live) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (s2 == 1 && k0 + 16 >= kend) break;
+                const int ko = s2 * 16 + 8 * hi;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Wh[(wn * 32 + l31) * LDH + ko]);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Wl[(wn * 32 + l31) * LDH + ko]);
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
+                    const int row = wm * (32 * TM) + 32 * t + l31;
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ah[row * LDH + ko]);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Al[row * LDH + ko]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
                 }
             }
         }
+        __syncthreads();
     }
+    gemm_epilogue<MODE, TM>(acc, m0, n0, wm, wn, l31, hi, M, N, addend, add_ld, maskT, mask_ld, out, out_ld, add2, add2_ld);
 }
 
 // out[M, N] += A^T B over the batch (A [batch, M], B [batch, N], both K-major), split into batch slices; out pre-zeroed.
@@ -393,7 +548,8 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
 // it the 128 x 64 tile (less LDS traffic per MFMA: D = 512 280 vs 298 us).  ~1 536 (64 x 64) / ~1 024 (128 x 64) blocks, but never
 // slices shorter than 512 / 256 batch rows (256 for a single tile): with few tiles the atomics of a short slice cost more than the
 // blocks it adds.  NRX_WGRAD_TILE / NRX_WGRAD_BLOCKS / NRX_WGRAD_MIN_ROWS override the choice (tools/run_wgrad_sweep.sh).
-void launch_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int64_t batch, float* out, float* colsum, bool vec, hipStream_t st) {
+void launch_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int64_t batch, float* out, float* colsum, bool vec, hipStream_t st,
+                  bool split = false) {
     static const int env_tile = getenv("NRX_WGRAD_TILE") ? atoi(getenv("NRX_WGRAD_TILE")) : 0;            // tuning: 64 | 128
     static const int env_blocks = getenv("NRX_WGRAD_BLOCKS") ? atoi(getenv("NRX_WGRAD_BLOCKS")) : 0;      // tuning: target block count
     static const int env_rows = getenv("NRX_WGRAD_MIN_ROWS") ? atoi(getenv("NRX_WGRAD_MIN_ROWS")) : 0;    // tuning: shortest batch slice
@@ -411,6 +567,12 @@ void launch_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, int 
     hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, VEC_, TM_>), grid, dim3(256), 0, st, A, lda, B, ldb, (int64_t)M, N, batch, kslice,     \
                        (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, out, (int64_t)N, nx, nt,              \
                        (const float*)nullptr, (int64_t)0, colsum)
+    if (split && vec && colsum == nullptr) {
+        if (small) hipLaunchKernelGGL((dcn2_gemm_split_kernel<WGRAD, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, (int64_t)M, N, batch, kslice,
+                                      (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, out, (int64_t)N, nx, nt, (const float*)nullptr, (int64_t)0);
+        else hipLaunchKernelGGL((dcn2_gemm_split_kernel<WGRAD, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, (int64_t)M, N, batch, kslice,
+                                (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, out, (int64_t)N, nx, nt, (const float*)nullptr, (int64_t)0);
+    } else
     if (small) { if (vec) NRX_WGRAD(true, 1); else NRX_WGRAD(false, 1); }
     else       { if (vec) NRX_WGRAD(true, 2); else NRX_WGRAD(false, 2); }
 #undef NRX_WGRAD
@@ -430,6 +592,8 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
                                     float* g_W, float* g_b, void* workspace, void* stream) {
     NRX_REQUIRE(x0 && xl && lin && W && g_out && g_xl && g_x0 && g_W && g_b && workspace && batch >= 0 && dim >= 1 && ld >= dim,
                 "nrx_dcn_v2_layer_bwd: bad argument");
+    const bool split = (relu & 2) != 0;        // flags as in nrx_dcn_v2_layer_fwd: bit 0 = ReLU, bit 1 = split-bf16 matrix math
+    relu &= 1;
     NRX_REQUIRE(!relu || out != nullptr, "nrx_dcn_v2_layer_bwd: the ReLU mask needs the layer's forward output");
     NRX_REQUIRE(g_ld >= dim && gxl_ld >= dim && gx0_ld >= dim, "nrx_dcn_v2_layer_bwd: bad leading dimension");
     NRX_REQUIRE(g_xl != g_out, "nrx_dcn_v2_layer_bwd: g_xl must not alias g_out");
@@ -467,13 +631,16 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
         const unsigned nx = (unsigned)((dim + BN - 1) / BN);
         const int64_t nt = (int64_t)nx * ((batch + BM - 1) / BM);
         NRX_REQUIRE(nt <= 0x7fffffffLL, "nrx_dcn_v2_layer_bwd: batch too large for one launch");
-        if (vec) hipLaunchKernelGGL((dcn2_gemm_kernel<DGRAD, true>), dim3((unsigned)nt), dim3(256), 0, st, glin, wld, W, (int64_t)dim, batch,
+        if (vec && split && batch >= 8)
+            hipLaunchKernelGGL((dcn2_gemm_split_kernel<DGRAD>), dim3((unsigned)nt), dim3(256), 0, st, glin, wld, W, (int64_t)dim, batch,
+                               dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, wld, g_xl, gxl_ld, nx, (unsigned)nt, fold, gx0_ld);
+        else if (vec) hipLaunchKernelGGL((dcn2_gemm_kernel<DGRAD, true>), dim3((unsigned)nt), dim3(256), 0, st, glin, wld, W, (int64_t)dim, batch,
                                     dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, wld, g_xl, gxl_ld, nx, (unsigned)nt, fold, gx0_ld, (float*)nullptr);
         else hipLaunchKernelGGL((dcn2_gemm_kernel<DGRAD, false>), dim3((unsigned)nt), dim3(256), 0, st, glin, wld, W, (int64_t)dim, batch,
                                 dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, wld, g_xl, gxl_ld, nx, (unsigned)nt, fold, gx0_ld, (float*)nullptr);
     }
     // wgrad: g_W[i, j] += sum_b glin[b, i] xl[b, j]   (M = N = dim, K = batch, split over the batch)
-    launch_wgrad(glin, wld, xl, ld, dim, dim, batch, g_W, nullptr, vec, st);
+    launch_wgrad(glin, wld, xl, ld, dim, dim, batch, g_W, nullptr, vec, st, split && batch >= 8);
     NRX_LAUNCH_CHECK("nrx_dcn_v2_layer_bwd");
     return NRX_OK;
 }

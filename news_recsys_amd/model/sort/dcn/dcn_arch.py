@@ -58,18 +58,18 @@ class DCNNet(nn.Module):
 
 
 class DCNv2Net(nn.Module):
-    def __init__(self, input_dim, num_layers=3):
+    def __init__(self, input_dim, num_layers=3, math="fp32"):
         super().__init__()
         layers = []
         for _ in range(num_layers):
             layers.append(DCNv2Layer(input_dim))
             layers.append(nn.ReLU())
         self.cross_net = nn.ModuleList(layers)
+        self.math = math            # "fp32" (default, exact fp32 fma chain) | "bf16x3" (split-bf16 matrix math, dcn_cfg.math)
 
     def forward(self, x):
         lins = [l.linear for l in self.cross_net if isinstance(l, DCNv2Layer)]
         if not lins:
             return x
-        W = torch.stack([l.weight for l in lins])
-        b = torch.stack([l.bias for l in lins])
-        return ops.dcn_v2(x, W, b, relu=True)
+        # the layers' own parameter tensors go to the kernels as they are: no torch.stack (two kernels + autograd nodes per step)
+        return ops.dcn_v2(x, [l.weight for l in lins], [l.bias for l in lins], relu=True, math=self.math)

@@ -1,7 +1,8 @@
 """DCN ranker: sigmoid(MLP(cat[x, cross(x)])).  Reference: src/model/sort/dcn/model.py
 (DCNModel :15-29, DCN :31-76).  The reference hard-codes 3 v1 cross layers (:36); optional config
-keys `dcn_cfg.cross_num_layers` and `dcn_cfg.version` (1 = reference behaviour, 2 = DCNv2Net, which
-the reference defines but never instantiates) are accepted, defaulting to the reference.
+keys `dcn_cfg.cross_num_layers`, `dcn_cfg.version` (1 = reference behaviour, 2 = DCNv2Net, which
+the reference defines but never instantiates) and, for version 2, `dcn_cfg.math` (fp32 | bf16x3) are accepted, defaulting to the
+reference.
 
 forward(batch) writes the concat straight into the left half of a [B, 2D] buffer and the cross
 output into its right half, so the reference's torch.cat([x, cross]) costs no extra pass."""
@@ -13,12 +14,14 @@ from .dcn_arch import DCNNet, DCNv2Net, DCNLayer, DCNv2Layer  # noqa: F401  (re-
 
 
 class DCNModel(torch.nn.Module):
-    def __init__(self, input_dim, cross_num_layers=3, deep_hidden_dims=(32, 32, 1), version=1):
+    def __init__(self, input_dim, cross_num_layers=3, deep_hidden_dims=(32, 32, 1), version=1, math="fp32"):
         super().__init__()
         self.input_dim = input_dim
         self.version = version
-        net = DCNNet if version == 1 else DCNv2Net
-        self.cross_net = net(input_dim=input_dim, num_layers=cross_num_layers)
+        if version == 1:
+            self.cross_net = DCNNet(input_dim=input_dim, num_layers=cross_num_layers)
+        else:
+            self.cross_net = DCNv2Net(input_dim=input_dim, num_layers=cross_num_layers, math=math)
         self.score_fc = MLP(dims=[input_dim * 2] + list(deep_hidden_dims))
 
     def forward(self, x):
@@ -41,7 +44,8 @@ class DCN(BaseModel):
         self.fuse_gather_cross = "auto" if str(fz).lower() == "auto" else bool(fz)
         self.score_fc = DCNModel(input_dim=self.user_input_dim + self.item_input_dim,
                                  cross_num_layers=int(cfg.get("cross_num_layers", 3)),
-                                 deep_hidden_dims=[128, 128, 128, 64, 1], version=int(cfg.get("version", 1)))
+                                 deep_hidden_dims=[128, 128, 128, 64, 1], version=int(cfg.get("version", 1)),
+                                 math=str(cfg.get("math", "fp32")))      # v2 only: fp32 (exact fma chain) | bf16x3 (split-bf16 MFMA)
 
     def get_inp_embedding(self, batch):
         features, _, _ = self.get_embeddings_from_batch(batch, self.user_feature_names | self.item_feature_names)

@@ -1161,7 +1161,7 @@ def embed_dcn_v1(plan: EmbedPlan, tables, inputs, w: torch.Tensor, b: torch.Tens
 
 
 # ------------------------------------------------------------------------------- DCN v2 (MFMA)
-def _dcn_v2_layer_backward(lib, x0, xl, lin, out, relu, W, g, g_x0, accumulate, gW=None, gb=None):
+def _dcn_v2_layer_backward(lib, x0, xl, lin, out, relu, W, g, g_x0, accumulate, gW=None, gb=None, math="fp32"):
     """One layer of the hand-written backward (nrx_dcn_v2_layer_bwd: elementwise prep + MFMA dgrad + MFMA wgrad).
     Returns (g_xl, g_W, g_b); g_x0 is written (accumulate bit 0 clear) or accumulated (set) in place, and folded into g_xl when bit 1 is set.
     `gW` / `gb`: contiguous destinations (a layer's slice of the stack's gradient tensors) written in place of fresh tensors."""
@@ -1173,61 +1173,73 @@ def _dcn_v2_layer_backward(lib, x0, xl, lin, out, relu, W, g, g_x0, accumulate, 
     if gb is None:
         gb = torch.empty((D,), dtype=torch.float32, device=xl.device)
     ws = torch.empty(max(1, lib.nrx_dcn_v2_layer_bwd_workspace(B, D)), dtype=torch.uint8, device=xl.device)
-    check(lib.nrx_dcn_v2_layer_bwd(x0.data_ptr(), xl.data_ptr(), D, lin.data_ptr(), _ptr(out), 1 if relu else 0, B, D, W.data_ptr(),
+    check(lib.nrx_dcn_v2_layer_bwd(x0.data_ptr(), xl.data_ptr(), D, lin.data_ptr(), _ptr(out), _dcn2_flags(relu, math), B, D, W.data_ptr(),
                                    g.data_ptr(), D, g_xl.data_ptr(), D, g_x0.data_ptr(), D, int(accumulate), gW.data_ptr(),
                                    gb.data_ptr(), ws.data_ptr(), _stream_ptr(xl)), "nrx_dcn_v2_layer_bwd")
     return g_xl, gW, gb
 
 
+DCN2_MATH = ("fp32", "bf16x3")
+
+
+def _dcn2_flags(relu: bool, math: str) -> int:
+    if math not in DCN2_MATH:
+        raise ValueError(f"dcn_v2 math must be one of {DCN2_MATH}")
+    return (1 if relu else 0) | (2 if math == "bf16x3" else 0)
+
+
 class _DcnV2Fn(torch.autograd.Function):
+    """The whole cross stack.  The per-layer parameters arrive as SEPARATE tensors (W_0 .. W_{n-1}, b_0 .. b_{n-1}: the modules'
+    own nn.Linear weights) -- no torch.stack per call, no stacked gradient to un-stack."""
+
     @staticmethod
-    def forward(ctx, x, W, b, relu):
+    def forward(ctx, x, relu, math, n, *params):
         lib = _lib.load()
         x = _f32c(x, "x")
-        W = _f32c(W, "W")
-        b = _f32c(b, "b")
         B, D = x.shape
-        n = W.shape[0]
-        if tuple(W.shape) != (n, D, D) or tuple(b.shape) != (n, D):
-            raise ValueError("W must be [n_layers, dim, dim] and b [n_layers, dim]")
-        train = any(ctx.needs_input_grad[:3])       # (grad mode is off inside forward: ask the node, not torch.is_grad_enabled)
+        Ws = [_f32c(w, "W") for w in params[:n]]
+        bs = [_f32c(v, "b") for v in params[n:]]
+        if len(bs) != n or any(tuple(w.shape) != (D, D) for w in Ws) or any(tuple(v.shape) != (D,) for v in bs):
+            raise ValueError("dcn_v2: every layer needs W [dim, dim] and b [dim]")
+        train = any(ctx.needs_input_grad)       # (grad mode is off inside forward: ask the node, not torch.is_grad_enabled)
+        flags = _dcn2_flags(relu, math)
         xs, lins = [x], []
         stream = _stream_ptr(x)
         for l in range(n):
             out = torch.empty_like(x)
             lin = torch.empty_like(x) if train else None      # x_l W^T + b, saved for the backward (one extra write, no GEMM later)
-            check(lib.nrx_dcn_v2_layer_fwd(x.data_ptr(), xs[-1].data_ptr(), D, B, D, W[l].data_ptr(), b[l].data_ptr(),
-                                           1 if relu else 0, out.data_ptr(), D, _ptr(lin), stream), "nrx_dcn_v2_layer_fwd")
+            check(lib.nrx_dcn_v2_layer_fwd(x.data_ptr(), xs[-1].data_ptr(), D, B, D, Ws[l].data_ptr(), bs[l].data_ptr(),
+                                           flags, out.data_ptr(), D, _ptr(lin), stream), "nrx_dcn_v2_layer_fwd")
             xs.append(out)
             lins.append(lin)
-        ctx.save_for_backward(W, *xs, *[t for t in lins if t is not None])
-        ctx.relu, ctx.n, ctx.train = relu, n, train
+        ctx.save_for_backward(*Ws, *xs, *[t for t in lins if t is not None])
+        ctx.relu, ctx.n, ctx.train, ctx.math = relu, n, train, math
         return xs[-1]
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
         n = ctx.n
-        W, *rest = ctx.saved_tensors
-        xs, lins = rest[:n + 1], rest[n + 1:]
+        saved = ctx.saved_tensors
+        Ws, xs, lins = saved[:n], saved[n:2 * n + 1], saved[2 * n + 1:]
         if len(lins) != n:
             raise RuntimeError("dcn_v2 backward: the forward ran without gradients enabled")
         x0 = xs[0]
         gx0 = torch.empty_like(x0)
-        gW = torch.empty_like(W)
-        gb = torch.empty((n, W.shape[1]), dtype=torch.float32, device=W.device)
         g = g.contiguous()
+        gWs, gbs = [None] * n, [None] * n
         for l in reversed(range(n)):
             # accumulate bit 0: layers before the last add to g_x0 (the last one writes it); bit 1: layer 0 folds the total into
             # its g_xl (x_0 IS the stack's input there): no separate `g + gx0` pass over [B, D]
             acc = (0 if l == n - 1 else 1) | (2 if l == 0 else 0)
-            g, _, _ = _dcn_v2_layer_backward(lib, x0, xs[l], lins[l], xs[l + 1], ctx.relu, W[l], g, gx0, accumulate=acc, gW=gW[l], gb=gb[l])
-        return g, gW, gb, None
+            g, gWs[l], gbs[l] = _dcn_v2_layer_backward(lib, x0, xs[l], lins[l], xs[l + 1], ctx.relu, Ws[l], g, gx0, accumulate=acc,
+                                                       math=ctx.math)
+        return (g, None, None, None, *gWs, *gbs)
 
 
 class _DcnV2LayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, xl, W, b, relu):
+    def forward(ctx, x0, xl, W, b, relu, math="fp32"):
         lib = _lib.load()
         x0, xl, W, b = _f32c(x0, "x0"), _f32c(xl, "xl"), _f32c(W, "W"), _f32c(b, "b")
         B, D = xl.shape
@@ -1237,9 +1249,9 @@ class _DcnV2LayerFn(torch.autograd.Function):
         train = any(ctx.needs_input_grad[:4])
         lin = torch.empty_like(xl) if train else None
         check(lib.nrx_dcn_v2_layer_fwd(x0.data_ptr(), xl.data_ptr(), D, B, D, W.data_ptr(), b.data_ptr(),
-                                       1 if relu else 0, out.data_ptr(), D, _ptr(lin), _stream_ptr(xl)), "nrx_dcn_v2_layer_fwd")
+                                       _dcn2_flags(relu, math), out.data_ptr(), D, _ptr(lin), _stream_ptr(xl)), "nrx_dcn_v2_layer_fwd")
         ctx.save_for_backward(x0, xl, W, out, *((lin,) if train else ()))
-        ctx.relu = relu
+        ctx.relu, ctx.math = relu, math
         return out
 
     @staticmethod
@@ -1249,18 +1261,28 @@ class _DcnV2LayerFn(torch.autograd.Function):
         if not rest:
             raise RuntimeError("dcn_v2_layer backward: the forward ran without gradients enabled")
         gx0 = torch.empty_like(x0)
-        g_xl, gW, gb = _dcn_v2_layer_backward(lib, x0, xl, rest[0], out, ctx.relu, W, g, gx0, accumulate=False)
-        return gx0, g_xl, gW, gb, None
+        g_xl, gW, gb = _dcn_v2_layer_backward(lib, x0, xl, rest[0], out, ctx.relu, W, g, gx0, accumulate=False, math=ctx.math)
+        return gx0, g_xl, gW, gb, None, None
 
 
-def dcn_v2_layer(x0: torch.Tensor, xl: torch.Tensor, W: torch.Tensor, b: torch.Tensor, relu: bool = False) -> torch.Tensor:
-    """One DCNv2Layer (dcn_arch.py:39-50): act(x0 * (xl W^T + b) + xl) on MFMA."""
-    return _DcnV2LayerFn.apply(x0, xl, W, b, relu)
+def dcn_v2_layer(x0: torch.Tensor, xl: torch.Tensor, W: torch.Tensor, b: torch.Tensor, relu: bool = False, math: str = "fp32") -> torch.Tensor:
+    """One DCNv2Layer (dcn_arch.py:39-50): act(x0 * (xl W^T + b) + xl) on MFMA.  math: "fp32" (default: the fp32 fma chain, value-
+    exact against the C oracle) or "bf16x3" (each operand split into two bfloat16 parts, three bf16 MFMAs, fp32 accumulate)."""
+    return _DcnV2LayerFn.apply(x0, xl, W, b, relu, math)
 
 
-def dcn_v2(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, relu: bool = True) -> torch.Tensor:
-    """DCNv2Net.forward (dcn_arch.py:83-91): x <- relu(x0 * (x W_l^T + b_l) + x) per layer, on MFMA."""
-    return _DcnV2Fn.apply(x, W, b, relu)
+def dcn_v2(x: torch.Tensor, W, b, relu: bool = True, math: str = "fp32") -> torch.Tensor:
+    """DCNv2Net.forward (dcn_arch.py:83-91): x <- relu(x0 * (x W_l^T + b_l) + x) per layer, on MFMA.
+    W / b: stacked tensors [n, dim, dim] / [n, dim], or sequences of the per-layer tensors (what the module passes: no stack)."""
+    Ws = list(W.unbind(0)) if isinstance(W, torch.Tensor) else list(W)
+    bs = list(b.unbind(0)) if isinstance(b, torch.Tensor) else list(b)
+    if len(Ws) != len(bs):
+        raise ValueError("W must be [n_layers, dim, dim] and b [n_layers, dim]")
+    if isinstance(W, torch.Tensor) and (W.dim() != 3 or W.shape[1] != W.shape[2] or tuple(b.shape) != tuple(W.shape[:2])):
+        raise ValueError("W must be [n_layers, dim, dim] and b [n_layers, dim]")
+    if not Ws:
+        return x
+    return _DcnV2Fn.apply(x, relu, math, len(Ws), *Ws, *bs)
 
 
 # ------------------------------------------------------------------------------- integer utilities
