@@ -427,6 +427,93 @@ class SingleGpuPath:
         return res
 
 
+# ------------------------------------------------------------------------------------ module path (the drop-in surface)
+def module_path_leg(path: "SingleGpuPath", prepared_fb_ms, steps: int):
+    """The same C2 work through the DROP-IN surface (what a user of the reference touches): the package's FM model class built from a
+    train_cf_fm.yaml-shaped config with the bench's 26 x 1M x 16 tables -- FM.get_embeddings_from_batch / FM.forward(batch) on an input
+    dict (src/model/BaseModel/base_model.py:284-308, src/model/sort/fm/model.py:48-59), eager, index check deferred, through
+    torch.autograd with the fused row-sparse backward (embeddings.sparse_grad: fused).  Reported next to the bound (PreparedEmbed) path the
+    headline times: GPU time per step from HIP events, host time per call from the wall clock of back-to-back un-synchronised calls."""
+    import tempfile
+    import yaml
+    from news_recsys_amd import ops
+    from news_recsys_amd.model.sort.fm.model import FM
+    dev = path.device
+    names = [f["name"] for f in path.feats]
+    D, rows = path.feats[0]["dim"], path.feats[0]["rows"]
+    cfg = {"name": "fm", "paths": {"out_basedir": tempfile.gettempdir(), "user_history_path": ""},
+           "features": {"sparse_feature_names": names, "dense_feature_names": [], "array_feature_names": [], "item_feature_names": names[:13],
+                        "user_feature_names": names[13:], "array_max_length": {}},
+           "embeddings": {"embedding_size": {n: D for n in names}, "embedding_table_size": {n: rows for n in names}, "share_emb_table_features": {},
+                          "sparse_grad": "fused"},
+           "dataset": {"batch_size": BATCH, "num_workers": 0, "pin_memory": False},
+           "train_hparams": {"val_freq": 1, "max_epoch": 1, "lr": 1e-3, "min_lr": 5e-6, "lr_milestones": [4, 20], "max_step": 30, "device": "gpu", "gpus": [0]}}
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        yaml.safe_dump(cfg, f)
+    with torch.device(dev):
+        model = FM(f.name)
+    model = model.to(dev)
+    for n, t in zip(names, path.tables):                     # the bench's own tables: no second 1.66 GB of parameters
+        model.embedding_tables[n].weight.data = t
+    os.unlink(f.name)
+    fn = model.user_feature_names | model.item_feature_names
+    out = {"model": "news_recsys_amd.model.sort.fm.model.FM from a train_cf_fm.yaml-shaped config (26 sparse x 1M x 16), input dict of int64 [B] ids, "
+                    "eager, index check deferred, embeddings.sparse_grad: fused",
+           "binding": "compiled (csrc/nrx_bind.cpp)" if ops._binding() is not None else "ctypes"}
+
+    def timed(fn_, n, sync_each=False):
+        for _ in range(5):
+            fn_()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        a.record()
+        for _ in range(n):
+            fn_()
+        b.record()
+        host = (time.perf_counter() - t0) / n
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n, host * 1e3
+
+    for B in (BATCH, 512):
+        batches = [{nm: x[:B] if B == BATCH else x[:B].clone() for nm, x in zip(names, ins)} for ins, _ in path.pool[:2]]
+        it = {"i": 0}
+
+        def fwd_nograd():
+            it["i"] += 1
+            with torch.no_grad():
+                model.get_embeddings_from_batch(batches[it["i"] & 1], fn)
+
+        def fwd_bwd():
+            it["i"] += 1
+            p = model(batches[it["i"] & 1])                   # sigmoid(bias + FM logit): gather + FM epilogue, autograd node
+            p.sum().backward()                                # -> FM gradient folded into the row-sparse backward, results in the sink
+            if model._sparse_sink is not None:
+                model._sparse_sink.clear()                    # (an optimizer would consume them here)
+
+        g_ms, h_ms = timed(fwd_nograd, min(steps, 200))
+        fb_ms, fbh_ms = timed(fwd_bwd, min(steps, 100))
+        with torch.autograd.set_multithreading_enabled(False):      # backward nodes run on the calling thread: no hand-off to the engine's device thread
+            fb1_ms, fb1h_ms = timed(fwd_bwd, min(steps, 100))
+        out[f"B{B}"] = {"get_embeddings_from_batch_us": g_ms * 1e3, "get_embeddings_from_batch_host_us_per_call": h_ms * 1e3,
+                        "forward_backward_autograd_us": fb_ms * 1e3, "forward_backward_host_us_per_step": fbh_ms * 1e3,
+                        "forward_backward_autograd_us_engine_thread_off": fb1_ms * 1e3,
+                        "forward_backward_host_us_per_step_engine_thread_off": fb1h_ms * 1e3}
+    if prepared_fb_ms:
+        e = out["B%d" % BATCH]
+        e["prepared_forward_backward_us"] = prepared_fb_ms * 1e3
+        e["autograd_over_prepared"] = e["forward_backward_autograd_us"] / (prepared_fb_ms * 1e3)
+        e["autograd_over_prepared_engine_thread_off"] = e["forward_backward_autograd_us_engine_thread_off"] / (prepared_fb_ms * 1e3)
+    out["note"] = ("GPU time per step from HIP events around back-to-back calls (host-bound when it equals the host time); the autograd step = "
+                   "FM.forward(batch) + p.sum().backward() with the row-sparse gradients left in the model's SparseGradSink (planning on the side "
+                   "stream at forward time); `prepared` = the bound launches of the fwd_bwd leg; *_engine_thread_off = the same step under "
+                   "torch.autograd.set_multithreading_enabled(False): PyTorch's backward otherwise hands every step to its device thread, ~140 us "
+                   "of wake-up and GIL hand-over per step on this host (tools/host_profile_module_step.py)")
+    ops.flush_index_checks()
+    del model
+    return out
+
+
 # ------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(path: SingleGpuPath, budget_s: float = 12.0):
     """Times the CPU oracle's C/OpenMP restatement of the reference path (oracle/nrx_oracle.c, checked
@@ -681,7 +768,7 @@ def main():
             stream_copy = None
 
     # secondary legs at N = 1, outside the headline timed region
-    distinct = fwd_bwd = wide_split = None
+    distinct = fwd_bwd = wide_split = module_path = None
     if world == 1 and not args.force_sharded and not args.headline_only:
         def time_calls(fn, n):
             # warm-up by TIME (>= 50 ms of the same launches): the legs that contain latency-bound launches (the backward's
@@ -757,6 +844,11 @@ def main():
                                "upstream gradients g_out [B, width]" + (" and g_fm [B]" if path.fm else "") + " given; result = unique "
                                "(table,row) keys + summed row gradients on the device (what optim.FusedSparseAdam consumes)"}
             del fwd, bwd
+        if args.workload == "c2" and args.ids == "uniform" and os.environ.get("NRX_BENCH_MODULE_PATH", "1") != "0":
+            try:
+                module_path = module_path_leg(path, fwd_bwd["ms_per_step"] if fwd_bwd else None, steps2)
+            except Exception as e:          # noqa: BLE001 -- a secondary leg must not cost the headline
+                module_path = {"error": f"{type(e).__name__}: {e}"}
 
     if hasattr(path, "overflowed"):
         # every rank must take the same branch: agree on the flag first (a lone SystemExit would strand the peers in the
@@ -823,6 +915,8 @@ def main():
             out["wide_split"] = wide_split
         if fwd_bwd is not None:
             out["fwd_bwd"] = fwd_bwd
+        if module_path is not None:
+            out["module_path"] = module_path
         if world == 1 and not args.no_cpu_baseline and not args.force_sharded:
             big = sum(t.numel() for t in path.tables) * 4 > (64 << 30)      # host copies of > 64 GB of tables: skip
             if not big:

@@ -107,6 +107,50 @@ def _stream_ptr(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+_BIND = None        # the compiled host binding (csrc/nrx_bind.cpp), False once it is known to be absent
+
+
+def _binding():
+    """news_recsys_amd/lib/nrx_bind*.so, or None: the compiled form of the per-batch host work of the module path (tensor
+    validation, descriptor refresh, output allocation, launch).  Optional -- without it the ctypes path below does the same work
+    more slowly; NRX_NO_BIND=1 disables it (host-overhead A/B)."""
+    global _BIND
+    if _BIND is None:
+        _BIND = False
+        if os.environ.get("NRX_NO_BIND") != "1":
+            try:
+                import glob
+                import importlib.util
+                cand = glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "nrx_bind*.so"))
+                if cand:
+                    spec = importlib.util.spec_from_file_location("nrx_bind", cand[0])
+                    mod = importlib.util.module_from_spec(spec)
+                    spec.loader.exec_module(mod)
+                    _BIND = mod
+            except Exception:       # noqa: BLE001 -- an unloadable binding (other torch build) must not take the package down
+                _BIND = False
+    return _BIND or None
+
+
+def _bound_plan(plan):
+    """The plan's BoundPlan of the compiled binding (created once), or None."""
+    bp = plan.__dict__.get("_bound", 0)
+    if bp == 0:
+        bp = None
+        mod = _binding()
+        if mod is not None and 0 < len(plan.slots) <= NRX_MAX_FEATURES:
+            lib = _lib.load()
+            addr = C.cast(lib.nrx_embed_fwd_train, C.c_void_p).value
+            bp = mod.BoundPlan([(s.kind, s.table if s.kind != NRX_DENSE else -1, s.dim, s.bag_len, s.out_col, s.wide_col, s.fm_field, s.flags)
+                                for s in plan.slots], plan.out_width, plan.wide_width, bool(plan.use_fm), addr)
+        plan.__dict__["_bound"] = bp
+    return bp
+
+
+def _raw_stream(dev: torch.device) -> int:
+    return torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+
+
 def _dev(t: torch.Tensor, what: str) -> torch.Tensor:
     if not t.is_cuda:
         raise _lib.NrxError(f"{what}: expected a ROCm device tensor, got device '{t.device}'. The HIP path has no CPU "
@@ -271,6 +315,15 @@ def _csr_plan_to_padded(plan: EmbedPlan, inputs, weights):
     return padded, inputs, weights
 
 
+def _table_meta(ctx):
+    """[(shape, device)] of the node's tables, formed on first use in the backward (26 tables x 2 attribute reads are ~8 us of
+    host time that an inference-only or discarded forward never needs)."""
+    tm = getattr(ctx, "_tm", None)
+    if tm is None:
+        tm = ctx._tm = [(t.shape, t.device) for t in ctx.tables_ref]
+    return tm
+
+
 class _EmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan: EmbedPlan, inputs, weights, out_ld, need_out, sparse_grad, index_check, *tables):
@@ -281,11 +334,51 @@ class _EmbedFn(torch.autograd.Function):
         ctx.tables = list(tables) if ctx.sink is not None else None
         if sparse_grad and any(s.flags & NRX_FEAT_BAG_CSR for s in plan.slots):
             plan, inputs, weights = _csr_plan_to_padded(plan, inputs, weights)      # the planner sorts padded [B, L] lookups
-        B, ins, ws = _prep_inputs(plan, tables, inputs, weights)
-        dev = tables[0].device if tables else ins[0].device
         ld = int(out_ld) if out_ld else plan.out_width
         if ld < plan.out_width:
             raise ValueError("out_ld smaller than the plan's out_width")
+        n_slots = len(plan.slots)
+        bp = _bound_plan(plan) if tables and tables[0].is_cuda else None
+        done = None
+        if bp is not None and (need_out or not plan.use_fm or n_slots <= NRX_MAX_FEATURES):
+            # compiled binding: validation + descriptors + allocation + launch in one call (None: a batch that needs a conversion)
+            dev = tables[0].device
+            status = None
+            if mode == "deferred":
+                sp = _deferred_status(plan.names).data_ptr()
+            elif mode == "off":
+                sp = 0
+            else:
+                status = torch.zeros(4, dtype=torch.int32, device=dev)
+                sp = status.data_ptr()
+            # (autograd only builds this node when some table requires grad: the field sums are always wanted in training form)
+            done = bp.forward(list(tables), inputs, weights, ld, need_out, sp, _raw_stream(dev), bool(plan.use_fm and need_out))
+            if type(done) is int:
+                check(done, "nrx_embed_fwd_train")
+        if done is not None:
+            B, out, wide, fm, sums = done
+            ins, ws = inputs, weights
+            scratch_out = False
+        else:
+            B, ins, ws, dev, out, wide, fm, sums, status, scratch_out = _EmbedFn._forward_ctypes(
+                lib, plan, tables, inputs, weights, ld, need_out, mode)
+        if status is not None and mode != "deferred":
+            if mode == "sync":
+                _raise_if_oob(status, plan.names)
+            else:
+                ev = torch.cuda.Event()
+                ev.record()
+                _pending_status.append((status, ev, plan.names))
+                while _pending_status and _pending_status[0][1].query():
+                    st, _, nm = _pending_status.pop(0)
+                    _raise_if_oob(st, nm)
+        return _EmbedFn._finish(ctx, plan, tables, B, ld, ins, ws, out, wide, fm, sums, need_out, scratch_out)
+
+    @staticmethod
+    def _forward_ctypes(lib, plan, tables, inputs, weights, ld, need_out, mode):
+        """The launch through ctypes (any batch: converts what needs converting)."""
+        B, ins, ws = _prep_inputs(plan, tables, inputs, weights)
+        dev = tables[0].device if tables else ins[0].device
         n_slots = len(plan.slots)
         # > 64 FM fields: the cross-field sums span launches, so the FM runs on the concat -- it is needed even when the
         # caller did not ask for it (returned as None all the same)
@@ -316,37 +409,32 @@ class _EmbedFn(torch.autograd.Function):
                 # > 64 FM fields: the cross-field sums cannot be split over launches; run FM on the concat
                 d0 = plan.slots[0].dim
                 check(lib.nrx_fm_fwd(out.data_ptr(), ld, n, d0, B, fm.data_ptr(), stream), "nrx_fm_fwd")
-        if status is not None and mode != "deferred":
-            if mode == "sync":
-                _raise_if_oob(status, plan.names)
-            else:
-                ev = torch.cuda.Event()
-                ev.record()
-                _pending_status.append((status, ev, plan.names))
-                while _pending_status and _pending_status[0][1].query():
-                    st, _, nm = _pending_status.pop(0)
-                    _raise_if_oob(st, nm)
+        return B, ins, ws, dev, out, wide, fm, sums, status, scratch_out
+
+    @staticmethod
+    def _finish(ctx, plan, tables, B, ld, ins, ws, out, wide, fm, sums, need_out, scratch_out):
         ctx.plan, ctx.B, ctx.ld = plan, B, ld
         ctx.ins, ctx.ws = ins, ws
-        ctx.table_meta = [(t.shape, t.device) for t in tables]
+        ctx.tables_ref = tables          # leaves (the module's parameters): shapes / devices are read from them in the backward
         # the FM backward needs the forward concat.  It is an OUTPUT of this node: it must go through save_for_backward --
         # a plain attribute would make a reference cycle (ctx -> out -> grad_fn -> ctx) that only the garbage collector
         # frees: 100+ MB per step kept alive, and a ~35 ms collection every few dozen steps
         ctx.has_fm_feat = bool(plan.use_fm and need_out)
         ctx.fm_sums = sums
         ctx.plans = None
-        if ctx.sparse_grad and PLAN_AHEAD and B > 0 and any(t.requires_grad for t in tables) and \
-                not torch.cuda.is_current_stream_capturing():
+        if ctx.sparse_grad and PLAN_AHEAD and B > 0 and not torch.cuda.is_current_stream_capturing() and \
+                any(t.requires_grad for t in tables):
             ctx.plans = {}
-            for D_, fs_ in _sparse_groups(plan):
+            for g_ in _sparse_group_cache(plan, tables):
+                fs_ = g_["fs"]
                 ids_ = [ins[i] for i in fs_]
-                if any(x.dtype != ids_[0].dtype for x in ids_):
-                    ids_ = [x.long() for x in ids_]
-                if sum(x.numel() for x in ids_) == 0:
-                    continue
-                tabs_ = [plan.slots[i].table for i in fs_]
-                ctx.plans[(D_, fs_[0])] = (ids_,) + sparse_plan_ahead(ids_, tabs_, [tables[t].shape[0] for t in tabs_], len(tables),
-                                                                      place_mask([plan.slots[i].kind for i in fs_]) if SPARSE_PLACE else None)
+                dt_ = ids_[0].dtype
+                for x in ids_:
+                    if x.dtype is not dt_:
+                        ids_ = [y.long() for y in ids_]
+                        break
+                ctx.plans[(g_["dim"], fs_[0])] = (ids_,) + sparse_plan_ahead(ids_, g_["tabs"], g_["rows"], len(tables),
+                                                                          g_["pmask"] if SPARSE_PLACE else None, static=g_["static"])
         if ctx.has_fm_feat:
             ctx.save_for_backward(out)
         ctx.set_materialize_grads(False)
@@ -356,10 +444,10 @@ class _EmbedFn(torch.autograd.Function):
     def backward(ctx, g_out, g_wide, g_fm):
         lib = _lib.load()
         plan, B, ld = ctx.plan, ctx.B, ctx.ld
-        n_tables = len(ctx.table_meta)
+        n_tables = len(_table_meta(ctx))
         if g_out is None and g_wide is None and g_fm is None:
             return (None,) * (7 + n_tables)
-        dev = ctx.table_meta[0][1]
+        dev = _table_meta(ctx)[0][1]
         stream = torch.cuda.current_stream(dev).cuda_stream
         if g_out is not None:
             g_out = _f32c(g_out, "grad of the concat")
@@ -385,7 +473,7 @@ class _EmbedFn(torch.autograd.Function):
             return (None,) * (7 + n_tables)
         if ctx.sparse_grad:
             return (None, None, None, None, None, None, None, *_sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg))
-        grads = [torch.zeros(shape, dtype=torch.float32, device=d) for shape, d in ctx.table_meta]
+        grads = [torch.zeros(shape, dtype=torch.float32, device=d) for shape, d in _table_meta(ctx)]
         if B > 0 and (g_out is not None or g_wide is not None or fmg is not None):
             gptrs = [g.data_ptr() for g in grads]
             n = len(plan.slots)
@@ -424,8 +512,12 @@ def _plan_stream(dev) -> "torch.cuda.Stream":
     return s
 
 
+import collections as _collections
+_plan_keepalive = _collections.deque()
+
+
 def sparse_plan_ahead(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int,
-                      place_feats: Optional[int] = None):
+                      place_feats: Optional[int] = None, static=None):
     """sparse_plan on a side stream: the planning of the backward depends only on the ids, so it can run while the forward,
     the dense part of the model and its backward occupy the main stream.  Returns ((order, uniq, seg, counts), event);
     the consumer makes its stream wait for `event` before reading the plan."""
@@ -433,17 +525,20 @@ def sparse_plan_ahead(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows
     cur = torch.cuda.current_stream(dev)
     side = _plan_stream(dev)
     side.wait_stream(cur)                      # the ids are ready where the caller's stream is now
-    for x in ids:
-        # the planner READS the ids on the side stream: tell the caching allocator, or an id tensor that dies early (a
-        # .long() / .contiguous() temporary, a csr_to_padded output, a forward whose loss is dropped without a backward)
-        # could have its block handed out again on the caller's stream while the sort is still reading it
-        x.record_stream(side)
     with torch.cuda.stream(side):
-        res = sparse_plan(ids, table_of, rows, n_tables, place_feats)
+        res = sparse_plan(ids, table_of, rows, n_tables, place_feats, static=static)
         ev = torch.cuda.Event()
         ev.record(side)
+    # The planner READS the ids on the side stream: an id tensor that dies early (a .long() / .contiguous() temporary, a
+    # csr_to_padded output, a forward whose loss is dropped without a backward) must not have its block handed out again on the
+    # caller's stream while the sort still reads it.  One reference per plan, held until the plan's event has passed (26
+    # record_stream calls were 40 us of host time per step); the outputs, allocated under the side stream and consumed under the
+    # caller's, do need record_stream.
+    _plan_keepalive.append((ev, ids))
+    while _plan_keepalive and _plan_keepalive[0][0].query():
+        _plan_keepalive.popleft()
     for t in res:
-        t.record_stream(cur)                   # allocated under the side stream, consumed (and freed) under the caller's
+        t.record_stream(cur)
     return res, ev
 
 
@@ -460,7 +555,7 @@ def place_mask(kinds: Sequence[int]) -> int:
 
 
 def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int,
-                place_feats: Optional[int] = None):
+                place_feats: Optional[int] = None, static=None):
     """nrx_sparse_plan: group the flat, feature-major lookups `ids` (one device tensor per feature, all int32 or
     all int64) by (table, row).  Returns device int64 tensors (order [n], uniq_keys [n], seg_start [n+1],
     counts [n_tables+2]); only the first counts[0] entries of uniq_keys / counts[0]+1 of seg_start are
@@ -482,15 +577,18 @@ def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequ
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in ids])
     lens = (C.c_int64 * n)(*[x.numel() for x in ids])
-    tof = (C.c_int32 * n)(*[int(t) for t in table_of])
-    rws = (C.c_int64 * n)(*[int(r) for r in rows])
+    if static is not None:                     # (table_of, rows) as ctypes arrays, built once per plan group
+        tof, rws = static
+    else:
+        tof = (C.c_int32 * n)(*[int(t) for t in table_of])
+        rws = (C.c_int64 * n)(*[int(r) for r in rows])
     if place_feats is not None:
         dest = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
         walk = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
         n_walk = torch.empty(1, dtype=torch.int64, device=dev)
         check(lib.nrx_sparse_plan_place(ptrs, lens, tof, rws, n, ids[0].element_size() * 8, n_tables, int(place_feats), order.data_ptr(),
                                         uniq.data_ptr(), seg.data_ptr(), counts.data_ptr(), dest.data_ptr(), walk.data_ptr(),
-                                        n_walk.data_ptr(), ws.data_ptr(), _stream_ptr(ids[0])), "nrx_sparse_plan_place")
+                                        n_walk.data_ptr(), ws.data_ptr(), _raw_stream(dev)), "nrx_sparse_plan_place")
         return order, uniq, seg, counts, dest, walk, n_walk
     check(lib.nrx_sparse_plan(ptrs, lens, tof, rws, n, ids[0].element_size() * 8, n_tables, order.data_ptr(), uniq.data_ptr(),
                               seg.data_ptr(), counts.data_ptr(), ws.data_ptr(), _stream_ptr(ids[0])), "nrx_sparse_plan")
@@ -506,6 +604,25 @@ def _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, wide_ld, n_uniq
                                    pl[4].data_ptr() if placed else None, pl[5].data_ptr() if placed else None,
                                    pl[6].data_ptr() if placed else None, lws.data_ptr(), lws.numel(), stream),
           "nrx_embed_bwd_placed")
+
+
+def _sparse_group_cache(plan: EmbedPlan, tables):
+    """Per launch group of the row-sparse backward, built once per (plan, table set): slot indices, the group's sub-plan (its cached
+    descriptor array lives there), table ids / row counts as the ctypes arrays nrx_sparse_plan takes, the placement mask."""
+    key = (len(tables), tables[0].data_ptr() if len(tables) else 0)
+    ent = plan.__dict__.get("_sg")
+    if ent is None or ent[0] != key:
+        groups = []
+        for D, fs in _sparse_groups(plan):
+            tabs = [plan.slots[i].table for i in fs]
+            n = len(fs)
+            groups.append(dict(dim=D, fs=fs, tabs=tabs, n=n,
+                               sub=EmbedPlan([plan.slots[i] for i in fs], out_width=plan.out_width, wide_width=plan.wide_width),
+                               static=((C.c_int32 * n)(*tabs), (C.c_int64 * n)(*[int(tables[t].shape[0]) for t in tabs])),
+                               rows=[int(tables[t].shape[0]) for t in tabs],
+                               pmask=place_mask([plan.slots[i].kind for i in fs])))
+        ent = plan.__dict__["_sg"] = (key, groups)
+    return ent[1]
 
 
 def _sparse_groups(plan: EmbedPlan):
@@ -531,20 +648,20 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
     padding rows get explicit zeros.  Returns torch.sparse_coo tensors (what nn.Embedding(sparse=True)
     produces), usable with SGD / SparseAdam / Adagrad."""
     plan, B, ld = ctx.plan, ctx.B, ctx.ld
-    n_tables = len(ctx.table_meta)
+    tables = ctx.tables_ref
+    n_tables = len(tables)
     grads = [None] * n_tables
     MASK = (1 << 40) - 1
     ahead = getattr(ctx, "plans", None) or {}
-    for D, fs in _sparse_groups(plan):
-        dev = ctx.table_meta[plan.slots[fs[0]].table][1]
-        tabs = [plan.slots[i].table for i in fs]
-        n = len(fs)
+    for grp in _sparse_group_cache(plan, tables):
+        D, fs, tabs, n = grp["dim"], grp["fs"], grp["tabs"], grp["n"]
+        dev = tables[tabs[0]].device
         pre = ahead.get((D, fs[0]))
-        pmask = place_mask([plan.slots[i].kind for i in fs]) if SPARSE_PLACE else None
+        pmask = grp["pmask"] if SPARSE_PLACE else None
         if pre is not None:                 # planned at forward time on the side stream (sparse_plan_ahead)
             ids, pl, ev = pre
             torch.cuda.current_stream(dev).wait_event(ev)
-            total = sum(x.numel() for x in ids)
+            total = pl[0].numel()
         else:
             ids = [ctx.ins[i] for i in fs]
             dt = ids[0].dtype
@@ -553,15 +670,16 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
             total = sum(x.numel() for x in ids)
             if total == 0:
                 continue
-            pl = sparse_plan(ids, tabs, [ctx.table_meta[t][0][0] for t in tabs], n_tables, pmask)
+            pl = sparse_plan(ids, tabs, grp["rows"], n_tables, pmask, static=grp["static"])
         uniq, counts = pl[1], pl[3]
         # The one host read (n_tables + 2 integers).  Reading it BEFORE the reduction lets the host build the
         # per-table COO tensors while that kernel runs (1.00 ms per C2 step vs 1.11 ms with the sync-free
         # n_unique_dev form of the call, which leaves the host work exposed after the GPU is done).
-        sub = EmbedPlan([plan.slots[i] for i in fs], out_width=plan.out_width, wide_width=plan.wide_width)
-        arr = _fill_features(sub, 0, n, [None] * n_tables, ids, [ctx.ws[i] for i in fs], table_ptrs=[0] * n_tables,
-                             fm=fmg is not None)
-        lws = torch.empty(lib.nrx_embed_bwd_workspace_for(arr, n, B, D), dtype=torch.uint8, device=dev)   # hot-row work lists, bag scales
+        arr = _group_features(grp, ids, [ctx.ws[i] for i in fs], fmg is not None)
+        wsz = grp.get("lws_bytes")
+        if wsz is None or wsz[0] != B:
+            wsz = grp["lws_bytes"] = (B, lib.nrx_embed_bwd_workspace_for(arr, n, B, D))
+        lws = torch.empty(wsz[1], dtype=torch.uint8, device=dev)   # hot-row work lists, bag scales
         if ctx.sink is not None:
             values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
             _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, total, counts, fmg, values, lws, stream)
@@ -581,14 +699,34 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
         rows = (uniq[:nu] & MASK).unsqueeze(0)
         for t in sorted(set(tabs)):
             lo, hi = cl[1 + t], cl[2 + t]
-            g = torch.sparse_coo_tensor(rows[:, lo:hi], values[lo:hi], size=ctx.table_meta[t][0], is_coalesced=True)
+            g = torch.sparse_coo_tensor(rows[:, lo:hi], values[lo:hi], size=tables[t].shape, is_coalesced=True)
             grads[t] = g if grads[t] is None else (grads[t] + g).coalesce()
+    if ctx.sink is not None:
+        return grads                        # the results went to the sink: no (empty) COO tensors to build -- 26 of them were 130 us per step
     for t in range(n_tables):
         if grads[t] is None:
-            shape, dev = ctx.table_meta[t]
+            shape, dev = _table_meta(ctx)[t]
             grads[t] = torch.sparse_coo_tensor(torch.zeros((1, 0), dtype=torch.int64, device=dev),
                                                torch.zeros((0, shape[1]), dtype=torch.float32, device=dev), size=shape)
     return grads
+
+
+def _group_features(grp, ids, ws, fm: bool):
+    """The descriptor array of one backward group (table pointers are not used by the sorted backward): static fields written
+    once per group, the id / weight pointer columns refreshed through a numpy view."""
+    import numpy as np
+    key = "arr_fm" if fm else "arr"
+    ent = grp.get(key)
+    if ent is None:
+        sub, n = grp["sub"], grp["n"]
+        arr = _fill_features(sub, 0, n, [None] * (max(grp["tabs"]) + 1), ids, ws, table_ptrs=[0] * (max(grp["tabs"]) + 1), fm=fm)
+        ent = grp[key] = (arr, np.frombuffer(arr, dtype=_feature_np_dtype()))
+        return arr
+    arr, view = ent
+    view["index"] = [x.data_ptr() for x in ids]
+    view["index_bits"] = ids[0].element_size() * 8
+    view["weight"] = [0 if w is None else w.data_ptr() for w in ws]
+    return arr
 
 
 _FEATURE_DTYPE = None
@@ -648,6 +786,32 @@ class _FastForward:
 
     def __call__(self, tables, inputs, weights, out_ld, need_out, mode):
         plan = self.plan
+        bp = _bound_plan(plan)
+        if bp is not None and type(tables) is list and type(inputs) is list and type(weights) is list and tables and tables[0].is_cuda:
+            dev = tables[0].device
+            status = None
+            if mode == "deferred":
+                sp = _deferred_status(plan.names).data_ptr()
+            elif mode == "off":
+                sp = 0
+            else:
+                status = torch.zeros(4, dtype=torch.int32, device=dev)
+                sp = status.data_ptr()
+            res = bp.forward(tables, inputs, weights, int(out_ld) if out_ld else 0, need_out, sp, _raw_stream(dev), False)
+            if res is not None:
+                if type(res) is int:
+                    check(res, "nrx_embed_fwd")
+                if status is not None:
+                    if mode == "sync":
+                        _raise_if_oob(status, plan.names)
+                    else:
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        _pending_status.append((status, ev, plan.names))
+                        while _pending_status and _pending_status[0][1].query():
+                            st, _, nm = _pending_status.pop(0)
+                            _raise_if_oob(st, nm)
+                return res[1], res[2], res[3]
         if tables is not self._tables_id or (tables and self._tkey != (len(tables), tables[0].data_ptr(), tables[-1].data_ptr())):
             self._bind_tables(tables)
         if self.simple:
@@ -1121,7 +1285,7 @@ class _EmbedDcnFn(torch.autograd.Function):
                 call.check()
         ctx.plan, ctx.B, ctx.ld = plan, call.B, plan.out_width
         ctx.ins, ctx.ws = call.ins, [None] * len(plan.slots)
-        ctx.table_meta = [(t.shape, t.device) for t in tables]
+        ctx.tables_ref = tables          # leaves (the module's parameters): shapes / devices are read from them in the backward
         ctx.has_fm_feat = False
         ctx.sink = sparse_grad if isinstance(sparse_grad, SparseGradSink) else None
         ctx.sparse_grad = bool(sparse_grad)
