@@ -250,8 +250,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_generic(const EmbedArgs a
 
     if (a.fm_out != nullptr) {
         // 0.5 * sum_k [(sum_f v)^2 - sum_f v^2] over this lane's 4 columns, then over the Q lanes
-        float part = 0.5f * ((fm_s.x * fm_s.x - fm_q.x) + (fm_s.y * fm_s.y - fm_q.y) +
-                             (fm_s.z * fm_s.z - fm_q.z) + (fm_s.w * fm_s.w - fm_q.w)) + fm_first;
+        float part = fm_lane_part(fm_s, fm_q, fm_first);
         if (a.fm_sums != nullptr && live) {     // field sums for the FM backward (one chunk: dims <= 4Q here)
             float* sp = a.fm_sums + b * a.sums_ld + 4 * q;
             const float sv[4] = {q == 0 ? fm_first : fm_s.x, fm_s.y, fm_s.z, fm_s.w};
@@ -262,6 +261,181 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_generic(const EmbedArgs a
         part = group_sum<Q>(part);
         if (live && q == 0) a.fm_out[b] = part;
     }
+}
+
+// --------------------------------------------------------------------------------------------
+// Small batches: ONE BLOCK PER SAMPLE.  The kernels above give a sample to Q lanes and let a block of 256 / Q samples walk
+// the features one after the other -- right for B = 65536, but the reference trains with B = 512 (sort/deep/train_cf_deep.yaml:48),
+// where that is 8 blocks on a 256-CU chip, each running 26 (or 50 bag entries') dependent load rounds: 12.6 us for the C2
+// plan, 21.9 us for the DSSM user tower (profiles/r02_small_batch_kernel_times.txt).  Here every (feature, bag entry, 16-byte
+// chunk) of the sample is one work item with its own thread: all of the sample's row fetches are in flight at once and land
+// in LDS; a second step forms the outputs from LDS IN THE ORDER the big kernels use -- bag entries summed sequentially in l,
+// FM fields accumulated sequentially in plan order by the first Q lanes -- so the result is bit-identical to theirs.
+// Eligible: sparse / dense / padded bag features, table dims % 4 == 0 (16-byte aligned tables), no wide routing, no CSR bags.
+// --------------------------------------------------------------------------------------------
+template <int Q>
+__device__ __forceinline__ float group_sum_rt(float v) { return group_sum<Q>(v); }
+
+__global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_small_kernel(const EmbedArgs args_in_kernarg) {
+    const NRX_CONST EmbedArgs* a = nrx_kernarg<EmbedArgs>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = a->n;
+    int* s_ibase = reinterpret_cast<int*>(smem);                 // [n + 1] first work item of feature fi
+    int* s_obase = s_ibase + (NRX_MAX_FEATURES + 1);             // [n + 1] first output chunk of feature fi
+    float4* s_rows = reinterpret_cast<float4*>(s_obase + (NRX_MAX_FEATURES + 1) + 2);     // [items] fetched row chunks (16-byte aligned: 2 x 65 + 2 ints)
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    // the descriptors go to LDS first (one coalesced pass over the kernarg block): a work item picks its feature by a per-thread
+    // index, and a per-thread read of the argument block is a global load -- three dependent ones (kind / dim, ids, table) in front of
+    // every row fetch
+    __shared__ FeatDev s_f[NRX_MAX_FEATURES];
+    {
+        const NRX_CONST uint32_t* src = reinterpret_cast<const NRX_CONST uint32_t*>(a->f);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_f);
+        for (int i = tid; i < n * (int)(sizeof(FeatDev) / 4); i += NRX_BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    // ---- item / output-chunk bases: one wavefront scans the <= 64 features
+    if (tid < 64) {
+        int items = 0, chunks = 0;
+        if (tid < n) {
+            const int L = s_f[tid].kind >= NRX_BAG_MASKED_MEAN ? s_f[tid].bag_len : 1;
+            chunks = s_f[tid].kind == NRX_DENSE ? 1 : s_f[tid].dim / 4;
+            items = L * chunks;
+        }
+        int ii = items, cc = chunks;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t1 = __shfl_up(ii, off, 64), t2 = __shfl_up(cc, off, 64);
+            if (tid >= off) { ii += t1; cc += t2; }
+        }
+        if (tid < n) { s_ibase[tid + 1] = ii; s_obase[tid + 1] = cc; }
+        if (tid == 0) { s_ibase[0] = 0; s_obase[0] = 0; }
+    }
+    __syncthreads();
+    const int n_items = s_ibase[n], n_out = s_obase[n];
+    float* s_wt = reinterpret_cast<float*>(s_rows + n_items);     // [items] the entry's weight (same for the chunks of an entry)
+    float4* s_val = reinterpret_cast<float4*>(s_wt + ((n_items + 3) & ~3));      // [n_out] finished output chunks (for the FM epilogue)
+    auto feat_of = [&](const int* base, int t) {                  // feature owning index t of a prefix array
+        int lo = 0, hi = n;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (base[mid] <= t) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    // ---- step 1: every work item fetches its row chunk
+    for (int t = tid; t < n_items; t += NRX_BLOCK) {
+        const int fi = feat_of(s_ibase, t);
+        const FeatDev& f = s_f[fi];
+        const int r = t - s_ibase[fi];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float w = 1.0f;
+        if (f.kind == NRX_DENSE) {
+            v.x = f.idx64 ? (float)reinterpret_cast<const double*>(f.index)[b] : reinterpret_cast<const float*>(f.index)[b];
+        } else {
+            const int C = f.dim / 4;
+            const int l = r / C, c = r - l * C;
+            const bool bag = f.kind >= NRX_BAG_MASKED_MEAN;
+            const int64_t gi = bag ? b * (int64_t)f.bag_len + l : b;
+            int64_t id = nrx_load_id(f.index, gi, f.idx64);
+            if (bag) w = f.weight ? f.weight[gi] : 1.0f;
+            if ((uint64_t)id >= (uint64_t)f.rows) {
+                if (c == 0) nrx_report_oob(a->status, a->feat_id[fi], b, id);
+                id = 0;
+            }
+            if (!bag || w != 0.f) v = *reinterpret_cast<const float4*>(f.table + id * (int64_t)f.dim + 4 * c);
+        }
+        s_rows[t] = v;
+        s_wt[t] = w;
+    }
+    __syncthreads();
+    // ---- step 2: one thread per output chunk; bags summed in entry order with the generic kernel's arithmetic
+    for (int t = tid; t < n_out; t += NRX_BLOCK) {
+        const int fi = feat_of(s_obase, t);
+        const FeatDev& f = s_f[fi];
+        const int c = t - s_obase[fi];
+        const int ib = s_ibase[fi];
+        float4 v;
+        if (f.kind < NRX_BAG_MASKED_MEAN) {
+            v = s_rows[ib + c];
+        } else {
+            const int C = f.dim / 4, L = f.bag_len;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            float den = 0.f;
+            constexpr int UB = 10;                        // LDS reads of UB entries issued ahead of their dependent adds
+            int l = 0;
+            for (; l + UB <= L; l += UB) {
+                float w[UB];
+                float4 r[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) { w[u] = s_wt[ib + (l + u) * C + c]; r[u] = s_rows[ib + (l + u) * C + c]; }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+#pragma clang fp contract(off)
+                    den += w[u];
+                    acc.x += r[u].x * w[u]; acc.y += r[u].y * w[u]; acc.z += r[u].z * w[u]; acc.w += r[u].w * w[u];
+                }
+            }
+            for (; l < L; ++l) {
+#pragma clang fp contract(off)
+                const float w = s_wt[ib + l * C + c];
+                const float4 r = s_rows[ib + l * C + c];
+                den += w;
+                acc.x += r.x * w; acc.y += r.y * w; acc.z += r.z * w; acc.w += r.w * w;
+            }
+            if (f.kind == NRX_BAG_MASKED_MEAN) {
+                const float d = den + 1e-8f;
+                v = make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d);
+            } else if (f.kind == NRX_BAG_MEAN) {
+                const float d = (float)L;
+                v = make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d);
+            } else {
+                v = acc;
+            }
+        }
+        s_val[t] = v;
+        if (a->out != nullptr) {
+            float* p = a->out + b * a->out_ld + f.out_col + 4 * c;
+            if (f.kind == NRX_DENSE) p[0] = v.x;
+            else if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) *reinterpret_cast<float4*>(p) = v;
+            else { p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w; }
+        }
+    }
+    if (a->fm_out == nullptr) return;
+    __syncthreads();
+    // ---- FM epilogue: the first Q lanes walk the fields in plan order, as a sample's Q lanes do in the big kernels
+    int Q = 1;
+    for (int fi = 0; fi < n; ++fi)
+        if (s_f[fi].fm) Q = s_f[fi].dim / 4;          // FM fields share one dim (fm/model.py:48-59 stacks them)
+    if (tid >= 64) return;
+    const int q = tid;
+    float fm_first = 0.f;
+    float4 fm_s = make_float4(0.f, 0.f, 0.f, 0.f), fm_q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < Q) {
+        for (int fi = 0; fi < n; ++fi) {
+            const FeatDev& f = s_f[fi];
+            if (f.fm) fm_accumulate(s_val[s_obase[fi] + q], 4 * q, f.dim, fm_first, fm_s, fm_q);
+        }
+    }
+    float part = fm_lane_part(fm_s, fm_q, fm_first);
+    if (a->fm_sums != nullptr && q < Q) {
+        float* sp = a->fm_sums + b * a->sums_ld + 4 * q;
+        const float sv[4] = {q == 0 ? fm_first : fm_s.x, fm_s.y, fm_s.z, fm_s.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * q + j < a->sums_ld) sp[j] = sv[j];
+    }
+    switch (Q) {                                         // the same butterfly as group_sum<Q> of the big kernels
+        case 1: break;
+        case 2: part = group_sum_rt<2>(part); break;
+        case 4: part = group_sum_rt<4>(part); break;
+        case 8: part = group_sum_rt<8>(part); break;
+        case 16: part = group_sum_rt<16>(part); break;
+        case 32: part = group_sum_rt<32>(part); break;
+        default: part = group_sum_rt<64>(part); break;
+    }
+    if (q == 0) a->fm_out[b] = part;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1415,6 +1589,47 @@ extern "C" int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, 
     for (int i = 0; i < n_feats; ++i)
         NRX_REQUIRE(!(feats[i].flags & NRX_FEAT_BAG_CSR) || feats[i].kind >= NRX_BAG_MASKED_MEAN,
                     "nrx_embed_fwd: feature %d: NRX_FEAT_BAG_CSR on a non-bag feature", i);
+    // ---- small batches: one block per sample (embed_fwd_small_kernel).  NRX_SMALL_BATCH = largest batch that takes it (0: never)
+    {
+        static const int64_t small_max = getenv("NRX_SMALL_BATCH") ? atoll(getenv("NRX_SMALL_BATCH")) : 2048;
+        bool ok = batch <= small_max;
+        int64_t items = 0, outs = 0;
+        int fm_fields = 0, fm_dim = 0;
+        for (int i = 0; i < n_feats && ok; ++i) {
+            const nrx_feature_t& s = feats[i];
+            ok = s.wide_col < 0 && !(s.flags & NRX_FEAT_BAG_CSR) && s.kind >= NRX_SPARSE && s.kind <= NRX_BAG_SUM;
+            if (s.kind != NRX_DENSE) ok = ok && s.table != nullptr && (s.dim & 3) == 0 && nrx_aligned16(s.table) && s.dim >= 4;
+            if (s.kind == NRX_BAG_MASKED_MEAN) ok = ok && s.weight != nullptr;
+            const int64_t L = s.kind >= NRX_BAG_MASKED_MEAN ? s.bag_len : 1, c = s.kind == NRX_DENSE ? 1 : s.dim / 4;
+            items += L * c;
+            outs += c;
+            if (s.fm_field) {
+                ok = ok && s.kind != NRX_DENSE && (fm_fields == 0 || fm_dim == s.dim) && s.dim <= 256;
+                fm_dim = s.dim;
+                ++fm_fields;
+            }
+        }
+        ok = ok && items <= 2048 && (fm_fields == 0 || fm_out != nullptr) && !(out == nullptr && fm_fields == 0);
+        if (ok) {
+            EmbedArgs a;
+            int max_dim, max_bag;
+            int rc = pack_features(feats, n_feats, a, max_dim, max_bag, "nrx_embed_fwd");
+            if (rc != NRX_OK) return rc;
+            for (int i = 0; i < NRX_MAX_FEATURES; ++i) a.feat_id[i] = (uint8_t)i;
+            a.batch = batch; a.out = out; a.out_ld = out_ld; a.wide = nullptr; a.wide_ld = 0;
+            a.fm_out = fm_fields > 0 ? fm_out : nullptr;
+            a.fm_sums = fm_fields > 0 ? fm_sums : nullptr;
+            a.sums_ld = sums_ld;
+            a.g_fm = nullptr; a.feat = nullptr; a.feat_ld = 0;
+            a.status = status;
+            a.n = n_feats;
+            a.lds_chunk = 0;
+            const size_t smem = (2 * (NRX_MAX_FEATURES + 1) + 2) * sizeof(int) + (size_t)items * 16 + (size_t)((items + 3) & ~(int64_t)3) * 4 + (size_t)outs * 16 + 16;
+            hipLaunchKernelGGL(embed_fwd_small_kernel, dim3((unsigned)batch), dim3(NRX_BLOCK), smem, st, a);
+            NRX_LAUNCH_CHECK("nrx_embed_fwd(small batch)");
+            return NRX_OK;
+        }
+    }
     // ---- uniform fast path?  One launch when every feature is single-valued with the same width D = 4Q.  Otherwise, with no FM
     // epilogue and no wide split in play, and enough lookups to amortise the launches, the features that DO qualify are served by one uniform launch
     // per width, each writing its own columns of the same concat, and only the rest -- bags, dense values, odd widths -- goes

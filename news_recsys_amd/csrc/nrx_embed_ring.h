@@ -50,7 +50,17 @@ __device__ __forceinline__ void fm_accumulate(float4 v, int k0, int D, float& fi
     if (k0 + 2 >= D) v.z = 0.f;
     if (k0 + 3 >= D) v.w = 0.f;
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+    // explicit fused multiply-adds: the ring, generic and one-block-per-sample kernels must form the SAME bits (left to the
+    // compiler's contraction choices two kernels differed in the last place)
+    sq.x = __builtin_fmaf(v.x, v.x, sq.x); sq.y = __builtin_fmaf(v.y, v.y, sq.y);
+    sq.z = __builtin_fmaf(v.z, v.z, sq.z); sq.w = __builtin_fmaf(v.w, v.w, sq.w);
+}
+
+// This lane's share of 0.5 * sum_k [(sum_f v)^2 - sum_f v^2] + (first-order sum): one definition, explicit operation order.
+__device__ __forceinline__ float fm_lane_part(const float4& s, const float4& sq, float first) {
+    const float a = __builtin_fmaf(s.x, s.x, -sq.x), b = __builtin_fmaf(s.y, s.y, -sq.y);
+    const float c = __builtin_fmaf(s.z, s.z, -sq.z), d = __builtin_fmaf(s.w, s.w, -sq.w);
+    return __builtin_fmaf(0.5f, ((a + b) + c) + d, first);
 }
 
 // sum over the Q lanes of a sample, result in all of them: DPP moves inside a 16-lane row (no LDS round trip);
@@ -192,8 +202,7 @@ __global__ __launch_bounds__(NRX_BLOCK, MINW) void embed_fwd_ring(const UniformA
     }
 
     if (FM) {
-        float part = 0.5f * ((fm_s.x * fm_s.x - fm_q.x) + (fm_s.y * fm_s.y - fm_q.y) +
-                             (fm_s.z * fm_s.z - fm_q.z) + (fm_s.w * fm_s.w - fm_q.w)) + fm_first;
+        float part = fm_lane_part(fm_s, fm_q, fm_first);
         if (a->fm_sums != nullptr) {   // S[b, :] = sum over fields (column 0: the first-order sum); the FM backward needs it
             nrx_f32x4 t;
             t.x = q == 0 ? fm_first : fm_s.x; t.y = fm_s.y; t.z = fm_s.z; t.w = fm_s.w;

@@ -147,7 +147,7 @@ def test_deferred_index_check_names_the_right_plan_and_flushes_at_epoch_end():
         m.get_embeddings_from_batch(batch, {"item_id", "user_id"})
         m.on_train_epoch_end()
     msg = str(ei.value)
-    assert "category" in msg and "sample 0" in msg and "id 1000000" in msg
+    assert "category" in msg and "sample " in msg and "id 1000000" in msg       # (every sample offends: which one reports first is a race)
     assert "'item_id'" not in msg.split("one of")[0]                                # never plainly blamed on plan B's feature
     m.on_fit_end()                                                                   # clear again: nothing raised
     m.get_embeddings_from_batch(batch, {"category", "user_history"})
