@@ -11,6 +11,21 @@
 #define NRX_BLOCK 256
 
 void nrx_set_error(const char* fmt, ...);
+// roctx range around an entry point (NRX_ROCTX=1 in the environment; libroctx64 is loaded on first use, never linked): shows the
+// library's calls as named ranges in rocprofv3 --marker-trace timelines.  Off: one predictable branch per call.
+void nrx_trace_push(const char* name);
+void nrx_trace_pop();
+extern int nrx_trace_on;       // -1 unknown, 0 off, 1 on
+struct NrxTrace {
+    bool on;
+    explicit NrxTrace(const char* name) : on(nrx_trace_on != 0) {
+        if (on) nrx_trace_push(name);
+    }
+    ~NrxTrace() {
+        if (on) nrx_trace_pop();
+    }
+};
+#define NRX_TRACE() NrxTrace nrx_trace_scope__(__func__)
 // zero-fill by a kernel launch (capture-safe replacement of hipMemsetAsync; see nrx_lib.hip); p and bytes dword-aligned
 int nrx_zero_async(void* p, size_t bytes, hipStream_t st);
 

@@ -386,6 +386,7 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_bf16x3_kernel(const float
 extern "C" int nrx_dcn_v2_layer_fwd(const float* x0, const float* xl, int64_t ld, int64_t batch, int32_t dim,
                                     const float* W, const float* bias, int32_t relu, float* out,
                                     int64_t out_ld, float* lin_out, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(x0 && xl && W && bias && out && batch >= 0 && dim >= 1 && ld >= dim && out_ld >= dim,
                 "nrx_dcn_v2_layer_fwd: bad argument");
     NRX_REQUIRE(out != xl && out != x0, "nrx_dcn_v2_layer_fwd: out must not alias the inputs");

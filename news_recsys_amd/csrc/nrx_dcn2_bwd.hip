@@ -590,6 +590,7 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
                                     int64_t batch, int32_t dim, const float* W, const float* g_out, int64_t g_ld,
                                     float* g_xl, int64_t gxl_ld, float* g_x0, int64_t gx0_ld, int32_t accumulate_x0,
                                     float* g_W, float* g_b, void* workspace, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(x0 && xl && lin && W && g_out && g_xl && g_x0 && g_W && g_b && workspace && batch >= 0 && dim >= 1 && ld >= dim,
                 "nrx_dcn_v2_layer_bwd: bad argument");
     const bool split = (relu & 2) != 0;        // flags as in nrx_dcn_v2_layer_fwd: bit 0 = ReLU, bit 1 = split-bf16 matrix math
@@ -647,6 +648,7 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
 
 extern "C" int nrx_linear_wgrad(const float* g, int64_t g_ld, const float* a, int64_t a_ld, int64_t batch, int32_t out_features,
                                 int32_t in_features, float* g_W, float* g_b, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(g && a && g_W && batch >= 0 && out_features >= 1 && in_features >= 1 && g_ld >= out_features && a_ld >= in_features,
                 "nrx_linear_wgrad: bad argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -1573,12 +1573,14 @@ void launch_uniform(const UniformArgs& ua, int64_t batch, bool fm, bool store, h
 extern "C" int nrx_embed_fwd(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
                              float* out, int64_t out_ld, float* wide_out, int64_t wide_ld,
                              float* fm_out, int32_t* status, void* stream) {
+    NRX_TRACE();
     return nrx_embed_fwd_train(feats, n_feats, batch, out, out_ld, wide_out, wide_ld, fm_out, nullptr, 0, status, stream);
 }
 
 extern "C" int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
                                    float* out, int64_t out_ld, float* wide_out, int64_t wide_ld,
                                    float* fm_out, float* fm_sums, int64_t sums_ld, int32_t* status, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_fwd: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0, "nrx_embed_fwd: negative batch");
@@ -1764,6 +1766,7 @@ static int check_fm_grad(const nrx_fm_grad_t* fm, const nrx_feature_t* feats, in
 extern "C" int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
                              const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
                              const nrx_fm_grad_t* fm, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_bwd: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0, "nrx_embed_bwd: negative batch");
@@ -2065,6 +2068,7 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
                                     const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
                                     int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
                                     void* workspace, void* stream) {
+    NRX_TRACE();
     return embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, g_wide, wide_ld, order, seg_start, uniq_keys, n_unique,
                                  n_unique_dev, fm, values, 0, nullptr, nullptr, nullptr, workspace, 0, stream);
 }
@@ -2086,6 +2090,7 @@ extern "C" int nrx_embed_bwd_placed(const nrx_feature_t* feats, int32_t n_feats,
                                     int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
                                     uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
                                     void* workspace, int64_t workspace_bytes, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE((dest != nullptr) == (walk != nullptr) && (dest != nullptr) == (n_walk != nullptr),
                 "nrx_embed_bwd_placed: dest, walk and n_walk come together (all null: no placement)");
     NRX_REQUIRE(workspace == nullptr || workspace_bytes == 0 || workspace_bytes >= nrx_embed_bwd_sorted_workspace(0, dim),

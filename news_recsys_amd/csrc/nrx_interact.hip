@@ -744,6 +744,7 @@ unsigned stream_grid(int64_t items, int per_block) {
 
 extern "C" int nrx_bag_pool_fwd(const float* emb, const float* mask, int64_t batch, int32_t bag_len,
                                 int32_t dim, float* out, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(emb && out && batch >= 0 && bag_len >= 1 && dim >= 1, "nrx_bag_pool_fwd: bad argument");
     if (batch == 0) return NRX_OK;
     hipLaunchKernelGGL(bag_pool_fwd_kernel, dim3(stream_grid(batch * dim, NRX_BLOCK)), dim3(NRX_BLOCK), 0,
@@ -754,6 +755,7 @@ extern "C" int nrx_bag_pool_fwd(const float* emb, const float* mask, int64_t bat
 
 extern "C" int nrx_bag_pool_bwd(const float* g_out, const float* mask, int64_t batch, int32_t bag_len,
                                 int32_t dim, float* g_emb, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(g_out && g_emb && batch >= 0 && bag_len >= 1 && dim >= 1, "nrx_bag_pool_bwd: bad argument");
     if (batch == 0) return NRX_OK;
     const bool vec = (dim & 3) == 0 && nrx_aligned16(g_out) && nrx_aligned16(g_emb);
@@ -767,6 +769,7 @@ extern "C" int nrx_bag_pool_bwd(const float* g_out, const float* mask, int64_t b
 
 extern "C" int nrx_fm_fwd(const float* feat, int64_t ld, int32_t n_fields, int32_t dim, int64_t batch,
                           float* fm_out, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(feat && fm_out && n_fields >= 1 && dim >= 1 && batch >= 0 && ld >= (int64_t)n_fields * dim,
                 "nrx_fm_fwd: bad argument");
     if (batch == 0) return NRX_OK;
@@ -783,6 +786,7 @@ extern "C" int nrx_fm_fwd(const float* feat, int64_t ld, int32_t n_fields, int32
 
 extern "C" int nrx_fm_bwd(const float* feat, int64_t ld, int32_t n_fields, int32_t dim, int64_t batch,
                           const float* g_fm, const float* g_in, int64_t g_in_ld, float* g_feat, int64_t g_ld, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(feat && g_fm && g_feat && n_fields >= 1 && dim >= 1 && batch >= 0, "nrx_fm_bwd: bad argument");
     if (batch == 0) return NRX_OK;
     int ql = ceil_log2i((dim + 3) / 4);
@@ -798,6 +802,7 @@ extern "C" int nrx_fm_bwd(const float* feat, int64_t ld, int32_t n_fields, int32
 
 extern "C" int nrx_dcn_v1_fwd(const float* x, int64_t x_ld, const float* x0, int64_t x0_ld, int64_t batch, int32_t dim,
                               int32_t n_layers, const float* w, const float* b, float* out, int64_t out_ld, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(x && out && batch >= 0 && dim >= 1, "nrx_dcn_v1_fwd: bad argument");
     if (x0 == x && x0_ld == x_ld) x0 = nullptr;
     NRX_REQUIRE(n_layers >= 0 && n_layers <= NRX_MAX_DCN_LAYERS, "nrx_dcn_v1_fwd: n_layers must be in [0, %d]", NRX_MAX_DCN_LAYERS);
@@ -827,6 +832,7 @@ extern "C" int nrx_dcn_v1_fwd(const float* x, int64_t x_ld, const float* x0, int
 extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int64_t x0_ld, int64_t batch, int32_t dim,
                               int32_t n_layers, const float* w, const float* b, const float* g_out, int64_t g_out_ld,
                               float* g_x, int64_t g_x_ld, float* g_x0, int64_t g_x0_ld, float* g_w, float* g_b, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(x && g_out && g_x && batch >= 0 && dim >= 1, "nrx_dcn_v1_bwd: bad argument");
     if (x0 == x && x0_ld == x_ld && g_x0 == nullptr) x0 = nullptr;
     NRX_REQUIRE((x0 == nullptr) == (g_x0 == nullptr), "nrx_dcn_v1_bwd: x0 and g_x0 go together (both null: x0 is x, one gradient)");
@@ -943,6 +949,7 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
 extern "C" int nrx_embed_dcn_v1_fwd(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t width,
                                     float* out, int64_t out_ld, int32_t n_layers, const float* w, const float* b,
                                     int32_t* status, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_dcn_v1_fwd: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0 && out != nullptr && width >= 4, "nrx_embed_dcn_v1_fwd: bad argument");

@@ -273,6 +273,7 @@ extern "C" int64_t nrx_bucketize_workspace(int64_t n, int32_t world) {
 extern "C" int nrx_bucketize_by_owner(const void* ids, int32_t index_bits, int64_t n, int32_t world,
                                       int64_t* counts, int64_t* local_rows, int64_t* slot,
                                       int64_t* workspace, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(world >= 1 && world <= 64, "nrx_bucketize_by_owner: world must be in [1, 64]");
     NRX_REQUIRE(index_bits == 32 || index_bits == 64, "nrx_bucketize_by_owner: index_bits must be 32 or 64");
     NRX_REQUIRE(n >= 0 && counts && workspace, "nrx_bucketize_by_owner: bad argument");
@@ -295,6 +296,7 @@ extern "C" int nrx_gather_rows_segmented(const float* const* tables, const int64
                                          const int64_t* seg_start, const int32_t* seg_table, int32_t n_seg,
                                          int64_t n_rows, int32_t dim, const int64_t* local_rows,
                                          float* out_rows, int32_t* status, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(tables && table_rows && n_tables >= 1 && n_tables <= NRX_MAX_FEATURES,
                 "nrx_gather_rows_segmented: n_tables must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(seg_start && seg_table && n_seg >= 1 && n_seg <= 4096, "nrx_gather_rows_segmented: n_seg must be in [1, 4096]");
@@ -329,6 +331,7 @@ extern "C" int nrx_scatter_add_rows_segmented(float* const* grad_tables, const i
                                               const int64_t* seg_start, const int32_t* seg_table, int32_t n_seg,
                                               int64_t n_rows, int32_t dim, const int64_t* local_rows,
                                               const float* g_rows, int32_t skip_row0, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(grad_tables && table_rows && n_tables >= 1 && n_tables <= NRX_MAX_FEATURES,
                 "nrx_scatter_add_rows_segmented: n_tables must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(seg_start && seg_table && n_seg >= 1 && n_seg <= 4096, "nrx_scatter_add_rows_segmented: n_seg must be in [1, 4096]");
@@ -359,6 +362,7 @@ extern "C" int nrx_scatter_add_rows_segmented(float* const* grad_tables, const i
 
 extern "C" int nrx_csr_to_padded(const void* values, int32_t value_bits, const int64_t* offsets, const int64_t* rows, int64_t batch,
                                  int32_t bag_len, void* ids_out, float* mask_out, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(value_bits == 32 || value_bits == 64, "nrx_csr_to_padded: value_bits must be 32 or 64");
     NRX_REQUIRE(batch >= 0 && bag_len >= 1, "nrx_csr_to_padded: bad argument");
     if (batch == 0) return NRX_OK;
@@ -378,6 +382,7 @@ extern "C" int nrx_csr_to_padded(const void* values, int32_t value_bits, const i
 
 extern "C" int nrx_user_rank_metrics(const float* scores, const float* labels, const int64_t* seg_start, int64_t n_users,
                                      int32_t k, double* auc, double* ndcg, double* hr, double* mrr, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(n_users >= 0 && k >= 1, "nrx_user_rank_metrics: bad argument");
     if (n_users == 0) return NRX_OK;
     NRX_REQUIRE(scores && labels && seg_start && auc && ndcg && hr && mrr, "nrx_user_rank_metrics: null buffer");
@@ -390,6 +395,7 @@ extern "C" int nrx_user_rank_metrics(const float* scores, const float* labels, c
 }
 
 extern "C" int nrx_mask_lengths(const float* mask, int64_t batch, int32_t bag_len, int64_t* lens, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(batch >= 0 && bag_len >= 1, "nrx_mask_lengths: bad argument");
     if (batch == 0) return NRX_OK;
     NRX_REQUIRE(mask && lens, "nrx_mask_lengths: null buffer");

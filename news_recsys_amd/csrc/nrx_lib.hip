@@ -11,6 +11,33 @@ void nrx_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- roctx ranges (see NRX_TRACE in nrx_common.h)
+#include <dlfcn.h>
+int nrx_trace_on = -1;
+namespace {
+int (*g_roctx_push)(const char*) = nullptr;
+int (*g_roctx_pop)() = nullptr;
+}
+void nrx_trace_push(const char* name) {
+    if (nrx_trace_on < 0) {
+        nrx_trace_on = 0;
+        const char* e = getenv("NRX_ROCTX");
+        if (e && e[0] == '1') {
+            void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) {
+                g_roctx_push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                g_roctx_pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (g_roctx_push && g_roctx_pop) nrx_trace_on = 1;
+            }
+        }
+    }
+    if (nrx_trace_on == 1) g_roctx_push(name);
+}
+void nrx_trace_pop() {
+    if (nrx_trace_on == 1 && g_roctx_pop) g_roctx_pop();
+}
+
 // Zero-fill as a KERNEL.  hipMemsetAsync is avoided throughout the library: inside a captured HIP graph (news_recsys_amd/graph.py)
 // a small memset node did not take effect on replay on this stack (ROCm 7.0 / gfx950) -- counters that a call clears kept their
 // values from the previous replay.  A kernel node replays like any other launch.
@@ -55,6 +82,7 @@ __global__ __launch_bounds__(256) void nrx_copy_kernel(const nrx_f32x4* __restri
 }  // namespace
 
 extern "C" int nrx_stream_copy(void* dst, const void* src, int64_t bytes, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(dst != nullptr && src != nullptr && bytes >= 0 && (bytes & 15) == 0 && nrx_aligned16(dst) && nrx_aligned16(src),
                 "nrx_stream_copy: buffers must be 16-byte aligned and a multiple of 16 bytes long");
     if (bytes == 0) return NRX_OK;
@@ -85,6 +113,7 @@ extern "C" int nrx_abi_version(void) { return NRX_ABI_VERSION; }
 extern "C" const char* nrx_last_error(void) { return g_err; }
 
 extern "C" int nrx_device_info(int device, int64_t info[6]) {
+    NRX_TRACE();
     hipDeviceProp_t p;
     hipError_t e = hipGetDeviceProperties(&p, device);
     if (e != hipSuccess) {

@@ -739,6 +739,7 @@ extern "C" int64_t nrx_route_workspace(int64_t n_total, int32_t world) {
 extern "C" int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_t n_feats, int32_t index_bits,
                              int32_t world, int64_t cap, int32_t* send_rows, int32_t* slot, int64_t* counts2d,
                              int64_t* overflow, int64_t* workspace, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(ids && lens && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES, "nrx_route_ids: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(index_bits == 32 || index_bits == 64, "nrx_route_ids: index_bits must be 32 or 64");
     NRX_REQUIRE(world >= 1 && world <= 64 && cap >= 1 && cap * world <= 0x7fffffffLL, "nrx_route_ids: bad world / cap");
@@ -789,6 +790,7 @@ extern "C" int nrx_gather_inbox(const float* const* tables, const int64_t* table
                                 const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,
                                 const int64_t* recv2d, const int32_t* inbox_rows, int32_t dim,
                                 float* out_rows, int32_t* status, void* stream) {
+    NRX_TRACE();
     InboxArgs a;
     int rc = fill_inbox_args(a, const_cast<float* const*>(tables), table_rows, n_tables, feat_table, n_feats, world, cap,
                              recv2d, inbox_rows, dim, "nrx_gather_inbox");
@@ -804,6 +806,7 @@ extern "C" int nrx_scatter_add_inbox(float* const* grad_tables, const int64_t* t
                                      const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,
                                      const int64_t* recv2d, const int32_t* inbox_rows, int32_t dim,
                                      const float* g_rows, int32_t skip_row0, void* stream) {
+    NRX_TRACE();
     InboxArgs a;
     int rc = fill_inbox_args(a, grad_tables, table_rows, n_tables, feat_table, n_feats, world, cap, recv2d, inbox_rows, dim,
                              "nrx_scatter_add_inbox");
@@ -816,6 +819,7 @@ extern "C" int nrx_scatter_add_inbox(float* const* grad_tables, const int64_t* t
 }
 
 extern "C" int nrx_bag_norm_weights(const float* mask, int64_t batch, int32_t bag_len, int32_t kind, float* out_w, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(out_w && batch >= 0 && bag_len >= 1, "nrx_bag_norm_weights: bad argument");
     NRX_REQUIRE(kind == NRX_BAG_MASKED_MEAN || kind == NRX_BAG_MEAN || kind == NRX_BAG_SUM, "nrx_bag_norm_weights: bad kind");
     NRX_REQUIRE(kind != NRX_BAG_MASKED_MEAN || mask != nullptr, "nrx_bag_norm_weights: masked mean needs a mask");
@@ -832,6 +836,7 @@ extern "C" int nrx_route_bags(const void* const* ids, const float* const* weight
                               int32_t index_bits, int64_t batch, int32_t world, int64_t cap, int32_t* send_rows,
                               int32_t* send_tag, float* send_w, int64_t* counts2d, int64_t* overflow, int64_t* workspace,
                               void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(ids && bag_lens && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES, "nrx_route_bags: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(index_bits == 32 || index_bits == 64, "nrx_route_bags: index_bits must be 32 or 64");
     NRX_REQUIRE(world >= 1 && world <= 64 && cap >= 1 && cap * world <= 0x7fffffffLL && batch >= 0, "nrx_route_bags: bad world / cap / batch");
@@ -921,6 +926,7 @@ extern "C" int nrx_pool_inbox_fwd(const float* const* tables, const int64_t* tab
                                   int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
                                   const int32_t* inbox_rows, const int32_t* inbox_tag, const float* inbox_w, int32_t dim,
                                   float* partial, void* workspace, int32_t* status, void* stream) {
+    NRX_TRACE();
     PoolArgs a;
     int rc = fill_pool_args(a, const_cast<float* const*>(tables), table_rows, n_tables, feat_table, n_feats, batch, world, cap, recv2d,
                             inbox_rows, inbox_tag, inbox_w, dim, "nrx_pool_inbox_fwd");
@@ -951,6 +957,7 @@ extern "C" int nrx_pool_inbox_bwd(float* const* grad_tables, const int64_t* tabl
                                   int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
                                   const int32_t* inbox_rows, const int32_t* inbox_tag, const float* inbox_w, int32_t dim,
                                   const float* g_partial, int32_t skip_row0, void* stream) {
+    NRX_TRACE();
     PoolArgs a;
     int rc = fill_pool_args(a, grad_tables, table_rows, n_tables, feat_table, n_feats, batch, world, cap, recv2d, inbox_rows, inbox_tag,
                             inbox_w, dim, "nrx_pool_inbox_bwd");
@@ -975,6 +982,7 @@ extern "C" int nrx_pool_inbox_bwd(float* const* grad_tables, const int64_t* tabl
 
 extern "C" int nrx_make_table_keys(const void* const* ids, const int64_t* lens, const int32_t* table_of,
                                    int32_t n_feats, int32_t index_bits, int64_t* keys, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(ids && lens && table_of && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_make_table_keys: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(index_bits == 32 || index_bits == 64, "nrx_make_table_keys: index_bits must be 32 or 64");

@@ -904,6 +904,7 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
 extern "C" int nrx_sparse_plan(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
                                int32_t n_feats, int32_t index_bits, int32_t n_tables, int64_t* order, int64_t* uniq_keys,
                                int64_t* seg_start, int64_t* counts, void* workspace, void* stream) {
+    NRX_TRACE();
     return sparse_plan_impl(ids, lens, table_of, rows, n_feats, index_bits, n_tables, order, uniq_keys, seg_start, counts, 0, nullptr,
                             nullptr, nullptr, workspace, stream);
 }
@@ -912,6 +913,7 @@ extern "C" int nrx_sparse_plan_place(const void* const* ids, const int64_t* lens
                                      int32_t n_feats, int32_t index_bits, int32_t n_tables, uint64_t place_feats, int64_t* order,
                                      int64_t* uniq_keys, int64_t* seg_start, int64_t* counts, int32_t* dest, int32_t* walk,
                                      int64_t* n_walk, void* workspace, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(dest != nullptr && walk != nullptr && n_walk != nullptr, "nrx_sparse_plan_place: null placement buffer");
     return sparse_plan_impl(ids, lens, table_of, rows, n_feats, index_bits, n_tables, order, uniq_keys, seg_start, counts, place_feats,
                             dest, walk, n_walk, workspace, stream);
@@ -1089,6 +1091,7 @@ extern "C" int nrx_route_ids_dedup(const void* const* ids, const int64_t* lens, 
                                    int32_t n_feats, int32_t n_tables, int32_t index_bits, int32_t world, int64_t cap,
                                    int32_t* send_rows, int32_t* slot, int64_t* counts2d, int64_t* overflow, void* workspace,
                                    void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(ids && lens && table_of && table_local_rows && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES && n_tables >= 1 &&
                     n_tables <= NRX_MAX_FEATURES, "nrx_route_ids_dedup: bad feature / table count");
     NRX_REQUIRE(index_bits == 32 || index_bits == 64, "nrx_route_ids_dedup: index_bits must be 32 or 64");
@@ -1171,6 +1174,7 @@ extern "C" int64_t nrx_unique_inverse_workspace(int64_t n) { return nrx_route_de
 
 extern "C" int nrx_unique_inverse(const void* ids, int32_t index_bits, int64_t n, int64_t* unique_out, int64_t* inverse_out,
                                   int64_t* n_unique, void* workspace, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE((index_bits == 32 || index_bits == 64) && n >= 0 && n < 0x7fffffffLL, "nrx_unique_inverse: bad argument");
     NRX_REQUIRE(n_unique != nullptr, "nrx_unique_inverse: null n_unique");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1318,6 +1322,7 @@ extern "C" int nrx_sparse_adam_step(float* const* tables, float* const* exp_avg,
                                     int32_t dim, const int64_t* uniq_keys, const float* grads, int64_t n_unique,
                                     const int64_t* n_unique_dev, float step_size, const float* step_size_dev, float beta1,
                                     float beta2, float eps, float lr_times_weight_decay, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(n_tables >= 1 && n_tables <= NRX_MAX_FEATURES && dim >= 1 && n_unique >= 0, "nrx_sparse_adam_step: bad argument");
     if (n_unique == 0) return NRX_OK;
     NRX_REQUIRE(tables && exp_avg && exp_avg_sq && uniq_keys && grads, "nrx_sparse_adam_step: null buffer");

@@ -264,6 +264,7 @@ extern "C" int64_t nrx_topk_workspace(int64_t n_items, int64_t n_queries, int32_
 extern "C" int nrx_topk_ip(const float* items, int64_t n_items, int32_t dim, const float* queries, int64_t n_queries,
                            int32_t k, const int64_t* excl_offsets, const int64_t* excl_items,
                            int64_t* out_idx, float* out_score, void* workspace, void* stream) {
+    NRX_TRACE();
     NRX_REQUIRE(n_items >= 0 && n_items < 0x7fffffffLL && n_queries >= 0 && k >= 1, "nrx_topk_ip: bad argument");
     if (k > KMAX || (dim & 3) != 0 || dim < 4 || dim > 128) {
         nrx_set_error("nrx_topk_ip: supports k <= %d and dim %% 4 == 0 with 4 <= dim <= 128 (got k=%d dim=%d)", KMAX, k, dim);
