@@ -1640,9 +1640,12 @@ extern "C" int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, 
     auto eligible = [&](const nrx_feature_t& s) {
         const int q = s.dim / 4;
         return s.kind == NRX_SPARSE && s.wide_col < 0 && s.index_bits == feats[0].index_bits && s.table != nullptr &&
-               nrx_aligned16(s.table) && (s.out_col & 3) == 0 && s.rows >= 1 && (s.dim & 3) == 0 && q >= 4 && q <= 64 && (q & (q - 1)) == 0;
+               nrx_aligned16(s.table) && s.rows >= 1 && (s.dim & 3) == 0 && q >= 4 && q <= 64 && (q & (q - 1)) == 0;
     };
-    const bool out_ok = (out == nullptr) || (nrx_aligned16(out) && (out_ld & 3) == 0);
+    // (first columns that are no multiple of 4 floats -- a dense value earlier in the sorted order -- and an unaligned `out` take the
+    // ring kernel's dword-aligned store form: UniformArgs::unal; they used to drop to the generic kernel, 0.33 vs 0.6+ of peak)
+    const bool out_ok = true;
+    const bool out_al = (out == nullptr) || (nrx_aligned16(out) && (out_ld & 3) == 0);
     int n_fm = 0, n_dims = 0, n_el = 0;
     int dims_seen[8];
     bool el[NRX_MAX_FEATURES];
@@ -1675,6 +1678,9 @@ extern "C" int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, 
             const int D0 = dims_seen[g], Q0 = D0 / 4;
             UniformArgs ua;
             int n = 0;
+            bool unal = !out_al;
+            for (int i = 0; i < n_feats; ++i)
+                if (el[i] && feats[i].dim == D0) unal |= (feats[i].out_col & 3) != 0;
             for (int i = 0; i < n_feats; ++i) {
                 if (!el[i] || feats[i].dim != D0) continue;
                 NRX_REQUIRE(feats[i].index != nullptr, "nrx_embed_fwd: feature %d: null index pointer", i);
@@ -1682,13 +1688,14 @@ extern "C" int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, 
                 ua.table[n] = feats[i].table;
                 ua.index[n] = feats[i].index;
                 ua.rows[n] = feats[i].rows;
-                ua.col4[n] = feats[i].out_col / 4;
+                ua.col4[n] = unal ? feats[i].out_col : feats[i].out_col / 4;
                 ua.feat_id[n] = (uint8_t)i;
                 ++n;
             }
             ua.batch = batch;
             ua.out = reinterpret_cast<float4*>(out);
-            ua.ld4 = out_ld / 4;
+            ua.ld4 = unal ? out_ld : out_ld / 4;
+            ua.unal = unal ? 1 : 0;
             ua.fm_out = fm_out;
             ua.fm_sums = (fm_out != nullptr && n_fm > 0) ? fm_sums : nullptr;
             ua.sums_ld = sums_ld;

@@ -36,8 +36,12 @@ struct UniformArgs {
     int32_t* status;
     int32_t n;
     int32_t idx64;                    // ids are int64 (else int32)
+    int32_t unal;                     // 1: some first column (or `out` / out_ld) is not a multiple of 4 floats -- a dense value in the
+                                      //    middle of the sorted feature order shifts everything after it: col4[] and ld4 are then in
+                                      //    FLOATS and the row leaves as a dword-aligned 16-byte store (global memory needs no more)
 };
 static_assert(sizeof(UniformArgs) <= 3584, "kernarg budget");
+typedef float nrx_ring_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // FM bookkeeping for one field chunk held by this lane (columns k0..k0+3 of the field):
 // column 0 is the first-order weight, columns 1.. are the factor vector.
@@ -92,7 +96,8 @@ __device__ __forceinline__ void consume(const NRX_CONST UniformArgs* a, int f, f
     if (STORE) {
         nrx_f32x4 t;
         t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-        ((NRX_GLOBAL nrx_f32x4*)(a->out))[row4 + a->col4[f]] = t;
+        if (a->unal) *(NRX_GLOBAL nrx_ring_f32x4u*)((NRX_GLOBAL float*)(a->out) + row4 + a->col4[f]) = t;      // row4 = b * ld + 4 q, in floats
+        else ((NRX_GLOBAL nrx_f32x4*)(a->out))[row4 + a->col4[f]] = t;
     }
     if (FM) fm_accumulate(v, q * 4, 4 * Q, fm_first, fm_s, fm_q);
 }
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(NRX_BLOCK, MINW) void embed_fwd_ring(const UniformA
     const int64_t b = b0 + sb;
     if (b >= a->batch) return;   // the Q lanes of a sample leave together: the FM shuffle stays inside the group
     const int32_t* s_my = s_ids + sb;
-    const int64_t row4 = b * a->ld4 + q;
+    const int64_t row4 = a->unal ? b * a->ld4 + 4 * q : b * a->ld4 + q;
 
     float fm_first = 0.f;
     float4 fm_s = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -1236,3 +1236,38 @@ def test_uniform_wide_split_bit_exact_vs_oracle(B, F, D, wide_every, idx_dtype):
         bad = [x.clone() for x in inputs]
         bad[-1][0] = 10 ** 6
         ops.embed_apply(plan, [t.detach() for t in tt], bad, weights)
+
+
+@pytest.mark.parametrize("B", [3000, 70000])
+@pytest.mark.parametrize("idx", [torch.int64, torch.int32])
+def test_dense_value_mid_order_keeps_later_features_on_the_ring_kernel(B, idx, monkeypatch):
+    """A dense value (one column) in the middle of the sorted feature order makes every later feature's first column a
+    non-multiple of 4 floats.  Those features now take the ring kernel's dword-aligned store form (UniformArgs::unal) instead of
+    the generic kernel; the concat (base_model.py:284-308) must be the same bits either way: checked against the numpy oracle's
+    gather / concat (verbatim copies) for widths 16 / 32 / 64 around two dense values, also with an `out` whose row stride and
+    base are not 16-byte aligned."""
+    monkeypatch.setenv("NRX_SPLIT_MIN_LOOKUPS", "1")            # take the per-width uniform launches at any batch
+    rng = np.random.default_rng(B)
+    dims = [16, 32, 16, 64, 32, 16, 16, 64, 32, 32, 16, 64]
+    slots, tables, inputs, col = [], [], [], 0
+    for i, d in enumerate(dims):
+        if i in (3, 8):                                         # dense values in the middle of the order
+            slots.append(ops.Slot(f"d{i}", NRX_DENSE, -1, 1, 0, col))
+            inputs.append(dev(rng.random(B).astype(np.float32)))
+            col += 1
+        rows = 500 + 37 * i
+        tables.append(dev(rng.standard_normal((rows, d)).astype(np.float32)))
+        slots.append(ops.Slot(f"f{i:02d}", NRX_SPARSE, len(tables) - 1, d, 0, col))
+        inputs.append(dev(rng.integers(0, rows, B)).to(idx))
+        col += d
+    plan = ops.EmbedPlan(slots, out_width=col)
+    out = ops.embed_apply(plan, tables, inputs, [None] * len(slots), index_check="sync")[0]
+    out_pad = ops.embed_apply(plan, tables, inputs, [None] * len(slots), out_ld=col + 3, index_check="sync")[0]      # odd row stride
+    ref = np.zeros((B, col), np.float32)
+    for s, x in zip(slots, inputs):
+        if s.kind == NRX_DENSE:
+            ref[:, s.out_col] = x.cpu().numpy()
+        else:
+            ref[:, s.out_col:s.out_col + s.dim] = tables[s.table].cpu().numpy()[x.cpu().numpy()]
+    assert np.array_equal(out.cpu().numpy(), ref)
+    assert np.array_equal(out_pad.cpu().numpy()[:, :col], ref)

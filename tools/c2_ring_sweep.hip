@@ -92,6 +92,7 @@ int main(int argc, char** argv) {
     };
     auto ua_for = [&](int pl, float* out, float* fmo) {
         UniformArgs ua;
+        ua.unal = 0;
         for (int i = 0; i < NRX_MAX_FEATURES; ++i) ua.feat_id[i] = (uint8_t)i;
         for (int f = 0; f < F; ++f) { ua.table[f] = tables[f]; ua.index[f] = ids[pl][f]; ua.rows[f] = rows; ua.col4[f] = f * Q; }
         ua.batch = B; ua.out = (float4*)out; ua.ld4 = (int64_t)F * Q; ua.fm_out = fmo; ua.fm_sums = nullptr; ua.sums_ld = 0; ua.status = status; ua.n = F; ua.idx64 = 1;
