@@ -835,7 +835,7 @@ def main():
                                     "algorithmic_bytes_definition": "forward (training form: + 4D field sums written per sample for FM) + backward: per lookup 8 B id (planner) "
                                                                     "+ 4D upstream row read (+ 4 B weight for a bag lookup) (+ 4D forward value read for FM fields) + 4D gradient "
                                                                     "row written + 8 B key written; per sample 4D field sums + 4 B g_fm read (FM).  The sort's own traffic is not counted",
-                                    "traffic": _traffic(args.workload + "_fwd_bwd"), "traffic_unit": "bytes/step",
+                                    "traffic": _traffic(args.workload + "_fwd_bwd") if args.ids == "uniform" else None, "traffic_unit": "bytes/step",
                                     "note": "achieved = algorithmic bytes per step / mean step time (HIP events over the timed steps: forward + planning + "
                                             "reduction, ~10 launches); traffic = fabric bytes per step summed over those launches from the committed PMC passes"},
                        "mode": "forward (training form: + FM field sums) + deterministic row-sparse backward: nrx_sparse_plan "

@@ -1926,6 +1926,7 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
     // threshold sweep (T = 16 / 24 / 32 / 48 / 64, fwd+bwd us): C4 521 / 505 / 493 / 492 / 492, C4 Zipf 581 / 575 / 564 / 598 / 674,
     // C2 Zipf 501 / 545 / 588 / 678 / 758, C5 478 / 491 / 527 / 578 / 618: bag launches (a few rows, each looked up ~L times) take 32
     if (has_bag) a.long_t = 2 * SORTED_LONG_T;
+    if (const char* e = getenv("NRX_LONG_T")) { const int v = atoi(e); if (v >= 2 && v <= 256) a.long_t = v; }      // measurement knob
     // placement mode: single-lookup rows are stored by the placement pass, the walk reduces the listed rows only
     const bool placed = fast && dest != nullptr;
     if (fast) {
@@ -1957,6 +1958,7 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
         }
         const int64_t groups = (n_rows + (wide_pass ? RB : R) - 1) / (wide_pass ? RB : R);
         const unsigned grid = (unsigned)((groups + tb - 1) / tb);
+        // (4 rows x 4 entries per lane group instead of 2 x 4: C5 446.9 -> 458.1 us, C3 163.2 -> 169.6 -- measured, not kept)
         if (workspace != nullptr) {        // long segments (hot rows) go through the wavefront-per-item path
             a.long_ws = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15);
             a.long_items_cap = off / SORTED_LONG_T + 8;
