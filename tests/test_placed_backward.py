@@ -87,7 +87,7 @@ def test_placed_backward_with_bag_features_equals_sorted_walk(kind, dist, monkey
     """The DSSM tower shape: item id + history bag (sharing the news table) + user id.  Only the single-valued features'
     lookups may be placed; a news row met once by the HISTORY is walked (its upstream row is scaled, not copied)."""
     rng = np.random.default_rng(17 + kind)
-    D, L, B, news, users = 16, 9, 2100, 6000, 50000
+    D, L, B, news, users = 16, 5, 2100, 6000, 50000        # (2 single-valued lookups of 7 per sample: above the quarter from which the plan places)
     slots = [ops.Slot("item_id", NRX_SPARSE, 0, D, 0, 0), ops.Slot("user_history", kind, 0, D, L, D), ops.Slot("user_id", NRX_SPARSE, 1, D, 0, 2 * D)]
     plan = ops.EmbedPlan(slots, out_width=3 * D)
     tables = [torch.from_numpy(rng.standard_normal((r, D)).astype(np.float32)).to(DEV) for r in (news, users)]
