@@ -48,8 +48,8 @@ class DCNNet(nn.Module):
     def forward(self, x):
         if len(self.cross_net) == 0:
             return x
-        w, b = self.stacked()
-        return ops.dcn_v1(x, w, b)
+        # the layers' own [dim, 1] parameters go in as they are (packed inside the op, outside autograd): no torch.stack nodes
+        return ops.dcn_v1_layers(x, [l.w for l in self.cross_net], [l.b for l in self.cross_net])
 
     def forward_cat_(self, buf):
         """buf [B, 2D] with x in the left half: fills the right half with cross(x) in place."""

@@ -1167,6 +1167,50 @@ class _DcnV1Fn(torch.autograd.Function):
         return gx, gw, gb, gx0
 
 
+class _DcnV1LayersFn(torch.autograd.Function):
+    """The v1 stack fed with the layers' OWN parameters (w_l, b_l of shape [dim, 1], what DCNLayer holds, dcn_arch.py:5-12): packed into
+    the [n_layers, dim] arrays the kernel reads inside forward -- outside autograd, so no stack / unbind nodes and no stacked gradient to
+    split: the per-layer gradients are views of the kernel's [n_layers, dim] outputs."""
+
+    @staticmethod
+    def forward(ctx, x, n, *params):
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        B, D = x.shape
+        w = torch.cat([p.reshape(1, -1) for p in params[:n]]).float()
+        b = torch.cat([p.reshape(1, -1) for p in params[n:]]).float()
+        if tuple(w.shape) != (n, D) or tuple(b.shape) != (n, D):
+            raise ValueError(f"cross weights are for dim {w.shape[1]}, input has dim {D}")
+        out = torch.empty_like(x)
+        check(lib.nrx_dcn_v1_fwd(x.data_ptr(), D, None, D, B, D, n, w.data_ptr(), b.data_ptr(), out.data_ptr(), D, _stream_ptr(x)),
+              "nrx_dcn_v1_fwd")
+        ctx.save_for_backward(x, w, b)
+        ctx.n, ctx.shapes = n, [p.shape for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, w, b = ctx.saved_tensors
+        g = _f32c(g, "grad")
+        B, D = x.shape
+        n = ctx.n
+        gx = torch.empty_like(x)
+        gw = torch.zeros_like(w)
+        gb = torch.zeros_like(b)
+        check(lib.nrx_dcn_v1_bwd(x.data_ptr(), D, None, D, B, D, n, w.data_ptr(), b.data_ptr(), g.data_ptr(), D, gx.data_ptr(), D, None, D,
+                                 gw.data_ptr(), gb.data_ptr(), _stream_ptr(x)), "nrx_dcn_v1_bwd")
+        grads = [gw[l].reshape(ctx.shapes[l]) for l in range(n)] + [gb[l].reshape(ctx.shapes[n + l]) for l in range(n)]
+        return (gx, None, *grads)
+
+
+def dcn_v1_layers(x: torch.Tensor, ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor]) -> torch.Tensor:
+    """DCNNet.forward (dcn_arch.py:63-70) from the layers' own parameter tensors (each [dim, 1] or [dim])."""
+    if len(ws) != len(bs) or not ws:
+        raise ValueError("dcn_v1_layers: one w and one b per layer")
+    return _DcnV1LayersFn.apply(x, len(ws), *ws, *bs)
+
+
 def dcn_v1(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, x0: Optional[torch.Tensor] = None) -> torch.Tensor:
     """DCNNet.forward (dcn_arch.py:63-70): all cross layers fused; w, b are [n_layers, dim].  With `x0` the stack
     starts from a later layer's input x (= x_l) and x0 is the cross network's layer-0 input -- the per-layer call
