@@ -17,7 +17,7 @@ from typing import Optional
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnrx_hip.so")
+LIB_PATH = os.environ.get("NRX_LIB") or os.path.join(_HERE, "lib", "libnrx_hip.so")      # NRX_LIB: another build of the library (A/B runs)
 
 NRX_ABI_VERSION = 2
 NRX_MAX_FEATURES = 64

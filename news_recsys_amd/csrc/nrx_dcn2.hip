@@ -259,7 +259,11 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_bf16x3_kernel(const float
                                                                   int64_t M, int N, const float* __restrict__ W, const float* __restrict__ bias,
                                                                   float* __restrict__ out, int64_t out_ld, unsigned nx,
                                                                   float* __restrict__ lin_out) {
-    __shared__ __attribute__((aligned(16))) unsigned short Ah[BM * LDH], Al[BM * LDH], Wh[BN * LDH], Wl[BN * LDH];
+    __shared__ __attribute__((aligned(16))) unsigned short s_all[2 * BM * LDH + 2 * BN * LDH];      // one array: the epilogue reuses it
+    unsigned short* const Ah = s_all;
+    unsigned short* const Al = Ah + BM * LDH;
+    unsigned short* const Wh = Al + BM * LDH;
+    unsigned short* const Wl = Wh + BN * LDH;
     const int K = N;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -347,36 +351,47 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_bf16x3_kernel(const float
         }
         __syncthreads();
     }
-    // epilogue: the fp32 kernel's (same C layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
-    const int col = n0 + wn * 32 + l31;
+    // Epilogue through LDS: an accumulator tile is "one column per lane" (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)),
+    // so applied straight from the registers every x_l / x_0 / lin / out access is a 4-byte one -- 16 instructions per array and tile.  With
+    // the matrix time gone those were the kernel: 89 us inference, 147 us in training form (two more arrays) at D = 320.  Each wavefront
+    // transposes its tile through its own 4.6 KB of LDS (the operand buffers are free now) and a lane owns 4 CONSECUTIVE columns of a
+    // row: 16-byte accesses, 8 rows x 128 bytes per instruction, 4 instructions per array and tile.
+    float* s_t = reinterpret_cast<float*>(s_all) + wid * (32 * 36);       // [32 rows][36 floats] per wavefront: 4 x 4608 of the 30720 bytes
+    const int er = lane >> 3, ec = (lane & 7) * 4;                         // this lane's row (of 8 per pass) and first column in the tile
+    const int colv = n0 + wn * 32 + ec;
     const bool same_x = (x0 == xl);
-    if (col < N) {
-        const float bc = bias[col];
-        const int64_t r0 = m0 + wm * (32 * TM);
-        const uint32_t lo = (uint32_t)(((int64_t)(4 * hi) * ld + col) * 4);
-        const uint32_t lo_o = (uint32_t)(((int64_t)(4 * hi) * out_ld + col) * 4);
-        const bool full = r0 + 32 * TM <= M;
+    const bool col_ok = colv < N;                                          // N % 4 == 0: the four columns are in or out together
+    const float4 bc = col_ok ? *reinterpret_cast<const float4*>(bias + colv) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t r0 = m0 + wm * (32 * TM);
 #pragma unroll
-        for (int t = 0; t < TM; ++t) {
-            float xv[16], x0v[16];
+    for (int t = 0; t < TM; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2);
-                if (!full && row + 4 * hi >= M) row = M - 1 - 4 * hi;          // clamp: the value is never stored
-                xv[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xl + row * ld) + lo);
-                x0v[r] = same_x ? xv[r] : *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x0 + row * ld) + lo);
+        for (int r = 0; r < 16; ++r) s_t[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36 + l31] = acc[t][r];
+        // (the wavefront reads back what it wrote: no block barrier -- the LDS operations of one wavefront complete in order; the
+        // waits keep the compiler from moving accesses across them)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float4 lin4[4], xv[4], x0v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lin4[j] = *reinterpret_cast<const float4*>(&s_t[(er + 8 * j) * 36 + ec]);
+            int64_t row = r0 + t * 32 + er + 8 * j;
+            row = row < M ? row : M - 1;                                    // clamp: the value is never stored
+            if (col_ok) {
+                xv[j] = *reinterpret_cast<const float4*>(xl + row * ld + colv);
+                x0v[j] = same_x ? xv[j] : *reinterpret_cast<const float4*>(x0 + row * ld + colv);
             }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2);
-                if (!full && row + 4 * hi >= M) continue;
-                const float lin = acc[t][r] + bc;
-                if (lin_out != nullptr)
-                    *reinterpret_cast<float*>(reinterpret_cast<char*>(lin_out + row * ld) + lo) = lin;
-                float v = fmaf(x0v[r], lin, xv[r]);
-                if (RELU) v = fmaxf(v, 0.f);
-                *reinterpret_cast<float*>(reinterpret_cast<char*>(out + row * out_ld) + lo_o) = v;
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int64_t row = r0 + t * 32 + er + 8 * j;
+            if (row >= M || !col_ok) continue;
+            const float4 lin = make_float4(lin4[j].x + bc.x, lin4[j].y + bc.y, lin4[j].z + bc.z, lin4[j].w + bc.w);
+            if (lin_out != nullptr) *reinterpret_cast<float4*>(lin_out + row * ld + colv) = lin;
+            float4 v = make_float4(fmaf(x0v[j].x, lin.x, xv[j].x), fmaf(x0v[j].y, lin.y, xv[j].y), fmaf(x0v[j].z, lin.z, xv[j].z),
+                                   fmaf(x0v[j].w, lin.w, xv[j].w));
+            if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            *reinterpret_cast<float4*>(out + row * out_ld + colv) = v;
         }
     }
 }
@@ -400,7 +415,9 @@ extern "C" int nrx_dcn_v2_layer_fwd(const float* x0, const float* xl, int64_t ld
     dim3 grid((unsigned)nblocks);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define NRX_DCN2(R_, V_) hipLaunchKernelGGL((dcn_v2_layer_kernel<R_, V_>), grid, dim3(256), 0, st, x0, xl, ld, batch, dim, W, bias, out, out_ld, nx, lin_out)
-    if (split && vec && batch >= 8) {        // (unaligned shapes and tiny batches take the fp32 kernel: more exact, never wrong)
+    const bool vec_epi = nrx_aligned16(x0) && nrx_aligned16(out) && (out_ld & 3) == 0 && nrx_aligned16(bias) &&
+                         (lin_out == nullptr || nrx_aligned16(lin_out));      // the split kernel's epilogue moves 16-byte pieces
+    if (split && vec && vec_epi && batch >= 8) {        // (unaligned shapes and tiny batches take the fp32 kernel: more exact, never wrong)
         if (relu) hipLaunchKernelGGL((dcn_v2_layer_bf16x3_kernel<true>), grid, dim3(256), 0, st, x0, xl, ld, batch, dim, W, bias, out, out_ld, nx, lin_out);
         else hipLaunchKernelGGL((dcn_v2_layer_bf16x3_kernel<false>), grid, dim3(256), 0, st, x0, xl, ld, batch, dim, W, bias, out, out_ld, nx, lin_out);
     } else
