@@ -187,6 +187,31 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM], int64_t m
 //   WGRAD: A(m, k) = glin[k * lda + m]   (K-major)     B(k, n) = xl[k * ldb + n]  (K-major)   epilogue: atomicAdd(out[m, n], C)
 // M, N, K are the GEMM's own dims (DGRAD: batch, D, D;  WGRAD: D, D, batch).  Rows / columns past M / N are clamped on
 // load (their products land in accumulator rows / columns that are never stored); a partial last K slab is zero-filled.
+// Block -> (tile, batch slice).  Hardware places block b on XCD b % 8, each XCD has its own L2.
+//   DGRAD (one slice): the nx column tiles of one row panel are consecutive on ONE XCD and share the panel in its L2 (the forward's
+//   bijective remap).
+//   WGRAD: every tile of the output reads a column block of A and one of B over the SAME batch slice, so ALL tiles of one slice go to one
+//   XCD, consecutively (slice = 8 * round + xcd): the slice's rows are fetched from DRAM once and shared through that L2 by the tiles
+//   running side by side.  In block order tile-fastest over all XCDs (round 2) the 25 tiles of a slice at D = 320 were spread over the
+//   8 L2s: 616 MB fetched per launch for 168 MB of operands, 7.0 TB/s -- the launch was bound by exactly that
+//   (profiles/r03_dcn_v2_bf16x3.txt).
+// The fp32 kernel keeps the round-2 order (SLICE_PER_XCD = false): it is bound by the fp32 matrix rate, not by traffic, and with a
+// slice's tiles side by side on one XCD its launch got SLOWER (D = 320: 133 -> 155 us, same box A/B of the whole step 485 -> 510 us;
+// the split-bf16 launch 91 -> 84 us).
+template <int MODE, bool SLICE_PER_XCD>
+__device__ __forceinline__ void gemm_block_to_tile(unsigned bid, unsigned ntiles, unsigned& tile, unsigned& ks) {
+    if (MODE == WGRAD && SLICE_PER_XCD) {
+        const unsigned xcd = bid & 7u, seq = bid >> 3;
+        ks = (seq / ntiles) * 8u + xcd;
+        tile = seq % ntiles;
+    } else {
+        const unsigned tile_lin = bid % ntiles;
+        ks = bid / ntiles;
+        const unsigned xcd = tile_lin & 7u, qd = ntiles >> 3, rm = ntiles & 7u;
+        tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (tile_lin >> 3);
+    }
+}
+
 template <int MODE, bool VEC, int TMv = 2>
 __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                          int64_t M, int N, int64_t K, int64_t kslice, const float* __restrict__ addend,
@@ -202,9 +227,9 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
     const int wm = wid >> 1, wn = wid & 1;
     const int l31 = lane & 31, hi = lane >> 5;
     // tile id (XCD-aware bijective remap as in the forward: the nx column tiles of one row panel share an L2) and K slice
-    const unsigned tile_lin = blockIdx.x % ntiles, ks = blockIdx.x / ntiles;
-    const unsigned xcd = tile_lin & 7u, qd = ntiles >> 3, rm = ntiles & 7u;
-    const unsigned logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (tile_lin >> 3);
+    unsigned logical, ks;
+    gemm_block_to_tile<MODE, false>(blockIdx.x, ntiles, logical, ks);
+    if ((int64_t)ks * kslice >= K) return;           // WGRAD: the slice count is rounded up to whole XCD rounds (block-uniform exit)
     const int64_t m0 = (int64_t)(logical / nx) * BM;
     const int n0 = (int)(logical % nx) * BN;
     const int64_t kbeg = (int64_t)ks * kslice;
@@ -437,6 +462,26 @@ struct KMajorStage {
             }
         }
     }
+    // Full slab (k0 + 32 <= kend): no selects and no per-lane 64-bit address arithmetic -- `slab` = &base[k0 * ld + row0] is wave-uniform
+    // (advanced on the scalar unit, + j rows of the source per load), `off[i]` a fixed 32-bit byte offset per lane (prepare()).  The
+    // guarded form above spent ~12 vector instructions per load: 34 per MFMA in the wgrad launch, which was bound by them
+    // (profiles/r03_dcn_v2_bf16x3.txt).
+    __device__ __forceinline__ void prepare(uint32_t (&off)[PAIRS], int64_t ld, int64_t row0, int64_t nrows, int tid) const {
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int f = tid + 256 * i, row = f % ROWS, oct = f / ROWS;
+            const int64_t r = row0 + row < nrows ? row : nrows - 1 - row0;            // clamped like load(): the product lands in rows never stored
+            off[i] = (uint32_t)(((int64_t)(8 * oct) * ld + r) * 4);
+        }
+    }
+    __device__ __forceinline__ void load_full(const char* __restrict__ slab, size_t ld_bytes, const uint32_t (&off)[PAIRS]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const char* rowj = slab + j * ld_bytes;
+#pragma unroll
+            for (int i = 0; i < PAIRS; ++i) v[i][j] = *reinterpret_cast<const float*>(rowj + off[i]);
+        }
+    }
     __device__ __forceinline__ void store(unsigned short* __restrict__ sh, unsigned short* __restrict__ sl, int tid) const {
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i) {
@@ -465,9 +510,9 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_split_kernel(const float* __
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
     const int l31 = lane & 31, hi = lane >> 5;
-    const unsigned tile_lin = blockIdx.x % ntiles, ks = blockIdx.x / ntiles;
-    const unsigned xcd = tile_lin & 7u, qd = ntiles >> 3, rm = ntiles & 7u;
-    const unsigned logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (tile_lin >> 3);
+    unsigned logical, ks;
+    gemm_block_to_tile<MODE, true>(blockIdx.x, ntiles, logical, ks);
+    if ((int64_t)ks * kslice >= K) return;           // WGRAD: the slice count is rounded up to whole XCD rounds (block-uniform exit)
     const int64_t m0 = (int64_t)(logical / nx) * BM;
     const int n0 = (int)(logical % nx) * BN;
     const int64_t kbeg = (int64_t)ks * kslice;
@@ -485,7 +530,31 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_split_kernel(const float* __
     KMajorStage<BM> ak;
     KMajorStage<BN> bk;
     const int srow = tid >> 3, skq = (tid & 7) * 4;
+    uint32_t oa4[MODE == DGRAD ? AP : 1], oak[KMajorStage<BM>::PAIRS], obk[KMajorStage<BN>::PAIRS];
+    if (MODE == DGRAD) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            const int64_t r = m0 + srow + 32 * p < M ? srow + 32 * p : M - 1 - m0;
+            oa4[p] = (uint32_t)((r * lda + skq) * 4);
+        }
+    } else {
+        ak.prepare(oak, lda, m0, M, tid);
+    }
+    bk.prepare(obk, ldb, n0, N, tid);
+    const char* const a_tile = reinterpret_cast<const char*>(MODE == DGRAD ? A + m0 * lda : A + m0);
+    const char* const b_tile = reinterpret_cast<const char*>(B + n0);
     auto load_slab = [&](int64_t k0) {
+        if (k0 + BK <= kend) {            // full slab (block-uniform): wave-uniform bases + fixed per-lane offsets
+            if (MODE == DGRAD) {
+                const char* ak0 = a_tile + (size_t)k0 * 4;
+#pragma unroll
+                for (int p = 0; p < AP; ++p) a4[p] = *reinterpret_cast<const float4*>(ak0 + oa4[p]);
+            } else {
+                ak.load_full(a_tile + (size_t)k0 * (size_t)lda * 4, (size_t)lda * 4, oak);
+            }
+            bk.load_full(b_tile + (size_t)k0 * (size_t)ldb * 4, (size_t)ldb * 4, obk);
+            return;
+        }
         if (MODE == DGRAD) {
 #pragma unroll
             for (int p = 0; p < AP; ++p) {
@@ -562,12 +631,13 @@ void launch_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, int 
     const int64_t kmin = env_rows ? (env_rows + BK - 1) / BK * BK : (small && nt > 1 ? 16 : 8) * BK;
     if (kslice < kmin) kslice = kmin;
     splits = (batch + kslice - 1) / kslice;
-    const dim3 grid((unsigned)(nt * splits));
+    const bool use_split = split && vec && colsum == nullptr;
+    const dim3 grid((unsigned)(nt * (use_split ? (splits + 7) / 8 * 8 : splits)));     // split kernel: whole XCD rounds of slices (gemm_block_to_tile); surplus blocks leave at once
 #define NRX_WGRAD(VEC_, TM_)                                                                                                          \
     hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, VEC_, TM_>), grid, dim3(256), 0, st, A, lda, B, ldb, (int64_t)M, N, batch, kslice,     \
                        (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, out, (int64_t)N, nx, nt,              \
                        (const float*)nullptr, (int64_t)0, colsum)
-    if (split && vec && colsum == nullptr) {
+    if (use_split) {
         if (small) hipLaunchKernelGGL((dcn2_gemm_split_kernel<WGRAD, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, (int64_t)M, N, batch, kslice,
                                       (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, out, (int64_t)N, nx, nt, (const float*)nullptr, (int64_t)0);
         else hipLaunchKernelGGL((dcn2_gemm_split_kernel<WGRAD, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, (int64_t)M, N, batch, kslice,
