@@ -255,11 +255,12 @@ __device__ __forceinline__ void split_bf16x4(const float4& v, uint2& hi, uint2& 
 }
 
 template <bool RELU>
-__global__ __launch_bounds__(256, 5) void dcn_v2_layer_bf16x3_kernel(const float* __restrict__ x0, const float* __restrict__ xl, int64_t ld,
+__global__ __launch_bounds__(256, 4) void dcn_v2_layer_bf16x3_kernel(const float* __restrict__ x0, const float* __restrict__ xl, int64_t ld,
                                                                   int64_t M, int N, const float* __restrict__ W, const float* __restrict__ bias,
                                                                   float* __restrict__ out, int64_t out_ld, unsigned nx,
                                                                   float* __restrict__ lin_out) {
-    __shared__ __attribute__((aligned(16))) unsigned short s_all[2 * BM * LDH + 2 * BN * LDH];      // one array: the epilogue reuses it
+    __shared__ __attribute__((aligned(16))) unsigned short s_all[16384];      // one array (operand images 30 720 B; the epilogue reuses it: 32 768 B, five blocks per CU)
+    static_assert(2 * BM * LDH + 2 * BN * LDH <= 16384, "operand images");
     unsigned short* const Ah = s_all;
     unsigned short* const Al = Ah + BM * LDH;
     unsigned short* const Wh = Al + BM * LDH;
@@ -302,6 +303,15 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_bf16x3_kernel(const float
     auto load_slab = [&](int k0) {
         const char* xk = xtile + (size_t)k0 * 4;
         const char* wk = wtile + (size_t)k0 * 4;
+        if (k0 + BK <= K) {        // full slab (block-uniform): plain loads.  Selects on the loaded values make the compiler wait for the loads
+                                   // where they are issued -- with them on every slab the "prefetch" was none (the loads were drained before the
+                                   // MFMAs they should have run under; seen in the ISA: s_waitcnt vmcnt(4) .. (0) right behind the loads)
+#pragma unroll
+            for (int p = 0; p < AP; ++p) a[p] = *reinterpret_cast<const float4*>(xk + oa[p]);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) w[p] = *reinterpret_cast<const float4*>(wk + ow[p]);
+            return;
+        }
         const bool ok = k0 + skq < K;                  // K % 4 == 0: a float4 is all-in or all-out; lanes past K re-read slab 0 and zero it
         const size_t back = ok ? 0 : (size_t)k0 * 4;
 #pragma unroll
@@ -316,7 +326,23 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_bf16x3_kernel(const float
         }
     };
     load_slab(0);
+    // The epilogue needs x_l[m0 .. m0+127, n0 .. n0+63] -- which IS two of the A slabs this block stages (k0 = n0 and n0 + 32): the staging
+    // registers of those two iterations are kept (32 VGPRs) and handed to the epilogue's lanes through LDS, instead of reading the tile from
+    // memory again ten slabs later, when it has left the L2 (the launch fetched x twice: 158 MB for 84 MB -- profiles/r03_dcn_v2_bf16x3.txt).
+    float4 xkeep[2][AP];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int p = 0; p < AP; ++p) xkeep[s2][p] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k0 = 0; k0 < K; k0 += BK) {
+        if (k0 == n0) {                                                    // (component by component: a struct copy under a condition left the arrays in scratch memory)
+#pragma unroll
+            for (int p = 0; p < AP; ++p) { xkeep[0][p].x = a[p].x; xkeep[0][p].y = a[p].y; xkeep[0][p].z = a[p].z; xkeep[0][p].w = a[p].w; }
+        }
+        if (k0 == n0 + BK) {
+#pragma unroll
+            for (int p = 0; p < AP; ++p) { xkeep[1][p].x = a[p].x; xkeep[1][p].y = a[p].y; xkeep[1][p].z = a[p].z; xkeep[1][p].w = a[p].w; }
+        }
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             uint2 h, l;
@@ -356,44 +382,67 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_bf16x3_kernel(const float
     // the matrix time gone those were the kernel: 89 us inference, 147 us in training form (two more arrays) at D = 320.  Each wavefront
     // transposes its tile through its own 4.6 KB of LDS (the operand buffers are free now) and a lane owns 4 CONSECUTIVE columns of a
     // row: 16-byte accesses, 8 rows x 128 bytes per instruction, 4 instructions per array and tile.
-    float* s_t = reinterpret_cast<float*>(s_all) + wid * (32 * 36);       // [32 rows][36 floats] per wavefront: 4 x 4608 of the 30720 bytes
     const int er = lane >> 3, ec = (lane & 7) * 4;                         // this lane's row (of 8 per pass) and first column in the tile
+    // x_l tile: staging layout -> epilogue layout.  The staging thread (wave j, lane) holds rows 8 j + (lane >> 3) + 32 p, columns
+    // 4 (lane & 7) + 32 s of the tile; the epilogue's (wave (wm, wn), lane) wants rows 64 wm + 32 t + 8 j + (lane >> 3), columns
+    // 32 wn + 4 (lane & 7): same lane, p = 2 wm + t, s = wn -- one conflict-free 16-byte LDS write / read per piece.  (The K loop
+    // ended on a barrier: the operand images are free.)
+    float4 xs[TM][4];
+    {
+        float4* s_x = reinterpret_cast<float4*>(s_all);                    // [wave 4][p 4][s 2][lane 64]: 32 768 bytes
+#pragma unroll
+        for (int p = 0; p < AP; ++p)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) s_x[((wid * AP + p) * 2 + s2) * 64 + lane] = xkeep[s2][p];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xs[t][j] = s_x[((j * AP + 2 * wm + t) * 2 + wn) * 64 + lane];
+        __syncthreads();
+    }
+    float* s_t = reinterpret_cast<float*>(s_all) + wid * (32 * 36);       // [32 rows][36 floats] per wavefront: 4 x 4608 bytes
     const int colv = n0 + wn * 32 + ec;
     const bool same_x = (x0 == xl);
     const bool col_ok = colv < N;                                          // N % 4 == 0: the four columns are in or out together
-    const float4 bc = col_ok ? *reinterpret_cast<const float4*>(bias + colv) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int colc = col_ok ? colv : 0;                                    // clamped: loads never branch, values past N are not stored
+    const float4 bc = *reinterpret_cast<const float4*>(bias + colc);
     const int64_t r0 = m0 + wm * (32 * TM);
+    auto tile_out = [&](auto same) {                 // same: x0 is x_l (a stack's first layer) -- nothing but the bias is read from memory
 #pragma unroll
-    for (int t = 0; t < TM; ++t) {
+        for (int t = 0; t < TM; ++t) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s_t[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36 + l31] = acc[t][r];
-        // (the wavefront reads back what it wrote: no block barrier -- the LDS operations of one wavefront complete in order; the
-        // waits keep the compiler from moving accesses across them)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        float4 lin4[4], xv[4], x0v[4];
+            for (int r = 0; r < 16; ++r) s_t[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36 + l31] = acc[t][r];
+            // (the wavefront reads back what it wrote: no block barrier -- the LDS operations of one wavefront complete in order; the
+            // waits keep the compiler from moving accesses across them)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float4 lin4[4], x0v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            lin4[j] = *reinterpret_cast<const float4*>(&s_t[(er + 8 * j) * 36 + ec]);
-            int64_t row = r0 + t * 32 + er + 8 * j;
-            row = row < M ? row : M - 1;                                    // clamp: the value is never stored
-            if (col_ok) {
-                xv[j] = *reinterpret_cast<const float4*>(xl + row * ld + colv);
-                x0v[j] = same_x ? xv[j] : *reinterpret_cast<const float4*>(x0 + row * ld + colv);
+            for (int j = 0; j < 4; ++j) {
+                lin4[j] = *reinterpret_cast<const float4*>(&s_t[(er + 8 * j) * 36 + ec]);
+                if (!decltype(same)::value) {
+                    int64_t row = r0 + t * 32 + er + 8 * j;
+                    row = row < M ? row : M - 1;                            // clamp: the value is never stored
+                    x0v[j] = *reinterpret_cast<const float4*>(x0 + row * ld + colc);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t row = r0 + t * 32 + er + 8 * j;
+                if (row >= M || !col_ok) continue;
+                const float xx = xs[t][j].x, xy = xs[t][j].y, xz = xs[t][j].z, xw = xs[t][j].w;
+                const float ox = decltype(same)::value ? xx : x0v[j].x, oy = decltype(same)::value ? xy : x0v[j].y;
+                const float oz = decltype(same)::value ? xz : x0v[j].z, ow4 = decltype(same)::value ? xw : x0v[j].w;
+                const float4 lin = make_float4(lin4[j].x + bc.x, lin4[j].y + bc.y, lin4[j].z + bc.z, lin4[j].w + bc.w);
+                if (lin_out != nullptr) *reinterpret_cast<float4*>(lin_out + row * ld + colv) = lin;
+                float4 v = make_float4(fmaf(ox, lin.x, xx), fmaf(oy, lin.y, xy), fmaf(oz, lin.z, xz), fmaf(ow4, lin.w, xw));
+                if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                *reinterpret_cast<float4*>(out + row * out_ld + colv) = v;
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t row = r0 + t * 32 + er + 8 * j;
-            if (row >= M || !col_ok) continue;
-            const float4 lin = make_float4(lin4[j].x + bc.x, lin4[j].y + bc.y, lin4[j].z + bc.z, lin4[j].w + bc.w);
-            if (lin_out != nullptr) *reinterpret_cast<float4*>(lin_out + row * ld + colv) = lin;
-            float4 v = make_float4(fmaf(x0v[j].x, lin.x, xv[j].x), fmaf(x0v[j].y, lin.y, xv[j].y), fmaf(x0v[j].z, lin.z, xv[j].z),
-                                   fmaf(x0v[j].w, lin.w, xv[j].w));
-            if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-            *reinterpret_cast<float4*>(out + row * out_ld + colv) = v;
-        }
-    }
+    };
+    if (same_x) tile_out(std::true_type{}); else tile_out(std::false_type{});
 }
 
 }  // namespace
