@@ -42,13 +42,16 @@ __device__ __forceinline__ float4 guarded_load4(const float* base, int64_t row, 
     return v;
 }
 
-template <bool RELU, bool VEC>
-__global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __restrict__ x0, const float* __restrict__ xl, int64_t ld,
+template <bool RELU, bool VEC, bool KEEPX = false>
+__global__ __launch_bounds__(256, KEEPX ? 4 : 5) void dcn_v2_layer_kernel(const float* __restrict__ x0, const float* __restrict__ xl, int64_t ld,
                                                            int64_t M, int N, const float* __restrict__ W, const float* __restrict__ bias,
                                                            float* __restrict__ out, int64_t out_ld, unsigned nx,
                                                            float* __restrict__ lin_out) {
-    __shared__ float As[BK * LDA];
-    __shared__ float Ws[BK * LDW];
+    constexpr int XLD = 68;                              // KEEPX: floats per row of the x_l tile handed to the epilogue through LDS
+    __shared__ __attribute__((aligned(16))) float s_all[KEEPX ? BM * XLD : BK * LDA + BK * LDW];
+    static_assert(BM * XLD >= BK * LDA + BK * LDW, "operand slabs");
+    float* const As = s_all;
+    float* const Ws = s_all + BK * LDA;
     const int K = N;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -126,8 +129,25 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __res
         }
     };
     load_slab(0);
+    // KEEPX: the epilogue's x_l tile is two of the A slabs this block stages (k0 = n0, n0 + 32); their staging registers are kept and
+    // handed over through LDS instead of a second fetch ten slabs later (see dcn_v2_layer_bf16x3_kernel)
+    float4 xkeep[KEEPX ? 2 : 1][AP];
+    if (KEEPX) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int p = 0; p < AP; ++p) xkeep[s2][p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
     for (int k0 = 0; k0 < K; k0 += BK) {
+        if (KEEPX && k0 == n0) {
+#pragma unroll
+            for (int p = 0; p < AP; ++p) { xkeep[0][p].x = a[p].x; xkeep[0][p].y = a[p].y; xkeep[0][p].z = a[p].z; xkeep[0][p].w = a[p].w; }
+        }
+        if (KEEPX && k0 == n0 + BK) {
+#pragma unroll
+            for (int p = 0; p < AP; ++p) { xkeep[KEEPX ? 1 : 0][p].x = a[p].x; xkeep[KEEPX ? 1 : 0][p].y = a[p].y; xkeep[KEEPX ? 1 : 0][p].z = a[p].z; xkeep[KEEPX ? 1 : 0][p].w = a[p].w; }
+        }
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             const int m = srow + 32 * p;
@@ -170,6 +190,13 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __res
     // Epilogue, also written for few VALU instructions: the address of register r's element is a wave-uniform
     // row pointer (tile base + constant * ld, scalar unit) plus one fixed per-lane byte offset, so a full
     // tile costs add-bias, fma, max per element; only a tile that crosses M takes the guarded path.
+    if (KEEPX) {                     // (the K loop ended on a barrier: the slabs are free)
+#pragma unroll
+        for (int p = 0; p < AP; ++p)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) *reinterpret_cast<float4*>(&s_all[(srow + 32 * p) * XLD + 32 * s2 + skq]) = xkeep[KEEPX ? s2 : 0][p];
+        __syncthreads();
+    }
     const int col = n0 + wn * 32 + l31;
     const bool same_x = (x0 == xl);
     if (col < N) {
@@ -186,7 +213,8 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __res
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2);      // + 4 * hi, folded into lo
-                        xv[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xl + row * ld) + lo);
+                        if (KEEPX) xv[r] = s_all[(wm * (32 * TM) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * XLD + wn * 32 + l31];
+                        else xv[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xl + row * ld) + lo);
                         x0v[r] = decltype(same)::value ? xv[r] : *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x0 + row * ld) + lo);
                     }
 #pragma unroll
@@ -209,7 +237,7 @@ __global__ __launch_bounds__(256, 5) void dcn_v2_layer_kernel(const float* __res
                 for (int r = 0; r < 16; ++r) {
                     const int64_t row = r0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if (row < M) {
-                        const float xv = xl[row * ld + col];
+                        const float xv = KEEPX ? s_all[(wm * (32 * TM) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * XLD + wn * 32 + l31] : xl[row * ld + col];
                         const float x0v = same_x ? xv : x0[row * ld + col];     // layer 0: x0 is x_l, one load
                         const float lin = acc[t][r] + bc;
                         if (lin_out != nullptr) lin_out[row * ld + col] = lin;
@@ -464,11 +492,16 @@ extern "C" int nrx_dcn_v2_layer_fwd(const float* x0, const float* xl, int64_t ld
     dim3 grid((unsigned)nblocks);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define NRX_DCN2(R_, V_) hipLaunchKernelGGL((dcn_v2_layer_kernel<R_, V_>), grid, dim3(256), 0, st, x0, xl, ld, batch, dim, W, bias, out, out_ld, nx, lin_out)
+    static const bool keepx_on = !(getenv("NRX_DCN2_KEEPX") && atoi(getenv("NRX_DCN2_KEEPX")) == 0);   // measurement knob: "0" = the epilogue fetches x_l again
     const bool vec_epi = nrx_aligned16(x0) && nrx_aligned16(out) && (out_ld & 3) == 0 && nrx_aligned16(bias) &&
                          (lin_out == nullptr || nrx_aligned16(lin_out));      // the split kernel's epilogue moves 16-byte pieces
     if (split && vec && vec_epi && batch >= 8) {        // (unaligned shapes and tiny batches take the fp32 kernel: more exact, never wrong)
         if (relu) hipLaunchKernelGGL((dcn_v2_layer_bf16x3_kernel<true>), grid, dim3(256), 0, st, x0, xl, ld, batch, dim, W, bias, out, out_ld, nx, lin_out);
         else hipLaunchKernelGGL((dcn_v2_layer_bf16x3_kernel<false>), grid, dim3(256), 0, st, x0, xl, ld, batch, dim, W, bias, out, out_ld, nx, lin_out);
+    } else
+    if (vec && keepx_on) {
+        if (relu) hipLaunchKernelGGL((dcn_v2_layer_kernel<true, true, true>), grid, dim3(256), 0, st, x0, xl, ld, batch, dim, W, bias, out, out_ld, nx, lin_out);
+        else hipLaunchKernelGGL((dcn_v2_layer_kernel<false, true, true>), grid, dim3(256), 0, st, x0, xl, ld, batch, dim, W, bias, out, out_ld, nx, lin_out);
     } else
     if (relu) { if (vec) NRX_DCN2(true, true); else NRX_DCN2(true, false); }
     else      { if (vec) NRX_DCN2(false, true); else NRX_DCN2(false, false); }
