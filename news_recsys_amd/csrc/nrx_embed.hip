@@ -1056,7 +1056,6 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
     constexpr int Q = 1 << QLOG2;
     constexpr int TB = NRX_BLOCK / Q;
     const int q = threadIdx.x & (Q - 1);
-    const int64_t u0 = ((int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2)) * R;
     // n = rows of this launch: all unique rows, or (placement mode) the `walk` list -- then u0 + r indexes the list
     int64_t n = a->n_unique;
     const bool listed = a->walk != nullptr;
@@ -1067,6 +1066,11 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
             n = nd < n ? nd : n;
         }
     }
+    // The grid is sized by a host-side BOUND on the row count (the count itself lives on the device): a block takes row groups
+    // blockIdx.x, blockIdx.x + gridDim.x, ... -- with one group per block, a C5 launch started ~15 000 blocks that each waited for
+    // the count to arrive from memory only to leave.
+    auto body = [&](int64_t blk) {
+    const int64_t u0 = (blk * TB + (threadIdx.x >> QLOG2)) * R;
     if (__ballot(u0 < n) == 0ull) return;      // whole wavefronts past the last row leave; inside the last live wavefront the
                                                // lane groups past it stay (the work-list append below is a wavefront scan)
     const NRX_GLOBAL int64_t* seg = nrx_gconst<int64_t>(a->seg_start);
@@ -1283,6 +1287,8 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (u0 + r < n && !lng[r]) nrx_stg4(a->values, urow[r] * (int64_t)Q + q, acc[r]);
+    };
+    for (int64_t blk = blockIdx.x; blk * (TB * R) < n; blk += gridDim.x) body(blk);
 }
 
 // Long segments.  An item = up to SORTED_LONG_CHUNK consecutive sorted entries of ONE unique row; a wavefront reduces an
@@ -1957,7 +1963,11 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             a.n_unique = n_rows;
         }
         const int64_t groups = (n_rows + (wide_pass ? RB : R) - 1) / (wide_pass ? RB : R);
-        const unsigned grid = (unsigned)((groups + tb - 1) / tb);
+        unsigned grid = (unsigned)((groups + tb - 1) / tb);
+        {   // the walk's blocks stride over the row groups: when the row count is a device-side number (n_rows is only its bound) a few rounds of resident blocks are enough
+            static const int cap = getenv("NRX_WALK_GRID") ? atoi(getenv("NRX_WALK_GRID")) : 4096;
+            if ((n_unique_dev != nullptr || placed) && cap > 0 && grid > (unsigned)cap) grid = (unsigned)cap;
+        }
         // (4 rows x 4 entries per lane group instead of 2 x 4: C5 446.9 -> 458.1 us, C3 163.2 -> 169.6 -- measured, not kept)
         if (workspace != nullptr) {        // long segments (hot rows) go through the wavefront-per-item path
             a.long_ws = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15);
