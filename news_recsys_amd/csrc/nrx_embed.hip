@@ -1048,9 +1048,21 @@ __device__ __forceinline__ void sorted_bag_entry(const NRX_CONST SortedBwdArgs* 
 
 // BAG: some features are bags -- a lookup's sample is (flat index) / L and its upstream row is scaled by the per-lookup
 // factor bag_scale_kernel left in a->scale (mask / (sum mask + 1e-8), 1 / L, or the weight).
-template <int QLOG2, int R, bool FM, bool BAG, bool UNAL, int UP = 1>
+// REG: the launch's features are `regular` (SortedBwdArgs::regular: single-valued, equally long, equally spaced columns, one FM flag) --
+// feature, sample and column of a sorted entry are then ARITHMETIC on its lookup number.  As a run-time branch inside the general decode
+// (round 2) it cost what the general decode costs: that one reads the per-feature fields from the argument block with vector loads, and with
+// both forms in one instruction stream the compiler waits vmcnt(0) in front of every row load -- the 8 row loads of a pass went out ONE AT A
+// TIME, each behind the previous one's arrival (seen in the ISA; the C5 walk ran at 1.65 TB/s with 86 % of its wave time waiting).
+template <int QLOG2, int R, bool FM, bool BAG, bool UNAL, int UP = 1, bool REG = false>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const SortedBwdArgs args_in_kernarg) {
     const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
+    // (REG) the launch's scalars, read once
+    const uint64_t reg_magic = a->uniform_magic;
+    const int64_t reg_len = a->uniform_len;
+    const int reg_col0 = a->col0, reg_stride = a->col_stride;
+    const bool reg_fm = a->all_fm != 0;
+    const float* const up_g = a->g_out;
+    const int64_t up_ld = a->out_ld;
     const bool bag_binary = BAG && a->bag_bits != nullptr && (a->long_ws[3] & 1) == 0;      // every bag weight is 0 or 1 (bag_scale_kernel)
     const bool need_bits = BAG && a->bag_bits != nullptr && (a->long_ws[3] & 2) != 0;       // some live lookup has weight 0
     constexpr int Q = 1 << QLOG2;
@@ -1192,6 +1204,19 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int j = 0; j < UP; ++j) {
+                if (REG && !BAG && !UNAL) {
+                    const int fi = (int)__umul64hi((uint64_t)p[r][j], reg_magic);
+                    const int64_t b = p[r][j] - (int64_t)fi * reg_len;
+                    const int col = reg_col0 + fi * reg_stride;
+                    sc[r][j] = 1.0f;
+                    g[r][j] = nrx_ldg4(up_g, (b * up_ld + col) / 4 + q);          // (REG launches have an upstream gradient: host-checked)
+                    if (FM) {
+                        gf[r][j] = reg_fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
+                        v[r][j] = nrx_ldg4(a->feat, (b * a->feat_ld + col) / 4 + q);
+                        s[r][j] = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
+                    }
+                    continue;
+                }
                 const FeatLite f = sorted_feat(a, sorted_feat_of(a, p[r][j]));
                 int64_t b;
                 if (BAG) {
@@ -2049,9 +2074,14 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
                 hipLaunchKernelGGL(stage_rows_kernel, dim3((unsigned)((batch * (dim / 4) + NRX_BLOCK - 1) / NRX_BLOCK), (unsigned)n_sg),
                                    dim3(NRX_BLOCK), 0, st, sg, g_out, out_ld, batch, (int)(dim / 4), gs);
         }
+        const bool reg = a.regular && g_out != nullptr && !unal;        // arithmetic decode (embed_bwd_sorted_fast_kernel<.., REG = true>)
 #define NRX_SF(QL_)                                                                                                        \
     {                                                                                                                      \
-        if (placed && has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        if (placed && has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else if (placed && !has_bag && !unal && !has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else if (!placed && has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false, 1, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else if (!placed && !has_fm && !unal && !has_bag && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false, 1, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else if (placed && has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
         else if (placed && unal) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, true, 4>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
         else if (placed && !has_bag) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
         else if (has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
