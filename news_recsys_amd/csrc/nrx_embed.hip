@@ -1048,12 +1048,69 @@ __device__ __forceinline__ void sorted_bag_entry(const NRX_CONST SortedBwdArgs* 
 
 // BAG: some features are bags -- a lookup's sample is (flat index) / L and its upstream row is scaled by the per-lookup
 // factor bag_scale_kernel left in a->scale (mask / (sum mask + 1e-8), 1 / L, or the weight).
+// The general decode (more than 4 features, not regular) through an LDS copy of the per-feature fields: the same fields read from the
+// argument block with per-lane indices are VECTOR loads (and a binary search over a->off[] a chain of them), counted in the same in-order
+// queue as the row loads -- every row load then waited for the decode loads of the entry before it.  LDS reads are counted separately.
+struct SortedFeatLds {
+    int64_t off[NRX_MAX_FEATURES + 1];
+    FeatLite f[NRX_MAX_FEATURES];
+};
+__device__ __forceinline__ void sorted_feat_stage(const NRX_CONST SortedBwdArgs* a, SortedFeatLds* t) {      // block-uniform call; ends on a barrier
+    for (int i = threadIdx.x; i <= a->n; i += NRX_BLOCK) t->off[i] = a->off[i];
+    for (int i = threadIdx.x; i < a->n; i += NRX_BLOCK) {
+        FeatLite f;
+        f.off = a->off[i]; f.magic = (uint64_t)a->f[i].rows; f.out_col = a->f[i].out_col; f.wide_col = a->f[i].wide_col;
+        f.bag_len = a->f[i].bag_len; f.kind = a->f[i].kind; f.fm = a->f[i].fm != 0; f.gs = a->f[i].table;
+        t->f[i] = f;
+    }
+    __syncthreads();
+}
+// DEC (a template argument of the walk / work-list kernels: ONE decode form per instruction stream -- with several behind run-time branches the
+// compiler's wait counts at every row load are those of the worst form):  1 = regular (arithmetic, see REG below);  2 = at most 4 features
+// (scalar compares and selects on argument words, no loads);  0 = general: the LDS copy.
+template <int DEC>
+__device__ __forceinline__ FeatLite sorted_decode(const NRX_CONST SortedBwdArgs* a, const SortedFeatLds* t, int64_t p) {
+    if (DEC == 2) {
+        const int64_t big = 0x7fffffffffffffffLL;
+        const int64_t o1 = a->n > 1 ? a->off[1] : big, o2 = a->n > 2 ? a->off[2] : big, o3 = a->n > 3 ? a->off[3] : big;
+        const int fi = (int)(p >= o1) + (int)(p >= o2) + (int)(p >= o3);
+        FeatLite f;
+        f.off = a->off[0]; f.magic = (uint64_t)a->f[0].rows; f.out_col = a->f[0].out_col; f.wide_col = a->f[0].wide_col;
+        f.bag_len = a->f[0].bag_len; f.kind = a->f[0].kind; f.fm = a->f[0].fm != 0; f.gs = a->f[0].table;
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {           // constant indices: scalar loads (entries past n are inside the block and unused)
+            const bool hit = fi == i;
+            f.off = hit ? a->off[i] : f.off;
+            f.magic = hit ? (uint64_t)a->f[i].rows : f.magic;
+            f.out_col = hit ? a->f[i].out_col : f.out_col;
+            f.wide_col = hit ? a->f[i].wide_col : f.wide_col;
+            f.bag_len = hit ? (int32_t)a->f[i].bag_len : f.bag_len;
+            f.kind = hit ? (int32_t)a->f[i].kind : f.kind;
+            f.fm = hit ? a->f[i].fm != 0 : f.fm;
+            f.gs = hit ? a->f[i].table : f.gs;
+        }
+        return f;
+    }
+    int fi;
+    if (a->uniform_len > 0) {
+        fi = (int)__umul64hi((uint64_t)p, a->uniform_magic);
+    } else {
+        int l0 = 0, h0 = a->n;
+        while (h0 - l0 > 1) {
+            const int mid = (l0 + h0) >> 1;
+            if (t->off[mid] <= p) l0 = mid; else h0 = mid;
+        }
+        fi = l0;
+    }
+    return t->f[fi];
+}
+
 // REG: the launch's features are `regular` (SortedBwdArgs::regular: single-valued, equally long, equally spaced columns, one FM flag) --
 // feature, sample and column of a sorted entry are then ARITHMETIC on its lookup number.  As a run-time branch inside the general decode
 // (round 2) it cost what the general decode costs: that one reads the per-feature fields from the argument block with vector loads, and with
 // both forms in one instruction stream the compiler waits vmcnt(0) in front of every row load -- the 8 row loads of a pass went out ONE AT A
 // TIME, each behind the previous one's arrival (seen in the ISA; the C5 walk ran at 1.65 TB/s with 86 % of its wave time waiting).
-template <int QLOG2, int R, bool FM, bool BAG, bool UNAL, int UP = 1, bool REG = false>
+template <int QLOG2, int R, bool FM, bool BAG, bool UNAL, int UP = 1, int DEC = 0>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const SortedBwdArgs args_in_kernarg) {
     const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
     // (REG) the launch's scalars, read once
@@ -1063,6 +1120,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
     const bool reg_fm = a->all_fm != 0;
     const float* const up_g = a->g_out;
     const int64_t up_ld = a->out_ld;
+    __shared__ SortedFeatLds s_ft;
+    constexpr bool REG = DEC == 1;
+    if (DEC == 0) sorted_feat_stage(a, &s_ft);
     const bool bag_binary = BAG && a->bag_bits != nullptr && (a->long_ws[3] & 1) == 0;      // every bag weight is 0 or 1 (bag_scale_kernel)
     const bool need_bits = BAG && a->bag_bits != nullptr && (a->long_ws[3] & 2) != 0;       // some live lookup has weight 0
     constexpr int Q = 1 << QLOG2;
@@ -1217,7 +1277,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
                     }
                     continue;
                 }
-                const FeatLite f = sorted_feat(a, sorted_feat_of(a, p[r][j]));
+                const FeatLite f = sorted_decode<DEC>(a, &s_ft, p[r][j]);
                 int64_t b;
                 if (BAG) {
                     sorted_bag_entry<UNAL>(a, f, p[r][j], q, Q, bag_binary, need_bits, b, g[r][j], sc[r][j]);
@@ -1265,7 +1325,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
             const int64_t pw = pn[r][0];
             int32_t id = -1;
             if (ei < hi[r]) {
-                const FeatLite f = sorted_feat(a, sorted_feat_of(a, pw));
+                const FeatLite f = sorted_decode<DEC>(a, &s_ft, pw);
                 uint64_t b = (uint64_t)(pw - f.off);
                 if (f.bag_len > 1) b = __umul64hi(b, f.magic);
                 id = (int32_t)((f.gs - a->gs_all) >> (QLOG2 + 2)) + (int32_t)b;
@@ -1320,9 +1380,18 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
 // item: its 64 / Q lane groups stride over the entries (two in flight each), then a fixed xor-shuffle tree adds the
 // groups -- the same entries always meet in the same order, so the result is reproducible.  A row of one item is written
 // straight to values; a row of several items leaves one partial per item, which sorted_combine_kernel adds in item order.
-template <int QLOG2, bool FM, bool BAG, bool UNAL>
+template <int QLOG2, bool FM, bool BAG, bool UNAL, int DEC = 0>      // DEC: as in embed_bwd_sorted_fast_kernel
 __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdArgs args_in_kernarg) {
     const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
+    const uint64_t reg_magic = a->uniform_magic;
+    const int64_t reg_len = a->uniform_len;
+    const int reg_col0 = a->col0, reg_stride = a->col_stride;
+    const bool reg_fm = a->all_fm != 0;
+    const float* const up_g = a->g_out;
+    const int64_t up_ld = a->out_ld;
+    __shared__ SortedFeatLds s_ft;
+    constexpr bool REG = DEC == 1;
+    if (DEC == 0) sorted_feat_stage(a, &s_ft);
     const bool bag_binary = BAG && a->bag_bits != nullptr && (a->long_ws[3] & 1) == 0;      // every bag weight is 0 or 1 (bag_scale_kernel)
     const bool need_bits = BAG && a->bag_bits != nullptr && (a->long_ws[3] & 2) != 0;
     constexpr int Q = 1 << QLOG2, G = 64 / Q;
@@ -1334,47 +1403,100 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
     for (int it = blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6); it < nitems; it += nwaves) {
         const LongItem w = items[it];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        constexpr int UL = 4;                                   // entries in flight per lane group
-        for (int64_t e0 = w.e_begin + g; e0 < w.e_end; e0 += UL * G) {
-            int64_t p[UL];
-            bool on[UL];
+        // The item's sorted entries in chunks of 64: ONE order word per lane and chunk (the next chunk's requested before this chunk's rows),
+        // handed to the lane groups through the cross-lane unit; group g takes entries g, g + G, g + 2G, ... of the item, as before (same
+        // accumulation order per group, same tree over the groups: same bits).  Round 2's loop fetched the order words of 4 entries per
+        // group on demand: two dependent round trips per 4 G entries.
+        if (BAG) {               // bag launches keep round 2's loop (order words fetched per lane group, 4 entries in flight): the chunked form measured
+                                 // 5-10 us slower on the C4 Zipf work list (50.6 -> 61.5 us for the launch)
+            constexpr int UB = 4;
+            for (int64_t e0 = w.e_begin + g; e0 < w.e_end; e0 += UB * G) {
+                int64_t p[UB];
+                bool on[UB];
 #pragma unroll
-            for (int k = 0; k < UL; ++k) {
-                on[k] = e0 + k * G < w.e_end;
-                p[k] = nrx_gconst<int64_t>(a->order)[on[k] ? e0 + k * G : w.e_begin];
-            }
-            float4 gr[UL], v[UL], s_[UL];
-            float gf[UL], sc[UL];
+                for (int k = 0; k < UB; ++k) {
+                    on[k] = e0 + k * G < w.e_end;
+                    p[k] = nrx_gconst<int64_t>(a->order)[on[k] ? e0 + k * G : w.e_begin];
+                }
+                float4 gr[UB];
+                float sc[UB];
 #pragma unroll
-            for (int k = 0; k < UL; ++k) {
-                const FeatLite f = sorted_feat(a, sorted_feat_of(a, p[k]));
-                int64_t b;
-                if (BAG) {
+                for (int k = 0; k < UB; ++k) {
+                    const FeatLite f = sorted_decode<DEC>(a, &s_ft, p[k]);
+                    int64_t b;
                     sorted_bag_entry<UNAL>(a, f, p[k], q, Q, bag_binary, need_bits, b, gr[k], sc[k]);
-                } else {
-                    b = p[k] - f.off;
-                    sc[k] = 1.0f;
-                    gr[k] = sorted_upstream<UNAL>(a, f, b, q);
                 }
-                if (FM) {
-                    gf[k] = f.fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
-                    v[k] = nrx_ldg4(a->feat, (b * a->feat_ld + f.out_col) / 4 + q);
-                    s_[k] = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
-                }
-            }
 #pragma unroll
-            for (int k = 0; k < UL; ++k) {
-                float4 t = gr[k];
-                if (FM) fm_fold4(t, gf[k], s_[k], v[k], q);
-                if (on[k]) {
-                    if (BAG) {
+                for (int k = 0; k < UB; ++k)
+                    if (on[k]) {
 #pragma clang fp contract(off)
-                        acc.x += t.x * sc[k]; acc.y += t.y * sc[k]; acc.z += t.z * sc[k]; acc.w += t.w * sc[k];
+                        acc.x += gr[k].x * sc[k]; acc.y += gr[k].y * sc[k]; acc.z += gr[k].z * sc[k]; acc.w += gr[k].w * sc[k];
+                    }
+            }
+        } else {
+        constexpr int UL = Q < 8 ? Q : 8;                       // rows in flight per lane group (a chunk gives every group Q entries)
+        int64_t pw_next = nrx_gconst<int64_t>(a->order)[w.e_begin + lane < w.e_end ? w.e_begin + lane : w.e_begin];
+        for (int64_t c0 = w.e_begin; c0 < w.e_end; c0 += 64) {
+            const int64_t pw = pw_next;
+            if (c0 + 64 < w.e_end) pw_next = nrx_gconst<int64_t>(a->order)[c0 + 64 + lane < w.e_end ? c0 + 64 + lane : w.e_begin];
+#pragma unroll
+            for (int kb = 0; kb < Q; kb += UL) {
+                if (c0 + (int64_t)kb * G >= w.e_end) break;               // wave-uniform (the sub-batch's first entry): every lane stays for the shuffles below
+                int64_t p[UL];
+                bool on[UL];
+#pragma unroll
+                for (int k = 0; k < UL; ++k) {
+                    const int idx = g + (kb + k) * G;
+                    on[k] = c0 + idx < w.e_end;
+                    p[k] = __shfl(pw, idx, 64);
+                }
+                float4 gr[UL], v[UL], s_[UL];
+                float gf[UL], sc[UL];
+#pragma unroll
+                for (int k = 0; k < UL; ++k) {
+                    if (REG && !BAG && !UNAL) {
+                        const int fi = (int)__umul64hi((uint64_t)p[k], reg_magic);
+                        const int64_t b = p[k] - (int64_t)fi * reg_len;
+                        const int col = reg_col0 + fi * reg_stride;
+                        sc[k] = 1.0f;
+                        gr[k] = nrx_ldg4(up_g, (b * up_ld + col) / 4 + q);
+                        if (FM) {
+                            gf[k] = reg_fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
+                            v[k] = nrx_ldg4(a->feat, (b * a->feat_ld + col) / 4 + q);
+                            s_[k] = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
+                        }
+                        continue;
+                    }
+                    const FeatLite f = sorted_decode<DEC>(a, &s_ft, p[k]);
+                    int64_t b;
+                    if (BAG) {
+                        sorted_bag_entry<UNAL>(a, f, p[k], q, Q, bag_binary, need_bits, b, gr[k], sc[k]);
                     } else {
-                        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                        b = p[k] - f.off;
+                        sc[k] = 1.0f;
+                        gr[k] = sorted_upstream<UNAL>(a, f, b, q);
+                    }
+                    if (FM) {
+                        gf[k] = f.fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
+                        v[k] = nrx_ldg4(a->feat, (b * a->feat_ld + f.out_col) / 4 + q);
+                        s_[k] = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < UL; ++k) {
+                    float4 t = gr[k];
+                    if (FM) fm_fold4(t, gf[k], s_[k], v[k], q);
+                    if (on[k]) {
+                        if (BAG) {
+#pragma clang fp contract(off)
+                            acc.x += t.x * sc[k]; acc.y += t.y * sc[k]; acc.z += t.z * sc[k]; acc.w += t.w * sc[k];
+                        } else {
+                            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                        }
                     }
                 }
             }
+        }
         }
 #pragma unroll
         for (int off = Q; off < 64; off <<= 1) {             // add the G lane groups: fixed tree
@@ -2074,30 +2196,33 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
                 hipLaunchKernelGGL(stage_rows_kernel, dim3((unsigned)((batch * (dim / 4) + NRX_BLOCK - 1) / NRX_BLOCK), (unsigned)n_sg),
                                    dim3(NRX_BLOCK), 0, st, sg, g_out, out_ld, batch, (int)(dim / 4), gs);
         }
-        const bool reg = a.regular && g_out != nullptr && !unal;        // arithmetic decode (embed_bwd_sorted_fast_kernel<.., REG = true>)
+        const bool reg = a.regular && g_out != nullptr && !unal;        // arithmetic decode (embed_bwd_sorted_fast_kernel<.., DEC = 1>)
+        const bool few = n_feats <= 4;                                  // scalar decode (DEC = 2); else the LDS table (DEC = 0)
 #define NRX_SF(QL_)                                                                                                        \
     {                                                                                                                      \
-        if (placed && has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else if (placed && !has_bag && !unal && !has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else if (!placed && has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false, 1, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else if (!placed && !has_fm && !unal && !has_bag && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false, 1, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else if (placed && has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else if (placed && unal) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, true, 4>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else if (placed && !has_bag) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else if (has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else if (unal) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, true, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else if (has_bag) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, false, 4>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a);      \
+        if (placed && has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4, 1>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else if (placed && !has_bag && !unal && !has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4, 1>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else if (!placed && has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false, 1, 1>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else if (!placed && !has_fm && !unal && !has_bag && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false, 1, 1>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+        else if (placed && has_fm) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4, 2>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4, 0>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); } \
+        else if (placed && unal) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, true, 4, 2>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, true, 4, 0>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); } \
+        else if (placed && !has_bag) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4, 2>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4, 0>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); } \
+        else if (has_fm) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false, 1, 2>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false, 1, 0>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); } \
+        else if (unal) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, true, true, 1, 2>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, true, true, 1, 0>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); } \
+        else if (has_bag) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, false, 4, 2>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, false, 4, 0>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); } \
+        else { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false, 1, 2>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false, 1, 0>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); } \
     }
         if (ql == 2) NRX_SF(2) else if (ql == 3) NRX_SF(3) else NRX_SF(4)
 #undef NRX_SF
         if (workspace != nullptr) {
 #define NRX_SL(QL_)                                                                                                        \
     {                                                                                                                      \
-        if (has_fm) hipLaunchKernelGGL((sorted_long_kernel<QL_, true, false, false>), dim3(2048), dim3(NRX_BLOCK), 0, st, a);      \
-        else if (unal) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, true>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); \
-        else if (has_bag) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, false>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); \
-        else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, false, false>), dim3(2048), dim3(NRX_BLOCK), 0, st, a);            \
+        if (has_fm && reg) hipLaunchKernelGGL((sorted_long_kernel<QL_, true, false, false, 1>), dim3(2048), dim3(NRX_BLOCK), 0, st, a);      \
+        else if (!has_fm && !unal && !has_bag && reg) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, false, false, 1>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); \
+        else if (has_fm) { if (few) hipLaunchKernelGGL((sorted_long_kernel<QL_, true, false, false, 2>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((sorted_long_kernel<QL_, true, false, false, 0>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); } \
+        else if (unal) { if (few) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, true, 2>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, true, 0>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); } \
+        else if (has_bag) { if (few) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, false, 2>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, false, 0>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); } \
+        else { if (few) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, false, false, 2>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, false, false, 0>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); } \
         hipLaunchKernelGGL((sorted_combine_kernel<QL_>), dim3(256), dim3(NRX_BLOCK), 0, st, a);                              \
     }
             if (ql == 2) NRX_SL(2) else if (ql == 3) NRX_SL(3) else NRX_SL(4)
