@@ -291,11 +291,20 @@ struct SegArgs {
     int64_t seg_off[NRX_MAX_FEATURES + 1];   // per table: first entry
     int32_t seg_tile[NRX_MAX_FEATURES + 1];  // per table: first tile
     int32_t seg_chunk[NRX_MAX_FEATURES + 1]; // per table: first chunk
-    uint8_t table[NRX_MAX_FEATURES];         // per slot
-    uint8_t seg_db[NRX_MAX_FEATURES];        // per table: digit width
+    // (dwords, bytes / nibbles packed: a byte array indexed by a wave-uniform number is still read with a VECTOR load -- the scalar unit
+    // of this target loads dwords only -- and every tile kernel began with such a load and a full wait for it before its first useful one)
+    uint32_t table_w[NRX_MAX_FEATURES / 4];  // per slot: table number, a byte each
+    uint32_t seg_db_w[NRX_MAX_FEATURES / 8]; // per table: digit width, a nibble each (<= SEG_MAX_DB = 10)
     int32_t n_slots, n_seg, idx64, row_bits, nb;     // nb = 1 << (widest digit) = row stride of hist / ctot / bin_base
 };
 static_assert(sizeof(SegArgs) <= 3584, "kernarg budget");
+__device__ __forceinline__ int seg_db_of(const NRX_CONST SegArgs* a, int seg) {                 // seg wave-uniform: scalar loads and shifts
+    seg = __builtin_amdgcn_readfirstlane(seg);
+    return (int)((a->seg_db_w[seg >> 3] >> ((seg & 7) * 4)) & 15u);
+}
+__device__ __forceinline__ uint32_t seg_table_of(const NRX_CONST SegArgs* a, int slot) {        // slot: any lane's
+    return (a->table_w[slot >> 2] >> ((slot & 3) * 8)) & 255u;
+}
 
 // Segment of a tile: the LAST segment whose first tile is <= tile = the number of entries 1 .. n-1 of the (<= 64-entry) array that are
 // <= tile.  One lane per entry: ONE vector load from the argument block, one compare, a ballot and a popcount per wavefront -- a binary
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
     extern __shared__ uint32_t s_hist[];
     const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
     const int tile = blockIdx.x, seg = seg_of_tile(a, tile);
-    const int nbins = 1 << a->seg_db[seg];
+    const int nbins = 1 << seg_db_of(a, seg);
     for (int b = threadIdx.x; b < nbins; b += SEG_THREADS) s_hist[b] = 0;
     const int64_t q0 = a->seg_off[seg] + (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE, qend = a->seg_off[seg + 1];
     const uint32_t dmask = (uint32_t)nbins - 1u;
@@ -366,7 +375,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
     __syncthreads();
     if (one_slot) {
         const int64_t rows = a->rows[lo], pbase = a->poff[lo] + (q0 - a->qoff[lo]);
-        const KeyT tkey = (KeyT)a->table[lo] << a->row_bits;
+        const KeyT tkey = (KeyT)seg_table_of(a, lo) << a->row_bits;
 #pragma unroll
         for (int j = 0; j < SEG_PER_THREAD; ++j) {
             const int64_t q = q0 + j * SEG_THREADS + threadIdx.x;
@@ -389,9 +398,9 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
             const int s = sl[j];
             int64_t v = id[j];
             if (v < 0 || v >= a->rows[s]) v = 0;
-            if (PAIR) reinterpret_cast<uint2*>(keys)[q] = make_uint2((uint32_t)(((KeyT)a->table[s] << a->row_bits) | (KeyT)v), (uint32_t)(a->poff[s] + (q - a->qoff[s])));
+            if (PAIR) reinterpret_cast<uint2*>(keys)[q] = make_uint2((uint32_t)(((KeyT)seg_table_of(a, s) << a->row_bits) | (KeyT)v), (uint32_t)(a->poff[s] + (q - a->qoff[s])));
             else {
-                keys[q] = ((KeyT)a->table[s] << a->row_bits) | (KeyT)v;
+                keys[q] = ((KeyT)seg_table_of(a, s) << a->row_bits) | (KeyT)v;
                 payload[q] = (uint32_t)(a->poff[s] + (q - a->qoff[s]));
             }
             atomicAdd(&s_hist[(uint32_t)v & dmask], 1u);
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_hist_kernel(const SegArgs arg
     extern __shared__ uint32_t s_hist[];
     const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
     const int tile = blockIdx.x, seg = seg_of_tile(a, tile);
-    const int db = a->seg_db[seg], nbins = 1 << db, shift = pass * db;
+    const int db = seg_db_of(a, seg), nbins = 1 << db, shift = pass * db;
     for (int b = threadIdx.x; b < nbins; b += SEG_THREADS) s_hist[b] = 0;
     const int64_t q0 = a->seg_off[seg] + (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE, qend = a->seg_off[seg + 1];
     const uint32_t dmask = (uint32_t)nbins - 1u;
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void seg_scan_chunks(const SegArgs args_
     const int seg = __builtin_amdgcn_readfirstlane(seg_count_le<int32_t>(a->seg_chunk, a->n_seg, chunk));
     const int nb = a->nb;
     const int bin = blockIdx.x * NRX_BLOCK + threadIdx.x;
-    if (bin >= (1 << a->seg_db[seg])) return;
+    if (bin >= (1 << seg_db_of(a, seg))) return;
     const int t0 = a->seg_tile[seg] + (chunk - a->seg_chunk[seg]) * SEG_CHUNK;
     const int t1 = t0 + SEG_CHUNK < a->seg_tile[seg + 1] ? t0 + SEG_CHUNK : a->seg_tile[seg + 1];
     uint32_t* h = hist + (size_t)t0 * nb + bin;
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void seg_scan_bins(const SegArgs args_in
                                                             uint32_t* __restrict__ bin_base) {
     __shared__ uint32_t s_part[NRX_BLOCK / 64];
     const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
-    const int seg = blockIdx.x, nb = a->nb, nbins = 1 << a->seg_db[seg];
+    const int seg = blockIdx.x, nb = a->nb, nbins = 1 << seg_db_of(a, seg);
     constexpr int PER = (1 << SEG_MAX_DB) / NRX_BLOCK;            // bins per thread: bin = i * 256 + tid (coalesced rows)
     const int nchunks = a->seg_chunk[seg + 1] - a->seg_chunk[seg];
     uint32_t v[PER];
@@ -520,7 +529,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
     const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tile = blockIdx.x, seg = seg_of_tile(a, tile);
-    const int db = a->seg_db[seg], nbins = 1 << db, shift = pass * db, nb = a->nb;
+    const int db = seg_db_of(a, seg), nbins = 1 << db, shift = pass * db, nb = a->nb;
     uint16_t* s_wh = reinterpret_cast<uint16_t*>(s_mem);  // [WAVES][nbins]: running bin counts of each wave's 512-entry chunk (16-bit: a tile
                                                           // holds 4096 entries; halves this area -- a third / fourth resident block per CU)
     uint32_t* s_bin = s_mem + WAVES * nbins / 2;          // [nbins]: the bin's first position inside the tile
@@ -567,6 +576,13 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
                 const uint32_t* h = (DIRECT == 1 ? hist : ctot) + (size_t)t0 * nb + b;
                 uint32_t before = DIRECT == 1 ? 0u : hist[(size_t)blockIdx.x * nb + b], all = 0;
                 int t = t0;
+                for (; t + 16 <= t1; t += 16, h += (size_t)16 * nb) {      // sixteen independent loads in flight (a C2 table is 16 tiles: one round trip, not two)
+                    uint32_t v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = h[(size_t)u * nb];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { all += v[u]; before += t + u < tile ? v[u] : 0u; }
+                }
                 for (; t + 8 <= t1; t += 8, h += (size_t)8 * nb) {         // eight independent loads in flight
                     uint32_t v[8];
 #pragma unroll
@@ -774,6 +790,8 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
     const bool force_rocprim = sort_env && !strcmp(sort_env, "rocprim");
     if (!force_rocprim && n_tables <= NRX_MAX_FEATURES) {
         SegArgs sa;
+        memset(sa.table_w, 0, sizeof(sa.table_w));
+        memset(sa.seg_db_w, 0, sizeof(sa.seg_db_w));
         const bool force_bins = sort_env && !strcmp(sort_env, "segmented-bins");      // tests: the seg_scan_bins path of very long segments
         int digit_cap = SEG_MAX_DB;                                   // NRX_PLAN_DIGIT_BITS narrows the digits (measurement knob)
         if (const char* e = getenv("NRX_PLAN_DIGIT_BITS")) { const int v = atoi(e); if (v >= 4 && v <= SEG_MAX_DB) digit_cap = v; }
@@ -793,13 +811,13 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
                 sa.qoff[slot] = q;
                 sa.poff[slot] = a.off[f];
                 sa.rows[slot] = rows[f];
-                sa.table[slot] = (uint8_t)t;
+                sa.table_w[slot >> 2] |= (uint32_t)(t & 255) << ((slot & 3) * 8);
                 if (rows[f] > seg_rows) seg_rows = rows[f];
                 q += lens[f];
                 ++slot;
             }
             const int db = (bits_for(seg_rows) + passes - 1) / passes;      // the segment's row bits, split evenly over the passes
-            sa.seg_db[t] = (uint8_t)db;
+            sa.seg_db_w[t >> 3] |= (uint32_t)(db & 15) << ((t & 7) * 4);
             if (db > max_db) max_db = db;
             const int tiles = (int)((q - sa.seg_off[t] + SEG_TILE - 1) / SEG_TILE);
             tile += tiles;
