@@ -491,12 +491,21 @@ def module_path_leg(path: "SingleGpuPath", prepared_fb_ms, steps: int):
             if model._sparse_sink is not None:
                 model._sparse_sink.clear()                    # (an optimizer would consume them here)
 
+        def fwd_bwd_hook():                                   # the step as a Lightning trainer drives it: LightningModule.backward(loss)
+            it["i"] += 1
+            p = model(batches[it["i"] & 1])
+            model.backward(p.sum())
+            if model._sparse_sink is not None:
+                model._sparse_sink.clear()
+
         g_ms, h_ms = timed(fwd_nograd, min(steps, 200))
         fb_ms, fbh_ms = timed(fwd_bwd, min(steps, 100))
+        fbk_ms, fbkh_ms = timed(fwd_bwd_hook, min(steps, 100))
         with torch.autograd.set_multithreading_enabled(False):      # backward nodes run on the calling thread: no hand-off to the engine's device thread
             fb1_ms, fb1h_ms = timed(fwd_bwd, min(steps, 100))
         out[f"B{B}"] = {"get_embeddings_from_batch_us": g_ms * 1e3, "get_embeddings_from_batch_host_us_per_call": h_ms * 1e3,
                         "forward_backward_autograd_us": fb_ms * 1e3, "forward_backward_host_us_per_step": fbh_ms * 1e3,
+                        "forward_backward_lightning_hook_us": fbk_ms * 1e3, "forward_backward_lightning_hook_host_us_per_step": fbkh_ms * 1e3,
                         "forward_backward_autograd_us_engine_thread_off": fb1_ms * 1e3,
                         "forward_backward_host_us_per_step_engine_thread_off": fb1h_ms * 1e3}
     if prepared_fb_ms:
@@ -504,9 +513,12 @@ def module_path_leg(path: "SingleGpuPath", prepared_fb_ms, steps: int):
         e["prepared_forward_backward_us"] = prepared_fb_ms * 1e3
         e["autograd_over_prepared"] = e["forward_backward_autograd_us"] / (prepared_fb_ms * 1e3)
         e["autograd_over_prepared_engine_thread_off"] = e["forward_backward_autograd_us_engine_thread_off"] / (prepared_fb_ms * 1e3)
+        e["lightning_hook_over_prepared"] = e["forward_backward_lightning_hook_us"] / (prepared_fb_ms * 1e3)
     out["note"] = ("GPU time per step from HIP events around back-to-back calls (host-bound when it equals the host time); the autograd step = "
                    "FM.forward(batch) + p.sum().backward() with the row-sparse gradients left in the model's SparseGradSink (planning on the side "
-                   "stream at forward time); `prepared` = the bound launches of the fwd_bwd leg; *_engine_thread_off = the same step under "
+                   "stream at forward time); `prepared` = the bound launches of the fwd_bwd leg; *_lightning_hook = the step with the backward entered "
+                   "through the model's LightningModule.backward hook (what a Lightning trainer calls; it runs the nodes on the calling thread); "
+                   "*_engine_thread_off = the plain step under "
                    "torch.autograd.set_multithreading_enabled(False): PyTorch's backward otherwise hands every step to its device thread, ~140 us "
                    "of wake-up and GIL hand-over per step on this host (tools/host_profile_module_step.py)")
     ops.flush_index_checks()

@@ -304,6 +304,14 @@ class BaseModel(LightningModule):
         self._val_score.append(scores.detach().float())
         self._val_label.append(batch["label"].reshape(-1)[:n].float())     # the reference zips view(-1): first n labels
 
+    def backward(self, loss, *args, **kwargs):
+        """Lightning hook (LightningModule.backward; the reference defines none: Lightning's default is ``loss.backward()``).  Every
+        reference trainer runs on ONE device (sort/deep/train.py:38-44, ``devices=1``), so the backward's nodes run on the calling thread:
+        PyTorch's engine otherwise hands each step to its device thread -- ~140 us of wake-up and GIL hand-over per step on the hosts
+        measured (profiles/r03_host_overhead.txt), more than the path's kernels take.  Same graph, same kernels, same results."""
+        with torch.autograd.set_multithreading_enabled(False):
+            loss.backward(*args, **kwargs)
+
     def on_train_epoch_end(self):
         """Lightning hook (the reference defines none on BaseModel): an out-of-range id met by the LAST training batches'
         deferred index checks must not stay unreported until some later call -- it raises here (IndexError)."""

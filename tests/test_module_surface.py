@@ -235,3 +235,20 @@ def test_deferred_index_report_with_several_plans_in_flight(monkeypatch):
     with pytest.raises(IndexError) as ei:
         ops._deferred_status(a)
     assert "feature 'user_history'" in str(ei.value)                      # one plan in the window: named plainly
+
+
+def test_lightning_backward_hook_gives_the_plain_backward_and_restores_the_engine_mode():
+    """BaseModel.backward (the LightningModule hook a trainer calls) runs the same backward on the calling thread: same gradients as
+    loss.backward(), and the process-wide autograd threading mode is what it was afterwards."""
+    m = Deep(cfg("cf_deep_small.yaml"))
+    head = torch.nn.Sequential(*[mod for mod in m.score_fc.modules() if isinstance(mod, torch.nn.Linear)][:1])      # the head's first layer (CPU: no kernels here)
+    x = torch.randn(6, head[0].in_features)
+    (head(x) ** 2).sum().backward()
+    want = [p.grad.clone() for p in head.parameters()]
+    for p in head.parameters():
+        p.grad = None
+    before = torch.autograd.is_multithreading_enabled()
+    m.backward((head(x) ** 2).sum())
+    assert torch.autograd.is_multithreading_enabled() == before
+    for p, w in zip(head.parameters(), want):
+        assert torch.equal(p.grad, w)
