@@ -104,7 +104,8 @@ def flush_index_checks() -> None:
 
 
 def _stream_ptr(t: torch.Tensor) -> int:
-    return torch.cuda.current_stream(t.device).cuda_stream
+    """Raw handle of the current stream of t's device (one C call: torch.cuda.current_stream() costs ~6 us of Python per call)."""
+    return torch._C._cuda_getCurrentRawStream(t.device.index)
 
 
 _BIND = None        # the compiled host binding (csrc/nrx_bind.cpp), False once it is known to be absent
@@ -149,6 +150,21 @@ def _bound_plan(plan):
 
 def _raw_stream(dev: torch.device) -> int:
     return torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+_stream_objs = {}
+
+
+def _cur_stream(dev: torch.device) -> "torch.cuda.Stream":
+    """torch.cuda.current_stream(dev), through a cache keyed by the raw handle (the Stream object is only needed for event calls)."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, torch._C._cuda_getCurrentRawStream(idx))
+    s = _stream_objs.get(key)
+    if s is None:
+        if len(_stream_objs) > 64:
+            _stream_objs.clear()
+        s = _stream_objs[key] = torch.cuda.current_stream(dev)
+    return s
 
 
 def _dev(t: torch.Tensor, what: str) -> torch.Tensor:
@@ -448,7 +464,7 @@ class _EmbedFn(torch.autograd.Function):
         if g_out is None and g_wide is None and g_fm is None:
             return (None,) * (7 + n_tables)
         dev = _table_meta(ctx)[0][1]
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _raw_stream(dev)
         if g_out is not None:
             g_out = _f32c(g_out, "grad of the concat")
         fmg = None
@@ -522,23 +538,26 @@ def sparse_plan_ahead(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows
     the dense part of the model and its backward occupy the main stream.  Returns ((order, uniq, seg, counts), event);
     the consumer makes its stream wait for `event` before reading the plan."""
     dev = ids[0].device
-    cur = torch.cuda.current_stream(dev)
+    cur = _cur_stream(dev)
     side = _plan_stream(dev)
     side.wait_stream(cur)                      # the ids are ready where the caller's stream is now
-    with torch.cuda.stream(side):
-        res = sparse_plan(ids, table_of, rows, n_tables, place_feats, static=static)
-        ev = torch.cuda.Event()
-        ev.record(side)
+    # The library takes the stream as an argument: the plan is enqueued on the side stream without making it PyTorch's current stream
+    # (`with torch.cuda.stream(side)` and the current_stream() lookups around it were ~50 us of host time per step).  The outputs and the
+    # workspace are therefore allocated under the CALLER's stream, after the wait above was recorded: whatever used their blocks before
+    # was enqueued on the caller's stream before that point, so the side stream's writes are ordered behind it; they are consumed (and
+    # later freed) on the caller's stream behind `ev`.  No record_stream anywhere.
+    hold = []
+    res = sparse_plan(ids, table_of, rows, n_tables, place_feats, static=static, stream=side.cuda_stream, keep=hold)
+    ev = torch.cuda.Event()
+    ev.record(side)
     # The planner READS the ids on the side stream: an id tensor that dies early (a .long() / .contiguous() temporary, a
     # csr_to_padded output, a forward whose loss is dropped without a backward) must not have its block handed out again on the
     # caller's stream while the sort still reads it.  One reference per plan, held until the plan's event has passed (26
-    # record_stream calls were 40 us of host time per step); the outputs, allocated under the side stream and consumed under the
-    # caller's, do need record_stream.
-    _plan_keepalive.append((ev, ids))
+    # record_stream calls were 40 us of host time per step).  The same reference keeps the plan's own tensors (and, through
+    # sparse_plan's return value, nothing else) alive when a forward is never followed by a backward.
+    _plan_keepalive.append((ev, ids, res, hold))
     while _plan_keepalive and _plan_keepalive[0][0].query():
         _plan_keepalive.popleft()
-    for t in res:
-        t.record_stream(cur)
     return res, ev
 
 
@@ -562,7 +581,7 @@ def place_mask(kinds: Sequence[int], bag_lens: Optional[Sequence[int]] = None) -
 
 
 def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int,
-                place_feats: Optional[int] = None, static=None):
+                place_feats: Optional[int] = None, static=None, stream: Optional[int] = None, keep: Optional[list] = None):
     """nrx_sparse_plan: group the flat, feature-major lookups `ids` (one device tensor per feature, all int32 or
     all int64) by (table, row).  Returns device int64 tensors (order [n], uniq_keys [n], seg_start [n+1],
     counts [n_tables+2]); only the first counts[0] entries of uniq_keys / counts[0]+1 of seg_start are
@@ -582,6 +601,10 @@ def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequ
     if nbytes < 0:
         raise ValueError("sparse_plan: too many lookups for one plan")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if stream is None:
+        stream = _raw_stream(dev)
+    elif keep is not None:
+        keep.append(ws)          # a foreign stream: the caller holds the workspace until the plan has run (sparse_plan_ahead)
     ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in ids])
     lens = (C.c_int64 * n)(*[x.numel() for x in ids])
     if static is not None:                     # (table_of, rows) as ctypes arrays, built once per plan group
@@ -595,10 +618,10 @@ def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequ
         n_walk = torch.empty(1, dtype=torch.int64, device=dev)
         check(lib.nrx_sparse_plan_place(ptrs, lens, tof, rws, n, ids[0].element_size() * 8, n_tables, int(place_feats), order.data_ptr(),
                                         uniq.data_ptr(), seg.data_ptr(), counts.data_ptr(), dest.data_ptr(), walk.data_ptr(),
-                                        n_walk.data_ptr(), ws.data_ptr(), _raw_stream(dev)), "nrx_sparse_plan_place")
+                                        n_walk.data_ptr(), ws.data_ptr(), stream), "nrx_sparse_plan_place")
         return order, uniq, seg, counts, dest, walk, n_walk
     check(lib.nrx_sparse_plan(ptrs, lens, tof, rws, n, ids[0].element_size() * 8, n_tables, order.data_ptr(), uniq.data_ptr(),
-                              seg.data_ptr(), counts.data_ptr(), ws.data_ptr(), _stream_ptr(ids[0])), "nrx_sparse_plan")
+                              seg.data_ptr(), counts.data_ptr(), ws.data_ptr(), stream), "nrx_sparse_plan")
     return order, uniq, seg, counts
 
 
@@ -667,7 +690,7 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
         pmask = grp["pmask"] if SPARSE_PLACE else None
         if pre is not None:                 # planned at forward time on the side stream (sparse_plan_ahead)
             ids, pl, ev = pre
-            torch.cuda.current_stream(dev).wait_event(ev)
+            _cur_stream(dev).wait_event(ev)
             total = pl[0].numel()
         else:
             ids = [ctx.ins[i] for i in fs]
