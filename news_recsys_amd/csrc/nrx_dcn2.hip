@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256, KEEPX ? 4 : 5) void dcn_v2_layer_kernel(const 
 #pragma unroll
                 for (int p = 0; p < 2; ++p) w[p] = *reinterpret_cast<const float4*>(wk + ow[p]);
             } else {                    // partial last slab: K % 4 == 0, so a float4 is all-in or all-out;
-                const bool ok = k0 + skq < K;                  // out-of-range lanes re-read slab 0 and zero it
-                const size_t back = ok ? 0 : (size_t)k0 * 4;
+                const bool ok = k0 + skq < K;                  // out-of-range lanes read column 0 of their row and zero it (k0 + skq of
+                const size_t back = ok ? 0 : (size_t)(k0 + skq) * 4;          // slab 0 lies past the row when K < 32: an out-of-bounds read at the tensor's end)
 #pragma unroll
                 for (int p = 0; p < AP; ++p) {
                     const float4 t = *reinterpret_cast<const float4*>(xk + oa[p] - back);
@@ -340,8 +340,8 @@ __global__ __launch_bounds__(256, 4) void dcn_v2_layer_bf16x3_kernel(const float
             for (int p = 0; p < 2; ++p) w[p] = *reinterpret_cast<const float4*>(wk + ow[p]);
             return;
         }
-        const bool ok = k0 + skq < K;                  // K % 4 == 0: a float4 is all-in or all-out; lanes past K re-read slab 0 and zero it
-        const size_t back = ok ? 0 : (size_t)k0 * 4;
+        const bool ok = k0 + skq < K;                  // K % 4 == 0: a float4 is all-in or all-out; lanes past K read column 0 of their row and zero it
+        const size_t back = ok ? 0 : (size_t)(k0 + skq) * 4;
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             const float4 t = *reinterpret_cast<const float4*>(xk + oa[p] - back);

@@ -289,8 +289,12 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
             } else {                    // partial last slab: out-of-range k re-reads slab kbeg's address and is zeroed
                 const bool oka = MODE == DGRAD ? k0 + skq + 4 <= kend : k0 + kk < kend;
                 const bool okb = k0 + kk < kend;
-                const size_t backa = oka ? 0 : (MODE == DGRAD ? (size_t)(k0 - kbeg) * 4 : (size_t)(k0 - kbeg) * (size_t)lda * 4);
-                const size_t backb = okb ? 0 : (size_t)(k0 - kbeg) * (size_t)ldb * 4;
+                // out-of-range lanes read the slice's FIRST k (column kbeg of their row / row kbeg of the K-major source): always inside the
+                // operand.  (They used to read "their" position of slab kbeg -- k = kbeg + skq, or source row kbeg + kk -- which lies past the
+                // row / past the batch when the slice is shorter than a slab: D = 16, or a batch of 11 rows read 20 rows past the end of the
+                // tensor.  The values were zeroed, so the results were right; the read faulted when the tensor ended at the end of a mapping.)
+                const size_t backa = oka ? 0 : (MODE == DGRAD ? (size_t)(k0 - kbeg + skq) * 4 : (size_t)(k0 - kbeg + kk) * (size_t)lda * 4);
+                const size_t backb = okb ? 0 : (size_t)(k0 - kbeg + kk) * (size_t)ldb * 4;
 #pragma unroll
                 for (int p = 0; p < AP; ++p) {
                     const float4 t = *reinterpret_cast<const float4*>(ak + oa[p] - backa);
