@@ -676,7 +676,9 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int acc_x0 = accumulate_x0 & 1;                          // bit 0: add to g_x0 instead of overwriting it
     const float* fold = (accumulate_x0 & 2) ? g_x0 : nullptr;      // bit 1: fold the (written or accumulated) g_x0 into g_xl (the stack's first layer)
-    if (nrx_zero_async(g_W, sizeof(float) * (size_t)dim * dim, st) != NRX_OK || nrx_zero_async(g_b, sizeof(float) * (size_t)dim, st) != NRX_OK)
+    if (g_b == g_W + (size_t)dim * dim) {          // g_b right behind g_W (what the Python layer allocates): one fill launch
+        if (nrx_zero_async(g_W, sizeof(float) * ((size_t)dim * dim + dim), st) != NRX_OK) return NRX_ERR_LAUNCH;
+    } else if (nrx_zero_async(g_W, sizeof(float) * (size_t)dim * dim, st) != NRX_OK || nrx_zero_async(g_b, sizeof(float) * (size_t)dim, st) != NRX_OK)
         return NRX_ERR_LAUNCH;
     if (batch == 0) return NRX_OK;
     const int64_t wld = (dim + 3) & ~3;
