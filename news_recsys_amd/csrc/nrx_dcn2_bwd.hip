@@ -195,9 +195,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM], int64_t m
 //   running side by side.  In block order tile-fastest over all XCDs (round 2) the 25 tiles of a slice at D = 320 were spread over the
 //   8 L2s: 616 MB fetched per launch for 168 MB of operands, 7.0 TB/s -- the launch was bound by exactly that
 //   (profiles/r03_dcn_v2_bf16x3.txt).
-// The fp32 kernel keeps the round-2 order (SLICE_PER_XCD = false): it is bound by the fp32 matrix rate, not by traffic, and with a
-// slice's tiles side by side on one XCD its launch got SLOWER (D = 320: 133 -> 155 us, same box A/B of the whole step 485 -> 510 us;
-// the split-bf16 launch 91 -> 84 us).
+// (With the round-2 slice count the fp32 launch got SLOWER under this order -- D = 320: 133 -> 155 us, step 485 -> 510 us -- until the count
+// was balanced over the XCDs' block slots: launch_wgrad.)
 template <int MODE, bool SLICE_PER_XCD>
 __device__ __forceinline__ void gemm_block_to_tile(unsigned bid, unsigned ntiles, unsigned& tile, unsigned& ks) {
     if (MODE == WGRAD && SLICE_PER_XCD) {
@@ -217,7 +216,8 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
                                                          int64_t M, int N, int64_t K, int64_t kslice, const float* __restrict__ addend,
                                                          int64_t add_ld, const uint32_t* __restrict__ maskT, int64_t mask_ld,
                                                          float* __restrict__ out, int64_t out_ld, unsigned nx, unsigned ntiles,
-                                                         const float* __restrict__ add2, int64_t add2_ld, float* __restrict__ colsum) {
+                                                         const float* __restrict__ add2, int64_t add2_ld, float* __restrict__ colsum,
+                                                         int slice_per_xcd = 0) {
     constexpr int TM = TMv, BM = 2 * TM * 32, LDA = BM + 1;      // TMv = 1: 64 x 64 block tiles (wgrad of narrow layers: twice the tiles)
     __shared__ float As[BK * LDA];
     __shared__ float Ws[BK * LDW];
@@ -228,7 +228,8 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
     const int l31 = lane & 31, hi = lane >> 5;
     // tile id (XCD-aware bijective remap as in the forward: the nx column tiles of one row panel share an L2) and K slice
     unsigned logical, ks;
-    gemm_block_to_tile<MODE, false>(blockIdx.x, ntiles, logical, ks);
+    if (MODE == WGRAD && slice_per_xcd) gemm_block_to_tile<MODE, true>(blockIdx.x, ntiles, logical, ks);
+    else gemm_block_to_tile<MODE, false>(blockIdx.x, ntiles, logical, ks);
     if ((int64_t)ks * kslice >= K) return;           // WGRAD: the slice count is rounded up to whole XCD rounds (block-uniform exit)
     const int64_t m0 = (int64_t)(logical / nx) * BM;
     const int n0 = (int)(logical % nx) * BN;
@@ -636,11 +637,28 @@ void launch_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, int 
     if (kslice < kmin) kslice = kmin;
     splits = (batch + kslice - 1) / kslice;
     const bool use_split = split && vec && colsum == nullptr;
-    const dim3 grid((unsigned)(nt * (use_split ? (splits + 7) / 8 * 8 : splits)));     // split kernel: whole XCD rounds of slices (gemm_block_to_tile); surplus blocks leave at once
+    // Slices per XCD (gemm_block_to_tile) with the slice count chosen so that every XCD's 32 x 4 block slots hold WHOLE slices in whole rounds:
+    // D = 320 (25 tiles of 64 x 64): 5 slices per XCD and round, 2 rounds -> 80 slices of 832 rows, 2000 blocks.  With the round-2 slice
+    // count (61) the same order left the XCDs unevenly loaded and the fp32 launch got slower (133 -> 155 us); balanced, it is faster for
+    // both kernels (same box, forward + backward per step: fp32 495.6 -> 491.5 us, split-bf16 343.6 -> 335.4, D = 512 1061 -> 1055).
+    // NRX_WGRAD_XCD=0 restores the round-2 order for the fp32 kernel and the unbalanced count.
+    static const int xcd_env = getenv("NRX_WGRAD_XCD") ? atoi(getenv("NRX_WGRAD_XCD")) : 1;
+    const bool xcd_fp32 = xcd_env == 1 && !use_split;
+    if (xcd_env == 1) {
+        const int64_t per_round = 128 / nt > 0 ? 128 / nt : 1;                 // slices an XCD's 32 x 4 block slots hold side by side
+        const int64_t want = env_blocks ? env_blocks : small ? 1536 : 1024;
+        int64_t rounds = (want + 4 * per_round * nt) / (8 * per_round * nt);
+        if (rounds < 1) rounds = 1;
+        splits = 8 * per_round * rounds;
+        kslice = ((batch + splits - 1) / splits + BK - 1) / BK * BK;
+        if (kslice < kmin) kslice = kmin;
+        splits = (batch + kslice - 1) / kslice;
+    }
+    const dim3 grid((unsigned)(nt * ((use_split || xcd_fp32) ? (splits + 7) / 8 * 8 : splits)));     // slices per XCD: whole XCD rounds of slices (gemm_block_to_tile); surplus blocks leave at once
 #define NRX_WGRAD(VEC_, TM_)                                                                                                          \
     hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, VEC_, TM_>), grid, dim3(256), 0, st, A, lda, B, ldb, (int64_t)M, N, batch, kslice,     \
                        (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, out, (int64_t)N, nx, nt,              \
-                       (const float*)nullptr, (int64_t)0, colsum)
+                       (const float*)nullptr, (int64_t)0, colsum, xcd_fp32 ? 1 : 0)
     if (use_split) {
         if (small) hipLaunchKernelGGL((dcn2_gemm_split_kernel<WGRAD, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, (int64_t)M, N, batch, kslice,
                                       (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, out, (int64_t)N, nx, nt, (const float*)nullptr, (int64_t)0);
