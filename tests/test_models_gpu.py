@@ -72,6 +72,22 @@ def test_model_forward_loss_and_all_grads_match_reference(cls, cfg_name, gname):
     np.testing.assert_allclose(inf.cpu().numpy(), g["out/forward"], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("cls,cfg_name,gname", [CASES[1], CASES[5]])
+def test_lightning_backward_hook_matches_the_reference_gradients(cls, cfg_name, gname):
+    """BaseModel.backward -- what a Lightning trainer calls instead of loss.backward() -- runs the SAME backward (on the calling
+    thread): every parameter gradient still matches the reference's, and the autograd threading mode is restored."""
+    g = gold(gname)
+    m = load_model(cls, cfg_name, g)
+    batch = batch_of(g)
+    before = torch.autograd.is_multithreading_enabled()
+    m.backward(m.bceLoss(m(batch), batch["label"][:, 0]))
+    assert torch.autograd.is_multithreading_enabled() == before
+    for k, p in m.named_parameters():
+        want = g["grad/" + k]
+        assert p.grad is not None, k
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want, rtol=2e-3, atol=2e-6 + 1e-4 * np.abs(want).max(), err_msg=k)
+
+
 def test_fm_materialising_api_bit_exact():
     g = gold("model_fm")
     m = load_model(FM, "cf_fm_small.yaml", g)
