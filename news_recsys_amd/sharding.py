@@ -819,6 +819,51 @@ def shard_model_(model, rank: int, world: int, group=None, backend=None):
     return model
 
 
+def full_state_dict(model, group=None) -> Dict[str, torch.Tensor]:
+    """Gather-on-save for a model converted by shard_model_: the REFERENCE's state_dict -- `embedding_tables.<name>.weight` as the full
+    [rows, D] table (base_model.py:531-536 loads it with strict=True), every other entry as it is (dense parameters are replicated) --
+    on every rank.  One all-gather per sharded table (shards padded to the longest, rank 0's); a checkpoint written from it loads into the
+    reference, into the unsharded mirror, or back into any world size through load_full_state_dict_."""
+    eng = getattr(model, "_shard_engine", None)
+    world = eng.world if eng is not None else 1
+    out: Dict[str, torch.Tensor] = {}
+    for k, v in model.state_dict().items():
+        name = k[len("embedding_tables."):-len(".weight")] if k.startswith("embedding_tables.") and k.endswith(".weight") else None
+        emb = model.embedding_tables[name] if name is not None and name in model.embedding_tables else None
+        rows = getattr(emb, "global_rows", None)
+        if rows is None or world == 1 or name in getattr(model, "_replicated_tables", ()):
+            out[k] = v.detach().clone()
+            continue
+        longest = local_row_count(rows, 0, world)
+        mine = local_row_count(rows, eng.rank, world)
+        pad = v.new_zeros((longest, v.shape[1]))
+        pad[:mine] = v.detach()[:mine]
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group if group is not None else eng.group)
+        out[k] = unshard_tables([p[:local_row_count(rows, r, world)] for r, p in enumerate(parts)])
+    return out
+
+
+def load_full_state_dict_(model, full: Dict[str, torch.Tensor], strict: bool = True):
+    """Scatter-on-load: a full (reference-shaped) state_dict into a model converted by shard_model_ -- every rank keeps rows rank::world of
+    each sharded table (a rank that owns no row of a tiny table keeps its one-row zero placeholder)."""
+    eng = getattr(model, "_shard_engine", None)
+    world, rank = (eng.world, eng.rank) if eng is not None else (1, 0)
+    local = {}
+    for k, v in full.items():
+        name = k[len("embedding_tables."):-len(".weight")] if k.startswith("embedding_tables.") and k.endswith(".weight") else None
+        emb = model.embedding_tables[name] if name is not None and name in model.embedding_tables else None
+        rows = getattr(emb, "global_rows", None)
+        if rows is None or world == 1 or name in getattr(model, "_replicated_tables", ()):
+            local[k] = v
+            continue
+        if v.shape[0] != rows:
+            raise ValueError(f"load_full_state_dict_: {k} has {v.shape[0]} rows, the sharded model was built for {rows}")
+        sh = shard_table(v, rank, world)
+        local[k] = sh if sh.shape[0] else v.new_zeros((1, v.shape[1]))
+    return model.load_state_dict(local, strict=strict)
+
+
 # --------------------------------------------------------------------------------- bench path (N > 1)
 class ShardedBenchPath:
     """bench.py's N>1 workload: the same synthetic configuration as the single-GPU path, tables
