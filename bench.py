@@ -428,6 +428,55 @@ class SingleGpuPath:
 
 
 # ------------------------------------------------------------------------------------ module path (the drop-in surface)
+MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X dense fp32 matrix peak (guides/MI355X_MICROARCH.md); v_mfma_f32_32x32x2_f32
+
+
+def dcn_v2_cross_leg(device, D: int):
+    """The C3 shape's DCN-v2 cross layer (x_{l+1} = x0 * (W x_l + b) + x_l, the path's only dense contraction) on
+    the matrix cores: one layer forward at B = 65 536 through the C-ABI (nrx_dcn_v2_layer_fwd), back-to-back launches after the clocks
+    have settled, HIP events on the launch stream.  fp32 = the default, value-exact against the C oracle; bf16x3 = the opt-in split-bf16
+    math (dcn_cfg.math), priced against the same fp32-equivalent flop count.  Algorithmic flops: (2 D^2 + 3 D) per row and layer."""
+    from news_recsys_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device=device).manual_seed(20260116 + 3)
+    x = torch.randn(BATCH, D, device=device, generator=gen)
+    W = torch.randn(D, D, device=device, generator=gen) / D ** 0.5
+    b = torch.randn(D, device=device, generator=gen) * 0.1
+    out = torch.empty_like(x)
+    lin = torch.empty_like(x)
+    st = torch.cuda.current_stream(device).cuda_stream
+    flops = (2.0 * D * D + 3.0 * D) * BATCH
+    res = {"shape": f"one cross layer, B = {BATCH}, D = {D} (the C3 concat width), x0 == x_l, ReLU, inputs resident in HBM",
+           "algorithmic_flops_per_launch": flops}
+    for name, flags in (("fp32", 1), ("bf16x3", 3)):
+        for train in (False, True):
+            lp = lin.data_ptr() if train else None
+            for _ in range(200):
+                lib.nrx_dcn_v2_layer_fwd(x.data_ptr(), x.data_ptr(), D, BATCH, D, W.data_ptr(), b.data_ptr(), flags, out.data_ptr(), D, lp, st)
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            n = 200
+            for _ in range(n):
+                lib.nrx_dcn_v2_layer_fwd(x.data_ptr(), x.data_ptr(), D, BATCH, D, W.data_ptr(), b.data_ptr(), flags, out.data_ptr(), D, lp, st)
+            e.record()
+            torch.cuda.synchronize()
+            us = a.elapsed_time(e) / n * 1e3
+            tf = flops / (us * 1e-6) / 1e12
+            if name == "fp32":
+                roof = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS}
+            else:       # three bf16 MFMAs per fragment pair: 16 us of matrix time at D = 320 -- the launch is bound by memory, priced as such
+                nbytes = (2 + (1 if train else 0)) * BATCH * D * 4 + D * D * 4 + D * 4      # x_l read, out (+ lin) written, W, b
+                gbps = nbytes / (us * 1e-6) / 1e9
+                roof = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                        "algorithmic_bytes_per_launch": nbytes, "fp32_equivalent_TFLOPs": tf}
+            res[name + ("_training_form" if train else "")] = {"us": us, "roofline": roof}
+    res["note"] = ("fp32: frac = algorithmic flops / launch time / the dense fp32 matrix peak.  bf16x3: the same contraction as three bf16 MFMAs per "
+                   "fragment pair (fp32 accumulate) leaves ~16 us of matrix time at this shape, so the launch is priced against HBM by its algorithmic "
+                   "bytes (x_l read once, out written once; profiles/r03_dcn_v2_bf16x3.txt says what it actually waits on); *_training_form also "
+                   "writes x_l W^T + b for the backward; counters: profiles/r03_dcn_*_rocprof_summary.txt")
+    return res
+
+
 def module_path_leg(path: "SingleGpuPath", prepared_fb_ms, steps: int):
     """The same C2 work through the DROP-IN surface (what a user of the reference touches): the package's FM model class built from a
     train_cf_fm.yaml-shaped config with the bench's 26 x 1M x 16 tables -- FM.get_embeddings_from_batch / FM.forward(batch) on an input
@@ -780,7 +829,7 @@ def main():
             stream_copy = None
 
     # secondary legs at N = 1, outside the headline timed region
-    distinct = fwd_bwd = wide_split = module_path = None
+    distinct = fwd_bwd = wide_split = module_path = dcn_v2_cross = None
     if world == 1 and not args.force_sharded and not args.headline_only:
         def time_calls(fn, n):
             # warm-up by TIME (>= 50 ms of the same launches): the legs that contain latency-bound launches (the backward's
@@ -856,6 +905,11 @@ def main():
                                "upstream gradients g_out [B, width]" + (" and g_fm [B]" if path.fm else "") + " given; result = unique "
                                "(table,row) keys + summed row gradients on the device (what optim.FusedSparseAdam consumes)"}
             del fwd, bwd
+        if args.workload == "c3":
+            try:
+                dcn_v2_cross = dcn_v2_cross_leg(device, sum(f["dim"] for f in path.feats))
+            except Exception as e:          # noqa: BLE001 -- a secondary leg must not cost the headline
+                dcn_v2_cross = {"error": f"{type(e).__name__}: {e}"}
         if args.workload == "c2" and args.ids == "uniform" and os.environ.get("NRX_BENCH_MODULE_PATH", "1") != "0":
             try:
                 module_path = module_path_leg(path, fwd_bwd["ms_per_step"] if fwd_bwd else None, steps2)
@@ -929,6 +983,8 @@ def main():
             out["fwd_bwd"] = fwd_bwd
         if module_path is not None:
             out["module_path"] = module_path
+        if dcn_v2_cross is not None:
+            out["dcn_v2_cross"] = dcn_v2_cross
         if world == 1 and not args.no_cpu_baseline and not args.force_sharded:
             big = sum(t.numel() for t in path.tables) * 4 > (64 << 30)      # host copies of > 64 GB of tables: skip
             if not big:
