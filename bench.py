@@ -470,6 +470,27 @@ def dcn_v2_cross_leg(device, D: int):
                 roof = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
                         "algorithmic_bytes_per_launch": nbytes, "fp32_equivalent_TFLOPs": tf}
             res[name + ("_training_form" if train else "")] = {"us": us, "roofline": roof}
+    # forward + hand-written backward (prep + dgrad + wgrad) of the one layer through the autograd wrapper (ops.dcn_v2): three GEMMs of 2 D^2 B flops
+    from news_recsys_amd import ops
+    xg = x.clone().requires_grad_(True)
+    Wg, bg = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    up = torch.randn(BATCH, D, device=device, generator=gen)
+    for name in ("fp32", "bf16x3"):
+        def step():
+            torch.autograd.grad(ops.dcn_v2(xg, [Wg], [bg], math=name), [xg, Wg, bg], up)
+        for _ in range(60):
+            step()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        n = 60
+        for _ in range(n):
+            step()
+        e.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(e) / n * 1e3
+        tf = 3 * 2.0 * D * D * BATCH / (us * 1e-6) / 1e12
+        res[name + "_forward_backward"] = {"us": us, "fp32_equivalent_TFLOPs": tf, "frac_of_fp32_matrix_peak": tf / MFMA_F32_PEAK_TFLOPS,
+                                           "flops": "3 x 2 D^2 B (forward, dgrad, wgrad)"}
     res["note"] = ("fp32: frac = algorithmic flops / launch time / the dense fp32 matrix peak.  bf16x3: the same contraction as three bf16 MFMAs per "
                    "fragment pair (fp32 accumulate) leaves ~16 us of matrix time at this shape, so the launch is priced against HBM by its algorithmic "
                    "bytes (x_l read once, out written once; profiles/r03_dcn_v2_bf16x3.txt says what it actually waits on); *_training_form also "
