@@ -173,6 +173,32 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_generic(const EmbedArgs a
                         const BagPair* row = s_bag + sb * stride;
                         constexpr int U = 8;
                         int l = 0;
+                        // 16-byte-aligned tables (every reference shape): the U row loads of a pass are issued unconditionally -- an entry with
+                        // weight 0 reads row 0 and its value is replaced by zeros where it is USED.  A load behind `if (w != 0)` is a branch around
+                        // a load: the compiler then waits vmcnt(0) in front of every one of them and the eight loads go out one behind the other
+                        // (seen in the ISA); so does the aligned / unaligned choice inside load_row4 when it is made per load.
+                        if (vec_load) {
+                            for (; l + U <= cur; l += U) {
+                                BagPair p[U];
+                                float4 r[U];
+#pragma unroll
+                                for (int u = 0; u < U; ++u) p[u] = row[l + u];
+#pragma unroll
+                                for (int u = 0; u < U; ++u)
+                                    r[u] = *reinterpret_cast<const float4*>(f.table + (int64_t)(p[u].w != 0.f ? p[u].id : 0) * (int64_t)D + k0);
+#pragma unroll
+                                for (int u = 0; u < U; ++u) {
+#pragma clang fp contract(off)
+                                    const bool on = p[u].w != 0.f;
+                                    const float rx = on ? r[u].x : 0.f, ry = on ? r[u].y : 0.f, rz = on ? r[u].z : 0.f, rw = on ? r[u].w : 0.f;
+                                    den += p[u].w;
+                                    acc.x += rx * p[u].w;
+                                    acc.y += ry * p[u].w;
+                                    acc.z += rz * p[u].w;
+                                    acc.w += rw * p[u].w;
+                                }
+                            }
+                        }
                         for (; l + U <= cur; l += U) {
                             BagPair p[U];
                             float4 r[U];
