@@ -117,6 +117,45 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_generic(const EmbedArgs a
     float4 fm_s = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 fm_q = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // The first few single-valued features of one chunk (dim <= 4Q, 16-byte-aligned table) are fetched UP FRONT -- id, then row -- so that their
+    // two dependent round trips run under the first bag feature's staging instead of in front of / behind it (a DSSM tower: user id + history
+    // bag + item id).  Which features those are is wave-uniform (scalar loads of the descriptors); the values wait in registers.
+    constexpr int NPRE = 4;
+    int pre_feat[NPRE];
+    float4 pre_row[NPRE];
+    {
+        int ns = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < NPRE; ++s2) pre_feat[s2] = -1;
+        for (int fi = 0; fi < a.n && ns < NPRE; ++fi) {
+            const FeatDev& f = a.f[fi];
+            if (f.kind == NRX_SPARSE && f.dim <= 4 * Q && (f.dim & 3) == 0 && (reinterpret_cast<uintptr_t>(f.table) & 15u) == 0) {
+#pragma unroll
+                for (int s2 = 0; s2 < NPRE; ++s2)
+                    if (s2 == ns) pre_feat[s2] = fi;
+                ++ns;
+            }
+        }
+        int64_t pid[NPRE];
+#pragma unroll
+        for (int s2 = 0; s2 < NPRE; ++s2) {
+            const int fi = pre_feat[s2] >= 0 ? pre_feat[s2] : 0;
+            pid[s2] = (pre_feat[s2] >= 0 && live) ? nrx_load_id(a.f[fi].index, b, a.f[fi].idx64) : 0;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < NPRE; ++s2) {
+            pre_row[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pre_feat[s2] >= 0) {
+                const FeatDev& f = a.f[pre_feat[s2]];
+                if ((uint64_t)pid[s2] >= (uint64_t)f.rows) {
+                    if (q == 0 && live) nrx_report_oob(a.status, a.feat_id[pre_feat[s2]], b, pid[s2]);
+                    pid[s2] = 0;
+                }
+                if (live && q * 4 < f.dim) pre_row[s2] = *reinterpret_cast<const float4*>(f.table + pid[s2] * (int64_t)f.dim + q * 4);
+            }
+        }
+    }
+
     for (int fi = 0; fi < a.n; ++fi) {
         const FeatDev& f = a.f[fi];
         const int D = f.dim;
@@ -125,7 +164,13 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_generic(const EmbedArgs a
             const int k0 = kc + q * 4;
             const bool active = live && k0 < D;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f.kind == NRX_SPARSE) {
+            bool pre = false;
+#pragma unroll
+            for (int s2 = 0; s2 < NPRE; ++s2)
+                if (fi == pre_feat[s2]) { v = pre_row[s2]; pre = true; }          // wave-uniform
+            if (pre) {
+                // fetched up front
+            } else if (f.kind == NRX_SPARSE) {
                 if (active) {
                     int64_t id = nrx_load_id(f.index, b, f.idx64);
                     if ((uint64_t)id >= (uint64_t)f.rows) {
