@@ -198,7 +198,47 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_generic(const EmbedArgs a
                 for (int l0 = 0; l0 < L; l0 += lc) {
                     const int cur = (L - l0) < lc ? (L - l0) : lc;
                     __syncthreads();
-                    for (int e = tid; e < nb * cur; e += NRX_BLOCK) {
+                    int e_first = tid;
+                    if (!(f.flags & NRX_FEAT_BAG_CSR)) {
+                        // padded form: four entries per thread and round, their id / weight loads issued together (one entry per round put
+                        // ~12 dependent round trips in front of the block's first row load at L = 50)
+                        constexpr int SU = 4;
+                        const int n_e = nb * cur;
+                        const bool has_w = f.weight != nullptr;
+                        for (; e_first < n_e; e_first += SU * NRX_BLOCK) {
+                            int64_t id4[SU];
+                            float w4[SU];
+                            int pos4[SU];
+#pragma unroll
+                            for (int u = 0; u < SU; ++u) {
+                                const int e = e_first + u * NRX_BLOCK;
+                                const int ec = e < n_e ? e : n_e - 1;
+                                const int s = ec / cur;
+                                const int l = ec - s * cur;
+                                const int64_t gi = (b0 + s) * (int64_t)L + l0 + l;
+                                pos4[u] = s * stride + l;
+                                id4[u] = nrx_load_id(f.index, gi, f.idx64);
+                                w4[u] = has_w ? f.weight[gi] : 1.0f;
+                            }
+#pragma unroll
+                            for (int u = 0; u < SU; ++u) {
+                                const int e = e_first + u * NRX_BLOCK;
+                                if (e < n_e) {
+                                    int64_t id = id4[u];
+                                    if ((uint64_t)id >= (uint64_t)f.rows) {
+                                        nrx_report_oob(a.status, a.feat_id[fi], b0 + e / cur, id);
+                                        id = 0;
+                                    }
+                                    BagPair p;
+                                    p.id = (int32_t)id;
+                                    p.w = w4[u];
+                                    s_bag[pos4[u]] = p;
+                                }
+                            }
+                        }
+                        e_first = nb * cur;          // (nothing left for the per-entry loop below)
+                    }
+                    for (int e = e_first; e < nb * cur; e += NRX_BLOCK) {
                         const int s = e / cur;
                         const int l = e - s * cur;
                         int64_t id;
