@@ -1672,8 +1672,25 @@ __global__ __launch_bounds__(NRX_BLOCK) void bag_scale_kernel(const float* __res
     const int64_t b = ((int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x) >> 4;
     if (b >= batch) return;                                   // whole 16-lane groups leave together
     float den = 0.f;
+    // L <= 64 (every reference shape): a lane's up to four weights are loaded TOGETHER and kept for the second loop -- the two loops each
+    // put one dependent round trip per 16 entries in front of the next
+    constexpr int WK = 4;
+    float wk[WK];
+    const bool keep = L <= 16 * WK && w != nullptr && kind != NRX_BAG_MEAN;
+    if (keep) {
+#pragma unroll
+        for (int i = 0; i < WK; ++i) {
+            const int l = q + 16 * i;
+            wk[i] = w[b * L + (l < L ? l : L - 1)];
+        }
+    }
     if (kind == NRX_BAG_MASKED_MEAN) {
-        for (int l = q; l < L; l += 16) den += w[b * L + l];
+        if (keep) {
+#pragma unroll
+            for (int i = 0; i < WK; ++i) den += q + 16 * i < L ? wk[i] : 0.f;
+        } else {
+            for (int l = q; l < L; l += 16) den += w[b * L + l];
+        }
         den = group_sum<16>(den) + 1e-8f;
     }
     const float one = kind == NRX_BAG_MASKED_MEAN ? 1.0f / den : (kind == NRX_BAG_MEAN ? 1.0f / (float)L : 1.0f);
@@ -1689,7 +1706,13 @@ __global__ __launch_bounds__(NRX_BLOCK) void bag_scale_kernel(const float* __res
     for (int l0 = 0; l0 < L; l0 += 16) {
         const int l = l0 + q;
         const bool in = l < L;
-        const float wv = (in && w != nullptr && kind != NRX_BAG_MEAN) ? w[b * L + l] : 1.0f;
+        float wv = 1.0f;
+        if (keep) {
+            const int i = l0 >> 4;
+            wv = in ? (i == 0 ? wk[0] : i == 1 ? wk[1] : i == 2 ? wk[2] : wk[3]) : 1.0f;
+        } else if (in && w != nullptr && kind != NRX_BAG_MEAN) {
+            wv = w[b * L + l];
+        }
         if (in) {
             float v;
             if (kind == NRX_BAG_MASKED_MEAN) v = wv / den;
