@@ -237,6 +237,44 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_generic(const EmbedArgs a
                             }
                         }
                         e_first = nb * cur;          // (nothing left for the per-entry loop below)
+                    } else if (s_off[nb] > s_off[0]) {
+                        // CSR form, same batching: positions past a bag's end read the block's first value (there is one) and become {0, pad weight}
+                        constexpr int SU = 4;
+                        const int n_e = nb * cur;
+                        const int64_t blk_first = s_off[0];
+                        const float pad_w = f.kind == NRX_BAG_MEAN ? 1.0f : 0.f;
+                        for (; e_first < n_e; e_first += SU * NRX_BLOCK) {
+                            int64_t id4[SU];
+                            bool in4[SU];
+                            int pos4[SU];
+#pragma unroll
+                            for (int u = 0; u < SU; ++u) {
+                                const int e = e_first + u * NRX_BLOCK;
+                                const int ec = e < n_e ? e : n_e - 1;
+                                const int s = ec / cur;
+                                const int l = ec - s * cur;
+                                const int64_t o0 = s_off[s];
+                                in4[u] = (int64_t)(l0 + l) < s_off[s + 1] - o0;
+                                pos4[u] = s * stride + l;
+                                id4[u] = nrx_load_id(f.index, in4[u] ? o0 + l0 + l : blk_first, f.idx64);
+                            }
+#pragma unroll
+                            for (int u = 0; u < SU; ++u) {
+                                const int e = e_first + u * NRX_BLOCK;
+                                if (e < n_e) {
+                                    int64_t id = in4[u] ? id4[u] : 0;
+                                    if ((uint64_t)id >= (uint64_t)f.rows) {
+                                        nrx_report_oob(a.status, a.feat_id[fi], b0 + e / cur, id);
+                                        id = 0;
+                                    }
+                                    BagPair p;
+                                    p.id = (int32_t)id;
+                                    p.w = in4[u] ? 1.0f : pad_w;
+                                    s_bag[pos4[u]] = p;
+                                }
+                            }
+                        }
+                        e_first = nb * cur;
                     }
                     for (int e = e_first; e < nb * cur; e += NRX_BLOCK) {
                         const int s = e / cur;
