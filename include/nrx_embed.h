@@ -226,6 +226,16 @@ NRX_API int nrx_sparse_adam_step(float* const* tables, float* const* exp_avg, fl
                          const int64_t* n_unique_dev, float step_size, const float* step_size_dev, float beta1,
                          float beta2, float eps, float lr_times_weight_decay, void* stream);
 
+/* Unique-row gradients -> dense gradient tables: for every unique entry u of nrx_sparse_plan / nrx_embed_bwd_sorted
+ * (key = (table << 40) | row, gradient rows[u, :dim]), tables[table][row, :dim] = rows[u] (accumulate == 0) or += rows[u]
+ * (accumulate != 0: a table fed by more than one reduction).  With zero-filled tables this forms what autograd gives the
+ * reference's nn.Embedding(size, dim, padding_idx=0) tables (src/model/BaseModel/base_model.py:164) -- a dense [rows, dim] .grad --
+ * from the deterministic sorted reduction, instead of the float atomics of nrx_embed_bwd.  tables: HOST array of n_tables
+ * (<= NRX_MAX_FEATURES) device pointers, all non-null.  n_unique_dev (optional, device int64[1]): actual count; n_unique is
+ * then an upper bound sizing the launch. */
+NRX_API int nrx_rows_to_dense(float* const* tables, int32_t n_tables, int32_t dim, const int64_t* uniq_keys, const float* rows,
+                      int64_t n_unique, const int64_t* n_unique_dev, int32_t accumulate, void* stream);
+
 /* Composite sort keys for nrx_embed_bwd_sorted over SEVERAL tables at once: for the flat,
  * feature-major lookup list of n_feats features (ids[f]: lens[f] elements; HOST pointer arrays),
  * keys[p] = (table_of[f] << 40) | id, so that one stable sort groups the lookups by (table, row).

@@ -114,6 +114,7 @@ SIGNATURES = {
     "nrx_sparse_plan_place": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, C.c_uint64, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nrx_sparse_adam_step": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p, _i64, _p, C.c_float, _p, C.c_float, C.c_float, C.c_float,
                                        C.c_float, _p]),
+    "nrx_rows_to_dense": (C.c_int, [_p, _i32, _i32, _p, _p, _i64, _p, _i32, _p]),
     "nrx_topk_workspace": (_i64, [_i64, _i64, _i32]),
     "nrx_topk_ip": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
 }

@@ -1334,7 +1334,114 @@ __global__ __launch_bounds__(NRX_BLOCK) void sparse_adam_kernel(const SparseAdam
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// Unique-row gradients -> dense gradient tables (the DEFAULT backward of the gather: nn.Embedding(sparse=False)'s
+// [rows, dim] .grad, formed from the deterministic sorted reduction instead of float atomics).
+// One lane group per 4 unique rows: key loads, then 4 independent row loads, then the stores.
+// --------------------------------------------------------------------------------------------
+struct RowsToDenseArgs {
+    float* table[NRX_MAX_FEATURES];
+    const int64_t* keys;        // (table << 40) | row, one per unique row
+    const float* rows;          // [n, dim]
+    const int64_t* n_dev;       // optional: actual count on the device
+    int64_t max_n;
+    int32_t n_tables;
+    int32_t dim;
+    int32_t accumulate;         // != 0: table row += (a table fed by more than one reduction); 0: plain store
+};
+
+template <int QLOG2, bool VEC, bool ACC>
+__global__ __launch_bounds__(NRX_BLOCK) void rows_to_dense_kernel(const RowsToDenseArgs args_in_kernarg) {
+    const NRX_CONST RowsToDenseArgs* a = nrx_kernarg<RowsToDenseArgs>();
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    constexpr int R = 4;
+    const int q = threadIdx.x & (Q - 1);
+    const int D = a->dim;
+    int64_t n = a->max_n;
+    if (a->n_dev != nullptr) {
+        const int64_t nd = nrx_gconst<int64_t>(a->n_dev)[0];
+        n = nd < n ? nd : n;
+    }
+    const int64_t u0 = ((int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2)) * R;
+    if (u0 >= n) return;
+    int64_t key[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) key[r] = u0 + r < n ? nrx_gconst<int64_t>(a->keys)[u0 + r] : -1;
+    float* p[R];
+    bool on[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t t = key[r] >> 40, row = key[r] & ((1ll << 40) - 1);
+        on[r] = key[r] >= 0 && t < a->n_tables;
+        p[r] = a->table[on[r] ? t : 0] + (on[r] ? row : 0) * D;
+    }
+    if (VEC) {
+        for (int k = q * 4; k < D; k += 4 * Q) {
+            float4 g[R], w[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                g[r] = nrx_ldg4(a->rows + (u0 + (on[r] ? r : 0)) * (int64_t)D + k, 0);
+                if (ACC) w[r] = nrx_ldg4(p[r] + k, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (on[r]) {
+                    if (ACC) { g[r].x += w[r].x; g[r].y += w[r].y; g[r].z += w[r].z; g[r].w += w[r].w; }
+                    nrx_stg4(p[r] + k, 0, g[r]);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (!on[r]) continue;
+            const float* g = a->rows + (u0 + r) * (int64_t)D;
+            for (int k = q; k < D; k += Q) p[r][k] = ACC ? p[r][k] + g[k] : g[k];
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int nrx_rows_to_dense(float* const* tables, int32_t n_tables, int32_t dim, const int64_t* uniq_keys, const float* rows,
+                                 int64_t n_unique, const int64_t* n_unique_dev, int32_t accumulate, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(n_tables >= 1 && n_tables <= NRX_MAX_FEATURES && dim >= 1 && n_unique >= 0, "nrx_rows_to_dense: bad argument");
+    if (n_unique == 0) return NRX_OK;
+    NRX_REQUIRE(tables && uniq_keys && rows, "nrx_rows_to_dense: null buffer");
+    RowsToDenseArgs a;
+    bool vec = (dim & 3) == 0 && nrx_aligned16(rows);
+    for (int t = 0; t < n_tables; ++t) {         // (tables of another width may be listed: the keys of this call never name them)
+        NRX_REQUIRE(tables[t] != nullptr, "nrx_rows_to_dense: table %d: null pointer", t);
+        a.table[t] = tables[t];
+        vec = vec && nrx_aligned16(tables[t]);
+    }
+    a.keys = uniq_keys;
+    a.rows = rows;
+    a.n_dev = n_unique_dev;
+    a.max_n = n_unique;
+    a.n_tables = n_tables;
+    a.dim = dim;
+    a.accumulate = accumulate;
+    int ql = 0;
+    while ((4 << ql) < dim && ql < 6) ++ql;
+    const int tb = NRX_BLOCK >> ql;
+    const int64_t groups = (n_unique + 3) / 4;
+    const unsigned grid = (unsigned)((groups + tb - 1) / tb);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define NRX_RD2(QL_, V_) if (accumulate) hipLaunchKernelGGL((rows_to_dense_kernel<QL_, V_, true>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
+                         else hipLaunchKernelGGL((rows_to_dense_kernel<QL_, V_, false>), dim3(grid), dim3(NRX_BLOCK), 0, st, a)
+#define NRX_RD(QL_) if (vec) { NRX_RD2(QL_, true); } else { NRX_RD2(QL_, false); }
+    switch (ql) {
+        case 0: NRX_RD(0); break; case 1: NRX_RD(1); break; case 2: NRX_RD(2); break; case 3: NRX_RD(3); break;
+        case 4: NRX_RD(4); break; case 5: NRX_RD(5); break; default: NRX_RD(6); break;
+    }
+#undef NRX_RD
+#undef NRX_RD2
+    NRX_LAUNCH_CHECK("nrx_rows_to_dense");
+    return NRX_OK;
+}
 
 extern "C" int nrx_sparse_adam_step(float* const* tables, float* const* exp_avg, float* const* exp_avg_sq, int32_t n_tables,
                                     int32_t dim, const int64_t* uniq_keys, const float* grads, int64_t n_unique,

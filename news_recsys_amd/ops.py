@@ -16,6 +16,7 @@ Operator                          replaces (reference file:line)
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
@@ -340,6 +341,30 @@ def _table_meta(ctx):
     return tm
 
 
+def _zero_grad_tables(meta):
+    """Zero-filled dense gradient tables: ONE allocation and ONE fill for all of them when they live on one device (26 tables
+    were 26 fill launches, ~100 us of host time per step); each table a view of it (row-aligned when all share one row width,
+    else 256-byte aligned)."""
+    if len(meta) < 2 or any(d != meta[0][1] for _, d in meta):
+        return [torch.zeros(shape, dtype=torch.float32, device=d) for shape, d in meta]
+    if all(len(shape) == 2 and shape[1] == meta[0][0][1] for shape, _ in meta):      # one row width: one split, no per-table slicing
+        rows = [shape[0] for shape, _ in meta]
+        return list(torch.zeros((sum(rows), meta[0][0][1]), dtype=torch.float32, device=meta[0][1]).split_with_sizes(rows))
+    offs, tot = [], 0
+    for shape, _ in meta:
+        offs.append(tot)
+        tot += (math.prod(shape) + 63) & ~63
+    buf = torch.zeros(tot, dtype=torch.float32, device=meta[0][1])
+    return [buf[o:o + math.prod(shape)].view(shape) for o, (shape, _) in zip(offs, meta)]
+
+
+def _dense_sorted_ok(plan, tables, sparse_grad, B) -> bool:
+    return (not sparse_grad and DENSE_BWD_SORTED and B > 0 and bool(tables) and tables[0].is_cuda
+            and not torch.cuda.is_current_stream_capturing()
+            and not any(s.flags & NRX_FEAT_BAG_CSR for s in plan.slots)
+            and any(s.kind != NRX_DENSE for s in plan.slots))
+
+
 class _EmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan: EmbedPlan, inputs, weights, out_ld, need_out, sparse_grad, index_check, *tables):
@@ -438,7 +463,10 @@ class _EmbedFn(torch.autograd.Function):
         ctx.has_fm_feat = bool(plan.use_fm and need_out)
         ctx.fm_sums = sums
         ctx.plans = None
-        if ctx.sparse_grad and PLAN_AHEAD and B > 0 and not torch.cuda.is_current_stream_capturing() and \
+        # default (dense-gradient) mode: the table grads are formed by the sorted reduction + nrx_rows_to_dense unless
+        # NRX_DENSE_BWD=atomic, the launch is being captured (the planner allocates) or a bag arrives as CSR
+        ctx.dense_sorted = _dense_sorted_ok(plan, tables, ctx.sparse_grad, B)
+        if (ctx.sparse_grad or ctx.dense_sorted) and PLAN_AHEAD and B > 0 and not torch.cuda.is_current_stream_capturing() and \
                 any(t.requires_grad for t in tables):
             ctx.plans = {}
             for g_ in _sparse_group_cache(plan, tables):
@@ -489,8 +517,10 @@ class _EmbedFn(torch.autograd.Function):
             return (None,) * (7 + n_tables)
         if ctx.sparse_grad:
             return (None, None, None, None, None, None, None, *_sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg))
-        grads = [torch.zeros(shape, dtype=torch.float32, device=d) for shape, d in _table_meta(ctx)]
-        if B > 0 and (g_out is not None or g_wide is not None or fmg is not None):
+        grads = _zero_grad_tables(_table_meta(ctx))
+        if getattr(ctx, "dense_sorted", False) and B > 0 and n_tables <= NRX_MAX_FEATURES:
+            _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg, dense_into=grads)
+        elif B > 0 and (g_out is not None or g_wide is not None or fmg is not None):
             gptrs = [g.data_ptr() for g in grads]
             n = len(plan.slots)
             for lo in range(0, n, NRX_MAX_FEATURES):
@@ -518,6 +548,7 @@ SPARSE_BWD_SYNC_FREE = False   # True: size the reduction for the worst case and
 
 
 _plan_streams = {}
+DENSE_BWD_SORTED = os.environ.get("NRX_DENSE_BWD", "sorted") != "atomic"      # default-mode table grads: sorted reduction (deterministic) or float atomics
 PLAN_AHEAD = True      # row-sparse training: plan the backward (sort, unique rows, segments) at FORWARD time on a side stream
 
 
@@ -669,18 +700,21 @@ def _sparse_groups(plan: EmbedPlan):
     return out
 
 
-def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
+def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=None):
     """Row-sparse, deterministic table grads.  Per group of tables sharing an embedding dim: ONE planning
     call (nrx_sparse_plan: compact (table, row) keys, table-segmented stable radix sort of the row bits, head
     flags + scan -> unique rows, segment starts, per-table split, all on the device), one host read of
     n_tables + 2 integers, ONE segmented-reduction launch (nrx_embed_bwd_sorted) summing the upstream rows
     of every unique (table, row) in sorted order.  No dense zero-fill, no atomics, bit-reproducible;
     padding rows get explicit zeros.  Returns torch.sparse_coo tensors (what nn.Embedding(sparse=True)
-    produces), usable with SGD / SparseAdam / Adagrad."""
+    produces), usable with SGD / SparseAdam / Adagrad.
+    dense_into (a list of zero-filled [rows, dim] tensors, one per table): the DEFAULT dense-gradient mode -- the same
+    planning and reduction, no host read at all, then nrx_rows_to_dense stores every unique row's sum at its place."""
     plan, B, ld = ctx.plan, ctx.B, ctx.ld
     tables = ctx.tables_ref
     n_tables = len(tables)
     grads = [None] * n_tables
+    dense_ptrs, dense_seen = None, set()
     MASK = (1 << 40) - 1
     ahead = getattr(ctx, "plans", None) or {}
     for grp in _sparse_group_cache(plan, tables):
@@ -710,6 +744,16 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
         if wsz is None or wsz[0] != B:
             wsz = grp["lws_bytes"] = (B, lib.nrx_embed_bwd_workspace_for(arr, n, B, D))
         lws = torch.empty(wsz[1], dtype=torch.uint8, device=dev)   # hot-row work lists, bag scales
+        if dense_into is not None:
+            values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
+            _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, total, counts, fmg, values, lws, stream)
+            if dense_ptrs is None:
+                dense_ptrs = (C.c_void_p * n_tables)(*[g.data_ptr() for g in dense_into])
+            again = any(t in dense_seen for t in tabs)      # > NRX_MAX_FEATURES features: a table may be fed by two groups
+            check(lib.nrx_rows_to_dense(dense_ptrs, n_tables, D, uniq.data_ptr(), values.data_ptr(), total, counts.data_ptr(),
+                                        1 if again else 0, stream), "nrx_rows_to_dense")
+            dense_seen.update(tabs)
+            continue
         if ctx.sink is not None:
             values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
             _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, total, counts, fmg, values, lws, stream)
@@ -731,7 +775,7 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None):
             lo, hi = cl[1 + t], cl[2 + t]
             g = torch.sparse_coo_tensor(rows[:, lo:hi], values[lo:hi], size=tables[t].shape, is_coalesced=True)
             grads[t] = g if grads[t] is None else (grads[t] + g).coalesce()
-    if ctx.sink is not None:
+    if ctx.sink is not None or dense_into is not None:
         return grads                        # the results went to the sink: no (empty) COO tensors to build -- 26 of them were 130 us per step
     for t in range(n_tables):
         if grads[t] is None:
@@ -1363,6 +1407,7 @@ class _EmbedDcnFn(torch.autograd.Function):
         ctx.has_fm_feat = False
         ctx.sink = sparse_grad if isinstance(sparse_grad, SparseGradSink) else None
         ctx.sparse_grad = bool(sparse_grad)
+        ctx.dense_sorted = _dense_sorted_ok(plan, tables, ctx.sparse_grad, call.B)
         ctx.tables = list(tables) if ctx.sink is not None else None
         ctx.save_for_backward(call.out, call.w, call.b)
         ctx.w_shape, ctx.b_shape = tuple(w.shape), tuple(b.shape)

@@ -1,0 +1,151 @@
+"""The DEFAULT (dense-gradient) backward of the gather -- what autograd gives the reference's nn.Embedding(size, dim, padding_idx=0)
+tables (src/model/BaseModel/base_model.py:164; backward of :262-308, + fm/model.py:18-26, widedeep/model.py:53-69) -- formed by the
+sorted reduction + nrx_rows_to_dense (ops.DENSE_BWD_SORTED, the default) against
+
+  * the row-sparse mode's COO gradients made dense: the same reduction, so BIT FOR BIT;
+  * itself, run twice: bit for bit (the mode is deterministic; float atomics are not);
+  * the float-atomic scatter (nrx_embed_bwd, NRX_DENSE_BWD=atomic), which test_hip_parity ties to the oracle and the goldens:
+    rtol 1e-5 / atol 1e-5 -- the two differ only in the order fp32 terms of a row are added (1e-4 for the Zipf cases, whose
+    hottest row sums thousands of terms: the two fp32 orders drift apart by a few ulp of the partial sums)."""
+import numpy as np
+import pytest
+import torch
+
+from news_recsys_amd import ops
+from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_SPARSE
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ids(rng, rows, shape, dist):
+    if dist == "uniform":
+        x = rng.integers(0, rows, shape)
+    else:                                                    # zipf: rows looked up hundreds of times
+        x = np.minimum(rng.zipf(1.2, shape) - 1, rows - 1)
+    x = np.asarray(x, np.int64)
+    x.reshape(-1)[:3] = 0                                    # the padding row is looked up too
+    return x
+
+
+def _grads(plan, tables, inputs, weights, ups, mode, monkeypatch):
+    monkeypatch.setattr(ops, "DENSE_BWD_SORTED", mode != "atomic")
+    ts = [t.clone().requires_grad_() for t in tables]
+    res = ops.embed_apply(plan, ts, inputs, weights, sparse_grad=(mode == "coo"))
+    loss = sum((r * u).sum() for r, u in zip(res, ups) if r is not None)
+    loss.backward()
+    torch.cuda.synchronize()
+    return [t.grad.to_dense() if mode == "coo" else t.grad for t in ts]
+
+
+def _check(plan, tables, inputs, weights, ups, monkeypatch, tol=1e-5):
+    a = _grads(plan, tables, inputs, weights, ups, "sorted", monkeypatch)
+    b = _grads(plan, tables, inputs, weights, ups, "sorted", monkeypatch)
+    c = _grads(plan, tables, inputs, weights, ups, "coo", monkeypatch)
+    d = _grads(plan, tables, inputs, weights, ups, "atomic", monkeypatch)
+    for ga, gb, gc, gd in zip(a, b, c, d):
+        assert not ga.is_sparse and ga.shape == gd.shape
+        assert torch.equal(ga.view(torch.int32), gb.view(torch.int32))          # run to run: bit for bit
+        assert torch.equal(ga, gc)                                              # == the row-sparse reduction
+        torch.testing.assert_close(ga, gd, rtol=tol, atol=tol)                  # ~ the atomic scatter (addition order only)
+        assert float(ga[0].abs().max()) == 0.0                                  # padding_idx = 0: the padding row gets no gradient
+
+
+CASES = [
+    # name, D, n_feats, rows per table, B, fm, wide feature indices, dist
+    ("c2_like_fm", 16, 26, 3000, 1500, True, (), "uniform"),
+    ("fm_zipf", 16, 9, 40000, 4000, True, (), "zipf"),
+    ("plain32", 32, 6, 2000, 1300, False, (), "uniform"),
+    ("plain64_zipf", 64, 5, 100000, 5000, False, (), "zipf"),
+    ("odd_dim_10", 10, 4, 700, 900, False, (), "uniform"),
+    ("wide16_zipf", 16, 6, 30000, 3000, False, (0, 5), "zipf"),
+]
+
+
+@pytest.mark.parametrize("name,D,n,rows,B,fm,wide,dist", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("idx", [torch.int64, torch.int32])
+def test_dense_backward_sorted_single_valued(name, D, n, rows, B, fm, wide, dist, idx, monkeypatch):
+    rng = np.random.default_rng(sum(map(ord, name)) + 3)
+    slots, col = [], 0
+    for i in range(n):
+        if i in wide:
+            slots.append(ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, col, wide_col=len([w for w in wide if w < i])))
+            col += D - 1
+        else:
+            slots.append(ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, col, fm_field=1 if fm else 0))
+            col += D
+    plan = ops.EmbedPlan(slots, out_width=col, wide_width=len(wide), use_fm=fm)
+    tables = [torch.from_numpy(rng.standard_normal((rows, D)).astype(np.float32)).to(DEV) for _ in range(n)]
+    inputs = [torch.from_numpy(_ids(rng, rows, (B,), dist)).to(DEV).to(idx) for _ in range(n)]
+    ups = (torch.from_numpy(rng.standard_normal((B, col)).astype(np.float32)).to(DEV),
+           torch.from_numpy(rng.standard_normal((B, max(len(wide), 1))).astype(np.float32)).to(DEV),
+           torch.from_numpy(rng.standard_normal((B,)).astype(np.float32)).to(DEV))
+    _check(plan, tables, inputs, [None] * n, ups, monkeypatch, tol=1e-4 if dist == "zipf" else 1e-5)
+
+
+@pytest.mark.parametrize("kind", [NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM])
+@pytest.mark.parametrize("dist", ["uniform", "zipf"])
+def test_dense_backward_sorted_tower_with_history_bag(kind, dist, monkeypatch):
+    """The DSSM tower shape: item id + history bag (sharing the news table) + user id."""
+    rng = np.random.default_rng(23 + kind)
+    D, L, B, news, users = 16, 7, 2100, 6000, 50000
+    slots = [ops.Slot("item_id", NRX_SPARSE, 0, D, 0, 0), ops.Slot("user_history", kind, 0, D, L, D), ops.Slot("user_id", NRX_SPARSE, 1, D, 0, 2 * D)]
+    plan = ops.EmbedPlan(slots, out_width=3 * D)
+    tables = [torch.from_numpy(rng.standard_normal((r, D)).astype(np.float32)).to(DEV) for r in (news, users)]
+    hist = _ids(rng, news, (B, L), dist)
+    lens = rng.integers(0, L + 1, B)
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.float32)
+    hist = np.where(mask > 0, hist, 0)
+    if kind == NRX_BAG_SUM:
+        mask = mask * rng.random((B, L)).astype(np.float32)
+    inputs = [torch.from_numpy(_ids(rng, news, (B,), dist)).to(DEV), torch.from_numpy(hist).to(DEV),
+              torch.from_numpy(_ids(rng, users, (B,), "uniform")).to(DEV)]
+    weights = [None, None if kind == NRX_BAG_MEAN else torch.from_numpy(mask).to(DEV), None]
+    ups = (torch.from_numpy(rng.standard_normal((B, 3 * D)).astype(np.float32)).to(DEV), None, None)
+    _check(plan, tables, inputs, weights, ups, monkeypatch, tol=1e-4 if dist == "zipf" else 1e-5)
+
+
+def test_dense_backward_sorted_two_widths_and_a_table_fed_by_two_reductions(monkeypatch):
+    """70 features of width 16 over 3 shared tables (two launch groups: the second ADDS into rows the first stored) + 4 features of
+    width 32 over their own table (a third reduction, another row width in the same table list)."""
+    rng = np.random.default_rng(5)
+    B, rows = 900, 400
+    slots, col = [], 0
+    for i in range(70):
+        slots.append(ops.Slot(f"a{i}", NRX_SPARSE, i % 3, 16, 0, col)); col += 16
+    for i in range(4):
+        slots.append(ops.Slot(f"b{i}", NRX_SPARSE, 3, 32, 0, col)); col += 32
+    plan = ops.EmbedPlan(slots, out_width=col)
+    tables = [torch.from_numpy(rng.standard_normal((rows, 16)).astype(np.float32)).to(DEV) for _ in range(3)]
+    tables.append(torch.from_numpy(rng.standard_normal((rows, 32)).astype(np.float32)).to(DEV))
+    inputs = [torch.from_numpy(_ids(rng, rows, (B,), "uniform")).to(DEV) for _ in slots]
+    ups = (torch.from_numpy(rng.standard_normal((B, col)).astype(np.float32)).to(DEV), None, None)
+    a = _grads(plan, tables, inputs, [None] * len(slots), ups, "sorted", monkeypatch)
+    b = _grads(plan, tables, inputs, [None] * len(slots), ups, "sorted", monkeypatch)
+    d = _grads(plan, tables, inputs, [None] * len(slots), ups, "atomic", monkeypatch)
+    for ga, gb, gd in zip(a, b, d):
+        assert torch.equal(ga.view(torch.int32), gb.view(torch.int32))
+        torch.testing.assert_close(ga, gd, rtol=1e-5, atol=2e-5)
+
+
+def test_rows_to_dense_c_abi_direct():
+    """nrx_rows_to_dense through the C-ABI: store and accumulate forms, the device-side count, a key list longer than the count."""
+    import ctypes as C
+    from news_recsys_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(1)
+    for D in (16, 10, 128):
+        t0 = torch.zeros(50, D, device=DEV); t1 = torch.zeros(70, D, device=DEV)
+        keys = torch.tensor([(0 << 40) | 3, (0 << 40) | 49, (1 << 40) | 0, (1 << 40) | 69, (1 << 40) | 5, (0 << 40) | 7], dtype=torch.int64, device=DEV)
+        rows = torch.randn(6, D, device=DEV, generator=g)
+        n_dev = torch.tensor([5], dtype=torch.int64, device=DEV)            # the 6th entry is beyond the count: not stored
+        ptrs = (C.c_void_p * 2)(t0.data_ptr(), t1.data_ptr())
+        st = torch.cuda.current_stream().cuda_stream
+        for acc in (0, 1, 1):
+            assert lib.nrx_rows_to_dense(ptrs, 2, D, keys.data_ptr(), rows.data_ptr(), 6, n_dev.data_ptr(), acc, st) == 0
+        torch.cuda.synchronize()
+        e0 = torch.zeros_like(t0); e1 = torch.zeros_like(t1)
+        e0[3], e0[49], e1[0], e1[69], e1[5] = rows[0] * 3, rows[1] * 3, rows[2] * 3, rows[3] * 3, rows[4] * 3
+        torch.testing.assert_close(t0, e0, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(t1, e1, rtol=1e-6, atol=1e-6)
+        assert float(t0[7].abs().max()) == 0.0
