@@ -81,7 +81,9 @@ typedef struct nrx_feature {
  * truncation.  Every entry counts with weight 1, i.e. the result is bit-identical to the padded form with DataReader's
  * mask (NRX_BAG_MASKED_MEAN: sum / (n + 1e-8); NRX_BAG_MEAN: the bag_len - n missing positions read row 0 like padding
  * ids do; NRX_BAG_SUM: sum) while a sample costs 4-8 B per REAL entry instead of 12 B x bag_len.  Accepted by
- * nrx_embed_fwd / nrx_embed_fwd_train / nrx_embed_bwd; the sorted backward wants the padded form (nrx_csr_to_padded). */
+ * nrx_embed_fwd / nrx_embed_fwd_train / nrx_embed_bwd; the sorted backward wants the padded form (nrx_csr_to_padded).
+ * (NRX_FEAT_ROW0_IS_DATA is likewise honoured by nrx_embed_bwd only: for the sorted backward row 0 of every table is the
+ * padding row and gets a zero gradient.) */
 #define NRX_FEAT_BAG_CSR 2
 
 /* ---- library ---------------------------------------------------------------------------- */

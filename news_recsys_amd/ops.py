@@ -24,7 +24,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_FEAT_BAG_CSR, NRX_MAX_FEATURES, NRX_SPARSE,
+from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_FEAT_BAG_CSR, NRX_FEAT_ROW0_IS_DATA, NRX_MAX_FEATURES, NRX_SPARSE,
                    NrxFeature, NrxFmGrad, check)
 
 # ------------------------------------------------------------------------------- helpers
@@ -361,7 +361,7 @@ def _zero_grad_tables(meta):
 def _dense_sorted_ok(plan, tables, sparse_grad, B) -> bool:
     return (not sparse_grad and DENSE_BWD_SORTED and B > 0 and bool(tables) and tables[0].is_cuda
             and not torch.cuda.is_current_stream_capturing()
-            and not any(s.flags & NRX_FEAT_BAG_CSR for s in plan.slots)
+            and not any(s.flags & (NRX_FEAT_BAG_CSR | NRX_FEAT_ROW0_IS_DATA) for s in plan.slots)      # (the planner's row 0 never trains)
             and any(s.kind != NRX_DENSE for s in plan.slots))
 
 
@@ -373,6 +373,9 @@ class _EmbedFn(torch.autograd.Function):
         ctx.sink = sparse_grad if isinstance(sparse_grad, SparseGradSink) else None
         ctx.sparse_grad = bool(sparse_grad)
         ctx.tables = list(tables) if ctx.sink is not None else None
+        if sparse_grad and any(s.flags & NRX_FEAT_ROW0_IS_DATA for s in plan.slots):
+            raise NotImplementedError("sparse_grad: the sorted backward treats row 0 of every table as the padding row; "
+                                      "a feature flagged NRX_FEAT_ROW0_IS_DATA (routed-row buffers) needs the dense-gradient mode")
         if sparse_grad and any(s.flags & NRX_FEAT_BAG_CSR for s in plan.slots):
             plan, inputs, weights = _csr_plan_to_padded(plan, inputs, weights)      # the planner sorts padded [B, L] lookups
         ld = int(out_ld) if out_ld else plan.out_width

@@ -149,3 +149,22 @@ def test_rows_to_dense_c_abi_direct():
         torch.testing.assert_close(t0, e0, rtol=1e-6, atol=1e-6)
         torch.testing.assert_close(t1, e1, rtol=1e-6, atol=1e-6)
         assert float(t0[7].abs().max()) == 0.0
+
+
+def test_row0_is_data_keeps_the_atomic_scatter_and_refuses_the_row_sparse_mode():
+    """A routed-row buffer (sharding step 4: NRX_FEAT_ROW0_IS_DATA) has no padding row: its slot 0 must receive its gradient.  The sorted
+    reduction gives row 0 of every table a zero gradient, so the default mode keeps nrx_embed_bwd for such a plan and sparse_grad refuses it."""
+    from news_recsys_amd._lib import NRX_FEAT_ROW0_IS_DATA
+    g = torch.Generator(device=DEV).manual_seed(3)
+    buf = torch.randn(64, 16, device=DEV, generator=g).requires_grad_()
+    slot = torch.randint(0, 64, (500,), device=DEV, generator=g)
+    slot[:5] = 0
+    plan = ops.EmbedPlan([ops.Slot("f", NRX_SPARSE, 0, 16, 0, 0, flags=NRX_FEAT_ROW0_IS_DATA)], out_width=16)
+    up = torch.randn(500, 16, device=DEV, generator=g)
+    out = ops.embed_apply(plan, [buf], [slot], [None])[0]
+    (out * up).sum().backward()
+    ref = torch.zeros(64, 16, device=DEV).index_add_(0, slot, up)
+    torch.testing.assert_close(buf.grad, ref, rtol=1e-5, atol=1e-5)
+    assert float(buf.grad[0].abs().max()) > 0
+    with pytest.raises(NotImplementedError):
+        ops.embed_apply(plan, [buf], [slot], [None], sparse_grad=True)
