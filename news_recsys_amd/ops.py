@@ -358,10 +358,10 @@ def _zero_grad_tables(meta):
     return [buf[o:o + math.prod(shape)].view(shape) for o, (shape, _) in zip(offs, meta)]
 
 
-def _dense_sorted_ok(plan, tables, sparse_grad, B) -> bool:
+def _dense_sorted_ok(plan, tables, sparse_grad, B, csr_ok=False) -> bool:
     return (not sparse_grad and DENSE_BWD_SORTED and B > 0 and bool(tables) and tables[0].is_cuda
             and not torch.cuda.is_current_stream_capturing()
-            and not any(s.flags & (NRX_FEAT_BAG_CSR | NRX_FEAT_ROW0_IS_DATA) for s in plan.slots)      # (the planner's row 0 never trains)
+            and not any(s.flags & ((0 if csr_ok else NRX_FEAT_BAG_CSR) | NRX_FEAT_ROW0_IS_DATA) for s in plan.slots)      # (the planner's row 0 never trains)
             and any(s.kind != NRX_DENSE for s in plan.slots))
 
 
@@ -467,8 +467,13 @@ class _EmbedFn(torch.autograd.Function):
         ctx.fm_sums = sums
         ctx.plans = None
         # default (dense-gradient) mode: the table grads are formed by the sorted reduction + nrx_rows_to_dense unless
-        # NRX_DENSE_BWD=atomic, the launch is being captured (the planner allocates) or a bag arrives as CSR
-        ctx.dense_sorted = _dense_sorted_ok(plan, tables, ctx.sparse_grad, B)
+        # NRX_DENSE_BWD=atomic, the launch is being captured (the planner allocates) or a feature reads a routed-row buffer
+        ctx.dense_sorted = _dense_sorted_ok(plan, tables, ctx.sparse_grad, B, csr_ok=True) and any(t.requires_grad for t in tables)
+        if ctx.dense_sorted and any(s.flags & NRX_FEAT_BAG_CSR for s in plan.slots):
+            # the forward ran on the CSR form; the backward's planner sorts padded [B, L] lookups (nrx_csr_to_padded: one small launch
+            # per bag feature) -- from here on the node only describes the backward
+            plan, ins, ws = _csr_plan_to_padded(plan, ins, ws)
+            ctx.plan, ctx.ins, ctx.ws = plan, ins, ws
         if (ctx.sparse_grad or ctx.dense_sorted) and PLAN_AHEAD and B > 0 and not torch.cuda.is_current_stream_capturing() and \
                 any(t.requires_grad for t in tables):
             ctx.plans = {}

@@ -168,3 +168,36 @@ def test_row0_is_data_keeps_the_atomic_scatter_and_refuses_the_row_sparse_mode()
     assert float(buf.grad[0].abs().max()) > 0
     with pytest.raises(NotImplementedError):
         ops.embed_apply(plan, [buf], [slot], [None], sparse_grad=True)
+
+
+@pytest.mark.parametrize("kind", [NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM])
+def test_dense_backward_sorted_csr_bags(kind, monkeypatch):
+    """A bag delivered as CSR values + offsets (ColumnarLoader(csr_bags=True)): the forward runs on the CSR form, the backward's planner on its
+    padded expansion (nrx_csr_to_padded at forward time) -- the same dense gradients, bit for bit, as the padded launch; bags longer than L are
+    cut to their first L entries in both."""
+    from news_recsys_amd._lib import NRX_FEAT_BAG_CSR
+    rng = np.random.default_rng(41 + kind)
+    D, L, B, news, users = 16, 6, 1900, 5000, 30000
+    lens = rng.integers(0, L + 3, B)                                     # some bags longer than L
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    values = rng.integers(1, news, int(offsets[-1])).astype(np.int64)
+    hist = np.zeros((B, L), np.int64); mask = np.zeros((B, L), np.float32)
+    for b in range(B):
+        n = min(int(lens[b]), L)
+        hist[b, :n] = values[offsets[b]:offsets[b] + n]
+        mask[b, :n] = 1.0
+    tables = [torch.from_numpy(rng.standard_normal((r, D)).astype(np.float32)).to(DEV) for r in (news, users)]
+    iid = torch.from_numpy(_ids(rng, news, (B,), "uniform")).to(DEV); uid = torch.from_numpy(_ids(rng, users, (B,), "uniform")).to(DEV)
+    ups = (torch.from_numpy(rng.standard_normal((B, 3 * D)).astype(np.float32)).to(DEV), None, None)
+    def plan_of(flags):
+        return ops.EmbedPlan([ops.Slot("item_id", NRX_SPARSE, 0, D, 0, 0), ops.Slot("user_history", kind, 0, D, L, D, flags=flags),
+                              ops.Slot("user_id", NRX_SPARSE, 1, D, 0, 2 * D)], out_width=3 * D)
+    w_pad = None if kind == NRX_BAG_MEAN else torch.from_numpy(mask).to(DEV)
+    pad = _grads(plan_of(0), tables, [iid, torch.from_numpy(hist).to(DEV), uid], [None, w_pad, None], ups, "sorted", monkeypatch)
+    csr_in = [iid, torch.from_numpy(values).to(DEV), uid]
+    csr_w = [None, torch.from_numpy(offsets).to(DEV), None]
+    csr = _grads(plan_of(NRX_FEAT_BAG_CSR), tables, csr_in, csr_w, ups, "sorted", monkeypatch)
+    atom = _grads(plan_of(NRX_FEAT_BAG_CSR), tables, csr_in, csr_w, ups, "atomic", monkeypatch)
+    for gp, gc, ga in zip(pad, csr, atom):
+        assert torch.equal(gp.view(torch.int32), gc.view(torch.int32))
+        torch.testing.assert_close(gc, ga, rtol=1e-5, atol=1e-5)
