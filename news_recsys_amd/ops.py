@@ -359,10 +359,20 @@ def _zero_grad_tables(meta):
 
 
 def _dense_sorted_ok(plan, tables, sparse_grad, B, csr_ok=False) -> bool:
-    return (not sparse_grad and DENSE_BWD_SORTED and B > 0 and bool(tables) and tables[0].is_cuda
-            and not torch.cuda.is_current_stream_capturing()
-            and not any(s.flags & ((0 if csr_ok else NRX_FEAT_BAG_CSR) | NRX_FEAT_ROW0_IS_DATA) for s in plan.slots)      # (the planner's row 0 never trains)
-            and any(s.kind != NRX_DENSE for s in plan.slots))
+    """Default (dense-gradient) mode: form the table grads by the sorted reduction + nrx_rows_to_dense?  The sorted path costs a fixed
+    ~25 launches (~0.2 ms of host and launch time per step), the atomic scatter ~0.2 us per 1000 lookups: from DENSE_SORTED_MIN lookups
+    per launch on (1 Mi: C2 / C4 at the bench batch) the sorted path is the faster one, below it the single atomic launch is
+    (profiles/r03_dense_backward.txt).  DENSE_BWD_SORTED: True = always (deterministic gradients at any size), False = never."""
+    if sparse_grad or DENSE_BWD_SORTED is False or B <= 0 or not tables or not tables[0].is_cuda or torch.cuda.is_current_stream_capturing():
+        return False
+    lookups = 0
+    for s in plan.slots:
+        if s.kind == NRX_DENSE:
+            continue
+        if s.flags & ((0 if csr_ok else NRX_FEAT_BAG_CSR) | NRX_FEAT_ROW0_IS_DATA):      # (the planner's row 0 never trains)
+            return False
+        lookups += max(1, s.bag_len)
+    return lookups > 0 and (DENSE_BWD_SORTED is True or B * lookups >= DENSE_SORTED_MIN)
 
 
 class _EmbedFn(torch.autograd.Function):
@@ -556,7 +566,10 @@ SPARSE_BWD_SYNC_FREE = False   # True: size the reduction for the worst case and
 
 
 _plan_streams = {}
-DENSE_BWD_SORTED = os.environ.get("NRX_DENSE_BWD", "sorted") != "atomic"      # default-mode table grads: sorted reduction (deterministic) or float atomics
+# default-mode (dense) table grads.  NRX_DENSE_BWD = auto (default: sorted reduction from DENSE_SORTED_MIN lookups per launch on, float atomics
+# below) | sorted (always: bit-reproducible gradients at any batch) | atomic (never).  DENSE_BWD_SORTED: None = auto, True, False.
+DENSE_BWD_SORTED = {"sorted": True, "atomic": False}.get(os.environ.get("NRX_DENSE_BWD", "auto"))
+DENSE_SORTED_MIN = int(os.environ.get("NRX_DENSE_SORTED_MIN", 1 << 20))
 PLAN_AHEAD = True      # row-sparse training: plan the backward (sort, unique rows, segments) at FORWARD time on a side stream
 
 

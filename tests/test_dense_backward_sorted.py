@@ -1,6 +1,6 @@
 """The DEFAULT (dense-gradient) backward of the gather -- what autograd gives the reference's nn.Embedding(size, dim, padding_idx=0)
 tables (src/model/BaseModel/base_model.py:164; backward of :262-308, + fm/model.py:18-26, widedeep/model.py:53-69) -- formed by the
-sorted reduction + nrx_rows_to_dense (ops.DENSE_BWD_SORTED, the default) against
+sorted reduction + nrx_rows_to_dense (the default from ops.DENSE_SORTED_MIN lookups per launch on; forced here) against
 
   * the row-sparse mode's COO gradients made dense: the same reduction, so BIT FOR BIT;
   * itself, run twice: bit for bit (the mode is deterministic; float atomics are not);
@@ -201,3 +201,22 @@ def test_dense_backward_sorted_csr_bags(kind, monkeypatch):
     for gp, gc, ga in zip(pad, csr, atom):
         assert torch.equal(gp.view(torch.int32), gc.view(torch.int32))
         torch.testing.assert_close(gc, ga, rtol=1e-5, atol=1e-5)
+
+
+def test_auto_mode_switches_on_the_lookup_count(monkeypatch):
+    """NRX_DENSE_BWD=auto (the default): the sorted path from DENSE_SORTED_MIN lookups per launch on (bag positions count), the single atomic launch
+    below; forced modes ignore the count; a plan reading a routed-row buffer never qualifies."""
+    from news_recsys_amd._lib import NRX_DENSE, NRX_FEAT_ROW0_IS_DATA
+    t = [torch.zeros(10, 16, device=DEV)]
+    plan = ops.EmbedPlan([ops.Slot("a", NRX_SPARSE, 0, 16, 0, 0), ops.Slot("h", NRX_BAG_MEAN, 0, 16, 7, 16), ops.Slot("d", NRX_DENSE, -1, 1, 0, 32)], out_width=33)
+    monkeypatch.setattr(ops, "DENSE_BWD_SORTED", None)
+    monkeypatch.setattr(ops, "DENSE_SORTED_MIN", 800)
+    assert ops._dense_sorted_ok(plan, t, False, 100) and not ops._dense_sorted_ok(plan, t, False, 99)      # 8 lookups per sample
+    assert not ops._dense_sorted_ok(plan, t, True, 100)                                                   # row-sparse mode: not this switch
+    monkeypatch.setattr(ops, "DENSE_BWD_SORTED", True)
+    assert ops._dense_sorted_ok(plan, t, False, 1)
+    monkeypatch.setattr(ops, "DENSE_BWD_SORTED", False)
+    assert not ops._dense_sorted_ok(plan, t, False, 1 << 20)
+    monkeypatch.setattr(ops, "DENSE_BWD_SORTED", True)
+    routed = ops.EmbedPlan([ops.Slot("a", NRX_SPARSE, 0, 16, 0, 0, flags=NRX_FEAT_ROW0_IS_DATA)], out_width=16)
+    assert not ops._dense_sorted_ok(routed, t, False, 1 << 20)

@@ -43,5 +43,5 @@ for rep in range(2):
     for _ in range(50): step()
     e.record(); host = (time.perf_counter() - t0) / 50 * 1e6
     torch.cuda.synchronize()
-    print(f"Deep, default dense-gradient mode ({'sorted reduction + rows_to_dense' if ops.DENSE_BWD_SORTED else 'float-atomic scatter'}): "
+    print(f"Deep, default dense-gradient mode (NRX_DENSE_BWD={os.environ.get('NRX_DENSE_BWD', 'auto')}): "
           f"{a.elapsed_time(e) / 50 * 1e3:7.1f} us per training step (host {host:6.1f} us)", flush=True)

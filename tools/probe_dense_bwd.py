@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from news_recsys_amd import ops
 from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN, NRX_SPARSE
 ops.set_index_check(os.environ.get("NRX_PROBE_INDEX_CHECK", "deferred"))      # "sync" (the module default) reads a status word per forward: the host then waits for the GPU every step
-dev = torch.device("cuda:0"); B, L, D = 65536, 50, 16
+dev = torch.device("cuda:0"); B, L, D = int(os.environ.get("NRX_PROBE_B", 65536)), 50, 16
 gen = torch.Generator(device=dev).manual_seed(5)
 import time
 HOST = [0.0]
