@@ -614,7 +614,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
     const bool live = b < a.batch;
     const int nb = (int)((a.batch - b0) < (int64_t)TB ? (a.batch - b0) : (int64_t)TB);
 
-    for (int fi = 0; fi < a.n; ++fi) {
+    // blockIdx.y strides over the features: a small batch is a handful of blocks, and one block walking 26 features is 26 dependent
+    // (upstream row, id) -> atomics round trips in a row; the host spreads them over gridDim.y blocks when the batch alone does not fill the chip
+    for (int fi = blockIdx.y; fi < a.n; fi += gridDim.y) {
         const FeatDev& f = a.f[fi];
         if (f.kind == NRX_DENSE) continue;
         const int D = f.dim;
@@ -660,7 +662,17 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
                         const int64_t n = offs[b + 1] - offs[b];
                         den = (float)(n < (int64_t)L ? n : (int64_t)L);      // the forward's sum of n ones
                     } else {
-                        for (int l = 0; l < L; ++l) den += f.weight[b * (int64_t)L + l];
+                        // eight weights in flight, added in position order (the loop as written waited for every load: L round trips per sample)
+                        const float* wp = f.weight + b * (int64_t)L;
+                        int l = 0;
+                        for (; l + 8 <= L; l += 8) {
+                            float w8[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) w8[u] = wp[l + u];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) den += w8[u];
+                        }
+                        for (; l < L; ++l) den += wp[l];
                     }
                 }
                 den += 1e-8f;
@@ -678,7 +690,41 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
             for (int l0 = 0; l0 < L; l0 += lc) {
                 const int cur = (L - l0) < lc ? (L - l0) : lc;
                 __syncthreads();
-                for (int e = tid; e < nb * cur; e += NRX_BLOCK) {
+                int e_first = tid;
+                if (!(f.flags & NRX_FEAT_BAG_CSR)) {
+                    // padded form: four entries per thread and round, their id / weight loads issued together (as in the forward's staging loop)
+                    constexpr int SU = 4;
+                    const int n_e = nb * cur;
+                    const bool has_w = f.weight != nullptr;
+                    for (; e_first < n_e; e_first += SU * NRX_BLOCK) {
+                        int64_t id4[SU];
+                        float w4[SU];
+                        int pos4[SU];
+#pragma unroll
+                        for (int u = 0; u < SU; ++u) {
+                            const int e = e_first + u * NRX_BLOCK;
+                            const int ec = e < n_e ? e : n_e - 1;
+                            const int s = ec / cur;
+                            const int l = ec - s * cur;
+                            const int64_t gi = (b0 + s) * (int64_t)L + l0 + l;
+                            pos4[u] = s * stride + l;
+                            id4[u] = nrx_load_id(f.index, gi, f.idx64);
+                            w4[u] = has_w ? f.weight[gi] : 1.0f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < SU; ++u) {
+                            if (e_first + u * NRX_BLOCK < n_e) {
+                                const bool oob = (uint64_t)id4[u] >= (uint64_t)f.rows;
+                                BagPair p;
+                                p.id = oob ? 0 : (int32_t)id4[u];
+                                p.w = oob ? 0.f : w4[u];
+                                s_bag[pos4[u]] = p;
+                            }
+                        }
+                    }
+                    e_first = n_e;
+                }
+                for (int e = e_first; e < nb * cur; e += NRX_BLOCK) {
                     const int s = e / cur;
                     const int l = e - s * cur;
                     int64_t id;
@@ -2130,7 +2176,12 @@ extern "C" int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_
     plan_generic(max_dim, max_bag, qlog2, a.lds_chunk, smem);
     const int tb = NRX_BLOCK >> qlog2;
     const unsigned grid = (unsigned)((batch + tb - 1) / tb);
-    NRX_QSWITCH(qlog2, { hipLaunchKernelGGL((embed_bwd_generic<QL>), dim3(grid), dim3(NRX_BLOCK), smem, st, a); });
+    static const int gy_env = getenv("NRX_BWD_GY") ? atoi(getenv("NRX_BWD_GY")) : 0;      // measurement knob: 0 = choose, n = that many feature slices
+    unsigned gy = 1;
+    if (gy_env > 0) gy = (unsigned)gy_env;
+    else while (gy < (unsigned)n_feats && grid * gy < 2048) gy *= 2;                         // until ~8 blocks per CU are in the launch
+    if (gy > (unsigned)n_feats) gy = (unsigned)n_feats;
+    NRX_QSWITCH(qlog2, { hipLaunchKernelGGL((embed_bwd_generic<QL>), dim3(grid, gy), dim3(NRX_BLOCK), smem, st, a); });
     NRX_LAUNCH_CHECK("nrx_embed_bwd");
     return NRX_OK;
 }
