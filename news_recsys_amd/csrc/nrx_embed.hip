@@ -645,7 +645,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
                 g = make_float4(gg[0], gg[1], gg[2], gg[3]);
             }
             if (f.kind == NRX_SPARSE) {
-                if (active) {
+                if (active && blockIdx.z == 0) {
                     const int64_t id = nrx_load_id(f.index, b, f.idx64);
                     if (id >= ((f.flags & NRX_FEAT_ROW0_IS_DATA) ? 0 : 1) && id < f.rows) atomic_add_row4(gtable, id, D, k0, g);
                 }
@@ -687,8 +687,13 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_generic(const EmbedArgs a
                 __syncthreads();
                 for (int i = tid; i <= nb; i += NRX_BLOCK) s_off[i] = reinterpret_cast<const int64_t*>(f.weight)[b0 + i];   // nb + 1 entries: nb can equal NRX_BLOCK
             }
-            for (int l0 = 0; l0 < L; l0 += lc) {
-                const int cur = (L - l0) < lc ? (L - l0) : lc;
+            // blockIdx.z strides over the bag positions (small batches: the host splits a bag's L entries over gridDim.z blocks, each with its own slice
+            // [zlo, zhi) of every sample's bag; the denominator above is formed in full by each)
+            const int zper = (L + (int)gridDim.z - 1) / (int)gridDim.z;
+            const int zlo = (int)blockIdx.z * zper;
+            const int zhi = (zlo + zper) < L ? (zlo + zper) : L;
+            for (int l0 = zlo; l0 < zhi; l0 += lc) {
+                const int cur = (zhi - l0) < lc ? (zhi - l0) : lc;
                 __syncthreads();
                 int e_first = tid;
                 if (!(f.flags & NRX_FEAT_BAG_CSR)) {
@@ -2181,7 +2186,13 @@ extern "C" int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_
     if (gy_env > 0) gy = (unsigned)gy_env;
     else while (gy < (unsigned)n_feats && grid * gy < 2048) gy *= 2;                         // until ~8 blocks per CU are in the launch
     if (gy > (unsigned)n_feats) gy = (unsigned)n_feats;
-    NRX_QSWITCH(qlog2, { hipLaunchKernelGGL((embed_bwd_generic<QL>), dim3(grid, gy), dim3(NRX_BLOCK), smem, st, a); });
+    static const int gz_env = getenv("NRX_BWD_GZ") ? atoi(getenv("NRX_BWD_GZ")) : 0;      // measurement knob: slices of a bag's positions
+    unsigned gz = 1;
+    if (gz_env > 0) gz = (unsigned)gz_env;
+    else while (gz * 8 <= (unsigned)max_bag && grid * gy * gz < 2048) gz *= 2;               // slices of >= 4 positions
+    if (max_bag > 0 && gz > (unsigned)max_bag) gz = (unsigned)max_bag;
+    if (max_bag <= 0) gz = 1;
+    NRX_QSWITCH(qlog2, { hipLaunchKernelGGL((embed_bwd_generic<QL>), dim3(grid, gy, gz), dim3(NRX_BLOCK), smem, st, a); });
     NRX_LAUNCH_CHECK("nrx_embed_bwd");
     return NRX_OK;
 }
