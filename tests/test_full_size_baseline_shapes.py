@@ -187,10 +187,11 @@ def test_backward_plan_at_baseline_shapes_matches_definition(shape, skew):
 
 
 @pytest.mark.parametrize("skew", [False, True])
-def test_c4_row_sparse_backward_equals_dense_backward_at_full_size(skew):
+def test_c4_row_sparse_backward_equals_dense_backward_at_full_size(skew, monkeypatch):
     """The deterministic row-sparse backward (planning + sorted segmented reduction: what `embeddings.sparse_grad` and the
-    bench's fwd_bwd leg run) against the dense-gradient backward (atomic scatter, a different kernel and no planning at
-    all) on the REAL C4 shape: user_id over the 10 M-row table, history L = 50 + item_id sharing the 200 k-row news table,
+    bench's fwd_bwd leg run) against the dense-gradient backward in both its forms -- the default at this size (the same
+    reduction + nrx_rows_to_dense: bit for bit the row-sparse result made dense) and the float-atomic scatter (NRX_DENSE_BWD=atomic:
+    a different kernel and no planning at all) -- on the REAL C4 shape: user_id over the 10 M-row table, history L = 50 + item_id sharing the 200 k-row news table,
     B = 65 536 -- 3.4 M lookups, an 800-tile segment next to a 16-tile one.  Densified, the two gradients agree to the
     atomics' summation-order noise; two sparse runs are bit-identical.  (Autograd of nn.Embedding + array_feature_pooling:
     src/model/BaseModel/base_model.py:262-282.)"""
@@ -215,15 +216,18 @@ def test_c4_row_sparse_backward_equals_dense_backward_at_full_size(skew):
                           ops.Slot("item_id", NRX_SPARSE, 1, D, 0, 2 * D)], out_width=3 * D)
     up = torch.randn((B, 3 * D), device=DEV, generator=gen)
     grads = {}
-    for mode in ("dense", "sparse", "sparse2"):
+    for mode in ("dense", "dense_auto", "sparse", "sparse2"):
+        monkeypatch.setattr(ops, "DENSE_BWD_SORTED", False if mode == "dense" else None)      # "dense": the atomic scatter; "dense_auto": the default
         tabs = [users.clone().requires_grad_(True), news.clone().requires_grad_(True)]
-        out = ops.embed_apply(plan, tabs, [uid, hist, iid], [None, mask, None], sparse_grad=mode != "dense")[0]
+        out = ops.embed_apply(plan, tabs, [uid, hist, iid], [None, mask, None], sparse_grad=mode.startswith("sparse"))[0]
         (out * up).sum().backward()
         grads[mode] = [t.grad for t in tabs]
         del out, tabs
-    for a, b in zip(grads["sparse"], grads["sparse2"]):
+    for a, b, da in zip(grads["sparse"], grads["sparse2"], grads["dense_auto"]):
         a, b = a.coalesce(), b.coalesce()
         assert torch.equal(a.indices(), b.indices()) and torch.equal(a.values(), b.values())           # bit-reproducible
+        assert not da.is_sparse and torch.equal(da[a.indices()[0]], a.values())                        # default dense mode (3.4 M lookups: sorted) == row-sparse
+        assert int((da != 0).any(1).sum()) <= a.indices().shape[1]                                     # ... and nothing outside its rows
     # float64 restatement of the definition (index_add of every lookup's contribution) + the L1 mass per row: fp32 sums of n
     # terms in ANY order stay within n * eps * sum|x|; hot rows of the skewed draw collect ~1e5 terms, so the bound is per row
     w = mask.double() / (mask.double().sum(1, keepdim=True) + 1e-8)
