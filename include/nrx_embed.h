@@ -108,6 +108,11 @@ NRX_API int nrx_embed_fwd(const nrx_feature_t* feats, int32_t n_feats, int64_t b
                   float* out, int64_t out_ld, float* wide_out, int64_t wide_ld,
                   float* fm_out, int32_t* status, void* stream);
 
+/* Largest batch nrx_embed_fwd / nrx_embed_fwd_train serve with the one-block-per-sample kernel (default 2048, first read from the
+ * environment variable NRX_SMALL_BATCH; 0 = never).  Process-wide; returns the previous limit; a negative argument only queries.  Both
+ * kernel families produce the same bits -- the knob exists so that tests and A/B runs can pick the family on any batch size.  */
+NRX_API int64_t nrx_set_small_batch_max(int64_t max_batch);
+
 /* Training form of nrx_embed_fwd: additionally leaves the FM epilogue's per-sample field sums in
  * fm_sums [B, sums_ld] (column k >= 1: sum_f v_fk, column 0: sum_f w_f; sums_ld >= the FM field dim) -- 4 B x dim per
  * sample, what the backward needs to form d fm / d field without a pass of its own (nrx_fm_grad_t below).

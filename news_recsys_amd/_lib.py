@@ -66,6 +66,7 @@ SIGNATURES = {
     "nrx_device_info": (C.c_int, [C.c_int, C.POINTER(_i64)]),
     "nrx_stream_copy": (C.c_int, [_p, _p, _i64, _p]),
     "nrx_embed_fwd": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p]),
+    "nrx_set_small_batch_max": (_i64, [_i64]),
     "nrx_embed_fwd_train": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p]),
     "nrx_embed_bwd": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, C.POINTER(NrxFmGrad), _p]),
     "nrx_embed_bwd_sorted_workspace": (_i64, [_i64, _i32]),

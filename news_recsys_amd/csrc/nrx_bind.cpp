@@ -28,11 +28,10 @@ struct BoundPlan {
     bool use_fm = false;
     int fm_dim = 0;
     fwd_train_fn fwd = nullptr;
-    // table binding cache: the list object and its first / last data pointers (a module's tables rarely change)
-    PyObject* tables_id = nullptr;
-    void* t_first = nullptr;
-    void* t_last = nullptr;
-    size_t n_tables = 0;
+    // what the descriptors were last bound to: every table's data pointer and row count (compared on every call -- a list's
+    // address says nothing, CPython reuses it, and a table in the MIDDLE of the list may be re-allocated or resized)
+    std::vector<const void*> bound_ptr;
+    std::vector<int64_t> bound_rows;
     c10::Device device{c10::kCPU};
 
     // slots: sequence of (kind, table, dim, bag_len, out_col, wide_col, fm_field, flags)
@@ -72,11 +71,26 @@ struct BoundPlan {
             f[i].table = static_cast<const float*>(ts[(size_t)k]->data_ptr());
             f[i].rows = ts[(size_t)k]->size(0);
         }
-        tables_id = tables;
-        n_tables = (size_t)nt;
-        t_first = nt ? ts[0]->data_ptr() : nullptr;
-        t_last = nt ? ts[(size_t)nt - 1]->data_ptr() : nullptr;
+        bound_ptr.resize((size_t)nt);
+        bound_rows.resize((size_t)nt);
+        for (Py_ssize_t i = 0; i < nt; ++i) {
+            bound_ptr[(size_t)i] = ts[(size_t)i]->data_ptr();
+            bound_rows[(size_t)i] = ts[(size_t)i]->size(0);
+        }
         if (nt) device = ts[0]->device();
+        return true;
+    }
+
+    // True when every table of the list is the storage (and row count) the descriptors hold.
+    bool tables_unchanged(PyObject* tables) const {
+        const Py_ssize_t nt = PyList_GET_SIZE(tables);
+        if ((size_t)nt != bound_ptr.size()) return false;
+        for (Py_ssize_t i = 0; i < nt; ++i) {
+            PyObject* o = PyList_GET_ITEM(tables, i);
+            if (!THPVariable_Check(o)) return false;
+            const at::Tensor& t = THPVariable_Unpack(o);
+            if (t.dim() != 2 || t.data_ptr() != bound_ptr[(size_t)i] || t.size(0) != bound_rows[(size_t)i]) return false;
+        }
         return true;
     }
 
@@ -88,14 +102,7 @@ struct BoundPlan {
         PyObject* tl = tables.ptr();
         const size_t n = f.size();
         if ((size_t)PyList_GET_SIZE(inputs.ptr()) != n || (size_t)PyList_GET_SIZE(weights.ptr()) != n || n == 0) return py::none();
-        bool rebind = tl != tables_id || (size_t)PyList_GET_SIZE(tl) != n_tables;
-        if (!rebind && n_tables) {
-            PyObject* a = PyList_GET_ITEM(tl, 0);
-            PyObject* b = PyList_GET_ITEM(tl, (Py_ssize_t)n_tables - 1);
-            rebind = !THPVariable_Check(a) || !THPVariable_Check(b) || THPVariable_Unpack(a).data_ptr() != t_first ||
-                     THPVariable_Unpack(b).data_ptr() != t_last;
-        }
-        if (rebind && !bind_tables(tl)) return py::none();
+        if (!tables_unchanged(tl) && !bind_tables(tl)) return py::none();
         int64_t B = -1;
         for (size_t i = 0; i < n; ++i) {
             PyObject* xo = PyList_GET_ITEM(inputs.ptr(), (Py_ssize_t)i);

@@ -22,6 +22,7 @@
 // The uniform kernel (nrx_embed_ring.h) is the same mapping specialised for "all features single-valued, same D = 4Q":
 // ids staged once per block in LDS, then a ring of R row loads per lane kept in flight across the feature walk.
 #include "nrx_common.h"
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 #include "nrx_embed_ring.h"   // UniformArgs, fm_accumulate, group_sum, embed_fwd_ring
@@ -424,6 +425,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_generic(const EmbedArgs a
 // --------------------------------------------------------------------------------------------
 template <int Q>
 __device__ __forceinline__ float group_sum_rt(float v) { return group_sum<Q>(v); }
+
+// static LDS of embed_fwd_small_kernel (its copy of the descriptors), counted by the launcher's 64 KB eligibility test
+#define NRX_SMALL_STATIC_LDS (NRX_MAX_FEATURES * sizeof(FeatDev))
 
 __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_small_kernel(const EmbedArgs args_in_kernarg) {
     const NRX_CONST EmbedArgs* a = nrx_kernarg<EmbedArgs>();
@@ -1964,6 +1968,26 @@ void launch_uniform(const UniformArgs& ua, int64_t batch, bool fm, bool store, h
 
 }  // namespace
 
+// Largest batch that takes the one-block-per-sample kernel.  Process-wide, settable at run time (nrx_set_small_batch_max) so that the
+// parity tests can put BOTH kernel families in front of the oracle on the same shapes; first read comes from NRX_SMALL_BATCH.
+static std::atomic<int64_t> g_small_batch_max{-1};
+static int64_t small_batch_max() {
+    int64_t v = g_small_batch_max.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("NRX_SMALL_BATCH");
+        v = e ? atoll(e) : 2048;
+        if (v < 0) v = 0;
+        g_small_batch_max.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+extern "C" int64_t nrx_set_small_batch_max(int64_t max_batch) {
+    const int64_t prev = small_batch_max();
+    if (max_batch >= 0) g_small_batch_max.store(max_batch, std::memory_order_relaxed);
+    return prev;
+}
+
 extern "C" int nrx_embed_fwd(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
                              float* out, int64_t out_ld, float* wide_out, int64_t wide_ld,
                              float* fm_out, int32_t* status, void* stream) {
@@ -1987,8 +2011,7 @@ extern "C" int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, 
                     "nrx_embed_fwd: feature %d: NRX_FEAT_BAG_CSR on a non-bag feature", i);
     // ---- small batches: one block per sample (embed_fwd_small_kernel).  NRX_SMALL_BATCH = largest batch that takes it (0: never)
     {
-        static const int64_t small_max = getenv("NRX_SMALL_BATCH") ? atoll(getenv("NRX_SMALL_BATCH")) : 2048;
-        bool ok = batch <= small_max;
+        bool ok = batch <= small_batch_max();
         int64_t items = 0, outs = 0;
         int fm_fields = 0, fm_dim = 0;
         for (int i = 0; i < n_feats && ok; ++i) {
@@ -2006,6 +2029,11 @@ extern "C" int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, 
             }
         }
         ok = ok && items <= 2048 && (fm_fields == 0 || fm_out != nullptr) && !(out == nullptr && fm_fields == 0);
+        // the block's LDS image (dynamic part below + the kernel's static descriptor copy) must fit a block's 64 KB: larger plans are
+        // the big kernels' -- a failed launch here would be an error where they would have served the plan
+        const size_t smem_small = (2 * (NRX_MAX_FEATURES + 1) + 2) * sizeof(int) + (size_t)items * 16 +
+                                  (size_t)((items + 3) & ~(int64_t)3) * 4 + (size_t)outs * 16 + 16;
+        ok = ok && smem_small + NRX_SMALL_STATIC_LDS <= 64 * 1024;
         if (ok) {
             EmbedArgs a;
             int max_dim, max_bag;
@@ -2020,8 +2048,7 @@ extern "C" int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, 
             a.status = status;
             a.n = n_feats;
             a.lds_chunk = 0;
-            const size_t smem = (2 * (NRX_MAX_FEATURES + 1) + 2) * sizeof(int) + (size_t)items * 16 + (size_t)((items + 3) & ~(int64_t)3) * 4 + (size_t)outs * 16 + 16;
-            hipLaunchKernelGGL(embed_fwd_small_kernel, dim3((unsigned)batch), dim3(NRX_BLOCK), smem, st, a);
+            hipLaunchKernelGGL(embed_fwd_small_kernel, dim3((unsigned)batch), dim3(NRX_BLOCK), smem_small, st, a);
             NRX_LAUNCH_CHECK("nrx_embed_fwd(small batch)");
             return NRX_OK;
         }

@@ -55,6 +55,10 @@ def _deferred_status(names: Sequence[str]) -> torch.Tensor:
         _host_status = torch.zeros(4, dtype=torch.int32).pin_memory()
     elif _host_status[0] != 0:
         _raise_deferred()
+    elif len(_host_status_names) > 4:
+        # the word reads clear: launches further back than the last few have long finished without an offence -- their name lists
+        # would only blur a later report ("one of: ..." naming features of unrelated plans)
+        del _host_status_names[:-4]
     if not any(n is names for n in _host_status_names):
         if len(_host_status_names) >= 16:      # launches still in flight are at most a few calls back
             del _host_status_names[0]

@@ -80,6 +80,18 @@ def build_plan(space, np_tables, batch, names, wide_names=(), fm=False):
     return plan, tables, inputs, weights, tnames
 
 
+@pytest.fixture(params=["small_kernel", "big_kernels"])
+def kernel_family(request):
+    """Both forward families in front of the same expectation: nrx_embed_fwd serves a batch up to the small-batch limit with
+    the one-block-per-sample kernel (embed_fwd_small_kernel) and anything larger with the lane-group kernels (embed_fwd_ring /
+    embed_fwd_generic / the wide-split kernels).  The limit is a run-time knob of the C-ABI (nrx_set_small_batch_max), so every
+    shape below -- ragged last blocks included -- meets the oracle through BOTH."""
+    lib = _lib.load()
+    prev = lib.nrx_set_small_batch_max((1 << 20) if request.param == "small_kernel" else 0)
+    yield request.param
+    lib.nrx_set_small_batch_max(prev)
+
+
 def space_of(cfg_name):
     cfg = yaml.safe_load(open(os.path.join(CONFIGS, cfg_name)))
     names = set(cfg["features"]["user_feature_names"]) | set(cfg["features"]["item_feature_names"])
@@ -90,7 +102,7 @@ def space_of(cfg_name):
 @pytest.mark.parametrize("gname,cfg", [("model_deep", "cf_deep_small.yaml"), ("model_fm", "cf_fm_small.yaml"),
                                        ("model_dcn", "cf_dcn_small.yaml"), ("model_widedeep", "cf_widedeep_small.yaml"),
                                        ("model_lr", "cf_lr_small.yaml")])
-def test_golden_embed_concat_bit_exact(gname, cfg):
+def test_golden_embed_concat_bit_exact(gname, cfg, kernel_family):
     g = load(gname)
     space, names, _ = space_of(cfg)
     plan, tables, inputs, weights, _ = build_plan(space, tables_of(params_of(g)), batch_of(g), names)
@@ -98,7 +110,7 @@ def test_golden_embed_concat_bit_exact(gname, cfg):
     assert np.array_equal(out.detach().cpu().numpy(), g["out/features"])      # gather + concat: bit-exact
 
 
-def test_golden_arrays_dense_shared():
+def test_golden_arrays_dense_shared(kernel_family):
     g = load("model_deep_array")
     space, names, _ = space_of("cf_array_small.yaml")
     p, b = params_of(g), batch_of(g)
@@ -119,7 +131,7 @@ def test_golden_arrays_dense_shared():
     assert np.array_equal(ops.embed_apply(plan, tables, inputs, weights)[0].detach().cpu().numpy(), g["case3/features"])
 
 
-def test_golden_fm_fused_and_standalone():
+def test_golden_fm_fused_and_standalone(kernel_family):
     g = load("model_fm")
     space, names, _ = space_of("cf_fm_small.yaml")
     plan, tables, inputs, weights, _ = build_plan(space, tables_of(params_of(g)), batch_of(g), names, fm=True)
@@ -337,12 +349,14 @@ def _rand_case(rng, B, specs, idx_dtype=np.int64):
 
 
 UNIFORM_CASES = [(1, 5, 16), (63, 26, 16), (64, 26, 16), (1000, 26, 16), (257, 13, 16), (300, 40, 32), (129, 5, 64),
-                 (77, 8, 128), (33, 3, 256), (500, 27, 16), (100, 1, 32), (90, 14, 64), (4096, 9, 16)]
+                 (77, 8, 128), (33, 3, 256), (500, 27, 16), (100, 1, 32), (90, 14, 64), (4096, 9, 16),
+                 # partial last blocks above the default small-batch limit (2048): the ring kernel's tail, with and without the FM epilogue
+                 (2049, 26, 16), (4097, 26, 16), (5000, 13, 32), (2051, 5, 64), (2500, 7, 256)]
 
 
 @pytest.mark.parametrize("B,F,D", UNIFORM_CASES)
 @pytest.mark.parametrize("idx_dtype", [np.int64, np.int32])
-def test_uniform_gather_concat_bit_exact_vs_oracle(B, F, D, idx_dtype):
+def test_uniform_gather_concat_bit_exact_vs_oracle(B, F, D, idx_dtype, kernel_family):
     rng = np.random.default_rng(B * 1000 + F * 10 + D)
     space, tables, batch = _rand_case(rng, B, [(NRX_SPARSE, 50 + 7 * i, D, 0) for i in range(F)], idx_dtype)
     want, _, _ = R.embed_concat(space, tables, batch, set(tables))
@@ -385,8 +399,8 @@ GENERIC_CASES = {
 
 
 @pytest.mark.parametrize("case", sorted(GENERIC_CASES))
-@pytest.mark.parametrize("B", [1, 37, 256, 1031])
-def test_generic_embed_vs_oracle(case, B, monkeypatch):
+@pytest.mark.parametrize("B", [1, 37, 256, 1031, 2049, 5000])
+def test_generic_embed_vs_oracle(case, B, monkeypatch, kernel_family):
     if case in ("many_mixed_dims", "deep_like_hybrid"):
         monkeypatch.setenv("NRX_SPLIT_MIN_LOOKUPS", "0")      # small batches: force the per-width split these cases are about
     rng = np.random.default_rng(sum(map(ord, case)) + B)
@@ -405,6 +419,79 @@ def test_generic_embed_vs_oracle(case, B, monkeypatch):
         else:
             assert np.array_equal(blk, ref)                                # copies: bit-exact
         col += d
+
+
+@pytest.mark.parametrize("B", [63, 2049, 4097, 5000])
+@pytest.mark.parametrize("shape", ["uniform_fm", "uniform_plain", "masked_bag_mix", "fm_with_bag"])
+def test_nothing_is_written_past_the_batch(shape, B, kernel_family):
+    """The tail guard of every forward kernel, seen from outside: the C-ABI call gets buffers with 300 spare rows behind the batch, filled
+    with a sentinel, and a batch that ends inside a block.  Rows [0, B) must equal the oracle, rows [B, B + 300) must still hold the
+    sentinel -- `out`, the FM logits and the FM field sums alike.  (A guard that lets the last block's idle lanes through reads ids past the
+    id arrays and stores rows past the batch: this is the test that sees it.)"""
+    import ctypes as C
+    rng = np.random.default_rng(B + len(shape))
+    D = 16
+    if shape.startswith("uniform"):
+        specs = [(NRX_SPARSE, 60 + 5 * i, D, 0) for i in range(26)]
+    elif shape == "masked_bag_mix":
+        specs = [(NRX_SPARSE, 300, D, 0), (NRX_BAG_MASKED_MEAN, 200, D, 50), (NRX_SPARSE, 90, D, 0), (NRX_BAG_MEAN, 40, D, 7)]
+    else:
+        specs = [(NRX_SPARSE, 300, D, 0), (NRX_BAG_MASKED_MEAN, 200, D, 20), (NRX_SPARSE, 90, D, 0)]
+    fm = shape in ("uniform_fm", "fm_with_bag")
+    PAD = 300
+    space, tables, batch = _rand_case(rng, B + PAD, specs)
+    # ids of the spare samples are LEGAL ids: whatever a broken guard stores there is a real row, not a fault -- the sentinel must catch it
+    names = set(tables)
+    plan, tt, inputs, weights, _ = build_plan(space, tables, batch, names, fm=fm)
+    head = {k: v[:B] for k, v in batch.items()}
+    want, dims, _, used = R.embed_concat_ex(space, tables, head, names)
+    lib = _lib.load()
+    W = plan.out_width
+    SENT = 12345.5
+    out = torch.full((B + PAD, W), SENT, device=DEV)
+    fm_out = torch.full((B + PAD,), SENT, device=DEV)
+    sums = torch.full((B + PAD, D), SENT, device=DEV)
+    status = torch.zeros(4, dtype=torch.int32, device=DEV)
+    arr = ops._fill_features(plan, 0, len(plan.slots), [t.detach() for t in tt], inputs, weights)
+    rc = lib.nrx_embed_fwd_train(arr, len(plan.slots), B, out.data_ptr(), W, None, 0, fm_out.data_ptr() if fm else None,
+                                 sums.data_ptr() if fm else None, D, status.data_ptr(), None)
+    assert rc == 0, lib.nrx_last_error()
+    torch.cuda.synchronize()
+    assert status.tolist()[0] == 0
+    got = out.cpu().numpy()
+    assert np.all(got[B:] == SENT), "rows past the batch were written"
+    col = 0
+    for fname, d in zip(used, dims):
+        if fname in space.array:
+            np.testing.assert_allclose(got[:B, col:col + d], want[:, col:col + d], rtol=1e-6, atol=1e-6)     # pooled: fp32 sum order
+        else:
+            assert np.array_equal(got[:B, col:col + d], want[:, col:col + d])
+        col += d
+    if fm:
+        assert np.all(fm_out.cpu().numpy()[B:] == SENT) and np.all(sums.cpu().numpy()[B:] == SENT)
+        w, v = R.fm_split(got[:B].astype(np.float64), dims)
+        ref = R.fm_logit(w, v, 0.0)[:, 0]
+        # fp32 accumulation against float64 over the same (pooled) field values: rtol 2e-5, atol 2e-5 * scale
+        np.testing.assert_allclose(fm_out.cpu().numpy()[:B], ref, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(ref).max()))
+        S = np.concatenate([w.sum(1, keepdims=True), v.sum(1)], axis=1)
+        np.testing.assert_allclose(sums.cpu().numpy()[:B], S, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(S).max()))
+
+
+@pytest.mark.parametrize("F,D,L", [(32, 256, 0), (31, 256, 0), (1, 64, 127), (1, 64, 128)])
+def test_small_batch_plans_at_the_lds_limit(F, D, L, kernel_family):
+    """Plans at the edge of what the one-block-per-sample kernel may take (<= 2048 work items AND an LDS image within a block's 64 KB):
+    32 x D = 256 is 2048 items + 2048 output chunks = 74 KB -- it must go to the lane-group kernels instead of failing the launch."""
+    rng = np.random.default_rng(F * D + L)
+    B = 5
+    specs = [(NRX_SPARSE, 40 + i, D, 0) for i in range(F)] if L == 0 else [(NRX_BAG_MASKED_MEAN, 90, D, L), (NRX_SPARSE, 33, D, 0)]
+    space, tables, batch = _rand_case(rng, B, specs)
+    want, dims, _, used = R.embed_concat_ex(space, tables, batch, set(tables))
+    plan, tt, inputs, weights, _ = build_plan(space, tables, batch, set(tables))
+    out = ops.embed_apply(plan, tt, inputs, weights)[0].detach().cpu().numpy()
+    if L == 0:
+        assert np.array_equal(out, want)
+    else:
+        np.testing.assert_allclose(out, want, rtol=1e-6, atol=1e-6)          # pooled: fp32 sum order
 
 
 def test_out_of_range_report_names_the_callers_feature_in_split_launches(monkeypatch):

@@ -77,6 +77,33 @@ def test_small_batch_kernel_is_bit_identical_to_the_big_kernels(name, B):
             assert torch.equal(_bits(a[:B]), _bits(b)), name
 
 
+@pytest.mark.parametrize("B", [1, 63, 257, 2049, 4096])
+@pytest.mark.parametrize("name", ["c2_fm", "c1_mixed", "dssm_user", "bags_mean_sum"])
+def test_both_families_on_the_same_batch_through_the_limit_knob(name, B):
+    """The same batch -- ragged last blocks on both sides of the default limit -- through nrx_set_small_batch_max(large) and (0): the
+    one-block-per-sample kernel and the lane-group kernels must agree bit for bit (outputs, FM logits)."""
+    from news_recsys_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(7 * len(name) + B)
+    plan, tables, inputs, weights = _case(name, rng, B)
+    ins = [x[:B].contiguous() for x in inputs]
+    ws = [None if w is None else w[:B].contiguous() for w in weights]
+    res = []
+    prev = lib.nrx_set_small_batch_max(-1)
+    try:
+        for limit in (1 << 20, 0):
+            lib.nrx_set_small_batch_max(limit)
+            assert lib.nrx_set_small_batch_max(-1) == limit
+            with torch.no_grad():
+                res.append(ops.embed_apply(plan, tables, ins, ws, index_check="sync"))
+    finally:
+        lib.nrx_set_small_batch_max(prev)
+    for a, b in zip(*res):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(_bits(a), _bits(b)), name
+
+
 def test_small_batch_training_form_field_sums_and_gradients():
     """FM plan with gradients: the small kernel writes the same field sums (consumed by the backward) -- loss gradients of the
     small batch equal those of the same samples inside a big batch, within fp32 atomics order for the dense scatter."""
