@@ -233,6 +233,22 @@ NRX_API int nrx_sparse_adam_step(float* const* tables, float* const* exp_avg, fl
                          const int64_t* n_unique_dev, float step_size, const float* step_size_dev, float beta1,
                          float beta2, float eps, float lr_times_weight_decay, void* stream);
 
+/* nrx_embed_bwd_placed with the DENSE gradient tables as its destination: every unique row's sum is stored (accumulate == 0) or added
+ * (accumulate != 0: a table fed by a second launch group) at grad_tables[table][row, :dim] -- the row the key names -- instead of
+ * values[u]: with zero-filled tables, the dense [rows, dim] .grad autograd gives the reference's nn.Embedding tables
+ * (src/model/BaseModel/base_model.py:164), formed by the deterministic sorted reduction in ONE pass (nrx_embed_bwd_placed +
+ * nrx_rows_to_dense write and re-read every unique row in between; same bits).  grad_tables: HOST array of n_tables
+ * (<= NRX_MAX_FEATURES) device pointers indexed by the plan's table ids, all non-null; feats[i].table must point at the gradient of
+ * feature i's table (= grad_tables[table_of[i]]); with a placement, feats[i].index of the placed features must be the ids the plan
+ * was made from (the placement pass reads the row number there).  Everything else as nrx_embed_bwd_placed. */
+NRX_API int nrx_embed_bwd_placed_dense(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                               const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                               const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
+                               int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm,
+                               float* const* grad_tables, int32_t n_tables, int32_t accumulate,
+                               uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Unique-row gradients -> dense gradient tables: for every unique entry u of nrx_sparse_plan / nrx_embed_bwd_sorted
  * (key = (table << 40) | row, gradient rows[u, :dim]), tables[table][row, :dim] = rows[u] (accumulate == 0) or += rows[u]
  * (accumulate != 0: a table fed by more than one reduction).  With zero-filled tables this forms what autograd gives the

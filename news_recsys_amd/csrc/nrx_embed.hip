@@ -812,6 +812,8 @@ struct SortedBwdArgs {
     int32_t n;
     int32_t dim;
     int32_t long_t;
+    int32_t dense;                 // 0: row sums -> values[u];  1 / 2: straight into the dense gradient tables, f[t].index = base of table t's
+                                   //    [rows, dim] gradient (the slot's id pointer is unused here), at the row the key names; 2 adds to what is there
     const float* gs_all;           // bag launches with 0/1 weights: ONE staging array of every feature's (pre-scaled) upstream rows
     const int32_t* walk;           // placement mode (nrx_embed_bwd_placed): the unique rows this launch reduces, and how many;
     const int64_t* n_walk_dev;     //   null = every unique row
@@ -820,6 +822,24 @@ struct SortedBwdArgs {
     int32_t all_fm;
 };
 static_assert(sizeof(SortedBwdArgs) <= 3840, "kernarg budget");
+
+// Where the gradient row of unique entry u (key = table << 40 | row) goes: values[u], or -- dense mode (nrx_embed_bwd_placed_dense) -- its
+// place in the table's dense gradient: what nrx_rows_to_dense did in a pass of its own (a read and a write of every unique row).
+__device__ __forceinline__ NRX_GLOBAL float* sorted_row_dst(const NRX_CONST SortedBwdArgs* a, int64_t u, int64_t key) {
+    if (a->dense == 0) return nrx_gmut<float>(a->values) + u * (int64_t)a->dim;
+    return nrx_gmut<float>(reinterpret_cast<float*>(const_cast<void*>(a->f[key >> 40].index))) + (key & ((1ll << 40) - 1)) * (int64_t)a->dim;
+}
+template <int Q>
+__device__ __forceinline__ void sorted_store4(const NRX_CONST SortedBwdArgs* a, int64_t u, int64_t key, int q, float4 acc) {
+    NRX_GLOBAL nrx_f32x4* dst = reinterpret_cast<NRX_GLOBAL nrx_f32x4*>(sorted_row_dst(a, u, key)) + q;       // dim == 4 Q in the fast kernels
+    if (a->dense == 2) {
+        const nrx_f32x4 o = *dst;
+        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    nrx_f32x4 t;
+    t.x = acc.x; t.y = acc.y; t.z = acc.z; t.w = acc.w;
+    *dst = t;
+}
 
 // feature of flat lookup p (<= 64 features): direct when every feature contributes the same number of lookups
 __device__ __forceinline__ int sorted_feat_of(const NRX_CONST SortedBwdArgs* a, int64_t p) {
@@ -851,7 +871,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_kernel(const Sorte
     const int64_t lo = nrx_gconst<int64_t>(a->seg_start)[u];
     int64_t hi = nrx_gconst<int64_t>(a->seg_start)[u + 1];
     // padding row (id 0) never trains (nn.Embedding(padding_idx=0)): its segment is skipped, zeros are written
-    if (a->uniq_keys != nullptr && (nrx_gconst<int64_t>(a->uniq_keys)[u] & ((1ll << 40) - 1)) == 0) hi = lo;
+    const int64_t ukey = a->uniq_keys != nullptr ? nrx_gconst<int64_t>(a->uniq_keys)[u] : 1;
+    if ((ukey & ((1ll << 40) - 1)) == 0) hi = lo;
+    const bool add_to = a->dense == 2;
     constexpr int MAXC = 4;            // up to 4 column chunks per lane (D <= 16 Q), else the slow loop below
     float acc[MAXC][4];
     const int nchunk = (D + 4 * Q - 1) / (4 * Q);
@@ -908,10 +930,10 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_kernel(const Sorte
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const int k0 = (c * Q + q) * 4;
-            NRX_GLOBAL float* dst = nrx_gmut<float>(a->values) + u * (int64_t)D + k0;
+            NRX_GLOBAL float* dst = sorted_row_dst(a, u, ukey) + k0;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (c < nchunk && k0 + j < D) dst[j] = acc[c][j];
+                if (c < nchunk && k0 + j < D) dst[j] = add_to ? acc[c][j] + dst[j] : acc[c][j];
         }
         return;
     }
@@ -951,10 +973,10 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_kernel(const Sorte
                 }
             }
         }
-        NRX_GLOBAL float* dst = nrx_gmut<float>(a->values) + u * (int64_t)D + k0;
+        NRX_GLOBAL float* dst = sorted_row_dst(a, u, ukey) + k0;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (k0 + j < D) dst[j] = ac[j];
+            if (k0 + j < D) dst[j] = add_to ? ac[j] + dst[j] : ac[j];
     }
 }
 
@@ -1103,10 +1125,16 @@ struct PlaceArgs {
     int32_t* long_ws;                    // the walk's four work-list counters: cleared here (the walk is the next launch)
     int32_t n;
     int32_t nt;                          // non-temporal upstream loads (default; NRX_PLACE_NT=0 turns them off): the rows are read once
+    // DENSE (nrx_embed_bwd_placed_dense): a placed row goes straight to its place in the table's dense gradient -- the lookup's own id
+    // names the row (the ids are read where they lie, sample-major), dest >= 0 only says "placed"
+    const void* ids[NRX_MAX_FEATURES];   // per placeable feature
+    float* grad[NRX_MAX_FEATURES];       // per placeable feature: base of its table's [rows, 4 Q] gradient
+    int32_t idx64;
+    int32_t add_to;                      // 1: add to what the table holds (a table fed by a second launch group)
 };
 static_assert(sizeof(PlaceArgs) <= 3584, "kernarg budget");
 
-template <int QLOG2, int U, bool FM, bool UNAL>
+template <int QLOG2, int U, bool FM, bool UNAL, bool DENSE = false>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceArgs args_in_kernarg) {
     const NRX_CONST PlaceArgs* a = nrx_kernarg<PlaceArgs>();
     constexpr int Q = 1 << QLOG2;
@@ -1152,8 +1180,12 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceA
     // then some -- sequential reads and random 64-byte row writes do not overlap well; non-temporal loads -7 us (C5 set: -16 us),
     // 4 instead of 8 fetches in flight -2 us, 13 in flight +36 us (3 waves per SIMD).
     const bool nt = a->nt != 0;
-    auto fetch = [&](int f, int32_t d, float4& g, float4& v) {          // f wave-uniform: column numbers come from scalar loads
+    auto fetch = [&](int f, int32_t& d, float4& g, float4& v) {          // f wave-uniform: column numbers come from scalar loads
         if (d >= 0) {
+            if (DENSE) {        // the row number replaces the unique index (a placed lookup's id is in range and not 0: the plan saw it)
+                const void* ip = a->ids[f];
+                d = a->idx64 ? (int32_t)nrx_gconst<int64_t>(ip)[b] : nrx_gconst<int32_t>(ip)[b];
+            }
             if (!UNAL && nt) {
                 g = nrx_ldg4_nt(a->g_out, (b * a->out_ld + a->out_col[f]) / 4 + q);
                 if (FM) v = nrx_ldg4_nt(a->feat, (b * a->feat_ld + a->out_col[f]) / 4 + q);
@@ -1169,7 +1201,16 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceA
             if (FM) fm_fold4(t, a->fm[f] ? gf : 0.f, S, v, q);
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);         // 0 + t, as the walk forms it (a -0 becomes +0 there too)
             acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-            nrx_stg4(a->values, (int64_t)d * Q + q, acc);
+            if (DENSE) {
+                float* base = a->grad[f];
+                if (a->add_to) {
+                    const float4 o = nrx_ldg4(base, (int64_t)d * Q + q);
+                    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+                }
+                nrx_stg4(base, (int64_t)d * Q + q, acc);
+            } else {
+                nrx_stg4(a->values, (int64_t)d * Q + q, acc);
+            }
         }
     };
     if (n >= U) {
@@ -1218,24 +1259,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceA
 #pragma unroll
         for (int u = 0; u < U; ++u) d[u] = f0 + u < n ? s_dest[(f0 + u) * TB + sb] : -1;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int f = f0 + u < n ? f0 + u : n - 1;            // wave-uniform: column numbers come from scalar loads
-            if (d[u] >= 0) {
-                g[u] = upstream_chunk<UNAL>(a->g_out, a->out_ld, a->g_wide, a->wide_ld, a->out_col[f], a->wide_col[f], b, q);
-                if (FM) v[u] = nrx_ldg4(a->feat, (b * a->feat_ld + a->out_col[f]) / 4 + q);
-            }
-        }
+        for (int u = 0; u < U; ++u) fetch(f0 + u < n ? f0 + u : n - 1, d[u], g[u], v[u]);      // wave-uniform feature: column numbers come from scalar loads
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int f = f0 + u < n ? f0 + u : n - 1;
-            if (d[u] >= 0) {
-                float4 t = g[u];
-                if (FM) fm_fold4(t, a->fm[f] ? gf : 0.f, S, v[u], q);
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);     // 0 + t, as the walk forms it (a -0 becomes +0 there too)
-                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-                nrx_stg4(a->values, (int64_t)d[u] * Q + q, acc);
-            }
-        }
+        for (int u = 0; u < U; ++u) place(f0 + u < n ? f0 + u : n - 1, d[u], g[u], v[u]);
     }
 }
 
@@ -1593,7 +1619,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (u0 + r < n && !lng[r]) nrx_stg4(a->values, urow[r] * (int64_t)Q + q, acc[r]);
+        if (u0 + r < n && !lng[r]) sorted_store4<Q>(a, urow[r], key[r], q, acc[r]);
     };
     for (int64_t blk = blockIdx.x; blk * (TB * R) < n; blk += gridDim.x) body(blk);
 }
@@ -1728,7 +1754,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
             acc.w += __shfl_xor(acc.w, off, 64);
         }
         if (g == 0) {
-            if (w.dest < 0) nrx_stg4(a->values, (int64_t)w.u * Q + q, acc);
+            if (w.dest < 0) sorted_store4<Q>(a, w.u, a->dense ? nrx_gconst<int64_t>(a->uniq_keys)[w.u] : 0, q, acc);
             else if (w.dest < a->long_slots_cap) nrx_stg4(partial, (int64_t)w.dest * Q + q, acc);
         }
     }
@@ -1761,7 +1787,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_combine_kernel(const SortedB
             acc.z += __shfl_xor(acc.z, off, 64);
             acc.w += __shfl_xor(acc.w, off, 64);
         }
-        if (g == 0) nrx_stg4(a->values, (int64_t)w.u * Q + q, acc);
+        if (g == 0) sorted_store4<Q>(a, w.u, a->dense ? nrx_gconst<int64_t>(a->uniq_keys)[w.u] : 0, q, acc);
     }
 }
 
@@ -2254,14 +2280,18 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
                                  const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
                                  int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
                                  uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
-                                 void* workspace, int64_t ws_bytes /* 0: the size nrx_embed_bwd_sorted_workspace promises */, void* stream) {
+                                 void* workspace, int64_t ws_bytes /* 0: the size nrx_embed_bwd_sorted_workspace promises */, void* stream,
+                                 float* const* grad_tables = nullptr, int32_t n_tables = 0, int32_t add_to = 0) {
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_bwd_sorted: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0 && dim >= 1 && n_unique >= 0, "nrx_embed_bwd_sorted: bad argument");
     const bool has_fm = fm != nullptr && fm->g_fm != nullptr;
     NRX_REQUIRE(g_out != nullptr || g_wide != nullptr || has_fm, "nrx_embed_bwd_sorted: no upstream gradient");
     if (n_unique == 0 || batch == 0) return NRX_OK;
-    NRX_REQUIRE(order && seg_start && values, "nrx_embed_bwd_sorted: null buffer");
+    const bool dense = grad_tables != nullptr;
+    NRX_REQUIRE(order && seg_start && (values || dense), "nrx_embed_bwd_sorted: null buffer");
+    NRX_REQUIRE(!dense || (uniq_keys != nullptr && n_tables >= 1 && n_tables <= NRX_MAX_FEATURES),
+                "nrx_embed_bwd_placed_dense: needs uniq_keys and 1 .. %d tables", NRX_MAX_FEATURES);
     {
         int rc = check_fm_grad(fm, feats, n_feats, "nrx_embed_bwd_sorted");
         if (rc != NRX_OK) return rc;
@@ -2281,6 +2311,8 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
     a.n_walk_dev = nullptr;
     a.gs_all = nullptr;
     a.long_t = SORTED_LONG_T;
+    a.dense = dense ? (add_to ? 2 : 1) : 0;
+    for (int i = 0; i < NRX_MAX_FEATURES; ++i) a.f[i].index = nullptr;
     int64_t off = 0;
     for (int i = 0; i < n_feats; ++i) {
         const nrx_feature_t& s = feats[i];
@@ -2294,7 +2326,6 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
         }
         FeatDev& d = a.f[i];
         d.table = nullptr;
-        d.index = nullptr;
         d.weight = (s.kind == NRX_BAG_MEAN) ? nullptr : s.weight;
         // fast form: `rows` carries the 2^64 reciprocal of bag_len (sample = lookup / bag_len as one multiply-high, exact for
         // lookups < 2^32; (2^64 - 1) / d + 1 is floor(2^64 / d) + 1, or 2^64 / d itself for a power of two -- both exact)
@@ -2311,6 +2342,16 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
         off += batch * (s.kind == NRX_SPARSE ? 1 : s.bag_len);
     }
     a.off[n_feats] = off;
+    bool grads_al = true;
+    if (dense) {                       // slot t of the descriptor array carries table t's gradient base (see SortedBwdArgs::dense)
+        for (int t = 0; t < n_tables; ++t) {
+            NRX_REQUIRE(grad_tables[t] != nullptr, "nrx_embed_bwd_placed_dense: table %d: null gradient pointer", t);
+            a.f[t].index = grad_tables[t];
+            grads_al = grads_al && nrx_aligned16(grad_tables[t]);
+        }
+        for (int i = 0; i < n_feats; ++i)
+            NRX_REQUIRE(feats[i].table != nullptr, "nrx_embed_bwd_placed_dense: feature %d: feats[i].table must be its table's gradient", i);
+    }
     a.uniform_len = a.off[1] - a.off[0];
     for (int i = 0; i < n_feats && a.uniform_len > 0; ++i)
         if (a.off[i + 1] - a.off[i] != a.uniform_len) a.uniform_len = 0;
@@ -2341,7 +2382,7 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
     const int tb = NRX_BLOCK >> ql;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // fast form: plain single-valued features, D = 4 Q exactly, float4-addressable everywhere
-    bool fast = dim == (4 << ql) && ql >= 2 && ql <= 4 && nrx_aligned16(values) &&
+    bool fast = dim == (4 << ql) && ql >= 2 && ql <= 4 && (dense ? grads_al : nrx_aligned16(values)) &&
                 (!has_fm || (g_out != nullptr && nrx_aligned16(fm->feat) && (fm->feat_ld & 3) == 0 && nrx_aligned16(fm->fm_sums) &&
                              (fm->sums_ld & 3) == 0 && fm->sums_ld >= dim));
     bool has_bag = false;
@@ -2375,6 +2416,11 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
                 if (!((place_feats >> i) & 1ull)) continue;
                 NRX_REQUIRE(feats[i].kind == NRX_SPARSE, "nrx_embed_bwd_placed: feature %d is not single-valued: it cannot be placed", i);
                 pa.off[n_place] = a.off[i];
+                pa.ids[n_place] = feats[i].index;
+                pa.grad[n_place] = const_cast<float*>(feats[i].table);
+                NRX_REQUIRE(!dense || (feats[i].index != nullptr && (feats[i].index_bits == 32 || feats[i].index_bits == 64) &&
+                                       feats[i].index_bits == feats[0].index_bits),
+                            "nrx_embed_bwd_placed_dense: feature %d: the placement pass reads the ids (one width per launch)", i);
                 pa.out_col[n_place] = feats[i].out_col;
                 pa.wide_col[n_place] = feats[i].wide_col;
                 pa.fm[n_place] = a.f[i].fm;
@@ -2410,6 +2456,8 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             pa.g_fm = a.g_fm; pa.fm_sums = a.fm_sums; pa.sums_ld = a.sums_ld; pa.feat = a.feat; pa.feat_ld = a.feat_ld;
             pa.dest = dest;
             pa.values = values;
+            pa.idx64 = feats[0].index_bits == 64;
+            pa.add_to = add_to ? 1 : 0;
             pa.long_ws = a.long_ws;
             pa.n = n_place;
             { const char* e = getenv("NRX_PLACE_NT"); pa.nt = e ? atoi(e) : 1; }
@@ -2419,7 +2467,10 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             constexpr int U = 8;
 #define NRX_PL(QL_)                                                                                                        \
     {                                                                                                                      \
-        if (has_fm && uvar == 4) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, true, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
+        if (dense && has_fm) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, true, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
+        else if (dense && unal) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, false, true, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa); \
+        else if (dense) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, false, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);        \
+        else if (has_fm && uvar == 4) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, true, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
         else if (has_fm) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, true, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
         else if (unal) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa); \
         else if (uvar == 4) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, false, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);        \
@@ -2524,6 +2575,22 @@ extern "C" int nrx_embed_bwd_sorted(const nrx_feature_t* feats, int32_t n_feats,
     NRX_TRACE();
     return embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, g_wide, wide_ld, order, seg_start, uniq_keys, n_unique,
                                  n_unique_dev, fm, values, 0, nullptr, nullptr, nullptr, workspace, 0, stream);
+}
+
+extern "C" int nrx_embed_bwd_placed_dense(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                                          const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                                          const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
+                                          int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm,
+                                          float* const* grad_tables, int32_t n_tables, int32_t accumulate,
+                                          uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
+                                          void* workspace, int64_t workspace_bytes, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(grad_tables != nullptr, "nrx_embed_bwd_placed_dense: null grad_tables");
+    NRX_REQUIRE((dest != nullptr) == (walk != nullptr) && (dest != nullptr) == (n_walk != nullptr),
+                "nrx_embed_bwd_placed_dense: dest, walk and n_walk come together (all null: no placement)");
+    return embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, g_wide, wide_ld, order, seg_start, uniq_keys, n_unique,
+                                 n_unique_dev, fm, nullptr, place_feats, dest, walk, n_walk, workspace, workspace_bytes, stream,
+                                 grad_tables, n_tables, accumulate);
 }
 
 // workspace size that also holds the pre-scaled upstream rows of the launch's 0/1-weight bag features

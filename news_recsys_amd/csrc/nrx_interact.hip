@@ -697,6 +697,89 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_dcn_v1_group_kernel(const Emb
     for (int u = 0; u < N; ++u) o[W / 4 + u * Q + q] = xl[u];
 }
 
+// Round 4 form of the grouped kernel.  What the one-tile-per-block form above makes every block do before its first useful request: stage
+// w / b in LDS (a global round trip + a barrier), THEN load its ids (a second round trip), THEN its rows (a third) -- for 16 samples, 4 096
+// times per launch, with the 2 N stores of a sample issued as one burst at the very end.  Here a block lives for the whole launch
+// (grid = resident blocks, tiles strided): the ids of the first tile are requested before w / b are staged, and inside the loop the ids of
+// tile i + 1 are requested before tile i's rows are waited for, so a wavefront spends ONE exposed round trip per tile (its rows) instead of
+// three, and the output -- written once, never re-read by this launch -- leaves with non-temporal stores (STNT).  Same arithmetic in the
+// same order as the kernel above: bit-identical results (tests/test_hip_parity.py::test_fused_gather_cross_*).
+template <int QLOG2, int N, bool IDX64, bool NT, bool STNT>
+__global__ __launch_bounds__(NRX_BLOCK) void embed_dcn_v1_group_persist_kernel(const EmbedDcnArgs args_in_kernarg) {
+    const NRX_CONST EmbedDcnArgs* a = nrx_kernarg<EmbedDcnArgs>();
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int W = a->width, NL = a->n_layers;
+    float4* s_w = reinterpret_cast<float4*>(smem);          // [NL][W/4]
+    float4* s_b = s_w + NL * (W / 4);
+    const int q = threadIdx.x & (Q - 1);
+    const int64_t batch = a->batch, stride = (int64_t)gridDim.x * TB;
+    int64_t b = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
+    auto load_ids = [&](int64_t bb, int64_t (&id)[N]) {
+        const int64_t bc = bb < batch ? bb : batch - 1;       // lanes past the batch re-read the last sample's ids (never stored)
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+            id[u] = IDX64 ? nrx_gconst<int64_t>(a->index[u])[bc] : (int64_t)nrx_gconst<int32_t>(a->index[u])[bc];
+    };
+    int64_t id[N];
+    load_ids(b, id);                                          // in flight while w / b are staged
+    for (int i = threadIdx.x; i < NL * (W / 4); i += NRX_BLOCK) {
+        s_w[i] = reinterpret_cast<const float4*>(a->w)[i];
+        s_b[i] = reinterpret_cast<const float4*>(a->b)[i];
+    }
+    __syncthreads();
+    for (; b - (threadIdx.x >> QLOG2) < batch; b += stride) {     // block-uniform trip count (the tile's first sample decides)
+        const bool live = b < batch;
+        float4 x0[N];
+        int bad_feat = -1;
+        int64_t bad_id = 0;
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            const bool bad = (uint64_t)id[u] >= (uint64_t)a->rows[u];
+            bad_feat = bad ? u : bad_feat;
+            bad_id = bad ? id[u] : bad_id;
+            x0[u] = NT ? nrx_ldg4_nt(a->table[u], (bad ? 0 : id[u]) * Q + q) : nrx_ldg4(a->table[u], (bad ? 0 : id[u]) * Q + q);
+        }
+        if (bad_feat >= 0 && q == 0 && live) nrx_report_oob(a->status, bad_feat, b, bad_id);
+        load_ids(b + stride, id);                             // next tile's ids: requested under this tile's rows
+        float4 xl[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u) xl[u] = x0[u];
+        for (int l = 0; l < NL; ++l) {
+            const float4* wl = s_w + l * (W / 4) + q;
+            const float4* bl = s_b + l * (W / 4) + q;
+            float part = 0.f;
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                const float4 wv = wl[u * Q];
+                part += xl[u].x * wv.x + xl[u].y * wv.y + xl[u].z * wv.z + xl[u].w * wv.w;
+            }
+            const float dot = group_sum_dpp<Q>(part);
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                const float4 bv = bl[u * Q];
+                xl[u].x = x0[u].x * dot + bv.x + xl[u].x;
+                xl[u].y = x0[u].y * dot + bv.y + xl[u].y;
+                xl[u].z = x0[u].z * dot + bv.z + xl[u].z;
+                xl[u].w = x0[u].w * dot + bv.w + xl[u].w;
+            }
+        }
+        if (live) {
+            NRX_GLOBAL nrx_f32x4* o = (NRX_GLOBAL nrx_f32x4*)(a->out + b * a->out_ld);
+#pragma unroll
+            for (int u = 0; u < 2 * N; ++u) {
+                const float4 v = u < N ? x0[u] : xl[u - N];
+                nrx_f32x4 t;
+                t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+                NRX_GLOBAL nrx_f32x4* dst = o + (u < N ? 0 : W / 4) + (u < N ? u : u - N) * Q + q;
+                if (STNT) __builtin_nontemporal_store(t, dst);
+                else *dst = t;
+            }
+        }
+    }
+}
+
 int ceil_log2i(int x) {
     int l = 0;
     while ((1 << l) < x) ++l;
@@ -1000,8 +1083,19 @@ extern "C" int nrx_embed_dcn_v1_fwd(const nrx_feature_t* feats, int32_t n_feats,
             int64_t table_bytes = 0;
             for (int i = 0; i < n_feats; ++i) table_bytes += feats[i].rows * (int64_t)D0 * 4;
             const bool nt = table_bytes > (256ll << 20);     // non-temporal row loads once the tables exceed the Infinity Cache
-#define NRX_EG3(QL_, N_, I_) do { if (nt) hipLaunchKernelGGL((embed_dcn_v1_group_kernel<QL_, N_, I_, true>), ggrid, dim3(NRX_BLOCK), smem, st, a); \
-                                  else hipLaunchKernelGGL((embed_dcn_v1_group_kernel<QL_, N_, I_, false>), ggrid, dim3(NRX_BLOCK), smem, st, a); } while (0)
+            // NRX_EDCN_VARIANT (measurement knob): 0 = one tile per block (round 1-3), 1 = persistent blocks, 2 = + non-temporal stores (default);
+            // NRX_EDCN_BPC = resident blocks per CU of the persistent forms
+            static const int variant = getenv("NRX_EDCN_VARIANT") ? atoi(getenv("NRX_EDCN_VARIANT")) : 2;
+            static const int bpc = getenv("NRX_EDCN_BPC") ? atoi(getenv("NRX_EDCN_BPC")) : 5;
+            const unsigned pg = ggrid.x < (unsigned)(256 * bpc) ? ggrid.x : (unsigned)(256 * bpc);
+            const dim3 pgrid(pg);
+#define NRX_EG3(QL_, N_, I_) do { \
+        if (variant >= 2 && nt) hipLaunchKernelGGL((embed_dcn_v1_group_persist_kernel<QL_, N_, I_, true, true>), pgrid, dim3(NRX_BLOCK), smem, st, a); \
+        else if (variant >= 2) hipLaunchKernelGGL((embed_dcn_v1_group_persist_kernel<QL_, N_, I_, false, true>), pgrid, dim3(NRX_BLOCK), smem, st, a); \
+        else if (variant == 1 && nt) hipLaunchKernelGGL((embed_dcn_v1_group_persist_kernel<QL_, N_, I_, true, false>), pgrid, dim3(NRX_BLOCK), smem, st, a); \
+        else if (variant == 1) hipLaunchKernelGGL((embed_dcn_v1_group_persist_kernel<QL_, N_, I_, false, false>), pgrid, dim3(NRX_BLOCK), smem, st, a); \
+        else if (nt) hipLaunchKernelGGL((embed_dcn_v1_group_kernel<QL_, N_, I_, true>), ggrid, dim3(NRX_BLOCK), smem, st, a); \
+        else hipLaunchKernelGGL((embed_dcn_v1_group_kernel<QL_, N_, I_, false>), ggrid, dim3(NRX_BLOCK), smem, st, a); } while (0)
 #define NRX_EG2(QL_, N_) do { if (a.idx64) NRX_EG3(QL_, N_, true); else NRX_EG3(QL_, N_, false); } while (0)
 #define NRX_EG(QL_) switch (n_feats) { case 2: NRX_EG2(QL_, 2); break; case 3: NRX_EG2(QL_, 3); break; case 4: NRX_EG2(QL_, 4); break; \
                                        case 5: NRX_EG2(QL_, 5); break; case 6: NRX_EG2(QL_, 6); break; case 7: NRX_EG2(QL_, 7); break; \

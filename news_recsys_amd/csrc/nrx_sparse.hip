@@ -275,8 +275,14 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo pl
 // Every step is order-preserving, so equal rows stay in (feature, sample) order: the result is the same permutation the
 // stable rocPRIM sort produces (tests compare both against the oracle's plan).
 // ---------------------------------------------------------------------------------------------------
-constexpr int SEG_TILE = 4096;                      // entries per block
-constexpr int SEG_THREADS = 512;                    // threads of the tile kernels: 8 wavefronts x 512 contiguous entries (the
+#ifndef NRX_SEG_TILE
+#define NRX_SEG_TILE 4096
+#endif
+#ifndef NRX_SEG_THREADS
+#define NRX_SEG_THREADS 512
+#endif
+constexpr int SEG_TILE = NRX_SEG_TILE;              // entries per block
+constexpr int SEG_THREADS = NRX_SEG_THREADS;        // threads of the tile kernels: 8 wavefronts x 512 contiguous entries (the
                                                     // kernels are latency-bound at these sizes: short serial chains, more of them)
 constexpr int SEG_PER_THREAD = SEG_TILE / SEG_THREADS;
 constexpr int SEG_MAX_DB = 10;                      // widest digit
@@ -296,6 +302,7 @@ struct SegArgs {
     uint32_t table_w[NRX_MAX_FEATURES / 4];  // per slot: table number, a byte each
     uint32_t seg_db_w[NRX_MAX_FEATURES / 8]; // per table: digit width, a nibble each (<= SEG_MAX_DB = 10)
     int32_t n_slots, n_seg, idx64, row_bits, nb;     // nb = 1 << (widest digit) = row stride of hist / ctot / bin_base
+    int32_t xcd;                                      // 1: blocks take their tiles in XCD order (seg_block_tile)
 };
 static_assert(sizeof(SegArgs) <= 3584, "kernarg budget");
 __device__ __forceinline__ int seg_db_of(const NRX_CONST SegArgs* a, int seg) {                 // seg wave-uniform: scalar loads and shifts
@@ -316,6 +323,15 @@ __device__ __forceinline__ int seg_count_le(const NRX_CONST T* arr, int n, T x) 
     const bool hit = lane >= 1 && lane < n && arr[lane < n ? lane : 0] <= x;
     return (int)__popcll(__ballot(hit));
 }
+// Tile of a block.  Workgroups land on XCD (block % 8), each XCD with its own L2: in launch order the 16 tiles of a C2 table are spread over
+// all eight L2s, so the 32-byte runs a tile scatters into the table's 1024 bins reach memory as eight partial copies of every line, and
+// the next pass (and the histogram rows in between) finds nothing of its input in its own L2.  With xcd set, XCD x takes the x-th eighth of
+// the tiles (a bijection of the grid, as in plan_emit_kernel): a table's whole sort -- pairs in, histogram rows, pairs out -- stays inside one L2.
+__device__ __forceinline__ int seg_block_tile(const NRX_CONST SegArgs* a) {
+    if (!a->xcd) return (int)blockIdx.x;
+    const unsigned x = blockIdx.x & 7u, i = blockIdx.x >> 3, qt = gridDim.x >> 3, rt = gridDim.x & 7u;
+    return (int)(x * qt + (x < rt ? x : rt) + i);
+}
 __device__ __forceinline__ int seg_of_tile(const NRX_CONST SegArgs* a, int tile) {
     return __builtin_amdgcn_readfirstlane(seg_count_le<int32_t>(a->seg_tile, a->n_seg, tile));
 }
@@ -327,7 +343,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
                                                                uint32_t* __restrict__ hist) {
     extern __shared__ uint32_t s_hist[];
     const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
-    const int tile = blockIdx.x, seg = seg_of_tile(a, tile);
+    const int tile = seg_block_tile(a), seg = seg_of_tile(a, tile);
     const int nbins = 1 << seg_db_of(a, seg);
     for (int b = threadIdx.x; b < nbins; b += SEG_THREADS) s_hist[b] = 0;
     const int64_t q0 = a->seg_off[seg] + (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE, qend = a->seg_off[seg + 1];
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_hist_kernel(const SegArgs arg
                                                              uint32_t* __restrict__ hist) {
     extern __shared__ uint32_t s_hist[];
     const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
-    const int tile = blockIdx.x, seg = seg_of_tile(a, tile);
+    const int tile = seg_block_tile(a), seg = seg_of_tile(a, tile);
     const int db = seg_db_of(a, seg), nbins = 1 << db, shift = pass * db;
     for (int b = threadIdx.x; b < nbins; b += SEG_THREADS) s_hist[b] = 0;
     const int64_t q0 = a->seg_off[seg] + (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE, qend = a->seg_off[seg + 1];
@@ -528,7 +544,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
     extern __shared__ uint32_t s_mem[];
     const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int tile = blockIdx.x, seg = seg_of_tile(a, tile);
+    const int tile = seg_block_tile(a), seg = seg_of_tile(a, tile);
     const int db = seg_db_of(a, seg), nbins = 1 << db, shift = pass * db, nb = a->nb;
     uint16_t* s_wh = reinterpret_cast<uint16_t*>(s_mem);  // [WAVES][nbins]: running bin counts of each wave's 512-entry chunk (16-bit: a tile
                                                           // holds 4096 entries; halves this area -- a third / fourth resident block per CU)
@@ -572,28 +588,28 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
                 // DIRECT 1: the rows are the segment's tile histograms; DIRECT 2 (seg_scan_chunks has run): the rows are its chunk
                 // totals, and the tile's own histogram row already holds the counts of the earlier tiles of its chunk
                 const int t0 = DIRECT == 1 ? a->seg_tile[seg] : a->seg_chunk[seg], t1 = DIRECT == 1 ? a->seg_tile[seg + 1] : a->seg_chunk[seg + 1];
-                const int tile = DIRECT == 1 ? (int)blockIdx.x : chunk;
+                const int mine = DIRECT == 1 ? tile : chunk;
                 const uint32_t* h = (DIRECT == 1 ? hist : ctot) + (size_t)t0 * nb + b;
-                uint32_t before = DIRECT == 1 ? 0u : hist[(size_t)blockIdx.x * nb + b], all = 0;
+                uint32_t before = DIRECT == 1 ? 0u : hist[(size_t)tile * nb + b], all = 0;
                 int t = t0;
                 for (; t + 16 <= t1; t += 16, h += (size_t)16 * nb) {      // sixteen independent loads in flight (a C2 table is 16 tiles: one round trip, not two)
                     uint32_t v[16];
 #pragma unroll
                     for (int u = 0; u < 16; ++u) v[u] = h[(size_t)u * nb];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) { all += v[u]; before += t + u < tile ? v[u] : 0u; }
+                    for (int u = 0; u < 16; ++u) { all += v[u]; before += t + u < mine ? v[u] : 0u; }
                 }
                 for (; t + 8 <= t1; t += 8, h += (size_t)8 * nb) {         // eight independent loads in flight
                     uint32_t v[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) v[u] = h[(size_t)u * nb];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { all += v[u]; before += t + u < tile ? v[u] : 0u; }
+                    for (int u = 0; u < 8; ++u) { all += v[u]; before += t + u < mine ? v[u] : 0u; }
                 }
                 for (; t < t1; ++t, h += nb) {
                     const uint32_t v = h[0];
                     all += v;
-                    before += t < tile ? v : 0u;
+                    before += t < mine ? v : 0u;
                 }
                 gbase[i] = before;
                 gtot[i] = all;
@@ -834,6 +850,8 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
         sa.idx64 = a.idx64;
         sa.row_bits = row_bits;
         sa.nb = 1 << max_db;
+        // tiles in XCD order (seg_block_tile): C2 plan 80.2 -> 73.8 us, C4 / C5 unchanged (profiles/r04_planner_variants.txt); NRX_SEG_XCD=0: launch order
+        { const char* e = getenv("NRX_SEG_XCD"); sa.xcd = e ? atoi(e) : 1; }
         const int nb = sa.nb;
         uint32_t* hist = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(temp) + align256(sort_temp_bytes<uint64_t>(n, 64)));
         uint32_t* ctot = hist + (size_t)tile * nb;

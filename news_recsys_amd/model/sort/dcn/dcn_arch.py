@@ -41,9 +41,11 @@ class DCNNet(nn.Module):
         self.cross_net = nn.ModuleList([DCNLayer(input_dim) for _ in range(num_layers)])
 
     def stacked(self):
-        w = torch.stack([l.w[:, 0] for l in self.cross_net]) if len(self.cross_net) else None
-        b = torch.stack([l.b[:, 0] for l in self.cross_net]) if len(self.cross_net) else None
-        return w, b
+        """(w, b) as [n_layers, dim] tensors for the fused launches -- each ONE autograd node over the layers' own [dim, 1] parameters
+        (ops.pack_rows: no per-layer select + torch.stack nodes, per-layer gradients are views of the kernels' [n_layers, dim] outputs)."""
+        if len(self.cross_net) == 0:
+            return None, None
+        return ops.pack_rows([l.w for l in self.cross_net]), ops.pack_rows([l.b for l in self.cross_net])
 
     def forward(self, x):
         if len(self.cross_net) == 0:

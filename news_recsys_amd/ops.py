@@ -770,13 +770,19 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
             wsz = grp["lws_bytes"] = (B, lib.nrx_embed_bwd_workspace_for(arr, n, B, D))
         lws = torch.empty(wsz[1], dtype=torch.uint8, device=dev)   # hot-row work lists, bag scales
         if dense_into is not None:
-            values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
-            _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, total, counts, fmg, values, lws, stream)
             if dense_ptrs is None:
                 dense_ptrs = (C.c_void_p * n_tables)(*[g.data_ptr() for g in dense_into])
             again = any(t in dense_seen for t in tabs)      # > NRX_MAX_FEATURES features: a table may be fed by two groups
-            check(lib.nrx_rows_to_dense(dense_ptrs, n_tables, D, uniq.data_ptr(), values.data_ptr(), total, counts.data_ptr(),
-                                        1 if again else 0, stream), "nrx_rows_to_dense")
+            # the reduction stores every unique row's sum at its place in the table's dense gradient (nrx_embed_bwd_placed_dense: the
+            # descriptors' table column carries the gradient of the feature's table) -- no values[] array, no nrx_rows_to_dense pass
+            arr = _group_features(grp, ids, [ctx.ws[i] for i in fs], fmg is not None, [dense_into[t].data_ptr() for t in tabs])
+            placed = len(pl) == 7
+            check(lib.nrx_embed_bwd_placed_dense(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, pl[0].data_ptr(),
+                                                 pl[2].data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), fmg, dense_ptrs, n_tables,
+                                                 1 if again else 0, int(pmask) if placed else 0,
+                                                 pl[4].data_ptr() if placed else None, pl[5].data_ptr() if placed else None,
+                                                 pl[6].data_ptr() if placed else None, lws.data_ptr(), lws.numel(), stream),
+                  "nrx_embed_bwd_placed_dense")
             dense_seen.update(tabs)
             continue
         if ctx.sink is not None:
@@ -810,9 +816,10 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
     return grads
 
 
-def _group_features(grp, ids, ws, fm: bool):
-    """The descriptor array of one backward group (table pointers are not used by the sorted backward): static fields written
-    once per group, the id / weight pointer columns refreshed through a numpy view."""
+def _group_features(grp, ids, ws, fm: bool, table_ptrs=None):
+    """The descriptor array of one backward group: static fields written once per group, the id / weight pointer columns refreshed
+    through a numpy view.  table_ptrs (one per feature of the group): the table column -- unused by the row-sparse reduction, the
+    gradient of the feature's table for the dense destination (nrx_embed_bwd_placed_dense)."""
     import numpy as np
     key = "arr_fm" if fm else "arr"
     ent = grp.get(key)
@@ -820,11 +827,13 @@ def _group_features(grp, ids, ws, fm: bool):
         sub, n = grp["sub"], grp["n"]
         arr = _fill_features(sub, 0, n, [None] * (max(grp["tabs"]) + 1), ids, ws, table_ptrs=[0] * (max(grp["tabs"]) + 1), fm=fm)
         ent = grp[key] = (arr, np.frombuffer(arr, dtype=_feature_np_dtype()))
-        return arr
+        if table_ptrs is None:
+            return arr
     arr, view = ent
     view["index"] = [x.data_ptr() for x in ids]
     view["index_bits"] = ids[0].element_size() * 8
     view["weight"] = [0 if w is None else w.data_ptr() for w in ws]
+    view["table"] = table_ptrs if table_ptrs is not None else 0
     return arr
 
 
@@ -1296,6 +1305,26 @@ class _DcnV1LayersFn(torch.autograd.Function):
         return (gx, None, *grads)
 
 
+class _PackRowsFn(torch.autograd.Function):
+    """n parameter tensors of `dim` elements each ([dim, 1] as DCNLayer holds them, dcn_arch.py:9-10) -> ONE [n, dim] tensor, as a single autograd
+    node: one cat kernel forward, and the per-layer gradients are views of the incoming [n, dim] gradient (torch.stack over `p[:, 0]` selects is
+    2 n + 1 nodes per call and an unbind + n copies in the backward)."""
+
+    @staticmethod
+    def forward(ctx, *params):
+        ctx.shapes = [p.shape for p in params]
+        return torch.cat([p.reshape(1, -1) for p in params]).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g[i].reshape(s) for i, s in enumerate(ctx.shapes))
+
+
+def pack_rows(params: Sequence[torch.Tensor]) -> torch.Tensor:
+    """[n, dim] from n per-layer parameter tensors (see _PackRowsFn)."""
+    return _PackRowsFn.apply(*params)
+
+
 def dcn_v1_layers(x: torch.Tensor, ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor]) -> torch.Tensor:
     """DCNNet.forward (dcn_arch.py:63-70) from the layers' own parameter tensors (each [dim, 1] or [dim])."""
     if len(ws) != len(bs) or not ws:
@@ -1432,7 +1461,7 @@ class _EmbedDcnFn(torch.autograd.Function):
         ctx.has_fm_feat = False
         ctx.sink = sparse_grad if isinstance(sparse_grad, SparseGradSink) else None
         ctx.sparse_grad = bool(sparse_grad)
-        ctx.dense_sorted = _dense_sorted_ok(plan, tables, ctx.sparse_grad, call.B)
+        ctx.dense_sorted = _dense_sorted_ok(plan, tables, ctx.sparse_grad, call.B) and any(ctx.needs_input_grad[5:])
         ctx.tables = list(tables) if ctx.sink is not None else None
         ctx.save_for_backward(call.out, call.w, call.b)
         ctx.w_shape, ctx.b_shape = tuple(w.shape), tuple(b.shape)

@@ -19,10 +19,14 @@ for n, r in zip(lens, rows):
     x = np.minimum(rng.zipf(1.05, n) - 1, r - 1) if dist == "zipf" else rng.integers(0, r, n)
     ids.append(torch.from_numpy(x.astype(np.int64)).cuda())
 nt = max(tab) + 1
-for _ in range(5): ops.sparse_plan(ids, tab, rows, nt)
+# the placement form (nrx_sparse_plan_place: dest / walk outputs), as the bench's backward calls it; PLACE=0: the plain plan
+pm = None
+if os.environ.get("PLACE", "1") != "0":
+    pm = ops.place_mask([0 if n == B else 2 for n in lens], [1 if n == B else n // B for n in lens])
+for _ in range(5): ops.sparse_plan(ids, tab, rows, nt, pm)
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
-for _ in range(steps): ops.sparse_plan(ids, tab, rows, nt)
+for _ in range(steps): ops.sparse_plan(ids, tab, rows, nt, pm)
 b.record(); torch.cuda.synchronize()
 print(f"{wl} ({dist} ids) plan [{os.environ.get('NRX_PLAN_SORT', 'segmented')}]: {a.elapsed_time(b) / steps * 1e3:.1f} us per call (includes the wrapper's allocations)")
