@@ -336,12 +336,13 @@ class SingleGpuPath:
                     ws.append(None)
             self.pool.append((ins, ws))
         self.bytes_per_impr = algorithmic_bytes_per_impression(feats, self.fm, col if self.cross else 0)
+        self.survey_bytes_per_impr = algorithmic_bytes_per_impression(feats, self.fm, 0)      # SURVEY 8d's own figure (C3: 2 600 B: "cross adds nothing if fused")
         self.granule_bytes_per_impr = granule_bytes_per_impression(feats, self.fm, col if self.cross else 0)
         self.bwd_bytes_per_impr = backward_bytes_per_impression(feats, self.fm)
         self.bytes_note = ("SURVEY 8d: per lookup 8 B id + 4D row read + 4D concat write"
                            + (", + 4 B FM logit per impression" if self.fm else "")
-                           + (f"; + {4 * col} B per impression for the fused cross output written next to x (SURVEY 8d's 2600 B "
-                              "counts the gather alone: the cross adds arithmetic but also this write)" if self.cross else ""))
+                           + (f" (= SURVEY 8d's figure for this workload: the gather alone, which `roofline.frac` uses); the fused launch also writes "
+                              f"{4 * col} B per impression of cross output next to x: `roofline.frac_with_cross_write` counts them too" if self.cross else ""))
         # one bound call per id buffer: descriptors are built once, a step only enqueues the launch(es)
         # The output buffer is recycled every step, as torch's caching allocator does for any real
         # loop (the module path allocates `out` with torch.empty per call and gets the same block back).
@@ -365,6 +366,15 @@ class SingleGpuPath:
         self.device = device
         from news_recsys_amd import _lib
         self.lib = _lib.load()
+        # c5 is the WideDeep configuration: the headline launch is what WideDeep.get_inp_embedding runs -- the gather WITH the column routing
+        # (src/model/sort/widedeep/model.py:53-69) -- and the plain concat of the same tables is the secondary leg (`plain_concat`);
+        # NRX_BENCH_C5_PLAIN=1 swaps them back (rounds 1-3)
+        self.plain_calls = None
+        if wl == "c5" and os.environ.get("NRX_BENCH_C5_PLAIN") != "1":
+            self.plain_calls = self.calls
+            self.calls = self.wide_split_calls(check_index=True)
+            self.desc += ("; headline = the gather with WideDeep.get_inp_embedding's column routing: column 0 of the 10 smallest tables -> wide "
+                          "[B, 10], everything else -> deep [B, 1270] (row stride padded to 1280 floats = whole 128-byte lines, as the WideDeep model asks for)")
 
     def check_indices(self):
         for c in (self.fused if self.fused is not None else self.calls):
@@ -380,7 +390,7 @@ class SingleGpuPath:
         fmb = torch.empty((BATCH,), dtype=torch.float32, device=self.device) if self.fm else None
         return [ops.PreparedEmbed(self.plan, self.tables, ins, ws, out_ld=self.ld, out=o, fm=fmb) for (ins, ws), o in zip(self.pool, outs)]
 
-    def wide_split_calls(self):
+    def wide_split_calls(self, check_index=False):
         """c5 only: the same gather with WideDeep.get_inp_embedding's column routing (src/model/sort/widedeep/model.py:53-69):
         column 0 of every wide feature goes to the wide tensor [B, n_wide], columns 1.. to the deep concat.  Wide features = the
         10 smallest tables (as in tests/test_full_size_baseline_shapes.py)."""
@@ -394,8 +404,9 @@ class SingleGpuPath:
             slots.append(ops.Slot(f["name"], NRX_SPARSE, self.plan.slots[i].table, f["dim"], 0, col, wide_col=w))
             col += f["dim"] - 1 if w >= 0 else f["dim"]
         plan = ops.EmbedPlan(slots, out_width=col, wide_width=len(wide_of))
-        out = torch.empty((BATCH, col), dtype=torch.float32, device=self.device)
-        return [ops.PreparedEmbed(plan, self.tables, ins, ws, out=out) for ins, ws in self.pool]
+        ld = (col + 31) // 32 * 32                  # 1270 -> 1280: rows start on a 128-byte line (WideDeep.get_inp_embedding pads the same way)
+        out = torch.empty((BATCH, ld), dtype=torch.float32, device=self.device)
+        return [ops.PreparedEmbed(plan, self.tables, ins, ws, out_ld=ld, out=out, check_index=check_index) for ins, ws in self.pool]
 
     def train_pass(self):
         """Forward (training form) + row-sparse backward of the gather path, bound once: (forward calls, backward calls).
@@ -882,12 +893,16 @@ def main():
                                 "stays in the 256 MiB Infinity Cache)"}
             del dcalls
         if args.workload == "c5":
-            wcalls = path.wide_split_calls()
+            if getattr(path, "plain_calls", None) is not None:     # headline = the split; this leg = the plain concat of the same tables
+                wcalls, key_note = path.plain_calls, ("plain_concat", "the same tables and ids WITHOUT the Wide&Deep column routing: one [B, 1280] concat "
+                                                      "(the headline of rounds 1-3)")
+            else:
+                wcalls, key_note = path.wide_split_calls(), ("wide_split", "the same tables and ids through WideDeep.get_inp_embedding's column routing "
+                                                             "(widedeep/model.py:53-69): column 0 of the 10 smallest tables -> wide tensor [B, 10], the rest -> "
+                                                             "deep concat [B, 1270], row stride 1280")
             ms = time_calls(lambda i: wcalls[i % len(wcalls)].run(), steps2)
             ach = bytes_per_impr * BATCH / (ms * 1e-3) / 1e9
-            wide_split = {"kernel_ms_mean": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBPS, "unit": "GB/s",
-                          "note": "the same tables and ids through WideDeep.get_inp_embedding's column routing (widedeep/model.py:53-69): "
-                                  "column 0 of the 10 smallest tables -> wide tensor [B, 10], the rest -> deep concat [B, 1270]"}
+            wide_split = {"leg": key_note[0], "kernel_ms_mean": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBPS, "unit": "GB/s", "note": key_note[1]}
             del wcalls
         if not path.cross:
             fwd, bwd = path.train_pass()
@@ -959,7 +974,12 @@ def main():
     def _build_line():
         total_impr = BATCH * world * args.steps
         ms_per_step = dt * 1e3 / args.steps
-        achieved = bytes_per_impr * BATCH / (kern_ms * 1e-3) / 1e9
+        # a workload with the fused cross (c3): SURVEY 8d prices the launch by the gather alone (2 600 B per impression, "cross adds nothing
+        # if fused") -- that is `frac`; the launch also WRITES the cross half of cat[x, cross] (4 x width B per impression), which
+        # `frac_with_cross_write` counts as well (the definition this line used up to round 3)
+        survey_bytes = getattr(path, "survey_bytes_per_impr", bytes_per_impr)
+        achieved = survey_bytes * BATCH / (kern_ms * 1e-3) / 1e9
+        achieved_cw = bytes_per_impr * BATCH / (kern_ms * 1e-3) / 1e9
         traffic = _traffic(args.workload) if (world == 1 and args.ids == "uniform") else None
         granule = getattr(path, "granule_bytes_per_impr", None)
         out = {
@@ -976,14 +996,17 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": desc, "batch_per_gpu": BATCH, "parallelism": parallelism,
-                       "algorithmic_bytes_per_impression": bytes_per_impr,
+                       "algorithmic_bytes_per_impression": survey_bytes,
+                       **({"algorithmic_bytes_per_impression_with_cross_write": bytes_per_impr} if survey_bytes != bytes_per_impr else {}),
                        "algorithmic_bytes_definition": getattr(path, "bytes_note", "SURVEY 8d"), "id_pool": 8,
                        "output_buffer": "recycled each step (as the caching allocator does); `distinct_output_buffers` has the other mode",
                        "index_check": "on (device status word, read once after the timed region)"},
             "step_us": spread,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "kernel_ms_mean": kern_ms, "algorithmic_bytes_per_launch": bytes_per_impr * BATCH,
+                         **({"frac_with_cross_write": achieved_cw / HBM_PEAK_GBPS, "achieved_with_cross_write": achieved_cw}
+                            if survey_bytes != bytes_per_impr else {}),
+                         "kernel_ms_mean": kern_ms, "algorithmic_bytes_per_launch": survey_bytes * BATCH,
                          "granule_bytes_per_launch": None if granule is None else granule * BATCH,
                          "stream_copy_GBps": stream_copy,
                          "traffic_GBps": None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9,
@@ -999,7 +1022,7 @@ def main():
         if distinct is not None:
             out["distinct_output_buffers"] = distinct
         if wide_split is not None:
-            out["wide_split"] = wide_split
+            out[wide_split["leg"]] = wide_split
         if fwd_bwd is not None:
             out["fwd_bwd"] = fwd_bwd
         if module_path is not None:
@@ -1034,7 +1057,7 @@ def main():
             out["secondary_note"] = note or secondary_note
         line = json.dumps(out)
         print(line, flush=True)
-        if os.environ.get("NRX_BENCH_OUT"):
+        if os.environ.get("NRX_BENCH_OUT") and os.environ.get("NRX_BENCH_CHILD") != "1":      # under the self-launcher only its merged line is filed
             with open(os.environ["NRX_BENCH_OUT"], "a") as f:
                 f.write(line + "\n")
 

@@ -704,7 +704,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_dcn_v1_group_kernel(const Emb
 // tile i + 1 are requested before tile i's rows are waited for, so a wavefront spends ONE exposed round trip per tile (its rows) instead of
 // three, and the output -- written once, never re-read by this launch -- leaves with non-temporal stores (STNT).  Same arithmetic in the
 // same order as the kernel above: bit-identical results (tests/test_hip_parity.py::test_fused_gather_cross_*).
-template <int QLOG2, int N, bool IDX64, bool NT, bool STNT>
+template <int QLOG2, int N, bool IDX64, bool NT, bool STNT, bool EARLY = false>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_dcn_v1_group_persist_kernel(const EmbedDcnArgs args_in_kernarg) {
     const NRX_CONST EmbedDcnArgs* a = nrx_kernarg<EmbedDcnArgs>();
     constexpr int Q = 1 << QLOG2;
@@ -742,7 +742,17 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_dcn_v1_group_persist_kernel(c
             x0[u] = NT ? nrx_ldg4_nt(a->table[u], (bad ? 0 : id[u]) * Q + q) : nrx_ldg4(a->table[u], (bad ? 0 : id[u]) * Q + q);
         }
         if (bad_feat >= 0 && q == 0 && live) nrx_report_oob(a->status, bad_feat, b, bad_id);
-        load_ids(b + stride, id);                             // next tile's ids: requested under this tile's rows
+        if (b - (threadIdx.x >> QLOG2) + stride < batch) load_ids(b + stride, id);       // next tile's ids: requested under this tile's rows
+        if (EARLY && live) {                                  // x leaves as soon as it has arrived, under the cross arithmetic
+            NRX_GLOBAL nrx_f32x4* o = (NRX_GLOBAL nrx_f32x4*)(a->out + b * a->out_ld);
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                nrx_f32x4 t;
+                t.x = x0[u].x; t.y = x0[u].y; t.z = x0[u].z; t.w = x0[u].w;
+                if (STNT) __builtin_nontemporal_store(t, o + u * Q + q);
+                else o[u * Q + q] = t;
+            }
+        }
         float4 xl[N];
 #pragma unroll
         for (int u = 0; u < N; ++u) xl[u] = x0[u];
@@ -768,7 +778,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_dcn_v1_group_persist_kernel(c
         if (live) {
             NRX_GLOBAL nrx_f32x4* o = (NRX_GLOBAL nrx_f32x4*)(a->out + b * a->out_ld);
 #pragma unroll
-            for (int u = 0; u < 2 * N; ++u) {
+            for (int u = EARLY ? N : 0; u < 2 * N; ++u) {
                 const float4 v = u < N ? x0[u] : xl[u - N];
                 nrx_f32x4 t;
                 t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
@@ -1086,11 +1096,15 @@ extern "C" int nrx_embed_dcn_v1_fwd(const nrx_feature_t* feats, int32_t n_feats,
             // NRX_EDCN_VARIANT (measurement knob): 0 = one tile per block (round 1-3), 1 = persistent blocks, 2 = + non-temporal stores (default);
             // NRX_EDCN_BPC = resident blocks per CU of the persistent forms
             static const int variant = getenv("NRX_EDCN_VARIANT") ? atoi(getenv("NRX_EDCN_VARIANT")) : 2;
-            static const int bpc = getenv("NRX_EDCN_BPC") ? atoi(getenv("NRX_EDCN_BPC")) : 5;
+            static const int bpc = getenv("NRX_EDCN_BPC") ? atoi(getenv("NRX_EDCN_BPC")) : 16;
             const unsigned pg = ggrid.x < (unsigned)(256 * bpc) ? ggrid.x : (unsigned)(256 * bpc);
             const dim3 pgrid(pg);
 #define NRX_EG3(QL_, N_, I_) do { \
-        if (variant >= 2 && nt) hipLaunchKernelGGL((embed_dcn_v1_group_persist_kernel<QL_, N_, I_, true, true>), pgrid, dim3(NRX_BLOCK), smem, st, a); \
+        if (variant == 4 && nt) hipLaunchKernelGGL((embed_dcn_v1_group_persist_kernel<QL_, N_, I_, true, true, true>), pgrid, dim3(NRX_BLOCK), smem, st, a); \
+        else if (variant == 4) hipLaunchKernelGGL((embed_dcn_v1_group_persist_kernel<QL_, N_, I_, false, true, true>), pgrid, dim3(NRX_BLOCK), smem, st, a); \
+        else if (variant == 5 && nt) hipLaunchKernelGGL((embed_dcn_v1_group_persist_kernel<QL_, N_, I_, true, false, true>), pgrid, dim3(NRX_BLOCK), smem, st, a); \
+        else if (variant == 5) hipLaunchKernelGGL((embed_dcn_v1_group_persist_kernel<QL_, N_, I_, false, false, true>), pgrid, dim3(NRX_BLOCK), smem, st, a); \
+        else if (variant >= 2 && nt) hipLaunchKernelGGL((embed_dcn_v1_group_persist_kernel<QL_, N_, I_, true, true>), pgrid, dim3(NRX_BLOCK), smem, st, a); \
         else if (variant >= 2) hipLaunchKernelGGL((embed_dcn_v1_group_persist_kernel<QL_, N_, I_, false, true>), pgrid, dim3(NRX_BLOCK), smem, st, a); \
         else if (variant == 1 && nt) hipLaunchKernelGGL((embed_dcn_v1_group_persist_kernel<QL_, N_, I_, true, false>), pgrid, dim3(NRX_BLOCK), smem, st, a); \
         else if (variant == 1) hipLaunchKernelGGL((embed_dcn_v1_group_persist_kernel<QL_, N_, I_, false, false>), pgrid, dim3(NRX_BLOCK), smem, st, a); \

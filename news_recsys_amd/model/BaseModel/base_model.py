@@ -261,8 +261,15 @@ class BaseModel(LightningModule):
             if self._sparse_sink is None:
                 self._sparse_sink = ops.SparseGradSink()
             sg = self._sparse_sink if torch.is_grad_enabled() else False
+        narrow = False
+        if out_ld is not None and out_ld < 0:          # -k: pad the row stride to a multiple of k floats, hand back the [B, width] view
+            k = -int(out_ld)
+            out_ld = (plan.out_width + k - 1) // k * k
+            narrow = out_ld != plan.out_width
+            if not narrow:
+                out_ld = None
         out, wide, fmv = ops.embed_apply(plan, tables, inputs, weights, out_ld=out_ld, need_out=need_out, sparse_grad=sg,
-                                         index_check=self.index_check)
+                                         index_check=self.index_check, narrow=narrow)
         return out, wide, fmv, list(dims), list(present)
 
     def _no_weights(self, n: int):

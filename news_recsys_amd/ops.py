@@ -369,6 +369,8 @@ def _dense_sorted_ok(plan, tables, sparse_grad, B, csr_ok=False) -> bool:
     (profiles/r03_dense_backward.txt).  DENSE_BWD_SORTED: True = always (deterministic gradients at any size), False = never."""
     if sparse_grad or DENSE_BWD_SORTED is False or B <= 0 or not tables or not tables[0].is_cuda or torch.cuda.is_current_stream_capturing():
         return False
+    if len(tables) > NRX_MAX_FEATURES:          # the dense destination names a table by its slot in a <= 64-entry argument array
+        return False
     lookups = 0
     for s in plan.slots:
         if s.kind == NRX_DENSE:
@@ -392,9 +394,14 @@ class _EmbedFn(torch.autograd.Function):
                                       "a feature flagged NRX_FEAT_ROW0_IS_DATA (routed-row buffers) needs the dense-gradient mode")
         if sparse_grad and any(s.flags & NRX_FEAT_BAG_CSR for s in plan.slots):
             plan, inputs, weights = _csr_plan_to_padded(plan, inputs, weights)      # the planner sorts padded [B, L] lookups
+        narrow = bool(out_ld) and int(out_ld) < 0          # embed_apply(narrow=True): a padded row stride, the caller gets the [B, out_width] view
+        out_ld = abs(int(out_ld)) if out_ld else None
+        ctx.narrow = narrow
         ld = int(out_ld) if out_ld else plan.out_width
         if ld < plan.out_width:
             raise ValueError("out_ld smaller than the plan's out_width")
+        if narrow and plan.use_fm:
+            raise ValueError("narrow=True is for plans without the FM epilogue (its backward reads the forward concat at the forward's stride)")
         n_slots = len(plan.slots)
         bp = _bound_plan(plan) if tables and tables[0].is_cuda else None
         done = None
@@ -482,14 +489,15 @@ class _EmbedFn(torch.autograd.Function):
         ctx.plans = None
         # default (dense-gradient) mode: the table grads are formed by the sorted reduction + nrx_rows_to_dense unless
         # NRX_DENSE_BWD=atomic, the launch is being captured (the planner allocates) or a feature reads a routed-row buffer
-        ctx.dense_sorted = _dense_sorted_ok(plan, tables, ctx.sparse_grad, B, csr_ok=True) and any(t.requires_grad for t in tables)
+        # (needs_input_grad follows the grad MODE too: a forward under torch.no_grad() -- leaf tables still say requires_grad -- plans nothing)
+        wants_grad = any(ctx.needs_input_grad[7:])
+        ctx.dense_sorted = wants_grad and _dense_sorted_ok(plan, tables, ctx.sparse_grad, B, csr_ok=True)
         if ctx.dense_sorted and any(s.flags & NRX_FEAT_BAG_CSR for s in plan.slots):
             # the forward ran on the CSR form; the backward's planner sorts padded [B, L] lookups (nrx_csr_to_padded: one small launch
             # per bag feature) -- from here on the node only describes the backward
             plan, ins, ws = _csr_plan_to_padded(plan, ins, ws)
             ctx.plan, ctx.ins, ctx.ws = plan, ins, ws
-        if (ctx.sparse_grad or ctx.dense_sorted) and PLAN_AHEAD and B > 0 and not torch.cuda.is_current_stream_capturing() and \
-                any(t.requires_grad for t in tables):
+        if (ctx.sparse_grad or ctx.dense_sorted) and PLAN_AHEAD and B > 0 and not torch.cuda.is_current_stream_capturing() and wants_grad:
             ctx.plans = {}
             for g_ in _sparse_group_cache(plan, tables):
                 fs_ = g_["fs"]
@@ -504,6 +512,8 @@ class _EmbedFn(torch.autograd.Function):
         if ctx.has_fm_feat:
             ctx.save_for_backward(out)
         ctx.set_materialize_grads(False)
+        if getattr(ctx, "narrow", False) and out is not None and not scratch_out:
+            out = out.narrow(1, 0, plan.out_width)      # the node's output IS the view: its gradient arrives as [B, out_width]
         return (None if scratch_out else out), wide, fm
 
     @staticmethod
@@ -517,6 +527,8 @@ class _EmbedFn(torch.autograd.Function):
         stream = _raw_stream(dev)
         if g_out is not None:
             g_out = _f32c(g_out, "grad of the concat")
+            if getattr(ctx, "narrow", False):
+                ld = ctx.ld = g_out.shape[1]            # the upstream gradient of the narrowed output is [B, out_width], contiguous
         fmg = None
         if g_fm is not None:
             fm_feat = ctx.saved_tensors[0] if getattr(ctx, "has_fm_feat", False) else None
@@ -979,7 +991,7 @@ class _FastForward:
 
 def embed_apply(plan: EmbedPlan, tables: Sequence[torch.Tensor], inputs: Sequence[torch.Tensor],
                 weights: Sequence[Optional[torch.Tensor]], out_ld: Optional[int] = None, need_out: bool = True,
-                sparse_grad=False, index_check: Optional[str] = None):
+                sparse_grad=False, index_check: Optional[str] = None, narrow: bool = False):
     """Run the fused gather(+pool)->concat.  index_check: None = the module-wide mode (set_index_check; default 'sync' =
     IndexError in the offending call, like torch on CPU), or 'deferred' / 'sync' / 'off' for this call.  Returns (out[B, out_ld or out_width] | None,
     wide[B, wide_width] | None, fm[B] | None).  Differentiable w.r.t. `tables`: dense grads by default
@@ -995,8 +1007,13 @@ def embed_apply(plan: EmbedPlan, tables: Sequence[torch.Tensor], inputs: Sequenc
             fast = plan.__dict__["_fast"] = _FastForward(plan)
         res = fast(tables, inputs, weights, out_ld, need_out, index_check or _INDEX_CHECK)
         if res is not None:
+            if narrow and res[0] is not None and res[0].shape[1] != plan.out_width:
+                return res[0].narrow(1, 0, plan.out_width), res[1], res[2]
             return res
-    return _EmbedFn.apply(plan, list(inputs), list(weights), out_ld, need_out, sparse_grad, index_check, *tables)
+    # narrow (with out_ld > out_width: a row stride padded for the kernels' sake, e.g. to a multiple of 4 floats so that the Wide&Deep split
+    # can store aligned 16-byte chunks): `out` comes back as the [B, out_width] view of the [B, out_ld] buffer
+    return _EmbedFn.apply(plan, list(inputs), list(weights), -int(out_ld) if (narrow and out_ld) else out_ld, need_out, sparse_grad,
+                          index_check, *tables)
 
 
 class PreparedEmbed:

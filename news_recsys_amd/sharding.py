@@ -802,6 +802,8 @@ def shard_model_(model, rank: int, world: int, group=None, backend=None):
         plan, table_names, dims, present = model._plan(batch, feature_names, fm, wide_names)
         if not present:
             return None, None, None, [], []
+        if out_ld is not None and out_ld < 0:       # "pad the row stride" request of the single-GPU path (BaseModel._embed): not used here
+            out_ld = None
         feats = []
         for s in plan.slots:
             tname = '' if s.kind == NRX_DENSE else table_names[s.table]
