@@ -584,7 +584,35 @@ def module_path_leg(path: "SingleGpuPath", prepared_fb_ms, steps: int):
         fbk_ms, fbkh_ms = timed(fwd_bwd_hook, min(steps, 100))
         with torch.autograd.set_multithreading_enabled(False):      # backward nodes run on the calling thread: no hand-off to the engine's device thread
             fb1_ms, fb1h_ms = timed(fwd_bwd, min(steps, 100))
+        # the same step replayed from a HIP graph (news_recsys_amd.graph.GraphedStep: index check still ON -- deferred status word inside
+        # the graph, IndexError at the next call --, plan made inline in the captured backward, count read on the device)
+        graphed = None
+        try:
+            from news_recsys_amd.graph import GraphedStep
+
+            def gstep(bt):
+                p = model(bt)
+                p.sum().backward()
+                if model._sparse_sink is not None:
+                    model._sparse_sink.clear()
+                return p
+
+            gs = GraphedStep(gstep, batches[0], warmup=3)
+
+            def graphed_call():
+                it["i"] += 1
+                gs(batches[it["i"] & 1])
+
+            gr_ms, grh_ms = timed(graphed_call, min(steps, 100))
+            rp_ms, rph_ms = timed(gs.graph.replay, min(steps, 100))
+            gs.check()
+            graphed = {"forward_backward_graphed_us": gr_ms * 1e3, "forward_backward_graphed_host_us_per_step": grh_ms * 1e3,
+                       "replay_only_us": rp_ms * 1e3, "replay_only_host_us_per_step": rph_ms * 1e3}
+            del gs
+        except Exception as e:       # noqa: BLE001 -- a secondary figure must not cost the line
+            graphed = {"error": f"{type(e).__name__}: {e}"[:300]}
         out[f"B{B}"] = {"get_embeddings_from_batch_us": g_ms * 1e3, "get_embeddings_from_batch_host_us_per_call": h_ms * 1e3,
+                        "graphed": graphed,
                         "forward_backward_autograd_us": fb_ms * 1e3, "forward_backward_host_us_per_step": fbh_ms * 1e3,
                         "forward_backward_lightning_hook_us": fbk_ms * 1e3, "forward_backward_lightning_hook_host_us_per_step": fbkh_ms * 1e3,
                         "forward_backward_autograd_us_engine_thread_off": fb1_ms * 1e3,
@@ -601,7 +629,9 @@ def module_path_leg(path: "SingleGpuPath", prepared_fb_ms, steps: int):
                    "through the model's LightningModule.backward hook (what a Lightning trainer calls; it runs the nodes on the calling thread); "
                    "*_engine_thread_off = the plain step under "
                    "torch.autograd.set_multithreading_enabled(False): PyTorch's backward otherwise hands every step to its device thread, ~140 us "
-                   "of wake-up and GIL hand-over per step on this host (tools/host_profile_module_step.py)")
+                   "of wake-up and GIL hand-over per step on this host (tools/host_profile_module_step.py); graphed = the same forward + backward "
+                   "captured once in a HIP graph (GraphedStep) and replayed: forward_backward_graphed_us includes the copy of the batch's 26 id tensors into "
+                   "the graph's static inputs, replay_only_us is the graph alone; the out-of-range-id check stays on inside the graph (deferred)")
     ops.flush_index_checks()
     del model
     return out

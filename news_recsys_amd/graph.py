@@ -8,11 +8,16 @@ loss, backward including the HIP scatter, optimizer -- can be captured once in a
 hipGraph) and replayed: 367 us per step at B = 1024, same losses, parameters equal to eager within float-atomic
 reordering (tools/bench_train_step.py, tests/test_graph_capture_gpu.py).
 
-Constraints while capturing (checked / arranged by `GraphedStep`): the out-of-range-id check must not read
-back (`ops.set_index_check("off")` for the duration of the capture and of every replay's semantics: ids are
-not validated inside a replay), dense table gradients only (`embeddings.sparse_grad` needs a host read per
-step), optimizers constructed with `capturable=True`, and batches of ONE fixed shape (inputs are copied into
-static tensors before each replay)."""
+Constraints while capturing (checked / arranged by `GraphedStep`): optimizers constructed with `capturable=True`, batches of ONE fixed
+shape (inputs are copied into static tensors before each replay), and `embeddings.sparse_grad: true` (COO gradients) is out: it reads the
+unique-row count back every step (`fused` and the default dense-gradient mode do not).
+
+The reference's error contract survives the capture (round 4): torch on CPU raises IndexError for an out-of-range id
+(src/model/BaseModel/base_model.py:271), and so does a replay -- one call late.  The step is captured in the DEFERRED check mode: every
+gather kernel records an offending id in a host-mapped status word (no read-back, nothing for the graph to replay but the kernel itself); the
+next `__call__`, `check()` or `ops.flush_index_checks()` reads that word on the host and raises IndexError naming the feature.  With
+`deterministic=True` the dense table gradients come from the sorted reduction at ANY batch size (planned inline, count read on the device):
+replays are bit-reproducible run to run, where the float-atomic scatter of small batches is not."""
 from __future__ import annotations
 
 from typing import Callable, Dict
@@ -28,11 +33,13 @@ class GraphedStep:
     returns the (static) result tensor -- valid until the next call."""
 
     def __init__(self, step_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor], example_batch: Dict[str, torch.Tensor],
-                 warmup: int = 3):
+                 warmup: int = 3, deterministic: bool = False):
         self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
-        prev = ops._INDEX_CHECK
+        prev, prev_sorted = ops._INDEX_CHECK, ops.DENSE_BWD_SORTED
         ops.flush_index_checks()
-        ops.set_index_check("off")
+        ops.set_index_check("deferred")            # the check stays ON inside the graph: a status word the kernels write, read on the host later
+        if deterministic:
+            ops.DENSE_BWD_SORTED = True            # the choice is baked into the captured launches
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -40,18 +47,38 @@ class GraphedStep:
                 for _ in range(max(1, warmup)):
                     step_fn(self._static)
             torch.cuda.current_stream().wait_stream(side)
+            ops.flush_index_checks()               # (the example batch must be clean)
+            del ops._host_status_names[:]
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self._result = step_fn(self._static)
+            self._names = list(ops._host_status_names)      # the feature-name lists of the captured gather launches
         finally:
             ops.set_index_check(prev)
+            ops.DENSE_BWD_SORTED = prev_sorted
+
+    def check(self) -> None:
+        """Raise IndexError if a replay so far met an out-of-range id (synchronises the device)."""
+        ops._remember_status_names(self._names)
+        ops.flush_index_checks()
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        dsts, srcs = [], []
         for k, dst in self._static.items():
             if torch.is_tensor(dst):
                 src = batch[k]
                 if src.shape != dst.shape or src.dtype != dst.dtype:
                     raise ValueError(f"GraphedStep: '{k}' is {tuple(src.shape)} {src.dtype}, captured {tuple(dst.shape)} {dst.dtype}")
-                dst.copy_(src, non_blocking=True)
+                if src.device != dst.device:
+                    dst.copy_(src, non_blocking=True)          # host batches: one H2D copy each
+                else:
+                    dsts.append(dst)
+                    srcs.append(src)
+        if dsts:
+            torch._foreach_copy_(dsts, srcs)                   # device batches: ONE multi-tensor launch per dtype, not one copy per feature
+                                                               # (26 copy_ calls were 135 us of host time per step at the C2 feature set)
+        if ops.deferred_index_error_pending():     # recorded by an earlier replay (or launch): raise now, like the reference would have then
+            self.check()
         self.graph.replay()
+        ops._remember_status_names(self._names)
         return self._result

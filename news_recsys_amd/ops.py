@@ -96,6 +96,22 @@ def _raise_if_oob(status: torch.Tensor, names: Sequence[str]) -> None:
                          f"sample {st[2]}, id {st[3]}")
 
 
+def _remember_status_names(name_lists) -> None:
+    """Re-register the feature-name lists of launches that will write the deferred status word without passing through _deferred_status
+    (the kernels of a replayed HIP graph: graph.GraphedStep) -- so that a late IndexError can name the feature."""
+    for names in name_lists:
+        if not any(n is names for n in _host_status_names):
+            if len(_host_status_names) >= 16:
+                del _host_status_names[0]
+            _host_status_names.append(names)
+
+
+def deferred_index_error_pending() -> bool:
+    """True when a launch has recorded an out-of-range id in the deferred status word since it was last cleared (a host read, no sync: the word
+    may lag the device by the launches still in flight)."""
+    return _host_status is not None and bool(_host_status[0] != 0)
+
+
 def flush_index_checks() -> None:
     """Raise IndexError for any out-of-range id seen by earlier 'lazy' / 'deferred' calls (synchronises the device)."""
     if _host_status is not None:
@@ -367,8 +383,10 @@ def _dense_sorted_ok(plan, tables, sparse_grad, B, csr_ok=False) -> bool:
     ~25 launches (~0.2 ms of host and launch time per step), the atomic scatter ~0.2 us per 1000 lookups: from DENSE_SORTED_MIN lookups
     per launch on (1 Mi: C2 / C4 at the bench batch) the sorted path is the faster one, below it the single atomic launch is
     (profiles/r03_dense_backward.txt).  DENSE_BWD_SORTED: True = always (deterministic gradients at any size), False = never."""
-    if sparse_grad or DENSE_BWD_SORTED is False or B <= 0 or not tables or not tables[0].is_cuda or torch.cuda.is_current_stream_capturing():
+    if sparse_grad or DENSE_BWD_SORTED is False or B <= 0 or not tables or not tables[0].is_cuda:
         return False
+    # (while a HIP graph is being captured the plan is made inline in the backward -- no side stream, no events to query -- and the reduction
+    # reads the unique-row count on the device: nothing in the sorted path reads back, so it captures like the atomic launch does)
     if len(tables) > NRX_MAX_FEATURES:          # the dense destination names a table by its slot in a <= 64-entry argument array
         return False
     lookups = 0

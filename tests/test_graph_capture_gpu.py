@@ -130,3 +130,99 @@ def test_graphed_fused_sparse_training_step_matches_eager():
         ops.set_index_check(mode_before)
     for p, q in zip(m_e.parameters(), m_g.parameters()):
         torch.testing.assert_close(p, q, rtol=1e-4, atol=2e-5)
+
+
+def test_out_of_range_id_inside_a_replay_raises_indexerror_naming_the_feature():
+    """The reference raises IndexError for an out-of-range id (torch on CPU, src/model/BaseModel/base_model.py:271).  A captured step keeps that
+    contract one call late: the gather kernels of the graph record the offence in the host-mapped status word, the next replay (or check())
+    raises IndexError with the feature's name; clean replays before and after are unaffected."""
+    from news_recsys_amd import ops
+    from news_recsys_amd.graph import GraphedStep
+    from news_recsys_amd.model.sort.deep.model import Deep
+    cfg = os.path.join(CONFIGS, "cf_array_small.yaml")
+    torch.manual_seed(11)
+    m = Deep(cfg).to(DEV)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    batches = [_batch(m, 128, gen) for _ in range(4)]
+
+    def step(b):
+        opt.zero_grad(set_to_none=False)
+        loss = F.binary_cross_entropy(m(b).view(-1), b["label"][:, 0])
+        loss.backward()
+        opt.step()
+        return loss
+
+    gs = GraphedStep(step, batches[0], warmup=2)
+    gs(batches[1])
+    gs.check()                                                  # clean so far
+    victim = sorted(m.sparse_feature_names)[0]
+    bad = dict(batches[2])
+    bad[victim] = bad[victim].clone()
+    bad[victim][5] = 10 ** 7
+    gs(bad)                                                     # the replay itself does not raise (nothing is read back) ...
+    with pytest.raises(IndexError, match=victim):
+        gs(batches[3])                                          # ... the next call does, naming the feature
+    gs(batches[3])                                              # the word was cleared by the raise: clean batches replay again
+    gs.check()
+    bad2 = dict(batches[1])
+    arr = sorted(m.array_feature_names)[0]
+    bad2[arr] = bad2[arr].clone()
+    bad2[arr][3, 2] = -4
+    bad2[arr + "_mask"] = bad2[arr + "_mask"].clone()
+    bad2[arr + "_mask"][3, 2] = 1.0
+    gs(bad2)
+    with pytest.raises(IndexError, match=arr):
+        gs.check()
+
+
+def test_deterministic_graphed_step_has_bit_reproducible_table_gradients():
+    """GraphedStep(deterministic=True): the dense table gradients of the captured step come from the sorted reduction at any batch size (planned
+    inside the graph, count read on the device) -- two replays from the same state give the same bits, and they equal the eager sorted path;
+    the default capture (float-atomic scatter at this batch size) only agrees within the order noise."""
+    from news_recsys_amd import ops
+    from news_recsys_amd.graph import GraphedStep
+    from news_recsys_amd.model.sort.deep.model import Deep
+    cfg = os.path.join(CONFIGS, "cf_array_small.yaml")
+    torch.manual_seed(13)
+    m = Deep(cfg).to(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    batches = [_batch(m, 512, gen) for _ in range(3)]
+    for b in batches:                                           # duplicates: rows that several samples hit, in every table
+        for n in m.sparse_feature_names:
+            b[n][::3] = b[n][0]
+    tabs = [e.weight for e in m.embedding_tables.values()]
+
+    def step(b):
+        for p in m.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        loss = F.binary_cross_entropy(m(b).view(-1), b["label"][:, 0])
+        loss.backward()
+        return loss
+
+    gs = GraphedStep(step, batches[0], warmup=2, deterministic=True)
+    runs = []
+    for _ in range(3):
+        gs(batches[1])
+        torch.cuda.synchronize()
+        runs.append([t.grad.clone() for t in tabs])
+    for g0, g1, g2 in zip(*runs):
+        assert torch.equal(g0.view(torch.int32), g1.view(torch.int32)) and torch.equal(g0.view(torch.int32), g2.view(torch.int32))
+    prev = ops.DENSE_BWD_SORTED
+    ops.DENSE_BWD_SORTED = True
+    try:
+        step(batches[1])                                        # eager, sorted path
+        torch.cuda.synchronize()
+        for g0, t in zip(runs[0], tabs):
+            assert torch.equal(g0.view(torch.int32), t.grad.view(torch.int32))
+    finally:
+        ops.DENSE_BWD_SORTED = prev
+    ops.DENSE_BWD_SORTED = False
+    try:
+        step(batches[1])                                        # eager, float atomics: same gradient up to the order of the additions
+        torch.cuda.synchronize()
+        for g0, t in zip(runs[0], tabs):
+            torch.testing.assert_close(g0, t.grad, rtol=1e-4, atol=1e-5)
+    finally:
+        ops.DENSE_BWD_SORTED = prev
