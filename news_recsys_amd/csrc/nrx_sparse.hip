@@ -731,6 +731,61 @@ int bits_for(int64_t v) {      // bits needed to represent values 0 .. v-1 (at l
     return b;
 }
 
+// Stable LSD sort of n (key, payload) pairs on the low `bits` bits of the keys, from the planner's tile kernels: the whole array is ONE
+// segment, digits of up to SEG_MAX_DB bits split evenly over the passes, per pass a histogram launch, the chunk scan (more than 32 tiles)
+// and the ranking scatter.  Keys and payloads travel as separate arrays (the consumers -- nrx_route_ids_dedup, nrx_unique_inverse -- read
+// them that way).  Returns through src / psrc the buffers that hold the sorted result (the in / out pair ping-pongs once per pass).
+// `scratch`: seg_scratch_bytes(n) bytes.  Same permutation as rocprim::radix_sort_pairs on the same bits (every step is order-preserving).
+template <typename KeyT>
+void seg_sort_generic(KeyT*& src, KeyT*& dst, uint32_t*& psrc, uint32_t*& pdst, int64_t n, int bits, void* scratch, hipStream_t st) {
+    SegArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    const int passes = (bits + SEG_MAX_DB - 1) / SEG_MAX_DB;
+    const int db = (bits + passes - 1) / passes;
+    const int tiles = (int)((n + SEG_TILE - 1) / SEG_TILE), chunks = (tiles + SEG_CHUNK - 1) / SEG_CHUNK;
+    sa.seg_off[0] = 0; sa.seg_off[1] = n;
+    sa.seg_tile[0] = 0; sa.seg_tile[1] = tiles;
+    sa.seg_chunk[0] = 0; sa.seg_chunk[1] = chunks;
+    sa.seg_db_w[0] = (uint32_t)db;
+    sa.qoff[0] = 0; sa.qoff[1] = n;
+    sa.n_slots = 1; sa.n_seg = 1; sa.idx64 = 0; sa.row_bits = bits; sa.nb = 1 << db;
+    { const char* e = getenv("NRX_SEG_XCD"); sa.xcd = e ? atoi(e) : 1; }
+    const int nb = sa.nb;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(scratch);
+    uint32_t* ctot = hist + (size_t)tiles * nb;
+    uint32_t* bin_base = ctot + (size_t)chunks * nb;
+    const size_t lds_hist = (size_t)nb * 4;
+    const size_t lds_scatter = (size_t)nb * (2 * (SEG_THREADS / 64) + 8) + (size_t)SEG_TILE * (4 + sizeof(KeyT));
+    static const bool lds_ok = [] {
+        const int bytes = (1 << SEG_MAX_DB) * (2 * (SEG_THREADS / 64) + 8) + SEG_TILE * (4 + (int)sizeof(KeyT));
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(seg_scatter_kernel<KeyT, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+    }();
+    (void)lds_ok;
+    const dim3 gchunks((unsigned)((nb + NRX_BLOCK - 1) / NRX_BLOCK), (unsigned)chunks);
+    for (int pass = 0; pass < passes; ++pass) {
+        hipLaunchKernelGGL((seg_hist_kernel<KeyT, false>), dim3((unsigned)tiles), dim3(SEG_THREADS), lds_hist, st, sa, (const KeyT*)src, pass, hist);
+        const char* se = getenv("NRX_PLAN_SORT");
+        const bool force_bins = se && !strcmp(se, "segmented-bins");      // tests: the seg_scan_bins path of very long arrays
+        if (tiles <= SEG_CHUNK) {
+            hipLaunchKernelGGL((seg_scatter_kernel<KeyT, 1, false>), dim3((unsigned)tiles), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src,
+                               (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst);
+        } else if (chunks <= SEG_DIRECT_CHUNKS && !force_bins) {
+            hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot);
+            hipLaunchKernelGGL((seg_scatter_kernel<KeyT, 2, false>), dim3((unsigned)tiles), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src,
+                               (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst);
+        } else {
+            hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot);
+            hipLaunchKernelGGL(seg_scan_bins, dim3(1), dim3(NRX_BLOCK), 0, st, sa, hist, ctot, bin_base);
+            hipLaunchKernelGGL((seg_scatter_kernel<KeyT, 0, false>), dim3((unsigned)tiles), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src,
+                               (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst);
+        }
+        KeyT* tk = src; src = dst; dst = tk;
+        uint32_t* tp = psrc; psrc = pdst; pdst = tp;
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t nrx_sparse_plan_workspace(int64_t n_lookups) {
@@ -1005,7 +1060,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void dedup_keys_kernel(const DedupArgs a
 template <typename KeyT>
 __global__ __launch_bounds__(NRX_BLOCK) void dedup_rank_kernel(const KeyT* __restrict__ skeys, const uint32_t* __restrict__ block_heads, int64_t n,
                                                                int owner_shift, int world, uint32_t* __restrict__ urank,
-                                                               uint32_t* __restrict__ owner_base /* [world + 1] */) {
+                                                               uint32_t* __restrict__ owner_base /* [world + 1] */,
+                                                               int grp_shift = 0, int n_groups = 0, uint32_t* __restrict__ grp_base = nullptr
+                                                               /* [n_groups + 1]: first unique entry of every (owner, table) group */) {
     constexpr int ROUNDS = PLAN_TILE / NRX_BLOCK, WAVES = NRX_BLOCK / 64;
     __shared__ uint32_t s_cell[ROUNDS * WAVES + 1];
     __shared__ uint32_t s_part[WAVES];
@@ -1056,10 +1113,19 @@ __global__ __launch_bounds__(NRX_BLOCK) void dedup_rank_kernel(const KeyT* __res
             const int64_t o = (int64_t)((uint64_t)key[j] >> owner_shift);
             const int64_t oprev = e == 0 ? -1 : (int64_t)((uint64_t)prev[j] >> owner_shift);
             for (int64_t t = oprev + 1; t <= o; ++t) owner_base[t] = u;
+            if (grp_base != nullptr) {
+                const int64_t g = (int64_t)((uint64_t)key[j] >> grp_shift);
+                const int64_t gprev = e == 0 ? -1 : (int64_t)((uint64_t)prev[j] >> grp_shift);
+                for (int64_t t = gprev + 1; t <= g; ++t) grp_base[t] = u;
+            }
         }
         if (e == n - 1) {
             const int64_t ol = (int64_t)((uint64_t)key[j] >> owner_shift);
             for (int64_t t = ol + 1; t <= world; ++t) owner_base[t] = u + 1;
+            if (grp_base != nullptr) {
+                const int64_t gl = (int64_t)((uint64_t)key[j] >> grp_shift);
+                for (int64_t t = gl + 1; t <= n_groups; ++t) grp_base[t] = u + 1;
+            }
         }
     }
 }
@@ -1069,8 +1135,16 @@ __global__ __launch_bounds__(NRX_BLOCK) void dedup_place_kernel(const KeyT* __re
                                                                 const uint32_t* __restrict__ urank, const uint32_t* __restrict__ owner_base,
                                                                 int64_t n, int row_bits, int table_bits, int world, int n_tables,
                                                                 int64_t cap, int32_t* __restrict__ send_rows, int32_t* __restrict__ slot,
-                                                                int64_t* __restrict__ counts2d, int64_t* __restrict__ overflow) {
+                                                                int64_t* __restrict__ counts2d, int64_t* __restrict__ overflow,
+                                                                const uint32_t* __restrict__ grp_base) {
     const int64_t e = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x;
+    // per-(owner, table) counts of unique rows = differences of the groups' first unique entries (dedup_rank_kernel).  One atomic per unique
+    // row onto world x n_tables counters was 3.6 ms of a 3.7 ms call at the C2 shape (1.66 M heads onto 208 addresses).
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < world * n_tables; i += NRX_BLOCK) {
+            const int o = i / n_tables, t = i - o * n_tables, g = (o << table_bits) | t;
+            counts2d[i] = (int64_t)grp_base[g + 1] - (int64_t)grp_base[g];
+        }
     if (e == 0) {
         int64_t worst = 0;
         for (int o = 0; o < world; ++o) {
@@ -1086,10 +1160,8 @@ __global__ __launch_bounds__(NRX_BLOCK) void dedup_place_kernel(const KeyT* __re
     const int64_t k = (int64_t)urank[e] - (int64_t)owner_base[o];
     const bool head = e == 0 || skeys[e - 1] != skeys[e];
     slot[spayload[e]] = k < cap ? (int32_t)(o * cap + k) : -1;
-    if (head) {
-        if (k < cap) send_rows[o * cap + k] = (int32_t)(key & ((1ull << row_bits) - 1));
-        atomicAdd((unsigned long long*)&counts2d[(int64_t)o * n_tables + t], 1ull);      // integer count: order-independent
-    }
+    if (head && k < cap) send_rows[o * cap + k] = (int32_t)(key & ((1ull << row_bits) - 1));
+    (void)t;
 }
 
 // np.unique(return_inverse=True) on the device, for the ABI's integer utility: sorted distinct values and, for
@@ -1120,7 +1192,8 @@ extern "C" int64_t nrx_route_dedup_workspace(int64_t n_total, int32_t world) {
     if (n_total < 0 || n_total >= 0xffffffffLL || world < 1) return -1;
     const size_t n = (size_t)(n_total > 0 ? n_total : 1);
     const size_t t1 = sort_temp_bytes<uint64_t>(n, 64);
-    return (int64_t)(2 * align256(n * 8) + 2 * align256(n * 4) + 2 * align256(n * 4) + align256((size_t)(world + 2) * 4) + align256(t1) + 256);
+    return (int64_t)(2 * align256(n * 8) + 2 * align256(n * 4) + 2 * align256(n * 4) + align256((size_t)(world + 2) * 4) +
+                     align256((((size_t)world << 6) + 2) * 4) + align256(t1) + seg_scratch_bytes(n) + 256);
 }
 
 extern "C" int nrx_route_ids_dedup(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* table_local_rows,
@@ -1176,24 +1249,38 @@ extern "C" int nrx_route_ids_dedup(const void* const* ids, const int64_t* lens, 
     uint32_t* heads = (uint32_t*)w;    w += align256((size_t)n * 4);
     uint32_t* urank = (uint32_t*)w;    w += align256((size_t)n * 4);
     uint32_t* obase = (uint32_t*)w;    w += align256((size_t)(world + 2) * 4);
+    uint32_t* gbase = (uint32_t*)w;    w += align256((((size_t)world << 6) + 2) * 4);
+    const int n_groups = world << a.table_bits;
     void* temp = w;
     int64_t g = (n + NRX_BLOCK - 1) / NRX_BLOCK;
     const unsigned gfull = (unsigned)g, gtile = (unsigned)((n + PLAN_TILE - 1) / PLAN_TILE);
     if (g > 4096) g = 4096;
     size_t tb = 0;
+    // the sort: the planner's own tile kernels (seg_sort_generic) -- NRX_PLAN_SORT=rocprim keeps the library sort (A/B, and the reference
+    // permutation the tests compare with)
+    const char* sort_env = getenv("NRX_PLAN_SORT");
+    const bool use_rocprim = sort_env && !strcmp(sort_env, "rocprim");
+    void* seg_scratch = reinterpret_cast<char*>(temp) + align256(sort_temp_bytes<uint64_t>(n, 64));
 #define NRX_DD(KeyT)                                                                                                       \
     {                                                                                                                      \
         hipLaunchKernelGGL(dedup_keys_kernel<KeyT>, dim3((unsigned)g), dim3(NRX_BLOCK), 0, st, a, (KeyT*)keys_in, pay_in);  \
-        tb = sort_temp_bytes<KeyT>(n, bits);                                                                               \
-        err = rocprim::radix_sort_pairs(temp, tb, (const KeyT*)keys_in, (KeyT*)keys_out, (const uint32_t*)pay_in, pay_out,  \
-                                        (size_t)n, 0u, (unsigned)bits, st);                                                \
+        KeyT* sk = (KeyT*)keys_out; uint32_t* sp = pay_out;                                                                \
+        if (use_rocprim) {                                                                                                 \
+            tb = sort_temp_bytes<KeyT>(n, bits);                                                                           \
+            err = rocprim::radix_sort_pairs(temp, tb, (const KeyT*)keys_in, (KeyT*)keys_out, (const uint32_t*)pay_in, pay_out, \
+                                            (size_t)n, 0u, (unsigned)bits, st);                                            \
+        } else {                                                                                                           \
+            KeyT* s0 = (KeyT*)keys_in; KeyT* s1 = (KeyT*)keys_out; uint32_t* p0 = pay_in; uint32_t* p1 = pay_out;          \
+            seg_sort_generic<KeyT>(s0, s1, p0, p1, n, bits, seg_scratch, st);                                              \
+            sk = s0; sp = p0;                                                                                              \
+        }                                                                                                                  \
         if (err == hipSuccess) {                                                                                           \
-            hipLaunchKernelGGL(plan_count_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, PlaceInfo(), (const KeyT*)keys_out, n, heads, (const uint32_t*)nullptr, 0); \
-            hipLaunchKernelGGL(dedup_rank_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out,          \
-                               (const uint32_t*)heads, n, a.table_bits + a.row_bits, world, urank, obase);                  \
-            hipLaunchKernelGGL(dedup_place_kernel<KeyT>, dim3(gfull), dim3(NRX_BLOCK), 0, st, (const KeyT*)keys_out,         \
-                               (const uint32_t*)pay_out, (const uint32_t*)urank, (const uint32_t*)obase, n, a.row_bits,     \
-                               a.table_bits, world, n_tables, cap, send_rows, slot, counts2d, overflow);                    \
+            hipLaunchKernelGGL(plan_count_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, PlaceInfo(), (const KeyT*)sk, n, heads, (const uint32_t*)nullptr, 0); \
+            hipLaunchKernelGGL(dedup_rank_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const KeyT*)sk,               \
+                               (const uint32_t*)heads, n, a.table_bits + a.row_bits, world, urank, obase, a.row_bits, n_groups, gbase); \
+            hipLaunchKernelGGL(dedup_place_kernel<KeyT>, dim3(gfull), dim3(NRX_BLOCK), 0, st, (const KeyT*)sk,              \
+                               (const uint32_t*)sp, (const uint32_t*)urank, (const uint32_t*)obase, n, a.row_bits,          \
+                               a.table_bits, world, n_tables, cap, send_rows, slot, counts2d, overflow, (const uint32_t*)gbase); \
         }                                                                                                                  \
     }
     if (bits <= 32) NRX_DD(uint32_t) else NRX_DD(uint64_t)
@@ -1230,17 +1317,26 @@ extern "C" int nrx_unique_inverse(const void* ids, int32_t index_bits, int64_t n
     void* temp = w;
     const unsigned gfull = (unsigned)((n + NRX_BLOCK - 1) / NRX_BLOCK), gtile = (unsigned)((n + PLAN_TILE - 1) / PLAN_TILE);
     hipLaunchKernelGGL(uinv_keys_kernel, dim3(gfull), dim3(NRX_BLOCK), 0, st, ids, (int)(index_bits == 64), n, keys_in, pay_in);
-    size_t tb = sort_temp_bytes<uint64_t>(n, 64);
-    hipError_t err = rocprim::radix_sort_pairs(temp, tb, (const uint64_t*)keys_in, keys_out, (const uint32_t*)pay_in, pay_out, (size_t)n,
-                                               0u, 64u, st);
-    if (err != hipSuccess) {
-        nrx_set_error("nrx_unique_inverse: rocPRIM call failed: %s", hipGetErrorString(err));
-        return NRX_ERR_LAUNCH;
+    const char* sort_env = getenv("NRX_PLAN_SORT");
+    uint64_t* sk = keys_out;
+    uint32_t* sp = pay_out;
+    if (sort_env && !strcmp(sort_env, "rocprim")) {            // the library sort (A/B knob; the default is the planner's own tile kernels)
+        size_t tb = sort_temp_bytes<uint64_t>(n, 64);
+        hipError_t err = rocprim::radix_sort_pairs(temp, tb, (const uint64_t*)keys_in, keys_out, (const uint32_t*)pay_in, pay_out, (size_t)n,
+                                                   0u, 64u, st);
+        if (err != hipSuccess) {
+            nrx_set_error("nrx_unique_inverse: rocPRIM call failed: %s", hipGetErrorString(err));
+            return NRX_ERR_LAUNCH;
+        }
+    } else {
+        uint64_t* s0 = keys_in; uint64_t* s1 = keys_out; uint32_t* p0 = pay_in; uint32_t* p1 = pay_out;
+        seg_sort_generic<uint64_t>(s0, s1, p0, p1, n, 64, reinterpret_cast<char*>(temp) + align256(sort_temp_bytes<uint64_t>(n, 64)), st);
+        sk = s0; sp = p0;
     }
-    hipLaunchKernelGGL(plan_count_kernel<uint64_t>, dim3(gtile), dim3(NRX_BLOCK), 0, st, PlaceInfo(), (const uint64_t*)keys_out, n, heads, (const uint32_t*)nullptr, 0);
-    hipLaunchKernelGGL(dedup_rank_kernel<uint64_t>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const uint64_t*)keys_out, (const uint32_t*)heads, n,
+    hipLaunchKernelGGL(plan_count_kernel<uint64_t>, dim3(gtile), dim3(NRX_BLOCK), 0, st, PlaceInfo(), (const uint64_t*)sk, n, heads, (const uint32_t*)nullptr, 0);
+    hipLaunchKernelGGL(dedup_rank_kernel<uint64_t>, dim3(gtile), dim3(NRX_BLOCK), 0, st, (const uint64_t*)sk, (const uint32_t*)heads, n,
                        64 - 1, 1, urank, obase);      // owner_shift 63: one "owner" (bit 63 may be set: two bases are reserved)
-    hipLaunchKernelGGL(uinv_emit_kernel, dim3(gfull), dim3(NRX_BLOCK), 0, st, (const uint64_t*)keys_out, (const uint32_t*)pay_out,
+    hipLaunchKernelGGL(uinv_emit_kernel, dim3(gfull), dim3(NRX_BLOCK), 0, st, (const uint64_t*)sk, (const uint32_t*)sp,
                        (const uint32_t*)urank, n, unique_out, inverse_out, n_unique);
     NRX_LAUNCH_CHECK("nrx_unique_inverse");
     return NRX_OK;

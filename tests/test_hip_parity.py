@@ -1034,6 +1034,30 @@ def test_route_ids_dedup_bit_exact_vs_oracle(world, lens, tables, cap, hi, dtype
         assert np.array_equal(got_local, ids // world) and np.array_equal(sl // cap, ids % world)
 
 
+@pytest.mark.parametrize("sort", ["segmented", "segmented-bins", "rocprim"])
+def test_dedup_and_unique_inverse_under_every_sort_at_multi_tile_sizes(sort, monkeypatch):
+    """nrx_route_ids_dedup and nrx_unique_inverse sort with the planner's own tile kernels (seg_sort_generic: one segment, every scan path --
+    <= 32 tiles direct, chunked, and the per-segment bin scan forced by NRX_PLAN_SORT=segmented-bins) or, NRX_PLAN_SORT=rocprim, the library
+    sort: the same results, bit for bit equal to the definitions (oracle/ref_np.py: route_ids_dedup; np.unique)."""
+    monkeypatch.setenv("NRX_PLAN_SORT", sort)
+    rng = np.random.default_rng(99)
+    for world, lens, tables, hi in [(8, [70000, 70000, 30001], [0, 1, 0], 90000), (4, [300000], [0], 1 << 19), (2, [4096 * 33 + 5, 17], [1, 0], 3000)]:
+        arrays = [rng.integers(0, hi, n) for n in lens]
+        nt = max(tables) + 1
+        lrows = [(hi + world - 1) // world + 1] * nt
+        cap = sum(lens)
+        send, slot, c2, over = ops.route_ids_dedup([torch.from_numpy(a).to(DEV) for a in arrays], tables, lrows, world, cap)
+        r_send, r_slot, r_c2, r_worst = R.route_ids_dedup(arrays, tables, lrows, world, cap)
+        assert np.array_equal(c2.cpu().numpy(), r_c2) and int(over.item()) == r_worst
+        assert np.array_equal(slot.cpu().numpy(), r_slot)
+        valid = r_send >= 0
+        assert np.array_equal(send.cpu().numpy()[valid], r_send[valid])
+    for a in (rng.integers(-2 ** 62, 2 ** 62, 150001), rng.integers(0, 5000, 4096 * 40 + 3), rng.integers(-7, 7, 4097)):
+        u, inv = ops.unique_inverse(torch.from_numpy(a).to(DEV))
+        ru, rinv = np.unique(a, return_inverse=True)
+        assert np.array_equal(u.cpu().numpy(), ru) and np.array_equal(inv.cpu().numpy(), rinv.reshape(a.shape))
+
+
 def test_unique_inverse_matches_numpy():
     """nrx_unique_inverse == np.unique(return_inverse=True): int64 incl. negatives and extremes, int32, empty, all-equal."""
     rng = np.random.default_rng(5)
