@@ -48,6 +48,7 @@ struct RouteArgs {
     int32_t* send_tag;
     float* send_w;
     int32_t bags;
+    int32_t* send_pos;   // optional (one-sided placement): the position of every sent id inside its feature (= the sample, for [B] features)
 };
 static_assert(sizeof(RouteArgs) <= 3840, "kernarg budget");
 
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void route_place(const RouteArgs args_in
         } else if (k < cap) {
             a->slot[p] = (int32_t)(c.owner[j] * cap + k);
             a->send_rows[c.owner[j] * cap + k] = c.local[j];
+            if (a->send_pos != nullptr) a->send_pos[c.owner[j] * cap + k] = (int32_t)(i0 + j * NRX_BLOCK + tid);
         } else {
             a->slot[p] = -1;
         }
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void route_single(const RouteArgs args_i
         if (p < a->cap) {
             a->slot[p] = (int32_t)p;
             a->send_rows[p] = c.local[j];
+            if (a->send_pos != nullptr) a->send_pos[p] = (int32_t)(i0 + j * NRX_BLOCK + tid);
         } else {
             a->slot[p] = -1;
         }
@@ -300,6 +303,13 @@ struct InboxArgs {
     int32_t* status;
     int32_t dim;
     int32_t skip_row0;
+    // one-sided placement (nrx_gather_inbox_place): a gathered row goes straight into its place in the REQUESTER's concat buffer --
+    // peer_out[s] (the buffer of source rank s, mapped into this process: hipIpc / a peer mapping; this rank's own for s == rank) at
+    // row inbox_pos[slot] (the sample), column feat_col[feature] -- instead of into a row buffer that travels back and is read again
+    float* peer_out[NRX_MAX_FEATURES];     // [world]
+    int32_t feat_col[NRX_MAX_FEATURES];    // [n_feats]
+    const int32_t* inbox_pos;
+    int64_t out_ld;
 };
 static_assert(sizeof(InboxArgs) <= 3584, "kernarg budget");
 
@@ -401,7 +411,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void inbox_kernel(const InboxArgs args_i
 // C2 at world = 1 (1.7 M rows of 64 B): 85 -> see profiles; results identical (a gather: bit-exact).
 constexpr int INBOX_NC = 4;   // chunks of INBOX_R slots per lane group and work item
 
-template <int QLOG2>
+template <int QLOG2, bool PLACE = false>
 __global__ __launch_bounds__(NRX_BLOCK) void inbox_gather_ring_kernel(const InboxArgs args_in_kernarg, int chunks_per_source) {
     const NRX_CONST InboxArgs* a = nrx_kernarg<InboxArgs>();
     constexpr int Q = 1 << QLOG2;
@@ -410,6 +420,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void inbox_gather_ring_kernel(const Inbo
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int64_t* s_pre = reinterpret_cast<int64_t*>(smem);       // [F + 1] prefix of the current source rank
     __shared__ const float* s_ptr[NS * TB];                  // the work item's row addresses (null past the source's count)
+    __shared__ float* s_dst[PLACE ? NS * TB : 1];            // PLACE: where each row goes in the requester's concat
     const int F = a->n_feats;
     const int64_t cap = a->cap;
     const int q = threadIdx.x & (Q - 1), g = threadIdx.x >> QLOG2;
@@ -450,6 +461,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void inbox_gather_ring_kernel(const Inbo
             const int pos = i * NRX_BLOCK + threadIdx.x;
             const int64_t j = base + pos;
             const float* ptr = nullptr;
+            float* dst = nullptr;
             if (j < total) {
                 int lo = 0, hi = F;
                 while (hi - lo > 1) {
@@ -463,8 +475,10 @@ __global__ __launch_bounds__(NRX_BLOCK) void inbox_gather_ring_kernel(const Inbo
                     row = 0;
                 }
                 ptr = a->table[tab] + row * (int64_t)a->dim;
+                if (PLACE) dst = a->peer_out[s] + (int64_t)nrx_gconst<int32_t>(a->inbox_pos)[s * cap + j] * a->out_ld + a->feat_col[lo];
             }
             s_ptr[pos] = ptr;
+            if (PLACE) s_dst[pos] = dst;
         }
         __syncthreads();
         auto fetch = [&](int i) -> float4 {
@@ -482,7 +496,11 @@ __global__ __launch_bounds__(NRX_BLOCK) void inbox_gather_ring_kernel(const Inbo
             for (int r = 0; r < R; ++r) {
                 const int i = c * R + r;
                 const int64_t j = j0 + (int64_t)i * TB;
-                if (j < total && q < D4) nrx_stg4(a->buf, (s * cap + j) * D4 + q, v[r]);
+                if (PLACE) {
+                    if (j < total && q < D4) nrx_stg4(s_dst[i * TB + g], q, v[r]);
+                } else if (j < total && q < D4) {
+                    nrx_stg4(a->buf, (s * cap + j) * D4 + q, v[r]);
+                }
                 if (c + 1 < INBOX_NC) v[r] = fetch(i + R);
             }
         }
@@ -736,10 +754,9 @@ extern "C" int64_t nrx_route_workspace(int64_t n_total, int32_t world) {
     return (nchunks * world + 1) / 2 + 1;
 }
 
-extern "C" int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_t n_feats, int32_t index_bits,
-                             int32_t world, int64_t cap, int32_t* send_rows, int32_t* slot, int64_t* counts2d,
-                             int64_t* overflow, int64_t* workspace, void* stream) {
-    NRX_TRACE();
+static int route_ids_impl(const void* const* ids, const int64_t* lens, int32_t n_feats, int32_t index_bits,
+                          int32_t world, int64_t cap, int32_t* send_rows, int32_t* slot, int64_t* counts2d,
+                          int64_t* overflow, int64_t* workspace, int32_t* send_pos, void* stream) {
     NRX_REQUIRE(ids && lens && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES, "nrx_route_ids: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(index_bits == 32 || index_bits == 64, "nrx_route_ids: index_bits must be 32 or 64");
     NRX_REQUIRE(world >= 1 && world <= 64 && cap >= 1 && cap * world <= 0x7fffffffLL, "nrx_route_ids: bad world / cap");
@@ -772,6 +789,7 @@ extern "C" int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_
     a.send_tag = nullptr;
     a.send_w = nullptr;
     a.bags = 0;
+    a.send_pos = send_pos;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (world == 1) {       // nothing to bucket: one narrowing pass; block 0 also writes the counts (= the lengths)
         const unsigned g = chunks > 0 ? (unsigned)chunks : 1u;
@@ -783,6 +801,68 @@ extern "C" int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_
     hipLaunchKernelGGL(route_scan, dim3(1), dim3(NRX_BLOCK), 0, st, a);
     if (chunks > 0) hipLaunchKernelGGL(route_place, dim3((unsigned)chunks), dim3(NRX_BLOCK), 0, st, a);
     NRX_LAUNCH_CHECK("nrx_route_ids");
+    return NRX_OK;
+}
+
+extern "C" int nrx_route_ids(const void* const* ids, const int64_t* lens, int32_t n_feats, int32_t index_bits,
+                             int32_t world, int64_t cap, int32_t* send_rows, int32_t* slot, int64_t* counts2d,
+                             int64_t* overflow, int64_t* workspace, void* stream) {
+    NRX_TRACE();
+    return route_ids_impl(ids, lens, n_feats, index_bits, world, cap, send_rows, slot, counts2d, overflow, workspace, nullptr, stream);
+}
+
+extern "C" int nrx_route_ids_pos(const void* const* ids, const int64_t* lens, int32_t n_feats, int32_t index_bits,
+                                 int32_t world, int64_t cap, int32_t* send_rows, int32_t* send_pos, int32_t* slot, int64_t* counts2d,
+                                 int64_t* overflow, int64_t* workspace, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(send_pos != nullptr, "nrx_route_ids_pos: null send_pos");
+    return route_ids_impl(ids, lens, n_feats, index_bits, world, cap, send_rows, slot, counts2d, overflow, workspace, send_pos, stream);
+}
+
+extern "C" int nrx_gather_inbox_place(const float* const* tables, const int64_t* table_rows, int32_t n_tables,
+                                      const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,
+                                      const int64_t* recv2d, const int32_t* inbox_rows, const int32_t* inbox_pos, int32_t dim,
+                                      float* const* peer_out, int64_t out_ld, const int32_t* feat_col, int32_t* status, void* stream) {
+    NRX_TRACE();
+    InboxArgs a;
+    int rc = fill_inbox_args(a, const_cast<float* const*>(tables), table_rows, n_tables, feat_table, n_feats, world, cap,
+                             recv2d, inbox_rows, dim, "nrx_gather_inbox_place");
+    if (rc != NRX_OK) return rc;
+    NRX_REQUIRE(inbox_pos && peer_out && feat_col && out_ld >= dim, "nrx_gather_inbox_place: null / bad placement argument");
+    if ((dim & 3) != 0 || dim > 256 || dim < 16 || (out_ld & 3) != 0) {
+        nrx_set_error("nrx_gather_inbox_place: rows of 16..256 floats (a multiple of 4) and a row stride that is a multiple of 4 floats");
+        return NRX_ERR_UNSUPPORTED;
+    }
+    for (int s = 0; s < world; ++s) {
+        NRX_REQUIRE(peer_out[s] != nullptr && nrx_aligned16(peer_out[s]), "nrx_gather_inbox_place: peer_out[%d] must be a 16-byte aligned mapping", s);
+        a.peer_out[s] = peer_out[s];
+    }
+    for (int f = 0; f < n_feats; ++f) {
+        NRX_REQUIRE(feat_col[f] >= 0 && (feat_col[f] & 3) == 0 && feat_col[f] + dim <= out_ld, "nrx_gather_inbox_place: feat_col[%d] must be a multiple of 4 inside the row", f);
+        a.feat_col[f] = feat_col[f];
+    }
+    a.inbox_pos = inbox_pos;
+    a.out_ld = out_ld;
+    a.buf = nullptr;
+    a.status = status;
+    a.skip_row0 = 0;
+    int ql = log2_ceil((dim + 3) / 4);
+    const int tb = NRX_BLOCK >> ql;
+    const int per_item = tb * INBOX_R * INBOX_NC;
+    const int64_t cps = (cap + per_item - 1) / per_item;
+    NRX_REQUIRE(cps * world <= 0x7fffffffLL, "nrx_gather_inbox_place: too many rows for one launch");
+    int64_t g = cps * world;
+    if (g > 256 * 6) g = 256 * 6;
+    const size_t smem = (size_t)(n_feats + 1) * sizeof(int64_t);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (ql) {
+        case 2: hipLaunchKernelGGL((inbox_gather_ring_kernel<2, true>), dim3((unsigned)g), dim3(NRX_BLOCK), smem, st, a, (int)cps); break;
+        case 3: hipLaunchKernelGGL((inbox_gather_ring_kernel<3, true>), dim3((unsigned)g), dim3(NRX_BLOCK), smem, st, a, (int)cps); break;
+        case 4: hipLaunchKernelGGL((inbox_gather_ring_kernel<4, true>), dim3((unsigned)g), dim3(NRX_BLOCK), smem, st, a, (int)cps); break;
+        case 5: hipLaunchKernelGGL((inbox_gather_ring_kernel<5, true>), dim3((unsigned)g), dim3(NRX_BLOCK), smem, st, a, (int)cps); break;
+        default: hipLaunchKernelGGL((inbox_gather_ring_kernel<6, true>), dim3((unsigned)g), dim3(NRX_BLOCK), smem, st, a, (int)cps); break;
+    }
+    NRX_LAUNCH_CHECK("nrx_gather_inbox_place");
     return NRX_OK;
 }
 

@@ -553,8 +553,16 @@ class PreparedShardedForward:
 
     def __init__(self, eng: RowShardedEmbedding, feats: Sequence[ShardedFeature], inputs, weights,
                  tables: Dict[str, torch.Tensor], out_ld: Optional[int] = None,
-                 out: Optional[torch.Tensor] = None, fm: Optional[torch.Tensor] = None, overlap_local: bool = True):
+                 out: Optional[torch.Tensor] = None, fm: Optional[torch.Tensor] = None, overlap_local: bool = True,
+                 one_sided: Optional[bool] = None):
+        """one_sided (default: the NRX_SHARD_ONE_SIDED environment variable, else off): ONE-SIDED PLACEMENT for the exchange groups of plain
+        single-valued features -- the owner's gather writes every row straight into its place in the REQUESTER's concat buffer, which every
+        rank maps at construction (hipIpc through torch's CUDA-IPC tensor sharing; over xGMI a peer mapping), instead of into a row buffer
+        that an all-to-all carries back and a final launch reads again.  Per step: ids + sample positions out (two int32 all-to-alls), the
+        owner's launch, one small collective as the completion fence.  Bags, wide-routed and dense features keep the buffer path; an FM
+        epilogue becomes a pass over the finished concat (nrx_fm_fwd)."""
         import ctypes as C
+        import os
         from . import _lib
         self.lib = _lib.load()
         self.eng = eng
@@ -565,6 +573,34 @@ class PreparedShardedForward:
         slot_of: Dict[int, torch.Tensor] = {}
         final_weights = list(weights)
         rets = []
+        if one_sided is None:
+            one_sided = os.environ.get("NRX_SHARD_ONE_SIDED", "0") == "1"
+        plan0 = eng._final_plan(feats, groups, pooled_set)
+        ld0 = int(out_ld) if out_ld else plan0.out_width
+        self.placed: List[int] = []                  # feature indices written by the owners (not by this rank's final launch)
+        self.peers = None
+        if one_sided and not eng.dedup and (ld0 & 3) == 0:
+            for gi, idxs in enumerate(groups):
+                D = feats[idxs[0]].dim
+                if gi in pooled_set or D % 4 or not (16 <= D <= 256):
+                    continue
+                # worth its two extra launches when rows cross the fabric (W > 1: it replaces the row all-to-all) or, at world 1, when the
+                # group is large (C4's two id features, 131 k rows: 166 -> 178 us with it; C5's 40 features: 277 -> 160 us)
+                if W == 1 and sum(inputs[i].numel() for i in idxs) < (1 << 20) and os.environ.get("NRX_SHARD_ONE_SIDED_MIN") is None:
+                    continue
+                if all(feats[i].kind == NRX_SPARSE and not feats[i].wide and plan0.slots[i].out_col % 4 == 0 and inputs[i].dim() == 1
+                       for i in idxs):
+                    self.placed += idxs
+        if self.placed and plan0.use_fm and (len(self.placed) != len(feats) or any(not f.fm for f in feats) or len({f.dim for f in feats}) != 1):
+            self.placed = []      # an FM epilogue over a mix of placed and locally written features: keep the buffer path (the fused launch does it)
+        placed_set = set(self.placed)
+        if placed_set:
+            B0 = inputs[0].shape[0]
+            if out is None:
+                out = torch.empty((B0, ld0), dtype=torch.float32, device=inputs[0].device)
+            self.peers = self._map_peer_buffers(eng, out)
+            self._peer_ptrs = (C.c_void_p * W)(*[t.data_ptr() for t in self.peers])
+            self._fence = (torch.zeros(W, dtype=torch.int32, device=out.device), torch.zeros(W, dtype=torch.int32, device=out.device))
         for gi, idxs in enumerate(groups):
             dev = inputs[idxs[0]].device
             if gi in pooled_set:
@@ -602,6 +638,17 @@ class PreparedShardedForward:
                 ret=torch.empty((W * cap, D), dtype=torch.float32, device=dev),
                 tp=(C.c_void_p * len(loc))(*[t.data_ptr() for t in loc]), tr=(C.c_int64 * len(loc))(*[t.shape[0] for t in loc]),
                 nt=len(loc), ft=(C.c_int32 * n)(*[table_names.index(feats[i].table) for i in idxs]), dev=dev)
+            if idxs[0] in placed_set:     # one-sided placement: no row buffers at all; the sample positions travel with the local rows
+                g["placed"] = True
+                g["rows_out"] = g["ret"] = None
+                g["send_pos"] = torch.empty(W * cap, dtype=torch.int32, device=dev)
+                g["inbox_pos"] = torch.empty(W * cap, dtype=torch.int32, device=dev)
+                g["cols"] = (C.c_int32 * n)(*[plan0.slots[i].out_col for i in idxs])
+                g["ld"] = ld0
+                if W == 1:
+                    g["inbox"], g["recv2d"], g["inbox_pos"] = g["send"], g["counts2d"], g["send_pos"]
+                self.groups.append(g)
+                continue
             if W == 1:        # a one-rank group exchanges with itself: the "received" buffers ARE the sent ones (no copies)
                 g["inbox"], g["recv2d"], g["ret"] = g["send"], g["counts2d"], g["rows_out"]
             off = 0
@@ -610,9 +657,38 @@ class PreparedShardedForward:
                 off += x.numel()
             self.groups.append(g)
             rets.append(g["ret"])
-        plan = eng._final_plan(feats, groups, pooled_set)
-        final_inputs = [inputs[i] if (f.kind == NRX_DENSE or f.replicated) else slot_of[i] for i, f in enumerate(feats)]
+        plan = plan0
         rets += [tables[n] for n in eng.replicated_tables(feats)]
+        self.fm_pass = None
+        if placed_set:
+            # the final launch covers what the owners did not place; the table indices of its slots still name `rets` entries in the order
+            # _final_plan assigned them, so placed groups keep a (never read) placeholder there
+            rest = [i for i in range(len(feats)) if i not in placed_set]
+            self.local = None
+            self.final = None
+            self.out = out
+            if plan.use_fm:
+                if fm is None:
+                    fm = torch.empty((inputs[0].shape[0],), dtype=torch.float32, device=out.device)
+                self.fm_pass = (len(feats), feats[0].dim, fm)
+            self.fm_out = fm
+            if rest:
+                ph = torch.empty((1, 1), dtype=torch.float32, device=out.device)
+                rets_full, k = [], 0
+                for gi, idxs in enumerate(groups):
+                    if idxs[0] in placed_set:
+                        rets_full.append(ph)
+                    else:
+                        rets_full.append(rets[k])
+                        k += 1
+                rets_full += rets[k:]
+                final_inputs = [inputs[i] if (f.kind == NRX_DENSE or f.replicated) else slot_of.get(i) for i, f in enumerate(feats)]
+                sp = ops.EmbedPlan([plan.slots[i] for i in rest], out_width=plan.out_width,
+                                   wide_width=plan.wide_width if any(feats[i].wide for i in rest) else 0)
+                self.final = ops.PreparedEmbed(sp, rets_full, [final_inputs[i] for i in rest], [final_weights[i] for i in rest],
+                                               out_ld=ld0, out=out)
+            return
+        final_inputs = [inputs[i] if (f.kind == NRX_DENSE or f.replicated) else slot_of[i] for i, f in enumerate(feats)]
         # Features that need no exchange (dense values, planner-replicated tables) do not wait for one: they get their own
         # launch on a side stream, concurrent with routing / all-to-alls / owner gather, and the routed features get a second
         # launch after the exchange -- both write their own columns of the same concat.  Not possible when one epilogue
@@ -645,6 +721,53 @@ class PreparedShardedForward:
             self._wide_from_local = wide_l
         else:
             self.final = ops.PreparedEmbed(plan, rets, final_inputs, final_weights, out_ld=out_ld, out=out, fm=fm)
+
+    @staticmethod
+    def _map_peer_buffers(eng, out: torch.Tensor):
+        """Every rank's concat buffer as THIS process addresses it: its own tensor, and for the peers a tensor rebuilt from the CUDA-IPC handle
+        torch exports (hipIpcGetMemHandle / hipIpcOpenMemHandle underneath; two rank processes on one GPU -- the test layout -- map each other
+        the same way).  With one process per GPU the mapping is a peer mapping over xGMI: a first tiny copy makes torch enable peer access."""
+        W = eng.world
+        if W == 1:
+            return [out]
+        from torch.multiprocessing.reductions import reduce_tensor
+        handles = [None] * W
+        dist.all_gather_object(handles, reduce_tensor(out), group=eng.group)
+        peers = []
+        for s in range(W):
+            if s == eng.rank:
+                peers.append(out)
+                continue
+            fn, args = handles[s]
+            t = fn(*args)
+            if t.device != out.device:
+                out[:1, :1].copy_(t[:1, :1])           # (enables peer access between the two devices; the element is rewritten every step)
+            peers.append(t)
+        if eng.host_staged or not out.is_cuda:
+            dist.barrier(group=eng.group)
+        else:
+            torch.cuda.synchronize(out.device)
+            dist.barrier(group=eng.group)
+        return peers
+
+    def _run_placed(self, g, stream):
+        """One-sided group: route (rows + sample positions) -> counts / rows / positions to the owners -> the owner's gather writes into the
+        requesters' buffers."""
+        eng, lib = self.eng, self.lib
+        W = eng.world
+        rc = lib.nrx_route_ids_pos(g["ptrs"], g["lens"], g["n"], g["bits"], W, g["cap"], g["send"].data_ptr(), g["send_pos"].data_ptr(),
+                                   g["slot"].data_ptr(), g["counts2d"].data_ptr(), g["overflow"].data_ptr(), g["ws"].data_ptr(), stream)
+        if rc:
+            ops.check(rc, "nrx_route_ids_pos")
+        if W > 1:
+            eng._a2a(g["recv2d"].view(-1), g["counts2d"].view(-1))
+            eng._a2a(g["inbox"], g["send"])
+            eng._a2a(g["inbox_pos"], g["send_pos"])
+        rc = lib.nrx_gather_inbox_place(g["tp"], g["tr"], g["nt"], g["ft"], g["n"], W, g["cap"], g["recv2d"].data_ptr(),
+                                        g["inbox"].data_ptr(), g["inbox_pos"].data_ptr(), g["D"], self._peer_ptrs, g["ld"], g["cols"],
+                                        None, stream)
+        if rc:
+            ops.check(rc, "nrx_gather_inbox_place")
 
     def _bind_pooled(self, eng, feats, idxs, inputs, weights, tables, C):
         """Buffers and descriptor arrays of one pooled-bag group (owner-side partial pooling)."""
@@ -714,6 +837,8 @@ class PreparedShardedForward:
     def run(self):
         eng, lib = self.eng, self.lib
         W = eng.world
+        if self.peers is not None:
+            return self._run_one_sided()
         if self.local is not None:          # the exchange-free features start now, on the side stream
             cur = torch.cuda.current_stream(self._side.device)
             self._side.wait_stream(cur)
@@ -743,6 +868,45 @@ class PreparedShardedForward:
         res = self.final.run()
         torch.cuda.current_stream(self._side.device).wait_stream(self._side)      # both halves of the concat are in place
         return res[0], (lres[1] if self._wide_from_local else res[1]), None
+
+    def _run_one_sided(self):
+        eng, lib = self.eng, self.lib
+        W = eng.world
+        for g in self.groups:
+            stream = torch.cuda.current_stream(g["dev"]).cuda_stream
+            if g.get("pooled"):
+                self._run_pooled(g, stream)
+            elif g.get("placed"):
+                self._run_placed(g, stream)
+            else:
+                rc = lib.nrx_route_ids(g["ptrs"], g["lens"], g["n"], g["bits"], W, g["cap"], g["send"].data_ptr(),
+                                       g["slot"].data_ptr(), g["counts2d"].data_ptr(), g["overflow"].data_ptr(),
+                                       g["ws"].data_ptr(), stream)
+                if rc:
+                    ops.check(rc, "nrx_route_ids")
+                if W > 1:
+                    eng._a2a(g["recv2d"].view(-1), g["counts2d"].view(-1))
+                    eng._a2a(g["inbox"], g["send"])
+                rc = lib.nrx_gather_inbox(g["tp"], g["tr"], g["nt"], g["ft"], g["n"], W, g["cap"], g["recv2d"].data_ptr(),
+                                          g["inbox"].data_ptr(), g["D"], g["rows_out"].data_ptr(), None, stream)
+                if rc:
+                    ops.check(rc, "nrx_gather_inbox")
+                if W > 1:
+                    eng._a2a(g["ret"].view(-1), g["rows_out"].view(-1))
+        res = self.final.run() if self.final is not None else (self.out, None, None)
+        if W > 1:
+            # completion fence: a collective enqueued behind every rank's placing launch -- when it has completed here, every owner's rows
+            # are in this rank's buffer (and the next step's first all-to-all keeps the owners from overwriting it too early)
+            eng._a2a(self._fence[0], self._fence[1])
+        fmv = None
+        if self.fm_pass is not None:
+            n, D, fmv = self.fm_pass
+            out = self.out
+            rc = lib.nrx_fm_fwd(out.data_ptr(), out.shape[1], n, D, out.shape[0], fmv.data_ptr(),
+                                torch.cuda.current_stream(out.device).cuda_stream)
+            if rc:
+                ops.check(rc, "nrx_fm_fwd")
+        return self.out, (res[1] if res is not None else None), fmv
 
     def overflowed(self) -> bool:
         """True if any run since the last call exceeded a block capacity (the kernels keep a running maximum)."""
@@ -939,7 +1103,9 @@ class ShardedBenchPath:
         groups = self.calls[0].groups
         if not groups or self.world == 1:
             return None
-        pairs = [(g["ret"], g["partial"] if g.get("pooled") else g["rows_out"]) for g in groups]
+        pairs = [(g["ret"], g["partial"] if g.get("pooled") else g["rows_out"]) for g in groups if not g.get("placed")]
+        if not pairs:
+            return None
         nbytes = sum(r.numel() * r.element_size() for r, _ in pairs)
         for _ in range(3):
             for r, src in pairs:

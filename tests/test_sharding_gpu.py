@@ -153,3 +153,38 @@ def test_planner_replicated_tables_match_direct_path():
         np.testing.assert_allclose(shards[n].grad.cpu().numpy(), leaf.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
     call = sharding.PreparedShardedForward(RowShardedEmbedding(0, 1, overflow_policy="defer"), feats_p, inputs, weights, tables)
     assert torch.equal(call.run()[0], out_d.detach())
+
+
+@pytest.mark.parametrize("fm", [False, True])
+def test_one_sided_placement_world1_equals_the_direct_path(fm, monkeypatch):
+    """PreparedShardedForward(one_sided=True) at world 1: the owner's gather (nrx_gather_inbox_place) writes every routed row straight into the
+    concat -- bit-exact against the direct fused launch; with an FM epilogue the logit comes from a pass over the finished concat
+    (nrx_fm_fwd), equal to the fused epilogue within fp32 summation order (rtol 1e-5: SURVEY 8a a5)."""
+    from news_recsys_amd import ops
+    from news_recsys_amd._lib import NRX_SPARSE
+    monkeypatch.setenv("NRX_SHARD_ONE_SIDED_MIN", "0")          # small test groups: lift the world-1 size threshold
+    g = torch.Generator(device=DEV).manual_seed(5)
+    B, F, D, rows = 3001, 9, 16, 5000
+    tables = {f"t{i}": torch.randn(rows + i, D, device=DEV, generator=g) for i in range(F)}
+    feats = [ShardedFeature(f"f{i}", NRX_SPARSE, f"t{i}", D, 0, False, fm) for i in range(F)]
+    inputs = [torch.randint(0, rows, (B,), device=DEV, generator=g) for _ in range(F)]
+    weights = [None] * F
+    plan = ops.EmbedPlan([ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, i * D, fm_field=int(fm)) for i in range(F)], out_width=F * D, use_fm=fm)
+    want, _, want_fm = ops.embed_apply(plan, [tables[f"t{i}"] for i in range(F)], inputs, weights)
+    eng = RowShardedEmbedding(0, 1, overflow_policy="defer")
+    call = sharding.PreparedShardedForward(eng, feats, inputs, weights, tables, one_sided=True)
+    assert len(call.placed) == F and call.final is None
+    for _ in range(2):
+        out, _, fmv = call.run()
+    assert torch.equal(out, want)
+    if fm:
+        torch.testing.assert_close(fmv, want_fm, rtol=1e-5, atol=1e-5 * float(want_fm.abs().max()))
+    assert not call.overflowed()
+    # a mix: one 16-wide bag and a dense value next to the placed features (they take the final launch, into the same concat)
+    tables2, feats2, inputs2, weights2 = _case(B=700)
+    ref = sharding.PreparedShardedForward(RowShardedEmbedding(0, 1, overflow_policy="defer"), feats2, inputs2, weights2, tables2).run()[0]
+    ld = (ref.shape[1] + 3) // 4 * 4
+    c2 = sharding.PreparedShardedForward(RowShardedEmbedding(0, 1, overflow_policy="defer"), feats2, inputs2, weights2, tables2, out_ld=ld,
+                                         one_sided=True)
+    got = c2.run()[0]
+    assert torch.equal(got[:, :ref.shape[1]], ref)

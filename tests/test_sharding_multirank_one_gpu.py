@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _worker(rank, world, port, q, mode, slack, replicate, prepared, dedup=False, pool_bags=True):
+def _worker(rank, world, port, q, mode, slack, replicate, prepared, dedup=False, pool_bags=True, one_sided=False):
     import os
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -38,6 +38,9 @@ def _worker(rank, world, port, q, mode, slack, replicate, prepared, dedup=False,
         inputs = [x.float() if x.dtype == torch.float64 else x for x in inputs]
         weights = [torch.from_numpy(b["user_history_mask"]).to(DEV) if f.kind == NRX_BAG_MASKED_MEAN else None for f in FEATS]
         if prepared:        # the sync-free bound forward bench.py uses at N > 1
+            if one_sided:
+                _one_sided_worker(eng, rank, shards, replicate, q)
+                return
             call = sharding.PreparedShardedForward(eng, feats, inputs, weights, {n: s.detach() for n, s in shards.items()})
             call.run()
             call.run()                                   # re-launchable: same buffers, same result
@@ -53,11 +56,47 @@ def _worker(rank, world, port, q, mode, slack, replicate, prepared, dedup=False,
         dist.destroy_process_group()
 
 
-def _run(world, mode, slack, replicate, prepared, dedup=False, pool_bags=True):
+# The one-sided layout: the single-valued 16-wide features first (16-byte aligned columns: what the owners can place), then the bags, the
+# 8-wide feature (too narrow for the placing kernel: it takes the buffer path in the same call) and the dense value.
+ORDER_1S = ["item_id", "user_id", "user_history", "user_click_cats", "category", "ctr"]
+COLS_SORTED = {"category": (0, 8), "ctr": (8, 9), "item_id": (9, 25), "user_click_cats": (25, 33), "user_history": (33, 49), "user_id": (49, 65)}
+
+
+def _one_sided_worker(eng, rank, shards, replicate, q):
+    by_name = {f.name: f for f in FEATS}
+    feats = [ShardedFeature(n, by_name[n].kind, by_name[n].table, by_name[n].dim, by_name[n].bag_len, False, False, by_name[n].table in replicate)
+             for n in ORDER_1S]
+    b = batch_for(rank)
+    inputs = [torch.from_numpy(np.asarray(b[n])).to(DEV) for n in ORDER_1S]
+    inputs = [x.float() if x.dtype == torch.float64 else x for x in inputs]
+    weights = [torch.from_numpy(b["user_history_mask"]).to(DEV) if f.kind == NRX_BAG_MASKED_MEAN else None for f in feats]
+    width = 65
+    ld = 68
+    call = sharding.PreparedShardedForward(eng, feats, inputs, weights, {n: s.detach() for n, s in shards.items()}, out_ld=ld, one_sided=True)
+    placed = sorted(feats[i].name for i in call.placed)
+    assert call.peers is not None and placed == [n for n in ("item_id", "user_id") if by_name[n].table not in replicate], placed
+    call.run()
+    res = call.run()                                     # re-launchable: same buffers, same result
+    torch.cuda.synchronize()
+    dist.barrier()                                       # test transport: every peer's placing launch has finished before anyone reads
+    torch.cuda.synchronize()
+    out = res[0][:, :width].detach().cpu().numpy()
+    # back to the sorted-name column order the oracle (and _check_outputs) use
+    cols, c = {}, 0
+    for n in ORDER_1S:
+        w = COLS_SORTED[n][1] - COLS_SORTED[n][0]
+        cols[n] = (c, c + w)
+        c += w
+    resorted = np.concatenate([out[:, cols[n][0]:cols[n][1]] for n in sorted(ORDER_1S)], axis=1)
+    q.put((rank, resorted, None, bool(call.overflowed())))
+    dist.barrier()                                       # nobody unmaps a buffer a peer may still be writing
+
+
+def _run(world, mode, slack, replicate, prepared, dedup=False, pool_bags=True, one_sided=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, slack, replicate, prepared, dedup, pool_bags)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, slack, replicate, prepared, dedup, pool_bags, one_sided)) for r in range(world)]
     for p in procs:
         p.start()
     results = {}
@@ -104,5 +143,16 @@ def test_hip_backend_forward_backward_with_several_ranks(world, mode, slack, rep
 @pytest.mark.parametrize("world,replicate", [(2, ()), (3, ("category",))])
 def test_hip_backend_prepared_sync_free_forward_with_several_ranks(world, replicate):
     results = _run(world, "capacity", 0.5, replicate, prepared=True)
+    _check_outputs(results, world)
+    assert not any(results[r][2] for r in range(world))
+
+
+@pytest.mark.parametrize("world,replicate", [(2, ()), (3, ("category",))])
+def test_one_sided_placement_with_several_ranks_on_one_gpu(world, replicate):
+    """ONE-SIDED PLACEMENT (PreparedShardedForward(one_sided=True)): every rank maps the other ranks' concat buffers (hipIpc through torch's
+    CUDA-IPC sharing -- the rank processes share cuda:0 here, on a node each maps its peers over xGMI), ids AND their sample positions go to the
+    owners, and the owner's gather (nrx_gather_inbox_place) writes each row straight into the requester's concat: no row buffer, no row
+    all-to-all, no second pass.  Same outputs as the buffer path: routed single-valued features bit-exact, pooled bags / dense values as before."""
+    results = _run(world, "capacity", 0.5, replicate, prepared=True, one_sided=True)
     _check_outputs(results, world)
     assert not any(results[r][2] for r in range(world))

@@ -29,5 +29,7 @@ if [ $STATS_ONLY = 0 ]; then
   done
 fi
 python3 tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+# the raw per-pass traces (tens of MB per collection) stay on the box: gpurun copies back at most 64 MiB of gpurun_out/
+[ "${KEEP_RAW:-0}" = 1 ] || rm -rf $OUT/stats $OUT/pmc[0-9]*
 grep -h "fwd+bwd\|us per" $OUT/stats.log | head -5
 head -60 $OUT/summary.txt

@@ -27,3 +27,24 @@ for _ in range(20):
 b.record()
 torch.cuda.synchronize()
 print(f"torch copy_: {2 * n * 20 / (a.elapsed_time(b) * 1e-3) / 1e9:8.1f} GB/s")
+
+# the runtime's own device-to-device copy (hipMemcpyDtoDAsync from the HIP runtime this process already has loaded): is the "box ceiling" of
+# bench.py's stream_copy_GBps an artefact of nrx_copy_kernel?  (round-3 review, hygiene item)
+import ctypes
+hip = None
+for line in open("/proc/self/maps"):
+    if "libamdhip64" in line:
+        hip = ctypes.CDLL(line.split()[-1])
+        break
+if hip is not None:
+    hip.hipMemcpyDtoDAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    hip.hipMemcpyDtoDAsync.restype = ctypes.c_int
+    for _ in range(3):
+        assert hip.hipMemcpyDtoDAsync(dst.data_ptr(), src.data_ptr(), n, st) == 0
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(20):
+        hip.hipMemcpyDtoDAsync(dst.data_ptr(), src.data_ptr(), n, st)
+    b.record()
+    torch.cuda.synchronize()
+    print(f"hipMemcpyDtoDAsync: {2 * n * 20 / (a.elapsed_time(b) * 1e-3) / 1e9:8.1f} GB/s (read + written)")
