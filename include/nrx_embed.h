@@ -249,6 +249,17 @@ NRX_API int nrx_embed_bwd_placed_dense(const nrx_feature_t* feats, int32_t n_fea
                                uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
                                void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The whole deterministic dense-gradient backward of one launch group in ONE call: nrx_sparse_plan_place (or nrx_sparse_plan when place == 0
+ * or the single-valued features are under a quarter of the lookups) + nrx_embed_bwd_placed_dense, all intermediates inside `workspace`
+ * (nrx_embed_bwd_dense_sorted_workspace bytes).  feats[i].index = the ids, feats[i].rows the table rows, feats[i].table the GRADIENT of feature
+ * i's table; table_of (HOST, n_feats): the table id of each feature; grad_tables (HOST, n_tables) as in nrx_embed_bwd_placed_dense.  Autograd of
+ * nn.Embedding over every lookup feature (src/model/BaseModel/base_model.py:262-308) with the reference's dense [rows, dim] .grad, bit-reproducible. */
+NRX_API int64_t nrx_embed_bwd_dense_sorted_workspace(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim, int32_t n_tables);
+NRX_API int nrx_embed_bwd_dense_sorted(const nrx_feature_t* feats, const int32_t* table_of, int32_t n_feats, int32_t n_tables, int64_t batch,
+                               int32_t dim, const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                               const nrx_fm_grad_t* fm, float* const* grad_tables, int32_t accumulate, int32_t place,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Unique-row gradients -> dense gradient tables: for every unique entry u of nrx_sparse_plan / nrx_embed_bwd_sorted
  * (key = (table << 40) | row, gradient rows[u, :dim]), tables[table][row, :dim] = rows[u] (accumulate == 0) or += rows[u]
  * (accumulate != 0: a table fed by more than one reduction).  With zero-filled tables this forms what autograd gives the

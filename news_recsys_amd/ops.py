@@ -515,7 +515,8 @@ class _EmbedFn(torch.autograd.Function):
             # per bag feature) -- from here on the node only describes the backward
             plan, ins, ws = _csr_plan_to_padded(plan, ins, ws)
             ctx.plan, ctx.ins, ctx.ws = plan, ins, ws
-        if (ctx.sparse_grad or ctx.dense_sorted) and PLAN_AHEAD and B > 0 and not torch.cuda.is_current_stream_capturing() and wants_grad:
+        small = ctx.dense_sorted and not ctx.sparse_grad and B * sum(max(1, s_.bag_len) for s_ in plan.slots if s_.kind != NRX_DENSE) < PLAN_AHEAD_MIN
+        if (ctx.sparse_grad or ctx.dense_sorted) and PLAN_AHEAD and B > 0 and not torch.cuda.is_current_stream_capturing() and wants_grad and not small:
             ctx.plans = {}
             for g_ in _sparse_group_cache(plan, tables):
                 fs_ = g_["fs"]
@@ -605,6 +606,7 @@ _plan_streams = {}
 DENSE_BWD_SORTED = {"sorted": True, "atomic": False}.get(os.environ.get("NRX_DENSE_BWD", "auto"))
 DENSE_SORTED_MIN = int(os.environ.get("NRX_DENSE_SORTED_MIN", 1 << 20))
 PLAN_AHEAD = True      # row-sparse training: plan the backward (sort, unique rows, segments) at FORWARD time on a side stream
+PLAN_AHEAD_MIN = int(os.environ.get("NRX_PLAN_AHEAD_MIN", 1 << 18))      # default-mode launches below this many lookups plan inline (one fused call)
 
 
 def _plan_stream(dev) -> "torch.cuda.Stream":
@@ -781,6 +783,31 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
             ids, pl, ev = pre
             _cur_stream(dev).wait_event(ev)
             total = pl[0].numel()
+        elif dense_into is not None and n_tables <= NRX_MAX_FEATURES:
+            # default mode, nothing planned ahead (small launches, captured steps): plan + reduction into the dense gradients in ONE library
+            # call with ONE workspace allocation (nrx_embed_bwd_dense_sorted) -- the ten allocations and two calls of the general path below
+            # were most of a small step's host time
+            ids = [ctx.ins[i] for i in fs]
+            dt = ids[0].dtype
+            if any(x.dtype != dt for x in ids):
+                ids = [x.long() for x in ids]
+            if sum(x.numel() for x in ids) == 0:
+                continue
+            if dense_ptrs is None:
+                dense_ptrs = (C.c_void_p * n_tables)(*[g.data_ptr() for g in dense_into])
+            again = any(t in dense_seen for t in tabs)
+            arr = _group_features(grp, ids, [ctx.ws[i] for i in fs], fmg is not None, [dense_into[t].data_ptr() for t in tabs])
+            import numpy as _np
+            _np.frombuffer(arr, dtype=_feature_np_dtype())["rows"] = grp["rows"]
+            wsz = grp.get("fused_ws")
+            if wsz is None or wsz[0] != B:
+                wsz = grp["fused_ws"] = (B, lib.nrx_embed_bwd_dense_sorted_workspace(arr, n, B, D, n_tables))
+            fws = torch.empty(wsz[1], dtype=torch.uint8, device=dev)
+            check(lib.nrx_embed_bwd_dense_sorted(arr, grp["static"][0], n, n_tables, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, fmg,
+                                                 dense_ptrs, 1 if again else 0, 1 if SPARSE_PLACE else 0, fws.data_ptr(), fws.numel(), stream),
+                  "nrx_embed_bwd_dense_sorted")
+            dense_seen.update(tabs)
+            continue
         else:
             ids = [ctx.ins[i] for i in fs]
             dt = ids[0].dtype
