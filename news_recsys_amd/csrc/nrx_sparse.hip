@@ -303,11 +303,24 @@ struct SegArgs {
     uint32_t seg_db_w[NRX_MAX_FEATURES / 8]; // per table: digit width, a nibble each (<= SEG_MAX_DB = 10)
     int32_t n_slots, n_seg, idx64, row_bits, nb;     // nb = 1 << (widest digit) = row stride of hist / ctot / bin_base
     int32_t xcd;                                      // 1: blocks take their tiles in XCD order (seg_block_tile)
+    // MSD form (round 4; launches whose LSD sort would take three or more passes): ONE scatter pass on each segment's HIGH digit (its top
+    // seg_db bits, i.e. key >> seg_shift), then the bins -- a few dozen entries each on uniform ids -- are sorted where they lie by
+    // seg_binsort_kernel (comparison ranks, any number of low bits); bins too large for that go to a work list
+    uint32_t seg_shift_w[NRX_MAX_FEATURES / 4];      // per table: low bits under the MSD digit, a byte each (0: the one pass sorts the segment)
+    int32_t msd;
+    int32_t small_max;                                // largest bin the rank sort takes
+    uint32_t* bin_start;                              // [n_seg][nb]: global position of every bin's first entry (written by the scatter pass)
+    int32_t* work;                                    // [4 + 4 * work_cap]: work[0] = items, then {start, size, low bits, 0} per large bin
+    int32_t work_cap;
 };
 static_assert(sizeof(SegArgs) <= 3584, "kernarg budget");
 __device__ __forceinline__ int seg_db_of(const NRX_CONST SegArgs* a, int seg) {                 // seg wave-uniform: scalar loads and shifts
     seg = __builtin_amdgcn_readfirstlane(seg);
     return (int)((a->seg_db_w[seg >> 3] >> ((seg & 7) * 4)) & 15u);
+}
+__device__ __forceinline__ int seg_shift_of(const NRX_CONST SegArgs* a, int seg) {              // seg wave-uniform
+    seg = __builtin_amdgcn_readfirstlane(seg);
+    return (int)((a->seg_shift_w[seg >> 2] >> ((seg & 3) * 8)) & 255u);
 }
 __device__ __forceinline__ uint32_t seg_table_of(const NRX_CONST SegArgs* a, int slot) {        // slot: any lane's
     return (a->table_w[slot >> 2] >> ((slot & 3) * 8)) & 255u;
@@ -345,6 +358,8 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
     const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
     const int tile = seg_block_tile(a), seg = seg_of_tile(a, tile);
     const int nbins = 1 << seg_db_of(a, seg);
+    const int hshift = a->msd ? seg_shift_of(a, seg) : 0;            // the digit this kernel histograms: the lowest (LSD) or the segment's highest (MSD)
+    if (a->msd && blockIdx.x == 0 && threadIdx.x == 0) a->work[0] = 0;   // the scatter pass (next launch) appends the large bins
     for (int b = threadIdx.x; b < nbins; b += SEG_THREADS) s_hist[b] = 0;
     const int64_t q0 = a->seg_off[seg] + (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE, qend = a->seg_off[seg + 1];
     const uint32_t dmask = (uint32_t)nbins - 1u;
@@ -403,7 +418,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
                     keys[q] = tkey | (KeyT)v;
                     payload[q] = (uint32_t)(pbase + j * SEG_THREADS + threadIdx.x);
                 }
-                atomicAdd(&s_hist[(uint32_t)v & dmask], 1u);
+                atomicAdd(&s_hist[(uint32_t)(v >> hshift) & dmask], 1u);
             }
         }
     } else {
@@ -419,7 +434,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
                 keys[q] = ((KeyT)seg_table_of(a, s) << a->row_bits) | (KeyT)v;
                 payload[q] = (uint32_t)(a->poff[s] + (q - a->qoff[s]));
             }
-            atomicAdd(&s_hist[(uint32_t)v & dmask], 1u);
+            atomicAdd(&s_hist[(uint32_t)(v >> hshift) & dmask], 1u);
         }
     }
     }
@@ -545,7 +560,8 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
     const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tile = seg_block_tile(a), seg = seg_of_tile(a, tile);
-    const int db = seg_db_of(a, seg), nbins = 1 << db, shift = pass * db, nb = a->nb;
+    const int db = seg_db_of(a, seg), nbins = 1 << db, nb = a->nb;
+    const int shift = a->msd ? seg_shift_of(a, seg) : pass * db;
     uint16_t* s_wh = reinterpret_cast<uint16_t*>(s_mem);  // [WAVES][nbins]: running bin counts of each wave's 512-entry chunk (16-bit: a tile
                                                           // holds 4096 entries; halves this area -- a third / fourth resident block per CU)
     uint32_t* s_bin = s_mem + WAVES * nbins / 2;          // [nbins]: the bin's first position inside the tile
@@ -674,6 +690,19 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
             const uint32_t start = base + inc - tot[i];
             s_bin[b] = start;
             s_gb[b] = (DIRECT ? gb + ginc - gtot[i] + gbase[i] : gbase[i]) - start;
+            if (DIRECT == 1 && a->msd && tile == a->seg_tile[seg]) {      // the segment's first tile publishes where every bin begins
+                const uint32_t bs = gb + ginc - gtot[i];
+                a->bin_start[(size_t)seg * nb + b] = bs;
+                if (shift > 0 && (int)gtot[i] > a->small_max) {            // too large for the rank sort: onto the work list
+                    const int k = atomicAdd(&a->work[0], 1);
+                    if (k < a->work_cap) {
+                        a->work[4 + 4 * k] = (int32_t)bs;
+                        a->work[5 + 4 * k] = (int32_t)gtot[i];
+                        a->work[6 + 4 * k] = shift;
+                        a->work[7 + 4 * k] = 0;
+                    }
+                }
+            }
         }
         for (int w = 0; w < WAVES; ++w) { carry += s_part[w]; if (DIRECT) gcarry += s_gpart[w]; }
     }
@@ -709,6 +738,182 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
     }
 }
 
+// MSD form, second step: the bins of a segment (entries that share table and high digit, in source order) are sorted by their low bits WHERE THEY
+// LIE.  grid (nb / 4 + SEG_WORKERS, n_seg).  Blocks x < nb / 4: one wavefront per bin of segment y -- up to 256 entries, 4 per lane; every entry's
+// (low bits, position) packs into one word, the bin's words go to the wavefront's 1 KB of LDS, and an entry's rank is the number of smaller words
+// (broadcast reads, one compare per pair): a stable order whatever the width of the low bits.  The other blocks walk the work list of the bins
+// that are larger (heavily skewed ids): a block sorts such a bin alone by streaming LSD passes through the second pair buffer (histogram by
+// all wavefronts, the order-preserving placement by one wavefront, ballots as in seg_scatter_kernel) -- slow but bounded, and exact.
+constexpr int SEG_SMALL_BIN = 256;
+constexpr int SEG_WORKERS = 2;           // work-list blocks per grid row
+#ifndef NRX_SEG_BPW
+#define NRX_SEG_BPW 1                    // measured on C5 / C2 (plan alone, us): 1 bin per wavefront 112.9 / 73.3, 2: 114.7 / 73.6, 4: 119.7 / 77.3
+#endif
+constexpr int SEG_BPW = NRX_SEG_BPW;     // bins per wavefront of the rank sort
+
+template <typename KeyT, bool PAIR>
+__device__ __forceinline__ void seg_pair_load(const KeyT* keys, const uint32_t* pay, int64_t i, KeyT& k, uint32_t& p) {
+    if (PAIR) { const uint2 v = reinterpret_cast<const uint2*>(keys)[i]; k = (KeyT)v.x; p = v.y; }
+    else { k = keys[i]; p = pay[i]; }
+}
+template <typename KeyT, bool PAIR>
+__device__ __forceinline__ void seg_pair_store(KeyT* keys, uint32_t* pay, int64_t i, KeyT k, uint32_t p) {
+    if (PAIR) reinterpret_cast<uint2*>(keys)[i] = make_uint2((uint32_t)k, p);
+    else { keys[i] = k; pay[i] = p; }
+}
+
+template <int NU>
+__device__ __forceinline__ void seg_rank_words(const uint32_t* sl, int sz, const uint32_t (&w)[4], uint32_t (&rank)[4]) {
+    for (int j = 0; j < sz; j += 4) {                             // broadcast reads: every lane the same four words
+        const uint4 q = *reinterpret_cast<const uint4*>(sl + j);
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+            rank[u] += (uint32_t)(q.x < w[u]) + (uint32_t)(q.y < w[u]) + (uint32_t)(q.z < w[u]) + (uint32_t)(q.w < w[u]);
+    }
+}
+
+template <typename KeyT, bool PAIR>
+__global__ __launch_bounds__(NRX_BLOCK) void seg_binsort_kernel(const SegArgs args_in_kernarg, KeyT* __restrict__ keys, uint32_t* __restrict__ pay,
+                                                                KeyT* __restrict__ keys2, uint32_t* __restrict__ pay2) {
+    const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nb = a->nb, nbx = (nb + 4 * SEG_BPW - 1) / (4 * SEG_BPW);
+    __shared__ __attribute__((aligned(16))) uint32_t s_low[NRX_BLOCK / 64][SEG_SMALL_BIN + 4];
+    __shared__ uint32_t s_hist[1 << SEG_MAX_DB];
+    __shared__ uint32_t s_scan[NRX_BLOCK / 64];
+    if ((int)blockIdx.x < nbx) {
+        const int seg = blockIdx.y;
+        const int shift = seg_shift_of(a, seg);
+        if (shift == 0 || a->seg_off[seg + 1] == a->seg_off[seg]) return;      // the scatter pass sorted this segment completely / no lookups
+        const int nbins = 1 << seg_db_of(a, seg);
+        // a wavefront takes SEG_BPW consecutive bins and requests ALL their entries before it ranks the first: one bin per wavefront was three
+        // dependent round trips (bin bounds, entries, stores) for 64 entries -- 41 000 wavefronts of ~7 us each on C5, 48 us for the launch
+        const int bin0 = (blockIdx.x * (NRX_BLOCK / 64) + wid) * SEG_BPW;
+        if (bin0 >= nbins) return;                               // wave-uniform
+        const uint32_t* bs = a->bin_start + (size_t)seg * nb;
+        const int64_t seg_end = a->seg_off[seg + 1];
+        int64_t bnd = seg_end;                                   // lane l < SEG_BPW + 1: where bin bin0 + l begins (the segment's end past the last bin)
+        if (lane <= SEG_BPW && bin0 + lane < nbins) bnd = (int64_t)bs[bin0 + lane];
+        int64_t start[SEG_BPW];
+        int sz[SEG_BPW];
+#pragma unroll
+        for (int g = 0; g < SEG_BPW; ++g) {
+            start[g] = __shfl(bnd, g, 64);
+            sz[g] = (int)(__shfl(bnd, g + 1, 64) - start[g]);
+            if (bin0 + g >= nbins || sz[g] > SEG_SMALL_BIN) sz[g] = 0;         // past the segment's bins / the work list's
+        }
+        const uint32_t lowmask = (1u << shift) - 1u;
+        KeyT k[SEG_BPW][4];
+        uint32_t p[SEG_BPW][4];
+#pragma unroll
+        for (int g = 0; g < SEG_BPW; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = lane + 64 * u;
+                k[g][u] = 0; p[g][u] = 0;
+                if (i < sz[g] && sz[g] > 1) seg_pair_load<KeyT, PAIR>(keys, pay, start[g] + i, k[g][u], p[g][u]);
+            }
+        uint32_t* sl = s_low[wid];
+#pragma unroll
+        for (int g = 0; g < SEG_BPW; ++g) {
+            if (sz[g] <= 1) continue;                            // wave-uniform: nothing to order
+            uint32_t w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = lane + 64 * u;
+                w[u] = ((((uint32_t)k[g][u]) & lowmask) << 8) | (uint32_t)i;      // (low bits, position): distinct words, <= 21 + 8 bits
+                if (i < sz[g]) sl[i] = w[u];
+            }
+            if (lane < 4) sl[sz[g] + lane] = 0xffffffffu;         // the tail of the last 4-word read
+            __builtin_amdgcn_wave_barrier();
+            uint32_t rank[4] = {0u, 0u, 0u, 0u};
+            // a lane owns entries lane, lane + 64, ...: only the first ceil(sz / 64) of its four slots hold one (wave-uniform) -- ranking all four
+            // regardless made the launch VALU-bound (a 64-entry bin did four times the compares it needs: 57 us on C5)
+            const int nu = (sz[g] + 63) >> 6;
+            if (nu == 1) seg_rank_words<1>(sl, sz[g], w, rank);
+            else if (nu == 2) seg_rank_words<2>(sl, sz[g], w, rank);
+            else if (nu == 3) seg_rank_words<3>(sl, sz[g], w, rank);
+            else seg_rank_words<4>(sl, sz[g], w, rank);
+            __builtin_amdgcn_wave_barrier();                      // the next bin reuses the words
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (lane + 64 * u < sz[g]) seg_pair_store<KeyT, PAIR>(keys, pay, start[g] + rank[u], k[g][u], p[g][u]);
+        }
+        return;
+    }
+    // ---- work-list blocks: the bins beyond SEG_SMALL_BIN entries, one at a time per block
+    const int nwork = a->work[0] < a->work_cap ? a->work[0] : a->work_cap;
+    const int worker = ((int)blockIdx.x - nbx) * gridDim.y + blockIdx.y, nworkers = SEG_WORKERS * gridDim.y;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int it = worker; it < nwork; it += nworkers) {
+        const int64_t start = a->work[4 + 4 * it];
+        const int sz = a->work[5 + 4 * it], lowbits = a->work[6 + 4 * it];
+        const int passes = (lowbits + SEG_MAX_DB - 1) / SEG_MAX_DB, dbw = (lowbits + passes - 1) / passes, nbins = 1 << dbw;
+        const uint32_t dmask = (uint32_t)nbins - 1u;
+        KeyT* sk = keys; uint32_t* sp = pay; KeyT* dk = keys2; uint32_t* dp = pay2;
+        for (int pass = 0; pass < passes; ++pass) {
+            const int sh = pass * dbw;
+            for (int b = tid; b < nbins; b += NRX_BLOCK) s_hist[b] = 0;
+            __syncthreads();
+            for (int i = tid; i < sz; i += NRX_BLOCK) {
+                KeyT kk; uint32_t pp;
+                seg_pair_load<KeyT, PAIR>(sk, sp, start + i, kk, pp);
+                atomicAdd(&s_hist[((uint32_t)kk >> sh) & dmask], 1u);
+            }
+            __syncthreads();
+            {   // exclusive scan of the <= 1024 counts: 4 consecutive bins per thread
+                uint32_t v[4], sum = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int b = tid * 4 + u; v[u] = b < nbins ? s_hist[b] : 0u; sum += v[u]; }
+                uint32_t inc = sum;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const uint32_t x = __shfl_up(inc, off, 64); if (lane >= off) inc += x; }
+                if (lane == 63) s_scan[wid] = inc;
+                __syncthreads();
+                uint32_t base = inc - sum;
+                for (int w2 = 0; w2 < wid; ++w2) base += s_scan[w2];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int b = tid * 4 + u; if (b < nbins) s_hist[b] = base; base += v[u]; }
+            }
+            __syncthreads();
+            if (wid == 0) {                                                  // order-preserving placement: one wavefront, 64 entries per round
+                for (int r0 = 0; r0 < sz; r0 += 64) {
+                    const int i = r0 + lane;
+                    const bool valid = i < sz;
+                    KeyT kk = 0; uint32_t pp = 0;
+                    if (valid) seg_pair_load<KeyT, PAIR>(sk, sp, start + i, kk, pp);
+                    const uint32_t d = ((uint32_t)kk >> sh) & dmask;
+                    unsigned long long peers = __ballot(valid);
+                    for (int b = 0; b < dbw; ++b) {
+                        const bool bit = (d >> b) & 1u;
+                        const unsigned long long bal = __ballot(bit);
+                        peers &= bit ? bal : ~bal;
+                    }
+                    const uint32_t before = (uint32_t)__popcll(peers & lt);
+                    uint32_t base = 0;
+                    if (valid) {
+                        base = s_hist[d];                                     // every peer reads the bin's position before its leader moves it
+                        if (before == 0) s_hist[d] = base + (uint32_t)__popcll(peers);
+                        seg_pair_store<KeyT, PAIR>(dk, dp, start + base + before, kk, pp);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            __syncthreads();
+            KeyT* tk = sk; sk = dk; dk = tk;
+            uint32_t* tp = sp; sp = dp; dp = tp;
+        }
+        if (sk != keys) {                                                     // an odd number of passes: the result sits in the second buffer
+            for (int i = tid; i < sz; i += NRX_BLOCK) {
+                KeyT kk; uint32_t pp;
+                seg_pair_load<KeyT, PAIR>(sk, sp, start + i, kk, pp);
+                seg_pair_store<KeyT, PAIR>(keys, pay, start + i, kk, pp);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 template <typename KeyT>
@@ -720,9 +925,11 @@ size_t sort_temp_bytes(int64_t n, int bits) {
 }
 
 // scratch of the table-segmented sort: per-tile histograms + per-segment totals and bases, at the widest digit
+inline size_t seg_work_cap(size_t n) { return n / SEG_SMALL_BIN + 64; }      // bins of more than SEG_SMALL_BIN entries: at most n / 256 of them
 inline size_t seg_scratch_bytes(size_t n) {
     const size_t tiles = n / SEG_TILE + NRX_MAX_FEATURES + 1;          // hist rows; ctot has at most as many rows as there are tiles / 32 + segments
-    return align256((tiles + tiles / SEG_CHUNK + 2 * (size_t)NRX_MAX_FEATURES + 1) * ((size_t)1 << SEG_MAX_DB) * sizeof(uint32_t));
+    return align256((tiles + tiles / SEG_CHUNK + 2 * (size_t)NRX_MAX_FEATURES + 1) * ((size_t)1 << SEG_MAX_DB) * sizeof(uint32_t)) +
+           align256(((size_t)NRX_MAX_FEATURES << SEG_MAX_DB) * sizeof(uint32_t)) + align256((4 + 4 * seg_work_cap(n)) * sizeof(int32_t));      // MSD: bin starts, work list
 }
 
 int bits_for(int64_t v) {      // bits needed to represent values 0 .. v-1 (at least 1)
@@ -867,6 +1074,23 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
         int digit_cap = SEG_MAX_DB;                                   // NRX_PLAN_DIGIT_BITS narrows the digits (measurement knob)
         if (const char* e = getenv("NRX_PLAN_DIGIT_BITS")) { const int v = atoi(e); if (v >= 4 && v <= SEG_MAX_DB) digit_cap = v; }
         const int passes = (row_bits + digit_cap - 1) / digit_cap;
+        // MSD form (see SegArgs::msd): where the LSD sort would need three passes or more (tables beyond 2^20 rows: C3's 100 M-row table, C5),
+        // when every segment has at most SEG_CHUNK tiles and its bins come out small on uniform ids.  NRX_PLAN_SORT=msd forces it wherever
+        // the structure allows (tests), =lsd forbids it.
+        const bool force_msd = sort_env && !strcmp(sort_env, "msd");
+        const bool forbid_msd = sort_env && (!strcmp(sort_env, "lsd") || force_bins);
+        bool msd = !forbid_msd && (force_msd || passes >= 3) && n < (1ll << 30);
+        memset(sa.seg_shift_w, 0, sizeof(sa.seg_shift_w));
+        if (msd) {
+            for (int t = 0; t < n_tables && msd; ++t) {
+                int64_t seg_rows = 1, seg_len = 0;
+                for (int f = 0; f < n_feats; ++f)
+                    if (table_of[f] == t && lens[f] > 0) { seg_len += lens[f]; if (rows[f] > seg_rows) seg_rows = rows[f]; }
+                const int rb = bits_for(seg_rows), dbm = rb < SEG_MAX_DB ? rb : SEG_MAX_DB, sh = rb - dbm;
+                if ((seg_len + SEG_TILE - 1) / SEG_TILE > SEG_CHUNK || sh > 21) msd = false;                  // DIRECT 1 scatter only; (low bits, position) in 29 bits
+                else if (sh > 0 && !force_msd && (seg_len >> dbm) > SEG_SMALL_BIN / 2) msd = false;          // average bin beyond 128 entries: the rank sort would not pay
+            }
+        }
         int slot = 0, tile = 0, chunk = 0, max_db = 1;
         bool chunked = false;
         int max_chunks = 0;
@@ -887,7 +1111,12 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
                 q += lens[f];
                 ++slot;
             }
-            const int db = (bits_for(seg_rows) + passes - 1) / passes;      // the segment's row bits, split evenly over the passes
+            int db = (bits_for(seg_rows) + passes - 1) / passes;            // the segment's row bits, split evenly over the passes
+            if (msd) {                                                       // ... or its top <= 10 bits, the rest left to the bin sort
+                const int rb = bits_for(seg_rows);
+                db = rb < SEG_MAX_DB ? rb : SEG_MAX_DB;
+                sa.seg_shift_w[t >> 2] |= (uint32_t)((rb - db) & 255) << ((t & 3) * 8);
+            }
             sa.seg_db_w[t >> 3] |= (uint32_t)(db & 15) << ((t & 7) * 4);
             if (db > max_db) max_db = db;
             const int tiles = (int)((q - sa.seg_off[t] + SEG_TILE - 1) / SEG_TILE);
@@ -911,6 +1140,15 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
         uint32_t* hist = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(temp) + align256(sort_temp_bytes<uint64_t>(n, 64)));
         uint32_t* ctot = hist + (size_t)tile * nb;
         uint32_t* bin_base = ctot + (size_t)chunk * nb;
+        {   // MSD outputs of the scatter pass: behind the LSD scratch (seg_scratch_bytes)
+            const size_t tiles_cap = (size_t)n / SEG_TILE + NRX_MAX_FEATURES + 1;
+            char* m0 = reinterpret_cast<char*>(hist) + align256((tiles_cap + tiles_cap / SEG_CHUNK + 2 * (size_t)NRX_MAX_FEATURES + 1) * ((size_t)1 << SEG_MAX_DB) * sizeof(uint32_t));
+            sa.bin_start = reinterpret_cast<uint32_t*>(m0);
+            sa.work = reinterpret_cast<int32_t*>(m0 + align256(((size_t)NRX_MAX_FEATURES << SEG_MAX_DB) * sizeof(uint32_t)));
+            sa.work_cap = (int32_t)seg_work_cap((size_t)n);
+            sa.small_max = SEG_SMALL_BIN;
+            sa.msd = msd ? 1 : 0;
+        }
         const size_t lds_hist = (size_t)nb * 4;
         const dim3 gchunks((unsigned)((nb + NRX_BLOCK - 1) / NRX_BLOCK), (unsigned)chunk);
 #define NRX_SEGSORT(KeyT)                                                                                                 \
@@ -927,7 +1165,15 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
         KeyT* src = (KeyT*)keys_in; KeyT* dst = (KeyT*)keys_out;                                                          \
         uint32_t* psrc = pay_in; uint32_t* pdst = pay_out;                                                                \
         hipLaunchKernelGGL((seg_keys_kernel<KeyT, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, src, psrc, hist); \
-        for (int pass = 0; pass < passes; ++pass) {                                                                       \
+        if (msd) {                                                                                                        \
+            hipLaunchKernelGGL((seg_scatter_kernel<KeyT, 1, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
+                               (const uint32_t*)psrc, 0, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst); \
+            KeyT* tk = src; src = dst; dst = tk;                                                                          \
+            uint32_t* tp = psrc; psrc = pdst; pdst = tp;                                                                  \
+            hipLaunchKernelGGL((seg_binsort_kernel<KeyT, PAIR_>), dim3((unsigned)((nb + 4 * SEG_BPW - 1) / (4 * SEG_BPW) + SEG_WORKERS), (unsigned)n_tables), dim3(NRX_BLOCK), 0, st, \
+                               sa, src, psrc, dst, pdst);                                                                 \
+        }                                                                                                                 \
+        for (int pass = 0; pass < (msd ? 0 : passes); ++pass) {                                                           \
             if (pass > 0) hipLaunchKernelGGL((seg_hist_kernel<KeyT, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, (const KeyT*)src, pass, hist); \
             if (chunked && (max_chunks > SEG_DIRECT_CHUNKS || force_bins)) {                                              \
                 hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot);                      \

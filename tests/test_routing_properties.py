@@ -104,9 +104,13 @@ def test_hip_bucketize_matches_definition(n, world, seed):
     dict(n=[200000, 4097, 140000], rows=[1 << 19, 11, 1 << 19], tab=[1, 0, 1], nt=2),    # a segment of 83 tiles: chunked scans
     dict(n=[9000, 4097], rows=[1 << 38, 11], tab=[1, 0], nt=2),                 # 38 row bits: four digit passes, 64-bit keys
     dict(n=[9000, 4097], rows=[1 << 21, 11], tab=[69, 0], nt=70),               # more tables than segments: library sort
+    dict(n=[60000, 65536, 9000], rows=[1 << 27, (1 << 24) + 77, 500], tab=[0, 2, 1], nt=3),    # three LSD passes: the MSD form by default (17 / 15 low bits
+                                                                                # through the rank sort; the 500-row table done by the one scatter)
+    dict(n=[50000, 30000], rows=[1 << 27, 1 << 22], tab=[0, 1], nt=2, zipf=1.05),             # ... skewed: bins of thousands of entries -> the work list,
+                                                                                # two streaming passes over 17 low bits
 ])
 @pytest.mark.parametrize("dtype", ["int64", "int32"])
-@pytest.mark.parametrize("sort", ["segmented", "segmented-bins", "rocprim"])
+@pytest.mark.parametrize("sort", ["segmented", "segmented-bins", "rocprim", "msd", "lsd"])
 def test_sparse_plan_bit_exact(case, dtype, sort, monkeypatch):
     """nrx_sparse_plan == its definition (oracle.ref_np.sparse_plan): stable order, unique keys, segment
     starts, per-table bounds -- including out-of-range / negative ids (row 0) and tables with no lookups."""
@@ -159,13 +163,20 @@ def test_sparse_plan_bit_exact(case, dtype, sort, monkeypatch):
 @given(lens=st.lists(st.integers(min_value=0, max_value=9000), min_size=1, max_size=7),
        row_bits=st.lists(st.integers(min_value=1, max_value=26), min_size=7, max_size=7),
        tabs=st.lists(st.integers(min_value=0, max_value=4), min_size=7, max_size=7),
-       skew=st.booleans(), seed=st.integers(0, 2 ** 16))
-def test_sparse_plan_segmented_sort_matches_definition(lens, row_bits, tabs, skew, seed):
+       skew=st.booleans(), seed=st.integers(0, 2 ** 16), msd=st.booleans())
+def test_sparse_plan_segmented_sort_matches_definition(lens, row_bits, tabs, skew, seed, msd):
     """The table-segmented planner sort on hypothesis-generated shapes: any mix of segment lengths (empty segments, tiles that
     hold several features, tables shared by non-adjacent features), digit plans from 1 to 26 row bits, uniform and heavily
     repeated ids -- same plan as the definition, bit for bit."""
+    import os
     import torch
     from news_recsys_amd import ops
+    # msd: the one-scatter + bin-sort form of the planner forced wherever the structure allows (the library reads the variable per call);
+    # skew then sends the repeated row's bin through the work-list path
+    if msd:
+        os.environ["NRX_PLAN_SORT"] = "msd"
+    else:
+        os.environ.pop("NRX_PLAN_SORT", None)
     rng = np.random.default_rng(seed)
     n = len(lens)
     tab = tabs[:n]
@@ -195,6 +206,7 @@ def test_sparse_plan_segmented_sort_matches_definition(lens, row_bits, tabs, ske
     assert int(n_walk.item()) == len(w_r) and np.array_equal(walk.cpu().numpy()[:len(w_r)], w_r)
     able = np.isin(np.repeat(np.arange(n), [len(x) for x in ids]), feats)              # dest is written for placeable lookups only
     assert np.array_equal(dest.cpu().numpy()[:len(d_r)][able], d_r[able]) and np.all(d_r[~able] == -1)
+    os.environ.pop("NRX_PLAN_SORT", None)
 
 
 def test_oracle_sparse_plan_place_definition():
