@@ -1131,6 +1131,7 @@ struct PlaceArgs {
     float* grad[NRX_MAX_FEATURES];       // per placeable feature: base of its table's [rows, 4 Q] gradient
     int32_t idx64;
     int32_t add_to;                      // 1: add to what the table holds (a table fed by a second launch group)
+    int32_t stnt;                        // 1: placed rows leave with non-temporal stores (measurement knob NRX_PLACE_STNT)
 };
 static_assert(sizeof(PlaceArgs) <= 3584, "kernarg budget");
 
@@ -1208,6 +1209,10 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceA
                     acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
                 }
                 nrx_stg4(base, (int64_t)d * Q + q, acc);
+            } else if (a->stnt) {
+                nrx_f32x4 tv;
+                tv.x = acc.x; tv.y = acc.y; tv.z = acc.z; tv.w = acc.w;
+                __builtin_nontemporal_store(tv, (NRX_GLOBAL nrx_f32x4*)(a->values) + (int64_t)d * Q + q);
             } else {
                 nrx_stg4(a->values, (int64_t)d * Q + q, acc);
             }
@@ -2143,6 +2148,16 @@ extern "C" int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, 
             ua.out = reinterpret_cast<float4*>(out);
             ua.ld4 = unal ? out_ld : out_ld / 4;
             ua.unal = unal ? 1 : 0;
+            {   // non-temporal stores for the concat when every piece a lane group writes is one or more WHOLE 128-byte lines (rows of >= 32
+                // floats, line-aligned columns and row stride): C5 plain concat 125.5 -> 124.3 us, 132.0 -> 128.5 with distinct output buffers.
+                // Half-line pieces (D = 16) must merge in L2 first: with non-temporal stores the C2 launch takes 77.8 us instead of 58.5
+                // (tools/ab_stnt.py; NRX_FWD_STNT=0|1 overrides)
+                bool lines = D0 >= 32 && !unal && out != nullptr && (reinterpret_cast<uintptr_t>(out) & 127u) == 0 && (out_ld & 31) == 0;
+                for (int i = 0; i < n_feats && lines; ++i)
+                    if (el[i] && feats[i].dim == D0) lines = (feats[i].out_col & 31) == 0;
+                const char* e = getenv("NRX_FWD_STNT");
+                ua.stnt = e ? atoi(e) : (lines ? 1 : 0);
+            }
             ua.fm_out = fm_out;
             ua.fm_sums = (fm_out != nullptr && n_fm > 0) ? fm_sums : nullptr;
             ua.sums_ld = sums_ld;
@@ -2458,6 +2473,7 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             pa.values = values;
             pa.idx64 = feats[0].index_bits == 64;
             pa.add_to = add_to ? 1 : 0;
+            { const char* e = getenv("NRX_PLACE_STNT"); pa.stnt = e ? atoi(e) : 0; }
             pa.long_ws = a.long_ws;
             pa.n = n_place;
             { const char* e = getenv("NRX_PLACE_NT"); pa.nt = e ? atoi(e) : 1; }

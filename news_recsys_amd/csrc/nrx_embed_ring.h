@@ -36,6 +36,7 @@ struct UniformArgs {
     int32_t* status;
     int32_t n;
     int32_t idx64;                    // ids are int64 (else int32)
+    int32_t stnt;                     // 1: the concat leaves with non-temporal stores (measurement knob NRX_FWD_STNT)
     int32_t unal;                     // 1: some first column (or `out` / out_ld) is not a multiple of 4 floats -- a dense value in the
                                       //    middle of the sorted feature order shifts everything after it: col4[] and ld4 are then in
                                       //    FLOATS and the row leaves as a dword-aligned 16-byte store (global memory needs no more)
@@ -97,6 +98,7 @@ __device__ __forceinline__ void consume(const NRX_CONST UniformArgs* a, int f, f
         nrx_f32x4 t;
         t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
         if (a->unal) *(NRX_GLOBAL nrx_ring_f32x4u*)((NRX_GLOBAL float*)(a->out) + row4 + a->col4[f]) = t;      // row4 = b * ld + 4 q, in floats
+        else if (a->stnt) __builtin_nontemporal_store(t, (NRX_GLOBAL nrx_f32x4*)(a->out) + row4 + a->col4[f]);
         else ((NRX_GLOBAL nrx_f32x4*)(a->out))[row4 + a->col4[f]] = t;
     }
     if (FM) fm_accumulate(v, q * 4, 4 * Q, fm_first, fm_s, fm_q);

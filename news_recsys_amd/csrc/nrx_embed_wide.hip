@@ -26,6 +26,7 @@ struct UniformWideArgs {
     int32_t* status;
     int32_t n;
     int32_t idx64;
+    int32_t stnt;                         // 1: the aligned chunks leave with non-temporal stores (rows on whole 128-byte lines: written once, read by the MLP later)
 };
 static_assert(sizeof(UniformWideArgs) <= 3584, "kernarg budget");
 
@@ -154,7 +155,8 @@ struct WideAl {
         if (!(q == 0 && w && p == 0)) {                         // (nothing pending in front of a wide feature: its lane 0 completes no chunk)
             nrx_f32x4 t;
             t.x = c.x; t.y = c.y; t.z = c.z; t.w = c.w;
-            *(NRX_GLOBAL nrx_f32x4*)(orow + a->col[f] - w + 4 * q - d) = t;
+            if (a->stnt) __builtin_nontemporal_store(t, (NRX_GLOBAL nrx_f32x4*)(orow + a->col[f] - w + 4 * q - d));
+            else *(NRX_GLOBAL nrx_f32x4*)(orow + a->col[f] - w + 4 * q - d) = t;
         }
         carry = nxt;
         p = d;
@@ -299,6 +301,7 @@ bool nrx_launch_uniform_wide(const nrx_feature_t* feats, int32_t n_feats, int64_
     const bool i64 = feats[0].index_bits == 64;
     const bool nt = table_bytes > (256ll << 20);
     ua.idx64 = i64;
+    { const char* e = getenv("NRX_FWD_STNT"); ua.stnt = e ? atoi(e) : 0; }
     if (n_feats >= 8 && n_feats * (NRX_BLOCK / (D0 / 4)) * 4 <= 48 * 1024) {      // ring form: >= R features, ids fit a modest LDS tile
         // aligned-chunk stores (WideAl): a gap-free deep row in feature order that starts on a 16-byte boundary, row stride % 4 floats == 0
         bool al = nrx_aligned16(out) && (out_ld & 3) == 0 && (feats[0].out_col & 3) == 0;
