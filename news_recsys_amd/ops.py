@@ -1812,9 +1812,10 @@ def scatter_add_rows_segmented(grad_tables: Sequence[torch.Tensor], seg_start: t
                                              1 if skip_row0 else 0, _stream_ptr(g_rows)), "nrx_scatter_add_rows_segmented")
 
 
-def route_ids(id_tensors: Sequence[torch.Tensor], world: int, cap: int):
+def route_ids(id_tensors: Sequence[torch.Tensor], world: int, cap: int, want_pos: bool = False):
     """Fixed-capacity routing of the ids of one exchange (no host synchronisation).
-    Returns (send_rows [world*cap] int32, slot [N] int32, counts2d [world, F] int64, overflow [1] int64)."""
+    Returns (send_rows [world*cap] int32, slot [N] int32, counts2d [world, F] int64, overflow [1] int64); with want_pos
+    (nrx_route_ids_pos, one-sided placement) also send_pos [world*cap] int32: the position of every sent id inside its feature."""
     lib = _lib.load()
     n = len(id_tensors)
     if not 1 <= n <= NRX_MAX_FEATURES:
@@ -1837,6 +1838,12 @@ def route_ids(id_tensors: Sequence[torch.Tensor], world: int, cap: int):
     ws = torch.empty(max(1, lib.nrx_route_workspace(total, world)), dtype=torch.int64, device=dev)
     ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
     lens = (C.c_int64 * n)(*[x.numel() for x in xs])
+    if want_pos:
+        send_pos = torch.empty(world * cap, dtype=torch.int32, device=dev)
+        check(lib.nrx_route_ids_pos(ptrs, lens, n, xs[0].element_size() * 8, world, cap, send_rows.data_ptr(), send_pos.data_ptr(),
+                                    slot.data_ptr(), counts2d.data_ptr(), overflow.data_ptr(), ws.data_ptr(), _stream_ptr(xs[0])),
+              "nrx_route_ids_pos")
+        return send_rows, slot, counts2d, overflow, send_pos
     check(lib.nrx_route_ids(ptrs, lens, n, xs[0].element_size() * 8, world, cap, send_rows.data_ptr(), slot.data_ptr(),
                             counts2d.data_ptr(), overflow.data_ptr(), ws.data_ptr(), _stream_ptr(xs[0])), "nrx_route_ids")
     return send_rows, slot, counts2d, overflow

@@ -220,3 +220,68 @@ def test_auto_mode_switches_on_the_lookup_count(monkeypatch):
     monkeypatch.setattr(ops, "DENSE_BWD_SORTED", True)
     routed = ops.EmbedPlan([ops.Slot("a", NRX_SPARSE, 0, 16, 0, 0, flags=NRX_FEAT_ROW0_IS_DATA)], out_width=16)
     assert not ops._dense_sorted_ok(routed, t, False, 1 << 20)
+
+
+@pytest.mark.parametrize("place", [1, 0])
+@pytest.mark.parametrize("B,dist", [(700, "uniform"), (3000, "zipf"), (1, "uniform")])
+def test_dense_sorted_backward_one_call_c_abi(B, dist, place):
+    """nrx_embed_bwd_dense_sorted through the C-ABI: plan + reduction into zero-filled dense gradient tables in ONE call with ONE workspace, against
+    a float64 index_add restatement of nn.Embedding's backward (src/model/BaseModel/base_model.py:262-308; the padding row gets no gradient),
+    tolerance 1e-5 * sum|contribution| (fp32 sums in a fixed order), and against itself run twice: bit for bit."""
+    import ctypes as C
+    from news_recsys_amd import _lib
+    from news_recsys_amd._lib import NrxFeature
+    lib = _lib.load()
+    rng = np.random.default_rng(B + place)
+    D, L = 16, 5
+    rows = [900, 4000]
+    ids = [_ids(rng, rows[0], (B,), dist), _ids(rng, rows[1], (B, L), dist), _ids(rng, rows[0], (B,), dist)]      # table 0 fed by two features
+    mask = (rng.random((B, L)) < 0.7).astype(np.float32)
+    ids[1] = np.where(mask > 0, np.maximum(ids[1], 1), 0)
+    table_of = [0, 1, 0]
+    kinds = [NRX_SPARSE, NRX_BAG_MASKED_MEAN, NRX_SPARSE]
+    cols = [0, D, 2 * D]
+    g_out = rng.standard_normal((B, 3 * D)).astype(np.float32)
+    d_ids = [torch.from_numpy(x).to(DEV) for x in ids]
+    d_mask = torch.from_numpy(mask).to(DEV)
+    d_g = torch.from_numpy(g_out).to(DEV)
+    results = []
+    for _ in range(2):
+        grads = [torch.zeros(r, D, device=DEV) for r in rows]
+        feats = (NrxFeature * 3)()
+        for i in range(3):
+            f = feats[i]
+            f.table, f.index, f.rows, f.dim, f.kind, f.index_bits = grads[table_of[i]].data_ptr(), d_ids[i].data_ptr(), rows[table_of[i]], D, kinds[i], 64
+            f.bag_len, f.out_col, f.wide_col, f.fm_field, f.flags = (L if kinds[i] != NRX_SPARSE else 0), cols[i], -1, 0, 0
+            f.weight = d_mask.data_ptr() if kinds[i] == NRX_BAG_MASKED_MEAN else None
+        tof = (C.c_int32 * 3)(*table_of)
+        gp = (C.c_void_p * 2)(*[g.data_ptr() for g in grads])
+        nbytes = lib.nrx_embed_bwd_dense_sorted_workspace(feats, 3, B, D, 2)
+        assert nbytes > 0
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        rc = lib.nrx_embed_bwd_dense_sorted(feats, tof, 3, 2, B, D, d_g.data_ptr(), 3 * D, None, 0, None, gp, 0, place, ws.data_ptr(), nbytes,
+                                            torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.nrx_last_error()
+        torch.cuda.synchronize()
+        results.append([g.cpu().numpy() for g in grads])
+    for a_, b_ in zip(*results):
+        assert np.array_equal(a_.view(np.int32), b_.view(np.int32))
+    want = [np.zeros((r, D), np.float64) for r in rows]
+    mag = [np.zeros((r, D), np.float64) for r in rows]
+    for i in (0, 2):
+        np.add.at(want[0], ids[i], g_out[:, cols[i]:cols[i] + D].astype(np.float64))
+        np.add.at(mag[0], ids[i], np.abs(g_out[:, cols[i]:cols[i] + D]).astype(np.float64))
+    den = mask.sum(1, keepdims=True).astype(np.float32) + np.float32(1e-8)
+    sc = (mask / den).astype(np.float64)                                   # d pooled / d row: w / (sum w + 1e-8)  (base_model.py:278-282)
+    for l in range(L):
+        contrib = g_out[:, D:2 * D].astype(np.float64) * sc[:, l:l + 1]
+        np.add.at(want[1], ids[1][:, l], contrib)
+        np.add.at(mag[1], ids[1][:, l], np.abs(contrib))
+    for t in range(2):
+        want[t][0] = 0
+        got = results[0][t]
+        assert np.all(got[0] == 0)
+        assert np.all(np.abs(got - want[t]) <= 1e-5 * mag[t] + 1e-7)
+    # an undersized workspace is refused
+    assert lib.nrx_embed_bwd_dense_sorted(feats, tof, 3, 2, B, D, d_g.data_ptr(), 3 * D, None, 0, None, gp, 0, place, ws.data_ptr(), 64,
+                                          torch.cuda.current_stream().cuda_stream) == -1

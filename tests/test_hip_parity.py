@@ -1008,6 +1008,56 @@ def test_route_ids_bit_exact_vs_oracle(world, lens, cap, dtype):
     assert np.array_equal(send.cpu().numpy()[valid], r_send[valid])      # unused slots are unspecified
 
 
+@pytest.mark.parametrize("world,lens,cap", [(1, [100], 100), (2, [63, 1, 300], 256), (8, [4096, 4096, 5000, 17], 2048), (3, [2050, 0, 777], 1024)])
+def test_route_ids_pos_and_one_sided_gather_c_abi(world, lens, cap):
+    """nrx_route_ids_pos: the same send blocks / slots / counts as nrx_route_ids (oracle: ref_np.route_ids) plus, per sent id, its position inside
+    its feature -- checked through the slot map (send_pos[slot[p]] == p's position).  Then nrx_gather_inbox_place with this process as every
+    'source' (the send blocks taken as the inbox of ONE owner that holds whole tables): each row lands at peer_out[s][pos, col(feature)]."""
+    import ctypes as C
+    rng = np.random.default_rng(sum(lens) + world)
+    rows = 5000
+    arrays = [rng.integers(0, rows, n) for n in lens]
+    ids = [torch.from_numpy(a).to(DEV) for a in arrays]
+    send, slot, c2, over, pos = ops.route_ids(ids, world, cap, want_pos=True)
+    r_send, r_slot, r_counts, r_worst = R.route_ids(arrays, world, cap)
+    assert np.array_equal(c2.cpu().numpy(), r_counts) and int(over.item()) == r_worst and np.array_equal(slot.cpu().numpy(), r_slot)
+    valid = r_send >= 0
+    assert np.array_equal(send.cpu().numpy()[valid], r_send[valid])
+    sl, ps = slot.cpu().numpy(), pos.cpu().numpy()
+    off = 0
+    for a in arrays:
+        s_ = sl[off:off + len(a)]
+        ok = s_ >= 0
+        assert np.array_equal(ps[s_[ok]], np.arange(len(a))[ok])
+        off += len(a)
+    if r_worst > cap:
+        return
+    # owner side: treat block s of the send buffer as what "source s" sent to an owner whose local row l of feature f is table_f[l]
+    lib = _lib.load()
+    D, F = 16, len(lens)
+    B = max(lens) if max(lens) else 1
+    tabs = [torch.from_numpy(rng.standard_normal((rows // world + 2, D)).astype(np.float32)).to(DEV) for _ in range(F)]
+    outs = [torch.full((B, F * D), -7.5, device=DEV) for _ in range(world)]
+    tp = (C.c_void_p * F)(*[t.data_ptr() for t in tabs]); tr = (C.c_int64 * F)(*[t.shape[0] for t in tabs])
+    ft = (C.c_int32 * F)(*range(F)); cols = (C.c_int32 * F)(*[f * D for f in range(F)])
+    po = (C.c_void_p * world)(*[o.data_ptr() for o in outs])
+    rc = lib.nrx_gather_inbox_place(tp, tr, F, ft, F, world, cap, c2.data_ptr(), send.data_ptr(), pos.data_ptr(), D, po, F * D, cols, None,
+                                    torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.nrx_last_error()
+    torch.cuda.synchronize()
+    want = [np.full((B, F * D), -7.5, np.float32) for _ in range(world)]
+    for f, a in enumerate(arrays):
+        t = tabs[f].cpu().numpy()
+        for i, v in enumerate(a):
+            want[v % world][i, f * D:(f + 1) * D] = t[v // world]
+    for o, w in zip(outs, want):
+        assert np.array_equal(o.cpu().numpy(), w)
+    # shapes the placing kernel does not take are refused, not mis-served
+    po1 = (C.c_void_p * world)(*[o.data_ptr() for o in outs])
+    assert lib.nrx_gather_inbox_place(tp, tr, F, ft, F, world, cap, c2.data_ptr(), send.data_ptr(), pos.data_ptr(), 8, po1, F * D, cols, None,
+                                      torch.cuda.current_stream().cuda_stream) == -3          # NRX_ERR_UNSUPPORTED: rows of 8 floats
+
+
 @pytest.mark.parametrize("world,lens,tables,cap,hi", [(1, [100], [0], 100, 50), (2, [63, 1, 300], [0, 1, 0], 256, 40),
                                                       (8, [4096, 4096, 5000, 17], [0, 1, 2, 1], 2048, 3000),
                                                       (3, [0, 777, 0, 2050], [1, 0, 0, 1], 1024, 1 << 20), (4, [5000], [0], 64, 100000)])
