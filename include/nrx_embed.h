@@ -143,6 +143,19 @@ NRX_API int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_t b
                   const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
                   const nrx_fm_grad_t* fm, void* stream);
 
+/* nrx_embed_bwd for the reference's own batch sizes (a few hundred to a few thousand samples), DETERMINISTIC: one launch, one block
+ * per gradient table; a block sorts its table's lookups in LDS and adds every row's contributions in sorted order -- no atomics, the
+ * same bits run to run, where nrx_embed_bwd's float atomics differ in the last place.  Arguments as nrx_embed_bwd, plus `accumulate`:
+ * 0 = every gradient row the launch touches is STORED (pre-zeroed tables, this call their only writer -- no read of the old row),
+ * 1 = added to what is there (a table fed by an earlier call too).  Returns NRX_ERR_UNSUPPORTED with nothing enqueued when the launch is outside its shapes (the caller
+ * then takes nrx_embed_bwd or the planned reduction): every table fed by <= 4096 lookups of this call, dim in {4, 8, 16, ... 256},
+ * 16-byte-aligned gradient rows, padded (not CSR) bags, rows < 2^32, ids of one width; FM folding only with 16-byte-aligned upstream
+ * columns and no wide feature.  Replaces, for those shapes, autograd's index_add_ of base_model.py:164's embeddings on the CPU
+ * (deterministic there too).                                                                                                      */
+NRX_API int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
+                  const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                  const nrx_fm_grad_t* fm, int32_t accumulate, void* stream);
+
 /* Deterministic row-sparse backward for ONE table (alternative to nrx_embed_bwd's dense atomics).
  * The caller has sorted the table's lookups by row id (stable): `order[e]` is the flat lookup index of
  * the e-th sorted entry, flat lookups being feature-major over the n_feats features that read the

@@ -23,6 +23,7 @@ NRX_ABI_VERSION = 2
 NRX_MAX_FEATURES = 64
 NRX_MAX_DCN_LAYERS = 8
 NRX_OK = 0
+NRX_ERR_UNSUPPORTED = -3
 
 # enum nrx_feature_kind
 NRX_SPARSE, NRX_DENSE, NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM = 0, 1, 2, 3, 4
@@ -69,6 +70,7 @@ SIGNATURES = {
     "nrx_set_small_batch_max": (_i64, [_i64]),
     "nrx_embed_fwd_train": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p]),
     "nrx_embed_bwd": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, C.POINTER(NrxFmGrad), _p]),
+    "nrx_embed_bwd_small": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, C.POINTER(NrxFmGrad), _i32, _p]),
     "nrx_embed_bwd_sorted_workspace": (_i64, [_i64, _i32]),
     "nrx_embed_bwd_sorted": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _i32, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p,
                                        C.POINTER(NrxFmGrad), _p, _p, _p]),

@@ -2221,6 +2221,302 @@ extern "C" int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, 
 }
 
 // FM gradient folded into the embedding backward (see nrx_fm_grad_t): validated once for both backward forms
+// ---- small deterministic dense backward (round 4): ONE launch, block per table, for the reference's own batch sizes.
+// A block gathers its table's lookups as (row << 32 | feature << 12 | position) keys in LDS, sorts them there (bitonic: <= 4096 keys),
+// finds the runs of equal rows and reduces each run IN SORTED ORDER straight into the table's dense gradient: no plan arrays, no workspace,
+// no atomics, so the result is the same bit pattern run to run -- what the float-atomic scatter (nrx_embed_bwd), one launch too, cannot say.
+// Rows with <= SD_LONG lookups are summed by one lane group in order; longer rows by a whole wavefront (lane groups stride the run, then a
+// fixed xor tree) -- both orders depend on the sorted keys only.  Eligibility is the host's business (nrx_embed_bwd_small).
+constexpr int SD_MAX = 4096;          // lookups per table (12 position bits in the key; 32 KB of keys)
+constexpr int SD_LONG = 32;
+constexpr int SD_THREADS = 1024;
+struct SmallDetArgs {
+    const void* ids[NRX_MAX_FEATURES];
+    const float* weight[NRX_MAX_FEATURES];
+    float* grad[NRX_MAX_FEATURES];          // the dense gradient of the feature's table
+    int64_t rows[NRX_MAX_FEATURES];
+    int32_t out_col[NRX_MAX_FEATURES];
+    int32_t wide_col[NRX_MAX_FEATURES];
+    // bag_len (0: single-valued) | kind << 16 | flags << 24 (1: FM field, 2: row 0 is data).  ONE 4-byte word per feature, no byte arrays
+    // indexed by the feature: with them the compiler formed `kernarg + f` once and addressed the 8-byte arrays as
+    // s_load_dwordx2 [kernarg + f], soffset 7 f -- and a scalar load ignores the two low bits of its base (wrong pointer for f % 4 != 0)
+    int32_t meta[NRX_MAX_FEATURES];
+    uint8_t seg_feat[NRX_MAX_FEATURES];     // feature indices grouped by table, ascending inside a table
+    uint8_t seg_ptr[NRX_MAX_FEATURES + 1];  // block s owns seg_feat[seg_ptr[s] .. seg_ptr[s + 1])
+    uint8_t seg_ql[NRX_MAX_FEATURES];       // log2(dim / 4) of block s's table
+    const float* g_out; int64_t out_ld;
+    const float* g_wide; int64_t wide_ld;
+    const float* g_fm; const float* fm_sums; int64_t sums_ld; const float* feat; int64_t feat_ld;
+    int32_t batch, idx64, n_pow2, add_to;
+};
+static_assert(sizeof(SmallDetArgs) <= 3840, "SmallDetArgs must fit the kernel-argument segment");
+
+struct SdFeat { const float* weight; const void* ids; int64_t rows; int32_t out_col, wide_col, L, kind, flags, den_base; };
+
+template <int E>
+__device__ __forceinline__ void sd_sort(uint64_t* s_key, int N, int NT, int tid) {
+    uint64_t k[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) k[e] = s_key[tid * E + e];
+    for (int k2 = 2; k2 <= N; k2 <<= 1) {
+        for (int j = k2 >> 1; j >= E; j >>= 1) {      // partner in another thread: thread tid ^ m, same slot e
+            const int m = j / E;
+            const bool lower = (tid & m) == 0;
+            uint64_t o[E];
+            if (m < 64) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) o[e] = (uint64_t)__shfl_xor((unsigned long long)k[e], m, 64);
+            } else {
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) s_key[e * NT + tid] = k[e];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) o[e] = s_key[e * NT + (tid ^ m)];
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool up = ((tid * E + e) & k2) == 0;
+                const bool take_min = lower == up;
+                const uint64_t lo = k[e] < o[e] ? k[e] : o[e], hi = k[e] < o[e] ? o[e] : k[e];
+                k[e] = take_min ? lo : hi;
+            }
+        }
+        // both keys in this thread: the distances are compile-time constants (a run-time j here indexed k[] dynamically -- the array went to
+        // scratch memory and the E > 1 sorts were no faster than the all-LDS form)
+#pragma unroll
+        for (int jj = E >> 1; jj > 0; jj >>= 1) {
+            if (jj <= (k2 >> 1)) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & jj) == 0) {
+                        const bool up = ((tid * E + e) & k2) == 0;
+                        const uint64_t x = k[e], y = k[e | jj];
+                        const bool sw = (x > y) == up;
+                        k[e] = sw ? y : x;
+                        k[e | jj] = sw ? x : y;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) s_key[tid * E + e] = k[e];
+}
+
+template <bool FM, bool UNAL>
+__global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const SmallDetArgs args_in_kernarg) {
+    const NRX_CONST SmallDetArgs* a = nrx_kernarg<SmallDetArgs>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char sd_smem[];
+    __shared__ SdFeat s_f[NRX_MAX_FEATURES];
+    __shared__ int s_wsum[SD_THREADS / 64];
+    __shared__ int s_nvalid, s_nuniq, s_nlong;
+    __shared__ uint16_t s_long[SD_MAX / SD_LONG];      // rows with more than SD_LONG lookups (any order: a row's sum does not depend on who forms it)
+    const int N = a->n_pow2;
+    uint64_t* s_key = reinterpret_cast<uint64_t*>(sd_smem);
+    uint16_t* s_us = reinterpret_cast<uint16_t*>(s_key + N);                 // [N + 2]: start of every run of equal rows, then the end
+    float* s_den = reinterpret_cast<float*>(sd_smem + (size_t)N * 8 + ((((size_t)N + 2) * 2 + 15) & ~(size_t)15));   // masked-mean denominators
+    const int tid = threadIdx.x, s = blockIdx.x, NT = blockDim.x;        // NT: a power of two, 256 .. SD_THREADS, <= N
+    const int f0 = a->seg_ptr[s], f1 = a->seg_ptr[s + 1];
+    const int B = a->batch;
+    // ---- per-feature fields of this table; denominators of its masked-mean bags
+    if (tid == 0) {                       // (uniform indices into the argument block: scalar loads)
+        int db = 0;
+        for (int fi = f0; fi < f1; ++fi) {
+            const int f = a->seg_feat[fi];
+            SdFeat t;
+            const int m = a->meta[f];
+            t.weight = a->weight[f]; t.ids = a->ids[f]; t.rows = a->rows[f]; t.out_col = a->out_col[f]; t.wide_col = a->wide_col[f];
+            t.L = m & 0xffff; t.kind = (m >> 16) & 0xff; t.flags = (m >> 24) & 0xff; t.den_base = db;
+            s_f[f] = t;
+            db += t.kind == NRX_BAG_MASKED_MEAN ? B : 0;
+        }
+        s_nvalid = N; s_nuniq = 0;
+    }
+    __syncthreads();
+    int base = 0;
+    for (int fi = f0; fi < f1; ++fi) {
+        const int f = a->seg_feat[fi];
+        const SdFeat ft = s_f[f];
+        const int L = ft.L, kind = ft.kind;
+        const int len = B * (L > 0 ? L : 1);
+        const bool keep0 = (ft.flags & 2) != 0;
+        const uint64_t rows = (uint64_t)ft.rows;
+        const NRX_GLOBAL float* w = nrx_gconst<float>(ft.weight);
+        const bool has_w = ft.weight != nullptr && kind != NRX_BAG_MEAN && kind != NRX_SPARSE;
+        for (int i = tid; i < len; i += NT) {
+            const int64_t id = a->idx64 ? nrx_gconst<int64_t>(ft.ids)[i] : (int64_t)nrx_gconst<int32_t>(ft.ids)[i];
+            bool ok = (uint64_t)id < rows && (id != 0 || keep0);
+            if (ok && has_w) ok = w[i] != 0.f;                       // a masked position adds nothing
+            s_key[base + i] = ok ? ((uint64_t)id << 32 | (uint32_t)f << 12 | (uint32_t)i) : ~0ull;
+        }
+        if (kind == NRX_BAG_MASKED_MEAN) {
+            float* den = s_den + ft.den_base;
+            for (int b = tid; b < B; b += NT) {
+                float d = 0.f;
+                for (int l = 0; l < L; ++l) d += w[(int64_t)b * L + l];
+                den[b] = d + 1e-8f;
+            }
+        }
+        base += len;
+    }
+    for (int i = base + tid; i < N; i += NT) s_key[i] = ~0ull;
+#if defined(NRX_SD_DEBUG) && NRX_SD_DEBUG == 4
+    return;
+#endif
+    // ---- bitonic sort of the N keys: E = N / NT keys per thread in registers (blocked: thread t owns sorted positions t E .. t E + E - 1).
+    // Partners inside the thread are exchanged in registers, inside the wavefront by shuffles; only the stages that cross wavefronts go
+    // through LDS with barriers (6 of 45 stages at N = 512, 10 of 78 at N = 4096 -- all 45 through LDS were 10 us of a 22 us launch)
+    __syncthreads();
+    if (N == NT) sd_sort<1>(s_key, N, NT, tid);
+    else if (N == 2 * NT) sd_sort<2>(s_key, N, NT, tid);
+    else sd_sort<4>(s_key, N, NT, tid);
+    __syncthreads();
+    // ---- runs of equal rows: thread t owns keys [t C, (t + 1) C)
+    const int C = N / NT;
+    int heads = 0;
+    for (int i = tid * C; i < (tid + 1) * C; ++i) {
+        const uint64_t kx = s_key[i];
+        const bool valid = kx != ~0ull;
+        const bool pv = i > 0 && s_key[i - 1] != ~0ull;
+        if (!valid && (i == 0 || pv)) s_nvalid = i;
+        heads += valid && (i == 0 || (uint32_t)(s_key[i - 1] >> 32) != (uint32_t)(kx >> 32));
+    }
+    int incl = heads;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int rank = incl - heads;
+    for (int j = 0; j < wv; ++j) rank += s_wsum[j];
+    if (tid == NT - 1) s_nuniq = rank + heads;
+    for (int i = tid * C; i < (tid + 1) * C; ++i) {
+        const uint64_t kx = s_key[i];
+        if (kx != ~0ull && (i == 0 || (uint32_t)(s_key[i - 1] >> 32) != (uint32_t)(kx >> 32))) s_us[rank++] = (uint16_t)i;
+    }
+    __syncthreads();
+    const int U = s_nuniq, n_valid = s_nvalid;
+    if (tid == 0) { s_us[U] = (uint16_t)n_valid; s_nlong = 0; }
+#if defined(NRX_SD_DEBUG) && NRX_SD_DEBUG == 3
+    return;
+#endif
+#if defined(NRX_SD_DEBUG) && NRX_SD_DEBUG < 3
+    if (tid == 0) {
+        printf("blk %d f0 %d f1 %d N %d U %d n_valid %d\n", s, f0, f1, N, U, n_valid);
+        for (int fi = f0; fi < f1; ++fi) { const int f = a->seg_feat[fi]; printf(" f %d L %d kind %d w %p oc %d\n", f, s_f[f].L, s_f[f].kind, (void*)s_f[f].weight, s_f[f].out_col); }
+        for (int i = 0; i < 6; ++i) printf(" key[%d] %llx\n", i, (unsigned long long)s_key[i]);
+        printf(" key[nv-1] %llx\n", (unsigned long long)s_key[n_valid - 1]);
+    }
+#if NRX_SD_DEBUG == 2
+    return;
+#endif
+#endif
+    __syncthreads();
+    for (int u = tid; u < U; u += NT)
+        if ((int)s_us[u + 1] - (int)s_us[u] > SD_LONG) s_long[atomicAdd(&s_nlong, 1)] = (uint16_t)u;
+    // ---- reduction
+    const int ql = a->seg_ql[s];
+    const int Q = 1 << ql, q = tid & (Q - 1);
+    const int64_t D = 4ll << ql;
+    NRX_GLOBAL float* gtab = nrx_gmut<float>(a->grad[a->seg_feat[f0]]);
+    auto contrib = [&](uint64_t key) -> float4 {
+        const uint32_t p = (uint32_t)key;
+        const int f = (int)(p >> 12), i = (int)(p & 4095u);
+        const SdFeat ft = s_f[f];
+        int64_t b = i;
+        float sc = 1.0f;
+        if (ft.L > 0) {
+            b = i / ft.L;
+            if (ft.kind == NRX_BAG_MASKED_MEAN) sc = nrx_gconst<float>(ft.weight)[i] / s_den[ft.den_base + b];
+            else if (ft.kind == NRX_BAG_MEAN) sc = 1.0f / (float)ft.L;
+            else if (ft.weight != nullptr) sc = nrx_gconst<float>(ft.weight)[i];
+        }
+        float4 t = upstream_chunk<UNAL>(a->g_out, a->out_ld, a->g_wide, a->wide_ld, ft.out_col, ft.wide_col, b, q);
+        if (FM) {
+            if (ft.flags & 1) {
+                const float gf = nrx_gconst<float>(a->g_fm)[b];
+                const float4 S = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
+                const float4 v = nrx_ldg4(a->feat, (b * a->feat_ld + ft.out_col) / 4 + q);
+                fm_fold4(t, gf, S, v, q);
+            }
+        }
+        return make_float4(t.x * sc, t.y * sc, t.z * sc, t.w * sc);      // (products then sums: nothing here contracts into an fma across the call)
+    };
+    const bool add_to = a->add_to != 0;
+    auto store = [&](uint32_t row, float4 acc) {
+        NRX_GLOBAL nrx_f32x4* dst = reinterpret_cast<NRX_GLOBAL nrx_f32x4*>(gtab + (int64_t)row * D) + q;
+        nrx_f32x4 r;
+        r.x = acc.x; r.y = acc.y; r.z = acc.z; r.w = acc.w;
+        if (add_to) {                       // a table fed by an earlier call too
+            const nrx_f32x4 o = *dst;
+            r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+        }
+        *dst = r;
+    };
+    // R rows per lane group in flight: a row is a chain key -> upstream row -> store, ~1 us of latency each; one after the other that was
+    // 8 chains per group at B = 512 (33 us per launch at the C2 shape), 64 at B = 4096
+    const int G = NT >> ql, g = tid >> ql;
+    constexpr int R = 4;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u0 = 0; u0 < U; u0 += G * R) {
+        int st[R], cnt[R];
+        float4 t0[R], t1[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int u = u0 + r * G + g;
+            st[r] = 0; cnt[r] = 0;
+            if (u < U) {
+                st[r] = s_us[u];
+                cnt[r] = s_us[u + 1] - st[r];
+                if (cnt[r] > SD_LONG) cnt[r] = 0;           // the wavefront loop below
+            }
+            t0[r] = cnt[r] > 0 ? contrib(s_key[st[r]]) : zero4;
+            t1[r] = cnt[r] > 1 ? contrib(s_key[st[r] + 1]) : zero4;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (cnt[r] == 0) continue;
+            float4 acc = zero4;
+            acc.x += t0[r].x; acc.y += t0[r].y; acc.z += t0[r].z; acc.w += t0[r].w;
+            if (cnt[r] > 1) { acc.x += t1[r].x; acc.y += t1[r].y; acc.z += t1[r].z; acc.w += t1[r].w; }
+            const int en = st[r] + cnt[r];
+            for (int e = st[r] + 2; e < en; e += 4) {
+                float4 t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = e + j < en ? contrib(s_key[e + j]) : zero4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (e + j < en) { acc.x += t[j].x; acc.y += t[j].y; acc.z += t[j].z; acc.w += t[j].w; }
+            }
+            store((uint32_t)(s_key[st[r]] >> 32), acc);
+        }
+    }
+    const int gg = lane >> ql, G64 = 64 >> ql;
+    __syncthreads();
+    const int n_long = s_nlong;
+    for (int li = wv; li < n_long; li += NT / 64) {
+        const int u = s_long[li];
+        const int st = s_us[u], en = s_us[u + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = st + gg; e < en; e += 2 * G64) {
+            const float4 t0 = contrib(s_key[e]);
+            const float4 t1 = e + G64 < en ? contrib(s_key[e + G64]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc.x += t0.x; acc.y += t0.y; acc.z += t0.z; acc.w += t0.w;
+            if (e + G64 < en) { acc.x += t1.x; acc.y += t1.y; acc.z += t1.z; acc.w += t1.w; }
+        }
+        for (int o = Q; o < 64; o <<= 1) {
+            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+            acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+        }
+        if (gg == 0) store((uint32_t)(s_key[st] >> 32), acc);
+    }
+}
+
 static int check_fm_grad(const nrx_fm_grad_t* fm, const nrx_feature_t* feats, int32_t n_feats, const char* who) {
     if (fm == nullptr || fm->g_fm == nullptr) return NRX_OK;
     NRX_REQUIRE(fm->fm_sums != nullptr && fm->feat != nullptr, "%s: FM gradient needs fm_sums and the forward concat", who);
@@ -2280,6 +2576,97 @@ extern "C" int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_
     if (max_bag <= 0) gz = 1;
     NRX_QSWITCH(qlog2, { hipLaunchKernelGGL((embed_bwd_generic<QL>), dim3(grid, gy, gz), dim3(NRX_BLOCK), smem, st, a); });
     NRX_LAUNCH_CHECK("nrx_embed_bwd");
+    return NRX_OK;
+}
+
+// The deterministic form of nrx_embed_bwd for small launches (embed_bwd_small_det_kernel): same arguments, same accumulate-into-the-table
+// contract, NRX_ERR_UNSUPPORTED (nothing enqueued, nrx_last_error untouched) when the launch is outside its shapes -- the caller then takes
+// nrx_embed_bwd.  Shapes: every table fed by <= 4096 lookups of this call, dim in {4, 8, 16, .. 256} with 16-byte-aligned gradient rows,
+// padded (not CSR) bags, rows < 2^32, ids of one width; FM folding only with 16-byte-aligned upstream columns and no wide feature.
+extern "C" int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
+                                   const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                                   const nrx_fm_grad_t* fm, int32_t accumulate, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
+                "nrx_embed_bwd_small: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
+    NRX_REQUIRE(batch >= 0, "nrx_embed_bwd_small: negative batch");
+    const bool has_fm = fm != nullptr && fm->g_fm != nullptr;
+    NRX_REQUIRE(g_out != nullptr || g_wide != nullptr || has_fm, "nrx_embed_bwd_small: no upstream gradient");
+    if (batch == 0) return NRX_OK;
+    if (batch > SD_MAX) return NRX_ERR_UNSUPPORTED;
+    int rc = check_fm_grad(fm, feats, n_feats, "nrx_embed_bwd_small");
+    if (rc != NRX_OK) return rc;
+    SmallDetArgs a = {};
+    bool unal = (reinterpret_cast<uintptr_t>(g_out) & 15) != 0 || (out_ld & 3) != 0;
+    bool any_fm = false;
+    int bits = 0;
+    // segments: features that share a gradient table, in order of first appearance
+    const float* seg_tab[NRX_MAX_FEATURES];
+    int64_t seg_n[NRX_MAX_FEATURES], seg_den[NRX_MAX_FEATURES];
+    int seg_dim[NRX_MAX_FEATURES], seg_of[NRX_MAX_FEATURES], n_seg = 0;
+    for (int i = 0; i < n_feats; ++i) {
+        const nrx_feature_t& f = feats[i];
+        seg_of[i] = -1;
+        if (f.kind == NRX_DENSE) continue;
+        NRX_REQUIRE(f.kind >= NRX_SPARSE && f.kind <= NRX_BAG_SUM, "nrx_embed_bwd_small: feature %d: bad kind %d", i, f.kind);
+        NRX_REQUIRE(f.table != nullptr && f.index != nullptr && f.rows >= 1 && f.dim >= 1, "nrx_embed_bwd_small: feature %d: null table / ids", i);
+        const bool bag = f.kind >= NRX_BAG_MASKED_MEAN;
+        NRX_REQUIRE(!bag || f.bag_len >= 1, "nrx_embed_bwd_small: feature %d: bag_len < 1", i);
+        NRX_REQUIRE(f.kind != NRX_BAG_MASKED_MEAN || f.weight != nullptr, "nrx_embed_bwd_small: feature %d: masked mean needs weights", i);
+        if ((f.flags & NRX_FEAT_BAG_CSR) || f.rows >= (1ll << 32) || (f.index_bits != 32 && f.index_bits != 64)) return NRX_ERR_UNSUPPORTED;
+        if (bits == 0) bits = f.index_bits;
+        if (bits != f.index_bits) return NRX_ERR_UNSUPPORTED;
+        int ql = -1;
+        for (int k = 0; k <= 6; ++k) if (f.dim == (4 << k)) ql = k;
+        if (ql < 0 || (reinterpret_cast<uintptr_t>(f.table) & 15) != 0) return NRX_ERR_UNSUPPORTED;
+        const int64_t len = batch * (bag ? f.bag_len : 1);
+        if (len > SD_MAX || (bag && f.bag_len > SD_MAX)) return NRX_ERR_UNSUPPORTED;
+        int sgi = -1;
+        for (int k = 0; k < n_seg; ++k) if (seg_tab[k] == f.table) sgi = k;
+        if (sgi < 0) { sgi = n_seg++; seg_tab[sgi] = f.table; seg_n[sgi] = 0; seg_den[sgi] = 0; seg_dim[sgi] = f.dim; }
+        if (seg_dim[sgi] != f.dim) return NRX_ERR_UNSUPPORTED;
+        seg_n[sgi] += len;
+        if (f.kind == NRX_BAG_MASKED_MEAN) seg_den[sgi] += batch;
+        if (seg_n[sgi] > SD_MAX) return NRX_ERR_UNSUPPORTED;
+        seg_of[i] = sgi;
+        if (f.wide_col >= 0 || (f.out_col & 3) != 0) unal = true;
+        const bool isfm = has_fm && f.fm_field != 0;
+        any_fm |= isfm;
+        a.ids[i] = f.index; a.weight[i] = f.weight; a.grad[i] = const_cast<float*>(f.table); a.rows[i] = f.rows;
+        a.out_col[i] = f.out_col; a.wide_col[i] = f.wide_col; a.meta[i] = (bag ? f.bag_len : 0) | f.kind << 16 | ((isfm ? 1 : 0) | ((f.flags & NRX_FEAT_ROW0_IS_DATA) ? 2 : 0)) << 24;
+    }
+    if (n_seg == 0) return NRX_OK;
+    if (any_fm && (unal || (reinterpret_cast<uintptr_t>(fm->fm_sums) & 15) != 0 || (reinterpret_cast<uintptr_t>(fm->feat) & 15) != 0 ||
+                   (fm->sums_ld & 3) != 0 || (fm->feat_ld & 3) != 0))
+        return NRX_ERR_UNSUPPORTED;
+    int64_t max_n = 0, max_den = 0;
+    int k = 0;
+    for (int sgi = 0; sgi < n_seg; ++sgi) {
+        a.seg_ptr[sgi] = (uint8_t)k;
+        for (int i = 0; i < n_feats; ++i) if (seg_of[i] == sgi) a.seg_feat[k++] = (uint8_t)i;
+        int ql = 0;
+        while ((4 << ql) != seg_dim[sgi]) ++ql;
+        a.seg_ql[sgi] = (uint8_t)ql;
+        if (seg_n[sgi] > max_n) max_n = seg_n[sgi];
+        if (seg_den[sgi] > max_den) max_den = seg_den[sgi];
+    }
+    a.seg_ptr[n_seg] = (uint8_t)k;
+    int N = 256;
+    while (N < max_n) N <<= 1;
+    a.n_pow2 = N;
+    a.add_to = accumulate != 0;
+    const int nt = N < SD_THREADS ? N : SD_THREADS;
+    a.batch = (int32_t)batch;
+    a.idx64 = bits == 64;
+    a.g_out = g_out; a.out_ld = out_ld; a.g_wide = g_wide; a.wide_ld = wide_ld;
+    a.g_fm = any_fm ? fm->g_fm : nullptr; a.fm_sums = any_fm ? fm->fm_sums : nullptr; a.sums_ld = any_fm ? fm->sums_ld : 0;
+    a.feat = any_fm ? fm->feat : nullptr; a.feat_ld = any_fm ? fm->feat_ld : 0;
+    const size_t smem = (size_t)N * 8 + ((((size_t)N + 2) * 2 + 15) & ~(size_t)15) + (size_t)max_den * 4 + 16;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (any_fm) hipLaunchKernelGGL((embed_bwd_small_det_kernel<true, false>), dim3(n_seg), dim3(nt), smem, st, a);
+    else if (unal) hipLaunchKernelGGL((embed_bwd_small_det_kernel<false, true>), dim3(n_seg), dim3(nt), smem, st, a);
+    else hipLaunchKernelGGL((embed_bwd_small_det_kernel<false, false>), dim3(n_seg), dim3(nt), smem, st, a);
+    NRX_LAUNCH_CHECK("nrx_embed_bwd_small");
     return NRX_OK;
 }
 

@@ -24,7 +24,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_FEAT_BAG_CSR, NRX_FEAT_ROW0_IS_DATA, NRX_MAX_FEATURES, NRX_SPARSE,
+from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_ERR_UNSUPPORTED, NRX_FEAT_BAG_CSR, NRX_FEAT_ROW0_IS_DATA, NRX_MAX_FEATURES, NRX_SPARSE,
                    NrxFeature, NrxFmGrad, check)
 
 # ------------------------------------------------------------------------------- helpers
@@ -579,6 +579,14 @@ class _EmbedFn(torch.autograd.Function):
             for lo in range(0, n, NRX_MAX_FEATURES):
                 hi = min(n, lo + NRX_MAX_FEATURES)
                 arr = _fill_features(plan, lo, hi, grads, ctx.ins, ctx.ws, table_ptrs=gptrs, cache_key="bwd")
+                if DENSE_SMALL_DET and DENSE_BWD_SORTED is not False and B <= 4096:
+                    # the reference's own batch sizes: ONE deterministic launch (block per table: LDS sort + in-order sums) when every table
+                    # of the launch is fed by <= 4096 lookups; NRX_ERR_UNSUPPORTED (nothing enqueued) sends the launch to the atomics
+                    rc = lib.nrx_embed_bwd_small(arr, hi - lo, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, fmg, 1 if lo else 0, stream)
+                    if rc == 0:
+                        continue
+                    if rc != NRX_ERR_UNSUPPORTED:
+                        check(rc, "nrx_embed_bwd_small")
                 check(lib.nrx_embed_bwd(arr, hi - lo, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, fmg, stream),
                       "nrx_embed_bwd")
         return (None, None, None, None, None, None, None, *grads)
@@ -605,6 +613,7 @@ _plan_streams = {}
 # below) | sorted (always: bit-reproducible gradients at any batch) | atomic (never).  DENSE_BWD_SORTED: None = auto, True, False.
 DENSE_BWD_SORTED = {"sorted": True, "atomic": False}.get(os.environ.get("NRX_DENSE_BWD", "auto"))
 DENSE_SORTED_MIN = int(os.environ.get("NRX_DENSE_SORTED_MIN", 1 << 20))
+DENSE_SMALL_DET = os.environ.get("NRX_DENSE_SMALL", "1") != "0"       # auto mode, small launches: the one-launch deterministic kernel where it applies
 PLAN_AHEAD = True      # row-sparse training: plan the backward (sort, unique rows, segments) at FORWARD time on a side stream
 PLAN_AHEAD_MIN = int(os.environ.get("NRX_PLAN_AHEAD_MIN", 1 << 18))      # default-mode launches below this many lookups plan inline (one fused call)
 
