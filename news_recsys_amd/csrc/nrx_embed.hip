@@ -2253,11 +2253,16 @@ static_assert(sizeof(SmallDetArgs) <= 3840, "SmallDetArgs must fit the kernel-ar
 
 struct SdFeat { const float* weight; const void* ids; int64_t rows; int32_t out_col, wide_col, L, kind, flags, den_base; };
 
-template <int E>
+// Bitonic sort of s_key[0 .. N) by the first NT threads of the block (N / NT = E keys each, in registers; blocked: thread t ends up with
+// sorted positions t E .. t E + E - 1).  Partners inside the thread are exchanged in registers, inside the wavefront by shuffles; only the
+// stages that cross wavefronts go through LDS with barriers (6 of 45 stages at N = 512, 10 of 78 at N = 4096 -- all of them through LDS were
+// 10 us of a 22 us launch).  Every thread of the block calls this (the barriers); NT is a multiple of 64, so a wavefront is in or out whole.
+template <int E, bool WAVE = false>
 __device__ __forceinline__ void sd_sort(uint64_t* s_key, int N, int NT, int tid) {
+    const bool active = tid < NT;         // WAVE: called by ONE wavefront (NT = 64, tid = lane): no stage crosses wavefronts, no barrier
     uint64_t k[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) k[e] = s_key[tid * E + e];
+    for (int e = 0; e < E; ++e) k[e] = active ? s_key[tid * E + e] : ~0ull;
     for (int k2 = 2; k2 <= N; k2 <<= 1) {
         for (int j = k2 >> 1; j >= E; j >>= 1) {      // partner in another thread: thread tid ^ m, same slot e
             const int m = j / E;
@@ -2268,11 +2273,13 @@ __device__ __forceinline__ void sd_sort(uint64_t* s_key, int N, int NT, int tid)
                 for (int e = 0; e < E; ++e) o[e] = (uint64_t)__shfl_xor((unsigned long long)k[e], m, 64);
             } else {
                 __syncthreads();
+                if (active) {
 #pragma unroll
-                for (int e = 0; e < E; ++e) s_key[e * NT + tid] = k[e];
+                    for (int e = 0; e < E; ++e) s_key[e * NT + tid] = k[e];
+                }
                 __syncthreads();
 #pragma unroll
-                for (int e = 0; e < E; ++e) o[e] = s_key[e * NT + (tid ^ m)];
+                for (int e = 0; e < E; ++e) o[e] = active ? s_key[e * NT + (tid ^ m)] : ~0ull;
             }
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -2300,9 +2307,20 @@ __device__ __forceinline__ void sd_sort(uint64_t* s_key, int N, int NT, int tid)
             }
         }
     }
-    __syncthreads();
+    if (!WAVE) __syncthreads();
+    if (active) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) s_key[tid * E + e] = k[e];
+        for (int e = 0; e < E; ++e) s_key[tid * E + e] = k[e];
+    }
+}
+
+// position in a list that the whole wavefront appends to: one LDS atomic per wavefront
+__device__ __forceinline__ int sd_append(int* counter, bool pred, int lane) {
+    const uint64_t m = __ballot(pred);
+    int base = 0;
+    if (lane == 0 && m != 0) base = atomicAdd(counter, (int)__popcll(m));
+    base = __shfl(base, 0, 64);
+    return base + (int)__popcll(m & ((1ull << lane) - 1ull));
 }
 
 template <bool FM, bool UNAL>
@@ -2311,15 +2329,25 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
     extern __shared__ __attribute__((aligned(16))) unsigned char sd_smem[];
     __shared__ SdFeat s_f[NRX_MAX_FEATURES];
     __shared__ int s_wsum[SD_THREADS / 64];
-    __shared__ int s_nvalid, s_nuniq, s_nlong;
+    __shared__ int s_nuniq, s_nlong, s_nsingle, s_nmulti;
     __shared__ uint16_t s_long[SD_MAX / SD_LONG];      // rows with more than SD_LONG lookups (any order: a row's sum does not depend on who forms it)
-    const int N = a->n_pow2;
+    const int N = a->n_pow2, H = 2 * N;
+    // dynamic LDS (sd_smem_bytes): keys | hash table (row, count), later the keys of the rows looked up more than once | run starts |
+    // positions of the once-only lookups | positions of the others | masked-mean denominators
     uint64_t* s_key = reinterpret_cast<uint64_t*>(sd_smem);
-    uint16_t* s_us = reinterpret_cast<uint16_t*>(s_key + N);                 // [N + 2]: start of every run of equal rows, then the end
-    float* s_den = reinterpret_cast<float*>(sd_smem + (size_t)N * 8 + ((((size_t)N + 2) * 2 + 15) & ~(size_t)15));   // masked-mean denominators
+    uint32_t* s_hrow = reinterpret_cast<uint32_t*>(s_key + N);
+    int* s_hcnt = reinterpret_cast<int*>(s_hrow + H);
+    uint64_t* s_mkey = reinterpret_cast<uint64_t*>(s_hrow);                  // (the hash table is dead by then)
+    uint16_t* s_us = reinterpret_cast<uint16_t*>(s_hcnt + H);                // [N + 8]: start of every run of equal rows, then the end
+    uint16_t* s_slot = s_us;                                                 // hash slot of every position, until the lists are made (H <= 8192: a slot fits, 0xffff = none)
+    uint16_t* s_single = s_us + N + 8;
+    uint16_t* s_mpos = s_single + N;
+    float* s_den = reinterpret_cast<float*>(s_mpos + N);
     const int tid = threadIdx.x, s = blockIdx.x, NT = blockDim.x;        // NT: a power of two, 256 .. SD_THREADS, <= N
+    const int lane = tid & 63, wv = tid >> 6;
     const int f0 = a->seg_ptr[s], f1 = a->seg_ptr[s + 1];
     const int B = a->batch;
+    const int hshift = 32 - (31 - __clz(H));
     // ---- per-feature fields of this table; denominators of its masked-mean bags
     if (tid == 0) {                       // (uniform indices into the argument block: scalar loads)
         int db = 0;
@@ -2332,8 +2360,9 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
             s_f[f] = t;
             db += t.kind == NRX_BAG_MASKED_MEAN ? B : 0;
         }
-        s_nvalid = N; s_nuniq = 0;
+        s_nuniq = 0; s_nlong = 0; s_nsingle = 0; s_nmulti = 0;
     }
+    for (int i = tid; i < H; i += NT) { s_hrow[i] = 0xffffffffu; s_hcnt[i] = 0; }
     __syncthreads();
     int base = 0;
     for (int fi = f0; fi < f1; ++fi) {
@@ -2350,6 +2379,20 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
             bool ok = (uint64_t)id < rows && (id != 0 || keep0);
             if (ok && has_w) ok = w[i] != 0.f;                       // a masked position adds nothing
             s_key[base + i] = ok ? ((uint64_t)id << 32 | (uint32_t)f << 12 | (uint32_t)i) : ~0ull;
+            // count the row's lookups: open addressing at load factor <= 1/2; which slot a row lands in depends on the race, the counts do not
+            int sl = 0xffff;
+            if (ok) {
+                const uint32_t row = (uint32_t)id;
+                uint32_t h = (row * 2654435761u) >> hshift;
+                while (true) {
+                    const uint32_t old = atomicCAS(&s_hrow[h], 0xffffffffu, row);
+                    if (old == 0xffffffffu || old == row) break;
+                    h = (h + 1) & (uint32_t)(H - 1);
+                }
+                atomicAdd(&s_hcnt[h], 1);
+                sl = (int)h;
+            }
+            s_slot[base + i] = (uint16_t)sl;
         }
         if (kind == NRX_BAG_MASKED_MEAN) {
             float* den = s_den + ft.den_base;
@@ -2361,65 +2404,31 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
         }
         base += len;
     }
-    for (int i = base + tid; i < N; i += NT) s_key[i] = ~0ull;
-#if defined(NRX_SD_DEBUG) && NRX_SD_DEBUG == 4
+    for (int i = base + tid; i < N; i += NT) { s_key[i] = ~0ull; s_slot[i] = 0xffff; }
+    __syncthreads();
+#if defined(NRX_SD_STOP) && NRX_SD_STOP == 1
     return;
 #endif
-    // ---- bitonic sort of the N keys: E = N / NT keys per thread in registers (blocked: thread t owns sorted positions t E .. t E + E - 1).
-    // Partners inside the thread are exchanged in registers, inside the wavefront by shuffles; only the stages that cross wavefronts go
-    // through LDS with barriers (6 of 45 stages at N = 512, 10 of 78 at N = 4096 -- all 45 through LDS were 10 us of a 22 us launch)
-    __syncthreads();
-    if (N == NT) sd_sort<1>(s_key, N, NT, tid);
-    else if (N == 2 * NT) sd_sort<2>(s_key, N, NT, tid);
-    else sd_sort<4>(s_key, N, NT, tid);
-    __syncthreads();
-    // ---- runs of equal rows: thread t owns keys [t C, (t + 1) C)
-    const int C = N / NT;
-    int heads = 0;
-    for (int i = tid * C; i < (tid + 1) * C; ++i) {
-        const uint64_t kx = s_key[i];
-        const bool valid = kx != ~0ull;
-        const bool pv = i > 0 && s_key[i - 1] != ~0ull;
-        if (!valid && (i == 0 || pv)) s_nvalid = i;
-        heads += valid && (i == 0 || (uint32_t)(s_key[i - 1] >> 32) != (uint32_t)(kx >> 32));
-    }
-    int incl = heads;
-    const int lane = tid & 63, wv = tid >> 6;
+    // ---- how often is each row looked up?  A row looked up ONCE (nearly all of them at these batch sizes over the reference's tables) needs no
+    // ordering: its gradient is that one lookup's contribution.  Only the others are sorted -- the full sort was half of the launch.
+    const int CNT = N / NT;               // 1, 2 or 4 positions per thread
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
-    }
-    if (lane == 63) s_wsum[wv] = incl;
-    __syncthreads();
-    int rank = incl - heads;
-    for (int j = 0; j < wv; ++j) rank += s_wsum[j];
-    if (tid == NT - 1) s_nuniq = rank + heads;
-    for (int i = tid * C; i < (tid + 1) * C; ++i) {
-        const uint64_t kx = s_key[i];
-        if (kx != ~0ull && (i == 0 || (uint32_t)(s_key[i - 1] >> 32) != (uint32_t)(kx >> 32))) s_us[rank++] = (uint16_t)i;
+    for (int c = 0; c < 4; ++c) {
+        if (c < CNT) {                    // (uniform: every lane of the block takes part in the appends)
+            const int sl = s_slot[c * NT + tid];
+            const int n = sl != 0xffff ? s_hcnt[sl] : 0;
+            const int ps = sd_append(&s_nsingle, n == 1, lane);
+            if (n == 1) s_single[ps] = (uint16_t)(c * NT + tid);
+            const int pm = sd_append(&s_nmulti, n > 1, lane);
+            if (n > 1) s_mpos[pm] = (uint16_t)(c * NT + tid);
+        }
     }
     __syncthreads();
-    const int U = s_nuniq, n_valid = s_nvalid;
-    if (tid == 0) { s_us[U] = (uint16_t)n_valid; s_nlong = 0; }
-#if defined(NRX_SD_DEBUG) && NRX_SD_DEBUG == 3
+    const int n_single = s_nsingle, n_multi = s_nmulti;
+#if defined(NRX_SD_STOP) && NRX_SD_STOP == 2
     return;
 #endif
-#if defined(NRX_SD_DEBUG) && NRX_SD_DEBUG < 3
-    if (tid == 0) {
-        printf("blk %d f0 %d f1 %d N %d U %d n_valid %d\n", s, f0, f1, N, U, n_valid);
-        for (int fi = f0; fi < f1; ++fi) { const int f = a->seg_feat[fi]; printf(" f %d L %d kind %d w %p oc %d\n", f, s_f[f].L, s_f[f].kind, (void*)s_f[f].weight, s_f[f].out_col); }
-        for (int i = 0; i < 6; ++i) printf(" key[%d] %llx\n", i, (unsigned long long)s_key[i]);
-        printf(" key[nv-1] %llx\n", (unsigned long long)s_key[n_valid - 1]);
-    }
-#if NRX_SD_DEBUG == 2
-    return;
-#endif
-#endif
-    __syncthreads();
-    for (int u = tid; u < U; u += NT)
-        if ((int)s_us[u + 1] - (int)s_us[u] > SD_LONG) s_long[atomicAdd(&s_nlong, 1)] = (uint16_t)u;
-    // ---- reduction
+    // ---- per-lookup contribution (columns 4q .. 4q + 3) and the store of a finished row
     const int ql = a->seg_ql[s];
     const int Q = 1 << ql, q = tid & (Q - 1);
     const int64_t D = 4ll << ql;
@@ -2458,54 +2467,38 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
         }
         *dst = r;
     };
-    // R rows per lane group in flight: a row is a chain key -> upstream row -> store, ~1 us of latency each; one after the other that was
-    // 8 chains per group at B = 512 (33 us per launch at the C2 shape), 64 at B = 4096
-    const int G = NT >> ql, g = tid >> ql;
-    constexpr int R = 4;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int u0 = 0; u0 < U; u0 += G * R) {
-        int st[R], cnt[R];
-        float4 t0[R], t1[R];
+    // ---- rows looked up once: RS per lane group in flight (a row is a chain position -> key -> upstream row -> store, ~1 us of latency;
+    // one after the other that was 16 chains per group at B = 4096).  w0: the first wavefront that takes part.
+    auto singles = [&](int w0) {
+        constexpr int RS = 8;
+        const int Gs = (NT - 64 * w0) >> ql, gs = (tid - 64 * w0) >> ql;
+        for (int x0 = 0; x0 < n_single; x0 += Gs * RS) {
+            uint64_t key[RS];
+            float4 t[RS];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int u = u0 + r * G + g;
-            st[r] = 0; cnt[r] = 0;
-            if (u < U) {
-                st[r] = s_us[u];
-                cnt[r] = s_us[u + 1] - st[r];
-                if (cnt[r] > SD_LONG) cnt[r] = 0;           // the wavefront loop below
+            for (int r = 0; r < RS; ++r) {
+                const int x = x0 + r * Gs + gs;
+                key[r] = x < n_single ? s_key[s_single[x]] : ~0ull;
             }
-            t0[r] = cnt[r] > 0 ? contrib(s_key[st[r]]) : zero4;
-            t1[r] = cnt[r] > 1 ? contrib(s_key[st[r] + 1]) : zero4;
-        }
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (cnt[r] == 0) continue;
-            float4 acc = zero4;
-            acc.x += t0[r].x; acc.y += t0[r].y; acc.z += t0[r].z; acc.w += t0[r].w;
-            if (cnt[r] > 1) { acc.x += t1[r].x; acc.y += t1[r].y; acc.z += t1[r].z; acc.w += t1[r].w; }
-            const int en = st[r] + cnt[r];
-            for (int e = st[r] + 2; e < en; e += 4) {
-                float4 t[4];
+            for (int r = 0; r < RS; ++r) t[r] = key[r] != ~0ull ? contrib(key[r]) : zero4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) t[j] = e + j < en ? contrib(s_key[e + j]) : zero4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (e + j < en) { acc.x += t[j].x; acc.y += t[j].y; acc.z += t[j].z; acc.w += t[j].w; }
+            for (int r = 0; r < RS; ++r) {
+                if (key[r] == ~0ull) continue;
+                float4 acc = zero4;       // 0 + t, as the sorted form adds its first term
+                acc.x += t[r].x; acc.y += t[r].y; acc.z += t[r].z; acc.w += t[r].w;
+                store((uint32_t)(key[r] >> 32), acc);
             }
-            store((uint32_t)(s_key[st[r]] >> 32), acc);
         }
-    }
+    };
     const int gg = lane >> ql, G64 = 64 >> ql;
-    __syncthreads();
-    const int n_long = s_nlong;
-    for (int li = wv; li < n_long; li += NT / 64) {
-        const int u = s_long[li];
-        const int st = s_us[u], en = s_us[u + 1];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // a run of more than SD_LONG lookups of one row, by a whole wavefront: its lane groups stride the run, then a fixed xor tree
+    auto long_run = [&](const uint64_t* keys, int st, int en) {
+        float4 acc = zero4;
         for (int e = st + gg; e < en; e += 2 * G64) {
-            const float4 t0 = contrib(s_key[e]);
-            const float4 t1 = e + G64 < en ? contrib(s_key[e + G64]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 t0 = contrib(keys[e]);
+            const float4 t1 = e + G64 < en ? contrib(keys[e + G64]) : zero4;
             acc.x += t0.x; acc.y += t0.y; acc.z += t0.z; acc.w += t0.w;
             if (e + G64 < en) { acc.x += t1.x; acc.y += t1.y; acc.z += t1.z; acc.w += t1.w; }
         }
@@ -2513,9 +2506,145 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
             acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
             acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
         }
-        if (gg == 0) store((uint32_t)(s_key[st] >> 32), acc);
+        if (gg == 0) store((uint32_t)(keys[st] >> 32), acc);
+    };
+    // the runs of <= SD_LONG lookups: lane group g_ of G_ takes runs g_, g_ + G_, ..., R at a time (their first two terms in flight together),
+    // each run added in order
+    auto runs = [&](const uint64_t* keys, int U_, int G_, int g_) {
+        constexpr int R = 4;
+        for (int u0 = 0; u0 < U_; u0 += G_ * R) {
+            int st[R], cnt[R];
+            float4 t0[R], t1[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int u = u0 + r * G_ + g_;
+                st[r] = 0; cnt[r] = 0;
+                if (u < U_) {
+                    st[r] = s_us[u];
+                    cnt[r] = s_us[u + 1] - st[r];
+                    if (cnt[r] > SD_LONG) cnt[r] = 0;       // long_run's
+                }
+                t0[r] = cnt[r] > 0 ? contrib(keys[st[r]]) : zero4;
+                t1[r] = cnt[r] > 1 ? contrib(keys[st[r] + 1]) : zero4;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (cnt[r] == 0) continue;
+                float4 acc = zero4;
+                acc.x += t0[r].x; acc.y += t0[r].y; acc.z += t0[r].z; acc.w += t0[r].w;
+                if (cnt[r] > 1) { acc.x += t1[r].x; acc.y += t1[r].y; acc.z += t1[r].z; acc.w += t1[r].w; }
+                const int en = st[r] + cnt[r];
+                for (int e = st[r] + 2; e < en; e += 4) {
+                    float4 t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[j] = e + j < en ? contrib(keys[e + j]) : zero4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (e + j < en) { acc.x += t[j].x; acc.y += t[j].y; acc.z += t[j].z; acc.w += t[j].w; }
+                }
+                store((uint32_t)(keys[st[r]] >> 32), acc);
+            }
+        }
+    };
+    if (n_multi <= 64) {
+        // the usual case at these batch sizes: a handful of lookups share their row with another.  Wavefront 0 sorts them with shuffles
+        // alone -- no barrier -- and adds their runs while the others store the once-only rows; the two parts used to run one after the
+        // other.  (Up to 256 keys, 4 per lane, through the general code was tried: slower -- one wavefront is then the tail of the launch)
+        if (wv != 0) { singles(1); return; }
+        if (n_multi == 0) return;
+        uint64_t k = lane < n_multi ? s_key[s_mpos[lane]] : ~0ull;
+        for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)k, j, 64);
+                const bool take_min = ((lane & j) == 0) == ((lane & k2) == 0);
+                const uint64_t lo = k < o ? k : o, hi = k < o ? o : k;
+                k = take_min ? lo : hi;
+            }
+        }
+        const uint32_t row = (uint32_t)(k >> 32);
+        const uint32_t prow = (uint32_t)__shfl_up((int)row, 1, 64);
+        const bool head = k != ~0ull && (lane == 0 || prow != row);
+        const uint64_t hm = __ballot(head);
+        const int n_rows = (int)__popcll(hm);
+        s_mkey[lane] = k;                 // (one wavefront: its LDS accesses complete in program order)
+        if (head) s_us[__popcll(hm & ((1ull << lane) - 1ull))] = (uint16_t)lane;
+        if (lane == 0) s_us[n_rows] = (uint16_t)n_multi;
+        for (int r = gg; r < n_rows; r += G64) {
+            const int st = s_us[r], en = s_us[r + 1];
+            if (en - st > SD_LONG) continue;
+            float4 acc = zero4;
+            for (int e = st; e < en; e += 4) {
+                float4 t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = e + j < en ? contrib(s_mkey[e + j]) : zero4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (e + j < en) { acc.x += t[j].x; acc.y += t[j].y; acc.z += t[j].z; acc.w += t[j].w; }
+            }
+            store((uint32_t)(s_mkey[st] >> 32), acc);
+        }
+        for (int r = 0; r < n_rows; ++r) {
+            const int st = s_us[r], en = s_us[r + 1];
+            if (en - st > SD_LONG) long_run(s_mkey, st, en);
+        }
+        return;
+    }
+    singles(0);
+#if defined(NRX_SD_STOP) && NRX_SD_STOP == 3
+    return;
+#endif
+    // ---- the other rows: sort their lookups by (row, feature, position), find the runs of equal rows, add each run in that order
+    int M = 64;
+    while (M < n_multi) M <<= 1;
+    for (int i = tid; i < M; i += NT) s_mkey[i] = i < n_multi ? s_key[s_mpos[i]] : ~0ull;
+    __syncthreads();
+    const int NTs = NT < M ? NT : M;
+    if (M == NTs) sd_sort<1>(s_mkey, M, NTs, tid);
+    else if (M == 2 * NTs) sd_sort<2>(s_mkey, M, NTs, tid);
+    else sd_sort<4>(s_mkey, M, NTs, tid);
+    __syncthreads();
+    const int C = M / NTs;                // thread t < NTs owns sorted keys [t C, (t + 1) C)
+    int heads = 0;
+    if (tid < NTs) {
+        for (int i = tid * C; i < (tid + 1) * C; ++i) {
+            const uint64_t kx = s_mkey[i];
+            heads += kx != ~0ull && (i == 0 || (uint32_t)(s_mkey[i - 1] >> 32) != (uint32_t)(kx >> 32));
+        }
+    }
+    int incl = heads;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int rank = incl - heads;
+    for (int j = 0; j < wv; ++j) rank += s_wsum[j];
+    if (tid == NT - 1) s_nuniq = rank + heads;
+    if (tid < NTs) {
+        for (int i = tid * C; i < (tid + 1) * C; ++i) {
+            const uint64_t kx = s_mkey[i];
+            if (kx != ~0ull && (i == 0 || (uint32_t)(s_mkey[i - 1] >> 32) != (uint32_t)(kx >> 32))) s_us[rank++] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+    const int U = s_nuniq;
+    if (tid == 0) s_us[U] = (uint16_t)n_multi;
+    __syncthreads();
+    for (int u = tid; u < U; u += NT)
+        if ((int)s_us[u + 1] - (int)s_us[u] > SD_LONG) s_long[atomicAdd(&s_nlong, 1)] = (uint16_t)u;
+    runs(s_mkey, U, NT >> ql, tid >> ql);
+    __syncthreads();
+    const int n_long = s_nlong;
+    for (int li = wv; li < n_long; li += NT / 64) {
+        const int u = s_long[li];
+        long_run(s_mkey, s_us[u], s_us[u + 1]);
     }
 }
+
+// dynamic LDS of embed_bwd_small_det_kernel for N keys and n_den denominators (the layout at the top of the kernel)
+static size_t sd_smem_bytes(size_t N, size_t n_den) { return N * 8 + 2 * N * 8 + (N + 8) * 2 + N * 2 + N * 2 + n_den * 4 + 16; }
 
 static int check_fm_grad(const nrx_fm_grad_t* fm, const nrx_feature_t* feats, int32_t n_feats, const char* who) {
     if (fm == nullptr || fm->g_fm == nullptr) return NRX_OK;
@@ -2661,8 +2790,16 @@ extern "C" int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, 
     a.g_out = g_out; a.out_ld = out_ld; a.g_wide = g_wide; a.wide_ld = wide_ld;
     a.g_fm = any_fm ? fm->g_fm : nullptr; a.fm_sums = any_fm ? fm->fm_sums : nullptr; a.sums_ld = any_fm ? fm->sums_ld : 0;
     a.feat = any_fm ? fm->feat : nullptr; a.feat_ld = any_fm ? fm->feat_ld : 0;
-    const size_t smem = (size_t)N * 8 + ((((size_t)N + 2) * 2 + 15) & ~(size_t)15) + (size_t)max_den * 4 + 16;
+    const size_t smem = sd_smem_bytes((size_t)N, (size_t)max_den);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static const bool lds_ok = [] {          // N = 4096 takes ~140 KB of the CU's 160 KB: above the 64 KB a kernel gets without asking
+        const int most = (int)sd_smem_bytes(SD_MAX, SD_MAX);
+        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_small_det_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_small_det_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_small_det_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
+        return ok;
+    }();
+    if (!lds_ok && smem > 60 * 1024) return NRX_ERR_UNSUPPORTED;
     if (any_fm) hipLaunchKernelGGL((embed_bwd_small_det_kernel<true, false>), dim3(n_seg), dim3(nt), smem, st, a);
     else if (unal) hipLaunchKernelGGL((embed_bwd_small_det_kernel<false, true>), dim3(n_seg), dim3(nt), smem, st, a);
     else hipLaunchKernelGGL((embed_bwd_small_det_kernel<false, false>), dim3(n_seg), dim3(nt), smem, st, a);

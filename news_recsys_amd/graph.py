@@ -16,8 +16,9 @@ The reference's error contract survives the capture (round 4): torch on CPU rais
 (src/model/BaseModel/base_model.py:271), and so does a replay -- one call late.  The step is captured in the DEFERRED check mode: every
 gather kernel records an offending id in a host-mapped status word (no read-back, nothing for the graph to replay but the kernel itself); the
 next `__call__`, `check()` or `ops.flush_index_checks()` reads that word on the host and raises IndexError naming the feature.  With
-`deterministic=True` the dense table gradients come from the sorted reduction at ANY batch size (planned inline, count read on the device):
-replays are bit-reproducible run to run, where the float-atomic scatter of small batches is not."""
+`deterministic=True` the dense table gradients come from a deterministic reduction at ANY batch size -- the one-launch small kernel
+(nrx_embed_bwd_small) where every table of the launch takes <= 4096 lookups, else the planned sorted reduction (planned inline, count read on the
+device): replays are bit-reproducible run to run, where the float-atomic scatter is not."""
 from __future__ import annotations
 
 from typing import Callable, Dict
@@ -39,7 +40,8 @@ class GraphedStep:
         ops.flush_index_checks()
         ops.set_index_check("deferred")            # the check stays ON inside the graph: a status word the kernels write, read on the host later
         if deterministic:
-            ops.DENSE_BWD_SORTED = True            # the choice is baked into the captured launches
+            ops.DENSE_BWD_SORTED = "det"           # the choice is baked into the captured launches: the one-launch deterministic kernel
+                                                   # where it applies (tables fed by <= 4096 lookups each), else the planned reduction
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

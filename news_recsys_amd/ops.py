@@ -396,7 +396,7 @@ def _dense_sorted_ok(plan, tables, sparse_grad, B, csr_ok=False) -> bool:
         if s.flags & ((0 if csr_ok else NRX_FEAT_BAG_CSR) | NRX_FEAT_ROW0_IS_DATA):      # (the planner's row 0 never trains)
             return False
         lookups += max(1, s.bag_len)
-    return lookups > 0 and (DENSE_BWD_SORTED is True or B * lookups >= DENSE_SORTED_MIN)
+    return lookups > 0 and (DENSE_BWD_SORTED in (True, "det") or B * lookups >= DENSE_SORTED_MIN)
 
 
 class _EmbedFn(torch.autograd.Function):
@@ -571,22 +571,33 @@ class _EmbedFn(torch.autograd.Function):
         if ctx.sparse_grad:
             return (None, None, None, None, None, None, None, *_sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg))
         grads = _zero_grad_tables(_table_meta(ctx))
+        has_up = g_out is not None or g_wide is not None or fmg is not None
+        n = len(plan.slots)
+
+        def small(lo, hi, arr):
+            """The reference's own batch sizes: ONE deterministic launch (nrx_embed_bwd_small: block per table, the lookups of rows hit more
+            than once sorted in LDS, in-order sums) when every table of the launch is fed by <= 4096 lookups; NRX_ERR_UNSUPPORTED (nothing
+            enqueued) sends the launch on to the caller's other path."""
+            if not (DENSE_SMALL_DET and B <= 4096):
+                return False
+            rc = lib.nrx_embed_bwd_small(arr, hi - lo, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, fmg, 1 if lo else 0, stream)
+            if rc != 0 and rc != NRX_ERR_UNSUPPORTED:
+                check(rc, "nrx_embed_bwd_small")
+            return rc == 0
+
         if getattr(ctx, "dense_sorted", False) and B > 0 and n_tables <= NRX_MAX_FEATURES:
-            _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg, dense_into=grads)
-        elif B > 0 and (g_out is not None or g_wide is not None or fmg is not None):
+            # "deterministic" (GraphedStep(deterministic=True)): the small kernel where it applies (a single launch of <= 64 features), else
+            # the planned reduction -- both bit-reproducible run to run; "sorted" always takes the planned reduction
+            if not (DENSE_BWD_SORTED == "det" and has_up and n <= NRX_MAX_FEATURES and
+                    small(0, n, _fill_features(plan, 0, n, grads, ctx.ins, ctx.ws, table_ptrs=[g.data_ptr() for g in grads], cache_key="bwd"))):
+                _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg, dense_into=grads)
+        elif B > 0 and has_up:
             gptrs = [g.data_ptr() for g in grads]
-            n = len(plan.slots)
             for lo in range(0, n, NRX_MAX_FEATURES):
                 hi = min(n, lo + NRX_MAX_FEATURES)
                 arr = _fill_features(plan, lo, hi, grads, ctx.ins, ctx.ws, table_ptrs=gptrs, cache_key="bwd")
-                if DENSE_SMALL_DET and DENSE_BWD_SORTED is not False and B <= 4096:
-                    # the reference's own batch sizes: ONE deterministic launch (block per table: LDS sort + in-order sums) when every table
-                    # of the launch is fed by <= 4096 lookups; NRX_ERR_UNSUPPORTED (nothing enqueued) sends the launch to the atomics
-                    rc = lib.nrx_embed_bwd_small(arr, hi - lo, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, fmg, 1 if lo else 0, stream)
-                    if rc == 0:
-                        continue
-                    if rc != NRX_ERR_UNSUPPORTED:
-                        check(rc, "nrx_embed_bwd_small")
+                if DENSE_BWD_SORTED is not False and small(lo, hi, arr):
+                    continue
                 check(lib.nrx_embed_bwd(arr, hi - lo, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, fmg, stream),
                       "nrx_embed_bwd")
         return (None, None, None, None, None, None, None, *grads)
@@ -610,8 +621,11 @@ SPARSE_BWD_SYNC_FREE = False   # True: size the reduction for the worst case and
 
 _plan_streams = {}
 # default-mode (dense) table grads.  NRX_DENSE_BWD = auto (default: sorted reduction from DENSE_SORTED_MIN lookups per launch on, float atomics
-# below) | sorted (always: bit-reproducible gradients at any batch) | atomic (never).  DENSE_BWD_SORTED: None = auto, True, False.
-DENSE_BWD_SORTED = {"sorted": True, "atomic": False}.get(os.environ.get("NRX_DENSE_BWD", "auto"))
+# below -- except that launches whose tables each take <= 4096 lookups, the reference's own batch sizes, use the one-launch deterministic kernel
+# nrx_embed_bwd_small) | sorted (always the planned reduction: bit-reproducible gradients at any batch) | deterministic (bit-reproducible by
+# the cheaper of the two: the small kernel where it applies, else the planned reduction) | atomic (never).
+# DENSE_BWD_SORTED: None = auto, True = sorted, "det" = deterministic, False = atomic.
+DENSE_BWD_SORTED = {"sorted": True, "atomic": False, "deterministic": "det"}.get(os.environ.get("NRX_DENSE_BWD", "auto"))
 DENSE_SORTED_MIN = int(os.environ.get("NRX_DENSE_SORTED_MIN", 1 << 20))
 DENSE_SMALL_DET = os.environ.get("NRX_DENSE_SMALL", "1") != "0"       # auto mode, small launches: the one-launch deterministic kernel where it applies
 PLAN_AHEAD = True      # row-sparse training: plan the backward (sort, unique rows, segments) at FORWARD time on a side stream

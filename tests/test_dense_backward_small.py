@@ -56,7 +56,7 @@ class _Counting:
 
 
 def _grads(plan, tables, inputs, weights, ups, mode, monkeypatch):
-    monkeypatch.setattr(ops, "DENSE_BWD_SORTED", {"auto": None, "atomic": False}[mode])
+    monkeypatch.setattr(ops, "DENSE_BWD_SORTED", {"auto": None, "atomic": False, "det": "det"}[mode])
     cnt = _Counting(_lib.load())
     monkeypatch.setattr(_lib, "load", lambda: cnt)
     ts = [t.clone().requires_grad_() for t in tables]
@@ -242,3 +242,23 @@ def test_small_backward_c_abi_direct_row0_data_and_out_of_range_ids():
     torch.cuda.synchronize()
     for g, b in zip(grads, before):
         assert torch.equal(g, b)
+
+
+def test_deterministic_mode_takes_the_small_kernel_where_it_applies_and_the_planned_reduction_elsewhere(monkeypatch):
+    """NRX_DENSE_BWD=deterministic (what GraphedStep(deterministic=True) captures): bit-reproducible gradients by the cheaper kernel --
+    nrx_embed_bwd_small for launches inside its shapes, the planned sorted reduction for the others; never the atomics."""
+    rng = np.random.default_rng(14)
+    for B, share, expect_small in ((700, False, True), (2000, True, False)):
+        n, rows, D = 3, 900, 16
+        slots = [ops.Slot(f"f{i}", NRX_SPARSE, 0 if share else i, D, 0, i * D) for i in range(n)]
+        plan = ops.EmbedPlan(slots, out_width=n * D)
+        tables = [torch.from_numpy(rng.standard_normal((rows, D)).astype(np.float32)).to(DEV) for _ in range(1 if share else n)]
+        inputs = [torch.from_numpy(_ids(rng, rows, (B,), "zipf")).to(DEV) for _ in range(n)]
+        ups = (torch.from_numpy(rng.standard_normal((B, n * D)).astype(np.float32)).to(DEV), None, None)
+        a, ca = _grads(plan, tables, inputs, [None] * n, ups, "det", monkeypatch)
+        b, _ = _grads(plan, tables, inputs, [None] * n, ups, "det", monkeypatch)
+        d, _ = _grads(plan, tables, inputs, [None] * n, ups, "atomic", monkeypatch)
+        assert ca.atomic == 0 and (ca.small_ok >= 1) == expect_small
+        for ga, gb, gd in zip(a, b, d):
+            assert torch.equal(ga.view(torch.int32), gb.view(torch.int32))
+            torch.testing.assert_close(ga, gd, rtol=1e-4, atol=1e-4)

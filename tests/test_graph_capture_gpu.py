@@ -210,9 +210,9 @@ def test_deterministic_graphed_step_has_bit_reproducible_table_gradients():
     for g0, g1, g2 in zip(*runs):
         assert torch.equal(g0.view(torch.int32), g1.view(torch.int32)) and torch.equal(g0.view(torch.int32), g2.view(torch.int32))
     prev = ops.DENSE_BWD_SORTED
-    ops.DENSE_BWD_SORTED = True
+    ops.DENSE_BWD_SORTED = "det"
     try:
-        step(batches[1])                                        # eager, sorted path
+        step(batches[1])                                        # eager, the same deterministic mode
         torch.cuda.synchronize()
         for g0, t in zip(runs[0], tabs):
             assert torch.equal(g0.view(torch.int32), t.grad.view(torch.int32))
