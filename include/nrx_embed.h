@@ -148,9 +148,9 @@ NRX_API int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_t b
  * same bits run to run, where nrx_embed_bwd's float atomics differ in the last place.  Arguments as nrx_embed_bwd, plus `accumulate`:
  * 0 = every gradient row the launch touches is STORED (pre-zeroed tables, this call their only writer -- no read of the old row),
  * 1 = added to what is there (a table fed by an earlier call too).  Returns NRX_ERR_UNSUPPORTED with nothing enqueued when the launch is outside its shapes (the caller
- * then takes nrx_embed_bwd or the planned reduction): every table fed by <= 4096 lookups of this call, dim in {4, 8, 16, ... 256},
- * 16-byte-aligned gradient rows, padded (not CSR) bags, rows < 2^32, ids of one width; FM folding only with 16-byte-aligned upstream
- * columns and no wide feature.  Replaces, for those shapes, autograd's index_add_ of base_model.py:164's embeddings on the CPU
+ * then takes nrx_embed_bwd or the planned reduction): every table fed by <= 4096 lookups of this call, dim <= 256, padded (not CSR)
+ * bags, rows < 2^32, ids of one width.  (Widths 4 * 2^k on 16-byte-aligned rows and columns move 16 bytes per lane; any other width or
+ * alignment -- the reference's 16 + 1-column wide features, LR's dim-1 tables -- goes element by element.)  Replaces, for those shapes, autograd's index_add_ of base_model.py:164's embeddings on the CPU
  * (deterministic there too).                                                                                                      */
 NRX_API int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
                   const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,

@@ -2243,7 +2243,8 @@ struct SmallDetArgs {
     int32_t meta[NRX_MAX_FEATURES];
     uint8_t seg_feat[NRX_MAX_FEATURES];     // feature indices grouped by table, ascending inside a table
     uint8_t seg_ptr[NRX_MAX_FEATURES + 1];  // block s owns seg_feat[seg_ptr[s] .. seg_ptr[s + 1])
-    uint8_t seg_ql[NRX_MAX_FEATURES];       // log2(dim / 4) of block s's table
+    uint8_t seg_ql[NRX_MAX_FEATURES];       // log2 of the lanes per row of block s's table (dim / 4, rounded up to a power of two)
+    int32_t seg_dim[NRX_MAX_FEATURES];      // its row width
     const float* g_out; int64_t out_ld;
     const float* g_wide; int64_t wide_ld;
     const float* g_fm; const float* fm_sums; int64_t sums_ld; const float* feat; int64_t feat_ld;
@@ -2323,7 +2324,7 @@ __device__ __forceinline__ int sd_append(int* counter, bool pred, int lane) {
     return base + (int)__popcll(m & ((1ull << lane) - 1ull));
 }
 
-template <bool FM, bool UNAL>
+template <bool FM, bool GEN>
 __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const SmallDetArgs args_in_kernarg) {
     const NRX_CONST SmallDetArgs* a = nrx_kernarg<SmallDetArgs>();
     extern __shared__ __attribute__((aligned(16))) unsigned char sd_smem[];
@@ -2431,7 +2432,7 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
     // ---- per-lookup contribution (columns 4q .. 4q + 3) and the store of a finished row
     const int ql = a->seg_ql[s];
     const int Q = 1 << ql, q = tid & (Q - 1);
-    const int64_t D = 4ll << ql;
+    const int64_t D = a->seg_dim[s];      // GEN: any width (the reference's wide features are 4 k + 1 wide), any alignment, element by element
     NRX_GLOBAL float* gtab = nrx_gmut<float>(a->grad[a->seg_feat[f0]]);
     auto contrib = [&](uint64_t key) -> float4 {
         const uint32_t p = (uint32_t)key;
@@ -2445,8 +2446,32 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
             else if (ft.kind == NRX_BAG_MEAN) sc = 1.0f / (float)ft.L;
             else if (ft.weight != nullptr) sc = nrx_gconst<float>(ft.weight)[i];
         }
-        float4 t = upstream_chunk<UNAL>(a->g_out, a->out_ld, a->g_wide, a->wide_ld, ft.out_col, ft.wide_col, b, q);
-        if (FM) {
+        float4 t;
+        if (GEN) {
+            float e[4] = {0.f, 0.f, 0.f, 0.f};
+            const NRX_GLOBAL float* go = nrx_gconst<float>(a->g_out);
+            const int shift = ft.wide_col >= 0 ? 1 : 0;          // a wide feature: column 0 comes from the wide gradient, the deep block is one narrower
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * q + j;
+                if (k < D) {
+                    if (shift && k == 0) e[j] = a->g_wide ? nrx_gconst<float>(a->g_wide)[b * a->wide_ld + ft.wide_col] : 0.f;
+                    else e[j] = go ? go[b * a->out_ld + ft.out_col + k - shift] : 0.f;
+                    if (FM) {
+                        if (ft.flags & 1) {           // d fm / d field: column 0 -> 1, column k -> S_k - v_k (fm_fold4's arithmetic)
+                            const float gf = nrx_gconst<float>(a->g_fm)[b];
+                            if (k == 0) e[j] += gf;
+                            else e[j] = __builtin_fmaf(gf, nrx_gconst<float>(a->fm_sums)[b * a->sums_ld + k] -
+                                                               nrx_gconst<float>(a->feat)[b * a->feat_ld + ft.out_col + k], e[j]);
+                        }
+                    }
+                }
+            }
+            t = make_float4(e[0], e[1], e[2], e[3]);
+        } else {
+            t = upstream_chunk<false>(a->g_out, a->out_ld, a->g_wide, a->wide_ld, ft.out_col, ft.wide_col, b, q);
+        }
+        if (FM && !GEN) {
             if (ft.flags & 1) {
                 const float gf = nrx_gconst<float>(a->g_fm)[b];
                 const float4 S = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
@@ -2458,6 +2483,14 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
     };
     const bool add_to = a->add_to != 0;
     auto store = [&](uint32_t row, float4 acc) {
+        if (GEN) {
+            NRX_GLOBAL float* d1 = gtab + (int64_t)row * D + 4 * q;
+            const float e[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * q + j < D) d1[j] = add_to ? d1[j] + e[j] : e[j];
+            return;
+        }
         NRX_GLOBAL nrx_f32x4* dst = reinterpret_cast<NRX_GLOBAL nrx_f32x4*>(gtab + (int64_t)row * D) + q;
         nrx_f32x4 r;
         r.x = acc.x; r.y = acc.y; r.z = acc.z; r.w = acc.w;
@@ -2708,10 +2741,11 @@ extern "C" int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_
     return NRX_OK;
 }
 
-// The deterministic form of nrx_embed_bwd for small launches (embed_bwd_small_det_kernel): same arguments, same accumulate-into-the-table
-// contract, NRX_ERR_UNSUPPORTED (nothing enqueued, nrx_last_error untouched) when the launch is outside its shapes -- the caller then takes
-// nrx_embed_bwd.  Shapes: every table fed by <= 4096 lookups of this call, dim in {4, 8, 16, .. 256} with 16-byte-aligned gradient rows,
-// padded (not CSR) bags, rows < 2^32, ids of one width; FM folding only with 16-byte-aligned upstream columns and no wide feature.
+// The deterministic form of nrx_embed_bwd for small launches (embed_bwd_small_det_kernel): same arguments + accumulate,
+// NRX_ERR_UNSUPPORTED (nothing enqueued, nrx_last_error untouched) when the launch is outside its shapes -- the caller then takes
+// nrx_embed_bwd.  Shapes: every table fed by <= 4096 lookups of this call, dim <= 256, padded (not CSR) bags, rows < 2^32, ids of one width.
+// Widths 4 * 2^k with 16-byte-aligned rows and upstream columns take the 16-byte form of the kernel, everything else (the reference's
+// 16 + 1-column wide features, LR's dim-1 tables) the element-by-element form.
 extern "C" int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
                                    const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
                                    const nrx_fm_grad_t* fm, int32_t accumulate, void* stream) {
@@ -2745,9 +2779,10 @@ extern "C" int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, 
         if ((f.flags & NRX_FEAT_BAG_CSR) || f.rows >= (1ll << 32) || (f.index_bits != 32 && f.index_bits != 64)) return NRX_ERR_UNSUPPORTED;
         if (bits == 0) bits = f.index_bits;
         if (bits != f.index_bits) return NRX_ERR_UNSUPPORTED;
-        int ql = -1;
-        for (int k = 0; k <= 6; ++k) if (f.dim == (4 << k)) ql = k;
-        if (ql < 0 || (reinterpret_cast<uintptr_t>(f.table) & 15) != 0) return NRX_ERR_UNSUPPORTED;
+        if (f.dim > 256) return NRX_ERR_UNSUPPORTED;
+        bool pow2 = false;
+        for (int k = 0; k <= 6; ++k) pow2 |= f.dim == (4 << k);
+        if (!pow2 || (reinterpret_cast<uintptr_t>(f.table) & 15) != 0) unal = true;      // element-by-element form
         const int64_t len = batch * (bag ? f.bag_len : 1);
         if (len > SD_MAX || (bag && f.bag_len > SD_MAX)) return NRX_ERR_UNSUPPORTED;
         int sgi = -1;
@@ -2765,17 +2800,18 @@ extern "C" int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, 
         a.out_col[i] = f.out_col; a.wide_col[i] = f.wide_col; a.meta[i] = (bag ? f.bag_len : 0) | f.kind << 16 | ((isfm ? 1 : 0) | ((f.flags & NRX_FEAT_ROW0_IS_DATA) ? 2 : 0)) << 24;
     }
     if (n_seg == 0) return NRX_OK;
-    if (any_fm && (unal || (reinterpret_cast<uintptr_t>(fm->fm_sums) & 15) != 0 || (reinterpret_cast<uintptr_t>(fm->feat) & 15) != 0 ||
+    if (any_fm && ((reinterpret_cast<uintptr_t>(fm->fm_sums) & 15) != 0 || (reinterpret_cast<uintptr_t>(fm->feat) & 15) != 0 ||
                    (fm->sums_ld & 3) != 0 || (fm->feat_ld & 3) != 0))
-        return NRX_ERR_UNSUPPORTED;
+        unal = true;                           // the element-by-element form folds FM terms at any alignment
     int64_t max_n = 0, max_den = 0;
     int k = 0;
     for (int sgi = 0; sgi < n_seg; ++sgi) {
         a.seg_ptr[sgi] = (uint8_t)k;
         for (int i = 0; i < n_feats; ++i) if (seg_of[i] == sgi) a.seg_feat[k++] = (uint8_t)i;
         int ql = 0;
-        while ((4 << ql) != seg_dim[sgi]) ++ql;
+        while ((4 << ql) < seg_dim[sgi]) ++ql;
         a.seg_ql[sgi] = (uint8_t)ql;
+        a.seg_dim[sgi] = seg_dim[sgi];
         if (seg_n[sgi] > max_n) max_n = seg_n[sgi];
         if (seg_den[sgi] > max_den) max_den = seg_den[sgi];
     }
@@ -2795,12 +2831,14 @@ extern "C" int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, 
     static const bool lds_ok = [] {          // N = 4096 takes ~140 KB of the CU's 160 KB: above the 64 KB a kernel gets without asking
         const int most = (int)sd_smem_bytes(SD_MAX, SD_MAX);
         bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_small_det_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_small_det_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
         ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_small_det_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
         ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_small_det_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
         return ok;
     }();
     if (!lds_ok && smem > 60 * 1024) return NRX_ERR_UNSUPPORTED;
-    if (any_fm) hipLaunchKernelGGL((embed_bwd_small_det_kernel<true, false>), dim3(n_seg), dim3(nt), smem, st, a);
+    if (any_fm && unal) hipLaunchKernelGGL((embed_bwd_small_det_kernel<true, true>), dim3(n_seg), dim3(nt), smem, st, a);
+    else if (any_fm) hipLaunchKernelGGL((embed_bwd_small_det_kernel<true, false>), dim3(n_seg), dim3(nt), smem, st, a);
     else if (unal) hipLaunchKernelGGL((embed_bwd_small_det_kernel<false, true>), dim3(n_seg), dim3(nt), smem, st, a);
     else hipLaunchKernelGGL((embed_bwd_small_det_kernel<false, false>), dim3(n_seg), dim3(nt), smem, st, a);
     NRX_LAUNCH_CHECK("nrx_embed_bwd_small");

@@ -101,6 +101,15 @@ CASES = [
     ("wide16_zipf", 16, 6, 30000, 3000, False, (0, 5), "zipf"),
     ("wide16_hot", 16, 4, 20, 1000, False, (1,), "hot"),
     ("one_sample", 16, 3, 10, 1, True, (), "uniform"),
+    # widths that are not 4 * 2^k (the reference's wide features are 16 + 1 columns: cf_widedeep_small.yaml) and rows that are not
+    # 16-byte aligned: the element-by-element form of the kernel
+    ("odd_dim_10", 10, 4, 700, 900, False, (), "uniform"),
+    ("wide17_zipf", 17, 5, 300, 1000, False, (1, 2, 4), "zipf"),
+    ("wide17_hot", 17, 3, 30, 2000, False, (0,), "hot"),
+    ("dim_1", 1, 3, 50, 400, False, (), "uniform"),
+    ("dim_200", 200, 2, 40, 150, False, (), "hot"),
+    ("lr_dim_1_fm", 1, 6, 60, 500, True, (), "uniform"),          # LR: dim-1 tables, the row sum is the FM epilogue's first-order term
+    ("fm_dim_12", 12, 4, 300, 600, True, (), "zipf"),
 ]
 
 
@@ -182,9 +191,9 @@ def test_small_backward_two_launch_groups_add_into_shared_tables(monkeypatch):
 
 def test_launches_outside_the_small_shapes_keep_the_atomic_scatter(monkeypatch):
     """A table fed by more than 4096 lookups of the launch (here 3 features x 2000 samples): NRX_ERR_UNSUPPORTED, nothing enqueued,
-    the step takes nrx_embed_bwd as before; an odd width likewise."""
+    the step takes nrx_embed_bwd as before; a row wider than 256 columns likewise."""
     rng = np.random.default_rng(8)
-    for D, B, share in ((16, 2000, True), (10, 300, False)):
+    for D, B, share in ((16, 2000, True), (264, 300, False)):
         n, rows = 3, 900
         slots = [ops.Slot(f"f{i}", NRX_SPARSE, 0 if share else i, D, 0, i * D) for i in range(n)]
         plan = ops.EmbedPlan(slots, out_width=n * D)
@@ -235,7 +244,7 @@ def test_small_backward_c_abi_direct_row0_data_and_out_of_range_ids():
     touched[torch.from_numpy(ids[1][ok1]).to(DEV)] = True
     assert torch.equal(grads[1][touched], first[touched]) and bool((grads[1][~touched] == 7.0).all())
     before = [g.clone() for g in grads]
-    arr[0].dim = arr[1].dim = 12              # not 4 << k
+    arr[0].dim = arr[1].dim = 260             # wider than 256 columns
     assert lib.nrx_embed_bwd_small(arr, 2, B, g_out.data_ptr(), 2 * D, None, 0, None, 1, stream) == NRX_ERR_UNSUPPORTED
     arr[0].dim = arr[1].dim = D
     assert lib.nrx_embed_bwd_small(arr, 2, 5000, g_out.data_ptr(), 2 * D, None, 0, None, 1, stream) == NRX_ERR_UNSUPPORTED
@@ -262,3 +271,26 @@ def test_deterministic_mode_takes_the_small_kernel_where_it_applies_and_the_plan
         for ga, gb, gd in zip(a, b, d):
             assert torch.equal(ga.view(torch.int32), gb.view(torch.int32))
             torch.testing.assert_close(ga, gd, rtol=1e-4, atol=1e-4)
+
+
+def test_reference_models_take_the_small_kernel_and_match_the_reference_gradients(monkeypatch):
+    """The reference's own models on the reference's golden batches (tests/golden/model_*.npz: state_dict, batch and the gradients its
+    autograd produced on the CPU -- tests/golden/gen_golden.py): in the default mode every embedding gradient of Deep, FM, DCN,
+    Wide&Deep, LR and the array-feature Deep is formed by nrx_embed_bwd_small -- no float-atomic launch -- and matches the reference's."""
+    from tests.test_models_gpu import CASES as MODEL_CASES, batch_of, gold, load_model
+    monkeypatch.setattr(ops, "DENSE_BWD_SORTED", None)
+    for cls, cfg_name, gname in MODEL_CASES:
+        g = gold(gname)
+        m = load_model(cls, cfg_name, g)
+        batch = batch_of(g)
+        cnt = _Counting(_lib.load())
+        monkeypatch.setattr(_lib, "load", lambda: cnt)
+        loss = m.bceLoss(m(batch), batch["label"][:, 0])
+        loss.backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(_lib, "load", cnt._lib.__class__ and (lambda lib=cnt._lib: lib))
+        assert cnt.small_ok >= 1 and cnt.atomic == 0, (gname, cnt.small, cnt.small_ok, cnt.atomic)
+        for name, emb in m.embedding_tables.items():
+            want = g[f"grad/embedding_tables.{name}.weight"]
+            np.testing.assert_allclose(emb.weight.grad.cpu().numpy(), want, rtol=2e-3, atol=2e-6 + 1e-4 * np.abs(want).max(), err_msg=f"{gname}:{name}")
+            assert torch.all(emb.weight.grad[0] == 0), name
