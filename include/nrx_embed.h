@@ -156,6 +156,16 @@ NRX_API int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, int
                   const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
                   const nrx_fm_grad_t* fm, int32_t accumulate, void* stream);
 
+/* The ROW-SPARSE form of nrx_embed_bwd_small (what the fused row-sparse optimizer's sink takes at the reference's batch sizes -- one launch where
+ * nrx_sparse_plan + nrx_embed_bwd_sorted are ~12): the block of a table leaves (key = table_of << 40 | row, the row's summed gradient) pairs in
+ * its own region of uniq_keys [capacity] / values [capacity, dim] -- as many slots as the table has lookups in the launch, regions in order of
+ * the tables' first appearance among the features, unused slots keyed -1 (nrx_sparse_adam_step skips negative keys).  Every row appears once; a
+ * region's pairs are in no particular order (the sums are order-fixed: same bits run to run).  feats[i].table is not read; table_of (HOST,
+ * n_feats, values in [0, 256)); one dim for all features; capacity >= the launch's lookups.  NRX_ERR_UNSUPPORTED as nrx_embed_bwd_small. */
+NRX_API int nrx_embed_bwd_small_sparse(const nrx_feature_t* feats, const int32_t* table_of, int32_t n_feats, int64_t batch,
+                  const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                  const nrx_fm_grad_t* fm, int64_t* uniq_keys, float* values, int64_t capacity, void* stream);
+
 /* Deterministic row-sparse backward for ONE table (alternative to nrx_embed_bwd's dense atomics).
  * The caller has sorted the table's lookups by row id (stable): `order[e]` is the flat lookup index of
  * the e-th sorted entry, flat lookups being feature-major over the n_feats features that read the

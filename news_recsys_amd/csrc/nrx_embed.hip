@@ -2245,6 +2245,12 @@ struct SmallDetArgs {
     uint8_t seg_ptr[NRX_MAX_FEATURES + 1];  // block s owns seg_feat[seg_ptr[s] .. seg_ptr[s + 1])
     uint8_t seg_ql[NRX_MAX_FEATURES];       // log2 of the lanes per row of block s's table (dim / 4, rounded up to a power of two)
     int32_t seg_dim[NRX_MAX_FEATURES];      // its row width
+    // SINK (nrx_embed_bwd_small_sparse): block s leaves its unique rows in slots seg_off[s] .. of (uniq, values) -- as many slots as the
+    // table has lookups in the launch, the unused ones keyed -1 -- instead of storing into a dense gradient
+    int32_t seg_off[NRX_MAX_FEATURES];
+    uint8_t seg_tid[NRX_MAX_FEATURES];      // the table index the keys carry (key = table << 40 | row)
+    int64_t* uniq;
+    float* values;
     const float* g_out; int64_t out_ld;
     const float* g_wide; int64_t wide_ld;
     const float* g_fm; const float* fm_sums; int64_t sums_ld; const float* feat; int64_t feat_ld;
@@ -2324,7 +2330,7 @@ __device__ __forceinline__ int sd_append(int* counter, bool pred, int lane) {
     return base + (int)__popcll(m & ((1ull << lane) - 1ull));
 }
 
-template <bool FM, bool GEN>
+template <bool FM, bool GEN, bool SINK = false>
 __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const SmallDetArgs args_in_kernarg) {
     const NRX_CONST SmallDetArgs* a = nrx_kernarg<SmallDetArgs>();
     extern __shared__ __attribute__((aligned(16))) unsigned char sd_smem[];
@@ -2406,6 +2412,10 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
         base += len;
     }
     for (int i = base + tid; i < N; i += NT) { s_key[i] = ~0ull; s_slot[i] = 0xffff; }
+    if (SINK) {                           // every slot of the region starts as filler; the rows found below overwrite theirs (after barriers)
+        NRX_GLOBAL int64_t* uq = nrx_gmut<int64_t>(a->uniq) + a->seg_off[s];
+        for (int i = tid; i < base; i += NT) uq[i] = -1;
+    }
     __syncthreads();
 #if defined(NRX_SD_STOP) && NRX_SD_STOP == 1
     return;
@@ -2482,7 +2492,24 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
         return make_float4(t.x * sc, t.y * sc, t.z * sc, t.w * sc);      // (products then sums: nothing here contracts into an fma across the call)
     };
     const bool add_to = a->add_to != 0;
-    auto store = [&](uint32_t row, float4 acc) {
+    const int64_t key_hi = SINK ? (int64_t)a->seg_tid[s] << 40 : 0;
+    const int64_t slot0 = SINK ? a->seg_off[s] : 0;
+    auto store = [&](int slot, uint32_t row, float4 acc) {
+        if (SINK) {                         // slot: the row's place in the block's region (once-only rows first, then the sorted runs)
+            if (q == 0) nrx_gmut<int64_t>(a->uniq)[slot0 + slot] = key_hi | (int64_t)row;
+            NRX_GLOBAL float* d1 = nrx_gmut<float>(a->values) + (slot0 + slot) * D + 4 * q;
+            if (GEN) {
+                const float e[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * q + j < D) d1[j] = e[j];
+            } else {
+                nrx_f32x4 r;
+                r.x = acc.x; r.y = acc.y; r.z = acc.z; r.w = acc.w;
+                *reinterpret_cast<NRX_GLOBAL nrx_f32x4*>(d1) = r;
+            }
+            return;
+        }
         if (GEN) {
             NRX_GLOBAL float* d1 = gtab + (int64_t)row * D + 4 * q;
             const float e[4] = {acc.x, acc.y, acc.z, acc.w};
@@ -2521,13 +2548,13 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
                 if (key[r] == ~0ull) continue;
                 float4 acc = zero4;       // 0 + t, as the sorted form adds its first term
                 acc.x += t[r].x; acc.y += t[r].y; acc.z += t[r].z; acc.w += t[r].w;
-                store((uint32_t)(key[r] >> 32), acc);
+                store(x0 + r * Gs + gs, (uint32_t)(key[r] >> 32), acc);
             }
         }
     };
     const int gg = lane >> ql, G64 = 64 >> ql;
     // a run of more than SD_LONG lookups of one row, by a whole wavefront: its lane groups stride the run, then a fixed xor tree
-    auto long_run = [&](const uint64_t* keys, int st, int en) {
+    auto long_run = [&](const uint64_t* keys, int st, int en, int slot) {
         float4 acc = zero4;
         for (int e = st + gg; e < en; e += 2 * G64) {
             const float4 t0 = contrib(keys[e]);
@@ -2539,7 +2566,7 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
             acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
             acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
         }
-        if (gg == 0) store((uint32_t)(keys[st] >> 32), acc);
+        if (gg == 0) store(slot, (uint32_t)(keys[st] >> 32), acc);
     };
     // the runs of <= SD_LONG lookups: lane group g_ of G_ takes runs g_, g_ + G_, ..., R at a time (their first two terms in flight together),
     // each run added in order
@@ -2575,7 +2602,7 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
                     for (int j = 0; j < 4; ++j)
                         if (e + j < en) { acc.x += t[j].x; acc.y += t[j].y; acc.z += t[j].z; acc.w += t[j].w; }
                 }
-                store((uint32_t)(keys[st[r]] >> 32), acc);
+                store(n_single + u0 + r * G_ + g_, (uint32_t)(keys[st[r]] >> 32), acc);
             }
         }
     };
@@ -2614,11 +2641,11 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
                 for (int j = 0; j < 4; ++j)
                     if (e + j < en) { acc.x += t[j].x; acc.y += t[j].y; acc.z += t[j].z; acc.w += t[j].w; }
             }
-            store((uint32_t)(s_mkey[st] >> 32), acc);
+            store(n_single + r, (uint32_t)(s_mkey[st] >> 32), acc);
         }
         for (int r = 0; r < n_rows; ++r) {
             const int st = s_us[r], en = s_us[r + 1];
-            if (en - st > SD_LONG) long_run(s_mkey, st, en);
+            if (en - st > SD_LONG) long_run(s_mkey, st, en, n_single + r);
         }
         return;
     }
@@ -2672,7 +2699,7 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
     const int n_long = s_nlong;
     for (int li = wv; li < n_long; li += NT / 64) {
         const int u = s_long[li];
-        long_run(s_mkey, s_us[u], s_us[u + 1]);
+        long_run(s_mkey, s_us[u], s_us[u + 1], n_single + u);
     }
 }
 
@@ -2746,10 +2773,12 @@ extern "C" int nrx_embed_bwd(const nrx_feature_t* feats, int32_t n_feats, int64_
 // nrx_embed_bwd.  Shapes: every table fed by <= 4096 lookups of this call, dim <= 256, padded (not CSR) bags, rows < 2^32, ids of one width.
 // Widths 4 * 2^k with 16-byte-aligned rows and upstream columns take the 16-byte form of the kernel, everything else (the reference's
 // 16 + 1-column wide features, LR's dim-1 tables) the element-by-element form.
-extern "C" int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
-                                   const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
-                                   const nrx_fm_grad_t* fm, int32_t accumulate, void* stream) {
-    NRX_TRACE();
+static int small_det_launch(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
+                            const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                            const nrx_fm_grad_t* fm, int32_t accumulate, void* stream,
+                            const int32_t* table_of /* sink form: the table index of every feature */, int64_t* sink_uniq, float* sink_values,
+                            int64_t sink_cap) {
+    const bool sink = sink_uniq != nullptr;
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_bwd_small: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0, "nrx_embed_bwd_small: negative batch");
@@ -2764,7 +2793,7 @@ extern "C" int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, 
     bool any_fm = false;
     int bits = 0;
     // segments: features that share a gradient table, in order of first appearance
-    const float* seg_tab[NRX_MAX_FEATURES];
+    int64_t seg_tab[NRX_MAX_FEATURES];
     int64_t seg_n[NRX_MAX_FEATURES], seg_den[NRX_MAX_FEATURES];
     int seg_dim[NRX_MAX_FEATURES], seg_of[NRX_MAX_FEATURES], n_seg = 0;
     for (int i = 0; i < n_feats; ++i) {
@@ -2772,7 +2801,8 @@ extern "C" int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, 
         seg_of[i] = -1;
         if (f.kind == NRX_DENSE) continue;
         NRX_REQUIRE(f.kind >= NRX_SPARSE && f.kind <= NRX_BAG_SUM, "nrx_embed_bwd_small: feature %d: bad kind %d", i, f.kind);
-        NRX_REQUIRE(f.table != nullptr && f.index != nullptr && f.rows >= 1 && f.dim >= 1, "nrx_embed_bwd_small: feature %d: null table / ids", i);
+        NRX_REQUIRE((sink || f.table != nullptr) && f.index != nullptr && f.rows >= 1 && f.dim >= 1, "nrx_embed_bwd_small: feature %d: null table / ids", i);
+        NRX_REQUIRE(!sink || (table_of[i] >= 0 && table_of[i] < 256), "nrx_embed_bwd_small_sparse: feature %d: table index outside [0, 256)", i);
         const bool bag = f.kind >= NRX_BAG_MASKED_MEAN;
         NRX_REQUIRE(!bag || f.bag_len >= 1, "nrx_embed_bwd_small: feature %d: bag_len < 1", i);
         NRX_REQUIRE(f.kind != NRX_BAG_MASKED_MEAN || f.weight != nullptr, "nrx_embed_bwd_small: feature %d: masked mean needs weights", i);
@@ -2782,12 +2812,14 @@ extern "C" int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, 
         if (f.dim > 256) return NRX_ERR_UNSUPPORTED;
         bool pow2 = false;
         for (int k = 0; k <= 6; ++k) pow2 |= f.dim == (4 << k);
-        if (!pow2 || (reinterpret_cast<uintptr_t>(f.table) & 15) != 0) unal = true;      // element-by-element form
+        if (!pow2 || (!sink && (reinterpret_cast<uintptr_t>(f.table) & 15) != 0)) unal = true;      // element-by-element form
         const int64_t len = batch * (bag ? f.bag_len : 1);
         if (len > SD_MAX || (bag && f.bag_len > SD_MAX)) return NRX_ERR_UNSUPPORTED;
         int sgi = -1;
-        for (int k = 0; k < n_seg; ++k) if (seg_tab[k] == f.table) sgi = k;
-        if (sgi < 0) { sgi = n_seg++; seg_tab[sgi] = f.table; seg_n[sgi] = 0; seg_den[sgi] = 0; seg_dim[sgi] = f.dim; }
+        const int64_t tab_id = sink ? (int64_t)table_of[i] : (int64_t)reinterpret_cast<uintptr_t>(f.table);
+        for (int k = 0; k < n_seg; ++k) if (seg_tab[k] == tab_id) sgi = k;
+        if (sgi < 0) { sgi = n_seg++; seg_tab[sgi] = tab_id; seg_n[sgi] = 0; seg_den[sgi] = 0; seg_dim[sgi] = f.dim; }
+        if (sink && f.dim != feats[0].dim) return NRX_ERR_UNSUPPORTED;          // one [cap, dim] values array
         if (seg_dim[sgi] != f.dim) return NRX_ERR_UNSUPPORTED;
         seg_n[sgi] += len;
         if (f.kind == NRX_BAG_MASKED_MEAN) seg_den[sgi] += batch;
@@ -2800,6 +2832,13 @@ extern "C" int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, 
         a.out_col[i] = f.out_col; a.wide_col[i] = f.wide_col; a.meta[i] = (bag ? f.bag_len : 0) | f.kind << 16 | ((isfm ? 1 : 0) | ((f.flags & NRX_FEAT_ROW0_IS_DATA) ? 2 : 0)) << 24;
     }
     if (n_seg == 0) return NRX_OK;
+    if (sink) {
+        if ((reinterpret_cast<uintptr_t>(sink_values) & 15) != 0) unal = true;
+        int64_t off = 0;
+        for (int sgi = 0; sgi < n_seg; ++sgi) { a.seg_off[sgi] = (int32_t)off; a.seg_tid[sgi] = (uint8_t)seg_tab[sgi]; off += seg_n[sgi]; }
+        NRX_REQUIRE(sink_cap >= off, "nrx_embed_bwd_small_sparse: capacity %lld < the launch's %lld lookups", (long long)sink_cap, (long long)off);
+        a.uniq = sink_uniq; a.values = sink_values;
+    }
     if (any_fm && ((reinterpret_cast<uintptr_t>(fm->fm_sums) & 15) != 0 || (reinterpret_cast<uintptr_t>(fm->feat) & 15) != 0 ||
                    (fm->sums_ld & 3) != 0 || (fm->feat_ld & 3) != 0))
         unal = true;                           // the element-by-element form folds FM terms at any alignment
@@ -2830,19 +2869,43 @@ extern "C" int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     static const bool lds_ok = [] {          // N = 4096 takes ~140 KB of the CU's 160 KB: above the 64 KB a kernel gets without asking
         const int most = (int)sd_smem_bytes(SD_MAX, SD_MAX);
-        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_small_det_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
-        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_small_det_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
-        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_small_det_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
-        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_small_det_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess;
+        bool ok = true;
+#define NRX_SD_ATTR(FM_, GEN_, SINK_) ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_small_det_kernel<FM_, GEN_, SINK_>), \
+                                                                      hipFuncAttributeMaxDynamicSharedMemorySize, most) == hipSuccess
+        NRX_SD_ATTR(true, false, false); NRX_SD_ATTR(true, true, false); NRX_SD_ATTR(false, true, false); NRX_SD_ATTR(false, false, false);
+        NRX_SD_ATTR(true, false, true); NRX_SD_ATTR(true, true, true); NRX_SD_ATTR(false, true, true); NRX_SD_ATTR(false, false, true);
+#undef NRX_SD_ATTR
         return ok;
     }();
     if (!lds_ok && smem > 60 * 1024) return NRX_ERR_UNSUPPORTED;
-    if (any_fm && unal) hipLaunchKernelGGL((embed_bwd_small_det_kernel<true, true>), dim3(n_seg), dim3(nt), smem, st, a);
-    else if (any_fm) hipLaunchKernelGGL((embed_bwd_small_det_kernel<true, false>), dim3(n_seg), dim3(nt), smem, st, a);
-    else if (unal) hipLaunchKernelGGL((embed_bwd_small_det_kernel<false, true>), dim3(n_seg), dim3(nt), smem, st, a);
-    else hipLaunchKernelGGL((embed_bwd_small_det_kernel<false, false>), dim3(n_seg), dim3(nt), smem, st, a);
+#define NRX_SD_GO(FM_, GEN_) do { if (sink) hipLaunchKernelGGL((embed_bwd_small_det_kernel<FM_, GEN_, true>), dim3(n_seg), dim3(nt), smem, st, a); \
+                                  else hipLaunchKernelGGL((embed_bwd_small_det_kernel<FM_, GEN_, false>), dim3(n_seg), dim3(nt), smem, st, a); } while (0)
+    if (any_fm && unal) NRX_SD_GO(true, true);
+    else if (any_fm) NRX_SD_GO(true, false);
+    else if (unal) NRX_SD_GO(false, true);
+    else NRX_SD_GO(false, false);
+#undef NRX_SD_GO
     NRX_LAUNCH_CHECK("nrx_embed_bwd_small");
     return NRX_OK;
+}
+
+extern "C" int nrx_embed_bwd_small(const nrx_feature_t* feats, int32_t n_feats, int64_t batch,
+                                   const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                                   const nrx_fm_grad_t* fm, int32_t accumulate, void* stream) {
+    NRX_TRACE();
+    return small_det_launch(feats, n_feats, batch, g_out, out_ld, g_wide, wide_ld, fm, accumulate, stream, nullptr, nullptr, nullptr, 0);
+}
+
+// The row-sparse form of the same launch: instead of storing into dense gradient tables, block s leaves (key = table_of << 40 | row, summed row)
+// pairs in its own region of (uniq_keys, values): as many slots as its table has lookups in the launch, regions in order of the tables' first
+// appearance among the features, unused slots keyed -1 (nrx_sparse_adam_step skips them).  What FusedSparseAdam's sink takes at the reference's
+// batch sizes in ONE launch (the planned form: ~12).  The pairs of a region are in no particular order; every row appears once.
+extern "C" int nrx_embed_bwd_small_sparse(const nrx_feature_t* feats, const int32_t* table_of, int32_t n_feats, int64_t batch,
+                                          const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                                          const nrx_fm_grad_t* fm, int64_t* uniq_keys, float* values, int64_t capacity, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(table_of != nullptr && uniq_keys != nullptr && values != nullptr, "nrx_embed_bwd_small_sparse: null table_of / uniq_keys / values");
+    return small_det_launch(feats, n_feats, batch, g_out, out_ld, g_wide, wide_ld, fm, 0, stream, table_of, uniq_keys, values, capacity);
 }
 
 extern "C" int64_t nrx_embed_bwd_sorted_workspace(int64_t n_lookups, int32_t dim) {

@@ -38,6 +38,7 @@ class FusedSparseAdam:
         self._index = {}         # id(tensor) -> position
         self.moments = []        # (exp_avg, exp_avg_sq) per table
         self._gmaps = {}         # table-list identity -> device map (launch-local table index -> position)
+        self._identity = {}      # table-list identity -> that map is the identity
 
     def _register(self, t: torch.Tensor) -> int:
         i = self._index.get(id(t))
@@ -60,10 +61,17 @@ class FusedSparseAdam:
         ck = tuple(id(t) for t in e["tables"])
         gmap = self._gmaps.get(ck)
         if gmap is None:        # built once per table list (a host-to-device copy: must not happen inside a graph capture)
-            gmap = torch.tensor([self._register(t) for t in e["tables"]], dtype=torch.int64, device=dev)
+            pos = [self._register(t) for t in e["tables"]]
+            gmap = torch.tensor(pos, dtype=torch.int64, device=dev)
             self._gmaps[ck] = gmap
+            self._identity[ck] = pos == list(range(len(pos)))
         k = e["uniq"]
-        valid = torch.arange(e["cap"], device=dev) < e["counts"][0]
+        if e.get("filler"):             # the one-launch small form: unused slots are keyed -1 wherever they are
+            if self._identity.get(ck):
+                return k                # launch-local table numbers ARE the optimizer's: the kernel skips negative keys itself
+            valid = k >= 0
+        else:
+            valid = torch.arange(e["cap"], device=dev) < e["counts"][0]
         local = torch.where(valid, k >> 40, torch.zeros_like(k))
         return torch.where(valid, (gmap[local] << 40) | (k & MASK), torch.full_like(k, BIG))
 

@@ -399,6 +399,20 @@ def _dense_sorted_ok(plan, tables, sparse_grad, B, csr_ok=False) -> bool:
     return lookups > 0 and (DENSE_BWD_SORTED in (True, "det") or B * lookups >= DENSE_SORTED_MIN)
 
 
+def _small_shapes(plan, B) -> bool:
+    """Every table of the launch fed by <= 4096 lookups (the one-block-per-table kernels' limit; the library has the last word)."""
+    if B > 4096 or B <= 0:
+        return False
+    per = {}
+    for s in plan.slots:
+        if s.kind == NRX_DENSE:
+            continue
+        if s.flags & NRX_FEAT_BAG_CSR or s.dim > 256:
+            return False
+        per[s.table] = per.get(s.table, 0) + B * max(1, s.bag_len)
+    return bool(per) and max(per.values()) <= 4096
+
+
 class _EmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan: EmbedPlan, inputs, weights, out_ld, need_out, sparse_grad, index_check, *tables):
@@ -516,6 +530,8 @@ class _EmbedFn(torch.autograd.Function):
             plan, ins, ws = _csr_plan_to_padded(plan, ins, ws)
             ctx.plan, ctx.ins, ctx.ws = plan, ins, ws
         small = ctx.dense_sorted and not ctx.sparse_grad and B * sum(max(1, s_.bag_len) for s_ in plan.slots if s_.kind != NRX_DENSE) < PLAN_AHEAD_MIN
+        if ctx.sink is not None and SPARSE_SMALL_DET and _small_shapes(plan, B):
+            small = True                 # the sink's one-launch form (nrx_embed_bwd_small_sparse) plans nothing
         if (ctx.sparse_grad or ctx.dense_sorted) and PLAN_AHEAD and B > 0 and not torch.cuda.is_current_stream_capturing() and wants_grad and not small:
             ctx.plans = {}
             for g_ in _sparse_group_cache(plan, tables):
@@ -611,6 +627,7 @@ class SparseGradSink:
 
     def __init__(self):
         self.pending = []       # dicts: tables (list of tensors, index = table id in the keys), dim, uniq, values, counts, cap
+                                # (filler=True: no counts -- unused slots anywhere in uniq carry key -1: nrx_embed_bwd_small_sparse's layout)
 
     def clear(self):
         self.pending.clear()
@@ -627,6 +644,7 @@ _plan_streams = {}
 # DENSE_BWD_SORTED: None = auto, True = sorted, "det" = deterministic, False = atomic.
 DENSE_BWD_SORTED = {"sorted": True, "atomic": False, "deterministic": "det"}.get(os.environ.get("NRX_DENSE_BWD", "auto"))
 DENSE_SORTED_MIN = int(os.environ.get("NRX_DENSE_SORTED_MIN", 1 << 20))
+SPARSE_SMALL_DET = os.environ.get("NRX_SPARSE_SMALL", "1") != "0"     # fused row-sparse mode (sink), small launches: the one-launch form likewise
 DENSE_SMALL_DET = os.environ.get("NRX_DENSE_SMALL", "1") != "0"       # auto mode, small launches: the one-launch deterministic kernel where it applies
 PLAN_AHEAD = True      # row-sparse training: plan the backward (sort, unique rows, segments) at FORWARD time on a side stream
 PLAN_AHEAD_MIN = int(os.environ.get("NRX_PLAN_AHEAD_MIN", 1 << 18))      # default-mode launches below this many lookups plan inline (one fused call)
@@ -802,6 +820,28 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
         dev = tables[tabs[0]].device
         pre = ahead.get((D, fs[0]))
         pmask = grp["pmask"] if SPARSE_PLACE else None
+        if pre is None and ctx.sink is not None and SPARSE_SMALL_DET and B <= 4096 and n_tables <= 256:
+            # fused row-sparse optimizer at the reference's batch sizes: ONE launch leaves (key, summed row) pairs in the sink's format --
+            # per-table regions with -1 fillers (nrx_embed_bwd_small_sparse); NRX_ERR_UNSUPPORTED: the planned reduction below
+            ids = [ctx.ins[i] for i in fs]
+            dt = ids[0].dtype
+            if any(x.dtype != dt for x in ids):
+                ids = [x.long() for x in ids]
+            total = sum(x.numel() for x in ids)
+            if total == 0:
+                continue
+            arr = _group_features(grp, ids, [ctx.ws[i] for i in fs], fmg is not None)
+            import numpy as _np
+            _np.frombuffer(arr, dtype=_feature_np_dtype())["rows"] = grp["rows"]
+            uniq = torch.empty(total, dtype=torch.int64, device=dev)
+            values = torch.empty((total, D), dtype=torch.float32, device=dev)
+            rc = lib.nrx_embed_bwd_small_sparse(arr, grp["static"][0], n, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, fmg,
+                                                uniq.data_ptr(), values.data_ptr(), total, stream)
+            if rc == 0:
+                ctx.sink.pending.append(dict(tables=ctx.tables, dim=D, uniq=uniq, values=values, counts=None, cap=total, filler=True))
+                continue
+            if rc != NRX_ERR_UNSUPPORTED:
+                check(rc, "nrx_embed_bwd_small_sparse")
         if pre is not None:                 # planned at forward time on the side stream (sparse_plan_ahead)
             ids, pl, ev = pre
             _cur_stream(dev).wait_event(ev)

@@ -294,3 +294,88 @@ def test_reference_models_take_the_small_kernel_and_match_the_reference_gradient
             want = g[f"grad/embedding_tables.{name}.weight"]
             np.testing.assert_allclose(emb.weight.grad.cpu().numpy(), want, rtol=2e-3, atol=2e-6 + 1e-4 * np.abs(want).max(), err_msg=f"{gname}:{name}")
             assert torch.all(emb.weight.grad[0] == 0), name
+
+
+def _sink_dense(plan, tables, inputs, weights, ups, monkeypatch):
+    """The same step through the row-sparse sink (what FusedSparseAdam drains), its (key, row) pairs scattered into dense tensors."""
+    monkeypatch.setattr(ops, "DENSE_BWD_SORTED", None)
+    ts = [t.clone().requires_grad_() for t in tables]
+    sink = ops.SparseGradSink()
+    res = ops.embed_apply(plan, ts, inputs, weights, sparse_grad=sink)
+    loss = sum((r * u).sum() for r, u in zip(res, ups) if r is not None)
+    loss.backward()
+    torch.cuda.synchronize()
+    out = [torch.zeros_like(t) for t in tables]
+    seen = [torch.zeros(t.shape[0], dtype=torch.int32, device=DEV) for t in tables]
+    lookups = 0
+    for e in sink.pending:
+        assert e.get("filler") is True, "the step did not take the one-launch row-sparse form"
+        k, v = e["uniq"], e["values"]
+        ok = k >= 0
+        lookups += k.numel()
+        t_of, row = (k[ok] >> 40), (k[ok] & ((1 << 40) - 1))
+        for t in range(len(tables)):
+            m = t_of == t
+            if bool(m.any()):
+                assert tables[t].shape[1] == e["dim"]
+                out[t][row[m]] = v[ok][m]
+                seen[t].index_add_(0, row[m], torch.ones_like(row[m], dtype=torch.int32))
+    for sn in seen:
+        assert int(sn.max()) <= 1                                               # every row appears once
+    return out, lookups
+
+
+SINK_CASES = ["deep_b512", "c2_like_fm_b512", "c2_like_fm_b4096", "fm_zipf", "fm_hot", "plain64_zipf", "dim128_hot", "wide16_zipf",
+              "odd_dim_10", "wide17_zipf", "lr_dim_1_fm", "one_sample"]
+
+
+@pytest.mark.parametrize("name", SINK_CASES)
+def test_small_row_sparse_form_leaves_the_same_rows_as_the_dense_form(name, monkeypatch):
+    """nrx_embed_bwd_small_sparse (the sink of the fused row-sparse optimizer): the (key, row) pairs, scattered, ARE the dense gradient of
+    nrx_embed_bwd_small -- bit for bit (same kernel, another destination) -- every row once, fillers keyed -1."""
+    _, D, n, rows, B, fm, wide, dist = [c for c in CASES if c[0] == name][0]
+    rng = np.random.default_rng(sum(map(ord, name)) + 11)
+    slots, col = [], 0
+    for i in range(n):
+        if i in wide:
+            slots.append(ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, col, wide_col=len([w for w in wide if w < i])))
+            col += D - 1
+        else:
+            slots.append(ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, col, fm_field=1 if fm else 0))
+            col += D
+    plan = ops.EmbedPlan(slots, out_width=col, wide_width=len(wide), use_fm=fm)
+    tables = [torch.from_numpy(rng.standard_normal((rows, D)).astype(np.float32)).to(DEV) for _ in range(n)]
+    inputs = [torch.from_numpy(_ids(rng, rows, (B,), dist)).to(DEV) for _ in range(n)]
+    ups = (torch.from_numpy(rng.standard_normal((B, col)).astype(np.float32)).to(DEV),
+           torch.from_numpy(rng.standard_normal((B, max(len(wide), 1))).astype(np.float32)).to(DEV),
+           torch.from_numpy(rng.standard_normal((B,)).astype(np.float32)).to(DEV))
+    dense, cnt = _grads(plan, tables, inputs, [None] * n, ups, "auto", monkeypatch)
+    assert cnt.small_ok >= 1
+    got, lookups = _sink_dense(plan, tables, inputs, [None] * n, ups, monkeypatch)
+    assert lookups == n * B
+    for a, b in zip(dense, got):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+@pytest.mark.parametrize("kind", [NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM])
+def test_small_row_sparse_form_tower_with_history_bag(kind, monkeypatch):
+    rng = np.random.default_rng(41 + kind)
+    D, L, B, news, users = 16, 7, 500, 6000, 50000
+    slots = [ops.Slot("item_id", NRX_SPARSE, 0, D, 0, 0), ops.Slot("user_history", kind, 0, D, L, D), ops.Slot("user_id", NRX_SPARSE, 1, D, 0, 2 * D)]
+    plan = ops.EmbedPlan(slots, out_width=3 * D)
+    tables = [torch.from_numpy(rng.standard_normal((r, D)).astype(np.float32)).to(DEV) for r in (news, users)]
+    hist = _ids(rng, news, (B, L), "zipf")
+    lens = rng.integers(0, L + 1, B)
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.float32)
+    hist = np.where(mask > 0, hist, 0)
+    if kind == NRX_BAG_SUM:
+        mask = mask * rng.random((B, L)).astype(np.float32)
+    inputs = [torch.from_numpy(_ids(rng, news, (B,), "zipf")).to(DEV), torch.from_numpy(hist).to(DEV),
+              torch.from_numpy(_ids(rng, users, (B,), "uniform")).to(DEV)]
+    weights = [None, None if kind == NRX_BAG_MEAN else torch.from_numpy(mask).to(DEV), None]
+    ups = (torch.from_numpy(rng.standard_normal((B, 3 * D)).astype(np.float32)).to(DEV), None, None)
+    dense, cnt = _grads(plan, tables, inputs, weights, ups, "auto", monkeypatch)
+    assert cnt.small_ok >= 1
+    got, _ = _sink_dense(plan, tables, inputs, weights, ups, monkeypatch)
+    for a, b in zip(dense, got):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
