@@ -401,6 +401,7 @@ class BaseModel(LightningModule):
                 sink = self._sparse_sink
             optimizer = SparseDenseAdam(table_params, [p for p in self.parameters() if id(p) not in ids], lr=hp.lr, fused_sink=sink)
         else:
-            optimizer = torch.optim.AdamW(self.parameters(), lr=hp.lr, betas=(0.9, 0.999))
+            from ..model_utils.optim import dense_adamw
+            optimizer = dense_adamw(self.parameters(), lr=hp.lr, betas=(0.9, 0.999))     # torch.optim.AdamW; its one-pass kernel on the GPU
         sched = CosinDecayLR(optimizer, lrs=[hp.lr, hp.min_lr], milestones=list(hp.lr_milestones))
         return {"optimizer": optimizer, "lr_scheduler": {"scheduler": sched, "interval": "step", "frequency": 1}}

@@ -13,6 +13,21 @@ import torch
 from ... import _lib, ops
 
 
+def dense_adamw(params, **kw):
+    """torch.optim.AdamW as the reference builds it (sort/deep/model.py:55, recall/DSSM/model.py) -- with torch's ONE-PASS multi-tensor kernel
+    (`fused=True`) when every parameter lives on the GPU: same update rule, one read and one write of (p, grad, m, v) instead of the ~10
+    elementwise passes of the default foreach form.  On the 26 x 100 k-row tables of a C2-shaped model the step (embedding forward, backward,
+    optimizer) goes 1110 -> 396 us at B = 512 (tools/probe_small_train_modes.py); NRX_ADAMW_FUSED=0 keeps torch's default."""
+    import os
+    params = list(params)
+    if os.environ.get("NRX_ADAMW_FUSED", "1") != "0" and params and all(torch.is_tensor(p) and p.is_cuda and p.is_floating_point() for p in params):
+        try:
+            return torch.optim.AdamW(params, fused=True, **kw)
+        except (RuntimeError, TypeError, ValueError):
+            pass
+    return torch.optim.AdamW(params, **kw)
+
+
 class FusedSparseAdam:
     """Adam(W) for the embedding tables, fused with the row-sparse backward.  The backward
     leaves (unique (table,row) keys, summed row gradients, counts) on the device in an ops.SparseGradSink; step()

@@ -113,7 +113,8 @@ class DSSM(BaseModel):
     def configure_optimizers(self):
         from ...model_utils.lr_schedule import CosinDecayLR
         hp = self.hparams_
-        optimizer = torch.optim.AdamW(self.parameters(), lr=hp["lr"], betas=(0.9, 0.999))
+        from ...model_utils.optim import dense_adamw
+        optimizer = dense_adamw(self.parameters(), lr=hp["lr"], betas=(0.9, 0.999))          # torch.optim.AdamW; its one-pass kernel on the GPU
         sched = CosinDecayLR(optimizer, lrs=[hp["lr"], hp["min_lr"]], milestones=list(hp["lr_milestones"]))
         return {"optimizer": optimizer, "lr_scheduler": {"scheduler": sched, "interval": "step", "frequency": 1}}
 

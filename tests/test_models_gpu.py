@@ -333,3 +333,24 @@ def test_training_steps_leave_no_uncollected_tensors():
         assert len(set(seen[3:])) == 1, seen
     finally:
         gc.enable()
+
+
+def test_dense_adamw_uses_the_one_pass_kernel_on_the_gpu_and_matches_the_default():
+    """configure_optimizers' AdamW (sort/deep/model.py:55): on the GPU torch's fused multi-tensor kernel, the same update as the default form."""
+    from news_recsys_amd.model.model_utils.optim import dense_adamw
+    g = torch.Generator(device=DEV).manual_seed(3)
+    ps = [torch.randn(300, 16, device=DEV, generator=g) for _ in range(3)]
+    a = [p.clone().requires_grad_() for p in ps]
+    b = [p.clone().requires_grad_() for p in ps]
+    oa = dense_adamw(a, lr=1e-2, betas=(0.9, 0.999))
+    ob = torch.optim.AdamW(b, lr=1e-2, betas=(0.9, 0.999), foreach=True)
+    assert isinstance(oa, torch.optim.AdamW) and oa.defaults.get("fused") is True
+    for _ in range(5):
+        grads = [torch.randn(300, 16, device=DEV, generator=g) for _ in ps]
+        for p, q, gr in zip(a, b, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    for p, q in zip(a, b):
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-6, atol=1e-7)
+    cpu = dense_adamw([torch.zeros(4, requires_grad=True)], lr=1e-2)
+    assert not cpu.defaults.get("fused")

@@ -23,10 +23,11 @@ def timed(fn, n=100, reps=3):
 for B in [int(x) for x in os.environ.get("NRX_PROBE_BATCHES", "512,2048").split(",")]:
     ids = [torch.randint(1, 100_000, (B,), device=dev, generator=gen) for _ in range(F)]
     up, upf = torch.randn(B, F * D, device=dev) * 1e-3, torch.randn(B, device=dev) * 1e-3
-    for mode in ("dense", "fused"):
+    for mode in ("dense", "dense_fusedkernel", "fused"):
         tabs = [torch.randn(100_000, D, device=dev).requires_grad_(True) for _ in range(F)]
-        if mode == "dense":
-            opt = torch.optim.Adam(tabs, lr=1e-3, capturable=True, foreach=True)
+        if mode.startswith("dense"):
+            opt = (torch.optim.AdamW(tabs, lr=1e-3, capturable=True, foreach=True) if mode == "dense" else
+                   torch.optim.AdamW(tabs, lr=1e-3, capturable=True, fused=True))      # torch's one-pass multi-tensor kernel
             def step():
                 opt.zero_grad(set_to_none=True)
                 out, _, fm = ops.embed_apply(plan, tabs, ids, [None] * F)
@@ -51,4 +52,4 @@ for B in [int(x) for x in os.environ.get("NRX_PROBE_BATCHES", "512,2048").split(
             tg = timed(g.replay)
         except Exception as e:
             print(f"   ({mode}: capture failed: {type(e).__name__}: {str(e)[:120]})")
-        print(f"B={B:5d} {mode:6s}: eager {te:7.1f} us   graph replay {tg:7.1f} us", flush=True)
+        print(f"B={B:5d} {mode:17s}: eager {te:7.1f} us   graph replay {tg:7.1f} us", flush=True)
