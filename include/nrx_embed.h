@@ -256,6 +256,20 @@ NRX_API int nrx_sparse_adam_step(float* const* tables, float* const* exp_avg, fl
                          const int64_t* n_unique_dev, float step_size, const float* step_size_dev, float beta1,
                          float beta2, float eps, float lr_times_weight_decay, void* stream);
 
+/* Exact dense AdamW from row-sparse gradients ("exact-dense mode").  The reference trains every embedding table with one dense
+ * torch.optim.AdamW over model.parameters() (src/model/sort/deep/model.py:54-65): every row moves every step.  nrx_rows_mark writes, for every
+ * key i = (t << 40 | row) of a unique-key list (negative keys / tables >= n_tables: fillers; row 0: the padding row), slot_maps[t][row] = i --
+ * the maps (int32 [rows[t]], all -1 before); nrx_dense_adamw_rows then does ONE AdamW step (torch's arithmetic: decoupled weight decay, bias
+ * corrections of step `step` >= 1) over EVERY row of the n_tables [rows[t], dim] tables, the gradient of a row being grads[slot] where its slot
+ * is >= 0 and zero elsewhere, and resets the slots it consumed to -1.  exp_avg / exp_avg_sq: [rows[t], dim] (torch's state layout).  hyper_dev
+ * (optional, device): {lr / bias_correction1, 1 / sqrt(bias_correction2)} read instead of the values derived from `step` (captured loops).  No dense
+ * gradient tensor is formed, zero-filled or read: 6 table-sized transfers per step instead of torch's 7 + the zero fill. */
+NRX_API int nrx_rows_mark(const int64_t* uniq_keys, int64_t n, const int64_t* n_dev, int32_t* const* slot_maps, const int64_t* rows,
+                  int32_t n_tables, void* stream);
+NRX_API int nrx_dense_adamw_rows(float* const* tables, float* const* exp_avg, float* const* exp_avg_sq, int32_t* const* slot_maps,
+                  const int64_t* rows, int32_t n_tables, int32_t dim, const float* grads, int64_t step, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, const float* hyper_dev, void* stream);
+
 /* nrx_embed_bwd_placed with the DENSE gradient tables as its destination: every unique row's sum is stored (accumulate == 0) or added
  * (accumulate != 0: a table fed by a second launch group) at grad_tables[table][row, :dim] -- the row the key names -- instead of
  * values[u]: with zero-filled tables, the dense [rows, dim] .grad autograd gives the reference's nn.Embedding tables

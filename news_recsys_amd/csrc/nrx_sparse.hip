@@ -1803,6 +1803,191 @@ extern "C" int nrx_rows_to_dense(float* const* tables, int32_t n_tables, int32_t
     return NRX_OK;
 }
 
+// ---- exact dense AdamW from row-sparse gradients ("exact-dense mode"): the reference trains every table with one dense
+// torch.optim.AdamW (sort/deep/model.py:55) -- EVERY row moves every step (weight decay, decaying moments), so the optimizer is a stream over the
+// whole tables however few rows the batch looked up.  This form does that stream ONCE: (p, m, v) of every row read and written, the gradient taken
+// from the backward's (key, row) pairs where there is one (a per-table slot map, -1 elsewhere, written by nrx_rows_mark and reset here) and zero
+// otherwise -- no dense gradient tensor is formed, zero-filled or read.  torch's single-tensor AdamW arithmetic, fp32.
+struct DenseAdamWArgs {
+    float* table[NRX_MAX_FEATURES];
+    float* m[NRX_MAX_FEATURES];
+    float* v[NRX_MAX_FEATURES];
+    int32_t* map[NRX_MAX_FEATURES];         // [rows] slot of the row's gradient in `grads`, or -1
+    int64_t rows[NRX_MAX_FEATURES];
+    int32_t tile0[NRX_MAX_FEATURES + 1];    // first block of every table
+    const float* grads;                     // [n, dim]
+    int32_t n_tables, dim;
+    float decay_keep, one_minus_b1, one_minus_b2, b2, step_size, inv_bc2_sqrt, eps;
+    const float* hyper_dev;                 // optional {lr / bias_correction1, 1 / sqrt(bias_correction2)} on the device (captured training loops)
+};
+static_assert(sizeof(DenseAdamWArgs) <= 3840, "kernarg budget");
+
+__device__ __forceinline__ float adamw_elem(float g, float& m, float& v, float w, const NRX_CONST DenseAdamWArgs* a, float step_size, float inv_bc2_sqrt) {
+    w *= a->decay_keep;                                   // param.mul_(1 - lr * weight_decay)
+    m = m + (g - m) * a->one_minus_b1;                    // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * a->b2 + g * g * a->one_minus_b2;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    const float denom = sqrtf(v) * inv_bc2_sqrt + a->eps;
+    return w - step_size * (m / denom);                  // param.addcdiv_(exp_avg, denom, value = -lr / bias_correction1)
+}
+
+template <int QLOG2, bool VEC>
+__global__ __launch_bounds__(NRX_BLOCK) void dense_adamw_rows_kernel(const DenseAdamWArgs args_in_kernarg) {
+    const NRX_CONST DenseAdamWArgs* a = nrx_kernarg<DenseAdamWArgs>();
+    constexpr int Q = 1 << QLOG2, TB = NRX_BLOCK / Q, R = 4;
+    const int q = threadIdx.x & (Q - 1), g = threadIdx.x >> QLOG2;
+    int t = 0;                              // the block's table: tile0[t] <= blockIdx.x < tile0[t + 1] (uniform)
+    while (t + 1 < a->n_tables && (int)blockIdx.x >= a->tile0[t + 1]) ++t;
+    const int64_t nrows = a->rows[t];
+    const int D = a->dim;
+    const float ss = a->hyper_dev != nullptr ? nrx_gconst<float>(a->hyper_dev)[0] : a->step_size;
+    const float ib = a->hyper_dev != nullptr ? nrx_gconst<float>(a->hyper_dev)[1] : a->inv_bc2_sqrt;
+    float* tab = a->table[t];
+    float* mt = a->m[t];
+    float* vt = a->v[t];
+    int32_t* map = a->map[t];
+    const int64_t r0 = ((int64_t)((int)blockIdx.x - a->tile0[t]) * TB + g) * R;
+    int slot[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) slot[r] = r0 + r < nrows ? map[r0 + r] : -1;
+    if (VEC) {
+        for (int k = q * 4; k < D; k += 4 * Q) {
+            float4 gr[R], w[R], m[R], v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t row = r0 + r < nrows ? r0 + r : 0;
+                gr[r] = slot[r] >= 0 ? nrx_ldg4(a->grads + (int64_t)slot[r] * D + k, 0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                w[r] = nrx_ldg4(tab + row * D + k, 0);
+                m[r] = nrx_ldg4(mt + row * D + k, 0);
+                v[r] = nrx_ldg4(vt + row * D + k, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (r0 + r >= nrows) continue;
+                w[r].x = adamw_elem(gr[r].x, m[r].x, v[r].x, w[r].x, a, ss, ib);
+                w[r].y = adamw_elem(gr[r].y, m[r].y, v[r].y, w[r].y, a, ss, ib);
+                w[r].z = adamw_elem(gr[r].z, m[r].z, v[r].z, w[r].z, a, ss, ib);
+                w[r].w = adamw_elem(gr[r].w, m[r].w, v[r].w, w[r].w, a, ss, ib);
+                const int64_t row = r0 + r;
+                nrx_stg4(tab + row * D + k, 0, w[r]);
+                nrx_stg4(mt + row * D + k, 0, m[r]);
+                nrx_stg4(vt + row * D + k, 0, v[r]);
+            }
+        }
+    } else {
+        for (int r = 0; r < R; ++r) {
+            if (r0 + r >= nrows) continue;
+            const int64_t row = r0 + r;
+            for (int k = q; k < D; k += Q) {
+                const float gk = slot[r] >= 0 ? a->grads[(int64_t)slot[r] * D + k] : 0.f;
+                float mk = mt[row * D + k], vk = vt[row * D + k];
+                tab[row * D + k] = adamw_elem(gk, mk, vk, tab[row * D + k], a, ss, ib);
+                mt[row * D + k] = mk;
+                vt[row * D + k] = vk;
+            }
+        }
+    }
+    if (q == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (slot[r] >= 0) map[r0 + r] = -1;       // the map is all -1 again when the launch ends
+    }
+}
+
+struct RowsMarkArgs {
+    int32_t* map[NRX_MAX_FEATURES];
+    int64_t rows[NRX_MAX_FEATURES];
+    const int64_t* keys;
+    const int64_t* n_dev;
+    int64_t max_n;
+    int32_t n_tables;
+};
+
+__global__ __launch_bounds__(NRX_BLOCK) void rows_mark_kernel(const RowsMarkArgs args_in_kernarg) {
+    const NRX_CONST RowsMarkArgs* a = nrx_kernarg<RowsMarkArgs>();
+    int64_t n = a->max_n;
+    if (a->n_dev != nullptr) {
+        const int64_t nd = nrx_gconst<int64_t>(a->n_dev)[0];
+        n = nd < n ? nd : n;
+    }
+    const int64_t i = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int64_t key = nrx_gconst<int64_t>(a->keys)[i];
+    const int64_t t = key >> 40, row = key & ((1ll << 40) - 1);
+    if (key < 0 || t >= a->n_tables || row == 0) return;         // filler keys; the padding row never trains
+    if (row < a->rows[t]) a->map[t][row] = (int32_t)i;
+}
+
+// slot_maps[t][row] = i for every key i = (t << 40 | row) of the list (negative keys and keys of tables >= n_tables are fillers; row 0 is the
+// padding row): the per-table row -> gradient-slot maps nrx_dense_adamw_rows reads.  The maps must be all -1 before (they are again after
+// nrx_dense_adamw_rows).  Keys must be unique.
+extern "C" int nrx_rows_mark(const int64_t* uniq_keys, int64_t n, const int64_t* n_dev, int32_t* const* slot_maps, const int64_t* rows,
+                             int32_t n_tables, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(n >= 0 && n <= 0x7fffffffll && n_tables >= 1 && n_tables <= NRX_MAX_FEATURES, "nrx_rows_mark: bad argument");
+    if (n == 0) return NRX_OK;
+    NRX_REQUIRE(uniq_keys && slot_maps && rows, "nrx_rows_mark: null buffer");
+    RowsMarkArgs a;
+    for (int t = 0; t < n_tables; ++t) {
+        NRX_REQUIRE(slot_maps[t] != nullptr && rows[t] >= 1, "nrx_rows_mark: table %d: null map / no rows", t);
+        a.map[t] = slot_maps[t];
+        a.rows[t] = rows[t];
+    }
+    a.keys = uniq_keys; a.n_dev = n_dev; a.max_n = n; a.n_tables = n_tables;
+    hipLaunchKernelGGL(rows_mark_kernel, dim3((unsigned)((n + NRX_BLOCK - 1) / NRX_BLOCK)), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), a);
+    NRX_LAUNCH_CHECK("nrx_rows_mark");
+    return NRX_OK;
+}
+
+// One AdamW step (torch.optim.AdamW's arithmetic: decoupled weight decay, bias corrections of step `step` >= 1) over EVERY row of the n_tables
+// [rows[t], dim] tables: the gradient of row r of table t is grads[slot_maps[t][r]] where that slot is >= 0 (nrx_rows_mark), zero elsewhere;
+// exp_avg / exp_avg_sq: [rows[t], dim] like the tables (torch's state layout).  Resets every slot it consumed to -1.  hyper_dev (optional, device):
+// {lr / bias_correction1, 1 / sqrt(bias_correction2)} read by the kernel instead of the values computed from `step` -- a loop captured in a
+// hipGraph advances them between replays.
+extern "C" int nrx_dense_adamw_rows(float* const* tables, float* const* exp_avg, float* const* exp_avg_sq, int32_t* const* slot_maps,
+                                    const int64_t* rows, int32_t n_tables, int32_t dim, const float* grads, int64_t step, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, const float* hyper_dev, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(n_tables >= 1 && n_tables <= NRX_MAX_FEATURES && dim >= 1 && step >= 1, "nrx_dense_adamw_rows: bad argument");
+    NRX_REQUIRE(tables && exp_avg && exp_avg_sq && slot_maps && rows, "nrx_dense_adamw_rows: null buffer");
+    DenseAdamWArgs a;
+    int ql = 0;
+    while ((4 << ql) < dim && ql < 6) ++ql;
+    const int tb = (NRX_BLOCK >> ql) * 4;                   // rows per block
+    bool vec = (dim & 3) == 0 && (grads == nullptr || nrx_aligned16(grads));
+    int64_t blocks = 0;
+    for (int t = 0; t < n_tables; ++t) {
+        NRX_REQUIRE(tables[t] && exp_avg[t] && exp_avg_sq[t] && slot_maps[t] && rows[t] >= 1, "nrx_dense_adamw_rows: table %d: null pointer / no rows", t);
+        a.table[t] = tables[t]; a.m[t] = exp_avg[t]; a.v[t] = exp_avg_sq[t]; a.map[t] = slot_maps[t]; a.rows[t] = rows[t];
+        a.tile0[t] = (int32_t)blocks;
+        blocks += (rows[t] + tb - 1) / tb;
+        vec = vec && nrx_aligned16(tables[t]) && nrx_aligned16(exp_avg[t]) && nrx_aligned16(exp_avg_sq[t]);
+    }
+    NRX_REQUIRE(blocks <= 0x7fffffffll, "nrx_dense_adamw_rows: too many rows for one launch");
+    a.tile0[n_tables] = (int32_t)blocks;
+    a.grads = grads;
+    a.n_tables = n_tables;
+    a.dim = dim;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.decay_keep = 1.0f - lr * weight_decay;
+    a.one_minus_b1 = 1.0f - beta1;
+    a.one_minus_b2 = 1.0f - beta2;
+    a.b2 = beta2;
+    a.step_size = (float)((double)lr / bc1);
+    a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    a.eps = eps;
+    a.hyper_dev = hyper_dev;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define NRX_DA(QL_) if (vec) hipLaunchKernelGGL((dense_adamw_rows_kernel<QL_, true>), dim3((unsigned)blocks), dim3(NRX_BLOCK), 0, st, a); \
+                    else hipLaunchKernelGGL((dense_adamw_rows_kernel<QL_, false>), dim3((unsigned)blocks), dim3(NRX_BLOCK), 0, st, a)
+    switch (ql) {
+        case 0: NRX_DA(0); break; case 1: NRX_DA(1); break; case 2: NRX_DA(2); break; case 3: NRX_DA(3); break;
+        case 4: NRX_DA(4); break; case 5: NRX_DA(5); break; default: NRX_DA(6); break;
+    }
+#undef NRX_DA
+    NRX_LAUNCH_CHECK("nrx_dense_adamw_rows");
+    return NRX_OK;
+}
+
 extern "C" int nrx_sparse_adam_step(float* const* tables, float* const* exp_avg, float* const* exp_avg_sq, int32_t n_tables,
                                     int32_t dim, const int64_t* uniq_keys, const float* grads, int64_t n_unique,
                                     const int64_t* n_unique_dev, float step_size, const float* step_size_dev, float beta1,

@@ -82,8 +82,10 @@ class BaseModel(LightningModule):
         # table gradients, for tables too large to zero-fill / dense-update every step
         # "fused": the same reduction stays on the device and optim.FusedSparseAdam updates the touched rows in
         # one launch (no COO tensors, no host read per step)
+        # "exact": the sink again, drained by optim.ExactDenseAdamW -- the reference's dense AdamW over EVERY row (weight decay, decaying
+        # moments: the same numbers as the default mode) streamed once per step, without a dense gradient tensor in between
         sg = e.get("sparse_grad", False)
-        self.sparse_grad = "fused" if str(sg).lower() == "fused" else bool(sg)
+        self.sparse_grad = str(sg).lower() if str(sg).lower() in ("fused", "exact") else bool(sg)
         self._sparse_sink = None
         # new optional key: how an out-of-range id surfaces on the fused batch path (get_embeddings_from_batch / forward).
         # "deferred" (default): no device synchronisation -- the kernel records the offence in a host-mapped status word
@@ -257,7 +259,7 @@ class BaseModel(LightningModule):
         inputs = [batch[n] for n in in_names]
         weights = self._no_weights(len(in_names)) if mask_names is None else [None if m is None else batch.get(m) for m in mask_names]
         sg = self.sparse_grad
-        if sg == "fused":
+        if sg in ("fused", "exact"):
             if self._sparse_sink is None:
                 self._sparse_sink = ops.SparseGradSink()
             sg = self._sparse_sink if torch.is_grad_enabled() else False
@@ -395,11 +397,12 @@ class BaseModel(LightningModule):
             table_params = [e.weight for e in self.embedding_tables.values()]
             ids = {id(p) for p in table_params}
             sink = None
-            if self.sparse_grad == "fused":
+            if self.sparse_grad in ("fused", "exact"):
                 if self._sparse_sink is None:
                     self._sparse_sink = ops.SparseGradSink()
                 sink = self._sparse_sink
-            optimizer = SparseDenseAdam(table_params, [p for p in self.parameters() if id(p) not in ids], lr=hp.lr, fused_sink=sink)
+            optimizer = SparseDenseAdam(table_params, [p for p in self.parameters() if id(p) not in ids], lr=hp.lr, fused_sink=sink,
+                                        exact=self.sparse_grad == "exact")
         else:
             from ..model_utils.optim import dense_adamw
             optimizer = dense_adamw(self.parameters(), lr=hp.lr, betas=(0.9, 0.999))     # torch.optim.AdamW; its one-pass kernel on the GPU

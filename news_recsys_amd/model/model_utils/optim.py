@@ -176,17 +176,91 @@ class FusedSparseAdam:
             v.copy_(mv["exp_avg_sq"])
 
 
+class ExactDenseAdamW(FusedSparseAdam):
+    """The reference's optimizer for the tables -- ONE dense torch.optim.AdamW over model.parameters() (sort/deep/model.py:54-65: every row of
+    every table moves every step: decoupled weight decay, decaying moments) -- fed from the row-sparse sink instead of dense .grad tensors:
+    `nrx_rows_mark` notes which rows have a gradient this step, `nrx_dense_adamw_rows` streams over every row of every table once (SURVEY 8f
+    row 2, "exact-dense mode").  Same numbers as torch.optim.AdamW on the dense gradients (tests/test_fused_sparse_adam_gpu.py); no dense
+    gradient is formed, zero-filled or read.  Every table in `params` is updated on every step(), looked up or not -- like AdamW with a zero
+    gradient.  exp_avg / exp_avg_sq are plain [rows, dim] tensors (torch's layout)."""
+
+    def __init__(self, sink, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, capturable=False):
+        super().__init__(sink, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable, params=list(params))
+        self.maps = []
+        for t in self.params:
+            self._register(t)
+
+    def _register(self, t: torch.Tensor) -> int:
+        i = self._index.get(id(t))
+        if i is None:
+            i = len(self.tables)
+            self._index[id(t)] = i
+            self.tables.append(t)
+            self.moments.append((torch.zeros_like(t), torch.zeros_like(t)))
+            self.maps.append(torch.full((t.shape[0],), -1, dtype=torch.int32, device=t.device))
+        return i
+
+    @torch.no_grad()
+    def step(self):
+        lib = _lib.load()
+        self.t += 1
+        by_dim = {}
+        for e in self.sink.pending:
+            by_dim.setdefault(e["dim"], []).append((self._global_keys(e), e["values"]))
+        n = len(self.tables)
+        if n > _lib.NRX_MAX_FEATURES:
+            raise NotImplementedError("ExactDenseAdamW: more than 64 distinct tables")
+        b1, b2 = self.betas
+        hyper = None
+        if self.capturable:             # the step count lives on the device: a captured loop advances the bias corrections between replays
+            dev0 = self.tables[0].device
+            if self._t_dev is None:
+                self._t_dev = torch.zeros((), dtype=torch.float64, device=dev0)
+            self._t_dev += 1
+            hyper = torch.stack([self.lr / (1.0 - b1 ** self._t_dev), 1.0 / torch.sqrt(1.0 - b2 ** self._t_dev)]).to(torch.float32)
+        elif torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ExactDenseAdamW: construct with capturable=True to capture step() in a graph (the step count is baked in otherwise)")
+        for dim in sorted({t.shape[1] for t in self.tables}):
+            idx = [i for i, t in enumerate(self.tables) if t.shape[1] == dim]
+            dev = self.tables[idx[0]].device
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            k = len(idx)
+            rows = (C.c_int64 * n)(*[t.shape[0] for t in self.tables])
+            maps_all = (C.c_void_p * n)(*[m.data_ptr() for m in self.maps])
+            vals = None
+            lst = by_dim.get(dim)
+            if lst:
+                if len(lst) == 1:
+                    keys, vals = lst[0]
+                else:       # one table fed by several backward groups: ONE gradient per row
+                    keys, vals = self._merge(torch.cat([kk for kk, _ in lst]), torch.cat([v for _, v in lst]))
+                ops.check(lib.nrx_rows_mark(keys.data_ptr(), keys.numel(), None, maps_all, rows, n, stream), "nrx_rows_mark")
+            tp = (C.c_void_p * k)(*[self.tables[i].data_ptr() for i in idx])
+            mp = (C.c_void_p * k)(*[self.moments[i][0].data_ptr() for i in idx])
+            vp = (C.c_void_p * k)(*[self.moments[i][1].data_ptr() for i in idx])
+            sp = (C.c_void_p * k)(*[self.maps[i].data_ptr() for i in idx])
+            rk = (C.c_int64 * k)(*[self.tables[i].shape[0] for i in idx])
+            ops.check(lib.nrx_dense_adamw_rows(tp, mp, vp, sp, rk, k, dim, vals.data_ptr() if vals is not None else None, self.t, self.lr, b1, b2,
+                                               self.eps, self.weight_decay, hyper.data_ptr() if hyper is not None else None, stream),
+                      "nrx_dense_adamw_rows")
+        self.sink.clear()
+
+
 class SparseDenseAdam(torch.optim.Optimizer):
     def __init__(self, sparse_params, dense_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, fused_sink=None,
-                 capturable=False):
+                 capturable=False, exact=False):
         """fused_sink: an ops.SparseGradSink -> the tables are updated by FusedSparseAdam from the sink instead of
-        torch.optim.SparseAdam from COO .grad tensors."""
+        torch.optim.SparseAdam from COO .grad tensors.  exact (with fused_sink): by ExactDenseAdamW -- the reference's dense AdamW over every
+        row, weight decay included, fed from the sink."""
         sparse_params, dense_params = list(sparse_params), list(dense_params)
         groups = [{"params": sparse_params, "sparse": True}]
         if dense_params:
             groups.append({"params": dense_params, "sparse": False})
         super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._sparse = (FusedSparseAdam(fused_sink, lr=lr, betas=betas, eps=eps, capturable=capturable, params=sparse_params)
+        if exact and fused_sink is None:
+            raise ValueError("SparseDenseAdam(exact=True) needs fused_sink")
+        self._sparse = (ExactDenseAdamW(fused_sink, sparse_params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable) if exact else
+                        FusedSparseAdam(fused_sink, lr=lr, betas=betas, eps=eps, capturable=capturable, params=sparse_params)
                         if fused_sink is not None
                         else torch.optim.SparseAdam(sparse_params, lr=lr, betas=betas, eps=eps))
         self._dense = (torch.optim.AdamW(dense_params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable)

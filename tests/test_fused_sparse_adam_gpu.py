@@ -166,3 +166,130 @@ def test_sparse_dense_adam_fused_checkpoint_resume():
         assert torch.equal(a.detach(), b.detach())
         assert not torch.equal(a.detach(), c.detach())
     assert torch.equal(lin.weight, lin_b.weight)
+
+
+@pytest.mark.parametrize("shared", [False, True])
+@pytest.mark.parametrize("B", [200, 6000])
+def test_exact_dense_adamw_from_the_sink_matches_torch_adamw_on_dense_gradients(shared, B):
+    """optim.ExactDenseAdamW (nrx_rows_mark + nrx_dense_adamw_rows) = the reference's optimizer for the tables, one dense torch.optim.AdamW
+    over every parameter (src/model/sort/deep/model.py:54-65): EVERY row of EVERY table moves every step (weight decay, decaying moments),
+    also a table no lookup touched.  Same weights and moments as torch.optim.AdamW fed with the dense gradients of the default mode; B = 200
+    goes through the one-launch small backward (filler keys), B = 6000 through the planned reduction (device-side count)."""
+    from news_recsys_amd import ops
+    from news_recsys_amd.model.model_utils.optim import ExactDenseAdamW
+    plan, tables, batch = _setup(7, shared)
+    extra = torch.randn(23, 16, device=DEV)                                       # a table of the model that this step never looks up
+    ref = [t.clone().requires_grad_(True) for t in tables + [extra]]
+    exa = [t.clone().requires_grad_(True) for t in tables + [extra]]
+    opt_ref = torch.optim.AdamW(ref, lr=0.03, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    sink = ops.SparseGradSink()
+    opt_exa = ExactDenseAdamW(sink, exa, lr=0.03, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for step in range(4):
+        ins, ws, up = batch()
+        if B != 200:                                                              # a larger batch of the same plan
+            rep = B // 200
+            ins = [x.repeat((rep,) + (1,) * (x.dim() - 1)) for x in ins]
+            ws = [None if w is None else w.repeat(rep, 1) for w in ws]
+            up = torch.randn(B, 56, device=DEV, generator=g)
+        if step == 2:
+            opt_ref.param_groups[0]["lr"] = opt_exa.lr = 0.01                     # a scheduler's edit
+        opt_ref.zero_grad()
+        (ops.embed_apply(plan, ref[:3], ins, ws)[0] * up).sum().backward()
+        ref[3].grad = torch.zeros_like(ref[3])                                    # AdamW moves a parameter whose gradient is zero
+        opt_ref.step()
+        (ops.embed_apply(plan, exa[:3], ins, ws, sparse_grad=sink)[0] * up).sum().backward()
+        assert all(t.grad is None for t in exa)
+        opt_exa.step()
+        assert not sink.pending and all(int((m >= 0).sum()) == 0 for m in opt_exa.maps)      # the slot maps are clean again
+    for i, (a, b) in enumerate(zip(ref, exa)):
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-5, atol=2e-6)
+        st = opt_ref.state[a]
+        # (the moments see the two backwards' fp32 addition orders directly: rows that sum ~100 terms differ by ~1e-5 absolute)
+        torch.testing.assert_close(st["exp_avg"], opt_exa.moments[i][0], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(st["exp_avg_sq"], opt_exa.moments[i][1], rtol=1e-4, atol=1e-5)
+    assert not torch.equal(exa[3].detach(), extra)                                # the untouched table decayed
+
+
+def test_model_trains_with_exact_sparse_grad_like_the_default_mode(tmp_path):
+    """`embeddings.sparse_grad: exact` through a model class against the default mode (dense .grad + torch.optim.AdamW over every parameter,
+    the reference's configure_optimizers): same parameters after a few steps from the same initialisation."""
+    import os
+    import yaml
+    import torch.nn.functional as F
+    from news_recsys_amd.model.sort.deep.model import Deep
+    from tests.conftest import CONFIGS
+    models = []
+    for mode in (False, "exact"):
+        cfg = yaml.safe_load(open(os.path.join(CONFIGS, "cf_array_small.yaml")))
+        cfg["embeddings"]["sparse_grad"] = mode
+        cfg["train_hparams"]["lr_milestones"] = [2000, 5000]
+        p = tmp_path / f"m_{mode}.yaml"
+        p.write_text(yaml.safe_dump(cfg))
+        torch.manual_seed(0)
+        models.append(Deep(str(p)).to(DEV))
+    models[1].load_state_dict(models[0].state_dict())
+    m0 = models[0]
+    g = torch.Generator(device=DEV).manual_seed(1)
+    b = {}
+    for n in m0.sparse_feature_names:
+        b[n] = torch.randint(1, m0.embedding_tables[m0._get_emb_feature_name(n)].weight.shape[0], (128,), device=DEV, generator=g)
+    for n in m0.array_feature_names:
+        b[n] = torch.randint(1, m0.embedding_tables[m0._get_emb_feature_name(n)].weight.shape[0], (128, 9), device=DEV, generator=g)
+        b[n + "_mask"] = (torch.rand(128, 9, device=DEV, generator=g) < 0.6).float()
+    b["label"] = (torch.rand(128, 2, device=DEV, generator=g) < 0.4).float()
+    for m in models:
+        opt = m.configure_optimizers()["optimizer"]
+        for _ in range(5):
+            opt.zero_grad()
+            F.binary_cross_entropy(m(b).view(-1), b["label"][:, 0]).backward()
+            opt.step()
+    assert all(e.weight.grad is None for e in models[1].embedding_tables.values())
+    for (k, p0), (_, p1) in zip(models[0].named_parameters(), models[1].named_parameters()):
+        torch.testing.assert_close(p0.detach(), p1.detach(), rtol=2e-4, atol=2e-6, msg=k)
+
+
+def test_exact_dense_adamw_captured_in_a_graph_advances_its_bias_corrections():
+    """ExactDenseAdamW(capturable=True): forward + backward + step() captured once, replayed on new batches -- the step count lives on the
+    device, so replay k uses the bias corrections of step k: same weights as torch.optim.AdamW stepping eagerly on the same batches."""
+    from news_recsys_amd import ops
+    from news_recsys_amd.model.model_utils.optim import ExactDenseAdamW
+    plan, tables, batch = _setup(9, True)
+    ref = [t.clone().requires_grad_(True) for t in tables]
+    exa = [t.clone().requires_grad_(True) for t in tables]
+    opt_ref = torch.optim.AdamW(ref, lr=0.02, weight_decay=0.01)
+    sink = ops.SparseGradSink()
+    opt_exa = ExactDenseAdamW(sink, exa, lr=0.02, weight_decay=0.01, capturable=True)
+    batches = [batch() for _ in range(5)]
+    static = [[x.clone() for x in batches[0][0]], [None if w is None else w.clone() for w in batches[0][1]], batches[0][2].clone()]
+    prev = ops._INDEX_CHECK
+    ops.set_index_check("off")
+    try:
+        def step():
+            (ops.embed_apply(plan, exa, static[0], static[1], sparse_grad=sink)[0] * static[2]).sum().backward()
+            opt_exa.step()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step()                                                               # warm-up = training step 1 (on batch 0)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()                                                               # captured; the capture itself runs nothing
+        for ins, ws, up in batches[1:]:
+            for d, x in zip(static[0], ins):
+                d.copy_(x)
+            for d, x in zip(static[1], ws):
+                if d is not None:
+                    d.copy_(x)
+            static[2].copy_(up)
+            g.replay()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_index_check(prev)
+    for ins, ws, up in batches:
+        opt_ref.zero_grad()
+        (ops.embed_apply(plan, ref, ins, ws)[0] * up).sum().backward()
+        opt_ref.step()
+    for a, b in zip(ref, exa):
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=5e-5, atol=5e-6)

@@ -6,7 +6,7 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from news_recsys_amd import ops
 from news_recsys_amd._lib import NRX_SPARSE
-from news_recsys_amd.model.model_utils.optim import FusedSparseAdam
+from news_recsys_amd.model.model_utils.optim import ExactDenseAdamW, FusedSparseAdam
 ops.set_index_check("off")
 dev = torch.device("cuda:0"); D, F = 16, 26
 gen = torch.Generator(device=dev).manual_seed(5)
@@ -23,7 +23,7 @@ def timed(fn, n=100, reps=3):
 for B in [int(x) for x in os.environ.get("NRX_PROBE_BATCHES", "512,2048").split(",")]:
     ids = [torch.randint(1, 100_000, (B,), device=dev, generator=gen) for _ in range(F)]
     up, upf = torch.randn(B, F * D, device=dev) * 1e-3, torch.randn(B, device=dev) * 1e-3
-    for mode in ("dense", "dense_fusedkernel", "fused"):
+    for mode in ("dense", "dense_fusedkernel", "exact", "fused"):
         tabs = [torch.randn(100_000, D, device=dev).requires_grad_(True) for _ in range(F)]
         if mode.startswith("dense"):
             opt = (torch.optim.AdamW(tabs, lr=1e-3, capturable=True, foreach=True) if mode == "dense" else
@@ -34,7 +34,8 @@ for B in [int(x) for x in os.environ.get("NRX_PROBE_BATCHES", "512,2048").split(
                 torch.autograd.backward([out, fm], [up, upf])
                 opt.step()
         else:
-            sink = ops.SparseGradSink(); opt = FusedSparseAdam(sink, lr=1e-3)
+            sink = ops.SparseGradSink()
+            opt = FusedSparseAdam(sink, lr=1e-3, capturable=True) if mode == "fused" else ExactDenseAdamW(sink, tabs, lr=1e-3, capturable=True)      # exact: dense AdamW over every row, fed from the sink
             def step():
                 out, _, fm = ops.embed_apply(plan, tabs, ids, [None] * F, sparse_grad=sink)
                 torch.autograd.backward([out, fm], [up, upf])
