@@ -611,8 +611,33 @@ def module_path_leg(path: "SingleGpuPath", prepared_fb_ms, steps: int):
             del gs
         except Exception as e:       # noqa: BLE001 -- a secondary figure must not cost the line
             graphed = {"error": f"{type(e).__name__}: {e}"[:300]}
+        train = None
+        if B == 512:
+            # a whole training step of the embedding layer at a batch size the reference's YAMLs use: forward + backward (LightningModule.backward hook) +
+            # optimizer -- `fused`: FusedSparseAdam on the looked-up rows (sparse_grad: fused; the one-launch row-sparse backward feeds its sink),
+            # `exact`: the reference's dense AdamW over every row of the 26 x 1M-row tables, streamed once from the same sink (sparse_grad: exact)
+            try:
+                from news_recsys_amd.model.model_utils.optim import ExactDenseAdamW, FusedSparseAdam
+                tabs = [model.embedding_tables[n].weight for n in names]
+                train = {}
+                for mode in ("fused", "exact"):
+                    opt = (FusedSparseAdam(model._sparse_sink, lr=1e-6, params=tabs) if mode == "fused" else
+                           ExactDenseAdamW(model._sparse_sink, tabs, lr=1e-6, weight_decay=0.0))     # (tiny lr, no decay: the bench's tables stay what they are)
+
+                    def train_step():
+                        it["i"] += 1
+                        p = model(batches[it["i"] & 1])
+                        model.backward(p.sum())
+                        opt.step()
+
+                    t_ms, th_ms = timed(train_step, 100 if mode == "fused" else 20)
+                    train[mode] = {"step_us": t_ms * 1e3, "host_us_per_step": th_ms * 1e3}
+                    del opt
+                    torch.cuda.empty_cache()
+            except Exception as e:       # noqa: BLE001 -- a secondary figure must not cost the line
+                train = {"error": f"{type(e).__name__}: {e}"[:300]}
         out[f"B{B}"] = {"get_embeddings_from_batch_us": g_ms * 1e3, "get_embeddings_from_batch_host_us_per_call": h_ms * 1e3,
-                        "graphed": graphed,
+                        "graphed": graphed, **({"train_step": train} if train is not None else {}),
                         "forward_backward_autograd_us": fb_ms * 1e3, "forward_backward_host_us_per_step": fbh_ms * 1e3,
                         "forward_backward_lightning_hook_us": fbk_ms * 1e3, "forward_backward_lightning_hook_host_us_per_step": fbkh_ms * 1e3,
                         "forward_backward_autograd_us_engine_thread_off": fb1_ms * 1e3,
@@ -631,7 +656,9 @@ def module_path_leg(path: "SingleGpuPath", prepared_fb_ms, steps: int):
                    "torch.autograd.set_multithreading_enabled(False): PyTorch's backward otherwise hands every step to its device thread, ~140 us "
                    "of wake-up and GIL hand-over per step on this host (tools/host_profile_module_step.py); graphed = the same forward + backward "
                    "captured once in a HIP graph (GraphedStep) and replayed: forward_backward_graphed_us includes the copy of the batch's 26 id tensors into "
-                   "the graph's static inputs, replay_only_us is the graph alone; the out-of-range-id check stays on inside the graph (deferred)")
+                   "the graph's static inputs, replay_only_us is the graph alone; the out-of-range-id check stays on inside the graph (deferred); "
+                   "B512.train_step = forward + backward (hook) + optimizer step, eager: `fused` = FusedSparseAdam on the looked-up rows, `exact` = "
+                   "the reference's dense AdamW over every row of the 26 x 1M-row tables (ExactDenseAdamW: 10 GB of table traffic per step by definition)")
     ops.flush_index_checks()
     del model
     return out
