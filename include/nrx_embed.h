@@ -265,7 +265,12 @@ NRX_API int nrx_sparse_adam_step(float* const* tables, float* const* exp_avg, fl
  * (optional, device): {lr / bias_correction1, 1 / sqrt(bias_correction2)} read instead of the values derived from `step` (captured loops).  No dense
  * gradient tensor is formed, zero-filled or read: 6 table-sized transfers per step instead of torch's 7 + the zero fill. */
 NRX_API int nrx_rows_mark(const int64_t* uniq_keys, int64_t n, const int64_t* n_dev, int32_t* const* slot_maps, const int64_t* rows,
-                  int32_t n_tables, void* stream);
+                  int32_t n_tables, int32_t unmark /* != 0: write -1 instead: undo a marking */, void* stream);
+/* Two unique-key lists that may name the same row (DSSM's two towers share the news table, recall/DSSM/model.py:148-180: two backward launches):
+ * with list A marked (nrx_rows_mark), every (key, row) pair of list B whose row A also holds is added to A's row (values_a[slot]) and its key
+ * becomes the filler -1; the other pairs of B stay.  One addition per shared row: deterministic.  Afterwards A and B are disjoint. */
+NRX_API int nrx_rows_merge(int64_t* keys_b, const float* values_b, int64_t n, const int64_t* n_dev, float* values_a, int32_t* const* slot_maps,
+                  const int64_t* rows, int32_t n_tables, int32_t dim, void* stream);
 NRX_API int nrx_dense_adamw_rows(float* const* tables, float* const* exp_avg, float* const* exp_avg_sq, int32_t* const* slot_maps,
                   const int64_t* rows, int32_t n_tables, int32_t dim, const float* grads, int64_t step, float lr, float beta1,
                   float beta2, float eps, float weight_decay, const float* hyper_dev, void* stream);

@@ -73,7 +73,8 @@ SIGNATURES = {
     "nrx_embed_bwd_small": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _p, _i64, _p, _i64, C.POINTER(NrxFmGrad), _i32, _p]),
     "nrx_embed_bwd_small_sparse": (C.c_int, [C.POINTER(NrxFeature), C.POINTER(C.c_int32), _i32, _i64, _p, _i64, _p, _i64, C.POINTER(NrxFmGrad),
                                              _p, _p, _i64, _p]),
-    "nrx_rows_mark": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _p]),
+    "nrx_rows_mark": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _i32, _p]),
+    "nrx_rows_merge": (C.c_int, [_p, _p, _i64, _p, _p, _p, _p, _i32, _i32, _p]),
     "nrx_dense_adamw_rows": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _p, _i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p, _p]),
     "nrx_embed_bwd_sorted_workspace": (_i64, [_i64, _i32]),
     "nrx_embed_bwd_sorted": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _i32, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p,

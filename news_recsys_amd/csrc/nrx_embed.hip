@@ -2417,9 +2417,6 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
         for (int i = tid; i < base; i += NT) uq[i] = -1;
     }
     __syncthreads();
-#if defined(NRX_SD_STOP) && NRX_SD_STOP == 1
-    return;
-#endif
     // ---- how often is each row looked up?  A row looked up ONCE (nearly all of them at these batch sizes over the reference's tables) needs no
     // ordering: its gradient is that one lookup's contribution.  Only the others are sorted -- the full sort was half of the launch.
     const int CNT = N / NT;               // 1, 2 or 4 positions per thread
@@ -2436,9 +2433,6 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
     }
     __syncthreads();
     const int n_single = s_nsingle, n_multi = s_nmulti;
-#if defined(NRX_SD_STOP) && NRX_SD_STOP == 2
-    return;
-#endif
     // ---- per-lookup contribution (columns 4q .. 4q + 3) and the store of a finished row
     const int ql = a->seg_ql[s];
     const int Q = 1 << ql, q = tid & (Q - 1);
@@ -2650,9 +2644,6 @@ __global__ __launch_bounds__(SD_THREADS) void embed_bwd_small_det_kernel(const S
         return;
     }
     singles(0);
-#if defined(NRX_SD_STOP) && NRX_SD_STOP == 3
-    return;
-#endif
     // ---- the other rows: sort their lookups by (row, feature, position), find the runs of equal rows, add each run in that order
     int M = 64;
     while (M < n_multi) M <<= 1;

@@ -1900,6 +1900,7 @@ struct RowsMarkArgs {
     const int64_t* n_dev;
     int64_t max_n;
     int32_t n_tables;
+    int32_t unmark;
 };
 
 __global__ __launch_bounds__(NRX_BLOCK) void rows_mark_kernel(const RowsMarkArgs args_in_kernarg) {
@@ -1914,14 +1915,48 @@ __global__ __launch_bounds__(NRX_BLOCK) void rows_mark_kernel(const RowsMarkArgs
     const int64_t key = nrx_gconst<int64_t>(a->keys)[i];
     const int64_t t = key >> 40, row = key & ((1ll << 40) - 1);
     if (key < 0 || t >= a->n_tables || row == 0) return;         // filler keys; the padding row never trains
-    if (row < a->rows[t]) a->map[t][row] = (int32_t)i;
+    if (row < a->rows[t]) a->map[t][row] = a->unmark ? -1 : (int32_t)i;
+}
+
+// Two unique-key lists that may name the same row (DSSM's towers share the news table: two backward launches, two sink entries): with list A
+// marked in the slot maps, every pair of list B whose row A also has is ADDED to A's row and its key becomes the filler -1; the rest of B stays.
+// A row has at most one pair in each list, so every sum is one addition: deterministic.  One lane group per pair of B.
+struct RowsMergeArgs {
+    int32_t* map[NRX_MAX_FEATURES];
+    int64_t rows[NRX_MAX_FEATURES];
+    int64_t* keys_b;
+    const float* values_b;
+    float* values_a;
+    const int64_t* n_dev;
+    int64_t max_n;
+    int32_t n_tables, dim;
+};
+
+__global__ __launch_bounds__(NRX_BLOCK) void rows_merge_kernel(const RowsMergeArgs args_in_kernarg) {
+    const NRX_CONST RowsMergeArgs* a = nrx_kernarg<RowsMergeArgs>();
+    int64_t n = a->max_n;
+    if (a->n_dev != nullptr) {
+        const int64_t nd = nrx_gconst<int64_t>(a->n_dev)[0];
+        n = nd < n ? nd : n;
+    }
+    const int q = threadIdx.x & 15;                              // 16 lanes per pair
+    const int64_t j = ((int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x) >> 4;
+    if (j >= n) return;
+    const int64_t key = a->keys_b[j];
+    const int64_t t = key >> 40, row = key & ((1ll << 40) - 1);
+    if (key < 0 || t >= a->n_tables || row == 0 || row >= a->rows[t]) return;
+    const int32_t sa = a->map[t][row];
+    if (sa < 0) return;
+    const int D = a->dim;
+    for (int k = q; k < D; k += 16) a->values_a[(int64_t)sa * D + k] += a->values_b[j * D + k];
+    if (q == 0) a->keys_b[j] = -1;
 }
 
 // slot_maps[t][row] = i for every key i = (t << 40 | row) of the list (negative keys and keys of tables >= n_tables are fillers; row 0 is the
 // padding row): the per-table row -> gradient-slot maps nrx_dense_adamw_rows reads.  The maps must be all -1 before (they are again after
-// nrx_dense_adamw_rows).  Keys must be unique.
+// nrx_dense_adamw_rows).  Keys must be unique.  unmark != 0: writes -1 instead (undoes a marking).
 extern "C" int nrx_rows_mark(const int64_t* uniq_keys, int64_t n, const int64_t* n_dev, int32_t* const* slot_maps, const int64_t* rows,
-                             int32_t n_tables, void* stream) {
+                             int32_t n_tables, int32_t unmark, void* stream) {
     NRX_TRACE();
     NRX_REQUIRE(n >= 0 && n <= 0x7fffffffll && n_tables >= 1 && n_tables <= NRX_MAX_FEATURES, "nrx_rows_mark: bad argument");
     if (n == 0) return NRX_OK;
@@ -1932,9 +1967,28 @@ extern "C" int nrx_rows_mark(const int64_t* uniq_keys, int64_t n, const int64_t*
         a.map[t] = slot_maps[t];
         a.rows[t] = rows[t];
     }
-    a.keys = uniq_keys; a.n_dev = n_dev; a.max_n = n; a.n_tables = n_tables;
+    a.keys = uniq_keys; a.n_dev = n_dev; a.max_n = n; a.n_tables = n_tables; a.unmark = unmark != 0;
     hipLaunchKernelGGL(rows_mark_kernel, dim3((unsigned)((n + NRX_BLOCK - 1) / NRX_BLOCK)), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), a);
     NRX_LAUNCH_CHECK("nrx_rows_mark");
+    return NRX_OK;
+}
+
+// keys_b / values_b [n, dim] merged into the list marked in slot_maps (values_a: its [.., dim] rows): see rows_merge_kernel.
+extern "C" int nrx_rows_merge(int64_t* keys_b, const float* values_b, int64_t n, const int64_t* n_dev, float* values_a, int32_t* const* slot_maps,
+                              const int64_t* rows, int32_t n_tables, int32_t dim, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(n >= 0 && n_tables >= 1 && n_tables <= NRX_MAX_FEATURES && dim >= 1, "nrx_rows_merge: bad argument");
+    if (n == 0) return NRX_OK;
+    NRX_REQUIRE(keys_b && values_b && values_a && slot_maps && rows, "nrx_rows_merge: null buffer");
+    RowsMergeArgs a;
+    for (int t = 0; t < n_tables; ++t) {
+        NRX_REQUIRE(slot_maps[t] != nullptr && rows[t] >= 1, "nrx_rows_merge: table %d: null map / no rows", t);
+        a.map[t] = slot_maps[t];
+        a.rows[t] = rows[t];
+    }
+    a.keys_b = keys_b; a.values_b = values_b; a.values_a = values_a; a.n_dev = n_dev; a.max_n = n; a.n_tables = n_tables; a.dim = dim;
+    hipLaunchKernelGGL(rows_merge_kernel, dim3((unsigned)((n * 16 + NRX_BLOCK - 1) / NRX_BLOCK)), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), a);
+    NRX_LAUNCH_CHECK("nrx_rows_merge");
     return NRX_OK;
 }
 

@@ -54,6 +54,8 @@ class FusedSparseAdam:
         self.moments = []        # (exp_avg, exp_avg_sq) per table
         self._gmaps = {}         # table-list identity -> device map (launch-local table index -> position)
         self._identity = {}      # table-list identity -> that map is the identity
+        self._maps = []          # per-table slot maps of the two-list merge (made on first use)
+        self.pair_merge = True   # two backward groups of one width: merge by marking (False: the sort-based _merge)
 
     def _register(self, t: torch.Tensor) -> int:
         i = self._index.get(id(t))
@@ -128,17 +130,38 @@ class FusedSparseAdam:
         tp = (C.c_void_p * n)(*[t.data_ptr() for t in self.tables])
         mp = (C.c_void_p * n)(*[m.data_ptr() for m, _ in self.moments])
         vp = (C.c_void_p * n)(*[v.data_ptr() for _, v in self.moments])
-        for dim, lst in by_dim.items():
-            if len(lst) == 1:
-                keys, vals = lst[0]
-            else:       # one table fed by several backward groups (DSSM's towers share the news table): ONE update per row
-                keys, vals = self._merge(torch.cat([k for k, _ in lst]), torch.cat([v for _, v in lst]))
-            dev = keys.device
+        def adam(keys, vals):
             ops.check(lib.nrx_sparse_adam_step(tp, mp, vp, n, dim, keys.data_ptr(), vals.data_ptr(), keys.numel(), None,
                                                step_size, ss_dev.data_ptr() if ss_dev is not None else None, b1, b2, self.eps,
                                                self.lr * self.weight_decay,
-                                               torch.cuda.current_stream(dev).cuda_stream), "nrx_sparse_adam_step")
+                                               torch.cuda.current_stream(keys.device).cuda_stream), "nrx_sparse_adam_step")
+
+        for dim, lst in by_dim.items():
+            if len(lst) == 1:
+                adam(*lst[0])
+            elif len(lst) == 2 and self.pair_merge:
+                # one table fed by two backward groups (DSSM's towers share the news table): ONE update per row.  List A is marked in per-table
+                # slot maps, the pairs of B that A also holds are added into A's rows and blanked (nrx_rows_merge), A is unmarked; the two lists
+                # are then disjoint: three small launches instead of a device sort + segment sums over the concatenation
+                (ka, va), (kb, vb) = lst
+                stream = torch.cuda.current_stream(ka.device).cuda_stream
+                maps = self._slot_maps()
+                rows = (C.c_int64 * n)(*[t.shape[0] for t in self.tables])
+                ops.check(lib.nrx_rows_mark(ka.data_ptr(), ka.numel(), None, maps, rows, n, 0, stream), "nrx_rows_mark")
+                ops.check(lib.nrx_rows_merge(kb.data_ptr(), vb.data_ptr(), kb.numel(), None, va.data_ptr(), maps, rows, n, dim, stream), "nrx_rows_merge")
+                ops.check(lib.nrx_rows_mark(ka.data_ptr(), ka.numel(), None, maps, rows, n, 1, stream), "nrx_rows_mark")
+                adam(ka, va)
+                adam(kb, vb)
+            else:
+                adam(*self._merge(torch.cat([k for k, _ in lst]), torch.cat([v for _, v in lst])))
         self.sink.clear()
+
+    def _slot_maps(self):
+        """int32 [rows] per table, all -1 between uses (nrx_rows_mark / nrx_rows_merge): made when a step first needs them."""
+        while len(self._maps) < len(self.tables):
+            t = self.tables[len(self._maps)]
+            self._maps.append(torch.full((t.shape[0],), -1, dtype=torch.int32, device=t.device))
+        return (C.c_void_p * len(self._maps))(*[m.data_ptr() for m in self._maps])
 
     def zero_grad(self, set_to_none: bool = True):
         self.sink.clear()
@@ -234,7 +257,7 @@ class ExactDenseAdamW(FusedSparseAdam):
                     keys, vals = lst[0]
                 else:       # one table fed by several backward groups: ONE gradient per row
                     keys, vals = self._merge(torch.cat([kk for kk, _ in lst]), torch.cat([v for _, v in lst]))
-                ops.check(lib.nrx_rows_mark(keys.data_ptr(), keys.numel(), None, maps_all, rows, n, stream), "nrx_rows_mark")
+                ops.check(lib.nrx_rows_mark(keys.data_ptr(), keys.numel(), None, maps_all, rows, n, 0, stream), "nrx_rows_mark")
             tp = (C.c_void_p * k)(*[self.tables[i].data_ptr() for i in idx])
             mp = (C.c_void_p * k)(*[self.moments[i][0].data_ptr() for i in idx])
             vp = (C.c_void_p * k)(*[self.moments[i][1].data_ptr() for i in idx])

@@ -21,6 +21,7 @@ import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -831,8 +832,7 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
             if total == 0:
                 continue
             arr = _group_features(grp, ids, [ctx.ws[i] for i in fs], fmg is not None)
-            import numpy as _np
-            _np.frombuffer(arr, dtype=_feature_np_dtype())["rows"] = grp["rows"]
+            np.frombuffer(arr, dtype=_feature_np_dtype())["rows"] = grp["rows"]
             uniq = torch.empty(total, dtype=torch.int64, device=dev)
             values = torch.empty((total, D), dtype=torch.float32, device=dev)
             rc = lib.nrx_embed_bwd_small_sparse(arr, grp["static"][0], n, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, fmg,
@@ -860,8 +860,7 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
                 dense_ptrs = (C.c_void_p * n_tables)(*[g.data_ptr() for g in dense_into])
             again = any(t in dense_seen for t in tabs)
             arr = _group_features(grp, ids, [ctx.ws[i] for i in fs], fmg is not None, [dense_into[t].data_ptr() for t in tabs])
-            import numpy as _np
-            _np.frombuffer(arr, dtype=_feature_np_dtype())["rows"] = grp["rows"]
+            np.frombuffer(arr, dtype=_feature_np_dtype())["rows"] = grp["rows"]
             wsz = grp.get("fused_ws")
             if wsz is None or wsz[0] != B:
                 wsz = grp["fused_ws"] = (B, lib.nrx_embed_bwd_dense_sorted_workspace(arr, n, B, D, n_tables))

@@ -57,7 +57,8 @@ def test_fused_sparse_adam_matches_torch_sparse_adam(shared):
         assert torch.equal(b[0], torch.zeros_like(b[0]))                         # the padding row never moves
 
 
-def test_fused_sparse_adam_merges_two_backward_groups_on_one_table():
+@pytest.mark.parametrize("pair_merge", [True, False])
+def test_fused_sparse_adam_merges_two_backward_groups_on_one_table(pair_merge):
     """Two embed calls reading the SAME table in one step (DSSM towers): one Adam update per row with the summed
     gradient, exactly what SparseAdam does with the accumulated COO grad."""
     from news_recsys_amd import ops
@@ -73,6 +74,7 @@ def test_fused_sparse_adam_merges_two_backward_groups_on_one_table():
     opt_ref = torch.optim.SparseAdam(ref, lr=0.1)
     sink = ops.SparseGradSink()
     opt_fus = FusedSparseAdam(sink, lr=0.1)
+    opt_fus.pair_merge = pair_merge              # True (default): nrx_rows_mark / nrx_rows_merge; False: the sort-based merge
     for _ in range(3):
         ia = [torch.randint(1, 40, (64,), device=DEV, generator=g), torch.randint(1, 30, (64,), device=DEV, generator=g)]
         ib = [torch.randint(1, 40, (64,), device=DEV, generator=g)]
@@ -87,6 +89,8 @@ def test_fused_sparse_adam_merges_two_backward_groups_on_one_table():
         loss.backward()
         assert len(sink.pending) == 2
         opt_fus.step()
+        assert all(int((m >= 0).sum()) == 0 for m in opt_fus._maps)               # the slot maps are clean between steps
+    assert (len(opt_fus._maps) > 0) == pair_merge
     for a, b in zip(ref, fus):
         torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-5, atol=2e-6)
 
