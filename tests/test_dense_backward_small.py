@@ -379,3 +379,45 @@ def test_small_row_sparse_form_tower_with_history_bag(kind, monkeypatch):
     got, _ = _sink_dense(plan, tables, inputs, weights, ups, monkeypatch)
     for a, b in zip(dense, got):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+@pytest.mark.parametrize("case", ["all_distinct_4096", "one_row_4096", "multi_64", "multi_65", "multi_256_of_3", "two_rows_alternating"])
+def test_small_backward_at_the_edges_of_its_paths(case, monkeypatch):
+    """The kernel's internal switches: a full table of 4096 distinct rows (hash table at its densest), ONE row looked up 4096 times (a
+    single wavefront-summed run), exactly 64 / 65 lookups sharing rows (the last size wavefront 0 sorts alone / the first the block sorts),
+    runs of three, two rows taking turns."""
+    rng = np.random.default_rng(17)
+    D, rows = 16, 6000
+    B = 4096
+    if case == "all_distinct_4096":
+        ids = rng.permutation(np.arange(1, rows))[:B]
+    elif case == "one_row_4096":
+        ids = np.full(B, 77)
+    elif case in ("multi_64", "multi_65"):
+        ids = rng.permutation(np.arange(200, rows))[:B]
+        ids[:64] = np.repeat(np.arange(1, 33), 2)                             # 32 rows looked up twice: 64 lookups that need ordering
+        if case == "multi_65":
+            ids[64] = 1                                                       # ... one of them a third time
+        ids = rng.permutation(ids)
+    elif case == "multi_256_of_3":
+        ids = rng.permutation(np.arange(400, rows))[:B]
+        ids[:768] = np.repeat(np.arange(1, 257), 3)
+        ids = rng.permutation(ids)
+    else:
+        ids = np.where(np.arange(B) % 2 == 0, 5, 9)
+    ids = np.asarray(ids, np.int64)
+    plan = ops.EmbedPlan([ops.Slot("f", NRX_SPARSE, 0, D, 0, 0, fm_field=1)], out_width=D, use_fm=True)
+    tables = [torch.from_numpy(rng.standard_normal((rows, D)).astype(np.float32)).to(DEV)]
+    inputs = [torch.from_numpy(ids).to(DEV)]
+    up = rng.standard_normal((B, D)).astype(np.float32)
+    upf = rng.standard_normal((B,)).astype(np.float32)
+    ups = (torch.from_numpy(up).to(DEV), None, torch.from_numpy(upf).to(DEV))
+    got = _check(plan, tables, inputs, [None], ups, monkeypatch, tol=2e-4)
+    # one FM field: S = v, so d fm / d v_k = 0 for k >= 1 and 1 for k = 0
+    g = up.astype(np.float64).copy()
+    g[:, 0] += upf
+    want = np.zeros((rows, D))
+    np.add.at(want, ids, g)
+    np.testing.assert_allclose(got[0].cpu().numpy(), want, rtol=3e-4, atol=3e-4)
+    sink_rows, lookups = _sink_dense(plan, tables, inputs, [None], ups, monkeypatch)
+    assert lookups == B and torch.equal(sink_rows[0].view(torch.int32), got[0].view(torch.int32))
