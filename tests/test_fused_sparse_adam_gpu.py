@@ -132,10 +132,11 @@ def test_model_trains_with_fused_sparse_grad(tmp_path):
         assert torch.isfinite(m(b)).all()
 
 
-def test_sparse_dense_adam_fused_checkpoint_resume():
+@pytest.mark.parametrize("exact", [False, True])
+def test_sparse_dense_adam_fused_checkpoint_resume(exact):
     """optimizer.state_dict() must carry FusedSparseAdam's moments and step count -- a run restored from it
     continues bit-identically (the sorted backward and the fused step are deterministic), a run restarted without it
-    does not."""
+    does not.  exact: the same for ExactDenseAdamW (the reference's dense AdamW fed from the sink)."""
     import copy
     from news_recsys_amd import ops
     from news_recsys_amd.model.model_utils.optim import SparseDenseAdam
@@ -146,7 +147,7 @@ def test_sparse_dense_adam_fused_checkpoint_resume():
     def build(tabs, lin_):
         sink = ops.SparseGradSink()
         ps = [t.clone().requires_grad_(True) for t in tabs]
-        return ps, sink, SparseDenseAdam(ps, list(lin_.parameters()), lr=0.05, fused_sink=sink)
+        return ps, sink, SparseDenseAdam(ps, list(lin_.parameters()), lr=0.05, fused_sink=sink, exact=exact)
 
     def run(ps, sink, opt, lin_, bs):
         for ins, ws, up in bs:
