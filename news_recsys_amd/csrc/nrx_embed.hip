@@ -1125,6 +1125,7 @@ struct PlaceArgs {
     int32_t* long_ws;                    // the walk's four work-list counters: cleared here (the walk is the next launch)
     int32_t n;
     int32_t nt;                          // non-temporal upstream loads (default; NRX_PLACE_NT=0 turns them off): the rows are read once
+    int32_t pair;                        // two features per ring step (NRX_PLACE_PAIR)
     // DENSE (nrx_embed_bwd_placed_dense): a placed row goes straight to its place in the table's dense gradient -- the lookup's own id
     // names the row (the ids are read where they lie, sample-major), dest >= 0 only says "placed"
     const void* ids[NRX_MAX_FEATURES];   // per placeable feature
@@ -1233,6 +1234,20 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceA
             int32_t dn[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) dn[u] = s_my[(f0 + U + u) * TB];
+            if (a->pair) {
+                // two features per step: the 64-byte pieces of features 2j and 2j + 1 of a sample are the two halves of one 128-byte line of the
+                // upstream rows -- requested back to back they are one L2 request, a store apart they were often two
+#pragma unroll
+                for (int u = 0; u < U; u += 2) {
+                    place(f0 + u, d[u], g[u], v[u]);
+                    place(f0 + u + 1, d[u + 1], g[u + 1], v[u + 1]);
+                    d[u] = dn[u];
+                    d[u + 1] = dn[u + 1];
+                    fetch(f0 + U + u, d[u], g[u], v[u]);
+                    fetch(f0 + U + u + 1, d[u + 1], g[u + 1], v[u + 1]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 place(f0 + u, d[u], g[u], v[u]);
@@ -3093,6 +3108,7 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             pa.long_ws = a.long_ws;
             pa.n = n_place;
             { const char* e = getenv("NRX_PLACE_NT"); pa.nt = e ? atoi(e) : 1; }
+            { const char* e = getenv("NRX_PLACE_PAIR"); pa.pair = e ? atoi(e) : 1; }      // C2: 318 -> 267 MB fetched per launch, 72.5 -> 70.7 us; C5 77.5 -> 75.6 us
             const int uvar = getenv("NRX_PLACE_U") ? atoi(getenv("NRX_PLACE_U")) : 4;       // fetches in flight per lane (4 | 8)
             const unsigned pgrid = (unsigned)((batch + tb - 1) / tb);
             const size_t plds = (size_t)n_place * tb * 4;
