@@ -1234,6 +1234,16 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceA
             int32_t dn[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) dn[u] = s_my[(f0 + U + u) * TB];
+            if (a->pair == 2) {               // (measurement form: all U stores, then all U fetches)
+#pragma unroll
+                for (int u = 0; u < U; ++u) place(f0 + u, d[u], g[u], v[u]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    d[u] = dn[u];
+                    fetch(f0 + U + u, d[u], g[u], v[u]);
+                }
+                continue;
+            }
             if (a->pair) {
                 // two features per step: the 64-byte pieces of features 2j and 2j + 1 of a sample are the two halves of one 128-byte line of the
                 // upstream rows -- requested back to back they are one L2 request, a store apart they were often two

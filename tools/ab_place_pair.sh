@@ -2,7 +2,7 @@
 # Dev (GPU box): the placement pass with one feature per ring step against two (NRX_PLACE_PAIR=1: the two 64-byte halves of an upstream line
 # requested back to back): kernel time (rocprofv3 --kernel-trace --stats) and fetched bytes (--pmc FETCH_SIZE, its own pass) on tools/profile_fwd_bwd.py.
 cd /tmp && export TMPDIR=/tmp
-for P in 0 1 0 1; do
+for P in ${PAIRS:-0 1 0 1}; do
   export NRX_PLACE_PAIR=$P
   rm -rf /tmp/pp_s /tmp/pp_f
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp_s -- python3 $GRAFT_REPO_ROOT/tools/profile_fwd_bwd.py ${WL:-c2} > /tmp/pp_s.log 2>&1
