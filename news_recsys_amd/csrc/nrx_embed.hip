@@ -2182,6 +2182,7 @@ extern "C" int nrx_embed_fwd_train(const nrx_feature_t* feats, int32_t n_feats, 
                     if (el[i] && feats[i].dim == D0) lines = (feats[i].out_col & 31) == 0;
                 const char* e = getenv("NRX_FWD_STNT");
                 ua.stnt = e ? atoi(e) : (lines ? 1 : 0);
+                { const char* e2 = getenv("NRX_FWD_PAIR"); ua.pair = e2 ? atoi(e2) : 1; }      // C2: 62.83 -> 62.46 us (three alternated pairs of runs on one box)
             }
             ua.fm_out = fm_out;
             ua.fm_sums = (fm_out != nullptr && n_fm > 0) ? fm_sums : nullptr;
