@@ -26,6 +26,7 @@ struct UniformWideArgs {
     int32_t* status;
     int32_t n;
     int32_t idx64;
+    int32_t pair;                         // 1 (default): two features per ring step -- two rows' chunk stores, then two row loads (NRX_WIDE_PAIR=0: one)
     int32_t stnt;                         // 1: the aligned chunks leave with non-temporal stores (rows on whole 128-byte lines: written once, read by the MLP later)
 };
 static_assert(sizeof(UniformWideArgs) <= 3584, "kernarg budget");
@@ -215,6 +216,16 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_ring_wide(const UniformWi
         int32_t idn[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) idn[u] = s_my[(f0 + R + u) * TB];
+        if (R % 2 == 0 && a->pair) {
+#pragma unroll
+            for (int u = 0; u + 1 < R; u += 2) {
+                put(f0 + u, v[u]);
+                put(f0 + u + 1, v[u + 1]);
+                v[u] = load_row<QLOG2, NT>(a->table[f0 + R + u], idn[u], q);
+                v[u + 1] = load_row<QLOG2, NT>(a->table[f0 + R + u + 1], idn[u + 1], q);
+            }
+            continue;
+        }
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             put(f0 + u, v[u]);
@@ -302,6 +313,7 @@ bool nrx_launch_uniform_wide(const nrx_feature_t* feats, int32_t n_feats, int64_
     const bool nt = table_bytes > (256ll << 20);
     ua.idx64 = i64;
     { const char* e = getenv("NRX_FWD_STNT"); ua.stnt = e ? atoi(e) : 0; }
+    { const char* e = getenv("NRX_WIDE_PAIR"); ua.pair = e ? atoi(e) : 1; }      // C5 split 149.1 -> 143.6 us (tools/probe_pair.py, one process, same tables)
     if (n_feats >= 8 && n_feats * (NRX_BLOCK / (D0 / 4)) * 4 <= 48 * 1024) {      // ring form: >= R features, ids fit a modest LDS tile
         // aligned-chunk stores (WideAl): a gap-free deep row in feature order that starts on a 16-byte boundary, row stride % 4 floats == 0
         bool al = nrx_aligned16(out) && (out_ld & 3) == 0 && (feats[0].out_col & 3) == 0;
