@@ -37,7 +37,6 @@ struct UniformArgs {
     int32_t n;
     int32_t idx64;                    // ids are int64 (else int32)
     int32_t stnt;                     // 1: the concat leaves with non-temporal stores (measurement knob NRX_FWD_STNT)
-    int32_t pair;                     // 1: two features per ring step -- two stores, then two loads (measurement knob NRX_FWD_PAIR)
     int32_t unal;                     // 1: some first column (or `out` / out_ld) is not a multiple of 4 floats -- a dense value in the
                                       //    middle of the sorted feature order shifts everything after it: col4[] and ld4 are then in
                                       //    FLOATS and the row leaves as a dword-aligned 16-byte store (global memory needs no more)
@@ -185,16 +184,6 @@ __global__ __launch_bounds__(NRX_BLOCK, MINW) void embed_fwd_ring(const UniformA
         int32_t idn[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) idn[u] = s_my[(f0 + R + u) * TB];
-        if (R % 2 == 0 && a->pair) {      // (R = 1 exists for launches of very few features)
-#pragma unroll
-            for (int u = 0; u + 1 < R; u += 2) {
-                consume<Q, FM, STORE>(a, f0 + u, v[u], q, row4, fm_first, fm_s, fm_q);
-                consume<Q, FM, STORE>(a, f0 + u + 1, v[u + 1], q, row4, fm_first, fm_s, fm_q);
-                v[u] = load_row<QLOG2, NT>(a->table[f0 + R + u], idn[u], q);
-                v[u + 1] = load_row<QLOG2, NT>(a->table[f0 + R + u + 1], idn[u + 1], q);
-            }
-            continue;
-        }
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             consume<Q, FM, STORE>(a, f0 + u, v[u], q, row4, fm_first, fm_s, fm_q);
