@@ -1125,7 +1125,6 @@ struct PlaceArgs {
     int32_t* long_ws;                    // the walk's four work-list counters: cleared here (the walk is the next launch)
     int32_t n;
     int32_t nt;                          // non-temporal upstream loads (default; NRX_PLACE_NT=0 turns them off): the rows are read once
-    int32_t pair;                        // host side only: features per ring step = which STEP instantiation is launched (NRX_PLACE_STEP)
     // DENSE (nrx_embed_bwd_placed_dense): a placed row goes straight to its place in the table's dense gradient -- the lookup's own id
     // names the row (the ids are read where they lie, sample-major), dest >= 0 only says "placed"
     const void* ids[NRX_MAX_FEATURES];   // per placeable feature
@@ -1136,9 +1135,7 @@ struct PlaceArgs {
 };
 static_assert(sizeof(PlaceArgs) <= 3584, "kernarg budget");
 
-// STEP: features per ring step (STEP stores, then STEP fetches).  A template parameter, not a run-time switch: with several forms unrolled side by
-// side in one kernel the register allocation of each moved with the presence of the others.
-template <int QLOG2, int U, bool FM, bool UNAL, bool DENSE = false, int STEP = 2>
+template <int QLOG2, int U, bool FM, bool UNAL, bool DENSE = false>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceArgs args_in_kernarg) {
     const NRX_CONST PlaceArgs* a = nrx_kernarg<PlaceArgs>();
     constexpr int Q = 1 << QLOG2;
@@ -1236,18 +1233,11 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceA
             int32_t dn[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) dn[u] = s_my[(f0 + U + u) * TB];
-            // STEP = 2: the 64-byte pieces of features 2j and 2j + 1 of a sample are the two halves of one 128-byte line of the upstream rows --
-            // requested back to back they are one fabric request, a store apart they were often two (C2: 318 -> 267 MB fetched per launch; the
-            // launch takes the same time: 74.5 us against 74.7 on one box, three alternated runs each)
 #pragma unroll
-            for (int u = 0; u < U; u += STEP) {
-#pragma unroll
-                for (int j = 0; j < STEP; ++j) place(f0 + u + j, d[u + j], g[u + j], v[u + j]);
-#pragma unroll
-                for (int j = 0; j < STEP; ++j) {
-                    d[u + j] = dn[u + j];
-                    fetch(f0 + U + u + j, d[u + j], g[u + j], v[u + j]);
-                }
+            for (int u = 0; u < U; ++u) {
+                place(f0 + u, d[u], g[u], v[u]);
+                d[u] = dn[u];
+                fetch(f0 + U + u, d[u], g[u], v[u]);
             }
         }
         // f0 + U <= n < f0 + 2U: drain; the n - f0 - U fetches still to be issued sit behind wave-uniform branches
@@ -3103,24 +3093,22 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             pa.long_ws = a.long_ws;
             pa.n = n_place;
             { const char* e = getenv("NRX_PLACE_NT"); pa.nt = e ? atoi(e) : 1; }
-            { const char* e = getenv("NRX_PLACE_STEP"); pa.pair = e ? atoi(e) : 2; }      // features per ring step: 2 (default) | 1 (rounds 1-3)
             const int uvar = getenv("NRX_PLACE_U") ? atoi(getenv("NRX_PLACE_U")) : 4;       // fetches in flight per lane (4 | 8)
             const unsigned pgrid = (unsigned)((batch + tb - 1) / tb);
             const size_t plds = (size_t)n_place * tb * 4;
             constexpr int U = 8;
-#define NRX_PL(QL_, ST_)                                                                                                        \
+#define NRX_PL(QL_)                                                                                                        \
     {                                                                                                                      \
-        if (dense && has_fm) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, true, false, true, ST_>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
-        else if (dense && unal) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, false, true, true, ST_>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa); \
-        else if (dense) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, false, false, true, ST_>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);        \
-        else if (has_fm && uvar == 4) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, true, false, false, ST_>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
-        else if (has_fm) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, true, false, false, ST_>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
-        else if (unal) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, false, true, false, ST_>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa); \
-        else if (uvar == 4) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, false, false, false, ST_>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);        \
-        else hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, false, false, false, ST_>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);        \
+        if (dense && has_fm) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, true, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
+        else if (dense && unal) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, false, true, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa); \
+        else if (dense) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, false, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);        \
+        else if (has_fm && uvar == 4) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, true, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
+        else if (has_fm) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, true, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
+        else if (unal) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa); \
+        else if (uvar == 4) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, false, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);        \
+        else hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, false, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);        \
     }
-            if (pa.pair == 1) { if (ql == 2) NRX_PL(2, 1) else if (ql == 3) NRX_PL(3, 1) else NRX_PL(4, 1) }
-            else { if (ql == 2) NRX_PL(2, 2) else if (ql == 3) NRX_PL(3, 2) else NRX_PL(4, 2) }
+            if (ql == 2) NRX_PL(2) else if (ql == 3) NRX_PL(3) else NRX_PL(4)
 #undef NRX_PL
         }
         if (has_bag) {

@@ -26,7 +26,6 @@ struct UniformWideArgs {
     int32_t* status;
     int32_t n;
     int32_t idx64;
-    int32_t pair;                         // features per ring step (host side only: picks the STEP instantiation; NRX_WIDE_STEP)
     int32_t stnt;                         // 1: the aligned chunks leave with non-temporal stores (rows on whole 128-byte lines: written once, read by the MLP later)
 };
 static_assert(sizeof(UniformWideArgs) <= 3584, "kernarg budget");
@@ -171,10 +170,7 @@ struct WideAl {
     }
 };
 
-// STEP: features per ring step -- STEP rows' stores, then STEP row loads (1: `store f; load f + R`, the ring of rounds 1-3).  A template
-// parameter: with the forms side by side behind a run-time switch the compiler's register allocation for one form moved with the presence of
-// the others (a "two per step" gain measured that way was the code layout's, not the form's).
-template <int QLOG2, int R, bool NT, bool AL = false, int STEP = 1>
+template <int QLOG2, int R, bool NT, bool AL = false>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_ring_wide(const UniformWideArgs args_in_kernarg_segment) {
     using namespace nrx_ring;
     const NRX_CONST UniformWideArgs* a = nrx_kernarg<UniformWideArgs>();
@@ -220,11 +216,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_fwd_ring_wide(const UniformWi
 #pragma unroll
         for (int u = 0; u < R; ++u) idn[u] = s_my[(f0 + R + u) * TB];
 #pragma unroll
-        for (int u = 0; u < R; u += STEP) {
-#pragma unroll
-            for (int j = 0; j < STEP; ++j) put(f0 + u + j, v[u + j]);
-#pragma unroll
-            for (int j = 0; j < STEP; ++j) v[u + j] = load_row<QLOG2, NT>(a->table[f0 + R + u + j], idn[u + j], q);
+        for (int u = 0; u < R; ++u) {
+            put(f0 + u, v[u]);
+            v[u] = load_row<QLOG2, NT>(a->table[f0 + R + u], idn[u], q);
         }
     }
     {
@@ -252,17 +246,9 @@ void launch_ring_wide(const UniformWideArgs& ua, int64_t batch, bool nt, bool al
     constexpr int R = 8;
     const dim3 grid((unsigned)((batch + TB - 1) / TB)), block(NRX_BLOCK);
     const size_t smem = (size_t)ua.n * TB * 4;
-    static_assert(R % 8 == 0, "the STEP forms divide the ring");
     if (al) {
-#define NRX_WIDE_GO(STEP_) do { if (nt) hipLaunchKernelGGL((embed_fwd_ring_wide<QLOG2, R, true, true, STEP_>), grid, block, smem, st, ua); \
-                                else hipLaunchKernelGGL((embed_fwd_ring_wide<QLOG2, R, false, true, STEP_>), grid, block, smem, st, ua); } while (0)
-        switch (ua.pair) {
-            case 2: NRX_WIDE_GO(2); break;
-            case 4: NRX_WIDE_GO(4); break;
-            case 8: NRX_WIDE_GO(8); break;
-            default: NRX_WIDE_GO(1); break;
-        }
-#undef NRX_WIDE_GO
+        if (nt) hipLaunchKernelGGL((embed_fwd_ring_wide<QLOG2, R, true, true>), grid, block, smem, st, ua);
+        else hipLaunchKernelGGL((embed_fwd_ring_wide<QLOG2, R, false, true>), grid, block, smem, st, ua);
         return;
     }
     if (nt) hipLaunchKernelGGL((embed_fwd_ring_wide<QLOG2, R, true>), grid, block, smem, st, ua);
@@ -316,7 +302,6 @@ bool nrx_launch_uniform_wide(const nrx_feature_t* feats, int32_t n_feats, int64_
     const bool nt = table_bytes > (256ll << 20);
     ua.idx64 = i64;
     { const char* e = getenv("NRX_FWD_STNT"); ua.stnt = e ? atoi(e) : 0; }
-    { const char* e = getenv("NRX_WIDE_STEP"); ua.pair = e ? atoi(e) : 1; }      // features per ring step of the aligned-chunk form: 1 | 2 | 4 | 8 (tools/probe_pair.py)
     if (n_feats >= 8 && n_feats * (NRX_BLOCK / (D0 / 4)) * 4 <= 48 * 1024) {      // ring form: >= R features, ids fit a modest LDS tile
         // aligned-chunk stores (WideAl): a gap-free deep row in feature order that starts on a 16-byte boundary, row stride % 4 floats == 0
         bool al = nrx_aligned16(out) && (out_ld & 3) == 0 && (feats[0].out_col & 3) == 0;
