@@ -1132,6 +1132,7 @@ struct PlaceArgs {
     int32_t idx64;
     int32_t add_to;                      // 1: add to what the table holds (a table fed by a second launch group)
     int32_t stnt;                        // 1: placed rows leave with non-temporal stores (measurement knob NRX_PLACE_STNT)
+    uint64_t fm_mask;                    // bit f = fm[f] (the full-line form reads flags of two features per step from here)
 };
 static_assert(sizeof(PlaceArgs) <= 3584, "kernarg budget");
 
@@ -1267,6 +1268,120 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceA
         for (int u = 0; u < U; ++u) fetch(f0 + u < n ? f0 + u : n - 1, d[u], g[u], v[u]);      // wave-uniform feature: column numbers come from scalar loads
 #pragma unroll
         for (int u = 0; u < U; ++u) place(f0 + u < n ? f0 + u : n - 1, d[u], g[u], v[u]);
+    }
+}
+
+// Full-line form of the placement pass for 64-byte rows (D = 16): a sample is owned by 2 Q = 8 lanes that take features 2j and 2j + 1 TOGETHER,
+// so one load instruction covers whole 128-byte lines of the upstream rows (and of the forward concat for FM) -- in the form above the two
+// halves of a line are requested by different instructions a ring step apart: 3.4 M 64-byte read requests per C2 launch and, with the
+// non-temporal hint, 318 MB fetched for 229 MB of distinct lines.  Same arithmetic per (sample, feature): bit-identical results.  The host
+// picks it when every pair (2j, 2j + 1) is one aligned line (place_lines_ok).
+template <int U, bool FM, bool DENSE>
+__global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_lines_kernel(const PlaceArgs args_in_kernarg) {
+    const NRX_CONST PlaceArgs* a = nrx_kernarg<PlaceArgs>();
+    constexpr int Q = 4;
+    constexpr int TB = NRX_BLOCK / (2 * Q);           // samples per block
+    extern __shared__ __attribute__((aligned(16))) int32_t s_dest[];      // [n][TB]
+    const int tid = threadIdx.x;
+    const int n = a->n;
+    const int64_t b0 = (int64_t)blockIdx.x * TB;
+    const int nb = (int)((a->batch - b0) < (int64_t)TB ? (a->batch - b0) : (int64_t)TB);
+    if (blockIdx.x == 0 && tid < 4 && a->long_ws != nullptr) a->long_ws[tid] = 0;
+    for (int i = tid; i < n * TB; i += NRX_BLOCK) {   // TB consecutive dest words per feature
+        const int f = i / TB, s = i - f * TB;
+        s_dest[i] = s < nb ? nrx_gconst<int32_t>(a->dest)[a->off[f] + b0 + s] : -1;
+    }
+    __syncthreads();
+    const int q = tid & (Q - 1);
+    const int par = (tid >> 2) & 1;
+    const int sb = tid >> 3;
+    const int64_t b = b0 + sb;
+    if (b >= a->batch) return;
+    float gf = 0.f;
+    float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FM) {
+        gf = nrx_gconst<float>(a->g_fm)[b];
+        S = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
+    }
+    const int np = (n + 1) >> 1;                      // feature pairs (an odd last feature: the upper half of the lanes idles)
+    const int32_t* s_my = s_dest + sb;
+    auto dest_of = [&](int j) -> int32_t {
+        const int f = 2 * j + par;
+        return f < n ? s_my[f * TB] : -1;
+    };
+    auto fetch = [&](int j, int32_t& d, float4& g, float4& v) {           // j wave-uniform: the two features' columns come from scalar loads
+        if (d >= 0) {
+            const int f0 = 2 * j, f1 = 2 * j + 1 < n ? 2 * j + 1 : 2 * j;
+            const int col = par ? a->out_col[f1] : a->out_col[f0];
+            if (DENSE) {
+                const void* ip = par ? a->ids[f1] : a->ids[f0];
+                d = a->idx64 ? (int32_t)nrx_gconst<int64_t>(ip)[b] : nrx_gconst<int32_t>(ip)[b];
+            }
+            g = nrx_ldg4_nt(a->g_out, (b * a->out_ld + col) / 4 + q);
+            if (FM) v = nrx_ldg4_nt(a->feat, (b * a->feat_ld + col) / 4 + q);
+        }
+    };
+    auto place = [&](int j, int32_t d, const float4& g, const float4& v) {
+        if (d >= 0) {
+            const int f0 = 2 * j, f1 = 2 * j + 1 < n ? 2 * j + 1 : 2 * j;
+            float4 t = g;
+            if (FM) fm_fold4(t, ((a->fm_mask >> (par ? f1 : f0)) & 1ull) ? gf : 0.f, S, v, q);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);         // 0 + t, as the walk forms it (a -0 becomes +0 there too)
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            if (DENSE) {
+                float* base = par ? a->grad[f1] : a->grad[f0];
+                if (a->add_to) {
+                    const float4 o = nrx_ldg4(base, (int64_t)d * Q + q);
+                    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+                }
+                nrx_stg4(base, (int64_t)d * Q + q, acc);
+            } else {
+                nrx_stg4(a->values, (int64_t)d * Q + q, acc);
+            }
+        }
+    };
+    if (np >= U) {
+        int32_t d[U];
+        float4 g[U], v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = dest_of(u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) fetch(u, d[u], g[u], v[u]);
+        int j0 = 0;
+        for (; j0 + 2 * U <= np; j0 += U) {
+            int32_t dn[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dn[u] = dest_of(j0 + U + u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                place(j0 + u, d[u], g[u], v[u]);
+                d[u] = dn[u];
+                fetch(j0 + U + u, d[u], g[u], v[u]);
+            }
+        }
+        int32_t dn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dn[u] = j0 + U + u < np ? dest_of(j0 + U + u) : -1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            place(j0 + u, d[u], g[u], v[u]);
+            d[u] = dn[u];
+            if (j0 + U + u < np) fetch(j0 + U + u, d[u], g[u], v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (j0 + U + u < np) place(j0 + U + u, d[u], g[u], v[u]);
+        return;
+    }
+    for (int j0 = 0; j0 < np; j0 += U) {
+        int32_t d[U];
+        float4 g[U], v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) d[u] = j0 + u < np ? dest_of(j0 + u) : -1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) fetch(j0 + u < np ? j0 + u : np - 1, d[u], g[u], v[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) place(j0 + u < np ? j0 + u : np - 1, d[u], g[u], v[u]);
     }
 }
 
@@ -3094,6 +3209,26 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             pa.n = n_place;
             { const char* e = getenv("NRX_PLACE_NT"); pa.nt = e ? atoi(e) : 1; }
             const int uvar = getenv("NRX_PLACE_U") ? atoi(getenv("NRX_PLACE_U")) : 4;       // fetches in flight per lane (4 | 8)
+            // full-line form (embed_bwd_place_lines_kernel): 64-byte rows whose feature pairs (2j, 2j + 1) are one aligned 128-byte line of the
+            // upstream rows (and of the forward concat); NRX_PLACE_LINES=0 keeps the one-feature-per-lane-group form
+            bool lines = ql == 2 && !unal && pa.nt != 0 && pa.stnt == 0 && g_out != nullptr && (reinterpret_cast<uintptr_t>(g_out) & 127) == 0 &&
+                         (out_ld & 31) == 0 && n_place <= 64;
+            if (lines && has_fm) lines = (reinterpret_cast<uintptr_t>(pa.feat) & 127) == 0 && (pa.feat_ld & 31) == 0;
+            pa.fm_mask = 0;
+            for (int i = 0; i < n_place; ++i) {
+                if (pa.fm[i]) pa.fm_mask |= 1ull << i;
+                if (pa.wide_col[i] >= 0) lines = false;
+                if ((i & 1) == 0 ? (pa.out_col[i] & 31) != 0 : pa.out_col[i] != pa.out_col[i - 1] + 16) lines = false;
+            }
+            { const char* e = getenv("NRX_PLACE_LINES"); if (e && atoi(e) == 0) lines = false; }
+            if (lines) {
+                const unsigned lgrid = (unsigned)((batch + 31) / 32);
+                const size_t llds = (size_t)n_place * 32 * 4;
+                if (dense && has_fm) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<4, true, true>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
+                else if (dense) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<4, false, true>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
+                else if (has_fm) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<4, true, false>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
+                else hipLaunchKernelGGL((embed_bwd_place_lines_kernel<4, false, false>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
+            } else {
             const unsigned pgrid = (unsigned)((batch + tb - 1) / tb);
             const size_t plds = (size_t)n_place * tb * 4;
             constexpr int U = 8;
@@ -3110,6 +3245,7 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
     }
             if (ql == 2) NRX_PL(2) else if (ql == 3) NRX_PL(3) else NRX_PL(4)
 #undef NRX_PL
+            }
         }
         if (has_bag) {
             char* end = reinterpret_cast<char*>(a.long_ws + 4) + a.long_items_cap * sizeof(LongItem) +
