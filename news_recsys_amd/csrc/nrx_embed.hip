@@ -1276,6 +1276,10 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceA
 // halves of a line are requested by different instructions a ring step apart: 3.4 M 64-byte read requests per C2 launch and, with the
 // non-temporal hint, 318 MB fetched for 229 MB of distinct lines.  Same arithmetic per (sample, feature): bit-identical results.  The host
 // picks it when every pair (2j, 2j + 1) is one aligned line (place_lines_ok).
+#ifndef NRX_LINES_U
+#define NRX_LINES_U 2                   // feature PAIRS in flight per lane (build-time knob for tools/build_variant.sh): C2 launch on one box, rotated
+                                        // builds: 8 -> 71.1 us, 4 -> 60.6 / 65.2 (two boxes), 3 -> 64.0, 2 -> 59.6 / 63.0, 1 -> 62.6
+#endif
 template <int U, bool FM, bool DENSE>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_lines_kernel(const PlaceArgs args_in_kernarg) {
     const NRX_CONST PlaceArgs* a = nrx_kernarg<PlaceArgs>();
@@ -3224,10 +3228,10 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             if (lines) {
                 const unsigned lgrid = (unsigned)((batch + 31) / 32);
                 const size_t llds = (size_t)n_place * 32 * 4;
-                if (dense && has_fm) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<4, true, true>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
-                else if (dense) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<4, false, true>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
-                else if (has_fm) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<4, true, false>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
-                else hipLaunchKernelGGL((embed_bwd_place_lines_kernel<4, false, false>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
+                if (dense && has_fm) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<NRX_LINES_U, true, true>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
+                else if (dense) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<NRX_LINES_U, false, true>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
+                else if (has_fm) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<NRX_LINES_U, true, false>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
+                else hipLaunchKernelGGL((embed_bwd_place_lines_kernel<NRX_LINES_U, false, false>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
             } else {
             const unsigned pgrid = (unsigned)((batch + tb - 1) / tb);
             const size_t plds = (size_t)n_place * tb * 4;
