@@ -3236,15 +3236,18 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             const unsigned pgrid = (unsigned)((batch + tb - 1) / tb);
             const size_t plds = (size_t)n_place * tb * 4;
             constexpr int U = 8;
+#ifndef NRX_PLACE_UDEF
+#define NRX_PLACE_UDEF 4                // fetches in flight per lane of the one-feature-per-lane-group form (build-time knob)
+#endif
 #define NRX_PL(QL_)                                                                                                        \
     {                                                                                                                      \
-        if (dense && has_fm) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, true, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
+        if (dense && has_fm) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, NRX_PLACE_UDEF, true, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
         else if (dense && unal) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, false, true, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa); \
-        else if (dense) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, false, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);        \
-        else if (has_fm && uvar == 4) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, true, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
+        else if (dense) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, NRX_PLACE_UDEF, false, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);        \
+        else if (has_fm && uvar == 4) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, NRX_PLACE_UDEF, true, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
         else if (has_fm) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, true, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);   \
         else if (unal) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa); \
-        else if (uvar == 4) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, 4, false, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);        \
+        else if (uvar == 4) hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, NRX_PLACE_UDEF, false, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);        \
         else hipLaunchKernelGGL((embed_bwd_place_kernel<QL_, U, false, false>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);        \
     }
             if (ql == 2) NRX_PL(2) else if (ql == 3) NRX_PL(3) else NRX_PL(4)
