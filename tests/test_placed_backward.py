@@ -165,3 +165,41 @@ def test_placed_backward_c2_shape_full_batch(monkeypatch):
     placed = d[d >= 0]
     assert len(np.unique(placed)) == len(placed) and len(placed) + nw == nu
     assert len(np.intersect1d(placed, walk[:nw].cpu().numpy())) == 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 9, 26, 27])
+@pytest.mark.parametrize("fm", [False, True])
+@pytest.mark.parametrize("dist", ["uniform", "zipf"])
+def test_full_line_placement_form_on_padded_rows_odd_and_even_feature_counts(n, fm, dist, monkeypatch):
+    """The full-line form of the placement pass (embed_bwd_place_lines_kernel: 8 lanes per sample take features 2j and 2j + 1 together) needs
+    rows of whole 128-byte lines: D = 16 features on a row stride that is a multiple of 32 floats.  With an odd feature count the last
+    pair is half empty.  Row-sparse (placed == walked, bit for bit) and dense destination (== the row-sparse result)."""
+    rng = np.random.default_rng(100 + n + 7 * fm)
+    D, rows, B = 16, 5000, 1300
+    ld = (16 * n + 31) // 32 * 32
+    slots = [ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, i * D, fm_field=int(fm)) for i in range(n)]
+    plan = ops.EmbedPlan(slots, out_width=n * D, use_fm=fm)
+    tables = [torch.from_numpy(rng.standard_normal((rows, D)).astype(np.float32)).to(DEV) for _ in range(n)]
+    inputs = [torch.from_numpy(_ids(rng, rows, (B,), dist)).to(DEV) for _ in range(n)]
+    g_out = torch.from_numpy(rng.standard_normal((B, n * D)).astype(np.float32)).to(DEV)
+    g_fm = torch.from_numpy(rng.standard_normal((B,)).astype(np.float32)).to(DEV)
+
+    def run(place, sparse, dense_sorted=None):
+        monkeypatch.setattr(ops, "SPARSE_PLACE", place)
+        monkeypatch.setattr(ops, "DENSE_BWD_SORTED", dense_sorted)
+        ts = [t.clone().requires_grad_() for t in tables]
+        out, _, fmv = ops.embed_apply(plan, ts, inputs, [None] * n, sparse_grad=sparse, out_ld=ld)
+        assert out.shape[1] == ld and out.stride(0) == ld
+        loss = (out[:, :n * D] * g_out).sum()
+        if fmv is not None:
+            loss = loss + (fmv * g_fm).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        return [t.grad.coalesce() if sparse else t.grad for t in ts]
+
+    a = run(True, True)
+    b = run(False, True)
+    _same(a, b)
+    d = run(True, False, dense_sorted=True)                   # the dense destination of the same reduction
+    for x, y in zip(a, d):
+        assert torch.equal(x.to_dense().view(torch.int32), y.view(torch.int32))
