@@ -404,6 +404,14 @@ def _small_shapes(plan, B) -> bool:
     """Every table of the launch fed by <= 4096 lookups (the one-block-per-table kernels' limit; the library has the last word)."""
     if B > 4096 or B <= 0:
         return False
+    memo = plan.__dict__.setdefault("_small_shapes_memo", {})
+    if B in memo:
+        return memo[B]
+    memo[B] = res = _small_shapes_uncached(plan, B)
+    return res
+
+
+def _small_shapes_uncached(plan, B) -> bool:
     per = {}
     for s in plan.slots:
         if s.kind == NRX_DENSE:
