@@ -973,9 +973,22 @@ def main():
             fb_ms = time_calls(both, steps2)
             # the leg is not only timed: every group's plan must list each (table, row) once, ascending, with segments that tile
             # the lookups exactly (a mis-sorted plan would still run at full speed)
+            planners = []
             for g in bwd[0].run():
                 nu = int(g["counts"][0].item())
                 uq, sg = g["uniq"][:nu], g["seg"][:nu + 1]
+                planners.append("one-kernel (LDS bitmaps)" if g["pairs"] else "sorted")
+                if g["pairs"]:
+                    # the one-kernel planner defines segments for the walk rows only: its result is checked against the SORTED planner's on the
+                    # same ids instead -- same unique rows, same row gradients bit for bit
+                    keys, vals = uq.clone(), g["values"][:nu].clone()
+                    pol, g["policy"] = g["policy"], None
+                    bwd[0].run()
+                    g["policy"] = pol
+                    nu2 = int(g["counts"][0].item())
+                    sg = g["seg"][:nu2 + 1]
+                    if not (nu2 == nu and torch.equal(keys, g["uniq"][:nu]) and torch.equal(vals.view(torch.int32), g["values"][:nu].view(torch.int32))):
+                        raise SystemExit("fwd_bwd leg: the one-kernel planner's gradients differ from the sorted planner's")
                 if not (nu > 0 and bool(torch.all(uq[1:] > uq[:-1])) and int(sg[0].item()) == 0 and int(sg[-1].item()) == g["total"]
                         and bool(torch.all(sg[1:] > sg[:-1])) and bool(torch.isfinite(g["values"][:nu]).all())):
                     raise SystemExit("fwd_bwd leg: the row-sparse backward's plan is inconsistent (unique rows not ascending / segments "
@@ -983,7 +996,7 @@ def main():
             fb_bytes = (bytes_per_impr + (4 * path.feats[0]["dim"] if path.fm else 0) + path.bwd_bytes_per_impr) * BATCH
             fb_ach = fb_bytes / (fb_ms * 1e-3) / 1e9
             fwd_bwd = {"ms_per_step": fb_ms, "value": BATCH / (fb_ms * 1e-3), "unit": "impressions/s",
-                       "forward_ms": f_ms, "backward_ms": fb_ms - f_ms,
+                       "forward_ms": f_ms, "backward_ms": fb_ms - f_ms, "planner": planners,
                        "roofline": {"bound": "hbm", "achieved": fb_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": fb_ach / HBM_PEAK_GBPS,
                                     "algorithmic_bytes_per_step": fb_bytes,
                                     "algorithmic_bytes_definition": "forward (training form: + 4D field sums written per sample for FM) + backward: per lookup 8 B id (planner) "

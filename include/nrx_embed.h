@@ -222,6 +222,49 @@ NRX_API int nrx_sparse_plan_place(const void* const* ids, const int64_t* lens, c
                           int64_t* uniq_keys, int64_t* seg_start, int64_t* counts, int32_t* dest, int32_t* walk,
                           int64_t* n_walk, void* workspace, void* stream);
 
+/* ONE-KERNEL planner for near-unique id batches over mid-size tables (the C2 shape: 26 tables x 1 M rows, 65 536 ids each): the role of
+ * nrx_sparse_plan_place by another method -- row bitmaps in LDS instead of a sort (csrc/nrx_plan_lds.hip).  Every feature must be
+ * single-valued and placeable (lens all equal), every feature of a table must state the same rows; nrx_sparse_plan_lds_ok says whether a launch
+ * qualifies (<= 4096 row ranges of 131 072 rows, scanning redundancy <= 16) -- else NRX_ERR_UNSUPPORTED and nothing is enqueued.  Outputs:
+ *   uniq_keys / counts   as nrx_sparse_plan (complete)
+ *   dest   [n] int32     dest[p] >= 0: lookup p's row is looked up once: its unique index (as nrx_sparse_plan_place); else -1
+ *   pairs  [n / 2 + 1][4] int32 (16-byte aligned), n_pairs [1] int64: one record {unique index u, first lookup, second lookup, 0} per row looked
+ *                        up exactly TWICE (not the padding row), ascending by u: the sum of two rows needs no sorted walk
+ *   walk / n_walk        the unique rows looked up three times or more, and the padding rows: ascending
+ *   order / seg_start    defined for the walk rows ONLY: row u owns order[seg_start[u] .. seg_start[u + 1]), its lookups ascending
+ *   stats  [4] int64     (optional) unique rows, walk rows, lookups of the walk rows, n -- what a caller needs to choose the planner for the
+ *                        NEXT batch: a batch with many rows looked up 3+ times is planned correctly but slowly here (one block sorts a range's list)
+ * state: nrx_sparse_plan_lds_state_bytes() device bytes, ZERO before the first call, then owned by the planner (one stream at a time);
+ * workspace: nrx_sparse_plan_lds_workspace(n) bytes of scratch.  Consumed by nrx_embed_bwd_placed_pairs.  Replaces, for these shapes, autograd's
+ * index bookkeeping of nn.Embedding (src/model/BaseModel/base_model.py:262-308). */
+NRX_API int64_t nrx_sparse_plan_lds_state_bytes(void);
+NRX_API int64_t nrx_sparse_plan_lds_workspace(int64_t n_lookups);
+NRX_API int nrx_sparse_plan_lds_ok(const int64_t* lens, const int32_t* table_of, const int64_t* rows, int32_t n_feats, int32_t n_tables);
+NRX_API int nrx_sparse_plan_lds(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
+                        int32_t n_feats, int32_t index_bits, int32_t n_tables, int64_t* order, int64_t* uniq_keys,
+                        int64_t* seg_start, int64_t* counts, int32_t* dest, int32_t* walk, int64_t* n_walk, int32_t* pairs,
+                        int64_t* n_pairs, int64_t* stats, void* state, void* workspace, void* stream);
+/* stats of a nrx_sparse_plan_place plan in the same format ({unique rows, walk rows, -1 = not counted, n}): a caller that picks the planner of the
+ * next batch from the previous batch's statistics has them from either planner.  stats may be mapped (pinned) host memory. */
+NRX_API int nrx_sparse_plan_stats(const int64_t* counts, const int64_t* n_walk, int64_t n_lookups, int64_t* stats, void* stream);
+
+/* The reduction behind nrx_sparse_plan_lds: nrx_embed_bwd_placed (values != NULL: row-sparse destination) or nrx_embed_bwd_placed_dense
+ * (grad_tables != NULL; n_tables, accumulate as there) -- exactly one of the two -- plus a pass over the pair records: a lane group fetches the
+ * two upstream rows of a record and stores 0 + first + second, the sum the sorted walk forms for a two-entry segment, bit for bit.
+ * Every feature must be NRX_SPARSE and named in place_feats; workspace as nrx_embed_bwd_placed (required).
+ * NRX_ERR_UNSUPPORTED (nothing enqueued) outside the placement pass's shapes (dim 16 / 32 / 64, 16-byte-aligned operands).
+ * aux_stream (optional, another stream of the same device; a measurement knob -- on C2 the overlap LOSES 11 us, profiles/r05_pairs_aux.txt): the
+ * pair pass, the walk and the work lists are enqueued THERE, behind what `stream` holds at the call, and the placement pass on `stream`, which
+ * then waits for aux_stream.  NULL: everything on `stream`, one launch after the other. */
+NRX_API int nrx_embed_bwd_placed_pairs(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                               const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                               const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
+                               int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
+                               float* const* grad_tables, int32_t n_tables, int32_t accumulate,
+                               uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
+                               const int32_t* pairs, const int64_t* n_pairs,
+                               void* workspace, int64_t workspace_bytes, void* aux_stream, void* stream);
+
 /* nrx_embed_bwd_sorted driven by a placement plan (nrx_sparse_plan_place): same arguments and the same values[] -- bit for
  * bit -- plus dest / walk / n_walk (all three NULL: no placement, every row is walked).  place_feats must be the mask the plan
  * was made with; it may only name NRX_SPARSE features.  Launch shapes outside the fast form (odd dims, unaligned FM inputs)

@@ -128,6 +128,13 @@ SIGNATURES = {
     "nrx_sparse_plan_workspace": (_i64, [_i64]),
     "nrx_sparse_plan": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     "nrx_sparse_plan_place": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, C.c_uint64, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nrx_sparse_plan_lds_state_bytes": (_i64, []),
+    "nrx_sparse_plan_lds_workspace": (_i64, [_i64]),
+    "nrx_sparse_plan_lds_ok": (C.c_int, [_p, _p, _p, _i32, _i32]),
+    "nrx_sparse_plan_lds": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nrx_sparse_plan_stats": (C.c_int, [_p, _p, _i64, _p, _p]),
+    "nrx_embed_bwd_placed_pairs": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _i32, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p,
+                                             C.POINTER(NrxFmGrad), _p, C.POINTER(_p), _i32, _i32, C.c_uint64, _p, _p, _p, _p, _p, _p, _i64, _p, _p]),
     "nrx_sparse_adam_step": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p, _i64, _p, C.c_float, _p, C.c_float, C.c_float, C.c_float,
                                        C.c_float, _p]),
     "nrx_rows_to_dense": (C.c_int, [_p, _i32, _i32, _p, _p, _i64, _p, _i32, _p]),

@@ -1748,6 +1748,70 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
     for (int64_t blk = blockIdx.x; blk * (TB * R) < n; blk += gridDim.x) body(blk);
 }
 
+// ---- Rows looked up exactly TWICE (placement plans of nrx_sparse_plan_lds).  The plan leaves one record {unique index, first lookup, second
+// lookup} per such row; a lane group takes a record, fetches the two upstream rows and stores 0 + first + second -- the sum the sorted walk forms
+// for a two-entry segment, bit for bit.  No order words, no segment bounds: one dependent round trip behind the record.  On uniform ids these rows
+// were nearly all of the walk's work (C2: 52 K of 53 K walked rows).  Here a->walk = the records, a->n_walk_dev = their number (device),
+// a->n_unique = its bound; a->long_ws (side-stream mode): the walk's work-list counters, cleared here.
+template <int QLOG2, bool FM, bool UNAL, int DEC>
+__global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_pairs_kernel(const SortedBwdArgs args_in_kernarg) {
+    const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
+    constexpr int Q = 1 << QLOG2, G = NRX_BLOCK / Q;
+    constexpr bool REG = DEC == 1;
+    __shared__ SortedFeatLds s_ft;
+    if (DEC == 0) sorted_feat_stage(a, &s_ft);
+    const uint64_t reg_magic = a->uniform_magic;
+    const int64_t reg_len = a->uniform_len;
+    const int reg_col0 = a->col0, reg_stride = a->col_stride;
+    const bool reg_fm = a->all_fm != 0;
+    const int tid = threadIdx.x, q = tid & (Q - 1), grp = tid >> QLOG2;
+    using nrx_i32x4 = __attribute__((ext_vector_type(4))) int;
+    const NRX_GLOBAL nrx_i32x4* recs = nrx_gconst<nrx_i32x4>(a->walk);
+    const int64_t cap = a->n_unique;
+    int64_t i = (int64_t)blockIdx.x * G + grp;
+    nrx_i32x4 rec = {0, 0, 0, 0};
+    if (i < cap) rec = recs[i];                         // requested next to the count: a record past the count is read (inside the buffer) and dropped
+    int64_t n = nrx_gconst<int64_t>(a->n_walk_dev)[0];
+    n = n < cap ? n : cap;
+    auto row_of = [&](int64_t p) -> float4 {          // the gradient row chunk of lookup p, as the walk forms it
+        float4 g, v = make_float4(0.f, 0.f, 0.f, 0.f), s = v;
+        float gf = 0.f;
+        if (REG && !UNAL) {
+            const int fi = (int)__umul64hi((uint64_t)p, reg_magic);
+            const int64_t b = p - (int64_t)fi * reg_len;
+            const int col = reg_col0 + fi * reg_stride;
+            g = nrx_ldg4(a->g_out, (b * a->out_ld + col) / 4 + q);
+            if (FM) {
+                gf = reg_fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
+                v = nrx_ldg4(a->feat, (b * a->feat_ld + col) / 4 + q);
+                s = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
+            }
+        } else {
+            const FeatLite f = sorted_decode<DEC>(a, &s_ft, p);
+            const int64_t b = p - f.off;
+            g = sorted_upstream<UNAL>(a, f, b, q);
+            if (FM) {
+                gf = f.fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
+                v = nrx_ldg4(a->feat, (b * a->feat_ld + f.out_col) / 4 + q);
+                s = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
+            }
+        }
+        if (FM) fm_fold4(g, gf, s, v, q);
+        return g;
+    };
+    for (; i < n; i += (int64_t)gridDim.x * G) {
+        const int64_t u = rec.x, p1 = (int64_t)(uint32_t)rec.y, p2 = (int64_t)(uint32_t)rec.z;
+        const int64_t inext = i + (int64_t)gridDim.x * G;
+        if (inext < n) rec = recs[inext];
+        const int64_t key = a->uniq_keys != nullptr ? nrx_gconst<int64_t>(a->uniq_keys)[u] : 1;
+        const float4 t_lo = row_of(p1), t_hi = row_of(p2);         // (the plan lists the lookups of a row in ascending order)
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc.x += t_lo.x; acc.y += t_lo.y; acc.z += t_lo.z; acc.w += t_lo.w;
+        acc.x += t_hi.x; acc.y += t_hi.y; acc.z += t_hi.z; acc.w += t_hi.w;
+        sorted_store4<Q>(a, u, key, q, acc);
+    }
+}
+
 // Long segments.  An item = up to SORTED_LONG_CHUNK consecutive sorted entries of ONE unique row; a wavefront reduces an
 // item: its 64 / Q lane groups stride over the entries (two in flight each), then a fixed xor-shuffle tree adds the
 // groups -- the same entries always meet in the same order, so the result is reproducible.  A row of one item is written
@@ -3031,7 +3095,10 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
                                  int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
                                  uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
                                  void* workspace, int64_t ws_bytes /* 0: the size nrx_embed_bwd_sorted_workspace promises */, void* stream,
-                                 float* const* grad_tables = nullptr, int32_t n_tables = 0, int32_t add_to = 0) {
+                                 float* const* grad_tables = nullptr, int32_t n_tables = 0, int32_t add_to = 0,
+                                 bool pairs = false /* the plan is nrx_sparse_plan_lds's: rows looked up twice are finished by embed_bwd_pairs_kernel */,
+                                 void* aux_stream = nullptr /* pairs: the pair pass, the walk and the work lists run THERE, next to the placement pass */,
+                                 const int32_t* pair_recs = nullptr, const int64_t* n_pairs = nullptr) {
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_bwd_sorted: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0 && dim >= 1 && n_unique >= 0, "nrx_embed_bwd_sorted: bad argument");
@@ -3152,6 +3219,10 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
     if (const char* e = getenv("NRX_LONG_T")) { const int v = atoi(e); if (v >= 2 && v <= 256) a.long_t = v; }      // measurement knob
     // placement mode: single-lookup rows are stored by the placement pass, the walk reduces the listed rows only
     const bool placed = fast && dest != nullptr;
+    if (pairs && !(placed && !has_bag)) {
+        nrx_set_error("nrx_embed_bwd_placed_pairs: the launch is outside the placement pass's shapes (dim 16 / 32 / 64, aligned operands, single-valued features)");
+        return NRX_ERR_UNSUPPORTED;
+    }
     if (fast) {
         constexpr int R = 4;
         constexpr int RB = 2;                   // bag launches: 2 rows x 4 entries per pass (see the kernel)
@@ -3189,6 +3260,7 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
         {   // the walk's blocks stride over the row groups: when the row count is a device-side number (n_rows is only its bound) a few rounds of resident blocks are enough
             static const int cap = getenv("NRX_WALK_GRID") ? atoi(getenv("NRX_WALK_GRID")) : 4096;
             if ((n_unique_dev != nullptr || placed) && cap > 0 && grid > (unsigned)cap) grid = (unsigned)cap;
+            if (pairs && grid > 512u) grid = 512u;      // (only the rows looked up 3+ times are walked: a few per thousand lookups on near-unique ids)
         }
         // (4 rows x 4 entries per lane group instead of 2 x 4: C5 446.9 -> 458.1 us, C3 163.2 -> 169.6 -- measured, not kept)
         if (workspace != nullptr) {        // long segments (hot rows) go through the wavefront-per-item path
@@ -3199,7 +3271,11 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             // the 16-byte memset node did not take effect on replay (counters kept growing, the list was read past what was written)
             // (placement mode: the placement pass clears them -- one launch less)
             if (!(placed && n_place > 0) && nrx_zero_async(a.long_ws, 16, st) != NRX_OK) return NRX_ERR_LAUNCH;
+            const bool side_zero = pairs && placed && n_place > 0 && aux_stream != nullptr && aux_stream != stream;      // (side-stream mode: the placement pass
+            if (side_zero && nrx_zero_async(a.long_ws, 16, reinterpret_cast<hipStream_t>(aux_stream)) != NRX_OK) return NRX_ERR_LAUNCH;      //  runs elsewhere: the counters are cleared on the walk's stream)
         }
+        const bool side_mode = pairs && aux_stream != nullptr && aux_stream != stream;
+        auto launch_place = [&]() {
         if (placed && n_place > 0) {
             pa.batch = batch;
             pa.g_out = g_out; pa.out_ld = out_ld; pa.g_wide = g_wide; pa.wide_ld = wide_ld;
@@ -3209,7 +3285,7 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             pa.idx64 = feats[0].index_bits == 64;
             pa.add_to = add_to ? 1 : 0;
             { const char* e = getenv("NRX_PLACE_STNT"); pa.stnt = e ? atoi(e) : 0; }
-            pa.long_ws = a.long_ws;
+            pa.long_ws = side_mode ? nullptr : a.long_ws;
             pa.n = n_place;
             { const char* e = getenv("NRX_PLACE_NT"); pa.nt = e ? atoi(e) : 1; }
             const int uvar = getenv("NRX_PLACE_U") ? atoi(getenv("NRX_PLACE_U")) : 4;       // fetches in flight per lane (4 | 8)
@@ -3253,6 +3329,47 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             if (ql == 2) NRX_PL(2) else if (ql == 3) NRX_PL(3) else NRX_PL(4)
 #undef NRX_PL
             }
+        }
+        };
+        // Pair plans with an auxiliary stream: the pair pass, the walk and the work lists are short chains of dependent round trips (18 + 10 + 9 us
+        // on C2, nearly all of it latency); the placement pass is 60 us of streaming.  They touch disjoint rows: the small launches go to the
+        // auxiliary stream FIRST (they get their wavefront slots before the placement pass fills every compute unit), the placement pass follows
+        // on the caller's stream, which then waits for the auxiliary one.
+        const bool side = pairs && aux_stream != nullptr && aux_stream != stream;
+        hipStream_t sw = side ? reinterpret_cast<hipStream_t>(aux_stream) : st;
+        static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+        if (side) {
+            if (ev_fork == nullptr) {
+                if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
+                    nrx_set_error("nrx_embed_bwd_placed_pairs: hipEventCreate failed");
+                    return NRX_ERR_LAUNCH;
+                }
+            }
+            if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(sw, ev_fork, 0) != hipSuccess) {
+                nrx_set_error("nrx_embed_bwd_placed_pairs: fork onto the auxiliary stream failed");
+                return NRX_ERR_LAUNCH;
+            }
+        }
+        if (!side) launch_place();
+        if (pairs) {
+            // (a plan with pair rows is a placement plan over single-valued features: the launch is `placed`, has no bags)
+            SortedBwdArgs pr = a;
+            pr.walk = pair_recs;
+            pr.n_walk_dev = n_pairs;
+            pr.n_unique = off / 2 + 1;                     // (at most every second lookup starts a pair)
+            const bool reg_p = a.regular && g_out != nullptr && !unal;
+            const int64_t pgroups = (pr.n_unique + (NRX_BLOCK >> ql) - 1) / (NRX_BLOCK >> ql);
+            const unsigned pgrid2 = (unsigned)(pgroups < 1024 ? pgroups : 1024);
+#define NRX_PR(QL_)                                                                                                        \
+    {                                                                                                                      \
+        if (has_fm && reg_p) hipLaunchKernelGGL((embed_bwd_pairs_kernel<QL_, true, false, 1>), dim3(pgrid2), dim3(NRX_BLOCK), 0, sw, pr);      \
+        else if (has_fm) hipLaunchKernelGGL((embed_bwd_pairs_kernel<QL_, true, false, 0>), dim3(pgrid2), dim3(NRX_BLOCK), 0, sw, pr);      \
+        else if (unal) hipLaunchKernelGGL((embed_bwd_pairs_kernel<QL_, false, true, 0>), dim3(pgrid2), dim3(NRX_BLOCK), 0, sw, pr);      \
+        else if (reg_p) hipLaunchKernelGGL((embed_bwd_pairs_kernel<QL_, false, false, 1>), dim3(pgrid2), dim3(NRX_BLOCK), 0, sw, pr);      \
+        else hipLaunchKernelGGL((embed_bwd_pairs_kernel<QL_, false, false, 0>), dim3(pgrid2), dim3(NRX_BLOCK), 0, sw, pr);      \
+    }
+            if (ql == 2) NRX_PR(2) else if (ql == 3) NRX_PR(3) else NRX_PR(4)
+#undef NRX_PR
         }
         if (has_bag) {
             char* end = reinterpret_cast<char*>(a.long_ws + 4) + a.long_items_cap * sizeof(LongItem) +
@@ -3305,33 +3422,44 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
         const bool few = n_feats <= 4;                                  // scalar decode (DEC = 2); else the LDS table (DEC = 0)
 #define NRX_SF(QL_)                                                                                                        \
     {                                                                                                                      \
-        if (placed && has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4, 1>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else if (placed && !has_bag && !unal && !has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4, 1>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else if (!placed && has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false, 1, 1>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else if (!placed && !has_fm && !unal && !has_bag && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false, 1, 1>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); \
-        else if (placed && has_fm) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4, 2>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4, 0>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); } \
-        else if (placed && unal) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, true, 4, 2>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, true, 4, 0>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); } \
-        else if (placed && !has_bag) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4, 2>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4, 0>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); } \
-        else if (has_fm) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false, 1, 2>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false, 1, 0>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); } \
-        else if (unal) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, true, true, 1, 2>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, true, true, 1, 0>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); } \
-        else if (has_bag) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, false, 4, 2>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, false, 4, 0>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); } \
-        else { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false, 1, 2>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false, 1, 0>), dim3(grid), dim3(NRX_BLOCK), 0, st, a); } \
+        if (placed && has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4, 1>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); \
+        else if (placed && !has_bag && !unal && !has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4, 1>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); \
+        else if (!placed && has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false, 1, 1>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); \
+        else if (!placed && !has_fm && !unal && !has_bag && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false, 1, 1>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); \
+        else if (placed && has_fm) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4, 2>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4, 0>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); } \
+        else if (placed && unal) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, true, 4, 2>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, true, 4, 0>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); } \
+        else if (placed && !has_bag) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4, 2>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4, 0>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); } \
+        else if (has_fm) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false, 1, 2>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false, 1, 0>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); } \
+        else if (unal) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, true, true, 1, 2>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, true, true, 1, 0>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); } \
+        else if (has_bag) { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, false, 4, 2>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, true, false, 4, 0>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); } \
+        else { if (few) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false, 1, 2>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); else hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false, 1, 0>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); } \
     }
         if (ql == 2) NRX_SF(2) else if (ql == 3) NRX_SF(3) else NRX_SF(4)
 #undef NRX_SF
         if (workspace != nullptr) {
 #define NRX_SL(QL_)                                                                                                        \
     {                                                                                                                      \
-        if (has_fm && reg) hipLaunchKernelGGL((sorted_long_kernel<QL_, true, false, false, 1>), dim3(2048), dim3(NRX_BLOCK), 0, st, a);      \
-        else if (!has_fm && !unal && !has_bag && reg) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, false, false, 1>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); \
-        else if (has_fm) { if (few) hipLaunchKernelGGL((sorted_long_kernel<QL_, true, false, false, 2>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((sorted_long_kernel<QL_, true, false, false, 0>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); } \
-        else if (unal) { if (few) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, true, 2>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, true, 0>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); } \
-        else if (has_bag) { if (few) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, false, 2>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, false, 0>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); } \
-        else { if (few) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, false, false, 2>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, false, false, 0>), dim3(2048), dim3(NRX_BLOCK), 0, st, a); } \
-        hipLaunchKernelGGL((sorted_combine_kernel<QL_>), dim3(256), dim3(NRX_BLOCK), 0, st, a);                              \
+        if (has_fm && reg) hipLaunchKernelGGL((sorted_long_kernel<QL_, true, false, false, 1>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a);      \
+        else if (!has_fm && !unal && !has_bag && reg) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, false, false, 1>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a); \
+        else if (has_fm) { if (few) hipLaunchKernelGGL((sorted_long_kernel<QL_, true, false, false, 2>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a); else hipLaunchKernelGGL((sorted_long_kernel<QL_, true, false, false, 0>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a); } \
+        else if (unal) { if (few) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, true, 2>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a); else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, true, 0>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a); } \
+        else if (has_bag) { if (few) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, false, 2>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a); else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, false, 0>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a); } \
+        else { if (few) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, false, false, 2>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a); else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, false, false, 0>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a); } \
+        hipLaunchKernelGGL((sorted_combine_kernel<QL_>), dim3(256), dim3(NRX_BLOCK), 0, sw, a);                              \
     }
             if (ql == 2) NRX_SL(2) else if (ql == 3) NRX_SL(3) else NRX_SL(4)
 #undef NRX_SL
+        }
+        if (side) {
+            if (hipEventRecord(ev_join, sw) != hipSuccess) {
+                nrx_set_error("nrx_embed_bwd_placed_pairs: join of the auxiliary stream failed");
+                return NRX_ERR_LAUNCH;
+            }
+            launch_place();
+            if (hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) {
+                nrx_set_error("nrx_embed_bwd_placed_pairs: join of the auxiliary stream failed");
+                return NRX_ERR_LAUNCH;
+            }
         }
         NRX_LAUNCH_CHECK("nrx_embed_bwd_sorted(fast)");
         return NRX_OK;
@@ -3461,4 +3589,27 @@ extern "C" int nrx_embed_bwd_placed(const nrx_feature_t* feats, int32_t n_feats,
                 "nrx_embed_bwd_placed: workspace_bytes too small");
     return embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, g_wide, wide_ld, order, seg_start, uniq_keys, n_unique,
                                  n_unique_dev, fm, values, place_feats, dest, walk, n_walk, workspace, workspace_bytes, stream);
+}
+
+// nrx_embed_bwd_placed / nrx_embed_bwd_placed_dense for the placement plans of nrx_sparse_plan_lds (pair records for the rows looked up twice).
+// values != NULL: row-sparse destination; grad_tables != NULL: the dense gradient tables.
+extern "C" int nrx_embed_bwd_placed_pairs(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                                          const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                                          const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
+                                          int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
+                                          float* const* grad_tables, int32_t n_tables, int32_t accumulate,
+                                          uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
+                                          const int32_t* pairs, const int64_t* n_pairs,
+                                          void* workspace, int64_t workspace_bytes, void* aux_stream, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(dest != nullptr && walk != nullptr && n_walk != nullptr && uniq_keys != nullptr && pairs != nullptr && n_pairs != nullptr,
+                "nrx_embed_bwd_placed_pairs: needs the whole plan (dest, walk, n_walk, pairs, n_pairs, uniq_keys)");
+    NRX_REQUIRE(nrx_aligned16(pairs), "nrx_embed_bwd_placed_pairs: pairs must be 16-byte aligned");
+    NRX_REQUIRE((values != nullptr) != (grad_tables != nullptr), "nrx_embed_bwd_placed_pairs: exactly one of values / grad_tables");
+    NRX_REQUIRE(workspace != nullptr, "nrx_embed_bwd_placed_pairs: needs the work-list workspace (nrx_embed_bwd_workspace_for)");
+    for (int i = 0; i < n_feats; ++i)
+        NRX_REQUIRE(feats != nullptr && feats[i].kind == NRX_SPARSE && ((place_feats >> i) & 1ull), "nrx_embed_bwd_placed_pairs: feature %d: every feature must be single-valued and placeable", i);
+    return embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, g_wide, wide_ld, order, seg_start, uniq_keys, n_unique,
+                                 n_unique_dev, fm, values, place_feats, dest, walk, n_walk, workspace, workspace_bytes, stream,
+                                 grad_tables, n_tables, accumulate, true, aux_stream, pairs, n_pairs);
 }

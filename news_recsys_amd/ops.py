@@ -552,7 +552,8 @@ class _EmbedFn(torch.autograd.Function):
                         ids_ = [y.long() for y in ids_]
                         break
                 ctx.plans[(g_["dim"], fs_[0])] = (ids_,) + sparse_plan_ahead(ids_, g_["tabs"], g_["rows"], len(tables),
-                                                                          g_["pmask"] if SPARSE_PLACE else None, static=g_["static"])
+                                                                          g_["pmask"] if SPARSE_PLACE else None, static=g_["static"],
+                                                                          policy=_group_policy(g_, B, len(tables)))
         if ctx.has_fm_feat:
             ctx.save_for_backward(out)
         ctx.set_materialize_grads(False)
@@ -670,8 +671,75 @@ import collections as _collections
 _plan_keepalive = _collections.deque()
 
 
+# Planner of the row-sparse backward.  NRX_PLAN_LDS = auto (default) | 1 | 0.  The one-kernel planner (nrx_sparse_plan_lds: row bitmaps in LDS, no
+# sort; C2: 43 us against 74-80) is FAST only on near-unique id batches -- rows looked up three times or more are sorted by single blocks there.
+# auto: every plan leaves its duplicate statistics in mapped host memory (no copy, no synchronisation: the kernel writes them, the host reads
+# whatever the last finished plan left), and the NEXT batch of the launch group takes the one-kernel planner iff the last one was near-unique.
+PLAN_LDS = os.environ.get("NRX_PLAN_LDS", "auto")
+_lds_states = {}
+
+
+_aux_streams = {}
+PAIRS_AUX = os.environ.get("NRX_PAIRS_AUX", "0") != "0"      # the pair pass / walk of a one-kernel plan on a second stream, next to the placement
+                                                              # pass: measured, LOSES (C2 213.8 -> 225.1 us: the small launches are chains of dependent
+                                                              # round trips and every trip takes longer under the placement pass's traffic); off
+
+
+def _aux_stream(dev: torch.device) -> Optional[int]:
+    """The stream nrx_embed_bwd_placed_pairs forks its small launches onto (one per device)."""
+    if not PAIRS_AUX:
+        return None
+    k = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = _aux_streams.get(k)
+    if s is None:
+        s = _aux_streams[k] = torch.cuda.Stream(device=dev)
+    return s.cuda_stream
+
+
+def _lds_state(dev: torch.device, stream: int) -> Optional[torch.Tensor]:
+    """The planner's persistent control block (ticket, epoch, per-block totals), one per (device, stream): zero before the first use."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(stream))
+    st = _lds_states.get(key)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None                      # (a captured step uses the planner only if an eager step made the block before)
+        st = torch.zeros(_lib.load().nrx_sparse_plan_lds_state_bytes(), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)          # once: the fill ran on the current stream, the planner may run on another
+        _lds_states[key] = st
+    return st
+
+
+class PlanPolicy:
+    """Per launch group: may the one-kernel planner take it (shape), and should it (the previous batch's duplicate statistics)."""
+
+    def __init__(self, lens, tof, rws, n, n_tables, total, all_sparse=True):
+        lib = _lib.load()
+        self.total = int(total)
+        self.eligible = bool(all_sparse and PLAN_LDS != "0" and total > 0 and lib.nrx_sparse_plan_lds_ok(lens, tof, rws, n, n_tables))
+        self.use_lds = PLAN_LDS == "1"
+        self.stats = None
+        if self.eligible:
+            self.stats = torch.zeros(4, dtype=torch.int64).pin_memory()
+            self.stats_ptr = self.stats.data_ptr()
+            self._np = self.stats.numpy()
+
+    def choose(self) -> bool:
+        if not self.eligible:
+            return False
+        if PLAN_LDS == "1":
+            return True
+        uniq, walk_rows, walk_look, n = (int(x) for x in self._np)
+        if n != self.total:
+            return self.use_lds              # nothing recorded yet for this batch size: the sorted planner
+        if walk_look < 0:                    # recorded by the sorted planner: rows that are not alone ~ walk rows, lookups not counted
+            self.use_lds = (n - uniq + walk_rows) * 10 <= n
+        else:                                # by the one-kernel planner: lookups of rows looked up 3+ times, and all duplicates
+            self.use_lds = walk_look * 32 <= n and (n - uniq) * 8 <= n
+        return self.use_lds
+
+
 def sparse_plan_ahead(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int,
-                      place_feats: Optional[int] = None, static=None):
+                      place_feats: Optional[int] = None, static=None, policy: Optional["PlanPolicy"] = None):
     """sparse_plan on a side stream: the planning of the backward depends only on the ids, so it can run while the forward,
     the dense part of the model and its backward occupy the main stream.  Returns ((order, uniq, seg, counts), event);
     the consumer makes its stream wait for `event` before reading the plan."""
@@ -685,7 +753,7 @@ def sparse_plan_ahead(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows
     # was enqueued on the caller's stream before that point, so the side stream's writes are ordered behind it; they are consumed (and
     # later freed) on the caller's stream behind `ev`.  No record_stream anywhere.
     hold = []
-    res = sparse_plan(ids, table_of, rows, n_tables, place_feats, static=static, stream=side.cuda_stream, keep=hold)
+    res = sparse_plan(ids, table_of, rows, n_tables, place_feats, static=static, stream=side.cuda_stream, keep=hold, policy=policy)
     ev = torch.cuda.Event()
     ev.record(side)
     # The planner READS the ids on the side stream: an id tensor that dies early (a .long() / .contiguous() temporary, a
@@ -719,14 +787,18 @@ def place_mask(kinds: Sequence[int], bag_lens: Optional[Sequence[int]] = None) -
 
 
 def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int,
-                place_feats: Optional[int] = None, static=None, stream: Optional[int] = None, keep: Optional[list] = None):
+                place_feats: Optional[int] = None, static=None, stream: Optional[int] = None, keep: Optional[list] = None,
+                policy: Optional["PlanPolicy"] = None):
     """nrx_sparse_plan: group the flat, feature-major lookups `ids` (one device tensor per feature, all int32 or
     all int64) by (table, row).  Returns device int64 tensors (order [n], uniq_keys [n], seg_start [n+1],
     counts [n_tables+2]); only the first counts[0] entries of uniq_keys / counts[0]+1 of seg_start are
     meaningful.  No host synchronisation.
     place_feats (bit mask over the features, see place_mask): nrx_sparse_plan_place -- three more device tensors, dest
     int32 [n] (unique index of a lookup whose row is looked up once, else -1), walk int32 [n] (the other unique rows)
-    and n_walk int64 [1]: what nrx_embed_bwd_placed consumes."""
+    and n_walk int64 [1]: what nrx_embed_bwd_placed consumes.
+    policy (PlanPolicy of the launch group): when it picks the one-kernel planner (nrx_sparse_plan_lds) the result has EIGHT entries -- the
+    seven above (order / seg defined for the walk rows only; n_walk int64 [2]: walk rows, pair records) plus pairs int32 [n / 2 + 1, 4], the
+    records {unique index, first lookup, second lookup, 0} of the rows looked up twice -- and goes to nrx_embed_bwd_placed_pairs."""
     lib = _lib.load()
     n = len(ids)
     dev = ids[0].device
@@ -735,14 +807,9 @@ def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequ
     uniq = torch.empty(total, dtype=torch.int64, device=dev)
     seg = torch.empty(total + 1, dtype=torch.int64, device=dev)
     counts = torch.empty(n_tables + 2, dtype=torch.int64, device=dev)
-    nbytes = lib.nrx_sparse_plan_workspace(total)
-    if nbytes < 0:
-        raise ValueError("sparse_plan: too many lookups for one plan")
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    own_stream = stream is None
     if stream is None:
         stream = _raw_stream(dev)
-    elif keep is not None:
-        keep.append(ws)          # a foreign stream: the caller holds the workspace until the plan has run (sparse_plan_ahead)
     ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in ids])
     lens = (C.c_int64 * n)(*[x.numel() for x in ids])
     if static is not None:                     # (table_of, rows) as ctypes arrays, built once per plan group
@@ -750,6 +817,29 @@ def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequ
     else:
         tof = (C.c_int32 * n)(*[int(t) for t in table_of])
         rws = (C.c_int64 * n)(*[int(r) for r in rows])
+    if policy is not None and place_feats is not None and policy.choose():
+        state = _lds_state(dev, stream)
+        if state is not None:
+            ws = torch.empty(lib.nrx_sparse_plan_lds_workspace(total), dtype=torch.uint8, device=dev)
+            dest = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+            walk = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+            n_walk = torch.empty(2, dtype=torch.int64, device=dev)                      # [0] walk rows  [1] pair records
+            pairs = torch.empty((total // 2 + 1, 4), dtype=torch.int32, device=dev)
+            rc = lib.nrx_sparse_plan_lds(ptrs, lens, tof, rws, n, ids[0].element_size() * 8, n_tables, order.data_ptr(), uniq.data_ptr(),
+                                         seg.data_ptr(), counts.data_ptr(), dest.data_ptr(), walk.data_ptr(), n_walk.data_ptr(),
+                                         pairs.data_ptr(), n_walk.data_ptr() + 8, policy.stats_ptr, state.data_ptr(), ws.data_ptr(), stream)
+            if rc == 0:
+                if not own_stream and keep is not None:
+                    keep.append(ws)
+                return order, uniq, seg, counts, dest, walk, n_walk, pairs
+            if rc != NRX_ERR_UNSUPPORTED:
+                check(rc, "nrx_sparse_plan_lds")
+    nbytes = lib.nrx_sparse_plan_workspace(total)
+    if nbytes < 0:
+        raise ValueError("sparse_plan: too many lookups for one plan")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if not own_stream and keep is not None:
+        keep.append(ws)          # a foreign stream: the caller holds the workspace until the plan has run (sparse_plan_ahead)
     if place_feats is not None:
         dest = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
         walk = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
@@ -757,21 +847,49 @@ def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequ
         check(lib.nrx_sparse_plan_place(ptrs, lens, tof, rws, n, ids[0].element_size() * 8, n_tables, int(place_feats), order.data_ptr(),
                                         uniq.data_ptr(), seg.data_ptr(), counts.data_ptr(), dest.data_ptr(), walk.data_ptr(),
                                         n_walk.data_ptr(), ws.data_ptr(), stream), "nrx_sparse_plan_place")
+        if policy is not None and policy.eligible and PLAN_LDS == "auto":      # what the next batch's choice of planner needs
+            lib.nrx_sparse_plan_stats(counts.data_ptr(), n_walk.data_ptr(), total, policy.stats_ptr, stream)
         return order, uniq, seg, counts, dest, walk, n_walk
     check(lib.nrx_sparse_plan(ptrs, lens, tof, rws, n, ids[0].element_size() * 8, n_tables, order.data_ptr(), uniq.data_ptr(),
                               seg.data_ptr(), counts.data_ptr(), ws.data_ptr(), stream), "nrx_sparse_plan")
     return order, uniq, seg, counts
 
 
-def _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, wide_ld, n_unique, n_unique_dev, fmg, values, lws, stream):
-    """nrx_embed_bwd_sorted, or nrx_embed_bwd_placed when the plan `pl` carries a placement (7 tensors)."""
+def _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, wide_ld, n_unique, n_unique_dev, fmg, values, lws, stream,
+                dense=None, replan=None):
+    """nrx_embed_bwd_sorted, or nrx_embed_bwd_placed when the plan `pl` carries a placement (7 tensors), or nrx_embed_bwd_placed_pairs for
+    a plan of the one-kernel planner (8 entries).  dense = (grad table pointers, n_tables, accumulate): the dense destination instead of
+    values.  Returns the plan that was used: a launch outside the pair pass's shapes (NRX_ERR_UNSUPPORTED, nothing enqueued) is planned
+    again by the sorted planner (`replan()`), whose plan every reduction takes."""
+    if len(pl) == 8:                    # nrx_sparse_plan_lds's plan: pair rows
+        rc = lib.nrx_embed_bwd_placed_pairs(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), wide_ld, pl[0].data_ptr(), pl[2].data_ptr(),
+                                            pl[1].data_ptr(), n_unique, _ptr(n_unique_dev), fmg,
+                                            values.data_ptr() if dense is None else None, dense[0] if dense else None,
+                                            dense[1] if dense else 0, dense[2] if dense else 0, int(pmask),
+                                            pl[4].data_ptr(), pl[5].data_ptr(), pl[6].data_ptr(), pl[7].data_ptr(), pl[6].data_ptr() + 8,
+                                            lws.data_ptr(), lws.numel(), _aux_stream(pl[0].device), stream)
+        if rc == 0:
+            return pl
+        if rc != NRX_ERR_UNSUPPORTED or replan is None:
+            check(rc, "nrx_embed_bwd_placed_pairs")
+        pl = replan()
+        if n_unique_dev is not None:
+            n_unique_dev = pl[3]
     order, uniq, seg = pl[0], pl[1], pl[2]
-    placed = len(pl) == 7
+    placed = len(pl) >= 7
+    if dense is not None:
+        check(lib.nrx_embed_bwd_placed_dense(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), wide_ld, order.data_ptr(), seg.data_ptr(),
+                                             uniq.data_ptr(), n_unique, _ptr(n_unique_dev), fmg, dense[0], dense[1], dense[2],
+                                             int(pmask) if placed else 0, pl[4].data_ptr() if placed else None,
+                                             pl[5].data_ptr() if placed else None, pl[6].data_ptr() if placed else None,
+                                             lws.data_ptr(), lws.numel(), stream), "nrx_embed_bwd_placed_dense")
+        return pl
     check(lib.nrx_embed_bwd_placed(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), wide_ld, order.data_ptr(), seg.data_ptr(),
                                    uniq.data_ptr(), n_unique, _ptr(n_unique_dev), fmg, values.data_ptr(), int(pmask) if placed else 0,
                                    pl[4].data_ptr() if placed else None, pl[5].data_ptr() if placed else None,
                                    pl[6].data_ptr() if placed else None, lws.data_ptr(), lws.numel(), stream),
           "nrx_embed_bwd_placed")
+    return pl
 
 
 def _sparse_group_cache(plan: EmbedPlan, tables):
@@ -788,9 +906,22 @@ def _sparse_group_cache(plan: EmbedPlan, tables):
                                sub=EmbedPlan([plan.slots[i] for i in fs], out_width=plan.out_width, wide_width=plan.wide_width),
                                static=((C.c_int32 * n)(*tabs), (C.c_int64 * n)(*[int(tables[t].shape[0]) for t in tabs])),
                                rows=[int(tables[t].shape[0]) for t in tabs],
-                               pmask=place_mask([plan.slots[i].kind for i in fs], [plan.slots[i].bag_len for i in fs])))
+                               pmask=place_mask([plan.slots[i].kind for i in fs], [plan.slots[i].bag_len for i in fs]),
+                               all_sparse=all(plan.slots[i].kind == NRX_SPARSE for i in fs) and D in (16, 32, 64), policy=None, policy_B=-1))
         ent = plan.__dict__["_sg"] = (key, groups)
     return ent[1]
+
+
+def _group_policy(grp, B: int, n_tables: int) -> Optional["PlanPolicy"]:
+    """The launch group's PlanPolicy at batch size B (built once per batch size; None: the group can never take the one-kernel planner)."""
+    if not grp["all_sparse"] or PLAN_LDS == "0" or not SPARSE_PLACE:
+        return None
+    if grp["policy_B"] != B:
+        n = grp["n"]
+        lens = (C.c_int64 * n)(*([B] * n))
+        grp["policy"] = PlanPolicy(lens, grp["static"][0], grp["static"][1], n, n_tables, B * n)
+        grp["policy_B"] = B
+    return grp["policy"]
 
 
 def _sparse_groups(plan: EmbedPlan):
@@ -886,8 +1017,16 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
             total = sum(x.numel() for x in ids)
             if total == 0:
                 continue
-            pl = sparse_plan(ids, tabs, grp["rows"], n_tables, pmask, static=grp["static"])
+            pl = sparse_plan(ids, tabs, grp["rows"], n_tables, pmask, static=grp["static"],
+                             policy=_group_policy(grp, B, n_tables) if n_tables <= NRX_MAX_FEATURES else None)
         uniq, counts = pl[1], pl[3]
+
+        def replan(ids=ids, tabs=tabs, grp=grp, pmask=pmask):
+            """The one-kernel planner's plan met a launch the pair pass does not take: the sorted planner's plan (same unique rows, same
+            counts), inline; the group stops choosing the one-kernel planner."""
+            grp["all_sparse"] = False
+            return sparse_plan(ids, tabs, grp["rows"], n_tables, pmask, static=grp["static"])
+
         # The one host read (n_tables + 2 integers).  Reading it BEFORE the reduction lets the host build the
         # per-table COO tensors while that kernel runs (1.00 ms per C2 step vs 1.11 ms with the sync-free
         # n_unique_dev form of the call, which leaves the host work exposed after the GPU is done).
@@ -903,30 +1042,25 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
             # the reduction stores every unique row's sum at its place in the table's dense gradient (nrx_embed_bwd_placed_dense: the
             # descriptors' table column carries the gradient of the feature's table) -- no values[] array, no nrx_rows_to_dense pass
             arr = _group_features(grp, ids, [ctx.ws[i] for i in fs], fmg is not None, [dense_into[t].data_ptr() for t in tabs])
-            placed = len(pl) == 7
-            check(lib.nrx_embed_bwd_placed_dense(arr, n, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, pl[0].data_ptr(),
-                                                 pl[2].data_ptr(), uniq.data_ptr(), total, counts.data_ptr(), fmg, dense_ptrs, n_tables,
-                                                 1 if again else 0, int(pmask) if placed else 0,
-                                                 pl[4].data_ptr() if placed else None, pl[5].data_ptr() if placed else None,
-                                                 pl[6].data_ptr() if placed else None, lws.data_ptr(), lws.numel(), stream),
-                  "nrx_embed_bwd_placed_dense")
+            _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, total, counts, fmg, None, lws, stream,
+                        dense=(dense_ptrs, n_tables, 1 if again else 0), replan=replan)
             dense_seen.update(tabs)
             continue
         if ctx.sink is not None:
             values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
-            _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, total, counts, fmg, values, lws, stream)
-            ctx.sink.pending.append(dict(tables=ctx.tables, dim=D, uniq=uniq, values=values, counts=counts, cap=total))
+            pl = _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, total, counts, fmg, values, lws, stream, replan=replan)
+            ctx.sink.pending.append(dict(tables=ctx.tables, dim=D, uniq=pl[1], values=values, counts=pl[3], cap=total))
             continue
         if SPARSE_BWD_SYNC_FREE:
             values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
-            _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, total, counts, fmg, values, lws, stream)
+            _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, total, counts, fmg, values, lws, stream, replan=replan)
             cl = counts.tolist()
             nu = cl[0]
         else:
             cl = counts.tolist()
             nu = cl[0]
             values = torch.empty((nu, D), dtype=torch.float32, device=dev)
-            _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, nu, None, fmg, values, lws, stream)
+            _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, nu, None, fmg, values, lws, stream, replan=replan)
                                                               # padding rows (id 0) come back as zeros
         rows = (uniq[:nu] & MASK).unsqueeze(0)
         for t in sorted(set(tabs)):
@@ -1234,17 +1368,39 @@ class PreparedSparseBackward:
                      pmask=place_mask([plan.slots[i].kind for i in fs], [plan.slots[i].bag_len for i in fs]) if SPARSE_PLACE else None,
                      dest=torch.empty(max(total, 1), dtype=torch.int32, device=dev),
                      walk=torch.empty(max(total, 1), dtype=torch.int32, device=dev),
-                     n_walk=torch.empty(1, dtype=torch.int64, device=dev),
+                     n_walk=torch.empty(2, dtype=torch.int64, device=dev),                 # [0] walk rows  [1] pair records (one-kernel planner)
+                     pair_recs=None,
                      lws=torch.empty(self.lib.nrx_embed_bwd_workspace_for(arr, n, fwd.B, D), dtype=torch.uint8, device=dev),
+                     pairs=False, lds_ws=None,
                      ptrs=(C.c_void_p * n)(*[x.data_ptr() for x in ids]), lens=(C.c_int64 * n)(*[x.numel() for x in ids]),
                      tof=(C.c_int32 * n)(*tabs), rws=(C.c_int64 * n)(*[fwd.tables[t].shape[0] for t in tabs]),
                      bits=ids[0].element_size() * 8, n_tables=n_tables,
                      arr=arr)
+            g["policy"] = None
+            if g["pmask"] is not None and D in (16, 32, 64) and all(plan.slots[i].kind == NRX_SPARSE for i in fs):
+                g["policy"] = PlanPolicy(g["lens"], g["tof"], g["rws"], n, n_tables, total)
+                if g["policy"].eligible:
+                    g["lds_ws"] = torch.empty(self.lib.nrx_sparse_plan_lds_workspace(total), dtype=torch.uint8, device=dev)
+                    g["pair_recs"] = torch.empty((total // 2 + 1, 4), dtype=torch.int32, device=dev)
             self.groups.append(g)
 
     def _plan(self, stream):
         lib = self.lib
         for g in self.groups:
+            g["pairs"] = False
+            pol = g["policy"]
+            if pol is not None and pol.choose():
+                state = _lds_state(self.fwd.device, stream)
+                if state is not None:
+                    rc = lib.nrx_sparse_plan_lds(g["ptrs"], g["lens"], g["tof"], g["rws"], g["n"], g["bits"], g["n_tables"], g["order"].data_ptr(),
+                                                 g["uniq"].data_ptr(), g["seg"].data_ptr(), g["counts"].data_ptr(), g["dest"].data_ptr(),
+                                                 g["walk"].data_ptr(), g["n_walk"].data_ptr(), g["pair_recs"].data_ptr(), g["n_walk"].data_ptr() + 8,
+                                                 pol.stats_ptr, state.data_ptr(), g["lds_ws"].data_ptr(), stream)
+                    if rc == 0:
+                        g["pairs"] = True
+                        continue
+                    if rc != NRX_ERR_UNSUPPORTED:
+                        check(rc, "nrx_sparse_plan_lds")
             if g["pmask"] is not None:
                 rc = lib.nrx_sparse_plan_place(g["ptrs"], g["lens"], g["tof"], g["rws"], g["n"], g["bits"], g["n_tables"], g["pmask"],
                                                g["order"].data_ptr(), g["uniq"].data_ptr(), g["seg"].data_ptr(), g["counts"].data_ptr(),
@@ -1254,6 +1410,8 @@ class PreparedSparseBackward:
                                          g["uniq"].data_ptr(), g["seg"].data_ptr(), g["counts"].data_ptr(), g["ws"].data_ptr(), stream)
             if rc:
                 check(rc, "nrx_sparse_plan")
+            if pol is not None and pol.eligible and PLAN_LDS == "auto" and g["pmask"] is not None:
+                lib.nrx_sparse_plan_stats(g["counts"].data_ptr(), g["n_walk"].data_ptr(), g["total"], pol.stats_ptr, stream)
 
     def plan_ahead(self):
         """Enqueue the planning (sort, unique rows, segments: it depends only on the ids) on a side stream NOW -- call it
@@ -1279,6 +1437,19 @@ class PreparedSparseBackward:
             self._plan(stream)
         for g in self.groups:
             pm = g["pmask"] is not None
+            if g["pairs"]:
+                rc = lib.nrx_embed_bwd_placed_pairs(g["arr"], g["n"], f.B, g["dim"], _ptr(self.g_out), f.ld, _ptr(self.g_wide), f.plan.wide_width,
+                                                    g["order"].data_ptr(), g["seg"].data_ptr(), g["uniq"].data_ptr(), g["total"],
+                                                    g["counts"].data_ptr(), self.fmg, g["values"].data_ptr(), None, 0, 0, g["pmask"],
+                                                    g["dest"].data_ptr(), g["walk"].data_ptr(), g["n_walk"].data_ptr(), g["pair_recs"].data_ptr(),
+                                                    g["n_walk"].data_ptr() + 8, g["lws"].data_ptr(), g["lws"].numel(), _aux_stream(f.device), stream)
+                if rc == NRX_ERR_UNSUPPORTED:           # outside the pair pass's shapes: plan again with the sorted planner, for good
+                    g["policy"] = None
+                    self._plan(stream)
+                else:
+                    if rc:
+                        check(rc, "nrx_embed_bwd_placed_pairs")
+                    continue
             rc = lib.nrx_embed_bwd_placed(g["arr"], g["n"], f.B, g["dim"], _ptr(self.g_out), f.ld, _ptr(self.g_wide), f.plan.wide_width,
                                           g["order"].data_ptr(), g["seg"].data_ptr(), g["uniq"].data_ptr(), g["total"],
                                           g["counts"].data_ptr(), self.fmg, g["values"].data_ptr(), g["pmask"] if pm else 0,

@@ -797,3 +797,28 @@ def sparse_plan_place(id_arrays, table_of, rows, n_tables: int, place_feats=None
     dest[first[placed]] = np.nonzero(placed)[0].astype(np.int32)
     walk = np.nonzero(~placed)[0].astype(np.int32)
     return order, uniq, seg, counts, dest, walk
+
+
+def sparse_plan_pairs(id_arrays, table_of, rows, n_tables: int):
+    """Definition of nrx_sparse_plan_lds (the one-kernel planner; same role as sparse_plan_place for the autograd of nn.Embedding,
+    base_model.py:262-308): uniq / counts as sparse_plan; per row with unique index u
+      looked up once (not the padding row)   -> dest[p] = u for its lookup p
+      looked up exactly twice (not padding)  -> dest = -1 for both lookups, one PAIR record (u, p1, p2), p1 < p2
+      otherwise (3+ lookups, or the padding row) -> dest = -1; u is on the walk list, its lookups (ascending) are walk_lookups[u].
+    Returns (uniq, counts, dest, pairs: int32 [k, 3] ascending by u, walk: int32 ascending, walk_lookups: dict u -> int64 array)."""
+    order, uniq, seg, counts = sparse_plan(id_arrays, table_of, rows, n_tables)
+    n = len(order)
+    dest = np.full(n, -1, np.int32)
+    seg_len = seg[1:] - seg[:-1]
+    row = uniq & ((np.int64(1) << np.int64(40)) - 1)
+    pairs, walk, walk_lookups = [], [], {}
+    for u in range(len(uniq)):
+        ps = order[seg[u]:seg[u + 1]]
+        if row[u] != 0 and seg_len[u] == 1:
+            dest[ps[0]] = u
+        elif row[u] != 0 and seg_len[u] == 2:
+            pairs.append((u, int(ps[0]), int(ps[1])))
+        else:
+            walk.append(u)
+            walk_lookups[u] = np.asarray(ps, np.int64)
+    return uniq, counts, dest, np.asarray(pairs, np.int32).reshape(-1, 3), np.asarray(walk, np.int32), walk_lookups

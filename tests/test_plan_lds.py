@@ -1,0 +1,236 @@
+"""The one-kernel planner of the row-sparse backward (nrx_sparse_plan_lds: row bitmaps in LDS, no sort) and the pair pass behind it
+(nrx_embed_bwd_placed_pairs), against
+  * its definition, oracle.ref_np.sparse_plan_pairs (itself written on oracle.ref_np.sparse_plan, the sorted plan's definition):
+    unique rows, per-table bounds, dest words, pair records and walk rows bit for bit;
+  * the sorted planner's backward (nrx_sparse_plan_place + nrx_embed_bwd_placed / _placed_dense), which earlier tests tie to the
+    reference's gradients (goldens, fp64 restatements): same unique rows, same row gradients BIT FOR BIT (int32 words);
+  * a float64 restatement of autograd's index_add (oracle.ref_np.embedding_grad_dense) directly, rtol 1e-5.
+Backward of src/model/BaseModel/base_model.py:262-308 (+ sort/fm/model.py:18-26)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from news_recsys_amd import _lib, ops
+from news_recsys_amd._lib import NRX_SPARSE
+from oracle import ref_np as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _plan_lds(ids_np, tab, rows, nt, dtype=torch.int64, misalign=False, state=None):
+    lib = _lib.load()
+    dev = torch.device(DEV)
+    ids = []
+    for x in ids_np:
+        t = torch.from_numpy(x).to(DEV).to(dtype)
+        if misalign:                                   # a view that starts 8 (or 4) bytes into its buffer: the one-id-per-load form
+            buf = torch.empty(t.numel() + 1, dtype=dtype, device=DEV)
+            buf[1:] = t
+            t = buf[1:]
+        ids.append(t)
+    n = len(ids)
+    total = sum(x.numel() for x in ids)
+    order = torch.full((total,), -7, dtype=torch.int64, device=DEV)
+    uniq = torch.full((total,), -7, dtype=torch.int64, device=DEV)
+    seg = torch.full((total + 1,), -7, dtype=torch.int64, device=DEV)
+    counts = torch.full((nt + 2,), -7, dtype=torch.int64, device=DEV)
+    dest = torch.full((total,), 0x7f7f7f7f, dtype=torch.int32, device=DEV)
+    walk = torch.full((total,), -7, dtype=torch.int32, device=DEV)
+    n_walk = torch.full((2,), -7, dtype=torch.int64, device=DEV)
+    pairs = torch.full((total // 2 + 1, 4), -7, dtype=torch.int32, device=DEV)
+    stats = torch.zeros(4, dtype=torch.int64, device=DEV)
+    if state is None:
+        state = torch.zeros(lib.nrx_sparse_plan_lds_state_bytes(), dtype=torch.uint8, device=DEV)
+    ws = torch.empty(lib.nrx_sparse_plan_lds_workspace(total), dtype=torch.uint8, device=DEV)
+    ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in ids])
+    lens = (C.c_int64 * n)(*[x.numel() for x in ids])
+    tof = (C.c_int32 * n)(*tab)
+    rws = (C.c_int64 * n)(*rows)
+    assert lib.nrx_sparse_plan_lds_ok(lens, tof, rws, n, nt) == 1
+    rc = lib.nrx_sparse_plan_lds(ptrs, lens, tof, rws, n, ids[0].element_size() * 8, nt, order.data_ptr(), uniq.data_ptr(), seg.data_ptr(),
+                                 counts.data_ptr(), dest.data_ptr(), walk.data_ptr(), n_walk.data_ptr(), pairs.data_ptr(), n_walk.data_ptr() + 8,
+                                 stats.data_ptr(), state.data_ptr(), ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "nrx_sparse_plan_lds")
+    torch.cuda.synchronize()
+    return dict(order=order.cpu().numpy(), uniq=uniq.cpu().numpy(), seg=seg.cpu().numpy(), counts=counts.cpu().numpy(),
+                dest=dest.cpu().numpy(), walk=walk.cpu().numpy(), n_walk=int(n_walk[0].item()), n_pairs=int(n_walk[1].item()),
+                pairs=pairs.cpu().numpy(), stats=stats.cpu().numpy(), total=total, state=state)
+
+
+def _check_against_definition(got, ids_np, tab, rows, nt):
+    uniq, counts, dest, pairs, walk, walk_lookups = R.sparse_plan_pairs(ids_np, tab, rows, nt)
+    nu, n = len(uniq), got["total"]
+    assert np.array_equal(got["counts"], counts)
+    assert np.array_equal(got["uniq"][:nu], uniq)
+    assert got["n_walk"] == len(walk) and np.array_equal(got["walk"][:len(walk)], walk)
+    assert np.array_equal(got["dest"][:n], dest)                               # once: u; every other lookup: -1
+    assert got["n_pairs"] == len(pairs) and np.array_equal(got["pairs"][:len(pairs), :3], pairs)      # twice: {u, first, second}, ascending
+    at = 0                                                                      # the walk rows' lookups: packed, in walk order, ascending
+    for u in walk:
+        ps = walk_lookups[int(u)]
+        assert got["seg"][u] == at and got["seg"][u + 1] == at + len(ps)
+        assert np.array_equal(got["order"][at:at + len(ps)], ps)
+        at += len(ps)
+    assert list(got["stats"]) == [nu, len(walk), at, n]
+
+
+def _case_ids(rng, kind, B, rows, n):
+    if kind == "uniform":
+        ids = [rng.integers(1, r, B) for r in rows]
+    elif kind == "dup":                                    # many rows looked up 2, 3, 4 ... times: the list, its sort, the walk rows
+        ids = [rng.integers(1, max(2, min(r, B // 3)), B) for r in rows]
+    elif kind == "one_range":                              # every lookup in ONE 131 072-row range: more than the LDS cache holds -> the re-scan path
+        ids = [rng.integers(1, min(r, 100000), B) for r in rows]
+    elif kind == "hot":                                    # a handful of very hot rows: lists beyond the LDS sort -> the in-place sort
+        ids = [np.where(rng.random(B) < 0.6, rng.integers(1, 6, B), rng.integers(1, r, B)) for r in rows]
+    else:
+        raise AssertionError(kind)
+    ids = [np.asarray(x, np.int64) for x in ids]
+    for x in ids:
+        x[:2] = 0                                          # the padding row
+        if len(x) > 3:
+            x[2] = -5                                      # out-of-range ids fall on the padding row
+            x[3] = 1 << 33
+    return ids
+
+
+PLAN_CASES = [
+    # name, kind, B, rows per feature, table of each feature, n_tables
+    ("c2_like", "uniform", 4099, [300000] * 6, list(range(6)), 6),
+    ("ragged_rows", "uniform", 3001, [131072, 131073, 17, 262145, 5000], [0, 1, 2, 3, 4], 5),
+    ("shared_table", "uniform", 2500, [200000, 200000, 70000], [0, 0, 2], 4),            # two features on table 0; table 1 and 3 unread
+    ("dup_heavy", "dup", 6000, [50000, 400000], [0, 1], 2),
+    ("cache_overflow", "one_range", 30011, [1000000, 300000], [0, 1], 2),
+    ("hot_rows", "hot", 20000, [500000], [0], 1),
+    ("tiny_batch", "uniform", 1, [1000, 200000], [0, 1], 2),
+    ("odd_batch", "uniform", 7, [1000], [0], 1),
+]
+
+
+@pytest.mark.parametrize("name,kind,B,rows,tab,nt", PLAN_CASES, ids=[c[0] for c in PLAN_CASES])
+@pytest.mark.parametrize("dtype,misalign", [(torch.int64, False), (torch.int32, False), (torch.int64, True), (torch.int32, True)],
+                         ids=["i64", "i32", "i64-unaligned", "i32-unaligned"])
+def test_plan_lds_equals_its_definition(name, kind, B, rows, tab, nt, dtype, misalign):
+    rng = np.random.default_rng(len(name) * 77 + B)
+    ids = _case_ids(rng, kind, B, rows, len(rows))
+    if dtype == torch.int32:
+        for x in ids:
+            if len(x) > 3:
+                x[3] = -9                                  # (2^33 does not exist in 32 bits)
+    got = _plan_lds(ids, tab, rows, nt, dtype, misalign)
+    _check_against_definition(got, ids, tab, rows, nt)
+
+
+def test_plan_lds_state_is_rearmed_between_calls_of_different_shapes():
+    """The control block (ticket, epoch, per-block totals) is left ready by every call: shapes with more and fewer row ranges alternate on ONE
+    state, and every plan still equals its definition (a stale total of an earlier call would shift the unique indices)."""
+    rng = np.random.default_rng(5)
+    lib = _lib.load()
+    state = torch.zeros(lib.nrx_sparse_plan_lds_state_bytes(), dtype=torch.uint8, device=DEV)
+    shapes = [([900000] * 3, [0, 1, 2], 3, 5000), ([40000], [0], 1, 777), ([2000000, 150000], [0, 1], 2, 9000), ([40000], [0], 1, 778)]
+    for _ in range(3):
+        for rows, tab, nt, B in shapes:
+            ids = _case_ids(rng, "uniform", B, rows, len(rows))
+            got = _plan_lds(ids, tab, rows, nt, state=state)
+            _check_against_definition(got, ids, tab, rows, nt)
+
+
+def test_plan_lds_refuses_launches_outside_its_shapes():
+    lib = _lib.load()
+    def ok(lens, tab, rows, nt):
+        n = len(lens)
+        return lib.nrx_sparse_plan_lds_ok((C.c_int64 * n)(*lens), (C.c_int32 * n)(*tab), (C.c_int64 * n)(*rows), n, nt)
+    assert ok([100, 100], [0, 1], [1000, 1000], 2) == 1
+    assert ok([100, 5000], [0, 1], [1000, 1000], 2) == 0            # a bag feature (its lookups are a multiple of the batch)
+    assert ok([65536] * 5, [0, 1, 2, 3, 4], [100_000_000, 1_000_000, 18, 270, 18], 5) == 0      # C3's 100 M-row table: 763 ranges scanning 65 536 ids each
+    assert ok([100, 100], [0, 0], [1000, 2000], 1) == 0             # one table, two row counts
+
+
+def _grads(plan, tables, inputs, g_out, g_fm, lds, sparse, monkeypatch):
+    monkeypatch.setattr(ops, "PLAN_LDS", "1" if lds else "0")
+    plan.__dict__.pop("_sg", None)                         # (the launch groups cache their planner policy)
+    ts = [t.clone().requires_grad_() for t in tables]
+    out, _, fm = ops.embed_apply(plan, ts, inputs, [None] * len(inputs), sparse_grad=sparse)
+    loss = (out * g_out).sum()
+    if fm is not None:
+        loss = loss + (fm * g_fm).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    return [t.grad.coalesce() if sparse else t.grad for t in ts]
+
+
+BWD_CASES = [
+    # name, D, n_feats, rows, B, fm, kind
+    ("c2_like_fm", 16, 26, 300000, 5000, True, "uniform"),
+    ("fm_dup", 16, 7, 60000, 9000, True, "dup"),
+    ("plain32", 32, 6, 200000, 4097, False, "uniform"),
+    ("plain64_hot", 64, 3, 500000, 6000, False, "hot"),
+    ("plain16_tiny", 16, 4, 150000, 31, False, "uniform"),
+    ("fm_one", 16, 2, 140000, 1, True, "uniform"),
+]
+
+
+@pytest.mark.parametrize("name,D,n,rows,B,fm,kind", BWD_CASES, ids=[c[0] for c in BWD_CASES])
+@pytest.mark.parametrize("dest", ["row_sparse", "dense"])
+def test_pairs_backward_equals_sorted_backward_and_float64(name, D, n, rows, B, fm, kind, dest, monkeypatch):
+    rng = np.random.default_rng(len(name) * 31 + D)
+    monkeypatch.setattr(ops, "DENSE_BWD_SORTED", True)      # dense destination: always the planned reduction
+    monkeypatch.setattr(ops, "PLAN_AHEAD_MIN", 0)           # ... planned by sparse_plan (not the one-call form) at every size
+    slots = [ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, i * D, fm_field=int(fm)) for i in range(n)]
+    plan = ops.EmbedPlan(slots, out_width=n * D, use_fm=fm)
+    tables_np = [rng.standard_normal((rows, D)).astype(np.float32) for _ in range(n)]
+    tables = [torch.from_numpy(t).to(DEV) for t in tables_np]
+    ids_np = _case_ids(rng, kind, B, [rows] * n, n)
+    for x in ids_np:
+        x[2:4] = 7                                          # (the forward rejects out-of-range ids)
+        x[:1] = 0
+    inputs = [torch.from_numpy(x).to(DEV) for x in ids_np]
+    g_out = torch.from_numpy(rng.standard_normal((B, n * D)).astype(np.float32)).to(DEV)
+    g_fm = torch.from_numpy(rng.standard_normal((B,)).astype(np.float32)).to(DEV)
+    sparse = dest == "row_sparse"
+    a = _grads(plan, tables, inputs, g_out, g_fm, True, sparse, monkeypatch)
+    b = _grads(plan, tables, inputs, g_out, g_fm, False, sparse, monkeypatch)
+    for x, y in zip(a, b):
+        if sparse:
+            assert torch.equal(x.indices(), y.indices())
+            assert torch.equal(x.values().view(torch.int32), y.values().view(torch.int32))
+        else:
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    # float64 restatement: d loss / d table = index_add of the upstream rows (+ the FM term g_fm * (S - v) per factor column, g_fm for column 0)
+    go = g_out.cpu().numpy().astype(np.float64)
+    up = [go[:, i * D:(i + 1) * D].copy() for i in range(n)]
+    if fm:
+        gf = g_fm.cpu().numpy().astype(np.float64)[:, None]
+        rows_v = [tables_np[i].astype(np.float64)[ids_np[i]] for i in range(n)]
+        S = sum(rows_v)
+        for i in range(n):
+            t = gf * (S - rows_v[i])
+            t[:, 0] = gf[:, 0]
+            up[i] += t
+    for i in range(n):
+        want = R.embedding_grad_dense(ids_np[i], up[i], rows)
+        got = (a[i].to_dense() if sparse else a[i]).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(want).max()))
+
+
+def test_policy_follows_the_previous_batch(monkeypatch):
+    """auto mode: the first batch of a launch group is planned by the sorted planner, which leaves the duplicate statistics; near-unique ids then
+    take the one-kernel planner, a duplicate-heavy batch sends the group back."""
+    monkeypatch.setattr(ops, "PLAN_LDS", "auto")
+    rng = np.random.default_rng(3)
+    n, B, rows = 4, 3000, 400000
+    lens = (C.c_int64 * n)(*([B] * n))
+    pol = ops.PlanPolicy(lens, (C.c_int32 * n)(*range(n)), (C.c_int64 * n)(*([rows] * n)), n, n, B * n)
+    assert pol.eligible
+    kinds = []
+    for kind in ["uniform", "uniform", "uniform", "dup", "dup", "uniform", "uniform"]:
+        src = rows if kind == "uniform" else 300
+        ids = [torch.from_numpy(rng.integers(1, src, B)).to(DEV) for _ in range(n)]
+        pl = ops.sparse_plan(ids, list(range(n)), [rows] * n, n, (1 << n) - 1, policy=pol)
+        torch.cuda.synchronize()
+        kinds.append(len(pl) == 8)
+    #          sorted (no statistics yet), lds, lds, lds (found out it was slow), sorted, sorted (found near-unique again), lds
+    assert kinds == [False, True, True, True, False, False, True]

@@ -224,3 +224,19 @@ def test_oracle_sparse_plan_place_definition():
     # every unique row is either placed exactly once or walked
     placed = sorted(d for d in dest.tolist() if d >= 0)
     assert sorted(placed + walk.tolist()) == list(range(len(uniq)))
+
+
+def test_oracle_sparse_plan_pairs_definition():
+    """The one-kernel planner's definition on a case small enough to read: once -> unique index, twice -> one pair record,
+    three times / the padding row -> the walk list with its lookups in ascending order."""
+    #           feature 0 (table 0)      feature 1 (table 0)   feature 2 (table 1)
+    ids = [np.array([5, 7, 0, 9, 7]), np.array([7, 2, 9, 0, 11]), np.array([3, 3, 3, 4, 6])]
+    uniq, counts, dest, pairs, walk, walk_lookups = R.sparse_plan_pairs(ids, [0, 0, 1], [16, 16, 8], 2)
+    rows, tabs = uniq & ((1 << 40) - 1), uniq >> 40
+    assert list(zip(tabs.tolist(), rows.tolist())) == [(0, 0), (0, 2), (0, 5), (0, 7), (0, 9), (0, 11), (1, 3), (1, 4), (1, 6)]
+    assert counts.tolist() == [9, 0, 6, 9]
+    #            p:  0   1   2   3   4 | 5  6   7   8  9 | 10  11  12  13 14
+    assert dest.tolist() == [2, -1, -1, -1, -1, -1, 1, -1, -1, 5, -1, -1, -1, 7, 8]     # row 9 twice (u = 4): a pair; row 7 three times: walked
+    assert pairs.tolist() == [[4, 3, 7]]
+    assert walk.tolist() == [0, 3, 6]
+    assert walk_lookups[0].tolist() == [2, 8] and walk_lookups[3].tolist() == [1, 4, 5] and walk_lookups[6].tolist() == [10, 11, 12]
