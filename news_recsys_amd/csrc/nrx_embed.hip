@@ -983,8 +983,8 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_kernel(const Sorte
 // ---- work lists of the long-segment path (workspace layout: 4 counters | items | multi-chunk rows | partial sums)
 constexpr int SORTED_LONG_T = 16;            // segments longer than this leave the lane-group kernel (32 for bag launches)
 constexpr int SORTED_LONG_CHUNK = 256;       // entries per work item (small: items are the unit of load balance)
-struct LongItem { int32_t u; int32_t dest; int64_t e_begin; int64_t e_end; };      // dest < 0: straight to values[u]
-struct LongMulti { int32_t u; int32_t slot0; int32_t nchunks; int32_t pad; };
+struct LongItem { int32_t u; int32_t dest; int64_t e_begin; int32_t len; int32_t m; };      // dest < 0: straight to values[u]; m: its row's LongMulti (several items)
+struct LongMulti { int32_t u; int32_t slot0; int32_t nchunks; int32_t done; };              // done: items of the row finished so far (the last one adds the partials)
 
 __device__ __forceinline__ LongItem* sorted_long_items(const NRX_CONST SortedBwdArgs* a) {
     return reinterpret_cast<LongItem*>(a->long_ws + 4);
@@ -997,14 +997,15 @@ __device__ __forceinline__ float* sorted_long_partials(const NRX_CONST SortedBwd
 }
 
 __device__ __forceinline__ void sorted_long_write_items(const NRX_CONST SortedBwdArgs* a, int32_t u, int64_t lo, int64_t hi, int nchunks,
-                                                        int slot0, int base) {
+                                                        int slot0, int base, int m) {
     for (int c = 0; c < nchunks; ++c) {
         if (base + c >= a->long_items_cap) break;
         LongItem w;
         w.u = u;
         w.dest = nchunks > 1 ? slot0 + c : -1;
         w.e_begin = lo + (int64_t)c * SORTED_LONG_CHUNK;
-        w.e_end = w.e_begin + SORTED_LONG_CHUNK < hi ? w.e_begin + SORTED_LONG_CHUNK : hi;
+        w.len = (int32_t)((w.e_begin + SORTED_LONG_CHUNK < hi ? w.e_begin + SORTED_LONG_CHUNK : hi) - w.e_begin);
+        w.m = m;
         sorted_long_items(a)[base + c] = w;
     }
 }
@@ -1477,12 +1478,84 @@ __device__ __forceinline__ FeatLite sorted_decode(const NRX_CONST SortedBwdArgs*
     return t->f[fi];
 }
 
+// ---- Rows looked up exactly TWICE (placement plans of nrx_sparse_plan_lds).  The plan leaves one record {unique index, first lookup, second
+// lookup} per such row; a lane group takes a record, fetches the two upstream rows and stores 0 + first + second -- the sum the sorted walk forms
+// for a two-entry segment, bit for bit.  No order words, no segment bounds: one dependent round trip behind the record.  On uniform ids these rows
+// were nearly all of the walk's work (C2: 52 K of 53 K walked rows).  The records ride in the argument block's bag fields (a pair plan has no bag
+// feature): a->scale = the records, a->bag_inv = their number (device int64), a->bag_bits = the number of BLOCKS of the launch that take records
+// (the walk kernel's first blocks: the pair rows and the walked rows are independent chains of round trips -- in one launch they overlap).
+__device__ __forceinline__ const void* pairs_recs(const NRX_CONST SortedBwdArgs* a) { return a->scale; }
+__device__ __forceinline__ int pairs_blocks(const NRX_CONST SortedBwdArgs* a) { return (int)reinterpret_cast<intptr_t>(a->bag_bits); }
+template <int QLOG2, bool FM, bool UNAL, int DEC>
+__device__ __forceinline__ void pairs_body(const NRX_CONST SortedBwdArgs* a, const SortedFeatLds* s_ft, int bx, int gx) {
+    constexpr int Q = 1 << QLOG2, G = NRX_BLOCK / Q;
+    constexpr bool REG = DEC == 1;
+    const uint64_t reg_magic = a->uniform_magic;
+    const int64_t reg_len = a->uniform_len;
+    const int reg_col0 = a->col0, reg_stride = a->col_stride;
+    const bool reg_fm = a->all_fm != 0;
+    const int tid = threadIdx.x, q = tid & (Q - 1), grp = tid >> QLOG2;
+    using nrx_i32x4 = __attribute__((ext_vector_type(4))) int;
+    const NRX_GLOBAL nrx_i32x4* recs = nrx_gconst<nrx_i32x4>(pairs_recs(a));
+    const int64_t cap = a->off[a->n] / 2 + 1;
+    int64_t i = (int64_t)bx * G + grp;
+    nrx_i32x4 rec = {0, 0, 0, 0};
+    if (i < cap) rec = recs[i];                         // requested next to the count: a record past the count is read (inside the buffer) and dropped
+    int64_t n = nrx_gconst<int64_t>(a->bag_inv)[0];
+    n = n < cap ? n : cap;
+    auto row_of = [&](int64_t p) -> float4 {          // the gradient row chunk of lookup p, as the walk forms it
+        float4 g, v = make_float4(0.f, 0.f, 0.f, 0.f), s = v;
+        float gf = 0.f;
+        if (REG && !UNAL) {
+            const int fi = (int)__umul64hi((uint64_t)p, reg_magic);
+            const int64_t b = p - (int64_t)fi * reg_len;
+            const int col = reg_col0 + fi * reg_stride;
+            g = nrx_ldg4(a->g_out, (b * a->out_ld + col) / 4 + q);
+            if (FM) {
+                gf = reg_fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
+                v = nrx_ldg4(a->feat, (b * a->feat_ld + col) / 4 + q);
+                s = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
+            }
+        } else {
+            const FeatLite f = sorted_decode<DEC>(a, s_ft, p);
+            const int64_t b = p - f.off;
+            g = sorted_upstream<UNAL>(a, f, b, q);
+            if (FM) {
+                gf = f.fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
+                v = nrx_ldg4(a->feat, (b * a->feat_ld + f.out_col) / 4 + q);
+                s = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
+            }
+        }
+        if (FM) fm_fold4(g, gf, s, v, q);
+        return g;
+    };
+    for (; i < n; i += (int64_t)gx * G) {
+        const int64_t u = rec.x, p1 = (int64_t)(uint32_t)rec.y, p2 = (int64_t)(uint32_t)rec.z;
+        const int64_t inext = i + (int64_t)gx * G;
+        if (inext < n) rec = recs[inext];
+        const int64_t key = a->uniq_keys != nullptr ? nrx_gconst<int64_t>(a->uniq_keys)[u] : 1;
+        const float4 t_lo = row_of(p1), t_hi = row_of(p2);         // (the plan lists the lookups of a row in ascending order)
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc.x += t_lo.x; acc.y += t_lo.y; acc.z += t_lo.z; acc.w += t_lo.w;
+        acc.x += t_hi.x; acc.y += t_hi.y; acc.z += t_hi.z; acc.w += t_hi.w;
+        sorted_store4<Q>(a, u, key, q, acc);
+    }
+}
+// (launches with Wide&Deep column routing: the records in a launch of their own)
+template <int QLOG2, bool FM, bool UNAL, int DEC>
+__global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_pairs_kernel(const SortedBwdArgs args_in_kernarg) {
+    const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
+    __shared__ SortedFeatLds s_ft;
+    if (DEC == 0) sorted_feat_stage(a, &s_ft);
+    pairs_body<QLOG2, FM, UNAL, DEC>(a, &s_ft, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // REG: the launch's features are `regular` (SortedBwdArgs::regular: single-valued, equally long, equally spaced columns, one FM flag) --
 // feature, sample and column of a sorted entry are then ARITHMETIC on its lookup number.  As a run-time branch inside the general decode
 // (round 2) it cost what the general decode costs: that one reads the per-feature fields from the argument block with vector loads, and with
 // both forms in one instruction stream the compiler waits vmcnt(0) in front of every row load -- the 8 row loads of a pass went out ONE AT A
 // TIME, each behind the previous one's arrival (seen in the ISA; the C5 walk ran at 1.65 TB/s with 86 % of its wave time waiting).
-template <int QLOG2, int R, bool FM, bool BAG, bool UNAL, int UP = 1, int DEC = 0>
+template <int QLOG2, int R, bool FM, bool BAG, bool UNAL, int UP = 1, int DEC = 0, bool PAIRS = false>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const SortedBwdArgs args_in_kernarg) {
     const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
     // (REG) the launch's scalars, read once
@@ -1495,6 +1568,16 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
     __shared__ SortedFeatLds s_ft;
     constexpr bool REG = DEC == 1;
     if (DEC == 0) sorted_feat_stage(a, &s_ft);
+    int64_t bx = blockIdx.x, gx = gridDim.x;
+    if (PAIRS) {               // the launch's first blocks take the pair records (pairs_body), the others walk
+        const int pb = pairs_blocks(a);
+        if (bx < pb) {
+            pairs_body<QLOG2, FM, UNAL, DEC>(a, &s_ft, (int)bx, pb);
+            return;
+        }
+        bx -= pb;
+        gx -= pb;
+    }
     const bool bag_binary = BAG && a->bag_bits != nullptr && (a->long_ws[3] & 1) == 0;      // every bag weight is 0 or 1 (bag_scale_kernel)
     const bool need_bits = BAG && a->bag_bits != nullptr && (a->long_ws[3] & 2) != 0;       // some live lookup has weight 0
     constexpr int Q = 1 << QLOG2;
@@ -1562,17 +1645,17 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
         for (int r = 0; r < R; ++r) {
             if (lng[r] && q == 0) {
                 const int nchunks = (int)((hi[r] - lo[r] + SORTED_LONG_CHUNK - 1) / SORTED_LONG_CHUNK);
-                int slot0 = -1;
+                int slot0 = -1, m = -1;
                 if (nchunks > 1) {
                     slot0 = atomicAdd(&a->long_ws[2], nchunks);
-                    const int m = atomicAdd(&a->long_ws[1], 1);
+                    m = atomicAdd(&a->long_ws[1], 1);
                     if (m < a->long_slots_cap) {
                         LongMulti w;
-                        w.u = (int32_t)urow[r]; w.slot0 = slot0; w.nchunks = nchunks; w.pad = 0;
+                        w.u = (int32_t)urow[r]; w.slot0 = slot0; w.nchunks = nchunks; w.done = 0;
                         sorted_long_multi(a)[m] = w;
                     }
                 }
-                sorted_long_write_items(a, (int32_t)urow[r], lo[r], hi[r], nchunks, slot0, base);
+                sorted_long_write_items(a, (int32_t)urow[r], lo[r], hi[r], nchunks, slot0, base, m);
                 base += nchunks;
             }
         }
@@ -1745,77 +1828,13 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
     for (int r = 0; r < R; ++r)
         if (u0 + r < n && !lng[r]) sorted_store4<Q>(a, urow[r], key[r], q, acc[r]);
     };
-    for (int64_t blk = blockIdx.x; blk * (TB * R) < n; blk += gridDim.x) body(blk);
-}
-
-// ---- Rows looked up exactly TWICE (placement plans of nrx_sparse_plan_lds).  The plan leaves one record {unique index, first lookup, second
-// lookup} per such row; a lane group takes a record, fetches the two upstream rows and stores 0 + first + second -- the sum the sorted walk forms
-// for a two-entry segment, bit for bit.  No order words, no segment bounds: one dependent round trip behind the record.  On uniform ids these rows
-// were nearly all of the walk's work (C2: 52 K of 53 K walked rows).  Here a->walk = the records, a->n_walk_dev = their number (device),
-// a->n_unique = its bound; a->long_ws (side-stream mode): the walk's work-list counters, cleared here.
-template <int QLOG2, bool FM, bool UNAL, int DEC>
-__global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_pairs_kernel(const SortedBwdArgs args_in_kernarg) {
-    const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
-    constexpr int Q = 1 << QLOG2, G = NRX_BLOCK / Q;
-    constexpr bool REG = DEC == 1;
-    __shared__ SortedFeatLds s_ft;
-    if (DEC == 0) sorted_feat_stage(a, &s_ft);
-    const uint64_t reg_magic = a->uniform_magic;
-    const int64_t reg_len = a->uniform_len;
-    const int reg_col0 = a->col0, reg_stride = a->col_stride;
-    const bool reg_fm = a->all_fm != 0;
-    const int tid = threadIdx.x, q = tid & (Q - 1), grp = tid >> QLOG2;
-    using nrx_i32x4 = __attribute__((ext_vector_type(4))) int;
-    const NRX_GLOBAL nrx_i32x4* recs = nrx_gconst<nrx_i32x4>(a->walk);
-    const int64_t cap = a->n_unique;
-    int64_t i = (int64_t)blockIdx.x * G + grp;
-    nrx_i32x4 rec = {0, 0, 0, 0};
-    if (i < cap) rec = recs[i];                         // requested next to the count: a record past the count is read (inside the buffer) and dropped
-    int64_t n = nrx_gconst<int64_t>(a->n_walk_dev)[0];
-    n = n < cap ? n : cap;
-    auto row_of = [&](int64_t p) -> float4 {          // the gradient row chunk of lookup p, as the walk forms it
-        float4 g, v = make_float4(0.f, 0.f, 0.f, 0.f), s = v;
-        float gf = 0.f;
-        if (REG && !UNAL) {
-            const int fi = (int)__umul64hi((uint64_t)p, reg_magic);
-            const int64_t b = p - (int64_t)fi * reg_len;
-            const int col = reg_col0 + fi * reg_stride;
-            g = nrx_ldg4(a->g_out, (b * a->out_ld + col) / 4 + q);
-            if (FM) {
-                gf = reg_fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
-                v = nrx_ldg4(a->feat, (b * a->feat_ld + col) / 4 + q);
-                s = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
-            }
-        } else {
-            const FeatLite f = sorted_decode<DEC>(a, &s_ft, p);
-            const int64_t b = p - f.off;
-            g = sorted_upstream<UNAL>(a, f, b, q);
-            if (FM) {
-                gf = f.fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
-                v = nrx_ldg4(a->feat, (b * a->feat_ld + f.out_col) / 4 + q);
-                s = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
-            }
-        }
-        if (FM) fm_fold4(g, gf, s, v, q);
-        return g;
-    };
-    for (; i < n; i += (int64_t)gridDim.x * G) {
-        const int64_t u = rec.x, p1 = (int64_t)(uint32_t)rec.y, p2 = (int64_t)(uint32_t)rec.z;
-        const int64_t inext = i + (int64_t)gridDim.x * G;
-        if (inext < n) rec = recs[inext];
-        const int64_t key = a->uniq_keys != nullptr ? nrx_gconst<int64_t>(a->uniq_keys)[u] : 1;
-        const float4 t_lo = row_of(p1), t_hi = row_of(p2);         // (the plan lists the lookups of a row in ascending order)
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        acc.x += t_lo.x; acc.y += t_lo.y; acc.z += t_lo.z; acc.w += t_lo.w;
-        acc.x += t_hi.x; acc.y += t_hi.y; acc.z += t_hi.z; acc.w += t_hi.w;
-        sorted_store4<Q>(a, u, key, q, acc);
-    }
+    for (int64_t blk = bx; blk * (TB * R) < n; blk += gx) body(blk);
 }
 
 // Long segments.  An item = up to SORTED_LONG_CHUNK consecutive sorted entries of ONE unique row; a wavefront reduces an
 // item: its 64 / Q lane groups stride over the entries (two in flight each), then a fixed xor-shuffle tree adds the
 // groups -- the same entries always meet in the same order, so the result is reproducible.  A row of one item is written
-// straight to values; a row of several items leaves one partial per item, which sorted_combine_kernel adds in item order.
+// straight to values; a row of several items leaves one partial per item, which the wavefront finishing the row's last item adds in item order.
 template <int QLOG2, bool FM, bool BAG, bool UNAL, int DEC = 0>      // DEC: as in embed_bwd_sorted_fast_kernel
 __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdArgs args_in_kernarg) {
     const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
@@ -1838,6 +1857,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
     const int nwaves = gridDim.x * (NRX_BLOCK / 64);
     for (int it = blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6); it < nitems; it += nwaves) {
         const LongItem w = items[it];
+        const int64_t w_end = w.e_begin + w.len;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         // The item's sorted entries in chunks of 64: ONE order word per lane and chunk (the next chunk's requested before this chunk's rows),
         // handed to the lane groups through the cross-lane unit; group g takes entries g, g + G, g + 2G, ... of the item, as before (same
@@ -1846,12 +1866,12 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
         if (BAG) {               // bag launches keep round 2's loop (order words fetched per lane group, 4 entries in flight): the chunked form measured
                                  // 5-10 us slower on the C4 Zipf work list (50.6 -> 61.5 us for the launch)
             constexpr int UB = 4;
-            for (int64_t e0 = w.e_begin + g; e0 < w.e_end; e0 += UB * G) {
+            for (int64_t e0 = w.e_begin + g; e0 < w_end; e0 += UB * G) {
                 int64_t p[UB];
                 bool on[UB];
 #pragma unroll
                 for (int k = 0; k < UB; ++k) {
-                    on[k] = e0 + k * G < w.e_end;
+                    on[k] = e0 + k * G < w_end;
                     p[k] = nrx_gconst<int64_t>(a->order)[on[k] ? e0 + k * G : w.e_begin];
                 }
                 float4 gr[UB];
@@ -1871,19 +1891,19 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
             }
         } else {
         constexpr int UL = Q < 8 ? Q : 8;                       // rows in flight per lane group (a chunk gives every group Q entries)
-        int64_t pw_next = nrx_gconst<int64_t>(a->order)[w.e_begin + lane < w.e_end ? w.e_begin + lane : w.e_begin];
-        for (int64_t c0 = w.e_begin; c0 < w.e_end; c0 += 64) {
+        int64_t pw_next = nrx_gconst<int64_t>(a->order)[w.e_begin + lane < w_end ? w.e_begin + lane : w.e_begin];
+        for (int64_t c0 = w.e_begin; c0 < w_end; c0 += 64) {
             const int64_t pw = pw_next;
-            if (c0 + 64 < w.e_end) pw_next = nrx_gconst<int64_t>(a->order)[c0 + 64 + lane < w.e_end ? c0 + 64 + lane : w.e_begin];
+            if (c0 + 64 < w_end) pw_next = nrx_gconst<int64_t>(a->order)[c0 + 64 + lane < w_end ? c0 + 64 + lane : w.e_begin];
 #pragma unroll
             for (int kb = 0; kb < Q; kb += UL) {
-                if (c0 + (int64_t)kb * G >= w.e_end) break;               // wave-uniform (the sub-batch's first entry): every lane stays for the shuffles below
+                if (c0 + (int64_t)kb * G >= w_end) break;               // wave-uniform (the sub-batch's first entry): every lane stays for the shuffles below
                 int64_t p[UL];
                 bool on[UL];
 #pragma unroll
                 for (int k = 0; k < UL; ++k) {
                     const int idx = g + (kb + k) * G;
-                    on[k] = c0 + idx < w.e_end;
+                    on[k] = c0 + idx < w_end;
                     p[k] = __shfl(pw, idx, 64);
                 }
                 float4 gr[UL], v[UL], s_[UL];
@@ -1945,37 +1965,35 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
             if (w.dest < 0) sorted_store4<Q>(a, w.u, a->dense ? nrx_gconst<int64_t>(a->uniq_keys)[w.u] : 0, q, acc);
             else if (w.dest < a->long_slots_cap) nrx_stg4(partial, (int64_t)w.dest * Q + q, acc);
         }
-    }
-}
-
-// A row of several items: a wavefront adds its partials -- the 64 / Q lane groups stride over them in item order, then the
-// same fixed xor-shuffle tree as above (a single lane group walking the ~400 partials of a 100 k-entry hot row took
-// 177 us on Zipf ids).
-template <int QLOG2>
-__global__ __launch_bounds__(NRX_BLOCK) void sorted_combine_kernel(const SortedBwdArgs args_in_kernarg) {
-    const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
-    constexpr int Q = 1 << QLOG2, G = 64 / Q;
-    const int lane = threadIdx.x & 63, q = lane & (Q - 1), g = lane >> QLOG2;
-    const int nmulti = a->long_ws[1] < a->long_slots_cap ? a->long_ws[1] : (int)a->long_slots_cap;
-    const LongMulti* multi = sorted_long_multi(a);
-    const float* partial = sorted_long_partials(a);
-    const int nwaves = gridDim.x * (NRX_BLOCK / 64);
-    for (int m = blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6); m < nmulti; m += nwaves) {
-        const LongMulti w = multi[m];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c = g; c < w.nchunks; c += G) {
-            if (w.slot0 + c >= a->long_slots_cap) break;
-            const float4 t = nrx_ldg4(partial, (int64_t)(w.slot0 + c) * Q + q);
-            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-        }
+        // A row of several items: the wavefront that finishes the row's LAST item adds the partials -- its lane groups stride over them in item
+        // order, then the same fixed xor-shuffle tree as above: whichever wavefront comes last forms the same sum.  (Was a launch of its own,
+        // sorted_combine_kernel: 4.6 us on every step to find, on uniform ids, an empty list.)
+        if (w.dest >= 0 && w.m >= 0 && w.m < a->long_slots_cap) {            // wave-uniform
+            LongMulti* mrow = sorted_long_multi(a) + w.m;
+            __threadfence();                                                 // this item's partial is out before the count says so
+            int old = 0;
+            if (lane == 0) old = atomicAdd(&mrow->done, 1);
+            old = __shfl(old, 0, 64);
+            const int nch = mrow->nchunks;
+            if (old == nch - 1) {
+                __threadfence();                                             // ... and the others' partials are seen after the count said so
+                const int slot0 = mrow->slot0;
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int c = g; c < nch; c += G) {
+                    if (slot0 + c >= a->long_slots_cap) break;
+                    const float4 tt = nrx_ldg4(partial, (int64_t)(slot0 + c) * Q + q);
+                    sum.x += tt.x; sum.y += tt.y; sum.z += tt.z; sum.w += tt.w;
+                }
 #pragma unroll
-        for (int off = Q; off < 64; off <<= 1) {
-            acc.x += __shfl_xor(acc.x, off, 64);
-            acc.y += __shfl_xor(acc.y, off, 64);
-            acc.z += __shfl_xor(acc.z, off, 64);
-            acc.w += __shfl_xor(acc.w, off, 64);
+                for (int off = Q; off < 64; off <<= 1) {
+                    sum.x += __shfl_xor(sum.x, off, 64);
+                    sum.y += __shfl_xor(sum.y, off, 64);
+                    sum.z += __shfl_xor(sum.z, off, 64);
+                    sum.w += __shfl_xor(sum.w, off, 64);
+                }
+                if (g == 0) sorted_store4<Q>(a, w.u, a->dense ? nrx_gconst<int64_t>(a->uniq_keys)[w.u] : 0, q, sum);
+            }
         }
-        if (g == 0) sorted_store4<Q>(a, w.u, a->dense ? nrx_gconst<int64_t>(a->uniq_keys)[w.u] : 0, q, acc);
     }
 }
 
@@ -3351,25 +3369,20 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             }
         }
         if (!side) launch_place();
+        unsigned pair_blocks = 0;
         if (pairs) {
             // (a plan with pair rows is a placement plan over single-valued features: the launch is `placed`, has no bags)
-            SortedBwdArgs pr = a;
-            pr.walk = pair_recs;
-            pr.n_walk_dev = n_pairs;
-            pr.n_unique = off / 2 + 1;                     // (at most every second lookup starts a pair)
-            const bool reg_p = a.regular && g_out != nullptr && !unal;
-            const int64_t pgroups = (pr.n_unique + (NRX_BLOCK >> ql) - 1) / (NRX_BLOCK >> ql);
-            const unsigned pgrid2 = (unsigned)(pgroups < 1024 ? pgroups : 1024);
-#define NRX_PR(QL_)                                                                                                        \
-    {                                                                                                                      \
-        if (has_fm && reg_p) hipLaunchKernelGGL((embed_bwd_pairs_kernel<QL_, true, false, 1>), dim3(pgrid2), dim3(NRX_BLOCK), 0, sw, pr);      \
-        else if (has_fm) hipLaunchKernelGGL((embed_bwd_pairs_kernel<QL_, true, false, 0>), dim3(pgrid2), dim3(NRX_BLOCK), 0, sw, pr);      \
-        else if (unal) hipLaunchKernelGGL((embed_bwd_pairs_kernel<QL_, false, true, 0>), dim3(pgrid2), dim3(NRX_BLOCK), 0, sw, pr);      \
-        else if (reg_p) hipLaunchKernelGGL((embed_bwd_pairs_kernel<QL_, false, false, 1>), dim3(pgrid2), dim3(NRX_BLOCK), 0, sw, pr);      \
-        else hipLaunchKernelGGL((embed_bwd_pairs_kernel<QL_, false, false, 0>), dim3(pgrid2), dim3(NRX_BLOCK), 0, sw, pr);      \
-    }
-            if (ql == 2) NRX_PR(2) else if (ql == 3) NRX_PR(3) else NRX_PR(4)
-#undef NRX_PR
+            const int64_t pgroups = (off / 2 + 1 + (NRX_BLOCK >> ql) - 1) / (NRX_BLOCK >> ql);      // (at most every second lookup starts a pair)
+            pair_blocks = (unsigned)(pgroups < 512 ? pgroups : 512);
+            a.scale = reinterpret_cast<const float*>(pair_recs);
+            a.bag_inv = reinterpret_cast<const float*>(n_pairs);
+            a.bag_bits = reinterpret_cast<const uint32_t*>(static_cast<intptr_t>(pair_blocks));
+            if (unal) {        // column routing: the records in a launch of their own (the fused walk form exists for the aligned shapes)
+                if (ql == 2) hipLaunchKernelGGL((embed_bwd_pairs_kernel<2, false, true, 0>), dim3(pair_blocks), dim3(NRX_BLOCK), 0, sw, a);
+                else if (ql == 3) hipLaunchKernelGGL((embed_bwd_pairs_kernel<3, false, true, 0>), dim3(pair_blocks), dim3(NRX_BLOCK), 0, sw, a);
+                else hipLaunchKernelGGL((embed_bwd_pairs_kernel<4, false, true, 0>), dim3(pair_blocks), dim3(NRX_BLOCK), 0, sw, a);
+                pair_blocks = 0;
+            }
         }
         if (has_bag) {
             char* end = reinterpret_cast<char*>(a.long_ws + 4) + a.long_items_cap * sizeof(LongItem) +
@@ -3422,7 +3435,11 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
         const bool few = n_feats <= 4;                                  // scalar decode (DEC = 2); else the LDS table (DEC = 0)
 #define NRX_SF(QL_)                                                                                                        \
     {                                                                                                                      \
-        if (placed && has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4, 1>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); \
+        if (pair_blocks != 0 && has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4, 1, true>), dim3(grid + pair_blocks), dim3(NRX_BLOCK), 0, sw, a); \
+        else if (pair_blocks != 0 && has_fm) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4, 0, true>), dim3(grid + pair_blocks), dim3(NRX_BLOCK), 0, sw, a); \
+        else if (pair_blocks != 0 && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4, 1, true>), dim3(grid + pair_blocks), dim3(NRX_BLOCK), 0, sw, a); \
+        else if (pair_blocks != 0) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4, 0, true>), dim3(grid + pair_blocks), dim3(NRX_BLOCK), 0, sw, a); \
+        else if (placed && has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, true, false, false, 4, 1>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); \
         else if (placed && !has_bag && !unal && !has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, RB, false, false, false, 4, 1>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); \
         else if (!placed && has_fm && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, true, false, false, 1, 1>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); \
         else if (!placed && !has_fm && !unal && !has_bag && reg) hipLaunchKernelGGL((embed_bwd_sorted_fast_kernel<QL_, R, false, false, false, 1, 1>), dim3(grid), dim3(NRX_BLOCK), 0, sw, a); \
@@ -3445,7 +3462,6 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
         else if (unal) { if (few) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, true, 2>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a); else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, true, 0>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a); } \
         else if (has_bag) { if (few) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, false, 2>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a); else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, true, false, 0>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a); } \
         else { if (few) hipLaunchKernelGGL((sorted_long_kernel<QL_, false, false, false, 2>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a); else hipLaunchKernelGGL((sorted_long_kernel<QL_, false, false, false, 0>), dim3(2048), dim3(NRX_BLOCK), 0, sw, a); } \
-        hipLaunchKernelGGL((sorted_combine_kernel<QL_>), dim3(256), dim3(NRX_BLOCK), 0, sw, a);                              \
     }
             if (ql == 2) NRX_SL(2) else if (ql == 3) NRX_SL(3) else NRX_SL(4)
 #undef NRX_SL

@@ -34,7 +34,7 @@ constexpr int PL_CACHE = 9728;                      // lookups of its range a bl
 constexpr int PL_PAIRS = 2048;                      // pair rows a block matches through LDS slots (beyond: through the sorted list)
 constexpr int PL_SORT = 4096;                       // 3+ lookups a block sorts in LDS (beyond: in place in global memory)
 constexpr int PL_MAX_BLOCKS = 4096;
-constexpr size_t PL_LDS = (size_t)4 * PL_WORDS * 4 + (size_t)PL_WORDS * 2 + (size_t)PL_PAIRS * 4 + (size_t)PL_CACHE * 8;
+constexpr size_t PL_LDS = (size_t)4 * PL_WORDS * 4 + (size_t)PL_WORDS * 2 + (size_t)PL_PAIRS * 4 + (size_t)(PL_CACHE + 64) * 8;      // (+ the spare entries)
 constexpr int PL_AGG = 4;                            // totals a block publishes
 constexpr size_t PL_STATE_BYTES = 256 + (size_t)PL_MAX_BLOCKS * PL_AGG * 8;
 
@@ -46,6 +46,7 @@ struct PlanLdsArgs {
     int32_t feat_of[NRX_MAX_FEATURES];
     int32_t blk_first[NRX_MAX_FEATURES + 1];    // table t's work items (row ranges)
     int32_t n_tables, n_blocks;
+    int32_t xcd_order, pad_;
     int64_t batch, n_total;
     uint32_t* ctl;                              // [0] ticket  [1] blocks done  [2] epoch  (zero before the first call; the kernel re-arms it)
     unsigned long long* agg;                    // [n_blocks][4]: (epoch + 1) << 32 | {unique rows, walk rows, their lookups, pair rows} of the block
@@ -54,6 +55,13 @@ struct PlanLdsArgs {
     unsigned long long* list3;
 };
 static_assert(sizeof(PlanLdsArgs) <= 3584, "kernarg budget");
+
+#ifdef NRX_PL_TIMING            // dev builds (tools/plan_lds_phases.py): wall-clock stamps of every block at the phase boundaries
+__device__ unsigned long long pl_stamps[PL_MAX_BLOCKS * 8];
+#define PL_T(k) do { if (threadIdx.x == 0) pl_stamps[8 * w + (k)] = wall_clock64(); } while (0)
+#else
+#define PL_T(k) do { } while (0)
+#endif
 
 template <bool IDX64>
 __device__ __forceinline__ uint64_t pl_id(const void* p, int64_t i) {
@@ -101,7 +109,16 @@ __global__ __launch_bounds__(PL_THREADS) void plan_lds_kernel(const PlanLdsArgs 
     __shared__ uint32_t s_wsum[PL_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) {
-        s_ticket = atomicAdd(&a->ctl[0], 1u);
+        // Which row range this block takes.  XCD order (launches of at most one block per compute unit: every block is resident, the chain below
+        // cannot wait for a block that has not started): block b runs on XCD b % 8, and XCD x takes the x-th eighth of the table-major list -- the
+        // ranges of a table sit on ONE XCD and its ids are fetched into ONE L2 (in ticket order the eight ranges of a table ran on eight XCDs: 8 x
+        // 13.6 MB of fabric reads for C2's ids, the scan ran at the fabric's rate).  Larger launches: ticket order (always safe).
+        if (a->xcd_order) {
+            const unsigned b = blockIdx.x, x = b & 7u, i = b >> 3, qt = (unsigned)a->n_blocks >> 3, rt = (unsigned)a->n_blocks & 7u;
+            s_ticket = x * qt + (x < rt ? x : rt) + i;
+        } else {
+            s_ticket = atomicAdd(&a->ctl[0], 1u);
+        }
         s_epoch = __hip_atomic_load(&a->ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         s_ncache = 0;
         s_nlist = 0;
@@ -114,9 +131,9 @@ __global__ __launch_bounds__(PL_THREADS) void plan_lds_kernel(const PlanLdsArgs 
     for (int i = 1; i < a->n_tables; ++i) t += w >= a->blk_first[i] ? 1 : 0;
     const uint32_t rb = (uint32_t)(w - a->blk_first[t]);
     const uint64_t rows = (uint64_t)a->rows[t];
+    PL_T(0);
     constexpr uint32_t RMASK = (1u << PL_RLOG) - 1;
-    // ---- scan the table's lookups: mark the rows of this range, keep their lookups.  A round = K ids per thread taken together: range
-    // tests, all the bitmap atomics in flight at once, ONE wave scan for the cache places; the next round's ids are requested before this
+    // ---- scan the table's lookups: keep those of this range.  A round = K ids per thread taken together: range tests, K unconditional LDS writes; the next round's ids are requested before this
     // round is looked at (a block is 16 wavefronts on a compute unit of its own: nothing else hides the latency).
     constexpr int PER = VEC ? (IDX64 ? 2 : 4) : 1;     // ids per load
     constexpr int U = VEC ? (IDX64 ? 4 : 2) : 8;       // loads per thread and round
@@ -128,18 +145,18 @@ __global__ __launch_bounds__(PL_THREADS) void plan_lds_kernel(const PlanLdsArgs 
         const void* idp = a->ids[f];
         const int64_t po = a->off[f];
         const int64_t nv = a->batch / PER;                // whole loads
-        uint64_t cur[K], nxt[K];
+        uint64_t bufa[K], bufb[K];
         auto fetch = [&](int64_t v0, uint64_t* dst) {
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 const int64_t v = v0 + (int64_t)j * PL_THREADS + tid;
                 if (VEC && IDX64) {
                     pl_ll2 x = {-1, -1};
-                    if (v < nv) x = __builtin_nontemporal_load(nrx_gconst<pl_ll2>(idp) + v);
+                    if (v < nv) x = nrx_gconst<pl_ll2>(idp)[v];          // (plain loads: the other ranges of the table read the same lines from L2)
                     dst[2 * j] = (uint64_t)x.x; dst[2 * j + 1] = (uint64_t)x.y;
                 } else if (VEC) {
                     pl_i4 x = {-1, -1, -1, -1};
-                    if (v < nv) x = __builtin_nontemporal_load(nrx_gconst<pl_i4>(idp) + v);
+                    if (v < nv) x = nrx_gconst<pl_i4>(idp)[v];
                     dst[4 * j] = (uint64_t)(int64_t)x.x; dst[4 * j + 1] = (uint64_t)(int64_t)x.y;
                     dst[4 * j + 2] = (uint64_t)(int64_t)x.z; dst[4 * j + 3] = (uint64_t)(int64_t)x.w;
                 } else {
@@ -147,12 +164,13 @@ __global__ __launch_bounds__(PL_THREADS) void plan_lds_kernel(const PlanLdsArgs 
                 }
             }
         };
-        fetch(0, cur);
-        for (int64_t v0 = 0; v0 < nv; v0 += (int64_t)U * PL_THREADS) {
-            fetch(v0 + (int64_t)U * PL_THREADS, nxt);
-            uint32_t lr[K], old[K];
+        auto process = [&](const uint64_t* cur, int64_t v0) {
+            // cache places without a cross-lane scan: per id one ballot (a scalar), the lane's rank among the set lanes (mbcnt), the running
+            // total in a scalar register; ONE LDS atomic per wavefront and round reserves the places (six dependent cross-lane steps per round
+            // were ~700 cycles of latency with four wavefronts per SIMD to hide them)
+            uint32_t lr[K], rank[K];
             bool in[K];
-            uint32_t cnt = 0;
+            uint32_t tot = 0;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int64_t v = v0 + (int64_t)(k / PER) * PL_THREADS + tid;
@@ -160,62 +178,63 @@ __global__ __launch_bounds__(PL_THREADS) void plan_lds_kernel(const PlanLdsArgs 
                 ur = ur >= rows ? 0ull : ur;                   // (negative ids are huge here): out-of-range ids fall on the padding row
                 in[k] = v < nv && (uint32_t)(ur >> PL_RLOG) == rb;
                 lr[k] = (uint32_t)ur & RMASK;
-                cnt += in[k] ? 1u : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                old[k] = 0;
-                if (in[k]) old[k] = atomicOr(&s_t[lr[k] >> 5], 1u << (lr[k] & 31));
-            }
-            uint32_t incl = cnt;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += o;
+                const unsigned long long bal = __ballot(in[k]);
+                rank[k] = tot + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                tot += (uint32_t)__popcll(bal);
             }
             uint32_t base = 0;
-            if (lane == 63 && incl != 0) base = atomicAdd(&s_ncache, incl);
-            base = __shfl(base, 63, 64);
-            uint32_t pos = base + incl - cnt;
+            if (lane == 0 && tot != 0) base = atomicAdd(&s_ncache, tot);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            // no branch per id: a lookup of another range (7 of 8) writes its lane's spare entry behind the cache
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                if (in[k]) {
-                    const int64_t v = v0 + (int64_t)(k / PER) * PL_THREADS + tid;
-                    if (pos < PL_CACHE) s_cache[pos] = ((unsigned long long)lr[k] << 32) | (unsigned long long)(uint32_t)(po + v * PER + (k % PER));
-                    ++pos;
-                    const uint32_t bit = 1u << (lr[k] & 31);
-                    if (old[k] & bit) {
-                        const uint32_t o2 = atomicOr(&s_m[lr[k] >> 5], bit);
-                        if (o2 & bit) atomicOr(&s_h[lr[k] >> 5], bit);
-                    }
-                }
+                const int64_t v = v0 + (int64_t)(k / PER) * PL_THREADS + tid;
+                const uint32_t pos = base + rank[k];
+                const uint32_t at = in[k] && pos < PL_CACHE ? pos : (uint32_t)PL_CACHE + lane;      // (a spare entry per lane: 64 lanes on one address are 64 conflicts)
+                s_cache[at] = ((unsigned long long)lr[k] << 32) | (unsigned long long)(uint32_t)(po + v * PER + (k % PER));
             }
-#pragma unroll
-            for (int k = 0; k < K; ++k) cur[k] = nxt[k];
+        };
+        // two buffers, the loop body written twice: a round's ids are requested a full round ahead, and nothing is moved between registers
+        const int64_t step = (int64_t)U * PL_THREADS;
+        fetch(0, bufa);
+        for (int64_t v0 = 0; v0 < nv; v0 += 2 * step) {
+            fetch(v0 + step, bufb);
+            process(bufa, v0);
+            if (v0 + step >= nv) break;
+            fetch(v0 + 2 * step, bufa);
+            process(bufb, v0 + step);
         }
         for (int64_t b = nv * PER + tid; b < a->batch; b += PL_THREADS) {           // the last ids past the whole loads
             uint64_t ur = pl_id<IDX64>(idp, b);
             ur = ur >= rows ? 0ull : ur;
             if ((uint32_t)(ur >> PL_RLOG) == rb) {
-                const uint32_t l = (uint32_t)ur & RMASK, bit = 1u << (l & 31);
-                const uint32_t o = atomicOr(&s_t[l >> 5], bit);
-                if (o & bit) {
-                    const uint32_t o2 = atomicOr(&s_m[l >> 5], bit);
-                    if (o2 & bit) atomicOr(&s_h[l >> 5], bit);
-                }
+                const uint32_t l = (uint32_t)ur & RMASK;
                 const uint32_t pos = atomicAdd(&s_ncache, 1u);
                 if (pos < PL_CACHE) s_cache[pos] = ((unsigned long long)l << 32) | (unsigned long long)(uint32_t)(po + b);
             }
         }
     }
     __syncthreads();
+    PL_T(1);
     const uint32_t ncache = s_ncache;
     const bool cached = ncache <= PL_CACHE;
+    // ---- mark: every lookup of the range ORs its row's bit into `looked up`; one that finds it set ORs `twice`; one that finds that set ORs `3+`
+    // (from the cache: dense wavefronts -- inside the scan the same atomics ran with one lane in eight active, eight times per round)
+    pl_for_each<IDX64>(a, t, rb, cached, ncache, s_cache, [&](uint32_t lr, uint32_t) {
+        const uint32_t bit = 1u << (lr & 31);
+        const uint32_t o = atomicOr(&s_t[lr >> 5], bit);
+        if (o & bit) {
+            const uint32_t o2 = atomicOr(&s_m[lr >> 5], bit);
+            if (o2 & bit) atomicOr(&s_h[lr >> 5], bit);
+        }
+    });
+    __syncthreads();
     if (tid == 0 && rb == 0 && (s_t[0] & 1u)) {              // the padding row never trains and is never placed: it goes to the list
         s_m[0] |= 1u;
         s_h[0] |= 1u;
     }
     __syncthreads();
+    PL_T(2);
     // ---- ranks inside the block, the block's totals: unique rows, walk rows (looked up 3+ times, padding), their lookups, pair rows (twice)
     uint32_t tw[4], pw[4], ct = 0, c3 = 0, c2 = 0;
 #pragma unroll
@@ -274,6 +293,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_lds_kernel(const PlanLdsArgs 
         }
     }
     for (int i = tid; i < PL_PAIRS; i += PL_THREADS) s_slot[i] = 0xffffffffu;
+    PL_T(3);
     if (tid < PL_AGG) {
         const uint32_t v = tid == 0 ? T_u : (tid == 1 ? T_3r : (tid == 2 ? T_3l : T_2));
         __hip_atomic_store(&a->agg[PL_AGG * w + tid], ((unsigned long long)mark << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -299,6 +319,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_lds_kernel(const PlanLdsArgs 
     for (int i = 0; i < PL_THREADS / 64; ++i) {
         base_u += (uint32_t)s_red[0][i]; base_w3 += (uint32_t)s_red[1][i]; base_o3 += (uint32_t)s_red[2][i]; base_p += (uint32_t)s_red[3][i];
     }
+    PL_T(4);
     // ---- per lookup of the range: its place.  A lookup of a row looked up once is placed (dest = unique index); the others go to the block's
     // list as (unique index << 33 | walk row ? 1 : 0) << 32 | lookup) -- sorted below, the two lookups of a pair row end up side by side
     const uint32_t m = T_3l + (pair_slots ? 0u : 2 * T_2);      // the block's list
@@ -341,6 +362,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_lds_kernel(const PlanLdsArgs 
         }
     }
     __syncthreads();
+    PL_T(5);
     // ---- the block's list in (row, lookup) order -> pair records; order / seg_start / walk for the walk rows
     if (m != 0) {
         unsigned long long* s_keys = s_cache;
@@ -429,6 +451,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_lds_kernel(const PlanLdsArgs 
             __syncthreads();
         }
     }
+    PL_T(6);
     // ---- the unique keys of the range in row order (= unique-index order), staged through LDS and written as whole lines
     {
         __syncthreads();
@@ -453,6 +476,7 @@ __global__ __launch_bounds__(PL_THREADS) void plan_lds_kernel(const PlanLdsArgs 
             __syncthreads();
         }
     }
+    PL_T(7);
     // ---- the last block out re-arms the state
     if (tid == 0) {
         const uint32_t d = atomicAdd(&a->ctl[1], 1u);
@@ -566,6 +590,16 @@ extern "C" int nrx_sparse_plan_lds(const void* const* ids, const int64_t* lens, 
     a.blk_first[n_tables] = nb;
     a.n_tables = n_tables;
     a.n_blocks = nb;
+    {
+        static int cus = 0;
+        if (cus == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+            else cus = 1;
+        }
+        const char* e = getenv("NRX_PLAN_LDS_XCD");
+        a.xcd_order = nb <= cus && !(e && e[0] == '0');
+    }
     a.batch = lens[0];
     a.n_total = off;
     a.ctl = reinterpret_cast<uint32_t*>(state);
@@ -592,3 +626,9 @@ extern "C" int nrx_sparse_plan_lds(const void* const* ids, const int64_t* lens, 
     NRX_LAUNCH_CHECK("nrx_sparse_plan_lds");
     return NRX_OK;
 }
+
+#ifdef NRX_PL_TIMING
+extern "C" __attribute__((visibility("default"))) int nrx_plan_lds_stamps(unsigned long long* out, int n_blocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pl_stamps), (size_t)n_blocks * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
