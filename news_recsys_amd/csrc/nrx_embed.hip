@@ -1281,12 +1281,17 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceA
 #define NRX_LINES_U 2                   // feature PAIRS in flight per lane (build-time knob for tools/build_variant.sh): C2 launch on one box, rotated
                                         // builds: 8 -> 71.1 us, 4 -> 60.6 / 65.2 (two boxes), 3 -> 64.0, 2 -> 59.6 / 63.0, 1 -> 62.6
 #endif
+constexpr int PLACE_LINES_TBP = 40;
 template <int U, bool FM, bool DENSE>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_lines_kernel(const PlaceArgs args_in_kernarg) {
     const NRX_CONST PlaceArgs* a = nrx_kernarg<PlaceArgs>();
     constexpr int Q = 4;
     constexpr int TB = NRX_BLOCK / (2 * Q);           // samples per block
-    extern __shared__ __attribute__((aligned(16))) int32_t s_dest[];      // [n][TB]
+    // a feature's TB dest words sit TBP apart: with stride TB = 32 the words of features 2j and 2j + 1 of a sample share a bank, and a wavefront
+    // (8 samples x the two features of a pair) read them as a two-way conflict: 44 % of the kernel's LDS cycles (profiles/r04_fwd_bwd_c2_rocprof_summary.txt).
+    // 40 = 8 mod 32: the second feature's eight words land eight banks on.
+    constexpr int TBP = PLACE_LINES_TBP;
+    extern __shared__ __attribute__((aligned(16))) int32_t s_dest[];      // [n][TBP]
     const int tid = threadIdx.x;
     const int n = a->n;
     const int64_t b0 = (int64_t)blockIdx.x * TB;
@@ -1294,7 +1299,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_lines_kernel(const 
     if (blockIdx.x == 0 && tid < 4 && a->long_ws != nullptr) a->long_ws[tid] = 0;
     for (int i = tid; i < n * TB; i += NRX_BLOCK) {   // TB consecutive dest words per feature
         const int f = i / TB, s = i - f * TB;
-        s_dest[i] = s < nb ? nrx_gconst<int32_t>(a->dest)[a->off[f] + b0 + s] : -1;
+        s_dest[f * TBP + s] = s < nb ? nrx_gconst<int32_t>(a->dest)[a->off[f] + b0 + s] : -1;
     }
     __syncthreads();
     const int q = tid & (Q - 1);
@@ -1312,7 +1317,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_lines_kernel(const 
     const int32_t* s_my = s_dest + sb;
     auto dest_of = [&](int j) -> int32_t {
         const int f = 2 * j + par;
-        return f < n ? s_my[f * TB] : -1;
+        return f < n ? s_my[f * TBP] : -1;
     };
     auto fetch = [&](int j, int32_t& d, float4& g, float4& v) {           // j wave-uniform: the two features' columns come from scalar loads
         if (d >= 0) {
@@ -3321,7 +3326,7 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             { const char* e = getenv("NRX_PLACE_LINES"); if (e && atoi(e) == 0) lines = false; }
             if (lines) {
                 const unsigned lgrid = (unsigned)((batch + 31) / 32);
-                const size_t llds = (size_t)n_place * 32 * 4;
+                const size_t llds = (size_t)n_place * PLACE_LINES_TBP * 4;
                 if (dense && has_fm) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<NRX_LINES_U, true, true>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
                 else if (dense) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<NRX_LINES_U, false, true>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
                 else if (has_fm) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<NRX_LINES_U, true, false>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);

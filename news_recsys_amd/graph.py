@@ -52,9 +52,13 @@ class GraphedStep:
             ops.flush_index_checks()               # (the example batch must be clean)
             del ops._host_status_names[:]
             self.graph = torch.cuda.CUDAGraph()
+            atomic_before = ops.dense_bwd_paths["atomic"]
             with torch.cuda.graph(self.graph):
                 self._result = step_fn(self._static)
             self._names = list(ops._host_status_names)      # the feature-name lists of the captured gather launches
+            if deterministic and ops.dense_bwd_paths["atomic"] != atomic_before:
+                raise RuntimeError("GraphedStep(deterministic=True): a backward launch of the captured step took the float-atomic scatter (more than "
+                                   "64 tables, or a feature on a routed-row buffer): its replays would not be bit-reproducible")
         finally:
             ops.set_index_check(prev)
             ops.DENSE_BWD_SORTED = prev_sorted

@@ -38,6 +38,11 @@ _host_status: Optional[torch.Tensor] = None       # pinned int32[4] the GPU writ
 _host_status_names: List[Sequence[str]] = []       # feature-name lists of the launches since the status word was last clear
 
 
+def _collections_counter():
+    import collections
+    return collections.Counter()
+
+
 def set_index_check(mode: str) -> None:
     global _INDEX_CHECK
     if mode not in ("sync", "deferred", "lazy", "off"):
@@ -400,6 +405,28 @@ def _dense_sorted_ok(plan, tables, sparse_grad, B, csr_ok=False) -> bool:
     return lookups > 0 and (DENSE_BWD_SORTED in (True, "det") or B * lookups >= DENSE_SORTED_MIN)
 
 
+# which form produced the dense table gradients, counted per backward launch: "small" (one-launch deterministic kernel), "sorted" (planned
+# reduction), "atomic" (float atomics).  GraphedStep(deterministic=True) checks that its capture took no "atomic" launch.
+dense_bwd_paths = _collections_counter()
+_atomic_warned = set()
+
+
+def _warn_atomic_fallback(plan, n_tables: int, B: int) -> None:
+    why = []
+    if n_tables > NRX_MAX_FEATURES:
+        why.append(f"{n_tables} tables (the planned reduction names a table in a {NRX_MAX_FEATURES}-entry argument array)")
+    if any(s_.flags & NRX_FEAT_ROW0_IS_DATA for s_ in plan.slots):
+        why.append("a feature reads a routed-row buffer whose row 0 is data (the planner's row 0 never trains)")
+    if not why:
+        why.append("the launch is outside both deterministic forms")
+    key = "; ".join(why)
+    if key not in _atomic_warned:
+        _atomic_warned.add(key)
+        import warnings
+        warnings.warn("NRX_DENSE_BWD / GraphedStep(deterministic=True): this backward launch (batch %d) falls back to float atomics -- its gradients are "
+                      "NOT bit-reproducible: %s" % (B, key), UserWarning, stacklevel=3)
+
+
 def _small_shapes(plan, B) -> bool:
     """Every table of the launch fed by <= 4096 lookups (the one-block-per-table kernels' limit; the library has the last word)."""
     if B > 4096 or B <= 0:
@@ -614,8 +641,11 @@ class _EmbedFn(torch.autograd.Function):
         if getattr(ctx, "dense_sorted", False) and B > 0 and n_tables <= NRX_MAX_FEATURES:
             # "deterministic" (GraphedStep(deterministic=True)): the small kernel where it applies (a single launch of <= 64 features), else
             # the planned reduction -- both bit-reproducible run to run; "sorted" always takes the planned reduction
-            if not (DENSE_BWD_SORTED == "det" and has_up and n <= NRX_MAX_FEATURES and
+            if (DENSE_BWD_SORTED == "det" and has_up and n <= NRX_MAX_FEATURES and
                     small(0, n, _fill_features(plan, 0, n, grads, ctx.ins, ctx.ws, table_ptrs=[g.data_ptr() for g in grads], cache_key="bwd"))):
+                dense_bwd_paths["small"] += 1
+            else:
+                dense_bwd_paths["sorted"] += 1
                 _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg, dense_into=grads)
         elif B > 0 and has_up:
             gptrs = [g.data_ptr() for g in grads]
@@ -623,7 +653,14 @@ class _EmbedFn(torch.autograd.Function):
                 hi = min(n, lo + NRX_MAX_FEATURES)
                 arr = _fill_features(plan, lo, hi, grads, ctx.ins, ctx.ws, table_ptrs=gptrs, cache_key="bwd")
                 if DENSE_BWD_SORTED is not False and small(lo, hi, arr):
+                    dense_bwd_paths["small"] += 1
                     continue
+                if DENSE_BWD_SORTED in (True, "det"):
+                    # a deterministic mode was asked for and neither deterministic form serves this launch (more than 64 tables, a routed-row
+                    # buffer whose row 0 is data, CSR bags / dims outside the small kernel): say so -- once per reason -- instead of silently
+                    # handing out gradients that differ in the last place from run to run
+                    _warn_atomic_fallback(plan, len(_table_meta(ctx)), B)
+                dense_bwd_paths["atomic"] += 1
                 check(lib.nrx_embed_bwd(arr, hi - lo, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, fmg, stream),
                       "nrx_embed_bwd")
         return (None, None, None, None, None, None, None, *grads)

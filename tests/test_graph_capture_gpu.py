@@ -226,3 +226,47 @@ def test_deterministic_graphed_step_has_bit_reproducible_table_gradients():
             torch.testing.assert_close(g0, t.grad, rtol=1e-4, atol=1e-5)
     finally:
         ops.DENSE_BWD_SORTED = prev
+
+
+def test_deterministic_mode_says_so_when_it_cannot_be_deterministic(monkeypatch):
+    """A deterministic mode that falls back to float atomics must not do so silently (round-4 advice): with more than 64 tables neither the
+    planned reduction nor -- beyond 4096 lookups per table -- the one-launch kernel serves the launch: the eager backward warns, and
+    GraphedStep(deterministic=True) refuses the capture."""
+    import warnings
+    from news_recsys_amd import ops
+    from news_recsys_amd._lib import NRX_SPARSE
+    from news_recsys_amd.graph import GraphedStep
+    n, D, rows, B = 66, 16, 600, 4100
+    slots = [ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, i * D) for i in range(n)]
+    plan = ops.EmbedPlan(slots, out_width=n * D)
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    tables = [torch.randn((rows, D), device=DEV, generator=gen).requires_grad_() for _ in range(n)]
+    ids = [torch.randint(0, rows, (B,), device=DEV, generator=gen) for _ in range(n)]
+
+    def step(_b=None):
+        for t in tables:
+            t.grad = None
+        out = ops.embed_apply(plan, tables, ids, [None] * n)[0]
+        out.sum().backward()
+        return out
+
+    monkeypatch.setattr(ops, "DENSE_BWD_SORTED", "det")
+    ops._atomic_warned.clear()
+    before = ops.dense_bwd_paths["atomic"]
+    with pytest.warns(UserWarning, match="float atomics"):
+        step()
+    assert ops.dense_bwd_paths["atomic"] > before
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(RuntimeError, match="float-atomic"):
+            GraphedStep(step, {"x": ids[0]}, warmup=1, deterministic=True)
+    # ... and the supported shape (<= 64 tables) still takes a deterministic form, silently
+    monkeypatch.setattr(ops, "DENSE_BWD_SORTED", "det")
+    plan2 = ops.EmbedPlan(slots[:8], out_width=8 * D)
+    before = dict(ops.dense_bwd_paths)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for t in tables[:8]:
+            t.grad = None
+        ops.embed_apply(plan2, tables[:8], ids[:8], [None] * 8)[0].sum().backward()
+    assert ops.dense_bwd_paths["atomic"] == before.get("atomic", 0) and ops.dense_bwd_paths["sorted"] + ops.dense_bwd_paths["small"] > before.get("sorted", 0) + before.get("small", 0)

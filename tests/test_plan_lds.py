@@ -153,7 +153,9 @@ def _grads(plan, tables, inputs, g_out, g_fm, lds, sparse, monkeypatch):
     monkeypatch.setattr(ops, "PLAN_LDS", "1" if lds else "0")
     plan.__dict__.pop("_sg", None)                         # (the launch groups cache their planner policy)
     ts = [t.clone().requires_grad_() for t in tables]
-    out, _, fm = ops.embed_apply(plan, ts, inputs, [None] * len(inputs), sparse_grad=sparse)
+    # the row stride padded to whole 128-byte lines (what the model classes do): an odd number of 64-byte features then still goes through the
+    # full-line placement pass, whose last pair has one feature
+    out, _, fm = ops.embed_apply(plan, ts, inputs, [None] * len(inputs), out_ld=g_out.shape[1], sparse_grad=sparse)
     loss = (out * g_out).sum()
     if fm is not None:
         loss = loss + (fm * g_fm).sum()
@@ -170,6 +172,9 @@ BWD_CASES = [
     ("plain64_hot", 64, 3, 500000, 6000, False, "hot"),
     ("plain16_tiny", 16, 4, 150000, 31, False, "uniform"),
     ("fm_one", 16, 2, 140000, 1, True, "uniform"),
+    ("plain16_1300", 16, 8, 200000, 1300, False, "uniform"),      # D = 16, no FM: the full-line placement pass <U, false, *>, even feature count
+    ("plain16_4097_odd", 16, 5, 150000, 4097, False, "dup"),      # ... odd feature count (the last pair's upper half idles), many pairs and 3+ rows
+    ("fm16_1300_odd", 16, 7, 160000, 1300, True, "uniform"),      # ... <U, true, *>
 ]
 
 
@@ -188,7 +193,9 @@ def test_pairs_backward_equals_sorted_backward_and_float64(name, D, n, rows, B, 
         x[2:4] = 7                                          # (the forward rejects out-of-range ids)
         x[:1] = 0
     inputs = [torch.from_numpy(x).to(DEV) for x in ids_np]
-    g_out = torch.from_numpy(rng.standard_normal((B, n * D)).astype(np.float32)).to(DEV)
+    ld = (n * D + 31) // 32 * 32
+    g_out = torch.zeros((B, ld), dtype=torch.float32, device=DEV)
+    g_out[:, :n * D] = torch.from_numpy(rng.standard_normal((B, n * D)).astype(np.float32)).to(DEV)
     g_fm = torch.from_numpy(rng.standard_normal((B,)).astype(np.float32)).to(DEV)
     sparse = dest == "row_sparse"
     a = _grads(plan, tables, inputs, g_out, g_fm, True, sparse, monkeypatch)
@@ -201,7 +208,7 @@ def test_pairs_backward_equals_sorted_backward_and_float64(name, D, n, rows, B, 
             assert torch.equal(x.view(torch.int32), y.view(torch.int32))
     # float64 restatement: d loss / d table = index_add of the upstream rows (+ the FM term g_fm * (S - v) per factor column, g_fm for column 0)
     go = g_out.cpu().numpy().astype(np.float64)
-    up = [go[:, i * D:(i + 1) * D].copy() for i in range(n)]
+    up = [go[:, i * D:(i + 1) * D].copy() for i in range(n)]          # (the padding columns carry no feature)
     if fm:
         gf = g_fm.cpu().numpy().astype(np.float64)[:, None]
         rows_v = [tables_np[i].astype(np.float64)[ids_np[i]] for i in range(n)]
@@ -212,8 +219,10 @@ def test_pairs_backward_equals_sorted_backward_and_float64(name, D, n, rows, B, 
             up[i] += t
     for i in range(n):
         want = R.embedding_grad_dense(ids_np[i], up[i], rows)
-        got = (a[i].to_dense() if sparse else a[i]).cpu().numpy()
-        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(want).max()))
+        assert not want[0].any()                            # the padding row is looked up (ids 0) and gets no gradient
+        for res in (a, b):                                  # the one-kernel plan + pair records, and the sorted plan: each against float64 directly
+            got = (res[i].to_dense() if sparse else res[i]).cpu().numpy()
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(want).max()))
 
 
 def test_policy_follows_the_previous_batch(monkeypatch):
