@@ -1190,7 +1190,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceA
                 d = a->idx64 ? (int32_t)nrx_gconst<int64_t>(ip)[b] : nrx_gconst<int32_t>(ip)[b];
             }
             if (!UNAL && nt) {
-                g = nrx_ldg4_nt(a->g_out, (b * a->out_ld + a->out_col[f]) / 4 + q);
+                g = a->g_out != nullptr ? nrx_ldg4_nt(a->g_out, (b * a->out_ld + a->out_col[f]) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (FM) v = nrx_ldg4_nt(a->feat, (b * a->feat_ld + a->out_col[f]) / 4 + q);
                 return;
             }
@@ -1282,7 +1282,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceA
                                         // builds: 8 -> 71.1 us, 4 -> 60.6 / 65.2 (two boxes), 3 -> 64.0, 2 -> 59.6 / 63.0, 1 -> 62.6
 #endif
 constexpr int PLACE_LINES_TBP = 40;
-template <int U, bool FM, bool DENSE>
+// HASG = false: no upstream gradient of the concat (an FM model whose loss reads the logit only, fm/model.py:44-59: the rows' gradient is the FM term
+// alone) -- the pass then reads the forward concat and the field sums, not 109 MB of zeros.
+template <int U, bool FM, bool DENSE, bool HASG = true>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_lines_kernel(const PlaceArgs args_in_kernarg) {
     const NRX_CONST PlaceArgs* a = nrx_kernarg<PlaceArgs>();
     constexpr int Q = 4;
@@ -1327,7 +1329,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_lines_kernel(const 
                 const void* ip = par ? a->ids[f1] : a->ids[f0];
                 d = a->idx64 ? (int32_t)nrx_gconst<int64_t>(ip)[b] : nrx_gconst<int32_t>(ip)[b];
             }
-            g = nrx_ldg4_nt(a->g_out, (b * a->out_ld + col) / 4 + q);
+            g = HASG ? nrx_ldg4_nt(a->g_out, (b * a->out_ld + col) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (FM) v = nrx_ldg4_nt(a->feat, (b * a->feat_ld + col) / 4 + q);
         }
     };
@@ -1515,7 +1517,7 @@ __device__ __forceinline__ void pairs_body(const NRX_CONST SortedBwdArgs* a, con
             const int fi = (int)__umul64hi((uint64_t)p, reg_magic);
             const int64_t b = p - (int64_t)fi * reg_len;
             const int col = reg_col0 + fi * reg_stride;
-            g = nrx_ldg4(a->g_out, (b * a->out_ld + col) / 4 + q);
+            g = a->g_out != nullptr ? nrx_ldg4(a->g_out, (b * a->out_ld + col) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (FM) {
                 gf = reg_fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
                 v = nrx_ldg4(a->feat, (b * a->feat_ld + col) / 4 + q);
@@ -1729,7 +1731,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
                     const int64_t b = p[r][j] - (int64_t)fi * reg_len;
                     const int col = reg_col0 + fi * reg_stride;
                     sc[r][j] = 1.0f;
-                    g[r][j] = nrx_ldg4(up_g, (b * up_ld + col) / 4 + q);          // (REG launches have an upstream gradient: host-checked)
+                    g[r][j] = up_g != nullptr ? nrx_ldg4(up_g, (b * up_ld + col) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);      // (no g_out: an FM model whose loss reads the logit only)
                     if (FM) {
                         gf[r][j] = reg_fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
                         v[r][j] = nrx_ldg4(a->feat, (b * a->feat_ld + col) / 4 + q);
@@ -1920,7 +1922,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
                         const int64_t b = p[k] - (int64_t)fi * reg_len;
                         const int col = reg_col0 + fi * reg_stride;
                         sc[k] = 1.0f;
-                        gr[k] = nrx_ldg4(up_g, (b * up_ld + col) / 4 + q);
+                        gr[k] = up_g != nullptr ? nrx_ldg4(up_g, (b * up_ld + col) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);
                         if (FM) {
                             gf[k] = reg_fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
                             v[k] = nrx_ldg4(a->feat, (b * a->feat_ld + col) / 4 + q);
@@ -3223,7 +3225,7 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // fast form: plain single-valued features, D = 4 Q exactly, float4-addressable everywhere
     bool fast = dim == (4 << ql) && ql >= 2 && ql <= 4 && (dense ? grads_al : nrx_aligned16(values)) &&
-                (!has_fm || (g_out != nullptr && nrx_aligned16(fm->feat) && (fm->feat_ld & 3) == 0 && nrx_aligned16(fm->fm_sums) &&
+                (!has_fm || (nrx_aligned16(fm->feat) && (fm->feat_ld & 3) == 0 && nrx_aligned16(fm->fm_sums) &&
                              (fm->sums_ld & 3) == 0 && fm->sums_ld >= dim));
     bool has_bag = false;
     bool unal = !(g_out == nullptr || (nrx_aligned16(g_out) && (out_ld & 3) == 0));      // wide routing / shifted columns / odd strides
@@ -3314,8 +3316,8 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             const int uvar = getenv("NRX_PLACE_U") ? atoi(getenv("NRX_PLACE_U")) : 4;       // fetches in flight per lane (4 | 8)
             // full-line form (embed_bwd_place_lines_kernel): 64-byte rows whose feature pairs (2j, 2j + 1) are one aligned 128-byte line of the
             // upstream rows (and of the forward concat); NRX_PLACE_LINES=0 keeps the one-feature-per-lane-group form
-            bool lines = ql == 2 && !unal && pa.nt != 0 && pa.stnt == 0 && g_out != nullptr && (reinterpret_cast<uintptr_t>(g_out) & 127) == 0 &&
-                         (out_ld & 31) == 0 && n_place <= 64;
+            bool lines = ql == 2 && !unal && pa.nt != 0 && pa.stnt == 0 && (g_out != nullptr || has_fm) && (reinterpret_cast<uintptr_t>(g_out) & 127) == 0 &&
+                         (g_out == nullptr || (out_ld & 31) == 0) && n_place <= 64;
             if (lines && has_fm) lines = (reinterpret_cast<uintptr_t>(pa.feat) & 127) == 0 && (pa.feat_ld & 31) == 0;
             pa.fm_mask = 0;
             for (int i = 0; i < n_place; ++i) {
@@ -3327,7 +3329,9 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             if (lines) {
                 const unsigned lgrid = (unsigned)((batch + 31) / 32);
                 const size_t llds = (size_t)n_place * PLACE_LINES_TBP * 4;
-                if (dense && has_fm) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<NRX_LINES_U, true, true>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
+                if (g_out == nullptr && dense) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<NRX_LINES_U, true, true, false>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
+                else if (g_out == nullptr) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<NRX_LINES_U, true, false, false>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
+                else if (dense && has_fm) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<NRX_LINES_U, true, true>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
                 else if (dense) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<NRX_LINES_U, false, true>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
                 else if (has_fm) hipLaunchKernelGGL((embed_bwd_place_lines_kernel<NRX_LINES_U, true, false>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
                 else hipLaunchKernelGGL((embed_bwd_place_lines_kernel<NRX_LINES_U, false, false>), dim3(lgrid), dim3(NRX_BLOCK), llds, st, pa);
@@ -3436,7 +3440,7 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
                 hipLaunchKernelGGL(stage_rows_kernel, dim3((unsigned)((batch * (dim / 4) + NRX_BLOCK - 1) / NRX_BLOCK), (unsigned)n_sg),
                                    dim3(NRX_BLOCK), 0, st, sg, g_out, out_ld, batch, (int)(dim / 4), gs);
         }
-        const bool reg = a.regular && g_out != nullptr && !unal;        // arithmetic decode (embed_bwd_sorted_fast_kernel<.., DEC = 1>)
+        const bool reg = a.regular && (g_out != nullptr || has_fm) && !unal;        // arithmetic decode (embed_bwd_sorted_fast_kernel<.., DEC = 1>)
         const bool few = n_feats <= 4;                                  // scalar decode (DEC = 2); else the LDS table (DEC = 0)
 #define NRX_SF(QL_)                                                                                                        \
     {                                                                                                                      \

@@ -53,7 +53,9 @@ class GraphedStep:
             del ops._host_status_names[:]
             self.graph = torch.cuda.CUDAGraph()
             atomic_before = ops.dense_bwd_paths["atomic"]
-            with torch.cuda.graph(self.graph):
+            # captured on the stream the warm-up steps ran on: whatever those steps set up per stream (the one-kernel planner's control block,
+            # ops._lds_state) is what the captured launches use
+            with torch.cuda.graph(self.graph, stream=side):
                 self._result = step_fn(self._static)
             self._names = list(ops._host_status_names)      # the feature-name lists of the captured gather launches
             if deterministic and ops.dense_bwd_paths["atomic"] != atomic_before:

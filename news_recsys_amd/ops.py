@@ -572,6 +572,10 @@ class _EmbedFn(torch.autograd.Function):
             ctx.plans = {}
             for g_ in _sparse_group_cache(plan, tables):
                 fs_ = g_["fs"]
+                pol_ = _group_policy(g_, B, len(tables))
+                if pol_ is not None and pol_.choose() and not PLAN_AHEAD_LDS:
+                    continue                 # the one-kernel planner: ONE 43 us launch that holds every compute unit -- next to the forward the two
+                                             # only contend (C2: 242 us per step against 214 planned inline, profiles/r05_plan_lds.txt): planned in the backward
                 ids_ = [ins[i] for i in fs_]
                 dt_ = ids_[0].dtype
                 for x in ids_:
@@ -580,7 +584,7 @@ class _EmbedFn(torch.autograd.Function):
                         break
                 ctx.plans[(g_["dim"], fs_[0])] = (ids_,) + sparse_plan_ahead(ids_, g_["tabs"], g_["rows"], len(tables),
                                                                           g_["pmask"] if SPARSE_PLACE else None, static=g_["static"],
-                                                                          policy=_group_policy(g_, B, len(tables)))
+                                                                          policy=pol_)
         if ctx.has_fm_feat:
             ctx.save_for_backward(out)
         ctx.set_materialize_grads(False)
@@ -694,6 +698,7 @@ DENSE_SORTED_MIN = int(os.environ.get("NRX_DENSE_SORTED_MIN", 1 << 20))
 SPARSE_SMALL_DET = os.environ.get("NRX_SPARSE_SMALL", "1") != "0"     # fused row-sparse mode (sink), small launches: the one-launch form likewise
 DENSE_SMALL_DET = os.environ.get("NRX_DENSE_SMALL", "1") != "0"       # auto mode, small launches: the one-launch deterministic kernel where it applies
 PLAN_AHEAD = True      # row-sparse training: plan the backward (sort, unique rows, segments) at FORWARD time on a side stream
+PLAN_AHEAD_LDS = os.environ.get("NRX_PLAN_AHEAD_LDS", "0") != "0"      # plan ahead (side stream) even when the group takes the one-kernel planner
 PLAN_AHEAD_MIN = int(os.environ.get("NRX_PLAN_AHEAD_MIN", 1 << 18))      # default-mode launches below this many lookups plan inline (one fused call)
 
 

@@ -149,15 +149,15 @@ def test_plan_lds_refuses_launches_outside_its_shapes():
     assert ok([100, 100], [0, 0], [1000, 2000], 1) == 0             # one table, two row counts
 
 
-def _grads(plan, tables, inputs, g_out, g_fm, lds, sparse, monkeypatch):
+def _grads(plan, tables, inputs, g_out, g_fm, lds, sparse, monkeypatch, only_fm=False):
     monkeypatch.setattr(ops, "PLAN_LDS", "1" if lds else "0")
     plan.__dict__.pop("_sg", None)                         # (the launch groups cache their planner policy)
     ts = [t.clone().requires_grad_() for t in tables]
     # the row stride padded to whole 128-byte lines (what the model classes do): an odd number of 64-byte features then still goes through the
     # full-line placement pass, whose last pair has one feature
     out, _, fm = ops.embed_apply(plan, ts, inputs, [None] * len(inputs), out_ld=g_out.shape[1], sparse_grad=sparse)
-    loss = (out * g_out).sum()
-    if fm is not None:
+    loss = (fm * g_fm).sum() if only_fm else (out * g_out).sum()         # only_fm: the concat gets NO gradient (an FM model's loss reads the logit)
+    if fm is not None and not only_fm:
         loss = loss + (fm * g_fm).sum()
     loss.backward()
     torch.cuda.synchronize()
@@ -175,6 +175,8 @@ BWD_CASES = [
     ("plain16_1300", 16, 8, 200000, 1300, False, "uniform"),      # D = 16, no FM: the full-line placement pass <U, false, *>, even feature count
     ("plain16_4097_odd", 16, 5, 150000, 4097, False, "dup"),      # ... odd feature count (the last pair's upper half idles), many pairs and 3+ rows
     ("fm16_1300_odd", 16, 7, 160000, 1300, True, "uniform"),      # ... <U, true, *>
+    ("fm16_logit_only", 16, 26, 250000, 3000, "only", "uniform"), # the FM model class: the loss reads the logit, the concat has no gradient
+    ("fm32_logit_only", 32, 5, 150000, 2049, "only", "dup"),
 ]
 
 
@@ -184,6 +186,8 @@ def test_pairs_backward_equals_sorted_backward_and_float64(name, D, n, rows, B, 
     rng = np.random.default_rng(len(name) * 31 + D)
     monkeypatch.setattr(ops, "DENSE_BWD_SORTED", True)      # dense destination: always the planned reduction
     monkeypatch.setattr(ops, "PLAN_AHEAD_MIN", 0)           # ... planned by sparse_plan (not the one-call form) at every size
+    only_fm = fm == "only"
+    fm = bool(fm)
     slots = [ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, i * D, fm_field=int(fm)) for i in range(n)]
     plan = ops.EmbedPlan(slots, out_width=n * D, use_fm=fm)
     tables_np = [rng.standard_normal((rows, D)).astype(np.float32) for _ in range(n)]
@@ -198,8 +202,8 @@ def test_pairs_backward_equals_sorted_backward_and_float64(name, D, n, rows, B, 
     g_out[:, :n * D] = torch.from_numpy(rng.standard_normal((B, n * D)).astype(np.float32)).to(DEV)
     g_fm = torch.from_numpy(rng.standard_normal((B,)).astype(np.float32)).to(DEV)
     sparse = dest == "row_sparse"
-    a = _grads(plan, tables, inputs, g_out, g_fm, True, sparse, monkeypatch)
-    b = _grads(plan, tables, inputs, g_out, g_fm, False, sparse, monkeypatch)
+    a = _grads(plan, tables, inputs, g_out, g_fm, True, sparse, monkeypatch, only_fm)
+    b = _grads(plan, tables, inputs, g_out, g_fm, False, sparse, monkeypatch, only_fm)
     for x, y in zip(a, b):
         if sparse:
             assert torch.equal(x.indices(), y.indices())
@@ -207,7 +211,7 @@ def test_pairs_backward_equals_sorted_backward_and_float64(name, D, n, rows, B, 
         else:
             assert torch.equal(x.view(torch.int32), y.view(torch.int32))
     # float64 restatement: d loss / d table = index_add of the upstream rows (+ the FM term g_fm * (S - v) per factor column, g_fm for column 0)
-    go = g_out.cpu().numpy().astype(np.float64)
+    go = g_out.cpu().numpy().astype(np.float64) * (0.0 if only_fm else 1.0)
     up = [go[:, i * D:(i + 1) * D].copy() for i in range(n)]          # (the padding columns carry no feature)
     if fm:
         gf = g_fm.cpu().numpy().astype(np.float64)[:, None]

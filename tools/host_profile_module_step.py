@@ -6,7 +6,10 @@ import torch, yaml
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from news_recsys_amd.model.sort.fm.model import FM
 dev = torch.device("cuda:0")
-F, D, rows, B = 26, 16, 100000, 512
+F, D = 26, 16
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 512            # usage: host_profile_module_step.py [fused|true|...] [B] [rows] [hook]
+rows = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
+HOOK = len(sys.argv) > 4 and sys.argv[4] == "hook"         # enter the backward through LightningModule.backward (what a trainer calls)
 names = [f"C{i:02d}" for i in range(F)]
 cfg = {"name": "fm", "paths": {"out_basedir": tempfile.gettempdir(), "user_history_path": ""},
        "features": {"sparse_feature_names": names, "dense_feature_names": [], "array_feature_names": [], "item_feature_names": names[:13],
@@ -21,7 +24,10 @@ m = FM(f.name).to(dev)
 batch = {n: torch.randint(1, rows, (B,), device=dev) for n in names}
 def step():
     p = m(batch)
-    p.sum().backward()
+    if HOOK:
+        m.backward(p.sum())
+    else:
+        p.sum().backward()
     if m._sparse_sink is not None:
         m._sparse_sink.clear()
 for _ in range(50):
