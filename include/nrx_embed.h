@@ -345,6 +345,16 @@ NRX_API int nrx_embed_bwd_dense_sorted(const nrx_feature_t* feats, const int32_t
                                const nrx_fm_grad_t* fm, float* const* grad_tables, int32_t accumulate, int32_t place,
                                void* workspace, int64_t workspace_bytes, void* stream);
 
+/* nrx_embed_bwd_dense_sorted with the planner as an argument.  planner == 1: the one-kernel planner (nrx_sparse_plan_lds; `state` = its control
+ * block, see there) when the launch qualifies -- every feature single-valued, dim 16 / 32 / 64, inside the planner's shapes -- else, and with
+ * planner == 0, the sorted planner.  stats (optional, int64 [4], may be mapped host memory): the plan's duplicate statistics in nrx_sparse_plan_lds's
+ * format, from either planner: what the caller's choice of planner for the NEXT batch needs.  Same gradients from both, bit for bit. */
+NRX_API int64_t nrx_embed_bwd_dense_planned_workspace(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim, int32_t n_tables);
+NRX_API int nrx_embed_bwd_dense_planned(const nrx_feature_t* feats, const int32_t* table_of, int32_t n_feats, int32_t n_tables, int64_t batch,
+                                int32_t dim, const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                                const nrx_fm_grad_t* fm, float* const* grad_tables, int32_t accumulate, int32_t planner,
+                                void* state, int64_t* stats, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Unique-row gradients -> dense gradient tables: for every unique entry u of nrx_sparse_plan / nrx_embed_bwd_sorted
  * (key = (table << 40) | row, gradient rows[u, :dim]), tables[table][row, :dim] = rows[u] (accumulate == 0) or += rows[u]
  * (accumulate != 0: a table fed by more than one reduction).  With zero-filled tables this forms what autograd gives the

@@ -402,7 +402,19 @@ def _dense_sorted_ok(plan, tables, sparse_grad, B, csr_ok=False) -> bool:
         if s.flags & ((0 if csr_ok else NRX_FEAT_BAG_CSR) | NRX_FEAT_ROW0_IS_DATA):      # (the planner's row 0 never trains)
             return False
         lookups += max(1, s.bag_len)
-    return lookups > 0 and (DENSE_BWD_SORTED in (True, "det") or B * lookups >= DENSE_SORTED_MIN)
+    if lookups <= 0:
+        return False
+    if DENSE_BWD_SORTED in (True, "det") or B * lookups >= DENSE_SORTED_MIN:
+        return True
+    # launches the one-kernel planner may take (single-valued features over mid-size tables): the planned reduction is ONE plan launch + placement +
+    # walk there -- within 1.03-1.10x of the atomic step from a few thousand samples on, faster from ~30 k (tools/ab_dense_default.py,
+    # profiles/r05_dense_default.txt) -- and bit-reproducible: the default from DENSE_LDS_MIN lookups on
+    if PLAN_LDS == "0" or not SPARSE_PLACE or B * lookups < max(DENSE_LDS_MIN, 1) or any(s.kind not in (NRX_SPARSE, NRX_DENSE) for s in plan.slots):
+        return False
+    if DENSE_SMALL_DET and _small_shapes(plan, B):
+        return False                     # (every table fed by <= 4096 lookups: the one-launch deterministic kernel's)
+    return all(g["all_sparse"] and _group_policy(g, B, len(tables)) is not None and _group_policy(g, B, len(tables)).eligible
+               for g in _sparse_group_cache(plan, tables))
 
 
 # which form produced the dense table gradients, counted per backward launch: "small" (one-launch deterministic kernel), "sorted" (planned
@@ -698,6 +710,8 @@ DENSE_SORTED_MIN = int(os.environ.get("NRX_DENSE_SORTED_MIN", 1 << 20))
 SPARSE_SMALL_DET = os.environ.get("NRX_SPARSE_SMALL", "1") != "0"     # fused row-sparse mode (sink), small launches: the one-launch form likewise
 DENSE_SMALL_DET = os.environ.get("NRX_DENSE_SMALL", "1") != "0"       # auto mode, small launches: the one-launch deterministic kernel where it applies
 PLAN_AHEAD = True      # row-sparse training: plan the backward (sort, unique rows, segments) at FORWARD time on a side stream
+DENSE_LDS_MIN = int(os.environ.get("NRX_DENSE_LDS_MIN", 1 << 16))       # default-mode launches from this many lookups on go through the one call that
+                                                                         # takes the planner as an argument (nrx_embed_bwd_dense_planned)
 PLAN_AHEAD_LDS = os.environ.get("NRX_PLAN_AHEAD_LDS", "0") != "0"      # plan ahead (side stream) even when the group takes the one-kernel planner
 PLAN_AHEAD_MIN = int(os.environ.get("NRX_PLAN_AHEAD_MIN", 1 << 18))      # default-mode launches below this many lookups plan inline (one fused call)
 
@@ -1042,6 +1056,22 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
             again = any(t in dense_seen for t in tabs)
             arr = _group_features(grp, ids, [ctx.ws[i] for i in fs], fmg is not None, [dense_into[t].data_ptr() for t in tabs])
             np.frombuffer(arr, dtype=_feature_np_dtype())["rows"] = grp["rows"]
+            pol = _group_policy(grp, B, n_tables) if B * n >= DENSE_LDS_MIN else None
+            if pol is not None and pol.eligible:
+                # a launch the one-kernel planner may take: the same one call with the planner as an argument (this batch's choice from the last
+                # batch's statistics, which either planner leaves in the policy's mapped words)
+                wsz = grp.get("planned_ws")
+                if wsz is None or wsz[0] != B:
+                    wsz = grp["planned_ws"] = (B, lib.nrx_embed_bwd_dense_planned_workspace(arr, n, B, D, n_tables))
+                fws = torch.empty(wsz[1], dtype=torch.uint8, device=dev)
+                state = _lds_state(dev, stream) if pol.choose() else None
+                check(lib.nrx_embed_bwd_dense_planned(arr, grp["static"][0], n, n_tables, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, fmg,
+                                                      dense_ptrs, 1 if again else 0, 1 if state is not None else 0,
+                                                      state.data_ptr() if state is not None else None,
+                                                      pol.stats_ptr if PLAN_LDS == "auto" else None, fws.data_ptr(), fws.numel(), stream),
+                      "nrx_embed_bwd_dense_planned")
+                dense_seen.update(tabs)
+                continue
             wsz = grp.get("fused_ws")
             if wsz is None or wsz[0] != B:
                 wsz = grp["fused_ws"] = (B, lib.nrx_embed_bwd_dense_sorted_workspace(arr, n, B, D, n_tables))

@@ -181,11 +181,14 @@ BWD_CASES = [
 
 
 @pytest.mark.parametrize("name,D,n,rows,B,fm,kind", BWD_CASES, ids=[c[0] for c in BWD_CASES])
-@pytest.mark.parametrize("dest", ["row_sparse", "dense"])
+@pytest.mark.parametrize("dest", ["row_sparse", "dense", "dense_one_call"])
 def test_pairs_backward_equals_sorted_backward_and_float64(name, D, n, rows, B, fm, kind, dest, monkeypatch):
     rng = np.random.default_rng(len(name) * 31 + D)
     monkeypatch.setattr(ops, "DENSE_BWD_SORTED", True)      # dense destination: always the planned reduction
-    monkeypatch.setattr(ops, "PLAN_AHEAD_MIN", 0)           # ... planned by sparse_plan (not the one-call form) at every size
+    # "dense": planned by sparse_plan at every size; "dense_one_call": plan + reduction in ONE library call that takes the planner as an argument
+    # (nrx_embed_bwd_dense_planned: what default-mode launches below PLAN_AHEAD_MIN lookups and captured steps use)
+    monkeypatch.setattr(ops, "PLAN_AHEAD_MIN", (1 << 40) if dest == "dense_one_call" else 0)
+    monkeypatch.setattr(ops, "DENSE_LDS_MIN", 0)
     only_fm = fm == "only"
     fm = bool(fm)
     slots = [ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, i * D, fm_field=int(fm)) for i in range(n)]
