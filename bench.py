@@ -919,6 +919,42 @@ def main():
 
     # secondary legs at N = 1, outside the headline timed region
     distinct = fwd_bwd = wide_split = module_path = dcn_v2_cross = None
+    def sharded_train_leg(path):
+        # the sharded engine's TRAINING step (every world size, 1 included): forward exchange + gradient all-to-all back to the owners + owner-side
+        # scatter into the shards' dense gradients, through autograd -- eager, un-bound (no PreparedShardedForward counterpart for the backward)
+        fwd_bwd = None
+        try:
+            if path.train_setup():
+                nst = max(5, min(args.steps, 30))
+                for i in range(3):
+                    path.train_step(i)
+                barrier()
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                ea.record()
+                for i in range(nst):
+                    path.train_step(3 + i)
+                eb.record()
+                barrier()
+                dts = time.perf_counter() - t0
+                if dist is not None:
+                    tt = torch.tensor([dts], dtype=torch.float64, device=device)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dts = tt.item()
+                fwd_bwd = {"ms_per_step": dts * 1e3 / nst, "gpu_ms_per_step_rank0": ea.elapsed_time(eb) / nst, "value": BATCH * world * nst / dts,
+                           "unit": "impressions/s", "steps": nst,
+                           "mode": "sharded engine, autograd form (RowShardedEmbedding.forward + backward): id routing + all-to-alls + owner gather / "
+                                   "owner-side pooling + fused final launch; backward: slot scatter of the upstream rows, gradient all-to-all to the owners, "
+                                   "owner-side scatter-add into the shards' DENSE gradients (zero-filled every step); eager launches from Python "
+                                   "(host time included: wall clock, max over ranks)"}
+            else:
+                fwd_bwd = {"skipped": "the shards' dense gradients (one zero-filled [local rows, dim] tensor per table and step) do not fit next to the tables"}
+        except Exception as e:          # noqa: BLE001 -- a secondary leg must not cost the headline
+            fwd_bwd = {"error": f"{type(e).__name__}: {e}"[:300]}
+        return fwd_bwd
+
+    if world == 1 and hasattr(path, "train_setup") and not args.headline_only:
+        fwd_bwd = sharded_train_leg(path)        # (N > 1: behind the headline line and the watchdog, with the other secondary legs)
     if world == 1 and not args.force_sharded and not args.headline_only:
         def time_calls(fn, n):
             # warm-up by TIME (>= 50 ms of the same launches): the legs that contain latency-bound launches (the backward's
@@ -1038,7 +1074,7 @@ def main():
                 dist.barrier()
                 dist.destroy_process_group()
             raise SystemExit("fixed-capacity exchange overflowed on some rank: rerun with a larger slack (ids too skewed)")
-    planner = strong = a2a = None
+    planner = strong = a2a = sharded_fb = None
     secondary_note = None
     emitted = {"done": False}
     def _build_line():
@@ -1123,6 +1159,8 @@ def main():
             out["strong_scaling"] = strong
         if a2a is not None:
             out["a2a"] = a2a
+        if sharded_fb is not None:
+            out["fwd_bwd"] = sharded_fb
         if note or secondary_note:
             out["secondary_note"] = note or secondary_note
         line = json.dumps(out)
@@ -1165,6 +1203,8 @@ def main():
                        "GBps_per_link": remote / (world - 1) / (ms * 1e-3) / 1e9,
                        "note": "the return all-to-all(s) of the row-sharded exchange alone (equal splits, max over ranks); "
                                "per link = remote bytes / (N-1) point-to-point xGMI links"}
+            if hasattr(path, "train_setup"):
+                sharded_fb = sharded_train_leg(path)
             del path
             torch.cuda.empty_cache()
             bs = BATCH // world

@@ -1097,6 +1097,33 @@ class ShardedBenchPath:
     def overflowed(self) -> bool:
         return any(c.overflowed() for c in self.calls)
 
+    def train_setup(self):
+        """The TRAINING step of the sharded engine (what a sharded model's backward runs; bench.py's sharded fwd_bwd leg): the autograd form of
+        the exchange -- forward as `step`, then the gradient all-to-all back to the owners and the owner-side scatter into the local shards'
+        dense gradients (nrx_scatter_add_inbox; pooled bags: nrx_pool_inbox_bwd).  Returns False when the shards' dense gradients (one
+        [local rows, dim] tensor per table, zero-filled every step -- the reference's nn.Embedding(sparse=False) semantics) do not fit."""
+        shard_bytes = sum(t.numel() * 4 for t in self.tables.values())
+        if shard_bytes > (24 << 30):
+            return False
+        self._train_tables = {n: t.detach().requires_grad_(True) for n, t in self.tables.items()}
+        width = sum(f.dim for f in self.feats)
+        gen = torch.Generator(device=next(iter(self.tables.values())).device).manual_seed(11)
+        self._g_out = torch.randn((self.batch, width), device=next(iter(self.tables.values())).device, generator=gen)
+        self._g_fm = torch.randn((self.batch,), device=self._g_out.device, generator=gen) if self.fm else None
+        return True
+
+    def train_step(self, i: int):
+        ins, ws = self.pool[i % len(self.pool)]
+        out, _, fm = self.eng.forward(self.feats, ins, ws, self._train_tables)
+        loss_like = [out]
+        grads = [self._g_out]
+        if fm is not None:
+            loss_like.append(fm)
+            grads.append(self._g_fm)
+        torch.autograd.backward(loss_like, grads)
+        for t in self._train_tables.values():
+            t.grad = None
+
     def a2a_probe(self, steps: int):
         """Times the RETURN all-to-all(s) of one bound forward alone (rows / partial sums coming back from the owners):
         {"bytes": bytes received per rank per step, "ms": mean per step}, or None when nothing is row-sharded."""
