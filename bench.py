@@ -664,6 +664,60 @@ def module_path_leg(path: "SingleGpuPath", prepared_fb_ms, steps: int):
     return out
 
 
+# ------------------------------------------------------------------------------------ input pipeline (host -> device)
+def input_pipeline_leg(path: "SingleGpuPath", n_batches: int = 24):
+    """SURVEY 8f row 1 at the headline shape: the columnar loader (news_recsys_amd.dataset.DataReader.columnar.ColumnarLoader, what replaces the
+    reference's text DataReader + collate, src/dataset/DataReader/data_reader.py:54-115) streaming C2 batches -- 26 int64 id columns, B = 65 536 --
+    from PAGE-LOCKED host columns into device batches, the next batch's host -> device copies on a side stream under the current batch's forward
+    launch.  Reported next to `value`, never as it: samples/s, the bytes that crossed the host link per second, and that rate as a fraction of what
+    one large pinned copy reaches on this box in this run."""
+    import numpy as np
+    from news_recsys_amd import ops
+    from news_recsys_amd.dataset.DataReader.columnar import ColumnarDataset, ColumnarLoader
+    dev = path.device
+    names = [f["name"] for f in path.feats]
+    rows = [f["rows"] for f in path.feats]
+    n = n_batches * BATCH
+    rng = np.random.default_rng(7)
+    cols = {nm: rng.integers(1, r, n, dtype=np.int64) for nm, r in zip(names, rows)}
+    ds = ColumnarDataset.from_arrays(cols, np.zeros((n, 1), np.float32))
+    loader = ColumnarLoader(ds, BATCH, dev, pinned=True)
+    # the link: one 256 MB page-locked buffer, copied asynchronously, a few times
+    big = torch.empty(256 << 20, dtype=torch.uint8).pin_memory()
+    dst = torch.empty_like(big, device=dev)
+    for _ in range(2):
+        dst.copy_(big, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        dst.copy_(big, non_blocking=True)
+    torch.cuda.synchronize()
+    link = 4 * big.numel() / (time.perf_counter() - t0) / 1e9
+    del big, dst
+
+    def epoch(consume):
+        for b in loader:
+            if consume:
+                with torch.no_grad():
+                    ops.embed_apply(path.plan, path.tables, [b[nm] for nm in names], [None] * len(names), index_check="off")
+    epoch(True)                                   # pins the columns, warms the allocator
+    torch.cuda.synchronize()
+    res = {}
+    for consume in (False, True):
+        t0 = time.perf_counter()
+        epoch(consume)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        nbytes = n * (len(names) * 8 + 4)
+        res["with_forward" if consume else "copies_only"] = {"samples_per_s": n / dt, "pcie_GBps": nbytes / dt / 1e9, "frac_of_link": nbytes / dt / 1e9 / link,
+                                                             "ms_per_batch": dt / n_batches * 1e3}
+    return {**res["with_forward"], "copies_only": res["copies_only"], "link_GBps_one_large_pinned_copy": link, "batches": n_batches,
+            "bytes_per_sample": len(names) * 8 + 4,
+            "note": "ColumnarLoader(pinned=True): the dataset's columns page-locked once, batch-blocked ([batch][column][B]): every batch = ONE 13.6 MB asynchronous "
+                    "copy (+ the labels) on a side stream, double-buffered -- 27 copies of 512 KB per batch ran at 36 % of the link; with_forward = each batch also runs the C2 gather + FM launch (ops.embed_apply, no grad) on the main stream.  "
+                    "The mmap form of the loader (two host copies per batch) reached 10 M samples/s (profiles/r01_loader_throughput.txt)"}
+
+
 # ------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(path: SingleGpuPath, budget_s: float = 12.0):
     """Times the CPU oracle's C/OpenMP restatement of the reference path (oracle/nrx_oracle.c, checked
@@ -953,6 +1007,12 @@ def main():
             fwd_bwd = {"error": f"{type(e).__name__}: {e}"[:300]}
         return fwd_bwd
 
+    input_pipeline = None
+    if world == 1 and not args.force_sharded and not args.headline_only and args.workload == "c2" and hasattr(path, "plan"):
+        try:
+            input_pipeline = input_pipeline_leg(path)
+        except Exception as e:          # noqa: BLE001 -- a secondary leg must not cost the line
+            input_pipeline = {"error": f"{type(e).__name__}: {e}"[:300]}
     if world == 1 and hasattr(path, "train_setup") and not args.headline_only:
         fwd_bwd = sharded_train_leg(path)        # (N > 1: behind the headline line and the watchdog, with the other secondary legs)
     if world == 1 and not args.force_sharded and not args.headline_only:
@@ -1135,6 +1195,8 @@ def main():
             out["module_path"] = module_path
         if dcn_v2_cross is not None:
             out["dcn_v2_cross"] = dcn_v2_cross
+        if input_pipeline is not None:
+            out["input_pipeline"] = input_pipeline
         if world == 1 and not args.no_cpu_baseline and not args.force_sharded:
             big = sum(t.numel() for t in path.tables) * 4 > (64 << 30)      # host copies of > 64 GB of tables: skip
             if not big:

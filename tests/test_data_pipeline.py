@@ -177,6 +177,30 @@ def test_resident_loader_yields_the_same_batches(col_dir, shuffle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shuffle", [False, True])
+@pytest.mark.parametrize("csr", [False, True])
+def test_pinned_loader_yields_the_same_batches(col_dir, shuffle, csr):
+    """pinned=True (columns page-locked once; a sequential batch = asynchronous copies straight from slices of them, double-buffered on a side
+    stream) == the streaming loader over the mmaps, bit for bit, sequential and shuffled, padded and CSR bags, over two epochs -- and the in-memory
+    dataset (ColumnarDataset.from_arrays) == the one read from the converted directory."""
+    ds = ColumnarDataset(col_dir)
+    mem = ColumnarDataset.from_arrays({k: np.array(v) for k, v in ds.sparse.items()}, np.array(ds.label), {k: np.array(v) for k, v in ds.dense.items()},
+                                      {k: (np.array(ds.values[k]), np.array(ds.offsets[k]), ds.max_len[k]) for k in ds.values})
+    a = ColumnarLoader(ds, 5, "cuda:0", shuffle=shuffle, seed=3, csr_bags=csr)
+    b = ColumnarLoader(mem, 5, "cuda:0", shuffle=shuffle, seed=3, csr_bags=csr, pinned=True)
+    for _ in range(2):
+        la, lb = list(a), list(b)
+        torch.cuda.synchronize()
+        assert len(la) == len(lb) == len(a)
+        for x, y in zip(la, lb):
+            assert set(x) == set(y)
+            for k in x:
+                assert x[k].dtype == y[k].dtype and torch.equal(x[k], y[k]), k
+    with pytest.raises(ValueError):
+        ColumnarLoader(ds, 5, "cpu", pinned=True)
+
+
+@pytest.mark.gpu
 def test_csr_bag_loader_batches_expand_to_the_reference_batches_and_feed_the_model(col_dir):
     """csr_bags=True: array features travel as stored (ids [nnz] + `name_offsets`); expanded by the oracle's definition of
     DataReader's padding (data_reader.py:96-109) they are the reference's batches, and the model's fused launch on the
