@@ -1161,6 +1161,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "headline_definition_version": 2,     # 2 (round 4 on): c5 `value` = the Wide&Deep split launch at row stride 1280 (rounds 1-3: the plain concat, now
+                                                  # the `plain_concat` leg); c3 roofline.frac prices the gather alone (2 600 B), frac_with_cross_write the old bytes
             "config": {"workload": desc, "batch_per_gpu": BATCH, "parallelism": parallelism,
                        "algorithmic_bytes_per_impression": survey_bytes,
                        **({"algorithmic_bytes_per_impression_with_cross_write": bytes_per_impr} if survey_bytes != bytes_per_impr else {}),
@@ -1168,8 +1170,15 @@ def main():
                        "output_buffer": "recycled each step (as the caching allocator does); `distinct_output_buffers` has the other mode",
                        "index_check": "on (device status word, read once after the timed region)"},
             "step_us": spread,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+            # (algorithmic bytes that exceed what the HBM peak could deliver -- skewed ids over a table that fits the 256 MB Infinity Cache / the L2s:
+            # most row reads never reach DRAM -- are not an HBM-roofline figure: the line says so instead of printing a fraction above 1 as "hbm")
+            "roofline": {"bound": "hbm" if achieved <= HBM_PEAK_GBPS else "cache", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS if achieved <= HBM_PEAK_GBPS else None,
+                         **({"algorithmic_over_hbm_peak": achieved / HBM_PEAK_GBPS,
+                             "bound_note": "the looked-up rows are served from the caches (ids concentrated on rows that stay resident): the algorithmic byte "
+                                           "rate exceeds the HBM peak, so no HBM-roofline fraction is given; the DRAM traffic of this id distribution was not "
+                                           "profiled (traffic: null)"} if achieved > HBM_PEAK_GBPS else {}),
+                         "traffic": traffic, "traffic_unit": "bytes/launch",
                          **({"frac_with_cross_write": achieved_cw / HBM_PEAK_GBPS, "achieved_with_cross_write": achieved_cw}
                             if survey_bytes != bytes_per_impr else {}),
                          "kernel_ms_mean": kern_ms, "algorithmic_bytes_per_launch": survey_bytes * BATCH,

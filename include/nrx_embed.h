@@ -526,6 +526,7 @@ NRX_API int nrx_gather_inbox(const float* const* tables, const int64_t* table_ro
  * written to  peer_out[s] + inbox_pos[s*cap + j] * out_ld + feat_col[f]  -- its final place in the REQUESTER's concat buffer.
  * peer_out (HOST, world): rank s's [B, out_ld] buffer as THIS process can address it (hipIpcOpenMemHandle / a peer mapping over
  * xGMI; this rank's own pointer at s == rank); feat_col (HOST, n_feats): first column of every feature, a multiple of 4; dim in
+ * out_rows: rows of a requester's buffer -- a position outside [0, out_rows) (it came from a peer) is dropped and reported through `status`;
  * 16..256, % 4 == 0, out_ld % 4 == 0 (else NRX_ERR_UNSUPPORTED).  The requester may read its buffer once every owner's launch
  * has completed (a collective after the launch on each rank's stream orders that).  Removes the row all-to-all AND the second pass
  * over the rows (the final launch that re-reads them): bytes per looked-up row 4D read + 4D written, once.                  */
@@ -535,7 +536,7 @@ NRX_API int nrx_route_ids_pos(const void* const* ids, const int64_t* lens, int32
 NRX_API int nrx_gather_inbox_place(const float* const* tables, const int64_t* table_rows, int32_t n_tables,
                            const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,
                            const int64_t* recv2d, const int32_t* inbox_rows, const int32_t* inbox_pos, int32_t dim,
-                           float* const* peer_out, int64_t out_ld, const int32_t* feat_col, int32_t* status, void* stream);
+                           float* const* peer_out, int64_t out_ld, int64_t out_rows, const int32_t* feat_col, int32_t* status, void* stream);
 /* Backward of nrx_gather_inbox: grad_tables[..][row] += g_rows[p] over the valid prefixes.        */
 NRX_API int nrx_scatter_add_inbox(float* const* grad_tables, const int64_t* table_rows, int32_t n_tables,
                           const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,

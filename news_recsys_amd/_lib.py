@@ -110,7 +110,7 @@ SIGNATURES = {
     "nrx_route_ids": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p]),
     "nrx_route_ids_pos": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "nrx_gather_inbox_place": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, C.POINTER(_i32), _i32, _i32, _i64, _p, _p, _p, _i32,
-                                         C.POINTER(_p), _i64, C.POINTER(_i32), _p, _p]),
+                                         C.POINTER(_p), _i64, _i64, C.POINTER(_i32), _p, _p]),
     "nrx_route_dedup_workspace": (_i64, [_i64, _i32]),
     "nrx_route_ids_dedup": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i64), _i32, _i32, _i32, _i32, _i64,
                                       _p, _p, _p, _p, _p, _p]),

@@ -310,6 +310,7 @@ struct InboxArgs {
     int32_t feat_col[NRX_MAX_FEATURES];    // [n_feats]
     const int32_t* inbox_pos;
     int64_t out_ld;
+    int64_t out_rows;                      // rows of a requester's buffer: a position past them (a corrupt word from a peer) is dropped and reported
 };
 static_assert(sizeof(InboxArgs) <= 3584, "kernarg budget");
 
@@ -475,7 +476,12 @@ __global__ __launch_bounds__(NRX_BLOCK) void inbox_gather_ring_kernel(const Inbo
                     row = 0;
                 }
                 ptr = a->table[tab] + row * (int64_t)a->dim;
-                if (PLACE) dst = a->peer_out[s] + (int64_t)nrx_gconst<int32_t>(a->inbox_pos)[s * cap + j] * a->out_ld + a->feat_col[lo];
+                if (PLACE) {
+                    // the position came from a peer: a word outside the requester's batch must not become a write into another process's memory
+                    const int64_t at = nrx_gconst<int32_t>(a->inbox_pos)[s * cap + j];
+                    if ((uint64_t)at < (uint64_t)a->out_rows) dst = a->peer_out[s] + at * a->out_ld + a->feat_col[lo];
+                    else nrx_report_oob(a->status, tab, s * cap + j, at);
+                }
             }
             s_ptr[pos] = ptr;
             if (PLACE) s_dst[pos] = dst;
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void inbox_gather_ring_kernel(const Inbo
                 const int i = c * R + r;
                 const int64_t j = j0 + (int64_t)i * TB;
                 if (PLACE) {
-                    if (j < total && q < D4) nrx_stg4(s_dst[i * TB + g], q, v[r]);
+                    if (j < total && q < D4 && s_dst[i * TB + g] != nullptr) nrx_stg4(s_dst[i * TB + g], q, v[r]);
                 } else if (j < total && q < D4) {
                     nrx_stg4(a->buf, (s * cap + j) * D4 + q, v[r]);
                 }
@@ -822,13 +828,13 @@ extern "C" int nrx_route_ids_pos(const void* const* ids, const int64_t* lens, in
 extern "C" int nrx_gather_inbox_place(const float* const* tables, const int64_t* table_rows, int32_t n_tables,
                                       const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,
                                       const int64_t* recv2d, const int32_t* inbox_rows, const int32_t* inbox_pos, int32_t dim,
-                                      float* const* peer_out, int64_t out_ld, const int32_t* feat_col, int32_t* status, void* stream) {
+                                      float* const* peer_out, int64_t out_ld, int64_t out_rows, const int32_t* feat_col, int32_t* status, void* stream) {
     NRX_TRACE();
     InboxArgs a;
     int rc = fill_inbox_args(a, const_cast<float* const*>(tables), table_rows, n_tables, feat_table, n_feats, world, cap,
                              recv2d, inbox_rows, dim, "nrx_gather_inbox_place");
     if (rc != NRX_OK) return rc;
-    NRX_REQUIRE(inbox_pos && peer_out && feat_col && out_ld >= dim, "nrx_gather_inbox_place: null / bad placement argument");
+    NRX_REQUIRE(inbox_pos && peer_out && feat_col && out_ld >= dim && out_rows >= 0, "nrx_gather_inbox_place: null / bad placement argument");
     if ((dim & 3) != 0 || dim > 256 || dim < 16 || (out_ld & 3) != 0) {
         nrx_set_error("nrx_gather_inbox_place: rows of 16..256 floats (a multiple of 4) and a row stride that is a multiple of 4 floats");
         return NRX_ERR_UNSUPPORTED;
@@ -843,6 +849,7 @@ extern "C" int nrx_gather_inbox_place(const float* const* tables, const int64_t*
     }
     a.inbox_pos = inbox_pos;
     a.out_ld = out_ld;
+    a.out_rows = out_rows;
     a.buf = nullptr;
     a.status = status;
     a.skip_row0 = 0;

@@ -180,7 +180,11 @@ class FusedSparseAdam:
             key = self._stable_index(t)
             m, v = self.moments[pos]
             tables[key if key is not None else f"unlisted:{pos}"] = {"exp_avg": m, "exp_avg_sq": v}
-        return {"t": self.t, "t_dev": None if self._t_dev is None else float(self._t_dev.item()), "tables": tables}
+        steps = {}
+        for pos, c in getattr(self, "_steps", {}).items():          # (ExactDenseAdamW: a table's own step count)
+            key = self._stable_index(self.tables[pos])
+            steps[key if key is not None else f"unlisted:{pos}"] = c
+        return {"t": self.t, "t_dev": None if self._t_dev is None else float(self._t_dev.item()), "tables": tables, "steps": steps}
 
     def load_state_dict(self, sd):
         self.t = int(sd["t"])
@@ -197,6 +201,8 @@ class FusedSparseAdam:
             m, v = self.moments[pos]
             m.copy_(mv["exp_avg"])
             v.copy_(mv["exp_avg_sq"])
+        if sd.get("steps"):
+            self._steps = {self._register(self.params[key]): int(c) for key, c in sd["steps"].items() if not isinstance(key, str)}
 
 
 class ExactDenseAdamW(FusedSparseAdam):
@@ -204,8 +210,10 @@ class ExactDenseAdamW(FusedSparseAdam):
     every table moves every step: decoupled weight decay, decaying moments) -- fed from the row-sparse sink instead of dense .grad tensors:
     `nrx_rows_mark` notes which rows have a gradient this step, `nrx_dense_adamw_rows` streams over every row of every table once (SURVEY 8f
     row 2, "exact-dense mode").  Same numbers as torch.optim.AdamW on the dense gradients (tests/test_fused_sparse_adam_gpu.py); no dense
-    gradient is formed, zero-filled or read.  Every table in `params` is updated on every step(), looked up or not -- like AdamW with a zero
-    gradient.  exp_avg / exp_avg_sq are plain [rows, dim] tensors (torch's layout)."""
+    gradient is formed, zero-filled or read.  As torch.optim.AdamW skips a parameter whose .grad is None, a step() updates the tables that a
+    backward launch of the step looked up (the sink entries name them) -- all of their rows -- and leaves the others alone, each table with
+    its own step count (capturable=True: one device-side count for all tables, every registered table is streamed every step).
+    exp_avg / exp_avg_sq are plain [rows, dim] tensors (torch's layout)."""
 
     def __init__(self, sink, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, capturable=False):
         super().__init__(sink, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable, params=list(params))
@@ -228,8 +236,20 @@ class ExactDenseAdamW(FusedSparseAdam):
         lib = _lib.load()
         self.t += 1
         by_dim = {}
+        touched = set()
         for e in self.sink.pending:
             by_dim.setdefault(e["dim"], []).append((self._global_keys(e), e["values"]))
+            for tid in e.get("table_ids", range(len(e["tables"]))):      # the tables this backward launch looked up
+                i = self._index.get(id(e["tables"][tid]))
+                if i is not None:
+                    touched.add(i)
+        if self.capturable:
+            touched = set(range(len(self.tables)))       # (one device-side step count: every table moves every step)
+        steps = getattr(self, "_steps", None)
+        if steps is None:
+            steps = self._steps = {}
+        for i in touched:
+            steps[i] = steps.get(i, 0) + 1
         n = len(self.tables)
         if n > _lib.NRX_MAX_FEATURES:
             raise NotImplementedError("ExactDenseAdamW: more than 64 distinct tables")
@@ -243,27 +263,31 @@ class ExactDenseAdamW(FusedSparseAdam):
             hyper = torch.stack([self.lr / (1.0 - b1 ** self._t_dev), 1.0 / torch.sqrt(1.0 - b2 ** self._t_dev)]).to(torch.float32)
         elif torch.cuda.is_current_stream_capturing():
             raise RuntimeError("ExactDenseAdamW: construct with capturable=True to capture step() in a graph (the step count is baked in otherwise)")
-        for dim in sorted({t.shape[1] for t in self.tables}):
-            idx = [i for i, t in enumerate(self.tables) if t.shape[1] == dim]
+        marked = {}
+        for dim, tstep in sorted({(self.tables[i].shape[1], steps[i]) for i in touched}):
+            idx = [i for i in sorted(touched) if self.tables[i].shape[1] == dim and steps[i] == tstep]
             dev = self.tables[idx[0]].device
             stream = torch.cuda.current_stream(dev).cuda_stream
             k = len(idx)
             rows = (C.c_int64 * n)(*[t.shape[0] for t in self.tables])
             maps_all = (C.c_void_p * n)(*[m.data_ptr() for m in self.maps])
-            vals = None
-            lst = by_dim.get(dim)
-            if lst:
-                if len(lst) == 1:
-                    keys, vals = lst[0]
-                else:       # one table fed by several backward groups: ONE gradient per row
-                    keys, vals = self._merge(torch.cat([kk for kk, _ in lst]), torch.cat([v for _, v in lst]))
-                ops.check(lib.nrx_rows_mark(keys.data_ptr(), keys.numel(), None, maps_all, rows, n, 0, stream), "nrx_rows_mark")
+            if dim not in marked:                    # a dim's rows are marked once; tables of the dim at another step count read the same marks
+                vals = None
+                lst = by_dim.get(dim)
+                if lst:
+                    if len(lst) == 1:
+                        keys, vals = lst[0]
+                    else:       # one table fed by several backward groups: ONE gradient per row
+                        keys, vals = self._merge(torch.cat([kk for kk, _ in lst]), torch.cat([v for _, v in lst]))
+                    ops.check(lib.nrx_rows_mark(keys.data_ptr(), keys.numel(), None, maps_all, rows, n, 0, stream), "nrx_rows_mark")
+                marked[dim] = vals
+            vals = marked[dim]
             tp = (C.c_void_p * k)(*[self.tables[i].data_ptr() for i in idx])
             mp = (C.c_void_p * k)(*[self.moments[i][0].data_ptr() for i in idx])
             vp = (C.c_void_p * k)(*[self.moments[i][1].data_ptr() for i in idx])
             sp = (C.c_void_p * k)(*[self.maps[i].data_ptr() for i in idx])
             rk = (C.c_int64 * k)(*[self.tables[i].shape[0] for i in idx])
-            ops.check(lib.nrx_dense_adamw_rows(tp, mp, vp, sp, rk, k, dim, vals.data_ptr() if vals is not None else None, self.t, self.lr, b1, b2,
+            ops.check(lib.nrx_dense_adamw_rows(tp, mp, vp, sp, rk, k, dim, vals.data_ptr() if vals is not None else None, tstep, self.lr, b1, b2,
                                                self.eps, self.weight_decay, hyper.data_ptr() if hyper is not None else None, stream),
                       "nrx_dense_adamw_rows")
         self.sink.clear()

@@ -61,10 +61,8 @@ def _deferred_status(names: Sequence[str]) -> torch.Tensor:
         _host_status = torch.zeros(4, dtype=torch.int32).pin_memory()
     elif _host_status[0] != 0:
         _raise_deferred()
-    elif len(_host_status_names) > 4:
-        # the word reads clear: launches further back than the last few have long finished without an offence -- their name lists
-        # would only blur a later report ("one of: ..." naming features of unrelated plans)
-        del _host_status_names[:-4]
+    # (the name lists are NOT trimmed when the word merely reads clear: with a deep launch queue an offence of a launch still in flight would
+    # later be reported against the wrong names; the 16-entry ring bounds the list, flush_index_checks -- device idle -- empties it)
     if not any(n is names for n in _host_status_names):
         if len(_host_status_names) >= 16:      # launches still in flight are at most a few calls back
             del _host_status_names[0]
@@ -124,6 +122,7 @@ def flush_index_checks() -> None:
         torch.cuda.synchronize()
         if _host_status[0] != 0:
             _raise_deferred()
+        del _host_status_names[:]          # the device is idle and the word is clear: no launch can report against these lists any more
     while _pending_status:
         status, ev, names = _pending_status.pop(0)
         ev.synchronize()
@@ -1033,7 +1032,7 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
             rc = lib.nrx_embed_bwd_small_sparse(arr, grp["static"][0], n, B, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, fmg,
                                                 uniq.data_ptr(), values.data_ptr(), total, stream)
             if rc == 0:
-                ctx.sink.pending.append(dict(tables=ctx.tables, dim=D, uniq=uniq, values=values, counts=None, cap=total, filler=True))
+                ctx.sink.pending.append(dict(tables=ctx.tables, dim=D, uniq=uniq, values=values, counts=None, cap=total, filler=True, table_ids=sorted(set(tabs))))
                 continue
             if rc != NRX_ERR_UNSUPPORTED:
                 check(rc, "nrx_embed_bwd_small_sparse")
@@ -1121,7 +1120,7 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
         if ctx.sink is not None:
             values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
             pl = _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, total, counts, fmg, values, lws, stream, replan=replan)
-            ctx.sink.pending.append(dict(tables=ctx.tables, dim=D, uniq=pl[1], values=values, counts=pl[3], cap=total))
+            ctx.sink.pending.append(dict(tables=ctx.tables, dim=D, uniq=pl[1], values=values, counts=pl[3], cap=total, table_ids=sorted(set(tabs))))
             continue
         if SPARSE_BWD_SYNC_FREE:
             values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique

@@ -764,8 +764,8 @@ class PreparedShardedForward:
             eng._a2a(g["inbox"], g["send"])
             eng._a2a(g["inbox_pos"], g["send_pos"])
         rc = lib.nrx_gather_inbox_place(g["tp"], g["tr"], g["nt"], g["ft"], g["n"], W, g["cap"], g["recv2d"].data_ptr(),
-                                        g["inbox"].data_ptr(), g["inbox_pos"].data_ptr(), g["D"], self._peer_ptrs, g["ld"], g["cols"],
-                                        None, stream)
+                                        g["inbox"].data_ptr(), g["inbox_pos"].data_ptr(), g["D"], self._peer_ptrs, g["ld"], self.out.shape[0],
+                                        g["cols"], None, stream)
         if rc:
             ops.check(rc, "nrx_gather_inbox_place")
 

@@ -1041,7 +1041,7 @@ def test_route_ids_pos_and_one_sided_gather_c_abi(world, lens, cap):
     tp = (C.c_void_p * F)(*[t.data_ptr() for t in tabs]); tr = (C.c_int64 * F)(*[t.shape[0] for t in tabs])
     ft = (C.c_int32 * F)(*range(F)); cols = (C.c_int32 * F)(*[f * D for f in range(F)])
     po = (C.c_void_p * world)(*[o.data_ptr() for o in outs])
-    rc = lib.nrx_gather_inbox_place(tp, tr, F, ft, F, world, cap, c2.data_ptr(), send.data_ptr(), pos.data_ptr(), D, po, F * D, cols, None,
+    rc = lib.nrx_gather_inbox_place(tp, tr, F, ft, F, world, cap, c2.data_ptr(), send.data_ptr(), pos.data_ptr(), D, po, F * D, B, cols, None,
                                     torch.cuda.current_stream().cuda_stream)
     assert rc == 0, lib.nrx_last_error()
     torch.cuda.synchronize()
@@ -1054,7 +1054,7 @@ def test_route_ids_pos_and_one_sided_gather_c_abi(world, lens, cap):
         assert np.array_equal(o.cpu().numpy(), w)
     # shapes the placing kernel does not take are refused, not mis-served
     po1 = (C.c_void_p * world)(*[o.data_ptr() for o in outs])
-    assert lib.nrx_gather_inbox_place(tp, tr, F, ft, F, world, cap, c2.data_ptr(), send.data_ptr(), pos.data_ptr(), 8, po1, F * D, cols, None,
+    assert lib.nrx_gather_inbox_place(tp, tr, F, ft, F, world, cap, c2.data_ptr(), send.data_ptr(), pos.data_ptr(), 8, po1, F * D, B, cols, None,
                                       torch.cuda.current_stream().cuda_stream) == -3          # NRX_ERR_UNSUPPORTED: rows of 8 floats
 
 
