@@ -301,6 +301,10 @@ struct SegArgs {
     // of this target loads dwords only -- and every tile kernel began with such a load and a full wait for it before its first useful one)
     uint32_t table_w[NRX_MAX_FEATURES / 4];  // per slot: table number, a byte each
     uint32_t seg_db_w[NRX_MAX_FEATURES / 8]; // per table: digit width, a nibble each (<= SEG_MAX_DB = 10)
+    uint32_t seg_p0_w[NRX_MAX_FEATURES / 8]; // per table (LSD form): the first pass the segment takes part in, a nibble each.  A segment whose row bits
+                                             // need fewer passes than the launch's widest table sits out the FIRST passes (C4: the 200 k-row news table
+                                             // -- 97 % of the lookups -- needs two 9-bit passes where the 10 M-row user table needs three): the key
+                                             // kernel leaves its pairs in the buffer its first pass reads, every pass kernel returns at once for it
     int32_t n_slots, n_seg, idx64, row_bits, nb;     // nb = 1 << (widest digit) = row stride of hist / ctot / bin_base
     int32_t xcd;                                      // 1: blocks take their tiles in XCD order (seg_block_tile)
     // MSD form (round 4; launches whose LSD sort would take three or more passes): ONE scatter pass on each segment's HIGH digit (its top
@@ -317,6 +321,10 @@ static_assert(sizeof(SegArgs) <= 3584, "kernarg budget");
 __device__ __forceinline__ int seg_db_of(const NRX_CONST SegArgs* a, int seg) {                 // seg wave-uniform: scalar loads and shifts
     seg = __builtin_amdgcn_readfirstlane(seg);
     return (int)((a->seg_db_w[seg >> 3] >> ((seg & 7) * 4)) & 15u);
+}
+__device__ __forceinline__ int seg_p0_of(const NRX_CONST SegArgs* a, int seg) {
+    seg = __builtin_amdgcn_readfirstlane(seg);
+    return (int)((a->seg_p0_w[seg >> 3] >> ((seg & 7) * 4)) & 15u);
 }
 __device__ __forceinline__ int seg_shift_of(const NRX_CONST SegArgs* a, int seg) {              // seg wave-uniform
     seg = __builtin_amdgcn_readfirstlane(seg);
@@ -352,11 +360,15 @@ __device__ __forceinline__ int seg_of_tile(const NRX_CONST SegArgs* a, int tile)
 // PAIR (32-bit keys): {key, payload} travel as one 8-byte element through every pass and into plan_count / plan_emit -- the scatter's
 // runs are short (4 entries per bin and tile at 10-bit digits), so one 32-byte piece per run instead of two 16-byte ones.
 template <typename KeyT, bool PAIR>
-__global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs args_in_kernarg, KeyT* __restrict__ keys, uint32_t* __restrict__ payload,
-                                                               uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs args_in_kernarg, KeyT* __restrict__ keys_a, uint32_t* __restrict__ payload_a,
+                                                               uint32_t* __restrict__ hist, KeyT* __restrict__ keys_b, uint32_t* __restrict__ payload_b) {
     extern __shared__ uint32_t s_hist[];
     const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
     const int tile = seg_block_tile(a), seg = seg_of_tile(a, tile);
+    // (a segment that starts at an odd pass: its pairs go to the buffer that pass reads)
+    const bool odd = !a->msd && (seg_p0_of(a, seg) & 1) != 0;
+    KeyT* __restrict__ keys = odd ? keys_b : keys_a;
+    uint32_t* __restrict__ payload = odd ? payload_b : payload_a;
     const int nbins = 1 << seg_db_of(a, seg);
     const int hshift = a->msd ? seg_shift_of(a, seg) : 0;            // the digit this kernel histograms: the lowest (LSD) or the segment's highest (MSD)
     if (a->msd && blockIdx.x == 0 && threadIdx.x == 0) a->work[0] = 0;   // the scatter pass (next launch) appends the large bins
@@ -449,7 +461,9 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_hist_kernel(const SegArgs arg
     extern __shared__ uint32_t s_hist[];
     const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
     const int tile = seg_block_tile(a), seg = seg_of_tile(a, tile);
-    const int db = seg_db_of(a, seg), nbins = 1 << db, shift = pass * db;
+    const int dpass = pass - seg_p0_of(a, seg);
+    if (dpass < 0) return;                           // the segment sits this pass out
+    const int db = seg_db_of(a, seg), nbins = 1 << db, shift = dpass * db;
     for (int b = threadIdx.x; b < nbins; b += SEG_THREADS) s_hist[b] = 0;
     const int64_t q0 = a->seg_off[seg] + (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE, qend = a->seg_off[seg + 1];
     const uint32_t dmask = (uint32_t)nbins - 1u;
@@ -470,10 +484,11 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_hist_kernel(const SegArgs arg
 
 // segments of more than SEG_CHUNK tiles: hist[tile][bin] -> exclusive prefix over the earlier tiles of the tile's chunk
 // (in place); ctot[chunk][bin] = the chunk's total.  grid (nb / 256, chunks)
-__global__ __launch_bounds__(NRX_BLOCK) void seg_scan_chunks(const SegArgs args_in_kernarg, uint32_t* __restrict__ hist, uint32_t* __restrict__ ctot) {
+__global__ __launch_bounds__(NRX_BLOCK) void seg_scan_chunks(const SegArgs args_in_kernarg, uint32_t* __restrict__ hist, uint32_t* __restrict__ ctot, int pass) {
     const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
     const int chunk = blockIdx.y;
     const int seg = __builtin_amdgcn_readfirstlane(seg_count_le<int32_t>(a->seg_chunk, a->n_seg, chunk));
+    if (!a->msd && pass < seg_p0_of(a, seg)) return;
     const int nb = a->nb;
     const int bin = blockIdx.x * NRX_BLOCK + threadIdx.x;
     if (bin >= (1 << seg_db_of(a, seg))) return;
@@ -495,10 +510,11 @@ __global__ __launch_bounds__(NRX_BLOCK) void seg_scan_chunks(const SegArgs args_
 // themselves).  Per bin: running sum over the segment's chunks (ctot in place); then the exclusive scan over the bins + the
 // segment's first entry -> bin_base[seg][bin].
 __global__ __launch_bounds__(NRX_BLOCK) void seg_scan_bins(const SegArgs args_in_kernarg, uint32_t* __restrict__ hist, uint32_t* __restrict__ ctot,
-                                                            uint32_t* __restrict__ bin_base) {
+                                                            uint32_t* __restrict__ bin_base, int pass) {
     __shared__ uint32_t s_part[NRX_BLOCK / 64];
     const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
     const int seg = blockIdx.x, nb = a->nb, nbins = 1 << seg_db_of(a, seg);
+    if (!a->msd && pass < seg_p0_of(a, seg)) return;
     constexpr int PER = (1 << SEG_MAX_DB) / NRX_BLOCK;            // bins per thread: bin = i * 256 + tid (coalesced rows)
     const int nchunks = a->seg_chunk[seg + 1] - a->seg_chunk[seg];
     uint32_t v[PER];
@@ -561,7 +577,9 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tile = seg_block_tile(a), seg = seg_of_tile(a, tile);
     const int db = seg_db_of(a, seg), nbins = 1 << db, nb = a->nb;
-    const int shift = a->msd ? seg_shift_of(a, seg) : pass * db;
+    const int dpass = a->msd ? 0 : pass - seg_p0_of(a, seg);
+    if (dpass < 0) return;                           // the segment sits this pass out: its pairs already lie in the buffer its first pass reads
+    const int shift = a->msd ? seg_shift_of(a, seg) : dpass * db;
     uint16_t* s_wh = reinterpret_cast<uint16_t*>(s_mem);  // [WAVES][nbins]: running bin counts of each wave's 512-entry chunk (16-bit: a tile
                                                           // holds 4096 entries; halves this area -- a third / fourth resident block per CU)
     uint32_t* s_bin = s_mem + WAVES * nbins / 2;          // [nbins]: the bin's first position inside the tile
@@ -979,12 +997,12 @@ void seg_sort_generic(KeyT*& src, KeyT*& dst, uint32_t*& psrc, uint32_t*& pdst, 
             hipLaunchKernelGGL((seg_scatter_kernel<KeyT, 1, false>), dim3((unsigned)tiles), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src,
                                (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst);
         } else if (chunks <= SEG_DIRECT_CHUNKS && !force_bins) {
-            hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot);
+            hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot, pass);
             hipLaunchKernelGGL((seg_scatter_kernel<KeyT, 2, false>), dim3((unsigned)tiles), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src,
                                (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst);
         } else {
-            hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot);
-            hipLaunchKernelGGL(seg_scan_bins, dim3(1), dim3(NRX_BLOCK), 0, st, sa, hist, ctot, bin_base);
+            hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot, pass);
+            hipLaunchKernelGGL(seg_scan_bins, dim3(1), dim3(NRX_BLOCK), 0, st, sa, hist, ctot, bin_base, pass);
             hipLaunchKernelGGL((seg_scatter_kernel<KeyT, 0, false>), dim3((unsigned)tiles), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src,
                                (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst);
         }
@@ -1081,6 +1099,8 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
         const bool forbid_msd = sort_env && (!strcmp(sort_env, "lsd") || force_bins);
         bool msd = !forbid_msd && (force_msd || passes >= 3) && n < (1ll << 30);
         memset(sa.seg_shift_w, 0, sizeof(sa.seg_shift_w));
+        memset(sa.seg_p0_w, 0, sizeof(sa.seg_p0_w));
+        const bool skip_off = getenv("NRX_SEG_SKIP") != nullptr && atoi(getenv("NRX_SEG_SKIP")) == 0;      // A/B knob: every segment takes every pass
         if (msd) {
             for (int t = 0; t < n_tables && msd; ++t) {
                 int64_t seg_rows = 1, seg_len = 0;
@@ -1111,7 +1131,11 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
                 q += lens[f];
                 ++slot;
             }
-            int db = (bits_for(seg_rows) + passes - 1) / passes;            // the segment's row bits, split evenly over the passes
+            // the segment's row bits, split evenly over the passes IT needs (a narrow table next to a wide one sits out the first passes)
+            const int passes_t = (bits_for(seg_rows) + digit_cap - 1) / digit_cap > 0 ? (bits_for(seg_rows) + digit_cap - 1) / digit_cap : 1;
+            const int p0 = (msd || skip_off) ? 0 : passes - (passes_t < passes ? passes_t : passes);
+            int db = (bits_for(seg_rows) + (passes - p0) - 1) / (passes - p0);
+            sa.seg_p0_w[t >> 3] |= (uint32_t)(p0 & 15) << ((t & 7) * 4);
             if (msd) {                                                       // ... or its top <= 10 bits, the rest left to the bin sort
                 const int rb = bits_for(seg_rows);
                 db = rb < SEG_MAX_DB ? rb : SEG_MAX_DB;
@@ -1164,7 +1188,7 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
         (void)lds_ok;                                                                                                     \
         KeyT* src = (KeyT*)keys_in; KeyT* dst = (KeyT*)keys_out;                                                          \
         uint32_t* psrc = pay_in; uint32_t* pdst = pay_out;                                                                \
-        hipLaunchKernelGGL((seg_keys_kernel<KeyT, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, src, psrc, hist); \
+        hipLaunchKernelGGL((seg_keys_kernel<KeyT, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, src, psrc, hist, dst, pdst); \
         if (msd) {                                                                                                        \
             hipLaunchKernelGGL((seg_scatter_kernel<KeyT, 1, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
                                (const uint32_t*)psrc, 0, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst); \
@@ -1176,12 +1200,12 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
         for (int pass = 0; pass < (msd ? 0 : passes); ++pass) {                                                           \
             if (pass > 0) hipLaunchKernelGGL((seg_hist_kernel<KeyT, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, (const KeyT*)src, pass, hist); \
             if (chunked && (max_chunks > SEG_DIRECT_CHUNKS || force_bins)) {                                              \
-                hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot);                      \
-                hipLaunchKernelGGL(seg_scan_bins, dim3((unsigned)n_tables), dim3(NRX_BLOCK), 0, st, sa, hist, ctot, bin_base); \
+                hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot, pass);                      \
+                hipLaunchKernelGGL(seg_scan_bins, dim3((unsigned)n_tables), dim3(NRX_BLOCK), 0, st, sa, hist, ctot, bin_base, pass); \
                 hipLaunchKernelGGL((seg_scatter_kernel<KeyT, 0, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
                                    (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst); \
             } else if (chunked) {                                                                                         \
-                hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot);                      \
+                hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot, pass);                      \
                 hipLaunchKernelGGL((seg_scatter_kernel<KeyT, 2, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
                                    (const uint32_t*)psrc, pass, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst); \
             } else {                                                                                                      \

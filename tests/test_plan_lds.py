@@ -250,3 +250,110 @@ def test_policy_follows_the_previous_batch(monkeypatch):
         kinds.append(len(pl) == 8)
     #          sorted (no statistics yet), lds, lds, lds (found out it was slow), sorted, sorted (found near-unique again), lds
     assert kinds == [False, True, True, True, False, False, True]
+
+
+def test_plan_lds_at_the_real_c2_counts():
+    """BASELINE config 2 at full size: 26 tables x 1 000 000 rows, 65 536 uniform ids each (1.7 M lookups, 208 row ranges) -- unique rows, per-table
+    bounds, dest words, pair records and walk rows against the definition (vectorised here: oracle.ref_np.sparse_plan + run lengths)."""
+    rng = np.random.default_rng(2026)
+    T, rows, B = 26, 1_000_000, 65_536
+    ids = [rng.integers(1, rows, B) for _ in range(T)]
+    for x in ids:
+        x[:3] = 0
+    got = _plan_lds(ids, list(range(T)), [rows] * T, T)
+    order, uniq, seg, counts = R.sparse_plan(ids, list(range(T)), [rows] * T, T)
+    nu, n = len(uniq), T * B
+    ln = seg[1:] - seg[:-1]
+    row = uniq & ((1 << 40) - 1)
+    once, twice = (ln == 1) & (row != 0), (ln == 2) & (row != 0)
+    assert np.array_equal(got["counts"], counts) and np.array_equal(got["uniq"][:nu], uniq)
+    dest = np.full(n, -1, np.int32)
+    dest[order[seg[:-1][once]]] = np.nonzero(once)[0]
+    assert np.array_equal(got["dest"][:n], dest)
+    pu = np.nonzero(twice)[0]
+    want_pairs = np.stack([pu, order[seg[:-1][twice]], order[seg[:-1][twice] + 1]], axis=1).astype(np.int32)
+    assert got["n_pairs"] == len(pu) and np.array_equal(got["pairs"][:len(pu), :3], want_pairs)
+    wu = np.nonzero(~once & ~twice)[0]
+    assert got["n_walk"] == len(wu) and np.array_equal(got["walk"][:len(wu)], wu.astype(np.int32))
+    at = 0
+    for u in wu:
+        k = int(ln[u])
+        assert got["seg"][u] == at and got["seg"][u + 1] == at + k and np.array_equal(got["order"][at:at + k], order[seg[u]:seg[u] + k])
+        at += k
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_plan_lds_random_shapes(seed):
+    """Random launches inside the planner's shapes: 1-9 tables of 1 .. 600 000 rows (several features may share a table), batch 1 .. 7000, ids from
+    uniform to heavily repeated, int32 or int64 -- the plan equals its definition."""
+    rng = np.random.default_rng(1000 + seed)
+    nt = int(rng.integers(1, 10))
+    trow = [int(rng.choice([1, 2, 33, 5000, 131072, 131073, 262144, 600000])) for _ in range(nt)]
+    nf = int(rng.integers(nt, nt + 4))
+    tab = list(range(nt)) + [int(rng.integers(0, nt)) for _ in range(nf - nt)]
+    rng.shuffle(tab)
+    B = int(rng.choice([1, 2, 63, 64, 65, 1000, 4097, 7000]))
+    rows = [trow[t] for t in tab]
+    ids = []
+    for r in rows:
+        span = max(1, int(r * rng.choice([1.0, 0.3, 0.01])))
+        ids.append(rng.integers(0, span, B))
+    dtype = torch.int32 if seed % 2 else torch.int64
+    got = _plan_lds(ids, tab, rows, nt, dtype)
+    _check_against_definition(got, ids, tab, rows, nt)
+
+
+def test_captured_step_takes_the_one_kernel_planner_and_replays_bit_for_bit(monkeypatch):
+    """A step captured in a HIP graph (forward + row-sparse backward into a sink) after eager warm-up steps on near-unique ids: the capture bakes in
+    the one-kernel planner (the policy's choice from the warm-up batches); replays on NEW ids give the same unique rows and row gradients, bit for
+    bit, as the eager sorted planner on those ids."""
+    monkeypatch.setattr(ops, "PLAN_LDS", "auto")
+    n, D, rows, B = 6, 16, 300000, 5000           # (above the one-launch small kernel's 4096 lookups per table: the planned reduction)
+    slots = [ops.Slot(f"f{i}", NRX_SPARSE, i, D, 0, i * D, fm_field=1) for i in range(n)]
+    plan = ops.EmbedPlan(slots, out_width=n * D, use_fm=True)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    tables = [torch.randn((rows, D), device=DEV, generator=gen).requires_grad_() for _ in range(n)]
+    static_ids = [torch.randint(1, rows, (B,), device=DEV, generator=gen) for _ in range(n)]
+    up = torch.randn((B, n * D), device=DEV, generator=gen)
+    upf = torch.randn((B,), device=DEV, generator=gen)
+    sink = ops.SparseGradSink()
+    keep = {}
+
+    def step():
+        sink.clear()
+        out, _, fm = ops.embed_apply(plan, tables, static_ids, [None] * n, sparse_grad=sink, index_check="off")
+        ((out * up).sum() + (fm * upf).sum()).backward()
+        e = sink.pending[0]
+        keep["uniq"], keep["values"], keep["counts"] = e["uniq"], e["values"], e["counts"]
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):                       # batch 1: sorted planner + statistics; batches 2, 3: the one-kernel planner
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()                     # (the warm-up plans' statistics have landed in the policy's mapped words: GraphedStep syncs here too)
+    pol = ops._group_policy(ops._sparse_group_cache(plan, tables)[0], B, n)
+    assert pol is not None and pol.choose()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        step()
+    for trial in range(3):
+        new = [torch.randint(1, rows, (B,), device=DEV, generator=gen) for _ in range(n)]
+        for dst, src in zip(static_ids, new):
+            dst.copy_(src)
+        g.replay()
+        torch.cuda.synchronize()
+        nu = int(keep["counts"][0].item())
+        ku, kv = keep["uniq"][:nu].clone(), keep["values"][:nu].clone()
+        monkeypatch.setattr(ops, "PLAN_LDS", "0")
+        plan.__dict__.pop("_sg", None)
+        ref_sink = ops.SparseGradSink()
+        out, _, fm = ops.embed_apply(plan, tables, new, [None] * n, sparse_grad=ref_sink, index_check="off")
+        ((out * up).sum() + (fm * upf).sum()).backward()
+        torch.cuda.synchronize()
+        e = ref_sink.pending[0]
+        assert int(e["counts"][0].item()) == nu and torch.equal(e["uniq"][:nu], ku)
+        assert torch.equal(e["values"][:nu].view(torch.int32), kv.view(torch.int32))
+        monkeypatch.setattr(ops, "PLAN_LDS", "auto")
+        plan.__dict__.pop("_sg", None)
