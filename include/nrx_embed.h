@@ -355,6 +355,16 @@ NRX_API int nrx_embed_bwd_dense_planned(const nrx_feature_t* feats, const int32_
                                 const nrx_fm_grad_t* fm, float* const* grad_tables, int32_t accumulate, int32_t planner,
                                 void* state, int64_t* stats, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The ROW-SPARSE counterpart of nrx_embed_bwd_dense_planned (what the fused optimizer's sink takes): plan + reduction of one launch group in ONE
+ * call.  uniq_keys [n] / values [n, dim] / counts [n_tables + 2] (n = the launch's lookups: the worst case) are the caller's -- they outlive the call;
+ * every intermediate lives in `workspace` (nrx_embed_bwd_sparse_planned_workspace bytes, reusable by the next call on the same stream).  planner /
+ * state / stats as nrx_embed_bwd_dense_planned.  Same keys and rows as nrx_sparse_plan_place + nrx_embed_bwd_placed, bit for bit. */
+NRX_API int64_t nrx_embed_bwd_sparse_planned_workspace(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim, int32_t n_tables);
+NRX_API int nrx_embed_bwd_sparse_planned(const nrx_feature_t* feats, const int32_t* table_of, int32_t n_feats, int32_t n_tables, int64_t batch,
+                                 int32_t dim, const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                                 const nrx_fm_grad_t* fm, int64_t* uniq_keys, float* values, int64_t* counts, int32_t planner,
+                                 void* state, int64_t* stats, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Unique-row gradients -> dense gradient tables: for every unique entry u of nrx_sparse_plan / nrx_embed_bwd_sorted
  * (key = (table << 40) | row, gradient rows[u, :dim]), tables[table][row, :dim] = rows[u] (accumulate == 0) or += rows[u]
  * (accumulate != 0: a table fed by more than one reduction).  With zero-filled tables this forms what autograd gives the

@@ -90,6 +90,9 @@ SIGNATURES = {
     "nrx_embed_bwd_dense_planned_workspace": (_i64, [C.POINTER(NrxFeature), _i32, _i64, _i32, _i32]),
     "nrx_embed_bwd_dense_planned": (C.c_int, [C.POINTER(NrxFeature), C.POINTER(_i32), _i32, _i32, _i64, _i32, _p, _i64, _p, _i64,
                                               C.POINTER(NrxFmGrad), C.POINTER(_p), _i32, _i32, _p, _p, _p, _i64, _p]),
+    "nrx_embed_bwd_sparse_planned_workspace": (_i64, [C.POINTER(NrxFeature), _i32, _i64, _i32, _i32]),
+    "nrx_embed_bwd_sparse_planned": (C.c_int, [C.POINTER(NrxFeature), C.POINTER(_i32), _i32, _i32, _i64, _i32, _p, _i64, _p, _i64,
+                                               C.POINTER(NrxFmGrad), _p, _p, _p, _i32, _p, _p, _p, _i64, _p]),
     "nrx_make_table_keys": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), C.POINTER(_i32), _i32, _i32, _p, _p]),
     "nrx_bag_pool_fwd": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     "nrx_bag_pool_bwd": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),

@@ -3671,6 +3671,79 @@ extern "C" int nrx_embed_bwd_dense_planned(const nrx_feature_t* feats, const int
                                  bwd_bytes, stream, grad_tables, n_tables, accumulate);
 }
 
+// The row-sparse counterpart of nrx_embed_bwd_dense_planned: plan (either planner) + reduction in ONE call, the unique keys, their summed rows and the
+// per-table counts left in caller-owned arrays (what the fused optimizer's sink holds), every intermediate in one workspace.
+extern "C" int64_t nrx_embed_bwd_sparse_planned_workspace(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim, int32_t n_tables) {
+    return nrx_embed_bwd_dense_planned_workspace(feats, n_feats, batch, dim, n_tables);
+}
+
+extern "C" int nrx_embed_bwd_sparse_planned(const nrx_feature_t* feats, const int32_t* table_of, int32_t n_feats, int32_t n_tables, int64_t batch,
+                                            int32_t dim, const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld,
+                                            const nrx_fm_grad_t* fm, int64_t* uniq_keys, float* values, int64_t* counts, int32_t planner,
+                                            void* state, int64_t* stats, void* workspace, int64_t workspace_bytes, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(feats && table_of && uniq_keys && values && counts && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES && n_tables >= 1 && n_tables <= NRX_MAX_FEATURES,
+                "nrx_embed_bwd_sparse_planned: bad argument");
+    NRX_REQUIRE(workspace != nullptr && workspace_bytes >= nrx_embed_bwd_sparse_planned_workspace(feats, n_feats, batch, dim, n_tables),
+                "nrx_embed_bwd_sparse_planned: workspace too small (nrx_embed_bwd_sparse_planned_workspace)");
+    if (batch == 0) return nrx_zero_async(counts, sizeof(int64_t) * (size_t)(n_tables + 2), reinterpret_cast<hipStream_t>(stream)) == NRX_OK ? NRX_OK : NRX_ERR_LAUNCH;
+    const void* ids[NRX_MAX_FEATURES];
+    int64_t lens[NRX_MAX_FEATURES], rows[NRX_MAX_FEATURES];
+    int64_t n = 0, n_sparse = 0;
+    uint64_t pmask = 0;
+    for (int i = 0; i < n_feats; ++i) {
+        const nrx_feature_t& s = feats[i];
+        NRX_REQUIRE(s.kind == NRX_SPARSE || (s.kind >= NRX_BAG_MASKED_MEAN && s.kind <= NRX_BAG_SUM), "nrx_embed_bwd_sparse_planned: feature %d: kind %d has no table gradient", i, s.kind);
+        NRX_REQUIRE(s.index != nullptr && s.index_bits == feats[0].index_bits && (s.index_bits == 32 || s.index_bits == 64),
+                    "nrx_embed_bwd_sparse_planned: feature %d: ids of one width (32 or 64 bits) are needed", i);
+        NRX_REQUIRE(!(s.flags & NRX_FEAT_BAG_CSR), "nrx_embed_bwd_sparse_planned: feature %d: CSR bags are not planned; expand with nrx_csr_to_padded", i);
+        NRX_REQUIRE(table_of[i] >= 0 && table_of[i] < n_tables && s.rows >= 1, "nrx_embed_bwd_sparse_planned: feature %d: bad table / rows", i);
+        ids[i] = s.index;
+        lens[i] = batch * (s.kind == NRX_SPARSE ? 1 : s.bag_len);
+        rows[i] = s.rows;
+        n += lens[i];
+        if (s.kind == NRX_SPARSE) { pmask |= 1ull << i; n_sparse += batch; }
+    }
+    const bool placed = pmask != 0 && n_sparse * 4 >= n;
+    char* w = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    int64_t* order = (int64_t*)w;     w += nrx_al256(nn * 8);
+    int64_t* seg = (int64_t*)w;       w += nrx_al256((nn + 1) * 8);
+    int32_t* dest = (int32_t*)w;      w += nrx_al256(nn * 4);
+    int32_t* walk = (int32_t*)w;      w += nrx_al256(nn * 4);
+    int64_t* n_walk = (int64_t*)w;    w += 256;                     // [0] walk rows  [1] pair records
+    int32_t* pairs = (int32_t*)w;     w += nrx_al256((size_t)(n / 2 + 1) * 16);
+    void* plan_ws = w;
+    {
+        const size_t a_ = nrx_al256((size_t)nrx_sparse_plan_workspace(n)), b_ = nrx_al256((size_t)nrx_sparse_plan_lds_workspace(n));
+        w += a_ > b_ ? a_ : b_;
+    }
+    void* bwd_ws = w;
+    const int64_t bwd_bytes = nrx_embed_bwd_workspace_for(feats, n_feats, batch, dim);
+    const int ql = ceil_log2((dim + 3) / 4);
+    int rc;
+    if (planner == 1 && state != nullptr && placed && n_sparse == n && dim == (4 << ql) && ql >= 2 && ql <= 4 &&
+        nrx_sparse_plan_lds_ok(lens, table_of, rows, n_feats, n_tables)) {
+        rc = nrx_sparse_plan_lds(ids, lens, table_of, rows, n_feats, feats[0].index_bits, n_tables, order, uniq_keys, seg, counts, dest, walk, n_walk,
+                                 pairs, n_walk + 1, stats, state, plan_ws, stream);
+        if (rc != NRX_OK) return rc;
+        rc = embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, g_wide, wide_ld, order, seg, uniq_keys, n, counts, fm, values, pmask, dest,
+                                   walk, n_walk, bwd_ws, bwd_bytes, stream, nullptr, 0, 0, true, nullptr, pairs, n_walk + 1);
+        if (rc != NRX_ERR_UNSUPPORTED) return rc;           // (outside the pair pass's shapes: nothing was enqueued -- the sorted planner's plan below)
+    }
+    if (placed) rc = nrx_sparse_plan_place(ids, lens, table_of, rows, n_feats, feats[0].index_bits, n_tables, pmask, order, uniq_keys, seg, counts,
+                                           dest, walk, n_walk, plan_ws, stream);
+    else rc = nrx_sparse_plan(ids, lens, table_of, rows, n_feats, feats[0].index_bits, n_tables, order, uniq_keys, seg, counts, plan_ws, stream);
+    if (rc != NRX_OK) return rc;
+    if (stats != nullptr && placed) {
+        rc = nrx_sparse_plan_stats(counts, n_walk, n, stats, stream);
+        if (rc != NRX_OK) return rc;
+    }
+    return embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, g_wide, wide_ld, order, seg, uniq_keys, n, counts, fm, values,
+                                 placed ? pmask : 0, placed ? dest : nullptr, placed ? walk : nullptr, placed ? n_walk : nullptr, bwd_ws,
+                                 bwd_bytes, stream);
+}
+
 // workspace size that also holds the pre-scaled upstream rows of the launch's 0/1-weight bag features
 extern "C" int64_t nrx_embed_bwd_workspace_for(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim) {
     if (feats == nullptr || n_feats < 0 || batch < 0 || dim < 1) return -1;

@@ -711,6 +711,7 @@ DENSE_SMALL_DET = os.environ.get("NRX_DENSE_SMALL", "1") != "0"       # auto mod
 PLAN_AHEAD = True      # row-sparse training: plan the backward (sort, unique rows, segments) at FORWARD time on a side stream
 DENSE_LDS_MIN = int(os.environ.get("NRX_DENSE_LDS_MIN", 1 << 16))       # default-mode launches from this many lookups on go through the one call that
                                                                          # takes the planner as an argument (nrx_embed_bwd_dense_planned)
+SINK_ONE_CALL = os.environ.get("NRX_SINK_ONE_CALL", "1") != "0"           # sink mode, inline plans: plan + reduction as ONE library call (A/B knob)
 PLAN_AHEAD_LDS = os.environ.get("NRX_PLAN_AHEAD_LDS", "0") != "0"      # plan ahead (side stream) even when the group takes the one-kernel planner
 PLAN_AHEAD_MIN = int(os.environ.get("NRX_PLAN_AHEAD_MIN", 1 << 18))      # default-mode launches below this many lookups plan inline (one fused call)
 
@@ -1036,6 +1037,35 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
                 continue
             if rc != NRX_ERR_UNSUPPORTED:
                 check(rc, "nrx_embed_bwd_small_sparse")
+        if pre is None and ctx.sink is not None and SINK_ONE_CALL and n_tables <= NRX_MAX_FEATURES:
+            # fused row-sparse optimizer, nothing planned ahead (a launch group the one-kernel planner takes is planned inline; captured steps): plan +
+            # reduction in ONE library call, every intermediate in a workspace the group keeps from step to step (same stream: the next step's
+            # kernels queue behind this one's) -- three allocations (keys, rows, counts: the sink holds them) and one call instead of thirteen and two
+            pol = _group_policy(grp, B, n_tables)
+            if pol is not None and pol.eligible and not any(plan.slots[i].flags & NRX_FEAT_BAG_CSR for i in fs):
+                ids = [ctx.ins[i] for i in fs]
+                dt = ids[0].dtype
+                if any(x.dtype != dt for x in ids):
+                    ids = [x.long() for x in ids]
+                total = B * n
+                if total == 0:
+                    continue
+                arr = _group_features(grp, ids, [ctx.ws[i] for i in fs], fmg is not None)
+                np.frombuffer(arr, dtype=_feature_np_dtype())["rows"] = grp["rows"]
+                wk = grp.get("sink_ws")
+                if wk is None or wk[0] != (B, stream):
+                    wk = grp["sink_ws"] = ((B, stream), torch.empty(lib.nrx_embed_bwd_sparse_planned_workspace(arr, n, B, D, n_tables), dtype=torch.uint8, device=dev))
+                uniq = torch.empty(total, dtype=torch.int64, device=dev)
+                values = torch.empty((total, D), dtype=torch.float32, device=dev)
+                counts = torch.empty(n_tables + 2, dtype=torch.int64, device=dev)
+                state = _lds_state(dev, stream) if pol.choose() else None
+                check(lib.nrx_embed_bwd_sparse_planned(arr, grp["static"][0], n, n_tables, B, D, _ptr(g_out), ld, _ptr(g_wide), plan.wide_width, fmg,
+                                                       uniq.data_ptr(), values.data_ptr(), counts.data_ptr(), 1 if state is not None else 0,
+                                                       state.data_ptr() if state is not None else None,
+                                                       pol.stats_ptr if PLAN_LDS == "auto" else None, wk[1].data_ptr(), wk[1].numel(), stream),
+                      "nrx_embed_bwd_sparse_planned")
+                ctx.sink.pending.append(dict(tables=ctx.tables, dim=D, uniq=uniq, values=values, counts=counts, cap=total, table_ids=sorted(set(tabs))))
+                continue
         if pre is not None:                 # planned at forward time on the side stream (sparse_plan_ahead)
             ids, pl, ev = pre
             _cur_stream(dev).wait_event(ev)

@@ -153,15 +153,31 @@ def _grads(plan, tables, inputs, g_out, g_fm, lds, sparse, monkeypatch, only_fm=
     monkeypatch.setattr(ops, "PLAN_LDS", "1" if lds else "0")
     plan.__dict__.pop("_sg", None)                         # (the launch groups cache their planner policy)
     ts = [t.clone().requires_grad_() for t in tables]
+    sink = ops.SparseGradSink() if sparse == "sink" else None
     # the row stride padded to whole 128-byte lines (what the model classes do): an odd number of 64-byte features then still goes through the
     # full-line placement pass, whose last pair has one feature
-    out, _, fm = ops.embed_apply(plan, ts, inputs, [None] * len(inputs), out_ld=g_out.shape[1], sparse_grad=sparse)
+    out, _, fm = ops.embed_apply(plan, ts, inputs, [None] * len(inputs), out_ld=g_out.shape[1], sparse_grad=sink if sink is not None else sparse)
     loss = (fm * g_fm).sum() if only_fm else (out * g_out).sum()         # only_fm: the concat gets NO gradient (an FM model's loss reads the logit)
     if fm is not None and not only_fm:
         loss = loss + (fm * g_fm).sum()
     loss.backward()
     torch.cuda.synchronize()
-    return [t.grad.coalesce() if sparse else t.grad for t in ts]
+    if sink is not None:                 # the fused optimizer's sink: (keys, rows, counts) on the device -> one dense tensor per table (every key once)
+        res = [torch.zeros_like(t) for t in ts]
+        keys_seen = 0
+        for e in sink.pending:
+            nu = int(e["counts"][0].item()) if e["counts"] is not None else e["uniq"].numel()
+            k, v = e["uniq"][:nu], e["values"][:nu]
+            live = k >= 0
+            k, v = k[live], v[live]
+            assert torch.unique(k).numel() == k.numel()
+            for ti in range(len(ts)):
+                m = (k >> 40) == ti
+                res[ti][(k[m] & ((1 << 40) - 1))] = v[m]
+            keys_seen += k.numel()
+        assert keys_seen > 0
+        return res
+    return [t.grad.coalesce() if sparse is True else t.grad for t in ts]
 
 
 BWD_CASES = [
@@ -181,7 +197,7 @@ BWD_CASES = [
 
 
 @pytest.mark.parametrize("name,D,n,rows,B,fm,kind", BWD_CASES, ids=[c[0] for c in BWD_CASES])
-@pytest.mark.parametrize("dest", ["row_sparse", "dense", "dense_one_call"])
+@pytest.mark.parametrize("dest", ["row_sparse", "dense", "dense_one_call", "sink_one_call"])
 def test_pairs_backward_equals_sorted_backward_and_float64(name, D, n, rows, B, fm, kind, dest, monkeypatch):
     rng = np.random.default_rng(len(name) * 31 + D)
     monkeypatch.setattr(ops, "DENSE_BWD_SORTED", True)      # dense destination: always the planned reduction
@@ -204,11 +220,13 @@ def test_pairs_backward_equals_sorted_backward_and_float64(name, D, n, rows, B, 
     g_out = torch.zeros((B, ld), dtype=torch.float32, device=DEV)
     g_out[:, :n * D] = torch.from_numpy(rng.standard_normal((B, n * D)).astype(np.float32)).to(DEV)
     g_fm = torch.from_numpy(rng.standard_normal((B,)).astype(np.float32)).to(DEV)
-    sparse = dest == "row_sparse"
+    sparse = True if dest == "row_sparse" else ("sink" if dest == "sink_one_call" else False)
+    if dest == "sink_one_call":
+        monkeypatch.setattr(ops, "SPARSE_SMALL_DET", False)      # (the planned reduction at every size, not the one-launch kernel of small batches)
     a = _grads(plan, tables, inputs, g_out, g_fm, True, sparse, monkeypatch, only_fm)
     b = _grads(plan, tables, inputs, g_out, g_fm, False, sparse, monkeypatch, only_fm)
     for x, y in zip(a, b):
-        if sparse:
+        if sparse is True:
             assert torch.equal(x.indices(), y.indices())
             assert torch.equal(x.values().view(torch.int32), y.values().view(torch.int32))
         else:
@@ -228,7 +246,7 @@ def test_pairs_backward_equals_sorted_backward_and_float64(name, D, n, rows, B, 
         want = R.embedding_grad_dense(ids_np[i], up[i], rows)
         assert not want[0].any()                            # the padding row is looked up (ids 0) and gets no gradient
         for res in (a, b):                                  # the one-kernel plan + pair records, and the sorted plan: each against float64 directly
-            got = (res[i].to_dense() if sparse else res[i]).cpu().numpy()
+            got = (res[i].to_dense() if sparse is True else res[i]).cpu().numpy()
             np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(want).max()))
 
 
