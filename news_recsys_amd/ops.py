@@ -1052,9 +1052,19 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
                     continue
                 arr = _group_features(grp, ids, [ctx.ws[i] for i in fs], fmg is not None)
                 np.frombuffer(arr, dtype=_feature_np_dtype())["rows"] = grp["rows"]
-                wk = grp.get("sink_ws")
-                if wk is None or wk[0] != (B, stream):
-                    wk = grp["sink_ws"] = ((B, stream), torch.empty(lib.nrx_embed_bwd_sparse_planned_workspace(arr, n, B, D, n_tables), dtype=torch.uint8, device=dev))
+                # the workspace: kept per (batch size, stream) between eager steps -- at most four, the least recently used one goes first (its last use
+                # was enqueued on its own stream: the caching allocator orders the reuse behind it).  While a HIP graph is being captured the
+                # workspace is allocated fresh, from the graph's own pool: a captured launch must not point into a buffer this cache may drop
+                if torch.cuda.is_current_stream_capturing():
+                    wk = (None, torch.empty(lib.nrx_embed_bwd_sparse_planned_workspace(arr, n, B, D, n_tables), dtype=torch.uint8, device=dev))
+                else:
+                    cache = grp.setdefault("sink_ws", {})
+                    wk = cache.pop((B, stream), None)
+                    if wk is None:
+                        wk = ((B, stream), torch.empty(lib.nrx_embed_bwd_sparse_planned_workspace(arr, n, B, D, n_tables), dtype=torch.uint8, device=dev))
+                        while len(cache) >= 4:
+                            cache.pop(next(iter(cache)))
+                    cache[(B, stream)] = wk
                 uniq = torch.empty(total, dtype=torch.int64, device=dev)
                 values = torch.empty((total, D), dtype=torch.float32, device=dev)
                 counts = torch.empty(n_tables + 2, dtype=torch.int64, device=dev)

@@ -300,6 +300,25 @@ def test_plan_lds_at_the_real_c2_counts():
         at += k
 
 
+def test_plan_lds_ticket_order_and_more_ranges_than_compute_units(monkeypatch):
+    """Launches of more row ranges than the device has compute units take their ranges in TICKET order (a block may wait only for blocks that
+    have started); NRX_PLAN_LDS_XCD=0 forces that order for any launch.  Both against the definition, repeatedly on one control block."""
+    lib = _lib.load()
+    rng = np.random.default_rng(8)
+    state = torch.zeros(lib.nrx_sparse_plan_lds_state_bytes(), dtype=torch.uint8, device=DEV)
+    T, rows, B = 40, 2_000_000, 1500                       # 40 x 16 = 640 row ranges
+    for _ in range(2):
+        ids = _case_ids(rng, "uniform", B, [rows] * T, T)
+        got = _plan_lds(ids, list(range(T)), [rows] * T, T, state=state)
+        _check_against_definition(got, ids, list(range(T)), [rows] * T, T)
+    monkeypatch.setenv("NRX_PLAN_LDS_XCD", "0")
+    for kind in ("uniform", "dup", "hot"):
+        rws = [300000, 131072, 600000]
+        ids = _case_ids(rng, kind, 6000, rws, 3)
+        got = _plan_lds(ids, [0, 1, 2], rws, 3, state=state)
+        _check_against_definition(got, ids, [0, 1, 2], rws, 3)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_plan_lds_random_shapes(seed):
     """Random launches inside the planner's shapes: 1-9 tables of 1 .. 600 000 rows (several features may share a table), batch 1 .. 7000, ids from
