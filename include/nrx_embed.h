@@ -398,6 +398,15 @@ NRX_API int nrx_fm_fwd(const float* feat, int64_t ld, int32_t n_fields, int32_t 
 NRX_API int nrx_fm_bwd(const float* feat, int64_t ld, int32_t n_fields, int32_t dim, int64_t batch,
                const float* g_fm, const float* g_in, int64_t g_in_ld, float* g_feat, int64_t g_ld, void* stream);
 
+/* FM head: out[b] = sigmoid(bias[0] + logit[b]) -- the last line of FMModel.forward (sort/fm/model.py:25-26; bias: a device scalar, NULL = 0) -- and
+ * its autograd in one launch: g_logit[b] = g_out[b * g_stride] * out[b] (1 - out[b]) (g_stride 0: one upstream value for every sample, what the
+ * gradient of a sum is) and g_bias[0] = sum_b g_logit[b] (NULL: not wanted), summed in a fixed order (bit-reproducible).  state: nrx_fm_head_state_bytes()
+ * device bytes, zero before the first use, then owned by the call (one stream at a time). */
+NRX_API int nrx_fm_head_fwd(const float* logit, const float* bias, float* out, int64_t batch, void* stream);
+NRX_API int64_t nrx_fm_head_state_bytes(void);
+NRX_API int nrx_fm_head_bwd(const float* g_out, int64_t g_stride, const float* out, float* g_logit, float* g_bias, void* state, int64_t batch,
+                    void* stream);
+
 /* ---- DCN v1 cross network: x_{l+1} = x0 * (x_l . w_l) + b_l + x_l ------------------------------
  * DCNLayer.forward / DCNNet.forward (dcn/dcn_arch.py:14-30, 63-70) in the algebraic O(B*D)
  * form (the reference materialises a [B,D,D] outer product).  w, b: device [n_layers, dim].

@@ -98,6 +98,9 @@ SIGNATURES = {
     "nrx_bag_pool_bwd": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     "nrx_fm_fwd": (C.c_int, [_p, _i64, _i32, _i32, _i64, _p, _p]),
     "nrx_fm_bwd": (C.c_int, [_p, _i64, _i32, _i32, _i64, _p, _p, _i64, _p, _i64, _p]),
+    "nrx_fm_head_fwd": (C.c_int, [_p, _p, _p, _i64, _p]),
+    "nrx_fm_head_state_bytes": (_i64, []),
+    "nrx_fm_head_bwd": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _p]),
     "nrx_dcn_v1_fwd": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p]),
     "nrx_dcn_v1_bwd": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p]),
     "nrx_embed_dcn_v1_fwd": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _i32, _p, _i64, _i32, _p, _p, _p, _p]),

@@ -893,6 +893,85 @@ extern "C" int nrx_fm_bwd(const float* feat, int64_t ld, int32_t n_fields, int32
     return NRX_OK;
 }
 
+// ---- FM head: sigmoid(bias + logit) (FMModel.forward, sort/fm/model.py:25-26) and its autograd, one launch each.  As torch ops the head was two
+// launches forward and three backward (add, sigmoid; sigmoid_backward, the bias gradient's sum, ...): 16 us of a 212 us captured step at B = 65 536.
+namespace {
+constexpr int FH_BLOCKS = 64;
+__global__ __launch_bounds__(NRX_BLOCK) void fm_head_fwd_kernel(const float* __restrict__ logit, const float* __restrict__ bias, float* __restrict__ out,
+                                                                int64_t batch) {
+    const float b = bias != nullptr ? bias[0] : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x; i < batch; i += (int64_t)gridDim.x * NRX_BLOCK) {
+        const float x = b + logit[i];
+        out[i] = 1.0f / (1.0f + expf(-x));
+    }
+}
+// g_logit = g_out * p (1 - p); g_bias = sum over the batch, DETERMINISTIC: block j sums its own contiguous slice with fixed trees and leaves
+// partial[j]; the block that arrives last (a counter in `state`, re-armed by that block) adds the partials in index order.
+__global__ __launch_bounds__(NRX_BLOCK) void fm_head_bwd_kernel(const float* __restrict__ g_out, int64_t g_stride, const float* __restrict__ out,
+                                                                float* __restrict__ g_logit, float* __restrict__ g_bias, uint32_t* __restrict__ state,
+                                                                int64_t batch) {
+    __shared__ float s_w[NRX_BLOCK / 64];
+    __shared__ uint32_t s_last;
+    const int64_t chunk = (batch + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < batch ? lo + chunk : batch;
+    float acc = 0.f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += NRX_BLOCK) {
+        const float p = out[i];
+        const float g = g_out[i * g_stride] * (p * (1.0f - p));
+        g_logit[i] = g;
+        acc += g;
+    }
+    if (g_bias == nullptr) return;
+    acc = nrx_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    float* partial = reinterpret_cast<float*>(state + 8);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        __threadfence();
+        s_last = atomicAdd(&state[0], 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x < 64) {
+        __threadfence();
+        float v = (int)threadIdx.x < (int)gridDim.x ? __hip_atomic_load(&partial[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        v = nrx_wave_sum(v);
+        if (threadIdx.x == 0) {
+            g_bias[0] = v;
+            state[0] = 0;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int nrx_fm_head_fwd(const float* logit, const float* bias, float* out, int64_t batch, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(logit && out && batch >= 0, "nrx_fm_head_fwd: bad argument");
+    if (batch == 0) return NRX_OK;
+    const int64_t g = (batch + NRX_BLOCK - 1) / NRX_BLOCK;
+    hipLaunchKernelGGL(fm_head_fwd_kernel, dim3((unsigned)(g < 1024 ? g : 1024)), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), logit, bias, out, batch);
+    NRX_LAUNCH_CHECK("nrx_fm_head_fwd");
+    return NRX_OK;
+}
+
+extern "C" int64_t nrx_fm_head_state_bytes(void) { return 32 + FH_BLOCKS * 4; }
+
+extern "C" int nrx_fm_head_bwd(const float* g_out, int64_t g_stride, const float* out, float* g_logit, float* g_bias, void* state, int64_t batch,
+                               void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(g_out && out && g_logit && batch >= 0 && (g_stride == 0 || g_stride == 1), "nrx_fm_head_bwd: bad argument");
+    NRX_REQUIRE(g_bias == nullptr || state != nullptr, "nrx_fm_head_bwd: the bias gradient needs the state words (nrx_fm_head_state_bytes, zero before the first use)");
+    if (batch == 0) {
+        if (g_bias != nullptr && nrx_zero_async(g_bias, 4, reinterpret_cast<hipStream_t>(stream)) != NRX_OK) return NRX_ERR_LAUNCH;
+        return NRX_OK;
+    }
+    const int64_t g = (batch + 1023) / 1024;
+    hipLaunchKernelGGL(fm_head_bwd_kernel, dim3((unsigned)(g < FH_BLOCKS ? g : FH_BLOCKS)), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), g_out, g_stride,
+                       out, g_logit, g_bias, reinterpret_cast<uint32_t*>(state), batch);
+    NRX_LAUNCH_CHECK("nrx_fm_head_bwd");
+    return NRX_OK;
+}
+
 extern "C" int nrx_dcn_v1_fwd(const float* x, int64_t x_ld, const float* x0, int64_t x0_ld, int64_t batch, int32_t dim,
                               int32_t n_layers, const float* w, const float* b, float* out, int64_t out_ld, void* stream) {
     NRX_TRACE();

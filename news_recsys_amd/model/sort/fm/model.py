@@ -23,7 +23,7 @@ class FMModel(torch.nn.Module):
         return self.from_logit(ops.fm_interaction(feat, Fn, K + 1))
 
     def from_logit(self, fm_logit):
-        return torch.sigmoid(self.bias + fm_logit.unsqueeze(1))
+        return ops.fm_head(fm_logit, self.bias)          # sigmoid(bias + logit) [B, 1]: one launch (and one in the backward)
 
 
 class FM(BaseModel):

@@ -1632,6 +1632,62 @@ class _FmFn(torch.autograd.Function):
         return gfeat, None, None
 
 
+_fm_head_states = {}
+
+
+def _fm_head_state(dev: torch.device, stream: int) -> Optional[torch.Tensor]:
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(stream))
+    st = _fm_head_states.get(key)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        st = torch.zeros(_lib.load().nrx_fm_head_state_bytes(), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        _fm_head_states[key] = st
+    return st
+
+
+class _FmHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logit, bias):
+        lib = _lib.load()
+        logit = _f32c(_dev(logit, "fm logit"), "fm logit").reshape(-1)
+        bias = _f32c(_dev(bias, "fm bias"), "fm bias")
+        out = torch.empty((logit.shape[0], 1), dtype=torch.float32, device=logit.device)
+        check(lib.nrx_fm_head_fwd(logit.data_ptr(), bias.data_ptr(), out.data_ptr(), logit.shape[0], _raw_stream(logit.device)), "nrx_fm_head_fwd")
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (out,) = ctx.saved_tensors
+        B = out.shape[0]
+        dev = out.device
+        stream = _raw_stream(dev)
+        if g.stride(0) == 0 and (g.dim() < 2 or g.shape[1] == 1):
+            gs, stride = g, 0                        # an expanded scalar (the gradient of .sum() / .mean()): read once, not materialised
+        else:
+            gs, stride = _f32c(g, "grad of the fm head"), 1
+        if gs.dtype != torch.float32:
+            gs, stride = _f32c(g.contiguous(), "grad of the fm head"), 1
+        g_logit = torch.empty((B,), dtype=torch.float32, device=dev)
+        want_b = ctx.needs_input_grad[1]
+        state = _fm_head_state(dev, stream) if want_b else None
+        if want_b and state is None:                 # (captured before any eager step made the state words: the torch form)
+            gl = (gs.reshape(-1)[:1].expand(B) if stride == 0 else gs.reshape(-1)) * (out.view(-1) * (1.0 - out.view(-1)))
+            return gl, gl.sum().reshape(1)
+        g_bias = torch.empty((1,), dtype=torch.float32, device=dev) if want_b else None
+        check(lib.nrx_fm_head_bwd(gs.data_ptr(), stride, out.data_ptr(), g_logit.data_ptr(), _ptr(g_bias), _ptr(state), B, stream), "nrx_fm_head_bwd")
+        return g_logit, g_bias
+
+
+def fm_head(fm_logit: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """sigmoid(bias + fm_logit) as [B, 1] -- the last line of FMModel.forward (src/model/sort/fm/model.py:25-26) -- one launch forward, one backward
+    (the bias gradient summed inside it, in a fixed order)."""
+    return _FmHeadFn.apply(fm_logit, bias)
+
+
 def fm_interaction(features: torch.Tensor, n_fields: int, dim: int) -> torch.Tensor:
     """[B, n_fields*dim] -> [B]: sum_f w_f + 0.5*sum_k[(sum_f v)^2 - sum_f v^2] (no bias, no sigmoid)."""
     return _FmFn.apply(features, n_fields, dim)

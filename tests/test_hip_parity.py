@@ -1475,3 +1475,38 @@ def test_dense_value_mid_order_keeps_later_features_on_the_ring_kernel(B, idx, m
             ref[:, s.out_col:s.out_col + s.dim] = tables[s.table].cpu().numpy()[x.cpu().numpy()]
     assert np.array_equal(out.cpu().numpy(), ref)
     assert np.array_equal(out_pad.cpu().numpy()[:, :col], ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 1000, 65536 + 3])
+def test_fm_head_forward_and_backward_vs_float64(B):
+    """ops.fm_head = the last line of FMModel.forward, sigmoid(bias + first + second) (src/model/sort/fm/model.py:25-26), and its autograd: one
+    launch each way.  Against torch in float64 (forward rtol 1e-6; gradients rtol 1e-5), with a per-sample upstream gradient and with the expanded
+    scalar a `.sum()` hands down (read once, not materialised); the bias gradient is summed in a fixed order: same bits run to run."""
+    from news_recsys_amd import ops
+    gen = torch.Generator(device="cuda:0").manual_seed(B)
+    logit = (torch.randn(B, device="cuda:0", generator=gen) * 3).requires_grad_()
+    bias = torch.tensor([0.37], device="cuda:0").requires_grad_()
+    up = torch.randn(B, 1, device="cuda:0", generator=gen)
+    l64, b64 = logit.detach().double().requires_grad_(), bias.detach().double().requires_grad_()
+    ref = torch.sigmoid(b64 + l64.unsqueeze(1))
+    out = ops.fm_head(logit, bias)
+    assert out.shape == (B, 1)
+    torch.testing.assert_close(out.double(), ref, rtol=1e-6, atol=1e-7)
+    (ref * up.double()).sum().backward()
+    (out * up).sum().backward()
+    # (p (1 - p) from the SAVED fp32 p, as torch's sigmoid_backward forms it: where p rounds towards 1 the factor 1 - p carries p's rounding, an
+    # absolute error of ~1e-7 on a gradient of ~1e-3 -- hence the absolute term)
+    torch.testing.assert_close(logit.grad.double(), l64.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bias.grad.double(), b64.grad, rtol=1e-5, atol=1e-6 * max(1.0, float(up.abs().sum()) ** 0.5))
+    gb = bias.grad.clone()
+    for _ in range(3):                                   # the expanded-scalar path, and bit-reproducibility of the bias sum
+        logit.grad = bias.grad = None
+        (ops.fm_head(logit, bias) * up).sum().backward()
+        assert torch.equal(bias.grad.view(torch.int32), gb.view(torch.int32))
+    logit.grad = bias.grad = None
+    l64.grad = b64.grad = None
+    ops.fm_head(logit, bias).sum().backward()
+    torch.sigmoid(b64 + l64.unsqueeze(1)).sum().backward()
+    torch.testing.assert_close(logit.grad.double(), l64.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bias.grad.double(), b64.grad, rtol=1e-5, atol=1e-6 * B ** 0.5 + 1e-5)
