@@ -329,8 +329,16 @@ class SingleGpuPath:
             ins, ws = [], []
             for f in feats:
                 if f["bag"]:
-                    ins.append(draw_ids(f["rows"], (BATCH, f["bag"]), device, gen, id_dist))
-                    ws.append(torch.ones((BATCH, f["bag"]), dtype=torch.float32, device=device))
+                    x = draw_ids(f["rows"], (BATCH, f["bag"]), device, gen, id_dist)
+                    w = torch.ones((BATCH, f["bag"]), dtype=torch.float32, device=device)
+                    if os.environ.get("NRX_BENCH_PADDED_HISTORY") == "1":
+                        # dev knob (never the headline: SURVEY 8d prices the bag as all valid): histories of uniform length 0 .. L padded with id 0
+                        # and mask 0, as the reference's DataReader leaves them
+                        n_valid = torch.randint(0, f["bag"] + 1, (BATCH, 1), device=device, generator=gen)
+                        w = (torch.arange(f["bag"], device=device)[None, :] < n_valid).float()
+                        x = x * w.long()
+                    ins.append(x)
+                    ws.append(w)
                 else:
                     ins.append(draw_ids(f["rows"], (BATCH,), device, gen, id_dist))
                     ws.append(None)

@@ -316,6 +316,12 @@ struct SegArgs {
     uint32_t* bin_start;                              // [n_seg][nb]: global position of every bin's first entry (written by the scatter pass)
     int32_t* work;                                    // [4 + 4 * work_cap]: work[0] = items, then {start, size, low bits, 0} per large bin
     int32_t work_cap;
+    // Padding split (launches with bag features; seg_split_kernel): the lookups of the padding row (id 0, out-of-range ids) -- half of a
+    // padded history -- have nothing to sort: the key kernel writes them, in lookup order, to the FRONT of their table's segment in the buffer the
+    // last pass leaves its result in, and the live pairs compacted behind them; every pass then sorts [seg_off + seg_lo, seg_end) only.
+    int32_t final_b;                                  // the buffer that holds the sorted pairs after the last pass: 0 = first, 1 = second
+    uint32_t* seg_lo;                                 // [n_seg]: padding lookups of the segment (null: no split, every pass sorts whole segments)
+    uint32_t* padcnt;                                 // [tiles]: padding lookups per input tile
 };
 static_assert(sizeof(SegArgs) <= 3584, "kernarg budget");
 __device__ __forceinline__ int seg_db_of(const NRX_CONST SegArgs* a, int seg) {                 // seg wave-uniform: scalar loads and shifts
@@ -355,6 +361,14 @@ __device__ __forceinline__ int seg_block_tile(const NRX_CONST SegArgs* a) {
 }
 __device__ __forceinline__ int seg_of_tile(const NRX_CONST SegArgs* a, int tile) {
     return __builtin_amdgcn_readfirstlane(seg_count_le<int32_t>(a->seg_tile, a->n_seg, tile));
+}
+
+// First entry of `tile` and the end of its segment.  With the padding split the tiles of a segment cover its LIVE zone (the padding pairs at the
+// front are in place already): the last tiles of the segment are then empty (q0 >= qend).
+__device__ __forceinline__ void seg_tile_range(const NRX_CONST SegArgs* a, int tile, int seg, int64_t& q0, int64_t& qend) {
+    const uint32_t lo = a->seg_lo != nullptr ? (uint32_t)__builtin_amdgcn_readfirstlane((int)a->seg_lo[seg]) : 0u;
+    q0 = a->seg_off[seg] + (int64_t)lo + (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE;
+    qend = a->seg_off[seg + 1];
 }
 
 // PAIR (32-bit keys): {key, payload} travel as one 8-byte element through every pass and into plan_count / plan_emit -- the scatter's
@@ -455,17 +469,153 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
     for (int b = threadIdx.x; b < nbins; b += SEG_THREADS) h[b] = s_hist[b];
 }
 
+// ---- padding split (SegArgs::seg_lo).  Rows and payloads of the entries of INPUT tile `tile` (entry j of a thread: q0 + j * SEG_THREADS + tid, as
+// in seg_keys_kernel; row 0 = the padding row: id 0 and out-of-range ids, which the forward reported).
+__device__ __forceinline__ void seg_tile_rows(const NRX_CONST SegArgs* a, int64_t q0, int64_t qend, int64_t (&v)[SEG_PER_THREAD],
+                                              uint32_t (&pay)[SEG_PER_THREAD], uint32_t (&tab)[SEG_PER_THREAD]) {
+    // a wave-uniform walk over the feature slots the tile touches (one, rarely two): every per-slot field is a scalar
+    int s = __builtin_amdgcn_readfirstlane(seg_count_le<int64_t>(a->qoff, a->n_slots, q0));
+    const int64_t tend = qend < q0 + SEG_TILE ? qend : q0 + SEG_TILE;
+#pragma unroll
+    for (int j = 0; j < SEG_PER_THREAD; ++j) { v[j] = 0; pay[j] = 0; tab[j] = 0; }
+    for (;;) {
+        const int64_t s_beg = a->qoff[s], s_end = a->qoff[s + 1], rows = a->rows[s], pb = a->poff[s] - s_beg;
+        const void* idp = a->ids[s];
+        const uint32_t t = seg_table_of(a, s);
+        int64_t id[SEG_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < SEG_PER_THREAD; ++j) {          // all id loads issued before anything waits
+            const int64_t q = q0 + j * SEG_THREADS + threadIdx.x;
+            id[j] = 0;
+            if (q >= s_beg && q < s_end && q < tend) id[j] = a->idx64 ? nrx_gconst<int64_t>(idp)[q - s_beg] : (int64_t)nrx_gconst<int32_t>(idp)[q - s_beg];
+        }
+#pragma unroll
+        for (int j = 0; j < SEG_PER_THREAD; ++j) {
+            const int64_t q = q0 + j * SEG_THREADS + threadIdx.x;
+            if (q >= s_beg && q < s_end && q < tend) {
+                v[j] = id[j] < 0 || id[j] >= rows ? 0 : id[j];
+                pay[j] = (uint32_t)(pb + q);
+                tab[j] = t;
+            }
+        }
+        if (s_end >= tend) break;
+        ++s;
+    }
+}
+
+// padcnt[tile] = the padding lookups among the tile's entries
+__global__ __launch_bounds__(SEG_THREADS) void seg_padcount_kernel(const SegArgs args_in_kernarg) {
+    const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
+    __shared__ uint32_t s_part[SEG_THREADS / 64];
+    const int tile = seg_block_tile(a), seg = seg_of_tile(a, tile);
+    const int64_t q0 = a->seg_off[seg] + (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE, qend = a->seg_off[seg + 1];
+    int64_t v[SEG_PER_THREAD];
+    uint32_t pay[SEG_PER_THREAD], tab[SEG_PER_THREAD];
+    seg_tile_rows(a, q0, qend, v, pay, tab);
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < SEG_PER_THREAD; ++j) c += (q0 + j * SEG_THREADS + threadIdx.x < qend && v[j] == 0) ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < SEG_THREADS / 64; ++w) t += s_part[w];
+        a->padcnt[tile] = t;
+    }
+}
+
+// The key kernel of the split: a stable two-way partition of the segment.  Padding pairs -> [seg_off, seg_off + P) of the buffer the last pass
+// writes (they are in their final place: row 0 sorts first, equal keys keep lookup order); live pairs -> [seg_off + P, seg_end) of the buffer the
+// segment's first pass reads, in lookup order.  P and the counts of the earlier tiles: summed by the block from padcnt[] (a segment has at most
+// SEG_SPLIT_MAX_TILES tiles in this mode).  The first pass's histogram is taken by seg_hist_kernel (the live tiles are not the input tiles).
+constexpr int SEG_SPLIT_MAX_TILES = 8192;
+template <typename KeyT, bool PAIR>
+__global__ __launch_bounds__(SEG_THREADS) void seg_split_kernel(const SegArgs args_in_kernarg, KeyT* __restrict__ keys_a, uint32_t* __restrict__ payload_a,
+                                                                KeyT* __restrict__ keys_b, uint32_t* __restrict__ payload_b) {
+    constexpr int WAVES = SEG_THREADS / 64, NE = WAVES * SEG_PER_THREAD;
+    static_assert(NE <= 64, "one wavefront scans the (round, wavefront) counts");
+    __shared__ uint32_t s_cnt[NE], s_pre[NE], s_part[2][WAVES];
+    const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tile = seg_block_tile(a), seg = seg_of_tile(a, tile);
+    if (a->msd && blockIdx.x == 0 && tid == 0) a->work[0] = 0;       // the scatter pass (a later launch) appends the large bins
+    const int t0 = a->seg_tile[seg], t1 = a->seg_tile[seg + 1];
+    const int64_t q0 = a->seg_off[seg] + (int64_t)(tile - t0) * SEG_TILE, qend = a->seg_off[seg + 1];
+    uint32_t before = 0, all = 0;                    // padding lookups of the segment's earlier tiles / of the whole segment
+    for (int t = t0 + tid; t < t1; t += SEG_THREADS) {
+        const uint32_t c = a->padcnt[t];
+        all += c;
+        before += t < tile ? c : 0u;
+    }
+    int64_t v[SEG_PER_THREAD];
+    uint32_t pay[SEG_PER_THREAD], tab[SEG_PER_THREAD];
+    seg_tile_rows(a, q0, qend, v, pay, tab);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { before += __shfl_xor(before, off, 64); all += __shfl_xor(all, off, 64); }
+    if (lane == 0) { s_part[0][wid] = before; s_part[1][wid] = all; }
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    uint32_t mine[SEG_PER_THREAD];
+    bool pad[SEG_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < SEG_PER_THREAD; ++j) {
+        pad[j] = q0 + j * SEG_THREADS + tid < qend && v[j] == 0;
+        const unsigned long long bal = __ballot(pad[j]);
+        mine[j] = (uint32_t)__popcll(bal & lt);
+        if (lane == 0) s_cnt[j * WAVES + wid] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    if (wid == 0) {                                  // exclusive scan of the counts in entry order: round-major, then wavefront
+        const uint32_t c = lane < NE ? s_cnt[lane] : 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t x = __shfl_up(inc, off, 64); if (lane >= off) inc += x; }
+        if (lane < NE) s_pre[lane] = inc - c;
+    }
+    __syncthreads();
+    before = 0; all = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { before += s_part[0][w]; all += s_part[1][w]; }
+    if (tile == t0 && tid == 0) a->seg_lo[seg] = all;
+    const bool odd = !a->msd && (seg_p0_of(a, seg) & 1) != 0;        // (a segment that starts at an odd pass: its pairs go to the buffer that pass reads)
+    KeyT* __restrict__ lk = odd ? keys_b : keys_a;
+    uint32_t* __restrict__ lp = odd ? payload_b : payload_a;
+    KeyT* __restrict__ pk = a->final_b ? keys_b : keys_a;
+    uint32_t* __restrict__ pp = a->final_b ? payload_b : payload_a;
+    const int64_t pad_base = a->seg_off[seg] + (int64_t)before;
+    const int64_t live_base = a->seg_off[seg] + (int64_t)all + ((int64_t)(tile - t0) * SEG_TILE - (int64_t)before);
+#pragma unroll
+    for (int j = 0; j < SEG_PER_THREAD; ++j) {
+        const int idx = j * SEG_THREADS + tid;
+        if (q0 + idx >= qend) continue;
+        const uint32_t pb = s_pre[j * WAVES + wid] + mine[j];         // padding lookups of the tile before this entry
+        const KeyT key = ((KeyT)tab[j] << a->row_bits) | (KeyT)v[j];
+        const int64_t pos = pad[j] ? pad_base + pb : live_base + ((int64_t)idx - (int64_t)pb);
+        KeyT* kk = pad[j] ? pk : lk;
+        uint32_t* pq = pad[j] ? pp : lp;
+        if (PAIR) reinterpret_cast<uint2*>(kk)[pos] = make_uint2((uint32_t)key, pay[j]);
+        else { kk[pos] = key; pq[pos] = pay[j]; }
+    }
+}
+
 template <typename KeyT, bool PAIR>
 __global__ __launch_bounds__(SEG_THREADS) void seg_hist_kernel(const SegArgs args_in_kernarg, const KeyT* __restrict__ keys, int pass,
                                                              uint32_t* __restrict__ hist) {
     extern __shared__ uint32_t s_hist[];
     const NRX_CONST SegArgs* a = nrx_kernarg<SegArgs>();
     const int tile = seg_block_tile(a), seg = seg_of_tile(a, tile);
-    const int dpass = pass - seg_p0_of(a, seg);
+    const int dpass = a->msd ? 0 : pass - seg_p0_of(a, seg);
     if (dpass < 0) return;                           // the segment sits this pass out
-    const int db = seg_db_of(a, seg), nbins = 1 << db, shift = dpass * db;
+    const int db = seg_db_of(a, seg), nbins = 1 << db, shift = a->msd ? seg_shift_of(a, seg) : dpass * db;
+    int64_t q0, qend;
+    seg_tile_range(a, tile, seg, q0, qend);
+    if (q0 >= qend) {                                // (padding split: a tile past the live zone) -- the scans still sum its row
+        uint32_t* hz = hist + (size_t)tile * a->nb;
+        for (int b = threadIdx.x; b < nbins; b += SEG_THREADS) hz[b] = 0;
+        return;
+    }
     for (int b = threadIdx.x; b < nbins; b += SEG_THREADS) s_hist[b] = 0;
-    const int64_t q0 = a->seg_off[seg] + (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE, qend = a->seg_off[seg + 1];
     const uint32_t dmask = (uint32_t)nbins - 1u;
     KeyT k[SEG_PER_THREAD];
 #pragma unroll
@@ -542,7 +692,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void seg_scan_bins(const SegArgs args_in
     }
     // exclusive scan over the bins in bin order: bin = i * 256 + tid -> scan each i-row across the block, carry between rows
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint32_t carry = (uint32_t)a->seg_off[seg];
+    uint32_t carry = (uint32_t)a->seg_off[seg] + (a->seg_lo != nullptr ? a->seg_lo[seg] : 0u);
     uint32_t* o = bin_base + (size_t)seg * nb;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -587,8 +737,14 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
     uint32_t* s_pay = s_gb + nbins;                       // [SEG_TILE]
     KeyT* s_key = reinterpret_cast<KeyT*>(s_pay + SEG_TILE);      // [SEG_TILE]
     __shared__ uint32_t s_part[WAVES], s_gpart[WAVES];
+    int64_t q0, qend;
+    seg_tile_range(a, tile, seg, q0, qend);
+    if (q0 >= qend) {                                // (padding split: a tile past the live zone)
+        if (DIRECT == 1 && a->msd && tile == a->seg_tile[seg])       // a segment of padding lookups only: every bin is empty
+            for (int b = tid; b < nbins; b += SEG_THREADS) a->bin_start[(size_t)seg * nb + b] = (uint32_t)qend;
+        return;
+    }
     for (int b = tid; b < WAVES * nbins / 2; b += SEG_THREADS) s_mem[b] = 0;
-    const int64_t q0 = a->seg_off[seg] + (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE, qend = a->seg_off[seg + 1];
     const int count = (int)(qend - q0 < SEG_TILE ? qend - q0 : SEG_TILE);
     const int64_t qw = q0 + (int64_t)wid * (64 * ROUNDS) + lane;         // wave w owns entries [w * 512, (w + 1) * 512) of the tile
     const uint32_t dmask = (uint32_t)nbins - 1u;
@@ -687,7 +843,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs 
         }
         tot[i] = run;
     }
-    uint32_t carry = 0, gcarry = DIRECT ? (uint32_t)a->seg_off[seg] : 0u;
+    uint32_t carry = 0, gcarry = DIRECT ? (uint32_t)(q0 - (int64_t)(tile - a->seg_tile[seg]) * SEG_TILE) : 0u;      // the segment's first (live) entry
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         if (i * SEG_THREADS >= nbins) break;
@@ -947,7 +1103,8 @@ inline size_t seg_work_cap(size_t n) { return n / SEG_SMALL_BIN + 64; }      // 
 inline size_t seg_scratch_bytes(size_t n) {
     const size_t tiles = n / SEG_TILE + NRX_MAX_FEATURES + 1;          // hist rows; ctot has at most as many rows as there are tiles / 32 + segments
     return align256((tiles + tiles / SEG_CHUNK + 2 * (size_t)NRX_MAX_FEATURES + 1) * ((size_t)1 << SEG_MAX_DB) * sizeof(uint32_t)) +
-           align256(((size_t)NRX_MAX_FEATURES << SEG_MAX_DB) * sizeof(uint32_t)) + align256((4 + 4 * seg_work_cap(n)) * sizeof(int32_t));      // MSD: bin starts, work list
+           align256(((size_t)NRX_MAX_FEATURES << SEG_MAX_DB) * sizeof(uint32_t)) + align256((4 + 4 * seg_work_cap(n)) * sizeof(int32_t)) +      // MSD: bin starts, work list
+           align256(tiles * sizeof(uint32_t)) + 256;                                                                                               // padding split: padcnt, seg_lo
 }
 
 int bits_for(int64_t v) {      // bits needed to represent values 0 .. v-1 (at least 1)
@@ -1023,7 +1180,7 @@ extern "C" int64_t nrx_sparse_plan_workspace(int64_t n_lookups) {
 static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
                             int32_t n_feats, int32_t index_bits, int32_t n_tables, int64_t* order, int64_t* uniq_keys,
                             int64_t* seg_start, int64_t* counts, uint64_t place_feats, int32_t* dest, int32_t* walk, int64_t* n_walk,
-                            void* workspace, void* stream) {
+                            void* workspace, void* stream, uint32_t opt_flags = 0) {
     NRX_REQUIRE(n_feats >= 0 && n_feats <= NRX_MAX_FEATURES && (index_bits == 32 || index_bits == 64) && n_tables >= 1 && n_tables < (1 << 20),
                 "nrx_sparse_plan: bad argument");
     NRX_REQUIRE(counts != nullptr, "nrx_sparse_plan: null counts");
@@ -1172,6 +1329,25 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
             sa.work_cap = (int32_t)seg_work_cap((size_t)n);
             sa.small_max = SEG_SMALL_BIN;
             sa.msd = msd ? 1 : 0;
+            sa.padcnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sa.work) + align256((4 + 4 * seg_work_cap((size_t)n)) * sizeof(int32_t)));
+            sa.seg_lo = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sa.padcnt) + align256(tiles_cap * sizeof(uint32_t)));
+            sa.final_b = msd ? 1 : (passes & 1);
+        }
+        // Padding split (SegArgs::seg_lo), asked for by the caller (nrx_sparse_plan_ex, NRX_PLAN_SPLIT_PADDING): worth it when a large share of the
+        // lookups name the padding row (padded histories: 142 -> 114 us for 3.4 M lookups, half of them padding) -- two more launches (the
+        // count, the first pass's histogram), then every pass on the live pairs only; a launch without padding pays ~17 us for nothing, and the
+        // planner cannot know: the caller does, from the statistics of its previous batch.  NRX_PLAN_PADSPLIT=1 / 0 forces / forbids it
+        // (tests run every planner case both ways).
+        bool split = (opt_flags & NRX_PLAN_SPLIT_PADDING) != 0;
+        {
+            const char* e = getenv("NRX_PLAN_PADSPLIT");
+            if (e && e[0] == '1') split = true;
+            else if (e && e[0] == '0') split = false;
+            for (int t = 0; t < n_tables && split; ++t)
+                if (sa.seg_tile[t + 1] - sa.seg_tile[t] > SEG_SPLIT_MAX_TILES) split = false;
+            if (!split) { sa.seg_lo = nullptr; sa.padcnt = nullptr; }
+            else if (getenv("NRX_SEG_XCD") == nullptr) sa.xcd = 0;         // the live tiles are the FIRST tiles of a segment: in XCD order (an eighth of the tile list per XCD) the empty tiles
+                                     // of a half-padding segment would idle whole XCDs; in launch order consecutive tiles alternate over the XCDs
         }
         const size_t lds_hist = (size_t)nb * 4;
         const dim3 gchunks((unsigned)((nb + NRX_BLOCK - 1) / NRX_BLOCK), (unsigned)chunk);
@@ -1188,7 +1364,13 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
         (void)lds_ok;                                                                                                     \
         KeyT* src = (KeyT*)keys_in; KeyT* dst = (KeyT*)keys_out;                                                          \
         uint32_t* psrc = pay_in; uint32_t* pdst = pay_out;                                                                \
-        hipLaunchKernelGGL((seg_keys_kernel<KeyT, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, src, psrc, hist, dst, pdst); \
+        if (split) {                                                                                                      \
+            hipLaunchKernelGGL(seg_padcount_kernel, dim3((unsigned)tile), dim3(SEG_THREADS), 0, st, sa);                         \
+            hipLaunchKernelGGL((seg_split_kernel<KeyT, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), 0, st, sa, src, psrc, dst, pdst); \
+            if (msd) hipLaunchKernelGGL((seg_hist_kernel<KeyT, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, (const KeyT*)src, 0, hist); \
+        } else {                                                                                                          \
+            hipLaunchKernelGGL((seg_keys_kernel<KeyT, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, src, psrc, hist, dst, pdst); \
+        }                                                                                                                 \
         if (msd) {                                                                                                        \
             hipLaunchKernelGGL((seg_scatter_kernel<KeyT, 1, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_scatter, st, sa, (const KeyT*)src, \
                                (const uint32_t*)psrc, 0, (const uint32_t*)hist, (const uint32_t*)ctot, (const uint32_t*)bin_base, dst, pdst); \
@@ -1198,7 +1380,7 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
                                sa, src, psrc, dst, pdst);                                                                 \
         }                                                                                                                 \
         for (int pass = 0; pass < (msd ? 0 : passes); ++pass) {                                                           \
-            if (pass > 0) hipLaunchKernelGGL((seg_hist_kernel<KeyT, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, (const KeyT*)src, pass, hist); \
+            if (pass > 0 || split) hipLaunchKernelGGL((seg_hist_kernel<KeyT, PAIR_>), dim3((unsigned)tile), dim3(SEG_THREADS), lds_hist, st, sa, (const KeyT*)src, pass, hist); \
             if (chunked && (max_chunks > SEG_DIRECT_CHUNKS || force_bins)) {                                              \
                 hipLaunchKernelGGL(seg_scan_chunks, gchunks, dim3(NRX_BLOCK), 0, st, sa, hist, ctot, pass);                      \
                 hipLaunchKernelGGL(seg_scan_bins, dim3((unsigned)n_tables), dim3(NRX_BLOCK), 0, st, sa, hist, ctot, bin_base, pass); \
@@ -1278,6 +1460,44 @@ extern "C" int nrx_sparse_plan_place(const void* const* ids, const int64_t* lens
     NRX_REQUIRE(dest != nullptr && walk != nullptr && n_walk != nullptr, "nrx_sparse_plan_place: null placement buffer");
     return sparse_plan_impl(ids, lens, table_of, rows, n_feats, index_bits, n_tables, order, uniq_keys, seg_start, counts, place_feats,
                             dest, walk, n_walk, workspace, stream);
+}
+
+namespace {
+// {unique rows, walk rows (-1: plan without placement), -1, n, lookups of the padding rows} of a finished plan
+__global__ void plan_ex_stats_kernel(const int64_t* __restrict__ uniq, const int64_t* __restrict__ seg_start, const int64_t* __restrict__ counts,
+                                     const int64_t* __restrict__ n_walk, int n_tables, int64_t n, int64_t* __restrict__ stats) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int64_t pads = 0;
+    for (int t = 0; t < n_tables; ++t) {
+        const int64_t first = counts[1 + t], last = counts[2 + t];
+        if (first < last && (uniq[first] & ((1ll << 40) - 1)) == 0) pads += seg_start[first + 1] - seg_start[first];
+    }
+    stats[0] = counts[0];
+    stats[1] = n_walk != nullptr ? n_walk[0] : -1;
+    stats[2] = -1;
+    stats[3] = n;
+    stats[4] = pads;
+}
+}  // namespace
+
+extern "C" int nrx_sparse_plan_ex(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
+                                  int32_t n_feats, int32_t index_bits, int32_t n_tables, uint64_t place_feats, uint32_t flags, int64_t* order,
+                                  int64_t* uniq_keys, int64_t* seg_start, int64_t* counts, int32_t* dest, int32_t* walk,
+                                  int64_t* n_walk, int64_t* stats, void* workspace, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE((dest != nullptr) == (walk != nullptr) && (dest != nullptr) == (n_walk != nullptr),
+                "nrx_sparse_plan_ex: dest, walk and n_walk go together (all null: the plan without placement)");
+    NRX_REQUIRE((flags & ~(uint32_t)NRX_PLAN_SPLIT_PADDING) == 0, "nrx_sparse_plan_ex: unknown flag");
+    const int rc = sparse_plan_impl(ids, lens, table_of, rows, n_feats, index_bits, n_tables, order, uniq_keys, seg_start, counts,
+                                    dest != nullptr ? place_feats : 0, dest, walk, n_walk, workspace, stream, flags);
+    if (rc != NRX_OK || stats == nullptr) return rc;
+    int64_t n = 0;
+    for (int f = 0; f < n_feats; ++f) n += lens[f];
+    if (n == 0) return rc;                    // (nothing planned: the caller's statistics stay as they are)
+    hipLaunchKernelGGL(plan_ex_stats_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), uniq_keys, seg_start, counts, n_walk,
+                       n_tables, n, stats);
+    NRX_LAUNCH_CHECK("nrx_sparse_plan_ex(stats)");
+    return NRX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------

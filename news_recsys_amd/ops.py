@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_ERR_UNSUPPORTED, NRX_FEAT_BAG_CSR, NRX_FEAT_ROW0_IS_DATA, NRX_MAX_FEATURES, NRX_SPARSE,
+from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_ERR_UNSUPPORTED, NRX_FEAT_BAG_CSR, NRX_PLAN_SPLIT_PADDING, NRX_FEAT_ROW0_IS_DATA, NRX_MAX_FEATURES, NRX_SPARSE,
                    NrxFeature, NrxFmGrad, check)
 
 # ------------------------------------------------------------------------------- helpers
@@ -595,7 +595,7 @@ class _EmbedFn(torch.autograd.Function):
                         break
                 ctx.plans[(g_["dim"], fs_[0])] = (ids_,) + sparse_plan_ahead(ids_, g_["tabs"], g_["rows"], len(tables),
                                                                           g_["pmask"] if SPARSE_PLACE else None, static=g_["static"],
-                                                                          policy=pol_)
+                                                                          policy=pol_, pad=_group_pad(g_, plan, B))
         if ctx.has_fm_feat:
             ctx.save_for_backward(out)
         ctx.set_materialize_grads(False)
@@ -794,8 +794,32 @@ class PlanPolicy:
         return self.use_lds
 
 
+PAD_SPLIT = os.environ.get("NRX_PAD_SPLIT", "auto")                     # auto: by the previous batch's share of padding lookups; 1 / 0: always / never
+PAD_SPLIT_MIN = int(os.environ.get("NRX_PAD_SPLIT_MIN", 3 << 19))      # lookups per launch group from which the split is considered (1.5 M)
+
+
+class PadPolicy:
+    """Per launch group with multi-valued features: should the planner set the padding lookups aside before it sorts
+    (NRX_PLAN_SPLIT_PADDING)?  Histories padded to max_len with id 0 (the reference's DataReader) are half padding -- the split plans
+    3.4 M such lookups in 114 us instead of 142 -- but a launch without padding loses ~17 us to it, and only the data knows: every plan leaves
+    its count of padding lookups in a mapped host word (no synchronisation), the next batch of the same size decides by it -- from a quarter
+    of the lookups on."""
+
+    def __init__(self, total: int):
+        self.total = int(total)
+        self.stats = torch.zeros(5, dtype=torch.int64).pin_memory()
+        self.stats_ptr = self.stats.data_ptr()
+        self._np = self.stats.numpy()
+
+    def choose(self) -> bool:
+        if PAD_SPLIT != "auto":
+            return PAD_SPLIT == "1"
+        n, pads = int(self._np[3]), int(self._np[4])
+        return n == self.total and pads * 4 >= n
+
+
 def sparse_plan_ahead(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int,
-                      place_feats: Optional[int] = None, static=None, policy: Optional["PlanPolicy"] = None):
+                      place_feats: Optional[int] = None, static=None, policy: Optional["PlanPolicy"] = None, pad: Optional["PadPolicy"] = None):
     """sparse_plan on a side stream: the planning of the backward depends only on the ids, so it can run while the forward,
     the dense part of the model and its backward occupy the main stream.  Returns ((order, uniq, seg, counts), event);
     the consumer makes its stream wait for `event` before reading the plan."""
@@ -809,7 +833,7 @@ def sparse_plan_ahead(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows
     # was enqueued on the caller's stream before that point, so the side stream's writes are ordered behind it; they are consumed (and
     # later freed) on the caller's stream behind `ev`.  No record_stream anywhere.
     hold = []
-    res = sparse_plan(ids, table_of, rows, n_tables, place_feats, static=static, stream=side.cuda_stream, keep=hold, policy=policy)
+    res = sparse_plan(ids, table_of, rows, n_tables, place_feats, static=static, stream=side.cuda_stream, keep=hold, policy=policy, pad=pad)
     ev = torch.cuda.Event()
     ev.record(side)
     # The planner READS the ids on the side stream: an id tensor that dies early (a .long() / .contiguous() temporary, a
@@ -844,7 +868,7 @@ def place_mask(kinds: Sequence[int], bag_lens: Optional[Sequence[int]] = None) -
 
 def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int,
                 place_feats: Optional[int] = None, static=None, stream: Optional[int] = None, keep: Optional[list] = None,
-                policy: Optional["PlanPolicy"] = None):
+                policy: Optional["PlanPolicy"] = None, pad: Optional["PadPolicy"] = None):
     """nrx_sparse_plan: group the flat, feature-major lookups `ids` (one device tensor per feature, all int32 or
     all int64) by (table, row).  Returns device int64 tensors (order [n], uniq_keys [n], seg_start [n+1],
     counts [n_tables+2]); only the first counts[0] entries of uniq_keys / counts[0]+1 of seg_start are
@@ -854,7 +878,9 @@ def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequ
     and n_walk int64 [1]: what nrx_embed_bwd_placed consumes.
     policy (PlanPolicy of the launch group): when it picks the one-kernel planner (nrx_sparse_plan_lds) the result has EIGHT entries -- the
     seven above (order / seg defined for the walk rows only; n_walk int64 [2]: walk rows, pair records) plus pairs int32 [n / 2 + 1, 4], the
-    records {unique index, first lookup, second lookup, 0} of the rows looked up twice -- and goes to nrx_embed_bwd_placed_pairs."""
+    records {unique index, first lookup, second lookup, 0} of the rows looked up twice -- and goes to nrx_embed_bwd_placed_pairs.
+    pad (PadPolicy of a launch group with multi-valued features): nrx_sparse_plan_ex -- the same plan, the padding lookups set aside before the
+    sort when the previous batch held enough of them, this batch's count left for the next one."""
     lib = _lib.load()
     n = len(ids)
     dev = ids[0].device
@@ -896,6 +922,17 @@ def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequ
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     if not own_stream and keep is not None:
         keep.append(ws)          # a foreign stream: the caller holds the workspace until the plan has run (sparse_plan_ahead)
+    if pad is not None and total > 0:
+        dest = walk = n_walk = None
+        if place_feats is not None:
+            dest = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+            walk = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+            n_walk = torch.empty(1, dtype=torch.int64, device=dev)
+        check(lib.nrx_sparse_plan_ex(ptrs, lens, tof, rws, n, ids[0].element_size() * 8, n_tables, int(place_feats or 0),
+                                     NRX_PLAN_SPLIT_PADDING if pad.choose() else 0, order.data_ptr(), uniq.data_ptr(), seg.data_ptr(),
+                                     counts.data_ptr(), _ptr(dest), _ptr(walk), _ptr(n_walk), pad.stats_ptr, ws.data_ptr(), stream),
+              "nrx_sparse_plan_ex")
+        return (order, uniq, seg, counts) if dest is None else (order, uniq, seg, counts, dest, walk, n_walk)
     if place_feats is not None:
         dest = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
         walk = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
@@ -978,6 +1015,18 @@ def _group_policy(grp, B: int, n_tables: int) -> Optional["PlanPolicy"]:
         grp["policy"] = PlanPolicy(lens, grp["static"][0], grp["static"][1], n, n_tables, B * n)
         grp["policy_B"] = B
     return grp["policy"]
+
+
+def _group_pad(grp, plan: EmbedPlan, B: int) -> Optional["PadPolicy"]:
+    """The launch group's PadPolicy at batch size B: groups with multi-valued features from PAD_SPLIT_MIN lookups on, else None."""
+    if PAD_SPLIT == "0":
+        return None
+    ent = grp.get("pad")
+    if ent is None or ent[0] != B:
+        total = sum(B * max(1, plan.slots[i].bag_len) for i in grp["fs"])
+        bags = any(plan.slots[i].kind != NRX_SPARSE for i in grp["fs"])
+        ent = grp["pad"] = (B, PadPolicy(total) if bags and total >= PAD_SPLIT_MIN else None)
+    return ent[1]
 
 
 def _sparse_groups(plan: EmbedPlan):
@@ -1129,7 +1178,7 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
             if total == 0:
                 continue
             pl = sparse_plan(ids, tabs, grp["rows"], n_tables, pmask, static=grp["static"],
-                             policy=_group_policy(grp, B, n_tables) if n_tables <= NRX_MAX_FEATURES else None)
+                             policy=_group_policy(grp, B, n_tables) if n_tables <= NRX_MAX_FEATURES else None, pad=_group_pad(grp, plan, B))
         uniq, counts = pl[1], pl[3]
 
         def replan(ids=ids, tabs=tabs, grp=grp, pmask=pmask):
@@ -1493,6 +1542,8 @@ class PreparedSparseBackward:
                 if g["policy"].eligible:
                     g["lds_ws"] = torch.empty(self.lib.nrx_sparse_plan_lds_workspace(total), dtype=torch.uint8, device=dev)
                     g["pair_recs"] = torch.empty((total // 2 + 1, 4), dtype=torch.int32, device=dev)
+            # multi-valued features: the padding lookups are set aside when the previous plan counted enough of them (PadPolicy)
+            g["pad"] = PadPolicy(total) if PAD_SPLIT != "0" and total >= PAD_SPLIT_MIN and any(plan.slots[i].kind != NRX_SPARSE for i in fs) else None
             self.groups.append(g)
 
     def _plan(self, stream):
@@ -1512,7 +1563,14 @@ class PreparedSparseBackward:
                         continue
                     if rc != NRX_ERR_UNSUPPORTED:
                         check(rc, "nrx_sparse_plan_lds")
-            if g["pmask"] is not None:
+            if g["pad"] is not None:
+                pm = g["pmask"] is not None
+                rc = lib.nrx_sparse_plan_ex(g["ptrs"], g["lens"], g["tof"], g["rws"], g["n"], g["bits"], g["n_tables"], g["pmask"] or 0,
+                                            NRX_PLAN_SPLIT_PADDING if g["pad"].choose() else 0, g["order"].data_ptr(), g["uniq"].data_ptr(),
+                                            g["seg"].data_ptr(), g["counts"].data_ptr(), g["dest"].data_ptr() if pm else None,
+                                            g["walk"].data_ptr() if pm else None, g["n_walk"].data_ptr() if pm else None,
+                                            g["pad"].stats_ptr, g["ws"].data_ptr(), stream)
+            elif g["pmask"] is not None:
                 rc = lib.nrx_sparse_plan_place(g["ptrs"], g["lens"], g["tof"], g["rws"], g["n"], g["bits"], g["n_tables"], g["pmask"],
                                                g["order"].data_ptr(), g["uniq"].data_ptr(), g["seg"].data_ptr(), g["counts"].data_ptr(),
                                                g["dest"].data_ptr(), g["walk"].data_ptr(), g["n_walk"].data_ptr(), g["ws"].data_ptr(), stream)

@@ -113,6 +113,64 @@ def test_placed_backward_with_bag_features_equals_sorted_walk(kind, dist, monkey
     _same(a, d)
 
 
+@pytest.mark.parametrize("dest", ["row_sparse", "dense"])
+def test_padded_history_steps_switch_to_the_padding_split_and_keep_their_gradients(dest, monkeypatch):
+    """The DSSM tower on histories padded with id 0 (the reference's DataReader pads every multi-valued feature to max_len): the first step plans
+    with the padding lookups in the sort and records how many there were (PadPolicy: a mapped host word, no synchronisation), the next step of
+    the same shape sets them aside before the sort (nrx_sparse_plan_ex, NRX_PLAN_SPLIT_PADDING) -- same gradients bit for bit, and equal to
+    NRX_PAD_SPLIT=0.  A batch without padding switches back."""
+    rng = np.random.default_rng(23)
+    D, L, B, news, users = 16, 20, 9000, 50000, 300000
+    monkeypatch.setattr(ops, "PAD_SPLIT_MIN", 1000)
+    monkeypatch.setattr(ops, "PLAN_AHEAD_MIN", 1000)                 # (the dense mode plans such a launch ahead too: the path that carries the policy)
+    monkeypatch.setattr(ops, "DENSE_BWD_SORTED", True)
+    slots = [ops.Slot("item_id", NRX_SPARSE, 0, D, 0, 0), ops.Slot("user_history", NRX_BAG_MASKED_MEAN, 0, D, L, D), ops.Slot("user_id", NRX_SPARSE, 1, D, 0, 2 * D)]
+    plan = ops.EmbedPlan(slots, out_width=3 * D)
+    tables = [torch.from_numpy(rng.standard_normal((r, D)).astype(np.float32)).to(DEV) for r in (news, users)]
+    lens = rng.integers(0, L + 1, B)
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.float32)
+    hist = np.where(mask > 0, rng.integers(1, news, (B, L)), 0)
+    full = rng.integers(1, news, (B, L))
+    item, user = rng.integers(1, news, B), rng.integers(1, users, B)
+    g_out = torch.from_numpy(rng.standard_normal((B, 3 * D)).astype(np.float32)).to(DEV)
+
+    ts = [t.clone().requires_grad_() for t in tables]               # (the launch groups -- and their policies -- are kept per table set)
+
+    def step(h, m, split):
+        monkeypatch.setattr(ops, "PAD_SPLIT", split)
+        for t in ts:
+            t.grad = None
+        out = ops.embed_apply(plan, ts, [torch.from_numpy(item).to(DEV), torch.from_numpy(h).to(DEV), torch.from_numpy(user).to(DEV)],
+                              [None, torch.from_numpy(m).to(DEV), None], sparse_grad=dest == "row_sparse")[0]
+        (out * g_out).sum().backward()
+        torch.cuda.synchronize()
+        return [t.grad.coalesce() if dest == "row_sparse" else t.grad for t in ts]
+
+    def same(ga, gb):
+        if dest == "row_sparse":
+            _same(ga, gb)
+        else:
+            for a, b in zip(ga, gb):
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+    ref = step(hist, mask, "0")
+    pol = ops._group_pad(ops._sparse_group_cache(plan, ts)[0], plan, B)
+    assert pol is None                                              # NRX_PAD_SPLIT=0: no policy, the plain planner calls
+    first = step(hist, mask, "auto")
+    pol = ops._group_pad(ops._sparse_group_cache(plan, ts)[0], plan, B)
+    assert pol is not None and int(pol.stats[4]) == int((hist == 0).sum()) and pol.choose()      # recorded by the first step: the next one splits
+    second = step(hist, mask, "auto")
+    same(ref, first)
+    same(ref, second)
+    ones = np.ones_like(mask)
+    a = step(full, ones, "auto")                                    # (planned with the split; finds no padding)
+    assert int(pol.stats[4]) == 0 and not pol.choose()
+    b = step(full, ones, "auto")
+    c = step(full, ones, "0")
+    same(a, c)
+    same(b, c)
+
+
 @pytest.mark.parametrize("live_zero", [False, True])
 @pytest.mark.parametrize("D", [16, 32, 64])
 def test_bag_backward_prescaled_rows_with_and_without_weight_bits(live_zero, D, monkeypatch):

@@ -209,6 +209,71 @@ def test_sparse_plan_segmented_sort_matches_definition(lens, row_bits, tabs, ske
     os.environ.pop("NRX_PLAN_SORT", None)
 
 
+@pytest.mark.gpu
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(lens=st.lists(st.integers(min_value=0, max_value=9000), min_size=1, max_size=6),
+       big=st.integers(min_value=0, max_value=300_000),
+       row_bits=st.lists(st.integers(min_value=1, max_value=26), min_size=7, max_size=7),
+       tabs=st.lists(st.integers(min_value=0, max_value=3), min_size=7, max_size=7),
+       pad=st.sampled_from([0.0, 0.5, 0.9, 1.0]), seed=st.integers(0, 2 ** 16),
+       sort=st.sampled_from([None, "msd", "lsd", "segmented-bins"]), place=st.booleans(), idx32=st.booleans())
+def test_sparse_plan_ex_padding_split_matches_definition(lens, big, row_bits, tabs, pad, seed, sort, place, idx32):
+    """nrx_sparse_plan_ex with NRX_PLAN_SPLIT_PADDING (the padding lookups set aside before the sort, every pass on the live lookups only) ==
+    the definition, bit for bit, like the unsplit plan: padded histories (a share `pad` of every feature's ids is 0; 1.0: a table that sees
+    padding only), one long feature (chunked segments), every sort form, with and without the placement outputs; and the statistics it leaves
+    (unique rows, walk rows, lookups, padding lookups) are this plan's."""
+    import os
+    import torch
+    from news_recsys_amd import ops
+    if sort:
+        os.environ["NRX_PLAN_SORT"] = sort
+    else:
+        os.environ.pop("NRX_PLAN_SORT", None)
+    rng = np.random.default_rng(seed)
+    lens = list(lens) + [big]
+    n = len(lens)
+    tab = tabs[:n]
+    nt = max(tab) + 1
+    rows_of_table = [max((1 << row_bits[t]) - (seed % 3 if row_bits[t] > 2 else 0), 1) for t in range(nt)]
+    rows = [rows_of_table[t] for t in tab]
+    ids = []
+    for ln, r in zip(lens, rows):
+        x = rng.integers(0, r, ln)
+        x = np.where(rng.random(ln) < pad, 0, x)
+        ids.append(x.astype(np.int32 if idx32 else np.int64))
+    feats = [f for f in range(n) if (seed >> f) & 1] if seed % 4 else list(range(n))
+    total = sum(lens)
+    pol = ops.PadPolicy(total)
+    prev = ops.PAD_SPLIT
+    ops.PAD_SPLIT = "1"
+    try:
+        res = ops.sparse_plan([torch.from_numpy(x).to("cuda:0") for x in ids], tab, rows, nt,
+                              place_feats=sum(1 << f for f in feats) if place else None, pad=pol)
+        torch.cuda.synchronize()
+    finally:
+        ops.PAD_SPLIT = prev
+        os.environ.pop("NRX_PLAN_SORT", None)
+    if total == 0:
+        return
+    ids64 = [x.astype(np.int64) for x in ids]
+    o_r, u_r, s_r, c_r, d_r, w_r = R.sparse_plan_place(ids64, tab, rows, nt, feats)
+    order, uniq, seg, counts = res[:4]
+    c = counts.cpu().numpy()
+    assert np.array_equal(c, c_r)
+    nu = int(c[0])
+    assert np.array_equal(order.cpu().numpy(), o_r)
+    assert np.array_equal(uniq.cpu().numpy()[:nu], u_r)
+    assert np.array_equal(seg.cpu().numpy()[:nu + 1], s_r)
+    if place:
+        dest, walk, n_walk = res[4:]
+        assert int(n_walk.item()) == len(w_r) and np.array_equal(walk.cpu().numpy()[:len(w_r)], w_r)
+        able = np.isin(np.repeat(np.arange(n), lens), feats)
+        assert np.array_equal(dest.cpu().numpy()[:len(d_r)][able], d_r[able])
+    st_ = pol.stats.numpy()
+    assert st_[0] == nu and st_[3] == total and st_[4] == sum(int((x == 0).sum()) for x in ids)
+    assert st_[1] == (len(w_r) if place else -1)
+
+
 def test_oracle_sparse_plan_place_definition():
     """The placement definition itself, on a case small enough to read: dest names the unique index of a row looked up once
     (not row 0, placeable feature), walk lists every other unique row."""
