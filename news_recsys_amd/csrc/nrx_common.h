@@ -28,6 +28,7 @@ struct NrxTrace {
 #define NRX_TRACE() NrxTrace nrx_trace_scope__(__func__)
 // zero-fill by a kernel launch (capture-safe replacement of hipMemsetAsync; see nrx_lib.hip); p and bytes dword-aligned
 int nrx_zero_async(void* p, size_t bytes, hipStream_t st);
+int nrx_zero2_async(void* p, size_t bytes_p, void* q, size_t bytes_q, hipStream_t st);
 
 #define NRX_REQUIRE(cond, ...)                \
     do {                                      \

@@ -3295,7 +3295,8 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             // the four work-list counters are cleared by a kernel (nrx_zero_async), not hipMemsetAsync: inside a captured HIP graph
             // the 16-byte memset node did not take effect on replay (counters kept growing, the list was read past what was written)
             // (placement mode: the placement pass clears them -- one launch less)
-            if (!(placed && n_place > 0) && nrx_zero_async(a.long_ws, 16, st) != NRX_OK) return NRX_ERR_LAUNCH;
+            // (launches with bag features: cleared together with the weight-bit words below -- one launch, not two)
+            if (!(placed && n_place > 0) && !has_bag && nrx_zero_async(a.long_ws, 16, st) != NRX_OK) return NRX_ERR_LAUNCH;
             const bool side_zero = pairs && placed && n_place > 0 && aux_stream != nullptr && aux_stream != stream;      // (side-stream mode: the placement pass
             if (side_zero && nrx_zero_async(a.long_ws, 16, reinterpret_cast<hipStream_t>(aux_stream)) != NRX_OK) return NRX_ERR_LAUNCH;      //  runs elsewhere: the counters are cleared on the walk's stream)
         }
@@ -3402,7 +3403,9 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             a.scale = scale;
             a.bag_inv = inv;
             a.bag_bits = bits;
-            if (nrx_zero_async(bits, (size_t)(off / 32 + 2) * 4, st) != NRX_OK) return NRX_ERR_LAUNCH;
+            if (!(placed && n_place > 0) && workspace != nullptr) {
+                if (nrx_zero2_async(a.long_ws, 16, bits, (size_t)(off / 32 + 2) * 4, st) != NRX_OK) return NRX_ERR_LAUNCH;
+            } else if (nrx_zero_async(bits, (size_t)(off / 32 + 2) * 4, st) != NRX_OK) return NRX_ERR_LAUNCH;
             // pre-scaled upstream rows of the 0/1-weight bag features ([batch, dim] each) live behind the bit words -- when the
             // caller's workspace is known to hold them (nrx_embed_bwd_workspace_for) and the launch reads g_out aligned
             float* gs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(bits + off / 32 + 2) + 255) & ~(uintptr_t)255);

@@ -386,8 +386,8 @@ def _zero_grad_tables(meta):
 def _dense_sorted_ok(plan, tables, sparse_grad, B, csr_ok=False) -> bool:
     """Default (dense-gradient) mode: form the table grads by the sorted reduction + nrx_rows_to_dense?  The sorted path costs a fixed
     ~25 launches (~0.2 ms of host and launch time per step), the atomic scatter ~0.2 us per 1000 lookups: from DENSE_SORTED_MIN lookups
-    per launch on (1 Mi: C2 / C4 at the bench batch) the sorted path is the faster one, below it the single atomic launch is
-    (profiles/r03_dense_backward.txt).  DENSE_BWD_SORTED: True = always (deterministic gradients at any size), False = never."""
+    per launch on (786 k: the C4 tower from B = 15 k) the sorted path is as fast or faster, below it the single atomic launch is
+    (profiles/r03_dense_backward.txt, r05_dense_default.txt).  DENSE_BWD_SORTED: True = always (deterministic gradients at any size), False = never."""
     if sparse_grad or DENSE_BWD_SORTED is False or B <= 0 or not tables or not tables[0].is_cuda:
         return False
     # (while a HIP graph is being captured the plan is made inline in the backward -- no side stream, no events to query -- and the reduction
@@ -705,7 +705,9 @@ _plan_streams = {}
 # the cheaper of the two: the small kernel where it applies, else the planned reduction) | atomic (never).
 # DENSE_BWD_SORTED: None = auto, True = sorted, "det" = deterministic, False = atomic.
 DENSE_BWD_SORTED = {"sorted": True, "atomic": False, "deterministic": "det"}.get(os.environ.get("NRX_DENSE_BWD", "auto"))
-DENSE_SORTED_MIN = int(os.environ.get("NRX_DENSE_SORTED_MIN", 1 << 20))
+DENSE_SORTED_MIN = int(os.environ.get("NRX_DENSE_SORTED_MIN", 3 << 18))      # 786 k lookups: from there the planned reduction replays as fast as the atomic
+                                                                            # launch on the C4 tower (B = 14 336: 125 vs 118 us, 16 384: 128 vs 130;
+                                                                            # profiles/r05_dense_default.txt) and is bit-reproducible
 SPARSE_SMALL_DET = os.environ.get("NRX_SPARSE_SMALL", "1") != "0"     # fused row-sparse mode (sink), small launches: the one-launch form likewise
 DENSE_SMALL_DET = os.environ.get("NRX_DENSE_SMALL", "1") != "0"       # auto mode, small launches: the one-launch deterministic kernel where it applies
 PLAN_AHEAD = True      # row-sparse training: plan the backward (sort, unique rows, segments) at FORWARD time on a side stream
@@ -713,7 +715,9 @@ DENSE_LDS_MIN = int(os.environ.get("NRX_DENSE_LDS_MIN", 1 << 16))       # defaul
                                                                          # takes the planner as an argument (nrx_embed_bwd_dense_planned)
 SINK_ONE_CALL = os.environ.get("NRX_SINK_ONE_CALL", "1") != "0"           # sink mode, inline plans: plan + reduction as ONE library call (A/B knob)
 PLAN_AHEAD_LDS = os.environ.get("NRX_PLAN_AHEAD_LDS", "0") != "0"      # plan ahead (side stream) even when the group takes the one-kernel planner
-PLAN_AHEAD_MIN = int(os.environ.get("NRX_PLAN_AHEAD_MIN", 1 << 18))      # default-mode launches below this many lookups plan inline (one fused call)
+PLAN_AHEAD_MIN = int(os.environ.get("NRX_PLAN_AHEAD_MIN", 1 << 20))      # default-mode launches below this many lookups plan inline (one fused call: the
+                                                                         # side-stream path's allocations and events were 240 us of host time per step
+                                                                         # at B = 8192 on the C4 tower against 123 inline)
 
 
 def _plan_stream(dev) -> "torch.cuda.Stream":
