@@ -465,6 +465,8 @@ NRX_API int nrx_dcn_v2_layer_fwd(const float* x0, const float* xl, int64_t ld, i
  * lin: the forward's lin_out; out: the forward's output (ReLU mask; may be NULL when relu == 0).  g_x0 is overwritten,
  * or accumulated into when bit 0 of accumulate_x0 is set (x0 feeds every layer); bit 1 additionally adds the resulting g_x0
  * into g_xl in the dgrad epilogue -- the stack's FIRST layer, whose x_l is x0, so that g_xl is dL/dx of the whole stack.  g_W [dim, dim] and g_b [dim] are overwritten.
+ * Launches: elementwise preparation + dgrad + wgrad (+ a fill); for dim <= 112 with aligned operands and fp32 math the preparation and the
+ * dgrad are ONE launch over 64-row panels (csrc/nrx_dcn2_bwd.hip, dcn2_bwd_panel_kernel: same g_xl / g_x0 value for value).
  * workspace: nrx_dcn_v2_layer_bwd_workspace(batch, dim) device bytes.                                           */
 NRX_API int64_t nrx_dcn_v2_layer_bwd_workspace(int64_t batch, int32_t dim);
 NRX_API int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld, const float* lin, const float* out, int32_t relu,

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
         if (n0 + n + 4 > N) n = N - 4 - n0 > 0 ? N - 4 - n0 : 0;
         ow[p] = (uint32_t)(((int64_t)kk * ldb + n) * 4);
     }
-    auto load_slab = [&](int64_t k0) {
+    auto load_slab = [&](int64_t k0, float4 (&a)[AP], float4 (&w)[2]) {
         if (VEC) {
             // K-major operands advance by whole rows of the source, the M-major one by 32 floats
             const char* ak = abase + (MODE == DGRAD ? (size_t)k0 * 4 : (size_t)k0 * (size_t)lda * 4);
@@ -347,10 +347,8 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
     float4 cs[AP];
 #pragma unroll
     for (int p = 0; p < AP; ++p) cs[p] = zero4();
-    if (kbeg < kend) load_slab(kbeg);
     const bool wave_live = m0 + wm * (32 * TM) < M && n0 + wn * 32 < N;      // wave-uniform
-
-    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    auto stage = [&](const float4 (&a)[AP], const float4 (&w)[2]) {
         if (MODE == DGRAD) {
 #pragma unroll
             for (int p = 0; p < AP; ++p) {
@@ -371,22 +369,18 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
                 if (do_cs) { cs[p].x += a[p].x; cs[p].y += a[p].y; cs[p].z += a[p].z; cs[p].w += a[p].w; }
             }
         }
-        {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int n = 4 * ((tid & 7) + 8 * p);
-                Ws[kk * LDW + n + 0] = w[p].x;
-                Ws[kk * LDW + n + 1] = w[p].y;
-                Ws[kk * LDW + n + 2] = w[p].z;
-                Ws[kk * LDW + n + 3] = w[p].w;
-            }
+        for (int p = 0; p < 2; ++p) {
+            const int n = 4 * ((tid & 7) + 8 * p);
+            Ws[kk * LDW + n + 0] = w[p].x;
+            Ws[kk * LDW + n + 1] = w[p].y;
+            Ws[kk * LDW + n + 2] = w[p].z;
+            Ws[kk * LDW + n + 3] = w[p].w;
         }
-        __syncthreads();
-        if (k0 + BK < kend) load_slab(k0 + BK);
-        if (!wave_live) {                              // this wave's 64 x 32 sub-tile lies wholly past M or N (D = 320: the third
-            __syncthreads();                           // 128-row tile of g_W has rows 320..383) -- it only helps staging
-            continue;
-        }
+    };
+    auto mma = [&](int64_t k0) {
+        if (!wave_live) return;                        // this wave's 64 x 32 sub-tile lies wholly past M or N (D = 320: the third 128-row tile of g_W
+                                                       // has rows 320..383) -- it only helps staging
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (h == 1 && k0 + BK / 2 >= kend) break;   // upper half of the last slab all padding: skip its MFMAs
@@ -403,6 +397,14 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
 #pragma unroll
                 for (int t = 0; t < TM; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][i], fb[i], acc[t], 0, 0, 0);
         }
+    };
+    if (kbeg < kend) load_slab(kbeg, a, w);
+    // (two slabs in flight instead of one: measured on the wgrad of narrow layers -- 31.6 vs 31.5 us at dim = 112, 135.0 vs 132.3 at 320 -- not kept)
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+        stage(a, w);
+        __syncthreads();
+        if (k0 + BK < kend) load_slab(k0 + BK, a, w);
+        mma(k0);
         __syncthreads();
     }
 
@@ -425,6 +427,174 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
         }
     }
     gemm_epilogue<MODE, TM>(acc, m0, n0, wm, wn, l31, hi, M, N, addend, add_ld, maskT, mask_ld, out, out_ld, add2, add2_ld);
+}
+
+// ---- narrow layers (dim <= 112, the reference's own width): preparation + dgrad in ONE launch --------------------------------------------------
+// At these widths every launch of the layer is a streaming pass -- K = dim is three or four slabs, the matrix work is nothing -- and the preparation
+// kernel alone moved 197 MB (reads g, x0, lin, out, g_x0; writes glin, g_x0, the mask bits) before the dgrad read glin and g again: 43.7 + 31.0 us of
+// the layer's 103.5 (profiles/r04_dcn_fp32_d112_rocprof_summary.txt).  Here a block owns a PANEL of 64 rows over ALL columns:
+//   * W -- all of it, 50 KB, from L2 -- and the panel's elementwise inputs are requested up front (W first: loads return in order, so W is stored to
+//     LDS while the panel's rows are still in flight);
+//   * g_x0 and glin (the wgrad's operand) leave for memory, glin also stays in LDS K-major (the dgrad's A operand, the whole K), gm = g (x) [out > 0]
+//     stays in registers;
+//   * the dgrad of the panel runs from LDS with no barrier inside (one 32 x 32 accumulator per wavefront and 64-column tile of the output; same k
+//     order as dcn2_gemm_kernel<DGRAD>: value for value its sums);
+//   * gm goes through LDS (the dead A panel's place) into the accumulator layout: g_xl = gm + glin W (+ g_x0 for the stack's first layer);
+//   * the first blocks clear g_W / g_b on the way (the wgrad launch behind adds to them: no fill launch); g_b comes from the wgrad's staging
+//     registers (launch_wgrad's colsum).
+// 80 KB of LDS: two blocks per compute unit.  232 MB of fabric traffic per launch (146 read + 89 written) against 294 for the two launches it
+// replaces: 54.6 us against 74.7 (+ 4.7 of the fill launch); a 3-layer forward + backward step at B = 65 536 396 -> 343 us
+// (profiles/r05_dcn_fp32_d112_rocprof_summary.txt).  Forms that lost on the way: W in K slabs inside the GEMM loop (a block's life was eight
+// dependent L2 round trips and barriers: 81.7 us); g and out re-read in the epilogue (they came from memory, not from L2: 206 MB read, 56.7 us).
+template <bool RELU>
+__global__ __launch_bounds__(256, 2) void dcn2_bwd_panel_kernel(const float* __restrict__ g, int64_t g_ld, const float* __restrict__ out,
+                                                                const float* __restrict__ x0, const float* __restrict__ lin, int64_t ld,
+                                                                int64_t M, int D, const float* __restrict__ W, float* __restrict__ glin, int64_t w_ld,
+                                                                float* __restrict__ g_x0, int64_t gx0_ld, int acc_x0, int fold,
+                                                                float* __restrict__ g_xl, int64_t gxl_ld, float* __restrict__ zero_a, int zero_na,
+                                                                float* __restrict__ zero_b, int zero_nb) {
+    constexpr int PM = 64, LDP = PM + 1, U = 4;
+    // g_W and g_b start from zero (the wgrad launch behind this one adds to them): cleared here instead of by a launch of their own
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < zero_na + zero_nb; i += gridDim.x * 256) {
+        if (i < zero_na) zero_a[i] = 0.f;
+        else zero_b[i - zero_na] = 0.f;
+    }
+    extern __shared__ __attribute__((aligned(16))) float panel_smem[];
+    const int Kp = (D + 15) & ~15;                    // the MFMA loop consumes K in halves of 16
+    const int LDF = D + 4;                            // (a multiple of 4: rows of W and of gm are stored as 16-byte pieces)
+    float* As = panel_smem;                           // [Kp][LDP]: glin of the panel, K-major
+    const int a_floats = Kp * LDP > PM * LDF ? Kp * LDP : PM * LDF;      // (the panel's place later holds gm as [64][LDF])
+    float* Wl = As + a_floats;                        // [Kp][LDF] (+ 64 floats of slack): ALL of W
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, hi = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * PM;
+    for (int i = tid; i < (Kp - D) * LDP; i += 256) As[D * LDP + i] = 0.f;
+    for (int i = tid; i < (Kp - D) * LDF + 64; i += 256) Wl[D * LDF + i] = 0.f;
+    const int c4n = D >> 2;
+    // W first (L2), the panel's rows behind it (memory): the loads return in order, so W is stored to LDS while the panel's are still in flight
+    constexpr int NW = 13;                            // float4 of W per thread: dim <= 112 -> at most 3136 / 256
+    float4 wv[NW];
+    {
+        const int n4 = D * c4n;
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = u * 256 + tid;
+            wv[u] = i < n4 ? reinterpret_cast<const float4*>(W)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // ---- the panel's elementwise part: thread = (row lane, 4 columns); U rows in flight, at most two rounds (a round covers >= 32 rows: dim <= 128);
+    // gm = g (x) [out > 0] stays in registers for the epilogue
+    constexpr int IT = 2;
+    float4 gmk[IT][U];
+    const int rpp = 256 / c4n;
+    const int rsub = tid / c4n, c4 = tid - rsub * c4n, cc = 4 * c4;
+    float4 gv[IT][U], xv[IT][U], lv[IT][U], ov[IT][U], ax[IT][U];
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rb = rsub + it * rpp * U;
+            const int64_t r = m0 + rb + u * rpp;
+            const int64_t rc = r < M ? r : M - 1;          // (rows past the batch: clamped loads, nothing stored)
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            gv[it][u] = xv[it][u] = lv[it][u] = ax[it][u] = z;
+            ov[it][u] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (rsub < rpp && rb + u * rpp < PM) {         // (rows past the panel are another block's)
+                gv[it][u] = *reinterpret_cast<const float4*>(g + rc * g_ld + cc);
+                xv[it][u] = *reinterpret_cast<const float4*>(x0 + rc * ld + cc);
+                lv[it][u] = *reinterpret_cast<const float4*>(lin + rc * ld + cc);
+                if (RELU) ov[it][u] = *reinterpret_cast<const float4*>(out + rc * ld + cc);
+                if (acc_x0) ax[it][u] = *reinterpret_cast<const float4*>(g_x0 + rc * gx0_ld + cc);
+            }
+        }
+    {
+        const int n4 = D * c4n;
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = u * 256 + tid;
+            if (i < n4) {
+                const int k = i / c4n, n = 4 * (i - k * c4n);
+                *reinterpret_cast<float4*>(Wl + k * LDF + n) = wv[u];
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = rsub + it * rpp * U + u * rpp;
+            float4 m_;
+            m_.x = !RELU || ov[it][u].x > 0.f ? gv[it][u].x : 0.f; m_.y = !RELU || ov[it][u].y > 0.f ? gv[it][u].y : 0.f;
+            m_.z = !RELU || ov[it][u].z > 0.f ? gv[it][u].z : 0.f; m_.w = !RELU || ov[it][u].w > 0.f ? gv[it][u].w : 0.f;
+            gmk[it][u] = m_;
+            if (rsub >= rpp || row >= PM) continue;
+            const float4 gl = make_float4(m_.x * xv[it][u].x, m_.y * xv[it][u].y, m_.z * xv[it][u].z, m_.w * xv[it][u].w);
+            const float4 gx = make_float4(fmaf(m_.x, lv[it][u].x, ax[it][u].x), fmaf(m_.y, lv[it][u].y, ax[it][u].y),
+                                          fmaf(m_.z, lv[it][u].z, ax[it][u].z), fmaf(m_.w, lv[it][u].w, ax[it][u].w));
+            As[(cc + 0) * LDP + row] = gl.x; As[(cc + 1) * LDP + row] = gl.y;
+            As[(cc + 2) * LDP + row] = gl.z; As[(cc + 3) * LDP + row] = gl.w;
+            if (m0 + row < M) {
+                *reinterpret_cast<float4*>(glin + (m0 + row) * w_ld + cc) = gl;
+                *reinterpret_cast<float4*>(g_x0 + (m0 + row) * gx0_ld + cc) = gx;
+            }
+        }
+    __syncthreads();          // the panel is in LDS; this block's g_x0 rows are written (the fold below reads them back)
+    // ---- dgrad of the panel, the one or two 64-column tiles of g_xl: both operands in LDS, no barrier inside
+    const int nx = (D + BN - 1) / BN;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+        if (nt >= nx) continue;
+        const float* wcol = Wl + nt * BN + wn * 32 + l31;      // (columns past dim read into the next row / the slack: their products are never stored)
+        const float* arow = As + wm * 32 + l31;
+        for (int k0 = 0; k0 < Kp; k0 += BK / 2) {
+            float fb[BK / 4], fa[BK / 4];
+#pragma unroll
+            for (int i = 0; i < BK / 4; ++i) {
+                const int kr = k0 + 2 * i + hi;
+                fb[i] = wcol[kr * LDF];
+                fa[i] = arow[kr * LDP];
+            }
+#pragma unroll
+            for (int i = 0; i < BK / 4; ++i) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc[nt], 0, 0, 0);
+        }
+    }
+    // ---- gm through LDS into the accumulator layout (the A panel is dead: its place, as [row][LDF])
+    __syncthreads();
+    float* Gs = As;
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = rsub + it * rpp * U + u * rpp;
+            if (rsub < rpp && row < PM) *reinterpret_cast<float4*>(Gs + row * LDF + cc) = gmk[it][u];
+        }
+    __syncthreads();
+    // epilogue (accumulator layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)): g_xl = gm + acc (+ g_x0)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = nt * BN + wn * 32 + l31;
+        if (nt >= nx || col >= D) continue;
+        const int rl0 = wm * 32 + 4 * hi;
+        float av[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = m0 + rl0 + (r & 3) + 8 * (r >> 2);
+            av[r] = fold && row < M ? g_x0[row * gx0_ld + col] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = rl0 + (r & 3) + 8 * (r >> 2);
+            const int64_t row = m0 + rl;
+            if (row >= M) continue;
+            float v = Gs[rl * LDF + col] + acc[nt][r];
+            if (fold) v += av[r];
+            g_xl[row * gxl_ld + col] = v;
+        }
+    }
 }
 
 // ---- the GEMM in split-bf16 math (flags bit 1; see dcn_v2_layer_bf16x3_kernel in nrx_dcn2.hip) ----------------------------------
@@ -694,17 +864,42 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int acc_x0 = accumulate_x0 & 1;                          // bit 0: add to g_x0 instead of overwriting it
     const float* fold = (accumulate_x0 & 2) ? g_x0 : nullptr;      // bit 1: fold the (written or accumulated) g_x0 into g_xl (the stack's first layer)
-    if (g_b == g_W + (size_t)dim * dim) {          // g_b right behind g_W (what the Python layer allocates): one fill launch
-        if (nrx_zero_async(g_W, sizeof(float) * ((size_t)dim * dim + dim), st) != NRX_OK) return NRX_ERR_LAUNCH;
-    } else if (nrx_zero_async(g_W, sizeof(float) * (size_t)dim * dim, st) != NRX_OK || nrx_zero_async(g_b, sizeof(float) * (size_t)dim, st) != NRX_OK)
-        return NRX_ERR_LAUNCH;
-    if (batch == 0) return NRX_OK;
     const int64_t wld = (dim + 3) & ~3;
-    float* glin = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    uint32_t* maskT = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(glin + batch * wld) + 255) & ~(uintptr_t)255);
     const bool vec = (dim & 3) == 0 && (ld & 3) == 0 && (g_ld & 3) == 0 && (gx0_ld & 3) == 0 && (gxl_ld & 3) == 0 && nrx_aligned16(x0) &&
                      nrx_aligned16(xl) && nrx_aligned16(lin) && nrx_aligned16(g_out) && nrx_aligned16(g_x0) && nrx_aligned16(g_xl) &&
                      nrx_aligned16(W) && (out == nullptr || nrx_aligned16(out));
+    // narrow layers, fp32 math, aligned operands: preparation + dgrad as one launch (dcn2_bwd_panel_kernel), which also clears g_W / g_b;
+    // NRX_DCN2_PANEL=0: the three-launch path
+    // (two blocks per compute unit need <= 80 KB of LDS each: dim <= 112; at dim = 128 -- 100 KB, one block -- the three launches are faster: 415 vs 426 us
+    // per 3-layer step)
+    static const bool panel_on = !(getenv("NRX_DCN2_PANEL") && atoi(getenv("NRX_DCN2_PANEL")) == 0);
+    const size_t kp_ = (size_t)((dim + 15) & ~15);
+    const size_t lds = ((kp_ * 65 > (size_t)64 * (dim + 4) ? kp_ * 65 : (size_t)64 * (dim + 4)) + kp_ * (dim + 4) + 64) * sizeof(float);
+    const bool panel = panel_on && vec && !split && dim >= 8 && dim <= 112 && lds <= 80 * 1024 && batch > 0;
+    if (!panel) {
+        if (g_b == g_W + (size_t)dim * dim) {          // g_b right behind g_W (what the Python layer allocates): one fill launch
+            if (nrx_zero_async(g_W, sizeof(float) * ((size_t)dim * dim + dim), st) != NRX_OK) return NRX_ERR_LAUNCH;
+        } else if (nrx_zero_async(g_W, sizeof(float) * (size_t)dim * dim, st) != NRX_OK || nrx_zero_async(g_b, sizeof(float) * (size_t)dim, st) != NRX_OK)
+            return NRX_ERR_LAUNCH;
+    }
+    if (batch == 0) return NRX_OK;
+    float* glin = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    uint32_t* maskT = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(glin + batch * wld) + 255) & ~(uintptr_t)255);
+    if (panel) {
+        static const bool attr = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn2_bwd_panel_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn2_bwd_panel_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) == hipSuccess;
+        }();
+        (void)attr;
+        const unsigned blocks = (unsigned)((batch + 63) / 64);
+        if (relu) hipLaunchKernelGGL((dcn2_bwd_panel_kernel<true>), dim3(blocks), dim3(256), lds, st, g_out, g_ld, out, x0, lin, ld, batch, (int)dim, W,
+                                     glin, wld, g_x0, gx0_ld, acc_x0, fold != nullptr ? 1 : 0, g_xl, gxl_ld, g_W, (int)(dim * dim), g_b, (int)dim);
+        else hipLaunchKernelGGL((dcn2_bwd_panel_kernel<false>), dim3(blocks), dim3(256), lds, st, g_out, g_ld, out, x0, lin, ld, batch, (int)dim, W,
+                                glin, wld, g_x0, gx0_ld, acc_x0, fold != nullptr ? 1 : 0, g_xl, gxl_ld, g_W, (int)(dim * dim), g_b, (int)dim);
+        launch_wgrad(glin, wld, xl, ld, dim, dim, batch, g_W, g_b, vec, st, false);       // (g_b: column sums of glin from the wgrad's staging registers)
+        NRX_LAUNCH_CHECK("nrx_dcn_v2_layer_bwd");
+        return NRX_OK;
+    }
     {
         int tl = 2;                                   // threads per row = 2^tl >= dim / 4 (<= 256)
         while ((4 << tl) < dim && tl < 8) ++tl;

@@ -752,6 +752,72 @@ def test_dcn_v2_layer_bwd_capi_padded_leading_dims(B, D, acc):
     assert (got[0].double() - gxl).abs().max().item() <= 1e-4 * max(1.0, gxl.abs().max().item())
 
 
+@pytest.mark.parametrize("relu", [1, 0])
+@pytest.mark.parametrize("acc", [0, 1, 3])
+@pytest.mark.parametrize("B,D", [(1, 8), (63, 16), (64, 112), (65, 112), (1000, 112), (4133, 112), (777, 128), (300, 100), (129, 64), (500, 36), (2000, 124)])
+def test_dcn_v2_layer_bwd_panel_form_equals_three_launch_path(B, D, acc, relu):
+    """Narrow layers (dim <= 128): preparation + dgrad in one launch (dcn2_bwd_panel_kernel) against the three-launch path in a child process
+    started with NRX_DCN2_PANEL=0 (the switch is read once per process) -- g_xl and g_x0 value for value (same sums in the same order), g_W /
+    g_b within the order of their batch-wide atomics; and all four against the fp64 definition (dcn_arch.py:33-50, 73-91)."""
+    import subprocess, sys, os, tempfile
+    from news_recsys_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device=DEV).manual_seed(B * 3 + D + acc)
+    rnd = lambda *shape: torch.randn(*shape, device=DEV, generator=gen)
+    x0, xl, g = rnd(B, D), rnd(B, D), rnd(B, D)
+    W, b = rnd(D, D) / D ** 0.5, rnd(D) * 0.1
+    W = W * (1.0 + torch.triu(torch.ones(D, D, device=DEV)))          # asymmetric: a transposed operand cannot pass
+    gx0_init = rnd(B, D)
+    with tempfile.TemporaryDirectory() as td:
+        torch.save(dict(x0=x0.cpu(), xl=xl.cpu(), g=g.cpu(), W=W.cpu(), b=b.cpu(), gx0=gx0_init.cpu(), acc=acc, relu=relu), os.path.join(td, "in.pt"))
+        code = (
+            "import sys, torch\n"
+            "sys.path.insert(0, %r)\n"
+            "from news_recsys_amd import _lib\n"
+            "lib = _lib.load()\n"
+            "d = torch.load(%r)\n"
+            "dev = 'cuda:0'\n"
+            "x0, xl, g, W, b, gx0 = (d[k].to(dev) for k in ('x0', 'xl', 'g', 'W', 'b', 'gx0'))\n"
+            "B, D = x0.shape\n"
+            "out, lin = torch.empty_like(x0), torch.empty_like(x0)\n"
+            "st = torch.cuda.current_stream().cuda_stream\n"
+            "assert lib.nrx_dcn_v2_layer_fwd(x0.data_ptr(), xl.data_ptr(), D, B, D, W.data_ptr(), b.data_ptr(), d['relu'], out.data_ptr(), D, lin.data_ptr(), st) == 0\n"
+            "gxl, gW, gb = torch.empty_like(x0), torch.empty(D, D, device=dev), torch.empty(D, device=dev)\n"
+            "ws = torch.empty(lib.nrx_dcn_v2_layer_bwd_workspace(B, D), dtype=torch.uint8, device=dev)\n"
+            "assert lib.nrx_dcn_v2_layer_bwd(x0.data_ptr(), xl.data_ptr(), D, lin.data_ptr(), out.data_ptr(), d['relu'], B, D, W.data_ptr(), g.data_ptr(), D,"
+            " gxl.data_ptr(), D, gx0.data_ptr(), D, d['acc'], gW.data_ptr(), gb.data_ptr(), ws.data_ptr(), st) == 0\n"
+            "torch.cuda.synchronize()\n"
+            "torch.save(dict(gxl=gxl.cpu(), gx0=gx0.cpu(), gW=gW.cpu(), gb=gb.cpu(), out=out.cpu()), %r)\n"
+        ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(td, "in.pt"), os.path.join(td, "out.pt"))
+        env = dict(os.environ, NRX_DCN2_PANEL="0")
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+        ref = torch.load(os.path.join(td, "out.pt"))
+    out, lin = torch.empty_like(x0), torch.empty_like(x0)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.nrx_dcn_v2_layer_fwd(x0.data_ptr(), xl.data_ptr(), D, B, D, W.data_ptr(), b.data_ptr(), relu, out.data_ptr(), D, lin.data_ptr(), st) == 0
+    gxl, gx0, gW, gb = torch.empty_like(x0), gx0_init.clone(), torch.empty(D, D, device=DEV), torch.empty(D, device=DEV)
+    ws = torch.empty(lib.nrx_dcn_v2_layer_bwd_workspace(B, D), dtype=torch.uint8, device=DEV)
+    assert lib.nrx_dcn_v2_layer_bwd(x0.data_ptr(), xl.data_ptr(), D, lin.data_ptr(), out.data_ptr(), relu, B, D, W.data_ptr(), g.data_ptr(), D,
+                                    gxl.data_ptr(), D, gx0.data_ptr(), D, acc, gW.data_ptr(), gb.data_ptr(), ws.data_ptr(), st) == 0, lib.nrx_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref["out"])
+    assert torch.equal(gxl.cpu(), ref["gxl"]) and torch.equal(gx0.cpu(), ref["gx0"])
+    torch.testing.assert_close(gW.cpu(), ref["gW"], rtol=1e-4, atol=1e-4 * max(1.0, B ** 0.5))
+    torch.testing.assert_close(gb.cpu(), ref["gb"], rtol=1e-4, atol=1e-4 * max(1.0, B ** 0.5))
+    m = (out > 0).double() if relu else torch.ones_like(out).double()
+    gm = g.double() * m
+    lin64 = xl.double() @ W.double().t() + b.double()
+    want_gx0 = gm * lin64 + (gx0_init.double() if acc & 1 else 0)
+    glin = gm * x0.double()
+    want_gxl = gm + glin @ W.double() + (want_gx0 if acc & 2 else 0)
+    tol = 1e-4
+    assert (gx0.double() - want_gx0).abs().max().item() <= tol * max(1.0, want_gx0.abs().max().item())
+    assert (gxl.double() - want_gxl).abs().max().item() <= tol * max(1.0, want_gxl.abs().max().item())
+    want_gW, want_gb = glin.t() @ xl.double(), glin.sum(0)
+    assert (gW.double() - want_gW).abs().max().item() <= 3e-6 * max(1.0, B ** 0.5) * max(1.0, want_gW.abs().max().item())
+    assert (gb.double() - want_gb).abs().max().item() <= 3e-6 * max(1.0, B ** 0.5) * max(1.0, want_gb.abs().max().item())
+
+
 # ----------------------------------------------------------------------------- integer utilities (bit-exact)
 @pytest.mark.parametrize("n,world", [(0, 2), (1, 1), (63, 2), (2048, 8), (2049, 8), (100000, 8), (77777, 3), (5000, 64)])
 @pytest.mark.parametrize("dtype", [torch.int64, torch.int32])
