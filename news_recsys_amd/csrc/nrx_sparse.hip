@@ -78,7 +78,33 @@ struct PlaceInfo {
     uint64_t feats;                 // bit f: lookups of feature f may be placed
     int32_t n;
     int32_t all;                    // every feature may be placed: no feature lookup needed
+    // SEG (segment-local keys): the sorted pairs carry the ROW only -- a launch whose table + row bits exceed 32 (C5: 40 tables up to 500 M rows)
+    // still sorts 8-byte {row, lookup} pairs instead of 8-byte keys + 4-byte payloads; the table of a sorted position is the run it lies in
+    int64_t seg_off[NRX_MAX_FEATURES + 1];      // first sorted position of table t's run (table-major; [n_seg] = n)
+    int32_t n_seg, pad_;
 };
+// SEG: the table of sorted position e = the last run that starts at or before e.  t_lo / b1: the table of the tile's first position and where the next
+// run starts (block-uniform, found once per tile); an entry past b1 walks on (rare: a tile that holds the end of a run).
+struct PlanSeg {
+    int t_lo;
+    int64_t b1;
+};
+__device__ __forceinline__ PlanSeg plan_seg_of_tile(const NRX_CONST PlaceInfo* pi, int64_t e_first) {
+    PlanSeg ps;
+    // one lane per run start: ONE vector load, a compare, a ballot (a scalar loop over 40 starts was 40 dependent loads: the count kernel 8 -> 18 us)
+    const int lane = threadIdx.x & 63;
+    const bool hit = lane >= 1 && lane < pi->n_seg && pi->seg_off[lane < pi->n_seg ? lane : 0] <= e_first;
+    const int t = __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(hit)));
+    ps.t_lo = t;
+    ps.b1 = t + 1 < pi->n_seg ? pi->seg_off[t + 1] : 0x7fffffffffffffffLL;
+    return ps;
+}
+__device__ __forceinline__ int plan_table_at(const NRX_CONST PlaceInfo* pi, const PlanSeg& ps, int64_t e) {
+    if (e < ps.b1) return e < 0 ? -1 : ps.t_lo;
+    int t = ps.t_lo + 1;
+    while (t + 1 < pi->n_seg && e >= pi->seg_off[t + 1]) ++t;
+    return t;
+}
 __device__ __forceinline__ bool plan_placeable(const NRX_CONST PlaceInfo* pi, uint32_t p) {
     if (pi->all) return true;
     int f = 0;
@@ -91,7 +117,7 @@ __device__ __forceinline__ bool plan_is_placed(bool head, bool next_head, KeyT k
     return head && next_head && ((uint64_t)key & rmask) != 0 && plan_placeable(pi, p);
 }
 
-template <typename KeyT, bool PAIR = false, bool PLACE = false>
+template <typename KeyT, bool PAIR = false, bool PLACE = false, bool SEG = false>
 __global__ __launch_bounds__(NRX_BLOCK) void plan_count_kernel(const PlaceInfo place_in_kernarg /* first: read through nrx_kernarg */,
                                                                const KeyT* __restrict__ skeys, int64_t n, uint32_t* __restrict__ block_heads,
                                                                const uint32_t* __restrict__ spayload, int row_bits) {
@@ -99,18 +125,33 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_count_kernel(const PlaceInfo p
     const int64_t e0 = (int64_t)blockIdx.x * PLAN_TILE + threadIdx.x;
     uint32_t c = 0, cw = 0;
     const uint64_t rmask = (1ull << row_bits) - 1;
+    // (the tile's keys are requested before the run lookup: the two do not depend on each other, and a block is one short chain of round trips)
+    constexpr int ROUNDS = PLAN_TILE / NRX_BLOCK;
+    KeyT key[ROUNDS], prev[ROUNDS];
 #pragma unroll
-    for (int j = 0; j < PLAN_TILE / NRX_BLOCK; ++j) {
+    for (int j = 0; j < ROUNDS; ++j) {
         const int64_t e = e0 + j * NRX_BLOCK;
-        const bool head = e < n && plan_is_head<KeyT, PAIR>(skeys, e);
+        const int64_t ec = e < n ? e : n - 1;
+        key[j] = plan_key_at<KeyT, PAIR>(skeys, ec);
+        prev[j] = plan_key_at<KeyT, PAIR>(skeys, ec > 0 ? ec - 1 : 0);
+    }
+    PlanSeg ps = {0, 0};
+    if (SEG) ps = plan_seg_of_tile(nrx_kernarg<PlaceInfo>(), (int64_t)blockIdx.x * PLAN_TILE > 0 ? (int64_t)blockIdx.x * PLAN_TILE - 1 : 0);
+#pragma unroll
+    for (int j = 0; j < ROUNDS; ++j) {
+        const int64_t e = e0 + j * NRX_BLOCK;
+        bool head = e < n && (e == 0 || key[j] != prev[j]);
+        if (SEG && e < n && e > 0)
+            head = head || plan_table_at(nrx_kernarg<PlaceInfo>(), ps, e) != plan_table_at(nrx_kernarg<PlaceInfo>(), ps, e - 1);
         c += (uint32_t)__popcll(__ballot(head));      // wave-uniform count
         if (PLACE) {
             const NRX_CONST PlaceInfo* pi = nrx_kernarg<PlaceInfo>();
             bool walked = false;
             if (head) {
-                const bool next_head = e + 1 >= n || plan_key_at<KeyT, PAIR>(skeys, e + 1) != plan_key_at<KeyT, PAIR>(skeys, e);
+                bool next_head = e + 1 >= n || plan_key_at<KeyT, PAIR>(skeys, e + 1) != key[j];
+                if (SEG && e + 1 < n) next_head = next_head || plan_table_at(pi, ps, e + 1) != plan_table_at(pi, ps, e);
                 const uint32_t pay = PAIR ? reinterpret_cast<const uint2*>(skeys)[e].y : spayload[e];
-                walked = !plan_is_placed<KeyT>(true, next_head, plan_key_at<KeyT, PAIR>(skeys, e), rmask, pi, pay);
+                walked = !plan_is_placed<KeyT>(true, next_head, key[j], rmask, pi, pay);
             }
             cw += (uint32_t)__popcll(__ballot(walked));
         }
@@ -128,7 +169,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_count_kernel(const PlaceInfo p
 
 // entry e of the tile is handled by thread (e % 256) in round (e / 256): coalesced key / payload / order accesses; the
 // rank of a head = heads of earlier blocks + heads of earlier (round, wave) cells + heads of lower lanes in its cell
-template <typename KeyT, bool PAIR = false, bool PLACE = false>
+template <typename KeyT, bool PAIR = false, bool PLACE = false, bool SEG = false>
 __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo place_in_kernarg /* first: read through nrx_kernarg */,
                                                               const KeyT* __restrict__ skeys, const uint32_t* __restrict__ spayload,
                                                               const uint32_t* __restrict__ block_heads, int64_t n, int row_bits,
@@ -185,14 +226,24 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo pl
     const uint64_t rmask = (1ull << row_bits) - 1;
     bool head[ROUNDS], walked[ROUNDS], placed[ROUNDS], able[ROUNDS];
     unsigned long long mask[ROUNDS], wmask[ROUNDS];
+    int tab[ROUNDS], tabp[ROUNDS];                 // SEG: table of the entry / of its predecessor (-1 before the first)
+    PlanSeg ps = {0, 0};
+    if (SEG) ps = plan_seg_of_tile(nrx_kernarg<PlaceInfo>(), (int64_t)tile * PLAN_TILE > 0 ? (int64_t)tile * PLAN_TILE - 1 : 0);
 #pragma unroll
     for (int j = 0; j < ROUNDS; ++j) {
         const int64_t e = e0 + j * NRX_BLOCK;
         head[j] = e < n && (e == 0 || key[j] != prev[j]);
+        tab[j] = tabp[j] = 0;
+        if (SEG && e < n) {
+            tab[j] = plan_table_at(nrx_kernarg<PlaceInfo>(), ps, e);
+            tabp[j] = e > 0 ? plan_table_at(nrx_kernarg<PlaceInfo>(), ps, e - 1) : -1;
+            head[j] = head[j] || tab[j] != tabp[j];
+        }
         mask[j] = __ballot(head[j]);
         if (lane == 0) s_cell[j * WAVES + wid] = (uint32_t)__popcll(mask[j]);
         if (PLACE) {
-            const bool next_head = e + 1 >= n || next[j] != key[j];
+            bool next_head = e + 1 >= n || next[j] != key[j];
+            if (SEG && e + 1 < n) next_head = next_head || plan_table_at(nrx_kernarg<PlaceInfo>(), ps, e + 1) != tab[j];
             able[j] = plan_placeable(nrx_kernarg<PlaceInfo>(), pay[j]);
             placed[j] = head[j] && next_head && ((uint64_t)key[j] & rmask) != 0 && able[j];
             walked[j] = head[j] && !placed[j];
@@ -236,17 +287,17 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo pl
         }
         if (head[j]) {
             const uint64_t k = (uint64_t)key[j];
-            const int64_t t = (int64_t)(k >> row_bits);
+            const int64_t t = SEG ? (int64_t)tab[j] : (int64_t)(k >> row_bits);
             uniq_keys[u] = (t << 40) | (int64_t)(k & rmask);
             seg_start[u] = e;
-            const int64_t tprev = e == 0 ? -1 : (int64_t)((uint64_t)prev[j] >> row_bits);
+            const int64_t tprev = e == 0 ? -1 : (SEG ? (int64_t)tabp[j] : (int64_t)((uint64_t)prev[j] >> row_bits));
             for (int64_t tt = tprev + 1; tt <= t; ++tt) counts[1 + tt] = u;     // first unique entry of tables tprev+1 .. t
         }
         if (e == n - 1) {
             const uint32_t nu = u + (head[j] ? 1u : 0u);
             counts[0] = nu;
             seg_start[nu] = n;
-            const int64_t tl = (int64_t)((uint64_t)key[j] >> row_bits);
+            const int64_t tl = SEG ? (int64_t)tab[j] : (int64_t)((uint64_t)key[j] >> row_bits);
             for (int64_t tt = tl + 1; tt <= n_tables; ++tt) counts[1 + tt] = nu;
         }
     }
@@ -319,6 +370,7 @@ struct SegArgs {
     // Padding split (launches with bag features; seg_split_kernel): the lookups of the padding row (id 0, out-of-range ids) -- half of a
     // padded history -- have nothing to sort: the key kernel writes them, in lookup order, to the FRONT of their table's segment in the buffer the
     // last pass leaves its result in, and the live pairs compacted behind them; every pass then sorts [seg_off + seg_lo, seg_end) only.
+    int32_t segkey;                                   // 1: the pairs carry the row only (PlaceInfo::seg_off names the table of a sorted position)
     int32_t final_b;                                  // the buffer that holds the sorted pairs after the last pass: 0 = first, 1 = second
     uint32_t* seg_lo;                                 // [n_seg]: padding lookups of the segment (null: no split, every pass sorts whole segments)
     uint32_t* padcnt;                                 // [tiles]: padding lookups per input tile
@@ -432,7 +484,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
     __syncthreads();
     if (one_slot) {
         const int64_t rows = a->rows[lo], pbase = a->poff[lo] + (q0 - a->qoff[lo]);
-        const KeyT tkey = (KeyT)seg_table_of(a, lo) << a->row_bits;
+        const KeyT tkey = a->segkey ? (KeyT)0 : (KeyT)((KeyT)seg_table_of(a, lo) << a->row_bits);
 #pragma unroll
         for (int j = 0; j < SEG_PER_THREAD; ++j) {
             const int64_t q = q0 + j * SEG_THREADS + threadIdx.x;
@@ -455,9 +507,10 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
             const int s = sl[j];
             int64_t v = id[j];
             if (v < 0 || v >= a->rows[s]) v = 0;
-            if (PAIR) reinterpret_cast<uint2*>(keys)[q] = make_uint2((uint32_t)(((KeyT)seg_table_of(a, s) << a->row_bits) | (KeyT)v), (uint32_t)(a->poff[s] + (q - a->qoff[s])));
+            const KeyT tk = a->segkey ? (KeyT)0 : (KeyT)((KeyT)seg_table_of(a, s) << a->row_bits);
+            if (PAIR) reinterpret_cast<uint2*>(keys)[q] = make_uint2((uint32_t)(tk | (KeyT)v), (uint32_t)(a->poff[s] + (q - a->qoff[s])));
             else {
-                keys[q] = ((KeyT)seg_table_of(a, s) << a->row_bits) | (KeyT)v;
+                keys[q] = tk | (KeyT)v;
                 payload[q] = (uint32_t)(a->poff[s] + (q - a->qoff[s]));
             }
             atomicAdd(&s_hist[(uint32_t)(v >> hshift) & dmask], 1u);
@@ -590,7 +643,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_split_kernel(const SegArgs ar
         const int idx = j * SEG_THREADS + tid;
         if (q0 + idx >= qend) continue;
         const uint32_t pb = s_pre[j * WAVES + wid] + mine[j];         // padding lookups of the tile before this entry
-        const KeyT key = ((KeyT)tab[j] << a->row_bits) | (KeyT)v[j];
+        const KeyT key = (a->segkey ? (KeyT)0 : (KeyT)((KeyT)tab[j] << a->row_bits)) | (KeyT)v[j];
         const int64_t pos = pad[j] ? pad_base + pb : live_base + ((int64_t)idx - (int64_t)pb);
         KeyT* kk = pad[j] ? pk : lk;
         uint32_t* pq = pad[j] ? pp : lp;
@@ -1351,7 +1404,7 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
         }
         const size_t lds_hist = (size_t)nb * 4;
         const dim3 gchunks((unsigned)((nb + NRX_BLOCK - 1) / NRX_BLOCK), (unsigned)chunk);
-#define NRX_SEGSORT(KeyT)                                                                                                 \
+#define NRX_SEGSORT(KeyT, SEG_)                                                                                           \
     {                                                                                                                     \
         constexpr bool PAIR_ = sizeof(KeyT) == 4;                                                                         \
         const size_t lds_scatter = (size_t)nb * (2 * (SEG_THREADS / 64) + 8) + (size_t)SEG_TILE * (4 + sizeof(KeyT));         \
@@ -1398,18 +1451,24 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
             uint32_t* tp = psrc; psrc = pdst; pdst = tp;                                                                  \
         }                                                                                                                 \
         if (dest != nullptr) {                                                                                            \
-            hipLaunchKernelGGL((plan_count_kernel<KeyT, PAIR_, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src, n, flags, (const uint32_t*)psrc, row_bits); \
-            hipLaunchKernelGGL((plan_emit_kernel<KeyT, PAIR_, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src,     \
+            hipLaunchKernelGGL((plan_count_kernel<KeyT, PAIR_, true, SEG_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src, n, flags, (const uint32_t*)psrc, row_bits); \
+            hipLaunchKernelGGL((plan_emit_kernel<KeyT, PAIR_, true, SEG_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src,     \
                                (const uint32_t*)psrc, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys,     \
                                seg_start, counts, dest, walk, n_walk);                                                    \
         } else {                                                                                                          \
-            hipLaunchKernelGGL((plan_count_kernel<KeyT, PAIR_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src, n, flags, (const uint32_t*)psrc, row_bits); \
-            hipLaunchKernelGGL((plan_emit_kernel<KeyT, PAIR_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src,           \
+            hipLaunchKernelGGL((plan_count_kernel<KeyT, PAIR_, false, SEG_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src, n, flags, (const uint32_t*)psrc, row_bits); \
+            hipLaunchKernelGGL((plan_emit_kernel<KeyT, PAIR_, false, SEG_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src,           \
                                (const uint32_t*)psrc, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys,     \
                                seg_start, counts, (int32_t*)nullptr, (int32_t*)nullptr, (int64_t*)nullptr);               \
         }                                                                                                                 \
     }
-        if (bits <= 32) NRX_SEGSORT(uint32_t) else NRX_SEGSORT(uint64_t)
+        // table + row bits beyond 32 (many tables next to a huge one): the pairs carry the ROW only, the table of a sorted position is the run it
+        // lies in (PlaceInfo::seg_off) -- 8 bytes per lookup through every pass instead of 12.  NRX_PLAN_SEGKEY=0: the 64-bit keys.
+        const bool segkey = bits > 32 && row_bits <= 32 && !(getenv("NRX_PLAN_SEGKEY") && atoi(getenv("NRX_PLAN_SEGKEY")) == 0);
+        sa.segkey = segkey ? 1 : 0;
+        for (int t = 0; t <= n_tables; ++t) pinfo.seg_off[t] = sa.seg_off[t];
+        pinfo.n_seg = n_tables;
+        if (bits <= 32) NRX_SEGSORT(uint32_t, false) else if (segkey) NRX_SEGSORT(uint32_t, true) else NRX_SEGSORT(uint64_t, false)
 #undef NRX_SEGSORT
         NRX_LAUNCH_CHECK("nrx_sparse_plan(segmented sort)");
         return NRX_OK;

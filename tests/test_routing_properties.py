@@ -274,6 +274,71 @@ def test_sparse_plan_ex_padding_split_matches_definition(lens, big, row_bits, ta
     assert st_[1] == (len(w_r) if place else -1)
 
 
+@pytest.mark.gpu
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(nt=st.sampled_from([5, 17, 40, 61]), lens=st.lists(st.integers(min_value=0, max_value=6000), min_size=64, max_size=64),
+       big=st.integers(min_value=0, max_value=200_000), rb=st.lists(st.sampled_from([1, 3, 9, 14, 20, 26, 29, 31]), min_size=64, max_size=64),
+       shared=st.booleans(), seed=st.integers(0, 2 ** 16), sort=st.sampled_from([None, "msd", "lsd", "segmented-bins"]), place=st.booleans(),
+       split=st.booleans(), skew=st.booleans())
+def test_sparse_plan_segment_local_keys_match_definition(nt, lens, big, rb, shared, seed, sort, place, split, skew):
+    """Launches whose table + row bits exceed 32 (many tables next to one of 2^29 .. 2^31 rows: the Wide&Deep shape): the sorted pairs carry the row
+    only and the table of a sorted position is the run it lies in (PlaceInfo::seg_off) -- same plan as the definition, bit for bit, and as the
+    64-bit-key form (NRX_PLAN_SEGKEY=0): runs that end inside a tile, empty tables, tables fed by two features, every sort form, with and
+    without placement and the padding split."""
+    import os
+    import torch
+    from news_recsys_amd import ops
+    rng = np.random.default_rng(seed)
+    rows_t = [max((1 << rb[t]) - (seed % 3 if rb[t] > 2 else 0), 1) for t in range(nt)]
+    rows_t[seed % nt] = (1 << 31) - 5 if seed % 2 else (1 << 29) + 3          # one table that alone needs 30 .. 31 row bits
+    tab = list(range(nt)) + ([int(x) for x in rng.integers(0, nt, 3)] if shared else [])       # (features sharing a table)
+    n = len(tab)
+    ln = [lens[i % 64] for i in range(n)]
+    ln[seed % n] = big
+    if seed % 5 == 0:
+        ln[(seed + 1) % n] = 0                                                  # an empty feature
+    rows = [rows_t[t] for t in tab]
+    ids = []
+    for l_, r in zip(ln, rows):
+        x = rng.integers(0, r, l_)
+        if skew and l_:
+            x = np.where(rng.random(l_) < 0.5, x[0], x)
+        if split and l_:
+            x = np.where(rng.random(l_) < 0.4, 0, x)
+        ids.append(x.astype(np.int64))
+    total = sum(ln)
+    if total == 0:
+        return
+    feats = [f for f in range(n) if (seed >> (f % 16)) & 1] if seed % 4 else list(range(n))
+    dev_ids = [torch.from_numpy(x).to("cuda:0") for x in ids]
+    o_r, u_r, s_r, c_r, d_r, w_r = R.sparse_plan_place(ids, tab, rows, nt, feats)
+    prev = ops.PAD_SPLIT
+    try:
+        if sort:
+            os.environ["NRX_PLAN_SORT"] = sort
+        ops.PAD_SPLIT = "1" if split else "0"
+        for segkey in ("1", "0"):
+            os.environ["NRX_PLAN_SEGKEY"] = segkey
+            res = ops.sparse_plan(dev_ids, tab, rows, nt, place_feats=sum(1 << f for f in feats) if place else None, pad=ops.PadPolicy(total))
+            torch.cuda.synchronize()
+            order, uniq, seg, counts = res[:4]
+            c = counts.cpu().numpy()
+            assert np.array_equal(c, c_r), segkey
+            nu = int(c[0])
+            assert np.array_equal(order.cpu().numpy(), o_r), segkey
+            assert np.array_equal(uniq.cpu().numpy()[:nu], u_r), segkey
+            assert np.array_equal(seg.cpu().numpy()[:nu + 1], s_r), segkey
+            if place:
+                dest, walk, n_walk = res[4:]
+                assert int(n_walk.item()) == len(w_r) and np.array_equal(walk.cpu().numpy()[:len(w_r)], w_r), segkey
+                able = np.isin(np.repeat(np.arange(n), ln), feats)
+                assert np.array_equal(dest.cpu().numpy()[:len(d_r)][able], d_r[able]), segkey
+    finally:
+        ops.PAD_SPLIT = prev
+        os.environ.pop("NRX_PLAN_SORT", None)
+        os.environ.pop("NRX_PLAN_SEGKEY", None)
+
+
 def test_oracle_sparse_plan_place_definition():
     """The placement definition itself, on a case small enough to read: dest names the unique index of a row looked up once
     (not row 0, placeable feature), walk lists every other unique row."""
