@@ -1025,12 +1025,14 @@ def _group_pad(grp, plan: EmbedPlan, B: int) -> Optional["PadPolicy"]:
     """The launch group's PadPolicy at batch size B: groups with multi-valued features from PAD_SPLIT_MIN lookups on, else None."""
     if PAD_SPLIT == "0":
         return None
-    ent = grp.get("pad")
-    if ent is None or ent[0] != B:
+    cache = grp.setdefault("pad", {})          # per batch size (an epoch's last, shorter batch must not reset the full batches' statistics)
+    if B not in cache:
         total = sum(B * max(1, plan.slots[i].bag_len) for i in grp["fs"])
         bags = any(plan.slots[i].kind != NRX_SPARSE for i in grp["fs"])
-        ent = grp["pad"] = (B, PadPolicy(total) if bags and total >= PAD_SPLIT_MIN else None)
-    return ent[1]
+        if len(cache) >= 4:
+            cache.pop(next(iter(cache)))
+        cache[B] = PadPolicy(total) if bags and total >= PAD_SPLIT_MIN else None
+    return cache[B]
 
 
 def _sparse_groups(plan: EmbedPlan):
