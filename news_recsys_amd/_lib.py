@@ -23,6 +23,8 @@ NRX_ABI_VERSION = 2
 NRX_MAX_FEATURES = 64
 NRX_MAX_DCN_LAYERS = 8
 NRX_OK = 0
+NRX_ERR_BAD_ARG = -1
+NRX_ERR_LAUNCH = -2
 NRX_ERR_UNSUPPORTED = -3
 NRX_PLAN_SPLIT_PADDING = 1          # nrx_sparse_plan_ex flags
 

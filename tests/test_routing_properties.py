@@ -339,6 +339,44 @@ def test_sparse_plan_segment_local_keys_match_definition(nt, lens, big, rb, shar
         os.environ.pop("NRX_PLAN_SEGKEY", None)
 
 
+@pytest.mark.gpu
+def test_sparse_plan_ex_rejects_half_a_placement_and_unknown_flags():
+    """nrx_sparse_plan_ex: dest / walk / n_walk go together; flag bits it does not know are an error, not ignored (NRX_ERR_BAD_ARG, nothing
+    enqueued); with all three null it is nrx_sparse_plan."""
+    import ctypes as C
+    import torch
+    from news_recsys_amd import _lib
+    lib = _lib.load()
+    dev = "cuda:0"
+    ids = torch.tensor([3, 0, 3, 5, 0, 1], dtype=torch.int64, device=dev)
+    n = ids.numel()
+    ptrs, lens = (C.c_void_p * 1)(ids.data_ptr()), (C.c_int64 * 1)(n)
+    tof, rws = (C.c_int32 * 1)(0), (C.c_int64 * 1)(8)
+    order, uniq, seg = (torch.empty(n + 1, dtype=torch.int64, device=dev) for _ in range(3))
+    counts = torch.empty(3, dtype=torch.int64, device=dev)
+    dest, walk = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
+    n_walk = torch.empty(1, dtype=torch.int64, device=dev)
+    stats = torch.zeros(5, dtype=torch.int64, device=dev)
+    ws = torch.empty(lib.nrx_sparse_plan_workspace(n), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def call(flags, d, w, nw):
+        return lib.nrx_sparse_plan_ex(ptrs, lens, tof, rws, 1, 64, 1, 1, flags, order.data_ptr(), uniq.data_ptr(), seg.data_ptr(), counts.data_ptr(),
+                                      d, w, nw, stats.data_ptr(), ws.data_ptr(), st)
+    assert call(0, dest.data_ptr(), None, n_walk.data_ptr()) == _lib.NRX_ERR_BAD_ARG
+    assert call(2, dest.data_ptr(), walk.data_ptr(), n_walk.data_ptr()) == _lib.NRX_ERR_BAD_ARG
+    for flags in (0, _lib.NRX_PLAN_SPLIT_PADDING):
+        assert call(flags, None, None, None) == 0, lib.nrx_last_error()
+        torch.cuda.synchronize()
+        o_r, u_r, s_r, c_r = R.sparse_plan([ids.cpu().numpy()], [0], [8], 1)
+        assert np.array_equal(counts.cpu().numpy(), c_r) and np.array_equal(order.cpu().numpy()[:n], o_r)
+        assert stats.tolist() == [int(c_r[0]), -1, -1, n, 2]
+        assert call(flags, dest.data_ptr(), walk.data_ptr(), n_walk.data_ptr()) == 0, lib.nrx_last_error()
+        torch.cuda.synchronize()
+        _, _, _, _, d_r, w_r = R.sparse_plan_place([ids.cpu().numpy()], [0], [8], 1, [0])
+        assert np.array_equal(dest.cpu().numpy(), d_r) and int(n_walk.item()) == len(w_r) and stats.tolist()[1] == len(w_r)
+
+
 def test_oracle_sparse_plan_place_definition():
     """The placement definition itself, on a case small enough to read: dest names the unique index of a row looked up once
     (not row 0, placeable feature), walk lists every other unique row."""
