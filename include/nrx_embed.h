@@ -465,6 +465,9 @@ NRX_API int nrx_dcn_v2_layer_fwd(const float* x0, const float* xl, int64_t ld, i
  * lin: the forward's lin_out; out: the forward's output (ReLU mask; may be NULL when relu == 0).  g_x0 is overwritten,
  * or accumulated into when bit 0 of accumulate_x0 is set (x0 feeds every layer); bit 1 additionally adds the resulting g_x0
  * into g_xl in the dgrad epilogue -- the stack's FIRST layer, whose x_l is x0, so that g_xl is dL/dx of the whole stack.  g_W [dim, dim] and g_b [dim] are overwritten.
+ * relu: bit 0 = ReLU, bit 1 = split-bf16 matrix math (as nrx_dcn_v2_layer_fwd), bit 2 = ORDERED wgrad: g_W / g_b summed over the batch slices in a fixed
+ * order instead of with float atomics (bit-reproducible; the wgrad then runs in fp32 math whatever bit 1 says); layers up to 128 wide take the
+ * ordered mode by default (it costs nothing there).
  * Launches: elementwise preparation + dgrad + wgrad (+ a fill); for dim <= 112 with aligned operands and fp32 math the preparation and the
  * dgrad are ONE launch over 64-row panels (csrc/nrx_dcn2_bwd.hip, dcn2_bwd_panel_kernel: same g_xl / g_x0 value for value).
  * workspace: nrx_dcn_v2_layer_bwd_workspace(batch, dim) device bytes.                                           */
@@ -482,6 +485,12 @@ NRX_API int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld, c
  * order not fixed).                                                                                                 */
 NRX_API int nrx_linear_wgrad(const float* g, int64_t g_ld, const float* a, int64_t a_ld, int64_t batch, int32_t out_features,
                      int32_t in_features, float* g_W, float* g_b, void* stream);
+/* nrx_linear_wgrad with g_W / g_b summed over the batch in a FIXED order -- the blocks store their batch slice's partial tile, a second launch adds the
+ * slices in slice order: no float atomics, the same bits run to run (what GraphedStep(deterministic=True) and NRX_WGRAD=ordered use).  workspace:
+ * nrx_linear_wgrad_ordered_workspace(batch, out_features, in_features) device bytes.  nrx_dcn_v2_layer_bwd takes the same mode as bit 2 of its flags. */
+NRX_API int64_t nrx_linear_wgrad_ordered_workspace(int64_t batch, int32_t out_features, int32_t in_features);
+NRX_API int nrx_linear_wgrad_ordered(const float* g, int64_t g_ld, const float* a, int64_t a_ld, int64_t batch, int32_t out_features,
+                                     int32_t in_features, float* g_W, float* g_b, void* workspace, void* stream);
 
 /* ---- integer utilities of the row-sharded path (bit-exact vs the CPU definitions) -------------
  * Row r of a table lives on rank r % world at local row r / world.                              */

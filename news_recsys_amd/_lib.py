@@ -111,6 +111,8 @@ SIGNATURES = {
     "nrx_dcn_v2_layer_bwd_workspace": (_i64, [_i64, _i32]),
     "nrx_dcn_v2_layer_bwd": (C.c_int, [_p, _p, _i64, _p, _p, _i32, _i64, _i32, _p, _p, _i64, _p, _i64, _p, _i64, _i32, _p, _p, _p, _p]),
     "nrx_linear_wgrad": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p]),
+    "nrx_linear_wgrad_ordered_workspace": (C.c_int64, [_i64, _i32, _i32]),
+    "nrx_linear_wgrad_ordered": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p]),
     "nrx_bucketize_workspace": (_i64, [_i64, _i32]),
     "nrx_bucketize_by_owner": (C.c_int, [_p, _i32, _i64, _i32, _p, _p, _p, _p, _p]),
     "nrx_gather_rows_segmented": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), _i32, _p, _p, _i32, _i64, _i32, _p, _p, _p, _p]),

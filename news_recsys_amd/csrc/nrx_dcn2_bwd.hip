@@ -118,7 +118,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void dcn_v2_bwd_prep_kernel(const float*
     for (int i = threadIdx.x; i < TPR * 4; i += NRX_BLOCK) {
         float t = 0.f;
         for (int r = 0; r < RPB; ++r) t += s_b[r * TPR * 4 + i];
-        if (i < D) unsafeAtomicAdd(g_b + i, t);
+        if (i < D && g_b != nullptr) unsafeAtomicAdd(g_b + i, t);      // (null: the column sums come from the wgrad launch -- the ordered mode)
     }
 }
 
@@ -172,6 +172,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM], int64_t m
                     float v = gmv + acc[t][r];
                     if (add2 != nullptr) v += add2[row * add2_ld + col];      // layer 0 (x0 is x_l): dL/dx = g_xl + g_x0 in one pass
                     out[row * out_ld + col] = v;
+                } else if (add2 != nullptr) {      // ordered mode: this batch slice's partial tile, summed in slice order by wgrad_reduce_kernel
+                    const_cast<float*>(add2)[row * (int64_t)N + col] = acc[t][r];
                 } else {
                     unsafeAtomicAdd(out + row * out_ld + col, acc[t][r]);
                 }
@@ -423,10 +425,12 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_kernel(const float* __restri
             float t = 0.f;
 #pragma unroll 8
             for (int k = 0; k < BK; ++k) t += As[k * LDA + tid];
-            unsafeAtomicAdd(colsum + m0 + tid, t);
+            if (MODE == WGRAD && add2 != nullptr) colsum[(int64_t)ks * M + m0 + tid] = t;      // (ordered mode: per slice)
+            else unsafeAtomicAdd(colsum + m0 + tid, t);
         }
     }
-    gemm_epilogue<MODE, TM>(acc, m0, n0, wm, wn, l31, hi, M, N, addend, add_ld, maskT, mask_ld, out, out_ld, add2, add2_ld);
+    gemm_epilogue<MODE, TM>(acc, m0, n0, wm, wn, l31, hi, M, N, addend, add_ld, maskT, mask_ld, out, out_ld,
+                            MODE == WGRAD && add2 != nullptr ? add2 + (int64_t)ks * add2_ld : add2, add2_ld);
 }
 
 // ---- narrow layers (dim <= 112, the reference's own width): preparation + dgrad in ONE launch --------------------------------------------------
@@ -786,37 +790,60 @@ __global__ __launch_bounds__(256, 4) void dcn2_gemm_split_kernel(const float* __
     gemm_epilogue<MODE, TM>(acc, m0, n0, wm, wn, l31, hi, M, N, addend, add_ld, maskT, mask_ld, out, out_ld, add2, add2_ld);
 }
 
-// out[M, N] += A^T B over the batch (A [batch, M], B [batch, N], both K-major), split into batch slices; out pre-zeroed.
-// Tile and slice choice (tools/dcn2_dgrad_probe.hip, B = 65 536): up to M = 384 the 64 x 64 block tile wins (M = 320 is 5 whole
-// tiles instead of 2.5; narrow layers get twice the tiles to spread over the CUs: D = 112 38 -> 30 us, D = 320 135 -> 123 us), above
-// it the 128 x 64 tile (less LDS traffic per MFMA: D = 512 280 vs 298 us).  ~1 536 (64 x 64) / ~1 024 (128 x 64) blocks, but never
-// slices shorter than 512 / 256 batch rows (256 for a single tile): with few tiles the atomics of a short slice cost more than the
-// blocks it adds.  NRX_WGRAD_TILE / NRX_WGRAD_BLOCKS / NRX_WGRAD_MIN_ROWS override the choice (tools/run_wgrad_sweep.sh).
-void launch_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int64_t batch, float* out, float* colsum, bool vec, hipStream_t st,
-                  bool split = false) {
+// Ordered mode of the wgrad (bit-reproducible g_W / g_b): the blocks store their batch slice's partial tile (and column sums) instead of adding them with
+// float atomics; this kernel sums the slices IN SLICE ORDER.  64 outputs x 16 slice groups per block: a thread sums every 16th slice of its output (a
+// fixed association: the same bits run to run), the groups are added in order through LDS.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, int slices, int64_t mn, float* __restrict__ out,
+                                                             const float* __restrict__ cs_partial, int m, float* __restrict__ colsum) {
+    __shared__ float s_p[16][64];
+    const int li = threadIdx.x & 63, c = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + li, tot = mn + (cs_partial != nullptr ? m : 0);
+    float a0 = 0.f, a1 = 0.f;
+    if (i < tot) {
+        const float* p = i < mn ? partial + i : cs_partial + (i - mn);
+        const int64_t stride = i < mn ? mn : m;
+        int s = c;
+        for (; s + 16 < slices; s += 32) { a0 += p[(int64_t)s * stride]; a1 += p[(int64_t)(s + 16) * stride]; }
+        if (s < slices) a0 += p[(int64_t)s * stride];
+    }
+    s_p[c][li] = a0 + a1;
+    __syncthreads();
+    if (c == 0 && i < tot) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += s_p[k][li];
+        if (i < mn) out[i] = v;
+        else colsum[i - mn] = v;
+    }
+}
+
+// The launch shape of the wgrad: tile height, tiles, batch slices, rows per slice (see launch_wgrad)
+struct WgradShape { bool small; unsigned nx, nt; int64_t splits, kslice; bool xcd; };
+WgradShape wgrad_shape(int M, int N, int64_t batch, bool use_split) {
     static const int env_tile = getenv("NRX_WGRAD_TILE") ? atoi(getenv("NRX_WGRAD_TILE")) : 0;            // tuning: 64 | 128
     static const int env_blocks = getenv("NRX_WGRAD_BLOCKS") ? atoi(getenv("NRX_WGRAD_BLOCKS")) : 0;      // tuning: target block count
     static const int env_rows = getenv("NRX_WGRAD_MIN_ROWS") ? atoi(getenv("NRX_WGRAD_MIN_ROWS")) : 0;    // tuning: shortest batch slice
-    const bool small = env_tile ? env_tile == 64 : M <= 384;
-    const int bm = small ? 64 : BM;
-    const unsigned nx = (unsigned)((N + BN - 1) / BN);
-    const unsigned nt = nx * (unsigned)((M + bm - 1) / bm);
-    int64_t splits = ((env_blocks ? env_blocks : small ? 1536 : 1024) + nt - 1) / nt;
+    WgradShape w;
+    w.small = env_tile ? env_tile == 64 : M <= 384;
+    const int bm = w.small ? 64 : BM;
+    w.nx = (unsigned)((N + BN - 1) / BN);
+    w.nt = w.nx * (unsigned)((M + bm - 1) / bm);
+    const unsigned nt = w.nt;
+    int64_t splits = ((env_blocks ? env_blocks : w.small ? 1536 : 1024) + nt - 1) / nt;
     int64_t kslice = ((batch + splits - 1) / splits + BK - 1) / BK * BK;
-    const int64_t kmin = env_rows ? (env_rows + BK - 1) / BK * BK : (small && nt > 1 ? 16 : 8) * BK;
+    const int64_t kmin = env_rows ? (env_rows + BK - 1) / BK * BK : (w.small && nt > 1 ? 16 : 8) * BK;
     if (kslice < kmin) kslice = kmin;
     splits = (batch + kslice - 1) / kslice;
-    const bool use_split = split && vec && colsum == nullptr;
     // Slices per XCD (gemm_block_to_tile) with the slice count chosen so that every XCD's 32 x 4 block slots hold WHOLE slices in whole rounds:
     // D = 320 (25 tiles of 64 x 64): 5 slices per XCD and round, 2 rounds -> 80 slices of 832 rows, 2000 blocks.  With the round-2 slice
     // count (61) the same order left the XCDs unevenly loaded and the fp32 launch got slower (133 -> 155 us); balanced, it is faster for
     // both kernels (same box, forward + backward per step: fp32 495.6 -> 491.5 us, split-bf16 343.6 -> 335.4, D = 512 1061 -> 1055).
     // NRX_WGRAD_XCD=0 restores the round-2 order for the fp32 kernel and the unbalanced count.
     static const int xcd_env = getenv("NRX_WGRAD_XCD") ? atoi(getenv("NRX_WGRAD_XCD")) : 1;
-    const bool xcd_fp32 = xcd_env == 1 && !use_split;
+    w.xcd = xcd_env == 1 && !use_split;
     if (xcd_env == 1) {
         const int64_t per_round = 128 / nt > 0 ? 128 / nt : 1;                 // slices an XCD's 32 x 4 block slots hold side by side
-        const int64_t want = env_blocks ? env_blocks : small ? 1536 : 1024;
+        const int64_t want = env_blocks ? env_blocks : w.small ? 1536 : 1024;
         int64_t rounds = (want + 4 * per_round * nt) / (8 * per_round * nt);
         if (rounds < 1) rounds = 1;
         splits = 8 * per_round * rounds;
@@ -824,11 +851,39 @@ void launch_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, int 
         if (kslice < kmin) kslice = kmin;
         splits = (batch + kslice - 1) / kslice;
     }
+    w.splits = splits;
+    w.kslice = kslice;
+    return w;
+}
+// scratch of the ordered mode: one [M, N] tile set and M column sums per batch slice
+size_t wgrad_ordered_bytes(int M, int N, int64_t batch) {
+    if (batch <= 0) return 0;
+    const WgradShape w = wgrad_shape(M, N, batch, false);
+    return (size_t)w.splits * ((size_t)M * N + (size_t)M) * sizeof(float) + 256;
+}
+
+// out[M, N] += A^T B over the batch (A [batch, M], B [batch, N], both K-major), split into batch slices; out pre-zeroed.
+// Tile and slice choice (tools/dcn2_dgrad_probe.hip, B = 65 536): up to M = 384 the 64 x 64 block tile wins (M = 320 is 5 whole
+// tiles instead of 2.5; narrow layers get twice the tiles to spread over the CUs: D = 112 38 -> 30 us, D = 320 135 -> 123 us), above
+// it the 128 x 64 tile (less LDS traffic per MFMA: D = 512 280 vs 298 us).  ~1 536 (64 x 64) / ~1 024 (128 x 64) blocks, but never
+// slices shorter than 512 / 256 batch rows (256 for a single tile): with few tiles the atomics of a short slice cost more than the
+// blocks it adds.  NRX_WGRAD_TILE / NRX_WGRAD_BLOCKS / NRX_WGRAD_MIN_ROWS override the choice (tools/run_wgrad_sweep.sh).
+// ordered (a scratch of wgrad_ordered_bytes): no atomics -- per-slice partials + wgrad_reduce_kernel; out / colsum need no zero fill then.
+void launch_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int64_t batch, float* out, float* colsum, bool vec, hipStream_t st,
+                  bool split = false, float* ordered = nullptr) {
+    const bool use_split = split && vec && colsum == nullptr && ordered == nullptr;
+    const WgradShape w = wgrad_shape(M, N, batch, use_split);
+    const bool small = w.small;
+    const unsigned nx = w.nx, nt = w.nt;
+    const int64_t splits = w.splits, kslice = w.kslice;
+    const bool xcd_fp32 = w.xcd;
+    const float* part = ordered;
+    float* cs_part = ordered != nullptr && colsum != nullptr ? ordered + (size_t)splits * M * N : colsum;
     const dim3 grid((unsigned)(nt * ((use_split || xcd_fp32) ? (splits + 7) / 8 * 8 : splits)));     // slices per XCD: whole XCD rounds of slices (gemm_block_to_tile); surplus blocks leave at once
 #define NRX_WGRAD(VEC_, TM_)                                                                                                          \
     hipLaunchKernelGGL((dcn2_gemm_kernel<WGRAD, VEC_, TM_>), grid, dim3(256), 0, st, A, lda, B, ldb, (int64_t)M, N, batch, kslice,     \
                        (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, out, (int64_t)N, nx, nt,              \
-                       (const float*)nullptr, (int64_t)0, colsum, xcd_fp32 ? 1 : 0)
+                       part, (int64_t)M * N, cs_part, xcd_fp32 ? 1 : 0)
     if (use_split) {
         if (small) hipLaunchKernelGGL((dcn2_gemm_split_kernel<WGRAD, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, (int64_t)M, N, batch, kslice,
                                       (const float*)nullptr, (int64_t)0, (const uint32_t*)nullptr, (int64_t)0, out, (int64_t)N, nx, nt, (const float*)nullptr, (int64_t)0);
@@ -838,6 +893,11 @@ void launch_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, int 
     if (small) { if (vec) NRX_WGRAD(true, 1); else NRX_WGRAD(false, 1); }
     else       { if (vec) NRX_WGRAD(true, 2); else NRX_WGRAD(false, 2); }
 #undef NRX_WGRAD
+    if (ordered != nullptr) {
+        const int64_t tot = (int64_t)M * N + (colsum != nullptr ? M : 0);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(1024), 0, st, part, (int)splits, (int64_t)M * N, out,
+                           colsum != nullptr ? (const float*)cs_part : (const float*)nullptr, M, colsum);
+    }
 }
 
 }  // namespace
@@ -845,7 +905,8 @@ void launch_wgrad(const float* A, int64_t lda, const float* B, int64_t ldb, int 
 extern "C" int64_t nrx_dcn_v2_layer_bwd_workspace(int64_t batch, int32_t dim) {
     if (batch < 0 || dim < 1) return -1;
     const int64_t ld = (dim + 3) & ~3;
-    return (batch + (batch + 31) / 32) * ld * (int64_t)sizeof(float) + 512;          // glin [batch, ld] + the ReLU mask bits [ceil(batch / 32), ld]
+    return (batch + (batch + 31) / 32) * ld * (int64_t)sizeof(float) + 512 +         // glin [batch, ld] + the ReLU mask bits [ceil(batch / 32), ld]
+           (int64_t)wgrad_ordered_bytes(dim, dim, batch) + 256;                      // + the per-slice partial tiles of the ordered wgrad (flags bit 2)
 }
 
 extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld, const float* lin, const float* out, int32_t relu,
@@ -856,6 +917,12 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
     NRX_REQUIRE(x0 && xl && lin && W && g_out && g_xl && g_x0 && g_W && g_b && workspace && batch >= 0 && dim >= 1 && ld >= dim,
                 "nrx_dcn_v2_layer_bwd: bad argument");
     const bool split = (relu & 2) != 0;        // flags as in nrx_dcn_v2_layer_fwd: bit 0 = ReLU, bit 1 = split-bf16 matrix math
+    // bit 2 (backward only): g_W / g_b summed over the batch slices in a fixed order (no float atomics).  Layers up to 128 wide take that mode
+    // whatever the bit says: there it costs nothing (dim = 64: GEMM 19.8 -> 12.7 us + 4.7 for the reduction launch; 112: 31.8 -> 28.1 + 5.0; at
+    // dim = 320 the 33 MB of partial tiles make it 12 us slower per layer) and the layer's whole backward is bit-reproducible.
+    // NRX_DCN2_NARROW_ORDERED=0: atomics unless asked.
+    static const bool narrow_ordered = !(getenv("NRX_DCN2_NARROW_ORDERED") && atoi(getenv("NRX_DCN2_NARROW_ORDERED")) == 0);
+    const bool ordered = (relu & 4) != 0 || (narrow_ordered && dim <= 128);
     relu &= 1;
     NRX_REQUIRE(!relu || out != nullptr, "nrx_dcn_v2_layer_bwd: the ReLU mask needs the layer's forward output");
     NRX_REQUIRE(g_ld >= dim && gxl_ld >= dim && gx0_ld >= dim, "nrx_dcn_v2_layer_bwd: bad leading dimension");
@@ -876,7 +943,7 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
     const size_t kp_ = (size_t)((dim + 15) & ~15);
     const size_t lds = ((kp_ * 65 > (size_t)64 * (dim + 4) ? kp_ * 65 : (size_t)64 * (dim + 4)) + kp_ * (dim + 4) + 64) * sizeof(float);
     const bool panel = panel_on && vec && !split && dim >= 8 && dim <= 112 && lds <= 80 * 1024 && batch > 0;
-    if (!panel) {
+    if (!panel && (!ordered || batch == 0)) {          // (the ordered wgrad writes every element of g_W / g_b: no fill)
         if (g_b == g_W + (size_t)dim * dim) {          // g_b right behind g_W (what the Python layer allocates): one fill launch
             if (nrx_zero_async(g_W, sizeof(float) * ((size_t)dim * dim + dim), st) != NRX_OK) return NRX_ERR_LAUNCH;
         } else if (nrx_zero_async(g_W, sizeof(float) * (size_t)dim * dim, st) != NRX_OK || nrx_zero_async(g_b, sizeof(float) * (size_t)dim, st) != NRX_OK)
@@ -885,6 +952,7 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
     if (batch == 0) return NRX_OK;
     float* glin = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     uint32_t* maskT = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(glin + batch * wld) + 255) & ~(uintptr_t)255);
+    float* part = ordered ? reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(maskT + ((batch + 31) / 32) * wld) + 255) & ~(uintptr_t)255) : nullptr;
     if (panel) {
         static const bool attr = [] {
             return hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn2_bwd_panel_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) == hipSuccess &&
@@ -896,7 +964,7 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
                                      glin, wld, g_x0, gx0_ld, acc_x0, fold != nullptr ? 1 : 0, g_xl, gxl_ld, g_W, (int)(dim * dim), g_b, (int)dim);
         else hipLaunchKernelGGL((dcn2_bwd_panel_kernel<false>), dim3(blocks), dim3(256), lds, st, g_out, g_ld, out, x0, lin, ld, batch, (int)dim, W,
                                 glin, wld, g_x0, gx0_ld, acc_x0, fold != nullptr ? 1 : 0, g_xl, gxl_ld, g_W, (int)(dim * dim), g_b, (int)dim);
-        launch_wgrad(glin, wld, xl, ld, dim, dim, batch, g_W, g_b, vec, st, false);       // (g_b: column sums of glin from the wgrad's staging registers)
+        launch_wgrad(glin, wld, xl, ld, dim, dim, batch, g_W, g_b, vec, st, false, part);       // (g_b: column sums of glin from the wgrad's staging registers)
         NRX_LAUNCH_CHECK("nrx_dcn_v2_layer_bwd");
         return NRX_OK;
     }
@@ -909,9 +977,9 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
 #define NRX_PREP(TL_)                                                                                                              \
     case TL_:                                                                                                                      \
         if (vec) hipLaunchKernelGGL((dcn_v2_bwd_prep_kernel<TL_, true>), dim3((unsigned)grid), dim3(NRX_BLOCK), 0, st, g_out, g_ld, out,  \
-                                    x0, lin, ld, batch, dim, relu, glin, wld, g_x0, gx0_ld, acc_x0, g_b, maskT);           \
+                                    x0, lin, ld, batch, dim, relu, glin, wld, g_x0, gx0_ld, acc_x0, ordered ? (float*)nullptr : g_b, maskT);           \
         else hipLaunchKernelGGL((dcn_v2_bwd_prep_kernel<TL_, false>), dim3((unsigned)grid), dim3(NRX_BLOCK), 0, st, g_out, g_ld, out,    \
-                                x0, lin, ld, batch, dim, relu, glin, wld, g_x0, gx0_ld, acc_x0, g_b, maskT);               \
+                                x0, lin, ld, batch, dim, relu, glin, wld, g_x0, gx0_ld, acc_x0, ordered ? (float*)nullptr : g_b, maskT);               \
         break;
         switch (tl) { NRX_PREP(2) NRX_PREP(3) NRX_PREP(4) NRX_PREP(5) NRX_PREP(6) NRX_PREP(7) default: NRX_PREP(8) }
 #undef NRX_PREP
@@ -930,8 +998,32 @@ extern "C" int nrx_dcn_v2_layer_bwd(const float* x0, const float* xl, int64_t ld
                                 dim, (int64_t)dim, (int64_t)dim, g_out, g_ld, mask, wld, g_xl, gxl_ld, nx, (unsigned)nt, fold, gx0_ld, (float*)nullptr);
     }
     // wgrad: g_W[i, j] += sum_b glin[b, i] xl[b, j]   (M = N = dim, K = batch, split over the batch)
-    launch_wgrad(glin, wld, xl, ld, dim, dim, batch, g_W, nullptr, vec, st, split && batch >= 8);
+    if (ordered) launch_wgrad(glin, wld, xl, ld, dim, dim, batch, g_W, g_b, vec, st, false, part);      // (fp32 matrix math whatever bit 1 says; g_b from its staging registers)
+    else launch_wgrad(glin, wld, xl, ld, dim, dim, batch, g_W, nullptr, vec, st, split && batch >= 8);
     NRX_LAUNCH_CHECK("nrx_dcn_v2_layer_bwd");
+    return NRX_OK;
+}
+
+extern "C" int64_t nrx_linear_wgrad_ordered_workspace(int64_t batch, int32_t out_features, int32_t in_features) {
+    if (batch < 0 || out_features < 1 || in_features < 1) return -1;
+    return (int64_t)wgrad_ordered_bytes(out_features, in_features, batch) + 256;
+}
+
+extern "C" int nrx_linear_wgrad_ordered(const float* g, int64_t g_ld, const float* a, int64_t a_ld, int64_t batch, int32_t out_features,
+                                        int32_t in_features, float* g_W, float* g_b, void* workspace, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(g && a && g_W && workspace && batch >= 0 && out_features >= 1 && in_features >= 1 && g_ld >= out_features && a_ld >= in_features,
+                "nrx_linear_wgrad_ordered: bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (batch == 0) {
+        if (nrx_zero_async(g_W, sizeof(float) * (size_t)out_features * in_features, st) != NRX_OK) return NRX_ERR_LAUNCH;
+        if (g_b != nullptr && nrx_zero_async(g_b, sizeof(float) * (size_t)out_features, st) != NRX_OK) return NRX_ERR_LAUNCH;
+        return NRX_OK;
+    }
+    const bool vec = (g_ld & 3) == 0 && (a_ld & 3) == 0 && (out_features & 3) == 0 && (in_features & 3) == 0 && nrx_aligned16(g) && nrx_aligned16(a);
+    float* part = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    launch_wgrad(g, g_ld, a, a_ld, out_features, in_features, batch, g_W, g_b, vec, st, false, part);
+    NRX_LAUNCH_CHECK("nrx_linear_wgrad_ordered");
     return NRX_OK;
 }
 

@@ -18,7 +18,8 @@ gather kernel records an offending id in a host-mapped status word (no read-back
 next `__call__`, `check()` or `ops.flush_index_checks()` reads that word on the host and raises IndexError naming the feature.  With
 `deterministic=True` the dense table gradients come from a deterministic reduction at ANY batch size -- the one-launch small kernel
 (nrx_embed_bwd_small) where every table of the launch takes <= 4096 lookups, else the planned sorted reduction (planned inline, count read on the
-device): replays are bit-reproducible run to run, where the float-atomic scatter is not."""
+device): replays are bit-reproducible run to run, where the float-atomic scatter is not.  The same switch puts the weight gradients this package
+computes over the batch (DCN-v2 layers, `ops.linear`) in their ordered mode (per-slice partial tiles added in slice order, `ops.WGRAD_ORDERED`)."""
 from __future__ import annotations
 
 from typing import Callable, Dict
@@ -36,12 +37,13 @@ class GraphedStep:
     def __init__(self, step_fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor], example_batch: Dict[str, torch.Tensor],
                  warmup: int = 3, deterministic: bool = False):
         self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
-        prev, prev_sorted = ops._INDEX_CHECK, ops.DENSE_BWD_SORTED
+        prev, prev_sorted, prev_wgrad = ops._INDEX_CHECK, ops.DENSE_BWD_SORTED, ops.WGRAD_ORDERED
         ops.flush_index_checks()
         ops.set_index_check("deferred")            # the check stays ON inside the graph: a status word the kernels write, read on the host later
         if deterministic:
             ops.DENSE_BWD_SORTED = "det"           # the choice is baked into the captured launches: the one-launch deterministic kernel
                                                    # where it applies (tables fed by <= 4096 lookups each), else the planned reduction
+            ops.WGRAD_ORDERED = True               # ... and the weight gradients of DCN-v2 layers / ops.linear add their batch slices in a fixed order
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -64,6 +66,7 @@ class GraphedStep:
         finally:
             ops.set_index_check(prev)
             ops.DENSE_BWD_SORTED = prev_sorted
+            ops.WGRAD_ORDERED = prev_wgrad
 
     def check(self) -> None:
         """Raise IndexError if a replay so far met an out-of-range id (synchronises the device)."""

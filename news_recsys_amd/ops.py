@@ -2048,19 +2048,23 @@ def _dcn_v2_layer_backward(lib, x0, xl, lin, out, relu, W, g, g_x0, accumulate, 
     if gb is None:
         gb = torch.empty((D,), dtype=torch.float32, device=xl.device)
     ws = torch.empty(max(1, lib.nrx_dcn_v2_layer_bwd_workspace(B, D)), dtype=torch.uint8, device=xl.device)
-    check(lib.nrx_dcn_v2_layer_bwd(x0.data_ptr(), xl.data_ptr(), D, lin.data_ptr(), _ptr(out), _dcn2_flags(relu, math), B, D, W.data_ptr(),
+    check(lib.nrx_dcn_v2_layer_bwd(x0.data_ptr(), xl.data_ptr(), D, lin.data_ptr(), _ptr(out), _dcn2_flags(relu, math, WGRAD_ORDERED), B, D, W.data_ptr(),
                                    g.data_ptr(), D, g_xl.data_ptr(), D, g_x0.data_ptr(), D, int(accumulate), gW.data_ptr(),
                                    gb.data_ptr(), ws.data_ptr(), _stream_ptr(xl)), "nrx_dcn_v2_layer_bwd")
     return g_xl, gW, gb
 
 
 DCN2_MATH = ("fp32", "bf16x3")
+# Weight gradients that contract over the batch (DCN-v2 layers, ops.linear): "atomic" = every batch slice's partial tile is added with float atomics
+# (the default: one launch); "ordered" = the partial tiles are stored and a second launch adds them in slice order -- the same bits run to run
+# (nrx_linear_wgrad_ordered, flags bit 2 of nrx_dcn_v2_layer_bwd).  GraphedStep(deterministic=True) captures its step in the ordered mode.
+WGRAD_ORDERED = os.environ.get("NRX_WGRAD", "atomic") == "ordered"
 
 
-def _dcn2_flags(relu: bool, math: str) -> int:
+def _dcn2_flags(relu: bool, math: str, ordered: bool = False) -> int:
     if math not in DCN2_MATH:
         raise ValueError(f"dcn_v2 math must be one of {DCN2_MATH}")
-    return (1 if relu else 0) | (2 if math == "bf16x3" else 0)
+    return (1 if relu else 0) | (2 if math == "bf16x3" else 0) | (4 if ordered else 0)
 
 
 class _DcnV2Fn(torch.autograd.Function):
@@ -2188,8 +2192,13 @@ class _LinearFn(torch.autograd.Function):
             gW = torch.empty_like(W, memory_format=torch.contiguous_format)
             if want_b:                        # the bias gradient comes out of the same pass over g
                 gb = torch.empty((W.shape[0],), dtype=torch.float32, device=W.device)
-            check(lib.nrx_linear_wgrad(g2.data_ptr(), g2.stride(0), a2.data_ptr(), a2.stride(0), g2.shape[0], W.shape[0], W.shape[1],
-                                       gW.data_ptr(), _ptr(gb), _stream_ptr(g2)), "nrx_linear_wgrad")
+            if WGRAD_ORDERED:
+                ws = torch.empty(max(1, lib.nrx_linear_wgrad_ordered_workspace(g2.shape[0], W.shape[0], W.shape[1])), dtype=torch.uint8, device=W.device)
+                check(lib.nrx_linear_wgrad_ordered(g2.data_ptr(), g2.stride(0), a2.data_ptr(), a2.stride(0), g2.shape[0], W.shape[0], W.shape[1],
+                                                   gW.data_ptr(), _ptr(gb), ws.data_ptr(), _stream_ptr(g2)), "nrx_linear_wgrad_ordered")
+            else:
+                check(lib.nrx_linear_wgrad(g2.data_ptr(), g2.stride(0), a2.data_ptr(), a2.stride(0), g2.shape[0], W.shape[0], W.shape[1],
+                                           gW.data_ptr(), _ptr(gb), _stream_ptr(g2)), "nrx_linear_wgrad")
         elif want_b:
             gb = g2.sum(0)
         return ga, gW, gb

@@ -68,3 +68,70 @@ def test_mlp_training_step_matches_plain_layers(monkeypatch):
     lf.backward()
     for (n, p), (_, q) in zip(plain.named_parameters(), fast.named_parameters()):
         assert torch.allclose(p.grad, q.grad, rtol=2e-4, atol=1e-7), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,in_f,out_f", [(1, 4, 4), (257, 416, 128), (4096, 128, 64), (1000, 64, 1), (777, 37, 19), (65536, 128, 128),
+                                               (20000, 112, 112), (70001, 320, 320), (5000, 1000, 130), (300000, 16, 16)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_linear_ordered_weight_gradient_is_bit_reproducible_and_matches_fp64(batch, in_f, out_f, bias, monkeypatch):
+    """ops.WGRAD_ORDERED (nrx_linear_wgrad_ordered): every batch slice's partial tile is STORED and the slices are added in slice order by a second
+    launch -- the same bits on every run (three runs compared word for word), where the default mode adds them with float atomics; against fp64
+    like the default mode.  Shapes: one slice, many slices, a last slice shorter than a slab, out_features = 1, unaligned widths (the scalar
+    load path), tiles past the matrix edge."""
+    from news_recsys_amd import ops
+    monkeypatch.setattr(ops, "WGRAD_ORDERED", True)
+    g = torch.Generator(device="cuda").manual_seed(batch + in_f + out_f)
+    a = torch.randn(batch, in_f, device="cuda", generator=g)
+    W = (torch.randn(out_f, in_f, device="cuda", generator=g) / in_f ** 0.5).requires_grad_()
+    b = torch.randn(out_f, device="cuda", generator=g, requires_grad=True) if bias else None
+    up = torch.randn(batch, out_f, device="cuda", generator=g)
+    runs = []
+    for _ in range(3):
+        W.grad = None
+        if b is not None:
+            b.grad = None
+        ops.linear(a, W, b).backward(up)
+        torch.cuda.synchronize()
+        runs.append((W.grad.clone(), b.grad.clone() if b is not None else None))
+    for gw, gb in runs[1:]:
+        assert torch.equal(gw.view(torch.int32), runs[0][0].view(torch.int32))
+        if b is not None:
+            assert torch.equal(gb.view(torch.int32), runs[0][1].view(torch.int32))
+    ref_w = up.double().t() @ a.double()
+    tol = 4e-6 * max(1.0, batch ** 0.5)
+    assert (runs[0][0].double() - ref_w).abs().max().item() <= tol * max(1.0, ref_w.abs().max().item())
+    if b is not None:
+        ref_b = up.double().sum(0)
+        assert (runs[0][1].double() - ref_b).abs().max().item() <= tol * max(1.0, ref_b.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,D,NL", [(130, 112, 3), (20011, 64, 2), (9000, 320, 2), (65, 37, 2), (30000, 16, 1), (4133, 128, 2)])
+@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+def test_dcn_v2_ordered_weight_gradients_are_bit_reproducible(B, D, NL, math, monkeypatch):
+    """The DCN-v2 stack's backward with flags bit 2 (ops.WGRAD_ORDERED): g_W and g_b of every layer word for word the same over three runs -- the panel
+    form (dim <= 112) and the three-launch form, aligned and unaligned widths -- and g_x unchanged by the switch (it never depended on atomics);
+    against the atomic mode within the order of its sums."""
+    from news_recsys_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(B + D + NL)
+    x = torch.randn(B, D, device="cuda", generator=gen).requires_grad_()
+    Ws = [(torch.randn(D, D, device="cuda", generator=gen) / D ** 0.5).requires_grad_() for _ in range(NL)]
+    bs = [(torch.randn(D, device="cuda", generator=gen) * 0.1).requires_grad_() for _ in range(NL)]
+    up = torch.randn(B, D, device="cuda", generator=gen)
+
+    def grads(ordered):
+        monkeypatch.setattr(ops, "WGRAD_ORDERED", ordered)
+        out = ops.dcn_v2(x, Ws, bs, math=math)
+        gs = torch.autograd.grad(out, [x] + Ws + bs, up)
+        torch.cuda.synchronize()
+        return [t.clone() for t in gs]
+    ref = grads(False)
+    runs = [grads(True) for _ in range(3)]
+    for r in runs[1:]:
+        for t0, t1 in zip(runs[0], r):
+            assert torch.equal(t0.view(torch.int32), t1.view(torch.int32))
+    assert torch.equal(runs[0][0], ref[0])                       # g_x: no batch-wide sum in it
+    for t0, t1 in zip(runs[0][1:], ref[1:]):
+        tol = (3e-3 if math == "bf16x3" else 1e-4) * max(1.0, B ** 0.5) * max(1.0, t1.abs().max().item()) * 1e-1
+        assert (t0 - t1).abs().max().item() <= tol
