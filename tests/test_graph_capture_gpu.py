@@ -228,6 +228,54 @@ def test_deterministic_graphed_step_has_bit_reproducible_table_gradients():
         ops.DENSE_BWD_SORTED = prev
 
 
+def test_deterministic_graphed_step_of_a_dcn_v2_model_reproduces_every_gradient(tmp_path, monkeypatch):
+    """GraphedStep(deterministic=True) on a DCN model with the v2 cross stack and the package's MLP weight gradient (utils.MLP_WGRAD): the captured step
+    takes the ORDERED weight gradients (ops.WGRAD_ORDERED: per-slice partial tiles added in slice order) next to the deterministic table gradients --
+    EVERY parameter's gradient is the same bits over three replays of the same batch; the default capture only promises that of nothing that sums
+    over the batch with atomics.  B = 6000: several batch slices per weight gradient, more than 4096 lookups per table."""
+    import yaml
+    from news_recsys_amd import ops
+    from news_recsys_amd.graph import GraphedStep
+    from news_recsys_amd.model.model_utils import utils as mlp_utils
+    from news_recsys_amd.model.sort.dcn.model import DCN
+    cfg = yaml.safe_load(open(os.path.join(CONFIGS, "cf_dcn_small.yaml")))
+    cfg.setdefault("dcn_cfg", {})["version"] = 2
+    cfg["dcn_cfg"]["cross_num_layers"] = 2
+    path = tmp_path / "dcn_v2.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    monkeypatch.setattr(mlp_utils, "MLP_WGRAD", True)
+    torch.manual_seed(29)
+    m = DCN(str(path)).to(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    batches = [_batch(m, 6000, gen) for _ in range(2)]
+
+    def step(b):
+        for p in m.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        loss = F.binary_cross_entropy(m(b).view(-1), b["label"][:, 0])
+        loss.backward()
+        return loss
+
+    before = ops.WGRAD_ORDERED
+    gs = GraphedStep(step, batches[0], warmup=2, deterministic=True)
+    assert ops.WGRAD_ORDERED == before                          # (the switch is the capture's, not the process's)
+    runs = []
+    for _ in range(3):
+        gs(batches[1])
+        torch.cuda.synchronize()
+        runs.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert len(runs[0]) >= 8
+    for n, g0 in runs[0].items():
+        for r in runs[1:]:
+            assert torch.equal(g0.view(torch.int32), r[n].view(torch.int32)), n
+    step(batches[1])                                            # eager, default modes: the same gradients up to the order of the additions
+    torch.cuda.synchronize()
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            torch.testing.assert_close(runs[0][n], p.grad, rtol=2e-3, atol=2e-5)
+
+
 def test_deterministic_mode_says_so_when_it_cannot_be_deterministic(monkeypatch):
     """A deterministic mode that falls back to float atomics must not do so silently (round-4 advice): with more than 64 tables neither the
     planned reduction nor -- beyond 4096 lookups per table -- the one-launch kernel serves the launch: the eager backward warns, and
