@@ -437,6 +437,15 @@ NRX_API int nrx_dcn_v1_fwd(const float* x, int64_t x_ld, const float* x0, int64_
 NRX_API int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int64_t x0_ld, int64_t batch, int32_t dim,
                    int32_t n_layers, const float* w, const float* b, const float* g_out, int64_t g_out_ld,
                    float* g_x, int64_t g_x_ld, float* g_x0, int64_t g_x0_ld, float* g_w, float* g_b, void* stream);
+/* nrx_dcn_v1_bwd with g_w / g_b (sums over the batch) added block by block in BLOCK ORDER by a second launch instead of with float atomics: the same
+ * bits run to run (g_x / g_x0 never depended on atomics).  g_w / g_b are overwritten (no zero fill needed).  workspace:
+ * nrx_dcn_v1_bwd_ordered_workspace(dim, n_layers) device bytes.  NRX_ERR_UNSUPPORTED (nothing enqueued) when n_layers x dim is beyond the LDS slabs
+ * of the fixed-order block sum (the per-row LDS-atomic body: e.g. 8 layers x 2048). */
+NRX_API int64_t nrx_dcn_v1_bwd_ordered_workspace(int32_t dim, int32_t n_layers);
+NRX_API int nrx_dcn_v1_bwd_ordered(const float* x, int64_t x_ld, const float* x0, int64_t x0_ld, int64_t batch, int32_t dim,
+                                   int32_t n_layers, const float* w, const float* b, const float* g_out, int64_t g_out_ld,
+                                   float* g_x, int64_t g_x_ld, float* g_x0, int64_t g_x0_ld, float* g_w, float* g_b, void* workspace,
+                                   void* stream);
 
 /* Fused gather -> concat -> DCN-v1 cross for the DCN ranker (dcn/model.py:25-29 on top of
  * base_model.py:284-308): out[:, 0:width] = concat of the looked-up rows (x), out[:, width:2*width] =

@@ -106,6 +106,8 @@ SIGNATURES = {
     "nrx_fm_head_bwd": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _p]),
     "nrx_dcn_v1_fwd": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p]),
     "nrx_dcn_v1_bwd": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p]),
+    "nrx_dcn_v1_bwd_ordered_workspace": (C.c_int64, [_i32, _i32]),
+    "nrx_dcn_v1_bwd_ordered": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p]),
     "nrx_embed_dcn_v1_fwd": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _i32, _p, _i64, _i32, _p, _p, _p, _p]),
     "nrx_dcn_v2_layer_fwd": (C.c_int, [_p, _p, _i64, _i64, _i32, _p, _p, _i32, _p, _i64, _p, _p]),
     "nrx_dcn_v2_layer_bwd_workspace": (_i64, [_i64, _i32]),

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
                                                                float* __restrict__ g_x, int64_t g_x_ld,
                                                                float* __restrict__ g_w, float* __restrict__ g_b,
                                                                const float* __restrict__ x0p, int64_t x0_ld,
-                                                               float* __restrict__ g_x0, int64_t g_x0_ld) {
+                                                               float* __restrict__ g_x0, int64_t g_x0_ld, int ordered) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Dp = (D + 3) & ~3;
     float* s_w = reinterpret_cast<float*>(smem);   // [NL][Dp]
@@ -508,8 +508,13 @@ __global__ __launch_bounds__(DCN_BWD_BLOCK) void dcn_v1_bwd_kernel(const float* 
         const int l = i / Dp, c = i - l * Dp;
 #ifndef NRX_PROBE_NOFLUSH
         if (c < D) {
-            unsafeAtomicAdd(&g_w[l * (int64_t)D + c], s_gw[i]);
-            unsafeAtomicAdd(&g_b[l * (int64_t)D + c], s_gb[i]);
+            if (ordered) {                  // this block's sums to its own slot [block][NL][D]: dcn_v1_reduce_kernel adds the blocks in block order
+                g_w[((int64_t)blockIdx.x * NL + l) * D + c] = s_gw[i];
+                g_b[((int64_t)blockIdx.x * NL + l) * D + c] = s_gb[i];
+            } else {
+                unsafeAtomicAdd(&g_w[l * (int64_t)D + c], s_gw[i]);
+                unsafeAtomicAdd(&g_b[l * (int64_t)D + c], s_gb[i]);
+            }
         }
 #endif
     }
@@ -1001,15 +1006,31 @@ extern "C" int nrx_dcn_v1_fwd(const float* x, int64_t x_ld, const float* x0, int
     return NRX_OK;
 }
 
-extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int64_t x0_ld, int64_t batch, int32_t dim,
-                              int32_t n_layers, const float* w, const float* b, const float* g_out, int64_t g_out_ld,
-                              float* g_x, int64_t g_x_ld, float* g_x0, int64_t g_x0_ld, float* g_w, float* g_b, void* stream) {
-    NRX_TRACE();
+// ordered_ws (null: float atomics): every block leaves its g_w / g_b sums in its own slot of the scratch, *grid_out = the blocks launched
+constexpr int DCN_V1_MAX_BLOCKS = 1024;
+static int dcn_v1_bwd_impl(const float* x, int64_t x_ld, const float* x0, int64_t x0_ld, int64_t batch, int32_t dim,
+                           int32_t n_layers, const float* w, const float* b, const float* g_out, int64_t g_out_ld,
+                           float* g_x, int64_t g_x_ld, float* g_x0, int64_t g_x0_ld, float* g_w_user, float* g_b_user, void* stream,
+                           float* ordered_ws, unsigned* grid_out) {
+    const int ordered = ordered_ws != nullptr ? 1 : 0;
+    float* g_w = ordered ? ordered_ws : g_w_user;
+    float* g_b = ordered ? ordered_ws + (size_t)DCN_V1_MAX_BLOCKS * (n_layers > 0 ? n_layers : 1) * dim : g_b_user;
+    unsigned last_grid = 0;
+    struct GridOut { unsigned* p; unsigned* v; ~GridOut() { if (p) *p = *v; } } grid_guard{grid_out, &last_grid};
     NRX_REQUIRE(x && g_out && g_x && batch >= 0 && dim >= 1, "nrx_dcn_v1_bwd: bad argument");
     if (x0 == x && x0_ld == x_ld && g_x0 == nullptr) x0 = nullptr;
     NRX_REQUIRE((x0 == nullptr) == (g_x0 == nullptr), "nrx_dcn_v1_bwd: x0 and g_x0 go together (both null: x0 is x, one gradient)");
     NRX_REQUIRE(n_layers >= 0 && n_layers <= NRX_MAX_DCN_LAYERS, "nrx_dcn_v1_bwd: n_layers must be in [0, %d]", NRX_MAX_DCN_LAYERS);
     NRX_REQUIRE(n_layers == 0 || (w && b && g_w && g_b), "nrx_dcn_v1_bwd: null cross weights");
+    if (ordered && n_layers > 0) {      // (the per-row LDS-atomic body -- n_layers x dim beyond the LDS slabs -- has no fixed order inside a block)
+        const size_t Dp_ = (size_t)((dim + 3) & ~3);
+        const bool vec_ = (dim & 3) == 0;
+        if (((size_t)4 * n_layers + (size_t)(vec_ && dim <= 128 ? 8 : 4) * n_layers * 2) * Dp_ * sizeof(float) > 128 * 1024 &&
+            !(n_layers <= 4 && (dim + 64 * (vec_ ? 4 : 1) - 1) / (64 * (vec_ ? 4 : 1)) <= 2)) {
+            nrx_set_error("nrx_dcn_v1_bwd_ordered: n_layers * dim too large for the ordered mode");
+            return NRX_ERR_UNSUPPORTED;
+        }
+    }
     NRX_REQUIRE(dim <= 2048, "nrx_dcn_v1_bwd: dim %d > 2048 unsupported", dim);
     if (batch == 0) return NRX_OK;
     const bool vec = (dim & 3) == 0 && (x_ld & 3) == 0 && (g_out_ld & 3) == 0 && (g_x_ld & 3) == 0 &&
@@ -1037,9 +1058,9 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
         auto kern = dcn_v1_bwd_kernel<(RR <= 2 ? RR : 2), VV, NLR_, DCN_BWD_BLOCK>;      /* nlr > 0 only with R <= 2 */     \
         if (smem > 64 * 1024)                                                                                       \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(DCN_BWD_BLOCK), smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, \
+        last_grid = grid; hipLaunchKernelGGL(kern, dim3(grid), dim3(DCN_BWD_BLOCK), smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, \
                            batch, dim, n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b,                      \
-                           (const float*)nullptr, (int64_t)0, (float*)nullptr, (int64_t)0);                         \
+                           (const float*)nullptr, (int64_t)0, (float*)nullptr, (int64_t)0, ordered);                         \
     })
     if (vec && dim <= 128) {          // two rows per wavefront (see nrx_dcn_v1_fwd)
         const int64_t pairs = (batch + 1) / 2;
@@ -1051,8 +1072,8 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
             auto kern = dcn_v1_bwd_kernel<1, 4, NLR_, BLK_, SEP_, 32>;                                              \
             if (smem > 64 * 1024)                                                                                   \
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(BLK_), smem, st, x, x_ld, batch, dim, n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, \
-                               g_w, g_b, x0, x0_ld, g_x0, g_x0_ld);                                                 \
+            last_grid = grid; hipLaunchKernelGGL(kern, dim3(grid), dim3(BLK_), smem, st, x, x_ld, batch, dim, n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, \
+                               g_w, g_b, x0, x0_ld, g_x0, g_x0_ld, ordered);                                                 \
         }
         if (x0 != nullptr && n_layers == 1) NRX_DCN_BWD_H(1, 1024, true)      // DCNLayer.forward(x_l, x_0): one layer, register accumulation
         else if (x0 != nullptr) { smem = gen_smem; NRX_DCN_BWD_H(0, 256, true) }
@@ -1074,8 +1095,8 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
             auto kern = dcn_v1_bwd_kernel<(RR <= 2 ? RR : 2), VV, 1, 1024, true>;
             if (smem > 64 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, batch, dim,
-                               n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b, x0, x0_ld, g_x0, g_x0_ld);
+            last_grid = grid; hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, batch, dim,
+                               n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b, x0, x0_ld, g_x0, g_x0_ld, ordered);
         });
         NRX_LAUNCH_CHECK("nrx_dcn_v1_bwd(x0, one layer)");
         return NRX_OK;
@@ -1088,16 +1109,16 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
             auto kern = dcn_v1_bwd_kernel<RR, VV, 0, 256, SEP_, 64, false>;                                         \
             if (gen_smem > 64 * 1024)                                                                               \
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gen_smem); \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), gen_smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, batch, dim, \
-                               n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b, x0, x0_ld, g_x0, g_x0_ld);   \
+            last_grid = grid; hipLaunchKernelGGL(kern, dim3(grid), dim3(256), gen_smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, batch, dim, \
+                               n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b, x0, x0_ld, g_x0, g_x0_ld, ordered);   \
         } else {                                                                                                    \
             unsigned grid = (unsigned)((batch + 512 / 64 - 1) / (512 / 64));                                        \
             if (grid > 512u) grid = 512u;                                                                           \
             auto kern = dcn_v1_bwd_kernel<RR, VV, 0, 512, SEP_, 64, true>;                                          \
             if (smem > 64 * 1024)                                                                                   \
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, batch, dim, \
-                               n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b, x0, x0_ld, g_x0, g_x0_ld);   \
+            last_grid = grid; hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, reinterpret_cast<hipStream_t>(stream), x, x_ld, batch, dim, \
+                               n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_w, g_b, x0, x0_ld, g_x0, g_x0_ld, ordered);   \
         }                                                                                                           \
     })
     if (x0 != nullptr) {      // separate layer-0 input, more than one layer (or a wide row): the generic body
@@ -1115,6 +1136,69 @@ extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int
 #undef NRX_DCN_BWD
 #undef NRX_DCN_BWD_GEN
     NRX_LAUNCH_CHECK("nrx_dcn_v1_bwd");
+    return NRX_OK;
+}
+
+namespace {
+// ordered mode: g_w / g_b = the blocks' slots added in block order (64 outputs x 16 block groups per block; a fixed association)
+__global__ __launch_bounds__(1024) void dcn_v1_reduce_kernel(const float* __restrict__ pw, const float* __restrict__ pb, int blocks, int n_out,
+                                                              float* __restrict__ g_w, float* __restrict__ g_b) {
+    __shared__ float s_p[16][64];
+    const int li = threadIdx.x & 63, c = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + li;
+    float a0 = 0.f, a1 = 0.f;
+    if (i < 2 * n_out) {
+        const float* p = i < n_out ? pw + i : pb + (i - n_out);
+        int sb = c;
+        for (; sb + 16 < blocks; sb += 32) { a0 += p[(int64_t)sb * n_out]; a1 += p[(int64_t)(sb + 16) * n_out]; }
+        if (sb < blocks) a0 += p[(int64_t)sb * n_out];
+    }
+    s_p[c][li] = a0 + a1;
+    __syncthreads();
+    if (c == 0 && i < 2 * n_out) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += s_p[k][li];
+        if (i < n_out) g_w[i] = v;
+        else g_b[i - n_out] = v;
+    }
+}
+}  // namespace
+
+extern "C" int nrx_dcn_v1_bwd(const float* x, int64_t x_ld, const float* x0, int64_t x0_ld, int64_t batch, int32_t dim,
+                              int32_t n_layers, const float* w, const float* b, const float* g_out, int64_t g_out_ld,
+                              float* g_x, int64_t g_x_ld, float* g_x0, int64_t g_x0_ld, float* g_w, float* g_b, void* stream) {
+    NRX_TRACE();
+    return dcn_v1_bwd_impl(x, x_ld, x0, x0_ld, batch, dim, n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_x0, g_x0_ld, g_w, g_b, stream, nullptr, nullptr);
+}
+
+extern "C" int64_t nrx_dcn_v1_bwd_ordered_workspace(int32_t dim, int32_t n_layers) {
+    if (dim < 1 || n_layers < 0 || n_layers > NRX_MAX_DCN_LAYERS) return -1;
+    return (int64_t)2 * DCN_V1_MAX_BLOCKS * (n_layers > 0 ? n_layers : 1) * dim * (int64_t)sizeof(float) + 512;
+}
+
+extern "C" int nrx_dcn_v1_bwd_ordered(const float* x, int64_t x_ld, const float* x0, int64_t x0_ld, int64_t batch, int32_t dim,
+                                      int32_t n_layers, const float* w, const float* b, const float* g_out, int64_t g_out_ld,
+                                      float* g_x, int64_t g_x_ld, float* g_x0, int64_t g_x0_ld, float* g_w, float* g_b, void* workspace,
+                                      void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(workspace != nullptr, "nrx_dcn_v1_bwd_ordered: null workspace");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (n_layers == 0 || batch == 0) {
+        if (n_layers > 0 && g_w && g_b &&
+            (nrx_zero_async(g_w, sizeof(float) * (size_t)n_layers * dim, st) != NRX_OK || nrx_zero_async(g_b, sizeof(float) * (size_t)n_layers * dim, st) != NRX_OK))
+            return NRX_ERR_LAUNCH;
+        return dcn_v1_bwd_impl(x, x_ld, x0, x0_ld, batch, dim, n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_x0, g_x0_ld, g_w, g_b, stream, nullptr, nullptr);
+    }
+    float* ws = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    unsigned grid = 0;
+    const int rc = dcn_v1_bwd_impl(x, x_ld, x0, x0_ld, batch, dim, n_layers, w, b, g_out, g_out_ld, g_x, g_x_ld, g_x0, g_x0_ld, g_w, g_b, stream, ws, &grid);
+    if (rc != NRX_OK) return rc;
+    NRX_REQUIRE(grid >= 1 && grid <= (unsigned)DCN_V1_MAX_BLOCKS, "nrx_dcn_v1_bwd_ordered: unexpected launch shape");
+    const int n_out = n_layers * dim;
+    hipLaunchKernelGGL(dcn_v1_reduce_kernel, dim3((unsigned)((2 * n_out + 63) / 64)), dim3(1024), 0, st, (const float*)ws,
+                       (const float*)(ws + (size_t)DCN_V1_MAX_BLOCKS * n_layers * dim), (int)grid, n_out, g_w, g_b);
+    NRX_LAUNCH_CHECK("nrx_dcn_v1_bwd_ordered");
     return NRX_OK;
 }
 

@@ -19,7 +19,8 @@ next `__call__`, `check()` or `ops.flush_index_checks()` reads that word on the 
 `deterministic=True` the dense table gradients come from a deterministic reduction at ANY batch size -- the one-launch small kernel
 (nrx_embed_bwd_small) where every table of the launch takes <= 4096 lookups, else the planned sorted reduction (planned inline, count read on the
 device): replays are bit-reproducible run to run, where the float-atomic scatter is not.  The same switch puts the weight gradients this package
-computes over the batch (DCN-v2 layers, `ops.linear`) in their ordered mode (per-slice partial tiles added in slice order, `ops.WGRAD_ORDERED`)."""
+computes over the batch (DCN-v1 / DCN-v2 cross layers, `ops.linear`) in their ordered mode (per-slice / per-block partial sums added in a fixed
+order by a second launch, `ops.WGRAD_ORDERED`); a capture that would still need float atomics somewhere is refused."""
 from __future__ import annotations
 
 from typing import Callable, Dict
@@ -61,8 +62,9 @@ class GraphedStep:
                 self._result = step_fn(self._static)
             self._names = list(ops._host_status_names)      # the feature-name lists of the captured gather launches
             if deterministic and ops.dense_bwd_paths["atomic"] != atomic_before:
-                raise RuntimeError("GraphedStep(deterministic=True): a backward launch of the captured step took the float-atomic scatter (more than "
-                                   "64 tables, or a feature on a routed-row buffer): its replays would not be bit-reproducible")
+                raise RuntimeError("GraphedStep(deterministic=True): a backward launch of the captured step took float atomics (an embedding launch "
+                                   "with more than 64 tables or a feature on a routed-row buffer, or a DCN-v1 stack beyond the ordered mode): its replays "
+                                   "would not be bit-reproducible")
         finally:
             ops.set_index_check(prev)
             ops.DENSE_BWD_SORTED = prev_sorted

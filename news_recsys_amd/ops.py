@@ -1766,6 +1766,27 @@ def _dcn_params(w: torch.Tensor, b: torch.Tensor):
     return w, b
 
 
+
+def _dcn_v1_bwd(lib, args, dim: int, n_layers: int, dev, stream) -> None:
+    """nrx_dcn_v1_bwd(*args, stream), or -- ops.WGRAD_ORDERED -- nrx_dcn_v1_bwd_ordered: the cross weights' and biases' gradients (sums over the
+    batch) added block by block in block order instead of with float atomics.  Stacks whose n_layers x dim is beyond the ordered mode's LDS slabs
+    (NRX_ERR_UNSUPPORTED, nothing enqueued) keep the atomic launch."""
+    if WGRAD_ORDERED and n_layers > 0:
+        ws = torch.empty(lib.nrx_dcn_v1_bwd_ordered_workspace(dim, n_layers), dtype=torch.uint8, device=dev)
+        rc = lib.nrx_dcn_v1_bwd_ordered(*args, ws.data_ptr(), stream)
+        if rc != NRX_ERR_UNSUPPORTED:
+            check(rc, "nrx_dcn_v1_bwd_ordered")
+            return
+        # not silently: the eager step warns (once per shape), a deterministic capture refuses (GraphedStep reads the counter)
+        dense_bwd_paths["atomic"] += 1
+        if ("dcn_v1", n_layers, dim) not in _atomic_warned:
+            _atomic_warned.add(("dcn_v1", n_layers, dim))
+            import warnings
+            warnings.warn(f"ordered weight gradients asked for, but a DCN stack of {n_layers} layers x {dim} columns is beyond the ordered mode of "
+                          "nrx_dcn_v1_bwd: its cross weights' gradients are summed with float atomics (not bit-reproducible)", RuntimeWarning, stacklevel=3)
+    check(lib.nrx_dcn_v1_bwd(*args, stream), "nrx_dcn_v1_bwd")
+
+
 class _DcnV1Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, x0):
@@ -1797,8 +1818,8 @@ class _DcnV1Fn(torch.autograd.Function):
         gx0 = torch.empty_like(x) if ctx.sep else None
         gw = torch.zeros_like(w)
         gb = torch.zeros_like(b)
-        check(lib.nrx_dcn_v1_bwd(x.data_ptr(), D, _ptr(x0), D, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), g.data_ptr(), D,
-                                 gx.data_ptr(), D, _ptr(gx0), D, gw.data_ptr(), gb.data_ptr(), _stream_ptr(x)), "nrx_dcn_v1_bwd")
+        _dcn_v1_bwd(lib, (x.data_ptr(), D, _ptr(x0), D, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), g.data_ptr(), D,
+                          gx.data_ptr(), D, _ptr(gx0), D, gw.data_ptr(), gb.data_ptr()), D, w.shape[0], x.device, _stream_ptr(x))
         return gx, gw, gb, gx0
 
 
@@ -1833,8 +1854,8 @@ class _DcnV1LayersFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         gw = torch.zeros_like(w)
         gb = torch.zeros_like(b)
-        check(lib.nrx_dcn_v1_bwd(x.data_ptr(), D, None, D, B, D, n, w.data_ptr(), b.data_ptr(), g.data_ptr(), D, gx.data_ptr(), D, None, D,
-                                 gw.data_ptr(), gb.data_ptr(), _stream_ptr(x)), "nrx_dcn_v1_bwd")
+        _dcn_v1_bwd(lib, (x.data_ptr(), D, None, D, B, D, n, w.data_ptr(), b.data_ptr(), g.data_ptr(), D, gx.data_ptr(), D, None, D,
+                          gw.data_ptr(), gb.data_ptr()), D, n, x.device, _stream_ptr(x))
         grads = [gw[l].reshape(ctx.shapes[l]) for l in range(n)] + [gb[l].reshape(ctx.shapes[n + l]) for l in range(n)]
         return (gx, None, *grads)
 
@@ -1904,9 +1925,9 @@ class _DcnV1CatFn(torch.autograd.Function):
         gbuf = torch.zeros_like(buf)          # right half of the input buffer was never read
         gw = torch.zeros_like(w)
         gb = torch.zeros_like(b)
-        check(lib.nrx_dcn_v1_bwd(buf.data_ptr(), W2, None, 0, B, D, w.shape[0], w.data_ptr(), b.data_ptr(),
-                                 g.data_ptr() + 4 * D, W2, gbuf.data_ptr(), W2, None, 0, gw.data_ptr(), gb.data_ptr(),
-                                 _stream_ptr(buf)), "nrx_dcn_v1_bwd")
+        _dcn_v1_bwd(lib, (buf.data_ptr(), W2, None, 0, B, D, w.shape[0], w.data_ptr(), b.data_ptr(),
+                          g.data_ptr() + 4 * D, W2, gbuf.data_ptr(), W2, None, 0, gw.data_ptr(), gb.data_ptr()), D, w.shape[0], buf.device,
+                    _stream_ptr(buf))
         gbuf[:, :D] += g[:, :D]
         return gbuf, gw, gb
 
@@ -2011,8 +2032,8 @@ class _EmbedDcnFn(torch.autograd.Function):
         gx = torch.empty((B, D), dtype=torch.float32, device=buf.device)
         gw = torch.zeros_like(w)
         gb = torch.zeros_like(b)
-        check(lib.nrx_dcn_v1_bwd(buf.data_ptr(), W2, None, 0, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), g.data_ptr() + 4 * D, W2,
-                                 gx.data_ptr(), D, None, 0, gw.data_ptr(), gb.data_ptr(), _stream_ptr(buf)), "nrx_dcn_v1_bwd")
+        _dcn_v1_bwd(lib, (buf.data_ptr(), W2, None, 0, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), g.data_ptr() + 4 * D, W2,
+                          gx.data_ptr(), D, None, 0, gw.data_ptr(), gb.data_ptr()), D, w.shape[0], buf.device, _stream_ptr(buf))
         gx += g[:, :D]
         table_grads = _EmbedFn.backward(ctx, gx, None, None)[7:]
         return (None, None, None, gw.view(ctx.w_shape), gb.view(ctx.b_shape), *table_grads)

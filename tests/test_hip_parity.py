@@ -608,6 +608,63 @@ def test_dcn_v1_vs_oracle(B, D, NL):
         np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(want).max() if want.size else 0.0))
 
 
+def test_dcn_v1_ordered_mode_says_so_when_a_stack_is_beyond_it(monkeypatch):
+    """8 layers x 1000 columns do not fit the LDS slabs of the fixed-order block sum: nrx_dcn_v1_bwd_ordered refuses (NRX_ERR_UNSUPPORTED, nothing
+    enqueued) and ops takes the atomic launch -- with a warning and a count that a deterministic capture refuses on, not silently."""
+    import warnings
+    monkeypatch.setattr(ops, "WGRAD_ORDERED", True)
+    monkeypatch.setattr(ops, "_atomic_warned", set())
+    rng = np.random.default_rng(8)
+    B, D, NL = 300, 1000, 8
+    x = dev(rng.standard_normal((B, D)).astype(np.float32)).requires_grad_(True)
+    w = dev((rng.standard_normal((NL, D)) / np.sqrt(D)).astype(np.float32)).requires_grad_(True)
+    b = dev((rng.standard_normal((NL, D)) * 0.1).astype(np.float32)).requires_grad_(True)
+    before = ops.dense_bwd_paths["atomic"]
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        ops.dcn_v1(x, w, b).sum().backward()
+        torch.cuda.synchronize()
+    assert any("beyond the ordered mode" in str(r.message) for r in rec)
+    assert ops.dense_bwd_paths["atomic"] == before + 1
+    gx, gw, gb = R.dcn_v1_bwd(x.detach().cpu().numpy(), w.detach().cpu().numpy(), b.detach().cpu().numpy(), np.ones((B, D), np.float32))
+    np.testing.assert_allclose(w.grad.cpu().numpy(), gw, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(gw).max()))
+
+
+@pytest.mark.parametrize("B,D,NL", [(1, 4, 1), (100, 320, 2), (9000, 112, 3), (6500, 37, 3), (3100, 320, 8), (5000, 2048, 1), (30000, 96, 6),
+                                    (70000, 320, 5), (20011, 640, 2), (65536, 64, 4), (12345, 128, 2)])
+@pytest.mark.parametrize("sep", [False, True])
+def test_dcn_v1_ordered_cross_gradients_are_bit_reproducible(B, D, NL, sep, monkeypatch):
+    """ops.WGRAD_ORDERED (nrx_dcn_v1_bwd_ordered): every block leaves its sums of g_w / g_b in its own slot and a second launch adds the blocks in
+    block order -- three runs word for word the same, every launch form of the backward (register accumulation 1 .. 4 layers, the slab body for
+    deeper / wider stacks, two rows per wavefront for dim <= 128, a separate layer-0 input), and equal to the atomic mode within the order of
+    its sums; g_x is untouched by the switch."""
+    rng = np.random.default_rng(B + D + NL)
+    x = dev(rng.standard_normal((B, D)).astype(np.float32)).requires_grad_(True)
+    x0 = dev(rng.standard_normal((B, D)).astype(np.float32)).requires_grad_(True) if sep else None
+    w = dev((rng.standard_normal((NL, D)) / np.sqrt(D)).astype(np.float32)).requires_grad_(True)
+    b = dev((rng.standard_normal((NL, D)) * 0.1).astype(np.float32)).requires_grad_(True)
+    up = dev(rng.standard_normal((B, D)).astype(np.float32))
+
+    def grads(ordered):
+        monkeypatch.setattr(ops, "WGRAD_ORDERED", ordered)
+        if sep:
+            gs = torch.autograd.grad(ops.dcn_v1(x, w, b, x0=x0), [x, x0, w, b], up)
+        else:
+            gs = torch.autograd.grad(ops.dcn_v1(x, w, b), [x, w, b], up)
+        torch.cuda.synchronize()
+        return [t.clone() for t in gs]
+    ref = grads(False)
+    runs = [grads(True) for _ in range(3)]
+    for r in runs[1:]:
+        for t0, t1 in zip(runs[0], r):
+            assert torch.equal(t0.view(torch.int32), t1.view(torch.int32))
+    n_x = 2 if sep else 1
+    for k in range(n_x):
+        assert torch.equal(runs[0][k], ref[k])
+    for t0, t1 in zip(runs[0][n_x:], ref[n_x:]):
+        torch.testing.assert_close(t0, t1, rtol=2e-4, atol=2e-5 * max(1.0, B ** 0.5) * max(1.0, t1.abs().max().item()) * 0.1)
+
+
 @pytest.mark.parametrize("B,D,NL", [(1, 4, 1), (200, 320, 2), (130, 112, 3), (65, 37, 2), (1000, 64, 1), (127, 129, 1),
                                     # 64 < D <= 128, D % 4 == 0: the narrow kernel (W in registers, persistent 64-row tiles) at every
                                     # group count, partial last tiles, and batches larger than one pass of the persistent grid
