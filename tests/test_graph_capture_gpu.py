@@ -306,7 +306,7 @@ def test_deterministic_mode_says_so_when_it_cannot_be_deterministic(monkeypatch)
     assert ops.dense_bwd_paths["atomic"] > before
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        with pytest.raises(RuntimeError, match="float-atomic"):
+        with pytest.raises(RuntimeError, match="float atomics"):
             GraphedStep(step, {"x": ids[0]}, warmup=1, deterministic=True)
     # ... and the supported shape (<= 64 tables) still takes a deterministic form, silently
     monkeypatch.setattr(ops, "DENSE_BWD_SORTED", "det")
