@@ -1767,23 +1767,35 @@ def _dcn_params(w: torch.Tensor, b: torch.Tensor):
 
 
 
-def _dcn_v1_bwd(lib, args, dim: int, n_layers: int, dev, stream) -> None:
-    """nrx_dcn_v1_bwd(*args, stream), or -- ops.WGRAD_ORDERED -- nrx_dcn_v1_bwd_ordered: the cross weights' and biases' gradients (sums over the
-    batch) added block by block in block order instead of with float atomics.  Stacks whose n_layers x dim is beyond the ordered mode's LDS slabs
-    (NRX_ERR_UNSUPPORTED, nothing enqueued) keep the atomic launch."""
-    if WGRAD_ORDERED and n_layers > 0:
+def _dcn_v1_grads(w: torch.Tensor, b: torch.Tensor):
+    """g_w / g_b buffers of a DCN-v1 backward: the ordered mode overwrites them, the atomic one adds into zeros (see _dcn_v1_bwd)."""
+    if (WGRAD_ORDERED or not WGRAD_ATOMIC) and w.shape[0] > 0:
+        return torch.empty_like(w), torch.empty_like(b)
+    return torch.zeros_like(w), torch.zeros_like(b)
+
+
+def _dcn_v1_bwd(lib, args, dim: int, n_layers: int, dev, stream, gw: torch.Tensor, gb: torch.Tensor) -> None:
+    """nrx_dcn_v1_bwd_ordered(*args, workspace, stream) -- the cross weights' and biases' gradients (sums over the batch) added block by block in
+    block order: as fast as or faster than the atomic launch with its two fills (B = 65 536, forward + backward: D = 112 x 3 layers 46.8 vs 51.2 us,
+    320 x 2 81.5 vs 82.6, 640 x 3 473.1 vs 469.4; profiles/r05_ordered_wgrad.txt) and bit-reproducible -- unless NRX_WGRAD=atomic, or the stack's
+    n_layers x dim is beyond the mode's LDS slabs
+    (NRX_ERR_UNSUPPORTED, nothing enqueued): then nrx_dcn_v1_bwd(*args, stream) into zero-filled g_w / g_b."""
+    if (WGRAD_ORDERED or not WGRAD_ATOMIC) and n_layers > 0:
         ws = torch.empty(lib.nrx_dcn_v1_bwd_ordered_workspace(dim, n_layers), dtype=torch.uint8, device=dev)
         rc = lib.nrx_dcn_v1_bwd_ordered(*args, ws.data_ptr(), stream)
         if rc != NRX_ERR_UNSUPPORTED:
             check(rc, "nrx_dcn_v1_bwd_ordered")
             return
-        # not silently: the eager step warns (once per shape), a deterministic capture refuses (GraphedStep reads the counter)
-        dense_bwd_paths["atomic"] += 1
-        if ("dcn_v1", n_layers, dim) not in _atomic_warned:
-            _atomic_warned.add(("dcn_v1", n_layers, dim))
-            import warnings
-            warnings.warn(f"ordered weight gradients asked for, but a DCN stack of {n_layers} layers x {dim} columns is beyond the ordered mode of "
-                          "nrx_dcn_v1_bwd: its cross weights' gradients are summed with float atomics (not bit-reproducible)", RuntimeWarning, stacklevel=3)
+        gw.zero_()
+        gb.zero_()
+        if WGRAD_ORDERED:
+            # asked for explicitly: not silently -- the eager step warns (once per shape), a deterministic capture refuses (GraphedStep reads the counter)
+            dense_bwd_paths["atomic"] += 1
+            if ("dcn_v1", n_layers, dim) not in _atomic_warned:
+                _atomic_warned.add(("dcn_v1", n_layers, dim))
+                import warnings
+                warnings.warn(f"ordered weight gradients asked for, but a DCN stack of {n_layers} layers x {dim} columns is beyond the ordered mode of "
+                              "nrx_dcn_v1_bwd: its cross weights' gradients are summed with float atomics (not bit-reproducible)", RuntimeWarning, stacklevel=3)
     check(lib.nrx_dcn_v1_bwd(*args, stream), "nrx_dcn_v1_bwd")
 
 
@@ -1816,10 +1828,9 @@ class _DcnV1Fn(torch.autograd.Function):
         B, D = x.shape
         gx = torch.empty_like(x)
         gx0 = torch.empty_like(x) if ctx.sep else None
-        gw = torch.zeros_like(w)
-        gb = torch.zeros_like(b)
+        gw, gb = _dcn_v1_grads(w, b)
         _dcn_v1_bwd(lib, (x.data_ptr(), D, _ptr(x0), D, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), g.data_ptr(), D,
-                          gx.data_ptr(), D, _ptr(gx0), D, gw.data_ptr(), gb.data_ptr()), D, w.shape[0], x.device, _stream_ptr(x))
+                          gx.data_ptr(), D, _ptr(gx0), D, gw.data_ptr(), gb.data_ptr()), D, w.shape[0], x.device, _stream_ptr(x), gw, gb)
         return gx, gw, gb, gx0
 
 
@@ -1852,10 +1863,9 @@ class _DcnV1LayersFn(torch.autograd.Function):
         B, D = x.shape
         n = ctx.n
         gx = torch.empty_like(x)
-        gw = torch.zeros_like(w)
-        gb = torch.zeros_like(b)
+        gw, gb = _dcn_v1_grads(w, b)
         _dcn_v1_bwd(lib, (x.data_ptr(), D, None, D, B, D, n, w.data_ptr(), b.data_ptr(), g.data_ptr(), D, gx.data_ptr(), D, None, D,
-                          gw.data_ptr(), gb.data_ptr()), D, n, x.device, _stream_ptr(x))
+                          gw.data_ptr(), gb.data_ptr()), D, n, x.device, _stream_ptr(x), gw, gb)
         grads = [gw[l].reshape(ctx.shapes[l]) for l in range(n)] + [gb[l].reshape(ctx.shapes[n + l]) for l in range(n)]
         return (gx, None, *grads)
 
@@ -1923,11 +1933,10 @@ class _DcnV1CatFn(torch.autograd.Function):
         B, W2 = buf.shape
         D = W2 // 2
         gbuf = torch.zeros_like(buf)          # right half of the input buffer was never read
-        gw = torch.zeros_like(w)
-        gb = torch.zeros_like(b)
+        gw, gb = _dcn_v1_grads(w, b)
         _dcn_v1_bwd(lib, (buf.data_ptr(), W2, None, 0, B, D, w.shape[0], w.data_ptr(), b.data_ptr(),
                           g.data_ptr() + 4 * D, W2, gbuf.data_ptr(), W2, None, 0, gw.data_ptr(), gb.data_ptr()), D, w.shape[0], buf.device,
-                    _stream_ptr(buf))
+                    _stream_ptr(buf), gw, gb)
         gbuf[:, :D] += g[:, :D]
         return gbuf, gw, gb
 
@@ -2030,10 +2039,9 @@ class _EmbedDcnFn(torch.autograd.Function):
         B, W2 = buf.shape
         D = W2 // 2
         gx = torch.empty((B, D), dtype=torch.float32, device=buf.device)
-        gw = torch.zeros_like(w)
-        gb = torch.zeros_like(b)
+        gw, gb = _dcn_v1_grads(w, b)
         _dcn_v1_bwd(lib, (buf.data_ptr(), W2, None, 0, B, D, w.shape[0], w.data_ptr(), b.data_ptr(), g.data_ptr() + 4 * D, W2,
-                          gx.data_ptr(), D, None, 0, gw.data_ptr(), gb.data_ptr()), D, w.shape[0], buf.device, _stream_ptr(buf))
+                          gx.data_ptr(), D, None, 0, gw.data_ptr(), gb.data_ptr()), D, w.shape[0], buf.device, _stream_ptr(buf), gw, gb)
         gx += g[:, :D]
         table_grads = _EmbedFn.backward(ctx, gx, None, None)[7:]
         return (None, None, None, gw.view(ctx.w_shape), gb.view(ctx.b_shape), *table_grads)
@@ -2076,10 +2084,15 @@ def _dcn_v2_layer_backward(lib, x0, xl, lin, out, relu, W, g, g_x0, accumulate, 
 
 
 DCN2_MATH = ("fp32", "bf16x3")
-# Weight gradients that contract over the batch (DCN-v2 layers, ops.linear): "atomic" = every batch slice's partial tile is added with float atomics
-# (the default: one launch); "ordered" = the partial tiles are stored and a second launch adds them in slice order -- the same bits run to run
-# (nrx_linear_wgrad_ordered, flags bit 2 of nrx_dcn_v2_layer_bwd).  GraphedStep(deterministic=True) captures its step in the ordered mode.
-WGRAD_ORDERED = os.environ.get("NRX_WGRAD", "atomic") == "ordered"
+# Weight gradients that contract over the batch (DCN cross layers, ops.linear), NRX_WGRAD: "atomic" = every batch slice's / block's partial sums are
+# added with float atomics; "ordered" = they are stored and a second launch adds them in a fixed order -- the same bits run to run
+# (nrx_linear_wgrad_ordered, nrx_dcn_v1_bwd_ordered, flags bit 2 of nrx_dcn_v2_layer_bwd); "auto" (default) = ordered wherever it is as fast.
+# GraphedStep(deterministic=True) captures its step in the ordered mode.
+WGRAD_ORDERED = os.environ.get("NRX_WGRAD", "auto") == "ordered"          # everywhere (what GraphedStep(deterministic=True) sets)
+WGRAD_ATOMIC = os.environ.get("NRX_WGRAD", "auto") == "atomic"            # nowhere (A/B); the default "auto": ordered where it costs nothing --
+                                                                          # ops.linear with a small scratch, every DCN-v1 stack the mode takes, DCN-v2
+                                                                          # layers up to 128 wide (decided in the library)
+LINEAR_ORDERED_MAX = int(os.environ.get("NRX_LINEAR_ORDERED_MAX", 64 << 20))      # ops.linear: ordered by default while its scratch is at most this many bytes
 
 
 def _dcn2_flags(relu: bool, math: str, ordered: bool = False) -> int:
@@ -2213,8 +2226,12 @@ class _LinearFn(torch.autograd.Function):
             gW = torch.empty_like(W, memory_format=torch.contiguous_format)
             if want_b:                        # the bias gradient comes out of the same pass over g
                 gb = torch.empty((W.shape[0],), dtype=torch.float32, device=W.device)
-            if WGRAD_ORDERED:
-                ws = torch.empty(max(1, lib.nrx_linear_wgrad_ordered_workspace(g2.shape[0], W.shape[0], W.shape[1])), dtype=torch.uint8, device=W.device)
+            # ordered (bit-reproducible) whenever its scratch is small: measured as fast or faster than the atomic form at every MLP shape tried
+            # (B = 65 536: [128, 128] 32.5 vs 37.9 us, [64, 128] 23.9 vs 27.8, [128, 416] 95.4 vs 95.5, [512, 416] 298.8 vs 292.0 -- the atomic form
+            # needs two fill launches, the ordered one a reduction; tools/ab_linear_wgrad.py)
+            wsz = lib.nrx_linear_wgrad_ordered_workspace(g2.shape[0], W.shape[0], W.shape[1])
+            if WGRAD_ORDERED or (not WGRAD_ATOMIC and wsz <= LINEAR_ORDERED_MAX):
+                ws = torch.empty(max(1, wsz), dtype=torch.uint8, device=W.device)
                 check(lib.nrx_linear_wgrad_ordered(g2.data_ptr(), g2.stride(0), a2.data_ptr(), a2.stride(0), g2.shape[0], W.shape[0], W.shape[1],
                                                    gW.data_ptr(), _ptr(gb), ws.data_ptr(), _stream_ptr(g2)), "nrx_linear_wgrad_ordered")
             else:

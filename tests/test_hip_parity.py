@@ -647,6 +647,7 @@ def test_dcn_v1_ordered_cross_gradients_are_bit_reproducible(B, D, NL, sep, monk
 
     def grads(ordered):
         monkeypatch.setattr(ops, "WGRAD_ORDERED", ordered)
+        monkeypatch.setattr(ops, "WGRAD_ATOMIC", not ordered)          # (the default, "auto", takes the ordered mode too)
         if sep:
             gs = torch.autograd.grad(ops.dcn_v1(x, w, b, x0=x0), [x, x0, w, b], up)
         else:
