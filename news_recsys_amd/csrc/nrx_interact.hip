@@ -1183,6 +1183,7 @@ extern "C" int nrx_dcn_v1_bwd_ordered(const float* x, int64_t x_ld, const float*
                                       void* stream) {
     NRX_TRACE();
     NRX_REQUIRE(workspace != nullptr, "nrx_dcn_v1_bwd_ordered: null workspace");
+    NRX_REQUIRE(n_layers < 0 || n_layers > NRX_MAX_DCN_LAYERS || n_layers == 0 || (g_w != nullptr && g_b != nullptr), "nrx_dcn_v1_bwd_ordered: null g_w / g_b");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (n_layers == 0 || batch == 0) {
         if (n_layers > 0 && g_w && g_b &&
