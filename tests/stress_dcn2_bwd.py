@@ -12,7 +12,7 @@ lib = _lib.load()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 DEV = "cuda:0"
-t0, n_done = time.time(), 0
+t0, n_done, n_panel, n_big = time.time(), 0, 0, 0
 st = torch.cuda.current_stream().cuda_stream
 while time.time() - t0 < budget:
     B = int(rng.choice([1, 2, 31, 63, 64, 65, 127, 129, 1000, 4097, 20011, 70000]))
@@ -59,4 +59,6 @@ while time.time() - t0 < budget:
         err = (got.double() - want).abs().max().item()
         assert err <= tol * max(1.0, want.abs().max().item()), dict(B=B, D=D, pad=pad, relu=relu, acc=acc, ordered=ordered, err=err)
     n_done += 1
-print(f"stress_dcn2_bwd: {n_done} random layers: all within tolerance of the fp64 definition, ordered runs word for word equal ({time.time() - t0:.0f} s)")
+    n_panel += D <= 112 and D % 4 == 0 and pad % 4 == 0
+    n_big += B >= 20011
+print(f"stress_dcn2_bwd: {n_done} random layers ({n_panel} in the panel form, {n_big} with 20 011 or 70 000 rows): all within tolerance of the fp64 definition, ordered runs word for word equal ({time.time() - t0:.0f} s)")
