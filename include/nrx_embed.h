@@ -251,12 +251,19 @@ NRX_API int nrx_sparse_plan_lds(const void* const* ids, const int64_t* lens, con
  * feature to max_len with id 0): 142 -> 114 us for 3.4 M lookups half of which are padding, ~17 us LOST on a launch without padding -- which
  * is why it is the caller's choice.  stats (null, or 5 int64 -- mapped host memory is fine): {unique rows, walk rows or -1, -1, n, lookups of
  * the padding rows} of THIS plan, written on the stream: what the caller decides the next batch's flag by (ops.PadPolicy).  Workspace as
- * nrx_sparse_plan. */
+ * nrx_sparse_plan.
+ * NRX_PLAN_PAIRS (placement form, every feature in place_feats): rows looked up exactly TWICE leave the walk list as records
+ * pairs[k] = {unique index, first lookup, second lookup, 0} (ascending; n_pairs[0] of them; capacity n / 2 + 1 records of 16 bytes) -- the plan
+ * nrx_sparse_plan_lds makes, from the sort: dest, walk, pairs as oracle/ref_np.py sparse_plan_pairs defines them (order / seg_start stay those
+ * of nrx_sparse_plan: complete) -- for nrx_embed_bwd_placed_pairs.  pairs / n_pairs are ignored without the flag (may be null).  (Measured on the
+ * bench shapes it does not pay behind the sort -- the longer emit kernel and the pair pass cost what the shorter walk saves: C5 394.6 -> 398.0 us per
+ * forward + backward -- so the Python layer leaves it off; it is the one-kernel planner's plan form made available from the sorted one.) */
 #define NRX_PLAN_SPLIT_PADDING 1u
+#define NRX_PLAN_PAIRS 2u
 NRX_API int nrx_sparse_plan_ex(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
                                int32_t n_feats, int32_t index_bits, int32_t n_tables, uint64_t place_feats, uint32_t flags, int64_t* order,
                                int64_t* uniq_keys, int64_t* seg_start, int64_t* counts, int32_t* dest, int32_t* walk, int64_t* n_walk,
-                               int64_t* stats, void* workspace, void* stream);
+                               int32_t* pairs, int64_t* n_pairs, int64_t* stats, void* workspace, void* stream);
 
 /* stats of a nrx_sparse_plan_place plan in the same format ({unique rows, walk rows, -1 = not counted, n}): a caller that picks the planner of the
  * next batch from the previous batch's statistics has them from either planner.  stats may be mapped (pinned) host memory. */

@@ -27,6 +27,7 @@ NRX_ERR_BAD_ARG = -1
 NRX_ERR_LAUNCH = -2
 NRX_ERR_UNSUPPORTED = -3
 NRX_PLAN_SPLIT_PADDING = 1          # nrx_sparse_plan_ex flags
+NRX_PLAN_PAIRS = 2
 
 # enum nrx_feature_kind
 NRX_SPARSE, NRX_DENSE, NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM = 0, 1, 2, 3, 4
@@ -149,7 +150,7 @@ SIGNATURES = {
     "nrx_sparse_plan_lds_ok": (C.c_int, [_p, _p, _p, _i32, _i32]),
     "nrx_sparse_plan_lds": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nrx_sparse_plan_stats": (C.c_int, [_p, _p, _i64, _p, _p]),
-    "nrx_sparse_plan_ex": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, C.c_uint64, C.c_uint32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nrx_sparse_plan_ex": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, C.c_uint64, C.c_uint32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nrx_embed_bwd_placed_pairs": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _i32, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p,
                                              C.POINTER(NrxFmGrad), _p, C.POINTER(_p), _i32, _i32, C.c_uint64, _p, _p, _p, _p, _p, _p, _i64, _p, _p]),
     "nrx_sparse_adam_step": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p, _i64, _p, C.c_float, _p, C.c_float, C.c_float, C.c_float,

@@ -120,10 +120,10 @@ __device__ __forceinline__ bool plan_is_placed(bool head, bool next_head, KeyT k
 template <typename KeyT, bool PAIR = false, bool PLACE = false, bool SEG = false>
 __global__ __launch_bounds__(NRX_BLOCK) void plan_count_kernel(const PlaceInfo place_in_kernarg /* first: read through nrx_kernarg */,
                                                                const KeyT* __restrict__ skeys, int64_t n, uint32_t* __restrict__ block_heads,
-                                                               const uint32_t* __restrict__ spayload, int row_bits) {
-    __shared__ uint32_t s_cnt[2 * (NRX_BLOCK / 64)];
+                                                               const uint32_t* __restrict__ spayload, int row_bits, int want_pairs = 0) {
+    __shared__ uint32_t s_cnt[3 * (NRX_BLOCK / 64)];
     const int64_t e0 = (int64_t)blockIdx.x * PLAN_TILE + threadIdx.x;
-    uint32_t c = 0, cw = 0;
+    uint32_t c = 0, cw = 0, cp = 0;
     const uint64_t rmask = (1ull << row_bits) - 1;
     // (the tile's keys are requested before the run lookup: the two do not depend on each other, and a block is one short chain of round trips)
     constexpr int ROUNDS = PLAN_TILE / NRX_BLOCK;
@@ -146,24 +146,33 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_count_kernel(const PlaceInfo p
         c += (uint32_t)__popcll(__ballot(head));      // wave-uniform count
         if (PLACE) {
             const NRX_CONST PlaceInfo* pi = nrx_kernarg<PlaceInfo>();
-            bool walked = false;
+            bool walked = false, pairh = false;
             if (head) {
                 bool next_head = e + 1 >= n || plan_key_at<KeyT, PAIR>(skeys, e + 1) != key[j];
                 if (SEG && e + 1 < n) next_head = next_head || plan_table_at(pi, ps, e + 1) != plan_table_at(pi, ps, e);
                 const uint32_t pay = PAIR ? reinterpret_cast<const uint2*>(skeys)[e].y : spayload[e];
                 walked = !plan_is_placed<KeyT>(true, next_head, key[j], rmask, pi, pay);
+                if (want_pairs && !next_head && ((uint64_t)key[j] & rmask) != 0) {      // a row looked up exactly twice: a pair record, not a walk row
+                    bool next2_head = e + 2 >= n || plan_key_at<KeyT, PAIR>(skeys, e + 2) != key[j];
+                    if (SEG && e + 2 < n) next2_head = next2_head || plan_table_at(pi, ps, e + 2) != plan_table_at(pi, ps, e);
+                    pairh = next2_head;
+                }
+                walked = walked && !pairh;
             }
             cw += (uint32_t)__popcll(__ballot(walked));
+            cp += (uint32_t)__popcll(__ballot(pairh));
         }
     }
     if ((threadIdx.x & 63) == 0) {
         s_cnt[threadIdx.x >> 6] = c;
         s_cnt[NRX_BLOCK / 64 + (threadIdx.x >> 6)] = cw;
+        s_cnt[2 * (NRX_BLOCK / 64) + (threadIdx.x >> 6)] = cp;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         block_heads[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
         if (PLACE) block_heads[gridDim.x + blockIdx.x] = s_cnt[4] + s_cnt[5] + s_cnt[6] + s_cnt[7];
+        if (PLACE && want_pairs) block_heads[2 * gridDim.x + blockIdx.x] = s_cnt[8] + s_cnt[9] + s_cnt[10] + s_cnt[11];
     }
 }
 
@@ -176,11 +185,13 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo pl
                                                               int32_t n_tables, int64_t* __restrict__ order,
                                                               int64_t* __restrict__ uniq_keys, int64_t* __restrict__ seg_start,
                                                               int64_t* __restrict__ counts, int32_t* __restrict__ dest,
-                                                              int32_t* __restrict__ walk, int64_t* __restrict__ n_walk) {
+                                                              int32_t* __restrict__ walk, int64_t* __restrict__ n_walk,
+                                                              int32_t* __restrict__ pairs = nullptr, int64_t* __restrict__ n_pairs = nullptr) {
     constexpr int ROUNDS = PLAN_TILE / NRX_BLOCK, WAVES = NRX_BLOCK / 64;
     __shared__ uint32_t s_cell[ROUNDS * WAVES + 1];
     __shared__ uint32_t s_wcell[ROUNDS * WAVES + 1];
-    __shared__ uint32_t s_part[2 * WAVES];
+    __shared__ uint32_t s_pcell[ROUNDS * WAVES + 1];
+    __shared__ uint32_t s_part[3 * WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // PLACE: the dest words of a tile (one table's lookups) all fall into that feature's stretch of dest -- B x 4 bytes.  Blocks
     // land on XCD (block % 8), each with its own L2: in launch order the eight XCDs would each hold PARTIAL lines of every
@@ -192,8 +203,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo pl
         tile = x * qt + (x < rt ? x : rt) + i;
     }
     const int64_t e0 = (int64_t)tile * PLAN_TILE + tid;
-    KeyT key[ROUNDS], prev[ROUNDS], next[ROUNDS];
-    uint32_t pay[ROUNDS];
+    KeyT key[ROUNDS], prev[ROUNDS], next[ROUNDS], next2[ROUNDS];
+    uint32_t pay[ROUNDS], pay1[ROUNDS];
+    const bool want_pairs = PLACE && pairs != nullptr;
 #pragma unroll
     for (int j = 0; j < ROUNDS; ++j) {            // all of the tile's loads are issued before anything waits
         const int64_t e = e0 + j * NRX_BLOCK;
@@ -208,24 +220,34 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo pl
         }
         prev[j] = plan_key_at<KeyT, PAIR>(skeys, ec > 0 ? ec - 1 : 0);
         if (PLACE) next[j] = plan_key_at<KeyT, PAIR>(skeys, ec + 1 < n ? ec + 1 : ec);
+        next2[j] = key[j];
+        pay1[j] = 0;
+        if (want_pairs) {                             // the entry behind the next one, and the next one's lookup: a pair record is {u, this lookup, the next}
+            next2[j] = plan_key_at<KeyT, PAIR>(skeys, ec + 2 < n ? ec + 2 : ec);
+            const int64_t e1 = ec + 1 < n ? ec + 1 : ec;
+            pay1[j] = PAIR ? reinterpret_cast<const uint2*>(skeys)[e1].y : spayload[e1];
+        }
     }
-    uint32_t acc = 0, wacc = 0;
+    uint32_t acc = 0, wacc = 0, pacc = 0;
     for (uint32_t i = tid; i < tile; i += NRX_BLOCK) {
         acc += block_heads[i];
         if (PLACE) wacc += block_heads[gridDim.x + i];
+        if (want_pairs) pacc += block_heads[2 * gridDim.x + i];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         acc += __shfl_xor(acc, off, 64);
         if (PLACE) wacc += __shfl_xor(wacc, off, 64);
+        if (PLACE) pacc += __shfl_xor(pacc, off, 64);
     }
     if (lane == 0) {
         s_part[wid] = acc;
         s_part[WAVES + wid] = wacc;
+        s_part[2 * WAVES + wid] = pacc;
     }
     const uint64_t rmask = (1ull << row_bits) - 1;
-    bool head[ROUNDS], walked[ROUNDS], placed[ROUNDS], able[ROUNDS];
-    unsigned long long mask[ROUNDS], wmask[ROUNDS];
+    bool head[ROUNDS], walked[ROUNDS], placed[ROUNDS], able[ROUNDS], pairh[ROUNDS];
+    unsigned long long mask[ROUNDS], wmask[ROUNDS], pmask[ROUNDS];
     int tab[ROUNDS], tabp[ROUNDS];                 // SEG: table of the entry / of its predecessor (-1 before the first)
     PlanSeg ps = {0, 0};
     if (SEG) ps = plan_seg_of_tile(nrx_kernarg<PlaceInfo>(), (int64_t)tile * PLAN_TILE > 0 ? (int64_t)tile * PLAN_TILE - 1 : 0);
@@ -246,9 +268,19 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo pl
             if (SEG && e + 1 < n) next_head = next_head || plan_table_at(nrx_kernarg<PlaceInfo>(), ps, e + 1) != tab[j];
             able[j] = plan_placeable(nrx_kernarg<PlaceInfo>(), pay[j]);
             placed[j] = head[j] && next_head && ((uint64_t)key[j] & rmask) != 0 && able[j];
-            walked[j] = head[j] && !placed[j];
+            pairh[j] = false;
+            if (want_pairs && head[j] && !next_head && ((uint64_t)key[j] & rmask) != 0) {
+                bool next2_head = e + 2 >= n || next2[j] != key[j];
+                if (SEG && e + 2 < n) next2_head = next2_head || plan_table_at(nrx_kernarg<PlaceInfo>(), ps, e + 2) != tab[j];
+                pairh[j] = next2_head;
+            }
+            walked[j] = head[j] && !placed[j] && !pairh[j];
             wmask[j] = __ballot(walked[j]);
-            if (lane == 0) s_wcell[j * WAVES + wid] = (uint32_t)__popcll(wmask[j]);
+            pmask[j] = __ballot(pairh[j]);
+            if (lane == 0) {
+                s_wcell[j * WAVES + wid] = (uint32_t)__popcll(wmask[j]);
+                s_pcell[j * WAVES + wid] = (uint32_t)__popcll(pmask[j]);
+            }
         }
     }
     __syncthreads();
@@ -270,6 +302,15 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo pl
         }
         s_wcell[ROUNDS * WAVES] = run;
     }
+    if (PLACE && tid == 128) {
+        uint32_t run = s_part[2 * WAVES] + s_part[2 * WAVES + 1] + s_part[2 * WAVES + 2] + s_part[2 * WAVES + 3];
+        for (int c = 0; c < ROUNDS * WAVES; ++c) {
+            const uint32_t v = s_pcell[c];
+            s_pcell[c] = run;
+            run += v;
+        }
+        s_pcell[ROUNDS * WAVES] = run;
+    }
     __syncthreads();
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -284,6 +325,16 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo pl
             const uint32_t wr = s_wcell[j * WAVES + wid] + (uint32_t)__popcll(wmask[j] & lt);
             if (walked[j]) walk[wr] = (int32_t)u;
             if (e == n - 1) n_walk[0] = (int64_t)(wr + (walked[j] ? 1u : 0u));
+            if (want_pairs) {
+                const uint32_t pr = s_pcell[j * WAVES + wid] + (uint32_t)__popcll(pmask[j] & lt);
+                if (pairh[j]) {
+                    typedef int nrx_i32x4e __attribute__((ext_vector_type(4)));
+                    nrx_i32x4e rec;
+                    rec.x = (int32_t)u; rec.y = (int32_t)pay[j]; rec.z = (int32_t)pay1[j]; rec.w = 0;
+                    reinterpret_cast<nrx_i32x4e*>(pairs)[pr] = rec;
+                }
+                if (e == n - 1) n_pairs[0] = (int64_t)pr;          // (the last entry starts no pair)
+            }
         }
         if (head[j]) {
             const uint64_t k = (uint64_t)key[j];
@@ -1233,7 +1284,7 @@ extern "C" int64_t nrx_sparse_plan_workspace(int64_t n_lookups) {
 static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
                             int32_t n_feats, int32_t index_bits, int32_t n_tables, int64_t* order, int64_t* uniq_keys,
                             int64_t* seg_start, int64_t* counts, uint64_t place_feats, int32_t* dest, int32_t* walk, int64_t* n_walk,
-                            void* workspace, void* stream, uint32_t opt_flags = 0) {
+                            void* workspace, void* stream, uint32_t opt_flags = 0, int32_t* pairs_out = nullptr, int64_t* n_pairs_out = nullptr) {
     NRX_REQUIRE(n_feats >= 0 && n_feats <= NRX_MAX_FEATURES && (index_bits == 32 || index_bits == 64) && n_tables >= 1 && n_tables < (1 << 20),
                 "nrx_sparse_plan: bad argument");
     NRX_REQUIRE(counts != nullptr, "nrx_sparse_plan: null counts");
@@ -1262,6 +1313,9 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
         pinfo.feats = place_feats & every;
         pinfo.all = pinfo.feats == every;
     }
+    // pair records (rows looked up exactly twice leave the walk list): only when every feature's lookups may be placed
+    if (dest == nullptr || !pinfo.all || n_pairs_out == nullptr) pairs_out = nullptr;
+    const int want_pairs = pairs_out != nullptr ? 1 : 0;
     const int row_bits = bits_for(max_rows), table_bits = bits_for(n_tables);
     NRX_REQUIRE(row_bits <= 40 && row_bits + table_bits <= 62, "nrx_sparse_plan: table too large for the composite key");
     NRX_REQUIRE(off < 0xffffffffLL, "nrx_sparse_plan: too many lookups for one plan");
@@ -1273,6 +1327,7 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
         int e = nrx_zero_async(counts, sizeof(int64_t) * (size_t)(n_tables + 2), st);
         if (e == NRX_OK && seg_start) e = nrx_zero_async(seg_start, sizeof(int64_t), st);
         if (e == NRX_OK && n_walk) e = nrx_zero_async(n_walk, sizeof(int64_t), st);
+        if (e == NRX_OK && n_pairs_out) e = nrx_zero_async(n_pairs_out, sizeof(int64_t), st);
         if (e != NRX_OK) return NRX_ERR_LAUNCH;
         return NRX_OK;
     }
@@ -1451,10 +1506,10 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
             uint32_t* tp = psrc; psrc = pdst; pdst = tp;                                                                  \
         }                                                                                                                 \
         if (dest != nullptr) {                                                                                            \
-            hipLaunchKernelGGL((plan_count_kernel<KeyT, PAIR_, true, SEG_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src, n, flags, (const uint32_t*)psrc, row_bits); \
+            hipLaunchKernelGGL((plan_count_kernel<KeyT, PAIR_, true, SEG_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src, n, flags, (const uint32_t*)psrc, row_bits, want_pairs); \
             hipLaunchKernelGGL((plan_emit_kernel<KeyT, PAIR_, true, SEG_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src,     \
                                (const uint32_t*)psrc, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys,     \
-                               seg_start, counts, dest, walk, n_walk);                                                    \
+                               seg_start, counts, dest, walk, n_walk, pairs_out, n_pairs_out);                            \
         } else {                                                                                                          \
             hipLaunchKernelGGL((plan_count_kernel<KeyT, PAIR_, false, SEG_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src, n, flags, (const uint32_t*)psrc, row_bits); \
             hipLaunchKernelGGL((plan_emit_kernel<KeyT, PAIR_, false, SEG_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src,           \
@@ -1481,10 +1536,10 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
                                         (size_t)n, 0u, (unsigned)bits, st);                                               \
         if (err == hipSuccess) {                                                                                          \
             if (dest != nullptr) {                                                                                        \
-                hipLaunchKernelGGL((plan_count_kernel<KeyT, false, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out, n, flags, (const uint32_t*)pay_out, row_bits); \
+                hipLaunchKernelGGL((plan_count_kernel<KeyT, false, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out, n, flags, (const uint32_t*)pay_out, row_bits, want_pairs); \
                 hipLaunchKernelGGL((plan_emit_kernel<KeyT, false, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out, \
                                    (const uint32_t*)pay_out, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys, \
-                                   seg_start, counts, dest, walk, n_walk);                                                \
+                                   seg_start, counts, dest, walk, n_walk, pairs_out, n_pairs_out);                        \
             } else {                                                                                                      \
                 hipLaunchKernelGGL(plan_count_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out, n, flags, (const uint32_t*)pay_out, row_bits); \
                 hipLaunchKernelGGL(plan_emit_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out,      \
@@ -1542,13 +1597,21 @@ __global__ void plan_ex_stats_kernel(const int64_t* __restrict__ uniq, const int
 extern "C" int nrx_sparse_plan_ex(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
                                   int32_t n_feats, int32_t index_bits, int32_t n_tables, uint64_t place_feats, uint32_t flags, int64_t* order,
                                   int64_t* uniq_keys, int64_t* seg_start, int64_t* counts, int32_t* dest, int32_t* walk,
-                                  int64_t* n_walk, int64_t* stats, void* workspace, void* stream) {
+                                  int64_t* n_walk, int32_t* pairs, int64_t* n_pairs, int64_t* stats, void* workspace, void* stream) {
     NRX_TRACE();
     NRX_REQUIRE((dest != nullptr) == (walk != nullptr) && (dest != nullptr) == (n_walk != nullptr),
                 "nrx_sparse_plan_ex: dest, walk and n_walk go together (all null: the plan without placement)");
-    NRX_REQUIRE((flags & ~(uint32_t)NRX_PLAN_SPLIT_PADDING) == 0, "nrx_sparse_plan_ex: unknown flag");
+    NRX_REQUIRE((flags & ~(uint32_t)(NRX_PLAN_SPLIT_PADDING | NRX_PLAN_PAIRS)) == 0, "nrx_sparse_plan_ex: unknown flag");
+    if (flags & NRX_PLAN_PAIRS) {
+        NRX_REQUIRE(dest != nullptr && pairs != nullptr && n_pairs != nullptr && nrx_aligned16(pairs),
+                    "nrx_sparse_plan_ex: NRX_PLAN_PAIRS needs the placement outputs, pairs (16-byte aligned) and n_pairs");
+        const uint64_t every = n_feats >= 64 ? ~0ull : ((1ull << n_feats) - 1);
+        NRX_REQUIRE((place_feats & every) == every, "nrx_sparse_plan_ex: NRX_PLAN_PAIRS needs every feature in place_feats (single-valued features only)");
+    }
+    const bool wp = (flags & NRX_PLAN_PAIRS) != 0;
     const int rc = sparse_plan_impl(ids, lens, table_of, rows, n_feats, index_bits, n_tables, order, uniq_keys, seg_start, counts,
-                                    dest != nullptr ? place_feats : 0, dest, walk, n_walk, workspace, stream, flags);
+                                    dest != nullptr ? place_feats : 0, dest, walk, n_walk, workspace, stream, flags & NRX_PLAN_SPLIT_PADDING,
+                                    wp ? pairs : nullptr, wp ? n_pairs : nullptr);
     if (rc != NRX_OK || stats == nullptr) return rc;
     int64_t n = 0;
     for (int f = 0; f < n_feats; ++f) n += lens[f];

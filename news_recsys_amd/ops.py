@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_ERR_UNSUPPORTED, NRX_FEAT_BAG_CSR, NRX_PLAN_SPLIT_PADDING, NRX_FEAT_ROW0_IS_DATA, NRX_MAX_FEATURES, NRX_SPARSE,
+from ._lib import (NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_DENSE, NRX_ERR_UNSUPPORTED, NRX_FEAT_BAG_CSR, NRX_PLAN_PAIRS, NRX_PLAN_SPLIT_PADDING, NRX_FEAT_ROW0_IS_DATA, NRX_MAX_FEATURES, NRX_SPARSE,
                    NrxFeature, NrxFmGrad, check)
 
 # ------------------------------------------------------------------------------- helpers
@@ -595,7 +595,7 @@ class _EmbedFn(torch.autograd.Function):
                         break
                 ctx.plans[(g_["dim"], fs_[0])] = (ids_,) + sparse_plan_ahead(ids_, g_["tabs"], g_["rows"], len(tables),
                                                                           g_["pmask"] if SPARSE_PLACE else None, static=g_["static"],
-                                                                          policy=pol_, pad=_group_pad(g_, plan, B))
+                                                                          policy=pol_, pad=_group_pad(g_, plan, B), pairs=g_["all_sparse"])
         if ctx.has_fm_feat:
             ctx.save_for_backward(out)
         ctx.set_materialize_grads(False)
@@ -798,6 +798,10 @@ class PlanPolicy:
         return self.use_lds
 
 
+PLAN_PAIRS = os.environ.get("NRX_PLAN_PAIRS", "0") != "0"              # sorted planner: rows looked up exactly twice as pair records (as the one-kernel
+                                                                       # planner leaves them) for launches of single-valued features.  Off: measured, it
+                                                                       # is not a win there -- the emit kernel's extra loads and the pair pass cost what
+                                                                       # the shorter walk saves (C5 394.6 -> 398.0 us, Zipf C2 419.4 -> 415.7)
 PAD_SPLIT = os.environ.get("NRX_PAD_SPLIT", "auto")                     # auto: by the previous batch's share of padding lookups; 1 / 0: always / never
 PAD_SPLIT_MIN = int(os.environ.get("NRX_PAD_SPLIT_MIN", 3 << 19))      # lookups per launch group from which the split is considered (1.5 M)
 
@@ -831,7 +835,8 @@ class PadPolicy:
 
 
 def sparse_plan_ahead(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int,
-                      place_feats: Optional[int] = None, static=None, policy: Optional["PlanPolicy"] = None, pad: Optional["PadPolicy"] = None):
+                      place_feats: Optional[int] = None, static=None, policy: Optional["PlanPolicy"] = None, pad: Optional["PadPolicy"] = None,
+                      pairs: bool = False):
     """sparse_plan on a side stream: the planning of the backward depends only on the ids, so it can run while the forward,
     the dense part of the model and its backward occupy the main stream.  Returns ((order, uniq, seg, counts), event);
     the consumer makes its stream wait for `event` before reading the plan."""
@@ -845,7 +850,7 @@ def sparse_plan_ahead(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows
     # was enqueued on the caller's stream before that point, so the side stream's writes are ordered behind it; they are consumed (and
     # later freed) on the caller's stream behind `ev`.  No record_stream anywhere.
     hold = []
-    res = sparse_plan(ids, table_of, rows, n_tables, place_feats, static=static, stream=side.cuda_stream, keep=hold, policy=policy, pad=pad)
+    res = sparse_plan(ids, table_of, rows, n_tables, place_feats, static=static, stream=side.cuda_stream, keep=hold, policy=policy, pad=pad, pairs=pairs)
     ev = torch.cuda.Event()
     ev.record(side)
     # The planner READS the ids on the side stream: an id tensor that dies early (a .long() / .contiguous() temporary, a
@@ -880,7 +885,7 @@ def place_mask(kinds: Sequence[int], bag_lens: Optional[Sequence[int]] = None) -
 
 def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequence[int], n_tables: int,
                 place_feats: Optional[int] = None, static=None, stream: Optional[int] = None, keep: Optional[list] = None,
-                policy: Optional["PlanPolicy"] = None, pad: Optional["PadPolicy"] = None):
+                policy: Optional["PlanPolicy"] = None, pad: Optional["PadPolicy"] = None, pairs: bool = False):
     """nrx_sparse_plan: group the flat, feature-major lookups `ids` (one device tensor per feature, all int32 or
     all int64) by (table, row).  Returns device int64 tensors (order [n], uniq_keys [n], seg_start [n+1],
     counts [n_tables+2]); only the first counts[0] entries of uniq_keys / counts[0]+1 of seg_start are
@@ -892,7 +897,9 @@ def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequ
     seven above (order / seg defined for the walk rows only; n_walk int64 [2]: walk rows, pair records) plus pairs int32 [n / 2 + 1, 4], the
     records {unique index, first lookup, second lookup, 0} of the rows looked up twice -- and goes to nrx_embed_bwd_placed_pairs.
     pad (PadPolicy of a launch group with multi-valued features): nrx_sparse_plan_ex -- the same plan, the padding lookups set aside before the
-    sort when the previous batch held enough of them, this batch's count left for the next one."""
+    sort when the previous batch held enough of them, this batch's count left for the next one.
+    pairs (every feature single-valued and named in place_feats): the sorted planner also leaves the rows looked up exactly twice as pair records
+    (NRX_PLAN_PAIRS) -- the eight-entry form above, from the sort."""
     lib = _lib.load()
     n = len(ids)
     dev = ids[0].device
@@ -942,9 +949,20 @@ def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequ
             n_walk = torch.empty(1, dtype=torch.int64, device=dev)
         check(lib.nrx_sparse_plan_ex(ptrs, lens, tof, rws, n, ids[0].element_size() * 8, n_tables, int(place_feats or 0),
                                      NRX_PLAN_SPLIT_PADDING if pad.choose() else 0, order.data_ptr(), uniq.data_ptr(), seg.data_ptr(),
-                                     counts.data_ptr(), _ptr(dest), _ptr(walk), _ptr(n_walk), pad.stats_arg(), ws.data_ptr(), stream),
+                                     counts.data_ptr(), _ptr(dest), _ptr(walk), _ptr(n_walk), None, None, pad.stats_arg(), ws.data_ptr(), stream),
               "nrx_sparse_plan_ex")
         return (order, uniq, seg, counts) if dest is None else (order, uniq, seg, counts, dest, walk, n_walk)
+    if pairs and PLAN_PAIRS and place_feats is not None and int(place_feats) == (1 << n) - 1 and total > 0:
+        dest = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        walk = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        n_walk = torch.empty(2, dtype=torch.int64, device=dev)                      # [0] walk rows  [1] pair records
+        recs = torch.empty((total // 2 + 1, 4), dtype=torch.int32, device=dev)
+        check(lib.nrx_sparse_plan_ex(ptrs, lens, tof, rws, n, ids[0].element_size() * 8, n_tables, int(place_feats), NRX_PLAN_PAIRS, order.data_ptr(),
+                                     uniq.data_ptr(), seg.data_ptr(), counts.data_ptr(), dest.data_ptr(), walk.data_ptr(), n_walk.data_ptr(),
+                                     recs.data_ptr(), n_walk.data_ptr() + 8, None, ws.data_ptr(), stream), "nrx_sparse_plan_ex")
+        if policy is not None and policy.eligible and PLAN_LDS == "auto":      # what the next batch's choice of planner needs
+            lib.nrx_sparse_plan_stats(counts.data_ptr(), n_walk.data_ptr(), total, policy.stats_ptr, stream)
+        return order, uniq, seg, counts, dest, walk, n_walk, recs
     if place_feats is not None:
         dest = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
         walk = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
@@ -1192,7 +1210,8 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
             if total == 0:
                 continue
             pl = sparse_plan(ids, tabs, grp["rows"], n_tables, pmask, static=grp["static"],
-                             policy=_group_policy(grp, B, n_tables) if n_tables <= NRX_MAX_FEATURES else None, pad=_group_pad(grp, plan, B))
+                             policy=_group_policy(grp, B, n_tables) if n_tables <= NRX_MAX_FEATURES else None, pad=_group_pad(grp, plan, B),
+                             pairs=grp["all_sparse"])
         uniq, counts = pl[1], pl[3]
 
         def replan(ids=ids, tabs=tabs, grp=grp, pmask=pmask):
@@ -1553,9 +1572,9 @@ class PreparedSparseBackward:
             g["policy"] = None
             if g["pmask"] is not None and D in (16, 32, 64) and all(plan.slots[i].kind == NRX_SPARSE for i in fs):
                 g["policy"] = PlanPolicy(g["lens"], g["tof"], g["rws"], n, n_tables, total)
+                g["pair_recs"] = torch.empty((total // 2 + 1, 4), dtype=torch.int32, device=dev)      # (either planner leaves pair records)
                 if g["policy"].eligible:
                     g["lds_ws"] = torch.empty(self.lib.nrx_sparse_plan_lds_workspace(total), dtype=torch.uint8, device=dev)
-                    g["pair_recs"] = torch.empty((total // 2 + 1, 4), dtype=torch.int32, device=dev)
             # multi-valued features: the padding lookups are set aside when the previous plan counted enough of them (PadPolicy)
             g["pad"] = PadPolicy(total) if PAD_SPLIT != "0" and total >= PAD_SPLIT_MIN and any(plan.slots[i].kind != NRX_SPARSE for i in fs) else None
             self.groups.append(g)
@@ -1577,12 +1596,18 @@ class PreparedSparseBackward:
                         continue
                     if rc != NRX_ERR_UNSUPPORTED:
                         check(rc, "nrx_sparse_plan_lds")
-            if g["pad"] is not None:
+            if PLAN_PAIRS and g.get("pair_recs") is not None and g.get("sorted_pairs", True) and g["pmask"] == (1 << g["n"]) - 1:
+                rc = lib.nrx_sparse_plan_ex(g["ptrs"], g["lens"], g["tof"], g["rws"], g["n"], g["bits"], g["n_tables"], g["pmask"], NRX_PLAN_PAIRS,
+                                            g["order"].data_ptr(), g["uniq"].data_ptr(), g["seg"].data_ptr(), g["counts"].data_ptr(),
+                                            g["dest"].data_ptr(), g["walk"].data_ptr(), g["n_walk"].data_ptr(), g["pair_recs"].data_ptr(),
+                                            g["n_walk"].data_ptr() + 8, None, g["ws"].data_ptr(), stream)
+                g["pairs"] = rc == 0
+            elif g["pad"] is not None:
                 pm = g["pmask"] is not None
                 rc = lib.nrx_sparse_plan_ex(g["ptrs"], g["lens"], g["tof"], g["rws"], g["n"], g["bits"], g["n_tables"], g["pmask"] or 0,
                                             NRX_PLAN_SPLIT_PADDING if g["pad"].choose() else 0, g["order"].data_ptr(), g["uniq"].data_ptr(),
                                             g["seg"].data_ptr(), g["counts"].data_ptr(), g["dest"].data_ptr() if pm else None,
-                                            g["walk"].data_ptr() if pm else None, g["n_walk"].data_ptr() if pm else None,
+                                            g["walk"].data_ptr() if pm else None, g["n_walk"].data_ptr() if pm else None, None, None,
                                             g["pad"].stats_arg(), g["ws"].data_ptr(), stream)
             elif g["pmask"] is not None:
                 rc = lib.nrx_sparse_plan_place(g["ptrs"], g["lens"], g["tof"], g["rws"], g["n"], g["bits"], g["n_tables"], g["pmask"],
@@ -1626,8 +1651,9 @@ class PreparedSparseBackward:
                                                     g["counts"].data_ptr(), self.fmg, g["values"].data_ptr(), None, 0, 0, g["pmask"],
                                                     g["dest"].data_ptr(), g["walk"].data_ptr(), g["n_walk"].data_ptr(), g["pair_recs"].data_ptr(),
                                                     g["n_walk"].data_ptr() + 8, g["lws"].data_ptr(), g["lws"].numel(), _aux_stream(f.device), stream)
-                if rc == NRX_ERR_UNSUPPORTED:           # outside the pair pass's shapes: plan again with the sorted planner, for good
+                if rc == NRX_ERR_UNSUPPORTED:           # outside the pair pass's shapes: plan again with the sorted planner and no pair records, for good
                     g["policy"] = None
+                    g["sorted_pairs"] = False
                     self._plan(stream)
                 else:
                     if rc:

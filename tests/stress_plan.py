@@ -35,7 +35,9 @@ while time.time() - t0 < budget:
         continue
     feats = [f for f in range(nf) if rng.integers(0, 2)] or [0]
     place = bool(rng.integers(0, 2))
-    o_r, u_r, s_r, c_r, d_r, w_r = R.sparse_plan_place([x.astype(np.int64) for x in ids], tab, rows, nt, feats)
+    ids64 = [x.astype(np.int64) for x in ids]
+    pairs_def = None
+    o_r, u_r, s_r, c_r, d_r, w_r = R.sparse_plan_place(ids64, tab, rows, nt, feats)
     dev_ids = [torch.from_numpy(x).to("cuda:0") for x in ids]
     for sort in (None, "msd", "lsd", "segmented-bins"):
         for split in ("1", "0"):
@@ -59,5 +61,20 @@ while time.time() - t0 < budget:
                 if not ok:
                     print("MISMATCH", dict(nt=nt, tab=tab, rows=rows, lens=lens, pad=pad, skew=skew, sort=sort, split=split, segkey=segkey, place=place, feats=feats))
                     sys.exit(1)
+                if split == "0":                       # ... and with pair records (NRX_PLAN_PAIRS: every feature placeable), against sparse_plan_pairs
+                    res = ops.sparse_plan(dev_ids, tab, rows, nt, place_feats=(1 << nf) - 1, pairs=True)
+                    torch.cuda.synchronize()
+                    if pairs_def is None:
+                        pairs_def = R.sparse_plan_pairs(ids64, tab, rows, nt)
+                    u_p, c_p, d_p, p_p, w_p, wl_p = pairs_def
+                    nu = len(u_p)
+                    ok = (len(res) == 8 and np.array_equal(res[3].cpu().numpy(), c_p) and np.array_equal(res[1].cpu().numpy()[:nu], u_p)
+                          and np.array_equal(res[0].cpu().numpy(), o_r) and np.array_equal(res[2].cpu().numpy()[:nu + 1], s_r)
+                          and np.array_equal(res[4].cpu().numpy()[:total], d_p) and int(res[6][0].item()) == len(w_p)
+                          and np.array_equal(res[5].cpu().numpy()[:len(w_p)], w_p) and int(res[6][1].item()) == len(p_p)
+                          and np.array_equal(res[7].cpu().numpy()[:len(p_p), :3], p_p))
+                    if not ok:
+                        print("MISMATCH (pair records)", dict(nt=nt, tab=tab, rows=rows, lens=lens, pad=pad, skew=skew, sort=sort, segkey=segkey))
+                        sys.exit(1)
     n_done += 1
-print(f"stress_plan: {n_done} random launches x 16 planner forms each: all equal to the definition ({time.time() - t0:.0f} s)")
+print(f"stress_plan: {n_done} random launches x 16 planner forms (+ 8 with pair records) each: all equal to the definition ({time.time() - t0:.0f} s)")

@@ -362,9 +362,10 @@ def test_sparse_plan_ex_rejects_half_a_placement_and_unknown_flags():
 
     def call(flags, d, w, nw):
         return lib.nrx_sparse_plan_ex(ptrs, lens, tof, rws, 1, 64, 1, 1, flags, order.data_ptr(), uniq.data_ptr(), seg.data_ptr(), counts.data_ptr(),
-                                      d, w, nw, stats.data_ptr(), ws.data_ptr(), st)
+                                      d, w, nw, None, None, stats.data_ptr(), ws.data_ptr(), st)
     assert call(0, dest.data_ptr(), None, n_walk.data_ptr()) == _lib.NRX_ERR_BAD_ARG
-    assert call(2, dest.data_ptr(), walk.data_ptr(), n_walk.data_ptr()) == _lib.NRX_ERR_BAD_ARG
+    assert call(4, dest.data_ptr(), walk.data_ptr(), n_walk.data_ptr()) == _lib.NRX_ERR_BAD_ARG          # an unknown flag bit
+    assert call(_lib.NRX_PLAN_PAIRS, dest.data_ptr(), walk.data_ptr(), n_walk.data_ptr()) == _lib.NRX_ERR_BAD_ARG      # pair records asked for, no place to put them
     for flags in (0, _lib.NRX_PLAN_SPLIT_PADDING):
         assert call(flags, None, None, None) == 0, lib.nrx_last_error()
         torch.cuda.synchronize()
