@@ -117,10 +117,11 @@ __device__ __forceinline__ bool plan_is_placed(bool head, bool next_head, KeyT k
     return head && next_head && ((uint64_t)key & rmask) != 0 && plan_placeable(pi, p);
 }
 
-template <typename KeyT, bool PAIR = false, bool PLACE = false, bool SEG = false>
+template <typename KeyT, bool PAIR = false, bool PLACE = false, bool SEG = false, bool PAIRS = false>
 __global__ __launch_bounds__(NRX_BLOCK) void plan_count_kernel(const PlaceInfo place_in_kernarg /* first: read through nrx_kernarg */,
                                                                const KeyT* __restrict__ skeys, int64_t n, uint32_t* __restrict__ block_heads,
-                                                               const uint32_t* __restrict__ spayload, int row_bits, int want_pairs = 0) {
+                                                               const uint32_t* __restrict__ spayload, int row_bits) {
+    constexpr bool want_pairs = PLACE && PAIRS;      // (a template flag: the extra loads and the third count were 2 us of C5's plan even when off)
     __shared__ uint32_t s_cnt[3 * (NRX_BLOCK / 64)];
     const int64_t e0 = (int64_t)blockIdx.x * PLAN_TILE + threadIdx.x;
     uint32_t c = 0, cw = 0, cp = 0;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_count_kernel(const PlaceInfo p
 
 // entry e of the tile is handled by thread (e % 256) in round (e / 256): coalesced key / payload / order accesses; the
 // rank of a head = heads of earlier blocks + heads of earlier (round, wave) cells + heads of lower lanes in its cell
-template <typename KeyT, bool PAIR = false, bool PLACE = false, bool SEG = false>
+template <typename KeyT, bool PAIR = false, bool PLACE = false, bool SEG = false, bool PAIRS = false>
 __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo place_in_kernarg /* first: read through nrx_kernarg */,
                                                               const KeyT* __restrict__ skeys, const uint32_t* __restrict__ spayload,
                                                               const uint32_t* __restrict__ block_heads, int64_t n, int row_bits,
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo pl
     const int64_t e0 = (int64_t)tile * PLAN_TILE + tid;
     KeyT key[ROUNDS], prev[ROUNDS], next[ROUNDS], next2[ROUNDS];
     uint32_t pay[ROUNDS], pay1[ROUNDS];
-    const bool want_pairs = PLACE && pairs != nullptr;
+    constexpr bool want_pairs = PLACE && PAIRS;
 #pragma unroll
     for (int j = 0; j < ROUNDS; ++j) {            // all of the tile's loads are issued before anything waits
         const int64_t e = e0 + j * NRX_BLOCK;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo pl
     for (int off = 32; off > 0; off >>= 1) {
         acc += __shfl_xor(acc, off, 64);
         if (PLACE) wacc += __shfl_xor(wacc, off, 64);
-        if (PLACE) pacc += __shfl_xor(pacc, off, 64);
+        if (want_pairs) pacc += __shfl_xor(pacc, off, 64);
     }
     if (lane == 0) {
         s_part[wid] = acc;
@@ -276,10 +277,10 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo pl
             }
             walked[j] = head[j] && !placed[j] && !pairh[j];
             wmask[j] = __ballot(walked[j]);
-            pmask[j] = __ballot(pairh[j]);
+            pmask[j] = want_pairs ? __ballot(pairh[j]) : 0ull;
             if (lane == 0) {
                 s_wcell[j * WAVES + wid] = (uint32_t)__popcll(wmask[j]);
-                s_pcell[j * WAVES + wid] = (uint32_t)__popcll(pmask[j]);
+                if (want_pairs) s_pcell[j * WAVES + wid] = (uint32_t)__popcll(pmask[j]);
             }
         }
     }
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void plan_emit_kernel(const PlaceInfo pl
         }
         s_wcell[ROUNDS * WAVES] = run;
     }
-    if (PLACE && tid == 128) {
+    if (want_pairs && tid == 128) {
         uint32_t run = s_part[2 * WAVES] + s_part[2 * WAVES + 1] + s_part[2 * WAVES + 2] + s_part[2 * WAVES + 3];
         for (int c = 0; c < ROUNDS * WAVES; ++c) {
             const uint32_t v = s_pcell[c];
@@ -1506,10 +1507,17 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
             uint32_t* tp = psrc; psrc = pdst; pdst = tp;                                                                  \
         }                                                                                                                 \
         if (dest != nullptr) {                                                                                            \
-            hipLaunchKernelGGL((plan_count_kernel<KeyT, PAIR_, true, SEG_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src, n, flags, (const uint32_t*)psrc, row_bits, want_pairs); \
+            if (want_pairs) {                                                                                             \
+                hipLaunchKernelGGL((plan_count_kernel<KeyT, PAIR_, true, SEG_, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src, n, flags, (const uint32_t*)psrc, row_bits); \
+                hipLaunchKernelGGL((plan_emit_kernel<KeyT, PAIR_, true, SEG_, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src, \
+                                   (const uint32_t*)psrc, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys, \
+                                   seg_start, counts, dest, walk, n_walk, pairs_out, n_pairs_out);                        \
+            } else {                                                                                                      \
+            hipLaunchKernelGGL((plan_count_kernel<KeyT, PAIR_, true, SEG_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src, n, flags, (const uint32_t*)psrc, row_bits); \
             hipLaunchKernelGGL((plan_emit_kernel<KeyT, PAIR_, true, SEG_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src,     \
                                (const uint32_t*)psrc, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys,     \
-                               seg_start, counts, dest, walk, n_walk, pairs_out, n_pairs_out);                            \
+                               seg_start, counts, dest, walk, n_walk);                                                    \
+            }                                                                                                             \
         } else {                                                                                                          \
             hipLaunchKernelGGL((plan_count_kernel<KeyT, PAIR_, false, SEG_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src, n, flags, (const uint32_t*)psrc, row_bits); \
             hipLaunchKernelGGL((plan_emit_kernel<KeyT, PAIR_, false, SEG_>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)src,           \
@@ -1536,10 +1544,17 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
                                         (size_t)n, 0u, (unsigned)bits, st);                                               \
         if (err == hipSuccess) {                                                                                          \
             if (dest != nullptr) {                                                                                        \
-                hipLaunchKernelGGL((plan_count_kernel<KeyT, false, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out, n, flags, (const uint32_t*)pay_out, row_bits, want_pairs); \
-                hipLaunchKernelGGL((plan_emit_kernel<KeyT, false, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out, \
+                if (want_pairs) {                                                                                         \
+                hipLaunchKernelGGL((plan_count_kernel<KeyT, false, true, false, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out, n, flags, (const uint32_t*)pay_out, row_bits); \
+                hipLaunchKernelGGL((plan_emit_kernel<KeyT, false, true, false, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out, \
                                    (const uint32_t*)pay_out, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys, \
                                    seg_start, counts, dest, walk, n_walk, pairs_out, n_pairs_out);                        \
+                } else {                                                                                                  \
+                hipLaunchKernelGGL((plan_count_kernel<KeyT, false, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out, n, flags, (const uint32_t*)pay_out, row_bits); \
+                hipLaunchKernelGGL((plan_emit_kernel<KeyT, false, true>), dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out, \
+                                   (const uint32_t*)pay_out, (const uint32_t*)flags, n, row_bits, n_tables, order, uniq_keys, \
+                                   seg_start, counts, dest, walk, n_walk);                                                \
+                }                                                                                                         \
             } else {                                                                                                      \
                 hipLaunchKernelGGL(plan_count_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out, n, flags, (const uint32_t*)pay_out, row_bits); \
                 hipLaunchKernelGGL(plan_emit_kernel<KeyT>, dim3(gtile), dim3(NRX_BLOCK), 0, st, pinfo, (const KeyT*)keys_out,      \

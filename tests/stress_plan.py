@@ -10,6 +10,7 @@ from news_recsys_amd import ops
 from oracle import ref_np as R
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ops.PLAN_PAIRS = True          # (the Python layer's default leaves the sorted planner's pair records off; checked here all the same)
 t0, n_done = time.time(), 0
 while time.time() - t0 < budget:
     nt = int(rng.choice([1, 2, 3, 7, 26, 40, 63]))
@@ -74,7 +75,10 @@ while time.time() - t0 < budget:
                           and np.array_equal(res[5].cpu().numpy()[:len(w_p)], w_p) and int(res[6][1].item()) == len(p_p)
                           and np.array_equal(res[7].cpu().numpy()[:len(p_p), :3], p_p))
                     if not ok:
-                        print("MISMATCH (pair records)", dict(nt=nt, tab=tab, rows=rows, lens=lens, pad=pad, skew=skew, sort=sort, segkey=segkey))
+                        which = dict(n=len(res), counts=np.array_equal(res[3].cpu().numpy(), c_p), uniq=np.array_equal(res[1].cpu().numpy()[:nu], u_p),
+                                     order=np.array_equal(res[0].cpu().numpy(), o_r), seg=np.array_equal(res[2].cpu().numpy()[:nu + 1], s_r),
+                                     dest=np.array_equal(res[4].cpu().numpy()[:total], d_p), n_walk=(res[6].tolist(), len(w_p), len(p_p)))
+                        print("MISMATCH (pair records)", which, dict(nt=nt, nf=nf, total=total, pad=pad, skew=skew, sort=sort, segkey=segkey))
                         sys.exit(1)
     n_done += 1
 print(f"stress_plan: {n_done} random launches x 16 planner forms (+ 8 with pair records) each: all equal to the definition ({time.time() - t0:.0f} s)")
