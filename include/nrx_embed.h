@@ -37,7 +37,7 @@ extern "C" {
 #define NRX_API
 #endif
 
-#define NRX_ABI_VERSION 2
+#define NRX_ABI_VERSION 3 /* 3 (round 6): nrx_gather_inbox_place gained `out_rows`, nrx_dcn_v2_layer_bwd flags bit 2 (round 5, unversioned then); + the per-feature routing and the sharded backward entry points */
 #define NRX_MAX_FEATURES 64   /* per launch; the host splits wider feature sets */
 #define NRX_MAX_DCN_LAYERS 8
 

@@ -19,7 +19,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NRX_LIB") or os.path.join(_HERE, "lib", "libnrx_hip.so")      # NRX_LIB: another build of the library (A/B runs)
 
-NRX_ABI_VERSION = 2
+NRX_ABI_VERSION = 3
 NRX_MAX_FEATURES = 64
 NRX_MAX_DCN_LAYERS = 8
 NRX_OK = 0

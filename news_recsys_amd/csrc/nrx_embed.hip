@@ -984,7 +984,19 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_kernel(const Sorte
 constexpr int SORTED_LONG_T = 16;            // segments longer than this leave the lane-group kernel (32 for bag launches)
 constexpr int SORTED_LONG_CHUNK = 256;       // entries per work item (small: items are the unit of load balance)
 struct LongItem { int32_t u; int32_t dest; int64_t e_begin; int32_t len; int32_t m; };      // dest < 0: straight to values[u]; m: its row's LongMulti (several items)
-struct LongMulti { int32_t u; int32_t slot0; int32_t nchunks; int32_t done; };              // done: items of the row finished so far (the last one adds the partials)
+struct LongMulti { int32_t u; int32_t slot0; int32_t nchunks; int32_t done; };              // done: items (or item GROUPS) of the row finished so far (the last one adds the partials)
+// Rows of more than SORTED_LONG_GROUP items (> 8192 lookups: the hottest ids of a Zipf law) count their items in groups of that many: a group's
+// last finisher adds the group's partials into a second-level partial, the last GROUP's finisher adds those.  One counter for all items of
+// such a row is ~1000 device-scope atomics on ONE address, which the memory side serialises at ~0.1 us each (C4 with Zipf ids: +90 us).
+// Slot layout of a multi-item row: [slot0, +nchunks) item partials | [+ngroups) group partials | [+ (ngroups + 3) / 4) slots of int32 group counters.
+constexpr int SORTED_LONG_GROUP = 32;
+__host__ __device__ __forceinline__ int sorted_long_groups(int nchunks) { return nchunks > SORTED_LONG_GROUP ? (nchunks + SORTED_LONG_GROUP - 1) / SORTED_LONG_GROUP : 0; }
+__host__ __device__ __forceinline__ int sorted_long_slots(int nchunks) {
+    const int ng = sorted_long_groups(nchunks);
+    return nchunks + (ng ? ng + (ng + 3) / 4 : 0);
+}
+// (sum of sorted_long_slots over the multi-item rows of n lookups: <= n / 256 + n / 257 item slots, + <= n / 4096 group slots and counter slots)
+__host__ __device__ __forceinline__ int64_t sorted_long_slots_cap(int64_t n) { return 2 * n / SORTED_LONG_CHUNK + n / 2048 + 8; }
 
 __device__ __forceinline__ LongItem* sorted_long_items(const NRX_CONST SortedBwdArgs* a) {
     return reinterpret_cast<LongItem*>(a->long_ws + 4);
@@ -1654,12 +1666,17 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
                 const int nchunks = (int)((hi[r] - lo[r] + SORTED_LONG_CHUNK - 1) / SORTED_LONG_CHUNK);
                 int slot0 = -1, m = -1;
                 if (nchunks > 1) {
-                    slot0 = atomicAdd(&a->long_ws[2], nchunks);
+                    slot0 = atomicAdd(&a->long_ws[2], sorted_long_slots(nchunks));
                     m = atomicAdd(&a->long_ws[1], 1);
                     if (m < a->long_slots_cap) {
                         LongMulti w;
                         w.u = (int32_t)urow[r]; w.slot0 = slot0; w.nchunks = nchunks; w.done = 0;
                         sorted_long_multi(a)[m] = w;
+                    }
+                    const int ng = sorted_long_groups(nchunks);
+                    if (ng != 0 && (int64_t)slot0 + sorted_long_slots(nchunks) <= a->long_slots_cap) {      // the group counters start at zero
+                        int32_t* gc = reinterpret_cast<int32_t*>(sorted_long_partials(a) + (int64_t)(slot0 + nchunks + ng) * (4 * Q));
+                        for (int j = 0; j < ng; ++j) gc[j] = 0;
                     }
                 }
                 sorted_long_write_items(a, (int32_t)urow[r], lo[r], hi[r], nchunks, slot0, base, m);
@@ -1838,6 +1855,26 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
     for (int64_t blk = bx; blk * (TB * R) < n; blk += gx) body(blk);
 }
 
+// Partial sums of multi-item rows cross XCDs inside ONE launch (the item that finishes a row last may run on another XCD than the items that
+// left the partials): agent-scope accesses -- the store is written through the XCD's L2, the load does not hit in it.  16 bytes as four dwords
+// (the atomic builtins take scalars; a few hundred partials per launch).
+__device__ __forceinline__ void long_partial_publish(float* base, int64_t i, float4 v) {
+    float* p = base + i * 4;
+    __hip_atomic_store(p + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 long_partial_fetch(const float* base, int64_t i) {
+    const float* p = base + i * 4;
+    float4 v;
+    v.x = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.z = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.w = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+
 // Long segments.  An item = up to SORTED_LONG_CHUNK consecutive sorted entries of ONE unique row; a wavefront reduces an
 // item: its 64 / Q lane groups stride over the entries (two in flight each), then a fixed xor-shuffle tree adds the
 // groups -- the same entries always meet in the same order, so the result is reproducible.  A row of one item is written
@@ -1970,26 +2007,37 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
         }
         if (g == 0) {
             if (w.dest < 0) sorted_store4<Q>(a, w.u, a->dense ? nrx_gconst<int64_t>(a->uniq_keys)[w.u] : 0, q, acc);
+#ifdef NRX_COMBINE_SEPARATE
             else if (w.dest < a->long_slots_cap) nrx_stg4(partial, (int64_t)w.dest * Q + q, acc);
+#else
+            else if (w.dest < a->long_slots_cap) long_partial_publish(partial, (int64_t)w.dest * Q + q, acc);
+#endif
         }
         // A row of several items: the wavefront that finishes the row's LAST item adds the partials -- its lane groups stride over them in item
         // order, then the same fixed xor-shuffle tree as above: whichever wavefront comes last forms the same sum.  (Was a launch of its own,
         // sorted_combine_kernel: 4.6 us on every step to find, on uniform ids, an empty list.)
+        // The hand-over costs NO fence.  Round 5 had `__threadfence()` on both sides of the count: at agent scope that is buffer_wbl2 + buffer_inv
+        // -- a write-back of every dirty line of the XCD's L2 (this launch's own gradient rows) and an invalidate, per ITEM: Zipf ids have
+        // thousands of multi-item rows and the launch went 54 -> 187 us (C2) / 43 -> 331 us (C4; profiles/r06_zipf_regression.txt).  Instead the
+        // partials alone are written THROUGH the L2 (agent-scope stores: sc1), the wavefront waits for their acknowledgement (vmcnt(0)) before
+        // its lane 0 counts the item (a device-scope atomic: performed at the memory side), and the last finisher -- whose loads are issued
+        // behind the returned count -- reads them with agent-scope loads, which do not hit in its own XCD's L2 (the slots are reused every step).
+#ifndef NRX_COMBINE_SEPARATE
         if (w.dest >= 0 && w.m >= 0 && w.m < a->long_slots_cap) {            // wave-uniform
             LongMulti* mrow = sorted_long_multi(a) + w.m;
-            __threadfence();                                                 // this item's partial is out before the count says so
-            int old = 0;
-            if (lane == 0) old = atomicAdd(&mrow->done, 1);
-            old = __shfl(old, 0, 64);
-            const int nch = mrow->nchunks;
-            if (old == nch - 1) {
-                __threadfence();                                             // ... and the others' partials are seen after the count said so
-                const int slot0 = mrow->slot0;
+            const int nch = mrow->nchunks, slot0 = mrow->slot0;
+            // `count` partials from slot `first` on, added by this wavefront: its lane groups stride over them (four in flight each), then the fixed tree
+            auto add_partials = [&](int first, int count) -> float4 {
                 float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int c = g; c < nch; c += G) {
-                    if (slot0 + c >= a->long_slots_cap) break;
-                    const float4 tt = nrx_ldg4(partial, (int64_t)(slot0 + c) * Q + q);
-                    sum.x += tt.x; sum.y += tt.y; sum.z += tt.z; sum.w += tt.w;
+                if ((int64_t)first + count > a->long_slots_cap) count = (int)a->long_slots_cap - first;
+                for (int c = g; c < count; c += 4 * G) {
+                    float4 tt[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        tt[k] = long_partial_fetch(partial, (int64_t)(first + (c + k * G < count ? c + k * G : c)) * Q + q);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (c + k * G < count) { sum.x += tt[k].x; sum.y += tt[k].y; sum.z += tt[k].z; sum.w += tt[k].w; }
                 }
 #pragma unroll
                 for (int off = Q; off < 64; off <<= 1) {
@@ -1998,11 +2046,71 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
                     sum.z += __shfl_xor(sum.z, off, 64);
                     sum.w += __shfl_xor(sum.w, off, 64);
                 }
+                return sum;
+            };
+            auto count_one = [&](int32_t* counter) -> int {                  // this wavefront's writes have reached memory before the count says so
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int old = 0;
+                if (lane == 0) old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return __shfl(old, 0, 64);
+            };
+            const int ng = sorted_long_groups(nch);
+            bool last = false;
+            int first = slot0, count = nch;
+            if (ng == 0) {
+                last = count_one(&mrow->done) == nch - 1;
+            } else if ((int64_t)slot0 + sorted_long_slots(nch) <= a->long_slots_cap) {
+                int32_t* gc = reinterpret_cast<int32_t*>(partial + (int64_t)(slot0 + nch + ng) * (4 * Q));
+                const int grp = (w.dest - slot0) / SORTED_LONG_GROUP;
+                const int gsz = nch - grp * SORTED_LONG_GROUP < SORTED_LONG_GROUP ? nch - grp * SORTED_LONG_GROUP : SORTED_LONG_GROUP;
+                if (count_one(gc + grp) == gsz - 1) {                        // this group's last item: its partials -> the group's partial
+                    const float4 gsum = add_partials(slot0 + grp * SORTED_LONG_GROUP, gsz);
+                    if (g == 0) long_partial_publish(partial, (int64_t)(slot0 + nch + grp) * Q + q, gsum);
+                    last = count_one(&mrow->done) == ng - 1;
+                    first = slot0 + nch;
+                    count = ng;
+                }
+            }
+            if (last) {
+                const float4 sum = add_partials(first, count);
                 if (g == 0) sorted_store4<Q>(a, w.u, a->dense ? nrx_gconst<int64_t>(a->uniq_keys)[w.u] : 0, q, sum);
             }
         }
+#endif
     }
 }
+
+#ifdef NRX_COMBINE_SEPARATE
+// A row of several items: a wavefront adds its partials -- the 64 / Q lane groups stride over them in item order, then the
+// same fixed xor-shuffle tree as above.
+template <int QLOG2>
+__global__ __launch_bounds__(NRX_BLOCK) void sorted_combine_kernel(const SortedBwdArgs args_in_kernarg) {
+    const NRX_CONST SortedBwdArgs* a = nrx_kernarg<SortedBwdArgs>();
+    constexpr int Q = 1 << QLOG2, G = 64 / Q;
+    const int lane = threadIdx.x & 63, q = lane & (Q - 1), g = lane >> QLOG2;
+    const int nmulti = a->long_ws[1] < a->long_slots_cap ? a->long_ws[1] : (int)a->long_slots_cap;
+    const LongMulti* multi = sorted_long_multi(a);
+    const float* partial = sorted_long_partials(a);
+    const int nwaves = gridDim.x * (NRX_BLOCK / 64);
+    for (int m = blockIdx.x * (NRX_BLOCK / 64) + (threadIdx.x >> 6); m < nmulti; m += nwaves) {
+        const LongMulti w = multi[m];
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = g; c < w.nchunks; c += G) {
+            if (w.slot0 + c >= a->long_slots_cap) break;
+            const float4 tt = nrx_ldg4(partial, (int64_t)(w.slot0 + c) * Q + q);
+            sum.x += tt.x; sum.y += tt.y; sum.z += tt.z; sum.w += tt.w;
+        }
+#pragma unroll
+        for (int off = Q; off < 64; off <<= 1) {
+            sum.x += __shfl_xor(sum.x, off, 64);
+            sum.y += __shfl_xor(sum.y, off, 64);
+            sum.z += __shfl_xor(sum.z, off, 64);
+            sum.w += __shfl_xor(sum.w, off, 64);
+        }
+        if (g == 0) sorted_store4<Q>(a, w.u, a->dense ? nrx_gconst<int64_t>(a->uniq_keys)[w.u] : 0, q, sum);
+    }
+}
+#endif
 
 // Per-lookup factor of a bag feature's upstream row (what the general kernel recomputes per lookup from the whole row of
 // weights): w / (sum_l w + 1e-8) (masked mean, base_model.py:278-282), 1 / L (mean) or w (sum).  16 lanes per sample.
@@ -3109,7 +3217,7 @@ extern "C" int nrx_embed_bwd_small_sparse(const nrx_feature_t* feats, const int3
 
 extern "C" int64_t nrx_embed_bwd_sorted_workspace(int64_t n_lookups, int32_t dim) {
     if (n_lookups < 0 || dim < 1) return -1;
-    const int64_t items = n_lookups / SORTED_LONG_T + 8, slots = 2 * n_lookups / SORTED_LONG_CHUNK + 8;
+    const int64_t items = n_lookups / SORTED_LONG_T + 8, slots = sorted_long_slots_cap(n_lookups);
     return 32 + items * (int64_t)sizeof(LongItem) + slots * (int64_t)sizeof(LongMulti) + slots * (int64_t)dim * 4 + 64 +
            2 * (n_lookups * 4 + 64) + n_lookups / 8 + 128;       // + bag features: per-lookup scale, per-sample factor, weight bits
 }
@@ -3291,7 +3399,7 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
         if (workspace != nullptr) {        // long segments (hot rows) go through the wavefront-per-item path
             a.long_ws = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(workspace) + 15) & ~(uintptr_t)15);
             a.long_items_cap = off / SORTED_LONG_T + 8;
-            a.long_slots_cap = 2 * off / SORTED_LONG_CHUNK + 8;
+            a.long_slots_cap = sorted_long_slots_cap(off);
             // the four work-list counters are cleared by a kernel (nrx_zero_async), not hipMemsetAsync: inside a captured HIP graph
             // the 16-byte memset node did not take effect on replay (counters kept growing, the list was read past what was written)
             // (placement mode: the placement pass clears them -- one launch less)
@@ -3477,6 +3585,11 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
     }
             if (ql == 2) NRX_SL(2) else if (ql == 3) NRX_SL(3) else NRX_SL(4)
 #undef NRX_SL
+#ifdef NRX_COMBINE_SEPARATE
+            if (ql == 2) hipLaunchKernelGGL((sorted_combine_kernel<2>), dim3(64), dim3(NRX_BLOCK), 0, sw, a);
+            else if (ql == 3) hipLaunchKernelGGL((sorted_combine_kernel<3>), dim3(64), dim3(NRX_BLOCK), 0, sw, a);
+            else hipLaunchKernelGGL((sorted_combine_kernel<4>), dim3(64), dim3(NRX_BLOCK), 0, sw, a);
+#endif
         }
         if (side) {
             if (hipEventRecord(ev_join, sw) != hipSuccess) {

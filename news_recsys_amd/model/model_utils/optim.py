@@ -201,8 +201,16 @@ class FusedSparseAdam:
             m, v = self.moments[pos]
             m.copy_(mv["exp_avg"])
             v.copy_(mv["exp_avg_sq"])
+        unlisted = [key for key in (sd.get("steps") or {}) if isinstance(key, str)]
+        if unlisted:
+            raise ValueError("load_state_dict: the checkpoint holds step counts of tables that were not in `params` when it was saved "
+                             f"({unlisted}); construct the optimizer with params=<the table list>")
         if sd.get("steps"):
-            self._steps = {self._register(self.params[key]): int(c) for key, c in sd["steps"].items() if not isinstance(key, str)}
+            self._steps = {self._register(self.params[key]): int(c) for key, c in sd["steps"].items()}
+        elif hasattr(self, "maps"):
+            # (ExactDenseAdamW) a checkpoint written before the per-table step counts existed: every table had moved on every one of the `t`
+            # steps -- restarting the tables at step 1 would apply lr / (1 - beta1) to the restored moments and leave torch.optim.AdamW's path
+            self._steps = {pos: self.t for pos in range(len(self.tables))}
 
 
 class ExactDenseAdamW(FusedSparseAdam):

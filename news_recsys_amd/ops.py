@@ -769,6 +769,27 @@ def _lds_state(dev: torch.device, stream: int) -> Optional[torch.Tensor]:
     return st
 
 
+_PINNED_CHUNKS = []           # page-locked int64 chunks, NEVER released: see _pinned_words
+_PINNED_USED = 0
+
+
+def _pinned_words(n: int):
+    """n int64 words of page-locked host memory that stay valid for the life of the process: (tensor view, address, numpy view).
+    The planners' statistics words are written by kernels through a raw address -- which is also baked into captured graphs -- so the memory
+    must outlive every launch and every replay that may still name it.  A pinned tensor owned by a policy object went back to torch's pinned
+    caching allocator when the policy was replaced (another batch size) or evicted, and a later plan or graph replay then wrote 32-40 bytes
+    into whatever that block had become (a ColumnarLoader staging batch, a status word).  Slices of an arena that is never freed cannot be
+    recycled; a policy costs 64 bytes of it."""
+    global _PINNED_USED
+    n = (int(n) + 7) & ~7
+    if not _PINNED_CHUNKS or _PINNED_USED + n > _PINNED_CHUNKS[-1].numel():
+        _PINNED_CHUNKS.append(torch.zeros(max(4096, n), dtype=torch.int64).pin_memory())
+        _PINNED_USED = 0
+    t = _PINNED_CHUNKS[-1][_PINNED_USED:_PINNED_USED + n]
+    _PINNED_USED += n
+    return t, t.data_ptr(), t.numpy()
+
+
 class PlanPolicy:
     """Per launch group: may the one-kernel planner take it (shape), and should it (the previous batch's duplicate statistics)."""
 
@@ -779,9 +800,7 @@ class PlanPolicy:
         self.use_lds = PLAN_LDS == "1"
         self.stats = None
         if self.eligible:
-            self.stats = torch.zeros(4, dtype=torch.int64).pin_memory()
-            self.stats_ptr = self.stats.data_ptr()
-            self._np = self.stats.numpy()
+            self.stats, self.stats_ptr, self._np = _pinned_words(4)
 
     def choose(self) -> bool:
         if not self.eligible:
@@ -815,9 +834,7 @@ class PadPolicy:
 
     def __init__(self, total: int):
         self.total = int(total)
-        self.stats = torch.zeros(5, dtype=torch.int64).pin_memory()
-        self.stats_ptr = self.stats.data_ptr()
-        self._np = self.stats.numpy()
+        self.stats, self.stats_ptr, self._np = _pinned_words(5)
 
     def choose(self) -> bool:
         if PAD_SPLIT != "auto":
@@ -925,14 +942,15 @@ def sparse_plan(ids: Sequence[torch.Tensor], table_of: Sequence[int], rows: Sequ
             dest = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
             walk = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
             n_walk = torch.empty(2, dtype=torch.int64, device=dev)                      # [0] walk rows  [1] pair records
-            pairs = torch.empty((total // 2 + 1, 4), dtype=torch.int32, device=dev)
+            recs = torch.empty((total // 2 + 1, 4), dtype=torch.int32, device=dev)       # (not `pairs`: that is the caller's flag, read again below
+                                                                                           #  when the planner declines the launch)
             rc = lib.nrx_sparse_plan_lds(ptrs, lens, tof, rws, n, ids[0].element_size() * 8, n_tables, order.data_ptr(), uniq.data_ptr(),
                                          seg.data_ptr(), counts.data_ptr(), dest.data_ptr(), walk.data_ptr(), n_walk.data_ptr(),
-                                         pairs.data_ptr(), n_walk.data_ptr() + 8, policy.stats_ptr, state.data_ptr(), ws.data_ptr(), stream)
+                                         recs.data_ptr(), n_walk.data_ptr() + 8, policy.stats_ptr, state.data_ptr(), ws.data_ptr(), stream)
             if rc == 0:
                 if not own_stream and keep is not None:
                     keep.append(ws)
-                return order, uniq, seg, counts, dest, walk, n_walk, pairs
+                return order, uniq, seg, counts, dest, walk, n_walk, recs
             if rc != NRX_ERR_UNSUPPORTED:
                 check(rc, "nrx_sparse_plan_lds")
     nbytes = lib.nrx_sparse_plan_workspace(total)
@@ -1040,9 +1058,13 @@ def _group_policy(grp, B: int, n_tables: int) -> Optional["PlanPolicy"]:
     if not grp["all_sparse"] or PLAN_LDS == "0" or not SPARSE_PLACE:
         return None
     if grp["policy_B"] != B:
-        n = grp["n"]
-        lens = (C.c_int64 * n)(*([B] * n))
-        grp["policy"] = PlanPolicy(lens, grp["static"][0], grp["static"][1], n, n_tables, B * n)
+        by_b = grp.setdefault("policies", {})          # one per batch size, kept: an epoch's shorter last batch (or an evaluation at another size)
+        pol = by_b.get(B)                              # must neither reset the full batches' statistics nor drop a policy a captured graph names
+        if pol is None:
+            n = grp["n"]
+            lens = (C.c_int64 * n)(*([B] * n))
+            pol = by_b[B] = PlanPolicy(lens, grp["static"][0], grp["static"][1], n, n_tables, B * n)
+        grp["policy"] = pol
         grp["policy_B"] = B
     return grp["policy"]
 
@@ -1055,9 +1077,7 @@ def _group_pad(grp, plan: EmbedPlan, B: int) -> Optional["PadPolicy"]:
     if B not in cache:
         total = sum(B * max(1, plan.slots[i].bag_len) for i in grp["fs"])
         bags = any(plan.slots[i].kind != NRX_SPARSE for i in grp["fs"])
-        if len(cache) >= 4:
-            cache.pop(next(iter(cache)))
-        cache[B] = PadPolicy(total) if bags and total >= PAD_SPLIT_MIN else None
+        cache[B] = PadPolicy(total) if bags and total >= PAD_SPLIT_MIN else None      # (never evicted: 64 bytes of the pinned arena each)
     return cache[B]
 
 
@@ -1246,15 +1266,16 @@ def _sorted_sparse_grads(ctx, lib, g_out, g_wide, stream, fmg=None, dense_into=N
             continue
         if SPARSE_BWD_SYNC_FREE:
             values = torch.empty((total, D), dtype=torch.float32, device=dev)     # worst case: every lookup unique
-            _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, total, counts, fmg, values, lws, stream, replan=replan)
-            cl = counts.tolist()
+            pl = _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, total, counts, fmg, values, lws, stream, replan=replan)
+            cl = pl[3].tolist()
             nu = cl[0]
         else:
             cl = counts.tolist()
             nu = cl[0]
             values = torch.empty((nu, D), dtype=torch.float32, device=dev)
-            _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, nu, None, fmg, values, lws, stream, replan=replan)
+            pl = _bwd_sorted(lib, pl, pmask, arr, n, B, D, g_out, ld, g_wide, plan.wide_width, nu, None, fmg, values, lws, stream, replan=replan)
                                                               # padding rows (id 0) come back as zeros
+        uniq = pl[1]          # (after a replan: the plan the reduction took -- the same unique rows and counts, in that plan's buffers)
         rows = (uniq[:nu] & MASK).unsqueeze(0)
         for t in sorted(set(tabs)):
             lo, hi = cl[1 + t], cl[2 + t]

@@ -38,7 +38,7 @@ def test_binding_matches_header():
 
 def test_load_and_abi_version_no_gpu_needed():
     lib = _lib.load()
-    assert lib.nrx_abi_version() == 2
+    assert lib.nrx_abi_version() == _lib.NRX_ABI_VERSION == 3
     assert lib.nrx_bucketize_workspace(5000, 8) == 3 * 8 + 8     # 3 chunks of 2048 ids + offsets
 
 

@@ -68,3 +68,23 @@ def test_step_runs_closure_with_grad_enabled():
     loss = opt.step(closure)
     assert loss is not None and loss.item() > 0
     assert not torch.equal(before[:8], emb.weight.detach()[:8]) and torch.equal(before[8:], emb.weight.detach()[8:])
+
+
+def test_exact_dense_adamw_restores_step_counts_from_a_checkpoint_without_them():
+    """A checkpoint written before ExactDenseAdamW kept per-table step counts has `t` but no `steps`: on load every registered table takes
+    `t` (each had moved on every step), so the bias corrections continue where torch.optim.AdamW's would; step counts saved under
+    an `unlisted:` key (a table that was not in `params`) are refused instead of dropped.  Host logic only: no kernel runs."""
+    import pytest
+    from news_recsys_amd import ops
+    from news_recsys_amd.model.model_utils.optim import ExactDenseAdamW
+    tables = [torch.zeros(5, 4), torch.zeros(7, 4)]
+    opt = ExactDenseAdamW(ops.SparseGradSink(), tables, lr=0.1)
+    old = {"t": 9, "t_dev": None, "tables": {i: {"exp_avg": torch.ones_like(t), "exp_avg_sq": torch.ones_like(t)} for i, t in enumerate(tables)}}
+    opt.load_state_dict(old)                                   # (no "steps" entry: the pre-round-5 format)
+    assert opt.t == 9 and opt._steps == {0: 9, 1: 9}
+    assert torch.equal(opt.moments[0][0], torch.ones(5, 4))
+    new = dict(old, steps={0: 9, 1: 4})                        # the current format: a table that was looked up in 4 of the 9 steps
+    opt.load_state_dict(new)
+    assert opt._steps == {0: 9, 1: 4}
+    with pytest.raises(ValueError, match="unlisted"):
+        opt.load_state_dict(dict(old, steps={0: 9, "unlisted:1": 4}))
