@@ -597,6 +597,43 @@ NRX_API int nrx_gather_inbox_place(const float* const* tables, const int64_t* ta
                            const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,
                            const int64_t* recv2d, const int32_t* inbox_rows, const int32_t* inbox_pos, int32_t dim,
                            float* const* peer_out, int64_t out_ld, int64_t out_rows, const int32_t* feat_col, int32_t* status, void* stream);
+/* ---- per-feature fixed-capacity routing (round 6): the exchange whose OWNER side is the single-GPU engine --------------------------------
+ * nrx_route_ids packs the features of a (source, owner) block behind each other at device-resident offsets: nothing on the owner is then a
+ * plain id array per feature.  Here every (source, owner, FEATURE) triple owns capf slots (n_feats single-valued features of `batch` ids each;
+ * ids: HOST array of device pointers, all int32 or all int64):
+ *   send_ids[(o * n_feats + f) * capf + k]  int32 OWNER ID of the k-th id of feature f owned by rank o (= id % world), in sample order:
+ *                                           0 = nothing (an empty slot k >= count -- the call zero-fills the tails -- or the global padding id 0);
+ *                                           v >= 1 = local row v - 1 of o's shard (id / world + 1).  Ids that cannot be rows (< 0, >= 2^31 - 1) go
+ *                                           to rank 0 as -1 / INT32_MAX, where the owner's forward reports them out of range.
+ *   send_pos (optional, same layout)        the sample b of that id (one-sided placement); 0 in the tails
+ *   slot[f * batch + b]                     int32 (o * capf + k) * n_feats + f: the lookup's row in the returned [world * capf, n_feats, dim]
+ *                                           buffer viewed as rows of `dim` floats -- and in the gradient send buffer; -1 when k >= capf
+ *   counts[o * n_feats + f]                 int64 ids of feature f owned by o (may exceed capf)
+ *   overflow[0]                             running maximum of those counts since the caller zeroed it (> capf: redo the step with a larger capf)
+ * After an equal-split all-to-all of send_ids (n_feats * capf words per peer) and nrx_inbox_transpose, the owner holds per feature ONE array of
+ * world * capf owner ids, [f][s][k]: a batch of world * capf pseudo-samples for nrx_embed_fwd, nrx_sparse_plan*, nrx_embed_bwd_* over shard
+ * tables that carry a LEADING DUMMY ROW (table pointer = the dummy row, rows = local rows + 1): owner id 0 reads zeros and never trains, exactly
+ * the padding row of a single-GPU table.  Rows / gradient rows travel as [s][k][f][dim] = a [world * capf, n_feats * dim] concat (out_col f * dim).
+ * ONE launch; deterministic (ballot ranks + a published-totals chain over the tiles of a feature; definition: oracle/ref_np.py route_feat).
+ * state: nrx_route_feat_state_bytes() device bytes, ZERO before the first call, then owned by the call (one stream at a time).
+ * No reference counterpart (the reference is single-device: src/model/sort/deep/train.py:38-44).                                              */
+NRX_API int64_t nrx_route_feat_state_bytes(int32_t n_feats, int64_t batch, int32_t world);
+NRX_API int nrx_route_feat(const void* const* ids, int32_t n_feats, int64_t batch, int32_t index_bits, int32_t world, int64_t capf,
+                   int32_t* send_ids, int32_t* send_pos, int32_t* slot, int64_t* counts, int64_t* overflow, void* state, void* stream);
+/* [world][n_feats][capf] int32 (as the all-to-all leaves it) -> [n_feats][world][capf] (per-feature arrays); optionally a second array (the
+ * positions) in the same launch.  capf % 4 == 0, 16-byte aligned buffers. */
+NRX_API int nrx_inbox_transpose(const int32_t* inbox_a, int32_t* out_a, const int32_t* inbox_b, int32_t* out_b, int32_t world, int32_t n_feats,
+                        int64_t capf, void* stream);
+/* The requester's half of the sharded backward (and any other permutation of upstream rows): values[dest[p], :dim] = the upstream row of lookup p
+ * -- g_out[b, cols of feature f] with the FM term folded in as in nrx_embed_bwd (fm may be NULL) -- for the flat, feature-major lookups p = f *
+ * batch + b of n_feats NRX_SPARSE features; dest[p] < 0: skipped.  Every written row is written once (dest is a partial permutation: the
+ * caller's promise).  This is nrx_embed_bwd_placed's placement pass with the caller's destinations: upstream rows read where they lie
+ * (sample-major, coalesced, whole 128-byte lines for 64-byte rows), one store per row.  NRX_ERR_UNSUPPORTED (nothing enqueued) outside its
+ * shapes (dim 16 / 32 / 64, 16-byte aligned operands, no wide routing).  Autograd of the row copies of
+ * src/model/BaseModel/base_model.py:262-271 with respect to the looked-up rows. */
+NRX_API int nrx_embed_bwd_scatter(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                          const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld, const nrx_fm_grad_t* fm,
+                          const int32_t* dest, float* values, void* stream);
 /* Backward of nrx_gather_inbox: grad_tables[..][row] += g_rows[p] over the valid prefixes.        */
 NRX_API int nrx_scatter_add_inbox(float* const* grad_tables, const int64_t* table_rows, int32_t n_tables,
                           const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,

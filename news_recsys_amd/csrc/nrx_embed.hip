@@ -3231,7 +3231,8 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
                                  float* const* grad_tables = nullptr, int32_t n_tables = 0, int32_t add_to = 0,
                                  bool pairs = false /* the plan is nrx_sparse_plan_lds's: rows looked up twice are finished by embed_bwd_pairs_kernel */,
                                  void* aux_stream = nullptr /* pairs: the pair pass, the walk and the work lists run THERE, next to the placement pass */,
-                                 const int32_t* pair_recs = nullptr, const int64_t* n_pairs = nullptr) {
+                                 const int32_t* pair_recs = nullptr, const int64_t* n_pairs = nullptr,
+                                 bool place_only = false /* nrx_embed_bwd_scatter: the placement pass alone (dest is the caller's) */) {
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_bwd_sorted: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0 && dim >= 1 && n_unique >= 0, "nrx_embed_bwd_sorted: bad argument");
@@ -3354,6 +3355,10 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
     const bool placed = fast && dest != nullptr;
     if (pairs && !(placed && !has_bag)) {
         nrx_set_error("nrx_embed_bwd_placed_pairs: the launch is outside the placement pass's shapes (dim 16 / 32 / 64, aligned operands, single-valued features)");
+        return NRX_ERR_UNSUPPORTED;
+    }
+    if (place_only && !(placed && !has_bag)) {
+        nrx_set_error("nrx_embed_bwd_scatter: the launch is outside the placement pass's shapes (dim 16 / 32 / 64, aligned operands, single-valued features)");
         return NRX_ERR_UNSUPPORTED;
     }
     if (fast) {
@@ -3487,6 +3492,10 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             }
         }
         if (!side) launch_place();
+        if (place_only) {
+            NRX_LAUNCH_CHECK("nrx_embed_bwd_scatter");
+            return NRX_OK;
+        }
         unsigned pair_blocks = 0;
         if (pairs) {
             // (a plan with pair rows is a placement plan over single-valued features: the launch is `placed`, has no bags)
@@ -3884,6 +3893,24 @@ extern "C" int nrx_embed_bwd_placed(const nrx_feature_t* feats, int32_t n_feats,
                 "nrx_embed_bwd_placed: workspace_bytes too small");
     return embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, g_wide, wide_ld, order, seg_start, uniq_keys, n_unique,
                                  n_unique_dev, fm, values, place_feats, dest, walk, n_walk, workspace, workspace_bytes, stream);
+}
+
+// The placement pass alone, with the caller's destinations: values[dest[p]] = the upstream row of lookup p (flat, feature-major), FM term folded
+// in.  The requester's half of the sharded backward (every lookup's gradient row goes to its slot of the send buffer: a permutation).
+extern "C" int nrx_embed_bwd_scatter(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                                     const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld, const nrx_fm_grad_t* fm,
+                                     const int32_t* dest, float* values, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(dest != nullptr && values != nullptr, "nrx_embed_bwd_scatter: null dest / values");
+    NRX_REQUIRE(n_feats >= 1 && n_feats <= NRX_MAX_FEATURES, "nrx_embed_bwd_scatter: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
+    for (int i = 0; i < n_feats; ++i)
+        NRX_REQUIRE(feats[i].kind == NRX_SPARSE, "nrx_embed_bwd_scatter: feature %d is not single-valued", i);
+    const uint64_t mask = n_feats == 64 ? ~0ull : ((1ull << n_feats) - 1ull);
+    // (order / seg_start are the walk's inputs: never read by the placement pass; any non-null address passes the argument checks)
+    const int64_t* dummy = reinterpret_cast<const int64_t*>(dest);
+    return embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, g_wide, wide_ld, dummy, dummy, nullptr, /*n_unique=*/1, nullptr, fm,
+                                 values, mask, dest, reinterpret_cast<const int32_t*>(dest), dummy, nullptr, 0, stream, nullptr, 0, 0, false, nullptr,
+                                 nullptr, nullptr, /*place_only=*/true);
 }
 
 // nrx_embed_bwd_placed / nrx_embed_bwd_placed_dense for the placement plans of nrx_sparse_plan_lds (pair records for the rows looked up twice).

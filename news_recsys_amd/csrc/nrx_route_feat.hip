@@ -1,0 +1,251 @@
+// Per-feature fixed-capacity routing for row-sharded tables (round 6; the reference is single-device -- every trainer is `devices=1`,
+// src/model/sort/deep/train.py:38-44 -- so there is no reference counterpart; the definition is oracle/ref_np.py route_feat).
+//
+// Why another layout.  nrx_route_ids gives every (source, owner) pair ONE block of `cap` slots with the features packed behind each other at
+// device-resident offsets: fine for a gather, but nothing on the owner's side is then a plain [batch] id array per feature, and none of the
+// single-GPU machinery (the fused forward, the planners, the placement pass, the sorted reduction, the row-sparse optimizer) can be pointed at
+// it.  Here every (source, owner, FEATURE) triple gets its own `capf` slots:
+//     send_ids[o][f][k]   k-th id of feature f owned by rank o, in sample order, as an OWNER ID: 0 = nothing (an empty slot, or the global
+//                         padding id 0), v >= 1 = local row v - 1 of the owner's shard (global row (v - 1) * world + o)
+// so that, after one equal-split all-to-all and a transposing copy, the owner holds per feature ONE id array of world * capf pseudo-samples
+// [f][s][k] -- a batch like any other for nrx_embed_fwd / nrx_sparse_plan* / nrx_embed_bwd_* over tables that carry a leading dummy row (owner id
+// 0 = that row: it reads as zeros and never trains, exactly the padding row of a single-GPU table).  Rows and gradient rows travel as
+// [s][k][f][dim] = a [world * capf, n_feats * dim] concat.
+//
+// ONE launch (nrx_route_ids: four).  A block takes a tile of 4096 ids of one feature (tiles in ticket order: every earlier tile has started),
+// ranks its ids per owner with ballots, publishes its per-owner totals and adds up those of the feature's earlier tiles (published words with
+// an epoch mark, relaxed agent-scope polling: the construction of nrx_plan_lds.hip's range chain), then places.  The last tile of a feature
+// knows the counts: it writes counts[o][f], raises the running overflow maximum, and zero-fills the tails.  No order-dependent atomic: the
+// result is the same run to run and equal to its definition bit for bit.
+#include <cstring>
+
+#include "nrx_common.h"
+
+namespace {
+
+constexpr int RF_THREADS = 256;
+constexpr int RF_ROUNDS = 16;
+constexpr int RF_TILE = RF_THREADS * RF_ROUNDS;      // 4096 ids per block
+constexpr int RF_WAVES = RF_THREADS / 64;
+constexpr int RF_MAX_WORLD = 64;
+
+struct RouteFeatArgs {
+    const void* ids[NRX_MAX_FEATURES];
+    int64_t batch;            // ids per feature
+    int64_t capf;
+    int32_t n_feats, world, idx64, tiles;      // tiles per feature
+    int32_t* send_ids;        // [world][n_feats][capf]
+    int32_t* send_pos;        // same layout, or null
+    int32_t* slot;            // [n_feats][batch]
+    int64_t* counts;          // [world][n_feats]
+    int64_t* overflow;
+    uint32_t* ctl;            // [0] ticket  [1] blocks done  [2] epoch
+    unsigned long long* agg;  // [n_feats * tiles][world]: (mark << 32) | total
+};
+static_assert(sizeof(RouteFeatArgs) <= 3584, "kernarg budget");
+
+__global__ __launch_bounds__(RF_THREADS) void route_feat_kernel(const RouteFeatArgs args_in_kernarg) {
+    const NRX_CONST RouteFeatArgs* a = nrx_kernarg<RouteFeatArgs>();
+    __shared__ int s_cell[RF_ROUNDS * RF_WAVES][RF_MAX_WORLD];      // ids of owner o in cell (round, wavefront), then their exclusive prefix
+    __shared__ int s_tot[RF_MAX_WORLD], s_base[RF_MAX_WORLD];
+    __shared__ uint32_t s_ticket, s_mark;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int W = a->world, n = a->n_feats, T = a->tiles;
+    if (tid == 0) {
+        s_ticket = atomicAdd(&a->ctl[0], 1u);
+        s_mark = __hip_atomic_load(&a->ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    }
+    if (tid < RF_MAX_WORLD) s_base[tid] = 0;
+    __syncthreads();
+    const int w = (int)s_ticket;
+    const uint32_t mark = s_mark;
+    const int f = w / T, tile = w - f * T;
+    const int64_t B = a->batch, i0 = (int64_t)tile * RF_TILE;
+    // ---- the tile's ids -> (owner, owner id)
+    int owner[RF_ROUNDS];
+    int32_t val[RF_ROUNDS];
+    {
+        const void* p = a->ids[f];
+        int64_t id[RF_ROUNDS];
+#pragma unroll
+        for (int j = 0; j < RF_ROUNDS; ++j) {
+            const int64_t i = i0 + j * RF_THREADS + tid;
+            id[j] = -1;
+            if (i < B) id[j] = a->idx64 ? nrx_gconst<int64_t>(p)[i] : (int64_t)nrx_gconst<int32_t>(p)[i];
+        }
+#pragma unroll
+        for (int j = 0; j < RF_ROUNDS; ++j) {
+            const int64_t i = i0 + j * RF_THREADS + tid;
+            if (i >= B) { owner[j] = -1; val[j] = 0; continue; }
+            // ids that cannot be rows go to rank 0 as -1 / INT32_MAX: the owner's forward reports them out of range (the reference raises IndexError)
+            if (id[j] < 0) { owner[j] = 0; val[j] = -1; }
+            else if (id[j] >= 0x7fffffffLL) { owner[j] = 0; val[j] = 0x7fffffff; }
+            else {
+                const uint32_t u = (uint32_t)id[j], l = u / (uint32_t)W;
+                owner[j] = (int)(u - l * (uint32_t)W);
+                val[j] = u == 0 ? 0 : (int32_t)(l + 1u);
+            }
+        }
+    }
+    // ---- ballot ranks inside (round, wavefront) cells
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int rank[RF_ROUNDS];
+#pragma unroll
+    for (int j = 0; j < RF_ROUNDS; ++j) {
+        rank[j] = 0;
+        for (int t = 0; t < W; ++t) {
+            const unsigned long long m = __ballot(owner[j] == t);
+            if (owner[j] == t) rank[j] = __popcll(m & lt);
+            if (lane == t) s_cell[j * RF_WAVES + wid][t] = __popcll(m);
+        }
+    }
+    __syncthreads();
+    if (tid < W) {                       // lane o: exclusive prefix of owner o's cells; the tile's total
+        int run = 0;
+        for (int c = 0; c < RF_ROUNDS * RF_WAVES; ++c) {
+            const int v = s_cell[c][tid];
+            s_cell[c][tid] = run;
+            run += v;
+        }
+        s_tot[tid] = run;
+        if (tile + 1 < T)                // (the feature's last tile has no successor)
+            __hip_atomic_store(&a->agg[((int64_t)f * T + tile) * W + tid], ((unsigned long long)mark << 32) | (unsigned)run, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- the earlier tiles of this feature: one (tile, owner) word per thread and round, summed per owner with LDS integer atomics
+    for (int j = tid; j < tile * W; j += RF_THREADS) {
+        const int o = j % W;
+        unsigned long long x;
+        do { x = __hip_atomic_load(&a->agg[(int64_t)f * T * W + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((uint32_t)(x >> 32) != mark);
+        atomicAdd(&s_base[o], (int)(uint32_t)x);          // integer sum: the value does not depend on the order
+    }
+    __syncthreads();
+    // ---- place
+    const int64_t capf = a->capf;
+    int32_t* __restrict__ send_ids = a->send_ids;
+    int32_t* __restrict__ send_pos = a->send_pos;
+    int32_t* __restrict__ slot = a->slot;
+#pragma unroll
+    for (int j = 0; j < RF_ROUNDS; ++j) {
+        if (owner[j] < 0) continue;
+        const int o = owner[j];
+        const int64_t i = i0 + j * RF_THREADS + tid;
+        const int64_t k = (int64_t)s_base[o] + s_cell[j * RF_WAVES + wid][o] + rank[j];
+        if (k < capf) {
+            const int64_t d = ((int64_t)o * n + f) * capf + k;
+            send_ids[d] = val[j];
+            if (send_pos != nullptr) send_pos[d] = (int32_t)i;
+            slot[(int64_t)f * B + i] = (int32_t)(((int64_t)o * capf + k) * n + f);
+        } else {
+            slot[(int64_t)f * B + i] = -1;
+        }
+    }
+    // ---- the feature's last tile: counts, overflow, tails
+    if (tile == T - 1) {
+        __syncthreads();                 // (s_base is rewritten below: every placement above has read it)
+        if (tid < W) {
+            const int64_t c = (int64_t)s_base[tid] + s_tot[tid];
+            a->counts[(int64_t)tid * n + f] = c;
+            s_base[tid] = (int)(c < capf ? c : capf);      // first empty slot of (owner, feature)
+        }
+        __syncthreads();
+        if (tid == 0) {
+            long long worst = 0;
+            for (int o = 0; o < W; ++o) {
+                const long long c = a->counts[(int64_t)o * n + f];
+                worst = c > worst ? c : worst;
+            }
+            atomicMax(reinterpret_cast<long long*>(a->overflow), worst);      // running maximum: order-independent
+        }
+        for (int o = 0; o < W; ++o) {
+            const int64_t base = ((int64_t)o * n + f) * capf;
+            for (int64_t k = s_base[o] + tid; k < capf; k += RF_THREADS) {
+                send_ids[base + k] = 0;
+                if (send_pos != nullptr) send_pos[base + k] = 0;
+            }
+        }
+    }
+    // ---- re-arm: the block that finishes last advances the epoch and clears the counters (every other block is done polling)
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t done = atomicAdd(&a->ctl[1], 1u);
+        if (done == (uint32_t)(n * T) - 1u) {
+            __hip_atomic_store(&a->ctl[2], mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a->ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a->ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// [world][n][capf] -> [n][world][capf] (the owner's per-feature id arrays), up to two arrays in one launch
+__global__ __launch_bounds__(NRX_BLOCK) void inbox_transpose_kernel(const int32_t* __restrict__ a_in, int32_t* __restrict__ a_out,
+                                                                   const int32_t* __restrict__ b_in, int32_t* __restrict__ b_out, int world, int n,
+                                                                   int64_t capf) {
+    const int64_t total = (int64_t)world * n * capf;
+    for (int64_t i = ((int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * NRX_BLOCK * 4) {
+        // capf % 4 == 0: a 16-byte piece never straddles two (source, feature) runs
+        const int64_t run = i / capf, k = i - run * capf;
+        const int s = (int)(run / n), f = (int)(run - (int64_t)s * n);
+        const int64_t o = ((int64_t)f * world + s) * capf + k;
+        typedef int nrx_i32x4t __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<nrx_i32x4t*>(a_out + o) = *reinterpret_cast<const nrx_i32x4t*>(a_in + i);
+        if (b_in != nullptr) *reinterpret_cast<nrx_i32x4t*>(b_out + o) = *reinterpret_cast<const nrx_i32x4t*>(b_in + i);
+    }
+}
+
+}      // namespace
+
+extern "C" int64_t nrx_route_feat_state_bytes(int32_t n_feats, int64_t batch, int32_t world) {
+    if (n_feats < 1 || n_feats > NRX_MAX_FEATURES || batch < 0 || world < 1 || world > RF_MAX_WORLD) return -1;
+    const int64_t tiles = (batch + RF_TILE - 1) / RF_TILE;
+    return 64 + (int64_t)n_feats * (tiles > 0 ? tiles : 1) * world * 8;
+}
+
+extern "C" int nrx_route_feat(const void* const* ids, int32_t n_feats, int64_t batch, int32_t index_bits, int32_t world, int64_t capf,
+                              int32_t* send_ids, int32_t* send_pos, int32_t* slot, int64_t* counts, int64_t* overflow, void* state, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(ids != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES, "nrx_route_feat: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
+    NRX_REQUIRE(world >= 1 && world <= RF_MAX_WORLD, "nrx_route_feat: world must be in [1, %d]", RF_MAX_WORLD);
+    NRX_REQUIRE(index_bits == 32 || index_bits == 64, "nrx_route_feat: index_bits must be 32 or 64");
+    NRX_REQUIRE(batch >= 0 && batch < 0x7fffffffLL && capf >= 1, "nrx_route_feat: bad batch / capf");
+    NRX_REQUIRE((int64_t)world * capf * n_feats < 0x7fffffffLL, "nrx_route_feat: world * capf * n_feats must stay below 2^31 (slot is int32)");
+    NRX_REQUIRE(send_ids && slot && counts && overflow && state, "nrx_route_feat: null buffer");
+    if (batch == 0) return NRX_OK;
+    RouteFeatArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < n_feats; ++i) {
+        NRX_REQUIRE(ids[i] != nullptr, "nrx_route_feat: feature %d: null ids", i);
+        a.ids[i] = ids[i];
+    }
+    a.batch = batch;
+    a.capf = capf;
+    a.n_feats = n_feats;
+    a.world = world;
+    a.idx64 = index_bits == 64;
+    a.tiles = (int32_t)((batch + RF_TILE - 1) / RF_TILE);
+    a.send_ids = send_ids;
+    a.send_pos = send_pos;
+    a.slot = slot;
+    a.counts = counts;
+    a.overflow = overflow;
+    a.ctl = reinterpret_cast<uint32_t*>(state);
+    a.agg = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(state) + 64);
+    hipLaunchKernelGGL(route_feat_kernel, dim3((unsigned)(n_feats * a.tiles)), dim3(RF_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
+    NRX_LAUNCH_CHECK("nrx_route_feat");
+    return NRX_OK;
+}
+
+extern "C" int nrx_inbox_transpose(const int32_t* inbox_a, int32_t* out_a, const int32_t* inbox_b, int32_t* out_b, int32_t world, int32_t n_feats,
+                                   int64_t capf, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(inbox_a != nullptr && out_a != nullptr && (inbox_b == nullptr) == (out_b == nullptr), "nrx_inbox_transpose: null buffer");
+    NRX_REQUIRE(world >= 1 && n_feats >= 1 && capf >= 4 && (capf & 3) == 0, "nrx_inbox_transpose: capf must be a positive multiple of 4");
+    NRX_REQUIRE(nrx_aligned16(inbox_a) && nrx_aligned16(out_a) && nrx_aligned16(inbox_b) && nrx_aligned16(out_b), "nrx_inbox_transpose: 16-byte aligned buffers");
+    const int64_t total = (int64_t)world * n_feats * capf;
+    int64_t blocks = (total / 4 + NRX_BLOCK - 1) / NRX_BLOCK;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(inbox_transpose_kernel, dim3((unsigned)blocks), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), inbox_a, out_a, inbox_b,
+                       out_b, (int)world, (int)n_feats, capf);
+    NRX_LAUNCH_CHECK("nrx_inbox_transpose");
+    return NRX_OK;
+}

@@ -781,12 +781,13 @@ def _pinned_words(n: int):
     into whatever that block had become (a ColumnarLoader staging batch, a status word).  Slices of an arena that is never freed cannot be
     recycled; a policy costs 64 bytes of it."""
     global _PINNED_USED
-    n = (int(n) + 7) & ~7
-    if not _PINNED_CHUNKS or _PINNED_USED + n > _PINNED_CHUNKS[-1].numel():
-        _PINNED_CHUNKS.append(torch.zeros(max(4096, n), dtype=torch.int64).pin_memory())
+    n = int(n)
+    room = (n + 7) & ~7                       # 64-byte granules
+    if not _PINNED_CHUNKS or _PINNED_USED + room > _PINNED_CHUNKS[-1].numel():
+        _PINNED_CHUNKS.append(torch.zeros(max(4096, room), dtype=torch.int64).pin_memory())
         _PINNED_USED = 0
     t = _PINNED_CHUNKS[-1][_PINNED_USED:_PINNED_USED + n]
-    _PINNED_USED += n
+    _PINNED_USED += room
     return t, t.data_ptr(), t.numpy()
 
 

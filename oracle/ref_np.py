@@ -506,6 +506,46 @@ def route_ids(id_arrays, world: int, cap: int):
     return send, slot, counts2d, int(counts2d.sum(axis=1).max()) if world else 0
 
 
+def route_feat(id_arrays, world: int, capf: int):
+    """Per-feature fixed-capacity routing (definition of nrx_route_feat; new in this build -- the reference is single-device,
+    src/model/sort/deep/train.py:38-44).  id_arrays: n integer arrays of B ids each.  Every (owner o, feature f) pair owns capf slots:
+      send_ids [world, n, capf] int32   OWNER IDS in sample order: 0 = nothing (empty slot / the global padding id 0), v >= 1 = local row v - 1 of
+                                        o's shard (id // world + 1); ids < 0 / >= 2^31 - 1 go to rank 0 as -1 / INT32_MAX
+      send_pos [world, n, capf] int32   the sample of each sent id (0 in the tails)
+      slot     [n, B] int32             (o * capf + k) * n + f, or -1 where k >= capf
+      counts   [world, n] int64         ids of f owned by o
+    Returns (send_ids, send_pos, slot, counts, counts.max())."""
+    n = len(id_arrays)
+    B = int(np.asarray(id_arrays[0]).size) if n else 0
+    I32MAX = (1 << 31) - 1
+    send_ids = np.zeros((world, n, capf), np.int32)
+    send_pos = np.zeros((world, n, capf), np.int32)
+    slot = np.full((n, B), -1, np.int32)
+    counts = np.zeros((world, n), np.int64)
+    for f, a in enumerate(id_arrays):
+        ids = np.asarray(a, np.int64).reshape(-1)
+        assert ids.size == B
+        bad_lo, bad_hi = ids < 0, ids >= I32MAX
+        owner = np.where(bad_lo | bad_hi, 0, ids % world)
+        val = np.where(bad_lo, -1, np.where(bad_hi, I32MAX, np.where(ids == 0, 0, ids // world + 1)))
+        for o in range(world):
+            pos = np.flatnonzero(owner == o)                 # ascending sample order = stable
+            counts[o, f] = pos.size
+            k = np.arange(pos.size)
+            ok = k < capf
+            send_ids[o, f, k[ok]] = val[pos[ok]]
+            send_pos[o, f, k[ok]] = pos[ok]
+            slot[f, pos[ok]] = (o * capf + k[ok]) * n + f
+    return send_ids, send_pos, slot, counts, int(counts.max()) if counts.size else 0
+
+
+def owner_ids_from_inbox(inbox: np.ndarray) -> np.ndarray:
+    """[world, n, capf] (what the equal-split all-to-all of route_feat's send_ids leaves on an owner: block s came from rank s) ->
+    [n, world * capf]: per feature ONE array of owner ids over world * capf pseudo-samples b' = s * capf + k (definition of nrx_inbox_transpose)."""
+    w, n, capf = inbox.shape
+    return np.ascontiguousarray(inbox.transpose(1, 0, 2)).reshape(n, w * capf)
+
+
 def gather_inbox(tables, feat_table, world: int, cap: int, recv2d, inbox_rows, dim: int):
     """Owner side (definition of nrx_gather_inbox): block s of the inbox holds sum_f recv2d[s, f] valid
     local rows, feature-major; slot p reads tables[feat_table[f]][inbox_rows[p]].  Unwritten slots = 0."""

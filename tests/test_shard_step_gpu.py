@@ -1,0 +1,245 @@
+"""The bound sharded training step (news_recsys_amd/shard_step.py) and its new kernels on one GPU.
+
+  * nrx_route_feat / nrx_inbox_transpose against their definitions (oracle/ref_np.py route_feat, owner_ids_from_inbox): integer work, bit-exact --
+    worlds 1 .. 8 and 64, int32 / int64 ids, ids that cannot be rows, the padding id, blocks that overflow their capacity, repeated launches on
+    one state block (the chain re-arms itself);
+  * nrx_embed_bwd_scatter against "values[dest[p]] = upstream row of lookup p" with and without the FM term (fp32, value-exact: copies and one
+    fused multiply-add chain restated in numpy), dest < 0 skipped;
+  * PreparedShardedStep at world 1 against the DIRECT path on the same tables: forward concat and FM logit bit for bit; the row-sparse gradient
+    (keys, values, counts) bit for bit with keys shifted by the arena's dummy row; one FusedSparseAdam step leaves the same weights.
+    (world 2 / 3 with rank processes sharing the GPU: tests/test_shard_step_multirank_one_gpu.py.)
+No reference counterpart: the reference is single-device (src/model/sort/deep/train.py:38-44); the arithmetic checked is that of
+src/model/BaseModel/base_model.py:262-308 and its autograd."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from news_recsys_amd import _lib, ops, shard_step
+from news_recsys_amd._lib import NRX_SPARSE, NrxFmGrad
+from news_recsys_amd.sharding import RowShardedEmbedding, ShardedFeature
+from oracle import ref_np
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _route(ids, world, capf, want_pos=True, state=None, overflow=None):
+    lib = _lib.load()
+    n, B = len(ids), ids[0].numel()
+    dev = ids[0].device
+    send = torch.full((world, n, capf), -7, dtype=torch.int32, device=dev)
+    pos = torch.full((world, n, capf), -7, dtype=torch.int32, device=dev) if want_pos else None
+    slot = torch.full((n, B), -9, dtype=torch.int32, device=dev)
+    counts = torch.full((world, n), -1, dtype=torch.int64, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int64, device=dev) if overflow is None else overflow
+    if state is None:
+        state = torch.zeros(lib.nrx_route_feat_state_bytes(n, B, world), dtype=torch.uint8, device=dev)
+    ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in ids])
+    ops.check(lib.nrx_route_feat(ptrs, n, B, ids[0].element_size() * 8, world, capf, send.data_ptr(), None if pos is None else pos.data_ptr(),
+                                 slot.data_ptr(), counts.data_ptr(), overflow.data_ptr(), state.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream), "nrx_route_feat")
+    torch.cuda.synchronize()
+    return send, pos, slot, counts, overflow, state
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5, 8, 64])
+@pytest.mark.parametrize("dt", [torch.int64, torch.int32])
+def test_route_feat_equals_its_definition(world, dt):
+    rng = np.random.default_rng(100 + world)
+    for n, B, rows in ((1, 1, 50), (3, 777, 90), (5, 4096, 100_000), (4, 9001, 1 << 20), (26, 12_345, 1_000_000)):
+        ids_np = [rng.integers(0, rows, B) for _ in range(n)]
+        ids_np[0][: min(B, 3)] = 0                                     # the padding id
+        if dt is torch.int64 and B > 10:
+            ids_np[-1][5] = -4                                         # cannot be rows: rank 0, reported there
+            ids_np[-1][6] = (1 << 31) + 5
+            ids_np[-1][7] = (1 << 31) - 1
+        if dt is torch.int32 and B > 10:
+            ids_np[-1][5] = -4
+        capf = B if world == 1 else int(B / world * 1.3) + 64
+        ids = [torch.from_numpy(x).to(DEV).to(dt) for x in ids_np]
+        send, pos, slot, counts, overflow, _ = _route(ids, world, capf)
+        w_send, w_pos, w_slot, w_counts, w_max = ref_np.route_feat(ids_np, world, capf)
+        assert np.array_equal(counts.cpu().numpy(), w_counts)
+        assert int(overflow.item()) == w_max
+        assert np.array_equal(send.cpu().numpy(), w_send)
+        assert np.array_equal(pos.cpu().numpy(), w_pos)
+        assert np.array_equal(slot.cpu().numpy(), w_slot)
+
+
+def test_route_feat_overflow_repeated_launches_and_skew():
+    """Blocks that exceed capf drop their surplus (slot = -1) and raise the running maximum; the same state block serves launch after launch."""
+    rng = np.random.default_rng(5)
+    world, n, B, capf = 4, 6, 20_000, 5_200
+    state = None
+    overflow = torch.zeros(1, dtype=torch.int64, device=DEV)
+    worst = 0
+    for it in range(6):
+        ids_np = [rng.integers(1, 50_000, B) for _ in range(n)]
+        if it % 2:
+            ids_np[2][rng.random(B) < 0.4] = 8                         # a hot id: its owner's block of feature 2 overflows
+        ids = [torch.from_numpy(x).to(DEV) for x in ids_np]
+        send, pos, slot, counts, overflow, state = _route(ids, world, capf, state=state, overflow=overflow)
+        w_send, w_pos, w_slot, w_counts, w_max = ref_np.route_feat(ids_np, world, capf)
+        worst = max(worst, w_max)
+        assert np.array_equal(send.cpu().numpy(), w_send) and np.array_equal(slot.cpu().numpy(), w_slot)
+        assert np.array_equal(pos.cpu().numpy(), w_pos) and np.array_equal(counts.cpu().numpy(), w_counts)
+        assert int(overflow.item()) == worst                           # a running maximum since the caller zeroed it
+        assert ((w_slot == -1).sum() > 0) == bool(it % 2)               # the hot id's block drops its surplus, the uniform launches drop nothing
+    assert worst > capf
+
+
+def test_inbox_transpose_equals_its_definition():
+    lib = _lib.load()
+    rng = np.random.default_rng(9)
+    for world, n, capf in ((2, 3, 64), (3, 26, 2048), (8, 5, 8256)):
+        a = rng.integers(-5, 1 << 30, (world, n, capf)).astype(np.int32)
+        b = rng.integers(0, 1 << 20, (world, n, capf)).astype(np.int32)
+        ta, tb = torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)
+        oa, ob = torch.empty((n, world * capf), dtype=torch.int32, device=DEV), torch.empty((n, world * capf), dtype=torch.int32, device=DEV)
+        st = torch.cuda.current_stream().cuda_stream
+        ops.check(lib.nrx_inbox_transpose(ta.data_ptr(), oa.data_ptr(), tb.data_ptr(), ob.data_ptr(), world, n, capf, st), "t")
+        assert np.array_equal(oa.cpu().numpy(), ref_np.owner_ids_from_inbox(a)) and np.array_equal(ob.cpu().numpy(), ref_np.owner_ids_from_inbox(b))
+        oa.zero_()
+        ops.check(lib.nrx_inbox_transpose(ta.data_ptr(), oa.data_ptr(), None, None, world, n, capf, st), "t")
+        assert np.array_equal(oa.cpu().numpy(), ref_np.owner_ids_from_inbox(a))
+
+
+@pytest.mark.parametrize("D,n,fm", [(16, 26, True), (16, 5, False), (32, 40, False), (64, 3, False), (16, 7, True)])
+def test_embed_bwd_scatter_places_every_upstream_row(D, n, fm):
+    lib = _lib.load()
+    rng = np.random.default_rng(D + n)
+    B = 3001
+    ld = n * D
+    g_out = torch.from_numpy(rng.standard_normal((B, ld)).astype(np.float32)).to(DEV)
+    perm = rng.permutation(n * B + 100)[: n * B].astype(np.int32)
+    perm[rng.random(n * B) < 0.01] = -1                                # skipped lookups (an overflowed block)
+    dest = torch.from_numpy(perm).to(DEV)
+    values = torch.full((n * B + 100, D), 7.0, dtype=torch.float32, device=DEV)
+    slots = [ops.Slot(f"f{i}", NRX_SPARSE, 0, D, 0, i * D, fm_field=int(fm)) for i in range(n)]
+    plan = ops.EmbedPlan(slots, out_width=ld, use_fm=fm)
+    ins = [dest[i * B:(i + 1) * B] for i in range(n)]
+    arr = ops._fill_features(plan, 0, n, [None], ins, [None] * n, table_ptrs=[values.data_ptr()], fm=fm)
+    fmg = None
+    if fm:
+        feat = torch.from_numpy(rng.standard_normal((B, ld)).astype(np.float32)).to(DEV)
+        sums = torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32)).to(DEV)
+        g_fm = torch.from_numpy(rng.standard_normal((B,)).astype(np.float32)).to(DEV)
+        fmg = NrxFmGrad(g_fm.data_ptr(), sums.data_ptr(), D, feat.data_ptr(), ld)
+    ops.check(lib.nrx_embed_bwd_scatter(arr, n, B, D, g_out.data_ptr(), ld, None, 0, fmg, dest.data_ptr(), values.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), "nrx_embed_bwd_scatter")
+    torch.cuda.synchronize()
+    want = np.full((n * B + 100, D), 7.0, np.float32)
+    g = g_out.cpu().numpy()
+    for i in range(n):
+        rows = g[:, i * D:(i + 1) * D].copy()
+        if fm:      # nrx_fm_grad_t: g + g_fm * (k == 0 ? 1 : sums[b, k] - feat[b, col + k]), one fma as the kernels form it
+            f_ = feat.cpu().numpy()[:, i * D:(i + 1) * D]
+            s_ = sums.cpu().numpy()
+            d_ = np.concatenate([np.ones((B, 1), np.float32), (s_[:, 1:] - f_[:, 1:]).astype(np.float32)], axis=1)
+            rows = (rows.astype(np.float64) + g_fm.cpu().numpy()[:, None].astype(np.float64) * d_.astype(np.float64)).astype(np.float32)
+        d = perm[i * B:(i + 1) * B]
+        want[d[d >= 0]] = rows[d >= 0]
+    got = values.cpu().numpy()
+    if fm:
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6)   # (fma vs the float64 restatement: last-place differences)
+    else:
+        assert np.array_equal(got, want)                              # pure copies
+
+
+def _direct(feats, tabs_full, inputs, fm, g_out, g_fm):
+    """The direct (unsharded) bound path on full tables: forward + row-sparse backward."""
+    names = sorted({f.table for f in feats})
+    slots, col = [], 0
+    for f in feats:
+        slots.append(ops.Slot(f.name, NRX_SPARSE, names.index(f.table), f.dim, 0, col, fm_field=int(fm)))
+        col += f.dim
+    plan = ops.EmbedPlan(slots, out_width=col, use_fm=fm)
+    sums = torch.empty((inputs[0].numel(), feats[0].dim), dtype=torch.float32, device=DEV) if fm else None
+    fwd = ops.PreparedEmbed(plan, [tabs_full[t] for t in names], inputs, [None] * len(feats), fm_sums=sums)
+    out, _, fmv = fwd.run()
+    bwd = ops.PreparedSparseBackward(fwd, g_out, g_fm)
+    groups = bwd.run()
+    torch.cuda.synchronize()
+    return out, fmv, groups, names
+
+
+@pytest.mark.parametrize("case", ["c2_like_fm", "two_dims", "shared_table", "tiny_tables"])
+def test_world_1_step_equals_the_direct_path_bit_for_bit(case):
+    rng = np.random.default_rng(sum(map(ord, case)))
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    fm = case == "c2_like_fm"
+    if case == "c2_like_fm":
+        B, spec = 8192, [(f"C{i:02d}", f"C{i:02d}", 16, 300_000) for i in range(26)]
+    elif case == "two_dims":
+        B, spec = 5000, [("a", "a", 16, 7000), ("b", "b", 32, 90_000), ("c", "c", 16, 50), ("d", "d", 32, 1200), ("e", "e", 64, 40_000)]
+    elif case == "shared_table":
+        B, spec = 3000, [("item_id", "item_id", 16, 20_000), ("last_click", "item_id", 16, 20_000), ("user_id", "user_id", 16, 70_000)]
+    else:
+        B, spec = 2500, [("x", "x", 16, 3), ("y", "y", 16, 18), ("z", "z", 16, 270)]
+    feats = [ShardedFeature(nm, NRX_SPARSE, tb, d, 0, False, fm) for nm, tb, d, _ in sorted(spec)]
+    rows = {tb: r for _, tb, _, r in spec}
+    dims = {tb: d for _, tb, d, _ in spec}
+    arenas = {t: shard_step.make_arena(rows[t], dims[t], 0, 1, DEV, generator=gen) for t in rows}
+    full = {t: shard_step.arena_shard(a).clone() for t, a in arenas.items()}      # world 1: the shard IS the table
+    inputs = [torch.from_numpy(rng.integers(0, rows[f.table], B)).to(DEV) for f in feats]
+    inputs[0][:5] = 0
+    width = sum(f.dim for f in feats)
+    g_out = torch.randn((B, width), device=DEV, generator=gen)
+    g_fm = torch.randn((B,), device=DEV, generator=gen) if fm else None
+    eng = RowShardedEmbedding(0, 1, overflow_policy="defer")
+    step = shard_step.PreparedShardedStep(eng, feats, inputs, [None] * len(feats), arenas).bind_backward(g_out, g_fm)
+    for _ in range(2):                                                # re-launchable: same buffers, same result
+        out, _, fmv = step.run()
+        entries = step.backward()
+    torch.cuda.synchronize()
+    assert not step.overflowed()
+    d_out, d_fm, d_groups, names = _direct(feats, full, inputs, fm, g_out, g_fm)
+    assert torch.equal(out, d_out)
+    if fm:
+        assert torch.equal(fmv, d_fm)
+    assert len(entries) == len(d_groups)
+    for e, d in zip(sorted(entries, key=lambda e: e["dim"]), sorted(d_groups, key=lambda g: g["dim"])):
+        nu = int(d["counts"][0])
+        assert int(e["counts"][0]) == nu
+        # the direct path numbers its tables over ALL table names; the entry over the group's own table list: compare by name
+        ek, dk = e["uniq"][:nu].cpu().numpy(), d["uniq"][:nu].cpu().numpy()
+        e_names = [next(n for n, a in arenas.items() if a is t) for t in e["tables"]]
+        e_tab = np.array([names.index(e_names[t]) for t in (ek >> 40)])
+        pad = (dk & ((1 << 40) - 1)) == 0                              # the padding row: owner id 0 = the arena's dummy row
+        assert np.array_equal(e_tab, dk >> 40)
+        assert np.array_equal(np.where(pad, 0, (ek & ((1 << 40) - 1)) - 1), dk & ((1 << 40) - 1))
+        ev, dv = e["values"][:nu], d["values"][:nu]
+        assert torch.equal(ev.view(torch.int32), dv.view(torch.int32))
+
+
+def test_world_1_fused_sparse_adam_step_moves_the_same_rows():
+    """forward + backward + FusedSparseAdam on the arenas == the same on the full tables (the direct path): same weights afterwards."""
+    from news_recsys_amd.model.model_utils.optim import FusedSparseAdam
+    rng = np.random.default_rng(2)
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    B = 4096
+    spec = [(f"f{i}", 16, 50_000 + 1000 * i) for i in range(6)]
+    feats = [ShardedFeature(nm, NRX_SPARSE, nm, d, 0, False, False) for nm, d, _ in spec]
+    arenas = {nm: shard_step.make_arena(r, d, 0, 1, DEV, generator=gen) for nm, d, r in spec}
+    full = {nm: shard_step.arena_shard(a).clone() for nm, a in arenas.items()}
+    inputs = [torch.from_numpy(rng.integers(0, r, B)).to(DEV) for _, _, r in spec]
+    g_out = torch.randn((B, 96), device=DEV, generator=gen)
+    eng = RowShardedEmbedding(0, 1, overflow_policy="defer")
+    step = shard_step.PreparedShardedStep(eng, feats, inputs, [None] * 6, arenas).bind_backward(g_out)
+    sink_a, sink_b = ops.SparseGradSink(), ops.SparseGradSink()
+    opt_a = FusedSparseAdam(sink_a, lr=0.05)
+    opt_b = FusedSparseAdam(sink_b, lr=0.05)
+    for _ in range(3):
+        step.run()
+        step.sink_entries(sink_a)
+        opt_a.step()
+        _, _, groups, names = _direct(feats, full, inputs, False, g_out, None)
+        for g in groups:
+            sink_b.pending.append(dict(tables=[full[n] for n in names], dim=g["dim"], uniq=g["uniq"], values=g["values"], counts=g["counts"], cap=g["cap"]))
+        opt_b.step()
+    torch.cuda.synchronize()
+    for nm in arenas:
+        assert torch.equal(arenas[nm][1:], full[nm]), nm
+        assert float(arenas[nm][0].abs().max()) == 0.0 and float(arenas[nm][1].abs().max()) == 0.0      # dummy row, global padding row

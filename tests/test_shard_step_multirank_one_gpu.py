@@ -1,0 +1,153 @@
+"""PreparedShardedStep (news_recsys_amd/shard_step.py) at world 2 and 3 with the PRODUCT kernels: the rank processes share cuda:0 and exchange
+through gloo with host-staged buffers (RowShardedEmbedding(host_staged=True) -- a test transport: RCCL refuses two ranks on one device).
+Everything else is what an 8-GPU node runs: nrx_route_feat for W > 1 owners, the equal-split exchanges, nrx_inbox_transpose, the owner's fused
+forward over its pseudo-batch, the slot-addressed final launch, nrx_embed_bwd_scatter, the owner-side planned reduction.
+
+Truth = the DIRECT (unsharded) bound path over the rank-major concatenation of the ranks' batches, on full tables, in the parent process:
+  * every rank's forward concat (and FM logit) equals its rows of the direct result bit for bit (row copies; the FM epilogue sums a sample's
+    fields in the same order);
+  * the UNION of the ranks' (key, value) sets equals the direct row-sparse gradient: same set of (table, global row) keys, every value bit for
+    bit -- an owner adds a row's lookups in (feature, source rank, sample) order, which is the direct reduction's order on the concatenation;
+  * two runs of the sharded step give the same bits (no atomics anywhere on the path).
+No reference counterpart (single-device reference: src/model/sort/deep/train.py:38-44); the arithmetic is autograd of
+src/model/BaseModel/base_model.py:262-308."""
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from news_recsys_amd import ops, shard_step
+from news_recsys_amd._lib import NRX_SPARSE
+from news_recsys_amd.sharding import RowShardedEmbedding, ShardedFeature
+from tests.test_sharding_gloo import _free_port
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+SPECS = {
+    # name -> (features: (name, table, dim, rows), per-rank batch, FM epilogue)
+    "fm16": ([(f"C{i:02d}", f"C{i:02d}", 16, 40_000 + 997 * i) for i in range(7)], 3000, True),
+    "mixed": ([("a", "a", 16, 5000), ("b", "b", 32, 70_000), ("item_id", "item_id", 16, 9000), ("last_click", "item_id", 16, 9000),
+               ("tiny", "tiny", 32, 5)], 2100, False),
+}
+
+
+def _full_tables(spec):
+    rng = np.random.default_rng(11)
+    tabs = {}
+    for _, t, d, r in spec:
+        if t not in tabs:
+            x = rng.standard_normal((r, d)).astype(np.float32)
+            x[0] = 0
+            tabs[t] = x
+    return tabs
+
+
+def _batch(spec, B, rank):
+    rng = np.random.default_rng(500 + rank)
+    ids = []
+    for _, t, d, r in sorted(spec):
+        x = rng.integers(0, r, B)
+        x[: 4] = 0                                        # padding ids on every rank
+        if r > 1000:
+            x[rng.random(B) < 0.05] = 17                  # a hot row: looked up by every rank (cross-source summation order matters)
+        ids.append(x)
+    width = sum(d for _, _, d, _ in spec)
+    return ids, rng.standard_normal((B, width)).astype(np.float32), rng.standard_normal((B,)).astype(np.float32)
+
+
+def _worker(rank, world, port, q, case):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        spec, B, fm = SPECS[case]
+        tabs = _full_tables(spec)
+        arenas = {t: shard_step.make_arena(x.shape[0], x.shape[1], rank, world, DEV, full=torch.from_numpy(x).to(DEV)) for t, x in tabs.items()}
+        feats = [ShardedFeature(nm, NRX_SPARSE, t, d, 0, False, fm) for nm, t, d, _ in sorted(spec)]
+        ids, up, up_fm = _batch(spec, B, rank)
+        inputs = [torch.from_numpy(x).to(DEV) for x in ids]
+        g_out = torch.from_numpy(up).to(DEV)
+        g_fm = torch.from_numpy(up_fm).to(DEV) if fm else None
+        eng = RowShardedEmbedding(rank, world, slack=0.5, host_staged=True, overflow_policy="defer")
+        step = shard_step.PreparedShardedStep(eng, feats, inputs, [None] * len(feats), arenas).bind_backward(g_out, g_fm)
+        runs = []
+        for _ in range(2):
+            out, _, fmv = step.run()
+            entries = step.backward()
+            torch.cuda.synchronize()
+            got = []
+            for e in entries:
+                nu = int(e["counts"][0])
+                names = [next(n for n, a in arenas.items() if a is t) for t in e["tables"]]
+                got.append((names, e["dim"], e["uniq"][:nu].cpu().numpy(), e["values"][:nu].cpu().numpy()))
+            runs.append((out.cpu().numpy().copy(), None if fmv is None else fmv.cpu().numpy().copy(), got))
+        over = step.overflowed()
+        same = np.array_equal(runs[0][0], runs[1][0]) and all(
+            np.array_equal(a[2], b[2]) and np.array_equal(a[3].view(np.int32), b[3].view(np.int32)) for a, b in zip(runs[0][2], runs[1][2]))
+        q.put((rank, runs[1][0], runs[1][1], runs[1][2], bool(over), bool(same)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", ["fm16", "mixed"])
+def test_sharded_step_equals_the_direct_path_on_the_concatenated_batch(world, case):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, case)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        item = q.get(timeout=300)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    spec, B, fm = SPECS[case]
+    tabs = _full_tables(spec)
+    names = sorted(tabs)
+    # ---- the direct path on the rank-major concatenation
+    batches = [_batch(spec, B, r) for r in range(world)]
+    inputs = [torch.from_numpy(np.concatenate([b[0][k] for b in batches])).to(DEV) for k in range(len(spec))]
+    g_out = torch.from_numpy(np.concatenate([b[1] for b in batches])).to(DEV)
+    g_fm = torch.from_numpy(np.concatenate([b[2] for b in batches])).to(DEV) if fm else None
+    slots, col = [], 0
+    for nm, t, d, _ in sorted(spec):
+        slots.append(ops.Slot(nm, NRX_SPARSE, names.index(t), d, 0, col, fm_field=int(fm)))
+        col += d
+    plan = ops.EmbedPlan(slots, out_width=col, use_fm=fm)
+    sums = torch.empty((world * B, 16), dtype=torch.float32, device=DEV) if fm else None
+    fwd = ops.PreparedEmbed(plan, [torch.from_numpy(tabs[t]).to(DEV) for t in names], inputs, [None] * len(spec), fm_sums=sums)
+    d_out, _, d_fm = fwd.run()
+    d_groups = ops.PreparedSparseBackward(fwd, g_out, g_fm).run()
+    torch.cuda.synchronize()
+    want = {}
+    for g in d_groups:
+        nu = int(g["counts"][0])
+        for k, v in zip(g["uniq"][:nu].cpu().numpy(), g["values"][:nu].cpu().numpy()):
+            if k & ((1 << 40) - 1):                                  # (the padding row's zero entry has no counterpart: owner id 0 is never keyed per table)
+                want[(names[k >> 40], int(k & ((1 << 40) - 1)))] = v
+    got = {}
+    for r in range(world):
+        out, fmv, entries, over, same = res[r]
+        assert not over and same
+        assert np.array_equal(out, d_out[r * B:(r + 1) * B].cpu().numpy())
+        if fm:
+            assert np.array_equal(fmv, d_fm[r * B:(r + 1) * B].cpu().numpy())
+        for tnames, dim, keys, vals in entries:
+            for k, v in zip(keys, vals):
+                row = int(k & ((1 << 40) - 1))
+                if row == 0:                                         # the arena's dummy row (empty slots, padding ids): zeros, never trained
+                    assert not v.any()
+                    continue
+                key = (tnames[k >> 40], (row - 1) * world + r)
+                assert key not in got
+                got[key] = v
+    assert set(got) == set(want)
+    for key, v in want.items():
+        assert np.array_equal(got[key].view(np.int32), v.view(np.int32)), key
