@@ -15,13 +15,15 @@ Default workload = BASELINE.json configs[1] ("c2": DeepFM-shaped, 26 sparse x 1M
 uniform ids): gather -> [B,416] concat + fused FM logit.  A fresh id batch (from a pool of 8) is used
 every step so no step re-reads the previous step's rows from cache.
 
-N > 1: every rank owns B=65536 impressions (weak scaling; `value`).  Two table layouts, BOTH timed by default:
-"row" = every table row-sharded (row r on rank r % N) with RCCL all-to-all id routing + row return / owner-side
-pooling (news_recsys_amd/sharding.py) -- the headline for c4 / c5; "auto" = planner: tables of at most 256 MiB are
-replicated, larger ones row-sharded -- the headline for c2 / c3 (their tables are small or few).  The other layout
-goes under "other_layout"; "strong_scaling" re-times the headline layout with the global batch fixed at 65536; "a2a"
-times the row-return all-to-all alone (GB/s per rank and per xGMI link).  A watchdog prints the headline line if a
-secondary leg stalls.  Rank 0 prints ONE JSON line.
+N > 1: every rank owns B=65536 impressions (weak scaling; `value`).  The headline layout is "row" for EVERY workload: every
+table row-sharded (row r on rank r % N) with RCCL all-to-all id routing + row return / owner-side pooling
+(news_recsys_amd/sharding.py, shard_step.py) -- what north_star scales.  "auto" = planner (tables of at most 256 MiB replicated,
+larger ones row-sharded) goes under "other_layout" with the number of tables it replicated; "strong_scaling" re-times the
+headline layout with the global batch fixed at 65536; "a2a" times the row-return all-to-all alone (GB/s per rank and per xGMI
+link, next to the 7 x 153 GB/s of the links); "fwd_bwd" is the bound sharded training step (forward + gradient exchange +
+owner-side row-sparse reduction) with its own roofline.  The N > 1 line also carries `rccl_ranks` (the process group's own world
+size and backend) and `scaling_vs_1gpu` (value / N over the DIRECT single-GPU path's committed number of the same workload).
+A watchdog prints the headline line if a secondary leg stalls.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -177,8 +179,8 @@ def parse_args(argv=None):
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded engine even at N=1 (testing)")
     ap.add_argument("--shard-mode", default="default", choices=["default", "row", "auto"],
                     help="N>1 headline layout: 'row' = every table row-sharded; 'auto' = planner (tables <= 256 MiB replicated, "
-                         "larger ones row-sharded); 'default' = row for c4 / c5, auto for c2 / c3.  The other layout is timed "
-                         "too (field `other_layout`).")
+                         "larger ones row-sharded); 'default' = row for every workload.  The other layout is timed "
+                         "too (field `other_layout`, which says how many tables it replicated).")
     ap.add_argument("--secondary-timeout", type=float, default=240.0,
                     help="N>1: seconds the secondary legs (other layout, strong scaling, a2a probe) may take before the "
                          "headline line is printed without them")
@@ -840,10 +842,26 @@ def cpu_baseline_torch(path: SingleGpuPath, budget_s: float = 10.0):
 
 
 # ------------------------------------------------------------------------------------ main
+def _direct_1gpu_reference(workload: str):
+    """The direct single-GPU path's headline value of `workload` from the newest committed bench lines (profiles/rNN_bench_lines_c2_c3_c4_c5.jsonl)."""
+    import glob
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_lines_c2_c3_c4_c5.jsonl")), reverse=True):
+        try:
+            for ln in open(fn):
+                d = json.loads(ln)
+                if d.get("n_gpus") == 1 and str(d.get("config", {}).get("workload", "")).startswith(workload + ":"):
+                    return {"value": d["value"], "source": os.path.relpath(fn, ROOT)}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
 def main():
     args = parse_args()
     if args.shard_mode == "default":
-        args.shard_mode = "row" if args.workload in ("c4", "c5") else "auto"
+        # the N > 1 headline is the layout north_star scales: EVERY table row-sharded, ids and rows crossing the fabric (round 5 took the planner
+        # layout for c2 / c3, whose 64 MB tables it replicates -- zero all-to-all: a data-parallel copy would have "scaled" 8x)
+        args.shard_mode = "row"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -1003,12 +1021,27 @@ def main():
                     tt = torch.tensor([dts], dtype=torch.float64, device=device)
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                     dts = tt.item()
-                fwd_bwd = {"ms_per_step": dts * 1e3 / nst, "gpu_ms_per_step_rank0": ea.elapsed_time(eb) / nst, "value": BATCH * world * nst / dts,
-                           "unit": "impressions/s", "steps": nst,
-                           "mode": "sharded engine, autograd form (RowShardedEmbedding.forward + backward): id routing + all-to-alls + owner gather / "
-                                   "owner-side pooling + fused final launch; backward: slot scatter of the upstream rows, gradient all-to-all to the owners, "
-                                   "owner-side scatter-add into the shards' DENSE gradients (zero-filled every step); eager launches from Python "
-                                   "(host time included: wall clock, max over ranks)"}
+                gpu_ms = ea.elapsed_time(eb) / nst
+                fb_bytes = (path.bytes_per_impr + (4 * path.feats[0].dim if path.fm else 0) + path.bwd_bytes_per_impr) * BATCH      # per rank
+                fb_ach = fb_bytes / (dts / nst) / 1e9
+                bound = getattr(path, "engine", "legacy") == "feat"
+                fwd_bwd = {"ms_per_step": dts * 1e3 / nst, "gpu_ms_per_step_rank0": gpu_ms, "value": BATCH * world * nst / dts,
+                           "unit": "impressions/s", "steps": nst, "engine": getattr(path, "engine", "legacy"),
+                           "host_bound": bool(dts * 1e3 / nst > 1.15 * gpu_ms),
+                           "roofline": {"bound": "hbm", "achieved": fb_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": fb_ach / HBM_PEAK_GBPS,
+                                        "algorithmic_bytes_per_step_per_rank": fb_bytes,
+                                        "note": "the DIRECT path's algorithmic bytes of one rank's batch (forward in training form + row-sparse backward, "
+                                                "bench.backward_bytes_per_impression) / wall time per step, max over ranks: the exchange's own traffic (ids, "
+                                                "rows and gradient rows through the send / receive buffers) is overhead of the method, not counted"},
+                           "mode": ("shard_step.PreparedShardedStep, bound: nrx_route_feat (one launch) + all-to-all of owner ids + the owner's fused forward over "
+                                    "its pseudo-batch + all-to-all of the rows + the slot-addressed final launch; backward: nrx_embed_bwd_scatter (every lookup's "
+                                    "upstream row to its slot, FM term folded in) + gradient all-to-all + the owner-side planned reduction (the single-GPU "
+                                    "planners, placement pass and sorted walk) into ROW-SPARSE (keys, values): deterministic, no dense shard gradient, no "
+                                    "float atomic, nothing read back; at world 1 the all-to-alls vanish (receive buffers = send buffers)") if bound else
+                                   ("sharded engine, autograd form (RowShardedEmbedding.forward + backward): id routing + all-to-alls + owner gather / "
+                                    "owner-side pooling + fused final launch; backward: slot scatter of the upstream rows, gradient all-to-all to the owners, "
+                                    "owner-side scatter-add into the shards' DENSE gradients (zero-filled every step); eager launches from Python "
+                                    "(host time included: wall clock, max over ranks)")}
             else:
                 fwd_bwd = {"skipped": "the shards' dense gradients (one zero-filled [local rows, dim] tensor per table and step) do not fit next to the tables"}
         except Exception as e:          # noqa: BLE001 -- a secondary leg must not cost the headline
@@ -1109,10 +1142,11 @@ def main():
                                     "traffic": _traffic(args.workload + "_fwd_bwd") if args.ids == "uniform" else None, "traffic_unit": "bytes/step",
                                     "note": "achieved = algorithmic bytes per step / mean step time (HIP events over the timed steps: forward + planning + "
                                             "reduction, ~10 launches); traffic = fabric bytes per step summed over those launches from the committed PMC passes"},
-                       "mode": "forward (training form: + FM field sums) + deterministic row-sparse backward: nrx_sparse_plan "
-                               "(table-segmented stable radix sort of the row bits, unique rows, segments; inline here -- in a training step it is "
-                               "enqueued on a side stream at forward time and hidden behind the dense model) + nrx_embed_bwd_sorted with the FM gradient folded in; "
-                               "upstream gradients g_out [B, width]" + (" and g_fm [B]" if path.fm else "") + " given; result = unique "
+                       "mode": "forward (training form: + FM field sums) + deterministic row-sparse backward: the planner named in `planner` ("
+                               + ("nrx_sparse_plan_lds: one kernel, row bitmaps in LDS, pair records for the rows looked up twice" if "one-kernel (LDS bitmaps)" in planners
+                                  else "nrx_sparse_plan_place / _ex: table-segmented stable radix sort of the row bits, unique rows, segments, placement")
+                               + "; inline here, chosen per batch from the previous batch's duplicate statistics) + the placement pass + the sorted walk with the FM "
+                               "gradient folded in; upstream gradients g_out [B, width]" + (" and g_fm [B]" if path.fm else "") + " given; result = unique "
                                "(table,row) keys + summed row gradients on the device (what optim.FusedSparseAdam consumes)"}
             del fwd, bwd
         if args.workload == "c3":
@@ -1227,6 +1261,24 @@ def main():
                                        "hbm_gib": round(info["global_mem_bytes"] / 2 ** 30, 1)}
         except Exception:
             pass
+        if hasattr(path, "n_sharded"):
+            out["config"]["layout"] = {"mode": args.shard_mode, "tables_row_sharded": path.n_sharded, "tables_replicated": path.n_replicated,
+                                       "engine": getattr(path, "engine", "legacy"),
+                                       "levers": "SURVEY 7 hard-part 1: (a) replication of small tables -- OFF in the row headline (that is `other_layout`), "
+                                                 "(b) per-destination dedup -- off (uniform ids have nothing to dedup; RowShardedEmbedding(dedup=True) exists), "
+                                                 "(c) owner-side pooling of bag features -- on (c4), (d) int32 owner ids on the wire, fixed-capacity "
+                                                 "equal-split all-to-alls, no host read inside a step -- on"}
+        if world > 1:
+            # what the process group itself reports (not the launcher's environment): the N > 1 line must be able to show that N ranks exchanged
+            out["rccl_ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                 "transport": "host-staged gloo (NRX_BENCH_HOST_STAGED test transport: NOT a measurement)" if staged else "RCCL over xGMI"}
+            ref = _direct_1gpu_reference(args.workload)
+            if ref is not None:
+                out["scaling_vs_1gpu"] = {"direct_1gpu_value": ref["value"], "direct_1gpu_source": ref["source"],
+                                          "ratio": out["value"] / ref["value"], "per_gpu_efficiency": out["value"] / world / ref["value"],
+                                          "note": "this line's whole-job value over the DIRECT single-GPU path's committed number of the same workload (no "
+                                                  "exchange at all): the price of the row-sharded exchange is inside the ratio.  The driver computes scaling "
+                                                  "efficiency itself from the per-N lines; this is the self-description"}
         return out
     base_line = _build_line() if rank == 0 else None      # everything of the headline, before any secondary leg runs
 
@@ -1280,8 +1332,10 @@ def main():
                 remote = probe["bytes"] * (world - 1) / world
                 a2a = {"bytes_per_rank_per_step": probe["bytes"], "ms": ms, "GBps_per_rank": remote / (ms * 1e-3) / 1e9,
                        "GBps_per_link": remote / (world - 1) / (ms * 1e-3) / 1e9,
+                       "xgmi_link_peak_GBps": 153.0, "xgmi_links_per_gpu": 7,
+                       "frac_of_link_peak": remote / (world - 1) / (ms * 1e-3) / 1e9 / 153.0,
                        "note": "the return all-to-all(s) of the row-sharded exchange alone (equal splits, max over ranks); "
-                               "per link = remote bytes / (N-1) point-to-point xGMI links"}
+                               "per link = remote bytes / (N-1) point-to-point xGMI links (7 x ~153 GB/s per GPU)"}
             if hasattr(path, "train_setup"):
                 sharded_fb = sharded_train_leg(path)
             del path
@@ -1300,7 +1354,8 @@ def main():
             dt2, _ = timed(p2.step)
             if not p2.overflowed():
                 planner = {"layout_mode": other, "value": BATCH * world * args.steps / dt2, "unit": "impressions/s",
-                           "ms_per_step": dt2 * 1e3 / args.steps, "layout": p2.desc,
+                           "ms_per_step": dt2 * 1e3 / args.steps, "layout": p2.desc, "tables_replicated": p2.n_replicated,
+                           "tables_row_sharded": p2.n_sharded,
                            "note": "the other table layout, same workload and steps; xGMI is point-to-point (one ~153 GB/s link "
                                    "per GPU pair), so an all-row-sharded row return is per-link bound, worst at N=2"}
             del p2

@@ -605,7 +605,7 @@ NRX_API int nrx_gather_inbox_place(const float* const* tables, const int64_t* ta
  *                                           0 = nothing (an empty slot k >= count -- the call zero-fills the tails -- or the global padding id 0);
  *                                           v >= 1 = local row v - 1 of o's shard (id / world + 1).  Ids that cannot be rows (< 0, >= 2^31 - 1) go
  *                                           to rank 0 as -1 / INT32_MAX, where the owner's forward reports them out of range.
- *   send_pos (optional, same layout)        the sample b of that id (one-sided placement); 0 in the tails
+ *   send_pos (optional, same layout)        the sample b of that id (one-sided placement); -1 in the tails
  *   slot[f * batch + b]                     int32 (o * capf + k) * n_feats + f: the lookup's row in the returned [world * capf, n_feats, dim]
  *                                           buffer viewed as rows of `dim` floats -- and in the gradient send buffer; -1 when k >= capf
  *   counts[o * n_feats + f]                 int64 ids of feature f owned by o (may exceed capf)
@@ -624,6 +624,17 @@ NRX_API int nrx_route_feat(const void* const* ids, int32_t n_feats, int64_t batc
  * positions) in the same launch.  capf % 4 == 0, 16-byte aligned buffers. */
 NRX_API int nrx_inbox_transpose(const int32_t* inbox_a, int32_t* out_a, const int32_t* inbox_b, int32_t* out_b, int32_t world, int32_t n_feats,
                         int64_t capf, void* stream);
+/* One-sided placement in the per-feature layout (the counterpart of nrx_gather_inbox_place): for every feature f and pseudo-sample b' = s * capf + k
+ * with owner_pos[f][b'] >= 0, the row tables[f][owner_ids[f][b']] (tables[f] = the ARENA base: row 0 the dummy row; owner id 0 writes zeros -- a
+ * lookup of the padding id) goes to peer_out[s] + owner_pos[f][b'] * out_ld + feat_col[f]: its final place in the REQUESTER's [out_rows, out_ld]
+ * concat, mapped by this process (hipIpc / a peer mapping over xGMI; its own buffer at s == rank).  owner_ids / owner_pos: [n_feats][world * capf]
+ * (nrx_inbox_transpose's output; at world 1 nrx_route_feat's own send arrays).  Positions >= out_rows and ids outside [0, table_rows[f]) are
+ * dropped / read as zeros and reported through `status` (device int32[4] or NULL).  dim 16 .. 256 (a power of two), feat_col and out_ld
+ * multiples of 4 (else NRX_ERR_UNSUPPORTED).  The requester may read its buffer once every owner's launch has completed (a collective behind the
+ * launches orders that).  Removes the row all-to-all AND the final un-permuting launch of the buffer path. */
+NRX_API int nrx_gather_place_feat(const float* const* tables, const int64_t* table_rows, const int32_t* feat_col, int32_t n_feats, int32_t world,
+                          int64_t capf, const int32_t* owner_ids, const int32_t* owner_pos, int32_t dim, float* const* peer_out,
+                          int64_t out_ld, int64_t out_rows, int32_t* status, void* stream);
 /* The requester's half of the sharded backward (and any other permutation of upstream rows): values[dest[p], :dim] = the upstream row of lookup p
  * -- g_out[b, cols of feature f] with the FM term folded in as in nrx_embed_bwd (fm may be NULL) -- for the flat, feature-major lookups p = f *
  * batch + b of n_feats NRX_SPARSE features; dest[p] < 0: skipped.  Every written row is written once (dest is a partial permutation: the
@@ -668,6 +679,16 @@ NRX_API int nrx_pool_inbox_bwd(float* const* grad_tables, const int64_t* table_r
                        int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
                        const int32_t* inbox_rows, const int32_t* inbox_tag, const float* inbox_w, int32_t dim,
                        const float* g_partial, int32_t skip_row0, void* stream);
+/* The pooled channel's backward in the single-GPU engine's terms (round 6; the bags of ONE table): every inbox entry e = s * cap + j of
+ * nrx_route_bags becomes one pseudo-lookup -- owner_ids[e] (int32 [world * cap]): 0 = nothing (past the block's count, the global padding row
+ * when skip_row0, a row outside [0, table_rows)), else local row + 1 = the row of the shard's ARENA (leading dummy row); g_rows[e, :dim] =
+ * inbox_w[e] * g_partial[s][inbox_tag[e]] (written for the live entries only).  A single-valued feature of world * cap pseudo-samples over the
+ * arena, upstream rows g_rows: nrx_sparse_plan* + nrx_embed_bwd_placed reduce it to deterministic row-sparse (keys, values) -- what
+ * nrx_pool_inbox_bwd does with float atomics into a dense shard gradient.  Autograd of the owner-side partial pooling
+ * (array_feature_pooling, src/model/BaseModel/base_model.py:273-282, split over the owners). */
+NRX_API int nrx_pool_inbox_expand(int64_t table_rows, int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
+                          const int32_t* inbox_rows, const int32_t* inbox_tag, const float* inbox_w, int32_t dim,
+                          const float* g_partial, int32_t skip_row0, int32_t* owner_ids, float* g_rows, void* stream);
 /* Expands a CSR batch of an array feature (values[offsets[b] .. offsets[b+1]), offsets relative to the
  * batch, device int64[batch+1]) into the reference's padded form: ids [batch, bag_len] (0-padded,
  * same integer width as `values`) and mask float32 [batch, bag_len] (1 = real, 0 = padding) --

@@ -647,6 +647,44 @@ __global__ __launch_bounds__(NRX_BLOCK) void pool_inbox_bwd_kernel(const PoolArg
     for (int k = q; k < D; k += Q) unsafeAtomicAdd(dst + k, nrx_gconst<float>(g)[k] * w);
 }
 
+// The pooled channel's backward as the single-GPU engine wants it (round 6): every inbox entry e = s * cap + j becomes ONE pseudo-lookup of the
+// pooled table -- its OWNER ID (0 = nothing: past the block's count, the global padding row, a row that cannot be one; else local row + 1: the
+// arena row) and its upstream row G[e] = w[e] * g_partial[s][tag[e]] -- so that the planners and the sorted reduction take over: deterministic
+// row-sparse (keys, values) instead of pool_inbox_bwd_kernel's float atomics into a dense shard gradient.  `partial` = g_partial (read only).
+template <int QLOG2>
+__global__ __launch_bounds__(NRX_BLOCK) void pool_inbox_expand_kernel(const PoolArgs args_in_kernarg, int32_t* __restrict__ owner_ids,
+                                                                     float* __restrict__ g_rows) {
+    const NRX_CONST PoolArgs* a = nrx_kernarg<PoolArgs>();
+    constexpr int Q = 1 << QLOG2;
+    constexpr int TB = NRX_BLOCK / Q;
+    const int s = blockIdx.y;
+    const int64_t total = pool_block_total(a, s);
+    const int q = threadIdx.x & (Q - 1);
+    const int64_t j = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
+    if (j >= a->cap) return;
+    const int64_t e = (int64_t)s * a->cap + j;
+    if (j >= total) {
+        if (q == 0) owner_ids[e] = 0;
+        return;
+    }
+    const int32_t tag = nrx_gconst<int32_t>(a->inbox_tag)[e];
+    const int32_t row = nrx_gconst<int32_t>(a->inbox_rows)[e];
+    const float w = nrx_gconst<float>(a->inbox_w)[e];
+    const int D = a->dim;
+    const bool live = (uint32_t)row < (uint64_t)a->rows[0] && !(a->skip_row0 && row == 0) && (uint32_t)tag < (uint64_t)(a->n_feats * a->batch);
+    if (q == 0) owner_ids[e] = live ? row + 1 : 0;
+    if (!live) return;
+    const float* g = a->partial + ((int64_t)s * a->n_feats * a->batch + tag) * D;
+    float* dst = g_rows + e * D;
+    if (D == 4 * Q) {
+        float4 v = nrx_ldg4(g, q);
+        v.x *= w; v.y *= w; v.z *= w; v.w *= w;
+        nrx_stg4(dst, q, v);
+    } else {
+        for (int k = q; k < D; k += Q) dst[k] = nrx_gconst<float>(g)[k] * w;
+    }
+}
+
 // normalised bag weights: masked mean w/(sum w + 1e-8) (base_model.py:278-282), plain mean 1/L (:275-276), sum w | 1
 __global__ __launch_bounds__(NRX_BLOCK) void bag_norm_weights_kernel(const float* __restrict__ mask, int64_t batch, int L, int kind,
                                                                      float* __restrict__ out) {
@@ -1064,6 +1102,36 @@ extern "C" int nrx_pool_inbox_bwd(float* const* grad_tables, const int64_t* tabl
 #undef NRX_CASE
     }
     NRX_LAUNCH_CHECK("nrx_pool_inbox_bwd");
+    return NRX_OK;
+}
+
+extern "C" int nrx_pool_inbox_expand(int64_t table_rows, int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
+                                     const int32_t* inbox_rows, const int32_t* inbox_tag, const float* inbox_w, int32_t dim,
+                                     const float* g_partial, int32_t skip_row0, int32_t* owner_ids, float* g_rows, void* stream) {
+    NRX_TRACE();
+    PoolArgs a;
+    float* dummy_table = g_rows;                      // (fill_pool_args wants a table pointer: never dereferenced here)
+    int32_t ft[NRX_MAX_FEATURES];
+    for (int f = 0; f < NRX_MAX_FEATURES; ++f) ft[f] = 0;
+    NRX_REQUIRE(g_partial != nullptr && owner_ids != nullptr && g_rows != nullptr, "nrx_pool_inbox_expand: null buffer");
+    NRX_REQUIRE((dim & 3) != 0 || (nrx_aligned16(g_partial) && nrx_aligned16(g_rows)), "nrx_pool_inbox_expand: 16-byte aligned rows");
+    int rc = fill_pool_args(a, &dummy_table, &table_rows, 1, ft, n_feats, batch, world, cap, recv2d, inbox_rows, inbox_tag, inbox_w, dim,
+                            "nrx_pool_inbox_expand");
+    if (rc != NRX_OK) return rc;
+    a.partial = const_cast<float*>(g_partial);
+    a.status = nullptr;
+    a.skip_row0 = skip_row0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int ql = pool_ql(dim);
+    const int tb = NRX_BLOCK >> ql;
+    const dim3 grid((unsigned)((cap + tb - 1) / tb), (unsigned)world);
+    switch (ql) {
+#define NRX_CASE(QL_) case QL_: hipLaunchKernelGGL((pool_inbox_expand_kernel<QL_>), grid, dim3(NRX_BLOCK), 0, st, a, owner_ids, g_rows); break;
+        NRX_CASE(0) NRX_CASE(1) NRX_CASE(2) NRX_CASE(3) NRX_CASE(4) NRX_CASE(5)
+        default: hipLaunchKernelGGL((pool_inbox_expand_kernel<6>), grid, dim3(NRX_BLOCK), 0, st, a, owner_ids, g_rows); break;
+#undef NRX_CASE
+    }
+    NRX_LAUNCH_CHECK("nrx_pool_inbox_expand");
     return NRX_OK;
 }
 

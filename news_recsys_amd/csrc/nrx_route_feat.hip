@@ -161,7 +161,7 @@ __global__ __launch_bounds__(RF_THREADS) void route_feat_kernel(const RouteFeatA
             const int64_t base = ((int64_t)o * n + f) * capf;
             for (int64_t k = s_base[o] + tid; k < capf; k += RF_THREADS) {
                 send_ids[base + k] = 0;
-                if (send_pos != nullptr) send_pos[base + k] = 0;
+                if (send_pos != nullptr) send_pos[base + k] = -1;      // (an empty slot: owner id 0 with a position = a lookup of the padding id)
             }
         }
     }
@@ -193,7 +193,114 @@ __global__ __launch_bounds__(NRX_BLOCK) void inbox_transpose_kernel(const int32_
     }
 }
 
+// One-sided placement in the per-feature layout: the owner's gather writes every row straight into its place in the REQUESTER's concat buffer
+// (peer[s] + pos * ld + col[f]) instead of into a [world * capf, n * dim] row buffer that an all-to-all carries back and a final launch re-reads.
+// A lane group of Q lanes owns a pseudo-sample b' = s * capf + k and walks the features with GP_R row loads in flight; owner id 0 with a
+// position >= 0 is a lookup of the padding id: zeros are written (position < 0: an empty slot, skipped).
+constexpr int GP_R = 8;
+struct GatherPlaceArgs {
+    const float* table[NRX_MAX_FEATURES];      // arena base (row 0 = the dummy row)
+    int64_t rows[NRX_MAX_FEATURES];            // arena rows
+    int32_t col[NRX_MAX_FEATURES];
+    float* peer[RF_MAX_WORLD];
+    const int32_t* oid;                        // [n][bp]
+    const int32_t* opos;                       // [n][bp]
+    int64_t bp, capf, ld, out_rows;
+    int32_t n, world;
+    int32_t* status;
+};
+static_assert(sizeof(GatherPlaceArgs) <= 3584, "kernarg budget");
+
+template <int QLOG2>
+__global__ __launch_bounds__(NRX_BLOCK) void gather_place_feat_kernel(const GatherPlaceArgs args_in_kernarg) {
+    const NRX_CONST GatherPlaceArgs* a = nrx_kernarg<GatherPlaceArgs>();
+    constexpr int Q = 1 << QLOG2, TB = NRX_BLOCK / Q;
+    const int q = threadIdx.x & (Q - 1);
+    const int64_t bp = a->bp;
+    const int n = a->n;
+    for (int64_t b = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2); b < bp; b += (int64_t)gridDim.x * TB) {
+        const int s = (int)(b / a->capf);
+        float* __restrict__ out = a->peer[s];
+        for (int f0 = 0; f0 < n; f0 += GP_R) {
+            int32_t id[GP_R], pos[GP_R];
+#pragma unroll
+            for (int r = 0; r < GP_R; ++r) {
+                const int f = f0 + r < n ? f0 + r : n - 1;
+                id[r] = nrx_gconst<int32_t>(a->oid)[(int64_t)f * bp + b];
+                pos[r] = nrx_gconst<int32_t>(a->opos)[(int64_t)f * bp + b];
+            }
+            float4 v[GP_R];
+#pragma unroll
+            for (int r = 0; r < GP_R; ++r) {
+                const int f = f0 + r < n ? f0 + r : n - 1;
+                v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f0 + r >= n || pos[r] < 0) { pos[r] = -1; continue; }
+                if (id[r] < 0 || (int64_t)id[r] >= a->rows[f]) {          // cannot be a row of this shard: zeros, reported
+                    if (q == 0) nrx_report_oob(a->status, f, b, id[r]);
+                    continue;
+                }
+                if (id[r] != 0) v[r] = nrx_ldg4_nt(a->table[f], (int64_t)id[r] * Q + q);
+            }
+#pragma unroll
+            for (int r = 0; r < GP_R; ++r) {
+                if (pos[r] < 0) continue;
+                const int f = f0 + r;
+                if ((int64_t)pos[r] >= a->out_rows) {                    // a position outside the requester's batch (it came from a peer): dropped, reported
+                    if (q == 0) nrx_report_oob(a->status, f, b, pos[r]);
+                    continue;
+                }
+                nrx_stg4(out, ((int64_t)pos[r] * a->ld + a->col[f]) / 4 + q, v[r]);
+            }
+        }
+    }
+}
+
 }      // namespace
+
+extern "C" int nrx_gather_place_feat(const float* const* tables, const int64_t* table_rows, const int32_t* feat_col, int32_t n_feats, int32_t world,
+                                     int64_t capf, const int32_t* owner_ids, const int32_t* owner_pos, int32_t dim, float* const* peer_out,
+                                     int64_t out_ld, int64_t out_rows, int32_t* status, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(tables && table_rows && feat_col && owner_ids && owner_pos && peer_out, "nrx_gather_place_feat: null argument");
+    NRX_REQUIRE(n_feats >= 1 && n_feats <= NRX_MAX_FEATURES && world >= 1 && world <= RF_MAX_WORLD && capf >= 1, "nrx_gather_place_feat: bad sizes");
+    if (!(dim == 16 || dim == 32 || dim == 64 || dim == 128 || dim == 256) || (out_ld & 3) != 0) {
+        nrx_set_error("nrx_gather_place_feat: dim must be 16 / 32 / 64 / 128 / 256 and out_ld a multiple of 4");
+        return NRX_ERR_UNSUPPORTED;
+    }
+    GatherPlaceArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < n_feats; ++i) {
+        NRX_REQUIRE(tables[i] != nullptr && nrx_aligned16(tables[i]) && (feat_col[i] & 3) == 0, "nrx_gather_place_feat: feature %d: aligned table and column", i);
+        a.table[i] = tables[i];
+        a.rows[i] = table_rows[i];
+        a.col[i] = feat_col[i];
+    }
+    for (int s = 0; s < world; ++s) {
+        NRX_REQUIRE(peer_out[s] != nullptr && nrx_aligned16(peer_out[s]), "nrx_gather_place_feat: peer %d: null / unaligned buffer", s);
+        a.peer[s] = peer_out[s];
+    }
+    a.oid = owner_ids;
+    a.opos = owner_pos;
+    a.bp = (int64_t)world * capf;
+    a.capf = capf;
+    a.ld = out_ld;
+    a.out_rows = out_rows;
+    a.n = n_feats;
+    a.world = world;
+    a.status = status;
+    const int ql = dim == 16 ? 2 : dim == 32 ? 3 : dim == 64 ? 4 : dim == 128 ? 5 : 6;
+    const int64_t tb = NRX_BLOCK >> ql;
+    int64_t blocks = (a.bp + tb - 1) / tb;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (ql == 2) hipLaunchKernelGGL((gather_place_feat_kernel<2>), dim3((unsigned)blocks), dim3(NRX_BLOCK), 0, st, a);
+    else if (ql == 3) hipLaunchKernelGGL((gather_place_feat_kernel<3>), dim3((unsigned)blocks), dim3(NRX_BLOCK), 0, st, a);
+    else if (ql == 4) hipLaunchKernelGGL((gather_place_feat_kernel<4>), dim3((unsigned)blocks), dim3(NRX_BLOCK), 0, st, a);
+    else if (ql == 5) hipLaunchKernelGGL((gather_place_feat_kernel<5>), dim3((unsigned)blocks), dim3(NRX_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((gather_place_feat_kernel<6>), dim3((unsigned)blocks), dim3(NRX_BLOCK), 0, st, a);
+    NRX_LAUNCH_CHECK("nrx_gather_place_feat");
+    return NRX_OK;
+}
 
 extern "C" int64_t nrx_route_feat_state_bytes(int32_t n_feats, int64_t batch, int32_t world) {
     if (n_feats < 1 || n_feats > NRX_MAX_FEATURES || batch < 0 || world < 1 || world > RF_MAX_WORLD) return -1;

@@ -22,8 +22,11 @@ With world == 1 the all-to-alls vanish (the receive buffers ARE the send buffers
 values equal the unsharded row-sparse gradient bit for bit (keys shifted by the dummy row).  With world > 1 an owner reduces a row's lookups
 in (feature, source rank, sample) order -- the order of the unsharded reduction over the rank-major concatenation of the batches.
 
-Scope: exchange groups of single-valued features (the C2 / C3 / C5 shapes) and planner-replicated / dense features next to them; row-sharded
-bag features keep `sharding.RowShardedEmbedding`'s pooled channel."""
+Bag features (C4's history) keep sharding.py's pooled channel for the forward -- the owner pools the rows it holds, ONE partial row per (sample,
+owner) comes back -- and get a bound backward here: the requester sends every owner the samples' upstream rows, `nrx_pool_inbox_expand` turns the
+owner's inbox entries into pseudo-lookups (owner id, w * upstream row) of ONE single-valued feature over the arena, and the same planned
+reduction takes over (row-sparse, deterministic; nrx_pool_inbox_bwd's float atomics into a dense shard gradient are gone).  A table fed by a
+pooled group AND a single-valued group (DSSM's news table) leaves two (keys, values) lists, which FusedSparseAdam merges into one update per row."""
 from __future__ import annotations
 
 import ctypes as C
@@ -66,21 +69,66 @@ class PreparedShardedStep:
 
     def __init__(self, eng: RowShardedEmbedding, feats: Sequence[ShardedFeature], inputs, weights, arenas: Dict[str, torch.Tensor],
                  out_ld: Optional[int] = None, out: Optional[torch.Tensor] = None, fm: Optional[torch.Tensor] = None, train: bool = True,
-                 slack: Optional[float] = None):
+                 slack: Optional[float] = None, one_sided: Optional[bool] = None):
+        """one_sided (default: NRX_SHARD_ONE_SIDED = 1 | 0, else on for plans without an FM epilogue): ONE-SIDED PLACEMENT of the forward -- the
+        sample positions travel with the owner ids and the owner's gather (nrx_gather_place_feat) writes every row straight into its place in the
+        requester's concat, which every rank maps once (hipIpc through torch's CUDA-IPC sharing; over xGMI a peer mapping): no row buffer, no
+        row all-to-all, no final un-permuting launch for those features; a small collective behind the launches is the completion fence.
+        The backward is the same either way (its slot map comes from the same routing launch)."""
+        import os
         self.lib = _lib.load()
         self.eng = eng
         self.feats = list(feats)
         W = eng.world
         self.keep = [inputs, weights, arenas]
         groups, pooled = eng.plan_groups(feats)
-        if pooled or any(f.kind not in (NRX_SPARSE, NRX_DENSE) and not f.replicated for f in feats):
-            raise NotImplementedError("PreparedShardedStep: row-sharded bag features are not bound here (RowShardedEmbedding pools them at the owner)")
+        for gi, idxs in enumerate(groups):
+            if gi not in pooled and any(feats[i].kind != NRX_SPARSE for i in idxs):
+                raise NotImplementedError("PreparedShardedStep: row-sharded bag features travel through the pooled channel (pool_bags=True, no wide routing)")
         self.groups: List[dict] = []
         rets = []
         slot_of: Dict[int, torch.Tensor] = {}
+        final_weights = list(weights)
         slack = eng.slack if slack is None else slack
-        for idxs in groups:
+        plan = eng._final_plan(feats, groups, pooled)
+        B0 = inputs[0].shape[0]
+        dev0 = inputs[0].device
+        ld0 = int(out_ld) if out_ld else plan.out_width
+        if one_sided is None:
+            env = os.environ.get("NRX_SHARD_ONE_SIDED")
+            one_sided = (env == "1") if env in ("0", "1") else not plan.use_fm
+        placed_groups = set()
+        if one_sided and not plan.use_fm and (ld0 & 3) == 0 and plan.wide_width == 0:
+            for gi, idxs in enumerate(groups):
+                D = feats[idxs[0]].dim
+                if gi not in pooled and D in (16, 32, 64, 128, 256) and all(plan.slots[i].out_col % 4 == 0 for i in idxs):
+                    placed_groups.add(gi)
+        self.peers = None
+        if placed_groups:
+            if out is None:
+                out = torch.empty((B0, ld0), dtype=torch.float32, device=dev0)
+            from .sharding import PreparedShardedForward
+            self.peers = PreparedShardedForward._map_peer_buffers(eng, out)
+            self._peer_ptrs = (C.c_void_p * W)(*[t.data_ptr() for t in self.peers])
+            self._fence = (torch.zeros(W, dtype=torch.int32, device=dev0), torch.zeros(W, dtype=torch.int32, device=dev0))
+        for gi, idxs in enumerate(groups):
             dev = inputs[idxs[0]].device
+            if gi in pooled:
+                # bag features: the pooled channel of sharding.py for the forward (nrx_route_bags -> owner-side partial pooling -> one partial row per
+                # (sample, owner) comes back); its backward is bound below (bind_backward): expansion into pseudo-lookups + the planned reduction
+                from .sharding import PreparedShardedForward
+                legacy = {t: arena_shard(a) for t, a in arenas.items()}
+                g = PreparedShardedForward._bind_pooled(self, eng, feats, idxs, inputs, weights, legacy, C)
+                tnames = sorted({feats[i].table for i in idxs})
+                if len(tnames) != 1:
+                    raise NotImplementedError("PreparedShardedStep: the bag features of one pooled exchange group must share ONE table")
+                g.update(pooled=True, placed=False, idxs=list(idxs), tables=[arenas[tnames[0]]], table_names=tnames)
+                for k, i in enumerate(idxs):
+                    slot_of[i] = eng._pooled_ids(g["B"], g["n"], k, dev)
+                    final_weights[i] = None
+                rets.append(g["ret"].view(-1, g["D"]))
+                self.groups.append(g)
+                continue
             ids = [inputs[i] for i in idxs]
             dt = ids[0].dtype
             if dt not in (torch.int32, torch.int64) or any(x.dtype != dt or not x.is_contiguous() or x.dim() != 1 for x in ids):
@@ -98,39 +146,71 @@ class PreparedShardedStep:
             state_bytes = self.lib.nrx_route_feat_state_bytes(n, B, W)
             if state_bytes < 0:
                 raise ValueError("PreparedShardedStep: group outside nrx_route_feat's limits")
-            g = dict(n=n, B=B, D=D, capf=capf, Bp=Bp, dev=dev, idxs=list(idxs), ids=ids, bits=ids[0].element_size() * 8, tables=tabs,
+            g = dict(pooled=False, n=n, B=B, D=D, capf=capf, Bp=Bp, dev=dev, idxs=list(idxs), ids=ids, bits=ids[0].element_size() * 8, tables=tabs,
                      table_names=table_names, ptrs=(C.c_void_p * n)(*[x.data_ptr() for x in ids]),
                      send_ids=torch.zeros((W, n, capf), dtype=torch.int32, device=dev),
                      slot=torch.empty((n, B), dtype=torch.int32, device=dev),
                      counts=torch.zeros((W, n), dtype=torch.int64, device=dev), overflow=torch.zeros(1, dtype=torch.int64, device=dev),
                      state=torch.zeros(state_bytes, dtype=torch.uint8, device=dev))
+            placed = gi in placed_groups
+            g["placed"] = placed
+            if placed:
+                g["send_pos"] = torch.full((W, n, capf), -1, dtype=torch.int32, device=dev)
             if W == 1:        # a one-rank group exchanges with itself: the "received" buffers ARE the sent ones, [1][n][capf] is already [n][1 * capf]
                 g["inbox"] = g["send_ids"]
                 g["oid"] = g["send_ids"].view(n, Bp)
+                if placed:
+                    g["inbox_pos"] = g["send_pos"]
+                    g["opos"] = g["send_pos"].view(n, Bp)
             else:
                 g["inbox"] = torch.zeros((W, n, capf), dtype=torch.int32, device=dev)
                 g["oid"] = torch.zeros((n, Bp), dtype=torch.int32, device=dev)
+                if placed:
+                    g["inbox_pos"] = torch.full((W, n, capf), -1, dtype=torch.int32, device=dev)
+                    g["opos"] = torch.full((n, Bp), -1, dtype=torch.int32, device=dev)
             # the owner's side: a plain batch of Bp pseudo-samples, n single-valued features, concat [Bp, n * D]
             oslots = [ops.Slot(feats[i].name, NRX_SPARSE, table_names.index(feats[i].table), D, 0, k * D) for k, i in enumerate(idxs)]
-            g["owner_fwd"] = ops.PreparedEmbed(ops.EmbedPlan(oslots, out_width=n * D), tabs, [g["oid"][k] for k in range(n)], [None] * n)
-            g["rows_out"] = g["owner_fwd"].out                                                   # [Bp, n * D]
-            g["ret"] = g["rows_out"] if W == 1 else torch.empty_like(g["rows_out"])
+            g["owner_fwd"] = ops.PreparedEmbed(ops.EmbedPlan(oslots, out_width=n * D), tabs, [g["oid"][k] for k in range(n)], [None] * n,
+                                               need_out=not placed)      # (placed: never run -- the descriptor of the owner's pseudo-batch for the backward)
             for k, i in enumerate(idxs):
                 slot_of[i] = g["slot"][k]
-            rets.append(g["ret"].view(-1, D))
+            if placed:
+                ft = [table_names.index(feats[i].table) for i in idxs]
+                g["tp"] = (C.c_void_p * n)(*[tabs[t].data_ptr() for t in ft])
+                g["tr"] = (C.c_int64 * n)(*[tabs[t].shape[0] for t in ft])
+                g["cols"] = (C.c_int32 * n)(*[plan.slots[i].out_col for i in idxs])
+                rets.append(torch.empty((1, D), dtype=torch.float32, device=dev))      # (the final plan's table list keeps a never-read placeholder)
+            else:
+                g["rows_out"] = g["owner_fwd"].out                                               # [Bp, n * D]
+                g["ret"] = g["rows_out"] if W == 1 else torch.empty_like(g["rows_out"])
+                rets.append(g["ret"].view(-1, D))
             self.groups.append(g)
-        # the requester's final launch: routed features read their returned rows by slot, replicated / dense features their own inputs
-        plan = eng._final_plan(feats, groups, ())
+        # the requester's final launch: routed features read their returned rows by slot, replicated / dense features their own inputs; features
+        # the owners placed are not its business
         rets += [arenas[t] for t in eng.replicated_tables(feats)]
         final_inputs = [inputs[i] if (f.kind == NRX_DENSE or f.replicated) else slot_of[i] for i, f in enumerate(feats)]
-        B0 = inputs[0].shape[0]
-        dev0 = inputs[0].device
         self.fm_sums = None
         if train and plan.use_fm:
             self.fm_sums = torch.empty((B0, max(f.dim for f in feats if f.fm)), dtype=torch.float32, device=dev0)
         self.plan = plan
-        self.final = ops.PreparedEmbed(plan, rets, final_inputs, list(weights), out_ld=out_ld, out=out, fm=fm, fm_sums=self.fm_sums)
+        placed_feats = {i for gi in placed_groups for i in groups[gi]}
+        rest = [i for i in range(len(feats)) if i not in placed_feats]
+        self.single = len(feats) <= ops.NRX_MAX_FEATURES
+        self.ld = ld0
+        if not placed_feats:
+            self.final = ops.PreparedEmbed(plan, rets, final_inputs, final_weights, out_ld=out_ld, out=out, fm=fm, fm_sums=self.fm_sums)
+            self.out = self.final.out
+        else:
+            self.out = out
+            self.final = None
+            if rest:
+                sp = ops.EmbedPlan([plan.slots[i] for i in rest], out_width=plan.out_width, wide_width=0)
+                self.final = ops.PreparedEmbed(sp, rets, [final_inputs[i] for i in rest], [final_weights[i] for i in rest], out_ld=ld0, out=out)
         self.bwd = None
+        # where the owner-side plan (it depends on the owner ids only) is enqueued: "inline" = in backward(), behind the gradient exchange;
+        # "backward" = on the planning side stream at the start of backward(), next to the pack launch and the gradient all-to-all;
+        # "forward" = on the side stream right behind the id exchange of run() (what ops.PLAN_AHEAD does for the direct training step)
+        self.plan_mode = os.environ.get("NRX_SHARD_PLAN", "inline")
 
     # ------------------------------------------------------------------ forward
     def run(self):
@@ -138,25 +218,47 @@ class PreparedShardedStep:
         W = eng.world
         for g in self.groups:
             stream = torch.cuda.current_stream(g["dev"]).cuda_stream
-            rc = lib.nrx_route_feat(g["ptrs"], g["n"], g["B"], g["bits"], W, g["capf"], g["send_ids"].data_ptr(), None, g["slot"].data_ptr(),
+            if g["pooled"]:
+                from .sharding import PreparedShardedForward
+                PreparedShardedForward._run_pooled(self, g, stream)
+                continue
+            placed = g["placed"]
+            rc = lib.nrx_route_feat(g["ptrs"], g["n"], g["B"], g["bits"], W, g["capf"], g["send_ids"].data_ptr(),
+                                    g["send_pos"].data_ptr() if placed else None, g["slot"].data_ptr(),
                                     g["counts"].data_ptr(), g["overflow"].data_ptr(), g["state"].data_ptr(), stream)
             if rc:
                 ops.check(rc, "nrx_route_feat")
             if W > 1:
                 eng._a2a(g["inbox"].view(-1), g["send_ids"].view(-1))
-                rc = lib.nrx_inbox_transpose(g["inbox"].data_ptr(), g["oid"].data_ptr(), None, None, W, g["n"], g["capf"], stream)
+                if placed:
+                    eng._a2a(g["inbox_pos"].view(-1), g["send_pos"].view(-1))
+                rc = lib.nrx_inbox_transpose(g["inbox"].data_ptr(), g["oid"].data_ptr(), g["inbox_pos"].data_ptr() if placed else None,
+                                             g["opos"].data_ptr() if placed else None, W, g["n"], g["capf"], stream)
                 if rc:
                     ops.check(rc, "nrx_inbox_transpose")
+            if self.bwd is not None and self.plan_mode == "forward" and not g["pooled"]:
+                self.bwd[self.groups.index(g)]["owner"].plan_ahead()
+            if placed:
+                rc = lib.nrx_gather_place_feat(g["tp"], g["tr"], g["cols"], g["n"], W, g["capf"], g["oid"].data_ptr(), g["opos"].data_ptr(), g["D"],
+                                               self._peer_ptrs, self.ld, self.out.shape[0], None, stream)
+                if rc:
+                    ops.check(rc, "nrx_gather_place_feat")
+                continue
             g["owner_fwd"].run()
             if W > 1:
                 eng._a2a(g["ret"].view(-1), g["rows_out"].view(-1))
-        return self.final.run()
+        res = self.final.run() if self.final is not None else (self.out, None, None)
+        if self.peers is not None and W > 1:
+            # completion fence: a collective enqueued behind every rank's placing launch -- when it has completed here, every owner's rows are in this
+            # rank's buffer (and the next step's first all-to-all keeps the owners from overwriting it too early)
+            eng._a2a(self._fence[0], self._fence[1])
+        return (self.out, res[1], res[2])
 
     def overflowed(self) -> bool:
         """True if some (owner, feature) block exceeded its capacity since the last call (one host read per group)."""
         bad = False
         for g in self.groups:
-            bad |= int(g["overflow"].item()) > g["capf"]
+            bad |= int(g["overflow"].item()) > (g["cap"] if g["pooled"] else g["capf"])
             g["overflow"].zero_()
         return bad
 
@@ -165,8 +267,7 @@ class PreparedShardedStep:
         """Bind the upstream gradient buffers (read in place on every backward()): g_out [B, out_ld] of the concat, g_fm [B] of the FM logit."""
         lib, eng, plan = self.lib, self.eng, self.plan
         W = eng.world
-        fwd = self.final
-        if not fwd.single:
+        if not self.single:
             raise ValueError("PreparedShardedStep: the backward covers plans of <= 64 features")
         self.g_out = None if g_out is None else ops._f32c(g_out, "g_out")
         self.fmg = None
@@ -174,10 +275,25 @@ class PreparedShardedStep:
             if self.fm_sums is None:
                 raise ValueError("an FM gradient needs train=True on an FM plan")
             self.g_fm = ops._f32c(g_fm, "g_fm")
-            self.fmg = NrxFmGrad(self.g_fm.data_ptr(), self.fm_sums.data_ptr(), self.fm_sums.shape[1], fwd.out.data_ptr(), fwd.ld)
-        n_final_tables = len(fwd.tables)
+            self.fmg = NrxFmGrad(self.g_fm.data_ptr(), self.fm_sums.data_ptr(), self.fm_sums.shape[1], self.out.data_ptr(), self.ld)
+        n_final_tables = len(self.groups) + len(eng.replicated_tables(self.feats))
         self.bwd = []
         for gi, g in enumerate(self.groups):
+            if g["pooled"]:
+                if self.g_out is None:
+                    raise ValueError("PreparedShardedStep: a pooled bag group needs the gradient of the concat")
+                n, D, B, cap = g["n"], g["D"], g["B"], g["cap"]
+                arena = g["tables"][0]
+                g_send = torch.empty((W, n * B, D), dtype=torch.float32, device=g["dev"])
+                g_recv = g_send if W == 1 else torch.empty_like(g_send)
+                oid = torch.zeros(W * cap, dtype=torch.int32, device=g["dev"])
+                rows = torch.zeros((W * cap, D), dtype=torch.float32, device=g["dev"])
+                # the owner's pseudo-batch: ONE single-valued feature of W * cap pseudo-lookups over the arena (never run forward: a descriptor)
+                pfwd = ops.PreparedEmbed(ops.EmbedPlan([ops.Slot(g["table_names"][0], NRX_SPARSE, 0, D, 0, 0)], out_width=D), [arena], [oid], [None],
+                                         need_out=False)
+                self.bwd.append(dict(pooled=True, g_send=g_send, g_recv=g_recv, oid=oid, rows=rows, owner=ops.PreparedSparseBackward(pfwd, rows),
+                                     cols=[plan.slots[i].out_col for i in g["idxs"]]))
+                continue
             n, D, Bp = g["n"], g["D"], g["Bp"]
             sub = ops.EmbedPlan([plan.slots[i] for i in g["idxs"]], out_width=plan.out_width, wide_width=plan.wide_width)
             slots_in = [g["slot"][k] for k in range(n)]
@@ -189,7 +305,7 @@ class PreparedShardedStep:
                 arr[k].rows = Bp * n
             g_recv = g_send if W == 1 else torch.empty_like(g_send)
             owner_bwd = ops.PreparedSparseBackward(g["owner_fwd"], g_recv)
-            self.bwd.append(dict(arr=arr, g_send=g_send, g_recv=g_recv, owner=owner_bwd, scatter_ok=True))
+            self.bwd.append(dict(pooled=False, arr=arr, g_send=g_send, g_recv=g_recv, owner=owner_bwd, scatter_ok=True))
         return self
 
     def backward(self):
@@ -198,13 +314,34 @@ class PreparedShardedStep:
         cap) -- valid until the next backward(); feed them to optim.FusedSparseAdam through `sink_entries`."""
         lib, eng = self.lib, self.eng
         W = eng.world
-        fwd = self.final
         out = []
+        if self.plan_mode == "backward":
+            for b in self.bwd:
+                if not b["pooled"]:
+                    b["owner"].plan_ahead()
         for g, b in zip(self.groups, self.bwd):
             stream = torch.cuda.current_stream(g["dev"]).cuda_stream
+            if b["pooled"]:
+                # d partial[o][tag] = the sample's upstream row for EVERY owner o (the requester adds the world partials): the same [n * B, D] block
+                # goes to every owner; the owner turns its inbox entries into pseudo-lookups with upstream rows w * g and reduces them like any batch
+                n, D, B = g["n"], g["D"], g["B"]
+                v = b["g_send"].view(W, n, B, D)
+                for k, col in enumerate(b["cols"]):
+                    v[:, k].copy_(self.g_out[:, col:col + D].unsqueeze(0).expand(W, B, D))
+                if W > 1:
+                    eng._a2a(b["g_recv"].view(-1), b["g_send"].view(-1))
+                rc = lib.nrx_pool_inbox_expand(g["tables"][0].shape[0] - 1, n, B, W, g["cap"], g["recv2d"].data_ptr(), g["inbox"].data_ptr(),
+                                               g["inbox_tag"].data_ptr(), g["inbox_w"].data_ptr(), D, b["g_recv"].data_ptr(), int(eng.rank == 0),
+                                               b["oid"].data_ptr(), b["rows"].data_ptr(), stream)
+                if rc:
+                    ops.check(rc, "nrx_pool_inbox_expand")
+                for og in b["owner"].run():
+                    out.append(dict(tables=g["tables"], dim=og["dim"], uniq=og["uniq"], values=og["values"], counts=og["counts"], cap=og["cap"],
+                                    table_ids=[0]))
+                continue
             rc = NRX_ERR_UNSUPPORTED
             if b["scatter_ok"]:
-                rc = lib.nrx_embed_bwd_scatter(b["arr"], g["n"], g["B"], g["D"], ops._ptr(self.g_out), fwd.ld, None, 0, self.fmg,
+                rc = lib.nrx_embed_bwd_scatter(b["arr"], g["n"], g["B"], g["D"], ops._ptr(self.g_out), self.ld, None, 0, self.fmg,
                                                g["slot"].data_ptr(), b["g_send"].data_ptr(), stream)
                 if rc == NRX_ERR_UNSUPPORTED:
                     b["scatter_ok"] = False
@@ -214,7 +351,7 @@ class PreparedShardedStep:
                 # outside the placement pass's shapes (odd dims, unaligned columns): the general kernel adds every lookup's row into the zero-filled
                 # send buffer -- every slot is written by one lookup, so the float atomics have nothing to reorder
                 b["g_send"].zero_()
-                ops.check(lib.nrx_embed_bwd(b["arr"], g["n"], g["B"], ops._ptr(self.g_out), fwd.ld, None, 0, self.fmg, stream), "nrx_embed_bwd")
+                ops.check(lib.nrx_embed_bwd(b["arr"], g["n"], g["B"], ops._ptr(self.g_out), self.ld, None, 0, self.fmg, stream), "nrx_embed_bwd")
             if W > 1:
                 eng._a2a(b["g_recv"].view(-1), b["g_send"].view(-1))
             for og in b["owner"].run():

@@ -1036,16 +1036,21 @@ class ShardedBenchPath:
     row-sharded over `world` ranks, B impressions per rank (weak scaling)."""
 
     def __init__(self, wl: str, device, seed: int, rank: int, world: int, batch: int, mode: str = "row", n_pool: int = 8,
-                 replicate_below_bytes: int = 256 << 20, host_staged: bool = False):
+                 replicate_below_bytes: int = 256 << 20, host_staged: bool = False, engine: Optional[str] = None):
         """mode "row": every table row-sharded (the north-star layout).  mode "auto": planner -- tables
         of at most `replicate_below_bytes` are held in full on every rank (no exchange for them), larger
-        ones are row-sharded."""
+        ones are row-sharded.
+        engine (default: NRX_SHARD_ENGINE, else "auto"): "feat" = shard_step.PreparedShardedStep (per-feature routing, the owner side is the
+        single-GPU engine: bound forward AND bound row-sparse backward); "legacy" = PreparedShardedForward + the autograd training step;
+        "auto" = "feat" whenever a table is row-sharded."""
+        import os
         import bench
         feats, self.desc = bench.workload_spec(wl)
         self.rank, self.world, self.batch = rank, world, batch
         self.eng = RowShardedEmbedding(rank, world, overflow_policy="defer", host_staged=host_staged)
         gen = torch.Generator(device=device).manual_seed(seed)
         self.tables: Dict[str, torch.Tensor] = {}
+        self.arenas: Dict[str, torch.Tensor] = {}      # row-sharded tables with their leading dummy row (shard_step.make_arena's layout)
         self.feats: List[ShardedFeature] = []
         self.fm = wl == "c2"
         self.n_replicated = self.n_sharded = 0
@@ -1056,11 +1061,15 @@ class ShardedBenchPath:
                 rep = mode == "auto" and f["rows"] * f["dim"] * 4 <= replicate_below_bytes
                 rep_of[tname] = rep
                 nrows = f["rows"] if rep else local_row_count(f["rows"], rank, world)
-                t = torch.empty((nrows, f["dim"]), dtype=torch.float32, device=device)
                 if rep:      # identical replica on every rank
+                    t = torch.empty((nrows, f["dim"]), dtype=torch.float32, device=device)
                     t.normal_(generator=torch.Generator(device=device).manual_seed(seed - rank + len(self.tables)))
-                else:
+                else:        # the shard is rows 1.. of an arena whose row 0 is the dummy row the bound step's owner ids name with 0
+                    arena = torch.empty((nrows + 1, f["dim"]), dtype=torch.float32, device=device)
+                    arena[0].zero_()
+                    t = arena[1:]
                     t.normal_(generator=gen)
+                    self.arenas[tname] = arena
                 if rank == 0 or rep:
                     t[0].zero_()
                 self.tables[tname] = t
@@ -1077,15 +1086,26 @@ class ShardedBenchPath:
                 ins.append(torch.randint(1, self.rows[f.name], shape, device=device, generator=gen))
                 ws.append(torch.ones(shape, dtype=torch.float32, device=device) if f.bag_len else None)
             self.pool.append((ins, ws))
-        self.bytes_per_impr = bench.algorithmic_bytes_per_impression(
-            [dict(dim=f.dim, bag=f.bag_len) for f in self.feats], self.fm, 0)
+        fdicts = [dict(dim=f.dim, bag=f.bag_len) for f in self.feats]
+        self.bytes_per_impr = bench.algorithmic_bytes_per_impression(fdicts, self.fm, 0)
+        self.bwd_bytes_per_impr = bench.backward_bytes_per_impression(fdicts, self.fm)
         self.desc += (f" -- {self.n_sharded} tables row-sharded over {world} GPUs, {self.n_replicated} replicated "
                       f"(mode={mode})")
 
         width = sum(f.dim for f in self.feats)
         out = torch.empty((batch, width), dtype=torch.float32, device=device)       # recycled (see bench.py)
         fmb = torch.empty((batch,), dtype=torch.float32, device=device) if self.fm else None
-        import os
+        engine = engine or os.environ.get("NRX_SHARD_ENGINE", "auto")
+        if engine == "auto":
+            engine = "feat" if self.n_sharded > 0 else "legacy"
+        self.engine = engine
+        if engine == "feat":
+            from .shard_step import PreparedShardedStep
+            tabs = {n: self.arenas.get(n, t) for n, t in self.tables.items()}
+            # (the first two calls are bound in training form -- they also leave the FM field sums the backward folds in; train_setup binds their backward)
+            self.calls = [PreparedShardedStep(self.eng, self.feats, ins, ws, tabs, out=out, fm=fmb, train=(k < 2))
+                          for k, (ins, ws) in enumerate(self.pool)]
+            return
         overlap = os.environ.get("NRX_SHARD_NO_OVERLAP") is None            # measurement knob: time the serial form
         self.calls = [PreparedShardedForward(self.eng, self.feats, ins, ws, self.tables, out=out, fm=fmb, overlap_local=overlap)
                       for ins, ws in self.pool]
@@ -1102,6 +1122,17 @@ class ShardedBenchPath:
         the exchange -- forward as `step`, then the gradient all-to-all back to the owners and the owner-side scatter into the local shards'
         dense gradients (nrx_scatter_add_inbox; pooled bags: nrx_pool_inbox_bwd).  Returns False when the shards' dense gradients (one
         [local rows, dim] tensor per table, zero-filled every step -- the reference's nn.Embedding(sparse=False) semantics) do not fit."""
+        dev = next(iter(self.tables.values())).device
+        width = sum(f.dim for f in self.feats)
+        if self.engine == "feat":
+            # the BOUND step: shard_step.PreparedShardedStep.backward -- slot scatter of the upstream rows (nrx_embed_bwd_scatter), gradient all-to-all,
+            # the owner-side planned reduction into row-sparse (keys, values): no dense shard gradient exists, so every workload fits
+            gen = torch.Generator(device=dev).manual_seed(11)
+            self._g_out = torch.randn((self.batch, width), device=dev, generator=gen)
+            self._g_fm = torch.randn((self.batch,), device=dev, generator=gen) if self.fm else None
+            for c in self.calls[:2]:
+                c.bind_backward(self._g_out, self._g_fm)
+            return True
         shard_bytes = sum(t.numel() * 4 for t in self.tables.values())
         if shard_bytes > (24 << 30):
             return False
@@ -1113,6 +1144,10 @@ class ShardedBenchPath:
         return True
 
     def train_step(self, i: int):
+        if self.engine == "feat":
+            c = self.calls[i % 2]
+            c.run()
+            return c.backward()
         ins, ws = self.pool[i % len(self.pool)]
         out, _, fm = self.eng.forward(self.feats, ins, ws, self._train_tables)
         loss_like = [out]
@@ -1130,7 +1165,7 @@ class ShardedBenchPath:
         groups = self.calls[0].groups
         if not groups or self.world == 1:
             return None
-        pairs = [(g["ret"], g["partial"] if g.get("pooled") else g["rows_out"]) for g in groups if not g.get("placed")]
+        pairs = [(g["ret"], g["partial"] if g.get("pooled") else g["rows_out"]) for g in groups if not g.get("placed")]     # (both engines name them so)
         if not pairs:
             return None
         nbytes = sum(r.numel() * r.element_size() for r, _ in pairs)

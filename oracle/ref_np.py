@@ -511,7 +511,7 @@ def route_feat(id_arrays, world: int, capf: int):
     src/model/sort/deep/train.py:38-44).  id_arrays: n integer arrays of B ids each.  Every (owner o, feature f) pair owns capf slots:
       send_ids [world, n, capf] int32   OWNER IDS in sample order: 0 = nothing (empty slot / the global padding id 0), v >= 1 = local row v - 1 of
                                         o's shard (id // world + 1); ids < 0 / >= 2^31 - 1 go to rank 0 as -1 / INT32_MAX
-      send_pos [world, n, capf] int32   the sample of each sent id (0 in the tails)
+      send_pos [world, n, capf] int32   the sample of each sent id (-1 in the tails)
       slot     [n, B] int32             (o * capf + k) * n + f, or -1 where k >= capf
       counts   [world, n] int64         ids of f owned by o
     Returns (send_ids, send_pos, slot, counts, counts.max())."""
@@ -519,7 +519,7 @@ def route_feat(id_arrays, world: int, capf: int):
     B = int(np.asarray(id_arrays[0]).size) if n else 0
     I32MAX = (1 << 31) - 1
     send_ids = np.zeros((world, n, capf), np.int32)
-    send_pos = np.zeros((world, n, capf), np.int32)
+    send_pos = np.full((world, n, capf), -1, np.int32)       # (-1 in the tails: an empty slot; owner id 0 WITH a position is a padding lookup)
     slot = np.full((n, B), -1, np.int32)
     counts = np.zeros((world, n), np.int64)
     for f, a in enumerate(id_arrays):

@@ -78,6 +78,18 @@ def test_bench_gpus2_self_launched_host_staged_end_to_end():
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "weak"
     assert "launcher" in line
     assert "strong_scaling" in line or "secondary_note" in line
+    # the N > 1 line describes itself (round 6): the headline layout is row-sharded for every workload -- the default c2 here: 26 tables, none
+    # replicated --, the process group reports its own size, the roofline is per rank, the ratio to the direct single-GPU path is stated
+    lay = line["config"]["layout"]
+    assert lay["mode"] == "row" and lay["tables_row_sharded"] == 26 and lay["tables_replicated"] == 0 and lay["engine"] == "feat"
+    assert line["rccl_ranks"]["world_size"] == 2 and "gloo" in line["rccl_ranks"]["backend"] and "NOT a measurement" in line["rccl_ranks"]["transport"]
+    assert line["roofline"]["achieved"] > 0 and line["roofline"]["algorithmic_bytes_per_launch"] == 3540 * 65536
+    assert line["scaling_vs_1gpu"]["direct_1gpu_value"] > 0 and "profiles/" in line["scaling_vs_1gpu"]["direct_1gpu_source"]
+    if "secondary_note" not in line:
+        assert line["a2a"]["GBps_per_link"] > 0 and line["a2a"]["xgmi_links_per_gpu"] == 7
+        assert line["other_layout"]["layout_mode"] == "auto" and line["other_layout"]["tables_replicated"] == 26
+        fb = line["fwd_bwd"]
+        assert fb["engine"] == "feat" and fb["roofline"]["frac"] > 0 and "PreparedShardedStep" in fb["mode"]
 
 
 @pytest.mark.gpu

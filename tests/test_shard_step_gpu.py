@@ -17,7 +17,7 @@ import pytest
 import torch
 
 from news_recsys_amd import _lib, ops, shard_step
-from news_recsys_amd._lib import NRX_SPARSE, NrxFmGrad
+from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_SPARSE, NrxFmGrad
 from news_recsys_amd.sharding import RowShardedEmbedding, ShardedFeature
 from oracle import ref_np
 
@@ -165,8 +165,9 @@ def _direct(feats, tabs_full, inputs, fm, g_out, g_fm):
     return out, fmv, groups, names
 
 
+@pytest.mark.parametrize("one_sided", [False, True])
 @pytest.mark.parametrize("case", ["c2_like_fm", "two_dims", "shared_table", "tiny_tables"])
-def test_world_1_step_equals_the_direct_path_bit_for_bit(case):
+def test_world_1_step_equals_the_direct_path_bit_for_bit(case, one_sided):
     rng = np.random.default_rng(sum(map(ord, case)))
     gen = torch.Generator(device=DEV).manual_seed(3)
     fm = case == "c2_like_fm"
@@ -189,7 +190,8 @@ def test_world_1_step_equals_the_direct_path_bit_for_bit(case):
     g_out = torch.randn((B, width), device=DEV, generator=gen)
     g_fm = torch.randn((B,), device=DEV, generator=gen) if fm else None
     eng = RowShardedEmbedding(0, 1, overflow_policy="defer")
-    step = shard_step.PreparedShardedStep(eng, feats, inputs, [None] * len(feats), arenas).bind_backward(g_out, g_fm)
+    step = shard_step.PreparedShardedStep(eng, feats, inputs, [None] * len(feats), arenas, one_sided=one_sided).bind_backward(g_out, g_fm)
+    assert all(g["placed"] == (one_sided and not fm) for g in step.groups)      # (an FM epilogue keeps the buffer path: its fused final launch)
     for _ in range(2):                                                # re-launchable: same buffers, same result
         out, _, fmv = step.run()
         entries = step.backward()
@@ -243,3 +245,129 @@ def test_world_1_fused_sparse_adam_step_moves_the_same_rows():
     for nm in arenas:
         assert torch.equal(arenas[nm][1:], full[nm]), nm
         assert float(arenas[nm][0].abs().max()) == 0.0 and float(arenas[nm][1].abs().max()) == 0.0      # dummy row, global padding row
+
+
+def test_gather_place_feat_equals_its_definition():
+    """nrx_gather_place_feat against numpy: every (feature, pseudo-sample) with a position writes its arena row (owner id 0: zeros) at
+    peer[s][pos, col_f]; empty slots (position -1) write nothing; ids outside the arena and positions outside the batch are dropped and counted."""
+    lib = _lib.load()
+    rng = np.random.default_rng(31)
+    for D, n, world, capf, B in ((16, 5, 1, 640, 640), (32, 3, 3, 256, 500), (64, 9, 2, 128, 200), (128, 2, 4, 64, 100)):
+        bp = world * capf
+        rows = [int(rng.integers(5, 400)) for _ in range(n)]
+        arenas = [torch.from_numpy(rng.standard_normal((r, D)).astype(np.float32)).to(DEV) for r in rows]
+        for a in arenas:
+            a[0].zero_()
+        oid = np.stack([rng.integers(0, r, bp) for r in rows]).astype(np.int32)
+        # every (source block, feature) names each sample position at most once -- what nrx_route_feat produces
+        opos = np.full((n, bp), -1, np.int32)
+        for f in range(n):
+            for s_ in range(world):
+                k = int(rng.integers(capf // 2, capf + 1))
+                opos[f, s_ * capf: s_ * capf + k] = rng.permutation(B)[:k] if k <= B else np.concatenate([rng.permutation(B), -np.ones(k - B, np.int64)])
+        oid[opos < 0] = 0
+        oid[0, 3], oid[1 % n, 7] = 0, 0                                  # padding lookups with a position: zeros are written
+        bad_id, bad_pos = 0, 0
+        if bp > 40:
+            if opos[0, 11] >= 0:
+                oid[0, 11] = rows[0] + 5; bad_id += 1
+            if opos[n - 1, 13] >= 0:
+                opos[n - 1, 13] = B + 2; bad_pos += 1
+        ld = n * D + 4
+        outs = [torch.full((B, ld), 9.0, dtype=torch.float32, device=DEV) for _ in range(world)]
+        cols = [f * D for f in range(n)]
+        status = torch.zeros(4, dtype=torch.int32, device=DEV)
+        t_oid, t_pos = torch.from_numpy(oid).to(DEV), torch.from_numpy(opos).to(DEV)
+        ops.check(lib.nrx_gather_place_feat((C.c_void_p * n)(*[a.data_ptr() for a in arenas]), (C.c_int64 * n)(*rows), (C.c_int32 * n)(*cols), n, world,
+                                            capf, t_oid.data_ptr(), t_pos.data_ptr(), D, (C.c_void_p * world)(*[o.data_ptr() for o in outs]), ld, B,
+                                            status.data_ptr(), torch.cuda.current_stream().cuda_stream), "nrx_gather_place_feat")
+        torch.cuda.synchronize()
+        want = [np.full((B, ld), 9.0, np.float32) for _ in range(world)]
+        tabs = [a.cpu().numpy() for a in arenas]
+        for f in range(n):
+            for b in range(bp):
+                p = opos[f, b]
+                if p < 0 or p >= B:
+                    continue
+                i = oid[f, b]
+                want[b // capf][p, cols[f]:cols[f] + D] = tabs[f][i] if 0 <= i < rows[f] else 0.0
+        for o, w in zip(outs, want):
+            assert np.array_equal(o.cpu().numpy(), w)
+        assert int(status[0]) == bad_id + bad_pos
+
+
+def _dense_from_entries(entries, arenas, world=1, rank=0):
+    """Sum of the (key, value) lists per table as dense [global rows, D] float64 arrays (a table may be fed by a pooled and a single-valued group)."""
+    out = {}
+    for e in entries:
+        nu = int(e["counts"][0])
+        keys, vals = e["uniq"][:nu].cpu().numpy(), e["values"][:nu].double().cpu().numpy()
+        for t, arena in enumerate(e["tables"]):
+            name = next(n for n, a in arenas.items() if a is arena)
+            sel = (keys >> 40) == t
+            rows = (keys[sel] & ((1 << 40) - 1))
+            live = rows > 0
+            d = out.setdefault(name, {})
+            for r, v in zip(rows[live], vals[sel][live]):
+                g = (int(r) - 1) * world + rank
+                d[g] = d.get(g, 0) + v
+    return out
+
+
+@pytest.mark.parametrize("kind", [NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN])
+def test_world_1_tower_with_a_history_bag_against_the_direct_path(kind):
+    """The DSSM tower (recall/DSSM/model.py:148-180): item_id + a history bag sharing the news table + user_id.  The bag goes through the pooled
+    channel (owner-side partial pooling); its bound backward expands the owner's inbox into pseudo-lookups and reduces them with the planned
+    reduction.  Forward: single-valued columns bit for bit, the pooled columns to rtol 1e-6 (the partial-sum order differs); gradient: per
+    (table, row) the sum of the lists equals the direct row-sparse gradient to fp32 summation tolerance; two runs give the same bits."""
+    rng = np.random.default_rng(17 + kind)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    D, L, B, news, users = 16, 11, 6000, 20_000, 300_000
+    feats = [ShardedFeature("item_id", NRX_SPARSE, "item_id", D), ShardedFeature("user_history", kind, "item_id", D, L),
+             ShardedFeature("user_id", NRX_SPARSE, "user_id", D)]
+    arenas = {"item_id": shard_step.make_arena(news, D, 0, 1, DEV, generator=gen), "user_id": shard_step.make_arena(users, D, 0, 1, DEV, generator=gen)}
+    full = {t: shard_step.arena_shard(a).clone() for t, a in arenas.items()}
+    hist = rng.integers(1, news, (B, L))
+    lens = rng.integers(0, L + 1, B)
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.float32)
+    hist = np.where(mask > 0, hist, 0)
+    inputs = [torch.from_numpy(rng.integers(0, news, B)).to(DEV), torch.from_numpy(hist).to(DEV), torch.from_numpy(rng.integers(1, users, B)).to(DEV)]
+    weights = [None, torch.from_numpy(mask).to(DEV) if kind == NRX_BAG_MASKED_MEAN else None, None]
+    g_out = torch.randn((B, 3 * D), device=DEV, generator=gen)
+    eng = RowShardedEmbedding(0, 1, overflow_policy="defer")
+    step = shard_step.PreparedShardedStep(eng, feats, inputs, weights, arenas).bind_backward(g_out)
+    assert [g["pooled"] for g in step.groups].count(True) == 1
+    runs = []
+    for _ in range(2):
+        out, _, _ = step.run()
+        entries = step.backward()
+        torch.cuda.synchronize()
+        runs.append((out.clone(), [(e["uniq"].clone(), e["values"].clone(), int(e["counts"][0])) for e in entries]))
+    assert not step.overflowed()
+    assert torch.equal(runs[0][0], runs[1][0])
+    for (k0, v0, n0), (k1, v1, n1) in zip(runs[0][1], runs[1][1]):
+        assert n0 == n1 and torch.equal(k0[:n0], k1[:n1]) and torch.equal(v0[:n0].view(torch.int32), v1[:n1].view(torch.int32))
+    # ---- the direct path
+    slots = [ops.Slot("item_id", NRX_SPARSE, 0, D, 0, 0), ops.Slot("user_history", kind, 0, D, L, D), ops.Slot("user_id", NRX_SPARSE, 1, D, 0, 2 * D)]
+    fwd = ops.PreparedEmbed(ops.EmbedPlan(slots, out_width=3 * D), [full["item_id"], full["user_id"]], inputs, weights)
+    d_out, _, _ = fwd.run()
+    d_groups = ops.PreparedSparseBackward(fwd, g_out).run()
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :D], d_out[:, :D]) and torch.equal(out[:, 2 * D:], d_out[:, 2 * D:])
+    torch.testing.assert_close(out[:, D:2 * D], d_out[:, D:2 * D], rtol=1e-6, atol=1e-6)
+    got = _dense_from_entries(entries, arenas)
+    names = ["item_id", "user_id"]
+    for g in d_groups:
+        nu = int(g["counts"][0])
+        keys, vals = g["uniq"][:nu].cpu().numpy(), g["values"][:nu].double().cpu().numpy()
+        scale = float(np.abs(vals).max())
+        seen = {n: 0 for n in names}
+        for k, v in zip(keys, vals):
+            r = int(k & ((1 << 40) - 1))
+            if r == 0:
+                continue
+            name = names[k >> 40]
+            seen[name] += 1
+            np.testing.assert_allclose(got[name][r], v, rtol=1e-5, atol=2e-6 * scale)
+        for n in names:
+            assert seen[n] == len(got[n])

@@ -57,7 +57,7 @@ def _batch(spec, B, rank):
     return ids, rng.standard_normal((B, width)).astype(np.float32), rng.standard_normal((B,)).astype(np.float32)
 
 
-def _worker(rank, world, port, q, case):
+def _worker(rank, world, port, q, case, one_sided):
     import os
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -72,12 +72,14 @@ def _worker(rank, world, port, q, case):
         g_out = torch.from_numpy(up).to(DEV)
         g_fm = torch.from_numpy(up_fm).to(DEV) if fm else None
         eng = RowShardedEmbedding(rank, world, slack=0.5, host_staged=True, overflow_policy="defer")
-        step = shard_step.PreparedShardedStep(eng, feats, inputs, [None] * len(feats), arenas).bind_backward(g_out, g_fm)
+        step = shard_step.PreparedShardedStep(eng, feats, inputs, [None] * len(feats), arenas, one_sided=one_sided).bind_backward(g_out, g_fm)
+        assert all(g["placed"] == (one_sided and not fm) for g in step.groups)
         runs = []
         for _ in range(2):
             out, _, fmv = step.run()
             entries = step.backward()
             torch.cuda.synchronize()
+            dist.barrier()                                # (one-sided: every peer's placing launch has finished before anyone reads its buffer)
             got = []
             for e in entries:
                 nu = int(e["counts"][0])
@@ -88,17 +90,20 @@ def _worker(rank, world, port, q, case):
         same = np.array_equal(runs[0][0], runs[1][0]) and all(
             np.array_equal(a[2], b[2]) and np.array_equal(a[3].view(np.int32), b[3].view(np.int32)) for a, b in zip(runs[0][2], runs[1][2]))
         q.put((rank, runs[1][0], runs[1][1], runs[1][2], bool(over), bool(same)))
+        dist.barrier()                                    # nobody unmaps a buffer a peer may still be writing
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("case", ["fm16", "mixed"])
-def test_sharded_step_equals_the_direct_path_on_the_concatenated_batch(world, case):
+@pytest.mark.parametrize("case,one_sided", [("fm16", False), ("mixed", False), ("mixed", True)])
+def test_sharded_step_equals_the_direct_path_on_the_concatenated_batch(world, case, one_sided):
+    """one_sided: the owners write the rows straight into the requesters' concat buffers (nrx_gather_place_feat; the rank processes map each
+    other's buffers through hipIpc) -- same outputs, same gradients."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, case)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, case, one_sided)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -151,3 +156,119 @@ def test_sharded_step_equals_the_direct_path_on_the_concatenated_batch(world, ca
     assert set(got) == set(want)
     for key, v in want.items():
         assert np.array_equal(got[key].view(np.int32), v.view(np.int32)), key
+
+
+# ---------------------------------------------------------------------------------------------- the tower with a history bag (pooled channel)
+def _tower_batch(rank, B, L, news, users):
+    rng = np.random.default_rng(900 + rank)
+    hist = rng.integers(1, news, (B, L))
+    hist[rng.random((B, L)) < 0.1] = 23                    # a hot news row in many bags of every rank
+    lens = rng.integers(0, L + 1, B)
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.float32)
+    hist = np.where(mask > 0, hist, 0)
+    return rng.integers(0, news, B), hist, mask, rng.integers(1, users, B), rng.standard_normal((B, 48)).astype(np.float32)
+
+
+def _tower_worker(rank, world, port, q):
+    import os
+    from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        D, L, B, news, users = 16, 9, 2500, 6000, 50_000
+        rng = np.random.default_rng(3)
+        tabs = {"item_id": rng.standard_normal((news, D)).astype(np.float32), "user_id": rng.standard_normal((users, D)).astype(np.float32)}
+        for t in tabs.values():
+            t[0] = 0
+        arenas = {t: shard_step.make_arena(x.shape[0], D, rank, world, DEV, full=torch.from_numpy(x).to(DEV)) for t, x in tabs.items()}
+        feats = [ShardedFeature("item_id", NRX_SPARSE, "item_id", D), ShardedFeature("user_history", NRX_BAG_MASKED_MEAN, "item_id", D, L),
+                 ShardedFeature("user_id", NRX_SPARSE, "user_id", D)]
+        item, hist, mask, user, up = _tower_batch(rank, B, L, news, users)
+        inputs = [torch.from_numpy(item).to(DEV), torch.from_numpy(hist).to(DEV), torch.from_numpy(user).to(DEV)]
+        weights = [None, torch.from_numpy(mask).to(DEV), None]
+        eng = RowShardedEmbedding(rank, world, slack=0.5, host_staged=True, overflow_policy="defer")
+        step = shard_step.PreparedShardedStep(eng, feats, inputs, weights, arenas, one_sided=False).bind_backward(torch.from_numpy(up).to(DEV))
+        res = []
+        for _ in range(2):
+            out, _, _ = step.run()
+            entries = step.backward()
+            torch.cuda.synchronize()
+            dist.barrier()
+            got = []
+            for e in entries:
+                nu = int(e["counts"][0])
+                names = [next(n for n, a in arenas.items() if a is t) for t in e["tables"]]
+                got.append((names, e["uniq"][:nu].cpu().numpy(), e["values"][:nu].cpu().numpy()))
+            res.append((out.cpu().numpy().copy(), got))
+        same = np.array_equal(res[0][0], res[1][0]) and all(np.array_equal(a[1], b[1]) and np.array_equal(a[2].view(np.int32), b[2].view(np.int32))
+                                                           for a, b in zip(res[0][1], res[1][1]))
+        q.put((rank, res[1][0], res[1][1], bool(step.overflowed()), bool(same)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_tower_with_a_pooled_history_bag(world):
+    """The DSSM tower at world 2 / 3: the history bag is pooled at the owners (forward) and its gradient comes back as row-sparse (keys, values)
+    from the owners' planned reduction (backward).  Against the direct path on the concatenated batch: single-valued columns bit for bit, the
+    pooled columns rtol 1e-6; per (table, global row) the sum over ranks and lists equals the direct gradient to fp32 summation tolerance; two
+    runs of the sharded step give the same bits."""
+    from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tower_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        item = q.get(timeout=300)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    D, L, B, news, users = 16, 9, 2500, 6000, 50_000
+    rng = np.random.default_rng(3)
+    tabs = {"item_id": rng.standard_normal((news, D)).astype(np.float32), "user_id": rng.standard_normal((users, D)).astype(np.float32)}
+    for t in tabs.values():
+        t[0] = 0
+    bs = [_tower_batch(r, B, L, news, users) for r in range(world)]
+    inputs = [torch.from_numpy(np.concatenate([b[0] for b in bs])).to(DEV), torch.from_numpy(np.concatenate([b[1] for b in bs])).to(DEV),
+              torch.from_numpy(np.concatenate([b[3] for b in bs])).to(DEV)]
+    weights = [None, torch.from_numpy(np.concatenate([b[2] for b in bs])).to(DEV), None]
+    g_out = torch.from_numpy(np.concatenate([b[4] for b in bs])).to(DEV)
+    slots = [ops.Slot("item_id", NRX_SPARSE, 0, D, 0, 0), ops.Slot("user_history", NRX_BAG_MASKED_MEAN, 0, D, L, D), ops.Slot("user_id", NRX_SPARSE, 1, D, 0, 2 * D)]
+    fwd = ops.PreparedEmbed(ops.EmbedPlan(slots, out_width=3 * D), [torch.from_numpy(tabs["item_id"]).to(DEV), torch.from_numpy(tabs["user_id"]).to(DEV)],
+                            inputs, weights)
+    d_out = fwd.run()[0].cpu().numpy()
+    d_groups = ops.PreparedSparseBackward(fwd, g_out).run()
+    torch.cuda.synchronize()
+    got = {"item_id": {}, "user_id": {}}
+    for r in range(world):
+        out, entries, over, same = res[r]
+        assert not over and same
+        want = d_out[r * B:(r + 1) * B]
+        assert np.array_equal(out[:, :D], want[:, :D]) and np.array_equal(out[:, 2 * D:], want[:, 2 * D:])
+        np.testing.assert_allclose(out[:, D:2 * D], want[:, D:2 * D], rtol=1e-6, atol=1e-6)
+        for tnames, keys, vals in entries:
+            for k, v in zip(keys, vals):
+                row = int(k & ((1 << 40) - 1))
+                if row == 0:
+                    assert not v.any()
+                    continue
+                d = got[tnames[k >> 40]]
+                key = (row - 1) * world + r
+                d[key] = d.get(key, 0) + v.astype(np.float64)
+    names = ["item_id", "user_id"]
+    n_want = {n: 0 for n in names}
+    for g in d_groups:
+        nu = int(g["counts"][0])
+        keys, vals = g["uniq"][:nu].cpu().numpy(), g["values"][:nu].double().cpu().numpy()
+        scale = float(np.abs(vals).max())
+        for k, v in zip(keys, vals):
+            r = int(k & ((1 << 40) - 1))
+            if r:
+                n_want[names[k >> 40]] += 1
+                np.testing.assert_allclose(got[names[k >> 40]][r], v, rtol=1e-5, atol=2e-6 * scale)
+    assert all(n_want[n] == len(got[n]) for n in names)

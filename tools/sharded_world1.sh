@@ -1,15 +1,17 @@
 #!/bin/bash
-# Dev (GPU box): the row-sharded engine at world = 1 (bench.py --force-sharded), buffer path against one-sided placement, per workload; appends the
-# bench lines to gpurun_out/r04_sharded_world1.jsonl and prints the step times.
-OUT=gpurun_out/r04_sharded_world1.jsonl; : > $OUT
-for wl in c2 c4 c5; do
-  for os in 0 1; do
-    line=$(NRX_SHARD_ONE_SIDED=$os NRX_BENCH_C5_SMALL=${C5SMALL:-0} python3 bench.py --workload $wl --force-sharded --shard-mode ${MODE:-row} --steps 200 --warmup 20 --headline-only --no-cpu-baseline 2>/dev/null | tail -1)
-    echo "$line" | python3 -c "
-import sys, json
-d = json.loads(sys.stdin.read())
-d['one_sided_placement'] = bool($os)
-print(json.dumps(d))" >> $OUT
-    echo "$wl one_sided=$os: $(echo "$line" | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step']*1e3,1), 'us/step')")"
-  done
+# Dev: the sharded engine at world 1 (the only place it can be measured here), row layout: bench lines with the bound training-step leg.
+#   tools/sharded_world1.sh [workloads...]      (default: c2 c5 c3 c4)
+cd "$GRAFT_REPO_ROOT" || exit 2
+F=gpurun_out/sharded_w1; mkdir -p $F
+export NRX_BENCH_OUT=$F/lines.jsonl; : > $NRX_BENCH_OUT
+for w in ${@:-c2 c5 c3 c4}; do
+  python3 bench.py --workload $w --force-sharded --shard-mode row --steps 100 --warmup 10 --no-cpu-baseline > $F/$w.log 2>&1
+  python3 - <<PY
+import json
+for l in open("$F/lines.jsonl"):
+    d = json.loads(l)
+    if d["config"]["workload"].startswith("$w:"):
+        fb = d.get("fwd_bwd", {})
+        print("$w", "fwd ms", round(d["ms_per_step"], 4), "engine", d["config"].get("layout", {}).get("engine"), "fwd_bwd", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in fb.items() if k in ("ms_per_step", "gpu_ms_per_step_rank0", "host_bound", "error", "skipped")}, "frac", round(fb.get("roofline", {}).get("frac", 0), 3))
+PY
 done
