@@ -689,6 +689,14 @@ NRX_API int nrx_pool_inbox_bwd(float* const* grad_tables, const int64_t* table_r
 NRX_API int nrx_pool_inbox_expand(int64_t table_rows, int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
                           const int32_t* inbox_rows, const int32_t* inbox_tag, const float* inbox_w, int32_t dim,
                           const float* g_partial, int32_t skip_row0, int32_t* owner_ids, float* g_rows, void* stream);
+/* g_rows == NULL: the owner ids alone (g_partial is then not read).  With them and nrx_pool_order_remap the expansion is never materialised: a
+ * plan of the owner ids (nrx_sparse_plan_place with place_feats = 0: every row is walked) lists inbox entries in order[]; the remap replaces
+ * every entry e = s * cap + j by s * n_tags + inbox_tag[e] -- the row of the [world * n_tags, dim] block of SAMPLE gradients the entry's upstream
+ * row is (n_tags = n_feats * batch) -- and nrx_embed_bwd_placed then reduces ONE single-valued feature whose g_out is that block (4 MB per
+ * source instead of a [world * cap, dim] array of expanded rows: the walk reads an L2-resident array, as the single-GPU bag backward does).
+ * The per-entry weight must already be IN the block: exact when all non-zero weights of a sample are equal (DataReader's 0/1 masks,
+ * src/dataset/DataReader/data_reader.py:96-109; mean pooling) -- the requester then sends g * w_sample; else use the expansion. */
+NRX_API int nrx_pool_order_remap(int64_t* order, int64_t n_entries, const int32_t* inbox_tag, int64_t cap, int64_t n_tags, int32_t world, void* stream);
 /* Expands a CSR batch of an array feature (values[offsets[b] .. offsets[b+1]), offsets relative to the
  * batch, device int64[batch+1]) into the reference's padded form: ids [batch, bag_len] (0-padded,
  * same integer width as `values`) and mask float32 [batch, bag_len] (1 = real, 0 = padding) --

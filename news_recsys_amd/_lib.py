@@ -120,6 +120,7 @@ SIGNATURES = {
     "nrx_route_feat": (C.c_int, [C.POINTER(_p), _i32, _i64, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "nrx_inbox_transpose": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i64, _p]),
     "nrx_pool_inbox_expand": (C.c_int, [_i64, _i32, _i64, _i32, _i64, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p]),
+    "nrx_pool_order_remap": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p]),
     "nrx_gather_place_feat": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), C.POINTER(_i32), _i32, _i32, _i64, _p, _p, _i32, C.POINTER(_p), _i64, _i64, _p, _p]),
     "nrx_embed_bwd_scatter": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _i32, _p, _i64, _p, _i64, C.POINTER(NrxFmGrad), _p, _p, _p]),
     "nrx_bucketize_workspace": (_i64, [_i64, _i32]),

@@ -3350,6 +3350,17 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
     // threshold sweep (T = 16 / 24 / 32 / 48 / 64, fwd+bwd us): C4 521 / 505 / 493 / 492 / 492, C4 Zipf 581 / 575 / 564 / 598 / 674,
     // C2 Zipf 501 / 545 / 588 / 678 / 758, C5 478 / 491 / 527 / 578 / 618: bag launches (a few rows, each looked up ~L times) take 32
     if (has_bag) a.long_t = 2 * SORTED_LONG_T;
+    {   // a launch of single-valued features whose lookups outnumber the rows of their tables eight times over (the sharded step's pooled channel: a
+        // bag feature's lookups arrive at the owner as ONE single-valued pseudo-feature, ~16 lookups per row of the pooled table) has the row
+        // statistics of a bag launch: the same threshold (measured there: 16 -> 32 is -5 % on C4)
+        int64_t distinct_rows = 0;
+        for (int i = 0; i < n_feats; ++i) {
+            bool seen = false;
+            for (int j = 0; j < i; ++j) seen |= feats[j].table == feats[i].table && feats[j].rows == feats[i].rows && feats[i].table != nullptr;
+            if (!seen) distinct_rows += feats[i].rows;
+        }
+        if (!has_bag && distinct_rows > 0 && off >= 8 * distinct_rows) a.long_t = 2 * SORTED_LONG_T;
+    }
     if (const char* e = getenv("NRX_LONG_T")) { const int v = atoi(e); if (v >= 2 && v <= 256) a.long_t = v; }      // measurement knob
     // placement mode: single-lookup rows are stored by the placement pass, the walk reduces the listed rows only
     const bool placed = fast && dest != nullptr;

@@ -673,7 +673,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void pool_inbox_expand_kernel(const Pool
     const int D = a->dim;
     const bool live = (uint32_t)row < (uint64_t)a->rows[0] && !(a->skip_row0 && row == 0) && (uint32_t)tag < (uint64_t)(a->n_feats * a->batch);
     if (q == 0) owner_ids[e] = live ? row + 1 : 0;
-    if (!live) return;
+    if (!live || g_rows == nullptr) return;
     const float* g = a->partial + ((int64_t)s * a->n_feats * a->batch + tag) * D;
     float* dst = g_rows + e * D;
     if (D == 4 * Q) {
@@ -1105,6 +1105,33 @@ extern "C" int nrx_pool_inbox_bwd(float* const* grad_tables, const int64_t* tabl
     return NRX_OK;
 }
 
+// order[i] names an inbox entry e = s * cap + j; what the reduction wants to fetch for it is the upstream row of its (source, tag): row
+// s * n_tags + tag[e] of the [world * n_tags, dim] block of (pre-scaled) sample gradients.  In place.
+__global__ __launch_bounds__(NRX_BLOCK) void pool_order_remap_kernel(int64_t* __restrict__ order, int64_t n, const int32_t* __restrict__ tag, int64_t cap,
+                                                                    int64_t n_tags, int64_t limit) {
+    for (int64_t i = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * NRX_BLOCK) {
+        const int64_t e = order[i];
+        int64_t r = 0;
+        if (e >= 0 && e < n) {
+            const int64_t t = tag[e];
+            r = (e / cap) * n_tags + (t >= 0 && t < n_tags ? t : 0);      // (entries past a block's count carry stale tags: their row is the padding row, never summed)
+        }
+        order[i] = r < limit ? r : 0;
+    }
+}
+
+extern "C" int nrx_pool_order_remap(int64_t* order, int64_t n_entries, const int32_t* inbox_tag, int64_t cap, int64_t n_tags, int32_t world, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(order != nullptr && inbox_tag != nullptr && n_entries >= 0 && cap >= 1 && n_tags >= 1 && world >= 1, "nrx_pool_order_remap: bad argument");
+    if (n_entries == 0) return NRX_OK;
+    int64_t blocks = (n_entries + NRX_BLOCK - 1) / NRX_BLOCK;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pool_order_remap_kernel, dim3((unsigned)blocks), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), order, n_entries, inbox_tag,
+                       cap, n_tags, (int64_t)world * n_tags);
+    NRX_LAUNCH_CHECK("nrx_pool_order_remap");
+    return NRX_OK;
+}
+
 extern "C" int nrx_pool_inbox_expand(int64_t table_rows, int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
                                      const int32_t* inbox_rows, const int32_t* inbox_tag, const float* inbox_w, int32_t dim,
                                      const float* g_partial, int32_t skip_row0, int32_t* owner_ids, float* g_rows, void* stream) {
@@ -1113,8 +1140,9 @@ extern "C" int nrx_pool_inbox_expand(int64_t table_rows, int32_t n_feats, int64_
     float* dummy_table = g_rows;                      // (fill_pool_args wants a table pointer: never dereferenced here)
     int32_t ft[NRX_MAX_FEATURES];
     for (int f = 0; f < NRX_MAX_FEATURES; ++f) ft[f] = 0;
-    NRX_REQUIRE(g_partial != nullptr && owner_ids != nullptr && g_rows != nullptr, "nrx_pool_inbox_expand: null buffer");
+    NRX_REQUIRE(owner_ids != nullptr && (g_rows == nullptr || g_partial != nullptr), "nrx_pool_inbox_expand: null buffer");
     NRX_REQUIRE((dim & 3) != 0 || (nrx_aligned16(g_partial) && nrx_aligned16(g_rows)), "nrx_pool_inbox_expand: 16-byte aligned rows");
+    if (dummy_table == nullptr) dummy_table = reinterpret_cast<float*>(owner_ids);
     int rc = fill_pool_args(a, &dummy_table, &table_rows, 1, ft, n_feats, batch, world, cap, recv2d, inbox_rows, inbox_tag, inbox_w, dim,
                             "nrx_pool_inbox_expand");
     if (rc != NRX_OK) return rc;

@@ -1545,8 +1545,13 @@ class PreparedSparseBackward:
     a dict(dim, uniq, values, counts, cap) exactly like an ops.SparseGradSink entry.  No autograd, no host reads."""
 
     def __init__(self, fwd: PreparedEmbed, g_out: Optional[torch.Tensor], g_fm: Optional[torch.Tensor] = None,
-                 g_wide: Optional[torch.Tensor] = None):
+                 g_wide: Optional[torch.Tensor] = None, place_feats: Optional[int] = None, post_plan=None):
+        """place_feats (optional): the placement mask instead of place_mask()'s -- 0 = a placement plan in which nothing is placeable: every row
+        is listed and walked, two rows x four entries per pass (the form for launches whose rows are all looked up many times), no placement
+        pass, and the plan always comes from the sorted planner.  post_plan (optional): callable(stream) enqueued between the plan and the
+        reduction (the sharded step's pooled channel rewrites order[] there: nrx_pool_order_remap)."""
         self.lib, self.fwd, plan = fwd.lib, fwd, fwd.plan
+        self.post_plan = post_plan
         if not fwd.single:
             raise ValueError("PreparedSparseBackward covers plans of <= 64 features")
         self.g_out = None if g_out is None else _f32c(g_out, "g_out")
@@ -1580,7 +1585,8 @@ class PreparedSparseBackward:
                      counts=torch.empty(n_tables + 2, dtype=torch.int64, device=dev),
                      ws=torch.empty(max(1, self.lib.nrx_sparse_plan_workspace(total)), dtype=torch.uint8, device=dev),
                      values=torch.empty((total, D), dtype=torch.float32, device=dev),
-                     pmask=place_mask([plan.slots[i].kind for i in fs], [plan.slots[i].bag_len for i in fs]) if SPARSE_PLACE else None,
+                     pmask=(place_feats if place_feats is not None else
+                            place_mask([plan.slots[i].kind for i in fs], [plan.slots[i].bag_len for i in fs]) if SPARSE_PLACE else None),
                      dest=torch.empty(max(total, 1), dtype=torch.int32, device=dev),
                      walk=torch.empty(max(total, 1), dtype=torch.int32, device=dev),
                      n_walk=torch.empty(2, dtype=torch.int64, device=dev),                 # [0] walk rows  [1] pair records (one-kernel planner)
@@ -1592,7 +1598,7 @@ class PreparedSparseBackward:
                      bits=ids[0].element_size() * 8, n_tables=n_tables,
                      arr=arr)
             g["policy"] = None
-            if g["pmask"] is not None and D in (16, 32, 64) and all(plan.slots[i].kind == NRX_SPARSE for i in fs):
+            if g["pmask"] is not None and place_feats is None and D in (16, 32, 64) and all(plan.slots[i].kind == NRX_SPARSE for i in fs):
                 g["policy"] = PlanPolicy(g["lens"], g["tof"], g["rws"], n, n_tables, total)
                 g["pair_recs"] = torch.empty((total // 2 + 1, 4), dtype=torch.int32, device=dev)      # (either planner leaves pair records)
                 if g["policy"].eligible:
@@ -1665,6 +1671,8 @@ class PreparedSparseBackward:
             self._plan_ev = None
         else:
             self._plan(stream)
+        if self.post_plan is not None:
+            self.post_plan(stream)
         for g in self.groups:
             pm = g["pmask"] is not None
             if g["pairs"]:

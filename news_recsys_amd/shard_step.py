@@ -69,16 +69,22 @@ class PreparedShardedStep:
 
     def __init__(self, eng: RowShardedEmbedding, feats: Sequence[ShardedFeature], inputs, weights, arenas: Dict[str, torch.Tensor],
                  out_ld: Optional[int] = None, out: Optional[torch.Tensor] = None, fm: Optional[torch.Tensor] = None, train: bool = True,
-                 slack: Optional[float] = None, one_sided: Optional[bool] = None):
+                 slack: Optional[float] = None, one_sided: Optional[bool] = None, binary_masks: bool = False):
         """one_sided (default: NRX_SHARD_ONE_SIDED = 1 | 0, else on for plans without an FM epilogue): ONE-SIDED PLACEMENT of the forward -- the
         sample positions travel with the owner ids and the owner's gather (nrx_gather_place_feat) writes every row straight into its place in the
         requester's concat, which every rank maps once (hipIpc through torch's CUDA-IPC sharing; over xGMI a peer mapping): no row buffer, no
         row all-to-all, no final un-permuting launch for those features; a small collective behind the launches is the completion fence.
-        The backward is the same either way (its slot map comes from the same routing launch)."""
+        The backward is the same either way (its slot map comes from the same routing launch).
+        binary_masks: the caller's promise that every bag's non-zero weights are equal (DataReader's 0/1 masks,
+        src/dataset/DataReader/data_reader.py:96-109; always true for mean pooling): the pooled channel's backward then never expands the owner's
+        entries into rows -- the requester sends the sample gradients pre-multiplied by the sample's weight, the owner's plan is rewritten to name
+        those rows (nrx_pool_order_remap) and the walk reads a [world * n * B, dim] block that stays in the L2 (the single-GPU bag backward's
+        form).  False (default): the general form (nrx_pool_inbox_expand: any weights)."""
         import os
         self.lib = _lib.load()
         self.eng = eng
         self.feats = list(feats)
+        self.binary_masks = bool(binary_masks)
         W = eng.world
         self.keep = [inputs, weights, arenas]
         groups, pooled = eng.plan_groups(feats)
@@ -287,12 +293,24 @@ class PreparedShardedStep:
                 g_send = torch.empty((W, n * B, D), dtype=torch.float32, device=g["dev"])
                 g_recv = g_send if W == 1 else torch.empty_like(g_send)
                 oid = torch.zeros(W * cap, dtype=torch.int32, device=g["dev"])
-                rows = torch.zeros((W * cap, D), dtype=torch.float32, device=g["dev"])
                 # the owner's pseudo-batch: ONE single-valued feature of W * cap pseudo-lookups over the arena (never run forward: a descriptor)
                 pfwd = ops.PreparedEmbed(ops.EmbedPlan([ops.Slot(g["table_names"][0], NRX_SPARSE, 0, D, 0, 0)], out_width=D), [arena], [oid], [None],
                                          need_out=False)
-                self.bwd.append(dict(pooled=True, g_send=g_send, g_recv=g_recv, oid=oid, rows=rows, owner=ops.PreparedSparseBackward(pfwd, rows),
-                                     cols=[plan.slots[i].out_col for i in g["idxs"]]))
+                b = dict(pooled=True, g_send=g_send, g_recv=g_recv, oid=oid, cols=[plan.slots[i].out_col for i in g["idxs"]], binary=self.binary_masks)
+                if self.binary_masks:
+                    # the upstream rows ARE the received block [W * n * B, D] (pre-scaled by the requester); order[] is rewritten to name its rows
+                    b["rows"] = None
+
+                    def remap(stream, g=g, b=b, lib=lib, W=W):
+                        og = b["owner"].groups[0]
+                        ops.check(lib.nrx_pool_order_remap(og["order"].data_ptr(), W * g["cap"], g["inbox_tag"].data_ptr(), g["cap"], g["n"] * g["B"], W,
+                                                           stream), "nrx_pool_order_remap")
+                    b["owner"] = ops.PreparedSparseBackward(pfwd, g_recv.view(-1, D), place_feats=0, post_plan=remap)
+                else:
+                    b["rows"] = torch.zeros((W * cap, D), dtype=torch.float32, device=g["dev"])
+                    b["owner"] = ops.PreparedSparseBackward(pfwd, b["rows"])
+                b["owner"].groups[0]["arr"][0].rows = arena.shape[0]      # (the reduction picks its long-row threshold by lookups per table row)
+                self.bwd.append(b)
                 continue
             n, D, Bp = g["n"], g["D"], g["Bp"]
             sub = ops.EmbedPlan([plan.slots[i] for i in g["idxs"]], out_width=plan.out_width, wide_width=plan.wide_width)
@@ -327,12 +345,15 @@ class PreparedShardedStep:
                 n, D, B = g["n"], g["D"], g["B"]
                 v = b["g_send"].view(W, n, B, D)
                 for k, col in enumerate(b["cols"]):
-                    v[:, k].copy_(self.g_out[:, col:col + D].unsqueeze(0).expand(W, B, D))
+                    src = self.g_out[:, col:col + D]
+                    if b["binary"]:       # every live entry of a sample carries the same normalised weight: the largest of its row (0 for an empty bag)
+                        src = src * g["wn"][k].amax(dim=1, keepdim=True)
+                    v[:, k].copy_(src.unsqueeze(0).expand(W, B, D))
                 if W > 1:
                     eng._a2a(b["g_recv"].view(-1), b["g_send"].view(-1))
                 rc = lib.nrx_pool_inbox_expand(g["tables"][0].shape[0] - 1, n, B, W, g["cap"], g["recv2d"].data_ptr(), g["inbox"].data_ptr(),
                                                g["inbox_tag"].data_ptr(), g["inbox_w"].data_ptr(), D, b["g_recv"].data_ptr(), int(eng.rank == 0),
-                                               b["oid"].data_ptr(), b["rows"].data_ptr(), stream)
+                                               b["oid"].data_ptr(), None if b["binary"] else b["rows"].data_ptr(), stream)
                 if rc:
                     ops.check(rc, "nrx_pool_inbox_expand")
                 for og in b["owner"].run():

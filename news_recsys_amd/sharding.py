@@ -1103,7 +1103,9 @@ class ShardedBenchPath:
             from .shard_step import PreparedShardedStep
             tabs = {n: self.arenas.get(n, t) for n, t in self.tables.items()}
             # (the first two calls are bound in training form -- they also leave the FM field sums the backward folds in; train_setup binds their backward)
-            self.calls = [PreparedShardedStep(self.eng, self.feats, ins, ws, tabs, out=out, fm=fmb, train=(k < 2))
+            # (binary_masks: the synthetic masks are all ones, as DataReader's are 0/1 -- NRX_SHARD_BINARY_MASKS=0 takes the general expansion)
+            self.calls = [PreparedShardedStep(self.eng, self.feats, ins, ws, tabs, out=out, fm=fmb, train=(k < 2),
+                                              binary_masks=os.environ.get("NRX_SHARD_BINARY_MASKS", "1") != "0")
                           for k, (ins, ws) in enumerate(self.pool)]
             return
         overlap = os.environ.get("NRX_SHARD_NO_OVERLAP") is None            # measurement knob: time the serial form

@@ -314,8 +314,9 @@ def _dense_from_entries(entries, arenas, world=1, rank=0):
     return out
 
 
+@pytest.mark.parametrize("binary", [False, True])
 @pytest.mark.parametrize("kind", [NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN])
-def test_world_1_tower_with_a_history_bag_against_the_direct_path(kind):
+def test_world_1_tower_with_a_history_bag_against_the_direct_path(kind, binary):
     """The DSSM tower (recall/DSSM/model.py:148-180): item_id + a history bag sharing the news table + user_id.  The bag goes through the pooled
     channel (owner-side partial pooling); its bound backward expands the owner's inbox into pseudo-lookups and reduces them with the planned
     reduction.  Forward: single-valued columns bit for bit, the pooled columns to rtol 1e-6 (the partial-sum order differs); gradient: per
@@ -335,7 +336,8 @@ def test_world_1_tower_with_a_history_bag_against_the_direct_path(kind):
     weights = [None, torch.from_numpy(mask).to(DEV) if kind == NRX_BAG_MASKED_MEAN else None, None]
     g_out = torch.randn((B, 3 * D), device=DEV, generator=gen)
     eng = RowShardedEmbedding(0, 1, overflow_policy="defer")
-    step = shard_step.PreparedShardedStep(eng, feats, inputs, weights, arenas).bind_backward(g_out)
+    # binary: the masks here are 0/1 (DataReader's): the pooled backward may skip the expansion (pre-scaled sample rows + nrx_pool_order_remap)
+    step = shard_step.PreparedShardedStep(eng, feats, inputs, weights, arenas, binary_masks=binary).bind_backward(g_out)
     assert [g["pooled"] for g in step.groups].count(True) == 1
     runs = []
     for _ in range(2):

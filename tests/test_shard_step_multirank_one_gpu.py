@@ -169,7 +169,7 @@ def _tower_batch(rank, B, L, news, users):
     return rng.integers(0, news, B), hist, mask, rng.integers(1, users, B), rng.standard_normal((B, 48)).astype(np.float32)
 
 
-def _tower_worker(rank, world, port, q):
+def _tower_worker(rank, world, port, q, binary):
     import os
     from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -188,7 +188,7 @@ def _tower_worker(rank, world, port, q):
         inputs = [torch.from_numpy(item).to(DEV), torch.from_numpy(hist).to(DEV), torch.from_numpy(user).to(DEV)]
         weights = [None, torch.from_numpy(mask).to(DEV), None]
         eng = RowShardedEmbedding(rank, world, slack=0.5, host_staged=True, overflow_policy="defer")
-        step = shard_step.PreparedShardedStep(eng, feats, inputs, weights, arenas, one_sided=False).bind_backward(torch.from_numpy(up).to(DEV))
+        step = shard_step.PreparedShardedStep(eng, feats, inputs, weights, arenas, one_sided=False, binary_masks=binary).bind_backward(torch.from_numpy(up).to(DEV))
         res = []
         for _ in range(2):
             out, _, _ = step.run()
@@ -208,8 +208,8 @@ def _tower_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_tower_with_a_pooled_history_bag(world):
+@pytest.mark.parametrize("world,binary", [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_tower_with_a_pooled_history_bag(world, binary):
     """The DSSM tower at world 2 / 3: the history bag is pooled at the owners (forward) and its gradient comes back as row-sparse (keys, values)
     from the owners' planned reduction (backward).  Against the direct path on the concatenated batch: single-valued columns bit for bit, the
     pooled columns rtol 1e-6; per (table, global row) the sum over ranks and lists equals the direct gradient to fp32 summation tolerance; two
@@ -218,7 +218,7 @@ def test_sharded_tower_with_a_pooled_history_bag(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_tower_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_tower_worker, args=(r, world, port, q, binary)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
