@@ -153,7 +153,7 @@ def self_launch(args, argv: list) -> int:
                 except ValueError:
                     continue
         if sec is not None:
-            for k in ("other_layout", "strong_scaling", "a2a", "secondary_note"):
+            for k in ("other_layout", "strong_scaling", "a2a", "fwd_bwd", "secondary_note"):
                 if k in sec:
                     head[k] = sec[k]
         if rc2 != 0 or sec is None:

@@ -260,6 +260,11 @@ NRX_API int nrx_sparse_plan_lds(const void* const* ids, const int64_t* lens, con
  * forward + backward -- so the Python layer leaves it off; it is the one-kernel planner's plan form made available from the sorted one.) */
 #define NRX_PLAN_SPLIT_PADDING 1u
 #define NRX_PLAN_PAIRS 2u
+/* NRX_PLAN_PAYLOAD (alone; place_feats = 0 or no placement outputs): `pairs` is read as `const uint32_t* payload` [n] and order[] lists
+ * payload[p] where it would list the lookup p -- same unique rows, segments and counts.  For callers whose reduction fetches a lookup's upstream
+ * row somewhere else than at its own position (the sharded step's pooled channel: an owner's inbox entry names the row of its (source, sample)
+ * in a block of sample gradients).  Served by the table-segmented sort (<= 64 tables); else NRX_ERR_UNSUPPORTED. */
+#define NRX_PLAN_PAYLOAD 4u
 NRX_API int nrx_sparse_plan_ex(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
                                int32_t n_feats, int32_t index_bits, int32_t n_tables, uint64_t place_feats, uint32_t flags, int64_t* order,
                                int64_t* uniq_keys, int64_t* seg_start, int64_t* counts, int32_t* dest, int32_t* walk, int64_t* n_walk,
@@ -696,6 +701,12 @@ NRX_API int nrx_pool_inbox_expand(int64_t table_rows, int32_t n_feats, int64_t b
  * source instead of a [world * cap, dim] array of expanded rows: the walk reads an L2-resident array, as the single-GPU bag backward does).
  * The per-entry weight must already be IN the block: exact when all non-zero weights of a sample are equal (DataReader's 0/1 masks,
  * src/dataset/DataReader/data_reader.py:96-109; mean pooling) -- the requester then sends g * w_sample; else use the expansion. */
+/* The owner ids of nrx_pool_inbox_expand alone (one thread per entry) and, optionally, every entry's payload for
+ * nrx_sparse_plan_ex(NRX_PLAN_PAYLOAD): payload[e] = s * n_feats * batch + inbox_tag[e] (0 for the entries that are nothing) -- the plan's order[]
+ * then names the rows of the block of sample gradients directly and nrx_pool_order_remap is not needed. */
+NRX_API int nrx_pool_inbox_owner_ids(int64_t table_rows, int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
+                             const int32_t* inbox_rows, const int32_t* inbox_tag, int32_t skip_row0, int32_t* owner_ids, uint32_t* payload,
+                             void* stream);
 NRX_API int nrx_pool_order_remap(int64_t* order, int64_t n_entries, const int32_t* inbox_tag, int64_t cap, int64_t n_tags, int32_t world, void* stream);
 /* Expands a CSR batch of an array feature (values[offsets[b] .. offsets[b+1]), offsets relative to the
  * batch, device int64[batch+1]) into the reference's padded form: ids [batch, bag_len] (0-padded,

@@ -28,6 +28,7 @@ NRX_ERR_LAUNCH = -2
 NRX_ERR_UNSUPPORTED = -3
 NRX_PLAN_SPLIT_PADDING = 1          # nrx_sparse_plan_ex flags
 NRX_PLAN_PAIRS = 2
+NRX_PLAN_PAYLOAD = 4
 
 # enum nrx_feature_kind
 NRX_SPARSE, NRX_DENSE, NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM = 0, 1, 2, 3, 4
@@ -120,6 +121,7 @@ SIGNATURES = {
     "nrx_route_feat": (C.c_int, [C.POINTER(_p), _i32, _i64, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "nrx_inbox_transpose": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i64, _p]),
     "nrx_pool_inbox_expand": (C.c_int, [_i64, _i32, _i64, _i32, _i64, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p]),
+    "nrx_pool_inbox_owner_ids": (C.c_int, [_i64, _i32, _i64, _i32, _i64, _p, _p, _p, _i32, _p, _p, _p]),
     "nrx_pool_order_remap": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p]),
     "nrx_gather_place_feat": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), C.POINTER(_i32), _i32, _i32, _i64, _p, _p, _i32, C.POINTER(_p), _i64, _i64, _p, _p]),
     "nrx_embed_bwd_scatter": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _i32, _p, _i64, _p, _i64, C.POINTER(NrxFmGrad), _p, _p, _p]),

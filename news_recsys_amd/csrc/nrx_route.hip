@@ -1105,6 +1105,28 @@ extern "C" int nrx_pool_inbox_bwd(float* const* grad_tables, const int64_t* tabl
     return NRX_OK;
 }
 
+// The owner ids alone, one thread per entry, and -- optionally -- every entry's PAYLOAD for nrx_sparse_plan_ex(NRX_PLAN_PAYLOAD): the row
+// s * n_tags + tag of the [world * n_tags, dim] block of sample gradients its upstream row is.
+__global__ __launch_bounds__(NRX_BLOCK) void pool_owner_ids_kernel(const PoolArgs args_in_kernarg, int32_t* __restrict__ owner_ids, uint32_t* __restrict__ payload) {
+    const NRX_CONST PoolArgs* a = nrx_kernarg<PoolArgs>();
+    const int s = blockIdx.y;
+    const int64_t total = pool_block_total(a, s);
+    const int64_t n_tags = (int64_t)a->n_feats * a->batch;
+    for (int64_t j = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x; j < a->cap; j += (int64_t)gridDim.x * NRX_BLOCK) {
+        const int64_t e = (int64_t)s * a->cap + j;
+        int32_t id = 0;
+        uint32_t pv = 0;
+        if (j < total) {
+            const int32_t tag = nrx_gconst<int32_t>(a->inbox_tag)[e];
+            const int32_t row = nrx_gconst<int32_t>(a->inbox_rows)[e];
+            const bool live = (uint32_t)row < (uint64_t)a->rows[0] && !(a->skip_row0 && row == 0) && (uint32_t)tag < (uint64_t)n_tags;
+            if (live) { id = row + 1; pv = (uint32_t)((int64_t)s * n_tags + tag); }
+        }
+        owner_ids[e] = id;
+        if (payload != nullptr) payload[e] = pv;
+    }
+}
+
 // order[i] names an inbox entry e = s * cap + j; what the reduction wants to fetch for it is the upstream row of its (source, tag): row
 // s * n_tags + tag[e] of the [world * n_tags, dim] block of (pre-scaled) sample gradients.  In place.
 __global__ __launch_bounds__(NRX_BLOCK) void pool_order_remap_kernel(int64_t* __restrict__ order, int64_t n, const int32_t* __restrict__ tag, int64_t cap,
@@ -1118,6 +1140,28 @@ __global__ __launch_bounds__(NRX_BLOCK) void pool_order_remap_kernel(int64_t* __
         }
         order[i] = r < limit ? r : 0;
     }
+}
+
+extern "C" int nrx_pool_inbox_owner_ids(int64_t table_rows, int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
+                                        const int32_t* inbox_rows, const int32_t* inbox_tag, int32_t skip_row0, int32_t* owner_ids, uint32_t* payload,
+                                        void* stream) {
+    NRX_TRACE();
+    PoolArgs a;
+    NRX_REQUIRE(owner_ids != nullptr, "nrx_pool_inbox_owner_ids: null owner_ids");
+    float* dummy_table = reinterpret_cast<float*>(owner_ids);      // (fill_pool_args wants a table pointer and a weight array: never dereferenced here)
+    int32_t ft[NRX_MAX_FEATURES];
+    for (int f = 0; f < NRX_MAX_FEATURES; ++f) ft[f] = 0;
+    int rc = fill_pool_args(a, &dummy_table, &table_rows, 1, ft, n_feats, batch, world, cap, recv2d, inbox_rows, inbox_tag,
+                            reinterpret_cast<const float*>(inbox_tag), 4, "nrx_pool_inbox_owner_ids");
+    if (rc != NRX_OK) return rc;
+    a.partial = nullptr;
+    a.status = nullptr;
+    a.skip_row0 = skip_row0;
+    int64_t bx = (cap + NRX_BLOCK - 1) / NRX_BLOCK;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(pool_owner_ids_kernel, dim3((unsigned)bx, (unsigned)world), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), a, owner_ids, payload);
+    NRX_LAUNCH_CHECK("nrx_pool_inbox_owner_ids");
+    return NRX_OK;
 }
 
 extern "C" int nrx_pool_order_remap(int64_t* order, int64_t n_entries, const int32_t* inbox_tag, int64_t cap, int64_t n_tags, int32_t world, void* stream) {

@@ -426,6 +426,7 @@ struct SegArgs {
     int32_t final_b;                                  // the buffer that holds the sorted pairs after the last pass: 0 = first, 1 = second
     uint32_t* seg_lo;                                 // [n_seg]: padding lookups of the segment (null: no split, every pass sorts whole segments)
     uint32_t* padcnt;                                 // [tiles]: padding lookups per input tile
+    const uint32_t* payload_src;                      // NRX_PLAN_PAYLOAD: the sorted payload of lookup p is payload_src[p] instead of p (null: p)
 };
 static_assert(sizeof(SegArgs) <= 3584, "kernarg budget");
 __device__ __forceinline__ int seg_db_of(const NRX_CONST SegArgs* a, int seg) {                 // seg wave-uniform: scalar loads and shifts
@@ -543,10 +544,12 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
             if (q < qend) {
                 int64_t v = id[j];
                 if (v < 0 || v >= rows) v = 0;            // out-of-range ids were reported by the forward; the padding row never trains
-                if (PAIR) reinterpret_cast<uint2*>(keys)[q] = make_uint2((uint32_t)(tkey | (KeyT)v), (uint32_t)(pbase + j * SEG_THREADS + threadIdx.x));
+                uint32_t pv = (uint32_t)(pbase + j * SEG_THREADS + threadIdx.x);
+                if (a->payload_src != nullptr) pv = a->payload_src[pv];
+                if (PAIR) reinterpret_cast<uint2*>(keys)[q] = make_uint2((uint32_t)(tkey | (KeyT)v), pv);
                 else {
                     keys[q] = tkey | (KeyT)v;
-                    payload[q] = (uint32_t)(pbase + j * SEG_THREADS + threadIdx.x);
+                    payload[q] = pv;
                 }
                 atomicAdd(&s_hist[(uint32_t)(v >> hshift) & dmask], 1u);
             }
@@ -560,10 +563,12 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_keys_kernel(const SegArgs arg
             int64_t v = id[j];
             if (v < 0 || v >= a->rows[s]) v = 0;
             const KeyT tk = a->segkey ? (KeyT)0 : (KeyT)((KeyT)seg_table_of(a, s) << a->row_bits);
-            if (PAIR) reinterpret_cast<uint2*>(keys)[q] = make_uint2((uint32_t)(tk | (KeyT)v), (uint32_t)(a->poff[s] + (q - a->qoff[s])));
+            uint32_t pv = (uint32_t)(a->poff[s] + (q - a->qoff[s]));
+            if (a->payload_src != nullptr) pv = a->payload_src[pv];
+            if (PAIR) reinterpret_cast<uint2*>(keys)[q] = make_uint2((uint32_t)(tk | (KeyT)v), pv);
             else {
                 keys[q] = tk | (KeyT)v;
-                payload[q] = (uint32_t)(a->poff[s] + (q - a->qoff[s]));
+                payload[q] = pv;
             }
             atomicAdd(&s_hist[(uint32_t)(v >> hshift) & dmask], 1u);
         }
@@ -1285,7 +1290,8 @@ extern "C" int64_t nrx_sparse_plan_workspace(int64_t n_lookups) {
 static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const int32_t* table_of, const int64_t* rows,
                             int32_t n_feats, int32_t index_bits, int32_t n_tables, int64_t* order, int64_t* uniq_keys,
                             int64_t* seg_start, int64_t* counts, uint64_t place_feats, int32_t* dest, int32_t* walk, int64_t* n_walk,
-                            void* workspace, void* stream, uint32_t opt_flags = 0, int32_t* pairs_out = nullptr, int64_t* n_pairs_out = nullptr) {
+                            void* workspace, void* stream, uint32_t opt_flags = 0, int32_t* pairs_out = nullptr, int64_t* n_pairs_out = nullptr,
+                            const uint32_t* payload_src = nullptr) {
     NRX_REQUIRE(n_feats >= 0 && n_feats <= NRX_MAX_FEATURES && (index_bits == 32 || index_bits == 64) && n_tables >= 1 && n_tables < (1 << 20),
                 "nrx_sparse_plan: bad argument");
     NRX_REQUIRE(counts != nullptr, "nrx_sparse_plan: null counts");
@@ -1350,8 +1356,13 @@ static int sparse_plan_impl(const void* const* ids, const int64_t* lens, const i
     // ---- default: table-segmented LSD sort (see the kernels' header); NRX_PLAN_SORT=rocprim forces the library sort
     const char* sort_env = getenv("NRX_PLAN_SORT");              // read per call: tests switch it between calls
     const bool force_rocprim = sort_env && !strcmp(sort_env, "rocprim");
+    if (payload_src != nullptr && (force_rocprim || n_tables > NRX_MAX_FEATURES)) {
+        nrx_set_error("nrx_sparse_plan_ex: NRX_PLAN_PAYLOAD is served by the table-segmented sort only (<= %d tables, NRX_PLAN_SORT != rocprim)", NRX_MAX_FEATURES);
+        return NRX_ERR_UNSUPPORTED;
+    }
     if (!force_rocprim && n_tables <= NRX_MAX_FEATURES) {
         SegArgs sa;
+        sa.payload_src = payload_src;
         memset(sa.table_w, 0, sizeof(sa.table_w));
         memset(sa.seg_db_w, 0, sizeof(sa.seg_db_w));
         const bool force_bins = sort_env && !strcmp(sort_env, "segmented-bins");      // tests: the seg_scan_bins path of very long segments
@@ -1616,7 +1627,13 @@ extern "C" int nrx_sparse_plan_ex(const void* const* ids, const int64_t* lens, c
     NRX_TRACE();
     NRX_REQUIRE((dest != nullptr) == (walk != nullptr) && (dest != nullptr) == (n_walk != nullptr),
                 "nrx_sparse_plan_ex: dest, walk and n_walk go together (all null: the plan without placement)");
-    NRX_REQUIRE((flags & ~(uint32_t)(NRX_PLAN_SPLIT_PADDING | NRX_PLAN_PAIRS)) == 0, "nrx_sparse_plan_ex: unknown flag");
+    NRX_REQUIRE((flags & ~(uint32_t)(NRX_PLAN_SPLIT_PADDING | NRX_PLAN_PAIRS | NRX_PLAN_PAYLOAD)) == 0, "nrx_sparse_plan_ex: unknown flag");
+    const uint32_t* payload_src = nullptr;
+    if (flags & NRX_PLAN_PAYLOAD) {
+        NRX_REQUIRE(flags == NRX_PLAN_PAYLOAD && pairs != nullptr && (dest == nullptr || place_feats == 0),
+                    "nrx_sparse_plan_ex: NRX_PLAN_PAYLOAD goes alone, with the payload array in `pairs` and nothing placeable (place_feats = 0)");
+        payload_src = reinterpret_cast<const uint32_t*>(pairs);
+    }
     if (flags & NRX_PLAN_PAIRS) {
         NRX_REQUIRE(dest != nullptr && pairs != nullptr && n_pairs != nullptr && nrx_aligned16(pairs),
                     "nrx_sparse_plan_ex: NRX_PLAN_PAIRS needs the placement outputs, pairs (16-byte aligned) and n_pairs");
@@ -1626,7 +1643,7 @@ extern "C" int nrx_sparse_plan_ex(const void* const* ids, const int64_t* lens, c
     const bool wp = (flags & NRX_PLAN_PAIRS) != 0;
     const int rc = sparse_plan_impl(ids, lens, table_of, rows, n_feats, index_bits, n_tables, order, uniq_keys, seg_start, counts,
                                     dest != nullptr ? place_feats : 0, dest, walk, n_walk, workspace, stream, flags & NRX_PLAN_SPLIT_PADDING,
-                                    wp ? pairs : nullptr, wp ? n_pairs : nullptr);
+                                    wp ? pairs : nullptr, wp ? n_pairs : nullptr, payload_src);
     if (rc != NRX_OK || stats == nullptr) return rc;
     int64_t n = 0;
     for (int f = 0; f < n_feats; ++f) n += lens[f];

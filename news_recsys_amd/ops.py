@@ -1545,13 +1545,17 @@ class PreparedSparseBackward:
     a dict(dim, uniq, values, counts, cap) exactly like an ops.SparseGradSink entry.  No autograd, no host reads."""
 
     def __init__(self, fwd: PreparedEmbed, g_out: Optional[torch.Tensor], g_fm: Optional[torch.Tensor] = None,
-                 g_wide: Optional[torch.Tensor] = None, place_feats: Optional[int] = None, post_plan=None):
+                 g_wide: Optional[torch.Tensor] = None, place_feats: Optional[int] = None, post_plan=None, payload: Optional[torch.Tensor] = None):
         """place_feats (optional): the placement mask instead of place_mask()'s -- 0 = a placement plan in which nothing is placeable: every row
         is listed and walked, two rows x four entries per pass (the form for launches whose rows are all looked up many times), no placement
         pass, and the plan always comes from the sorted planner.  post_plan (optional): callable(stream) enqueued between the plan and the
         reduction (the sharded step's pooled channel rewrites order[] there: nrx_pool_order_remap)."""
         self.lib, self.fwd, plan = fwd.lib, fwd, fwd.plan
         self.post_plan = post_plan
+        # payload (int32 / uint32 [lookups], with place_feats = 0): nrx_sparse_plan_ex(NRX_PLAN_PAYLOAD) -- order[] lists payload[p] instead of p
+        if payload is not None and (place_feats != 0 or payload.dtype not in (torch.int32, torch.uint32) or not payload.is_contiguous()):
+            raise ValueError("PreparedSparseBackward: payload needs place_feats=0 and a contiguous 32-bit tensor")
+        self.payload = payload
         if not fwd.single:
             raise ValueError("PreparedSparseBackward covers plans of <= 64 features")
         self.g_out = None if g_out is None else _f32c(g_out, "g_out")
@@ -1624,7 +1628,12 @@ class PreparedSparseBackward:
                         continue
                     if rc != NRX_ERR_UNSUPPORTED:
                         check(rc, "nrx_sparse_plan_lds")
-            if PLAN_PAIRS and g.get("pair_recs") is not None and g.get("sorted_pairs", True) and g["pmask"] == (1 << g["n"]) - 1:
+            if self.payload is not None:
+                rc = lib.nrx_sparse_plan_ex(g["ptrs"], g["lens"], g["tof"], g["rws"], g["n"], g["bits"], g["n_tables"], 0, _lib.NRX_PLAN_PAYLOAD,
+                                            g["order"].data_ptr(), g["uniq"].data_ptr(), g["seg"].data_ptr(), g["counts"].data_ptr(),
+                                            g["dest"].data_ptr(), g["walk"].data_ptr(), g["n_walk"].data_ptr(), self.payload.data_ptr(), None, None,
+                                            g["ws"].data_ptr(), stream)
+            elif PLAN_PAIRS and g.get("pair_recs") is not None and g.get("sorted_pairs", True) and g["pmask"] == (1 << g["n"]) - 1:
                 rc = lib.nrx_sparse_plan_ex(g["ptrs"], g["lens"], g["tof"], g["rws"], g["n"], g["bits"], g["n_tables"], g["pmask"], NRX_PLAN_PAIRS,
                                             g["order"].data_ptr(), g["uniq"].data_ptr(), g["seg"].data_ptr(), g["counts"].data_ptr(),
                                             g["dest"].data_ptr(), g["walk"].data_ptr(), g["n_walk"].data_ptr(), g["pair_recs"].data_ptr(),

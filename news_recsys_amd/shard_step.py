@@ -77,8 +77,8 @@ class PreparedShardedStep:
         The backward is the same either way (its slot map comes from the same routing launch).
         binary_masks: the caller's promise that every bag's non-zero weights are equal (DataReader's 0/1 masks,
         src/dataset/DataReader/data_reader.py:96-109; always true for mean pooling): the pooled channel's backward then never expands the owner's
-        entries into rows -- the requester sends the sample gradients pre-multiplied by the sample's weight, the owner's plan is rewritten to name
-        those rows (nrx_pool_order_remap) and the walk reads a [world * n * B, dim] block that stays in the L2 (the single-GPU bag backward's
+        entries into rows -- the requester sends the sample gradients pre-multiplied by the sample's weight, the owner's plan lists those rows
+        directly (nrx_sparse_plan_ex with NRX_PLAN_PAYLOAD) and the walk reads a [world * n * B, dim] block that stays in the L2 (the single-GPU bag backward's
         form).  False (default): the general form (nrx_pool_inbox_expand: any weights)."""
         import os
         self.lib = _lib.load()
@@ -300,12 +300,8 @@ class PreparedShardedStep:
                 if self.binary_masks:
                     # the upstream rows ARE the received block [W * n * B, D] (pre-scaled by the requester); order[] is rewritten to name its rows
                     b["rows"] = None
-
-                    def remap(stream, g=g, b=b, lib=lib, W=W):
-                        og = b["owner"].groups[0]
-                        ops.check(lib.nrx_pool_order_remap(og["order"].data_ptr(), W * g["cap"], g["inbox_tag"].data_ptr(), g["cap"], g["n"] * g["B"], W,
-                                                           stream), "nrx_pool_order_remap")
-                    b["owner"] = ops.PreparedSparseBackward(pfwd, g_recv.view(-1, D), place_feats=0, post_plan=remap)
+                    b["payload"] = torch.zeros(W * cap, dtype=torch.int32, device=g["dev"])
+                    b["owner"] = ops.PreparedSparseBackward(pfwd, g_recv.view(-1, D), place_feats=0, payload=b["payload"])
                 else:
                     b["rows"] = torch.zeros((W * cap, D), dtype=torch.float32, device=g["dev"])
                     b["owner"] = ops.PreparedSparseBackward(pfwd, b["rows"])
@@ -351,9 +347,13 @@ class PreparedShardedStep:
                     v[:, k].copy_(src.unsqueeze(0).expand(W, B, D))
                 if W > 1:
                     eng._a2a(b["g_recv"].view(-1), b["g_send"].view(-1))
-                rc = lib.nrx_pool_inbox_expand(g["tables"][0].shape[0] - 1, n, B, W, g["cap"], g["recv2d"].data_ptr(), g["inbox"].data_ptr(),
-                                               g["inbox_tag"].data_ptr(), g["inbox_w"].data_ptr(), D, b["g_recv"].data_ptr(), int(eng.rank == 0),
-                                               b["oid"].data_ptr(), None if b["binary"] else b["rows"].data_ptr(), stream)
+                if b["binary"]:
+                    rc = lib.nrx_pool_inbox_owner_ids(g["tables"][0].shape[0] - 1, n, B, W, g["cap"], g["recv2d"].data_ptr(), g["inbox"].data_ptr(),
+                                                      g["inbox_tag"].data_ptr(), int(eng.rank == 0), b["oid"].data_ptr(), b["payload"].data_ptr(), stream)
+                else:
+                    rc = lib.nrx_pool_inbox_expand(g["tables"][0].shape[0] - 1, n, B, W, g["cap"], g["recv2d"].data_ptr(), g["inbox"].data_ptr(),
+                                                   g["inbox_tag"].data_ptr(), g["inbox_w"].data_ptr(), D, b["g_recv"].data_ptr(), int(eng.rank == 0),
+                                                   b["oid"].data_ptr(), b["rows"].data_ptr(), stream)
                 if rc:
                     ops.check(rc, "nrx_pool_inbox_expand")
                 for og in b["owner"].run():

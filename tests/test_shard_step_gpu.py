@@ -373,3 +373,74 @@ def test_world_1_tower_with_a_history_bag_against_the_direct_path(kind, binary):
             np.testing.assert_allclose(got[name][r], v, rtol=1e-5, atol=2e-6 * scale)
         for n in names:
             assert seen[n] == len(got[n])
+
+
+def test_plan_payload_lists_the_payload_of_every_lookup():
+    """nrx_sparse_plan_ex(NRX_PLAN_PAYLOAD): the same plan (unique keys, segments, counts) whose order[] names payload[p] where the plain plan names
+    p -- integer work, bit-exact against payload[order] of the plain plan; and nrx_pool_order_remap applied to the plain plan gives the same list
+    for the pooled channel's payload (s * n_tags + tag)."""
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    for n_feats, lens, rows in ((1, [50_000], [3000]), (3, [7000, 7000, 9000], [500, 40_000, 500]), (2, [4097, 100], [1 << 21, 17])):
+        ids = [torch.from_numpy(rng.integers(0, r, l)).to(DEV).to(torch.int32) for l, r in zip(lens, rows)]
+        tof = list(range(n_feats)) if n_feats != 3 else [0, 1, 0]
+        n_tables = max(tof) + 1
+        total = sum(lens)
+        payload = torch.from_numpy(rng.integers(0, 1 << 20, total).astype(np.int32)).to(DEV)
+
+        def plan(flags, pl):
+            order = torch.empty(total, dtype=torch.int64, device=DEV); uniq = torch.empty(total, dtype=torch.int64, device=DEV)
+            seg = torch.empty(total + 1, dtype=torch.int64, device=DEV); counts = torch.empty(n_tables + 2, dtype=torch.int64, device=DEV)
+            dest = torch.empty(total, dtype=torch.int32, device=DEV); walk = torch.empty(total, dtype=torch.int32, device=DEV)
+            n_walk = torch.empty(2, dtype=torch.int64, device=DEV)
+            ws = torch.empty(lib.nrx_sparse_plan_workspace(total), dtype=torch.uint8, device=DEV)
+            ops.check(lib.nrx_sparse_plan_ex((C.c_void_p * n_feats)(*[x.data_ptr() for x in ids]), (C.c_int64 * n_feats)(*lens), (C.c_int32 * n_feats)(*tof),
+                                             (C.c_int64 * n_feats)(*rows), n_feats, 32, n_tables, 0, flags, order.data_ptr(), uniq.data_ptr(), seg.data_ptr(),
+                                             counts.data_ptr(), dest.data_ptr(), walk.data_ptr(), n_walk.data_ptr(), None if pl is None else pl.data_ptr(), None,
+                                             None, ws.data_ptr(), torch.cuda.current_stream().cuda_stream), "nrx_sparse_plan_ex")
+            torch.cuda.synchronize()
+            return order, uniq, seg, counts, walk, n_walk
+        o0, u0, s0, c0, w0, nw0 = plan(0, None)
+        o1, u1, s1, c1, w1, nw1 = plan(_lib.NRX_PLAN_PAYLOAD, payload)
+        nu = int(c0[0])
+        assert torch.equal(c0, c1) and torch.equal(u0[:nu], u1[:nu]) and torch.equal(s0[:nu + 1], s1[:nu + 1])
+        assert int(nw0[0]) == int(nw1[0]) == nu and torch.equal(w0[:nu], w1[:nu])          # nothing placeable: every row is walked
+        assert torch.equal(o1, payload.long()[o0])
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_pool_owner_ids_payload_and_remap(world):
+    """nrx_pool_inbox_owner_ids / nrx_pool_order_remap against numpy on a routed bag batch (ops.route_bags' inbox layout)."""
+    lib = _lib.load()
+    rng = np.random.default_rng(world)
+    B, L, n, rows_local = 700, 9, 2, 900
+    cap = 12288 if world == 1 else 4096
+    ids = [torch.from_numpy(rng.integers(0, rows_local * world, (B, L))).to(DEV) for _ in range(n)]
+    w = [torch.from_numpy((rng.random((B, L)) < 0.7).astype(np.float32)).to(DEV) for _ in range(n)]
+    send_rows, send_tag, send_w, counts2d, overflow = ops.route_bags(ids, w, world, cap)
+    torch.cuda.synchronize()
+    assert int(overflow.item()) <= cap
+    # (the test plays owner 0 of a symmetric exchange: block s of the inbox = what THIS rank's routing addressed to owner s)
+    recv2d = counts2d.clone()
+    oid = torch.full((world * cap,), -5, dtype=torch.int32, device=DEV)
+    pay = torch.full((world * cap,), -5, dtype=torch.int32, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    for skip in (0, 1):
+        ops.check(lib.nrx_pool_inbox_owner_ids(rows_local, n, B, world, cap, recv2d.data_ptr(), send_rows.data_ptr(), send_tag.data_ptr(), skip,
+                                               oid.data_ptr(), pay.data_ptr(), st), "owner_ids")
+        torch.cuda.synchronize()
+        r, t, c = send_rows.cpu().numpy().reshape(world, cap), send_tag.cpu().numpy().reshape(world, cap), recv2d.cpu().numpy().sum(1)
+        want_id, want_pay = np.zeros((world, cap), np.int32), np.zeros((world, cap), np.int32)
+        for s_ in range(world):
+            k = np.arange(cap) < min(c[s_], cap)
+            live = k & (r[s_] >= 0) & (r[s_] < rows_local) & ~((r[s_] == 0) & bool(skip)) & (t[s_] >= 0) & (t[s_] < n * B)
+            want_id[s_] = np.where(live, r[s_] + 1, 0)
+            want_pay[s_] = np.where(live, s_ * n * B + t[s_], 0)
+        assert np.array_equal(oid.cpu().numpy().reshape(world, cap), want_id) and np.array_equal(pay.cpu().numpy().reshape(world, cap), want_pay)
+    order = torch.from_numpy(rng.permutation(world * cap)).to(DEV)
+    before = order.cpu().numpy()
+    ops.check(lib.nrx_pool_order_remap(order.data_ptr(), world * cap, send_tag.data_ptr(), cap, n * B, world, st), "remap")
+    torch.cuda.synchronize()
+    tg = np.clip(send_tag.cpu().numpy(), None, None)
+    tt = np.where((tg[before] >= 0) & (tg[before] < n * B), tg[before], 0)
+    assert np.array_equal(order.cpu().numpy(), (before // cap) * (n * B) + tt)
