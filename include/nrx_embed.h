@@ -419,6 +419,10 @@ NRX_API int nrx_bag_pool_bwd(const float* g_out, const float* mask, int64_t batc
  * FM.get_inp_embedding + FMModel.forward without bias/sigmoid (fm/model.py:18-26,48-59).       */
 NRX_API int nrx_fm_fwd(const float* feat, int64_t ld, int32_t n_fields, int32_t dim, int64_t batch,
                float* fm_out, void* stream);
+/* Training form of nrx_fm_fwd: also leaves the field sums nrx_embed_fwd_train's epilogue leaves (fm_sums [B, sums_ld]: column k >= 1 sum_f v_fk,
+ * column 0 sum_f w_f; sums_ld >= dim) -- for a concat that was finished by someone else (the owners of a one-sided sharded forward). */
+NRX_API int nrx_fm_fwd_train(const float* feat, int64_t ld, int32_t n_fields, int32_t dim, int64_t batch,
+                     float* fm_out, float* fm_sums, int64_t sums_ld, void* stream);
 /* g_feat[b, :] = (g_in ? g_in[b, :] : 0) + g_fm[b] * d fm / d feat[b, :].  g_in may be g_feat (in place) or another
  * buffer (e.g. the upstream gradient of the concat, left untouched: no copy needed) or NULL.                 */
 NRX_API int nrx_fm_bwd(const float* feat, int64_t ld, int32_t n_fields, int32_t dim, int64_t batch,
@@ -650,6 +654,27 @@ NRX_API int nrx_gather_place_feat(const float* const* tables, const int64_t* tab
 NRX_API int nrx_embed_bwd_scatter(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
                           const float* g_out, int64_t out_ld, const float* g_wide, int64_t wide_ld, const nrx_fm_grad_t* fm,
                           const int32_t* dest, float* values, void* stream);
+/* ---- the sharded backward WITHOUT the owner's placement pass (round 6) ------------------------------------------------------------------
+ * A gradient row whose table row is looked up once in the whole exchange needs no reduction: the requester can write it straight into the owner's
+ * values[u].  The owner plans first (its plan depends on the owner ids only) and the plan's dest[] travels back to the requesters in send_ids'
+ * layout; nrx_shard_dest_combine turns (slot, dest_req) into ONE destination per lookup -- dest_out[p] = (owner << shift) | row of the owner's
+ * gradient ARENA (values rows first; from row recv_row0 on the receive buffer [source][k][f], whose row for this lookup is (rank * capf + k) *
+ * n_feats + f), -1 for a dropped lookup; nrx_embed_bwd_scatter_multi (nrx_embed_bwd_scatter with `bases[owner]` = the owner's arena as this process
+ * maps it: hipIpc / a peer mapping; its own at owner == rank) stores every lookup's upstream row there -- the requester's pack IS the owner's
+ * placement pass -- and nrx_embed_bwd_walk reduces what is left on the owner: the listed rows (and the pair records of an nrx_sparse_plan_lds
+ * plan; pairs / n_pairs NULL for a sorted plan) from the receive buffer, nrx_embed_bwd_placed(_pairs) minus the placement pass: same values bit
+ * for bit.  A collective between the scatter and the walk is the completion fence.  At world 1 the backward is the direct path's: plan, one
+ * placement pass, walk.  NRX_ERR_UNSUPPORTED outside the placement pass's shapes (dim 16 / 32 / 64, aligned operands). */
+NRX_API int nrx_shard_dest_combine(const int32_t* slot, const int32_t* dest_req, int32_t n_feats, int64_t batch, int64_t capf, int64_t recv_row0,
+                           int32_t rank, int32_t world, int32_t shift, int32_t* dest_out, void* stream);
+NRX_API int nrx_embed_bwd_scatter_multi(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                                const float* g_out, int64_t out_ld, const nrx_fm_grad_t* fm, const int32_t* dest,
+                                float* const* bases, int32_t n_bases, int32_t shift, void* stream);
+NRX_API int nrx_embed_bwd_walk(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                       const float* g_out, int64_t out_ld, const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
+                       int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
+                       uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
+                       const int32_t* pairs, const int64_t* n_pairs, void* workspace, int64_t workspace_bytes, void* stream);
 /* Backward of nrx_gather_inbox: grad_tables[..][row] += g_rows[p] over the valid prefixes.        */
 NRX_API int nrx_scatter_add_inbox(float* const* grad_tables, const int64_t* table_rows, int32_t n_tables,
                           const int32_t* feat_table, int32_t n_feats, int32_t world, int64_t cap,

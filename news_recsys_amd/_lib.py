@@ -102,6 +102,7 @@ SIGNATURES = {
     "nrx_bag_pool_fwd": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     "nrx_bag_pool_bwd": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     "nrx_fm_fwd": (C.c_int, [_p, _i64, _i32, _i32, _i64, _p, _p]),
+    "nrx_fm_fwd_train": (C.c_int, [_p, _i64, _i32, _i32, _i64, _p, _p, _i64, _p]),
     "nrx_fm_bwd": (C.c_int, [_p, _i64, _i32, _i32, _i64, _p, _p, _i64, _p, _i64, _p]),
     "nrx_fm_head_fwd": (C.c_int, [_p, _p, _p, _i64, _p]),
     "nrx_fm_head_state_bytes": (_i64, []),
@@ -121,6 +122,10 @@ SIGNATURES = {
     "nrx_route_feat": (C.c_int, [C.POINTER(_p), _i32, _i64, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "nrx_inbox_transpose": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i64, _p]),
     "nrx_pool_inbox_expand": (C.c_int, [_i64, _i32, _i64, _i32, _i64, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p]),
+    "nrx_shard_dest_combine": (C.c_int, [_p, _p, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _p, _p]),
+    "nrx_embed_bwd_scatter_multi": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _i32, _p, _i64, C.POINTER(NrxFmGrad), _p, C.POINTER(_p), _i32, _i32, _p]),
+    "nrx_embed_bwd_walk": (C.c_int, [C.POINTER(NrxFeature), _i32, _i64, _i32, _p, _i64, _p, _p, _p, _i64, _p, C.POINTER(NrxFmGrad), _p,
+                                     C.c_uint64, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "nrx_pool_inbox_owner_ids": (C.c_int, [_i64, _i32, _i64, _i32, _i64, _p, _p, _p, _i32, _p, _p, _p]),
     "nrx_pool_order_remap": (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p]),
     "nrx_gather_place_feat": (C.c_int, [C.POINTER(_p), C.POINTER(_i64), C.POINTER(_i32), _i32, _i32, _i64, _p, _p, _i32, C.POINTER(_p), _i64, _i64, _p, _p]),

@@ -1146,10 +1146,11 @@ struct PlaceArgs {
     int32_t add_to;                      // 1: add to what the table holds (a table fed by a second launch group)
     int32_t stnt;                        // 1: placed rows leave with non-temporal stores (measurement knob NRX_PLACE_STNT)
     uint64_t fm_mask;                    // bit f = fm[f] (the full-line form reads flags of two features per step from here)
+    int32_t multi_shift;                 // MULTI (nrx_embed_bwd_scatter_multi): dest = (base number << multi_shift) | row; the bases live in grad[]
 };
 static_assert(sizeof(PlaceArgs) <= 3584, "kernarg budget");
 
-template <int QLOG2, int U, bool FM, bool UNAL, bool DENSE = false>
+template <int QLOG2, int U, bool FM, bool UNAL, bool DENSE = false, bool MULTI = false>
 __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceArgs args_in_kernarg) {
     const NRX_CONST PlaceArgs* a = nrx_kernarg<PlaceArgs>();
     constexpr int Q = 1 << QLOG2;
@@ -1223,6 +1224,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_place_kernel(const PlaceA
                     acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
                 }
                 nrx_stg4(base, (int64_t)d * Q + q, acc);
+            } else if (MULTI) {     // the row goes to one of several buffers (the owners' arenas, as this process maps them): base number in the high bits
+                float* base = a->grad[(uint32_t)d >> a->multi_shift];
+                nrx_stg4(base, (int64_t)(d & ((1 << a->multi_shift) - 1)) * Q + q, acc);
             } else if (a->stnt) {
                 nrx_f32x4 tv;
                 tv.x = acc.x; tv.y = acc.y; tv.z = acc.z; tv.w = acc.w;
@@ -3232,7 +3236,9 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
                                  bool pairs = false /* the plan is nrx_sparse_plan_lds's: rows looked up twice are finished by embed_bwd_pairs_kernel */,
                                  void* aux_stream = nullptr /* pairs: the pair pass, the walk and the work lists run THERE, next to the placement pass */,
                                  const int32_t* pair_recs = nullptr, const int64_t* n_pairs = nullptr,
-                                 bool place_only = false /* nrx_embed_bwd_scatter: the placement pass alone (dest is the caller's) */) {
+                                 bool place_only = false /* nrx_embed_bwd_scatter: the placement pass alone (dest is the caller's) */,
+                                 float* const* multi_bases = nullptr, int multi_n = 0, int multi_shift = 0 /* place_only into several buffers */,
+                                 bool skip_place = false /* nrx_embed_bwd_walk: the placed rows are in values already (written by the requesters) */) {
     NRX_REQUIRE(feats != nullptr && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES,
                 "nrx_embed_bwd_sorted: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
     NRX_REQUIRE(batch >= 0 && dim >= 1 && n_unique >= 0, "nrx_embed_bwd_sorted: bad argument");
@@ -3368,6 +3374,14 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
         nrx_set_error("nrx_embed_bwd_placed_pairs: the launch is outside the placement pass's shapes (dim 16 / 32 / 64, aligned operands, single-valued features)");
         return NRX_ERR_UNSUPPORTED;
     }
+    if (skip_place && !(placed && !has_bag)) {
+        nrx_set_error("nrx_embed_bwd_walk: the launch is outside the placement plan's shapes (dim 16 / 32 / 64, aligned operands, single-valued features)");
+        return NRX_ERR_UNSUPPORTED;
+    }
+    if (place_only && multi_bases != nullptr && unal) {
+        nrx_set_error("nrx_embed_bwd_scatter_multi: aligned upstream rows only");
+        return NRX_ERR_UNSUPPORTED;
+    }
     if (place_only && !(placed && !has_bag)) {
         nrx_set_error("nrx_embed_bwd_scatter: the launch is outside the placement pass's shapes (dim 16 / 32 / 64, aligned operands, single-valued features)");
         return NRX_ERR_UNSUPPORTED;
@@ -3420,13 +3434,13 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
             // the 16-byte memset node did not take effect on replay (counters kept growing, the list was read past what was written)
             // (placement mode: the placement pass clears them -- one launch less)
             // (launches with bag features: cleared together with the weight-bit words below -- one launch, not two)
-            if (!(placed && n_place > 0) && !has_bag && nrx_zero_async(a.long_ws, 16, st) != NRX_OK) return NRX_ERR_LAUNCH;
+            if ((!(placed && n_place > 0) || skip_place) && !has_bag && nrx_zero_async(a.long_ws, 16, st) != NRX_OK) return NRX_ERR_LAUNCH;
             const bool side_zero = pairs && placed && n_place > 0 && aux_stream != nullptr && aux_stream != stream;      // (side-stream mode: the placement pass
             if (side_zero && nrx_zero_async(a.long_ws, 16, reinterpret_cast<hipStream_t>(aux_stream)) != NRX_OK) return NRX_ERR_LAUNCH;      //  runs elsewhere: the counters are cleared on the walk's stream)
         }
         const bool side_mode = pairs && aux_stream != nullptr && aux_stream != stream;
         auto launch_place = [&]() {
-        if (placed && n_place > 0) {
+        if (placed && n_place > 0 && !skip_place) {
             pa.batch = batch;
             pa.g_out = g_out; pa.out_ld = out_ld; pa.g_wide = g_wide; pa.wide_ld = wide_ld;
             pa.g_fm = a.g_fm; pa.fm_sums = a.fm_sums; pa.sums_ld = a.sums_ld; pa.feat = a.feat; pa.feat_ld = a.feat_ld;
@@ -3451,6 +3465,20 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
                 if ((i & 1) == 0 ? (pa.out_col[i] & 31) != 0 : pa.out_col[i] != pa.out_col[i - 1] + 16) lines = false;
             }
             { const char* e = getenv("NRX_PLACE_LINES"); if (e && atoi(e) == 0) lines = false; }
+            pa.multi_shift = 0;
+            if (multi_bases != nullptr) {      // several destination buffers: the one-feature-per-lane-group form carries the base table (in grad[])
+                for (int i = 0; i < multi_n; ++i) pa.grad[i] = multi_bases[i];
+                pa.multi_shift = multi_shift;
+                const unsigned pgrid = (unsigned)((batch + tb - 1) / tb);
+                const size_t plds = (size_t)n_place * tb * 4;
+                if (ql == 2) { if (has_fm) hipLaunchKernelGGL((embed_bwd_place_kernel<2, 4, true, false, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);
+                               else hipLaunchKernelGGL((embed_bwd_place_kernel<2, 4, false, false, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa); }
+                else if (ql == 3) { if (has_fm) hipLaunchKernelGGL((embed_bwd_place_kernel<3, 4, true, false, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);
+                                    else hipLaunchKernelGGL((embed_bwd_place_kernel<3, 4, false, false, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa); }
+                else { if (has_fm) hipLaunchKernelGGL((embed_bwd_place_kernel<4, 4, true, false, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa);
+                       else hipLaunchKernelGGL((embed_bwd_place_kernel<4, 4, false, false, false, true>), dim3(pgrid), dim3(NRX_BLOCK), plds, st, pa); }
+                return;
+            }
             if (lines) {
                 const unsigned lgrid = (unsigned)((batch + 31) / 32);
                 const size_t llds = (size_t)n_place * PLACE_LINES_TBP * 4;
@@ -3922,6 +3950,44 @@ extern "C" int nrx_embed_bwd_scatter(const nrx_feature_t* feats, int32_t n_feats
     return embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, g_wide, wide_ld, dummy, dummy, nullptr, /*n_unique=*/1, nullptr, fm,
                                  values, mask, dest, reinterpret_cast<const int32_t*>(dest), dummy, nullptr, 0, stream, nullptr, 0, 0, false, nullptr,
                                  nullptr, nullptr, /*place_only=*/true);
+}
+
+// nrx_embed_bwd_scatter into SEVERAL buffers: dest[p] = (base number << shift) | row -- the owners' gradient arenas as this process maps them.
+extern "C" int nrx_embed_bwd_scatter_multi(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                                           const float* g_out, int64_t out_ld, const nrx_fm_grad_t* fm, const int32_t* dest,
+                                           float* const* bases, int32_t n_bases, int32_t shift, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(dest != nullptr && bases != nullptr && n_bases >= 1 && n_bases <= NRX_MAX_FEATURES && shift >= 1 && shift <= 30 &&
+                    (int64_t)n_bases <= (1ll << (31 - shift)),
+                "nrx_embed_bwd_scatter_multi: needs dest, 1..%d bases and a shift that leaves the base number below bit 31", NRX_MAX_FEATURES);
+    NRX_REQUIRE(n_feats >= 1 && n_feats <= NRX_MAX_FEATURES, "nrx_embed_bwd_scatter_multi: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
+    for (int i = 0; i < n_feats; ++i)
+        NRX_REQUIRE(feats[i].kind == NRX_SPARSE && feats[i].wide_col < 0, "nrx_embed_bwd_scatter_multi: feature %d is not a plain single-valued feature", i);
+    for (int i = 0; i < n_bases; ++i)
+        NRX_REQUIRE(bases[i] != nullptr && nrx_aligned16(bases[i]), "nrx_embed_bwd_scatter_multi: base %d: null / unaligned", i);
+    const uint64_t mask = n_feats == 64 ? ~0ull : ((1ull << n_feats) - 1ull);
+    const int64_t* dummy = reinterpret_cast<const int64_t*>(dest);
+    return embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, nullptr, 0, dummy, dummy, nullptr, /*n_unique=*/1, nullptr, fm,
+                                 bases[0], mask, dest, reinterpret_cast<const int32_t*>(dest), dummy, nullptr, 0, stream, nullptr, 0, 0, false, nullptr,
+                                 nullptr, nullptr, /*place_only=*/true, bases, n_bases, shift);
+}
+
+// The reduction WITHOUT its placement pass: the rows the plan places (dest >= 0) are in values[] already -- written there by the requesters
+// (nrx_embed_bwd_scatter_multi with dest = the plan's unique index) -- and only the listed rows (and the pair records) are reduced from g_out.
+extern "C" int nrx_embed_bwd_walk(const nrx_feature_t* feats, int32_t n_feats, int64_t batch, int32_t dim,
+                                  const float* g_out, int64_t out_ld, const int64_t* order, const int64_t* seg_start, const int64_t* uniq_keys,
+                                  int64_t n_unique, const int64_t* n_unique_dev, const nrx_fm_grad_t* fm, float* values,
+                                  uint64_t place_feats, const int32_t* dest, const int32_t* walk, const int64_t* n_walk,
+                                  const int32_t* pairs, const int64_t* n_pairs, void* workspace, int64_t workspace_bytes, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(dest != nullptr && walk != nullptr && n_walk != nullptr && uniq_keys != nullptr && values != nullptr && workspace != nullptr,
+                "nrx_embed_bwd_walk: needs the placement plan (dest, walk, n_walk, uniq_keys), values and the work-list workspace");
+    NRX_REQUIRE((pairs == nullptr) == (n_pairs == nullptr) && (pairs == nullptr || nrx_aligned16(pairs)), "nrx_embed_bwd_walk: pairs and n_pairs go together");
+    for (int i = 0; i < n_feats; ++i)
+        NRX_REQUIRE(feats != nullptr && feats[i].kind == NRX_SPARSE, "nrx_embed_bwd_walk: feature %d: single-valued features only", i);
+    return embed_bwd_sorted_impl(feats, n_feats, batch, dim, g_out, out_ld, nullptr, 0, order, seg_start, uniq_keys, n_unique, n_unique_dev, fm, values,
+                                 place_feats, dest, walk, n_walk, workspace, workspace_bytes, stream, nullptr, 0, 0, pairs != nullptr, nullptr, pairs, n_pairs,
+                                 false, nullptr, 0, 0, /*skip_place=*/true);
 }
 
 // nrx_embed_bwd_placed / nrx_embed_bwd_placed_dense for the placement plans of nrx_sparse_plan_lds (pair records for the rows looked up twice).

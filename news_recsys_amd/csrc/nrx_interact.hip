@@ -92,7 +92,8 @@ __device__ __forceinline__ float4 ld4(const float* p, int k0, int D, bool vec) {
 
 template <int QLOG2>
 __global__ __launch_bounds__(NRX_BLOCK) void fm_fwd_kernel(const float* __restrict__ feat, int64_t ld, int F, int D,
-                                                           int64_t batch, float* __restrict__ fm_out, bool vec) {
+                                                           int64_t batch, float* __restrict__ fm_out, bool vec,
+                                                           float* __restrict__ sums = nullptr, int64_t sums_ld = 0) {
     constexpr int Q = 1 << QLOG2;
     constexpr int TB = NRX_BLOCK / Q;
     const int q = threadIdx.x & (Q - 1);
@@ -113,6 +114,14 @@ __global__ __launch_bounds__(NRX_BLOCK) void fm_fwd_kernel(const float* __restri
             }
         }
         total += 0.5f * ((s.x * s.x - sq.x) + (s.y * s.y - sq.y) + (s.z * s.z - sq.z) + (s.w * s.w - sq.w)) + first;
+        if (sums != nullptr && live && k0 < D) {      // training form: the field sums the backward folds in (column 0: sum of the first-order weights)
+            float* dst = sums + b * sums_ld + k0;
+            const float v0 = k0 == 0 ? first : s.x;
+            dst[0] = v0;
+            if (k0 + 1 < D) dst[1] = s.y;
+            if (k0 + 2 < D) dst[2] = s.z;
+            if (k0 + 3 < D) dst[3] = s.w;
+        }
     }
 #pragma unroll
     for (int off = Q / 2; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
@@ -879,6 +888,23 @@ extern "C" int nrx_fm_fwd(const float* feat, int64_t ld, int32_t n_fields, int32
     NRX_QSWITCH(ql, { hipLaunchKernelGGL((fm_fwd_kernel<QL>), dim3(grid), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
                                          feat, ld, n_fields, dim, batch, fm_out, vec); });
     NRX_LAUNCH_CHECK("nrx_fm_fwd");
+    return NRX_OK;
+}
+
+extern "C" int nrx_fm_fwd_train(const float* feat, int64_t ld, int32_t n_fields, int32_t dim, int64_t batch,
+                                float* fm_out, float* fm_sums, int64_t sums_ld, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(feat && fm_out && fm_sums && n_fields >= 1 && dim >= 1 && batch >= 0 && ld >= (int64_t)n_fields * dim && sums_ld >= dim,
+                "nrx_fm_fwd_train: bad argument");
+    if (batch == 0) return NRX_OK;
+    int ql = ceil_log2i((dim + 3) / 4);
+    if (ql > 6) ql = 6;
+    const bool vec = (dim & 3) == 0 && (ld & 3) == 0 && nrx_aligned16(feat);
+    const int tb = NRX_BLOCK >> ql;
+    const unsigned grid = (unsigned)((batch + tb - 1) / tb);
+    NRX_QSWITCH(ql, { hipLaunchKernelGGL((fm_fwd_kernel<QL>), dim3(grid), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
+                                         feat, ld, n_fields, dim, batch, fm_out, vec, fm_sums, sums_ld); });
+    NRX_LAUNCH_CHECK("nrx_fm_fwd_train");
     return NRX_OK;
 }
 

@@ -24,7 +24,10 @@
 namespace {
 
 constexpr int RF_THREADS = 256;
-constexpr int RF_ROUNDS = 16;
+#ifndef NRX_RF_ROUNDS
+#define NRX_RF_ROUNDS 16
+#endif
+constexpr int RF_ROUNDS = NRX_RF_ROUNDS;
 constexpr int RF_TILE = RF_THREADS * RF_ROUNDS;      // 4096 ids per block
 constexpr int RF_WAVES = RF_THREADS / 64;
 constexpr int RF_MAX_WORLD = 64;
@@ -51,6 +54,37 @@ __global__ __launch_bounds__(RF_THREADS) void route_feat_kernel(const RouteFeatA
     __shared__ uint32_t s_ticket, s_mark;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int W = a->world, n = a->n_feats, T = a->tiles;
+    if (W == 1) {
+        // one rank: every id stays here, in sample order (k = b): nothing to rank, no chain -- one narrowing pass, as nrx_route_ids has for its layout
+        const int f = (int)blockIdx.x / T, tile = (int)blockIdx.x - f * T;
+        const int64_t B = a->batch, i0 = (int64_t)tile * RF_TILE, capf = a->capf;
+        const void* p = a->ids[f];
+#pragma unroll
+        for (int j = 0; j < RF_ROUNDS; ++j) {
+            const int64_t i = i0 + j * RF_THREADS + tid;
+            if (i >= B) continue;
+            const int64_t id = a->idx64 ? nrx_gconst<int64_t>(p)[i] : (int64_t)nrx_gconst<int32_t>(p)[i];
+            const int32_t v = id < 0 ? -1 : id >= 0x7fffffffLL ? 0x7fffffff : id == 0 ? 0 : (int32_t)(id + 1);
+            if (i < capf) {
+                a->send_ids[(int64_t)f * capf + i] = v;
+                if (a->send_pos != nullptr) a->send_pos[(int64_t)f * capf + i] = (int32_t)i;
+                a->slot[(int64_t)f * B + i] = (int32_t)(i * n + f);
+            } else {
+                a->slot[(int64_t)f * B + i] = -1;
+            }
+        }
+        if (tile == T - 1) {
+            if (tid == 0) {
+                a->counts[f] = B;
+                atomicMax(reinterpret_cast<long long*>(a->overflow), (long long)B);
+            }
+            for (int64_t k = B + tid; k < capf; k += RF_THREADS) {
+                a->send_ids[(int64_t)f * capf + k] = 0;
+                if (a->send_pos != nullptr) a->send_pos[(int64_t)f * capf + k] = -1;
+            }
+        }
+        return;
+    }
     if (tid == 0) {
         s_ticket = atomicAdd(&a->ctl[0], 1u);
         s_mark = __hip_atomic_load(&a->ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -255,7 +289,42 @@ __global__ __launch_bounds__(NRX_BLOCK) void gather_place_feat_kernel(const Gath
     }
 }
 
+// Where does the gradient row of lookup p = (f, b) go?  The owner's plan says (dest_req: the plan's dest[] of the owners, brought back by an all-to-all
+// in send_ids' layout [o][f][k]): to values[u] of owner o when its row is looked up once in the whole exchange (u = the unique index), else to
+// this rank's block of the owner's receive buffer [source][k][f].  Both live in ONE arena per owner -- values rows first, the receive buffer from row
+// `recv_row0` on -- so the answer is one number: (owner << shift) | row of that arena.  -1: the lookup was dropped (an overflowed block).
+__global__ __launch_bounds__(NRX_BLOCK) void shard_dest_combine_kernel(const int32_t* __restrict__ slot, const int32_t* __restrict__ dest_req, int n, int64_t batch,
+                                                                      int64_t capf, int64_t recv_row0, int rank, int shift, int32_t* __restrict__ out) {
+    const int64_t total = (int64_t)n * batch;
+    for (int64_t p = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x; p < total; p += (int64_t)gridDim.x * NRX_BLOCK) {
+        const int32_t sl = slot[p];
+        int32_t r = -1;
+        if (sl >= 0) {
+            const int64_t f = p / batch, ok = sl / n, o = ok / capf, k = ok - o * capf;
+            const int32_t d = dest_req[(o * n + f) * capf + k];
+            const int64_t row = d >= 0 ? (int64_t)d : recv_row0 + ((int64_t)rank * capf + k) * n + f;
+            r = (int32_t)((o << shift) | row);
+        }
+        out[p] = r;
+    }
+}
+
 }      // namespace
+
+extern "C" int nrx_shard_dest_combine(const int32_t* slot, const int32_t* dest_req, int32_t n_feats, int64_t batch, int64_t capf, int64_t recv_row0,
+                                      int32_t rank, int32_t world, int32_t shift, int32_t* dest_out, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(slot && dest_req && dest_out && n_feats >= 1 && batch >= 0 && capf >= 1 && rank >= 0 && rank < world, "nrx_shard_dest_combine: bad argument");
+    NRX_REQUIRE(shift >= 1 && shift <= 30 && (int64_t)world <= (1ll << (31 - shift)) && recv_row0 + (int64_t)world * capf * n_feats <= (1ll << shift),
+                "nrx_shard_dest_combine: (owner << shift) | row must fit 31 bits");
+    if (batch == 0) return NRX_OK;
+    int64_t blocks = ((int64_t)n_feats * batch + NRX_BLOCK - 1) / NRX_BLOCK;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(shard_dest_combine_kernel, dim3((unsigned)blocks), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), slot, dest_req, (int)n_feats,
+                       batch, capf, recv_row0, (int)rank, (int)shift, dest_out);
+    NRX_LAUNCH_CHECK("nrx_shard_dest_combine");
+    return NRX_OK;
+}
 
 extern "C" int nrx_gather_place_feat(const float* const* tables, const int64_t* table_rows, const int32_t* feat_col, int32_t n_feats, int32_t world,
                                      int64_t capf, const int32_t* owner_ids, const int32_t* owner_pos, int32_t dim, float* const* peer_out,

@@ -1545,7 +1545,8 @@ class PreparedSparseBackward:
     a dict(dim, uniq, values, counts, cap) exactly like an ops.SparseGradSink entry.  No autograd, no host reads."""
 
     def __init__(self, fwd: PreparedEmbed, g_out: Optional[torch.Tensor], g_fm: Optional[torch.Tensor] = None,
-                 g_wide: Optional[torch.Tensor] = None, place_feats: Optional[int] = None, post_plan=None, payload: Optional[torch.Tensor] = None):
+                 g_wide: Optional[torch.Tensor] = None, place_feats: Optional[int] = None, post_plan=None, payload: Optional[torch.Tensor] = None,
+                 values: Optional[torch.Tensor] = None):
         """place_feats (optional): the placement mask instead of place_mask()'s -- 0 = a placement plan in which nothing is placeable: every row
         is listed and walked, two rows x four entries per pass (the form for launches whose rows are all looked up many times), no placement
         pass, and the plan always comes from the sorted planner.  post_plan (optional): callable(stream) enqueued between the plan and the
@@ -1556,6 +1557,9 @@ class PreparedSparseBackward:
         if payload is not None and (place_feats != 0 or payload.dtype not in (torch.int32, torch.uint32) or not payload.is_contiguous()):
             raise ValueError("PreparedSparseBackward: payload needs place_feats=0 and a contiguous 32-bit tensor")
         self.payload = payload
+        # values (optional, plans of ONE embedding dim): the [lookups, dim] buffer the unique rows' gradients go to instead of one allocated here
+        # (the sharded step keeps it at the head of an arena the requesters write placed rows into: plan_only() + run_walk())
+        self._values_arg = values
         if not fwd.single:
             raise ValueError("PreparedSparseBackward covers plans of <= 64 features")
         self.g_out = None if g_out is None else _f32c(g_out, "g_out")
@@ -1588,7 +1592,7 @@ class PreparedSparseBackward:
                      seg=torch.empty(total + 1, dtype=torch.int64, device=dev),
                      counts=torch.empty(n_tables + 2, dtype=torch.int64, device=dev),
                      ws=torch.empty(max(1, self.lib.nrx_sparse_plan_workspace(total)), dtype=torch.uint8, device=dev),
-                     values=torch.empty((total, D), dtype=torch.float32, device=dev),
+                     values=values if values is not None else torch.empty((total, D), dtype=torch.float32, device=dev),
                      pmask=(place_feats if place_feats is not None else
                             place_mask([plan.slots[i].kind for i in fs], [plan.slots[i].bag_len for i in fs]) if SPARSE_PLACE else None),
                      dest=torch.empty(max(total, 1), dtype=torch.int32, device=dev),
@@ -1610,6 +1614,39 @@ class PreparedSparseBackward:
             # multi-valued features: the padding lookups are set aside when the previous plan counted enough of them (PadPolicy)
             g["pad"] = PadPolicy(total) if PAD_SPLIT != "0" and total >= PAD_SPLIT_MIN and any(plan.slots[i].kind != NRX_SPARSE for i in fs) else None
             self.groups.append(g)
+        if values is not None and (len(self.groups) != 1 or tuple(values.shape) != (self.groups[0]["total"], self.groups[0]["dim"])
+                                   or values.dtype != torch.float32 or not values.is_contiguous()):
+            raise ValueError("PreparedSparseBackward: `values` must be a contiguous float32 [lookups, dim] tensor for a plan of one embedding dim")
+
+    def plan_only(self):
+        """Enqueue the planning alone on the current stream (the following run_walk() / run() uses it)."""
+        dev = self.fwd.device
+        self._plan(torch.cuda.current_stream(dev).cuda_stream)
+        if self.post_plan is not None:
+            self.post_plan(torch.cuda.current_stream(dev).cuda_stream)
+        self._planned = True
+
+    def run_walk(self):
+        """The reduction WITHOUT its placement pass (nrx_embed_bwd_walk), after plan_only(): the rows the plan places are in values[] already --
+        the sharded step's requesters wrote them there (nrx_embed_bwd_scatter_multi with the plan's dest[]) -- and only the listed rows and the
+        pair records are reduced from g_out.  Same (keys, values, counts) as run(), bit for bit."""
+        lib, f = self.lib, self.fwd
+        stream = torch.cuda.current_stream(f.device).cuda_stream
+        if not getattr(self, "_planned", False):
+            raise RuntimeError("run_walk() needs plan_only() first")
+        self._planned = False
+        for g in self.groups:
+            if g["pmask"] is None:
+                raise RuntimeError("run_walk(): the plan has no placement")
+            pr = g["pairs"]
+            rc = lib.nrx_embed_bwd_walk(g["arr"], g["n"], f.B, g["dim"], _ptr(self.g_out), f.ld, g["order"].data_ptr(), g["seg"].data_ptr(),
+                                        g["uniq"].data_ptr(), g["total"], g["counts"].data_ptr(), self.fmg, g["values"].data_ptr(), g["pmask"],
+                                        g["dest"].data_ptr(), g["walk"].data_ptr(), g["n_walk"].data_ptr(),
+                                        g["pair_recs"].data_ptr() if pr else None, g["n_walk"].data_ptr() + 8 if pr else None,
+                                        g["lws"].data_ptr(), g["lws"].numel(), stream)
+            if rc:
+                check(rc, "nrx_embed_bwd_walk")
+        return self.groups
 
     def _plan(self, stream):
         lib = self.lib

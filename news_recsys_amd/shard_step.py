@@ -102,13 +102,19 @@ class PreparedShardedStep:
         ld0 = int(out_ld) if out_ld else plan.out_width
         if one_sided is None:
             env = os.environ.get("NRX_SHARD_ONE_SIDED")
-            one_sided = (env == "1") if env in ("0", "1") else not plan.use_fm
+            one_sided = (env == "1") if env in ("0", "1") else True
         placed_groups = set()
-        if one_sided and not plan.use_fm and (ld0 & 3) == 0 and plan.wide_width == 0:
+        # an FM epilogue spans a sample's fields: with one-sided placement nobody holds them in one launch, so the logit (and, in training form, the
+        # field sums) come from a pass over the FINISHED concat (nrx_fm_fwd_train) -- when every feature is an FM field of one width
+        fm_ok = plan.use_fm and all(f.fm and f.kind == NRX_SPARSE and not f.replicated for f in feats) and len({f.dim for f in feats}) == 1 \
+            and len(feats) <= ops.NRX_MAX_FEATURES
+        if one_sided and (not plan.use_fm or fm_ok) and (ld0 & 3) == 0 and plan.wide_width == 0:
             for gi, idxs in enumerate(groups):
                 D = feats[idxs[0]].dim
                 if gi not in pooled and D in (16, 32, 64, 128, 256) and all(plan.slots[i].out_col % 4 == 0 for i in idxs):
                     placed_groups.add(gi)
+            if plan.use_fm and len(placed_groups) != len(groups):
+                placed_groups = set()
         self.peers = None
         if placed_groups:
             if out is None:
@@ -203,12 +209,16 @@ class PreparedShardedStep:
         rest = [i for i in range(len(feats)) if i not in placed_feats]
         self.single = len(feats) <= ops.NRX_MAX_FEATURES
         self.ld = ld0
+        self.fm_pass = None
         if not placed_feats:
             self.final = ops.PreparedEmbed(plan, rets, final_inputs, final_weights, out_ld=out_ld, out=out, fm=fm, fm_sums=self.fm_sums)
             self.out = self.final.out
         else:
             self.out = out
             self.final = None
+            if plan.use_fm:
+                self.fm_out = fm if fm is not None else torch.empty((B0,), dtype=torch.float32, device=dev0)
+                self.fm_pass = (len(feats), feats[0].dim)
             if rest:
                 sp = ops.EmbedPlan([plan.slots[i] for i in rest], out_width=plan.out_width, wide_width=0)
                 self.final = ops.PreparedEmbed(sp, rets, [final_inputs[i] for i in rest], [final_weights[i] for i in rest], out_ld=ld0, out=out)
@@ -242,7 +252,7 @@ class PreparedShardedStep:
                                              g["opos"].data_ptr() if placed else None, W, g["n"], g["capf"], stream)
                 if rc:
                     ops.check(rc, "nrx_inbox_transpose")
-            if self.bwd is not None and self.plan_mode == "forward" and not g["pooled"]:
+            if self.bwd is not None and self.plan_mode == "forward" and not g["pooled"] and not self.bwd[self.groups.index(g)]["direct"]:
                 self.bwd[self.groups.index(g)]["owner"].plan_ahead()
             if placed:
                 rc = lib.nrx_gather_place_feat(g["tp"], g["tr"], g["cols"], g["n"], W, g["capf"], g["oid"].data_ptr(), g["opos"].data_ptr(), g["D"],
@@ -258,6 +268,17 @@ class PreparedShardedStep:
             # completion fence: a collective enqueued behind every rank's placing launch -- when it has completed here, every owner's rows are in this
             # rank's buffer (and the next step's first all-to-all keeps the owners from overwriting it too early)
             eng._a2a(self._fence[0], self._fence[1])
+        if self.fm_pass is not None:
+            nf, D = self.fm_pass
+            stream = torch.cuda.current_stream(self.out.device).cuda_stream
+            if self.fm_sums is not None:
+                rc = lib.nrx_fm_fwd_train(self.out.data_ptr(), self.ld, nf, D, self.out.shape[0], self.fm_out.data_ptr(), self.fm_sums.data_ptr(),
+                                          self.fm_sums.shape[1], stream)
+            else:
+                rc = lib.nrx_fm_fwd(self.out.data_ptr(), self.ld, nf, D, self.out.shape[0], self.fm_out.data_ptr(), stream)
+            if rc:
+                ops.check(rc, "nrx_fm_fwd")
+            return (self.out, res[1], self.fm_out)
         return (self.out, res[1], res[2])
 
     def overflowed(self) -> bool:
@@ -269,10 +290,21 @@ class PreparedShardedStep:
         return bad
 
     # ------------------------------------------------------------------ backward
-    def bind_backward(self, g_out: Optional[torch.Tensor], g_fm: Optional[torch.Tensor] = None):
-        """Bind the upstream gradient buffers (read in place on every backward()): g_out [B, out_ld] of the concat, g_fm [B] of the FM logit."""
+    def bind_backward(self, g_out: Optional[torch.Tensor], g_fm: Optional[torch.Tensor] = None, direct_grad: Optional[bool] = None):
+        """Bind the upstream gradient buffers (read in place on every backward()): g_out [B, out_ld] of the concat, g_fm [B] of the FM logit.
+        direct_grad (default: NRX_SHARD_DIRECT_GRAD = 1 | 0, else on where it applies -- exchange groups of 16 / 32 / 64-wide single-valued
+        features with aligned columns): THE REQUESTER'S PACK IS THE OWNER'S PLACEMENT PASS.  The owner plans first and its plan's dest[] comes
+        back to the requesters (an int32 all-to-all in the ids' layout); a gradient row whose table row is looked up ONCE in the whole exchange
+        is written by the requester straight into the owner's values[u] (the owners' gradient arenas are mapped once: hipIpc / peer mappings;
+        nrx_embed_bwd_scatter_multi), the others into its block of the owner's receive buffer, and the owner reduces only the listed rows
+        (nrx_embed_bwd_walk).  No gradient all-to-all, no owner-side placement pass: at world 1 the backward is the direct path's (plan, one
+        placement pass, walk).  Same (keys, values) bit for bit as the buffered form."""
+        import os
         lib, eng, plan = self.lib, self.eng, self.plan
         W = eng.world
+        if direct_grad is None:
+            env = os.environ.get("NRX_SHARD_DIRECT_GRAD")
+            direct_grad = env != "0"
         if not self.single:
             raise ValueError("PreparedShardedStep: the backward covers plans of <= 64 features")
         self.g_out = None if g_out is None else ops._f32c(g_out, "g_out")
@@ -296,7 +328,7 @@ class PreparedShardedStep:
                 # the owner's pseudo-batch: ONE single-valued feature of W * cap pseudo-lookups over the arena (never run forward: a descriptor)
                 pfwd = ops.PreparedEmbed(ops.EmbedPlan([ops.Slot(g["table_names"][0], NRX_SPARSE, 0, D, 0, 0)], out_width=D), [arena], [oid], [None],
                                          need_out=False)
-                b = dict(pooled=True, g_send=g_send, g_recv=g_recv, oid=oid, cols=[plan.slots[i].out_col for i in g["idxs"]], binary=self.binary_masks)
+                b = dict(pooled=True, direct=False, g_send=g_send, g_recv=g_recv, oid=oid, cols=[plan.slots[i].out_col for i in g["idxs"]], binary=self.binary_masks)
                 if self.binary_masks:
                     # the upstream rows ARE the received block [W * n * B, D] (pre-scaled by the requester); order[] is rewritten to name its rows
                     b["rows"] = None
@@ -311,15 +343,40 @@ class PreparedShardedStep:
             n, D, Bp = g["n"], g["D"], g["Bp"]
             sub = ops.EmbedPlan([plan.slots[i] for i in g["idxs"]], out_width=plan.out_width, wide_width=plan.wide_width)
             slots_in = [g["slot"][k] for k in range(n)]
-            g_send = torch.zeros((Bp, n * D), dtype=torch.float32, device=g["dev"])
-            # descriptors of the pack launch: the group's features as the final launch sees them (columns, FM flags); table = the send buffer
-            arr = ops._fill_features(sub, 0, n, [None] * n_final_tables, slots_in, [None] * n, table_ptrs=[g_send.data_ptr()] * n_final_tables,
+            # descriptors of the pack launch: the group's features as the final launch sees them (columns, FM flags); table = the send buffer (set below)
+            arr = ops._fill_features(sub, 0, n, [None] * n_final_tables, slots_in, [None] * n, table_ptrs=[0] * n_final_tables,
                                      fm=self.fmg is not None)
             for k in range(n):
                 arr[k].rows = Bp * n
+            cap_v = n * Bp                                   # the owner's lookups = the worst-case number of unique rows
+            shift = max(1, (cap_v + Bp * n - 1).bit_length())
+            direct = bool(direct_grad) and D in (16, 32, 64) and (self.ld & 3) == 0 and all(plan.slots[i].out_col % 4 == 0 for i in g["idxs"]) \
+                and self.g_out is not None and shift <= 30 and W <= (1 << (31 - shift)) and g["owner_fwd"].single
+            if direct:
+                # ONE arena per group on every rank: the owner's values rows first, its receive buffer [source][k][f] behind them
+                arena = torch.zeros((cap_v + Bp * n, D), dtype=torch.float32, device=g["dev"])
+                values, g_recv = arena[:cap_v], arena[cap_v:].view(Bp, n * D)
+                owner_bwd = ops.PreparedSparseBackward(g["owner_fwd"], g_recv, values=values)
+                og = owner_bwd.groups[0]
+                if og["pmask"] is None:
+                    direct = False
+            if direct:
+                from .sharding import PreparedShardedForward
+                peers = PreparedShardedForward._map_peer_buffers(eng, arena)
+                b = dict(pooled=False, direct=True, arr=arr, owner=owner_bwd, arena=arena, peers=peers, shift=shift, cap_v=cap_v,
+                         bases=(C.c_void_p * W)(*[t.data_ptr() for t in peers]), dest2=torch.empty(n * g["B"], dtype=torch.int32, device=g["dev"]),
+                         fence=(torch.zeros(W, dtype=torch.int32, device=g["dev"]), torch.zeros(W, dtype=torch.int32, device=g["dev"])))
+                if W > 1:       # the plan's dest[] back to the requesters: [f][s][k] -> [s][f][k] -> all-to-all -> [o][f][k]
+                    b["dest_t"] = torch.empty((W, n, g["capf"]), dtype=torch.int32, device=g["dev"])
+                    b["dest_req"] = torch.empty((W, n, g["capf"]), dtype=torch.int32, device=g["dev"])
+                self.bwd.append(b)
+                continue
+            g_send = torch.zeros((Bp, n * D), dtype=torch.float32, device=g["dev"])
+            for k in range(n):
+                arr[k].table = g_send.data_ptr()
             g_recv = g_send if W == 1 else torch.empty_like(g_send)
             owner_bwd = ops.PreparedSparseBackward(g["owner_fwd"], g_recv)
-            self.bwd.append(dict(pooled=False, arr=arr, g_send=g_send, g_recv=g_recv, owner=owner_bwd, scatter_ok=True))
+            self.bwd.append(dict(pooled=False, direct=False, arr=arr, g_send=g_send, g_recv=g_recv, owner=owner_bwd, scatter_ok=True))
         return self
 
     def backward(self):
@@ -331,7 +388,7 @@ class PreparedShardedStep:
         out = []
         if self.plan_mode == "backward":
             for b in self.bwd:
-                if not b["pooled"]:
+                if not b["pooled"] and not b["direct"]:
                     b["owner"].plan_ahead()
         for g, b in zip(self.groups, self.bwd):
             stream = torch.cuda.current_stream(g["dev"]).cuda_stream
@@ -359,6 +416,25 @@ class PreparedShardedStep:
                 for og in b["owner"].run():
                     out.append(dict(tables=g["tables"], dim=og["dim"], uniq=og["uniq"], values=og["values"], counts=og["counts"], cap=og["cap"],
                                     table_ids=[0]))
+                continue
+            if b["direct"]:
+                owner = b["owner"]
+                owner.plan_only()
+                dest_req = owner.groups[0]["dest"]
+                if W > 1:
+                    # (nrx_inbox_transpose with the roles of its two outer dimensions swapped: [f][s][k] -> [s][f][k])
+                    ops.check(lib.nrx_inbox_transpose(dest_req.data_ptr(), b["dest_t"].data_ptr(), None, None, g["n"], W, g["capf"], stream), "nrx_inbox_transpose")
+                    eng._a2a(b["dest_req"].view(-1), b["dest_t"].view(-1))
+                    dest_req = b["dest_req"]
+                ops.check(lib.nrx_shard_dest_combine(g["slot"].data_ptr(), dest_req.data_ptr(), g["n"], g["B"], g["capf"], b["cap_v"], eng.rank, W,
+                                                     b["shift"], b["dest2"].data_ptr(), stream), "nrx_shard_dest_combine")
+                ops.check(lib.nrx_embed_bwd_scatter_multi(b["arr"], g["n"], g["B"], g["D"], ops._ptr(self.g_out), self.ld, self.fmg, b["dest2"].data_ptr(),
+                                                          b["bases"], W, b["shift"], stream), "nrx_embed_bwd_scatter_multi")
+                if W > 1:       # completion fence: when this collective has completed here, every requester's rows are in this rank's arena
+                    eng._a2a(b["fence"][0], b["fence"][1])
+                for og in owner.run_walk():
+                    out.append(dict(tables=g["tables"], dim=og["dim"], uniq=og["uniq"], values=og["values"], counts=og["counts"], cap=og["cap"],
+                                    table_ids=list(range(len(g["tables"])))))
                 continue
             rc = NRX_ERR_UNSUPPORTED
             if b["scatter_ok"]:

@@ -1,0 +1,119 @@
+"""The per-feature exchange PROTOCOL of news_recsys_amd/shard_step.py over real rank processes on the CPU (gloo, world 2 and 3), with every local
+step taken from its DEFINITION in oracle/ref_np.py -- the functions the HIP kernels are checked against bit for bit on the GPU
+(tests/test_shard_step_gpu.py): route_feat, owner_ids_from_inbox, a row gather over an arena with a leading dummy row.  What this pins without
+a GPU is the layout algebra between the ranks:
+
+  * equal-split all_to_all_single of send_ids [world, n, capf] leaves block s = what rank s addressed to this owner;
+  * the owner's concat [world * capf, n * D] returned by an equal-split all-to-all is addressed on the requester by slot = (o * capf + k) * n + f;
+  * the forward equals a plain gather of the global rows (src/model/BaseModel/base_model.py:262-271) bit for bit on every rank;
+  * the backward -- every lookup's upstream row to its slot, all-to-all, owner-side sum per owner id -- gives, over all owners, exactly the
+    dense gradient np.add.at forms on the concatenated batch (float64 here: the summation order is not what this test is about);
+  * the owner's plan destinations travel back in the ids' layout (the direct-gradient mode's dest exchange): dest_req[o, f, k] of a lookup is the
+    entry its owner computed for pseudo-sample s * capf + k.
+The product path has no CPU implementation (ops raise without the HIP library): this test imports only the oracle and torch.distributed."""
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_np
+from tests.test_sharding_gloo import _free_port
+
+N_FEATS, B, D = 4, 300, 8
+ROWS = [50, 1000, 7, 333]
+
+
+def _tables():
+    rng = np.random.default_rng(1)
+    t = [rng.standard_normal((r, D)) for r in ROWS]
+    for x in t:
+        x[0] = 0
+    return t
+
+
+def _batch(rank):
+    rng = np.random.default_rng(40 + rank)
+    ids = [rng.integers(0, r, B) for r in ROWS]
+    ids[0][:3] = 0
+    return ids, rng.standard_normal((B, N_FEATS * D))
+
+
+def _a2a(x: np.ndarray) -> np.ndarray:
+    t = torch.from_numpy(np.ascontiguousarray(x).reshape(-1))
+    out = torch.empty_like(t)
+    dist.all_to_all_single(out, t)
+    return out.numpy().reshape(x.shape)
+
+
+def _worker(rank, world, port, q):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tabs = _tables()
+        # arenas: a dummy row 0, then this rank's rows rank::world (shard_step.make_arena's layout)
+        arenas = [np.concatenate([np.zeros((1, D)), t[rank::world]]) for t in tabs]
+        ids, up = _batch(rank)
+        capf = (int(B / world * 1.6) + 64 + 63) // 64 * 64
+        send_ids, send_pos, slot, counts, worst = ref_np.route_feat(ids, world, capf)
+        assert worst <= capf
+        inbox = _a2a(send_ids)                                             # block s: from rank s
+        oid = ref_np.owner_ids_from_inbox(inbox)                           # [n, world * capf]
+        rows_out = np.concatenate([arenas[f][oid[f]] for f in range(N_FEATS)], axis=1)      # the owner's concat [world * capf, n * D]
+        ret = _a2a(rows_out.reshape(world, capf, N_FEATS * D)).reshape(world * capf * N_FEATS, D)
+        out = np.concatenate([ret[slot[f]] for f in range(N_FEATS)], axis=1)                # the requester's final launch: un-permute by slot
+        # ---- backward: every lookup's upstream row to its slot; all-to-all; the owner sums per owner id
+        g_send = np.zeros((world * capf * N_FEATS, D))
+        for f in range(N_FEATS):
+            g_send[slot[f]] = up[:, f * D:(f + 1) * D]
+        g_recv = _a2a(g_send.reshape(world, capf, N_FEATS * D)).reshape(world * capf, N_FEATS * D)
+        grads = []
+        for f in range(N_FEATS):
+            g = np.zeros_like(arenas[f])
+            np.add.at(g, oid[f], g_recv[:, f * D:(f + 1) * D])
+            g[0] = 0                                                      # the dummy row: empty slots and padding ids, never trained
+            grads.append(g[1:])                                            # -> rows rank::world
+        # ---- the dest exchange of the direct-gradient mode: an owner-side per-pseudo-lookup word comes back in the ids' layout
+        word = (np.arange(N_FEATS)[:, None] * 1_000_000 + rank * 100_000 + np.arange(world * capf)[None, :]).astype(np.int32)      # [f][s * capf + k]
+        back = _a2a(np.ascontiguousarray(word.reshape(N_FEATS, world, capf).transpose(1, 0, 2)))                                  # -> [o][f][k] on the requester
+        ok = True
+        for f in range(N_FEATS):
+            for b in range(0, B, 37):
+                o, k = divmod(slot[f, b] // N_FEATS, capf)
+                ok &= int(back[o, f, k]) == f * 1_000_000 + o * 100_000 + rank * capf + k
+        q.put((rank, out, grads, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_per_feature_exchange_protocol_over_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        item = q.get(timeout=120)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tabs = _tables()
+    want_g = [np.zeros_like(t) for t in tabs]
+    for r in range(world):
+        ids, up = _batch(r)
+        out, grads, ok = res[r]
+        assert ok
+        want = np.concatenate([tabs[f][ids[f]] for f in range(N_FEATS)], axis=1)
+        assert np.array_equal(out, want)                                   # row copies: bit for bit
+        for f in range(N_FEATS):
+            np.add.at(want_g[f], ids[f], up[:, f * D:(f + 1) * D])
+    for f in range(N_FEATS):
+        want_g[f][0] = 0                                                   # padding_idx = 0 (base_model.py:164)
+        for r in range(world):
+            np.testing.assert_allclose(res[r][1][f], want_g[f][r::world], rtol=1e-12, atol=1e-12)

@@ -2,7 +2,8 @@
 """Regression gate over the committed bench lines: every timed leg of a round's `profiles/rNN_bench_lines*.jsonl` against the previous
 round's file of the same name, leg by leg (a leg = a numeric entry whose key names a duration: *_ms, *_us, ms_per_*, us_per_*, .us).
 Exit code 1 when any GPU-time leg is more than --tol (default 10 %) slower -- the check round 5 did not have when its Zipf legs went from
-281 / 410 us to 414 / 674 us unnoticed.  Host-time legs (`*host_us*`) are listed but never fail the gate: they follow the box's CPU.
+281 / 410 us to 414 / 674 us unnoticed.  Host-time legs (`*host_us*`, and the eager module-path legs, which are launched from Python step by
+step) are listed but never fail the gate: they follow the box's CPU.
 
     tools/compare_bench_lines.py                 # newest round in profiles/ against the one before it
     tools/compare_bench_lines.py 6 5             # round 6 against round 5
@@ -35,7 +36,9 @@ def tag(line):
     cfg = line.get("config", {})
     wl = str(cfg.get("workload", "?")).split(":")[0].strip()
     ids = "zipf" if "zipf" in json.dumps(cfg).lower() else "uniform"
-    return (wl, line.get("n_gpus", 1), ids, str(cfg.get("shard_mode", cfg.get("layout", ""))))
+    lay = cfg.get("layout")
+    sharded = "sharded" if (isinstance(lay, dict) or "row-sharded over" in str(cfg.get("workload", ""))) else "direct"
+    return (wl, line.get("n_gpus", 1), ids, sharded)
 
 
 def load(path):
@@ -60,7 +63,8 @@ def compare(new_path, old_path, tol):
             if k not in old[t] or old[t][k] <= 0:
                 continue
             r = new[t][k] / old[t][k]
-            host = "host" in k
+            # host-time legs: named so, or the eager module-path legs (launched from Python step by step: GPU time = host time there)
+            host = "host" in k or re.search(r"module_path\..*(autograd_us|hook_us|step_us|graphed_us)", k) is not None
             flag = ""
             if r > 1.0 + tol:
                 flag = "  (host time: not gated)" if host else "  <-- SLOWER"
