@@ -697,6 +697,9 @@ NRX_API int nrx_scatter_add_inbox(float* const* grad_tables, const int64_t* tabl
  *                          nrx_scatter_add_inbox)
  * The source finishes with an NRX_BAG_SUM of bag_len = world over the returned slabs (rows o*n_feats*batch + tag).  */
 NRX_API int nrx_bag_norm_weights(const float* mask, int64_t batch, int32_t bag_len, int32_t kind, float* out_w, void* stream);
+/* nrx_bag_norm_weights that also leaves out_inv[b]: the weight every live entry of sample b carries when the mask is 0 / 1 (1 / (sum w + 1e-8), 0
+ * for an empty bag; 1 / L for the plain mean) -- what the bound sharded step's pooled backward pre-multiplies the sample's upstream row by. */
+NRX_API int nrx_bag_norm_weights_inv(const float* mask, int64_t batch, int32_t bag_len, int32_t kind, float* out_w, float* out_inv, void* stream);
 NRX_API int nrx_route_bags(const void* const* ids, const float* const* weights, const int32_t* bag_lens, int32_t n_feats,
                    int32_t index_bits, int64_t batch, int32_t world, int64_t cap, int32_t* send_rows, int32_t* send_tag,
                    float* send_w, int64_t* counts2d, int64_t* overflow, int64_t* workspace, void* stream);

@@ -687,7 +687,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void pool_inbox_expand_kernel(const Pool
 
 // normalised bag weights: masked mean w/(sum w + 1e-8) (base_model.py:278-282), plain mean 1/L (:275-276), sum w | 1
 __global__ __launch_bounds__(NRX_BLOCK) void bag_norm_weights_kernel(const float* __restrict__ mask, int64_t batch, int L, int kind,
-                                                                     float* __restrict__ out) {
+                                                                     float* __restrict__ out, float* __restrict__ inv_out = nullptr) {
     // bags of up to 64 entries: 16 lanes per sample, four samples per wavefront (a wavefront per 50-entry bag left most lanes
     // idle: 14.8 us at the C4 shape); longer bags: one wavefront per sample.  Sum order per sample is fixed either way.
     const bool narrow = L <= 64;
@@ -715,6 +715,9 @@ __global__ __launch_bounds__(NRX_BLOCK) void bag_norm_weights_kernel(const float
         const float m = (kind == NRX_BAG_MEAN || mask == nullptr) ? 1.0f : mask[b * L + l];
         out[b * L + l] = m / den;
     }
+    // the weight every live entry of the sample carries when the mask is 0 / 1 (1 / den; 0 for an empty bag): what the pooled channel's
+    // backward pre-multiplies the sample's upstream row by (shard_step, binary_masks)
+    if (inv_out != nullptr && q == 0) inv_out[b] = (kind == NRX_BAG_MASKED_MEAN && den <= 1e-8f) ? 0.f : 1.0f / den;
 }
 
 int log2_ceil(int x) {
@@ -952,8 +955,22 @@ extern "C" int nrx_bag_norm_weights(const float* mask, int64_t batch, int32_t ba
     const int per_block = NRX_BLOCK / (bag_len <= 64 ? 16 : 64);
     const unsigned grid = (unsigned)((batch + per_block - 1) / per_block);
     hipLaunchKernelGGL(bag_norm_weights_kernel, dim3(grid), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), mask, batch,
-                       bag_len, kind, out_w);
+                       bag_len, kind, out_w, (float*)nullptr);
     NRX_LAUNCH_CHECK("nrx_bag_norm_weights");
+    return NRX_OK;
+}
+
+extern "C" int nrx_bag_norm_weights_inv(const float* mask, int64_t batch, int32_t bag_len, int32_t kind, float* out_w, float* out_inv, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(out_w != nullptr && out_inv != nullptr && batch >= 0 && bag_len >= 1, "nrx_bag_norm_weights_inv: bad argument");
+    NRX_REQUIRE(kind == NRX_BAG_MASKED_MEAN || kind == NRX_BAG_MEAN || kind == NRX_BAG_SUM, "nrx_bag_norm_weights_inv: not a bag kind");
+    NRX_REQUIRE(kind != NRX_BAG_MASKED_MEAN || mask != nullptr, "nrx_bag_norm_weights_inv: masked mean needs a mask");
+    if (batch == 0) return NRX_OK;
+    const int per_block = NRX_BLOCK / (bag_len <= 64 ? 16 : 64);
+    const unsigned grid = (unsigned)((batch + per_block - 1) / per_block);
+    hipLaunchKernelGGL(bag_norm_weights_kernel, dim3(grid), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), mask, batch,
+                       bag_len, kind, out_w, out_inv);
+    NRX_LAUNCH_CHECK("nrx_bag_norm_weights_inv");
     return NRX_OK;
 }
 

@@ -135,6 +135,8 @@ class PreparedShardedStep:
                 if len(tnames) != 1:
                     raise NotImplementedError("PreparedShardedStep: the bag features of one pooled exchange group must share ONE table")
                 g.update(pooled=True, placed=False, idxs=list(idxs), tables=[arenas[tnames[0]]], table_names=tnames)
+                if self.binary_masks and train:
+                    g["inv"] = [torch.zeros(g["B"], dtype=torch.float32, device=dev) for _ in idxs]
                 for k, i in enumerate(idxs):
                     slot_of[i] = eng._pooled_ids(g["B"], g["n"], k, dev)
                     final_weights[i] = None
@@ -399,8 +401,8 @@ class PreparedShardedStep:
                 v = b["g_send"].view(W, n, B, D)
                 for k, col in enumerate(b["cols"]):
                     src = self.g_out[:, col:col + D]
-                    if b["binary"]:       # every live entry of a sample carries the same normalised weight: the largest of its row (0 for an empty bag)
-                        src = src * g["wn"][k].amax(dim=1, keepdim=True)
+                    if b["binary"]:       # every live entry of a sample carries the same normalised weight (0 for an empty bag): the forward left it
+                        src = src * (g["inv"][k].unsqueeze(1) if g.get("inv") is not None else g["wn"][k].amax(dim=1, keepdim=True))
                     v[:, k].copy_(src.unsqueeze(0).expand(W, B, D))
                 if W > 1:
                     eng._a2a(b["g_recv"].view(-1), b["g_send"].view(-1))
@@ -428,8 +430,12 @@ class PreparedShardedStep:
                     dest_req = b["dest_req"]
                 ops.check(lib.nrx_shard_dest_combine(g["slot"].data_ptr(), dest_req.data_ptr(), g["n"], g["B"], g["capf"], b["cap_v"], eng.rank, W,
                                                      b["shift"], b["dest2"].data_ptr(), stream), "nrx_shard_dest_combine")
-                ops.check(lib.nrx_embed_bwd_scatter_multi(b["arr"], g["n"], g["B"], g["D"], ops._ptr(self.g_out), self.ld, self.fmg, b["dest2"].data_ptr(),
-                                                          b["bases"], W, b["shift"], stream), "nrx_embed_bwd_scatter_multi")
+                if W == 1:      # one arena: the single-destination form (whole 128-byte lines per instruction for 64-byte rows), dest2 = the arena row
+                    ops.check(lib.nrx_embed_bwd_scatter(b["arr"], g["n"], g["B"], g["D"], ops._ptr(self.g_out), self.ld, None, 0, self.fmg,
+                                                        b["dest2"].data_ptr(), b["arena"].data_ptr(), stream), "nrx_embed_bwd_scatter")
+                else:
+                    ops.check(lib.nrx_embed_bwd_scatter_multi(b["arr"], g["n"], g["B"], g["D"], ops._ptr(self.g_out), self.ld, self.fmg, b["dest2"].data_ptr(),
+                                                              b["bases"], W, b["shift"], stream), "nrx_embed_bwd_scatter_multi")
                 if W > 1:       # completion fence: when this collective has completed here, every requester's rows are in this rank's arena
                     eng._a2a(b["fence"][0], b["fence"][1])
                 for og in owner.run_walk():

@@ -812,8 +812,11 @@ class PreparedShardedForward:
     def _run_pooled(self, g, stream):
         eng, lib = self.eng, self.lib
         W = eng.world
-        for m, w, kind, L in zip(g["masks"], g["wn"], g["kinds"], g["lens"]):
-            rc = lib.nrx_bag_norm_weights(None if m is None else m.data_ptr(), g["B"], L, kind, w.data_ptr(), stream)
+        for k, (m, w, kind, L) in enumerate(zip(g["masks"], g["wn"], g["kinds"], g["lens"])):
+            if g.get("inv") is not None:       # (the bound training step, 0/1 masks: the per-sample weight rides along)
+                rc = lib.nrx_bag_norm_weights_inv(None if m is None else m.data_ptr(), g["B"], L, kind, w.data_ptr(), g["inv"][k].data_ptr(), stream)
+            else:
+                rc = lib.nrx_bag_norm_weights(None if m is None else m.data_ptr(), g["B"], L, kind, w.data_ptr(), stream)
             if rc:
                 ops.check(rc, "nrx_bag_norm_weights")
         rc = lib.nrx_route_bags(g["ptrs"], g["wptrs"], g["bl"], g["n"], g["bits"], g["B"], W, g["cap"], g["send"].data_ptr(),
