@@ -134,17 +134,24 @@ __global__ __launch_bounds__(RF_THREADS) void route_feat_kernel(const RouteFeatA
         }
     }
     __syncthreads();
-    if (tid < W) {                       // lane o: exclusive prefix of owner o's cells; the tile's total
-        int run = 0;
-        for (int c = 0; c < RF_ROUNDS * RF_WAVES; ++c) {
-            const int v = s_cell[c][tid];
-            s_cell[c][tid] = run;
-            run += v;
+    // exclusive prefix of every owner's cells and the tile's totals: a wavefront per owner (wavefront w takes owners w, w + 4, ...), lane c = cell c,
+    // one shuffle scan -- 64 serial LDS round trips per owner in a single lane were ~3 us of every block's critical path
+    static_assert(RF_ROUNDS * RF_WAVES <= 64, "one lane per cell");
+    for (int o = wid; o < W; o += RF_WAVES) {
+        const int v = lane < RF_ROUNDS * RF_WAVES ? s_cell[lane][o] : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
         }
-        s_tot[tid] = run;
-        if (tile + 1 < T)                // (the feature's last tile has no successor)
-            __hip_atomic_store(&a->agg[((int64_t)f * T + tile) * W + tid], ((unsigned long long)mark << 32) | (unsigned)run, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < RF_ROUNDS * RF_WAVES) s_cell[lane][o] = incl - v;
+        if (lane == 63) {
+            s_tot[o] = incl;
+            if (tile + 1 < T)            // (the feature's last tile has no successor)
+                __hip_atomic_store(&a->agg[((int64_t)f * T + tile) * W + o], ((unsigned long long)mark << 32) | (unsigned)incl, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     // ---- the earlier tiles of this feature: one (tile, owner) word per thread and round, summed per owner with LDS integer atomics
     for (int j = tid; j < tile * W; j += RF_THREADS) {
