@@ -305,6 +305,8 @@ class PreparedShardedStep:
         lib, eng, plan = self.lib, self.eng, self.plan
         W = eng.world
         if direct_grad is None:
+            direct_grad = getattr(self, "_direct_grad_default", None)
+        if direct_grad is None:
             env = os.environ.get("NRX_SHARD_DIRECT_GRAD")
             direct_grad = env != "0"
         if not self.single:
@@ -466,3 +468,119 @@ class PreparedShardedStep:
         """backward() into a SparseGradSink (what optim.FusedSparseAdam drains)."""
         sink.pending.extend(self.backward())
         return sink
+
+
+# --------------------------------------------------------------------------------- model integration
+class _ShardedStepFn(torch.autograd.Function):
+    """The bound step inside autograd: forward = step.run(); backward = the gradient exchange + the owner-side reduction, whose (keys, values)
+    go to the model's SparseGradSink (what optim.FusedSparseAdam drains) -- the tables never see a dense .grad."""
+
+    @staticmethod
+    def forward(ctx, step, sink, scale, want_out, want_fm, anchor):
+        out, _, fm = step.run()
+        ctx.step, ctx.sink, ctx.scale = step, sink, scale
+        ctx.set_materialize_grads(False)
+        return (out if want_out else None), (fm if want_fm else None)
+
+    @staticmethod
+    def backward(ctx, g_out, g_fm):
+        step = ctx.step
+        if g_out is None and g_fm is None:
+            return None, None, None, None, None, None
+        if ctx.scale != 1.0:           # every rank's loss is a mean over ITS batch: the tables see the gradient of the global-batch mean
+            g_out = None if g_out is None else g_out * ctx.scale
+            g_fm = None if g_fm is None else g_fm * ctx.scale
+        step.set_upstream(g_out, g_fm)
+        ctx.sink.pending.extend(step.backward())
+        return None, None, None, None, None, None
+
+
+def _set_upstream(self, g_out, g_fm):
+    """(Re)bind the upstream gradients of the next backward(): the first call allocates the exchange and plan buffers (bind_backward), later
+    calls only swap the pointers the pack launch reads."""
+    g_out = None if g_out is None else ops._f32c(g_out, "g_out")
+    g_fm = None if g_fm is None else ops._f32c(g_fm, "g_fm")
+    if self.bwd is None:
+        self.bind_backward(g_out, g_fm)
+        self._had = (g_out is not None, g_fm is not None)
+        return
+    if (g_out is not None, g_fm is not None) != self._had:
+        raise RuntimeError("PreparedShardedStep: the set of upstream gradients changed between steps (bind a step per loss form)")
+    self.g_out = g_out
+    if g_fm is not None:
+        self.g_fm = g_fm
+        self.fmg = NrxFmGrad(g_fm.data_ptr(), self.fm_sums.data_ptr(), self.fm_sums.shape[1], self.out.data_ptr(), self.ld)
+
+
+PreparedShardedStep.set_upstream = _set_upstream
+
+
+def shard_model_step_(model, rank: int, world: int, group=None, host_staged: bool = False, slack: float = 0.05, binary_masks: bool = True,
+                      one_sided: Optional[bool] = None, direct_grad: Optional[bool] = None, grad_average: bool = True):
+    """Convert a BaseModel in place to row-sharded tables TRAINED BY THE BOUND STEP (the counterpart of sharding.shard_model_, whose backward
+    forms dense shard gradients): every `embedding_tables[name].weight` becomes this rank's ARENA ([1 + local rows, D]: row 0 the dummy row,
+    rows 1.. = global rows rank::world), `_embed` runs a PreparedShardedStep bound per (feature set, batch size) -- the batch's ids are copied into
+    the step's own buffers -- and the backward leaves row-sparse (keys, values) in `model._sparse_sink`; `configure_optimizers()` then builds
+    SparseDenseAdam over the arenas (FusedSparseAdam on the looked-up rows) + AdamW for the dense parameters, which the caller all-reduces
+    (sharding.allreduce_dense_grads(sharding.data_parallel_params(model), world)).  state_dict keys are unchanged; the table values are the
+    arenas (full_state_dict / load_full_state_dict_ convert to and from the reference's full tables).
+    binary_masks: the array features' masks are 0/1 (DataReader's, src/dataset/DataReader/data_reader.py:96-109).
+    grad_average: scale the table gradients by 1 / world (every rank's loss is a mean over its own batch)."""
+    import torch.nn as nn
+    from .sharding import RowShardedEmbedding, ShardedFeature
+    eng = RowShardedEmbedding(rank, world, group, None, slack=slack, host_staged=host_staged, overflow_policy="defer")
+    model.sparse_grad = "fused"
+    if getattr(model, "_sparse_sink", None) is None:
+        model._sparse_sink = ops.SparseGradSink()
+    model._replicated_tables = ()
+    for name, emb in list(model.embedding_tables.items()):
+        w = emb.weight.data
+        arena = make_arena(emb.num_embeddings, w.shape[1], rank, world, w.device, full=w)
+        new = nn.Embedding(arena.shape[0], arena.shape[1])
+        new.weight = nn.Parameter(arena, requires_grad=False)      # (updated in place by FusedSparseAdam from the sink, never through .grad)
+        new.global_rows = emb.num_embeddings
+        new.arena = True
+        model.embedding_tables[name] = new
+    model._shard_engine = eng
+    model._shard_steps = {}
+    scale = 1.0 / world if (grad_average and world > 1) else 1.0
+
+    def _embed_step(batch, feature_names, fm=False, wide_names=(), out_ld=None, need_out=True):
+        plan, table_names, dims, present = model._plan(batch, feature_names, fm, wide_names)
+        if not present:
+            return None, None, None, [], []
+        if wide_names:
+            raise NotImplementedError("shard_model_step_: Wide&Deep column routing is not bound (sharding.shard_model_ serves it)")
+        if out_ld is not None and out_ld < 0:
+            out_ld = None
+        names = [s.name for s in plan.slots]
+        masks = [f"{s.name}_mask" if s.kind == ops.NRX_BAG_MASKED_MEAN else None for s in plan.slots]
+        B = batch[names[0]].shape[0]
+        key = (tuple(names), B, bool(fm), out_ld, tuple(str(batch[n].dtype) for n in names))
+        ent = model._shard_steps.get(key)
+        if ent is None:
+            feats = [ShardedFeature(s.name, s.kind, '' if s.kind == NRX_DENSE else table_names[s.table], s.dim, s.bag_len, False, bool(s.fm_field))
+                     for s in plan.slots]
+            bufs = [batch[n].detach().clone().contiguous() for n in names]
+            wbufs = [None if m is None else batch[m].detach().clone().contiguous() for m in masks]
+            arenas = {t: model.embedding_tables[t].weight.data for t in table_names}
+            step = PreparedShardedStep(eng, feats, bufs, wbufs, arenas, out_ld=out_ld, train=True, slack=slack, one_sided=one_sided,
+                                       binary_masks=binary_masks)
+            step._direct_grad_default = direct_grad
+            anchor = torch.zeros(1, device=bufs[0].device, requires_grad=True)
+            ent = model._shard_steps[key] = (step, bufs, wbufs, anchor)
+        step, bufs, wbufs, anchor = ent
+        for b_, n in zip(bufs, names):
+            b_.copy_(batch[n])
+        for w_, m in zip(wbufs, masks):
+            if w_ is not None:
+                w_.copy_(batch[m])
+        if torch.is_grad_enabled():
+            out, fmv = _ShardedStepFn.apply(step, model._sparse_sink, scale, need_out, bool(fm), anchor)
+        else:
+            o, _, f_ = step.run()
+            out, fmv = (o if need_out else None), (f_ if fm else None)
+        return out, None, fmv, list(dims), list(present)
+
+    model._embed = _embed_step
+    return model

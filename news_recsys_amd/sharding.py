@@ -1000,13 +1000,17 @@ def full_state_dict(model, group=None) -> Dict[str, torch.Tensor]:
         name = k[len("embedding_tables."):-len(".weight")] if k.startswith("embedding_tables.") and k.endswith(".weight") else None
         emb = model.embedding_tables[name] if name is not None and name in model.embedding_tables else None
         rows = getattr(emb, "global_rows", None)
-        if rows is None or world == 1 or name in getattr(model, "_replicated_tables", ()):
+        if rows is None or name in getattr(model, "_replicated_tables", ()) or (world == 1 and not getattr(emb, "arena", False)):
             out[k] = v.detach().clone()
+            continue
+        if world == 1:
+            out[k] = v.detach()[1:].clone()
             continue
         longest = local_row_count(rows, 0, world)
         mine = local_row_count(rows, eng.rank, world)
         pad = v.new_zeros((longest, v.shape[1]))
-        pad[:mine] = v.detach()[:mine]
+        lo = 1 if getattr(emb, "arena", False) else 0      # (shard_step.shard_model_step_: the local table is an arena with a leading dummy row)
+        pad[:mine] = v.detach()[lo:lo + mine]
         parts = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(parts, pad, group=group if group is not None else eng.group)
         out[k] = unshard_tables([p[:local_row_count(rows, r, world)] for r, p in enumerate(parts)])
@@ -1023,12 +1027,18 @@ def load_full_state_dict_(model, full: Dict[str, torch.Tensor], strict: bool = T
         name = k[len("embedding_tables."):-len(".weight")] if k.startswith("embedding_tables.") and k.endswith(".weight") else None
         emb = model.embedding_tables[name] if name is not None and name in model.embedding_tables else None
         rows = getattr(emb, "global_rows", None)
-        if rows is None or world == 1 or name in getattr(model, "_replicated_tables", ()):
+        if rows is None or name in getattr(model, "_replicated_tables", ()) or (world == 1 and not getattr(emb, "arena", False)):
             local[k] = v
             continue
         if v.shape[0] != rows:
             raise ValueError(f"load_full_state_dict_: {k} has {v.shape[0]} rows, the sharded model was built for {rows}")
         sh = shard_table(v, rank, world)
+        if getattr(emb, "arena", False):
+            sh = torch.cat([v.new_zeros((1, v.shape[1])), sh])
+            if rank == 0 and sh.shape[0] > 1:
+                sh[1].zero_()
+            local[k] = sh
+            continue
         local[k] = sh if sh.shape[0] else v.new_zeros((1, v.shape[1]))
     return model.load_state_dict(local, strict=strict)
 
