@@ -1334,8 +1334,8 @@ def main():
                        "GBps_per_link": remote / (world - 1) / (ms * 1e-3) / 1e9,
                        "xgmi_link_peak_GBps": 153.0, "xgmi_links_per_gpu": 7,
                        "frac_of_link_peak": remote / (world - 1) / (ms * 1e-3) / 1e9 / 153.0,
-                       "note": "the return all-to-all(s) of the row-sharded exchange alone (equal splits, max over ranks); "
-                               "per link = remote bytes / (N-1) point-to-point xGMI links (7 x ~153 GB/s per GPU)"}
+                       "what": probe.get("what"),
+                       "note": "equal splits, max over ranks; per link = remote bytes / (N-1) point-to-point xGMI links (7 x ~153 GB/s per GPU)"}
             if hasattr(path, "train_setup"):
                 sharded_fb = sharded_train_leg(path)
             del path

@@ -1181,8 +1181,16 @@ class ShardedBenchPath:
         if not groups or self.world == 1:
             return None
         pairs = [(g["ret"], g["partial"] if g.get("pooled") else g["rows_out"]) for g in groups if not g.get("placed")]     # (both engines name them so)
+        what = "the return all-to-all(s) of the row-sharded exchange alone (rows / partial sums coming back from the owners)"
         if not pairs:
-            return None
+            # one-sided placement: the rows do not come back through a collective at all (the owners write them into the requesters' buffers);
+            # what crosses in collectives is the owner ids and the sample positions
+            pairs = [(g["inbox"], g["send_ids"]) for g in groups if g.get("placed") and "send_ids" in g]
+            pairs += [(g["inbox_pos"], g["send_pos"]) for g in groups if g.get("placed") and "send_pos" in g]
+            what = ("one-sided placement: no row all-to-all exists (the owners write the rows into the requesters' mapped buffers); timed here: the id + "
+                    "position all-to-alls of the exchange")
+            if not pairs:
+                return None
         nbytes = sum(r.numel() * r.element_size() for r, _ in pairs)
         for _ in range(3):
             for r, src in pairs:
@@ -1195,4 +1203,4 @@ class ShardedBenchPath:
                 self.eng._a2a(r.view(-1), src.view(-1))
         b.record()
         torch.cuda.synchronize()
-        return {"bytes": nbytes, "ms": a.elapsed_time(b) / steps}
+        return {"bytes": nbytes, "ms": a.elapsed_time(b) / steps, "what": what}
