@@ -69,7 +69,7 @@ class PreparedShardedStep:
 
     def __init__(self, eng: RowShardedEmbedding, feats: Sequence[ShardedFeature], inputs, weights, arenas: Dict[str, torch.Tensor],
                  out_ld: Optional[int] = None, out: Optional[torch.Tensor] = None, fm: Optional[torch.Tensor] = None, train: bool = True,
-                 slack: Optional[float] = None, one_sided: Optional[bool] = None, binary_masks: bool = False):
+                 slack: Optional[float] = None, one_sided: Optional[bool] = None, binary_masks: bool = False, check_index: bool = False):
         """one_sided (default: NRX_SHARD_ONE_SIDED = 1 | 0, else on for plans without an FM epilogue): ONE-SIDED PLACEMENT of the forward -- the
         sample positions travel with the owner ids and the owner's gather (nrx_gather_place_feat) writes every row straight into its place in the
         requester's concat, which every rank maps once (hipIpc through torch's CUDA-IPC sharing; over xGMI a peer mapping): no row buffer, no
@@ -85,6 +85,9 @@ class PreparedShardedStep:
         self.eng = eng
         self.feats = list(feats)
         self.binary_masks = bool(binary_masks)
+        # check_index: the owners' launches record lookups that cannot be rows of their shard (an id outside its table: the reference's nn.Embedding
+        # raises IndexError on the CPU, src/model/BaseModel/base_model.py:271) in a device status word; check() reads it, agrees over the ranks and raises
+        self.status = torch.zeros(4, dtype=torch.int32, device=inputs[0].device) if check_index else None
         W = eng.world
         self.keep = [inputs, weights, arenas]
         groups, pooled = eng.plan_groups(feats)
@@ -185,7 +188,8 @@ class PreparedShardedStep:
             # the owner's side: a plain batch of Bp pseudo-samples, n single-valued features, concat [Bp, n * D]
             oslots = [ops.Slot(feats[i].name, NRX_SPARSE, table_names.index(feats[i].table), D, 0, k * D) for k, i in enumerate(idxs)]
             g["owner_fwd"] = ops.PreparedEmbed(ops.EmbedPlan(oslots, out_width=n * D), tabs, [g["oid"][k] for k in range(n)], [None] * n,
-                                               need_out=not placed)      # (placed: never run -- the descriptor of the owner's pseudo-batch for the backward)
+                                               need_out=not placed,      # (placed: never run -- the descriptor of the owner's pseudo-batch for the backward)
+                                               check_index=check_index and not placed)
             for k, i in enumerate(idxs):
                 slot_of[i] = g["slot"][k]
             if placed:
@@ -258,7 +262,7 @@ class PreparedShardedStep:
                 self.bwd[self.groups.index(g)]["owner"].plan_ahead()
             if placed:
                 rc = lib.nrx_gather_place_feat(g["tp"], g["tr"], g["cols"], g["n"], W, g["capf"], g["oid"].data_ptr(), g["opos"].data_ptr(), g["D"],
-                                               self._peer_ptrs, self.ld, self.out.shape[0], None, stream)
+                                               self._peer_ptrs, self.ld, self.out.shape[0], ops._ptr(self.status), stream)
                 if rc:
                     ops.check(rc, "nrx_gather_place_feat")
                 continue
@@ -282,6 +286,32 @@ class PreparedShardedStep:
                 ops.check(rc, "nrx_fm_fwd")
             return (self.out, res[1], self.fm_out)
         return (self.out, res[1], res[2])
+
+    def check(self):
+        """Raise IndexError if a lookup of a run since the last check() named a row outside its table on ANY rank (every rank raises together: one
+        small all-reduce + one host read), RuntimeError if a block overflowed its capacity (lookups were dropped: redo with a larger slack).
+        Call it off the hot path -- shard_model_step_ does every 64th step."""
+        bad = torch.zeros(2, dtype=torch.int64, device=self.groups[0]["dev"] if self.groups else "cpu")
+        if self.status is not None:
+            bad[0] = self.status[0].to(torch.int64)
+        for g in self.groups:
+            if not g["pooled"] and not g["placed"] and g["owner_fwd"].status is not None:
+                bad[0] += g["owner_fwd"].status[0].to(torch.int64)
+            over = (g["overflow"][0] > (g["cap"] if g["pooled"] else g["capf"])).to(torch.int64)
+            bad[1] = torch.maximum(bad[1], over)
+        self.eng._all_reduce_max(bad)
+        n_bad, over = bad.tolist()
+        if self.status is not None:
+            self.status.zero_()
+        for g in self.groups:
+            g["overflow"].zero_()
+            if not g["pooled"] and not g["placed"] and g["owner_fwd"].status is not None:
+                g["owner_fwd"].status.zero_()
+        if n_bad:
+            raise IndexError("index out of range in self: a routed lookup named a row outside its table on some rank")
+        if over:
+            raise RuntimeError("PreparedShardedStep: an exchange block overflowed its capacity on some rank (lookups were dropped): ids too skewed for "
+                               "this slack -- rebuild the step with a larger `slack`")
 
     def overflowed(self) -> bool:
         """True if some (owner, feature) block exceeded its capacity since the last call (one host read per group)."""
@@ -565,7 +595,8 @@ def shard_model_step_(model, rank: int, world: int, group=None, host_staged: boo
             wbufs = [None if m is None else batch[m].detach().clone().contiguous() for m in masks]
             arenas = {t: model.embedding_tables[t].weight.data for t in table_names}
             step = PreparedShardedStep(eng, feats, bufs, wbufs, arenas, out_ld=out_ld, train=True, slack=slack, one_sided=one_sided,
-                                       binary_masks=binary_masks)
+                                       binary_masks=binary_masks, check_index=getattr(model, "index_check", "deferred") != "off")
+            step._calls = 0
             step._direct_grad_default = direct_grad
             anchor = torch.zeros(1, device=bufs[0].device, requires_grad=True)
             ent = model._shard_steps[key] = (step, bufs, wbufs, anchor)
@@ -575,6 +606,9 @@ def shard_model_step_(model, rank: int, world: int, group=None, host_staged: boo
         for w_, m in zip(wbufs, masks):
             if w_ is not None:
                 w_.copy_(batch[m])
+        step._calls += 1
+        if step._calls % 64 == 1 and step._calls > 1:       # deferred: out-of-range ids / dropped lookups of the last 64 steps surface here, on every rank
+            step.check()
         if torch.is_grad_enabled():
             out, fmv = _ShardedStepFn.apply(step, model._sparse_sink, scale, need_out, bool(fm), anchor)
         else:

@@ -450,3 +450,27 @@ def test_pool_owner_ids_payload_and_remap(world):
     tg = np.clip(send_tag.cpu().numpy(), None, None)
     tt = np.where((tg[before] >= 0) & (tg[before] < n * B), tg[before], 0)
     assert np.array_equal(order.cpu().numpy(), (before // cap) * (n * B) + tt)
+
+
+@pytest.mark.parametrize("one_sided", [False, True])
+def test_check_raises_index_error_and_overflow(one_sided):
+    """An id outside its table is an IndexError (the reference's nn.Embedding raises it on the CPU, base_model.py:271) -- deferred to check();
+    a block that overflowed its capacity is a RuntimeError (lookups were dropped)."""
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    feats = [ShardedFeature("a", NRX_SPARSE, "a", 16), ShardedFeature("b", NRX_SPARSE, "b", 16)]
+    arenas = {"a": shard_step.make_arena(500, 16, 0, 1, DEV, generator=gen), "b": shard_step.make_arena(90, 16, 0, 1, DEV, generator=gen)}
+    ids = [torch.randint(0, 500, (300,), device=DEV, generator=gen), torch.randint(0, 90, (300,), device=DEV, generator=gen)]
+    eng = RowShardedEmbedding(0, 1, overflow_policy="defer")
+    step = shard_step.PreparedShardedStep(eng, feats, ids, [None, None], arenas, one_sided=one_sided, check_index=True)
+    step.run()
+    step.check()                                         # clean
+    ids[1][7] = 90                                       # one past the table
+    step.run()
+    with pytest.raises(IndexError):
+        step.check()
+    ids[1][7] = 3
+    step.run()
+    step.check()                                         # the record was cleared
+    step.groups[0]["overflow"].fill_(10 ** 9)            # (a dropped block, as nrx_route_feat reports it)
+    with pytest.raises(RuntimeError, match="overflowed"):
+        step.check()
