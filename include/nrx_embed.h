@@ -703,6 +703,14 @@ NRX_API int nrx_bag_norm_weights_inv(const float* mask, int64_t batch, int32_t b
 NRX_API int nrx_route_bags(const void* const* ids, const float* const* weights, const int32_t* bag_lens, int32_t n_feats,
                    int32_t index_bits, int64_t batch, int32_t world, int64_t cap, int32_t* send_rows, int32_t* send_tag,
                    float* send_w, int64_t* counts2d, int64_t* overflow, int64_t* workspace, void* stream);
+/* nrx_route_bags in ONE launch (round 6): same arguments and the same results bit for bit (definition: oracle/ref_np.py route_bags), with a state
+ * block in the place of the workspace -- nrx_route_bags_one_state_bytes() device bytes, ZERO before the first call, then owned by the call (one
+ * stream at a time).  nrx_route_feat's construction (ballot ranks + published per-tile totals, an epoch mark, relaxed agent-scope polling) with the
+ * chain over all tiles of all features.  Slots past a block's count are left untouched, as nrx_route_bags leaves them. */
+NRX_API int64_t nrx_route_bags_one_state_bytes(const int32_t* bag_lens, int32_t n_feats, int64_t batch, int32_t world);
+NRX_API int nrx_route_bags_one(const void* const* ids, const float* const* weights, const int32_t* bag_lens, int32_t n_feats,
+                       int32_t index_bits, int64_t batch, int32_t world, int64_t cap, int32_t* send_rows, int32_t* send_tag,
+                       float* send_w, int64_t* counts2d, int64_t* overflow, void* state, void* stream);
 NRX_API int64_t nrx_pool_inbox_workspace(int32_t n_feats, int64_t batch, int32_t world);
 NRX_API int nrx_pool_inbox_fwd(const float* const* tables, const int64_t* table_rows, int32_t n_tables, const int32_t* feat_table,
                        int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,

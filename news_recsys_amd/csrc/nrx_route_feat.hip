@@ -42,8 +42,11 @@ struct RouteFeatArgs {
     int32_t* slot;            // [n_feats][batch]
     int64_t* counts;          // [world][n_feats]
     int64_t* overflow;
-    uint32_t* ctl;            // [0] ticket  [1] blocks done  [2] epoch
+    uint32_t* ctl;            // [0] ticket  [1] features done  [2] epoch  [8 + f] tiles of feature f done
     unsigned long long* agg;  // [n_feats * tiles][world]: (mark << 32) | total
+    int32_t use_ticket;       // 0: tile = blockIdx.x (every block of the launch is resident: nothing can wait for a block that has not started);
+                              // 1: tiles are handed out in start order.  The ticket is ONE address: the memory side serialises device-scope atomics
+                              // on it at ~40 ns each -- 416 tickets were 17 of the launch's 33 us (tools/bench_route_bags.py, the timing builds)
 };
 static_assert(sizeof(RouteFeatArgs) <= 3584, "kernarg budget");
 
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(RF_THREADS) void route_feat_kernel(const RouteFeatA
         return;
     }
     if (tid == 0) {
-        s_ticket = atomicAdd(&a->ctl[0], 1u);
+        s_ticket = a->use_ticket ? atomicAdd(&a->ctl[0], 1u) : blockIdx.x;
         s_mark = __hip_atomic_load(&a->ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     }
     if (tid < RF_MAX_WORLD) s_base[tid] = 0;
@@ -206,15 +209,196 @@ __global__ __launch_bounds__(RF_THREADS) void route_feat_kernel(const RouteFeatA
             }
         }
     }
-    // ---- re-arm: the block that finishes last advances the epoch and clears the counters (every other block is done polling)
+    // ---- re-arm: the block that finishes last advances the epoch and clears the counters (every other block is done polling).  Counted per feature
+    // first (T blocks per counter), then once per feature: n x T atomics on one address would serialise the launch's tail
     __syncthreads();
     if (tid == 0) {
-        const uint32_t done = atomicAdd(&a->ctl[1], 1u);
-        if (done == (uint32_t)(n * T) - 1u) {
-            __hip_atomic_store(&a->ctl[2], mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a->ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a->ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t fd = atomicAdd(&a->ctl[8 + f], 1u);
+        if (fd == (uint32_t)T - 1u) {
+            __hip_atomic_store(&a->ctl[8 + f], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t done = atomicAdd(&a->ctl[1], 1u);
+            if (done == (uint32_t)n - 1u) {
+                __hip_atomic_store(&a->ctl[2], mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a->ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a->ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
+    }
+}
+
+// ---- nrx_route_bags in ONE launch (round 6): the pooled-bag channel's routing -- same outputs, same layout (one block of `cap` slots per owner,
+// the features behind each other inside it, lookups with weight 0 not sent) -- by nrx_route_feat's construction with the chain running over ALL
+// tiles (tiles are enumerated feature-major, so "the entries of owner o before this tile" IS the position inside o's block): a tile publishes
+// its per-owner totals and adds up those of every earlier tile; a feature's last tile adds up the feature's tiles for counts2d; the last tile
+// of all raises the running overflow maximum.  (nrx_route_bags: histogram, scan and placement launches: 46 us for C4's 3.3 M lookups.)
+struct RouteBagsArgs {
+    const void* ids[NRX_MAX_FEATURES];
+    const float* weight[NRX_MAX_FEATURES];
+    int64_t len[NRX_MAX_FEATURES];           // batch * bag_len
+    int32_t bag_len[NRX_MAX_FEATURES];
+    uint64_t magic_len[NRX_MAX_FEATURES];    // floor(2^64 / bag_len) + 1: sample = umul64hi(entry, magic), exact for entries < 2^32 (a 64-bit division per
+                                             // entry was most of this launch's instruction count)
+    uint64_t magic_world;                    // the same for id / world
+    int32_t use_ticket;                      // as RouteFeatArgs::use_ticket
+    int32_t tile0[NRX_MAX_FEATURES + 1];     // first tile of each feature
+    int64_t batch, cap;
+    int32_t n_feats, world, idx64, tiles;
+    int32_t* send_rows;
+    int32_t* send_tag;
+    float* send_w;
+    int64_t* counts2d;                       // [world][n_feats]
+    int64_t* overflow;
+    uint32_t* ctl;
+    unsigned long long* agg;                 // [tiles][world]: a tile's totals
+    unsigned long long* gagg;                // [tiles / RB_GROUP][world]: the totals of a whole group of RB_GROUP tiles (published by the group's last tile)
+};
+static_assert(sizeof(RouteBagsArgs) <= 3584, "kernarg budget");
+constexpr int RB_GROUP = 32;                 // tiles per group of the two-level chain: a tile adds up <= 31 tile totals + tiles / 32 group totals,
+                                             // not every earlier tile's (800 tiles on C4: 320 k uncached polls per launch, the launch was no faster than
+                                             // the three it replaced)
+
+__global__ __launch_bounds__(RF_THREADS) void route_bags_one_kernel(const RouteBagsArgs args_in_kernarg) {
+    const NRX_CONST RouteBagsArgs* a = nrx_kernarg<RouteBagsArgs>();
+    __shared__ int s_cell[RF_ROUNDS * RF_WAVES][RF_MAX_WORLD];
+    __shared__ int s_tot[RF_MAX_WORLD], s_base[RF_MAX_WORLD], s_feat[RF_MAX_WORLD];
+    __shared__ uint32_t s_ticket, s_mark;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int W = a->world, n = a->n_feats, T = a->tiles;
+    if (tid == 0) {
+        s_ticket = a->use_ticket ? atomicAdd(&a->ctl[0], 1u) : blockIdx.x;
+        s_mark = __hip_atomic_load(&a->ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    }
+    if (tid < RF_MAX_WORLD) { s_base[tid] = 0; s_feat[tid] = 0; }
+    __syncthreads();
+    const int w = (int)s_ticket;
+    const uint32_t mark = s_mark;
+    int f = 0;
+    for (int i = 1; i < n; ++i) f += w >= a->tile0[i] ? 1 : 0;
+    const int tile = w - a->tile0[f];
+    const int64_t len = a->len[f], i0 = (int64_t)tile * RF_TILE;
+    int owner[RF_ROUNDS];
+    int32_t val[RF_ROUNDS];
+    float wt[RF_ROUNDS];
+    {
+        const void* p = a->ids[f];
+        const float* wp = a->weight[f];
+        int64_t id[RF_ROUNDS];
+#pragma unroll
+        for (int j = 0; j < RF_ROUNDS; ++j) {
+            const int64_t i = i0 + j * RF_THREADS + tid;
+            id[j] = 0;
+            wt[j] = 1.0f;
+            if (i < len) {
+                id[j] = a->idx64 ? nrx_gconst<int64_t>(p)[i] : (int64_t)nrx_gconst<int32_t>(p)[i];
+                if (wp != nullptr) wt[j] = nrx_gconst<float>(wp)[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RF_ROUNDS; ++j) {
+            const int64_t i = i0 + j * RF_THREADS + tid;
+            if (i >= len || wt[j] == 0.f) { owner[j] = -1; val[j] = 0; continue; }      // a lookup with weight 0 is not sent at all
+            if (id[j] < 0) { owner[j] = 0; val[j] = -1; }
+            else if (id[j] > 0x7fffffffLL) { owner[j] = 0; val[j] = 0x7fffffff; }
+            else {
+                const uint32_t u = (uint32_t)id[j], l = W == 1 ? u : (uint32_t)__umul64hi((uint64_t)u, a->magic_world);
+                owner[j] = (int)(u - l * (uint32_t)W);
+                val[j] = (int32_t)l;
+            }
+        }
+    }
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int rank[RF_ROUNDS];
+#pragma unroll
+    for (int j = 0; j < RF_ROUNDS; ++j) {
+        rank[j] = 0;
+        for (int t = 0; t < W; ++t) {
+            const unsigned long long m = __ballot(owner[j] == t);
+            if (owner[j] == t) rank[j] = __popcll(m & lt);
+            if (lane == t) s_cell[j * RF_WAVES + wid][t] = __popcll(m);
+        }
+    }
+    __syncthreads();
+    for (int o = wid; o < W; o += RF_WAVES) {
+        const int v = lane < RF_ROUNDS * RF_WAVES ? s_cell[lane][o] : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane < RF_ROUNDS * RF_WAVES) s_cell[lane][o] = incl - v;
+        if (lane == 63) {
+            s_tot[o] = incl;
+            __hip_atomic_store(&a->agg[(int64_t)w * W + o], ((unsigned long long)mark << 32) | (unsigned)incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // the entries of every owner before tile x (all features: the block layout packs them behind each other) = the totals of the whole groups
+    // before x's group + the totals of the tiles of x's group before x; one word per thread and round, summed with LDS integer atomics.
+    // Two phases, so that a group's total never waits for an earlier group's: (A) the tiles of the own group -> the group's last tile publishes
+    // the group total; (B) the earlier groups' totals.
+    auto poll = [&](const unsigned long long* p) -> int {
+        unsigned long long v;
+        do { v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((uint32_t)(v >> 32) != mark);
+        return (int)(uint32_t)v;
+    };
+    auto tiles_before_in_group = [&](int x, int* dst) {
+        const int g0 = x / RB_GROUP, nt = (x - g0 * RB_GROUP) * W;
+        for (int j = tid; j < nt; j += RF_THREADS) atomicAdd(&dst[j % W], poll(&a->agg[(int64_t)g0 * RB_GROUP * W + j]));
+    };
+    auto groups_before = [&](int x, int* dst) {
+        const int ng = (x / RB_GROUP) * W;
+        for (int j = tid; j < ng; j += RF_THREADS) atomicAdd(&dst[j % W], poll(&a->gagg[j]));
+    };
+    const bool last_of_feat = w + 1 == a->tile0[f + 1];
+#ifndef NRX_RB_NO_CHAIN          // (dev timing builds leave the chain out: wrong positions, the launch's time without its inter-block waits)
+    tiles_before_in_group(w, s_base);
+    __syncthreads();
+    if ((w % RB_GROUP) == RB_GROUP - 1 && tid < W)
+        __hip_atomic_store(&a->gagg[(int64_t)(w / RB_GROUP) * W + tid], ((unsigned long long)mark << 32) | (unsigned)(s_base[tid] + s_tot[tid]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    groups_before(w, s_base);
+    if (last_of_feat) {                                          // (where the feature began: counts2d = where it ends - where it began)
+        tiles_before_in_group(a->tile0[f], s_feat);
+        groups_before(a->tile0[f], s_feat);
+    }
+#endif
+    __syncthreads();
+    const int64_t cap = a->cap, B = a->batch;
+    const int L = a->bag_len[f];
+    const uint64_t magic_l = a->magic_len[f];
+    const int32_t tag0 = (int32_t)(f * B);
+#pragma unroll
+    for (int j = 0; j < RF_ROUNDS; ++j) {
+        if (owner[j] < 0) continue;
+        const int o = owner[j];
+        const int64_t i = i0 + j * RF_THREADS + tid;
+        const int64_t k = (int64_t)s_base[o] + s_cell[j * RF_WAVES + wid][o] + rank[j];
+#ifdef NRX_RB_NO_STORE
+        if (k < 0) {
+#else
+        if (k < cap) {
+#endif
+            const int64_t d = (int64_t)o * cap + k;
+            a->send_rows[d] = val[j];
+            a->send_tag[d] = tag0 + (L == 1 ? (int32_t)i : (int32_t)__umul64hi((uint64_t)i, magic_l));
+            a->send_w[d] = wt[j];
+        }
+    }
+    if (last_of_feat && tid < W) a->counts2d[(int64_t)tid * n + f] = (int64_t)s_base[tid] + s_tot[tid] - s_feat[tid];
+    if (w == T - 1 && tid == 0) {
+        long long worst = 0;
+        for (int o = 0; o < W; ++o) {
+            const long long c = (long long)s_base[o] + s_tot[o];
+            worst = c > worst ? c : worst;
+        }
+        atomicMax(reinterpret_cast<long long*>(a->overflow), worst);
+    }
+    // ---- re-arm: the LAST tile has, by then, read a word of every group and of every tile of its own group: every block of the launch has read the
+    // epoch (it published with it) and taken its ticket -- no count of finished blocks is needed (T atomics on one address would serialise the tail)
+    __syncthreads();
+    if (w == T - 1 && tid == 0) {
+        __hip_atomic_store(&a->ctl[2], mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a->ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -316,6 +500,28 @@ __global__ __launch_bounds__(NRX_BLOCK) void shard_dest_combine_kernel(const int
     }
 }
 
+// May the launch take tile = blockIdx.x (no ticket)?  When every one of its blocks fits the device at once: then no block can wait for one that
+// never gets a slot.  (Blocks are dispatched in index order per XCD -- block i to XCD i % 8 -- so even with part of the device held by another
+// stream the smallest unstarted tile's XCD only runs smaller tiles, which do not wait for it; the ticket path needs no such argument and serves
+// the larger launches.)  Occupancy is asked of the runtime once per kernel.
+bool all_resident(const void* kernel, int64_t blocks) {
+    static thread_local const void* cached_k[4] = {nullptr, nullptr, nullptr, nullptr};
+    static thread_local int64_t cached_cap[4] = {0, 0, 0, 0};
+    int64_t capacity = -1;
+    for (int i = 0; i < 4; ++i)
+        if (cached_k[i] == kernel) capacity = cached_cap[i];
+    if (capacity < 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RF_THREADS, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return false;
+        capacity = (int64_t)per_cu * cus;
+        for (int i = 0; i < 4; ++i)
+            if (cached_k[i] == nullptr) { cached_k[i] = kernel; cached_cap[i] = capacity; break; }
+    }
+    return blocks <= capacity;
+}
+
 }      // namespace
 
 extern "C" int nrx_shard_dest_combine(const int32_t* slot, const int32_t* dest_req, int32_t n_feats, int64_t batch, int64_t capf, int64_t recv_row0,
@@ -381,7 +587,7 @@ extern "C" int nrx_gather_place_feat(const float* const* tables, const int64_t* 
 extern "C" int64_t nrx_route_feat_state_bytes(int32_t n_feats, int64_t batch, int32_t world) {
     if (n_feats < 1 || n_feats > NRX_MAX_FEATURES || batch < 0 || world < 1 || world > RF_MAX_WORLD) return -1;
     const int64_t tiles = (batch + RF_TILE - 1) / RF_TILE;
-    return 64 + (int64_t)n_feats * (tiles > 0 ? tiles : 1) * world * 8;
+    return 512 + (int64_t)n_feats * (tiles > 0 ? tiles : 1) * world * 8;
 }
 
 extern "C" int nrx_route_feat(const void* const* ids, int32_t n_feats, int64_t batch, int32_t index_bits, int32_t world, int64_t capf,
@@ -412,9 +618,64 @@ extern "C" int nrx_route_feat(const void* const* ids, int32_t n_feats, int64_t b
     a.counts = counts;
     a.overflow = overflow;
     a.ctl = reinterpret_cast<uint32_t*>(state);
-    a.agg = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(state) + 64);
+    a.agg = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(state) + 512);
+    a.use_ticket = world > 1 && !all_resident(reinterpret_cast<const void*>(route_feat_kernel), (int64_t)n_feats * a.tiles);
     hipLaunchKernelGGL(route_feat_kernel, dim3((unsigned)(n_feats * a.tiles)), dim3(RF_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
     NRX_LAUNCH_CHECK("nrx_route_feat");
+    return NRX_OK;
+}
+
+extern "C" int64_t nrx_route_bags_one_state_bytes(const int32_t* bag_lens, int32_t n_feats, int64_t batch, int32_t world) {
+    if (bag_lens == nullptr || n_feats < 1 || n_feats > NRX_MAX_FEATURES || batch < 0 || world < 1 || world > RF_MAX_WORLD) return -1;
+    int64_t tiles = 0;
+    for (int f = 0; f < n_feats; ++f) tiles += (batch * bag_lens[f] + RF_TILE - 1) / RF_TILE;
+    return 64 + ((tiles > 0 ? tiles : 1) + tiles / RB_GROUP + 1) * world * 8;
+}
+
+extern "C" int nrx_route_bags_one(const void* const* ids, const float* const* weights, const int32_t* bag_lens, int32_t n_feats, int32_t index_bits,
+                                  int64_t batch, int32_t world, int64_t cap, int32_t* send_rows, int32_t* send_tag, float* send_w, int64_t* counts2d,
+                                  int64_t* overflow, void* state, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(ids && bag_lens && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES, "nrx_route_bags_one: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
+    NRX_REQUIRE(index_bits == 32 || index_bits == 64, "nrx_route_bags_one: index_bits must be 32 or 64");
+    NRX_REQUIRE(world >= 1 && world <= RF_MAX_WORLD && cap >= 1 && cap * world <= 0x7fffffffLL && batch >= 0, "nrx_route_bags_one: bad world / cap / batch");
+    NRX_REQUIRE((int64_t)n_feats * batch <= 0x7fffffffLL, "nrx_route_bags_one: n_feats * batch must fit 31 bits");
+    NRX_REQUIRE(send_rows && send_tag && send_w && counts2d && overflow && state, "nrx_route_bags_one: null buffer");
+    RouteBagsArgs a;
+    memset(&a, 0, sizeof(a));
+    int64_t tiles = 0, total = 0;
+    for (int f = 0; f < n_feats; ++f) {
+        NRX_REQUIRE(bag_lens[f] >= 1 && (batch == 0 || ids[f] != nullptr), "nrx_route_bags_one: feature %d: bad ids / bag_len", f);
+        a.ids[f] = ids[f];
+        a.weight[f] = weights ? weights[f] : nullptr;
+        a.len[f] = batch * bag_lens[f];
+        a.bag_len[f] = bag_lens[f];
+        a.magic_len[f] = bag_lens[f] > 1 ? ~0ull / (uint64_t)bag_lens[f] + 1 : 0;
+        a.tile0[f] = (int32_t)tiles;
+        tiles += (a.len[f] + RF_TILE - 1) / RF_TILE;
+        total += a.len[f];
+    }
+    a.tile0[n_feats] = (int32_t)tiles;
+    a.magic_world = world > 1 ? ~0ull / (uint64_t)world + 1 : 0;
+    NRX_REQUIRE(total <= 0x7fffffffLL && tiles < (1 << 24), "nrx_route_bags_one: too many ids for one exchange");
+    if (tiles == 0) return NRX_OK;
+    a.batch = batch;
+    a.cap = cap;
+    a.n_feats = n_feats;
+    a.world = world;
+    a.idx64 = index_bits == 64;
+    a.tiles = (int32_t)tiles;
+    a.send_rows = send_rows;
+    a.send_tag = send_tag;
+    a.send_w = send_w;
+    a.counts2d = counts2d;
+    a.overflow = overflow;
+    a.ctl = reinterpret_cast<uint32_t*>(state);
+    a.agg = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(state) + 64);
+    a.gagg = a.agg + tiles * world;
+    a.use_ticket = !all_resident(reinterpret_cast<const void*>(route_bags_one_kernel), tiles);
+    hipLaunchKernelGGL(route_bags_one_kernel, dim3((unsigned)tiles), dim3(RF_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
+    NRX_LAUNCH_CHECK("nrx_route_bags_one");
     return NRX_OK;
 }
 

@@ -807,6 +807,11 @@ class PreparedShardedForward:
                  nt=len(loc), ft=(C.c_int32 * n)(*[table_names.index(feats[i].table) for i in idxs]), dev=dev)
         if W == 1:
             g["inbox"], g["inbox_tag"], g["inbox_w"], g["recv2d"], g["ret"] = g["send"], g["send_tag"], g["send_w"], g["counts2d"], g["partial"]
+        import os
+        if os.environ.get("NRX_ROUTE_BAGS", "one") != "legacy":      # the one-launch routing (round 6); "legacy": histogram + scan + placement launches
+            nb = self.lib.nrx_route_bags_one_state_bytes(g["bl"], n, B, W)
+            if nb > 0:
+                g["rstate"] = torch.zeros(nb, dtype=torch.uint8, device=dev)
         return g
 
     def _run_pooled(self, g, stream):
@@ -819,9 +824,14 @@ class PreparedShardedForward:
                 rc = lib.nrx_bag_norm_weights(None if m is None else m.data_ptr(), g["B"], L, kind, w.data_ptr(), stream)
             if rc:
                 ops.check(rc, "nrx_bag_norm_weights")
-        rc = lib.nrx_route_bags(g["ptrs"], g["wptrs"], g["bl"], g["n"], g["bits"], g["B"], W, g["cap"], g["send"].data_ptr(),
-                                g["send_tag"].data_ptr(), g["send_w"].data_ptr(), g["counts2d"].data_ptr(), g["overflow"].data_ptr(),
-                                g["ws"].data_ptr(), stream)
+        if g.get("rstate") is not None:
+            rc = lib.nrx_route_bags_one(g["ptrs"], g["wptrs"], g["bl"], g["n"], g["bits"], g["B"], W, g["cap"], g["send"].data_ptr(),
+                                        g["send_tag"].data_ptr(), g["send_w"].data_ptr(), g["counts2d"].data_ptr(), g["overflow"].data_ptr(),
+                                        g["rstate"].data_ptr(), stream)
+        else:
+            rc = lib.nrx_route_bags(g["ptrs"], g["wptrs"], g["bl"], g["n"], g["bits"], g["B"], W, g["cap"], g["send"].data_ptr(),
+                                    g["send_tag"].data_ptr(), g["send_w"].data_ptr(), g["counts2d"].data_ptr(), g["overflow"].data_ptr(),
+                                    g["ws"].data_ptr(), stream)
         if rc:
             ops.check(rc, "nrx_route_bags")
         if W > 1:

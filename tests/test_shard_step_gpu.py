@@ -474,3 +474,47 @@ def test_check_raises_index_error_and_overflow(one_sided):
     step.groups[0]["overflow"].fill_(10 ** 9)            # (a dropped block, as nrx_route_feat reports it)
     with pytest.raises(RuntimeError, match="overflowed"):
         step.check()
+
+
+@pytest.mark.parametrize("world", [1, 2, 5, 8])
+@pytest.mark.parametrize("dt", [torch.int64, torch.int32])
+def test_route_bags_one_launch_equals_its_definition_and_the_three_launch_form(world, dt):
+    """nrx_route_bags_one: the pooled channel's routing in one launch -- integer work (and verbatim float weights), bit-exact against
+    oracle/ref_np.py route_bags on the slots in use and against nrx_route_bags on every output word it defines; repeated launches on one state."""
+    lib = _lib.load()
+    rng = np.random.default_rng(60 + world)
+    state = None
+    for rep, (n, B, Ls, rows) in enumerate(((1, 300, [7], 1000), (3, 2000, [9, 1, 50], 200_000), (2, 9000, [50, 3], 5_000_000))):
+        ids_np = [rng.integers(0, rows, (B, L)) for L in Ls]
+        w_np = [((rng.random((B, L)) < 0.6) * rng.random((B, L))).astype(np.float32) for L in Ls]
+        if dt is torch.int64:
+            ids_np[0][0, 0] = -3
+            ids_np[0][1, 0] = (1 << 31) + 9
+            w_np[0][0, 0] = w_np[0][1, 0] = 0.5
+        total = sum(int((w != 0).sum()) for w in w_np)
+        cap = total + 64 if world == 1 else int(total / world * 1.4) + 64
+        ids = [torch.from_numpy(x).to(DEV).to(dt) for x in ids_np]
+        ws = [torch.from_numpy(x).to(DEV) for x in w_np]
+        want = ref_np.route_bags([x if dt is torch.int64 else x.astype(np.int32) for x in ids_np], w_np, world, cap)
+        l_rows, l_tag, l_w, l_c2d, l_over = ops.route_bags(ids, ws, world, cap)                      # the three-launch form
+        rows_o = torch.full((world * cap,), -7, dtype=torch.int32, device=DEV)
+        tag_o = torch.full((world * cap,), -7, dtype=torch.int32, device=DEV)
+        w_o = torch.full((world * cap,), -7.0, dtype=torch.float32, device=DEV)
+        c2d = torch.full((world, n), -1, dtype=torch.int64, device=DEV)
+        over = torch.zeros(1, dtype=torch.int64, device=DEV)
+        bl = (C.c_int32 * n)(*Ls)
+        state = torch.zeros(lib.nrx_route_bags_one_state_bytes(bl, n, B, world), dtype=torch.uint8, device=DEV)
+        for _ in range(2):                                                                            # the chain re-arms itself
+            ops.check(lib.nrx_route_bags_one((C.c_void_p * n)(*[x.data_ptr() for x in ids]), (C.c_void_p * n)(*[x.data_ptr() for x in ws]), bl, n,
+                                             ids[0].element_size() * 8, B, world, cap, rows_o.data_ptr(), tag_o.data_ptr(), w_o.data_ptr(),
+                                             c2d.data_ptr(), over.data_ptr(), state.data_ptr(), torch.cuda.current_stream().cuda_stream), "route_bags_one")
+        torch.cuda.synchronize()
+        assert np.array_equal(c2d.cpu().numpy(), want[3]) and int(over.item()) == want[4]
+        assert torch.equal(c2d, l_c2d)
+        used = np.zeros(world * cap, bool)
+        for o in range(world):
+            used[o * cap: o * cap + min(int(want[3][o].sum()), cap)] = True
+        assert np.array_equal(rows_o.cpu().numpy()[used], want[0][used]) and np.array_equal(tag_o.cpu().numpy()[used], want[1][used])
+        assert np.array_equal(w_o.cpu().numpy()[used], want[2][used])
+        assert np.array_equal(rows_o.cpu().numpy()[used], l_rows.cpu().numpy()[used]) and np.array_equal(w_o.cpu().numpy()[used], l_w.cpu().numpy()[used])
+        assert (rows_o.cpu().numpy()[~used] == -7).all()                                              # slots past a block's count: untouched
