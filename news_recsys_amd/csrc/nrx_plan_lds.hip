@@ -477,14 +477,12 @@ __global__ __launch_bounds__(PL_THREADS) void plan_lds_kernel(const PlanLdsArgs 
         }
     }
     PL_T(7);
-    // ---- the last block out re-arms the state
-    if (tid == 0) {
-        const uint32_t d = atomicAdd(&a->ctl[1], 1u);
-        if (d == (uint32_t)a->n_blocks - 1) {
-            a->ctl[0] = 0;
-            a->ctl[1] = 0;
-            __hip_atomic_store(&a->ctl[2], mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    // ---- the LAST block of the chain re-arms the state: it has read the published totals of every other block, so every block has read the epoch
+    // (a block publishes with it) and taken its ticket.  (Round 5 counted the finished blocks in ctl[1]: n_blocks device-scope atomics on ONE address,
+    // which the memory side serialises at ~40 ns each -- blocks that finish together queued for up to 8 us of the launch's tail.)
+    if (tid == 0 && w == a->n_blocks - 1) {
+        a->ctl[0] = 0;
+        __hip_atomic_store(&a->ctl[2], mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
