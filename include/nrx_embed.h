@@ -85,6 +85,10 @@ typedef struct nrx_feature {
  * (NRX_FEAT_ROW0_IS_DATA is likewise honoured by nrx_embed_bwd only: for the sorted backward row 0 of every table is the
  * padding row and gets a zero gradient.) */
 #define NRX_FEAT_BAG_CSR 2
+/* nrx_feature.flags, single-valued features of the sorted backward (nrx_embed_bwd_sorted / _placed / _walk): the caller knows that the feature's
+ * lookups outnumber the rows they name many times over (a bag feature flattened into one pseudo-feature: the sharded step's pooled channel) -- rows
+ * leave the in-order walk for the wavefront-per-chunk work lists from 32 lookups on, as in a launch with bag features, instead of 16. */
+#define NRX_FEAT_MANY_PER_ROW 4
 
 /* ---- library ---------------------------------------------------------------------------- */
 NRX_API int nrx_abi_version(void);

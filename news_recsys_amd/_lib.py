@@ -34,6 +34,7 @@ NRX_PLAN_PAYLOAD = 4
 NRX_SPARSE, NRX_DENSE, NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM = 0, 1, 2, 3, 4
 NRX_FEAT_ROW0_IS_DATA = 1
 NRX_FEAT_BAG_CSR = 2
+NRX_FEAT_MANY_PER_ROW = 4
 
 
 class NrxFeature(C.Structure):

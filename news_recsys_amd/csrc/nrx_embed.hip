@@ -1654,37 +1654,91 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
         if (lng[r] && q == 0) need += (int)((hi[r] - lo[r] + SORTED_LONG_CHUNK - 1) / SORTED_LONG_CHUNK);
     }
     if (__ballot(need != 0) != 0ull) {                       // wave-uniform
+        // Round 6: ONE request per wavefront to the item / multi-row counters (a 64-bit add on the adjacent words long_ws[0] | long_ws[1]) and one more
+        // to the slot counter only when the wavefront holds a multi-item row -- the memory side serialises requests to one line at ~40 ns each, and a
+        // Zipf batch sent three per wavefront with long rows (C2 Zipf: ~570 requests = 23 of the walk's 44 us).  And the items of a row of many
+        // chunks are written by the WHOLE wavefront: the hottest row of C4's Zipf batch is ~960 items, which one lane wrote one after the other.
         const int lane = threadIdx.x & 63;
-        int incl = need;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        int base = 0;
-        if (lane == 63) base = atomicAdd(&a->long_ws[0], incl);
-        base = __shfl(base, 63, 64) + incl - need;
+        int n_multi = 0, n_slots = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (lng[r] && q == 0) {
                 const int nchunks = (int)((hi[r] - lo[r] + SORTED_LONG_CHUNK - 1) / SORTED_LONG_CHUNK);
+                if (nchunks > 1) { ++n_multi; n_slots += sorted_long_slots(nchunks); }
+            }
+        }
+        unsigned long long packed = (unsigned long long)(uint32_t)need | ((unsigned long long)(uint32_t)n_multi << 32);
+        unsigned long long incl = packed;
+        int incl_s = n_slots;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long t = __shfl_up(incl, off, 64);
+            const int ts = __shfl_up(incl_s, off, 64);
+            if (lane >= off) { incl += t; incl_s += ts; }
+        }
+        unsigned long long base2 = 0;
+        int base_s = 0;
+        const int tot_s = __shfl(incl_s, 63, 64);
+        if (lane == 63) {
+            base2 = atomicAdd(reinterpret_cast<unsigned long long*>(a->long_ws), incl);      // (long_ws is 16-byte aligned: [0] items, [1] multi-item rows)
+            if (tot_s != 0) base_s = atomicAdd(&a->long_ws[2], tot_s);
+        }
+        base2 = __shfl(base2, 63, 64) + incl - packed;
+        int base = (int)(uint32_t)base2, m_next = (int)(uint32_t)(base2 >> 32);
+        int slot_next = __shfl(base_s, 63, 64) + incl_s - n_slots;
+        // per row: its first item, its slots, its multi-row record; rows of more than a few chunks are handed to the whole wavefront below
+        constexpr int COOP = 4;
+        int c_n[R], c_slot0[R], c_base[R], c_m[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            c_n[r] = 0; c_slot0[r] = -1; c_base[r] = 0; c_m[r] = -1;
+            if (lng[r] && q == 0) {
+                const int nchunks = (int)((hi[r] - lo[r] + SORTED_LONG_CHUNK - 1) / SORTED_LONG_CHUNK);
                 int slot0 = -1, m = -1;
                 if (nchunks > 1) {
-                    slot0 = atomicAdd(&a->long_ws[2], sorted_long_slots(nchunks));
-                    m = atomicAdd(&a->long_ws[1], 1);
+                    slot0 = slot_next;
+                    slot_next += sorted_long_slots(nchunks);
+                    m = m_next++;
                     if (m < a->long_slots_cap) {
                         LongMulti w;
                         w.u = (int32_t)urow[r]; w.slot0 = slot0; w.nchunks = nchunks; w.done = 0;
                         sorted_long_multi(a)[m] = w;
                     }
-                    const int ng = sorted_long_groups(nchunks);
-                    if (ng != 0 && (int64_t)slot0 + sorted_long_slots(nchunks) <= a->long_slots_cap) {      // the group counters start at zero
-                        int32_t* gc = reinterpret_cast<int32_t*>(sorted_long_partials(a) + (int64_t)(slot0 + nchunks + ng) * (4 * Q));
-                        for (int j = 0; j < ng; ++j) gc[j] = 0;
-                    }
                 }
-                sorted_long_write_items(a, (int32_t)urow[r], lo[r], hi[r], nchunks, slot0, base, m);
+                if (nchunks <= COOP) {
+                    const int ng = sorted_long_groups(nchunks);      // (0 for so few chunks)
+                    (void)ng;
+                    sorted_long_write_items(a, (int32_t)urow[r], lo[r], hi[r], nchunks, slot0, base, m);
+                } else {
+                    c_n[r] = nchunks; c_slot0[r] = slot0; c_base[r] = base; c_m[r] = m;
+                }
                 base += nchunks;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            unsigned long long todo = __ballot(c_n[r] != 0);
+            while (todo != 0ull) {                               // wave-uniform: one row of many chunks at a time, every lane writes items
+                const int src = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const int nchunks = __shfl(c_n[r], src, 64), slot0 = __shfl(c_slot0[r], src, 64), b0 = __shfl(c_base[r], src, 64), m = __shfl(c_m[r], src, 64);
+                const int32_t u = (int32_t)__shfl(urow[r], src, 64);
+                const int64_t rlo = __shfl(lo[r], src, 64), rhi = __shfl(hi[r], src, 64);
+                for (int c = lane; c < nchunks; c += 64) {
+                    if (b0 + c >= a->long_items_cap) break;
+                    LongItem w;
+                    w.u = u;
+                    w.dest = slot0 + c;
+                    w.e_begin = rlo + (int64_t)c * SORTED_LONG_CHUNK;
+                    w.len = (int32_t)((w.e_begin + SORTED_LONG_CHUNK < rhi ? w.e_begin + SORTED_LONG_CHUNK : rhi) - w.e_begin);
+                    w.m = m;
+                    sorted_long_items(a)[b0 + c] = w;
+                }
+                const int ng = sorted_long_groups(nchunks);
+                if (ng != 0 && (int64_t)slot0 + sorted_long_slots(nchunks) <= a->long_slots_cap) {      // the group counters start at zero
+                    int32_t* gc = reinterpret_cast<int32_t*>(sorted_long_partials(a) + (int64_t)(slot0 + nchunks + ng) * (4 * Q));
+                    for (int j = lane; j < ng; j += 64) gc[j] = 0;
+                }
             }
         }
     }
@@ -3356,17 +3410,13 @@ static int embed_bwd_sorted_impl(const nrx_feature_t* feats, int32_t n_feats, in
     // threshold sweep (T = 16 / 24 / 32 / 48 / 64, fwd+bwd us): C4 521 / 505 / 493 / 492 / 492, C4 Zipf 581 / 575 / 564 / 598 / 674,
     // C2 Zipf 501 / 545 / 588 / 678 / 758, C5 478 / 491 / 527 / 578 / 618: bag launches (a few rows, each looked up ~L times) take 32
     if (has_bag) a.long_t = 2 * SORTED_LONG_T;
-    {   // a launch of single-valued features whose lookups outnumber the rows of their tables eight times over (the sharded step's pooled channel: a
-        // bag feature's lookups arrive at the owner as ONE single-valued pseudo-feature, ~16 lookups per row of the pooled table) has the row
-        // statistics of a bag launch: the same threshold (measured there: 16 -> 32 is -5 % on C4)
-        int64_t distinct_rows = 0;
-        for (int i = 0; i < n_feats; ++i) {
-            bool seen = false;
-            for (int j = 0; j < i; ++j) seen |= feats[j].table == feats[i].table && feats[j].rows == feats[i].rows && feats[i].table != nullptr;
-            if (!seen) distinct_rows += feats[i].rows;
-        }
-        if (!has_bag && distinct_rows > 0 && off >= 8 * distinct_rows) a.long_t = 2 * SORTED_LONG_T;
-    }
+    // NRX_FEAT_MANY_PER_ROW (the sharded step's pooled channel: a bag feature's lookups arrive at the owner as ONE single-valued pseudo-feature, ~16
+    // lookups per row of the pooled table): the row statistics of a bag launch, hence its threshold (16 -> 32: the walk 110 -> 68 us, the work lists
+    // 103 -> 5 us on C4's pseudo-batch).  A flag of the CALLER, not a guess from the table sizes: the threshold decides which rows leave the
+    // in-order walk for the tree-summed work lists, so two call paths of one launch must agree on it to produce the same bits (a heuristic on
+    // feats[].rows -- which the row-sparse and the dense entry points fill differently -- broke exactly that: tests/stress_embed_bwd.py).
+    for (int i = 0; i < n_feats; ++i)
+        if (!has_bag && (feats[i].flags & NRX_FEAT_MANY_PER_ROW)) a.long_t = 2 * SORTED_LONG_T;
     if (const char* e = getenv("NRX_LONG_T")) { const int v = atoi(e); if (v >= 2 && v <= 256) a.long_t = v; }      // measurement knob
     // placement mode: single-lookup rows are stored by the placement pass, the walk reduces the listed rows only
     const bool placed = fast && dest != nullptr;

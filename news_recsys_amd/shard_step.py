@@ -371,7 +371,7 @@ class PreparedShardedStep:
                 else:
                     b["rows"] = torch.zeros((W * cap, D), dtype=torch.float32, device=g["dev"])
                     b["owner"] = ops.PreparedSparseBackward(pfwd, b["rows"])
-                b["owner"].groups[0]["arr"][0].rows = arena.shape[0]      # (the reduction picks its long-row threshold by lookups per table row)
+                b["owner"].groups[0]["arr"][0].flags |= _lib.NRX_FEAT_MANY_PER_ROW      # (~L lookups per row: the bag threshold of the work lists)
                 self.bwd.append(b)
                 continue
             n, D, Bp = g["n"], g["D"], g["Bp"]
