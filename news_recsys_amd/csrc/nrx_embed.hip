@@ -982,7 +982,10 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_kernel(const Sorte
 
 // ---- work lists of the long-segment path (workspace layout: 4 counters | items | multi-chunk rows | partial sums)
 constexpr int SORTED_LONG_T = 16;            // segments longer than this leave the lane-group kernel (32 for bag launches)
-constexpr int SORTED_LONG_CHUNK = 256;       // entries per work item (small: items are the unit of load balance)
+#ifndef NRX_LONG_CHUNK
+#define NRX_LONG_CHUNK 256
+#endif
+constexpr int SORTED_LONG_CHUNK = NRX_LONG_CHUNK;       // entries per work item (small: items are the unit of load balance)
 struct LongItem { int32_t u; int32_t dest; int64_t e_begin; int32_t len; int32_t m; };      // dest < 0: straight to values[u]; m: its row's LongMulti (several items)
 struct LongMulti { int32_t u; int32_t slot0; int32_t nchunks; int32_t done; };              // done: items (or item GROUPS) of the row finished so far (the last one adds the partials)
 // Rows of more than SORTED_LONG_GROUP items (> 8192 lookups: the hottest ids of a Zipf law) count their items in groups of that many: a group's
