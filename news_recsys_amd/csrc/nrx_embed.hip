@@ -1777,6 +1777,11 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
             for (int j = 0; j < (WIDE ? 1 : UP); ++j) pn[r][j] = nrx_gconst<int64_t>(a->order)[e[r] + j < hi[r] ? e[r] + j : lo[0]];
         }
     }
+    // FM fields: the forward value v of a lookup is its table row -- the SAME bits for every lookup of one unique row (the forward copies rows
+    // verbatim) -- so a row's first entry fetches it and the others reuse it: one 128-byte line per ROW instead of per lookup, same fold, same
+    // bits (Zipf ids: half of the lookups sit on rows looked up more than 16 times; the walk and the work lists read a third less).
+    float4 vrow[R];
+    bool have_v = false;
     auto pass = [&]() -> bool {
         int64_t p[R][UP];
         bool on[R][UP];
@@ -1812,7 +1817,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
                     g[r][j] = up_g != nullptr ? nrx_ldg4(up_g, (b * up_ld + col) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);      // (no g_out: an FM model whose loss reads the logit only)
                     if (FM) {
                         gf[r][j] = reg_fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
-                        v[r][j] = nrx_ldg4(a->feat, (b * a->feat_ld + col) / 4 + q);
+                        if (j == 0 && !have_v) v[r][0] = nrx_ldg4(a->feat, (b * a->feat_ld + col) / 4 + q);
                         s[r][j] = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
                     }
                     continue;
@@ -1828,17 +1833,22 @@ __global__ __launch_bounds__(NRX_BLOCK) void embed_bwd_sorted_fast_kernel(const 
                 }
                 if (FM) {
                     gf[r][j] = f.fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
-                    v[r][j] = nrx_ldg4(a->feat, (b * a->feat_ld + f.out_col) / 4 + q);
+                    if (j == 0 && !have_v) v[r][0] = nrx_ldg4(a->feat, (b * a->feat_ld + f.out_col) / 4 + q);
                     s[r][j] = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
                 }
             }
+        if (FM && !have_v) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) vrow[r] = v[r][0];
+            have_v = true;
+        }
         bool more = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
 #pragma unroll
             for (int j = 0; j < UP; ++j) {
                 float4 t = g[r][j];
-                if (FM) fm_fold4(t, gf[r][j], s[r][j], v[r][j], q);      // d fm / d field: column 0 -> 1, column k -> S_k - v_k
+                if (FM) fm_fold4(t, gf[r][j], s[r][j], vrow[r], q);      // d fm / d field: column 0 -> 1, column k -> S_k - v_k
                 if (on[r][j]) {               // added in sorted order: j ascending inside the pass
                     if (BAG) {
 #pragma clang fp contract(off)
@@ -1996,6 +2006,8 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
             }
         } else {
         constexpr int UL = Q < 8 ? Q : 8;                       // rows in flight per lane group (a chunk gives every group Q entries)
+        float4 vrow = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool have_v = false;
         int64_t pw_next = nrx_gconst<int64_t>(a->order)[w.e_begin + lane < w_end ? w.e_begin + lane : w.e_begin];
         for (int64_t c0 = w.e_begin; c0 < w_end; c0 += 64) {
             const int64_t pw = pw_next;
@@ -2011,7 +2023,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
                     on[k] = c0 + idx < w_end;
                     p[k] = __shfl(pw, idx, 64);
                 }
-                float4 gr[UL], v[UL], s_[UL];
+                float4 gr[UL], s_[UL];
                 float gf[UL], sc[UL];
 #pragma unroll
                 for (int k = 0; k < UL; ++k) {
@@ -2023,7 +2035,7 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
                         gr[k] = up_g != nullptr ? nrx_ldg4(up_g, (b * up_ld + col) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);
                         if (FM) {
                             gf[k] = reg_fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
-                            v[k] = nrx_ldg4(a->feat, (b * a->feat_ld + col) / 4 + q);
+                            if (k == 0 && !have_v) vrow = nrx_ldg4(a->feat, (b * a->feat_ld + col) / 4 + q);      // (the item's row: one forward value for all its entries)
                             s_[k] = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
                         }
                         continue;
@@ -2039,14 +2051,15 @@ __global__ __launch_bounds__(NRX_BLOCK) void sorted_long_kernel(const SortedBwdA
                     }
                     if (FM) {
                         gf[k] = f.fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
-                        v[k] = nrx_ldg4(a->feat, (b * a->feat_ld + f.out_col) / 4 + q);
+                        if (k == 0 && !have_v) vrow = nrx_ldg4(a->feat, (b * a->feat_ld + f.out_col) / 4 + q);
                         s_[k] = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
                     }
                 }
+                have_v = true;
 #pragma unroll
                 for (int k = 0; k < UL; ++k) {
                     float4 t = gr[k];
-                    if (FM) fm_fold4(t, gf[k], s_[k], v[k], q);
+                    if (FM) fm_fold4(t, gf[k], s_[k], vrow, q);
                     if (on[k]) {
                         if (BAG) {
 #pragma clang fp contract(off)
