@@ -1111,6 +1111,7 @@ def main():
             # the leg is not only timed: every group's plan must list each (table, row) once, ascending, with segments that tile
             # the lookups exactly (a mis-sorted plan would still run at full speed)
             planners = []
+            fwd[0].run()          # (the concat and the FM field sums the backward folds in must be THIS batch's: the output buffer is recycled over the id pool)
             for g in bwd[0].run():
                 nu = int(g["counts"][0].item())
                 uq, sg = g["uniq"][:nu], g["seg"][:nu + 1]

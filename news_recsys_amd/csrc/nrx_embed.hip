@@ -1529,8 +1529,11 @@ __device__ __forceinline__ void pairs_body(const NRX_CONST SortedBwdArgs* a, con
     if (i < cap) rec = recs[i];                         // requested next to the count: a record past the count is read (inside the buffer) and dropped
     int64_t n = nrx_gconst<int64_t>(a->bag_inv)[0];
     n = n < cap ? n : cap;
-    auto row_of = [&](int64_t p) -> float4 {          // the gradient row chunk of lookup p, as the walk forms it
-        float4 g, v = make_float4(0.f, 0.f, 0.f, 0.f), s = v;
+    // (FM: the row's forward value is fetched with its FIRST lookup and reused for the second -- the same bits for every lookup of a row, and what
+    //  the walk does for the rows it reduces: both planners' plans give the same gradient even over a concat that does not belong to these ids)
+    float4 v_first = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto row_of = [&](int64_t p, bool first) -> float4 {          // the gradient row chunk of lookup p, as the walk forms it
+        float4 g, v = v_first, s = make_float4(0.f, 0.f, 0.f, 0.f);
         float gf = 0.f;
         if (REG && !UNAL) {
             const int fi = (int)__umul64hi((uint64_t)p, reg_magic);
@@ -1539,7 +1542,7 @@ __device__ __forceinline__ void pairs_body(const NRX_CONST SortedBwdArgs* a, con
             g = a->g_out != nullptr ? nrx_ldg4(a->g_out, (b * a->out_ld + col) / 4 + q) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (FM) {
                 gf = reg_fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
-                v = nrx_ldg4(a->feat, (b * a->feat_ld + col) / 4 + q);
+                if (first) v = v_first = nrx_ldg4(a->feat, (b * a->feat_ld + col) / 4 + q);
                 s = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
             }
         } else {
@@ -1548,7 +1551,7 @@ __device__ __forceinline__ void pairs_body(const NRX_CONST SortedBwdArgs* a, con
             g = sorted_upstream<UNAL>(a, f, b, q);
             if (FM) {
                 gf = f.fm ? nrx_gconst<float>(a->g_fm)[b] : 0.f;
-                v = nrx_ldg4(a->feat, (b * a->feat_ld + f.out_col) / 4 + q);
+                if (first) v = v_first = nrx_ldg4(a->feat, (b * a->feat_ld + f.out_col) / 4 + q);
                 s = nrx_ldg4(a->fm_sums, (b * a->sums_ld) / 4 + q);
             }
         }
@@ -1560,7 +1563,7 @@ __device__ __forceinline__ void pairs_body(const NRX_CONST SortedBwdArgs* a, con
         const int64_t inext = i + (int64_t)gx * G;
         if (inext < n) rec = recs[inext];
         const int64_t key = a->uniq_keys != nullptr ? nrx_gconst<int64_t>(a->uniq_keys)[u] : 1;
-        const float4 t_lo = row_of(p1), t_hi = row_of(p2);         // (the plan lists the lookups of a row in ascending order)
+        const float4 t_lo = row_of(p1, true), t_hi = row_of(p2, false);         // (the plan lists the lookups of a row in ascending order)
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         acc.x += t_lo.x; acc.y += t_lo.y; acc.z += t_lo.z; acc.w += t_lo.w;
         acc.x += t_hi.x; acc.y += t_hi.y; acc.z += t_hi.z; acc.w += t_hi.w;
