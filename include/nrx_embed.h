@@ -715,6 +715,31 @@ NRX_API int64_t nrx_route_bags_one_state_bytes(const int32_t* bag_lens, int32_t 
 NRX_API int nrx_route_bags_one(const void* const* ids, const float* const* weights, const int32_t* bag_lens, int32_t n_feats,
                        int32_t index_bits, int64_t batch, int32_t world, int64_t cap, int32_t* send_rows, int32_t* send_tag,
                        float* send_w, int64_t* counts2d, int64_t* overflow, void* state, void* stream);
+/* The routing launch with the launches either side of it folded in (round 6; replaces nrx_bag_norm_weights + nrx_route_bags_one at the source and
+ * the memset + marking pass inside nrx_pool_inbox_fwd at the owner).  masks[f] = the RAW mask / weights of feature f (null: all ones), kinds[f] =
+ * NRX_BAG_MASKED_MEAN | NRX_BAG_MEAN | NRX_BAG_SUM: the weight that travels is mask / den, formed in the launch with nrx_bag_norm_weights' own
+ * arithmetic and summation order (bit-identical; inv_out[f], optional: nrx_bag_norm_weights_inv's out_inv).  Tiles hold WHOLE samples, so the
+ * entries of one (sample, owner) are contiguous in the owner's block and the tile writes their bounds: send_run [world][n_feats * batch][2] int32 =
+ * {first slot, one past the last} of tag's run inside block o ({0, 0}: no entry; clamped to cap) -- send_tag is not written at all.  send_rows /
+ * send_w / counts2d / overflow: as nrx_route_bags_one (definition: oracle/ref_np.py route_bags + bag_norm_weights; the runs: route_bags_runs).
+ * nrx_route_bags_runs_state_bytes returns 0 for shapes outside this form (a bag longer than 4096 entries, or 4096 / bag_len * world > 4096):
+ * use nrx_route_bags_one there.  The state block is ZERO before the first call, then owned by the call. */
+NRX_API int64_t nrx_route_bags_runs_state_bytes(const int32_t* bag_lens, int32_t n_feats, int64_t batch, int32_t world);
+NRX_API int nrx_route_bags_runs(const void* const* ids, const float* const* masks, const int32_t* kinds, const int32_t* bag_lens, int32_t n_feats,
+                        int32_t index_bits, int64_t batch, int32_t world, int64_t cap, int32_t* send_rows, float* send_w, int32_t* send_run,
+                        float* const* inv_out, int64_t* counts2d, int64_t* overflow, void* state, void* stream);
+/* nrx_pool_inbox_fwd over run bounds that arrived with the exchange (block s of `run` = source s's send_run block for this owner): the pooling
+ * launch alone; same partial sums bit for bit. */
+NRX_API int nrx_pool_inbox_fwd_runs(const float* const* tables, const int64_t* table_rows, int32_t n_tables, const int32_t* feat_table,
+                            int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
+                            const int32_t* inbox_rows, const float* inbox_w, const int32_t* run, int32_t dim, float* partial,
+                            int32_t* status, void* stream);
+/* The training step's per-entry words of the runs form, from the run bounds (the tags stayed at the source): tag_out [world * cap] (what
+ * nrx_pool_inbox_expand reads as inbox_tag; only the entries inside runs are written), and / or oid_out (+ payload_out) [world * cap] =
+ * nrx_pool_inbox_owner_ids' words exactly (table_rows / skip_row0 as there; every slot written, owner id 0 past a block's count). */
+NRX_API int nrx_pool_inbox_runs_words(int64_t table_rows, int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
+                              const int32_t* inbox_rows, const int32_t* run, int32_t skip_row0, int32_t* tag_out, int32_t* oid_out,
+                              uint32_t* payload_out, void* stream);
 NRX_API int64_t nrx_pool_inbox_workspace(int32_t n_feats, int64_t batch, int32_t world);
 NRX_API int nrx_pool_inbox_fwd(const float* const* tables, const int64_t* table_rows, int32_t n_tables, const int32_t* feat_table,
                        int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,

@@ -566,6 +566,43 @@ __global__ __launch_bounds__(NRX_BLOCK) void pool_mark_kernel(const PoolArgs arg
 }
 
 // pass 2: one Q-lane group per (source, tag) walks its run with AHEAD rows in flight -- the shape of the fused bag kernel
+// The training step's per-entry words from the run bounds (nrx_pool_inbox_runs_words): the tags stayed at the source in the runs form, and what
+// the backward's launches over the inbox read per entry follows from the run an entry lies in -- its tag (tag_out: nrx_pool_inbox_expand's
+// inbox_tag), or its OWNER ID and PAYLOAD (oid_out / payload_out: exactly nrx_pool_inbox_owner_ids' words).  16 lanes per (source, tag) write the
+// run's entries (adjacent tags' runs are adjacent: whole lines leave); the slots past a block's count get owner id 0 / payload 0.  (Written inside
+// the pooling launch instead, these 4-byte stores cost it 43 us: partial lines evicted between the row fetches.)
+struct PoolEmit {
+    int32_t* tag_out;
+    int32_t* oid_out;
+    uint32_t* payload_out;
+};
+__global__ __launch_bounds__(NRX_BLOCK) void pool_runs_words_kernel(const PoolArgs args_in_kernarg, const int32_t* __restrict__ run, const PoolEmit em) {
+    const NRX_CONST PoolArgs* a = nrx_kernarg<PoolArgs>();
+    const int s = blockIdx.y;
+    const int q = threadIdx.x & 15;
+    const int64_t ntag = (int64_t)a->n_feats * a->batch;
+    const int64_t base = (int64_t)s * a->cap;
+    if (em.oid_out != nullptr) {
+        const int64_t total = pool_block_total(a, s);
+        for (int64_t j = total + (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x; j < a->cap; j += (int64_t)gridDim.x * NRX_BLOCK) {
+            em.oid_out[base + j] = 0;
+            if (em.payload_out != nullptr) em.payload_out[base + j] = 0u;
+        }
+    }
+    for (int64_t tag = (int64_t)blockIdx.x * (NRX_BLOCK / 16) + (threadIdx.x >> 4); tag < ntag; tag += (int64_t)gridDim.x * (NRX_BLOCK / 16)) {
+        const int2 r = reinterpret_cast<const int2*>(run)[(int64_t)s * ntag + tag];
+        for (int e = r.x + q; e < r.y; e += 16) {
+            if (em.tag_out != nullptr) em.tag_out[base + e] = (int32_t)tag;
+            if (em.oid_out != nullptr) {
+                const int32_t row = nrx_gconst<int32_t>(a->inbox_rows)[base + e];
+                const bool live = (uint32_t)row < (uint64_t)a->rows[0] && !(a->skip_row0 && row == 0);
+                em.oid_out[base + e] = live ? row + 1 : 0;
+                if (em.payload_out != nullptr) em.payload_out[base + e] = live ? (uint32_t)((int64_t)s * ntag + tag) : 0u;
+            }
+        }
+    }
+}
+
 template <int QLOG2>
 __global__ __launch_bounds__(NRX_BLOCK) void pool_inbox_fwd_kernel(const PoolArgs args_in_kernarg, const int32_t* __restrict__ run) {
     const NRX_CONST PoolArgs* a = nrx_kernarg<PoolArgs>();
@@ -576,15 +613,16 @@ __global__ __launch_bounds__(NRX_BLOCK) void pool_inbox_fwd_kernel(const PoolArg
     const int q = threadIdx.x & (Q - 1);
     const int64_t ntag = (int64_t)a->n_feats * a->batch;
     const int64_t tag = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2);
+    const int64_t base = (int64_t)s * a->cap;
     if (tag >= ntag) return;
     const int32_t lo = run[((int64_t)s * ntag + tag) * 2], hi = run[((int64_t)s * ntag + tag) * 2 + 1];
-    const int64_t base = (int64_t)s * a->cap;
     const int D = a->dim;
     const int f = (int)(tag / a->batch);
     const int tix = a->feat_table[f];
     const float* table = a->table[tix];
     const int64_t nrows = a->rows[tix];
     const bool vec = (D & 3) == 0;
+
     for (int k0 = q * 4; k0 < D; k0 += 4 * Q) {              // one pass when D <= 4Q (the launch picks Q for that)
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int e0 = lo; e0 < hi; e0 += AHEAD) {
@@ -1092,6 +1130,67 @@ extern "C" int nrx_pool_inbox_fwd(const float* const* tables, const int64_t* tab
 #undef NRX_CASE
     }
     NRX_LAUNCH_CHECK("nrx_pool_inbox_fwd");
+    return NRX_OK;
+}
+
+// The owner's pooling launch alone, over run bounds that ARRIVED (nrx_route_bags_runs wrote them at the source; block s of `run` = what source s
+// sent): no memset, no marking pass over the entries.
+extern "C" int nrx_pool_inbox_fwd_runs(const float* const* tables, const int64_t* table_rows, int32_t n_tables, const int32_t* feat_table,
+                                       int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
+                                       const int32_t* inbox_rows, const float* inbox_w, const int32_t* run, int32_t dim, float* partial,
+                                       int32_t* status, void* stream) {
+    NRX_TRACE();
+    PoolArgs a;
+    NRX_REQUIRE(run != nullptr, "nrx_pool_inbox_fwd_runs: null run");
+    int rc = fill_pool_args(a, const_cast<float* const*>(tables), table_rows, n_tables, feat_table, n_feats, batch, world, cap, recv2d,
+                            inbox_rows, run /* (no tag array: never read) */, inbox_w, dim, "nrx_pool_inbox_fwd_runs");
+    if (rc != NRX_OK) return rc;
+    NRX_REQUIRE(partial != nullptr, "nrx_pool_inbox_fwd_runs: null partial");
+    a.inbox_tag = nullptr;
+    a.partial = partial;
+    a.status = status;
+    a.skip_row0 = 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t ntag = (int64_t)n_feats * batch;
+    const int ql = pool_ql(dim);
+    const int tb = NRX_BLOCK >> ql;
+    const dim3 grid((unsigned)((ntag + tb - 1) / tb), (unsigned)world);
+    switch (ql) {
+#define NRX_CASE(QL_) case QL_: hipLaunchKernelGGL((pool_inbox_fwd_kernel<QL_>), grid, dim3(NRX_BLOCK), 0, st, a, run); break;
+        NRX_CASE(0) NRX_CASE(1) NRX_CASE(2) NRX_CASE(3) NRX_CASE(4) NRX_CASE(5)
+        default: hipLaunchKernelGGL((pool_inbox_fwd_kernel<6>), grid, dim3(NRX_BLOCK), 0, st, a, run); break;
+#undef NRX_CASE
+    }
+    NRX_LAUNCH_CHECK("nrx_pool_inbox_fwd_runs");
+    return NRX_OK;
+}
+
+extern "C" int nrx_pool_inbox_runs_words(int64_t table_rows, int32_t n_feats, int64_t batch, int32_t world, int64_t cap, const int64_t* recv2d,
+                                         const int32_t* inbox_rows, const int32_t* run, int32_t skip_row0, int32_t* tag_out, int32_t* oid_out,
+                                         uint32_t* payload_out, void* stream) {
+    NRX_TRACE();
+    PoolArgs a;
+    NRX_REQUIRE(run != nullptr && (tag_out != nullptr || oid_out != nullptr), "nrx_pool_inbox_runs_words: null run / nothing to write");
+    NRX_REQUIRE(payload_out == nullptr || oid_out != nullptr, "nrx_pool_inbox_runs_words: payload_out goes with oid_out");
+    float* dummy_table = reinterpret_cast<float*>(const_cast<int32_t*>(run));      // (fill_pool_args wants a table pointer and a weight array: never dereferenced here)
+    int32_t ft[NRX_MAX_FEATURES];
+    for (int f = 0; f < NRX_MAX_FEATURES; ++f) ft[f] = 0;
+    int rc = fill_pool_args(a, &dummy_table, &table_rows, 1, ft, n_feats, batch, world, cap, recv2d, inbox_rows, run, reinterpret_cast<const float*>(run), 4,
+                            "nrx_pool_inbox_runs_words");
+    if (rc != NRX_OK) return rc;
+    a.inbox_tag = nullptr;
+    a.partial = nullptr;
+    a.status = nullptr;
+    a.skip_row0 = skip_row0;
+    PoolEmit em;
+    em.tag_out = tag_out;
+    em.oid_out = oid_out;
+    em.payload_out = payload_out;
+    const int64_t ntag = (int64_t)n_feats * batch;
+    int64_t bx = (ntag + NRX_BLOCK / 16 - 1) / (NRX_BLOCK / 16);
+    if (bx > 8192) bx = 8192;
+    hipLaunchKernelGGL(pool_runs_words_kernel, dim3((unsigned)bx, (unsigned)world), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), a, run, em);
+    NRX_LAUNCH_CHECK("nrx_pool_inbox_runs_words");
     return NRX_OK;
 }
 

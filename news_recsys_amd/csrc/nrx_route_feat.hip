@@ -234,7 +234,6 @@ __global__ __launch_bounds__(RF_THREADS) void route_feat_kernel(const RouteFeatA
 struct RouteBagsArgs {
     const void* ids[NRX_MAX_FEATURES];
     const float* weight[NRX_MAX_FEATURES];
-    int64_t len[NRX_MAX_FEATURES];           // batch * bag_len
     int32_t bag_len[NRX_MAX_FEATURES];
     uint64_t magic_len[NRX_MAX_FEATURES];    // floor(2^64 / bag_len) + 1: sample = umul64hi(entry, magic), exact for entries < 2^32 (a 64-bit division per
                                              // entry was most of this launch's instruction count)
@@ -251,15 +250,30 @@ struct RouteBagsArgs {
     uint32_t* ctl;
     unsigned long long* agg;                 // [tiles][world]: a tile's totals
     unsigned long long* gagg;                // [tiles / RB_GROUP][world]: the totals of a whole group of RB_GROUP tiles (published by the group's last tile)
+    // the RUNS form (nrx_route_bags_runs): tiles of WHOLE samples, the weights normalised here, run bounds instead of tags
+    int32_t tile_len[NRX_MAX_FEATURES];      // entries per tile: RF_TILE, or (RUNS) spt * bag_len with spt = RF_TILE / bag_len samples
+    int32_t kind[NRX_MAX_FEATURES];          // (RUNS) NRX_BAG_*: weight[] holds the RAW mask
+    float* inv_out[NRX_MAX_FEATURES];        // (RUNS, optional) [batch]: 1 / den of every sample (0 for an empty masked bag)
+    int32_t* send_run;                       // (RUNS) [world][n_feats * batch][2]: first and one-past-last slot of the (owner, tag) run inside o's block
 };
 static_assert(sizeof(RouteBagsArgs) <= 3584, "kernarg budget");
 constexpr int RB_GROUP = 32;                 // tiles per group of the two-level chain: a tile adds up <= 31 tile totals + tiles / 32 group totals,
                                              // not every earlier tile's (800 tiles on C4: 320 k uncached polls per launch, the launch was no faster than
                                              // the three it replaced)
 
-__global__ __launch_bounds__(RF_THREADS) void route_bags_one_kernel(const RouteBagsArgs args_in_kernarg) {
+// RUNS (nrx_route_bags_runs, round 6): the two launches either side of the routing are folded in.  A tile holds WHOLE samples (spt = 4096 / L of
+// them), so (1) the normalised weights are formed here from the raw mask -- nrx_bag_norm_weights' arithmetic and summation order, the sample sums
+// in LDS -- and (2) the entries of one (sample, owner) are contiguous inside the tile's part of o's block: the tile writes where that RUN starts
+// and ends (send_run) instead of a tag per entry, which is what the owner's pooling launch needs (it spent a launch of its own, pool_mark_kernel
+// over every entry behind a memset, finding the runs from the tags).
+template <bool RUNS>
+__global__ __launch_bounds__(RF_THREADS) __attribute__((amdgpu_waves_per_eu(4)))      // (four blocks per compute unit: C4's ~810 tiles are all resident)
+void route_bags_one_kernel(const RouteBagsArgs args_in_kernarg) {
     const NRX_CONST RouteBagsArgs* a = nrx_kernarg<RouteBagsArgs>();
     __shared__ int s_cell[RF_ROUNDS * RF_WAVES][RF_MAX_WORLD];
+    __shared__ __attribute__((aligned(16))) uint32_t s_aux[RUNS ? RF_TILE : 1];      // (RUNS) the sample sums (float), then the local sample of every
+                                                                                   // entry in owner order (uint16)
+    __shared__ int s_pref[RF_MAX_WORLD];
     __shared__ int s_tot[RF_MAX_WORLD], s_base[RF_MAX_WORLD], s_feat[RF_MAX_WORLD];
     __shared__ uint32_t s_ticket, s_mark;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -275,7 +289,27 @@ __global__ __launch_bounds__(RF_THREADS) void route_bags_one_kernel(const RouteB
     int f = 0;
     for (int i = 1; i < n; ++i) f += w >= a->tile0[i] ? 1 : 0;
     const int tile = w - a->tile0[f];
-    const int64_t len = a->len[f], i0 = (int64_t)tile * RF_TILE;
+    const int TL = RUNS ? a->tile_len[f] : RF_TILE;
+    const int64_t i0 = (int64_t)tile * TL;
+    const int64_t len_f = a->batch * a->bag_len[f];
+    const int64_t len = RUNS ? (len_f < i0 + TL ? len_f : i0 + TL) : len_f;      // (RUNS: the tile's own end)
+    const int L_ = a->bag_len[f];
+    const int64_t smp0 = RUNS ? i0 / L_ : 0;                                // the tile's first sample
+    const int ns = RUNS ? (int)((len - i0) / L_) : 0;                       // ... and how many it holds
+    // (RUNS) the sample of the thread's j-th entry inside the tile: (j * 256 + tid) / L by a float multiply -- exact: the quotient's rounding error
+    // (< 4096 / L * 2^-22) is a thousandth of the half-step the + 0.5 keeps it away from an integer (a 64-bit multiply-high per entry and pass was
+    // a third of this launch's instructions)
+    const float inv_l = 1.0f / (float)L_;
+    auto local_sample = [&](int j) -> int { return (int)(((float)(j * RF_THREADS + tid) + 0.5f) * inv_l); };
+    if constexpr (RUNS) {
+        // the (owner, tag) pairs of this tile's samples without an entry keep the empty run 0..0: written first, the real bounds below overwrite them
+        // (same block, behind barriers)
+        const int64_t ntag = (int64_t)n * a->batch, t0 = (int64_t)f * a->batch + smp0;
+        for (int j = tid; j < W * ns; j += RF_THREADS) {
+            const int o = j / ns, b = j - o * ns;
+            reinterpret_cast<int2*>(a->send_run)[(int64_t)o * ntag + t0 + b] = make_int2(0, 0);
+        }
+    }
     int owner[RF_ROUNDS];
     int32_t val[RF_ROUNDS];
     float wt[RF_ROUNDS];
@@ -290,8 +324,51 @@ __global__ __launch_bounds__(RF_THREADS) void route_bags_one_kernel(const RouteB
             wt[j] = 1.0f;
             if (i < len) {
                 id[j] = a->idx64 ? nrx_gconst<int64_t>(p)[i] : (int64_t)nrx_gconst<int32_t>(p)[i];
-                if (wp != nullptr) wt[j] = nrx_gconst<float>(wp)[i];
+                if (wp != nullptr && !(RUNS && a->kind[f] == NRX_BAG_MEAN)) wt[j] = nrx_gconst<float>(wp)[i];
             }
+        }
+        if constexpr (RUNS) {
+            // the weight that travels = m / den, as nrx_bag_norm_weights writes it.  den of a masked mean: the tile's raw masks go to LDS (read from
+            // memory once), lane groups add each sample's up in nrx_bag_norm_weights' order (16 lanes per sample up to 64 entries, else a
+            // wavefront: the same partial sums, the same tree) and leave the sum IN PLACE, in the sample's first word.
+            float* s_m = reinterpret_cast<float*>(s_aux);
+            const int kind = a->kind[f];
+            if (kind == NRX_BAG_MASKED_MEAN) {
+#pragma unroll
+                for (int j = 0; j < RF_ROUNDS; ++j) s_m[j * RF_THREADS + tid] = wt[j];          // (past the tile's end: never read)
+                __syncthreads();
+                const bool narrow = L_ <= 64;
+                const int gl = narrow ? 16 : 64, q = tid & (gl - 1);
+                for (int b0 = 0; b0 < ns; b0 += RF_THREADS / gl) {                  // (ns, b0: block-uniform)
+                    const int b = b0 + tid / gl;
+                    float part = 0.f;
+                    if (b < ns)
+                        for (int l = q; l < L_; l += gl) part += s_m[b * L_ + l];
+                    if (narrow) {
+                        part += nrx_dpp<0xB1>(part);
+                        part += nrx_dpp<0x4E>(part);
+                        part += nrx_dpp<0x141>(part);
+                        part += nrx_dpp<0x140>(part);
+                    } else {
+                        part = nrx_wave_sum(part);
+                    }
+                    if (b < ns && q == 0) s_m[b * L_] = part + 1e-8f;               // (every lane of the group has read its words: the DPP steps are behind the loads)
+                }
+                __syncthreads();
+            }
+            const float den_fixed = kind == NRX_BAG_MEAN ? (float)L_ : 1.0f;
+#pragma unroll
+            for (int j = 0; j < RF_ROUNDS; ++j) {
+                const int64_t i = i0 + j * RF_THREADS + tid;
+                if (i < len) {
+                    const int b = local_sample(j);
+                    const float den = kind == NRX_BAG_MASKED_MEAN ? s_m[b * L_] : den_fixed;
+                    wt[j] = wt[j] / den;
+                    if (a->inv_out[f] != nullptr && (int64_t)(smp0 + b) * L_ == i)          // the sample's first entry writes 1 / den
+                        a->inv_out[f][smp0 + b] = (kind == NRX_BAG_MASKED_MEAN && den <= 1e-8f) ? 0.f : 1.0f / den;
+                }
+            }
+            __syncthreads();         // (s_aux is reused below)
         }
 #pragma unroll
         for (int j = 0; j < RF_ROUNDS; ++j) {
@@ -336,6 +413,36 @@ __global__ __launch_bounds__(RF_THREADS) void route_bags_one_kernel(const RouteB
     // before x's group + the totals of the tiles of x's group before x; one word per thread and round, summed with LDS integer atomics.
     // Two phases, so that a group's total never waits for an earlier group's: (A) the tiles of the own group -> the group's last tile publishes
     // the group total; (B) the earlier groups' totals.
+    // RUNS: which entries open / close a (sample, owner) run -- found HERE, from the places inside the tile alone, while the chain's totals arrive:
+    // every entry leaves its local sample at its place in the tile's owner-major order (LDS); an entry opens its run when the entry before it
+    // there is another sample's (or there is none: tiles hold whole samples), and closes it when the next one is.
+    uint32_t opn = 0, cls = 0;
+    if constexpr (RUNS) {
+        uint16_t* s_smp = reinterpret_cast<uint16_t*>(s_aux);
+        __syncthreads();                         // (s_cell / s_tot of every owner)
+        if (tid == 0) {
+            int run = 0;
+            for (int o = 0; o < W; ++o) { s_pref[o] = run; run += s_tot[o]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RF_ROUNDS; ++j) rank[j] += owner[j] >= 0 ? s_cell[j * RF_WAVES + wid][owner[j]] : 0;      // -> the place among the tile's entries of the owner
+#pragma unroll
+        for (int j = 0; j < RF_ROUNDS; ++j) {
+            if (owner[j] < 0) continue;
+            s_smp[s_pref[owner[j]] + rank[j]] = (uint16_t)local_sample(j);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RF_ROUNDS; ++j) {
+            if (owner[j] < 0) continue;
+            const int o = owner[j];
+            const int at = s_pref[o] + rank[j];
+            const uint16_t me = (uint16_t)local_sample(j);
+            if (rank[j] == 0 || s_smp[at - 1] != me) opn |= 1u << j;
+            if (rank[j] == s_tot[o] - 1 || s_smp[at + 1] != me) cls |= 1u << j;
+        }
+    }
     auto poll = [&](const unsigned long long* p) -> int {
         unsigned long long v;
         do { v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((uint32_t)(v >> 32) != mark);
@@ -367,12 +474,15 @@ __global__ __launch_bounds__(RF_THREADS) void route_bags_one_kernel(const RouteB
     const int L = a->bag_len[f];
     const uint64_t magic_l = a->magic_len[f];
     const int32_t tag0 = (int32_t)(f * B);
+    const int64_t ntag_r = (int64_t)n * B;
 #pragma unroll
     for (int j = 0; j < RF_ROUNDS; ++j) {
         if (owner[j] < 0) continue;
         const int o = owner[j];
         const int64_t i = i0 + j * RF_THREADS + tid;
-        const int64_t k = (int64_t)s_base[o] + s_cell[j * RF_WAVES + wid][o] + rank[j];
+        const int pt = RUNS ? rank[j] : s_cell[j * RF_WAVES + wid][o] + rank[j];            // place among the tile's entries of owner o
+        const int64_t k = (int64_t)s_base[o] + pt;
+        const int32_t smp = RUNS ? (int32_t)smp0 + local_sample(j) : (L == 1 ? (int32_t)i : (int32_t)__umul64hi((uint64_t)i, magic_l));
 #ifdef NRX_RB_NO_STORE
         if (k < 0) {
 #else
@@ -380,8 +490,13 @@ __global__ __launch_bounds__(RF_THREADS) void route_bags_one_kernel(const RouteB
 #endif
             const int64_t d = (int64_t)o * cap + k;
             a->send_rows[d] = val[j];
-            a->send_tag[d] = tag0 + (L == 1 ? (int32_t)i : (int32_t)__umul64hi((uint64_t)i, magic_l));
+            if (!RUNS) a->send_tag[d] = tag0 + smp;
             a->send_w[d] = wt[j];
+        }
+        if (RUNS && ((opn | cls) >> j) & 1u) {      // the bounds of the (sample, owner) run this entry opens / closes (clamped to the block)
+            int32_t* r = a->send_run + ((int64_t)o * ntag_r + tag0 + smp) * 2;
+            if ((opn >> j) & 1u) r[0] = (int32_t)(k < cap ? k : cap);
+            if ((cls >> j) & 1u) r[1] = (int32_t)(k + 1 < cap ? k + 1 : cap);
         }
     }
     if (last_of_feat && tid < W) a->counts2d[(int64_t)tid * n + f] = (int64_t)s_base[tid] + s_tot[tid] - s_feat[tid];
@@ -648,12 +763,11 @@ extern "C" int nrx_route_bags_one(const void* const* ids, const float* const* we
         NRX_REQUIRE(bag_lens[f] >= 1 && (batch == 0 || ids[f] != nullptr), "nrx_route_bags_one: feature %d: bad ids / bag_len", f);
         a.ids[f] = ids[f];
         a.weight[f] = weights ? weights[f] : nullptr;
-        a.len[f] = batch * bag_lens[f];
         a.bag_len[f] = bag_lens[f];
         a.magic_len[f] = bag_lens[f] > 1 ? ~0ull / (uint64_t)bag_lens[f] + 1 : 0;
         a.tile0[f] = (int32_t)tiles;
-        tiles += (a.len[f] + RF_TILE - 1) / RF_TILE;
-        total += a.len[f];
+        tiles += (batch * bag_lens[f] + RF_TILE - 1) / RF_TILE;
+        total += batch * bag_lens[f];
     }
     a.tile0[n_feats] = (int32_t)tiles;
     a.magic_world = world > 1 ? ~0ull / (uint64_t)world + 1 : 0;
@@ -673,9 +787,80 @@ extern "C" int nrx_route_bags_one(const void* const* ids, const float* const* we
     a.ctl = reinterpret_cast<uint32_t*>(state);
     a.agg = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(state) + 64);
     a.gagg = a.agg + tiles * world;
-    a.use_ticket = !all_resident(reinterpret_cast<const void*>(route_bags_one_kernel), tiles);
-    hipLaunchKernelGGL(route_bags_one_kernel, dim3((unsigned)tiles), dim3(RF_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
+    a.use_ticket = !all_resident(reinterpret_cast<const void*>(route_bags_one_kernel<false>), tiles);
+    hipLaunchKernelGGL(route_bags_one_kernel<false>, dim3((unsigned)tiles), dim3(RF_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
     NRX_LAUNCH_CHECK("nrx_route_bags_one");
+    return NRX_OK;
+}
+
+// tiles of whole samples: spt = RF_TILE / L samples (the form needs L <= RF_TILE and spt * world run words per tile <= RF_TILE)
+static bool route_bags_runs_ok(const int32_t* bag_lens, int32_t n_feats, int32_t world) {
+    for (int f = 0; f < n_feats; ++f)
+        if (bag_lens[f] < 1 || bag_lens[f] > RF_TILE || (int64_t)(RF_TILE / bag_lens[f]) * world > RF_TILE) return false;
+    return true;
+}
+
+extern "C" int64_t nrx_route_bags_runs_state_bytes(const int32_t* bag_lens, int32_t n_feats, int64_t batch, int32_t world) {
+    if (bag_lens == nullptr || n_feats < 1 || n_feats > NRX_MAX_FEATURES || batch < 0 || world < 1 || world > RF_MAX_WORLD) return -1;
+    if (!route_bags_runs_ok(bag_lens, n_feats, world)) return 0;             // not this form's shape: nrx_route_bags_one + nrx_pool_inbox_fwd
+    int64_t tiles = 0;
+    for (int f = 0; f < n_feats; ++f) {
+        const int64_t spt = RF_TILE / bag_lens[f];
+        tiles += (batch + spt - 1) / spt;
+    }
+    return 64 + ((tiles > 0 ? tiles : 1) + tiles / RB_GROUP + 1) * world * 8;
+}
+
+extern "C" int nrx_route_bags_runs(const void* const* ids, const float* const* masks, const int32_t* kinds, const int32_t* bag_lens, int32_t n_feats,
+                                   int32_t index_bits, int64_t batch, int32_t world, int64_t cap, int32_t* send_rows, float* send_w, int32_t* send_run,
+                                   float* const* inv_out, int64_t* counts2d, int64_t* overflow, void* state, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(ids && bag_lens && kinds && n_feats >= 1 && n_feats <= NRX_MAX_FEATURES, "nrx_route_bags_runs: n_feats must be in [1, %d]", NRX_MAX_FEATURES);
+    NRX_REQUIRE(index_bits == 32 || index_bits == 64, "nrx_route_bags_runs: index_bits must be 32 or 64");
+    NRX_REQUIRE(world >= 1 && world <= RF_MAX_WORLD && cap >= 1 && cap * world <= 0x7fffffffLL && batch >= 0, "nrx_route_bags_runs: bad world / cap / batch");
+    NRX_REQUIRE((int64_t)n_feats * batch * world * 2 <= 0x7fffffffLL, "nrx_route_bags_runs: world * n_feats * batch run words must fit 31 bits");
+    NRX_REQUIRE(send_rows && send_w && send_run && counts2d && overflow && state, "nrx_route_bags_runs: null buffer");
+    NRX_REQUIRE(route_bags_runs_ok(bag_lens, n_feats, world), "nrx_route_bags_runs: not this form's shape (nrx_route_bags_runs_state_bytes returned 0)");
+    RouteBagsArgs a;
+    memset(&a, 0, sizeof(a));
+    int64_t tiles = 0, total = 0;
+    for (int f = 0; f < n_feats; ++f) {
+        NRX_REQUIRE(batch == 0 || ids[f] != nullptr, "nrx_route_bags_runs: feature %d: null ids", f);
+        NRX_REQUIRE(kinds[f] == NRX_BAG_SUM || kinds[f] == NRX_BAG_MEAN || kinds[f] == NRX_BAG_MASKED_MEAN, "nrx_route_bags_runs: feature %d: kind must be a bag kind", f);
+        NRX_REQUIRE(kinds[f] != NRX_BAG_MASKED_MEAN || (masks && masks[f]) || batch == 0, "nrx_route_bags_runs: feature %d: a masked mean needs its mask", f);
+        const int64_t spt = RF_TILE / bag_lens[f];
+        a.ids[f] = ids[f];
+        a.weight[f] = masks ? masks[f] : nullptr;
+        a.kind[f] = kinds[f];
+        a.inv_out[f] = inv_out ? inv_out[f] : nullptr;
+        a.bag_len[f] = bag_lens[f];
+        a.tile_len[f] = (int32_t)(spt * bag_lens[f]);
+        a.magic_len[f] = bag_lens[f] > 1 ? ~0ull / (uint64_t)bag_lens[f] + 1 : 0;
+        a.tile0[f] = (int32_t)tiles;
+        tiles += (batch + spt - 1) / spt;
+        total += batch * bag_lens[f];
+    }
+    a.tile0[n_feats] = (int32_t)tiles;
+    a.magic_world = world > 1 ? ~0ull / (uint64_t)world + 1 : 0;
+    NRX_REQUIRE(total <= 0x7fffffffLL && tiles < (1 << 24), "nrx_route_bags_runs: too many ids for one exchange");
+    if (tiles == 0) return NRX_OK;
+    a.batch = batch;
+    a.cap = cap;
+    a.n_feats = n_feats;
+    a.world = world;
+    a.idx64 = index_bits == 64;
+    a.tiles = (int32_t)tiles;
+    a.send_rows = send_rows;
+    a.send_w = send_w;
+    a.send_run = send_run;
+    a.counts2d = counts2d;
+    a.overflow = overflow;
+    a.ctl = reinterpret_cast<uint32_t*>(state);
+    a.agg = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(state) + 64);
+    a.gagg = a.agg + tiles * world;
+    a.use_ticket = !all_resident(reinterpret_cast<const void*>(route_bags_one_kernel<true>), tiles);
+    hipLaunchKernelGGL(route_bags_one_kernel<true>, dim3((unsigned)tiles), dim3(RF_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
+    NRX_LAUNCH_CHECK("nrx_route_bags_runs");
     return NRX_OK;
 }
 

@@ -438,10 +438,17 @@ class PreparedShardedStep:
                     v[:, k].copy_(src.unsqueeze(0).expand(W, B, D))
                 if W > 1:
                     eng._a2a(b["g_recv"].view(-1), b["g_send"].view(-1))
-                if b["binary"]:
+                runs = g.get("runs_state") is not None      # (the tags stayed at the source: the per-entry words come from the run bounds)
+                if b["binary"] and runs:
+                    rc = lib.nrx_pool_inbox_runs_words(g["tables"][0].shape[0] - 1, n, B, W, g["cap"], g["recv2d"].data_ptr(), g["inbox"].data_ptr(),
+                                                       g["run"].data_ptr(), int(eng.rank == 0), None, b["oid"].data_ptr(), b["payload"].data_ptr(), stream)
+                elif b["binary"]:
                     rc = lib.nrx_pool_inbox_owner_ids(g["tables"][0].shape[0] - 1, n, B, W, g["cap"], g["recv2d"].data_ptr(), g["inbox"].data_ptr(),
                                                       g["inbox_tag"].data_ptr(), int(eng.rank == 0), b["oid"].data_ptr(), b["payload"].data_ptr(), stream)
                 else:
+                    if runs:
+                        ops.check(lib.nrx_pool_inbox_runs_words(g["tables"][0].shape[0] - 1, n, B, W, g["cap"], g["recv2d"].data_ptr(), g["inbox"].data_ptr(),
+                                                                g["run"].data_ptr(), 0, g["inbox_tag"].data_ptr(), None, None, stream), "nrx_pool_inbox_runs_words")
                     rc = lib.nrx_pool_inbox_expand(g["tables"][0].shape[0] - 1, n, B, W, g["cap"], g["recv2d"].data_ptr(), g["inbox"].data_ptr(),
                                                    g["inbox_tag"].data_ptr(), g["inbox_w"].data_ptr(), D, b["g_recv"].data_ptr(), int(eng.rank == 0),
                                                    b["oid"].data_ptr(), b["rows"].data_ptr(), stream)

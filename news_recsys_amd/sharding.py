@@ -35,6 +35,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import ctypes
+
 import torch
 import torch.distributed as dist
 
@@ -808,15 +810,60 @@ class PreparedShardedForward:
         if W == 1:
             g["inbox"], g["inbox_tag"], g["inbox_w"], g["recv2d"], g["ret"] = g["send"], g["send_tag"], g["send_w"], g["counts2d"], g["partial"]
         import os
-        if os.environ.get("NRX_ROUTE_BAGS", "one") != "legacy":      # the one-launch routing (round 6); "legacy": histogram + scan + placement launches
+        # routing: "runs" (default, round 6) = ONE launch that also normalises the weights and writes the (owner, tag) run bounds the owner's pooling
+        # launch needs (they travel in the place of the per-entry tags); "one" = the one-launch routing behind nrx_bag_norm_weights, runs found by
+        # the owner (memset + marking pass); "legacy" = histogram + scan + placement launches
+        how = os.environ.get("NRX_ROUTE_BAGS", "runs")
+        if how == "runs":
+            nb = self.lib.nrx_route_bags_runs_state_bytes(g["bl"], n, B, W)
+            if nb > 0:
+                g["runs_state"] = torch.zeros(nb, dtype=torch.uint8, device=dev)
+                g["send_run"] = torch.empty((W, n * B, 2), dtype=torch.int32, device=dev)
+                g["run"] = g["send_run"] if W == 1 else torch.empty((W, n * B, 2), dtype=torch.int32, device=dev)
+                g["mptrs"] = (C.c_void_p * n)(*[(0 if m is None else m.data_ptr()) for m in masks])
+                g["kinds_c"] = (C.c_int32 * n)(*g["kinds"])
+                if any(m is not None and (not m.is_contiguous() or m.dtype != torch.float32) for m in masks):
+                    raise ValueError("PreparedShardedForward: the masks of a pooled group must be contiguous float32 (they are bound by address)")
+            else:
+                how = "one"
+        if how == "one":
             nb = self.lib.nrx_route_bags_one_state_bytes(g["bl"], n, B, W)
             if nb > 0:
                 g["rstate"] = torch.zeros(nb, dtype=torch.uint8, device=dev)
         return g
 
+    def _run_pooled_runs(self, g, stream):
+        """The pooled channel with the run bounds written by the routing launch (nrx_route_bags_runs -> nrx_pool_inbox_fwd_runs): two launches
+        instead of five (+ a memset), the tags stay home."""
+        eng, lib = self.eng, self.lib
+        W = eng.world
+        if "inv_c" not in g:
+            inv = g.get("inv")
+            g["inv_c"] = (ctypes.c_void_p * g["n"])(*[t.data_ptr() for t in inv]) if inv is not None else None
+        ip = g["inv_c"]
+        rc = lib.nrx_route_bags_runs(g["ptrs"], g["mptrs"], g["kinds_c"], g["bl"], g["n"], g["bits"], g["B"], W, g["cap"], g["send"].data_ptr(),
+                                     g["send_w"].data_ptr(), g["send_run"].data_ptr(), ip, g["counts2d"].data_ptr(), g["overflow"].data_ptr(),
+                                     g["runs_state"].data_ptr(), stream)
+        if rc:
+            ops.check(rc, "nrx_route_bags_runs")
+        if W > 1:
+            eng._a2a(g["recv2d"].view(-1), g["counts2d"].view(-1))
+            eng._a2a(g["inbox"], g["send"])
+            eng._a2a(g["run"].view(-1), g["send_run"].view(-1))
+            eng._a2a(g["inbox_w"], g["send_w"])
+        rc = lib.nrx_pool_inbox_fwd_runs(g["tp"], g["tr"], g["nt"], g["ft"], g["n"], g["B"], W, g["cap"], g["recv2d"].data_ptr(),
+                                         g["inbox"].data_ptr(), g["inbox_w"].data_ptr(), g["run"].data_ptr(), g["D"], g["partial"].data_ptr(),
+                                         None, stream)
+        if rc:
+            ops.check(rc, "nrx_pool_inbox_fwd_runs")
+        if W > 1:
+            eng._a2a(g["ret"].view(-1), g["partial"].view(-1))
+
     def _run_pooled(self, g, stream):
         eng, lib = self.eng, self.lib
         W = eng.world
+        if g.get("runs_state") is not None:
+            return PreparedShardedForward._run_pooled_runs(self, g, stream)
         for k, (m, w, kind, L) in enumerate(zip(g["masks"], g["wn"], g["kinds"], g["lens"])):
             if g.get("inv") is not None:       # (the bound training step, 0/1 masks: the per-sample weight rides along)
                 rc = lib.nrx_bag_norm_weights_inv(None if m is None else m.data_ptr(), g["B"], L, kind, w.data_ptr(), g["inv"][k].data_ptr(), stream)

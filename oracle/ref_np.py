@@ -640,6 +640,36 @@ def route_bags(id_arrays, weights, world: int, cap: int):
     return send, tag, sw, counts2d, int(fill.max()) if world else 0
 
 
+def route_bags_runs(id_arrays, weights, world: int, cap: int):
+    """Definition of nrx_route_bags_runs' send_run: run[o, tag] = (first slot, one past the last slot) of tag's entries inside owner o's block
+    under route_bags' order (feature-major, then sample, then position: the entries of a tag are contiguous there), both CLAMPED to cap (a run
+    that overflows the block ends at cap; one that lies beyond it is the empty run (cap, cap)); (0, 0) for a tag without an entry."""
+    F = len(id_arrays)
+    B = id_arrays[0].shape[0] if F else 0
+    run = np.zeros((world, F * B, 2), np.int32)
+    fill = np.zeros(world, np.int64)
+    I32MAX = (1 << 31) - 1
+    for f, ids in enumerate(id_arrays):
+        ids = np.asarray(ids, np.int64)
+        L = ids.shape[1]
+        w = np.ones((B, L), F32) if weights[f] is None else np.asarray(weights[f], F32)
+        flat, wf = ids.reshape(-1), w.reshape(-1)
+        keep = wf != 0
+        bad = (flat < 0) | (flat > I32MAX)
+        owner = np.where(bad, 0, flat % world)
+        smp = np.arange(flat.size) // L
+        for o in range(world):
+            pos = np.flatnonzero(keep & (owner == o))
+            t = f * B + smp[pos]
+            if t.size:
+                first = np.flatnonzero(np.r_[True, t[1:] != t[:-1]])
+                last = np.r_[first[1:], t.size]
+                run[o, t[first], 0] = np.minimum(fill[o] + first, cap)
+                run[o, t[first], 1] = np.minimum(fill[o] + last, cap)
+            fill[o] += pos.size
+    return run
+
+
 def pool_inbox(tables, feat_table, batch: int, world: int, cap: int, recv2d, inbox_rows, inbox_tag, inbox_w, dim: int):
     """Definition of nrx_pool_inbox_fwd: partial[s, tag] = sum over block s's valid entries with that tag of
     w * tables[feat_table[tag // batch]][row], accumulated in entry order (fp32, product then add)."""

@@ -17,7 +17,7 @@ import pytest
 import torch
 
 from news_recsys_amd import _lib, ops, shard_step
-from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_SPARSE, NrxFmGrad
+from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_SPARSE, NrxFmGrad
 from news_recsys_amd.sharding import RowShardedEmbedding, ShardedFeature
 from oracle import ref_np
 
@@ -518,3 +518,178 @@ def test_route_bags_one_launch_equals_its_definition_and_the_three_launch_form(w
         assert np.array_equal(w_o.cpu().numpy()[used], want[2][used])
         assert np.array_equal(rows_o.cpu().numpy()[used], l_rows.cpu().numpy()[used]) and np.array_equal(w_o.cpu().numpy()[used], l_w.cpu().numpy()[used])
         assert (rows_o.cpu().numpy()[~used] == -7).all()                                              # slots past a block's count: untouched
+
+
+@pytest.mark.parametrize("world", [1, 2, 5, 8])
+@pytest.mark.parametrize("dt", [torch.int64, torch.int32])
+def test_route_bags_runs_equals_norm_weights_plus_route_bags_one_and_the_run_definition(world, dt):
+    """nrx_route_bags_runs = nrx_bag_norm_weights(_inv) + nrx_route_bags_one in one launch, with run bounds in the place of tags: the rows, the
+    travelling weights (the normalisation's bits included: arbitrary float masks), counts2d, the overflow maximum and 1 / den word for word; send_run
+    against oracle/ref_np.py route_bags_runs (with the oracle's own weights where the masks are 0/1: numpy's sum order is not the launch's); repeated
+    launches on one state; blocks that overflow keep their bounds inside the block."""
+    lib = _lib.load()
+    rng = np.random.default_rng(90 + world)
+    st = torch.cuda.current_stream().cuda_stream
+    shapes = ((1, 300, [7], 1000), (3, 2000, [9, 1, 50], 200_000), (2, 9000, [50, 3], 5_000_000), (1, 70, [100], 999), (1, 5, [4096], 50),
+              (2, 40, [1365, 2], 777), (1, 33, [2047], 10_000))
+    for rep, (n, B, Ls, rows) in enumerate(shapes):
+        kinds = [(NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM)[(rep + f) % 3] for f in range(n)]
+        for binary in (True, False):
+            ids_np = [rng.integers(0, rows, (B, L)) for L in Ls]
+            m_np = [(rng.random((B, L)) < 0.6).astype(np.float32) * (1.0 if binary else rng.random((B, L)).astype(np.float32)) for L in Ls]
+            m_np[0][B // 2] = 0                                                        # an empty bag
+            ids = [torch.from_numpy(x).to(DEV).to(dt) for x in ids_np]
+            ms = [None if k == NRX_BAG_MEAN else torch.from_numpy(m).to(DEV) for k, m in zip(kinds, m_np)]
+            inv_want = [torch.empty(B, device=DEV) for _ in range(n)]
+            wn = [torch.empty((B, L), device=DEV) for L in Ls]
+            for f in range(n):
+                ops.check(lib.nrx_bag_norm_weights_inv(None if ms[f] is None else ms[f].data_ptr(), B, Ls[f], kinds[f], wn[f].data_ptr(),
+                                                       inv_want[f].data_ptr(), st), "norm")
+            total = sum(int((w != 0).sum()) for w in wn)
+            for tight in (False, True):
+                cap = (total + 64 if world == 1 else int(total / world * 1.4) + 64) if not tight else max(8, total // (2 * world))
+                bl = (C.c_int32 * n)(*Ls)
+                one = [torch.full((world * cap,), -7, dtype=torch.int32, device=DEV), torch.full((world * cap,), -7, dtype=torch.int32, device=DEV),
+                       torch.full((world * cap,), -7.0, device=DEV), torch.zeros((world, n), dtype=torch.int64, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)]
+                s1 = torch.zeros(lib.nrx_route_bags_one_state_bytes(bl, n, B, world), dtype=torch.uint8, device=DEV)
+                idp = (C.c_void_p * n)(*[x.data_ptr() for x in ids])
+                ops.check(lib.nrx_route_bags_one(idp, (C.c_void_p * n)(*[x.data_ptr() for x in wn]), bl, n, ids[0].element_size() * 8, B, world, cap,
+                                                 one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr(), one[3].data_ptr(), one[4].data_ptr(), s1.data_ptr(), st), "one")
+                nb = lib.nrx_route_bags_runs_state_bytes(bl, n, B, world)
+                assert (nb > 0) == all(4096 // L * world <= 4096 for L in Ls)       # (short bags x many owners: too many run words per tile for this form)
+                if nb == 0:
+                    continue
+                s2 = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+                rows_o = torch.full((world * cap,), -7, dtype=torch.int32, device=DEV)
+                w_o = torch.full((world * cap,), -7.0, device=DEV)
+                run = torch.full((world, n * B, 2), -7, dtype=torch.int32, device=DEV)
+                inv = [torch.full((B,), -7.0, device=DEV) for _ in range(n)]
+                c2d = torch.zeros((world, n), dtype=torch.int64, device=DEV)
+                over = torch.zeros(1, dtype=torch.int64, device=DEV)
+                for _ in range(2):
+                    ops.check(lib.nrx_route_bags_runs(idp, (C.c_void_p * n)(*[(0 if m is None else m.data_ptr()) for m in ms]), (C.c_int32 * n)(*kinds), bl, n,
+                                                      ids[0].element_size() * 8, B, world, cap, rows_o.data_ptr(), w_o.data_ptr(), run.data_ptr(),
+                                                      (C.c_void_p * n)(*[x.data_ptr() for x in inv]), c2d.data_ptr(), over.data_ptr(), s2.data_ptr(), st), "runs")
+                torch.cuda.synchronize()
+                assert torch.equal(c2d, one[3]) and torch.equal(over, one[4])
+                assert (int(over.item()) > cap) == tight
+                used = np.zeros(world * cap, bool)
+                for o in range(world):
+                    used[o * cap: o * cap + min(int(c2d[o].sum()), cap)] = True
+                u = torch.from_numpy(used).to(DEV)
+                assert torch.equal(rows_o[u], one[0][u]) and torch.equal(w_o[u].view(torch.int32), one[2][u].view(torch.int32))
+                assert bool((rows_o[~u] == -7).all())
+                for f in range(n):
+                    assert torch.equal(inv[f].view(torch.int32), inv_want[f].view(torch.int32))
+                wn_np = [w.cpu().numpy() for w in wn]                                                                # (the launch's own weights: which entries travel)
+                assert np.array_equal(run.cpu().numpy(), ref_np.route_bags_runs(ids_np, wn_np, world, cap))
+                got_run, tags = run.cpu().numpy(), one[1].cpu().numpy()                                             # ... and the one-launch form's tags lie in their runs
+                for o in range(world):
+                    k = np.flatnonzero(used[o * cap:(o + 1) * cap])
+                    tg = tags[o * cap + k]
+                    assert (got_run[o, tg, 0] <= k).all() and (k < got_run[o, tg, 1]).all()
+                if binary and not tight and dt is torch.int64:                                                       # ... and from the oracle's
+                    wo = [ref_np.bag_norm_weights(None if k == NRX_BAG_MEAN else m, B, L, {NRX_BAG_MASKED_MEAN: "masked_mean", NRX_BAG_MEAN: "mean", NRX_BAG_SUM: "sum"}[k])
+                          for k, m, L in zip(kinds, m_np, Ls)]
+                    ref = ref_np.route_bags(ids_np, wo, world, cap)
+                    assert np.array_equal(c2d.cpu().numpy(), ref[3])
+                    assert np.array_equal(run.cpu().numpy(), ref_np.route_bags_runs(ids_np, wo, world, cap))
+                    assert np.array_equal(rows_o.cpu().numpy()[used], ref[0][used])
+    assert lib.nrx_route_bags_runs_state_bytes((C.c_int32 * 1)(5000), 1, 10, 1) == 0          # a bag longer than a tile: not this form
+    assert lib.nrx_route_bags_runs_state_bytes((C.c_int32 * 1)(2), 1, 10, 8) == 0             # 2048 samples x 8 owners of run words per tile
+
+
+@pytest.mark.parametrize("world", [1, 3])
+@pytest.mark.parametrize("D", [16, 24, 64])
+def test_pool_inbox_fwd_runs_equals_pool_inbox_fwd_and_the_runs_give_the_backwards_words(world, D):
+    """nrx_pool_inbox_fwd_runs over the routing launch's run bounds: the partial sums bit for bit those of nrx_pool_inbox_fwd (memset + marking pass
+    over the tags); nrx_pool_inbox_runs_words: tag_out = the tags on every entry of a run (nothing else written), oid_out / payload_out =
+    nrx_pool_inbox_owner_ids' words on ALL world * cap slots."""
+    lib = _lib.load()
+    rng = np.random.default_rng(5 + world + D)
+    st = torch.cuda.current_stream().cuda_stream
+    B, Ls, rows_local = 900, [9, 30], 700
+    n = len(Ls)
+    ids = [torch.from_numpy(rng.integers(0, rows_local * world, (B, L))).to(DEV) for L in Ls]
+    ms = [torch.from_numpy((rng.random((B, L)) < 0.7).astype(np.float32)).to(DEV) for L in Ls]
+    kinds = [NRX_BAG_MASKED_MEAN, NRX_BAG_SUM]
+    table = torch.randn((rows_local, D), device=DEV)
+    total = sum(int((m != 0).sum()) for m in ms)
+    cap = total + 64 if world == 1 else int(total / world * 1.5) + 64
+    bl = (C.c_int32 * n)(*Ls)
+    wn = [ops.bag_norm_weights(m, B, L, k) for m, L, k in zip(ms, Ls, kinds)]
+    l_rows, l_tag, l_w, l_c2d, _ = ops.route_bags(ids, wn, world, cap)
+    want = ops.pool_inbox([table], [0, 0], B, world, cap, l_c2d, l_rows, l_tag, l_w)          # (the test plays owner 0 of a symmetric exchange)
+    rows_o = torch.empty(world * cap, dtype=torch.int32, device=DEV)
+    w_o = torch.empty(world * cap, device=DEV)
+    run = torch.empty((world, n * B, 2), dtype=torch.int32, device=DEV)
+    c2d = torch.zeros((world, n), dtype=torch.int64, device=DEV)
+    over = torch.zeros(1, dtype=torch.int64, device=DEV)
+    state = torch.zeros(lib.nrx_route_bags_runs_state_bytes(bl, n, B, world), dtype=torch.uint8, device=DEV)
+    ops.check(lib.nrx_route_bags_runs((C.c_void_p * n)(*[x.data_ptr() for x in ids]), (C.c_void_p * n)(*[m.data_ptr() for m in ms]), (C.c_int32 * n)(*kinds), bl, n,
+                                      64, B, world, cap, rows_o.data_ptr(), w_o.data_ptr(), run.data_ptr(), None, c2d.data_ptr(), over.data_ptr(),
+                                      state.data_ptr(), st), "runs")
+    tp, tr, ft = (C.c_void_p * 1)(table.data_ptr()), (C.c_int64 * 1)(rows_local), (C.c_int32 * n)(0, 0)
+    partial = torch.full((world, n * B, D), 7.0, device=DEV)
+    ops.check(lib.nrx_pool_inbox_fwd_runs(tp, tr, 1, ft, n, B, world, cap, c2d.data_ptr(), rows_o.data_ptr(), w_o.data_ptr(), run.data_ptr(), D,
+                                          partial.data_ptr(), None, st), "fwd_runs")
+    torch.cuda.synchronize()
+    assert torch.equal(partial.view(torch.int32), want.view(torch.int32))
+    used = torch.zeros(world * cap, dtype=torch.bool, device=DEV)
+    for o in range(world):
+        used[o * cap: o * cap + int(c2d[o].sum())] = True
+    for skip in (0, 1):
+        tag_o = torch.full((world * cap,), -7, dtype=torch.int32, device=DEV)
+        oid = torch.full((world * cap,), -7, dtype=torch.int32, device=DEV)
+        pay = torch.full((world * cap,), -7, dtype=torch.int32, device=DEV)
+        ops.check(lib.nrx_pool_inbox_runs_words(rows_local, n, B, world, cap, c2d.data_ptr(), rows_o.data_ptr(), run.data_ptr(), skip, tag_o.data_ptr(),
+                                                oid.data_ptr(), pay.data_ptr(), st), "runs_words")
+        want_id, want_pay = torch.empty_like(oid), torch.empty_like(pay)
+        ops.check(lib.nrx_pool_inbox_owner_ids(rows_local, n, B, world, cap, l_c2d.data_ptr(), l_rows.data_ptr(), l_tag.data_ptr(), skip,
+                                               want_id.data_ptr(), want_pay.data_ptr(), st), "owner_ids")
+        torch.cuda.synchronize()
+        assert torch.equal(oid, want_id) and torch.equal(pay, want_pay)
+        assert torch.equal(tag_o[used], l_tag[used]) and bool((tag_o[~used] == -7).all())
+    only_tags = torch.full((world * cap,), -7, dtype=torch.int32, device=DEV)
+    ops.check(lib.nrx_pool_inbox_runs_words(rows_local, n, B, world, cap, c2d.data_ptr(), rows_o.data_ptr(), run.data_ptr(), 0, only_tags.data_ptr(), None, None, st),
+              "runs_words")
+    torch.cuda.synchronize()
+    assert torch.equal(only_tags[used], l_tag[used])
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_the_three_routings_of_the_pooled_channel_give_the_same_step_bit_for_bit(binary, monkeypatch):
+    """NRX_ROUTE_BAGS = runs (default) | one | legacy: the same forward and the same (keys, values) word for word."""
+    rng = np.random.default_rng(23)
+    D, L, B, news = 16, 50, 5000, 30_000
+    feats = [ShardedFeature("item_id", NRX_SPARSE, "item_id", D), ShardedFeature("user_history", NRX_BAG_MASKED_MEAN, "item_id", D, L)]
+    hist = rng.integers(1, news, (B, L))
+    mask = (np.arange(L)[None, :] < rng.integers(0, L + 1, B)[:, None]).astype(np.float32)
+    inputs = [torch.from_numpy(rng.integers(0, news, B)).to(DEV), torch.from_numpy(np.where(mask > 0, hist, 0)).to(DEV)]
+    weights = [None, torch.from_numpy(mask).to(DEV)]
+    g_out = torch.randn((B, 2 * D), device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    res = {}
+    for how in ("runs", "one", "legacy"):
+        monkeypatch.setenv("NRX_ROUTE_BAGS", how)
+        arenas = {"item_id": shard_step.make_arena(news, D, 0, 1, DEV, generator=torch.Generator(device=DEV).manual_seed(4))}
+        eng = RowShardedEmbedding(0, 1, overflow_policy="defer")
+        step = shard_step.PreparedShardedStep(eng, feats, inputs, weights, arenas, binary_masks=binary)
+        g = next(g for g in step.groups if g["pooled"])
+        assert (g.get("runs_state") is not None) == (how == "runs") and (g.get("rstate") is not None) == (how == "one")
+        out, _, _ = step.run()
+        step.bind_backward(g_out)
+        first = [(e["uniq"].clone(), e["values"].clone(), int(e["counts"][0])) for e in step.backward()]
+        for _ in range(2):
+            out, _, _ = step.run()
+            entries = step.backward()
+        torch.cuda.synchronize()
+        assert not step.overflowed()
+        cur = [(e["uniq"].clone(), e["values"].clone(), int(e["counts"][0])) for e in entries]
+        for (k0, v0, n0), (k1, v1, n1) in zip(first, cur):
+            assert n0 == n1 and torch.equal(k0[:n0], k1[:n1]) and torch.equal(v0[:n0].view(torch.int32), v1[:n1].view(torch.int32))
+        res[how] = (out.clone(), cur)
+    for how in ("one", "legacy"):
+        assert torch.equal(res["runs"][0].view(torch.int32), res[how][0].view(torch.int32))
+        assert len(res["runs"][1]) == len(res[how][1])
+        for (k0, v0, n0), (k1, v1, n1) in zip(res["runs"][1], res[how][1]):
+            assert n0 == n1 and torch.equal(k0[:n0], k1[:n1]) and torch.equal(v0[:n0].view(torch.int32), v1[:n1].view(torch.int32))

@@ -30,4 +30,17 @@ def timed(fn, reps=100):
 ptrs = [(C.c_void_p * 1)(x.data_ptr()) for x in pool]
 one = timed(lambda i: lib.nrx_route_bags_one(ptrs[i % 4], wp, bl, 1, 64, B, W, cap, rows_o.data_ptr(), tag_o.data_ptr(), w_o.data_ptr(), c2d.data_ptr(), over.data_ptr(), state.data_ptr(), st))
 three = timed(lambda i: lib.nrx_route_bags(ptrs[i % 4], wp, bl, 1, 64, B, W, cap, rows_o.data_ptr(), tag_o.data_ptr(), w_o.data_ptr(), c2d.data_ptr(), over.data_ptr(), ws.data_ptr(), st))
+nb = lib.nrx_route_bags_runs_state_bytes(bl, 1, B, W)
+runs = float("nan")
+if nb > 0:
+    s2 = torch.zeros(nb, dtype=torch.uint8, device=dev)
+    run = torch.empty((W, B, 2), dtype=torch.int32, device=dev)
+    inv = torch.empty(B, dtype=torch.float32, device=dev)
+    kinds = (C.c_int32 * 1)(2)       # NRX_BAG_MASKED_MEAN
+    ip = (C.c_void_p * 1)(inv.data_ptr())
+    wn = torch.empty_like(w)
+    runs = timed(lambda i: lib.nrx_route_bags_runs(ptrs[i % 4], wp, kinds, bl, 1, 64, B, W, cap, rows_o.data_ptr(), w_o.data_ptr(), run.data_ptr(), ip, c2d.data_ptr(), over.data_ptr(), s2.data_ptr(), st))
+    both = timed(lambda i: (lib.nrx_bag_norm_weights_inv(w.data_ptr(), B, L, 2, wn.data_ptr(), inv.data_ptr(), st),
+                            lib.nrx_route_bags_one(ptrs[i % 4], (C.c_void_p * 1)(wn.data_ptr()), bl, 1, 64, B, W, cap, rows_o.data_ptr(), tag_o.data_ptr(), w_o.data_ptr(), c2d.data_ptr(), over.data_ptr(), state.data_ptr(), st)))
+    print(f"world {W}: nrx_route_bags_runs {runs:.1f} us  against nrx_bag_norm_weights_inv + nrx_route_bags_one {both:.1f} us")
 print(f"world {W}: nrx_route_bags_one {one:.1f} us, nrx_route_bags {three:.1f} us  (lib {os.path.basename(os.environ.get('NRX_LIB', 'default'))})")
