@@ -628,11 +628,31 @@ __global__ __launch_bounds__(NRX_BLOCK) void pool_inbox_fwd_kernel(const PoolArg
         for (int e0 = lo; e0 < hi; e0 += AHEAD) {
             int32_t row[AHEAD];
             float w[AHEAD];
+            // the eight entries' {row, weight}: fetched ONCE per lane group -- lane q loads entries q * EPL .. and the group exchanges them (every
+            // lane loading all eight was 16 load instructions of 16 scattered words each: two thirds of this launch's L2 requests)
+            constexpr int EPL = Q >= AHEAD ? 1 : AHEAD / Q;
+            if constexpr (Q == 1) {
 #pragma unroll
-            for (int u = 0; u < AHEAD; ++u) {
-                const int e = e0 + u < hi ? e0 + u : lo;
-                row[u] = nrx_gconst<int32_t>(a->inbox_rows)[base + e];
-                w[u] = e0 + u < hi ? nrx_gconst<float>(a->inbox_w)[base + e] : 0.f;
+                for (int u = 0; u < AHEAD; ++u) {
+                    const int e = e0 + u < hi ? e0 + u : lo;
+                    row[u] = nrx_gconst<int32_t>(a->inbox_rows)[base + e];
+                    w[u] = e0 + u < hi ? nrx_gconst<float>(a->inbox_w)[base + e] : 0.f;
+                }
+            } else {
+                int32_t myrow[EPL];
+                float myw[EPL];
+#pragma unroll
+                for (int x = 0; x < EPL; ++x) {
+                    const int u = q * EPL + x;
+                    const int e = (u < AHEAD && e0 + u < hi) ? e0 + u : lo;
+                    myrow[x] = nrx_gconst<int32_t>(a->inbox_rows)[base + e];
+                    myw[x] = (u < AHEAD && e0 + u < hi) ? nrx_gconst<float>(a->inbox_w)[base + e] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < AHEAD; ++u) {
+                    row[u] = __shfl(myrow[u % EPL], u / EPL, Q);
+                    w[u] = __shfl(myw[u % EPL], u / EPL, Q);
+                }
             }
             float4 v[AHEAD];
 #pragma unroll
