@@ -537,7 +537,10 @@ __global__ __launch_bounds__(NRX_BLOCK) void inbox_transpose_kernel(const int32_
 // (peer[s] + pos * ld + col[f]) instead of into a [world * capf, n * dim] row buffer that an all-to-all carries back and a final launch re-reads.
 // A lane group of Q lanes owns a pseudo-sample b' = s * capf + k and walks the features with GP_R row loads in flight; owner id 0 with a
 // position >= 0 is a lookup of the padding id: zeros are written (position < 0: an empty slot, skipped).
-constexpr int GP_R = 8;
+#ifndef NRX_GP_R
+#define NRX_GP_R 8
+#endif
+constexpr int GP_R = NRX_GP_R;
 struct GatherPlaceArgs {
     const float* table[NRX_MAX_FEATURES];      // arena base (row 0 = the dummy row)
     int64_t rows[NRX_MAX_FEATURES];            // arena rows
@@ -561,14 +564,17 @@ __global__ __launch_bounds__(NRX_BLOCK) void gather_place_feat_kernel(const Gath
     for (int64_t b = (int64_t)blockIdx.x * TB + (threadIdx.x >> QLOG2); b < bp; b += (int64_t)gridDim.x * TB) {
         const int s = (int)(b / a->capf);
         float* __restrict__ out = a->peer[s];
-        for (int f0 = 0; f0 < n; f0 += GP_R) {
-            int32_t id[GP_R], pos[GP_R];
+        // the next eight features' {owner id, position} are requested BEFORE the current eight's rows are waited for (two register sets, the loop body
+        // written twice: a chunk was two dependent round trips -- ids, then rows -- and a 26-feature sample four chunks)
+        auto fetch = [&](int f0, int32_t* id, int32_t* pos) {
 #pragma unroll
             for (int r = 0; r < GP_R; ++r) {
                 const int f = f0 + r < n ? f0 + r : n - 1;
                 id[r] = nrx_gconst<int32_t>(a->oid)[(int64_t)f * bp + b];
                 pos[r] = nrx_gconst<int32_t>(a->opos)[(int64_t)f * bp + b];
             }
+        };
+        auto process = [&](int f0, const int32_t* id, int32_t* pos) {
             float4 v[GP_R];
 #pragma unroll
             for (int r = 0; r < GP_R; ++r) {
@@ -591,6 +597,15 @@ __global__ __launch_bounds__(NRX_BLOCK) void gather_place_feat_kernel(const Gath
                 }
                 nrx_stg4(out, ((int64_t)pos[r] * a->ld + a->col[f]) / 4 + q, v[r]);
             }
+        };
+        int32_t ida[GP_R], posa[GP_R], idb[GP_R], posb[GP_R];
+        fetch(0, ida, posa);
+        for (int f0 = 0; f0 < n; f0 += 2 * GP_R) {
+            if (f0 + GP_R < n) fetch(f0 + GP_R, idb, posb);
+            process(f0, ida, posa);
+            if (f0 + GP_R >= n) break;
+            if (f0 + 2 * GP_R < n) fetch(f0 + 2 * GP_R, ida, posa);
+            process(f0 + GP_R, idb, posb);
         }
     }
 }
