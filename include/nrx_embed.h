@@ -704,6 +704,11 @@ NRX_API int nrx_bag_norm_weights(const float* mask, int64_t batch, int32_t bag_l
 /* nrx_bag_norm_weights that also leaves out_inv[b]: the weight every live entry of sample b carries when the mask is 0 / 1 (1 / (sum w + 1e-8), 0
  * for an empty bag; 1 / L for the plain mean) -- what the bound sharded step's pooled backward pre-multiplies the sample's upstream row by. */
 NRX_API int nrx_bag_norm_weights_inv(const float* mask, int64_t batch, int32_t bag_len, int32_t kind, float* out_w, float* out_inv, void* stream);
+/* The pooled channel's backward, requester side: dst[c * copy_stride + b * dim + k] = g_out[b * ld + col + k] * (scale ? scale[b] : 1) for
+ * c < copies -- the [batch, dim] block of sample gradients of one bag feature, once per owner (the bound sharded step's g_send; scale = the 1 / den
+ * of nrx_bag_norm_weights_inv when the masks are 0 / 1).  Plain fp32 multiply: the same values torch's broadcast multiply gives. */
+NRX_API int nrx_bag_upstream_rows(const float* g_out, int64_t ld, int32_t col, int32_t dim, int64_t batch, const float* scale, int32_t copies,
+                          int64_t copy_stride, float* dst, void* stream);
 NRX_API int nrx_route_bags(const void* const* ids, const float* const* weights, const int32_t* bag_lens, int32_t n_feats,
                    int32_t index_bits, int64_t batch, int32_t world, int64_t cap, int32_t* send_rows, int32_t* send_tag,
                    float* send_w, int64_t* counts2d, int64_t* overflow, int64_t* workspace, void* stream);

@@ -149,6 +149,7 @@ SIGNATURES = {
     "nrx_bag_norm_weights_inv": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p]),
     "nrx_route_bags_one_state_bytes": (_i64, [C.POINTER(_i32), _i32, _i64, _i32]),
     "nrx_route_bags_one": (C.c_int, [C.POINTER(_p), C.POINTER(_p), C.POINTER(_i32), _i32, _i32, _i64, _i32, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "nrx_bag_upstream_rows": (C.c_int, [_p, _i64, _i32, _i32, _i64, _p, _i32, _i64, _p, _p]),
     "nrx_route_bags_runs_state_bytes": (_i64, [C.POINTER(_i32), _i32, _i64, _i32]),
     "nrx_route_bags_runs": (C.c_int, [C.POINTER(_p), C.POINTER(_p), C.POINTER(_i32), C.POINTER(_i32), _i32, _i32, _i64, _i32, _i64, _p, _p, _p,
                                       C.POINTER(_p), _p, _p, _p, _p]),

@@ -1032,6 +1032,35 @@ extern "C" int nrx_bag_norm_weights_inv(const float* mask, int64_t batch, int32_
     return NRX_OK;
 }
 
+// The pooled channel's backward, requester side: the block of sample gradients every owner gets -- column block [col, col + dim) of the upstream
+// gradient of the concat, each row times its sample's weight (scale, optional), written `copies` times at a stride (one copy per owner).
+__global__ __launch_bounds__(NRX_BLOCK) void bag_upstream_rows_kernel(const float* __restrict__ g_out, int64_t ld, int col, int dim, int64_t batch,
+                                                                     const float* __restrict__ scale, int copies, int64_t copy_stride,
+                                                                     float* __restrict__ dst) {
+    const int64_t total = batch * dim;
+    for (int64_t i = (int64_t)blockIdx.x * NRX_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * NRX_BLOCK) {
+        const int64_t b = i / dim;
+        const int k = (int)(i - b * dim);
+        float v = g_out[b * ld + col + k];
+        if (scale != nullptr) v *= scale[b];
+        for (int c = 0; c < copies; ++c) dst[(int64_t)c * copy_stride + i] = v;
+    }
+}
+
+extern "C" int nrx_bag_upstream_rows(const float* g_out, int64_t ld, int32_t col, int32_t dim, int64_t batch, const float* scale, int32_t copies,
+                                     int64_t copy_stride, float* dst, void* stream) {
+    NRX_TRACE();
+    NRX_REQUIRE(g_out != nullptr && dst != nullptr && dim >= 1 && col >= 0 && ld >= (int64_t)col + dim && batch >= 0 && copies >= 1 &&
+                (copies == 1 || copy_stride >= batch * dim), "nrx_bag_upstream_rows: bad argument");
+    if (batch == 0) return NRX_OK;
+    int64_t blocks = (batch * dim + NRX_BLOCK - 1) / NRX_BLOCK;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bag_upstream_rows_kernel, dim3((unsigned)blocks), dim3(NRX_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), g_out, ld, (int)col,
+                       (int)dim, batch, scale, (int)copies, copy_stride, dst);
+    NRX_LAUNCH_CHECK("nrx_bag_upstream_rows");
+    return NRX_OK;
+}
+
 extern "C" int nrx_route_bags(const void* const* ids, const float* const* weights, const int32_t* bag_lens, int32_t n_feats,
                               int32_t index_bits, int64_t batch, int32_t world, int64_t cap, int32_t* send_rows,
                               int32_t* send_tag, float* send_w, int64_t* counts2d, int64_t* overflow, int64_t* workspace,

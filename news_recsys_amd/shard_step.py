@@ -430,12 +430,12 @@ class PreparedShardedStep:
                 # d partial[o][tag] = the sample's upstream row for EVERY owner o (the requester adds the world partials): the same [n * B, D] block
                 # goes to every owner; the owner turns its inbox entries into pseudo-lookups with upstream rows w * g and reduces them like any batch
                 n, D, B = g["n"], g["D"], g["B"]
-                v = b["g_send"].view(W, n, B, D)
                 for k, col in enumerate(b["cols"]):
-                    src = self.g_out[:, col:col + D]
+                    scale = None
                     if b["binary"]:       # every live entry of a sample carries the same normalised weight (0 for an empty bag): the forward left it
-                        src = src * (g["inv"][k].unsqueeze(1) if g.get("inv") is not None else g["wn"][k].amax(dim=1, keepdim=True))
-                    v[:, k].copy_(src.unsqueeze(0).expand(W, B, D))
+                        scale = g["inv"][k] if g.get("inv") is not None else g["wn"][k].amax(dim=1).contiguous()
+                    ops.check(lib.nrx_bag_upstream_rows(self.g_out.data_ptr(), self.ld, col, D, B, None if scale is None else scale.data_ptr(), W,
+                                                        n * B * D, b["g_send"].data_ptr() + 4 * k * B * D, stream), "nrx_bag_upstream_rows")
                 if W > 1:
                     eng._a2a(b["g_recv"].view(-1), b["g_send"].view(-1))
                 runs = g.get("runs_state") is not None      # (the tags stayed at the source: the per-entry words come from the run bounds)
