@@ -235,15 +235,50 @@ class PreparedShardedStep:
         self.plan_mode = os.environ.get("NRX_SHARD_PLAN", "inline")
 
     # ------------------------------------------------------------------ forward
+    def _side_streams(self):
+        """Exchange groups are independent of each other until the final launch (forward) / the returned lists (backward): with more than one --
+        the DSSM tower: a single-valued group next to the pooled history bag -- the smaller groups' chains of short launches run on a side
+        stream NEXT TO the largest group's (NRX_SHARD_OVERLAP=0: one after the other).  Returns (side stream or None, index of the group that
+        stays on the current stream).  Forked and joined with wait_stream on both sides: capturable."""
+        if getattr(self, "_overlap", None) is None:
+            import os
+            how = os.environ.get("NRX_SHARD_OVERLAP", "1")          # 1 (default) | fwd | bwd | 0
+            self._overlap = how if (len(self.groups) > 1 and how != "0") else ""
+            self._side = torch.cuda.Stream(device=self.groups[0]["dev"]) if self._overlap else None
+            size = [(self.eng.world * g["cap"] if g["pooled"] else g["n"] * g["B"]) for g in self.groups]
+            self._main_group = max(range(len(size)), key=lambda i: size[i]) if size else 0
+        return self._side, self._main_group
+
+    def _each_group(self, fn, what="fwd"):
+        """fn(index) for every exchange group: the largest on the current stream, the others on the side stream (fork before, join after)."""
+        side, main = self._side_streams()
+        # (measured, C4 at world 1: both directions forked 404 -> 355 us per training step; the forward alone gains nothing from its fork -- its short
+        # group runs next to the ROUTING launch of the long one, a chain of waiting blocks, and slows it by what it saves -- so a forward-only
+        # step does not fork)
+        if side is None or self._overlap not in ("1", what) or (what == "fwd" and self._overlap == "1" and self.bwd is None):
+            for gi in range(len(self.groups)):
+                fn(gi)
+            return
+        cur = torch.cuda.current_stream(side.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for gi in range(len(self.groups)):
+                if gi != main:
+                    fn(gi)
+        fn(main)
+        cur.wait_stream(side)
+
     def run(self):
         eng, lib = self.eng, self.lib
         W = eng.world
-        for g in self.groups:
+
+        def one(gi):
+            g = self.groups[gi]
             stream = torch.cuda.current_stream(g["dev"]).cuda_stream
             if g["pooled"]:
                 from .sharding import PreparedShardedForward
                 PreparedShardedForward._run_pooled(self, g, stream)
-                continue
+                return
             placed = g["placed"]
             rc = lib.nrx_route_feat(g["ptrs"], g["n"], g["B"], g["bits"], W, g["capf"], g["send_ids"].data_ptr(),
                                     g["send_pos"].data_ptr() if placed else None, g["slot"].data_ptr(),
@@ -265,10 +300,12 @@ class PreparedShardedStep:
                                                self._peer_ptrs, self.ld, self.out.shape[0], ops._ptr(self.status), stream)
                 if rc:
                     ops.check(rc, "nrx_gather_place_feat")
-                continue
+                return
             g["owner_fwd"].run()
             if W > 1:
                 eng._a2a(g["ret"].view(-1), g["rows_out"].view(-1))
+
+        self._each_group(one)
         res = self.final.run() if self.final is not None else (self.out, None, None)
         if self.peers is not None and W > 1:
             # completion fence: a collective enqueued behind every rank's placing launch -- when it has completed here, every owner's rows are in this
@@ -419,12 +456,14 @@ class PreparedShardedStep:
         cap) -- valid until the next backward(); feed them to optim.FusedSparseAdam through `sink_entries`."""
         lib, eng = self.lib, self.eng
         W = eng.world
-        out = []
         if self.plan_mode == "backward":
             for b in self.bwd:
                 if not b["pooled"] and not b["direct"]:
                     b["owner"].plan_ahead()
-        for g, b in zip(self.groups, self.bwd):
+        outs = [[] for _ in self.groups]
+
+        def one(gi):
+            g, b, out = self.groups[gi], self.bwd[gi], outs[gi]
             stream = torch.cuda.current_stream(g["dev"]).cuda_stream
             if b["pooled"]:
                 # d partial[o][tag] = the sample's upstream row for EVERY owner o (the requester adds the world partials): the same [n * B, D] block
@@ -457,7 +496,7 @@ class PreparedShardedStep:
                 for og in b["owner"].run():
                     out.append(dict(tables=g["tables"], dim=og["dim"], uniq=og["uniq"], values=og["values"], counts=og["counts"], cap=og["cap"],
                                     table_ids=[0]))
-                continue
+                return
             if b["direct"]:
                 owner = b["owner"]
                 owner.plan_only()
@@ -480,7 +519,7 @@ class PreparedShardedStep:
                 for og in owner.run_walk():
                     out.append(dict(tables=g["tables"], dim=og["dim"], uniq=og["uniq"], values=og["values"], counts=og["counts"], cap=og["cap"],
                                     table_ids=list(range(len(g["tables"])))))
-                continue
+                return
             rc = NRX_ERR_UNSUPPORTED
             if b["scatter_ok"]:
                 rc = lib.nrx_embed_bwd_scatter(b["arr"], g["n"], g["B"], g["D"], ops._ptr(self.g_out), self.ld, None, 0, self.fmg,
@@ -499,7 +538,9 @@ class PreparedShardedStep:
             for og in b["owner"].run():
                 out.append(dict(tables=g["tables"], dim=og["dim"], uniq=og["uniq"], values=og["values"], counts=og["counts"], cap=og["cap"],
                                 table_ids=list(range(len(g["tables"])))))
-        return out
+
+        self._each_group(one, "bwd")
+        return [e for o in outs for e in o]
 
     def sink_entries(self, sink: "ops.SparseGradSink"):
         """backward() into a SparseGradSink (what optim.FusedSparseAdam drains)."""
