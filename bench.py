@@ -1033,15 +1033,42 @@ def main():
                                         "note": "the DIRECT path's algorithmic bytes of one rank's batch (forward in training form + row-sparse backward, "
                                                 "bench.backward_bytes_per_impression) / wall time per step, max over ranks: the exchange's own traffic (ids, "
                                                 "rows and gradient rows through the send / receive buffers) is overhead of the method, not counted"},
-                           "mode": ("shard_step.PreparedShardedStep, bound: nrx_route_feat (one launch) + all-to-all of owner ids + the owner's fused forward over "
-                                    "its pseudo-batch + all-to-all of the rows + the slot-addressed final launch; backward: nrx_embed_bwd_scatter (every lookup's "
-                                    "upstream row to its slot, FM term folded in) + gradient all-to-all + the owner-side planned reduction (the single-GPU "
-                                    "planners, placement pass and sorted walk) into ROW-SPARSE (keys, values): deterministic, no dense shard gradient, no "
-                                    "float atomic, nothing read back; at world 1 the all-to-alls vanish (receive buffers = send buffers)") if bound else
+                           "mode": ("shard_step.PreparedShardedStep, bound: nrx_route_feat (one launch) + all-to-all of owner ids (+ positions) + the owner's "
+                                    "placing gather straight into the requester's concat (one-sided; FM: one pass over the finished concat) -- bag features: "
+                                    "nrx_route_bags_runs (routing + weight normalisation + run bounds in one launch) + owner-side pooling; backward: the owner "
+                                    "plans first (the single-GPU planners), its plan's dest[] travels back, nrx_embed_bwd_scatter(_multi) writes every upstream "
+                                    "row (FM term folded in) to its place in the owner's gradient arena, the owner's sorted walk reduces the listed rows into "
+                                    "ROW-SPARSE (keys, values): deterministic, no dense shard gradient, no float atomic, nothing read back; independent "
+                                    "exchange groups run side by side on two streams; at world 1 the all-to-alls vanish (receive buffers = send buffers)") if bound else
                                    ("sharded engine, autograd form (RowShardedEmbedding.forward + backward): id routing + all-to-alls + owner gather / "
                                     "owner-side pooling + fused final launch; backward: slot scatter of the upstream rows, gradient all-to-all to the owners, "
                                     "owner-side scatter-add into the shards' DENSE gradients (zero-filled every step); eager launches from Python "
                                     "(host time included: wall clock, max over ranks)")}
+                if bound and world == 1:
+                    # the same step captured in a HIP graph (it allocates nothing, reads nothing back and forks / joins its groups with wait_stream):
+                    # GPU time without the host's launches; one id set (the eager loop above alternates two)
+                    try:
+                        c = path.calls[0]
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph):
+                            c.run()
+                            c.backward()
+                        for _ in range(3):
+                            graph.replay()
+                        ga, gb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        ga.record()
+                        for _ in range(nst):
+                            graph.replay()
+                        gb.record()
+                        torch.cuda.synchronize()
+                        fwd_bwd["graphed"] = {"replay_ms_per_step": ga.elapsed_time(gb) / nst,
+                                              "note": "forward + backward of the bound step captured in one HIP graph, replayed: same launches, no host time -- and NOT faster "
+                                                      "than the eager loop while the host keeps ahead of the GPU (a graph's nodes are dispatched one by one with a "
+                                                      "dependency barrier between them; eager launches queue back to back): what the capture buys is a step whose "
+                                                      "time does not depend on the host"}
+                        del graph
+                    except Exception as e:          # noqa: BLE001
+                        fwd_bwd["graphed"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             else:
                 fwd_bwd = {"skipped": "the shards' dense gradients (one zero-filled [local rows, dim] tensor per table and step) do not fit next to the tables"}
         except Exception as e:          # noqa: BLE001 -- a secondary leg must not cost the headline

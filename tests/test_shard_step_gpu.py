@@ -693,3 +693,56 @@ def test_the_three_routings_of_the_pooled_channel_give_the_same_step_bit_for_bit
         assert len(res["runs"][1]) == len(res[how][1])
         for (k0, v0, n0), (k1, v1, n1) in zip(res["runs"][1], res[how][1]):
             assert n0 == n1 and torch.equal(k0[:n0], k1[:n1]) and torch.equal(v0[:n0].view(torch.int32), v1[:n1].view(torch.int32))
+
+
+@pytest.mark.parametrize("case", ["tower_two_groups", "fm_one_group"])
+def test_world_1_step_is_capturable_and_the_graph_replays_the_eager_bits(case):
+    """The bound step allocates nothing, reads nothing back and forks / joins its exchange groups with wait_stream: forward + backward captured in a
+    HIP graph replay the eager step's concat, keys, values and counts word for word (a DSSM tower: two groups side by side on two streams, the
+    pooled channel's two-launch forward; an FM plan: one-sided placement + the pass over the finished concat)."""
+    rng = np.random.default_rng(3)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    D, B = 16, 6000
+    if case == "tower_two_groups":
+        L, news, users = 11, 20_000, 300_000
+        feats = [ShardedFeature("item_id", NRX_SPARSE, "item_id", D), ShardedFeature("user_history", NRX_BAG_MASKED_MEAN, "item_id", D, L),
+                 ShardedFeature("user_id", NRX_SPARSE, "user_id", D)]
+        arenas = {"item_id": shard_step.make_arena(news, D, 0, 1, DEV, generator=gen), "user_id": shard_step.make_arena(users, D, 0, 1, DEV, generator=gen)}
+        mask = (np.arange(L)[None, :] < rng.integers(0, L + 1, B)[:, None]).astype(np.float32)
+        inputs = [torch.from_numpy(rng.integers(0, news, B)).to(DEV), torch.from_numpy(np.where(mask > 0, rng.integers(1, news, (B, L)), 0)).to(DEV),
+                  torch.from_numpy(rng.integers(1, users, B)).to(DEV)]
+        weights = [None, torch.from_numpy(mask).to(DEV), None]
+        g_fm = None
+    else:
+        n, rows = 7, 50_000
+        feats = [ShardedFeature(f"C{i}", NRX_SPARSE, f"C{i}", D, fm=True) for i in range(n)]
+        arenas = {f"C{i}": shard_step.make_arena(rows, D, 0, 1, DEV, generator=gen) for i in range(n)}
+        inputs = [torch.from_numpy(rng.integers(0, rows, B)).to(DEV) for _ in range(n)]
+        weights = [None] * n
+        g_fm = torch.randn(B, device=DEV, generator=gen)
+    g_out = torch.randn((B, sum(f.dim for f in feats)), device=DEV, generator=gen)
+    eng = RowShardedEmbedding(0, 1, overflow_policy="defer")
+    step = shard_step.PreparedShardedStep(eng, feats, inputs, weights, arenas, binary_masks=True).bind_backward(g_out, g_fm)
+    if case == "tower_two_groups":
+        assert len(step.groups) == 2 and step._side_streams()[0] is not None
+    for _ in range(3):                                  # (the planners choose from the previous batch's statistics: settled before the capture)
+        out, _, fm = step.run()
+        entries = step.backward()
+    torch.cuda.synchronize()
+    want = (out.clone(), None if fm is None else fm.clone(), [(e["uniq"].clone(), e["values"].clone(), int(e["counts"][0])) for e in entries])
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out2, _, fm2 = step.run()
+        entries2 = step.backward()
+    out2.zero_()
+    for e in entries2:
+        e["values"].zero_()
+        e["counts"].zero_()
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out2.view(torch.int32), want[0].view(torch.int32))
+    assert fm is None or torch.equal(fm2.view(torch.int32), want[1].view(torch.int32))
+    assert len(entries2) == len(want[2])
+    for e, (k, v, n) in zip(entries2, want[2]):
+        assert int(e["counts"][0]) == n and torch.equal(e["uniq"][:n], k[:n]) and torch.equal(e["values"][:n].view(torch.int32), v[:n].view(torch.int32))
