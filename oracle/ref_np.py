@@ -670,6 +670,17 @@ def route_bags_runs(id_arrays, weights, world: int, cap: int):
     return run
 
 
+def tags_from_runs(run, world: int, cap: int):
+    """Definition of nrx_pool_inbox_runs_words' tag_out: block s of `run` ([world, n_tags, 2], as it ARRIVED at the owner) names, per tag, the
+    slots of block s that hold its entries; every slot inside a run gets its tag, the others stay -1."""
+    run = np.asarray(run).reshape(world, -1, 2)
+    tag = np.full(world * cap, -1, np.int64)
+    for s_ in range(world):
+        for t in np.flatnonzero(run[s_, :, 1] > run[s_, :, 0]):
+            tag[s_ * cap + run[s_, t, 0]: s_ * cap + run[s_, t, 1]] = t
+    return tag
+
+
 def pool_inbox(tables, feat_table, batch: int, world: int, cap: int, recv2d, inbox_rows, inbox_tag, inbox_w, dim: int):
     """Definition of nrx_pool_inbox_fwd: partial[s, tag] = sum over block s's valid entries with that tag of
     w * tables[feat_table[tag // batch]][row], accumulated in entry order (fp32, product then add)."""

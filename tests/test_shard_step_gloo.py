@@ -9,7 +9,10 @@ a GPU is the layout algebra between the ranks:
   * the backward -- every lookup's upstream row to its slot, all-to-all, owner-side sum per owner id -- gives, over all owners, exactly the
     dense gradient np.add.at forms on the concatenated batch (float64 here: the summation order is not what this test is about);
   * the owner's plan destinations travel back in the ids' layout (the direct-gradient mode's dest exchange): dest_req[o, f, k] of a lookup is the
-    entry its owner computed for pseudo-sample s * capf + k.
+    entry its owner computed for pseudo-sample s * capf + k;
+  * the pooled bag channel in its RUNS form (test_pooled_runs_protocol_over_gloo): rows, weights and the (owner, tag) run bounds travel (no tags);
+    the owner rebuilds every entry's tag from the runs that arrived, pools per (source, tag), the partial rows go back and the requester adds the
+    world partials of a sample -- equal to array_feature_pooling on the full table (base_model.py:273-282).
 The product path has no CPU implementation (ops raise without the HIP library): this test imports only the oracle and torch.distributed."""
 import numpy as np
 import pytest
@@ -117,3 +120,73 @@ def test_per_feature_exchange_protocol_over_gloo(world):
         want_g[f][0] = 0                                                   # padding_idx = 0 (base_model.py:164)
         for r in range(world):
             np.testing.assert_allclose(res[r][1][f], want_g[f][r::world], rtol=1e-12, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------- the pooled channel, runs form
+BL, BB, BD, BROWS = 7, 90, 4, 61
+
+
+def _bag_batch(rank):
+    rng = np.random.default_rng(70 + rank)
+    ids = rng.integers(0, BROWS, (BB, BL))
+    mask = (np.arange(BL)[None, :] < rng.integers(0, BL + 1, BB)[:, None]).astype(np.float32)
+    return np.where(mask > 0, ids, 0), mask
+
+
+def _bag_worker(rank, world, port, q):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        table = np.random.default_rng(2).standard_normal((BROWS, BD)).astype(np.float32)
+        table[0] = 0
+        shard = table[rank::world]                                         # local row = global row // world
+        ids, mask = _bag_batch(rank)
+        wn = ref_np.bag_norm_weights(mask, BB, BL, "masked_mean")
+        cap = int(BB * BL / world * 1.3) + 16                              # (the same on every rank: from the shapes, as capacity_for does)
+        send_rows, send_tag, send_w, counts2d, worst = ref_np.route_bags([ids], [wn], world, cap)
+        assert worst <= cap
+        run = ref_np.route_bags_runs([ids], [wn], world, cap)              # [world, BB, 2]: what travels in the place of the tags
+        inbox_rows, inbox_w = _a2a(send_rows.reshape(world, cap)), _a2a(send_w.reshape(world, cap))
+        run_in = _a2a(run)
+        recv2d = _a2a(counts2d.reshape(world, 1))
+        tags = ref_np.tags_from_runs(run_in, world, cap)                   # the owner's view of every entry's tag
+        used = np.zeros(world * cap, bool)
+        for s_ in range(world):
+            used[s_ * cap: s_ * cap + int(recv2d[s_, 0])] = True
+        ok = bool((tags[used] >= 0).all() and (tags[~used] == -1).all())  # every arrived entry lies in exactly one run, nothing else does
+        # ... and they are the tags the source would have sent
+        tags_sent = _a2a(send_tag.reshape(world, cap)).reshape(-1)
+        ok &= bool(np.array_equal(tags[used], tags_sent[used]))
+        partial = ref_np.pool_inbox([shard], [0], BB, world, cap, recv2d, inbox_rows.reshape(-1), tags, inbox_w.reshape(-1), BD)      # [world, BB, BD]
+        back = _a2a(partial)                                               # block o: owner o's partial rows of MY samples
+        pooled = back.astype(np.float64).sum(axis=0)
+        q.put((rank, pooled, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pooled_runs_protocol_over_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bag_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        item = q.get(timeout=120)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    table = np.random.default_rng(2).standard_normal((BROWS, BD)).astype(np.float32)
+    table[0] = 0
+    for r in range(world):
+        ids, mask = _bag_batch(r)
+        pooled, ok = res[r]
+        assert ok
+        want = ref_np.array_pool(table[ids], mask)                         # base_model.py:273-282
+        np.testing.assert_allclose(pooled, want, rtol=1e-5, atol=1e-6)

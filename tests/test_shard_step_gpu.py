@@ -650,6 +650,8 @@ def test_pool_inbox_fwd_runs_equals_pool_inbox_fwd_and_the_runs_give_the_backwar
         torch.cuda.synchronize()
         assert torch.equal(oid, want_id) and torch.equal(pay, want_pay)
         assert torch.equal(tag_o[used], l_tag[used]) and bool((tag_o[~used] == -7).all())
+        want_tags = ref_np.tags_from_runs(run.cpu().numpy(), world, cap)                        # the definition: -1 outside the runs
+        assert np.array_equal(np.where(tag_o.cpu().numpy() == -7, -1, tag_o.cpu().numpy()), want_tags)
     only_tags = torch.full((world * cap,), -7, dtype=torch.int32, device=DEV)
     ops.check(lib.nrx_pool_inbox_runs_words(rows_local, n, B, world, cap, c2d.data_ptr(), rows_o.data_ptr(), run.data_ptr(), 0, only_tags.data_ptr(), None, None, st),
               "runs_words")
