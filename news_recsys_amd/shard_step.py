@@ -243,10 +243,19 @@ class PreparedShardedStep:
         if getattr(self, "_overlap", None) is None:
             import os
             how = os.environ.get("NRX_SHARD_OVERLAP", "1")          # 1 (default) | fwd | bwd | 0
-            self._overlap = how if (len(self.groups) > 1 and how != "0") else ""
+            # Launches whose blocks WAIT FOR EACH OTHER must not meet a second launch of that kind on the other stream unless both are sure to be
+            # resident together (two half-started chains can hold each other's slots):
+            #  * the one-kernel planner (plan_lds_kernel: one 158 KB-LDS block per compute unit, every block resident by construction) may be taken
+            #    by single-valued groups only -- a pooled group's plan is always the sorted one -- so at most ONE single-valued group may exist;
+            #  * the routing launches (chains over tiles): the forward forks only when the side groups' routing launches are small next to the
+            #    device (<= one block per compute unit: they cannot fill an XCD, so the long chain's lowest waiting tile always finds its slot).
+            single = sum(1 for g in self.groups if not g["pooled"])
+            self._overlap = how if (len(self.groups) > 1 and how != "0" and single <= 1) else ""
             self._side = torch.cuda.Stream(device=self.groups[0]["dev"]) if self._overlap else None
             size = [(self.eng.world * g["cap"] if g["pooled"] else g["n"] * g["B"]) for g in self.groups]
             self._main_group = max(range(len(size)), key=lambda i: size[i]) if size else 0
+            tiles = [(sum(-(-g["B"] // max(1, 4096 // L)) for L in g["lens"]) if g["pooled"] else g["n"] * -(-g["B"] // 4096)) for g in self.groups]
+            self._fwd_fork_ok = sum(t for i, t in enumerate(tiles) if i != self._main_group) <= 256
         return self._side, self._main_group
 
     def _each_group(self, fn, what="fwd"):
@@ -255,7 +264,7 @@ class PreparedShardedStep:
         # (measured, C4 at world 1: both directions forked 404 -> 355 us per training step; the forward alone gains nothing from its fork -- its short
         # group runs next to the ROUTING launch of the long one, a chain of waiting blocks, and slows it by what it saves -- so a forward-only
         # step does not fork)
-        if side is None or self._overlap not in ("1", what) or (what == "fwd" and self._overlap == "1" and self.bwd is None):
+        if side is None or self._overlap not in ("1", what) or (what == "fwd" and (not self._fwd_fork_ok or (self._overlap == "1" and self.bwd is None))):
             for gi in range(len(self.groups)):
                 fn(gi)
             return
