@@ -122,10 +122,15 @@ class PreparedShardedStep:
         if placed_groups:
             if out is None:
                 out = torch.empty((B0, ld0), dtype=torch.float32, device=dev0)
-            from .sharding import PreparedShardedForward
-            self.peers = PreparedShardedForward._map_peer_buffers(eng, out)
-            self._peer_ptrs = (C.c_void_p * W)(*[t.data_ptr() for t in self.peers])
-            self._fence = (torch.zeros(W, dtype=torch.int32, device=dev0), torch.zeros(W, dtype=torch.int32, device=dev0))
+            from .sharding import PeerMappingError, PreparedShardedForward
+            try:
+                self.peers = PreparedShardedForward._map_peer_buffers(eng, out)
+                self._peer_ptrs = (C.c_void_p * W)(*[t.data_ptr() for t in self.peers])
+                self._fence = (torch.zeros(W, dtype=torch.int32, device=dev0), torch.zeros(W, dtype=torch.int32, device=dev0))
+            except PeerMappingError as e:          # (raised on every rank together: all take the buffered form)
+                import warnings
+                warnings.warn(f"PreparedShardedStep: one-sided placement is not available here, taking the all-to-all form of the forward ({e})")
+                self.peers, placed_groups = None, set()
         for gi, idxs in enumerate(groups):
             dev = inputs[idxs[0]].device
             if gi in pooled:
@@ -441,8 +446,14 @@ class PreparedShardedStep:
                 if og["pmask"] is None:
                     direct = False
             if direct:
-                from .sharding import PreparedShardedForward
-                peers = PreparedShardedForward._map_peer_buffers(eng, arena)
+                from .sharding import PeerMappingError, PreparedShardedForward
+                try:
+                    peers = PreparedShardedForward._map_peer_buffers(eng, arena)
+                except PeerMappingError as e:      # (raised on every rank together: all take the buffered form)
+                    import warnings
+                    warnings.warn(f"PreparedShardedStep: the gradient arenas cannot be mapped here, taking the all-to-all form of the backward ({e})")
+                    direct = False
+            if direct:
                 b = dict(pooled=False, direct=True, arr=arr, owner=owner_bwd, arena=arena, peers=peers, shift=shift, cap_v=cap_v,
                          bases=(C.c_void_p * W)(*[t.data_ptr() for t in peers]), dest2=torch.empty(n * g["B"], dtype=torch.int32, device=g["dev"]),
                          fence=(torch.zeros(W, dtype=torch.int32, device=g["dev"]), torch.zeros(W, dtype=torch.int32, device=g["dev"])))

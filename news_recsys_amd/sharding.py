@@ -116,6 +116,10 @@ class HipBackend:
 
 
 # --------------------------------------------------------------------------------- feature description
+class PeerMappingError(RuntimeError):
+    """Raised on EVERY rank when some rank could not map its peers' buffers (PreparedShardedForward._map_peer_buffers)."""
+
+
 @dataclass
 class ShardedFeature:
     name: str
@@ -732,24 +736,36 @@ class PreparedShardedForward:
         W = eng.world
         if W == 1:
             return [out]
+        import os
         from torch.multiprocessing.reductions import reduce_tensor
-        handles = [None] * W
-        dist.all_gather_object(handles, reduce_tensor(out), group=eng.group)
-        peers = []
-        for s in range(W):
-            if s == eng.rank:
-                peers.append(out)
-                continue
-            fn, args = handles[s]
-            t = fn(*args)
-            if t.device != out.device:
-                out[:1, :1].copy_(t[:1, :1])           # (enables peer access between the two devices; the element is rewritten every step)
-            peers.append(t)
-        if eng.host_staged or not out.is_cuda:
-            dist.barrier(group=eng.group)
-        else:
-            torch.cuda.synchronize(out.device)
-            dist.barrier(group=eng.group)
+        # A mapping that cannot be made (no IPC between the processes, no peer access between the devices) must not strand the other ranks in a
+        # collective: every rank tries, the ranks agree (one small all-reduce), and ALL raise PeerMappingError together -- the callers then take
+        # the buffered (all-to-all) forms, which need no mapping.  NRX_DEBUG_FAIL_PEER_MAP=<rank>: that rank pretends to fail (tests).
+        peers, err = [], None
+        try:
+            handles = [None] * W
+            dist.all_gather_object(handles, reduce_tensor(out), group=eng.group)
+            if os.environ.get("NRX_DEBUG_FAIL_PEER_MAP") == str(eng.rank):
+                raise RuntimeError("NRX_DEBUG_FAIL_PEER_MAP")
+            for s in range(W):
+                if s == eng.rank:
+                    peers.append(out)
+                    continue
+                fn, args = handles[s]
+                t = fn(*args)
+                if t.device != out.device:
+                    out[:1, :1].copy_(t[:1, :1])           # (enables peer access between the two devices; the element is rewritten every step)
+                peers.append(t)
+            if out.is_cuda:
+                torch.cuda.synchronize(out.device)
+        except Exception as e:          # noqa: BLE001 -- whatever went wrong, the ranks must leave this function together
+            err = e
+        bad = torch.tensor([0 if err is None else 1], dtype=torch.int64, device=out.device)
+        eng._all_reduce_max(bad)
+        if int(bad.item()):
+            raise PeerMappingError("one-sided placement needs every rank's buffer mapped into every other rank (CUDA IPC / peer access): "
+                                   + (f"this rank failed with {type(err).__name__}: {err}" if err is not None else "another rank could not map it"))
+        dist.barrier(group=eng.group)
         return peers
 
     def _run_placed(self, g, stream):

@@ -57,10 +57,14 @@ def _batch(spec, B, rank):
     return ids, rng.standard_normal((B, width)).astype(np.float32), rng.standard_normal((B,)).astype(np.float32)
 
 
-def _worker(rank, world, port, q, case, one_sided, direct_grad):
+def _worker(rank, world, port, q, case, one_sided, direct_grad, fail_map=False):
     import os
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if fail_map:
+        os.environ["NRX_DEBUG_FAIL_PEER_MAP"] = "1"           # rank 1 pretends it cannot map its peers' buffers: EVERY rank must fall back
+        import warnings
+        warnings.simplefilter("ignore")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         spec, B, fm = SPECS[case]
@@ -73,7 +77,7 @@ def _worker(rank, world, port, q, case, one_sided, direct_grad):
         g_fm = torch.from_numpy(up_fm).to(DEV) if fm else None
         eng = RowShardedEmbedding(rank, world, slack=0.5, host_staged=True, overflow_policy="defer")
         step = shard_step.PreparedShardedStep(eng, feats, inputs, [None] * len(feats), arenas, one_sided=one_sided).bind_backward(g_out, g_fm, direct_grad=direct_grad)
-        assert all(g["placed"] == one_sided for g in step.groups) and all(b["direct"] == direct_grad for b in step.bwd)
+        assert all(g["placed"] == (one_sided and not fail_map) for g in step.groups) and all(b["direct"] == (direct_grad and not fail_map) for b in step.bwd)
         runs = []
         for _ in range(2):
             out, _, fmv = step.run()
@@ -96,16 +100,18 @@ def _worker(rank, world, port, q, case, one_sided, direct_grad):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("case,one_sided,direct_grad", [("fm16", False, False), ("mixed", False, False), ("mixed", True, False),
-                                                        ("fm16", False, True), ("mixed", True, True), ("fm16", True, True)])
-def test_sharded_step_equals_the_direct_path_on_the_concatenated_batch(world, case, one_sided, direct_grad):
+@pytest.mark.parametrize("case,one_sided,direct_grad,fail_map", [("fm16", False, False, False), ("mixed", False, False, False), ("mixed", True, False, False),
+                                                                 ("fm16", False, True, False), ("mixed", True, True, False), ("fm16", True, True, False),
+                                                                 ("fm16", True, True, True)])
+def test_sharded_step_equals_the_direct_path_on_the_concatenated_batch(world, case, one_sided, direct_grad, fail_map):
     """one_sided: the owners write the rows straight into the requesters' concat buffers (nrx_gather_place_feat; the rank processes map each
     other's buffers through hipIpc) -- same outputs, same gradients.  direct_grad: the requesters write the gradient rows that need no reduction
     straight into the owners' values[] (the owners' plans came back first; the arenas are mapped the same way) -- same (keys, values)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, case, one_sided, direct_grad)) for r in range(world)]
+    # (fail_map: one rank cannot map its peers -- PeerMappingError is raised on every rank together and all take the all-to-all forms: same results)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, case, one_sided, direct_grad, fail_map)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
