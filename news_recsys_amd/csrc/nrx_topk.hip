@@ -277,8 +277,12 @@ extern "C" int nrx_topk_ip(const float* items, int64_t n_items, int32_t dim, con
     const int K = pick_k(k);
     const int S = choose_splits(n_items, n_queries);
     const int64_t per_split = ((n_items + S - 1) / S + 63) & ~63ll;
-    const bool pad = (dim & 7) != 0;
     const int H4 = dim <= 8 ? 1 : (dim <= 16 ? 2 : (dim <= 32 ? 4 : (dim <= 64 ? 8 : 16)));
+    // the row is padded to 8 H4 elements: every dim that is not exactly that wide needs the zero selects.  (Was `dim % 8 != 0`: a 40-wide row in
+    // the 64-wide form read 24 floats past its end unselected -- the next items' values times the query's zeros, harmless, except behind the LAST
+    // item, where it is whatever lies past the tensor: a NaN there made that item's score NaN (tests/test_topk_retrieval.py's property sweep
+    // failed once in five full-suite runs on N = 1, dim = 40), and the read could fault at the end of a mapping.)
+    const bool pad = dim != 8 * H4;
     char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     int* p_idx = reinterpret_cast<int*>(ws);
     float* p_score = reinterpret_cast<float*>(ws + (size_t)2 * S * n_queries * K * sizeof(int));
