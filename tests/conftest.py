@@ -40,3 +40,20 @@ def golden_dir():
 @pytest.fixture(scope="session")
 def config_dir():
     return CONFIGS
+
+
+@pytest.fixture(autouse=True)
+def _poison_recycled_gpu_memory(request):
+    """NRX_TEST_POISON=1 (a checker mode, off by default): before every GPU test, blocks of the caching allocator's small and large pools are
+    filled with 0xFF bytes (float NaN, int -1) and released, so the `torch.empty` buffers of the test -- outputs, workspaces, state blocks -- start
+    from poison instead of from whatever an earlier test left (often zeros).  A kernel that reads what it never wrote, or reads past a tensor
+    into its neighbour, then fails here instead of once in five full-suite runs (how nrx_topk_ip's unselected padding was found: HISTORY §11)."""
+    if os.environ.get("NRX_TEST_POISON") != "1" or "gpu" not in request.keywords or not _has_gpu():
+        yield
+        return
+    import torch
+    big = [torch.full((64 << 20,), 0xFF, dtype=torch.uint8, device="cuda:0") for _ in range(6)]
+    small = [torch.full((256 << 10,), 0xFF, dtype=torch.uint8, device="cuda:0") for _ in range(256)]
+    torch.cuda.synchronize()
+    del big, small
+    yield

@@ -8,6 +8,7 @@ import os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import _poison
 from news_recsys_amd import ops
 from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_SPARSE
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -16,6 +17,7 @@ DEV = "cuda:0"
 ops.set_index_check("deferred")
 t0, n_done = time.time(), 0
 while time.time() - t0 < budget:
+    _poison.poison()
     nf = int(rng.choice([1, 2, 3, 5, 9, 26, 30]))
     nt = int(rng.integers(1, nf + 1))
     B = int(rng.choice([1, 3, 64, 700, 4097, 9000, 30000]))

@@ -12,6 +12,7 @@ import os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import _poison
 from news_recsys_amd import ops, shard_step
 from news_recsys_amd._lib import NRX_BAG_MASKED_MEAN, NRX_BAG_MEAN, NRX_BAG_SUM, NRX_SPARSE
 from news_recsys_amd.sharding import RowShardedEmbedding, ShardedFeature
@@ -20,6 +21,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 DEV = "cuda:0"
 t0, n_done, n_forms = time.time(), 0, 0
 while time.time() - t0 < budget:
+    _poison.poison()
     B = int(rng.choice([1, 3, 64, 81, 700, 4097, 9000, 20000]))
     dims = sorted(set(int(d) for d in rng.choice([16, 32, 64], int(rng.integers(1, 4)))))
     tables, feats, ins, ws, look = {}, [], [], [], 0
