@@ -7,6 +7,7 @@ import os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import _poison
 from news_recsys_amd import _lib
 lib = _lib.load()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -15,6 +16,7 @@ DEV = "cuda:0"
 t0, n_done, n_panel, n_big = time.time(), 0, 0, 0
 st = torch.cuda.current_stream().cuda_stream
 while time.time() - t0 < budget:
+    _poison.poison()
     B = int(rng.choice([1, 2, 31, 63, 64, 65, 127, 129, 1000, 4097, 20011, 70000]))
     D = int(rng.choice([4, 8, 12, 16, 36, 37, 64, 96, 100, 108, 112, 116, 128, 129, 200, 320, 340]))
     if B * D > 12_000_000:

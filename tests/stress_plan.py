@@ -6,6 +6,7 @@ import os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import _poison
 from news_recsys_amd import ops
 from oracle import ref_np as R
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -13,6 +14,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ops.PLAN_PAIRS = True          # (the Python layer's default leaves the sorted planner's pair records off; checked here all the same)
 t0, n_done = time.time(), 0
 while time.time() - t0 < budget:
+    _poison.poison()
     nt = int(rng.choice([1, 2, 3, 7, 26, 40, 63]))
     nf = min(64, nt + int(rng.integers(0, 3)))
     tab = list(range(nt)) + [int(x) for x in rng.integers(0, nt, nf - nt)]

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import _poison
 import ctypes as C
 from news_recsys_amd import _lib
 import test_plan_lds as T
@@ -18,6 +19,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0, n_done, n_skipped, state = time.time(), 0, 0, None
 kinds = ["uniform", "dup", "one_range", "hot"]
 while time.time() - t0 < budget:
+    _poison.poison()
     nt = int(rng.choice([1, 2, 5, 13, 26, 40]))
     nf = min(40, nt + int(rng.integers(0, 3)))
     tab = [int(x) for x in rng.permutation(nt)[:min(nf, nt)]] + [int(x) for x in rng.integers(0, nt, max(0, nf - nt))]
