@@ -63,3 +63,13 @@ def test_product_path_has_no_cpu_fallback():
         ops.embed_apply(plan, [torch.zeros(3, 4)], [torch.tensor([1, 2])], [None])
     with pytest.raises(_lib.NrxError):
         ops.dcn_v1(torch.zeros(2, 4), torch.zeros(1, 4), torch.zeros(1, 4))
+
+
+def test_the_drivers_build_check_follows_the_bindings_abi_version():
+    """__graft_entry__.build() -- the driver's "does it build" check -- must compare the library's ABI version with _lib.NRX_ABI_VERSION, not with a
+    literal (a literal 2 survived the bump to 3 and failed the check until the end of round 6)."""
+    import inspect
+    import re
+    import __graft_entry__ as entry
+    src = inspect.getsource(entry.build)
+    assert "_lib.NRX_ABI_VERSION" in src and re.search(r"nrx_abi_version\(\)\s*==\s*\d", src) is None
