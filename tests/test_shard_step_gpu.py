@@ -726,7 +726,8 @@ def test_world_1_step_is_capturable_and_the_graph_replays_the_eager_bits(case):
     eng = RowShardedEmbedding(0, 1, overflow_policy="defer")
     step = shard_step.PreparedShardedStep(eng, feats, inputs, weights, arenas, binary_masks=True).bind_backward(g_out, g_fm)
     if case == "tower_two_groups":
-        assert len(step.groups) == 2 and step._side_streams()[0] is not None
+        import os
+        assert len(step.groups) == 2 and (step._side_streams()[0] is not None or os.environ.get("NRX_SHARD_OVERLAP", "1") != "1")
     for _ in range(3):                                  # (the planners choose from the previous batch's statistics: settled before the capture)
         out, _, fm = step.run()
         entries = step.backward()
