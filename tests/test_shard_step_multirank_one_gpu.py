@@ -66,6 +66,8 @@ def _worker(rank, world, port, q, case, one_sided, direct_grad, fail_map=False):
         import warnings
         warnings.simplefilter("ignore")
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import _poison
+    _poison.poison()          # (NRX_TEST_POISON=1: this rank's buffers start from 0xFF bytes)
     try:
         spec, B, fm = SPECS[case]
         tabs = _full_tables(spec)
@@ -185,6 +187,8 @@ def _tower_worker(rank, world, port, q, binary):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import _poison
+    _poison.poison()          # (NRX_TEST_POISON=1: this rank's buffers start from 0xFF bytes)
     try:
         D, L, B, news, users = 16, 9, 2500, 6000, 50_000
         rng = np.random.default_rng(3)
@@ -294,6 +298,8 @@ def _model_worker(rank, world, port, q, cls_name, cfg, gname):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import _poison
+    _poison.poison()          # (NRX_TEST_POISON=1: this rank's buffers start from 0xFF bytes)
     try:
         g = dict(np.load(os.path.join(GOLDEN, gname + ".npz"), allow_pickle=False))
         m = {"Deep": Deep, "FM": FM}[cls_name](os.path.join(CONFIGS, cfg))

@@ -23,6 +23,8 @@ def _worker(rank, world, port, q, mode, slack, replicate, prepared, dedup=False,
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import _poison
+    _poison.poison()          # (NRX_TEST_POISON=1: this rank's buffers start from 0xFF bytes)
     try:
         tabs = full_tables()
         shards = {n: (torch.from_numpy(t).clone() if n in replicate else sharding.shard_table(torch.from_numpy(t), rank, world)
