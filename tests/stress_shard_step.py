@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dev (GPU box): random towers through the BOUND SHARDED STEP (news_recsys_amd/shard_step.py) at world 1 -- 1 .. 12 single-valued features over
 shared tables of one to three widths (16 / 32 / 64), zero to two bag groups (masked-mean / mean / sum bags of 1 .. 130 entries, one pooled table per
-width; 0/1 masks or float weights, empty bags, padded histories), batches 1 .. 20 000, uniform / skewed ids with padding ids -- in every form
+width; 0/1 masks or float weights, empty bags, padded histories), batches 1 .. 20 000, int64 / int32 ids, uniform / skewed with padding ids -- in every form
 of the step: one-sided placement on / off, the requester's pack as the owner's placement pass on / off, the pooled channel's three routings
 (NRX_ROUTE_BAGS = runs | one | legacy), binary-mask fast path on / off, exchange groups side by side or one after the other.
 Checked against a float64 restatement in torch (F.embedding + the pooling of src/model/BaseModel/base_model.py:262-282, autograd for the gradients):
@@ -23,6 +23,7 @@ t0, n_done, n_forms = time.time(), 0, 0
 while time.time() - t0 < budget:
     _poison.poison()
     B = int(rng.choice([1, 3, 64, 81, 700, 4097, 9000, 20000]))
+    idt = torch.int64 if rng.integers(0, 3) else torch.int32             # (every feature of a tower: the ids of an exchange group share a dtype)
     dims = sorted(set(int(d) for d in rng.choice([16, 32, 64], int(rng.integers(1, 4)))))
     tables, feats, ins, ws, look = {}, [], [], [], 0
     for d in dims:
@@ -35,7 +36,7 @@ while time.time() - t0 < budget:
         skew = rng.integers(0, 3) == 0
         x = rng.integers(0, rows, B) if not skew else np.minimum(rng.zipf(1.3, B) - 1, rows - 1)
         feats.append(ShardedFeature(f"s{f}", NRX_SPARSE, t, d))
-        ins.append(torch.from_numpy(np.asarray(x, np.int64)).to(DEV))
+        ins.append(torch.from_numpy(np.asarray(x, np.int64)).to(DEV).to(idt))
         ws.append(None)
         look += B
     binary_ok = True
@@ -58,7 +59,7 @@ while time.time() - t0 < budget:
                     binary_ok = False
                 w = m
             feats.append(ShardedFeature(f"b{d}_{f}", kind, bag_table, d, L))
-            ins.append(torch.from_numpy(np.asarray(x, np.int64)).to(DEV))
+            ins.append(torch.from_numpy(np.asarray(x, np.int64)).to(DEV).to(idt))
             ws.append(None if w is None else torch.from_numpy(np.asarray(w, np.float32)).to(DEV))
             look += B * L
     if look > 1_200_000:
@@ -71,7 +72,7 @@ while time.time() - t0 < budget:
     t64 = {n: shard_step.arena_shard(a).double().requires_grad_() for n, a in arenas.items()}
     outs, col, cols = [], 0, []
     for f, x, w in zip(feats, ins, ws):
-        e = torch.nn.functional.embedding(x, t64[f.table])
+        e = torch.nn.functional.embedding(x.long(), t64[f.table])
         if f.kind == NRX_SPARSE:
             outs.append(e)
         elif f.kind == NRX_BAG_MASKED_MEAN:
@@ -87,7 +88,7 @@ while time.time() - t0 < budget:
     ref_g = dict(zip(t64, torch.autograd.grad(ref_out, list(t64.values()), up.double(), allow_unused=True)))
     n_max = {n: 1 for n in tables}
     for f, x in zip(feats, ins):
-        v = x.reshape(-1)
+        v = x.reshape(-1).long()
         c = torch.bincount(v[v > 0], minlength=1)
         n_max[f.table] += int(c.max().item()) if c.numel() else 0
     first_out = None
