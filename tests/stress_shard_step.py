@@ -2,7 +2,7 @@
 """Dev (GPU box): random towers through the BOUND SHARDED STEP (news_recsys_amd/shard_step.py) at world 1 -- 1 .. 12 single-valued features over
 shared tables of one to three widths (16 / 32 / 64), zero to two bag groups (masked-mean / mean / sum bags of 1 .. 130 entries, one pooled table per
 width; 0/1 masks or float weights, empty bags, padded histories), batches 1 .. 20 000, int64 / int32 ids, uniform / skewed with padding ids -- in every form
-of the step: one-sided placement on / off, the requester's pack as the owner's placement pass on / off, the pooled channel's three routings
+of the step (one tower in four is an FM plan: fields of one width, the logit and its gradient checked too): one-sided placement on / off, the requester's pack as the owner's placement pass on / off, the pooled channel's three routings
 (NRX_ROUTE_BAGS = runs | one | legacy), binary-mask fast path on / off, exchange groups side by side or one after the other.
 Checked against a float64 restatement in torch (F.embedding + the pooling of src/model/BaseModel/base_model.py:262-282, autograd for the gradients):
 the single-valued columns of the concat bit for bit, the pooled columns and every table's gradient (the sum of the step's (key, value) lists) within
@@ -24,7 +24,8 @@ while time.time() - t0 < budget:
     _poison.poison()
     B = int(rng.choice([1, 3, 64, 81, 700, 4097, 9000, 20000]))
     idt = torch.int64 if rng.integers(0, 3) else torch.int32             # (every feature of a tower: the ids of an exchange group share a dtype)
-    dims = sorted(set(int(d) for d in rng.choice([16, 32, 64], int(rng.integers(1, 4)))))
+    fm = bool(rng.integers(0, 4) == 0)                                   # an FM tower: single-valued fields of ONE width, the logit + its gradient too
+    dims = sorted(set(int(d) for d in rng.choice([16, 32, 64], 1 if fm else int(rng.integers(1, 4)))))
     tables, feats, ins, ws, look = {}, [], [], [], 0
     for d in dims:
         for t in range(int(rng.integers(1, 4))):
@@ -35,13 +36,13 @@ while time.time() - t0 < budget:
         rows, d = tables[t]
         skew = rng.integers(0, 3) == 0
         x = rng.integers(0, rows, B) if not skew else np.minimum(rng.zipf(1.3, B) - 1, rows - 1)
-        feats.append(ShardedFeature(f"s{f}", NRX_SPARSE, t, d))
+        feats.append(ShardedFeature(f"s{f}", NRX_SPARSE, t, d, 0, False, fm))
         ins.append(torch.from_numpy(np.asarray(x, np.int64)).to(DEV).to(idt))
         ws.append(None)
         look += B
     binary_ok = True
     for d in dims:
-        if rng.integers(0, 2) == 0:
+        if fm or rng.integers(0, 2) == 0:
             continue
         bag_table = [n for n in names if tables[n][1] == d][0]          # the bag features of one pooled group share ONE table
         rows = tables[bag_table][0]
@@ -68,6 +69,7 @@ while time.time() - t0 < budget:
     arenas = {n: shard_step.make_arena(r, d, 0, 1, DEV, generator=gen) for n, (r, d) in tables.items()}
     width = sum(f.dim for f in feats)
     up = torch.randn(B, width, device=DEV, generator=gen)
+    up_fm = torch.randn(B, device=DEV, generator=gen) if fm else None
     # ---- float64 restatement
     t64 = {n: shard_step.arena_shard(a).double().requires_grad_() for n, a in arenas.items()}
     outs, col, cols = [], 0, []
@@ -85,7 +87,13 @@ while time.time() - t0 < budget:
         cols.append((col, f.dim, f.kind))
         col += f.dim
     ref_out = torch.cat(outs, 1)
-    ref_g = dict(zip(t64, torch.autograd.grad(ref_out, list(t64.values()), up.double(), allow_unused=True)))
+    ref_fm = None
+    if fm:      # sort/fm/model.py:18-26,48-59: column 0 of every field = its first-order weight, the rest its factor vector
+        e3 = torch.stack(outs, 1)                                            # [B, fields, D]
+        v = e3[:, :, 1:]
+        ref_fm = e3[:, :, 0].sum(1) + 0.5 * ((v.sum(1) ** 2) - (v ** 2).sum(1)).sum(1)
+    loss = (ref_out * up.double()).sum() + ((ref_fm * up_fm.double()).sum() if fm else 0.0)
+    ref_g = dict(zip(t64, torch.autograd.grad(loss, list(t64.values()), allow_unused=True)))
     n_max = {n: 1 for n in tables}
     for f, x in zip(feats, ins):
         v = x.reshape(-1).long()
@@ -99,14 +107,16 @@ while time.time() - t0 < budget:
         os.environ["NRX_ROUTE_BAGS"], os.environ["NRX_SHARD_OVERLAP"] = route, overlap
         eng = RowShardedEmbedding(0, 1, overflow_policy="defer")
         step = shard_step.PreparedShardedStep(eng, feats, ins, ws, arenas, one_sided=one_sided, binary_masks=binary, check_index=True)
-        step.bind_backward(up, direct_grad=direct)
+        step.bind_backward(up, up_fm, direct_grad=direct)
         what = dict(B=B, feats=[(f.name, f.kind, f.table, f.dim, f.bag_len) for f in feats], tables=tables, one_sided=one_sided, direct=direct, route=route,
                     binary=binary, overlap=overlap)
         runs = []
         for _ in range(2):
-            out, _, _ = step.run()
+            out, _, fmv = step.run()
             entries = step.backward()
             torch.cuda.synchronize()
+            if fm:
+                assert (fmv.double() - ref_fm.detach()).abs().max().item() <= 2e-5 * max(1.0, ref_fm.abs().max().item()) + 1e-5 * len(feats), ("FM logit", B, len(feats))
             runs.append((out.clone(), [(e["uniq"][:int(e["counts"][0])].clone(), e["values"][:int(e["counts"][0])].clone()) for e in entries]))
         step.check()
         assert torch.equal(runs[0][0].view(torch.int32), runs[1][0].view(torch.int32)), ("two runs, forward", what)
