@@ -642,8 +642,11 @@ class PreparedShardedForward:
                 inbox=torch.empty(W * cap, dtype=torch.int32, device=dev),
                 rows_out=torch.empty((W * cap, D), dtype=torch.float32, device=dev),
                 ret=torch.empty((W * cap, D), dtype=torch.float32, device=dev),
-                tp=(C.c_void_p * len(loc))(*[t.data_ptr() for t in loc]), tr=(C.c_int64 * len(loc))(*[t.shape[0] for t in loc]),
+                # (an empty shard -- fewer table rows than ranks -- has no address: a zero row stands in, the row count stays 0)
+                stand_in=torch.zeros((1, D), dtype=torch.float32, device=dev),
+                tr=(C.c_int64 * len(loc))(*[t.shape[0] for t in loc]),
                 nt=len(loc), ft=(C.c_int32 * n)(*[table_names.index(feats[i].table) for i in idxs]), dev=dev)
+            g["tp"] = (C.c_void_p * len(loc))(*[(t if t.shape[0] else g["stand_in"]).data_ptr() for t in loc])
             if idxs[0] in placed_set:     # one-sided placement: no row buffers at all; the sample positions travel with the local rows
                 g["placed"] = True
                 g["rows_out"] = g["ret"] = None
@@ -805,6 +808,10 @@ class PreparedShardedForward:
             if feats[i].table not in table_names:
                 table_names.append(feats[i].table)
         loc = [tables[t] for t in table_names]
+        # a table with fewer rows than ranks leaves some ranks an EMPTY shard (a 5-row category table at world 8): its tensor has no address, and
+        # the pooling launch -- which reads row 0 for the entries it masks out -- wants one: a zero row stands in (the row count stays 0, so
+        # every entry that reaches this owner is reported as out of range and contributes nothing)
+        stand_in = torch.zeros((1, D), dtype=torch.float32, device=dev)
         masks = [weights[i] if feats[i].kind != NRX_BAG_MEAN else None for i in idxs]
         wn = [torch.empty((B, feats[i].bag_len), dtype=torch.float32, device=dev) for i in idxs]
         g = dict(pooled=True, n=n, B=B, cap=cap, D=D, bits=ids[0].element_size() * 8, ids=ids, masks=masks, wn=wn,
@@ -821,8 +828,8 @@ class PreparedShardedForward:
                  partial=torch.empty((W, n * B, D), dtype=torch.float32, device=dev),
                  pws=torch.empty(max(1, self.lib.nrx_pool_inbox_workspace(n, B, W)), dtype=torch.uint8, device=dev),
                  ret=torch.empty((W, n * B, D), dtype=torch.float32, device=dev),
-                 tp=(C.c_void_p * len(loc))(*[t.data_ptr() for t in loc]), tr=(C.c_int64 * len(loc))(*[t.shape[0] for t in loc]),
-                 nt=len(loc), ft=(C.c_int32 * n)(*[table_names.index(feats[i].table) for i in idxs]), dev=dev)
+                 tp=(C.c_void_p * len(loc))(*[(t if t.shape[0] else stand_in).data_ptr() for t in loc]), tr=(C.c_int64 * len(loc))(*[t.shape[0] for t in loc]),
+                 nt=len(loc), ft=(C.c_int32 * n)(*[table_names.index(feats[i].table) for i in idxs]), dev=dev, stand_in=stand_in)
         if W == 1:
             g["inbox"], g["inbox_tag"], g["inbox_w"], g["recv2d"], g["ret"] = g["send"], g["send_tag"], g["send_w"], g["counts2d"], g["partial"]
         import os
