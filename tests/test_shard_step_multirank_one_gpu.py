@@ -378,3 +378,86 @@ def test_bound_sharded_model_on_two_ranks_trains_like_the_unsharded_model(cls_na
         else:
             for r in range(world):
                 np.testing.assert_allclose(res[r][k], w, rtol=1e-5, atol=1e-6, err_msg=f"{k} rank {r}")
+
+
+# ---------------------------------------------------------------------------------------------- a table with fewer rows than ranks: empty shards
+def _tiny_worker(rank, world, port, q):
+    import os
+    from news_recsys_amd._lib import NRX_BAG_MEAN
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import _poison
+    _poison.poison()
+    try:
+        D, L, B = 16, 2, 500
+        rng = np.random.default_rng(5)
+        tabs = {"tiny": rng.standard_normal((2, D)).astype(np.float32), "big": rng.standard_normal((300, D)).astype(np.float32)}
+        for t in tabs.values():
+            t[0] = 0
+        arenas = {t: shard_step.make_arena(x.shape[0], D, rank, world, DEV, full=torch.from_numpy(x).to(DEV)) for t, x in tabs.items()}
+        assert arenas["tiny"].shape[0] == (2 if rank < 2 else 1)            # rank 2 owns no row of the 2-row table: its arena is the dummy row alone
+        feats = [ShardedFeature("a", NRX_SPARSE, "big", D), ShardedFeature("cats", NRX_BAG_MEAN, "tiny", D, L)]
+        r2 = np.random.default_rng(50 + rank)
+        inputs = [torch.from_numpy(r2.integers(0, 300, B)).to(DEV), torch.from_numpy(r2.integers(0, 2, (B, L))).to(DEV)]
+        up = torch.from_numpy(r2.standard_normal((B, 2 * D)).astype(np.float32)).to(DEV)
+        eng = RowShardedEmbedding(rank, world, slack=3.0, host_staged=True, overflow_policy="defer")
+        step = shard_step.PreparedShardedStep(eng, feats, inputs, [None, None], arenas, one_sided=False, binary_masks=True).bind_backward(up)
+        out, _, _ = step.run()
+        entries = step.backward()
+        torch.cuda.synchronize()
+        dist.barrier()
+        step.check()
+        got = {}
+        for e in entries:
+            nu = int(e["counts"][0])
+            for ti, arena in enumerate(e["tables"]):
+                name = next(n for n, a in arenas.items() if a is arena)
+                keys, vals = e["uniq"][:nu].cpu().numpy(), e["values"][:nu].cpu().numpy()
+                for k, v in zip(keys, vals):
+                    if (k >> 40) == ti and (k & ((1 << 40) - 1)) > 0:
+                        key = (name, int((k & ((1 << 40) - 1)) - 1) * world + rank)
+                        got[key] = got.get(key, 0) + v.astype(np.float64)
+        q.put((rank, out.cpu().numpy(), got))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_table_with_fewer_rows_than_ranks_leaves_an_empty_shard_that_works():
+    """World 3, a bag feature over a 2-row table (a tiny category table on many ranks): rank 2's shard of it is EMPTY -- its pooled channel handed
+    the pooling launch a null table (found by tests/stress_shard_step_multirank.py).  Forward: single-valued columns bit for bit, the mean-pooled
+    columns rtol 1e-6 against torch on the full tables; gradient of the tiny table's one trainable row = the sum over all ranks' bags."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tiny_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        item = q.get(timeout=300)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    D, L, B = 16, 2, 500
+    rng = np.random.default_rng(5)
+    tabs = {"tiny": rng.standard_normal((2, D)).astype(np.float32), "big": rng.standard_normal((300, D)).astype(np.float32)}
+    for t in tabs.values():
+        t[0] = 0
+    g_tiny = np.zeros(D)
+    seen = {}
+    for r in range(world):
+        r2 = np.random.default_rng(50 + r)
+        a, cats = r2.integers(0, 300, B), r2.integers(0, 2, (B, L))
+        up = r2.standard_normal((B, 2 * D)).astype(np.float32)
+        out, got = res[r]
+        assert np.array_equal(out[:, :D], tabs["big"][a])
+        np.testing.assert_allclose(out[:, D:], tabs["tiny"][cats].mean(1), rtol=1e-6, atol=1e-6)
+        g_tiny += ((cats == 1).sum(1, keepdims=True) * up[:, D:].astype(np.float64) / L).sum(0)      # d mean / d row 1 = (its count in the bag) / L
+        for k, v in got.items():
+            assert k not in seen
+            seen[k] = v
+    assert ("tiny", 1) in seen and ("tiny", 0) not in seen                 # row 0 is the padding row: it never trains
+    np.testing.assert_allclose(seen[("tiny", 1)], g_tiny, rtol=1e-5, atol=1e-5)
