@@ -190,3 +190,32 @@ def test_pooled_runs_protocol_over_gloo(world):
         assert ok
         want = ref_np.array_pool(table[ids], mask)                         # base_model.py:273-282
         np.testing.assert_allclose(pooled, want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("world", [1, 2, 5])
+def test_oracle_runs_and_tags_agree(world):
+    """CPU: the two definitions the runs form rests on are consistent with route_bags -- every routed entry lies in the run of its tag, the runs
+    tile each block's used slots in order, tags_from_runs gives back route_bags' tags, an overflowing block keeps its bounds inside the block."""
+    rng = np.random.default_rng(7 + world)
+    for case in range(6):
+        n = int(rng.integers(1, 4))
+        B = int(rng.integers(1, 60))
+        Ls = [int(rng.integers(1, 9)) for _ in range(n)]
+        ids = [rng.integers(0, 40, (B, L)) for L in Ls]
+        ws = [((rng.random((B, L)) < 0.6) * rng.random((B, L))).astype(np.float32) for L in Ls]
+        total = sum(int((w != 0).sum()) for w in ws)
+        for cap in (total + 3, max(1, total // (2 * world))):
+            rows, tags, sw, c2d, worst = ref_np.route_bags(ids, ws, world, cap)
+            run = ref_np.route_bags_runs(ids, ws, world, cap)
+            assert run.shape == (world, n * B, 2) and (run[..., 0] <= run[..., 1]).all() and (run <= cap).all()
+            back = ref_np.tags_from_runs(run, world, cap)
+            for o in range(world):
+                used = min(int(c2d[o].sum()), cap)
+                assert np.array_equal(back[o * cap: o * cap + used], tags[o * cap: o * cap + used])
+                assert (back[o * cap + used: (o + 1) * cap] == -1).all()
+                live = np.flatnonzero(run[o, :, 1] > run[o, :, 0])                  # non-empty runs, in tag order, tile [0, used)
+                if live.size:
+                    assert run[o, live[0], 0] == 0 and run[o, live[-1], 1] == used
+                    assert np.array_equal(run[o, live[1:], 0], run[o, live[:-1], 1])
+                else:
+                    assert used == 0
